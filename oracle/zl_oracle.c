@@ -1,0 +1,906 @@
+/*
+ * zl_oracle.c -- CPU ORACLE, TEST INFRASTRUCTURE ONLY (see zl_oracle.h header comment).
+ *
+ * Plain C99 restatement of the reference's hot-path arithmetic.  Every function cites the
+ * reference file:line (relative to /root/reference) it follows.  No code is copied: the CUDA
+ * kernels are re-expressed as scalar loops that make the same roundings in the same order.
+ *
+ * Conventions used to mirror what the CUDA binary computes under IEEE-754:
+ *   - `a += b * c` on floats in device code is contracted by nvcc into one fp32 FMA  -> fmaf().
+ *   - __hfma2 / __hadd2 / __hmul2 round ONCE to fp16 per lane                         -> h_fma() etc.
+ *   - warp shuffle-down trees (offsets 16,8,4,2,1) are replayed pairwise in that order.
+ * Build with -ffp-contract=off so that the C compiler adds no contractions of its own.
+ */
+#include "zl_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* soft-float conversions                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float zlo_f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    if (exp == 0) {
+        if (man == 0) return bits_f32(sign);
+        float v = (float)man * 5.9604644775390625e-08f; /* man * 2^-24, exact */
+        return sign ? -v : v;
+    }
+    if (exp == 31) return bits_f32(sign | 0x7f800000u | (man << 13));
+    return bits_f32(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+/* round-to-nearest-even of a double to a format with `mbits` explicit mantissa bits, minimum
+ * normal exponent `emin`; returns (n, e) such that value = n * 2^(e - mbits), n in [0, 2^(mbits+1)] */
+uint16_t zlo_f64_to_f16(double d) {
+    uint16_t sign = signbit(d) ? 0x8000u : 0;
+    double a = fabs(d);
+    if (isnan(d)) return (uint16_t)(sign | 0x7e00u);
+    if (a >= 65520.0) return (uint16_t)(sign | 0x7c00u);      /* overflow (or inf) -> inf */
+    if (a < 2.9802322387695312e-08) return sign;               /* < 2^-25 -> 0; tie 2^-25 -> even 0 below */
+    int e;
+    (void)frexp(a, &e);                                        /* a = f * 2^e, f in [0.5,1) */
+    e -= 1;                                                    /* a in [2^e, 2^(e+1)) */
+    if (e < -14) {                                             /* subnormal: quantum 2^-24 */
+        double n = nearbyint(ldexp(a, 24));                    /* RNE (default rounding mode) */
+        return (uint16_t)(sign | (uint16_t)n);                 /* n == 1024 -> smallest normal */
+    }
+    double n = nearbyint(ldexp(a, 10 - e));                    /* in [1024, 2048] */
+    if (n >= 2048.0) { n = 1024.0; e += 1; }
+    return (uint16_t)(sign | (uint16_t)((e + 15) << 10) | ((uint16_t)n - 1024u));
+}
+
+uint16_t zlo_f32_to_f16(float f) { return zlo_f64_to_f16((double)f); }
+
+float zlo_bf16_to_f32(uint16_t h) { return bits_f32((uint32_t)h << 16); }
+
+uint16_t zlo_f32_to_bf16(float f) {
+    uint32_t u = f32_bits(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u); /* NaN */
+    uint32_t lsb = (u >> 16) & 1u;
+    u += 0x7fffu + lsb;
+    return (uint16_t)(u >> 16);
+}
+
+static uint16_t f64_to_bf16(double d) {
+    /* exact single rounding double -> bf16 (8-bit significand, emin -126) */
+    uint16_t sign = signbit(d) ? 0x8000u : 0;
+    double a = fabs(d);
+    if (isnan(d)) return (uint16_t)(sign | 0x7fc0u);
+    if (a >= 3.3961775292304601e38) return (uint16_t)(sign | 0x7f80u); /* (2-2^-8)*2^127 */
+    if (a == 0.0) return sign;
+    int e;
+    (void)frexp(a, &e);
+    e -= 1;
+    if (e < -126) {
+        double n = nearbyint(ldexp(a, 133));                   /* quantum 2^-133 */
+        return (uint16_t)(sign | (uint16_t)n);
+    }
+    double n = nearbyint(ldexp(a, 7 - e));                     /* in [128, 256] */
+    if (n >= 256.0) { n = 128.0; e += 1; }
+    return (uint16_t)(sign | (uint16_t)((e + 127) << 7) | ((uint16_t)n - 128u));
+}
+
+void zlo_f32_to_f16_array(const float* in, uint16_t* out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = zlo_f32_to_f16(in[i]);
+}
+void zlo_f16_to_f32_array(const uint16_t* in, float* out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = zlo_f16_to_f32(in[i]);
+}
+
+static inline float T2f(uint16_t v, int dt) { return dt ? zlo_bf16_to_f32(v) : zlo_f16_to_f32(v); }
+static inline uint16_t f2T(float f, int dt) { return dt ? zlo_f32_to_bf16(f) : zlo_f32_to_f16(f); }
+static inline uint16_t d2T(double d, int dt) { return dt ? f64_to_bf16(d) : zlo_f64_to_f16(d); }
+
+/* fp16 fused multiply-add with a single rounding (what __hfma2 does per lane).  a*b is exact in
+ * double (22 significant bits); a*b+c in double is either exact or far from any fp16 tie. */
+static inline uint16_t h_fma(uint16_t a, uint16_t b, uint16_t c) {
+    return zlo_f64_to_f16((double)zlo_f16_to_f32(a) * (double)zlo_f16_to_f32(b) + (double)zlo_f16_to_f32(c));
+}
+static inline uint16_t h_mul(uint16_t a, uint16_t b) {
+    return zlo_f64_to_f16((double)zlo_f16_to_f32(a) * (double)zlo_f16_to_f32(b));
+}
+
+/* shuffle-down tree of a 32-lane warp, result in lane 0 (bm/include/bmengine/functions/reduce.cuh:41-47) */
+static inline float warp32_tree_sum(float* x) {
+    for (int off = 16; off > 0; off >>= 1)
+        for (int l = 0; l < off; ++l) x[l] = x[l] + x[l + off];
+    return x[0];
+}
+
+/* block reduce (reduce.cuh:92-107): per-warp tree, then warp 0 trees the per-warp results */
+static float block_tree_sum(const float* per_thread, int threads) {
+    float warp_res[32];
+    int nwarp = threads / 32;
+    for (int w = 0; w < 32; ++w) warp_res[w] = 0.f;
+    for (int w = 0; w < nwarp; ++w) {
+        float lane[32];
+        for (int l = 0; l < 32; ++l) lane[l] = per_thread[w * 32 + l];
+        warp_res[w] = warp32_tree_sum(lane);
+    }
+    return warp32_tree_sum(warp_res);
+}
+
+static inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* a4: load-time layout transforms                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/nn/quant/gptq/qdq_4.cuh:16-35 (shuffle_4bit_8) applied to every word of the (K/8, N) matrix
+ * (q_gemm.cu:778-791 shuffle_kernel): even weights go to the low 16 bits, odd ones to the high 16. */
+void zlo_gptq_shuffle(uint32_t* qweight, int64_t k8, int64_t n) {
+    for (int64_t i = 0; i < k8 * n; ++i) {
+        uint32_t qa = qweight[i], qb = 0;
+        for (int j = 0; j < 4; ++j) {
+            uint32_t even = qa & 0xfu, odd = (qa >> 4) & 0xfu;
+            qa >>= 8;
+            qb |= even << (4 * j);
+            qb |= odd << (4 * j + 16);
+        }
+        qweight[i] = qb;
+    }
+}
+
+/* src/nn/quant/gptq/utils.cu:61-88: +1 on every nibble with 0xF wrapping to 0 (no carry) */
+void zlo_gptq_increase_zero(uint32_t* qzeros, int64_t nwords) {
+    for (int64_t i = 0; i < nwords; ++i) {
+        uint32_t q = qzeros[i], r = 0;
+        for (int j = 0; j < 8; ++j) {
+            uint32_t nib = (q >> (4 * j)) & 0xfu;
+            nib = (nib == 0xfu) ? 0u : nib + 1u;
+            r |= nib << (4 * j);
+        }
+        qzeros[i] = r;
+    }
+}
+
+/* src/nn/quant/gptq/utils.cu:177-214: nibble j of word i -> byte 8*i + j */
+void zlo_gptq_q4_to_q8(const uint32_t* in, uint8_t* out, int64_t nwords) {
+    for (int64_t i = 0; i < nwords; ++i)
+        for (int j = 0; j < 8; ++j) out[8 * i + j] = (uint8_t)((in[i] >> (4 * j)) & 0xfu);
+}
+
+#define DEF_TRANSPOSE(NAME, TYPE)                                                          \
+    void NAME(const TYPE* in, TYPE* out, int64_t rows, int64_t cols) {                     \
+        for (int64_t r = 0; r < rows; ++r)                                                 \
+            for (int64_t c = 0; c < cols; ++c) out[c * rows + r] = in[r * cols + c];       \
+    }
+DEF_TRANSPOSE(zlo_transpose_u32, uint32_t)
+DEF_TRANSPOSE(zlo_transpose_u16, uint16_t)
+DEF_TRANSPOSE(zlo_transpose_u8, uint8_t)
+
+/* src/nn/quant/gptq/utils.cu:25-58: AWQ nibble order [0,4,1,5,2,6,3,7] -> natural, in place */
+void zlo_awq_un_shuffle(uint32_t* q, int64_t dim0, int64_t n) {
+    static const int de[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    for (int64_t i = 0; i < dim0 * n; ++i) {
+        uint32_t in = q[i], out = 0;
+        for (int s = 0; s < 8; ++s) out |= ((in >> (de[s] * 4)) & 0xfu) << (s * 4);
+        q[i] = out;
+    }
+}
+
+/* src/nn/quant/gptq/utils.cu:121-174: AWQ (K, N/8) -> GPTQ-style (K/8, N); with use_exllama the 8
+ * k-nibbles of an output word are stored in exllama order (even k low half, odd k high half) */
+void zlo_awq_shuffle(const uint32_t* in, uint32_t* out, int64_t k, int64_t n, int use_exllama) {
+    static const int de[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    static const int sfl[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+    int64_t n8 = n / 8;
+    for (int64_t kb = 0; kb < k / 8; ++kb)
+        for (int64_t nb = 0; nb < n8; ++nb) {
+            uint32_t dq[8][8];
+            for (int r = 0; r < 8; ++r) {
+                uint32_t q = in[(kb * 8 + r) * n8 + nb];
+                for (int s = 0; s < 8; ++s) dq[r][s] = (q >> (de[s] * 4)) & 0xfu;
+            }
+            for (int c = 0; c < 8; ++c) {
+                uint32_t q = 0;
+                for (int s = 0; s < 8; ++s) q += dq[use_exllama ? sfl[s] : s][c] << (s * 4);
+                out[kb * n + nb * 8 + c] = q;
+            }
+        }
+}
+
+/* Int4GPTQ::preprocess_weight + transpose_weight (src/nn/linear/linear.cpp:1139-1160, 1085-1099),
+ * no act-order: shuffle qweight, +1 zeros, zeros nibble->byte, transpose all three to k-major. */
+void zlo_gptq_prepare_k_major(const uint32_t* qweight_hf, const uint32_t* qzeros_hf,
+                              const uint16_t* scales_hf, int64_t k, int64_t n, int64_t g,
+                              uint32_t* qw_km, uint8_t* qz_km, uint16_t* sc_km) {
+    int64_t k8 = k / 8, ng = k / g;
+    uint32_t* qw = (uint32_t*)malloc(sizeof(uint32_t) * k8 * n);
+    memcpy(qw, qweight_hf, sizeof(uint32_t) * k8 * n);
+    zlo_gptq_shuffle(qw, k8, n);
+    zlo_transpose_u32(qw, qw_km, k8, n);
+    free(qw);
+    uint32_t* qz = (uint32_t*)malloc(sizeof(uint32_t) * ng * (n / 8));
+    memcpy(qz, qzeros_hf, sizeof(uint32_t) * ng * (n / 8));
+    zlo_gptq_increase_zero(qz, ng * (n / 8));
+    uint8_t* qz8 = (uint8_t*)malloc((size_t)ng * n);
+    zlo_gptq_q4_to_q8(qz, qz8, ng * (n / 8));
+    zlo_transpose_u8(qz8, qz_km, ng, n);
+    free(qz);
+    free(qz8);
+    zlo_transpose_u16(scales_hf, sc_km, ng, n);
+}
+
+/* AutoGPTQ v1 on-disk format definition: W[k,n] = (q - (zstored + 1)) * s with
+ * the +1 wrapping 15 -> 0 as the reference's increase_zero does.  Output (N, K) in fp64. */
+void zlo_gptq_dequant_hf_naive(const uint32_t* qweight_hf, const uint32_t* qzeros_hf,
+                               const uint16_t* scales_hf, const int32_t* g_idx,
+                               int64_t k, int64_t n, int64_t g, double* w_nk) {
+    int64_t n8 = n / 8;
+    for (int64_t kk = 0; kk < k; ++kk) {
+        int64_t grp = g_idx ? g_idx[kk] : kk / g;
+        for (int64_t nn = 0; nn < n; ++nn) {
+            int q = (int)((qweight_hf[(kk / 8) * n + nn] >> (4 * (kk % 8))) & 0xfu);
+            int zs = (int)((qzeros_hf[grp * n8 + nn / 8] >> (4 * (nn % 8))) & 0xfu);
+            int z = (zs == 15) ? 0 : zs + 1;
+            w_nk[nn * k + kk] = (double)(q - z) * (double)zlo_f16_to_f32(scales_hf[grp * n + nn]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a2: W4A16 k-major GEMM, R flavour                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* dequant_8x4bit (q_gemm_k_major.cu:74-99): word -> 8 fp16 values (q - z), exact.  Natural weight
+ * order j = 0..7; weight 2p sits in nibble p, weight 2p+1 in nibble p+4 (exllama-shuffled word). */
+static inline void dequant_word(uint32_t w, int zero, uint16_t d[8]) {
+    for (int p = 0; p < 4; ++p) {
+        int even = (int)((w >> (4 * p)) & 0xfu), odd = (int)((w >> (4 * p + 16)) & 0xfu);
+        d[2 * p] = zlo_f64_to_f16((double)(even - zero));
+        d[2 * p + 1] = zlo_f64_to_f16((double)(odd - zero));
+    }
+}
+
+/* dot_8_half (q_gemm_k_major.cu:101-108): two interleaved fp16 accumulators (even k, odd k), four
+ * hfma2 steps, then f32(lo) + f32(hi) */
+static inline float dot8_half(const uint16_t d[8], const uint16_t* a) {
+    uint16_t lo = 0, hi = 0;
+    for (int i = 0; i < 4; ++i) {
+        lo = h_fma(d[2 * i], a[2 * i], lo);
+        hi = h_fma(d[2 * i + 1], a[2 * i + 1], hi);
+    }
+    return zlo_f16_to_f32(lo) + zlo_f16_to_f32(hi);
+}
+
+/* DEV_gemm_warp_reduce + warpReduceSum (q_gemm_k_major.cu:127-174, 217-220): lane l of a 32-lane
+ * warp walks words l, l+32, ... with acc = fma(dot8, scale, acc); lanes are then tree-summed. */
+static float gemv_row_R(const uint16_t* x, const uint32_t* qw_row, const uint8_t* qz_row,
+                        const uint16_t* sc_row, int64_t k8, int64_t g8, int sym) {
+    float lane_acc[32];
+    for (int l = 0; l < 32; ++l) {
+        float acc = 0.f;
+        for (int64_t w = l; w < k8; w += 32) {
+            int64_t gi = w / g8;
+            float scale = zlo_f16_to_f32(sc_row[gi]);
+            int zero = sym ? 8 : (int)qz_row[gi];
+            uint16_t d[8];
+            dequant_word(qw_row[w], zero, d);
+            acc = fmaf(dot8_half(d, x + 8 * w), scale, acc);
+        }
+        lane_acc[l] = acc;
+    }
+    return warp32_tree_sum(lane_acc);
+}
+
+/* KERNEL_gemm_warp_reduce (q_gemm_k_major.cu:176-237): C = half(alpha*acc + bias), alpha = 1;
+ * ADD_C: half(float(C) + acc + bias).  Per-row arithmetic is identical for every WRAP_M, so any M
+ * (the reference routes M <= 40 here, :1101-1115) is M independent row-vectors. */
+void zlo_gptq_gemm_k_major(const uint16_t* x, const uint32_t* qw, const uint8_t* qz,
+                           const uint16_t* sc, const uint16_t* bias, uint16_t* y,
+                           int64_t m, int64_t n, int64_t k, int64_t g, int sym, int add_c) {
+    int64_t k8 = k / 8, g8 = g / 8, ng = k / g;
+#pragma omp parallel for schedule(static)
+    for (int64_t nn = 0; nn < n; ++nn)
+        for (int64_t mm = 0; mm < m; ++mm) {
+            float acc = gemv_row_R(x + mm * k, qw + nn * k8, qz + nn * ng, sc + nn * ng, k8, g8, sym);
+            float b = bias ? zlo_f16_to_f32(bias[nn]) : 0.f;
+            float r;
+            if (add_c) r = (zlo_f16_to_f32(y[mm * n + nn]) + acc) + b;
+            else r = acc + b;
+            y[mm * n + nn] = zlo_f32_to_f16(r);
+        }
+}
+
+void zlo_gptq_gemm_k_major_exact(const uint16_t* x, const uint32_t* qw, const uint8_t* qz,
+                                 const uint16_t* sc, const uint16_t* bias, double* y,
+                                 int64_t m, int64_t n, int64_t k, int64_t g, int sym) {
+    int64_t k8 = k / 8, g8 = g / 8, ng = k / g;
+#pragma omp parallel for schedule(static)
+    for (int64_t nn = 0; nn < n; ++nn)
+        for (int64_t mm = 0; mm < m; ++mm) {
+            double acc = 0.0;
+            for (int64_t w = 0; w < k8; ++w) {
+                int64_t gi = w / g8;
+                double s = (double)zlo_f16_to_f32(sc[nn * ng + gi]);
+                int zero = sym ? 8 : (int)qz[nn * ng + gi];
+                uint32_t word = qw[nn * k8 + w];
+                double part = 0.0;
+                for (int p = 0; p < 4; ++p) {
+                    int even = (int)((word >> (4 * p)) & 0xfu), odd = (int)((word >> (4 * p + 16)) & 0xfu);
+                    part += (double)(even - zero) * (double)zlo_f16_to_f32(x[mm * k + 8 * w + 2 * p]);
+                    part += (double)(odd - zero) * (double)zlo_f16_to_f32(x[mm * k + 8 * w + 2 * p + 1]);
+                }
+                acc += part * s;
+            }
+            if (bias) acc += (double)zlo_f16_to_f32(bias[nn]);
+            y[mm * n + nn] = acc;
+        }
+}
+
+/* KERNEL_dequant<half,0> (q_gemm_k_major.cu:843-886): W16[n,k] = rn16(rn16(q - z) * s) */
+void zlo_gptq_dequant_k_major(const uint32_t* qw, const uint8_t* qz, const uint16_t* sc,
+                              uint16_t* out, int64_t n, int64_t k, int64_t g) {
+    int64_t k8 = k / 8, g8 = g / 8, ng = k / g;
+#pragma omp parallel for schedule(static)
+    for (int64_t nn = 0; nn < n; ++nn)
+        for (int64_t w = 0; w < k8; ++w) {
+            uint16_t d[8];
+            dequant_word(qw[nn * k8 + w], (int)qz[nn * ng + w / g8], d);
+            uint16_t s = sc[nn * ng + w / g8];
+            for (int j = 0; j < 8; ++j) out[nn * k + 8 * w + j] = h_mul(d[j], s);
+        }
+}
+
+/* KERNEL_gemm_fuse_gate_in (q_gemm_k_major.cu:529-578): out = half(silu(acc1) * acc2) with the
+ * file-local silu(x) = x / (1.0 + expf(-x)) evaluated in double (:239-241), product in fp32 */
+void zlo_gptq_gemm_fuse_gate_in(const uint16_t* x,
+                                const uint32_t* qw1, const uint8_t* qz1, const uint16_t* sc1,
+                                const uint32_t* qw2, const uint8_t* qz2, const uint16_t* sc2,
+                                uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t g, int sym) {
+    int64_t k8 = k / 8, g8 = g / 8, ng = k / g;
+#pragma omp parallel for schedule(static)
+    for (int64_t nn = 0; nn < n; ++nn)
+        for (int64_t mm = 0; mm < m; ++mm) {
+            float a1 = gemv_row_R(x + mm * k, qw1 + nn * k8, qz1 + nn * ng, sc1 + nn * ng, k8, g8, sym);
+            float a2 = gemv_row_R(x + mm * k, qw2 + nn * k8, qz2 + nn * ng, sc2 + nn * ng, k8, g8, sym);
+            float sl = (float)((double)a1 / (1.0 + (double)expf(-a1)));
+            y[mm * n + nn] = zlo_f32_to_f16(sl * a2);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a17: RMSNorm                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* KERNEL_layernorm_rms (src/nn/layernorm/layernorm.cu:10-42), launch shape :92-93:
+ * threads = min(round_up(dim,32),1024); per-thread strided fma chain of v*v, block tree, /dim,
+ * rsqrt(.+eps) (oracle: 1/sqrtf, the GPU instruction is a <=2ulp approximation),
+ * y = T(((v*r)*w)/scale); fused add: v = f32(x)+f32(x2), out_sum = T(v), norm uses the fp32 v. */
+void zlo_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* out, int64_t rows, int64_t dim,
+                 float eps, float scale, const uint16_t* x2, uint16_t* out_sum, int dtype) {
+    int threads = round_up_i((int)dim, 32);
+    if (threads > 1024) threads = 1024;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        float* v = (float*)malloc(sizeof(float) * dim);
+        float part[1024];
+        for (int t = 0; t < threads; ++t) {
+            float acc = 0.f;
+            for (int64_t i = t; i < dim; i += threads) {
+                float val = T2f(x[r * dim + i], dtype);
+                if (x2) {
+                    val += T2f(x2[r * dim + i], dtype);
+                    if (out_sum) out_sum[r * dim + i] = f2T(val, dtype);
+                }
+                v[i] = val;
+                acc = fmaf(val, val, acc);
+            }
+            part[t] = acc;
+        }
+        float ms = block_tree_sum(part, threads) / (float)dim;
+        float rs = 1.0f / sqrtf(ms + eps);
+        for (int64_t i = 0; i < dim; ++i)
+            out[r * dim + i] = f2T(v[i] * rs * T2f(w[i], dtype) / scale, dtype);
+        free(v);
+    }
+}
+
+void zlo_rmsnorm_exact(const uint16_t* x, const uint16_t* w, double* out, int64_t rows, int64_t dim,
+                       float eps, float scale, const uint16_t* x2, int dtype) {
+    for (int64_t r = 0; r < rows; ++r) {
+        double ss = 0.0;
+        for (int64_t i = 0; i < dim; ++i) {
+            double v = (double)T2f(x[r * dim + i], dtype) + (x2 ? (double)T2f(x2[r * dim + i], dtype) : 0.0);
+            ss += v * v;
+        }
+        double rs = 1.0 / sqrt(ss / (double)dim + (double)eps);
+        for (int64_t i = 0; i < dim; ++i) {
+            double v = (double)T2f(x[r * dim + i], dtype) + (x2 ? (double)T2f(x2[r * dim + i], dtype) : 0.0);
+            out[r * dim + i] = v * rs * (double)T2f(w[i], dtype) / (double)scale;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a13: RoPE                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline int half_dim_index(int col, int half_dim, int neox) { /* rope_common.cuh:3-12 */
+    return neox ? (col < half_dim ? col : col - half_dim) : col / 2;
+}
+
+/* KERNEL_rope_cos_sin (src/nn/position/rope_preparer.cu:49-69) */
+void zlo_rope_cos_sin(const int32_t* pos, float* cosv, float* sinv, int64_t s, int64_t d,
+                      float base, int neox) {
+    for (int64_t t = 0; t < s; ++t)
+        for (int col = 0; col < d; ++col) {
+            int i = half_dim_index(col, (int)d / 2, neox);
+            float inv_freq = powf(base, -(float)(i * 2) / (float)d);
+            float freq = (float)pos[t] * inv_freq;
+            cosv[t * d + col] = cosf(freq);
+            sinv[t * d + col] = sinf(freq);
+        }
+}
+
+/* KERNEL_rope_cos_sin_llama3 (rope_preparer.cu:124-160) */
+void zlo_rope_cos_sin_llama3(const int32_t* pos, float* cosv, float* sinv, int64_t s, int64_t d,
+                             float base, float factor, float low_freq_factor,
+                             float high_freq_factor, float old_context_len, int neox) {
+    for (int64_t t = 0; t < s; ++t)
+        for (int col = 0; col < d; ++col) {
+            int i = half_dim_index(col, (int)d / 2, neox);
+            float inv_freq = powf(base, -(float)(i * 2) / (float)d);
+            float low_wl = old_context_len / low_freq_factor;
+            float high_wl = old_context_len / high_freq_factor;
+            float pi = 3.141592653589793f;
+            float wavelen = 2.f * pi / inv_freq;
+            if (wavelen < high_wl) {
+            } else if (wavelen > low_wl) {
+                inv_freq = inv_freq / factor;
+            } else {
+                float smooth = (old_context_len / wavelen - low_freq_factor) / (high_freq_factor - low_freq_factor);
+                /* (1-s)*inv/factor + s*inv : nvcc contracts the final mul+add into an fma */
+                inv_freq = fmaf(smooth, inv_freq, (1.f - smooth) * inv_freq / factor);
+            }
+            float freq = (float)pos[t] * inv_freq;
+            cosv[t * d + col] = cosf(freq);
+            sinv[t * d + col] = sinf(freq);
+        }
+}
+
+/* rope_one_value (rope_common.cuh:14-34): a*cos -/+ b*sin in fp32 (second product fused) */
+static inline float rope_val(float a, float b, float c, float s, int minus) {
+    return minus ? fmaf(-b, s, a * c) : fmaf(b, s, a * c);
+}
+
+/* KERNEL_rotary_embedding_qk (src/nn/position/rotary_embedding_fuse.cu:19-67): split fused qkv,
+ * neox rotation with freq = pos * powf(theta, -2i/D) computed in fp32, one rounding to T */
+void zlo_rotary_embedding_qk(const int32_t* pos, const uint16_t* in, uint16_t* q, uint16_t* k,
+                             uint16_t* v, int64_t s, int64_t h, int64_t hkv, int64_t d,
+                             float theta, int dtype) {
+    int64_t all = h + 2 * hkv, half = d / 2;
+    for (int64_t t = 0; t < s; ++t)
+        for (int64_t head = 0; head < all; ++head) {
+            const uint16_t* src = in + (t * all + head) * d;
+            if (head >= h + hkv) {
+                memcpy(v + (t * hkv + (head - h - hkv)) * d, src, sizeof(uint16_t) * d);
+                continue;
+            }
+            uint16_t* dst = head >= h ? k + (t * hkv + (head - h)) * d : q + (t * h + head) * d;
+            for (int64_t col = 0; col < d; ++col) {
+                int64_t i = col < half ? col : col - half;
+                float freq = (float)pos[t] * powf(theta, -(float)(i * 2) / (float)d);
+                float c = cosf(freq), sn = sinf(freq);
+                float a = T2f(src[col], dtype);
+                float r = col < half ? rope_val(a, T2f(src[col + half], dtype), c, sn, 1)
+                                     : rope_val(a, T2f(src[col - half], dtype), c, sn, 0);
+                dst[col] = f2T(r, dtype);
+            }
+        }
+}
+
+/* KERNEL_rope_qk_with_cache (src/nn/position/rotary_embedding_fuse_cache.cu:23-64) */
+void zlo_rope_qk_cache(const float* cosv, const float* sinv, const uint16_t* in, uint16_t* q,
+                       uint16_t* k, uint16_t* v, int64_t s, int64_t h, int64_t hkv, int64_t d,
+                       int neox, int dtype) {
+    int64_t all = h + 2 * hkv, half = d / 2;
+    for (int64_t t = 0; t < s; ++t)
+        for (int64_t head = 0; head < all; ++head) {
+            const uint16_t* src = in + (t * all + head) * d;
+            if (head >= h + hkv) {
+                memcpy(v + (t * hkv + (head - h - hkv)) * d, src, sizeof(uint16_t) * d);
+                continue;
+            }
+            uint16_t* dst = head >= h ? k + (t * hkv + (head - h)) * d : q + (t * h + head) * d;
+            for (int64_t col = 0; col < d; ++col) {
+                float c = cosv[t * d + col], sn = sinv[t * d + col];
+                float a = T2f(src[col], dtype);
+                float r;
+                if (neox) r = col < half ? rope_val(a, T2f(src[col + half], dtype), c, sn, 1)
+                                         : rope_val(a, T2f(src[col - half], dtype), c, sn, 0);
+                else r = (col % 2 == 0) ? rope_val(a, T2f(src[col + 1], dtype), c, sn, 1)
+                                        : rope_val(a, T2f(src[col - 1], dtype), c, sn, 0);
+                dst[col] = f2T(r, dtype);
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a14: KV scatter                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* KERNEL_copy_to_rag_buffer2 (src/kvcache/ragged_buffer_kernel.cu:194-222): placement < 0 skips */
+void zlo_copy_to_rag_buffer2(const int32_t* placement, const int32_t* buf_lens,
+                             const uint16_t* k_src, const uint16_t* v_src,
+                             uint16_t* const* k_bufs, uint16_t* const* v_bufs,
+                             int64_t b, int64_t len_q, int64_t hkv, int64_t d, int bshd) {
+    for (int64_t bi = 0; bi < b; ++bi)
+        for (int64_t qi = 0; qi < len_q; ++qi) {
+            int64_t xi = bi * len_q + qi;
+            int64_t p = placement[xi];
+            if (p < 0) continue;
+            int64_t len_buf = buf_lens[bi];
+            for (int64_t head = 0; head < hkv; ++head) {
+                int64_t so = (xi * hkv + head) * d;
+                int64_t dof = bshd ? (p * hkv + head) * d : (head * len_buf + p) * d;
+                memcpy(k_bufs[bi] + dof, k_src + so, sizeof(uint16_t) * d);
+                memcpy(v_bufs[bi] + dof, v_src + so, sizeof(uint16_t) * d);
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a15: decode attention                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* q . k for one key: multiply_q_k_block (attention_kernel.cu:26-50) for D == 128 (lane handles 4
+ * consecutive d, fma chain from 0, 32-lane tree); other D: one sequential fp32 fma chain
+ * (association of the D != 128 variants is not replayed). */
+static float qk_dot(const uint16_t* q, const uint16_t* kr, int64_t d, int dtype) {
+    if (d == 128) {
+        float lane[32];
+        for (int l = 0; l < 32; ++l) {
+            float res = 0.f;
+            for (int j = 0; j < 4; ++j) res = fmaf(T2f(q[4 * l + j], dtype), T2f(kr[4 * l + j], dtype), res);
+            lane[l] = res;
+        }
+        return warp32_tree_sum(lane);
+    }
+    float res = 0.f;
+    for (int64_t j = 0; j < d; ++j) res = fmaf(T2f(q[j], dtype), T2f(kr[j], dtype), res);
+    return res;
+}
+
+/* softmax_mask_block (attention_kernel.cu:434-489) with blockDim = 1024: every thread's partial sum
+ * starts at 1e-20, max starts at -1e20; p = e / Z (fp32 division).  Returns max and Z. */
+static void softmax_mask(float* s, const int8_t* mask, float scale, int64_t len, float* out_max,
+                         float* out_sum) {
+    float mx = -1e20f;
+    for (int64_t i = 0; i < len; ++i) {
+        s[i] = mask[i] ? s[i] * scale : -INFINITY;
+        mx = fmaxf(mx, s[i]);
+    }
+    float part[1024];
+    for (int t = 0; t < 1024; ++t) {
+        float acc = 1e-20f;
+        for (int64_t i = t; i < len; i += 1024) {
+            float e = expf(s[i] - mx);
+            s[i] = e;
+            acc += e;
+        }
+        part[t] = acc;
+    }
+    float z = block_tree_sum(part, 1024);
+    for (int64_t i = 0; i < len; ++i) s[i] = s[i] / z;
+    if (out_max) *out_max = mx;
+    if (out_sum) *out_sum = z;
+}
+
+/* multiply_score_v_block2 (attention_kernel.cu:166-202): NUM_SPLIT = 1024/D contiguous shards of
+ * ceil(len/NUM_SPLIT) keys, each an fp32 fma chain, shards summed by a shuffle-down tree */
+static void score_v(const float* p, const uint16_t* v, int64_t stride, int64_t len, int64_t d,
+                    int dtype, float* out) {
+    int ns = (1024 % d == 0 && d <= 512) ? (int)(1024 / d) : 1;
+    int64_t ls = (len + ns - 1) / ns;
+    for (int64_t col = 0; col < d; ++col) {
+        float sh[32];
+        for (int s = 0; s < ns; ++s) {
+            float res = 0.f;
+            int64_t st = s * ls, en = st + ls < len ? st + ls : len;
+            for (int64_t i = st; i < en; ++i) res = fmaf(p[i], T2f(v[i * stride + col], dtype), res);
+            sh[s] = res;
+        }
+        for (int off = ns / 2; off > 0; off >>= 1)
+            for (int l = 0; l < off; ++l) sh[l] += sh[l + off];
+        out[col] = sh[0];
+    }
+}
+
+static int64_t mask_offset(const int32_t* buf_lens, int64_t bi, int64_t len_q) {
+    int64_t off = 0;
+    for (int64_t i = 0; i < bi; ++i) off += buf_lens[i];
+    return off * len_q;
+}
+
+/* KERNEL_mqa_rag_buffer1 (attention_kernel.cu:673-725), the default GQA decode kernel */
+void zlo_mqa_rag_buffer(const uint16_t* q, const int32_t* buf_lens,
+                        const uint16_t* const* k_bufs, const uint16_t* const* v_bufs,
+                        const int8_t* mask, uint16_t* out, int64_t b, int64_t len_q, int64_t h,
+                        int64_t hkv, int64_t d, float scale, int bshd, int dtype) {
+    int64_t m_query = h / hkv;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+    for (int64_t bi = 0; bi < b; ++bi)
+        for (int64_t head = 0; head < h; ++head) {
+            int64_t len = buf_lens[bi], hk = head / m_query;
+            int64_t stride = bshd ? hkv * d : d;
+            int64_t off = bshd ? hk * d : hk * len * d;
+            float* s = (float*)malloc(sizeof(float) * (len > 0 ? len : 1));
+            float* o = (float*)malloc(sizeof(float) * d);
+            for (int64_t qi = 0; qi < len_q; ++qi) {
+                const uint16_t* qv = q + ((bi * len_q + qi) * h + head) * d;
+                for (int64_t j = 0; j < len; ++j) s[j] = qk_dot(qv, k_bufs[bi] + off + j * stride, d, dtype);
+                const int8_t* mk = mask + mask_offset(buf_lens, bi, len_q) + qi * len;
+                softmax_mask(s, mk, scale, len, NULL, NULL);
+                score_v(s, v_bufs[bi] + off, stride, len, d, dtype, o);
+                for (int64_t c = 0; c < d; ++c) out[((bi * len_q + qi) * h + head) * d + c] = f2T(o[c], dtype);
+            }
+            free(s);
+            free(o);
+        }
+}
+
+/* KERNEL_mqa_rag_buffer_split_kv + KERNEL_mqa_combine (attention_kernel.cu:729-800, 880-923):
+ * len <= 512 -> single pass; else num_split contiguous chunks of ceil(len/num_split), each
+ * normalised by its own Z, combined with scale2 = Z_s / Zg * exp(m_s - m) in fp32 */
+void zlo_mqa_rag_buffer_split_kv(const uint16_t* q, const int32_t* buf_lens,
+                                 const uint16_t* const* k_bufs, const uint16_t* const* v_bufs,
+                                 const int8_t* mask, uint16_t* out, int64_t b, int64_t len_q,
+                                 int64_t h, int64_t hkv, int64_t d, float scale, int bshd,
+                                 int dtype, int num_split) {
+    int64_t m_query = h / hkv;
+    for (int64_t bi = 0; bi < b; ++bi)
+        for (int64_t head = 0; head < h; ++head) {
+            int64_t len = buf_lens[bi], hk = head / m_query;
+            int64_t stride = bshd ? hkv * d : d;
+            int64_t off = bshd ? hk * d : hk * len * d;
+            float* s = (float*)malloc(sizeof(float) * (len > 0 ? len : 1));
+            float* cache = (float*)malloc(sizeof(float) * d * (num_split > 0 ? num_split : 1));
+            for (int64_t qi = 0; qi < len_q; ++qi) {
+                const uint16_t* qv = q + ((bi * len_q + qi) * h + head) * d;
+                const int8_t* mk = mask + mask_offset(buf_lens, bi, len_q) + qi * len;
+                uint16_t* dst = out + ((bi * len_q + qi) * h + head) * d;
+                if (len <= 512 || num_split <= 1) {
+                    for (int64_t j = 0; j < len; ++j) s[j] = qk_dot(qv, k_bufs[bi] + off + j * stride, d, dtype);
+                    softmax_mask(s, mk, scale, len, NULL, NULL);
+                    score_v(s, v_bufs[bi] + off, stride, len, d, dtype, cache);
+                    for (int64_t c = 0; c < d; ++c) dst[c] = f2T(cache[c], dtype);
+                    continue;
+                }
+                float lmax[32], lsum[32];
+                int64_t ls = (len + num_split - 1) / num_split;
+                for (int sp = 0; sp < num_split; ++sp) {
+                    int64_t st = sp * ls;
+                    int64_t l2 = ls < len - st ? ls : len - st;
+                    if (l2 < 0) l2 = 0;
+                    for (int64_t j = 0; j < l2; ++j) s[j] = qk_dot(qv, k_bufs[bi] + off + (st + j) * stride, d, dtype);
+                    softmax_mask(s, mk + st, scale, l2, &lmax[sp], &lsum[sp]);
+                    score_v(s, v_bufs[bi] + off + st * stride, stride, l2, d, dtype, cache + sp * d);
+                }
+                float t[32];
+                float gmax = -1e20f;
+                for (int sp = 0; sp < num_split; ++sp) gmax = fmaxf(gmax, lmax[sp]);
+                float scale1[32];
+                for (int l = 0; l < 32; ++l) {
+                    scale1[l] = l < num_split ? expf(lmax[l] - gmax) : 0.f;
+                    t[l] = l < num_split ? lsum[l] * scale1[l] : 0.f;
+                }
+                float gsum = warp32_tree_sum(t);
+                for (int64_t c = 0; c < d; ++c) {
+                    float res = 0.f;
+                    for (int sp = 0; sp < num_split; ++sp)
+                        res = fmaf(cache[sp * d + c], lsum[sp] / gsum * scale1[sp], res);
+                    dst[c] = f2T(res, dtype);
+                }
+            }
+            free(s);
+            free(cache);
+        }
+}
+
+void zlo_mqa_rag_buffer_exact(const uint16_t* q, const int32_t* buf_lens,
+                              const uint16_t* const* k_bufs, const uint16_t* const* v_bufs,
+                              const int8_t* mask, double* out, int64_t b, int64_t len_q, int64_t h,
+                              int64_t hkv, int64_t d, float scale, int bshd, int dtype) {
+    int64_t m_query = h / hkv;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+    for (int64_t bi = 0; bi < b; ++bi)
+        for (int64_t head = 0; head < h; ++head) {
+            int64_t len = buf_lens[bi], hk = head / m_query;
+            int64_t stride = bshd ? hkv * d : d;
+            int64_t off = bshd ? hk * d : hk * len * d;
+            double* s = (double*)malloc(sizeof(double) * (len > 0 ? len : 1));
+            for (int64_t qi = 0; qi < len_q; ++qi) {
+                const uint16_t* qv = q + ((bi * len_q + qi) * h + head) * d;
+                const int8_t* mk = mask + mask_offset(buf_lens, bi, len_q) + qi * len;
+                double mx = -1e20;
+                for (int64_t j = 0; j < len; ++j) {
+                    double acc = 0.0;
+                    const uint16_t* kr = k_bufs[bi] + off + j * stride;
+                    for (int64_t c = 0; c < d; ++c) acc += (double)T2f(qv[c], dtype) * (double)T2f(kr[c], dtype);
+                    s[j] = mk[j] ? acc * (double)scale : -INFINITY;
+                    if (s[j] > mx) mx = s[j];
+                }
+                double z = 1e-20;
+                for (int64_t j = 0; j < len; ++j) { s[j] = exp(s[j] - mx); z += s[j]; }
+                for (int64_t c = 0; c < d; ++c) {
+                    double acc = 0.0;
+                    for (int64_t j = 0; j < len; ++j)
+                        acc += s[j] / z * (double)T2f(v_bufs[bi][off + j * stride + c], dtype);
+                    out[((bi * len_q + qi) * h + head) * d + c] = acc;
+                }
+            }
+            free(s);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a18: element-wise                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* element_add_scale (src/nn/block/block_kernel.cu:8-17): arithmetic in T, one rounding per op */
+void zlo_element_add_scale(const uint16_t* a, const uint16_t* b, uint16_t* c, int64_t n,
+                           float scale, int scale_residual, int dtype) {
+    uint16_t st = f2T(scale, dtype);
+    for (int64_t i = 0; i < n; ++i) {
+        double av = T2f(a[i], dtype), bv = T2f(b[i], dtype), sv = T2f(st, dtype);
+        if (scale_residual) c[i] = d2T((double)T2f(d2T(av + bv, dtype), dtype) * sv, dtype);
+        else c[i] = d2T(av + (double)T2f(d2T(bv * sv, dtype), dtype), dtype);
+    }
+}
+
+/* KERNEL_silu_mul_inplace (src/nn/linear/activation_kernel.cu:70-80), silu (functions/activation.cuh:12-14) */
+void zlo_silu_mul(const uint16_t* inp, const uint16_t* in2, uint16_t* out, int64_t n, int dtype) {
+    for (int64_t i = 0; i < n; ++i) {
+        float x = T2f(inp[i], dtype);
+        float sl = x / (1.0f + expf(-x));
+        out[i] = f2T(sl * T2f(in2[i], dtype), dtype);
+    }
+}
+
+/* KERNEL_gelu_mul_inplace (activation_kernel.cu:59-69), gelu (functions/activation.cuh:8-10) */
+void zlo_gelu_mul(const uint16_t* inp, const uint16_t* in2, uint16_t* out, int64_t n, int dtype) {
+    for (int64_t i = 0; i < n; ++i) {
+        float x = T2f(inp[i], dtype);
+        float ge = 0.5f * x * (1.0f + tanhf(0.7978845608028654f * x * (1.0f + 0.044715f * x * x)));
+        out[i] = f2T(ge * T2f(in2[i], dtype), dtype);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a22 / a21                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* BM_KERNEL(embedding) (src/nn/embedding/embedding.cu:23-44) */
+void zlo_embedding(const int32_t* ids, const uint16_t* weight, uint16_t* out, int64_t s,
+                   int64_t dim, int32_t begin, int32_t end, float scale, int dtype) {
+    for (int64_t t = 0; t < s; ++t) {
+        int32_t id = ids[t];
+        int in_range = id >= begin && id < end;
+        for (int64_t c = 0; c < dim; ++c)
+            out[t * dim + c] = in_range ? f2T(T2f(weight[(int64_t)(id - begin) * dim + c], dtype) * scale, dtype)
+                                        : f2T(0.f, dtype);
+    }
+}
+
+/* functions::Gemm (bm/functions/gemm.cpp:258-344) with fp32 compute type: y = T(alpha*(x.w^T) + bias).
+ * cuBLASLt's summation order is not in the tree -> sequential fp32 fma chain (association unpinned). */
+void zlo_gemm_nt(const uint16_t* x, const uint16_t* w, const uint16_t* bias, uint16_t* y,
+                 int64_t m, int64_t n, int64_t k, float alpha, int dtype) {
+#pragma omp parallel for schedule(static)
+    for (int64_t nn = 0; nn < n; ++nn)
+        for (int64_t mm = 0; mm < m; ++mm) {
+            float acc = 0.f;
+            for (int64_t kk = 0; kk < k; ++kk) acc = fmaf(T2f(x[mm * k + kk], dtype), T2f(w[nn * k + kk], dtype), acc);
+            float r = alpha * acc + (bias ? T2f(bias[nn], dtype) : 0.f);
+            y[mm * n + nn] = f2T(r, dtype);
+        }
+}
+
+void zlo_gemm_nt_exact(const uint16_t* x, const uint16_t* w, const uint16_t* bias, double* y,
+                       int64_t m, int64_t n, int64_t k, float alpha, int dtype) {
+#pragma omp parallel for schedule(static)
+    for (int64_t nn = 0; nn < n; ++nn)
+        for (int64_t mm = 0; mm < m; ++mm) {
+            double acc = 0.0;
+            for (int64_t kk = 0; kk < k; ++kk) acc += (double)T2f(x[mm * k + kk], dtype) * (double)T2f(w[nn * k + kk], dtype);
+            y[mm * n + nn] = (double)alpha * acc + (bias ? (double)T2f(bias[nn], dtype) : 0.0);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a8..a11: INT8                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* quant_calc_scale<T,127> (src/nn/quant/int8/quant_kernel.cu:15-47) */
+void zlo_quant_calc_scale(const uint16_t* x, int8_t* q, float* scale, int64_t m, int64_t k,
+                          int dtype) {
+    for (int64_t r = 0; r < m; ++r) {
+        float amax = 0.f;
+        for (int64_t i = 0; i < k; ++i) {
+            float v = fabsf(T2f(x[r * k + i], dtype));
+            amax = v > amax ? v : amax;
+        }
+        float bs = 127.f / amax;
+        for (int64_t i = 0; i < k; ++i) q[r * k + i] = (int8_t)nearbyintf(T2f(x[r * k + i], dtype) * bs);
+        scale[r] = amax / 127.f;
+    }
+}
+
+/* fuse_layernorm_rms_quant (quant_kernel.cu:106-151): abs-max of the fp32 products x*w is reduced
+ * in T (rounded to T), 127.0/amax and amax*rs/127. go through double */
+void zlo_rmsnorm_quant(const uint16_t* x, const uint16_t* w, uint16_t* out, int8_t* q,
+                       float* out_scale, int64_t rows, int64_t dim, float eps, float scale,
+                       int dtype) {
+    int threads = round_up_i((int)dim, 32);
+    if (threads > 1024) threads = 1024;
+    for (int64_t r = 0; r < rows; ++r) {
+        float* vw = (float*)malloc(sizeof(float) * dim);
+        float part[1024];
+        float amax = 0.f;
+        for (int t = 0; t < threads; ++t) {
+            float acc = 0.f;
+            for (int64_t i = t; i < dim; i += threads) {
+                float v = T2f(x[r * dim + i], dtype);
+                acc = fmaf(v, v, acc);
+                float p = v * T2f(w[i], dtype);
+                vw[i] = p;
+                float pa = fabsf(p);
+                amax = pa > amax ? pa : amax;
+            }
+            part[t] = acc;
+        }
+        float ss = block_tree_sum(part, threads);
+        float rs = 1.0f / sqrtf(ss / (float)dim + eps);
+        amax = T2f(f2T(amax, dtype), dtype);
+        float bs = (float)(127.0 / (double)amax);
+        for (int64_t i = 0; i < dim; ++i) {
+            float v = vw[i] / scale;
+            out[r * dim + i] = f2T(v * rs, dtype);
+            q[r * dim + i] = (int8_t)nearbyintf(v * bs);
+        }
+        out_scale[r] = (float)((double)(amax * rs) / 127.);
+        free(vw);
+    }
+}
+
+/* cuBLASLt IMMA int8 x int8 -> int32 (src/nn/linear/linear.cpp:557-635): exact integer result */
+void zlo_int8_gemm_nt(const int8_t* a, const int8_t* b, int32_t* c, int64_t m, int64_t n,
+                      int64_t k) {
+#pragma omp parallel for schedule(static)
+    for (int64_t nn = 0; nn < n; ++nn)
+        for (int64_t mm = 0; mm < m; ++mm) {
+            int32_t acc = 0;
+            for (int64_t kk = 0; kk < k; ++kk) acc += (int32_t)a[mm * k + kk] * (int32_t)b[nn * k + kk];
+            c[mm * n + nn] = acc;
+        }
+}
+
+/* KERNEL_quant_scale_back (quant_kernel.cu:231-246) */
+void zlo_quant_scale_back(const int32_t* c, const float* sx, const uint16_t* sy, uint16_t* out,
+                          int64_t m, int64_t n, int dtype) {
+    for (int64_t r = 0; r < m; ++r)
+        for (int64_t col = 0; col < n; ++col)
+            out[r * n + col] = f2T((float)c[r * n + col] * sx[r] * T2f(sy[col], dtype), dtype);
+}
+
+/* quant_back_act_mul (quant_kernel.cu:589-614): act 0 = silu, 1 = gelu */
+void zlo_quant_back_act_mul(const int32_t* a, const float* asx, const uint16_t* asy,
+                            const int32_t* b, const float* bsx, const uint16_t* bsy,
+                            uint16_t* out, int64_t m, int64_t n, int act, int dtype) {
+    for (int64_t r = 0; r < m; ++r)
+        for (int64_t col = 0; col < n; ++col) {
+            float ab = (float)a[r * n + col] * asx[r] * T2f(asy[col], dtype);
+            float bb = (float)b[r * n + col] * bsx[r] * T2f(bsy[col], dtype);
+            float gate = act == 0 ? ab / (1.0f + expf(-ab))
+                                  : 0.5f * ab * (1.0f + tanhf(0.7978845608028654f * ab * (1.0f + 0.044715f * ab * ab)));
+            out[r * n + col] = f2T(bb * gate, dtype);
+        }
+}

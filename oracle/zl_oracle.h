@@ -1,0 +1,145 @@
+/*
+ * zl_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NEVER SHIPPED OR MEASURED AS THE PRODUCT).
+ *
+ * A plain-C restatement of the arithmetic of ZhiLight's quantized-GEMM + fused-attention decode
+ * hot path, used ONLY by tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py as the checker / CPU baseline.  The product path (zhilight_amd/)
+ * never links, imports or falls back to anything in this directory.
+ *
+ * PARITY STATUS: "parity unpinned" for the quantized kernels (GPTQ/AWQ/INT8), the ragged-KV decode
+ * attention, fused qkv+RoPE and fused add+RMSNorm: the reference is CUDA-only (cannot be built or
+ * run here) and its own tests hold no golden vectors / never exercise those kernels
+ * (SURVEY.md 8c).  Each function below cites the reference file:line it restates, including the
+ * reference's rounding points.  The parts the reference tests DO pin through their in-test PyTorch
+ * models (neox RoPE, softmax attention, gated feed-forward, linear, embedding) are pinned by
+ * tests/golden/ fixtures generated from those PyTorch models (tests/golden/gen_from_reference.py).
+ *
+ * Two flavours where floating point is involved:
+ *   R ("reference-faithful"): reproduces the CUDA kernel's rounding points and reduction order
+ *     (fp16 hfma2 partial dots, fp32 fma, 32-lane shuffle trees, ...), so that it is bit-for-bit
+ *     what the CUDA kernel computes under IEEE arithmetic.
+ *   E ("exact"): the same mathematical function accumulated in fp64.
+ *
+ * dtype codes: 0 = fp16 (IEEE binary16), 1 = bf16.   All tensors are dense row-major.
+ * All citations are relative to /root/reference.
+ */
+#ifndef ZL_ORACLE_H
+#define ZL_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scalar conversions (soft float, no CPU fp16 support assumed) ---- */
+uint16_t zlo_f32_to_f16(float f);
+uint16_t zlo_f64_to_f16(double d);
+float    zlo_f16_to_f32(uint16_t h);
+uint16_t zlo_f32_to_bf16(float f);
+float    zlo_bf16_to_f32(uint16_t h);
+void zlo_f32_to_f16_array(const float* in, uint16_t* out, int64_t n);
+void zlo_f16_to_f32_array(const uint16_t* in, float* out, int64_t n);
+
+/* ---- a4: GPTQ / AWQ load-time layout transforms (bit-exact integer work) ---- */
+void zlo_gptq_shuffle(uint32_t* qweight, int64_t k8, int64_t n);
+void zlo_gptq_increase_zero(uint32_t* qzeros, int64_t nwords);
+void zlo_gptq_q4_to_q8(const uint32_t* in, uint8_t* out, int64_t nwords);
+void zlo_transpose_u32(const uint32_t* in, uint32_t* out, int64_t rows, int64_t cols);
+void zlo_transpose_u16(const uint16_t* in, uint16_t* out, int64_t rows, int64_t cols);
+void zlo_transpose_u8(const uint8_t* in, uint8_t* out, int64_t rows, int64_t cols);
+void zlo_awq_un_shuffle(uint32_t* q, int64_t dim0, int64_t n);
+void zlo_awq_shuffle(const uint32_t* in, uint32_t* out, int64_t k, int64_t n, int use_exllama);
+void zlo_gptq_prepare_k_major(const uint32_t* qweight_hf, const uint32_t* qzeros_hf,
+                              const uint16_t* scales_hf, int64_t k, int64_t n, int64_t g,
+                              uint32_t* qw_km, uint8_t* qz_km, uint16_t* sc_km);
+void zlo_gptq_dequant_hf_naive(const uint32_t* qweight_hf, const uint32_t* qzeros_hf,
+                               const uint16_t* scales_hf, const int32_t* g_idx,
+                               int64_t k, int64_t n, int64_t g, double* w_nk);
+
+/* ---- a2/a3/a5: W4A16 k-major GEMM ---- */
+void zlo_gptq_gemm_k_major(const uint16_t* x, const uint32_t* qw, const uint8_t* qz,
+                           const uint16_t* sc, const uint16_t* bias, uint16_t* y,
+                           int64_t m, int64_t n, int64_t k, int64_t g, int sym, int add_c);
+void zlo_gptq_gemm_k_major_exact(const uint16_t* x, const uint32_t* qw, const uint8_t* qz,
+                                 const uint16_t* sc, const uint16_t* bias, double* y,
+                                 int64_t m, int64_t n, int64_t k, int64_t g, int sym);
+void zlo_gptq_dequant_k_major(const uint32_t* qw, const uint8_t* qz, const uint16_t* sc,
+                              uint16_t* out, int64_t n, int64_t k, int64_t g);
+void zlo_gptq_gemm_fuse_gate_in(const uint16_t* x,
+                                const uint32_t* qw1, const uint8_t* qz1, const uint16_t* sc1,
+                                const uint32_t* qw2, const uint8_t* qz2, const uint16_t* sc2,
+                                uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t g, int sym);
+
+/* ---- a17: RMSNorm (+ fused residual add) ---- */
+void zlo_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* out, int64_t rows, int64_t dim,
+                 float eps, float scale, const uint16_t* x2, uint16_t* out_sum, int dtype);
+void zlo_rmsnorm_exact(const uint16_t* x, const uint16_t* w, double* out, int64_t rows, int64_t dim,
+                       float eps, float scale, const uint16_t* x2, int dtype);
+
+/* ---- a13: RoPE ---- */
+void zlo_rope_cos_sin(const int32_t* pos, float* cosv, float* sinv, int64_t s, int64_t d,
+                      float base, int neox);
+void zlo_rope_cos_sin_llama3(const int32_t* pos, float* cosv, float* sinv, int64_t s, int64_t d,
+                             float base, float factor, float low_freq_factor,
+                             float high_freq_factor, float old_context_len, int neox);
+void zlo_rotary_embedding_qk(const int32_t* pos, const uint16_t* in, uint16_t* q, uint16_t* k,
+                             uint16_t* v, int64_t s, int64_t h, int64_t hkv, int64_t d,
+                             float theta, int dtype);
+void zlo_rope_qk_cache(const float* cosv, const float* sinv, const uint16_t* in, uint16_t* q,
+                       uint16_t* k, uint16_t* v, int64_t s, int64_t h, int64_t hkv, int64_t d,
+                       int neox, int dtype);
+
+/* ---- a14: ragged KV scatter ---- */
+void zlo_copy_to_rag_buffer2(const int32_t* placement, const int32_t* buf_lens,
+                             const uint16_t* k_src, const uint16_t* v_src,
+                             uint16_t* const* k_bufs, uint16_t* const* v_bufs,
+                             int64_t b, int64_t len_q, int64_t hkv, int64_t d, int bshd);
+
+/* ---- a15: decode attention over ragged KV ---- */
+void zlo_mqa_rag_buffer(const uint16_t* q, const int32_t* buf_lens,
+                        const uint16_t* const* k_bufs, const uint16_t* const* v_bufs,
+                        const int8_t* mask, uint16_t* out, int64_t b, int64_t len_q, int64_t h,
+                        int64_t hkv, int64_t d, float scale, int bshd, int dtype);
+void zlo_mqa_rag_buffer_split_kv(const uint16_t* q, const int32_t* buf_lens,
+                                 const uint16_t* const* k_bufs, const uint16_t* const* v_bufs,
+                                 const int8_t* mask, uint16_t* out, int64_t b, int64_t len_q,
+                                 int64_t h, int64_t hkv, int64_t d, float scale, int bshd,
+                                 int dtype, int num_split);
+void zlo_mqa_rag_buffer_exact(const uint16_t* q, const int32_t* buf_lens,
+                              const uint16_t* const* k_bufs, const uint16_t* const* v_bufs,
+                              const int8_t* mask, double* out, int64_t b, int64_t len_q, int64_t h,
+                              int64_t hkv, int64_t d, float scale, int bshd, int dtype);
+
+/* ---- a18: element-wise ---- */
+void zlo_element_add_scale(const uint16_t* a, const uint16_t* b, uint16_t* c, int64_t n,
+                           float scale, int scale_residual, int dtype);
+void zlo_silu_mul(const uint16_t* inp, const uint16_t* in2, uint16_t* out, int64_t n, int dtype);
+void zlo_gelu_mul(const uint16_t* inp, const uint16_t* in2, uint16_t* out, int64_t n, int dtype);
+
+/* ---- a22 / a21: embedding, dense NT GEMM (lm_head) ---- */
+void zlo_embedding(const int32_t* ids, const uint16_t* weight, uint16_t* out, int64_t s,
+                   int64_t dim, int32_t begin, int32_t end, float scale, int dtype);
+void zlo_gemm_nt(const uint16_t* x, const uint16_t* w, const uint16_t* bias, uint16_t* y,
+                 int64_t m, int64_t n, int64_t k, float alpha, int dtype);
+void zlo_gemm_nt_exact(const uint16_t* x, const uint16_t* w, const uint16_t* bias, double* y,
+                       int64_t m, int64_t n, int64_t k, float alpha, int dtype);
+
+/* ---- a8..a11: INT8 (W8A8 dynamic per-token) ---- */
+void zlo_quant_calc_scale(const uint16_t* x, int8_t* q, float* scale, int64_t m, int64_t k,
+                          int dtype);
+void zlo_rmsnorm_quant(const uint16_t* x, const uint16_t* w, uint16_t* out, int8_t* q,
+                       float* out_scale, int64_t rows, int64_t dim, float eps, float scale,
+                       int dtype);
+void zlo_int8_gemm_nt(const int8_t* a, const int8_t* b, int32_t* c, int64_t m, int64_t n,
+                      int64_t k);
+void zlo_quant_scale_back(const int32_t* c, const float* sx, const uint16_t* sy, uint16_t* out,
+                          int64_t m, int64_t n, int dtype);
+void zlo_quant_back_act_mul(const int32_t* a, const float* asx, const uint16_t* asy,
+                            const int32_t* b, const float* bsx, const uint16_t* bsy,
+                            uint16_t* out, int64_t m, int64_t n, int act, int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

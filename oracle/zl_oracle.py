@@ -1,0 +1,360 @@
+"""ctypes/numpy front-end of the CPU ORACLE (oracle/zl_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg of
+bench.py.  The product package (zhilight_amd/) never imports this module.
+
+fp16 / bf16 tensors travel as numpy uint16 arrays (raw bits); helpers `h2u`/`u2h` convert between
+numpy float16 and the raw view.  dtype codes: 0 = fp16, 1 = bf16.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libzl_oracle.so")
+
+
+def build(force=False):
+    """Compile the oracle with gcc (make).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "zl_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.zlo_f16_to_f32.restype = C.c_float
+        _lib.zlo_bf16_to_f32.restype = C.c_float
+        _lib.zlo_f32_to_f16.restype = C.c_uint16
+        _lib.zlo_f32_to_f16.argtypes = [C.c_float]
+        _lib.zlo_f64_to_f16.restype = C.c_uint16
+        _lib.zlo_f64_to_f16.argtypes = [C.c_double]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i(x):
+    return C.c_int64(int(x))
+
+
+def _f(x):
+    return C.c_float(float(x))
+
+
+def h2u(a):
+    """float16 ndarray -> uint16 raw bits (contiguous)."""
+    return np.ascontiguousarray(a, dtype=np.float16).view(np.uint16)
+
+
+def u2h(a):
+    return np.ascontiguousarray(a, dtype=np.uint16).view(np.float16)
+
+
+def bf16_to_f32(a):
+    return (np.ascontiguousarray(a, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def f32_to_bf16(a):
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    lsb = (u >> 16) & 1
+    return ((u + 0x7FFF + lsb) >> 16).astype(np.uint16)
+
+
+def to_f32(a, dtype=0):
+    return bf16_to_f32(a) if dtype else u2h(a).astype(np.float32)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ----------------------------------------------------------------------------- a4 layout
+def gptq_shuffle(qweight):
+    q = _c(qweight, np.uint32).copy()
+    lib().zlo_gptq_shuffle(_p(q), _i(q.shape[0]), _i(q.shape[1]))
+    return q
+
+
+def gptq_increase_zero(qzeros):
+    q = _c(qzeros, np.uint32).copy()
+    lib().zlo_gptq_increase_zero(_p(q), _i(q.size))
+    return q
+
+
+def gptq_q4_to_q8(qzeros):
+    q = _c(qzeros, np.uint32)
+    out = np.empty(q.shape[:-1] + (q.shape[-1] * 8,), np.uint8)
+    lib().zlo_gptq_q4_to_q8(_p(q), _p(out), _i(q.size))
+    return out
+
+
+def awq_un_shuffle(q):
+    q = _c(q, np.uint32).copy()
+    lib().zlo_awq_un_shuffle(_p(q), _i(q.shape[0]), _i(q.shape[1]))
+    return q
+
+
+def awq_shuffle(qweight, use_exllama=True):
+    q = _c(qweight, np.uint32)
+    k, n8 = q.shape
+    out = np.empty((k // 8, n8 * 8), np.uint32)
+    lib().zlo_awq_shuffle(_p(q), _p(out), _i(k), _i(n8 * 8), C.c_int(int(use_exllama)))
+    return out
+
+
+def gptq_prepare_k_major(qweight_hf, qzeros_hf, scales_hf, group_size):
+    """HF (K/8,N) int32, (K/G,N/8) int32, (K/G,N) fp16-bits -> k-major (N,K/8), (N,K/G) u8, (N,K/G)."""
+    qw, qz, sc = _c(qweight_hf, np.uint32), _c(qzeros_hf, np.uint32), _c(scales_hf, np.uint16)
+    k, n = qw.shape[0] * 8, qw.shape[1]
+    ng = k // group_size
+    o_qw, o_qz, o_sc = np.empty((n, k // 8), np.uint32), np.empty((n, ng), np.uint8), np.empty((n, ng), np.uint16)
+    lib().zlo_gptq_prepare_k_major(_p(qw), _p(qz), _p(sc), _i(k), _i(n), _i(group_size), _p(o_qw), _p(o_qz), _p(o_sc))
+    return o_qw, o_qz, o_sc
+
+
+def gptq_dequant_hf_naive(qweight_hf, qzeros_hf, scales_hf, group_size, g_idx=None):
+    qw, qz, sc = _c(qweight_hf, np.uint32), _c(qzeros_hf, np.uint32), _c(scales_hf, np.uint16)
+    k, n = qw.shape[0] * 8, qw.shape[1]
+    gi = None if g_idx is None else _c(g_idx, np.int32)
+    out = np.empty((n, k), np.float64)
+    lib().zlo_gptq_dequant_hf_naive(_p(qw), _p(qz), _p(sc), _p(gi), _i(k), _i(n), _i(group_size), _p(out))
+    return out
+
+
+# ----------------------------------------------------------------------------- a2/a3/a5 GEMM
+def gptq_gemm_k_major(x, qw, qz, sc, bias=None, sym=False, add_c=None):
+    x, qw, qz, sc = _c(x, np.uint16), _c(qw, np.uint32), _c(qz, np.uint8), _c(sc, np.uint16)
+    m, k = x.shape
+    n = qw.shape[0]
+    g = k // sc.shape[1]
+    y = np.zeros((m, n), np.uint16) if add_c is None else _c(add_c, np.uint16).copy()
+    b = None if bias is None else _c(bias, np.uint16)
+    lib().zlo_gptq_gemm_k_major(_p(x), _p(qw), _p(qz), _p(sc), _p(b), _p(y), _i(m), _i(n), _i(k), _i(g),
+                                C.c_int(int(sym)), C.c_int(0 if add_c is None else 1))
+    return y
+
+
+def gptq_gemm_k_major_exact(x, qw, qz, sc, bias=None, sym=False):
+    x, qw, qz, sc = _c(x, np.uint16), _c(qw, np.uint32), _c(qz, np.uint8), _c(sc, np.uint16)
+    m, k = x.shape
+    n = qw.shape[0]
+    g = k // sc.shape[1]
+    y = np.empty((m, n), np.float64)
+    b = None if bias is None else _c(bias, np.uint16)
+    lib().zlo_gptq_gemm_k_major_exact(_p(x), _p(qw), _p(qz), _p(sc), _p(b), _p(y), _i(m), _i(n), _i(k), _i(g),
+                                      C.c_int(int(sym)))
+    return y
+
+
+def gptq_dequant_k_major(qw, qz, sc):
+    qw, qz, sc = _c(qw, np.uint32), _c(qz, np.uint8), _c(sc, np.uint16)
+    n, k = qw.shape[0], qw.shape[1] * 8
+    out = np.empty((n, k), np.uint16)
+    lib().zlo_gptq_dequant_k_major(_p(qw), _p(qz), _p(sc), _p(out), _i(n), _i(k), _i(k // sc.shape[1]))
+    return out
+
+
+def gptq_gemm_fuse_gate_in(x, w1, w2, sym=False):
+    x = _c(x, np.uint16)
+    qw1, qz1, sc1 = (_c(w1[0], np.uint32), _c(w1[1], np.uint8), _c(w1[2], np.uint16))
+    qw2, qz2, sc2 = (_c(w2[0], np.uint32), _c(w2[1], np.uint8), _c(w2[2], np.uint16))
+    m, k = x.shape
+    n = qw1.shape[0]
+    y = np.empty((m, n), np.uint16)
+    lib().zlo_gptq_gemm_fuse_gate_in(_p(x), _p(qw1), _p(qz1), _p(sc1), _p(qw2), _p(qz2), _p(sc2), _p(y),
+                                     _i(m), _i(n), _i(k), _i(k // sc1.shape[1]), C.c_int(int(sym)))
+    return y
+
+
+# ----------------------------------------------------------------------------- norm
+def rmsnorm(x, w, eps, scale=1.0, x2=None, dtype=0):
+    x, w = _c(x, np.uint16), _c(w, np.uint16)
+    rows, dim = x.shape
+    out = np.empty_like(x)
+    x2c = None if x2 is None else _c(x2, np.uint16)
+    out_sum = None if x2 is None else np.empty_like(x)
+    lib().zlo_rmsnorm(_p(x), _p(w), _p(out), _i(rows), _i(dim), _f(eps), _f(scale), _p(x2c), _p(out_sum),
+                      C.c_int(dtype))
+    return (out, out_sum) if x2 is not None else out
+
+
+def rmsnorm_exact(x, w, eps, scale=1.0, x2=None, dtype=0):
+    x, w = _c(x, np.uint16), _c(w, np.uint16)
+    rows, dim = x.shape
+    out = np.empty((rows, dim), np.float64)
+    x2c = None if x2 is None else _c(x2, np.uint16)
+    lib().zlo_rmsnorm_exact(_p(x), _p(w), _p(out), _i(rows), _i(dim), _f(eps), _f(scale), _p(x2c), C.c_int(dtype))
+    return out
+
+
+# ----------------------------------------------------------------------------- rope
+def rope_cos_sin(pos, d, base, neox=True, llama3=None):
+    pos = _c(pos, np.int32)
+    s = pos.size
+    cs, sn = np.empty((s, d), np.float32), np.empty((s, d), np.float32)
+    if llama3 is None:
+        lib().zlo_rope_cos_sin(_p(pos), _p(cs), _p(sn), _i(s), _i(d), _f(base), C.c_int(int(neox)))
+    else:
+        factor, low, high, old = llama3
+        lib().zlo_rope_cos_sin_llama3(_p(pos), _p(cs), _p(sn), _i(s), _i(d), _f(base), _f(factor), _f(low),
+                                      _f(high), _f(old), C.c_int(int(neox)))
+    return cs, sn
+
+
+def rotary_embedding_qk(pos, x, h, hkv, d, theta, dtype=0):
+    pos, x = _c(pos, np.int32), _c(x, np.uint16)
+    s = pos.size
+    q, k, v = np.empty((s, h * d), np.uint16), np.empty((s, hkv * d), np.uint16), np.empty((s, hkv * d), np.uint16)
+    lib().zlo_rotary_embedding_qk(_p(pos), _p(x), _p(q), _p(k), _p(v), _i(s), _i(h), _i(hkv), _i(d), _f(theta),
+                                  C.c_int(dtype))
+    return q, k, v
+
+
+def rope_qk_cache(cs, sn, x, h, hkv, d, neox=True, dtype=0):
+    cs, sn, x = _c(cs, np.float32), _c(sn, np.float32), _c(x, np.uint16)
+    s = cs.shape[0]
+    q, k, v = np.empty((s, h * d), np.uint16), np.empty((s, hkv * d), np.uint16), np.empty((s, hkv * d), np.uint16)
+    lib().zlo_rope_qk_cache(_p(cs), _p(sn), _p(x), _p(q), _p(k), _p(v), _i(s), _i(h), _i(hkv), _i(d),
+                            C.c_int(int(neox)), C.c_int(dtype))
+    return q, k, v
+
+
+# ----------------------------------------------------------------------------- kv + attention
+def _ptr_array(bufs):
+    arr = (C.c_void_p * len(bufs))()
+    for i, b in enumerate(bufs):
+        arr[i] = b.ctypes.data
+    return arr
+
+
+def copy_to_rag_buffer2(placement, buf_lens, k_src, v_src, k_bufs, v_bufs, bshd=True):
+    """In place on the per-task numpy uint16 buffers in k_bufs / v_bufs."""
+    placement, buf_lens = _c(placement, np.int32), _c(buf_lens, np.int32)
+    k_src, v_src = _c(k_src, np.uint16), _c(v_src, np.uint16)
+    b, len_q, hkv, d = k_src.shape
+    lib().zlo_copy_to_rag_buffer2(_p(placement), _p(buf_lens), _p(k_src), _p(v_src), _ptr_array(k_bufs),
+                                  _ptr_array(v_bufs), _i(b), _i(len_q), _i(hkv), _i(d), C.c_int(int(bshd)))
+
+
+def mqa_rag_buffer(q, buf_lens, k_bufs, v_bufs, mask, hkv, scale, bshd=True, dtype=0, num_split=0, exact=False):
+    q, buf_lens, mask = _c(q, np.uint16), _c(buf_lens, np.int32), _c(mask, np.int8)
+    b, len_q, h, d = q.shape
+    kp, vp = _ptr_array(k_bufs), _ptr_array(v_bufs)
+    if exact:
+        out = np.empty(q.shape, np.float64)
+        lib().zlo_mqa_rag_buffer_exact(_p(q), _p(buf_lens), kp, vp, _p(mask), _p(out), _i(b), _i(len_q), _i(h),
+                                       _i(hkv), _i(d), _f(scale), C.c_int(int(bshd)), C.c_int(dtype))
+        return out
+    out = np.empty_like(q)
+    if num_split:
+        lib().zlo_mqa_rag_buffer_split_kv(_p(q), _p(buf_lens), kp, vp, _p(mask), _p(out), _i(b), _i(len_q), _i(h),
+                                          _i(hkv), _i(d), _f(scale), C.c_int(int(bshd)), C.c_int(dtype),
+                                          C.c_int(num_split))
+    else:
+        lib().zlo_mqa_rag_buffer(_p(q), _p(buf_lens), kp, vp, _p(mask), _p(out), _i(b), _i(len_q), _i(h), _i(hkv),
+                                 _i(d), _f(scale), C.c_int(int(bshd)), C.c_int(dtype))
+    return out
+
+
+# ----------------------------------------------------------------------------- element-wise
+def element_add_scale(a, b, scale=1.0, scale_residual=True, dtype=0):
+    a, b = _c(a, np.uint16), _c(b, np.uint16)
+    c = np.empty_like(a)
+    lib().zlo_element_add_scale(_p(a), _p(b), _p(c), _i(a.size), _f(scale), C.c_int(int(scale_residual)),
+                                C.c_int(dtype))
+    return c
+
+
+def silu_mul(a, b, dtype=0):
+    a, b = _c(a, np.uint16), _c(b, np.uint16)
+    out = np.empty_like(a)
+    lib().zlo_silu_mul(_p(a), _p(b), _p(out), _i(a.size), C.c_int(dtype))
+    return out
+
+
+def gelu_mul(a, b, dtype=0):
+    a, b = _c(a, np.uint16), _c(b, np.uint16)
+    out = np.empty_like(a)
+    lib().zlo_gelu_mul(_p(a), _p(b), _p(out), _i(a.size), C.c_int(dtype))
+    return out
+
+
+# ----------------------------------------------------------------------------- embedding / dense gemm
+def embedding(ids, weight, scale=1.0, begin=0, end=None, dtype=0):
+    ids, weight = _c(ids, np.int32), _c(weight, np.uint16)
+    end = weight.shape[0] + begin if end is None else end
+    out = np.empty((ids.size, weight.shape[1]), np.uint16)
+    lib().zlo_embedding(_p(ids), _p(weight), _p(out), _i(ids.size), _i(weight.shape[1]), C.c_int32(begin),
+                        C.c_int32(end), _f(scale), C.c_int(dtype))
+    return out
+
+
+def gemm_nt(x, w, bias=None, alpha=1.0, dtype=0, exact=False):
+    x, w = _c(x, np.uint16), _c(w, np.uint16)
+    m, k = x.shape
+    n = w.shape[0]
+    b = None if bias is None else _c(bias, np.uint16)
+    if exact:
+        y = np.empty((m, n), np.float64)
+        lib().zlo_gemm_nt_exact(_p(x), _p(w), _p(b), _p(y), _i(m), _i(n), _i(k), _f(alpha), C.c_int(dtype))
+    else:
+        y = np.empty((m, n), np.uint16)
+        lib().zlo_gemm_nt(_p(x), _p(w), _p(b), _p(y), _i(m), _i(n), _i(k), _f(alpha), C.c_int(dtype))
+    return y
+
+
+# ----------------------------------------------------------------------------- int8
+def quant_calc_scale(x, dtype=0):
+    x = _c(x, np.uint16)
+    m, k = x.shape
+    q, s = np.empty((m, k), np.int8), np.empty((m,), np.float32)
+    lib().zlo_quant_calc_scale(_p(x), _p(q), _p(s), _i(m), _i(k), C.c_int(dtype))
+    return q, s
+
+
+def rmsnorm_quant(x, w, eps, scale=1.0, dtype=0):
+    x, w = _c(x, np.uint16), _c(w, np.uint16)
+    rows, dim = x.shape
+    out, q, s = np.empty_like(x), np.empty((rows, dim), np.int8), np.empty((rows,), np.float32)
+    lib().zlo_rmsnorm_quant(_p(x), _p(w), _p(out), _p(q), _p(s), _i(rows), _i(dim), _f(eps), _f(scale),
+                            C.c_int(dtype))
+    return out, q, s
+
+
+def int8_gemm_nt(a, b):
+    a, b = _c(a, np.int8), _c(b, np.int8)
+    m, k = a.shape
+    n = b.shape[0]
+    c = np.empty((m, n), np.int32)
+    lib().zlo_int8_gemm_nt(_p(a), _p(b), _p(c), _i(m), _i(n), _i(k))
+    return c
+
+
+def quant_scale_back(c, sx, sy, dtype=0):
+    c, sx, sy = _c(c, np.int32), _c(sx, np.float32), _c(sy, np.uint16)
+    m, n = c.shape
+    out = np.empty((m, n), np.uint16)
+    lib().zlo_quant_scale_back(_p(c), _p(sx), _p(sy), _p(out), _i(m), _i(n), C.c_int(dtype))
+    return out
+
+
+def quant_back_act_mul(a, asx, asy, b, bsx, bsy, act="silu", dtype=0):
+    a, b = _c(a, np.int32), _c(b, np.int32)
+    m, n = a.shape
+    out = np.empty((m, n), np.uint16)
+    lib().zlo_quant_back_act_mul(_p(a), _p(_c(asx, np.float32)), _p(_c(asy, np.uint16)), _p(b),
+                                 _p(_c(bsx, np.float32)), _p(_c(bsy, np.uint16)), _p(out), _i(m), _i(n),
+                                 C.c_int(0 if act == "silu" else 1), C.c_int(dtype))
+    return out
