@@ -1,0 +1,229 @@
+/*
+ * zhilight_amd.h -- C ABI of the MI355X (gfx950) decode hot path.
+ *
+ * This is the drop-in boundary: one flat `extern "C"` launcher per kernel
+ * family of ZhiLight's `src/nn` quantized-GEMM + fused-attention path.  Every launcher
+ *   - takes raw DEVICE pointers, sizes and a `hipStream_t` (passed as void*),
+ *   - only enqueues work on that stream: it never allocates, never synchronises, keeps no global
+ *     mutable state and is re-entrant (several host threads, one per GPU, may call concurrently),
+ *   - returns 0 on success, a negative ZL_E* code for an invalid argument, or a positive
+ *     hipError_t if the launch itself failed.  Nothing throws.
+ * The C++ `nn::` / `gptq::` / `int8_op::` wrappers of the reference (which allocate outputs with
+ * `ctx.tensor` and raise BMEngineException) sit directly on top of these; INTEGRATION.md shows the
+ * binding.  Each declaration cites the reference interface it replaces (paths relative to the
+ * ZhiLight tree).
+ *
+ * dtype codes: ZL_F16 = 0 (IEEE half), ZL_BF16 = 1.  All tensors are dense row-major unless a
+ * stride is passed.  "T" below means the activation dtype.
+ */
+#ifndef ZHILIGHT_AMD_H
+#define ZHILIGHT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZL_VERSION 100 /* 0.1.0 */
+
+enum { ZL_F16 = 0, ZL_BF16 = 1 };
+
+enum {
+    ZL_OK = 0,
+    ZL_EINVAL = -1,   /* null pointer / non-positive size */
+    ZL_ESHAPE = -2,   /* shape not supported by the kernel (alignment, divisibility) */
+    ZL_EDTYPE = -3,   /* dtype not supported on this path */
+    ZL_ELIMIT = -4    /* exceeds a hardware limit (LDS, grid) */
+};
+
+typedef void* zl_stream_t; /* hipStream_t */
+
+int zl_version(void);
+const char* zl_status_string(int status);
+/* number of CUs of the current device (cached per call; used by grid heuristics). >0 or -hipError */
+int zl_device_cu_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * a4  Load-time layout transforms (bit-exact integer work).
+ * Replaces nn::gptq::gptq_shuffle / increase_zero / q4_to_q8 / un_shuffle / shuffle_awq
+ * (src/nn/quant/gptq/gptq.h:24-49,141-148; kernels utils.cu:25-214, q_gemm.cu:778-791) and
+ * functions::Transpose as used by Int4GPTQ::transpose_weight (src/nn/linear/linear.cpp:1085-1099).
+ * ---------------------------------------------------------------------------------------------- */
+int zl_gptq_shuffle(uint32_t* qweight /* (K/8,N) in place */, int64_t k8, int64_t n, zl_stream_t s);
+int zl_gptq_increase_zero(uint32_t* qzeros /* in place */, int64_t nwords, zl_stream_t s);
+int zl_gptq_q4_to_q8(const uint32_t* in, uint8_t* out /* 8*nwords bytes */, int64_t nwords, zl_stream_t s);
+int zl_transpose_2d(const void* in, void* out, int64_t rows, int64_t cols, int elem_size /*1,2,4*/, zl_stream_t s);
+int zl_awq_un_shuffle(uint32_t* q /* (dim0,n) in place */, int64_t dim0, int64_t n, zl_stream_t s);
+int zl_awq_shuffle(const uint32_t* in /* (K,N/8) */, uint32_t* out /* (K/8,N) */, int64_t k, int64_t n,
+                   int use_exllama, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * ZLW4: the gfx950-native packed W4 layout consumed by zl_w4a16_gemm (DESIGN.md "ZLW4 layout").
+ * It is produced once at load time from the reference's k-major tensors
+ *     qweight (N, K/8) uint32 (exllama-shuffled words), qzeros (N, K/G) uint8, scales (N, K/G) fp16
+ * i.e. exactly what Int4GPTQ::preprocess_weight + transpose_weight leave on the device
+ * (src/nn/linear/linear.cpp:1139-1160, 1085-1099), so it plays the role of that load-time step.
+ *   Kp = K rounded up to 1024, Np = N rounded up to 2, Q = Kp/1024, C = max(1, 256/G)
+ *   qw     : uint32 [Np/2][Q][64][4]   word (row 2*pr + lane/32, index (lane%32) + 32*(4q+j))
+ *   scales : fp16   [Np][Q][C][4]      scale of group ((1024q + 256j)/G + c)
+ *   zeros  : uint16 [Np][Q][C]         the same 4 groups' zero points, one nibble each (bits 4j)
+ * Padding rows / words hold q = z = 0, scale = 0 (contribute exactly 0).
+ * row_interleave != 0 packs source row (i%2)*(N/2) + i/2 at packed row i, so that a vertically
+ * concatenated [gate; up] matrix ends up as (gate_n, up_n) row pairs for the fused silu*mul epilogue.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t n, k, group_size;   /* logical shape */
+    int64_t np, kp, q, c;       /* padded shape, loads per row, scale classes */
+    int64_t qw_bytes, scales_bytes, zeros_bytes;
+} zl_w4_layout_t;
+
+int zl_w4_layout(int64_t n, int64_t k, int64_t group_size, zl_w4_layout_t* out);
+int zl_w4_pack(const uint32_t* qweight_km, const uint8_t* qzeros_km, const uint16_t* scales_km,
+               int64_t n, int64_t k, int64_t group_size, int row_interleave,
+               uint32_t* qw, uint16_t* scales, uint16_t* zeros, zl_stream_t s);
+/* inverse of zl_w4_pack's qw/zeros/scales for row n (debug / tests): dequantised fp16 rows,
+ * W16[n,k] = rn16(rn16(q - z) * s)  -- nn::gptq::dequant_k_major, out_type 0
+ * (src/nn/quant/gptq/q_gemm_k_major.cu:907-952, kernel :843-886) */
+int zl_w4_dequant(const uint32_t* qw, const uint16_t* scales, const uint16_t* zeros,
+                  int64_t n, int64_t k, int64_t group_size, uint16_t* out /* (N,K) fp16 */, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a2/a5  W4A16 GEMM for decode batches, y = x . dequant(W)^T (+ epilogue).
+ * Replaces nn::gptq::gptq_gemm_k_major for M <= 40 / KERNEL_gemm_warp_reduce
+ * (src/nn/quant/gptq/q_gemm_k_major.cu:957-1116, 127-237) and nn::gptq::gemm_fuse_gate_in (:765-829).
+ * Arithmetic per 8-weight word is the reference's: exact fp16 (q - z), two fp16 hfma2 accumulators,
+ * f32(lo) + f32(hi), fp32 fma with the group scale, lanes walking words l, l+32, ... and a 32-lane
+ * shuffle-down tree -- results are bit-identical to the CUDA kernel's.
+ *
+ * x fp16 (M, K) row stride ldx elements; y fp16 (M, N) (N/2 columns when ZL_EPI_SILU_MUL).
+ * prologue: if norm_weight != NULL the input rows are RMS-normalised on the fly,
+ *           x' = T(x * rsqrt(mean(x^2) + eps) * w)  (LayerNorm::forward, src/nn/layernorm/layernorm.cu:10-42)
+ * epilogue flags:
+ *   ZL_EPI_BIAS      y = half(acc + bias[n])
+ *   ZL_EPI_ADD_C     y = half(float(y) + acc + bias)            (kernel's ADD_C)
+ *   ZL_EPI_RESIDUAL  y = half( float(residual[m,n]) + float(half(acc + bias)) )
+ *                    = element_add_scale_out(residual, linear_out, scale = 1)  (src/nn/block/block_kernel.cu:8-17)
+ *   ZL_EPI_SILU_MUL  weights packed with row_interleave: out[m,j] = half(silu(float(half(g))) * float(half(u)))
+ *                    = gate_mul_inplace("silu") on the two fp16 linears (src/nn/linear/activation_kernel.cu:70-106)
+ *   ZL_EPI_SILU_MUL_F32  same without the intermediate fp16 roundings = KERNEL_gemm_fuse_gate_in (:529-578)
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    ZL_EPI_BIAS = 1, ZL_EPI_ADD_C = 2, ZL_EPI_RESIDUAL = 4, ZL_EPI_SILU_MUL = 8, ZL_EPI_SILU_MUL_F32 = 16
+};
+
+int zl_w4a16_gemm(const uint16_t* x, int64_t ldx,
+                  const uint32_t* qw, const uint16_t* scales, const uint16_t* zeros,
+                  const uint16_t* bias, const uint16_t* residual, uint16_t* y,
+                  int64_t m, int64_t n, int64_t k, int64_t group_size, int sym,
+                  const uint16_t* norm_weight, float norm_eps, int epilogue, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a21  Dense NT GEMM for small M (lm_head, NormalLinear decode): y = T(alpha * x . W^T + bias),
+ * fp32 accumulate.  Replaces functions::Gemm::forward (bm/functions/gemm.cpp:505-542) on the decode
+ * path: RawEmbedding::projection (src/nn/embedding/embedding.cu:274-289).
+ * ---------------------------------------------------------------------------------------------- */
+int zl_gemm_nt_small_m(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K) */, const uint16_t* bias,
+                       uint16_t* y, int64_t m, int64_t n, int64_t k, float alpha, int dtype,
+                       const uint16_t* norm_weight, float norm_eps, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a17  RMSNorm and fused residual-add + RMSNorm.
+ * Replaces nn::LayerNorm::forward / fuse_add (src/nn/layernorm/layernorm.cu:408-432, 227-302).
+ * out = T(v * rsqrt(mean(v^2)+eps) * w / scale), v = f32(x) (+ f32(x2); out_sum = T(v) if given).
+ * ---------------------------------------------------------------------------------------------- */
+int zl_rmsnorm(const uint16_t* x, const uint16_t* weight, uint16_t* out, int64_t rows, int64_t dim,
+               float eps, float scale, const uint16_t* x2, uint16_t* out_sum, int dtype, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a13  RoPE.  Replaces RopePreparer::compute_cos_sin (src/nn/position/rope_preparer.cu:49-69,
+ * 124-160), rotary_embedding_qk (rotary_embedding_fuse.cu:70-123) and rope_qk_cache
+ * (rotary_embedding_fuse_cache.cu:65-125).  cos/sin are fp32 (S, D).
+ * ---------------------------------------------------------------------------------------------- */
+int zl_rope_cos_sin(const int32_t* pos, float* cosv, float* sinv, int64_t s_len, int64_t d, float base,
+                    int neox, zl_stream_t s);
+int zl_rope_cos_sin_llama3(const int32_t* pos, float* cosv, float* sinv, int64_t s_len, int64_t d, float base,
+                           float factor, float low_freq_factor, float high_freq_factor,
+                           float old_context_len, int neox, zl_stream_t s);
+int zl_rotary_embedding_qk(const int32_t* pos, const uint16_t* in, uint16_t* q, uint16_t* k, uint16_t* v,
+                           int64_t s_len, int64_t h, int64_t hkv, int64_t d, float theta, int dtype,
+                           zl_stream_t s);
+int zl_rope_qk_cache(const float* cosv, const float* sinv, const uint16_t* in, uint16_t* q, uint16_t* k,
+                     uint16_t* v, int64_t s_len, int64_t h, int64_t hkv, int64_t d, int neox, int dtype,
+                     zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a14  Scatter new K/V rows into the per-task ragged buffers.
+ * Replaces nn::copy_to_rag_buffer2 (src/kvcache/ragged_buffer_kernel.cu:254-300, kernel :194-222).
+ * k_bufs / v_bufs: DEVICE arrays of B raw pointers (RagBufferContext::buf_k_addr,
+ * src/model/rag_buffer_context.h:141-188); layout per task BSHD (len_buf,Hkv,D) or BHSD (Hkv,len_buf,D).
+ * ---------------------------------------------------------------------------------------------- */
+int zl_copy_to_rag_buffer2(const int32_t* placement, const int32_t* buf_lens, const uint16_t* k_src,
+                           const uint16_t* v_src, uint16_t* const* k_bufs, uint16_t* const* v_bufs,
+                           int64_t b, int64_t len_q, int64_t hkv, int64_t d, int bshd, zl_stream_t s);
+
+/* Fused decode-step front end: split fused qkv rows, rotate q and k with cached cos/sin, write q
+ * and scatter k,v straight into the ragged buffers (rope_qk_cache + copy_to_rag_buffer2 in one
+ * launch; same roundings: one rounding to T after the fp32 rotation). len_q == 1 per task. */
+int zl_rope_scatter_decode(const float* cosv, const float* sinv, const uint16_t* qkv /* (B,(H+2Hkv)D) */,
+                           uint16_t* q /* (B,H*D) */, const int32_t* placement /* (B) */,
+                           const int32_t* buf_lens, uint16_t* const* k_bufs, uint16_t* const* v_bufs,
+                           int64_t b, int64_t h, int64_t hkv, int64_t d, int neox, int bshd, int dtype,
+                           zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a15  Decode ("search") attention over ragged KV.
+ * Replaces nn::multi_query_attention_rag_buffer / attention_qkv_rag_buffer
+ * (src/nn/attention/attention_kernel.cu:1252-1457, 1150-1213; kernels :673-923) and
+ * get_mqa_workspace (:1237-1250).
+ *   out[b,q,h,:] = softmax_j( mask[b][q,j] ? scale * q.K_j : -inf ) . V      (max init -1e20, Z init 1e-20)
+ * q/out (B, len_q, H, D) T; buf_lens (B) int32; k_bufs/v_bufs device arrays of B pointers;
+ * mask int8 concatenated per task (len_q x len_buf_b), may be NULL with valid_lens (B) != NULL meaning
+ * "the first valid_lens[b] entries are visible" (the greedy/sampling decode case).
+ * workspace: zl_decode_attn_workspace_bytes() bytes of device scratch (split-KV partials).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t zl_decode_attn_workspace_bytes(int64_t b, int64_t len_q, int64_t h, int64_t d, int64_t max_len_buf);
+int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
+                   const uint16_t* const* v_bufs, const int8_t* mask, const int32_t* valid_lens,
+                   uint16_t* out, void* workspace, int64_t b, int64_t len_q, int64_t h, int64_t hkv,
+                   int64_t d, float scale, int64_t max_len_buf, int bshd, int dtype, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a18  Element-wise.  Replaces nn::element_add_scale_out (src/nn/block/block_kernel.cu:19-50) and
+ * nn::gate_mul_inplace (src/nn/linear/activation_kernel.cu:82-106; act 0 = silu, 1 = gelu).
+ * ---------------------------------------------------------------------------------------------- */
+int zl_element_add_scale(const uint16_t* a, const uint16_t* b, uint16_t* c, int64_t n, float scale,
+                         int scale_residual, int dtype, zl_stream_t s);
+int zl_gate_mul(const uint16_t* gate, const uint16_t* up, uint16_t* out, int64_t n, int act, int dtype,
+                zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a22  Embedding lookup.  Replaces RawEmbedding::forward (src/nn/embedding/embedding.cu:260-272,
+ * kernel :23-44): out = in-range ? T(f32(weight[id-begin]) * scale) : 0.
+ * ---------------------------------------------------------------------------------------------- */
+int zl_embedding(const int32_t* ids, const uint16_t* weight, uint16_t* out, int64_t s_len, int64_t dim,
+                 int32_t begin, int32_t end, float scale, int dtype, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a8..a11  INT8 (W8A8, dynamic per-token).  Replaces int8_op::quant_calc_scale, layernorm_quant,
+ * quant_scale_back, quant_back_act_mul (src/nn/quant/int8/quant_kernel.h:15-128; kernels
+ * quant_kernel.cu:15-47, 106-151, 231-246, 589-614) and the cuBLASLt IMMA call of
+ * Int8Linear::forward (src/nn/linear/linear.cpp:557-635).  Integer results are bit-exact.
+ * ---------------------------------------------------------------------------------------------- */
+int zl_quant_calc_scale(const uint16_t* x, int8_t* q, float* scale, int64_t m, int64_t k, int dtype,
+                        zl_stream_t s);
+int zl_rmsnorm_quant(const uint16_t* x, const uint16_t* weight, uint16_t* out, int8_t* q, float* out_scale,
+                     int64_t rows, int64_t dim, float eps, float scale, int dtype, zl_stream_t s);
+int zl_int8_gemm_nt(const int8_t* a /* (M,K) */, const int8_t* b /* (N,K) */, int32_t* c /* (M,N) */,
+                    int64_t m, int64_t n, int64_t k, zl_stream_t s);
+int zl_quant_scale_back(const int32_t* c, const float* scale_x, const uint16_t* scale_y, uint16_t* out,
+                        int64_t m, int64_t n, int dtype, zl_stream_t s);
+int zl_quant_back_act_mul(const int32_t* a, const float* a_sx, const uint16_t* a_sy, const int32_t* b,
+                          const float* b_sx, const uint16_t* b_sy, uint16_t* out, int64_t m, int64_t n,
+                          int act, int dtype, zl_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZHILIGHT_AMD_H */

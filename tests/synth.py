@@ -1,0 +1,30 @@
+"""Seeded synthetic inputs of SURVEY.md 8(d): HF-layout GPTQ tensors, activations, KV."""
+import numpy as np
+
+
+def gptq_hf(rng, k, n, g, sym=False):
+    """qweight (K/8,N) int32 uniform nibbles; qzeros (K/G,N/8) int32 nibbles 0..14 stored as zero-1
+    (sym: all 7 => zero 8); scales (K/G,N) fp16 = |N(0,1)|*0.02/8 + 1e-4 (returned as uint16 bits)."""
+    nib = rng.integers(0, 16, size=(k, n), dtype=np.uint32)
+    qweight = np.zeros((k // 8, n), np.uint32)
+    for j in range(8):
+        qweight |= nib[j::8, :] << np.uint32(4 * j)
+    ng = k // g
+    zn = np.full((ng, n), 7, np.uint32) if sym else rng.integers(0, 15, size=(ng, n), dtype=np.uint32)
+    qzeros = np.zeros((ng, n // 8), np.uint32)
+    for j in range(8):
+        qzeros |= zn[:, j::8] << np.uint32(4 * j)
+    scales = (np.abs(rng.standard_normal((ng, n))) * 0.02 / 8 + 1e-4).astype(np.float16)
+    return qweight, qzeros, scales.view(np.uint16)
+
+
+def act(rng, m, k, scale=1.0):
+    return (rng.standard_normal((m, k)) * scale).astype(np.float16)
+
+
+def ulp_diff_f16(a_bits, b_bits):
+    """|a-b| in fp16 ulps computed on the monotonic integer line (raw uint16 inputs)."""
+    def key(u):
+        u = u.astype(np.int32)
+        return np.where(u & 0x8000, 0x8000 - (u & 0x7FFF), u + 0x8000)  # -0 == +0
+    return np.abs(key(np.asarray(a_bits)) - key(np.asarray(b_bits)))

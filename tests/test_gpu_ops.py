@@ -1,0 +1,283 @@
+"""GPU parity for the non-GEMM rows of SURVEY 8a (a8-a11, a13-a18, a21, a22) through the C ABI vs the
+CPU oracle.  Integer / index / copy work is bit-exact; fp work within the stated ulp / relative bars."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.view(dtype)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _bits(t):
+    return _np(t.view(torch.int16)).view(np.uint16)
+
+
+def _to_bits(x, dtype, oracle):
+    return oracle.f32_to_bf16(x.astype(np.float32)) if dtype else oracle.h2u(x.astype(np.float16))
+
+
+def _tt(bits, dev, dtype):
+    return _t(bits.view(np.int16), dev, torch.bfloat16 if dtype else torch.float16)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dim,eps", [(4096, 1e-5), (2304, 1e-6), (8192, 1e-5)])
+def test_rmsnorm(oracle, dev, dim, eps, dtype):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(0)
+    x = _to_bits(rng.standard_normal((5, dim)) * 2, dtype, oracle)
+    x2 = _to_bits(rng.standard_normal((5, dim)), dtype, oracle)
+    w = _to_bits(1 + 0.1 * rng.standard_normal(dim), dtype, oracle)
+    ref = oracle.rmsnorm(x, w, eps, dtype=dtype)
+    got = _bits(ops.rmsnorm(_tt(x, dev, dtype), _tt(w, dev, dtype), eps))
+    ulp = synth.ulp_diff_f16(got, ref)
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 0.02, (ulp.max(), (ulp > 0).mean())   # bar: <= 1 ulp of T
+    exact = oracle.rmsnorm_exact(x, w, eps, dtype=dtype)
+    assert np.abs(oracle.to_f32(got, dtype) - exact).max() <= np.abs(exact).max() * (2 ** -8 if dtype else 2 ** -11) * 1.01
+    ref2, refsum = oracle.rmsnorm(x, w, eps, x2=x2, dtype=dtype)
+    o, osum = ops.rmsnorm(_tt(x, dev, dtype), _tt(w, dev, dtype), eps, x2=_tt(x2, dev, dtype))
+    assert np.array_equal(_bits(osum), refsum)   # T(f32(a)+f32(b)): exact
+    ulp = synth.ulp_diff_f16(_bits(o), ref2)
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 0.02
+
+
+@pytest.mark.parametrize("theta", [1e4, 5e5])
+def test_rope_tables_and_fused_qk(oracle, dev, theta):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(1)
+    h, hkv, d = 8, 2, 128
+    pos = np.concatenate([np.arange(0, 70), [1024, 4095, 8191, 131071]]).astype(np.int32)
+    s = pos.size
+    for llama3 in (None, (8.0, 1.0, 4.0, 8192.0)):
+        rc, rs = oracle.rope_cos_sin(pos, d, theta, True, llama3)
+        gc, gs = ops.rope_cos_sin(_t(pos, dev), d, theta, True, llama3)
+        # fp32 trig of arguments up to 1.3e5: device vs glibc agree to a few ulp of the ARGUMENT rounding
+        assert np.abs(_np(gc) - rc).max() < 2e-6 and np.abs(_np(gs) - rs).max() < 2e-6
+    x = synth.act(rng, s, (h + 2 * hkv) * d)
+    rq, rk, rv = oracle.rotary_embedding_qk(pos, oracle.h2u(x), h, hkv, d, theta)
+    gq, gk, gv = ops.rotary_embedding_qk(_t(pos, dev), _t(x, dev), h, hkv, d, theta)
+    assert np.array_equal(_bits(gv), rv)
+    for g_, r_ in ((gq, rq), (gk, rk)):
+        ulp = synth.ulp_diff_f16(_bits(g_), r_)
+        assert ulp.max() <= 2 and (ulp > 1).mean() < 1e-3, ulp.max()    # bar: <= 2 fp16 ulp
+    # cached variant: identical cos/sin input -> bit-exact except fma association (<= 1 ulp)
+    rc, rs = oracle.rope_cos_sin(pos, d, theta, True, (8.0, 1.0, 4.0, 8192.0))
+    for neox in (True, False):
+        rq, rk, rv = oracle.rope_qk_cache(rc, rs, oracle.h2u(x), h, hkv, d, neox)
+        gq, gk, gv = ops.rope_qk_cache(_t(rc, dev), _t(rs, dev), _t(x, dev), h, hkv, d, neox)
+        assert np.array_equal(_bits(gv), rv)
+        assert np.array_equal(_bits(gq), rq) and np.array_equal(_bits(gk), rk)
+
+
+def _make_kv(rng, lens, hkv, d, bshd, dev, dtype=0, oracle=None):
+    kb, vb = [], []
+    for L in lens:
+        shape = (L, hkv, d) if bshd else (hkv, L, d)
+        kb.append(_to_bits(rng.standard_normal(shape), dtype, oracle))
+        vb.append(_to_bits(rng.standard_normal(shape), dtype, oracle))
+    tdt = torch.bfloat16 if dtype else torch.float16
+    dk = [_t(a.view(np.int16), dev, tdt) for a in kb]
+    dv = [_t(a.view(np.int16), dev, tdt) for a in vb]
+    return kb, vb, dk, dv
+
+
+@pytest.mark.parametrize("bshd", [True, False])
+def test_kv_scatter_bit_exact(oracle, dev, bshd):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(2)
+    hkv, d, len_q = 8, 128, 3
+    lens = [64, 128, 192, 65]
+    kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, bshd, dev, oracle=oracle)
+    b = len(lens)
+    placement = np.stack([rng.choice(L, len_q, replace=False) for L in lens]).astype(np.int32)
+    placement[1, 1] = -1
+    ks, vs = synth.act(rng, b * len_q, hkv * d).reshape(b, len_q, hkv, d), synth.act(rng, b * len_q, hkv * d).reshape(b, len_q, hkv, d)
+    oracle.copy_to_rag_buffer2(placement, np.array(lens, np.int32), oracle.h2u(ks), oracle.h2u(vs), kb, vb, bshd)
+    ops.copy_to_rag_buffer2(_t(placement, dev), _t(np.array(lens, np.int32), dev), _t(ks, dev), _t(vs, dev),
+                            ops.make_ptr_table(dk), ops.make_ptr_table(dv), bshd)
+    for i in range(b):
+        assert np.array_equal(_bits(dk[i]), kb[i]) and np.array_equal(_bits(dv[i]), vb[i])
+
+
+def _mask_for(lens, len_q, rng, mode):
+    parts = []
+    for L in lens:
+        if mode == "prefix":
+            vis = rng.integers(1, L + 1)
+            m = np.zeros((len_q, L), np.int8)
+            m[:, :vis] = 1
+        else:
+            m = (rng.random((len_q, L)) < 0.7).astype(np.int8)
+            m[:, 0] = 1
+        parts.append(m.reshape(-1))
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("h,hkv,d,len_q", [(32, 8, 128, 1), (32, 32, 128, 1), (16, 2, 64, 1), (8, 2, 128, 4), (4, 4, 256, 2)])
+@pytest.mark.parametrize("bshd", [True, False])
+def test_decode_attention(oracle, dev, h, hkv, d, len_q, bshd):
+    """A.6 oracle (fp32, reference association) and fp64 oracle; bar 1e-3 relative to max|out| (the
+    reference's own test uses atol = max|out|/100, tests/test_attention.py:320-322)."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(3)
+    lens = [1, 63, 64, 130, 1088, 517]
+    b = len(lens)
+    kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, bshd, dev, oracle=oracle)
+    q = synth.act(rng, b * len_q * h, d).reshape(b, len_q, h, d)
+    scale = 1.0 / np.sqrt(d)
+    for mode in ("prefix", "random"):
+        mask = _mask_for(lens, len_q, rng, mode)
+        ref = oracle.u2h(oracle.mqa_rag_buffer(oracle.h2u(q), np.array(lens, np.int32), kb, vb, mask, hkv, scale, bshd)).astype(np.float64)
+        exact = oracle.mqa_rag_buffer(oracle.h2u(q), np.array(lens, np.int32), kb, vb, mask, hkv, scale, bshd, exact=True)
+        got = ops.multi_query_attention_rag_buffer(_t(q, dev), _t(np.array(lens, np.int32), dev), ops.make_ptr_table(dk),
+                                                   ops.make_ptr_table(dv), _t(mask, dev), scale, max(lens), hkv, bshd=bshd)
+        g = _np(got).astype(np.float64)
+        assert np.isfinite(g).all()
+        tol = 1e-3 * max(1.0, np.abs(exact).max())
+        assert np.abs(g - exact).max() < tol, np.abs(g - exact).max()
+        assert np.abs(g - ref).max() < 2 * tol
+
+
+def test_decode_attention_valid_lens_and_bf16(oracle, dev):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(4)
+    h, hkv, d = 32, 8, 128
+    lens = [1088, 1088, 256]
+    valid = [1025, 7, 256]
+    for dtype in (0, 1):
+        kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, True, dev, dtype, oracle)
+        q = _to_bits(rng.standard_normal((3, 1, h, d)), dtype, oracle)
+        mask = np.concatenate([(np.arange(L) < v).astype(np.int8) for L, v in zip(lens, valid)])
+        exact = oracle.mqa_rag_buffer(q, np.array(lens, np.int32), kb, vb, mask, hkv, 0.088, True, dtype=dtype, exact=True)
+        got = ops.multi_query_attention_rag_buffer(_tt(q, dev, dtype), _t(np.array(lens, np.int32), dev),
+                                                   ops.make_ptr_table(dk), ops.make_ptr_table(dv), None, 0.088, max(lens), hkv,
+                                                   valid_lens=_t(np.array(valid, np.int32), dev))
+        g = oracle.to_f32(_bits(got), dtype).astype(np.float64)
+        rel = 1e-3 if dtype == 0 else 5e-3   # output rounding of bf16 is 2^-9 relative
+        assert np.abs(g - exact).max() < rel * max(1.0, np.abs(exact).max())
+
+
+def test_decode_attention_long_split(oracle, dev):
+    """L = 32768 exercises many splits + combine; checked against the fp64 oracle and against the
+    reference's split-KV + combine restatement."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(5)
+    h, hkv, d = 8, 2, 128
+    lens = [32768, 4096]
+    kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, True, dev, oracle=oracle)
+    q = synth.act(rng, 2 * h, d).reshape(2, 1, h, d)
+    mask = np.ones(sum(lens), np.int8)
+    exact = oracle.mqa_rag_buffer(oracle.h2u(q), np.array(lens, np.int32), kb, vb, mask, hkv, 0.088, True, exact=True)
+    ref_split = oracle.u2h(oracle.mqa_rag_buffer(oracle.h2u(q), np.array(lens, np.int32), kb, vb, mask, hkv, 0.088, True,
+                                                 num_split=8)).astype(np.float64)
+    got = _np(ops.multi_query_attention_rag_buffer(_t(q, dev), _t(np.array(lens, np.int32), dev), ops.make_ptr_table(dk),
+                                                   ops.make_ptr_table(dv), _t(mask, dev), 0.088, max(lens), hkv)).astype(np.float64)
+    tol = 1e-3 * max(1.0, np.abs(exact).max())
+    assert np.abs(got - exact).max() < tol and np.abs(got - ref_split).max() < 2 * tol
+
+
+def test_rope_scatter_decode_matches_unfused(oracle, dev):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(6)
+    h, hkv, d, b = 32, 8, 128, 4
+    lens = [128, 192, 64, 256]
+    kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, True, dev, oracle=oracle)
+    pos = np.array([100, 150, 3, 255], np.int32)
+    placement = pos.copy()
+    qkv = synth.act(rng, b, (h + 2 * hkv) * d)
+    cs, sn = oracle.rope_cos_sin(pos, d, 5e5, True, (8.0, 1.0, 4.0, 8192.0))
+    rq, rk, rv = oracle.rope_qk_cache(cs, sn, oracle.h2u(qkv), h, hkv, d, True)
+    oracle.copy_to_rag_buffer2(placement.reshape(b, 1), np.array(lens, np.int32), rk.reshape(b, 1, hkv, d), rv.reshape(b, 1, hkv, d), kb, vb, True)
+    gq = ops.rope_scatter_decode(_t(cs, dev), _t(sn, dev), _t(qkv, dev), _t(placement, dev), _t(np.array(lens, np.int32), dev),
+                                 ops.make_ptr_table(dk), ops.make_ptr_table(dv), h, hkv, d)
+    assert np.array_equal(_bits(gq), rq)
+    for i in range(b):
+        assert np.array_equal(_bits(dk[i]), kb[i]) and np.array_equal(_bits(dv[i]), vb[i])
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_elementwise_and_embedding(oracle, dev, dtype):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(7)
+    n = 14336 * 2 + 3
+    a, b_ = _to_bits(rng.standard_normal(n) * 3, dtype, oracle), _to_bits(rng.standard_normal(n) * 3, dtype, oracle)
+    for scale, sr in ((1.0, True), (0.3, True), (1.4, False)):
+        ref = oracle.element_add_scale(a, b_, scale, sr, dtype)
+        got = _bits(ops.element_add_scale(_tt(a, dev, dtype), _tt(b_, dev, dtype), scale, sr))
+        assert np.array_equal(got, ref)   # T arithmetic, one rounding per op: bit-exact
+    for act, fn in (("silu", oracle.silu_mul), ("gelu", oracle.gelu_mul)):
+        ref = fn(a, b_, dtype)
+        got = _bits(ops.gate_mul(_tt(a, dev, dtype).clone(), _tt(b_, dev, dtype), act))
+        ulp = synth.ulp_diff_f16(got, ref)
+        assert ulp.max() <= 1 and (ulp > 0).mean() < 5e-3, (act, ulp.max(), (ulp > 0).mean())  # device expf/tanhf vs glibc
+    vocab, dim = 1000, 2304
+    w = _to_bits(rng.standard_normal((vocab, dim)), dtype, oracle)
+    ids = rng.integers(0, vocab, 17).astype(np.int32)
+    for scale, begin, end in ((1.0, 0, vocab), (12.0, 0, vocab), (1.0, 100, 600)):
+        wv = w[begin:end] if (begin, end) != (0, vocab) else w
+        ref = oracle.embedding(ids, wv, scale, begin, end, dtype)
+        got = _bits(ops.embedding(_t(ids, dev), _tt(wv, dev, dtype), scale, begin, end))
+        assert np.array_equal(got, ref)   # indexing: bit-exact
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("m", [1, 3, 8])
+def test_dense_gemm_small_m(oracle, dev, dtype, m):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(8)
+    n, k = 1000, 2304
+    x = _to_bits(rng.standard_normal((m, k)), dtype, oracle)
+    w = _to_bits(rng.standard_normal((n, k)) * 0.05, dtype, oracle)
+    bias = _to_bits(rng.standard_normal(n), dtype, oracle)
+    exact = oracle.gemm_nt(x, w, bias, 0.5, dtype, exact=True)
+    got = oracle.to_f32(_bits(ops.gemm_nt_small_m(_tt(x, dev, dtype), _tt(w, dev, dtype), _tt(bias, dev, dtype), 0.5)), dtype)
+    rel = 1e-3 if dtype == 0 else 8e-3
+    assert np.abs(got - exact).max() < rel * np.abs(exact).max()
+    # fused final-norm prologue
+    nw = _to_bits(1 + 0.1 * rng.standard_normal(k), dtype, oracle)
+    xn = oracle.rmsnorm(x, nw, 1e-5, dtype=dtype)
+    exact = oracle.gemm_nt(xn, w, None, 1.0, dtype, exact=True)
+    got = oracle.to_f32(_bits(ops.gemm_nt_small_m(_tt(x, dev, dtype), _tt(w, dev, dtype), norm_weight=_tt(nw, dev, dtype), norm_eps=1e-5)), dtype)
+    assert np.abs(got - exact).max() < 2 * rel * np.abs(exact).max()
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_int8_path_bit_exact(oracle, dev, dtype):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(9)
+    m, k, n = 33, 4096, 512
+    x = _to_bits(rng.standard_normal((m, k)) * rng.uniform(0.1, 10, (m, 1)), dtype, oracle)
+    rq, rs = oracle.quant_calc_scale(x, dtype)
+    gq, gs = ops.quant_calc_scale(_tt(x, dev, dtype))
+    assert np.array_equal(_np(gq), rq) and np.array_equal(_np(gs), rs)
+    w8 = rng.integers(-127, 128, (n, k)).astype(np.int8)
+    rc = oracle.int8_gemm_nt(rq, w8)
+    gc = ops.int8_gemm_nt(gq, _t(w8, dev))
+    assert np.array_equal(_np(gc), rc)
+    sy = _to_bits(np.abs(rng.standard_normal(n)) * 0.01, dtype, oracle)
+    tdt = torch.bfloat16 if dtype else torch.float16
+    assert np.array_equal(_bits(ops.quant_scale_back(gc, gs, _tt(sy, dev, dtype), tdt)), oracle.quant_scale_back(rc, rs, sy, dtype))
+    rc2 = oracle.int8_gemm_nt(rq, w8[::-1].copy())
+    gc2 = ops.int8_gemm_nt(gq, _t(w8[::-1].copy(), dev))
+    ref = oracle.quant_back_act_mul(rc, rs, sy, rc2, rs, sy, "silu", dtype)
+    got = _bits(ops.quant_back_act_mul(gc, gs, _tt(sy, dev, dtype), gc2, gs, _tt(sy, dev, dtype), "silu", tdt))
+    ulp = synth.ulp_diff_f16(got, ref)
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 5e-3
+    # fused rmsnorm + quant
+    nw = _to_bits(1 + 0.1 * rng.standard_normal(k), dtype, oracle)
+    ro, rq2, rs2 = oracle.rmsnorm_quant(x, nw, 1e-5, 1.0, dtype)
+    go, gq2, gs2 = ops.layernorm_quant(_tt(x, dev, dtype), _tt(nw, dev, dtype), 1e-5)
+    assert np.array_equal(_np(gq2), rq2)            # int8 codes: bit-exact (independent of the rsqrt)
+    assert np.allclose(_np(gs2), rs2, rtol=3e-7, atol=0)   # scale carries the block-sum association
+    ulp = synth.ulp_diff_f16(_bits(go), ro)
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 0.02

@@ -1,0 +1,77 @@
+"""Micro-benchmark of the W4A16 decode GEMM on the Llama-3-8B shapes: per-launch time
+with HIP events, weights rotated through distinct buffers (> 256 MB Infinity Cache) so they come
+from HBM.  Usage: python tools/bench_gemv.py [--m 1] [--iters 50] [--layers 8]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zhilight_amd import ops  # noqa: E402
+
+
+def rand_w4(n, k, g, dev, interleave=False):
+    L = ops.W4Weight.layout(n, k, g)
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (L.qw_bytes // 4,), dtype=torch.int32, device=dev)
+    sc = (torch.rand(L.scales_bytes // 2, device=dev) * 0.005 + 1e-4).to(torch.float16)
+    zs = torch.randint(-2 ** 15, 2 ** 15 - 1, (L.zeros_bytes // 2,), dtype=torch.int16, device=dev)
+    return ops.W4Weight(n, k, g, qw, sc, zs, row_interleave=interleave)
+
+
+def alg_bytes(n, k, g, m):
+    return k * n * (0.5 + 2.0 / g + 0.5 / g) + m * k * 2 + m * n * 2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--m", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--layers", type=int, default=8)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    shapes = [("qkv", 6144, 4096, 0), ("o", 4096, 4096, 0), ("gate_up", 28672, 4096, ops.EPI_SILU_MUL), ("down", 4096, 14336, 0)]
+    ws = {name: [rand_w4(n, k, 128, dev, interleave=bool(epi)) for _ in range(a.layers)] for name, n, k, epi in shapes}
+    nw = torch.ones(14336, dtype=torch.float16, device=dev)
+    tot_t, tot_b = 0.0, 0.0
+    for name, n, k, epi in shapes:
+        x = torch.randn(a.m, k, dtype=torch.float16, device=dev)
+        out = torch.empty(a.m, n // 2 if epi else n, dtype=torch.float16, device=dev)
+        for variant in ("plain", "norm"):
+            kw = dict(norm_weight=nw[:k], norm_eps=1e-5) if variant == "norm" else {}
+            for w in ws[name]:
+                ops.w4a16_gemm(x, w, out=out, epilogue=epi, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(a.iters):
+                ops.w4a16_gemm(x, ws[name][i % a.layers], out=out, epilogue=epi, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / a.iters
+            b = alg_bytes(n, k, 128, a.m)
+            print(f"{name:8s} {variant:5s} M={a.m} N={n} K={k}: {us:8.2f} us/launch  {b / us / 1e3:8.1f} GB/s  ({b / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)")
+            if variant == "plain":
+                tot_t += us
+                tot_b += b
+    print(f"layer total (plain): {tot_t:.2f} us, {tot_b / tot_t / 1e3:.1f} GB/s ({tot_b / tot_t / 1e3 / 80:.1f}% of 8 TB/s), x32 layers = {tot_t * 32:.0f} us")
+    # lm_head
+    w = [torch.randn(128256, 4096, dtype=torch.float16, device=dev) * 0.02 for _ in range(2)]
+    x = torch.randn(a.m, 4096, dtype=torch.float16, device=dev)
+    out = torch.empty(a.m, 128256, dtype=torch.float16, device=dev)
+    for i in range(2):
+        ops.gemm_nt_small_m(x, w[i], out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(10):
+        ops.gemm_nt_small_m(x, w[i % 2], out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 10
+    b = 128256 * 4096 * 2
+    print(f"lm_head M={a.m}: {us:.1f} us  {b / us / 1e3:.1f} GB/s ({b / us / 1e3 / 80:.1f}% of 8 TB/s)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""ctypes loader for libzhilight_amd.so (the gfx950 C-ABI library, include/zhilight_amd.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved this raises,
+so a GPU box can never silently run anything but the HIP path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libzhilight_amd.so")
+
+# every entry point declared in include/zhilight_amd.h (kept in sync by tests/test_abi.py)
+SYMBOLS = [
+    "zl_version", "zl_status_string", "zl_device_cu_count",
+    "zl_gptq_shuffle", "zl_gptq_increase_zero", "zl_gptq_q4_to_q8", "zl_transpose_2d",
+    "zl_awq_un_shuffle", "zl_awq_shuffle",
+    "zl_w4_layout", "zl_w4_pack", "zl_w4_dequant", "zl_w4a16_gemm",
+    "zl_gemm_nt_small_m", "zl_rmsnorm",
+    "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rotary_embedding_qk", "zl_rope_qk_cache",
+    "zl_copy_to_rag_buffer2", "zl_rope_scatter_decode",
+    "zl_decode_attn_workspace_bytes", "zl_decode_attn",
+    "zl_element_add_scale", "zl_gate_mul", "zl_embedding",
+    "zl_quant_calc_scale", "zl_rmsnorm_quant", "zl_int8_gemm_nt", "zl_quant_scale_back",
+    "zl_quant_back_act_mul",
+]
+
+
+class W4Layout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in
+                ("n", "k", "group_size", "np", "kp", "q", "c", "qw_bytes", "scales_bytes", "zeros_bytes")]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it is absent -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} not found: build it with `python -m zhilight_amd.build` "
+                "(hipcc --offload-arch=gfx950). zhilight_amd has no CPU/PyTorch fallback.")
+        l = C.CDLL(SO_PATH)
+        for name in SYMBOLS:
+            getattr(l, name)  # AttributeError if the library does not export it
+        l.zl_status_string.restype = C.c_char_p
+        l.zl_decode_attn_workspace_bytes.restype = C.c_int64
+        _lib = l
+    return _lib
+
+
+class ZLError(RuntimeError):
+    """Raised for a non-zero status of a C-ABI call (the reference raises BMEngineException ->
+    Python RuntimeError for the same conditions)."""
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().zl_status_string(C.c_int(status)).decode()
+        raise ZLError(f"{what}: status {status}: {msg}")

@@ -1,0 +1,208 @@
+// int8_ops.hip -- W8A8 dynamic per-token path.  Integer outputs are bit-exact
+// with the reference: same abs-max rule, round-half-even (v_rndne_f32), int32-exact MFMA GEMM.
+//   quant_calc_scale            src/nn/quant/int8/quant_kernel.cu:15-47
+//   fuse_layernorm_rms_quant    src/nn/quant/int8/quant_kernel.cu:106-151
+//   int8 x int8 -> int32 GEMM   src/nn/linear/linear.cpp:557-635 (cuBLASLt IMMA there)
+//   quant_scale_back            src/nn/quant/int8/quant_kernel.cu:231-246
+//   quant_back_act_mul          src/nn/quant/int8/quant_kernel.cu:589-614
+#include "zl_common.h"
+
+namespace {
+
+// one workgroup (256) per row
+template <int DT>
+__global__ __launch_bounds__(256) void k_quant_rows(const uint16_t* __restrict__ x, int8_t* __restrict__ q,
+                                                    float* __restrict__ scale, int k) {
+    __shared__ float red[16];
+    const size_t off = (size_t)blockIdx.x * k;
+    float amax = 0.f;
+    for (int i = threadIdx.x; i < k; i += 256) amax = fmaxf(amax, fabsf(ZT<DT>::to_f32(x[off + i])));
+    amax = zl_block_max(amax, red);
+    const float bs = 127.f / amax;
+    for (int i = threadIdx.x; i < k; i += 256)
+        q[off + i] = (int8_t)__builtin_rintf(ZT<DT>::to_f32(x[off + i]) * bs);
+    if (threadIdx.x == 0) scale[blockIdx.x] = amax / 127.f;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_rmsnorm_quant(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                       uint16_t* __restrict__ out, int8_t* __restrict__ q,
+                                                       float* __restrict__ out_scale, int dim, float eps,
+                                                       float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* vw = reinterpret_cast<float*>(smem);
+    float* red = vw + dim;
+    const size_t off = (size_t)blockIdx.x * dim;
+    float ss = 0.f, amax = 0.f;
+    for (int i = threadIdx.x; i < dim; i += 256) {
+        const float v = ZT<DT>::to_f32(x[off + i]);
+        ss = __builtin_fmaf(v, v, ss);
+        const float pw = v * ZT<DT>::to_f32(w[i]);
+        vw[i] = pw;
+        amax = fmaxf(amax, fabsf(pw));
+    }
+    ss = zl_block_sum(ss, red);
+    const float rs = zl_rsqrt_rn(ss / (float)dim + eps);
+    amax = zl_block_max(amax, red);
+    amax = ZT<DT>::to_f32(ZT<DT>::from_f32(amax));             // the reference reduces the max in T
+    const float bs = (float)(127.0 / (double)amax);
+    for (int i = threadIdx.x; i < dim; i += 256) {
+        const float v = vw[i] / scale;
+        out[off + i] = ZT<DT>::from_f32(v * rs);
+        q[off + i] = (int8_t)__builtin_rintf(v * bs);
+    }
+    if (threadIdx.x == 0) out_scale[blockIdx.x] = (float)((double)(amax * rs) / 127.);
+}
+
+// ---- int8 GEMM: C[m,n] = sum_k A[m,k] * B[n,k], int32.  v_mfma_i32_16x16x64_i8.
+// A fragment: lane (row = lane&15, kq = lane>>4) holds 16 consecutive k (4 VGPRs) of x row m0+row.
+// B fragment: lane (col = lane&15, kq) holds 16 consecutive k of weight row n0+col (one dwordx4).
+// C: lane holds rows 4*(lane>>4)+i (i=0..3) of column lane&15.
+// One wave per 16 weight rows and MT*16 activation rows; K split over gridDim.y with exact int32
+// atomics when splitk > 1 (integer addition is associative: still bit-exact and deterministic).
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int MTILES>
+__global__ __launch_bounds__(256) void k_int8_gemm(const int8_t* __restrict__ a, const int8_t* __restrict__ b,
+                                                   int32_t* __restrict__ c, int m, int n, int k, int k_per_split,
+                                                   int use_atomic) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * 16;
+    if (n0 >= n) return;
+    const int m0 = blockIdx.z * (MTILES * 16);
+    const int kb = blockIdx.y * k_per_split, ke = min(k, kb + k_per_split);
+    const int col = lane & 15, kq = lane >> 4;
+    v4i acc[MTILES];
+#pragma unroll
+    for (int t = 0; t < MTILES; ++t) acc[t] = (v4i){0, 0, 0, 0};
+    const bool ncol_ok = (n0 + col) < n;
+    const int8_t* brow = b + (size_t)(n0 + col) * k;
+    for (int k0 = kb; k0 < ke; k0 += 64) {
+        const int kk = k0 + 16 * kq;
+        v4i bf = (v4i){0, 0, 0, 0};
+        if (ncol_ok && kk < ke) bf = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(brow + kk));
+#pragma unroll
+        for (int t = 0; t < MTILES; ++t) {
+            const int row = m0 + t * 16 + col;  // A uses lane&15 as the row index
+            v4i af = (v4i){0, 0, 0, 0};
+            if (row < m && kk < ke) af = *reinterpret_cast<const v4i*>(a + (size_t)row * k + kk);
+            acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MTILES; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + t * 16 + 4 * kq + i;
+            if (row < m && ncol_ok) {
+                int32_t* dst = c + (size_t)row * n + n0 + col;
+                if (use_atomic) atomicAdd(dst, acc[t][i]);
+                else *dst = acc[t][i];
+            }
+        }
+}
+
+template <int DT>
+__global__ void k_scale_back(const int32_t* __restrict__ c, const float* __restrict__ sx,
+                             const uint16_t* __restrict__ sy, uint16_t* __restrict__ out, int n) {
+    const int r = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < n) {
+        const size_t pos = (size_t)r * n + col;
+        out[pos] = ZT<DT>::from_f32((float)c[pos] * sx[r] * ZT<DT>::to_f32(sy[col]));
+    }
+}
+
+template <int DT>
+__global__ void k_back_act_mul(const int32_t* __restrict__ a, const float* __restrict__ asx,
+                               const uint16_t* __restrict__ asy, const int32_t* __restrict__ b,
+                               const float* __restrict__ bsx, const uint16_t* __restrict__ bsy,
+                               uint16_t* __restrict__ out, int n, int act) {
+    const int r = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < n) {
+        const size_t pos = (size_t)r * n + col;
+        const float ab = (float)a[pos] * asx[r] * ZT<DT>::to_f32(asy[col]);
+        const float bb = (float)b[pos] * bsx[r] * ZT<DT>::to_f32(bsy[col]);
+        float gate;
+        if (act == 0) gate = ab / (1.0f + expf(-ab));
+        else gate = 0.5f * ab * (1.0f + tanhf(0.7978845608028654f * ab * (1.0f + 0.044715f * ab * ab)));
+        out[pos] = ZT<DT>::from_f32(bb * gate);
+    }
+}
+
+}  // namespace
+
+#define ZL_DT_SWITCH(dtype, EXPR_F16, EXPR_BF16) \
+    if ((dtype) == ZL_F16) { EXPR_F16; } else if ((dtype) == ZL_BF16) { EXPR_BF16; } else return ZL_EDTYPE;
+
+extern "C" {
+
+int zl_quant_calc_scale(const uint16_t* x, int8_t* q, float* scale, int64_t m, int64_t k, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(x && q && scale && m > 0 && k > 0, ZL_EINVAL);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_quant_rows<ZL_F16>, dim3((unsigned)m), dim3(256), 0, (hipStream_t)s, x, q, scale, (int)k),
+        hipLaunchKernelGGL(k_quant_rows<ZL_BF16>, dim3((unsigned)m), dim3(256), 0, (hipStream_t)s, x, q, scale, (int)k))
+    return zl_launch_status();
+}
+
+int zl_rmsnorm_quant(const uint16_t* x, const uint16_t* weight, uint16_t* out, int8_t* q, float* out_scale,
+                     int64_t rows, int64_t dim, float eps, float scale, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(x && weight && out && q && out_scale && rows > 0 && dim > 0, ZL_EINVAL);
+    size_t lds = (size_t)dim * 4 + 64;
+    ZL_CHECK_ARG(lds <= 64 * 1024, ZL_ELIMIT);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_rmsnorm_quant<ZL_F16>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)s, x, weight, out, q, out_scale, (int)dim, eps, scale),
+        hipLaunchKernelGGL(k_rmsnorm_quant<ZL_BF16>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)s, x, weight, out, q, out_scale, (int)dim, eps, scale))
+    return zl_launch_status();
+}
+
+int zl_int8_gemm_nt(const int8_t* a, const int8_t* b, int32_t* c, int64_t m, int64_t n, int64_t k, zl_stream_t s) {
+    ZL_CHECK_ARG(a && b && c && m > 0 && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(k % 16 == 0, ZL_ESHAPE);
+    const int mt = m > 48 ? 4 : (m > 32 ? 3 : (m > 16 ? 2 : 1));
+    const int gz = (int)((m + mt * 16 - 1) / (mt * 16));
+    const int gx = (int)((n + 63) / 64);
+    // split K so that at least ~1024 waves stream the weights
+    int splitk = 1;
+    while ((int64_t)gx * 4 * splitk < 1024 && k / (splitk * 2) >= 512 && (k / (splitk * 2)) % 64 == 0) splitk *= 2;
+    const int kps = (int)((k / splitk + 63) / 64 * 64);
+    hipStream_t hs = (hipStream_t)s;
+    if (splitk > 1) {
+        hipError_t e = hipMemsetAsync(c, 0, (size_t)m * n * 4, hs);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid((unsigned)gx, (unsigned)splitk, (unsigned)gz);
+    switch (mt) {
+        case 1: hipLaunchKernelGGL(k_int8_gemm<1>, grid, dim3(256), 0, hs, a, b, c, (int)m, (int)n, (int)k, kps, splitk > 1); break;
+        case 2: hipLaunchKernelGGL(k_int8_gemm<2>, grid, dim3(256), 0, hs, a, b, c, (int)m, (int)n, (int)k, kps, splitk > 1); break;
+        case 3: hipLaunchKernelGGL(k_int8_gemm<3>, grid, dim3(256), 0, hs, a, b, c, (int)m, (int)n, (int)k, kps, splitk > 1); break;
+        default: hipLaunchKernelGGL(k_int8_gemm<4>, grid, dim3(256), 0, hs, a, b, c, (int)m, (int)n, (int)k, kps, splitk > 1); break;
+    }
+    return zl_launch_status();
+}
+
+int zl_quant_scale_back(const int32_t* c, const float* scale_x, const uint16_t* scale_y, uint16_t* out, int64_t m,
+                        int64_t n, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(c && scale_x && scale_y && out && m > 0 && n > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(m <= 65535, ZL_ELIMIT);
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)m);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_scale_back<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, c, scale_x, scale_y, out, (int)n),
+        hipLaunchKernelGGL(k_scale_back<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, c, scale_x, scale_y, out, (int)n))
+    return zl_launch_status();
+}
+
+int zl_quant_back_act_mul(const int32_t* a, const float* a_sx, const uint16_t* a_sy, const int32_t* b,
+                          const float* b_sx, const uint16_t* b_sy, uint16_t* out, int64_t m, int64_t n, int act,
+                          int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(a && a_sx && a_sy && b && b_sx && b_sy && out && m > 0 && n > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(m <= 65535, ZL_ELIMIT);
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)m);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_back_act_mul<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, a, a_sx, a_sy, b, b_sx, b_sy, out, (int)n, act),
+        hipLaunchKernelGGL(k_back_act_mul<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, a, a_sx, a_sy, b, b_sx, b_sy, out, (int)n, act))
+    return zl_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+// misc_ops.hip -- the small fused/element-wise kernels of the decode path (SURVEY 8a rows a13, a14,
+// a17, a18, a22) plus library utilities.  All are tiny HBM/L2-bound byte movers: 16-byte vector
+// accesses, one workgroup per row (or grid-stride), fp32 math with ONE rounding to T at the same
+// points as the reference kernels cited at each launcher.
+#include "zl_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm (+ residual add).  src/nn/layernorm/layernorm.cu:10-42
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void k_rmsnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                 uint16_t* __restrict__ out, int dim, float eps, float scale,
+                                                 const uint16_t* __restrict__ x2, uint16_t* __restrict__ out_sum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* vbuf = reinterpret_cast<float*>(smem);  // dim floats
+    float* red = vbuf + dim;
+    const size_t off = (size_t)blockIdx.x * dim;
+    float ss = 0.f;
+    for (int i = threadIdx.x * 8; i < dim; i += 256 * 8) {  // dim % 8 == 0
+        uint4 a = *reinterpret_cast<const uint4*>(x + off + i);
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (x2) b = *reinterpret_cast<const uint4*>(x2 + off + i);
+        const uint32_t au[4] = {a.x, a.y, a.z, a.w}, bu[4] = {b.x, b.y, b.z, b.w};
+        uint32_t su[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v0 = ZT<DT>::to_f32((uint16_t)(au[e] & 0xffff)), v1 = ZT<DT>::to_f32((uint16_t)(au[e] >> 16));
+            if (x2) {
+                v0 += ZT<DT>::to_f32((uint16_t)(bu[e] & 0xffff));
+                v1 += ZT<DT>::to_f32((uint16_t)(bu[e] >> 16));
+                su[e] = (uint32_t)ZT<DT>::from_f32(v0) | ((uint32_t)ZT<DT>::from_f32(v1) << 16);
+            }
+            vbuf[i + 2 * e] = v0;
+            vbuf[i + 2 * e + 1] = v1;
+            ss = __builtin_fmaf(v0, v0, ss);
+            ss = __builtin_fmaf(v1, v1, ss);
+        }
+        if (x2 && out_sum) *reinterpret_cast<uint4*>(out_sum + off + i) = make_uint4(su[0], su[1], su[2], su[3]);
+    }
+    ss = zl_block_sum(ss, red);
+    const float rs = zl_rsqrt_rn(ss / (float)dim + eps);
+    for (int i = threadIdx.x * 8; i < dim; i += 256 * 8) {
+        uint4 wv = *reinterpret_cast<const uint4*>(w + i);
+        const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = vbuf[i + 2 * e] * rs * ZT<DT>::to_f32((uint16_t)(wu[e] & 0xffff)) / scale;
+            float b = vbuf[i + 2 * e + 1] * rs * ZT<DT>::to_f32((uint16_t)(wu[e] >> 16)) / scale;
+            o[e] = (uint32_t)ZT<DT>::from_f32(a) | ((uint32_t)ZT<DT>::from_f32(b) << 16);
+        }
+        *reinterpret_cast<uint4*>(out + off + i) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE tables.  src/nn/position/rope_preparer.cu:49-69, 124-160
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int half_dim_index(int col, int half_dim, int neox) {
+    return neox ? (col < half_dim ? col : col - half_dim) : col / 2;
+}
+
+__global__ void k_rope_cos_sin(const int32_t* __restrict__ pos, float* __restrict__ cosv, float* __restrict__ sinv,
+                               int d, float base, int neox, int llama3, float factor, float low_ff, float high_ff,
+                               float old_ctx) {
+    const int col = threadIdx.x;
+    if (col >= d) return;
+    const int i = half_dim_index(col, d / 2, neox);
+    float inv_freq = powf(base, -(float)(i * 2) / (float)d);
+    if (llama3) {
+        const float low_wl = old_ctx / low_ff, high_wl = old_ctx / high_ff;
+        const float pi = 3.141592653589793f;
+        const float wavelen = 2.f * pi / inv_freq;
+        if (wavelen < high_wl) {
+        } else if (wavelen > low_wl) {
+            inv_freq = inv_freq / factor;
+        } else {
+            const float smooth = (old_ctx / wavelen - low_ff) / (high_ff - low_ff);
+            inv_freq = __builtin_fmaf(smooth, inv_freq, (1.f - smooth) * inv_freq / factor);
+        }
+    }
+    const float freq = (float)pos[blockIdx.x] * inv_freq;
+    cosv[(size_t)blockIdx.x * d + col] = cosf(freq);
+    sinv[(size_t)blockIdx.x * d + col] = sinf(freq);
+}
+
+__device__ __forceinline__ float rope_val(float a, float b, float c, float s, bool minus) {
+    return minus ? __builtin_fmaf(-b, s, a * c) : __builtin_fmaf(b, s, a * c);
+}
+
+// grid (S, H + 2Hkv), block D.  MODE 0: angles computed (rotary_embedding_fuse.cu:19-67);
+// MODE 1: cached cos/sin (rotary_embedding_fuse_cache.cu:23-64)
+template <int DT, int MODE>
+__global__ void k_rope_qk(const int32_t* __restrict__ pos, const float* __restrict__ cosv,
+                          const float* __restrict__ sinv, const uint16_t* __restrict__ in, uint16_t* __restrict__ q,
+                          uint16_t* __restrict__ k, uint16_t* __restrict__ v, int h, int hkv, int d, float theta,
+                          int neox) {
+    const int t = blockIdx.x, head = blockIdx.y, col = threadIdx.x, all = h + 2 * hkv, half = d / 2;
+    if (col >= d) return;
+    const uint16_t* src = in + ((size_t)t * all + head) * d;
+    if (head >= h + hkv) {
+        v[((size_t)t * hkv + (head - h - hkv)) * d + col] = src[col];
+        return;
+    }
+    float c, s;
+    if (MODE == 0) {
+        const int i = col < half ? col : col - half;
+        const float freq = (float)pos[t] * powf(theta, -(float)(i * 2) / (float)d);
+        c = cosf(freq);
+        s = sinf(freq);
+    } else {
+        c = cosv[(size_t)t * d + col];
+        s = sinv[(size_t)t * d + col];
+    }
+    const float a = ZT<DT>::to_f32(src[col]);
+    float r;
+    if (MODE == 0 || neox)
+        r = col < half ? rope_val(a, ZT<DT>::to_f32(src[col + half]), c, s, true)
+                       : rope_val(a, ZT<DT>::to_f32(src[col - half]), c, s, false);
+    else
+        r = (col & 1) == 0 ? rope_val(a, ZT<DT>::to_f32(src[col + 1]), c, s, true)
+                           : rope_val(a, ZT<DT>::to_f32(src[col - 1]), c, s, false);
+    uint16_t* dst = head >= h ? k + ((size_t)t * hkv + (head - h)) * d : q + ((size_t)t * h + head) * d;
+    dst[col] = ZT<DT>::from_f32(r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// KV scatter.  src/kvcache/ragged_buffer_kernel.cu:194-222.  grid (B, len_q, Hkv), block D/8 (16 B lanes)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_copy_to_rag_buffer2(const int32_t* __restrict__ placement, const int32_t* __restrict__ buf_lens,
+                                      const uint16_t* __restrict__ k_src, const uint16_t* __restrict__ v_src,
+                                      uint16_t* const* __restrict__ k_bufs, uint16_t* const* __restrict__ v_bufs,
+                                      int d, int bshd) {
+    const int b = blockIdx.x, len_q = gridDim.y, hkv = gridDim.z, head = blockIdx.z;
+    const int xi = b * len_q + blockIdx.y;
+    const int p = placement[xi];
+    if (p < 0) return;
+    const int64_t len_buf = buf_lens[b];
+    const size_t so = ((size_t)xi * hkv + head) * d;
+    const size_t dof = bshd ? ((size_t)p * hkv + head) * d : ((size_t)head * len_buf + p) * d;
+    for (int i = threadIdx.x * 8; i < d; i += blockDim.x * 8) {
+        *reinterpret_cast<uint4*>(k_bufs[b] + dof + i) = *reinterpret_cast<const uint4*>(k_src + so + i);
+        *reinterpret_cast<uint4*>(v_bufs[b] + dof + i) = *reinterpret_cast<const uint4*>(v_src + so + i);
+    }
+}
+
+// fused decode front end: grid (B, H + 2Hkv), block D; q rotated -> q out, k rotated -> cache, v -> cache
+template <int DT>
+__global__ void k_rope_scatter_decode(const float* __restrict__ cosv, const float* __restrict__ sinv,
+                                      const uint16_t* __restrict__ qkv, uint16_t* __restrict__ q,
+                                      const int32_t* __restrict__ placement, const int32_t* __restrict__ buf_lens,
+                                      uint16_t* const* __restrict__ k_bufs, uint16_t* const* __restrict__ v_bufs, int h,
+                                      int hkv, int d, int neox, int bshd) {
+    const int t = blockIdx.x, head = blockIdx.y, col = threadIdx.x, all = h + 2 * hkv, half = d / 2;
+    if (col >= d) return;
+    const uint16_t* src = qkv + ((size_t)t * all + head) * d;
+    const int p = placement[t];
+    const int64_t len_buf = buf_lens[t];
+    if (head >= h + hkv) {
+        if (p < 0) return;
+        const int hk = head - h - hkv;
+        const size_t dof = bshd ? ((size_t)p * hkv + hk) * d : ((size_t)hk * len_buf + p) * d;
+        v_bufs[t][dof + col] = src[col];
+        return;
+    }
+    const float c = cosv[(size_t)t * d + col], s = sinv[(size_t)t * d + col];
+    const float a = ZT<DT>::to_f32(src[col]);
+    float r;
+    if (neox)
+        r = col < half ? rope_val(a, ZT<DT>::to_f32(src[col + half]), c, s, true)
+                       : rope_val(a, ZT<DT>::to_f32(src[col - half]), c, s, false);
+    else
+        r = (col & 1) == 0 ? rope_val(a, ZT<DT>::to_f32(src[col + 1]), c, s, true)
+                           : rope_val(a, ZT<DT>::to_f32(src[col - 1]), c, s, false);
+    const uint16_t o = ZT<DT>::from_f32(r);
+    if (head < h) {
+        q[((size_t)t * h + head) * d + col] = o;
+    } else if (p >= 0) {
+        const int hk = head - h;
+        const size_t dof = bshd ? ((size_t)p * hkv + hk) * d : ((size_t)hk * len_buf + p) * d;
+        k_bufs[t][dof + col] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise.  src/nn/block/block_kernel.cu:8-17, src/nn/linear/activation_kernel.cu:59-80
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ uint16_t t_add(uint16_t a, uint16_t b) {  // one rounding to T (exact sum in fp32*)
+    // fp16: the fp32 sum of two halfs is exact; bf16: may round in fp32 first (documented)
+    return ZT<DT>::from_f32(ZT<DT>::to_f32(a) + ZT<DT>::to_f32(b));
+}
+template <int DT>
+__device__ __forceinline__ uint16_t t_mul(uint16_t a, uint16_t b) {  // product of two T is exact in fp32
+    return ZT<DT>::from_f32(ZT<DT>::to_f32(a) * ZT<DT>::to_f32(b));
+}
+
+template <int DT>
+__global__ void k_add_scale(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ c,
+                            int64_t n, uint16_t scale_t, int scale_residual) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        c[i] = scale_residual ? t_mul<DT>(t_add<DT>(a[i], b[i]), scale_t) : t_add<DT>(a[i], t_mul<DT>(b[i], scale_t));
+}
+
+template <int DT>
+__global__ void k_gate_mul(const uint16_t* __restrict__ g, const uint16_t* __restrict__ u, uint16_t* __restrict__ out,
+                           int64_t n, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = ZT<DT>::to_f32(g[i]);
+        float a;
+        if (act == 0) a = x / (1.0f + expf(-x));
+        else a = 0.5f * x * (1.0f + tanhf(0.7978845608028654f * x * (1.0f + 0.044715f * x * x)));
+        out[i] = ZT<DT>::from_f32(a * ZT<DT>::to_f32(u[i]));
+    }
+}
+
+// embedding: grid (S), block 256, 16-byte lanes.  src/nn/embedding/embedding.cu:23-44
+template <int DT>
+__global__ void k_embedding(const int32_t* __restrict__ ids, const uint16_t* __restrict__ w, uint16_t* __restrict__ out,
+                            int dim, int begin, int end, float scale) {
+    int id = ids[blockIdx.x];
+    const bool in_range = id >= begin && id < end;
+    id -= begin;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x)
+        out[(size_t)blockIdx.x * dim + i] =
+            in_range ? ZT<DT>::from_f32(ZT<DT>::to_f32(w[(size_t)id * dim + i]) * scale) : ZT<DT>::from_f32(0.f);
+}
+
+inline int grid_1d(int64_t n, int threads) {
+    int64_t g = (n + threads - 1) / threads;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+#define ZL_DT_SWITCH(dtype, EXPR_F16, EXPR_BF16) \
+    if ((dtype) == ZL_F16) { EXPR_F16; } else if ((dtype) == ZL_BF16) { EXPR_BF16; } else return ZL_EDTYPE;
+
+extern "C" {
+
+int zl_version(void) { return ZL_VERSION; }
+
+const char* zl_status_string(int st) {
+    switch (st) {
+        case ZL_OK: return "ok";
+        case ZL_EINVAL: return "invalid argument (null pointer or non-positive size)";
+        case ZL_ESHAPE: return "shape/alignment not supported by this kernel";
+        case ZL_EDTYPE: return "dtype not supported on this path";
+        case ZL_ELIMIT: return "exceeds a hardware limit (LDS / grid)";
+        default: return st > 0 ? hipGetErrorString((hipError_t)st) : "unknown status";
+    }
+}
+
+int zl_device_cu_count(void) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return -(int)e;
+    static int cache[64] = {0};
+    if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+    int cus = 0;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return -(int)e;
+    if (dev >= 0 && dev < 64) cache[dev] = cus;  // benign race: same value from every thread
+    return cus;
+}
+
+int zl_rmsnorm(const uint16_t* x, const uint16_t* weight, uint16_t* out, int64_t rows, int64_t dim, float eps,
+               float scale, const uint16_t* x2, uint16_t* out_sum, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(x && weight && out && rows > 0 && dim > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(dim % 8 == 0, ZL_ESHAPE);
+    size_t lds = (size_t)dim * 4 + 64;
+    ZL_CHECK_ARG(lds <= 64 * 1024, ZL_ELIMIT);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_rmsnorm<ZL_F16>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)s, x, weight, out, (int)dim, eps, scale, x2, out_sum),
+        hipLaunchKernelGGL(k_rmsnorm<ZL_BF16>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)s, x, weight, out, (int)dim, eps, scale, x2, out_sum))
+    return zl_launch_status();
+}
+
+int zl_rope_cos_sin(const int32_t* pos, float* cosv, float* sinv, int64_t s_len, int64_t d, float base, int neox,
+                    zl_stream_t s) {
+    ZL_CHECK_ARG(pos && cosv && sinv && s_len > 0 && d > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 1024 && d % 2 == 0, ZL_ESHAPE);
+    hipLaunchKernelGGL(k_rope_cos_sin, dim3((unsigned)s_len), dim3((unsigned)d), 0, (hipStream_t)s, pos, cosv, sinv,
+                       (int)d, base, neox, 0, 1.f, 1.f, 1.f, 1.f);
+    return zl_launch_status();
+}
+
+int zl_rope_cos_sin_llama3(const int32_t* pos, float* cosv, float* sinv, int64_t s_len, int64_t d, float base,
+                           float factor, float low_freq_factor, float high_freq_factor, float old_context_len,
+                           int neox, zl_stream_t s) {
+    ZL_CHECK_ARG(pos && cosv && sinv && s_len > 0 && d > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 1024 && d % 2 == 0, ZL_ESHAPE);
+    hipLaunchKernelGGL(k_rope_cos_sin, dim3((unsigned)s_len), dim3((unsigned)d), 0, (hipStream_t)s, pos, cosv, sinv,
+                       (int)d, base, neox, 1, factor, low_freq_factor, high_freq_factor, old_context_len);
+    return zl_launch_status();
+}
+
+int zl_rotary_embedding_qk(const int32_t* pos, const uint16_t* in, uint16_t* q, uint16_t* k, uint16_t* v,
+                           int64_t s_len, int64_t h, int64_t hkv, int64_t d, float theta, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(pos && in && q && k && v && s_len > 0 && h > 0 && hkv > 0 && d > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 1024 && d % 2 == 0 && h + 2 * hkv <= 65535, ZL_ESHAPE);
+    dim3 grid((unsigned)s_len, (unsigned)(h + 2 * hkv));
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL((k_rope_qk<ZL_F16, 0>), grid, dim3((unsigned)d), 0, (hipStream_t)s, pos, nullptr, nullptr, in, q, k, v, (int)h, (int)hkv, (int)d, theta, 1),
+        hipLaunchKernelGGL((k_rope_qk<ZL_BF16, 0>), grid, dim3((unsigned)d), 0, (hipStream_t)s, pos, nullptr, nullptr, in, q, k, v, (int)h, (int)hkv, (int)d, theta, 1))
+    return zl_launch_status();
+}
+
+int zl_rope_qk_cache(const float* cosv, const float* sinv, const uint16_t* in, uint16_t* q, uint16_t* k, uint16_t* v,
+                     int64_t s_len, int64_t h, int64_t hkv, int64_t d, int neox, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(cosv && sinv && in && q && k && v && s_len > 0 && h > 0 && hkv > 0 && d > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 1024 && d % 2 == 0 && h + 2 * hkv <= 65535, ZL_ESHAPE);
+    dim3 grid((unsigned)s_len, (unsigned)(h + 2 * hkv));
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL((k_rope_qk<ZL_F16, 1>), grid, dim3((unsigned)d), 0, (hipStream_t)s, nullptr, cosv, sinv, in, q, k, v, (int)h, (int)hkv, (int)d, 0.f, neox),
+        hipLaunchKernelGGL((k_rope_qk<ZL_BF16, 1>), grid, dim3((unsigned)d), 0, (hipStream_t)s, nullptr, cosv, sinv, in, q, k, v, (int)h, (int)hkv, (int)d, 0.f, neox))
+    return zl_launch_status();
+}
+
+int zl_copy_to_rag_buffer2(const int32_t* placement, const int32_t* buf_lens, const uint16_t* k_src,
+                           const uint16_t* v_src, uint16_t* const* k_bufs, uint16_t* const* v_bufs, int64_t b,
+                           int64_t len_q, int64_t hkv, int64_t d, int bshd, zl_stream_t s) {
+    ZL_CHECK_ARG(placement && buf_lens && k_src && v_src && k_bufs && v_bufs && b > 0 && len_q > 0 && hkv > 0 && d > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d % 8 == 0 && len_q <= 65535 && hkv <= 65535, ZL_ESHAPE);
+    dim3 grid((unsigned)b, (unsigned)len_q, (unsigned)hkv);
+    hipLaunchKernelGGL(k_copy_to_rag_buffer2, grid, dim3(64), 0, (hipStream_t)s, placement, buf_lens, k_src, v_src,
+                       k_bufs, v_bufs, (int)d, bshd);
+    return zl_launch_status();
+}
+
+int zl_rope_scatter_decode(const float* cosv, const float* sinv, const uint16_t* qkv, uint16_t* q,
+                           const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                           uint16_t* const* v_bufs, int64_t b, int64_t h, int64_t hkv, int64_t d, int neox, int bshd,
+                           int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(cosv && sinv && qkv && q && placement && buf_lens && k_bufs && v_bufs && b > 0 && h > 0 && hkv > 0 && d > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 1024 && d % 2 == 0 && h + 2 * hkv <= 65535, ZL_ESHAPE);
+    dim3 grid((unsigned)b, (unsigned)(h + 2 * hkv));
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_rope_scatter_decode<ZL_F16>, grid, dim3((unsigned)d), 0, (hipStream_t)s, cosv, sinv, qkv, q, placement, buf_lens, k_bufs, v_bufs, (int)h, (int)hkv, (int)d, neox, bshd),
+        hipLaunchKernelGGL(k_rope_scatter_decode<ZL_BF16>, grid, dim3((unsigned)d), 0, (hipStream_t)s, cosv, sinv, qkv, q, placement, buf_lens, k_bufs, v_bufs, (int)h, (int)hkv, (int)d, neox, bshd))
+    return zl_launch_status();
+}
+
+int zl_element_add_scale(const uint16_t* a, const uint16_t* b, uint16_t* c, int64_t n, float scale, int scale_residual,
+                         int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(a && b && c && n > 0, ZL_EINVAL);
+    if (dtype == ZL_F16) {
+        uint16_t st = __builtin_bit_cast(uint16_t, (_Float16)scale);
+        hipLaunchKernelGGL(k_add_scale<ZL_F16>, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)s, a, b, c, n, st, scale_residual);
+    } else if (dtype == ZL_BF16) {
+        uint32_t u = __builtin_bit_cast(uint32_t, scale);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        hipLaunchKernelGGL(k_add_scale<ZL_BF16>, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)s, a, b, c, n, (uint16_t)(u >> 16), scale_residual);
+    } else
+        return ZL_EDTYPE;
+    return zl_launch_status();
+}
+
+int zl_gate_mul(const uint16_t* gate, const uint16_t* up, uint16_t* out, int64_t n, int act, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(gate && up && out && n > 0 && (act == 0 || act == 1), ZL_EINVAL);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_gate_mul<ZL_F16>, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)s, gate, up, out, n, act),
+        hipLaunchKernelGGL(k_gate_mul<ZL_BF16>, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)s, gate, up, out, n, act))
+    return zl_launch_status();
+}
+
+int zl_embedding(const int32_t* ids, const uint16_t* weight, uint16_t* out, int64_t s_len, int64_t dim, int32_t begin,
+                 int32_t end, float scale, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(ids && weight && out && s_len > 0 && dim > 0, ZL_EINVAL);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_embedding<ZL_F16>, dim3((unsigned)s_len), dim3(256), 0, (hipStream_t)s, ids, weight, out, (int)dim, begin, end, scale),
+        hipLaunchKernelGGL(k_embedding<ZL_BF16>, dim3((unsigned)s_len), dim3(256), 0, (hipStream_t)s, ids, weight, out, (int)dim, begin, end, scale))
+    return zl_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,391 @@
+"""Operator-level Python mirror of the reference's `nn::` / `gptq::` / `int8_op::` free functions
+(the "bmengine op" surface of SURVEY.md 8b) on top of the C ABI.
+
+PyTorch is used for device memory and streams only: every function takes CUDA tensors, allocates its
+output like the reference op does with `ctx.tensor(...)`, and enqueues ONE C-ABI launcher on the
+current torch stream.  There is no CPU / eager fallback: without the HIP library these raise.
+
+Names, argument meaning and error behaviour follow the reference (citations on each function;
+paths relative to the ZhiLight tree).
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import W4Layout, ZLError, check, lib
+
+F16, BF16 = 0, 1
+EPI_BIAS, EPI_ADD_C, EPI_RESIDUAL, EPI_SILU_MUL, EPI_SILU_MUL_F32 = 1, 2, 4, 8, 16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _i(v):
+    return C.c_int64(int(v))
+
+
+def _f(v):
+    return C.c_float(float(v))
+
+
+def _dt(t):
+    if t.dtype == torch.float16:
+        return F16
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise ZLError(f"unsupported activation dtype {t.dtype}")
+
+
+def _chk_cuda(*ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.is_contiguous()):
+            raise ZLError("tensors must be contiguous CUDA tensors")
+
+
+# --------------------------------------------------------------------------------------------------
+# a4: load-time layout transforms  (src/nn/quant/gptq/gptq.h:24-49,141-148)
+# --------------------------------------------------------------------------------------------------
+def gptq_shuffle(qweight):
+    """In place on a (K/8, N) int32 tensor -- nn::gptq::gptq_shuffle without act-order."""
+    _chk_cuda(qweight)
+    check(lib().zl_gptq_shuffle(_p(qweight), _i(qweight.shape[0]), _i(qweight.shape[1]), _stream()), "gptq_shuffle")
+    return qweight
+
+
+def increase_zero(qzeros):
+    _chk_cuda(qzeros)
+    check(lib().zl_gptq_increase_zero(_p(qzeros), _i(qzeros.numel()), _stream()), "increase_zero")
+    return qzeros
+
+
+def q4_to_q8(qzeros):
+    _chk_cuda(qzeros)
+    out = torch.empty(qzeros.shape[:-1] + (qzeros.shape[-1] * 8,), dtype=torch.uint8, device=qzeros.device)
+    check(lib().zl_gptq_q4_to_q8(_p(qzeros), _p(out), _i(qzeros.numel()), _stream()), "q4_to_q8")
+    return out
+
+
+def transpose_2d(t):
+    """functions::Transpose for a 2-D tensor of 1/2/4-byte elements."""
+    _chk_cuda(t)
+    rows, cols = t.shape
+    out = torch.empty((cols, rows), dtype=t.dtype, device=t.device)
+    check(lib().zl_transpose_2d(_p(t), _p(out), _i(rows), _i(cols), C.c_int(t.element_size()), _stream()), "transpose")
+    return out
+
+
+def awq_un_shuffle(q):
+    _chk_cuda(q)
+    check(lib().zl_awq_un_shuffle(_p(q), _i(q.shape[0]), _i(q.shape[1]), _stream()), "un_shuffle")
+    return q
+
+
+def shuffle_awq(qweight, use_exllama=True):
+    _chk_cuda(qweight)
+    k, n8 = qweight.shape
+    out = torch.empty((k // 8, n8 * 8), dtype=qweight.dtype, device=qweight.device)
+    check(lib().zl_awq_shuffle(_p(qweight), _p(out), _i(k), _i(n8 * 8), C.c_int(int(use_exllama)), _stream()),
+          "shuffle_awq")
+    return out
+
+
+class W4Weight:
+    """A W4 (GPTQ / AWQ-as-exllama) linear weight in the gfx950-native ZLW4 layout (include/zhilight_amd.h).
+
+    Plays the role of Int4GPTQ's device-side state after load_state_dict -> preprocess_weight ->
+    transpose_weight (src/nn/linear/linear.cpp:1139-1244)."""
+
+    def __init__(self, n, k, group_size, qw, scales, zeros, sym=False, row_interleave=False):
+        self.n, self.k, self.group_size = n, k, group_size
+        self.qw, self.scales, self.zeros = qw, scales, zeros
+        self.sym, self.row_interleave = sym, row_interleave
+
+    @staticmethod
+    def layout(n, k, group_size):
+        L = W4Layout()
+        check(lib().zl_w4_layout(_i(n), _i(k), _i(group_size), C.byref(L)), "w4_layout")
+        return L
+
+    @classmethod
+    def from_k_major(cls, qweight_km, qzeros_km, scales_km, group_size, sym=False, row_interleave=False):
+        """qweight (N,K/8) int32 shuffled words, qzeros (N,K/G) uint8, scales (N,K/G) fp16."""
+        _chk_cuda(qweight_km, qzeros_km, scales_km)
+        n, k = qweight_km.shape[0], qweight_km.shape[1] * 8
+        L = cls.layout(n, k, group_size)
+        dev = qweight_km.device
+        qw = torch.empty(L.qw_bytes // 4, dtype=torch.int32, device=dev)
+        sc = torch.empty(L.scales_bytes // 2, dtype=torch.float16, device=dev)
+        zs = torch.empty(L.zeros_bytes // 2, dtype=torch.int16, device=dev)
+        check(lib().zl_w4_pack(_p(qweight_km), _p(qzeros_km), _p(scales_km), _i(n), _i(k), _i(group_size),
+                               C.c_int(int(row_interleave)), _p(qw), _p(sc), _p(zs), _stream()), "w4_pack")
+        return cls(n, k, group_size, qw, sc, zs, sym, row_interleave)
+
+    @classmethod
+    def from_hf_gptq(cls, qweight, qzeros, scales, group_size, sym=False, row_interleave=False):
+        """HF / AutoGPTQ tensors: qweight (K/8,N) int32, qzeros (K/G,N/8) int32, scales (K/G,N) fp16.
+        Same steps as the reference's load path: shuffle, +1 zeros, nibble->byte, transpose x3."""
+        qw = gptq_shuffle(qweight.clone())
+        qz = q4_to_q8(increase_zero(qzeros.clone()))
+        return cls.from_k_major(transpose_2d(qw), transpose_2d(qz), transpose_2d(scales.contiguous()), group_size,
+                                sym, row_interleave)
+
+    def dequant(self):
+        """(N, K) fp16 = rn16(rn16(q - z) * s) -- nn::gptq::dequant_k_major(out_type=0)."""
+        out = torch.empty((self.n, self.k), dtype=torch.float16, device=self.qw.device)
+        check(lib().zl_w4_dequant(_p(self.qw), _p(self.scales), _p(self.zeros), _i(self.n), _i(self.k),
+                                  _i(self.group_size), _p(out), _stream()), "w4_dequant")
+        return out
+
+    def nbytes(self):
+        return self.qw.numel() * 4 + self.scales.numel() * 2 + self.zeros.numel() * 2
+
+
+def w4a16_gemm(x, w, bias=None, residual=None, out=None, norm_weight=None, norm_eps=1e-5, epilogue=0):
+    """y = x . dequant(W)^T with optional fused RMSNorm prologue and bias / ADD_C / residual / silu*mul
+    epilogue -- nn::gptq::gptq_gemm_k_major (M <= 40 branch) and nn::gptq::gemm_fuse_gate_in
+    (src/nn/quant/gptq/q_gemm_k_major.cu:957-1116, 765-829)."""
+    if x.dtype != torch.float16:
+        raise ZLError("A must be half")  # q_gemm_k_major.cu:989
+    _chk_cuda(x, bias, residual, norm_weight)
+    x2 = x.reshape(-1, x.shape[-1])
+    m, k = x2.shape
+    if k != w.k:
+        raise ZLError("size K mismatch")
+    silu = epilogue & (EPI_SILU_MUL | EPI_SILU_MUL_F32)
+    n_out = w.n // 2 if silu else w.n
+    if out is None:
+        out = torch.empty((m, n_out), dtype=torch.float16, device=x.device)
+    elif tuple(out.shape[-2:]) != (m, n_out) and out.numel() != m * n_out:
+        raise ZLError("Wrong output size()")
+    if bias is not None:
+        epilogue |= EPI_BIAS
+    check(lib().zl_w4a16_gemm(_p(x2), _i(x2.stride(0)), _p(w.qw), _p(w.scales), _p(w.zeros), _p(bias), _p(residual),
+                              _p(out), _i(m), _i(w.n), _i(k), _i(w.group_size), C.c_int(int(w.sym)),
+                              _p(norm_weight), _f(norm_eps), C.c_int(epilogue), _stream()), "w4a16_gemm")
+    return out
+
+
+def gemm_nt_small_m(x, weight, bias=None, alpha=1.0, out=None, norm_weight=None, norm_eps=1e-5):
+    """y = T(alpha * x . W^T + bias) -- functions::Gemm(trans_b=True) on the decode path (lm_head)."""
+    _chk_cuda(x, weight, bias, norm_weight)
+    x2 = x.reshape(-1, x.shape[-1])
+    m, k = x2.shape
+    n = weight.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    check(lib().zl_gemm_nt_small_m(_p(x2), _i(x2.stride(0)), _p(weight), _p(bias), _p(out), _i(m), _i(n), _i(k),
+                                   _f(alpha), C.c_int(_dt(x)), _p(norm_weight), _f(norm_eps), _stream()),
+          "gemm_nt_small_m")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# a17 / a13 / a14 / a18 / a22
+# --------------------------------------------------------------------------------------------------
+def rmsnorm(x, weight, eps, scale=1.0, x2=None, out=None, out_sum=None):
+    """LayerNorm::forward (rms) / fuse_add (src/nn/layernorm/layernorm.cu:227-302)."""
+    _chk_cuda(x, weight, x2)
+    xr = x.reshape(-1, x.shape[-1])
+    rows, dim = xr.shape
+    if out is None:
+        out = torch.empty_like(xr)
+    if x2 is not None and out_sum is None:
+        out_sum = torch.empty_like(xr)
+    check(lib().zl_rmsnorm(_p(xr), _p(weight), _p(out), _i(rows), _i(dim), _f(eps), _f(scale), _p(x2), _p(out_sum),
+                           C.c_int(_dt(x)), _stream()), "rmsnorm")
+    return (out, out_sum) if x2 is not None else out
+
+
+def rope_cos_sin(pos, dim_head, base, neox=True, llama3=None):
+    """RopePreparer::compute_cos_sin (src/nn/position/rope_preparer.cu); llama3 = (factor, low, high, old_len)."""
+    _chk_cuda(pos)
+    s = pos.numel()
+    cs = torch.empty((s, dim_head), dtype=torch.float32, device=pos.device)
+    sn = torch.empty_like(cs)
+    if llama3 is None:
+        check(lib().zl_rope_cos_sin(_p(pos), _p(cs), _p(sn), _i(s), _i(dim_head), _f(base), C.c_int(int(neox)),
+                                    _stream()), "rope_cos_sin")
+    else:
+        fac, low, high, old = llama3
+        check(lib().zl_rope_cos_sin_llama3(_p(pos), _p(cs), _p(sn), _i(s), _i(dim_head), _f(base), _f(fac), _f(low),
+                                           _f(high), _f(old), C.c_int(int(neox)), _stream()), "rope_cos_sin_llama3")
+    return cs, sn
+
+
+def rotary_embedding_qk(pos, x, num_heads, num_kv_heads, dim_head, rope_theta):
+    """nn::rotary_embedding_qk (src/nn/position/rotary_embedding_fuse.cu:70-123)."""
+    _chk_cuda(pos, x)
+    s = pos.numel()
+    q = torch.empty((s, num_heads * dim_head), dtype=x.dtype, device=x.device)
+    k = torch.empty((s, num_kv_heads * dim_head), dtype=x.dtype, device=x.device)
+    v = torch.empty_like(k)
+    check(lib().zl_rotary_embedding_qk(_p(pos), _p(x), _p(q), _p(k), _p(v), _i(s), _i(num_heads), _i(num_kv_heads),
+                                       _i(dim_head), _f(rope_theta), C.c_int(_dt(x)), _stream()), "rotary_embedding_qk")
+    return q, k, v
+
+
+def rope_qk_cache(cos, sin, x, num_heads, num_kv_heads, dim_head, neox=True):
+    """nn::rope_qk_cache (src/nn/position/rotary_embedding_fuse_cache.cu:65-125)."""
+    _chk_cuda(cos, sin, x)
+    s = cos.shape[0]
+    q = torch.empty((s, num_heads * dim_head), dtype=x.dtype, device=x.device)
+    k = torch.empty((s, num_kv_heads * dim_head), dtype=x.dtype, device=x.device)
+    v = torch.empty_like(k)
+    check(lib().zl_rope_qk_cache(_p(cos), _p(sin), _p(x), _p(q), _p(k), _p(v), _i(s), _i(num_heads), _i(num_kv_heads),
+                                 _i(dim_head), C.c_int(int(neox)), C.c_int(_dt(x)), _stream()), "rope_qk_cache")
+    return q, k, v
+
+
+def make_ptr_table(tensors, device=None):
+    """Device array of raw pointers, one per task -- RagBufferContext::buf_k_addr
+    (src/model/rag_buffer_context.h:141-188)."""
+    device = device or tensors[0].device
+    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=device)
+
+
+def copy_to_rag_buffer2(placement, buf_lens, k_src, v_src, k_addrs, v_addrs, bshd=True):
+    """nn::copy_to_rag_buffer2 (src/kvcache/ragged_buffer_kernel.cu:254-300)."""
+    _chk_cuda(placement, buf_lens, k_src, v_src, k_addrs, v_addrs)
+    b, len_q, hkv, d = k_src.shape
+    if placement.dim() != 2:
+        raise ZLError("placement is not 2d")
+    check(lib().zl_copy_to_rag_buffer2(_p(placement), _p(buf_lens), _p(k_src), _p(v_src), _p(k_addrs), _p(v_addrs),
+                                       _i(b), _i(len_q), _i(hkv), _i(d), C.c_int(int(bshd)), _stream()),
+          "copy_to_rag_buffer2")
+
+
+def rope_scatter_decode(cos, sin, qkv, placement, buf_lens, k_addrs, v_addrs, num_heads, num_kv_heads, dim_head,
+                        neox=True, bshd=True, q_out=None):
+    """rope_qk_cache + copy_to_rag_buffer2 fused for len_q == 1 decode rows."""
+    _chk_cuda(cos, sin, qkv, placement, buf_lens, k_addrs, v_addrs)
+    b = qkv.shape[0]
+    if q_out is None:
+        q_out = torch.empty((b, num_heads * dim_head), dtype=qkv.dtype, device=qkv.device)
+    check(lib().zl_rope_scatter_decode(_p(cos), _p(sin), _p(qkv), _p(q_out), _p(placement), _p(buf_lens), _p(k_addrs),
+                                       _p(v_addrs), _i(b), _i(num_heads), _i(num_kv_heads), _i(dim_head),
+                                       C.c_int(int(neox)), C.c_int(int(bshd)), C.c_int(_dt(qkv)), _stream()),
+          "rope_scatter_decode")
+    return q_out
+
+
+def decode_attn_workspace(b, len_q, h, d, max_len_buf, device):
+    nbytes = lib().zl_decode_attn_workspace_bytes(_i(b), _i(len_q), _i(h), _i(d), _i(max_len_buf))
+    if nbytes < 0:
+        check(int(nbytes), "decode_attn_workspace_bytes")
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+
+def multi_query_attention_rag_buffer(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, mask, scale, max_len_buf,
+                                     num_kv_heads, valid_lens=None, bshd=True, out=None, workspace=None):
+    """nn::multi_query_attention_rag_buffer / attention_qkv_rag_buffer
+    (src/nn/attention/attention_kernel.cu:1252-1457, 1150-1213).  batch_q (B, len_q, H, D)."""
+    _chk_cuda(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, mask, valid_lens)
+    b, len_q, h, d = batch_q.shape
+    if out is None:
+        out = torch.empty_like(batch_q)
+    if workspace is None:
+        workspace = decode_attn_workspace(b, len_q, h, d, max_len_buf, batch_q.device)
+    check(lib().zl_decode_attn(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(mask),
+                               _p(valid_lens), _p(out), _p(workspace), _i(b), _i(len_q), _i(h), _i(num_kv_heads),
+                               _i(d), _f(scale), _i(max_len_buf), C.c_int(int(bshd)), C.c_int(_dt(batch_q)),
+                               _stream()), "decode_attn")
+    return out
+
+
+def element_add_scale(a, b, scale=1.0, scale_residual=True, out=None):
+    """nn::element_add_scale_out (src/nn/block/block_kernel.cu:19-50)."""
+    _chk_cuda(a, b)
+    if a.shape != b.shape:
+        raise ZLError("a,b shape mismatch")
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().zl_element_add_scale(_p(a), _p(b), _p(out), _i(a.numel()), _f(scale), C.c_int(int(scale_residual)),
+                                     C.c_int(_dt(a)), _stream()), "element_add_scale")
+    return out
+
+
+def gate_mul(inp, in2, gate_type="silu", out=None):
+    """nn::gate_mul_inplace (src/nn/linear/activation_kernel.cu:82-106); out defaults to in place."""
+    _chk_cuda(inp, in2)
+    if gate_type not in ("silu", "gelu"):
+        raise ZLError("Unsupported gate type: " + gate_type)
+    out = inp if out is None else out
+    check(lib().zl_gate_mul(_p(inp), _p(in2), _p(out), _i(inp.numel()), C.c_int(0 if gate_type == "silu" else 1),
+                            C.c_int(_dt(inp)), _stream()), "gate_mul")
+    return out
+
+
+def embedding(ids, weight, scale=1.0, begin=0, end=None):
+    """RawEmbedding::forward (src/nn/embedding/embedding.cu:260-272)."""
+    _chk_cuda(ids, weight)
+    if ids.dtype != torch.int32:
+        raise ZLError("ids dtype mismatch")
+    end = begin + weight.shape[0] if end is None else end
+    out = torch.empty(tuple(ids.shape) + (weight.shape[1],), dtype=weight.dtype, device=weight.device)
+    check(lib().zl_embedding(_p(ids), _p(weight), _p(out), _i(ids.numel()), _i(weight.shape[1]), C.c_int32(begin),
+                             C.c_int32(end), _f(scale), C.c_int(_dt(weight)), _stream()), "embedding")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# a8..a11: INT8
+# --------------------------------------------------------------------------------------------------
+def quant_calc_scale(x):
+    """int8_op::quant_calc_scale (src/nn/quant/int8/quant_kernel.cu:49-103) -> (int8 (M,K), fp32 scale (M))."""
+    _chk_cuda(x)
+    xr = x.reshape(-1, x.shape[-1])
+    m, k = xr.shape
+    q = torch.empty((m, k), dtype=torch.int8, device=x.device)
+    s = torch.empty((m,), dtype=torch.float32, device=x.device)
+    check(lib().zl_quant_calc_scale(_p(xr), _p(q), _p(s), _i(m), _i(k), C.c_int(_dt(x)), _stream()), "quant_calc_scale")
+    return q, s
+
+
+def layernorm_quant(x, weight, eps, scale=1.0):
+    """int8_op::layernorm_quant (src/nn/quant/int8/quant_kernel.cu:153-227) -> (T out, int8, fp32 scale)."""
+    _chk_cuda(x, weight)
+    xr = x.reshape(-1, x.shape[-1])
+    rows, dim = xr.shape
+    out = torch.empty_like(xr)
+    q = torch.empty((rows, dim), dtype=torch.int8, device=x.device)
+    s = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(lib().zl_rmsnorm_quant(_p(xr), _p(weight), _p(out), _p(q), _p(s), _i(rows), _i(dim), _f(eps), _f(scale),
+                                 C.c_int(_dt(x)), _stream()), "layernorm_quant")
+    return out, q, s
+
+
+def int8_gemm_nt(a, b):
+    """int8 (M,K) x int8 (N,K)^T -> int32 (M,N): the IMMA GEMM of Int8Linear::forward."""
+    _chk_cuda(a, b)
+    m, k = a.shape
+    n = b.shape[0]
+    c = torch.empty((m, n), dtype=torch.int32, device=a.device)
+    check(lib().zl_int8_gemm_nt(_p(a), _p(b), _p(c), _i(m), _i(n), _i(k), _stream()), "int8_gemm_nt")
+    return c
+
+
+def quant_scale_back(c, scale_x, scale_y, dtype=torch.float16):
+    """int8_op::quant_scale_back (src/nn/quant/int8/quant_kernel.cu:248-306)."""
+    _chk_cuda(c, scale_x, scale_y)
+    m, n = c.shape
+    out = torch.empty((m, n), dtype=dtype, device=c.device)
+    check(lib().zl_quant_scale_back(_p(c), _p(scale_x), _p(scale_y), _p(out), _i(m), _i(n), C.c_int(_dt(out)),
+                                    _stream()), "quant_scale_back")
+    return out
+
+
+def quant_back_act_mul(a, a_sx, a_sy, b, b_sx, b_sy, act="silu", dtype=torch.float16):
+    """int8_op::quant_back_act_mul (src/nn/quant/int8/quant_kernel.cu:616-676)."""
+    _chk_cuda(a, a_sx, a_sy, b, b_sx, b_sy)
+    m, n = a.shape
+    out = torch.empty((m, n), dtype=dtype, device=a.device)
+    check(lib().zl_quant_back_act_mul(_p(a), _p(a_sx), _p(a_sy), _p(b), _p(b_sx), _p(b_sy), _p(out), _i(m), _i(n),
+                                      C.c_int(0 if act == "silu" else 1), C.c_int(_dt(out)), _stream()),
+          "quant_back_act_mul")
+    return out
