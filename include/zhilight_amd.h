@@ -67,8 +67,10 @@ int zl_awq_shuffle(const uint32_t* in /* (K,N/8) */, uint32_t* out /* (K/8,N) */
  * (src/nn/linear/linear.cpp:1139-1160, 1085-1099), so it plays the role of that load-time step.
  *   Kp = K rounded up to 1024, Np = N rounded up to 2, Q = Kp/1024, C = max(1, 256/G)
  *   qw     : uint32 [Np/2][Q][64][4]   word (row 2*pr + lane/32, index (lane%32) + 32*(4q+j))
- *   scales : fp16   [Np][Q][C][4]      scale of group ((1024q + 256j)/G + c)
- *   zeros  : uint16 [Np][Q][C]         the same 4 groups' zero points, one nibble each (bits 4j)
+ *   scales : fp16   [Np/2][Q][2][C][4] scale of group ((1024q + 256j)/G + c) of row 2*pr + h
+ *   zeros  : uint16 [Np/2][Q][2][C]    the same 4 groups' zero points, one nibble each (bits 4j)
+ * i.e. everything one wave-load (pair pr, load q) needs is contiguous and the three streams advance
+ * linearly: 1 KiB of words, 2*C*8 B of scales, 2*C*2 B of zeros per load.
  * Padding rows / words hold q = z = 0, scale = 0 (contribute exactly 0).
  * row_interleave != 0 packs source row (i%2)*(N/2) + i/2 at packed row i, so that a vertically
  * concatenated [gate; up] matrix ends up as (gate_n, up_n) row pairs for the fused silu*mul epilogue.

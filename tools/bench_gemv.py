@@ -42,10 +42,17 @@ def main():
             for w in ws[name]:
                 ops.w4a16_gemm(x, w, out=out, epilogue=epi, **kw)
             torch.cuda.synchronize()
+            # capture the launches in a hipGraph: python/ctypes call overhead (~10 us) would otherwise
+            # dominate the 2-10 us kernels
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for i in range(a.iters):
+                    ops.w4a16_gemm(x, ws[name][i % a.layers], out=out, epilogue=epi, **kw)
+            gr.replay()
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for i in range(a.iters):
-                ops.w4a16_gemm(x, ws[name][i % a.layers], out=out, epilogue=epi, **kw)
+            gr.replay()
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.iters

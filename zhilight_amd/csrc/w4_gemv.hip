@@ -19,19 +19,19 @@
 //    input row while its first weight loads are in flight) and fused epilogues (bias, ADD_C,
 //    residual add, silu*mul on interleaved gate/up rows).
 //  * no cross-wave reduction, no atomics, no split-K: a wave finishes its rows alone.
+#include <stdlib.h>
 #include "zl_common.h"
 #include "zl_stage.h"
 
 namespace {
 
-constexpr int kRing = 8;  // weight loads in flight per wave (8 KiB)
 
 struct W4Params {
     const uint16_t* x;
     int64_t ldx;
     const uint4* qw;
-    const uint2* scales;    // [row][q][c] x 4 halfs
-    const uint16_t* zeros;  // [row][q][c] 4 nibbles
+    const uint2* scales;    // [pair][q][h][c] x 4 halfs
+    const uint16_t* zeros;  // [pair][q][h][c] 4 nibbles
     const uint16_t* bias;
     const uint16_t* residual;
     uint16_t* y;
@@ -48,32 +48,73 @@ typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ hv2 as_hv2(uint32_t u) { return __builtin_bit_cast(hv2, u); }
 
-// one 8-weight word against MT activation rows: acc[m] = fma(dot8_half(w, x_m), scale, acc[m])
-template <int MT>
-__device__ __forceinline__ void word_step(uint32_t w, float scale, hv2 z1, hv2 z16, const uint4 (&xa)[MT],
-                                          float (&acc)[MT]) {
-    const hv2 one16 = {(_Float16)0.0625f, (_Float16)0.0625f};
-    const hv2 zero2 = {(_Float16)0.f, (_Float16)0.f};
-    const uint32_t magic = 0x64006400u;  // half2(1024, 1024)
-    hv2 d0 = as_hv2((w & 0x000f000fu) | magic) + z1;                                   // (w0,w1) - z
-    hv2 d1 = __builtin_elementwise_fma(as_hv2((w & 0x00f000f0u) | magic), one16, z16);  // (w2,w3) - z
-    uint32_t wb = w >> 8;
-    hv2 d2 = as_hv2((wb & 0x000f000fu) | magic) + z1;                                   // (w4,w5) - z
-    hv2 d3 = __builtin_elementwise_fma(as_hv2((wb & 0x00f000f0u) | magic), one16, z16);  // (w6,w7) - z
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        hv2 r = __builtin_elementwise_fma(d0, as_hv2(xa[m].x), zero2);
-        r = __builtin_elementwise_fma(d1, as_hv2(xa[m].y), r);
-        r = __builtin_elementwise_fma(d2, as_hv2(xa[m].z), r);
-        r = __builtin_elementwise_fma(d3, as_hv2(xa[m].w), r);
-        float dot = (float)r.x + (float)r.y;
-        acc[m] = __builtin_fmaf(dot, scale, acc[m]);
+// ---- the 8-weight word step, hand-scheduled --------------------------------------------------
+// The kernel is VALU-ISSUE bound (rocprofv3: ~115 VALU ops per 1 KiB of weights, SIMDs ~80 % busy
+// issuing), so instruction count is the currency.  Two asm blocks per word:
+//   DEQ (9 ops): the four (w & mask) | 0x6400 extractions as fused v_and_or_b32 (gfx950 VOP3 takes no
+//        32-bit literals, so hipcc splits the C expression into v_and + v_or; with the mask in an
+//        SGPR and the magic in a VGPR the fused form encodes), then the exact fp16 (q - z).
+//   DOT (6 ops per activation row): the reference's hfma2 chain, f32(lo) + f32(hi) as ONE
+//        v_fma_mix_f32 (f16 operands widened exactly, one fp32 rounding == __half2float(lo) +
+//        __half2float(hi)), and acc = fma(dot, scale, acc) as v_fma_mix_f32 reading the f16 scale.
+// Everything inside is plain dependent VALU (hardware-interlocked, no wait states needed).
+struct DeqWord {
+    uint32_t d0, d1, d2, d3;  // half2 (q - z) for weight pairs (0,1) (2,3) (4,5) (6,7)
+};
+
+__device__ __forceinline__ DeqWord deq_word(uint32_t w, uint32_t z1, uint32_t z16, uint32_t mask_lo,
+                                            uint32_t mask_hi, uint32_t magic, uint32_t one16) {
+    DeqWord d;
+    uint32_t wb;
+    asm("v_lshrrev_b32 %4, 8, %5\n\t"
+        "v_and_or_b32 %0, %5, %8, %10\n\t"
+        "v_and_or_b32 %1, %5, %9, %10\n\t"
+        "v_and_or_b32 %2, %4, %8, %10\n\t"
+        "v_and_or_b32 %3, %4, %9, %10\n\t"
+        "v_pk_add_f16 %0, %0, %6\n\t"
+        "v_pk_fma_f16 %1, %1, %11, %7\n\t"
+        "v_pk_add_f16 %2, %2, %6\n\t"
+        "v_pk_fma_f16 %3, %3, %11, %7"
+        : "=&v"(d.d0), "=&v"(d.d1), "=&v"(d.d2), "=&v"(d.d3), "=&v"(wb)
+        : "v"(w), "v"(z1), "v"(z16), "s"(mask_lo), "s"(mask_hi), "v"(magic), "v"(one16));
+    return d;
+}
+
+// SCALE_HI selects which half of `scale2` (two packed fp16 scales) multiplies the dot
+template <bool SCALE_HI>
+__device__ __forceinline__ float dot_word(const DeqWord& d, const uint4& xa, uint32_t scale2, float acc) {
+    uint32_t r;
+    float t;
+    if constexpr (SCALE_HI) {
+        asm("v_pk_fma_f16 %0, %3, %7, 0\n\t"
+            "v_pk_fma_f16 %0, %4, %8, %0\n\t"
+            "v_pk_fma_f16 %0, %5, %9, %0\n\t"
+            "v_pk_fma_f16 %0, %6, %10, %0\n\t"
+            "v_fma_mix_f32 %1, %0, 1.0, %0 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+            "v_fma_mix_f32 %2, %1, %11, %2 op_sel:[0,1,0] op_sel_hi:[0,1,0]"
+            : "=&v"(r), "=&v"(t), "+v"(acc)
+            : "v"(d.d0), "v"(d.d1), "v"(d.d2), "v"(d.d3), "v"(xa.x), "v"(xa.y), "v"(xa.z), "v"(xa.w), "v"(scale2));
+    } else {
+        asm("v_pk_fma_f16 %0, %3, %7, 0\n\t"
+            "v_pk_fma_f16 %0, %4, %8, %0\n\t"
+            "v_pk_fma_f16 %0, %5, %9, %0\n\t"
+            "v_pk_fma_f16 %0, %6, %10, %0\n\t"
+            "v_fma_mix_f32 %1, %0, 1.0, %0 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+            "v_fma_mix_f32 %2, %1, %11, %2 op_sel:[0,0,0] op_sel_hi:[0,1,0]"
+            : "=&v"(r), "=&v"(t), "+v"(acc)
+            : "v"(d.d0), "v"(d.d1), "v"(d.d2), "v"(d.d3), "v"(xa.x), "v"(xa.y), "v"(xa.z), "v"(xa.w), "v"(scale2));
     }
+    return acc;
 }
 
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
 
-template <int MT>
+// kRing = weight loads in flight per wave (1 KiB each).
+// XL    = activation loads (16 B) per thread per row held in registers across the weight prologue:
+//         the x loads are issued FIRST (oldest in the in-order VMEM queue), then the ring of weight
+//         loads, so x (an L2 hit) can be normalised and written to LDS while the HBM loads fly.
+//         XL = 0 selects the generic "stage x, then start streaming" order for very large K.
+template <int MT, int kRing, int XL>
 __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* xs = reinterpret_cast<uint16_t*>(smem);                 // [MT][kp]
@@ -94,36 +135,118 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
     npairs = npairs < 0 ? 0 : (npairs > p.pairs_per_wave ? p.pairs_per_wave : npairs);
     const int total = npairs * Q;
 
-    // ---- per-lane streams: weights advance 64 uint4 per item, meta advance C entries per item
-    const uint4* wptr = p.qw + ((size_t)pair0 * Q) * 64 + lane;
-    const size_t meta_row_stride = (size_t)Q * p.c_classes;
-    const size_t meta_base = ((size_t)(2 * pair0 + h)) * meta_row_stride + cls;
+    // ---- per-lane streams: weights advance 64 uint4 per item, meta advance C entries per item.
+    // A wave without work (tail of the grid) still runs the branch-free load sequence on the last
+    // pair and discards it: no VMEM instruction may sit behind a branch (see `issue` below).
+    const int pair0c = pair0 < p.pairs_total ? pair0 : p.pairs_total - 1;
+    const uint4* wptr = p.qw + ((size_t)pair0c * Q) * 64 + lane;
+    const uint2* sptr = p.scales + ((size_t)pair0c * Q * 2 + h) * p.c_classes + cls;
+    const uint16_t* zptr = p.zeros + ((size_t)pair0c * Q * 2 + h) * p.c_classes + cls;
+    const int meta_step = 2 * p.c_classes;
 
+    // ---- (1) activation loads into registers (no branches: clamped addresses + selects)
+    uint4 xr[MT][XL > 0 ? XL : 1];
+    uint4 nwr[XL > 0 ? XL : 1];
+    if constexpr (XL > 0) {
+        const uint16_t* nwp = p.norm_w ? p.norm_w : p.x;  // dummy but valid address when unused
+#pragma unroll
+        for (int l = 0; l < XL; ++l) {
+            const int i = (threadIdx.x + l * 256) * 8;
+            nwr[l] = *reinterpret_cast<const uint4*>(nwp + (i < p.k ? i : p.k - 8));
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const uint16_t* xrow = p.x + (size_t)((m0 + m) < p.m ? (m0 + m) : 0) * p.ldx;
+#pragma unroll
+            for (int l = 0; l < XL; ++l) {
+                const int i = (threadIdx.x + l * 256) * 8;
+                xr[m][l] = *reinterpret_cast<const uint4*>(xrow + (i < p.k ? i : p.k - 8));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        zl_stage_rows<ZL_F16, MT, 256>(p.x, p.ldx, m0, p.m, p.k, p.kp, p.norm_w, p.norm_eps, xs, red);
+    }
+
+    // ---- (2) weight ring prologue
     uint4 wq[kRing];
     uint2 sc[kRing];
-    uint32_t zq[kRing];
-
-    // item `it` of this wave: pair pair0 + it / Q, load q = it % Q.  Rows of a pair are adjacent
-    // in the meta arrays (row 2pr, 2pr+1), so meta index = base + (it/Q)*2*stride + (it%Q)*C
-    int iss_pair = 0, iss_q = 0;  // position of the next item to issue
+    uint16_t zq[kRing];  // kept 16-bit until consumed: a widening at issue time would be sunk to the
+                         // loop tail by hipcc and drain the ring there
+    // Item i of this wave = (pair pair0 + i / Q, load i % Q).  The issue stream is CLAMPED to the
+    // wave's last item (a few duplicate, cache-hitting loads at the very end) so that no branch ever
+    // surrounds a VMEM instruction: hipcc then keeps counted s_waitcnt vmcnt(N) in the steady-state
+    // loop instead of draining the ring with vmcnt(0) at every loop header.
+    int iss_idx = 0;
     auto issue = [&](int slot) {
         wq[slot] = zl_load_nt(wptr);
-        wptr += 64;
-        const size_t mi = meta_base + (size_t)iss_pair * 2 * meta_row_stride + (size_t)iss_q * p.c_classes;
-        sc[slot] = p.scales[mi];
-        zq[slot] = p.sym ? 0x8888u : (uint32_t)p.zeros[mi];
-        if (++iss_q == Q) {
-            iss_q = 0;
-            ++iss_pair;
-        }
+        sc[slot] = zl_load_nt(sptr);
+        zq[slot] = zl_load_nt(zptr);
+        const bool adv = iss_idx + 1 < total;  // wave-uniform
+        ++iss_idx;
+        wptr += adv ? 64 : 0;
+        sptr += adv ? meta_step : 0;
+        zptr += adv ? meta_step : 0;
     };
 
+    // pin the prologue's issue order slot by slot: the loop-header s_waitcnt is the minimum over the
+    // preheader and back-edge paths, so a regrouped prologue would force vmcnt(~0) there
 #pragma unroll
-    for (int s = 0; s < kRing; ++s)
-        if (s < total) issue(s);
+    for (int s = 0; s < kRing; ++s) {
+        issue(s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
-    // ---- stage the activation rows into LDS (optionally RMS-normalised), zero the K padding
-    zl_stage_rows<ZL_F16, MT, 256>(p.x, p.ldx, m0, p.m, p.k, p.kp, p.norm_w, p.norm_eps, xs, red);
+    // ---- (3) activation rows -> LDS (optionally RMS-normalised: LayerNorm::forward semantics,
+    // src/nn/layernorm/layernorm.cu:10-42), K padding zeroed
+    if constexpr (XL > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bool live = (m0 + m) < p.m;
+            float rs = 1.f;
+            if (p.norm_w) {
+                float ss = 0.f;
+#pragma unroll
+                for (int l = 0; l < XL; ++l) {
+                    const int i = (threadIdx.x + l * 256) * 8;
+                    if (i < p.k) {
+                        const uint32_t u[4] = {xr[m][l].x, xr[m][l].y, xr[m][l].z, xr[m][l].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const hv2 hh = as_hv2(u[e]);
+                            ss = __builtin_fmaf((float)hh.x, (float)hh.x, ss);
+                            ss = __builtin_fmaf((float)hh.y, (float)hh.y, ss);
+                        }
+                    }
+                }
+                ss = zl_block_sum(ss, red);
+                rs = zl_rsqrt_rn(ss / (float)p.k + p.norm_eps);
+            }
+#pragma unroll
+            for (int l = 0; l < XL; ++l) {
+                const int i = (threadIdx.x + l * 256) * 8;
+                if (i < p.kp) {
+                    uint4 v = xr[m][l];
+                    if (!live || i >= p.k) v = make_uint4(0, 0, 0, 0);
+                    if (p.norm_w && i < p.k) {
+                        const uint4 wv = nwr[l];
+                        uint32_t u[4] = {v.x, v.y, v.z, v.w};
+                        const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const hv2 hh = as_hv2(u[e]), ww = as_hv2(wu[e]);
+                            hv2 o;
+                            o.x = zl_f32_to_f16((float)hh.x * rs * (float)ww.x);
+                            o.y = zl_f32_to_f16((float)hh.y * rs * (float)ww.y);
+                            u[e] = __builtin_bit_cast(uint32_t, o);
+                        }
+                        v = make_uint4(u[0], u[1], u[2], u[3]);
+                    }
+                    *reinterpret_cast<uint4*>(xs + (size_t)m * p.kp + i) = v;
+                }
+            }
+        }
+    }
     __syncthreads();
 
     // ---- main loop
@@ -131,26 +254,33 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = 0.f;
     int cq = 0, cpair = pair0;  // position of the item being consumed
+    // loop-invariant operands of the dequant (SGPR masks, VGPR magic 0x6400 = half 1024)
+    const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
+    const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(0x00f000f0u);
+    uint32_t magic = 0x64006400u, one16 = 0x2c002c00u;  // half2(1024), half2(1/16)
+    asm volatile("" : "+v"(magic), "+v"(one16));  // keep them in VGPRs (opaque to constant propagation)
     const uint16_t* xlane = xs + 8 * r;
 
-    auto consume = [&](int slot) {
+    auto consume = [&](int slot, bool valid) {
         const uint32_t wds[4] = {wq[slot].x, wq[slot].y, wq[slot].z, wq[slot].w};
-        const hv2 s01 = as_hv2(sc[slot].x), s23 = as_hv2(sc[slot].y);
-        const float scl[4] = {(float)s01.x, (float)s01.y, (float)s23.x, (float)s23.y};
+        // an item past the end of the wave's run is neutralised by zero scales: fma(dot, 0, acc) == acc
+        const uint32_t s01 = valid ? sc[slot].x : 0u, s23 = valid ? sc[slot].y : 0u;
         const uint32_t z4 = zq[slot];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t z = (z4 >> (4 * j)) & 0xfu;
-            const hv2 z1 = as_hv2(0xe400e400u | z | (z << 16));  // -(1024 + z), exact
+            const uint32_t z1 = 0xe400e400u | z | (z << 16);                        // half2 -(1024 + z), exact
             const hv2 c960 = {(_Float16)960.f, (_Float16)960.f};
-            const hv2 z16 = z1 + c960;                            // -(64 + z), exact
-            uint4 xa[MT];
+            const uint32_t z16 = __builtin_bit_cast(uint32_t, as_hv2(z1) + c960);  // half2 -(64 + z), exact
+            const DeqWord d = deq_word(wds[j], z1, z16, mask_lo, mask_hi, magic, one16);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                xa[m] = *reinterpret_cast<const uint4*>(xlane + (size_t)m * p.kp + 8 * (32 * (4 * cq + j)));
-            word_step<MT>(wds[j], scl[j], z1, z16, xa, acc);
+            for (int m = 0; m < MT; ++m) {
+                const uint4 xa = *reinterpret_cast<const uint4*>(xlane + (size_t)m * p.kp + 8 * (32 * (4 * cq + j)));
+                if (j & 1) acc[m] = dot_word<true>(d, xa, j < 2 ? s01 : s23, acc[m]);
+                else acc[m] = dot_word<false>(d, xa, j < 2 ? s01 : s23, acc[m]);
+            }
         }
-        if (++cq == Q) {
+        if (valid && ++cq == Q) {
             // ---- row pair finished: replay the reference's 32-lane shuffle-down tree per half-wave and
             // park the fp32 sums in this wave's LDS slot; the epilogue runs once, after the stream.
             cq = 0;
@@ -166,15 +296,18 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
         }
     };
 
+    if (total > 0) {
+        int it = 0;
 #pragma unroll 1
-    for (int it = 0; it < total; it += kRing) {
+        for (; it + kRing < total; it += kRing) {  // steady state: every slot valid, consumed, re-issued
 #pragma unroll
-        for (int s = 0; s < kRing; ++s) {
-            if (it + s < total) {
-                consume(s);
-                if (it + s + kRing < total) issue(s);
+            for (int s = 0; s < kRing; ++s) {
+                consume(s, true);
+                issue(s);
             }
         }
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) consume(s, it + s < total);  // last (possibly partial) ring
     }
 
     // ---- epilogue: lane i of the wave finishes row (or gate/up pair) i of the wave's run; stores
@@ -196,13 +329,13 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
                 }
                 float o;
                 if (p.epi & ZL_EPI_SILU_MUL) {
-                    g = (float)(_Float16)g;  // the two fp16 linear outputs
-                    u = (float)(_Float16)u;
+                    g = (float)zl_f32_to_f16(g);  // the two fp16 linear outputs
+                    u = (float)zl_f32_to_f16(u);
                     o = silu_f32(g) * u;
                 } else {
                     o = (float)((double)g / (1.0 + (double)expf(-g))) * u;
                 }
-                p.y[orow + pr] = __builtin_bit_cast(uint16_t, (_Float16)o);
+                p.y[orow + pr] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(o));
             } else {
                 const int row = 2 * pair0 + lane;
                 if (row >= p.n) continue;
@@ -211,25 +344,25 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
                 float o;
                 if (p.epi & ZL_EPI_ADD_C) o = ((float)__builtin_bit_cast(_Float16, p.y[orow + row]) + v) + b;
                 else o = v + b;
-                _Float16 y16 = (_Float16)o;
+                _Float16 y16 = zl_f32_to_f16(o);
                 if (p.epi & ZL_EPI_RESIDUAL)
-                    y16 = (_Float16)((float)__builtin_bit_cast(_Float16, p.residual[orow + row]) + (float)y16);
+                    y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, p.residual[orow + row]) + (float)y16);
                 p.y[orow + row] = __builtin_bit_cast(uint16_t, y16);
             }
         }
     }
 }
 
-template <int MT>
+template <int MT, int kRing, int XL>
 int launch(const W4Params& p, int grid_x, int grid_y, hipStream_t st) {
     size_t lds = (size_t)MT * p.kp * 2 + 64 + 4 * 64 * MT * 4;
     if (lds > 160 * 1024) return ZL_ELIMIT;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm<MT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm<MT, kRing, XL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_w4a16_gemm<MT>, dim3(grid_x, grid_y), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((k_w4a16_gemm<MT, kRing, XL>), dim3(grid_x, grid_y), dim3(256), lds, st, p);
     return zl_launch_status();
 }
 
@@ -266,34 +399,42 @@ extern "C" int zl_w4a16_gemm(const uint16_t* x, int64_t ldx, const uint32_t* qw,
 
     // rows-per-pass: the VALU budget of the reference-exact arithmetic holds up to ~3 rows per
     // weight pass at HBM speed; LDS must hold MT * Kp halfs
-    int mt = m >= 4 ? 4 : (int)m;
-    while (mt > 1 && (size_t)mt * L.kp * 2 + 64 + 4096 > 64 * 1024) --mt;
-    if (mt == 3 && m > 3) mt = 2;
+    int mt = m >= 3 ? 4 : (int)m;
+    while (mt > 1 && (size_t)mt * L.kp * 2 + 64 + 4096 > 64 * 1024) mt >>= 1;
     const int grid_y = (int)((m + mt - 1) / mt);
 
-    // grid: j workgroups (4 waves) per CU; each wave owns a contiguous run of row pairs.  Pick j
-    // in 1..4 minimising pairs handled per CU (the HBM-bound time), ties -> more waves in flight.
+    // grid: the kernel is VALU-issue bound with dependent fp16 chains, so it wants as many waves per
+    // SIMD as the ~100 VGPRs allow (4) plus a queue of further workgroups that the dispatcher uses to
+    // even out the tail: 8 four-wave workgroups per CU measured best on the Llama-3-8B shapes
+    // (gate_up 15.5 us vs 18.2 us at 2 per CU).  Each wave owns a contiguous run of row pairs.
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
-    int best_j = 1, best_cost = 1 << 30, best_ppw = 1;
-    for (int j = 1; j <= 4; ++j) {
-        int waves = cus * j * 4;
-        int ppw = (p.pairs_total + waves - 1) / waves;
-        int cost = ppw * j * 4;
-        if (cost < best_cost || (cost == best_cost && j > best_j)) {
-            best_cost = cost; best_j = j; best_ppw = ppw;
-        }
+    int wgs_per_cu = 8;
+    if (const char* e = getenv("ZL_W4_WGS_PER_CU")) {  // tuning override (read-only, no state kept)
+        int v = atoi(e);
+        if (v >= 1 && v <= 16) wgs_per_cu = v;
     }
+    int best_ppw = (p.pairs_total + cus * wgs_per_cu * 4 - 1) / (cus * wgs_per_cu * 4);
+    if (best_ppw < 1) best_ppw = 1;
     if (best_ppw > 32) best_ppw = 32;  // LDS result slots: 64 rows per wave
     p.pairs_per_wave = best_ppw;
     const int waves_needed = (p.pairs_total + best_ppw - 1) / best_ppw;
     const int grid_x = (waves_needed + 3) / 4;
 
     hipStream_t hs = (hipStream_t)s;
+    // ring depth: never more loads in flight than the wave has items (no dummy loads for tiny runs);
+    // XL: x loads per thread kept in registers (2 -> K <= 4096, 8 -> K <= 16384 with few rows, else 0)
+    const bool small = (int64_t)best_ppw * L.q < 8;
+    const int xl = L.kp <= 4096 ? 2 : ((L.kp <= 16384 && mt <= 2) ? 8 : 0);
+#define ZL_W4_LAUNCH(MT)                                                                     \
+    if (xl == 2)                                                                             \
+        return small ? launch<MT, 4, 2>(p, grid_x, grid_y, hs) : launch<MT, 8, 2>(p, grid_x, grid_y, hs); \
+    if (xl == 8) return launch<MT, 8, 8>(p, grid_x, grid_y, hs);                             \
+    return small ? launch<MT, 4, 0>(p, grid_x, grid_y, hs) : launch<MT, 8, 0>(p, grid_x, grid_y, hs);
     switch (mt) {
-        case 1: return launch<1>(p, grid_x, grid_y, hs);
-        case 2: return launch<2>(p, grid_x, grid_y, hs);
-        case 3: return launch<3>(p, grid_x, grid_y, hs);
-        default: return launch<4>(p, grid_x, grid_y, hs);
+        case 1: ZL_W4_LAUNCH(1)
+        case 2: ZL_W4_LAUNCH(2)
+        default: ZL_W4_LAUNCH(4)
     }
+#undef ZL_W4_LAUNCH
 }

@@ -124,8 +124,11 @@ __global__ void k_pack_meta(const uint8_t* __restrict__ qz_km, const uint16_t* _
                             int64_t g, int64_t np, int64_t q_loads, int64_t c_classes, int interleave) {
     int64_t total = np * q_loads * c_classes;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // destination index i = ((pr * Q + q) * 2 + h) * C + c
         int64_t c = i % c_classes, t = i / c_classes;
-        int64_t q = t % q_loads, row = t / q_loads;
+        int64_t hh = t & 1;
+        t >>= 1;
+        int64_t q = t % q_loads, row = 2 * (t / q_loads) + hh;
         int64_t src_row = interleave ? ((row & 1) * (n / 2) + (row >> 1)) : row;
         uint16_t z4 = 0;
 #pragma unroll
@@ -154,14 +157,14 @@ __global__ void k_w4_dequant(const uint32_t* __restrict__ qw, const uint16_t* __
         int lane = (int)((row & 1) * 32 + r);
         uint32_t word = qw[(((row >> 1) * q_loads + q) * 64 + lane) * 4 + j];
         int64_t c = (c_classes > 1) ? (r / (32 / c_classes)) : 0;
-        int64_t mi = (row * q_loads + q) * c_classes + c;
+        int64_t mi = (((row >> 1) * q_loads + q) * 2 + (row & 1)) * c_classes + c;
         float s = (float)__builtin_bit_cast(_Float16, scales[mi * 4 + j]);
         int z = (zeros[mi] >> (4 * j)) & 0xf;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int nib = (e & 1) ? ((word >> (4 * (e >> 1) + 16)) & 0xf) : ((word >> (4 * (e >> 1))) & 0xf);
             _Float16 d = (_Float16)(float)(nib - z);
-            _Float16 v = (_Float16)((float)d * s);  // product of two fp16 is exact in fp32 -> one rounding
+            _Float16 v = zl_f32_to_f16((float)d * s);  // product of two fp16 is exact in fp32 -> one rounding
             out[row * k + 8 * w + e] = __builtin_bit_cast(uint16_t, v);
         }
     }

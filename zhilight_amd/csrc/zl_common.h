@@ -22,18 +22,33 @@ typedef _Float16 h16;
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // streamed-once data (weights): non-temporal 16-byte load, keeps L2/MALL for activations and KV
 __device__ __forceinline__ uint4 zl_load_nt(const uint4* p) {
     u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint2 zl_load_nt(const uint2* p) {
+    u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint16_t zl_load_nt(const uint16_t* p) { return __builtin_nontemporal_load(p); }
+
+// fp32 -> fp16 with the fp32 value MATERIALISED first.  Without the barrier LLVM folds
+// fptrunc(fmul(a, fpext(b))) into v_fma_mixlo_f16, i.e. rounds the exact product once to fp16 and
+// skips the fp32 rounding the reference (and the oracle) perform -- a real 1-ulp difference on
+// near-ties (seen on quant_scale_back).  The empty asm costs no instruction.
+__device__ __forceinline__ _Float16 zl_f32_to_f16(float f) {
+    asm volatile("" : "+v"(f));
+    return (_Float16)f;
+}
 
 // ---- scalar type helpers: activations travel as raw 16-bit patterns ----
 template <int DT> struct ZT;
 template <> struct ZT<ZL_F16> {
     static __device__ __forceinline__ float to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
-    static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, zl_f32_to_f16(f)); }
 };
 template <> struct ZT<ZL_BF16> {
     static __device__ __forceinline__ float to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
