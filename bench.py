@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- decode throughput of the MI355X-native ZhiLight hot path.
+
+Workload (BASELINE.json configs[1]): Llama-3-8B GPTQ-Int4 (group 128), TP=1, batch-1 greedy decode at
+KV length ~1024, synthetic random-init weights of the real shapes and a random KV history
+(no checkpoints / datasets in this environment).  A "step" is ONE decode step of the whole model:
+embedding -> 32 x (fused RMSNorm+qkv W4A16 GEMV, RoPE + KV scatter, GQA decode attention,
+o_proj GEMV + residual, fused RMSNorm + gate|up GEMV + silu*mul, down GEMV + residual) ->
+fused final norm + fp16 lm_head GEMV -> argmax -> position / KV bookkeeping, captured in one hipGraph.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+
+N > 1 (launched with torch.distributed.run, one rank per GPU): the decode path shards as independent
+TP=1 replicas (one model + its own requests per GPU, no data-path collective), i.e. weak scaling;
+`value` is the whole-job aggregate tokens/s.  Rank 0 prints ONE JSON line with, besides the contract
+fields, `roofline` (the W4A16 GEMV kernel: algorithmic bytes / HIP-event time, vs 8 TB/s HBM) and
+`cpu_baseline` (the CPU oracle timed on a bounded sample on this box's host cores).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes_w4(n, k, g, m):
+    """canonical GPTQ bytes (int4 + fp16 scale + 4-bit zero per group) + activations."""
+    return k * n * (0.5 + 2.0 / g + 0.5 / g) + m * k * 2 + m * n * 2
+
+
+def cpu_baseline(cfg, batch, seq):
+    """The reference has no CPU path for the model; this times OUR CPU restatement (oracle/, kind
+    "port", R flavour, OpenMP over all host cores) on a bounded sample of one decode step:
+    the four W4A16 linears of ONE of the 32 layers + 1/16 of the lm_head rows + one layer's decode
+    attention, extrapolated to a full step."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import zl_oracle as zo
+    rng = np.random.default_rng(0)
+    g = 128
+    hd, kvd = cfg.num_heads * cfg.dim_head, cfg.num_kv_heads * cfg.dim_head
+    shapes = [(hd + 2 * kvd, cfg.dim_model), (cfg.dim_model, hd), (2 * cfg.dim_ff, cfg.dim_model), (cfg.dim_model, cfg.dim_ff)]
+    t_lin = 0.0
+    for n, k in shapes:
+        qw = rng.integers(0, 2 ** 32, size=(n, k // 8), dtype=np.uint64).astype(np.uint32)
+        qz = rng.integers(0, 16, size=(n, k // g), dtype=np.uint8)
+        sc = (np.abs(rng.standard_normal((n, k // g))) * 0.0025 + 1e-4).astype(np.float16).view(np.uint16)
+        x = rng.standard_normal((batch, k)).astype(np.float16).view(np.uint16)
+        t0 = time.perf_counter()
+        zo.gptq_gemm_k_major(x, qw, qz, sc)
+        t_lin += time.perf_counter() - t0
+    rows = cfg.vocab_size // 16
+    w = (rng.standard_normal((rows, cfg.dim_model)) * 0.02).astype(np.float16).view(np.uint16)
+    x = rng.standard_normal((batch, cfg.dim_model)).astype(np.float16).view(np.uint16)
+    t0 = time.perf_counter()
+    zo.gemm_nt(x, w)
+    t_head = (time.perf_counter() - t0) * 16
+    kb = [rng.standard_normal((seq, cfg.num_kv_heads, cfg.dim_head)).astype(np.float16).view(np.uint16) for _ in range(batch)]
+    q = rng.standard_normal((batch, 1, cfg.num_heads, cfg.dim_head)).astype(np.float16).view(np.uint16)
+    mask = np.ones(batch * seq, np.int8)
+    t0 = time.perf_counter()
+    zo.mqa_rag_buffer(q, np.full(batch, seq, np.int32), kb, kb, mask, cfg.num_kv_heads, 0.088)
+    t_attn = time.perf_counter() - t0
+    t_step = cfg.num_layers * (t_lin + t_attn) + t_head
+    return {
+        "value": batch / t_step, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+        "sample": (f"oracle/ R-flavour CPU port (the reference has no CPU path): 1 of {cfg.num_layers} layers' W4A16 linears "
+                   f"({t_lin:.2f} s) + decode attention ({t_attn:.2f} s) + 1/16 of lm_head rows, extrapolated to a full step"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--seq", type=int, default=1024)
+    ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (marks the result invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from zhilight_amd import ops  # noqa: F401  (raises if the HIP library is missing)
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+
+    cfg = ModelConfig.llama3_8b()
+    if args.layers:
+        cfg.num_layers = args.layers
+    batch, seq = args.batch, args.seq
+    model = LLaMA(cfg, QuantConfig(5, 128), dev).init_random(seed=1234 + rank)
+    len_buf = (seq + args.warmup + args.steps + 4 + 63) // 64 * 64
+    ctx = model.new_context(batch, len_buf, seq, fill_random=True)
+    ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
+
+    def step():
+        logits = model.encode(ctx)
+        model.advance(ctx, torch.argmax(logits, dim=-1))
+
+    step()  # eager once: allocates the step's buffers, caches device attributes
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(args.warmup):
+        graph.replay()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline leg (rank 0): the dominant kernel = the W4A16 GEMV (k_w4a16_gemm).  All 4 x 32 GEMV
+    # launches of one step, in model order on the real (distinct, HBM-cold: 3.6 GB >> 256 MB
+    # Infinity Cache) weights, captured without the other kernels; HIP events on the launch stream.
+    roof = None
+    if rank == 0:
+        bufs = model._buffers(batch)
+        launches = []
+        for layer in model.layers:
+            launches += [(bufs["hidden"], layer.qkv, bufs["qkv"], dict(norm_weight=layer.ln_attn, norm_eps=cfg.eps)),
+                         (bufs["attn"], layer.attn_out, bufs["hidden"], dict(residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL)),
+                         (bufs["hidden"], layer.w_in_gated, bufs["act"], dict(norm_weight=layer.ln_ff, norm_eps=cfg.eps, epilogue=ops.EPI_SILU_MUL)),
+                         (bufs["act"], layer.w_out, bufs["hidden"], dict(residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL))]
+        bufs["hidden"].normal_()
+        bufs["attn"].normal_()
+
+        def gemvs():
+            for x, lin, out, kw in launches:
+                ops.w4a16_gemm(x, lin.weight, out=out, **kw)
+        gemvs()
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            gemvs()
+        g2.replay()
+        torch.cuda.synchronize()
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g2.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t_launch = e0.elapsed_time(e1) * 1e-3 / (reps * len(launches))
+        tot_bytes = sum(alg_bytes_w4(lin.weight.n, lin.weight.k, lin.weight.group_size, batch) for _, lin, _, _ in launches)
+        per_launch = tot_bytes / len(launches)
+        achieved = per_launch / t_launch / 1e9
+        roof = {"bound": "hbm", "kernel": "k_w4a16_gemm (W4A16 GEMV, 4 launches/layer)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3),
+                "note": "avg over the 128 GEMV launches of one step incl. inter-kernel gaps (graph replay, HIP events)"}
+
+    if rank == 0:
+        value = world * batch * args.steps / elapsed
+        # whole-step algorithmic bytes: int4 linears + fp16 lm_head + KV read
+        step_bytes = (sum(alg_bytes_w4(l.weight.n, l.weight.k, 128, batch) for lay in model.layers
+                          for l in (lay.qkv, lay.attn_out, lay.w_in_gated, lay.w_out))
+                      + cfg.vocab_size * cfg.dim_model * 2
+                      + batch * cfg.num_layers * 2 * cfg.num_kv_heads * seq * cfg.dim_head * 2)
+        out = {
+            "metric": "decode tokens/s (Llama-3-8B GPTQ-Int4, TP=1 per GPU, batch %d, seq %d)" % (batch, seq),
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "Llama-3-8B GPTQ-Int4 g128 TP=1 batch=%d decode seq=%d (BASELINE configs[1])" % (batch, seq),
+                       "layers": cfg.num_layers, "parallelism": "dp%d (independent TP=1 replicas)" % world,
+                       "global_batch": world * batch, "seq_len": seq, "valid": not args.layers},
+            "per_gpu_tokens_per_s": round(value / world, 2),
+            "step_hbm_roofline_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, batch, seq)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""GPU parity of the whole decode step (EncoderLayer / LLaMA::encode wiring)
+against the oracle composed op by op in the reference's single-stream order
+(src/nn/block/block.cpp:86-143, src/nn/attention/attention.cpp:846-964, src/nn/feedforward/feedforward.cpp:113-137)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _hf_state(rng, cfg, g):
+    sd = {}
+    hd, kvd = cfg.num_heads * cfg.dim_head, cfg.num_kv_heads * cfg.dim_head
+
+    def lin(name, din, dout):
+        qw, qz, sc = synth.gptq_hf(rng, din, dout, g)
+        # keep activations O(1): scales ~ 1/sqrt(din)/4
+        sc = (np.abs(rng.standard_normal(sc.shape)) * (0.5 / np.sqrt(din)) / 4 + 1e-4).astype(np.float16).view(np.uint16)
+        sd[name + ".qweight"], sd[name + ".qzeros"], sd[name + ".scales"] = qw.view(np.int32), qz.view(np.int32), sc.view(np.float16)
+    for i in range(cfg.num_layers):
+        p = f"model.layers.{i}."
+        sd[p + "input_layernorm.weight"] = (1 + 0.1 * rng.standard_normal(cfg.dim_model)).astype(np.float16)
+        sd[p + "post_attention_layernorm.weight"] = (1 + 0.1 * rng.standard_normal(cfg.dim_model)).astype(np.float16)
+        lin(p + "self_attn.q_proj", cfg.dim_model, hd)
+        lin(p + "self_attn.k_proj", cfg.dim_model, kvd)
+        lin(p + "self_attn.v_proj", cfg.dim_model, kvd)
+        lin(p + "self_attn.o_proj", hd, cfg.dim_model)
+        lin(p + "mlp.gate_proj", cfg.dim_model, cfg.dim_ff)
+        lin(p + "mlp.up_proj", cfg.dim_model, cfg.dim_ff)
+        lin(p + "mlp.down_proj", cfg.dim_ff, cfg.dim_model)
+    sd["model.embed_tokens.weight"] = (rng.standard_normal((cfg.vocab_size, cfg.dim_model)) * 0.5).astype(np.float16)
+    sd["model.norm.weight"] = (1 + 0.1 * rng.standard_normal(cfg.dim_model)).astype(np.float16)
+    sd["lm_head.weight"] = (rng.standard_normal((cfg.vocab_size, cfg.dim_model)) * 0.05).astype(np.float16)
+    return sd
+
+
+class OracleModel:
+    def __init__(self, oracle, cfg, sd, g, batch, len_buf):
+        self.o, self.cfg, self.g = oracle, cfg, g
+        self.sd = sd
+        self.km = {}
+        for k in sd:
+            if k.endswith(".qweight"):
+                base = k[:-8]
+                self.km[base] = oracle.gptq_prepare_k_major(sd[base + ".qweight"].view(np.uint32), sd[base + ".qzeros"].view(np.uint32),
+                                                            sd[base + ".scales"].view(np.uint16), g)
+        shp = (len_buf, cfg.num_kv_heads, cfg.dim_head)
+        self.kb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
+        self.vb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
+        self.len_buf = len_buf
+
+    def step(self, tokens, pos):
+        o, c = self.o, self.cfg
+        b = len(tokens)
+        h = o.embedding(np.asarray(tokens, np.int32), o.h2u(self.sd["model.embed_tokens.weight"]))
+        llama3 = (8.0, 1.0, 4.0, 8192.0)
+        cs, sn = o.rope_cos_sin(np.asarray(pos, np.int32), c.dim_head, c.rope_theta, True, llama3)
+        lens = np.full(b, self.len_buf, np.int32)
+        mask = np.concatenate([(np.arange(self.len_buf) <= p).astype(np.int8) for p in pos])
+        for i in range(c.num_layers):
+            p = f"model.layers.{i}."
+            xn = o.rmsnorm(h, o.h2u(self.sd[p + "input_layernorm.weight"]), c.eps)
+            qkv = np.concatenate([o.gptq_gemm_k_major(xn, *self.km[p + "self_attn." + n + "_proj"]) for n in "qkv"], axis=1)
+            q, k, v = o.rope_qk_cache(cs, sn, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
+            o.copy_to_rag_buffer2(np.asarray(pos, np.int32).reshape(b, 1), lens, k.reshape(b, 1, c.num_kv_heads, c.dim_head),
+                                  v.reshape(b, 1, c.num_kv_heads, c.dim_head), self.kb[i], self.vb[i], True)
+            att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask, c.num_kv_heads,
+                                   1.0 / np.sqrt(c.dim_head), True).reshape(b, -1)
+            h = o.element_add_scale(h, o.gptq_gemm_k_major(att, *self.km[p + "self_attn.o_proj"]), 1.0, True)
+            xn = o.rmsnorm(h, o.h2u(self.sd[p + "post_attention_layernorm.weight"]), c.eps)
+            act = o.silu_mul(o.gptq_gemm_k_major(xn, *self.km[p + "mlp.gate_proj"]), o.gptq_gemm_k_major(xn, *self.km[p + "mlp.up_proj"]))
+            h = o.element_add_scale(h, o.gptq_gemm_k_major(act, *self.km[p + "mlp.down_proj"]), 1.0, True)
+        xn = o.rmsnorm(h, o.h2u(self.sd["model.norm.weight"]), c.eps)
+        return o.gemm_nt(xn, o.h2u(self.sd["lm_head.weight"]), exact=True), h
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_decode_steps_match_oracle(oracle, dev, batch):
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(0)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5,
+                      rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                    "original_max_position_embeddings": 8192})
+    g = 128
+    sd = _hf_state(rng, cfg, g)
+    model = LLaMA(cfg, QuantConfig(5, g), dev).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    len_buf = 64
+    ctx = model.new_context(batch, len_buf, 0)
+    om = OracleModel(oracle, cfg, sd, g, batch, len_buf)
+    tokens = rng.integers(0, cfg.vocab_size, batch).astype(np.int32)
+    ctx.tokens.copy_(torch.from_numpy(tokens))
+    for step in range(4):
+        logits = model.encode(ctx)
+        got = logits.float().cpu().numpy().astype(np.float64)
+        ref, _ = om.step(tokens, [step] * batch)
+        scale = np.abs(ref).max()
+        # north_star bar: logits within 1e-3 rel of the reference path
+        assert np.abs(got - ref).max() <= 1e-3 * scale + 2.0 ** -11 * scale, (step, np.abs(got - ref).max() / scale)
+        nxt_ref = ref.argmax(axis=1)
+        nxt = logits.argmax(dim=1)
+        assert np.array_equal(nxt.cpu().numpy(), nxt_ref), "greedy tokens differ"
+        model.advance(ctx, nxt)
+        tokens = nxt_ref.astype(np.int32)
+    # KV written by the fused rope+scatter kernel equals the oracle's buffers (first 4 slots)
+    for li in range(cfg.num_layers):
+        for bi in range(batch):
+            gk = ctx.kv[bi][li, 0].cpu().numpy()[:4].astype(np.float64)
+            rk = oracle.u2h(om.kb[li][bi][:4]).astype(np.float64)
+            assert np.abs(gk - rk).max() <= 2.0 ** -9 * np.abs(rk).max(), np.abs(gk - rk).max()
+            gv = ctx.kv[bi][li, 1].cpu().numpy()[:4].astype(np.float64)
+            rv = oracle.u2h(om.vb[li][bi][:4]).astype(np.float64)
+            assert np.abs(gv - rv).max() <= 2.0 ** -9 * np.abs(rv).max()

@@ -1,0 +1,100 @@
+"""CPU self-consistency of the oracle: format definitions, R vs E gap, integer exactness, soft-float."""
+import numpy as np
+import pytest
+
+import synth
+
+
+def test_soft_float_conversions(oracle):
+    rng = np.random.default_rng(0)
+    f = (rng.standard_normal(20000) * 10.0 ** rng.integers(-8, 5, 20000)).astype(np.float32)
+    mine = np.array([oracle.lib().zlo_f32_to_f16(float(v)) for v in f], np.uint16)
+    assert np.array_equal(mine, f.astype(np.float16).view(np.uint16))
+    for special in (0.0, -0.0, 65504.0, 65519.99, 65520.0, 1e9, 5.96e-8, 2.98e-8, 2.9802322387695312e-08, 6.1e-5):
+        assert oracle.lib().zlo_f64_to_f16(special) == int(np.float64(special).astype(np.float16).view(np.uint16))
+    import torch
+    bf = oracle.f32_to_bf16(f)
+    assert np.array_equal(bf.view(np.int16), torch.from_numpy(f).to(torch.bfloat16).view(torch.int16).numpy())
+
+
+@pytest.mark.parametrize("k,n,g", [(1024, 256, 128), (2048, 64, 64), (1024, 32, 32)])
+def test_k_major_transform_equals_format_definition(oracle, k, n, g):
+    rng = np.random.default_rng(1)
+    qw, qz, sc = synth.gptq_hf(rng, k, n, g)
+    km = oracle.gptq_prepare_k_major(qw, qz, sc, g)
+    w16 = oracle.u2h(oracle.gptq_dequant_k_major(*km))
+    naive = oracle.gptq_dequant_hf_naive(qw, qz, sc, g).astype(np.float16)
+    assert np.array_equal(w16, naive)
+    # exact GEMM equals x @ W^T of the format definition
+    x = synth.act(rng, 3, k)
+    yE = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), *km)
+    assert np.allclose(yE, x.astype(np.float64) @ oracle.gptq_dequant_hf_naive(qw, qz, sc, g).T, rtol=1e-12, atol=1e-12)
+    # the reference-faithful flavour is within its fp16-partial-dot noise of the exact one
+    yR = oracle.u2h(oracle.gptq_gemm_k_major(oracle.h2u(x), *km)).astype(np.float64)
+    rel = np.abs(yR - yE).max() / np.sqrt((yE ** 2).mean())
+    assert rel < 6e-3, rel
+
+
+def test_increase_zero_wraps_and_shuffle_is_a_permutation(oracle):
+    allz = np.arange(0, 2 ** 16, dtype=np.uint32)
+    allz = (allz | (allz << 16)).reshape(256, 256).astype(np.uint32)
+    out = oracle.gptq_increase_zero(allz)
+    for j in range(8):
+        a, b = (allz >> (4 * j)) & 0xF, (out >> (4 * j)) & 0xF
+        assert np.array_equal(b, (a + 1) % 16)
+    rng = np.random.default_rng(2)
+    q = rng.integers(0, 2 ** 32, size=(16, 8), dtype=np.uint64).astype(np.uint32)
+    s = oracle.gptq_shuffle(q)
+    for j in range(4):
+        assert np.array_equal((s >> (4 * j)) & 0xF, (q >> (8 * j)) & 0xF)              # even weights, low half
+        assert np.array_equal((s >> (4 * j + 16)) & 0xF, (q >> (8 * j + 4)) & 0xF)     # odd weights, high half
+
+
+def test_awq_transforms_roundtrip(oracle):
+    rng = np.random.default_rng(3)
+    k, n = 64, 32
+    nib = rng.integers(0, 16, size=(k, n), dtype=np.uint32)
+    order = [0, 4, 1, 5, 2, 6, 3, 7]                      # AWQ nibble order inside a word (utils.cu:33)
+    awq = np.zeros((k, n // 8), np.uint32)
+    for pos, col in enumerate(order):
+        # nibble at bit position 4*col holds logical column `pos`... AWQ: logical column j sits at position order^-1
+        pass
+    # un_shuffle maps nibble positions de = [0,4,1,5,2,6,3,7] -> 0..7
+    for s, src in enumerate(order):
+        awq |= nib[:, s::8] << np.uint32(4 * src)
+    nat = oracle.awq_un_shuffle(awq)
+    for s in range(8):
+        assert np.array_equal((nat >> (4 * s)) & 0xF, nib[:, s::8])
+    g = oracle.awq_shuffle(awq, use_exllama=False)          # (K/8, N): nibble s of word = row 8*kb + s
+    for s in range(8):
+        assert np.array_equal((g >> (4 * s)) & 0xF, nib[s::8, :])
+    ge = oracle.awq_shuffle(awq, use_exllama=True)
+    assert np.array_equal(ge, oracle.gptq_shuffle(g))
+
+
+def test_int8_gemm_is_exact_and_quant_rule(oracle):
+    rng = np.random.default_rng(4)
+    a = rng.integers(-127, 128, (5, 256)).astype(np.int8)
+    b = rng.integers(-127, 128, (7, 256)).astype(np.int8)
+    assert np.array_equal(oracle.int8_gemm_nt(a, b), a.astype(np.int64) @ b.astype(np.int64).T)
+    x = synth.act(rng, 4, 512, 3.0)
+    q, s = oracle.quant_calc_scale(oracle.h2u(x))
+    amax = np.abs(x.astype(np.float32)).max(axis=1)
+    assert np.array_equal(s, amax / np.float32(127.0))
+    assert np.array_equal(q, np.rint(x.astype(np.float32) * (np.float32(127.0) / amax)[:, None]).astype(np.int8))
+    assert np.abs(q).max() == 127
+
+
+def test_attention_oracle_flavours_agree(oracle):
+    rng = np.random.default_rng(5)
+    h, hkv, d = 8, 2, 128
+    lens = [700, 33]
+    kb = [oracle.h2u(rng.standard_normal((L, hkv, d)).astype(np.float16)) for L in lens]
+    vb = [oracle.h2u(rng.standard_normal((L, hkv, d)).astype(np.float16)) for L in lens]
+    q = oracle.h2u(rng.standard_normal((2, 1, h, d)).astype(np.float16))
+    mask = np.concatenate([(rng.random(L) < 0.8).astype(np.int8) for L in lens])
+    mask[0] = mask[700] = 1
+    a = oracle.u2h(oracle.mqa_rag_buffer(q, np.array(lens, np.int32), kb, vb, mask, hkv, 0.088)).astype(np.float64)
+    b = oracle.u2h(oracle.mqa_rag_buffer(q, np.array(lens, np.int32), kb, vb, mask, hkv, 0.088, num_split=4)).astype(np.float64)
+    e = oracle.mqa_rag_buffer(q, np.array(lens, np.int32), kb, vb, mask, hkv, 0.088, exact=True)
+    assert np.abs(a - e).max() < 2e-3 and np.abs(b - e).max() < 2e-3

@@ -6,6 +6,12 @@ so a GPU box can never silently run anything but the HIP path.
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own libamdhip64; it must be the HIP runtime of the process BEFORE our library
+# (linked against the same soname) is dlopen'ed, otherwise two runtimes coexist and torch's streams
+# and allocations are foreign to our launches ("no ROCm-capable device").  torch is the plumbing for
+# device memory and streams on this path, so importing it here is not optional.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libzhilight_amd.so")
 

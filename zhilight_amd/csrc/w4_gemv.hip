@@ -23,6 +23,20 @@
 #include "zl_common.h"
 #include "zl_stage.h"
 
+// ---- optional phase-timestamp probe (build with -DZL_W4_PROBE; tools/ubench/probe_gemv.py) --------
+#ifdef ZL_W4_PROBE
+__device__ unsigned long long* zl_probe_buf = nullptr;  // [waves][8] wall-clock ticks (100 MHz)
+extern "C" int zl_debug_set_probe(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(zl_probe_buf), &p, sizeof(p));
+}
+#define ZL_PROBE(slot)                                                                                 \
+    do {                                                                                                \
+        if (zl_probe_buf && lane == 0) zl_probe_buf[(size_t)(blockIdx.x * 4 + wave) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define ZL_PROBE(slot) do {} while (0)
+#endif
+
 namespace {
 
 
@@ -129,6 +143,7 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
     const int Q = p.q_loads;
 
     float* res = res_all + wave * 64 * MT;
+    ZL_PROBE(0);
     const int gw = blockIdx.x * 4 + wave;
     const int pair0 = gw * p.pairs_per_wave;
     int npairs = p.pairs_total - pair0;
@@ -197,6 +212,7 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    ZL_PROBE(1);
     // ---- (3) activation rows -> LDS (optionally RMS-normalised: LayerNorm::forward semantics,
     // src/nn/layernorm/layernorm.cu:10-42), K padding zeroed
     if constexpr (XL > 0) {
@@ -248,6 +264,7 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
         }
     }
     __syncthreads();
+    ZL_PROBE(2);
 
     // ---- main loop
     float acc[MT];
@@ -310,6 +327,7 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
         for (int s = 0; s < kRing; ++s) consume(s, it + s < total);  // last (possibly partial) ring
     }
 
+    ZL_PROBE(3);
     // ---- epilogue: lane i of the wave finishes row (or gate/up pair) i of the wave's run; stores
     // of consecutive lanes are consecutive fp16 elements.
     const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
@@ -351,6 +369,7 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
             }
         }
     }
+    ZL_PROBE(4);
 }
 
 template <int MT, int kRing, int XL>

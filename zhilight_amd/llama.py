@@ -1,0 +1,330 @@
+"""Host-side mirror of the reference's decode ("search") path for LLaMA-like models:
+`model::LLaMA::encode` -> N x `nn::EncoderLayer::forward` -> `get_logits`
+(src/model/llama.cpp:75-165, src/nn/block/block.cpp:86-143, src/nn/attention/attention.cpp:846-964,
+src/nn/feedforward/feedforward.cpp:113-137), with the per-step device state of
+`model::DynBatchContext` / `RagBufferContext` (src/model/dyn_batch_context.h:29-200,
+src/model/rag_buffer_context.h:141-188).
+
+Only what the decode hot path needs lives here: weight containers, the per-task ragged KV buffers
+with their device pointer tables, and the kernel sequence of one step.  PyTorch supplies device
+memory and the stream; every arithmetic step is one C-ABI launcher from `ops`.
+
+Kernel sequence per layer (7 launches; the reference issues ~14 for the same math):
+  1. w4a16_gemm  [RMSNorm(ln_attn) prologue]  hidden -> fused q|k|v             (project_q/k/v)
+  2. rope_scatter_decode                       rotate q,k (cached cos/sin), k,v -> ragged KV
+  3. decode_attn partial + 4. combine          softmax(q.K^T).V over the task's KV
+  5. w4a16_gemm  [residual epilogue]           attn_out + hidden -> hidden       (attn_out + add)
+  6. w4a16_gemm  [RMSNorm(ln_ff) prologue, silu*mul epilogue]  -> act           (w_in, w_gated, gate_mul)
+  7. w4a16_gemm  [residual epilogue]           w_out + hidden -> hidden
+The roundings are the reference's single-stream path: every linear output, the norm output, the
+rotated q/k, the attention output and each residual sum is rounded to fp16 exactly where the
+reference materialises an fp16 tensor.
+"""
+import math
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+@dataclass
+class ModelConfig:
+    """Subset of model::ModelConfig (src/model/model_config.hpp:27-130) used on this path; key names
+    follow `pydict_to_model_config` (src/py_export/py_model_config.cpp:77-151)."""
+    num_layers: int = 32
+    dim_model: int = 4096
+    num_heads: int = 32
+    dim_head: int = 128
+    dim_ff: int = 14336
+    vocab_size: int = 128256
+    num_kv_heads: int = 8
+    eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_scaling: Optional[dict] = None     # {"rope_type": "llama3", "factor":8, "low_freq_factor":1, ...}
+    activate_fn: str = "silu"
+    scale_emb: float = 1.0
+    dim_model_base: int = 0                 # MiniCPM: logits scale = dim_model_base / dim_model
+    scale_depth: float = -1.0               # MiniCPM residual scale scale_depth / sqrt(num_layers)
+    tie_lm_head: bool = False
+
+    @classmethod
+    def from_hf(cls, cfg: dict):
+        """HF config.json -> ModelConfig (zhilight/config/adapter.py + py_model_config.cpp key names)."""
+        hidden, heads = cfg["hidden_size"], cfg["num_attention_heads"]
+        return cls(
+            num_layers=cfg["num_hidden_layers"], dim_model=hidden, num_heads=heads,
+            dim_head=cfg.get("head_dim", hidden // heads), dim_ff=cfg["intermediate_size"],
+            vocab_size=cfg["vocab_size"], num_kv_heads=cfg.get("num_key_value_heads", heads),
+            eps=cfg.get("rms_norm_eps", 1e-5), rope_theta=cfg.get("rope_theta", 10000.0),
+            rope_scaling=cfg.get("rope_scaling"), activate_fn=cfg.get("hidden_act", "silu"),
+            scale_emb=cfg.get("scale_emb", 1.0), dim_model_base=cfg.get("dim_model_base", 0),
+            scale_depth=cfg.get("scale_depth", -1.0), tie_lm_head=cfg.get("tie_word_embeddings", False))
+
+    @classmethod
+    def llama3_8b(cls):
+        return cls()
+
+
+@dataclass
+class QuantConfig:
+    """model::QuantConfig (src/model/model_config.hpp:132-177); quant_type 5 = GPTQ W4A16 k-major."""
+    quant_type: int = 5
+    group_size: int = 128
+    sym: bool = False
+    act_order: bool = False
+
+    @classmethod
+    def from_hf(cls, qc: dict):
+        """QuantConfig.adapt_hf_config (zhilight/quant.py:35-80): gptq -> type 5."""
+        if qc.get("quant_method", "gptq") != "gptq" or qc.get("bits", 4) != 4:
+            raise ops.ZLError("only GPTQ 4-bit checkpoints are supported on this path")
+        if qc.get("desc_act", False):
+            raise ops.ZLError("desc_act (act-order) checkpoints need the legacy exllama path: not implemented")
+        return cls(5, qc.get("group_size", 128), qc.get("sym", False), False)
+
+
+def hf_name_to_internal(name: str) -> str:
+    """LLaMALoader._replace_name (zhilight/loader.py:250-358), LLaMA/GPTQ subset."""
+    s = name
+    s = re.sub(r"model\.embed_tokens\.weight", "token_embedding.weight", s)
+    s = re.sub(r"model\.norm\.weight", "output_layernorm.weight", s)
+    s = re.sub(r"model\.layers\.([0-9]+)\.input_layernorm\.", r"layers.\1.ln_attn.", s)
+    s = re.sub(r"model\.layers\.([0-9]+)\.post_attention_layernorm\.weight", r"layers.\1.ln_ff.weight", s)
+    s = re.sub(r"model\.layers\.([0-9]+)\.self_attn\.([qkv])_proj\.", r"layers.\1.attn.project_\2.", s)
+    s = re.sub(r"model\.layers\.([0-9]+)\.self_attn\.o_proj\.", r"layers.\1.attn.attn_out.", s)
+    s = re.sub(r"model\.layers\.([0-9]+)\.mlp\.gate_proj\.", r"layers.\1.ff.w_in.", s)
+    s = re.sub(r"model\.layers\.([0-9]+)\.mlp\.up_proj\.", r"layers.\1.ff.w_gated.", s)
+    s = re.sub(r"model\.layers\.([0-9]+)\.mlp\.down_proj\.", r"layers.\1.ff.w_out.", s)
+    return "llama." + s
+
+
+def _dev_t(a, device, dtype=None):
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    t = t.to(device).contiguous()
+    return t if dtype is None else t.view(dtype)
+
+
+class Int4GPTQ:
+    """nn::Linear with the Int4GPTQ implementation (src/nn/linear/linear.cpp:638-1244): holds the
+    load-time-transformed weight; `fuse` mirrors Linear::fuse / fuse3 (row concatenation)."""
+
+    def __init__(self, name, dim_in, dim_out, quant: QuantConfig):
+        self.name, self.dim_in, self.dim_out, self.quant = name, dim_in, dim_out, quant
+        self.km = None      # k-major (qweight, qzeros, scales) device tensors until packed
+        self.weight: Optional[ops.W4Weight] = None
+        self.bias = None
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str, device):
+        qw = _dev_t(sd[prefix + ".qweight"], device, torch.int32)
+        qz = _dev_t(sd[prefix + ".qzeros"], device, torch.int32)
+        sc = _dev_t(sd[prefix + ".scales"], device, torch.float16)
+        if qw.shape != (self.dim_in // 8, self.dim_out):
+            raise ops.ZLError(f"{prefix}: qweight shape {tuple(qw.shape)} != {(self.dim_in // 8, self.dim_out)}")
+        # Int4GPTQ::preprocess_weight + transpose_weight: shuffle, +1 zeros, nibble->byte, transposes
+        qw = ops.transpose_2d(ops.gptq_shuffle(qw.clone()))
+        qz = ops.transpose_2d(ops.q4_to_q8(ops.increase_zero(qz.clone())))
+        self.km = (qw, qz, ops.transpose_2d(sc))
+        if prefix + ".bias" in sd:
+            self.bias = _dev_t(sd[prefix + ".bias"], device, torch.float16)
+
+    @staticmethod
+    def fuse(name, parts: List["Int4GPTQ"], row_interleave=False):
+        out = Int4GPTQ(name, parts[0].dim_in, sum(p.dim_out for p in parts), parts[0].quant)
+        out.km = tuple(torch.cat([p.km[i] for p in parts], dim=0).contiguous() for i in range(3))
+        if any(p.bias is not None for p in parts):
+            out.bias = torch.cat([p.bias if p.bias is not None else
+                                  torch.zeros(p.dim_out, dtype=torch.float16, device=out.km[0].device) for p in parts])
+        out.pack(row_interleave)
+        return out
+
+    def pack(self, row_interleave=False):
+        self.weight = ops.W4Weight.from_k_major(*self.km, self.quant.group_size, self.quant.sym, row_interleave)
+        if row_interleave and self.bias is not None:
+            half = self.dim_out // 2
+            self.bias = torch.stack([self.bias[:half], self.bias[half:]], dim=1).reshape(-1).contiguous()
+        self.km = None
+        return self
+
+    def forward(self, x, **kw):
+        return ops.w4a16_gemm(x, self.weight, bias=self.bias, **kw)
+
+
+class EncoderLayer:
+    """nn::EncoderLayer (src/nn/block/block.h:15-63): ln_attn, attn{project_q,k,v,attn_out}, ln_ff,
+    ff{w_in,w_gated,w_out}; q/k/v and w_in/w_gated are fused at load (CPM_FUSE_QKV / CPM_FUSE_FF_IN)."""
+
+    def __init__(self, cfg: ModelConfig, quant: QuantConfig, idx: int):
+        self.cfg, self.quant, self.idx = cfg, quant, idx
+        self.ln_attn = self.ln_ff = None
+        self.qkv = self.attn_out = self.w_in_gated = self.w_out = None
+
+    def load_state_dict(self, sd, prefix, device):
+        c, q = self.cfg, self.quant
+        hd = c.num_heads * c.dim_head
+        kvd = c.num_kv_heads * c.dim_head
+        self.ln_attn = _dev_t(sd[prefix + ".ln_attn.weight"], device, torch.float16)
+        self.ln_ff = _dev_t(sd[prefix + ".ln_ff.weight"], device, torch.float16)
+
+        def lin(sub, din, dout):
+            l = Int4GPTQ(prefix + "." + sub, din, dout, q)
+            l.load_state_dict(sd, prefix + "." + sub, device)
+            return l
+        self.qkv = Int4GPTQ.fuse(prefix + ".attn.project_qkv",
+                                 [lin("attn.project_q", c.dim_model, hd), lin("attn.project_k", c.dim_model, kvd),
+                                  lin("attn.project_v", c.dim_model, kvd)])
+        self.attn_out = lin("attn.attn_out", hd, c.dim_model).pack()
+        self.w_in_gated = Int4GPTQ.fuse(prefix + ".ff.w_in_gated",
+                                        [lin("ff.w_in", c.dim_model, c.dim_ff), lin("ff.w_gated", c.dim_model, c.dim_ff)],
+                                        row_interleave=True)
+        self.w_out = lin("ff.w_out", c.dim_ff, c.dim_model).pack()
+
+    def init_random(self, device, gen):
+        """Synthetic weights of the right shapes, generated directly in the packed layout."""
+        c, q = self.cfg, self.quant
+        hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
+        self.ln_attn = (1.0 + 0.05 * torch.randn(c.dim_model, device=device, generator=gen)).to(torch.float16)
+        self.ln_ff = (1.0 + 0.05 * torch.randn(c.dim_model, device=device, generator=gen)).to(torch.float16)
+
+        def rnd(name, din, dout, interleave=False):
+            l = Int4GPTQ(name, din, dout, q)
+            L = ops.W4Weight.layout(dout, din, q.group_size)
+            qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (L.qw_bytes // 4,), dtype=torch.int32, device=device, generator=gen)
+            sc = (torch.rand(L.scales_bytes // 2, device=device, generator=gen) * (1.0 / math.sqrt(din) / 4.0) + 1e-4).to(torch.float16)
+            zs = torch.randint(-2 ** 15, 2 ** 15 - 1, (L.zeros_bytes // 2,), dtype=torch.int16, device=device, generator=gen)
+            l.weight = ops.W4Weight(dout, din, q.group_size, qw, sc, zs, q.sym, interleave)
+            return l
+        self.qkv = rnd("qkv", c.dim_model, hd + 2 * kvd)
+        self.attn_out = rnd("attn_out", hd, c.dim_model)
+        self.w_in_gated = rnd("w_in_gated", c.dim_model, 2 * c.dim_ff, True)
+        self.w_out = rnd("w_out", c.dim_ff, c.dim_model)
+
+    def weight_bytes(self):
+        return sum(l.weight.nbytes() for l in (self.qkv, self.attn_out, self.w_in_gated, self.w_out))
+
+
+@dataclass
+class DynBatchContext:
+    """Per-step device state of a decode batch (model::DynBatchContext s_token / s_position /
+    s_placement / s_len_buf, src/model/dyn_batch_context.h:29-200) + the RagBufferContext tables."""
+    tokens: torch.Tensor        # (B) int32
+    positions: torch.Tensor     # (B) int32
+    placement: torch.Tensor     # (B) int32   slot of the new token in the task's KV buffer
+    buf_lens: torch.Tensor      # (B) int32   allocated length of each task's buffer
+    valid_lens: torch.Tensor    # (B) int32   visible keys = position + 1 (greedy / sampling decode)
+    k_addrs: torch.Tensor       # (num_layers, B) int64 raw pointers
+    v_addrs: torch.Tensor
+    max_len_buf: int
+    kv: List[torch.Tensor] = field(default_factory=list)  # owners: per task (layers, 2, len_buf, Hkv, D)
+
+
+class LLaMA:
+    """model::LLaMA (src/model/llama.cpp:11-165) restricted to the dynamic-batch decode step."""
+
+    def __init__(self, cfg: ModelConfig, quant: QuantConfig, device="cuda:0"):
+        if cfg.scale_depth > 0:
+            raise ops.ZLError("scale_depth (MiniCPM residual scaling) is not wired into the fused epilogues yet")
+        self.cfg, self.quant, self.device = cfg, quant, torch.device(device)
+        self.layers = [EncoderLayer(cfg, quant, i) for i in range(cfg.num_layers)]
+        self.token_embedding = self.output_layernorm = self.lm_head = None
+        self._bufs = {}
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], hf_names=True):
+        sd = {hf_name_to_internal(k) if hf_names else k: v for k, v in state_dict.items()}
+        dev = self.device
+        self.token_embedding = _dev_t(sd["llama.token_embedding.weight"], dev, torch.float16)
+        self.output_layernorm = _dev_t(sd["llama.output_layernorm.weight"], dev, torch.float16)
+        self.lm_head = self.token_embedding if self.cfg.tie_lm_head else _dev_t(sd["llama.lm_head.weight"], dev, torch.float16)
+        for i, layer in enumerate(self.layers):
+            layer.load_state_dict(sd, f"llama.layers.{i}", dev)
+        return self
+
+    def init_random(self, seed=0):
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        c, dev = self.cfg, self.device
+        self.token_embedding = (torch.randn(c.vocab_size, c.dim_model, device=dev, generator=gen) * 0.5).to(torch.float16)
+        self.output_layernorm = torch.ones(c.dim_model, dtype=torch.float16, device=dev)
+        self.lm_head = (torch.randn(c.vocab_size, c.dim_model, device=dev, generator=gen) * 0.02).to(torch.float16)
+        for layer in self.layers:
+            layer.init_random(dev, gen)
+        return self
+
+    # ---- KV state ------------------------------------------------------------------------------
+    def new_context(self, batch: int, len_buf: int, start_pos: int, fill_random=False) -> DynBatchContext:
+        """`batch` tasks whose first `start_pos` tokens are already in the KV buffers (zero- or
+        random-filled here: the reference zero-fills, src/kvcache/transformer_buffer.cu:290-330)."""
+        c, dev = self.cfg, self.device
+        kv = []
+        for _ in range(batch):
+            shape = (c.num_layers, 2, len_buf, c.num_kv_heads, c.dim_head)
+            t = torch.randn(shape, dtype=torch.float16, device=dev) if fill_random else torch.zeros(shape, dtype=torch.float16, device=dev)
+            kv.append(t)
+        k_addrs = torch.tensor([[t[l, 0].data_ptr() for t in kv] for l in range(c.num_layers)], dtype=torch.int64, device=dev)
+        v_addrs = torch.tensor([[t[l, 1].data_ptr() for t in kv] for l in range(c.num_layers)], dtype=torch.int64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        return DynBatchContext(
+            tokens=torch.zeros(batch, **i32), positions=torch.full((batch,), start_pos, **i32),
+            placement=torch.full((batch,), start_pos, **i32), buf_lens=torch.full((batch,), len_buf, **i32),
+            valid_lens=torch.full((batch,), start_pos + 1, **i32), k_addrs=k_addrs, v_addrs=v_addrs,
+            max_len_buf=len_buf, kv=kv)
+
+    def _buffers(self, b):
+        if b not in self._bufs:
+            c, dev = self.cfg, self.device
+            f16 = dict(dtype=torch.float16, device=dev)
+            hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
+            self._bufs[b] = dict(
+                hidden=torch.empty(b, c.dim_model, **f16), qkv=torch.empty(b, hd + 2 * kvd, **f16),
+                q=torch.empty(b, hd, **f16), attn=torch.empty(b, hd, **f16), act=torch.empty(b, c.dim_ff, **f16),
+                logits=torch.empty(b, c.vocab_size, **f16))
+        return self._bufs[b]
+
+    # ---- one decode step -----------------------------------------------------------------------
+    def encode(self, ctx: DynBatchContext, workspace=None):
+        """LLaMA::encode for a pure decode ("search") batch: returns logits (B, vocab) fp16."""
+        c = self.cfg
+        b = ctx.tokens.numel()
+        bufs = self._buffers(b)
+        if workspace is None:
+            workspace = self._bufs.setdefault(("ws", b, ctx.max_len_buf),
+                                              ops.decode_attn_workspace(b, 1, c.num_heads, c.dim_head, ctx.max_len_buf, self.device))
+        llama3 = None
+        rs = c.rope_scaling
+        if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+            llama3 = (rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"])
+        hidden = ops.embedding(ctx.tokens, self.token_embedding, c.scale_emb)      # token_embedding
+        cos, sin = ops.rope_cos_sin(ctx.positions, c.dim_head, c.rope_theta, True, llama3)  # RopePreparer
+        scale = 1.0 / math.sqrt(c.dim_head)
+        for li, layer in enumerate(self.layers):
+            ops.w4a16_gemm(hidden, layer.qkv.weight, bias=layer.qkv.bias, out=bufs["qkv"],
+                           norm_weight=layer.ln_attn, norm_eps=c.eps)
+            ops.rope_scatter_decode(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li],
+                                    c.num_heads, c.num_kv_heads, c.dim_head, q_out=bufs["q"])
+            ops.multi_query_attention_rag_buffer(
+                bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li], None, scale,
+                ctx.max_len_buf, c.num_kv_heads, valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
+                workspace=workspace)
+            ops.w4a16_gemm(bufs["attn"], layer.attn_out.weight, bias=layer.attn_out.bias, residual=hidden, out=hidden,
+                           epilogue=ops.EPI_RESIDUAL)
+            ops.w4a16_gemm(hidden, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, out=bufs["act"],
+                           norm_weight=layer.ln_ff, norm_eps=c.eps, epilogue=ops.EPI_SILU_MUL)
+            ops.w4a16_gemm(bufs["act"], layer.w_out.weight, bias=layer.w_out.bias, residual=hidden, out=hidden,
+                           epilogue=ops.EPI_RESIDUAL)
+        alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
+        return ops.gemm_nt_small_m(hidden, self.lm_head, alpha=alpha, out=bufs["logits"],
+                                   norm_weight=self.output_layernorm, norm_eps=c.eps)
+
+    def advance(self, ctx: DynBatchContext, next_tokens: torch.Tensor):
+        """Device-side bookkeeping between steps (what fill_search_tokens does on the host in the
+        reference, src/generator/batch_generator.cpp:1226-1335): no host sync, graph-capturable."""
+        ctx.tokens.copy_(next_tokens.to(torch.int32))
+        ctx.positions.add_(1)
+        ctx.placement.add_(1)
+        ctx.valid_lens.add_(1)
+
+    def weight_bytes(self):
+        return sum(l.weight_bytes() for l in self.layers)
