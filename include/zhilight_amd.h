@@ -191,6 +191,17 @@ int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* c
                    uint16_t* out, void* workspace, int64_t b, int64_t len_q, int64_t h, int64_t hkv,
                    int64_t d, float scale, int64_t max_len_buf, int bshd, int dtype, zl_stream_t s);
 
+/* Fused decode attention front end (len_q == 1 per task, prefix visibility): rope_qk_cache +
+ * copy_to_rag_buffer2 + multi_query_attention_rag_buffer in one pass over the fused qkv rows
+ * (B, (H + 2 Hkv) D).  q and the new k are rotated with the cached cos/sin (one rounding to T, as the
+ * unfused kernels do), the new k/v row is stored at placement[b] by the workgroup whose KV split owns
+ * that slot and consumed from registers, so results equal the three-kernel sequence. */
+int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* qkv, const int32_t* placement,
+                         const int32_t* buf_lens, const int32_t* valid_lens, uint16_t* const* k_bufs,
+                         uint16_t* const* v_bufs, uint16_t* out, void* workspace, int64_t b, int64_t h,
+                         int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int neox, int bshd, int dtype,
+                         zl_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * a18  Element-wise.  Replaces nn::element_add_scale_out (src/nn/block/block_kernel.cu:19-50) and
  * nn::gate_mul_inplace (src/nn/linear/activation_kernel.cu:82-106; act 0 = silu, 1 = gelu).

@@ -290,3 +290,40 @@ def test_int8_path_bit_exact(oracle, dev, dtype):
     assert np.allclose(_np(gs2), rs2, rtol=3e-7, atol=0)   # scale carries the block-sum association
     ulp = synth.ulp_diff_f16(_bits(go), ro)
     assert ulp.max() <= 1 and (ulp > 0).mean() < 0.02
+
+
+@pytest.mark.parametrize("neox", [True, False])
+@pytest.mark.parametrize("bshd", [True, False])
+def test_decode_attention_fused_equals_three_kernel_sequence(oracle, dev, neox, bshd):
+    """zl_decode_attn_fused == rope_qk_cache + copy_to_rag_buffer2 + multi_query_attention_rag_buffer:
+    KV buffers bit-identical, attention output within the attention bar (same rounded q/k/v feed it)."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(11)
+    h, hkv, d, b = 32, 8, 128, 5
+    lens = [1088, 192, 64, 256, 128]
+    pos = np.array([1024, 150, 0, 255, 127], np.int32)     # incl. first token and last slot of a buffer
+    kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, bshd, dev, oracle=oracle)
+    kb2, vb2 = [a.copy() for a in kb], [a.copy() for a in vb]
+    dk2, dv2 = [t.clone() for t in dk], [t.clone() for t in dv]
+    qkv = synth.act(rng, b, (h + 2 * hkv) * d)
+    cs, sn = oracle.rope_cos_sin(pos, d, 5e5, neox, (8.0, 1.0, 4.0, 8192.0))
+    lens_np, valid = np.array(lens, np.int32), (pos + 1).astype(np.int32)
+    # oracle: three steps
+    rq, rk, rv = oracle.rope_qk_cache(cs, sn, oracle.h2u(qkv), h, hkv, d, neox)
+    oracle.copy_to_rag_buffer2(pos.reshape(b, 1), lens_np, rk.reshape(b, 1, hkv, d), rv.reshape(b, 1, hkv, d), kb, vb, bshd)
+    mask = np.concatenate([(np.arange(L) < v).astype(np.int8) for L, v in zip(lens, valid)])
+    exact = oracle.mqa_rag_buffer(rq.reshape(b, 1, h, d), lens_np, kb, vb, mask, hkv, 0.088, bshd, exact=True).reshape(b, -1)
+    # device: fused
+    got = ops.decode_attention_fused(_t(cs, dev), _t(sn, dev), _t(qkv, dev), _t(pos, dev), _t(lens_np, dev), _t(valid, dev),
+                                     ops.make_ptr_table(dk), ops.make_ptr_table(dv), h, hkv, d, 0.088, max(lens), neox, bshd)
+    for i in range(b):
+        assert np.array_equal(_bits(dk[i]), kb[i]) and np.array_equal(_bits(dv[i]), vb[i])
+    g = _np(got).astype(np.float64)
+    assert np.abs(g - exact).max() < 1e-3 * max(1.0, np.abs(exact).max())
+    # device: unfused sequence on fresh copies gives the same output up to the split association
+    gq = ops.rope_scatter_decode(_t(cs, dev), _t(sn, dev), _t(qkv, dev), _t(pos, dev), _t(lens_np, dev),
+                                 ops.make_ptr_table(dk2), ops.make_ptr_table(dv2), h, hkv, d, neox, bshd)
+    ref = ops.multi_query_attention_rag_buffer(gq.view(b, 1, h, d), _t(lens_np, dev), ops.make_ptr_table(dk2),
+                                               ops.make_ptr_table(dv2), None, 0.088, max(lens), hkv,
+                                               valid_lens=_t(valid, dev), bshd=bshd)
+    assert np.array_equal(_bits(got), _bits(ref.view(b, -1)))

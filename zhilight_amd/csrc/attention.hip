@@ -38,6 +38,14 @@ struct AttnParams {
     int passes, split_len, max_splits;
     float scale;
     int bshd;
+    // fused decode front end (FUSE): q/k/v come from the fused qkv rows and are rotated in-kernel
+    const uint16_t* qkv;        // (B, (H + 2 Hkv) * D)
+    const float* cosv;          // (B, D)
+    const float* sinv;
+    const int32_t* placement;   // (B) slot of the new token in its task's buffers
+    uint16_t* const* k_bufs_w;  // writable views of k_bufs / v_bufs
+    uint16_t* const* v_bufs_w;
+    int neox;
 };
 
 typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
@@ -78,7 +86,60 @@ __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
     }
 }
 
-template <int DT, int D, int RT>
+// rotate 8 consecutive head-dim elements (a) with their rotation partners (b): one rounding to T,
+// same fp32 expression as rope_one_value (src/nn/position/rope_common.cuh:14-34)
+template <int DT>
+__device__ __forceinline__ uint4 rope8(const uint4& a, const uint4& b, const float* c, const float* s, int d0, int half,
+                                       int neox) {
+    float af[8], bf[8];
+    unpack8<DT>(a, af);
+    unpack8<DT>(b, bf);
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        float r[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = e + t;
+            bool minus;
+            float partner;
+            if (neox) {
+                minus = (d0 + i) < half;
+                partner = bf[i];
+            } else {
+                minus = (i & 1) == 0;
+                partner = af[i ^ 1];
+            }
+            r[t] = minus ? __builtin_fmaf(-partner, s[i], af[i] * c[i]) : __builtin_fmaf(partner, s[i], af[i] * c[i]);
+        }
+        o[e / 2] = (uint32_t)ZT<DT>::from_f32(r[0]) | ((uint32_t)ZT<DT>::from_f32(r[1]) << 16);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// sum over the LPK lanes that share a key row, result in every one of them.  DPP only (VALU, no LDS
+// crossbar): xor 1 / xor 2 by quad_perm, then row_half_mirror (quad pairs) and row_mirror (halves of the
+// 16-lane row); a key row wider than one DPP row (D = 256) needs one real cross-row shuffle.
+template <int LPK>
+__device__ __forceinline__ float key_row_sum(float v) {
+#ifdef ZL_ATTN_NO_DPP
+#pragma unroll
+    for (int off = LPK / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+#endif
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    if (LPK >= 8)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+    if (LPK >= 16)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+    if (LPK >= 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+// MASKED = false: prefix visibility (valid_lens), the decode fast path -- no per-key visibility work at all
+// because the split range is already clipped to the visible prefix.
+template <int DT, int D, int RT, bool FUSE, bool MASKED>
 __global__ __launch_bounds__(256) void k_decode_attn_partial(const AttnParams p) {
     constexpr int LPK = D / 8;       // lanes per key row
     constexpr int KPS = 64 / LPK;    // keys per wave-step
@@ -87,37 +148,93 @@ __global__ __launch_bounds__(256) void k_decode_attn_partial(const AttnParams p)
 
     const int b = blockIdx.z / p.passes, pass = blockIdx.z % p.passes;
     const int hk = blockIdx.y, split = blockIdx.x;
+    // all scalar inputs are fetched before the first use so the dependent-load chain is one level deep
     const int len = p.buf_lens[b];
+    const int vlen_in = MASKED ? 0x7fffffff : p.valid_lens[b];
+    const uint16_t* kbase = p.k_bufs[b];
+    const uint16_t* vbase = p.v_bufs[b];
+    const int place = FUSE ? p.placement[b] : -1;
+    const int elen = MASKED ? len : min(len, vlen_in);
     const int t0 = split * p.split_len;
-    if (t0 >= len) return;
-    const int t1 = min(len, t0 + p.split_len);
+    // FUSE: the workgroup whose split covers the new token's slot must store it even if that slot is
+    // not (yet) visible, so it may not leave before the store below
+    const bool owns_new = FUSE && place >= t0 && place < t0 + p.split_len && place < len;
+    if (t0 >= elen && !owns_new) return;
+    const int t1 = min(elen, t0 + p.split_len);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPK, dp = lane % LPK;
-
-    const uint16_t* kbase = p.k_bufs[b];
-    const uint16_t* vbase = p.v_bufs[b];
     const size_t kv_stride = p.bshd ? (size_t)p.hkv * D : (size_t)D;
     const size_t kv_off = (p.bshd ? (size_t)hk * D : (size_t)hk * len * D) + dp * 8;
 
+    // ---- first KV chunk of this wave: issued before anything else (batch-1 decode is a latency chain).
+    // Addresses are clamped into the buffer, so the loads need no branch even for a wave without work.
+    uint4 kk[kSteps], vv[kSteps];
+    int c0 = t0 + wave * CHUNK;
+    const int last_key = t1 > 0 ? t1 - 1 : 0;
+#define ZL_LOAD_CHUNK(base)                                                                      \
+    _Pragma("unroll") for (int st = 0; st < kSteps; ++st) {                                      \
+        const int key_ = (base) + st * KPS + grp;                                                \
+        const int kc_ = key_ < last_key ? key_ : last_key;                                       \
+        kk[st] = *reinterpret_cast<const uint4*>(kbase + kv_off + (size_t)kc_ * kv_stride);     \
+        vv[st] = *reinterpret_cast<const uint4*>(vbase + kv_off + (size_t)kc_ * kv_stride);     \
+    }
+    if (len <= 0) return;
+    ZL_LOAD_CHUNK(c0)
+
     size_t mask_off = 0;
-    if (p.mask) {
+    if (MASKED) {
         for (int i = 0; i < b; ++i) mask_off += (size_t)p.buf_lens[i];
         mask_off *= p.len_q;
     }
-    const int vlen = p.valid_lens ? p.valid_lens[b] : len;
 
     uint4 qv[RT];
     int q_of_row[RT];
+    uint4 k_new = make_uint4(0, 0, 0, 0), v_new = make_uint4(0, 0, 0, 0);
+    if constexpr (FUSE) {
+        // q rows, the new k row and the new v row of this kv head straight from the fused qkv vector
+        constexpr int half = D / 2;
+        const int d0 = dp * 8;
+        const int pd0 = p.neox ? (d0 < half ? d0 + half : d0 - half) : d0;
+        float c[8], sn[8];
+        const float4* cp = reinterpret_cast<const float4*>(p.cosv + (size_t)b * D + d0);
+        const float4* sp = reinterpret_cast<const float4*>(p.sinv + (size_t)b * D + d0);
+        const float4 c0v = cp[0], c1v = cp[1], s0v = sp[0], s1v = sp[1];
+        c[0] = c0v.x; c[1] = c0v.y; c[2] = c0v.z; c[3] = c0v.w; c[4] = c1v.x; c[5] = c1v.y; c[6] = c1v.z; c[7] = c1v.w;
+        sn[0] = s0v.x; sn[1] = s0v.y; sn[2] = s0v.z; sn[3] = s0v.w; sn[4] = s1v.x; sn[5] = s1v.y; sn[6] = s1v.z; sn[7] = s1v.w;
+        const uint16_t* row = p.qkv + (size_t)b * (p.h + 2 * p.hkv) * D;
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const int rr = pass * RT + i;
-        qv[i] = make_uint4(0, 0, 0, 0);
-        q_of_row[i] = 0;
-        if (rr < p.rows) {
-            const int qi = rr / p.n_rep, head = hk * p.n_rep + rr % p.n_rep;
-            q_of_row[i] = qi;
-            qv[i] = *reinterpret_cast<const uint4*>(p.q + (((size_t)b * p.len_q + qi) * p.h + head) * D + dp * 8);
+        for (int i = 0; i < RT; ++i) {
+            qv[i] = make_uint4(0, 0, 0, 0);
+            q_of_row[i] = 0;
+            const int rr = pass * RT + i;
+            if (rr < p.rows) {
+                const uint16_t* src = row + (size_t)(hk * p.n_rep + rr) * D;
+                qv[i] = rope8<DT>(*reinterpret_cast<const uint4*>(src + d0), *reinterpret_cast<const uint4*>(src + pd0), c, sn,
+                                  d0, half, p.neox);
+            }
+        }
+        const uint16_t* ksrc = row + (size_t)(p.h + hk) * D;
+        k_new = rope8<DT>(*reinterpret_cast<const uint4*>(ksrc + d0), *reinterpret_cast<const uint4*>(ksrc + pd0), c, sn, d0,
+                          half, p.neox);
+        v_new = *reinterpret_cast<const uint4*>(row + (size_t)(p.h + p.hkv + hk) * D + d0);
+        // the workgroup whose split owns the new token's slot stores the row (copy_to_rag_buffer2 semantics)
+        if (owns_new && pass == 0 && wave == 0 && grp == 0) {
+            *reinterpret_cast<uint4*>(p.k_bufs_w[b] + kv_off + (size_t)place * kv_stride) = k_new;
+            *reinterpret_cast<uint4*>(p.v_bufs_w[b] + kv_off + (size_t)place * kv_stride) = v_new;
+        }
+        if (t0 >= elen) return;  // wave-uniform: nothing visible in this split
+    } else {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int rr = pass * RT + i;
+            qv[i] = make_uint4(0, 0, 0, 0);
+            q_of_row[i] = 0;
+            if (rr < p.rows) {
+                const int qi = rr / p.n_rep, head = hk * p.n_rep + rr % p.n_rep;
+                q_of_row[i] = qi;
+                qv[i] = *reinterpret_cast<const uint4*>(p.q + (((size_t)b * p.len_q + qi) * p.h + head) * D + dp * 8);
+            }
         }
     }
 
@@ -130,34 +247,26 @@ __global__ __launch_bounds__(256) void k_decode_attn_partial(const AttnParams p)
         for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
     }
 
-    for (int c0 = t0 + wave * CHUNK; c0 < t1; c0 += 4 * CHUNK) {
-        uint4 kk[kSteps], vv[kSteps];
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) {
-            const int key = c0 + st * KPS + grp;
-            kk[st] = make_uint4(0, 0, 0, 0);
-            vv[st] = make_uint4(0, 0, 0, 0);
-            if (key < t1) {
-                kk[st] = *reinterpret_cast<const uint4*>(kbase + kv_off + (size_t)key * kv_stride);
-                vv[st] = *reinterpret_cast<const uint4*>(vbase + kv_off + (size_t)key * kv_stride);
-            }
-        }
+    while (c0 < t1) {
         float sc[RT][kSteps];
-        bool vis_any[kSteps];
 #pragma unroll
         for (int st = 0; st < kSteps; ++st) {
             const int key = c0 + st * KPS + grp;
-            vis_any[st] = false;
+            if (FUSE && key == place) {  // the row written by this launch: take it from registers
+                kk[st] = k_new;
+                vv[st] = v_new;
+            }
+            const bool inb = key < t1;
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                float d = dot8<DT>(qv[i], kk[st]);
-#pragma unroll
-                for (int off = LPK / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-                bool vis = key < t1;
-                if (vis) vis = p.mask ? (p.mask[mask_off + (size_t)q_of_row[i] * len + key] != 0) : (key < vlen);
-                vis_any[st] = vis_any[st] || vis;
+                const float d = key_row_sum<LPK>(dot8<DT>(qv[i], kk[st]));
+                bool vis = inb;
+                if (MASKED) {
+                    if (vis) vis = p.mask[mask_off + (size_t)q_of_row[i] * len + key] != 0;
+                }
                 sc[i][st] = vis ? d * p.scale : -INFINITY;
             }
+            if (!inb) vv[st] = make_uint4(0, 0, 0, 0);  // clamped duplicate: contributes p = 0, keep it finite
         }
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
@@ -175,9 +284,15 @@ __global__ __launch_bounds__(256) void k_decode_attn_partial(const AttnParams p)
         for (int st = 0; st < kSteps; ++st) {
             float vf[8];
             unpack8<DT>(vv[st], vf);
-            if (!vis_any[st]) {
+            if (MASKED) {
+                // a key no query row sees must not leak a (possibly non-finite) V row: p = 0 times inf is NaN
+                bool any = false;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) vf[e] = 0.f;  // never let an unseen (possibly garbage) V row in
+                for (int i = 0; i < RT; ++i) any = any || (sc[i][st] != -INFINITY);
+                if (!any) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vf[e] = 0.f;
+                }
             }
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
@@ -187,7 +302,11 @@ __global__ __launch_bounds__(256) void k_decode_attn_partial(const AttnParams p)
                 for (int e = 0; e < 8; ++e) acc[i][e] = __builtin_fmaf(pr, vf[e], acc[i][e]);
             }
         }
+        c0 += 4 * CHUNK;
+        if (c0 >= t1) break;
+        ZL_LOAD_CHUNK(c0)
     }
+#undef ZL_LOAD_CHUNK
 
     // ---- merge the KPS lane-groups of the wave
 #pragma unroll
@@ -243,36 +362,63 @@ __global__ __launch_bounds__(256) void k_decode_attn_partial(const AttnParams p)
     }
 }
 
-// grid (B*len_q*H), block D
+// grid (B*len_q*H), block D.  Split statistics go through LDS once; the per-d accumulation then issues
+// independent loads back to back (the first version walked the splits with dependent loads: 6 us).
 template <int DT, int D>
 __global__ void k_decode_attn_combine(const AttnParams p) {
+    constexpr int kMaxS = 512;
+    __shared__ float sf[kMaxS];
+    __shared__ float red[16];
     const int vh = blockIdx.x;
     const int b = vh / (p.len_q * p.h);
     const int len = p.buf_lens[b];
-    const int ns = (len + p.split_len - 1) / p.split_len;
+    const int vlen_in = p.valid_lens ? p.valid_lens[b] : 0x7fffffff;
+    const int elen = p.mask ? len : min(len, vlen_in);
+    const int ns = min((elen + p.split_len - 1) / p.split_len, kMaxS);
     const int d = threadIdx.x;
     const float* src = p.ws + (size_t)vh * p.max_splits * (D + 2);
-    float mn = -1e20f;
-    for (int s = 0; s < ns; ++s) mn = fmaxf(mn, src[(size_t)s * (D + 2) + D]);
-    float a = 0.f, z = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        const float f = __expf(src[(size_t)s * (D + 2) + D] - mn);
-        a = __builtin_fmaf(src[(size_t)s * (D + 2) + d], f, a);
-        z = __builtin_fmaf(src[(size_t)s * (D + 2) + D + 1], f, z);
+    float mloc = -1e20f;
+    for (int s = d; s < ns; s += D) {
+        const float ms = src[(size_t)s * (D + 2) + D];
+        sf[s] = ms;
+        mloc = fmaxf(mloc, ms);
     }
+    const float mn = zl_block_max(mloc, red);
+    float zloc = 0.f;
+    for (int s = d; s < ns; s += D) {
+        const float f = __expf(sf[s] - mn);
+        sf[s] = f;
+        zloc = __builtin_fmaf(src[(size_t)s * (D + 2) + D + 1], f, zloc);
+    }
+    const float z = zl_block_sum(zloc, red);  // also orders the sf[] writes before the reads below
+    float a = 0.f;
+    int s = 0;
+    for (; s + 4 <= ns; s += 4) {
+        const float v0 = src[(size_t)(s + 0) * (D + 2) + d], v1 = src[(size_t)(s + 1) * (D + 2) + d];
+        const float v2 = src[(size_t)(s + 2) * (D + 2) + d], v3 = src[(size_t)(s + 3) * (D + 2) + d];
+        a = __builtin_fmaf(v0, sf[s], a);
+        a = __builtin_fmaf(v1, sf[s + 1], a);
+        a = __builtin_fmaf(v2, sf[s + 2], a);
+        a = __builtin_fmaf(v3, sf[s + 3], a);
+    }
+    for (; s < ns; ++s) a = __builtin_fmaf(src[(size_t)s * (D + 2) + d], sf[s], a);
     p.out[(size_t)vh * D + d] = ZT<DT>::from_f32(a / (z + 1e-20f));
 }
 
-template <int DT, int D>
+template <int DT, int D, bool FUSE>
 int launch_d(const AttnParams& p, hipStream_t st) {
     dim3 grid((unsigned)p.max_splits, (unsigned)p.hkv, (unsigned)(p.b * p.passes));
     const int rt = p.rows >= 8 ? 8 : (p.rows >= 4 ? 4 : (p.rows >= 2 ? 2 : 1));
+#define ZL_ATTN_RT(RT)                                                                                          \
+    if (p.mask) hipLaunchKernelGGL((k_decode_attn_partial<DT, D, RT, FUSE, true>), grid, dim3(256), 0, st, p);      \
+    else hipLaunchKernelGGL((k_decode_attn_partial<DT, D, RT, FUSE, false>), grid, dim3(256), 0, st, p);
     switch (rt) {
-        case 1: hipLaunchKernelGGL((k_decode_attn_partial<DT, D, 1>), grid, dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((k_decode_attn_partial<DT, D, 2>), grid, dim3(256), 0, st, p); break;
-        case 4: hipLaunchKernelGGL((k_decode_attn_partial<DT, D, 4>), grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL((k_decode_attn_partial<DT, D, 8>), grid, dim3(256), 0, st, p); break;
+        case 1: ZL_ATTN_RT(1) break;
+        case 2: ZL_ATTN_RT(2) break;
+        case 4: ZL_ATTN_RT(4) break;
+        default: ZL_ATTN_RT(8) break;
     }
+#undef ZL_ATTN_RT
     int e = zl_launch_status();
     if (e) return e;
     hipLaunchKernelGGL((k_decode_attn_combine<DT, D>), dim3((unsigned)(p.b * p.len_q * p.h)), dim3(D), 0, st, p);
@@ -311,15 +457,43 @@ int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* c
     p.scale = scale; p.bshd = bshd;
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
-#define ZL_ATTN_D(DT)                                          \
+    p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
+#define ZL_ATTN_D(DT, FUSE)                                    \
     switch (d) {                                               \
-        case 64: return launch_d<DT, 64>(p, hs);               \
-        case 128: return launch_d<DT, 128>(p, hs);             \
-        case 256: return launch_d<DT, 256>(p, hs);             \
+        case 64: return launch_d<DT, 64, FUSE>(p, hs);         \
+        case 128: return launch_d<DT, 128, FUSE>(p, hs);       \
+        case 256: return launch_d<DT, 256, FUSE>(p, hs);       \
         default: return ZL_ESHAPE;                             \
     }
-    if (dtype == ZL_F16) { ZL_ATTN_D(ZL_F16) }
-    ZL_ATTN_D(ZL_BF16)
+    if (dtype == ZL_F16) { ZL_ATTN_D(ZL_F16, false) }
+    ZL_ATTN_D(ZL_BF16, false)
+}
+
+int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* qkv, const int32_t* placement,
+                         const int32_t* buf_lens, const int32_t* valid_lens, uint16_t* const* k_bufs,
+                         uint16_t* const* v_bufs, uint16_t* out, void* workspace, int64_t b, int64_t h, int64_t hkv,
+                         int64_t d, float scale, int64_t max_len_buf, int neox, int bshd, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(cosv && sinv && qkv && placement && buf_lens && valid_lens && k_bufs && v_bufs && out && workspace, ZL_EINVAL);
+    ZL_CHECK_ARG(b > 0 && h > 0 && hkv > 0 && d > 0 && max_len_buf > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(h % hkv == 0, ZL_ESHAPE);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    AttnParams p;
+    p.q = nullptr; p.buf_lens = buf_lens;
+    p.k_bufs = reinterpret_cast<const uint16_t* const*>(k_bufs);
+    p.v_bufs = reinterpret_cast<const uint16_t* const*>(v_bufs);
+    p.mask = nullptr; p.valid_lens = valid_lens; p.out = out; p.ws = (float*)workspace;
+    p.b = (int)b; p.len_q = 1; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
+    p.rows = p.n_rep;
+    const int rt = p.rows >= 8 ? 8 : (p.rows >= 4 ? 4 : (p.rows >= 2 ? 2 : 1));
+    p.passes = (p.rows + rt - 1) / rt;
+    p.split_len = attn_split_len(b, hkv, max_len_buf);
+    p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    p.scale = scale; p.bshd = bshd;
+    p.qkv = qkv; p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.k_bufs_w = k_bufs; p.v_bufs_w = v_bufs; p.neox = neox;
+    ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
+    hipStream_t hs = (hipStream_t)s;
+    if (dtype == ZL_F16) { ZL_ATTN_D(ZL_F16, true) }
+    ZL_ATTN_D(ZL_BF16, true)
 #undef ZL_ATTN_D
 }
 

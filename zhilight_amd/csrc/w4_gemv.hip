@@ -23,6 +23,13 @@
 #include "zl_common.h"
 #include "zl_stage.h"
 
+// Workgroup = 8 wavefronts (512 threads): the activation row(s) are staged ONCE per workgroup, and one
+// or two workgroups fill a CU, so the L1/TA traffic and the barrier latency of the x staging are paid
+// once or twice per CU instead of eight times (in-kernel probe: 2.3 us of the 4.4 us o_proj wave
+// lifetime was x staging with 256-thread workgroups, 8 per CU).
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+
 // ---- optional phase-timestamp probe (build with -DZL_W4_PROBE; tools/ubench/probe_gemv.py) --------
 #ifdef ZL_W4_PROBE
 __device__ unsigned long long* zl_probe_buf = nullptr;  // [waves][8] wall-clock ticks (100 MHz)
@@ -31,7 +38,7 @@ extern "C" int zl_debug_set_probe(void* p) {
 }
 #define ZL_PROBE(slot)                                                                                 \
     do {                                                                                                \
-        if (zl_probe_buf && lane == 0) zl_probe_buf[(size_t)(blockIdx.x * 4 + wave) * 8 + (slot)] = wall_clock64(); \
+        if (zl_probe_buf && lane == 0) zl_probe_buf[(size_t)(blockIdx.x * kWaves + wave) * 8 + (slot)] = wall_clock64(); \
     } while (0)
 #else
 #define ZL_PROBE(slot) do {} while (0)
@@ -129,7 +136,7 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)
 //         loads, so x (an L2 hit) can be normalised and written to LDS while the HBM loads fly.
 //         XL = 0 selects the generic "stage x, then start streaming" order for very large K.
 template <int MT, int kRing, int XL>
-__global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
+__global__ __launch_bounds__(kThreads, 4) void k_w4a16_gemm(const W4Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* xs = reinterpret_cast<uint16_t*>(smem);                 // [MT][kp]
     float* red = reinterpret_cast<float*>(smem + (size_t)MT * p.kp * 2);  // 16 floats
@@ -142,9 +149,9 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
     const int m0 = blockIdx.y * MT;
     const int Q = p.q_loads;
 
-    float* res = res_all + wave * 64 * MT;
+    float* res = res_all + wave * 64 * MT;  // [kWaves][64 rows][MT]
     ZL_PROBE(0);
-    const int gw = blockIdx.x * 4 + wave;
+    const int gw = blockIdx.x * kWaves + wave;
     const int pair0 = gw * p.pairs_per_wave;
     int npairs = p.pairs_total - pair0;
     npairs = npairs < 0 ? 0 : (npairs > p.pairs_per_wave ? p.pairs_per_wave : npairs);
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
         const uint16_t* nwp = p.norm_w ? p.norm_w : p.x;  // dummy but valid address when unused
 #pragma unroll
         for (int l = 0; l < XL; ++l) {
-            const int i = (threadIdx.x + l * 256) * 8;
+            const int i = (threadIdx.x + l * kThreads) * 8;
             nwr[l] = *reinterpret_cast<const uint4*>(nwp + (i < p.k ? i : p.k - 8));
         }
 #pragma unroll
@@ -174,13 +181,13 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
             const uint16_t* xrow = p.x + (size_t)((m0 + m) < p.m ? (m0 + m) : 0) * p.ldx;
 #pragma unroll
             for (int l = 0; l < XL; ++l) {
-                const int i = (threadIdx.x + l * 256) * 8;
+                const int i = (threadIdx.x + l * kThreads) * 8;
                 xr[m][l] = *reinterpret_cast<const uint4*>(xrow + (i < p.k ? i : p.k - 8));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     } else {
-        zl_stage_rows<ZL_F16, MT, 256>(p.x, p.ldx, m0, p.m, p.k, p.kp, p.norm_w, p.norm_eps, xs, red);
+        zl_stage_rows<ZL_F16, MT, kThreads>(p.x, p.ldx, m0, p.m, p.k, p.kp, p.norm_w, p.norm_eps, xs, red);
     }
 
     // ---- (2) weight ring prologue
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
                 float ss = 0.f;
 #pragma unroll
                 for (int l = 0; l < XL; ++l) {
-                    const int i = (threadIdx.x + l * 256) * 8;
+                    const int i = (threadIdx.x + l * kThreads) * 8;
                     if (i < p.k) {
                         const uint32_t u[4] = {xr[m][l].x, xr[m][l].y, xr[m][l].z, xr[m][l].w};
 #pragma unroll
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
             }
 #pragma unroll
             for (int l = 0; l < XL; ++l) {
-                const int i = (threadIdx.x + l * 256) * 8;
+                const int i = (threadIdx.x + l * kThreads) * 8;
                 if (i < p.kp) {
                     uint4 v = xr[m][l];
                     if (!live || i >= p.k) v = make_uint4(0, 0, 0, 0);
@@ -374,14 +381,14 @@ __global__ __launch_bounds__(256) void k_w4a16_gemm(const W4Params p) {
 
 template <int MT, int kRing, int XL>
 int launch(const W4Params& p, int grid_x, int grid_y, hipStream_t st) {
-    size_t lds = (size_t)MT * p.kp * 2 + 64 + 4 * 64 * MT * 4;
+    size_t lds = (size_t)MT * p.kp * 2 + 64 + kWaves * 64 * MT * 4;
     if (lds > 160 * 1024) return ZL_ELIMIT;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm<MT, kRing, XL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((k_w4a16_gemm<MT, kRing, XL>), dim3(grid_x, grid_y), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((k_w4a16_gemm<MT, kRing, XL>), dim3(grid_x, grid_y), dim3(kThreads), lds, st, p);
     return zl_launch_status();
 }
 
@@ -422,33 +429,33 @@ extern "C" int zl_w4a16_gemm(const uint16_t* x, int64_t ldx, const uint32_t* qw,
     while (mt > 1 && (size_t)mt * L.kp * 2 + 64 + 4096 > 64 * 1024) mt >>= 1;
     const int grid_y = (int)((m + mt - 1) / mt);
 
-    // grid: the kernel is VALU-issue bound with dependent fp16 chains, so it wants as many waves per
-    // SIMD as the ~100 VGPRs allow (4) plus a queue of further workgroups that the dispatcher uses to
-    // even out the tail: 8 four-wave workgroups per CU measured best on the Llama-3-8B shapes
-    // (gate_up 15.5 us vs 18.2 us at 2 per CU).  Each wave owns a contiguous run of row pairs.
+    // grid: 16 wavefronts per CU (two 8-wave workgroups; ~100 VGPRs -> 4 waves per SIMD), each wave owns
+    // a contiguous run of row pairs; small matrices get one workgroup per CU.
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
-    int wgs_per_cu = 8;
+    int wgs_per_cu = (p.pairs_total + cus * kWaves - 1) / (cus * kWaves) >= 2 ? 2 : 1;
     if (const char* e = getenv("ZL_W4_WGS_PER_CU")) {  // tuning override (read-only, no state kept)
         int v = atoi(e);
         if (v >= 1 && v <= 16) wgs_per_cu = v;
     }
-    int best_ppw = (p.pairs_total + cus * wgs_per_cu * 4 - 1) / (cus * wgs_per_cu * 4);
+    int best_ppw = (p.pairs_total + cus * wgs_per_cu * kWaves - 1) / (cus * wgs_per_cu * kWaves);
     if (best_ppw < 1) best_ppw = 1;
     if (best_ppw > 32) best_ppw = 32;  // LDS result slots: 64 rows per wave
     p.pairs_per_wave = best_ppw;
     const int waves_needed = (p.pairs_total + best_ppw - 1) / best_ppw;
-    const int grid_x = (waves_needed + 3) / 4;
+    const int grid_x = (waves_needed + kWaves - 1) / kWaves;
 
     hipStream_t hs = (hipStream_t)s;
     // ring depth: never more loads in flight than the wave has items (no dummy loads for tiny runs);
     // XL: x loads per thread kept in registers (2 -> K <= 4096, 8 -> K <= 16384 with few rows, else 0)
     const bool small = (int64_t)best_ppw * L.q < 8;
-    const int xl = L.kp <= 4096 ? 2 : ((L.kp <= 16384 && mt <= 2) ? 8 : 0);
+    const int xl_need = (int)((L.kp + kThreads * 8 - 1) / (kThreads * 8));
+    const int xl = xl_need <= 1 ? 1 : (xl_need <= 2 ? 2 : ((xl_need <= 4 && mt <= 2) ? 4 : 0));
 #define ZL_W4_LAUNCH(MT)                                                                     \
-    if (xl == 2)                                                                             \
-        return small ? launch<MT, 4, 2>(p, grid_x, grid_y, hs) : launch<MT, 8, 2>(p, grid_x, grid_y, hs); \
-    if (xl == 8) return launch<MT, 8, 8>(p, grid_x, grid_y, hs);                             \
+    if (xl == 1)                                                                             \
+        return small ? launch<MT, 4, 1>(p, grid_x, grid_y, hs) : launch<MT, 8, 1>(p, grid_x, grid_y, hs); \
+    if (xl == 2) return launch<MT, 8, 2>(p, grid_x, grid_y, hs);                             \
+    if (xl == 4) return launch<MT, 8, 4>(p, grid_x, grid_y, hs);                             \
     return small ? launch<MT, 4, 0>(p, grid_x, grid_y, hs) : launch<MT, 8, 0>(p, grid_x, grid_y, hs);
     switch (mt) {
         case 1: ZL_W4_LAUNCH(1)

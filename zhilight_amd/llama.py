@@ -9,13 +9,13 @@ Only what the decode hot path needs lives here: weight containers, the per-task 
 with their device pointer tables, and the kernel sequence of one step.  PyTorch supplies device
 memory and the stream; every arithmetic step is one C-ABI launcher from `ops`.
 
-Kernel sequence per layer (7 launches; the reference issues ~14 for the same math):
+Kernel sequence per layer (6 launches; the reference issues ~14 for the same math):
   1. w4a16_gemm  [RMSNorm(ln_attn) prologue]  hidden -> fused q|k|v             (project_q/k/v)
-  2. rope_scatter_decode                       rotate q,k (cached cos/sin), k,v -> ragged KV
-  3. decode_attn partial + 4. combine          softmax(q.K^T).V over the task's KV
-  5. w4a16_gemm  [residual epilogue]           attn_out + hidden -> hidden       (attn_out + add)
-  6. w4a16_gemm  [RMSNorm(ln_ff) prologue, silu*mul epilogue]  -> act           (w_in, w_gated, gate_mul)
-  7. w4a16_gemm  [residual epilogue]           w_out + hidden -> hidden
+  2. decode_attn_fused: rotate q,k (cached cos/sin), k,v -> ragged KV, split-KV softmax(q.K^T).V
+  3. combine of the KV splits
+  4. w4a16_gemm  [residual epilogue]           attn_out + hidden -> hidden       (attn_out + add)
+  5. w4a16_gemm  [RMSNorm(ln_ff) prologue, silu*mul epilogue]  -> act           (w_in, w_gated, gate_mul)
+  6. w4a16_gemm  [residual epilogue]           w_out + hidden -> hidden
 The roundings are the reference's single-stream path: every linear output, the norm output, the
 rotated q/k, the attention output and each residual sum is rounded to fp16 exactly where the
 reference materialises an fp16 tensor.
@@ -302,12 +302,9 @@ class LLaMA:
         for li, layer in enumerate(self.layers):
             ops.w4a16_gemm(hidden, layer.qkv.weight, bias=layer.qkv.bias, out=bufs["qkv"],
                            norm_weight=layer.ln_attn, norm_eps=c.eps)
-            ops.rope_scatter_decode(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li],
-                                    c.num_heads, c.num_kv_heads, c.dim_head, q_out=bufs["q"])
-            ops.multi_query_attention_rag_buffer(
-                bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li], None, scale,
-                ctx.max_len_buf, c.num_kv_heads, valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
-                workspace=workspace)
+            ops.decode_attention_fused(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.valid_lens, ctx.k_addrs[li],
+                                       ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, scale, ctx.max_len_buf,
+                                       out=bufs["attn"], workspace=workspace)
             ops.w4a16_gemm(bufs["attn"], layer.attn_out.weight, bias=layer.attn_out.bias, residual=hidden, out=hidden,
                            epilogue=ops.EPI_RESIDUAL)
             ops.w4a16_gemm(hidden, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, out=bufs["act"],

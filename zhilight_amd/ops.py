@@ -298,6 +298,23 @@ def multi_query_attention_rag_buffer(batch_q, buf_lens, key_buf_addrs, val_buf_a
     return out
 
 
+def decode_attention_fused(cos, sin, qkv, placement, buf_lens, valid_lens, k_addrs, v_addrs, num_heads, num_kv_heads,
+                           dim_head, scale, max_len_buf, neox=True, bshd=True, out=None, workspace=None):
+    """rope_qk_cache + copy_to_rag_buffer2 + multi_query_attention_rag_buffer for len_q == 1 decode rows in
+    one launch pair (partial + combine); returns the attention output (B, H*D)."""
+    _chk_cuda(cos, sin, qkv, placement, buf_lens, valid_lens, k_addrs, v_addrs)
+    b = qkv.shape[0]
+    if out is None:
+        out = torch.empty((b, num_heads * dim_head), dtype=qkv.dtype, device=qkv.device)
+    if workspace is None:
+        workspace = decode_attn_workspace(b, 1, num_heads, dim_head, max_len_buf, qkv.device)
+    check(lib().zl_decode_attn_fused(_p(cos), _p(sin), _p(qkv), _p(placement), _p(buf_lens), _p(valid_lens), _p(k_addrs),
+                                     _p(v_addrs), _p(out), _p(workspace), _i(b), _i(num_heads), _i(num_kv_heads),
+                                     _i(dim_head), _f(scale), _i(max_len_buf), C.c_int(int(neox)), C.c_int(int(bshd)),
+                                     C.c_int(_dt(qkv)), _stream()), "decode_attn_fused")
+    return out
+
+
 def element_add_scale(a, b, scale=1.0, scale_residual=True, out=None):
     """nn::element_add_scale_out (src/nn/block/block_kernel.cu:19-50)."""
     _chk_cuda(a, b)
