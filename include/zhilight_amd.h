@@ -122,6 +122,28 @@ int zl_w4a16_gemm(const uint16_t* x, int64_t ldx,
                   const uint16_t* norm_weight, float norm_eps, int epilogue, zl_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * a2/a3  W4A16 GEMM on the matrix cores: y = x . dequant(W)^T for decode batches (16 activation rows per
+ * weight pass, any M by passes -- the reference also chunks M by 16, q_gemm_k_major.cu:1109-1112).
+ * Arithmetic = the reference's fp32-accumulating flavour (the M > 40 branch: dequant_k_major + fp32-compute
+ * GEMM, src/nn/quant/gptq/q_gemm_k_major.cu:1083-1100): exact (q - z) in fp16, fp32 group sums, one fp32
+ * fma with the group scale; NOT bit-identical to the warp-reduce kernel (zl_w4a16_gemm is), but within
+ * fp32 rounding of the exact result.  Same prologue / epilogue flags as zl_w4a16_gemm.
+ * ZLW4M layout (zl_w4m_pack from the same k-major tensors; group_size = a multiple of 128):
+ *   qw   : u32 [N/16][K/128][64][4]   16-row x 128-k tiles, one dwordx4 per lane = its four MFMA B fragments
+ *   meta : u32 [N/16][K/128][16]      per row and tile: f16 scale | f16 -(1024 + zero) << 16
+ * zl_w4m_layout reports qw_bytes and the meta size in scales_bytes (zeros_bytes = 0).
+ * ---------------------------------------------------------------------------------------------- */
+int zl_w4m_layout(int64_t n, int64_t k, int64_t group_size, zl_w4_layout_t* out);
+int zl_w4m_pack(const uint32_t* qweight_km, const uint8_t* qzeros_km, const uint16_t* scales_km,
+                int64_t n, int64_t k, int64_t group_size, int row_interleave,
+                uint32_t* qw, uint32_t* meta, zl_stream_t s);
+int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx,
+                       const uint32_t* qw, const uint32_t* meta,
+                       const uint16_t* bias, const uint16_t* residual, uint16_t* y,
+                       int64_t m, int64_t n, int64_t k, int64_t group_size,
+                       const uint16_t* norm_weight, float norm_eps, int epilogue, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * a21  Dense NT GEMM for small M (lm_head, NormalLinear decode): y = T(alpha * x . W^T + bias),
  * fp32 accumulate.  Replaces functions::Gemm::forward (bm/functions/gemm.cpp:505-542) on the decode
  * path: RawEmbedding::projection (src/nn/embedding/embedding.cu:274-289).

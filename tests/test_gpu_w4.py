@@ -184,3 +184,73 @@ def test_gemm_error_behaviour(dev):
         ops.w4a16_gemm(torch.zeros(1, 2048, dtype=torch.float16, device=dev), w)
     with pytest.raises(ZLError, match="A must be half"):
         ops.w4a16_gemm(torch.zeros(1, 1024, dtype=torch.bfloat16, device=dev), w)
+
+
+# ---------------------------------------------------------------------------------------------------
+# MFMA flavour (fp32 accumulation): checked against the exact fp64 oracle and against the restatement of
+# the reference's M > 40 branch (dequant_k_major -> fp16 weights, fp32-accumulating GEMM)
+# ---------------------------------------------------------------------------------------------------
+def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=False):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(seed)
+    g = 128
+    n8 = (n + 7) // 8 * 8
+    qw, qz, sc = synth.gptq_hf(rng, k, n8, g)
+    km = tuple(np.ascontiguousarray(a[:n]) for a in oracle.gptq_prepare_k_major(qw, qz, sc, g))
+    w = ops.W4MWeight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), g)
+    x = synth.act(rng, m, k, 2.0 if norm else 1.0)
+    b = (rng.standard_normal(n) * 0.1).astype(np.float16) if bias else None
+    nw = (1.0 + 0.1 * rng.standard_normal(k)).astype(np.float16) if norm else None
+    res = synth.act(rng, m, n) if residual else None
+    xin = oracle.rmsnorm(oracle.h2u(x), oracle.h2u(nw), 1e-5) if norm else oracle.h2u(x)
+    exact = oracle.gptq_gemm_k_major_exact(xin, *km, bias=None if b is None else oracle.h2u(b))
+    y = ops.w4a16_gemm_mfma(_t(x, dev), w, bias=None if b is None else _t(b, dev), residual=None if res is None else _t(res, dev),
+                            norm_weight=None if nw is None else _t(nw, dev), norm_eps=1e-5,
+                            epilogue=ops.EPI_RESIDUAL if residual else 0)
+    got = _np(y).astype(np.float64)
+    if residual:
+        exact = res.astype(np.float64) + exact.astype(np.float16).astype(np.float64)
+    rms = np.sqrt((exact ** 2).mean())
+    # fp16 output rounding (2^-11 relative) + fp32 accumulation noise; with the fused norm the normalised
+    # input may differ by 1 fp16 ulp on a few elements (block-sum association)
+    tol = 2.0 ** -10 * np.abs(exact) + (3e-4 if norm else 2e-5) * rms
+    assert (np.abs(got - exact) <= tol).all(), float((np.abs(got - exact) / rms).max())
+    if not (norm or residual):
+        # the reference's M > 40 branch: W16 = rn16(rn16(q - z) * s), fp32-accumulating GEMM
+        w16 = oracle.gptq_dequant_k_major(*km)
+        ref40 = oracle.gemm_nt(oracle.h2u(x), w16, None if b is None else oracle.h2u(b), exact=True)
+        assert (np.abs(got - ref40) <= 2.0 ** -10 * np.abs(ref40) + 1.5e-3 * rms).all()  # fp16 output rounding + W16 weight rounding
+        # and the warp-reduce kernel's own noise level vs both
+        r = oracle.u2h(oracle.gptq_gemm_k_major(oracle.h2u(x), *km, bias=None if b is None else oracle.h2u(b))).astype(np.float64)
+        assert np.abs(got - r).max() <= 6e-3 * rms                                     # the warp-reduce kernel's fp16 noise
+
+
+@pytest.mark.parametrize("m", [1, 2, 5, 8, 16, 17, 33])
+def test_mfma_gemm_small(oracle, dev, m):
+    _check_mfma(oracle, dev, 2048, 264, m, seed=20 + m)
+
+
+@pytest.mark.parametrize("k,n", [(1024, 16), (1152, 40), (4096, 6144), (14336, 512), (4096, 4096)])
+def test_mfma_gemm_shapes(oracle, dev, k, n):
+    _check_mfma(oracle, dev, k, n, 1, seed=30)
+    _check_mfma(oracle, dev, k, n, 9, seed=31, bias=True)
+
+
+def test_mfma_gemm_fused_norm_residual_silu(oracle, dev):
+    from zhilight_amd import ops
+    _check_mfma(oracle, dev, 2048, 256, 3, seed=40, norm=True)
+    _check_mfma(oracle, dev, 2048, 256, 3, seed=41, residual=True)
+    rng = np.random.default_rng(42)
+    k, nff, g, m = 2048, 192, 128, 4
+    qw1, qz1, sc1 = synth.gptq_hf(rng, k, nff, g)
+    qw2, qz2, sc2 = synth.gptq_hf(rng, k, nff, g)
+    km1, km2 = oracle.gptq_prepare_k_major(qw1, qz1, sc1, g), oracle.gptq_prepare_k_major(qw2, qz2, sc2, g)
+    cat = [np.concatenate([a, b], axis=0) for a, b in zip(km1, km2)]
+    w = ops.W4MWeight.from_k_major(_t(cat[0].view(np.int32), dev), _t(cat[1], dev), _t(cat[2], dev, torch.float16), g,
+                                   row_interleave=True)
+    x = synth.act(rng, m, k)
+    ge = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), *km1).astype(np.float16)
+    ue = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), *km2).astype(np.float16)
+    ref = oracle.u2h(oracle.silu_mul(oracle.h2u(ge), oracle.h2u(ue))).astype(np.float64)
+    got = _np(ops.w4a16_gemm_mfma(_t(x, dev), w, epilogue=ops.EPI_SILU_MUL)).astype(np.float64)
+    assert np.abs(got - ref).max() <= 2.0 ** -9 * max(1.0, np.abs(ref).max())

@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libzhilight_amd.so")
+# ZHILIGHT_AMD_SO: load an experimental build of the same library instead (tools/ubench/variant.sh)
+SO_PATH = os.environ.get("ZHILIGHT_AMD_SO") or os.path.join(_HERE, "libzhilight_amd.so")
 
 # every entry point declared in include/zhilight_amd.h (kept in sync by tests/test_abi.py)
 SYMBOLS = [
@@ -21,6 +22,7 @@ SYMBOLS = [
     "zl_gptq_shuffle", "zl_gptq_increase_zero", "zl_gptq_q4_to_q8", "zl_transpose_2d",
     "zl_awq_un_shuffle", "zl_awq_shuffle",
     "zl_w4_layout", "zl_w4_pack", "zl_w4_dequant", "zl_w4a16_gemm",
+    "zl_w4m_layout", "zl_w4m_pack", "zl_w4a16_gemm_mfma",
     "zl_gemm_nt_small_m", "zl_rmsnorm",
     "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rotary_embedding_qk", "zl_rope_qk_cache",
     "zl_copy_to_rag_buffer2", "zl_rope_scatter_decode",

@@ -171,6 +171,56 @@ def w4a16_gemm(x, w, bias=None, residual=None, out=None, norm_weight=None, norm_
     return out
 
 
+class W4MWeight:
+    """The same W4 linear weight in the MFMA-oriented ZLW4M layout (16-row x 128-k tiles + per-row meta)."""
+
+    def __init__(self, n, k, group_size, qw, meta, row_interleave=False):
+        self.n, self.k, self.group_size = n, k, group_size
+        self.qw, self.meta, self.row_interleave = qw, meta, row_interleave
+
+    @staticmethod
+    def layout(n, k, group_size):
+        L = W4Layout()
+        check(lib().zl_w4m_layout(_i(n), _i(k), _i(group_size), C.byref(L)), "w4m_layout")
+        return L
+
+    @classmethod
+    def from_k_major(cls, qweight_km, qzeros_km, scales_km, group_size, row_interleave=False):
+        _chk_cuda(qweight_km, qzeros_km, scales_km)
+        n, k = qweight_km.shape[0], qweight_km.shape[1] * 8
+        L = cls.layout(n, k, group_size)
+        dev = qweight_km.device
+        qw = torch.empty(L.qw_bytes // 4, dtype=torch.int32, device=dev)
+        meta = torch.empty(L.scales_bytes // 4, dtype=torch.int32, device=dev)
+        check(lib().zl_w4m_pack(_p(qweight_km), _p(qzeros_km), _p(scales_km), _i(n), _i(k), _i(group_size),
+                                C.c_int(int(row_interleave)), _p(qw), _p(meta), _stream()), "w4m_pack")
+        return cls(n, k, group_size, qw, meta, row_interleave)
+
+    def nbytes(self):
+        return self.qw.numel() * 4 + self.meta.numel() * 4
+
+
+def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, norm_eps=1e-5, epilogue=0):
+    """MFMA flavour of w4a16_gemm (fp32 accumulation = the numerics of the reference's M > 40 branch)."""
+    if x.dtype != torch.float16:
+        raise ZLError("A must be half")
+    _chk_cuda(x, bias, residual, norm_weight)
+    x2 = x.reshape(-1, x.shape[-1])
+    m, k = x2.shape
+    if k != w.k:
+        raise ZLError("size K mismatch")
+    silu = epilogue & (EPI_SILU_MUL | EPI_SILU_MUL_F32)
+    n_out = w.n // 2 if silu else w.n
+    if out is None:
+        out = torch.empty((m, n_out), dtype=torch.float16, device=x.device)
+    if bias is not None:
+        epilogue |= EPI_BIAS
+    check(lib().zl_w4a16_gemm_mfma(_p(x2), _i(x2.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(residual),
+                                   _p(out), _i(m), _i(w.n), _i(k), _i(w.group_size), _p(norm_weight), _f(norm_eps),
+                                   C.c_int(epilogue), _stream()), "w4a16_gemm_mfma")
+    return out
+
+
 def gemm_nt_small_m(x, weight, bias=None, alpha=1.0, out=None, norm_weight=None, norm_eps=1e-5):
     """y = T(alpha * x . W^T + bias) -- functions::Gemm(trans_b=True) on the decode path (lm_head)."""
     _chk_cuda(x, weight, bias, norm_weight)
