@@ -144,7 +144,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline leg (rank 0): the dominant kernel = the W4A16 GEMV (k_w4a16_gemm).  All 4 x 32 GEMV
+    # ---- roofline leg (rank 0): the dominant kernel = the W4A16 GEMV (k_w4a16_mfma by default,
+    # k_w4a16_gemm under ZL_W4_ALGO=exact).  All 4 x 32 GEMV
     # launches of one step, in model order on the real (distinct, HBM-cold: 3.6 GB >> 256 MB
     # Infinity Cache) weights, captured without the other kernels; HIP events on the launch stream.
     roof = None
@@ -161,7 +162,7 @@ def main():
 
         def gemvs():
             for x, lin, out, kw in launches:
-                ops.w4a16_gemm(x, lin.weight, out=out, **kw)
+                ops.w4_linear(x, lin.weight, out=out, **kw)
         gemvs()
         torch.cuda.synchronize()
         g2 = torch.cuda.CUDAGraph()
@@ -180,7 +181,8 @@ def main():
         tot_bytes = sum(alg_bytes_w4(lin.weight.n, lin.weight.k, lin.weight.group_size, batch) for _, lin, _, _ in launches)
         per_launch = tot_bytes / len(launches)
         achieved = per_launch / t_launch / 1e9
-        roof = {"bound": "hbm", "kernel": "k_w4a16_gemm (W4A16 GEMV, 4 launches/layer)", "achieved": round(achieved, 1),
+        kname = "k_w4a16_mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "k_w4a16_gemm"
+        roof = {"bound": "hbm", "kernel": kname + " (W4A16 GEMV, 4 launches/layer)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3),
                 "note": "avg over the 128 GEMV launches of one step incl. inter-kernel gaps (graph replay, HIP events)"}
@@ -199,7 +201,8 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "Llama-3-8B GPTQ-Int4 g128 TP=1 batch=%d decode seq=%d (BASELINE configs[1])" % (batch, seq),
                        "layers": cfg.num_layers, "parallelism": "dp%d (independent TP=1 replicas)" % world,
-                       "global_batch": world * batch, "seq_len": seq, "valid": not args.layers},
+                       "global_batch": world * batch, "seq_len": seq, "valid": not args.layers,
+                       "w4_algo": "mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "exact"},
             "per_gpu_tokens_per_s": round(value / world, 2),
             "step_hbm_roofline_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,

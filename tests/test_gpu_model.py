@@ -76,9 +76,14 @@ class OracleModel:
         return o.gemm_nt(xn, o.h2u(self.sd["lm_head.weight"]), exact=True), h
 
 
+@pytest.mark.parametrize("algo", ["mfma", "exact"])
 @pytest.mark.parametrize("batch", [1, 3])
-def test_decode_steps_match_oracle(oracle, dev, batch):
+def test_decode_steps_match_oracle(oracle, dev, batch, algo, monkeypatch):
+    """Both W4A16 kernels against the reference-faithful oracle (warp-reduce arithmetic): "exact" replays
+    it bit for bit per GEMM, "mfma" accumulates in fp32 -- the whole-model logits of either stay inside
+    north_star's 1e-3 bar."""
     from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    monkeypatch.setenv("ZL_W4_ALGO", algo)
     rng = np.random.default_rng(0)
     cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2,
                       eps=1e-5, rope_theta=5e5,
@@ -101,7 +106,13 @@ def test_decode_steps_match_oracle(oracle, dev, batch):
         assert np.abs(got - ref).max() <= 1e-3 * scale + 2.0 ** -11 * scale, (step, np.abs(got - ref).max() / scale)
         nxt_ref = ref.argmax(axis=1)
         nxt = logits.argmax(dim=1)
-        assert np.array_equal(nxt.cpu().numpy(), nxt_ref), "greedy tokens differ"
+        nxt_np = nxt.cpu().numpy()
+        if algo == "exact":
+            assert np.array_equal(nxt_np, nxt_ref), "greedy tokens differ"
+        else:  # a different token is only acceptable on a reference near-tie (inside the logit tolerance)
+            for bi in range(batch):
+                assert ref[bi, nxt_ref[bi]] - ref[bi, nxt_np[bi]] <= 2e-3 * scale, "greedy tokens differ beyond a near-tie"
+        nxt = torch.from_numpy(nxt_ref).to(nxt.device)
         model.advance(ctx, nxt)
         tokens = nxt_ref.astype(np.int32)
     # KV written by the fused rope+scatter kernel equals the oracle's buffers (first 4 slots)

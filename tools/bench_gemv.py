@@ -12,21 +12,11 @@ from zhilight_amd import ops  # noqa: E402
 
 
 def rand_w4(n, k, g, dev, interleave=False):
-    L = ops.W4Weight.layout(n, k, g)
-    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (L.qw_bytes // 4,), dtype=torch.int32, device=dev)
-    sc = (torch.rand(L.scales_bytes // 2, device=dev) * 0.005 + 1e-4).to(torch.float16)
-    zs = torch.randint(-2 ** 15, 2 ** 15 - 1, (L.zeros_bytes // 2,), dtype=torch.int16, device=dev)
-    return ops.W4Weight(n, k, g, qw, sc, zs, row_interleave=interleave)
+    return ops.W4Weight.random(n, k, g, dev, row_interleave=interleave)
 
 
 def rand_w4m(n, k, g, dev, interleave=False):
-    L = ops.W4MWeight.layout(n, k, g)
-    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (L.qw_bytes // 4,), dtype=torch.int32, device=dev)
-    sc = (torch.rand(L.scales_bytes // 4, device=dev) * 0.005 + 1e-4).to(torch.float16).view(torch.int16).to(torch.int32) & 0xffff
-    z = torch.randint(0, 16, (L.scales_bytes // 4,), dtype=torch.int32, device=dev)
-    meta = (sc | ((0xe400 | z) << 16)).to(torch.int64)
-    meta = torch.where(meta >= 2 ** 31, meta - 2 ** 32, meta).to(torch.int32)
-    return ops.W4MWeight(n, k, g, qw, meta, row_interleave=interleave)
+    return ops.W4MWeight.random(n, k, g, dev, row_interleave=interleave)
 
 
 def alg_bytes(n, k, g, m):

@@ -21,6 +21,7 @@ rotated q/k, the attention output and each residual sum is rounded to fp16 exact
 reference materialises an fp16 tensor.
 """
 import math
+import os
 import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -108,6 +109,20 @@ def _dev_t(a, device, dtype=None):
     return t if dtype is None else t.view(dtype)
 
 
+def w4_algo(quant) -> str:
+    """Which W4A16 kernel a quantized linear runs -- the counterpart of the reference's GPTQ_KERNEL_ALGO
+    switch (src/nn/quant/gptq/q_gemm_k_major.cu:1075-1100).  "mfma" (default): dequant -> MFMA with fp32
+    accumulation, the arithmetic of the reference's dequant+GEMM branch; "exact": the warp-reduce
+    kernel replayed bit for bit.  Set ZL_W4_ALGO=exact to select the latter; group sizes the MFMA tile
+    cannot hold (not a multiple of 128) use it automatically."""
+    algo = os.environ.get("ZL_W4_ALGO", "mfma").lower()
+    if algo not in ("mfma", "exact"):
+        raise ops.ZLError(f"ZL_W4_ALGO={algo!r}: expected 'mfma' or 'exact'")
+    if quant.group_size % 128 != 0:
+        return "exact"
+    return algo
+
+
 class Int4GPTQ:
     """nn::Linear with the Int4GPTQ implementation (src/nn/linear/linear.cpp:638-1244): holds the
     load-time-transformed weight; `fuse` mirrors Linear::fuse / fuse3 (row concatenation)."""
@@ -142,7 +157,10 @@ class Int4GPTQ:
         return out
 
     def pack(self, row_interleave=False):
-        self.weight = ops.W4Weight.from_k_major(*self.km, self.quant.group_size, self.quant.sym, row_interleave)
+        if w4_algo(self.quant) == "mfma":
+            self.weight = ops.W4MWeight.from_k_major(*self.km, self.quant.group_size, row_interleave)
+        else:
+            self.weight = ops.W4Weight.from_k_major(*self.km, self.quant.group_size, self.quant.sym, row_interleave)
         if row_interleave and self.bias is not None:
             half = self.dim_out // 2
             self.bias = torch.stack([self.bias[:half], self.bias[half:]], dim=1).reshape(-1).contiguous()
@@ -150,7 +168,7 @@ class Int4GPTQ:
         return self
 
     def forward(self, x, **kw):
-        return ops.w4a16_gemm(x, self.weight, bias=self.bias, **kw)
+        return ops.w4_linear(x, self.weight, bias=self.bias, **kw)
 
 
 class EncoderLayer:
@@ -191,11 +209,11 @@ class EncoderLayer:
 
         def rnd(name, din, dout, interleave=False):
             l = Int4GPTQ(name, din, dout, q)
-            L = ops.W4Weight.layout(dout, din, q.group_size)
-            qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (L.qw_bytes // 4,), dtype=torch.int32, device=device, generator=gen)
-            sc = (torch.rand(L.scales_bytes // 2, device=device, generator=gen) * (1.0 / math.sqrt(din) / 4.0) + 1e-4).to(torch.float16)
-            zs = torch.randint(-2 ** 15, 2 ** 15 - 1, (L.zeros_bytes // 2,), dtype=torch.int16, device=device, generator=gen)
-            l.weight = ops.W4Weight(dout, din, q.group_size, qw, sc, zs, q.sym, interleave)
+            mag = 1.0 / math.sqrt(din) / 4.0
+            if w4_algo(q) == "mfma":
+                l.weight = ops.W4MWeight.random(dout, din, q.group_size, device, gen, mag, interleave)
+            else:
+                l.weight = ops.W4Weight.random(dout, din, q.group_size, device, gen, mag, q.sym, interleave)
             return l
         self.qkv = rnd("qkv", c.dim_model, hd + 2 * kvd)
         self.attn_out = rnd("attn_out", hd, c.dim_model)
@@ -300,16 +318,16 @@ class LLaMA:
         cos, sin = ops.rope_cos_sin(ctx.positions, c.dim_head, c.rope_theta, True, llama3)  # RopePreparer
         scale = 1.0 / math.sqrt(c.dim_head)
         for li, layer in enumerate(self.layers):
-            ops.w4a16_gemm(hidden, layer.qkv.weight, bias=layer.qkv.bias, out=bufs["qkv"],
+            ops.w4_linear(hidden, layer.qkv.weight, bias=layer.qkv.bias, out=bufs["qkv"],
                            norm_weight=layer.ln_attn, norm_eps=c.eps)
             ops.decode_attention_fused(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.valid_lens, ctx.k_addrs[li],
                                        ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, scale, ctx.max_len_buf,
                                        out=bufs["attn"], workspace=workspace)
-            ops.w4a16_gemm(bufs["attn"], layer.attn_out.weight, bias=layer.attn_out.bias, residual=hidden, out=hidden,
+            ops.w4_linear(bufs["attn"], layer.attn_out.weight, bias=layer.attn_out.bias, residual=hidden, out=hidden,
                            epilogue=ops.EPI_RESIDUAL)
-            ops.w4a16_gemm(hidden, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, out=bufs["act"],
+            ops.w4_linear(hidden, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, out=bufs["act"],
                            norm_weight=layer.ln_ff, norm_eps=c.eps, epilogue=ops.EPI_SILU_MUL)
-            ops.w4a16_gemm(bufs["act"], layer.w_out.weight, bias=layer.w_out.bias, residual=hidden, out=hidden,
+            ops.w4_linear(bufs["act"], layer.w_out.weight, bias=layer.w_out.bias, residual=hidden, out=hidden,
                            epilogue=ops.EPI_RESIDUAL)
         alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
         return ops.gemm_nt_small_m(hidden, self.lm_head, alpha=alpha, out=bufs["logits"],

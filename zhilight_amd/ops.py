@@ -145,6 +145,16 @@ class W4Weight:
     def nbytes(self):
         return self.qw.numel() * 4 + self.scales.numel() * 2 + self.zeros.numel() * 2
 
+    @classmethod
+    def random(cls, n, k, group_size, device, gen=None, scale_mag=0.005, sym=False, row_interleave=False):
+        """Synthetic weight generated directly in the packed layout (benchmarks: no checkpoint I/O)."""
+        L = cls.layout(n, k, group_size)
+        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (L.qw_bytes // 4,), dtype=torch.int32, device=device, generator=gen)
+        sc = (torch.rand(L.scales_bytes // 2, device=device, generator=gen) * scale_mag + 1e-4).to(torch.float16)
+        zs = torch.randint(-2 ** 15, 2 ** 15 - 1, (L.zeros_bytes // 2,), dtype=torch.int16, device=device, generator=gen)
+        return cls(n, k, group_size, qw, sc, zs, sym, row_interleave)
+
+
 
 def w4a16_gemm(x, w, bias=None, residual=None, out=None, norm_weight=None, norm_eps=1e-5, epilogue=0):
     """y = x . dequant(W)^T with optional fused RMSNorm prologue and bias / ADD_C / residual / silu*mul
@@ -199,6 +209,19 @@ class W4MWeight:
     def nbytes(self):
         return self.qw.numel() * 4 + self.meta.numel() * 4
 
+    @classmethod
+    def random(cls, n, k, group_size, device, gen=None, scale_mag=0.005, row_interleave=False):
+        """Synthetic weight generated directly in the packed layout (benchmarks: no checkpoint I/O)."""
+        L = cls.layout(n, k, group_size)
+        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (L.qw_bytes // 4,), dtype=torch.int32, device=device, generator=gen)
+        cnt = L.scales_bytes // 4
+        sc = (torch.rand(cnt, device=device, generator=gen) * scale_mag + 1e-4).to(torch.float16)
+        sc = sc.view(torch.int16).to(torch.int32) & 0xffff
+        z = torch.randint(0, 16, (cnt,), dtype=torch.int32, device=device, generator=gen)
+        meta = (sc | ((0xe400 | z) << 16)).to(torch.int64)
+        meta = torch.where(meta >= 2 ** 31, meta - 2 ** 32, meta).to(torch.int32)
+        return cls(n, k, group_size, qw, meta, row_interleave)
+
 
 def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, norm_eps=1e-5, epilogue=0):
     """MFMA flavour of w4a16_gemm (fp32 accumulation = the numerics of the reference's M > 40 branch)."""
@@ -219,6 +242,14 @@ def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, 
                                    _p(out), _i(m), _i(w.n), _i(k), _i(w.group_size), _p(norm_weight), _f(norm_eps),
                                    C.c_int(epilogue), _stream()), "w4a16_gemm_mfma")
     return out
+
+
+def w4_linear(x, w, **kw):
+    """W4A16 linear on whichever packed layout the weight holds (W4Weight: bit-exact warp-reduce
+    arithmetic; W4MWeight: fp32-accumulating MFMA arithmetic)."""
+    if isinstance(w, W4MWeight):
+        return w4a16_gemm_mfma(x, w, **kw)
+    return w4a16_gemm(x, w, **kw)
 
 
 def gemm_nt_small_m(x, weight, bias=None, alpha=1.0, out=None, norm_weight=None, norm_eps=1e-5):
