@@ -1,0 +1,63 @@
+"""Fused decode attention (rope + KV scatter + split-KV softmax + split merge) per-launch time, hipGraph-captured:
+`layers` launches over distinct KV buffers per replay, like one decode step.
+usage: python tools/bench_attn.py [--batch 1] [--seq 1024] [--layers 32]
+(an in-launch split merge by the last-arriving workgroup was tried against the separate combine kernel:
+13.1 vs ~13.9 us stand-alone, but +0.7 us per layer inside the decode step -- not kept)"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zhilight_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--seq", type=int, default=1024)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    h, hkv, d = 32, 8, 128
+    len_buf = (a.seq + 64 + 63) // 64 * 64
+    kv = [torch.randn(a.layers, 2, len_buf, hkv, d, dtype=torch.float16, device=dev) for _ in range(a.batch)]
+    k_addrs = torch.tensor([[t[l, 0].data_ptr() for t in kv] for l in range(a.layers)], dtype=torch.int64, device=dev)
+    v_addrs = torch.tensor([[t[l, 1].data_ptr() for t in kv] for l in range(a.layers)], dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    pos = torch.full((a.batch,), a.seq, **i32)
+    buf_lens = torch.full((a.batch,), len_buf, **i32)
+    valid = torch.full((a.batch,), a.seq + 1, **i32)
+    cos, sin = ops.rope_cos_sin(pos, d, 5e5, True, None)
+    qkv = torch.randn(a.batch, (h + 2 * hkv) * d, dtype=torch.float16, device=dev)
+    out = torch.empty(a.batch, h * d, dtype=torch.float16, device=dev)
+    ws = ops.decode_attn_workspace(a.batch, 1, h, d, len_buf, dev)
+
+    def run():
+        for l in range(a.layers):
+            ops.decode_attention_fused(cos, sin, qkv, pos, buf_lens, valid, k_addrs[l], v_addrs[l], h, hkv, d,
+                                       1.0 / math.sqrt(d), len_buf, out=out, workspace=ws)
+    run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (a.iters * a.layers)
+    kvb = a.batch * 2 * hkv * (a.seq + 1) * d * 2
+    print(f"batch={a.batch} seq={a.seq}: {us:7.2f} us/launch   KV {kvb / 1e6:.2f} MB -> {kvb / us / 1e3:7.1f} GB/s"
+          "")
+
+
+if __name__ == "__main__":
+    main()
