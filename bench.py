@@ -113,8 +113,7 @@ def main():
     ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
 
     def step():
-        logits = model.encode(ctx)
-        model.advance(ctx, torch.argmax(logits, dim=-1))
+        model.step_greedy(ctx)   # encode + greedy pick + advance of the batch state, all on the device
 
     step()  # eager once: allocates the step's buffers, caches device attributes
     torch.cuda.synchronize()
@@ -182,8 +181,18 @@ def main():
         per_launch = tot_bytes / len(launches)
         achieved = per_launch / t_launch / 1e9
         kname = "k_w4a16_mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "k_w4a16_gemm"
+        # HBM traffic per launch: measured off-line with rocprofv3 --pmc (a counter pass cannot run inside
+        # this process); the committed summary is per kernel flavour and for these four shapes only
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemv_traffic.json")) as fh:
+                tj = json.load(fh)
+            if tj.get("kernel") == kname and not args.layers and batch == 1:
+                traffic = int(tj["avg_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roof = {"bound": "hbm", "kernel": kname + " (W4A16 GEMV, 4 launches/layer)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3),
                 "note": "avg over the 128 GEMV launches of one step incl. inter-kernel gaps (graph replay, HIP events)"}
 

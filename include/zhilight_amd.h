@@ -151,6 +151,19 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx,
 int zl_gemm_nt_small_m(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K) */, const uint16_t* bias,
                        uint16_t* y, int64_t m, int64_t n, int64_t k, float alpha, int dtype,
                        const uint16_t* norm_weight, float norm_eps, zl_stream_t s);
+/* lm_head + greedy pick without a separate argmax pass over the logits: the GEMV leaves each wavefront's
+ * best (rounded logit, row index) in argmax_ws (zl_argmax_workspace_bytes(m, n) bytes); zl_greedy_advance
+ * reduces them per activation row (first index on ties, like torch.argmax) and does the between-steps
+ * bookkeeping of a decode batch on the device -- tokens <- pick, positions / placement / valid_lens += 1
+ * (any of the five output pointers may be NULL) -- the job of fill_search_tokens on the host in the
+ * reference (src/generator/batch_generator.cpp:1226-1335). */
+int64_t zl_argmax_workspace_bytes(int64_t m, int64_t n);
+int zl_gemm_nt_small_m_argmax(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K) */, const uint16_t* bias,
+                              uint16_t* y, int64_t m, int64_t n, int64_t k, float alpha, int dtype,
+                              const uint16_t* norm_weight, float norm_eps, void* argmax_ws, zl_stream_t s);
+int zl_greedy_advance(const void* argmax_ws, int64_t m, int64_t n, int32_t* tokens, int32_t* positions,
+                      int32_t* placement, int32_t* valid_lens, int64_t* next_tokens, zl_stream_t s);
+
 
 /* ------------------------------------------------------------------------------------------------
  * a17  RMSNorm and fused residual-add + RMSNorm.

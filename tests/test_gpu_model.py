@@ -124,3 +124,30 @@ def test_decode_steps_match_oracle(oracle, dev, batch, algo, monkeypatch):
             gv = ctx.kv[bi][li, 1].cpu().numpy()[:4].astype(np.float64)
             rv = oracle.u2h(om.vb[li][bi][:4]).astype(np.float64)
             assert np.abs(gv - rv).max() <= 2.0 ** -9 * np.abs(rv).max()
+
+
+def test_step_greedy_matches_argmax_and_advances(dev):
+    """The in-launch greedy pick equals torch.argmax on the logits (first index on ties) and the device-side
+    bookkeeping equals LLaMA.advance."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(5)
+    for m, n, k in [(1, 1000, 256), (3, 4099, 512), (5, 128256, 128)]:
+        x = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float16)).to(dev)
+        w = torch.from_numpy((rng.standard_normal((n, k)) * 0.05).astype(np.float16)).to(dev)
+        w[n // 2] = w[7]            # exact ties between rows 7 and n/2: the pick must be the first one
+        w[n - 1] = w[7]
+        ws = ops.argmax_workspace(m, n, dev)
+        logits = ops.gemm_nt_small_m(x, w, argmax_ws=ws)
+        i32 = dict(dtype=torch.int32, device=dev)
+        tokens, pos, place, valid = (torch.zeros(m, **i32), torch.full((m,), 3, **i32), torch.full((m,), 4, **i32),
+                                     torch.full((m,), 5, **i32))
+        nxt = torch.empty(m, dtype=torch.int64, device=dev)
+        ops.greedy_advance(ws, m, n, tokens, pos, place, valid, nxt)
+        ref = torch.argmax(logits.float(), dim=-1)
+        # torch.argmax does not promise the first index on ties: check value equality + first-index rule
+        lf = logits.float()
+        for r in range(m):
+            first = int((lf[r] == lf[r].max()).nonzero()[0, 0])
+            assert int(nxt[r]) == first, (m, n, r, int(nxt[r]), first, int(ref[r]))
+        assert torch.equal(tokens.long(), nxt)
+        assert pos.tolist() == [4] * m and place.tolist() == [5] * m and valid.tolist() == [6] * m

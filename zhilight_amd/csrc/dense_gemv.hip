@@ -25,6 +25,8 @@ struct DenseParams {
     int m, n, k, kp;       // kp = k rounded up to 512 (one wave-load)
     int loads_per_row;     // kp / 512
     int rows_per_wave;
+    float2* argmax_ws;     // optional: per (activation row, global wave) best (value, row index) of the wave
+    int total_waves;
 };
 
 typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
@@ -81,8 +83,14 @@ __global__ __launch_bounds__(256) void k_dense_gemv(const DenseParams p) {
     __syncthreads();
 
     float acc[MT];
+    float best_v[MT];
+    int best_i[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    for (int m = 0; m < MT; ++m) {
+        acc[m] = 0.f;
+        best_v[m] = -INFINITY;
+        best_i[m] = 0x7fffffff;
+    }
     int cl = 0, crow = row0;
     auto consume = [&](int slot) {
 #pragma unroll
@@ -98,7 +106,14 @@ __global__ __launch_bounds__(256) void k_dense_gemv(const DenseParams p) {
                 acc[m] = 0.f;
                 if (lane == 0 && (m0 + m) < p.m) {
                     float b = p.bias ? ZT<DT>::to_f32(p.bias[crow]) : 0.f;
-                    p.y[(size_t)(m0 + m) * p.n + crow] = ZT<DT>::from_f32(p.alpha * v + b);
+                    const uint16_t y16 = ZT<DT>::from_f32(p.alpha * v + b);
+                    p.y[(size_t)(m0 + m) * p.n + crow] = y16;
+                    // greedy pick on the ROUNDED logit, first index on ties (rows ascend inside a wave)
+                    const float yv = ZT<DT>::to_f32(y16);
+                    if (yv > best_v[m] || best_i[m] == 0x7fffffff) {
+                        best_v[m] = yv;
+                        best_i[m] = crow;
+                    }
                 }
             }
             ++crow;
@@ -113,6 +128,58 @@ __global__ __launch_bounds__(256) void k_dense_gemv(const DenseParams p) {
                 if (it + s + kRing < total) issue(s);
             }
         }
+    }
+    if (p.argmax_ws && lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if ((m0 + m) < p.m)
+                p.argmax_ws[(size_t)(m0 + m) * p.total_waves + gw] = make_float2(best_v[m], __int_as_float(best_i[m]));
+    }
+}
+
+// Greedy next token from the per-wave candidates + the per-step bookkeeping of a decode batch in ONE small
+// launch (what fill_search_tokens does on the host in the reference between steps,
+// src/generator/batch_generator.cpp:1226-1335): tokens <- argmax, positions / placement / valid_lens += 1.
+// One workgroup per task; candidates are scanned in wave order (= ascending row index), ties keep the
+// lowest index like torch.argmax / the reference's top-1.
+__global__ __launch_bounds__(256) void k_greedy_advance(const float2* ws, int total_waves, int32_t* tokens,
+                                                        int32_t* positions, int32_t* placement, int32_t* valid_lens,
+                                                        int64_t* next_out) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int w = threadIdx.x; w < total_waves; w += 256) {
+        const float2 c = ws[(size_t)b * total_waves + w];
+        const int ci = __float_as_int(c.y);
+        if (ci != 0x7fffffff && (c.x > bv || (c.x == bv && ci < bi) || bi == 0x7fffffff)) {
+            bv = c.x;
+            bi = ci;
+        }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float ov = sv[threadIdx.x + off];
+            const int oi = si[threadIdx.x + off];
+            if (oi != 0x7fffffff && (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x]) ||
+                                     si[threadIdx.x] == 0x7fffffff)) {
+                sv[threadIdx.x] = ov;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int tok = si[0] == 0x7fffffff ? 0 : si[0];
+        if (tokens) tokens[b] = tok;
+        if (next_out) next_out[b] = tok;
+        if (positions) positions[b] += 1;
+        if (placement) placement[b] += 1;
+        if (valid_lens) valid_lens[b] += 1;
     }
 }
 
@@ -131,9 +198,24 @@ int launch(const DenseParams& p, int gx, int gy, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int zl_gemm_nt_small_m(const uint16_t* x, int64_t ldx, const uint16_t* w, const uint16_t* bias, uint16_t* y,
-                                  int64_t m, int64_t n, int64_t k, float alpha, int dtype,
-                                  const uint16_t* norm_weight, float norm_eps, zl_stream_t s) {
+static int dense_waves(int64_t n, int* rows_per_wave, int* gx) {
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    const int waves = cus * 8;  // two 4-wave workgroups per CU
+    *rows_per_wave = (int)((n + waves - 1) / waves);
+    *gx = (int)(((n + *rows_per_wave - 1) / *rows_per_wave + 3) / 4);
+    return *gx * 4;
+}
+
+extern "C" int64_t zl_argmax_workspace_bytes(int64_t m, int64_t n) {
+    if (m <= 0 || n <= 0) return ZL_EINVAL;
+    int rpw, gx;
+    return m * (int64_t)dense_waves(n, &rpw, &gx) * 8;
+}
+
+static int gemm_nt_small_m_impl(const uint16_t* x, int64_t ldx, const uint16_t* w, const uint16_t* bias, uint16_t* y,
+                                int64_t m, int64_t n, int64_t k, float alpha, int dtype, const uint16_t* norm_weight,
+                                float norm_eps, void* argmax_ws, zl_stream_t s) {
     ZL_CHECK_ARG(x && w && y && m > 0 && n > 0 && k > 0, ZL_EINVAL);
     ZL_CHECK_ARG(k % 8 == 0 && ldx % 8 == 0 && ldx >= k, ZL_ESHAPE);
     ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
@@ -147,11 +229,9 @@ extern "C" int zl_gemm_nt_small_m(const uint16_t* x, int64_t ldx, const uint16_t
     while (mt > 1 && (size_t)mt * p.kp * 2 + 64 > 64 * 1024) --mt;
     if (mt == 3) mt = 2;
     const int gy = (int)((m + mt - 1) / mt);
-    int cus = zl_device_cu_count();
-    if (cus <= 0) cus = 256;
-    const int waves = cus * 8;  // two 4-wave workgroups per CU
-    p.rows_per_wave = (int)((n + waves - 1) / waves);
-    const int gx = (int)(((n + p.rows_per_wave - 1) / p.rows_per_wave + 3) / 4);
+    int gx;
+    p.total_waves = dense_waves(n, &p.rows_per_wave, &gx);
+    p.argmax_ws = reinterpret_cast<float2*>(argmax_ws);
     hipStream_t hs = (hipStream_t)s;
 #define ZL_DISPATCH(DT)                                      \
     switch (mt) {                                            \
@@ -162,4 +242,27 @@ extern "C" int zl_gemm_nt_small_m(const uint16_t* x, int64_t ldx, const uint16_t
     if (dtype == ZL_F16) { ZL_DISPATCH(ZL_F16) }
     ZL_DISPATCH(ZL_BF16)
 #undef ZL_DISPATCH
+}
+
+extern "C" int zl_gemm_nt_small_m(const uint16_t* x, int64_t ldx, const uint16_t* w, const uint16_t* bias, uint16_t* y,
+                                  int64_t m, int64_t n, int64_t k, float alpha, int dtype,
+                                  const uint16_t* norm_weight, float norm_eps, zl_stream_t s) {
+    return gemm_nt_small_m_impl(x, ldx, w, bias, y, m, n, k, alpha, dtype, norm_weight, norm_eps, nullptr, s);
+}
+
+extern "C" int zl_gemm_nt_small_m_argmax(const uint16_t* x, int64_t ldx, const uint16_t* w, const uint16_t* bias,
+                                         uint16_t* y, int64_t m, int64_t n, int64_t k, float alpha, int dtype,
+                                         const uint16_t* norm_weight, float norm_eps, void* argmax_ws, zl_stream_t s) {
+    ZL_CHECK_ARG(argmax_ws, ZL_EINVAL);
+    return gemm_nt_small_m_impl(x, ldx, w, bias, y, m, n, k, alpha, dtype, norm_weight, norm_eps, argmax_ws, s);
+}
+
+extern "C" int zl_greedy_advance(const void* argmax_ws, int64_t m, int64_t n, int32_t* tokens, int32_t* positions,
+                                 int32_t* placement, int32_t* valid_lens, int64_t* next_tokens, zl_stream_t s) {
+    ZL_CHECK_ARG(argmax_ws && m > 0 && n > 0, ZL_EINVAL);
+    int rpw, gx;
+    const int tw = dense_waves(n, &rpw, &gx);
+    hipLaunchKernelGGL(k_greedy_advance, dim3((unsigned)m), dim3(256), 0, (hipStream_t)s,
+                       reinterpret_cast<const float2*>(argmax_ws), tw, tokens, positions, placement, valid_lens, next_tokens);
+    return zl_launch_status();
 }

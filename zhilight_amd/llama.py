@@ -302,7 +302,7 @@ class LLaMA:
         return self._bufs[b]
 
     # ---- one decode step -----------------------------------------------------------------------
-    def encode(self, ctx: DynBatchContext, workspace=None):
+    def encode(self, ctx: DynBatchContext, workspace=None, argmax_ws=None):
         """LLaMA::encode for a pure decode ("search") batch: returns logits (B, vocab) fp16."""
         c = self.cfg
         b = ctx.tokens.numel()
@@ -331,7 +331,21 @@ class LLaMA:
                            epilogue=ops.EPI_RESIDUAL)
         alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
         return ops.gemm_nt_small_m(hidden, self.lm_head, alpha=alpha, out=bufs["logits"],
-                                   norm_weight=self.output_layernorm, norm_eps=c.eps)
+                                   norm_weight=self.output_layernorm, norm_eps=c.eps, argmax_ws=argmax_ws)
+
+    def step_greedy(self, ctx: DynBatchContext):
+        """One greedy decode step entirely on the device (graph-capturable): encode, pick the arg-max token
+        inside the lm_head launch + one small reduction, and advance the batch state.  Returns
+        (logits, next_tokens int64)."""
+        b = ctx.tokens.numel()
+        key = ("argmax", b)
+        if key not in self._bufs:
+            self._bufs[key] = (ops.argmax_workspace(b, self.cfg.vocab_size, self.device),
+                               torch.empty(b, dtype=torch.int64, device=self.device))
+        ws, nxt = self._bufs[key]
+        logits = self.encode(ctx, argmax_ws=ws)
+        ops.greedy_advance(ws, b, self.cfg.vocab_size, ctx.tokens, ctx.positions, ctx.placement, ctx.valid_lens, nxt)
+        return logits, nxt
 
     def advance(self, ctx: DynBatchContext, next_tokens: torch.Tensor):
         """Device-side bookkeeping between steps (what fill_search_tokens does on the host in the

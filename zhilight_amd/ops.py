@@ -252,18 +252,40 @@ def w4_linear(x, w, **kw):
     return w4a16_gemm(x, w, **kw)
 
 
-def gemm_nt_small_m(x, weight, bias=None, alpha=1.0, out=None, norm_weight=None, norm_eps=1e-5):
-    """y = T(alpha * x . W^T + bias) -- functions::Gemm(trans_b=True) on the decode path (lm_head)."""
-    _chk_cuda(x, weight, bias, norm_weight)
+def gemm_nt_small_m(x, weight, bias=None, alpha=1.0, out=None, norm_weight=None, norm_eps=1e-5, argmax_ws=None):
+    """y = T(alpha * x . W^T + bias) -- functions::Gemm(trans_b=True) on the decode path (lm_head).
+    With argmax_ws (argmax_workspace) the launch also leaves per-wave greedy candidates for greedy_advance."""
+    _chk_cuda(x, weight, bias, norm_weight, argmax_ws)
     x2 = x.reshape(-1, x.shape[-1])
     m, k = x2.shape
     n = weight.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=x.dtype, device=x.device)
-    check(lib().zl_gemm_nt_small_m(_p(x2), _i(x2.stride(0)), _p(weight), _p(bias), _p(out), _i(m), _i(n), _i(k),
-                                   _f(alpha), C.c_int(_dt(x)), _p(norm_weight), _f(norm_eps), _stream()),
-          "gemm_nt_small_m")
+    if argmax_ws is None:
+        check(lib().zl_gemm_nt_small_m(_p(x2), _i(x2.stride(0)), _p(weight), _p(bias), _p(out), _i(m), _i(n), _i(k),
+                                       _f(alpha), C.c_int(_dt(x)), _p(norm_weight), _f(norm_eps), _stream()),
+              "gemm_nt_small_m")
+    else:
+        check(lib().zl_gemm_nt_small_m_argmax(_p(x2), _i(x2.stride(0)), _p(weight), _p(bias), _p(out), _i(m), _i(n),
+                                              _i(k), _f(alpha), C.c_int(_dt(x)), _p(norm_weight), _f(norm_eps),
+                                              _p(argmax_ws), _stream()), "gemm_nt_small_m_argmax")
     return out
+
+
+def argmax_workspace(m, n, device):
+    nbytes = lib().zl_argmax_workspace_bytes(_i(m), _i(n))
+    if nbytes < 0:
+        check(int(nbytes), "argmax_workspace_bytes")
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+
+def greedy_advance(argmax_ws, m, n, tokens=None, positions=None, placement=None, valid_lens=None, next_tokens=None):
+    """Reduce the lm_head's per-wave candidates to the greedy token of each row and advance the decode
+    batch's device state (tokens <- pick, the three counters += 1); returns next_tokens (int64) if given."""
+    _chk_cuda(argmax_ws, tokens, positions, placement, valid_lens, next_tokens)
+    check(lib().zl_greedy_advance(_p(argmax_ws), _i(m), _i(n), _p(tokens), _p(positions), _p(placement),
+                                  _p(valid_lens), _p(next_tokens), _stream()), "greedy_advance")
+    return next_tokens
 
 
 # --------------------------------------------------------------------------------------------------
