@@ -377,6 +377,31 @@ __global__ void k_decode_attn_combine(const AttnParams p) {
     const int ns = min((elen + p.split_len - 1) / p.split_len, kMaxS);
     const int d = threadIdx.x;
     const float* src = p.ws + (size_t)vh * p.max_splits * (D + 2);
+    if (ns <= 16) {
+        // few splits (batch-1 decode): ONE memory round trip -- the accumulator loads do not wait for the
+        // statistics, both are in flight together; the statistics reach every thread through LDS
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(size_t)min(u, max(ns - 1, 0)) * (D + 2) + d];
+        if (d < ns) {
+            sf[d] = src[(size_t)d * (D + 2) + D];
+            sf[64 + d] = src[(size_t)d * (D + 2) + D + 1];
+        }
+        __syncthreads();
+        float mn = -1e20f;
+        for (int s = 0; s < ns; ++s) mn = fmaxf(mn, sf[s]);
+        float a = 0.f, z = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (u < ns) {
+                const float f = __expf(sf[u] - mn);
+                a = __builtin_fmaf(v[u], f, a);
+                z = __builtin_fmaf(sf[64 + u], f, z);
+            }
+        }
+        p.out[(size_t)vh * D + d] = ZT<DT>::from_f32(a / (z + 1e-20f));
+        return;
+    }
     float mloc = -1e20f;
     for (int s = d; s < ns; s += D) {
         const float ms = src[(size_t)s * (D + 2) + D];
