@@ -270,6 +270,24 @@ int zl_quant_scale_back(const int32_t* c, const float* scale_x, const uint16_t* 
 int zl_quant_back_act_mul(const int32_t* a, const float* a_sx, const uint16_t* a_sy, const int32_t* b,
                           const float* b_sx, const uint16_t* b_sy, uint16_t* out, int64_t m, int64_t n,
                           int act, int dtype, zl_stream_t s);
+/* The other scale-back flavours of the reference, same arithmetic T(float(int32) * sx[row] * sy[col]):
+ *   zl_quant_scale_back3             int8_op::quant_scale_back3 (quant_kernel.cu:311-384): fused qkv result -> q | k | v
+ *   zl_quant_back_element_add_scale  quant_back_element_add_scale (:530-583): T((back + float(b)) * scale)
+ *   zl_quant_back_transpose          quant_back_transpose (:475-527): (B, len_q, H, D) int32 -> (B, H, len_q, D) T
+ *   zl_quant_back_copy_to_buffer     quant_back_copy_to_buffer (:389-469): scatter rows into (B, H, len_buf, D)
+ *                                    buffers at placement[b, t] (NULL = identity, negative = padded row skipped);
+ *                                    strides in elements, 0 for the 3-d (single task) form. */
+int zl_quant_scale_back3(const int32_t* c, const float* scale_x, const uint16_t* scale_y, uint16_t* q, uint16_t* k,
+                         uint16_t* v, int64_t m, int64_t n, int64_t dim_q, int64_t dim_kv, int dtype, zl_stream_t s);
+int zl_quant_back_element_add_scale(const int32_t* a, const float* scale_x, const uint16_t* scale_y, const uint16_t* b,
+                                    float scale, uint16_t* out, int64_t m, int64_t n, int dtype, zl_stream_t s);
+int zl_quant_back_transpose(const int32_t* inp, const float* scale_x, const uint16_t* scale_y, uint16_t* out,
+                            int64_t batch, int64_t len_q, int64_t heads, int64_t dim_head, int dtype, zl_stream_t s);
+int zl_quant_back_copy_to_buffer(const int32_t* src, const float* scale_x, const uint16_t* scale_y,
+                                 const int32_t* placement, uint16_t* dst, int64_t batch, int64_t len_kv, int64_t heads,
+                                 int64_t dim_head, int64_t len_buf, int64_t src_stride, int64_t dst_stride,
+                                 int64_t place_stride, int dtype, zl_stream_t s);
+
 
 #ifdef __cplusplus
 }

@@ -904,3 +904,57 @@ void zlo_quant_back_act_mul(const int32_t* a, const float* asx, const uint16_t* 
             out[r * n + col] = f2T(bb * gate, dtype);
         }
 }
+
+/* quant_scale_back3 (quant_kernel.cu:311-384): the fused qkv GEMM's int32 result split into q | k | v */
+void zlo_quant_scale_back3(const int32_t* c, const float* sx, const uint16_t* sy, uint16_t* q, uint16_t* k,
+                           uint16_t* v, int64_t m, int64_t n, int64_t dim_q, int64_t dim_kv, int dtype) {
+    for (int64_t r = 0; r < m; ++r)
+        for (int64_t col = 0; col < n; ++col) {
+            const uint16_t val = f2T((float)c[r * n + col] * sx[r] * T2f(sy[col], dtype), dtype);
+            if (col < dim_q) q[r * dim_q + col] = val;
+            else if (col < dim_q + dim_kv) k[r * dim_kv + col - dim_q] = val;
+            else v[r * dim_kv + col - dim_q - dim_kv] = val;
+        }
+}
+
+/* quant_back_element_add_scale (quant_kernel.cu:530-545): T((float(a) sx sy + float(b)) * scale) */
+void zlo_quant_back_element_add_scale(const int32_t* a, const float* sx, const uint16_t* sy, const uint16_t* b,
+                                      float scale, uint16_t* out, int64_t m, int64_t n, int dtype) {
+    for (int64_t r = 0; r < m; ++r)
+        for (int64_t col = 0; col < n; ++col) {
+            const float qb = (float)a[r * n + col] * sx[r] * T2f(sy[col], dtype);
+            out[r * n + col] = f2T((qb + T2f(b[r * n + col], dtype)) * scale, dtype);
+        }
+}
+
+/* quant_back_transpose (quant_kernel.cu:475-489): (batch, len_q, heads, d) int32 -> (batch, heads, len_q, d) T */
+void zlo_quant_back_transpose(const int32_t* inp, const float* sx, const uint16_t* sy, uint16_t* out,
+                              int64_t batch, int64_t len_q, int64_t heads, int64_t d, int dtype) {
+    for (int64_t b = 0; b < batch; ++b)
+        for (int64_t t = 0; t < len_q; ++t)
+            for (int64_t h = 0; h < heads; ++h)
+                for (int64_t e = 0; e < d; ++e) {
+                    const float x = sx[b * len_q + t], y = T2f(sy[h * d + e], dtype);
+                    out[((b * heads + h) * len_q + t) * d + e] =
+                        f2T((float)inp[((b * len_q + t) * heads + h) * d + e] * x * y, dtype);
+                }
+}
+
+/* quant_back_copy_to_buffer (quant_kernel.cu:389-415): scatter the scaled-back k/v rows into
+ * (batch, heads, len_buf, d) buffers at placement[b, t] (negative = padded row, skipped; NULL = identity) */
+void zlo_quant_back_copy_to_buffer(const int32_t* src, const float* sx, const uint16_t* sy, const int32_t* placement,
+                                   uint16_t* dst, int64_t batch, int64_t len_kv, int64_t heads, int64_t d,
+                                   int64_t len_buf, int64_t src_stride, int64_t dst_stride, int64_t place_stride,
+                                   int dtype) {
+    for (int64_t b = 0; b < batch; ++b)
+        for (int64_t t = 0; t < len_kv; ++t) {
+            const int64_t pos = placement ? placement[b * place_stride + t] : t;
+            if (pos < 0) continue;
+            for (int64_t h = 0; h < heads; ++h)
+                for (int64_t e = 0; e < d; ++e) {
+                    const float x = sx[b * len_kv + t], y = T2f(sy[h * d + e], dtype);
+                    dst[b * dst_stride + (h * len_buf + pos) * d + e] =
+                        f2T((float)src[b * src_stride + (t * heads + h) * d + e] * x * y, dtype);
+                }
+        }
+}

@@ -139,6 +139,18 @@ void zlo_quant_back_act_mul(const int32_t* a, const float* asx, const uint16_t* 
                             const int32_t* b, const float* bsx, const uint16_t* bsy,
                             uint16_t* out, int64_t m, int64_t n, int act, int dtype);
 
+
+void zlo_quant_scale_back3(const int32_t* c, const float* sx, const uint16_t* sy, uint16_t* q, uint16_t* k,
+                           uint16_t* v, int64_t m, int64_t n, int64_t dim_q, int64_t dim_kv, int dtype);
+void zlo_quant_back_element_add_scale(const int32_t* a, const float* sx, const uint16_t* sy, const uint16_t* b,
+                                      float scale, uint16_t* out, int64_t m, int64_t n, int dtype);
+void zlo_quant_back_transpose(const int32_t* inp, const float* sx, const uint16_t* sy, uint16_t* out,
+                              int64_t batch, int64_t len_q, int64_t heads, int64_t d, int dtype);
+void zlo_quant_back_copy_to_buffer(const int32_t* src, const float* sx, const uint16_t* sy, const int32_t* placement,
+                                   uint16_t* dst, int64_t batch, int64_t len_kv, int64_t heads, int64_t d,
+                                   int64_t len_buf, int64_t src_stride, int64_t dst_stride, int64_t place_stride,
+                                   int dtype);
+
 #ifdef __cplusplus
 }
 #endif

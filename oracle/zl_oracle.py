@@ -358,3 +358,43 @@ def quant_back_act_mul(a, asx, asy, b, bsx, bsy, act="silu", dtype=0):
                                  _p(_c(bsx, np.float32)), _p(_c(bsy, np.uint16)), _p(out), _i(m), _i(n),
                                  C.c_int(0 if act == "silu" else 1), C.c_int(dtype))
     return out
+
+
+def quant_scale_back3(c, sx, sy, dim_q, dim_kv, dtype=0):
+    c = _c(c, np.int32)
+    m, n = c.shape
+    q, k, v = np.empty((m, dim_q), np.uint16), np.empty((m, dim_kv), np.uint16), np.empty((m, dim_kv), np.uint16)
+    lib().zlo_quant_scale_back3(_p(c), _p(_c(sx, np.float32)), _p(_c(sy, np.uint16)), _p(q), _p(k), _p(v), _i(m), _i(n),
+                                _i(dim_q), _i(dim_kv), C.c_int(dtype))
+    return q, k, v
+
+
+def quant_back_element_add_scale(a, sx, sy, b, scale, dtype=0):
+    a = _c(a, np.int32)
+    m, n = a.shape
+    out = np.empty((m, n), np.uint16)
+    lib().zlo_quant_back_element_add_scale(_p(a), _p(_c(sx, np.float32)), _p(_c(sy, np.uint16)), _p(_c(b, np.uint16)),
+                                           C.c_float(scale), _p(out), _i(m), _i(n), C.c_int(dtype))
+    return out
+
+
+def quant_back_transpose(inp, sx, sy, dtype=0):
+    inp = _c(inp, np.int32)
+    b, t, h, d = inp.shape
+    out = np.empty((b, h, t, d), np.uint16)
+    lib().zlo_quant_back_transpose(_p(inp), _p(_c(sx, np.float32)), _p(_c(sy, np.uint16)), _p(out), _i(b), _i(t), _i(h),
+                                   _i(d), C.c_int(dtype))
+    return out
+
+
+def quant_back_copy_to_buffer(src, sx, sy, placement, dst, dtype=0):
+    """src (batch, len_kv, heads, d) int32; dst (batch, heads, len_buf, d) uint16, updated in place."""
+    src = _c(src, np.int32)
+    b, t, h, d = src.shape
+    assert dst.flags["C_CONTIGUOUS"] and dst.dtype == np.uint16
+    len_buf = dst.shape[2]
+    pl = None if placement is None else _c(placement, np.int32)
+    lib().zlo_quant_back_copy_to_buffer(_p(src), _p(_c(sx, np.float32)), _p(_c(sy, np.uint16)), _p(pl), _p(dst), _i(b),
+                                        _i(t), _i(h), _i(d), _i(len_buf), _i(t * h * d), _i(h * len_buf * d),
+                                        _i(0 if pl is None or pl.ndim == 1 else pl.shape[1]), C.c_int(dtype))
+    return dst

@@ -327,3 +327,45 @@ def test_decode_attention_fused_equals_three_kernel_sequence(oracle, dev, neox, 
                                                ops.make_ptr_table(dv2), None, 0.088, max(lens), hkv,
                                                valid_lens=_t(valid, dev), bshd=bshd)
     assert np.array_equal(_bits(got), _bits(ref.view(b, -1)))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_int8_scale_back_variants_bit_exact(oracle, dev, dtype):
+    """quant_scale_back3 / quant_back_element_add_scale / quant_back_transpose / quant_back_copy_to_buffer
+    (src/nn/quant/int8/quant_kernel.cu:311-583): same single-rounding arithmetic as quant_scale_back."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(21)
+    b, t, h, hk, d = 2, 5, 6, 2, 64
+    m, dim_q, dim_kv = b * t, h * d, hk * d
+    n = dim_q + 2 * dim_kv
+    c = rng.integers(-2 ** 20, 2 ** 20, (m, n)).astype(np.int32)
+    sx = np.abs(rng.standard_normal(m)).astype(np.float32) * 0.01 + 1e-4
+    sy = _to_bits(np.abs(rng.standard_normal(n)) * 0.01 + 1e-4, dtype, oracle)
+    gq, gk, gv = ops.quant_scale_back3(_t(c, dev), _t(sx, dev), _tt(sy, dev, dtype), dim_q, dim_kv)
+    rq, rk, rv = oracle.quant_scale_back3(c, sx, sy, dim_q, dim_kv, dtype)
+    assert np.array_equal(_bits(gq), rq) and np.array_equal(_bits(gk), rk) and np.array_equal(_bits(gv), rv)
+    with pytest.raises(ops.ZLError):
+        ops.quant_scale_back3(_t(c, dev), _t(sx, dev), _tt(sy, dev, dtype), dim_q, dim_kv + 1)
+
+    badd = _to_bits(rng.standard_normal((m, n)), dtype, oracle)
+    got = ops.quant_back_element_add_scale(_t(c, dev), _t(sx, dev), _tt(sy, dev, dtype), _tt(badd, dev, dtype), 0.5)
+    assert np.array_equal(_bits(got), oracle.quant_back_element_add_scale(c, sx, sy, badd, 0.5, dtype))
+
+    c4 = c[:, :dim_q].copy().reshape(b, t, h, d)
+    syq = sy[:dim_q].copy()
+    got = ops.quant_back_transpose(_t(c4, dev), _t(sx.reshape(b, t), dev), _tt(syq, dev, dtype))
+    assert np.array_equal(_bits(got), oracle.quant_back_transpose(c4, sx, syq, dtype))
+
+    len_buf = 16
+    place = np.stack([rng.permutation(len_buf)[:t] for _ in range(b)]).astype(np.int32)
+    place[1, 2] = -1                                   # padded row: must be left untouched
+    init = _to_bits(rng.standard_normal((b, h, len_buf, d)), dtype, oracle)
+    ref = oracle.quant_back_copy_to_buffer(c4, sx, syq, place, init.copy(), dtype)
+    dst = _tt(init.copy(), dev, dtype)
+    ops.quant_back_copy_to_buffer(_t(c4, dev), _t(sx.reshape(b, t), dev), _tt(syq, dev, dtype), _t(place, dev), dst)
+    assert np.array_equal(_bits(dst), ref)
+    # 3-d form without placement
+    ref3 = oracle.quant_back_copy_to_buffer(c4[:1], sx[:t], syq, None, init[:1].copy(), dtype)[0]
+    dst3 = _tt(init[0].copy(), dev, dtype)
+    ops.quant_back_copy_to_buffer(_t(c4[0], dev), _t(sx[:t], dev), _tt(syq, dev, dtype), None, dst3)
+    assert np.array_equal(_bits(dst3), ref3)

@@ -30,7 +30,8 @@ SYMBOLS = [
     "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_fused",
     "zl_element_add_scale", "zl_gate_mul", "zl_embedding",
     "zl_quant_calc_scale", "zl_rmsnorm_quant", "zl_int8_gemm_nt", "zl_quant_scale_back",
-    "zl_quant_back_act_mul",
+    "zl_quant_back_act_mul", "zl_quant_scale_back3", "zl_quant_back_element_add_scale", "zl_quant_back_transpose",
+    "zl_quant_back_copy_to_buffer",
 ]
 
 

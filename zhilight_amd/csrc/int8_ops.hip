@@ -131,6 +131,65 @@ __global__ void k_back_act_mul(const int32_t* __restrict__ a, const float* __res
     }
 }
 
+// The remaining scale-back flavours of the reference (quant_kernel.cu:311-567) are the same arithmetic
+// T(float(int32) * sx[row] * sy[col]) with a different destination (and, for one, a fused residual add):
+// one kernel, the destination computed per mode.
+enum { kBack3 = 0, kBackAdd = 1, kBackTranspose = 2, kBackToBuffer = 3 };
+struct BackParams {
+    const int32_t* src;
+    const float* sx;
+    const uint16_t* sy;
+    uint16_t *o0, *o1, *o2;
+    const uint16_t* addend;
+    const int32_t* placement;
+    float scale;
+    int64_t rows, n;                 // logical (row, col) view of src: row = (b, t), col = (head, e)
+    int64_t dim_q, dim_kv;           // kBack3
+    int64_t len_q, heads, d, len_buf, src_stride, dst_stride, place_stride;  // kBackTranspose / kBackToBuffer
+};
+
+template <int DT, int MODE>
+__global__ void k_scale_back_ex(const BackParams p) {
+    const int64_t r = blockIdx.y;
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= p.n) return;
+    if constexpr (MODE == kBack3 || MODE == kBackAdd) {
+        const int64_t pos = r * p.n + col;
+        const float qb = (float)p.src[pos] * p.sx[r] * ZT<DT>::to_f32(p.sy[col]);
+        if constexpr (MODE == kBackAdd) {
+            p.o0[pos] = ZT<DT>::from_f32((qb + ZT<DT>::to_f32(p.addend[pos])) * p.scale);
+        } else {
+            const uint16_t v = ZT<DT>::from_f32(qb);
+            if (col < p.dim_q) p.o0[r * p.dim_q + col] = v;
+            else if (col < p.dim_q + p.dim_kv) p.o1[r * p.dim_kv + col - p.dim_q] = v;
+            else p.o2[r * p.dim_kv + col - p.dim_q - p.dim_kv] = v;
+        }
+    } else {
+        const int64_t b = r / p.len_q, t = r % p.len_q;   // len_q doubles as len_kv for the buffer scatter
+        const int64_t h = col / p.d, e = col % p.d;
+        const float x = p.sx[b * p.len_q + t], y = ZT<DT>::to_f32(p.sy[col]);
+        if constexpr (MODE == kBackTranspose) {
+            const float qb = (float)p.src[((b * p.len_q + t) * p.heads + h) * p.d + e] * x * y;
+            p.o0[((b * p.heads + h) * p.len_q + t) * p.d + e] = ZT<DT>::from_f32(qb);
+        } else {
+            const int64_t pos_buf = p.placement ? p.placement[b * p.place_stride + t] : t;
+            if (pos_buf < 0) return;   // padded row
+            const float qb = (float)p.src[b * p.src_stride + (t * p.heads + h) * p.d + e] * x * y;
+            p.o0[b * p.dst_stride + (h * p.len_buf + pos_buf) * p.d + e] = ZT<DT>::from_f32(qb);
+        }
+    }
+}
+
+template <int MODE>
+int launch_back(const BackParams& p, int dtype, hipStream_t st) {
+    if (p.rows > 65535) return ZL_ELIMIT;
+    dim3 grid((unsigned)((p.n + 255) / 256), (unsigned)p.rows);
+    if (dtype == ZL_F16) hipLaunchKernelGGL((k_scale_back_ex<ZL_F16, MODE>), grid, dim3(256), 0, st, p);
+    else if (dtype == ZL_BF16) hipLaunchKernelGGL((k_scale_back_ex<ZL_BF16, MODE>), grid, dim3(256), 0, st, p);
+    else return ZL_EDTYPE;
+    return zl_launch_status();
+}
+
 }  // namespace
 
 #define ZL_DT_SWITCH(dtype, EXPR_F16, EXPR_BF16) \
@@ -203,6 +262,47 @@ int zl_quant_back_act_mul(const int32_t* a, const float* a_sx, const uint16_t* a
         hipLaunchKernelGGL(k_back_act_mul<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, a, a_sx, a_sy, b, b_sx, b_sy, out, (int)n, act),
         hipLaunchKernelGGL(k_back_act_mul<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, a, a_sx, a_sy, b, b_sx, b_sy, out, (int)n, act))
     return zl_launch_status();
+}
+
+int zl_quant_scale_back3(const int32_t* c, const float* scale_x, const uint16_t* scale_y, uint16_t* q, uint16_t* k,
+                         uint16_t* v, int64_t m, int64_t n, int64_t dim_q, int64_t dim_kv, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(c && scale_x && scale_y && q && k && v && m > 0 && n > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(dim_q >= 0 && dim_kv >= 0 && dim_q + 2 * dim_kv == n, ZL_ESHAPE);
+    BackParams p = {};
+    p.src = c; p.sx = scale_x; p.sy = scale_y; p.o0 = q; p.o1 = k; p.o2 = v;
+    p.rows = m; p.n = n; p.dim_q = dim_q; p.dim_kv = dim_kv;
+    return launch_back<kBack3>(p, dtype, (hipStream_t)s);
+}
+
+int zl_quant_back_element_add_scale(const int32_t* a, const float* scale_x, const uint16_t* scale_y, const uint16_t* b,
+                                    float scale, uint16_t* out, int64_t m, int64_t n, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(a && scale_x && scale_y && b && out && m > 0 && n > 0, ZL_EINVAL);
+    BackParams p = {};
+    p.src = a; p.sx = scale_x; p.sy = scale_y; p.o0 = out; p.addend = b; p.scale = scale;
+    p.rows = m; p.n = n;
+    return launch_back<kBackAdd>(p, dtype, (hipStream_t)s);
+}
+
+int zl_quant_back_transpose(const int32_t* inp, const float* scale_x, const uint16_t* scale_y, uint16_t* out,
+                            int64_t batch, int64_t len_q, int64_t heads, int64_t dim_head, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(inp && scale_x && scale_y && out && batch > 0 && len_q > 0 && heads > 0 && dim_head > 0, ZL_EINVAL);
+    BackParams p = {};
+    p.src = inp; p.sx = scale_x; p.sy = scale_y; p.o0 = out;
+    p.rows = batch * len_q; p.n = heads * dim_head; p.len_q = len_q; p.heads = heads; p.d = dim_head;
+    return launch_back<kBackTranspose>(p, dtype, (hipStream_t)s);
+}
+
+int zl_quant_back_copy_to_buffer(const int32_t* src, const float* scale_x, const uint16_t* scale_y,
+                                 const int32_t* placement, uint16_t* dst, int64_t batch, int64_t len_kv, int64_t heads,
+                                 int64_t dim_head, int64_t len_buf, int64_t src_stride, int64_t dst_stride,
+                                 int64_t place_stride, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(src && scale_x && scale_y && dst && batch > 0 && len_kv > 0 && heads > 0 && dim_head > 0 && len_buf > 0,
+                 ZL_EINVAL);
+    BackParams p = {};
+    p.src = src; p.sx = scale_x; p.sy = scale_y; p.o0 = dst; p.placement = placement;
+    p.rows = batch * len_kv; p.n = heads * dim_head; p.len_q = len_kv; p.heads = heads; p.d = dim_head;
+    p.len_buf = len_buf; p.src_stride = src_stride; p.dst_stride = dst_stride; p.place_stride = place_stride;
+    return launch_back<kBackToBuffer>(p, dtype, (hipStream_t)s);
 }
 
 }  // extern "C"

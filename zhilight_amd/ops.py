@@ -509,3 +509,58 @@ def quant_back_act_mul(a, a_sx, a_sy, b, b_sx, b_sy, act="silu", dtype=torch.flo
                                       C.c_int(0 if act == "silu" else 1), C.c_int(_dt(out)), _stream()),
           "quant_back_act_mul")
     return out
+
+
+def quant_scale_back3(c, scale_x, scale_y, dim_q, dim_kv):
+    """int8_op::quant_scale_back3 (src/nn/quant/int8/quant_kernel.cu:311-384): fused qkv int32 -> q, k, v."""
+    _chk_cuda(c, scale_x, scale_y)
+    m, n = c.shape
+    if dim_q + 2 * dim_kv != n:
+        raise ZLError("Wrong size")
+    mk = lambda w: torch.empty((m, w), dtype=scale_y.dtype, device=c.device)  # noqa: E731
+    q, k, v = mk(dim_q), mk(dim_kv), mk(dim_kv)
+    check(lib().zl_quant_scale_back3(_p(c), _p(scale_x), _p(scale_y), _p(q), _p(k), _p(v), _i(m), _i(n), _i(dim_q),
+                                     _i(dim_kv), C.c_int(_dt(q)), _stream()), "quant_scale_back3")
+    return q, k, v
+
+
+def quant_back_element_add_scale(a, scale_x, scale_y, b, scale=1.0):
+    """int8_op::quant_back_element_add_scale (quant_kernel.cu:530-583): T((back(a) + float(b)) * scale)."""
+    _chk_cuda(a, scale_x, scale_y, b)
+    m, n = a.shape
+    out = torch.empty((m, n), dtype=b.dtype, device=a.device)
+    check(lib().zl_quant_back_element_add_scale(_p(a), _p(scale_x), _p(scale_y), _p(b), _f(scale), _p(out), _i(m), _i(n),
+                                                C.c_int(_dt(out)), _stream()), "quant_back_element_add_scale")
+    return out
+
+
+def quant_back_transpose(h_q, scale_x, scale_y):
+    """int8_op::quant_back_transpose (quant_kernel.cu:475-527): (B, len_q, H, D) int32 -> (B, H, len_q, D)."""
+    _chk_cuda(h_q, scale_x, scale_y)
+    if h_q.dim() != 4:
+        raise ZLError("input is not 4d")
+    b, t, h, d = h_q.shape
+    out = torch.empty((b, h, t, d), dtype=scale_y.dtype, device=h_q.device)
+    check(lib().zl_quant_back_transpose(_p(h_q), _p(scale_x), _p(scale_y), _p(out), _i(b), _i(t), _i(h), _i(d),
+                                        C.c_int(_dt(out)), _stream()), "quant_back_transpose")
+    return out
+
+
+def quant_back_copy_to_buffer(src, scale_x, scale_y, placement, dst):
+    """int8_op::quant_back_copy_to_buffer (quant_kernel.cu:389-469): src (B, len_kv, H, D) or (len_kv, H, D) int32
+    scattered into dst (B, H, len_buf, D) / (H, len_buf, D) at placement (None = identity, < 0 = skipped)."""
+    _chk_cuda(src, scale_x, scale_y, placement, dst)
+    if not ((src.dim() == 3 and dst.dim() == 3) or (src.dim() == 4 and dst.dim() == 4)):
+        raise ZLError("src and dst must be 3/4-dimensional")
+    batch = 1 if src.dim() == 3 else src.shape[0]
+    len_kv, h, d = src.shape[-3:]
+    len_buf = dst.shape[-2]
+    if dst.shape[-3] != h or dst.shape[-1] != d:
+        raise ZLError("dim mismatch")
+    src_stride = 0 if src.dim() == 3 else src.stride(0)
+    dst_stride = 0 if dst.dim() == 3 else dst.stride(0)
+    place_stride = 0 if placement is None or placement.dim() == 1 else placement.stride(0)
+    check(lib().zl_quant_back_copy_to_buffer(_p(src), _p(scale_x), _p(scale_y), _p(placement), _p(dst), _i(batch),
+                                             _i(len_kv), _i(h), _i(d), _i(len_buf), _i(src_stride), _i(dst_stride),
+                                             _i(place_stride), C.c_int(_dt(dst)), _stream()), "quant_back_copy_to_buffer")
+    return dst
