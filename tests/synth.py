@@ -28,3 +28,22 @@ def ulp_diff_f16(a_bits, b_bits):
         u = u.astype(np.int32)
         return np.where(u & 0x8000, 0x8000 - (u & 0x7FFF), u + 0x8000)  # -0 == +0
     return np.abs(key(np.asarray(a_bits)) - key(np.asarray(b_bits)))
+
+
+AWQ_PACK_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)   # AutoAWQ: nibble i of a packed word holds column 8c + order[i]
+
+
+def awq_hf(rng, k, n, g):
+    """An AWQ ("gemm" version) checkpoint triple and the integers behind it: qweight (K, N/8) int32, qzeros
+    (K/G, N/8) int32 (zero points as used, no -1), scales (K/G, N) fp16 bits; plus q (K,N) and z (K/G,N)."""
+    q = rng.integers(0, 16, size=(k, n), dtype=np.uint32)
+    ng = k // g
+    z = rng.integers(0, 16, size=(ng, n), dtype=np.uint32)
+
+    def pack(a):
+        out = np.zeros((a.shape[0], n // 8), np.uint32)
+        for i, o in enumerate(AWQ_PACK_ORDER):
+            out |= a[:, o::8] << np.uint32(4 * i)
+        return out
+    scales = (np.abs(rng.standard_normal((ng, n))) * 0.02 / 8 + 1e-4).astype(np.float16)
+    return pack(q), pack(z), scales.view(np.uint16), q, z

@@ -254,3 +254,35 @@ def test_mfma_gemm_fused_norm_residual_silu(oracle, dev):
     ref = oracle.u2h(oracle.silu_mul(oracle.h2u(ge), oracle.h2u(ue))).astype(np.float64)
     got = _np(ops.w4a16_gemm_mfma(_t(x, dev), w, epilogue=ops.EPI_SILU_MUL)).astype(np.float64)
     assert np.abs(got - ref).max() <= 2.0 ** -9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("algo", ["mfma", "exact"])
+def test_awq_checkpoint_linear(oracle, dev, algo, monkeypatch):
+    """An AWQ checkpoint through the AWQ-as-exllama load route (Int4GPTQ is_awq, linear.cpp:1139-1143):
+    the linear equals x . ((q - z) * s)^T from the integers the checkpoint was packed from."""
+    from zhilight_amd import ops
+    from zhilight_amd.llama import Int4GPTQ, QuantConfig
+    monkeypatch.setenv("ZL_W4_ALGO", algo)
+    rng = np.random.default_rng(77)
+    k, n, g, m = 1024, 384, 128, 3
+    qw, qz, sc, q, z = synth.awq_hf(rng, k, n, g)
+    quant = QuantConfig.from_hf(dict(quant_method="awq", bits=4, group_size=g, zero_point=True, version="gemm"))
+    lin = Int4GPTQ("l", k, n, quant)
+    lin.load_state_dict({"l.qweight": torch.from_numpy(qw.view(np.int32)), "l.qzeros": torch.from_numpy(qz.view(np.int32)),
+                         "l.scales": torch.from_numpy(sc.view(np.float16))}, "l", dev)
+    # the load transform equals the oracle's restatement of the reference's
+    tr = lambda a: np.ascontiguousarray(a.T)   # functions::Transpose of a 2-d tensor  # noqa: E731
+    km_ref = (tr(oracle.awq_shuffle(qw, True)), tr(oracle.gptq_q4_to_q8(oracle.awq_un_shuffle(qz))), tr(sc))
+    assert np.array_equal(_np(lin.km[0]).view(np.uint32), km_ref[0])
+    assert np.array_equal(_np(lin.km[1]), km_ref[1])
+    assert np.array_equal(_np(lin.km[2]).view(np.uint16), km_ref[2])
+    lin.pack()
+    x = synth.act(rng, m, k)
+    got = _np(lin.forward(_t(x, dev))).astype(np.float64)
+    w = (q.astype(np.float64) - np.repeat(z, g, axis=0)) * np.repeat(sc.view(np.float16).astype(np.float64), g, axis=0)
+    ref = x.astype(np.float64) @ w                       # (m, n)
+    rms = np.sqrt((ref ** 2).mean())
+    assert np.abs(got - ref).max() <= 2.0 ** -10 * np.abs(ref).max() + 4e-3 * rms
+    if algo == "exact":   # and bit for bit the reference-faithful kernel arithmetic on the converted operands
+        r = oracle.gptq_gemm_k_major(oracle.h2u(x), *km_ref)
+        assert np.array_equal(_np(lin.forward(_t(x, dev))).view(np.uint16), r)

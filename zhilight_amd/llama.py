@@ -72,20 +72,34 @@ class ModelConfig:
 
 @dataclass
 class QuantConfig:
-    """model::QuantConfig (src/model/model_config.hpp:132-177); quant_type 5 = GPTQ W4A16 k-major."""
+    """model::QuantConfig (src/model/model_config.hpp:132-177); quant_type 5 = GPTQ W4A16 k-major.
+    `awq` marks an AWQ checkpoint taken through the reference's AWQ_USE_EXLLAMA route
+    (Int4GPTQ with is_awq, src/nn/linear/linear.cpp:694-698, 1139-1143): the tensors are converted to the
+    same k-major operands at load, the kernels are the GPTQ ones."""
     quant_type: int = 5
     group_size: int = 128
     sym: bool = False
     act_order: bool = False
+    awq: bool = False
 
     @classmethod
     def from_hf(cls, qc: dict):
-        """QuantConfig.adapt_hf_config (zhilight/quant.py:35-80): gptq -> type 5."""
-        if qc.get("quant_method", "gptq") != "gptq" or qc.get("bits", 4) != 4:
-            raise ops.ZLError("only GPTQ 4-bit checkpoints are supported on this path")
+        """QuantConfig.adapt_hf_config (zhilight/quant.py:35-88): gptq -> type 5; awq -> type 5 with the AWQ
+        load transform (what the reference does under AWQ_USE_EXLLAMA=1, its faster decode route)."""
+        method = qc.get("quant_method", "gptq")
+        if method not in ("gptq", "awq"):
+            raise ops.ZLError(f"Unsupported quant_method {method}")
+        if qc.get("bits", 4) != 4:
+            raise ops.ZLError("Only bits=4 is supported")
+        if qc.get("is_marlin_format", False):
+            raise ops.ZLError(f"Unsupported Marlin {method}")
         if qc.get("desc_act", False):
             raise ops.ZLError("desc_act (act-order) checkpoints need the legacy exllama path: not implemented")
-        return cls(5, qc.get("group_size", 128), qc.get("sym", False), False)
+        if method == "awq":
+            if not qc.get("zero_point", True):
+                raise ops.ZLError("AWQ checkpoints without zero points are not supported")
+            return cls(5, qc.get("group_size", 128), False, False, True)
+        return cls(5, qc.get("group_size", 128), qc.get("sym", False), False, False)
 
 
 def hf_name_to_internal(name: str) -> str:
@@ -137,11 +151,20 @@ class Int4GPTQ:
         qw = _dev_t(sd[prefix + ".qweight"], device, torch.int32)
         qz = _dev_t(sd[prefix + ".qzeros"], device, torch.int32)
         sc = _dev_t(sd[prefix + ".scales"], device, torch.float16)
-        if qw.shape != (self.dim_in // 8, self.dim_out):
-            raise ops.ZLError(f"{prefix}: qweight shape {tuple(qw.shape)} != {(self.dim_in // 8, self.dim_out)}")
-        # Int4GPTQ::preprocess_weight + transpose_weight: shuffle, +1 zeros, nibble->byte, transposes
-        qw = ops.transpose_2d(ops.gptq_shuffle(qw.clone()))
-        qz = ops.transpose_2d(ops.q4_to_q8(ops.increase_zero(qz.clone())))
+        if self.quant.awq:
+            # AWQ on disk: qweight (K, N/8) with the [0,4,1,5,2,6,3,7] nibble order, zeros stored as they are
+            # used (no +1).  Int4GPTQ::preprocess_weight, is_awq branch: shuffle_awq -> (K/8, N) exllama
+            # words, un_shuffle of the zero nibbles; from there on it is the GPTQ operand set.
+            if qw.shape != (self.dim_in, self.dim_out // 8):
+                raise ops.ZLError(f"{prefix}: qweight shape {tuple(qw.shape)} != {(self.dim_in, self.dim_out // 8)}")
+            qw = ops.transpose_2d(ops.shuffle_awq(qw, True))
+            qz = ops.transpose_2d(ops.q4_to_q8(ops.awq_un_shuffle(qz.clone())))
+        else:
+            if qw.shape != (self.dim_in // 8, self.dim_out):
+                raise ops.ZLError(f"{prefix}: qweight shape {tuple(qw.shape)} != {(self.dim_in // 8, self.dim_out)}")
+            # Int4GPTQ::preprocess_weight + transpose_weight: shuffle, +1 zeros, nibble->byte, transposes
+            qw = ops.transpose_2d(ops.gptq_shuffle(qw.clone()))
+            qz = ops.transpose_2d(ops.q4_to_q8(ops.increase_zero(qz.clone())))
         self.km = (qw, qz, ops.transpose_2d(sc))
         if prefix + ".bias" in sd:
             self.bias = _dev_t(sd[prefix + ".bias"], device, torch.float16)
