@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (marks the result invalid)")
+    ap.add_argument("--no-ttft", action="store_true", help="skip the prompt-encode (TTFT) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,6 +112,26 @@ def main():
     len_buf = (seq + args.warmup + args.steps + 4 + 63) // 64 * 64
     ctx = model.new_context(batch, len_buf, seq, fill_random=True)
     ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
+
+    # ---- TTFT leg (rank 0, reported next to the decode metric): encode a `seq`-token prompt of one task
+    # (M-tiled W4A16 GEMMs, causal attention) and pick the first token.  HIP events around eager launches.
+    ttft_ms = None
+    if rank == 0 and not args.no_ttft:
+        pctx = model.new_context(1, len_buf, 0)
+        prompt = torch.randint(0, cfg.vocab_size, (seq,), device=dev, dtype=torch.int32)
+        model.prefill(pctx, 0, prompt)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record()
+        for _ in range(reps):
+            model.prefill(pctx, 0, prompt)
+        e1.record()
+        torch.cuda.synchronize()
+        ttft_ms = e0.elapsed_time(e1) / reps
+        del pctx
+        model._bufs = {k: v for k, v in model._bufs.items() if not (isinstance(k, tuple) and k[0] == "prefill")}
+        torch.cuda.empty_cache()
 
     def step():
         model.step_greedy(ctx)   # encode + greedy pick + advance of the batch state, all on the device
@@ -213,6 +234,8 @@ def main():
                        "global_batch": world * batch, "seq_len": seq, "valid": not args.layers,
                        "w4_algo": "mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "exact"},
             "per_gpu_tokens_per_s": round(value / world, 2),
+            "ttft_ms": None if ttft_ms is None else round(ttft_ms, 3),
+            "ttft_note": "prompt of seq tokens, one task, first greedy token; eager launches, HIP events, mean of 3",
             "step_hbm_roofline_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
         }

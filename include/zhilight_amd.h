@@ -142,6 +142,14 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx,
                        const uint16_t* bias, const uint16_t* residual, uint16_t* y,
                        int64_t m, int64_t n, int64_t k, int64_t group_size,
                        const uint16_t* norm_weight, float norm_eps, int epilogue, zl_stream_t s);
+/* M > 16 flavour on the same ZLW4M operands (prefill chunks, decode batches > 16): W16 = rn16(rn16(q - z) * s)
+ * formed in registers, fp32-accumulating MFMA GEMM -- bit for bit the weights dequant_k_major writes out for
+ * the reference's M > 40 branch (q_gemm_k_major.cu:843-952, 1083-1100) without materialising them; K must be
+ * a multiple of 128; no norm prologue.  zl_w4a16_gemm_mfma forwards to it for m > 16. */
+int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
+                        const uint16_t* bias, const uint16_t* residual, uint16_t* y,
+                        int64_t m, int64_t n, int64_t k, int64_t group_size, int epilogue, zl_stream_t s);
+
 
 /* ------------------------------------------------------------------------------------------------
  * a21  Dense NT GEMM for small M (lm_head, NormalLinear decode): y = T(alpha * x . W^T + bias),

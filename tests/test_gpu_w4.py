@@ -208,18 +208,31 @@ def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=Fal
                             norm_weight=None if nw is None else _t(nw, dev), norm_eps=1e-5,
                             epilogue=ops.EPI_RESIDUAL if residual else 0)
     got = _np(y).astype(np.float64)
+    # m > 16 without a fused norm runs the M-tiled kernel: it multiplies with W16 = rn16(rn16(q - z) * s), the
+    # matrix the reference's M > 40 branch dequantises (dequant_k_major), so THAT product is its exact value
+    tiled = m > 16 and not norm
+    w16 = oracle.gptq_dequant_k_major(*km)
+    ref40 = oracle.gemm_nt(xin, w16, None if b is None else oracle.h2u(b), exact=True)
+    lin = np.zeros_like(exact)
     if residual:
+        # the linear output is rounded to fp16 BEFORE the residual add: a 1-ulp flip of it (fp32 noise on a
+        # rounding tie) survives the add, so the bound carries |linear| as well as |sum|
+        lin = np.abs(exact)
         exact = res.astype(np.float64) + exact.astype(np.float16).astype(np.float64)
+        ref40 = res.astype(np.float64) + ref40.astype(np.float16).astype(np.float64)
     rms = np.sqrt((exact ** 2).mean())
     # fp16 output rounding (2^-11 relative) + fp32 accumulation noise; with the fused norm the normalised
     # input may differ by 1 fp16 ulp on a few elements (block-sum association)
-    tol = 2.0 ** -10 * np.abs(exact) + (3e-4 if norm else 2e-5) * rms
-    assert (np.abs(got - exact) <= tol).all(), float((np.abs(got - exact) / rms).max())
+    tight = 2.0 ** -10 * (np.abs(exact) + lin) + (3e-4 if norm else 2e-5) * rms
+    loose = 2.0 ** -10 * (np.abs(exact) + lin) + 1.5e-3 * rms   # + the W16 weight rounding between the two flavours
+    d_exact, d_40 = np.abs(got - exact), np.abs(got - ref40)
+    if tiled:
+        assert (d_40 <= 2.0 ** -10 * (np.abs(ref40) + lin) + 2e-5 * rms).all(), float((d_40 / rms).max())
+        assert (d_exact <= loose).all(), float((d_exact / rms).max())
+    else:
+        assert (d_exact <= tight).all(), float((d_exact / rms).max())
     if not (norm or residual):
-        # the reference's M > 40 branch: W16 = rn16(rn16(q - z) * s), fp32-accumulating GEMM
-        w16 = oracle.gptq_dequant_k_major(*km)
-        ref40 = oracle.gemm_nt(oracle.h2u(x), w16, None if b is None else oracle.h2u(b), exact=True)
-        assert (np.abs(got - ref40) <= 2.0 ** -10 * np.abs(ref40) + 1.5e-3 * rms).all()  # fp16 output rounding + W16 weight rounding
+        assert (d_40 <= 2.0 ** -10 * np.abs(ref40) + 1.5e-3 * rms).all()
         # and the warp-reduce kernel's own noise level vs both
         r = oracle.u2h(oracle.gptq_gemm_k_major(oracle.h2u(x), *km, bias=None if b is None else oracle.h2u(b))).astype(np.float64)
         assert np.abs(got - r).max() <= 6e-3 * rms                                     # the warp-reduce kernel's fp16 noise
@@ -234,6 +247,33 @@ def test_mfma_gemm_small(oracle, dev, m):
 def test_mfma_gemm_shapes(oracle, dev, k, n):
     _check_mfma(oracle, dev, k, n, 1, seed=30)
     _check_mfma(oracle, dev, k, n, 9, seed=31, bias=True)
+
+
+@pytest.mark.parametrize("m,k,n", [(17, 1024, 264), (33, 2048, 40), (64, 4096, 512), (100, 1152 + 128, 1000), (257, 2048, 384)])
+def test_tiled_gemm_shapes(oracle, dev, m, k, n):
+    """M > 16: the M-tiled kernel (w4_gemm_tiled.hip) incl. ragged M / N tails, bias and residual epilogues."""
+    _check_mfma(oracle, dev, k, n, m, seed=50 + m)
+    _check_mfma(oracle, dev, k, n, m, seed=51 + m, bias=True)
+    _check_mfma(oracle, dev, k, n, m, seed=52 + m, residual=True)
+
+
+def test_tiled_gemm_silu_mul(oracle, dev):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(61)
+    k, nff, g, m = 1024, 200, 128, 70
+    qw1, qz1, sc1 = synth.gptq_hf(rng, k, nff, g)
+    qw2, qz2, sc2 = synth.gptq_hf(rng, k, nff, g)
+    km1, km2 = oracle.gptq_prepare_k_major(qw1, qz1, sc1, g), oracle.gptq_prepare_k_major(qw2, qz2, sc2, g)
+    cat = [np.concatenate([a, b], axis=0) for a, b in zip(km1, km2)]
+    w = ops.W4MWeight.from_k_major(_t(cat[0].view(np.int32), dev), _t(cat[1], dev), _t(cat[2], dev, torch.float16), g,
+                                   row_interleave=True)
+    x = synth.act(rng, m, k)
+    ge = oracle.gemm_nt(oracle.h2u(x), oracle.gptq_dequant_k_major(*km1), exact=True).astype(np.float16)
+    ue = oracle.gemm_nt(oracle.h2u(x), oracle.gptq_dequant_k_major(*km2), exact=True).astype(np.float16)
+    ref = oracle.u2h(oracle.silu_mul(oracle.h2u(ge), oracle.h2u(ue))).astype(np.float64)
+    got = _np(ops.w4a16_gemm_mfma(_t(x, dev), w, epilogue=ops.EPI_SILU_MUL)).astype(np.float64)
+    assert got.shape == (m, nff)
+    assert np.abs(got - ref).max() <= 2.0 ** -9 * max(1.0, np.abs(ref).max())
 
 
 def test_mfma_gemm_fused_norm_residual_silu(oracle, dev):

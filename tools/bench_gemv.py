@@ -41,8 +41,8 @@ def main():
         x = torch.randn(a.m, k, dtype=torch.float16, device=dev)
         out = torch.empty(a.m, n // 2 if epi else n, dtype=torch.float16, device=dev)
         for variant in ("plain", "norm"):
-            if variant == "norm" and k > 8192:
-                continue  # the model never fuses a norm into the down projection
+            if variant == "norm" and (k > 8192 or a.m > 16):
+                continue  # the model never fuses a norm into the down projection / into multi-pass GEMMs
             kw = dict(norm_weight=nw[:k], norm_eps=1e-5) if variant == "norm" else {}
             for w in ws[name]:
                 gemm(x, w, out=out, epilogue=epi, **kw)
@@ -62,11 +62,15 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.iters
             b = alg_bytes(n, k, 128, a.m)
-            print(f"{name:8s} {variant:5s} M={a.m} N={n} K={k}: {us:8.2f} us/launch  {b / us / 1e3:8.1f} GB/s  ({b / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)")
+            tf = 2.0 * a.m * n * k / us / 1e6
+            print(f"{name:8s} {variant:5s} M={a.m} N={n} K={k}: {us:8.2f} us/launch  {b / us / 1e3:8.1f} GB/s  ({b / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)"
+                  + (f"  {tf:7.1f} TFLOP/s ({tf / 2500 * 100:4.1f}% of 2.5 PF)" if a.m >= 32 else ""))
             if variant == "plain":
                 tot_t += us
                 tot_b += b
     print(f"layer total (plain): {tot_t:.2f} us, {tot_b / tot_t / 1e3:.1f} GB/s ({tot_b / tot_t / 1e3 / 80:.1f}% of 8 TB/s), x32 layers = {tot_t * 32:.0f} us")
+    if a.m > 64:
+        return
     # lm_head
     w = [torch.randn(128256, 4096, dtype=torch.float16, device=dev) * 0.02 for _ in range(2)]
     x = torch.randn(a.m, 4096, dtype=torch.float16, device=dev)

@@ -1,0 +1,265 @@
+// w4_gemm_tiled.hip -- W4A16 GEMM for M > 16 (prefill chunks, large decode batches) on the matrix cores.
+//
+// Reference: the M > 40 branch of gptq_gemm_k_major (src/nn/quant/gptq/q_gemm_k_major.cu:1083-1100):
+// dequant_k_major writes the WHOLE fp16 weight matrix W16 = rn16(rn16(q - z) * s) to memory (:843-952,
+// 2 bytes per weight, every call) and hands it to cuBLAS (fp32 accumulate).  Here the same W16 values are
+// produced in registers right in front of the MFMA that consumes them -- the 4-bit weights are read once
+// per M-tile and nothing is materialised:
+//   y[m,n] = half( sum_k x[m,k] * W16[n,k] (+ bias[n]) ),  products exact in fp32, fp32 accumulation.
+// (The M <= 16 kernel applies the scale to fp32 group sums instead; like in the reference the two row
+// ranges therefore round differently.)
+//
+// Tiling (ZLW4M layout, see w4_mfma.hip): workgroup = 4 waves = BM x 128 outputs, wave = BM x 32 (two
+// 16-row weight tiles share every activation fragment read from LDS); K advances in 128-k chunks = one
+// ZLW4M item per weight tile; the activation chunk (BM x 128 halfs) is double-buffered in LDS with padded
+// rows (conflict-free ds_read_b128), global -> registers one chunk ahead; the weight items ride an 8-slot
+// ring of non-temporal buffer loads (4 chunks ahead).  Per chunk and wave: 2 x 52 VALU ops of dequant feed
+// 2 x 4 x (BM/16) MFMAs (v_mfma_f32_16x16x32_f16) on 2 x BM/16 independent accumulators.
+#include <stdlib.h>
+#include "zl_common.h"
+
+namespace {
+
+constexpr int kWavesT = 4;
+constexpr int kThreadsT = kWavesT * 64;
+constexpr int kBN = kWavesT * 32;
+constexpr int kRingT = 8;          // items (2 per chunk)
+constexpr int kRowHalfs = 128 + 8; // padded LDS row
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
+
+struct TiledParams {
+    const uint16_t* x;
+    int64_t ldx;
+    const uint4* qw;
+    const uint32_t* meta;
+    uint32_t qw_bytes, meta_bytes;
+    const uint16_t* bias;
+    const uint16_t* residual;
+    uint16_t* y;
+    int m, n, k;
+    int groups;      // k / 128 chunks
+    int tiles;       // ceil(n / 16)
+    int epi, ld_out;
+};
+
+__device__ __forceinline__ uint32_t and_or_t(uint32_t w, uint32_t mask_s, uint32_t magic_v) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mask_s), "v"(magic_v));
+    return r;
+}
+
+// word -> 8 x fp16 rn16((q - z) * s): exact (q - z), one rounding in the multiply == dequant_k_major
+__device__ __forceinline__ h8 dequant_scaled(uint32_t w, hv2 z1, hv2 z16, hv2 s2, uint32_t mask_lo, uint32_t mask_hi,
+                                             uint32_t magic) {
+    const hv2 one16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    const hv2 d0 = (__builtin_bit_cast(hv2, and_or_t(w, mask_lo, magic)) + z1) * s2;
+    const hv2 d1 = __builtin_elementwise_fma(__builtin_bit_cast(hv2, and_or_t(w, mask_hi, magic)), one16, z16) * s2;
+    const uint32_t wb = w >> 8;
+    const hv2 d2 = (__builtin_bit_cast(hv2, and_or_t(wb, mask_lo, magic)) + z1) * s2;
+    const hv2 d3 = __builtin_elementwise_fma(__builtin_bit_cast(hv2, and_or_t(wb, mask_hi, magic)), one16, z16) * s2;
+    h8 a;
+    a[0] = d0.x; a[1] = d0.y; a[2] = d1.x; a[3] = d1.y; a[4] = d2.x; a[5] = d2.y; a[6] = d3.x; a[7] = d3.y;
+    return a;
+}
+
+__device__ __forceinline__ float silu_t(float x) { return x / (1.0f + expf(-x)); }
+
+template <int BM>
+__global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledParams p) {
+    constexpr int RB = BM / 16;               // 16-row blocks of the M tile
+    constexpr int XR = BM / 16;               // uint4 per thread per x chunk (16 threads x 16 B per row)
+    __shared__ __attribute__((aligned(16))) uint16_t xs[2][BM * kRowHalfs];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrow = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * BM;
+    const int tile0 = blockIdx.x * (kBN / 16) + wave * 2;   // this wave's two 16-row weight tiles
+    const int G = p.groups;
+
+    // ---- weight ring: item (j, g) of this wave = tile (tile0 + j), chunk g
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
+    const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)nrow * 4u;
+    const int t0c = tile0 < p.tiles ? tile0 : p.tiles - 1, t1c = tile0 + 1 < p.tiles ? tile0 + 1 : p.tiles - 1;
+    const uint32_t base0 = (uint32_t)t0c * (uint32_t)G, base1 = (uint32_t)t1c * (uint32_t)G;
+    uint4 wq[kRingT];
+    uint32_t mt[kRingT];
+    int iss_g = 0;                            // next chunk to issue (both tiles)
+    auto issue_pair = [&](int slot0) {
+        const uint32_t g = (uint32_t)(iss_g < G ? iss_g : G - 1);
+        const uint32_t it0 = base0 + g, it1 = base1 + g;
+        wq[slot0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off, it0 * 1024u, 2));
+        mt[slot0] = __builtin_amdgcn_raw_buffer_load_b32(rm, m_off, it0 * 64u, 2);
+        wq[slot0 + 1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off, it1 * 1024u, 2));
+        mt[slot0 + 1] = __builtin_amdgcn_raw_buffer_load_b32(rm, m_off, it1 * 64u, 2);
+        ++iss_g;
+    };
+
+    // ---- activation chunk loads: thread -> (row = tid / 16 + 16 r, 16-byte column tid % 16)
+    const int xrow = threadIdx.x >> 4, xcol = (threadIdx.x & 15) * 8;
+    uint4 xr[XR];
+    auto load_x = [&](int g) {
+        const int gc = g < G ? g : G - 1;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int row = m0 + xrow + 16 * r;
+            const int rc = row < p.m ? row : p.m - 1;
+            xr[r] = *reinterpret_cast<const uint4*>(p.x + (size_t)rc * p.ldx + (size_t)gc * 128 + xcol);
+            if (row >= p.m) xr[r] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < XR; ++r)
+            *reinterpret_cast<uint4*>(&xs[buf][(xrow + 16 * r) * kRowHalfs + xcol]) = xr[r];
+    };
+
+    load_x(0);
+#pragma unroll
+    for (int s = 0; s < kRingT; s += 2) {
+        issue_pair(s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    store_x(0);
+    load_x(1);
+    __syncthreads();
+
+    const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
+    const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(0x00f000f0u);
+    uint32_t magic = 0x64006400u;
+    asm volatile("" : "+v"(magic));
+    const hv2 c960 = {(_Float16)960.f, (_Float16)960.f};
+
+    f4 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        acc[rb][0] = (f4){0.f, 0.f, 0.f, 0.f};
+        acc[rb][1] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // one K chunk: dequantise the two weight items, refill their ring slots, run the MFMAs of all row blocks
+    auto chunk = [&](int slot0, int buf) {
+        h8 bfr[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t mw = mt[slot0 + j];
+            const hv2 z1 = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(mw, mw, 0x03020302u));
+            const hv2 z16 = z1 + c960;
+            const hv2 s2 = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(mw, mw, 0x01000100u));
+            const uint32_t wds[4] = {wq[slot0 + j].x, wq[slot0 + j].y, wq[slot0 + j].z, wq[slot0 + j].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bfr[j][t] = dequant_scaled(wds[t], z1, z16, s2, mask_lo, mask_hi, magic);
+        }
+        issue_pair(slot0);
+        const uint16_t* xb = &xs[buf][nrow * kRowHalfs + kq * 8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(xb + rb * 16 * kRowHalfs + t * 32));
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bfr[0][t], acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bfr[1][t], acc[rb][1], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: 4 chunks per turn of the ring (static slot indices)
+    int g = 0;
+#pragma unroll 1
+    for (; g < G; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (g + u < G) {                  // workgroup-uniform
+                chunk(2 * u, (g + u) & 1);
+                store_x((g + u + 1) & 1);     // chunk g+u+1 (loaded one step ago) -> the other buffer
+                load_x(g + u + 2);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: C fragment = column n (lane & 15), rows 4 kq + i of each 16-row block
+    const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = (tile0 + j) * 16 + nrow;
+        const float b = ((p.epi & ZL_EPI_BIAS) && p.bias && n < p.n) ? (float)__builtin_bit_cast(_Float16, p.bias[n]) : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + rb * 16 + 4 * kq + i;
+                float v = acc[rb][j][i];
+                if (!silu) {
+                    if (row < p.m && n < p.n) {
+                        const size_t o = (size_t)row * p.ld_out + n;
+                        float ov;
+                        if (p.epi & ZL_EPI_ADD_C) ov = ((float)__builtin_bit_cast(_Float16, p.y[o]) + v) + b;
+                        else ov = v + b;
+                        _Float16 y16 = zl_f32_to_f16(ov);
+                        if (p.epi & ZL_EPI_RESIDUAL)
+                            y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, p.residual[o]) + (float)y16);
+                        p.y[o] = __builtin_bit_cast(uint16_t, y16);
+                    }
+                } else {
+                    // rows of the packed matrix interleave gate (even n) and up (odd n): partner = lane ^ 1
+                    v += b;
+                    const float other = __shfl_xor(v, 1, 64);
+                    if ((nrow & 1) == 0 && row < p.m && n + 1 < p.n) {
+                        float gt = v, up = other, ov;
+                        if (p.epi & ZL_EPI_SILU_MUL) {
+                            gt = (float)zl_f32_to_f16(gt);
+                            up = (float)zl_f32_to_f16(up);
+                            ov = silu_t(gt) * up;
+                        } else {
+                            ov = (float)((double)gt / (1.0 + (double)expf(-gt))) * up;
+                        }
+                        p.y[(size_t)row * p.ld_out + n / 2] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(ov));
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// called by zl_w4a16_gemm_mfma for m > 16 (same operands)
+extern "C" int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
+                                   const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n,
+                                   int64_t k, int64_t group_size, int epilogue, zl_stream_t s) {
+    ZL_CHECK_ARG(x && qw && meta && y && m > 0 && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(ldx >= k && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && k % 128 == 0, ZL_ESHAPE);
+    ZL_CHECK_ARG(!(epilogue & ZL_EPI_RESIDUAL) || residual, ZL_EINVAL);
+    zl_w4_layout_t L;
+    int st = zl_w4m_layout(n, k, group_size, &L);
+    if (st) return st;
+    const bool silu = epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32);
+    ZL_CHECK_ARG(!silu || n % 2 == 0, ZL_ESHAPE);
+    if (L.qw_bytes >= (int64_t)1 << 32) return ZL_ELIMIT;
+    TiledParams p;
+    p.x = x; p.ldx = ldx;
+    p.qw = reinterpret_cast<const uint4*>(qw);
+    p.meta = meta;
+    p.qw_bytes = (uint32_t)L.qw_bytes; p.meta_bytes = (uint32_t)L.scales_bytes;
+    p.bias = bias; p.residual = residual; p.y = y;
+    p.m = (int)m; p.n = (int)n; p.k = (int)k;
+    p.groups = (int)(k / 128);
+    p.tiles = (int)(L.np / 16);
+    p.epi = epilogue;
+    p.ld_out = (int)(silu ? n / 2 : n);
+    const int gx = (int)((L.np + kBN - 1) / kBN);
+    hipStream_t hs = (hipStream_t)s;
+    if (m <= 32) {
+        ZL_CHECK_ARG((m + 31) / 32 <= 65535, ZL_ELIMIT);
+        hipLaunchKernelGGL(k_w4a16_gemm_tiled<32>, dim3(gx, (unsigned)((m + 31) / 32)), dim3(kThreadsT), 0, hs, p);
+    } else {
+        ZL_CHECK_ARG((m + 63) / 64 <= 65535, ZL_ELIMIT);
+        hipLaunchKernelGGL(k_w4a16_gemm_tiled<64>, dim3(gx, (unsigned)((m + 63) / 64)), dim3(kThreadsT), 0, hs, p);
+    }
+    return zl_launch_status();
+}

@@ -333,10 +333,7 @@ class LLaMA:
         if workspace is None:
             workspace = self._bufs.setdefault(("ws", b, ctx.max_len_buf),
                                               ops.decode_attn_workspace(b, 1, c.num_heads, c.dim_head, ctx.max_len_buf, self.device))
-        llama3 = None
-        rs = c.rope_scaling
-        if rs and rs.get("rope_type", rs.get("type")) == "llama3":
-            llama3 = (rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"])
+        llama3 = self._llama3_rope()
         hidden = ops.embedding(ctx.tokens, self.token_embedding, c.scale_emb)      # token_embedding
         cos, sin = ops.rope_cos_sin(ctx.positions, c.dim_head, c.rope_theta, True, llama3)  # RopePreparer
         scale = 1.0 / math.sqrt(c.dim_head)
@@ -355,6 +352,62 @@ class LLaMA:
         alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
         return ops.gemm_nt_small_m(hidden, self.lm_head, alpha=alpha, out=bufs["logits"],
                                    norm_weight=self.output_layernorm, norm_eps=c.eps, argmax_ws=argmax_ws)
+
+    def _llama3_rope(self):
+        rs = self.cfg.rope_scaling
+        if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+            return (rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"])
+        return None
+
+    def prefill(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor):
+        """The "encode part" of a task (LLaMA::encode with len_q = prompt length for one task:
+        src/model/llama.cpp:75-165, Attention::impl::NormalImpl::dynamic_batch_forward encode branch,
+        src/nn/attention/attention.cpp:846-964 / attn_encode_group :442-622): runs the whole prompt through
+        the layers, fills the task's KV buffers at slots 0..S-1, leaves the task ready for decode steps
+        (tokens <- greedy first token, positions = placement = S, valid_lens = S + 1) and returns the logits of
+        the last prompt position (1, vocab).  Sequence: separate RMSNorm, W4A16 GEMM (M = S: the M-tiled MFMA
+        kernel, the arithmetic of the reference's M > 40 dequant + GEMM branch), rope_qk_cache,
+        copy_to_rag_buffer2, causal attention through the mask form of multi_query_attention_rag_buffer."""
+        c, dev = self.cfg, self.device
+        s = int(prompt.numel())
+        if s < 1 or s + 1 > ctx.max_len_buf:
+            raise ops.ZLError("prompt does not fit the task's KV buffer")
+        tokens = prompt.to(device=dev, dtype=torch.int32).contiguous()
+        pos = torch.arange(s, dtype=torch.int32, device=dev)
+        hidden = ops.embedding(tokens, self.token_embedding, c.scale_emb)
+        cos, sin = ops.rope_cos_sin(pos, c.dim_head, c.rope_theta, True, self._llama3_rope())
+        placement = pos.view(1, s)
+        buf_lens = ctx.buf_lens[task:task + 1]
+        key = ("prefill", s, ctx.max_len_buf)
+        if key not in self._bufs:
+            mask = torch.tril(torch.ones(s, ctx.max_len_buf, dtype=torch.int8, device=dev)).contiguous()
+            ws = ops.decode_attn_workspace(1, s, c.num_heads, c.dim_head, ctx.max_len_buf, dev)
+            self._bufs[key] = (mask, ws)
+        mask, ws = self._bufs[key]
+        scale = 1.0 / math.sqrt(c.dim_head)
+        for li, layer in enumerate(self.layers):
+            ka, va = ctx.k_addrs[li][task:task + 1], ctx.v_addrs[li][task:task + 1]
+            xn = ops.rmsnorm(hidden, layer.ln_attn, c.eps)
+            qkv = ops.w4_linear(xn, layer.qkv.weight, bias=layer.qkv.bias)
+            q, k, v = ops.rope_qk_cache(cos, sin, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
+            ops.copy_to_rag_buffer2(placement, buf_lens, k.view(1, s, c.num_kv_heads, c.dim_head),
+                                    v.view(1, s, c.num_kv_heads, c.dim_head), ka, va)
+            att = ops.multi_query_attention_rag_buffer(q.view(1, s, c.num_heads, c.dim_head), buf_lens, ka, va, mask, scale,
+                                                       ctx.max_len_buf, c.num_kv_heads, workspace=ws)
+            ops.w4_linear(att.view(s, -1), layer.attn_out.weight, bias=layer.attn_out.bias, residual=hidden, out=hidden,
+                          epilogue=ops.EPI_RESIDUAL)
+            xn = ops.rmsnorm(hidden, layer.ln_ff, c.eps)
+            act = ops.w4_linear(xn, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, epilogue=ops.EPI_SILU_MUL)
+            ops.w4_linear(act, layer.w_out.weight, bias=layer.w_out.bias, residual=hidden, out=hidden,
+                          epilogue=ops.EPI_RESIDUAL)
+        alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
+        logits = ops.gemm_nt_small_m(hidden[s - 1:s], self.lm_head, alpha=alpha, norm_weight=self.output_layernorm,
+                                     norm_eps=c.eps)
+        ctx.tokens[task] = torch.argmax(logits[0].float()).to(torch.int32)
+        ctx.positions[task] = s
+        ctx.placement[task] = s
+        ctx.valid_lens[task] = s + 1
+        return logits
 
     def step_greedy(self, ctx: DynBatchContext):
         """One greedy decode step entirely on the device (graph-capturable): encode, pick the arg-max token
