@@ -246,6 +246,19 @@ int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* q
                          zl_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * a16  Prompt ("encode part") attention of ONE task's chunk, causal, on the matrix cores.
+ * Replaces attn_encode_group -> FlashDecoding::mha_fwd (src/nn/attention/attention.cpp:442-622; the
+ * arithmetic of the external flash-attn library): query row i of the chunk sits at position pos0 + i and
+ * sees keys 0 .. pos0 + i of the task's K/V buffer (BSHD (len_buf, Hkv, D) or BHSD), which must already
+ * hold the chunk's own rows (copy_to_rag_buffer2 first).  q / out (s_q, H, D) fp16; D = 128.  fp32 softmax,
+ * fp16 probabilities into the P.V product, fp32 accumulation.
+ * ---------------------------------------------------------------------------------------------- */
+int zl_prefill_attn(const uint16_t* q, const uint16_t* k_buf, const uint16_t* v_buf, uint16_t* out, int64_t s_q,
+                    int64_t pos0, int64_t h, int64_t hkv, int64_t d, float scale, int64_t len_buf, int bshd,
+                    int dtype, zl_stream_t s);
+
+
+/* ------------------------------------------------------------------------------------------------
  * a18  Element-wise.  Replaces nn::element_add_scale_out (src/nn/block/block_kernel.cu:19-50) and
  * nn::gate_mul_inplace (src/nn/linear/activation_kernel.cu:82-106; act 0 = silu, 1 = gelu).
  * ---------------------------------------------------------------------------------------------- */

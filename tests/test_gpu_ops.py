@@ -369,3 +369,25 @@ def test_int8_scale_back_variants_bit_exact(oracle, dev, dtype):
     dst3 = _tt(init[0].copy(), dev, dtype)
     ops.quant_back_copy_to_buffer(_t(c4[0], dev), _t(sx[:t], dev), _tt(syq, dev, dtype), None, dst3)
     assert np.array_equal(_bits(dst3), ref3)
+
+
+@pytest.mark.parametrize("s_q,pos0,h,hkv,bshd", [(70, 0, 8, 2, True), (200, 37, 4, 4, True), (64, 0, 4, 1, False), (1, 5, 8, 2, True),
+                                                 (129, 300, 8, 8, True)])
+def test_prefill_attention(oracle, dev, s_q, pos0, h, hkv, bshd):
+    """zl_prefill_attn (causal MFMA attention of one task's chunk) vs the oracle's exact attention with a causal
+    mask; probabilities are rounded to fp16 before P.V like in flash attention -> ~1e-3 of the output scale."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(s_q + pos0)
+    d = 128
+    len_buf = (pos0 + s_q + 63) // 64 * 64 + 64
+    q = (rng.standard_normal((s_q, h, d)) * 1.5).astype(np.float16)
+    kb = rng.standard_normal((len_buf, hkv, d)).astype(np.float16)
+    vb = rng.standard_normal((len_buf, hkv, d)).astype(np.float16)
+    if not bshd:
+        kb, vb = np.ascontiguousarray(kb.transpose(1, 0, 2)), np.ascontiguousarray(vb.transpose(1, 0, 2))
+    mask = (np.arange(len_buf)[None, :] <= (pos0 + np.arange(s_q))[:, None]).astype(np.int8)
+    ref = oracle.mqa_rag_buffer(oracle.h2u(q)[None], np.array([len_buf], np.int32), [oracle.h2u(kb)], [oracle.h2u(vb)], mask, hkv,
+                                1.0 / np.sqrt(d), bshd, exact=True)[0]
+    got = _np(ops.prefill_attention(_t(q, dev), _t(kb, dev), _t(vb, dev), pos0, hkv, 1.0 / np.sqrt(d), bshd)).astype(np.float64)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()

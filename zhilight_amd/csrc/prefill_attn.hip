@@ -1,0 +1,195 @@
+// prefill_attn.hip -- causal ("encode part") attention of one task's prompt chunk on the matrix cores.
+//
+// Reference: attn_encode_group (src/nn/attention/attention.cpp:442-622) -> FlashDecoding::mha_fwd, i.e. the
+// external flash-attn library (forbidden to borrow): out[q,h,:] = softmax_j<=pos(q)( scale * q.K_j ) . V with
+// the K/V rows already in the task's buffer (the chunk's own rows are written before this runs, like
+// copy_to_buffer in the reference), fp32 softmax, probabilities rounded to fp16 for the P.V product (what
+// flash-attn does), fp32 accumulation.
+//
+// One workgroup = 64 query rows of one q head, 4 waves x 16 rows; key tiles of 64 rows go through LDS
+// once per workgroup (K as stored; V transposed and key-permuted on the way in, so that every MFMA
+// operand is one ds_read_b128).  Orientation: S^T = K.Q^T, so a lane's score registers belong to ONE
+// query (lane & 15) -- row maxima need two cross-lane steps -- and, rounded to fp16, ARE the A operand
+// of the P.V product (k index = key) with no transposition.  O accumulates in the C layout (rows 4 kq + i),
+// its per-row rescale factors cross over through a 64-byte LDS strip per wave.
+#include <stdlib.h>
+#include "zl_common.h"
+
+namespace {
+
+constexpr int kBQ = 64, kBK = 64, kD = 128;
+constexpr int kKRow = kD + 8;       // K tile row (halfs), padded: conflict-free b128 reads
+constexpr int kVRow = kBK + 8;      // V^T tile row (halfs)
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct PrefillParams {
+    const uint16_t* q;      // (s_q, h, D)
+    const uint16_t* k;      // task buffer, BSHD (len_buf, hkv, D) or BHSD (hkv, len_buf, D)
+    const uint16_t* v;
+    uint16_t* out;          // (s_q, h, D)
+    int s_q, pos0, h, hkv, n_rep, len_buf, bshd;
+    float scale;
+};
+
+// position of key `kk` (0..31 inside a 32-key group) in the permuted V^T row: the 8 keys that form one MFMA
+// A/B k-chunk for lane group kq -- {4 kq + i} and {16 + 4 kq + i} -- are contiguous
+__device__ __forceinline__ int vperm(int kk) { return ((kk & 15) >> 2) * 8 + (kk >> 4) * 4 + (kk & 3); }
+
+__global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t ks[kBK * kKRow];
+    __shared__ __attribute__((aligned(16))) uint16_t vt[kD * kVRow];
+    __shared__ __attribute__((aligned(16))) float strip[4][16];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = lane & 15, kq = lane >> 4;
+    const int head = blockIdx.y, hk = head / p.n_rep;
+    const int q0 = blockIdx.x * kBQ;
+    const int qrow = q0 + wave * 16 + nq;                 // the query this lane's scores belong to
+    const int qpos = p.pos0 + qrow;                       // its position: keys 0 .. qpos are visible
+    const size_t kv_stride = p.bshd ? (size_t)p.hkv * kD : (size_t)kD;
+    const size_t kv_off = p.bshd ? (size_t)hk * kD : (size_t)hk * p.len_buf * kD;
+
+    // Q fragments (B operand of S^T = K.Q^T): column q = lane & 15, k-chunk = d 32 t + 8 kq .. +7
+    h8 qf[4];
+    {
+        const int qr = qrow < p.s_q ? qrow : p.s_q - 1;
+        const uint16_t* qp = p.q + ((size_t)qr * p.h + head) * kD + 8 * kq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qf[t] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(qp + 32 * t));
+    }
+
+    f4 o[8];                                              // O block: column d = 16 db + (lane & 15), rows q = 4 kq + i
+#pragma unroll
+    for (int db = 0; db < 8; ++db) o[db] = (f4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e20f, l_run = 0.f;                    // per query (lane & 15), replicated over kq
+
+    const int last_q = min(q0 + kBQ, p.s_q) - 1;
+    const int n_keys = p.pos0 + last_q + 1;               // keys any row of this block may see
+    const int n_tiles = (n_keys + kBK - 1) / kBK;
+
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int key0 = tile * kBK;
+        __syncthreads();                                  // previous tile fully consumed
+        // ---- stage K (as is) and V (transposed, key-permuted) : thread -> key = tid % 64, d chunks tid / 64 + 4 c
+        {
+            const int key = threadIdx.x & 63;
+            const int kg = key0 + key;
+            const int kc = kg < n_keys ? kg : n_keys - 1;
+            const uint16_t* kp = p.k + kv_off + (size_t)kc * kv_stride;
+            const uint16_t* vp = p.v + kv_off + (size_t)kc * kv_stride;
+            const int vcol = (key >> 5) * 32 + vperm(key & 31);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int dch = (threadIdx.x >> 6) + 4 * c;       // 16 chunks of 8 d
+                const uint4 kv4 = *reinterpret_cast<const uint4*>(kp + dch * 8);
+                uint4 vv4 = *reinterpret_cast<const uint4*>(vp + dch * 8);
+                if (kg >= n_keys) vv4 = make_uint4(0, 0, 0, 0);   // finite: its probability is exactly 0
+                *reinterpret_cast<uint4*>(&ks[key * kKRow + dch * 8]) = kv4;
+                const uint32_t vw[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    vt[(dch * 8 + e) * kVRow + vcol] = (uint16_t)((vw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T : 4 key blocks x 4 d steps; lane: query nq, keys key0 + 16 kb + 4 kq + i
+        f4 st[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            st[kb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&ks[(kb * 16 + nq) * kKRow + 32 * t + 8 * kq]));
+                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[t], st[kb], 0, 0, 0);
+            }
+        }
+        // ---- scale, causal mask, online softmax for query nq (its 64 scores live in 4 lanes x 16 registers)
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = key0 + kb * 16 + 4 * kq + i;
+                const float sv = key <= qpos ? st[kb][i] * p.scale : -INFINITY;
+                st[kb][i] = sv;
+                mloc = fmaxf(mloc, sv);
+            }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float lsum = 0.f;
+        h8 pf[2];                                         // P as the A operand of P.V: k-chunk kq of key group j
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pv = __expf(st[2 * j + half][i] - m_new);
+                    const _Float16 ph = (_Float16)pv;
+                    lsum += (float)ph;                    // the normaliser sums what the product uses
+                    pf[j][half * 4 + i] = ph;
+                }
+            }
+        }
+        l_run = l_run * alpha + lsum;                     // per-lane partial; lanes of a query are merged at the end
+        // ---- rescale O: the factor of row q = 4 kq + i comes from the lane whose nq is that row
+        if (kq == 0) strip[wave][nq] = alpha;
+        __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the strip write has landed (wave-private)
+        const f4 al = *reinterpret_cast<const f4*>(&strip[wave][4 * kq]);
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            o[db][0] *= al[0]; o[db][1] *= al[1]; o[db][2] *= al[2]; o[db][3] *= al[3];
+        }
+        // ---- O += P . V : 2 key groups x 8 d blocks
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const h8 b = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&vt[(db * 16 + nq) * kVRow + j * 32 + 8 * kq]));
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[j], b, o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise: l of query nq = sum over its 4 lanes; bring 1/l to the C layout through the strip
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (kq == 0) strip[wave][nq] = 1.0f / (l_run + 1e-20f);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const f4 inv = *reinterpret_cast<const f4*>(&strip[wave][4 * kq]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = q0 + wave * 16 + 4 * kq + i;
+        if (row >= p.s_q) continue;
+        uint16_t* op = p.out + ((size_t)row * p.h + head) * kD + nq;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) op[db * 16] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(o[db][i] * inv[i]));
+    }
+}
+
+}  // namespace
+
+extern "C" int zl_prefill_attn(const uint16_t* q, const uint16_t* k_buf, const uint16_t* v_buf, uint16_t* out, int64_t s_q,
+                               int64_t pos0, int64_t h, int64_t hkv, int64_t d, float scale, int64_t len_buf, int bshd,
+                               int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(q && k_buf && v_buf && out && s_q > 0 && pos0 >= 0 && h > 0 && hkv > 0 && len_buf > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(h % hkv == 0 && pos0 + s_q <= len_buf, ZL_ESHAPE);
+    ZL_CHECK_ARG(d == kD, ZL_ESHAPE);          // other head sizes: the mask form of zl_decode_attn
+    ZL_CHECK_ARG(dtype == ZL_F16, ZL_EDTYPE);
+    ZL_CHECK_ARG(h <= 65535, ZL_ELIMIT);
+    PrefillParams p;
+    p.q = q; p.k = k_buf; p.v = v_buf; p.out = out;
+    p.s_q = (int)s_q; p.pos0 = (int)pos0; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
+    p.len_buf = (int)len_buf; p.bshd = bshd; p.scale = scale;
+    hipLaunchKernelGGL(k_prefill_attn_f16, dim3((unsigned)((s_q + kBQ - 1) / kBQ), (unsigned)h), dim3(256), 0,
+                       (hipStream_t)s, p);
+    return zl_launch_status();
+}

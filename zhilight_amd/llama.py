@@ -359,6 +359,16 @@ class LLaMA:
             return (rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"])
         return None
 
+    def _prefill_mask(self, s, len_buf):
+        """causal mask + workspace for head sizes the MFMA prefill kernel does not cover"""
+        key = ("prefill", s, len_buf)
+        if key not in self._bufs:
+            c, dev = self.cfg, self.device
+            mask = torch.tril(torch.ones(s, len_buf, dtype=torch.int8, device=dev)).contiguous()
+            ws = ops.decode_attn_workspace(1, s, c.num_heads, c.dim_head, len_buf, dev)
+            self._bufs[key] = (mask, ws)
+        return self._bufs[key]
+
     def prefill(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor):
         """The "encode part" of a task (LLaMA::encode with len_q = prompt length for one task:
         src/model/llama.cpp:75-165, Attention::impl::NormalImpl::dynamic_batch_forward encode branch,
@@ -367,7 +377,8 @@ class LLaMA:
         (tokens <- greedy first token, positions = placement = S, valid_lens = S + 1) and returns the logits of
         the last prompt position (1, vocab).  Sequence: separate RMSNorm, W4A16 GEMM (M = S: the M-tiled MFMA
         kernel, the arithmetic of the reference's M > 40 dequant + GEMM branch), rope_qk_cache,
-        copy_to_rag_buffer2, causal attention through the mask form of multi_query_attention_rag_buffer."""
+        copy_to_rag_buffer2, causal MFMA attention (prefill_attention; other head sizes: the mask form of
+        multi_query_attention_rag_buffer)."""
         c, dev = self.cfg, self.device
         s = int(prompt.numel())
         if s < 1 or s + 1 > ctx.max_len_buf:
@@ -378,12 +389,6 @@ class LLaMA:
         cos, sin = ops.rope_cos_sin(pos, c.dim_head, c.rope_theta, True, self._llama3_rope())
         placement = pos.view(1, s)
         buf_lens = ctx.buf_lens[task:task + 1]
-        key = ("prefill", s, ctx.max_len_buf)
-        if key not in self._bufs:
-            mask = torch.tril(torch.ones(s, ctx.max_len_buf, dtype=torch.int8, device=dev)).contiguous()
-            ws = ops.decode_attn_workspace(1, s, c.num_heads, c.dim_head, ctx.max_len_buf, dev)
-            self._bufs[key] = (mask, ws)
-        mask, ws = self._bufs[key]
         scale = 1.0 / math.sqrt(c.dim_head)
         for li, layer in enumerate(self.layers):
             ka, va = ctx.k_addrs[li][task:task + 1], ctx.v_addrs[li][task:task + 1]
@@ -392,8 +397,13 @@ class LLaMA:
             q, k, v = ops.rope_qk_cache(cos, sin, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
             ops.copy_to_rag_buffer2(placement, buf_lens, k.view(1, s, c.num_kv_heads, c.dim_head),
                                     v.view(1, s, c.num_kv_heads, c.dim_head), ka, va)
-            att = ops.multi_query_attention_rag_buffer(q.view(1, s, c.num_heads, c.dim_head), buf_lens, ka, va, mask, scale,
-                                                       ctx.max_len_buf, c.num_kv_heads, workspace=ws)
+            if c.dim_head == 128 and q.dtype == torch.float16:
+                att = ops.prefill_attention(q.view(s, c.num_heads, c.dim_head), ctx.kv[task][li, 0], ctx.kv[task][li, 1], 0,
+                                            c.num_kv_heads, scale)
+            else:
+                mask, ws = self._prefill_mask(s, ctx.max_len_buf)
+                att = ops.multi_query_attention_rag_buffer(q.view(1, s, c.num_heads, c.dim_head), buf_lens, ka, va, mask,
+                                                           scale, ctx.max_len_buf, c.num_kv_heads, workspace=ws)
             ops.w4_linear(att.view(s, -1), layer.attn_out.weight, bias=layer.attn_out.bias, residual=hidden, out=hidden,
                           epilogue=ops.EPI_RESIDUAL)
             xn = ops.rmsnorm(hidden, layer.ln_ff, c.eps)

@@ -418,6 +418,22 @@ def decode_attention_fused(cos, sin, qkv, placement, buf_lens, valid_lens, k_add
     return out
 
 
+def prefill_attention(q, k_buf, v_buf, pos0, num_kv_heads, scale, bshd=True, out=None):
+    """Causal attention of one task's prompt chunk (attn_encode_group -> flash attention in the reference,
+    src/nn/attention/attention.cpp:442-622).  q (s_q, H, D); k_buf / v_buf the task's buffers (len_buf, Hkv, D)
+    [bshd] or (Hkv, len_buf, D), already holding the chunk's rows at pos0 .. pos0 + s_q - 1."""
+    _chk_cuda(q, k_buf, v_buf)
+    if q.dtype != torch.float16:
+        raise ZLError("prefill_attention: fp16 only")
+    s_q, h, d = q.shape
+    len_buf = k_buf.shape[0] if bshd else k_buf.shape[1]
+    if out is None:
+        out = torch.empty_like(q)
+    check(lib().zl_prefill_attn(_p(q), _p(k_buf), _p(v_buf), _p(out), _i(s_q), _i(pos0), _i(h), _i(num_kv_heads), _i(d),
+                                _f(scale), _i(len_buf), C.c_int(int(bshd)), C.c_int(_dt(q)), _stream()), "prefill_attn")
+    return out
+
+
 def element_add_scale(a, b, scale=1.0, scale_residual=True, out=None):
     """nn::element_add_scale_out (src/nn/block/block_kernel.cu:19-50)."""
     _chk_cuda(a, b)
