@@ -190,7 +190,7 @@ def test_gemm_error_behaviour(dev):
 # MFMA flavour (fp32 accumulation): checked against the exact fp64 oracle and against the restatement of
 # the reference's M > 40 branch (dequant_k_major -> fp16 weights, fp32-accumulating GEMM)
 # ---------------------------------------------------------------------------------------------------
-def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=False):
+def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=False, force_tiled=False):
     from zhilight_amd import ops
     rng = np.random.default_rng(seed)
     g = 128
@@ -204,13 +204,17 @@ def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=Fal
     res = synth.act(rng, m, n) if residual else None
     xin = oracle.rmsnorm(oracle.h2u(x), oracle.h2u(nw), 1e-5) if norm else oracle.h2u(x)
     exact = oracle.gptq_gemm_k_major_exact(xin, *km, bias=None if b is None else oracle.h2u(b))
-    y = ops.w4a16_gemm_mfma(_t(x, dev), w, bias=None if b is None else _t(b, dev), residual=None if res is None else _t(res, dev),
-                            norm_weight=None if nw is None else _t(nw, dev), norm_eps=1e-5,
-                            epilogue=ops.EPI_RESIDUAL if residual else 0)
+    if force_tiled:
+        y = ops.w4a16_gemm_tiled(_t(x, dev), w, bias=None if b is None else _t(b, dev), residual=None if res is None else _t(res, dev),
+                                 epilogue=ops.EPI_RESIDUAL if residual else 0)
+    else:
+        y = ops.w4a16_gemm_mfma(_t(x, dev), w, bias=None if b is None else _t(b, dev), residual=None if res is None else _t(res, dev),
+                                norm_weight=None if nw is None else _t(nw, dev), norm_eps=1e-5,
+                                epilogue=ops.EPI_RESIDUAL if residual else 0)
     got = _np(y).astype(np.float64)
-    # m > 16 without a fused norm runs the M-tiled kernel: it multiplies with W16 = rn16(rn16(q - z) * s), the
+    # m > 64 without a fused norm runs the M-tiled kernel: it multiplies with W16 = rn16(rn16(q - z) * s), the
     # matrix the reference's M > 40 branch dequantises (dequant_k_major), so THAT product is its exact value
-    tiled = m > 16 and not norm
+    tiled = force_tiled or (m > 64 and not norm)
     w16 = oracle.gptq_dequant_k_major(*km)
     ref40 = oracle.gemm_nt(xin, w16, None if b is None else oracle.h2u(b), exact=True)
     lin = np.zeros_like(exact)
@@ -251,10 +255,13 @@ def test_mfma_gemm_shapes(oracle, dev, k, n):
 
 @pytest.mark.parametrize("m,k,n", [(17, 1024, 264), (33, 2048, 40), (64, 4096, 512), (100, 1152 + 128, 1000), (257, 2048, 384)])
 def test_tiled_gemm_shapes(oracle, dev, m, k, n):
-    """M > 16: the M-tiled kernel (w4_gemm_tiled.hip) incl. ragged M / N tails, bias and residual epilogues."""
-    _check_mfma(oracle, dev, k, n, m, seed=50 + m)
-    _check_mfma(oracle, dev, k, n, m, seed=51 + m, bias=True)
-    _check_mfma(oracle, dev, k, n, m, seed=52 + m, residual=True)
+    """The M-tiled kernel (w4_gemm_tiled.hip, both M-tile heights) incl. ragged M / N tails, bias and residual
+    epilogues; and the public entry for the same shapes (16-row passes up to M = 64, the tiled kernel above)."""
+    _check_mfma(oracle, dev, k, n, m, seed=50 + m, force_tiled=True)
+    _check_mfma(oracle, dev, k, n, m, seed=51 + m, bias=True, force_tiled=True)
+    _check_mfma(oracle, dev, k, n, m, seed=52 + m, residual=True, force_tiled=True)
+    _check_mfma(oracle, dev, k, n, m, seed=53 + m, bias=True)
+    _check_mfma(oracle, dev, k, n, m, seed=54 + m, residual=True)
 
 
 def test_tiled_gemm_silu_mul(oracle, dev):

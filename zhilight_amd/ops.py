@@ -244,6 +244,25 @@ def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, 
     return out
 
 
+def w4a16_gemm_tiled(x, w, bias=None, residual=None, out=None, epilogue=0):
+    """The M-tiled MFMA GEMM called directly (w4a16_gemm_mfma forwards to it for M > 64)."""
+    if x.dtype != torch.float16:
+        raise ZLError("A must be half")
+    _chk_cuda(x, bias, residual)
+    x2 = x.reshape(-1, x.shape[-1])
+    m, k = x2.shape
+    if k != w.k:
+        raise ZLError("size K mismatch")
+    silu = epilogue & (EPI_SILU_MUL | EPI_SILU_MUL_F32)
+    if out is None:
+        out = torch.empty((m, w.n // 2 if silu else w.n), dtype=torch.float16, device=x.device)
+    if bias is not None:
+        epilogue |= EPI_BIAS
+    check(lib().zl_w4a16_gemm_tiled(_p(x2), _i(x2.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(residual), _p(out),
+                                    _i(m), _i(w.n), _i(k), _i(w.group_size), C.c_int(epilogue), _stream()), "w4a16_gemm_tiled")
+    return out
+
+
 def w4_linear(x, w, **kw):
     """W4A16 linear on whichever packed layout the weight holds (W4Weight: bit-exact warp-reduce
     arithmetic; W4MWeight: fp32-accumulating MFMA arithmetic)."""
