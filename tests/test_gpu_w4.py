@@ -239,7 +239,7 @@ def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=Fal
         assert (d_40 <= 2.0 ** -10 * np.abs(ref40) + 1.5e-3 * rms).all()
         # and the warp-reduce kernel's own noise level vs both
         r = oracle.u2h(oracle.gptq_gemm_k_major(oracle.h2u(x), *km, bias=None if b is None else oracle.h2u(b))).astype(np.float64)
-        assert np.abs(got - r).max() <= 6e-3 * rms                                     # the warp-reduce kernel's fp16 noise
+        assert np.abs(got - r).max() <= 1e-2 * rms                                     # the warp-reduce kernel's fp16 noise (max over up to 6e5 outputs)
 
 
 @pytest.mark.parametrize("m", [1, 2, 5, 8, 16, 17, 33])
@@ -253,7 +253,8 @@ def test_mfma_gemm_shapes(oracle, dev, k, n):
     _check_mfma(oracle, dev, k, n, 9, seed=31, bias=True)
 
 
-@pytest.mark.parametrize("m,k,n", [(17, 1024, 264), (33, 2048, 40), (64, 4096, 512), (100, 1152 + 128, 1000), (257, 2048, 384)])
+@pytest.mark.parametrize("m,k,n", [(17, 1024, 264), (33, 2048, 40), (64, 4096, 512), (100, 1152 + 128, 1000), (257, 2048, 384),
+                                   (300, 1024, 2048)])
 def test_tiled_gemm_shapes(oracle, dev, m, k, n):
     """The M-tiled kernel (w4_gemm_tiled.hip, both M-tile heights) incl. ragged M / N tails, bias and residual
     epilogues; and the public entry for the same shapes (16-row passes up to M = 64, the tiled kernel above)."""

@@ -71,7 +71,8 @@ template <int BM>
 __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledParams p) {
     constexpr int RB = BM / 16;               // 16-row blocks of the M tile
     constexpr int XR = BM / 16;               // uint4 per thread per x chunk (16 threads x 16 B per row)
-    __shared__ __attribute__((aligned(16))) uint16_t xs[2][BM * kRowHalfs];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
+    uint16_t (*xs)[BM * kRowHalfs] = reinterpret_cast<uint16_t (*)[BM * kRowHalfs]>(smem_t);   // [2][BM * kRowHalfs]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -254,12 +255,27 @@ extern "C" int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_
     p.ld_out = (int)(silu ? n / 2 : n);
     const int gx = (int)((L.np + kBN - 1) / kBN);
     hipStream_t hs = (hipStream_t)s;
-    if (m <= 32) {
-        ZL_CHECK_ARG((m + 31) / 32 <= 65535, ZL_ELIMIT);
-        hipLaunchKernelGGL(k_w4a16_gemm_tiled<32>, dim3(gx, (unsigned)((m + 31) / 32)), dim3(kThreadsT), 0, hs, p);
-    } else {
-        ZL_CHECK_ARG((m + 63) / 64 <= 65535, ZL_ELIMIT);
-        hipLaunchKernelGGL(k_w4a16_gemm_tiled<64>, dim3(gx, (unsigned)((m + 63) / 64)), dim3(kThreadsT), 0, hs, p);
+    // M-tile height: taller tiles amortise the dequant over more MFMAs (the VALU and the MFMA pipe do not
+    // overlap here: 143 VALU + 32 MFMA per chunk and wave at BM = 64 measured 40 % MFMA-busy); 128 rows need
+    // enough M to still fill the chip
+    static const int bm_env = [] { const char* e = getenv("ZL_W4_TILED_BM"); return e ? atoi(e) : 0; }();
+    int bm = m <= 32 ? 32 : (m * (int64_t)gx >= 128 * 512 ? 128 : 64);
+    if (bm_env == 32 || bm_env == 64 || bm_env == 128) bm = bm_env;
+    ZL_CHECK_ARG((m + bm - 1) / bm <= 65535, ZL_ELIMIT);
+    const dim3 grid(gx, (unsigned)((m + bm - 1) / bm));
+    const size_t lds = (size_t)2 * bm * kRowHalfs * 2;
+#define ZL_TILED_LAUNCH(BMV)                                                                                   \
+    {                                                                                                          \
+        if (lds > 64 * 1024) {                                                                                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm_tiled<BMV>),        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+            if (e != hipSuccess) return ZL_ELIMIT;                                                             \
+        }                                                                                                      \
+        hipLaunchKernelGGL(k_w4a16_gemm_tiled<BMV>, grid, dim3(kThreadsT), lds, hs, p);                         \
     }
+    if (bm == 32) ZL_TILED_LAUNCH(32)
+    else if (bm == 64) ZL_TILED_LAUNCH(64)
+    else ZL_TILED_LAUNCH(128)
+#undef ZL_TILED_LAUNCH
     return zl_launch_status();
 }
