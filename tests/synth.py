@@ -47,3 +47,23 @@ def awq_hf(rng, k, n, g):
         return out
     scales = (np.abs(rng.standard_normal((ng, n))) * 0.02 / 8 + 1e-4).astype(np.float16)
     return pack(q), pack(z), scales.view(np.uint16), q, z
+
+
+def gptq_act_order_hf(rng, k, n, g):
+    """A desc_act GPTQ checkpoint: rows are assigned to groups through a random permutation (g_idx); returns
+    (qweight, qzeros, scales_bits, g_idx) in the HF layout plus the dense fp16 matrix W16[n, k] =
+    rn16(rn16(q - z) * s) the reference's dequantiser would produce for it."""
+    qweight, qzeros, scales_bits = gptq_hf(rng, k, n, g)
+    order = rng.permutation(k)
+    g_idx = np.empty(k, np.int32)
+    g_idx[order] = np.arange(k, dtype=np.int32) // g
+    q = np.zeros((k, n), np.int32)
+    for j in range(8):
+        q[j::8] = (qweight >> np.uint32(4 * j)) & 0xF
+    z = np.zeros((k // g, n), np.int32)
+    for j in range(8):
+        z[:, j::8] = ((qzeros >> np.uint32(4 * j)) & 0xF) + 1
+    s = scales_bits.view(np.float16)
+    d = (q - z[g_idx]).astype(np.float16)                              # exact
+    w16 = (d.astype(np.float32) * s[g_idx].astype(np.float32)).astype(np.float16)   # one rounding of an exact product
+    return qweight, qzeros, scales_bits, g_idx, np.ascontiguousarray(w16.T)

@@ -245,3 +245,43 @@ def test_prefill_then_decode_matches_oracle(oracle, dev):
         assert np.abs(lg - rf).max() <= 3e-3 * sc, (step, np.abs(lg - rf).max() / sc, np.abs(ex - rf).max() / sc)
         tok = int(rf.argmax(axis=1)[0])
         model.advance(ctx, torch.tensor([tok], device=dev))
+
+
+def test_act_order_model_prefill_and_decode(oracle, dev):
+    """A desc_act checkpoint through the whole layer stack (unfused q/k/v and gate/up, per-linear activation
+    gather): prompt encode against the oracle run on the dense W16 matrices of the same checkpoint."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(13)
+    cfg = ModelConfig(num_layers=2, dim_model=512, num_heads=4, dim_head=128, dim_ff=1024, vocab_size=256, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5,
+                      rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                    "original_max_position_embeddings": 8192})
+    g, s, len_buf = 128, 70, 128
+    sd = _hf_state(rng, cfg, g)
+    w16 = {}
+    for key in [k for k in sd if k.endswith(".qweight")]:
+        base = key[:-8]
+        kdim, ndim = sd[key].shape[0] * 8, sd[key].shape[1]
+        qw, qz, sc, g_idx, dense = synth.gptq_act_order_hf(rng, kdim, ndim, g)
+        sd[base + ".qweight"], sd[base + ".qzeros"], sd[base + ".scales"] = qw.view(np.int32), qz.view(np.int32), sc.view(np.float16)
+        sd[base + ".g_idx"] = g_idx
+        w16[base] = oracle.h2u(dense)
+    quant = QuantConfig.from_hf(dict(quant_method="gptq", bits=4, group_size=g, desc_act=True))
+    model = LLaMA(cfg, quant, dev).load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    assert model.layers[0].unfused is not None
+    ctx = model.new_context(1, len_buf, 0)
+    om = OracleModel(oracle, cfg, sd, g, 1, len_buf)
+    om.w16 = w16                                          # dense matrices of the act-order checkpoint
+    prompt = rng.integers(0, cfg.vocab_size, s).astype(np.int32)
+    got = model.prefill(ctx, 0, torch.from_numpy(prompt)).float().cpu().numpy().astype(np.float64)
+    ref = om.prefill(0, prompt)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-3 * scale + 2.0 ** -11 * scale, np.abs(got - ref).max() / scale
+    # one decode step from there runs (unfused decode path) and stays finite / close to a re-encode of s+1 tokens
+    tok = int(ref.argmax(axis=1)[0])
+    ctx.tokens[0] = tok
+    lg = model.encode(ctx).float().cpu().numpy().astype(np.float64)
+    ctx2 = model.new_context(1, len_buf, 0)
+    lg2 = model.prefill(ctx2, 0, torch.from_numpy(np.concatenate([prompt, [tok]]).astype(np.int32))).float().cpu().numpy()
+    assert np.isfinite(lg).all()
+    assert np.abs(lg - lg2).max() <= 4e-3 * np.abs(lg2).max()

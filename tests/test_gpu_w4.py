@@ -334,3 +334,33 @@ def test_awq_checkpoint_linear(oracle, dev, algo, monkeypatch):
     if algo == "exact":   # and bit for bit the reference-faithful kernel arithmetic on the converted operands
         r = oracle.gptq_gemm_k_major(oracle.h2u(x), *km_ref)
         assert np.array_equal(_np(lin.forward(_t(x, dev))).view(np.uint16), r)
+
+
+@pytest.mark.parametrize("algo", ["mfma", "exact"])
+def test_act_order_linear(oracle, dev, algo, monkeypatch):
+    """desc_act checkpoints (a6): rows regrouped at load, activation columns gathered in forward -- equals
+    x . W^T for W[k, n] = (q - z[g_idx[k]]) * s[g_idx[k]]."""
+    from zhilight_amd.llama import Int4GPTQ, QuantConfig
+    monkeypatch.setenv("ZL_W4_ALGO", algo)
+    rng = np.random.default_rng(91)
+    k, n, g = 1024, 256, 128
+    qw, qz, sc, g_idx, w16 = synth.gptq_act_order_hf(rng, k, n, g)
+    quant = QuantConfig.from_hf(dict(quant_method="gptq", bits=4, group_size=g, desc_act=True))
+    lin = Int4GPTQ("l", k, n, quant)
+    lin.load_state_dict({"l.qweight": torch.from_numpy(qw.view(np.int32)), "l.qzeros": torch.from_numpy(qz.view(np.int32)),
+                         "l.scales": torch.from_numpy(sc.view(np.float16)), "l.g_idx": torch.from_numpy(g_idx)}, "l", dev)
+    assert lin.perm is not None
+    lin.pack()
+    for m in (1, 5, 70):
+        x = synth.act(rng, m, k)
+        got = _np(lin.forward(_t(x, dev))).astype(np.float64)
+        ref = x.astype(np.float64) @ w16.astype(np.float64).T
+        rms = np.sqrt((ref ** 2).mean())
+        assert np.abs(got - ref).max() <= 2.0 ** -10 * np.abs(ref).max() + 6e-3 * rms, (m, np.abs(got - ref).max() / rms)
+    # a g_idx that is not a regrouping into groups of g is rejected
+    bad = g_idx.copy()
+    bad[0] = bad[1]
+    with pytest.raises(Exception):
+        Int4GPTQ("l", k, n, quant).load_state_dict(
+            {"l.qweight": torch.from_numpy(qw.view(np.int32)), "l.qzeros": torch.from_numpy(qz.view(np.int32)),
+             "l.scales": torch.from_numpy(sc.view(np.float16)), "l.g_idx": torch.from_numpy(bad)}, "l", dev)

@@ -93,13 +93,12 @@ class QuantConfig:
             raise ops.ZLError("Only bits=4 is supported")
         if qc.get("is_marlin_format", False):
             raise ops.ZLError(f"Unsupported Marlin {method}")
-        if qc.get("desc_act", False):
-            raise ops.ZLError("desc_act (act-order) checkpoints need the legacy exllama path: not implemented")
+        act_order = bool(qc.get("desc_act", False))
         if method == "awq":
             if not qc.get("zero_point", True):
                 raise ops.ZLError("AWQ checkpoints without zero points are not supported")
             return cls(5, qc.get("group_size", 128), False, False, True)
-        return cls(5, qc.get("group_size", 128), qc.get("sym", False), False, False)
+        return cls(5, qc.get("group_size", 128), qc.get("sym", False), act_order, False)
 
 
 def hf_name_to_internal(name: str) -> str:
@@ -146,6 +145,7 @@ class Int4GPTQ:
         self.km = None      # k-major (qweight, qzeros, scales) device tensors until packed
         self.weight: Optional[ops.W4Weight] = None
         self.bias = None
+        self.perm = None    # act-order: activation column gather applied in forward()
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str, device):
         qw = _dev_t(sd[prefix + ".qweight"], device, torch.int32)
@@ -162,6 +162,8 @@ class Int4GPTQ:
         else:
             if qw.shape != (self.dim_in // 8, self.dim_out):
                 raise ops.ZLError(f"{prefix}: qweight shape {tuple(qw.shape)} != {(self.dim_in // 8, self.dim_out)}")
+            if self.quant.act_order and prefix + ".g_idx" in sd:
+                qw = self._apply_act_order(qw, _dev_t(sd[prefix + ".g_idx"], device, torch.int32), prefix)
             # Int4GPTQ::preprocess_weight + transpose_weight: shuffle, +1 zeros, nibble->byte, transposes
             qw = ops.transpose_2d(ops.gptq_shuffle(qw.clone()))
             qz = ops.transpose_2d(ops.q4_to_q8(ops.increase_zero(qz.clone())))
@@ -169,8 +171,33 @@ class Int4GPTQ:
         if prefix + ".bias" in sd:
             self.bias = _dev_t(sd[prefix + ".bias"], device, torch.float16)
 
+    def _apply_act_order(self, qw, g_idx, prefix):
+        """desc_act checkpoints (the reference sorts with argsort(g_idx) and lets its exllama
+        kernel read x through that permutation, src/nn/linear/linear.cpp:1144-1147, q_gemm.cu:104-251).  Same
+        math, done at the boundary: the weight ROWS are put in group order once at load (then every group is
+        128 consecutive k again and zeros/scales are already in group order), and forward() gathers the
+        activation columns with the same permutation before the ordinary kernel runs."""
+        k, g = self.dim_in, self.quant.group_size
+        if g_idx.numel() != k:
+            raise ops.ZLError(f"{prefix}: g_idx has {g_idx.numel()} entries, expected {k}")
+        perm = torch.argsort(g_idx.to(torch.int64), stable=True)
+        if not torch.equal(g_idx.to(torch.int64)[perm], torch.arange(k, device=g_idx.device) // g):
+            raise ops.ZLError(f"{prefix}: g_idx is not a regrouping into groups of {g}")
+        if torch.equal(perm, torch.arange(k, device=perm.device)):
+            return qw                                     # trivial order (static groups)
+        shifts = torch.arange(8, device=qw.device, dtype=torch.int32) * 4
+        nib = ((qw.unsqueeze(1) >> shifts.view(1, 8, 1)) & 0xF).reshape(k, -1)       # (K, N) nibbles, row 8r + j
+        nib = nib.index_select(0, perm).reshape(k // 8, 8, -1)
+        packed = torch.zeros_like(qw)
+        for j in range(8):
+            packed |= nib[:, j, :] << (4 * j)
+        self.perm = perm.to(torch.int32)
+        return packed
+
     @staticmethod
     def fuse(name, parts: List["Int4GPTQ"], row_interleave=False):
+        if any(p.perm is not None for p in parts):
+            raise ops.ZLError("act-order linears cannot be fused: each carries its own input permutation")
         out = Int4GPTQ(name, parts[0].dim_in, sum(p.dim_out for p in parts), parts[0].quant)
         out.km = tuple(torch.cat([p.km[i] for p in parts], dim=0).contiguous() for i in range(3))
         if any(p.bias is not None for p in parts):
@@ -191,6 +218,10 @@ class Int4GPTQ:
         return self
 
     def forward(self, x, **kw):
+        if self.perm is not None:
+            if kw.get("norm_weight") is not None:
+                raise ops.ZLError("act-order linears take an already normalised input")
+            x = x.index_select(-1, self.perm)
         return ops.w4_linear(x, self.weight, bias=self.bias, **kw)
 
 
@@ -202,6 +233,7 @@ class EncoderLayer:
         self.cfg, self.quant, self.idx = cfg, quant, idx
         self.ln_attn = self.ln_ff = None
         self.qkv = self.attn_out = self.w_in_gated = self.w_out = None
+        self.unfused = None     # act-order checkpoints: [q, k, v, w_in, w_gated] as separate linears
 
     def load_state_dict(self, sd, prefix, device):
         c, q = self.cfg, self.quant
@@ -214,14 +246,17 @@ class EncoderLayer:
             l = Int4GPTQ(prefix + "." + sub, din, dout, q)
             l.load_state_dict(sd, prefix + "." + sub, device)
             return l
-        self.qkv = Int4GPTQ.fuse(prefix + ".attn.project_qkv",
-                                 [lin("attn.project_q", c.dim_model, hd), lin("attn.project_k", c.dim_model, kvd),
-                                  lin("attn.project_v", c.dim_model, kvd)])
+        pq, pk, pv = lin("attn.project_q", c.dim_model, hd), lin("attn.project_k", c.dim_model, kvd), lin("attn.project_v", c.dim_model, kvd)
+        w_in, w_gated = lin("ff.w_in", c.dim_model, c.dim_ff), lin("ff.w_gated", c.dim_model, c.dim_ff)
         self.attn_out = lin("attn.attn_out", hd, c.dim_model).pack()
-        self.w_in_gated = Int4GPTQ.fuse(prefix + ".ff.w_in_gated",
-                                        [lin("ff.w_in", c.dim_model, c.dim_ff), lin("ff.w_gated", c.dim_model, c.dim_ff)],
-                                        row_interleave=True)
         self.w_out = lin("ff.w_out", c.dim_ff, c.dim_model).pack()
+        if any(l.perm is not None for l in (pq, pk, pv, w_in, w_gated)):
+            # act-order: every linear reads x through its own permutation, so q/k/v and gate/up stay separate
+            # (the reference's act-order route gives up the same fusions)
+            self.unfused = [l.pack() for l in (pq, pk, pv, w_in, w_gated)]
+        else:
+            self.qkv = Int4GPTQ.fuse(prefix + ".attn.project_qkv", [pq, pk, pv])
+            self.w_in_gated = Int4GPTQ.fuse(prefix + ".ff.w_in_gated", [w_in, w_gated], row_interleave=True)
 
     def init_random(self, device, gen):
         """Synthetic weights of the right shapes, generated directly in the packed layout."""
@@ -243,8 +278,27 @@ class EncoderLayer:
         self.w_in_gated = rnd("w_in_gated", c.dim_model, 2 * c.dim_ff, True)
         self.w_out = rnd("w_out", c.dim_ff, c.dim_model)
 
+    def linears(self):
+        return list(self.unfused) + [self.attn_out, self.w_out] if self.unfused else [self.qkv, self.attn_out, self.w_in_gated, self.w_out]
+
     def weight_bytes(self):
-        return sum(l.weight.nbytes() for l in (self.qkv, self.attn_out, self.w_in_gated, self.w_out))
+        return sum(l.weight.nbytes() for l in self.linears())
+
+    # the two fused projections, or their act-order stand-ins (separate RMSNorm, per-linear gather, concat / gate_mul)
+    def project_qkv(self, hidden, eps, out=None):
+        if self.unfused is None:
+            return ops.w4_linear(hidden, self.qkv.weight, bias=self.qkv.bias, out=out, norm_weight=self.ln_attn, norm_eps=eps)
+        xn = ops.rmsnorm(hidden, self.ln_attn, eps)
+        parts = [l.forward(xn) for l in self.unfused[:3]]
+        return torch.cat(parts, dim=1, out=out) if out is not None else torch.cat(parts, dim=1)
+
+    def ff_in(self, hidden, eps, out=None):
+        if self.unfused is None:
+            return ops.w4_linear(hidden, self.w_in_gated.weight, bias=self.w_in_gated.bias, out=out, norm_weight=self.ln_ff,
+                                 norm_eps=eps, epilogue=ops.EPI_SILU_MUL)
+        xn = ops.rmsnorm(hidden, self.ln_ff, eps)
+        gate = self.unfused[3].forward(xn, out=out)
+        return ops.gate_mul(gate, self.unfused[4].forward(xn), "silu")
 
 
 @dataclass
@@ -338,17 +392,13 @@ class LLaMA:
         cos, sin = ops.rope_cos_sin(ctx.positions, c.dim_head, c.rope_theta, True, llama3)  # RopePreparer
         scale = 1.0 / math.sqrt(c.dim_head)
         for li, layer in enumerate(self.layers):
-            ops.w4_linear(hidden, layer.qkv.weight, bias=layer.qkv.bias, out=bufs["qkv"],
-                           norm_weight=layer.ln_attn, norm_eps=c.eps)
+            layer.project_qkv(hidden, c.eps, out=bufs["qkv"])
             ops.decode_attention_fused(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.valid_lens, ctx.k_addrs[li],
                                        ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, scale, ctx.max_len_buf,
                                        out=bufs["attn"], workspace=workspace)
-            ops.w4_linear(bufs["attn"], layer.attn_out.weight, bias=layer.attn_out.bias, residual=hidden, out=hidden,
-                           epilogue=ops.EPI_RESIDUAL)
-            ops.w4_linear(hidden, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, out=bufs["act"],
-                           norm_weight=layer.ln_ff, norm_eps=c.eps, epilogue=ops.EPI_SILU_MUL)
-            ops.w4_linear(bufs["act"], layer.w_out.weight, bias=layer.w_out.bias, residual=hidden, out=hidden,
-                           epilogue=ops.EPI_RESIDUAL)
+            layer.attn_out.forward(bufs["attn"], residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
+            layer.ff_in(hidden, c.eps, out=bufs["act"])
+            layer.w_out.forward(bufs["act"], residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
         alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
         return ops.gemm_nt_small_m(hidden, self.lm_head, alpha=alpha, out=bufs["logits"],
                                    norm_weight=self.output_layernorm, norm_eps=c.eps, argmax_ws=argmax_ws)
@@ -393,7 +443,10 @@ class LLaMA:
         for li, layer in enumerate(self.layers):
             ka, va = ctx.k_addrs[li][task:task + 1], ctx.v_addrs[li][task:task + 1]
             xn = ops.rmsnorm(hidden, layer.ln_attn, c.eps)
-            qkv = ops.w4_linear(xn, layer.qkv.weight, bias=layer.qkv.bias)
+            if layer.unfused is None:
+                qkv = ops.w4_linear(xn, layer.qkv.weight, bias=layer.qkv.bias)
+            else:
+                qkv = torch.cat([l.forward(xn) for l in layer.unfused[:3]], dim=1)
             q, k, v = ops.rope_qk_cache(cos, sin, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
             ops.copy_to_rag_buffer2(placement, buf_lens, k.view(1, s, c.num_kv_heads, c.dim_head),
                                     v.view(1, s, c.num_kv_heads, c.dim_head), ka, va)
@@ -404,12 +457,13 @@ class LLaMA:
                 mask, ws = self._prefill_mask(s, ctx.max_len_buf)
                 att = ops.multi_query_attention_rag_buffer(q.view(1, s, c.num_heads, c.dim_head), buf_lens, ka, va, mask,
                                                            scale, ctx.max_len_buf, c.num_kv_heads, workspace=ws)
-            ops.w4_linear(att.view(s, -1), layer.attn_out.weight, bias=layer.attn_out.bias, residual=hidden, out=hidden,
-                          epilogue=ops.EPI_RESIDUAL)
+            layer.attn_out.forward(att.view(s, -1), residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
             xn = ops.rmsnorm(hidden, layer.ln_ff, c.eps)
-            act = ops.w4_linear(xn, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, epilogue=ops.EPI_SILU_MUL)
-            ops.w4_linear(act, layer.w_out.weight, bias=layer.w_out.bias, residual=hidden, out=hidden,
-                          epilogue=ops.EPI_RESIDUAL)
+            if layer.unfused is None:
+                act = ops.w4_linear(xn, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, epilogue=ops.EPI_SILU_MUL)
+            else:
+                act = ops.gate_mul(layer.unfused[3].forward(xn), layer.unfused[4].forward(xn), "silu")
+            layer.w_out.forward(act, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
         alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
         logits = ops.gemm_nt_small_m(hidden[s - 1:s], self.lm_head, alpha=alpha, norm_weight=self.output_layernorm,
                                      norm_eps=c.eps)
