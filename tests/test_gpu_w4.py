@@ -254,7 +254,7 @@ def test_mfma_gemm_shapes(oracle, dev, k, n):
 
 
 @pytest.mark.parametrize("m,k,n", [(17, 1024, 264), (33, 2048, 40), (64, 4096, 512), (100, 1152 + 128, 1000), (257, 2048, 384),
-                                   (300, 1024, 2048)])
+                                   (300, 1024, 2048), (515, 2304, 200)])
 def test_tiled_gemm_shapes(oracle, dev, m, k, n):
     """The M-tiled kernel (w4_gemm_tiled.hip, both M-tile heights) incl. ragged M / N tails, bias and residual
     epilogues; and the public entry for the same shapes (16-row passes up to M = 64, the tiled kernel above)."""
@@ -265,10 +265,11 @@ def test_tiled_gemm_shapes(oracle, dev, m, k, n):
     _check_mfma(oracle, dev, k, n, m, seed=54 + m, residual=True)
 
 
-def test_tiled_gemm_silu_mul(oracle, dev):
+@pytest.mark.parametrize("m", [70, 300])
+def test_tiled_gemm_silu_mul(oracle, dev, m):
     from zhilight_amd import ops
     rng = np.random.default_rng(61)
-    k, nff, g, m = 1024, 200, 128, 70
+    k, nff, g = 1024, 200, 128
     qw1, qz1, sc1 = synth.gptq_hf(rng, k, nff, g)
     qw2, qz2, sc2 = synth.gptq_hf(rng, k, nff, g)
     km1, km2 = oracle.gptq_prepare_k_major(qw1, qz1, sc1, g), oracle.gptq_prepare_k_major(qw2, qz2, sc2, g)
