@@ -230,6 +230,13 @@ def test_prefill_then_decode_matches_oracle(oracle, dev):
         rv = oracle.u2h(om.vb[li][0][:s]).astype(np.float64)
         assert np.abs(gv - rv).max() <= 2.0 ** -9 * np.abs(rv).max()
     assert int(ctx.positions[0]) == s and int(ctx.placement[0]) == s and int(ctx.valid_lens[0]) == s + 1
+    # chunked prefill (three pieces, each attending to the KV of the ones before) gives the same logits and KV
+    ctx_c = model.new_context(1, len_buf, 0)
+    got_c = model.prefill(ctx_c, 0, torch.from_numpy(prompt), chunk=27).float().cpu().numpy().astype(np.float64)
+    assert np.abs(got_c - ref).max() <= 1e-3 * scale + 2.0 ** -11 * scale
+    assert int(ctx_c.positions[0]) == s and int(ctx_c.valid_lens[0]) == s + 1
+    dk = (ctx_c.kv[0][:, :, :s].float() - ctx.kv[0][:, :, :s].float()).abs().max().item()
+    assert dk <= 2.0 ** -8 * ctx.kv[0][:, :, :s].float().abs().max().item()
     # decode continues from the prefilled state (feed the oracle's greedy token to both)
     tok = int(ref.argmax(axis=1)[0])
     ctx.tokens[0] = tok

@@ -409,17 +409,29 @@ class LLaMA:
             return (rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"])
         return None
 
-    def _prefill_mask(self, s, len_buf):
+    def _prefill_mask(self, s, len_buf, pos0=0):
         """causal mask + workspace for head sizes the MFMA prefill kernel does not cover"""
-        key = ("prefill", s, len_buf)
+        key = ("prefill", s, len_buf, pos0)
         if key not in self._bufs:
             c, dev = self.cfg, self.device
-            mask = torch.tril(torch.ones(s, len_buf, dtype=torch.int8, device=dev)).contiguous()
+            mask = torch.tril(torch.ones(s, len_buf, dtype=torch.int8, device=dev), diagonal=pos0).contiguous()
             ws = ops.decode_attn_workspace(1, s, c.num_heads, c.dim_head, len_buf, dev)
             self._bufs[key] = (mask, ws)
         return self._bufs[key]
 
-    def prefill(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor):
+    def prefill(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor, chunk: int = 0):
+        """Prompt encode, optionally in chunks of `chunk` tokens (the reference's chunked prefill,
+        src/generator/batch_generator.cpp:1048-1084: a long prompt enters the batch piece by piece, each piece
+        attending to the KV of the pieces before it)."""
+        s = int(prompt.numel())
+        if chunk <= 0 or chunk >= s:
+            return self._prefill_chunk(ctx, task, prompt, 0)
+        logits = None
+        for p0 in range(0, s, chunk):
+            logits = self._prefill_chunk(ctx, task, prompt[p0:p0 + chunk], p0)
+        return logits
+
+    def _prefill_chunk(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor, pos0: int):
         """The "encode part" of a task (LLaMA::encode with len_q = prompt length for one task:
         src/model/llama.cpp:75-165, Attention::impl::NormalImpl::dynamic_batch_forward encode branch,
         src/nn/attention/attention.cpp:846-964 / attn_encode_group :442-622): runs the whole prompt through
@@ -431,10 +443,10 @@ class LLaMA:
         multi_query_attention_rag_buffer)."""
         c, dev = self.cfg, self.device
         s = int(prompt.numel())
-        if s < 1 or s + 1 > ctx.max_len_buf:
+        if s < 1 or pos0 + s + 1 > ctx.max_len_buf:
             raise ops.ZLError("prompt does not fit the task's KV buffer")
         tokens = prompt.to(device=dev, dtype=torch.int32).contiguous()
-        pos = torch.arange(s, dtype=torch.int32, device=dev)
+        pos = torch.arange(pos0, pos0 + s, dtype=torch.int32, device=dev)
         hidden = ops.embedding(tokens, self.token_embedding, c.scale_emb)
         cos, sin = ops.rope_cos_sin(pos, c.dim_head, c.rope_theta, True, self._llama3_rope())
         placement = pos.view(1, s)
@@ -451,10 +463,10 @@ class LLaMA:
             ops.copy_to_rag_buffer2(placement, buf_lens, k.view(1, s, c.num_kv_heads, c.dim_head),
                                     v.view(1, s, c.num_kv_heads, c.dim_head), ka, va)
             if c.dim_head == 128 and q.dtype == torch.float16:
-                att = ops.prefill_attention(q.view(s, c.num_heads, c.dim_head), ctx.kv[task][li, 0], ctx.kv[task][li, 1], 0,
+                att = ops.prefill_attention(q.view(s, c.num_heads, c.dim_head), ctx.kv[task][li, 0], ctx.kv[task][li, 1], pos0,
                                             c.num_kv_heads, scale)
             else:
-                mask, ws = self._prefill_mask(s, ctx.max_len_buf)
+                mask, ws = self._prefill_mask(s, ctx.max_len_buf, pos0)
                 att = ops.multi_query_attention_rag_buffer(q.view(1, s, c.num_heads, c.dim_head), buf_lens, ka, va, mask,
                                                            scale, ctx.max_len_buf, c.num_kv_heads, workspace=ws)
             layer.attn_out.forward(att.view(s, -1), residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
@@ -468,9 +480,9 @@ class LLaMA:
         logits = ops.gemm_nt_small_m(hidden[s - 1:s], self.lm_head, alpha=alpha, norm_weight=self.output_layernorm,
                                      norm_eps=c.eps)
         ctx.tokens[task] = torch.argmax(logits[0].float()).to(torch.int32)
-        ctx.positions[task] = s
-        ctx.placement[task] = s
-        ctx.valid_lens[task] = s + 1
+        ctx.positions[task] = pos0 + s
+        ctx.placement[task] = pos0 + s
+        ctx.valid_lens[task] = pos0 + s + 1
         return logits
 
     def step_greedy(self, ctx: DynBatchContext):
