@@ -159,6 +159,11 @@ int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
 int zl_gemm_nt_small_m(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K) */, const uint16_t* bias,
                        uint16_t* y, int64_t m, int64_t n, int64_t k, float alpha, int dtype,
                        const uint16_t* norm_weight, float norm_eps, zl_stream_t s);
+/* The same product for more than a handful of rows (lm_head at decode batches > 4, unquantised linears,
+ * prompt chunks) on the matrix cores: fp32-accumulating MFMA GEMM, one rounding to T; K % 128 == 0. */
+int zl_gemm_nt(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K) */, const uint16_t* bias, uint16_t* y,
+               int64_t m, int64_t n, int64_t k, float alpha, int dtype, zl_stream_t s);
+
 /* lm_head + greedy pick without a separate argmax pass over the logits: the GEMV leaves each wavefront's
  * best (rounded logit, row index) in argmax_ws (zl_argmax_workspace_bytes(m, n) bytes); zl_greedy_advance
  * reduces them per activation row (first index on ties, like torch.argmax) and does the between-steps

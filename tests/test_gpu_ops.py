@@ -391,3 +391,19 @@ def test_prefill_attention(oracle, dev, s_q, pos0, h, hkv, bshd):
     got = _np(ops.prefill_attention(_t(q, dev), _t(kb, dev), _t(vb, dev), pos0, hkv, 1.0 / np.sqrt(d), bshd)).astype(np.float64)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("m,n,k", [(5, 1000, 256), (16, 128, 128), (33, 4100, 512), (100, 300, 1024), (8, 128256, 128)])
+def test_dense_gemm_nt_mfma(oracle, dev, dtype, m, n, k):
+    """zl_gemm_nt (a21: functions::Gemm NT, fp32 accumulation) vs the exact product, incl. ragged M / N and bias."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(m + n)
+    x = _to_bits(rng.standard_normal((m, k)), dtype, oracle)
+    w = _to_bits(rng.standard_normal((n, k)) * 0.05, dtype, oracle)
+    bias = _to_bits(rng.standard_normal(n) * 0.1, dtype, oracle)
+    rel = 2.0 ** -8 if dtype else 2.0 ** -11
+    for b in (None, bias):
+        exact = oracle.gemm_nt(x, w, b, 0.5, dtype, exact=True)
+        got = oracle.to_f32(_bits(ops.gemm_nt(_tt(x, dev, dtype), _tt(w, dev, dtype), None if b is None else _tt(b, dev, dtype), 0.5)), dtype)
+        assert (np.abs(got - exact) <= 1.01 * rel * np.abs(exact) + 1e-5 * np.abs(exact).max()).all()

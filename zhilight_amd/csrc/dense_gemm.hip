@@ -1,0 +1,163 @@
+// dense_gemm.hip -- fp16 / bf16 NT GEMM on the matrix cores for M > 4: y = T(alpha * x . W^T + bias), W (N, K).
+//
+// Replaces functions::Gemm::forward (bm/functions/gemm.cpp:505-599, cuBLASLt) where the decode path meets a
+// dense matrix with more than a handful of rows: RawEmbedding::projection (the lm_head,
+// src/nn/embedding/embedding.cu:274-289) for decode batches, NormalLinear for unquantised models and prompt
+// chunks.  fp32 accumulation, one rounding to T (the reference's HIGH_PRECISION GEMM mode).  M <= 4 stays on
+// the wave-per-row GEMV (dense_gemv.hip), which streams at 6.5 TB/s.
+//
+// Same tiling as w4_gemm_tiled.hip without the dequant: workgroup = 4 waves = BM x 128 outputs, wave = BM x 32
+// (two 16-column weight tiles share every activation fragment), K in 128-k chunks; the activation chunk is
+// double-buffered in LDS; weight fragments (lane = row n, 8 consecutive k: 16 B) are loaded straight into
+// the MFMA B registers two chunks ahead (a 16-row x 128-k tile is 16 x 256 contiguous bytes).
+#include <stdlib.h>
+#include "zl_common.h"
+
+namespace {
+
+constexpr int kDW = 4, kDT = kDW * 64, kDBN = kDW * 32, kDRow = 128 + 8;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct DenseGemmParams {
+    const uint16_t* x;
+    int64_t ldx;
+    const uint16_t* w;
+    const uint16_t* bias;
+    uint16_t* y;
+    float alpha;
+    int m, n, k, groups;
+};
+
+template <int DT>
+__device__ __forceinline__ f4 mfma16(uint4 a, uint4 b, f4 c) {
+    if constexpr (DT == ZL_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+}
+
+template <int DT, int BM>
+__global__ __launch_bounds__(kDT, 2) void k_dense_gemm(const DenseGemmParams p) {
+    constexpr int RB = BM / 16, XR = BM / 16;
+    __shared__ __attribute__((aligned(16))) uint16_t xs[2][BM * kDRow];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrow = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * BM;
+    const int n_base = blockIdx.x * kDBN + wave * 32;
+    const int G = p.groups;
+
+    // weight fragments of chunk g: tile j (rows n_base + 16 j + nrow), step t: 16 B at k = 128 g + 32 t + 8 kq
+    int nr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n_base + 16 * j + nrow;
+        nr[j] = n < p.n ? n : p.n - 1;
+    }
+    uint4 wf[2][2][4];                       // [ring slot][tile][t]
+    auto load_w = [&](int slot, int g) {
+        const int gc = g < G ? g : G - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint16_t* src = p.w + (size_t)nr[j] * p.k + (size_t)gc * 128 + 8 * kq;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[slot][j][t] = zl_load_nt(reinterpret_cast<const uint4*>(src + 32 * t));
+        }
+    };
+    const int xrow = threadIdx.x >> 4, xcol = (threadIdx.x & 15) * 8;
+    uint4 xr[XR];
+    auto load_x = [&](int g) {
+        const int gc = g < G ? g : G - 1;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int row = m0 + xrow + 16 * r;
+            const int rc = row < p.m ? row : p.m - 1;
+            xr[r] = *reinterpret_cast<const uint4*>(p.x + (size_t)rc * p.ldx + (size_t)gc * 128 + xcol);
+            if (row >= p.m) xr[r] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < XR; ++r) *reinterpret_cast<uint4*>(&xs[buf][(xrow + 16 * r) * kDRow + xcol]) = xr[r];
+    };
+
+    load_x(0);
+    load_w(0, 0);
+    load_w(1, 1);
+    store_x(0);
+    load_x(1);
+    __syncthreads();
+
+    f4 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        acc[rb][0] = (f4){0.f, 0.f, 0.f, 0.f};
+        acc[rb][1] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    int g = 0;
+#pragma unroll 1
+    for (; g < G; g += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (g + u < G) {                 // workgroup-uniform; g even: chunk parity = u
+                const uint16_t* xb = &xs[u][nrow * kDRow + kq * 8];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const uint4 a = *reinterpret_cast<const uint4*>(xb + rb * 16 * kDRow + t * 32);
+                        acc[rb][0] = mfma16<DT>(a, wf[u][0][t], acc[rb][0]);
+                        acc[rb][1] = mfma16<DT>(a, wf[u][1][t], acc[rb][1]);
+                    }
+                }
+                load_w(u, g + u + 2);        // the slot just consumed <- two chunks ahead
+                store_x(u ^ 1);
+                load_x(g + u + 2);
+                __syncthreads();
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n_base + 16 * j + nrow;
+        const float b = (p.bias && n < p.n) ? ZT<DT>::to_f32(p.bias[n]) : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + rb * 16 + 4 * kq + i;
+                if (row < p.m && n < p.n) p.y[(size_t)row * p.n + n] = ZT<DT>::from_f32(p.alpha * acc[rb][j][i] + b);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int zl_gemm_nt(const uint16_t* x, int64_t ldx, const uint16_t* w, const uint16_t* bias, uint16_t* y, int64_t m,
+                          int64_t n, int64_t k, float alpha, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(x && w && y && m > 0 && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(k % 128 == 0 && ldx % 8 == 0 && ldx >= k && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, ZL_ESHAPE);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    DenseGemmParams p;
+    p.x = x; p.ldx = ldx; p.w = w; p.bias = bias; p.y = y; p.alpha = alpha;
+    p.m = (int)m; p.n = (int)n; p.k = (int)k; p.groups = (int)(k / 128);
+    const unsigned gx = (unsigned)((n + kDBN - 1) / kDBN);
+    hipStream_t hs = (hipStream_t)s;
+    const int bm = m <= 16 ? 16 : (m <= 32 ? 32 : 64);
+    ZL_CHECK_ARG((m + bm - 1) / bm <= 65535, ZL_ELIMIT);
+    const dim3 grid(gx, (unsigned)((m + bm - 1) / bm));
+#define ZL_DG(DT)                                                                              \
+    if (bm == 16) hipLaunchKernelGGL((k_dense_gemm<DT, 16>), grid, dim3(kDT), 0, hs, p);       \
+    else if (bm == 32) hipLaunchKernelGGL((k_dense_gemm<DT, 32>), grid, dim3(kDT), 0, hs, p);  \
+    else hipLaunchKernelGGL((k_dense_gemm<DT, 64>), grid, dim3(kDT), 0, hs, p);
+    if (dtype == ZL_F16) { ZL_DG(ZL_F16) } else { ZL_DG(ZL_BF16) }
+#undef ZL_DG
+    return zl_launch_status();
+}

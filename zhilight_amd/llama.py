@@ -400,6 +400,10 @@ class LLaMA:
             layer.ff_in(hidden, c.eps, out=bufs["act"])
             layer.w_out.forward(bufs["act"], residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
         alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
+        if b > 4 and argmax_ws is None and c.dim_model % 128 == 0:
+            # more rows than the streaming GEMV handles per weight pass: separate norm + MFMA GEMM (one pass)
+            xn = ops.rmsnorm(hidden, self.output_layernorm, c.eps)
+            return ops.gemm_nt(xn, self.lm_head, alpha=alpha, out=bufs["logits"])
         return ops.gemm_nt_small_m(hidden, self.lm_head, alpha=alpha, out=bufs["logits"],
                                    norm_weight=self.output_layernorm, norm_eps=c.eps, argmax_ws=argmax_ws)
 
@@ -490,6 +494,11 @@ class LLaMA:
         inside the lm_head launch + one small reduction, and advance the batch state.  Returns
         (logits, next_tokens int64)."""
         b = ctx.tokens.numel()
+        if b > 4:   # the in-launch pick rides the small-M GEMV; bigger batches: MFMA lm_head + a plain argmax
+            logits = self.encode(ctx)
+            nxt = torch.argmax(logits, dim=-1)
+            self.advance(ctx, nxt)
+            return logits, nxt
         key = ("argmax", b)
         if key not in self._bufs:
             self._bufs[key] = (ops.argmax_workspace(b, self.cfg.vocab_size, self.device),

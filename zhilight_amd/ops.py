@@ -291,6 +291,22 @@ def gemm_nt_small_m(x, weight, bias=None, alpha=1.0, out=None, norm_weight=None,
     return out
 
 
+def gemm_nt(x, weight, bias=None, alpha=1.0, out=None):
+    """functions::Gemm(trans_b=True) for any M on the matrix cores (K % 128 == 0); M <= 4 callers want
+    gemm_nt_small_m, which streams the weights at HBM speed."""
+    _chk_cuda(x, weight, bias)
+    x2 = x.reshape(-1, x.shape[-1])
+    m, k = x2.shape
+    n = weight.shape[0]
+    if weight.shape[1] != k:
+        raise ZLError("size K mismatch")
+    if out is None:
+        out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    check(lib().zl_gemm_nt(_p(x2), _i(x2.stride(0)), _p(weight), _p(bias), _p(out), _i(m), _i(n), _i(k), _f(alpha),
+                           C.c_int(_dt(x)), _stream()), "gemm_nt")
+    return out
+
+
 def argmax_workspace(m, n, device):
     nbytes = lib().zl_argmax_workspace_bytes(_i(m), _i(n))
     if nbytes < 0:
