@@ -287,6 +287,9 @@ class EncoderLayer:
     # the two fused projections, or their act-order stand-ins (separate RMSNorm, per-linear gather, concat / gate_mul)
     def project_qkv(self, hidden, eps, out=None):
         if self.unfused is None:
+            if hidden.shape[0] > 4:   # the fused norm prologue normalises row by row per workgroup: beyond a few
+                xn = ops.rmsnorm(hidden, self.ln_attn, eps)   # rows one separate RMSNorm launch is cheaper
+                return ops.w4_linear(xn, self.qkv.weight, bias=self.qkv.bias, out=out)
             return ops.w4_linear(hidden, self.qkv.weight, bias=self.qkv.bias, out=out, norm_weight=self.ln_attn, norm_eps=eps)
         xn = ops.rmsnorm(hidden, self.ln_attn, eps)
         parts = [l.forward(xn) for l in self.unfused[:3]]
@@ -294,6 +297,9 @@ class EncoderLayer:
 
     def ff_in(self, hidden, eps, out=None):
         if self.unfused is None:
+            if hidden.shape[0] > 4:
+                xn = ops.rmsnorm(hidden, self.ln_ff, eps)
+                return ops.w4_linear(xn, self.w_in_gated.weight, bias=self.w_in_gated.bias, out=out, epilogue=ops.EPI_SILU_MUL)
             return ops.w4_linear(hidden, self.w_in_gated.weight, bias=self.w_in_gated.bias, out=out, norm_weight=self.ln_ff,
                                  norm_eps=eps, epilogue=ops.EPI_SILU_MUL)
         xn = ops.rmsnorm(hidden, self.ln_ff, eps)
