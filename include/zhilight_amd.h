@@ -44,6 +44,11 @@ int zl_version(void);
 const char* zl_status_string(int status);
 /* number of CUs of the current device (cached per call; used by grid heuristics). >0 or -hipError */
 int zl_device_cu_count(void);
+/* Pre-size the library's per-device scratch (split-K partial sums of the M-tiled GEMMs).  It grows on demand
+ * outside stream capture; call this before capturing a graph whose first eager run you skipped.  Launchers
+ * that use the scratch are ordered by the stream they run on: use one compute stream per device. */
+int zl_workspace_reserve(int64_t bytes);
+
 
 /* ------------------------------------------------------------------------------------------------
  * a4  Load-time layout transforms (bit-exact integer work).

@@ -212,9 +212,9 @@ def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=Fal
                                 norm_weight=None if nw is None else _t(nw, dev), norm_eps=1e-5,
                                 epilogue=ops.EPI_RESIDUAL if residual else 0)
     got = _np(y).astype(np.float64)
-    # m > 64 without a fused norm runs the M-tiled kernel: it multiplies with W16 = rn16(rn16(q - z) * s), the
+    # m > 16 without a fused norm runs the M-tiled kernel: it multiplies with W16 = rn16(rn16(q - z) * s), the
     # matrix the reference's M > 40 branch dequantises (dequant_k_major), so THAT product is its exact value
-    tiled = force_tiled or (m > 64 and not norm)
+    tiled = force_tiled or (m > 16 and not norm)
     w16 = oracle.gptq_dequant_k_major(*km)
     ref40 = oracle.gemm_nt(xin, w16, None if b is None else oracle.h2u(b), exact=True)
     lin = np.zeros_like(exact)
@@ -257,7 +257,7 @@ def test_mfma_gemm_shapes(oracle, dev, k, n):
                                    (300, 1024, 2048), (515, 2304, 200)])
 def test_tiled_gemm_shapes(oracle, dev, m, k, n):
     """The M-tiled kernel (w4_gemm_tiled.hip, both M-tile heights) incl. ragged M / N tails, bias and residual
-    epilogues; and the public entry for the same shapes (16-row passes up to M = 64, the tiled kernel above)."""
+    epilogues, split-K for the short grids; and the public entry for the same shapes."""
     _check_mfma(oracle, dev, k, n, m, seed=50 + m, force_tiled=True)
     _check_mfma(oracle, dev, k, n, m, seed=51 + m, bias=True, force_tiled=True)
     _check_mfma(oracle, dev, k, n, m, seed=52 + m, residual=True, force_tiled=True)

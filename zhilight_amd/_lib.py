@@ -18,7 +18,7 @@ SO_PATH = os.environ.get("ZHILIGHT_AMD_SO") or os.path.join(_HERE, "libzhilight_
 
 # every entry point declared in include/zhilight_amd.h (kept in sync by tests/test_abi.py)
 SYMBOLS = [
-    "zl_version", "zl_status_string", "zl_device_cu_count",
+    "zl_version", "zl_status_string", "zl_device_cu_count", "zl_workspace_reserve",
     "zl_gptq_shuffle", "zl_gptq_increase_zero", "zl_gptq_q4_to_q8", "zl_transpose_2d",
     "zl_awq_un_shuffle", "zl_awq_shuffle",
     "zl_w4_layout", "zl_w4_pack", "zl_w4_dequant", "zl_w4a16_gemm",

@@ -253,6 +253,34 @@ const char* zl_status_string(int st) {
     }
 }
 
+// ---- per-device scratch for launchers that split a product over workgroups (split-K partial sums).
+// One buffer per device, grown on demand OUTSIDE stream capture (hipMalloc is not capturable): callers that
+// capture graphs run the step once eagerly first, or reserve explicitly.  Launches using it must be
+// stream-ordered with respect to each other (one compute stream per device, as in the reference's engine).
+static void* g_ws_ptr[64] = {nullptr};
+static size_t g_ws_size[64] = {0};
+
+void* zlint_workspace(size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (g_ws_size[dev] >= bytes) return g_ws_ptr[dev];
+    void* np = nullptr;
+    const size_t want = bytes < (size_t)(64 << 20) ? (size_t)(64 << 20) : bytes;   // 64 MiB floor
+    if (hipMalloc(&np, want) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (g_ws_ptr[dev]) (void)hipFree(g_ws_ptr[dev]);
+    g_ws_ptr[dev] = np;
+    g_ws_size[dev] = want;
+    return np;
+}
+
+int zl_workspace_reserve(int64_t bytes) {
+    ZL_CHECK_ARG(bytes >= 0, ZL_EINVAL);
+    return zlint_workspace((size_t)bytes) || bytes == 0 ? ZL_OK : ZL_ELIMIT;
+}
+
 int zl_device_cu_count(void) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

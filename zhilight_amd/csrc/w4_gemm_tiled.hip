@@ -43,6 +43,11 @@ struct TiledParams {
     int groups;      // k / 128 chunks
     int tiles;       // ceil(n / 16)
     int epi, ld_out;
+    // split-K (few rows, few column tiles): blockIdx.z handles chunks [z * split_chunks, ...) and leaves its raw
+    // fp32 partial in ws[z][row][n] (row stride ld_ws); k_splitk_epilogue sums the splits in index order
+    int split_chunks;
+    float* ws;
+    int ld_ws;
 };
 
 __device__ __forceinline__ uint32_t and_or_t(uint32_t w, uint32_t mask_s, uint32_t magic_v) {
@@ -79,17 +84,18 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
     const int nrow = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.y * BM;
     const int tile0 = blockIdx.x * (kBN / 16) + wave * 2;   // this wave's two 16-row weight tiles
-    const int G = p.groups;
+    const int g_begin = p.ws ? blockIdx.z * p.split_chunks : 0;
+    const int G = p.ws ? min(p.groups, g_begin + p.split_chunks) : p.groups;   // one past this workgroup's last chunk
 
     // ---- weight ring: item (j, g) of this wave = tile (tile0 + j), chunk g
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
     const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)nrow * 4u;
     const int t0c = tile0 < p.tiles ? tile0 : p.tiles - 1, t1c = tile0 + 1 < p.tiles ? tile0 + 1 : p.tiles - 1;
-    const uint32_t base0 = (uint32_t)t0c * (uint32_t)G, base1 = (uint32_t)t1c * (uint32_t)G;
+    const uint32_t base0 = (uint32_t)t0c * (uint32_t)p.groups, base1 = (uint32_t)t1c * (uint32_t)p.groups;
     uint4 wq[kRingT];
     uint32_t mt[kRingT];
-    int iss_g = 0;                            // next chunk to issue (both tiles)
+    int iss_g = g_begin;                      // next chunk to issue (both tiles)
     auto issue_pair = [&](int slot0) {
         const uint32_t g = (uint32_t)(iss_g < G ? iss_g : G - 1);
         const uint32_t it0 = base0 + g, it1 = base1 + g;
@@ -119,14 +125,14 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
             *reinterpret_cast<uint4*>(&xs[buf][(xrow + 16 * r) * kRowHalfs + xcol]) = xr[r];
     };
 
-    load_x(0);
+    load_x(g_begin);
 #pragma unroll
     for (int s = 0; s < kRingT; s += 2) {
         issue_pair(s);
         __builtin_amdgcn_sched_barrier(0);
     }
     store_x(0);
-    load_x(1);
+    load_x(g_begin + 1);
     __syncthreads();
 
     const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
@@ -169,18 +175,35 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
     };
 
     // ---- main loop: 4 chunks per turn of the ring (static slot indices)
-    int g = 0;
+    int g = g_begin;                          // ring slots and LDS buffers go by the LOCAL chunk index (g - g_begin)
 #pragma unroll 1
     for (; g < G; g += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (g + u < G) {                  // workgroup-uniform
-                chunk(2 * u, (g + u) & 1);
-                store_x((g + u + 1) & 1);     // chunk g+u+1 (loaded one step ago) -> the other buffer
+                chunk(2 * u, u & 1);
+                store_x((u + 1) & 1);         // chunk g+u+1 (loaded one step ago) -> the other buffer
                 load_x(g + u + 2);
                 __syncthreads();
             }
         }
+    }
+
+    if (p.ws) {                               // split-K: raw partial sums, epilogue in k_splitk_epilogue
+        float* wsz = p.ws + (size_t)blockIdx.z * p.m * p.ld_ws;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = (tile0 + j) * 16 + nrow;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + rb * 16 + 4 * kq + i;
+                    if (row < p.m && n < p.ld_ws) wsz[(size_t)row * p.ld_ws + n] = acc[rb][j][i];
+                }
+            }
+        }
+        return;
     }
 
     // ---- epilogue: C fragment = column n (lane & 15), rows 4 kq + i of each 16-row block
@@ -227,7 +250,52 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
     }
 }
 
+// sums the split-K partials in split order (deterministic) and applies the launcher's epilogue
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict__ ws, int splits, int m, int n, int ld_ws,
+                                                         const uint16_t* __restrict__ bias, const uint16_t* residual,
+                                                         uint16_t* y, int epi, int ld_out) {
+    const bool silu = (epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
+    const int cols = silu ? n / 2 : n;
+    const int64_t total = (int64_t)m * cols;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / cols), c = (int)(idx % cols);
+        auto sum = [&](int nn) {
+            float v = 0.f;
+            for (int z = 0; z < splits; ++z) v += ws[((size_t)z * m + row) * ld_ws + nn];
+            return v;
+        };
+        if (!silu) {
+            const float v = sum(c);
+            const float b = ((epi & ZL_EPI_BIAS) && bias) ? (float)__builtin_bit_cast(_Float16, bias[c]) : 0.f;
+            const size_t o = (size_t)row * ld_out + c;
+            float ov;
+            if (epi & ZL_EPI_ADD_C) ov = ((float)__builtin_bit_cast(_Float16, y[o]) + v) + b;
+            else ov = v + b;
+            _Float16 y16 = zl_f32_to_f16(ov);
+            if (epi & ZL_EPI_RESIDUAL) y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, residual[o]) + (float)y16);
+            y[o] = __builtin_bit_cast(uint16_t, y16);
+        } else {
+            float gt = sum(2 * c), up = sum(2 * c + 1);
+            if ((epi & ZL_EPI_BIAS) && bias) {
+                gt += (float)__builtin_bit_cast(_Float16, bias[2 * c]);
+                up += (float)__builtin_bit_cast(_Float16, bias[2 * c + 1]);
+            }
+            float ov;
+            if (epi & ZL_EPI_SILU_MUL) {
+                gt = (float)zl_f32_to_f16(gt);
+                up = (float)zl_f32_to_f16(up);
+                ov = silu_t(gt) * up;
+            } else {
+                ov = (float)((double)gt / (1.0 + (double)expf(-gt))) * up;
+            }
+            y[(size_t)row * ld_out + c] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(ov));
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" void* zlint_workspace(size_t bytes);   // misc_ops.hip
 
 // called by zl_w4a16_gemm_mfma for m > 16 (same operands)
 extern "C" int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
@@ -262,7 +330,28 @@ extern "C" int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_
     int bm = m <= 32 ? 32 : (m * (int64_t)gx >= 128 * 512 ? 128 : 64);
     if (bm_env == 32 || bm_env == 64 || bm_env == 128) bm = bm_env;
     ZL_CHECK_ARG((m + bm - 1) / bm <= 65535, ZL_ELIMIT);
-    const dim3 grid(gx, (unsigned)((m + bm - 1) / bm));
+    const int gy = (int)((m + bm - 1) / bm);
+    // too few workgroups for the chip (decode batches: one M tile, N / 128 column tiles): split K over
+    // blockIdx.z so that ~2 workgroups per CU exist, >= 4 chunks each; partials go through the device scratch
+    static const int split_env = [] { const char* e = getenv("ZL_W4_TILED_SPLITK"); return e ? atoi(e) : 0; }();
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    int splits = 1;
+    if ((int64_t)gx * gy < cus) {
+        splits = (int)((2 * (int64_t)cus + (int64_t)gx * gy - 1) / ((int64_t)gx * gy));
+        const int max_s = p.groups / 4 > 0 ? p.groups / 4 : 1;
+        if (splits > max_s) splits = max_s;
+        if (splits > 32) splits = 32;
+    }
+    if (split_env > 0) splits = split_env <= p.groups ? split_env : p.groups;
+    p.ws = nullptr; p.split_chunks = p.groups; p.ld_ws = (int)L.np;
+    if (splits > 1) {
+        p.split_chunks = (p.groups + splits - 1) / splits;
+        splits = (p.groups + p.split_chunks - 1) / p.split_chunks;       // no empty split
+        p.ws = reinterpret_cast<float*>(zlint_workspace((size_t)splits * m * L.np * sizeof(float)));
+        if (!p.ws) return ZL_ELIMIT;
+    }
+    const dim3 grid(gx, (unsigned)gy, (unsigned)splits);
     const size_t lds = (size_t)2 * bm * kRowHalfs * 2;
 #define ZL_TILED_LAUNCH(BMV)                                                                                   \
     {                                                                                                          \
@@ -277,5 +366,11 @@ extern "C" int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_
     else if (bm == 64) ZL_TILED_LAUNCH(64)
     else ZL_TILED_LAUNCH(128)
 #undef ZL_TILED_LAUNCH
+    st = zl_launch_status();
+    if (st || splits <= 1) return st;
+    const int64_t outs = m * (silu ? n / 2 : n);
+    const unsigned rgrid = (unsigned)((outs + 255) / 256 > 4096 ? 4096 : (outs + 255) / 256);
+    hipLaunchKernelGGL(k_splitk_epilogue, dim3(rgrid), dim3(256), 0, hs, p.ws, splits, (int)m, (int)n, p.ld_ws, bias, residual, y,
+                       epilogue, p.ld_out);
     return zl_launch_status();
 }

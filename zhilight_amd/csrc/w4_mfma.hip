@@ -599,11 +599,10 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const
     const bool silu = epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32);
     ZL_CHECK_ARG(!silu || n % 2 == 0, ZL_ESHAPE);
     hipStream_t hs = (hipStream_t)s;
-    // many rows: the M-tiled kernel (w4_gemm_tiled.hip; no fused norm prologue) reads the weights once per 64
-    // rows and runs 650-830 TFLOP/s at M >= 1024.  Its K loop is serial per workgroup, so for the decode
-    // batches in between (17..64 rows) repeated 16-row passes of this streaming kernel are still faster
-    // (M = 32: 114 vs 167 us per Llama-3-8B layer; M = 64: on par)
-    static const int tiled_min_m = [] { const char* e = getenv("ZL_W4_TILED_MIN_M"); return e ? atoi(e) : 65; }();
+    // more than one 16-row pass: the M-tiled kernel (w4_gemm_tiled.hip; no fused norm prologue) reads the
+    // weights once per 32-128 rows; with few rows it splits K over workgroups to fill the chip
+    // (M = 32: 82 vs 113 us per Llama-3-8B layer for two passes of this kernel; M = 64: 109 vs 224)
+    static const int tiled_min_m = [] { const char* e = getenv("ZL_W4_TILED_MIN_M"); return e ? atoi(e) : 17; }();
     if (m >= tiled_min_m && !norm_weight && k % 128 == 0)
         return zl_w4a16_gemm_tiled(x, ldx, qw, meta, bias, residual, y, m, n, k, group_size, epilogue, s);
 
