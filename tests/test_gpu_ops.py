@@ -407,3 +407,16 @@ def test_dense_gemm_nt_mfma(oracle, dev, dtype, m, n, k):
         exact = oracle.gemm_nt(x, w, b, 0.5, dtype, exact=True)
         got = oracle.to_f32(_bits(ops.gemm_nt(_tt(x, dev, dtype), _tt(w, dev, dtype), None if b is None else _tt(b, dev, dtype), 0.5)), dtype)
         assert (np.abs(got - exact) <= 1.01 * rel * np.abs(exact) + 1e-5 * np.abs(exact).max()).all()
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 128, 256), (5, 1000, 1024), (32, 4096, 4096), (33, 520, 2304), (100, 300, 512),
+                                   (7, 64, 272)])
+def test_int8_gemm_shapes_bit_exact(oracle, dev, m, n, k):
+    """zl_int8_gemm_nt: the tiled kernel (K % 256 == 0; split-K with int32 atomics = exact) and the simple one
+    (other K) against the oracle, ragged M / N."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(m * 7 + n)
+    a = rng.integers(-127, 128, (m, k)).astype(np.int8)
+    w = rng.integers(-127, 128, (n, k)).astype(np.int8)
+    got = _np(ops.int8_gemm_nt(_t(a, dev), _t(w, dev)))
+    assert np.array_equal(got, oracle.int8_gemm_nt(a, w))

@@ -102,6 +102,112 @@ __global__ __launch_bounds__(256) void k_int8_gemm(const int8_t* __restrict__ a,
         }
 }
 
+// Tiled int8 GEMM (the Int8Linear hot kernel, functions::Gemm int8 path of linear.cpp:557-635 / cuBLASLt IMMA):
+// same structure as dense_gemm.hip -- workgroup = 4 waves = BM x 128 outputs, wave = BM x 32, K in 256-byte
+// chunks, the activation chunk double-buffered in LDS, weight fragments (lane = row n, 16 consecutive k) loaded
+// two chunks ahead straight into the MFMA B registers (v_mfma_i32_16x16x64_i8).  Few workgroups (decode
+// batches) -> K split over blockIdx.z with int32 atomics: integer addition is associative, so the result is
+// exact and order-independent.
+constexpr int kI8Row = 256 + 16;    // padded LDS row (bytes)
+
+template <int BM>
+__global__ __launch_bounds__(256, 2) void k_int8_gemm_tiled(const int8_t* __restrict__ a, const int8_t* __restrict__ b,
+                                                            int32_t* __restrict__ c, int m, int n, int k, int chunks,
+                                                            int split_chunks, int use_atomic) {
+    constexpr int RB = BM / 16, XR = BM / 16;
+    __shared__ __attribute__((aligned(16))) int8_t xs[2][BM * kI8Row];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrow = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * BM;
+    const int n_base = blockIdx.x * 128 + wave * 32;
+    const int g_begin = blockIdx.z * split_chunks;
+    const int G = min(chunks, g_begin + split_chunks);
+    int nr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nn = n_base + 16 * j + nrow;
+        nr[j] = nn < n ? nn : n - 1;
+    }
+    v4i wf[2][2][4];
+    auto load_w = [&](int slot, int g) {
+        const int gc = g < G ? g : G - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int8_t* src = b + (size_t)nr[j] * k + (size_t)gc * 256 + 16 * kq;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[slot][j][t] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src + 64 * t));
+        }
+    };
+    const int xrow = threadIdx.x >> 4, xcol = (threadIdx.x & 15) * 16;
+    v4i xr[XR];
+    auto load_x = [&](int g) {
+        const int gc = g < G ? g : G - 1;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int row = m0 + xrow + 16 * r;
+            const int rc = row < m ? row : m - 1;
+            xr[r] = *reinterpret_cast<const v4i*>(a + (size_t)rc * k + (size_t)gc * 256 + xcol);
+            if (row >= m) xr[r] = (v4i){0, 0, 0, 0};
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < XR; ++r) *reinterpret_cast<v4i*>(&xs[buf][(xrow + 16 * r) * kI8Row + xcol]) = xr[r];
+    };
+    load_x(g_begin);
+    load_w(0, g_begin);
+    load_w(1, g_begin + 1);
+    store_x(0);
+    load_x(g_begin + 1);
+    __syncthreads();
+    v4i acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        acc[rb][0] = (v4i){0, 0, 0, 0};
+        acc[rb][1] = (v4i){0, 0, 0, 0};
+    }
+    int g = g_begin;
+#pragma unroll 1
+    for (; g < G; g += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (g + u < G) {
+                const int8_t* xb = &xs[u][nrow * kI8Row + kq * 16];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const v4i af = *reinterpret_cast<const v4i*>(xb + rb * 16 * kI8Row + t * 64);
+                        acc[rb][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, wf[u][0][t], acc[rb][0], 0, 0, 0);
+                        acc[rb][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, wf[u][1][t], acc[rb][1], 0, 0, 0);
+                    }
+                }
+                load_w(u, g + u + 2);
+                store_x(u ^ 1);
+                load_x(g + u + 2);
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nn = n_base + 16 * j + nrow;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + rb * 16 + 4 * kq + i;
+                if (row < m && nn < n) {
+                    int32_t* dst = c + (size_t)row * n + nn;
+                    if (use_atomic) atomicAdd(dst, acc[rb][j][i]);
+                    else *dst = acc[rb][j][i];
+                }
+            }
+        }
+    }
+}
+
 template <int DT>
 __global__ void k_scale_back(const int32_t* __restrict__ c, const float* __restrict__ sx,
                              const uint16_t* __restrict__ sy, uint16_t* __restrict__ out, int n) {
@@ -219,6 +325,33 @@ int zl_rmsnorm_quant(const uint16_t* x, const uint16_t* weight, uint16_t* out, i
 int zl_int8_gemm_nt(const int8_t* a, const int8_t* b, int32_t* c, int64_t m, int64_t n, int64_t k, zl_stream_t s) {
     ZL_CHECK_ARG(a && b && c && m > 0 && n > 0 && k > 0, ZL_EINVAL);
     ZL_CHECK_ARG(k % 16 == 0, ZL_ESHAPE);
+    hipStream_t hs0 = (hipStream_t)s;
+    if (k % 256 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0) {
+        const int bm = m <= 16 ? 16 : (m <= 32 ? 32 : 64);
+        const int gxt = (int)((n + 127) / 128), gyt = (int)((m + bm - 1) / bm);
+        ZL_CHECK_ARG(gyt <= 65535, ZL_ELIMIT);
+        const int chunks = (int)(k / 256);
+        int cus = zl_device_cu_count();
+        if (cus <= 0) cus = 256;
+        int splits = 1;
+        if ((int64_t)gxt * gyt < cus) {
+            splits = (int)((2 * (int64_t)cus + (int64_t)gxt * gyt - 1) / ((int64_t)gxt * gyt));
+            const int max_s = chunks / 4 > 0 ? chunks / 4 : 1;
+            if (splits > max_s) splits = max_s;
+            if (splits > 32) splits = 32;
+        }
+        int sc = (chunks + splits - 1) / splits;
+        splits = (chunks + sc - 1) / sc;
+        if (splits > 1) {
+            hipError_t e = hipMemsetAsync(c, 0, (size_t)m * n * 4, hs0);
+            if (e != hipSuccess) return (int)e;
+        }
+        const dim3 grid((unsigned)gxt, (unsigned)gyt, (unsigned)splits);
+        if (bm == 16) hipLaunchKernelGGL(k_int8_gemm_tiled<16>, grid, dim3(256), 0, hs0, a, b, c, (int)m, (int)n, (int)k, chunks, sc, splits > 1);
+        else if (bm == 32) hipLaunchKernelGGL(k_int8_gemm_tiled<32>, grid, dim3(256), 0, hs0, a, b, c, (int)m, (int)n, (int)k, chunks, sc, splits > 1);
+        else hipLaunchKernelGGL(k_int8_gemm_tiled<64>, grid, dim3(256), 0, hs0, a, b, c, (int)m, (int)n, (int)k, chunks, sc, splits > 1);
+        return zl_launch_status();
+    }
     const int mt = m > 48 ? 4 : (m > 32 ? 3 : (m > 16 ? 2 : 1));
     const int gz = (int)((m + mt * 16 - 1) / (mt * 16));
     const int gx = (int)((n + 63) / 64);

@@ -531,12 +531,12 @@ def layernorm_quant(x, weight, eps, scale=1.0):
     return out, q, s
 
 
-def int8_gemm_nt(a, b):
+def int8_gemm_nt(a, b, out=None):
     """int8 (M,K) x int8 (N,K)^T -> int32 (M,N): the IMMA GEMM of Int8Linear::forward."""
     _chk_cuda(a, b)
     m, k = a.shape
     n = b.shape[0]
-    c = torch.empty((m, n), dtype=torch.int32, device=a.device)
+    c = out if out is not None else torch.empty((m, n), dtype=torch.int32, device=a.device)
     check(lib().zl_int8_gemm_nt(_p(a), _p(b), _p(c), _i(m), _i(n), _i(k), _stream()), "int8_gemm_nt")
     return c
 
