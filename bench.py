@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (marks the result invalid)")
     ap.add_argument("--no-ttft", action="store_true", help="skip the prompt-encode (TTFT) leg")
+    ap.add_argument("--quant", choices=["gptq", "int8"], default="gptq",
+                    help="gptq = BASELINE configs[1] (the headline); int8 = configs[2] (AutoInt8 linears, use --batch 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -108,7 +110,8 @@ def main():
     if args.layers:
         cfg.num_layers = args.layers
     batch, seq = args.batch, args.seq
-    model = LLaMA(cfg, QuantConfig(5, 128), dev).init_random(seed=1234 + rank)
+    int8 = args.quant == "int8"
+    model = LLaMA(cfg, QuantConfig(2, 0) if int8 else QuantConfig(5, 128), dev).init_random(seed=1234 + rank)
     len_buf = (seq + args.warmup + args.steps + 4 + 63) // 64 * 64
     ctx = model.new_context(batch, len_buf, seq, fill_random=True)
     ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
@@ -169,7 +172,37 @@ def main():
     # launches of one step, in model order on the real (distinct, HBM-cold: 3.6 GB >> 256 MB
     # Infinity Cache) weights, captured without the other kernels; HIP events on the launch stream.
     roof = None
-    if rank == 0:
+    if rank == 0 and int8:
+        # dominant kernel of the int8 route = k_int8_gemm_tiled, five launches per layer (1 B per weight)
+        lays = model.layers
+        xq = torch.randint(-127, 128, (batch, cfg.dim_ff), dtype=torch.int8, device=dev)
+        launches = [(lin, lin.dim_in) for lay in lays for lin in lay.linears()]
+
+        def gemms():
+            for lin, k in launches:
+                lin.gemm(xq_by_k[k])
+        xq_by_k = {k: xq[:, :k].contiguous() for k in {l.dim_in for l, _ in launches}}
+        gemms()
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            gemms()
+        g2.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            g2.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t_launch = e0.elapsed_time(e1) * 1e-3 / (10 * len(launches))
+        per_launch = sum(l.dim_in * l.dim_out + batch * (l.dim_in + 4 * l.dim_out) for l, _ in launches) / len(launches)
+        achieved = per_launch / t_launch / 1e9
+        roof = {"bound": "hbm", "kernel": "k_int8_gemm_tiled (int8 x int8 -> int32, 5 launches/layer)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3),
+                "note": "avg over the 160 int8 GEMM launches of one step incl. the split-K memsets and inter-kernel gaps"}
+    if rank == 0 and not int8:
         bufs = model._buffers(batch)
         launches = []
         for layer in model.layers:
@@ -220,26 +253,31 @@ def main():
     if rank == 0:
         value = world * batch * args.steps / elapsed
         # whole-step algorithmic bytes: int4 linears + fp16 lm_head + KV read
-        step_bytes = (sum(alg_bytes_w4(l.weight.n, l.weight.k, 128, batch) for lay in model.layers
-                          for l in (lay.qkv, lay.attn_out, lay.w_in_gated, lay.w_out))
+        if int8:
+            lin_bytes = sum(l.dim_in * l.dim_out + 2 * l.dim_out for lay in model.layers for l in lay.linears())
+        else:
+            lin_bytes = sum(alg_bytes_w4(l.weight.n, l.weight.k, 128, batch) for lay in model.layers
+                            for l in (lay.qkv, lay.attn_out, lay.w_in_gated, lay.w_out))
+        step_bytes = (lin_bytes
                       + cfg.vocab_size * cfg.dim_model * 2
                       + batch * cfg.num_layers * 2 * cfg.num_kv_heads * seq * cfg.dim_head * 2)
         out = {
-            "metric": "decode tokens/s (Llama-3-8B GPTQ-Int4, TP=1 per GPU, batch %d, seq %d)" % (batch, seq),
+            "metric": "decode tokens/s (Llama-3-8B %s, TP=1 per GPU, batch %d, seq %d)" % ("INT8" if int8 else "GPTQ-Int4", batch, seq),
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "Llama-3-8B GPTQ-Int4 g128 TP=1 batch=%d decode seq=%d (BASELINE configs[1])" % (batch, seq),
+            "config": {"workload": ("Llama-3-8B INT8 (AutoInt8 linears) TP=1 batch=%d decode seq=%d (BASELINE configs[2])" if int8 else
+                                    "Llama-3-8B GPTQ-Int4 g128 TP=1 batch=%d decode seq=%d (BASELINE configs[1])") % (batch, seq),
                        "layers": cfg.num_layers, "parallelism": "dp%d (independent TP=1 replicas)" % world,
                        "global_batch": world * batch, "seq_len": seq, "valid": not args.layers,
-                       "w4_algo": "mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "exact"},
+                       "w4_algo": None if int8 else ("mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "exact")},
             "per_gpu_tokens_per_s": round(value / world, 2),
             "ttft_ms": None if ttft_ms is None else round(ttft_ms, 3),
             "ttft_note": "prompt of seq tokens, one task, first greedy token; eager launches, HIP events, mean of 3",
             "step_hbm_roofline_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not int8:
             out["cpu_baseline"] = cpu_baseline(cfg, batch, seq)
         else:
             out["cpu_baseline"] = None

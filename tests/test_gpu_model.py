@@ -292,3 +292,98 @@ def test_act_order_model_prefill_and_decode(oracle, dev):
     lg2 = model.prefill(ctx2, 0, torch.from_numpy(np.concatenate([prompt, [tok]]).astype(np.int32))).float().cpu().numpy()
     assert np.isfinite(lg).all()
     assert np.abs(lg - lg2).max() <= 4e-3 * np.abs(lg2).max()
+
+
+def _dense_state(rng, cfg):
+    sd = {}
+    hd, kvd = cfg.num_heads * cfg.dim_head, cfg.num_kv_heads * cfg.dim_head
+
+    def lin(name, din, dout):
+        sd[name + ".weight"] = (rng.standard_normal((dout, din)) * (0.7 / np.sqrt(din))).astype(np.float16)
+    for i in range(cfg.num_layers):
+        p = f"model.layers.{i}."
+        sd[p + "input_layernorm.weight"] = (1 + 0.1 * rng.standard_normal(cfg.dim_model)).astype(np.float16)
+        sd[p + "post_attention_layernorm.weight"] = (1 + 0.1 * rng.standard_normal(cfg.dim_model)).astype(np.float16)
+        for n, din, dout in (("self_attn.q_proj", cfg.dim_model, hd), ("self_attn.k_proj", cfg.dim_model, kvd),
+                             ("self_attn.v_proj", cfg.dim_model, kvd), ("self_attn.o_proj", hd, cfg.dim_model),
+                             ("mlp.gate_proj", cfg.dim_model, cfg.dim_ff), ("mlp.up_proj", cfg.dim_model, cfg.dim_ff),
+                             ("mlp.down_proj", cfg.dim_ff, cfg.dim_model)):
+            lin(p + n, din, dout)
+    sd["model.embed_tokens.weight"] = (rng.standard_normal((cfg.vocab_size, cfg.dim_model)) * 0.5).astype(np.float16)
+    sd["model.norm.weight"] = (1 + 0.1 * rng.standard_normal(cfg.dim_model)).astype(np.float16)
+    sd["lm_head.weight"] = (rng.standard_normal((cfg.vocab_size, cfg.dim_model)) * 0.05).astype(np.float16)
+    return sd
+
+
+class OracleInt8Model:
+    """The int8 (AutoInt8) layer stack composed from the oracle's restatements of the reference ops, with the same
+    fusions as zhilight_amd.llama.Int8EncoderLayer."""
+
+    def __init__(self, oracle, cfg, sd, batch, len_buf):
+        self.o, self.cfg, self.sd, self.len_buf = oracle, cfg, sd, len_buf
+        self.w = {}
+        for k, v in sd.items():
+            if k.endswith("_proj.weight"):
+                q, s = oracle.quant_calc_scale(oracle.h2u(v))
+                self.w[k[:-7]] = (q, oracle.h2u(s.astype(np.float16)))
+        shp = (len_buf, cfg.num_kv_heads, cfg.dim_head)
+        self.kb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
+        self.vb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
+
+    def step(self, tokens, pos):
+        o, c = self.o, self.cfg
+        b = len(tokens)
+        h = o.embedding(np.asarray(tokens, np.int32), o.h2u(self.sd["model.embed_tokens.weight"]))
+        cs, sn = o.rope_cos_sin(np.asarray(pos, np.int32), c.dim_head, c.rope_theta, True, (8.0, 1.0, 4.0, 8192.0))
+        lens = np.full(b, self.len_buf, np.int32)
+        mask = np.concatenate([(np.arange(self.len_buf) <= p).astype(np.int8) for p in pos])
+        for i in range(c.num_layers):
+            p = f"model.layers.{i}."
+            _, xq, sx = o.rmsnorm_quant(h, o.h2u(self.sd[p + "input_layernorm.weight"]), c.eps)
+            qkv = np.concatenate([o.quant_scale_back(o.int8_gemm_nt(xq, self.w[p + "self_attn." + n + "_proj"][0]), sx,
+                                                     self.w[p + "self_attn." + n + "_proj"][1]) for n in "qkv"], axis=1)
+            q, k, v = o.rope_qk_cache(cs, sn, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
+            o.copy_to_rag_buffer2(np.asarray(pos, np.int32).reshape(b, 1), lens, k.reshape(b, 1, c.num_kv_heads, c.dim_head),
+                                  v.reshape(b, 1, c.num_kv_heads, c.dim_head), self.kb[i], self.vb[i], True)
+            att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask, c.num_kv_heads,
+                                   1.0 / np.sqrt(c.dim_head), True).reshape(b, -1)
+            aq, sa = o.quant_calc_scale(att)
+            wo = self.w[p + "self_attn.o_proj"]
+            h = o.quant_back_element_add_scale(o.int8_gemm_nt(aq, wo[0]), sa, wo[1], h, 1.0)
+            _, xq, sx = o.rmsnorm_quant(h, o.h2u(self.sd[p + "post_attention_layernorm.weight"]), c.eps)
+            wg, wu, wd = self.w[p + "mlp.gate_proj"], self.w[p + "mlp.up_proj"], self.w[p + "mlp.down_proj"]
+            act = o.quant_back_act_mul(o.int8_gemm_nt(xq, wg[0]), sx, wg[1], o.int8_gemm_nt(xq, wu[0]), sx, wu[1], "silu")
+            aq, sa = o.quant_calc_scale(act)
+            h = o.quant_back_element_add_scale(o.int8_gemm_nt(aq, wd[0]), sa, wd[1], h, 1.0)
+        xn = o.rmsnorm(h, o.h2u(self.sd["model.norm.weight"]), c.eps)
+        return o.gemm_nt(xn, o.h2u(self.sd["lm_head.weight"]), exact=True)
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_int8_model_decode_matches_oracle(oracle, dev, batch):
+    """BASELINE configs[2] in miniature: the AutoInt8 layer stack (weights quantised at load, per-row activation
+    quantisation, int8 MFMA GEMM, fused scale-back epilogues) against the oracle's composition of the same ops."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(23)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5,
+                      rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                    "original_max_position_embeddings": 8192})
+    sd = _dense_state(rng, cfg)
+    model = LLaMA(cfg, QuantConfig(2, 0), dev).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    len_buf = 64
+    ctx = model.new_context(batch, len_buf, 0)
+    om = OracleInt8Model(oracle, cfg, sd, batch, len_buf)
+    # the load-time weight quantisation is bit-exact
+    l0 = model.layers[0]
+    wq = np.concatenate([om.w["model.layers.0.self_attn." + n + "_proj"][0] for n in "qkv"], axis=0)
+    assert np.array_equal(l0.qkv.weight.cpu().numpy(), wq)
+    tokens = rng.integers(0, cfg.vocab_size, batch).astype(np.int32)
+    ctx.tokens.copy_(torch.from_numpy(tokens))
+    for step in range(3):
+        got = model.encode(ctx).float().cpu().numpy().astype(np.float64)
+        ref = om.step(tokens, [step] * batch)
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 2e-3 * scale, (step, np.abs(got - ref).max() / scale)
+        tokens = ref.argmax(axis=1).astype(np.int32)
+        model.advance(ctx, torch.from_numpy(tokens).to(dev))

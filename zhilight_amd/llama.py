@@ -225,6 +225,103 @@ class Int4GPTQ:
         return ops.w4_linear(x, self.weight, bias=self.bias, **kw)
 
 
+class Int8Linear:
+    """nn::Linear with the Int8Linear implementation (src/nn/linear/linear.cpp:430-635, quant type 2 = AutoInt8):
+    the fp16 weight is quantised per output row at load (quant_calc_scale: scale = amax / 127, stored in T),
+    forward = per-row activation quantisation, int8 x int8 -> int32 GEMM, scale back."""
+
+    def __init__(self, name, dim_in, dim_out):
+        self.name, self.dim_in, self.dim_out = name, dim_in, dim_out
+        self.weight = self.scale = self.bias = None     # int8 (N, K), T (N), T (N)
+
+    def load_state_dict(self, sd, prefix, device):
+        w = _dev_t(sd[prefix + ".weight"], device)
+        if tuple(w.shape) != (self.dim_out, self.dim_in):
+            raise ops.ZLError(f"{prefix}: weight shape {tuple(w.shape)} != {(self.dim_out, self.dim_in)}")
+        self.weight, s = ops.quant_calc_scale(w)
+        self.scale = s.to(w.dtype)                       # functions::typecast(w_scale, dtype)
+        if prefix + ".bias" in sd:
+            self.bias = _dev_t(sd[prefix + ".bias"], device)
+        return self
+
+    @staticmethod
+    def fuse(name, parts: List["Int8Linear"]):
+        out = Int8Linear(name, parts[0].dim_in, sum(p.dim_out for p in parts))
+        out.weight = torch.cat([p.weight for p in parts], dim=0).contiguous()
+        out.scale = torch.cat([p.scale for p in parts]).contiguous()
+        return out
+
+    @classmethod
+    def random(cls, name, dim_in, dim_out, device, gen):
+        l = cls(name, dim_in, dim_out)
+        l.weight = torch.randint(-127, 128, (dim_out, dim_in), dtype=torch.int8, device=device, generator=gen)
+        l.scale = (torch.rand(dim_out, device=device, generator=gen) * (0.02 / math.sqrt(dim_in)) + 1e-5).to(torch.float16)
+        return l
+
+    def nbytes(self):
+        return self.weight.numel() + self.scale.numel() * 2
+
+    def gemm(self, xq):
+        """int32 (M, N) = xq . W^T -- the caller fuses the scale-back"""
+        return ops.int8_gemm_nt(xq, self.weight)
+
+
+class Int8EncoderLayer:
+    """EncoderLayer over Int8Linear (BASELINE configs[2]) with the fusions of the reference's
+    int8 route: layernorm_quant feeds q/k/v (one shared int8 input, src/nn/linear/linear.cpp:568-583),
+    quant_scale_back on the fused qkv product, quant_back_act_mul for the gated FF
+    (src/nn/feedforward/feedforward.cpp:163-187), quant_back_element_add_scale for the residual adds."""
+
+    def __init__(self, cfg: ModelConfig, quant: QuantConfig, idx: int):
+        self.cfg, self.quant, self.idx = cfg, quant, idx
+        self.unfused = None
+
+    def load_state_dict(self, sd, prefix, device):
+        c = self.cfg
+        hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
+        self.ln_attn = _dev_t(sd[prefix + ".ln_attn.weight"], device)
+        self.ln_ff = _dev_t(sd[prefix + ".ln_ff.weight"], device)
+        lin = lambda sub, din, dout: Int8Linear(prefix + "." + sub, din, dout).load_state_dict(sd, prefix + "." + sub, device)  # noqa: E731
+        self.qkv = Int8Linear.fuse(prefix + ".attn.project_qkv",
+                                   [lin("attn.project_q", c.dim_model, hd), lin("attn.project_k", c.dim_model, kvd),
+                                    lin("attn.project_v", c.dim_model, kvd)])
+        self.attn_out = lin("attn.attn_out", hd, c.dim_model)
+        self.w_in, self.w_gated = lin("ff.w_in", c.dim_model, c.dim_ff), lin("ff.w_gated", c.dim_model, c.dim_ff)
+        self.w_out = lin("ff.w_out", c.dim_ff, c.dim_model)
+
+    def init_random(self, device, gen):
+        c = self.cfg
+        hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
+        self.ln_attn = (1.0 + 0.05 * torch.randn(c.dim_model, device=device, generator=gen)).to(torch.float16)
+        self.ln_ff = (1.0 + 0.05 * torch.randn(c.dim_model, device=device, generator=gen)).to(torch.float16)
+        self.qkv = Int8Linear.random("qkv", c.dim_model, hd + 2 * kvd, device, gen)
+        self.attn_out = Int8Linear.random("attn_out", hd, c.dim_model, device, gen)
+        self.w_in = Int8Linear.random("w_in", c.dim_model, c.dim_ff, device, gen)
+        self.w_gated = Int8Linear.random("w_gated", c.dim_model, c.dim_ff, device, gen)
+        self.w_out = Int8Linear.random("w_out", c.dim_ff, c.dim_model, device, gen)
+
+    def linears(self):
+        return [self.qkv, self.attn_out, self.w_in, self.w_gated, self.w_out]
+
+    def weight_bytes(self):
+        return sum(l.nbytes() for l in self.linears())
+
+    def project_qkv(self, hidden, eps, out=None):
+        _, xq, sx = ops.layernorm_quant(hidden, self.ln_attn, eps)
+        return ops.quant_scale_back(self.qkv.gemm(xq), sx, self.qkv.scale, hidden.dtype, out=out)
+
+    def attn_out_add(self, attn, hidden):
+        aq, sa = ops.quant_calc_scale(attn)
+        ops.quant_back_element_add_scale(self.attn_out.gemm(aq), sa, self.attn_out.scale, hidden, 1.0, out=hidden)
+
+    def ff_add(self, hidden, eps, act_buf=None):
+        _, xq, sx = ops.layernorm_quant(hidden, self.ln_ff, eps)
+        act = ops.quant_back_act_mul(self.w_in.gemm(xq), sx, self.w_in.scale, self.w_gated.gemm(xq), sx, self.w_gated.scale,
+                                     "silu", hidden.dtype)
+        aq, sa = ops.quant_calc_scale(act)
+        ops.quant_back_element_add_scale(self.w_out.gemm(aq), sa, self.w_out.scale, hidden, 1.0, out=hidden)
+
+
 class EncoderLayer:
     """nn::EncoderLayer (src/nn/block/block.h:15-63): ln_attn, attn{project_q,k,v,attn_out}, ln_ff,
     ff{w_in,w_gated,w_out}; q/k/v and w_in/w_gated are fused at load (CPM_FUSE_QKV / CPM_FUSE_FF_IN)."""
@@ -295,6 +392,15 @@ class EncoderLayer:
         parts = [l.forward(xn) for l in self.unfused[:3]]
         return torch.cat(parts, dim=1, out=out) if out is not None else torch.cat(parts, dim=1)
 
+    def attn_out_add(self, attn, hidden):
+        """hidden += attn_out(attn) in place (linear + element_add_scale fused in the epilogue)"""
+        self.attn_out.forward(attn, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
+
+    def ff_add(self, hidden, eps, act_buf=None):
+        """hidden += w_out(silu(w_in(ln(hidden))) * w_gated(ln(hidden))) in place"""
+        act = self.ff_in(hidden, eps, out=act_buf)
+        self.w_out.forward(act, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
+
     def ff_in(self, hidden, eps, out=None):
         if self.unfused is None:
             if hidden.shape[0] > 4:
@@ -329,7 +435,8 @@ class LLaMA:
         if cfg.scale_depth > 0:
             raise ops.ZLError("scale_depth (MiniCPM residual scaling) is not wired into the fused epilogues yet")
         self.cfg, self.quant, self.device = cfg, quant, torch.device(device)
-        self.layers = [EncoderLayer(cfg, quant, i) for i in range(cfg.num_layers)]
+        layer_cls = Int8EncoderLayer if quant.quant_type == 2 else EncoderLayer   # 2 = AutoInt8 (zhilight/quant.py:11)
+        self.layers = [layer_cls(cfg, quant, i) for i in range(cfg.num_layers)]
         self.token_embedding = self.output_layernorm = self.lm_head = None
         self._bufs = {}
 
@@ -402,9 +509,8 @@ class LLaMA:
             ops.decode_attention_fused(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.valid_lens, ctx.k_addrs[li],
                                        ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, scale, ctx.max_len_buf,
                                        out=bufs["attn"], workspace=workspace)
-            layer.attn_out.forward(bufs["attn"], residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
-            layer.ff_in(hidden, c.eps, out=bufs["act"])
-            layer.w_out.forward(bufs["act"], residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
+            layer.attn_out_add(bufs["attn"], hidden)
+            layer.ff_add(hidden, c.eps, bufs["act"])
         alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
         if b > 4 and argmax_ws is None and c.dim_model % 128 == 0:
             # more rows than the streaming GEMV handles per weight pass: separate norm + MFMA GEMM (one pass)
@@ -464,11 +570,7 @@ class LLaMA:
         scale = 1.0 / math.sqrt(c.dim_head)
         for li, layer in enumerate(self.layers):
             ka, va = ctx.k_addrs[li][task:task + 1], ctx.v_addrs[li][task:task + 1]
-            xn = ops.rmsnorm(hidden, layer.ln_attn, c.eps)
-            if layer.unfused is None:
-                qkv = ops.w4_linear(xn, layer.qkv.weight, bias=layer.qkv.bias)
-            else:
-                qkv = torch.cat([l.forward(xn) for l in layer.unfused[:3]], dim=1)
+            qkv = layer.project_qkv(hidden, c.eps)
             q, k, v = ops.rope_qk_cache(cos, sin, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
             ops.copy_to_rag_buffer2(placement, buf_lens, k.view(1, s, c.num_kv_heads, c.dim_head),
                                     v.view(1, s, c.num_kv_heads, c.dim_head), ka, va)
@@ -479,13 +581,8 @@ class LLaMA:
                 mask, ws = self._prefill_mask(s, ctx.max_len_buf, pos0)
                 att = ops.multi_query_attention_rag_buffer(q.view(1, s, c.num_heads, c.dim_head), buf_lens, ka, va, mask,
                                                            scale, ctx.max_len_buf, c.num_kv_heads, workspace=ws)
-            layer.attn_out.forward(att.view(s, -1), residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
-            xn = ops.rmsnorm(hidden, layer.ln_ff, c.eps)
-            if layer.unfused is None:
-                act = ops.w4_linear(xn, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, epilogue=ops.EPI_SILU_MUL)
-            else:
-                act = ops.gate_mul(layer.unfused[3].forward(xn), layer.unfused[4].forward(xn), "silu")
-            layer.w_out.forward(act, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
+            layer.attn_out_add(att.view(s, -1), hidden)
+            layer.ff_add(hidden, c.eps)
         alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
         logits = ops.gemm_nt_small_m(hidden[s - 1:s], self.lm_head, alpha=alpha, norm_weight=self.output_layernorm,
                                      norm_eps=c.eps)

@@ -541,11 +541,12 @@ def int8_gemm_nt(a, b, out=None):
     return c
 
 
-def quant_scale_back(c, scale_x, scale_y, dtype=torch.float16):
+def quant_scale_back(c, scale_x, scale_y, dtype=torch.float16, out=None):
     """int8_op::quant_scale_back (src/nn/quant/int8/quant_kernel.cu:248-306)."""
     _chk_cuda(c, scale_x, scale_y)
     m, n = c.shape
-    out = torch.empty((m, n), dtype=dtype, device=c.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=dtype, device=c.device)
     check(lib().zl_quant_scale_back(_p(c), _p(scale_x), _p(scale_y), _p(out), _i(m), _i(n), C.c_int(_dt(out)),
                                     _stream()), "quant_scale_back")
     return out
@@ -575,11 +576,13 @@ def quant_scale_back3(c, scale_x, scale_y, dim_q, dim_kv):
     return q, k, v
 
 
-def quant_back_element_add_scale(a, scale_x, scale_y, b, scale=1.0):
-    """int8_op::quant_back_element_add_scale (quant_kernel.cu:530-583): T((back(a) + float(b)) * scale)."""
+def quant_back_element_add_scale(a, scale_x, scale_y, b, scale=1.0, out=None):
+    """int8_op::quant_back_element_add_scale (quant_kernel.cu:530-583): T((back(a) + float(b)) * scale);
+    out may alias b (element-wise)."""
     _chk_cuda(a, scale_x, scale_y, b)
     m, n = a.shape
-    out = torch.empty((m, n), dtype=b.dtype, device=a.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=b.dtype, device=a.device)
     check(lib().zl_quant_back_element_add_scale(_p(a), _p(scale_x), _p(scale_y), _p(b), _f(scale), _p(out), _i(m), _i(n),
                                                 C.c_int(_dt(out)), _stream()), "quant_back_element_add_scale")
     return out
