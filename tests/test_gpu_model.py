@@ -387,3 +387,102 @@ def test_int8_model_decode_matches_oracle(oracle, dev, batch):
         assert np.abs(got - ref).max() <= 2e-3 * scale, (step, np.abs(got - ref).max() / scale)
         tokens = ref.argmax(axis=1).astype(np.int32)
         model.advance(ctx, torch.from_numpy(tokens).to(dev))
+
+
+class OracleDenseModel:
+    """Unquantised layer stack from the oracle's ops (dense GEMM exact-accumulated then rounded to T)."""
+
+    def __init__(self, oracle, cfg, sd, batch, len_buf, dtype):
+        self.o, self.cfg, self.sd, self.len_buf, self.dt = oracle, cfg, sd, len_buf, dtype
+        shp = (len_buf, cfg.num_kv_heads, cfg.dim_head)
+        self.kb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
+        self.vb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
+
+    def _w(self, name):
+        return self.sd[name]          # already T bits (uint16)
+
+    def _lin(self, x, name):
+        return self.o.gemm_nt(x, self._w(name + ".weight"), None, 1.0, self.dt)
+
+    def step(self, tokens, pos):
+        o, c, dt = self.o, self.cfg, self.dt
+        b = len(tokens)
+        h = o.embedding(np.asarray(tokens, np.int32), self._w("model.embed_tokens.weight"), c.scale_emb, dtype=dt)
+        cs, sn = o.rope_cos_sin(np.asarray(pos, np.int32), c.dim_head, c.rope_theta, True)
+        lens = np.full(b, self.len_buf, np.int32)
+        mask = np.concatenate([(np.arange(self.len_buf) <= p).astype(np.int8) for p in pos])
+        rs, sr = c.residual_scale, c.scale_depth <= 0
+        for i in range(c.num_layers):
+            p = f"model.layers.{i}."
+            xn = o.rmsnorm(h, self._w(p + "input_layernorm.weight"), c.eps, dtype=dt)
+            qkv = np.concatenate([self._lin(xn, p + "self_attn." + n + "_proj") for n in "qkv"], axis=1)
+            q, k, v = o.rope_qk_cache(cs, sn, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True, dt)
+            o.copy_to_rag_buffer2(np.asarray(pos, np.int32).reshape(b, 1), lens, k.reshape(b, 1, c.num_kv_heads, c.dim_head),
+                                  v.reshape(b, 1, c.num_kv_heads, c.dim_head), self.kb[i], self.vb[i], True)
+            att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask, c.num_kv_heads,
+                                   1.0 / np.sqrt(c.dim_head), True, dtype=dt).reshape(b, -1)
+            h = o.element_add_scale(h, self._lin(att, p + "self_attn.o_proj"), rs, sr, dt)
+            xn = o.rmsnorm(h, self._w(p + "post_attention_layernorm.weight"), c.eps, dtype=dt)
+            act = o.silu_mul(self._lin(xn, p + "mlp.gate_proj"), self._lin(xn, p + "mlp.up_proj"), dt)
+            h = o.element_add_scale(h, self._lin(act, p + "mlp.down_proj"), rs, sr, dt)
+        ln_scale = (c.dim_model / c.dim_model_base) if c.dim_model_base > 0 else 1.0
+        xn = o.rmsnorm(h, self._w("model.norm.weight"), c.eps, ln_scale, dtype=dt)
+        head = "model.embed_tokens.weight" if c.tie_lm_head else "lm_head.weight"
+        return o.gemm_nt(xn, self._w(head), None, 1.0, dt, exact=True)
+
+
+@pytest.mark.parametrize("dtype,minicpm", [(0, False), (1, True)])
+def test_dense_model_decode_matches_oracle(oracle, dev, dtype, minicpm):
+    """Unquantised models (BASELINE configs[0] in miniature when minicpm: bf16, scale_emb, scale_depth residuals,
+    dim_model_base logit scaling, tied lm_head) through the dense GEMV / MFMA GEMM kernels."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(31 + dtype)
+    cfg = ModelConfig(num_layers=2, dim_model=512, num_heads=4, dim_head=128, dim_ff=1024, vocab_size=384, num_kv_heads=4,
+                      eps=1e-5, rope_theta=1e4, dtype="bfloat16" if dtype else "half",
+                      scale_emb=12.0 if minicpm else 1.0, scale_depth=1.4 if minicpm else -1.0,
+                      dim_model_base=256 if minicpm else 0, tie_lm_head=minicpm)
+    sd32 = _dense_state(rng, cfg)
+    if minicpm:
+        sd32["model.embed_tokens.weight"] = (sd32["model.embed_tokens.weight"].astype(np.float32) * 0.08).astype(np.float16)
+    bits = {k: _to_T_bits(oracle, v, dtype) for k, v in sd32.items()}
+    tdt = torch.bfloat16 if dtype else torch.float16
+    sd_t = {k: torch.from_numpy(v.view(np.int16)).view(tdt) for k, v in bits.items()}
+    batch, len_buf = 2, 64
+    model = LLaMA(cfg, QuantConfig(0, 0), dev).load_state_dict(sd_t)
+    ctx = model.new_context(batch, len_buf, 0)
+    om = OracleDenseModel(oracle, cfg, bits, batch, len_buf, dtype)
+    tokens = rng.integers(0, cfg.vocab_size, batch).astype(np.int32)
+    ctx.tokens.copy_(torch.from_numpy(tokens))
+    tol = 2e-2 if dtype else 2e-3          # bf16 carries 8 mantissa bits through every rounding point
+    for step in range(3):
+        got = model.encode(ctx).float().cpu().numpy().astype(np.float64)
+        ref = om.step(tokens, [step] * batch)
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= tol * scale, (step, np.abs(got - ref).max() / scale)
+        tokens = ref.argmax(axis=1).astype(np.int32)
+        model.advance(ctx, torch.from_numpy(tokens).to(dev))
+
+
+def _to_T_bits(oracle, a, dtype):
+    return oracle.f32_to_bf16(a.astype(np.float32)) if dtype else oracle.h2u(a.astype(np.float16))
+
+
+def test_minicpm_shaped_model_prefill_consistent_with_decode(dev):
+    """MiniCPM-2B geometry (bf16, D = 64, dim 2304, tied 122753-row lm_head; 2 layers): prompt encode and
+    token-by-token decode of the same sequence agree -- exercises the D = 64 attention kernels, the ragged
+    lm_head and the mask-form prefill attention."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    cfg = ModelConfig.minicpm_2b()
+    cfg.num_layers = 2
+    model = LLaMA(cfg, QuantConfig(0, 0), dev).init_random(seed=3)
+    model.token_embedding.mul_(0.1)
+    toks = torch.randint(0, cfg.vocab_size, (9,), dtype=torch.int32, device=dev)
+    ctx_p = model.new_context(1, 64, 0)
+    lp = model.prefill(ctx_p, 0, toks).float()
+    ctx_d = model.new_context(1, 64, 0)
+    for t in range(9):
+        ctx_d.tokens[0] = toks[t]
+        ld = model.encode(ctx_d).float()
+        model.advance(ctx_d, toks[t:t + 1])       # tokens are overwritten next round; only the counters matter
+    assert torch.isfinite(lp).all() and torch.isfinite(ld).all()
+    assert (lp - ld).abs().max().item() <= 3e-2 * ld.abs().max().item()

@@ -51,6 +51,17 @@ class ModelConfig:
     dim_model_base: int = 0                 # MiniCPM: logits scale = dim_model_base / dim_model
     scale_depth: float = -1.0               # MiniCPM residual scale scale_depth / sqrt(num_layers)
     tie_lm_head: bool = False
+    dtype: str = "half"                     # "half" | "bfloat16" (unquantised models; the W4 / int8 routes are fp16)
+
+    @property
+    def torch_dtype(self):
+        return torch.bfloat16 if self.dtype in ("bfloat16", "bf16") else torch.float16
+
+    @property
+    def residual_scale(self):
+        """EncoderLayer scale (src/nn/block/block.cpp:55-58): MiniCPM ("cpm_dragonfly") adds scale_depth/sqrt(L)
+        times the sub-layer output to the residual; everything else a plain sum."""
+        return (self.scale_depth / math.sqrt(self.num_layers)) if self.scale_depth > 0 else 1.0
 
     @classmethod
     def from_hf(cls, cfg: dict):
@@ -63,11 +74,19 @@ class ModelConfig:
             eps=cfg.get("rms_norm_eps", 1e-5), rope_theta=cfg.get("rope_theta", 10000.0),
             rope_scaling=cfg.get("rope_scaling"), activate_fn=cfg.get("hidden_act", "silu"),
             scale_emb=cfg.get("scale_emb", 1.0), dim_model_base=cfg.get("dim_model_base", 0),
-            scale_depth=cfg.get("scale_depth", -1.0), tie_lm_head=cfg.get("tie_word_embeddings", False))
+            scale_depth=cfg.get("scale_depth", -1.0), tie_lm_head=cfg.get("tie_word_embeddings", False),
+            dtype={"bfloat16": "bfloat16", "float16": "half"}.get(cfg.get("torch_dtype", "float16"), "half"))
 
     @classmethod
     def llama3_8b(cls):
         return cls()
+
+    @classmethod
+    def minicpm_2b(cls):
+        """openbmb/MiniCPM-2B-sft-bf16 (BASELINE configs[0]): "cpm_dragonfly" scalings, tied lm_head, D = 64."""
+        return cls(num_layers=40, dim_model=2304, num_heads=36, dim_head=64, dim_ff=5760, vocab_size=122753, num_kv_heads=36,
+                   eps=1e-5, rope_theta=10000.0, scale_emb=12.0, dim_model_base=256, scale_depth=1.4, tie_lm_head=True,
+                   dtype="bfloat16")
 
 
 @dataclass
@@ -223,6 +242,107 @@ class Int4GPTQ:
                 raise ops.ZLError("act-order linears take an already normalised input")
             x = x.index_select(-1, self.perm)
         return ops.w4_linear(x, self.weight, bias=self.bias, **kw)
+
+
+class NormalLinear:
+    """nn::Linear with the NormalLinear implementation (src/nn/linear/linear.cpp:140-428): y = T(x . W^T + bias),
+    fp32 accumulation.  Up to 4 rows the wave-per-row GEMV (HBM speed, optional fused RMSNorm), above the MFMA
+    GEMM."""
+
+    def __init__(self, name, dim_in, dim_out):
+        self.name, self.dim_in, self.dim_out = name, dim_in, dim_out
+        self.weight = self.bias = None
+
+    def load_state_dict(self, sd, prefix, device, dtype):
+        self.weight = _dev_t(sd[prefix + ".weight"], device).to(dtype).contiguous()
+        if tuple(self.weight.shape) != (self.dim_out, self.dim_in):
+            raise ops.ZLError(f"{prefix}: weight shape {tuple(self.weight.shape)} != {(self.dim_out, self.dim_in)}")
+        if prefix + ".bias" in sd:
+            self.bias = _dev_t(sd[prefix + ".bias"], device).to(dtype)
+        return self
+
+    @staticmethod
+    def fuse(name, parts: List["NormalLinear"]):
+        out = NormalLinear(name, parts[0].dim_in, sum(p.dim_out for p in parts))
+        out.weight = torch.cat([p.weight for p in parts], dim=0).contiguous()
+        if any(p.bias is not None for p in parts):
+            out.bias = torch.cat([p.bias if p.bias is not None else torch.zeros(p.dim_out, dtype=out.weight.dtype,
+                                                                                  device=out.weight.device) for p in parts])
+        return out
+
+    @classmethod
+    def random(cls, name, dim_in, dim_out, device, gen, dtype):
+        l = cls(name, dim_in, dim_out)
+        l.weight = (torch.randn(dim_out, dim_in, device=device, generator=gen) * (0.7 / math.sqrt(dim_in))).to(dtype)
+        return l
+
+    def nbytes(self):
+        return self.weight.numel() * 2
+
+    def forward(self, x, out=None, norm_weight=None, norm_eps=1e-5):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.shape[0] <= 4 or self.dim_in % 128 != 0:
+            return ops.gemm_nt_small_m(x2, self.weight, bias=self.bias, out=out, norm_weight=norm_weight, norm_eps=norm_eps)
+        if norm_weight is not None:
+            x2 = ops.rmsnorm(x2, norm_weight, norm_eps)
+        return ops.gemm_nt(x2, self.weight, bias=self.bias, out=out)
+
+
+class DenseEncoderLayer:
+    """EncoderLayer over NormalLinear (unquantised fp16 / bf16 models, BASELINE configs[0] MiniCPM): fused q|k|v
+    projection, separate w_in / w_gated + gate_mul_inplace (src/nn/feedforward/feedforward.cpp:113-137), residual
+    adds through element_add_scale_out with the layer scale (src/nn/block/block.cpp:123-140)."""
+
+    def __init__(self, cfg: ModelConfig, quant: QuantConfig, idx: int):
+        self.cfg, self.quant, self.idx = cfg, quant, idx
+        self.unfused = None
+
+    def load_state_dict(self, sd, prefix, device):
+        c, dt = self.cfg, self.cfg.torch_dtype
+        hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
+        self.ln_attn = _dev_t(sd[prefix + ".ln_attn.weight"], device).to(dt)
+        self.ln_ff = _dev_t(sd[prefix + ".ln_ff.weight"], device).to(dt)
+        lin = lambda sub, din, dout: NormalLinear(prefix + "." + sub, din, dout).load_state_dict(sd, prefix + "." + sub, device, dt)  # noqa: E731
+        self.qkv = NormalLinear.fuse(prefix + ".attn.project_qkv",
+                                     [lin("attn.project_q", c.dim_model, hd), lin("attn.project_k", c.dim_model, kvd),
+                                      lin("attn.project_v", c.dim_model, kvd)])
+        self.attn_out = lin("attn.attn_out", hd, c.dim_model)
+        self.w_in, self.w_gated = lin("ff.w_in", c.dim_model, c.dim_ff), lin("ff.w_gated", c.dim_model, c.dim_ff)
+        self.w_out = lin("ff.w_out", c.dim_ff, c.dim_model)
+
+    def init_random(self, device, gen):
+        c, dt = self.cfg, self.cfg.torch_dtype
+        hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
+        self.ln_attn = (1.0 + 0.05 * torch.randn(c.dim_model, device=device, generator=gen)).to(dt)
+        self.ln_ff = (1.0 + 0.05 * torch.randn(c.dim_model, device=device, generator=gen)).to(dt)
+        self.qkv = NormalLinear.random("qkv", c.dim_model, hd + 2 * kvd, device, gen, dt)
+        self.attn_out = NormalLinear.random("attn_out", hd, c.dim_model, device, gen, dt)
+        self.w_in = NormalLinear.random("w_in", c.dim_model, c.dim_ff, device, gen, dt)
+        self.w_gated = NormalLinear.random("w_gated", c.dim_model, c.dim_ff, device, gen, dt)
+        self.w_out = NormalLinear.random("w_out", c.dim_ff, c.dim_model, device, gen, dt)
+
+    def linears(self):
+        return [self.qkv, self.attn_out, self.w_in, self.w_gated, self.w_out]
+
+    def weight_bytes(self):
+        return sum(l.nbytes() for l in self.linears())
+
+    def project_qkv(self, hidden, eps, out=None):
+        return self.qkv.forward(hidden, out=out, norm_weight=self.ln_attn, norm_eps=eps)
+
+    def _add(self, hidden, sub):
+        # residual first, T arithmetic: c = a + b * T(scale) for MiniCPM, (a + b) * T(1) otherwise
+        rs = self.cfg.residual_scale
+        ops.element_add_scale(hidden, sub, rs, scale_residual=(self.cfg.scale_depth <= 0), out=hidden)
+
+    def attn_out_add(self, attn, hidden):
+        self._add(hidden, self.attn_out.forward(attn))
+
+    def ff_add(self, hidden, eps, act_buf=None):
+        xn = ops.rmsnorm(hidden, self.ln_ff, eps)
+        gate = self.w_in.forward(xn, out=act_buf)
+        act = ops.gate_mul(gate, self.w_gated.forward(xn), "gelu" if self.cfg.activate_fn.startswith("gelu") else "silu")
+        self._add(hidden, self.w_out.forward(act))
 
 
 class Int8Linear:
@@ -432,10 +552,13 @@ class LLaMA:
     """model::LLaMA (src/model/llama.cpp:11-165) restricted to the dynamic-batch decode step."""
 
     def __init__(self, cfg: ModelConfig, quant: QuantConfig, device="cuda:0"):
-        if cfg.scale_depth > 0:
-            raise ops.ZLError("scale_depth (MiniCPM residual scaling) is not wired into the fused epilogues yet")
+        if cfg.scale_depth > 0 and quant.quant_type != 0:
+            raise ops.ZLError("scale_depth (MiniCPM residual scaling) is only wired into the unquantised layer stack")
+        if quant.quant_type != 0 and cfg.torch_dtype != torch.float16:
+            raise ops.ZLError("the W4A16 / int8 routes are fp16 (q_gemm_k_major.cu:989 asserts half)")
         self.cfg, self.quant, self.device = cfg, quant, torch.device(device)
-        layer_cls = Int8EncoderLayer if quant.quant_type == 2 else EncoderLayer   # 2 = AutoInt8 (zhilight/quant.py:11)
+        # QuantType (zhilight/quant.py:8-19): 0 NoQuant, 2 AutoInt8, 5 GPTQ (AWQ-as-exllama rides on 5)
+        layer_cls = {0: DenseEncoderLayer, 2: Int8EncoderLayer}.get(quant.quant_type, EncoderLayer)
         self.layers = [layer_cls(cfg, quant, i) for i in range(cfg.num_layers)]
         self.token_embedding = self.output_layernorm = self.lm_head = None
         self._bufs = {}
@@ -444,9 +567,10 @@ class LLaMA:
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], hf_names=True):
         sd = {hf_name_to_internal(k) if hf_names else k: v for k, v in state_dict.items()}
         dev = self.device
-        self.token_embedding = _dev_t(sd["llama.token_embedding.weight"], dev, torch.float16)
-        self.output_layernorm = _dev_t(sd["llama.output_layernorm.weight"], dev, torch.float16)
-        self.lm_head = self.token_embedding if self.cfg.tie_lm_head else _dev_t(sd["llama.lm_head.weight"], dev, torch.float16)
+        dt = self.cfg.torch_dtype
+        self.token_embedding = _dev_t(sd["llama.token_embedding.weight"], dev).to(dt).contiguous()
+        self.output_layernorm = _dev_t(sd["llama.output_layernorm.weight"], dev).to(dt).contiguous()
+        self.lm_head = self.token_embedding if self.cfg.tie_lm_head else _dev_t(sd["llama.lm_head.weight"], dev).to(dt).contiguous()
         for i, layer in enumerate(self.layers):
             layer.load_state_dict(sd, f"llama.layers.{i}", dev)
         return self
@@ -454,9 +578,10 @@ class LLaMA:
     def init_random(self, seed=0):
         gen = torch.Generator(device=self.device).manual_seed(seed)
         c, dev = self.cfg, self.device
-        self.token_embedding = (torch.randn(c.vocab_size, c.dim_model, device=dev, generator=gen) * 0.5).to(torch.float16)
-        self.output_layernorm = torch.ones(c.dim_model, dtype=torch.float16, device=dev)
-        self.lm_head = (torch.randn(c.vocab_size, c.dim_model, device=dev, generator=gen) * 0.02).to(torch.float16)
+        dt = c.torch_dtype
+        self.token_embedding = (torch.randn(c.vocab_size, c.dim_model, device=dev, generator=gen) * 0.5).to(dt)
+        self.output_layernorm = torch.ones(c.dim_model, dtype=dt, device=dev)
+        self.lm_head = self.token_embedding if c.tie_lm_head else (torch.randn(c.vocab_size, c.dim_model, device=dev, generator=gen) * 0.02).to(dt)
         for layer in self.layers:
             layer.init_random(dev, gen)
         return self
@@ -469,7 +594,7 @@ class LLaMA:
         kv = []
         for _ in range(batch):
             shape = (c.num_layers, 2, len_buf, c.num_kv_heads, c.dim_head)
-            t = torch.randn(shape, dtype=torch.float16, device=dev) if fill_random else torch.zeros(shape, dtype=torch.float16, device=dev)
+            t = torch.randn(shape, dtype=c.torch_dtype, device=dev) if fill_random else torch.zeros(shape, dtype=c.torch_dtype, device=dev)
             kv.append(t)
         k_addrs = torch.tensor([[t[l, 0].data_ptr() for t in kv] for l in range(c.num_layers)], dtype=torch.int64, device=dev)
         v_addrs = torch.tensor([[t[l, 1].data_ptr() for t in kv] for l in range(c.num_layers)], dtype=torch.int64, device=dev)
@@ -483,7 +608,7 @@ class LLaMA:
     def _buffers(self, b):
         if b not in self._bufs:
             c, dev = self.cfg, self.device
-            f16 = dict(dtype=torch.float16, device=dev)
+            f16 = dict(dtype=c.torch_dtype, device=dev)
             hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
             self._bufs[b] = dict(
                 hidden=torch.empty(b, c.dim_model, **f16), qkv=torch.empty(b, hd + 2 * kvd, **f16),
@@ -511,13 +636,21 @@ class LLaMA:
                                        out=bufs["attn"], workspace=workspace)
             layer.attn_out_add(bufs["attn"], hidden)
             layer.ff_add(hidden, c.eps, bufs["act"])
-        alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
-        if b > 4 and argmax_ws is None and c.dim_model % 128 == 0:
-            # more rows than the streaming GEMV handles per weight pass: separate norm + MFMA GEMM (one pass)
-            xn = ops.rmsnorm(hidden, self.output_layernorm, c.eps)
-            return ops.gemm_nt(xn, self.lm_head, alpha=alpha, out=bufs["logits"])
-        return ops.gemm_nt_small_m(hidden, self.lm_head, alpha=alpha, out=bufs["logits"],
-                                   norm_weight=self.output_layernorm, norm_eps=c.eps, argmax_ws=argmax_ws)
+        return self._logits(hidden, bufs["logits"], argmax_ws)
+
+    def _logits(self, hidden, out=None, argmax_ws=None):
+        """output_layernorm + lm_head (get_logits, src/model/llama.cpp:150-165).  MiniCPM divides the normalised
+        row by dim_model / dim_model_base inside the norm (ln_after_enc's scale, llama.cpp:13-21)."""
+        c = self.cfg
+        rows = hidden.shape[0]
+        ln_scale = (c.dim_model / c.dim_model_base) if c.dim_model_base > 0 else 1.0
+        if (rows > 4 and argmax_ws is None and c.dim_model % 128 == 0) or ln_scale != 1.0:
+            xn = ops.rmsnorm(hidden, self.output_layernorm, c.eps, ln_scale)
+            if rows > 4 and argmax_ws is None and c.dim_model % 128 == 0:
+                return ops.gemm_nt(xn, self.lm_head, out=out)      # more rows than the streaming GEMV takes per pass
+            return ops.gemm_nt_small_m(xn, self.lm_head, out=out, argmax_ws=argmax_ws)
+        return ops.gemm_nt_small_m(hidden, self.lm_head, out=out, norm_weight=self.output_layernorm, norm_eps=c.eps,
+                                   argmax_ws=argmax_ws)
 
     def _llama3_rope(self):
         rs = self.cfg.rope_scaling
@@ -583,9 +716,7 @@ class LLaMA:
                                                            scale, ctx.max_len_buf, c.num_kv_heads, workspace=ws)
             layer.attn_out_add(att.view(s, -1), hidden)
             layer.ff_add(hidden, c.eps)
-        alpha = (c.dim_model_base / c.dim_model) if c.dim_model_base > 0 else 1.0
-        logits = ops.gemm_nt_small_m(hidden[s - 1:s], self.lm_head, alpha=alpha, norm_weight=self.output_layernorm,
-                                     norm_eps=c.eps)
+        logits = self._logits(hidden[s - 1:s])
         ctx.tokens[task] = torch.argmax(logits[0].float()).to(torch.int32)
         ctx.positions[task] = pos0 + s
         ctx.placement[task] = pos0 + s
