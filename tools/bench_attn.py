@@ -20,11 +20,13 @@ def main():
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--bhsd", action="store_true", help="KV buffers (Hkv, len_buf, D) instead of (len_buf, Hkv, D)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     h, hkv, d = 32, 8, 128
     len_buf = (a.seq + 64 + 63) // 64 * 64
-    kv = [torch.randn(a.layers, 2, len_buf, hkv, d, dtype=torch.float16, device=dev) for _ in range(a.batch)]
+    shape = (a.layers, 2, hkv, len_buf, d) if a.bhsd else (a.layers, 2, len_buf, hkv, d)
+    kv = [torch.randn(shape, dtype=torch.float16, device=dev) for _ in range(a.batch)]
     k_addrs = torch.tensor([[t[l, 0].data_ptr() for t in kv] for l in range(a.layers)], dtype=torch.int64, device=dev)
     v_addrs = torch.tensor([[t[l, 1].data_ptr() for t in kv] for l in range(a.layers)], dtype=torch.int64, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
@@ -39,7 +41,7 @@ def main():
     def run():
         for l in range(a.layers):
             ops.decode_attention_fused(cos, sin, qkv, pos, buf_lens, valid, k_addrs[l], v_addrs[l], h, hkv, d,
-                                       1.0 / math.sqrt(d), len_buf, out=out, workspace=ws)
+                                       1.0 / math.sqrt(d), len_buf, bshd=not a.bhsd, out=out, workspace=ws)
     run()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
