@@ -486,3 +486,89 @@ def test_minicpm_shaped_model_prefill_consistent_with_decode(dev):
         model.advance(ctx_d, toks[t:t + 1])       # tokens are overwritten next round; only the counters matter
     assert torch.isfinite(lp).all() and torch.isfinite(ld).all()
     assert (lp - ld).abs().max().item() <= 3e-2 * ld.abs().max().item()
+
+
+class _ThreadTP:
+    """Stand-in for the RCCL group: both ranks of a TP = 2 model run as two threads on one GPU; the collectives
+    meet at a thread barrier (same default stream, so the device work is ordered)."""
+
+    def __init__(self, size):
+        import threading
+        self.size = size
+        self.barrier = threading.Barrier(size)
+        self.slots = [None] * size
+
+    def view(self, rank):
+        from zhilight_amd.parallel import TPGroup
+        outer = self
+
+        class G(TPGroup):
+            def __init__(self):
+                self.group, self.rank, self.size = None, rank, outer.size
+
+            def all_reduce_sum(self, t):
+                outer.slots[rank] = t
+                outer.barrier.wait()
+                tot = outer.slots[0].float()
+                for o in outer.slots[1:]:
+                    tot = tot + o.float()        # the reduction order of a 2-rank ring is a single add
+                tot = tot.to(t.dtype)
+                outer.barrier.wait()
+                t.copy_(tot)
+                return t
+
+            def all_gather_columns(self, t):
+                outer.slots[rank] = t
+                outer.barrier.wait()
+                full = torch.cat(list(outer.slots), dim=-1)
+                outer.barrier.wait()
+                return full
+        return G()
+
+
+def test_tensor_parallel_decode_matches_single_gpu(dev):
+    """TP = 2 (column-parallel q/k/v/gate/up, row-parallel attn_out/w_out + all-reduce, vocab-parallel lm_head +
+    all-gather) against the unsharded model on the same checkpoint: logits agree to the fp16 noise of the
+    partial-sum rounding, greedy tokens equal."""
+    import threading
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(41)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5)
+    sd = {k: torch.from_numpy(v) for k, v in _hf_state(rng, cfg, 128).items()}
+    ref_model = LLaMA(cfg, QuantConfig(5, 128), dev).load_state_dict(sd)
+    fake = _ThreadTP(2)
+    models = [LLaMA(cfg, QuantConfig(5, 128), dev, tp=fake.view(r)).load_state_dict(sd) for r in range(2)]
+    assert models[0].cfg.num_heads == 4 and models[0].lm_head.shape[0] == 256
+    batch, len_buf = 2, 64
+    tokens = rng.integers(0, cfg.vocab_size, batch).astype(np.int32)
+    ref_ctx = ref_model.new_context(batch, len_buf, 0)
+    ref_ctx.tokens.copy_(torch.from_numpy(tokens))
+    ctxs = [m.new_context(batch, len_buf, 0) for m in models]
+    for c in ctxs:
+        c.tokens.copy_(torch.from_numpy(tokens))
+    for step in range(3):
+        ref = ref_model.encode(ref_ctx).float()
+        outs = [None, None]
+        errs = []
+
+        def run(r):
+            try:
+                outs[r] = models[r].encode(ctxs[r]).float()
+            except Exception as e:       # pragma: no cover
+                errs.append(e)
+                fake.barrier.abort()
+        th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not errs, errs
+        assert torch.equal(outs[0], outs[1])                       # every rank ends with the full logits
+        scale = ref.abs().max().item()
+        assert (outs[0] - ref).abs().max().item() <= 2e-3 * scale
+        nxt = ref.argmax(dim=-1)
+        assert torch.equal(outs[0].argmax(dim=-1), nxt)
+        ref_model.advance(ref_ctx, nxt)
+        for m, c in zip(models, ctxs):
+            m.advance(c, nxt)

@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import parallel
 
 
 @dataclass
@@ -446,11 +447,14 @@ class EncoderLayer:
     """nn::EncoderLayer (src/nn/block/block.h:15-63): ln_attn, attn{project_q,k,v,attn_out}, ln_ff,
     ff{w_in,w_gated,w_out}; q/k/v and w_in/w_gated are fused at load (CPM_FUSE_QKV / CPM_FUSE_FF_IN)."""
 
-    def __init__(self, cfg: ModelConfig, quant: QuantConfig, idx: int):
+    def __init__(self, cfg: ModelConfig, quant: QuantConfig, idx: int, tp=None):
         self.cfg, self.quant, self.idx = cfg, quant, idx
         self.ln_attn = self.ln_ff = None
         self.qkv = self.attn_out = self.w_in_gated = self.w_out = None
         self.unfused = None     # act-order checkpoints: [q, k, v, w_in, w_gated] as separate linears
+        # tensor parallelism (SURVEY 8e): cfg holds the LOCAL head / ff counts; q/k/v and gate/up are column-parallel,
+        # attn_out / w_out row-parallel: their partial outputs are summed over the ranks before the residual add
+        self.tp = tp if tp is not None and tp.size > 1 else None
 
     def load_state_dict(self, sd, prefix, device):
         c, q = self.cfg, self.quant
@@ -459,14 +463,29 @@ class EncoderLayer:
         self.ln_attn = _dev_t(sd[prefix + ".ln_attn.weight"], device, torch.float16)
         self.ln_ff = _dev_t(sd[prefix + ".ln_ff.weight"], device, torch.float16)
 
-        def lin(sub, din, dout):
-            l = Int4GPTQ(prefix + "." + sub, din, dout, q)
+        tp = self.tp
+        ws = tp.size if tp else 1
+
+        def lin(sub, din, dout, mode=None):
+            # the checkpoint holds the FULL matrix; a TP rank keeps its column (output rows) or row (input columns) slice
+            full_in, full_out = (din * ws if mode == "row" else din), (dout * ws if mode == "column" else dout)
+            l = Int4GPTQ(prefix + "." + sub, full_in, full_out, q)
             l.load_state_dict(sd, prefix + "." + sub, device)
+            if tp and mode:
+                if l.perm is not None:
+                    raise ops.ZLError("act-order checkpoints are not supported under tensor parallelism")
+                l.km = parallel.shard_k_major(*l.km, q.group_size, mode, tp.rank, tp.size)
+                l.dim_in, l.dim_out = din, dout
+                if l.bias is not None and mode == "column":
+                    l.bias = l.bias[tp.rank * dout:(tp.rank + 1) * dout].contiguous()
+                if l.bias is not None and mode == "row" and tp.rank != 0:
+                    l.bias = None                     # added once, by rank 0's partial sum
             return l
-        pq, pk, pv = lin("attn.project_q", c.dim_model, hd), lin("attn.project_k", c.dim_model, kvd), lin("attn.project_v", c.dim_model, kvd)
-        w_in, w_gated = lin("ff.w_in", c.dim_model, c.dim_ff), lin("ff.w_gated", c.dim_model, c.dim_ff)
-        self.attn_out = lin("attn.attn_out", hd, c.dim_model).pack()
-        self.w_out = lin("ff.w_out", c.dim_ff, c.dim_model).pack()
+        pq, pk, pv = (lin("attn.project_q", c.dim_model, hd, "column"), lin("attn.project_k", c.dim_model, kvd, "column"),
+                      lin("attn.project_v", c.dim_model, kvd, "column"))
+        w_in, w_gated = lin("ff.w_in", c.dim_model, c.dim_ff, "column"), lin("ff.w_gated", c.dim_model, c.dim_ff, "column")
+        self.attn_out = lin("attn.attn_out", hd, c.dim_model, "row").pack()
+        self.w_out = lin("ff.w_out", c.dim_ff, c.dim_model, "row").pack()
         if any(l.perm is not None for l in (pq, pk, pv, w_in, w_gated)):
             # act-order: every linear reads x through its own permutation, so q/k/v and gate/up stay separate
             # (the reference's act-order route gives up the same fusions)
@@ -512,13 +531,24 @@ class EncoderLayer:
         parts = [l.forward(xn) for l in self.unfused[:3]]
         return torch.cat(parts, dim=1, out=out) if out is not None else torch.cat(parts, dim=1)
 
+    def _row_parallel_add(self, lin, x, hidden):
+        """hidden += sum over TP ranks of lin(x): ModelContext::reduce_sum on the fp16 partial outputs, then the
+        residual add in T arithmetic (src/nn/block/block.cpp:123-140, src/model/model_context.cpp:203-242)"""
+        part = lin.forward(x)
+        self.tp.all_reduce_sum(part)
+        ops.element_add_scale(hidden, part, 1.0, True, out=hidden)
+
     def attn_out_add(self, attn, hidden):
         """hidden += attn_out(attn) in place (linear + element_add_scale fused in the epilogue)"""
+        if self.tp:
+            return self._row_parallel_add(self.attn_out, attn, hidden)
         self.attn_out.forward(attn, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
 
     def ff_add(self, hidden, eps, act_buf=None):
         """hidden += w_out(silu(w_in(ln(hidden))) * w_gated(ln(hidden))) in place"""
         act = self.ff_in(hidden, eps, out=act_buf)
+        if self.tp:
+            return self._row_parallel_add(self.w_out, act, hidden)
         self.w_out.forward(act, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
 
     def ff_in(self, hidden, eps, out=None):
@@ -551,7 +581,9 @@ class DynBatchContext:
 class LLaMA:
     """model::LLaMA (src/model/llama.cpp:11-165) restricted to the dynamic-batch decode step."""
 
-    def __init__(self, cfg: ModelConfig, quant: QuantConfig, device="cuda:0"):
+    def __init__(self, cfg: ModelConfig, quant: QuantConfig, device="cuda:0", tp=None):
+        """tp: parallel.TPGroup (rank, size, process group) for tensor parallelism over the GPUs of a node -- W4 route
+        only; heads, kv heads, dim_ff and the vocabulary must divide by the TP degree."""
         if cfg.scale_depth > 0 and quant.quant_type != 0:
             raise ops.ZLError("scale_depth (MiniCPM residual scaling) is only wired into the unquantised layer stack")
         if quant.quant_type != 0 and cfg.torch_dtype != torch.float16:
@@ -559,7 +591,20 @@ class LLaMA:
         self.cfg, self.quant, self.device = cfg, quant, torch.device(device)
         # QuantType (zhilight/quant.py:8-19): 0 NoQuant, 2 AutoInt8, 5 GPTQ (AWQ-as-exllama rides on 5)
         layer_cls = {0: DenseEncoderLayer, 2: Int8EncoderLayer}.get(quant.quant_type, EncoderLayer)
-        self.layers = [layer_cls(cfg, quant, i) for i in range(cfg.num_layers)]
+        self.tp = tp if tp is not None and tp.size > 1 else None
+        self.full_cfg = cfg
+        if self.tp:
+            if layer_cls is not EncoderLayer:
+                raise ops.ZLError("tensor parallelism is wired into the W4A16 layer stack only")
+            t = self.tp.size
+            if cfg.num_heads % t or cfg.num_kv_heads % t or cfg.dim_ff % t or cfg.vocab_size % t:
+                raise ops.ZLError("heads, kv heads, dim_ff and vocab_size must be divisible by the TP degree")
+            import dataclasses
+            cfg = dataclasses.replace(cfg, num_heads=cfg.num_heads // t, num_kv_heads=cfg.num_kv_heads // t, dim_ff=cfg.dim_ff // t)
+            self.cfg = cfg                            # the LOCAL geometry drives buffers, KV and kernels
+            self.layers = [EncoderLayer(cfg, quant, i, self.tp) for i in range(cfg.num_layers)]
+        else:
+            self.layers = [layer_cls(cfg, quant, i) for i in range(cfg.num_layers)]
         self.token_embedding = self.output_layernorm = self.lm_head = None
         self._bufs = {}
 
@@ -571,6 +616,9 @@ class LLaMA:
         self.token_embedding = _dev_t(sd["llama.token_embedding.weight"], dev).to(dt).contiguous()
         self.output_layernorm = _dev_t(sd["llama.output_layernorm.weight"], dev).to(dt).contiguous()
         self.lm_head = self.token_embedding if self.cfg.tie_lm_head else _dev_t(sd["llama.lm_head.weight"], dev).to(dt).contiguous()
+        if self.tp:                                   # vocab-parallel projection (embedding.cu:353-385)
+            v = self.cfg.vocab_size // self.tp.size
+            self.lm_head = self.lm_head[self.tp.rank * v:(self.tp.rank + 1) * v].contiguous()
         for i, layer in enumerate(self.layers):
             layer.load_state_dict(sd, f"llama.layers.{i}", dev)
         return self
@@ -581,7 +629,8 @@ class LLaMA:
         dt = c.torch_dtype
         self.token_embedding = (torch.randn(c.vocab_size, c.dim_model, device=dev, generator=gen) * 0.5).to(dt)
         self.output_layernorm = torch.ones(c.dim_model, dtype=dt, device=dev)
-        self.lm_head = self.token_embedding if c.tie_lm_head else (torch.randn(c.vocab_size, c.dim_model, device=dev, generator=gen) * 0.02).to(dt)
+        vloc = c.vocab_size // self.tp.size if self.tp else c.vocab_size
+        self.lm_head = self.token_embedding if (c.tie_lm_head and not self.tp) else (torch.randn(vloc, c.dim_model, device=dev, generator=gen) * 0.02).to(dt)
         for layer in self.layers:
             layer.init_random(dev, gen)
         return self
@@ -643,6 +692,14 @@ class LLaMA:
         row by dim_model / dim_model_base inside the norm (ln_after_enc's scale, llama.cpp:13-21)."""
         c = self.cfg
         rows = hidden.shape[0]
+        if self.tp:                                   # local vocabulary slice, then all-gather of the logits
+            part = ops.gemm_nt_small_m(hidden, self.lm_head, norm_weight=self.output_layernorm, norm_eps=c.eps) if rows <= 4 else \
+                ops.gemm_nt(ops.rmsnorm(hidden, self.output_layernorm, c.eps), self.lm_head)
+            full = self.tp.all_gather_columns(part)
+            if out is not None:
+                out.copy_(full)
+                return out
+            return full
         ln_scale = (c.dim_model / c.dim_model_base) if c.dim_model_base > 0 else 1.0
         if (rows > 4 and argmax_ws is None and c.dim_model % 128 == 0) or ln_scale != 1.0:
             xn = ops.rmsnorm(hidden, self.output_layernorm, c.eps, ln_scale)
@@ -728,7 +785,7 @@ class LLaMA:
         inside the lm_head launch + one small reduction, and advance the batch state.  Returns
         (logits, next_tokens int64)."""
         b = ctx.tokens.numel()
-        if b > 4:   # the in-launch pick rides the small-M GEMV; bigger batches: MFMA lm_head + a plain argmax
+        if b > 4 or self.tp:   # the in-launch pick rides the small-M GEMV; bigger batches / TP: plain argmax on the logits
             logits = self.encode(ctx)
             nxt = torch.argmax(logits, dim=-1)
             self.advance(ctx, nxt)

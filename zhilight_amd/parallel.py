@@ -12,6 +12,23 @@ import torch
 import torch.distributed as dist
 
 
+class TPGroup:
+    """Tensor-parallel group of this process: rank, size and the torch.distributed group (None = world).  The two
+    collectives of the path are methods so that a test can stand in for RCCL (tests/test_gpu_model.py runs both
+    ranks of a TP = 2 model on one GPU with a thread-barrier group)."""
+
+    def __init__(self, rank=None, size=None, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.size = dist.get_world_size(group) if size is None else size
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        return reduce_sum(t, self.group)
+
+    def all_gather_columns(self, t: torch.Tensor):
+        return all_gather_columns(t, self.group)
+
+
 def shard_k_major(qweight, qzeros, scales, group_size, mode, rank, world):
     """Slice k-major GPTQ tensors (N,K/8) int32 / (N,K/G) uint8 / (N,K/G) fp16 for tensor parallelism.
     mode "column": output rows [rank*N/world, ...); mode "row": input columns, K/world must be a
