@@ -91,6 +91,8 @@ def main():
                          "w_out, vocab-parallel lm_head) instead of N independent replicas; strong scaling")
     ap.add_argument("--quant", choices=["gptq", "int8"], default="gptq",
                     help="gptq = BASELINE configs[1] (the headline); int8 = configs[2] (AutoInt8 linears, use --batch 32)")
+    ap.add_argument("--kv-cache-dtype", choices=["fp16", "int8"], default="fp16",
+                    help="int8: the reference's KV_CACHE_DTYPE=int8 cache (u8 codes + fp32 scales); not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,7 +123,7 @@ def main():
         torch.manual_seed(1234)            # every rank must draw the same tokens / KV contents
     model = LLaMA(cfg, QuantConfig(2, 0) if int8 else QuantConfig(5, 128), dev, tp=tp).init_random(seed=1234 + rank)
     len_buf = (seq + args.warmup + args.steps + 4 + 63) // 64 * 64
-    ctx = model.new_context(batch, len_buf, seq, fill_random=True)
+    ctx = model.new_context(batch, len_buf, seq, fill_random=True, kv_cache_dtype=None if args.kv_cache_dtype == "fp16" else "int8")
     ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
 
     # ---- TTFT leg (rank 0, reported next to the decode metric): encode a `seq`-token prompt of one task
@@ -287,6 +289,7 @@ def main():
                        "layers": cfg.num_layers,
                        "parallelism": ("tp%d (one model over %d GPUs, RCCL all-reduce)" % (world, world)) if tp else "dp%d (independent TP=1 replicas)" % world,
                        "global_batch": (1 if tp else world) * batch, "seq_len": seq, "valid": not args.layers,
+                       "kv_cache_dtype": args.kv_cache_dtype,
                        "w4_algo": None if int8 else ("mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "exact")},
             "per_gpu_tokens_per_s": round(value / world, 2),
             "note_tp": "TP mode was not exercised on multi-GPU hardware in round 1 (1-GPU dev box); numerics covered by the TP=2 emulation test" if tp else None,

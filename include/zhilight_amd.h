@@ -256,6 +256,45 @@ int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* q
                          zl_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * a15q  INT8 KV cache (RagBufferContext::is_cache_quant, src/model/rag_buffer_context.h:96).
+ * A cached K/V row of one kv head is D unsigned codes + one fp32 scale:
+ *     code = 128 + rint(x * 127 / amax)   scale = amax / 127      (round half even)
+ * i.e. int8_op::quant_calc_scale(ctx, x, 127, 128)  (src/nn/quant/int8/quant_kernel.cu:15-47, :49-80).
+ * Per task: codes u8 (len_buf, Hkv, D) [bshd] or (Hkv, len_buf, D); scales fp32 (len_buf, Hkv) or
+ * (Hkv, len_buf); both reached through device arrays of B pointers (buf_k_addr / scale_k_addr,
+ * src/nn/attention/attention.cpp:664-667).
+ *
+ * zl_quant_calc_scale_zp        the bare op (q_zero = 128 for the cache, 0 gives zl_quant_calc_scale's codes + 0).
+ * zl_quant_copy_to_rag_buffer   quantise k_src / v_src (B*len_q, Hkv, D) rows and scatter codes and scales to
+ *                               slot placement[token] of their task: replaces 2 x quant_calc_scale + 2 x
+ *                               copy_to_rag_buffer2 (attention.cpp:656-676) and TransformerBuffer::copy for
+ *                               a quantised buffer (src/kvcache/transformer_buffer.cu:128-134).
+ * zl_rope_quant_scatter_decode  the same with rope_qk_cache in front, over fused qkv rows (len_q == 1):
+ *                               rotated q -> q (B, H*D); rotated k is rounded to T before it is quantised.
+ * zl_decode_attn_quant          multi_query_attention_rag_buffer with scale_k/scale_v given
+ *                               (attention_kernel.cu:1384-1416, KERNEL_mqa_rag_buffer_split_kv_quant :802-878,
+ *                               quant_attention.cuh:39-123):
+ *     out = softmax_j( mask ? scale * sk_j * q.(K_j - 128) : -inf ) . ( sv_j * (V_j - 128) )
+ *                               fp32 accumulation (the reference forms q.(K-128) in fp16); same workspace
+ *                               as zl_decode_attn.
+ * ---------------------------------------------------------------------------------------------- */
+int zl_quant_calc_scale_zp(const uint16_t* x, uint8_t* q, float* scale, int64_t m, int64_t k, int q_zero, int dtype,
+                           zl_stream_t s);
+int zl_quant_copy_to_rag_buffer(const int32_t* placement, const int32_t* buf_lens, const uint16_t* k_src,
+                                const uint16_t* v_src, uint8_t* const* k_bufs, uint8_t* const* v_bufs,
+                                float* const* k_scales, float* const* v_scales, int64_t b, int64_t len_q,
+                                int64_t hkv, int64_t d, int bshd, int dtype, zl_stream_t s);
+int zl_rope_quant_scatter_decode(const float* cosv, const float* sinv, const uint16_t* qkv, uint16_t* q,
+                                 const int32_t* placement, const int32_t* buf_lens, uint8_t* const* k_bufs,
+                                 uint8_t* const* v_bufs, float* const* k_scales, float* const* v_scales, int64_t b,
+                                 int64_t h, int64_t hkv, int64_t d, int neox, int bshd, int dtype, zl_stream_t s);
+int zl_decode_attn_quant(const uint16_t* q, const int32_t* buf_lens, const uint8_t* const* k_bufs,
+                         const uint8_t* const* v_bufs, const float* const* k_scales, const float* const* v_scales,
+                         const int8_t* mask, const int32_t* valid_lens, uint16_t* out, void* workspace, int64_t b,
+                         int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale, int64_t max_len_buf,
+                         int bshd, int dtype, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * a16  Prompt ("encode part") attention of ONE task's chunk, causal, on the matrix cores.
  * Replaces attn_encode_group -> FlashDecoding::mha_fwd (src/nn/attention/attention.cpp:442-622; the
  * arithmetic of the external flash-attn library): query row i of the chunk sits at position pos0 + i and

@@ -958,3 +958,65 @@ void zlo_quant_back_copy_to_buffer(const int32_t* src, const float* sx, const ui
                 }
         }
 }
+
+/* quant_calc_scale with a zero point (quant_kernel.cu:15-47, q_zero != 0): the INT8 KV cache rows,
+ * u8 = q_zero + rint(x * 127 / amax), scale = amax / 127 (attention.cpp:656-661 uses q_zero = 128) */
+void zlo_quant_calc_scale_zp(const uint16_t* x, uint8_t* q, float* scale, int64_t m, int64_t k, int q_zero, int dtype) {
+    for (int64_t r = 0; r < m; ++r) {
+        float amax = 0.f;
+        for (int64_t i = 0; i < k; ++i) {
+            float v = fabsf(T2f(x[r * k + i], dtype));
+            amax = v > amax ? v : amax;
+        }
+        float bs = amax > 0.f ? 127.f / amax : 0.f; /* a zero row: codes q_zero, scale 0 (the reference divides by 0) */
+        for (int64_t i = 0; i < k; ++i)
+            q[r * k + i] = (uint8_t)((float)q_zero + nearbyintf(T2f(x[r * k + i], dtype) * bs));
+        scale[r] = amax / 127.f;
+    }
+}
+
+/* Decode attention over an INT8 KV cache, exact (fp64) statement of KERNEL_mqa_rag_buffer_split_kv_quant
+ * (attention_kernel.cu:802-878, quant_attention.cuh:39-123):
+ *   logit_j = scale * sk_j * sum_d q_d (K_jd - 128);  p = softmax over the visible j;
+ *   out_d = sum_j p_j * sv_j * (V_jd - 128).
+ * K/V u8 (len_buf, hkv, d) [bshd] or (hkv, len_buf, d); scales float (len_buf, hkv) / (hkv, len_buf). */
+void zlo_mqa_rag_buffer_quant_exact(const uint16_t* q, const int32_t* buf_lens, const uint8_t* const* k_bufs,
+                                    const uint8_t* const* v_bufs, const float* const* k_scales,
+                                    const float* const* v_scales, const int8_t* mask, double* out, int64_t b,
+                                    int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale, int bshd, int dtype) {
+    int64_t n_rep = h / hkv, mask_off = 0;
+    for (int64_t bi = 0; bi < b; ++bi) {
+        int64_t len = buf_lens[bi];
+        double* lg = (double*)malloc(sizeof(double) * (len > 0 ? len : 1));
+        for (int64_t qi = 0; qi < len_q; ++qi)
+            for (int64_t hh = 0; hh < h; ++hh) {
+                int64_t hk = hh / n_rep;
+                const uint16_t* qv = q + ((bi * len_q + qi) * h + hh) * d;
+                double mx = -1e300;
+                for (int64_t j = 0; j < len; ++j) {
+                    if (!mask[mask_off + qi * len + j]) { lg[j] = -1e300; continue; }
+                    const uint8_t* kr = k_bufs[bi] + (bshd ? (j * hkv + hk) * d : (hk * len + j) * d);
+                    double dot = 0;
+                    for (int64_t e = 0; e < d; ++e) dot += (double)T2f(qv[e], dtype) * ((double)kr[e] - 128.0);
+                    double sk = k_scales[bi][bshd ? j * hkv + hk : hk * len + j];
+                    lg[j] = dot * sk * (double)scale;
+                    if (lg[j] > mx) mx = lg[j];
+                }
+                double z = 0;
+                for (int64_t j = 0; j < len; ++j) {
+                    lg[j] = lg[j] <= -1e299 ? 0.0 : exp(lg[j] - mx);
+                    z += lg[j];
+                }
+                double* o = out + ((bi * len_q + qi) * h + hh) * d;
+                for (int64_t e = 0; e < d; ++e) o[e] = 0;
+                for (int64_t j = 0; j < len; ++j) {
+                    if (lg[j] == 0.0) continue;
+                    const uint8_t* vr = v_bufs[bi] + (bshd ? (j * hkv + hk) * d : (hk * len + j) * d);
+                    double w = lg[j] / (z + 1e-20) * (double)v_scales[bi][bshd ? j * hkv + hk : hk * len + j];
+                    for (int64_t e = 0; e < d; ++e) o[e] += w * ((double)vr[e] - 128.0);
+                }
+            }
+        free(lg);
+        mask_off += len_q * len;
+    }
+}

@@ -151,6 +151,13 @@ void zlo_quant_back_copy_to_buffer(const int32_t* src, const float* sx, const ui
                                    int64_t len_buf, int64_t src_stride, int64_t dst_stride, int64_t place_stride,
                                    int dtype);
 
+
+void zlo_quant_calc_scale_zp(const uint16_t* x, uint8_t* q, float* scale, int64_t m, int64_t k, int q_zero, int dtype);
+void zlo_mqa_rag_buffer_quant_exact(const uint16_t* q, const int32_t* buf_lens, const uint8_t* const* k_bufs,
+                                    const uint8_t* const* v_bufs, const float* const* k_scales,
+                                    const float* const* v_scales, const int8_t* mask, double* out, int64_t b,
+                                    int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale, int bshd, int dtype);
+
 #ifdef __cplusplus
 }
 #endif

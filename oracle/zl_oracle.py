@@ -398,3 +398,23 @@ def quant_back_copy_to_buffer(src, sx, sy, placement, dst, dtype=0):
                                         _i(t), _i(h), _i(d), _i(len_buf), _i(t * h * d), _i(h * len_buf * d),
                                         _i(0 if pl is None or pl.ndim == 1 else pl.shape[1]), C.c_int(dtype))
     return dst
+
+
+def quant_calc_scale_zp(x, q_zero=128, dtype=0):
+    """INT8 KV cache rows: u8 codes with a zero point + fp32 scale per row."""
+    x = _c(x, np.uint16)
+    m, k = x.shape
+    q, s = np.empty((m, k), np.uint8), np.empty((m,), np.float32)
+    lib().zlo_quant_calc_scale_zp(_p(x), _p(q), _p(s), _i(m), _i(k), C.c_int(q_zero), C.c_int(dtype))
+    return q, s
+
+
+def mqa_rag_buffer_quant(q, buf_lens, k_bufs, v_bufs, k_scales, v_scales, mask, hkv, scale, bshd=True, dtype=0):
+    """exact (fp64) decode attention over u8 K/V buffers + fp32 per-(key, kv head) scales."""
+    q, buf_lens, mask = _c(q, np.uint16), _c(buf_lens, np.int32), _c(mask, np.int8)
+    b, len_q, h, d = q.shape
+    out = np.empty(q.shape, np.float64)
+    lib().zlo_mqa_rag_buffer_quant_exact(_p(q), _p(buf_lens), _ptr_array(k_bufs), _ptr_array(v_bufs), _ptr_array(k_scales),
+                                         _ptr_array(v_scales), _p(mask), _p(out), _i(b), _i(len_q), _i(h), _i(hkv), _i(d),
+                                         _f(scale), C.c_int(int(bshd)), C.c_int(dtype))
+    return out

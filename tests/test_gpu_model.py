@@ -37,9 +37,16 @@ def _hf_state(rng, cfg, g):
 
 
 class OracleModel:
-    def __init__(self, oracle, cfg, sd, g, batch, len_buf):
+    def __init__(self, oracle, cfg, sd, g, batch, len_buf, kv_quant=False):
         self.o, self.cfg, self.g = oracle, cfg, g
         self.sd = sd
+        self.kv_quant = kv_quant
+        if kv_quant:   # INT8 KV cache: u8 codes (128 = zero) + fp32 scale per (slot, kv head)
+            cs, ss = (len_buf, cfg.num_kv_heads, cfg.dim_head), (len_buf, cfg.num_kv_heads)
+            self.kc = [[np.full(cs, 128, np.uint8) for _ in range(batch)] for _ in range(cfg.num_layers)]
+            self.vc = [[np.full(cs, 128, np.uint8) for _ in range(batch)] for _ in range(cfg.num_layers)]
+            self.ks = [[np.zeros(ss, np.float32) for _ in range(batch)] for _ in range(cfg.num_layers)]
+            self.vs = [[np.zeros(ss, np.float32) for _ in range(batch)] for _ in range(cfg.num_layers)]
         self.km = {}
         for k in sd:
             if k.endswith(".qweight"):
@@ -65,10 +72,13 @@ class OracleModel:
         if not commit:   # evaluate without touching the KV buffers (a second flavour of the same step)
             import copy
             saved = (copy.deepcopy(self.kb), copy.deepcopy(self.vb))
+            saved_q = copy.deepcopy((self.kc, self.vc, self.ks, self.vs)) if self.kv_quant else None
             try:
                 return self.step(tokens, pos, flavour, True)
             finally:
                 self.kb, self.vb = saved
+                if self.kv_quant:
+                    self.kc, self.vc, self.ks, self.vs = saved_q
         h = o.embedding(np.asarray(tokens, np.int32), o.h2u(self.sd["model.embed_tokens.weight"]))
         llama3 = (8.0, 1.0, 4.0, 8192.0)
         cs, sn = o.rope_cos_sin(np.asarray(pos, np.int32), c.dim_head, c.rope_theta, True, llama3)
@@ -79,16 +89,36 @@ class OracleModel:
             xn = o.rmsnorm(h, o.h2u(self.sd[p + "input_layernorm.weight"]), c.eps)
             qkv = np.concatenate([self._gemv(xn, p + "self_attn." + n + "_proj", flavour) for n in "qkv"], axis=1)
             q, k, v = o.rope_qk_cache(cs, sn, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
-            o.copy_to_rag_buffer2(np.asarray(pos, np.int32).reshape(b, 1), lens, k.reshape(b, 1, c.num_kv_heads, c.dim_head),
-                                  v.reshape(b, 1, c.num_kv_heads, c.dim_head), self.kb[i], self.vb[i], True)
-            att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask, c.num_kv_heads,
-                                   1.0 / np.sqrt(c.dim_head), True).reshape(b, -1)
+            if self.kv_quant:
+                self._quant_store(i, range(b), [[p_] for p_ in pos], k, v)
+                att = o.mqa_rag_buffer_quant(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kc[i], self.vc[i], self.ks[i],
+                                             self.vs[i], mask, c.num_kv_heads, 1.0 / np.sqrt(c.dim_head), True)
+                att = o.h2u(att.astype(np.float16)).reshape(b, -1)
+            else:
+                o.copy_to_rag_buffer2(np.asarray(pos, np.int32).reshape(b, 1), lens, k.reshape(b, 1, c.num_kv_heads, c.dim_head),
+                                      v.reshape(b, 1, c.num_kv_heads, c.dim_head), self.kb[i], self.vb[i], True)
+                att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask, c.num_kv_heads,
+                                       1.0 / np.sqrt(c.dim_head), True).reshape(b, -1)
             h = o.element_add_scale(h, self._gemv(att, p + "self_attn.o_proj", flavour), 1.0, True)
             xn = o.rmsnorm(h, o.h2u(self.sd[p + "post_attention_layernorm.weight"]), c.eps)
             act = o.silu_mul(self._gemv(xn, p + "mlp.gate_proj", flavour), self._gemv(xn, p + "mlp.up_proj", flavour))
             h = o.element_add_scale(h, self._gemv(act, p + "mlp.down_proj", flavour), 1.0, True)
         xn = o.rmsnorm(h, o.h2u(self.sd["model.norm.weight"]), c.eps)
         return o.gemm_nt(xn, o.h2u(self.sd["lm_head.weight"]), exact=True), h
+
+    def _quant_store(self, layer, tasks, slots, k, v):
+        """quant_calc_scale(127, 128) of the rows of k / v (tokens, Hkv*D) -> the tasks' code / scale buffers"""
+        o, c = self.o, self.cfg
+        kq, ksc = o.quant_calc_scale_zp(np.ascontiguousarray(k).reshape(-1, c.dim_head), 128, 0)
+        vq, vsc = o.quant_calc_scale_zp(np.ascontiguousarray(v).reshape(-1, c.dim_head), 128, 0)
+        kq, vq = kq.reshape(-1, c.num_kv_heads, c.dim_head), vq.reshape(-1, c.num_kv_heads, c.dim_head)
+        ksc, vsc = ksc.reshape(-1, c.num_kv_heads), vsc.reshape(-1, c.num_kv_heads)
+        r = 0
+        for t, sl in zip(tasks, slots):
+            for slot in sl:
+                self.kc[layer][t][slot], self.vc[layer][t][slot] = kq[r], vq[r]
+                self.ks[layer][t][slot], self.vs[layer][t][slot] = ksc[r], vsc[r]
+                r += 1
 
     def _lin40(self, x, name):
         """The reference's M > 40 branch: dequant_k_major -> W16, fp32-accumulating GEMM (exact here), fp16 out."""
@@ -114,6 +144,8 @@ class OracleModel:
             q, k, v = o.rope_qk_cache(cs, sn, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
             o.copy_to_rag_buffer2(pos.reshape(1, s), lens, k.reshape(1, s, c.num_kv_heads, c.dim_head),
                                   v.reshape(1, s, c.num_kv_heads, c.dim_head), [self.kb[i][task]], [self.vb[i][task]], True)
+            if self.kv_quant:   # the prompt attends to its unquantised rows (kb / vb above), the cache gets the codes
+                self._quant_store(i, [task], [list(range(s))], k, v)
             att = o.mqa_rag_buffer(q.reshape(1, s, c.num_heads, c.dim_head), lens, [self.kb[i][task]], [self.vb[i][task]], mask,
                                    c.num_kv_heads, 1.0 / np.sqrt(c.dim_head), True).reshape(s, -1)
             h = o.element_add_scale(h, self._lin40(att, p + "self_attn.o_proj"), 1.0, True)
@@ -572,3 +604,69 @@ def test_tensor_parallel_decode_matches_single_gpu(dev):
         ref_model.advance(ref_ctx, nxt)
         for m, c in zip(models, ctxs):
             m.advance(c, nxt)
+
+
+def test_int8_kv_cache_prefill_and_decode(oracle, dev):
+    """KV_CACHE_DTYPE=int8 (src/model/model_context.cpp:61-79): prompt encode writes codes + scales (bit-exact
+    with the oracle's cache), decode steps attend over the codes; logits within 1e-3 of the oracle composed with
+    the exact quantised attention (E linears) and within 3e-3 of the R flavour."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(21)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5,
+                      rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                    "original_max_position_embeddings": 8192})
+    g = 128
+    sd = _hf_state(rng, cfg, g)
+    model = LLaMA(cfg, QuantConfig(5, g), dev).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    len_buf, s = 128, 45
+    ctx = model.new_context(1, len_buf, 0, kv_cache_dtype="int8")
+    assert ctx.kv_quant and ctx.kv[0].dtype == torch.uint8
+    om = OracleModel(oracle, cfg, sd, g, 1, len_buf, kv_quant=True)
+    prompt = rng.integers(0, cfg.vocab_size, s).astype(np.int32)
+    logits = model.prefill(ctx, 0, torch.from_numpy(prompt)).float().cpu().numpy().astype(np.float64)
+    ref = om.prefill(0, prompt)
+    assert np.abs(logits - ref).max() < 2e-3 * np.abs(ref).max()
+    # the cache of layer 0: the K rows differ from the oracle's by fp16 roundings of the GEMM only, so the
+    # codes agree up to +-1 on a few elements and the scales to an fp16 ulp
+    got_codes = ctx.kv[0][0, 0, :s].cpu().numpy().astype(np.int32)
+    dcode = np.abs(got_codes - om.kc[0][0][:s].astype(np.int32))
+    assert dcode.max() <= 1 and (dcode != 0).mean() < 0.02
+    gs, rs = ctx.kv_scales[0][0, 0, :s].cpu().numpy(), om.ks[0][0][:s]
+    assert np.abs(gs - rs).max() <= 2.0 ** -9 * rs.max()
+    with pytest.raises(Exception):
+        model.prefill(ctx, 0, torch.from_numpy(prompt), chunk=16)
+    # decode continuation from the oracle's cache state (so both sides attend over the same codes)
+    for li in range(cfg.num_layers):
+        ctx.kv[0][li, 0].copy_(torch.from_numpy(om.kc[li][0]))
+        ctx.kv[0][li, 1].copy_(torch.from_numpy(om.vc[li][0]))
+        ctx.kv_scales[0][li, 0].copy_(torch.from_numpy(om.ks[li][0]))
+        ctx.kv_scales[0][li, 1].copy_(torch.from_numpy(om.vs[li][0]))
+    ctx.positions.fill_(s); ctx.placement.fill_(s); ctx.valid_lens.fill_(s + 1)
+    tok = np.array([int(ref.argmax())], np.int32)
+    ctx.tokens.copy_(torch.from_numpy(tok))
+    for step in range(3):
+        got = model.encode(ctx).float().cpu().numpy().astype(np.float64)
+        ref_e, _ = om.step(tok, [s + step], flavour="E", commit=False)
+        ref_r, _ = om.step(tok, [s + step], flavour="R")
+        assert np.abs(got - ref_e).max() < 1e-3 * np.abs(ref_e).max(), np.abs(got - ref_e).max() / np.abs(ref_e).max()
+        assert np.abs(got - ref_r).max() < 3e-3 * np.abs(ref_r).max()
+        # re-sync the device cache with the oracle's (R-flavour) rows so the next step starts from equal state
+        for li in range(cfg.num_layers):
+            ctx.kv[0][li, 0].copy_(torch.from_numpy(om.kc[li][0])); ctx.kv[0][li, 1].copy_(torch.from_numpy(om.vc[li][0]))
+            ctx.kv_scales[0][li, 0].copy_(torch.from_numpy(om.ks[li][0])); ctx.kv_scales[0][li, 1].copy_(torch.from_numpy(om.vs[li][0]))
+        best = int(ref_r.argmax())
+        model.advance(ctx, torch.tensor([best], device=dev))
+        tok = np.array([best], np.int32)
+
+
+def test_int8_kv_cache_env_switch(dev, monkeypatch):
+    from zhilight_amd import ops
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    cfg = ModelConfig(num_layers=1, dim_model=256, num_heads=2, dim_head=128, dim_ff=256, vocab_size=128, num_kv_heads=1)
+    model = LLaMA(cfg, QuantConfig(5, 128), dev).init_random()
+    monkeypatch.setenv("KV_CACHE_DTYPE", "int8")
+    assert model.new_context(1, 16, 0).kv_quant
+    monkeypatch.setenv("KV_CACHE_DTYPE", "fp8")
+    with pytest.raises(ops.ZLError):
+        model.new_context(1, 16, 0)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--bhsd", action="store_true", help="KV buffers (Hkv, len_buf, D) instead of (len_buf, Hkv, D)")
+    ap.add_argument("--q8", action="store_true", help="INT8 KV cache: rope+quantise+scatter launch, then attention over codes")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     h, hkv, d = 32, 8, 128
@@ -38,7 +39,25 @@ def main():
     out = torch.empty(a.batch, h * d, dtype=torch.float16, device=dev)
     ws = ops.decode_attn_workspace(a.batch, 1, h, d, len_buf, dev)
 
+    if a.q8:
+        kv = [torch.randint(0, 256, shape, dtype=torch.uint8, device=dev) for _ in range(a.batch)]
+        sc = [torch.rand(shape[:-1], dtype=torch.float32, device=dev) * 0.03 + 0.005 for _ in range(a.batch)]
+        k_addrs = torch.tensor([[t[l, 0].data_ptr() for t in kv] for l in range(a.layers)], dtype=torch.int64, device=dev)
+        v_addrs = torch.tensor([[t[l, 1].data_ptr() for t in kv] for l in range(a.layers)], dtype=torch.int64, device=dev)
+        ks_addrs = torch.tensor([[t[l, 0].data_ptr() for t in sc] for l in range(a.layers)], dtype=torch.int64, device=dev)
+        vs_addrs = torch.tensor([[t[l, 1].data_ptr() for t in sc] for l in range(a.layers)], dtype=torch.int64, device=dev)
+        qb = torch.empty(a.batch, h * d, dtype=torch.float16, device=dev)
+
     def run():
+        if a.q8:
+            for l in range(a.layers):
+                ops.rope_quant_scatter_decode(cos, sin, qkv, pos, buf_lens, k_addrs[l], v_addrs[l], ks_addrs[l], vs_addrs[l],
+                                              h, hkv, d, bshd=not a.bhsd, q_out=qb)
+                ops.multi_query_attention_rag_buffer_quant(qb.view(a.batch, 1, h, d), buf_lens, k_addrs[l], v_addrs[l],
+                                                           ks_addrs[l], vs_addrs[l], None, 1.0 / math.sqrt(d), len_buf, hkv,
+                                                           valid_lens=valid, bshd=not a.bhsd,
+                                                           out=out.view(a.batch, 1, h, d), workspace=ws)
+            return
         for l in range(a.layers):
             ops.decode_attention_fused(cos, sin, qkv, pos, buf_lens, valid, k_addrs[l], v_addrs[l], h, hkv, d,
                                        1.0 / math.sqrt(d), len_buf, bshd=not a.bhsd, out=out, workspace=ws)
@@ -56,7 +75,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (a.iters * a.layers)
-    kvb = a.batch * 2 * hkv * (a.seq + 1) * d * 2
+    kvb = a.batch * 2 * hkv * (a.seq + 1) * (d + 4 if a.q8 else d * 2)
     print(f"batch={a.batch} seq={a.seq}: {us:7.2f} us/launch   KV {kvb / 1e6:.2f} MB -> {kvb / us / 1e3:7.1f} GB/s"
           "")
 

@@ -27,7 +27,9 @@ SYMBOLS = [
     "zl_rmsnorm",
     "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rotary_embedding_qk", "zl_rope_qk_cache",
     "zl_copy_to_rag_buffer2", "zl_rope_scatter_decode",
-    "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_fused", "zl_prefill_attn",
+    "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_fused",
+    "zl_quant_calc_scale_zp", "zl_quant_copy_to_rag_buffer", "zl_rope_quant_scatter_decode", "zl_decode_attn_quant",
+    "zl_prefill_attn",
     "zl_element_add_scale", "zl_gate_mul", "zl_embedding",
     "zl_quant_calc_scale", "zl_rmsnorm_quant", "zl_int8_gemm_nt", "zl_quant_scale_back",
     "zl_quant_back_act_mul", "zl_quant_scale_back3", "zl_quant_back_element_add_scale", "zl_quant_back_transpose",

@@ -46,6 +46,9 @@ struct AttnParams {
     uint16_t* const* k_bufs_w;  // writable views of k_bufs / v_bufs
     uint16_t* const* v_bufs_w;
     int neox;
+    // INT8 cache (k_decode_attn_partial_q8): k_bufs / v_bufs hold u8 codes, one fp32 scale per (key, kv head)
+    const float* const* k_scales;
+    const float* const* v_scales;
 };
 
 typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
@@ -362,6 +365,244 @@ __global__ __launch_bounds__(256) void k_decode_attn_partial(const AttnParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// INT8 KV cache.  Reference: KERNEL_mqa_rag_buffer_split_kv_quant (attention_kernel.cu:802-878) with
+// quant_attention.cuh:39-123:  logit_j = scale * sk_j * q.(K_j - 128),  out = sum_j p_j sv_j (V_j - 128).
+// Same split/merge structure as the fp16 kernel; a key row is D bytes, so a lane's 16 B hold 16 codes,
+// a row takes D/16 lanes and a wave-step covers twice the keys (HBM bytes per key: 2 D + 8 instead of 4 D).
+// codes -> exact fp16 (code - 128) without a conversion instruction: byte | 0x6400 is the half 1024 + code,
+// one packed subtract of 1152 later it is (code - 128); q.k is then v_dot2_f32_f16 with fp32 accumulation
+// (the reference multiplies and adds in fp16 there).  P.V converts the codes to fp32.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void codes_to_h2(const uint4& w, hv2 (&h)[8]) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+    const hv2 bias = {(_Float16)1152.f, (_Float16)1152.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[2 * e] = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(0x64646464u, u[e], 0x04010400u)) - bias;
+        h[2 * e + 1] = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(0x64646464u, u[e], 0x04030402u)) - bias;
+    }
+}
+__device__ __forceinline__ void codes_to_f32(const uint4& w, float (&f)[16]) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[4 * e + j] = (float)((u[e] >> (8 * j)) & 0xffu) - 128.f;
+    }
+}
+
+template <int DT, int D, int RT, bool MASKED>
+__global__ __launch_bounds__(256) void k_decode_attn_partial_q8(const AttnParams p) {
+    constexpr int LPK = D / 16;      // lanes per key row (16 codes each)
+    constexpr int KPS = 64 / LPK;    // keys per wave-step
+    constexpr int CHUNK = KPS * kSteps;
+    constexpr int QW = DT == ZL_F16 ? 8 : 16;
+    __shared__ float xw[4][RT][D + 2];
+
+    const int b = blockIdx.z / p.passes, pass = blockIdx.z % p.passes;
+    const int hk = blockIdx.y, split = blockIdx.x;
+    const int len = p.buf_lens[b];
+    const int vlen_in = MASKED ? 0x7fffffff : p.valid_lens[b];
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_bufs[b]);
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_bufs[b]);
+    const float* ksc = p.k_scales[b];
+    const float* vsc = p.v_scales[b];
+    const int elen = MASKED ? len : min(len, vlen_in);
+    const int t0 = split * p.split_len;
+    if (t0 >= elen || len <= 0) return;
+    const int t1 = min(elen, t0 + p.split_len);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPK, dp = lane % LPK;
+    const size_t kv_stride = p.bshd ? (size_t)p.hkv * D : (size_t)D;
+    const size_t kv_off = (p.bshd ? (size_t)hk * D : (size_t)hk * len * D) + dp * 16;
+    const size_t sc_stride = p.bshd ? (size_t)p.hkv : 1;
+    const size_t sc_off = p.bshd ? (size_t)hk : (size_t)hk * len;
+
+    uint4 kk[kSteps], vv[kSteps];
+    float ks[kSteps], vs[kSteps];
+    int c0 = t0 + wave * CHUNK;
+    const int last_key = t1 - 1;
+#define ZL_LOAD_CHUNK_Q8(base)                                                                   \
+    _Pragma("unroll") for (int st = 0; st < kSteps; ++st) {                                      \
+        const int key_ = (base) + st * KPS + grp;                                                \
+        const int kc_ = key_ < last_key ? key_ : last_key;                                       \
+        kk[st] = *reinterpret_cast<const uint4*>(kbase + kv_off + (size_t)kc_ * kv_stride);     \
+        vv[st] = *reinterpret_cast<const uint4*>(vbase + kv_off + (size_t)kc_ * kv_stride);     \
+        ks[st] = ksc[sc_off + (size_t)kc_ * sc_stride];                                          \
+        vs[st] = vsc[sc_off + (size_t)kc_ * sc_stride];                                          \
+    }
+    ZL_LOAD_CHUNK_Q8(c0)
+
+    size_t mask_off = 0;
+    if (MASKED) {
+        for (int i = 0; i < b; ++i) mask_off += (size_t)p.buf_lens[i];
+        mask_off *= p.len_q;
+    }
+
+    // q: fp16 stays packed (dot2), bf16 is widened to fp32
+    hv2 qh[RT][8];
+    float qf[RT][QW];
+    int q_of_row[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int rr = pass * RT + i;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        q_of_row[i] = 0;
+        if (rr < p.rows) {
+            const int qi = rr / p.n_rep, head = hk * p.n_rep + rr % p.n_rep;
+            q_of_row[i] = qi;
+            const uint16_t* qp = p.q + (((size_t)b * p.len_q + qi) * p.h + head) * D + dp * 16;
+            lo = *reinterpret_cast<const uint4*>(qp);
+            hi = *reinterpret_cast<const uint4*>(qp + 8);
+        }
+        if constexpr (DT == ZL_F16) {
+            const uint32_t u[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qh[i][e] = __builtin_bit_cast(hv2, u[e]);
+        } else {
+            float a[8], c[8];
+            unpack8<DT>(lo, a);
+            unpack8<DT>(hi, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qf[i][e] = a[e];
+                qf[i][8 + e] = c[e];
+            }
+        }
+    }
+
+    float m[RT], l[RT], acc[RT][16];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        m[i] = -1e20f;
+        l[i] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    }
+
+    while (c0 < t1) {
+        float sc[RT][kSteps];
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) {
+            const int key = c0 + st * KPS + grp;
+            const bool inb = key < t1;
+            const float lscale = ks[st] * p.scale;
+            hv2 kh[8];
+            float kf[16];
+            if constexpr (DT == ZL_F16) codes_to_h2(kk[st], kh);
+            else codes_to_f32(kk[st], kf);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                float d = 0.f;
+                if constexpr (DT == ZL_F16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d = __builtin_amdgcn_fdot2(qh[i][e], kh[e], d, false);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) d = __builtin_fmaf(qf[i][e], kf[e], d);
+                }
+                d = key_row_sum<LPK>(d);
+                bool vis = inb;
+                if (MASKED) {
+                    if (vis) vis = p.mask[mask_off + (size_t)q_of_row[i] * len + key] != 0;
+                }
+                sc[i][st] = vis ? d * lscale : -INFINITY;
+            }
+            if (!inb) vs[st] = 0.f;   // clamped duplicate: weight 0
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            float mc = sc[i][0];
+#pragma unroll
+            for (int st = 1; st < kSteps; ++st) mc = fmaxf(mc, sc[i][st]);
+            const float mn = fmaxf(m[i], mc);
+            const float alpha = __expf(m[i] - mn);
+            m[i] = mn;
+            l[i] *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] *= alpha;
+        }
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) {
+            float vf[16];
+            codes_to_f32(vv[st], vf);
+            float sv = vs[st];
+            if (MASKED) {
+                // a key no row sees: its scale may be uninitialised memory (inf/nan) -- weight it by exactly 0
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < RT; ++i) any = any || (sc[i][st] != -INFINITY);
+                if (!any) sv = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const float pr = __expf(sc[i][st] - m[i]);
+                l[i] += pr;
+                const float w = pr * sv;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = __builtin_fmaf(w, vf[e], acc[i][e]);
+            }
+        }
+        c0 += 4 * CHUNK;
+        if (c0 >= t1) break;
+        ZL_LOAD_CHUNK_Q8(c0)
+    }
+#undef ZL_LOAD_CHUNK_Q8
+
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const float m2 = __shfl_xor(m[i], off, 64), l2 = __shfl_xor(l[i], off, 64);
+            const float mn = fmaxf(m[i], m2);
+            const float f1 = __expf(m[i] - mn), f2 = __expf(m2 - mn);
+            l[i] = l[i] * f1 + l2 * f2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float a2 = __shfl_xor(acc[i][e], off, 64);
+                acc[i][e] = acc[i][e] * f1 + a2 * f2;
+            }
+            m[i] = mn;
+        }
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xw[wave][i][dp * 16 + e] = acc[i][e];
+            if (dp == 0) {
+                xw[wave][i][D] = m[i];
+                xw[wave][i][D + 1] = l[i];
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < RT * D; idx += 256) {
+        const int i = idx / D, d = idx % D;
+        const int rr = pass * RT + i;
+        if (rr >= p.rows) continue;
+        float mn = xw[0][i][D];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, xw[w][i][D]);
+        float a = 0.f, lt = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __expf(xw[w][i][D] - mn);
+            a = __builtin_fmaf(xw[w][i][d], f, a);
+            lt = __builtin_fmaf(xw[w][i][D + 1], f, lt);
+        }
+        const int qi = rr / p.n_rep, head = hk * p.n_rep + rr % p.n_rep;
+        float* dst = p.ws + ((((size_t)b * p.len_q + qi) * p.h + head) * p.max_splits + split) * (D + 2);
+        dst[d] = a;
+        if (d == 0) {
+            dst[D] = mn;
+            dst[D + 1] = lt;
+        }
+    }
+}
+
 // grid (B*len_q*H), block D.  Split statistics go through LDS once; the per-d accumulation then issues
 // independent loads back to back (the first version walked the splits with dependent loads: 6 us).
 template <int DT, int D>
@@ -450,6 +691,25 @@ int launch_d(const AttnParams& p, hipStream_t st) {
     return zl_launch_status();
 }
 
+template <int DT, int D>
+int launch_q8(const AttnParams& p, hipStream_t st) {
+    dim3 grid((unsigned)p.max_splits, (unsigned)p.hkv, (unsigned)(p.b * p.passes));
+    const int rt = p.rows >= 4 ? 4 : (p.rows >= 2 ? 2 : 1);
+#define ZL_ATTN_RT(RT)                                                                                       \
+    if (p.mask) hipLaunchKernelGGL((k_decode_attn_partial_q8<DT, D, RT, true>), grid, dim3(256), 0, st, p);  \
+    else hipLaunchKernelGGL((k_decode_attn_partial_q8<DT, D, RT, false>), grid, dim3(256), 0, st, p);
+    switch (rt) {
+        case 1: ZL_ATTN_RT(1) break;
+        case 2: ZL_ATTN_RT(2) break;
+        default: ZL_ATTN_RT(4) break;
+    }
+#undef ZL_ATTN_RT
+    int e = zl_launch_status();
+    if (e) return e;
+    hipLaunchKernelGGL((k_decode_attn_combine<DT, D>), dim3((unsigned)(p.b * p.len_q * p.h)), dim3(D), 0, st, p);
+    return zl_launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -483,6 +743,7 @@ int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* c
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
+    p.k_scales = p.v_scales = nullptr;
 #define ZL_ATTN_D(DT, FUSE)                                    \
     switch (d) {                                               \
         case 64: return launch_d<DT, 64, FUSE>(p, hs);         \
@@ -515,11 +776,46 @@ int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* q
     p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
     p.scale = scale; p.bshd = bshd;
     p.qkv = qkv; p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.k_bufs_w = k_bufs; p.v_bufs_w = v_bufs; p.neox = neox;
+    p.k_scales = p.v_scales = nullptr;
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
     if (dtype == ZL_F16) { ZL_ATTN_D(ZL_F16, true) }
     ZL_ATTN_D(ZL_BF16, true)
 #undef ZL_ATTN_D
+}
+
+int zl_decode_attn_quant(const uint16_t* q, const int32_t* buf_lens, const uint8_t* const* k_bufs,
+                         const uint8_t* const* v_bufs, const float* const* k_scales, const float* const* v_scales,
+                         const int8_t* mask, const int32_t* valid_lens, uint16_t* out, void* workspace, int64_t b,
+                         int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd,
+                         int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(q && buf_lens && k_bufs && v_bufs && k_scales && v_scales && out && workspace, ZL_EINVAL);
+    ZL_CHECK_ARG(mask || valid_lens, ZL_EINVAL);
+    ZL_CHECK_ARG(b > 0 && len_q > 0 && h > 0 && hkv > 0 && d > 0 && max_len_buf > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(h % hkv == 0, ZL_ESHAPE);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    AttnParams p;
+    p.q = q; p.buf_lens = buf_lens;
+    p.k_bufs = reinterpret_cast<const uint16_t* const*>(k_bufs);
+    p.v_bufs = reinterpret_cast<const uint16_t* const*>(v_bufs);
+    p.k_scales = k_scales; p.v_scales = v_scales;
+    p.mask = mask; p.valid_lens = valid_lens; p.out = out; p.ws = (float*)workspace;
+    p.b = (int)b; p.len_q = (int)len_q; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
+    p.rows = p.len_q * p.n_rep;
+    const int rt = p.rows >= 4 ? 4 : (p.rows >= 2 ? 2 : 1);
+    p.passes = (p.rows + rt - 1) / rt;
+    p.split_len = attn_split_len(b, hkv, max_len_buf);
+    p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    p.scale = scale; p.bshd = bshd;
+    ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
+    p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
+    hipStream_t hs = (hipStream_t)s;
+    switch (d) {
+        case 64: return dtype == ZL_F16 ? launch_q8<ZL_F16, 64>(p, hs) : launch_q8<ZL_BF16, 64>(p, hs);
+        case 128: return dtype == ZL_F16 ? launch_q8<ZL_F16, 128>(p, hs) : launch_q8<ZL_BF16, 128>(p, hs);
+        case 256: return dtype == ZL_F16 ? launch_q8<ZL_F16, 256>(p, hs) : launch_q8<ZL_BF16, 256>(p, hs);
+        default: return ZL_ESHAPE;
+    }
 }
 
 }  // extern "C"

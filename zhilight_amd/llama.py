@@ -576,6 +576,12 @@ class DynBatchContext:
     v_addrs: torch.Tensor
     max_len_buf: int
     kv: List[torch.Tensor] = field(default_factory=list)  # owners: per task (layers, 2, len_buf, Hkv, D)
+    # INT8 KV cache (KV_CACHE_DTYPE=int8, src/model/model_context.cpp:61-79): kv holds u8 codes, one fp32
+    # scale per (slot, kv head) in kv_scales: per task (layers, 2, len_buf, Hkv)
+    kv_quant: bool = False
+    ks_addrs: Optional[torch.Tensor] = None
+    vs_addrs: Optional[torch.Tensor] = None
+    kv_scales: List[torch.Tensor] = field(default_factory=list)
 
 
 class LLaMA:
@@ -636,15 +642,34 @@ class LLaMA:
         return self
 
     # ---- KV state ------------------------------------------------------------------------------
-    def new_context(self, batch: int, len_buf: int, start_pos: int, fill_random=False) -> DynBatchContext:
+    def new_context(self, batch: int, len_buf: int, start_pos: int, fill_random=False, kv_cache_dtype=None) -> DynBatchContext:
         """`batch` tasks whose first `start_pos` tokens are already in the KV buffers (zero- or
-        random-filled here: the reference zero-fills, src/kvcache/transformer_buffer.cu:290-330)."""
+        random-filled here: the reference zero-fills, src/kvcache/transformer_buffer.cu:290-330).
+        kv_cache_dtype: None (the model dtype) or "int8"; default from the reference's switch, the environment
+        variable KV_CACHE_DTYPE (src/model/model_context.cpp:61-79)."""
         c, dev = self.cfg, self.device
-        kv = []
+        if kv_cache_dtype is None:
+            kv_cache_dtype = os.environ.get("KV_CACHE_DTYPE") or None
+        if kv_cache_dtype not in (None, "int8"):
+            raise ops.ZLError(f"Unsupported dtype: {kv_cache_dtype}")
+        kv, kv_scales = [], []
         for _ in range(batch):
             shape = (c.num_layers, 2, len_buf, c.num_kv_heads, c.dim_head)
-            t = torch.randn(shape, dtype=c.torch_dtype, device=dev) if fill_random else torch.zeros(shape, dtype=c.torch_dtype, device=dev)
+            if kv_cache_dtype == "int8":
+                t = torch.randint(0, 256, shape, dtype=torch.uint8, device=dev) if fill_random else \
+                    torch.full(shape, 128, dtype=torch.uint8, device=dev)
+                sc = torch.rand(shape[:-1], dtype=torch.float32, device=dev) * 0.03 + 0.005 if fill_random else \
+                    torch.zeros(shape[:-1], dtype=torch.float32, device=dev)
+                kv_scales.append(sc)
+            else:
+                t = torch.randn(shape, dtype=c.torch_dtype, device=dev) if fill_random else torch.zeros(shape, dtype=c.torch_dtype, device=dev)
             kv.append(t)
+        quant_kw = {}
+        if kv_cache_dtype == "int8":
+            quant_kw = dict(
+                kv_quant=True, kv_scales=kv_scales,
+                ks_addrs=torch.tensor([[t[l, 0].data_ptr() for t in kv_scales] for l in range(c.num_layers)], dtype=torch.int64, device=dev),
+                vs_addrs=torch.tensor([[t[l, 1].data_ptr() for t in kv_scales] for l in range(c.num_layers)], dtype=torch.int64, device=dev))
         k_addrs = torch.tensor([[t[l, 0].data_ptr() for t in kv] for l in range(c.num_layers)], dtype=torch.int64, device=dev)
         v_addrs = torch.tensor([[t[l, 1].data_ptr() for t in kv] for l in range(c.num_layers)], dtype=torch.int64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -652,7 +677,7 @@ class LLaMA:
             tokens=torch.zeros(batch, **i32), positions=torch.full((batch,), start_pos, **i32),
             placement=torch.full((batch,), start_pos, **i32), buf_lens=torch.full((batch,), len_buf, **i32),
             valid_lens=torch.full((batch,), start_pos + 1, **i32), k_addrs=k_addrs, v_addrs=v_addrs,
-            max_len_buf=len_buf, kv=kv)
+            max_len_buf=len_buf, kv=kv, **quant_kw)
 
     def _buffers(self, b):
         if b not in self._bufs:
@@ -680,9 +705,19 @@ class LLaMA:
         scale = 1.0 / math.sqrt(c.dim_head)
         for li, layer in enumerate(self.layers):
             layer.project_qkv(hidden, c.eps, out=bufs["qkv"])
-            ops.decode_attention_fused(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.valid_lens, ctx.k_addrs[li],
-                                       ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, scale, ctx.max_len_buf,
-                                       out=bufs["attn"], workspace=workspace)
+            if ctx.kv_quant:
+                # attention.cpp:652-676 + :725-745: rotate, quantise the new K/V rows into the u8 cache, attend over codes
+                ops.rope_quant_scatter_decode(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li],
+                                              ctx.ks_addrs[li], ctx.vs_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head,
+                                              q_out=bufs["q"])
+                ops.multi_query_attention_rag_buffer_quant(
+                    bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li], ctx.ks_addrs[li],
+                    ctx.vs_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads, valid_lens=ctx.valid_lens,
+                    out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head), workspace=workspace)
+            else:
+                ops.decode_attention_fused(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.valid_lens, ctx.k_addrs[li],
+                                           ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, scale, ctx.max_len_buf,
+                                           out=bufs["attn"], workspace=workspace)
             layer.attn_out_add(bufs["attn"], hidden)
             layer.ff_add(hidden, c.eps, bufs["act"])
         return self._logits(hidden, bufs["logits"], argmax_ws)
@@ -751,6 +786,10 @@ class LLaMA:
         s = int(prompt.numel())
         if s < 1 or pos0 + s + 1 > ctx.max_len_buf:
             raise ops.ZLError("prompt does not fit the task's KV buffer")
+        if ctx.kv_quant and pos0 != 0:
+            # the reference de-quantises the earlier chunks there ("WARNING: de-quantize prompt kv cache!",
+            # attention.cpp:511-516); not wired here
+            raise ops.ZLError("chunked prefill is not supported with the INT8 KV cache")
         tokens = prompt.to(device=dev, dtype=torch.int32).contiguous()
         pos = torch.arange(pos0, pos0 + s, dtype=torch.int32, device=dev)
         hidden = ops.embedding(tokens, self.token_embedding, c.scale_emb)
@@ -762,6 +801,22 @@ class LLaMA:
             ka, va = ctx.k_addrs[li][task:task + 1], ctx.v_addrs[li][task:task + 1]
             qkv = layer.project_qkv(hidden, c.eps)
             q, k, v = ops.rope_qk_cache(cos, sin, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
+            if ctx.kv_quant:
+                # attn_encode_group with a quantised buffer (attention.cpp:494-510): the prompt attends to its own
+                # UNquantised K/V rows while their codes go to the cache
+                k3, v3 = k.view(s, c.num_kv_heads, c.dim_head), v.view(s, c.num_kv_heads, c.dim_head)
+                ops.quant_copy_to_rag_buffer(pos, buf_lens, k3, v3, ka, va, ctx.ks_addrs[li][task:task + 1],
+                                             ctx.vs_addrs[li][task:task + 1], len_q=s)
+                if c.dim_head == 128 and q.dtype == torch.float16:
+                    att = ops.prefill_attention(q.view(s, c.num_heads, c.dim_head), k3, v3, 0, c.num_kv_heads, scale)
+                else:
+                    mask, ws = self._prefill_mask(s, s, 0)
+                    att = ops.multi_query_attention_rag_buffer(
+                        q.view(1, s, c.num_heads, c.dim_head), torch.tensor([s], dtype=torch.int32, device=dev),
+                        ops.make_ptr_table([k3]), ops.make_ptr_table([v3]), mask, scale, s, c.num_kv_heads, workspace=ws)
+                layer.attn_out_add(att.view(s, -1), hidden)
+                layer.ff_add(hidden, c.eps)
+                continue
             ops.copy_to_rag_buffer2(placement, buf_lens, k.view(1, s, c.num_kv_heads, c.dim_head),
                                     v.view(1, s, c.num_kv_heads, c.dim_head), ka, va)
             if c.dim_head == 128 and q.dtype == torch.float16:

@@ -453,6 +453,64 @@ def decode_attention_fused(cos, sin, qkv, placement, buf_lens, valid_lens, k_add
     return out
 
 
+def quant_calc_scale_zp(x, q_zero=128):
+    """int8_op::quant_calc_scale(ctx, x, 127, q_zero) (src/nn/quant/int8/quant_kernel.cu:49-80): the INT8 KV cache's
+    row quantiser -> (u8 codes (M, K), fp32 scale (M))."""
+    _chk_cuda(x)
+    xr = x.reshape(-1, x.shape[-1])
+    m, k = xr.shape
+    q = torch.empty((m, k), dtype=torch.uint8, device=x.device)
+    s = torch.empty((m,), dtype=torch.float32, device=x.device)
+    check(lib().zl_quant_calc_scale_zp(_p(xr), _p(q), _p(s), _i(m), _i(k), C.c_int(q_zero), C.c_int(_dt(x)), _stream()),
+          "quant_calc_scale_zp")
+    return q, s
+
+
+def quant_copy_to_rag_buffer(placement, buf_lens, k_src, v_src, k_addrs, v_addrs, k_scale_addrs, v_scale_addrs, len_q=1,
+                             bshd=True):
+    """quant_calc_scale(127, 128) + copy_to_rag_buffer2 for the codes and the scales (attention.cpp:656-676).
+    k_src / v_src (B*len_q, Hkv, D)."""
+    _chk_cuda(placement, buf_lens, k_src, v_src, k_addrs, v_addrs, k_scale_addrs, v_scale_addrs)
+    tokens, hkv, d = k_src.shape
+    check(lib().zl_quant_copy_to_rag_buffer(_p(placement), _p(buf_lens), _p(k_src), _p(v_src), _p(k_addrs), _p(v_addrs),
+                                            _p(k_scale_addrs), _p(v_scale_addrs), _i(tokens // len_q), _i(len_q), _i(hkv),
+                                            _i(d), C.c_int(int(bshd)), C.c_int(_dt(k_src)), _stream()),
+          "quant_copy_to_rag_buffer")
+
+
+def rope_quant_scatter_decode(cos, sin, qkv, placement, buf_lens, k_addrs, v_addrs, k_scale_addrs, v_scale_addrs,
+                              num_heads, num_kv_heads, dim_head, neox=True, bshd=True, q_out=None):
+    """rope_qk_cache + quantise + scatter of the new K/V rows for len_q == 1 decode rows; returns the rotated q."""
+    _chk_cuda(cos, sin, qkv, placement, buf_lens, k_addrs, v_addrs, k_scale_addrs, v_scale_addrs)
+    b = qkv.shape[0]
+    if q_out is None:
+        q_out = torch.empty((b, num_heads * dim_head), dtype=qkv.dtype, device=qkv.device)
+    check(lib().zl_rope_quant_scatter_decode(_p(cos), _p(sin), _p(qkv), _p(q_out), _p(placement), _p(buf_lens),
+                                             _p(k_addrs), _p(v_addrs), _p(k_scale_addrs), _p(v_scale_addrs), _i(b),
+                                             _i(num_heads), _i(num_kv_heads), _i(dim_head), C.c_int(int(neox)),
+                                             C.c_int(int(bshd)), C.c_int(_dt(qkv)), _stream()),
+          "rope_quant_scatter_decode")
+    return q_out
+
+
+def multi_query_attention_rag_buffer_quant(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, scale_k_addrs, scale_v_addrs,
+                                           mask, scale, max_len_buf, num_kv_heads, valid_lens=None, bshd=True, out=None,
+                                           workspace=None):
+    """nn::multi_query_attention_rag_buffer with scale_key_addrs / scale_val_addrs (INT8 KV cache;
+    src/nn/attention/attention_kernel.cu:1384-1416).  batch_q (B, len_q, H, D)."""
+    _chk_cuda(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, scale_k_addrs, scale_v_addrs, mask, valid_lens)
+    b, len_q, h, d = batch_q.shape
+    if out is None:
+        out = torch.empty_like(batch_q)
+    if workspace is None:
+        workspace = decode_attn_workspace(b, len_q, h, d, max_len_buf, batch_q.device)
+    check(lib().zl_decode_attn_quant(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(scale_k_addrs),
+                                     _p(scale_v_addrs), _p(mask), _p(valid_lens), _p(out), _p(workspace), _i(b),
+                                     _i(len_q), _i(h), _i(num_kv_heads), _i(d), _f(scale), _i(max_len_buf),
+                                     C.c_int(int(bshd)), C.c_int(_dt(batch_q)), _stream()), "decode_attn_quant")
+    return out
+
+
 def prefill_attention(q, k_buf, v_buf, pos0, num_kv_heads, scale, bshd=True, out=None):
     """Causal attention of one task's prompt chunk (attn_encode_group -> flash attention in the reference,
     src/nn/attention/attention.cpp:442-622).  q (s_q, H, D); k_buf / v_buf the task's buffers (len_buf, Hkv, D)
