@@ -214,7 +214,8 @@ def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=Fal
     got = _np(y).astype(np.float64)
     # m > 16 without a fused norm runs the M-tiled kernel: it multiplies with W16 = rn16(rn16(q - z) * s), the
     # matrix the reference's M > 40 branch dequantises (dequant_k_major), so THAT product is its exact value
-    tiled = force_tiled or (m > 16 and not norm)
+    # (17..32 rows with K <= 8192 stay on the streaming arithmetic: the phase-pipelined kernel, w4_phase.hip)
+    tiled = force_tiled or (m > 16 and not norm and not (m <= 32 and k <= 8192))
     w16 = oracle.gptq_dequant_k_major(*km)
     ref40 = oracle.gemm_nt(xin, w16, None if b is None else oracle.h2u(b), exact=True)
     lin = np.zeros_like(exact)
@@ -263,6 +264,39 @@ def test_tiled_gemm_shapes(oracle, dev, m, k, n):
     _check_mfma(oracle, dev, k, n, m, seed=52 + m, residual=True, force_tiled=True)
     _check_mfma(oracle, dev, k, n, m, seed=53 + m, bias=True)
     _check_mfma(oracle, dev, k, n, m, seed=54 + m, residual=True)
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("m", [5, 16, 17, 32])
+def test_phase_gemm_rounds(oracle, dev, m, rounds, monkeypatch):
+    """The phase-pipelined streaming kernel (w4_phase.hip), every tiles-per-workgroup instantiation x both row-block
+    counts: ragged N (tile overrun of the last workgroup), K with a partial last phase, K shorter than one ring,
+    bias / residual epilogues."""
+    monkeypatch.setenv("ZL_W4_PHASE_ROUNDS", str(rounds))
+    _check_mfma(oracle, dev, 1152, 16 * (3 * rounds - 1) + 8, m, seed=70 + m + rounds)                 # 2 phases, partial
+    _check_mfma(oracle, dev, 4096, 16 * 2 * rounds, m, seed=71 + m + rounds, bias=True)                # 4 phases
+    _check_mfma(oracle, dev, 9 * 1024 + 256, 16 * rounds + 16, m, seed=72 + m + rounds, residual=True)  # 10 phases, beyond any BODY
+
+
+@pytest.mark.parametrize("m", [8, 24])
+def test_phase_gemm_silu_mul(oracle, dev, m):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(62)
+    k, nff, g = 2048, 200, 128
+    qw1, qz1, sc1 = synth.gptq_hf(rng, k, nff, g)
+    qw2, qz2, sc2 = synth.gptq_hf(rng, k, nff, g)
+    km1, km2 = oracle.gptq_prepare_k_major(qw1, qz1, sc1, g), oracle.gptq_prepare_k_major(qw2, qz2, sc2, g)
+    cat = [np.concatenate([a, b], axis=0) for a, b in zip(km1, km2)]
+    w = ops.W4MWeight.from_k_major(_t(cat[0].view(np.int32), dev), _t(cat[1], dev), _t(cat[2], dev, torch.float16), g,
+                                   row_interleave=True)
+    x = synth.act(rng, m, k)
+    ge = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), *km1).astype(np.float16)
+    ue = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), *km2).astype(np.float16)
+    ref = oracle.u2h(oracle.silu_mul(oracle.h2u(ge), oracle.h2u(ue))).astype(np.float64)
+    got = _np(ops.w4a16_gemm_mfma(_t(x, dev), w, epilogue=ops.EPI_SILU_MUL)).astype(np.float64)
+    assert got.shape == (m, nff)
+    # a gate / up value on a rounding tie may flip by one fp16 ulp (fp32 accumulation noise): 2^-9 of max|out|
+    assert np.abs(got - ref).max() <= 2.0 ** -9 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("m", [70, 300])

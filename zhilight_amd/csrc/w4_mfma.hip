@@ -552,6 +552,11 @@ inline int grid_for(int64_t n) {
 
 }  // namespace
 
+// w4_phase.hip: the phase-pipelined streaming kernel for 5..32 rows
+int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                        uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
+                        int k, int groups, int tiles, int epilogue, int ld_out, int rounds_override, hipStream_t hs);
+
 extern "C" {
 
 #ifdef ZL_W4M_PROBE
@@ -602,6 +607,20 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const
     // more than one 16-row pass: the M-tiled kernel (w4_gemm_tiled.hip; no fused norm prologue) reads the
     // weights once per 32-128 rows; with few rows it splits K over workgroups to fill the chip
     // (M = 32: 82 vs 113 us per Llama-3-8B layer for two passes of this kernel; M = 64: 109 vs 224)
+    // 5..32 rows without a fused norm: the phase-pipelined streaming kernel (w4_phase.hip).  With more than 16
+    // rows every workgroup pulls M x K activations through L2, so a long K (the down projection) stays on
+    // the M-tiled kernel, whose 128-column workgroups share them.
+    {
+        auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        static const int ph_min_m = env_int("ZL_W4_PHASE_MIN_M", 5), ph_max_m = env_int("ZL_W4_PHASE_MAX_M", 32);
+        static const int ph_maxk_16 = env_int("ZL_W4_PHASE_MAXK16", 1 << 30), ph_maxk_32 = env_int("ZL_W4_PHASE_MAXK32", 8192);
+        const int ph_rounds = env_int("ZL_W4_PHASE_ROUNDS", 0);   // read per call: the tests sweep it
+        if (!norm_weight && m >= ph_min_m && m <= ph_max_m && m <= 32 && k <= (m <= 16 ? ph_maxk_16 : ph_maxk_32) &&
+            L.qw_bytes < ((int64_t)1 << 32))
+            return zl_w4a16_gemm_phase(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y,
+                                       (int)m, (int)n, (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n),
+                                       ph_rounds, hs);
+    }
     static const int tiled_min_m = [] { const char* e = getenv("ZL_W4_TILED_MIN_M"); return e ? atoi(e) : 17; }();
     if (m >= tiled_min_m && !norm_weight && k % 128 == 0)
         return zl_w4a16_gemm_tiled(x, ldx, qw, meta, bias, residual, y, m, n, k, group_size, epilogue, s);

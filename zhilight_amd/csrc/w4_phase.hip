@@ -1,0 +1,350 @@
+// w4_phase.hip -- W4A16 GEMM for decode batches of 5..32 rows: the streaming kernel of w4_mfma.hip with the
+// activations fed through LDS in K phases instead of being staged whole.
+//
+// Same arithmetic as k_w4a16_mfma (fp32 group sums on the matrix cores, one fp32 fma per group with the
+// scale; see the header of w4_mfma.hip for the reference branch it corresponds to), same ZLW4M weight
+// layout, same epilogues.  What changes is how x reaches the MFMA:
+//   * k_w4a16_mfma stages all M x K activations in LDS before the first weight is used.  Up to 4 rows that
+//     hides behind the first HBM round trip; 8-16 rows cost 1.4-3 us of exposed staging per launch, a K of
+//     14336 does not fit at all (its fallback reads fragments from L2 per item: 14-18 us), and 32 rows never
+//     fit (two passes, or the M-tiled kernel + split-K epilogue: 84 us per Llama-3-8B layer at M = 32).
+//   * here K is cut into phases of 1024 k.  A workgroup (8 waves, one per CU) owns R row tiles; in a phase
+//     wave w takes the w-th 128-k item of every tile, so the eight waves finish a phase together and ONE
+//     LDS buffer pair (2 x 16 MB rows x 1024 k) serves any K.  Accumulators of all R tiles stay in
+//     registers across the phases (R x MB x 4 VGPRs), the weight ring runs across phase boundaries.
+//   * vmcnt retires in order, so an x load must be OLDER than every weight load that is still in flight
+//     when the x data is needed, or waiting for it drains the ring: the loads of phase p are issued XP
+//     phases ahead (XP * R >= D - 1, D = ring depth) and ride in registers until the end of phase p - 1,
+//     when they are stored to the idle LDS buffer; one barrier per phase.
+// MB = 1: M <= 16, MB = 2: M <= 32 (two accumulator sets share every dequantised weight fragment).
+#include <stdlib.h>
+#include "zl_common.h"
+
+namespace {
+
+constexpr int kT = 512, kW = 8;
+constexpr int kPK = 1024;            // k per phase = kW items of 128
+constexpr int kXS = kPK + 8;         // LDS x row, halfs (padded: conflict-free b128 fragment reads)
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
+
+struct PhaseParams {
+    const uint16_t* x;
+    int64_t ldx;
+    const uint4* qw;
+    const uint32_t* meta;
+    uint32_t qw_bytes, meta_bytes;
+    const uint16_t* bias;
+    const uint16_t* residual;
+    uint16_t* y;
+    int m, n, k;
+    int groups;        // 128-k items per row tile
+    int tiles;         // 16-row tiles
+    int phases;        // ceil(groups / 8)
+    int epi, ld_out;
+};
+
+constexpr int ring_depth(int r) { return r == 1 ? 3 : r == 2 ? 4 : r == 3 ? 6 : r == 4 ? 8 : r; }
+constexpr int x_ahead(int r) { return r <= 4 ? 2 : 1; }
+constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
+constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
+
+__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_s, uint32_t magic_v) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mask_s), "v"(magic_v));
+    return r;
+}
+
+__device__ __forceinline__ h8 dequant_word(uint32_t w, hv2 z1, hv2 z16, uint32_t mask_lo, uint32_t mask_hi, uint32_t magic) {
+    const hv2 one16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    const hv2 d0 = __builtin_bit_cast(hv2, and_or(w, mask_lo, magic)) + z1;
+    const hv2 d1 = __builtin_elementwise_fma(__builtin_bit_cast(hv2, and_or(w, mask_hi, magic)), one16, z16);
+    const uint32_t wb = w >> 8;
+    const hv2 d2 = __builtin_bit_cast(hv2, and_or(wb, mask_lo, magic)) + z1;
+    const hv2 d3 = __builtin_elementwise_fma(__builtin_bit_cast(hv2, and_or(wb, mask_hi, magic)), one16, z16);
+    h8 a;
+    a[0] = d0.x; a[1] = d0.y; a[2] = d1.x; a[3] = d1.y; a[4] = d2.x; a[5] = d2.y; a[6] = d3.x; a[7] = d3.y;
+    return a;
+}
+
+struct Guard { static constexpr bool value = true; };
+struct NoGuard { static constexpr bool value = false; };
+
+__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
+
+template <int R, int MB>
+__global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
+    constexpr int D = ring_depth(R), XP = x_ahead(R), BODY = lcm_(D, R * XP);
+    constexpr int XC = 4 * MB;                       // 16-byte x chunks per thread per phase (16 MB rows x 128 chunks)
+    constexpr int kBuf = MB * 16 * kXS;              // halfs per LDS phase buffer
+    static_assert(BODY % R == 0 && (BODY / R) % XP == 0 && BODY % D == 0, "static ring / accumulator / x-set indices");
+    static_assert(XP * R >= D - 2, "x loads must be older than the weights in flight when they are consumed");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrow = lane & 15, kq = lane >> 4;
+    const int P = p.phases, total = P * R;
+    const int tile0 = blockIdx.x * R;
+
+    // ---- activations: chunk c of a thread = row (tid >> 7) + 4 c, halfs 8 (tid & 127) .. +7 of the phase
+    const int xrow0 = threadIdx.x >> 7, xcc = (threadIdx.x & 127) * 8;
+    uint4 xr[XP][XC];
+    auto load_x = [&](int set, int ph) {             // set: static
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+            const int row = xrow0 + 4 * c, kk = ph * kPK + xcc;
+            const bool live = row < p.m && kk < p.k && ph < P;
+            const uint16_t* src = p.x + (live ? (size_t)row * p.ldx + kk : 0);
+            xr[set][c] = *reinterpret_cast<const uint4*>(src);
+            if (!live) xr[set][c] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_x = [&](int set, int ph) {            // into buffer ph & 1
+        uint16_t* dst = xs + (ph & 1) * kBuf + xcc;
+#pragma unroll
+        for (int c = 0; c < XC; ++c) *reinterpret_cast<uint4*>(dst + (xrow0 + 4 * c) * kXS) = xr[set][c];
+    };
+#pragma unroll
+    for (int q = 0; q < XP; ++q) load_x(q, q);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- weight ring.  Item sequence of wave w: for phase: for r < R: (tile0 + r, 8 phase + w); the byte
+    //      offset lives in SGPRs (buffer soffset), advanced by one of two strides; out-of-range tiles read
+    //      zeros (buffer bounds), items past K meet zero activations.
+    uint4 wq[D];
+    uint32_t mt[D];
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
+    const uint32_t it0 = (uint32_t)tile0 * (uint32_t)p.groups + (uint32_t)wave;
+    uint32_t qs = it0 * 1024u, ms = it0 * 64u;
+    const int tile_step = p.groups, phase_step = kW - (R - 1) * p.groups;
+    const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)nrow * 4u;
+    int iss_left = total - 1;
+    auto issue = [&](int slot, int r_of_item) {      // both static
+        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off, qs, 2 /* nt */));
+        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(rm, m_off, ms, 2);
+        const int adv = iss_left > 0 ? 1 : 0;        // exhausted: keep re-reading the last item (an L2 hit)
+        --iss_left;
+        const int d = adv * (r_of_item == R - 1 ? phase_step : tile_step);
+        qs += (uint32_t)d * 1024u;
+        ms += (uint32_t)d * 64u;
+    };
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) {
+        issue(s, s % R);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mt[D - 1] = 0;                                   // the neutral "previous item" of the first step
+    wq[D - 1] = make_uint4(0, 0, 0, 0);
+
+    store_x(0, 0);
+    __syncthreads();
+
+    const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
+    const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(0x00f000f0u);
+    uint32_t magic = 0x64006400u;
+    asm volatile("" : "+v"(magic));
+    // A fragment (activations): row m = 16 mb + (lane & 15), k = 128 wave + 32 t + 8 kq .. +7 of the phase
+    const uint16_t* xl = xs + nrow * kXS + wave * 128 + 8 * kq;
+
+    f4 acc[R][MB], accg_prev[MB];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[r][b] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b) accg_prev[b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    auto finish_prev = [&](int rp, int pslot) {      // acc[rp] += scale * group sum of the previous item
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            asm("v_fma_mix_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n\t"
+                "v_fma_mix_f32 %1, %5, %8, %1 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n\t"
+                "v_fma_mix_f32 %2, %6, %8, %2 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n\t"
+                "v_fma_mix_f32 %3, %7, %8, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]"
+                : "+v"(acc[rp][b][0]), "+v"(acc[rp][b][1]), "+v"(acc[rp][b][2]), "+v"(acc[rp][b][3])
+                : "v"(accg_prev[b][0]), "v"(accg_prev[b][1]), "v"(accg_prev[b][2]), "v"(accg_prev[b][3]), "v"(mt[pslot]));
+        }
+    };
+    // one ring step (same order as k_w4a16_mfma: dequantise, scale-accumulate the previous item, MFMAs back to back)
+    auto step = [&](int slot, int pslot, int rp, int r_issue, int ph) {
+        const uint16_t* xb = xl + (ph & 1) * kBuf;
+        uint4 bv[MB][4];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[b][t] = *reinterpret_cast<const uint4*>(xb + b * 16 * kXS + 32 * t);
+        }
+        const hv2 z1 = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(mt[slot], mt[slot], 0x03020302u));
+        const hv2 c960 = {(_Float16)960.f, (_Float16)960.f};
+        const hv2 z16 = z1 + c960;
+        const uint32_t wds[4] = {wq[slot].x, wq[slot].y, wq[slot].z, wq[slot].w};
+        h8 a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = dequant_word(wds[t], z1, z16, mask_lo, mask_hi, magic);
+        finish_prev(rp, pslot);
+        __builtin_amdgcn_sched_barrier(0);
+        f4 accg[MB];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) accg[b] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+                accg[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, bv[b][t]), a[t], accg[b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) accg_prev[b] = accg[b];
+        issue(pslot, r_issue);
+    };
+    // BODY steps starting at a phase boundary (k, ph); GUARD: the stream may end inside (wave-uniform tests)
+    auto body = [&](int k, int ph, auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+#pragma unroll
+        for (int s = 0; s < BODY; ++s) {
+            if (GUARD && k + s >= total) break;
+            const int r = s % R, j = s / R;          // static
+            const int php = ph + j;
+            if (r == 0) load_x(j % XP, php + XP);     // set (phase % XP): free since the end of phase php - 1
+            step(s % D, (s + D - 1) % D, (s + R - 1) % R, (s + D - 1) % R, php);
+            if (r == R - 1) {
+                if (php + 1 < P) {                    // workgroup-uniform
+                    store_x((j + 1) % XP, php + 1);
+                    __syncthreads();
+                }
+            }
+        }
+    };
+    if (total >= BODY) {
+        int k = 0, ph = 0;
+#pragma unroll 1
+        do {
+            body(k, ph, NoGuard{});
+            k += BODY;
+            ph += BODY / R;
+        } while (k + BODY <= total);
+        body(k, ph, Guard{});
+    } else {
+        body(0, 0, Guard{});
+    }
+    {   // the last item's scale-accumulate (static register indices only)
+        const int last = (total - 1) % BODY;
+#pragma unroll
+        for (int s = 0; s < BODY; ++s) {
+            if (last == s) finish_prev(s % R, s % D);
+        }
+    }
+    __syncthreads();                                  // every wave is done with the x buffers: reuse them
+
+    // ---- park the partial C fragments, reduce over the 8 waves in fixed order, epilogue
+    f4* red = reinterpret_cast<f4*>(smem);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) red[((r * MB + b) * kW + wave) * 64 + lane] = acc[r][b];
+    }
+    __syncthreads();
+    const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
+    const float* redf = reinterpret_cast<const float*>(red);
+    const int per_tile = (silu ? 8 : 16) * p.m;
+    const int nouts = R * per_tile;
+    for (int o = threadIdx.x; o < nouts; o += kT) {
+        const int r = o / per_tile, rem = o % per_tile;
+        const int tile = tile0 + r;
+        if (tile >= p.tiles) continue;
+        auto total_of = [&](int n_local, int m) {
+            const int b = m >> 4, ln = ((m & 15) >> 2) * 16 + n_local, i = m & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) v += redf[(((size_t)(r * MB + b) * kW + w) * 64 + ln) * 4 + i];
+            return v;
+        };
+        if (!silu) {
+            const int m = rem >> 4, n_local = rem & 15;
+            const int row = tile * 16 + n_local;
+            if (row < p.n) {
+                const float v = total_of(n_local, m);
+                const size_t orow = (size_t)m * p.ld_out;
+                const float bb = ((p.epi & ZL_EPI_BIAS) && p.bias) ? (float)__builtin_bit_cast(_Float16, p.bias[row]) : 0.f;
+                float ov;
+                if (p.epi & ZL_EPI_ADD_C) ov = ((float)__builtin_bit_cast(_Float16, p.y[orow + row]) + v) + bb;
+                else ov = v + bb;
+                _Float16 y16 = zl_f32_to_f16(ov);
+                if (p.epi & ZL_EPI_RESIDUAL)
+                    y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, p.residual[orow + row]) + (float)y16);
+                p.y[orow + row] = __builtin_bit_cast(uint16_t, y16);
+            }
+        } else {
+            const int m = rem >> 3, j = rem & 7;
+            const int pr = tile * 8 + j;
+            if (2 * pr + 1 < p.n) {
+                float g = total_of(2 * j, m), u = total_of(2 * j + 1, m);
+                if ((p.epi & ZL_EPI_BIAS) && p.bias) {
+                    g += (float)__builtin_bit_cast(_Float16, p.bias[2 * pr]);
+                    u += (float)__builtin_bit_cast(_Float16, p.bias[2 * pr + 1]);
+                }
+                float ov;
+                if (p.epi & ZL_EPI_SILU_MUL) {
+                    g = (float)zl_f32_to_f16(g);
+                    u = (float)zl_f32_to_f16(u);
+                    ov = silu_f32(g) * u;
+                } else {
+                    ov = (float)((double)g / (1.0 + (double)expf(-g))) * u;
+                }
+                p.y[(size_t)m * p.ld_out + pr] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(ov));
+            }
+        }
+    }
+}
+
+template <int R, int MB>
+int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
+    constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS * 2;
+    constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
+    constexpr size_t lds = x_bytes > red_bytes ? x_bytes : red_bytes;
+    static_assert(lds <= 160 * 1024, "LDS");
+    if (lds > 64 * 1024) {
+        static bool done = false;   // per instantiation
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return ZL_ELIMIT;
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB>), dim3(grid), dim3(kT), lds, hs, p);
+    return zl_launch_status();
+}
+
+}  // namespace
+
+// internal (called by zl_w4a16_gemm_mfma): 1 <= m <= 32, no fused norm.  rounds_override: 0 = pick
+int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                        uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
+                        int k, int groups, int tiles, int epilogue, int ld_out, int rounds_override, hipStream_t hs) {
+    PhaseParams p;
+    p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
+    p.meta_bytes = meta_bytes; p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k;
+    p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = epilogue; p.ld_out = ld_out;
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    // tiles per workgroup: one generation of workgroups when 8 tiles per CU suffice, else full-size workgroups
+    int r = (tiles + cus - 1) / cus;
+    if (r > 8) r = 8;
+    if (rounds_override > 0 && rounds_override <= 8) r = rounds_override;
+    const int grid = (tiles + r - 1) / r;
+    const int mb = m <= 16 ? 1 : 2;
+#define ZL_PH(RR)                                                                  \
+    case RR: return mb == 1 ? launch_phase<RR, 1>(p, grid, hs) : launch_phase<RR, 2>(p, grid, hs);
+    switch (r) {
+        ZL_PH(1) ZL_PH(2) ZL_PH(3) ZL_PH(4) ZL_PH(5) ZL_PH(6) ZL_PH(7) ZL_PH(8)
+    }
+#undef ZL_PH
+    return ZL_EINVAL;
+}
