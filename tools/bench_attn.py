@@ -21,15 +21,22 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--bhsd", action="store_true", help="KV buffers (Hkv, len_buf, D) instead of (len_buf, Hkv, D)")
+    ap.add_argument("--alias", action="store_true", help="experiment: every task and layer reads the SAME KV buffer (cache-resident): the kernel's compute/latency floor")
+    ap.add_argument("--unfused", action="store_true", help="rope+scatter launch, then zl_decode_attn (the matrix-core kernel when it applies)")
     ap.add_argument("--q8", action="store_true", help="INT8 KV cache: rope+quantise+scatter launch, then attention over codes")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     h, hkv, d = 32, 8, 128
     len_buf = (a.seq + 64 + 63) // 64 * 64
     shape = (a.layers, 2, hkv, len_buf, d) if a.bhsd else (a.layers, 2, len_buf, hkv, d)
-    kv = [torch.randn(shape, dtype=torch.float16, device=dev) for _ in range(a.batch)]
+    kv = [torch.randn(shape, dtype=torch.float16, device=dev) for _ in range(1 if a.alias else a.batch)]
+    if a.alias:
+        kv = [kv[0]] * a.batch
     k_addrs = torch.tensor([[t[l, 0].data_ptr() for t in kv] for l in range(a.layers)], dtype=torch.int64, device=dev)
     v_addrs = torch.tensor([[t[l, 1].data_ptr() for t in kv] for l in range(a.layers)], dtype=torch.int64, device=dev)
+    if a.alias:
+        k_addrs[:] = k_addrs[0, 0]
+        v_addrs[:] = v_addrs[0, 0]
     i32 = dict(dtype=torch.int32, device=dev)
     pos = torch.full((a.batch,), a.seq, **i32)
     buf_lens = torch.full((a.batch,), len_buf, **i32)
@@ -48,7 +55,16 @@ def main():
         vs_addrs = torch.tensor([[t[l, 1].data_ptr() for t in sc] for l in range(a.layers)], dtype=torch.int64, device=dev)
         qb = torch.empty(a.batch, h * d, dtype=torch.float16, device=dev)
 
+    qb2 = torch.empty(a.batch, h * d, dtype=torch.float16, device=dev)
+
     def run():
+        if a.unfused:
+            for l in range(a.layers):
+                ops.rope_scatter_decode(cos, sin, qkv, pos, buf_lens, k_addrs[l], v_addrs[l], h, hkv, d, bshd=not a.bhsd, q_out=qb2)
+                ops.multi_query_attention_rag_buffer(qb2.view(a.batch, 1, h, d), buf_lens, k_addrs[l], v_addrs[l], None,
+                                                     1.0 / math.sqrt(d), len_buf, hkv, valid_lens=valid, bshd=not a.bhsd,
+                                                     out=out.view(a.batch, 1, h, d), workspace=ws)
+            return
         if a.q8:
             for l in range(a.layers):
                 ops.rope_quant_scatter_decode(cos, sin, qkv, pos, buf_lens, k_addrs[l], v_addrs[l], ks_addrs[l], vs_addrs[l],

@@ -19,6 +19,7 @@
 //    fp32 registers per lane-group and is merged group->wave->workgroup at the end.
 //  * partial (acc[D], m, l) per split goes to a small fp32 workspace; a second tiny kernel merges
 //    the splits:  out = sum_s acc_s e^{m_s-M} / (sum_s l_s e^{m_s-M} + 1e-20).
+#include <stdlib.h>
 #include "zl_common.h"
 
 namespace {
@@ -55,6 +56,8 @@ typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
 
 // split length: multiple of 128 keys, grown so that about >= 1024 workgroups exist when possible
 static inline int attn_split_len(int64_t b, int64_t hkv, int64_t max_len) {
+    static const int forced = [] { const char* e = getenv("ZL_ATTN_SPLIT"); return e ? atoi(e) : 0; }();   // experiments
+    if (forced >= 128 && forced % 128 == 0) return forced;
     int64_t want = (max_len * b * hkv) / 1024;
     int64_t ls = (want / 128) * 128;
     if (ls < 128) ls = 128;
@@ -603,6 +606,200 @@ __global__ __launch_bounds__(256) void k_decode_attn_partial_q8(const AttnParams
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Matrix-core decode attention (fp16, D = 128, prefix visibility, len_q * n_rep <= 16 query rows per kv head).
+// The VALU kernel above is instruction-issue bound once the batch fills the chip (batch 32, seq 1024: 35 us
+// with the KV cache-resident vs 49 us from HBM; ~660 VALU instructions per 32-key chunk and wave).  Here a
+// 32-key chunk costs 16 MFMAs + ~90 VALU:
+//   S^T = K . Q^T      K rows are the A operand straight from global memory (lane = key, 8 d per k-chunk),
+//                      Q^T the B operand (rows beyond len_q * n_rep are zero); C: lane = (query m = lane & 15,
+//                      keys 4 kq + i of each 16-key block) -- a lane's scores all belong to ONE query row.
+//   softmax            per lane + two cross-lane steps for the row maximum; probabilities rounded to fp16
+//                      (flash-attention arithmetic, like prefill_attn.hip), the normaliser sums what the
+//                      product uses.
+//   O^T = V^T . P^T    P^T (this lane's own eight probabilities) IS the B operand; V^T comes from a wave-private
+//                      row-major LDS copy of the V chunk through ds_read_b64_tr_b16 (a 16-lane group reads a
+//                      4-key x 16-d block, lane i receives column i: tools/ubench/tr_probe.hip).  C: lane =
+//                      (query m, d = 16 db + 4 kq + i): rescaling by e^{m_old - m_new} is lane-local.
+// Waves are independent inside the loop (no barrier); splits, workspace format and the combine kernel are
+// those of the VALU kernel.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+constexpr int kMD = 128;
+constexpr int kMVS = kMD + 16;      // LDS V row stride (halfs): 288 B, conflict-free transpose reads
+
+__global__ __launch_bounds__(256) void k_decode_attn_mfma(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t vs[4][32 * kMVS];      // 36 KB; reused for the wave merge
+    const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
+    const int len = p.buf_lens[b];
+    const int vlen_in = p.valid_lens[b];
+    const uint16_t* kbase = p.k_bufs[b];
+    const uint16_t* vbase = p.v_bufs[b];
+    const int elen = min(len, vlen_in);
+    const int t0 = split * p.split_len;
+    if (t0 >= elen || len <= 0) return;
+    const int t1 = min(elen, t0 + p.split_len);
+    const int last_key = t1 - 1;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const size_t kv_stride = p.bshd ? (size_t)p.hkv * kMD : (size_t)kMD;
+    const size_t kv_off = p.bshd ? (size_t)hk * kMD : (size_t)hk * len * kMD;
+
+    uint4 kk[2][4], vv0, vv1, vv2, vv3, vv4, vv5, vv6, vv7;
+    int c0 = t0 + wave * 32;
+    // clamped, branch-free: past the end of the split the loads re-read its last row (cache hits)
+#define ZL_MFMA_LOAD_K(base)                                                                                   \
+    _Pragma("unroll") for (int blk_ = 0; blk_ < 2; ++blk_) {                                                   \
+        const int key_ = (base) + 16 * blk_ + r;                                                               \
+        const uint16_t* src_ = kbase + kv_off + (size_t)(key_ < last_key ? key_ : last_key) * kv_stride + 8 * kq; \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) kk[blk_][t_] = *reinterpret_cast<const uint4*>(src_ + 32 * t_); \
+    }
+    // (vv as eight named registers: as an indexed array the compiler left it on the stack)
+#define ZL_MFMA_V1(j_, base)                                                                                   \
+    {                                                                                                          \
+        const int key_ = (base) + 4 * j_ + (lane >> 4);                                                        \
+        vv##j_ = *reinterpret_cast<const uint4*>(vbase + kv_off + (size_t)(key_ < last_key ? key_ : last_key) * kv_stride + (lane & 15) * 8); \
+    }
+#define ZL_MFMA_LOAD_V(base)                                                                                   \
+    ZL_MFMA_V1(0, base) ZL_MFMA_V1(1, base) ZL_MFMA_V1(2, base) ZL_MFMA_V1(3, base) ZL_MFMA_V1(4, base)        \
+    ZL_MFMA_V1(5, base) ZL_MFMA_V1(6, base) ZL_MFMA_V1(7, base)
+    ZL_MFMA_LOAD_K(c0)
+    ZL_MFMA_LOAD_V(c0)
+
+    // Q^T fragments: query row m = r -> (qi, head)
+    h8v qf[4];
+    {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        const bool live = r < p.rows;
+        const int rr = live ? r : 0;
+        const int qi = rr / p.n_rep, head = hk * p.n_rep + rr % p.n_rep;
+        const uint16_t* qp = p.q + (((size_t)b * p.len_q + qi) * p.h + head) * kMD + 8 * kq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint4 v = *reinterpret_cast<const uint4*>(qp + 32 * t);
+            qf[t] = __builtin_bit_cast(h8v, live ? v : z);
+        }
+    }
+
+    f4v o[8];
+#pragma unroll
+    for (int db = 0; db < 8; ++db) o[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e20f, l_run = 0.f;
+    uint16_t* vsw = vs[wave];
+    const uint16_t* vtr = vsw + (4 * kq + (r >> 2)) * kMVS + 4 * (r & 3);   // transpose-read address of this lane
+
+    if (c0 >= t1) c0 = -1;                             // a wave without keys: skip the loop, keep the merge
+    while (c0 >= 0) {
+        // ---- S^T = K . Q^T
+        f4v st[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            st[blk] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                st[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, kk[blk][t]), qf[t], st[blk], 0, 0, 0);
+        }
+        // ---- the V chunk to LDS (row-major), then the NEXT chunk's loads: they fly during softmax and P.V
+        {
+            uint16_t* vdst = vsw + (lane >> 4) * kMVS + (lane & 15) * 8;
+#define ZL_MFMA_VST(j_) *reinterpret_cast<uint4*>(vdst + 4 * j_ * kMVS) = vv##j_;
+            ZL_MFMA_VST(0) ZL_MFMA_VST(1) ZL_MFMA_VST(2) ZL_MFMA_VST(3) ZL_MFMA_VST(4) ZL_MFMA_VST(5) ZL_MFMA_VST(6) ZL_MFMA_VST(7)
+#undef ZL_MFMA_VST
+        }
+        const int cur = c0;
+        c0 += 4 * 32;
+        ZL_MFMA_LOAD_K(c0)
+        ZL_MFMA_LOAD_V(c0)
+        // ---- online softmax of query row r over this lane's 8 keys (+ the 3 other lanes of the row)
+        float sv[2][4];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = cur + 16 * blk + 4 * kq + i;
+                sv[blk][i] = key < t1 ? st[blk][i] * p.scale : -INFINITY;
+                mloc = fmaxf(mloc, sv[blk][i]);
+            }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        h8v pf;
+        float lsum = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const _Float16 ph = (_Float16)__expf(sv[blk][i] - m_new);
+                lsum += (float)ph;
+                pf[blk * 4 + i] = ph;
+            }
+        }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+        }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(vtr + 16 * db));
+            const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(vtr + 16 * kMVS + 16 * db));
+            typedef short s8v __attribute__((ext_vector_type(8)));
+            const s8v a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), pf, o[db], 0, 0, 0);
+        }
+        if (c0 >= t1) break;
+    }
+#undef ZL_MFMA_LOAD_K
+#undef ZL_MFMA_LOAD_V
+#undef ZL_MFMA_V1
+
+    // ---- merge: the row's normaliser lives in 4 lanes; then the 4 waves through LDS (aliases the V staging)
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();
+    float* xw = reinterpret_cast<float*>(&vs[0][0]);       // [wave][16 rows][D + 2]
+    if (r < p.rows) {
+        float* dst = xw + ((size_t)wave * 16 + r) * (kMD + 2);
+#pragma unroll
+        for (int db = 0; db < 8; ++db) *reinterpret_cast<f4v*>(dst + 16 * db + 4 * kq) = o[db];
+        if (kq == 0) {
+            dst[kMD] = m_run;
+            dst[kMD + 1] = l_run;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < p.rows * kMD; idx += 256) {
+        const int i = idx / kMD, d = idx % kMD;
+        const float* src = xw + (size_t)i * (kMD + 2);
+        constexpr int WS = 16 * (kMD + 2);
+        float mn = src[kMD];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, src[w * WS + kMD]);
+        float a = 0.f, lt = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __expf(src[w * WS + kMD] - mn);
+            a = __builtin_fmaf(src[w * WS + d], f, a);
+            lt = __builtin_fmaf(src[w * WS + kMD + 1], f, lt);
+        }
+        const int qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
+        float* dst = p.ws + ((((size_t)b * p.len_q + qi) * p.h + head) * p.max_splits + split) * (kMD + 2);
+        dst[d] = a;
+        if (d == 0) {
+            dst[kMD] = mn;
+            dst[kMD + 1] = lt;
+        }
+    }
+}
+
 // grid (B*len_q*H), block D.  Split statistics go through LDS once; the per-d accumulation then issues
 // independent loads back to back (the first version walked the splits with dependent loads: 6 us).
 template <int DT, int D>
@@ -744,6 +941,17 @@ int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* c
     hipStream_t hs = (hipStream_t)s;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
     p.k_scales = p.v_scales = nullptr;
+    {   // decode fast path on the matrix cores: all query rows of a kv head in one 16-row MFMA block
+        static const int use_mfma = [] { const char* e = getenv("ZL_ATTN_MFMA"); return e ? atoi(e) : 1; }();
+        if (use_mfma && !mask && dtype == ZL_F16 && d == kMD && p.rows <= 16) {
+            p.passes = 1;
+            hipLaunchKernelGGL(k_decode_attn_mfma, dim3((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b), dim3(256), 0, hs, p);
+            int e = zl_launch_status();
+            if (e) return e;
+            hipLaunchKernelGGL((k_decode_attn_combine<ZL_F16, kMD>), dim3((unsigned)(b * len_q * h)), dim3(kMD), 0, hs, p);
+            return zl_launch_status();
+        }
+    }
 #define ZL_ATTN_D(DT, FUSE)                                    \
     switch (d) {                                               \
         case 64: return launch_d<DT, 64, FUSE>(p, hs);         \
