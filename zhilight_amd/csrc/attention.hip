@@ -610,13 +610,13 @@ __global__ __launch_bounds__(256) void k_decode_attn_partial_q8(const AttnParams
 // Matrix-core decode attention (fp16, D = 128, prefix visibility, len_q * n_rep <= 16 query rows per kv head).
 // The VALU kernel above is instruction-issue bound once the batch fills the chip (batch 32, seq 1024: 35 us
 // with the KV cache-resident vs 49 us from HBM; ~660 VALU instructions per 32-key chunk and wave).  Here a
-// 32-key chunk costs 16 MFMAs + ~90 VALU:
+// 32-key chunk costs 24 MFMAs + ~100 VALU:
 //   S^T = K . Q^T      K rows are the A operand straight from global memory (lane = key, 8 d per k-chunk),
 //                      Q^T the B operand (rows beyond len_q * n_rep are zero); C: lane = (query m = lane & 15,
 //                      keys 4 kq + i of each 16-key block) -- a lane's scores all belong to ONE query row.
-//   softmax            per lane + two cross-lane steps for the row maximum; probabilities rounded to fp16
-//                      (flash-attention arithmetic, like prefill_attn.hip), the normaliser sums what the
-//                      product uses.
+//   softmax            per lane + two cross-lane steps for the row maximum; fp32 probabilities enter the product
+//                      as a hi + lo pair of fp16 values (the reference's decode kernel multiplies fp32
+//                      probabilities; a single fp16 rounding of p moved INT8-route logits by 1e-2).
 //   O^T = V^T . P^T    P^T (this lane's own eight probabilities) IS the B operand; V^T comes from a wave-private
 //                      row-major LDS copy of the V chunk through ds_read_b64_tr_b16 (a 16-lane group reads a
 //                      4-key x 16-d block, lane i receives column i: tools/ubench/tr_probe.hip).  C: lane =
@@ -730,15 +730,19 @@ __global__ __launch_bounds__(256) void k_decode_attn_mfma(const AttnParams p) {
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __expf(m_run - m_new);
         m_run = m_new;
-        h8v pf;
+        // probabilities as hi + lo fp16 parts (two MFMAs per V fragment): the product sees p to ~2^-22, i.e. the fp32
+        // probabilities of the reference's decode kernel, not flash-attention's fp16 ones
+        h8v pf, pl;
         float lsum = 0.f;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const _Float16 ph = (_Float16)__expf(sv[blk][i] - m_new);
-                lsum += (float)ph;
+                const float pr = __expf(sv[blk][i] - m_new);
+                const _Float16 ph = (_Float16)pr;
+                lsum += pr;
                 pf[blk * 4 + i] = ph;
+                pl[blk * 4 + i] = (_Float16)(pr - (float)ph);
             }
         }
         l_run = l_run * alpha + lsum;
@@ -754,6 +758,7 @@ __global__ __launch_bounds__(256) void k_decode_attn_mfma(const AttnParams p) {
             typedef short s8v __attribute__((ext_vector_type(8)));
             const s8v a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), pf, o[db], 0, 0, 0);
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), pl, o[db], 0, 0, 0);
         }
         if (c0 >= t1) break;
     }

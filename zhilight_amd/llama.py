@@ -703,6 +703,8 @@ class LLaMA:
         hidden = ops.embedding(ctx.tokens, self.token_embedding, c.scale_emb)      # token_embedding
         cos, sin = ops.rope_cos_sin(ctx.positions, c.dim_head, c.rope_theta, True, llama3)  # RopePreparer
         scale = 1.0 / math.sqrt(c.dim_head)
+        mfma_attn = (c.dim_head == 128 and c.torch_dtype == torch.float16 and c.num_heads // c.num_kv_heads <= 16
+                     and os.environ.get("ZL_ATTN_MFMA", "1") != "0")
         for li, layer in enumerate(self.layers):
             layer.project_qkv(hidden, c.eps, out=bufs["qkv"])
             if ctx.kv_quant:
@@ -714,6 +716,15 @@ class LLaMA:
                     bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li], ctx.ks_addrs[li],
                     ctx.vs_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads, valid_lens=ctx.valid_lens,
                     out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head), workspace=workspace)
+            elif mfma_attn:
+                # rope + KV scatter in one small launch, then the matrix-core decode attention (attention.hip:
+                # k_decode_attn_mfma; 11.0 / 18.7 / 39.8 us vs 11.9 / 24.0 / 49.7 us for the fused VALU kernel at batch 1 / 8 / 32)
+                ops.rope_scatter_decode(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li],
+                                        c.num_heads, c.num_kv_heads, c.dim_head, q_out=bufs["q"])
+                ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
+                                                     ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
+                                                     valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
+                                                     workspace=workspace)
             else:
                 ops.decode_attention_fused(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.valid_lens, ctx.k_addrs[li],
                                            ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, scale, ctx.max_len_buf,
