@@ -630,7 +630,7 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 constexpr int kMD = 128;
 constexpr int kMVS = kMD + 16;      // LDS V row stride (halfs): 288 B, conflict-free transpose reads
 
-__global__ __launch_bounds__(256) void k_decode_attn_mfma(const AttnParams p) {
+__global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t vs[4][32 * kMVS];      // 36 KB; reused for the wave merge
     const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
     const int len = p.buf_lens[b];

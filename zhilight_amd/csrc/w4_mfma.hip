@@ -555,7 +555,8 @@ inline int grid_for(int64_t n) {
 // w4_phase.hip: the phase-pipelined streaming kernel for 5..32 rows
 int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                         uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
-                        int k, int groups, int tiles, int epilogue, int ld_out, int rounds_override, hipStream_t hs);
+                        int k, int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps,
+                        int rounds_override, hipStream_t hs);
 
 extern "C" {
 
@@ -615,11 +616,13 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const
         static const int ph_min_m = env_int("ZL_W4_PHASE_MIN_M", 5), ph_max_m = env_int("ZL_W4_PHASE_MAX_M", 32);
         static const int ph_maxk_16 = env_int("ZL_W4_PHASE_MAXK16", 1 << 30), ph_maxk_32 = env_int("ZL_W4_PHASE_MAXK32", 8192);
         const int ph_rounds = env_int("ZL_W4_PHASE_ROUNDS", 0);   // read per call: the tests sweep it
-        if (!norm_weight && m >= ph_min_m && m <= ph_max_m && m <= 32 && k <= (m <= 16 ? ph_maxk_16 : ph_maxk_32) &&
-            L.qw_bytes < ((int64_t)1 << 32))
+        static const int ph_small = env_int("ZL_W4_PHASE_SMALL", 1);   // 1..4 rows with K <= 4096 (incl. the fused norm)
+        const bool rows_5_32 = !norm_weight && m >= ph_min_m && m <= ph_max_m && m <= 32 && k <= (m <= 16 ? ph_maxk_16 : ph_maxk_32);
+        const bool rows_1_4 = ph_small && m <= 4 && m < ph_min_m && k <= 4096;
+        if ((rows_5_32 || rows_1_4) && L.qw_bytes < ((int64_t)1 << 32))
             return zl_w4a16_gemm_phase(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y,
                                        (int)m, (int)n, (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n),
-                                       ph_rounds, hs);
+                                       norm_weight, norm_eps, ph_rounds, hs);
     }
     static const int tiled_min_m = [] { const char* e = getenv("ZL_W4_TILED_MIN_M"); return e ? atoi(e) : 17; }();
     if (m >= tiled_min_m && !norm_weight && k % 128 == 0)

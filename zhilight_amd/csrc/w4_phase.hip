@@ -44,6 +44,8 @@ struct PhaseParams {
     int tiles;         // 16-row tiles
     int phases;        // ceil(groups / 8)
     int epi, ld_out;
+    const uint16_t* norm_w;   // NORM instantiations: fused RMSNorm prologue (M <= 4, K <= 4096)
+    float norm_eps;
 };
 
 constexpr int ring_depth(int r) { return r == 1 ? 3 : r == 2 ? 4 : r == 3 ? 6 : r == 4 ? 8 : r; }
@@ -74,13 +76,18 @@ struct NoGuard { static constexpr bool value = false; };
 
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
 
-template <int R, int MB>
+// NORM (MB = 1, M <= 4, K <= 4096): the whole activation block is register-resident from the start (thread t holds
+// halfs 8 t .. 8 t + 7 of every row, the stand-alone RMSNorm kernel's assignment and summation order, so the
+// normalised values are bit-identical to a separate zl_rmsnorm launch); the thread quarter that holds phase p's
+// slice stores it, normalised, at the end of phase p - 1.
+template <int R, int MB, bool NORM>
 __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
-    constexpr int D = ring_depth(R), XP = x_ahead(R), BODY = lcm_(D, R * XP);
+    constexpr int D = ring_depth(R), XP = NORM ? 1 : x_ahead(R), BODY = lcm_(D, R * XP);
+    static_assert(!NORM || MB == 1, "fused norm: one row block");
     constexpr int XC = 4 * MB;                       // 16-byte x chunks per thread per phase (16 MB rows x 128 chunks)
     constexpr int kBuf = MB * 16 * kXS;              // halfs per LDS phase buffer
     static_assert(BODY % R == 0 && (BODY / R) % XP == 0 && BODY % D == 0, "static ring / accumulator / x-set indices");
-    static_assert(XP * R >= D - 2, "x loads must be older than the weights in flight when they are consumed");
+    static_assert(NORM || XP * R >= D - 2, "x loads must be older than the weights in flight when they are consumed");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* xs = reinterpret_cast<uint16_t*>(smem);
 
@@ -108,8 +115,20 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
 #pragma unroll
         for (int c = 0; c < XC; ++c) *reinterpret_cast<uint4*>(dst + (xrow0 + 4 * c) * kXS) = xr[set][c];
     };
+    uint4 xn4[4], nw4 = make_uint4(0, 0, 0, 0);     // NORM: rows 0..3, this thread's 8 halfs; the norm weight slice
+    if constexpr (NORM) {
+        const int idx = threadIdx.x * 8;
 #pragma unroll
-    for (int q = 0; q < XP; ++q) load_x(q, q);
+        for (int m = 0; m < 4; ++m) {
+            const bool live = m < p.m && idx < p.k;
+            xn4[m] = *reinterpret_cast<const uint4*>(p.x + (live ? (size_t)m * p.ldx + idx : 0));
+            if (!live) xn4[m] = make_uint4(0, 0, 0, 0);
+        }
+        nw4 = *reinterpret_cast<const uint4*>(p.norm_w + (idx < p.k ? idx : 0));
+    } else {
+#pragma unroll
+        for (int q = 0; q < XP; ++q) load_x(q, q);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- weight ring.  Item sequence of wave w: for phase: for r < R: (tile0 + r, 8 phase + w); the byte
@@ -141,7 +160,54 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     mt[D - 1] = 0;                                   // the neutral "previous item" of the first step
     wq[D - 1] = make_uint4(0, 0, 0, 0);
 
-    store_x(0, 0);
+    auto store_norm = [&](int ph) {                  // the quarter of the workgroup that holds phase ph's k range
+        if ((int)(threadIdx.x >> 7) == ph) {
+            uint16_t* dst = xs + (ph & 1) * kBuf + xcc;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m < p.m) *reinterpret_cast<uint4*>(dst + m * kXS) = xn4[m];
+            }
+        }
+    };
+    if constexpr (NORM) {
+        // sum of squares: per-thread chain, 64-lane butterfly, waves in order (zl_block_sum's order)
+        float* scratch = reinterpret_cast<float*>(smem + 2 * (size_t)kBuf * 2);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const uint32_t u[4] = {xn4[m].x, xn4[m].y, xn4[m].z, xn4[m].w};
+            float run = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const hv2 hh = __builtin_bit_cast(hv2, u[e]);
+                run = __builtin_fmaf((float)hh.x, (float)hh.x, run);
+                run = __builtin_fmaf((float)hh.y, (float)hh.y, run);
+            }
+            const float part = zl_wave_sum(run);
+            if (lane == 0) scratch[m * kW + wave] = part;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) tot += scratch[m * kW + w];
+            const float rs = zl_rsqrt_rn(tot / (float)p.k + p.norm_eps);
+            uint32_t u[4] = {xn4[m].x, xn4[m].y, xn4[m].z, xn4[m].w};
+            const uint32_t wu[4] = {nw4.x, nw4.y, nw4.z, nw4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const hv2 hh = __builtin_bit_cast(hv2, u[e]), ww = __builtin_bit_cast(hv2, wu[e]);
+                hv2 o;
+                o.x = zl_f32_to_f16((float)hh.x * rs * (float)ww.x);
+                o.y = zl_f32_to_f16((float)hh.y * rs * (float)ww.y);
+                u[e] = __builtin_bit_cast(uint32_t, o);
+            }
+            xn4[m] = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+        store_norm(0);
+    } else {
+        store_x(0, 0);
+    }
     __syncthreads();
 
     const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
@@ -211,11 +277,12 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
             if (GUARD && k + s >= total) break;
             const int r = s % R, j = s / R;          // static
             const int php = ph + j;
-            if (r == 0) load_x(j % XP, php + XP);     // set (phase % XP): free since the end of phase php - 1
+            if (!NORM && r == 0) load_x(j % XP, php + XP);   // set (phase % XP): free since the end of phase php - 1
             step(s % D, (s + D - 1) % D, (s + R - 1) % R, (s + D - 1) % R, php);
             if (r == R - 1) {
                 if (php + 1 < P) {                    // workgroup-uniform
-                    store_x((j + 1) % XP, php + 1);
+                    if constexpr (NORM) store_norm(php + 1);
+                    else store_x((j + 1) % XP, php + 1);
                     __syncthreads();
                 }
             }
@@ -303,35 +370,38 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     }
 }
 
-template <int R, int MB>
+template <int R, int MB, bool NORM>
 int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
-    constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS * 2;
+    constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS * 2 + (NORM ? 4 * kW * 4 : 0);
     constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
     constexpr size_t lds = x_bytes > red_bytes ? x_bytes : red_bytes;
     static_assert(lds <= 160 * 1024, "LDS");
     if (lds > 64 * 1024) {
         static bool done = false;   // per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return ZL_ELIMIT;
             done = true;
         }
     }
-    hipLaunchKernelGGL((k_w4a16_phase<R, MB>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM>), dim3(grid), dim3(kT), lds, hs, p);
     return zl_launch_status();
 }
 
 }  // namespace
 
-// internal (called by zl_w4a16_gemm_mfma): 1 <= m <= 32, no fused norm.  rounds_override: 0 = pick
+// internal (called by zl_w4a16_gemm_mfma): 1 <= m <= 32; norm_w != null (fused RMSNorm): m <= 4 and k <= 4096.
+// rounds_override: 0 = pick
 int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                         uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
-                        int k, int groups, int tiles, int epilogue, int ld_out, int rounds_override, hipStream_t hs) {
+                        int k, int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps,
+                        int rounds_override, hipStream_t hs) {
+    if (norm_w && (m > 4 || k > 4096)) return ZL_ESHAPE;
     PhaseParams p;
     p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
     p.meta_bytes = meta_bytes; p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k;
-    p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = epilogue; p.ld_out = ld_out;
+    p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = epilogue; p.ld_out = ld_out; p.norm_w = norm_w; p.norm_eps = norm_eps;
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
     // tiles per workgroup: one generation of workgroups when 8 tiles per CU suffice, else full-size workgroups
@@ -340,8 +410,10 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     if (rounds_override > 0 && rounds_override <= 8) r = rounds_override;
     const int grid = (tiles + r - 1) / r;
     const int mb = m <= 16 ? 1 : 2;
-#define ZL_PH(RR)                                                                  \
-    case RR: return mb == 1 ? launch_phase<RR, 1>(p, grid, hs) : launch_phase<RR, 2>(p, grid, hs);
+#define ZL_PH(RR)                                                                                              \
+    case RR:                                                                                                   \
+        if (norm_w) return launch_phase<RR, 1, true>(p, grid, hs);                                             \
+        return mb == 1 ? launch_phase<RR, 1, false>(p, grid, hs) : launch_phase<RR, 2, false>(p, grid, hs);
     switch (r) {
         ZL_PH(1) ZL_PH(2) ZL_PH(3) ZL_PH(4) ZL_PH(5) ZL_PH(6) ZL_PH(7) ZL_PH(8)
     }
