@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_w4.py tests/test_gpu_model.py -x -q -m gpu 2>&1 | tail -3
-for m in 1 2 4; do timeout 100 python tools/bench_gemv.py --mfma --m $m 2>&1 | grep -E "plain|norm|layer"; done
-echo "== old (ZL_W4_PHASE_SMALL=0)"
-ZL_W4_PHASE_SMALL=0 timeout 100 python tools/bench_gemv.py --mfma --m 1 2>&1 | grep -E "plain|norm|layer"
-timeout 300 python bench.py --no-cpu-baseline --no-ttft 2>&1 | tail -1 | cut -c1-200
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests/test_gpu_w4.py -x -q -m gpu 2>&1 | tail -2
+for m in 1 8 16 32; do timeout 100 python tools/bench_gemv.py --mfma --m $m 2>&1 | grep -E "plain|norm|layer"; done
+timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -d gpurun_out/pmc_lds/pass0 -o p --output-format csv -- python tools/prof_one.py 28672 4096 8 6 mfma > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_lds k_w4a16
