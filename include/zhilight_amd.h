@@ -255,6 +255,20 @@ int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* q
                          int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int neox, int bshd, int dtype,
                          zl_stream_t s);
 
+/* Fused qkv projection + rotary + KV scatter for the len_q == 1 rows of a decode batch (the north star's "fused
+ * qkv+rotary"): zl_w4a16_gemm_mfma of the fused (H + 2 Hkv) D x K projection [optionally with the RMSNorm prologue],
+ * then rope_qk_cache (neox, cached cos/sin) on the fp16-rounded outputs and copy_to_rag_buffer2 of the new k / v rows,
+ * all in the GEMV epilogue -- bit-identical to zl_w4a16_gemm_mfma + zl_rope_scatter_decode
+ * (src/nn/attention/attention.cpp:846-900 issues project_q/k/v, rotary_embedding and copy_to_rag_buffer2 separately).
+ * x (M, K) fp16, one row per task; q_out (M, H*D); tables as for zl_rope_scatter_decode.
+ * Covers 1 <= M <= 32, D % 32 == 0, norm_weight only with M <= 4 and K <= 4096, K <= 8192 beyond 16 rows;
+ * ZL_ESHAPE otherwise (use the two-call sequence). */
+int zl_w4a16_qkv_rope_scatter(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
+                              const uint16_t* bias, const uint16_t* norm_weight, float norm_eps, const float* cosv,
+                              const float* sinv, const int32_t* placement, const int32_t* buf_lens,
+                              uint16_t* const* k_bufs, uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h,
+                              int64_t hkv, int64_t d, int64_t k, int64_t group_size, int bshd, zl_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * a15q  INT8 KV cache (RagBufferContext::is_cache_quant, src/model/rag_buffer_context.h:96).
  * A cached K/V row of one kv head is D unsigned codes + one fp32 scale:

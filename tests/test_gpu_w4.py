@@ -399,3 +399,43 @@ def test_act_order_linear(oracle, dev, algo, monkeypatch):
         Int4GPTQ("l", k, n, quant).load_state_dict(
             {"l.qweight": torch.from_numpy(qw.view(np.int32)), "l.qzeros": torch.from_numpy(qz.view(np.int32)),
              "l.scales": torch.from_numpy(sc.view(np.float16)), "l.g_idx": torch.from_numpy(bad)}, "l", dev)
+
+
+@pytest.mark.parametrize("m,norm", [(1, True), (3, True), (4, False), (8, False), (16, False), (17, False), (32, False)])
+@pytest.mark.parametrize("bshd", [True, False])
+def test_fused_qkv_rotary_scatter_equals_two_call_sequence(oracle, dev, m, norm, bshd):
+    """zl_w4a16_qkv_rope_scatter == zl_w4a16_gemm_mfma + zl_rope_scatter_decode, bit for bit: rotated q, and the K / V
+    buffers (incl. a task whose placement is -1 and the last slot of a buffer); bias on."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(80 + m)
+    h, hkv, d, k, g = 8, 2, 128, 1024 + 256, 128
+    n = (h + 2 * hkv) * d
+    qw, qz, sc = synth.gptq_hf(rng, k, n, g)
+    km = oracle.gptq_prepare_k_major(qw, qz, sc, g)
+    w = ops.W4MWeight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), g)
+    x = _t(synth.act(rng, m, k, 2.0 if norm else 1.0), dev)
+    bias = _t((rng.standard_normal(n) * 0.1).astype(np.float16), dev)
+    nw = _t((1.0 + 0.1 * rng.standard_normal(k)).astype(np.float16), dev) if norm else None
+    lens = [int(v) for v in rng.integers(2, 6, m) * 32]
+    pos = np.array([int(rng.integers(0, L)) for L in lens], np.int32)
+    pos[0] = lens[0] - 1
+    placement = pos.copy()
+    if m > 1:
+        placement[1] = -1
+    cs, sn = oracle.rope_cos_sin(pos, d, 5e5, True, (8.0, 1.0, 4.0, 8192.0))
+    shape = (lambda L: (L, hkv, d)) if bshd else (lambda L: (hkv, L, d))
+    mk = lambda: [torch.full(shape(L), 3.0, dtype=torch.float16, device=dev) for L in lens]
+    k1, v1, k2, v2 = mk(), mk(), mk(), mk()
+    lens_t, place_t = _t(np.array(lens, np.int32), dev), _t(placement, dev)
+    # two calls
+    qkv = ops.w4a16_gemm_mfma(x, w, bias=bias, norm_weight=nw, norm_eps=1e-5)
+    q_ref = ops.rope_scatter_decode(_t(cs, dev), _t(sn, dev), qkv, place_t, lens_t, ops.make_ptr_table(k1), ops.make_ptr_table(v1),
+                                    h, hkv, d, True, bshd)
+    # fused
+    assert ops.w4_qkv_rope_scatter_ok(m, k, d, norm)
+    q_got = ops.w4_qkv_rope_scatter(x, w, _t(cs, dev), _t(sn, dev), place_t, lens_t, ops.make_ptr_table(k2), ops.make_ptr_table(v2),
+                                    h, hkv, d, bias=bias, norm_weight=nw, norm_eps=1e-5, bshd=bshd)
+    assert torch.equal(q_got, q_ref)
+    for a, b_ in zip(k1 + v1, k2 + v2):
+        assert torch.equal(a, b_)
+    assert not torch.equal(k1[0], torch.full_like(k1[0], 3.0))

@@ -1,6 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_gpu_w4.py -x -q -m gpu 2>&1 | tail -2
-for m in 1 8 16 32; do timeout 100 python tools/bench_gemv.py --mfma --m $m 2>&1 | grep -E "plain|norm|layer"; done
-timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -d gpurun_out/pmc_lds/pass0 -o p --output-format csv -- python tools/prof_one.py 28672 4096 8 6 mfma > /dev/null 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_lds k_w4a16
+timeout 1200 python -m pytest tests/test_gpu_w4.py tests/test_gpu_model.py -x -q -m gpu -k "fused_qkv or model or decode or prefill or step" 2>&1 | tail -3
+for b in 1 8 32; do timeout 300 python bench.py --no-cpu-baseline --no-ttft --batch $b 2>&1 | tail -1 | cut -c1-200; done
+ZL_FUSE_QKV_ROPE=0 timeout 300 python bench.py --no-cpu-baseline --no-ttft --batch 1 2>&1 | tail -1 | cut -c1-200

@@ -558,6 +558,12 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
                         int k, int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps,
                         int rounds_override, hipStream_t hs);
 
+int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                             uint32_t meta_bytes, const uint16_t* bias, int m, int n, int k, int groups, int tiles,
+                             const uint16_t* norm_w, float norm_eps, const float* cosv, const float* sinv,
+                             const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                             uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs);
+
 extern "C" {
 
 #ifdef ZL_W4M_PROBE
@@ -711,6 +717,29 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const
         if (st) return st;
     }
     return ZL_OK;
+}
+
+int zl_w4a16_qkv_rope_scatter(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
+                              const uint16_t* bias, const uint16_t* norm_weight, float norm_eps, const float* cosv,
+                              const float* sinv, const int32_t* placement, const int32_t* buf_lens,
+                              uint16_t* const* k_bufs, uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h,
+                              int64_t hkv, int64_t d, int64_t k, int64_t group_size, int bshd, zl_stream_t s) {
+    ZL_CHECK_ARG(x && qw && meta && cosv && sinv && placement && buf_lens && k_bufs && v_bufs && q_out, ZL_EINVAL);
+    ZL_CHECK_ARG(m > 0 && h > 0 && hkv > 0 && d > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(ldx >= k && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, ZL_ESHAPE);
+    const int64_t n = (h + 2 * hkv) * d;
+    zl_w4_layout_t L;
+    int st = zl_w4m_layout(n, k, group_size, &L);
+    if (st) return st;
+    // what the phase-pipelined kernel covers (zl_w4a16_gemm_mfma's own dispatch rules); callers fall back to
+    // zl_w4a16_gemm_mfma + zl_rope_scatter_decode outside of it
+    ZL_CHECK_ARG(m <= 32 && d % 32 == 0 && h % 1 == 0 && L.np == n, ZL_ESHAPE);
+    ZL_CHECK_ARG(!norm_weight || (m <= 4 && k <= 4096), ZL_ESHAPE);
+    ZL_CHECK_ARG(m <= 16 || k <= 8192, ZL_ESHAPE);
+    ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+    return zl_w4a16_gemm_phase_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n,
+                                    (int)k, (int)L.q, (int)(L.np / 16), norm_weight, norm_eps, cosv, sinv, placement,
+                                    buf_lens, k_bufs, v_bufs, q_out, (int)h, (int)hkv, (int)d, bshd, (hipStream_t)s);
 }
 
 }  // extern "C"

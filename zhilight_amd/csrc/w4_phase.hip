@@ -46,6 +46,17 @@ struct PhaseParams {
     int epi, ld_out;
     const uint16_t* norm_w;   // NORM instantiations: fused RMSNorm prologue (M <= 4, K <= 4096)
     float norm_eps;
+    // ROPE instantiations (the fused qkv projection of a decode step: rotate q and k, scatter k / v into the ragged
+    // KV buffers, q to its own buffer -- rope_qk_cache + copy_to_rag_buffer2 in the GEMV epilogue)
+    const float* cosv;          // (M, D) neox tables
+    const float* sinv;
+    const int32_t* placement;   // (M)
+    const int32_t* buf_lens;    // (M)
+    uint16_t* const* k_bufs;
+    uint16_t* const* v_bufs;
+    uint16_t* q_out;            // (M, H * D)
+    int h, hkv, d, bshd;
+    int pair_stride;            // tiles between a column and its rotation partner: D / 32
 };
 
 constexpr int ring_depth(int r) { return r == 1 ? 3 : r == 2 ? 4 : r == 3 ? 6 : r == 4 ? 8 : r; }
@@ -80,8 +91,12 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)
 // halfs 8 t .. 8 t + 7 of every row, the stand-alone RMSNorm kernel's assignment and summation order, so the
 // normalised values are bit-identical to a separate zl_rmsnorm launch); the thread quarter that holds phase p's
 // slice stores it, normalised, at the end of phase p - 1.
-template <int R, int MB, bool NORM>
+// ROPE (R = 2): the workgroup's two tiles are a column block and its rotation partners (D/2 columns = D/32 tiles
+// further), so the neox rotation of q and k happens in the epilogue on the fp16-rounded projection outputs, with the
+// roundings of the separate kernels (rope_common.cuh:14-34: one rounding to T after the fp32 rotation).
+template <int R, int MB, bool NORM, bool ROPE>
 __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
+    static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
     constexpr int D = ring_depth(R), XP = NORM ? 1 : x_ahead(R), BODY = lcm_(D, R * XP);
     static_assert(!NORM || MB == 1, "fused norm: one row block");
     constexpr int XC = 4 * MB;                       // 16-byte x chunks per thread per phase (16 MB rows x 128 chunks)
@@ -95,7 +110,9 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nrow = lane & 15, kq = lane >> 4;
     const int P = p.phases, total = P * R;
-    const int tile0 = blockIdx.x * R;
+    // ROPE: workgroup b owns tiles {base, base + s}, base = (b / s) * 2 s + b % s  (s = pair_stride)
+    const int tile0 = ROPE ? (blockIdx.x / p.pair_stride) * 2 * p.pair_stride + blockIdx.x % p.pair_stride : blockIdx.x * R;
+    const int tile_stride = ROPE ? p.pair_stride : 1;
 
     // ---- activations: chunk c of a thread = row (tid >> 7) + 4 c, halfs 8 (tid & 127) .. +7 of the phase
     const int xrow0 = threadIdx.x >> 7, xcc = (threadIdx.x & 127) * 8;
@@ -140,7 +157,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
     const uint32_t it0 = (uint32_t)tile0 * (uint32_t)p.groups + (uint32_t)wave;
     uint32_t qs = it0 * 1024u, ms = it0 * 64u;
-    const int tile_step = p.groups, phase_step = kW - (R - 1) * p.groups;
+    const int tile_step = tile_stride * p.groups, phase_step = kW - (R - 1) * tile_stride * p.groups;
     const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)nrow * 4u;
     int iss_left = total - 1;
     auto issue = [&](int slot, int r_of_item) {      // both static
@@ -317,8 +334,58 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
         for (int b = 0; b < MB; ++b) red[((r * MB + b) * kW + wave) * 64 + lane] = acc[r][b];
     }
     __syncthreads();
-    const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
     const float* redf = reinterpret_cast<const float*>(red);
+    if constexpr (ROPE) {
+        const int half = p.d / 2;
+        for (int o = threadIdx.x; o < 16 * p.m; o += kT) {
+            const int m = o >> 4, n_local = o & 15;
+            const int b = m >> 4, ln = ((m & 15) >> 2) * 16 + n_local, i = m & 3;
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) {
+                v0 += redf[(((size_t)(0 * MB + b) * kW + w) * 64 + ln) * 4 + i];
+                v1 += redf[(((size_t)(1 * MB + b) * kW + w) * 64 + ln) * 4 + i];
+            }
+            const int n0 = tile0 * 16 + n_local, n1 = n0 + half;       // columns of the fused qkv row
+            if ((p.epi & ZL_EPI_BIAS) && p.bias) {
+                v0 += (float)__builtin_bit_cast(_Float16, p.bias[n0]);
+                v1 += (float)__builtin_bit_cast(_Float16, p.bias[n1]);
+            }
+            const float a = (float)zl_f32_to_f16(v0), bb = (float)zl_f32_to_f16(v1);   // the projection's fp16 outputs
+            const int head = n0 / p.d, dcol = n0 % p.d;                 // dcol < half
+            if (head < p.h + p.hkv) {
+                const float c0 = p.cosv[(size_t)m * p.d + dcol], s0 = p.sinv[(size_t)m * p.d + dcol];
+                const float c1 = p.cosv[(size_t)m * p.d + dcol + half], s1 = p.sinv[(size_t)m * p.d + dcol + half];
+                const uint16_t r0 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(-bb, s0, a * c0)));
+                const uint16_t r1 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(a, s1, bb * c1)));
+                if (head < p.h) {
+                    uint16_t* dst = p.q_out + ((size_t)m * p.h + head) * p.d + dcol;
+                    dst[0] = r0;
+                    dst[half] = r1;
+                } else {
+                    const int place = p.placement[m];
+                    if (place >= 0) {
+                        const int hk = head - p.h;
+                        const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
+                        uint16_t* dst = p.k_bufs[m] + row * p.d + dcol;
+                        dst[0] = r0;
+                        dst[half] = r1;
+                    }
+                }
+            } else {
+                const int place = p.placement[m];
+                if (place >= 0) {
+                    const int hk = head - p.h - p.hkv;
+                    const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
+                    uint16_t* dst = p.v_bufs[m] + row * p.d + dcol;
+                    dst[0] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v0));
+                    dst[half] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v1));
+                }
+            }
+        }
+        return;
+    }
+    const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
     const int per_tile = (silu ? 8 : 16) * p.m;
     const int nouts = R * per_tile;
     for (int o = threadIdx.x; o < nouts; o += kT) {
@@ -370,7 +437,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     }
 }
 
-template <int R, int MB, bool NORM>
+template <int R, int MB, bool NORM, bool ROPE = false>
 int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
     constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS * 2 + (NORM ? 4 * kW * 4 : 0);
     constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
@@ -379,13 +446,13 @@ int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
     if (lds > 64 * 1024) {
         static bool done = false;   // per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return ZL_ELIMIT;
             done = true;
         }
     }
-    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE>), dim3(grid), dim3(kT), lds, hs, p);
     return zl_launch_status();
 }
 
@@ -402,6 +469,8 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
     p.meta_bytes = meta_bytes; p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k;
     p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = epilogue; p.ld_out = ld_out; p.norm_w = norm_w; p.norm_eps = norm_eps;
+    p.cosv = p.sinv = nullptr; p.placement = p.buf_lens = nullptr; p.k_bufs = p.v_bufs = nullptr; p.q_out = nullptr;
+    p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
     // tiles per workgroup: one generation of workgroups when 8 tiles per CU suffice, else full-size workgroups
@@ -419,4 +488,25 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     }
 #undef ZL_PH
     return ZL_EINVAL;
+}
+
+// internal (called by zl_w4a16_qkv_rope_scatter): the fused qkv projection of a decode step with the neox rotation and
+// the KV scatter in the epilogue.  n = (h + 2 hkv) * d, d % 32 == 0, 1 <= m <= 32, norm_w != null: m <= 4 and k <= 4096.
+int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                             uint32_t meta_bytes, const uint16_t* bias, int m, int n, int k, int groups, int tiles,
+                             const uint16_t* norm_w, float norm_eps, const float* cosv, const float* sinv,
+                             const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                             uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs) {
+    if (m < 1 || m > 32 || d % 32 != 0 || n != (h + 2 * hkv) * d || tiles * 16 != n) return ZL_ESHAPE;
+    if (norm_w && (m > 4 || k > 4096)) return ZL_ESHAPE;
+    PhaseParams p;
+    p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
+    p.meta_bytes = meta_bytes; p.bias = bias; p.residual = nullptr; p.y = nullptr; p.m = m; p.n = n; p.k = k;
+    p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = bias ? ZL_EPI_BIAS : 0; p.ld_out = n;
+    p.norm_w = norm_w; p.norm_eps = norm_eps;
+    p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs;
+    p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd; p.pair_stride = d / 32;
+    const int grid = tiles / 2;
+    if (norm_w) return launch_phase<2, 1, true, true>(p, grid, hs);
+    return m <= 16 ? launch_phase<2, 1, false, true>(p, grid, hs) : launch_phase<2, 2, false, true>(p, grid, hs);
 }

@@ -705,7 +705,24 @@ class LLaMA:
         scale = 1.0 / math.sqrt(c.dim_head)
         mfma_attn = (c.dim_head == 128 and c.torch_dtype == torch.float16 and c.num_heads // c.num_kv_heads <= 16
                      and os.environ.get("ZL_ATTN_MFMA", "1") != "0")
+        # fused qkv projection + rotary + KV scatter in the GEMV epilogue (zl_w4a16_qkv_rope_scatter) where it applies
+        fuse_qkv_rope = (mfma_attn and not ctx.kv_quant and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
+                         and all(isinstance(l, EncoderLayer) and l.unfused is None and isinstance(l.qkv.weight, ops.W4MWeight)
+                                 for l in self.layers)
+                         and ops.w4_qkv_rope_scatter_ok(b, c.dim_model, c.dim_head, norm=b <= 4))
         for li, layer in enumerate(self.layers):
+            if fuse_qkv_rope:
+                xin = hidden if b <= 4 else ops.rmsnorm(hidden, layer.ln_attn, c.eps)
+                ops.w4_qkv_rope_scatter(xin, layer.qkv.weight, cos, sin, ctx.placement, ctx.buf_lens, ctx.k_addrs[li],
+                                        ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, bias=layer.qkv.bias,
+                                        norm_weight=layer.ln_attn if b <= 4 else None, norm_eps=c.eps, q_out=bufs["q"])
+                ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
+                                                     ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
+                                                     valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
+                                                     workspace=workspace)
+                layer.attn_out_add(bufs["attn"], hidden)
+                layer.ff_add(hidden, c.eps, bufs["act"])
+                continue
             layer.project_qkv(hidden, c.eps, out=bufs["qkv"])
             if ctx.kv_quant:
                 # attention.cpp:652-676 + :725-745: rotate, quantise the new K/V rows into the u8 cache, attend over codes

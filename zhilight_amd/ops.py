@@ -412,6 +412,28 @@ def rope_scatter_decode(cos, sin, qkv, placement, buf_lens, k_addrs, v_addrs, nu
     return q_out
 
 
+def w4_qkv_rope_scatter_ok(m, k, dim_head, norm):
+    """what zl_w4a16_qkv_rope_scatter covers (otherwise: w4_linear + rope_scatter_decode)"""
+    return m <= 32 and dim_head % 32 == 0 and (not norm or (m <= 4 and k <= 4096)) and (m <= 16 or k <= 8192)
+
+
+def w4_qkv_rope_scatter(x, w, cos, sin, placement, buf_lens, k_addrs, v_addrs, num_heads, num_kv_heads, dim_head, bias=None,
+                        norm_weight=None, norm_eps=1e-5, bshd=True, q_out=None):
+    """fused qkv projection (W4MWeight w, (H + 2 Hkv) D rows) + neox rotary + KV scatter for decode rows; returns the
+    rotated q (M, H*D).  Bit-identical to w4_linear(..) followed by rope_scatter_decode(..)."""
+    _chk_cuda(x, cos, sin, placement, buf_lens, k_addrs, v_addrs, bias, norm_weight)
+    if not isinstance(w, W4MWeight) or x.dtype != torch.float16:
+        raise ZLError("w4_qkv_rope_scatter: fp16 activations and a ZLW4M weight")
+    m, k = x.shape
+    if q_out is None:
+        q_out = torch.empty((m, num_heads * dim_head), dtype=x.dtype, device=x.device)
+    check(lib().zl_w4a16_qkv_rope_scatter(_p(x), _i(x.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(norm_weight),
+                                          _f(norm_eps), _p(cos), _p(sin), _p(placement), _p(buf_lens), _p(k_addrs),
+                                          _p(v_addrs), _p(q_out), _i(m), _i(num_heads), _i(num_kv_heads), _i(dim_head),
+                                          _i(k), _i(w.group_size), C.c_int(int(bshd)), _stream()), "w4a16_qkv_rope_scatter")
+    return q_out
+
+
 def decode_attn_workspace(b, len_q, h, d, max_len_buf, device):
     nbytes = lib().zl_decode_attn_workspace_bytes(_i(b), _i(len_q), _i(h), _i(d), _i(max_len_buf))
     if nbytes < 0:
