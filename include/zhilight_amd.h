@@ -354,6 +354,26 @@ int zl_quant_scale_back(const int32_t* c, const float* scale_x, const uint16_t* 
 int zl_quant_back_act_mul(const int32_t* a, const float* a_sx, const uint16_t* a_sy, const int32_t* b,
                           const float* b_sx, const uint16_t* b_sy, uint16_t* out, int64_t m, int64_t n,
                           int act, int dtype, zl_stream_t s);
+/* ------------------------------------------------------------------------------------------------
+ * a8-a11 fused for decode batches: Int8Linear::forward's GEMM + scale-back in ONE launch (1 <= M <= 32).
+ * Replaces functions::Gemm int8 (src/nn/linear/linear.cpp:557-635) followed by quant_scale_back
+ * (quant_kernel.cu:231-246), quant_back_element_add_scale (:311-340) or quant_back_act_mul (:589-614);
+ * the integer product is exact, the float expression behind it is the reference's, so the result is
+ * bit-identical to zl_int8_gemm_nt + zl_quant_scale_back / _back_element_add_scale / _back_act_mul.
+ * Weights in the ZLW8M streaming layout (zl_w8m_pack from the (N, K) int8 rows; row_interleave packs
+ * [w_in; w_gated] as (gate_n, up_n) row pairs and expects scale_y interleaved the same way):
+ *   ZL_W8_BACK      out[m,n]   = T(float(c) * sx[m] * float(sy[n]))
+ *   ZL_W8_BACK_ADD  out[m,n]   = T((float(c) * sx[m] * float(sy[n]) + float(addend[m,n])) * scale)
+ *   ZL_W8_ACT_SILU / ZL_W8_ACT_GELU   out[m,j] = T(up_j * act(gate_j)),  N/2 columns
+ * More rows: ZL_ESHAPE (use zl_int8_gemm_nt + the scale-back launchers).
+ * ---------------------------------------------------------------------------------------------- */
+enum zl_w8_epilogue { ZL_W8_BACK = 0, ZL_W8_BACK_ADD = 1, ZL_W8_ACT_SILU = 2, ZL_W8_ACT_GELU = 3 };
+int64_t zl_w8m_bytes(int64_t n, int64_t k);
+int zl_w8m_pack(const int8_t* w /* (N,K) */, int64_t n, int64_t k, int row_interleave, void* qw, zl_stream_t s);
+int zl_w8a8_gemm_phase(const int8_t* xq /* (M,K) */, const float* scale_x /* (M) */, const void* qw,
+                       const uint16_t* scale_y /* (N) T */, const uint16_t* addend, uint16_t* out, int64_t m, int64_t n,
+                       int64_t k, float scale, int epilogue, int dtype, zl_stream_t s);
+
 /* The other scale-back flavours of the reference, same arithmetic T(float(int32) * sx[row] * sy[col]):
  *   zl_quant_scale_back3             int8_op::quant_scale_back3 (quant_kernel.cu:311-384): fused qkv result -> q | k | v
  *   zl_quant_back_element_add_scale  quant_back_element_add_scale (:530-583): T((back + float(b)) * scale)

@@ -456,3 +456,35 @@ def test_int8_gemm_shapes_bit_exact(oracle, dev, m, n, k):
     w = rng.integers(-127, 128, (n, k)).astype(np.int8)
     got = _np(ops.int8_gemm_nt(_t(a, dev), _t(w, dev)))
     assert np.array_equal(got, oracle.int8_gemm_nt(a, w))
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("m", [1, 7, 16, 17, 32])
+def test_w8a8_streaming_gemm_bit_identical(oracle, dev, m, rounds, monkeypatch):
+    """zl_w8a8_gemm_phase (every tiles-per-workgroup x row-block instantiation) == zl_int8_gemm_nt + the scale-back
+    launchers, bit for bit, for the three epilogues the Int8 layer uses; ragged N, K with a partial last phase and K
+    beyond one unrolled body; the int32 product itself is checked against the oracle."""
+    from zhilight_amd import ops
+    monkeypatch.setenv("ZL_W8_PHASE_ROUNDS", str(rounds))
+    rng = np.random.default_rng(200 + m + rounds)
+    for k, n in ((1152, 16 * (2 * rounds) + 8), (4096, 16 * rounds), (9 * 1024 + 256, 16 * rounds + 16)):
+        a = rng.integers(-127, 128, (m, k), dtype=np.int8)
+        w = rng.integers(-127, 128, (n, k), dtype=np.int8)
+        sx = rng.uniform(0.01, 0.05, m).astype(np.float32)
+        sy = rng.uniform(0.001, 0.01, n).astype(np.float16)
+        add = synth.act(rng, m, n)
+        ta, tw, tsx, tsy, tadd = _t(a, dev), _t(w, dev), _t(sx, dev), _t(sy, dev), _t(add, dev)
+        c = ops.int8_gemm_nt(ta, tw)
+        assert np.array_equal(_np(c), oracle.int8_gemm_nt(a, w))
+        w8 = ops.W8MWeight.from_rows(tw, tsy)
+        got = ops.w8a8_gemm_phase(ta, tsx, w8, ops.W8_BACK)
+        assert torch.equal(got, ops.quant_scale_back(c, tsx, tsy, torch.float16))
+        got = ops.w8a8_gemm_phase(ta, tsx, w8, ops.W8_BACK_ADD, addend=tadd, scale=1.0)
+        assert torch.equal(got, ops.quant_back_element_add_scale(c, tsx, tsy, tadd, 1.0))
+        if n % 2 == 0:
+            w8g = ops.W8MWeight.from_rows(tw, tsy, row_interleave=True)
+            got = ops.w8a8_gemm_phase(ta, tsx, w8g, ops.W8_ACT_SILU)
+            h2 = n // 2
+            ref = ops.quant_back_act_mul(c[:, :h2].contiguous(), tsx, tsy[:h2].contiguous(), c[:, h2:].contiguous(), tsx,
+                                         tsy[h2:].contiguous(), "silu", torch.float16)
+            assert torch.equal(got, ref)

@@ -1,0 +1,329 @@
+// w8_phase.hip -- W8A8 (AutoInt8) GEMM for decode batches of 1..32 rows with the scale-back fused in the epilogue.
+//
+// Reference: Int8Linear::forward = quant_calc_scale / layernorm_quant of the activations,
+// int8 x int8 -> int32 GEMM (cuBLASLt IMMA, src/nn/linear/linear.cpp:557-635), then one of the scale-back kernels
+// (src/nn/quant/int8/quant_kernel.cu:231-246 quant_scale_back, :311-340 quant_back_element_add_scale, :589-614
+// quant_back_act_mul):   T( float(c) * sx[row] * float(sy[col]) )  [+ residual / gated activation].
+// The integer GEMM is exact, so fusing those float expressions behind it changes nothing: the output is
+// bit-identical to zl_int8_gemm_nt + zl_quant_scale_back* (tests/test_gpu_ops.py).
+//
+// Structure = w4_phase.hip without the dequantisation: one 8-wave workgroup per CU owns R row tiles of 16 output
+// rows, K is cut into phases of 1024 k, in a phase wave w takes the w-th 128-k item (2 KiB: two 16-byte B
+// fragments per lane) of every tile, int32 accumulators of all R tiles stay in registers across the phases
+// (v_mfma_i32_16x16x64_i8 accumulates straight into them), the int8 activations go through one double-buffered
+// LDS phase buffer (16 MB rows x 1 KiB), weight ring across the phase boundaries, x loads issued XP phases ahead
+// so that they are older than every weight load in flight when they are consumed (in-order vmcnt).
+//
+// ZLW8M layout (zl_w8m_pack): tile = 16 output rows x 128 k = 2 KiB:
+//   qw : [N/16][Kp/128][2][64 lanes][16 B]   lane (n = lane & 15, kq = lane >> 4), half j: k = 128 g + 64 j + 16 kq .. +15
+// Kp = K rounded up to 128 (zero padded); row_interleave packs [w_in; w_gated] as (gate_n, up_n) row pairs.
+#include <stdlib.h>
+#include "zl_common.h"
+
+namespace {
+
+constexpr int kT = 512, kW = 8;
+constexpr int kPK = 1024;            // k (= bytes) per phase
+constexpr int kXS = kPK + 16;        // LDS x row stride, bytes
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+enum { kBack = 0, kBackAdd = 1, kActSilu = 2, kActGelu = 3 };
+
+struct W8Params {
+    const int8_t* x;           // (M, K) int8 activations
+    const float* sx;           // (M) activation scales
+    const uint4* qw;
+    uint32_t qw_bytes;
+    const uint16_t* sy;        // (N) weight scales, T (interleaved like the rows for the gated epilogues)
+    const uint16_t* addend;    // (M, N) T   [kBackAdd]
+    uint16_t* y;
+    float scale;               // [kBackAdd]
+    int m, n, k;
+    int groups, tiles, phases;
+    int epi, ld_out, dtype;
+};
+
+constexpr int ring_depth(int r) { return r == 1 ? 3 : r == 2 ? 4 : r == 3 ? 6 : r == 4 ? 8 : r; }
+constexpr int x_ahead(int r) { return r == 1 ? 3 : r <= 4 ? 2 : 1; }
+constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
+constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
+
+struct Guard { static constexpr bool value = true; };
+struct NoGuard { static constexpr bool value = false; };
+
+template <int DT>
+__device__ __forceinline__ float back(int c, float sx, uint16_t sy) { return (float)c * sx * ZT<DT>::to_f32(sy); }
+
+template <int R, int MB>
+__global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
+    constexpr int D = ring_depth(R), XP = x_ahead(R), BODY = lcm_(D, R * XP);
+    constexpr int XC = 2 * MB;                       // 16-byte x chunks per thread per phase (16 MB rows x 64 chunks)
+    constexpr int kBuf = MB * 16 * kXS;              // bytes per LDS phase buffer
+    static_assert(BODY % R == 0 && (BODY / R) % XP == 0 && BODY % D == 0 && D % R == 0, "static indices");
+    static_assert(XP * R >= D - 1, "x loads must be older than the weights in flight when they are consumed");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrow = lane & 15, kq = lane >> 4;
+    const int P = p.phases, total = P * R;
+    const int tile0 = blockIdx.x * R;
+
+    // ---- activations: chunk c of a thread = row (tid >> 6) + 8 c, bytes 16 (tid & 63) .. +15 of the phase
+    const int xrow0 = threadIdx.x >> 6, xcc = (threadIdx.x & 63) * 16;
+    v4i xr[XP][XC];
+    auto load_x = [&](int set, int ph) {
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+            const int row = xrow0 + 8 * c, kk = ph * kPK + xcc;
+            const bool live = row < p.m && kk < p.k && ph < P;
+            xr[set][c] = *reinterpret_cast<const v4i*>(p.x + (live ? (size_t)row * p.k + kk : 0));
+            if (!live) xr[set][c] = (v4i){0, 0, 0, 0};
+        }
+    };
+    auto store_x = [&](int set, int ph) {
+        unsigned char* dst = smem + (ph & 1) * kBuf + xcc;
+#pragma unroll
+        for (int c = 0; c < XC; ++c) *reinterpret_cast<v4i*>(dst + (xrow0 + 8 * c) * kXS) = xr[set][c];
+    };
+#pragma unroll
+    for (int q = 0; q < XP; ++q) load_x(q, q);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- weight ring: item (tile, g) = 2 KiB at ((tile * groups + g) * 2048); wave w: for phase: for r: (tile0 + r, 8 ph + w)
+    v4i wq[D][2];
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
+    uint32_t qs = ((uint32_t)tile0 * (uint32_t)p.groups + (uint32_t)wave) * 2048u;
+    const int tile_step = p.groups, phase_step = kW - (R - 1) * p.groups;
+    const uint32_t q_off = (uint32_t)lane * 16u;
+    int iss_left = total - 1;
+    auto issue = [&](int slot, int r_of_item) {
+        wq[slot][0] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off, qs, 2 /* nt */));
+        wq[slot][1] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off + 1024u, qs, 2));
+        const int adv = iss_left > 0 ? 1 : 0;        // exhausted: keep re-reading the last item (a cache hit)
+        --iss_left;
+        const int d = adv * (r_of_item == R - 1 ? phase_step : tile_step);
+        qs += (uint32_t)d * 2048u;
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        issue(s, s % R);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    store_x(0, 0);
+    __syncthreads();
+
+    // A fragment (activations): row m = 16 mb + (lane & 15), bytes 128 wave + 64 j + 16 kq .. +15 of the phase
+    const unsigned char* xl = smem + nrow * kXS + wave * 128 + 16 * kq;
+
+    v4i acc[R][MB];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[r][b] = (v4i){0, 0, 0, 0};
+    }
+    auto step = [&](int slot, int r, int ph) {
+        const unsigned char* xb = xl + (ph & 1) * kBuf;
+        v4i af[MB][2];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) af[b][j] = *reinterpret_cast<const v4i*>(xb + b * 16 * kXS + 64 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+                acc[r][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[b][j], wq[slot][j], acc[r][b], 0, 0, 0);
+        }
+        issue(slot, r);                               // item i + D: same r (D % R == 0 or D == R)
+    };
+    auto body = [&](int k, int ph, auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+#pragma unroll
+        for (int s = 0; s < BODY; ++s) {
+            if (GUARD && k + s >= total) break;
+            const int r = s % R, j = s / R;
+            const int php = ph + j;
+            if (r == 0) load_x(j % XP, php + XP);
+            step(s % D, r, php);
+            if (r == R - 1) {
+                if (php + 1 < P) {
+                    store_x((j + 1) % XP, php + 1);
+                    __syncthreads();
+                }
+            }
+        }
+    };
+    if (total >= BODY) {
+        int k = 0, ph = 0;
+#pragma unroll 1
+        do {
+            body(k, ph, NoGuard{});
+            k += BODY;
+            ph += BODY / R;
+        } while (k + BODY <= total);
+        body(k, ph, Guard{});
+    } else {
+        body(0, 0, Guard{});
+    }
+    __syncthreads();
+
+    // ---- park the partial C fragments (exact integers: any order), reduce over the 8 waves, scale back
+    v4i* red = reinterpret_cast<v4i*>(smem);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) red[((r * MB + b) * kW + wave) * 64 + lane] = acc[r][b];
+    }
+    __syncthreads();
+    const int* redi = reinterpret_cast<const int*>(red);
+    const bool gated = p.epi == kActSilu || p.epi == kActGelu;
+    const int per_tile = (gated ? 8 : 16) * p.m;
+    for (int o = threadIdx.x; o < R * per_tile; o += kT) {
+        const int r = o / per_tile, rem = o % per_tile;
+        const int tile = tile0 + r;
+        if (tile >= p.tiles) continue;
+        auto total_of = [&](int n_local, int m) {
+            const int b = m >> 4, ln = ((m & 15) >> 2) * 16 + n_local, i = m & 3;
+            int v = 0;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) v += redi[(((size_t)(r * MB + b) * kW + w) * 64 + ln) * 4 + i];
+            return v;
+        };
+        if (!gated) {
+            const int m = rem >> 4, n_local = rem & 15;
+            const int col = tile * 16 + n_local;
+            if (col >= p.n) continue;
+            const int c = total_of(n_local, m);
+            const size_t pos = (size_t)m * p.ld_out + col;
+            const float sx = p.sx[m];
+            if (p.dtype == ZL_F16) {
+                const float qb = back<ZL_F16>(c, sx, p.sy[col]);
+                p.y[pos] = p.epi == kBackAdd ? ZT<ZL_F16>::from_f32((qb + ZT<ZL_F16>::to_f32(p.addend[pos])) * p.scale)
+                                             : ZT<ZL_F16>::from_f32(qb);
+            } else {
+                const float qb = back<ZL_BF16>(c, sx, p.sy[col]);
+                p.y[pos] = p.epi == kBackAdd ? ZT<ZL_BF16>::from_f32((qb + ZT<ZL_BF16>::to_f32(p.addend[pos])) * p.scale)
+                                             : ZT<ZL_BF16>::from_f32(qb);
+            }
+        } else {
+            const int m = rem >> 3, j = rem & 7;
+            const int pr = tile * 8 + j;
+            if (2 * pr + 1 >= p.n) continue;
+            const int ca = total_of(2 * j, m), cb = total_of(2 * j + 1, m);
+            const float sx = p.sx[m];
+            float ab, bb;
+            if (p.dtype == ZL_F16) {
+                ab = back<ZL_F16>(ca, sx, p.sy[2 * pr]);
+                bb = back<ZL_F16>(cb, sx, p.sy[2 * pr + 1]);
+            } else {
+                ab = back<ZL_BF16>(ca, sx, p.sy[2 * pr]);
+                bb = back<ZL_BF16>(cb, sx, p.sy[2 * pr + 1]);
+            }
+            float gate;
+            if (p.epi == kActSilu) gate = ab / (1.0f + expf(-ab));
+            else gate = 0.5f * ab * (1.0f + tanhf(0.7978845608028654f * ab * (1.0f + 0.044715f * ab * ab)));
+            const float ov = bb * gate;
+            p.y[(size_t)m * p.ld_out + pr] = p.dtype == ZL_F16 ? ZT<ZL_F16>::from_f32(ov) : ZT<ZL_BF16>::from_f32(ov);
+        }
+    }
+}
+
+template <int R, int MB>
+int launch_w8(const W8Params& p, int grid, hipStream_t hs) {
+    constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS;
+    constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
+    constexpr size_t lds = x_bytes > red_bytes ? x_bytes : red_bytes;
+    static_assert(lds <= 160 * 1024, "LDS");
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w8a8_phase<R, MB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return ZL_ELIMIT;
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((k_w8a8_phase<R, MB>), dim3(grid), dim3(kT), lds, hs, p);
+    return zl_launch_status();
+}
+
+// (N, K) int8 row-major -> ZLW8M
+__global__ void k_pack_w8m(const int8_t* __restrict__ w, uint32_t* __restrict__ dst, int64_t n, int64_t k, int64_t tiles,
+                           int64_t groups, int interleave) {
+    const int64_t total = tiles * groups * 512;           // u32 words: 2 halves x 64 lanes x 4
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63), j = (int)((i >> 8) & 1);
+        const int64_t tg = i >> 9, g = tg % groups, tile = tg / groups;
+        const int64_t row = tile * 16 + (lane & 15);
+        const int64_t kk = g * 128 + 64 * j + 16 * (lane >> 4) + 4 * e;
+        const int64_t src_row = interleave ? ((row & 1) * (n / 2) + (row >> 1)) : row;
+        uint32_t v = 0;
+        if (row < n) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (kk + b < k) v |= (uint32_t)(uint8_t)w[src_row * k + kk + b] << (8 * b);
+            }
+        }
+        dst[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t zl_w8m_bytes(int64_t n, int64_t k) {
+    if (n <= 0 || k <= 0) return ZL_EINVAL;
+    return ((n + 15) / 16) * ((k + 127) / 128) * 2048;
+}
+
+int zl_w8m_pack(const int8_t* w, int64_t n, int64_t k, int row_interleave, void* qw, zl_stream_t s) {
+    ZL_CHECK_ARG(w && qw && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(!row_interleave || n % 2 == 0, ZL_ESHAPE);
+    const int64_t tiles = (n + 15) / 16, groups = (k + 127) / 128;
+    int64_t g = (tiles * groups * 512 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_pack_w8m, dim3((unsigned)g), dim3(256), 0, (hipStream_t)s, w, reinterpret_cast<uint32_t*>(qw), n, k,
+                       tiles, groups, row_interleave);
+    return zl_launch_status();
+}
+
+int zl_w8a8_gemm_phase(const int8_t* xq, const float* scale_x, const void* qw, const uint16_t* scale_y,
+                       const uint16_t* addend, uint16_t* out, int64_t m, int64_t n, int64_t k, float scale, int epilogue,
+                       int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(xq && scale_x && qw && scale_y && out && m > 0 && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(epilogue >= kBack && epilogue <= kActGelu, ZL_EINVAL);
+    ZL_CHECK_ARG(epilogue != kBackAdd || addend, ZL_EINVAL);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    ZL_CHECK_ARG(m <= 32 && k % 16 == 0 && ((uintptr_t)xq & 15) == 0, ZL_ESHAPE);   // more rows: zl_int8_gemm_nt + scale back
+    const bool gated = epilogue == kActSilu || epilogue == kActGelu;
+    ZL_CHECK_ARG(!gated || n % 2 == 0, ZL_ESHAPE);
+    const int64_t bytes = zl_w8m_bytes(n, k);
+    ZL_CHECK_ARG(bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+    W8Params p;
+    p.x = xq; p.sx = scale_x; p.qw = reinterpret_cast<const uint4*>(qw); p.qw_bytes = (uint32_t)bytes; p.sy = scale_y;
+    p.addend = addend; p.y = out; p.scale = scale; p.m = (int)m; p.n = (int)n; p.k = (int)k;
+    p.groups = (int)((k + 127) / 128); p.tiles = (int)((n + 15) / 16); p.phases = (p.groups + kW - 1) / kW;
+    p.epi = epilogue; p.ld_out = (int)(gated ? n / 2 : n); p.dtype = dtype;
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    int r = (p.tiles + cus - 1) / cus;
+    if (r > 8) r = 8;
+    {
+        const char* e = getenv("ZL_W8_PHASE_ROUNDS");      // tests sweep the instantiations
+        if (e && atoi(e) >= 1 && atoi(e) <= 8) r = atoi(e);
+    }
+    const int grid = (p.tiles + r - 1) / r;
+    hipStream_t hs = (hipStream_t)s;
+#define ZL_W8(RR) \
+    case RR: return m <= 16 ? launch_w8<RR, 1>(p, grid, hs) : launch_w8<RR, 2>(p, grid, hs);
+    switch (r) { ZL_W8(1) ZL_W8(2) ZL_W8(3) ZL_W8(4) ZL_W8(5) ZL_W8(6) ZL_W8(7) ZL_W8(8) }
+#undef ZL_W8
+    return ZL_EINVAL;
+}
+
+}  // extern "C"

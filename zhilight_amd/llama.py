@@ -386,6 +386,13 @@ class Int8Linear:
         """int32 (M, N) = xq . W^T -- the caller fuses the scale-back"""
         return ops.int8_gemm_nt(xq, self.weight)
 
+    def stream_weight(self):
+        """the ZLW8M copy for the decode kernel (zl_w8a8_gemm_phase), packed on first use; the (N, K) rows stay for the
+        tiled GEMM of prompt chunks and batches beyond 32 rows"""
+        if getattr(self, "_w8m", None) is None:
+            self._w8m = ops.W8MWeight.from_rows(self.weight, self.scale)
+        return self._w8m
+
 
 class Int8EncoderLayer:
     """EncoderLayer over Int8Linear (BASELINE configs[2]) with the fusions of the reference's
@@ -427,16 +434,37 @@ class Int8EncoderLayer:
     def weight_bytes(self):
         return sum(l.nbytes() for l in self.linears())
 
+    # Decode batches (<= 32 rows): the streaming int8 kernel with the scale-back fused in its epilogue
+    # (zl_w8a8_gemm_phase: 4 GEMM launches per layer instead of 5 GEMMs + 4 scale-back kernels + split-K memsets;
+    # bit-identical results).  More rows: the tiled int8 GEMM + the reference's separate scale-back kernels.
+    @staticmethod
+    def _stream(rows):
+        return rows <= 32 and os.environ.get("ZL_W8_PHASE", "1") != "0"
+
+    def _gated_stream_weight(self):
+        if getattr(self, "_w8m_gated", None) is None:
+            self._w8m_gated = ops.W8MWeight.from_rows(torch.cat([self.w_in.weight, self.w_gated.weight], dim=0),
+                                                      torch.cat([self.w_in.scale, self.w_gated.scale]), row_interleave=True)
+        return self._w8m_gated
+
     def project_qkv(self, hidden, eps, out=None):
         _, xq, sx = ops.layernorm_quant(hidden, self.ln_attn, eps)
+        if self._stream(hidden.shape[0]):
+            return ops.w8a8_gemm_phase(xq, sx, self.qkv.stream_weight(), ops.W8_BACK, out=out, dtype=hidden.dtype)
         return ops.quant_scale_back(self.qkv.gemm(xq), sx, self.qkv.scale, hidden.dtype, out=out)
 
     def attn_out_add(self, attn, hidden):
         aq, sa = ops.quant_calc_scale(attn)
+        if self._stream(hidden.shape[0]):
+            return ops.w8a8_gemm_phase(aq, sa, self.attn_out.stream_weight(), ops.W8_BACK_ADD, addend=hidden, scale=1.0, out=hidden)
         ops.quant_back_element_add_scale(self.attn_out.gemm(aq), sa, self.attn_out.scale, hidden, 1.0, out=hidden)
 
     def ff_add(self, hidden, eps, act_buf=None):
         _, xq, sx = ops.layernorm_quant(hidden, self.ln_ff, eps)
+        if self._stream(hidden.shape[0]):
+            act = ops.w8a8_gemm_phase(xq, sx, self._gated_stream_weight(), ops.W8_ACT_SILU, out=act_buf, dtype=hidden.dtype)
+            aq, sa = ops.quant_calc_scale(act)
+            return ops.w8a8_gemm_phase(aq, sa, self.w_out.stream_weight(), ops.W8_BACK_ADD, addend=hidden, scale=1.0, out=hidden)
         act = ops.quant_back_act_mul(self.w_in.gemm(xq), sx, self.w_in.scale, self.w_gated.gemm(xq), sx, self.w_gated.scale,
                                      "silu", hidden.dtype)
         aq, sa = ops.quant_calc_scale(act)

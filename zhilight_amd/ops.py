@@ -587,6 +587,49 @@ def embedding(ids, weight, scale=1.0, begin=0, end=None):
 # --------------------------------------------------------------------------------------------------
 # a8..a11: INT8
 # --------------------------------------------------------------------------------------------------
+W8_BACK, W8_BACK_ADD, W8_ACT_SILU, W8_ACT_GELU = 0, 1, 2, 3
+
+
+class W8MWeight:
+    """int8 weight (N, K) in the ZLW8M streaming layout of zl_w8a8_gemm_phase + its per-row scale (T, interleaved with
+    the rows when row_interleave)."""
+
+    def __init__(self, n, k, qw, scale, row_interleave=False):
+        self.n, self.k, self.qw, self.scale, self.row_interleave = n, k, qw, scale, row_interleave
+
+    @classmethod
+    def from_rows(cls, w_int8, scale, row_interleave=False):
+        _chk_cuda(w_int8, scale)
+        n, k = w_int8.shape
+        nbytes = lib().zl_w8m_bytes(_i(n), _i(k))
+        if nbytes < 0:
+            check(int(nbytes), "w8m_bytes")
+        qw = torch.empty(nbytes, dtype=torch.uint8, device=w_int8.device)
+        check(lib().zl_w8m_pack(_p(w_int8.contiguous()), _i(n), _i(k), C.c_int(int(row_interleave)), _p(qw), _stream()), "w8m_pack")
+        if row_interleave:
+            scale = torch.stack([scale[:n // 2], scale[n // 2:]], dim=1).reshape(-1)
+        return cls(n, k, qw, scale.contiguous(), row_interleave)
+
+    def nbytes(self):
+        return self.qw.numel() + self.scale.numel() * 2
+
+
+def w8a8_gemm_phase(xq, sx, w: W8MWeight, epilogue=W8_BACK, addend=None, scale=1.0, out=None, dtype=torch.float16):
+    """Int8Linear GEMM + scale-back in one launch for 1..32 rows (zl_w8a8_gemm_phase)."""
+    _chk_cuda(xq, sx, addend, out)
+    m, k = xq.shape
+    if k != w.k:
+        raise ZLError("w8a8_gemm_phase: K mismatch")
+    gated = epilogue in (W8_ACT_SILU, W8_ACT_GELU)
+    if gated != w.row_interleave:
+        raise ZLError("w8a8_gemm_phase: gated epilogues need a row-interleaved weight (and only they do)")
+    if out is None:
+        out = torch.empty((m, w.n // 2 if gated else w.n), dtype=dtype, device=xq.device)
+    check(lib().zl_w8a8_gemm_phase(_p(xq), _p(sx), _p(w.qw), _p(w.scale), _p(addend), _p(out), _i(m), _i(w.n), _i(k), _f(scale),
+                                   C.c_int(epilogue), C.c_int(_dt(out)), _stream()), "w8a8_gemm_phase")
+    return out
+
+
 def quant_calc_scale(x):
     """int8_op::quant_calc_scale (src/nn/quant/int8/quant_kernel.cu:49-103) -> (int8 (M,K), fp32 scale (M))."""
     _chk_cuda(x)
