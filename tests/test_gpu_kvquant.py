@@ -162,6 +162,38 @@ def test_decode_attention_quant_valid_lens_bf16_and_garbage_tail(oracle, dev):
         assert np.isfinite(gm).all() and np.abs(gm - exact).max() < rel * max(1.0, np.abs(exact).max())
 
 
+@pytest.mark.parametrize("h,hkv,len_q", [(32, 8, 1), (32, 32, 1), (16, 1, 1), (8, 2, 2), (16, 4, 4), (28, 4, 1)])
+@pytest.mark.parametrize("bshd", [True, False])
+def test_decode_attention_quant_matrix_core_path(oracle, dev, h, hkv, len_q, bshd):
+    """prefix visibility, fp16, D = 128, <= 16 query rows per kv head: k_decode_attn_mfma_q8 vs the fp64 oracle; ragged
+    lengths around the 32-key chunk and 128-key split boundaries; NaN scales / arbitrary codes past the visible prefix"""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(47)
+    d = 128
+    lens = [64, 64, 64, 160, 160, 160, 1088, 1088, 640]
+    valid = [1, 31, 33, 127, 128, 129, 1025, 517, 640]
+    b = len(lens)
+    host, _ = _empty_cache(lens, hkv, d, bshd, dev, rng)
+    dev_host = [[a.copy() for a in arrs] for arrs in host]
+    for bi, v in enumerate(valid):
+        for arr, poison in ((dev_host[2][bi], np.nan), (dev_host[3][bi], np.inf)):
+            if bshd:
+                arr[v:] = poison
+            else:
+                arr[:, v:] = poison
+    devt = [[_t(a, dev) for a in arrs] for arrs in dev_host]
+    q = synth.act(rng, b * len_q * h, d).reshape(b, len_q, h, d)
+    scale = 1.0 / np.sqrt(d)
+    lens_np = np.array(lens, np.int32)
+    mask = np.concatenate([np.tile((np.arange(L) < v).astype(np.int8), len_q) for L, v in zip(lens, valid)])
+    exact = oracle.mqa_rag_buffer_quant(oracle.h2u(q), lens_np, *host, mask, hkv, scale, bshd)
+    got = ops.multi_query_attention_rag_buffer_quant(_t(q, dev), _t(lens_np, dev), *[ops.make_ptr_table(x) for x in devt], None,
+                                                     scale, max(lens), hkv, valid_lens=_t(np.array(valid, np.int32), dev), bshd=bshd)
+    g = _np(got).astype(np.float64)
+    assert np.isfinite(g).all()
+    assert np.abs(g - exact).max() < 1e-3 * max(1.0, np.abs(exact).max()), np.abs(g - exact).max()
+
+
 def test_decode_attention_quant_long_split(oracle, dev):
     from zhilight_amd import ops
     rng = np.random.default_rng(45)

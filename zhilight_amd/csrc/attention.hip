@@ -805,6 +805,215 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
     }
 }
 
+// INT8 KV cache on the matrix cores: the kernel above with u8 codes in HBM (half the bytes per key).  A lane's 16-byte
+// K load holds 16 consecutive d of its key = the A fragments of TWO MFMA steps (the contraction order over d is
+// permuted accordingly: step 2u + h of lane quarter kq covers d = 16 (kq + 4u) + 8h .. +7, for K and for Q alike);
+// codes become exact fp16 (code - 128) through the 0x6400 trick (one v_perm + one v_pk_add per pair); the key's k-scale
+// multiplies its score, its v-scale its probability (before the hi + lo split; the normaliser sums the unscaled
+// probabilities); V chunks are converted in registers and staged in LDS as fp16, so the P.V half is unchanged.
+__global__ __launch_bounds__(256, 3) void k_decode_attn_mfma_q8(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t vs[4][32 * kMVS];
+    const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
+    const int len = p.buf_lens[b];
+    const int vlen_in = p.valid_lens[b];
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k_bufs[b]);
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v_bufs[b]);
+    const float* ksc = p.k_scales[b];
+    const float* vsc = p.v_scales[b];
+    const int elen = min(len, vlen_in);
+    const int t0 = split * p.split_len;
+    if (t0 >= elen || len <= 0) return;
+    const int t1 = min(elen, t0 + p.split_len);
+    const int last_key = t1 - 1;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const size_t kv_stride = p.bshd ? (size_t)p.hkv * kMD : (size_t)kMD;          // bytes
+    const size_t kv_off = p.bshd ? (size_t)hk * kMD : (size_t)hk * len * kMD;
+    const size_t sc_stride = p.bshd ? (size_t)p.hkv : 1;
+    const size_t sc_off = p.bshd ? (size_t)hk : (size_t)hk * len;
+
+    uint4 kk[2][2], vv0, vv1, vv2, vv3;
+    float ksv[2][4], vsv[2][4];
+    int c0 = t0 + wave * 32;
+#define ZL_Q8_LOAD_K(base)                                                                                     \
+    _Pragma("unroll") for (int blk_ = 0; blk_ < 2; ++blk_) {                                                   \
+        const int key_ = (base) + 16 * blk_ + r;                                                               \
+        const uint8_t* src_ = kbase + kv_off + (size_t)(key_ < last_key ? key_ : last_key) * kv_stride + 16 * kq; \
+        kk[blk_][0] = *reinterpret_cast<const uint4*>(src_);                                                   \
+        kk[blk_][1] = *reinterpret_cast<const uint4*>(src_ + 64);                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+            const int ks_ = (base) + 16 * blk_ + 4 * kq + i_;                                                  \
+            const size_t so_ = sc_off + (size_t)(ks_ < last_key ? ks_ : last_key) * sc_stride;                 \
+            ksv[blk_][i_] = ksc[so_];                                                                          \
+            vsv[blk_][i_] = vsc[so_];                                                                          \
+        }                                                                                                      \
+    }
+    // V: lane loads 16 codes of key (base + 8 j + lane / 8), d = 16 (lane % 8) .. +15
+#define ZL_Q8_V1(j_, base)                                                                                     \
+    {                                                                                                          \
+        const int key_ = (base) + 8 * j_ + (lane >> 3);                                                        \
+        vv##j_ = *reinterpret_cast<const uint4*>(vbase + kv_off + (size_t)(key_ < last_key ? key_ : last_key) * kv_stride + (lane & 7) * 16); \
+    }
+#define ZL_Q8_LOAD_V(base) ZL_Q8_V1(0, base) ZL_Q8_V1(1, base) ZL_Q8_V1(2, base) ZL_Q8_V1(3, base)
+    ZL_Q8_LOAD_K(c0)
+    ZL_Q8_LOAD_V(c0)
+
+    // Q^T fragments in the permuted d order: step t = 2u + h: d = 16 (kq + 4u) + 8h .. +7
+    h8v qf[4];
+    {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        const bool live = r < p.rows;
+        const int rr = live ? r : 0;
+        const int qi = rr / p.n_rep, head = hk * p.n_rep + rr % p.n_rep;
+        const uint16_t* qp = p.q + (((size_t)b * p.len_q + qi) * p.h + head) * kMD + 16 * kq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint4 v = *reinterpret_cast<const uint4*>(qp + 64 * (t >> 1) + 8 * (t & 1));
+            qf[t] = __builtin_bit_cast(h8v, live ? v : z);
+        }
+    }
+
+    f4v o[8];
+#pragma unroll
+    for (int db = 0; db < 8; ++db) o[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e20f, l_run = 0.f;
+    uint16_t* vsw = vs[wave];
+    const uint16_t* vtr = vsw + (4 * kq + (r >> 2)) * kMVS + 4 * (r & 3);
+    const hv2 bias = {(_Float16)1152.f, (_Float16)1152.f};
+    // 8 codes (two words) -> 8 halfs of (code - 128)
+    auto cvt8 = [&](uint32_t w0, uint32_t w1) {
+        uint4 o4;
+        o4.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(hv2, __builtin_amdgcn_perm(0x64646464u, w0, 0x04010400u)) - bias);
+        o4.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(hv2, __builtin_amdgcn_perm(0x64646464u, w0, 0x04030402u)) - bias);
+        o4.z = __builtin_bit_cast(uint32_t, __builtin_bit_cast(hv2, __builtin_amdgcn_perm(0x64646464u, w1, 0x04010400u)) - bias);
+        o4.w = __builtin_bit_cast(uint32_t, __builtin_bit_cast(hv2, __builtin_amdgcn_perm(0x64646464u, w1, 0x04030402u)) - bias);
+        return o4;
+    };
+
+    if (c0 >= t1) c0 = -1;
+    while (c0 >= 0) {
+        // ---- S^T = (K - 128) . Q^T
+        f4v st[2];
+        float ks_cur[2][4], vs_cur[2][4];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            st[blk] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint4 c = kk[blk][u];
+                st[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, cvt8(c.x, c.y)), qf[2 * u], st[blk], 0, 0, 0);
+                st[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, cvt8(c.z, c.w)), qf[2 * u + 1], st[blk], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ks_cur[blk][i] = ksv[blk][i];
+                vs_cur[blk][i] = vsv[blk][i];
+            }
+        }
+        // ---- the V chunk, converted, to LDS as fp16 (row-major); then the NEXT chunk's loads
+        {
+            uint16_t* vdst = vsw + (lane >> 3) * kMVS + (lane & 7) * 16;
+#define ZL_Q8_VST(j_)                                                                                          \
+            *reinterpret_cast<uint4*>(vdst + 8 * j_ * kMVS) = cvt8(vv##j_.x, vv##j_.y);                        \
+            *reinterpret_cast<uint4*>(vdst + 8 * j_ * kMVS + 8) = cvt8(vv##j_.z, vv##j_.w);
+            ZL_Q8_VST(0) ZL_Q8_VST(1) ZL_Q8_VST(2) ZL_Q8_VST(3)
+#undef ZL_Q8_VST
+        }
+        const int cur = c0;
+        c0 += 4 * 32;
+        ZL_Q8_LOAD_K(c0)
+        ZL_Q8_LOAD_V(c0)
+        // ---- online softmax
+        float sv[2][4];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = cur + 16 * blk + 4 * kq + i;
+                sv[blk][i] = key < t1 ? st[blk][i] * (ks_cur[blk][i] * p.scale) : -INFINITY;
+                mloc = fmaxf(mloc, sv[blk][i]);
+            }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        h8v pf, pl;
+        float lsum = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = cur + 16 * blk + 4 * kq + i;
+                const float pr = __expf(sv[blk][i] - m_new);
+                lsum += pr;
+                const float pw = key < t1 ? pr * vs_cur[blk][i] : 0.f;   // a clamped duplicate's scale is a real one; weight 0 anyway
+                const _Float16 ph = (_Float16)pw;
+                pf[blk * 4 + i] = ph;
+                pl[blk * 4 + i] = (_Float16)(pw - (float)ph);
+            }
+        }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+        }
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(vtr + 16 * db));
+            const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(vtr + 16 * kMVS + 16 * db));
+            typedef short s8v __attribute__((ext_vector_type(8)));
+            const s8v a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), pf, o[db], 0, 0, 0);
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), pl, o[db], 0, 0, 0);
+        }
+        if (c0 >= t1) break;
+    }
+#undef ZL_Q8_LOAD_K
+#undef ZL_Q8_LOAD_V
+#undef ZL_Q8_V1
+
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();
+    float* xw = reinterpret_cast<float*>(&vs[0][0]);
+    if (r < p.rows) {
+        float* dst = xw + ((size_t)wave * 16 + r) * (kMD + 2);
+#pragma unroll
+        for (int db = 0; db < 8; ++db) *reinterpret_cast<f4v*>(dst + 16 * db + 4 * kq) = o[db];
+        if (kq == 0) {
+            dst[kMD] = m_run;
+            dst[kMD + 1] = l_run;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < p.rows * kMD; idx += 256) {
+        const int i = idx / kMD, d = idx % kMD;
+        const float* src = xw + (size_t)i * (kMD + 2);
+        constexpr int WS = 16 * (kMD + 2);
+        float mn = src[kMD];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, src[w * WS + kMD]);
+        float a = 0.f, lt = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __expf(src[w * WS + kMD] - mn);
+            a = __builtin_fmaf(src[w * WS + d], f, a);
+            lt = __builtin_fmaf(src[w * WS + kMD + 1], f, lt);
+        }
+        const int qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
+        float* dst = p.ws + ((((size_t)b * p.len_q + qi) * p.h + head) * p.max_splits + split) * (kMD + 2);
+        dst[d] = a;
+        if (d == 0) {
+            dst[kMD] = mn;
+            dst[kMD + 1] = lt;
+        }
+    }
+}
+
 // grid (B*len_q*H), block D.  Split statistics go through LDS once; the per-d accumulation then issues
 // independent loads back to back (the first version walked the splits with dependent loads: 6 us).
 template <int DT, int D>
@@ -1023,6 +1232,17 @@ int zl_decode_attn_quant(const uint16_t* q, const int32_t* buf_lens, const uint8
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
     hipStream_t hs = (hipStream_t)s;
+    {   // decode fast path on the matrix cores
+        static const int use_mfma = [] { const char* e = getenv("ZL_ATTN_MFMA"); return e ? atoi(e) : 1; }();
+        if (use_mfma && !mask && dtype == ZL_F16 && d == kMD && p.len_q * p.n_rep <= 16) {
+            p.passes = 1;
+            hipLaunchKernelGGL(k_decode_attn_mfma_q8, dim3((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b), dim3(256), 0, hs, p);
+            int e = zl_launch_status();
+            if (e) return e;
+            hipLaunchKernelGGL((k_decode_attn_combine<ZL_F16, kMD>), dim3((unsigned)(b * len_q * h)), dim3(kMD), 0, hs, p);
+            return zl_launch_status();
+        }
+    }
     switch (d) {
         case 64: return dtype == ZL_F16 ? launch_q8<ZL_F16, 64>(p, hs) : launch_q8<ZL_BF16, 64>(p, hs);
         case 128: return dtype == ZL_F16 ? launch_q8<ZL_F16, 128>(p, hs) : launch_q8<ZL_BF16, 128>(p, hs);
