@@ -214,8 +214,9 @@ def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=Fal
     got = _np(y).astype(np.float64)
     # m > 16 without a fused norm runs the M-tiled kernel: it multiplies with W16 = rn16(rn16(q - z) * s), the
     # matrix the reference's M > 40 branch dequantises (dequant_k_major), so THAT product is its exact value
-    # (17..32 rows with K <= 8192 stay on the streaming arithmetic: the phase-pipelined kernel, w4_phase.hip)
-    tiled = force_tiled or (m > 16 and not norm and not (m <= 32 and k <= 8192))
+    # (up to 32 rows stay on the streaming arithmetic: the phase-pipelined kernel, w4_phase.hip -- K beyond 8192 with
+    # 17..32 rows through its K-split variant)
+    tiled = force_tiled or (m > 32 and not norm)
     w16 = oracle.gptq_dequant_k_major(*km)
     ref40 = oracle.gemm_nt(xin, w16, None if b is None else oracle.h2u(b), exact=True)
     lin = np.zeros_like(exact)
@@ -276,6 +277,23 @@ def test_phase_gemm_rounds(oracle, dev, m, rounds, monkeypatch):
     _check_mfma(oracle, dev, 1152, 16 * (3 * rounds - 1) + 8, m, seed=70 + m + rounds)                 # 2 phases, partial
     _check_mfma(oracle, dev, 4096, 16 * 2 * rounds, m, seed=71 + m + rounds, bias=True)                # 4 phases
     _check_mfma(oracle, dev, 9 * 1024 + 256, 16 * rounds + 16, m, seed=72 + m + rounds, residual=True)  # 10 phases, beyond any BODY
+
+
+@pytest.mark.parametrize("m", [17, 25, 32])
+def test_phase_gemm_k_split(oracle, dev, m):
+    """17..32 rows with K > 8192: K split over adjacent workgroups, partials merged by the last arriver in split order
+    (deterministic); ragged N, K with a partial last phase and an odd phase count, bias / residual; repeated launches
+    leave the arrival counters clean"""
+    from zhilight_amd import ops
+    _check_mfma(oracle, dev, 9 * 1024 + 256, 16 * 9 + 8, m, seed=110 + m)
+    _check_mfma(oracle, dev, 14336, 256, m, seed=111 + m, bias=True)
+    _check_mfma(oracle, dev, 14336, 512, m, seed=112 + m, residual=True)
+    rng = np.random.default_rng(113)
+    w = ops.W4MWeight.random(1024, 14336, 128, dev)
+    x = _t(synth.act(rng, m, 14336), dev)
+    y0 = ops.w4a16_gemm_mfma(x, w)
+    for _ in range(5):
+        assert torch.equal(ops.w4a16_gemm_mfma(x, w), y0)
 
 
 @pytest.mark.parametrize("m", [8, 24])

@@ -276,6 +276,23 @@ void* zlint_workspace(size_t bytes) {
     return np;
 }
 
+// zeroed per-device counters for in-launch last-arriver hand-offs (users leave them zero)
+extern "C" int* zlint_counters(void) {
+    static int* g_cnt[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_cnt[dev]) {
+        int* np = nullptr;
+        if (hipMalloc(&np, 16384 * sizeof(int)) != hipSuccess || hipMemset(np, 0, 16384 * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        (void)hipDeviceSynchronize();
+        g_cnt[dev] = np;
+    }
+    return g_cnt[dev];
+}
+
 int zl_workspace_reserve(int64_t bytes) {
     ZL_CHECK_ARG(bytes >= 0, ZL_EINVAL);
     return zlint_workspace((size_t)bytes) || bytes == 0 ? ZL_OK : ZL_ELIMIT;

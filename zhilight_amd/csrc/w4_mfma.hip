@@ -620,7 +620,10 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const
     {
         auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         static const int ph_min_m = env_int("ZL_W4_PHASE_MIN_M", 5), ph_max_m = env_int("ZL_W4_PHASE_MAX_M", 32);
-        static const int ph_maxk_16 = env_int("ZL_W4_PHASE_MAXK16", 1 << 30), ph_maxk_32 = env_int("ZL_W4_PHASE_MAXK32", 8192);
+        static const int ph_ksplit = env_int("ZL_W4_PHASE_KSPLIT", 2);   // long K, 17..32 rows: K split inside the phase kernel
+        static const int ph_maxk_16 = env_int("ZL_W4_PHASE_MAXK16", 1 << 30);
+        const bool can_split = (ph_ksplit == 2 || ph_ksplit == 4) && !silu && !norm_weight;
+        const int ph_maxk_32 = can_split ? (1 << 30) : env_int("ZL_W4_PHASE_MAXK32", 8192);
         const int ph_rounds = env_int("ZL_W4_PHASE_ROUNDS", 0);   // read per call: the tests sweep it
         static const int ph_small = env_int("ZL_W4_PHASE_SMALL", 1);   // 1..4 rows with K <= 4096 (incl. the fused norm)
         const bool rows_5_32 = !norm_weight && m >= ph_min_m && m <= ph_max_m && m <= 32 && k <= (m <= 16 ? ph_maxk_16 : ph_maxk_32);

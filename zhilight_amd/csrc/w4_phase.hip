@@ -57,6 +57,11 @@ struct PhaseParams {
     uint16_t* q_out;            // (M, H * D)
     int h, hkv, d, bshd;
     int pair_stride;            // tiles between a column and its rotation partner: D / 32
+    // KS > 1 instantiations: K split over KS adjacent workgroups (long K with 17..32 rows: halves / quarters the
+    // activation bytes each workgroup pulls through L2); fp32 partials meet in ks_ws, the last arriver sums them in
+    // split order and runs the epilogue
+    float* ks_ws;               // [KS][M][N]
+    int* ks_counter;            // one per tile group, zero between launches
 };
 
 constexpr int ring_depth(int r) { return r == 1 ? 3 : r == 2 ? 4 : r == 3 ? 6 : r == 4 ? 8 : r; }
@@ -94,9 +99,10 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)
 // ROPE (R = 2): the workgroup's two tiles are a column block and its rotation partners (D/2 columns = D/32 tiles
 // further), so the neox rotation of q and k happens in the epilogue on the fp16-rounded projection outputs, with the
 // roundings of the separate kernels (rope_common.cuh:14-34: one rounding to T after the fp32 rotation).
-template <int R, int MB, bool NORM, bool ROPE>
+template <int R, int MB, bool NORM, bool ROPE, int KS = 1>
 __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
+    static_assert(KS == 1 || (!ROPE && !NORM), "K split: plain / bias / residual epilogues only");
     constexpr int D = ring_depth(R), XP = NORM ? 1 : x_ahead(R), BODY = lcm_(D, R * XP);
     static_assert(!NORM || MB == 1, "fused norm: one row block");
     constexpr int XC = 4 * MB;                       // 16-byte x chunks per thread per phase (16 MB rows x 128 chunks)
@@ -109,9 +115,12 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nrow = lane & 15, kq = lane >> 4;
-    const int P = p.phases, total = P * R;
+    // K split: workgroup (tile group tg, split ksi) streams phases ph0 .. ph0 + P - 1 of its R tiles
+    const int ksi = KS > 1 ? (int)(blockIdx.x % KS) : 0, tg = KS > 1 ? (int)(blockIdx.x / KS) : (int)blockIdx.x;
+    const int PP = (p.phases + KS - 1) / KS, ph0 = ksi * PP;
+    const int P = KS > 1 ? max(0, min(p.phases, ph0 + PP) - ph0) : p.phases, total = P * R;
     // ROPE: workgroup b owns tiles {base, base + s}, base = (b / s) * 2 s + b % s  (s = pair_stride)
-    const int tile0 = ROPE ? (blockIdx.x / p.pair_stride) * 2 * p.pair_stride + blockIdx.x % p.pair_stride : blockIdx.x * R;
+    const int tile0 = ROPE ? (blockIdx.x / p.pair_stride) * 2 * p.pair_stride + blockIdx.x % p.pair_stride : tg * R;
     const int tile_stride = ROPE ? p.pair_stride : 1;
 
     // ---- activations: chunk c of a thread = row (tid >> 7) + 4 c, halfs 8 (tid & 127) .. +7 of the phase
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     auto load_x = [&](int set, int ph) {             // set: static
 #pragma unroll
         for (int c = 0; c < XC; ++c) {
-            const int row = xrow0 + 4 * c, kk = ph * kPK + xcc;
+            const int row = xrow0 + 4 * c, kk = (ph0 + ph) * kPK + xcc;
             const bool live = row < p.m && kk < p.k && ph < P;
             const uint16_t* src = p.x + (live ? (size_t)row * p.ldx + kk : 0);
             xr[set][c] = *reinterpret_cast<const uint4*>(src);
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     uint32_t mt[D];
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
-    const uint32_t it0 = (uint32_t)tile0 * (uint32_t)p.groups + (uint32_t)wave;
+    const uint32_t it0 = (uint32_t)tile0 * (uint32_t)p.groups + (uint32_t)(ph0 * kW) + (uint32_t)wave;
     uint32_t qs = it0 * 1024u, ms = it0 * 64u;
     const int tile_step = tile_stride * p.groups, phase_step = kW - (R - 1) * tile_stride * p.groups;
     const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)nrow * 4u;
@@ -335,6 +344,52 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     }
     __syncthreads();
     const float* redf = reinterpret_cast<const float*>(red);
+    if constexpr (KS > 1) {
+        // partials: agent-scope (write-through) stores; the barrier below waits for them (vmcnt(0)); one agent-scope
+        // atomic per workgroup elects the last arriver, which reads all KS partials back with agent-scope loads
+        auto total_of = [&](int r, int n_local, int m) {
+            const int b = m >> 4, ln = ((m & 15) >> 2) * 16 + n_local, i = m & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) v += redf[(((size_t)(r * MB + b) * kW + w) * 64 + ln) * 4 + i];
+            return v;
+        };
+        const int nouts = R * 16 * p.m;
+        for (int o = threadIdx.x; o < nouts; o += kT) {
+            const int r = o / (16 * p.m), rem = o % (16 * p.m);
+            const int m = rem >> 4, n_local = rem & 15, col = (tile0 + r) * 16 + n_local;
+            if (col < p.n) __hip_atomic_store(p.ks_ws + ((size_t)ksi * p.m + m) * p.n + col, total_of(r, n_local, m), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(p.ks_counter + tg, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == KS - 1) __hip_atomic_store(p.ks_counter + tg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = old == KS - 1;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        for (int o = threadIdx.x; o < nouts; o += kT) {
+            const int r = o / (16 * p.m), rem = o % (16 * p.m);
+            const int m = rem >> 4, n_local = rem & 15, row = (tile0 + r) * 16 + n_local;
+            if (row >= p.n) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int sp = 0; sp < KS; ++sp)
+                v += __hip_atomic_load(p.ks_ws + ((size_t)sp * p.m + m) * p.n + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const size_t orow = (size_t)m * p.ld_out;
+            const float bb = ((p.epi & ZL_EPI_BIAS) && p.bias) ? (float)__builtin_bit_cast(_Float16, p.bias[row]) : 0.f;
+            float ov;
+            if (p.epi & ZL_EPI_ADD_C) ov = ((float)__builtin_bit_cast(_Float16, p.y[orow + row]) + v) + bb;
+            else ov = v + bb;
+            _Float16 y16 = zl_f32_to_f16(ov);
+            if (p.epi & ZL_EPI_RESIDUAL)
+                y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, p.residual[orow + row]) + (float)y16);
+            p.y[orow + row] = __builtin_bit_cast(uint16_t, y16);
+        }
+        return;
+    }
     if constexpr (ROPE) {
         const int half = p.d / 2;
         for (int o = threadIdx.x; o < 16 * p.m; o += kT) {
@@ -437,7 +492,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     }
 }
 
-template <int R, int MB, bool NORM, bool ROPE = false>
+template <int R, int MB, bool NORM, bool ROPE = false, int KS = 1>
 int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
     constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS * 2 + (NORM ? 4 * kW * 4 : 0);
     constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
@@ -446,17 +501,20 @@ int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
     if (lds > 64 * 1024) {
         static bool done = false;   // per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE, KS>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return ZL_ELIMIT;
             done = true;
         }
     }
-    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS>), dim3(grid), dim3(kT), lds, hs, p);
     return zl_launch_status();
 }
 
 }  // namespace
+
+extern "C" void* zlint_workspace(size_t bytes);   // misc_ops.hip: per-device scratch (grow-only; reserve before capture)
+extern "C" int* zlint_counters(void);             // misc_ops.hip: per-device zeroed int[16384]
 
 // internal (called by zl_w4a16_gemm_mfma): 1 <= m <= 32; norm_w != null (fused RMSNorm): m <= 4 and k <= 4096.
 // rounds_override: 0 = pick
@@ -471,6 +529,18 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = epilogue; p.ld_out = ld_out; p.norm_w = norm_w; p.norm_eps = norm_eps;
     p.cosv = p.sinv = nullptr; p.placement = p.buf_lens = nullptr; p.k_bufs = p.v_bufs = nullptr; p.q_out = nullptr;
     p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
+    p.ks_ws = nullptr; p.ks_counter = nullptr;
+    {   // long K with more than 16 rows: K split over 2 or 4 adjacent workgroups (R = KS tiles each, same grid size)
+        static const int ksplit = [] { const char* e = getenv("ZL_W4_PHASE_KSPLIT"); return e ? atoi(e) : 2; }();
+        const bool plain = !(epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) && !norm_w;
+        if ((ksplit == 2 || ksplit == 4) && m > 16 && k > 8192 && plain && tiles / ksplit <= 16384) {
+            p.ks_ws = reinterpret_cast<float*>(zlint_workspace((size_t)ksplit * m * n * sizeof(float)));
+            p.ks_counter = zlint_counters();
+            if (!p.ks_ws || !p.ks_counter) return ZL_ELIMIT;
+            const int grid = (tiles + ksplit - 1) / ksplit * ksplit;
+            return ksplit == 2 ? launch_phase<2, 2, false, false, 2>(p, grid, hs) : launch_phase<4, 2, false, false, 4>(p, grid, hs);
+        }
+    }
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
     // tiles per workgroup: one generation of workgroups when 8 tiles per CU suffice, else full-size workgroups
