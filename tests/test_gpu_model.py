@@ -670,3 +670,33 @@ def test_int8_kv_cache_env_switch(dev, monkeypatch):
     monkeypatch.setenv("KV_CACHE_DTYPE", "fp8")
     with pytest.raises(ops.ZLError):
         model.new_context(1, 16, 0)
+
+
+@pytest.mark.parametrize("batch", [5, 20, 40])
+def test_decode_batch_sizes_cover_every_linear_kernel(oracle, dev, batch):
+    """batches that take the other W4A16 routes: 5 (phase kernel, one row block, separate RMSNorm, fused qkv+rotary),
+    20 (two row blocks; K-split for the long-K down projection), 40 (M-tiled kernel: the W16 arithmetic of the reference's
+    M > 40 branch, unfused rotary) -- two steps each against the oracle with exact linears (1e-3; 3e-3 for the tiled route,
+    whose fp16 weight rounding the E oracle does not model)"""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(31 + batch)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=9 * 1024 + 256, vocab_size=512, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5,
+                      rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                    "original_max_position_embeddings": 8192})
+    g = 128
+    sd = _hf_state(rng, cfg, g)
+    model = LLaMA(cfg, QuantConfig(5, g), dev).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    len_buf = 64
+    ctx = model.new_context(batch, len_buf, 0)
+    om = OracleModel(oracle, cfg, sd, g, batch, len_buf)
+    tokens = rng.integers(0, cfg.vocab_size, batch).astype(np.int32)
+    ctx.tokens.copy_(torch.from_numpy(tokens))
+    for step in range(2):
+        got = model.encode(ctx).float().cpu().numpy().astype(np.float64)
+        ref, _ = om.step(tokens, [step] * batch, flavour="E")
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= (3e-3 if batch > 32 else 1e-3) * scale, (step, np.abs(got - ref).max() / scale)
+        nxt = ref.argmax(axis=1)
+        model.advance(ctx, torch.from_numpy(nxt).to(dev))
+        tokens = nxt.astype(np.int32)
