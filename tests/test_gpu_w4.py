@@ -279,7 +279,7 @@ def test_phase_gemm_rounds(oracle, dev, m, rounds, monkeypatch):
     _check_mfma(oracle, dev, 9 * 1024 + 256, 16 * rounds + 16, m, seed=72 + m + rounds, residual=True)  # 10 phases, beyond any BODY
 
 
-@pytest.mark.parametrize("m", [17, 25, 32])
+@pytest.mark.parametrize("m", [13, 16, 17, 25, 32])
 def test_phase_gemm_k_split(oracle, dev, m):
     """17..32 rows with K > 8192: K split over adjacent workgroups, partials merged by the last arriver in split order
     (deterministic); ragged N, K with a partial last phase and an odd phase count, bias / residual; repeated launches
