@@ -296,6 +296,23 @@ def test_phase_gemm_k_split(oracle, dev, m):
         assert torch.equal(ops.w4a16_gemm_mfma(x, w), y0)
 
 
+def test_streaming_gemm_random_shapes(oracle, dev, monkeypatch):
+    """40 seeded random (M, N, K, epilogue, tiles-per-workgroup) draws over the streaming kernels' whole dispatch range
+    (1..32 rows; fused norm where the launcher offers it; K from one partial phase to 20 phases; ragged N)"""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        m = int(rng.integers(1, 33))
+        k = 128 * int(rng.integers(1, 161))
+        n = 8 * int(rng.integers(2, 80))
+        norm = bool(rng.integers(0, 2)) and m <= 4 and k <= 4096
+        kind = int(rng.integers(0, 3))
+        if rng.integers(0, 2):
+            monkeypatch.setenv("ZL_W4_PHASE_ROUNDS", str(int(rng.integers(1, 9))))
+        else:
+            monkeypatch.delenv("ZL_W4_PHASE_ROUNDS", raising=False)
+        _check_mfma(oracle, dev, k, n, m, seed=1000 + case, bias=kind == 1, residual=kind == 2 and not norm, norm=norm)
+
+
 @pytest.mark.parametrize("m", [8, 24])
 def test_phase_gemm_silu_mul(oracle, dev, m):
     from zhilight_amd import ops
