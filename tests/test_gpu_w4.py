@@ -296,6 +296,16 @@ def test_phase_gemm_k_split(oracle, dev, m):
         assert torch.equal(ops.w4a16_gemm_mfma(x, w), y0)
 
 
+@pytest.mark.parametrize("k,n,norm,bias", [(8192, 2560, True, True), (2048, 8192, False, False), (8192, 1856, True, False), (7424, 1024, False, False)])
+def test_qwen2_72b_tp4_rank_shapes(oracle, dev, k, n, norm, bias):
+    """per-rank projections of BASELINE configs[3] (Qwen2-72B GPTQ-Int4, TP = 4: dim 8192, 16 + 2 x 2 heads of 128, dim_ff
+    29696 / 4 = 7424 = 58 groups; qkv carries a bias; gate|up and o cut to 1/8 of their rows to keep the CPU oracle
+    quick): decode rows 1 and 8"""
+    _check_mfma(oracle, dev, k, n, 1, seed=300 + n, norm=norm, bias=bias)
+    _check_mfma(oracle, dev, k, n, 8, seed=301 + n, bias=bias)
+    _check_mfma(oracle, dev, k, n, 20, seed=302 + n, residual=not bias)
+
+
 def test_streaming_gemm_random_shapes(oracle, dev, monkeypatch):
     """40 seeded random (M, N, K, epilogue, tiles-per-workgroup) draws over the streaming kernels' whole dispatch range
     (1..32 rows; fused norm where the launcher offers it; K from one partial phase to 20 phases; ragged N)"""
