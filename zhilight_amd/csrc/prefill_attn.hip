@@ -7,8 +7,11 @@
 // flash-attn does), fp32 accumulation.
 //
 // One workgroup = 64 query rows of one q head, 4 waves x 16 rows; key tiles of 64 rows go through LDS
-// once per workgroup (K as stored; V transposed and key-permuted on the way in, so that every MFMA
-// operand is one ds_read_b128).  Orientation: S^T = K.Q^T, so a lane's score registers belong to ONE
+// once per workgroup, both as stored (coalesced ds_write_b128); the V fragments of the P.V product (lane = column d,
+// 8 keys) come out of the row-major tile through ds_read_b64_tr_b16 (a 16-lane group reads a 4-key x 16-d block, lane i
+// gets column i: tools/ubench/tr_probe.hip) -- the first version transposed V with 32 two-byte LDS writes per thread
+// and tile (53.7 -> 48.7 us at S = 1024).  Tried on top, no gain: the next tile's loads one tile ahead in registers
+// (50.8 us), query tiles rotated by the head index so that every XCD sees every tile length (55.6 us).  Orientation: S^T = K.Q^T, so a lane's score registers belong to ONE
 // query (lane & 15) -- row maxima need two cross-lane steps -- and, rounded to fp16, ARE the A operand
 // of the P.V product (k index = key) with no transposition.  O accumulates in the C layout (rows 4 kq + i),
 // its per-row rescale factors cross over through a 64-byte LDS strip per wave.
@@ -19,7 +22,7 @@ namespace {
 
 constexpr int kBQ = 64, kBK = 64, kD = 128;
 constexpr int kKRow = kD + 8;       // K tile row (halfs), padded: conflict-free b128 reads
-constexpr int kVRow = kBK + 8;      // V^T tile row (halfs)
+constexpr int kVRow = kD + 16;      // V tile row (halfs): 288 B, conflict-free transpose reads
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -34,13 +37,9 @@ struct PrefillParams {
     float scale;
 };
 
-// position of key `kk` (0..31 inside a 32-key group) in the permuted V^T row: the 8 keys that form one MFMA
-// A/B k-chunk for lane group kq -- {4 kq + i} and {16 + 4 kq + i} -- are contiguous
-__device__ __forceinline__ int vperm(int kk) { return ((kk & 15) >> 2) * 8 + (kk >> 4) * 4 + (kk & 3); }
-
 __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t ks[kBK * kKRow];
-    __shared__ __attribute__((aligned(16))) uint16_t vt[kD * kVRow];
+    __shared__ __attribute__((aligned(16))) uint16_t vt[kBK * kVRow];
     __shared__ __attribute__((aligned(16))) float strip[4][16];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -80,7 +79,6 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
             const int kc = kg < n_keys ? kg : n_keys - 1;
             const uint16_t* kp = p.k + kv_off + (size_t)kc * kv_stride;
             const uint16_t* vp = p.v + kv_off + (size_t)kc * kv_stride;
-            const int vcol = (key >> 5) * 32 + vperm(key & 31);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int dch = (threadIdx.x >> 6) + 4 * c;       // 16 chunks of 8 d
@@ -88,10 +86,7 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
                 uint4 vv4 = *reinterpret_cast<const uint4*>(vp + dch * 8);
                 if (kg >= n_keys) vv4 = make_uint4(0, 0, 0, 0);   // finite: its probability is exactly 0
                 *reinterpret_cast<uint4*>(&ks[key * kKRow + dch * 8]) = kv4;
-                const uint32_t vw[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    vt[(dch * 8 + e) * kVRow + vcol] = (uint16_t)((vw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                *reinterpret_cast<uint4*>(&vt[key * kVRow + dch * 8]) = vv4;
             }
         }
         __syncthreads();
@@ -148,13 +143,19 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
         for (int db = 0; db < 8; ++db) {
             o[db][0] *= al[0]; o[db][1] *= al[1]; o[db][2] *= al[2]; o[db][3] *= al[3];
         }
-        // ---- O += P . V : 2 key groups x 8 d blocks
+        // ---- O += P . V : 2 key groups x 8 d blocks; B fragment (column d = 16 db + nq, keys 32 j + {4 kq + i, 16 + 4 kq + i})
+        //      = two transposed 8-byte reads of the row-major V tile
+        const uint16_t* vtr = vt + (4 * kq + (nq >> 2)) * kVRow + 4 * (nq & 3);
+        typedef short s4 __attribute__((ext_vector_type(4)));
+        typedef short s8 __attribute__((ext_vector_type(8)));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int db = 0; db < 8; ++db) {
-                const h8 b = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&vt[(db * 16 + nq) * kVRow + j * 32 + 8 * kq]));
-                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[j], b, o[db], 0, 0, 0);
+                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(vtr + (32 * j) * kVRow + 16 * db));
+                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(vtr + (32 * j + 16) * kVRow + 16 * db));
+                const s8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[j], __builtin_bit_cast(h8, b), o[db], 0, 0, 0);
             }
         }
     }
