@@ -86,6 +86,9 @@ def test_rope_tables_and_fused_qk(oracle, dev, theta):
         gq, gk, gv = ops.rope_qk_cache(_t(rc, dev), _t(rs, dev), _t(x, dev), h, hkv, d, neox)
         assert np.array_equal(_bits(gv), rv)
         assert np.array_equal(_bits(gq), rq) and np.array_equal(_bits(gk), rk)
+        # a few rows only: the element-per-thread kernel (>= 16 rows run the 16-byte-per-thread one above)
+        gq5, gk5, gv5 = ops.rope_qk_cache(_t(rc[:5], dev), _t(rs[:5], dev), _t(x[:5], dev), h, hkv, d, neox)
+        assert np.array_equal(_bits(gq5), rq[:5]) and np.array_equal(_bits(gk5), rk[:5]) and np.array_equal(_bits(gv5), rv[:5])
 
 
 def _make_kv(rng, lens, hkv, d, bshd, dev, dtype=0, oracle=None):

@@ -126,6 +126,57 @@ __global__ void k_rope_qk(const int32_t* __restrict__ pos, const float* __restri
     dst[col] = ZT<DT>::from_f32(r);
 }
 
+// Prompt-sized rope_qk_cache: grid S, block 256; a thread rotates 8 consecutive head-dim elements per trip (16-byte
+// accesses; the element-per-thread kernel above spent 15.8 us on a 1024-token chunk, 2-byte accesses).  Same fp32
+// expression per element (rope_val), so the outputs are bit-identical.
+template <int DT>
+__global__ __launch_bounds__(256) void k_rope_qk_vec(const float* __restrict__ cosv, const float* __restrict__ sinv,
+                                                     const uint16_t* __restrict__ in, uint16_t* __restrict__ q,
+                                                     uint16_t* __restrict__ k, uint16_t* __restrict__ v, int h, int hkv, int d,
+                                                     int neox) {
+    const int t = blockIdx.x, all = h + 2 * hkv, half = d / 2, cpr = d / 8;
+    const uint16_t* row = in + (size_t)t * all * d;
+    for (int c = threadIdx.x; c < all * cpr; c += 256) {
+        const int head = c / cpr, d0 = (c % cpr) * 8;
+        const uint16_t* src = row + (size_t)head * d;
+        const uint4 a = *reinterpret_cast<const uint4*>(src + d0);
+        if (head >= h + hkv) {
+            *reinterpret_cast<uint4*>(v + ((size_t)t * hkv + (head - h - hkv)) * d + d0) = a;
+            continue;
+        }
+        const int pd0 = neox ? (d0 < half ? d0 + half : d0 - half) : d0;
+        const uint4 b = *reinterpret_cast<const uint4*>(src + pd0);
+        const uint32_t au[4] = {a.x, a.y, a.z, a.w}, bu[4] = {b.x, b.y, b.z, b.w};
+        float af[8], bf[8], cs[8], sn[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            af[2 * e] = ZT<DT>::to_f32((uint16_t)(au[e] & 0xffff));
+            af[2 * e + 1] = ZT<DT>::to_f32((uint16_t)(au[e] >> 16));
+            bf[2 * e] = ZT<DT>::to_f32((uint16_t)(bu[e] & 0xffff));
+            bf[2 * e + 1] = ZT<DT>::to_f32((uint16_t)(bu[e] >> 16));
+        }
+        const float4* cp = reinterpret_cast<const float4*>(cosv + (size_t)t * d + d0);
+        const float4* sp = reinterpret_cast<const float4*>(sinv + (size_t)t * d + d0);
+        const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+        cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+        sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            float r[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = e + u;
+                if (neox) r[u] = rope_val(af[i], bf[i], cs[i], sn[i], d0 < half);
+                else r[u] = rope_val(af[i], af[i ^ 1], cs[i], sn[i], (i & 1) == 0);
+            }
+            o[e / 2] = (uint32_t)ZT<DT>::from_f32(r[0]) | ((uint32_t)ZT<DT>::from_f32(r[1]) << 16);
+        }
+        uint16_t* dst = head >= h ? k + ((size_t)t * hkv + (head - h)) * d : q + ((size_t)t * h + head) * d;
+        *reinterpret_cast<uint4*>(dst + d0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // KV scatter.  src/kvcache/ragged_buffer_kernel.cu:194-222.  grid (B, len_q, Hkv), block D/8 (16 B lanes)
 // ------------------------------------------------------------------------------------------------
@@ -357,6 +408,13 @@ int zl_rope_qk_cache(const float* cosv, const float* sinv, const uint16_t* in, u
                      int64_t s_len, int64_t h, int64_t hkv, int64_t d, int neox, int dtype, zl_stream_t s) {
     ZL_CHECK_ARG(cosv && sinv && in && q && k && v && s_len > 0 && h > 0 && hkv > 0 && d > 0, ZL_EINVAL);
     ZL_CHECK_ARG(d <= 1024 && d % 2 == 0 && h + 2 * hkv <= 65535, ZL_ESHAPE);
+    if (s_len >= 16 && d % 16 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 &&
+        ((uintptr_t)v & 15) == 0 && ((uintptr_t)cosv & 15) == 0 && ((uintptr_t)sinv & 15) == 0) {   // prompt chunks
+        ZL_DT_SWITCH(dtype,
+            hipLaunchKernelGGL(k_rope_qk_vec<ZL_F16>, dim3((unsigned)s_len), dim3(256), 0, (hipStream_t)s, cosv, sinv, in, q, k, v, (int)h, (int)hkv, (int)d, neox),
+            hipLaunchKernelGGL(k_rope_qk_vec<ZL_BF16>, dim3((unsigned)s_len), dim3(256), 0, (hipStream_t)s, cosv, sinv, in, q, k, v, (int)h, (int)hkv, (int)d, neox))
+        return zl_launch_status();
+    }
     dim3 grid((unsigned)s_len, (unsigned)(h + 2 * hkv));
     ZL_DT_SWITCH(dtype,
         hipLaunchKernelGGL((k_rope_qk<ZL_F16, 1>), grid, dim3((unsigned)d), 0, (hipStream_t)s, nullptr, cosv, sinv, in, q, k, v, (int)h, (int)hkv, (int)d, 0.f, neox),
