@@ -10,8 +10,9 @@
 // once per workgroup, both as stored (coalesced ds_write_b128); the V fragments of the P.V product (lane = column d,
 // 8 keys) come out of the row-major tile through ds_read_b64_tr_b16 (a 16-lane group reads a 4-key x 16-d block, lane i
 // gets column i: tools/ubench/tr_probe.hip) -- the first version transposed V with 32 two-byte LDS writes per thread
-// and tile (53.7 -> 48.7 us at S = 1024).  Tried on top, no gain: the next tile's loads one tile ahead in registers
-// (50.8 us), query tiles rotated by the head index so that every XCD sees every tile length (55.6 us).  Orientation: S^T = K.Q^T, so a lane's score registers belong to ONE
+// and tile (53.7 -> 48.7 us at S = 1024); the next tile's loads ride one tile ahead in registers (another -10 %: a lone
+// workgroup spends ~2.7 us per 64-key tile, mostly LDS + VALU: each of the 4 waves re-reads the whole K tile).  Query
+// tiles rotated by the head index so that every XCD sees every tile length changed nothing.  Orientation: S^T = K.Q^T, so a lane's score registers belong to ONE
 // query (lane & 15) -- row maxima need two cross-lane steps -- and, rounded to fp16, ARE the A operand
 // of the P.V product (k index = key) with no transposition.  O accumulates in the C layout (rows 4 kq + i),
 // its per-row rescale factors cross over through a 64-byte LDS strip per wave.
@@ -69,27 +70,35 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
     const int n_keys = p.pos0 + last_q + 1;               // keys any row of this block may see
     const int n_tiles = (n_keys + kBK - 1) / kBK;
 
+    // K / V tile loads ride in registers one tile ahead (thread -> key = tid % 64, d chunks tid / 64 + 4 c): a workgroup
+    // is one latency chain per tile otherwise (3 us per 64-key tile, ~2 of them waiting for the loads)
+    uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;         // (named: as arrays filled from two places they end up on the stack)
+    const int skey = threadIdx.x & 63, sdch = threadIdx.x >> 6;
+#define ZL_PF_LOAD1(c_, kp_, vp_, dead_)                                                                   \
+    kr##c_ = *reinterpret_cast<const uint4*>((kp_) + (sdch + 4 * c_) * 8);                               \
+    vr##c_ = *reinterpret_cast<const uint4*>((vp_) + (sdch + 4 * c_) * 8);                               \
+    if (dead_) vr##c_ = make_uint4(0, 0, 0, 0);           /* finite: its probability is exactly 0 */
+#define ZL_PF_LOAD(tile_)                                                                                  \
+    {                                                                                                      \
+        const int kg_ = (tile_) * kBK + skey;                                                              \
+        const int kc_ = kg_ < n_keys ? kg_ : n_keys - 1;                                                   \
+        const uint16_t* kp_ = p.k + kv_off + (size_t)kc_ * kv_stride;                                     \
+        const uint16_t* vp_ = p.v + kv_off + (size_t)kc_ * kv_stride;                                     \
+        const bool dead_ = kg_ >= n_keys;                                                                  \
+        ZL_PF_LOAD1(0, kp_, vp_, dead_) ZL_PF_LOAD1(1, kp_, vp_, dead_) ZL_PF_LOAD1(2, kp_, vp_, dead_) ZL_PF_LOAD1(3, kp_, vp_, dead_) \
+    }
+    ZL_PF_LOAD(0)
+
     for (int tile = 0; tile < n_tiles; ++tile) {
         const int key0 = tile * kBK;
         __syncthreads();                                  // previous tile fully consumed
-        // ---- stage K (as is) and V (transposed, key-permuted) : thread -> key = tid % 64, d chunks tid / 64 + 4 c
-        {
-            const int key = threadIdx.x & 63;
-            const int kg = key0 + key;
-            const int kc = kg < n_keys ? kg : n_keys - 1;
-            const uint16_t* kp = p.k + kv_off + (size_t)kc * kv_stride;
-            const uint16_t* vp = p.v + kv_off + (size_t)kc * kv_stride;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int dch = (threadIdx.x >> 6) + 4 * c;       // 16 chunks of 8 d
-                const uint4 kv4 = *reinterpret_cast<const uint4*>(kp + dch * 8);
-                uint4 vv4 = *reinterpret_cast<const uint4*>(vp + dch * 8);
-                if (kg >= n_keys) vv4 = make_uint4(0, 0, 0, 0);   // finite: its probability is exactly 0
-                *reinterpret_cast<uint4*>(&ks[key * kKRow + dch * 8]) = kv4;
-                *reinterpret_cast<uint4*>(&vt[key * kVRow + dch * 8]) = vv4;
-            }
-        }
+#define ZL_PF_ST(c_)                                                                                       \
+        *reinterpret_cast<uint4*>(&ks[skey * kKRow + (sdch + 4 * c_) * 8]) = kr##c_;                       \
+        *reinterpret_cast<uint4*>(&vt[skey * kVRow + (sdch + 4 * c_) * 8]) = vr##c_;
+        ZL_PF_ST(0) ZL_PF_ST(1) ZL_PF_ST(2) ZL_PF_ST(3)
+#undef ZL_PF_ST
         __syncthreads();
+        ZL_PF_LOAD(tile + 1)                              // clamped past the end; in flight during this tile's MFMAs
 
         // ---- S^T = K . Q^T : 4 key blocks x 4 d steps; lane: query nq, keys key0 + 16 kb + 4 kq + i
         f4 st[4];
@@ -160,6 +169,8 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
         }
     }
 
+#undef ZL_PF_LOAD
+#undef ZL_PF_LOAD1
     // ---- normalise: l of query nq = sum over its 4 lanes; bring 1/l to the C layout through the strip
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
