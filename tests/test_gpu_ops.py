@@ -181,35 +181,38 @@ def test_decode_attention_valid_lens_and_bf16(oracle, dev):
 
 @pytest.mark.parametrize("h,hkv,len_q", [(32, 8, 1), (32, 32, 1), (16, 1, 1), (8, 2, 2), (16, 4, 4), (28, 4, 1), (24, 8, 5)])
 @pytest.mark.parametrize("bshd", [True, False])
-def test_decode_attention_matrix_core_path(oracle, dev, h, hkv, len_q, bshd):
-    """prefix visibility (valid_lens), fp16, D = 128, up to 16 query rows per kv head: k_decode_attn_mfma (probabilities
-    rounded to fp16 inside the P.V product, fp32 accumulation) vs the fp64 oracle; ragged lengths around the 32-key
-    chunk and 128-key split boundaries; NaN in the never-visible tail of V must not leak."""
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_decode_attention_matrix_core_path(oracle, dev, h, hkv, len_q, bshd, dtype):
+    """prefix visibility (valid_lens), fp16 / bf16, D = 128, up to 16 query rows per kv head: k_decode_attn_mfma
+    (probabilities as a hi + lo pair, fp32 accumulation) vs the fp64 oracle; ragged lengths around the 32-key chunk and
+    128-key split boundaries; NaN in the never-visible tail of V must not leak."""
     from zhilight_amd import ops
     rng = np.random.default_rng(33)
     d = 128
     lens = [64, 64, 64, 160, 160, 160, 1088, 1088, 640]
     valid = [1, 31, 33, 127, 128, 129, 1025, 517, 640]
     b = len(lens)
-    kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, bshd, dev, oracle=oracle)
+    kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, bshd, dev, dtype, oracle)
+    tdt = torch.bfloat16 if dtype else torch.float16
     for bi, (L, v) in enumerate(zip(lens, valid)):       # poison (device copy only) what must never reach the result
         if v < L:
             pv = vb[bi].copy()
             if bshd:
-                pv[v:] = np.uint16(0x7e00)
+                pv[v:] = np.uint16(0x7fc0 if dtype else 0x7e00)
             else:
-                pv[:, v:] = np.uint16(0x7e00)
-            dv[bi].copy_(_t(pv.view(np.int16), dev, torch.float16))
-    q = synth.act(rng, b * len_q * h, d).reshape(b, len_q, h, d)
+                pv[:, v:] = np.uint16(0x7fc0 if dtype else 0x7e00)
+            dv[bi].copy_(_t(pv.view(np.int16), dev, tdt))
+    q = _to_bits(rng.standard_normal((b, len_q, h, d)), dtype, oracle)
     scale = 1.0 / np.sqrt(d)
     mask = np.concatenate([np.tile((np.arange(L) < v).astype(np.int8), len_q) for L, v in zip(lens, valid)])
-    exact = oracle.mqa_rag_buffer(oracle.h2u(q), np.array(lens, np.int32), kb, vb, mask, hkv, scale, bshd, exact=True)
-    got = ops.multi_query_attention_rag_buffer(_t(q, dev), _t(np.array(lens, np.int32), dev), ops.make_ptr_table(dk),
+    exact = oracle.mqa_rag_buffer(q, np.array(lens, np.int32), kb, vb, mask, hkv, scale, bshd, dtype=dtype, exact=True)
+    got = ops.multi_query_attention_rag_buffer(_tt(q, dev, dtype), _t(np.array(lens, np.int32), dev), ops.make_ptr_table(dk),
                                                ops.make_ptr_table(dv), None, scale, max(lens), hkv,
                                                valid_lens=_t(np.array(valid, np.int32), dev), bshd=bshd)
-    g = _np(got).astype(np.float64)
+    g = oracle.to_f32(_bits(got), dtype).astype(np.float64)
     assert np.isfinite(g).all()
-    assert np.abs(g - exact).max() < 1e-3 * max(1.0, np.abs(exact).max()), np.abs(g - exact).max()
+    rel = 5e-3 if dtype else 1e-3                        # bf16 output rounding is 2^-9 relative
+    assert np.abs(g - exact).max() < rel * max(1.0, np.abs(exact).max()), np.abs(g - exact).max()
 
 
 def test_decode_attention_long_split(oracle, dev):

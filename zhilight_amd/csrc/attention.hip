@@ -635,6 +635,17 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 constexpr int kMD = 128;
 constexpr int kMVS = kMD + 16;      // LDS V row stride (halfs): 288 B, conflict-free transpose reads
 
+// DT: ZL_F16 / ZL_BF16 (v_mfma_f32_16x16x32_bf16; the hi + lo probability pair then carries 16 mantissa bits)
+template <int DT>
+__device__ __forceinline__ f4v mfma_t(uint4 a, uint4 b, f4v c) {
+    typedef __bf16 b8v __attribute__((ext_vector_type(8)));
+    if constexpr (DT == ZL_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8v, a), __builtin_bit_cast(b8v, b), c, 0, 0, 0);
+}
+
+template <int DT>
 __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t vs[4][32 * kMVS];      // 36 KB; reused for the wave merge
     const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
@@ -675,7 +686,7 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
     ZL_MFMA_LOAD_V(c0)
 
     // Q^T fragments: query row m = r -> (qi, head)
-    h8v qf[4];
+    uint4 qf[4];
     {
         uint4 z = make_uint4(0, 0, 0, 0);
         const bool live = r < p.rows;
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             uint4 v = *reinterpret_cast<const uint4*>(qp + 32 * t);
-            qf[t] = __builtin_bit_cast(h8v, live ? v : z);
+            qf[t] = live ? v : z;
         }
     }
 
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
             st[blk] = (f4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                st[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, kk[blk][t]), qf[t], st[blk], 0, 0, 0);
+                st[blk] = mfma_t<DT>(kk[blk][t], qf[t], st[blk]);
         }
         // ---- the V chunk to LDS (row-major), then the NEXT chunk's loads: they fly during softmax and P.V
         {
@@ -737,19 +748,33 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
         m_run = m_new;
         // probabilities as hi + lo fp16 parts (two MFMAs per V fragment): the product sees p to ~2^-22, i.e. the fp32
         // probabilities of the reference's decode kernel, not flash-attention's fp16 ones
-        h8v pf, pl;
+        float pr[2][4];
         float lsum = 0.f;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float pr = __expf(sv[blk][i] - m_new);
-                const _Float16 ph = (_Float16)pr;
-                lsum += pr;
-                pf[blk * 4 + i] = ph;
-                pl[blk * 4 + i] = (_Float16)(pr - (float)ph);
+                pr[blk][i] = __expf(sv[blk][i] - m_new);
+                lsum += pr[blk][i];
             }
         }
+        auto cvt = [](float x) -> uint16_t {             // plain RNE conversion (one v_cvt for fp16)
+            if constexpr (DT == ZL_F16) return __builtin_bit_cast(uint16_t, (_Float16)x);
+            else {
+                uint32_t u = __builtin_bit_cast(uint32_t, x);
+                return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            }
+        };
+        auto hi_lo = [&](float a, float b2, uint32_t& hw, uint32_t& lw) {   // two probabilities -> packed hi word, lo word
+            const uint16_t ah = cvt(a), bh = cvt(b2);
+            hw = (uint32_t)ah | ((uint32_t)bh << 16);
+            lw = (uint32_t)cvt(a - ZT<DT>::to_f32(ah)) | ((uint32_t)cvt(b2 - ZT<DT>::to_f32(bh)) << 16);
+        };
+        uint4 pf, pl;
+        hi_lo(pr[0][0], pr[0][1], pf.x, pl.x);
+        hi_lo(pr[0][2], pr[0][3], pf.y, pl.y);
+        hi_lo(pr[1][0], pr[1][1], pf.z, pl.z);
+        hi_lo(pr[1][2], pr[1][3], pf.w, pl.w);
         l_run = l_run * alpha + lsum;
 #pragma unroll
         for (int db = 0; db < 8; ++db) {
@@ -762,8 +787,8 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
             const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(vtr + 16 * kMVS + 16 * db));
             typedef short s8v __attribute__((ext_vector_type(8)));
             const s8v a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), pf, o[db], 0, 0, 0);
-            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), pl, o[db], 0, 0, 0);
+            o[db] = mfma_t<DT>(__builtin_bit_cast(uint4, a), pf, o[db]);
+            o[db] = mfma_t<DT>(__builtin_bit_cast(uint4, a), pl, o[db]);
         }
         if (c0 >= t1) break;
     }
@@ -1162,12 +1187,15 @@ int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* c
     p.k_scales = p.v_scales = nullptr;
     {   // decode fast path on the matrix cores: all query rows of a kv head in one 16-row MFMA block
         static const int use_mfma = [] { const char* e = getenv("ZL_ATTN_MFMA"); return e ? atoi(e) : 1; }();
-        if (use_mfma && !mask && dtype == ZL_F16 && d == kMD && p.rows <= 16) {
+        if (use_mfma && !mask && d == kMD && p.rows <= 16) {
             p.passes = 1;
-            hipLaunchKernelGGL(k_decode_attn_mfma, dim3((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b), dim3(256), 0, hs, p);
+            const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
+            if (dtype == ZL_F16) hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, hs, p);
+            else hipLaunchKernelGGL(k_decode_attn_mfma<ZL_BF16>, grid, dim3(256), 0, hs, p);
             int e = zl_launch_status();
             if (e) return e;
-            hipLaunchKernelGGL((k_decode_attn_combine<ZL_F16, kMD>), dim3((unsigned)(b * len_q * h)), dim3(kMD), 0, hs, p);
+            if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_combine<ZL_F16, kMD>), dim3((unsigned)(b * len_q * h)), dim3(kMD), 0, hs, p);
+            else hipLaunchKernelGGL((k_decode_attn_combine<ZL_BF16, kMD>), dim3((unsigned)(b * len_q * h)), dim3(kMD), 0, hs, p);
             return zl_launch_status();
         }
     }

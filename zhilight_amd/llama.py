@@ -731,7 +731,7 @@ class LLaMA:
         hidden = ops.embedding(ctx.tokens, self.token_embedding, c.scale_emb)      # token_embedding
         cos, sin = ops.rope_cos_sin(ctx.positions, c.dim_head, c.rope_theta, True, llama3)  # RopePreparer
         scale = 1.0 / math.sqrt(c.dim_head)
-        mfma_attn = (c.dim_head == 128 and c.torch_dtype == torch.float16 and c.num_heads // c.num_kv_heads <= 16
+        mfma_attn = (c.dim_head == 128 and c.num_heads // c.num_kv_heads <= 16
                      and os.environ.get("ZL_ATTN_MFMA", "1") != "0")
         # fused qkv projection + rotary + KV scatter in the GEMV epilogue (zl_w4a16_qkv_rope_scatter) where it applies
         fuse_qkv_rope = (mfma_attn and not ctx.kv_quant and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
