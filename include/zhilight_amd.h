@@ -313,8 +313,8 @@ int zl_decode_attn_quant(const uint16_t* q, const int32_t* buf_lens, const uint8
  * Replaces attn_encode_group -> FlashDecoding::mha_fwd (src/nn/attention/attention.cpp:442-622; the
  * arithmetic of the external flash-attn library): query row i of the chunk sits at position pos0 + i and
  * sees keys 0 .. pos0 + i of the task's K/V buffer (BSHD (len_buf, Hkv, D) or BHSD), which must already
- * hold the chunk's own rows (copy_to_rag_buffer2 first).  q / out (s_q, H, D) fp16; D = 128.  fp32 softmax,
- * fp16 probabilities into the P.V product, fp32 accumulation.
+ * hold the chunk's own rows (copy_to_rag_buffer2 first).  q / out (s_q, H, D) fp16 or bf16; D = 128.  fp32 softmax,
+ * probabilities rounded to T into the P.V product, fp32 accumulation.
  * ---------------------------------------------------------------------------------------------- */
 int zl_prefill_attn(const uint16_t* q, const uint16_t* k_buf, const uint16_t* v_buf, uint16_t* out, int64_t s_q,
                     int64_t pos0, int64_t h, int64_t hkv, int64_t d, float scale, int64_t len_buf, int bshd,

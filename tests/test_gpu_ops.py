@@ -433,6 +433,14 @@ def test_prefill_attention(oracle, dev, s_q, pos0, h, hkv, bshd):
     got = _np(ops.prefill_attention(_t(q, dev), _t(kb, dev), _t(vb, dev), pos0, hkv, 1.0 / np.sqrt(d), bshd)).astype(np.float64)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    # bf16: the same kernel on v_mfma_f32_16x16x32_bf16; probabilities rounded to bf16 (2^-9): 1.5e-2 of the output scale
+    qb, kbb, vbb = (oracle.f32_to_bf16(a.astype(np.float32)) for a in (q, kb, vb))
+    refb = oracle.mqa_rag_buffer(qb[None], np.array([len_buf], np.int32), [kbb], [vbb], mask, hkv, 1.0 / np.sqrt(d), bshd, dtype=1,
+                                 exact=True)[0]
+    gotb = ops.prefill_attention(_tt(qb, dev, 1), _tt(kbb, dev, 1), _tt(vbb, dev, 1), pos0, hkv, 1.0 / np.sqrt(d), bshd)
+    gb = oracle.to_f32(_bits(gotb), 1).astype(np.float64)
+    assert np.isfinite(gb).all()
+    assert np.abs(gb - refb).max() <= 1.5e-2 * np.abs(refb).max(), np.abs(gb - refb).max() / np.abs(refb).max()
 
 
 @pytest.mark.parametrize("dtype", [0, 1])

@@ -38,7 +38,18 @@ struct PrefillParams {
     float scale;
 };
 
-__global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams p) {
+template <int DT>
+__device__ __forceinline__ f4 pf_mfma(uint4 a, uint4 b, f4 c) {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    if constexpr (DT == ZL_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+}
+
+// DT = ZL_F16 / ZL_BF16: probabilities are rounded to T for the P.V product (flash-attention arithmetic)
+template <int DT>
+__global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t ks[kBK * kKRow];
     __shared__ __attribute__((aligned(16))) uint16_t vt[kBK * kVRow];
     __shared__ __attribute__((aligned(16))) float strip[4][16];
@@ -53,12 +64,12 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
     const size_t kv_off = p.bshd ? (size_t)hk * kD : (size_t)hk * p.len_buf * kD;
 
     // Q fragments (B operand of S^T = K.Q^T): column q = lane & 15, k-chunk = d 32 t + 8 kq .. +7
-    h8 qf[4];
+    uint4 qf[4];
     {
         const int qr = qrow < p.s_q ? qrow : p.s_q - 1;
         const uint16_t* qp = p.q + ((size_t)qr * p.h + head) * kD + 8 * kq;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) qf[t] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(qp + 32 * t));
+        for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const uint4*>(qp + 32 * t);
     }
 
     f4 o[8];                                              // O block: column d = 16 db + (lane & 15), rows q = 4 kq + i
@@ -107,8 +118,8 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
             st[kb] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&ks[(kb * 16 + nq) * kKRow + 32 * t + 8 * kq]));
-                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[t], st[kb], 0, 0, 0);
+                const uint4 a = *reinterpret_cast<const uint4*>(&ks[(kb * 16 + nq) * kKRow + 32 * t + 8 * kq]);
+                st[kb] = pf_mfma<DT>(a, qf[t], st[kb]);
             }
         }
         // ---- scale, causal mask, online softmax for query nq (its 64 scores live in 4 lanes x 16 registers)
@@ -129,19 +140,28 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
         const float alpha = __expf(m_run - m_new);
         m_run = m_new;
         float lsum = 0.f;
-        h8 pf[2];                                         // P as the A operand of P.V: k-chunk kq of key group j
+        uint4 pf[2];                                      // P as the A operand of P.V: k-chunk kq of key group j
+        auto cvt = [](float x) -> uint16_t {
+            if constexpr (DT == ZL_F16) return __builtin_bit_cast(uint16_t, (_Float16)x);
+            else {
+                const uint32_t u = __builtin_bit_cast(uint32_t, x);
+                return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            }
+        };
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            uint32_t w[4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float pv = __expf(st[2 * j + half][i] - m_new);
-                    const _Float16 ph = (_Float16)pv;
-                    lsum += (float)ph;                    // the normaliser sums what the product uses
-                    pf[j][half * 4 + i] = ph;
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const uint16_t p0 = cvt(__expf(st[2 * j + half][2 * i2] - m_new));
+                    const uint16_t p1 = cvt(__expf(st[2 * j + half][2 * i2 + 1] - m_new));
+                    lsum += ZT<DT>::to_f32(p0) + ZT<DT>::to_f32(p1);   // the normaliser sums what the product uses
+                    w[half * 2 + i2] = (uint32_t)p0 | ((uint32_t)p1 << 16);
                 }
             }
+            pf[j] = make_uint4(w[0], w[1], w[2], w[3]);
         }
         l_run = l_run * alpha + lsum;                     // per-lane partial; lanes of a query are merged at the end
         // ---- rescale O: the factor of row q = 4 kq + i comes from the lane whose nq is that row
@@ -164,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
                 const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(vtr + (32 * j) * kVRow + 16 * db));
                 const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(vtr + (32 * j + 16) * kVRow + 16 * db));
                 const s8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[j], __builtin_bit_cast(h8, b), o[db], 0, 0, 0);
+                o[db] = pf_mfma<DT>(pf[j], __builtin_bit_cast(uint4, b), o[db]);
             }
         }
     }
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn_f16(const PrefillParams
         if (row >= p.s_q) continue;
         uint16_t* op = p.out + ((size_t)row * p.h + head) * kD + nq;
 #pragma unroll
-        for (int db = 0; db < 8; ++db) op[db * 16] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(o[db][i] * inv[i]));
+        for (int db = 0; db < 8; ++db) op[db * 16] = ZT<DT>::from_f32(o[db][i] * inv[i]);
     }
 }
 
@@ -195,13 +215,14 @@ extern "C" int zl_prefill_attn(const uint16_t* q, const uint16_t* k_buf, const u
     ZL_CHECK_ARG(q && k_buf && v_buf && out && s_q > 0 && pos0 >= 0 && h > 0 && hkv > 0 && len_buf > 0, ZL_EINVAL);
     ZL_CHECK_ARG(h % hkv == 0 && pos0 + s_q <= len_buf, ZL_ESHAPE);
     ZL_CHECK_ARG(d == kD, ZL_ESHAPE);          // other head sizes: the mask form of zl_decode_attn
-    ZL_CHECK_ARG(dtype == ZL_F16, ZL_EDTYPE);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
     ZL_CHECK_ARG(h <= 65535, ZL_ELIMIT);
     PrefillParams p;
     p.q = q; p.k = k_buf; p.v = v_buf; p.out = out;
     p.s_q = (int)s_q; p.pos0 = (int)pos0; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
     p.len_buf = (int)len_buf; p.bshd = bshd; p.scale = scale;
-    hipLaunchKernelGGL(k_prefill_attn_f16, dim3((unsigned)((s_q + kBQ - 1) / kBQ), (unsigned)h), dim3(256), 0,
-                       (hipStream_t)s, p);
+    const dim3 grid((unsigned)((s_q + kBQ - 1) / kBQ), (unsigned)h);
+    if (dtype == ZL_F16) hipLaunchKernelGGL(k_prefill_attn<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, p);
+    else hipLaunchKernelGGL(k_prefill_attn<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, p);
     return zl_launch_status();
 }

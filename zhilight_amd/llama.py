@@ -863,7 +863,7 @@ class LLaMA:
                 k3, v3 = k.view(s, c.num_kv_heads, c.dim_head), v.view(s, c.num_kv_heads, c.dim_head)
                 ops.quant_copy_to_rag_buffer(pos, buf_lens, k3, v3, ka, va, ctx.ks_addrs[li][task:task + 1],
                                              ctx.vs_addrs[li][task:task + 1], len_q=s)
-                if c.dim_head == 128 and q.dtype == torch.float16:
+                if c.dim_head == 128:
                     att = ops.prefill_attention(q.view(s, c.num_heads, c.dim_head), k3, v3, 0, c.num_kv_heads, scale)
                 else:
                     mask, ws = self._prefill_mask(s, s, 0)
@@ -875,7 +875,7 @@ class LLaMA:
                 continue
             ops.copy_to_rag_buffer2(placement, buf_lens, k.view(1, s, c.num_kv_heads, c.dim_head),
                                     v.view(1, s, c.num_kv_heads, c.dim_head), ka, va)
-            if c.dim_head == 128 and q.dtype == torch.float16:
+            if c.dim_head == 128:
                 att = ops.prefill_attention(q.view(s, c.num_heads, c.dim_head), ctx.kv[task][li, 0], ctx.kv[task][li, 1], pos0,
                                             c.num_kv_heads, scale)
             else:

@@ -538,8 +538,8 @@ def prefill_attention(q, k_buf, v_buf, pos0, num_kv_heads, scale, bshd=True, out
     src/nn/attention/attention.cpp:442-622).  q (s_q, H, D); k_buf / v_buf the task's buffers (len_buf, Hkv, D)
     [bshd] or (Hkv, len_buf, D), already holding the chunk's rows at pos0 .. pos0 + s_q - 1."""
     _chk_cuda(q, k_buf, v_buf)
-    if q.dtype != torch.float16:
-        raise ZLError("prefill_attention: fp16 only")
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise ZLError("prefill_attention: fp16 / bf16 only")
     s_q, h, d = q.shape
     len_buf = k_buf.shape[0] if bshd else k_buf.shape[1]
     if out is None:
