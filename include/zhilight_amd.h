@@ -373,6 +373,12 @@ int zl_w8m_pack(const int8_t* w /* (N,K) */, int64_t n, int64_t k, int row_inter
 int zl_w8a8_gemm_phase(const int8_t* xq /* (M,K) */, const float* scale_x /* (M) */, const void* qw,
                        const uint16_t* scale_y /* (N) T */, const uint16_t* addend, uint16_t* out, int64_t m, int64_t n,
                        int64_t k, float scale, int epilogue, int dtype, zl_stream_t s);
+/* The INT8 route's fused qkv projection of a decode step: zl_w8a8_gemm_phase(ZL_W8_BACK) + zl_rope_scatter_decode in one
+ * launch (neox, cached cos/sin; bit-identical to the two calls).  1 <= M <= 32, D % 32 == 0. */
+int zl_w8a8_qkv_rope_scatter(const int8_t* xq, const float* scale_x, const void* qw, const uint16_t* scale_y,
+                             const float* cosv, const float* sinv, const int32_t* placement, const int32_t* buf_lens,
+                             uint16_t* const* k_bufs, uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h,
+                             int64_t hkv, int64_t d, int64_t k, int bshd, int dtype, zl_stream_t s);
 
 /* The other scale-back flavours of the reference, same arithmetic T(float(int32) * sx[row] * sy[col]):
  *   zl_quant_scale_back3             int8_op::quant_scale_back3 (quant_kernel.cu:311-384): fused qkv result -> q | k | v

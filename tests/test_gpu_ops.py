@@ -502,3 +502,38 @@ def test_w8a8_streaming_gemm_bit_identical(oracle, dev, m, rounds, monkeypatch):
             ref = ops.quant_back_act_mul(c[:, :h2].contiguous(), tsx, tsy[:h2].contiguous(), c[:, h2:].contiguous(), tsx,
                                          tsy[h2:].contiguous(), "silu", torch.float16)
             assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("m", [1, 8, 16, 17, 32])
+@pytest.mark.parametrize("bshd", [True, False])
+def test_w8a8_fused_qkv_rotary_scatter_bit_identical(oracle, dev, m, bshd):
+    """zl_w8a8_qkv_rope_scatter == zl_w8a8_gemm_phase(BACK) + zl_rope_scatter_decode, bit for bit (q, K / V buffers),
+    incl. a task whose placement is -1"""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(400 + m)
+    h, hkv, d, k = 8, 2, 128, 1024 + 256
+    n = (h + 2 * hkv) * d
+    a = _t(rng.integers(-127, 128, (m, k), dtype=np.int8), dev)
+    w = _t(rng.integers(-127, 128, (n, k), dtype=np.int8), dev)
+    sx = _t(rng.uniform(0.002, 0.01, m).astype(np.float32), dev)
+    sy = _t(rng.uniform(0.001, 0.004, n).astype(np.float16), dev)
+    w8 = ops.W8MWeight.from_rows(w, sy)
+    lens = [int(v) for v in rng.integers(2, 6, m) * 32]
+    pos = np.array([int(rng.integers(0, L)) for L in lens], np.int32)
+    placement = pos.copy()
+    if m > 1:
+        placement[1] = -1
+    cs, sn = oracle.rope_cos_sin(pos, d, 5e5, True, (8.0, 1.0, 4.0, 8192.0))
+    shape = (lambda L: (L, hkv, d)) if bshd else (lambda L: (hkv, L, d))
+    mk = lambda: [torch.full(shape(L), 3.0, dtype=torch.float16, device=dev) for L in lens]
+    k1, v1, k2, v2 = mk(), mk(), mk(), mk()
+    lens_t, place_t = _t(np.array(lens, np.int32), dev), _t(placement, dev)
+    qkv = ops.w8a8_gemm_phase(a, sx, w8, ops.W8_BACK)
+    q_ref = ops.rope_scatter_decode(_t(cs, dev), _t(sn, dev), qkv, place_t, lens_t, ops.make_ptr_table(k1), ops.make_ptr_table(v1),
+                                    h, hkv, d, True, bshd)
+    q_got = ops.w8a8_qkv_rope_scatter(a, sx, w8, _t(cs, dev), _t(sn, dev), place_t, lens_t, ops.make_ptr_table(k2),
+                                      ops.make_ptr_table(v2), h, hkv, d, bshd=bshd)
+    assert torch.equal(q_got, q_ref)
+    for x1, x2 in zip(k1 + v1, k2 + v2):
+        assert torch.equal(x1, x2)
+    assert not torch.equal(k1[0], torch.full_like(k1[0], 3.0))

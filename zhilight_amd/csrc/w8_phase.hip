@@ -42,6 +42,15 @@ struct W8Params {
     int m, n, k;
     int groups, tiles, phases;
     int epi, ld_out, dtype;
+    // ROPE instantiation (fused qkv projection of a decode step: scale back, neox rotation of q and k, KV scatter)
+    const float* cosv;
+    const float* sinv;
+    const int32_t* placement;
+    const int32_t* buf_lens;
+    uint16_t* const* k_bufs;
+    uint16_t* const* v_bufs;
+    uint16_t* q_out;
+    int h, hkv, d, bshd, pair_stride;
 };
 
 constexpr int ring_depth(int r) { return r == 1 ? 3 : r == 2 ? 4 : r == 3 ? 6 : r == 4 ? 8 : r; }
@@ -55,8 +64,11 @@ struct NoGuard { static constexpr bool value = false; };
 template <int DT>
 __device__ __forceinline__ float back(int c, float sx, uint16_t sy) { return (float)c * sx * ZT<DT>::to_f32(sy); }
 
-template <int R, int MB>
+// ROPE (R = 2): the two tiles of a workgroup are a column block and its rotation partners (D/2 columns further), as in
+// w4_phase.hip; the epilogue = quant_scale_back, then rope_qk_cache + copy_to_rag_buffer2 on the T-rounded values.
+template <int R, int MB, bool ROPE = false>
 __global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
+    static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
     constexpr int D = ring_depth(R), XP = x_ahead(R), BODY = lcm_(D, R * XP);
     constexpr int XC = 2 * MB;                       // 16-byte x chunks per thread per phase (16 MB rows x 64 chunks)
     constexpr int kBuf = MB * 16 * kXS;              // bytes per LDS phase buffer
@@ -68,7 +80,8 @@ __global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nrow = lane & 15, kq = lane >> 4;
     const int P = p.phases, total = P * R;
-    const int tile0 = blockIdx.x * R;
+    const int tile0 = ROPE ? (int)(blockIdx.x / p.pair_stride) * 2 * p.pair_stride + (int)(blockIdx.x % p.pair_stride) : (int)blockIdx.x * R;
+    const int tile_stride = ROPE ? p.pair_stride : 1;
 
     // ---- activations: chunk c of a thread = row (tid >> 6) + 8 c, bytes 16 (tid & 63) .. +15 of the phase
     const int xrow0 = threadIdx.x >> 6, xcc = (threadIdx.x & 63) * 16;
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
     v4i wq[D][2];
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
     uint32_t qs = ((uint32_t)tile0 * (uint32_t)p.groups + (uint32_t)wave) * 2048u;
-    const int tile_step = p.groups, phase_step = kW - (R - 1) * p.groups;
+    const int tile_step = tile_stride * p.groups, phase_step = kW - (R - 1) * tile_stride * p.groups;
     const uint32_t q_off = (uint32_t)lane * 16u;
     int iss_left = total - 1;
     auto issue = [&](int slot, int r_of_item) {
@@ -180,6 +193,58 @@ __global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
     }
     __syncthreads();
     const int* redi = reinterpret_cast<const int*>(red);
+    if constexpr (ROPE) {
+        const int half = p.d / 2;
+        for (int o = threadIdx.x; o < 16 * p.m; o += kT) {
+            const int m = o >> 4, n_local = o & 15;
+            const int b = m >> 4, ln = ((m & 15) >> 2) * 16 + n_local, i = m & 3;
+            int c0 = 0, c1 = 0;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) {
+                c0 += redi[(((size_t)(0 * MB + b) * kW + w) * 64 + ln) * 4 + i];
+                c1 += redi[(((size_t)(1 * MB + b) * kW + w) * 64 + ln) * 4 + i];
+            }
+            const int n0 = tile0 * 16 + n_local, n1 = n0 + half;
+            const float sx = p.sx[m];
+            // the projection's T outputs (quant_scale_back), then the rotation in fp32 with one rounding to T
+            uint16_t a16, b16;
+            if (p.dtype == ZL_F16) {
+                a16 = ZT<ZL_F16>::from_f32(back<ZL_F16>(c0, sx, p.sy[n0]));
+                b16 = ZT<ZL_F16>::from_f32(back<ZL_F16>(c1, sx, p.sy[n1]));
+            } else {
+                a16 = ZT<ZL_BF16>::from_f32(back<ZL_BF16>(c0, sx, p.sy[n0]));
+                b16 = ZT<ZL_BF16>::from_f32(back<ZL_BF16>(c1, sx, p.sy[n1]));
+            }
+            const int head = n0 / p.d, dcol = n0 % p.d;
+            uint16_t* dst = nullptr;
+            uint16_t r0 = a16, r1 = b16;
+            if (head < p.h + p.hkv) {
+                const float a = p.dtype == ZL_F16 ? ZT<ZL_F16>::to_f32(a16) : ZT<ZL_BF16>::to_f32(a16);
+                const float bb = p.dtype == ZL_F16 ? ZT<ZL_F16>::to_f32(b16) : ZT<ZL_BF16>::to_f32(b16);
+                const float cs0 = p.cosv[(size_t)m * p.d + dcol], s0 = p.sinv[(size_t)m * p.d + dcol];
+                const float cs1 = p.cosv[(size_t)m * p.d + dcol + half], s1 = p.sinv[(size_t)m * p.d + dcol + half];
+                const float v0 = __builtin_fmaf(-bb, s0, a * cs0), v1 = __builtin_fmaf(a, s1, bb * cs1);
+                r0 = p.dtype == ZL_F16 ? ZT<ZL_F16>::from_f32(v0) : ZT<ZL_BF16>::from_f32(v0);
+                r1 = p.dtype == ZL_F16 ? ZT<ZL_F16>::from_f32(v1) : ZT<ZL_BF16>::from_f32(v1);
+            }
+            if (head < p.h) {
+                dst = p.q_out + ((size_t)m * p.h + head) * p.d + dcol;
+            } else {
+                const int place = p.placement[m];
+                if (place >= 0) {
+                    const bool is_v = head >= p.h + p.hkv;
+                    const int hk = head - p.h - (is_v ? p.hkv : 0);
+                    const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
+                    dst = (is_v ? p.v_bufs : p.k_bufs)[m] + row * p.d + dcol;
+                }
+            }
+            if (dst) {
+                dst[0] = r0;
+                dst[half] = r1;
+            }
+        }
+        return;
+    }
     const bool gated = p.epi == kActSilu || p.epi == kActGelu;
     const int per_tile = (gated ? 8 : 16) * p.m;
     for (int o = threadIdx.x; o < R * per_tile; o += kT) {
@@ -232,7 +297,7 @@ __global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
     }
 }
 
-template <int R, int MB>
+template <int R, int MB, bool ROPE = false>
 int launch_w8(const W8Params& p, int grid, hipStream_t hs) {
     constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS;
     constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
@@ -241,13 +306,13 @@ int launch_w8(const W8Params& p, int grid, hipStream_t hs) {
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w8a8_phase<R, MB>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w8a8_phase<R, MB, ROPE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return ZL_ELIMIT;
             done = true;
         }
     }
-    hipLaunchKernelGGL((k_w8a8_phase<R, MB>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w8a8_phase<R, MB, ROPE>), dim3(grid), dim3(kT), lds, hs, p);
     return zl_launch_status();
 }
 
@@ -309,6 +374,8 @@ int zl_w8a8_gemm_phase(const int8_t* xq, const float* scale_x, const void* qw, c
     p.addend = addend; p.y = out; p.scale = scale; p.m = (int)m; p.n = (int)n; p.k = (int)k;
     p.groups = (int)((k + 127) / 128); p.tiles = (int)((n + 15) / 16); p.phases = (p.groups + kW - 1) / kW;
     p.epi = epilogue; p.ld_out = (int)(gated ? n / 2 : n); p.dtype = dtype;
+    p.cosv = p.sinv = nullptr; p.placement = p.buf_lens = nullptr; p.k_bufs = p.v_bufs = nullptr; p.q_out = nullptr;
+    p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
     int r = (p.tiles + cus - 1) / cus;
@@ -324,6 +391,28 @@ int zl_w8a8_gemm_phase(const int8_t* xq, const float* scale_x, const void* qw, c
     switch (r) { ZL_W8(1) ZL_W8(2) ZL_W8(3) ZL_W8(4) ZL_W8(5) ZL_W8(6) ZL_W8(7) ZL_W8(8) }
 #undef ZL_W8
     return ZL_EINVAL;
+}
+
+int zl_w8a8_qkv_rope_scatter(const int8_t* xq, const float* scale_x, const void* qw, const uint16_t* scale_y,
+                             const float* cosv, const float* sinv, const int32_t* placement, const int32_t* buf_lens,
+                             uint16_t* const* k_bufs, uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h,
+                             int64_t hkv, int64_t d, int64_t k, int bshd, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(xq && scale_x && qw && scale_y && cosv && sinv && placement && buf_lens && k_bufs && v_bufs && q_out, ZL_EINVAL);
+    ZL_CHECK_ARG(m > 0 && h > 0 && hkv > 0 && d > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    ZL_CHECK_ARG(m <= 32 && d % 32 == 0 && k % 16 == 0 && ((uintptr_t)xq & 15) == 0, ZL_ESHAPE);
+    const int64_t n = (h + 2 * hkv) * d;
+    const int64_t bytes = zl_w8m_bytes(n, k);
+    ZL_CHECK_ARG(bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+    W8Params p;
+    p.x = xq; p.sx = scale_x; p.qw = reinterpret_cast<const uint4*>(qw); p.qw_bytes = (uint32_t)bytes; p.sy = scale_y;
+    p.addend = nullptr; p.y = nullptr; p.scale = 1.f; p.m = (int)m; p.n = (int)n; p.k = (int)k;
+    p.groups = (int)((k + 127) / 128); p.tiles = (int)(n / 16); p.phases = (p.groups + kW - 1) / kW;
+    p.epi = kBack; p.ld_out = (int)n; p.dtype = dtype;
+    p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs;
+    p.q_out = q_out; p.h = (int)h; p.hkv = (int)hkv; p.d = (int)d; p.bshd = bshd; p.pair_stride = (int)(d / 32);
+    const int grid = p.tiles / 2;
+    return m <= 16 ? launch_w8<2, 1, true>(p, grid, (hipStream_t)s) : launch_w8<2, 2, true>(p, grid, (hipStream_t)s);
 }
 
 }  // extern "C"

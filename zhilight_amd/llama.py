@@ -738,7 +738,22 @@ class LLaMA:
                          and all(isinstance(l, EncoderLayer) and l.unfused is None and isinstance(l.qkv.weight, ops.W4MWeight)
                                  for l in self.layers)
                          and ops.w4_qkv_rope_scatter_ok(b, c.dim_model, c.dim_head, norm=b <= 4))
+        fuse_qkv_rope_i8 = (mfma_attn and not ctx.kv_quant and b <= 32 and c.dim_head % 32 == 0
+                            and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
+                            and all(isinstance(l, Int8EncoderLayer) and l._stream(b) for l in self.layers))
         for li, layer in enumerate(self.layers):
+            if fuse_qkv_rope_i8:
+                # INT8 route: layernorm_quant, then the streaming W8A8 kernel with scale-back + rotary + KV scatter fused
+                _, xq, sx = ops.layernorm_quant(hidden, layer.ln_attn, c.eps)
+                ops.w8a8_qkv_rope_scatter(xq, sx, layer.qkv.stream_weight(), cos, sin, ctx.placement, ctx.buf_lens, ctx.k_addrs[li],
+                                          ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, q_out=bufs["q"])
+                ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
+                                                     ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
+                                                     valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
+                                                     workspace=workspace)
+                layer.attn_out_add(bufs["attn"], hidden)
+                layer.ff_add(hidden, c.eps, bufs["act"])
+                continue
             if fuse_qkv_rope:
                 xin = hidden if b <= 4 else ops.rmsnorm(hidden, layer.ln_attn, c.eps)
                 ops.w4_qkv_rope_scatter(xin, layer.qkv.weight, cos, sin, ctx.placement, ctx.buf_lens, ctx.k_addrs[li],

@@ -630,6 +630,22 @@ def w8a8_gemm_phase(xq, sx, w: W8MWeight, epilogue=W8_BACK, addend=None, scale=1
     return out
 
 
+def w8a8_qkv_rope_scatter(xq, sx, w: W8MWeight, cos, sin, placement, buf_lens, k_addrs, v_addrs, num_heads, num_kv_heads,
+                          dim_head, bshd=True, q_out=None, dtype=torch.float16):
+    """INT8 fused qkv projection + scale-back + neox rotary + KV scatter for decode rows; returns the rotated q (M, H*D)."""
+    _chk_cuda(xq, sx, cos, sin, placement, buf_lens, k_addrs, v_addrs)
+    m, k = xq.shape
+    if k != w.k or w.n != (num_heads + 2 * num_kv_heads) * dim_head or w.row_interleave:
+        raise ZLError("w8a8_qkv_rope_scatter: weight shape")
+    if q_out is None:
+        q_out = torch.empty((m, num_heads * dim_head), dtype=dtype, device=xq.device)
+    check(lib().zl_w8a8_qkv_rope_scatter(_p(xq), _p(sx), _p(w.qw), _p(w.scale), _p(cos), _p(sin), _p(placement), _p(buf_lens),
+                                         _p(k_addrs), _p(v_addrs), _p(q_out), _i(m), _i(num_heads), _i(num_kv_heads),
+                                         _i(dim_head), _i(k), C.c_int(int(bshd)), C.c_int(_dt(q_out)), _stream()),
+          "w8a8_qkv_rope_scatter")
+    return q_out
+
+
 def quant_calc_scale(x):
     """int8_op::quant_calc_scale (src/nn/quant/int8/quant_kernel.cu:49-103) -> (int8 (M,K), fp32 scale (M))."""
     _chk_cuda(x)
