@@ -2,6 +2,7 @@
 // a17, a18, a22) plus library utilities.  All are tiny HBM/L2-bound byte movers: 16-byte vector
 // accesses, one workgroup per row (or grid-stride), fp32 math with ONE rounding to T at the same
 // points as the reference kernels cited at each launcher.
+#include <mutex>
 #include "zl_common.h"
 
 namespace {
@@ -310,10 +311,12 @@ const char* zl_status_string(int st) {
 // stream-ordered with respect to each other (one compute stream per device, as in the reference's engine).
 static void* g_ws_ptr[64] = {nullptr};
 static size_t g_ws_size[64] = {0};
+static std::mutex g_ws_mutex;     // host threads of one process (one per GPU in the reference's engine) may arrive together
 
 void* zlint_workspace(size_t bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (g_ws_size[dev] >= bytes) return g_ws_ptr[dev];
     void* np = nullptr;
     const size_t want = bytes < (size_t)(64 << 20) ? (size_t)(64 << 20) : bytes;   // 64 MiB floor
@@ -321,7 +324,10 @@ void* zlint_workspace(size_t bytes) {
         (void)hipGetLastError();
         return nullptr;
     }
-    if (g_ws_ptr[dev]) (void)hipFree(g_ws_ptr[dev]);
+    if (g_ws_ptr[dev]) {
+        (void)hipDeviceSynchronize();   // work enqueued on the old buffer finishes before it goes away
+        (void)hipFree(g_ws_ptr[dev]);
+    }
     g_ws_ptr[dev] = np;
     g_ws_size[dev] = want;
     return np;
@@ -332,6 +338,7 @@ extern "C" int* zlint_counters(void) {
     static int* g_cnt[64] = {nullptr};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (!g_cnt[dev]) {
         int* np = nullptr;
         if (hipMalloc(&np, 16384 * sizeof(int)) != hipSuccess || hipMemset(np, 0, 16384 * sizeof(int)) != hipSuccess) {
