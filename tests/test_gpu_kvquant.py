@@ -229,3 +229,42 @@ def test_quantised_cache_tracks_fp16_cache(oracle, dev):
     ref = _np(ops.multi_query_attention_rag_buffer(_t(q, dev), lens, ops.make_ptr_table(dk), ops.make_ptr_table(dv), None, 0.088,
                                                    L, hkv, valid_lens=valid)).astype(np.float64)
     assert np.abs(got - ref).max() < 2e-2 * np.abs(ref).max()
+
+
+def test_matrix_core_attention_random_shapes(oracle, dev):
+    """24 seeded random draws (tasks, kv heads, GQA ratio, rows per kv head <= 16, ragged buffer / visible lengths, layout,
+    dtype, fp16 cache or INT8 cache) through the matrix-core decode attention kernels vs the fp64 oracles"""
+    from zhilight_amd import ops
+    from test_gpu_ops import _make_kv
+    rng = np.random.default_rng(777)
+    d = 128
+    for case in range(24):
+        hkv = int(rng.choice([1, 2, 4, 8]))
+        n_rep = int(rng.choice([1, 2, 4, 8]))
+        len_q = int(rng.choice([1, 2])) if n_rep <= 8 else 1
+        h = hkv * n_rep
+        b = int(rng.integers(1, 6))
+        lens = [int(v) * 64 for v in rng.integers(1, 12, b)]
+        valid = [int(rng.integers(1, L + 1)) for L in lens]
+        bshd = bool(rng.integers(0, 2))
+        quant = bool(rng.integers(0, 2))
+        dtype = 0 if quant else int(rng.integers(0, 2))
+        lens_np, valid_np = np.array(lens, np.int32), np.array(valid, np.int32)
+        mask = np.concatenate([np.tile((np.arange(L) < v).astype(np.int8), len_q) for L, v in zip(lens, valid)])
+        q = _to_bits(rng.standard_normal((b, len_q, h, d)), dtype, oracle)
+        scale = 1.0 / np.sqrt(d)
+        if quant:
+            host, devt = _empty_cache(lens, hkv, d, bshd, dev, rng)
+            exact = oracle.mqa_rag_buffer_quant(q, lens_np, *host, mask, hkv, scale, bshd)
+            got = ops.multi_query_attention_rag_buffer_quant(_tt(q, dev, dtype), _t(lens_np, dev), *[ops.make_ptr_table(x) for x in devt],
+                                                             None, scale, max(lens), hkv, valid_lens=_t(valid_np, dev), bshd=bshd)
+        else:
+            kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, bshd, dev, dtype, oracle)
+            exact = oracle.mqa_rag_buffer(q, lens_np, kb, vb, mask, hkv, scale, bshd, dtype=dtype, exact=True)
+            got = ops.multi_query_attention_rag_buffer(_tt(q, dev, dtype), _t(lens_np, dev), ops.make_ptr_table(dk),
+                                                       ops.make_ptr_table(dv), None, scale, max(lens), hkv,
+                                                       valid_lens=_t(valid_np, dev), bshd=bshd)
+        g = oracle.to_f32(_bits(got), dtype).astype(np.float64)
+        rel = 5e-3 if dtype else 1e-3
+        assert np.isfinite(g).all(), case
+        assert np.abs(g - exact).max() < rel * max(1.0, np.abs(exact).max()), (case, hkv, n_rep, len_q, b, lens, valid, bshd, quant, dtype)
