@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
             xn4[m] = *reinterpret_cast<const uint4*>(p.x + (live ? (size_t)m * p.ldx + idx : 0));
             if (!live) xn4[m] = make_uint4(0, 0, 0, 0);
         }
-        nw4 = *reinterpret_cast<const uint4*>(p.norm_w + (idx < p.k ? idx : 0));
+        if (p.norm_w) nw4 = *reinterpret_cast<const uint4*>(p.norm_w + (idx < p.k ? idx : 0));
     } else {
 #pragma unroll
         for (int q = 0; q < XP; ++q) load_x(q, q);
@@ -196,10 +196,14 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
         }
     };
     if constexpr (NORM) {
+      // (norm_w == null: the register-resident staging alone -- up to 4 rows it beats the per-phase loads: 4.9 vs 5.1 us
+      //  on the o projection at one row)
+      if (p.norm_w) {
         // sum of squares: per-thread chain, 64-lane butterfly, waves in order (zl_block_sum's order)
         float* scratch = reinterpret_cast<float*>(smem + 2 * (size_t)kBuf * 2);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
+            if (m >= p.m) break;                      // workgroup-uniform: a batch-1 step pays for one row, not four
             const uint32_t u[4] = {xn4[m].x, xn4[m].y, xn4[m].z, xn4[m].w};
             float run = 0.f;
 #pragma unroll
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
+            if (m >= p.m) break;
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < kW; ++w) tot += scratch[m * kW + w];
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
             }
             xn4[m] = make_uint4(u[0], u[1], u[2], u[3]);
         }
+      }
         store_norm(0);
     } else {
         store_x(0, 0);
@@ -554,7 +560,7 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     const int mb = m <= 16 ? 1 : 2;
 #define ZL_PH(RR)                                                                                              \
     case RR:                                                                                                   \
-        if (norm_w) return launch_phase<RR, 1, true>(p, grid, hs);                                             \
+        if (norm_w || (m <= 4 && k <= 4096)) return launch_phase<RR, 1, true>(p, grid, hs);                    \
         return mb == 1 ? launch_phase<RR, 1, false>(p, grid, hs) : launch_phase<RR, 2, false>(p, grid, hs);
     switch (r) {
         ZL_PH(1) ZL_PH(2) ZL_PH(3) ZL_PH(4) ZL_PH(5) ZL_PH(6) ZL_PH(7) ZL_PH(8)
@@ -580,6 +586,6 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
     p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs;
     p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd; p.pair_stride = d / 32;
     const int grid = tiles / 2;
-    if (norm_w) return launch_phase<2, 1, true, true>(p, grid, hs);
+    if (norm_w || (m <= 4 && k <= 4096)) return launch_phase<2, 1, true, true>(p, grid, hs);
     return m <= 16 ? launch_phase<2, 1, false, true>(p, grid, hs) : launch_phase<2, 2, false, true>(p, grid, hs);
 }
