@@ -244,9 +244,11 @@ def main():
         bufs = model._buffers(batch)
         launches = []
         for layer in model.layers:
-            # the model fuses the RMSNorm into the GEMV up to 4 rows and launches it separately beyond (llama.py)
-            nq = dict(norm_weight=layer.ln_attn, norm_eps=cfg.eps) if batch <= 4 else {}
-            nf = dict(norm_weight=layer.ln_ff, norm_eps=cfg.eps) if batch <= 4 else {}
+            # the model fuses the RMSNorm into the GEMV up to 8 rows (4 for the bit-exact kernel) and launches it separately
+            # beyond (llama.py: _fused_norm_rows)
+            from zhilight_amd.llama import _fused_norm_rows
+            nq = dict(norm_weight=layer.ln_attn, norm_eps=cfg.eps) if batch <= _fused_norm_rows(layer.qkv.weight) else {}
+            nf = dict(norm_weight=layer.ln_ff, norm_eps=cfg.eps) if batch <= _fused_norm_rows(layer.w_in_gated.weight) else {}
             launches += [(bufs["hidden"], layer.qkv, bufs["qkv"], nq),
                          (bufs["attn"], layer.attn_out, bufs["hidden"], dict(residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL)),
                          (bufs["hidden"], layer.w_in_gated, bufs["act"], dict(epilogue=ops.EPI_SILU_MUL, **nf)),

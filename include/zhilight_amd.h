@@ -261,7 +261,7 @@ int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* q
  * all in the GEMV epilogue -- bit-identical to zl_w4a16_gemm_mfma + zl_rope_scatter_decode
  * (src/nn/attention/attention.cpp:846-900 issues project_q/k/v, rotary_embedding and copy_to_rag_buffer2 separately).
  * x (M, K) fp16, one row per task; q_out (M, H*D); tables as for zl_rope_scatter_decode.
- * Covers 1 <= M <= 32, D % 32 == 0, norm_weight only with M <= 4 and K <= 4096, K <= 8192 beyond 16 rows;
+ * Covers 1 <= M <= 32, D % 32 == 0, norm_weight only with M <= 8 and K <= 4096, K <= 8192 beyond 16 rows;
  * ZL_ESHAPE otherwise (use the two-call sequence). */
 int zl_w4a16_qkv_rope_scatter(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
                               const uint16_t* bias, const uint16_t* norm_weight, float norm_eps, const float* cosv,

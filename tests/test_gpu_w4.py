@@ -306,6 +306,17 @@ def test_qwen2_72b_tp4_rank_shapes(oracle, dev, k, n, norm, bias):
     _check_mfma(oracle, dev, k, n, 20, seed=302 + n, residual=not bias)
 
 
+@pytest.mark.parametrize("m", [2, 5, 7, 8])
+def test_phase_gemm_fused_norm_rows(oracle, dev, m, monkeypatch):
+    """the register-resident fused RMSNorm of the phase kernel for 1..8 rows (one instantiation of the row reductions
+    per row count), K with a partial last phase and K = 4096, several tiles-per-workgroup settings"""
+    for rounds in (1, 2, 7):
+        monkeypatch.setenv("ZL_W4_PHASE_ROUNDS", str(rounds))
+        _check_mfma(oracle, dev, 1152, 16 * rounds + 8, m, seed=130 + m + rounds, norm=True)
+    monkeypatch.delenv("ZL_W4_PHASE_ROUNDS")
+    _check_mfma(oracle, dev, 4096, 264, m, seed=135 + m, norm=True, bias=True)
+
+
 def test_streaming_gemm_random_shapes(oracle, dev, monkeypatch):
     """40 seeded random (M, N, K, epilogue, tiles-per-workgroup) draws over the streaming kernels' whole dispatch range
     (1..32 rows; fused norm where the launcher offers it; K from one partial phase to 20 phases; ragged N)"""
@@ -314,7 +325,7 @@ def test_streaming_gemm_random_shapes(oracle, dev, monkeypatch):
         m = int(rng.integers(1, 33))
         k = 128 * int(rng.integers(1, 161))
         n = 8 * int(rng.integers(2, 80))
-        norm = bool(rng.integers(0, 2)) and m <= 4 and k <= 4096
+        norm = bool(rng.integers(0, 2)) and m <= 8 and k <= 4096
         kind = int(rng.integers(0, 3))
         if rng.integers(0, 2):
             monkeypatch.setenv("ZL_W4_PHASE_ROUNDS", str(int(rng.integers(1, 9))))
@@ -446,7 +457,7 @@ def test_act_order_linear(oracle, dev, algo, monkeypatch):
              "l.scales": torch.from_numpy(sc.view(np.float16)), "l.g_idx": torch.from_numpy(bad)}, "l", dev)
 
 
-@pytest.mark.parametrize("m,norm", [(1, True), (3, True), (4, False), (8, False), (16, False), (17, False), (32, False)])
+@pytest.mark.parametrize("m,norm", [(1, True), (3, True), (4, False), (6, True), (8, True), (8, False), (16, False), (17, False), (32, False)])
 @pytest.mark.parametrize("bshd", [True, False])
 def test_fused_qkv_rotary_scatter_equals_two_call_sequence(oracle, dev, m, norm, bshd):
     """zl_w4a16_qkv_rope_scatter == zl_w4a16_gemm_mfma + zl_rope_scatter_decode, bit for bit: rotated q, and the K / V

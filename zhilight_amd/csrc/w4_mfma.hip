@@ -627,7 +627,7 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const
         const int ph_rounds = env_int("ZL_W4_PHASE_ROUNDS", 0);   // read per call: the tests sweep it
         static const int ph_small = env_int("ZL_W4_PHASE_SMALL", 1);   // 1..4 rows with K <= 4096 (incl. the fused norm)
         const bool rows_5_32 = !norm_weight && m >= ph_min_m && m <= ph_max_m && m <= 32 && k <= (m <= 16 ? ph_maxk_16 : ph_maxk_32);
-        const bool rows_1_4 = ph_small && m <= 4 && m < ph_min_m && k <= 4096;
+        const bool rows_1_4 = ph_small && k <= 4096 && (norm_weight ? m <= 8 : (m <= 4 && m < ph_min_m));   // fused norm: <= 8 rows
         if ((rows_5_32 || rows_1_4) && L.qw_bytes < ((int64_t)1 << 32))
             return zl_w4a16_gemm_phase(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y,
                                        (int)m, (int)n, (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n),
@@ -737,7 +737,7 @@ int zl_w4a16_qkv_rope_scatter(const uint16_t* x, int64_t ldx, const uint32_t* qw
     // what the phase-pipelined kernel covers (zl_w4a16_gemm_mfma's own dispatch rules); callers fall back to
     // zl_w4a16_gemm_mfma + zl_rope_scatter_decode outside of it
     ZL_CHECK_ARG(m <= 32 && d % 32 == 0 && h % 1 == 0 && L.np == n, ZL_ESHAPE);
-    ZL_CHECK_ARG(!norm_weight || (m <= 4 && k <= 4096), ZL_ESHAPE);
+    ZL_CHECK_ARG(!norm_weight || (m <= 8 && k <= 4096), ZL_ESHAPE);
     ZL_CHECK_ARG(m <= 16 || k <= 8192, ZL_ESHAPE);
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
     return zl_w4a16_gemm_phase_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n,

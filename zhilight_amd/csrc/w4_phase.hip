@@ -18,6 +18,7 @@
 //     when they are stored to the idle LDS buffer; one barrier per phase.
 // MB = 1: M <= 16, MB = 2: M <= 32 (two accumulator sets share every dequantised weight fragment).
 #include <stdlib.h>
+#include <type_traits>
 #include "zl_common.h"
 
 namespace {
@@ -141,14 +142,17 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
 #pragma unroll
         for (int c = 0; c < XC; ++c) *reinterpret_cast<uint4*>(dst + (xrow0 + 4 * c) * kXS) = xr[set][c];
     };
-    uint4 xn4[4], nw4 = make_uint4(0, 0, 0, 0);     // NORM: rows 0..3, this thread's 8 halfs; the norm weight slice
+    constexpr int kNR = 8;                           // rows the register-resident (NORM) variant carries
+    uint4 xn4[kNR], nw4 = make_uint4(0, 0, 0, 0);   // NORM: rows 0..7, this thread's 8 halfs; the norm weight slice
     if constexpr (NORM) {
         const int idx = threadIdx.x * 8;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const bool live = m < p.m && idx < p.k;
-            xn4[m] = *reinterpret_cast<const uint4*>(p.x + (live ? (size_t)m * p.ldx + idx : 0));
-            if (!live) xn4[m] = make_uint4(0, 0, 0, 0);
+        for (int m = 0; m < kNR; ++m) {
+            xn4[m] = make_uint4(0, 0, 0, 0);
+            if (m < p.m) {                             // workgroup-uniform: no load instructions for rows that do not exist
+                xn4[m] = *reinterpret_cast<const uint4*>(p.x + (idx < p.k ? (size_t)m * p.ldx + idx : 0));
+                if (idx >= p.k) xn4[m] = make_uint4(0, 0, 0, 0);
+            }
         }
         if (p.norm_w) nw4 = *reinterpret_cast<const uint4*>(p.norm_w + (idx < p.k ? idx : 0));
     } else {
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
         if ((int)(threadIdx.x >> 7) == ph) {
             uint16_t* dst = xs + (ph & 1) * kBuf + xcc;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < kNR; ++m) {
                 if (m < p.m) *reinterpret_cast<uint4*>(dst + m * kXS) = xn4[m];
             }
         }
@@ -199,41 +203,63 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
       // (norm_w == null: the register-resident staging alone -- up to 4 rows it beats the per-phase loads: 4.9 vs 5.1 us
       //  on the o projection at one row)
       if (p.norm_w) {
-        // sum of squares: per-thread chain, 64-lane butterfly, waves in order (zl_block_sum's order)
+        // sum of squares: per-thread chain, 64-lane butterfly, waves in order (zl_block_sum's order).  Instantiated per
+        // live row count so that the rows' shuffle chains sit in one basic block and interleave (a batch-1 step pays
+        // for one row; with a loop exit per row four rows cost 1.5 us).
         float* scratch = reinterpret_cast<float*>(smem + 2 * (size_t)kBuf * 2);
+        auto norm_rows = [&](auto nr_tag) {
+            constexpr int NRL = decltype(nr_tag)::value;
+            float part[NRL];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (m >= p.m) break;                      // workgroup-uniform: a batch-1 step pays for one row, not four
-            const uint32_t u[4] = {xn4[m].x, xn4[m].y, xn4[m].z, xn4[m].w};
-            float run = 0.f;
+            for (int m = 0; m < NRL; ++m) {
+                const uint32_t u[4] = {xn4[m].x, xn4[m].y, xn4[m].z, xn4[m].w};
+                float run = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const hv2 hh = __builtin_bit_cast(hv2, u[e]);
-                run = __builtin_fmaf((float)hh.x, (float)hh.x, run);
-                run = __builtin_fmaf((float)hh.y, (float)hh.y, run);
+                for (int e = 0; e < 4; ++e) {
+                    const hv2 hh = __builtin_bit_cast(hv2, u[e]);
+                    run = __builtin_fmaf((float)hh.x, (float)hh.x, run);
+                    run = __builtin_fmaf((float)hh.y, (float)hh.y, run);
+                }
+                part[m] = run;
             }
-            const float part = zl_wave_sum(run);
-            if (lane == 0) scratch[m * kW + wave] = part;
-        }
-        __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (m >= p.m) break;
-            float tot = 0.f;
+            for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-            for (int w = 0; w < kW; ++w) tot += scratch[m * kW + w];
-            const float rs = zl_rsqrt_rn(tot / (float)p.k + p.norm_eps);
-            uint32_t u[4] = {xn4[m].x, xn4[m].y, xn4[m].z, xn4[m].w};
-            const uint32_t wu[4] = {nw4.x, nw4.y, nw4.z, nw4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const hv2 hh = __builtin_bit_cast(hv2, u[e]), ww = __builtin_bit_cast(hv2, wu[e]);
-                hv2 o;
-                o.x = zl_f32_to_f16((float)hh.x * rs * (float)ww.x);
-                o.y = zl_f32_to_f16((float)hh.y * rs * (float)ww.y);
-                u[e] = __builtin_bit_cast(uint32_t, o);
+                for (int m = 0; m < NRL; ++m) part[m] += __shfl_xor(part[m], off, 64);   // zl_wave_sum's order, rows interleaved
             }
-            xn4[m] = make_uint4(u[0], u[1], u[2], u[3]);
+            if (lane == 0) {
+#pragma unroll
+                for (int m = 0; m < NRL; ++m) scratch[m * kW + wave] = part[m];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < NRL; ++m) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < kW; ++w) tot += scratch[m * kW + w];
+                const float rs = zl_rsqrt_rn(tot / (float)p.k + p.norm_eps);
+                uint32_t u[4] = {xn4[m].x, xn4[m].y, xn4[m].z, xn4[m].w};
+                const uint32_t wu[4] = {nw4.x, nw4.y, nw4.z, nw4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const hv2 hh = __builtin_bit_cast(hv2, u[e]), ww = __builtin_bit_cast(hv2, wu[e]);
+                    hv2 o;
+                    o.x = zl_f32_to_f16((float)hh.x * rs * (float)ww.x);
+                    o.y = zl_f32_to_f16((float)hh.y * rs * (float)ww.y);
+                    u[e] = __builtin_bit_cast(uint32_t, o);
+                }
+                xn4[m] = make_uint4(u[0], u[1], u[2], u[3]);
+            }
+        };
+        switch (p.m) {                                // workgroup-uniform
+            case 1: norm_rows(std::integral_constant<int, 1>{}); break;
+            case 2: norm_rows(std::integral_constant<int, 2>{}); break;
+            case 3: norm_rows(std::integral_constant<int, 3>{}); break;
+            case 4: norm_rows(std::integral_constant<int, 4>{}); break;
+            case 5: norm_rows(std::integral_constant<int, 5>{}); break;
+            case 6: norm_rows(std::integral_constant<int, 6>{}); break;
+            case 7: norm_rows(std::integral_constant<int, 7>{}); break;
+            default: norm_rows(std::integral_constant<int, 8>{}); break;
         }
       }
         store_norm(0);
@@ -500,7 +526,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
 
 template <int R, int MB, bool NORM, bool ROPE = false, int KS = 1>
 int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
-    constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS * 2 + (NORM ? 4 * kW * 4 : 0);
+    constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS * 2 + (NORM ? 8 * kW * 4 : 0);
     constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
     constexpr size_t lds = x_bytes > red_bytes ? x_bytes : red_bytes;
     static_assert(lds <= 160 * 1024, "LDS");
@@ -528,7 +554,7 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
                         uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
                         int k, int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps,
                         int rounds_override, hipStream_t hs) {
-    if (norm_w && (m > 4 || k > 4096)) return ZL_ESHAPE;
+    if (norm_w && (m > 8 || k > 4096)) return ZL_ESHAPE;
     PhaseParams p;
     p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
     p.meta_bytes = meta_bytes; p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k;
@@ -577,7 +603,7 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
                              const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
                              uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs) {
     if (m < 1 || m > 32 || d % 32 != 0 || n != (h + 2 * hkv) * d || tiles * 16 != n) return ZL_ESHAPE;
-    if (norm_w && (m > 4 || k > 4096)) return ZL_ESHAPE;
+    if (norm_w && (m > 8 || k > 4096)) return ZL_ESHAPE;
     PhaseParams p;
     p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
     p.meta_bytes = meta_bytes; p.bias = bias; p.residual = nullptr; p.y = nullptr; p.m = m; p.n = n; p.k = k;

@@ -471,6 +471,12 @@ class Int8EncoderLayer:
         ops.quant_back_element_add_scale(self.w_out.gemm(aq), sa, self.w_out.scale, hidden, 1.0, out=hidden)
 
 
+def _fused_norm_rows(weight):
+    """rows up to which the W4A16 kernel of this weight fuses the RMSNorm prologue: 8 for the phase-pipelined MFMA kernel
+    (register-resident activations, K <= 4096), 4 otherwise"""
+    return 8 if isinstance(weight, ops.W4MWeight) and weight.k <= 4096 and weight.group_size % 128 == 0 else 4
+
+
 class EncoderLayer:
     """nn::EncoderLayer (src/nn/block/block.h:15-63): ln_attn, attn{project_q,k,v,attn_out}, ln_ff,
     ff{w_in,w_gated,w_out}; q/k/v and w_in/w_gated are fused at load (CPM_FUSE_QKV / CPM_FUSE_FF_IN)."""
@@ -551,8 +557,8 @@ class EncoderLayer:
     # the two fused projections, or their act-order stand-ins (separate RMSNorm, per-linear gather, concat / gate_mul)
     def project_qkv(self, hidden, eps, out=None):
         if self.unfused is None:
-            if hidden.shape[0] > 4:   # the fused norm prologue normalises row by row per workgroup: beyond a few
-                xn = ops.rmsnorm(hidden, self.ln_attn, eps)   # rows one separate RMSNorm launch is cheaper
+            if hidden.shape[0] > _fused_norm_rows(self.qkv.weight):   # the fused norm prologue normalises every row in every
+                xn = ops.rmsnorm(hidden, self.ln_attn, eps)           # workgroup: beyond a few rows a separate launch is cheaper
                 return ops.w4_linear(xn, self.qkv.weight, bias=self.qkv.bias, out=out)
             return ops.w4_linear(hidden, self.qkv.weight, bias=self.qkv.bias, out=out, norm_weight=self.ln_attn, norm_eps=eps)
         xn = ops.rmsnorm(hidden, self.ln_attn, eps)
@@ -581,7 +587,7 @@ class EncoderLayer:
 
     def ff_in(self, hidden, eps, out=None):
         if self.unfused is None:
-            if hidden.shape[0] > 4:
+            if hidden.shape[0] > _fused_norm_rows(self.w_in_gated.weight):
                 xn = ops.rmsnorm(hidden, self.ln_ff, eps)
                 return ops.w4_linear(xn, self.w_in_gated.weight, bias=self.w_in_gated.bias, out=out, epilogue=ops.EPI_SILU_MUL)
             return ops.w4_linear(hidden, self.w_in_gated.weight, bias=self.w_in_gated.bias, out=out, norm_weight=self.ln_ff,
@@ -737,7 +743,7 @@ class LLaMA:
         fuse_qkv_rope = (mfma_attn and not ctx.kv_quant and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
                          and all(isinstance(l, EncoderLayer) and l.unfused is None and isinstance(l.qkv.weight, ops.W4MWeight)
                                  for l in self.layers)
-                         and ops.w4_qkv_rope_scatter_ok(b, c.dim_model, c.dim_head, norm=b <= 4))
+                         and ops.w4_qkv_rope_scatter_ok(b, c.dim_model, c.dim_head, norm=b <= 8))
         fuse_qkv_rope_i8 = (mfma_attn and not ctx.kv_quant and b <= 32 and c.dim_head % 32 == 0
                             and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
                             and all(isinstance(l, Int8EncoderLayer) and l._stream(b) for l in self.layers))
@@ -755,10 +761,10 @@ class LLaMA:
                 layer.ff_add(hidden, c.eps, bufs["act"])
                 continue
             if fuse_qkv_rope:
-                xin = hidden if b <= 4 else ops.rmsnorm(hidden, layer.ln_attn, c.eps)
+                xin = hidden if b <= 8 else ops.rmsnorm(hidden, layer.ln_attn, c.eps)
                 ops.w4_qkv_rope_scatter(xin, layer.qkv.weight, cos, sin, ctx.placement, ctx.buf_lens, ctx.k_addrs[li],
                                         ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, bias=layer.qkv.bias,
-                                        norm_weight=layer.ln_attn if b <= 4 else None, norm_eps=c.eps, q_out=bufs["q"])
+                                        norm_weight=layer.ln_attn if b <= 8 else None, norm_eps=c.eps, q_out=bufs["q"])
                 ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
                                                      ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
                                                      valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),

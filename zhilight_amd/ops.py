@@ -414,7 +414,7 @@ def rope_scatter_decode(cos, sin, qkv, placement, buf_lens, k_addrs, v_addrs, nu
 
 def w4_qkv_rope_scatter_ok(m, k, dim_head, norm):
     """what zl_w4a16_qkv_rope_scatter covers (otherwise: w4_linear + rope_scatter_decode)"""
-    return m <= 32 and dim_head % 32 == 0 and (not norm or (m <= 4 and k <= 4096)) and (m <= 16 or k <= 8192)
+    return m <= 32 and dim_head % 32 == 0 and (not norm or (m <= 8 and k <= 4096)) and (m <= 16 or k <= 8192)
 
 
 def w4_qkv_rope_scatter(x, w, cos, sin, placement, buf_lens, k_addrs, v_addrs, num_heads, num_kv_heads, dim_head, bias=None,
