@@ -118,7 +118,7 @@ def main():
     int8 = args.quant == "int8"
     tp = None
     if args.tp and world > 1:
-        from zhilight_amd.parallel import TPGroup
+        from zhilight_amd.parallel import TPGroup, max_over_ranks
         tp = TPGroup()
         torch.manual_seed(1234)            # every rank must draw the same tokens / KV contents
     model = LLaMA(cfg, QuantConfig(2, 0) if int8 else QuantConfig(5, 128), dev, tp=tp).init_random(seed=1234 + rank)
@@ -144,6 +144,39 @@ def main():
         ttft_ms = e0.elapsed_time(e1) / reps
         del pctx
         model._bufs = {k: v for k, v in model._bufs.items() if not (isinstance(k, tuple) and k[0] == "prefill")}
+        torch.cuda.empty_cache()
+
+    # TP: every rank encodes the same prompt (the collectives need all of them); once single-stream, once as the
+    # reference's DUAL_STREAM=1 route (all-reduce of one half on the second stream behind the other half's compute)
+    ttft_dual_ms = None
+    if tp is not None and not args.no_ttft:
+        gen = torch.Generator(device=dev).manual_seed(7)
+        prompt = torch.randint(0, cfg.vocab_size, (seq,), device=dev, dtype=torch.int32, generator=gen)
+
+        def ttft_leg(dual):
+            saved = {k: os.environ.get(k) for k in ("DUAL_STREAM", "DUAL_STREAM_THRESHOLD")}
+            os.environ["DUAL_STREAM"] = "1" if dual else "0"
+            os.environ["DUAL_STREAM_THRESHOLD"] = str(min(1024, seq - 1))
+            try:
+                pctx = model.new_context(1, len_buf, 0)
+                model.prefill(pctx, 0, prompt)
+                torch.cuda.synchronize()
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    model.prefill(pctx, 0, prompt)
+                e1.record()
+                torch.cuda.synchronize()
+                return max_over_ranks(e0.elapsed_time(e1) / 3, dev)
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        ttft_ms = ttft_leg(False)
+        ttft_dual_ms = ttft_leg(True)
         torch.cuda.empty_cache()
 
     def step():
@@ -321,6 +354,7 @@ def main():
             "per_gpu_tokens_per_s": round(value / world, 2),
             "note_tp": "TP mode was not exercised on multi-GPU hardware in round 1 (1-GPU dev box); numerics covered by the TP=2 emulation test" if tp else None,
             "ttft_ms": None if ttft_ms is None else round(ttft_ms, 3),
+            "ttft_dual_stream_ms": None if ttft_dual_ms is None else round(ttft_dual_ms, 3),
             "ttft_note": "prompt of seq tokens, one task, first greedy token; eager launches, HIP events, mean of 3",
             "step_hbm_roofline_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,

@@ -522,7 +522,9 @@ def test_minicpm_shaped_model_prefill_consistent_with_decode(dev):
 
 class _ThreadTP:
     """Stand-in for the RCCL group: both ranks of a TP = 2 model run as two threads on one GPU; the collectives
-    meet at a thread barrier (same default stream, so the device work is ordered)."""
+    meet at a thread barrier.  The calling stream is drained before each barrier (the dual-stream path calls from
+    a per-rank reduce stream, so device order alone does not relate the ranks); the write-back stays asynchronous
+    on the calling stream, like a real collective."""
 
     def __init__(self, size):
         import threading
@@ -539,12 +541,14 @@ class _ThreadTP:
                 self.group, self.rank, self.size = None, rank, outer.size
 
             def all_reduce_sum(self, t):
+                torch.cuda.current_stream().synchronize()      # this rank's partial is complete
                 outer.slots[rank] = t
                 outer.barrier.wait()
                 tot = outer.slots[0].float()
                 for o in outer.slots[1:]:
                     tot = tot + o.float()        # the reduction order of a 2-rank ring is a single add
                 tot = tot.to(t.dtype)
+                torch.cuda.current_stream().synchronize()      # every slot has been read before anyone overwrites its own
                 outer.barrier.wait()
                 t.copy_(tot)
                 return t
@@ -603,6 +607,82 @@ def test_tensor_parallel_decode_matches_single_gpu(dev):
         assert torch.equal(outs[0].argmax(dim=-1), nxt)
         ref_model.advance(ref_ctx, nxt)
         for m, c in zip(models, ctxs):
+            m.advance(c, nxt)
+
+
+def _run_ranks(fake, fn, n=2):
+    import threading
+    outs, errs = [None] * n, []
+
+    def run(r):
+        try:
+            outs[r] = fn(r)
+        except Exception as e:       # pragma: no cover
+            errs.append(e)
+            fake.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    return outs
+
+
+@pytest.mark.parametrize("s_prompt", [50, 33])
+def test_tensor_parallel_dual_stream_prefill(dev, monkeypatch, s_prompt):
+    """DUAL_STREAM=1 (src/model/llama.cpp:102-110 -> dual_stream_encode, src/nn/block/block.cpp:205-441): the TP = 2
+    prompt encode in two parts with the all-reduces on the second stream gives the logits and the KV of the
+    single-stream TP encode (add_fuse_ln normalises the un-rounded sum: fp16 noise) and of the unsharded model;
+    the decode steps that follow read that KV."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(43)
+    cfg = ModelConfig(num_layers=3, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5)
+    sd = {k: torch.from_numpy(v) for k, v in _hf_state(rng, cfg, 128).items()}
+    ref_model = LLaMA(cfg, QuantConfig(5, 128), dev).load_state_dict(sd)
+    fake = _ThreadTP(2)
+    models = [LLaMA(cfg, QuantConfig(5, 128), dev, tp=fake.view(r)).load_state_dict(sd) for r in range(2)]
+    prompt = torch.from_numpy(rng.integers(0, cfg.vocab_size, s_prompt).astype(np.int64))
+    len_buf = 128
+    ref_ctx = ref_model.new_context(1, len_buf, 0)
+    ref = ref_model.prefill(ref_ctx, 0, prompt).float()
+    scale = ref.abs().max().item()
+
+    # single-stream TP encode
+    ctx_s = [m.new_context(1, len_buf, 0) for m in models]
+    single = _run_ranks(fake, lambda r: models[r].prefill(ctx_s[r], 0, prompt).float())
+    assert not getattr(models[0], "dual_stream_runs", 0)
+
+    monkeypatch.setenv("DUAL_STREAM", "1")
+    monkeypatch.setenv("DUAL_STREAM_THRESHOLD", "16")
+    ctx_d = [m.new_context(1, len_buf, 0) for m in models]
+    dual = _run_ranks(fake, lambda r: models[r].prefill(ctx_d[r], 0, prompt).float())
+    torch.cuda.synchronize()
+    assert models[0].dual_stream_runs == 1 and models[1].dual_stream_runs == 1
+    assert torch.equal(dual[0], dual[1])
+    assert (dual[0] - single[0]).abs().max().item() <= 2e-3 * scale
+    assert (dual[0] - ref).abs().max().item() <= 2e-3 * scale
+    assert torch.equal(dual[0].argmax(dim=-1), ref.argmax(dim=-1))
+    for r in range(2):      # same KV rows as the single-stream TP encode, to fp16 noise of the hidden stream
+        a, b = ctx_d[r].kv[0][:, :, :s_prompt].float(), ctx_s[r].kv[0][:, :, :s_prompt].float()
+        assert (a - b).abs().max().item() <= 1e-2 * b.abs().max().item()
+        assert int(ctx_d[r].positions[0]) == s_prompt and int(ctx_d[r].valid_lens[0]) == s_prompt + 1
+
+    # chunked + dual-stream: every piece above the threshold takes the two-stream route (CHUNKED_PREFILL with DUAL_STREAM)
+    ctx_c = [m.new_context(1, len_buf, 0) for m in models]
+    chunked = _run_ranks(fake, lambda r: models[r].prefill(ctx_c[r], 0, prompt, chunk=24).float())
+    assert models[0].dual_stream_runs >= 2
+    assert (chunked[0] - ref).abs().max().item() <= 2e-3 * scale
+
+    for step in range(2):
+        ref_step = ref_model.encode(ref_ctx).float()
+        outs = _run_ranks(fake, lambda r: models[r].encode(ctx_d[r]).float())
+        assert (outs[0] - ref_step).abs().max().item() <= 2e-3 * ref_step.abs().max().item()
+        nxt = ref_step.argmax(dim=-1)
+        assert torch.equal(outs[0].argmax(dim=-1), nxt)
+        ref_model.advance(ref_ctx, nxt)
+        for m, c in zip(models, ctx_d):
             m.advance(c, nxt)
 
 

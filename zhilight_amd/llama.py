@@ -555,13 +555,16 @@ class EncoderLayer:
         return sum(l.weight.nbytes() for l in self.linears())
 
     # the two fused projections, or their act-order stand-ins (separate RMSNorm, per-linear gather, concat / gate_mul)
-    def project_qkv(self, hidden, eps, out=None):
+    def project_qkv(self, hidden, eps, out=None, normed=None):
+        """normed: ln_attn(hidden) already computed by the caller (the dual-stream path's fused add + norm)"""
         if self.unfused is None:
+            if normed is not None:
+                return ops.w4_linear(normed, self.qkv.weight, bias=self.qkv.bias, out=out)
             if hidden.shape[0] > _fused_norm_rows(self.qkv.weight):   # the fused norm prologue normalises every row in every
                 xn = ops.rmsnorm(hidden, self.ln_attn, eps)           # workgroup: beyond a few rows a separate launch is cheaper
                 return ops.w4_linear(xn, self.qkv.weight, bias=self.qkv.bias, out=out)
             return ops.w4_linear(hidden, self.qkv.weight, bias=self.qkv.bias, out=out, norm_weight=self.ln_attn, norm_eps=eps)
-        xn = ops.rmsnorm(hidden, self.ln_attn, eps)
+        xn = normed if normed is not None else ops.rmsnorm(hidden, self.ln_attn, eps)
         parts = [l.forward(xn) for l in self.unfused[:3]]
         return torch.cat(parts, dim=1, out=out) if out is not None else torch.cat(parts, dim=1)
 
@@ -585,14 +588,16 @@ class EncoderLayer:
             return self._row_parallel_add(self.w_out, act, hidden)
         self.w_out.forward(act, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
 
-    def ff_in(self, hidden, eps, out=None):
+    def ff_in(self, hidden, eps, out=None, normed=None):
         if self.unfused is None:
+            if normed is not None:
+                return ops.w4_linear(normed, self.w_in_gated.weight, bias=self.w_in_gated.bias, out=out, epilogue=ops.EPI_SILU_MUL)
             if hidden.shape[0] > _fused_norm_rows(self.w_in_gated.weight):
                 xn = ops.rmsnorm(hidden, self.ln_ff, eps)
                 return ops.w4_linear(xn, self.w_in_gated.weight, bias=self.w_in_gated.bias, out=out, epilogue=ops.EPI_SILU_MUL)
             return ops.w4_linear(hidden, self.w_in_gated.weight, bias=self.w_in_gated.bias, out=out, norm_weight=self.ln_ff,
                                  norm_eps=eps, epilogue=ops.EPI_SILU_MUL)
-        xn = ops.rmsnorm(hidden, self.ln_ff, eps)
+        xn = normed if normed is not None else ops.rmsnorm(hidden, self.ln_ff, eps)
         gate = self.unfused[3].forward(xn, out=out)
         return ops.gate_mul(gate, self.unfused[4].forward(xn), "silu")
 
@@ -843,10 +848,96 @@ class LLaMA:
         attending to the KV of the pieces before it)."""
         s = int(prompt.numel())
         if chunk <= 0 or chunk >= s:
-            return self._prefill_chunk(ctx, task, prompt, 0)
+            return self._encode_prompt(ctx, task, prompt, 0)
         logits = None
         for p0 in range(0, s, chunk):
-            logits = self._prefill_chunk(ctx, task, prompt[p0:p0 + chunk], p0)
+            logits = self._encode_prompt(ctx, task, prompt[p0:p0 + chunk], p0)
+        return logits
+
+    def _encode_prompt(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor, pos0: int):
+        """LLaMA::encode's switch (src/model/llama.cpp:102-110): with DUAL_STREAM=1, more than one TP rank and more
+        than DUAL_STREAM_THRESHOLD (1024) tokens in the piece, the layers run as dual_stream_encode."""
+        if (self.tp and int(os.environ.get("DUAL_STREAM", "0")) > 0 and not ctx.kv_quant
+                and int(prompt.numel()) > int(os.environ.get("DUAL_STREAM_THRESHOLD", "1024"))):
+            return self._prefill_dual_stream(ctx, task, prompt, pos0)
+        return self._prefill_chunk(ctx, task, prompt, pos0)
+
+    def _prefill_dual_stream(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor, pos0: int):
+        """EncoderLayer::impl::dual_stream_encode (src/nn/block/block.cpp:205-441) on two HIP streams: the piece is
+        cut in DUAL_STREAM_NUM_SPLIT (2) parts of round_up(ceil(S / 2), 16) rows; every row-parallel partial output
+        (attn_out, w_out) is all-reduced on a second, higher-priority stream while the main stream computes the other
+        part, so the xGMI transfer of one half hides behind the GEMMs / attention of the other.  Part k of a layer
+        starts with add_fuse_ln (layernorm.cu:227-302: c = T(hidden + reduced), norm of the fp32 sum) once its own
+        reduce has landed; the later part attends to the earlier part's K/V through the cache, like a prefill chunk.
+        Ordering is stream events only (main -> reduce before the collective, reduce -> main before the add); the
+        partial stays referenced until the main stream has consumed it, so no allocator hand-over is needed."""
+        c, dev = self.cfg, self.device
+        s = int(prompt.numel())
+        if s < 1 or pos0 + s + 1 > ctx.max_len_buf:
+            raise ops.ZLError("prompt does not fit the task's KV buffer")
+        num_split = max(1, int(os.environ.get("DUAL_STREAM_NUM_SPLIT", "2")))
+        round_up = max(1, int(os.environ.get("DUAL_STREAM_SPLIT_ROUND_UP", "16")))
+        part = -(-(-(-s // num_split)) // round_up) * round_up
+        bounds = [(a, min(a + part, s)) for a in range(0, s, part)]
+        tokens = prompt.to(device=dev, dtype=torch.int32).contiguous()
+        pos = torch.arange(pos0, pos0 + s, dtype=torch.int32, device=dev)
+        hidden_all = ops.embedding(tokens, self.token_embedding, c.scale_emb)
+        cos, sin = ops.rope_cos_sin(pos, c.dim_head, c.rope_theta, True, self._llama3_rope())
+        buf_lens = ctx.buf_lens[task:task + 1]
+        scale = 1.0 / math.sqrt(c.dim_head)
+        main = torch.cuda.current_stream(dev)
+        if "reduce_stream" not in self._bufs:
+            self._bufs["reduce_stream"] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("DUAL_STREAM_PRIORITY", "-1")))
+        red = self._bufs["reduce_stream"]
+        main_ev = [torch.cuda.Event() for _ in bounds]
+        done_ev = [torch.cuda.Event() for _ in bounds]
+        hidden = [hidden_all[a:b] for a, b in bounds]
+        pending = [None] * len(bounds)
+
+        def reduce_async(k, partial):
+            main_ev[k].record(main)
+            red.wait_event(main_ev[k])
+            with torch.cuda.stream(red):
+                self.tp.all_reduce_sum(partial)
+                done_ev[k].record(red)
+            pending[k] = partial
+
+        def reduced(k):
+            partial, pending[k] = pending[k], None
+            main.wait_event(done_ev[k])
+            return partial
+
+        for li, layer in enumerate(self.layers):
+            ka, va = ctx.k_addrs[li][task:task + 1], ctx.v_addrs[li][task:task + 1]
+            for k, (a, b) in enumerate(bounds):
+                n = b - a
+                if li == 0:
+                    xn = ops.rmsnorm(hidden[k], layer.ln_attn, c.eps)
+                else:
+                    xn, hidden[k] = ops.rmsnorm(hidden[k], layer.ln_attn, c.eps, x2=reduced(k))
+                qkv = layer.project_qkv(None, c.eps, normed=xn)
+                q, kr, v = ops.rope_qk_cache(cos[a:b], sin[a:b], qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
+                ops.copy_to_rag_buffer2(pos[a:b].view(1, n), buf_lens, kr.view(1, n, c.num_kv_heads, c.dim_head),
+                                        v.view(1, n, c.num_kv_heads, c.dim_head), ka, va)
+                if c.dim_head == 128:
+                    att = ops.prefill_attention(q.view(n, c.num_heads, c.dim_head), ctx.kv[task][li, 0], ctx.kv[task][li, 1],
+                                                pos0 + a, c.num_kv_heads, scale)
+                else:
+                    mask, ws = self._prefill_mask(n, ctx.max_len_buf, pos0 + a)
+                    att = ops.multi_query_attention_rag_buffer(q.view(1, n, c.num_heads, c.dim_head), buf_lens, ka, va, mask,
+                                                               scale, ctx.max_len_buf, c.num_kv_heads, workspace=ws)
+                reduce_async(k, layer.attn_out.forward(att.view(n, -1)))
+            for k in range(len(bounds)):
+                xn, hidden[k] = ops.rmsnorm(hidden[k], layer.ln_ff, c.eps, x2=reduced(k))
+                reduce_async(k, layer.w_out.forward(layer.ff_in(None, c.eps, normed=xn)))
+        for k in range(len(bounds)):
+            hidden[k] = ops.element_add_scale(hidden[k], reduced(k), 1.0, True)
+        self.dual_stream_runs = getattr(self, "dual_stream_runs", 0) + 1
+        logits = self._logits(hidden[-1][-1:])
+        ctx.tokens[task] = torch.argmax(logits[0].float()).to(torch.int32)
+        ctx.positions[task] = pos0 + s
+        ctx.placement[task] = pos0 + s
+        ctx.valid_lens[task] = pos0 + s + 1
         return logits
 
     def _prefill_chunk(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor, pos0: int):
