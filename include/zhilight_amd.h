@@ -269,6 +269,24 @@ int zl_w4a16_qkv_rope_scatter(const uint16_t* x, int64_t ldx, const uint32_t* qw
                               uint16_t* const* k_bufs, uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h,
                               int64_t hkv, int64_t d, int64_t k, int64_t group_size, int bshd, zl_stream_t s);
 
+/* Decode attention with the split merge folded into the attention output projection (len_q == 1 per task, prefix
+ * visibility, D == 128, H / Hkv <= 16: the matrix-core kernel).  zl_decode_attn_splits is zl_decode_attn without its
+ * merge launch: it leaves the split-KV partials in `workspace`; zl_w4a16_gemm_attn_merge is zl_w4a16_gemm_mfma of the
+ * attn_out projection (src/nn/attention/attention.cpp:944-958) whose activation rows are merged from those partials in
+ * the GEMV prologue, with the merge kernel's arithmetic and order -- bit-identical to zl_decode_attn +
+ * zl_w4a16_gemm_mfma, one launch less per layer.  split_len = zl_decode_attn_split_len(b, hkv, max_len_buf),
+ * max_splits = ceil(max_len_buf / split_len); the workspace, buf_lens and valid_lens are the ones given to
+ * zl_decode_attn_splits.  Covers M = B <= 4, K = H * 128 <= 4096, max_splits <= 16, no gated epilogue, at most two
+ * row tiles per CU; ZL_ESHAPE otherwise (use the two-call sequence). */
+int64_t zl_decode_attn_split_len(int64_t b, int64_t hkv, int64_t max_len_buf);
+int zl_decode_attn_splits(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
+                          const uint16_t* const* v_bufs, const int32_t* valid_lens, void* workspace, int64_t b, int64_t h,
+                          int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, int dtype, zl_stream_t s);
+int zl_w4a16_gemm_attn_merge(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens,
+                             int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
+                             const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
+                             int64_t group_size, int epilogue, zl_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * a15q  INT8 KV cache (RagBufferContext::is_cache_quant, src/model/rag_buffer_context.h:96).
  * A cached K/V row of one kv head is D unsigned codes + one fp32 scale:

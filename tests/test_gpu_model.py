@@ -206,6 +206,35 @@ def test_decode_steps_match_oracle(oracle, dev, batch, algo, monkeypatch):
             assert np.abs(gv - rv).max() <= 2.0 ** -9 * np.abs(rv).max()
 
 
+@pytest.mark.parametrize("batch,max_b", [(1, "1"), (3, "4")])
+def test_decode_step_attention_merge_in_projection_is_bit_identical(dev, batch, max_b, monkeypatch):
+    """The decode step with the attention split merge folded into the attn_out projection (default at batch 1) gives
+    the logits of the step with the separate merge launch, bit for bit, over several steps (growing KV)."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(9)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5)
+    sd = {k: torch.from_numpy(v) for k, v in _hf_state(rng, cfg, 128).items()}
+    model = LLaMA(cfg, QuantConfig(5, 128), dev).load_state_dict(sd)
+    tokens = torch.from_numpy(rng.integers(0, cfg.vocab_size, batch).astype(np.int32))
+    outs = {}
+    for merge in ("0", "1"):
+        monkeypatch.setenv("ZL_ATTN_MERGE", merge)
+        monkeypatch.setenv("ZL_ATTN_MERGE_MAX_B", max_b)
+        ctx = model.new_context(batch, 512, 250, fill_random=False)
+        torch.manual_seed(3)
+        for t in ctx.kv:
+            t.copy_(torch.randn(t.shape, device=dev).to(t.dtype))
+        ctx.tokens.copy_(tokens)
+        seq = []
+        for _ in range(8):                 # crosses the 256-key split boundary
+            logits = model.encode(ctx).clone()
+            seq.append(logits)
+            model.advance(ctx, logits.argmax(dim=-1))
+        outs[merge] = torch.stack(seq)
+    assert torch.equal(outs["0"], outs["1"])
+
+
 def test_step_greedy_matches_argmax_and_advances(dev):
     """The in-launch greedy pick equals torch.argmax on the logits (first index on ties) and the device-side
     bookkeeping equals LLaMA.advance."""

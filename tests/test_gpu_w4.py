@@ -495,3 +495,65 @@ def test_fused_qkv_rotary_scatter_equals_two_call_sequence(oracle, dev, m, norm,
     for a, b_ in zip(k1 + v1, k2 + v2):
         assert torch.equal(a, b_)
     assert not torch.equal(k1[0], torch.full_like(k1[0], 3.0))
+
+
+@pytest.mark.parametrize("b,h,hkv,n,lens,valid", [
+    (1, 32, 8, 4096, [1088], [1025]),                       # the batch-1 decode step: 9 splits, the last holds one key
+    (1, 32, 8, 4096, [1088], [1]),                          # a single key
+    (1, 16, 4, 2048 + 16, [2048], [2048]),                  # K = 2048: half the threads hold no activation; 16 splits
+    (3, 32, 8, 4096, [640, 128, 1088], [517, 128, 1000]),   # ragged tasks, different split counts per row
+    (4, 32, 4, 8192, [256, 192, 64, 256], [129, 192, 33, 256]),   # two row tiles per workgroup
+])
+def test_attention_split_merge_in_attn_out_projection(oracle, dev, b, h, hkv, n, lens, valid):
+    """zl_decode_attn_splits + zl_w4a16_gemm_attn_merge (the split merge in the GEMV prologue) == zl_decode_attn +
+    zl_w4a16_gemm_mfma bit for bit, plain and residual epilogues."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(600 + b + n)
+    d, g, k = 128, 128, h * 128
+    n8 = (n + 7) // 8 * 8
+    qw, qz, sc = synth.gptq_hf(rng, k, n8, g)
+    km = tuple(np.ascontiguousarray(a[:n]) for a in oracle.gptq_prepare_k_major(qw, qz, sc, g))
+    w = ops.W4MWeight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), g)
+    max_len = max(lens)
+    dk = [torch.randn(L, hkv, d, device=dev).half() for L in lens]
+    dv = [torch.randn(L, hkv, d, device=dev).half() for L in lens]
+    q = torch.randn(b, 1, h, d, device=dev).half()
+    bl, vl = _t(np.array(lens, np.int32), dev), _t(np.array(valid, np.int32), dev)
+    ka, va = ops.make_ptr_table(dk), ops.make_ptr_table(dv)
+    scale = 1.0 / np.sqrt(d)
+    import os
+    os.environ["ZL_ATTN_MERGE_MAX_B"] = "4"
+    try:
+        plan = ops.attn_merge_plan(b, h, hkv, d, max_len, w)
+    finally:
+        del os.environ["ZL_ATTN_MERGE_MAX_B"]
+    assert plan is not None
+    ws = ops.decode_attn_workspace(b, 1, h, d, max_len, dev)
+    att = ops.multi_query_attention_rag_buffer(q, bl, ka, va, None, scale, max_len, hkv, valid_lens=vl, workspace=ws)
+    res = torch.randn(b, n, device=dev).half()
+    want = ops.w4a16_gemm_mfma(att.view(b, k), w)
+    want_res = ops.w4a16_gemm_mfma(att.view(b, k), w, residual=res, epilogue=ops.EPI_RESIDUAL)
+    ws.fill_(float("nan"))                                   # nothing stale may be read
+    ops.decode_attention_splits(q, bl, ka, va, vl, scale, max_len, hkv, ws)
+    got = ops.w4_attn_out_merge(ws, bl, vl, plan, b, w)
+    got_res = ops.w4_attn_out_merge(ws, bl, vl, plan, b, w, residual=res, epilogue=ops.EPI_RESIDUAL)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, want) and torch.equal(got_res, want_res)
+
+
+def test_attention_split_merge_plan_limits(dev):
+    from zhilight_amd import ops
+    from zhilight_amd._lib import ZLError
+    w = ops.W4MWeight(4096, 4096, 128, None, None)
+    assert ops.attn_merge_plan(1, 32, 8, 128, 1088, w) == (128, 9)
+    assert ops.attn_merge_plan(2, 32, 8, 128, 1088, w) is None          # ZL_ATTN_MERGE_MAX_B defaults to 1
+    assert ops.attn_merge_plan(1, 32, 8, 128, 4096, w) is None          # 32 splits
+    assert ops.attn_merge_plan(1, 32, 8, 64, 1088, w) is None
+    ws = torch.zeros(1 << 16, dtype=torch.float32, device=dev)
+    i32 = torch.ones(8, dtype=torch.int32, device=dev)
+    wq = torch.zeros(8 * 1024 * 1024 // 4, dtype=torch.int32, device=dev)
+    real = ops.W4MWeight(4096, 4096, 128, wq, wq)
+    with pytest.raises(ZLError):
+        ops.w4_attn_out_merge(ws, i32, i32, (128, 9), 5, real)          # more than 4 rows
+    with pytest.raises(ZLError):
+        ops.w4_attn_out_merge(ws, i32, i32, (128, 17), 1, real)         # more than 16 splits

@@ -28,6 +28,7 @@ SYMBOLS = [
     "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rotary_embedding_qk", "zl_rope_qk_cache",
     "zl_copy_to_rag_buffer2", "zl_rope_scatter_decode", "zl_w4a16_qkv_rope_scatter",
     "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_fused",
+    "zl_decode_attn_split_len", "zl_decode_attn_splits", "zl_w4a16_gemm_attn_merge",
     "zl_quant_calc_scale_zp", "zl_quant_copy_to_rag_buffer", "zl_rope_quant_scatter_decode", "zl_decode_attn_quant",
     "zl_prefill_attn",
     "zl_element_add_scale", "zl_gate_mul", "zl_embedding",
@@ -59,6 +60,7 @@ def lib():
             getattr(l, name)  # AttributeError if the library does not export it
         l.zl_status_string.restype = C.c_char_p
         l.zl_decode_attn_workspace_bytes.restype = C.c_int64
+        l.zl_decode_attn_split_len.restype = C.c_int64
         l.zl_argmax_workspace_bytes.restype = C.c_int64
         l.zl_w8m_bytes.restype = C.c_int64
         _lib = l

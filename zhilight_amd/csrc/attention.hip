@@ -1210,6 +1210,34 @@ int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* c
     ZL_ATTN_D(ZL_BF16, false)
 }
 
+int64_t zl_decode_attn_split_len(int64_t b, int64_t hkv, int64_t max_len_buf) {
+    if (b <= 0 || hkv <= 0 || max_len_buf <= 0) return ZL_EINVAL;
+    return attn_split_len(b, hkv, max_len_buf);
+}
+
+int zl_decode_attn_splits(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
+                          const uint16_t* const* v_bufs, const int32_t* valid_lens, void* workspace, int64_t b, int64_t h,
+                          int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(q && buf_lens && k_bufs && v_bufs && valid_lens && workspace, ZL_EINVAL);
+    ZL_CHECK_ARG(b > 0 && h > 0 && hkv > 0 && d > 0 && max_len_buf > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(h % hkv == 0 && d == kMD && h / hkv <= 16 && b <= 65535 && hkv <= 65535, ZL_ESHAPE);   // the matrix-core kernel
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    AttnParams p;
+    p.q = q; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs; p.mask = nullptr; p.valid_lens = valid_lens;
+    p.out = nullptr; p.ws = (float*)workspace;
+    p.b = (int)b; p.len_q = 1; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
+    p.rows = p.n_rep; p.passes = 1;
+    p.split_len = attn_split_len(b, hkv, max_len_buf);
+    p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    p.scale = scale; p.bshd = bshd;
+    p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
+    p.k_scales = p.v_scales = nullptr;
+    const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
+    if (dtype == ZL_F16) hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, p);
+    else hipLaunchKernelGGL(k_decode_attn_mfma<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, p);
+    return zl_launch_status();
+}
+
 int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* qkv, const int32_t* placement,
                          const int32_t* buf_lens, const int32_t* valid_lens, uint16_t* const* k_bufs,
                          uint16_t* const* v_bufs, uint16_t* out, void* workspace, int64_t b, int64_t h, int64_t hkv,

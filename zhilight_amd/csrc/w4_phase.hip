@@ -63,6 +63,12 @@ struct PhaseParams {
     // split order and runs the epilogue
     float* ks_ws;               // [KS][M][N]
     int* ks_counter;            // one per tile group, zero between launches
+    // MERGE instantiations (the attention output projection of a decode step): the activations are the split-KV
+    // partials of the decode attention kernel (attention.hip workspace: [row][head][split][128 acc | max | sum] fp32);
+    // the merge of k_decode_attn_combine runs in the prologue, so the step has one launch less.  Uses buf_lens above.
+    const float* mg_ws;
+    const int32_t* mg_valid_lens;
+    int mg_split_len, mg_max_splits;
 };
 
 constexpr int ring_depth(int r) { return r == 1 ? 3 : r == 2 ? 4 : r == 3 ? 6 : r == 4 ? 8 : r; }
@@ -100,8 +106,13 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)
 // ROPE (R = 2): the workgroup's two tiles are a column block and its rotation partners (D/2 columns = D/32 tiles
 // further), so the neox rotation of q and k happens in the epilogue on the fp16-rounded projection outputs, with the
 // roundings of the separate kernels (rope_common.cuh:14-34: one rounding to T after the fp32 rotation).
-template <int R, int MB, bool NORM, bool ROPE, int KS = 1>
-__global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
+// MERGE (NORM staging, M <= 4, K = heads x 128 <= 4096, <= 16 splits): x row m = the merged decode-attention splits of
+// task m, computed per thread for its own 8 halfs with k_decode_attn_combine's arithmetic and order (bit-identical).
+// One workgroup per CU (the grid has at most one generation), so the prologue may hold 16 splits x 8 floats in VGPRs
+// and have every load of a row in flight at once.
+template <int R, int MB, bool NORM, bool ROPE, int KS = 1, bool MERGE = false>
+__global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhaseParams p) {
+    static_assert(!MERGE || (NORM && !ROPE && KS == 1), "split merge: register-resident staging");
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
     static_assert(KS == 1 || (!ROPE && !NORM), "K split: plain / bias / residual epilogues only");
     constexpr int D = ring_depth(R), XP = NORM ? 1 : x_ahead(R), BODY = lcm_(D, R * XP);
@@ -142,9 +153,12 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
 #pragma unroll
         for (int c = 0; c < XC; ++c) *reinterpret_cast<uint4*>(dst + (xrow0 + 4 * c) * kXS) = xr[set][c];
     };
-    constexpr int kNR = 8;                           // rows the register-resident (NORM) variant carries
+    constexpr int kNR = MERGE ? 4 : 8;               // rows the register-resident (NORM) variant carries
     uint4 xn4[kNR], nw4 = make_uint4(0, 0, 0, 0);   // NORM: rows 0..7, this thread's 8 halfs; the norm weight slice
-    if constexpr (NORM) {
+    if constexpr (MERGE) {
+#pragma unroll
+        for (int m = 0; m < kNR; ++m) xn4[m] = make_uint4(0, 0, 0, 0);
+    } else if constexpr (NORM) {
         const int idx = threadIdx.x * 8;
 #pragma unroll
         for (int m = 0; m < kNR; ++m) {
@@ -202,7 +216,67 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     if constexpr (NORM) {
       // (norm_w == null: the register-resident staging alone -- up to 4 rows it beats the per-phase loads: 4.9 vs 5.1 us
       //  on the o projection at one row)
-      if (p.norm_w) {
+      if constexpr (MERGE) {   // after the ring issue: the first weights are in flight while the splits merge
+        // Thread (head = t / 16, j = t % 16) merges d = 2 j + 32 e, + 1 (e < 4): one load instruction then covers 128
+        // contiguous bytes per head (8-byte lanes at 32-byte stride took 4x the cache-line accesses and 4 us).  The
+        // fp16 results change hands through LDS (the phase-1 x buffer, idle until the end of phase 0) into the
+        // staging assignment (thread t: halfs 8 t .. 8 t + 7).
+        constexpr int kS = 16, kWS = 128 + 2;        // splits held at once; floats per split record
+        const int idx = threadIdx.x * 8, heads = p.k >> 7;
+        const bool act = idx < p.k;
+        const int head = act ? (int)(threadIdx.x >> 4) : 0, j = threadIdx.x & 15;
+        uint32_t* scr = reinterpret_cast<uint32_t*>(xs + kBuf);   // [row][2048] fp16 pairs
+        static_assert(kBuf * 2 >= 4 * 2048 * 4, "merge scratch");
+#pragma unroll
+        for (int m = 0; m < kNR; ++m) {
+            if (m < p.m) {                             // workgroup-uniform
+                const int elen = min(p.buf_lens[m], p.mg_valid_lens[m]);
+                const int ns = min((elen + p.mg_split_len - 1) / p.mg_split_len, kS);
+                const float* src = p.mg_ws + ((size_t)m * heads + head) * p.mg_max_splits * kWS;
+                float2 st[kS], v[kS][4];
+#pragma unroll
+                for (int u = 0; u < kS; ++u) {
+                    st[u] = make_float2(-1e20f, 0.f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = make_float2(0.f, 0.f);
+                    if (u < ns) {                      // uniform: no loads for splits that do not exist
+                        st[u] = *reinterpret_cast<const float2*>(src + (size_t)u * kWS + 128);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[u][e] = *reinterpret_cast<const float2*>(src + (size_t)u * kWS + 2 * j + 32 * e);
+                    }
+                }
+                float mn = -1e20f;
+#pragma unroll
+                for (int u = 0; u < kS; ++u) mn = fmaxf(mn, st[u].x);
+                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, z = 0.f;
+#pragma unroll
+                for (int u = 0; u < kS; ++u) {
+                    if (u < ns) {
+                        const float f = __expf(st[u].x - mn);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[2 * e] = __builtin_fmaf(v[u][e].x, f, a[2 * e]);
+                            a[2 * e + 1] = __builtin_fmaf(v[u][e].y, f, a[2 * e + 1]);
+                        }
+                        z = __builtin_fmaf(st[u].y, f, z);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hv2 hh;
+                    hh.x = zl_f32_to_f16(a[2 * e] / (z + 1e-20f));
+                    hh.y = zl_f32_to_f16(a[2 * e + 1] / (z + 1e-20f));
+                    if (act) scr[m * 2048 + head * 64 + j + 16 * e] = __builtin_bit_cast(uint32_t, hh);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kNR; ++m) {
+            if (m < p.m && act) xn4[m] = *reinterpret_cast<const uint4*>(scr + m * 2048 + threadIdx.x * 4);
+        }
+      }
+      if constexpr (!MERGE) if (p.norm_w) {
         // sum of squares: per-thread chain, 64-lane butterfly, waves in order (zl_block_sum's order).  Instantiated per
         // live row count so that the rows' shuffle chains sit in one basic block and interleave (a batch-1 step pays
         // for one row; with a loop exit per row four rows cost 1.5 us).
@@ -524,7 +598,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_phase(const PhaseParams p) {
     }
 }
 
-template <int R, int MB, bool NORM, bool ROPE = false, int KS = 1>
+template <int R, int MB, bool NORM, bool ROPE = false, int KS = 1, bool MERGE = false>
 int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
     constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS * 2 + (NORM ? 8 * kW * 4 : 0);
     constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
@@ -533,13 +607,13 @@ int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
     if (lds > 64 * 1024) {
         static bool done = false;   // per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE, KS>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return ZL_ELIMIT;
             done = true;
         }
     }
-    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE>), dim3(grid), dim3(kT), lds, hs, p);
     return zl_launch_status();
 }
 
@@ -562,6 +636,7 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     p.cosv = p.sinv = nullptr; p.placement = p.buf_lens = nullptr; p.k_bufs = p.v_bufs = nullptr; p.q_out = nullptr;
     p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
     p.ks_ws = nullptr; p.ks_counter = nullptr;
+    p.mg_ws = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
     {   // long K with more than 16 rows: K split over 2 or 4 adjacent workgroups (R = KS tiles each, same grid size)
         static const int ksplit = [] { const char* e = getenv("ZL_W4_PHASE_KSPLIT"); return e ? atoi(e) : 2; }();
         const bool plain = !(epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) && !norm_w;
@@ -611,7 +686,35 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
     p.norm_w = norm_w; p.norm_eps = norm_eps;
     p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs;
     p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd; p.pair_stride = d / 32;
+    p.ks_ws = nullptr; p.ks_counter = nullptr;
+    p.mg_ws = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
     const int grid = tiles / 2;
     if (norm_w || (m <= 4 && k <= 4096)) return launch_phase<2, 1, true, true>(p, grid, hs);
     return m <= 16 ? launch_phase<2, 1, false, true>(p, grid, hs) : launch_phase<2, 2, false, true>(p, grid, hs);
+}
+
+// internal (called by zl_w4a16_gemm_attn_merge): the attention output projection of a decode step reading the
+// split-KV partials of zl_decode_attn_splits instead of a merged activation row.  m <= 4, k = heads * 128 <= 4096,
+// max_splits <= 16, at most one generation of workgroups (tiles <= 2 * CUs).
+int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len,
+                              int max_splits, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                              uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
+                              int k, int groups, int tiles, int epilogue, hipStream_t hs) {
+    if (m < 1 || m > 4 || k > 4096 || k % 128 != 0 || max_splits < 1 || max_splits > 16 || split_len < 1) return ZL_ESHAPE;
+    if (epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) return ZL_ESHAPE;
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    const int r = (tiles + cus - 1) / cus;
+    if (r > 2) return ZL_ESHAPE;
+    PhaseParams p;
+    p.x = nullptr; p.ldx = 0; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
+    p.meta_bytes = meta_bytes; p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k;
+    p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = epilogue; p.ld_out = n;
+    p.norm_w = nullptr; p.norm_eps = 0.f;
+    p.cosv = p.sinv = nullptr; p.placement = nullptr; p.buf_lens = buf_lens; p.k_bufs = p.v_bufs = nullptr; p.q_out = nullptr;
+    p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
+    p.ks_ws = nullptr; p.ks_counter = nullptr;
+    p.mg_ws = ws; p.mg_valid_lens = valid_lens; p.mg_split_len = split_len; p.mg_max_splits = max_splits;
+    const int grid = (tiles + r - 1) / r;
+    return r == 1 ? launch_phase<1, 1, true, false, 1, true>(p, grid, hs) : launch_phase<2, 1, true, false, 1, true>(p, grid, hs);
 }

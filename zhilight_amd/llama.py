@@ -752,6 +752,12 @@ class LLaMA:
         fuse_qkv_rope_i8 = (mfma_attn and not ctx.kv_quant and b <= 32 and c.dim_head % 32 == 0
                             and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
                             and all(isinstance(l, Int8EncoderLayer) and l._stream(b) for l in self.layers))
+        # a few rows: the split merge of the decode attention rides in the attn_out projection's prologue (one launch less)
+        merge_plan = None
+        if (fuse_qkv_rope and not self.tp and os.environ.get("ZL_ATTN_MERGE", "1") != "0"
+                and all(l.attn_out.perm is None for l in self.layers)):
+            merge_plan = ops.attn_merge_plan(b, c.num_heads, c.num_kv_heads, c.dim_head, ctx.max_len_buf,
+                                             self.layers[0].attn_out.weight)
         for li, layer in enumerate(self.layers):
             if fuse_qkv_rope_i8:
                 # INT8 route: layernorm_quant, then the streaming W8A8 kernel with scale-back + rotary + KV scatter fused
@@ -770,6 +776,13 @@ class LLaMA:
                 ops.w4_qkv_rope_scatter(xin, layer.qkv.weight, cos, sin, ctx.placement, ctx.buf_lens, ctx.k_addrs[li],
                                         ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, bias=layer.qkv.bias,
                                         norm_weight=layer.ln_attn if b <= 8 else None, norm_eps=c.eps, q_out=bufs["q"])
+                if merge_plan:
+                    ops.decode_attention_splits(bufs["q"].view(b, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
+                                                ctx.v_addrs[li], ctx.valid_lens, scale, ctx.max_len_buf, c.num_kv_heads, workspace)
+                    ops.w4_attn_out_merge(workspace, ctx.buf_lens, ctx.valid_lens, merge_plan, b, layer.attn_out.weight,
+                                          bias=layer.attn_out.bias, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
+                    layer.ff_add(hidden, c.eps, bufs["act"])
+                    continue
                 ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
                                                      ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
                                                      valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),

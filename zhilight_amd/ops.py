@@ -9,6 +9,7 @@ Names, argument meaning and error behaviour follow the reference (citations on e
 paths relative to the ZhiLight tree).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -455,6 +456,49 @@ def multi_query_attention_rag_buffer(batch_q, buf_lens, key_buf_addrs, val_buf_a
                                _p(valid_lens), _p(out), _p(workspace), _i(b), _i(len_q), _i(h), _i(num_kv_heads),
                                _i(d), _f(scale), _i(max_len_buf), C.c_int(int(bshd)), C.c_int(_dt(batch_q)),
                                _stream()), "decode_attn")
+    return out
+
+
+def attn_merge_plan(b, num_heads, num_kv_heads, dim_head, max_len_buf, w):
+    """(split_len, max_splits) when zl_decode_attn_splits + zl_w4a16_gemm_attn_merge cover this decode batch and
+    projection weight, else None (callers use multi_query_attention_rag_buffer + w4_linear).  ZL_ATTN_MERGE_MAX_B
+    (default 1) bounds the batch: every workgroup of the projection merges all rows, which stops paying early."""
+    if not isinstance(w, W4MWeight) or dim_head != 128 or num_heads % num_kv_heads or num_heads // num_kv_heads > 16:
+        return None
+    if b > min(4, int(os.environ.get("ZL_ATTN_MERGE_MAX_B", "1"))) or w.k != num_heads * 128 or w.k > 4096:
+        return None
+    split_len = int(lib().zl_decode_attn_split_len(_i(b), _i(num_kv_heads), _i(max_len_buf)))
+    max_splits = (max_len_buf + split_len - 1) // split_len
+    cus = lib().zl_device_cu_count()
+    if max_splits > 16 or (w.n + 15) // 16 > 2 * (cus if cus > 0 else 256):
+        return None
+    return split_len, max_splits
+
+
+def decode_attention_splits(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, valid_lens, scale, max_len_buf, num_kv_heads,
+                            workspace, bshd=True):
+    """multi_query_attention_rag_buffer without its merge launch: the split-KV partials stay in `workspace` for
+    w4_attn_out_merge.  batch_q (B, 1, H, 128) or (B, H, 128)."""
+    _chk_cuda(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, valid_lens, workspace)
+    b, h, d = batch_q.shape[0], batch_q.shape[-2], batch_q.shape[-1]
+    check(lib().zl_decode_attn_splits(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(valid_lens),
+                                      _p(workspace), _i(b), _i(h), _i(num_kv_heads), _i(d), _f(scale), _i(max_len_buf),
+                                      C.c_int(int(bshd)), C.c_int(_dt(batch_q)), _stream()), "decode_attn_splits")
+    return workspace
+
+
+def w4_attn_out_merge(workspace, buf_lens, valid_lens, plan, b, w, bias=None, residual=None, out=None, epilogue=0):
+    """attn_out projection whose activation rows are merged from the decode attention's split-KV partials in the GEMV
+    prologue (zl_w4a16_gemm_attn_merge): bit-identical to the merge launch + w4a16_gemm_mfma."""
+    _chk_cuda(workspace, buf_lens, valid_lens, bias, residual)
+    split_len, max_splits = plan
+    if out is None:
+        out = torch.empty((b, w.n), dtype=torch.float16, device=workspace.device)
+    if bias is not None:
+        epilogue |= EPI_BIAS
+    check(lib().zl_w4a16_gemm_attn_merge(_p(workspace), _p(buf_lens), _p(valid_lens), _i(split_len), _i(max_splits), _p(w.qw),
+                                         _p(w.meta), _p(bias), _p(residual), _p(out), _i(b), _i(w.n), _i(w.k),
+                                         _i(w.group_size), C.c_int(epilogue), _stream()), "w4a16_gemm_attn_merge")
     return out
 
 
