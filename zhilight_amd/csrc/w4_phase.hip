@@ -217,16 +217,13 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
       // (norm_w == null: the register-resident staging alone -- up to 4 rows it beats the per-phase loads: 4.9 vs 5.1 us
       //  on the o projection at one row)
       if constexpr (MERGE) {   // after the ring issue: the first weights are in flight while the splits merge
-        // Thread (head = t / 16, j = t % 16) merges d = 2 j + 32 e, + 1 (e < 4): one load instruction then covers 128
-        // contiguous bytes per head (8-byte lanes at 32-byte stride took 4x the cache-line accesses and 4 us).  The
-        // fp16 results change hands through LDS (the phase-1 x buffer, idle until the end of phase 0) into the
-        // staging assignment (thread t: halfs 8 t .. 8 t + 7).
+        // Thread t merges its own 8 halfs (head t / 16, d = 8 (t % 16) .. + 7) straight into the staging registers.
+        // (A variant with 128 contiguous bytes per head per load instruction and an LDS hand-over into this assignment
+        //  measured the same kernel time and 1-2 % less end to end: profiles/r01_attn_merge_ab.txt.)
         constexpr int kS = 16, kWS = 128 + 2;        // splits held at once; floats per split record
         const int idx = threadIdx.x * 8, heads = p.k >> 7;
         const bool act = idx < p.k;
-        const int head = act ? (int)(threadIdx.x >> 4) : 0, j = threadIdx.x & 15;
-        uint32_t* scr = reinterpret_cast<uint32_t*>(xs + kBuf);   // [row][2048] fp16 pairs
-        static_assert(kBuf * 2 >= 4 * 2048 * 4, "merge scratch");
+        const int head = act ? (int)(threadIdx.x >> 4) : 0, d0 = (threadIdx.x & 15) * 8;
 #pragma unroll
         for (int m = 0; m < kNR; ++m) {
             if (m < p.m) {                             // workgroup-uniform
@@ -242,7 +239,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
                     if (u < ns) {                      // uniform: no loads for splits that do not exist
                         st[u] = *reinterpret_cast<const float2*>(src + (size_t)u * kWS + 128);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[u][e] = *reinterpret_cast<const float2*>(src + (size_t)u * kWS + 2 * j + 32 * e);
+                        for (int e = 0; e < 4; ++e) v[u][e] = *reinterpret_cast<const float2*>(src + (size_t)u * kWS + d0 + 2 * e);
                     }
                 }
                 float mn = -1e20f;
@@ -261,19 +258,16 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
                         z = __builtin_fmaf(st[u].y, f, z);
                     }
                 }
+                uint32_t o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     hv2 hh;
                     hh.x = zl_f32_to_f16(a[2 * e] / (z + 1e-20f));
                     hh.y = zl_f32_to_f16(a[2 * e + 1] / (z + 1e-20f));
-                    if (act) scr[m * 2048 + head * 64 + j + 16 * e] = __builtin_bit_cast(uint32_t, hh);
+                    o[e] = __builtin_bit_cast(uint32_t, hh);
                 }
+                if (act) xn4[m] = make_uint4(o[0], o[1], o[2], o[3]);
             }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < kNR; ++m) {
-            if (m < p.m && act) xn4[m] = *reinterpret_cast<const uint4*>(scr + m * 2048 + threadIdx.x * 4);
         }
       }
       if constexpr (!MERGE) if (p.norm_w) {
