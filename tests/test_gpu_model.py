@@ -715,6 +715,40 @@ def test_tensor_parallel_dual_stream_prefill(dev, monkeypatch, s_prompt):
             m.advance(c, nxt)
 
 
+def test_tensor_parallel_kv_head_replication(dev, monkeypatch):
+    """Fewer kv heads than TP ranks: ATTN_KV_REP_TP=1 (src/nn/attention/attention.cpp:126-134) gives each group of
+    TP / Hkv ranks the same kv head; without it the model refuses.  TP = 2 over a single-kv-head checkpoint against
+    the unsharded model: prompt encode + decode steps."""
+    from zhilight_amd import ops
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(47)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=1,
+                      eps=1e-5, rope_theta=5e5)
+    sd = {k: torch.from_numpy(v) for k, v in _hf_state(rng, cfg, 128).items()}
+    ref_model = LLaMA(cfg, QuantConfig(5, 128), dev).load_state_dict(sd)
+    fake = _ThreadTP(2)
+    with pytest.raises(ops.ZLError, match="ATTN_KV_REP_TP"):
+        LLaMA(cfg, QuantConfig(5, 128), dev, tp=fake.view(0))
+    monkeypatch.setenv("ATTN_KV_REP_TP", "1")
+    models = [LLaMA(cfg, QuantConfig(5, 128), dev, tp=fake.view(r)).load_state_dict(sd) for r in range(2)]
+    assert models[0].cfg.num_heads == 4 and models[0].cfg.num_kv_heads == 1 and models[1].layers[0].kv_part == (0, 1)
+    prompt = torch.from_numpy(rng.integers(0, cfg.vocab_size, 21).astype(np.int64))
+    ref_ctx = ref_model.new_context(1, 64, 0)
+    ctxs = [m.new_context(1, 64, 0) for m in models]
+    ref = ref_model.prefill(ref_ctx, 0, prompt).float()
+    outs = _run_ranks(fake, lambda r: models[r].prefill(ctxs[r], 0, prompt).float())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    for step in range(2):
+        ref = ref_model.encode(ref_ctx).float()
+        outs = _run_ranks(fake, lambda r: models[r].encode(ctxs[r]).float())
+        assert (outs[0] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+        nxt = ref.argmax(dim=-1)
+        ref_model.advance(ref_ctx, nxt)
+        for m, c in zip(models, ctxs):
+            m.advance(c, nxt)
+
+
 def test_int8_kv_cache_prefill_and_decode(oracle, dev):
     """KV_CACHE_DTYPE=int8 (src/model/model_context.cpp:61-79): prompt encode writes codes + scales (bit-exact
     with the oracle's cache), decode steps attend over the codes; logits within 1e-3 of the oracle composed with

@@ -498,25 +498,27 @@ class EncoderLayer:
         self.ln_ff = _dev_t(sd[prefix + ".ln_ff.weight"], device, torch.float16)
 
         tp = self.tp
-        ws = tp.size if tp else 1
 
-        def lin(sub, din, dout, mode=None):
+        def lin(sub, din, dout, mode=None, part=None):
             # the checkpoint holds the FULL matrix; a TP rank keeps its column (output rows) or row (input columns) slice
-            full_in, full_out = (din * ws if mode == "row" else din), (dout * ws if mode == "column" else dout)
+            # (part = (index, count) overrides (rank, size): replicated kv heads)
+            idx, cnt = part if part else ((tp.rank, tp.size) if tp else (0, 1))
+            full_in, full_out = (din * cnt if mode == "row" else din), (dout * cnt if mode == "column" else dout)
             l = Int4GPTQ(prefix + "." + sub, full_in, full_out, q)
             l.load_state_dict(sd, prefix + "." + sub, device)
             if tp and mode:
                 if l.perm is not None:
                     raise ops.ZLError("act-order checkpoints are not supported under tensor parallelism")
-                l.km = parallel.shard_k_major(*l.km, q.group_size, mode, tp.rank, tp.size)
+                l.km = parallel.shard_k_major(*l.km, q.group_size, mode, idx, cnt)
                 l.dim_in, l.dim_out = din, dout
                 if l.bias is not None and mode == "column":
-                    l.bias = l.bias[tp.rank * dout:(tp.rank + 1) * dout].contiguous()
+                    l.bias = l.bias[idx * dout:(idx + 1) * dout].contiguous()
                 if l.bias is not None and mode == "row" and tp.rank != 0:
                     l.bias = None                     # added once, by rank 0's partial sum
             return l
-        pq, pk, pv = (lin("attn.project_q", c.dim_model, hd, "column"), lin("attn.project_k", c.dim_model, kvd, "column"),
-                      lin("attn.project_v", c.dim_model, kvd, "column"))
+        kv_part = getattr(self, "kv_part", None)
+        pq, pk, pv = (lin("attn.project_q", c.dim_model, hd, "column"), lin("attn.project_k", c.dim_model, kvd, "column", kv_part),
+                      lin("attn.project_v", c.dim_model, kvd, "column", kv_part))
         w_in, w_gated = lin("ff.w_in", c.dim_model, c.dim_ff, "column"), lin("ff.w_gated", c.dim_model, c.dim_ff, "column")
         self.attn_out = lin("attn.attn_out", hd, c.dim_model, "row").pack()
         self.w_out = lin("ff.w_out", c.dim_ff, c.dim_model, "row").pack()
@@ -642,12 +644,21 @@ class LLaMA:
             if layer_cls is not EncoderLayer:
                 raise ops.ZLError("tensor parallelism is wired into the W4A16 layer stack only")
             t = self.tp.size
-            if cfg.num_heads % t or cfg.num_kv_heads % t or cfg.dim_ff % t or cfg.vocab_size % t:
-                raise ops.ZLError("heads, kv heads, dim_ff and vocab_size must be divisible by the TP degree")
+            # fewer kv heads than ranks: with ATTN_KV_REP_TP=1 the reference gives rank r kv head r / (TP / Hkv), i.e.
+            # groups of TP / Hkv ranks hold (and cache) the same kv head (src/nn/attention/attention.cpp:126-134)
+            kv_part = None
+            if (cfg.num_kv_heads < t and t % cfg.num_kv_heads == 0 and int(os.environ.get("ATTN_KV_REP_TP", "0")) > 0):
+                kv_part = (self.tp.rank // (t // cfg.num_kv_heads), cfg.num_kv_heads)
+            if cfg.num_heads % t or (kv_part is None and cfg.num_kv_heads % t) or cfg.dim_ff % t or cfg.vocab_size % t:
+                raise ops.ZLError("heads, kv heads, dim_ff and vocab_size must be divisible by the TP degree "
+                                  "(fewer kv heads than ranks: ATTN_KV_REP_TP=1)")
             import dataclasses
-            cfg = dataclasses.replace(cfg, num_heads=cfg.num_heads // t, num_kv_heads=cfg.num_kv_heads // t, dim_ff=cfg.dim_ff // t)
+            cfg = dataclasses.replace(cfg, num_heads=cfg.num_heads // t, num_kv_heads=1 if kv_part else cfg.num_kv_heads // t,
+                                      dim_ff=cfg.dim_ff // t)
             self.cfg = cfg                            # the LOCAL geometry drives buffers, KV and kernels
             self.layers = [EncoderLayer(cfg, quant, i, self.tp) for i in range(cfg.num_layers)]
+            for l in self.layers:
+                l.kv_part = kv_part
         else:
             self.layers = [layer_cls(cfg, quant, i) for i in range(cfg.num_layers)]
         self.token_embedding = self.output_layernorm = self.lm_head = None
