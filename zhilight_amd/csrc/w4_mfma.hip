@@ -229,16 +229,23 @@ __global__ __launch_bounds__(kThreads, 4) void k_w4a16_mfma(const MfmaParams p) 
     const int round_jump = tpr * p.groups - (nit - 1);
     const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)nrow * 4u;
     int iss_left = total - 1, iss_jrem = nit;
+    // exhausted stream: refills go through a zero-length descriptor (out-of-range buffer loads return zeros without a
+    // memory access; re-reading the last item kept kRing - 1 loads per wave in flight when the kernel should retire)
+    const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rqc = total > 0 ? rq : rnull, rmc = total > 0 ? rm : rnull;
     auto issue = [&](int slot) {
-        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off, qs, 2 /* nt */));
+        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rqc, q_off, qs, 2 /* nt */));
 #ifndef ZL_EXP_NOMETA
-        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(rm, m_off, ms, 2);
+        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(rmc, m_off, ms, 2);
 #else
         mt[slot] = 0xec083c00u + ms;
 #endif
         // one compare per select keeps these on the scalar unit (s_cmp + s_cselect_b32); combining two
         // conditions into a bool makes the compiler build lane masks and do the select on the VALU
-        const int adv = iss_left > 0 ? 1 : 0;
+        const bool more = iss_left > 0;
+        const int adv = more ? 1 : 0;
+        rqc = more ? rqc : rnull;
+        rmc = more ? rmc : rnull;
         --iss_left;
         const int wrap = iss_jrem == 1 ? adv : 0;
         iss_jrem = wrap != 0 ? nit : iss_jrem - adv;

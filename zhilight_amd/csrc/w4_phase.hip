@@ -21,6 +21,10 @@
 #include <type_traits>
 #include "zl_common.h"
 
+#ifdef ZL_PHASE_PROBE
+static int zl_probe_seq = 0;
+#endif
+
 namespace {
 
 constexpr int kT = 512, kW = 8;
@@ -30,6 +34,29 @@ constexpr int kXS = kPK + 8;         // LDS x row, halfs (padded: conflict-free 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
+
+// ---- optional timeline probe (build with -DZL_PHASE_PROBE; tools/ubench/probe_phase.py) ---------------
+#ifdef ZL_PHASE_PROBE
+// Launches of this kernel are numbered on the host (PhaseParams::probe_id); the four launches zl_probe_sel .. +3 record.
+__device__ unsigned long long* zl_probe_p = nullptr;  // [4 launches][2048 workgroups * 8 waves][8] wall-clock ticks (100 MHz)
+__device__ int zl_probe_sel = 0;
+// The slot pointer is resolved ONCE at kernel entry (ZL_PPROBE_INIT): resolving it per stamp needs a vector load and the
+// vmcnt(0) behind it drains the weight ring, i.e. the stamp would move what it measures.
+#define ZL_PPROBE_INIT()                                                                                      \
+    unsigned long long* pp_ = nullptr;                                                                        \
+    {                                                                                                         \
+        const int pl_ = p.probe_id - zl_probe_sel;                                                            \
+        if (zl_probe_p && (threadIdx.x & 63) == 0 && pl_ >= 0 && pl_ < 4 && blockIdx.x < 2048)                \
+            pp_ = zl_probe_p + ((size_t)pl_ * 16384 + blockIdx.x * kW + (threadIdx.x >> 6)) * 8;              \
+    }
+#define ZL_PPROBE(slot)                                                                                       \
+    do {                                                                                                      \
+        if (pp_) pp_[slot] = wall_clock64();                                                                  \
+    } while (0)
+#else
+#define ZL_PPROBE_INIT() do {} while (0)
+#define ZL_PPROBE(slot) do {} while (0)
+#endif
 
 struct PhaseParams {
     const uint16_t* x;
@@ -69,9 +96,28 @@ struct PhaseParams {
     const float* mg_ws;
     const int32_t* mg_valid_lens;
     int mg_split_len, mg_max_splits;
+    int xfirst;                 // wait for the activation loads before the weight ring is issued (see k_w4a16_phase)
+#ifdef ZL_PHASE_PROBE
+    int probe_id;
+#endif
 };
 
-constexpr int ring_depth(int r) { return r == 1 ? 3 : r == 2 ? 4 : r == 3 ? 6 : r == 4 ? 8 : r; }
+// Ring depth.  Register-resident (NORM) staging has no ordering constraint between x and the ring, so the short streams
+// of one or two tiles per workgroup (K = 4096: 4 / 8 items per wave) have EVERY item in flight from the start: with 2-3
+// in flight they paid two to three dependent memory round trips (qkv 6.6 -> , o 4.6 ->  us at one row).
+#ifndef ZL_PH_D1
+#define ZL_PH_D1 3
+#endif
+#ifndef ZL_PH_D2
+#define ZL_PH_D2 4
+#endif
+#ifndef ZL_PH_D7
+#define ZL_PH_D7 7
+#endif
+constexpr int ring_depth(int r, bool norm = false) {
+    return norm ? (r == 1 ? ZL_PH_D1 : r == 2 ? ZL_PH_D2 : r == 3 ? 6 : r == 4 ? 8 : r == 7 ? ZL_PH_D7 : r)
+                : (r == 1 ? 3 : r == 2 ? 4 : r == 3 ? 6 : r == 4 ? 8 : r);
+}
 constexpr int x_ahead(int r) { return r <= 4 ? 2 : 1; }
 constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
 constexpr int lcm_(int a, int b) { return a / gcd_(a, b) * b; }
@@ -115,7 +161,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
     static_assert(!MERGE || (NORM && !ROPE && KS == 1), "split merge: register-resident staging");
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
     static_assert(KS == 1 || (!ROPE && !NORM), "K split: plain / bias / residual epilogues only");
-    constexpr int D = ring_depth(R), XP = NORM ? 1 : x_ahead(R), BODY = lcm_(D, R * XP);
+    constexpr int D = ring_depth(R, NORM), XP = NORM ? 1 : x_ahead(R), BODY = lcm_(D, R * XP);
     static_assert(!NORM || MB == 1, "fused norm: one row block");
     constexpr int XC = 4 * MB;                       // 16-byte x chunks per thread per phase (16 MB rows x 128 chunks)
     constexpr int kBuf = MB * 16 * kXS;              // halfs per LDS phase buffer
@@ -123,6 +169,8 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
     static_assert(NORM || XP * R >= D - 2, "x loads must be older than the weights in flight when they are consumed");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* xs = reinterpret_cast<uint16_t*>(smem);
+    ZL_PPROBE_INIT();
+    ZL_PPROBE(0);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -174,6 +222,11 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
         for (int q = 0; q < XP; ++q) load_x(q, q);
     }
     __builtin_amdgcn_sched_barrier(0);
+    // The fabric serves an XCD's requests in arrival order: a workgroup dispatched 0.3-0.5 us after its neighbours finds
+    // their whole weight rings queued in front of its 16-byte-per-thread activation load.  xfirst holds the ring back
+    // until the activations have landed (short streams, which are latency-bound anyway).
+    if (p.xfirst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- weight ring.  Item sequence of wave w: for phase: for r < R: (tile0 + r, 8 phase + w); the byte
     //      offset lives in SGPRs (buffer soffset), advanced by one of two strides; out-of-range tiles read
@@ -187,14 +240,22 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
     const int tile_step = tile_stride * p.groups, phase_step = kW - (R - 1) * tile_stride * p.groups;
     const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)nrow * 4u;
     int iss_left = total - 1;
+    // Exhausted stream: the remaining ring refills go through a zero-length descriptor -- out-of-range buffer loads return
+    // zeros without touching memory.  (Re-reading the last item instead, the first cut, kept D - 1 cache-hit loads per
+    // wave in flight at the end of the kernel, and a wave does not retire before its loads have landed.)
+    const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rqc = total > 0 ? rq : rnull, rmc = total > 0 ? rm : rnull;
     auto issue = [&](int slot, int r_of_item) {      // both static
-        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off, qs, 2 /* nt */));
-        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(rm, m_off, ms, 2);
-        const int adv = iss_left > 0 ? 1 : 0;        // exhausted: keep re-reading the last item (an L2 hit)
+        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rqc, q_off, qs, 2 /* nt */));
+        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(rmc, m_off, ms, 2);
+        const bool more = iss_left > 0;
+        const int adv = more ? 1 : 0;
         --iss_left;
         const int d = adv * (r_of_item == R - 1 ? phase_step : tile_step);
         qs += (uint32_t)d * 1024u;
         ms += (uint32_t)d * 64u;
+        rqc = more ? rqc : rnull;
+        rmc = more ? rmc : rnull;
     };
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) {
@@ -203,6 +264,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
     }
     mt[D - 1] = 0;                                   // the neutral "previous item" of the first step
     wq[D - 1] = make_uint4(0, 0, 0, 0);
+    ZL_PPROBE(1);
 
     auto store_norm = [&](int ph) {                  // the quarter of the workgroup that holds phase ph's k range
         if ((int)(threadIdx.x >> 7) == ph) {
@@ -335,6 +397,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
         store_x(0, 0);
     }
     __syncthreads();
+    ZL_PPROBE(2);
 
     const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
     const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(0x00f000f0u);
@@ -405,6 +468,9 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
             const int php = ph + j;
             if (!NORM && r == 0) load_x(j % XP, php + XP);   // set (phase % XP): free since the end of phase php - 1
             step(s % D, (s + D - 1) % D, (s + R - 1) % R, (s + D - 1) % R, php);
+#ifdef ZL_PHASE_PROBE
+            if (k == 0 && s == 0) ZL_PPROBE(3);
+#endif
             if (r == R - 1) {
                 if (php + 1 < P) {                    // workgroup-uniform
                     if constexpr (NORM) store_norm(php + 1);
@@ -433,6 +499,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
             if (last == s) finish_prev(s % R, s % D);
         }
     }
+    ZL_PPROBE(4);
     __syncthreads();                                  // every wave is done with the x buffers: reuse them
 
     // ---- park the partial C fragments, reduce over the 8 waves in fixed order, epilogue
@@ -443,6 +510,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
         for (int b = 0; b < MB; ++b) red[((r * MB + b) * kW + wave) * 64 + lane] = acc[r][b];
     }
     __syncthreads();
+    ZL_PPROBE(5);
     const float* redf = reinterpret_cast<const float*>(red);
     if constexpr (KS > 1) {
         // partials: agent-scope (write-through) stores; the barrier below waits for them (vmcnt(0)); one agent-scope
@@ -538,6 +606,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
                 }
             }
         }
+        ZL_PPROBE(6);
         return;
     }
     const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
@@ -590,6 +659,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
             }
         }
     }
+    ZL_PPROBE(6);
 }
 
 template <int R, int MB, bool NORM, bool ROPE = false, int KS = 1, bool MERGE = false>
@@ -607,11 +677,36 @@ int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
             done = true;
         }
     }
+#ifdef ZL_PHASE_PROBE
+    PhaseParams pp = p;
+    pp.probe_id = zl_probe_seq++;     // host-side launch number (all instantiations share it)
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE>), dim3(grid), dim3(kT), lds, hs, pp);
+#else
     hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE>), dim3(grid), dim3(kT), lds, hs, p);
+#endif
     return zl_launch_status();
 }
 
 }  // namespace
+
+#ifdef ZL_PHASE_PROBE
+extern "C" int zl_debug_probe_seq(void) { return zl_probe_seq; }
+extern "C" int zl_debug_set_probe_p(void* p, int sel) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(zl_probe_p), &p, sizeof(p));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(zl_probe_sel), &sel, sizeof(sel));
+    return (int)e;
+}
+#endif
+
+// short streams (<= 2 tiles per CU of K <= 4096): activations first.  ZL_W4_PHASE_XFIRST=0/1/2: never / short streams / always
+static int phase_xfirst(int tiles, int k) {
+    static const int mode = [] { const char* e = getenv("ZL_W4_PHASE_XFIRST"); return e ? atoi(e) : 1; }();
+    if (mode == 0) return 0;
+    if (mode == 2) return 1;
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    return tiles <= 2 * cus && k <= 4096;
+}
 
 extern "C" void* zlint_workspace(size_t bytes);   // misc_ops.hip: per-device scratch (grow-only; reserve before capture)
 extern "C" int* zlint_counters(void);             // misc_ops.hip: per-device zeroed int[16384]
@@ -631,6 +726,7 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
     p.ks_ws = nullptr; p.ks_counter = nullptr;
     p.mg_ws = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
+    p.xfirst = phase_xfirst(tiles, k);
     {   // long K with more than 16 rows: K split over 2 or 4 adjacent workgroups (R = KS tiles each, same grid size)
         static const int ksplit = [] { const char* e = getenv("ZL_W4_PHASE_KSPLIT"); return e ? atoi(e) : 2; }();
         const bool plain = !(epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) && !norm_w;
@@ -682,6 +778,7 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
     p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd; p.pair_stride = d / 32;
     p.ks_ws = nullptr; p.ks_counter = nullptr;
     p.mg_ws = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
+    p.xfirst = phase_xfirst(tiles, k);
     const int grid = tiles / 2;
     if (norm_w || (m <= 4 && k <= 4096)) return launch_phase<2, 1, true, true>(p, grid, hs);
     return m <= 16 ? launch_phase<2, 1, false, true>(p, grid, hs) : launch_phase<2, 2, false, true>(p, grid, hs);
@@ -709,6 +806,7 @@ int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const in
     p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
     p.ks_ws = nullptr; p.ks_counter = nullptr;
     p.mg_ws = ws; p.mg_valid_lens = valid_lens; p.mg_split_len = split_len; p.mg_max_splits = max_splits;
+    p.xfirst = 0;
     const int grid = (tiles + r - 1) / r;
     return r == 1 ? launch_phase<1, 1, true, false, 1, true>(p, grid, hs) : launch_phase<2, 1, true, false, 1, true>(p, grid, hs);
 }
