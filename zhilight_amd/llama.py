@@ -826,6 +826,7 @@ class LLaMA:
                                            out=bufs["attn"], workspace=workspace)
             layer.attn_out_add(bufs["attn"], hidden)
             layer.ff_add(hidden, c.eps, bufs["act"])
+        self.last_hidden = hidden                      # (B, dim_model) before the output norm: the parity tests read it
         return self._logits(hidden, bufs["logits"], argmax_ws)
 
     def _logits(self, hidden, out=None, argmax_ws=None):
