@@ -77,6 +77,194 @@ def cpu_baseline(cfg, batch, seq):
     }
 
 
+def roofline_int8(model, cfg, batch, dev):
+    """dominant kernel of the int8 route = k_w8a8_phase (streaming W8A8 GEMM with the scale-back fused: qkv, attn_out,
+    w_in|w_gated, w_out = 4 launches per layer, 1 B per weight); beyond 32 rows the tiled GEMM runs instead"""
+    from zhilight_amd import ops
+    roof = None
+    # dominant kernel of the int8 route = k_w8a8_phase (streaming W8A8 GEMM with the scale-back fused: qkv, attn_out,
+    # w_in|w_gated, w_out = 4 launches per layer, 1 B per weight); beyond 32 rows the tiled GEMM runs instead
+    lays = model.layers
+    stream = batch <= 32
+    xq = torch.randint(-127, 128, (batch, cfg.dim_ff), dtype=torch.int8, device=dev)
+    sxv = torch.full((batch,), 0.02, dtype=torch.float32, device=dev)
+    hid = torch.zeros(batch, cfg.dim_model, dtype=torch.float16, device=dev)
+    if stream:
+        launches = []
+        for lay in lays:
+            launches += [(lay.qkv.stream_weight(), ops.W8_BACK, None), (lay.attn_out.stream_weight(), ops.W8_BACK_ADD, hid),
+                         (lay._gated_stream_weight(), ops.W8_ACT_SILU, None), (lay.w_out.stream_weight(), ops.W8_BACK_ADD, hid)]
+        xq_by_k = {k: xq[:, :k].contiguous() for k in {w.k for w, _, _ in launches}}
+        outs = {(w.n, e): torch.empty(batch, w.n // 2 if e == ops.W8_ACT_SILU else w.n, dtype=torch.float16, device=dev)
+                for w, e, _ in launches}
+
+        def gemms():
+            for w, e, add in launches:
+                ops.w8a8_gemm_phase(xq_by_k[w.k], sxv, w, e, addend=add, out=outs[(w.n, e)])
+        per_launch = sum(w.n * w.k + batch * (w.k + 2 * w.n) for w, _, _ in launches) / len(launches)
+        kdesc = "k_w8a8_phase (W8A8 streaming GEMM + fused scale-back, 4 launches/layer)"
+    else:
+        launches = [(lin, lin.dim_in) for lay in lays for lin in lay.linears()]
+        xq_by_k = {k: xq[:, :k].contiguous() for k in {l.dim_in for l, _ in launches}}
+
+        def gemms():
+            for lin, k in launches:
+                lin.gemm(xq_by_k[k])
+        per_launch = sum(l.dim_in * l.dim_out + batch * (l.dim_in + 4 * l.dim_out) for l, _ in launches) / len(launches)
+        kdesc = "k_int8_gemm_tiled (int8 x int8 -> int32, 5 launches/layer)"
+    gemms()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        gemms()
+    g2.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        g2.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    t_launch = e0.elapsed_time(e1) * 1e-3 / (10 * len(launches))
+    achieved = per_launch / t_launch / 1e9
+    roof = {"bound": "hbm", "kernel": kdesc, "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3),
+            "note": "avg over the int8 GEMM launches of one step incl. inter-kernel gaps (graph replay, HIP events)"}
+    return roof
+
+
+def roofline_w4(model, cfg, batch, dev, layers_override=False):
+    """the W4A16 GEMV launches of one step (4 x 32, model order, on the real HBM-cold weights: 3.6 GB >> 256 MB Infinity
+    Cache), captured without the other kernels; HIP events on the launch stream"""
+    from zhilight_amd import ops
+    roof = None
+    bufs = model._buffers(batch)
+    launches = []
+    for layer in model.layers:
+        # the model fuses the RMSNorm into the GEMV up to 8 rows (4 for the bit-exact kernel) and launches it separately
+        # beyond (llama.py: _fused_norm_rows)
+        from zhilight_amd.llama import _fused_norm_rows
+        nq = dict(norm_weight=layer.ln_attn, norm_eps=cfg.eps) if batch <= _fused_norm_rows(layer.qkv.weight) else {}
+        nf = dict(norm_weight=layer.ln_ff, norm_eps=cfg.eps) if batch <= _fused_norm_rows(layer.w_in_gated.weight) else {}
+        launches += [(bufs["hidden"], layer.qkv, bufs["qkv"], nq),
+                     (bufs["attn"], layer.attn_out, bufs["hidden"], dict(residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL)),
+                     (bufs["hidden"], layer.w_in_gated, bufs["act"], dict(epilogue=ops.EPI_SILU_MUL, **nf)),
+                     (bufs["act"], layer.w_out, bufs["hidden"], dict(residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL))]
+    bufs["hidden"].normal_()
+    bufs["attn"].normal_()
+
+    def gemvs():
+        for x, lin, out, kw in launches:
+            ops.w4_linear(x, lin.weight, out=out, **kw)
+    gemvs()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        gemvs()
+    g2.replay()
+    torch.cuda.synchronize()
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g2.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    t_launch = e0.elapsed_time(e1) * 1e-3 / (reps * len(launches))
+    tot_bytes = sum(alg_bytes_w4(lin.weight.n, lin.weight.k, lin.weight.group_size, batch) for _, lin, _, _ in launches)
+    per_launch = tot_bytes / len(launches)
+    achieved = per_launch / t_launch / 1e9
+    # MFMA flavour: k_w4a16_phase streams qkv / o / gate|up (and the down projection for 5..16 rows),
+    # k_w4a16_mfma the long-K down projection up to 4 rows, k_w4a16_gemm_tiled the down projection beyond 16 rows
+    kname = "k_w4a16_phase+k_w4a16_mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "k_w4a16_gemm"
+    # HBM traffic per launch: measured off-line with rocprofv3 --pmc (a counter pass cannot run inside
+    # this process); the committed summary is per kernel flavour and for these four shapes only
+    traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemv_traffic.json")) as fh:
+            tj = json.load(fh)
+        if tj.get("kernel", "").startswith(kname.split("+")[0]) and not layers_override and batch == 1:
+            traffic = int(tj["avg_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    roof = {"bound": "hbm", "kernel": kname + " (W4A16 GEMV, 4 launches/layer)", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3),
+            "note": "avg over the 128 GEMV launches of one step incl. inter-kernel gaps (graph replay, HIP events)"}
+
+    return roof
+
+
+def step_bytes_of(model, cfg, batch, seq, int8):
+    """whole-step algorithmic bytes: quantised linears + fp16 lm_head + KV read"""
+    if int8:
+        lin_bytes = sum(l.dim_in * l.dim_out + 2 * l.dim_out for lay in model.layers for l in lay.linears())
+    else:
+        lin_bytes = sum(alg_bytes_w4(l.weight.n, l.weight.k, 128, batch) for lay in model.layers
+                        for l in (lay.qkv, lay.attn_out, lay.w_in_gated, lay.w_out))
+    return lin_bytes + cfg.vocab_size * cfg.dim_model * 2 + batch * cfg.num_layers * 2 * cfg.num_kv_heads * seq * cfg.dim_head * 2
+
+
+def extra_decode_run(model, cfg, batch, seq, steps, warmup, dev, int8):
+    """north_star asks for batch 1 / 8 / 32 (and BASELINE configs[2] is the INT8 route at batch 32): the same timed
+    region as the headline (hipGraph replay of the whole step, synchronise on both sides), one GPU, reported as extra
+    keys of the one JSON line."""
+    len_buf = (seq + warmup + steps + 4 + 63) // 64 * 64
+    ctx = model.new_context(batch, len_buf, seq, fill_random=True)
+    ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
+    model.step_greedy(ctx)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        model.step_greedy(ctx)
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    roof = roofline_int8(model, cfg, batch, dev) if int8 else roofline_w4(model, cfg, batch, dev)
+    del graph, ctx
+    torch.cuda.empty_cache()
+    return {"workload": "Llama-3-8B %s TP=1 batch=%d decode seq=%d" % ("INT8 (AutoInt8 linears)" if int8 else "GPTQ-Int4 g128", batch, seq),
+            "batch": batch, "value": round(batch * steps / elapsed, 2), "unit": "tokens/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "steps": steps, "warmup": warmup,
+            "step_hbm_roofline_frac": round(step_bytes_of(model, cfg, batch, seq, int8) / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": roof}
+
+
+def check_against_oracle(model, batch, dev):
+    """Before anything is timed: the weights bench.py generates (directly in the packed ZLW4M layout, never seen by a
+    test) are unpacked again (zl_w4m_unpack) and the four W4A16 linears of layer 0 and of the last layer, run through the
+    HIP path exactly as the step runs them, must reproduce the CPU oracle's exact product of the unpacked operands.
+    Returns the worst max|err| / max|ref| (raises above 1e-3, north_star's bar)."""
+    import numpy as np
+    from zhilight_amd import ops
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import zl_oracle as zo
+    worst = 0.0
+    gen = torch.Generator(device=dev).manual_seed(99)
+    for layer in (model.layers[0], model.layers[-1]):
+        for lin in (layer.qkv, layer.attn_out, layer.w_in_gated, layer.w_out):
+            w = lin.weight
+            if not isinstance(w, ops.W4MWeight):
+                return None                             # ZL_W4_ALGO=exact: that kernel is bit-tested against R elsewhere
+            x = torch.randn(batch, w.k, device=dev, generator=gen).to(torch.float16)
+            y = ops.w4_linear(x, w).float().cpu().numpy().astype(np.float64)
+            if w.row_interleave:
+                y = np.concatenate([y[:, 0::2], y[:, 1::2]], axis=1)
+            qw, qz, sc = (t.cpu().numpy() for t in w.to_k_major())
+            ref = zo.gptq_gemm_k_major_exact(x.cpu().numpy().view(np.uint16), qw.view(np.uint32), qz, sc.view(np.uint16))
+            err = float(np.abs(y - ref).max() / np.abs(ref).max())
+            worst = max(worst, err)
+            if not err <= 1e-3:
+                raise SystemExit("bench: HIP W4A16 linear %s deviates from the CPU oracle: %.3g" % (lin.name, err))
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +282,8 @@ def main():
     ap.add_argument("--kv-cache-dtype", choices=["fp16", "int8"], default="fp16",
                     help="int8: the reference's KV_CACHE_DTYPE=int8 cache (u8 codes + fp32 scales); not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra legs of the default run (batch 8 / 32 of the headline model, INT8 route at batch 32)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,6 +315,7 @@ def main():
     len_buf = (seq + args.warmup + args.steps + 4 + 63) // 64 * 64
     ctx = model.new_context(batch, len_buf, seq, fill_random=True, kv_cache_dtype=None if args.kv_cache_dtype == "fp16" else "int8")
     ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
+    oracle_check = check_against_oracle(model, batch, dev) if (rank == 0 and not int8 and tp is None) else None
 
     # ---- TTFT leg (rank 0, reported next to the decode metric): encode a `seq`-token prompt of one task
     # (M-tiled W4A16 GEMMs, causal attention) and pick the first token.  HIP events around eager launches.
@@ -218,127 +409,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline leg (rank 0): the dominant kernel = the W4A16 GEMV (k_w4a16_phase / k_w4a16_mfma by default,
-    # k_w4a16_gemm under ZL_W4_ALGO=exact).  All 4 x 32 GEMV
-    # launches of one step, in model order on the real (distinct, HBM-cold: 3.6 GB >> 256 MB
-    # Infinity Cache) weights, captured without the other kernels; HIP events on the launch stream.
+    # ---- roofline leg (rank 0): the dominant kernel (W4A16 GEMV: k_w4a16_phase / k_w4a16_mfma by default, k_w4a16_gemm
+    # under ZL_W4_ALGO=exact; int8 route: k_w8a8_phase)
     roof = None
     if rank == 0 and int8:
-        # dominant kernel of the int8 route = k_w8a8_phase (streaming W8A8 GEMM with the scale-back fused: qkv, attn_out,
-        # w_in|w_gated, w_out = 4 launches per layer, 1 B per weight); beyond 32 rows the tiled GEMM runs instead
-        lays = model.layers
-        stream = batch <= 32
-        xq = torch.randint(-127, 128, (batch, cfg.dim_ff), dtype=torch.int8, device=dev)
-        sxv = torch.full((batch,), 0.02, dtype=torch.float32, device=dev)
-        hid = torch.zeros(batch, cfg.dim_model, dtype=torch.float16, device=dev)
-        if stream:
-            launches = []
-            for lay in lays:
-                launches += [(lay.qkv.stream_weight(), ops.W8_BACK, None), (lay.attn_out.stream_weight(), ops.W8_BACK_ADD, hid),
-                             (lay._gated_stream_weight(), ops.W8_ACT_SILU, None), (lay.w_out.stream_weight(), ops.W8_BACK_ADD, hid)]
-            xq_by_k = {k: xq[:, :k].contiguous() for k in {w.k for w, _, _ in launches}}
-            outs = {(w.n, e): torch.empty(batch, w.n // 2 if e == ops.W8_ACT_SILU else w.n, dtype=torch.float16, device=dev)
-                    for w, e, _ in launches}
-
-            def gemms():
-                for w, e, add in launches:
-                    ops.w8a8_gemm_phase(xq_by_k[w.k], sxv, w, e, addend=add, out=outs[(w.n, e)])
-            per_launch = sum(w.n * w.k + batch * (w.k + 2 * w.n) for w, _, _ in launches) / len(launches)
-            kdesc = "k_w8a8_phase (W8A8 streaming GEMM + fused scale-back, 4 launches/layer)"
-        else:
-            launches = [(lin, lin.dim_in) for lay in lays for lin in lay.linears()]
-            xq_by_k = {k: xq[:, :k].contiguous() for k in {l.dim_in for l, _ in launches}}
-
-            def gemms():
-                for lin, k in launches:
-                    lin.gemm(xq_by_k[k])
-            per_launch = sum(l.dim_in * l.dim_out + batch * (l.dim_in + 4 * l.dim_out) for l, _ in launches) / len(launches)
-            kdesc = "k_int8_gemm_tiled (int8 x int8 -> int32, 5 launches/layer)"
-        gemms()
-        torch.cuda.synchronize()
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
-            gemms()
-        g2.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            g2.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        t_launch = e0.elapsed_time(e1) * 1e-3 / (10 * len(launches))
-        achieved = per_launch / t_launch / 1e9
-        roof = {"bound": "hbm", "kernel": kdesc, "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3),
-                "note": "avg over the int8 GEMM launches of one step incl. inter-kernel gaps (graph replay, HIP events)"}
+        roof = roofline_int8(model, cfg, batch, dev)
     if rank == 0 and not int8 and tp is None:
-        bufs = model._buffers(batch)
-        launches = []
-        for layer in model.layers:
-            # the model fuses the RMSNorm into the GEMV up to 8 rows (4 for the bit-exact kernel) and launches it separately
-            # beyond (llama.py: _fused_norm_rows)
-            from zhilight_amd.llama import _fused_norm_rows
-            nq = dict(norm_weight=layer.ln_attn, norm_eps=cfg.eps) if batch <= _fused_norm_rows(layer.qkv.weight) else {}
-            nf = dict(norm_weight=layer.ln_ff, norm_eps=cfg.eps) if batch <= _fused_norm_rows(layer.w_in_gated.weight) else {}
-            launches += [(bufs["hidden"], layer.qkv, bufs["qkv"], nq),
-                         (bufs["attn"], layer.attn_out, bufs["hidden"], dict(residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL)),
-                         (bufs["hidden"], layer.w_in_gated, bufs["act"], dict(epilogue=ops.EPI_SILU_MUL, **nf)),
-                         (bufs["act"], layer.w_out, bufs["hidden"], dict(residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL))]
-        bufs["hidden"].normal_()
-        bufs["attn"].normal_()
+        roof = roofline_w4(model, cfg, batch, dev, bool(args.layers))
 
-        def gemvs():
-            for x, lin, out, kw in launches:
-                ops.w4_linear(x, lin.weight, out=out, **kw)
-        gemvs()
-        torch.cuda.synchronize()
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
-            gemvs()
-        g2.replay()
-        torch.cuda.synchronize()
-        reps = 10
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            g2.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        t_launch = e0.elapsed_time(e1) * 1e-3 / (reps * len(launches))
-        tot_bytes = sum(alg_bytes_w4(lin.weight.n, lin.weight.k, lin.weight.group_size, batch) for _, lin, _, _ in launches)
-        per_launch = tot_bytes / len(launches)
-        achieved = per_launch / t_launch / 1e9
-        # MFMA flavour: k_w4a16_phase streams qkv / o / gate|up (and the down projection for 5..16 rows),
-        # k_w4a16_mfma the long-K down projection up to 4 rows, k_w4a16_gemm_tiled the down projection beyond 16 rows
-        kname = "k_w4a16_phase+k_w4a16_mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "k_w4a16_gemm"
-        # HBM traffic per launch: measured off-line with rocprofv3 --pmc (a counter pass cannot run inside
-        # this process); the committed summary is per kernel flavour and for these four shapes only
-        traffic = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemv_traffic.json")) as fh:
-                tj = json.load(fh)
-            if tj.get("kernel", "").startswith(kname.split("+")[0]) and not args.layers and batch == 1:
-                traffic = int(tj["avg_bytes_per_launch"])
-        except (OSError, ValueError, KeyError):
-            traffic = None
-        roof = {"bound": "hbm", "kernel": kname + " (W4A16 GEMV, 4 launches/layer)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3),
-                "note": "avg over the 128 GEMV launches of one step incl. inter-kernel gaps (graph replay, HIP events)"}
+    # ---- extra legs of the default single-GPU run: batch 8 / 32 on the headline model, BASELINE configs[2] (INT8, batch 32)
+    extras = None
+    if (rank == 0 and world == 1 and not args.no_extras and not int8 and tp is None and batch == 1 and not args.layers
+            and args.kv_cache_dtype == "fp16"):
+        esteps, ewarm = max(8, args.steps // 2), max(2, args.warmup // 2)
+        extras = [extra_decode_run(model, cfg, b, seq, esteps, ewarm, dev, False) for b in (8, 32)]
+        del ctx, graph
+        model8 = LLaMA(cfg, QuantConfig(2, 0), dev).init_random(seed=4321)
+        extras.append(extra_decode_run(model8, cfg, 32, seq, esteps, ewarm, dev, True))
+        del model8
+        torch.cuda.empty_cache()
 
     if rank == 0:
         value = (1 if tp else world) * batch * args.steps / elapsed
-        # whole-step algorithmic bytes: int4 linears + fp16 lm_head + KV read
-        if int8:
-            lin_bytes = sum(l.dim_in * l.dim_out + 2 * l.dim_out for lay in model.layers for l in lay.linears())
-        else:
-            lin_bytes = sum(alg_bytes_w4(l.weight.n, l.weight.k, 128, batch) for lay in model.layers
-                            for l in (lay.qkv, lay.attn_out, lay.w_in_gated, lay.w_out))
-        step_bytes = (lin_bytes
-                      + cfg.vocab_size * cfg.dim_model * 2
-                      + batch * cfg.num_layers * 2 * cfg.num_kv_heads * seq * cfg.dim_head * 2)
+        step_bytes = step_bytes_of(model, cfg, batch, seq, int8)
         out = {
             "metric": "decode tokens/s (Llama-3-8B %s, TP=1 per GPU, batch %d, seq %d)" % ("INT8" if int8 else "GPTQ-Int4", batch, seq),
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -358,6 +451,10 @@ def main():
             "ttft_note": "prompt of seq tokens, one task, first greedy token; eager launches, HIP events, mean of 3",
             "step_hbm_roofline_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
+            "other_batches": extras,
+            "oracle_check": None if oracle_check is None else {
+                "what": "layer 0 and last layer, four W4A16 linears each, HIP output vs the CPU oracle's exact product of the "
+                        "unpacked (zl_w4m_unpack) bench weights, before the timed region", "max_err_over_max_ref": round(oracle_check, 6)},
         }
         if world == 1 and not args.no_cpu_baseline and not int8:
             out["cpu_baseline"] = cpu_baseline(cfg, batch, seq)

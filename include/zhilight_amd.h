@@ -142,6 +142,10 @@ int zl_w4m_layout(int64_t n, int64_t k, int64_t group_size, zl_w4_layout_t* out)
 int zl_w4m_pack(const uint32_t* qweight_km, const uint8_t* qzeros_km, const uint16_t* scales_km,
                 int64_t n, int64_t k, int64_t group_size, int row_interleave,
                 uint32_t* qw, uint32_t* meta, zl_stream_t s);
+/* inverse of zl_w4m_pack: the k-major operands (N,K/8) u32 / (N,K/G) u8 zeros (already +1, low nibble) / (N,K/G) f16
+ * scales back out of a ZLW4M weight -- what a checker (or dequant_k_major, q_gemm_k_major.cu:907-952) reads. */
+int zl_w4m_unpack(const uint32_t* qw, const uint32_t* meta, int64_t n, int64_t k, int64_t group_size, int row_interleave,
+                  uint32_t* qweight_km, uint8_t* qzeros_km, uint16_t* scales_km, zl_stream_t s);
 int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx,
                        const uint32_t* qw, const uint32_t* meta,
                        const uint16_t* bias, const uint16_t* residual, uint16_t* y,

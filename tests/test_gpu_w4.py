@@ -557,3 +557,27 @@ def test_attention_split_merge_plan_limits(dev):
         ops.w4_attn_out_merge(ws, i32, i32, (128, 9), 5, real)          # more than 4 rows
     with pytest.raises(ZLError):
         ops.w4_attn_out_merge(ws, i32, i32, (128, 17), 1, real)         # more than 16 splits
+
+
+@pytest.mark.parametrize("k,n,g,inter", [(1024, 256, 128, False), (4096, 1000, 128, False), (2048, 528, 256, True), (1152, 40, 128, True)])
+def test_w4m_pack_unpack_round_trip(oracle, dev, k, n, g, inter):
+    """zl_w4m_unpack is the exact inverse of zl_w4m_pack (ragged N, group = 2 tiles, row-interleaved gate|up pairs), and a
+    weight generated directly in the packed layout (W4MWeight.random: what bench.py times) unpacks to operands whose exact
+    product the kernel reproduces -- the check bench.py runs before its timed region."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(k + n)
+    qw, qz, sc = synth.gptq_hf(rng, k, (n + 7) // 8 * 8, g)
+    km = tuple(np.ascontiguousarray(a[:n]) for a in oracle.gptq_prepare_k_major(qw, qz, sc, g))
+    w = ops.W4MWeight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), g, row_interleave=inter)
+    uq, uz, us = w.to_k_major()
+    assert np.array_equal(_np(uq).view(np.uint32), km[0])
+    assert np.array_equal(_np(uz), km[1] & 0xF)
+    assert np.array_equal(_np(us).view(np.uint16), km[2])
+    wr = ops.W4MWeight.random(n // 16 * 16 or 16, k, g, dev, row_interleave=inter)
+    rq, rz, rs = wr.to_k_major()
+    x = synth.act(rng, 3, k)
+    y = _np(ops.w4a16_gemm_mfma(_t(x, dev), wr)).astype(np.float64)
+    if inter:
+        y = np.concatenate([y[:, 0::2], y[:, 1::2]], axis=1)
+    exact = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), _np(rq).view(np.uint32), _np(rz), _np(rs).view(np.uint16))
+    assert np.abs(y - exact).max() <= 2.0 ** -10 * np.abs(exact).max() + 1e-6

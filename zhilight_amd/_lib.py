@@ -22,7 +22,7 @@ SYMBOLS = [
     "zl_gptq_shuffle", "zl_gptq_increase_zero", "zl_gptq_q4_to_q8", "zl_transpose_2d",
     "zl_awq_un_shuffle", "zl_awq_shuffle",
     "zl_w4_layout", "zl_w4_pack", "zl_w4_dequant", "zl_w4a16_gemm",
-    "zl_w4m_layout", "zl_w4m_pack", "zl_w4a16_gemm_mfma", "zl_w4a16_gemm_tiled",
+    "zl_w4m_layout", "zl_w4m_pack", "zl_w4m_unpack", "zl_w4a16_gemm_mfma", "zl_w4a16_gemm_tiled",
     "zl_gemm_nt_small_m", "zl_gemm_nt", "zl_argmax_workspace_bytes", "zl_gemm_nt_small_m_argmax", "zl_greedy_advance",
     "zl_rmsnorm",
     "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rotary_embedding_qk", "zl_rope_qk_cache",

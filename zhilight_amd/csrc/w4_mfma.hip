@@ -552,6 +552,37 @@ __global__ void k_pack_m_meta(const uint8_t* __restrict__ qz_km, const uint16_t*
     }
 }
 
+// ---- inverse of the packer: ZLW4M -> the k-major operands (every word / row is read from the slot k_pack_m_* wrote it to)
+__global__ void k_unpack_m_qw(const uint32_t* __restrict__ src, uint32_t* __restrict__ qw_km, int64_t n, int64_t k8,
+                              int64_t tiles, int64_t groups, int interleave) {
+    const int64_t total = tiles * groups * 256;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        const int64_t tg = i >> 8, g = tg % groups, tile = tg / groups;
+        const int64_t row = tile * 16 + (lane & 15);
+        const int64_t word = g * 16 + 4 * t + (lane >> 4);
+        const int64_t dst_row = interleave ? ((row & 1) * (n / 2) + (row >> 1)) : row;
+        if (row < n && word < k8) qw_km[dst_row * k8 + word] = src[i];
+    }
+}
+
+__global__ void k_unpack_m_meta(const uint32_t* __restrict__ meta, uint8_t* __restrict__ qz_km, uint16_t* __restrict__ sc_km,
+                                int64_t n, int64_t ng, int64_t group_items, int64_t tiles, int64_t groups, int interleave) {
+    const int64_t total = tiles * groups * 16;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i & 15);
+        const int64_t tg = i >> 4, g = tg % groups, tile = tg / groups;
+        if (g % group_items != 0) continue;            // the pair is repeated on each 128-k item of its group
+        const int64_t grp = g / group_items, row = tile * 16 + r;
+        const int64_t dst_row = interleave ? ((row & 1) * (n / 2) + (row >> 1)) : row;
+        if (row < n && grp < ng) {
+            const uint32_t v = meta[i];
+            sc_km[dst_row * ng + grp] = (uint16_t)(v & 0xffffu);
+            qz_km[dst_row * ng + grp] = (uint8_t)((v >> 16) & 0xfu);
+        }
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -608,6 +639,21 @@ int zl_w4m_pack(const uint32_t* qweight_km, const uint8_t* qzeros_km, const uint
                        k / 8, tiles, L.q, row_interleave);
     hipLaunchKernelGGL(k_pack_m_meta, dim3(grid_for(tiles * L.q * 16)), dim3(256), 0, (hipStream_t)s, qzeros_km,
                        scales_km, meta, n, k / g, g / 128, tiles, L.q, row_interleave);
+    return zl_launch_status();
+}
+
+int zl_w4m_unpack(const uint32_t* qw, const uint32_t* meta, int64_t n, int64_t k, int64_t g, int row_interleave,
+                  uint32_t* qweight_km, uint8_t* qzeros_km, uint16_t* scales_km, zl_stream_t s) {
+    ZL_CHECK_ARG(qweight_km && qzeros_km && scales_km && qw && meta, ZL_EINVAL);
+    zl_w4_layout_t L;
+    int st = zl_w4m_layout(n, k, g, &L);
+    if (st) return st;
+    ZL_CHECK_ARG(!row_interleave || n % 2 == 0, ZL_ESHAPE);
+    const int64_t tiles = L.np / 16;
+    hipLaunchKernelGGL(k_unpack_m_qw, dim3(grid_for(tiles * L.q * 256)), dim3(256), 0, (hipStream_t)s, qw, qweight_km, n,
+                       k / 8, tiles, L.q, row_interleave);
+    hipLaunchKernelGGL(k_unpack_m_meta, dim3(grid_for(tiles * L.q * 16)), dim3(256), 0, (hipStream_t)s, meta, qzeros_km,
+                       scales_km, n, k / g, g / 128, tiles, L.q, row_interleave);
     return zl_launch_status();
 }
 

@@ -210,17 +210,32 @@ class W4MWeight:
     def nbytes(self):
         return self.qw.numel() * 4 + self.meta.numel() * 4
 
+    def to_k_major(self):
+        """zl_w4m_unpack: (qweight (N,K/8) int32, qzeros (N,K/G) uint8, scales (N,K/G) fp16) -- the operands of
+        gptq_gemm_k_major (q_gemm_k_major.cu:957-1116), in checkpoint row order even for a row-interleaved weight."""
+        dev = self.qw.device
+        ng = self.k // self.group_size
+        qw = torch.empty((self.n, self.k // 8), dtype=torch.int32, device=dev)
+        qz = torch.empty((self.n, ng), dtype=torch.uint8, device=dev)
+        sc = torch.empty((self.n, ng), dtype=torch.float16, device=dev)
+        check(lib().zl_w4m_unpack(_p(self.qw), _p(self.meta), _i(self.n), _i(self.k), _i(self.group_size),
+                                  C.c_int(int(self.row_interleave)), _p(qw), _p(qz), _p(sc), _stream()), "w4m_unpack")
+        return qw, qz, sc
+
     @classmethod
     def random(cls, n, k, group_size, device, gen=None, scale_mag=0.005, row_interleave=False):
         """Synthetic weight generated directly in the packed layout (benchmarks: no checkpoint I/O)."""
         L = cls.layout(n, k, group_size)
         qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (L.qw_bytes // 4,), dtype=torch.int32, device=device, generator=gen)
-        cnt = L.scales_bytes // 4
+        gi = group_size // 128                          # the (scale, zero) pair is repeated on each 128-k item of its group
+        cnt = L.scales_bytes // 4 // gi
         sc = (torch.rand(cnt, device=device, generator=gen) * scale_mag + 1e-4).to(torch.float16)
         sc = sc.view(torch.int16).to(torch.int32) & 0xffff
         z = torch.randint(0, 16, (cnt,), dtype=torch.int32, device=device, generator=gen)
         meta = (sc | ((0xe400 | z) << 16)).to(torch.int64)
         meta = torch.where(meta >= 2 ** 31, meta - 2 ** 32, meta).to(torch.int32)
+        if gi > 1:
+            meta = meta.view(-1, 1, 16).expand(-1, gi, 16).reshape(-1).contiguous()
         return cls(n, k, group_size, qw, meta, row_interleave)
 
 
