@@ -1,0 +1,168 @@
+"""GPU parity THROUGH the C++ boundary: Python -> zl_internals (pybind) -> nn:: / int8_op:: wrappers with the
+reference's signatures (zhilight_amd/hostcpp/nn_amd.cpp) on the bmengine-on-HIP shim -> C ABI -> HIP kernels, checked
+against the CPU oracle.  (The other test_gpu_* files drive the same C ABI through ctypes.)  Mirrors what the reference
+tests through `zhilight.internals_` (tests/py_export_internal/)."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cx(dev):
+    from zhilight_amd import _lib
+    _lib.lib()
+    from zhilight_amd import zl_internals
+    return zl_internals.Context(0)
+
+
+def test_tensor_surface_and_pool(cx):
+    a = np.arange(7 * 5, dtype=np.int32).reshape(7, 5)
+    got = cx.tensor_roundtrip(a, 2, 6)
+    assert np.array_equal(got, a[2:6].reshape(-1))
+    before = cx.used_memory()
+    for _ in range(3):                                   # blocks are recycled: the pool does not grow
+        cx.tensor_roundtrip(a, 0, 7)
+    assert cx.used_memory() == before and cx.peak_memory() >= before
+
+
+@pytest.mark.parametrize("prepack", [True, False])
+@pytest.mark.parametrize("m,k,n", [(1, 4096, 6144), (8, 2048, 272), (33, 1024, 64)])
+def test_gptq_gemm_k_major_through_cpp(cx, oracle, m, k, n, prepack):
+    """nn::gptq::gptq_gemm_k_major (gptq.h:82-95) with the operands pre-packed by amd_pack_k_major (the load-time path)
+    and with the raw k-major operands of an unmodified caller; + bias."""
+    rng = np.random.default_rng(m + k)
+    qw, qz, sc = synth.gptq_hf(rng, k, n, 128)
+    km = oracle.gptq_prepare_k_major(qw, qz, sc, 128)
+    x = synth.act(rng, m, k)
+    bias = (rng.standard_normal(n) * 0.1).astype(np.float16)
+    got = cx.gptq_gemm_k_major(x, km[0], km[1], km[2].view(np.float16), bias=bias, prepack=prepack).astype(np.float64)
+    exact = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), *km, bias=oracle.h2u(bias))
+    if m > 32:    # the M-tiled kernel multiplies with W16 = rn16(rn16(q - z) s), the reference's M > 40 arithmetic
+        exact = oracle.gemm_nt(oracle.h2u(x), oracle.gptq_dequant_k_major(*km), oracle.h2u(bias), exact=True)
+    rms = np.sqrt((exact ** 2).mean())
+    assert (np.abs(got - exact) <= 2.0 ** -10 * np.abs(exact) + 3e-5 * rms).all()
+
+
+def test_gptq_small_group_takes_the_bit_exact_kernel(cx, oracle):
+    """group 32 does not fit the matrix-core tile: the wrapper routes to the warp-reduce arithmetic kernel, whose result
+    is bit-identical to the R oracle (KERNEL_gemm_warp_reduce, q_gemm_k_major.cu:127-237)."""
+    rng = np.random.default_rng(5)
+    qw, qz, sc = synth.gptq_hf(rng, 1024, 40, 32)
+    km = oracle.gptq_prepare_k_major(qw, qz, sc, 32)
+    x = synth.act(rng, 3, 1024)
+    got = cx.gptq_gemm_k_major(x, km[0], km[1], km[2].view(np.float16), prepack=False)
+    ref = oracle.gptq_gemm_k_major(oracle.h2u(x), *km)
+    assert np.array_equal(got.view(np.uint16), ref)
+
+
+def test_gptq_sym_and_dequant_and_gate(cx, oracle):
+    rng = np.random.default_rng(6)
+    k, n = 1024, 128
+    qw, qz, sc = synth.gptq_hf(rng, k, n, 128, sym=True)
+    km = oracle.gptq_prepare_k_major(qw, qz, sc, 128)
+    x = synth.act(rng, 2, k)
+    got = cx.gptq_gemm_k_major(x, km[0], np.zeros_like(km[1]), km[2].view(np.float16), sym=True, prepack=False).astype(np.float64)
+    exact = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), *km, sym=True)
+    assert np.abs(got - exact).max() <= 2.0 ** -10 * np.abs(exact).max()
+    # dequant_k_major: bit-exact W16 = rn16(rn16(q - z) s), raw and packed operands
+    w16 = oracle.gptq_dequant_k_major(*km)
+    for prepack in (False, True):
+        assert np.array_equal(cx.gptq_dequant_k_major(km[0], km[1], km[2].view(np.float16), prepack).view(np.uint16), w16)
+    # gemm_fuse_gate_in = silu(x W1^T) * (x W2^T)
+    qw2, qz2, sc2 = synth.gptq_hf(rng, k, n, 128)
+    km2 = oracle.gptq_prepare_k_major(qw2, qz2, sc2, 128)
+    qw1, qz1, sc1 = synth.gptq_hf(rng, k, n, 128)
+    km1 = oracle.gptq_prepare_k_major(qw1, qz1, sc1, 128)
+    got = cx.gemm_fuse_gate_in(x, km1[0], km1[1], km1[2].view(np.float16), km2[0], km2[1], km2[2].view(np.float16)).astype(np.float64)
+    g = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), *km1).astype(np.float16)
+    u = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), *km2).astype(np.float16)
+    ref = oracle.u2h(oracle.silu_mul(oracle.h2u(g), oracle.h2u(u))).astype(np.float64)
+    assert np.abs(got - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
+
+
+def test_gptq_load_transforms_bit_exact(cx, oracle):
+    rng = np.random.default_rng(7)
+    qw, qz, sc = synth.gptq_hf(rng, 1024, 256, 128)
+    q, z8 = cx.gptq_load_transforms(qw, qz)
+    assert np.array_equal(q, oracle.gptq_shuffle(qw))
+    assert np.array_equal(z8.reshape(-1), oracle.gptq_q4_to_q8(oracle.gptq_increase_zero(qz)).reshape(-1))
+
+
+@pytest.mark.parametrize("b,len_q,lens", [(1, 1, [1088]), (3, 1, [64, 200, 130]), (2, 4, [96, 70])])
+def test_multi_query_attention_rag_buffer_through_cpp(cx, oracle, b, len_q, lens):
+    rng = np.random.default_rng(b + len_q)
+    h, hkv, d = 32, 8, 128
+    q = synth.act(rng, b * len_q * h, d).reshape(b, len_q, h, d)
+    kb = [synth.act(rng, L * hkv, d).reshape(L, hkv, d) for L in lens]
+    vb = [synth.act(rng, L * hkv, d).reshape(L, hkv, d) for L in lens]
+    mask = np.concatenate([(rng.random((len_q, L)) < 0.8).astype(np.int8).reshape(-1) for L in lens])
+    scale = 1.0 / np.sqrt(d)
+    got = cx.multi_query_attention_rag_buffer(q, np.asarray(lens, np.int32), kb, vb, mask, scale, max(lens), h // hkv).astype(np.float64)
+    ref = oracle.mqa_rag_buffer(oracle.h2u(q), np.asarray(lens, np.int32), [oracle.h2u(a) for a in kb], [oracle.h2u(a) for a in vb], mask,
+                                hkv, scale, True, exact=True)
+    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+def test_rope_scatter_norm_elementwise_through_cpp(cx, oracle):
+    rng = np.random.default_rng(11)
+    h, hkv, d, s = 8, 2, 128, 5
+    pos = np.array([0, 3, 17, 1024, 8191], np.int32)
+    cs, sn = oracle.rope_cos_sin(pos, d, 5e5, True)
+    x = synth.act(rng, s, (h + 2 * hkv) * d)
+    q, k, v = cx.rope_qk_cache(cs, sn, x, h, hkv, d, True)
+    rq, rk, rv = oracle.rope_qk_cache(cs, sn, oracle.h2u(x), h, hkv, d, True)
+    for got, ref in ((q, rq), (k, rk), (v, rv)):
+        assert synth.ulp_diff_f16(got.view(np.uint16), ref).max() <= 1
+    # scatter two tasks' rows
+    lens = np.array([16, 24], np.int32)
+    place = np.array([[3], [23]], np.int32)
+    ks, vs = synth.act(rng, 2 * hkv, d).reshape(2, 1, hkv, d), synth.act(rng, 2 * hkv, d).reshape(2, 1, hkv, d)
+    kb = [np.zeros((L, hkv, d), np.float16) for L in lens]
+    vb = [np.zeros((L, hkv, d), np.float16) for L in lens]
+    ko, vo = cx.copy_to_rag_buffer2(place, lens, ks, vs, kb, vb)
+    for t in range(2):
+        assert np.array_equal(ko[t][place[t, 0]], ks[t, 0]) and np.array_equal(vo[t][place[t, 0]], vs[t, 0])
+        assert np.count_nonzero(ko[t]) == np.count_nonzero(ks[t, 0])
+    # RMSNorm, fused add + norm, residual add, gated activation
+    xx, yy = synth.act(rng, 4, 4096, 2.0), synth.act(rng, 4, 4096)
+    w = (1 + 0.1 * rng.standard_normal(4096)).astype(np.float16)
+    assert synth.ulp_diff_f16(cx.layernorm(xx, w, 1e-5, 1.0).view(np.uint16), oracle.rmsnorm(oracle.h2u(xx), oracle.h2u(w), 1e-5)).max() <= 1
+    out, ssum = cx.layernorm_fuse_add(xx, yy, w, 1e-5)
+    ro, rsum = oracle.rmsnorm(oracle.h2u(xx), oracle.h2u(w), 1e-5, x2=oracle.h2u(yy))
+    assert synth.ulp_diff_f16(out.view(np.uint16), ro).max() <= 1
+    assert np.array_equal(ssum.view(np.uint16), rsum)
+    assert np.array_equal(cx.element_add_scale(xx, yy, 0.5, True).view(np.uint16), oracle.element_add_scale(oracle.h2u(xx), oracle.h2u(yy), 0.5, True))
+    assert synth.ulp_diff_f16(cx.gate_mul(xx, yy, "silu").view(np.uint16), oracle.silu_mul(oracle.h2u(xx), oracle.h2u(yy))).max() <= 1
+
+
+def test_int8_route_through_cpp_is_bit_exact(cx, oracle):
+    """Int8Linear::forward composed from the int8_op:: wrappers: quantised rows, int32 product and the scaled-back
+    outputs are bit-identical to the oracle (north_star: bit-exact for INT8 GEMM)."""
+    rng = np.random.default_rng(12)
+    m, k, n = 5, 1024, 384
+    x = synth.act(rng, m, k, 3.0)
+    wq = rng.integers(-127, 128, size=(n, k), dtype=np.int8)
+    ws = (np.abs(rng.standard_normal(n)) * 0.01 + 1e-3).astype(np.float16)
+    q, sx = cx.quant_calc_scale(x)
+    rq, rsx = oracle.quant_calc_scale(oracle.h2u(x))
+    assert np.array_equal(q, rq) and np.array_equal(sx, rsx)
+    y, acc = cx.int8_linear(x, wq, ws)
+    racc = oracle.int8_gemm_nt(rq, wq)
+    assert np.array_equal(acc, racc)
+    assert np.array_equal(y.view(np.uint16), oracle.quant_scale_back(racc, rsx, oracle.h2u(ws)))
+    w = (1 + 0.1 * rng.standard_normal(k)).astype(np.float16)
+    out, q2, s2 = cx.layernorm_quant(x, w, 1e-5)
+    ro, rq2, rs2 = oracle.rmsnorm_quant(oracle.h2u(x), oracle.h2u(w), 1e-5)
+    assert np.array_equal(q2, rq2) and np.allclose(s2, rs2, rtol=3e-7, atol=0)   # the scale carries the block-sum association
+    assert synth.ulp_diff_f16(out.view(np.uint16), ro).max() <= 1
+    b_acc = rng.integers(-50000, 50000, size=(m, n), dtype=np.int32)
+    got = cx.quant_back_act_mul(racc, rsx, ws, b_acc, rsx, ws, "silu")
+    assert synth.ulp_diff_f16(got.view(np.uint16), oracle.quant_back_act_mul(racc, rsx, oracle.h2u(ws), b_acc, rsx, oracle.h2u(ws), "silu")).max() <= 1
+
+
+def test_errors_become_bmengine_exceptions(cx):
+    with pytest.raises(RuntimeError, match="size K mismatch"):
+        cx.raises_on_bad_shape()

@@ -51,7 +51,37 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if jobs or force or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    build_hostcpp(force, verbose)
     return OUT
+
+
+HOSTCPP = os.path.join(HERE, "hostcpp")
+
+
+def hostcpp_target():
+    import sysconfig
+    return os.path.join(HERE, "zl_internals" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_hostcpp(force=False, verbose=False):
+    """The C++ host layer (bmengine-on-HIP shim + the reference's nn:: / int8_op:: operator names over the C ABI) and its
+    pybind11 test module zhilight_amd/zl_internals*.so.  Host code only: g++ against the HIP runtime headers."""
+    import pybind11
+    import sysconfig
+    srcs = [os.path.join(HOSTCPP, f) for f in ("bm_hip.cpp", "nn_amd.cpp", "py_internals.cpp")]
+    deps = srcs + [os.path.join(HOSTCPP, f) for f in ("bm_hip.h", "nn_amd.h")] + [os.path.join(HERE, "..", "include", "zhilight_amd.h")]
+    target = hostcpp_target()
+    if not (force or _stale(target, deps)):
+        return target
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
+           "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]] + srcs + [
+           "-o", target, "-L" + HERE, "-lzhilight_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return target
 
 
 if __name__ == "__main__":

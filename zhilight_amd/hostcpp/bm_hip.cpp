@@ -1,0 +1,318 @@
+// bm_hip.cpp -- storage, tensors and the per-device context behind bm_hip.h (HIP runtime only; no torch, no BLAS).
+#include "bm_hip.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+#include <sstream>
+
+BMEngineException::BMEngineException(const std::string& msg, const char* file, int line, const char* func, const std::string& info)
+    : std::runtime_error(msg) {
+    std::ostringstream os;
+    os << "File: " << file << ":" << line << " " << func << "\n" << msg << "\n" << info << "\n";
+    text_ = os.str();
+}
+
+namespace bmengine {
+namespace core {
+
+static const char* kTypeNames[] = {"double", "float", "half", "int8", "int16", "int32", "bfloat", "fp8_e4m3", "fp8_e5m2"};
+static const size_t kTypeSizes[] = {8, 4, 2, 1, 2, 4, 2, 1, 1};
+
+const char* get_data_type_name(DataType dtype) { return kTypeNames[(int)dtype]; }
+DataType name_to_data_type(const std::string& name) {
+    for (int i = 0; i < 9; ++i)
+        if (name == kTypeNames[i]) return (DataType)i;
+    if (name == "bfloat16" || name == "bf16") return DataType::kBFloat16;
+    if (name == "float16" || name == "fp16") return DataType::kHalf;
+    if (name == "int") return DataType::kInt32;
+    throw std::runtime_error("unknown data type name " + name);
+}
+size_t get_elem_size(DataType dtype) { return kTypeSizes[(int)dtype]; }
+size_t get_numel(const std::vector<size_t>& size) {
+    size_t n = 1;
+    for (size_t s : size) n *= s;
+    return n;
+}
+
+// ---- storage -------------------------------------------------------------------------------------------------------
+struct Storage {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+    std::function<void(void*, size_t)> release;      // back to the pool / hipFree / free / nothing (borrowed)
+    ~Storage() {
+        if (release) release(ptr, bytes);
+    }
+};
+
+// Size-class pool over hipMalloc: blocks are rounded up to a power of two between 1 KB and 64 MB (multiples of 64 MB
+// above) and recycled.  Blocks never move, so a raw pointer taken from a live Tensor stays valid (the reference's arena
+// may defragment unless a GCStopper is alive, allocator.cpp:74-109).
+class Pool {
+public:
+    explicit Pool(int device) : device_(device) {}
+    ~Pool() { trim(); }
+    static size_t round(size_t n) {
+        size_t c = 1024;
+        while (c < n && c < ((size_t)64 << 20)) c <<= 1;
+        if (c >= n) return c;
+        const size_t unit = (size_t)64 << 20;
+        return (n + unit - 1) / unit * unit;
+    }
+    void* get(size_t cls) {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = free_.find(cls);
+        void* p = nullptr;
+        if (it != free_.end() && !it->second.empty()) {
+            p = it->second.back();
+            it->second.pop_back();
+        } else {
+            hipError_t e = hipMalloc(&p, cls);
+            if (e != hipSuccess) {
+                trim_locked();
+                e = hipMalloc(&p, cls);
+            }
+            if (e != hipSuccess) throw std::runtime_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+            reserved_ += cls;
+        }
+        used_ += cls;
+        peak_ = std::max(peak_, used_);
+        return p;
+    }
+    void put(void* p, size_t cls) {
+        std::lock_guard<std::mutex> lk(mu_);
+        free_[cls].push_back(p);
+        used_ -= cls;
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lk(mu_);
+        trim_locked();
+    }
+    size_t used() const { return used_; }
+    size_t peak() const { return peak_; }
+
+private:
+    void trim_locked() {
+        for (auto& kv : free_) {
+            for (void* p : kv.second) {
+                (void)hipFree(p);
+                reserved_ -= kv.first;
+            }
+            kv.second.clear();
+        }
+    }
+    int device_;
+    std::mutex mu_;
+    std::map<size_t, std::vector<void*>> free_;
+    size_t used_ = 0, peak_ = 0, reserved_ = 0;
+};
+
+// ---- Tensor --------------------------------------------------------------------------------------------------------
+Tensor::Tensor() = default;
+Tensor::~Tensor() = default;
+Tensor::Tensor(const Tensor&) = default;
+Tensor::Tensor(Tensor&&) noexcept = default;
+Tensor& Tensor::operator=(const Tensor&) = default;
+Tensor& Tensor::operator=(Tensor&&) noexcept = default;
+
+void Tensor::set_shape(const std::vector<size_t>& s) {
+    shape_ = s;
+    strides_.assign(s.size(), 1);
+    for (int i = (int)s.size() - 2; i >= 0; --i) strides_[i] = strides_[i + 1] * s[i + 1];
+}
+size_t Tensor::numel() const { return mem_ ? get_numel(shape_) : 0; }
+int Tensor::normalize_dim(int dim) const {
+    const int n = ndim();
+    BM_ASSERT(dim >= -n && dim < n, "dim out of range");
+    return dim < 0 ? dim + n : dim;
+}
+void* Tensor::data() const {
+    BM_ASSERT(mem_ && mem_->ptr, "Tensor is empty");
+    return (char*)mem_->ptr + offset_;
+}
+void* Tensor::nullable_data() const { return mem_ && mem_->ptr ? (char*)mem_->ptr + offset_ : nullptr; }
+size_t Tensor::mem_bytes() const { return mem_ ? mem_->bytes - offset_ : 0; }
+bool Tensor::is_continuous() const {
+    size_t expect = 1;
+    for (int i = ndim() - 1; i >= 0; --i) {
+        if (shape_[i] != 1 && strides_[i] != expect) return false;
+        expect *= shape_[i];
+    }
+    return true;
+}
+Tensor Tensor::view_unchecked(const std::vector<size_t>& size, DataType dtype) const {
+    Tensor t(*this);
+    t.quant_scale = quant_scale;
+    t.dtype_ = dtype;
+    t.set_shape(size);
+    return t;
+}
+Tensor Tensor::view_type(const std::vector<size_t>& size, DataType dtype) const {
+    BM_ASSERT(is_continuous(), "view of a non-continuous tensor");
+    BM_ASSERT_EQ(get_numel(size) * get_elem_size(dtype), nbytes(), "view: size mismatch");
+    return view_unchecked(size, dtype);
+}
+Tensor Tensor::view(const std::vector<size_t>& size) const { return view_type(size, dtype_); }
+Tensor Tensor::slice_dim0(size_t from, size_t to) const {
+    BM_ASSERT(ndim() >= 1 && from <= to && to <= shape_[0], "slice_dim0 out of range");
+    Tensor t(*this);
+    t.offset_ = offset_ + from * strides_[0] * get_elem_size(dtype_);
+    t.shape_[0] = to - from;
+    return t;
+}
+Tensor Tensor::index_dim0(size_t i) const {
+    BM_ASSERT(ndim() >= 1 && i < shape_[0], "index_dim0 out of range");
+    Tensor t(*this);
+    t.offset_ = offset_ + i * strides_[0] * get_elem_size(dtype_);
+    t.shape_.erase(t.shape_.begin());
+    t.strides_.erase(t.strides_.begin());
+    return t;
+}
+Tensor Tensor::virtual_slice(size_t from, size_t len, int dim) const {
+    const int d = normalize_dim(dim);
+    BM_ASSERT(from + len <= shape_[d], "virtual_slice out of range");
+    Tensor t(*this);
+    t.offset_ = offset_ + from * strides_[d] * get_elem_size(dtype_);
+    t.shape_[d] = len;
+    return t;
+}
+std::vector<Tensor> Tensor::chunk() const {
+    std::vector<Tensor> out;
+    for (size_t i = 0; i < shape_[0]; ++i) out.push_back(index_dim0(i));
+    return out;
+}
+Tensor Tensor::squeeze() const {
+    std::vector<size_t> s;
+    for (size_t v : shape_)
+        if (v != 1) s.push_back(v);
+    return view(s);
+}
+void Tensor::from_buffer(const void* host, bool async, hipStream_t stream) {
+    BM_ASSERT(is_continuous(), "from_buffer needs a continuous tensor");
+    if (device_ < 0) {
+        std::memcpy(data(), host, nbytes());
+        return;
+    }
+    BM_HIPRT_ASSERT(hipMemcpyAsync(data(), host, nbytes(), hipMemcpyHostToDevice, stream));
+    if (!async) BM_HIPRT_ASSERT(hipStreamSynchronize(stream));
+}
+void Tensor::to_buffer(void* host, hipStream_t stream) const {
+    BM_ASSERT(is_continuous(), "to_buffer needs a continuous tensor");
+    if (device_ < 0) {
+        std::memcpy(host, data(), nbytes());
+        return;
+    }
+    BM_HIPRT_ASSERT(hipMemcpyAsync(host, data(), nbytes(), hipMemcpyDeviceToHost, stream));
+    BM_HIPRT_ASSERT(hipStreamSynchronize(stream));
+}
+Tensor Tensor::from_external(const std::vector<size_t>& shape, DataType dtype, void* ptr, size_t nbytes, int device, bool own_ptr) {
+    BM_ASSERT(get_numel(shape) * get_elem_size(dtype) <= nbytes, "from_external: buffer too small");
+    Tensor t;
+    t.mem_ = std::make_shared<Storage>();
+    t.mem_->ptr = ptr;
+    t.mem_->bytes = nbytes;
+    t.mem_->device = device;
+    if (own_ptr) t.mem_->release = device >= 0 ? std::function<void(void*, size_t)>([](void* p, size_t) { (void)hipFree(p); })
+                                               : std::function<void(void*, size_t)>([](void* p, size_t) { std::free(p); });
+    t.dtype_ = dtype;
+    t.device_ = device;
+    t.set_shape(shape);
+    return t;
+}
+std::string Tensor::info(int) const {
+    std::ostringstream os;
+    os << "Tensor(" << (name_.empty() ? "?" : name_) << ", " << get_data_type_name(dtype_) << ", [";
+    for (size_t i = 0; i < shape_.size(); ++i) os << (i ? "," : "") << shape_[i];
+    os << "], device " << device_ << ")";
+    return os.str();
+}
+
+// ---- Context -------------------------------------------------------------------------------------------------------
+class ContextImpl {
+public:
+    int device, rank, world;
+    hipDeviceProp_t prop;
+    std::shared_ptr<Pool> pool;                      // shared with the tensors it handed out
+    Stream stream;
+    Context::ReduceHook reduce;
+    long next_id = 0;
+};
+const std::string Context::EMPTY_STR;
+
+Context::Context(int device, int rank, int world_size) : pimpl(new ContextImpl) {
+    pimpl->device = device;
+    pimpl->rank = rank;
+    pimpl->world = world_size;
+    BM_HIPRT_ASSERT(hipSetDevice(device));
+    BM_HIPRT_ASSERT(hipGetDeviceProperties(&pimpl->prop, device));
+    pimpl->pool = std::make_shared<Pool>(device);
+    pimpl->stream = get_stream();
+}
+Context::~Context() = default;
+int Context::active_device() const { return pimpl->device; }
+int Context::rank() const { return pimpl->rank; }
+int Context::world_size() const { return pimpl->world; }
+int Context::get_compute_capability() const { return 90; }
+int Context::get_mp_count() const { return pimpl->prop.multiProcessorCount; }
+int Context::get_max_shared_memory() const { return (int)pimpl->prop.sharedMemPerBlock; }
+int Context::get_L2_cache_size() const { return pimpl->prop.l2CacheSize; }
+Stream Context::current_stream() const { return pimpl->stream; }
+void Context::set_current_stream(Stream s) { pimpl->stream = std::move(s); }
+hipStream_t Context::current_cuda_stream() const { return pimpl->stream->ptr; }
+Stream Context::get_stream() const {
+    hipStream_t s;
+    BM_HIPRT_ASSERT(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return std::make_shared<Stream_>(s, [](hipStream_t p) { (void)hipStreamDestroy(p); });
+}
+Tensor Context::tensor(const std::vector<size_t>& size, DataType dtype, const std::string& name, size_t round_up_bytes) const {
+    const size_t nbytes = get_numel(size) * get_elem_size(dtype);
+    if (nbytes == 0) return Tensor();
+    const size_t want = (nbytes + round_up_bytes - 1) / round_up_bytes * round_up_bytes;
+    const size_t cls = Pool::round(want);
+    std::shared_ptr<Pool> pool = pimpl->pool;
+    Tensor t;
+    t.mem_ = std::make_shared<Storage>();
+    t.mem_->ptr = pool->get(cls);
+    t.mem_->bytes = cls;
+    t.mem_->device = pimpl->device;
+    t.mem_->release = [pool, cls](void* p, size_t) { pool->put(p, cls); };
+    t.dtype_ = dtype;
+    t.device_ = pimpl->device;
+    t.set_shape(size);
+    t.id_ = pimpl->next_id++;
+    t.name_ = name;
+    return t;
+}
+Tensor Context::cuda(const Tensor& cpu_tensor) const {
+    if (cpu_tensor.device() >= 0 || cpu_tensor.empty()) return cpu_tensor;
+    Tensor t = tensor(cpu_tensor.shape(), cpu_tensor.dtype(), cpu_tensor.name());
+    t.from_buffer(cpu_tensor.data(), false, current_cuda_stream());
+    return t;
+}
+const Tensor Context::copy(const Tensor& src) const {
+    if (src.empty()) return Tensor();
+    BM_ASSERT(src.is_continuous(), "copy of a non-continuous tensor");
+    Tensor t = tensor(src.shape(), src.dtype(), src.name());
+    BM_HIPRT_ASSERT(hipMemcpyAsync(t.data(), src.data(), src.nbytes(), src.device() >= 0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                   current_cuda_stream()));
+    return t;
+}
+size_t Context::used_memory() const { return pimpl->pool->used(); }
+size_t Context::peak_memory() const { return pimpl->pool->peak(); }
+void Context::mem_gc() { pimpl->pool->trim(); }
+void Context::recordEvent(const std::string&, int, float) const {}
+void Context::set_reduce_hook(ReduceHook h) { pimpl->reduce = std::move(h); }
+Tensor Context::reduce_sum(Tensor& data, DataType out_type) const {
+    BM_ASSERT(out_type == data.dtype(), "reduce_sum: the output type is the input type on this path");
+    if (pimpl->world > 1) {
+        BM_ASSERT(pimpl->reduce, "reduce_sum: no communicator installed (Context::set_reduce_hook)");
+        pimpl->reduce(data, current_cuda_stream());
+    }
+    return data;
+}
+
+}  // namespace core
+}  // namespace bmengine

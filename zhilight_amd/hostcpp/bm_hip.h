@@ -1,0 +1,220 @@
+// bm_hip.h -- the slice of bmengine's tensor / context surface that ZhiLight's hot-path host code touches, re-built on
+// the HIP runtime for MI355X.  Source-compatible with the reference for the members it declares (same namespace, class
+// and member names, argument orders and meanings), so the reference's callers -- Int4GPTQ::forward (src/nn/linear/
+// linear.cpp:934-1004), NormalImpl::dynamic_batch_forward (src/nn/attention/attention.cpp:846-964), FeedForward
+// (src/nn/feedforward/feedforward.cpp:113-187), EncoderLayer (src/nn/block/block.cpp:86-143) -- compile against it with
+// cudaStream_t spelled hipStream_t.  What it mirrors:
+//   core::DataType      3rd/bmengine/bmengine/include/bmengine/core/dtype.h:12-22 (same enumerator order)
+//   core::Tensor        .../core/tensor.h:30-138  (shape / stride / dtype / data<T>(), view, slice_dim0, index_dim0,
+//                       virtual_slice, chunk, from_buffer / to_buffer, from_external, the public quant_scale side tensor)
+//   core::Stream        .../core/stream.h:12-27
+//   core::Context       .../core/context.h:24-173 (tensor(), null_tensor(), current_stream(), set_current_stream(),
+//                       rank / world_size, get_mp_count / get_compute_capability / get_max_shared_memory, recordEvent,
+//                       is_BSHD, high_precision, reduce_sum)
+//   BMEngineException   .../core/exception.h:25-130 (+ the BM_ASSERT* / BM_CUDART_ASSERT macros)
+// Nothing below is taken from those files beyond the names: storage is a ref-counted block from a per-context size-class
+// pool over hipMalloc (the reference carves a movable arena, allocator.cpp:31-226; tensors here never move, so raw
+// pointers stay valid while their Tensor lives), a Context is bound to one device and one thread.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <functional>
+#include <initializer_list>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+class BMEngineException : public std::runtime_error {
+public:
+    BMEngineException(const std::string& msg, const char* file, int line, const char* func, const std::string& info = "");
+    const char* what() const noexcept override { return text_.c_str(); }
+
+private:
+    std::string text_;
+};
+
+#define BM_EXCEPTION(msg) throw BMEngineException(msg, __FILE__, __LINE__, __PRETTY_FUNCTION__)
+#define BM_ASSERT(cond, msg)                                                                            \
+    do {                                                                                                \
+        if (__builtin_expect(!(cond), 0))                                                               \
+            throw BMEngineException("Assertion failed: " #cond, __FILE__, __LINE__, __PRETTY_FUNCTION__, msg); \
+    } while (0)
+#define BM_ASSERT_EQ(x, y, msg)                                                                         \
+    do {                                                                                                \
+        if (__builtin_expect((x) != (y), 0))                                                            \
+            throw BMEngineException(std::string("Assertion failed: " #x " != " #y " i.e. ") + std::to_string(x) + " != " + \
+                                        std::to_string(y), __FILE__, __LINE__, __PRETTY_FUNCTION__, msg); \
+    } while (0)
+#define BM_ASSERT_LE(x, y, msg)                                                                         \
+    do {                                                                                                \
+        if (__builtin_expect((x) > (y), 0))                                                             \
+            throw BMEngineException(std::string("Assertion failed: " #x " <= " #y " i.e. ") + std::to_string(x) + " <= " + \
+                                        std::to_string(y), __FILE__, __LINE__, __PRETTY_FUNCTION__, msg); \
+    } while (0)
+// the reference spells the runtime check BM_CUDART_ASSERT; both names are accepted
+#define BM_HIPRT_ASSERT(expr)                                                                           \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (__builtin_expect(e_ != hipSuccess, 0))                                                      \
+            throw BMEngineException(std::string("HIP runtime error: ") + hipGetErrorString(e_), __FILE__, __LINE__, \
+                                    __PRETTY_FUNCTION__, #expr);                                        \
+    } while (0)
+#define BM_CUDART_ASSERT(expr) BM_HIPRT_ASSERT(expr)
+
+namespace bmengine {
+namespace core {
+
+enum class DataType { kDouble, kFloat, kHalf, kInt8, kInt16, kInt32, kBFloat16, kFP8_E4M3, kFP8_E5M2 };
+const char* get_data_type_name(DataType dtype);
+DataType name_to_data_type(const std::string& name);
+size_t get_elem_size(DataType dtype);
+size_t get_numel(const std::vector<size_t>& size);
+
+struct Stream_ {
+    hipStream_t ptr;
+    std::function<void(hipStream_t)> deleter;
+    Stream_(hipStream_t p, std::function<void(hipStream_t)> d) : ptr(p), deleter(std::move(d)) {}
+    Stream_(const Stream_&) = delete;
+    Stream_& operator=(const Stream_&) = delete;
+    ~Stream_() { if (deleter) deleter(ptr); }
+};
+typedef std::shared_ptr<Stream_> Stream;
+
+class Context;
+struct Storage;   // ref-counted device (or host) block
+
+class Tensor {
+public:
+    std::shared_ptr<Tensor> quant_scale;           // int8 activations carry their per-row scale (linear.cpp:557-635)
+    void set_quant_scale(const Tensor& scale) { quant_scale = std::make_shared<Tensor>(scale); }
+
+    Tensor();
+    ~Tensor();
+    Tensor(const Tensor&);
+    Tensor(Tensor&&) noexcept;
+    Tensor& operator=(const Tensor&);
+    Tensor& operator=(Tensor&&) noexcept;
+
+    long id() const { return id_; }
+    void set_id(long i) const { id_ = i; }
+    const std::string& name() const { return name_; }
+    void set_name(const std::string& n) const { name_ = n; }
+
+    DataType dtype() const { return dtype_; }
+    int ndim() const { return (int)shape_.size(); }
+    size_t numel() const;
+    size_t nbytes() const { return numel() * get_elem_size(dtype_); }
+    bool empty() const { return numel() == 0; }
+    const std::vector<size_t>& size() const { return shape_; }
+    const std::vector<size_t>& shape() const { return shape_; }
+    int normalize_dim(int dim) const;
+    size_t size(int dim) const { return shape_[normalize_dim(dim)]; }
+    size_t stride(int dim) const { return strides_[normalize_dim(dim)]; }
+    size_t stride_bytes(int dim) const { return stride(dim) * get_elem_size(dtype_); }
+
+    void* data() const;                              // throws on an empty tensor
+    void* nullable_data() const;                     // nullptr for an empty tensor
+    void* mutable_data() { return data(); }
+    template <typename T> T* data() const { return reinterpret_cast<T*>(data()); }
+    template <typename T> T* mutable_data() { return reinterpret_cast<T*>(data()); }
+    size_t mem_bytes() const;
+    int device() const { return device_; }           // -1: host
+
+    Tensor view(const std::vector<size_t>& size) const;
+    Tensor view_type(const std::vector<size_t>& size, DataType dtype) const;
+    Tensor view_unchecked(const std::vector<size_t>& size, DataType dtype) const;
+    Tensor index_dim0(size_t i) const;
+    Tensor slice_dim0(size_t from, size_t to) const;
+    Tensor slice_dim0_len(size_t from, size_t len) const { return slice_dim0(from, from + len); }
+    Tensor virtual_slice(size_t from, size_t len, int dim = -1) const;   // strided: no longer continuous
+    bool is_continuous() const;
+    std::vector<Tensor> chunk() const;
+    Tensor squeeze() const;
+
+    void from_buffer(const void* host, bool async = false, hipStream_t stream = nullptr);
+    void to_buffer(void* host, hipStream_t stream = nullptr) const;
+    template <typename T> std::vector<T> to_vector(hipStream_t stream = nullptr) const {
+        std::vector<T> v(nbytes() / sizeof(T));
+        to_buffer(v.data(), stream);
+        return v;
+    }
+    // wrap memory owned elsewhere (device = -1: host); own_ptr: free it (hipFree / free) with the last reference
+    static Tensor from_external(const std::vector<size_t>& shape, DataType dtype, void* ptr, size_t nbytes, int device = -1,
+                                bool own_ptr = false);
+    std::string info(int level = 0) const;
+
+private:
+    friend class Context;
+    std::shared_ptr<Storage> mem_;
+    size_t offset_ = 0;                              // bytes into mem_
+    std::vector<size_t> shape_, strides_;            // strides in elements
+    DataType dtype_ = DataType::kHalf;
+    int device_ = -1;
+    mutable long id_ = -1;
+    mutable std::string name_;
+    void set_shape(const std::vector<size_t>& s);
+};
+
+class ContextImpl;
+// One Context per device per thread (context.cpp:275-280).  All launches of the nn:: wrappers go to current_stream().
+class Context {
+public:
+    static const std::string EMPTY_STR;
+    explicit Context(int device, int rank = 0, int world_size = 1);
+    ~Context();
+    Context(const Context&) = delete;
+
+    int active_device() const;
+    int rank() const;
+    int world_size() const;
+    int get_compute_capability() const;              // 90: the reference gates dual-stream / wmma paths on > 80
+    int get_mp_count() const;
+    int get_max_shared_memory() const;
+    int get_L2_cache_size() const;
+
+    Stream current_stream() const;
+    void set_current_stream(Stream s);
+    hipStream_t current_cuda_stream() const;         // (name kept from the reference)
+    Stream get_stream() const;                       // a fresh non-blocking stream
+
+    Tensor null_tensor() const { return Tensor(); }
+    Tensor tensor(const std::vector<size_t>& size, DataType dtype, const std::string& name = EMPTY_STR,
+                  size_t round_up_bytes = 1024) const;
+    Tensor cuda(const Tensor& cpu_tensor) const;     // host -> device copy on the current stream (synchronous)
+    template <typename T> Tensor tensor_of(const std::vector<T>& data, const std::vector<size_t>& shape, DataType dt) const {
+        Tensor t = tensor(shape, dt);
+        BM_ASSERT_EQ(data.size() * sizeof(T), t.nbytes(), "data not fit for tensor");
+        t.from_buffer(data.data());
+        return t;
+    }
+    const Tensor copy(const Tensor& t) const;
+
+    size_t used_memory() const;
+    size_t peak_memory() const;
+    void mem_gc();                                   // return cached blocks to the driver
+
+    void recordEvent(const std::string& name, int ev_level = 2, float flops = 0) const;
+    int debug() const { return 0; }
+    int current_layer() const { return cur_layer_; }
+    void set_current_layer(int i) { cur_layer_ = i; }
+    int high_precision() const { return high_precision_; }
+    void set_high_precision(int level) { high_precision_ = level; }
+    bool is_BSHD() const { return bshd_; }
+    void set_BSHD(bool b) { bshd_ = b; }
+
+    // tensor parallelism: sum over the ranks of the node (ModelContext::reduce_sum, model_context.cpp:203-242).  The hook
+    // is installed by the communicator owner (RCCL / the one-shot xGMI all-reduce); with world_size 1 it is the identity.
+    typedef std::function<void(Tensor& data, hipStream_t stream)> ReduceHook;
+    void set_reduce_hook(ReduceHook h);
+    Tensor reduce_sum(Tensor& data, DataType out_type) const;
+
+private:
+    std::unique_ptr<ContextImpl> pimpl;
+    int cur_layer_ = -1, high_precision_ = 0;
+    bool bshd_ = true;                               // Python default flash_attention=True (zhilight/dynamic_batch.py:36)
+};
+
+}  // namespace core
+}  // namespace bmengine

@@ -1,0 +1,380 @@
+// nn_amd.cpp -- the reference's operator names (nn_amd.h) bound to the MI355X C ABI.  Thin by design: argument checks
+// in the reference's words, output allocation through the Context, one (occasionally two) zl_* launches on the
+// context's current stream, status -> BMEngineException.  No kernel code here and no torch.
+#include "nn_amd.h"
+
+#include "../../include/zhilight_amd.h"
+
+using bmengine::core::Context;
+using bmengine::core::DataType;
+using bmengine::core::Tensor;
+
+namespace {
+
+void zl_check(int st, const char* what) {
+    if (st == 0) return;
+    BM_EXCEPTION(std::string(what) + ": status " + std::to_string(st) + ": " + zl_status_string(st));
+}
+int zdt(DataType t) {
+    BM_ASSERT(t == DataType::kHalf || t == DataType::kBFloat16, "half or bfloat16 expected");
+    return t == DataType::kHalf ? ZL_F16 : ZL_BF16;
+}
+zl_stream_t st_of(const Context& ctx) { return (zl_stream_t)ctx.current_cuda_stream(); }
+const uint16_t* u16(const Tensor& t) { return t.data<const uint16_t>(); }
+uint16_t* u16m(Tensor& t) { return t.data<uint16_t>(); }
+size_t rows_of(const Tensor& t) { return t.numel() / t.size(-1); }
+
+}  // namespace
+
+namespace nn {
+namespace gptq {
+
+void gptq_shuffle(const Context& ctx, Tensor& q_weight, Tensor q_perm) {
+    BM_ASSERT_EQ(q_weight.ndim(), 2, "q_weight is not 2d");
+    BM_ASSERT(q_perm.numel() == 0, "act-order checkpoints: regroup the rows at load (see INTEGRATION.md)");
+    zl_check(zl_gptq_shuffle(q_weight.data<uint32_t>(), q_weight.size(0), q_weight.size(1), st_of(ctx)), "gptq_shuffle");
+}
+void un_shuffle(const Context& ctx, Tensor& input) {
+    BM_ASSERT_EQ(input.ndim(), 2, "input is not 2d");
+    zl_check(zl_awq_un_shuffle(input.data<uint32_t>(), input.size(0), input.size(1), st_of(ctx)), "un_shuffle");
+}
+void increase_zero(const Context& ctx, Tensor& input) {
+    zl_check(zl_gptq_increase_zero(input.data<uint32_t>(), input.numel(), st_of(ctx)), "increase_zero");
+}
+Tensor shuffle_awq(const Context& ctx, Tensor& input, bool use_exllama) {
+    BM_ASSERT_EQ(input.ndim(), 2, "input is not 2d");
+    const size_t k = input.size(0), n = input.size(1) * 8;
+    Tensor out = ctx.tensor({k / 8, n}, DataType::kInt32);
+    zl_check(zl_awq_shuffle(input.data<uint32_t>(), out.data<uint32_t>(), k, n, use_exllama, st_of(ctx)), "shuffle_awq");
+    return out;
+}
+Tensor q4_to_q8(const Context& ctx, const Tensor& input) {
+    std::vector<size_t> shape = input.shape();
+    shape.back() *= 8;
+    Tensor out = ctx.tensor(shape, DataType::kInt8);
+    zl_check(zl_gptq_q4_to_q8(input.data<uint32_t>(), out.data<uint8_t>(), input.numel(), st_of(ctx)), "q4_to_q8");
+    return out;
+}
+
+static bool is_packed(const Tensor& scales) { return scales.dtype() == DataType::kInt32; }
+
+PackedW4 amd_pack_k_major(const Context& ctx, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales,
+                          bool row_interleave) {
+    BM_ASSERT_EQ(q_weight.ndim(), 2, "q_weight is not 2d");
+    BM_ASSERT(scales.dtype() == DataType::kHalf, "scales must be half");
+    const int64_t n = q_weight.size(0), k = q_weight.size(1) * 8, g = k / scales.size(1);
+    BM_ASSERT_EQ(qzeros.numel(), scales.numel(), "qzeros / scales mismatch");
+    zl_w4_layout_t L;
+    zl_check(zl_w4m_layout(n, k, g, &L), "amd_pack_k_major: group_size must be a multiple of 128 and K of 8");
+    BM_ASSERT_EQ(L.np, n, "amd_pack_k_major: N must be a multiple of 16");
+    PackedW4 p;
+    p.q_weight = ctx.tensor({(size_t)n, (size_t)k / 8}, DataType::kInt32, q_weight.name());
+    p.scales = ctx.tensor({(size_t)n, (size_t)L.q}, DataType::kInt32, scales.name());
+    BM_ASSERT_EQ((int64_t)p.q_weight.nbytes(), L.qw_bytes, "layout");
+    BM_ASSERT_EQ((int64_t)p.scales.nbytes(), L.scales_bytes, "layout");
+    zl_check(zl_w4m_pack(q_weight.data<uint32_t>(), qzeros.data<uint8_t>(), u16(scales), n, k, g, row_interleave,
+                         p.q_weight.data<uint32_t>(), p.scales.data<uint32_t>(), st_of(ctx)), "amd_pack_k_major");
+    return p;
+}
+
+// raw k-major operands of a packed weight (dequant_k_major on a packed weight)
+static std::tuple<Tensor, Tensor, Tensor> unpack(const Context& ctx, const Tensor& qw, const Tensor& meta) {
+    const size_t n = qw.size(0), k = qw.size(1) * 8, ng = k / 128;
+    Tensor q = ctx.tensor({n, k / 8}, DataType::kInt32), z = ctx.tensor({n, ng}, DataType::kInt8), s = ctx.tensor({n, ng}, DataType::kHalf);
+    zl_check(zl_w4m_unpack(qw.data<uint32_t>(), meta.data<uint32_t>(), n, k, 128, 0, q.data<uint32_t>(), z.data<uint8_t>(),
+                           s.data<uint16_t>(), st_of(ctx)), "w4m_unpack");
+    return {q, z, s};
+}
+
+Tensor dequant_k_major(const Context& ctx, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales, int out_type) {
+    BM_ASSERT_EQ(out_type, 0, "dequant_k_major: half output only");
+    if (is_packed(scales)) {
+        auto raw = unpack(ctx, q_weight, scales);
+        return dequant_k_major(ctx, std::get<0>(raw), std::get<1>(raw), std::get<2>(raw), 0);
+    }
+    const int64_t n = q_weight.size(0), k = q_weight.size(1) * 8, g = k / scales.size(1);
+    zl_w4_layout_t L;
+    zl_check(zl_w4_layout(n, k, g, &L), "dequant_k_major");
+    Tensor qw = ctx.tensor({(size_t)L.qw_bytes / 4}, DataType::kInt32), sc = ctx.tensor({(size_t)L.scales_bytes / 2}, DataType::kHalf),
+           zr = ctx.tensor({(size_t)L.zeros_bytes / 2}, DataType::kInt16);
+    zl_check(zl_w4_pack(q_weight.data<uint32_t>(), qzeros.data<uint8_t>(), u16(scales), n, k, g, 0, qw.data<uint32_t>(),
+                        sc.data<uint16_t>(), zr.data<uint16_t>(), st_of(ctx)), "dequant_k_major: pack");
+    Tensor out = ctx.tensor({(size_t)n, (size_t)k}, DataType::kHalf);
+    zl_check(zl_w4_dequant(qw.data<uint32_t>(), sc.data<uint16_t>(), zr.data<uint16_t>(), n, k, g, u16m(out), st_of(ctx)),
+             "dequant_k_major");
+    return out;
+}
+
+Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales,
+                         const Tensor& q_perm, const Tensor& rev_perm, const Tensor* bias, bool sym, bool cache_only,
+                         Tensor* output, const Tensor* precomputed_w8) {
+    BM_ASSERT(a.dtype() == DataType::kHalf, "A must be half");                       // q_gemm_k_major.cu:989
+    BM_ASSERT(q_perm.numel() == 0 && rev_perm.numel() == 0, "act-order: permute the input first (permute_input) and pass empty perms");
+    BM_ASSERT(!cache_only && !precomputed_w8, "W4A8 pre-conversion is not part of this path");
+    BM_ASSERT_EQ(q_weight.ndim(), 2, "q_weight is not 2d");
+    const int64_t n = q_weight.size(0), k = q_weight.size(1) * 8;
+    BM_ASSERT_EQ((int64_t)a.size(-1), k, "size K mismatch");
+    const int64_t m = rows_of(a);
+    std::vector<size_t> oshape = a.shape();
+    oshape.back() = n;
+    Tensor out = output ? *output : ctx.tensor(oshape, DataType::kHalf);
+    BM_ASSERT_EQ(out.numel(), (size_t)(m * n), "output shape mismatch");
+    const int64_t ldx = a.ndim() >= 2 ? a.stride(-2) : k;
+    const uint16_t* bptr = bias && bias->numel() ? u16(*bias) : nullptr;
+    const int epi = bptr ? ZL_EPI_BIAS : 0;
+    if (is_packed(scales)) {
+        zl_check(zl_w4a16_gemm_mfma(u16(a), ldx, q_weight.data<uint32_t>(), scales.data<uint32_t>(), bptr, nullptr, u16m(out), m, n,
+                                    k, 128, nullptr, 0.f, epi, st_of(ctx)), "gptq_gemm_k_major");
+        return out;
+    }
+    // raw k-major operands: re-tile into temporaries, then the same launch.  sym: every zero point is 8
+    // (q_gemm_k_major.cu:148-150)
+    BM_ASSERT(scales.dtype() == DataType::kHalf, "scales must be half");
+    const int64_t g = k / scales.size(1);
+    Tensor zeros = qzeros;
+    if (sym) {
+        zeros = ctx.tensor(scales.shape(), DataType::kInt8);
+        BM_HIPRT_ASSERT(hipMemsetAsync(zeros.data(), 8, zeros.nbytes(), ctx.current_cuda_stream()));
+    }
+    zl_w4_layout_t L;
+    if (zl_w4m_layout(n, k, g, &L) == ZL_OK && L.np == n) {
+        PackedW4 p = amd_pack_k_major(ctx, q_weight, zeros, scales);
+        zl_check(zl_w4a16_gemm_mfma(u16(a), ldx, p.q_weight.data<uint32_t>(), p.scales.data<uint32_t>(), bptr, nullptr, u16m(out), m,
+                                    n, k, g, nullptr, 0.f, epi, st_of(ctx)), "gptq_gemm_k_major");
+        return out;
+    }
+    // group sizes / row counts the matrix-core tiles do not take: the warp-reduce arithmetic kernel (bit-identical to
+    // KERNEL_gemm_warp_reduce, q_gemm_k_major.cu:127-237) on its own layout
+    zl_check(zl_w4_layout(n, k, g, &L), "gptq_gemm_k_major");
+    Tensor qw = ctx.tensor({(size_t)L.qw_bytes / 4}, DataType::kInt32), sc = ctx.tensor({(size_t)L.scales_bytes / 2}, DataType::kHalf),
+           zr = ctx.tensor({(size_t)L.zeros_bytes / 2}, DataType::kInt16);
+    zl_check(zl_w4_pack(q_weight.data<uint32_t>(), zeros.data<uint8_t>(), u16(scales), n, k, g, 0, qw.data<uint32_t>(),
+                        sc.data<uint16_t>(), zr.data<uint16_t>(), st_of(ctx)), "gptq_gemm_k_major: pack");
+    zl_check(zl_w4a16_gemm(u16(a), ldx, qw.data<uint32_t>(), sc.data<uint16_t>(), zr.data<uint16_t>(), bptr, nullptr, u16m(out), m, n, k,
+                           g, 0, nullptr, 0.f, epi, st_of(ctx)), "gptq_gemm_k_major");
+    return out;
+}
+
+Tensor gemm_fuse_gate_in(const Context& ctx, const Tensor& a, const Tensor& q_weight1, const Tensor& qzeros1, const Tensor& scales1,
+                         const Tensor& rev_perm1, const Tensor& q_weight2, const Tensor& qzeros2, const Tensor& scales2,
+                         const Tensor& rev_perm2, bool sym) {
+    // silu(a W1^T) * (a W2^T).  Operands handed over separately: two GEMVs + the gated activation (the fused single
+    // launch needs the two matrices interleaved row by row -- amd_pack_k_major(row_interleave) on [W1; W2] at load and
+    // zl_w4a16_gemm_mfma(ZL_EPI_SILU_MUL), which is what the decode step of this repository runs)
+    Tensor g = gptq_gemm_k_major(ctx, a, q_weight1, qzeros1, scales1, Tensor(), rev_perm1, nullptr, sym);
+    Tensor u = gptq_gemm_k_major(ctx, a, q_weight2, qzeros2, scales2, Tensor(), rev_perm2, nullptr, sym);
+    gate_mul_inplace(ctx, g, u, "silu");
+    return g;
+}
+
+}  // namespace gptq
+
+// ---- attention -----------------------------------------------------------------------------------------------------
+AttentionWorkspace get_mqa_workspace(const Context& ctx, const Tensor& batch_q, int max_len_buf, bool) {
+    BM_ASSERT_EQ(batch_q.ndim(), 4, "batch_q is not 4d");
+    const int64_t bytes = zl_decode_attn_workspace_bytes(batch_q.size(0), batch_q.size(1), batch_q.size(2), batch_q.size(3), max_len_buf);
+    AttentionWorkspace ws;
+    ws.cache = ctx.tensor({(size_t)(bytes + 3) / 4}, DataType::kFloat, "mqa_workspace");
+    return ws;
+}
+
+void multi_query_attention_rag_buffer(const Context& ctx, const Tensor& batch_q, const Tensor& buf_lens, const Tensor& key_buf_addrs,
+                                      const Tensor& val_buf_addrs, const Tensor& mask, const float scale, const int max_len_buf,
+                                      Tensor& output, const int m_query, int, const AttentionWorkspace& ws,
+                                      const Tensor& scale_key_addrs, const Tensor& scale_val_addrs, DataType) {
+    BM_ASSERT_EQ(batch_q.ndim(), 4, "batch_q is not 4d");
+    const int64_t b = batch_q.size(0), len_q = batch_q.size(1), h = batch_q.size(2), d = batch_q.size(3);
+    BM_ASSERT(m_query > 0 && h % m_query == 0, "num_heads must be a multiple of m_query");
+    BM_ASSERT_EQ((int64_t)buf_lens.numel(), b, "buf_lens size mismatch");
+    BM_ASSERT_EQ((int64_t)key_buf_addrs.numel(), b, "key_buf_addrs size mismatch");
+    BM_ASSERT_EQ(output.numel(), batch_q.numel(), "output shape mismatch");
+    AttentionWorkspace local = ws.cache.numel() ? ws : get_mqa_workspace(ctx, batch_q, max_len_buf, scale_key_addrs.numel() > 0);
+    const int8_t* mptr = mask.numel() ? mask.data<const int8_t>() : nullptr;
+    BM_ASSERT(mptr, "mask is required (int8, concatenated per task)");
+    const int hkv = (int)(h / m_query);
+    if (scale_key_addrs.numel()) {
+        zl_check(zl_decode_attn_quant(u16(batch_q), buf_lens.data<int32_t>(), key_buf_addrs.data<const uint8_t* const>(),
+                                      val_buf_addrs.data<const uint8_t* const>(), scale_key_addrs.data<const float* const>(),
+                                      scale_val_addrs.data<const float* const>(), mptr, nullptr, u16m(output), local.cache.data(), b,
+                                      len_q, h, hkv, d, scale, max_len_buf, ctx.is_BSHD(), zdt(batch_q.dtype()), st_of(ctx)),
+                 "multi_query_attention_rag_buffer (int8 kv)");
+        return;
+    }
+    zl_check(zl_decode_attn(u16(batch_q), buf_lens.data<int32_t>(), key_buf_addrs.data<const uint16_t* const>(),
+                            val_buf_addrs.data<const uint16_t* const>(), mptr, nullptr, u16m(output), local.cache.data(), b, len_q, h,
+                            hkv, d, scale, max_len_buf, ctx.is_BSHD(), zdt(batch_q.dtype()), st_of(ctx)),
+             "multi_query_attention_rag_buffer");
+}
+
+// ---- rotary / scatter / element-wise -------------------------------------------------------------------------------
+void rotary_embedding_qk(const Context& ctx, const Tensor& pos, const Tensor& in, Tensor& out_q, Tensor& out_k, Tensor& out_v,
+                         size_t num_heads, size_t num_kv_heads, size_t dim_head, float rope_theta, DataType dtype) {
+    const size_t s = pos.numel();
+    BM_ASSERT_EQ(in.numel(), s * (num_heads + 2 * num_kv_heads) * dim_head, "in shape mismatch");
+    zl_check(zl_rotary_embedding_qk(pos.data<int32_t>(), u16(in), u16m(out_q), u16m(out_k), u16m(out_v), s, num_heads, num_kv_heads,
+                                    dim_head, rope_theta, zdt(dtype), st_of(ctx)), "rotary_embedding_qk");
+}
+void rope_qk_cache(const Context& ctx, const Tensor& cos, const Tensor& sin, const Tensor& in, Tensor& out_q, Tensor& out_k,
+                   Tensor& out_v, size_t num_heads, size_t num_kv_heads, size_t dim_head, DataType dtype, bool neox_style) {
+    BM_ASSERT(cos.dtype() == DataType::kFloat && sin.dtype() == DataType::kFloat, "cos / sin must be float");
+    const size_t s = cos.numel() / dim_head;
+    BM_ASSERT_EQ(in.numel(), s * (num_heads + 2 * num_kv_heads) * dim_head, "in shape mismatch");
+    zl_check(zl_rope_qk_cache(cos.data<float>(), sin.data<float>(), u16(in), u16m(out_q), u16m(out_k), u16m(out_v), s, num_heads,
+                              num_kv_heads, dim_head, neox_style, zdt(dtype), st_of(ctx)), "rope_qk_cache");
+}
+void copy_to_rag_buffer2(const Context& ctx, const Tensor& placement, const Tensor& buf_lens, const Tensor& k_src, const Tensor& v_src,
+                         Tensor* buf_k_addr, Tensor* buf_v_addr, bool is_scale) {
+    BM_ASSERT(!is_scale, "scale rows travel with zl_quant_copy_to_rag_buffer on this path");
+    BM_ASSERT_EQ(k_src.ndim(), 4, "k_src is not (batch, len_q, num_kv_heads, dim_head)");
+    zl_check(zl_copy_to_rag_buffer2(placement.data<int32_t>(), buf_lens.data<int32_t>(), u16(k_src), u16(v_src),
+                                    buf_k_addr->data<uint16_t* const>(), buf_v_addr->data<uint16_t* const>(), k_src.size(0), k_src.size(1),
+                                    k_src.size(2), k_src.size(3), ctx.is_BSHD(), st_of(ctx)), "copy_to_rag_buffer2");
+}
+void element_add_scale_out(const Context& ctx, const Tensor& a, const Tensor& b, Tensor& c, float scale, bool scale_residual) {
+    BM_ASSERT_EQ(a.numel(), b.numel(), "shape mismatch");
+    zl_check(zl_element_add_scale(u16(a), u16(b), u16m(c), a.numel(), scale, scale_residual, zdt(a.dtype()), st_of(ctx)),
+             "element_add_scale");
+}
+Tensor element_add_scale(const Context& ctx, const Tensor& a, const Tensor& b, float scale, bool scale_residual) {
+    Tensor c = ctx.tensor(a.shape(), a.dtype());
+    element_add_scale_out(ctx, a, b, c, scale, scale_residual);
+    return c;
+}
+void gate_mul_inplace(const Context& ctx, Tensor& inp, const Tensor& in2, const std::string& gate_type) {
+    BM_ASSERT_EQ(inp.numel(), in2.numel(), "shape mismatch");
+    BM_ASSERT(gate_type == "silu" || gate_type == "gelu", "unsupported gate type " + gate_type);
+    zl_check(zl_gate_mul(u16(inp), u16(in2), u16m(inp), inp.numel(), gate_type == "gelu", zdt(inp.dtype()), st_of(ctx)), "gate_mul");
+}
+
+// ---- RMSNorm -------------------------------------------------------------------------------------------------------
+LayerNorm::LayerNorm(const Context&, int dim_model, bool, float eps, float scale, DataType dtype, int)
+    : dim_model_(dim_model), eps_(eps), scale_(scale), dtype_(dtype) {}
+void LayerNorm::load_state_dict(const Context& ctx, const std::map<std::string, const Tensor>& state_dict, const std::string& prefix,
+                                bool allow_missing) {
+    auto it = state_dict.find(prefix + ".weight");
+    if (it == state_dict.end()) {
+        BM_ASSERT(allow_missing, "missing parameter " + prefix + ".weight");
+        return;
+    }
+    BM_ASSERT_EQ((int)it->second.numel(), dim_model_, "layernorm weight size mismatch");
+    weight_ = ctx.cuda(it->second);
+}
+Tensor LayerNorm::forward(const Context& ctx, const Tensor& x) {
+    BM_ASSERT_EQ((int)x.size(-1), dim_model_, "dim mismatch");
+    Tensor out = ctx.tensor(x.shape(), x.dtype());
+    zl_check(zl_rmsnorm(u16(x), u16(weight_), u16m(out), rows_of(x), dim_model_, eps_, scale_, nullptr, nullptr, zdt(x.dtype()),
+                        st_of(ctx)), "LayerNorm::forward");
+    return out;
+}
+Tensor LayerNorm::fuse_add(const Context& ctx, const Tensor& a, const Tensor& b, Tensor& c) {
+    BM_ASSERT_EQ(a.numel(), b.numel(), "shape mismatch");
+    Tensor out = ctx.tensor(a.shape(), a.dtype());
+    zl_check(zl_rmsnorm(u16(a), u16(weight_), u16m(out), rows_of(a), dim_model_, eps_, scale_, u16(b), u16m(c), zdt(a.dtype()),
+                        st_of(ctx)), "LayerNorm::fuse_add");
+    return out;
+}
+void LayerNorm::inplace(const Context& ctx, Tensor& x) {
+    zl_check(zl_rmsnorm(u16(x), u16(weight_), u16m(x), rows_of(x), dim_model_, eps_, scale_, nullptr, nullptr, zdt(x.dtype()),
+                        st_of(ctx)), "LayerNorm::inplace");
+}
+
+}  // namespace nn
+
+// ---- int8 ----------------------------------------------------------------------------------------------------------
+namespace int8_op {
+
+static std::vector<size_t> scale_shape(const Tensor& x) { return std::vector<size_t>(x.shape().begin(), x.shape().end() - 1); }
+
+void quant_calc_scale(const Context& ctx, const Tensor& input, Tensor* output, Tensor* output_scale, int q_max, int q_zero) {
+    BM_ASSERT_EQ(q_max, 127, "q_max");
+    const int64_t k = input.size(-1), m = input.numel() / k;
+    if (q_zero == 0)
+        zl_check(zl_quant_calc_scale(input.data<uint16_t>(), output->data<int8_t>(), output_scale->data<float>(), m, k, zdt(input.dtype()),
+                                     st_of(ctx)), "quant_calc_scale");
+    else
+        zl_check(zl_quant_calc_scale_zp(input.data<uint16_t>(), output->data<uint8_t>(), output_scale->data<float>(), m, k, q_zero,
+                                        zdt(input.dtype()), st_of(ctx)), "quant_calc_scale");
+}
+Tensor quant_calc_scale(const Context& ctx, const Tensor& input, int q_max, int q_zero) {
+    Tensor out = ctx.tensor(input.shape(), DataType::kInt8);
+    Tensor sc = ctx.tensor(scale_shape(input), DataType::kFloat);
+    quant_calc_scale(ctx, input, &out, &sc, q_max, q_zero);
+    out.set_quant_scale(sc);
+    return out;
+}
+void set_quant_scale(Tensor& tensor, const Tensor& scale) { tensor.set_quant_scale(scale); }
+
+Tensor quant_scale_back(const Context& ctx, const Tensor& input, const Tensor* scale_x, const Tensor* scale_y, DataType out_type,
+                        Tensor* output) {
+    BM_ASSERT(input.dtype() == DataType::kInt32, "input must be int32");
+    const DataType ot = out_type == DataType::kDouble ? scale_y->dtype() : out_type;   // kDouble = "the weight scale's type"
+    const int64_t n = input.size(-1), m = input.numel() / n;
+    Tensor out = output ? *output : ctx.tensor(input.shape(), ot);
+    zl_check(zl_quant_scale_back(input.data<int32_t>(), scale_x->data<float>(), scale_y->data<uint16_t>(), out.data<uint16_t>(), m, n,
+                                 zdt(ot), st_of(ctx)), "quant_scale_back");
+    return out;
+}
+void quant_scale_back3(const Context& ctx, const Tensor& input, const Tensor* scale_x, const Tensor* scale_y, int dim_q, int dim_kv,
+                       Tensor* q, Tensor* k, Tensor* v) {
+    const int64_t n = input.size(-1), m = input.numel() / n;
+    BM_ASSERT_EQ(n, (int64_t)dim_q + 2 * dim_kv, "dim mismatch");
+    zl_check(zl_quant_scale_back3(input.data<int32_t>(), scale_x->data<float>(), scale_y->data<uint16_t>(), q->data<uint16_t>(),
+                                  k->data<uint16_t>(), v->data<uint16_t>(), m, n, dim_q, dim_kv, zdt(scale_y->dtype()), st_of(ctx)),
+             "quant_scale_back3");
+}
+void layernorm_quant(const Context& ctx, const Tensor& input, const Tensor& weight, Tensor* output, Tensor* output_int8,
+                     Tensor* scale_output, float eps, float scale) {
+    const int64_t dim = input.size(-1), rows = input.numel() / dim;
+    zl_check(zl_rmsnorm_quant(input.data<uint16_t>(), weight.data<uint16_t>(), output ? output->data<uint16_t>() : nullptr,
+                              output_int8->data<int8_t>(), scale_output->data<float>(), rows, dim, eps, scale, zdt(input.dtype()),
+                              st_of(ctx)), "layernorm_quant");
+}
+Tensor quant_back_element_add_scale(const Context& ctx, const Tensor& input, const Tensor* scale_x, const Tensor* scale_y,
+                                    const Tensor& input_b, float scale) {
+    const int64_t n = input.size(-1), m = input.numel() / n;
+    Tensor out = ctx.tensor(input.shape(), input_b.dtype());
+    zl_check(zl_quant_back_element_add_scale(input.data<int32_t>(), scale_x->data<float>(), scale_y->data<uint16_t>(),
+                                             input_b.data<uint16_t>(), scale, out.data<uint16_t>(), m, n, zdt(input_b.dtype()), st_of(ctx)),
+             "quant_back_element_add_scale");
+    return out;
+}
+Tensor quant_back_transpose(const Context& ctx, const Tensor& input, const Tensor* scale_x, const Tensor* scale_y) {
+    BM_ASSERT_EQ(input.ndim(), 4, "input is not (batch, len_q, num_heads, dim_head)");
+    const size_t b = input.size(0), lq = input.size(1), h = input.size(2), d = input.size(3);
+    Tensor out = ctx.tensor({b, h, lq, d}, scale_y->dtype());
+    zl_check(zl_quant_back_transpose(input.data<int32_t>(), scale_x->data<float>(), scale_y->data<uint16_t>(), out.data<uint16_t>(), b, lq,
+                                     h, d, zdt(scale_y->dtype()), st_of(ctx)), "quant_back_transpose");
+    return out;
+}
+Tensor quant_back_act_mul(const Context& ctx, const Tensor& A, const Tensor* a_scale_x, const Tensor* a_scale_y, const Tensor& B,
+                          const Tensor* b_scale_x, const Tensor* b_scale_y, const std::string& act_type) {
+    BM_ASSERT(act_type == "silu" || act_type == "gelu", "unsupported activation " + act_type);
+    const int64_t n = A.size(-1), m = A.numel() / n;
+    Tensor out = ctx.tensor(A.shape(), a_scale_y->dtype());
+    zl_check(zl_quant_back_act_mul(A.data<int32_t>(), a_scale_x->data<float>(), a_scale_y->data<uint16_t>(), B.data<int32_t>(),
+                                   b_scale_x->data<float>(), b_scale_y->data<uint16_t>(), out.data<uint16_t>(), m, n, act_type == "gelu",
+                                   zdt(a_scale_y->dtype()), st_of(ctx)), "quant_back_act_mul");
+    return out;
+}
+void quant_back_copy_to_buffer(const Context& ctx, int num_heads, int len_kv, int len_buf, int dim_head, const Tensor* placement,
+                               const Tensor& src, const Tensor* scale_x, const Tensor* scale_y, const Tensor& dst) {
+    const bool batched = src.ndim() == 4;            // (batch, len_kv, num_heads, dim_head) -> (batch, num_heads, len_buf, dim_head)
+    const int64_t batch = batched ? src.size(0) : 1;
+    zl_check(zl_quant_back_copy_to_buffer(src.data<int32_t>(), scale_x->data<float>(), scale_y->data<uint16_t>(),
+                                          placement && placement->numel() ? placement->data<int32_t>() : nullptr, dst.data<uint16_t>(),
+                                          batch, len_kv, num_heads, dim_head, len_buf, batched ? src.stride(0) : 0,
+                                          batched ? dst.stride(0) : 0, batched && placement && placement->numel() ? len_kv : 0,
+                                          zdt(dst.dtype()), st_of(ctx)), "quant_back_copy_to_buffer");
+}
+Tensor int8_gemm_nt(const Context& ctx, const Tensor& a, const Tensor& b) {
+    BM_ASSERT(a.dtype() == DataType::kInt8 && b.dtype() == DataType::kInt8, "int8 operands expected");
+    const int64_t k = a.size(-1), m = a.numel() / k, n = b.size(0);
+    BM_ASSERT_EQ((int64_t)b.size(1), k, "size K mismatch");
+    std::vector<size_t> shape = a.shape();
+    shape.back() = n;
+    Tensor c = ctx.tensor(shape, DataType::kInt32);
+    zl_check(zl_int8_gemm_nt(a.data<int8_t>(), b.data<int8_t>(), c.data<int32_t>(), m, n, k, st_of(ctx)), "int8_gemm_nt");
+    return c;
+}
+
+}  // namespace int8_op

@@ -1,0 +1,155 @@
+// nn_amd.h -- the free functions / layers ZhiLight's hot-path host code calls, with the reference's signatures, on top
+// of the MI355X C ABI (include/zhilight_amd.h).  A maintainer swaps the CUDA translation units behind these names for
+// nn_amd.cpp; the callers (linear.cpp, attention.cpp, feedforward.cpp, block.cpp, layernorm users) stay as they are.
+// Every wrapper: checks shapes / dtypes with BM_ASSERT (-> BMEngineException, as the reference), allocates its outputs
+// with ctx.tensor(...), launches on ctx.current_stream(), turns a non-zero C-ABI status into BMEngineException.
+//
+// reference header                                   | names provided here
+//   src/nn/quant/gptq/gptq.h:10-184                  | nn::gptq::{gptq_gemm_k_major, gemm_fuse_gate_in, dequant_k_major, gptq_shuffle,
+//                                                    |            increase_zero, q4_to_q8, un_shuffle, shuffle_awq} + amd_pack_k_major
+//   src/nn/quant/int8/quant_kernel.h:15-128          | int8_op::{quant_calc_scale x2, set_quant_scale, quant_scale_back, quant_scale_back3,
+//                                                    |           layernorm_quant, quant_back_element_add_scale, quant_back_transpose,
+//                                                    |           quant_back_act_mul, quant_back_copy_to_buffer} + int8_gemm_nt
+//   src/nn/attention/attention_kernel.h:55-80        | nn::{AttentionWorkspace, get_mqa_workspace, multi_query_attention_rag_buffer}
+//   src/nn/position/rotary_embedding.h:34-61         | nn::{rotary_embedding_qk, rope_qk_cache}
+//   src/kvcache/ragged_buffer_kernel.h:27-36         | nn::copy_to_rag_buffer2
+//   src/nn/block/block_kernel.h                      | nn::{element_add_scale, element_add_scale_out}
+//   src/nn/linear/activation_kernel.h:8-16           | nn::gate_mul_inplace
+//   src/nn/layernorm/layernorm.h:7-37                | nn::LayerNorm {forward, fuse_add, inplace}
+#pragma once
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "bm_hip.h"
+
+namespace nn {
+using namespace bmengine;
+
+namespace gptq {
+
+// ---- load-time transforms (Int4GPTQ::load_state_dict, linear.cpp:1162-1244) -----------------------------------------
+void gptq_shuffle(const core::Context& ctx, core::Tensor& q_weight, core::Tensor q_perm);   // (K/8, N) int32 in place; q_perm must be empty
+void un_shuffle(const core::Context& ctx, core::Tensor& input);                             // AWQ nibble order -> natural, in place
+void increase_zero(const core::Context& ctx, core::Tensor& input);                          // every nibble + 1 (15 wraps to 0), in place
+core::Tensor shuffle_awq(const core::Context& ctx, core::Tensor& input, bool use_exllama);  // (K, N/8) -> (K/8, N)
+core::Tensor q4_to_q8(const core::Context& ctx, const core::Tensor& input);                 // int32 words -> one byte per nibble
+
+// ---- the k-major GEMM family ---------------------------------------------------------------------------------------
+// q_weight (N, K/8) int32 exllama-shuffled words, qzeros (N, K/G) int8 (already +1), scales (N, K/G) half: the operands
+// Int4GPTQ keeps after preprocess_weight + transpose_weight.  The MI355X kernels stream a re-tiled copy of them; it is
+// built by amd_pack_k_major ONCE per weight (the one line a maintainer adds at the end of Int4GPTQ::load_state_dict),
+// which returns the packed tensors behind the same three names: q_weight' (N, K/8) int32 = ZLW4M nibble tiles, qzeros'
+// EMPTY, scales' (N, K/128) int32 = ZLW4M meta words.  gptq_gemm_k_major recognises the packed form by scales.dtype() ==
+// kInt32; handed the raw k-major operands it packs them into temporaries on every call (correct, slow: the path a
+// completely unmodified caller takes).  q_perm / rev_perm (act-order) must be empty here: see nn_amd.cpp.
+struct PackedW4 {
+    core::Tensor q_weight, qzeros, scales;
+};
+PackedW4 amd_pack_k_major(const core::Context& ctx, const core::Tensor& q_weight, const core::Tensor& qzeros,
+                          const core::Tensor& scales, bool row_interleave = false);
+
+core::Tensor dequant_k_major(const core::Context& ctx, const core::Tensor& q_weight, const core::Tensor& qzeros,
+                             const core::Tensor& scales, int out_type = 0);
+
+core::Tensor gptq_gemm_k_major(const core::Context& ctx,
+                               const core::Tensor& a,          // (M, K)
+                               const core::Tensor& q_weight,   // (N, K / 8)
+                               const core::Tensor& qzeros,     // (N, K / group_size)
+                               const core::Tensor& scales,     // (N, K / group_size)
+                               const core::Tensor& q_perm,     // (K)
+                               const core::Tensor& rev_perm,   // (K)
+                               const core::Tensor* bias, bool sym, bool cache_only = false, core::Tensor* output = nullptr,
+                               const core::Tensor* precomputed_w8 = nullptr);
+
+core::Tensor gemm_fuse_gate_in(const core::Context& ctx, const core::Tensor& a, const core::Tensor& q_weight1,
+                               const core::Tensor& qzeros1, const core::Tensor& scales1, const core::Tensor& rev_perm1,
+                               const core::Tensor& q_weight2, const core::Tensor& qzeros2, const core::Tensor& scales2,
+                               const core::Tensor& rev_perm2, bool sym);
+}  // namespace gptq
+
+// ---- attention -----------------------------------------------------------------------------------------------------
+struct AttentionWorkspace {
+    core::Tensor cache;
+    core::Tensor local_max;
+    core::Tensor local_sum_exp;
+};
+AttentionWorkspace get_mqa_workspace(const core::Context& ctx, const core::Tensor& batch_q, int max_len_buf, bool is_quantized);
+
+void multi_query_attention_rag_buffer(const core::Context& ctx,
+                                      const core::Tensor& batch_q,        // (batch, len_q, num_kv_heads * m_query, dim_head)
+                                      const core::Tensor& buf_lens,       // (batch)
+                                      const core::Tensor& key_buf_addrs,  // (batch) => (num_kv_heads, len_buf, dim_head)
+                                      const core::Tensor& val_buf_addrs,
+                                      const core::Tensor& mask,           // (batch) => (len_q, len_buf)
+                                      const float scale, const int max_len_buf,
+                                      core::Tensor& output,               // like batch_q
+                                      const int m_query = 8, int algo_id = -1, const AttentionWorkspace& ws = {},
+                                      const core::Tensor& scale_key_addrs = core::Tensor(),
+                                      const core::Tensor& scale_val_addrs = core::Tensor(),
+                                      core::DataType dequant_dtype = core::DataType::kHalf);
+
+// ---- rotary, KV scatter, element-wise ------------------------------------------------------------------------------
+void rotary_embedding_qk(const core::Context& ctx, const core::Tensor& pos, const core::Tensor& in, core::Tensor& out_q,
+                         core::Tensor& out_k, core::Tensor& out_v, size_t num_heads, size_t num_kv_heads, size_t dim_head,
+                         float rope_theta, core::DataType dtype);
+void rope_qk_cache(const core::Context& ctx, const core::Tensor& cos, const core::Tensor& sin, const core::Tensor& in,
+                   core::Tensor& out_q, core::Tensor& out_k, core::Tensor& out_v, size_t num_heads, size_t num_kv_heads,
+                   size_t dim_head, core::DataType dtype, bool neox_style);
+void copy_to_rag_buffer2(const core::Context& ctx, const core::Tensor& placement, const core::Tensor& buf_lens,
+                         const core::Tensor& k_src, const core::Tensor& v_src, core::Tensor* buf_k_addr, core::Tensor* buf_v_addr,
+                         bool is_scale = false);
+core::Tensor element_add_scale(const core::Context& ctx, const core::Tensor& a, const core::Tensor& b, float scale,
+                               bool scale_residual = true);
+void element_add_scale_out(const core::Context& ctx, const core::Tensor& a, const core::Tensor& b, core::Tensor& c, float scale,
+                           bool scale_residual = true);
+void gate_mul_inplace(const core::Context& ctx, core::Tensor& inp, const core::Tensor& in2, const std::string& gate_type);
+
+// ---- RMSNorm layer -------------------------------------------------------------------------------------------------
+class LayerNorm {
+public:
+    LayerNorm(const core::Context& ctx, int dim_model, bool quant = false, float eps = 1e-6, float scale = 1.0,
+              core::DataType dtype = core::DataType::kHalf, int num_head = 1);
+    core::Tensor forward(const core::Context& ctx, const core::Tensor& x);
+    core::Tensor fuse_add(const core::Context& ctx, const core::Tensor& a, const core::Tensor& b, core::Tensor& c);   // c = a + b
+    void inplace(const core::Context& ctx, core::Tensor& x);
+    void load_state_dict(const core::Context& ctx, const std::map<std::string, const core::Tensor>& state_dict,
+                         const std::string& prefix, bool allow_missing = false);
+    const core::Tensor& weight() const { return weight_; }
+
+private:
+    int dim_model_;
+    float eps_, scale_;
+    core::DataType dtype_;
+    core::Tensor weight_;
+};
+}  // namespace nn
+
+namespace int8_op {
+using namespace bmengine;
+
+void quant_calc_scale(const core::Context& ctx, const core::Tensor& input, core::Tensor* output, core::Tensor* output_scale,
+                      int q_max = 127, int q_zero = 0);
+core::Tensor quant_calc_scale(const core::Context& ctx, const core::Tensor& input, int q_max = 127, int q_zero = 0);
+void set_quant_scale(core::Tensor& tensor, const core::Tensor& scale);
+core::Tensor quant_scale_back(const core::Context& ctx, const core::Tensor& input, const core::Tensor* scale_x,
+                              const core::Tensor* scale_y, core::DataType out_type = core::DataType::kDouble,
+                              core::Tensor* output = nullptr);
+void quant_scale_back3(const core::Context& ctx, const core::Tensor& input, const core::Tensor* scale_x, const core::Tensor* scale_y,
+                       int dim_q, int dim_kv, core::Tensor* q, core::Tensor* k, core::Tensor* v);
+void layernorm_quant(const core::Context& ctx, const core::Tensor& input, const core::Tensor& weight, core::Tensor* output,
+                     core::Tensor* output_int8, core::Tensor* scale_output, float eps, float scale);
+core::Tensor quant_back_element_add_scale(const core::Context& ctx, const core::Tensor& input, const core::Tensor* scale_x,
+                                          const core::Tensor* scale_y, const core::Tensor& input_b, float scale);
+core::Tensor quant_back_transpose(const core::Context& ctx, const core::Tensor& input, const core::Tensor* scale_x,
+                                  const core::Tensor* scale_y);
+core::Tensor quant_back_act_mul(const core::Context& ctx, const core::Tensor& A, const core::Tensor* a_scale_x,
+                                const core::Tensor* a_scale_y, const core::Tensor& B, const core::Tensor* b_scale_x,
+                                const core::Tensor* b_scale_y, const std::string& act_type);
+void quant_back_copy_to_buffer(const core::Context& ctx, int num_heads, int len_kv, int len_buf, int dim_head,
+                               const core::Tensor* placement, const core::Tensor& src, const core::Tensor* scale_x,
+                               const core::Tensor* scale_y, const core::Tensor& dst);
+// the IMMA product of Int8Linear::forward (linear.cpp:600-616: functions::Gemm int8 x int8^T -> int32)
+core::Tensor int8_gemm_nt(const core::Context& ctx, const core::Tensor& a, const core::Tensor& b);
+}  // namespace int8_op

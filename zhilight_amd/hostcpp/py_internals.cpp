@@ -1,0 +1,206 @@
+// py_internals.cpp -- pybind11 test module over the C++ operator layer (the role of the reference's
+// `zhilight.internals_`, tests/py_export_internal/*.cpp): numpy in, numpy out, every call goes
+//     Python -> this file -> nn:: / int8_op:: wrapper (nn_amd.cpp, reference signatures) -> C ABI -> HIP kernel
+// so the GPU tests can check the C++ boundary itself against the CPU oracle.  No torch types anywhere.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "nn_amd.h"
+
+namespace py = pybind11;
+using namespace bmengine;
+using core::DataType;
+using core::Tensor;
+
+namespace {
+
+DataType dt_of(const py::array& a) {
+    const char k = a.dtype().kind();
+    const auto sz = a.itemsize();
+    if (k == 'f' && sz == 2) return DataType::kHalf;
+    if (k == 'f' && sz == 4) return DataType::kFloat;
+    if (k == 'f' && sz == 8) return DataType::kDouble;
+    if ((k == 'i' || k == 'u') && sz == 1) return DataType::kInt8;
+    if ((k == 'i' || k == 'u') && sz == 2) return DataType::kInt16;     // bf16 travels as int16 views (zhilight/llama.py:190-199)
+    if ((k == 'i' || k == 'u') && sz == 4) return DataType::kInt32;
+    if ((k == 'i' || k == 'u') && sz == 8) return DataType::kDouble;    // addresses
+    throw std::runtime_error("unsupported numpy dtype");
+}
+
+struct PyCtx {
+    std::unique_ptr<core::Context> ctx;
+    explicit PyCtx(int device) : ctx(new core::Context(device)) {}
+
+    Tensor up(const py::array& a, int as_dtype = -1) const {
+        py::array c = py::array::ensure(a, py::array::c_style);
+        std::vector<size_t> shape(c.shape(), c.shape() + c.ndim());
+        if (c.size() == 0) return Tensor();
+        Tensor t = ctx->tensor(shape, as_dtype >= 0 ? (DataType)as_dtype : dt_of(c));
+        t.from_buffer(c.data(), false, ctx->current_cuda_stream());
+        return t;
+    }
+    Tensor up_opt(const py::object& o, int as_dtype = -1) const { return o.is_none() ? Tensor() : up(py::cast<py::array>(o), as_dtype); }
+    py::array down(const Tensor& t, const char* np_dtype) const {
+        std::vector<py::ssize_t> shape(t.shape().begin(), t.shape().end());
+        py::array out(py::dtype(np_dtype), shape);
+        if (t.numel()) t.to_buffer(out.mutable_data(), ctx->current_cuda_stream());
+        return out;
+    }
+    // device array of raw pointers to per-task buffers (RagBufferContext::buf_k_addr)
+    Tensor addr_table(const std::vector<Tensor>& bufs) const {
+        std::vector<void*> p;
+        for (auto& b : bufs) p.push_back(b.data());
+        Tensor t = ctx->tensor({p.size()}, DataType::kDouble);
+        t.from_buffer(p.data(), false, ctx->current_cuda_stream());
+        return t;
+    }
+    std::vector<Tensor> up_list(const py::list& l) const {
+        std::vector<Tensor> v;
+        for (auto h : l) v.push_back(up(py::cast<py::array>(h)));
+        return v;
+    }
+};
+
+const int kBF = (int)DataType::kBFloat16;
+const char* fdt(bool bf16) { return bf16 ? "uint16" : "float16"; }
+
+}  // namespace
+
+PYBIND11_MODULE(zl_internals, m) {
+    m.doc() = "C++ operator layer of zhilight_amd (bmengine-on-HIP shim + nn:: wrappers) exposed for tests";
+    py::register_exception<BMEngineException>(m, "BMEngineException", PyExc_RuntimeError);
+
+    py::class_<PyCtx>(m, "Context")
+        .def(py::init<int>(), py::arg("device") = 0)
+        .def("used_memory", [](PyCtx& c) { return c.ctx->used_memory(); })
+        .def("peak_memory", [](PyCtx& c) { return c.ctx->peak_memory(); })
+        .def("set_bshd", [](PyCtx& c, bool b) { c.ctx->set_BSHD(b); })
+        // ---- tensor surface (views, slices) exercised directly
+        .def("tensor_roundtrip", [](PyCtx& c, py::array a, size_t from, size_t to) {
+            Tensor t = c.up(a);
+            Tensor s = t.slice_dim0(from, to);
+            Tensor v = s.view({s.numel()});
+            BM_ASSERT(v.is_continuous(), "slice of dim 0 stays continuous");
+            return c.down(v, py::str(a.dtype()).cast<std::string>().c_str());
+        })
+        // ---- GPTQ
+        .def("gptq_gemm_k_major", [](PyCtx& c, py::array x, py::array qw, py::array qz, py::array sc, py::object bias, bool sym,
+                                      bool prepack) {
+            Tensor tx = c.up(x), tq = c.up(qw), tz = c.up(qz), ts = c.up(sc), tb = c.up_opt(bias);
+            if (prepack) {   // what Int4GPTQ::load_state_dict does once per weight
+                auto p = nn::gptq::amd_pack_k_major(*c.ctx, tq, tz, ts);
+                tq = p.q_weight; tz = p.qzeros; ts = p.scales;
+            }
+            Tensor y = nn::gptq::gptq_gemm_k_major(*c.ctx, tx, tq, tz, ts, Tensor(), Tensor(), tb.numel() ? &tb : nullptr, sym);
+            return c.down(y, "float16");
+        }, py::arg("x"), py::arg("qweight"), py::arg("qzeros"), py::arg("scales"), py::arg("bias") = py::none(), py::arg("sym") = false,
+           py::arg("prepack") = true)
+        .def("gptq_dequant_k_major", [](PyCtx& c, py::array qw, py::array qz, py::array sc, bool prepack) {
+            Tensor tq = c.up(qw), tz = c.up(qz), ts = c.up(sc);
+            if (prepack) {
+                auto p = nn::gptq::amd_pack_k_major(*c.ctx, tq, tz, ts);
+                tq = p.q_weight; tz = p.qzeros; ts = p.scales;
+            }
+            return c.down(nn::gptq::dequant_k_major(*c.ctx, tq, tz, ts), "float16");
+        }, py::arg("qweight"), py::arg("qzeros"), py::arg("scales"), py::arg("prepack") = false)
+        .def("gemm_fuse_gate_in", [](PyCtx& c, py::array x, py::array q1, py::array z1, py::array s1, py::array q2, py::array z2,
+                                      py::array s2) {
+            Tensor y = nn::gptq::gemm_fuse_gate_in(*c.ctx, c.up(x), c.up(q1), c.up(z1), c.up(s1), Tensor(), c.up(q2), c.up(z2), c.up(s2),
+                                                   Tensor(), false);
+            return c.down(y, "float16");
+        })
+        .def("gptq_load_transforms", [](PyCtx& c, py::array qweight_hf, py::array qzeros_hf) {
+            // Int4GPTQ::preprocess_weight (linear.cpp:1139-1160): shuffle the words, +1 the zeros, one byte per zero
+            Tensor q = c.up(qweight_hf), z = c.up(qzeros_hf);
+            nn::gptq::gptq_shuffle(*c.ctx, q, Tensor());
+            nn::gptq::increase_zero(*c.ctx, z);
+            Tensor z8 = nn::gptq::q4_to_q8(*c.ctx, z);
+            return py::make_tuple(c.down(q, "uint32"), c.down(z8, "uint8"));
+        })
+        // ---- attention / rope / scatter
+        .def("multi_query_attention_rag_buffer", [](PyCtx& c, py::array q, py::array buf_lens, py::list kbufs, py::list vbufs, py::array mask,
+                                                     float scale, int max_len_buf, int m_query, bool bf16) {
+            Tensor tq = c.up(q, bf16 ? kBF : -1), tl = c.up(buf_lens), tm = c.up(mask);
+            auto ks = c.up_list(kbufs), vs = c.up_list(vbufs);
+            Tensor ka = c.addr_table(ks), va = c.addr_table(vs);
+            Tensor out = c.ctx->tensor(tq.shape(), tq.dtype());
+            nn::multi_query_attention_rag_buffer(*c.ctx, tq, tl, ka, va, tm, scale, max_len_buf, out, m_query);
+            return c.down(out, fdt(bf16));
+        }, py::arg("q"), py::arg("buf_lens"), py::arg("k_bufs"), py::arg("v_bufs"), py::arg("mask"), py::arg("scale"), py::arg("max_len_buf"),
+           py::arg("m_query"), py::arg("bf16") = false)
+        .def("rope_qk_cache", [](PyCtx& c, py::array cosv, py::array sinv, py::array in, size_t h, size_t hkv, size_t d, bool neox) {
+            Tensor ti = c.up(in);
+            const size_t s = ti.size(0);
+            Tensor q = c.ctx->tensor({s, h * d}, DataType::kHalf), k = c.ctx->tensor({s, hkv * d}, DataType::kHalf),
+                   v = c.ctx->tensor({s, hkv * d}, DataType::kHalf);
+            nn::rope_qk_cache(*c.ctx, c.up(cosv), c.up(sinv), ti, q, k, v, h, hkv, d, DataType::kHalf, neox);
+            return py::make_tuple(c.down(q, "float16"), c.down(k, "float16"), c.down(v, "float16"));
+        })
+        .def("copy_to_rag_buffer2", [](PyCtx& c, py::array placement, py::array buf_lens, py::array k_src, py::array v_src, py::list kbufs,
+                                        py::list vbufs) {
+            auto ks = c.up_list(kbufs), vs = c.up_list(vbufs);
+            Tensor ka = c.addr_table(ks), va = c.addr_table(vs);
+            nn::copy_to_rag_buffer2(*c.ctx, c.up(placement), c.up(buf_lens), c.up(k_src), c.up(v_src), &ka, &va);
+            py::list ko, vo;
+            for (auto& t : ks) ko.append(c.down(t, "float16"));
+            for (auto& t : vs) vo.append(c.down(t, "float16"));
+            return py::make_tuple(ko, vo);
+        })
+        // ---- norm / element-wise
+        .def("layernorm", [](PyCtx& c, py::array x, py::array w, float eps, float scale) {
+            nn::LayerNorm ln(*c.ctx, (int)w.size(), false, eps, scale);
+            std::map<std::string, const Tensor> sd;
+            sd.emplace("ln.weight", c.up(w));
+            ln.load_state_dict(*c.ctx, sd, "ln");
+            return c.down(ln.forward(*c.ctx, c.up(x)), "float16");
+        })
+        .def("layernorm_fuse_add", [](PyCtx& c, py::array a, py::array b, py::array w, float eps) {
+            nn::LayerNorm ln(*c.ctx, (int)w.size(), false, eps);
+            std::map<std::string, const Tensor> sd;
+            sd.emplace("ln.weight", c.up(w));
+            ln.load_state_dict(*c.ctx, sd, "ln");
+            Tensor ta = c.up(a), sum = c.ctx->tensor(ta.shape(), ta.dtype());
+            Tensor out = ln.fuse_add(*c.ctx, ta, c.up(b), sum);
+            return py::make_tuple(c.down(out, "float16"), c.down(sum, "float16"));
+        })
+        .def("element_add_scale", [](PyCtx& c, py::array a, py::array b, float scale, bool scale_residual) {
+            return c.down(nn::element_add_scale(*c.ctx, c.up(a), c.up(b), scale, scale_residual), "float16");
+        })
+        .def("gate_mul", [](PyCtx& c, py::array a, py::array b, std::string act) {
+            Tensor ta = c.up(a);
+            nn::gate_mul_inplace(*c.ctx, ta, c.up(b), act);
+            return c.down(ta, "float16");
+        })
+        // ---- int8
+        .def("quant_calc_scale", [](PyCtx& c, py::array x) {
+            Tensor q = int8_op::quant_calc_scale(*c.ctx, c.up(x));
+            BM_ASSERT(q.quant_scale, "quant_scale side tensor missing");
+            return py::make_tuple(c.down(q, "int8"), c.down(*q.quant_scale, "float32"));
+        })
+        .def("layernorm_quant", [](PyCtx& c, py::array x, py::array w, float eps) {
+            Tensor tx = c.up(x);
+            Tensor out = c.ctx->tensor(tx.shape(), tx.dtype()), q = c.ctx->tensor(tx.shape(), DataType::kInt8),
+                   sc = c.ctx->tensor({tx.numel() / tx.size(-1)}, DataType::kFloat);
+            int8_op::layernorm_quant(*c.ctx, tx, c.up(w), &out, &q, &sc, eps, 1.0f);
+            return py::make_tuple(c.down(out, "float16"), c.down(q, "int8"), c.down(sc, "float32"));
+        })
+        .def("int8_linear", [](PyCtx& c, py::array x, py::array w_q, py::array w_scale) {
+            // Int8Linear::forward (linear.cpp:557-635): quantise the rows, int8 x int8^T -> int32, scale back
+            Tensor xq = int8_op::quant_calc_scale(*c.ctx, c.up(x));
+            Tensor acc = int8_op::int8_gemm_nt(*c.ctx, xq, c.up(w_q));
+            Tensor ws = c.up(w_scale);
+            Tensor y = int8_op::quant_scale_back(*c.ctx, acc, xq.quant_scale.get(), &ws);
+            return py::make_tuple(c.down(y, "float16"), c.down(acc, "int32"));
+        })
+        .def("quant_back_act_mul", [](PyCtx& c, py::array a, py::array asx, py::array asy, py::array b, py::array bsx, py::array bsy,
+                                       std::string act) {
+            Tensor tasx = c.up(asx), tasy = c.up(asy), tbsx = c.up(bsx), tbsy = c.up(bsy);
+            return c.down(int8_op::quant_back_act_mul(*c.ctx, c.up(a), &tasx, &tasy, c.up(b), &tbsx, &tbsy, act), "float16");
+        })
+        .def("raises_on_bad_shape", [](PyCtx& c) {
+            Tensor a = c.ctx->tensor({1, 64}, DataType::kHalf), q = c.ctx->tensor({16, 16}, DataType::kInt32),
+                   z = c.ctx->tensor({16, 1}, DataType::kInt8), s = c.ctx->tensor({16, 1}, DataType::kHalf);
+            nn::gptq::gptq_gemm_k_major(*c.ctx, a, q, z, s, Tensor(), Tensor(), nullptr, false);   // K = 128 vs 64: throws
+        });
+}
