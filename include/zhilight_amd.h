@@ -4,8 +4,10 @@
  * This is the drop-in boundary: one flat `extern "C"` launcher per kernel
  * family of ZhiLight's `src/nn` quantized-GEMM + fused-attention path.  Every launcher
  *   - takes raw DEVICE pointers, sizes and a `hipStream_t` (passed as void*),
- *   - only enqueues work on that stream: it never allocates, never synchronises, keeps no global
- *     mutable state and is re-entrant (several host threads, one per GPU, may call concurrently),
+ *   - only enqueues work on that stream: it never allocates, never synchronises, reads no environment variable, keeps
+ *     no global mutable state and is re-entrant (several host threads, one per GPU, may call concurrently).  Launchers
+ *     that split a product over workgroups take their scratch from the CALLER (zl_w4_opts_t::scratch, the attention
+ *     workspace); tuning overrides are explicit arguments of the *_ex entry points,
  *   - returns 0 on success, a negative ZL_E* code for an invalid argument, or a positive
  *     hipError_t if the launch itself failed.  Nothing throws.
  * The C++ `nn::` / `gptq::` / `int8_op::` wrappers of the reference (which allocate outputs with
@@ -44,10 +46,6 @@ int zl_version(void);
 const char* zl_status_string(int status);
 /* number of CUs of the current device (cached per call; used by grid heuristics). >0 or -hipError */
 int zl_device_cu_count(void);
-/* Pre-size the library's per-device scratch (split-K partial sums of the M-tiled GEMMs).  It grows on demand
- * outside stream capture; call this before capturing a graph whose first eager run you skipped.  Launchers
- * that use the scratch are ordered by the stream they run on: use one compute stream per device. */
-int zl_workspace_reserve(int64_t bytes);
 
 
 /* ------------------------------------------------------------------------------------------------
@@ -151,6 +149,29 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx,
                        const uint16_t* bias, const uint16_t* residual, uint16_t* y,
                        int64_t m, int64_t n, int64_t k, int64_t group_size,
                        const uint16_t* norm_weight, float norm_eps, int epilogue, zl_stream_t s);
+
+/* Options of the W4A16 matrix-core launchers (zero / NULL = the launcher's own choice everywhere).
+ *   scratch        device memory for the K-split paths (13..32 rows with K > 8192 on the streaming kernel; short grids of
+ *                  the M-tiled kernel): zl_w4a16_scratch_bytes(m, n) bytes, whose first ZL_SCRATCH_HEADER bytes hold
+ *                  arrival counters that must be ZERO before the first launch (launches leave them zero) -- one scratch
+ *                  per stream that may run such launches concurrently.  NULL / too small: the launchers take their
+ *                  unsplit routes (same results, slower for those shapes).
+ *   the rest       overrides the tests / micro-benchmarks sweep: tiles per workgroup of the phase kernel (1..8), its K split
+ *                  (2 or 4; -1 = off) and the row count it starts at, the row range the phase kernel takes, the row count from
+ *                  which the M-tiled kernel takes over, its M-tile height (32 / 64 / 128) and forced split count, k-slices
+ *                  and rounds of k_w4a16_mfma. */
+#define ZL_SCRATCH_HEADER 65536
+typedef struct {
+    void* scratch;
+    int64_t scratch_bytes;
+    int phase_rounds, phase_ksplit, phase_ksplit_min_m, phase_min_m, phase_max_m, phase_small_off;
+    int tiled_min_m, tiled_bm, tiled_splitk;
+    int mfma_ks, mfma_rounds;
+} zl_w4_opts_t;
+int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n);
+int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias,
+                          const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t group_size,
+                          const uint16_t* norm_weight, float norm_eps, int epilogue, const zl_w4_opts_t* opts, zl_stream_t s);
 /* M > 16 flavour on the same ZLW4M operands (prefill chunks, decode batches > 16): W16 = rn16(rn16(q - z) * s)
  * formed in registers, fp32-accumulating MFMA GEMM -- bit for bit the weights dequant_k_major writes out for
  * the reference's M > 40 branch (q_gemm_k_major.cu:843-952, 1083-1100) without materialising them; K must be
@@ -158,6 +179,9 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx,
 int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
                         const uint16_t* bias, const uint16_t* residual, uint16_t* y,
                         int64_t m, int64_t n, int64_t k, int64_t group_size, int epilogue, zl_stream_t s);
+int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
+                           const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
+                           int64_t group_size, int epilogue, const zl_w4_opts_t* opts, zl_stream_t s);
 
 
 /* ------------------------------------------------------------------------------------------------
@@ -247,6 +271,12 @@ int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* c
                    const uint16_t* const* v_bufs, const int8_t* mask, const int32_t* valid_lens,
                    uint16_t* out, void* workspace, int64_t b, int64_t len_q, int64_t h, int64_t hkv,
                    int64_t d, float scale, int64_t max_len_buf, int bshd, int dtype, zl_stream_t s);
+/* algo: 0 = the launcher's choice (matrix-core kernel where it applies), 1 = the VALU split-KV kernel (the one masks,
+ * D != 128 and more than 16 query rows per kv head always take) */
+int zl_decode_attn_ex(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
+                      const uint16_t* const* v_bufs, const int8_t* mask, const int32_t* valid_lens,
+                      uint16_t* out, void* workspace, int64_t b, int64_t len_q, int64_t h, int64_t hkv,
+                      int64_t d, float scale, int64_t max_len_buf, int bshd, int dtype, int algo, zl_stream_t s);
 
 /* Fused decode attention front end (len_q == 1 per task, prefix visibility): rope_qk_cache +
  * copy_to_rag_buffer2 + multi_query_attention_rag_buffer in one pass over the fused qkv rows
@@ -329,6 +359,11 @@ int zl_decode_attn_quant(const uint16_t* q, const int32_t* buf_lens, const uint8
                          const int8_t* mask, const int32_t* valid_lens, uint16_t* out, void* workspace, int64_t b,
                          int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale, int64_t max_len_buf,
                          int bshd, int dtype, zl_stream_t s);
+int zl_decode_attn_quant_ex(const uint16_t* q, const int32_t* buf_lens, const uint8_t* const* k_bufs,
+                         const uint8_t* const* v_bufs, const float* const* k_scales, const float* const* v_scales,
+                         const int8_t* mask, const int32_t* valid_lens, uint16_t* out, void* workspace, int64_t b,
+                         int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale, int64_t max_len_buf,
+                         int bshd, int dtype, int algo, zl_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * a16  Prompt ("encode part") attention of ONE task's chunk, causal, on the matrix cores.
@@ -395,6 +430,10 @@ int zl_w8m_pack(const int8_t* w /* (N,K) */, int64_t n, int64_t k, int row_inter
 int zl_w8a8_gemm_phase(const int8_t* xq /* (M,K) */, const float* scale_x /* (M) */, const void* qw,
                        const uint16_t* scale_y /* (N) T */, const uint16_t* addend, uint16_t* out, int64_t m, int64_t n,
                        int64_t k, float scale, int epilogue, int dtype, zl_stream_t s);
+/* rounds: tiles per workgroup override (1..8; 0 = pick) */
+int zl_w8a8_gemm_phase_ex(const int8_t* xq /* (M,K) */, const float* scale_x /* (M) */, const void* qw,
+                       const uint16_t* scale_y /* (N) T */, const uint16_t* addend, uint16_t* out, int64_t m, int64_t n,
+                       int64_t k, float scale, int epilogue, int dtype, int rounds, zl_stream_t s);
 /* The INT8 route's fused qkv projection of a decode step: zl_w8a8_gemm_phase(ZL_W8_BACK) + zl_rope_scatter_decode in one
  * launch (neox, cached cos/sin; bit-identical to the two calls).  1 <= M <= 32, D % 32 == 0. */
 int zl_w8a8_qkv_rope_scatter(const int8_t* xq, const float* scale_x, const void* qw, const uint16_t* scale_y,

@@ -18,25 +18,32 @@ SO_PATH = os.environ.get("ZHILIGHT_AMD_SO") or os.path.join(_HERE, "libzhilight_
 
 # every entry point declared in include/zhilight_amd.h (kept in sync by tests/test_abi.py)
 SYMBOLS = [
-    "zl_version", "zl_status_string", "zl_device_cu_count", "zl_workspace_reserve",
+    "zl_version", "zl_status_string", "zl_device_cu_count",
     "zl_gptq_shuffle", "zl_gptq_increase_zero", "zl_gptq_q4_to_q8", "zl_transpose_2d",
     "zl_awq_un_shuffle", "zl_awq_shuffle",
     "zl_w4_layout", "zl_w4_pack", "zl_w4_dequant", "zl_w4a16_gemm",
-    "zl_w4m_layout", "zl_w4m_pack", "zl_w4m_unpack", "zl_w4a16_gemm_mfma", "zl_w4a16_gemm_tiled",
+    "zl_w4m_layout", "zl_w4m_pack", "zl_w4m_unpack", "zl_w4a16_gemm_mfma", "zl_w4a16_gemm_tiled", "zl_w4a16_scratch_bytes", "zl_w4a16_gemm_mfma_ex", "zl_w4a16_gemm_tiled_ex",
     "zl_gemm_nt_small_m", "zl_gemm_nt", "zl_argmax_workspace_bytes", "zl_gemm_nt_small_m_argmax", "zl_greedy_advance",
     "zl_rmsnorm",
     "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rotary_embedding_qk", "zl_rope_qk_cache",
     "zl_copy_to_rag_buffer2", "zl_rope_scatter_decode", "zl_w4a16_qkv_rope_scatter",
-    "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_fused",
+    "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_ex", "zl_decode_attn_fused",
     "zl_decode_attn_split_len", "zl_decode_attn_splits", "zl_w4a16_gemm_attn_merge",
-    "zl_quant_calc_scale_zp", "zl_quant_copy_to_rag_buffer", "zl_rope_quant_scatter_decode", "zl_decode_attn_quant",
+    "zl_quant_calc_scale_zp", "zl_quant_copy_to_rag_buffer", "zl_rope_quant_scatter_decode", "zl_decode_attn_quant", "zl_decode_attn_quant_ex",
     "zl_prefill_attn",
     "zl_element_add_scale", "zl_gate_mul", "zl_embedding",
-    "zl_w8m_bytes", "zl_w8m_pack", "zl_w8a8_gemm_phase", "zl_w8a8_qkv_rope_scatter",
+    "zl_w8m_bytes", "zl_w8m_pack", "zl_w8a8_gemm_phase", "zl_w8a8_gemm_phase_ex", "zl_w8a8_qkv_rope_scatter",
     "zl_quant_calc_scale", "zl_rmsnorm_quant", "zl_int8_gemm_nt", "zl_quant_scale_back",
     "zl_quant_back_act_mul", "zl_quant_scale_back3", "zl_quant_back_element_add_scale", "zl_quant_back_transpose",
     "zl_quant_back_copy_to_buffer",
 ]
+
+
+class W4Opts(C.Structure):
+    """zl_w4_opts_t: caller-provided scratch + explicit tuning overrides of the W4A16 matrix-core launchers"""
+    _fields_ = [("scratch", C.c_void_p), ("scratch_bytes", C.c_int64)] + [(n, C.c_int) for n in (
+        "phase_rounds", "phase_ksplit", "phase_ksplit_min_m", "phase_min_m", "phase_max_m", "phase_small_off",
+        "tiled_min_m", "tiled_bm", "tiled_splitk", "mfma_ks", "mfma_rounds")]
 
 
 class W4Layout(C.Structure):
@@ -63,6 +70,7 @@ def lib():
         l.zl_decode_attn_split_len.restype = C.c_int64
         l.zl_argmax_workspace_bytes.restype = C.c_int64
         l.zl_w8m_bytes.restype = C.c_int64
+        l.zl_w4a16_scratch_bytes.restype = C.c_int64
         _lib = l
     return _lib
 

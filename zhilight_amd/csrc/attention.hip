@@ -19,12 +19,12 @@
 //    fp32 registers per lane-group and is merged group->wave->workgroup at the end.
 //  * partial (acc[D], m, l) per split goes to a small fp32 workspace; a second tiny kernel merges
 //    the splits:  out = sum_s acc_s e^{m_s-M} / (sum_s l_s e^{m_s-M} + 1e-20).
-#include <stdlib.h>
 #include "zl_common.h"
 
 namespace {
 
 constexpr int kSteps = 8;  // key-steps per chunk
+constexpr int kMaxSplits = 512;   // splits a merge can hold (k_decode_attn_combine's kMaxS)
 
 struct AttnParams {
     const uint16_t* q;
@@ -56,8 +56,6 @@ typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
 
 // split length: multiple of 128 keys, grown so that about >= 1024 workgroups exist when possible
 static inline int attn_split_len(int64_t b, int64_t hkv, int64_t max_len) {
-    static const int forced = [] { const char* e = getenv("ZL_ATTN_SPLIT"); return e ? atoi(e) : 0; }();   // experiments
-    if (forced >= 128 && forced % 128 == 0) return forced;
     // about 1024 workgroups (4 resident per CU = one generation).  Short splits pay their fixed cost twice when the
     // grid spills into a second generation, so they are rounded up instead (batch 32, 1088-key buffers: 3 splits of
     // 384 keys instead of 5 of 256: 34.7 vs 37.6 us per layer); long splits keep the round-down (8192 keys, batch 8:
@@ -67,6 +65,10 @@ static inline int attn_split_len(int64_t b, int64_t hkv, int64_t max_len) {
     if (ls < 128) ls = 128;
     if (ls <= 256 && ((max_len + ls - 1) / ls) * b * hkv > 1024) ls += 128;
     if (ls > 2048) ls = 2048;
+    // the merge (k_decode_attn_combine, the attn_out prologue) holds at most kMaxSplits splits: few (task, kv head) pairs
+    // with a very long buffer (batch 1, one local kv head under ATTN_KV_REP_TP, 128 k keys) would otherwise exceed it and
+    // silently drop keys.  Beyond kMaxSplits * 2048 keys the launchers return ZL_ELIMIT.
+    while ((max_len + ls - 1) / ls > kMaxSplits && ls < (int64_t)1 << 30) ls += 128;
     return (int)ls;
 }
 
@@ -1166,6 +1168,14 @@ int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* c
                    const uint16_t* const* v_bufs, const int8_t* mask, const int32_t* valid_lens, uint16_t* out,
                    void* workspace, int64_t b, int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale,
                    int64_t max_len_buf, int bshd, int dtype, zl_stream_t s) {
+    return zl_decode_attn_ex(q, buf_lens, k_bufs, v_bufs, mask, valid_lens, out, workspace, b, len_q, h, hkv, d, scale, max_len_buf,
+                             bshd, dtype, 0, s);
+}
+
+int zl_decode_attn_ex(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
+                      const uint16_t* const* v_bufs, const int8_t* mask, const int32_t* valid_lens, uint16_t* out,
+                      void* workspace, int64_t b, int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale,
+                      int64_t max_len_buf, int bshd, int dtype, int algo, zl_stream_t s) {
     ZL_CHECK_ARG(q && buf_lens && k_bufs && v_bufs && out && workspace, ZL_EINVAL);
     ZL_CHECK_ARG(mask || valid_lens, ZL_EINVAL);
     ZL_CHECK_ARG(b > 0 && len_q > 0 && h > 0 && hkv > 0 && d > 0 && max_len_buf > 0, ZL_EINVAL);
@@ -1180,14 +1190,14 @@ int zl_decode_attn(const uint16_t* q, const int32_t* buf_lens, const uint16_t* c
     p.passes = (p.rows + rt - 1) / rt;
     p.split_len = attn_split_len(b, hkv, max_len_buf);
     p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
     p.k_scales = p.v_scales = nullptr;
     {   // decode fast path on the matrix cores: all query rows of a kv head in one 16-row MFMA block
-        static const int use_mfma = [] { const char* e = getenv("ZL_ATTN_MFMA"); return e ? atoi(e) : 1; }();
-        if (use_mfma && !mask && d == kMD && p.rows <= 16) {
+        if (algo != 1 && !mask && d == kMD && p.rows <= 16) {
             p.passes = 1;
             const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
             if (dtype == ZL_F16) hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, hs, p);
@@ -1229,6 +1239,7 @@ int zl_decode_attn_splits(const uint16_t* q, const int32_t* buf_lens, const uint
     p.rows = p.n_rep; p.passes = 1;
     p.split_len = attn_split_len(b, hkv, max_len_buf);
     p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
     p.k_scales = p.v_scales = nullptr;
@@ -1257,6 +1268,7 @@ int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* q
     p.passes = (p.rows + rt - 1) / rt;
     p.split_len = attn_split_len(b, hkv, max_len_buf);
     p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     p.qkv = qkv; p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.k_bufs_w = k_bufs; p.v_bufs_w = v_bufs; p.neox = neox;
     p.k_scales = p.v_scales = nullptr;
@@ -1272,6 +1284,15 @@ int zl_decode_attn_quant(const uint16_t* q, const int32_t* buf_lens, const uint8
                          const int8_t* mask, const int32_t* valid_lens, uint16_t* out, void* workspace, int64_t b,
                          int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd,
                          int dtype, zl_stream_t s) {
+    return zl_decode_attn_quant_ex(q, buf_lens, k_bufs, v_bufs, k_scales, v_scales, mask, valid_lens, out, workspace, b, len_q, h, hkv,
+                                   d, scale, max_len_buf, bshd, dtype, 0, s);
+}
+
+int zl_decode_attn_quant_ex(const uint16_t* q, const int32_t* buf_lens, const uint8_t* const* k_bufs,
+                         const uint8_t* const* v_bufs, const float* const* k_scales, const float* const* v_scales,
+                         const int8_t* mask, const int32_t* valid_lens, uint16_t* out, void* workspace, int64_t b,
+                         int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd,
+                         int dtype, int algo, zl_stream_t s) {
     ZL_CHECK_ARG(q && buf_lens && k_bufs && v_bufs && k_scales && v_scales && out && workspace, ZL_EINVAL);
     ZL_CHECK_ARG(mask || valid_lens, ZL_EINVAL);
     ZL_CHECK_ARG(b > 0 && len_q > 0 && h > 0 && hkv > 0 && d > 0 && max_len_buf > 0, ZL_EINVAL);
@@ -1289,13 +1310,13 @@ int zl_decode_attn_quant(const uint16_t* q, const int32_t* buf_lens, const uint8
     p.passes = (p.rows + rt - 1) / rt;
     p.split_len = attn_split_len(b, hkv, max_len_buf);
     p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
     hipStream_t hs = (hipStream_t)s;
     {   // decode fast path on the matrix cores
-        static const int use_mfma = [] { const char* e = getenv("ZL_ATTN_MFMA"); return e ? atoi(e) : 1; }();
-        if (use_mfma && !mask && dtype == ZL_F16 && d == kMD && p.len_q * p.n_rep <= 16) {
+        if (algo != 1 && !mask && dtype == ZL_F16 && d == kMD && p.len_q * p.n_rep <= 16) {
             p.passes = 1;
             hipLaunchKernelGGL(k_decode_attn_mfma_q8, dim3((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b), dim3(256), 0, hs, p);
             int e = zl_launch_status();

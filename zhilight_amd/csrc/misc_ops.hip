@@ -305,57 +305,6 @@ const char* zl_status_string(int st) {
     }
 }
 
-// ---- per-device scratch for launchers that split a product over workgroups (split-K partial sums).
-// One buffer per device, grown on demand OUTSIDE stream capture (hipMalloc is not capturable): callers that
-// capture graphs run the step once eagerly first, or reserve explicitly.  Launches using it must be
-// stream-ordered with respect to each other (one compute stream per device, as in the reference's engine).
-static void* g_ws_ptr[64] = {nullptr};
-static size_t g_ws_size[64] = {0};
-static std::mutex g_ws_mutex;     // host threads of one process (one per GPU in the reference's engine) may arrive together
-
-void* zlint_workspace(size_t bytes) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    if (g_ws_size[dev] >= bytes) return g_ws_ptr[dev];
-    void* np = nullptr;
-    const size_t want = bytes < (size_t)(64 << 20) ? (size_t)(64 << 20) : bytes;   // 64 MiB floor
-    if (hipMalloc(&np, want) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    if (g_ws_ptr[dev]) {
-        (void)hipDeviceSynchronize();   // work enqueued on the old buffer finishes before it goes away
-        (void)hipFree(g_ws_ptr[dev]);
-    }
-    g_ws_ptr[dev] = np;
-    g_ws_size[dev] = want;
-    return np;
-}
-
-// zeroed per-device counters for in-launch last-arriver hand-offs (users leave them zero)
-extern "C" int* zlint_counters(void) {
-    static int* g_cnt[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    if (!g_cnt[dev]) {
-        int* np = nullptr;
-        if (hipMalloc(&np, 16384 * sizeof(int)) != hipSuccess || hipMemset(np, 0, 16384 * sizeof(int)) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        (void)hipDeviceSynchronize();
-        g_cnt[dev] = np;
-    }
-    return g_cnt[dev];
-}
-
-int zl_workspace_reserve(int64_t bytes) {
-    ZL_CHECK_ARG(bytes >= 0, ZL_EINVAL);
-    return zlint_workspace((size_t)bytes) || bytes == 0 ? ZL_OK : ZL_ELIMIT;
-}
-
 int zl_device_cu_count(void) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

@@ -15,7 +15,6 @@
 // rows (conflict-free ds_read_b128), global -> registers one chunk ahead; the weight items ride an 8-slot
 // ring of non-temporal buffer loads (4 chunks ahead).  Per chunk and wave: 2 x 52 VALU ops of dequant feed
 // 2 x 4 x (BM/16) MFMAs (v_mfma_f32_16x16x32_f16) on 2 x BM/16 independent accumulators.
-#include <stdlib.h>
 #include "zl_common.h"
 
 namespace {
@@ -295,12 +294,18 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
 
 }  // namespace
 
-extern "C" void* zlint_workspace(size_t bytes);   // misc_ops.hip
-
-// called by zl_w4a16_gemm_mfma for m > 16 (same operands)
 extern "C" int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
                                    const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n,
                                    int64_t k, int64_t group_size, int epilogue, zl_stream_t s) {
+    return zl_w4a16_gemm_tiled_ex(x, ldx, qw, meta, bias, residual, y, m, n, k, group_size, epilogue, nullptr, s);
+}
+
+// called by zl_w4a16_gemm_mfma_ex for m > 16 (same operands)
+extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
+                                      const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n,
+                                      int64_t k, int64_t group_size, int epilogue, const zl_w4_opts_t* opts, zl_stream_t s) {
+    static const zl_w4_opts_t kNoOpts = {};
+    const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
     ZL_CHECK_ARG(x && qw && meta && y && m > 0 && n > 0 && k > 0, ZL_EINVAL);
     ZL_CHECK_ARG(ldx >= k && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && k % 128 == 0, ZL_ESHAPE);
     ZL_CHECK_ARG(!(epilogue & ZL_EPI_RESIDUAL) || residual, ZL_EINVAL);
@@ -326,14 +331,14 @@ extern "C" int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_
     // M-tile height: taller tiles amortise the dequant over more MFMAs (the VALU and the MFMA pipe do not
     // overlap here: 143 VALU + 32 MFMA per chunk and wave at BM = 64 measured 40 % MFMA-busy); 128 rows need
     // enough M to still fill the chip
-    static const int bm_env = [] { const char* e = getenv("ZL_W4_TILED_BM"); return e ? atoi(e) : 0; }();
+    const int bm_env = o.tiled_bm;
     int bm = m <= 32 ? 32 : (m * (int64_t)gx >= 128 * 512 ? 128 : 64);
     if (bm_env == 32 || bm_env == 64 || bm_env == 128) bm = bm_env;
     ZL_CHECK_ARG((m + bm - 1) / bm <= 65535, ZL_ELIMIT);
     const int gy = (int)((m + bm - 1) / bm);
     // too few workgroups for the chip (decode batches: one M tile, N / 128 column tiles): split K over
     // blockIdx.z so that ~2 workgroups per CU exist, >= 4 chunks each; partials go through the device scratch
-    static const int split_env = [] { const char* e = getenv("ZL_W4_TILED_SPLITK"); return e ? atoi(e) : 0; }();
+    const int split_env = o.tiled_splitk;
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
     int splits = 1;
@@ -348,8 +353,15 @@ extern "C" int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_
     if (splits > 1) {
         p.split_chunks = (p.groups + splits - 1) / splits;
         splits = (p.groups + p.split_chunks - 1) / p.split_chunks;       // no empty split
-        p.ws = reinterpret_cast<float*>(zlint_workspace((size_t)splits * m * L.np * sizeof(float)));
-        if (!p.ws) return ZL_ELIMIT;
+        // partials in the caller's scratch (behind the counter header); without enough of it: one split (same result
+        // up to the summation order of the fp32 partials, fewer workgroups)
+        const int64_t need = ZL_SCRATCH_HEADER + (int64_t)splits * m * L.np * (int64_t)sizeof(float);
+        if (o.scratch && o.scratch_bytes >= need) {
+            p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(o.scratch) + ZL_SCRATCH_HEADER);
+        } else {
+            splits = 1;
+            p.split_chunks = p.groups;
+        }
     }
     const dim3 grid(gx, (unsigned)gy, (unsigned)splits);
     const size_t lds = (size_t)2 * bm * kRowHalfs * 2;

@@ -434,10 +434,6 @@ extern "C" int zl_w4a16_gemm(const uint16_t* x, int64_t ldx, const uint32_t* qw,
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
     int wgs_per_cu = (p.pairs_total + cus * kWaves - 1) / (cus * kWaves) >= 2 ? 2 : 1;
-    if (const char* e = getenv("ZL_W4_WGS_PER_CU")) {  // tuning override (read-only, no state kept)
-        int v = atoi(e);
-        if (v >= 1 && v <= 16) wgs_per_cu = v;
-    }
     int best_ppw = (p.pairs_total + cus * wgs_per_cu * kWaves - 1) / (cus * wgs_per_cu * kWaves);
     if (best_ppw < 1) best_ppw = 1;
     if (best_ppw > 32) best_ppw = 32;  // LDS result slots: 64 rows per wave

@@ -594,7 +594,7 @@ inline int grid_for(int64_t n) {
 int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                         uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
                         int k, int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps,
-                        int rounds_override, hipStream_t hs);
+                        const zl_w4_opts_t* opts, hipStream_t hs);
 
 int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len,
                               int max_splits, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
@@ -657,9 +657,23 @@ int zl_w4m_unpack(const uint32_t* qw, const uint32_t* meta, int64_t n, int64_t k
     return zl_launch_status();
 }
 
+int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n) {
+    if (m <= 0 || n <= 0) return ZL_EINVAL;
+    const int64_t np = (n + 127) / 128 * 128;
+    return ZL_SCRATCH_HEADER + 32 * m * np * (int64_t)sizeof(float);   // <= 32 K splits of fp32 partials
+}
+
 int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias,
                        const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t group_size,
                        const uint16_t* norm_weight, float norm_eps, int epilogue, zl_stream_t s) {
+    return zl_w4a16_gemm_mfma_ex(x, ldx, qw, meta, bias, residual, y, m, n, k, group_size, norm_weight, norm_eps, epilogue, nullptr, s);
+}
+
+int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias,
+                          const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t group_size,
+                          const uint16_t* norm_weight, float norm_eps, int epilogue, const zl_w4_opts_t* opts, zl_stream_t s) {
+    static const zl_w4_opts_t kNoOpts = {};
+    const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
     ZL_CHECK_ARG(x && qw && meta && y && m > 0 && n > 0 && k > 0, ZL_EINVAL);
     ZL_CHECK_ARG(ldx >= k && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, ZL_ESHAPE);
     ZL_CHECK_ARG(!(epilogue & ZL_EPI_RESIDUAL) || residual, ZL_EINVAL);
@@ -676,24 +690,21 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const
     // rows every workgroup pulls M x K activations through L2, so a long K (the down projection) stays on
     // the M-tiled kernel, whose 128-column workgroups share them.
     {
-        auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-        static const int ph_min_m = env_int("ZL_W4_PHASE_MIN_M", 5), ph_max_m = env_int("ZL_W4_PHASE_MAX_M", 32);
-        static const int ph_ksplit = env_int("ZL_W4_PHASE_KSPLIT", 2);   // long K, 17..32 rows: K split inside the phase kernel
-        static const int ph_maxk_16 = env_int("ZL_W4_PHASE_MAXK16", 1 << 30);
-        const bool can_split = (ph_ksplit == 2 || ph_ksplit == 4) && !silu && !norm_weight;
-        const int ph_maxk_32 = can_split ? (1 << 30) : env_int("ZL_W4_PHASE_MAXK32", 8192);
-        const int ph_rounds = env_int("ZL_W4_PHASE_ROUNDS", 0);   // read per call: the tests sweep it
-        static const int ph_small = env_int("ZL_W4_PHASE_SMALL", 1);   // 1..4 rows with K <= 4096 (incl. the fused norm)
-        const bool rows_5_32 = !norm_weight && m >= ph_min_m && m <= ph_max_m && m <= 32 && k <= (m <= 16 ? ph_maxk_16 : ph_maxk_32);
-        const bool rows_1_4 = ph_small && k <= 4096 && (norm_weight ? m <= 8 : (m <= 4 && m < ph_min_m));   // fused norm: <= 8 rows
+        const int ph_min_m = o.phase_min_m > 0 ? o.phase_min_m : 5, ph_max_m = o.phase_max_m > 0 ? o.phase_max_m : 32;
+        const int ph_ksplit = o.phase_ksplit ? o.phase_ksplit : 2;   // long K, 13..32 rows: K split inside the phase kernel
+        const bool have_scratch = o.scratch && o.scratch_bytes >= ZL_SCRATCH_HEADER + (int64_t)ph_ksplit * m * n * (int64_t)sizeof(float);
+        const bool can_split = (ph_ksplit == 2 || ph_ksplit == 4) && !silu && !norm_weight && have_scratch;
+        const int ph_maxk_32 = can_split ? (1 << 30) : 8192;
+        const bool rows_5_32 = !norm_weight && m >= ph_min_m && m <= ph_max_m && m <= 32 && k <= (m <= 16 ? (1 << 30) : ph_maxk_32);
+        const bool rows_1_4 = !o.phase_small_off && k <= 4096 && (norm_weight ? m <= 8 : (m <= 4 && m < ph_min_m));   // fused norm: <= 8 rows
         if ((rows_5_32 || rows_1_4) && L.qw_bytes < ((int64_t)1 << 32))
             return zl_w4a16_gemm_phase(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y,
                                        (int)m, (int)n, (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n),
-                                       norm_weight, norm_eps, ph_rounds, hs);
+                                       norm_weight, norm_eps, &o, hs);
     }
-    static const int tiled_min_m = [] { const char* e = getenv("ZL_W4_TILED_MIN_M"); return e ? atoi(e) : 17; }();
+    const int tiled_min_m = o.tiled_min_m > 0 ? o.tiled_min_m : 17;
     if (m >= tiled_min_m && !norm_weight && k % 128 == 0)
-        return zl_w4a16_gemm_tiled(x, ldx, qw, meta, bias, residual, y, m, n, k, group_size, epilogue, s);
+        return zl_w4a16_gemm_tiled_ex(x, ldx, qw, meta, bias, residual, y, m, n, k, group_size, epilogue, &o, s);
 
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
@@ -738,12 +749,9 @@ int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const
                 }
             }
         }
-        {   // experiment overrides (tools/bench_gemv.py sweeps): ZL_MFMA_KS / ZL_MFMA_ROUNDS
-            static const int ks_env = [] { const char* e = getenv("ZL_MFMA_KS"); return e ? atoi(e) : 0; }();
-            static const int rounds_env = [] { const char* e = getenv("ZL_MFMA_ROUNDS"); return e ? atoi(e) : 0; }();
-            if (ks_env > 0 && ks_env <= kWaves && (ks_env & (ks_env - 1)) == 0) best_ks = ks_env;
-            if (rounds_env > 0 && rounds_env <= kMaxRounds) best_rounds = rounds_env;
-        }
+        // explicit overrides (micro-benchmark sweeps)
+        if (o.mfma_ks > 0 && o.mfma_ks <= kWaves && (o.mfma_ks & (o.mfma_ks - 1)) == 0) best_ks = o.mfma_ks;
+        if (o.mfma_rounds > 0 && o.mfma_rounds <= kMaxRounds) best_rounds = o.mfma_rounds;
         p.ks = best_ks;
         p.items_per_slice = (p.groups + best_ks - 1) / best_ks;
         p.rounds = best_rounds;

@@ -17,7 +17,6 @@
 //     phases ahead (XP * R >= D - 1, D = ring depth) and ride in registers until the end of phase p - 1,
 //     when they are stored to the idle LDS buffer; one barrier per phase.
 // MB = 1: M <= 16, MB = 2: M <= 32 (two accumulator sets share every dequantised weight fragment).
-#include <stdlib.h>
 #include <type_traits>
 #include "zl_common.h"
 
@@ -96,7 +95,6 @@ struct PhaseParams {
     const float* mg_ws;
     const int32_t* mg_valid_lens;
     int mg_split_len, mg_max_splits;
-    int xfirst;                 // wait for the activation loads before the weight ring is issued (see k_w4a16_phase)
 #ifdef ZL_PHASE_PROBE
     int probe_id;
 #endif
@@ -221,11 +219,6 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
 #pragma unroll
         for (int q = 0; q < XP; ++q) load_x(q, q);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // The fabric serves an XCD's requests in arrival order: a workgroup dispatched 0.3-0.5 us after its neighbours finds
-    // their whole weight rings queued in front of its 16-byte-per-thread activation load.  xfirst holds the ring back
-    // until the activations have landed (short streams, which are latency-bound anyway).
-    if (p.xfirst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- weight ring.  Item sequence of wave w: for phase: for r < R: (tile0 + r, 8 phase + w); the byte
@@ -698,25 +691,15 @@ extern "C" int zl_debug_set_probe_p(void* p, int sel) {
 }
 #endif
 
-// short streams (<= 2 tiles per CU of K <= 4096): activations first.  ZL_W4_PHASE_XFIRST=0/1/2: never / short streams / always
-static int phase_xfirst(int tiles, int k) {
-    static const int mode = [] { const char* e = getenv("ZL_W4_PHASE_XFIRST"); return e ? atoi(e) : 1; }();
-    if (mode == 0) return 0;
-    if (mode == 2) return 1;
-    int cus = zl_device_cu_count();
-    if (cus <= 0) cus = 256;
-    return tiles <= 2 * cus && k <= 4096;
-}
-
-extern "C" void* zlint_workspace(size_t bytes);   // misc_ops.hip: per-device scratch (grow-only; reserve before capture)
-extern "C" int* zlint_counters(void);             // misc_ops.hip: per-device zeroed int[16384]
-
 // internal (called by zl_w4a16_gemm_mfma): 1 <= m <= 32; norm_w != null (fused RMSNorm): m <= 4 and k <= 4096.
 // rounds_override: 0 = pick
 int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                         uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
                         int k, int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps,
-                        int rounds_override, hipStream_t hs) {
+                        const zl_w4_opts_t* opts, hipStream_t hs) {
+    static const zl_w4_opts_t kNoOpts = {};
+    const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
+    const int rounds_override = o.phase_rounds;
     if (norm_w && (m > 8 || k > 4096)) return ZL_ESHAPE;
     PhaseParams p;
     p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
@@ -726,16 +709,17 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
     p.ks_ws = nullptr; p.ks_counter = nullptr;
     p.mg_ws = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
-    p.xfirst = phase_xfirst(tiles, k);
-    {   // long K with more than 16 rows: K split over 2 or 4 adjacent workgroups (R = KS tiles each, same grid size)
-        static const int ksplit = [] { const char* e = getenv("ZL_W4_PHASE_KSPLIT"); return e ? atoi(e) : 2; }();
+    {   // long K with 13..32 rows: K split over 2 or 4 adjacent workgroups (R = KS tiles each, same grid size); the fp32
+        // partials and the arrival counters live in the caller's scratch (zl_w4_opts_t)
+        const int ksplit = o.phase_ksplit ? o.phase_ksplit : 2;
         const bool plain = !(epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) && !norm_w;
         // (K = 14336: 16 rows 14.6 vs 15.9 us, 8 rows 13.4 vs 12.9 us -> from 13 rows on)
-        static const int ksplit_min_m = [] { const char* e = getenv("ZL_W4_PHASE_KSPLIT_MINM"); return e ? atoi(e) : 13; }();
-        if ((ksplit == 2 || ksplit == 4) && m >= ksplit_min_m && k > 8192 && plain && tiles / ksplit <= 16384) {
-            p.ks_ws = reinterpret_cast<float*>(zlint_workspace((size_t)ksplit * m * n * sizeof(float)));
-            p.ks_counter = zlint_counters();
-            if (!p.ks_ws || !p.ks_counter) return ZL_ELIMIT;
+        const int ksplit_min_m = o.phase_ksplit_min_m > 0 ? o.phase_ksplit_min_m : 13;
+        const int64_t need = ZL_SCRATCH_HEADER + (int64_t)ksplit * m * n * (int64_t)sizeof(float);
+        if ((ksplit == 2 || ksplit == 4) && m >= ksplit_min_m && k > 8192 && plain && tiles / ksplit <= 16384 && o.scratch &&
+            o.scratch_bytes >= need) {
+            p.ks_counter = reinterpret_cast<int*>(o.scratch);
+            p.ks_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(o.scratch) + ZL_SCRATCH_HEADER);
             const int grid = (tiles + ksplit - 1) / ksplit * ksplit;
             if (m <= 16) return ksplit == 2 ? launch_phase<2, 1, false, false, 2>(p, grid, hs) : launch_phase<4, 1, false, false, 4>(p, grid, hs);
             return ksplit == 2 ? launch_phase<2, 2, false, false, 2>(p, grid, hs) : launch_phase<4, 2, false, false, 4>(p, grid, hs);
@@ -778,7 +762,6 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
     p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd; p.pair_stride = d / 32;
     p.ks_ws = nullptr; p.ks_counter = nullptr;
     p.mg_ws = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
-    p.xfirst = phase_xfirst(tiles, k);
     const int grid = tiles / 2;
     if (norm_w || (m <= 4 && k <= 4096)) return launch_phase<2, 1, true, true>(p, grid, hs);
     return m <= 16 ? launch_phase<2, 1, false, true>(p, grid, hs) : launch_phase<2, 2, false, true>(p, grid, hs);
@@ -806,7 +789,6 @@ int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const in
     p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
     p.ks_ws = nullptr; p.ks_counter = nullptr;
     p.mg_ws = ws; p.mg_valid_lens = valid_lens; p.mg_split_len = split_len; p.mg_max_splits = max_splits;
-    p.xfirst = 0;
     const int grid = (tiles + r - 1) / r;
     return r == 1 ? launch_phase<1, 1, true, false, 1, true>(p, grid, hs) : launch_phase<2, 1, true, false, 1, true>(p, grid, hs);
 }

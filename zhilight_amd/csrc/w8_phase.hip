@@ -17,7 +17,6 @@
 // ZLW8M layout (zl_w8m_pack): tile = 16 output rows x 128 k = 2 KiB:
 //   qw : [N/16][Kp/128][2][64 lanes][16 B]   lane (n = lane & 15, kq = lane >> 4), half j: k = 128 g + 64 j + 16 kq .. +15
 // Kp = K rounded up to 128 (zero padded); row_interleave packs [w_in; w_gated] as (gate_n, up_n) row pairs.
-#include <stdlib.h>
 #include "zl_common.h"
 
 namespace {
@@ -360,6 +359,12 @@ int zl_w8m_pack(const int8_t* w, int64_t n, int64_t k, int row_interleave, void*
 int zl_w8a8_gemm_phase(const int8_t* xq, const float* scale_x, const void* qw, const uint16_t* scale_y,
                        const uint16_t* addend, uint16_t* out, int64_t m, int64_t n, int64_t k, float scale, int epilogue,
                        int dtype, zl_stream_t s) {
+    return zl_w8a8_gemm_phase_ex(xq, scale_x, qw, scale_y, addend, out, m, n, k, scale, epilogue, dtype, 0, s);
+}
+
+int zl_w8a8_gemm_phase_ex(const int8_t* xq, const float* scale_x, const void* qw, const uint16_t* scale_y,
+                          const uint16_t* addend, uint16_t* out, int64_t m, int64_t n, int64_t k, float scale, int epilogue,
+                          int dtype, int rounds, zl_stream_t s) {
     ZL_CHECK_ARG(xq && scale_x && qw && scale_y && out && m > 0 && n > 0 && k > 0, ZL_EINVAL);
     ZL_CHECK_ARG(epilogue >= kBack && epilogue <= kActGelu, ZL_EINVAL);
     ZL_CHECK_ARG(epilogue != kBackAdd || addend, ZL_EINVAL);
@@ -380,10 +385,7 @@ int zl_w8a8_gemm_phase(const int8_t* xq, const float* scale_x, const void* qw, c
     if (cus <= 0) cus = 256;
     int r = (p.tiles + cus - 1) / cus;
     if (r > 8) r = 8;
-    {
-        const char* e = getenv("ZL_W8_PHASE_ROUNDS");      // tests sweep the instantiations
-        if (e && atoi(e) >= 1 && atoi(e) <= 8) r = atoi(e);
-    }
+    if (rounds >= 1 && rounds <= 8) r = rounds;      // explicit override: the tests sweep the instantiations
     const int grid = (p.tiles + r - 1) / r;
     hipStream_t hs = (hipStream_t)s;
 #define ZL_W8(RR) \

@@ -239,6 +239,11 @@ public:
     Stream stream;
     Context::ReduceHook reduce;
     long next_id = 0;
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    ~ContextImpl() {
+        if (scratch) (void)hipFree(scratch);
+    }
 };
 const std::string Context::EMPTY_STR;
 
@@ -300,6 +305,25 @@ const Tensor Context::copy(const Tensor& src) const {
                                    current_cuda_stream()));
     return t;
 }
+void* Context::scratch(size_t bytes) const {
+    if (pimpl->scratch_bytes < bytes) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(pimpl->stream->ptr, &st);
+        if (st != hipStreamCaptureStatusNone) return pimpl->scratch;     // keep what exists: the launchers then do not split
+        const size_t want = std::max(bytes, (size_t)64 << 20);
+        void* p = nullptr;
+        BM_HIPRT_ASSERT(hipMalloc(&p, want));
+        BM_HIPRT_ASSERT(hipMemset(p, 0, want));
+        if (pimpl->scratch) {
+            BM_HIPRT_ASSERT(hipDeviceSynchronize());
+            (void)hipFree(pimpl->scratch);
+        }
+        pimpl->scratch = p;
+        pimpl->scratch_bytes = want;
+    }
+    return pimpl->scratch;
+}
+size_t Context::scratch_bytes() const { return pimpl->scratch_bytes; }
 size_t Context::used_memory() const { return pimpl->pool->used(); }
 size_t Context::peak_memory() const { return pimpl->pool->peak(); }
 void Context::mem_gc() { pimpl->pool->trim(); }

@@ -191,6 +191,11 @@ public:
     }
     const Tensor copy(const Tensor& t) const;
 
+    // a persistent zero-initialised device buffer of at least `bytes` (the caller-provided scratch of the C ABI's K-split
+    // launchers, zl_w4_opts_t::scratch): grown on demand, never while a stream capture is open
+    void* scratch(size_t bytes) const;
+    size_t scratch_bytes() const;
+
     size_t used_memory() const;
     size_t peak_memory() const;
     void mem_gc();                                   // return cached blocks to the driver

@@ -23,6 +23,15 @@ zl_stream_t st_of(const Context& ctx) { return (zl_stream_t)ctx.current_cuda_str
 const uint16_t* u16(const Tensor& t) { return t.data<const uint16_t>(); }
 uint16_t* u16m(Tensor& t) { return t.data<uint16_t>(); }
 size_t rows_of(const Tensor& t) { return t.numel() / t.size(-1); }
+// the C ABI takes its split-K scratch from the caller: the context keeps one zeroed buffer per device
+zl_w4_opts_t w4_opts(const Context& ctx, int64_t m, int64_t n) {
+    zl_w4_opts_t o = {};
+    if (m > 4) {
+        o.scratch = ctx.scratch((size_t)zl_w4a16_scratch_bytes(m, n));
+        o.scratch_bytes = (int64_t)ctx.scratch_bytes();
+    }
+    return o;
+}
 
 }  // namespace
 
@@ -122,9 +131,10 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a, const Tensor& q_we
     const int64_t ldx = a.ndim() >= 2 ? a.stride(-2) : k;
     const uint16_t* bptr = bias && bias->numel() ? u16(*bias) : nullptr;
     const int epi = bptr ? ZL_EPI_BIAS : 0;
+    const zl_w4_opts_t opts = w4_opts(ctx, m, n);
     if (is_packed(scales)) {
-        zl_check(zl_w4a16_gemm_mfma(u16(a), ldx, q_weight.data<uint32_t>(), scales.data<uint32_t>(), bptr, nullptr, u16m(out), m, n,
-                                    k, 128, nullptr, 0.f, epi, st_of(ctx)), "gptq_gemm_k_major");
+        zl_check(zl_w4a16_gemm_mfma_ex(u16(a), ldx, q_weight.data<uint32_t>(), scales.data<uint32_t>(), bptr, nullptr, u16m(out), m, n,
+                                       k, 128, nullptr, 0.f, epi, &opts, st_of(ctx)), "gptq_gemm_k_major");
         return out;
     }
     // raw k-major operands: re-tile into temporaries, then the same launch.  sym: every zero point is 8
@@ -139,8 +149,8 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a, const Tensor& q_we
     zl_w4_layout_t L;
     if (zl_w4m_layout(n, k, g, &L) == ZL_OK && L.np == n) {
         PackedW4 p = amd_pack_k_major(ctx, q_weight, zeros, scales);
-        zl_check(zl_w4a16_gemm_mfma(u16(a), ldx, p.q_weight.data<uint32_t>(), p.scales.data<uint32_t>(), bptr, nullptr, u16m(out), m,
-                                    n, k, g, nullptr, 0.f, epi, st_of(ctx)), "gptq_gemm_k_major");
+        zl_check(zl_w4a16_gemm_mfma_ex(u16(a), ldx, p.q_weight.data<uint32_t>(), p.scales.data<uint32_t>(), bptr, nullptr, u16m(out), m,
+                                       n, k, g, nullptr, 0.f, epi, &opts, st_of(ctx)), "gptq_gemm_k_major");
         return out;
     }
     // group sizes / row counts the matrix-core tiles do not take: the warp-reduce arithmetic kernel (bit-identical to

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from ._lib import W4Layout, ZLError, check, lib
+from ._lib import W4Layout, W4Opts, ZLError, check, lib
 
 F16, BF16 = 0, 1
 EPI_BIAS, EPI_ADD_C, EPI_RESIDUAL, EPI_SILU_MUL, EPI_SILU_MUL_F32 = 1, 2, 4, 8, 16
@@ -239,6 +239,52 @@ class W4MWeight:
         return cls(n, k, group_size, qw, meta, row_interleave)
 
 
+def _attn_algo():
+    """zl_decode_attn_ex algo: ZL_ATTN_MFMA=0 forces the VALU split-KV kernel (tests cover both)"""
+    return 1 if os.environ.get("ZL_ATTN_MFMA", "1") == "0" else 0
+
+
+_SCRATCH = {}
+# tuning overrides of the W4A16 launchers: read HERE, on the host side, per call (the C ABI reads no environment); the
+# tests and micro-benchmarks sweep them
+_W4_ENV = (("phase_rounds", "ZL_W4_PHASE_ROUNDS"), ("phase_ksplit", "ZL_W4_PHASE_KSPLIT"), ("phase_ksplit_min_m", "ZL_W4_PHASE_KSPLIT_MINM"),
+           ("phase_min_m", "ZL_W4_PHASE_MIN_M"), ("phase_max_m", "ZL_W4_PHASE_MAX_M"), ("tiled_min_m", "ZL_W4_TILED_MIN_M"),
+           ("tiled_bm", "ZL_W4_TILED_BM"), ("tiled_splitk", "ZL_W4_TILED_SPLITK"), ("mfma_ks", "ZL_MFMA_KS"), ("mfma_rounds", "ZL_MFMA_ROUNDS"))
+
+
+def w4_scratch(device, m, n):
+    """The caller-provided scratch of the K-split W4A16 paths (zl_w4_opts_t::scratch): one zero-initialised buffer per
+    device, grown on demand OUTSIDE stream capture (run a step eagerly before capturing it, as bench.py does).  Launches
+    that use it must be ordered among themselves -- one compute stream per device at a time, like the reference's engine
+    (the dual-stream prompt encode only runs collectives on its second stream); a caller with concurrent GEMM streams
+    passes its own buffers through zl_w4a16_gemm_mfma_ex."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    need = int(lib().zl_w4a16_scratch_bytes(_i(m), _i(n)))
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            return buf                                 # too small during capture: the launchers take their unsplit routes
+        if buf is not None:
+            torch.cuda.synchronize(device)             # work enqueued on the old buffer finishes before it goes away
+        buf = torch.zeros(max(need, 64 << 20), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+def _w4_opts(device, m, n):
+    o = W4Opts()
+    buf = w4_scratch(device, m, n) if m > 4 else None   # up to 4 rows no launcher splits over workgroups
+    if buf is not None:
+        o.scratch, o.scratch_bytes = buf.data_ptr(), buf.numel()
+    for field, env in _W4_ENV:
+        v = os.environ.get(env)
+        if v:
+            setattr(o, field, int(v))
+    if os.environ.get("ZL_W4_PHASE_SMALL") == "0":
+        o.phase_small_off = 1
+    return o
+
+
 def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, norm_eps=1e-5, epilogue=0):
     """MFMA flavour of w4a16_gemm (fp32 accumulation = the numerics of the reference's M > 40 branch)."""
     if x.dtype != torch.float16:
@@ -254,9 +300,10 @@ def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, 
         out = torch.empty((m, n_out), dtype=torch.float16, device=x.device)
     if bias is not None:
         epilogue |= EPI_BIAS
-    check(lib().zl_w4a16_gemm_mfma(_p(x2), _i(x2.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(residual),
-                                   _p(out), _i(m), _i(w.n), _i(k), _i(w.group_size), _p(norm_weight), _f(norm_eps),
-                                   C.c_int(epilogue), _stream()), "w4a16_gemm_mfma")
+    opts = _w4_opts(x.device, m, w.n)
+    check(lib().zl_w4a16_gemm_mfma_ex(_p(x2), _i(x2.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(residual),
+                                      _p(out), _i(m), _i(w.n), _i(k), _i(w.group_size), _p(norm_weight), _f(norm_eps),
+                                      C.c_int(epilogue), C.byref(opts), _stream()), "w4a16_gemm_mfma")
     return out
 
 
@@ -274,8 +321,10 @@ def w4a16_gemm_tiled(x, w, bias=None, residual=None, out=None, epilogue=0):
         out = torch.empty((m, w.n // 2 if silu else w.n), dtype=torch.float16, device=x.device)
     if bias is not None:
         epilogue |= EPI_BIAS
-    check(lib().zl_w4a16_gemm_tiled(_p(x2), _i(x2.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(residual), _p(out),
-                                    _i(m), _i(w.n), _i(k), _i(w.group_size), C.c_int(epilogue), _stream()), "w4a16_gemm_tiled")
+    opts = _w4_opts(x.device, max(m, 5), w.n)
+    check(lib().zl_w4a16_gemm_tiled_ex(_p(x2), _i(x2.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(residual), _p(out),
+                                       _i(m), _i(w.n), _i(k), _i(w.group_size), C.c_int(epilogue), C.byref(opts), _stream()),
+          "w4a16_gemm_tiled")
     return out
 
 
@@ -467,10 +516,10 @@ def multi_query_attention_rag_buffer(batch_q, buf_lens, key_buf_addrs, val_buf_a
         out = torch.empty_like(batch_q)
     if workspace is None:
         workspace = decode_attn_workspace(b, len_q, h, d, max_len_buf, batch_q.device)
-    check(lib().zl_decode_attn(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(mask),
+    check(lib().zl_decode_attn_ex(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(mask),
                                _p(valid_lens), _p(out), _p(workspace), _i(b), _i(len_q), _i(h), _i(num_kv_heads),
                                _i(d), _f(scale), _i(max_len_buf), C.c_int(int(bshd)), C.c_int(_dt(batch_q)),
-                               _stream()), "decode_attn")
+                               C.c_int(_attn_algo()), _stream()), "decode_attn")
     return out
 
 
@@ -585,10 +634,10 @@ def multi_query_attention_rag_buffer_quant(batch_q, buf_lens, key_buf_addrs, val
         out = torch.empty_like(batch_q)
     if workspace is None:
         workspace = decode_attn_workspace(b, len_q, h, d, max_len_buf, batch_q.device)
-    check(lib().zl_decode_attn_quant(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(scale_k_addrs),
+    check(lib().zl_decode_attn_quant_ex(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(scale_k_addrs),
                                      _p(scale_v_addrs), _p(mask), _p(valid_lens), _p(out), _p(workspace), _i(b),
                                      _i(len_q), _i(h), _i(num_kv_heads), _i(d), _f(scale), _i(max_len_buf),
-                                     C.c_int(int(bshd)), C.c_int(_dt(batch_q)), _stream()), "decode_attn_quant")
+                                     C.c_int(int(bshd)), C.c_int(_dt(batch_q)), C.c_int(_attn_algo()), _stream()), "decode_attn_quant")
     return out
 
 
@@ -684,8 +733,9 @@ def w8a8_gemm_phase(xq, sx, w: W8MWeight, epilogue=W8_BACK, addend=None, scale=1
         raise ZLError("w8a8_gemm_phase: gated epilogues need a row-interleaved weight (and only they do)")
     if out is None:
         out = torch.empty((m, w.n // 2 if gated else w.n), dtype=dtype, device=xq.device)
-    check(lib().zl_w8a8_gemm_phase(_p(xq), _p(sx), _p(w.qw), _p(w.scale), _p(addend), _p(out), _i(m), _i(w.n), _i(k), _f(scale),
-                                   C.c_int(epilogue), C.c_int(_dt(out)), _stream()), "w8a8_gemm_phase")
+    rounds = int(os.environ.get("ZL_W8_PHASE_ROUNDS", "0") or 0)     # tests sweep the instantiations
+    check(lib().zl_w8a8_gemm_phase_ex(_p(xq), _p(sx), _p(w.qw), _p(w.scale), _p(addend), _p(out), _i(m), _i(w.n), _i(k), _f(scale),
+                                      C.c_int(epilogue), C.c_int(_dt(out)), C.c_int(rounds), _stream()), "w8a8_gemm_phase")
     return out
 
 
