@@ -537,3 +537,65 @@ def test_w8a8_fused_qkv_rotary_scatter_bit_identical(oracle, dev, m, bshd):
     for x1, x2 in zip(k1 + v1, k2 + v2):
         assert torch.equal(x1, x2)
     assert not torch.equal(k1[0], torch.full_like(k1[0], 3.0))
+
+
+@pytest.mark.parametrize("bshd", [True, False])
+def test_kv_scatter_drops_slots_outside_the_buffer(oracle, dev, bshd):
+    """a placement >= len_buf (one decode step too many: the device-side bookkeeping bumps it without a bound)
+    must not write anywhere -- every scatter flavour (copy_to_rag_buffer2, the fused rope + scatter, the qkv-GEMV epilogue,
+    the INT8-cache quantising scatter) leaves all buffers untouched; the reference asserts pos_buf < len_buf
+    (ragged_buffer_kernel.cu:194-222)."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(21)
+    h, hkv, d = 8, 2, 128
+    lens = [64, 128]
+    b = len(lens)
+    # the two tasks' buffers are carved from ONE allocation with a guard tensor right behind: a stray write shows there
+    def carve():
+        tot = sum(L * hkv * d for L in lens)
+        blob = torch.zeros(tot + 4096, dtype=torch.float16, device=dev)
+        outs, off = [], 0
+        for L in lens:
+            outs.append(blob[off:off + L * hkv * d].view((L, hkv, d) if bshd else (hkv, L, d)))
+            off += L * hkv * d
+        return blob, outs
+    kblob, dk = carve()
+    vblob, dv = carve()
+    place = torch.tensor([lens[0], lens[1] + 5], dtype=torch.int32, device=dev)          # both past the end
+    lens_t = _t(np.array(lens, np.int32), dev)
+    ks, vs = _t(synth.act(rng, b, hkv * d).reshape(b, 1, hkv, d), dev), _t(synth.act(rng, b, hkv * d).reshape(b, 1, hkv, d), dev)
+    kt, vt = ops.make_ptr_table(dk), ops.make_ptr_table(dv)
+    ops.copy_to_rag_buffer2(place.view(b, 1), lens_t, ks, vs, kt, vt, bshd)
+    pos = np.array([3, 4], np.int32)
+    cs, sn = oracle.rope_cos_sin(pos, d, 1e4, True)
+    qkv = _t(synth.act(rng, b, (h + 2 * hkv) * d), dev)
+    ops.rope_scatter_decode(_t(cs, dev), _t(sn, dev), qkv, place, lens_t, kt, vt, h, hkv, d, bshd=bshd)
+    w = ops.W4MWeight.random((h + 2 * hkv) * d, 1024, 128, dev)
+    x = _t(synth.act(rng, b, 1024), dev)
+    ops.w4_qkv_rope_scatter(x, w, _t(cs, dev), _t(sn, dev), place, lens_t, kt, vt, h, hkv, d, bshd=bshd)
+    torch.cuda.synchronize()
+    assert not kblob.any() and not vblob.any()
+
+
+def test_decode_attention_single_kv_head_very_long_buffer(oracle, dev):
+    """batch 1 with ONE local kv head (the ATTN_KV_REP_TP geometry) and a 131072-slot buffer wanted 1024 splits
+    of 128 keys; the merge holds 512 -> keys beyond 65536 were dropped silently.  The split length now grows to fit."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(22)
+    h, hkv, d, L = 4, 1, 128, 131072
+    assert ops.decode_attn_split_len(1, hkv, L) * 512 >= L
+    q = synth.act(rng, h, d).reshape(1, 1, h, d)
+    kb = (rng.standard_normal((L, hkv, d)) * 0.5).astype(np.float16)
+    vb = np.zeros((L, hkv, d), np.float16)
+    vb[L - 1000:] = 1.0                                     # only the LAST keys carry value mass: dropping them shows
+    kb[L - 1000:] = kb[L - 1000:] + (q[0, 0, 0] * 0.5).astype(np.float16)   # ... and they attract the attention
+    dk, dv = [_t(kb, dev)], [_t(vb, dev)]
+    valid = torch.tensor([L], dtype=torch.int32, device=dev)
+    out = ops.multi_query_attention_rag_buffer(_t(q, dev), _t(np.array([L], np.int32), dev), ops.make_ptr_table(dk), ops.make_ptr_table(dv),
+                                               None, 1.0 / np.sqrt(d), L, hkv, valid_lens=valid)
+    got = _np(out).astype(np.float64)
+    mask = np.ones(L, np.int8)
+    ref = oracle.mqa_rag_buffer(oracle.h2u(q), np.array([L], np.int32), [oracle.h2u(kb)], [oracle.h2u(vb)], mask, hkv, 1.0 / np.sqrt(d),
+                                True, exact=True)
+    assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-3)
+    assert ref[0, 0, 0].mean() > 0.5                         # the tail really dominates (else the test proves nothing)

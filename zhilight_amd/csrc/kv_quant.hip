@@ -91,7 +91,7 @@ __global__ void k_kv_quant_store(const KvQuantParams p) {
         }
         val = ZT<DT>::to_f32(o);                            // the cache sees the rounded row
     }
-    if (place < 0) return;                                  // block-uniform
+    if (place < 0 || place >= len_buf) return;              // block-uniform; a slot outside the buffer is never written
     const float amax = zl_block_max(fabsf(val), red);
     const float bs = amax > 0.f ? 127.f / amax : 0.f;
     const uint8_t code = (uint8_t)(128.f + __builtin_rintf(val * bs));

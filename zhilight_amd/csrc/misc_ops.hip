@@ -188,8 +188,10 @@ __global__ void k_copy_to_rag_buffer2(const int32_t* __restrict__ placement, con
     const int b = blockIdx.x, len_q = gridDim.y, hkv = gridDim.z, head = blockIdx.z;
     const int xi = b * len_q + blockIdx.y;
     const int p = placement[xi];
-    if (p < 0) return;
     const int64_t len_buf = buf_lens[b];
+    // a slot outside the task's buffer is never written (the reference asserts pos_buf < len_buf,
+    // ragged_buffer_kernel.cu:194-222); negative = padded row
+    if (p < 0 || p >= len_buf) return;
     const size_t so = ((size_t)xi * hkv + head) * d;
     const size_t dof = bshd ? ((size_t)p * hkv + head) * d : ((size_t)head * len_buf + p) * d;
     for (int i = threadIdx.x * 8; i < d; i += blockDim.x * 8) {
@@ -208,8 +210,8 @@ __global__ void k_rope_scatter_decode(const float* __restrict__ cosv, const floa
     const int t = blockIdx.x, head = blockIdx.y, col = threadIdx.x, all = h + 2 * hkv, half = d / 2;
     if (col >= d) return;
     const uint16_t* src = qkv + ((size_t)t * all + head) * d;
-    const int p = placement[t];
     const int64_t len_buf = buf_lens[t];
+    const int p = placement[t] < len_buf ? placement[t] : -1;    // outside the buffer: dropped like a padded row
     if (head >= h + hkv) {
         if (p < 0) return;
         const int hk = head - h - hkv;

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
                     dst[half] = r1;
                 } else {
                     const int place = p.placement[m];
-                    if (place >= 0) {
+                    if (place >= 0 && place < p.buf_lens[m]) {
                         const int hk = head - p.h;
                         const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
                         uint16_t* dst = p.k_bufs[m] + row * p.d + dcol;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
                 }
             } else {
                 const int place = p.placement[m];
-                if (place >= 0) {
+                if (place >= 0 && place < p.buf_lens[m]) {
                     const int hk = head - p.h - p.hkv;
                     const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
                     uint16_t* dst = p.v_bufs[m] + row * p.d + dcol;

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
                 dst = p.q_out + ((size_t)m * p.h + head) * p.d + dcol;
             } else {
                 const int place = p.placement[m];
-                if (place >= 0) {
+                if (place >= 0 && place < p.buf_lens[m]) {
                     const bool is_v = head >= p.h + p.hkv;
                     const int hk = head - p.h - (is_v ? p.hkv : 0);
                     const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;

@@ -362,7 +362,10 @@ class Int8Linear:
         self.weight, s = ops.quant_calc_scale(w)
         self.scale = s.to(w.dtype)                       # functions::typecast(w_scale, dtype)
         if prefix + ".bias" in sd:
-            self.bias = _dev_t(sd[prefix + ".bias"], device)
+            # the reference concatenates the biases in fuse3 and adds them after the scale-back (linear.cpp:459-461,
+            # 631-632); the fused scale-back epilogues of this route carry none yet -- refuse instead of dropping it
+            raise ops.ZLError(f"{prefix}: bias tensors are not supported on the int8 route (checkpoints with q/k/v biases, "
+                              "e.g. Qwen2: use the GPTQ / fp16 routes)")
         return self
 
     @staticmethod
@@ -853,8 +856,13 @@ class LLaMA:
 
     def _llama3_rope(self):
         rs = self.cfg.rope_scaling
-        if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+        kind = rs.get("rope_type", rs.get("type")) if rs else None
+        if kind == "llama3":
             return (rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"])
+        if kind not in (None, "default"):
+            # the reference also knows "dynamic" and "yarn" (rotary_embedding.cu:131-670); running such a checkpoint with
+            # unscaled frequencies would be silently wrong
+            raise ops.ZLError(f"rope_scaling type {kind!r} is not supported on this path (supported: llama3)")
         return None
 
     def _prefill_mask(self, s, len_buf, pos0=0):

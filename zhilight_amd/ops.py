@@ -239,6 +239,11 @@ class W4MWeight:
         return cls(n, k, group_size, qw, meta, row_interleave)
 
 
+def decode_attn_split_len(b, num_kv_heads, max_len_buf):
+    """keys per split of the split-KV decode attention kernels for this batch geometry (zl_decode_attn_split_len)"""
+    return int(lib().zl_decode_attn_split_len(_i(b), _i(num_kv_heads), _i(max_len_buf)))
+
+
 def _attn_algo():
     """zl_decode_attn_ex algo: ZL_ATTN_MFMA=0 forces the VALU split-KV kernel (tests cover both)"""
     return 1 if os.environ.get("ZL_ATTN_MFMA", "1") == "0" else 0
