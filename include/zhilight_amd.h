@@ -411,6 +411,35 @@ int zl_quant_scale_back(const int32_t* c, const float* scale_x, const uint16_t* 
 int zl_quant_back_act_mul(const int32_t* a, const float* a_sx, const uint16_t* a_sy, const int32_t* b,
                           const float* b_sx, const uint16_t* b_sy, uint16_t* out, int64_t m, int64_t n,
                           int act, int dtype, zl_stream_t s);
+/* W4A8, int8 activations on W4 weights (W4_INT8_ALGO: the M > W4_A8_M_THRES branch of gptq_gemm_k_major,
+ * src/nn/quant/gptq/q_gemm_k_major.cu:1036-1073).  Load time, per row of the dequantised matrix W16 (N, K) fp16
+ * (zl_w4_dequant): scale[n] = amax / 127 in fp32 (Int4GPTQ::calc_w4a8_scale, linear.cpp:1101-1112), w8 =
+ * int8(nearbyintf(float(w) * (1.f / scale))) (KERNEL_dequant<int8_t, 1>, :843-905) -- bit-exact codes.  Forward:
+ * zl_quant_calc_scale(a) -> zl_int8_gemm_nt(a_q, w8) -> zl_quant_scale_back_f32 (quant_scale_back with the fp32 weight
+ * scale): y = half(float(acc) * sx[m] * sy[n]). */
+int zl_w4a8_weight_to_int8(const uint16_t* w16, int8_t* w8, float* scale, int64_t n, int64_t k, zl_stream_t s);
+int zl_quant_scale_back_f32(const int32_t* c, const float* scale_x, const float* scale_y, uint16_t* out, int64_t m, int64_t n,
+                            zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * a7  AWQ checkpoints in their on-disk layout (no repack): qweight (K, N/8) int32, qzeros (K/G, N/8) int32 (zero points
+ * as used), scales (K/G, N) fp16; nibble i of a word = column 8c + {0,2,4,6,1,3,5,7}[i].
+ * Replaces nn::awq::awq_dequantize / awq_gemm (src/nn/quant/awq/awq.h:10-25; dequantize_weights, gemm_kernels.cu:277-330;
+ * gemm_forward_4bit_cuda_m16nXk32 :32-275 + KERNEL_sum_dim0 :381-400; dequantize_s4_to_fp16x2, dequantize.cuh:45-112).
+ *   W16[k,n] = rn16(fp16(q - z) * s)                      (exact difference, ONE rounding)
+ *   zl_awq_gemm: 32-row K tiles dealt round-robin to split_k_iters splits, fp32 accumulation of x * W16 inside a split,
+ *   the split's partial rounded to FP16 (workspace: zl_awq_gemm_workspace_bytes = splits * M * N * 2 bytes), partials
+ *   summed in fp32 in split order, one rounding to fp16.  OC % 64 == 0 and group_size % 32 == 0 as in the reference
+ *   (:426-433).  Any M (8 rows per weight pass); the reference switches to dequantise + GEMM at M >= 256
+ *   (linear.cpp:1560-1565): zl_awq_dequantize + zl_transpose_2d + zl_gemm_nt.
+ * ---------------------------------------------------------------------------------------------- */
+int zl_awq_dequantize(const uint32_t* qweight, const uint32_t* qzeros, const uint16_t* scales, uint16_t* out /* (K,N) fp16 */,
+                      int64_t k, int64_t n, int64_t group_size, zl_stream_t s);
+int64_t zl_awq_gemm_workspace_bytes(int64_t m, int64_t n, int64_t split_k_iters);
+int zl_awq_gemm(const uint16_t* x, int64_t ldx, const uint32_t* qweight, const uint32_t* qzeros, const uint16_t* scales,
+                uint16_t* y, void* workspace, int64_t m, int64_t n, int64_t k, int64_t group_size, int64_t split_k_iters,
+                zl_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * a8-a11 fused for decode batches: Int8Linear::forward's GEMM + scale-back in ONE launch (1 <= M <= 32).
  * Replaces functions::Gemm int8 (src/nn/linear/linear.cpp:557-635) followed by quant_scale_back

@@ -1020,3 +1020,81 @@ void zlo_mqa_rag_buffer_quant_exact(const uint16_t* q, const int32_t* buf_lens, 
         mask_off += len_q * len;
     }
 }
+
+/* ==== native AWQ ======================================================================================
+ * On-disk AWQ "gemm" layout: qweight (K, N/8) int32, qzeros (K/G, N/8) int32, scales (K/G, N) fp16; nibble i of a word
+ * holds column 8c + order[i], order = {0,2,4,6,1,3,5,7} (the inverse of the extraction table {0,4,1,5,2,6,3,7},
+ * src/nn/quant/gptq/utils.cu:33,132; dequantize_s4_to_fp16x2, src/nn/quant/awq/dequantize.cuh:45-112, returns the eight
+ * values in column order).  Zero points are stored as used (no -1). */
+static const int kAwqOrder[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+
+/* dequantize_weights (src/nn/quant/awq/gemm_kernels.cu:277-330): W16[k,n] = rn16( fp16(q - z) * s ) -- the sub.f16x2 is
+ * exact on these small integers, the fma.rn.f16x2(., s, 0) rounds the product once */
+void zlo_awq_dequantize(const uint32_t* qweight, const uint32_t* qzeros, const uint16_t* scales, uint16_t* out,
+                        int64_t k, int64_t n, int64_t g) {
+    const int64_t n8 = n / 8;
+#pragma omp parallel for schedule(static)
+    for (int64_t kk = 0; kk < k; ++kk)
+        for (int64_t c = 0; c < n8; ++c) {
+            const uint32_t w = qweight[kk * n8 + c], z = qzeros[(kk / g) * n8 + c];
+            for (int i = 0; i < 8; ++i) {
+                const int col = (int)(8 * c + kAwqOrder[i]);
+                const int d = (int)((w >> (4 * i)) & 0xF) - (int)((z >> (4 * i)) & 0xF);
+                out[kk * n + col] = h_mul(zlo_f32_to_f16((float)d), scales[(kk / g) * n + col]);
+            }
+        }
+}
+
+/* awq_gemm (gemm_kernels.cu:404-468) = gemm_forward_4bit_cuda_m16nXk32 (:32-275) + KERNEL_sum_dim0 (:381-400):
+ * the 32-row K tiles are dealt round-robin to split_k_iters workgroups (tile t = i * split_k_iters + z, :114-117), each
+ * accumulates its products x * W16 in fp32 (mma.sync m16n8k16 f32 += f16 x f16: products exact, summed here in k order --
+ * the tensor core's internal order inside a k16 step is not specified) and writes its partial C as FP16 (:269); the
+ * partials are then added in fp32 in split order and rounded to fp16.  w16 = zlo_awq_dequantize's output. */
+void zlo_awq_gemm(const uint16_t* x, const uint16_t* w16, uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t split_k_iters) {
+    const int64_t tiles = (k + 31) / 32;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int64_t mm = 0; mm < m; ++mm)
+        for (int64_t nn = 0; nn < n; ++nn) {
+            float total = 0.f;
+            for (int64_t z = 0; z < split_k_iters; ++z) {
+                float acc = 0.f;
+                for (int64_t t = z; t < tiles; t += split_k_iters)
+                    for (int64_t kk = 32 * t; kk < 32 * t + 32 && kk < k; ++kk)
+                        acc += zlo_f16_to_f32(x[mm * k + kk]) * zlo_f16_to_f32(w16[kk * n + nn]);
+                total += zlo_f16_to_f32(zlo_f32_to_f16(acc));
+            }
+            y[mm * n + nn] = zlo_f32_to_f16(total);
+        }
+}
+
+/* exact product with the same W16 (fp64 accumulation, no intermediate rounding) */
+void zlo_awq_gemm_exact(const uint16_t* x, const uint16_t* w16, double* y, int64_t m, int64_t n, int64_t k) {
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int64_t mm = 0; mm < m; ++mm)
+        for (int64_t nn = 0; nn < n; ++nn) {
+            double acc = 0.0;
+            for (int64_t kk = 0; kk < k; ++kk) acc += (double)zlo_f16_to_f32(x[mm * k + kk]) * (double)zlo_f16_to_f32(w16[kk * n + nn]);
+            y[mm * n + nn] = acc;
+        }
+}
+
+/* ==== W4A8, int8 activations on W4 weights (the M > W4_A8_M_THRES branch of gptq_gemm_k_major,
+ * src/nn/quant/gptq/q_gemm_k_major.cu:1036-1073) ====================================================================
+ * load time (Int4GPTQ::calc_w4a8_scale, src/nn/linear/linear.cpp:1101-1112): scale[n] = max_k |W16[n,k]| / 127 in fp32;
+ * KERNEL_dequant<int8_t, 1> (q_gemm_k_major.cu:843-905): w8[n,k] = int8(nearbyintf(float(W16[n,k]) * (1.f / scale[n]))).
+ * forward: a_q, a_s = quant_calc_scale(a); acc = a_q . w8^T (int32, exact); y = half(float(acc) * a_s[m] * scale[n]). */
+void zlo_w4a8_weight_to_int8(const uint16_t* w16, int8_t* w8, float* scale, int64_t n, int64_t k) {
+#pragma omp parallel for schedule(static)
+    for (int64_t nn = 0; nn < n; ++nn) {
+        float amax = 0.f;
+        for (int64_t kk = 0; kk < k; ++kk) amax = fmaxf(amax, fabsf(zlo_f16_to_f32(w16[nn * k + kk])));
+        const float s = amax / 127.f;
+        scale[nn] = s;
+        const float r = 1.f / s;
+        for (int64_t kk = 0; kk < k; ++kk) w8[nn * k + kk] = (int8_t)nearbyintf(zlo_f16_to_f32(w16[nn * k + kk]) * r);
+    }
+}
+void zlo_quant_scale_back_f32(const int32_t* c, const float* sx, const float* sy, uint16_t* out, int64_t m, int64_t n) {
+    for (int64_t mm = 0; mm < m; ++mm)
+        for (int64_t nn = 0; nn < n; ++nn) out[mm * n + nn] = zlo_f32_to_f16((float)c[mm * n + nn] * sx[mm] * sy[nn]);
+}

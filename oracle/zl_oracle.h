@@ -158,6 +158,14 @@ void zlo_mqa_rag_buffer_quant_exact(const uint16_t* q, const int32_t* buf_lens, 
                                     const float* const* v_scales, const int8_t* mask, double* out, int64_t b,
                                     int64_t len_q, int64_t h, int64_t hkv, int64_t d, float scale, int bshd, int dtype);
 
+/* native AWQ (A.9) and W4A8 (q_gemm_k_major.cu:1036-1073) */
+void zlo_awq_dequantize(const uint32_t* qweight, const uint32_t* qzeros, const uint16_t* scales, uint16_t* out,
+                        int64_t k, int64_t n, int64_t g);
+void zlo_awq_gemm(const uint16_t* x, const uint16_t* w16, uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t split_k_iters);
+void zlo_awq_gemm_exact(const uint16_t* x, const uint16_t* w16, double* y, int64_t m, int64_t n, int64_t k);
+void zlo_w4a8_weight_to_int8(const uint16_t* w16, int8_t* w8, float* scale, int64_t n, int64_t k);
+void zlo_quant_scale_back_f32(const int32_t* c, const float* sx, const float* sy, uint16_t* out, int64_t m, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -418,3 +418,44 @@ def mqa_rag_buffer_quant(q, buf_lens, k_bufs, v_bufs, k_scales, v_scales, mask, 
                                          _ptr_array(v_scales), _p(mask), _p(out), _i(b), _i(len_q), _i(h), _i(hkv), _i(d),
                                          _f(scale), C.c_int(int(bshd)), C.c_int(dtype))
     return out
+
+
+# ---- native AWQ (A.9) and W4A8 ---------------------------------------------------------------------------------------
+def awq_dequantize(qweight, qzeros, scales, group_size):
+    """dequantize_weights: AWQ on-disk tensors -> W16 (K, N) fp16 bits, W16 = rn16(fp16(q - z) * s)"""
+    qweight, qzeros, scales = _c(qweight, np.uint32), _c(qzeros, np.uint32), _c(scales, np.uint16)
+    k, n = qweight.shape[0], qweight.shape[1] * 8
+    out = np.empty((k, n), np.uint16)
+    lib().zlo_awq_dequantize(_p(qweight), _p(qzeros), _p(scales), _p(out), _i(k), _i(n), _i(group_size))
+    return out
+
+
+def awq_gemm(x, w16, split_k_iters=32, exact=False):
+    """awq_gemm on the dequantised matrix w16 (K, N): split-K with fp16 partials (R) or the exact fp64 product"""
+    x, w16 = _c(x, np.uint16), _c(w16, np.uint16)
+    m, k = x.shape
+    n = w16.shape[1]
+    if exact:
+        y = np.empty((m, n), np.float64)
+        lib().zlo_awq_gemm_exact(_p(x), _p(w16), _p(y), _i(m), _i(n), _i(k))
+        return y
+    y = np.empty((m, n), np.uint16)
+    lib().zlo_awq_gemm(_p(x), _p(w16), _p(y), _i(m), _i(n), _i(k), _i(split_k_iters))
+    return y
+
+
+def w4a8_weight_to_int8(w16):
+    """calc_w4a8_scale + KERNEL_dequant<int8_t,1>: W16 (N, K) fp16 bits -> (w8 int8 (N, K), scale fp32 (N))"""
+    w16 = _c(w16, np.uint16)
+    n, k = w16.shape
+    w8, sc = np.empty((n, k), np.int8), np.empty((n,), np.float32)
+    lib().zlo_w4a8_weight_to_int8(_p(w16), _p(w8), _p(sc), _i(n), _i(k))
+    return w8, sc
+
+
+def quant_scale_back_f32(c, sx, sy):
+    c, sx, sy = _c(c, np.int32), _c(sx, np.float32), _c(sy, np.float32)
+    m, n = c.shape
+    out = np.empty((m, n), np.uint16)
+    lib().zlo_quant_scale_back_f32(_p(c), _p(sx), _p(sy), _p(out), _i(m), _i(n))
+    return out

@@ -83,6 +83,27 @@ def test_gptq_sym_and_dequant_and_gate(cx, oracle):
     assert np.abs(got - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
 
 
+def test_awq_and_w4a8_through_cpp(cx, oracle):
+    """nn::awq::awq_gemm / awq_dequantize (awq.h:10-25) and the W4A8 int8 branch of gptq_gemm_k_major with precomputed_w8"""
+    rng = np.random.default_rng(8)
+    k, n, g = 1024, 1280, 128
+    qw, qz, sc, _, _ = synth.awq_hf(rng, k, n, g)
+    w16 = oracle.awq_dequantize(qw, qz, sc, g)
+    assert np.array_equal(cx.awq_dequantize(qw, qz, sc.view(np.float16)).view(np.uint16), w16)
+    x = synth.act(rng, 5, k)
+    got = cx.awq_gemm(x, qw, qz, sc.view(np.float16), 32).astype(np.float64)
+    exact = oracle.awq_gemm(oracle.h2u(x), w16, exact=True)
+    assert np.abs(got - exact).max() <= 1e-3 * np.abs(exact).max()
+    gw, gz, gs = synth.gptq_hf(rng, k, n, g)
+    km = oracle.gptq_prepare_k_major(gw, gz, gs, g)
+    xb = synth.act(rng, 48, k, 2.0)
+    y, w8, ws = cx.gptq_w4a8(xb, km[0], km[1], km[2].view(np.float16))
+    rw8, rs = oracle.w4a8_weight_to_int8(oracle.gptq_dequant_k_major(*km))
+    assert np.array_equal(w8, rw8) and np.array_equal(ws, rs)
+    rq, rsx = oracle.quant_calc_scale(oracle.h2u(xb))
+    assert np.array_equal(y.view(np.uint16), oracle.quant_scale_back_f32(oracle.int8_gemm_nt(rq, rw8), rsx, rs))
+
+
 def test_gptq_load_transforms_bit_exact(cx, oracle):
     rng = np.random.default_rng(7)
     qw, qz, sc = synth.gptq_hf(rng, 1024, 256, 128)

@@ -98,3 +98,30 @@ def test_attention_oracle_flavours_agree(oracle):
     b = oracle.u2h(oracle.mqa_rag_buffer(q, np.array(lens, np.int32), kb, vb, mask, hkv, 0.088, num_split=4)).astype(np.float64)
     e = oracle.mqa_rag_buffer(q, np.array(lens, np.int32), kb, vb, mask, hkv, 0.088, exact=True)
     assert np.abs(a - e).max() < 2e-3 and np.abs(b - e).max() < 2e-3
+
+
+def test_awq_oracle_matches_the_format_definition_and_its_own_exact_product():
+    """native AWQ restatement: dequantize == (q - z) * s from the integers the AutoAWQ tensors were packed from
+    (one fp16 rounding), == the dense matrix the AWQ-as-exllama re-route dequantises (transposed); the split-K result with
+    fp16 partials stays within fp16-partial noise of the exact product."""
+    import synth
+    import zl_oracle as oracle
+    rng = np.random.default_rng(4)
+    k, n, g = 1056, 192, 32
+    qw, qz, sc, q, z = synth.awq_hf(rng, k, n, g)
+    w16 = oracle.awq_dequantize(qw, qz, sc, g)
+    d = (q.astype(np.int32) - np.repeat(z.astype(np.int32), g, axis=0)).astype(np.float16)
+    ref = (d.astype(np.float32) * np.repeat(sc.view(np.float16), g, axis=0).astype(np.float32)).astype(np.float16)
+    assert np.array_equal(w16, ref.view(np.uint16))
+    tr = lambda a: np.ascontiguousarray(a.T)   # noqa: E731
+    km = (tr(oracle.awq_shuffle(qw, True)), tr(oracle.gptq_q4_to_q8(oracle.awq_un_shuffle(qz))), tr(sc))
+    assert np.array_equal(oracle.gptq_dequant_k_major(*km), tr(w16))
+    x = synth.act(rng, 3, k)
+    r = oracle.u2h(oracle.awq_gemm(oracle.h2u(x), w16, 32)).astype(np.float64)
+    e = oracle.awq_gemm(oracle.h2u(x), w16, exact=True)
+    assert np.abs(r - e).max() <= 2e-3 * np.sqrt((e ** 2).mean())
+    # W4A8: codes bounded, scale = amax / 127, round trip within half a code
+    w8, s = oracle.w4a8_weight_to_int8(tr(w16))
+    wf = oracle.u2h(tr(w16)).astype(np.float32)
+    assert np.abs(w8).max() == 127 and np.allclose(s, np.abs(wf).max(axis=1) / 127.0, rtol=1e-6)
+    assert np.abs(w8.astype(np.float32) * s[:, None] - wf).max() <= 0.5001 * s.max()

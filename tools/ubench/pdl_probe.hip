@@ -30,9 +30,9 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 // acquire fence (one lane) + plain loads (the guide's R1 form).
 __global__ __launch_bounds__(kT, 2) void k_stage(const u4* __restrict__ w, int items_per_wave, const unsigned short* vin,
                                                  unsigned short* vout, int stage, const Ctl* wait_ctl, Ctl* my_ctl,
-                                                 int overlapped, Err* err, unsigned* sink) {
+                                                 int overlapped, Err* err, unsigned* sink, int stamp = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) atomicMin(&err->t_start[stage & 63], wall_clock64());
+    if (stamp && threadIdx.x == 0) atomicMin(&err->t_start[stage & 63], wall_clock64());
     const u4* src = w + ((size_t)(blockIdx.x * 8 + wave) * items_per_wave) * 64 + lane;   // 1 KiB items, contiguous per wave
     u4 ring[kRing];
     int issued = 0;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kT, 2) void k_stage(const u4* __restrict__ w, int i
             if (old + 1 == members) __hip_atomic_fetch_add(&my_ctl->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (threadIdx.x == 0) atomicMax(&err->t_end[stage & 63], wall_clock64());
+    if (stamp && threadIdx.x == 0) atomicMax(&err->t_end[stage & 63], wall_clock64());
 }
 
 int main(int argc, char** argv) {
@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
     Ctl* ctl; CK(hipMalloc(&ctl, sizeof(Ctl) * stages));
     Err* err; CK(hipMalloc(&err, sizeof(Err)));
     unsigned* sink; CK(hipMalloc(&sink, 4096));
-    if (argc > 2) {   // eager two-stream run of 8 stages with a timeline (100 MHz ticks -> us)
+    if (argc == 3) {   // eager two-stream run of 8 stages with a timeline (100 MHz ticks -> us)
         const int ns = 8, ipw = 14;
         std::vector<Err> hz(1);
         CK(hipMemset(err, 0, sizeof(Err)));
@@ -124,13 +124,39 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         for (int st = 0; st < ns; ++st)
             hipLaunchKernelGGL(k_stage, dim3(grid), dim3(kT), 0, (st & 1) ? s1 : s0, w[st % nbuf], ipw, vec + (st & 1) * kVec,
-                               vec + ((st + 1) & 1) * kVec, st, st > 0 ? ctl + st - 1 : nullptr, ctl + st, 1, err, sink);
+                               vec + ((st + 1) & 1) * kVec, st, st > 0 ? ctl + st - 1 : nullptr, ctl + st, 1, err, sink, 1);
         CK(hipDeviceSynchronize());
         Err h; CK(hipMemcpy(&h, err, sizeof(h), hipMemcpyDeviceToHost));
         printf("eager two-stream: stale=%u expired=%u\n", h.stale, h.expired);
         for (int st = 0; st < ns; ++st)
             printf("  stage %d: start %8.2f us  end %8.2f us  expired WGs %u\n", st, (h.t_start[st] - h.t_start[0]) / 100.0,
                    (h.t_end[st] - h.t_start[0]) / 100.0, h.exp_stage[st]);
+        return 0;
+    }
+    if (argc > 3) {   // eager launches from this host thread: one stream with kernel boundaries vs two streams + completion words
+        const int ns = 400;
+        Ctl* ctl2; CK(hipMalloc(&ctl2, sizeof(Ctl) * ns));
+        for (int ipw : {4, 8, 14, 28}) for (int mode = 0; mode < 2; ++mode) {
+            float best = 1e9f;
+            Err h{};
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipMemset(ctl2, 0, sizeof(Ctl) * ns)); CK(hipMemset(vec, 0, kVec * 4)); CK(hipMemset(err, 0, sizeof(Err)));
+                CK(hipDeviceSynchronize());
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                CK(hipEventRecord(e0, s0));
+                if (mode) { hipEvent_t f; CK(hipEventCreate(&f)); CK(hipEventRecord(f, s0)); CK(hipStreamWaitEvent(s1, f, 0)); }
+                for (int st = 0; st < ns; ++st)
+                    hipLaunchKernelGGL(k_stage, dim3(grid), dim3(kT), 0, (mode && (st & 1)) ? s1 : s0, w[st % nbuf], ipw, vec + (st & 1) * kVec,
+                                       vec + ((st + 1) & 1) * kVec, st, (mode && st > 0) ? ctl2 + st - 1 : nullptr, ctl2 + st, mode, err, sink, 0);
+                if (mode) { hipEvent_t j; CK(hipEventCreate(&j)); CK(hipEventRecord(j, s1)); CK(hipStreamWaitEvent(s0, j, 0)); }
+                CK(hipEventRecord(e1, s0)); CK(hipDeviceSynchronize());
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                best = ms < best ? ms : best;
+                CK(hipMemcpy(&h, err, sizeof(h), hipMemcpyDeviceToHost));
+            }
+            printf("eager %3d KiB/WG %s: %6.2f us/stage  stale=%u expired=%u maxspin=%u\n", ipw * 8, mode ? "two streams + flags" : "one stream          ",
+                   best * 1e3 / ns, h.stale, h.expired, h.maxspin);
+        }
         return 0;
     }
     for (int ipw : {4, 8, 14, 28}) {                        // items (KiB) per wave: 32 / 64 / 112 / 224 KiB per workgroup
@@ -145,7 +171,8 @@ int main(int argc, char** argv) {
                 hipStream_t s = (mode && (st & 1)) ? s1 : s0;
                 // stage st reads buffer st & 1 (every element == st after the first lap ... see below) and writes the other
                 hipLaunchKernelGGL(k_stage, dim3(grid), dim3(kT), 0, s, w[st % nbuf], ipw, vec + (st & 1) * kVec,
-                                   vec + ((st + 1) & 1) * kVec, st, (mode && st > 0) ? ctl + st - 1 : nullptr, ctl + st, mode, err, sink);
+                                   vec + ((st + 1) & 1) * kVec, st, (mode && st > 0) ? ctl + st - 1 : nullptr, ctl + st, mode, err, sink,
+                                   (mode == 1 && ipw == 14) ? 1 : 0);
             }
             if (mode) { CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0)); }
             CK(hipStreamEndCapture(s0, &g));

@@ -36,6 +36,8 @@ SYMBOLS = [
     "zl_quant_calc_scale", "zl_rmsnorm_quant", "zl_int8_gemm_nt", "zl_quant_scale_back",
     "zl_quant_back_act_mul", "zl_quant_scale_back3", "zl_quant_back_element_add_scale", "zl_quant_back_transpose",
     "zl_quant_back_copy_to_buffer",
+    "zl_w4a8_weight_to_int8", "zl_quant_scale_back_f32",
+    "zl_awq_dequantize", "zl_awq_gemm_workspace_bytes", "zl_awq_gemm",
 ]
 
 
@@ -71,6 +73,7 @@ def lib():
         l.zl_argmax_workspace_bytes.restype = C.c_int64
         l.zl_w8m_bytes.restype = C.c_int64
         l.zl_w4a16_scratch_bytes.restype = C.c_int64
+        l.zl_awq_gemm_workspace_bytes.restype = C.c_int64
         _lib = l
     return _lib
 

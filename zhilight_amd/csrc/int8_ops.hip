@@ -287,6 +287,33 @@ __global__ void k_scale_back(const int32_t* __restrict__ c, const float* __restr
     }
 }
 
+// ---- W4A8 (int8 activations on W4 weights: the M > W4_A8_M_THRES branch of gptq_gemm_k_major, q_gemm_k_major.cu:1036-1073)
+// load time: row n of the dequantised matrix W16 -> scale[n] = amax / 127 (fp32, Int4GPTQ::calc_w4a8_scale,
+// linear.cpp:1101-1112) and w8 = int8(nearbyintf(float(w) * (1.f / scale))) (KERNEL_dequant<int8_t, 1>, :843-905)
+__global__ __launch_bounds__(256) void k_w4a8_rows_to_int8(const uint16_t* __restrict__ w16, int8_t* __restrict__ w8,
+                                                           float* __restrict__ scale, int64_t k) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const uint16_t* src = w16 + row * k;
+    float amax = 0.f;
+    for (int64_t i = threadIdx.x; i < k; i += blockDim.x) amax = fmaxf(amax, fabsf(ZT<ZL_F16>::to_f32(src[i])));
+    amax = zl_block_max(amax, red);
+    const float sc = amax / 127.f;
+    if (threadIdx.x == 0) scale[row] = sc;
+    const float r = 1.f / sc;
+    for (int64_t i = threadIdx.x; i < k; i += blockDim.x) w8[row * k + i] = (int8_t)nearbyintf(ZT<ZL_F16>::to_f32(src[i]) * r);
+}
+// forward: y = half(float(acc) * sx[m] * sy[n]) with the fp32 per-row weight scale (quant_scale_back on a float scale_y)
+__global__ void k_scale_back_f32(const int32_t* __restrict__ c, const float* __restrict__ sx, const float* __restrict__ sy,
+                                 uint16_t* __restrict__ out, int n) {
+    const int r = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < n) {
+        const size_t pos = (size_t)r * n + col;
+        out[pos] = ZT<ZL_F16>::from_f32((float)c[pos] * sx[r] * sy[col]);
+    }
+}
+
 template <int DT>
 __global__ void k_back_act_mul(const int32_t* __restrict__ a, const float* __restrict__ asx,
                                const uint16_t* __restrict__ asy, const int32_t* __restrict__ b,
@@ -465,6 +492,22 @@ int zl_quant_scale_back(const int32_t* c, const float* scale_x, const uint16_t* 
     ZL_DT_SWITCH(dtype,
         hipLaunchKernelGGL(k_scale_back<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, c, scale_x, scale_y, out, (int)n),
         hipLaunchKernelGGL(k_scale_back<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, c, scale_x, scale_y, out, (int)n))
+    return zl_launch_status();
+}
+
+int zl_w4a8_weight_to_int8(const uint16_t* w16, int8_t* w8, float* scale, int64_t n, int64_t k, zl_stream_t s) {
+    ZL_CHECK_ARG(w16 && w8 && scale && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(n <= 0x7fffffff, ZL_ELIMIT);
+    hipLaunchKernelGGL(k_w4a8_rows_to_int8, dim3((unsigned)n), dim3(256), 0, (hipStream_t)s, w16, w8, scale, k);
+    return zl_launch_status();
+}
+
+int zl_quant_scale_back_f32(const int32_t* c, const float* scale_x, const float* scale_y, uint16_t* out, int64_t m, int64_t n,
+                            zl_stream_t s) {
+    ZL_CHECK_ARG(c && scale_x && scale_y && out && m > 0 && n > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(m <= 65535, ZL_ELIMIT);
+    hipLaunchKernelGGL(k_scale_back_f32, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, (hipStream_t)s, c, scale_x,
+                       scale_y, out, (int)n);
     return zl_launch_status();
 }
 

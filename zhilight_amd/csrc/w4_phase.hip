@@ -421,6 +421,15 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
     };
     // one ring step (same order as k_w4a16_mfma: dequantise, scale-accumulate the previous item, MFMAs back to back)
     auto step = [&](int slot, int pslot, int rp, int r_issue, int ph) {
+#ifdef ZL_EXP_NOCOMPUTE   // ablation: the stream structure alone (no LDS fragment reads, no dequant, no MFMA)
+        {
+            const uint32_t v = wq[slot].x ^ wq[slot].y ^ wq[slot].z ^ wq[slot].w ^ mt[slot];
+            acc[rp][0][0] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, acc[rp][0][0]) ^ v);
+            issue(pslot, r_issue);
+            (void)ph;
+            return;
+        }
+#endif
         const uint16_t* xb = xl + (ph & 1) * kBuf;
         uint4 bv[MB][4];
 #pragma unroll
@@ -428,6 +437,32 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
 #pragma unroll
             for (int t = 0; t < 4; ++t) bv[b][t] = *reinterpret_cast<const uint4*>(xb + b * 16 * kXS + 32 * t);
         }
+#ifdef ZL_EXP_NODEQ       // ablation: LDS reads + MFMAs kept, the nibble extraction / zero subtraction dropped
+        {
+            h8 a0[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint4 u = make_uint4(wq[slot].x + t, wq[slot].y, wq[slot].z, wq[slot].w ^ mt[slot]);
+                a0[t] = __builtin_bit_cast(h8, u);
+            }
+            finish_prev(rp, pslot);
+            __builtin_amdgcn_sched_barrier(0);
+            f4 accg0[MB];
+#pragma unroll
+            for (int b = 0; b < MB; ++b) accg0[b] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int b = 0; b < MB; ++b)
+                    accg0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, bv[b][t]), a0[t], accg0[b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < MB; ++b) accg_prev[b] = accg0[b];
+            issue(pslot, r_issue);
+            return;
+        }
+#endif
         const hv2 z1 = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(mt[slot], mt[slot], 0x03020302u));
         const hv2 c960 = {(_Float16)960.f, (_Float16)960.f};
         const hv2 z16 = z1 + c960;
@@ -464,6 +499,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
 #ifdef ZL_PHASE_PROBE
             if (k == 0 && s == 0) ZL_PPROBE(3);
 #endif
+#ifndef ZL_EXP_NOPHASE     // ablation: no per-phase staging / barrier
             if (r == R - 1) {
                 if (php + 1 < P) {                    // workgroup-uniform
                     if constexpr (NORM) store_norm(php + 1);
@@ -471,6 +507,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
                     __syncthreads();
                 }
             }
+#endif
         }
     };
     if (total >= BODY) {

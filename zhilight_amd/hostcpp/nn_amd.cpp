@@ -95,8 +95,25 @@ static std::tuple<Tensor, Tensor, Tensor> unpack(const Context& ctx, const Tenso
     return {q, z, s};
 }
 
+void calc_w4a8_scale(const Context& ctx, Tensor& q_weight, const Tensor& qzeros, const Tensor& scales) {
+    Tensor w16 = dequant_k_major(ctx, q_weight, qzeros, scales, 0);
+    Tensor w8 = ctx.tensor(w16.shape(), DataType::kInt8), sc = ctx.tensor({w16.size(0)}, DataType::kFloat);
+    zl_check(zl_w4a8_weight_to_int8(u16(w16), w8.data<int8_t>(), sc.data<float>(), w16.size(0), w16.size(1), st_of(ctx)),
+             "calc_w4a8_scale");
+    q_weight.set_quant_scale(sc);
+}
+
 Tensor dequant_k_major(const Context& ctx, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales, int out_type) {
-    BM_ASSERT_EQ(out_type, 0, "dequant_k_major: half output only");
+    if (out_type == 1) {     // W4A8: int8 codes with the row scale calc_w4a8_scale left on q_weight
+        BM_ASSERT(q_weight.quant_scale, "dequant_k_major(out_type 1) needs q_weight.quant_scale (calc_w4a8_scale)");
+        Tensor w16 = dequant_k_major(ctx, q_weight, qzeros, scales, 0);
+        Tensor w8 = ctx.tensor(w16.shape(), DataType::kInt8), sc = ctx.tensor({w16.size(0)}, DataType::kFloat);
+        zl_check(zl_w4a8_weight_to_int8(u16(w16), w8.data<int8_t>(), sc.data<float>(), w16.size(0), w16.size(1), st_of(ctx)),
+                 "dequant_k_major to int8");
+        w8.set_quant_scale(*q_weight.quant_scale);
+        return w8;
+    }
+    BM_ASSERT_EQ(out_type, 0, "dequant_k_major: out_type 0 (half) or 1 (int8)");
     if (is_packed(scales)) {
         auto raw = unpack(ctx, q_weight, scales);
         return dequant_k_major(ctx, std::get<0>(raw), std::get<1>(raw), std::get<2>(raw), 0);
@@ -119,11 +136,23 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a, const Tensor& q_we
                          Tensor* output, const Tensor* precomputed_w8) {
     BM_ASSERT(a.dtype() == DataType::kHalf, "A must be half");                       // q_gemm_k_major.cu:989
     BM_ASSERT(q_perm.numel() == 0 && rev_perm.numel() == 0, "act-order: permute the input first (permute_input) and pass empty perms");
-    BM_ASSERT(!cache_only && !precomputed_w8, "W4A8 pre-conversion is not part of this path");
+    BM_ASSERT(!cache_only, "cache_only (layer_cache warm-up) has no meaning here: pass precomputed_w8");
     BM_ASSERT_EQ(q_weight.ndim(), 2, "q_weight is not 2d");
     const int64_t n = q_weight.size(0), k = q_weight.size(1) * 8;
     BM_ASSERT_EQ((int64_t)a.size(-1), k, "size K mismatch");
     const int64_t m = rows_of(a);
+    if (precomputed_w8 && precomputed_w8->numel() && m > 40 && !bias && n > 1024) {
+        // W4A8 INT8 branch (q_gemm_k_major.cu:1036-1073): int8 rows x int8 codes -> int32, scaled back with the fp32 row scale
+        BM_ASSERT(precomputed_w8->quant_scale, "precomputed_w8 carries no scale");
+        Tensor aq = int8_op::quant_calc_scale(ctx, a);
+        Tensor acc = int8_op::int8_gemm_nt(ctx, aq, *precomputed_w8);
+        std::vector<size_t> osh = a.shape();
+        osh.back() = n;
+        Tensor o = output ? *output : ctx.tensor(osh, DataType::kHalf);
+        zl_check(zl_quant_scale_back_f32(acc.data<int32_t>(), aq.quant_scale->data<float>(), precomputed_w8->quant_scale->data<float>(),
+                                         u16m(o), m, n, st_of(ctx)), "gptq_gemm_k_major (W4A8)");
+        return o;
+    }
     std::vector<size_t> oshape = a.shape();
     oshape.back() = n;
     Tensor out = output ? *output : ctx.tensor(oshape, DataType::kHalf);
@@ -178,6 +207,29 @@ Tensor gemm_fuse_gate_in(const Context& ctx, const Tensor& a, const Tensor& q_we
 }
 
 }  // namespace gptq
+
+namespace awq {
+Tensor awq_dequantize(const Context& ctx, Tensor _kernel, Tensor _scaling_factors, Tensor _zeros, int, int, int) {
+    BM_ASSERT_EQ(_kernel.ndim(), 2, "kernel is not 2d");
+    const int64_t k = _kernel.size(0), n = _kernel.size(1) * 8, g = k / _scaling_factors.size(0);
+    Tensor out = ctx.tensor({(size_t)k, (size_t)n}, DataType::kHalf);
+    zl_check(zl_awq_dequantize(_kernel.data<uint32_t>(), _zeros.data<uint32_t>(), u16(_scaling_factors), u16m(out), k, n, g, st_of(ctx)),
+             "awq_dequantize");
+    return out;
+}
+Tensor awq_gemm(const Context& ctx, Tensor _in_feats, Tensor _kernel, Tensor _scaling_factors, Tensor _zeros, size_t split_k_iters) {
+    BM_ASSERT(_in_feats.dtype() == DataType::kHalf, "in_feats must be half");
+    const int64_t m = _in_feats.size(0), k = _in_feats.size(1), n = _kernel.size(1) * 8, g = k / _scaling_factors.size(0);
+    BM_ASSERT_EQ((int64_t)_kernel.size(0), k, "size K mismatch");
+    if (n % 64 != 0) throw std::invalid_argument("OC is not multiple of cta_N = 64");            // the reference's own checks
+    if (g % 32 != 0) throw std::invalid_argument("Group size should be a multiple of 32");
+    Tensor ws = ctx.tensor({(size_t)zl_awq_gemm_workspace_bytes(m < 8 ? m : 8, n, (int64_t)split_k_iters)}, DataType::kInt8);
+    Tensor out = ctx.tensor({(size_t)m, (size_t)n}, DataType::kHalf);
+    zl_check(zl_awq_gemm(u16(_in_feats), _in_feats.stride(0), _kernel.data<uint32_t>(), _zeros.data<uint32_t>(), u16(_scaling_factors),
+                         u16m(out), ws.data(), m, n, k, g, (int64_t)split_k_iters, st_of(ctx)), "awq_gemm");
+    return out;
+}
+}  // namespace awq
 
 // ---- attention -----------------------------------------------------------------------------------------------------
 AttentionWorkspace get_mqa_workspace(const Context& ctx, const Tensor& batch_q, int max_len_buf, bool) {

@@ -50,8 +50,12 @@ struct PackedW4 {
 PackedW4 amd_pack_k_major(const core::Context& ctx, const core::Tensor& q_weight, const core::Tensor& qzeros,
                           const core::Tensor& scales, bool row_interleave = false);
 
+// out_type 0: W16 (N, K) half.  out_type 1 (W4A8, q_gemm_k_major.cu:907-952 with KERNEL_dequant<int8_t,1>): int8 codes
+// (N, K) = nearbyintf(W16 / scale[n]); like the reference it needs q_weight.quant_scale, set by calc_w4a8_scale below
+// (Int4GPTQ::calc_w4a8_scale, linear.cpp:1101-1112: scale[n] = max_k |W16[n,k]| / 127, float).
 core::Tensor dequant_k_major(const core::Context& ctx, const core::Tensor& q_weight, const core::Tensor& qzeros,
                              const core::Tensor& scales, int out_type = 0);
+void calc_w4a8_scale(const core::Context& ctx, core::Tensor& q_weight, const core::Tensor& qzeros, const core::Tensor& scales);
 
 core::Tensor gptq_gemm_k_major(const core::Context& ctx,
                                const core::Tensor& a,          // (M, K)
@@ -68,6 +72,15 @@ core::Tensor gemm_fuse_gate_in(const core::Context& ctx, const core::Tensor& a, 
                                const core::Tensor& q_weight2, const core::Tensor& qzeros2, const core::Tensor& scales2,
                                const core::Tensor& rev_perm2, bool sym);
 }  // namespace gptq
+
+namespace awq {
+// AWQ tensors as stored (src/nn/quant/awq/awq.h:10-25): _kernel (K, N/8) int32, _scaling_factors (K/G, N) half,
+// _zeros (K/G, N/8) int32.  thx / thy are launch shapes of the CUDA kernel and ignored here.
+core::Tensor awq_dequantize(const core::Context& ctx, core::Tensor _kernel, core::Tensor _scaling_factors, core::Tensor _zeros,
+                            int split_k_iters, int thx, int thy);
+core::Tensor awq_gemm(const core::Context& ctx, core::Tensor _in_feats, core::Tensor _kernel, core::Tensor _scaling_factors,
+                      core::Tensor _zeros, size_t split_k_iters);
+}  // namespace awq
 
 // ---- attention -----------------------------------------------------------------------------------------------------
 struct AttentionWorkspace {

@@ -118,6 +118,20 @@ PYBIND11_MODULE(zl_internals, m) {
             Tensor z8 = nn::gptq::q4_to_q8(*c.ctx, z);
             return py::make_tuple(c.down(q, "uint32"), c.down(z8, "uint8"));
         })
+        .def("awq_gemm", [](PyCtx& c, py::array x, py::array qweight, py::array qzeros, py::array scales, size_t split_k_iters) {
+            return c.down(nn::awq::awq_gemm(*c.ctx, c.up(x), c.up(qweight), c.up(scales), c.up(qzeros), split_k_iters), "float16");
+        })
+        .def("awq_dequantize", [](PyCtx& c, py::array qweight, py::array qzeros, py::array scales) {
+            return c.down(nn::awq::awq_dequantize(*c.ctx, c.up(qweight), c.up(scales), c.up(qzeros), 0, 0, 0), "float16");
+        })
+        .def("gptq_w4a8", [](PyCtx& c, py::array x, py::array qw, py::array qz, py::array sc) {
+            // W4_INT8_ALGO: scale + int8 codes at load (calc_w4a8_scale, dequant_k_major(out_type 1)), then the M > 40 branch
+            Tensor tq = c.up(qw), tz = c.up(qz), ts = c.up(sc);
+            nn::gptq::calc_w4a8_scale(*c.ctx, tq, tz, ts);
+            Tensor w8 = nn::gptq::dequant_k_major(*c.ctx, tq, tz, ts, 1);
+            Tensor y = nn::gptq::gptq_gemm_k_major(*c.ctx, c.up(x), tq, tz, ts, Tensor(), Tensor(), nullptr, false, false, nullptr, &w8);
+            return py::make_tuple(c.down(y, "float16"), c.down(w8, "int8"), c.down(*w8.quant_scale, "float32"));
+        })
         // ---- attention / rope / scatter
         .def("multi_query_attention_rag_buffer", [](PyCtx& c, py::array q, py::array buf_lens, py::list kbufs, py::list vbufs, py::array mask,
                                                      float scale, int max_len_buf, int m_query, bool bf16) {

@@ -245,6 +245,58 @@ class Int4GPTQ:
         return ops.w4_linear(x, self.weight, bias=self.bias, **kw)
 
 
+class AWQLinear:
+    """nn::Linear with the AWQ implementation (src/nn/linear/linear.cpp:1400-1600, what an AWQ checkpoint runs on when
+    AWQ_USE_EXLLAMA is not set): the checkpoint tensors stay in their on-disk layout -- qweight (K, N/8), qzeros (K/G, N/8),
+    scales (K/G, N) -- and forward is nn::awq::awq_gemm below 256 rows (split-K 32, fp16 partials) or awq_dequantize + a
+    fp32-accumulating GEMM from 256 rows on (linear.cpp:1560-1565).  The format-faithful route; the default AWQ route
+    (AWQ_USE_EXLLAMA=1, Int4GPTQ above) re-tiles the same tensors once for the matrix-core kernels."""
+
+    def __init__(self, name, dim_in, dim_out, quant: QuantConfig):
+        self.name, self.dim_in, self.dim_out, self.quant = name, dim_in, dim_out, quant
+        self.qweight = self.qzeros = self.scales = self.bias = None
+        self.perm = None
+
+    @property
+    def weight(self):
+        return self
+
+    def nbytes(self):
+        return self.qweight.numel() * 4 + self.qzeros.numel() * 4 + self.scales.numel() * 2
+
+    def load_state_dict(self, sd, prefix, device):
+        self.qweight = _dev_t(sd[prefix + ".qweight"], device, torch.int32).contiguous()
+        self.qzeros = _dev_t(sd[prefix + ".qzeros"], device, torch.int32).contiguous()
+        self.scales = _dev_t(sd[prefix + ".scales"], device, torch.float16).contiguous()
+        if self.qweight.shape != (self.dim_in, self.dim_out // 8):
+            raise ops.ZLError(f"{prefix}: qweight shape {tuple(self.qweight.shape)} != {(self.dim_in, self.dim_out // 8)}")
+        if prefix + ".bias" in sd:
+            self.bias = _dev_t(sd[prefix + ".bias"], device, torch.float16)
+        return self
+
+    def pack(self, row_interleave=False):
+        return self
+
+    def forward(self, x, out=None, residual=None, epilogue=0, **kw):
+        if kw.get("norm_weight") is not None:
+            raise ops.ZLError("AWQ linears take an already normalised input")
+        g = self.quant.group_size
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.shape[0] < 256:
+            y = ops.awq_gemm(x2, self.qweight, self.qzeros, self.scales, g)
+        else:
+            w16 = ops.transpose_2d(ops.awq_dequantize(self.qweight, self.qzeros, self.scales, g))      # (N, K)
+            y = ops.gemm_nt(x2, w16)
+        if self.bias is not None:
+            y = y + self.bias                                # add_bias in T arithmetic
+        if epilogue & ops.EPI_RESIDUAL:
+            return ops.element_add_scale(residual, y, 1.0, True, out=out if out is not None else residual)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+
 class NormalLinear:
     """nn::Linear with the NormalLinear implementation (src/nn/linear/linear.cpp:140-428): y = T(x . W^T + bias),
     fp32 accumulation.  Up to 4 rows the wave-per-row GEMV (HBM speed, optional fused RMSNorm), above the MFMA
@@ -519,6 +571,19 @@ class EncoderLayer:
                 if l.bias is not None and mode == "row" and tp.rank != 0:
                     l.bias = None                     # added once, by rank 0's partial sum
             return l
+        if q.awq and os.environ.get("AWQ_USE_EXLLAMA", "1") == "0":
+            # the reference's native AWQ route: every linear on its own, tensors as stored (no q/k/v or gate/up fusion)
+            if tp:
+                raise ops.ZLError("the native AWQ route is not wired into tensor parallelism (use AWQ_USE_EXLLAMA=1)")
+
+            def alin(sub, din, dout):
+                return AWQLinear(prefix + "." + sub, din, dout, q).load_state_dict(sd, prefix + "." + sub, device)
+            self.unfused = [alin("attn.project_q", c.dim_model, hd), alin("attn.project_k", c.dim_model, kvd),
+                            alin("attn.project_v", c.dim_model, kvd), alin("ff.w_in", c.dim_model, c.dim_ff),
+                            alin("ff.w_gated", c.dim_model, c.dim_ff)]
+            self.attn_out = alin("attn.attn_out", hd, c.dim_model)
+            self.w_out = alin("ff.w_out", c.dim_ff, c.dim_model)
+            return
         kv_part = getattr(self, "kv_part", None)
         pq, pk, pv = (lin("attn.project_q", c.dim_model, hd, "column"), lin("attn.project_k", c.dim_model, kvd, "column", kv_part),
                       lin("attn.project_v", c.dim_model, kvd, "column", kv_part))

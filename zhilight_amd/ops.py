@@ -871,3 +871,65 @@ def quant_back_copy_to_buffer(src, scale_x, scale_y, placement, dst):
                                              _i(len_kv), _i(h), _i(d), _i(len_buf), _i(src_stride), _i(dst_stride),
                                              _i(place_stride), C.c_int(_dt(dst)), _stream()), "quant_back_copy_to_buffer")
     return dst
+
+
+# --------------------------------------------------------------------------------------------------
+# a7  AWQ checkpoints in their on-disk layout (no repack) and f3  W4A8
+# --------------------------------------------------------------------------------------------------
+def awq_dequantize(qweight, qzeros, scales, group_size):
+    """nn::awq::awq_dequantize (src/nn/quant/awq/gemm_kernels.cu:277-330): (K, N/8) int32 -> W16 (K, N) fp16."""
+    _chk_cuda(qweight, qzeros, scales)
+    k, n = qweight.shape[0], qweight.shape[1] * 8
+    out = torch.empty((k, n), dtype=torch.float16, device=qweight.device)
+    check(lib().zl_awq_dequantize(_p(qweight), _p(qzeros), _p(scales), _p(out), _i(k), _i(n), _i(group_size), _stream()),
+          "awq_dequantize")
+    return out
+
+
+def awq_gemm(x, qweight, qzeros, scales, group_size, split_k_iters=32, out=None):
+    """nn::awq::awq_gemm (gemm_kernels.cu:404-468) on the AWQ tensors as stored: split-K with fp16 partials summed in fp32."""
+    if x.dtype != torch.float16:
+        raise ZLError("in_feats must be half")
+    _chk_cuda(x, qweight, qzeros, scales)
+    x2 = x.reshape(-1, x.shape[-1])
+    m, k = x2.shape
+    n = qweight.shape[1] * 8
+    if qweight.shape[0] != k:
+        raise ZLError("size K mismatch")
+    if n % 64:
+        raise ZLError("OC is not multiple of cta_N = 64")
+    if group_size % 32:
+        raise ZLError("Group size should be a multiple of 32")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float16, device=x.device)
+    ws = torch.empty(int(lib().zl_awq_gemm_workspace_bytes(_i(min(m, 8)), _i(n), _i(split_k_iters))), dtype=torch.uint8, device=x.device)
+    check(lib().zl_awq_gemm(_p(x2), _i(x2.stride(0)), _p(qweight), _p(qzeros), _p(scales), _p(out), _p(ws), _i(m), _i(n), _i(k),
+                            _i(group_size), _i(split_k_iters), _stream()), "awq_gemm")
+    return out
+
+
+def w4a8_weight_to_int8(w16):
+    """Int4GPTQ::calc_w4a8_scale + dequant_k_major(out_type 1): W16 (N, K) fp16 -> (w8 int8 (N, K), scale fp32 (N))."""
+    _chk_cuda(w16)
+    n, k = w16.shape
+    w8 = torch.empty((n, k), dtype=torch.int8, device=w16.device)
+    sc = torch.empty((n,), dtype=torch.float32, device=w16.device)
+    check(lib().zl_w4a8_weight_to_int8(_p(w16), _p(w8), _p(sc), _i(n), _i(k), _stream()), "w4a8_weight_to_int8")
+    return w8, sc
+
+
+def quant_scale_back_f32(c, sx, sy, out=None):
+    """quant_scale_back with an fp32 per-row weight scale (the W4A8 forward): half(float(c) * sx[m] * sy[n])"""
+    _chk_cuda(c, sx, sy)
+    m, n = c.shape
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float16, device=c.device)
+    check(lib().zl_quant_scale_back_f32(_p(c), _p(sx), _p(sy), _p(out), _i(m), _i(n), _stream()), "quant_scale_back_f32")
+    return out
+
+
+def w4a8_linear(x, w8, w_scale, out=None):
+    """gptq_gemm_k_major's W4_INT8 branch (q_gemm_k_major.cu:1036-1073): quantise the activation rows, int8 x int8 -> int32
+    on the matrix cores, scale back with the fp32 weight scale."""
+    xq, sx = quant_calc_scale(x)
+    return quant_scale_back_f32(int8_gemm_nt(xq, w8), sx, w_scale, out=out)
