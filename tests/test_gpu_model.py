@@ -843,3 +843,97 @@ def test_decode_batch_sizes_cover_every_linear_kernel(oracle, dev, batch):
         nxt = ref.argmax(axis=1)
         model.advance(ctx, torch.from_numpy(nxt).to(dev))
         tokens = nxt.astype(np.int32)
+
+
+def _act_order_state_shared(rng, cfg, g, oracle):
+    """A desc_act checkpoint as GPTQ really produces it: linears that see the same input share their g_idx (q/k/v; gate/up),
+    attn_out and w_out have their own.  Returns the HF state dict + the dense W16 matrices for the oracle."""
+    sd = _hf_state(rng, cfg, g)
+    w16, shared = {}, {}
+    for key in [k for k in sd if k.endswith(".qweight")]:
+        base = key[:-8]
+        kdim, ndim = sd[key].shape[0] * 8, sd[key].shape[1]
+        grp = base.rsplit(".", 1)[0] + ("qkv" if base.endswith(("q_proj", "k_proj", "v_proj")) else
+                                        "gu" if base.endswith(("gate_proj", "up_proj")) else base)
+        qw, qz, sc, g_idx, dense = synth.gptq_act_order_hf(rng, kdim, ndim, g)
+        if grp in shared:                                  # re-derive the dense matrix under the shared order
+            g_idx = shared[grp]
+            q = np.zeros((kdim, ndim), np.int32)
+            for j in range(8):
+                q[j::8] = (qw >> np.uint32(4 * j)) & 0xF
+            z = np.zeros((kdim // g, ndim), np.int32)
+            for j in range(8):
+                z[:, j::8] = ((qz >> np.uint32(4 * j)) & 0xF) + 1
+            d = (q - z[g_idx]).astype(np.float16)
+            dense = np.ascontiguousarray((d.astype(np.float32) * sc.view(np.float16)[g_idx].astype(np.float32)).astype(np.float16).T)
+        shared[grp] = g_idx
+        sd[base + ".qweight"], sd[base + ".qzeros"], sd[base + ".scales"] = qw.view(np.int32), qz.view(np.int32), sc.view(np.float16)
+        sd[base + ".g_idx"] = g_idx
+        w16[base] = oracle.h2u(dense)
+    return sd, w16
+
+
+def test_act_order_shared_orders_fuse_and_feed_forward_needs_no_gather(oracle, dev):
+    """desc_act with the orders GPTQ produces (q/k/v share one, gate/up share one): q|k|v and gate|up stay FUSED behind one
+    gather each, w_in / w_gated are stored with their output columns in w_out's regrouped order so w_out reads its input
+    as produced (the reference's permute_ff_up_out, linear.cpp:1168-1210); prompt encode and decode match the oracle run
+    on the dense matrices of the same checkpoint."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(17)
+    cfg = ModelConfig(num_layers=2, dim_model=512, num_heads=4, dim_head=128, dim_ff=1024, vocab_size=256, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5, rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0,
+                                                               "high_freq_factor": 4.0, "original_max_position_embeddings": 8192})
+    g, s, len_buf = 128, 70, 128
+    sd, w16 = _act_order_state_shared(rng, cfg, g, oracle)
+    quant = QuantConfig.from_hf(dict(quant_method="gptq", bits=4, group_size=g, desc_act=True))
+    model = LLaMA(cfg, quant, dev).load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    lay = model.layers[0]
+    assert lay.unfused is None and lay.qkv.perm is not None and lay.w_in_gated.perm is not None
+    assert lay.w_out.perm is None and lay.attn_out.perm is not None       # ff output order folded into w_in | w_gated
+    ctx = model.new_context(1, len_buf, 0)
+    om = OracleModel(oracle, cfg, sd, g, 1, len_buf)
+    om.w16 = w16
+    prompt = rng.integers(0, cfg.vocab_size, s).astype(np.int32)
+    got = model.prefill(ctx, 0, torch.from_numpy(prompt)).float().cpu().numpy().astype(np.float64)
+    ref = om.prefill(0, prompt)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-3 * scale + 2.0 ** -11 * scale, np.abs(got - ref).max() / scale
+    tok = int(ref.argmax(axis=1)[0])
+    ctx.tokens[0] = tok
+    lg = model.encode(ctx).float().cpu().numpy().astype(np.float64)
+    ctx2 = model.new_context(1, len_buf, 0)
+    lg2 = model.prefill(ctx2, 0, torch.from_numpy(np.concatenate([prompt, [tok]]).astype(np.int32))).float().cpu().numpy()
+    assert np.abs(lg - lg2).max() <= 4e-3 * np.abs(lg2).max()
+
+
+def test_act_order_under_tensor_parallelism(oracle, dev):
+    """desc_act + TP = 2 (both ranks on this GPU, thread-barrier collectives): column-parallel q|k|v / gate|up keep their
+    shared gather, the row-parallel w_out slices the order it shares with w_in | w_gated, attn_out all-gathers the attention
+    output and reads it through its rank's slice of the permutation -- logits equal the unsharded model's."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(19)
+    cfg = ModelConfig(num_layers=2, dim_model=512, num_heads=4, dim_head=128, dim_ff=1024, vocab_size=256, num_kv_heads=2,
+                      eps=1e-5, rope_theta=5e5)
+    sd, _ = _act_order_state_shared(rng, cfg, 128, oracle)
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    quant = QuantConfig.from_hf(dict(quant_method="gptq", bits=4, group_size=128, desc_act=True))
+    ref_model = LLaMA(cfg, quant, dev).load_state_dict(sd)
+    fake = _ThreadTP(2)
+    models = [LLaMA(cfg, quant, dev, tp=fake.view(r)).load_state_dict(sd) for r in range(2)]
+    assert getattr(models[0].layers[0].attn_out, "tp_gather_perm", None) is not None
+    batch, len_buf = 2, 64
+    tokens = torch.from_numpy(rng.integers(0, cfg.vocab_size, batch).astype(np.int32))
+    ref_ctx = ref_model.new_context(batch, len_buf, 0)
+    ref_ctx.tokens.copy_(tokens)
+    ctxs = [m.new_context(batch, len_buf, 0) for m in models]
+    for c in ctxs:
+        c.tokens.copy_(tokens)
+    for step in range(2):
+        ref = ref_model.encode(ref_ctx).float()
+        outs = _run_ranks(fake, lambda r: models[r].encode(ctxs[r]).float())
+        assert torch.equal(outs[0], outs[1])
+        assert (outs[0] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+        nxt = ref.argmax(dim=-1)
+        ref_model.advance(ref_ctx, nxt)
+        for m, c in zip(models, ctxs):
+            m.advance(c, nxt)

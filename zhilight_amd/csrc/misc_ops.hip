@@ -404,6 +404,22 @@ int zl_rope_scatter_decode(const float* cosv, const float* sinv, const uint16_t*
     return zl_launch_status();
 }
 
+// out[r, i] = x[r, perm[i]] (16-bit elements): nn::gptq::permute_input (gptq.h:155-159), the activation gather in front of
+// an act-order (desc_act) linear whose rows were regrouped at load
+__global__ void k_permute_input(const uint16_t* __restrict__ x, const int32_t* __restrict__ perm, uint16_t* __restrict__ out,
+                                int64_t ldx, int64_t k) {
+    const int64_t r = blockIdx.y;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < k; i += (int64_t)gridDim.x * blockDim.x)
+        out[r * k + i] = x[r * ldx + perm[i]];
+}
+
+int zl_permute_input(const uint16_t* x, int64_t ldx, const int32_t* perm, uint16_t* out, int64_t rows, int64_t k, zl_stream_t s) {
+    ZL_CHECK_ARG(x && perm && out && rows > 0 && k > 0 && ldx >= 1, ZL_EINVAL);
+    ZL_CHECK_ARG(rows <= 65535, ZL_ELIMIT);
+    hipLaunchKernelGGL(k_permute_input, dim3(grid_1d(k, 256), (unsigned)rows), dim3(256), 0, (hipStream_t)s, x, perm, out, ldx, k);
+    return zl_launch_status();
+}
+
 int zl_element_add_scale(const uint16_t* a, const uint16_t* b, uint16_t* c, int64_t n, float scale, int scale_residual,
                          int dtype, zl_stream_t s) {
     ZL_CHECK_ARG(a && b && c && n > 0, ZL_EINVAL);

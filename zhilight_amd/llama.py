@@ -167,10 +167,24 @@ class Int4GPTQ:
         self.bias = None
         self.perm = None    # act-order: activation column gather applied in forward()
 
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str, device):
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str, device, out_perm=None, input_prepermuted=False):
+        """out_perm: reorder the OUTPUT columns (w_in / w_gated permuted by w_out's input order, the reference's
+        permute_ff_up_out, linear.cpp:1168-1186).  input_prepermuted: the producer already delivers the activations in this
+        linear's regrouped row order (w_out behind such w_in / w_gated): no gather in forward (linear.cpp:1188-1210)."""
         qw = _dev_t(sd[prefix + ".qweight"], device, torch.int32)
         qz = _dev_t(sd[prefix + ".qzeros"], device, torch.int32)
         sc = _dev_t(sd[prefix + ".scales"], device, torch.float16)
+        if out_perm is not None:
+            if self.quant.awq:
+                raise ops.ZLError("output permutation is a GPTQ act-order transform")
+            idx = out_perm.to(torch.int64)
+            qw = qw.index_select(1, idx).contiguous()
+            sc = sc.index_select(1, idx).contiguous()
+            shifts = torch.arange(8, device=qz.device, dtype=torch.int32) * 4
+            zn = ((qz.unsqueeze(-1) >> shifts) & 0xF).reshape(qz.shape[0], -1).index_select(1, idx).reshape(qz.shape[0], -1, 8)
+            qz = torch.zeros_like(qz)
+            for j in range(8):
+                qz |= zn[:, :, j] << (4 * j)
         if self.quant.awq:
             # AWQ on disk: qweight (K, N/8) with the [0,4,1,5,2,6,3,7] nibble order, zeros stored as they are
             # used (no +1).  Int4GPTQ::preprocess_weight, is_awq branch: shuffle_awq -> (K/8, N) exllama
@@ -188,8 +202,12 @@ class Int4GPTQ:
             qw = ops.transpose_2d(ops.gptq_shuffle(qw.clone()))
             qz = ops.transpose_2d(ops.q4_to_q8(ops.increase_zero(qz.clone())))
         self.km = (qw, qz, ops.transpose_2d(sc))
+        if input_prepermuted:
+            self.perm = None
         if prefix + ".bias" in sd:
             self.bias = _dev_t(sd[prefix + ".bias"], device, torch.float16)
+            if out_perm is not None:
+                self.bias = self.bias.index_select(0, out_perm.to(torch.int64)).contiguous()
 
     def _apply_act_order(self, qw, g_idx, prefix):
         """desc_act checkpoints (the reference sorts with argsort(g_idx) and lets its exllama
@@ -216,15 +234,21 @@ class Int4GPTQ:
 
     @staticmethod
     def fuse(name, parts: List["Int4GPTQ"], row_interleave=False):
-        if any(p.perm is not None for p in parts):
-            raise ops.ZLError("act-order linears cannot be fused: each carries its own input permutation")
+        if not Int4GPTQ.same_perm(parts):
+            raise ops.ZLError("act-order linears with different input permutations cannot be fused")
         out = Int4GPTQ(name, parts[0].dim_in, sum(p.dim_out for p in parts), parts[0].quant)
+        out.perm = parts[0].perm                        # shared: q/k/v (gate/up) see the same input, so GPTQ gives them one order
         out.km = tuple(torch.cat([p.km[i] for p in parts], dim=0).contiguous() for i in range(3))
         if any(p.bias is not None for p in parts):
             out.bias = torch.cat([p.bias if p.bias is not None else
                                   torch.zeros(p.dim_out, dtype=torch.float16, device=out.km[0].device) for p in parts])
         out.pack(row_interleave)
         return out
+
+    @staticmethod
+    def same_perm(parts):
+        first = parts[0].perm
+        return all((p.perm is None) == (first is None) and (first is None or torch.equal(p.perm, first)) for p in parts)
 
     def pack(self, row_interleave=False):
         if w4_algo(self.quant) == "mfma":
@@ -241,7 +265,7 @@ class Int4GPTQ:
         if self.perm is not None:
             if kw.get("norm_weight") is not None:
                 raise ops.ZLError("act-order linears take an already normalised input")
-            x = x.index_select(-1, self.perm)
+            x = ops.permute_input(x, self.perm)
         return ops.w4_linear(x, self.weight, bias=self.bias, **kw)
 
 
@@ -554,16 +578,30 @@ class EncoderLayer:
 
         tp = self.tp
 
-        def lin(sub, din, dout, mode=None, part=None):
+        # act-order feed-forward: w_in / w_gated OUTPUT columns are stored in w_out's regrouped input order, so the
+        # activation reaches w_out already permuted (no gather, and a TP rank's column slice of w_in / w_gated matches its
+        # row slice of w_out) -- the reference's permute_ff_up_out (linear.cpp:1168-1210)
+        ff_out_perm = None
+        g_out = sd.get(prefix + ".ff.w_out.g_idx") if q.act_order else None
+        if g_out is not None:
+            g64 = _dev_t(g_out, device, torch.int32).to(torch.int64)
+            op = torch.argsort(g64, stable=True)
+            if not torch.equal(op, torch.arange(op.numel(), device=op.device)):
+                ff_out_perm = op.to(torch.int32)
+
+        def lin(sub, din, dout, mode=None, part=None, out_perm=None, prepermuted=False):
             # the checkpoint holds the FULL matrix; a TP rank keeps its column (output rows) or row (input columns) slice
             # (part = (index, count) overrides (rank, size): replicated kv heads)
             idx, cnt = part if part else ((tp.rank, tp.size) if tp else (0, 1))
             full_in, full_out = (din * cnt if mode == "row" else din), (dout * cnt if mode == "column" else dout)
             l = Int4GPTQ(prefix + "." + sub, full_in, full_out, q)
-            l.load_state_dict(sd, prefix + "." + sub, device)
+            l.load_state_dict(sd, prefix + "." + sub, device, out_perm=out_perm, input_prepermuted=prepermuted)
             if tp and mode:
-                if l.perm is not None:
-                    raise ops.ZLError("act-order checkpoints are not supported under tensor parallelism")
+                if l.perm is not None and mode == "row":
+                    # row-parallel with an input gather left (attn_out): the rank keeps rows [idx K/cnt, ...) of the REGROUPED
+                    # order, which are scattered over all heads -- forward all-gathers the attention output first
+                    l.tp_gather_perm = l.perm[idx * din:(idx + 1) * din].contiguous()
+                    l.perm = None
                 l.km = parallel.shard_k_major(*l.km, q.group_size, mode, idx, cnt)
                 l.dim_in, l.dim_out = din, dout
                 if l.bias is not None and mode == "column":
@@ -587,12 +625,13 @@ class EncoderLayer:
         kv_part = getattr(self, "kv_part", None)
         pq, pk, pv = (lin("attn.project_q", c.dim_model, hd, "column"), lin("attn.project_k", c.dim_model, kvd, "column", kv_part),
                       lin("attn.project_v", c.dim_model, kvd, "column", kv_part))
-        w_in, w_gated = lin("ff.w_in", c.dim_model, c.dim_ff, "column"), lin("ff.w_gated", c.dim_model, c.dim_ff, "column")
+        w_in = lin("ff.w_in", c.dim_model, c.dim_ff, "column", out_perm=ff_out_perm)
+        w_gated = lin("ff.w_gated", c.dim_model, c.dim_ff, "column", out_perm=ff_out_perm)
         self.attn_out = lin("attn.attn_out", hd, c.dim_model, "row").pack()
-        self.w_out = lin("ff.w_out", c.dim_ff, c.dim_model, "row").pack()
-        if any(l.perm is not None for l in (pq, pk, pv, w_in, w_gated)):
-            # act-order: every linear reads x through its own permutation, so q/k/v and gate/up stay separate
-            # (the reference's act-order route gives up the same fusions)
+        self.w_out = lin("ff.w_out", c.dim_ff, c.dim_model, "row", prepermuted=ff_out_perm is not None).pack()
+        if not (Int4GPTQ.same_perm([pq, pk, pv]) and Int4GPTQ.same_perm([w_in, w_gated])):
+            # act-order with DIFFERENT input orders inside a group (not what GPTQ produces for linears sharing their input,
+            # but a legal checkpoint): every linear gathers x itself, q/k/v and gate/up stay separate
             self.unfused = [l.pack() for l in (pq, pk, pv, w_in, w_gated)]
         else:
             self.qkv = Int4GPTQ.fuse(prefix + ".attn.project_qkv", [pq, pk, pv])
@@ -628,6 +667,9 @@ class EncoderLayer:
     def project_qkv(self, hidden, eps, out=None, normed=None):
         """normed: ln_attn(hidden) already computed by the caller (the dual-stream path's fused add + norm)"""
         if self.unfused is None:
+            if self.qkv.perm is not None:                 # act-order: RMSNorm, ONE gather for the fused q|k|v, then the GEMV
+                xn = normed if normed is not None else ops.rmsnorm(hidden, self.ln_attn, eps)
+                return ops.w4_linear(ops.permute_input(xn, self.qkv.perm), self.qkv.weight, bias=self.qkv.bias, out=out)
             if normed is not None:
                 return ops.w4_linear(normed, self.qkv.weight, bias=self.qkv.bias, out=out)
             if hidden.shape[0] > _fused_norm_rows(self.qkv.weight):   # the fused norm prologue normalises every row in every
@@ -638,10 +680,18 @@ class EncoderLayer:
         parts = [l.forward(xn) for l in self.unfused[:3]]
         return torch.cat(parts, dim=1, out=out) if out is not None else torch.cat(parts, dim=1)
 
+    def row_partial(self, lin, x):
+        """this rank's partial output of a row-parallel linear.  act-order attn_out: the rank's regrouped rows span all
+        heads, so the attention output is all-gathered and read through the rank's slice of the permutation first"""
+        gp = getattr(lin, "tp_gather_perm", None)
+        if gp is not None:
+            x = ops.permute_input(self.tp.all_gather_columns(x), gp)
+        return lin.forward(x)
+
     def _row_parallel_add(self, lin, x, hidden):
         """hidden += sum over TP ranks of lin(x): ModelContext::reduce_sum on the fp16 partial outputs, then the
         residual add in T arithmetic (src/nn/block/block.cpp:123-140, src/model/model_context.cpp:203-242)"""
-        part = lin.forward(x)
+        part = self.row_partial(lin, x)
         self.tp.all_reduce_sum(part)
         ops.element_add_scale(hidden, part, 1.0, True, out=hidden)
 
@@ -660,6 +710,10 @@ class EncoderLayer:
 
     def ff_in(self, hidden, eps, out=None, normed=None):
         if self.unfused is None:
+            if self.w_in_gated.perm is not None:
+                xn = normed if normed is not None else ops.rmsnorm(hidden, self.ln_ff, eps)
+                return ops.w4_linear(ops.permute_input(xn, self.w_in_gated.perm), self.w_in_gated.weight, bias=self.w_in_gated.bias,
+                                     out=out, epilogue=ops.EPI_SILU_MUL)
             if normed is not None:
                 return ops.w4_linear(normed, self.w_in_gated.weight, bias=self.w_in_gated.bias, out=out, epilogue=ops.EPI_SILU_MUL)
             if hidden.shape[0] > _fused_norm_rows(self.w_in_gated.weight):
@@ -825,7 +879,8 @@ class LLaMA:
                      and os.environ.get("ZL_ATTN_MFMA", "1") != "0")
         # fused qkv projection + rotary + KV scatter in the GEMV epilogue (zl_w4a16_qkv_rope_scatter) where it applies
         fuse_qkv_rope = (mfma_attn and not ctx.kv_quant and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
-                         and all(isinstance(l, EncoderLayer) and l.unfused is None and isinstance(l.qkv.weight, ops.W4MWeight)
+                         and all(isinstance(l, EncoderLayer) and l.unfused is None and l.qkv.perm is None
+                                 and isinstance(l.qkv.weight, ops.W4MWeight)
                                  for l in self.layers)
                          and ops.w4_qkv_rope_scatter_ok(b, c.dim_model, c.dim_head, norm=b <= 8))
         fuse_qkv_rope_i8 = (mfma_attn and not ctx.kv_quant and b <= 32 and c.dim_head % 32 == 0
@@ -1024,10 +1079,10 @@ class LLaMA:
                     mask, ws = self._prefill_mask(n, ctx.max_len_buf, pos0 + a)
                     att = ops.multi_query_attention_rag_buffer(q.view(1, n, c.num_heads, c.dim_head), buf_lens, ka, va, mask,
                                                                scale, ctx.max_len_buf, c.num_kv_heads, workspace=ws)
-                reduce_async(k, layer.attn_out.forward(att.view(n, -1)))
+                reduce_async(k, layer.row_partial(layer.attn_out, att.view(n, -1)))
             for k in range(len(bounds)):
                 xn, hidden[k] = ops.rmsnorm(hidden[k], layer.ln_ff, c.eps, x2=reduced(k))
-                reduce_async(k, layer.w_out.forward(layer.ff_in(None, c.eps, normed=xn)))
+                reduce_async(k, layer.row_partial(layer.w_out, layer.ff_in(None, c.eps, normed=xn)))
         for k in range(len(bounds)):
             hidden[k] = ops.element_add_scale(hidden[k], reduced(k), 1.0, True)
         self.dual_stream_runs = getattr(self, "dual_stream_runs", 0) + 1

@@ -674,6 +674,21 @@ def element_add_scale(a, b, scale=1.0, scale_residual=True, out=None):
     return out
 
 
+def permute_input(x, perm, out=None):
+    """nn::gptq::permute_input (src/nn/quant/gptq/gptq.h:155-159): out[..., i] = x[..., perm[i]] (perm int32, any length)."""
+    _chk_cuda(x, perm)
+    if perm.dtype != torch.int32:
+        raise ZLError("perm dtype mismatch")
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    k = perm.numel()
+    if out is None:
+        out = torch.empty((x2.shape[0], k), dtype=x.dtype, device=x.device)
+    check(lib().zl_permute_input(_p(x2), _i(x2.stride(0)), _p(perm), _p(out), _i(x2.shape[0]), _i(k), _stream()), "permute_input")
+    return out
+
+
 def gate_mul(inp, in2, gate_type="silu", out=None):
     """nn::gate_mul_inplace (src/nn/linear/activation_kernel.cu:82-106); out defaults to in place."""
     _chk_cuda(inp, in2)
