@@ -308,8 +308,14 @@ def main():
     int8 = args.quant == "int8"
     tp = None
     if args.tp and world > 1:
-        from zhilight_amd.parallel import TPGroup, max_over_ranks
-        tp = TPGroup()
+        from zhilight_amd.parallel import DirectTPGroup, TPGroup, max_over_ranks
+        # the direct transports (own RCCL communicator + one-shot peer-read all-reduce with the residual add fused: one launch
+        # per exchange, capturable); torch.distributed is then only the bootstrap channel
+        try:
+            tp = TPGroup() if os.environ.get("ZL_TP_BACKEND") == "torch" else DirectTPGroup()
+        except Exception as e:                 # noqa: BLE001
+            sys.stderr.write("bench: direct TP transports unavailable (%s); using torch.distributed collectives\n" % str(e).splitlines()[0])
+            tp = TPGroup()
         torch.manual_seed(1234)            # every rank must draw the same tokens / KV contents
     model = LLaMA(cfg, QuantConfig(2, 0) if int8 else QuantConfig(5, 128), dev, tp=tp).init_random(seed=1234 + rank)
     len_buf = (seq + args.warmup + args.steps + 4 + 63) // 64 * 64
@@ -445,7 +451,7 @@ def main():
                        "kv_cache_dtype": args.kv_cache_dtype,
                        "w4_algo": None if int8 else ("mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "exact")},
             "per_gpu_tokens_per_s": round(value / world, 2),
-            "note_tp": "TP mode was not exercised on multi-GPU hardware in round 1 (1-GPU dev box); numerics covered by the TP=2 emulation test" if tp else None,
+            "note_tp": ("TP transports: %s; never run on more than one GPU by the builder (1-GPU dev box): protocol covered by in-process / two-process tests on one device" % type(tp).__name__) if tp else None,
             "ttft_ms": None if ttft_ms is None else round(ttft_ms, 3),
             "ttft_dual_stream_ms": None if ttft_dual_ms is None else round(ttft_dual_ms, 3),
             "ttft_note": "prompt of seq tokens, one task, first greedy token; eager launches, HIP events, mean of 3",

@@ -56,3 +56,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     with pytest.raises(ImportError, match="no CPU/PyTorch fallback"):
         _lib.lib()
     importlib.reload(_lib)
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """libzhilight_amd_comm.so (include/zhilight_amd_comm.h): loads without a GPU, exports every declared entry point"""
+    import re
+    from zhilight_amd import _lib
+    lib = _lib.comm_lib()
+    hdr = open(os.path.join(ROOT, "include", "zhilight_amd_comm.h")).read()
+    declared = set(re.findall(r"\b(zl_(?:comm|ar)_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.COMM_SYMBOLS), declared ^ set(_lib.COMM_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)

@@ -1,0 +1,143 @@
+"""GPU tests of the exchange step (include/zhilight_amd_comm.h): the direct RCCL communicator and
+the one-shot peer-read all-reduce with the fused residual add.  A 1-GPU box can only run world-size-1 RCCL and the one-shot
+protocol with both ranks on the same device (two threads with plain pointers; two processes through hipIpc handles) -- that
+covers the flags / epochs / slot parity / rank-order arithmetic, not cross-GPU memory visibility; the 2-GPU test runs where
+two devices are visible."""
+import os
+import subprocess
+import sys
+import tempfile
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_communicator_world_size_one(dev):
+    from zhilight_amd.parallel import RcclComm
+    comm = RcclComm(0, 1, lambda b: b)
+    x = torch.randn(3, 4096, device=dev).half()
+    y = x.clone()
+    comm.all_reduce_sum(y)
+    assert torch.equal(x, y)
+    assert torch.equal(comm.all_gather(x)[0], x)
+    assert torch.equal(comm.reduce_scatter_sum(x.view(-1)), x.view(-1))
+    comm.broadcast(y)
+    torch.cuda.synchronize()
+    comm.close()
+
+
+def _expected(xs, res, dtype):
+    tot = xs[0].float()
+    for o in xs[1:]:
+        tot = tot + o.float()          # rank order, fp32
+    want = tot.to(dtype)
+    if res is not None:
+        want = (res.float() + want.float()).to(dtype)   # residual add in T arithmetic (exact sum of two T values, one rounding)
+    return want
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_shot_all_reduce_in_process_ranks(dev, world):
+    """`world` ranks as threads of this process, each on its own stream, buffers addressed directly: message sequence with
+    changing sizes (the device-side epochs and the slot parity), with / without the fused residual, eager and under hipGraph
+    replay; every rank ends with bit-identical sums."""
+    from zhilight_amd.parallel import OneShotAllReduce
+    maxb = 1 << 20
+    addrs = [OneShotAllReduce.alloc(maxb)[0] for _ in range(world)]
+    ars = [OneShotAllReduce(r, world, addrs, maxb, dev) for r in range(world)]
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    torch.cuda.synchronize()
+    msgs = [(4096, torch.float16, True), (8, torch.float16, False), (32 * 4096, torch.float16, True), (64 * 4096, torch.bfloat16, True),
+            (4096, torch.float16, True), (128 * 4096, torch.float16, False)]
+    results, errs = [[None] * len(msgs) for _ in range(world)], []
+    ins = [[torch.randn(n, device=dev).to(dt) for r in range(world)] for (n, dt, _) in msgs]
+    ress = [torch.randn(n, device=dev).to(dt) for (n, dt, _) in msgs]
+    torch.cuda.synchronize()
+
+    def run(r):
+        try:
+            with torch.cuda.stream(streams[r]):
+                for i, (n, dt, wr) in enumerate(msgs):
+                    out = torch.empty_like(ins[i][r])
+                    ars[r].all_reduce(ins[i][r], residual=ress[i] if wr else None, out=out)
+                    results[r][i] = out
+                streams[r].synchronize()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    for i, (n, dt, wr) in enumerate(msgs):
+        want = _expected(ins[i], ress[i] if wr else None, dt)
+        for r in range(world):
+            assert torch.equal(results[r][i], want), (i, r)
+    assert all(a.status() == 0 for a in ars)
+    # hipGraph: each rank captures two messages on its stream; the graphs are replayed concurrently three times
+    n, dt = 4096, torch.float16
+    gx = [torch.randn(n, device=dev).to(dt) for _ in range(world)]
+    hid = [torch.zeros(n, device=dev, dtype=dt) for _ in range(world)]
+    graphs = []
+    for r in range(world):
+        # (capturing one rank alone: its kernel would wait for peers that are not running, so capture does not launch -- fine)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=streams[r]):
+            ars[r].all_reduce(gx[r], residual=hid[r], out=hid[r])      # hidden += sum
+            ars[r].all_reduce(gx[r], residual=hid[r], out=hid[r])
+        graphs.append(g)
+
+    def replay(r):
+        try:
+            with torch.cuda.stream(streams[r]):
+                for _ in range(3):
+                    graphs[r].replay()
+                streams[r].synchronize()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=replay, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    want = torch.zeros(n, dtype=dt, device=dev)
+    s = _expected(gx, None, dt)
+    for _ in range(6):
+        want = (want.float() + s.float()).to(dt)
+    for r in range(world):
+        assert torch.equal(hid[r], want)
+    assert all(a.status() == 0 for a in ars)
+
+
+def test_one_shot_all_reduce_two_processes_ipc(dev):
+    """two PROCESSES, buffers exchanged as hipIpc handles (both on device 0 here): the cross-process mapping path"""
+    with tempfile.TemporaryDirectory() as d:
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ar_worker.py"), str(r), "2", d, "0"],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        outs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=180)
+            except subprocess.TimeoutExpired:     # pragma: no cover
+                p.kill()
+                o, _ = p.communicate()
+            outs.append(o)
+        for r, o in enumerate(outs):
+            assert f"RESULT {r} ok" in o, o[-2000:]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_one_shot_all_reduce_two_gpus(dev):   # pragma: no cover  (1-GPU dev box)
+    with tempfile.TemporaryDirectory() as d:
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ar_worker.py"), str(r), "2", d, str(r)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        for r, p in enumerate(procs):
+            o, _ = p.communicate(timeout=180)
+            assert f"RESULT {r} ok" in o, o[-2000:]

@@ -78,6 +78,32 @@ def lib():
     return _lib
 
 
+COMM_SO_PATH = os.path.join(_HERE, "libzhilight_amd_comm.so")
+COMM_SYMBOLS = [
+    "zl_comm_unique_id", "zl_comm_create", "zl_comm_destroy", "zl_comm_rank", "zl_comm_size", "zl_comm_all_reduce_sum",
+    "zl_comm_all_gather", "zl_comm_reduce_scatter_sum", "zl_comm_broadcast", "zl_comm_send", "zl_comm_recv",
+    "zl_comm_group_start", "zl_comm_group_end",
+    "zl_ar_buffer_bytes", "zl_ar_state_bytes", "zl_ar_alloc", "zl_ar_free", "zl_ar_export", "zl_ar_open", "zl_ar_close",
+    "zl_ar_init", "zl_ar_all_reduce", "zl_ar_status",
+]
+_comm = None
+
+
+def comm_lib():
+    """Load (once) libzhilight_amd_comm.so (include/zhilight_amd_comm.h): RCCL communicator + one-shot all-reduce."""
+    global _comm
+    if _comm is None:
+        if not os.path.exists(COMM_SO_PATH):
+            raise ImportError(f"{COMM_SO_PATH} not found: build it with `python -m zhilight_amd.build`")
+        l = C.CDLL(COMM_SO_PATH)
+        for name in COMM_SYMBOLS:
+            getattr(l, name)
+        l.zl_ar_buffer_bytes.restype = C.c_int64
+        l.zl_ar_state_bytes.restype = C.c_int64
+        _comm = l
+    return _comm
+
+
 class ZLError(RuntimeError):
     """Raised for a non-zero status of a C-ABI call (the reference raises BMEngineException ->
     Python RuntimeError for the same conditions)."""

@@ -52,7 +52,27 @@ def build(force=False, verbose=False):
     if jobs or force or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
     build_hostcpp(force, verbose)
+    build_comm(force, verbose)
     return OUT
+
+
+COMM_OUT = os.path.join(HERE, "libzhilight_amd_comm.so")
+
+
+def build_comm(force=False, verbose=False):
+    """libzhilight_amd_comm.so: the tensor-parallel exchange step (direct RCCL communicator + one-shot peer-read all-reduce,
+    include/zhilight_amd_comm.h).  Separate from the main library so that single-GPU users carry no RCCL dependency."""
+    src = os.path.join(HERE, "csrc_comm", "comm.hip")
+    deps = [src, os.path.join(HERE, "..", "include", "zhilight_amd_comm.h"), os.path.join(HERE, "..", "include", "zhilight_amd.h")]
+    if not (force or _stale(COMM_OUT, deps)):
+        return COMM_OUT
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-shared", "-o", COMM_OUT, src,
+           "-L" + os.path.join(rocm, "lib"), "-lrccl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return COMM_OUT
 
 
 HOSTCPP = os.path.join(HERE, "hostcpp")

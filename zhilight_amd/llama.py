@@ -692,6 +692,9 @@ class EncoderLayer:
         """hidden += sum over TP ranks of lin(x): ModelContext::reduce_sum on the fp16 partial outputs, then the
         residual add in T arithmetic (src/nn/block/block.cpp:123-140, src/model/model_context.cpp:203-242)"""
         part = self.row_partial(lin, x)
+        fused = getattr(self.tp, "all_reduce_add", None)
+        if fused is not None and fused(part, hidden) is not None:      # one-shot all-reduce with the residual add in its launch
+            return
         self.tp.all_reduce_sum(part)
         ops.element_add_scale(hidden, part, 1.0, True, out=hidden)
 

@@ -78,3 +78,154 @@ def max_over_ranks(value: float, device="cpu", group=None) -> float:
 def aggregate_throughput(units_per_rank: float, elapsed_max: float, world: int) -> float:
     """Whole-job throughput of `world` independent replicas (weak scaling): all units / max time."""
     return world * units_per_rank / elapsed_max
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Direct transports (include/zhilight_amd_comm.h): an RCCL communicator per GPU and the one-shot peer-read all-reduce.
+# torch.distributed is only the BOOTSTRAP channel here (it ships the 128-byte unique id / the 64-byte IPC handles once).
+# ----------------------------------------------------------------------------------------------------------------------
+import ctypes as _C
+
+_DT = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2, torch.int32: 3, torch.int8: 4}
+
+
+def _comm():
+    from ._lib import comm_lib
+    return comm_lib()
+
+
+def _check(st, what):
+    if st != 0:
+        from ._lib import ZLError
+        raise ZLError(f"{what}: status {st}" + (f" (ncclResult_t {st - 1000})" if st >= 1000 else ""))
+
+
+def _stream():
+    return _C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class RcclComm:
+    """ncclCommInitRank on this process' current device (engine.cpp:140-157); collectives go to torch's CURRENT stream
+    (c10d::NCCL*, 3rd/bmengine/bmengine/c10d/c10d.cpp:24-146).  `exchange(obj_or_None) -> obj` broadcasts rank 0's bytes."""
+
+    def __init__(self, rank, size, broadcast_bytes):
+        L = _comm()
+        uid = (_C.c_char * 128)()
+        if rank == 0:
+            _check(L.zl_comm_unique_id(uid), "ncclGetUniqueId")
+        raw = broadcast_bytes(bytes(uid) if rank == 0 else None)
+        self._h = _C.c_void_p()
+        _check(L.zl_comm_create(_C.byref(self._h), size, rank, _C.c_char_p(raw)), "ncclCommInitRank")
+        self.rank, self.size = rank, size
+
+    def all_reduce_sum(self, t, out=None):
+        out = t if out is None else out
+        _check(_comm().zl_comm_all_reduce_sum(self._h, _C.c_void_p(t.data_ptr()), _C.c_void_p(out.data_ptr()), _C.c_int64(t.numel()),
+                                              _DT[t.dtype], _stream()), "ncclAllReduce")
+        return out
+
+    def all_gather(self, t):
+        out = torch.empty((self.size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        _check(_comm().zl_comm_all_gather(self._h, _C.c_void_p(t.data_ptr()), _C.c_void_p(out.data_ptr()), _C.c_int64(t.numel()),
+                                          _DT[t.dtype], _stream()), "ncclAllGather")
+        return out
+
+    def reduce_scatter_sum(self, t):
+        out = torch.empty((t.numel() // self.size,), dtype=t.dtype, device=t.device)
+        _check(_comm().zl_comm_reduce_scatter_sum(self._h, _C.c_void_p(t.data_ptr()), _C.c_void_p(out.data_ptr()),
+                                                  _C.c_int64(out.numel()), _DT[t.dtype], _stream()), "ncclReduceScatter")
+        return out
+
+    def broadcast(self, t, root=0):
+        _check(_comm().zl_comm_broadcast(self._h, _C.c_void_p(t.data_ptr()), _C.c_int64(t.numel()), _DT[t.dtype], root, _stream()),
+               "ncclBroadcast")
+        return t
+
+    def close(self):
+        if self._h:
+            _comm().zl_comm_destroy(self._h)
+            self._h = _C.c_void_p()
+
+
+class OneShotAllReduce:
+    """zl_ar_*: every rank's partial rows published in a buffer the peers map, per-chunk flags pushed to the peers, rows read
+    back over the direct links and summed in rank order (+ the layer's residual add), one launch per message.
+    `buffers`: the `size` device addresses as THIS rank sees them (own buffer at index rank)."""
+
+    def __init__(self, rank, size, buffers, max_message_bytes, device):
+        L = _comm()
+        self.rank, self.size, self.max_bytes = rank, size, max_message_bytes
+        self.state = torch.zeros(int(L.zl_ar_state_bytes()), dtype=torch.uint8, device=device)
+        arr = (_C.c_void_p * size)(*[_C.c_void_p(b) for b in buffers])
+        _check(L.zl_ar_init(_C.c_void_p(self.state.data_ptr()), size, rank, arr, _C.c_int64(max_message_bytes), _stream()), "zl_ar_init")
+
+    @staticmethod
+    def alloc(max_message_bytes):
+        """(address, bytes) of a zeroed fine-grained buffer peers can map"""
+        L = _comm()
+        nbytes = int(L.zl_ar_buffer_bytes(_C.c_int64(max_message_bytes)))
+        p = _C.c_void_p()
+        _check(L.zl_ar_alloc(_C.c_int64(nbytes), _C.byref(p)), "zl_ar_alloc")
+        return p.value, nbytes
+
+    @staticmethod
+    def export(addr):
+        h = (_C.c_char * 64)()
+        _check(_comm().zl_ar_export(_C.c_void_p(addr), h), "hipIpcGetMemHandle")
+        return bytes(h)
+
+    @staticmethod
+    def open(handle):
+        p = _C.c_void_p()
+        _check(_comm().zl_ar_open(_C.c_char_p(handle), _C.byref(p)), "hipIpcOpenMemHandle")
+        return p.value
+
+    def all_reduce(self, x, residual=None, out=None):
+        """out = T(T(sum over ranks of x) + residual); x (.., n) fp16 / bf16 contiguous, n * rows * 2 <= max_message_bytes"""
+        if x.numel() * 2 > self.max_bytes:
+            from ._lib import ZLError
+            raise ZLError("one-shot all-reduce: message larger than the exchange buffers")
+        out = x if out is None else out
+        _check(_comm().zl_ar_all_reduce(_C.c_void_p(self.state.data_ptr()), _C.c_void_p(x.data_ptr()),
+                                        _C.c_void_p(residual.data_ptr()) if residual is not None else None, _C.c_void_p(out.data_ptr()),
+                                        _C.c_int64(x.numel()), _DT[x.dtype], _stream()), "zl_ar_all_reduce")
+        return out
+
+    def status(self):
+        return int(_comm().zl_ar_status(_C.c_void_p(self.state.data_ptr()), _stream()))
+
+
+class DirectTPGroup(TPGroup):
+    """TPGroup on the direct transports: RCCL communicator for the bandwidth-bound messages, the one-shot all-reduce (with the
+    residual add fused) up to `oneshot_bytes`.  Bootstrapped over an existing torch.distributed group (gloo is enough)."""
+
+    def __init__(self, group=None, oneshot_bytes=1 << 20, device=None):
+        super().__init__(group=group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+
+        def bcast(b):
+            box = [b]
+            dist.broadcast_object_list(box, src=0, group=group)
+            return box[0]
+        self.comm = RcclComm(self.rank, self.size, bcast)
+        addr, _ = OneShotAllReduce.alloc(oneshot_bytes)
+        handles = [None] * self.size
+        dist.all_gather_object(handles, OneShotAllReduce.export(addr), group=group)
+        bufs = [addr if r == self.rank else OneShotAllReduce.open(handles[r]) for r in range(self.size)]
+        self.oneshot = OneShotAllReduce(self.rank, self.size, bufs, oneshot_bytes, dev)
+        self.oneshot_bytes = oneshot_bytes
+
+    def all_reduce_sum(self, t):
+        if t.numel() * 2 <= self.oneshot_bytes and t.numel() % 8 == 0 and t.dtype in (torch.float16, torch.bfloat16):
+            return self.oneshot.all_reduce(t)
+        return self.comm.all_reduce_sum(t)
+
+    def all_reduce_add(self, part, hidden):
+        """hidden <- hidden + sum over ranks of part, in place (block.cpp:123-140); fused into the one-shot launch when it fits"""
+        if part.numel() * 2 <= self.oneshot_bytes and part.numel() % 8 == 0 and part.dtype in (torch.float16, torch.bfloat16):
+            return self.oneshot.all_reduce(part, residual=hidden, out=hidden)
+        return None
+
+    def all_gather_columns(self, t):
+        parts = self.comm.all_gather(t.contiguous())
+        return torch.cat(list(parts), dim=-1)
