@@ -182,11 +182,13 @@ def roofline_w4(model, cfg, batch, dev, layers_override=False):
     # this process); the committed summary is per kernel flavour and for these four shapes only
     traffic = None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemv_traffic.json")) as fh:
+        import glob
+        tfile = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_gemv_traffic.json")))[-1]
+        with open(tfile) as fh:
             tj = json.load(fh)
         if tj.get("kernel", "").startswith(kname.split("+")[0]) and not layers_override and batch == 1:
             traffic = int(tj["avg_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, IndexError):
         traffic = None
     roof = {"bound": "hbm", "kernel": kname + " (W4A16 GEMV, 4 launches/layer)", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

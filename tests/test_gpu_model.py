@@ -777,8 +777,17 @@ def test_int8_kv_cache_prefill_and_decode(oracle, dev):
     assert dcode.max() <= 1 and (dcode != 0).mean() < 0.02
     gs, rs = ctx.kv_scales[0][0, 0, :s].cpu().numpy(), om.ks[0][0][:s]
     assert np.abs(gs - rs).max() <= 2.0 ** -9 * rs.max()
-    with pytest.raises(Exception):
-        model.prefill(ctx, 0, torch.from_numpy(prompt), chunk=16)
+    # chunked prefill into the INT8 cache (attention.cpp:497-510: the prompt keeps attending to its unquantised rows, held
+    # in temporary buffers, while the codes go to the cache): same logits, same codes up to the GEMM's fp16 noise
+    ctx_c = model.new_context(1, len_buf, 0, kv_cache_dtype="int8")
+    lc = model.prefill(ctx_c, 0, torch.from_numpy(prompt), chunk=16).float().cpu().numpy().astype(np.float64)
+    assert np.abs(lc - ref).max() < 2e-3 * np.abs(ref).max()
+    assert not ctx_c.unquant_kv                                            # temporaries released with the prompt
+    dc = np.abs(ctx_c.kv[0][0, 0, :s].cpu().numpy().astype(np.int32) - got_codes)
+    assert dc.max() <= 1 and (dc != 0).mean() < 0.02
+    assert int(ctx_c.positions[0]) == s and int(ctx_c.tokens[0]) == int(ctx.tokens[0])
+    with pytest.raises(Exception):                                         # a later piece without the temporaries
+        model._encode_prompt(model.new_context(1, len_buf, 0, kv_cache_dtype="int8"), 0, torch.from_numpy(prompt[:8]), 8)
     # decode continuation from the oracle's cache state (so both sides attend over the same codes)
     for li in range(cfg.num_layers):
         ctx.kv[0][li, 0].copy_(torch.from_numpy(om.kc[li][0]))
@@ -937,3 +946,32 @@ def test_act_order_under_tensor_parallelism(oracle, dev):
         ref_model.advance(ref_ctx, nxt)
         for m, c in zip(models, ctxs):
             m.advance(c, nxt)
+
+
+def test_decode_past_the_kv_buffers_is_refused_and_harmless(dev):
+    """ADVICE r01: the device-side bookkeeping bumps placement without a bound.  Eager steps raise once the buffers are full;
+    a replayed (captured) step beyond the end writes nothing outside the task's buffers."""
+    from zhilight_amd import ops
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2)
+    model = LLaMA(cfg, QuantConfig(5, 128), dev).init_random(seed=3)
+    ctx = model.new_context(1, 64, 61)
+    ctx.tokens.fill_(5)
+    for _ in range(3):
+        model.step_greedy(ctx)
+    with pytest.raises(ops.ZLError, match="past the end of the KV buffers"):
+        model.step_greedy(ctx)
+    # captured step replayed past the end: every KV byte of the task is what it was (the new rows are dropped)
+    ctx2 = model.new_context(1, 64, 62)
+    ctx2.tokens.fill_(5)
+    model.step_greedy(ctx2)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        model.step_greedy(ctx2)
+    g.replay()                       # placement 63: the last slot
+    torch.cuda.synchronize()
+    before = ctx2.kv[0].clone()
+    g.replay()                       # placement 64 = len_buf: outside
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ctx2.kv[0], before)

@@ -7,6 +7,9 @@ make -C oracle -s
 timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 2500 gpurun_out/${tag}_bench.json
 rm -rf gpurun_out/${tag}_prof; timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -o bench --output-format csv -- python bench.py --no-cpu-baseline --steps 16 --warmup 2 > gpurun_out/${tag}_prof.log 2>&1
 cp $(find gpurun_out/${tag}_prof -name 'bench_kernel_stats.csv' | head -1) gpurun_out/${tag}_bench_kernel_stats.csv
+# the headline leg alone (batch 1 decode, no TTFT / batch legs): per-kernel averages of the decode step
+rm -rf gpurun_out/${tag}_prof_b1; timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof_b1 -o bench --output-format csv -- python bench.py --no-cpu-baseline --no-ttft --no-extras --steps 32 --warmup 2 > gpurun_out/${tag}_prof_b1.log 2>&1
+cp $(find gpurun_out/${tag}_prof_b1 -name 'bench_kernel_stats.csv' | head -1) gpurun_out/${tag}_decode_kernel_stats.csv
 # counters in their own runs (no trace domains)
 timeout 600 tools/pmc.sh gpurun_out/${tag}_pmc_gateup k_w4a16 -- python tools/prof_one.py 28672 4096 1 6 mfma > /dev/null; cp gpurun_out/${tag}_pmc_gateup/summary.txt gpurun_out/${tag}_gemv_gateup_pmc.txt
 for shp in "6144 4096" "4096 4096" "28672 4096" "4096 14336"; do
@@ -30,7 +33,5 @@ out["avg_bytes_per_launch"] = int(tot / 4)
 json.dump(out, open("gpurun_out/${tag}_gemv_traffic.json", "w"), indent=2)
 print(out)
 PY
-( for b in 8 32; do timeout 300 python bench.py --no-cpu-baseline --no-ttft --batch $b | tail -1; done
-  timeout 300 python bench.py --no-cpu-baseline --no-ttft --batch 32 --quant int8 | tail -1
-  timeout 300 python bench.py --no-cpu-baseline --no-ttft --batch 32 --kv-cache-dtype int8 | tail -1 ) > gpurun_out/${tag}_bench_batches.jsonl 2>/dev/null
-cut -c1-260 gpurun_out/${tag}_bench_batches.jsonl
+# (batch 8 / 32 and the INT8 route are legs of the default bench.py run since round 2: other_batches in the bench line)
+timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extras --batch 32 --kv-cache-dtype int8 | tail -1 > gpurun_out/${tag}_bench_kvint8_b32.json 2>/dev/null

@@ -748,6 +748,11 @@ class DynBatchContext:
     ks_addrs: Optional[torch.Tensor] = None
     vs_addrs: Optional[torch.Tensor] = None
     kv_scales: List[torch.Tensor] = field(default_factory=list)
+    # host-side bound on the device-side bookkeeping (advance / zl_greedy_advance bump placement with no host round trip):
+    # decode steps that still fit the tasks' buffers.  Eager steps raise when it is used up; a caller replaying a captured
+    # step bounds its replays itself (the scatter kernels drop a row whose slot lies outside its buffer -- never a stray write)
+    steps_left: int = 1 << 60
+    unquant_kv: Dict[int, torch.Tensor] = field(default_factory=dict)   # INT8 cache: a chunked prompt's temporary fp16 K/V
 
 
 class LLaMA:
@@ -849,6 +854,7 @@ class LLaMA:
         v_addrs = torch.tensor([[t[l, 1].data_ptr() for t in kv] for l in range(c.num_layers)], dtype=torch.int64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         return DynBatchContext(
+            steps_left=len_buf - start_pos,
             tokens=torch.zeros(batch, **i32), positions=torch.full((batch,), start_pos, **i32),
             placement=torch.full((batch,), start_pos, **i32), buf_lens=torch.full((batch,), len_buf, **i32),
             valid_lens=torch.full((batch,), start_pos + 1, **i32), k_addrs=k_addrs, v_addrs=v_addrs,
@@ -870,6 +876,9 @@ class LLaMA:
         """LLaMA::encode for a pure decode ("search") batch: returns logits (B, vocab) fp16."""
         c = self.cfg
         b = ctx.tokens.numel()
+        if ctx.steps_left <= 0 and not torch.cuda.is_current_stream_capturing():
+            raise ops.ZLError("decode step past the end of the KV buffers (placement >= len_buf): grow the buffers first "
+                              "(the reference asserts pos_buf < len_buf, ragged_buffer_kernel.cu:194-222)")
         bufs = self._buffers(b)
         if workspace is None:
             workspace = self._bufs.setdefault(("ws", b, ctx.max_len_buf),
@@ -1006,8 +1015,18 @@ class LLaMA:
         if chunk <= 0 or chunk >= s:
             return self._encode_prompt(ctx, task, prompt, 0)
         logits = None
-        for p0 in range(0, s, chunk):
-            logits = self._encode_prompt(ctx, task, prompt[p0:p0 + chunk], p0)
+        if ctx.kv_quant:
+            # INT8 KV cache: the prompt keeps attending to its UNquantised K/V rows across the chunks, held in temporary
+            # buffers for the duration of the prompt (dyn_batch->unquant_key_buf, attention.cpp:497-510) while the codes go
+            # to the cache; the decode steps that follow read the cache
+            c = self.cfg
+            ctx.unquant_kv[task] = torch.zeros((c.num_layers, 2, (s + 63) // 64 * 64, c.num_kv_heads, c.dim_head),
+                                               dtype=c.torch_dtype, device=self.device)
+        try:
+            for p0 in range(0, s, chunk):
+                logits = self._encode_prompt(ctx, task, prompt[p0:p0 + chunk], p0)
+        finally:
+            ctx.unquant_kv.pop(task, None)
         return logits
 
     def _encode_prompt(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor, pos0: int):
@@ -1094,6 +1113,7 @@ class LLaMA:
         ctx.positions[task] = pos0 + s
         ctx.placement[task] = pos0 + s
         ctx.valid_lens[task] = pos0 + s + 1
+        ctx.steps_left = min(ctx.steps_left, ctx.max_len_buf - (pos0 + s))
         return logits
 
     def _prefill_chunk(self, ctx: DynBatchContext, task: int, prompt: torch.Tensor, pos0: int):
@@ -1110,10 +1130,11 @@ class LLaMA:
         s = int(prompt.numel())
         if s < 1 or pos0 + s + 1 > ctx.max_len_buf:
             raise ops.ZLError("prompt does not fit the task's KV buffer")
-        if ctx.kv_quant and pos0 != 0:
-            # the reference de-quantises the earlier chunks there ("WARNING: de-quantize prompt kv cache!",
-            # attention.cpp:511-516); not wired here
-            raise ops.ZLError("chunked prefill is not supported with the INT8 KV cache")
+        unq = ctx.unquant_kv.get(task) if ctx.kv_quant else None
+        if ctx.kv_quant and pos0 != 0 and unq is None:
+            # a later piece without the prompt's temporary unquantised buffers (prefill(chunk=...) keeps them): the reference
+            # falls back to de-quantising the cache there ("WARNING: de-quantize prompt kv cache!", attention.cpp:511-516)
+            raise ops.ZLError("chunked prefill into the INT8 KV cache goes through LLaMA.prefill(chunk=...)")
         tokens = prompt.to(device=dev, dtype=torch.int32).contiguous()
         pos = torch.arange(pos0, pos0 + s, dtype=torch.int32, device=dev)
         hidden = ops.embedding(tokens, self.token_embedding, c.scale_emb)
@@ -1131,7 +1152,20 @@ class LLaMA:
                 k3, v3 = k.view(s, c.num_kv_heads, c.dim_head), v.view(s, c.num_kv_heads, c.dim_head)
                 ops.quant_copy_to_rag_buffer(pos, buf_lens, k3, v3, ka, va, ctx.ks_addrs[li][task:task + 1],
                                              ctx.vs_addrs[li][task:task + 1], len_q=s)
-                if c.dim_head == 128:
+                if unq is not None:
+                    # chunked: this piece's rows join the prompt's unquantised buffers, the piece attends to all of them
+                    tk, tv = unq[li, 0], unq[li, 1]
+                    tl = torch.tensor([tk.shape[0]], dtype=torch.int32, device=dev)
+                    ops.copy_to_rag_buffer2(placement, tl, k3.view(1, s, c.num_kv_heads, c.dim_head), v3.view(1, s, c.num_kv_heads, c.dim_head),
+                                            ops.make_ptr_table([tk]), ops.make_ptr_table([tv]))
+                    if c.dim_head == 128:
+                        att = ops.prefill_attention(q.view(s, c.num_heads, c.dim_head), tk, tv, pos0, c.num_kv_heads, scale)
+                    else:
+                        mask, ws = self._prefill_mask(s, tk.shape[0], pos0)
+                        att = ops.multi_query_attention_rag_buffer(q.view(1, s, c.num_heads, c.dim_head), tl, ops.make_ptr_table([tk]),
+                                                                   ops.make_ptr_table([tv]), mask, scale, tk.shape[0], c.num_kv_heads,
+                                                                   workspace=ws)
+                elif c.dim_head == 128:
                     att = ops.prefill_attention(q.view(s, c.num_heads, c.dim_head), k3, v3, 0, c.num_kv_heads, scale)
                 else:
                     mask, ws = self._prefill_mask(s, s, 0)
@@ -1157,6 +1191,7 @@ class LLaMA:
         ctx.positions[task] = pos0 + s
         ctx.placement[task] = pos0 + s
         ctx.valid_lens[task] = pos0 + s + 1
+        ctx.steps_left = min(ctx.steps_left, ctx.max_len_buf - (pos0 + s))
         return logits
 
     def step_greedy(self, ctx: DynBatchContext):
@@ -1176,6 +1211,7 @@ class LLaMA:
         ws, nxt = self._bufs[key]
         logits = self.encode(ctx, argmax_ws=ws)
         ops.greedy_advance(ws, b, self.cfg.vocab_size, ctx.tokens, ctx.positions, ctx.placement, ctx.valid_lens, nxt)
+        ctx.steps_left -= 1
         return logits, nxt
 
     def advance(self, ctx: DynBatchContext, next_tokens: torch.Tensor):
@@ -1185,6 +1221,7 @@ class LLaMA:
         ctx.positions.add_(1)
         ctx.placement.add_(1)
         ctx.valid_lens.add_(1)
+        ctx.steps_left -= 1
 
     def weight_bytes(self):
         return sum(l.weight_bytes() for l in self.layers)
