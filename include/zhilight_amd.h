@@ -229,6 +229,21 @@ int zl_rope_cos_sin(const int32_t* pos, float* cosv, float* sinv, int64_t s_len,
 int zl_rope_cos_sin_llama3(const int32_t* pos, float* cosv, float* sinv, int64_t s_len, int64_t d, float base,
                            float factor, float low_freq_factor, float high_freq_factor,
                            float old_context_len, int neox, zl_stream_t s);
+/* dynamic-NTK and YaRN angle tables for the same fused rotation kernels (RotaryEmbedding "dynamic", YarnImpl:
+ * src/nn/position/rotary_embedding.cu:19-61, 400-447, 506-553).  dynamic: theta scaled per row from its sequence length
+ * (seq_len[t], NULL = pos[t]: a decode row) with the reference's integer exponent dim_head / (dim_head - 2); yarn: inv_freq
+ * blended between interpolation and extrapolation over the pair index (low, high from yarn_find_correction_dim, computed by
+ * the caller in double like YarnImpl), cos / sin multiplied by mscale.  The reference rotates with these angles in T
+ * arithmetic (cos / sin rounded to T first); the fused kernels here rotate in fp32 with one rounding (<= 2 ulp apart). */
+int zl_rope_cos_sin_dynamic(const int32_t* pos, const int32_t* seq_len, float* cosv, float* sinv, int64_t s_len, int64_t d,
+                            float base, float factor, float max_position_embeddings, int neox, zl_stream_t s);
+int zl_rope_cos_sin_yarn(const int32_t* pos, float* cosv, float* sinv, int64_t s_len, int64_t d, float base, float factor,
+                         float low, float high, float mscale, int neox, zl_stream_t s);
+/* per-head norms of q / k before the rotation (x rows ld_in elements apart, head h at column h * d; in place when out == x):
+ *   mode 0: RMSNorm over dim_head with one (d) weight -- Qwen3's q_norm / k_norm (src/nn/attention/attention.cpp:110-113,871-876)
+ *   mode 1: KERNEL_layernorm_multi_head, weight (heads, d), mean-subtracted (src/nn/layernorm/layernorm.cu:305-325, use_qk_norm) */
+int zl_head_norm(const uint16_t* x, const uint16_t* weight, uint16_t* out, int64_t rows, int64_t heads, int64_t d, int64_t ld_in,
+                 int64_t ld_out, float eps, int mode, int dtype, zl_stream_t s);
 int zl_rotary_embedding_qk(const int32_t* pos, const uint16_t* in, uint16_t* q, uint16_t* k, uint16_t* v,
                            int64_t s_len, int64_t h, int64_t hkv, int64_t d, float theta, int dtype,
                            zl_stream_t s);

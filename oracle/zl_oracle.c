@@ -466,6 +466,92 @@ void zlo_rope_cos_sin_llama3(const int32_t* pos, float* cosv, float* sinv, int64
         }
 }
 
+/* RotaryEmbedding::impl "dynamic" angles (src/nn/position/rotary_embedding.cu:19-61): theta grows with the row's sequence
+ * length once it passes max_position_embeddings; the exponent dim_head / (dim_head - 2) is an int / int quotient in the
+ * reference (:38), kept as written.  seq_len NULL: the row is its own last position (a decode row). */
+void zlo_rope_cos_sin_dynamic(const int32_t* pos, const int32_t* seq_len, float* cosv, float* sinv, int64_t s, int64_t d,
+                              float base, float factor, float max_pos, int neox) {
+    for (int64_t t = 0; t < s; ++t) {
+        float theta = base;
+        int len = seq_len ? seq_len[t] : pos[t];
+        if ((float)len > max_pos)
+            theta *= powf((factor * (float)len / max_pos) - (factor - 1.f), (float)((int)d / ((int)d - 2)));
+        for (int col = 0; col < d; ++col) {
+            int i = half_dim_index(col, (int)d / 2, neox);
+            float freq = (float)pos[t] * powf(theta, -(float)(i * 2) / (float)d);
+            cosv[t * d + col] = cosf(freq);
+            sinv[t * d + col] = sinf(freq);
+        }
+    }
+}
+
+/* YarnImpl's constructor (rotary_embedding.cu:506-553): low / high pair indices and the cos / sin multiplier, in double */
+void zlo_yarn_params(double base, int dim_head, int original_max_position, double factor, int beta_fast, int beta_slow,
+                     double attn_factor, int deepseek, double mscale, double mscale_all_dim, float* low, float* high,
+                     float* out_mscale) {
+    const double PI = 3.141592653589793;
+    double c_fast = (dim_head * log((double)original_max_position / (beta_fast * 2 * PI))) / (2 * log(base));
+    double c_slow = (dim_head * log((double)original_max_position / (beta_slow * 2 * PI))) / (2 * log(base));
+    double lo = floor(c_fast), hi = ceil(c_slow);
+    *low = (float)(lo > 0. ? lo : 0.);
+    *high = (float)(hi < dim_head - 1. ? hi : dim_head - 1.);
+    double g1 = factor <= 1. ? 1. : 0.1 * log(factor) + 1.0;
+    float m = (float)(g1 * (double)(float)attn_factor);
+    if (deepseek) {
+        double ga = factor <= 1. ? 1. : 0.1 * mscale * log(factor) + 1.0;
+        double gb = factor <= 1. ? 1. : 0.1 * mscale_all_dim * log(factor) + 1.0;
+        m = (float)(ga / gb * (double)(float)attn_factor);
+    }
+    *out_mscale = m;
+}
+
+/* KERNEL_yarn_rope_neox_style's angle (rotary_embedding.cu:398-447): cos / sin of pos * blended inv_freq, times mscale */
+void zlo_rope_cos_sin_yarn(const int32_t* pos, float* cosv, float* sinv, int64_t s, int64_t d, float base, float factor,
+                           float low, float high, float mscale, int neox) {
+    for (int64_t t = 0; t < s; ++t)
+        for (int col = 0; col < d; ++col) {
+            int i = half_dim_index(col, (int)d / 2, neox);
+            float fi = (float)i;
+            float pos_freq = powf(base, (float)(i * 2) / (float)d);
+            float extrap = 1.0f / pos_freq, interp = 1.0f / (factor * pos_freq);
+            float ramp = fi <= low ? 0.f : (fi >= high ? 1.f : (fi - low) / (high - low));
+            float mask = 1.f - ramp;
+            float inv_freq = fmaf(interp, ramp, extrap * mask); /* a*b + c*d: contracted to one fma by nvcc */
+            float freq = (float)pos[t] * inv_freq;
+            cosv[t * d + col] = cosf(freq) * mscale;
+            sinv[t * d + col] = sinf(freq) * mscale;
+        }
+}
+
+/* per-head norms of q / k: mode 0 = LayerNorm(dim_head) rms on the (rows, heads, dim_head) view, one weight for all heads
+ * (Qwen3 q_norm / k_norm, src/nn/attention/attention.cpp:110-113,871-876 -> KERNEL_layernorm_rms, layernorm.cu:14-43);
+ * mode 1 = KERNEL_layernorm_multi_head (layernorm.cu:329-353): mean-subtracted, weight (heads, d) */
+void zlo_head_norm(const uint16_t* x, const uint16_t* w, uint16_t* out, int64_t rows, int64_t heads, int64_t d,
+                   int64_t ld_in, int64_t ld_out, float eps, int mode, int dtype) {
+    int threads = mode == 1 ? (int)d : round_up_i((int)d, 32);
+    if (threads > 1024) threads = 1024;
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t h = 0; h < heads; ++h) {
+            const uint16_t* xr = x + r * ld_in + h * d;
+            uint16_t* orow = out + r * ld_out + h * d;
+            float part[1024], v[1024];
+            for (int64_t i = 0; i < d; ++i) v[i] = T2f(xr[i], dtype);
+            if (mode == 1) {
+                for (int t = 0; t < threads; ++t) part[t] = t < d ? v[t] : 0.f;
+                float mean = block_tree_sum(part, threads) / (float)d;
+                for (int64_t i = 0; i < d; ++i) v[i] -= mean;
+            }
+            for (int t = 0; t < threads; ++t) {
+                float acc = 0.f;
+                for (int64_t i = t; i < d; i += threads) acc = fmaf(v[i], v[i], acc);
+                part[t] = acc;
+            }
+            float rs = 1.0f / sqrtf(block_tree_sum(part, threads) / (float)d + eps);
+            for (int64_t i = 0; i < d; ++i)
+                orow[i] = f2T(v[i] * rs * T2f(w[(mode == 1 ? h * d : 0) + i], dtype), dtype);
+        }
+}
+
 /* rope_one_value (rope_common.cuh:14-34): a*cos -/+ b*sin in fp32 (second product fused) */
 static inline float rope_val(float a, float b, float c, float s, int minus) {
     return minus ? fmaf(-b, s, a * c) : fmaf(b, s, a * c);

@@ -80,6 +80,15 @@ void zlo_rmsnorm_exact(const uint16_t* x, const uint16_t* w, double* out, int64_
 /* ---- a13: RoPE ---- */
 void zlo_rope_cos_sin(const int32_t* pos, float* cosv, float* sinv, int64_t s, int64_t d,
                       float base, int neox);
+void zlo_rope_cos_sin_dynamic(const int32_t* pos, const int32_t* seq_len, float* cosv, float* sinv, int64_t s, int64_t d,
+                              float base, float factor, float max_pos, int neox);
+void zlo_yarn_params(double base, int dim_head, int original_max_position, double factor, int beta_fast, int beta_slow,
+                     double attn_factor, int deepseek, double mscale, double mscale_all_dim, float* low, float* high,
+                     float* out_mscale);
+void zlo_rope_cos_sin_yarn(const int32_t* pos, float* cosv, float* sinv, int64_t s, int64_t d, float base, float factor,
+                           float low, float high, float mscale, int neox);
+void zlo_head_norm(const uint16_t* x, const uint16_t* w, uint16_t* out, int64_t rows, int64_t heads, int64_t d,
+                   int64_t ld_in, int64_t ld_out, float eps, int mode, int dtype);
 void zlo_rope_cos_sin_llama3(const int32_t* pos, float* cosv, float* sinv, int64_t s, int64_t d,
                              float base, float factor, float low_freq_factor,
                              float high_freq_factor, float old_context_len, int neox);

@@ -213,6 +213,44 @@ def rope_cos_sin(pos, d, base, neox=True, llama3=None):
     return cs, sn
 
 
+def rope_cos_sin_dynamic(pos, d, base, factor, max_pos, seq_len=None, neox=True):
+    pos = _c(pos, np.int32)
+    s = pos.size
+    sl = None if seq_len is None else _c(seq_len, np.int32)
+    cs, sn = np.empty((s, d), np.float32), np.empty((s, d), np.float32)
+    lib().zlo_rope_cos_sin_dynamic(_p(pos), _p(sl) if sl is not None else None, _p(cs), _p(sn), _i(s), _i(d), _f(base),
+                                   _f(factor), _f(max_pos), C.c_int(int(neox)))
+    return cs, sn
+
+
+def yarn_params(base, dim_head, original_max_position, factor, beta_fast=32, beta_slow=1, attn_factor=1.0, deepseek=False,
+                mscale=0.0, mscale_all_dim=0.0):
+    factor, mscale, mscale_all_dim = (C.c_float(v).value for v in (factor, mscale, mscale_all_dim))
+    lo, hi, m = C.c_float(), C.c_float(), C.c_float()
+    lib().zlo_yarn_params(C.c_double(base), C.c_int(dim_head), C.c_int(original_max_position), C.c_double(factor),
+                          C.c_int(beta_fast), C.c_int(beta_slow), C.c_double(attn_factor), C.c_int(int(deepseek)),
+                          C.c_double(mscale), C.c_double(mscale_all_dim), C.byref(lo), C.byref(hi), C.byref(m))
+    return lo.value, hi.value, m.value
+
+
+def rope_cos_sin_yarn(pos, d, base, factor, low, high, mscale, neox=True):
+    pos = _c(pos, np.int32)
+    s = pos.size
+    cs, sn = np.empty((s, d), np.float32), np.empty((s, d), np.float32)
+    lib().zlo_rope_cos_sin_yarn(_p(pos), _p(cs), _p(sn), _i(s), _i(d), _f(base), _f(factor), _f(low), _f(high), _f(mscale),
+                                C.c_int(int(neox)))
+    return cs, sn
+
+
+def head_norm(x, w, heads, d, eps, mode=0, dtype=0):
+    x, w = _c(x, np.uint16), _c(w, np.uint16)
+    rows = x.shape[0]
+    out = np.empty_like(x)
+    lib().zlo_head_norm(_p(x), _p(w), _p(out), _i(rows), _i(heads), _i(d), _i(x.shape[1]), _i(x.shape[1]), _f(eps),
+                        C.c_int(mode), C.c_int(dtype))
+    return out
+
+
 def rotary_embedding_qk(pos, x, h, hkv, d, theta, dtype=0):
     pos, x = _c(pos, np.int32), _c(x, np.uint16)
     s = pos.size

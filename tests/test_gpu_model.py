@@ -39,6 +39,7 @@ def _hf_state(rng, cfg, g):
 class OracleModel:
     def __init__(self, oracle, cfg, sd, g, batch, len_buf, kv_quant=False):
         self.o, self.cfg, self.g = oracle, cfg, g
+        self.rope_kind = ((cfg.rope_scaling or {}).get("rope_type") or "llama3")
         self.sd = sd
         self.kv_quant = kv_quant
         if kv_quant:   # INT8 KV cache: u8 codes (128 = zero) + fp32 scale per (slot, kv head)
@@ -57,6 +58,36 @@ class OracleModel:
         self.kb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
         self.vb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
         self.len_buf = len_buf
+
+    def _tables(self, pos):
+        """cos / sin of one forward: llama3 (the default of these tests), dynamic NTK (sequence length = the call's last
+        position, rotary_embedding.cu:36) or yarn"""
+        o, c = self.o, self.cfg
+        pos = np.asarray(pos, np.int32)
+        rs = c.rope_scaling or {}
+        if self.rope_kind == "dynamic":
+            return o.rope_cos_sin_dynamic(pos, c.dim_head, c.rope_theta, rs["factor"], c.max_position_embeddings,
+                                          np.full(pos.size, pos[-1], np.int32))
+        if self.rope_kind == "yarn":
+            low, high, msc = o.yarn_params(c.rope_theta, c.dim_head, rs["original_max_position_embeddings"], rs["factor"],
+                                           rs.get("beta_fast", 32), rs.get("beta_slow", 1), rs.get("attn_factor", 1.0))
+            return o.rope_cos_sin_yarn(pos, c.dim_head, c.rope_theta, rs["factor"], low, high, msc)
+        return o.rope_cos_sin(pos, c.dim_head, c.rope_theta, True, (8.0, 1.0, 4.0, 8192.0))
+
+    def _qk_norm(self, i, qkv):
+        """q_norm / k_norm on the q and k windows before the rotation (attention.cpp:864-876)"""
+        o, c = self.o, self.cfg
+        if not c.qk_norm:
+            return qkv
+        hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
+        mode = 0 if c.qk_norm == "head" else 1
+        p = f"model.layers.{i}.self_attn."
+        qkv = qkv.copy()
+        qkv[:, :hd] = o.head_norm(np.ascontiguousarray(qkv[:, :hd]), o.h2u(self.sd[p + "q_norm.weight"]), c.num_heads, c.dim_head,
+                                  c.eps, mode)
+        qkv[:, hd:hd + kvd] = o.head_norm(np.ascontiguousarray(qkv[:, hd:hd + kvd]), o.h2u(self.sd[p + "k_norm.weight"]),
+                                          c.num_kv_heads, c.dim_head, c.eps, mode)
+        return qkv
 
     def _gemv(self, x, name, flavour):
         """decode linear: 'R' = the reference's warp-reduce kernel arithmetic (fp16 hfma2 partial sums, its own
@@ -80,14 +111,14 @@ class OracleModel:
                 if self.kv_quant:
                     self.kc, self.vc, self.ks, self.vs = saved_q
         h = o.embedding(np.asarray(tokens, np.int32), o.h2u(self.sd["model.embed_tokens.weight"]))
-        llama3 = (8.0, 1.0, 4.0, 8192.0)
-        cs, sn = o.rope_cos_sin(np.asarray(pos, np.int32), c.dim_head, c.rope_theta, True, llama3)
+        cs, sn = self._tables(pos)
         lens = np.full(b, self.len_buf, np.int32)
         mask = np.concatenate([(np.arange(self.len_buf) <= p).astype(np.int8) for p in pos])
         for i in range(c.num_layers):
             p = f"model.layers.{i}."
             xn = o.rmsnorm(h, o.h2u(self.sd[p + "input_layernorm.weight"]), c.eps)
             qkv = np.concatenate([self._gemv(xn, p + "self_attn." + n + "_proj", flavour) for n in "qkv"], axis=1)
+            qkv = self._qk_norm(i, qkv)
             q, k, v = o.rope_qk_cache(cs, sn, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
             if self.kv_quant:
                 self._quant_store(i, range(b), [[p_] for p_ in pos], k, v)
@@ -134,13 +165,14 @@ class OracleModel:
         s = len(tokens)
         h = o.embedding(np.asarray(tokens, np.int32), o.h2u(self.sd["model.embed_tokens.weight"]))
         pos = np.arange(s, dtype=np.int32)
-        cs, sn = o.rope_cos_sin(pos, c.dim_head, c.rope_theta, True, (8.0, 1.0, 4.0, 8192.0))
+        cs, sn = self._tables(pos)
         lens = np.full(1, self.len_buf, np.int32)
         mask = np.tril(np.ones((s, self.len_buf), np.int8))
         for i in range(c.num_layers):
             p = f"model.layers.{i}."
             xn = o.rmsnorm(h, o.h2u(self.sd[p + "input_layernorm.weight"]), c.eps)
             qkv = np.concatenate([self._lin40(xn, p + "self_attn." + n + "_proj") for n in "qkv"], axis=1)
+            qkv = self._qk_norm(i, qkv)
             q, k, v = o.rope_qk_cache(cs, sn, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
             o.copy_to_rag_buffer2(pos.reshape(1, s), lens, k.reshape(1, s, c.num_kv_heads, c.dim_head),
                                   v.reshape(1, s, c.num_kv_heads, c.dim_head), [self.kb[i][task]], [self.vb[i][task]], True)
@@ -975,3 +1007,47 @@ def test_decode_past_the_kv_buffers_is_refused_and_harmless(dev):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(ctx2.kv[0], before)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qk_norm,rope", [("head", "yarn"), ("multi_head", "dynamic"), (None, "yarn")])
+def test_qk_norm_and_scaled_rope_model_matches_oracle(oracle, dev, qk_norm, rope):
+    """Qwen3-style q_norm / k_norm (per-head RMSNorm) or the multi-head LayerNorm of use_qk_norm, with YaRN or dynamic-NTK
+    angles (positions past the scaling threshold): prompt + decode steps against the oracle restatement, same bars as the
+    plain model.  The fused qkv + rotary GEMV epilogue is off for these models (the norm sits between projection and rotation)."""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    rng = np.random.default_rng(11)
+    rs = ({"rope_type": "yarn", "factor": 4.0, "original_max_position_embeddings": 32, "beta_fast": 32, "beta_slow": 1}
+          if rope == "yarn" else {"rope_type": "dynamic", "factor": 2.0})
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2,
+                      eps=1e-6, rope_theta=1e4, rope_scaling=rs, qk_norm=qk_norm, max_position_embeddings=48)
+    g, s, len_buf = 128, 70, 128
+    sd = _hf_state(rng, cfg, g)
+    if qk_norm:
+        for i in range(cfg.num_layers):
+            nq, nk = (cfg.dim_head, cfg.dim_head) if qk_norm == "head" else (cfg.num_heads * cfg.dim_head, cfg.num_kv_heads * cfg.dim_head)
+            sd[f"model.layers.{i}.self_attn.q_norm.weight"] = (1 + 0.2 * rng.standard_normal(nq)).astype(np.float16)
+            sd[f"model.layers.{i}.self_attn.k_norm.weight"] = (1 + 0.2 * rng.standard_normal(nk)).astype(np.float16)
+    model = LLaMA(cfg, QuantConfig(5, g), dev).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ctx = model.new_context(1, len_buf, 0)
+    om = OracleModel(oracle, cfg, sd, g, 1, len_buf)
+    prompt = rng.integers(0, cfg.vocab_size, s).astype(np.int32)
+    got = model.prefill(ctx, 0, torch.from_numpy(prompt)).float().cpu().numpy().astype(np.float64)
+    ref = om.prefill(0, prompt)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-3 * scale + 2.0 ** -11 * scale, np.abs(got - ref).max() / scale
+    for li in range(cfg.num_layers):
+        gk = ctx.kv[0][li, 0].cpu().numpy()[:s].astype(np.float64)
+        rk = oracle.u2h(om.kb[li][0][:s]).astype(np.float64)
+        assert np.abs(gk - rk).max() <= 2.0 ** -9 * np.abs(rk).max()
+    tok = int(ref.argmax(axis=1)[0])
+    ctx.tokens[0] = tok
+    for step in range(2):
+        lg = model.encode(ctx).float().cpu().numpy().astype(np.float64)
+        ex, _ = om.step([tok], [s + step], flavour="E", commit=False)
+        rf, _ = om.step([tok], [s + step], flavour="R")
+        sc = np.abs(rf).max()
+        assert np.abs(lg - ex).max() <= 1e-3 * sc + 2.0 ** -11 * sc, (step, np.abs(lg - ex).max() / sc)
+        assert np.abs(lg - rf).max() <= 3e-3 * sc
+        tok = int(rf.argmax(axis=1)[0])
+        model.advance(ctx, torch.tensor([tok], device=dev))

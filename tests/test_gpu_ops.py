@@ -599,3 +599,51 @@ def test_decode_attention_single_kv_head_very_long_buffer(oracle, dev):
                                 True, exact=True)
     assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-3)
     assert ref[0, 0, 0].mean() > 0.5                         # the tail really dominates (else the test proves nothing)
+
+
+@pytest.mark.gpu
+def test_rope_tables_dynamic_ntk_and_yarn(oracle, dev):
+    """RotaryEmbedding "dynamic" and YarnImpl angles (rotary_embedding.cu:19-61, 398-553) as cos / sin tables: device vs
+    oracle within the angle's fp32 uncertainty (pos x a few ulp of inv_freq), the host-side yarn constants bit-equal."""
+    from zhilight_amd import ops
+    d = 128
+    pos = np.concatenate([np.arange(0, 70), [1024, 4095, 8191, 40000, 131071]]).astype(np.int32)
+    bound = 1e-6 + 6 * 2.0 ** -24 * np.maximum(pos[:, None].astype(np.float64), 1.0)
+    for theta in (1e4, 1e6):
+        for seq in (None, np.full(pos.size, 131071, np.int32), pos[::-1].copy()):
+            rc, rs = oracle.rope_cos_sin_dynamic(pos, d, theta, 2.0, 4096.0, seq)
+            gc, gs = ops.rope_cos_sin_dynamic(_t(pos, dev), d, theta, 2.0, 4096.0, None if seq is None else _t(seq, dev))
+            assert (np.abs(_np(gc) - rc) <= bound).all() and (np.abs(_np(gs) - rs) <= bound).all()
+        for deepseek, kw in ((False, {}), (True, dict(mscale=1.0, mscale_all_dim=0.707))):
+            ref_p = oracle.yarn_params(theta, d, 4096, 40.0, 32, 1, 1.0, deepseek, **kw)
+            got_p = ops.yarn_params(theta, d, 4096, 40.0, 32, 1, 1.0, deepseek, **kw)
+            assert ref_p == got_p, (ref_p, got_p)
+            rc, rs = oracle.rope_cos_sin_yarn(pos, d, theta, 40.0, *ref_p)
+            gc, gs = ops.rope_cos_sin_yarn(_t(pos, dev), d, theta, 40.0, *got_p)
+            b2 = bound * max(1.0, ref_p[2])
+            assert (np.abs(_np(gc) - rc) <= b2).all() and (np.abs(_np(gs) - rs) <= b2).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_head_norm_matches_oracle(oracle, dev, mode, dtype):
+    """q_norm / k_norm over dim_head (mode 0: Qwen3 RMSNorm, one weight; mode 1: KERNEL_layernorm_multi_head), in place on a
+    column window of a wider fused-projection row."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(5 + mode)
+    tdt = torch.float16 if dtype == 0 else torch.bfloat16
+    for rows, heads, d in ((1, 32, 128), (7, 8, 64), (33, 2, 256)):
+        wide = torch.from_numpy(rng.standard_normal((rows, heads * d + 2 * d)).astype(np.float32) * 2 + 0.3).to(dev).to(tdt)
+        w = torch.from_numpy(1 + 0.2 * rng.standard_normal(d if mode == 0 else heads * d).astype(np.float32)).to(dev).to(tdt)
+        x = wide[:, d:d + heads * d]
+        xb = x.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+        ref = oracle.head_norm(xb, w.view(torch.int16).cpu().numpy().view(np.uint16), heads, d, 1e-6, mode, dtype)
+        keep = wide.clone()
+        out = ops.head_norm(x, w, heads, d, 1e-6, mode)
+        got = out.view(torch.int16).cpu().numpy().view(np.uint16)
+        ulp = synth.ulp_diff_f16(got, ref) if dtype == 0 else np.abs(got.astype(np.int64) - ref.astype(np.int64))
+        assert ulp.max() <= 1 and (ulp > 0).mean() < 0.02, (rows, heads, d, ulp.max(), (ulp > 0).mean())
+        ops.head_norm(x, w, heads, d, 1e-6, mode, out=x)       # in place on the window; the columns around it untouched
+        assert torch.equal(x.contiguous().view(torch.int16), out.view(torch.int16))
+        assert torch.equal(wide[:, :d], keep[:, :d]) and torch.equal(wide[:, d + heads * d:], keep[:, d + heads * d:])

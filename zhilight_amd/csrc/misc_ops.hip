@@ -87,6 +87,62 @@ __global__ void k_rope_cos_sin(const int32_t* __restrict__ pos, float* __restric
     sinv[(size_t)blockIdx.x * d + col] = sinf(freq);
 }
 
+// dynamic-NTK and YaRN angle tables (RotaryEmbedding::impl "dynamic" / YarnImpl, src/nn/position/rotary_embedding.cu:19-61,
+// 400-447, 506-553), as cached cos / sin for the fused rotation kernels:
+//   dynamic: theta' = theta * ((factor * L / max_pos) - (factor - 1)) ^ (d / (d - 2))   when L > max_pos, L = the row's
+//            sequence length (the reference reads the LAST position of the row, :36); the exponent is the reference's
+//            INTEGER quotient dim_head / (dim_head - 2) (= 1 for every real head size), reproduced as written
+//   yarn:    inv_freq = interp * ramp + extrap * (1 - ramp), ramp = clamp((i - low) / (high - low)) over the pair index i,
+//            cos / sin scaled by mscale (low, high, mscale computed on the host in double like YarnImpl's constructor)
+__global__ void k_rope_cos_sin_scaled(const int32_t* __restrict__ pos, const int32_t* __restrict__ seq_len,
+                                      float* __restrict__ cosv, float* __restrict__ sinv, int d, float base, int neox, int type,
+                                      float factor, float p1, float p2, float p3) {
+    const int col = threadIdx.x;
+    if (col >= d) return;
+    const int i = half_dim_index(col, d / 2, neox);
+    const int t = blockIdx.x;
+    float freq, scale = 1.f;
+    if (type == 2) {            // dynamic NTK: p1 = max_position_embeddings
+        float theta = base;
+        const int len = seq_len ? seq_len[t] : pos[t];
+        if ((float)len > p1) theta *= powf((factor * (float)len / p1) - (factor - 1.f), (float)(d / (d - 2)));
+        freq = (float)pos[t] * powf(theta, -(float)(i * 2) / (float)d);
+    } else {                    // yarn: p1 = low, p2 = high, p3 = mscale
+        const float pos_freq = powf(base, (float)(i * 2) / (float)d);
+        const float extrap = 1.0f / pos_freq, interp = 1.0f / (factor * pos_freq);
+        const float fi = (float)i;
+        const float ramp = fi <= p1 ? 0.f : (fi >= p2 ? 1.f : (fi - p1) / (p2 - p1));
+        freq = (float)pos[t] * __builtin_fmaf(interp, ramp, extrap * (1.f - ramp));
+        scale = p3;
+    }
+    cosv[(size_t)t * d + col] = cosf(freq) * scale;
+    sinv[(size_t)t * d + col] = sinf(freq) * scale;
+}
+
+// per-head norms of q / k (grid (rows, heads), block d <= 1024; in place when out == x):
+//   mode 0  RMSNorm over dim_head with ONE weight (d) for every head: Qwen3's q_norm / k_norm (attention.cpp:110-113, 871-876:
+//           LayerNorm(dim_head) on the (rows, heads, dim_head) view): out = T(v * rsqrt(mean(v^2) + eps) * w[col])
+//   mode 1  KERNEL_layernorm_multi_head (layernorm.cu:305-325, use_qk_norm): v = x - mean(x); out = T(v * rsqrt(mean(v^2) + eps) *
+//           w[head][col])
+template <int DT>
+__global__ void k_head_norm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, uint16_t* __restrict__ out, int d,
+                            int64_t ld_in, int64_t ld_out, float eps, int mode) {
+    __shared__ float red[16];
+    const int col = threadIdx.x, head = blockIdx.y;
+    const int64_t row = blockIdx.x;
+    float v = col < d ? ZT<DT>::to_f32(x[row * ld_in + (int64_t)head * d + col]) : 0.f;
+    if (mode == 1) {
+        const float mean = zl_block_sum(v, red) / (float)d;
+        v = col < d ? v - mean : 0.f;
+    }
+    const float var = zl_block_sum(v * v, red) / (float)d;
+    const float r = zl_rsqrt_rn(var + eps);
+    if (col < d) {
+        const float wv = ZT<DT>::to_f32(w[(mode == 1 ? (int64_t)head * d : 0) + col]);
+        out[row * ld_out + (int64_t)head * d + col] = ZT<DT>::from_f32(v * r * wv);
+    }
+}
+
 __device__ __forceinline__ float rope_val(float a, float b, float c, float s, bool minus) {
     return minus ? __builtin_fmaf(-b, s, a * c) : __builtin_fmaf(b, s, a * c);
 }
@@ -348,6 +404,35 @@ int zl_rope_cos_sin_llama3(const int32_t* pos, float* cosv, float* sinv, int64_t
     ZL_CHECK_ARG(d <= 1024 && d % 2 == 0, ZL_ESHAPE);
     hipLaunchKernelGGL(k_rope_cos_sin, dim3((unsigned)s_len), dim3((unsigned)d), 0, (hipStream_t)s, pos, cosv, sinv,
                        (int)d, base, neox, 1, factor, low_freq_factor, high_freq_factor, old_context_len);
+    return zl_launch_status();
+}
+
+int zl_rope_cos_sin_dynamic(const int32_t* pos, const int32_t* seq_len, float* cosv, float* sinv, int64_t s_len, int64_t d, float base,
+                            float factor, float max_position_embeddings, int neox, zl_stream_t s) {
+    ZL_CHECK_ARG(pos && cosv && sinv && s_len > 0 && d > 2 && max_position_embeddings > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 1024 && d % 2 == 0, ZL_ESHAPE);
+    hipLaunchKernelGGL(k_rope_cos_sin_scaled, dim3((unsigned)s_len), dim3((unsigned)d), 0, (hipStream_t)s, pos, seq_len, cosv, sinv,
+                       (int)d, base, neox, 2, factor, max_position_embeddings, 0.f, 0.f);
+    return zl_launch_status();
+}
+
+int zl_rope_cos_sin_yarn(const int32_t* pos, float* cosv, float* sinv, int64_t s_len, int64_t d, float base, float factor, float low,
+                         float high, float mscale, int neox, zl_stream_t s) {
+    ZL_CHECK_ARG(pos && cosv && sinv && s_len > 0 && d > 0 && factor > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 1024 && d % 2 == 0, ZL_ESHAPE);
+    hipLaunchKernelGGL(k_rope_cos_sin_scaled, dim3((unsigned)s_len), dim3((unsigned)d), 0, (hipStream_t)s, pos, nullptr, cosv, sinv,
+                       (int)d, base, neox, 3, factor, low, high, mscale);
+    return zl_launch_status();
+}
+
+int zl_head_norm(const uint16_t* x, const uint16_t* weight, uint16_t* out, int64_t rows, int64_t heads, int64_t d, int64_t ld_in,
+                 int64_t ld_out, float eps, int mode, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(x && weight && out && rows > 0 && heads > 0 && d > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 1024 && heads <= 65535 && ld_in >= heads * d && ld_out >= heads * d && (mode == 0 || mode == 1), ZL_ESHAPE);
+    const dim3 grid((unsigned)rows, (unsigned)heads), block((unsigned)((d + 63) / 64 * 64));
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_head_norm<ZL_F16>, grid, block, 0, (hipStream_t)s, x, weight, out, (int)d, ld_in, ld_out, eps, mode),
+        hipLaunchKernelGGL(k_head_norm<ZL_BF16>, grid, block, 0, (hipStream_t)s, x, weight, out, (int)d, ld_in, ld_out, eps, mode))
     return zl_launch_status();
 }
 

@@ -52,6 +52,9 @@ class ModelConfig:
     dim_model_base: int = 0                 # MiniCPM: logits scale = dim_model_base / dim_model
     scale_depth: float = -1.0               # MiniCPM residual scale scale_depth / sqrt(num_layers)
     tie_lm_head: bool = False
+    qk_norm: Optional[str] = None           # "head": Qwen3 q_norm / k_norm (dim_head weight); "multi_head": use_qk_norm
+    max_position_embeddings: int = 0        # dynamic-NTK rope threshold
+    model_type: str = "llama"
     dtype: str = "half"                     # "half" | "bfloat16" (unquantised models; the W4 / int8 routes are fp16)
 
     @property
@@ -76,6 +79,9 @@ class ModelConfig:
             rope_scaling=cfg.get("rope_scaling"), activate_fn=cfg.get("hidden_act", "silu"),
             scale_emb=cfg.get("scale_emb", 1.0), dim_model_base=cfg.get("dim_model_base", 0),
             scale_depth=cfg.get("scale_depth", -1.0), tie_lm_head=cfg.get("tie_word_embeddings", False),
+            qk_norm=("head" if cfg.get("model_type") in ("qwen3", "qwen3_moe") else
+                     "multi_head" if cfg.get("use_qk_norm") else None),     # attention.cpp:110-117
+            max_position_embeddings=cfg.get("max_position_embeddings", 0), model_type=cfg.get("model_type", "llama"),
             dtype={"bfloat16": "bfloat16", "float16": "half"}.get(cfg.get("torch_dtype", "float16"), "half"))
 
     @classmethod
@@ -130,6 +136,7 @@ def hf_name_to_internal(name: str) -> str:
     s = re.sub(r"model\.layers\.([0-9]+)\.post_attention_layernorm\.weight", r"layers.\1.ln_ff.weight", s)
     s = re.sub(r"model\.layers\.([0-9]+)\.self_attn\.([qkv])_proj\.", r"layers.\1.attn.project_\2.", s)
     s = re.sub(r"model\.layers\.([0-9]+)\.self_attn\.o_proj\.", r"layers.\1.attn.attn_out.", s)
+    s = re.sub(r"model\.layers\.([0-9]+)\.self_attn\.([qk])_norm\.", r"layers.\1.attn.\2_norm.", s)
     s = re.sub(r"model\.layers\.([0-9]+)\.mlp\.gate_proj\.", r"layers.\1.ff.w_in.", s)
     s = re.sub(r"model\.layers\.([0-9]+)\.mlp\.up_proj\.", r"layers.\1.ff.w_gated.", s)
     s = re.sub(r"model\.layers\.([0-9]+)\.mlp\.down_proj\.", r"layers.\1.ff.w_out.", s)
@@ -807,7 +814,41 @@ class LLaMA:
             self.lm_head = self.lm_head[self.tp.rank * v:(self.tp.rank + 1) * v].contiguous()
         for i, layer in enumerate(self.layers):
             layer.load_state_dict(sd, f"llama.layers.{i}", dev)
+            layer.q_norm = layer.k_norm = None
+            if self.cfg.qk_norm:
+                layer.q_norm, layer.k_norm = (self._qk_norm_weight(sd[f"llama.layers.{i}.attn.{n}_norm.weight"], n)
+                                              for n in ("q", "k"))
         return self
+
+    def _qk_norm_weight(self, w, which):
+        """q_norm / k_norm weights (attention.cpp:110-117): (dim_head) for "head"; (heads * dim_head) for "multi_head", of
+        which a TP rank keeps its heads' rows (replicated kv heads: the one head it holds)."""
+        c, fc = self.cfg, self.full_cfg
+        t = _dev_t(w, self.device).to(c.torch_dtype).reshape(-1)
+        if c.qk_norm == "head":
+            if t.numel() != c.dim_head:
+                raise ops.ZLError("q_norm / k_norm weight must have dim_head elements")
+            return t.contiguous()
+        full = fc.num_heads if which == "q" else fc.num_kv_heads
+        loc = c.num_heads if which == "q" else c.num_kv_heads
+        if t.numel() != full * c.dim_head:
+            raise ops.ZLError("q_norm / k_norm weight must have heads * dim_head elements")
+        if self.tp:
+            kv_part = getattr(self.layers[0], "kv_part", None)
+            first = kv_part[0] if (which == "k" and kv_part) else self.tp.rank * loc
+            t = t.view(full, c.dim_head)[first:first + loc]
+        return t.contiguous()
+
+    def apply_qk_norm(self, layer, qkv):
+        """q_norm / k_norm in place on the q and k windows of the fused projection, before the rotation
+        (attention.cpp:864-876 fused, :904-915 separate projections)."""
+        c = self.cfg
+        if not c.qk_norm:
+            return
+        hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
+        mode = 0 if c.qk_norm == "head" else 1
+        ops.head_norm(qkv[:, :hd], layer.q_norm, c.num_heads, c.dim_head, c.eps, mode, out=qkv[:, :hd])
+        ops.head_norm(qkv[:, hd:hd + kvd], layer.k_norm, c.num_kv_heads, c.dim_head, c.eps, mode, out=qkv[:, hd:hd + kvd])
 
     def init_random(self, seed=0):
         gen = torch.Generator(device=self.device).manual_seed(seed)
@@ -819,6 +860,11 @@ class LLaMA:
         self.lm_head = self.token_embedding if (c.tie_lm_head and not self.tp) else (torch.randn(vloc, c.dim_model, device=dev, generator=gen) * 0.02).to(dt)
         for layer in self.layers:
             layer.init_random(dev, gen)
+            layer.q_norm = layer.k_norm = None
+            if c.qk_norm:
+                nq, nk = (c.dim_head, c.dim_head) if c.qk_norm == "head" else (c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head)
+                layer.q_norm = (1.0 + 0.1 * torch.randn(nq, device=dev, generator=gen)).to(dt)
+                layer.k_norm = (1.0 + 0.1 * torch.randn(nk, device=dev, generator=gen)).to(dt)
         return self
 
     # ---- KV state ------------------------------------------------------------------------------
@@ -883,19 +929,19 @@ class LLaMA:
         if workspace is None:
             workspace = self._bufs.setdefault(("ws", b, ctx.max_len_buf),
                                               ops.decode_attn_workspace(b, 1, c.num_heads, c.dim_head, ctx.max_len_buf, self.device))
-        llama3 = self._llama3_rope()
         hidden = ops.embedding(ctx.tokens, self.token_embedding, c.scale_emb)      # token_embedding
-        cos, sin = ops.rope_cos_sin(ctx.positions, c.dim_head, c.rope_theta, True, llama3)  # RopePreparer
+        cos, sin = self._rope_tables(ctx.positions)                                # RopePreparer
         scale = 1.0 / math.sqrt(c.dim_head)
         mfma_attn = (c.dim_head == 128 and c.num_heads // c.num_kv_heads <= 16
                      and os.environ.get("ZL_ATTN_MFMA", "1") != "0")
         # fused qkv projection + rotary + KV scatter in the GEMV epilogue (zl_w4a16_qkv_rope_scatter) where it applies
         fuse_qkv_rope = (mfma_attn and not ctx.kv_quant and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
+                         and not c.qk_norm
                          and all(isinstance(l, EncoderLayer) and l.unfused is None and l.qkv.perm is None
                                  and isinstance(l.qkv.weight, ops.W4MWeight)
                                  for l in self.layers)
                          and ops.w4_qkv_rope_scatter_ok(b, c.dim_model, c.dim_head, norm=b <= 8))
-        fuse_qkv_rope_i8 = (mfma_attn and not ctx.kv_quant and b <= 32 and c.dim_head % 32 == 0
+        fuse_qkv_rope_i8 = (mfma_attn and not ctx.kv_quant and b <= 32 and c.dim_head % 32 == 0 and not c.qk_norm
                             and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
                             and all(isinstance(l, Int8EncoderLayer) and l._stream(b) for l in self.layers))
         # a few rows: the split merge of the decode attention rides in the attn_out projection's prologue (one launch less)
@@ -937,6 +983,7 @@ class LLaMA:
                 layer.ff_add(hidden, c.eps, bufs["act"])
                 continue
             layer.project_qkv(hidden, c.eps, out=bufs["qkv"])
+            self.apply_qk_norm(layer, bufs["qkv"])
             if ctx.kv_quant:
                 # attention.cpp:652-676 + :725-745: rotate, quantise the new K/V rows into the u8 cache, attend over codes
                 ops.rope_quant_scatter_decode(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li],
@@ -986,16 +1033,33 @@ class LLaMA:
         return ops.gemm_nt_small_m(hidden, self.lm_head, out=out, norm_weight=self.output_layernorm, norm_eps=c.eps,
                                    argmax_ws=argmax_ws)
 
-    def _llama3_rope(self):
-        rs = self.cfg.rope_scaling
+    def _rope_tables(self, pos):
+        """cos / sin (rows, dim_head) fp32 of one forward's positions: RopePreparer (rope_preparer.cu:49-160) for plain and
+        llama3 frequencies, the RotaryEmbedding variants "dynamic" (NTK) and "yarn" (rotary_embedding.cu:19-61, 398-553)
+        as tables for the same fused rotation kernels."""
+        c = self.cfg
+        rs = c.rope_scaling
         kind = rs.get("rope_type", rs.get("type")) if rs else None
+        if kind in (None, "default"):
+            return ops.rope_cos_sin(pos, c.dim_head, c.rope_theta, True, None)
         if kind == "llama3":
-            return (rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"])
-        if kind not in (None, "default"):
-            # the reference also knows "dynamic" and "yarn" (rotary_embedding.cu:131-670); running such a checkpoint with
-            # unscaled frequencies would be silently wrong
-            raise ops.ZLError(f"rope_scaling type {kind!r} is not supported on this path (supported: llama3)")
-        return None
+            return ops.rope_cos_sin(pos, c.dim_head, c.rope_theta, True,
+                                    (rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"]))
+        if kind == "dynamic":
+            if c.max_position_embeddings <= 0:
+                raise ops.ZLError("dynamic rope scaling needs max_position_embeddings")
+            # the reference reads ONE sequence length per forward: the position of the call's last row (rotary_embedding.cu:36,
+            # gridDim.x - 1 of the flat (tokens, dim) view) -- for a decode batch that is the last task's position
+            seq_len = pos[-1:].expand(pos.numel()).contiguous()
+            return ops.rope_cos_sin_dynamic(pos, c.dim_head, c.rope_theta, rs["factor"], c.max_position_embeddings, seq_len)
+        if kind == "yarn":
+            deepseek = c.model_type in ("deepseek_v2", "deepseek_v3")
+            low, high, msc = ops.yarn_params(c.rope_theta, c.dim_head, rs["original_max_position_embeddings"], rs["factor"],
+                                             int(rs.get("beta_fast", 32)), int(rs.get("beta_slow", 1)),
+                                             rs.get("attn_factor", 1.0), deepseek, rs.get("mscale", 0.0),
+                                             rs.get("mscale_all_dim", 0.0))
+            return ops.rope_cos_sin_yarn(pos, c.dim_head, c.rope_theta, rs["factor"], low, high, msc)
+        raise ops.ZLError(f"rope_scaling type {kind!r} is not supported (supported: llama3, dynamic, yarn)")
 
     def _prefill_mask(self, s, len_buf, pos0=0):
         """causal mask + workspace for head sizes the MFMA prefill kernel does not cover"""
@@ -1057,7 +1121,7 @@ class LLaMA:
         tokens = prompt.to(device=dev, dtype=torch.int32).contiguous()
         pos = torch.arange(pos0, pos0 + s, dtype=torch.int32, device=dev)
         hidden_all = ops.embedding(tokens, self.token_embedding, c.scale_emb)
-        cos, sin = ops.rope_cos_sin(pos, c.dim_head, c.rope_theta, True, self._llama3_rope())
+        cos, sin = self._rope_tables(pos)
         buf_lens = ctx.buf_lens[task:task + 1]
         scale = 1.0 / math.sqrt(c.dim_head)
         main = torch.cuda.current_stream(dev)
@@ -1091,6 +1155,7 @@ class LLaMA:
                 else:
                     xn, hidden[k] = ops.rmsnorm(hidden[k], layer.ln_attn, c.eps, x2=reduced(k))
                 qkv = layer.project_qkv(None, c.eps, normed=xn)
+                self.apply_qk_norm(layer, qkv)
                 q, kr, v = ops.rope_qk_cache(cos[a:b], sin[a:b], qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
                 ops.copy_to_rag_buffer2(pos[a:b].view(1, n), buf_lens, kr.view(1, n, c.num_kv_heads, c.dim_head),
                                         v.view(1, n, c.num_kv_heads, c.dim_head), ka, va)
@@ -1138,13 +1203,14 @@ class LLaMA:
         tokens = prompt.to(device=dev, dtype=torch.int32).contiguous()
         pos = torch.arange(pos0, pos0 + s, dtype=torch.int32, device=dev)
         hidden = ops.embedding(tokens, self.token_embedding, c.scale_emb)
-        cos, sin = ops.rope_cos_sin(pos, c.dim_head, c.rope_theta, True, self._llama3_rope())
+        cos, sin = self._rope_tables(pos)
         placement = pos.view(1, s)
         buf_lens = ctx.buf_lens[task:task + 1]
         scale = 1.0 / math.sqrt(c.dim_head)
         for li, layer in enumerate(self.layers):
             ka, va = ctx.k_addrs[li][task:task + 1], ctx.v_addrs[li][task:task + 1]
             qkv = layer.project_qkv(hidden, c.eps)
+            self.apply_qk_norm(layer, qkv)
             q, k, v = ops.rope_qk_cache(cos, sin, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
             if ctx.kv_quant:
                 # attn_encode_group with a quantised buffer (attention.cpp:494-510): the prompt attends to its own

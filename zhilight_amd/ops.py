@@ -10,6 +10,7 @@ paths relative to the ZhiLight tree).
 """
 import ctypes as C
 import os
+import math
 
 import torch
 
@@ -424,6 +425,73 @@ def rope_cos_sin(pos, dim_head, base, neox=True, llama3=None):
         check(lib().zl_rope_cos_sin_llama3(_p(pos), _p(cs), _p(sn), _i(s), _i(dim_head), _f(base), _f(fac), _f(low),
                                            _f(high), _f(old), C.c_int(int(neox)), _stream()), "rope_cos_sin_llama3")
     return cs, sn
+
+
+def rope_cos_sin_dynamic(pos, dim_head, base, factor, max_position_embeddings, seq_len=None, neox=True):
+    """RotaryEmbedding "dynamic" (NTK) angles (src/nn/position/rotary_embedding.cu:19-61); seq_len (s,) int32 = the position
+    the reference reads as the row's sequence length (None: the row's own position)."""
+    _chk_cuda(pos)
+    s = pos.numel()
+    cs = torch.empty((s, dim_head), dtype=torch.float32, device=pos.device)
+    sn = torch.empty_like(cs)
+    if seq_len is not None:
+        _chk_cuda(seq_len)
+        if seq_len.numel() != s or seq_len.dtype != torch.int32:
+            raise ZLError("rope_cos_sin_dynamic: seq_len must be int32 (s,)")
+    check(lib().zl_rope_cos_sin_dynamic(_p(pos), _p(seq_len) if seq_len is not None else None, _p(cs), _p(sn), _i(s),
+                                        _i(dim_head), _f(base), _f(factor), _f(max_position_embeddings), C.c_int(int(neox)),
+                                        _stream()), "rope_cos_sin_dynamic")
+    return cs, sn
+
+
+def yarn_params(base, dim_head, original_max_position, factor, beta_fast=32, beta_slow=1, attn_factor=1.0, deepseek=False,
+                mscale=0.0, mscale_all_dim=0.0):
+    """YarnImpl's constructor (rotary_embedding.cu:506-553): (low, high, mscale) in double, narrowed to float."""
+    def corr(rot):
+        return (dim_head * math.log(original_max_position / (rot * 2 * 3.141592653589793))) / (2 * math.log(base))
+
+    def get_mscale(scale, m=1.0):
+        return 1.0 if scale <= 1.0 else 0.1 * m * math.log(scale) + 1.0
+    f32 = lambda v: C.c_float(v).value  # noqa: E731  (the reference keeps factor / mscale / attn_factor as float members)
+    factor, mscale, mscale_all_dim = f32(factor), f32(mscale), f32(mscale_all_dim)
+    low = max(float(math.floor(corr(beta_fast))), 0.0)
+    high = min(float(math.ceil(corr(beta_slow))), dim_head - 1.0)
+    af = f32(attn_factor)
+    m = get_mscale(factor) * af
+    if deepseek:
+        m = get_mscale(factor, mscale) / get_mscale(factor, mscale_all_dim) * af
+    return f32(low), f32(high), f32(m)
+
+
+def rope_cos_sin_yarn(pos, dim_head, base, factor, low, high, mscale, neox=True):
+    """YaRN angles (KERNEL_yarn_rope_neox_style, rotary_embedding.cu:398-447): cos / sin already multiplied by mscale."""
+    _chk_cuda(pos)
+    s = pos.numel()
+    cs = torch.empty((s, dim_head), dtype=torch.float32, device=pos.device)
+    sn = torch.empty_like(cs)
+    check(lib().zl_rope_cos_sin_yarn(_p(pos), _p(cs), _p(sn), _i(s), _i(dim_head), _f(base), _f(factor), _f(low), _f(high),
+                                     _f(mscale), C.c_int(int(neox)), _stream()), "rope_cos_sin_yarn")
+    return cs, sn
+
+
+def head_norm(x, weight, num_heads, dim_head, eps, mode=0, out=None):
+    """q_norm / k_norm over dim_head: mode 0 = Qwen3's RMSNorm with one (dim_head) weight (attention.cpp:110-113,871-876),
+    mode 1 = KERNEL_layernorm_multi_head with a (heads, dim_head) weight (layernorm.cu:329-353).  x (rows, >= heads*dim_head)
+    may be a column slice of a wider row (a q or k window of the fused qkv projection); in place with out=x."""
+    _chk_cuda(weight)
+    if not x.is_cuda or (out is not None and not out.is_cuda):
+        raise ZLError("tensors must be CUDA tensors")
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] != num_heads * dim_head:
+        raise ZLError("head_norm: x must be (rows, heads * dim_head) with unit column stride")
+    if weight.numel() != (dim_head if mode == 0 else num_heads * dim_head) or weight.dtype != x.dtype:
+        raise ZLError("head_norm: weight shape / dtype mismatch")
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+    elif out.shape != x.shape or out.stride(1) != 1 or out.dtype != x.dtype:
+        raise ZLError("head_norm: out shape mismatch")
+    check(lib().zl_head_norm(_p(x), _p(weight), _p(out), _i(x.shape[0]), _i(num_heads), _i(dim_head), _i(x.stride(0)),
+                             _i(out.stride(0)), _f(eps), C.c_int(mode), _dt(x), _stream()), "head_norm")
+    return out
 
 
 def rotary_embedding_qk(pos, x, num_heads, num_kv_heads, dim_head, rope_theta):
