@@ -230,7 +230,9 @@ def _check_mfma(oracle, dev, k, n, m, seed, bias=False, norm=False, residual=Fal
     # fp16 output rounding (2^-11 relative) + fp32 accumulation noise; with the fused norm the normalised
     # input may differ by 1 fp16 ulp on a few elements (block-sum association)
     tight = 2.0 ** -10 * (np.abs(exact) + lin) + (3e-4 if norm else 2e-5) * rms
-    loose = 2.0 ** -10 * (np.abs(exact) + lin) + 1.5e-3 * rms   # + the W16 weight rounding between the two flavours
+    # + the W16 weight rounding between the two flavours (rn16 of (q - z) * s: with one or two groups per row the
+    # per-group rounding patterns do not average out over K)
+    loose = 2.0 ** -10 * (np.abs(exact) + lin) + 1.5e-3 * max(1.0, (1024.0 / k) ** 0.5) * rms
     d_exact, d_40 = np.abs(got - exact), np.abs(got - ref40)
     if tiled:
         assert (d_40 <= 2.0 ** -10 * (np.abs(ref40) + lin) + 2e-5 * rms).all(), float((d_40 / rms).max())
@@ -265,6 +267,22 @@ def test_tiled_gemm_shapes(oracle, dev, m, k, n):
     _check_mfma(oracle, dev, k, n, m, seed=52 + m, residual=True, force_tiled=True)
     _check_mfma(oracle, dev, k, n, m, seed=53 + m, bias=True)
     _check_mfma(oracle, dev, k, n, m, seed=54 + m, residual=True)
+
+
+@pytest.mark.parametrize("m,k,n,splitk,force", [(128, 1024, 256, 0, 0), (257, 2048, 384, 0, 0), (1000, 1152 + 128, 1000, 0, 0),
+                                                (130, 4096, 512, 3, 0), (70, 1024, 520, 0, 1), (384, 128, 256, 0, 0),
+                                                (256, 256, 4096, 0, 0)])
+def test_wide_gemm_shapes(oracle, dev, m, k, n, splitk, force, monkeypatch):
+    """The prompt-chunk tile (k_w4a16_gemm_wide: 128 x 256 outputs per workgroup, activations by LDS-DMA into the swizzled
+    stage image): ragged M / N, one- and two-chunk K (shorter than the pipeline), K that is not a multiple of 4 stages,
+    split-K through the caller's scratch, bias / residual epilogues; the same bars as the other M-tiled kernel."""
+    if splitk:
+        monkeypatch.setenv("ZL_W4_TILED_SPLITK", str(splitk))
+    if force:
+        monkeypatch.setenv("ZL_W4_TILED_WIDE", "1")
+    _check_mfma(oracle, dev, k, n, m, seed=70 + m, force_tiled=True)
+    _check_mfma(oracle, dev, k, n, m, seed=71 + m, bias=True, force_tiled=True)
+    _check_mfma(oracle, dev, k, n, m, seed=72 + m, residual=True, force_tiled=True)
 
 
 @pytest.mark.parametrize("rounds", [1, 2, 3, 4, 5, 6, 7, 8])

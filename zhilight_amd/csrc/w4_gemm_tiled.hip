@@ -23,7 +23,11 @@ constexpr int kWavesT = 4;
 constexpr int kThreadsT = kWavesT * 64;
 constexpr int kBN = kWavesT * 32;
 constexpr int kRingT = 8;          // items (2 per chunk)
+#ifdef ZL_TILED_SWZ
+constexpr int kRowHalfs = 128;     // 256-B rows, 16-byte unit u of row r at u ^ (r & 15): conflict-free ds_read_b128 / ds_write_b128
+#else
 constexpr int kRowHalfs = 128 + 8; // padded LDS row
+#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -121,7 +125,11 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
     auto store_x = [&](int buf) {
 #pragma unroll
         for (int r = 0; r < XR; ++r)
+#ifdef ZL_TILED_SWZ
+            *reinterpret_cast<uint4*>(&xs[buf][(xrow + 16 * r) * kRowHalfs + (((threadIdx.x & 15) ^ xrow) * 8)]) = xr[r];
+#else
             *reinterpret_cast<uint4*>(&xs[buf][(xrow + 16 * r) * kRowHalfs + xcol]) = xr[r];
+#endif
     };
 
     load_x(g_begin);
@@ -158,15 +166,30 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
             const hv2 s2 = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(mw, mw, 0x01000100u));
             const uint32_t wds[4] = {wq[slot0 + j].x, wq[slot0 + j].y, wq[slot0 + j].z, wq[slot0 + j].w};
 #pragma unroll
+#ifdef ZL_TEXP_NODEQ
+            for (int t = 0; t < 4; ++t) bfr[j][t] = __builtin_bit_cast(h8, make_uint4(wds[t], mw, wds[(t + 1) & 3], magic));
+#else
             for (int t = 0; t < 4; ++t) bfr[j][t] = dequant_scaled(wds[t], z1, z16, s2, mask_lo, mask_hi, magic);
+#endif
         }
         issue_pair(slot0);
+#ifdef ZL_TILED_SWZ
+        const unsigned char* xb8 = reinterpret_cast<const unsigned char*>(&xs[buf][0]) + nrow * 256;
+        const uint32_t u0 = (uint32_t)((kq ^ nrow) * 16);
+#else
         const uint16_t* xb = &xs[buf][nrow * kRowHalfs + kq * 8];
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
+#ifdef ZL_TEXP_NOLDS
+                const h8 a = __builtin_bit_cast(h8, make_uint4(magic + rb, magic + t, mask_lo, mask_hi));
+#elif defined(ZL_TILED_SWZ)
+                const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(xb8 + rb * 4096 + (u0 ^ (uint32_t)(t * 64))));
+#else
                 const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(xb + rb * 16 * kRowHalfs + t * 32));
+#endif
                 acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bfr[0][t], acc[rb][0], 0, 0, 0);
                 acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bfr[1][t], acc[rb][1], 0, 0, 0);
             }
@@ -181,9 +204,13 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
         for (int u = 0; u < 4; ++u) {
             if (g + u < G) {                  // workgroup-uniform
                 chunk(2 * u, u & 1);
+#ifndef ZL_TEXP_NOSTAGE
                 store_x((u + 1) & 1);         // chunk g+u+1 (loaded one step ago) -> the other buffer
                 load_x(g + u + 2);
+#endif
+#ifndef ZL_TEXP_NOBAR
                 __syncthreads();
+#endif
             }
         }
     }
@@ -246,6 +273,325 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_w4a16_gemm_wide -- the prompt-chunk GEMM (M >= 128): same operands, same arithmetic, a tile shaped for the LDS pipe
+// and scheduled inside the wave.
+//
+// PMC of k_w4a16_gemm_tiled<128> (wave = 128 x 32 outputs, two workgroups per CU) showed all three pipes loaded at once:
+// every activation fragment read from LDS fed two MFMAs (128 KB of ds_read_b128 per 128-k chunk and workgroup = as many
+// cycles as its 256 MFMAs), 2-way bank conflicts on top, 176 VALU next to 64 MFMAs per chunk and wave.  Here:
+//   * workgroup = 4 waves = 128 x 256 outputs, wave = 128 x 64: FOUR weight tiles share every activation fragment (half
+//     the LDS reads per MFMA, half the dequant VALU per MFMA of a 64-row tile); ONE workgroup per CU with the whole
+//     register file (128 accumulators, a 4-chunk weight ring, two sets of B fragments, three activation fragments);
+//   * everything that is not an MFMA rides in the shadow of the MFMAs of the SAME wave: the k-step is cut into 8 blocks
+//     of 4 MFMAs (one 16-row block x four tiles), each block carries one activation-fragment read two blocks ahead, one
+//     eighth of the NEXT k-step's dequantisation (half a word: 7 VALU), and one piece of the activation staging or of the
+//     weight ring refill; sched_barrier pins the block order, the compiler schedules inside a block;
+//   * the LDS image of the activation chunk (128 rows x 256 B) is XOR-swizzled: 16-byte unit u of row r sits at
+//     u ^ (r & 15): the 16 rows of a ds_read_b128 lane group cover the 64 banks exactly once, and so do the 8 units of a
+//     ds_write_b128 lane group;
+//   * blockIdx -> (column tile, row tile) such that the row tiles of one column tile run on ONE XCD at the same time: its
+//     weights come from HBM once and from that XCD's L2 for the other row tiles.
+constexpr int kWideBM = 128;
+constexpr int kWideChunkBytes = kWideBM * 128 * 2;   // one 128-k activation chunk in LDS
+constexpr int kWideRing = 2;                         // weight chunks in flight (4 items each): ~2 x 2 000 cycles ahead
+
+template <int U>
+struct WideIdx { static constexpr int value = U; };
+
+// the main loop of k_w4a16_gemm_wide is written in issue order: volatile one-instruction asm statements keep their source
+// order, so the dequant VALU can be placed BETWEEN the MFMAs of a block (a wave issues in order: four MFMAs back to back
+// hold it for ~50 cycles and the VALU behind them then runs with the matrix pipe idle)
+__device__ __forceinline__ uint32_t wv_and_or(uint32_t w, uint32_t mask_s, uint32_t magic_v) {
+    uint32_t r;
+    asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mask_s), "v"(magic_v));
+    return r;
+}
+__device__ __forceinline__ uint32_t wv_lshr8(uint32_t w) {
+    uint32_t r;
+    asm volatile("v_lshrrev_b32 %0, 8, %1" : "=v"(r) : "v"(w));
+    return r;
+}
+__device__ __forceinline__ uint32_t wv_pk_add(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t wv_pk_fma(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t wv_pk_mul(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+#ifndef ZL_WIDE_OCC
+#define ZL_WIDE_OCC 1
+#endif
+__global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const TiledParams p, const int gx, const int gy) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_w[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrow = lane & 15, kq = lane >> 4;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int ry = local % gy, cx = (local / gy) * 8 + xcd;
+    if (cx >= gx) return;
+    const int m0 = ry * kWideBM;
+    const int tile0 = cx * 16 + wave * 4;                      // this wave's four 16-column weight tiles
+    const int g_begin = p.ws ? blockIdx.y * p.split_chunks : 0;
+    const int G = p.ws ? min(p.groups, g_begin + p.split_chunks) : p.groups;
+
+    // ---- weight ring: kWideRing chunks x 4 items
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
+    const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)nrow * 4u;
+    uint32_t tbase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tbase[j] = (uint32_t)(tile0 + j < p.tiles ? tile0 + j : p.tiles - 1) * (uint32_t)p.groups;
+    uint4 wq[4 * kWideRing];
+    uint32_t mt[4 * kWideRing];
+    auto issue_item = [&](int slot, int j, int g) {
+        const uint32_t it = tbase[j] + (uint32_t)(g < G ? g : G - 1);
+        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off, it * 1024u, 2));
+        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(rm, m_off, it * 64u, 2);
+    };
+
+    // ---- activation staging: thread -> (row tid / 16 + 16 r, 16-byte unit tid % 16), LDS unit = unit ^ (row & 15);
+    // rows through a buffer descriptor (rows past M clamp to the last row: never stored)
+    const int xrow = threadIdx.x >> 4, xu = threadIdx.x & 15;
+    const uint32_t xs_off = (uint32_t)(xrow * 256 + ((xu ^ xrow) * 16));
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0xffffffffu, 0x00020000);
+    uint32_t xg_off[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = m0 + xrow + 16 * r;
+        xg_off[r] = (uint32_t)(((size_t)(row < p.m ? row : p.m - 1) * p.ldx + xu * 8) * 2);
+    }
+    uint4 xr[8];
+    auto load_x1 = [&](int r, int g) {
+        const uint32_t gc = (uint32_t)(g < G ? g : G - 1);
+        xr[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, xg_off[r], gc * 256u, 0));
+    };
+    auto store_x1 = [&](int r, uint32_t buf_off) {
+        *reinterpret_cast<uint4*>(smem_w + buf_off + xs_off + r * 4096) = xr[r];
+    };
+    // fragment reads: row 16 rb + nrow, unit (4 t + kq) ^ nrow
+    const uint32_t a_off0 = (uint32_t)(nrow * 256 + ((kq ^ nrow) * 16));     // t = 0; t > 0: ^ (64 t)
+
+    const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
+    const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(0x00f000f0u);
+    uint32_t magic = 0x64006400u;
+    asm volatile("" : "+v"(magic));
+    const hv2 c960 = {(_Float16)960.f, (_Float16)960.f};
+    const hv2 one16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    uint32_t one16_v = 0x2c002c00u;                            // 0.0625 x 2, in a VGPR for the asm statements
+    asm volatile("" : "+v"(one16_v));
+
+    f4 acc[8][4];
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[rb][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    hv2 z1[4], z16[4], s2[4];
+    // live == false: a chunk past the end (odd chunk counts run the second half of the unrolled pair on the clamped last
+    // chunk): its scales are zero, so it adds exact zeros
+    auto load_consts = [&](int slot0, bool live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t mw = mt[slot0 + j];
+            z1[j] = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(mw, mw, 0x03020302u));
+            z16[j] = z1[j] + c960;
+            s2[j] = __builtin_bit_cast(hv2, live ? __builtin_amdgcn_perm(mw, mw, 0x01000100u) : 0u);
+        }
+    };
+    auto word_of = [&](int slot, int t) -> uint32_t {
+        return t == 0 ? wq[slot].x : (t == 1 ? wq[slot].y : (t == 2 ? wq[slot].z : wq[slot].w));
+    };
+    // B fragments of two k-steps as raw words: bw[set][tile][4]; half h of a word fills [2 h], [2 h + 1] (dequant_scaled's order)
+    uint32_t bw[2][4][4];
+    auto dequant_half = [&](int set, int j, uint32_t w, int h) {
+        const uint32_t ws = h ? (w >> 8) : w;
+        const hv2 lo = (__builtin_bit_cast(hv2, and_or_t(ws, mask_lo, magic)) + z1[j]) * s2[j];
+        const hv2 hi = __builtin_elementwise_fma(__builtin_bit_cast(hv2, and_or_t(ws, mask_hi, magic)), one16, z16[j]) * s2[j];
+        bw[set][j][2 * h] = __builtin_bit_cast(uint32_t, lo);
+        bw[set][j][2 * h + 1] = __builtin_bit_cast(uint32_t, hi);
+    };
+    auto bfrag = [&](int set, int j) -> h8 {
+        return __builtin_bit_cast(h8, make_uint4(bw[set][j][0], bw[set][j][1], bw[set][j][2], bw[set][j][3]));
+    };
+
+    // ---- prologue
+#pragma unroll
+    for (int r = 0; r < 8; ++r) load_x1(r, g_begin);
+#pragma unroll
+    for (int c = 0; c < kWideRing; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_item(4 * c + j, j, g_begin + c);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) store_x1(r, 0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) load_x1(r, g_begin + 1);
+    load_consts(0, true);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dequant_half(0, j, word_of(j, 0), 0);
+        dequant_half(0, j, word_of(j, 0), 1);
+    }
+    __syncthreads();
+
+    uint4 af[4];
+    // one 128-k chunk; U = chunk index mod 2: ring slots 4 U .. 4 U + 3, LDS buffer U.  Straight-line code: 32 blocks of
+    // 4 MFMAs (k-step t = blk / 8, 16-row block rb = blk % 8), each with its share of everything else
+    auto chunk = [&](auto Uc, int g, bool next_live) {
+        constexpr int U = decltype(Uc)::value;
+        constexpr int cs = 4 * U, ns = 4 * (U ^ 1);
+        constexpr uint32_t xb = U * kWideChunkBytes, xo = (U ^ 1) * kWideChunkBytes;
+        auto read_a = [&](int slot, int blk) {
+            af[slot] = *reinterpret_cast<const uint4*>(smem_w + xb + (a_off0 ^ (uint32_t)((blk >> 3) * 64)) + (blk & 7) * 4096);
+        };
+        read_a(0, 0);
+        read_a(1, 1);
+        read_a(2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int blk = 0; blk < 32; ++blk) {
+            const int t = blk >> 3, rb = blk & 7;
+#ifndef ZL_WEXP_NOLDS
+            if (blk + 3 < 32) read_a((blk + 3) & 3, blk + 3);
+#endif
+            const h8 a = __builtin_bit_cast(h8, af[blk & 3]);
+            // the accumulators are tied to ONE AGPR quad each (inline asm "+a"): with the builtin the allocator rotates 64
+            // of the 128 accumulators through copies at the loop back-edge (192 v_accvgpr moves per two chunks, each
+            // serialising against its MFMA)
+#define ZL_WIDE_MFMA(J)                                                                                      \
+    {                                                                                                        \
+        const h8 bb = bfrag(t & 1, J);                                                                       \
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[rb][J]) : "v"(a), "v"(bb));         \
+    }
+            // one eighth of the next k-step's B fragments between the MFMAs: tile dj = rb / 2, half dh = rb & 1 of word
+            // t + 1 of this chunk (t == 3: word 0 of the next chunk, with its meta)
+            const int dj = rb >> 1, dh = rb & 1, dset = (t + 1) & 1;
+            if (t == 3 && rb == 0) load_consts(ns, next_live);
+            const uint32_t w = t < 3 ? word_of(cs + dj, t + 1) : word_of(ns + dj, 0);
+#ifdef ZL_WEXP_NODEQ
+            ZL_WIDE_MFMA(0) ZL_WIDE_MFMA(1) ZL_WIDE_MFMA(2) ZL_WIDE_MFMA(3)
+            bw[dset][dj][2 * dh] = w;
+#else
+            const uint32_t ws = dh ? wv_lshr8(w) : w;
+            ZL_WIDE_MFMA(0)
+            const uint32_t x_lo = wv_and_or(ws, mask_lo, magic), x_hi = wv_and_or(ws, mask_hi, magic);
+            ZL_WIDE_MFMA(1)
+            const uint32_t y_lo = wv_pk_add(x_lo, __builtin_bit_cast(uint32_t, z1[dj]));
+            const uint32_t y_hi = wv_pk_fma(x_hi, one16_v, __builtin_bit_cast(uint32_t, z16[dj]));
+            ZL_WIDE_MFMA(2)
+            bw[dset][dj][2 * dh] = wv_pk_mul(y_lo, __builtin_bit_cast(uint32_t, s2[dj]));
+            bw[dset][dj][2 * dh + 1] = wv_pk_mul(y_hi, __builtin_bit_cast(uint32_t, s2[dj]));
+            ZL_WIDE_MFMA(3)
+#endif
+            // staging: piece r of chunk g + 1 (loaded one chunk ago) -> the other LDS buffer, its registers take chunk g + 2
+#ifndef ZL_WEXP_NOSTAGE
+            if (t < 2 && (blk & 1) == 0) {
+                store_x1(blk >> 1, xo);
+                load_x1(blk >> 1, g + 2);
+            }
+#endif
+            if (t == 3 && rb >= 1 && rb <= 4) issue_item(cs + rb - 1, rb - 1, g + kWideRing);
+#ifndef ZL_WEXP_NOPIN
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+#ifndef ZL_WEXP_NOBAR
+        __syncthreads();
+#endif
+    };
+
+#pragma unroll 1
+    for (int g = g_begin; g < G; g += 2) {
+        chunk(WideIdx<0>{}, g, g + 1 < G);
+        chunk(WideIdx<1>{}, g + 1, g + 2 < G);
+    }
+
+    // the MFMAs are inline asm: the compiler does not know that the accumulators come out of the matrix pipe and inserts no
+    // wait states between the last MFMAs and the first reads of their results (observed: registers of the last block read
+    // one MFMA early).  MFMAs retire in order, so the results of the last two blocks are passed through builtin MFMAs that
+    // add exact zeros: the compiler then orders every read of those behind the pipe, and everything older is done by then.
+    {
+        const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int rb = 6; rb < 8; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zero8, zero8, acc[rb][j], 0, 0, 0);
+    }
+    // ---- epilogue (row-block-major like the main loop: the accumulators stay where the loop left them)
+    if (p.ws) {
+        float* wsz = p.ws + (size_t)blockIdx.y * p.m * p.ld_ws;
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = (tile0 + j) * 16 + nrow;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + rb * 16 + 4 * kq + i;
+                    if (row < p.m && n < p.ld_ws) wsz[(size_t)row * p.ld_ws + n] = acc[rb][j][i];
+                }
+            }
+        return;
+    }
+    float bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = (tile0 + j) * 16 + nrow;
+        bj[j] = ((p.epi & ZL_EPI_BIAS) && p.bias && n < p.n) ? (float)__builtin_bit_cast(_Float16, p.bias[n]) : 0.f;
+    }
+    // three separately unrolled passes (one runs): a single loop with all the branches is too large to unroll, and a
+    // rolled loop would index the accumulators dynamically (= spill them)
+    auto for_each = [&](auto fn) {
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fn(m0 + rb * 16 + 4 * kq + i, (tile0 + j) * 16 + nrow, acc[rb][j][i] , bj[j]);
+    };
+    if (!(p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32))) {
+        for_each([&](int row, int n, float v, float b) {
+            if (row < p.m && n < p.n) {
+                const size_t o = (size_t)row * p.ld_out + n;
+                float ov;
+                if (p.epi & ZL_EPI_ADD_C) ov = ((float)__builtin_bit_cast(_Float16, p.y[o]) + v) + b;
+                else ov = v + b;
+                _Float16 y16 = zl_f32_to_f16(ov);
+                if (p.epi & ZL_EPI_RESIDUAL) y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, p.residual[o]) + (float)y16);
+                p.y[o] = __builtin_bit_cast(uint16_t, y16);
+            }
+        });
+    } else if (p.epi & ZL_EPI_SILU_MUL) {
+        // rows of the packed matrix interleave gate (even n) and up (odd n): partner = lane ^ 1
+        for_each([&](int row, int n, float v, float b) {
+            v += b;
+            const float other = __shfl_xor(v, 1, 64);
+            if ((nrow & 1) == 0 && row < p.m && n + 1 < p.n) {
+                const float gt = (float)zl_f32_to_f16(v), up = (float)zl_f32_to_f16(other);
+                p.y[(size_t)row * p.ld_out + n / 2] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(silu_t(gt) * up));
+            }
+        });
+    } else {
+        for_each([&](int row, int n, float v, float b) {
+            v += b;
+            const float other = __shfl_xor(v, 1, 64);
+            if ((nrow & 1) == 0 && row < p.m && n + 1 < p.n) {
+                const float ov = (float)((double)v / (1.0 + (double)expf(-v))) * other;
+                p.y[(size_t)row * p.ld_out + n / 2] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(ov));
+            }
+        });
     }
 }
 
@@ -328,6 +674,43 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
     p.ld_out = (int)(silu ? n / 2 : n);
     const int gx = (int)((L.np + kBN - 1) / kBN);
     hipStream_t hs = (hipStream_t)s;
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    // prompt chunks: the 128 x 256 tile (k_w4a16_gemm_wide)
+    if (o.tiled_wide >= 0 && o.tiled_bm == 0 && (m >= 128 || (o.tiled_wide > 0 && m > 32)) && L.np >= 256) {
+        const int gxw = (int)((L.np + 255) / 256), gyw = (int)((m + kWideBM - 1) / kWideBM);
+        int splits = 1;
+        if ((int64_t)gxw * gyw < cus) {                    // N = 4096 projections at M = 1024: 128 tiles for 256 CUs
+            splits = (int)((2 * (int64_t)cus + (int64_t)gxw * gyw - 1) / ((int64_t)gxw * gyw));
+            const int max_s = p.groups / 8 > 0 ? p.groups / 8 : 1;
+            if (splits > max_s) splits = max_s;
+            if (splits > 8) splits = 8;
+        }
+        if (o.tiled_splitk > 0) splits = o.tiled_splitk <= p.groups ? o.tiled_splitk : p.groups;
+        p.ws = nullptr; p.split_chunks = p.groups; p.ld_ws = (int)L.np;
+        if (splits > 1) {
+            p.split_chunks = (p.groups + splits - 1) / splits;
+            splits = (p.groups + p.split_chunks - 1) / p.split_chunks;
+            const int64_t need = ZL_SCRATCH_HEADER + (int64_t)splits * m * L.np * (int64_t)sizeof(float);
+            if (o.scratch && o.scratch_bytes >= need) {
+                p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(o.scratch) + ZL_SCRATCH_HEADER);
+            } else {
+                splits = 1;
+                p.split_chunks = p.groups;
+            }
+        }
+        const int64_t wgs = (int64_t)((gxw + 7) / 8) * 8 * gyw;
+        ZL_CHECK_ARG(wgs <= 0x7fffffff, ZL_ELIMIT);
+        hipLaunchKernelGGL(k_w4a16_gemm_wide, dim3((unsigned)wgs, (unsigned)splits), dim3(256), 2 * kWideChunkBytes, hs, p,
+                           gxw, gyw);
+        st = zl_launch_status();
+        if (st || splits <= 1) return st;
+        const int64_t outs = m * (silu ? n / 2 : n);
+        const unsigned rgrid = (unsigned)((outs + 255) / 256 > 4096 ? 4096 : (outs + 255) / 256);
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3(rgrid), dim3(256), 0, hs, p.ws, splits, (int)m, (int)n, p.ld_ws, bias, residual, y,
+                           epilogue, p.ld_out);
+        return zl_launch_status();
+    }
     // M-tile height: taller tiles amortise the dequant over more MFMAs (the VALU and the MFMA pipe do not
     // overlap here: 143 VALU + 32 MFMA per chunk and wave at BM = 64 measured 40 % MFMA-busy); 128 rows need
     // enough M to still fill the chip
@@ -339,8 +722,6 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
     // too few workgroups for the chip (decode batches: one M tile, N / 128 column tiles): split K over
     // blockIdx.z so that ~2 workgroups per CU exist, >= 4 chunks each; partials go through the device scratch
     const int split_env = o.tiled_splitk;
-    int cus = zl_device_cu_count();
-    if (cus <= 0) cus = 256;
     int splits = 1;
     if ((int64_t)gx * gy < cus) {
         splits = (int)((2 * (int64_t)cus + (int64_t)gx * gy - 1) / ((int64_t)gx * gy));
