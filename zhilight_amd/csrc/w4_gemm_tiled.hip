@@ -463,9 +463,6 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
 #pragma unroll
         for (int blk = 0; blk < 32; ++blk) {
             const int t = blk >> 3, rb = blk & 7;
-#ifndef ZL_WEXP_NOLDS
-            if (blk + 3 < 32) read_a((blk + 3) & 3, blk + 3);
-#endif
             const h8 a = __builtin_bit_cast(h8, af[blk & 3]);
             // the accumulators are tied to ONE AGPR quad each (inline asm "+a"): with the builtin the allocator rotates 64
             // of the 128 accumulators through copies at the loop back-edge (192 v_accvgpr moves per two chunks, each
@@ -481,26 +478,40 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
             if (t == 3 && rb == 0) load_consts(ns, next_live);
             const uint32_t w = t < 3 ? word_of(cs + dj, t + 1) : word_of(ns + dj, 0);
 #ifdef ZL_WEXP_NODEQ
-            ZL_WIDE_MFMA(0) ZL_WIDE_MFMA(1) ZL_WIDE_MFMA(2) ZL_WIDE_MFMA(3)
-            bw[dset][dj][2 * dh] = w;
-#else
-            const uint32_t ws = dh ? wv_lshr8(w) : w;
             ZL_WIDE_MFMA(0)
-            const uint32_t x_lo = wv_and_or(ws, mask_lo, magic), x_hi = wv_and_or(ws, mask_hi, magic);
-            ZL_WIDE_MFMA(1)
-            const uint32_t y_lo = wv_pk_add(x_lo, __builtin_bit_cast(uint32_t, z1[dj]));
-            const uint32_t y_hi = wv_pk_fma(x_hi, one16_v, __builtin_bit_cast(uint32_t, z16[dj]));
-            ZL_WIDE_MFMA(2)
-            bw[dset][dj][2 * dh] = wv_pk_mul(y_lo, __builtin_bit_cast(uint32_t, s2[dj]));
-            bw[dset][dj][2 * dh + 1] = wv_pk_mul(y_hi, __builtin_bit_cast(uint32_t, s2[dj]));
-            ZL_WIDE_MFMA(3)
+#ifndef ZL_WEXP_NOLDS
+            if (blk + 3 < 32) read_a((blk + 3) & 3, blk + 3);
 #endif
-            // staging: piece r of chunk g + 1 (loaded one chunk ago) -> the other LDS buffer, its registers take chunk g + 2
+            ZL_WIDE_MFMA(1)
 #ifndef ZL_WEXP_NOSTAGE
             if (t < 2 && (blk & 1) == 0) {
                 store_x1(blk >> 1, xo);
                 load_x1(blk >> 1, g + 2);
             }
+#endif
+            ZL_WIDE_MFMA(2) ZL_WIDE_MFMA(3)
+            bw[dset][dj][2 * dh] = w;
+#else
+            const uint32_t ws = dh ? wv_lshr8(w) : w;
+            ZL_WIDE_MFMA(0)
+#ifndef ZL_WEXP_NOLDS
+            if (blk + 3 < 32) read_a((blk + 3) & 3, blk + 3);
+#endif
+            const uint32_t x_lo = wv_and_or(ws, mask_lo, magic), x_hi = wv_and_or(ws, mask_hi, magic);
+            ZL_WIDE_MFMA(1)
+            const uint32_t y_lo = wv_pk_add(x_lo, __builtin_bit_cast(uint32_t, z1[dj]));
+            const uint32_t y_hi = wv_pk_fma(x_hi, one16_v, __builtin_bit_cast(uint32_t, z16[dj]));
+#ifndef ZL_WEXP_NOSTAGE
+            // staging: piece r of chunk g + 1 (loaded one chunk ago) -> the other LDS buffer, its registers take chunk g + 2
+            if (t < 2 && (blk & 1) == 0) {
+                store_x1(blk >> 1, xo);
+                load_x1(blk >> 1, g + 2);
+            }
+#endif
+            ZL_WIDE_MFMA(2)
+            bw[dset][dj][2 * dh] = wv_pk_mul(y_lo, __builtin_bit_cast(uint32_t, s2[dj]));
+            bw[dset][dj][2 * dh + 1] = wv_pk_mul(y_hi, __builtin_bit_cast(uint32_t, s2[dj]));
+            ZL_WIDE_MFMA(3)
 #endif
             if (t == 3 && rb >= 1 && rb <= 4) issue_item(cs + rb - 1, rb - 1, g + kWideRing);
 #ifndef ZL_WEXP_NOPIN
@@ -574,15 +585,32 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
             }
         });
     } else if (p.epi & ZL_EPI_SILU_MUL) {
-        // rows of the packed matrix interleave gate (even n) and up (odd n): partner = lane ^ 1
-        for_each([&](int row, int n, float v, float b) {
-            v += b;
-            const float other = __shfl_xor(v, 1, 64);
-            if ((nrow & 1) == 0 && row < p.m && n + 1 < p.n) {
-                const float gt = (float)zl_f32_to_f16(v), up = (float)zl_f32_to_f16(other);
-                p.y[(size_t)row * p.ld_out + n / 2] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(silu_t(gt) * up));
+        // rows of the packed matrix interleave gate (even n) and up (odd n): partner = lane ^ 1.  Both lanes of a pair work:
+        // the even lane finishes rows i = 0, 1 of each quad, the odd lane rows i = 2, 3 (each sends the partner the two values
+        // it needs: one DPP swap per register instead of 128 silu evaluations on half of the lanes)
+        const bool odd = (nrow & 1) != 0;
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = (tile0 + j) * 16 + nrow;
+                const float b = bj[j];
+                float v[4], o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[rb][j][i] + b;
+                    o[i] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[i]), 0xb1, 0xf, 0xf, true));
+                }
+                // even lane: (gate, up) = (v, o) rows 0, 1; odd lane: (gate, up) = (o, v) rows 2, 3; column n / 2 either way
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float gt32 = odd ? o[2 + h] : v[h], up32 = odd ? v[2 + h] : o[h];
+                    const int row = m0 + rb * 16 + 4 * kq + (odd ? 2 + h : h);
+                    const float gt = (float)zl_f32_to_f16(gt32), up = (float)zl_f32_to_f16(up32);
+                    if (row < p.m && (n | 1) < p.n)
+                        p.y[(size_t)row * p.ld_out + n / 2] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(silu_t(gt) * up));
+                }
             }
-        });
     } else {
         for_each([&](int row, int n, float v, float b) {
             v += b;
@@ -679,12 +707,15 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
     // prompt chunks: the 128 x 256 tile (k_w4a16_gemm_wide)
     if (o.tiled_wide >= 0 && o.tiled_bm == 0 && (m >= 128 || (o.tiled_wide > 0 && m > 32)) && L.np >= 256) {
         const int gxw = (int)((L.np + 255) / 256), gyw = (int)((m + kWideBM - 1) / kWideBM);
+        // one workgroup per CU: fewer tiles than CUs (N = 4096 projections at M = 1024: 128 tiles) split K just far enough to
+        // give every CU one workgroup (fp32 partials through the caller's scratch, summed in split order)
         int splits = 1;
-        if ((int64_t)gxw * gyw < cus) {                    // N = 4096 projections at M = 1024: 128 tiles for 256 CUs
-            splits = (int)((2 * (int64_t)cus + (int64_t)gxw * gyw - 1) / ((int64_t)gxw * gyw));
+        if ((int64_t)gxw * gyw * 4 <= (int64_t)cus * 3) {
+            splits = (int)(cus / ((int64_t)gxw * gyw));
             const int max_s = p.groups / 8 > 0 ? p.groups / 8 : 1;
             if (splits > max_s) splits = max_s;
             if (splits > 8) splits = 8;
+            if (splits < 1) splits = 1;
         }
         if (o.tiled_splitk > 0) splits = o.tiled_splitk <= p.groups ? o.tiled_splitk : p.groups;
         p.ws = nullptr; p.split_chunks = p.groups; p.ld_ws = (int)L.np;
