@@ -41,6 +41,50 @@ def _expected(xs, res, dtype):
     return want
 
 
+# (at most 4 in-process ranks: the runtime multiplexes streams onto 4 hardware queues, and two ranks sharing a queue would wait
+# for each other forever -- an artefact of emulating the ranks on one GPU)
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_shot_all_reduce_skewed_ranks_and_changing_sizes(dev, world):
+    """The slot / flag protocol under skew: 80 messages whose sizes (hence chunk counts and chunk extents) change from one to
+    the next, with a random rank held back by a device-side sleep before each of its launches -- a rank one message ahead must
+    neither starve a slow peer (its newer flag overwrites the one the peer waits for: waiters accept >=) nor overwrite rows
+    the peer still reads (slots alternate with the MESSAGE number, not per chunk)."""
+    from zhilight_amd.parallel import OneShotAllReduce
+    maxb = 1 << 19
+    addrs = [OneShotAllReduce.alloc(maxb)[0] for _ in range(world)]
+    ars = [OneShotAllReduce(r, world, addrs, maxb, dev) for r in range(world)]
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    rng = np.random.default_rng(world)
+    sizes = [8, 4096, 6144, 8 * 4096, 3 * 4096 + 8, 32 * 4096, 64 * 4096, 2048]
+    msgs = [int(sizes[rng.integers(len(sizes))]) for _ in range(80)]
+    slow = [int(rng.integers(world)) for _ in msgs]
+    ins = [[torch.randn(n, device=dev).half() for _ in range(world)] for n in msgs]
+    results, errs = [[None] * len(msgs) for _ in range(world)], []
+    torch.cuda.synchronize()
+
+    def run(r):
+        try:
+            with torch.cuda.stream(streams[r]):
+                for i in range(len(msgs)):
+                    if slow[i] == r:
+                        torch.cuda._sleep(400000)          # ~0.2 ms on the device, this rank's stream only
+                    results[r][i] = ars[r].all_reduce(ins[i][r], out=torch.empty_like(ins[i][r]))
+                streams[r].synchronize()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert all(a.status() == 0 for a in ars)
+    for i in range(len(msgs)):
+        want = _expected(ins[i], None, torch.float16)
+        for r in range(world):
+            assert torch.equal(results[r][i], want), (i, r, msgs[i])
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_one_shot_all_reduce_in_process_ranks(dev, world):
     """`world` ranks as threads of this process, each on its own stream, buffers addressed directly: message sequence with

@@ -51,7 +51,8 @@ struct ArState {                               // device-resident, private to th
     int64_t max_bytes;
     int world, rank;
     unsigned err;
-    unsigned epoch[kMaxChunks];                // per chunk: message sequence number (device-side: survives graph replay)
+    unsigned epoch[kMaxChunks];                // the message sequence number, one copy per workgroup index (device-side:
+                                               // survives graph replay); all copies advance with every launch
 };
 
 __device__ __forceinline__ uint16_t* slot_of(const ArState* st, int r, unsigned parity) {
@@ -77,8 +78,11 @@ template <> __device__ __forceinline__ uint16_t from_f32<1>(float f) {
 }
 
 // One launch = one all-reduce.  Workgroup c owns element chunk c on EVERY rank, so chunk c only ever waits for the peers'
-// chunk c: no grid-wide step.  Two data slots by epoch parity: a rank can be at most one message ahead of a peer (it needs
-// the peer's flag of message e to finish e), so slot e & 1 is never overwritten while a peer still reads it.
+// chunk c: no grid-wide step.  Two data slots by the parity of the MESSAGE number e (the same for every chunk of a message,
+// whatever its size): a rank can be at most one message ahead of a peer (it needs the peer's flags of message e to finish
+// e), so slot e & 1 is never overwritten while a peer still reads it -- also when consecutive messages cut the slot into
+// different chunks.  A flag holds the number of the last message its chunk index was published for: a waiter accepts any
+// value >= e (a peer that is one message ahead has already overwritten e with e + 1; its slot e & 1 is still intact).
 template <int DT>
 __global__ __launch_bounds__(256) void k_ar(ArState* st, const uint16_t* __restrict__ x, const uint16_t* __restrict__ residual,
                                             uint16_t* __restrict__ out, int64_t n, int64_t per) {
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void k_ar(ArState* st, const uint16_t* __restr
     if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
         const unsigned* f = flags_of(st, rank) + (int)threadIdx.x * kMaxChunks + c;
         unsigned polls = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
             __builtin_amdgcn_s_sleep(1);
             if (++polls > kMaxPolls) {
                 atomicAdd(&st->err, 1u);
@@ -148,6 +152,8 @@ __global__ __launch_bounds__(256) void k_ar(ArState* st, const uint16_t* __restr
                                                        o[4] | ((uint32_t)o[5] << 16), o[6] | ((uint32_t)o[7] << 16));
     }
     if (threadIdx.x == 0) st->epoch[c] = e;
+    // the copies of the workgroup indices this message did not use (nobody reads them in this launch)
+    if (c == 0 && (int)threadIdx.x >= (int)gridDim.x && threadIdx.x < kMaxChunks) st->epoch[threadIdx.x] = e;
 }
 
 }  // namespace
