@@ -167,7 +167,8 @@ typedef struct {
     int phase_rounds, phase_ksplit, phase_ksplit_min_m, phase_min_m, phase_max_m, phase_small_off;
     int tiled_min_m, tiled_bm, tiled_splitk;
     int mfma_ks, mfma_rounds;
-    int tiled_wide;   /* prompt-chunk tile (128 x 256 outputs per workgroup, M >= 128): 0 default (on), -1 off, 1 force for any M > 32 */
+    int tiled_wide;   /* prompt-chunk tiles (128 / 256 x 256 outputs per workgroup, M >= 128): 0 default (on, height by cost model), -1 off,
+                         1 also for 32 < M < 128, 2 128-row tiles only, 3 256-row tiles whenever M > 128 */
 } zl_w4_opts_t;
 int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n);
 int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias,

@@ -295,8 +295,9 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
 //     ds_write_b128 lane group;
 //   * blockIdx -> (column tile, row tile) such that the row tiles of one column tile run on ONE XCD at the same time: its
 //     weights come from HBM once and from that XCD's L2 for the other row tiles.
-constexpr int kWideBM = 128;
-constexpr int kWideChunkBytes = kWideBM * 128 * 2;   // one 128-k activation chunk in LDS
+// M tile = 16 RB rows, RB = 8 (128 rows) or 16 (256 rows: the dequant VALU of a weight item is shared by twice the MFMAs --
+// a SIMD runs MFMAs and VALU one after the other, not side by side: PMC of the 128-row tile, 2 048 MFMA + 1 124 VALU cycles
+// per chunk and wave in a 3 850-cycle chunk)
 constexpr int kWideRing = 2;                         // weight chunks in flight (4 items each): ~2 x 2 000 cycles ahead
 
 template <int U>
@@ -334,7 +335,11 @@ __device__ __forceinline__ uint32_t wv_pk_mul(uint32_t a, uint32_t b) {
 #ifndef ZL_WIDE_OCC
 #define ZL_WIDE_OCC 1
 #endif
+template <int RB>
 __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const TiledParams p, const int gx, const int gy) {
+    constexpr int kWideBM = 16 * RB;
+    constexpr int kWideChunkBytes = kWideBM * 128 * 2;         // one 128-k activation chunk in LDS
+    constexpr int NBLK = 4 * RB;                               // blocks of 4 MFMAs per chunk
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_w[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -367,13 +372,13 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     const int xrow = threadIdx.x >> 4, xu = threadIdx.x & 15;
     const uint32_t xs_off = (uint32_t)(xrow * 256 + ((xu ^ xrow) * 16));
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0xffffffffu, 0x00020000);
-    uint32_t xg_off[8];
+    uint32_t xg_off[RB];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < RB; ++r) {
         const int row = m0 + xrow + 16 * r;
         xg_off[r] = (uint32_t)(((size_t)(row < p.m ? row : p.m - 1) * p.ldx + xu * 8) * 2);
     }
-    uint4 xr[8];
+    uint4 xr[RB];
     auto load_x1 = [&](int r, int g) {
         const uint32_t gc = (uint32_t)(g < G ? g : G - 1);
         xr[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, xg_off[r], gc * 256u, 0));
@@ -393,9 +398,9 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     uint32_t one16_v = 0x2c002c00u;                            // 0.0625 x 2, in a VGPR for the asm statements
     asm volatile("" : "+v"(one16_v));
 
-    f4 acc[8][4];
+    f4 acc[RB][4];
 #pragma unroll
-    for (int rb = 0; rb < 8; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[rb][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
@@ -429,15 +434,15 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
 
     // ---- prologue
 #pragma unroll
-    for (int r = 0; r < 8; ++r) load_x1(r, g_begin);
+    for (int r = 0; r < RB; ++r) load_x1(r, g_begin);
 #pragma unroll
     for (int c = 0; c < kWideRing; ++c)
 #pragma unroll
         for (int j = 0; j < 4; ++j) issue_item(4 * c + j, j, g_begin + c);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) store_x1(r, 0);
+    for (int r = 0; r < RB; ++r) store_x1(r, 0);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) load_x1(r, g_begin + 1);
+    for (int r = 0; r < RB; ++r) load_x1(r, g_begin + 1);
     load_consts(0, true);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -454,15 +459,15 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
         constexpr int cs = 4 * U, ns = 4 * (U ^ 1);
         constexpr uint32_t xb = U * kWideChunkBytes, xo = (U ^ 1) * kWideChunkBytes;
         auto read_a = [&](int slot, int blk) {
-            af[slot] = *reinterpret_cast<const uint4*>(smem_w + xb + (a_off0 ^ (uint32_t)((blk >> 3) * 64)) + (blk & 7) * 4096);
+            af[slot] = *reinterpret_cast<const uint4*>(smem_w + xb + (a_off0 ^ (uint32_t)((blk / RB) * 64)) + (blk % RB) * 4096);
         };
         read_a(0, 0);
         read_a(1, 1);
         read_a(2, 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int blk = 0; blk < 32; ++blk) {
-            const int t = blk >> 3, rb = blk & 7;
+        for (int blk = 0; blk < NBLK; ++blk) {
+            const int t = blk / RB, rb = blk % RB;
             const h8 a = __builtin_bit_cast(h8, af[blk & 3]);
             // the accumulators are tied to ONE AGPR quad each (inline asm "+a"): with the builtin the allocator rotates 64
             // of the 128 accumulators through copies at the loop back-edge (192 v_accvgpr moves per two chunks, each
@@ -474,33 +479,38 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     }
             // one eighth of the next k-step's B fragments between the MFMAs: tile dj = rb / 2, half dh = rb & 1 of word
             // t + 1 of this chunk (t == 3: word 0 of the next chunk, with its meta)
-            const int dj = rb >> 1, dh = rb & 1, dset = (t + 1) & 1;
+            // blocks with rb % (RB / 8) == 0 carry one of the 8 dequant slices of the next k-step: slice sl = tile sl / 2, half sl & 1
+            const bool deq = (rb % (RB / 8)) == 0;
+            const int sl = rb / (RB / 8), dj = sl >> 1, dh = sl & 1, dset = (t + 1) & 1;
             if (t == 3 && rb == 0) load_consts(ns, next_live);
             const uint32_t w = t < 3 ? word_of(cs + dj, t + 1) : word_of(ns + dj, 0);
+            uint32_t ws = 0, x_lo = 0, x_hi = 0, y_lo = 0, y_hi = 0;
 #ifdef ZL_WEXP_NODEQ
-            ZL_WIDE_MFMA(0)
-#ifndef ZL_WEXP_NOLDS
-            if (blk + 3 < 32) read_a((blk + 3) & 3, blk + 3);
-#endif
-            ZL_WIDE_MFMA(1)
-#ifndef ZL_WEXP_NOSTAGE
-            if (t < 2 && (blk & 1) == 0) {
-                store_x1(blk >> 1, xo);
-                load_x1(blk >> 1, g + 2);
-            }
-#endif
-            ZL_WIDE_MFMA(2) ZL_WIDE_MFMA(3)
-            bw[dset][dj][2 * dh] = w;
+            if (deq) bw[dset][dj][2 * dh] = w;
+#define ZL_WIDE_DEQ(STEP)
 #else
-            const uint32_t ws = dh ? wv_lshr8(w) : w;
+#define ZL_WIDE_DEQ(STEP)                                                                                   \
+    if (deq) {                                                                                               \
+        if (STEP == 0) ws = dh ? wv_lshr8(w) : w;                                                            \
+        if (STEP == 1) { x_lo = wv_and_or(ws, mask_lo, magic); x_hi = wv_and_or(ws, mask_hi, magic); }       \
+        if (STEP == 2) {                                                                                     \
+            y_lo = wv_pk_add(x_lo, __builtin_bit_cast(uint32_t, z1[dj]));                                    \
+            y_hi = wv_pk_fma(x_hi, one16_v, __builtin_bit_cast(uint32_t, z16[dj]));                          \
+        }                                                                                                    \
+        if (STEP == 3) {                                                                                     \
+            bw[dset][dj][2 * dh] = wv_pk_mul(y_lo, __builtin_bit_cast(uint32_t, s2[dj]));                    \
+            bw[dset][dj][2 * dh + 1] = wv_pk_mul(y_hi, __builtin_bit_cast(uint32_t, s2[dj]));                \
+        }                                                                                                    \
+    }
+#endif
+            ZL_WIDE_DEQ(0)
             ZL_WIDE_MFMA(0)
 #ifndef ZL_WEXP_NOLDS
-            if (blk + 3 < 32) read_a((blk + 3) & 3, blk + 3);
+            if (blk + 3 < NBLK) read_a((blk + 3) & 3, blk + 3);
 #endif
-            const uint32_t x_lo = wv_and_or(ws, mask_lo, magic), x_hi = wv_and_or(ws, mask_hi, magic);
+            ZL_WIDE_DEQ(1)
             ZL_WIDE_MFMA(1)
-            const uint32_t y_lo = wv_pk_add(x_lo, __builtin_bit_cast(uint32_t, z1[dj]));
-            const uint32_t y_hi = wv_pk_fma(x_hi, one16_v, __builtin_bit_cast(uint32_t, z16[dj]));
+            ZL_WIDE_DEQ(2)
 #ifndef ZL_WEXP_NOSTAGE
             // staging: piece r of chunk g + 1 (loaded one chunk ago) -> the other LDS buffer, its registers take chunk g + 2
             if (t < 2 && (blk & 1) == 0) {
@@ -509,10 +519,10 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
             }
 #endif
             ZL_WIDE_MFMA(2)
-            bw[dset][dj][2 * dh] = wv_pk_mul(y_lo, __builtin_bit_cast(uint32_t, s2[dj]));
-            bw[dset][dj][2 * dh + 1] = wv_pk_mul(y_hi, __builtin_bit_cast(uint32_t, s2[dj]));
+            ZL_WIDE_DEQ(3)
             ZL_WIDE_MFMA(3)
-#endif
+#undef ZL_WIDE_DEQ
+#undef ZL_WIDE_MFMA
             if (t == 3 && rb >= 1 && rb <= 4) issue_item(cs + rb - 1, rb - 1, g + kWideRing);
 #ifndef ZL_WEXP_NOPIN
             __builtin_amdgcn_sched_barrier(0);
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     {
         const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int rb = 6; rb < 8; ++rb)
+        for (int rb = RB - 2; rb < RB; ++rb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zero8, zero8, acc[rb][j], 0, 0, 0);
     }
@@ -544,7 +554,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     if (p.ws) {
         float* wsz = p.ws + (size_t)blockIdx.y * p.m * p.ld_ws;
 #pragma unroll
-        for (int rb = 0; rb < 8; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = (tile0 + j) * 16 + nrow;
@@ -566,7 +576,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     // rolled loop would index the accumulators dynamically (= spill them)
     auto for_each = [&](auto fn) {
 #pragma unroll
-        for (int rb = 0; rb < 8; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
         // it needs: one DPP swap per register instead of 128 silu evaluations on half of the lanes)
         const bool odd = (nrow & 1) != 0;
 #pragma unroll
-        for (int rb = 0; rb < 8; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = (tile0 + j) * 16 + nrow;
@@ -704,20 +714,40 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
     hipStream_t hs = (hipStream_t)s;
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
-    // prompt chunks: the 128 x 256 tile (k_w4a16_gemm_wide)
+    // prompt chunks: the 128 x 256 / 256 x 256 tiles (k_w4a16_gemm_wide<8 / 16>)
     if (o.tiled_wide >= 0 && o.tiled_bm == 0 && (m >= 128 || (o.tiled_wide > 0 && m > 32)) && L.np >= 256) {
-        const int gxw = (int)((L.np + 255) / 256), gyw = (int)((m + kWideBM - 1) / kWideBM);
-        // one workgroup per CU: fewer tiles than CUs (N = 4096 projections at M = 1024: 128 tiles) split K just far enough to
-        // give every CU one workgroup (fp32 partials through the caller's scratch, summed in split order)
-        int splits = 1;
-        if ((int64_t)gxw * gyw * 4 <= (int64_t)cus * 3) {
-            splits = (int)(cus / ((int64_t)gxw * gyw));
-            const int max_s = p.groups / 8 > 0 ? p.groups / 8 : 1;
-            if (splits > max_s) splits = max_s;
-            if (splits > 8) splits = 8;
-            if (splits < 1) splits = 1;
+        const int gxw = (int)((L.np + 255) / 256);
+        // tile height and K splits by a small cost model (cycles per 128-k chunk and workgroup measured: 3 850 for 128 rows,
+        // ~6 100 for 256 rows = 21 % less per row; a launch takes ceil(tiles x splits / CUs) rounds of chunks / splits chunks;
+        // fewer tiles than CUs split K just far enough to give every CU one workgroup -- fp32 partials through the caller's
+        // scratch, summed in split order)
+        int best_rb = 8, best_splits = 1;
+        double best_cost = 0;
+        for (int rb = 8; rb <= 16; rb += 8) {
+            if (rb == 16 && (m <= 128 || o.tiled_wide == 2)) break;        // (tiled_wide == 2: 128-row tiles only)
+            const int64_t tiles = (int64_t)gxw * ((m + 16 * rb - 1) / (16 * rb));
+            int sp = 1;
+            if (tiles * 4 <= (int64_t)cus * 3) {
+                sp = (int)(cus / tiles);
+                const int max_s = p.groups / 8 > 0 ? p.groups / 8 : 1;
+                sp = sp > max_s ? max_s : sp;
+                sp = sp > 8 ? 8 : (sp < 1 ? 1 : sp);
+            }
+            if (o.tiled_splitk > 0) sp = o.tiled_splitk <= p.groups ? o.tiled_splitk : p.groups;
+            const int64_t need = ZL_SCRATCH_HEADER + (int64_t)sp * m * L.np * (int64_t)sizeof(float);
+            if (sp > 1 && !(o.scratch && o.scratch_bytes >= need)) sp = 1;
+            const int64_t rounds = (tiles * sp + cus - 1) / cus;
+            const double cost = (double)rounds * (double)((p.groups + sp - 1) / sp) * (rb == 16 ? 6100.0 : 3850.0) +
+                                (sp > 1 ? 0.004 * (double)sp * (double)m * (double)L.np : 0.0);
+            if (rb == 8 || cost < best_cost) {
+                best_cost = cost;
+                best_rb = rb;
+                best_splits = sp;
+            }
         }
-        if (o.tiled_splitk > 0) splits = o.tiled_splitk <= p.groups ? o.tiled_splitk : p.groups;
+        if (o.tiled_wide == 3 && m > 128) best_rb = 16;                    // (experiments: force the 256-row tile)
+        const int rbw = best_rb, gyw = (int)((m + 16 * rbw - 1) / (16 * rbw));
+        int splits = best_splits;
         p.ws = nullptr; p.split_chunks = p.groups; p.ld_ws = (int)L.np;
         if (splits > 1) {
             p.split_chunks = (p.groups + splits - 1) / splits;
@@ -732,8 +762,19 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
         }
         const int64_t wgs = (int64_t)((gxw + 7) / 8) * 8 * gyw;
         ZL_CHECK_ARG(wgs <= 0x7fffffff, ZL_ELIMIT);
-        hipLaunchKernelGGL(k_w4a16_gemm_wide, dim3((unsigned)wgs, (unsigned)splits), dim3(256), 2 * kWideChunkBytes, hs, p,
-                           gxw, gyw);
+        const size_t ldsw = (size_t)2 * 16 * rbw * 256;
+        if (rbw == 16) {
+            static bool attr_set = false;                                   // idempotent: a race only repeats the call
+            if (!attr_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm_wide<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)ldsw) != hipSuccess)
+                    return ZL_ELIMIT;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_w4a16_gemm_wide<16>, dim3((unsigned)wgs, (unsigned)splits), dim3(256), ldsw, hs, p, gxw, gyw);
+        } else {
+            hipLaunchKernelGGL(k_w4a16_gemm_wide<8>, dim3((unsigned)wgs, (unsigned)splits), dim3(256), ldsw, hs, p, gxw, gyw);
+        }
         st = zl_launch_status();
         if (st || splits <= 1) return st;
         const int64_t outs = m * (silu ? n / 2 : n);
