@@ -1,4 +1,5 @@
-"""Worker of tests/test_gpu_comm.py: one rank of a two-process one-shot all-reduce over hipIpc-mapped buffers.
+"""Worker of tests/test_gpu_comm.py: one rank of a multi-process one-shot all-reduce over hipIpc-mapped buffers (fixed
+messages with / without the residual, then a run of messages of changing size with one rank held back before each).
 usage: python _ar_worker.py <rank> <world> <exchange dir> <device index of this rank>"""
 import os
 import sys
@@ -39,8 +40,27 @@ def inputs(msg, r, n, dtype):
 
 
 ok = True
-for msg, (n, dtype, with_res) in enumerate([(4096, torch.float16, True), (8, torch.float16, False), (32 * 4096, torch.float16, True),
-                                            (4096 * 64, torch.bfloat16, True), (4096, torch.float16, True)] * 3):
+import random  # noqa: E402
+rnd = random.Random(7)                      # the same sequence on every rank
+sizes = [8, 4096, 6144, 8 * 4096, 3 * 4096 + 8, 32 * 4096, 64 * 4096, 2048]
+skewed = [(rnd.choice(sizes), torch.float16, False, rnd.randrange(world)) for _ in range(60)]
+fixed = [(4096, torch.float16, True, -1), (8, torch.float16, False, -1), (32 * 4096, torch.float16, True, -1),
+         (4096 * 64, torch.bfloat16, True, -1), (4096, torch.float16, True, -1)] * 3
+# cold-start skew between the processes (first use of an operator on a freshly paged-in box can stall one of them for
+# seconds, longer than the bounded waits of the kernel): touch every host-side code path once, then meet
+for (n, dtype, _, _) in fixed[:5]:
+    a = inputs(0, 0, n, dtype)
+    torch.equal((a.float() + a.float()).to(dtype).to(dev).cpu(), a)
+torch.cuda.synchronize()
+open(os.path.join(xdir, f"ready{rank}"), "w").close()
+t0 = time.time()
+while not all(os.path.exists(os.path.join(xdir, f"ready{r}")) for r in range(world)):
+    if time.time() - t0 > 120:
+        raise SystemExit("peers never became ready")
+    time.sleep(0.005)
+for msg, (n, dtype, with_res, slow) in enumerate(fixed + skewed):
+    if slow == rank:
+        time.sleep(0.003)                   # this rank enters the message late: its peers are one message ahead at most
     xs = [inputs(msg, r, n, dtype) for r in range(world)]
     res = inputs(msg, 99, n, dtype)
     x = xs[rank].to(dev)
@@ -52,5 +72,9 @@ for msg, (n, dtype, with_res) in enumerate([(4096, torch.float16, True), (8, tor
     want = tot.to(dtype)
     if with_res:
         want = (res.float() + want.float()).to(dtype)
-    ok = ok and torch.equal(out.cpu(), want)
+    good = torch.equal(out.cpu(), want)
+    if not good or (msg % 16 == 15 and ar.status() != 0):
+        print("FIRST FAILURE rank", rank, "message", msg, "n", n, "slow", slow, "status", ar.status(), flush=True)
+        ok = False
+        break
 print("RESULT", rank, "ok" if ok and ar.status() == 0 else f"FAIL status={ar.status()}", flush=True)
