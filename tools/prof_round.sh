@@ -33,5 +33,9 @@ out["avg_bytes_per_launch"] = int(tot / 4)
 json.dump(out, open("gpurun_out/${tag}_gemv_traffic.json", "w"), indent=2)
 print(out)
 PY
+# prompt GEMM (gate|up at M = 1024): counters of the wide tile, own passes
+timeout 600 tools/pmc.sh gpurun_out/${tag}_pmc_wide k_w4a16_gemm_wide -- python tools/prof_one.py 28672 4096 1024 6 mfma > /dev/null; cp gpurun_out/${tag}_pmc_wide/summary.txt gpurun_out/${tag}_prefill_gemm_wide_gateup_m1024_pmc.txt
+python tools/bench_gemv.py --mfma --m 1024 --iters 20 2>&1 | grep -v amdgpu.ids | tail -5 > gpurun_out/${tag}_prefill_linears_m1024.txt
+python tools/bench_gemv.py --mfma --m 4096 --iters 10 2>&1 | grep -v amdgpu.ids | tail -5 > gpurun_out/${tag}_prefill_linears_m4096.txt
 # (batch 8 / 32 and the INT8 route are legs of the default bench.py run since round 2: other_batches in the bench line)
 timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extras --batch 32 --kv-cache-dtype int8 | tail -1 > gpurun_out/${tag}_bench_kvint8_b32.json 2>/dev/null
