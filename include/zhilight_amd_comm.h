@@ -14,8 +14,9 @@
  *               its direct xGMI links and sums them in RANK ORDER in fp32 -- every rank gets bit-identical sums -- with the
  *               residual add of the layer fused (ModelContext::reduce_sum + element_add_scale, src/model/
  *               model_context.cpp:203-242, src/nn/block/block.cpp:123-140).  One launch, no host round trip, epoch
- *               counters live on the device: capturable in a hipGraph and replayable.  Every wait is bounded: on expiry the
- *               launch sets the error word of its state (zl_ar_status) instead of hanging.
+ *               counters live on the device: capturable in a hipGraph and replayable.  Every wait is bounded (2^22 polls, about
+ *               0.6 s on MI355X: a peer later than that -- a stalled host thread, a dead rank -- makes the launch set the
+ *               error word of its state, zl_ar_status, instead of hanging; the step's results are then invalid).
  * Status codes as in zhilight_amd.h (0 ok, < 0 ZL_E*, > 0 hipError_t); ncclResult_t errors are returned as 1000 + code.
  */
 #ifndef ZHILIGHT_AMD_COMM_H

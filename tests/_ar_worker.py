@@ -7,6 +7,9 @@ import time
 
 import torch
 
+torch.set_num_threads(1)    # several workers x the default intra-op pool oversubscribe the host: parallel regions of the larger
+                            # messages then stall a rank for longer than the kernel's bounded waits (0.6 s)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 rank, world, xdir, devi = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])

@@ -647,3 +647,25 @@ def test_head_norm_matches_oracle(oracle, dev, mode, dtype):
         ops.head_norm(x, w, heads, d, 1e-6, mode, out=x)       # in place on the window; the columns around it untouched
         assert torch.equal(x.contiguous().view(torch.int16), out.view(torch.int16))
         assert torch.equal(wide[:, :d], keep[:, :d]) and torch.equal(wide[:, d + heads * d:], keep[:, d + heads * d:])
+
+
+@pytest.mark.gpu
+def test_caller_supplied_outputs_are_checked(dev):
+    """a wrong `out` (shape / dtype / non-contiguous) is refused by the host wrappers instead of being overrun by the launcher"""
+    from zhilight_amd import ops
+    from zhilight_amd._lib import ZLError
+    w = ops.W4MWeight.random(256, 1024, 128, dev)
+    x = torch.randn(3, 1024, device=dev).half()
+    for bad in (torch.empty(3, 128, dtype=torch.float16, device=dev), torch.empty(3, 256, dtype=torch.float32, device=dev),
+                torch.empty(3, 512, dtype=torch.float16, device=dev)[:, ::2]):
+        with pytest.raises(ZLError):
+            ops.w4a16_gemm_mfma(x, w, out=bad)
+        with pytest.raises(ZLError):
+            ops.w4a16_gemm_tiled(x, w, out=bad)
+    dw = torch.randn(256, 1024, device=dev).half()
+    with pytest.raises(ZLError):
+        ops.gemm_nt(x, dw, out=torch.empty(3, 255, dtype=torch.float16, device=dev))
+    with pytest.raises(ZLError):
+        ops.gemm_nt_small_m(x, dw, out=torch.empty(2, 256, dtype=torch.float16, device=dev))
+    ok = torch.empty(3, 256, dtype=torch.float16, device=dev)
+    assert ops.w4a16_gemm_mfma(x, w, out=ok) is ok and ops.gemm_nt(x, dw, out=ok) is ok

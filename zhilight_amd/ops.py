@@ -36,6 +36,13 @@ def _f(v):
     return C.c_float(float(v))
 
 
+def _chk_out(out, m, n, dtype, device, what):
+    """a caller-supplied output: (m, n) elements of `dtype`, contiguous rows, on the input's device (the launchers write
+    m * n elements at out.data_ptr(): a wrong one is a silent overrun)"""
+    if out.dtype != dtype or out.device != device or not out.is_contiguous() or out.numel() != m * n:
+        raise ZLError(f"{what}: Wrong output size() / dtype / layout")
+
+
 def _dt(t):
     if t.dtype == torch.float16:
         return F16
@@ -304,6 +311,8 @@ def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, 
     n_out = w.n // 2 if silu else w.n
     if out is None:
         out = torch.empty((m, n_out), dtype=torch.float16, device=x.device)
+    else:
+        _chk_out(out, m, n_out, torch.float16, x.device, "w4a16_gemm_mfma")
     if bias is not None:
         epilogue |= EPI_BIAS
     opts = _w4_opts(x.device, m, w.n)
@@ -325,6 +334,8 @@ def w4a16_gemm_tiled(x, w, bias=None, residual=None, out=None, epilogue=0):
     silu = epilogue & (EPI_SILU_MUL | EPI_SILU_MUL_F32)
     if out is None:
         out = torch.empty((m, w.n // 2 if silu else w.n), dtype=torch.float16, device=x.device)
+    else:
+        _chk_out(out, m, w.n // 2 if silu else w.n, torch.float16, x.device, "w4a16_gemm_tiled")
     if bias is not None:
         epilogue |= EPI_BIAS
     opts = _w4_opts(x.device, max(m, 5), w.n)
@@ -351,6 +362,8 @@ def gemm_nt_small_m(x, weight, bias=None, alpha=1.0, out=None, norm_weight=None,
     n = weight.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    else:
+        _chk_out(out, m, n, x.dtype, x.device, "gemm_nt_small_m")
     if argmax_ws is None:
         check(lib().zl_gemm_nt_small_m(_p(x2), _i(x2.stride(0)), _p(weight), _p(bias), _p(out), _i(m), _i(n), _i(k),
                                        _f(alpha), C.c_int(_dt(x)), _p(norm_weight), _f(norm_eps), _stream()),
@@ -373,6 +386,8 @@ def gemm_nt(x, weight, bias=None, alpha=1.0, out=None):
         raise ZLError("size K mismatch")
     if out is None:
         out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    else:
+        _chk_out(out, m, n, x.dtype, x.device, "gemm_nt")
     check(lib().zl_gemm_nt(_p(x2), _i(x2.stride(0)), _p(weight), _p(bias), _p(out), _i(m), _i(n), _i(k), _f(alpha),
                            C.c_int(_dt(x)), _stream()), "gemm_nt")
     return out
