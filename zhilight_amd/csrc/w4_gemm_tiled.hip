@@ -676,6 +676,55 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
     }
 }
 
+// the same sums for the plain epilogues, four columns per thread (16-byte partial loads, 8-byte stores): the split
+// projections of a prompt chunk (attn_out, w_out at M = 1024) spent 17 us per launch in the scalar version
+__global__ __launch_bounds__(256) void k_splitk_epilogue_v4(const float* __restrict__ ws, int splits, int m, int n, int ld_ws,
+                                                            const uint16_t* __restrict__ bias, const uint16_t* residual,
+                                                            uint16_t* y, int epi, int ld_out) {
+    const int cols4 = n / 4;
+    const int64_t total = (int64_t)m * cols4;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / cols4), c = (int)(idx % cols4) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < splits; ++z) {
+            const float4 t = *reinterpret_cast<const float4*>(ws + ((size_t)z * m + row) * ld_ws + c);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        const size_t o = (size_t)row * ld_out + c;
+        uint16_t bb[4] = {0, 0, 0, 0}, yy[4] = {0, 0, 0, 0}, rr[4] = {0, 0, 0, 0};
+        if ((epi & ZL_EPI_BIAS) && bias) *reinterpret_cast<uint2*>(bb) = *reinterpret_cast<const uint2*>(bias + c);
+        if (epi & ZL_EPI_ADD_C) *reinterpret_cast<uint2*>(yy) = *reinterpret_cast<const uint2*>(y + o);
+        if (epi & ZL_EPI_RESIDUAL) *reinterpret_cast<uint2*>(rr) = *reinterpret_cast<const uint2*>(residual + o);
+        uint16_t out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float b = ((epi & ZL_EPI_BIAS) && bias) ? (float)__builtin_bit_cast(_Float16, bb[i]) : 0.f;
+            float ov;
+            if (epi & ZL_EPI_ADD_C) ov = ((float)__builtin_bit_cast(_Float16, yy[i]) + v[i]) + b;
+            else ov = v[i] + b;
+            _Float16 y16 = zl_f32_to_f16(ov);
+            if (epi & ZL_EPI_RESIDUAL) y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, rr[i]) + (float)y16);
+            out[i] = __builtin_bit_cast(uint16_t, y16);
+        }
+        *reinterpret_cast<uint2*>(y + o) = *reinterpret_cast<uint2*>(out);
+    }
+}
+
+// picks the vector version where the shapes and pointers allow
+static int launch_splitk_epilogue(const float* ws, int splits, int64_t m, int64_t n, int ld_ws, const uint16_t* bias,
+                                  const uint16_t* residual, uint16_t* y, int epi, int ld_out, hipStream_t hs) {
+    const bool silu = (epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
+    const bool v4 = !silu && n % 4 == 0 && ld_ws % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)y & 7) == 0 &&
+                    (!bias || ((uintptr_t)bias & 7) == 0) && (!residual || ((uintptr_t)residual & 7) == 0);
+    const int64_t outs = v4 ? m * (n / 4) : m * (silu ? n / 2 : n);
+    const unsigned rgrid = (unsigned)((outs + 255) / 256 > 8192 ? 8192 : (outs + 255) / 256);
+    if (v4)
+        hipLaunchKernelGGL(k_splitk_epilogue_v4, dim3(rgrid), dim3(256), 0, hs, ws, splits, (int)m, (int)n, ld_ws, bias, residual, y, epi, ld_out);
+    else
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3(rgrid), dim3(256), 0, hs, ws, splits, (int)m, (int)n, ld_ws, bias, residual, y, epi, ld_out);
+    return zl_launch_status();
+}
+
 }  // namespace
 
 extern "C" int zl_w4a16_gemm_tiled(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
@@ -718,7 +767,7 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
     if (o.tiled_wide >= 0 && o.tiled_bm == 0 && (m >= 128 || (o.tiled_wide > 0 && m > 32)) && L.np >= 256) {
         const int gxw = (int)((L.np + 255) / 256);
         // tile height and K splits by a small cost model (cycles per 128-k chunk and workgroup measured: 3 850 for 128 rows,
-        // ~6 100 for 256 rows = 21 % less per row; a launch takes ceil(tiles x splits / CUs) rounds of chunks / splits chunks;
+        // ~7 000 for 256 rows = 9 % less per row; a launch takes ceil(tiles x splits / CUs) rounds of chunks / splits chunks;
         // fewer tiles than CUs split K just far enough to give every CU one workgroup -- fp32 partials through the caller's
         // scratch, summed in split order)
         int best_rb = 8, best_splits = 1;
@@ -737,7 +786,7 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
             const int64_t need = ZL_SCRATCH_HEADER + (int64_t)sp * m * L.np * (int64_t)sizeof(float);
             if (sp > 1 && !(o.scratch && o.scratch_bytes >= need)) sp = 1;
             const int64_t rounds = (tiles * sp + cus - 1) / cus;
-            const double cost = (double)rounds * (double)((p.groups + sp - 1) / sp) * (rb == 16 ? 6100.0 : 3850.0) +
+            const double cost = (double)rounds * (double)((p.groups + sp - 1) / sp) * (rb == 16 ? 7000.0 : 3850.0) +
                                 (sp > 1 ? 0.004 * (double)sp * (double)m * (double)L.np : 0.0);
             if (rb == 8 || cost < best_cost) {
                 best_cost = cost;
@@ -777,11 +826,7 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
         }
         st = zl_launch_status();
         if (st || splits <= 1) return st;
-        const int64_t outs = m * (silu ? n / 2 : n);
-        const unsigned rgrid = (unsigned)((outs + 255) / 256 > 4096 ? 4096 : (outs + 255) / 256);
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3(rgrid), dim3(256), 0, hs, p.ws, splits, (int)m, (int)n, p.ld_ws, bias, residual, y,
-                           epilogue, p.ld_out);
-        return zl_launch_status();
+        return launch_splitk_epilogue(p.ws, splits, m, n, p.ld_ws, bias, residual, y, epilogue, p.ld_out, hs);
     }
     // M-tile height: taller tiles amortise the dequant over more MFMAs (the VALU and the MFMA pipe do not
     // overlap here: 143 VALU + 32 MFMA per chunk and wave at BM = 64 measured 40 % MFMA-busy); 128 rows need
@@ -833,9 +878,5 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
 #undef ZL_TILED_LAUNCH
     st = zl_launch_status();
     if (st || splits <= 1) return st;
-    const int64_t outs = m * (silu ? n / 2 : n);
-    const unsigned rgrid = (unsigned)((outs + 255) / 256 > 4096 ? 4096 : (outs + 255) / 256);
-    hipLaunchKernelGGL(k_splitk_epilogue, dim3(rgrid), dim3(256), 0, hs, p.ws, splits, (int)m, (int)n, p.ld_ws, bias, residual, y,
-                       epilogue, p.ld_out);
-    return zl_launch_status();
+    return launch_splitk_epilogue(p.ws, splits, m, n, p.ld_ws, bias, residual, y, epilogue, p.ld_out, hs);
 }
