@@ -95,6 +95,29 @@ int zl_w4_dequant(const uint32_t* qw, const uint16_t* scales, const uint16_t* ze
                   int64_t n, int64_t k, int64_t group_size, uint16_t* out /* (N,K) fp16 */, zl_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * f3  Fused MoE GEMVs of the decode path (FUSE_GPTQ_MOE=1): nn::gptq::gemm_moe_up / gemm_moe_down
+ * (src/nn/quant/gptq/q_gemm_k_major.cu:392-520, kernels :243-390).  Every expert's matrix is packed by zl_w4_pack on its
+ * own (gate / up: the (2 n_ff, K) matrix with row_interleave = 1); expert e starts expert_stride_* BYTES after expert 0 in
+ * each of the three arrays (strides >= the zl_w4_layout sizes, multiples of 16 / 8 / 2, scales_stride / 8 == zeros_stride / 2).
+ * expert_ids (M, top_k) int32: the token's routed experts; the n_shared shared experts follow at ids shared_base,
+ * shared_base + 1, ... (the reference's SHARED_EXP_ID = experts stored - n_shared) with weight 1.  exp_parallel: only experts
+ * with id % world_size == rank are local (stored at id / world_size), the others are skipped like in the reference.
+ *   up:   out[m, t, n] = half( silu(x_m . gate_e[n]) * (x_m . up_e[n]) ),  out (M, top_k + n_shared, n_ff); skipped experts: 0
+ *   down: out[m, n]    = half( sum_t w[m, t] * (a[m, t] . W_e[n]) )  (add_c: + float(out[m, n])),  a (M, top_k + n_shared, K)
+ * Arithmetic: DEV_gemm_warp_reduce per (token, expert, row) = the decode GEMV's; down scales the per-lane fp32 partials by
+ * the routing weight before the 32-lane tree (one fma per expert), silu in double like the file-local helper -- bit-identical
+ * to the CUDA kernels.  1 <= top_k + n_shared <= 32. */
+int zl_w4a16_moe_up(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint16_t* scales, const uint16_t* zeros,
+                    int64_t expert_stride_qw, int64_t expert_stride_scales, int64_t expert_stride_zeros,
+                    const int32_t* expert_ids, uint16_t* out, int64_t m, int64_t n_ff, int64_t k, int64_t group_size,
+                    int top_k, int n_shared, int shared_base, int exp_parallel, int world_size, int rank, zl_stream_t s);
+int zl_w4a16_moe_down(const uint16_t* a, int64_t lda, const uint32_t* qw, const uint16_t* scales, const uint16_t* zeros,
+                      int64_t expert_stride_qw, int64_t expert_stride_scales, int64_t expert_stride_zeros,
+                      const int32_t* expert_ids, const float* expert_weights, uint16_t* out, int64_t m, int64_t n,
+                      int64_t k, int64_t group_size, int top_k, int n_shared, int shared_base, int exp_parallel,
+                      int world_size, int rank, int add_c, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * a2/a5  W4A16 GEMM for decode batches, y = x . dequant(W)^T (+ epilogue).
  * Replaces nn::gptq::gptq_gemm_k_major for M <= 40 / KERNEL_gemm_warp_reduce
  * (src/nn/quant/gptq/q_gemm_k_major.cu:957-1116, 127-237) and nn::gptq::gemm_fuse_gate_in (:765-829).

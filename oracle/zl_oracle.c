@@ -290,6 +290,86 @@ static float gemv_row_R(const uint16_t* x, const uint32_t* qw_row, const uint8_t
     return warp32_tree_sum(lane_acc);
 }
 
+/* the 32 per-lane partial sums of DEV_gemm_warp_reduce<1> (what gemv_row_R feeds its tree with) */
+static void gemv_row_lanes(const uint16_t* x, const uint32_t* qw_row, const uint8_t* qz_row, const uint16_t* sc_row, int64_t k8,
+                           int64_t g8, int sym, float* lane_acc) {
+    for (int l = 0; l < 32; ++l) {
+        float acc = 0.f;
+        for (int64_t w = l; w < k8; w += 32) {
+            int64_t gi = w / g8;
+            float scale = zlo_f16_to_f32(sc_row[gi]);
+            int zero = sym ? 8 : (int)qz_row[gi];
+            uint16_t d[8];
+            dequant_word(qw_row[w], zero, d);
+            acc = fmaf(dot8_half(d, x + 8 * w), scale, acc);
+        }
+        lane_acc[l] = acc;
+    }
+}
+
+/* the token's expert t: id in the stacked arrays, or -1 when skipped (KERNEL_gemm_moe_up :276-288, _down :349-360) */
+static int moe_expert(const int32_t* ids, int64_t m, int t, int top_k, int shared_base, int exp_parallel, int world, int rank) {
+    if (t >= top_k) return shared_base + t - top_k;
+    int e = ids[m * top_k + t];
+    if (exp_parallel) {
+        if ((e % world) != rank) return -1;
+        e /= world;
+    }
+    return e;
+}
+
+/* KERNEL_gemm_moe_up (q_gemm_k_major.cu:243-320): C[m, t, n] = half(silu(acc1) * acc2), silu in double (:239-241), C zero-filled
+ * for skipped experts (:423).  qw1 / qw2 etc.: (E, N, ...) stacks of k-major tensors (gate and up) */
+void zlo_gptq_moe_up(const uint16_t* x, const uint32_t* qw1, const uint8_t* qz1, const uint16_t* sc1, const uint32_t* qw2,
+                     const uint8_t* qz2, const uint16_t* sc2, const int32_t* ids, uint16_t* out, int64_t m, int64_t n, int64_t k,
+                     int64_t g, int sym, int top_k, int n_shared, int shared_base, int exp_parallel, int world, int rank) {
+    int64_t k8 = k / 8, g8 = g / 8, ng = k / g;
+    int T = top_k + n_shared;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int64_t mm = 0; mm < m; ++mm)
+        for (int t = 0; t < T; ++t) {
+            int e = moe_expert(ids, mm, t, top_k, shared_base, exp_parallel, world, rank);
+            for (int64_t nn = 0; nn < n; ++nn) {
+                uint16_t* o = out + (mm * T + t) * n + nn;
+                if (e < 0) {
+                    *o = 0;
+                    continue;
+                }
+                int64_t row = (int64_t)e * n + nn;
+                float a1 = gemv_row_R(x + mm * k, qw1 + row * k8, qz1 + row * ng, sc1 + row * ng, k8, g8, sym);
+                float a2 = gemv_row_R(x + mm * k, qw2 + row * k8, qz2 + row * ng, sc2 + row * ng, k8, g8, sym);
+                float s = (float)((double)a1 / (1.0 + (double)expf(-a1)));
+                *o = zlo_f32_to_f16(s * a2);
+            }
+        }
+}
+
+/* KERNEL_gemm_moe_down (q_gemm_k_major.cu:322-390): per lane acc_all += acc_th * weight over the token's experts (the product
+ * and the sum contract to one fma under nvcc's default -fmad), then the 32-lane tree; C = half(acc) or half(float(C) + acc) */
+void zlo_gptq_moe_down(const uint16_t* a, const uint32_t* qw, const uint8_t* qz, const uint16_t* sc, const int32_t* ids,
+                       const float* weights, uint16_t* out, int64_t m, int64_t n, int64_t k, int64_t g, int sym, int top_k,
+                       int n_shared, int shared_base, int exp_parallel, int world, int rank, int add_c) {
+    int64_t k8 = k / 8, g8 = g / 8, ng = k / g;
+    int T = top_k + n_shared;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int64_t mm = 0; mm < m; ++mm)
+        for (int64_t nn = 0; nn < n; ++nn) {
+            float all[32], part[32];
+            for (int l = 0; l < 32; ++l) all[l] = 0.f;
+            for (int t = 0; t < T; ++t) {
+                int e = moe_expert(ids, mm, t, top_k, shared_base, exp_parallel, world, rank);
+                if (e < 0) continue;
+                int64_t row = (int64_t)e * n + nn;
+                gemv_row_lanes(a + (mm * T + t) * k, qw + row * k8, qz + row * ng, sc + row * ng, k8, g8, sym, part);
+                float w = t < top_k ? weights[mm * top_k + t] : 1.f;
+                for (int l = 0; l < 32; ++l) all[l] = fmaf(part[l], w, all[l]);
+            }
+            float acc = warp32_tree_sum(all);
+            uint16_t* o = out + mm * n + nn;
+            *o = zlo_f32_to_f16(add_c ? zlo_f16_to_f32(*o) + acc : acc);
+        }
+}
+
 /* KERNEL_gemm_warp_reduce (q_gemm_k_major.cu:176-237): C = half(alpha*acc + bias), alpha = 1;
  * ADD_C: half(float(C) + acc + bias).  Per-row arithmetic is identical for every WRAP_M, so any M
  * (the reference routes M <= 40 here, :1101-1115) is M independent row-vectors. */

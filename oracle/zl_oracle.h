@@ -61,6 +61,12 @@ void zlo_gptq_dequant_hf_naive(const uint32_t* qweight_hf, const uint32_t* qzero
 void zlo_gptq_gemm_k_major(const uint16_t* x, const uint32_t* qw, const uint8_t* qz,
                            const uint16_t* sc, const uint16_t* bias, uint16_t* y,
                            int64_t m, int64_t n, int64_t k, int64_t g, int sym, int add_c);
+void zlo_gptq_moe_up(const uint16_t* x, const uint32_t* qw1, const uint8_t* qz1, const uint16_t* sc1, const uint32_t* qw2,
+                     const uint8_t* qz2, const uint16_t* sc2, const int32_t* ids, uint16_t* out, int64_t m, int64_t n, int64_t k,
+                     int64_t g, int sym, int top_k, int n_shared, int shared_base, int exp_parallel, int world, int rank);
+void zlo_gptq_moe_down(const uint16_t* a, const uint32_t* qw, const uint8_t* qz, const uint16_t* sc, const int32_t* ids,
+                       const float* weights, uint16_t* out, int64_t m, int64_t n, int64_t k, int64_t g, int sym, int top_k,
+                       int n_shared, int shared_base, int exp_parallel, int world, int rank, int add_c);
 void zlo_gptq_gemm_k_major_exact(const uint16_t* x, const uint32_t* qw, const uint8_t* qz,
                                  const uint16_t* sc, const uint16_t* bias, double* y,
                                  int64_t m, int64_t n, int64_t k, int64_t g, int sym);

@@ -146,6 +146,39 @@ def gptq_gemm_k_major(x, qw, qz, sc, bias=None, sym=False, add_c=None):
     return y
 
 
+def gptq_moe_up(x, km1, km2, ids, n_shared=0, shared_base=0, sym=False, exp_parallel=False, world=1, rank=0):
+    """km1 / km2: (qw (E, N, K/8) u32, qz (E, N, K/G) u8, sc (E, N, K/G) u16) stacks of gate / up; ids (M, top_k) int32"""
+    x = _c(x, np.uint16)
+    q1, z1, s1 = (_c(a, t) for a, t in zip(km1, (np.uint32, np.uint8, np.uint16)))
+    q2, z2, s2 = (_c(a, t) for a, t in zip(km2, (np.uint32, np.uint8, np.uint16)))
+    ids = _c(ids, np.int32)
+    m, k = x.shape
+    n = q1.shape[1]
+    g = k // s1.shape[2]
+    top_k = ids.shape[1]
+    out = np.zeros((m, top_k + n_shared, n), np.uint16)
+    lib().zlo_gptq_moe_up(_p(x), _p(q1), _p(z1), _p(s1), _p(q2), _p(z2), _p(s2), _p(ids), _p(out), _i(m), _i(n), _i(k), _i(g),
+                          C.c_int(int(sym)), C.c_int(top_k), C.c_int(n_shared), C.c_int(shared_base), C.c_int(int(exp_parallel)),
+                          C.c_int(world), C.c_int(rank))
+    return out
+
+
+def gptq_moe_down(a, km, ids, weights, n_shared=0, shared_base=0, sym=False, exp_parallel=False, world=1, rank=0, add_c=None):
+    """a (M, top_k + n_shared, K) fp16 bits; km: (E, N, ...) stacks; weights (M, top_k) float32"""
+    a = _c(a, np.uint16)
+    q, z, s = (_c(t_, d) for t_, d in zip(km, (np.uint32, np.uint8, np.uint16)))
+    ids, weights = _c(ids, np.int32), _c(weights, np.float32)
+    m, _, k = a.shape
+    n = q.shape[1]
+    g = k // s.shape[2]
+    top_k = ids.shape[1]
+    out = np.zeros((m, n), np.uint16) if add_c is None else _c(add_c, np.uint16).copy()
+    lib().zlo_gptq_moe_down(_p(a), _p(q), _p(z), _p(s), _p(ids), _p(weights), _p(out), _i(m), _i(n), _i(k), _i(g), C.c_int(int(sym)),
+                            C.c_int(top_k), C.c_int(n_shared), C.c_int(shared_base), C.c_int(int(exp_parallel)), C.c_int(world),
+                            C.c_int(rank), C.c_int(0 if add_c is None else 1))
+    return out
+
+
 def gptq_gemm_k_major_exact(x, qw, qz, sc, bias=None, sym=False):
     x, qw, qz, sc = _c(x, np.uint16), _c(qw, np.uint32), _c(qz, np.uint8), _c(sc, np.uint16)
     m, k = x.shape

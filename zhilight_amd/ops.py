@@ -165,6 +165,77 @@ class W4Weight:
 
 
 
+class W4MoEWeight:
+    """The experts of one MoE projection, each packed like a W4Weight, stacked `stride` elements apart (what the reference
+    keeps as (E, N, K/8) / (E, N, K/G) tensors for its fused MoE kernels, src/nn/feedforward/feedforward.cpp FUSE_GPTQ_MOE).
+    gate / up: pass the (2 n_ff, K) [gate; up] k-major tensors of every expert with row_interleave=True."""
+
+    def __init__(self, experts, n, k, group_size, qw, scales, zeros, row_interleave):
+        self.experts, self.n, self.k, self.group_size = experts, n, k, group_size
+        self.qw, self.scales, self.zeros, self.row_interleave = qw, scales, zeros, row_interleave
+        L = W4Weight.layout(n, k, group_size)
+        self.stride_bytes = (L.qw_bytes, L.scales_bytes, L.zeros_bytes)
+
+    @classmethod
+    def from_k_major(cls, qweights, qzeros, scales, group_size, row_interleave=False):
+        """lists (one entry per expert) of qweight (N, K/8) int32, qzeros (N, K/G) uint8, scales (N, K/G) fp16"""
+        ws = [W4Weight.from_k_major(q, z, s, group_size, False, row_interleave) for q, z, s in zip(qweights, qzeros, scales)]
+        w0 = ws[0]
+        return cls(len(ws), w0.n, w0.k, group_size, torch.stack([w.qw for w in ws]).contiguous(),
+                   torch.stack([w.scales for w in ws]).contiguous(), torch.stack([w.zeros for w in ws]).contiguous(), row_interleave)
+
+    def nbytes(self):
+        return self.qw.numel() * 4 + self.scales.numel() * 2 + self.zeros.numel() * 2
+
+
+def moe_up(x, w: W4MoEWeight, expert_ids, n_shared=0, exp_parallel=False, world_size=1, rank=0, out=None):
+    """nn::gptq::gemm_moe_up (q_gemm_k_major.cu:392-455): out (M, top_k + n_shared, n_ff) = silu(x . gate_e) * (x . up_e) for
+    the token's experts; the shared experts are the LAST n_shared of the stack."""
+    if x.dtype != torch.float16 or not w.row_interleave:
+        raise ZLError("moe_up: half activations, row-interleaved [gate; up] experts")
+    _chk_cuda(x, expert_ids)
+    m, k = x.shape
+    if k != w.k or expert_ids.dtype != torch.int32 or expert_ids.shape[0] != m:
+        raise ZLError("moe_up: shape / dtype mismatch")
+    top_k, n_ff = expert_ids.shape[1], w.n // 2
+    if out is None:
+        out = torch.empty((m, top_k + n_shared, n_ff), dtype=torch.float16, device=x.device)
+    else:
+        _chk_out(out, m * (top_k + n_shared), n_ff, torch.float16, x.device, "moe_up")
+    sq, ss, sz = w.stride_bytes
+    check(lib().zl_w4a16_moe_up(_p(x), _i(x.stride(0)), _p(w.qw), _p(w.scales), _p(w.zeros), _i(sq), _i(ss), _i(sz), _p(expert_ids),
+                                _p(out), _i(m), _i(n_ff), _i(k), _i(w.group_size), C.c_int(top_k), C.c_int(n_shared),
+                                C.c_int(w.experts - n_shared), C.c_int(int(exp_parallel)), C.c_int(world_size), C.c_int(rank),
+                                _stream()), "w4a16_moe_up")
+    return out
+
+
+def moe_down(a, w: W4MoEWeight, expert_ids, expert_weights, n_shared=0, exp_parallel=False, world_size=1, rank=0, out=None,
+             add_c=False):
+    """nn::gptq::gemm_moe_down (q_gemm_k_major.cu:457-520): out (M, N) = sum over the token's experts of weight * (a[m, t] . W_e)
+    (+ out with add_c); a (M, top_k + n_shared, K)."""
+    if a.dtype != torch.float16 or w.row_interleave:
+        raise ZLError("moe_down: half activations, plain experts")
+    _chk_cuda(a, expert_ids, expert_weights)
+    m, t, k = a.shape
+    top_k = expert_ids.shape[1]
+    if k != w.k or t != top_k + n_shared or expert_ids.dtype != torch.int32 or expert_weights.dtype != torch.float32 or \
+            tuple(expert_weights.shape) != tuple(expert_ids.shape) or expert_ids.shape[0] != m:
+        raise ZLError("moe_down: shape / dtype mismatch")
+    if out is None:
+        if add_c:
+            raise ZLError("moe_down: add_c needs the output to add to")
+        out = torch.empty((m, w.n), dtype=torch.float16, device=a.device)
+    else:
+        _chk_out(out, m, w.n, torch.float16, a.device, "moe_down")
+    sq, ss, sz = w.stride_bytes
+    check(lib().zl_w4a16_moe_down(_p(a), _i(k), _p(w.qw), _p(w.scales), _p(w.zeros), _i(sq), _i(ss), _i(sz), _p(expert_ids),
+                                  _p(expert_weights), _p(out), _i(m), _i(w.n), _i(k), _i(w.group_size), C.c_int(top_k),
+                                  C.c_int(n_shared), C.c_int(w.experts - n_shared), C.c_int(int(exp_parallel)), C.c_int(world_size),
+                                  C.c_int(rank), C.c_int(int(add_c)), _stream()), "w4a16_moe_down")
+    return out
+
+
 def w4a16_gemm(x, w, bias=None, residual=None, out=None, norm_weight=None, norm_eps=1e-5, epilogue=0):
     """y = x . dequant(W)^T with optional fused RMSNorm prologue and bias / ADD_C / residual / silu*mul
     epilogue -- nn::gptq::gptq_gemm_k_major (M <= 40 branch) and nn::gptq::gemm_fuse_gate_in
