@@ -176,12 +176,14 @@ def test_one_full_layer_and_lm_head_batch1(oracle, dev):
         assert rec["logits_vs_R_max"] <= 1e-3 + rec["R_vs_E_max"], rec   # and no further from R than R's own fp16 noise allows
 
 
-@pytest.mark.parametrize("batch", [1, 8, 32])
-def test_stack_of_eight_full_layers(oracle, dev, batch):
+@pytest.mark.parametrize("batch,layers", [(1, 8), (8, 8), (32, 8 if os.environ.get("ZL_FULLGEOM_DEEP") else 4)])
+def test_stack_of_eight_full_layers(oracle, dev, batch, layers):
     """The same hidden state through 8 DISTINCT full-geometry layers (every decode dispatch of the W4 route: fused-norm
     phase kernel, split merge in the attn_out projection at batch 1, 2-row-block phase kernel and the K-split down
-    projection at batch 32), then the final norm and a 4096-row lm_head."""
-    rec = _decode_case(oracle, dev, 8, 4096, batch, 1024, "stack8", max_batch=32)[0]
+    projection at batch 32), then the final norm and a 4096-row lm_head.  (Batch 32 runs 4 layers by default: the CPU
+    oracle's two flavours of the 8-layer case take 107 s of the suite; ZL_FULLGEOM_DEEP=1 runs all 8 -- the record in
+    profiles/r02_parity_fullgeom.jsonl.)"""
+    rec = _decode_case(oracle, dev, layers, 4096, batch, 1024, f"stack{layers}", max_batch=32)[0]
     assert rec["logits_vs_E_max"] <= 1e-3, rec
     assert rec["logits_vs_R_max"] <= 1e-3 + rec["R_vs_E_max"], rec
     assert rec["logits_vs_E_rms"] <= 5e-4, rec
