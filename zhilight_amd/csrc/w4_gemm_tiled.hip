@@ -23,11 +23,7 @@ constexpr int kWavesT = 4;
 constexpr int kThreadsT = kWavesT * 64;
 constexpr int kBN = kWavesT * 32;
 constexpr int kRingT = 8;          // items (2 per chunk)
-#ifdef ZL_TILED_SWZ
-constexpr int kRowHalfs = 128;     // 256-B rows, 16-byte unit u of row r at u ^ (r & 15): conflict-free ds_read_b128 / ds_write_b128
-#else
-constexpr int kRowHalfs = 128 + 8; // padded LDS row
-#endif
+constexpr int kRowHalfs = 128 + 8; // padded LDS row (an XOR-swizzled 256-B row image measured the same: 312 us)
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -125,11 +121,7 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
     auto store_x = [&](int buf) {
 #pragma unroll
         for (int r = 0; r < XR; ++r)
-#ifdef ZL_TILED_SWZ
-            *reinterpret_cast<uint4*>(&xs[buf][(xrow + 16 * r) * kRowHalfs + (((threadIdx.x & 15) ^ xrow) * 8)]) = xr[r];
-#else
             *reinterpret_cast<uint4*>(&xs[buf][(xrow + 16 * r) * kRowHalfs + xcol]) = xr[r];
-#endif
     };
 
     load_x(g_begin);
@@ -173,20 +165,13 @@ __global__ __launch_bounds__(kThreadsT, 2) void k_w4a16_gemm_tiled(const TiledPa
 #endif
         }
         issue_pair(slot0);
-#ifdef ZL_TILED_SWZ
-        const unsigned char* xb8 = reinterpret_cast<const unsigned char*>(&xs[buf][0]) + nrow * 256;
-        const uint32_t u0 = (uint32_t)((kq ^ nrow) * 16);
-#else
         const uint16_t* xb = &xs[buf][nrow * kRowHalfs + kq * 8];
-#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
 #ifdef ZL_TEXP_NOLDS
                 const h8 a = __builtin_bit_cast(h8, make_uint4(magic + rb, magic + t, mask_lo, mask_hi));
-#elif defined(ZL_TILED_SWZ)
-                const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(xb8 + rb * 4096 + (u0 ^ (uint32_t)(t * 64))));
 #else
                 const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(xb + rb * 16 * kRowHalfs + t * 32));
 #endif

@@ -660,7 +660,11 @@ int zl_w4m_unpack(const uint32_t* qw, const uint32_t* meta, int64_t n, int64_t k
 int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return ZL_EINVAL;
     const int64_t np = (n + 127) / 128 * 128;
-    return ZL_SCRATCH_HEADER + 32 * m * np * (int64_t)sizeof(float);   // <= 32 K splits of fp32 partials
+    // fp32 split-K partials, the largest any launcher asks for: up to 32 splits only while the tiles do not fill the chip
+    // (few rows: 32 x min(m, 32) x np; more rows: splits x tiles <= ~2 x CUs, i.e. splits x m x np <= 2 m np + 2 x 256 CUs
+    // x the largest tile, 256 x 256) -- not 32 x m x np, which was 3.8 GB for a 1024-token gate|up
+    const int64_t few = 32 * (m < 32 ? m : 32) * np;
+    return ZL_SCRATCH_HEADER + (few + 2 * m * np + 2 * 256 * 256 * 256) * (int64_t)sizeof(float);
 }
 
 int zl_w4a16_gemm_mfma(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias,
