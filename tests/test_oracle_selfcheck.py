@@ -125,3 +125,45 @@ def test_awq_oracle_matches_the_format_definition_and_its_own_exact_product():
     wf = oracle.u2h(tr(w16)).astype(np.float32)
     assert np.abs(w8).max() == 127 and np.allclose(s, np.abs(wf).max(axis=1) / 127.0, rtol=1e-6)
     assert np.abs(w8.astype(np.float32) * s[:, None] - wf).max() <= 0.5001 * s.max()
+
+
+def test_moe_oracle_against_the_definition(oracle):
+    """zlo_gptq_moe_up / _down (KERNEL_gemm_moe_up / _down restated) against fp64 sums over the token's LOCAL experts: routed
+    ids under expert parallelism (id % world == rank, stored at id / world), shared experts appended with weight 1, ADD_C."""
+    rng = np.random.default_rng(21)
+    e, n_sh, n, k, g, m, top_k, world, rank = 3, 1, 24, 256, 128, 3, 2, 2, 1
+
+    def experts(rows, cols):
+        l = [oracle.gptq_prepare_k_major(*synth.gptq_hf(rng, cols, rows, g), g) for _ in range(e + n_sh)]
+        return l, tuple(np.stack([a[i] for a in l]) for i in range(3))
+    gl, gs = experts(n, k)
+    ul, us = experts(n, k)
+    dl, ds = experts(16, k)
+    ids = np.array([[1, 4], [3, 5], [0, 2]], np.int32)            # global ids, 6 routed experts over 2 ranks
+    wts = rng.random((m, top_k)).astype(np.float32)
+    x = synth.act(rng, m, k)
+    up = oracle.u2h(oracle.gptq_moe_up(oracle.h2u(x), gs, us, ids, n_sh, e, False, True, world, rank)).astype(np.float64)
+    assert up.shape == (m, top_k + n_sh, n)
+    a = synth.act(rng, m * (top_k + n_sh), k).reshape(m, top_k + n_sh, k)
+    base = synth.act(rng, m, 16)
+    dn = oracle.u2h(oracle.gptq_moe_down(oracle.h2u(a), ds, ids, wts, n_sh, e, False, True, world, rank)).astype(np.float64)
+    dn_add = oracle.u2h(oracle.gptq_moe_down(oracle.h2u(a), ds, ids, wts, n_sh, e, False, True, world, rank,
+                                             add_c=oracle.h2u(base))).astype(np.float64)
+    for mm in range(m):
+        want_dn = np.zeros(16)
+        for t in range(top_k + n_sh):
+            if t < top_k:
+                gid = int(ids[mm, t])
+                local, ex, w = gid % world == rank, gid // world, float(wts[mm, t])
+            else:
+                local, ex, w = True, e + t - top_k, 1.0
+            if not local:
+                assert (up[mm, t] == 0).all()
+                continue
+            a1 = oracle.gptq_gemm_k_major_exact(oracle.h2u(x[mm:mm + 1]), *gl[ex])[0]
+            a2 = oracle.gptq_gemm_k_major_exact(oracle.h2u(x[mm:mm + 1]), *ul[ex])[0]
+            ref = a1 / (1 + np.exp(-a1)) * a2
+            assert np.abs(up[mm, t] - ref).max() <= 3e-3 * max(1.0, np.abs(ref).max())
+            want_dn += w * oracle.gptq_gemm_k_major_exact(oracle.h2u(a[mm, t:t + 1]), *dl[ex])[0]
+        assert np.abs(dn[mm] - want_dn).max() <= 3e-3 * max(1.0, np.abs(want_dn).max())
+        assert np.abs(dn_add[mm] - (want_dn + base[mm].astype(np.float64))).max() <= 4e-3 * max(1.0, np.abs(want_dn).max())
