@@ -187,3 +187,29 @@ def test_int8_route_through_cpp_is_bit_exact(cx, oracle):
 def test_errors_become_bmengine_exceptions(cx):
     with pytest.raises(RuntimeError, match="size K mismatch"):
         cx.raises_on_bad_shape()
+
+
+@pytest.mark.parametrize("prepack", [True, False])
+def test_moe_feed_forward_through_cpp_is_bit_exact(cx, oracle, prepack):
+    """nn::gptq::gemm_moe_up / gemm_moe_down with the reference's operands ((EXP, N, K/8) stacks, int8 zeros, float routing
+    weights): packed once (amd_pack_moe, the load path) or per call (an unmodified caller); both bit-equal to the oracle's
+    restatement of the CUDA kernels."""
+    rng = np.random.default_rng(31)
+    e, n_ff, k, dim, g, m, top_k = 4, 64, 256, 48, 128, 3, 2
+
+    def stack(rows, cols):
+        l = [oracle.gptq_prepare_k_major(*synth.gptq_hf(rng, cols, rows, g), g) for _ in range(e)]
+        return tuple(np.stack([a[i] for a in l]) for i in range(3))
+    gs, us, ds = stack(n_ff, k), stack(n_ff, k), stack(dim, 128)
+    ids = np.stack([rng.choice(e, top_k, replace=False) for _ in range(m)]).astype(np.int32)
+    wts = rng.random((m, top_k)).astype(np.float32)
+    x = synth.act(rng, m, k)
+    # the down projection reads the first 64 of its 128 input columns from the up output (zero-padded to one group)
+    ref_up = oracle.gptq_moe_up(oracle.h2u(x), gs, us, ids)
+    a_in = np.zeros((m, top_k, 128), np.float16)
+    a_in[:, :, :n_ff] = oracle.u2h(ref_up)
+    ref_dn = oracle.gptq_moe_down(oracle.h2u(a_in), ds, ids, wts)
+    got_up, got_dn = cx.gemm_moe_steps(x, gs[0].view(np.int32), gs[1], oracle.u2h(gs[2]), us[0].view(np.int32), us[1], oracle.u2h(us[2]),
+                                       a_in, ds[0].view(np.int32), ds[1], oracle.u2h(ds[2]), ids, wts, 0, prepack)
+    assert np.array_equal(got_up.view(np.uint16), ref_up)
+    assert np.array_equal(got_dn.view(np.uint16), ref_dn)

@@ -206,6 +206,117 @@ Tensor gemm_fuse_gate_in(const Context& ctx, const Tensor& a, const Tensor& q_we
     return g;
 }
 
+// ---- fused MoE GEMVs
+PackedMoE amd_pack_moe(const Context& ctx, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales, const Tensor* q_weight2,
+                       const Tensor* qzeros2, const Tensor* scales2) {
+    BM_ASSERT_EQ(q_weight.ndim(), 3, "q_weight must be (EXP, N, K / 8)");
+    BM_ASSERT(scales.dtype() == DataType::kHalf, "scales must be half");
+    const bool pair = q_weight2 != nullptr;
+    if (pair) BM_ASSERT(qzeros2 && scales2 && q_weight2->shape() == q_weight.shape(), "in and gate should have same shape.");
+    const int64_t e = q_weight.size(0), n1 = q_weight.size(1), k = q_weight.size(2) * 8, g = k / scales.size(2);
+    const int64_t n = pair ? 2 * n1 : n1;
+    zl_w4_layout_t L;
+    zl_check(zl_w4_layout(n, k, g, &L), "amd_pack_moe");
+    PackedMoE p;
+    p.experts = e; p.n = n; p.k = k; p.group_size = g; p.row_interleave = pair;
+    p.q_weight = ctx.tensor({(size_t)e, (size_t)L.qw_bytes / 4}, DataType::kInt32);
+    p.scales = ctx.tensor({(size_t)e, (size_t)L.scales_bytes / 2}, DataType::kHalf);
+    p.zeros = ctx.tensor({(size_t)e, (size_t)L.zeros_bytes / 2}, DataType::kInt16);
+    const size_t ng = (size_t)(k / g);
+    Tensor cq, cz, cs;
+    if (pair) {        // [gate; up] of one expert, contiguous: the pack kernel interleaves the rows
+        cq = ctx.tensor({(size_t)n, (size_t)k / 8}, DataType::kInt32);
+        cz = ctx.tensor({(size_t)n, ng}, DataType::kInt8);
+        cs = ctx.tensor({(size_t)n, ng}, DataType::kHalf);
+    }
+    hipStream_t hs = (hipStream_t)st_of(ctx);
+    for (int64_t i = 0; i < e; ++i) {
+        const uint32_t* q = q_weight.data<uint32_t>() + (size_t)i * n1 * (k / 8);
+        const uint8_t* z = qzeros.data<uint8_t>() + (size_t)i * n1 * ng;
+        const uint16_t* sc = u16(scales) + (size_t)i * n1 * ng;
+        if (pair) {
+            const size_t qb = (size_t)n1 * (k / 8) * 4, zb = (size_t)n1 * ng, sb = (size_t)n1 * ng * 2;
+            BM_ASSERT(hipMemcpyAsync(cq.data<uint32_t>(), q, qb, hipMemcpyDeviceToDevice, hs) == hipSuccess, "copy");
+            BM_ASSERT(hipMemcpyAsync(cq.data<uint32_t>() + qb / 4, q_weight2->data<uint32_t>() + (size_t)i * n1 * (k / 8), qb,
+                                     hipMemcpyDeviceToDevice, hs) == hipSuccess, "copy");
+            BM_ASSERT(hipMemcpyAsync(cz.data<uint8_t>(), z, zb, hipMemcpyDeviceToDevice, hs) == hipSuccess, "copy");
+            BM_ASSERT(hipMemcpyAsync(cz.data<uint8_t>() + zb, qzeros2->data<uint8_t>() + (size_t)i * n1 * ng, zb, hipMemcpyDeviceToDevice,
+                                     hs) == hipSuccess, "copy");
+            BM_ASSERT(hipMemcpyAsync(u16m(cs), sc, sb, hipMemcpyDeviceToDevice, hs) == hipSuccess, "copy");
+            BM_ASSERT(hipMemcpyAsync(u16m(cs) + sb / 2, u16(*scales2) + (size_t)i * n1 * ng, sb, hipMemcpyDeviceToDevice, hs) == hipSuccess,
+                      "copy");
+            q = cq.data<uint32_t>(); z = cz.data<uint8_t>(); sc = u16(cs);
+        }
+        zl_check(zl_w4_pack(q, z, sc, n, k, g, pair ? 1 : 0, p.q_weight.data<uint32_t>() + (size_t)i * (L.qw_bytes / 4),
+                            u16m(p.scales) + (size_t)i * (L.scales_bytes / 2),
+                            reinterpret_cast<uint16_t*>(p.zeros.data<int16_t>()) + (size_t)i * (L.zeros_bytes / 2), st_of(ctx)),
+                 "amd_pack_moe");
+    }
+    return p;
+}
+
+static void moe_strides(const PackedMoE& w, int64_t* sq, int64_t* ss, int64_t* sz) {
+    zl_w4_layout_t L;
+    zl_check(zl_w4_layout(w.n, w.k, w.group_size, &L), "moe layout");
+    *sq = L.qw_bytes; *ss = L.scales_bytes; *sz = L.zeros_bytes;
+}
+
+Tensor gemm_moe_up_packed(const Context& ctx, const Tensor& a, const PackedMoE& w, const Tensor& expert_ids, int n_shared_expert,
+                          bool exp_parallel) {
+    BM_ASSERT_LE(a.ndim(), 2, "Wrong ndim");
+    BM_ASSERT(a.dtype() == DataType::kHalf && w.row_interleave, "gemm_moe_up: half activations, [gate; up] experts");
+    BM_ASSERT_EQ((int64_t)a.size(-1), w.k, "size K mismatch");
+    const int64_t m = a.ndim() == 2 ? a.size(0) : 1, top_k = expert_ids.size(-1), n_ff = w.n / 2;
+    Tensor c = ctx.tensor({(size_t)m, (size_t)(top_k + n_shared_expert), (size_t)n_ff}, a.dtype());
+    int64_t sq, ss, sz;
+    moe_strides(w, &sq, &ss, &sz);
+    zl_check(zl_w4a16_moe_up(u16(a), w.k, w.q_weight.data<uint32_t>(), u16(w.scales), reinterpret_cast<const uint16_t*>(w.zeros.data<int16_t>()),
+                             sq, ss, sz, expert_ids.data<int32_t>(), u16m(c), m, n_ff, w.k, w.group_size, (int)top_k, n_shared_expert,
+                             (int)(w.experts - n_shared_expert), exp_parallel, ctx.world_size(), ctx.rank(), st_of(ctx)), "gemm_moe_up");
+    return c;
+}
+
+Tensor gemm_moe_down_packed(const Context& ctx, const Tensor& a, const PackedMoE& w, const Tensor& expert_ids, const Tensor& expert_weights,
+                            int n_shared_expert, bool exp_parallel, Tensor* output) {
+    BM_ASSERT_EQ(a.ndim(), 3, "Wrong ndim");
+    BM_ASSERT(a.dtype() == DataType::kHalf && !w.row_interleave, "gemm_moe_down: half activations, plain experts");
+    BM_ASSERT(expert_weights.dtype() == DataType::kFloat, "expert_weights must be float");
+    const int64_t m = a.size(0), top_k = expert_ids.size(-1);
+    BM_ASSERT_EQ((int64_t)a.size(1), top_k + n_shared_expert, "TOP_K mismatch");
+    BM_ASSERT_EQ((int64_t)a.size(2), w.k, "size K mismatch");
+    const bool add_c = output && output->numel() > 0;
+    Tensor c = add_c ? *output : ctx.tensor({(size_t)m, (size_t)w.n}, a.dtype());
+    int64_t sq, ss, sz;
+    moe_strides(w, &sq, &ss, &sz);
+    zl_check(zl_w4a16_moe_down(u16(a), w.k, w.q_weight.data<uint32_t>(), u16(w.scales),
+                               reinterpret_cast<const uint16_t*>(w.zeros.data<int16_t>()), sq, ss, sz, expert_ids.data<int32_t>(),
+                               expert_weights.data<float>(), u16m(c), m, w.n, w.k, w.group_size, (int)top_k, n_shared_expert,
+                               (int)(w.experts - n_shared_expert), exp_parallel, ctx.world_size(), ctx.rank(), add_c ? 1 : 0, st_of(ctx)),
+             "gemm_moe_down");
+    if (output && !add_c) *output = c;
+    return c;
+}
+
+Tensor gemm_moe_up(const Context& ctx, const Tensor& a, const Tensor& q_weight1, const Tensor& qzeros1, const Tensor& scales1,
+                   const Tensor& rev_perm1, const Tensor& q_weight2, const Tensor& qzeros2, const Tensor& scales2, const Tensor& rev_perm2,
+                   bool sym, const Tensor& expert_ids, int n_shared_expert, bool exp_parallel) {
+    BM_ASSERT(rev_perm1.numel() == 0 && rev_perm2.numel() == 0, "gemm_moe_up: act-order experts are not supported (nor by the reference kernel)");
+    BM_ASSERT(qzeros1.dtype() == DataType::kInt8, "qzeros must be int8");
+    BM_ASSERT(qzeros2.dtype() == DataType::kInt8, "qzeros must be int8");
+    (void)sym;     // sym checkpoints carry zero points of 8: the packed zeros hold them
+    PackedMoE w = amd_pack_moe(ctx, q_weight1, qzeros1, scales1, &q_weight2, &qzeros2, &scales2);
+    return gemm_moe_up_packed(ctx, a, w, expert_ids, n_shared_expert, exp_parallel);
+}
+
+Tensor gemm_moe_down(const Context& ctx, const Tensor& a, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales,
+                     const Tensor& expert_ids, const Tensor& expert_weights, bool sym, int n_shared_expert, bool exp_parallel,
+                     Tensor* output) {
+    BM_ASSERT(qzeros.dtype() == DataType::kInt8, "qzeros must be int8");
+    (void)sym;
+    PackedMoE w = amd_pack_moe(ctx, q_weight, qzeros, scales);
+    return gemm_moe_down_packed(ctx, a, w, expert_ids, expert_weights, n_shared_expert, exp_parallel, output);
+}
+
 }  // namespace gptq
 
 namespace awq {

@@ -6,7 +6,8 @@
 //
 // reference header                                   | names provided here
 //   src/nn/quant/gptq/gptq.h:10-184                  | nn::gptq::{gptq_gemm_k_major, gemm_fuse_gate_in, dequant_k_major, gptq_shuffle,
-//                                                    |            increase_zero, q4_to_q8, un_shuffle, shuffle_awq} + amd_pack_k_major
+//                                                    |            increase_zero, q4_to_q8, un_shuffle, shuffle_awq, gemm_moe_up, gemm_moe_down}
+//                                                    |            + amd_pack_k_major, amd_pack_moe
 //   src/nn/quant/int8/quant_kernel.h:15-128          | int8_op::{quant_calc_scale x2, set_quant_scale, quant_scale_back, quant_scale_back3,
 //                                                    |           layernorm_quant, quant_back_element_add_scale, quant_back_transpose,
 //                                                    |           quant_back_act_mul, quant_back_copy_to_buffer} + int8_gemm_nt
@@ -71,6 +72,32 @@ core::Tensor gemm_fuse_gate_in(const core::Context& ctx, const core::Tensor& a, 
                                const core::Tensor& qzeros1, const core::Tensor& scales1, const core::Tensor& rev_perm1,
                                const core::Tensor& q_weight2, const core::Tensor& qzeros2, const core::Tensor& scales2,
                                const core::Tensor& rev_perm2, bool sym);
+
+// FUSE_GPTQ_MOE (src/nn/quant/gptq/gptq.h: gemm_moe_up / gemm_moe_down, q_gemm_k_major.cu:392-520).  The operands are the
+// reference's (EXP, N, K/8) int32 / (EXP, N, K/G) int8 / (EXP, N, K/G) half stacks; this repository's kernels want every
+// expert packed (zl_w4_pack; gate / up row-interleaved) and stacked: amd_pack_moe does that once at load
+// (FeedForward::load_state_dict), the *_packed entry points take its result.  The entry points with the reference's
+// signatures pack temporaries on every call (correct, slow: what an unmodified caller gets).
+struct PackedMoE {
+    core::Tensor q_weight, scales, zeros;      // (EXP, bytes of one packed expert) each
+    int64_t experts = 0, n = 0, k = 0, group_size = 0;
+    bool row_interleave = false;
+};
+PackedMoE amd_pack_moe(const core::Context& ctx, const core::Tensor& q_weight, const core::Tensor& qzeros, const core::Tensor& scales,
+                       const core::Tensor* q_weight2 = nullptr, const core::Tensor* qzeros2 = nullptr,
+                       const core::Tensor* scales2 = nullptr);      // with the second set: [gate; up], row-interleaved
+core::Tensor gemm_moe_up_packed(const core::Context& ctx, const core::Tensor& a, const PackedMoE& w, const core::Tensor& expert_ids,
+                                int n_shared_expert, bool exp_parallel);
+core::Tensor gemm_moe_down_packed(const core::Context& ctx, const core::Tensor& a, const PackedMoE& w, const core::Tensor& expert_ids,
+                                  const core::Tensor& expert_weights, int n_shared_expert, bool exp_parallel,
+                                  core::Tensor* output = nullptr);     // output given: ADD_C (accumulates into it)
+core::Tensor gemm_moe_up(const core::Context& ctx, const core::Tensor& a, const core::Tensor& q_weight1, const core::Tensor& qzeros1,
+                         const core::Tensor& scales1, const core::Tensor& rev_perm1, const core::Tensor& q_weight2,
+                         const core::Tensor& qzeros2, const core::Tensor& scales2, const core::Tensor& rev_perm2, bool sym,
+                         const core::Tensor& expert_ids, int n_shared_expert, bool exp_parallel);
+core::Tensor gemm_moe_down(const core::Context& ctx, const core::Tensor& a, const core::Tensor& q_weight, const core::Tensor& qzeros,
+                           const core::Tensor& scales, const core::Tensor& expert_ids, const core::Tensor& expert_weights, bool sym,
+                           int n_shared_expert, bool exp_parallel, core::Tensor* output = nullptr);
 }  // namespace gptq
 
 namespace awq {

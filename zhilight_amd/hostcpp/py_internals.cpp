@@ -110,6 +110,26 @@ PYBIND11_MODULE(zl_internals, m) {
                                                    Tensor(), false);
             return c.down(y, "float16");
         })
+        .def("gemm_moe_steps", [](PyCtx& c, py::array x, py::array q1, py::array z1, py::array s1, py::array q2, py::array z2,
+                                   py::array s2, py::array a_down, py::array qd, py::array zd, py::array sd, py::array ids, py::array wts,
+                                   int n_shared, bool prepack) {
+            // the two fused MoE GEMVs of FeedForward under FUSE_GPTQ_MOE: up = silu(x . gate_e) * (x . up_e) per (token, expert),
+            // down = weighted sum over the token's experts of a_down[m, t] . W_e; returns (up (M, T, n_ff), down (M, dim))
+            Tensor tx = c.up(x), ta = c.up(a_down), ti = c.up(ids), tw = c.up(wts);
+            Tensor tq1 = c.up(q1), tz1 = c.up(z1), ts1 = c.up(s1), tq2 = c.up(q2), tz2 = c.up(z2), ts2 = c.up(s2);
+            Tensor tqd = c.up(qd), tzd = c.up(zd), tsd = c.up(sd);
+            Tensor up, down;
+            if (prepack) {     // the load path: pack once, then the *_packed entry points
+                auto wu = nn::gptq::amd_pack_moe(*c.ctx, tq1, tz1, ts1, &tq2, &tz2, &ts2);
+                auto wd = nn::gptq::amd_pack_moe(*c.ctx, tqd, tzd, tsd);
+                up = nn::gptq::gemm_moe_up_packed(*c.ctx, tx, wu, ti, n_shared, false);
+                down = nn::gptq::gemm_moe_down_packed(*c.ctx, ta, wd, ti, tw, n_shared, false);
+            } else {           // the reference's own signatures
+                up = nn::gptq::gemm_moe_up(*c.ctx, tx, tq1, tz1, ts1, Tensor(), tq2, tz2, ts2, Tensor(), false, ti, n_shared, false);
+                down = nn::gptq::gemm_moe_down(*c.ctx, ta, tqd, tzd, tsd, ti, tw, false, n_shared, false);
+            }
+            return py::make_tuple(c.down(up, "float16"), c.down(down, "float16"));
+        })
         .def("gptq_load_transforms", [](PyCtx& c, py::array qweight_hf, py::array qzeros_hf) {
             // Int4GPTQ::preprocess_weight (linear.cpp:1139-1160): shuffle the words, +1 the zeros, one byte per zero
             Tensor q = c.up(qweight_hf), z = c.up(qzeros_hf);
