@@ -191,7 +191,7 @@ typedef struct {
     int tiled_min_m, tiled_bm, tiled_splitk;
     int mfma_ks, mfma_rounds;
     int tiled_wide;   /* prompt-chunk tiles (128 / 256 x 256 outputs per workgroup, M >= 128): 0 default (on, height by cost model), -1 off,
-                         1 also for 32 < M < 128, 2 128-row tiles only, 3 256-row tiles whenever M > 128 */
+                         1 also for 32 < M < 128, 2 128-row tiles only, 3 256-row tiles whenever M > 128, 4 192-column tiles */
 } zl_w4_opts_t;
 int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n);
 int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias,

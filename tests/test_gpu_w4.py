@@ -272,12 +272,14 @@ def test_tiled_gemm_shapes(oracle, dev, m, k, n):
 @pytest.mark.parametrize("m,k,n,splitk,force", [(128, 1024, 256, 0, 0), (257, 2048, 384, 0, 0), (1000, 1152 + 128, 1000, 0, 0),
                                                 (130, 4096, 512, 3, 0), (70, 1024, 520, 0, 1), (384, 128, 256, 0, 0),
                                                 (256, 256, 4096, 0, 0), (300, 1024, 512, 0, 3), (515, 2304, 776, 0, 3),
-                                                (257, 4096, 256, 2, 3), (1024, 384, 1024, 0, 3)])
+                                                (257, 4096, 256, 2, 3), (1024, 384, 1024, 0, 3), (300, 1024, 200, 0, 4), (515, 1152, 776, 0, 4),
+                                                (1024, 512, 6144, 0, 0)])
 def test_wide_gemm_shapes(oracle, dev, m, k, n, splitk, force, monkeypatch):
     """The prompt-chunk tiles (k_w4a16_gemm_wide<8 / 16>: 128 or 256 x 256 outputs per workgroup, swizzled LDS image of the
     activation chunk, MFMA / dequant interleave in issue order): ragged M / N, one- and two-chunk K (shorter than the
     pipeline), odd chunk counts (the zero-scale tail chunk), split-K through the caller's scratch, bias / residual epilogues;
-    force = ZL_W4_TILED_WIDE (1: also below 128 rows, 3: the 256-row tile); the same bars as the other M-tiled kernel."""
+    force = ZL_W4_TILED_WIDE (1: also below 128 rows, 3: the 256-row tile, 4: 192-column tiles -- what the cost model picks
+    for N = 6144, the last case); the same bars as the other M-tiled kernel."""
     if splitk:
         monkeypatch.setenv("ZL_W4_TILED_SPLITK", str(splitk))
     if force:

@@ -320,7 +320,9 @@ __device__ __forceinline__ uint32_t wv_pk_mul(uint32_t a, uint32_t b) {
 #ifndef ZL_WIDE_OCC
 #define ZL_WIDE_OCC 1
 #endif
-template <int RB>
+// NT = 16-column weight tiles per wave (4: 256 columns per workgroup; 3: 192 -- N = 6144 = 32 x 192 gives the qkv projection
+// of a 1024-token chunk 256 workgroups instead of 192)
+template <int RB, int NT>
 __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const TiledParams p, const int gx, const int gy) {
     constexpr int kWideBM = 16 * RB;
     constexpr int kWideChunkBytes = kWideBM * 128 * 2;         // one 128-k activation chunk in LDS
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     const int ry = local % gy, cx = (local / gy) * 8 + xcd;
     if (cx >= gx) return;
     const int m0 = ry * kWideBM;
-    const int tile0 = cx * 16 + wave * 4;                      // this wave's four 16-column weight tiles
+    const int tile0 = cx * (4 * NT) + wave * NT;               // this wave's NT 16-column weight tiles
     const int g_begin = p.ws ? blockIdx.y * p.split_chunks : 0;
     const int G = p.ws ? min(p.groups, g_begin + p.split_chunks) : p.groups;
 
@@ -341,11 +343,11 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
     const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)nrow * 4u;
-    uint32_t tbase[4];
+    uint32_t tbase[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tbase[j] = (uint32_t)(tile0 + j < p.tiles ? tile0 + j : p.tiles - 1) * (uint32_t)p.groups;
-    uint4 wq[4 * kWideRing];
-    uint32_t mt[4 * kWideRing];
+    for (int j = 0; j < NT; ++j) tbase[j] = (uint32_t)(tile0 + j < p.tiles ? tile0 + j : p.tiles - 1) * (uint32_t)p.groups;
+    uint4 wq[NT * kWideRing];
+    uint32_t mt[NT * kWideRing];
     auto issue_item = [&](int slot, int j, int g) {
         const uint32_t it = tbase[j] + (uint32_t)(g < G ? g : G - 1);
         wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off, it * 1024u, 2));
@@ -383,18 +385,18 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     uint32_t one16_v = 0x2c002c00u;                            // 0.0625 x 2, in a VGPR for the asm statements
     asm volatile("" : "+v"(one16_v));
 
-    f4 acc[RB][4];
+    f4 acc[RB][NT];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[rb][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[rb][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    hv2 z1[4], z16[4], s2[4];
+    hv2 z1[NT], z16[NT], s2[NT];
     // live == false: a chunk past the end (odd chunk counts run the second half of the unrolled pair on the clamped last
     // chunk): its scales are zero, so it adds exact zeros
     auto load_consts = [&](int slot0, bool live) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const uint32_t mw = mt[slot0 + j];
             z1[j] = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(mw, mw, 0x03020302u));
             z16[j] = z1[j] + c960;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
         return t == 0 ? wq[slot].x : (t == 1 ? wq[slot].y : (t == 2 ? wq[slot].z : wq[slot].w));
     };
     // B fragments of two k-steps as raw words: bw[set][tile][4]; half h of a word fills [2 h], [2 h + 1] (dequant_scaled's order)
-    uint32_t bw[2][4][4];
+    uint32_t bw[2][NT][4];
     auto dequant_half = [&](int set, int j, uint32_t w, int h) {
         const uint32_t ws = h ? (w >> 8) : w;
         const hv2 lo = (__builtin_bit_cast(hv2, and_or_t(ws, mask_lo, magic)) + z1[j]) * s2[j];
@@ -423,14 +425,14 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
 #pragma unroll
     for (int c = 0; c < kWideRing; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) issue_item(4 * c + j, j, g_begin + c);
+        for (int j = 0; j < NT; ++j) issue_item(NT * c + j, j, g_begin + c);
 #pragma unroll
     for (int r = 0; r < RB; ++r) store_x1(r, 0);
 #pragma unroll
     for (int r = 0; r < RB; ++r) load_x1(r, g_begin + 1);
     load_consts(0, true);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NT; ++j) {
         dequant_half(0, j, word_of(j, 0), 0);
         dequant_half(0, j, word_of(j, 0), 1);
     }
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     // 4 MFMAs (k-step t = blk / 8, 16-row block rb = blk % 8), each with its share of everything else
     auto chunk = [&](auto Uc, int g, bool next_live) {
         constexpr int U = decltype(Uc)::value;
-        constexpr int cs = 4 * U, ns = 4 * (U ^ 1);
+        constexpr int cs = NT * U, ns = NT * (U ^ 1);
         constexpr uint32_t xb = U * kWideChunkBytes, xo = (U ^ 1) * kWideChunkBytes;
         auto read_a = [&](int slot, int blk) {
             af[slot] = *reinterpret_cast<const uint4*>(smem_w + xb + (a_off0 ^ (uint32_t)((blk / RB) * 64)) + (blk % RB) * 4096);
@@ -464,9 +466,10 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     }
             // one eighth of the next k-step's B fragments between the MFMAs: tile dj = rb / 2, half dh = rb & 1 of word
             // t + 1 of this chunk (t == 3: word 0 of the next chunk, with its meta)
-            // blocks with rb % (RB / 8) == 0 carry one of the 8 dequant slices of the next k-step: slice sl = tile sl / 2, half sl & 1
-            const bool deq = (rb % (RB / 8)) == 0;
-            const int sl = rb / (RB / 8), dj = sl >> 1, dh = sl & 1, dset = (t + 1) & 1;
+            // blocks with rb % (RB / 8) == 0 carry one of the 2 NT dequant slices of the next k-step: slice sl = tile sl / 2, half sl & 1
+            const int sl = rb / (RB / 8);
+            const bool deq = (rb % (RB / 8)) == 0 && sl < 2 * NT;
+            const int dj = deq ? sl >> 1 : 0, dh = sl & 1, dset = (t + 1) & 1;
             if (t == 3 && rb == 0) load_consts(ns, next_live);
             const uint32_t w = t < 3 ? word_of(cs + dj, t + 1) : word_of(ns + dj, 0);
             uint32_t ws = 0, x_lo = 0, x_hi = 0, y_lo = 0, y_hi = 0;
@@ -505,10 +508,10 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
 #endif
             ZL_WIDE_MFMA(2)
             ZL_WIDE_DEQ(3)
-            ZL_WIDE_MFMA(3)
+            if constexpr (NT > 3) ZL_WIDE_MFMA(3)
 #undef ZL_WIDE_DEQ
 #undef ZL_WIDE_MFMA
-            if (t == 3 && rb >= 1 && rb <= 4) issue_item(cs + rb - 1, rb - 1, g + kWideRing);
+            if (t == 3 && rb >= 1 && rb <= NT) issue_item(cs + rb - 1, rb - 1, g + kWideRing);
 #ifndef ZL_WEXP_NOPIN
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
 #pragma unroll
         for (int rb = RB - 2; rb < RB; ++rb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zero8, zero8, acc[rb][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zero8, zero8, acc[rb][j], 0, 0, 0);
     }
     // ---- epilogue (row-block-major like the main loop: the accumulators stay where the loop left them)
     if (p.ws) {
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 const int n = (tile0 + j) * 16 + nrow;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -551,9 +554,9 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
             }
         return;
     }
-    float bj[4];
+    float bj[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NT; ++j) {
         const int n = (tile0 + j) * 16 + nrow;
         bj[j] = ((p.epi & ZL_EPI_BIAS) && p.bias && n < p.n) ? (float)__builtin_bit_cast(_Float16, p.bias[n]) : 0.f;
     }
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fn(m0 + rb * 16 + 4 * kq + i, (tile0 + j) * 16 + nrow, acc[rb][j][i] , bj[j]);
     };
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 const int n = (tile0 + j) * 16 + nrow;
                 const float b = bj[j];
                 float v[4], o[4];
@@ -748,39 +751,45 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
     hipStream_t hs = (hipStream_t)s;
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
-    // prompt chunks: the 128 x 256 / 256 x 256 tiles (k_w4a16_gemm_wide<8 / 16>)
-    if (o.tiled_wide >= 0 && o.tiled_bm == 0 && (m >= 128 || (o.tiled_wide > 0 && m > 32)) && L.np >= 256) {
-        const int gxw = (int)((L.np + 255) / 256);
-        // tile height and K splits by a small cost model (cycles per 128-k chunk and workgroup measured: 3 850 for 128 rows,
-        // ~7 000 for 256 rows = 9 % less per row; a launch takes ceil(tiles x splits / CUs) rounds of chunks / splits chunks;
-        // fewer tiles than CUs split K just far enough to give every CU one workgroup -- fp32 partials through the caller's
-        // scratch, summed in split order)
-        int best_rb = 8, best_splits = 1;
-        double best_cost = 0;
-        for (int rb = 8; rb <= 16; rb += 8) {
-            if (rb == 16 && (m <= 128 || o.tiled_wide == 2)) break;        // (tiled_wide == 2: 128-row tiles only)
-            const int64_t tiles = (int64_t)gxw * ((m + 16 * rb - 1) / (16 * rb));
-            int sp = 1;
-            if (tiles * 4 <= (int64_t)cus * 3) {
-                sp = (int)(cus / tiles);
-                const int max_s = p.groups / 8 > 0 ? p.groups / 8 : 1;
-                sp = sp > max_s ? max_s : sp;
-                sp = sp > 8 ? 8 : (sp < 1 ? 1 : sp);
+    // prompt chunks: k_w4a16_gemm_wide<RB, NT> -- 128 / 256 rows x 256 / 192 columns per workgroup
+    if (o.tiled_wide >= 0 && o.tiled_bm == 0 && (m >= 128 || (o.tiled_wide > 0 && m > 32)) && L.np >= 192) {
+        // tile shape and K splits by a small cost model.  Cycles per 128-k chunk and workgroup ~ 64 RB NT (MFMA) + 281 NT
+        // (dequant and the rest of the VALU) + the per-chunk remainder (measured: 3 850 for 128 x 256, ~7 000 for 256 x 256);
+        // a launch takes ceil(tiles x splits / CUs) rounds of chunks / splits chunks; fewer tiles than CUs split K just far
+        // enough to give every CU one workgroup -- fp32 partials through the caller's scratch, summed in split order.
+        // 192-column tiles exist for N that 256 leaves short of the chip: N = 6144 (qkv) = 24 x 256 = 32 x 192.
+        int best_rb = 8, best_nt = 4, best_splits = 1;
+        double best_cost = -1;
+        for (int nt = 4; nt >= 3; --nt)
+            for (int rb = 8; rb <= 16; rb += 8) {
+                if (rb == 16 && (m <= 128 || o.tiled_wide == 2)) continue;    // (tiled_wide == 2: 128-row tiles only)
+                if (nt == 4 && L.np < 256) continue;
+                const int64_t tiles = ((L.np + 64 * nt - 1) / (64 * nt)) * ((m + 16 * rb - 1) / (16 * rb));
+                int sp = 1;
+                if (tiles * 4 <= (int64_t)cus * 3) {
+                    sp = (int)(cus / tiles);
+                    const int max_s = p.groups / 8 > 0 ? p.groups / 8 : 1;
+                    sp = sp > max_s ? max_s : sp;
+                    sp = sp > 8 ? 8 : (sp < 1 ? 1 : sp);
+                }
+                if (o.tiled_splitk > 0) sp = o.tiled_splitk <= p.groups ? o.tiled_splitk : p.groups;
+                const int64_t need = ZL_SCRATCH_HEADER + (int64_t)sp * m * L.np * (int64_t)sizeof(float);
+                if (sp > 1 && !(o.scratch && o.scratch_bytes >= need)) sp = 1;
+                const int64_t rounds = (tiles * sp + cus - 1) / cus;
+                const double chunk = 64.0 * rb * nt + 281.0 * nt + (rb == 16 ? 1780.0 : 700.0);
+                const double cost = (double)rounds * (double)((p.groups + sp - 1) / sp) * chunk +
+                                    (sp > 1 ? 0.004 * (double)sp * (double)m * (double)L.np : 0.0);
+                if (best_cost < 0 || cost < best_cost * 0.97) {             // (3 %: prefer the earlier, wider candidate on a tie)
+                    best_cost = cost;
+                    best_rb = rb;
+                    best_nt = nt;
+                    best_splits = sp;
+                }
             }
-            if (o.tiled_splitk > 0) sp = o.tiled_splitk <= p.groups ? o.tiled_splitk : p.groups;
-            const int64_t need = ZL_SCRATCH_HEADER + (int64_t)sp * m * L.np * (int64_t)sizeof(float);
-            if (sp > 1 && !(o.scratch && o.scratch_bytes >= need)) sp = 1;
-            const int64_t rounds = (tiles * sp + cus - 1) / cus;
-            const double cost = (double)rounds * (double)((p.groups + sp - 1) / sp) * (rb == 16 ? 7000.0 : 3850.0) +
-                                (sp > 1 ? 0.004 * (double)sp * (double)m * (double)L.np : 0.0);
-            if (rb == 8 || cost < best_cost) {
-                best_cost = cost;
-                best_rb = rb;
-                best_splits = sp;
-            }
-        }
         if (o.tiled_wide == 3 && m > 128) best_rb = 16;                    // (experiments: force the 256-row tile)
-        const int rbw = best_rb, gyw = (int)((m + 16 * rbw - 1) / (16 * rbw));
+        if (o.tiled_wide == 4) best_nt = 3;                                 // (experiments: force 192-column tiles)
+        const int rbw = best_rb, ntw = best_nt;
+        const int gxw = (int)((L.np + 64 * ntw - 1) / (64 * ntw)), gyw = (int)((m + 16 * rbw - 1) / (16 * rbw));
         int splits = best_splits;
         p.ws = nullptr; p.split_chunks = p.groups; p.ld_ws = (int)L.np;
         if (splits > 1) {
@@ -797,18 +806,25 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
         const int64_t wgs = (int64_t)((gxw + 7) / 8) * 8 * gyw;
         ZL_CHECK_ARG(wgs <= 0x7fffffff, ZL_ELIMIT);
         const size_t ldsw = (size_t)2 * 16 * rbw * 256;
-        if (rbw == 16) {
-            static bool attr_set = false;                                   // idempotent: a race only repeats the call
-            if (!attr_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm_wide<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)ldsw) != hipSuccess)
-                    return ZL_ELIMIT;
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(k_w4a16_gemm_wide<16>, dim3((unsigned)wgs, (unsigned)splits), dim3(256), ldsw, hs, p, gxw, gyw);
-        } else {
-            hipLaunchKernelGGL(k_w4a16_gemm_wide<8>, dim3((unsigned)wgs, (unsigned)splits), dim3(256), ldsw, hs, p, gxw, gyw);
-        }
+        const dim3 gridw((unsigned)wgs, (unsigned)splits);
+#define ZL_WIDE_LAUNCH(RBV, NTV)                                                                                             \
+    {                                                                                                                        \
+        if (ldsw > 64 * 1024) {                                                                                              \
+            static bool attr_set = false; /* idempotent: a race only repeats the call */                                     \
+            if (!attr_set) {                                                                                                 \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm_wide<RBV, NTV>),                         \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw) != hipSuccess)                \
+                    return ZL_ELIMIT;                                                                                        \
+                attr_set = true;                                                                                             \
+            }                                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((k_w4a16_gemm_wide<RBV, NTV>), gridw, dim3(256), ldsw, hs, p, gxw, gyw);                          \
+    }
+        if (rbw == 16 && ntw == 4) ZL_WIDE_LAUNCH(16, 4)
+        else if (rbw == 16) ZL_WIDE_LAUNCH(16, 3)
+        else if (ntw == 4) ZL_WIDE_LAUNCH(8, 4)
+        else ZL_WIDE_LAUNCH(8, 3)
+#undef ZL_WIDE_LAUNCH
         st = zl_launch_status();
         if (st || splits <= 1) return st;
         return launch_splitk_epilogue(p.ws, splits, m, n, p.ld_ws, bias, residual, y, epilogue, p.ld_out, hs);
