@@ -190,6 +190,9 @@ typedef struct {
     int phase_rounds, phase_ksplit, phase_ksplit_min_m, phase_min_m, phase_max_m, phase_small_off;
     int tiled_min_m, tiled_bm, tiled_splitk;
     int mfma_ks, mfma_rounds;
+    int small_algo;   /* 1..4 rows: 0 = the integer-plane kernel (w4_i8p.hip: nibbles expanded to int8, activations as three byte planes of a
+                         per-group block-floating integer, v_mfma_i32_16x16x64_i8; the default), 1 = the fp16-dequant kernels of
+                         rounds 1-2 (k_w4a16_phase / k_w4a16_mfma) */
     int tiled_wide;   /* prompt-chunk tiles (128 / 256 x 256 outputs per workgroup, M >= 128): 0 default (on, height by cost model), -1 off,
                          1 also for 32 < M < 128, 2 128-row tiles only, 3 256-row tiles whenever M > 128, 4 192-column tiles */
 } zl_w4_opts_t;
@@ -342,6 +345,13 @@ int zl_w4a16_qkv_rope_scatter(const uint16_t* x, int64_t ldx, const uint32_t* qw
                               const float* sinv, const int32_t* placement, const int32_t* buf_lens,
                               uint16_t* const* k_bufs, uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h,
                               int64_t hkv, int64_t d, int64_t k, int64_t group_size, int bshd, zl_stream_t s);
+/* the same with the launcher options (zl_w4_opts_t::small_algo selects the kernel family for 1..4 rows) */
+int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
+                                 const uint16_t* bias, const uint16_t* norm_weight, float norm_eps, const float* cosv,
+                                 const float* sinv, const int32_t* placement, const int32_t* buf_lens,
+                                 uint16_t* const* k_bufs, uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h,
+                                 int64_t hkv, int64_t d, int64_t k, int64_t group_size, int bshd, const zl_w4_opts_t* opts,
+                                 zl_stream_t s);
 
 /* Decode attention with the split merge folded into the attention output projection (len_q == 1 per task, prefix
  * visibility, D == 128, H / Hkv <= 16: the matrix-core kernel).  zl_decode_attn_splits is zl_decode_attn without its

@@ -1,0 +1,570 @@
+// w4_i8p.hip -- W4A16 GEMV for 1..4 activation rows: the batch-1 decode hot path (gptq_gemm_k_major's M <= 4 regime,
+// src/nn/quant/gptq/q_gemm_k_major.cu:957-1116 / KERNEL_gemm_warp_reduce :127-237) on the INTEGER matrix cores.
+//
+// Why another kernel.  k_w4a16_phase spends 53 VALU issue slots per 1 KiB weight item (exact fp16 (q - z) of 2048 nibbles,
+// 4 fp16 MFMAs): a SIMD dequantises ~8 items/us while HBM delivers ~6 per SIMD, and nothing is consumed before the
+// activations are staged -- so the short projections of a decode layer (32..64 KiB per CU, everything in flight from the
+// start) run their whole compute AFTER the bytes have landed (profiles/r02_phase_timeline_in_step.txt).  Here:
+//   * the nibbles are only EXPANDED to bytes (w & 0x0f0f0f0f, (w >> 4) & 0x0f0f0f0f: 3 VALU per 8 weights) and contracted
+//     by v_mfma_i32_16x16x64_i8 (2 per item instead of 4 fp16 MFMAs);
+//   * the activations become integers: per 128-k group a block-floating-point scale 2^e (e from the group's largest
+//     magnitude), X = rint(x * 2^(36 - Ef)) (|X| < 2^22, exact for every fp16 value within 2^-12 of the group maximum,
+//     2^-22 of it otherwise), split into three balanced signed-byte digits X = 65536 b2 + 256 b1 + b0 that ride as three
+//     ROWS of the MFMA's A operand (a batch row = rows 4 r .. 4 r + 2, so up to 4 batch rows share every instruction);
+//   * per item and lane: D = 65536 D0 + 256 D1 + D2 = sum_k X_k q_k EXACTLY (int32), then in fp32
+//         acc += s * (xscale * D - z * (xscale * sum_k X_k))
+//     with the group constants (xscale, 65536 xscale, xscale * SX, 1024 * that) read from LDS once per group: 7 VALU.
+//     The zero point costs one fma per item instead of a subtraction per weight.
+//   21 issue slots per item instead of 53, no fp16 rounding anywhere inside a group: the result is the exact product of the
+//   fp16 activations with (q - z) * s up to fp32 accumulation over the groups -- closer to the exact value than both the
+//   reference's fp16-partial-sum kernel and its dequant + GEMM branch (parity: tests/test_gpu_w4.py, bar = output rounding).
+//   * the prologue loads the activations, WAITS for them, and only then issues the weight ring: with the ring issued first
+//     the (older!) activation loads come back behind ~60 KiB of weights per CU, 2.6 us after entry instead of 0.7
+//     (tools/ubench/bcast_probe.hip, profiles/r03_bcast_probe.txt); the RMSNorm, the integer conversion and the LDS
+//     transposition then run while the first weights are in flight;
+//   * a wave keeps ONE group's A fragments in registers for all R row tiles of the workgroup (wave w owns the groups
+//     g = w mod 8): no LDS reads per item, no phase barriers; the only barriers are the two of the prologue and the one in
+//     front of the cross-wave reduction.
+// Same ZLW4M operands, same epilogues and the same fused front ends (RMSNorm prologue, neox rotary + KV scatter) as
+// k_w4a16_phase; the split-merge prologue is gone (the merged attention rows come from the attention kernel).
+#include "zl_common.h"
+
+namespace {
+
+constexpr int kT = 512, kW = 8;
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct I8Params {
+    const uint16_t* x;
+    int64_t ldx;
+    const uint4* qw;
+    const uint32_t* meta;
+    uint32_t qw_bytes, meta_bytes;
+    const uint16_t* bias;
+    const uint16_t* residual;
+    uint16_t* y;
+    int m, n, k;
+    int groups;        // 128-k items per row tile
+    int tiles;         // 16-row tiles
+    int epi, ld_out;
+    const uint16_t* norm_w;
+    float norm_eps;
+    // ROPE instantiations (fused qkv projection of a decode step)
+    const float* cosv;
+    const float* sinv;
+    const int32_t* placement;
+    const int32_t* buf_lens;
+    uint16_t* const* k_bufs;
+    uint16_t* const* v_bufs;
+    uint16_t* q_out;
+    int h, hkv, d, bshd;
+    int pair_stride;
+};
+
+// ---- optional timeline probe (build with -DZL_I8P_PROBE; tools/ubench/probe_i8p.py): wall-clock stamps (100 MHz) per wave,
+//      [workgroup][wave][8]; every launch overwrites them, so after a replayed chain they describe its last launch
+#ifdef ZL_I8P_PROBE
+__device__ unsigned long long* zl_probe_i8 = nullptr;
+#define ZL_IPROBE_INIT()                                                                               \
+    unsigned long long* pp_ = nullptr;                                                                 \
+    if (zl_probe_i8 && (threadIdx.x & 63) == 0 && blockIdx.x < 2048)                                   \
+        pp_ = zl_probe_i8 + ((size_t)blockIdx.x * kW + (threadIdx.x >> 6)) * 8;
+#define ZL_IPROBE(slot)                                                                                \
+    do {                                                                                               \
+        if (pp_) pp_[slot] = wall_clock64();                                                           \
+    } while (0)
+#else
+#define ZL_IPROBE_INIT() do {} while (0)
+#define ZL_IPROBE(slot) do {} while (0)
+#endif
+
+// ---- DPP helpers (wave64, rows of 16 lanes) ----------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// all-reduce inside each row of 16 lanes by rotations (row_ror:8,4,2,1)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0x128>(0.f, v);
+    v += dpp_f<0x124>(0.f, v);
+    v += dpp_f<0x122>(0.f, v);
+    v += dpp_f<0x121>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ int row16_sum(int v) {
+    v += dpp_i<0x128>(0, v);
+    v += dpp_i<0x124>(0, v);
+    v += dpp_i<0x122>(0, v);
+    v += dpp_i<0x121>(0, v);
+    return v;
+}
+__device__ __forceinline__ int row16_max(int v) {
+    v = max(v, dpp_i<0x128>(0, v));
+    v = max(v, dpp_i<0x124>(0, v));
+    v = max(v, dpp_i<0x122>(0, v));
+    v = max(v, dpp_i<0x121>(0, v));
+    return v;
+}
+// sum over the 64 lanes, valid in lanes 48..63 (row_bcast15 into rows 1 / 3, row_bcast31 into rows 2 / 3)
+__device__ __forceinline__ float wave_sum_hi(float v) {
+    v = row16_sum(v);
+    v += dpp_f<0x142, 0xA>(0.f, v);
+    v += dpp_f<0x143, 0xC>(0.f, v);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
+
+// R: row tiles per workgroup.  ROPE (R = 2): the two tiles are a column block and its rotation partners (w4_phase.hip).
+// NORM: fused RMSNorm prologue.  Rows M <= 4 and column blocks C = ceil(groups per wave / 4) <= 4 are runtime, M * C <= 8.
+template <int R, bool ROPE, bool NORM>
+__global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
+    static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
+#ifndef ZL_I8P_RING
+#define ZL_I8P_RING 16
+#endif
+    // groups the ring runs ahead: ~16 KiB per wave in flight -- not for the steady state (a CU sustains ~10 B/clk whatever is
+    // queued) but so that the stream keeps flowing through the 2-4 us of the prologue
+    constexpr int XD = R == 1 ? ZL_I8P_RING : R == 2 ? ZL_I8P_RING / 2 : R <= 4 ? (ZL_I8P_RING >= 16 ? 4 : 2) : (ZL_I8P_RING >= 16 ? 2 : 1);
+    constexpr int D = R * XD;                                  // ring slots
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ZL_IPROBE_INIT();
+    ZL_IPROBE(0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int M = p.m, K = p.k, groups = p.groups;
+    const int rec = 64 * M;                                    // bytes per (group, mfma, kq) record: 4 M slots of 16 bytes
+    const int Gw = (groups + kW - 1) / kW;                     // groups per wave: wave w owns g = w + 8 gi
+    const int C = (Gw + 3) / 4;                                // column blocks: four groups (one 16-byte load per lane) each
+    const int nbuf = C > 1 ? 2 : 1;
+    // LDS, wave-private (a wave's DS instructions execute in order: no workgroup barrier before the final reduction,
+    // except for the eight partial sums of the fused RMSNorm):
+    //   xh [C][M][64][16 B]                        the wave's (normalised) fp16 octets
+    //   pl [nbuf][4 groups][2 mfma][4 kq][rec]     integer planes of ONE column block, converted when the stream reaches it
+    //   cs [nbuf][4 groups][4 rows][4 f32]         group constants
+    //   xw [C][64][16 B]                           NORM: the wave's slice of the norm weight
+    const int xh_bytes = C * M * 1024, pl_bytes = nbuf * 32 * rec, cs_bytes = nbuf * 256, xw_bytes = NORM ? C * 1024 : 0;
+    const int wave_bytes = xh_bytes + pl_bytes + cs_bytes + xw_bytes;
+    unsigned char* xh = smem + (size_t)wave * wave_bytes;
+    unsigned char* pl = xh + xh_bytes;
+    float* cs = reinterpret_cast<float*>(pl + pl_bytes);
+    unsigned char* xw = pl + pl_bytes + cs_bytes;
+    float* red = reinterpret_cast<float*>(smem + (size_t)kW * wave_bytes);            // [R][8 waves][64]
+    float* scratch = red + R * kW * 64;                                               // [4 rows][8 waves]
+
+    const int tile0 = ROPE ? (blockIdx.x / p.pair_stride) * 2 * p.pair_stride + blockIdx.x % p.pair_stride : blockIdx.x * R;
+    const int tile_stride = ROPE ? p.pair_stride : 1;
+    const int my_groups = wave < groups ? (groups - wave + kW - 1) / kW : 0;          // groups this wave owns
+
+    // ---- activations first.  A wave loads exactly the k ranges of ITS groups: lane l holds octet l & 15 of group
+    //      g = w + 8 (4 c + (l >> 4)) of a row -- one 16-byte load per lane covers the four groups of a column block
+    //      slot s = (column block s / M, row s % M): static registers, runtime addresses
+    uint4 xr[8], nwr[4];
+    const int lgi = lane >> 4, uo = lane & 15;
+    const int nslots = C * M;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        nwr[c] = make_uint4(0, 0, 0, 0);
+        const int g = wave + kW * (4 * c + lgi);
+        if (NORM && c < C) nwr[c] = *reinterpret_cast<const uint4*>(p.norm_w + (g < groups ? g * 128 + uo * 8 : 0));
+    }
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        xr[sl] = make_uint4(0, 0, 0, 0);
+        if (sl < nslots) {                              // workgroup-uniform: no load instructions for slots that do not exist
+            const int c = sl / M, row = sl - c * M;
+            const int g = wave + kW * (4 * c + lgi);
+            xr[sl] = *reinterpret_cast<const uint4*>(p.x + (g < groups ? (size_t)row * p.ldx + g * 128 + uo * 8 : 0));
+            if (g >= groups) xr[sl] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the activations have landed BEFORE the first weight is requested:
+    __builtin_amdgcn_sched_barrier(0);                 // issued behind the ring they come back 2 us later (bcast_probe.hip)
+    ZL_IPROBE(1);
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl)
+        if (sl < nslots) *reinterpret_cast<uint4*>(xh + ((size_t)sl * 64 + lane) * 16) = xr[sl];
+    if constexpr (NORM) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) *reinterpret_cast<uint4*>(xw + ((size_t)c * 64 + lane) * 16) = nwr[c];
+    }
+
+    // ---- weight ring: wave w streams the items (tile0 + r, g = w + 8 gi), gi-major; everything the ring holds goes out now
+    uint4 wq[D];
+    uint32_t mt[D];
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, 0, 0x00020000);
+    const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)(lane & 15) * 4u;
+    auto issue = [&](int slot, int gi, int r) {        // slot, r: static
+        const int g = wave + kW * gi;
+        const bool ok = g < groups;                    // wave-uniform; tiles past the end fall outside the descriptor
+        const uint32_t it = (uint32_t)(tile0 + r * tile_stride) * (uint32_t)groups + (uint32_t)g;
+        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rq : rnull, q_off, it * 1024u, 2 /* nt */));
+        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(ok ? rm : rnull, m_off, it * 64u, 2);
+    };
+
+    // ---- fused RMSNorm (LayerNorm::forward, src/nn/layernorm/layernorm.cu:10-42): rs per row.  One workgroup barrier; the
+    //      wave's partial sums are parked before the ring goes out, the barrier itself comes after
+    if constexpr (NORM) {
+#pragma unroll 1
+        for (int row = 0; row < M; ++row) {
+            float t = 0.f;
+#pragma unroll 1
+            for (int c = 0; c < C; ++c) {
+                const uint4 xv = *reinterpret_cast<const uint4*>(xh + ((size_t)(c * M + row) * 64 + lane) * 16);
+                const uint32_t u[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const h16x2 hh = __builtin_bit_cast(h16x2, u[e]);
+                    t = __builtin_fmaf((float)hh.x, (float)hh.x, t);
+                    t = __builtin_fmaf((float)hh.y, (float)hh.y, t);
+                }
+            }
+            t = wave_sum_hi(t);
+            if (lane == 63) scratch[row * kW + wave] = t;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < D; ++q) issue(q, q / R, q % R);
+    __builtin_amdgcn_sched_barrier(0);
+    ZL_IPROBE(2);
+    if constexpr (NORM) {
+        __syncthreads();
+        const bool pow2 = (K & (K - 1)) == 0;
+        const float inv_k = 1.0f / (float)K;
+        // normalised octets T(f32(x) * rs * f32(w)) (the stand-alone kernel's expression) back into xh
+#pragma unroll 1
+        for (int row = 0; row < M; ++row) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) tot += scratch[row * kW + w];
+            const float rsl = zl_rsqrt_rn((pow2 ? tot * inv_k : tot / (float)K) + p.norm_eps);
+#pragma unroll 1
+            for (int c = 0; c < C; ++c) {
+                unsigned char* xp = xh + ((size_t)(c * M + row) * 64 + lane) * 16;
+                const uint4 xv = *reinterpret_cast<const uint4*>(xp), wv = *reinterpret_cast<const uint4*>(xw + ((size_t)c * 64 + lane) * 16);
+                uint32_t u[4] = {xv.x, xv.y, xv.z, xv.w};
+                const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const h16x2 hh = __builtin_bit_cast(h16x2, u[e]), ww = __builtin_bit_cast(h16x2, wu[e]);
+                    h16x2 o;
+                    o.x = zl_f32_to_f16((float)hh.x * rsl * (float)ww.x);
+                    o.y = zl_f32_to_f16((float)hh.y * rsl * (float)ww.y);
+                    u[e] = __builtin_bit_cast(uint32_t, o);
+                }
+                *reinterpret_cast<uint4*>(xp) = make_uint4(u[0], u[1], u[2], u[3]);
+            }
+        }
+    }
+
+    // ---- integer planes of column block c -> buffer c & 1, when the stream reaches it.  Octet uo of group gl = lane >> 4:
+    //      MFMA uo / 8, half (uo / 4) % 2, kq = uo % 4 -- the k positions word t = uo / 4 of lane kq covers in the ZLW4M item;
+    //      byte order inside the 8-byte piece = the order (w & 0x0f0f0f0f | (w >> 4) & 0x0f0f0f0f) leaves the nibbles in:
+    //      k offsets 0 4 1 5 | 2 6 3 7.  Digits without shifts: Y = X + 0x808080 (formed by the fma that scales x, exact
+    //      below 2^24); its three low bytes are the balanced digits of X with their top bits flipped (a carry into byte
+    //      j + 1 happens exactly when digit j wraps), so b_j = byte_j(Y) ^ 0x80.
+    auto convert = [&](int c) {
+        unsigned char* plb = pl + (size_t)(c & (nbuf - 1)) * 32 * rec;
+        float* csb = cs + (size_t)(c & (nbuf - 1)) * 64;
+        const bool live = wave + kW * (4 * c + lgi) < groups;
+#pragma unroll 1
+        for (int row = 0; row < M; ++row) {
+            {
+                const uint4 xv = *reinterpret_cast<const uint4*>(xh + ((size_t)(c * M + row) * 64 + lane) * 16);
+                const uint32_t u[4] = {xv.x, xv.y, xv.z, xv.w};
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const us2 m01 = __builtin_elementwise_max(__builtin_bit_cast(us2, u[0] & 0x7fff7fffu), __builtin_bit_cast(us2, u[1] & 0x7fff7fffu));
+                const us2 m23 = __builtin_elementwise_max(__builtin_bit_cast(us2, u[2] & 0x7fff7fffu), __builtin_bit_cast(us2, u[3] & 0x7fff7fffu));
+                const us2 mm = __builtin_elementwise_max(m01, m23);
+                int am = max((int)mm.x, (int)mm.y);
+                am = row16_max(am);                     // the group = 16 lanes = one DPP row
+                const int ef = min(am >> 10, 30);       // exponent field of the group's largest magnitude: |x| < 2^(Ef - 14)
+                const float up = __builtin_bit_cast(float, (uint32_t)(163 - ef) << 23);     // 2^(36 - Ef): |X| < 2^22
+                const float xscale = __builtin_bit_cast(float, (uint32_t)(91 + ef) << 23);  // 2^(Ef - 36)
+                uint32_t Y[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const h16x2 hh = __builtin_bit_cast(h16x2, u[e]);
+                    Y[2 * e] = (uint32_t)__builtin_fmaf((float)hh.x, up, 8421504.f);
+                    Y[2 * e + 1] = (uint32_t)__builtin_fmaf((float)hh.y, up, 8421504.f);
+                }
+                int sx = (int)(((Y[0] + Y[1]) + (Y[2] + Y[3])) + ((Y[4] + Y[5]) + (Y[6] + Y[7]))) - 8 * 0x808080;
+                sx = row16_sum(sx);
+                auto planes_of = [&](int i0, int i1, int i2, int i3, uint32_t& d2, uint32_t& d1, uint32_t& d0) {
+                    const uint32_t P = __builtin_amdgcn_perm(Y[i1], Y[i0], 0x05010400u);    // [a.b0, b.b0, a.b1, b.b1]
+                    const uint32_t Q = __builtin_amdgcn_perm(Y[i3], Y[i2], 0x05010400u);
+                    const uint32_t P2 = __builtin_amdgcn_perm(Y[i1], Y[i0], 0x0c0c0602u);   // [a.b2, b.b2, 0, 0]
+                    const uint32_t Q2 = __builtin_amdgcn_perm(Y[i3], Y[i2], 0x0c0c0602u);
+                    d0 = __builtin_amdgcn_perm(Q, P, 0x05040100u) ^ 0x80808080u;
+                    d1 = __builtin_amdgcn_perm(Q, P, 0x07060302u) ^ 0x80808080u;
+                    d2 = __builtin_amdgcn_perm(Q2, P2, 0x05040100u) ^ 0x80808080u;
+                };
+                uint32_t a2, a1, a0, b2, b1, b0;
+                planes_of(0, 4, 1, 5, a2, a1, a0);
+                planes_of(2, 6, 3, 7, b2, b1, b0);
+                unsigned char* dst = plb + (size_t)((lgi * 2 + (uo >> 3)) * 4 + (uo & 3)) * rec + (size_t)(4 * row) * 16 + ((uo >> 2) & 1) * 8;
+                if (live) {
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(a2, b2);
+                    *reinterpret_cast<uint2*>(dst + 16) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2*>(dst + 32) = make_uint2(a0, b0);
+                    if (row == 0) *reinterpret_cast<uint2*>(dst + 48) = make_uint2(0, 0);      // the zero slot idle lanes read
+                    if (uo == 0) {
+                        const float bx = xscale * (float)sx;
+                        *reinterpret_cast<float4*>(csb + (lgi * 4 + row) * 4) = make_float4(xscale, 65536.f * xscale, bx, 1024.f * bx);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back what its own lanes wrote
+        __builtin_amdgcn_wave_barrier();
+    };
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    convert(0);
+    ZL_IPROBE(3);
+
+    // ---- main loop: group gi's A fragments and constants sit in registers for its R items; the next group's are fetched
+    //      (and, at a column-block boundary, converted) while they are consumed
+    const int kq = lane >> 4, row16 = lane & 15;
+    const int aslot = (row16 < 4 * M && (row16 & 3) != 3) ? row16 : 3;   // A rows: batch row r = rows 4 r .. 4 r + 2 (digits b2 b1 b0)
+    const int crow = min(kq, M - 1);                                     // C: lane = (batch row lane >> 4, column lane & 15)
+    auto frag_addr = [&](int gi) -> const unsigned char* {
+        return pl + (size_t)((gi >> 2) & (nbuf - 1)) * 32 * rec + (size_t)((gi & 3) * 8 + kq) * rec + aslot * 16;
+    };
+    auto cst_addr = [&](int gi) -> const float* { return cs + ((gi >> 2) & (nbuf - 1)) * 64 + ((gi & 3) * 4 + crow) * 4; };
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    const uint32_t m4 = __builtin_amdgcn_readfirstlane(0x0f0f0f0fu);
+    const v4i zero4 = (v4i){0, 0, 0, 0};
+    v4i a0 = zero4, a1 = zero4;
+    float4 cst = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (my_groups > 0) {
+        a0 = *reinterpret_cast<const v4i*>(frag_addr(0));
+        a1 = *reinterpret_cast<const v4i*>(frag_addr(0) + 4 * rec);
+        cst = *reinterpret_cast<const float4*>(cst_addr(0));
+    }
+    for (int gi0 = 0; gi0 < my_groups; gi0 += XD) {
+#pragma unroll
+        for (int j = 0; j < XD; ++j) {
+            const int gi = gi0 + j;
+            if (j > 0 && gi >= my_groups) break;
+            const int gn = min(gi + 1, my_groups - 1);                   // past the wave's last group: weights and scales read as zeros
+            // the stream reaches the next column block: convert it before its first fragments are fetched
+            if ((XD % 4 == 0 ? (j & 3) == 3 : (gi & 3) == 3) && gi + 1 < my_groups) convert((gi + 1) >> 2);
+            const v4i n0 = *reinterpret_cast<const v4i*>(frag_addr(gn));
+            const v4i n1 = *reinterpret_cast<const v4i*>(frag_addr(gn) + 4 * rec);
+            const float4 cn = *reinterpret_cast<const float4*>(cst_addr(gn));
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int slot = j * R + r;
+                const uint4 w = wq[slot];
+                const uint32_t mw = mt[slot];
+                v4i b0, b1;
+                b0[0] = (int)(w.x & m4); b0[1] = (int)((w.x >> 4) & m4); b0[2] = (int)(w.y & m4); b0[3] = (int)((w.y >> 4) & m4);
+                b1[0] = (int)(w.z & m4); b1[1] = (int)((w.z >> 4) & m4); b1[2] = (int)(w.w & m4); b1[3] = (int)((w.w >> 4) & m4);
+                v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, zero4, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, d, 0, 0, 0);
+                issue(slot, gi + XD, r);
+                const h16x2 sm = __builtin_bit_cast(h16x2, mw);          // .x = scale, .y = -(1024 + zero)
+                const float f12 = (float)((d[1] << 8) + d[2]), f0 = (float)d[0];
+                float t = __builtin_fmaf((float)sm.y, cst.z, cst.w);      // -(1024 + z) B + 1024 B = -z B
+                t = __builtin_fmaf(f12, cst.x, t);
+                t = __builtin_fmaf(f0, cst.y, t);
+                acc[r] = __builtin_fmaf((float)sm.x, t, acc[r]);
+#ifdef ZL_I8P_PROBE
+                if (gi == 0 && r == 0) ZL_IPROBE(4);
+#endif
+            }
+            a0 = n0; a1 = n1; cst = cn;
+        }
+    }
+
+    // ---- reduce over the 8 waves in fixed order, epilogue
+    ZL_IPROBE(5);
+#pragma unroll
+    for (int r = 0; r < R; ++r) red[(r * kW + wave) * 64 + lane] = acc[r];
+    __syncthreads();
+    ZL_IPROBE(6);
+    auto total_of = [&](int r, int n_local, int m) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kW; ++w) v += red[(r * kW + w) * 64 + m * 16 + n_local];
+        return v;
+    };
+    if constexpr (ROPE) {
+        const int half = p.d / 2;
+        for (int o = threadIdx.x; o < 16 * M; o += kT) {
+            const int m = o >> 4, n_local = o & 15;
+            float v0 = total_of(0, n_local, m), v1 = total_of(1, n_local, m);
+            const int n0 = tile0 * 16 + n_local, n1 = n0 + half;       // columns of the fused qkv row
+            if ((p.epi & ZL_EPI_BIAS) && p.bias) {
+                v0 += (float)__builtin_bit_cast(_Float16, p.bias[n0]);
+                v1 += (float)__builtin_bit_cast(_Float16, p.bias[n1]);
+            }
+            const float a = (float)zl_f32_to_f16(v0), bb = (float)zl_f32_to_f16(v1);   // the projection's fp16 outputs
+            const int head = n0 / p.d, dcol = n0 % p.d;                 // dcol < half
+            if (head < p.h + p.hkv) {
+                const float c0 = p.cosv[(size_t)m * p.d + dcol], s0 = p.sinv[(size_t)m * p.d + dcol];
+                const float c1 = p.cosv[(size_t)m * p.d + dcol + half], s1 = p.sinv[(size_t)m * p.d + dcol + half];
+                const uint16_t r0 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(-bb, s0, a * c0)));
+                const uint16_t r1 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(a, s1, bb * c1)));
+                if (head < p.h) {
+                    uint16_t* dst = p.q_out + ((size_t)m * p.h + head) * p.d + dcol;
+                    dst[0] = r0;
+                    dst[half] = r1;
+                } else {
+                    const int place = p.placement[m];
+                    if (place >= 0 && place < p.buf_lens[m]) {
+                        const int hk = head - p.h;
+                        const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
+                        uint16_t* dst = p.k_bufs[m] + row * p.d + dcol;
+                        dst[0] = r0;
+                        dst[half] = r1;
+                    }
+                }
+            } else {
+                const int place = p.placement[m];
+                if (place >= 0 && place < p.buf_lens[m]) {
+                    const int hk = head - p.h - p.hkv;
+                    const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
+                    uint16_t* dst = p.v_bufs[m] + row * p.d + dcol;
+                    dst[0] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v0));
+                    dst[half] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v1));
+                }
+            }
+        }
+        ZL_IPROBE(7);
+        return;
+    }
+    const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
+    const int per_tile = (silu ? 8 : 16) * M;
+    const int nouts = R * per_tile;
+    for (int o = threadIdx.x; o < nouts; o += kT) {
+        const int r = o / per_tile, rem = o % per_tile;
+        const int tile = tile0 + r;
+        if (tile >= p.tiles) continue;
+        if (!silu) {
+            const int m = rem >> 4, n_local = rem & 15;
+            const int row = tile * 16 + n_local;
+            if (row < p.n) {
+                const float v = total_of(r, n_local, m);
+                const size_t orow = (size_t)m * p.ld_out;
+                const float bb = ((p.epi & ZL_EPI_BIAS) && p.bias) ? (float)__builtin_bit_cast(_Float16, p.bias[row]) : 0.f;
+                float ov;
+                if (p.epi & ZL_EPI_ADD_C) ov = ((float)__builtin_bit_cast(_Float16, p.y[orow + row]) + v) + bb;
+                else ov = v + bb;
+                _Float16 y16 = zl_f32_to_f16(ov);
+                if (p.epi & ZL_EPI_RESIDUAL)
+                    y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, p.residual[orow + row]) + (float)y16);
+                p.y[orow + row] = __builtin_bit_cast(uint16_t, y16);
+            }
+        } else {
+            const int m = rem >> 3, j = rem & 7;
+            const int pr = tile * 8 + j;
+            if (2 * pr + 1 < p.n) {
+                float g = total_of(r, 2 * j, m), u = total_of(r, 2 * j + 1, m);
+                if ((p.epi & ZL_EPI_BIAS) && p.bias) {
+                    g += (float)__builtin_bit_cast(_Float16, p.bias[2 * pr]);
+                    u += (float)__builtin_bit_cast(_Float16, p.bias[2 * pr + 1]);
+                }
+                float ov;
+                if (p.epi & ZL_EPI_SILU_MUL) {
+                    g = (float)zl_f32_to_f16(g);
+                    u = (float)zl_f32_to_f16(u);
+                    ov = silu_f32(g) * u;
+                } else {
+                    ov = (float)((double)g / (1.0 + (double)expf(-g))) * u;
+                }
+                p.y[(size_t)m * p.ld_out + pr] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(ov));
+            }
+        }
+    }
+    ZL_IPROBE(7);
+}
+
+static size_t i8p_wave_bytes(int groups, int m, bool norm) {
+    const size_t gw = (groups + kW - 1) / kW, c = (gw + 3) / 4, nbuf = c > 1 ? 2 : 1;
+    return c * m * 1024 + nbuf * 32 * 64 * (size_t)m + nbuf * 256 + (norm ? c * 1024 : 0);
+}
+
+template <int R, bool ROPE, bool NORM>
+int launch_i8p_n(const I8Params& p, int grid, hipStream_t hs) {
+    const size_t lds = kW * i8p_wave_bytes(p.groups, p.m, NORM) + (size_t)R * kW * 64 * 4 + 4 * kW * 4;
+    if (lds > 160 * 1024) return ZL_ELIMIT;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_i8p<R, ROPE, NORM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ZL_ELIMIT;
+    }
+    hipLaunchKernelGGL((k_w4a16_i8p<R, ROPE, NORM>), dim3(grid), dim3(kT), lds, hs, p);
+    return zl_launch_status();
+}
+template <int R, bool ROPE>
+int launch_i8p(const I8Params& p, int grid, hipStream_t hs) {
+    return p.norm_w ? launch_i8p_n<R, ROPE, true>(p, grid, hs) : launch_i8p_n<R, ROPE, false>(p, grid, hs);
+}
+
+}  // namespace
+
+#ifdef ZL_I8P_PROBE
+extern "C" int zl_debug_set_probe_i8p(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(zl_probe_i8), &p, sizeof(p)); }
+#endif
+
+// what the kernel covers: 1..4 rows, K a multiple of 128 (ZLW4M tiles) up to 16384, rows x column blocks <= 8, LDS
+bool zl_w4a16_i8p_covers(int64_t m, int64_t k) {
+    if (m < 1 || m > 4 || k < 128 || k % 128 != 0 || k > 16384) return false;
+    const int groups = (int)(k / 128);
+    const int64_t c = ((groups + kW - 1) / kW + 3) / 4;
+    return m * c <= 8 && kW * i8p_wave_bytes(groups, (int)m, true) + 8 * kW * 64 * 4 + 4 * kW * 4 <= 160 * 1024;
+}
+
+// internal (called by zl_w4a16_gemm_mfma_ex): zl_w4a16_i8p_covers(m, k)
+int zl_w4a16_gemm_i8p(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                      uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k,
+                      int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps, int rounds_override,
+                      hipStream_t hs) {
+    if (!zl_w4a16_i8p_covers(m, k)) return ZL_ESHAPE;
+    I8Params p;
+    p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes; p.meta_bytes = meta_bytes;
+    p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k; p.groups = groups; p.tiles = tiles; p.epi = epilogue;
+    p.ld_out = ld_out; p.norm_w = norm_w; p.norm_eps = norm_eps;
+    p.cosv = p.sinv = nullptr; p.placement = p.buf_lens = nullptr; p.k_bufs = p.v_bufs = nullptr; p.q_out = nullptr;
+    p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    int r = (tiles + cus - 1) / cus;
+    if (r > 8) r = 8;
+    if (rounds_override > 0 && rounds_override <= 8) r = rounds_override;
+    const int grid = (tiles + r - 1) / r;
+#define ZL_I8(RR) case RR: return launch_i8p<RR, false>(p, grid, hs);
+    switch (r) { ZL_I8(1) ZL_I8(2) ZL_I8(3) ZL_I8(4) ZL_I8(5) ZL_I8(6) ZL_I8(7) ZL_I8(8) }
+#undef ZL_I8
+    return ZL_EINVAL;
+}
+
+// internal (called by zl_w4a16_qkv_rope_scatter): the fused qkv projection with the neox rotation and the KV scatter
+int zl_w4a16_gemm_i8p_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                           uint32_t meta_bytes, const uint16_t* bias, int m, int n, int k, int groups, int tiles,
+                           const uint16_t* norm_w, float norm_eps, const float* cosv, const float* sinv,
+                           const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                           uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs) {
+    if (!zl_w4a16_i8p_covers(m, k) || d % 32 != 0 || n != (h + 2 * hkv) * d || tiles * 16 != n) return ZL_ESHAPE;
+    I8Params p;
+    p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes; p.meta_bytes = meta_bytes;
+    p.bias = bias; p.residual = nullptr; p.y = nullptr; p.m = m; p.n = n; p.k = k; p.groups = groups; p.tiles = tiles;
+    p.epi = bias ? ZL_EPI_BIAS : 0; p.ld_out = n; p.norm_w = norm_w; p.norm_eps = norm_eps;
+    p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs;
+    p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd; p.pair_stride = d / 32;
+    const int grid = tiles / 2;
+    return launch_i8p<2, true>(p, grid, hs);
+}

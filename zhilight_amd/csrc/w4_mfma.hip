@@ -596,6 +596,16 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
                         int k, int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps,
                         const zl_w4_opts_t* opts, hipStream_t hs);
 
+bool zl_w4a16_i8p_covers(int64_t m, int64_t k);
+int zl_w4a16_gemm_i8p(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                      uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k,
+                      int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps, int rounds_override,
+                      hipStream_t hs);
+int zl_w4a16_gemm_i8p_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                           uint32_t meta_bytes, const uint16_t* bias, int m, int n, int k, int groups, int tiles,
+                           const uint16_t* norm_w, float norm_eps, const float* cosv, const float* sinv,
+                           const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                           uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs);
 int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len,
                               int max_splits, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                               uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
@@ -693,6 +703,11 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
     // 5..32 rows without a fused norm: the phase-pipelined streaming kernel (w4_phase.hip).  With more than 16
     // rows every workgroup pulls M x K activations through L2, so a long K (the down projection) stays on
     // the M-tiled kernel, whose 128-column workgroups share them.
+    // 1..4 rows (1..2 with a long K): the integer-plane kernel (w4_i8p.hip), the batch-1 decode default
+    if (!o.small_algo && zl_w4a16_i8p_covers(m, k) && L.qw_bytes < ((int64_t)1 << 32))
+        return zl_w4a16_gemm_i8p(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
+                                 (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), norm_weight, norm_eps,
+                                 o.phase_rounds, hs);
     {
         const int ph_min_m = o.phase_min_m > 0 ? o.phase_min_m : 5, ph_max_m = o.phase_max_m > 0 ? o.phase_max_m : 32;
         const int ph_ksplit = o.phase_ksplit ? o.phase_ksplit : 2;   // long K, 13..32 rows: K split inside the phase kernel
@@ -797,6 +812,16 @@ int zl_w4a16_qkv_rope_scatter(const uint16_t* x, int64_t ldx, const uint32_t* qw
                               const float* sinv, const int32_t* placement, const int32_t* buf_lens,
                               uint16_t* const* k_bufs, uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h,
                               int64_t hkv, int64_t d, int64_t k, int64_t group_size, int bshd, zl_stream_t s) {
+    return zl_w4a16_qkv_rope_scatter_ex(x, ldx, qw, meta, bias, norm_weight, norm_eps, cosv, sinv, placement, buf_lens, k_bufs,
+                                        v_bufs, q_out, m, h, hkv, d, k, group_size, bshd, nullptr, s);
+}
+
+int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta,
+                                 const uint16_t* bias, const uint16_t* norm_weight, float norm_eps, const float* cosv,
+                                 const float* sinv, const int32_t* placement, const int32_t* buf_lens,
+                                 uint16_t* const* k_bufs, uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h,
+                                 int64_t hkv, int64_t d, int64_t k, int64_t group_size, int bshd, const zl_w4_opts_t* opts,
+                                 zl_stream_t s) {
     ZL_CHECK_ARG(x && qw && meta && cosv && sinv && placement && buf_lens && k_bufs && v_bufs && q_out, ZL_EINVAL);
     ZL_CHECK_ARG(m > 0 && h > 0 && hkv > 0 && d > 0 && k > 0, ZL_EINVAL);
     ZL_CHECK_ARG(ldx >= k && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, ZL_ESHAPE);
@@ -810,6 +835,10 @@ int zl_w4a16_qkv_rope_scatter(const uint16_t* x, int64_t ldx, const uint32_t* qw
     ZL_CHECK_ARG(!norm_weight || (m <= 8 && k <= 4096), ZL_ESHAPE);
     ZL_CHECK_ARG(m <= 16 || k <= 8192, ZL_ESHAPE);
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+    if (!(opts && opts->small_algo) && zl_w4a16_i8p_covers(m, k))
+        return zl_w4a16_gemm_i8p_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n,
+                                      (int)k, (int)L.q, (int)(L.np / 16), norm_weight, norm_eps, cosv, sinv, placement,
+                                      buf_lens, k_bufs, v_bufs, q_out, (int)h, (int)hkv, (int)d, bshd, (hipStream_t)s);
     return zl_w4a16_gemm_phase_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n,
                                     (int)k, (int)L.q, (int)(L.np / 16), norm_weight, norm_eps, cosv, sinv, placement,
                                     buf_lens, k_bufs, v_bufs, q_out, (int)h, (int)hkv, (int)d, bshd, (hipStream_t)s);

@@ -366,6 +366,8 @@ def _w4_opts(device, m, n):
             setattr(o, field, int(v))
     if os.environ.get("ZL_W4_PHASE_SMALL") == "0":
         o.phase_small_off = 1
+    if os.environ.get("ZL_W4_SMALL_ALGO"):             # 1: the fp16-dequant kernels of rounds 1-2 for 1..4 rows
+        o.small_algo = int(os.environ["ZL_W4_SMALL_ALGO"])
     return o
 
 
@@ -651,10 +653,12 @@ def w4_qkv_rope_scatter(x, w, cos, sin, placement, buf_lens, k_addrs, v_addrs, n
     m, k = x.shape
     if q_out is None:
         q_out = torch.empty((m, num_heads * dim_head), dtype=x.dtype, device=x.device)
-    check(lib().zl_w4a16_qkv_rope_scatter(_p(x), _i(x.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(norm_weight),
-                                          _f(norm_eps), _p(cos), _p(sin), _p(placement), _p(buf_lens), _p(k_addrs),
-                                          _p(v_addrs), _p(q_out), _i(m), _i(num_heads), _i(num_kv_heads), _i(dim_head),
-                                          _i(k), _i(w.group_size), C.c_int(int(bshd)), _stream()), "w4a16_qkv_rope_scatter")
+    opts = _w4_opts(x.device, m, w.n)
+    check(lib().zl_w4a16_qkv_rope_scatter_ex(_p(x), _i(x.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(norm_weight),
+                                             _f(norm_eps), _p(cos), _p(sin), _p(placement), _p(buf_lens), _p(k_addrs),
+                                             _p(v_addrs), _p(q_out), _i(m), _i(num_heads), _i(num_kv_heads), _i(dim_head),
+                                             _i(k), _i(w.group_size), C.c_int(int(bshd)), C.byref(opts), _stream()),
+          "w4a16_qkv_rope_scatter")
     return q_out
 
 
