@@ -119,18 +119,15 @@ __device__ __forceinline__ float wave_sum_hi(float v) {
 
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
 
-// R: row tiles per workgroup.  ROPE (R = 2): the two tiles are a column block and its rotation partners (w4_phase.hip).
-// NORM: fused RMSNorm prologue.  Rows M <= 4 and column blocks C = ceil(groups per wave / 4) <= 4 are runtime, M * C <= 8.
-template <int R, bool ROPE, bool NORM>
+// R: row tiles per workgroup.  LONGK: more than four groups per wave (K > 4096: rows <= 2, K <= 16384).  ROPE (R = 2): the
+// two tiles are a column block and its rotation partners (w4_phase.hip).  NORM: fused RMSNorm prologue.
+template <int R, bool LONGK, bool ROPE, bool NORM>
 __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
-#ifndef ZL_I8P_RING
-#define ZL_I8P_RING 16
-#endif
-    // groups the ring runs ahead: ~16 KiB per wave in flight -- not for the steady state (a CU sustains ~10 B/clk whatever is
-    // queued) but so that the stream keeps flowing through the 2-4 us of the prologue
-    constexpr int XD = R == 1 ? ZL_I8P_RING : R == 2 ? ZL_I8P_RING / 2 : R <= 4 ? (ZL_I8P_RING >= 16 ? 4 : 2) : (ZL_I8P_RING >= 16 ? 2 : 1);
-    constexpr int D = R * XD;                                  // ring slots
+    constexpr int XD = R >= 8 ? 1 : (8 / R > 0 ? 8 / R : 1);   // groups the ring runs ahead (8 KiB per wave in flight: with 16
+    constexpr int D = R * XD;                                  // the issue itself stalls for microseconds)
+    constexpr int NS = LONGK ? 8 : 4;                          // activation octet slots per thread
+    constexpr int NR = LONGK ? 2 : 4;                          // rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ZL_IPROBE_INIT();
     ZL_IPROBE(0);
@@ -139,63 +136,45 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
     const int M = p.m, K = p.k, groups = p.groups;
     const int rec = 64 * M;                                    // bytes per (group, mfma, kq) record: 4 M slots of 16 bytes
     const int Gw = (groups + kW - 1) / kW;                     // groups per wave: wave w owns g = w + 8 gi
-    const int C = (Gw + 3) / 4;                                // column blocks: four groups (one 16-byte load per lane) each
-    const int nbuf = C > 1 ? 2 : 1;
-    // LDS, wave-private (a wave's DS instructions execute in order: no workgroup barrier before the final reduction,
-    // except for the eight partial sums of the fused RMSNorm):
-    //   xh [C][M][64][16 B]                        the wave's (normalised) fp16 octets
-    //   pl [nbuf][4 groups][2 mfma][4 kq][rec]     integer planes of ONE column block, converted when the stream reaches it
-    //   cs [nbuf][4 groups][4 rows][4 f32]         group constants
-    //   xw [C][64][16 B]                           NORM: the wave's slice of the norm weight
-    const int xh_bytes = C * M * 1024, pl_bytes = nbuf * 32 * rec, cs_bytes = nbuf * 256, xw_bytes = NORM ? C * 1024 : 0;
-    const int wave_bytes = xh_bytes + pl_bytes + cs_bytes + xw_bytes;
-    unsigned char* xh = smem + (size_t)wave * wave_bytes;
-    unsigned char* pl = xh + xh_bytes;
-    float* cs = reinterpret_cast<float*>(pl + pl_bytes);
-    unsigned char* xw = pl + pl_bytes + cs_bytes;
-    float* red = reinterpret_cast<float*>(smem + (size_t)kW * wave_bytes);            // [R][8 waves][64]
+    // LDS: wave-private regions -- nothing below needs a workgroup barrier before the final reduction (a wave's DS
+    // instructions execute in order), except the eight partial sums of the fused RMSNorm
+    unsigned char* planes = smem + (size_t)wave * Gw * 8 * rec;                       // [gi][mfma][kq][4 M slots][16]
+    float* consts = reinterpret_cast<float*>(smem + (size_t)kW * Gw * 8 * rec) + (size_t)wave * Gw * 16;   // [gi][row 0..3][4]
+    float* red = reinterpret_cast<float*>(smem + (size_t)kW * Gw * 8 * rec) + (size_t)kW * Gw * 16;        // [R][8 waves][64]
     float* scratch = red + R * kW * 64;                                               // [4 rows][8 waves]
 
     const int tile0 = ROPE ? (blockIdx.x / p.pair_stride) * 2 * p.pair_stride + blockIdx.x % p.pair_stride : blockIdx.x * R;
     const int tile_stride = ROPE ? p.pair_stride : 1;
     const int my_groups = wave < groups ? (groups - wave + kW - 1) / kW : 0;          // groups this wave owns
 
-    // ---- activations first.  A wave loads exactly the k ranges of ITS groups: lane l holds octet l & 15 of group
-    //      g = w + 8 (4 c + (l >> 4)) of a row -- one 16-byte load per lane covers the four groups of a column block
-    //      slot s = (column block s / M, row s % M): static registers, runtime addresses
-    uint4 xr[8], nwr[4];
+    // ---- activations first.  A wave loads exactly the k ranges of ITS groups: slot s = (row, column block c), lane l holds
+    //      octet l & 15 of group g = w + 8 (4 c + (l >> 4)) -- one 16-byte load per lane covers four groups of a row
+    uint4 xr[NS], nw[LONGK ? 4 : 1];
     const int lgi = lane >> 4, uo = lane & 15;
-    const int nslots = C * M;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        nwr[c] = make_uint4(0, 0, 0, 0);
+    for (int c = 0; c < (LONGK ? 4 : 1); ++c) {
+        nw[c] = make_uint4(0, 0, 0, 0);
         const int g = wave + kW * (4 * c + lgi);
-        if (NORM && c < C) nwr[c] = *reinterpret_cast<const uint4*>(p.norm_w + (g < groups ? g * 128 + uo * 8 : 0));
+        if (NORM && 4 * c < Gw) nw[c] = *reinterpret_cast<const uint4*>(p.norm_w + (g < groups ? g * 128 + uo * 8 : 0));
     }
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-        xr[sl] = make_uint4(0, 0, 0, 0);
-        if (sl < nslots) {                              // workgroup-uniform: no load instructions for slots that do not exist
-            const int c = sl / M, row = sl - c * M;
-            const int g = wave + kW * (4 * c + lgi);
-            xr[sl] = *reinterpret_cast<const uint4*>(p.x + (g < groups ? (size_t)row * p.ldx + g * 128 + uo * 8 : 0));
-            if (g >= groups) xr[sl] = make_uint4(0, 0, 0, 0);
+    for (int s = 0; s < NS; ++s) {
+        const int row = LONGK ? (s & 1) : s, c = LONGK ? (s >> 1) : 0;
+        const int g = wave + kW * (4 * c + lgi);
+        xr[s] = make_uint4(0, 0, 0, 0);
+        if (row < M && 4 * c < Gw) {                    // workgroup-uniform: no load instructions for slots that do not exist
+            xr[s] = *reinterpret_cast<const uint4*>(p.x + (g < groups ? (size_t)row * p.ldx + g * 128 + uo * 8 : 0));
+            if (g >= groups) xr[s] = make_uint4(0, 0, 0, 0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the activations have landed BEFORE the first weight is requested:
     __builtin_amdgcn_sched_barrier(0);                 // issued behind the ring they come back 2 us later (bcast_probe.hip)
     ZL_IPROBE(1);
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl)
-        if (sl < nslots) *reinterpret_cast<uint4*>(xh + ((size_t)sl * 64 + lane) * 16) = xr[sl];
-    if constexpr (NORM) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < C) *reinterpret_cast<uint4*>(xw + ((size_t)c * 64 + lane) * 16) = nwr[c];
-    }
 
-    // ---- weight ring: wave w streams the items (tile0 + r, g = w + 8 gi), gi-major; everything the ring holds goes out now
+    // ---- weight ring: wave w streams the items (tile0 + r, g = w + 8 gi), gi-major.  The D prologue items are issued
+    //      IN BETWEEN the stages of the activation conversion below: a wave that issues them back to back sits in VMEM issue
+    //      for 0.6-1.5 us (a CU takes ~10 B/clk of misses whatever is queued) with its VALU work stuck behind
     uint4 wq[D];
     uint32_t mt[D];
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
@@ -209,161 +188,156 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
         wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rq : rnull, q_off, it * 1024u, 2 /* nt */));
         mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(ok ? rm : rnull, m_off, it * 64u, 2);
     };
-
-    // ---- fused RMSNorm (LayerNorm::forward, src/nn/layernorm/layernorm.cu:10-42): rs per row.  One workgroup barrier; the
-    //      wave's partial sums are parked before the ring goes out, the barrier itself comes after
-    if constexpr (NORM) {
-#pragma unroll 1
-        for (int row = 0; row < M; ++row) {
-            float t = 0.f;
-#pragma unroll 1
-            for (int c = 0; c < C; ++c) {
-                const uint4 xv = *reinterpret_cast<const uint4*>(xh + ((size_t)(c * M + row) * 64 + lane) * 16);
-                const uint32_t u[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const h16x2 hh = __builtin_bit_cast(h16x2, u[e]);
-                    t = __builtin_fmaf((float)hh.x, (float)hh.x, t);
-                    t = __builtin_fmaf((float)hh.y, (float)hh.y, t);
-                }
-            }
-            t = wave_sum_hi(t);
-            if (lane == 63) scratch[row * kW + wave] = t;
-        }
+#define ZL_ISSUE_RANGE(LO, HI)                                     \
+    {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                         \
+        _Pragma("unroll") for (int q = (LO); q < (HI); ++q) issue(q, q / R, q % R); \
+        __builtin_amdgcn_sched_barrier(0);                         \
     }
-    __builtin_amdgcn_sched_barrier(0);
+    // prologue items [0, Q0) go ahead of the norm's barrier, the rest between the four stages of the first slot's conversion
+    constexpr int Q0 = NORM ? D / 2 : 0, QS = (D - Q0 + 3) / 4;
+    constexpr int QB1 = Q0 + QS < D ? Q0 + QS : D, QB2 = Q0 + 2 * QS < D ? Q0 + 2 * QS : D, QB3 = Q0 + 3 * QS < D ? Q0 + 3 * QS : D;
+
+    // ---- fused RMSNorm (LayerNorm::forward, src/nn/layernorm/layernorm.cu:10-42): rs per row.  One workgroup barrier, with
+    //      half of the ring issued in front of it (the rest would make the waves wait for each other's VMEM issue)
+    float rs[NR];
 #pragma unroll
-    for (int q = 0; q < D; ++q) issue(q, q / R, q % R);
-    __builtin_amdgcn_sched_barrier(0);
-    ZL_IPROBE(2);
+    for (int r = 0; r < NR; ++r) rs[r] = 1.f;
     if constexpr (NORM) {
+        float part[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) part[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int row = LONGK ? (s & 1) : s;
+            const uint32_t u[4] = {xr[s].x, xr[s].y, xr[s].z, xr[s].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const h16x2 hh = __builtin_bit_cast(h16x2, u[e]);
+                part[row] = __builtin_fmaf((float)hh.x, (float)hh.x, part[row]);
+                part[row] = __builtin_fmaf((float)hh.y, (float)hh.y, part[row]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r < M) {
+                const float t = wave_sum_hi(part[r]);
+                if (lane == 63) scratch[r * kW + wave] = t;
+            }
+        }
+        ZL_ISSUE_RANGE(0, Q0)
         __syncthreads();
         const bool pow2 = (K & (K - 1)) == 0;
         const float inv_k = 1.0f / (float)K;
-        // normalised octets T(f32(x) * rs * f32(w)) (the stand-alone kernel's expression) back into xh
-#pragma unroll 1
-        for (int row = 0; row < M; ++row) {
-            float tot = 0.f;
 #pragma unroll
-            for (int w = 0; w < kW; ++w) tot += scratch[row * kW + w];
-            const float rsl = zl_rsqrt_rn((pow2 ? tot * inv_k : tot / (float)K) + p.norm_eps);
-#pragma unroll 1
-            for (int c = 0; c < C; ++c) {
-                unsigned char* xp = xh + ((size_t)(c * M + row) * 64 + lane) * 16;
-                const uint4 xv = *reinterpret_cast<const uint4*>(xp), wv = *reinterpret_cast<const uint4*>(xw + ((size_t)c * 64 + lane) * 16);
-                uint32_t u[4] = {xv.x, xv.y, xv.z, xv.w};
-                const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
+        for (int r = 0; r < NR; ++r) {
+            if (r < M) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < kW; ++w) tot += scratch[r * kW + w];
+                rs[r] = zl_rsqrt_rn((pow2 ? tot * inv_k : tot / (float)K) + p.norm_eps);
+            }
+        }
+    }
+    ZL_IPROBE(2);
+
+    // ---- integer planes.  Octet uo of group (gi): MFMA uo / 8, half (uo / 4) % 2, kq = uo % 4 -- the k positions word
+    //      t = uo / 4 of lane kq covers in the ZLW4M item; byte order inside the 8-byte piece = the order
+    //      (w & 0x0f0f0f0f | (w >> 4) & 0x0f0f0f0f) leaves the nibbles in: k offsets 0 4 1 5 | 2 6 3 7.
+    //      Digits without shifts: Y = X + 0x808080 (formed by the fma that scales x, exact below 2^24); its three low bytes
+    //      are the balanced digits of X with their top bits flipped (a carry into byte j + 1 happens exactly when digit j
+    //      wraps), so b_j = byte_j(Y) ^ 0x80.
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int row = LONGK ? (s & 1) : s, c = LONGK ? (s >> 1) : 0;
+        if (row < M && 4 * c < Gw) {
+            const int gi = 4 * c + lgi;
+            const bool live = wave + kW * gi < groups;
+            uint32_t u[4] = {xr[s].x, xr[s].y, xr[s].z, xr[s].w};
+            if constexpr (NORM) {
+                const uint32_t wu[4] = {nw[c].x, nw[c].y, nw[c].z, nw[c].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const h16x2 hh = __builtin_bit_cast(h16x2, u[e]), ww = __builtin_bit_cast(h16x2, wu[e]);
                     h16x2 o;
-                    o.x = zl_f32_to_f16((float)hh.x * rsl * (float)ww.x);
-                    o.y = zl_f32_to_f16((float)hh.y * rsl * (float)ww.y);
+                    o.x = zl_f32_to_f16((float)hh.x * rs[row] * (float)ww.x);
+                    o.y = zl_f32_to_f16((float)hh.y * rs[row] * (float)ww.y);
                     u[e] = __builtin_bit_cast(uint32_t, o);
                 }
-                *reinterpret_cast<uint4*>(xp) = make_uint4(u[0], u[1], u[2], u[3]);
             }
+            // largest magnitude of the group (16 lanes = one DPP row): exponent field Ef of its fp16 pattern
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const us2 m01 = __builtin_elementwise_max(__builtin_bit_cast(us2, u[0] & 0x7fff7fffu), __builtin_bit_cast(us2, u[1] & 0x7fff7fffu));
+            const us2 m23 = __builtin_elementwise_max(__builtin_bit_cast(us2, u[2] & 0x7fff7fffu), __builtin_bit_cast(us2, u[3] & 0x7fff7fffu));
+            const us2 mm = __builtin_elementwise_max(m01, m23);
+            int am = max((int)mm.x, (int)mm.y);
+            am = row16_max(am);
+            if (s == 0) ZL_ISSUE_RANGE(Q0, QB1)
+            const int ef = min(am >> 10, 30);
+            const float up = __builtin_bit_cast(float, (uint32_t)(163 - ef) << 23);     // 2^(36 - Ef): |x| < 2^(Ef - 14) -> |X| < 2^22
+            const float xscale = __builtin_bit_cast(float, (uint32_t)(91 + ef) << 23);  // 2^(Ef - 36)
+            uint32_t Y[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const h16x2 hh = __builtin_bit_cast(h16x2, u[e]);
+                Y[2 * e] = (uint32_t)__builtin_fmaf((float)hh.x, up, 8421504.f);
+                Y[2 * e + 1] = (uint32_t)__builtin_fmaf((float)hh.y, up, 8421504.f);
+            }
+            int sx = (int)(((Y[0] + Y[1]) + (Y[2] + Y[3])) + ((Y[4] + Y[5]) + (Y[6] + Y[7]))) - 8 * 0x808080;
+            sx = row16_sum(sx);
+            if (s == 0) ZL_ISSUE_RANGE(QB1, QB2)
+            // byte gather: [v0 v4 v1 v5] and [v2 v6 v3 v7] of the three digit planes
+            auto planes_of = [&](int i0, int i1, int i2, int i3, uint32_t& d2, uint32_t& d1, uint32_t& d0) {
+                const uint32_t P = __builtin_amdgcn_perm(Y[i1], Y[i0], 0x05010400u);    // [a.b0, b.b0, a.b1, b.b1]
+                const uint32_t Q = __builtin_amdgcn_perm(Y[i3], Y[i2], 0x05010400u);
+                const uint32_t P2 = __builtin_amdgcn_perm(Y[i1], Y[i0], 0x0c0c0602u);   // [a.b2, b.b2, 0, 0]
+                const uint32_t Q2 = __builtin_amdgcn_perm(Y[i3], Y[i2], 0x0c0c0602u);
+                d0 = __builtin_amdgcn_perm(Q, P, 0x05040100u) ^ 0x80808080u;
+                d1 = __builtin_amdgcn_perm(Q, P, 0x07060302u) ^ 0x80808080u;
+                d2 = __builtin_amdgcn_perm(Q2, P2, 0x05040100u) ^ 0x80808080u;
+            };
+            uint32_t a2, a1, a0, b2, b1, b0;
+            planes_of(0, 4, 1, 5, a2, a1, a0);
+            planes_of(2, 6, 3, 7, b2, b1, b0);
+            if (s == 0) ZL_ISSUE_RANGE(QB2, QB3)
+            unsigned char* dst = planes + (size_t)((gi * 2 + (uo >> 3)) * 4 + (uo & 3)) * rec + (size_t)(4 * row) * 16 + ((uo >> 2) & 1) * 8;
+            if (live) {
+                *reinterpret_cast<uint2*>(dst) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2*>(dst + 16) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(dst + 32) = make_uint2(a0, b0);
+                if (row == 0) *reinterpret_cast<uint2*>(dst + 48) = make_uint2(0, 0);          // the zero slot idle lanes read
+                if (uo == 0) {
+                    const float bx = xscale * (float)sx;
+                    *reinterpret_cast<float4*>(consts + ((size_t)gi * 4 + row) * 4) = make_float4(xscale, 65536.f * xscale, bx, 1024.f * bx);
+                }
+            }
+            if (s == 0) ZL_ISSUE_RANGE(QB3, D)
         }
     }
-
-    // ---- integer planes of column block c -> buffer c & 1, when the stream reaches it.  Octet uo of group gl = lane >> 4:
-    //      MFMA uo / 8, half (uo / 4) % 2, kq = uo % 4 -- the k positions word t = uo / 4 of lane kq covers in the ZLW4M item;
-    //      byte order inside the 8-byte piece = the order (w & 0x0f0f0f0f | (w >> 4) & 0x0f0f0f0f) leaves the nibbles in:
-    //      k offsets 0 4 1 5 | 2 6 3 7.  Digits without shifts: Y = X + 0x808080 (formed by the fma that scales x, exact
-    //      below 2^24); its three low bytes are the balanced digits of X with their top bits flipped (a carry into byte
-    //      j + 1 happens exactly when digit j wraps), so b_j = byte_j(Y) ^ 0x80.
-    auto convert = [&](int c) {
-        unsigned char* plb = pl + (size_t)(c & (nbuf - 1)) * 32 * rec;
-        float* csb = cs + (size_t)(c & (nbuf - 1)) * 64;
-        const bool live = wave + kW * (4 * c + lgi) < groups;
-#pragma unroll 1
-        for (int row = 0; row < M; ++row) {
-            {
-                const uint4 xv = *reinterpret_cast<const uint4*>(xh + ((size_t)(c * M + row) * 64 + lane) * 16);
-                const uint32_t u[4] = {xv.x, xv.y, xv.z, xv.w};
-                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                const us2 m01 = __builtin_elementwise_max(__builtin_bit_cast(us2, u[0] & 0x7fff7fffu), __builtin_bit_cast(us2, u[1] & 0x7fff7fffu));
-                const us2 m23 = __builtin_elementwise_max(__builtin_bit_cast(us2, u[2] & 0x7fff7fffu), __builtin_bit_cast(us2, u[3] & 0x7fff7fffu));
-                const us2 mm = __builtin_elementwise_max(m01, m23);
-                int am = max((int)mm.x, (int)mm.y);
-                am = row16_max(am);                     // the group = 16 lanes = one DPP row
-                const int ef = min(am >> 10, 30);       // exponent field of the group's largest magnitude: |x| < 2^(Ef - 14)
-                const float up = __builtin_bit_cast(float, (uint32_t)(163 - ef) << 23);     // 2^(36 - Ef): |X| < 2^22
-                const float xscale = __builtin_bit_cast(float, (uint32_t)(91 + ef) << 23);  // 2^(Ef - 36)
-                uint32_t Y[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const h16x2 hh = __builtin_bit_cast(h16x2, u[e]);
-                    Y[2 * e] = (uint32_t)__builtin_fmaf((float)hh.x, up, 8421504.f);
-                    Y[2 * e + 1] = (uint32_t)__builtin_fmaf((float)hh.y, up, 8421504.f);
-                }
-                int sx = (int)(((Y[0] + Y[1]) + (Y[2] + Y[3])) + ((Y[4] + Y[5]) + (Y[6] + Y[7]))) - 8 * 0x808080;
-                sx = row16_sum(sx);
-                auto planes_of = [&](int i0, int i1, int i2, int i3, uint32_t& d2, uint32_t& d1, uint32_t& d0) {
-                    const uint32_t P = __builtin_amdgcn_perm(Y[i1], Y[i0], 0x05010400u);    // [a.b0, b.b0, a.b1, b.b1]
-                    const uint32_t Q = __builtin_amdgcn_perm(Y[i3], Y[i2], 0x05010400u);
-                    const uint32_t P2 = __builtin_amdgcn_perm(Y[i1], Y[i0], 0x0c0c0602u);   // [a.b2, b.b2, 0, 0]
-                    const uint32_t Q2 = __builtin_amdgcn_perm(Y[i3], Y[i2], 0x0c0c0602u);
-                    d0 = __builtin_amdgcn_perm(Q, P, 0x05040100u) ^ 0x80808080u;
-                    d1 = __builtin_amdgcn_perm(Q, P, 0x07060302u) ^ 0x80808080u;
-                    d2 = __builtin_amdgcn_perm(Q2, P2, 0x05040100u) ^ 0x80808080u;
-                };
-                uint32_t a2, a1, a0, b2, b1, b0;
-                planes_of(0, 4, 1, 5, a2, a1, a0);
-                planes_of(2, 6, 3, 7, b2, b1, b0);
-                unsigned char* dst = plb + (size_t)((lgi * 2 + (uo >> 3)) * 4 + (uo & 3)) * rec + (size_t)(4 * row) * 16 + ((uo >> 2) & 1) * 8;
-                if (live) {
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(a2, b2);
-                    *reinterpret_cast<uint2*>(dst + 16) = make_uint2(a1, b1);
-                    *reinterpret_cast<uint2*>(dst + 32) = make_uint2(a0, b0);
-                    if (row == 0) *reinterpret_cast<uint2*>(dst + 48) = make_uint2(0, 0);      // the zero slot idle lanes read
-                    if (uo == 0) {
-                        const float bx = xscale * (float)sx;
-                        *reinterpret_cast<float4*>(csb + (lgi * 4 + row) * 4) = make_float4(xscale, 65536.f * xscale, bx, 1024.f * bx);
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back what its own lanes wrote
-        __builtin_amdgcn_wave_barrier();
-    };
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#undef ZL_ISSUE_RANGE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back what its own lanes wrote: program order suffices
     __builtin_amdgcn_wave_barrier();
-    convert(0);
     ZL_IPROBE(3);
 
-    // ---- main loop: group gi's A fragments and constants sit in registers for its R items; the next group's are fetched
-    //      (and, at a column-block boundary, converted) while they are consumed
+    // ---- main loop
     const int kq = lane >> 4, row16 = lane & 15;
     const int aslot = (row16 < 4 * M && (row16 & 3) != 3) ? row16 : 3;   // A rows: batch row r = rows 4 r .. 4 r + 2 (digits b2 b1 b0)
+    const unsigned char* a_base = planes + (size_t)kq * rec + aslot * 16;
     const int crow = min(kq, M - 1);                                     // C: lane = (batch row lane >> 4, column lane & 15)
-    auto frag_addr = [&](int gi) -> const unsigned char* {
-        return pl + (size_t)((gi >> 2) & (nbuf - 1)) * 32 * rec + (size_t)((gi & 3) * 8 + kq) * rec + aslot * 16;
-    };
-    auto cst_addr = [&](int gi) -> const float* { return cs + ((gi >> 2) & (nbuf - 1)) * 64 + ((gi & 3) * 4 + crow) * 4; };
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
     const uint32_t m4 = __builtin_amdgcn_readfirstlane(0x0f0f0f0fu);
     const v4i zero4 = (v4i){0, 0, 0, 0};
-    v4i a0 = zero4, a1 = zero4;
-    float4 cst = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (my_groups > 0) {
-        a0 = *reinterpret_cast<const v4i*>(frag_addr(0));
-        a1 = *reinterpret_cast<const v4i*>(frag_addr(0) + 4 * rec);
-        cst = *reinterpret_cast<const float4*>(cst_addr(0));
-    }
+
     for (int gi0 = 0; gi0 < my_groups; gi0 += XD) {
 #pragma unroll
         for (int j = 0; j < XD; ++j) {
             const int gi = gi0 + j;
             if (j > 0 && gi >= my_groups) break;
-            const int gn = min(gi + 1, my_groups - 1);                   // past the wave's last group: weights and scales read as zeros
-            // the stream reaches the next column block: convert it before its first fragments are fetched
-            if ((XD % 4 == 0 ? (j & 3) == 3 : (gi & 3) == 3) && gi + 1 < my_groups) convert((gi + 1) >> 2);
-            const v4i n0 = *reinterpret_cast<const v4i*>(frag_addr(gn));
-            const v4i n1 = *reinterpret_cast<const v4i*>(frag_addr(gn) + 4 * rec);
-            const float4 cn = *reinterpret_cast<const float4*>(cst_addr(gn));
+            const v4i a0 = *reinterpret_cast<const v4i*>(a_base + (size_t)(gi * 2 + 0) * 4 * rec);
+            const v4i a1 = *reinterpret_cast<const v4i*>(a_base + (size_t)(gi * 2 + 1) * 4 * rec);
+            const float4 cst = *reinterpret_cast<const float4*>(consts + ((size_t)gi * 4 + crow) * 4);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int slot = j * R + r;
@@ -385,7 +359,6 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
                 if (gi == 0 && r == 0) ZL_IPROBE(4);
 #endif
             }
-            a0 = n0; a1 = n1; cst = cn;
         }
     }
 
@@ -492,26 +465,28 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
     ZL_IPROBE(7);
 }
 
-static size_t i8p_wave_bytes(int groups, int m, bool norm) {
-    const size_t gw = (groups + kW - 1) / kW, c = (gw + 3) / 4, nbuf = c > 1 ? 2 : 1;
-    return c * m * 1024 + nbuf * 32 * 64 * (size_t)m + nbuf * 256 + (norm ? c * 1024 : 0);
+static size_t i8p_lds_bytes(int groups, int m, int r) {
+    const size_t gw = (groups + kW - 1) / kW;
+    return kW * gw * 8 * 64 * (size_t)m + kW * gw * 64 + (size_t)r * kW * 64 * 4 + 4 * kW * 4;
 }
 
-template <int R, bool ROPE, bool NORM>
+template <int R, bool LONGK, bool ROPE, bool NORM>
 int launch_i8p_n(const I8Params& p, int grid, hipStream_t hs) {
-    const size_t lds = kW * i8p_wave_bytes(p.groups, p.m, NORM) + (size_t)R * kW * 64 * 4 + 4 * kW * 4;
+    const size_t lds = i8p_lds_bytes(p.groups, p.m, R);
     if (lds > 160 * 1024) return ZL_ELIMIT;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_i8p<R, ROPE, NORM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_i8p<R, LONGK, ROPE, NORM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return ZL_ELIMIT;
     }
-    hipLaunchKernelGGL((k_w4a16_i8p<R, ROPE, NORM>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w4a16_i8p<R, LONGK, ROPE, NORM>), dim3(grid), dim3(kT), lds, hs, p);
     return zl_launch_status();
 }
 template <int R, bool ROPE>
 int launch_i8p(const I8Params& p, int grid, hipStream_t hs) {
-    return p.norm_w ? launch_i8p_n<R, ROPE, true>(p, grid, hs) : launch_i8p_n<R, ROPE, false>(p, grid, hs);
+    const bool lk = p.groups > 4 * kW;
+    if (p.norm_w) return lk ? launch_i8p_n<R, true, ROPE, true>(p, grid, hs) : launch_i8p_n<R, false, ROPE, true>(p, grid, hs);
+    return lk ? launch_i8p_n<R, true, ROPE, false>(p, grid, hs) : launch_i8p_n<R, false, ROPE, false>(p, grid, hs);
 }
 
 }  // namespace
@@ -520,12 +495,10 @@ int launch_i8p(const I8Params& p, int grid, hipStream_t hs) {
 extern "C" int zl_debug_set_probe_i8p(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(zl_probe_i8), &p, sizeof(p)); }
 #endif
 
-// what the kernel covers: 1..4 rows, K a multiple of 128 (ZLW4M tiles) up to 16384, rows x column blocks <= 8, LDS
+// what the kernel covers: 1..4 rows with K <= 4096, 1..2 rows with K <= 16384, K a multiple of 128 (ZLW4M tiles), LDS
 bool zl_w4a16_i8p_covers(int64_t m, int64_t k) {
-    if (m < 1 || m > 4 || k < 128 || k % 128 != 0 || k > 16384) return false;
-    const int groups = (int)(k / 128);
-    const int64_t c = ((groups + kW - 1) / kW + 3) / 4;
-    return m * c <= 8 && kW * i8p_wave_bytes(groups, (int)m, true) + 8 * kW * 64 * 4 + 4 * kW * 4 <= 160 * 1024;
+    if (m < 1 || m > 4 || k < 128 || k % 128 != 0 || k > 16384 || (k > 4096 && m > 2)) return false;
+    return i8p_lds_bytes((int)(k / 128), (int)m, 8) <= 160 * 1024;
 }
 
 // internal (called by zl_w4a16_gemm_mfma_ex): zl_w4a16_i8p_covers(m, k)
