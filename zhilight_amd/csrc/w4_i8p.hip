@@ -167,6 +167,58 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
             if (g >= groups) xr[s] = make_uint4(0, 0, 0, 0);
         }
     }
+    // ROPE: what the epilogue of this thread needs from memory (rotation table entries, the task's slot and buffer
+    // pointers) is requested now, next to the activations -- in the epilogue these were three dependent round trips
+    float rp_c0 = 0.f, rp_s0 = 0.f, rp_c1 = 0.f, rp_s1 = 0.f;
+    int rp_place = -1, rp_blen = 0;
+    uint16_t* rp_kv = nullptr;
+    if constexpr (ROPE) {
+        if ((int)threadIdx.x < 16 * M) {
+            const int m = threadIdx.x >> 4, n0 = tile0 * 16 + (threadIdx.x & 15);
+            const int head = n0 / p.d, dcol = n0 % p.d, half = p.d / 2;
+            if (head < p.h + p.hkv) {
+                rp_c0 = p.cosv[(size_t)m * p.d + dcol]; rp_s0 = p.sinv[(size_t)m * p.d + dcol];
+                rp_c1 = p.cosv[(size_t)m * p.d + dcol + half]; rp_s1 = p.sinv[(size_t)m * p.d + dcol + half];
+            }
+            if (head >= p.h) {
+                rp_place = p.placement[m];
+                rp_blen = p.buf_lens[m];
+                rp_kv = head < p.h + p.hkv ? p.k_bufs[m] : p.v_bufs[m];
+            }
+        }
+    }
+    // the other epilogues: every thread owns at most one output (R * 16 * M <= 512); its bias / residual / previous-output
+    // operands are requested now as well (one more round trip at the very end of the kernel otherwise)
+    const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
+    float ep_b0 = 0.f, ep_b1 = 0.f, ep_res = 0.f, ep_prev = 0.f;
+    int ep_r = 0, ep_m = 0, ep_nl = 0, ep_col = -1;       // tile slot, row, column inside the tile, output column (-1: none)
+    if constexpr (!ROPE) {
+        const int per_tile = (silu ? 8 : 16) * M;
+        if ((int)threadIdx.x < R * per_tile) {
+            ep_r = threadIdx.x / per_tile;
+            const int rem = threadIdx.x % per_tile, tile = tile0 + ep_r;
+            if (!silu) {
+                ep_m = rem >> 4; ep_nl = rem & 15;
+                const int row = tile * 16 + ep_nl;
+                if (tile < p.tiles && row < p.n) {
+                    ep_col = row;
+                    if ((p.epi & ZL_EPI_BIAS) && p.bias) ep_b0 = (float)__builtin_bit_cast(_Float16, p.bias[row]);
+                    if (p.epi & ZL_EPI_ADD_C) ep_prev = (float)__builtin_bit_cast(_Float16, p.y[(size_t)ep_m * p.ld_out + row]);
+                    if (p.epi & ZL_EPI_RESIDUAL) ep_res = (float)__builtin_bit_cast(_Float16, p.residual[(size_t)ep_m * p.ld_out + row]);
+                }
+            } else {
+                ep_m = rem >> 3; ep_nl = rem & 7;
+                const int pr = tile * 8 + ep_nl;
+                if (tile < p.tiles && 2 * pr + 1 < p.n) {
+                    ep_col = pr;
+                    if ((p.epi & ZL_EPI_BIAS) && p.bias) {
+                        ep_b0 = (float)__builtin_bit_cast(_Float16, p.bias[2 * pr]);
+                        ep_b1 = (float)__builtin_bit_cast(_Float16, p.bias[2 * pr + 1]);
+                    }
+                }
+            }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the activations have landed BEFORE the first weight is requested:
     __builtin_amdgcn_sched_barrier(0);                 // issued behind the ring they come back 2 us later (bcast_probe.hip)
@@ -376,8 +428,8 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
     };
     if constexpr (ROPE) {
         const int half = p.d / 2;
-        for (int o = threadIdx.x; o < 16 * M; o += kT) {
-            const int m = o >> 4, n_local = o & 15;
+        if ((int)threadIdx.x < 16 * M) {                 // 16 M <= 64 threads; their table entries / pointers came with the prologue
+            const int m = threadIdx.x >> 4, n_local = threadIdx.x & 15;
             float v0 = total_of(0, n_local, m), v1 = total_of(1, n_local, m);
             const int n0 = tile0 * 16 + n_local, n1 = n0 + half;       // columns of the fused qkv row
             if ((p.epi & ZL_EPI_BIAS) && p.bias) {
@@ -387,79 +439,50 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
             const float a = (float)zl_f32_to_f16(v0), bb = (float)zl_f32_to_f16(v1);   // the projection's fp16 outputs
             const int head = n0 / p.d, dcol = n0 % p.d;                 // dcol < half
             if (head < p.h + p.hkv) {
-                const float c0 = p.cosv[(size_t)m * p.d + dcol], s0 = p.sinv[(size_t)m * p.d + dcol];
-                const float c1 = p.cosv[(size_t)m * p.d + dcol + half], s1 = p.sinv[(size_t)m * p.d + dcol + half];
-                const uint16_t r0 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(-bb, s0, a * c0)));
-                const uint16_t r1 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(a, s1, bb * c1)));
+                const uint16_t r0 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(-bb, rp_s0, a * rp_c0)));
+                const uint16_t r1 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(a, rp_s1, bb * rp_c1)));
                 if (head < p.h) {
                     uint16_t* dst = p.q_out + ((size_t)m * p.h + head) * p.d + dcol;
                     dst[0] = r0;
                     dst[half] = r1;
-                } else {
-                    const int place = p.placement[m];
-                    if (place >= 0 && place < p.buf_lens[m]) {
-                        const int hk = head - p.h;
-                        const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
-                        uint16_t* dst = p.k_bufs[m] + row * p.d + dcol;
-                        dst[0] = r0;
-                        dst[half] = r1;
-                    }
+                } else if (rp_place >= 0 && rp_place < rp_blen) {
+                    const int hk = head - p.h;
+                    const size_t row = p.bshd ? (size_t)rp_place * p.hkv + hk : (size_t)hk * rp_blen + rp_place;
+                    uint16_t* dst = rp_kv + row * p.d + dcol;
+                    dst[0] = r0;
+                    dst[half] = r1;
                 }
-            } else {
-                const int place = p.placement[m];
-                if (place >= 0 && place < p.buf_lens[m]) {
-                    const int hk = head - p.h - p.hkv;
-                    const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
-                    uint16_t* dst = p.v_bufs[m] + row * p.d + dcol;
-                    dst[0] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v0));
-                    dst[half] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v1));
-                }
+            } else if (rp_place >= 0 && rp_place < rp_blen) {
+                const int hk = head - p.h - p.hkv;
+                const size_t row = p.bshd ? (size_t)rp_place * p.hkv + hk : (size_t)hk * rp_blen + rp_place;
+                uint16_t* dst = rp_kv + row * p.d + dcol;
+                dst[0] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v0));
+                dst[half] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v1));
             }
         }
         ZL_IPROBE(7);
         return;
     }
-    const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
-    const int per_tile = (silu ? 8 : 16) * M;
-    const int nouts = R * per_tile;
-    for (int o = threadIdx.x; o < nouts; o += kT) {
-        const int r = o / per_tile, rem = o % per_tile;
-        const int tile = tile0 + r;
-        if (tile >= p.tiles) continue;
+    if (ep_col >= 0) {
         if (!silu) {
-            const int m = rem >> 4, n_local = rem & 15;
-            const int row = tile * 16 + n_local;
-            if (row < p.n) {
-                const float v = total_of(r, n_local, m);
-                const size_t orow = (size_t)m * p.ld_out;
-                const float bb = ((p.epi & ZL_EPI_BIAS) && p.bias) ? (float)__builtin_bit_cast(_Float16, p.bias[row]) : 0.f;
-                float ov;
-                if (p.epi & ZL_EPI_ADD_C) ov = ((float)__builtin_bit_cast(_Float16, p.y[orow + row]) + v) + bb;
-                else ov = v + bb;
-                _Float16 y16 = zl_f32_to_f16(ov);
-                if (p.epi & ZL_EPI_RESIDUAL)
-                    y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, p.residual[orow + row]) + (float)y16);
-                p.y[orow + row] = __builtin_bit_cast(uint16_t, y16);
-            }
+            const float v = total_of(ep_r, ep_nl, ep_m);
+            float ov;
+            if (p.epi & ZL_EPI_ADD_C) ov = (ep_prev + v) + ep_b0;
+            else ov = v + ep_b0;
+            _Float16 y16 = zl_f32_to_f16(ov);
+            if (p.epi & ZL_EPI_RESIDUAL) y16 = zl_f32_to_f16(ep_res + (float)y16);
+            p.y[(size_t)ep_m * p.ld_out + ep_col] = __builtin_bit_cast(uint16_t, y16);
         } else {
-            const int m = rem >> 3, j = rem & 7;
-            const int pr = tile * 8 + j;
-            if (2 * pr + 1 < p.n) {
-                float g = total_of(r, 2 * j, m), u = total_of(r, 2 * j + 1, m);
-                if ((p.epi & ZL_EPI_BIAS) && p.bias) {
-                    g += (float)__builtin_bit_cast(_Float16, p.bias[2 * pr]);
-                    u += (float)__builtin_bit_cast(_Float16, p.bias[2 * pr + 1]);
-                }
-                float ov;
-                if (p.epi & ZL_EPI_SILU_MUL) {
-                    g = (float)zl_f32_to_f16(g);
-                    u = (float)zl_f32_to_f16(u);
-                    ov = silu_f32(g) * u;
-                } else {
-                    ov = (float)((double)g / (1.0 + (double)expf(-g))) * u;
-                }
-                p.y[(size_t)m * p.ld_out + pr] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(ov));
+            float g = total_of(ep_r, 2 * ep_nl, ep_m) + ep_b0, u = total_of(ep_r, 2 * ep_nl + 1, ep_m) + ep_b1;
+            float ov;
+            if (p.epi & ZL_EPI_SILU_MUL) {
+                g = (float)zl_f32_to_f16(g);
+                u = (float)zl_f32_to_f16(u);
+                ov = silu_f32(g) * u;
+            } else {
+                ov = (float)((double)g / (1.0 + (double)expf(-g))) * u;
             }
+            p.y[(size_t)ep_m * p.ld_out + ep_col] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(ov));
         }
     }
     ZL_IPROBE(7);
