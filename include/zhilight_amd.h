@@ -363,6 +363,18 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
  * zl_decode_attn_splits.  Covers M = B <= 4, K = H * 128 <= 4096, max_splits <= 16, no gated epilogue, at most two
  * row tiles per CU; ZL_ESHAPE otherwise (use the two-call sequence). */
 int64_t zl_decode_attn_split_len(int64_t b, int64_t hkv, int64_t max_len_buf);
+/* The same pair with HALF-PRECISION partials (the default of the decode step since round 3): zl_decode_attn_splits_h leaves
+ * each split's NORMALISED output row as fp16 plus its fp32 (max, sum) -- 264 instead of 520 bytes per (head, split), and every
+ * workgroup of the merging projection re-reads all of them -- and zl_w4a16_gemm_attn_merge_h (the integer-plane kernel,
+ * w4_i8p.hip) merges them in its prologue with k_decode_attn_combine's weights.  Not bit-identical to the merge launch (one
+ * extra fp16 rounding of the partial rows: within 2^-11 of the largest partial); same coverage and arguments, fp16 only. */
+int zl_decode_attn_splits_h(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
+                            const uint16_t* const* v_bufs, const int32_t* valid_lens, void* workspace, int64_t b, int64_t h,
+                            int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, zl_stream_t s);
+int zl_w4a16_gemm_attn_merge_h(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens,
+                               int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
+                               const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
+                               int64_t group_size, int epilogue, zl_stream_t s);
 int zl_decode_attn_splits(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
                           const uint16_t* const* v_bufs, const int32_t* valid_lens, void* workspace, int64_t b, int64_t h,
                           int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, int dtype, zl_stream_t s);

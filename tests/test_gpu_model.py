@@ -238,10 +238,15 @@ def test_decode_steps_match_oracle(oracle, dev, batch, algo, monkeypatch):
             assert np.abs(gv - rv).max() <= 2.0 ** -9 * np.abs(rv).max()
 
 
+@pytest.mark.parametrize("algo", ["i8p_half", "phase_f32"])
 @pytest.mark.parametrize("batch,max_b", [(1, "1"), (3, "4")])
-def test_decode_step_attention_merge_in_projection_is_bit_identical(dev, batch, max_b, monkeypatch):
-    """The decode step with the attention split merge folded into the attn_out projection (default at batch 1) gives
-    the logits of the step with the separate merge launch, bit for bit, over several steps (growing KV)."""
+def test_decode_step_attention_merge_in_projection_is_bit_identical(dev, batch, max_b, algo, monkeypatch):
+    """The decode step with the attention split merge folded into the attn_out projection (default at batch 1) against the
+    step with the separate merge launch over several steps (growing KV): bit for bit with the round-2 kernels and their fp32
+    partials (ZL_W4_SMALL_ALGO=1); with the default pair (half-precision partials, w4_i8p.hip) the merged rows may differ
+    by one fp16 ulp, so the logits agree within 1e-3 of the largest logit instead."""
+    if algo == "phase_f32":
+        monkeypatch.setenv("ZL_W4_SMALL_ALGO", "1")
     from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
     rng = np.random.default_rng(9)
     cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2,
@@ -264,7 +269,12 @@ def test_decode_step_attention_merge_in_projection_is_bit_identical(dev, batch, 
             seq.append(logits)
             model.advance(ctx, logits.argmax(dim=-1))
         outs[merge] = torch.stack(seq)
-    assert torch.equal(outs["0"], outs["1"])
+    if algo == "phase_f32":
+        assert torch.equal(outs["0"], outs["1"])
+    else:
+        a, b_ = outs["0"].float(), outs["1"].float()
+        assert (a - b_).abs().max().item() <= 1e-3 * a.abs().max().item()
+        assert torch.equal(a[0].argmax(dim=-1), b_[0].argmax(dim=-1))      # first step: same greedy tokens
 
 
 def test_step_greedy_matches_argmax_and_advances(dev):

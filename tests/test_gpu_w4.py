@@ -526,10 +526,17 @@ def test_fused_qkv_rotary_scatter_equals_two_call_sequence(oracle, dev, m, norm,
     (3, 32, 8, 4096, [640, 128, 1088], [517, 128, 1000]),   # ragged tasks, different split counts per row
     (4, 32, 4, 8192, [256, 192, 64, 256], [129, 192, 33, 256]),   # two row tiles per workgroup
 ])
-def test_attention_split_merge_in_attn_out_projection(oracle, dev, b, h, hkv, n, lens, valid):
-    """zl_decode_attn_splits + zl_w4a16_gemm_attn_merge (the split merge in the GEMV prologue) == zl_decode_attn +
-    zl_w4a16_gemm_mfma bit for bit, plain and residual epilogues."""
+@pytest.mark.parametrize("algo", ["i8p_half", "phase_f32"])
+def test_attention_split_merge_in_attn_out_projection(oracle, dev, b, h, hkv, n, lens, valid, algo, monkeypatch):
+    """The split merge in the attn_out projection's prologue against zl_decode_attn + zl_w4a16_gemm_mfma, plain and residual
+    epilogues.  phase_f32 (ZL_W4_SMALL_ALGO=1: zl_decode_attn_splits + zl_w4a16_gemm_attn_merge, fp32 partials, the round-2
+    kernels): bit for bit.  i8p_half (the default: zl_decode_attn_splits_h + zl_w4a16_gemm_attn_merge_h): the partial rows
+    pass through fp16 once more, so the merged activations may differ from the merge launch's by one fp16 ulp of the largest
+    partial -- the projection outputs then agree within 2^-9 of the output scale (random signs over K = 4096 terms), and the
+    merged rows themselves are checked against the merge launch through an identity-like probe below."""
     from zhilight_amd import ops
+    if algo == "phase_f32":
+        monkeypatch.setenv("ZL_W4_SMALL_ALGO", "1")
     rng = np.random.default_rng(600 + b + n)
     d, g, k = 128, 128, h * 128
     n8 = (n + 7) // 8 * 8
@@ -560,7 +567,15 @@ def test_attention_split_merge_in_attn_out_projection(oracle, dev, b, h, hkv, n,
     got = ops.w4_attn_out_merge(ws, bl, vl, plan, b, w)
     got_res = ops.w4_attn_out_merge(ws, bl, vl, plan, b, w, residual=res, epilogue=ops.EPI_RESIDUAL)
     assert torch.isfinite(got.float()).all()
-    assert torch.equal(got, want) and torch.equal(got_res, want_res)
+    if algo == "phase_f32":
+        assert torch.equal(got, want) and torch.equal(got_res, want_res)
+    else:
+        tol = 2.0 ** -9 * want.float().abs().max().item()
+        assert (got.float() - want.float()).abs().max().item() <= tol
+        assert (got_res.float() - want_res.float()).abs().max().item() <= tol + 2.0 ** -10 * want_res.float().abs().max().item()
+        # the fraction of outputs that moved at all stays small-ish and unbiased: mean signed difference ~ 0
+        diff = got.float() - want.float()
+        assert abs(diff.mean().item()) <= 0.05 * tol
 
 
 def test_attention_split_merge_plan_limits(dev):
@@ -603,3 +618,25 @@ def test_w4m_pack_unpack_round_trip(oracle, dev, k, n, g, inter):
         y = np.concatenate([y[:, 0::2], y[:, 1::2]], axis=1)
     exact = oracle.gptq_gemm_k_major_exact(oracle.h2u(x), _np(rq).view(np.uint32), _np(rz), _np(rs).view(np.uint16))
     assert np.abs(y - exact).max() <= 2.0 ** -10 * np.abs(exact).max() + 1e-6
+
+
+@pytest.mark.parametrize("n,k,m", [(8192, 4096, 4), (12288, 4096, 4), (4096, 4096, 3), (4096, 14336, 2)])
+def test_i8p_rows_repeated_against_fp16_kernels(dev, n, k, m):
+    """The integer-plane kernel (default for 1..4 rows) against the round-2 fp16-dequant kernels on fresh random activations, 12
+    times per shape.  Regression for a source-operand hazard: with the A / B registers of v_mfma_i32_16x16x64_i8 reused one
+    issue slot after the MFMA, the rows of its last pass -- the FOURTH batch row -- came out wrong in one tile every other
+    launch (N = 8192: two tiles per workgroup), everything else exact."""
+    from zhilight_amd import ops
+    import os
+    torch.manual_seed(n + k + m)
+    w = ops.W4MWeight.random(n, k, 128, dev)
+    for it in range(12):
+        x = torch.randn(m, k, dtype=torch.float16, device=dev)
+        os.environ["ZL_W4_SMALL_ALGO"] = "1"
+        try:
+            want = ops.w4a16_gemm_mfma(x, w)
+        finally:
+            del os.environ["ZL_W4_SMALL_ALGO"]
+        got = ops.w4a16_gemm_mfma(x, w)
+        tol = 2.0 ** -10 * want.float().abs().max().item()      # both within fp16 output rounding of the exact product
+        assert (got.float() - want.float()).abs().max().item() <= tol, it

@@ -50,6 +50,9 @@ struct AttnParams {
     // INT8 cache (k_decode_attn_partial_q8): k_bufs / v_bufs hold u8 codes, one fp32 scale per (key, kv head)
     const float* const* k_scales;
     const float* const* v_scales;
+    // k_decode_attn_mfma: 1 = partials leave as NORMALISED fp16 rows [vh][split][128] + fp32 (max, sum) pairs behind them
+    // (zl_decode_attn_splits_h: 264 instead of 520 bytes per (head, split) for the merging projection to re-read)
+    int half_partials;
 };
 
 typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
@@ -828,7 +831,18 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
             lt = __builtin_fmaf(src[w * WS + kMD + 1], f, lt);
         }
         const int qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
-        float* dst = p.ws + ((((size_t)b * p.len_q + qi) * p.h + head) * p.max_splits + split) * (kMD + 2);
+        const size_t rec = (((size_t)b * p.len_q + qi) * p.h + head) * p.max_splits + split;
+        if (p.half_partials) {
+            uint16_t* hp = reinterpret_cast<uint16_t*>(p.ws);
+            hp[rec * kMD + d] = __builtin_bit_cast(uint16_t, (_Float16)(a / lt));      // lt >= 1: the split's largest score gives exp(0)
+            if (d == 0) {
+                float* st = p.ws + (size_t)p.b * p.len_q * p.h * p.max_splits * (kMD / 2) + rec * 2;
+                st[0] = mn;
+                st[1] = lt;
+            }
+            continue;
+        }
+        float* dst = p.ws + rec * (kMD + 2);
         dst[d] = a;
         if (d == 0) {
             dst[kMD] = mn;
@@ -1195,7 +1209,7 @@ int zl_decode_attn_ex(const uint16_t* q, const int32_t* buf_lens, const uint16_t
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
-    p.k_scales = p.v_scales = nullptr;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 0;
     {   // decode fast path on the matrix cores: all query rows of a kv head in one 16-row MFMA block
         if (algo != 1 && !mask && d == kMD && p.rows <= 16) {
             p.passes = 1;
@@ -1242,10 +1256,32 @@ int zl_decode_attn_splits(const uint16_t* q, const int32_t* buf_lens, const uint
     ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
-    p.k_scales = p.v_scales = nullptr;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 0;
     const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
     if (dtype == ZL_F16) hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, p);
     else hipLaunchKernelGGL(k_decode_attn_mfma<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, p);
+    return zl_launch_status();
+}
+
+int zl_decode_attn_splits_h(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
+                            const uint16_t* const* v_bufs, const int32_t* valid_lens, void* workspace, int64_t b, int64_t h,
+                            int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, zl_stream_t s) {
+    ZL_CHECK_ARG(q && buf_lens && k_bufs && v_bufs && valid_lens && workspace, ZL_EINVAL);
+    ZL_CHECK_ARG(b > 0 && h > 0 && hkv > 0 && d > 0 && max_len_buf > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(h % hkv == 0 && d == kMD && h / hkv <= 16 && b <= 65535 && hkv <= 65535, ZL_ESHAPE);   // the matrix-core kernel
+    AttnParams p;
+    p.q = q; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs; p.mask = nullptr; p.valid_lens = valid_lens;
+    p.out = nullptr; p.ws = (float*)workspace;
+    p.b = (int)b; p.len_q = 1; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
+    p.rows = p.n_rep; p.passes = 1;
+    p.split_len = attn_split_len(b, hkv, max_len_buf);
+    p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
+    p.scale = scale; p.bshd = bshd;
+    p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 1;
+    const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
+    hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, p);
     return zl_launch_status();
 }
 
@@ -1271,7 +1307,7 @@ int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* q
     ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     p.qkv = qkv; p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.k_bufs_w = k_bufs; p.v_bufs_w = v_bufs; p.neox = neox;
-    p.k_scales = p.v_scales = nullptr;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 0;
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
     if (dtype == ZL_F16) { ZL_ATTN_D(ZL_F16, true) }
@@ -1302,7 +1338,7 @@ int zl_decode_attn_quant_ex(const uint16_t* q, const int32_t* buf_lens, const ui
     p.q = q; p.buf_lens = buf_lens;
     p.k_bufs = reinterpret_cast<const uint16_t* const*>(k_bufs);
     p.v_bufs = reinterpret_cast<const uint16_t* const*>(v_bufs);
-    p.k_scales = k_scales; p.v_scales = v_scales;
+    p.k_scales = k_scales; p.v_scales = v_scales; p.half_partials = 0;
     p.mask = mask; p.valid_lens = valid_lens; p.out = out; p.ws = (float*)workspace;
     p.b = (int)b; p.len_q = (int)len_q; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
     p.rows = p.len_q * p.n_rep;

@@ -59,6 +59,12 @@ struct I8Params {
     uint16_t* q_out;
     int h, hkv, d, bshd;
     int pair_stride;
+    // MERGE instantiations (attn_out projection of a decode step): the activation rows are merged from the decode attention's
+    // half-precision split partials (zl_decode_attn_splits_h: fp16 [row][head][split][128], then fp32 (max, sum) pairs)
+    const uint16_t* mg_part;
+    const float* mg_stat;
+    const int32_t* mg_valid_lens;   // with buf_lens: keys per task -> live splits
+    int mg_split_len, mg_max_splits;
 };
 
 // ---- optional timeline probe (build with -DZL_I8P_PROBE; tools/ubench/probe_i8p.py): wall-clock stamps (100 MHz) per wave,
@@ -121,9 +127,14 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)
 
 // R: row tiles per workgroup.  LONGK: more than four groups per wave (K > 4096: rows <= 2, K <= 16384).  ROPE (R = 2): the
 // two tiles are a column block and its rotation partners (w4_phase.hip).  NORM: fused RMSNorm prologue.
-template <int R, bool LONGK, bool ROPE, bool NORM>
+// MERGE (K = heads x 128 <= 4096, <= 16 splits): slot `row` of a lane = octet l & 15 of head w + 8 (l >> 4) of task `row`,
+// merged from the attention's split partials (k_decode_attn_combine's weights; the partials are normalised fp16 rows, so
+// out = sum_s l_s e^(m_s - m) O_s / sum_s l_s e^(m_s - m)): a wave reads only the heads of ITS groups, the workgroup as a whole
+// every partial once.
+template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE = false>
 __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
+    static_assert(!MERGE || (!LONGK && !ROPE && !NORM), "split merge: one column block, plain prologue");
     constexpr int XD = R >= 8 ? 1 : (8 / R > 0 ? 8 / R : 1);   // groups the ring runs ahead (8 KiB per wave in flight: with 16
     constexpr int D = R * XD;                                  // the issue itself stalls for microseconds)
     constexpr int NS = LONGK ? 8 : 4;                          // activation octet slots per thread
@@ -162,6 +173,51 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
         const int row = LONGK ? (s & 1) : s, c = LONGK ? (s >> 1) : 0;
         const int g = wave + kW * (4 * c + lgi);
         xr[s] = make_uint4(0, 0, 0, 0);
+        if constexpr (MERGE) {
+            if (row < M) {
+                constexpr int kS = 16;
+                const int head = g < groups ? g : 0;
+                const size_t rec0 = ((size_t)row * groups + head) * p.mg_max_splits;
+                uint4 pv[kS];
+                float2 st[kS];
+#pragma unroll
+                for (int u = 0; u < kS; ++u) {           // every record the launch geometry allows; dead ones are masked below
+                    const size_t rec = rec0 + (u < p.mg_max_splits ? u : 0);
+                    pv[u] = *reinterpret_cast<const uint4*>(p.mg_part + rec * 128 + uo * 8);
+                    st[u] = *reinterpret_cast<const float2*>(p.mg_stat + rec * 2);
+                }
+                const int elen = min(p.buf_lens[row], p.mg_valid_lens[row]);
+                const int ns = min((elen + p.mg_split_len - 1) / p.mg_split_len, kS);
+                float mn = -1e20f;
+#pragma unroll
+                for (int u = 0; u < kS; ++u) mn = fmaxf(mn, u < ns ? st[u].x : -1e20f);
+                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, z = 0.f;
+#pragma unroll
+                for (int u = 0; u < kS; ++u) {
+                    if (u < ns) {                        // workgroup-uniform
+                        const float f = st[u].y * __expf(st[u].x - mn);
+                        const uint32_t w4[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const h16x2 hh = __builtin_bit_cast(h16x2, w4[e]);
+                            a[2 * e] = __builtin_fmaf((float)hh.x, f, a[2 * e]);
+                            a[2 * e + 1] = __builtin_fmaf((float)hh.y, f, a[2 * e + 1]);
+                        }
+                        z += f;
+                    }
+                }
+                const float zi = z + 1e-20f;
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h16x2 hh;
+                    hh.x = zl_f32_to_f16(a[2 * e] / zi);
+                    hh.y = zl_f32_to_f16(a[2 * e + 1] / zi);
+                    o[e] = __builtin_bit_cast(uint32_t, hh);
+                }
+                if (g < groups) xr[s] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        } else
         if (row < M && 4 * c < Gw) {                    // workgroup-uniform: no load instructions for slots that do not exist
             xr[s] = *reinterpret_cast<const uint4*>(p.x + (g < groups ? (size_t)row * p.ldx + g * 128 + uo * 8 : 0));
             if (g >= groups) xr[s] = make_uint4(0, 0, 0, 0);
@@ -367,7 +423,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
         }
     }
 #undef ZL_ISSUE_RANGE
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back what its own lanes wrote: program order suffices
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave reads back what its own lanes wrote
     __builtin_amdgcn_wave_barrier();
     ZL_IPROBE(3);
 
@@ -406,6 +462,13 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
                 float t = __builtin_fmaf((float)sm.y, cst.z, cst.w);      // -(1024 + z) B + 1024 B = -z B
                 t = __builtin_fmaf(f12, cst.x, t);
                 t = __builtin_fmaf(f0, cst.y, t);
+                // The MFMA's A / B registers stay allocated until here.  hipcc (ROCm 7.2) lets a VALU instruction overwrite a
+                // source of v_mfma_i32_16x16x64_i8 one issue slot after the MFMA (seen: v_cvt_f32_f16_sdwa into a dword of SrcA
+                // right behind the group's last MFMA); the matrix pipe reads its 128-bit operands over several passes, and
+                // the rows of the LAST pass (12..15 = batch row 3) then see the new value -- sporadically wrong outputs for
+                // the fourth batch row only (tools/ubench/_dbg_m4.py).  `t` depends on the MFMA's result, so this point is
+                // >= 30 cycles behind it.
+                asm volatile("" : "+v"(t) : "v"(b0), "v"(b1), "v"(a0), "v"(a1));
                 acc[r] = __builtin_fmaf((float)sm.x, t, acc[r]);
 #ifdef ZL_I8P_PROBE
                 if (gi == 0 && r == 0) ZL_IPROBE(4);
@@ -493,16 +556,16 @@ static size_t i8p_lds_bytes(int groups, int m, int r) {
     return kW * gw * 8 * 64 * (size_t)m + kW * gw * 64 + (size_t)r * kW * 64 * 4 + 4 * kW * 4;
 }
 
-template <int R, bool LONGK, bool ROPE, bool NORM>
+template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE = false>
 int launch_i8p_n(const I8Params& p, int grid, hipStream_t hs) {
     const size_t lds = i8p_lds_bytes(p.groups, p.m, R);
     if (lds > 160 * 1024) return ZL_ELIMIT;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_i8p<R, LONGK, ROPE, NORM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_i8p<R, LONGK, ROPE, NORM, MERGE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return ZL_ELIMIT;
     }
-    hipLaunchKernelGGL((k_w4a16_i8p<R, LONGK, ROPE, NORM>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w4a16_i8p<R, LONGK, ROPE, NORM, MERGE>), dim3(grid), dim3(kT), lds, hs, p);
     return zl_launch_status();
 }
 template <int R, bool ROPE>
@@ -536,6 +599,7 @@ int zl_w4a16_gemm_i8p(const uint16_t* x, int64_t ldx, const uint32_t* qw, const 
     p.ld_out = ld_out; p.norm_w = norm_w; p.norm_eps = norm_eps;
     p.cosv = p.sinv = nullptr; p.placement = p.buf_lens = nullptr; p.k_bufs = p.v_bufs = nullptr; p.q_out = nullptr;
     p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
+    p.mg_part = nullptr; p.mg_stat = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
     int r = (tiles + cus - 1) / cus;
@@ -561,6 +625,35 @@ int zl_w4a16_gemm_i8p_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, c
     p.epi = bias ? ZL_EPI_BIAS : 0; p.ld_out = n; p.norm_w = norm_w; p.norm_eps = norm_eps;
     p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs;
     p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd; p.pair_stride = d / 32;
+    p.mg_part = nullptr; p.mg_stat = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
     const int grid = tiles / 2;
     return launch_i8p<2, true>(p, grid, hs);
+}
+
+// internal (called by zl_w4a16_gemm_attn_merge_h): the attention output projection of a decode step reading the half-precision
+// split partials of zl_decode_attn_splits_h.  m <= 4, k = heads * 128 <= 4096, max_splits <= 16.
+int zl_w4a16_gemm_i8p_merge(const void* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len, int max_splits,
+                            const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
+                            const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups,
+                            int tiles, int epilogue, hipStream_t hs) {
+    if (m < 1 || m > 4 || k > 4096 || k % 128 != 0 || max_splits < 1 || max_splits > 16 || split_len < 1) return ZL_ESHAPE;
+    if (epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) return ZL_ESHAPE;
+    I8Params p;
+    p.x = nullptr; p.ldx = 0; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes; p.meta_bytes = meta_bytes;
+    p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k; p.groups = groups; p.tiles = tiles; p.epi = epilogue;
+    p.ld_out = n; p.norm_w = nullptr; p.norm_eps = 0.f;
+    p.cosv = p.sinv = nullptr; p.placement = nullptr; p.buf_lens = buf_lens; p.k_bufs = p.v_bufs = nullptr; p.q_out = nullptr;
+    p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
+    p.mg_part = reinterpret_cast<const uint16_t*>(ws);
+    p.mg_stat = reinterpret_cast<const float*>(ws) + (size_t)m * groups * max_splits * 64;   // behind the fp16 rows (128 halfs each)
+    p.mg_valid_lens = valid_lens; p.mg_split_len = split_len; p.mg_max_splits = max_splits;
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    int r = (tiles + cus - 1) / cus;
+    if (r > 8) r = 8;
+    const int grid = (tiles + r - 1) / r;
+#define ZL_I8M(RR) case RR: return launch_i8p_n<RR, false, false, false, true>(p, grid, hs);
+    switch (r) { ZL_I8M(1) ZL_I8M(2) ZL_I8M(3) ZL_I8M(4) ZL_I8M(5) ZL_I8M(6) ZL_I8M(7) ZL_I8M(8) }
+#undef ZL_I8M
+    return ZL_EINVAL;
 }

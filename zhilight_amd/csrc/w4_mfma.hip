@@ -606,6 +606,10 @@ int zl_w4a16_gemm_i8p_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, c
                            const uint16_t* norm_w, float norm_eps, const float* cosv, const float* sinv,
                            const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
                            uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs);
+int zl_w4a16_gemm_i8p_merge(const void* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len, int max_splits,
+                            const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
+                            const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups,
+                            int tiles, int epilogue, hipStream_t hs);
 int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len,
                               int max_splits, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                               uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
@@ -862,6 +866,25 @@ int zl_w4a16_gemm_attn_merge(const void* attn_workspace, const int32_t* buf_lens
     return zl_w4a16_gemm_phase_merge(reinterpret_cast<const float*>(attn_workspace), buf_lens, valid_lens, (int)split_len,
                                      (int)max_splits, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual,
                                      y, (int)m, (int)n, (int)k, (int)L.q, (int)(L.np / 16), epilogue, (hipStream_t)s);
+}
+
+int zl_w4a16_gemm_attn_merge_h(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens,
+                               int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
+                               const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
+                               int64_t group_size, int epilogue, zl_stream_t s) {
+    ZL_CHECK_ARG(attn_workspace && buf_lens && valid_lens && qw && meta && y, ZL_EINVAL);
+    ZL_CHECK_ARG(m > 0 && n > 0 && k > 0 && split_len > 0 && max_splits > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(!(epilogue & ZL_EPI_BIAS) || bias, ZL_EINVAL);
+    ZL_CHECK_ARG(!(epilogue & (ZL_EPI_RESIDUAL | ZL_EPI_ADD_C)) || residual, ZL_EINVAL);
+    ZL_CHECK_ARG(m <= 4 && k <= 4096 && k % 128 == 0 && max_splits <= 16, ZL_ESHAPE);
+    ZL_CHECK_ARG(!(epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)), ZL_ESHAPE);
+    zl_w4_layout_t L;
+    int st = zl_w4m_layout(n, k, group_size, &L);
+    if (st) return st;
+    ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+    return zl_w4a16_gemm_i8p_merge(attn_workspace, buf_lens, valid_lens, (int)split_len, (int)max_splits, qw, meta,
+                                   (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n, (int)k,
+                                   (int)L.q, (int)(L.np / 16), epilogue, (hipStream_t)s);
 }
 
 }  // extern "C"

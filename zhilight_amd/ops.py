@@ -702,12 +702,24 @@ def attn_merge_plan(b, num_heads, num_kv_heads, dim_head, max_len_buf, w):
     return split_len, max_splits
 
 
+def _merge_half(t=None):
+    """half-precision split partials + the integer-plane merging projection (zl_decode_attn_splits_h /
+    zl_w4a16_gemm_attn_merge_h) unless the round-2 kernels are asked for (ZL_W4_SMALL_ALGO=1) or the rows are not fp16"""
+    return os.environ.get("ZL_W4_SMALL_ALGO", "0") != "1" and os.environ.get("ZL_ATTN_MERGE_HALF", "1") != "0" and \
+        (t is None or t.dtype == torch.float16)
+
+
 def decode_attention_splits(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, valid_lens, scale, max_len_buf, num_kv_heads,
                             workspace, bshd=True):
     """multi_query_attention_rag_buffer without its merge launch: the split-KV partials stay in `workspace` for
     w4_attn_out_merge.  batch_q (B, 1, H, 128) or (B, H, 128)."""
     _chk_cuda(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, valid_lens, workspace)
     b, h, d = batch_q.shape[0], batch_q.shape[-2], batch_q.shape[-1]
+    if _merge_half(batch_q):
+        check(lib().zl_decode_attn_splits_h(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(valid_lens),
+                                            _p(workspace), _i(b), _i(h), _i(num_kv_heads), _i(d), _f(scale), _i(max_len_buf),
+                                            C.c_int(int(bshd)), _stream()), "decode_attn_splits_h")
+        return workspace
     check(lib().zl_decode_attn_splits(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(valid_lens),
                                       _p(workspace), _i(b), _i(h), _i(num_kv_heads), _i(d), _f(scale), _i(max_len_buf),
                                       C.c_int(int(bshd)), C.c_int(_dt(batch_q)), _stream()), "decode_attn_splits")
@@ -723,9 +735,10 @@ def w4_attn_out_merge(workspace, buf_lens, valid_lens, plan, b, w, bias=None, re
         out = torch.empty((b, w.n), dtype=torch.float16, device=workspace.device)
     if bias is not None:
         epilogue |= EPI_BIAS
-    check(lib().zl_w4a16_gemm_attn_merge(_p(workspace), _p(buf_lens), _p(valid_lens), _i(split_len), _i(max_splits), _p(w.qw),
-                                         _p(w.meta), _p(bias), _p(residual), _p(out), _i(b), _i(w.n), _i(w.k),
-                                         _i(w.group_size), C.c_int(epilogue), _stream()), "w4a16_gemm_attn_merge")
+    fn = lib().zl_w4a16_gemm_attn_merge_h if _merge_half() else lib().zl_w4a16_gemm_attn_merge
+    check(fn(_p(workspace), _p(buf_lens), _p(valid_lens), _i(split_len), _i(max_splits), _p(w.qw),
+             _p(w.meta), _p(bias), _p(residual), _p(out), _i(b), _i(w.n), _i(w.k),
+             _i(w.group_size), C.c_int(epilogue), _stream()), "w4a16_gemm_attn_merge")
     return out
 
 
