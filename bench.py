@@ -134,29 +134,33 @@ def roofline_int8(model, cfg, batch, dev):
     return roof
 
 
-def roofline_w4(model, cfg, batch, dev, layers_override=False):
-    """the W4A16 GEMV launches of one step (4 x 32, model order, on the real HBM-cold weights: 3.6 GB >> 256 MB Infinity
-    Cache), captured without the other kernels; HIP events on the launch stream"""
+def roofline_w4(model, cfg, batch, dev, ctx, layers_override=False):
+    """The W4A16 GEMV launches of one step -- 4 x 32, IN THE VARIANTS THE STEP ITSELF LAUNCHES (fused RMSNorm + rotary + KV
+    scatter on qkv, split merge + residual on attn_out, norm + silu*mul on gate|up, residual on down: LLaMA.encode(...,
+    gemv_only=True)), model order, on the real HBM-cold weights (3.6 GB >> 256 MB Infinity Cache), captured without the
+    attention / embedding / lm_head kernels; HIP events on the launch stream."""
     from zhilight_amd import ops
-    roof = None
     bufs = model._buffers(batch)
-    launches = []
-    for layer in model.layers:
-        # the model fuses the RMSNorm into the GEMV up to 8 rows (4 for the bit-exact kernel) and launches it separately
-        # beyond (llama.py: _fused_norm_rows)
-        from zhilight_amd.llama import _fused_norm_rows
-        nq = dict(norm_weight=layer.ln_attn, norm_eps=cfg.eps) if batch <= _fused_norm_rows(layer.qkv.weight) else {}
-        nf = dict(norm_weight=layer.ln_ff, norm_eps=cfg.eps) if batch <= _fused_norm_rows(layer.w_in_gated.weight) else {}
-        launches += [(bufs["hidden"], layer.qkv, bufs["qkv"], nq),
-                     (bufs["attn"], layer.attn_out, bufs["hidden"], dict(residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL)),
-                     (bufs["hidden"], layer.w_in_gated, bufs["act"], dict(epilogue=ops.EPI_SILU_MUL, **nf)),
-                     (bufs["act"], layer.w_out, bufs["hidden"], dict(residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL))]
+    lins = [lin for layer in model.layers for lin in (layer.qkv, layer.attn_out, layer.w_in_gated, layer.w_out)]
     bufs["hidden"].normal_()
     bufs["attn"].normal_()
+    in_step = False
+    if batch <= 8:                                     # beyond 8 rows the two RMSNorms are launches of their own: plain projections
+        try:
+            model.encode(ctx, gemv_only=True)
+            in_step = True
+        except ops.ZLError:
+            in_step = False                            # a route without the fused decode launches
 
     def gemvs():
-        for x, lin, out, kw in launches:
-            ops.w4_linear(x, lin.weight, out=out, **kw)
+        if in_step:
+            model.encode(ctx, gemv_only=True)
+            return
+        for layer in model.layers:
+            ops.w4_linear(bufs["hidden"], layer.qkv.weight, out=bufs["qkv"])
+            ops.w4_linear(bufs["attn"], layer.attn_out.weight, out=bufs["hidden"], residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL)
+            ops.w4_linear(bufs["hidden"], layer.w_in_gated.weight, out=bufs["act"], epilogue=ops.EPI_SILU_MUL)
+            ops.w4_linear(bufs["act"], layer.w_out.weight, out=bufs["hidden"], residual=bufs["hidden"], epilogue=ops.EPI_RESIDUAL)
     gemvs()
     torch.cuda.synchronize()
     g2 = torch.cuda.CUDAGraph()
@@ -171,13 +175,15 @@ def roofline_w4(model, cfg, batch, dev, layers_override=False):
         g2.replay()
     e1.record()
     torch.cuda.synchronize()
-    t_launch = e0.elapsed_time(e1) * 1e-3 / (reps * len(launches))
-    tot_bytes = sum(alg_bytes_w4(lin.weight.n, lin.weight.k, lin.weight.group_size, batch) for _, lin, _, _ in launches)
-    per_launch = tot_bytes / len(launches)
+    nl = len(lins) + (len(model.layers) if in_step and batch > 8 else 0)   # beyond 8 rows the qkv norm is its own (counted) launch
+    t_launch = e0.elapsed_time(e1) * 1e-3 / (reps * len(lins))
+    tot_bytes = sum(alg_bytes_w4(lin.weight.n, lin.weight.k, lin.weight.group_size, batch) for lin in lins)
+    per_launch = tot_bytes / len(lins)
     achieved = per_launch / t_launch / 1e9
-    # MFMA flavour: k_w4a16_phase streams qkv / o / gate|up (and the down projection for 5..16 rows),
-    # k_w4a16_mfma the long-K down projection up to 4 rows, k_w4a16_gemm_tiled the down projection beyond 16 rows
-    kname = "k_w4a16_phase+k_w4a16_mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "k_w4a16_gemm"
+    mfma = isinstance(model.layers[0].qkv.weight, ops.W4MWeight)
+    small = os.environ.get("ZL_W4_SMALL_ALGO", "0") != "1"
+    # 1..4 rows: k_w4a16_i8p (integer planes) for all four; 5..32: k_w4a16_phase (+ k_w4a16_mfma / k_w4a16_gemm_tiled on the long K)
+    kname = ("k_w4a16_i8p" if batch <= 4 and small else "k_w4a16_phase+k_w4a16_mfma") if mfma else "k_w4a16_gemm"
     # HBM traffic per launch: measured off-line with rocprofv3 --pmc (a counter pass cannot run inside
     # this process); the committed summary is per kernel flavour and for these four shapes only
     traffic = None
@@ -190,11 +196,12 @@ def roofline_w4(model, cfg, batch, dev, layers_override=False):
             traffic = int(tj["avg_bytes_per_launch"])
     except (OSError, ValueError, KeyError, IndexError):
         traffic = None
-    roof = {"bound": "hbm", "kernel": kname + " (W4A16 GEMV, 4 launches/layer)", "achieved": round(achieved, 1),
+    roof = {"bound": "hbm", "kernel": kname + " (W4A16 GEMV, 4 launches/layer, the step's own fused variants)" if in_step
+            else kname + " (W4A16 GEMV, 4 launches/layer, plain variants)", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3),
-            "note": "avg over the 128 GEMV launches of one step incl. inter-kernel gaps (graph replay, HIP events)"}
-
+            "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3), "launches_timed": nl,
+            "note": "avg over the %d GEMV launches of one step incl. the kernel boundaries between them (graph replay, HIP events); "
+                    "in-step rocprofv3 averages of the same kernels: profiles/r03_decode_kernel_stats.csv" % len(lins)}
     return roof
 
 
@@ -228,7 +235,7 @@ def extra_decode_run(model, cfg, batch, seq, steps, warmup, dev, int8):
         graph.replay()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    roof = roofline_int8(model, cfg, batch, dev) if int8 else roofline_w4(model, cfg, batch, dev)
+    roof = roofline_int8(model, cfg, batch, dev) if int8 else roofline_w4(model, cfg, batch, dev, ctx)
     del graph, ctx
     torch.cuda.empty_cache()
     return {"workload": "Llama-3-8B %s TP=1 batch=%d decode seq=%d" % ("INT8 (AutoInt8 linears)" if int8 else "GPTQ-Int4 g128", batch, seq),
@@ -423,7 +430,7 @@ def main():
     if rank == 0 and int8:
         roof = roofline_int8(model, cfg, batch, dev)
     if rank == 0 and not int8 and tp is None:
-        roof = roofline_w4(model, cfg, batch, dev, bool(args.layers))
+        roof = roofline_w4(model, cfg, batch, dev, ctx, bool(args.layers))
 
     # ---- extra legs of the default single-GPU run: batch 8 / 32 on the headline model, BASELINE configs[2] (INT8, batch 32)
     extras = None

@@ -303,8 +303,10 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
         __builtin_amdgcn_sched_barrier(0);                         \
     }
     // prologue items [0, Q0) go ahead of the norm's barrier, the rest between the four stages of the first slot's conversion
-    constexpr int Q0 = NORM ? D / 2 : 0, QS = (D - Q0 + 3) / 4;
-    constexpr int QB1 = Q0 + QS < D ? Q0 + QS : D, QB2 = Q0 + 2 * QS < D ? Q0 + 2 * QS : D, QB3 = Q0 + 3 * QS < D ? Q0 + 3 * QS : D;
+    // prologue items [0, Q0) go ahead of the norm's barrier, the rest between the conversion stages of row 0's first column
+    // block (LONGK: first two blocks, which always exist): stage position pos of NP gets items [QLO(pos), QLO(pos + 1))
+    constexpr int Q0 = NORM ? D / 2 : 0, NP = LONGK ? 8 : 4;
+#define ZL_QLO(pos) (Q0 + ((D - Q0) * (pos) + NP - 1) / NP)
 
     // ---- fused RMSNorm (LayerNorm::forward, src/nn/layernorm/layernorm.cu:10-42): rs per row.  One workgroup barrier, with
     //      half of the ring issued in front of it (the rest would make the waves wait for each other's VMEM issue)
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
             const us2 mm = __builtin_elementwise_max(m01, m23);
             int am = max((int)mm.x, (int)mm.y);
             am = row16_max(am);
-            if (s == 0) ZL_ISSUE_RANGE(Q0, QB1)
+            if (row == 0 && c < NP / 4) ZL_ISSUE_RANGE(ZL_QLO(4 * c + 0), ZL_QLO(4 * c + 1))
             const int ef = min(am >> 10, 30);
             const float up = __builtin_bit_cast(float, (uint32_t)(163 - ef) << 23);     // 2^(36 - Ef): |x| < 2^(Ef - 14) -> |X| < 2^22
             const float xscale = __builtin_bit_cast(float, (uint32_t)(91 + ef) << 23);  // 2^(Ef - 36)
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
             }
             int sx = (int)(((Y[0] + Y[1]) + (Y[2] + Y[3])) + ((Y[4] + Y[5]) + (Y[6] + Y[7]))) - 8 * 0x808080;
             sx = row16_sum(sx);
-            if (s == 0) ZL_ISSUE_RANGE(QB1, QB2)
+            if (row == 0 && c < NP / 4) ZL_ISSUE_RANGE(ZL_QLO(4 * c + 1), ZL_QLO(4 * c + 2))
             // byte gather: [v0 v4 v1 v5] and [v2 v6 v3 v7] of the three digit planes
             auto planes_of = [&](int i0, int i1, int i2, int i3, uint32_t& d2, uint32_t& d1, uint32_t& d0) {
                 const uint32_t P = __builtin_amdgcn_perm(Y[i1], Y[i0], 0x05010400u);    // [a.b0, b.b0, a.b1, b.b1]
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
             uint32_t a2, a1, a0, b2, b1, b0;
             planes_of(0, 4, 1, 5, a2, a1, a0);
             planes_of(2, 6, 3, 7, b2, b1, b0);
-            if (s == 0) ZL_ISSUE_RANGE(QB2, QB3)
+            if (row == 0 && c < NP / 4) ZL_ISSUE_RANGE(ZL_QLO(4 * c + 2), ZL_QLO(4 * c + 3))
             unsigned char* dst = planes + (size_t)((gi * 2 + (uo >> 3)) * 4 + (uo & 3)) * rec + (size_t)(4 * row) * 16 + ((uo >> 2) & 1) * 8;
             if (live) {
                 *reinterpret_cast<uint2*>(dst) = make_uint2(a2, b2);
@@ -419,10 +421,11 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
                     *reinterpret_cast<float4*>(consts + ((size_t)gi * 4 + row) * 4) = make_float4(xscale, 65536.f * xscale, bx, 1024.f * bx);
                 }
             }
-            if (s == 0) ZL_ISSUE_RANGE(QB3, D)
+            if (row == 0 && c < NP / 4) ZL_ISSUE_RANGE(ZL_QLO(4 * c + 3), ZL_QLO(4 * c + 4))
         }
     }
 #undef ZL_ISSUE_RANGE
+#undef ZL_QLO
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave reads back what its own lanes wrote
     __builtin_amdgcn_wave_barrier();
     ZL_IPROBE(3);

@@ -918,8 +918,11 @@ class LLaMA:
         return self._bufs[b]
 
     # ---- one decode step -----------------------------------------------------------------------
-    def encode(self, ctx: DynBatchContext, workspace=None, argmax_ws=None):
-        """LLaMA::encode for a pure decode ("search") batch: returns logits (B, vocab) fp16."""
+    def encode(self, ctx: DynBatchContext, workspace=None, argmax_ws=None, gemv_only=False):
+        """LLaMA::encode for a pure decode ("search") batch: returns logits (B, vocab) fp16.
+        gemv_only (bench.py's roofline leg): issue ONLY the four quantised projections of every layer, exactly as the step
+        launches them (fused norm / rotary + scatter / split merge / gated activation / residual), on whatever the buffers
+        hold -- no embedding, attention or lm_head; returns None."""
         c = self.cfg
         b = ctx.tokens.numel()
         if ctx.steps_left <= 0 and not torch.cuda.is_current_stream_capturing():
@@ -929,7 +932,10 @@ class LLaMA:
         if workspace is None:
             workspace = self._bufs.setdefault(("ws", b, ctx.max_len_buf),
                                               ops.decode_attn_workspace(b, 1, c.num_heads, c.dim_head, ctx.max_len_buf, self.device))
-        hidden = ops.embedding(ctx.tokens, self.token_embedding, c.scale_emb)      # token_embedding
+        if gemv_only:
+            hidden = bufs["hidden"]
+        else:
+            hidden = ops.embedding(ctx.tokens, self.token_embedding, c.scale_emb)  # token_embedding
         cos, sin = self._rope_tables(ctx.positions)                                # RopePreparer
         scale = 1.0 / math.sqrt(c.dim_head)
         mfma_attn = (c.dim_head == 128 and c.num_heads // c.num_kv_heads <= 16
@@ -969,19 +975,23 @@ class LLaMA:
                                         ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, bias=layer.qkv.bias,
                                         norm_weight=layer.ln_attn if b <= 8 else None, norm_eps=c.eps, q_out=bufs["q"])
                 if merge_plan:
-                    ops.decode_attention_splits(bufs["q"].view(b, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
-                                                ctx.v_addrs[li], ctx.valid_lens, scale, ctx.max_len_buf, c.num_kv_heads, workspace)
+                    if not gemv_only:
+                        ops.decode_attention_splits(bufs["q"].view(b, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
+                                                    ctx.v_addrs[li], ctx.valid_lens, scale, ctx.max_len_buf, c.num_kv_heads, workspace)
                     ops.w4_attn_out_merge(workspace, ctx.buf_lens, ctx.valid_lens, merge_plan, b, layer.attn_out.weight,
                                           bias=layer.attn_out.bias, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
                     layer.ff_add(hidden, c.eps, bufs["act"])
                     continue
-                ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
-                                                     ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
-                                                     valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
-                                                     workspace=workspace)
+                if not gemv_only:
+                    ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
+                                                         ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
+                                                         valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
+                                                         workspace=workspace)
                 layer.attn_out_add(bufs["attn"], hidden)
                 layer.ff_add(hidden, c.eps, bufs["act"])
                 continue
+            if gemv_only:
+                raise ops.ZLError("gemv_only: the fused W4 decode route only")
             layer.project_qkv(hidden, c.eps, out=bufs["qkv"])
             self.apply_qk_norm(layer, bufs["qkv"])
             if ctx.kv_quant:
@@ -1008,6 +1018,8 @@ class LLaMA:
                                            out=bufs["attn"], workspace=workspace)
             layer.attn_out_add(bufs["attn"], hidden)
             layer.ff_add(hidden, c.eps, bufs["act"])
+        if gemv_only:
+            return None
         self.last_hidden = hidden                      # (B, dim_model) before the output norm: the parity tests read it
         return self._logits(hidden, bufs["logits"], argmax_ws)
 
