@@ -190,3 +190,96 @@ def test_stack_of_eight_full_layers(oracle, dev, batch, layers):
     assert rec["logits_vs_R_max"] <= 1e-3 + rec["R_vs_E_max"], rec
     assert rec["logits_vs_E_max"] <= max(1e-3, 0.5 * rec["R_vs_E_max"]), rec
     assert rec["logits_vs_E_rms"] <= max(5e-4, 0.5 * rec["R_vs_E_rms"]), rec
+
+
+@pytest.mark.skipif(bool(os.environ.get("ZL_FULLGEOM_SKIP32")), reason="ZL_FULLGEOM_SKIP32 set (builder's quick runs)")
+def test_thirty_two_full_layers_batch1(oracle, dev):
+    """the depth the metric is quoted on.  32 DISTINCT full-geometry layers (dim 4096, dim_ff 14336, 32 / 8
+    heads, 1024 keys of history per layer), batch 1 -- the step bench.py times: fused norm + qkv + rotary + scatter,
+    matrix-core attention with half-precision split partials, merging attn_out projection, gate|up + silu*mul, down, all four
+    projections on the integer-plane kernel -- then the final norm and a 4096-row lm_head, against both oracle flavours.
+    Hard bars: 1e-3 of the largest logit against the exact-linear oracle E, and no further from R (the reference's fp16
+    partial sums) than R's own distance to E plus 1e-3."""
+    rec = _decode_case(oracle, dev, 32, 4096, 1, 1024, "stack32")[0]
+    assert rec["logits_vs_E_max"] <= 1e-3, rec
+    assert rec["logits_vs_R_max"] <= 1e-3 + rec["R_vs_E_max"], rec
+    assert rec["hidden_vs_E_max"] <= 2e-3, rec
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# INT8 route (BASELINE configs[2]) at full geometry, batch 32 -- VERDICT r02 weak 3
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,n", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
+def test_int8_linears_full_geometry_batch32_bit_exact(oracle, dev, k, n):
+    """Int8Linear::forward (linear.cpp:557-635) on the four Llama-3-8B matrices at 32 rows: the int32 product of
+    zl_int8_gemm_nt equals the oracle's exactly, and the streaming kernel the decode step launches (k_w8a8_phase: GEMM +
+    quant_scale_back / quant_back_element_add_scale / quant_back_act_mul in its epilogue, quant_kernel.cu:231-246, 589-614)
+    equals the separate launches bit for bit."""
+    from zhilight_amd import ops
+    from test_gpu_ops import _np as _npi
+    rng = np.random.default_rng(k + n)
+    m = 32
+    a = rng.integers(-127, 128, (m, k), dtype=np.int8)
+    w = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    sx = rng.uniform(0.01, 0.05, m).astype(np.float32)
+    sy = rng.uniform(0.001, 0.01, n).astype(np.float16)
+    ta, tw, tsx, tsy = _t(a, dev), _t(w, dev), _t(sx, dev), _t(sy, dev)
+    c = ops.int8_gemm_nt(ta, tw)
+    assert np.array_equal(_npi(c), oracle.int8_gemm_nt(a, w))
+    if n == 28672:
+        w8g = ops.W8MWeight.from_rows(tw, tsy, row_interleave=True)
+        h2 = n // 2
+        ref = ops.quant_back_act_mul(c[:, :h2].contiguous(), tsx, tsy[:h2].contiguous(), c[:, h2:].contiguous(), tsx,
+                                     tsy[h2:].contiguous(), "silu", torch.float16)
+        assert torch.equal(ops.w8a8_gemm_phase(ta, tsx, w8g, ops.W8_ACT_SILU), ref)
+    else:
+        w8 = ops.W8MWeight.from_rows(tw, tsy)
+        assert torch.equal(ops.w8a8_gemm_phase(ta, tsx, w8, ops.W8_BACK), ops.quant_scale_back(c, tsx, tsy, torch.float16))
+        add = _t(synth.act(rng, m, n), dev)
+        assert torch.equal(ops.w8a8_gemm_phase(ta, tsx, w8, ops.W8_BACK_ADD, addend=add, scale=1.0),
+                           ops.quant_back_element_add_scale(c, tsx, tsy, add, 1.0))
+
+
+def test_int8_full_geometry_layer_and_lm_head_batch32(oracle, dev):
+    """One full-geometry AutoInt8 layer (weights quantised at load: bit-exact codes; per-row activation quantisation; streaming
+    W8A8 kernels with fused scale-back, rotary + scatter, gated activation, residual) + final norm + a 4096-row lm_head at
+    batch 32 over 1024 keys of history: the layer's output rows equal the oracle's composition of the reference's ops (almost)
+    everywhere bit for bit, logits within 1e-3 of the largest logit (north_star's bar; the 2-layer dim-1024 test used 2e-3)."""
+    from zhilight_amd.llama import LLaMA, QuantConfig
+    from test_gpu_model import OracleInt8Model, _dense_state
+    rng = np.random.default_rng(77)
+    cfg = _cfg(1, 4096)
+    sd = _dense_state(rng, cfg)
+    model = LLaMA(cfg, QuantConfig(2, 0), dev).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    batch, hist = 32, 1024
+    len_buf = (hist + 1 + 63) // 64 * 64
+    om = OracleInt8Model(oracle, cfg, sd, batch, len_buf)
+    wq = np.concatenate([om.w["model.layers.0.self_attn." + n + "_proj"][0] for n in "qkv"], axis=0)
+    assert np.array_equal(model.layers[0].qkv.weight.cpu().numpy(), wq)          # load-time quantisation: bit-exact
+    ctx = model.new_context(batch, len_buf, hist)
+    for b in range(batch):
+        for which, bufs in enumerate((om.kb, om.vb)):
+            h = synth.act(rng, hist * cfg.num_kv_heads, cfg.dim_head).reshape(hist, cfg.num_kv_heads, cfg.dim_head)
+            bufs[0][b][:hist] = h.view(np.uint16)
+            ctx.kv[b][0, which, :hist].copy_(torch.from_numpy(h))
+    tokens = rng.integers(0, cfg.vocab_size, batch).astype(np.int32)
+    ctx.tokens.copy_(torch.from_numpy(tokens))
+    got = model.encode(ctx).float().cpu().numpy().astype(np.float64)
+    ref = om.step(tokens, [hist] * batch)
+    ref2 = om.step(tokens, [hist] * batch, attn_exact=True)
+    e_max, e_rms = _errors(got, ref)
+    e2_max, e2_rms = _errors(got, ref2)
+    s_max, s_rms = _errors(ref2, ref)
+    _record(case="int8 layer+lm_head", layers=1, batch=batch, kv_len=hist + 1, vocab=cfg.vocab_size, logits_vs_oracle_max=e_max,
+            logits_vs_oracle_rms=e_rms, logits_vs_oracle_exact_attn_max=e2_max, logits_vs_oracle_exact_attn_rms=e2_rms,
+            oracle_vs_oracle_exact_attn_max=s_max, oracle_vs_oracle_exact_attn_rms=s_rms)
+    hid = model.last_hidden.float().cpu().numpy().astype(np.float64)
+    hr = oracle.u2h(om.last_hidden).astype(np.float64)
+    differing = float((hid != hr).mean())
+    print("int8 full geometry: vs oracle", e_max, e_rms, "vs oracle(exact attention)", e2_max, e2_rms, "oracle vs oracle", s_max, s_rms)
+    _record(case="int8 layer hidden", differing_fraction=differing)
+    # every op of the layer is integer-exact or within one rounding given identical inputs, and with the rotation angles from a
+    # correctly rounded powf the inputs ARE identical: the layer's output rows equal the oracle's bit for bit (before that fix:
+    # 3e-3 rms -- a 1e-4 rad angle difference at position 1024 flips activation codes of the int8 quantiser)
+    assert differing <= 1e-3, differing
+    assert e_max <= 1e-3, (e_max, e_rms)

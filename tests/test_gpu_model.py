@@ -433,7 +433,10 @@ class OracleInt8Model:
         self.kb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
         self.vb = [[np.zeros(shp, np.uint16) for _ in range(batch)] for _ in range(cfg.num_layers)]
 
-    def step(self, tokens, pos):
+    def step(self, tokens, pos, attn_exact=False):
+        """attn_exact: the attention rows from the fp64 statement rounded once to fp16 instead of the reference kernel's fp32
+        order -- a second, equally valid producer of the int8 quantiser's input (what a different attention kernel of the
+        reference itself would be): the distance between the two is the route's own sensitivity to one-ulp producers."""
         o, c = self.o, self.cfg
         b = len(tokens)
         h = o.embedding(np.asarray(tokens, np.int32), o.h2u(self.sd["model.embed_tokens.weight"]))
@@ -448,8 +451,12 @@ class OracleInt8Model:
             q, k, v = o.rope_qk_cache(cs, sn, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
             o.copy_to_rag_buffer2(np.asarray(pos, np.int32).reshape(b, 1), lens, k.reshape(b, 1, c.num_kv_heads, c.dim_head),
                                   v.reshape(b, 1, c.num_kv_heads, c.dim_head), self.kb[i], self.vb[i], True)
-            att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask, c.num_kv_heads,
-                                   1.0 / np.sqrt(c.dim_head), True).reshape(b, -1)
+            if attn_exact:
+                att = o.h2u(o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask,
+                                             c.num_kv_heads, 1.0 / np.sqrt(c.dim_head), True, exact=True).astype(np.float16)).reshape(b, -1)
+            else:
+                att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask, c.num_kv_heads,
+                                       1.0 / np.sqrt(c.dim_head), True).reshape(b, -1)
             aq, sa = o.quant_calc_scale(att)
             wo = self.w[p + "self_attn.o_proj"]
             h = o.quant_back_element_add_scale(o.int8_gemm_nt(aq, wo[0]), sa, wo[1], h, 1.0)
@@ -458,6 +465,7 @@ class OracleInt8Model:
             act = o.quant_back_act_mul(o.int8_gemm_nt(xq, wg[0]), sx, wg[1], o.int8_gemm_nt(xq, wu[0]), sx, wu[1], "silu")
             aq, sa = o.quant_calc_scale(act)
             h = o.quant_back_element_add_scale(o.int8_gemm_nt(aq, wd[0]), sa, wd[1], h, 1.0)
+        self.last_hidden = h
         xn = o.rmsnorm(h, o.h2u(self.sd["model.norm.weight"]), c.eps)
         return o.gemm_nt(xn, o.h2u(self.sd["lm_head.weight"]), exact=True)
 

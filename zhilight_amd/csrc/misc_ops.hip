@@ -69,7 +69,10 @@ __global__ void k_rope_cos_sin(const int32_t* __restrict__ pos, float* __restric
     const int col = threadIdx.x;
     if (col >= d) return;
     const int i = half_dim_index(col, d / 2, neox);
-    float inv_freq = powf(base, -(float)(i * 2) / (float)d);
+    // powf of the reference (rope_preparer.cu:61) with a CORRECTLY ROUNDED result: the angle is position x inv_freq, so one ulp of
+    // the device powf (6e-8 relative) is 1e-4 rad at position 1024 -- enough to move a fifth of the rotated fp16 values by an ulp
+    // and, on the INT8 route, to flip activation codes (0.3 % logit noise against the CPU oracle, tests/test_gpu_fullgeom.py)
+    float inv_freq = (float)pow((double)base, (double)(-(float)(i * 2) / (float)d));
     if (llama3) {
         const float low_wl = old_ctx / low_ff, high_wl = old_ctx / high_ff;
         const float pi = 3.141592653589793f;
@@ -105,10 +108,10 @@ __global__ void k_rope_cos_sin_scaled(const int32_t* __restrict__ pos, const int
     if (type == 2) {            // dynamic NTK: p1 = max_position_embeddings
         float theta = base;
         const int len = seq_len ? seq_len[t] : pos[t];
-        if ((float)len > p1) theta *= powf((factor * (float)len / p1) - (factor - 1.f), (float)(d / (d - 2)));
-        freq = (float)pos[t] * powf(theta, -(float)(i * 2) / (float)d);
+        if ((float)len > p1) theta *= (float)pow((double)((factor * (float)len / p1) - (factor - 1.f)), (double)(float)(d / (d - 2)));
+        freq = (float)pos[t] * (float)pow((double)theta, (double)(-(float)(i * 2) / (float)d));
     } else {                    // yarn: p1 = low, p2 = high, p3 = mscale
-        const float pos_freq = powf(base, (float)(i * 2) / (float)d);
+        const float pos_freq = (float)pow((double)base, (double)((float)(i * 2) / (float)d));
         const float extrap = 1.0f / pos_freq, interp = 1.0f / (factor * pos_freq);
         const float fi = (float)i;
         const float ramp = fi <= p1 ? 0.f : (fi >= p2 ? 1.f : (fi - p1) / (p2 - p1));
@@ -164,7 +167,7 @@ __global__ void k_rope_qk(const int32_t* __restrict__ pos, const float* __restri
     float c, s;
     if (MODE == 0) {
         const int i = col < half ? col : col - half;
-        const float freq = (float)pos[t] * powf(theta, -(float)(i * 2) / (float)d);
+        const float freq = (float)pos[t] * (float)pow((double)theta, (double)(-(float)(i * 2) / (float)d));   // correctly rounded powf (see k_rope_cos_sin)
         c = cosf(freq);
         s = sinf(freq);
     } else {
