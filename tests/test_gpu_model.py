@@ -40,6 +40,7 @@ class OracleModel:
     def __init__(self, oracle, cfg, sd, g, batch, len_buf, kv_quant=False):
         self.o, self.cfg, self.g = oracle, cfg, g
         self.rope_kind = ((cfg.rope_scaling or {}).get("rope_type") or "llama3")
+        self.exact_attention = False   # flavour E: exact linears only (rounds 1-2) / exact attention as well
         self.sd = sd
         self.kv_quant = kv_quant
         if kv_quant:   # INT8 KV cache: u8 codes (128 = zero) + fp32 scale per (slot, kv head)
@@ -91,11 +92,23 @@ class OracleModel:
 
     def _gemv(self, x, name, flavour):
         """decode linear: 'R' = the reference's warp-reduce kernel arithmetic (fp16 hfma2 partial sums, its own
-        noise ~1e-3 of the output rms), 'E' = exact (fp64) sum rounded once to fp16"""
+        noise ~1e-3 of the output rms), 'E' = exact (fp64) sum rounded once to fp16.
+        'T' = E with the rounding of 1 output in 2000 of layer 0's q projection moved by one ulp (what another
+        tie-breaking / summation order of an equally exact kernel does): the distance of a T run from an E run is the
+        conditioning of the fp16 network itself -- one flipped rounding shifts every output of the next projection by
+        ~1e-5 relative, which flips ~3 % of ITS roundings, and three projections later every element carries an
+        independent fp16 rounding's worth of difference."""
         o = self.o
         if flavour == "R":
             return o.gptq_gemm_k_major(x, *self.km[name])
-        return o.h2u(o.gptq_gemm_k_major_exact(x, *self.km[name]).astype(np.float16))
+        y = o.h2u(o.gptq_gemm_k_major_exact(x, *self.km[name]).astype(np.float16))
+        if flavour == "T" and name.endswith("layers.0.self_attn.q_proj"):
+            rng = np.random.default_rng(12345)
+            y = y.copy()
+            idx = rng.choice(y.size, max(1, y.size // 2000), replace=False)
+            flat = y.reshape(-1)
+            flat[idx] = flat[idx] + np.where(rng.random(idx.size) < 0.5, 1, -1).astype(np.int32).astype(np.uint16)   # +-1 ulp of the magnitude
+        return y
 
     def step(self, tokens, pos, flavour="R", commit=True):
         o, c = self.o, self.cfg
@@ -128,8 +141,15 @@ class OracleModel:
             else:
                 o.copy_to_rag_buffer2(np.asarray(pos, np.int32).reshape(b, 1), lens, k.reshape(b, 1, c.num_kv_heads, c.dim_head),
                                       v.reshape(b, 1, c.num_kv_heads, c.dim_head), self.kb[i], self.vb[i], True)
-                att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask, c.num_kv_heads,
-                                       1.0 / np.sqrt(c.dim_head), True).reshape(b, -1)
+                if flavour in ("E", "T") and self.exact_attention:
+                    # E = exact arithmetic between the reference's rounding points: the attention rows from the fp64 statement,
+                    # rounded once to T (R keeps the restated kernel: fp32 FMA order, expf -- its own 1e-4-relative noise moves
+                    # a third of the fp16 outputs by an ulp, which the next projection spreads over every hidden element)
+                    att = o.h2u(o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask,
+                                                 c.num_kv_heads, 1.0 / np.sqrt(c.dim_head), True, exact=True).astype(np.float16)).reshape(b, -1)
+                else:
+                    att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, self.kb[i], self.vb[i], mask,
+                                           c.num_kv_heads, 1.0 / np.sqrt(c.dim_head), True).reshape(b, -1)
             h = o.element_add_scale(h, self._gemv(att, p + "self_attn.o_proj", flavour), 1.0, True)
             xn = o.rmsnorm(h, o.h2u(self.sd[p + "post_attention_layernorm.weight"]), c.eps)
             act = o.silu_mul(self._gemv(xn, p + "mlp.gate_proj", flavour), self._gemv(xn, p + "mlp.up_proj", flavour))
