@@ -391,10 +391,12 @@ def main():
     step()  # eager once: allocates the step's buffers, caches device attributes
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
+    captured = False
     try:
         with torch.cuda.graph(graph):
             step()
         replay = graph.replay
+        captured = True
     except RuntimeError as e:              # a collective that cannot be captured: run the step eagerly
         if tp is None:
             raise
@@ -418,6 +420,9 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    tp_expired = None
+    if tp is not None and hasattr(tp, "oneshot"):
+        tp_expired = tp.oneshot.status()       # bounded waits that expired (their outputs are NaN-poisoned by the kernel)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -460,7 +465,10 @@ def main():
                        "kv_cache_dtype": args.kv_cache_dtype,
                        "w4_algo": None if int8 else ("mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "exact")},
             "per_gpu_tokens_per_s": round(value / world, 2),
-            "note_tp": ("TP transports: %s; never run on more than one GPU by the builder (1-GPU dev box): protocol covered by in-process / two-process tests on one device" % type(tp).__name__) if tp else None,
+            "note_tp": ("TP transports: %s, RCCL communicator over %d ranks (0 = none), one-shot exchange expired waits: %s, step %s; the "
+                        "builder's boxes have one GPU: the exchange step is covered there by a two-process model test on one device "
+                        "(tests/test_gpu_comm.py)" % (type(tp).__name__, getattr(tp, "rccl_ranks", world if tp else 0), tp_expired,
+                                                      "captured in one hipGraph" if captured else "launched eagerly")) if tp else None,
             "ttft_ms": None if ttft_ms is None else round(ttft_ms, 3),
             "ttft_dual_stream_ms": None if ttft_dual_ms is None else round(ttft_dual_ms, 3),
             "ttft_note": "prompt of seq tokens, one task, first greedy token; eager launches, HIP events, mean of 3",

@@ -729,6 +729,8 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
     const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
     ZL_CHECK_ARG(x && qw && meta && y && m > 0 && n > 0 && k > 0, ZL_EINVAL);
     ZL_CHECK_ARG(ldx >= k && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && k % 128 == 0, ZL_ESHAPE);
+    // the kernels address the activations with 32-bit byte offsets (buffer descriptors): refuse what would wrap
+    ZL_CHECK_ARG(((m - 1) * ldx + k) * 2 < ((int64_t)1 << 32), ZL_ELIMIT);
     ZL_CHECK_ARG(!(epilogue & ZL_EPI_RESIDUAL) || residual, ZL_EINVAL);
     zl_w4_layout_t L;
     int st = zl_w4m_layout(n, k, group_size, &L);
@@ -810,13 +812,10 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
 #define ZL_WIDE_LAUNCH(RBV, NTV)                                                                                             \
     {                                                                                                                        \
         if (ldsw > 64 * 1024) {                                                                                              \
-            static bool attr_set = false; /* idempotent: a race only repeats the call */                                     \
-            if (!attr_set) {                                                                                                 \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm_wide<RBV, NTV>),                         \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw) != hipSuccess)                \
-                    return ZL_ELIMIT;                                                                                        \
-                attr_set = true;                                                                                             \
-            }                                                                                                                \
+            /* every launch: the attribute is per device, and one process may drive several (the reference's engine) */      \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm_wide<RBV, NTV>),                             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw) != hipSuccess)                    \
+                return ZL_ELIMIT;                                                                                            \
         }                                                                                                                    \
         hipLaunchKernelGGL((k_w4a16_gemm_wide<RBV, NTV>), gridw, dim3(256), ldsw, hs, p, gxw, gyw);                          \
     }

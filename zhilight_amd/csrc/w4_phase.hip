@@ -699,13 +699,10 @@ int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
     constexpr size_t lds = x_bytes > red_bytes ? x_bytes : red_bytes;
     static_assert(lds <= 160 * 1024, "LDS");
     if (lds > 64 * 1024) {
-        static bool done = false;   // per instantiation
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return ZL_ELIMIT;
-            done = true;
-        }
+        // every launch: the attribute is per device, and one process may drive several
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ZL_ELIMIT;
     }
 #ifdef ZL_PHASE_PROBE
     PhaseParams pp = p;

@@ -86,8 +86,9 @@ template <> __device__ __forceinline__ uint16_t from_f32<1>(float f) {
 template <int DT>
 __global__ __launch_bounds__(256) void k_ar(ArState* st, const uint16_t* __restrict__ x, const uint16_t* __restrict__ residual,
                                             uint16_t* __restrict__ out, int64_t n, int64_t per) {
-    __shared__ unsigned s_epoch;
+    __shared__ unsigned s_epoch, s_timeout;
     const int c = blockIdx.x, world = st->world, rank = st->rank;
+    if (threadIdx.x == 0) s_timeout = 0;
     if (n * 2 > st->max_bytes) {                         // message larger than the slots: refuse (error word), touch nothing
         if (threadIdx.x == 0) atomicAdd(&st->err, 1u);
         return;
@@ -101,6 +102,9 @@ __global__ __launch_bounds__(256) void k_ar(ArState* st, const uint16_t* __restr
     for (int64_t i = i0 + (int64_t)threadIdx.x * 8; i < i1; i += 256 * 8)
         *reinterpret_cast<uint4*>(mine + i) = *reinterpret_cast<const uint4*>(x + i);
     __atomic_thread_fence(__ATOMIC_RELEASE);            // system scope: the rows are in memory before any flag
+    // (ROCm 7.2 may drop the s_waitcnt vmcnt(0) behind buffer_wbl2 when it can prove this wave's scoreboard empty; inline asm is
+    //  invisible to that pass -- MI355X_MICROARCH.md, "compiler hazard")
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if ((int)threadIdx.x < world && (int)threadIdx.x != rank)
         __hip_atomic_store(flags_of(st, (int)threadIdx.x) + rank * kMaxChunks + c, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(256) void k_ar(ArState* st, const uint16_t* __restr
             __builtin_amdgcn_s_sleep(1);
             if (++polls > kMaxPolls) {
                 atomicAdd(&st->err, 1u);
+                s_timeout = 1;                          // benign race: every writer stores 1
                 break;
             }
         }
@@ -141,6 +146,13 @@ __global__ __launch_bounds__(256) void k_ar(ArState* st, const uint16_t* __restr
         uint16_t o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = from_f32<DT>(acc[j]);
+        if (s_timeout) {
+            // a peer never published this chunk within the bounded wait: the sum would be silently wrong (and the ranks would
+            // diverge) -- poison it instead, so that it cannot pass unnoticed (NaN propagates into the logits); zl_ar_status
+            // reports the count
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = DT == ZL_F16 ? (uint16_t)0x7e00 : (uint16_t)0x7fc0;
+        }
         if (residual) {
             const uint4 rv = *reinterpret_cast<const uint4*>(residual + i);
             const uint32_t ru[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -254,11 +266,9 @@ int64_t zl_ar_state_bytes(void) { return (int64_t)sizeof(ArState); }
 int zl_ar_alloc(int64_t bytes, void** out) {
     ZL_CHECK_ARG(out && bytes > 0, ZL_EINVAL);
     void* p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        ZL_HIP(hipMalloc(&p, (size_t)bytes));
-    }
+    // fine-grained (peer-coherent) memory or nothing: flags and rows in a coarse-grained allocation are not guaranteed to become
+    // visible to the peers inside a launch
+    ZL_HIP(hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained));
     ZL_HIP(hipMemset(p, 0, (size_t)bytes));
     ZL_HIP(hipDeviceSynchronize());
     *out = p;

@@ -1,3 +1,4 @@
+#include <vector>
 // bm_hip.cpp -- storage, tensors and the per-device context behind bm_hip.h (HIP runtime only; no torch, no BLAS).
 #include "bm_hip.h"
 
@@ -241,8 +242,10 @@ public:
     long next_id = 0;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    std::vector<void*> retired;                      // outgrown scratch blocks, alive as long as the context
     ~ContextImpl() {
         if (scratch) (void)hipFree(scratch);
+        for (void* p : retired) (void)hipFree(p);
     }
 };
 const std::string Context::EMPTY_STR;
@@ -314,10 +317,8 @@ void* Context::scratch(size_t bytes) const {
         void* p = nullptr;
         BM_HIPRT_ASSERT(hipMalloc(&p, want));
         BM_HIPRT_ASSERT(hipMemset(p, 0, want));
-        if (pimpl->scratch) {
-            BM_HIPRT_ASSERT(hipDeviceSynchronize());
-            (void)hipFree(pimpl->scratch);
-        }
+        // an outgrown block is retired, not freed: a hipGraph captured earlier has its address in the K-split launches
+        if (pimpl->scratch) pimpl->retired.push_back(pimpl->scratch);
         pimpl->scratch = p;
         pimpl->scratch_bytes = want;
     }

@@ -329,6 +329,7 @@ def _attn_algo():
 
 
 _SCRATCH = {}
+_SCRATCH_RETIRED = []   # outgrown scratch buffers, kept alive for the graphs that captured them
 # tuning overrides of the W4A16 launchers: read HERE, on the host side, per call (the C ABI reads no environment); the
 # tests and micro-benchmarks sweep them
 _W4_ENV = (("phase_rounds", "ZL_W4_PHASE_ROUNDS"), ("phase_ksplit", "ZL_W4_PHASE_KSPLIT"), ("phase_ksplit_min_m", "ZL_W4_PHASE_KSPLIT_MINM"),
@@ -349,10 +350,18 @@ def w4_scratch(device, m, n):
         if torch.cuda.is_current_stream_capturing():
             return buf                                 # too small during capture: the launchers take their unsplit routes
         if buf is not None:
-            torch.cuda.synchronize(device)             # work enqueued on the old buffer finishes before it goes away
+            # a buffer that has been handed out is NEVER freed: a hipGraph captured earlier has its address baked into the
+            # K-split launches (arrival counters + fp32 partials) and would scribble over whatever the allocator put there next
+            _SCRATCH_RETIRED.append(buf)
         buf = torch.zeros(max(need, 64 << 20), dtype=torch.uint8, device=device)
         _SCRATCH[key] = buf
     return buf
+
+
+def w4_scratch_reserve(device, m_max, n_max):
+    """size the device's K-split scratch once for the largest (rows, columns) any later call will ask for -- before capturing
+    graphs, so that no later growth retires the buffer they hold"""
+    return w4_scratch(device, m_max, n_max)
 
 
 def _w4_opts(device, m, n):

@@ -199,26 +199,45 @@ class DirectTPGroup(TPGroup):
     """TPGroup on the direct transports: RCCL communicator for the bandwidth-bound messages, the one-shot all-reduce (with the
     residual add fused) up to `oneshot_bytes`.  Bootstrapped over an existing torch.distributed group (gloo is enough)."""
 
-    def __init__(self, group=None, oneshot_bytes=1 << 20, device=None):
+    def __init__(self, group=None, oneshot_bytes=1 << 20, device=None, rccl=True):
+        """rccl=False: the one-shot exchange only (every collective of the decode step fits it; what two ranks sharing ONE GPU
+        can run -- RCCL refuses duplicate devices): larger messages then raise."""
         super().__init__(group=group)
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        src = dist.get_global_rank(group, 0) if group is not None else 0     # `src` of broadcast_object_list is a GLOBAL rank
 
         def bcast(b):
             box = [b]
-            dist.broadcast_object_list(box, src=0, group=group)
+            dist.broadcast_object_list(box, src=src, group=group)
             return box[0]
-        self.comm = RcclComm(self.rank, self.size, bcast)
+        self.comm = RcclComm(self.rank, self.size, bcast) if rccl else None
+        self.rccl_ranks = self.size if rccl else 0
         addr, _ = OneShotAllReduce.alloc(oneshot_bytes)
+        self._own_buffer = addr
         handles = [None] * self.size
         dist.all_gather_object(handles, OneShotAllReduce.export(addr), group=group)
         bufs = [addr if r == self.rank else OneShotAllReduce.open(handles[r]) for r in range(self.size)]
         self.oneshot = OneShotAllReduce(self.rank, self.size, bufs, oneshot_bytes, dev)
         self.oneshot_bytes = oneshot_bytes
 
+    def _need_rccl(self, what):
+        if self.comm is None:
+            from ._lib import ZLError
+            raise ZLError(f"DirectTPGroup(rccl=False): {what} does not fit the one-shot exchange")
+        return self.comm
+
     def all_reduce_sum(self, t):
         if t.numel() * 2 <= self.oneshot_bytes and t.numel() % 8 == 0 and t.dtype in (torch.float16, torch.bfloat16):
             return self.oneshot.all_reduce(t)
-        return self.comm.all_reduce_sum(t)
+        return self._need_rccl("this all-reduce").all_reduce_sum(t)
+
+    def check(self):
+        """raise if any one-shot exchange since the last check timed out (its output rows are NaN-poisoned by the kernel, so a
+        missed check cannot turn into silently wrong sums); synchronises the stream -- call between steps, not under capture"""
+        n = self.oneshot.status()
+        if n:
+            from ._lib import ZLError
+            raise ZLError(f"one-shot all-reduce: {n} bounded waits expired (a peer stalled for more than the kernel's poll budget)")
 
     def all_reduce_add(self, part, hidden):
         """hidden <- hidden + sum over ranks of part, in place (block.cpp:123-140); fused into the one-shot launch when it fits"""
@@ -227,5 +246,19 @@ class DirectTPGroup(TPGroup):
         return None
 
     def all_gather_columns(self, t):
+        if self.comm is None:
+            # one-shot only: a gather is the sum of the ranks' zero-padded slices (adding zeros is exact)
+            rows, n = t.shape[0], t.shape[-1]
+            wide = torch.zeros(rows, self.size * n, dtype=t.dtype, device=t.device)
+            wide[:, self.rank * n:(self.rank + 1) * n] = t
+            if wide.numel() * 2 > self.oneshot_bytes or wide.numel() % 8:
+                self._need_rccl("this all-gather")
+            return self.oneshot.all_reduce(wide)
         parts = self.comm.all_gather(t.contiguous())
         return torch.cat(list(parts), dim=-1)
+
+    def close(self):
+        """release the exchange buffer (peers must have stopped using it) and the communicator"""
+        if getattr(self, "_own_buffer", None):
+            _comm().zl_ar_free(_C.c_void_p(self._own_buffer))
+            self._own_buffer = None
