@@ -240,6 +240,23 @@ int zl_greedy_advance(const void* argmax_ws, int64_t m, int64_t n, int32_t* toke
 
 
 /* ------------------------------------------------------------------------------------------------
+ * a20 (second half)  INT8-compressed tensor-parallel reduce: the three kernels ModelContext::reduce_tp_int8
+ * (src/model/model_context.cpp:244-326, REDUCE_TP_INT8_THRES) runs around its send / recv rounds --
+ * int8_op::quant_group_32, dequant_sum_quant_g32, dequant_group_32 (src/nn/quant/int8/quant_kernel.h:95-128,
+ * quant_reduce_kernel.cu:13-105, 270-330, 107-150).  Values in groups of 32: code = rint(v * 127 / absmax), scale =
+ * T(absmax / 127); the owner of a slice adds its OWN unquantised rows to the peers' dequantised codes (in the order the
+ * caller stacks them: rank + 1, rank + 2, ... mod world), re-quantises the sum, and every rank dequantises what it gathers.
+ * Bit-exact restatements (integer codes and T scales); world_size in {2, 4, 8} like the reference.  The exchange rounds
+ * themselves are zl_comm_send / zl_comm_recv inside zl_comm_group_start / _end (include/zhilight_amd_comm.h):
+ * zhilight_amd/parallel.py::DirectTPGroup.reduce_tp_int8 composes them.
+ * ---------------------------------------------------------------------------------------------- */
+int zl_quant_group_32(const uint16_t* x, int8_t* q, uint16_t* scale, int64_t groups, int dtype, zl_stream_t s);
+int zl_dequant_sum_quant_g32(const uint16_t* my /* (groups, 32) */, const int8_t* q_others /* (world - 1, groups, 32) */,
+                             const uint16_t* scale_others /* (world - 1, groups) */, int8_t* q_sum, uint16_t* scale_sum,
+                             int64_t groups, int world_size, int dtype, zl_stream_t s);
+int zl_dequant_group_32(const int8_t* q, const uint16_t* scale, uint16_t* out, int64_t groups, int dtype, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * a17  RMSNorm and fused residual-add + RMSNorm.
  * Replaces nn::LayerNorm::forward / fuse_add (src/nn/layernorm/layernorm.cu:408-432, 227-302).
  * out = T(v * rsqrt(mean(v^2)+eps) * w / scale), v = f32(x) (+ f32(x2); out_sum = T(v) if given).

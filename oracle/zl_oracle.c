@@ -1264,3 +1264,50 @@ void zlo_quant_scale_back_f32(const int32_t* c, const float* sx, const float* sy
     for (int64_t mm = 0; mm < m; ++mm)
         for (int64_t nn = 0; nn < n; ++nn) out[mm * n + nn] = zlo_f32_to_f16((float)c[mm * n + nn] * sx[mm] * sy[nn]);
 }
+
+/* ---- INT8-compressed tensor-parallel reduce: the three kernels of ModelContext::reduce_tp_int8
+ * (src/model/model_context.cpp:244-326; src/nn/quant/int8/quant_reduce_kernel.cu:13-105, 107-150, 270-330).  TEST INFRASTRUCTURE.
+ *   quant_group_32:        per group of 32: abs_max = max |v| (exact: warpReduceMaxB<T> of values that ARE T);
+ *                          q = int8(nearbyintf(v * 127.0f / abs_max)) [fmul, then fdiv]; scale = T(abs_max / 127.0f)
+ *   dequant_sum_quant_g32: sum = f32(my); for r < WS - 1: sum = fmaf(f32(q_r), f32(T scale_r), sum) (nvcc contracts `sum += a * b`);
+ *                          abs_max = max over the group of T(|sum|) -- the template argument of warpReduceMaxB<T> rounds the fp32
+ *                          magnitude to T first; q = int8(nearbyintf(sum * 127.0f / abs_max)); scale = T(abs_max / 127.0f)
+ *   dequant_group_32:      out = T(f32(q) * f32(scale))
+ * A group of zeros divides by zero in the reference (NaN codes); here: codes 0, scale 0 (documented deviation, never hit by
+ * real activations). */
+void zlo_quant_group_32(const uint16_t* x, int8_t* q, uint16_t* scale, int64_t groups, int dtype) {
+    for (int64_t g = 0; g < groups; ++g) {
+        float amax = 0.f;
+        for (int i = 0; i < 32; ++i) {
+            float v = fabsf(T2f(x[g * 32 + i], dtype));
+            amax = v > amax ? v : amax;
+        }
+        for (int i = 0; i < 32; ++i) {
+            float v = T2f(x[g * 32 + i], dtype);
+            q[g * 32 + i] = amax > 0.f ? (int8_t)nearbyintf(v * 127.0f / amax) : 0;
+        }
+        scale[g] = f2T(amax / 127.0f, dtype);
+    }
+}
+
+void zlo_dequant_sum_quant_g32(const uint16_t* my, const int8_t* q_others, const uint16_t* scale_others, int8_t* out_q,
+                               uint16_t* out_scale, int64_t groups, int world, int dtype) {
+    for (int64_t g = 0; g < groups; ++g) {
+        float sum[32], amax = 0.f;
+        for (int i = 0; i < 32; ++i) {
+            float s = T2f(my[g * 32 + i], dtype);
+            for (int r = 0; r < world - 1; ++r)
+                s = fmaf((float)q_others[(r * groups + g) * 32 + i], T2f(scale_others[r * groups + g], dtype), s);
+            sum[i] = s;
+            float a = T2f(f2T(fabsf(s), dtype), dtype);
+            amax = a > amax ? a : amax;
+        }
+        for (int i = 0; i < 32; ++i) out_q[g * 32 + i] = amax > 0.f ? (int8_t)nearbyintf(sum[i] * 127.0f / amax) : 0;
+        out_scale[g] = f2T(amax / 127.0f, dtype);
+    }
+}
+
+void zlo_dequant_group_32(const int8_t* q, const uint16_t* scale, uint16_t* out, int64_t groups, int dtype) {
+    for (int64_t g = 0; g < groups; ++g)
+        for (int i = 0; i < 32; ++i) out[g * 32 + i] = f2T((float)q[g * 32 + i] * T2f(scale[g], dtype), dtype);
+}

@@ -181,6 +181,12 @@ void zlo_awq_gemm_exact(const uint16_t* x, const uint16_t* w16, double* y, int64
 void zlo_w4a8_weight_to_int8(const uint16_t* w16, int8_t* w8, float* scale, int64_t n, int64_t k);
 void zlo_quant_scale_back_f32(const int32_t* c, const float* sx, const float* sy, uint16_t* out, int64_t m, int64_t n);
 
+/* INT8-compressed tensor-parallel reduce (quant_reduce_kernel.cu) */
+void zlo_quant_group_32(const uint16_t* x, int8_t* q, uint16_t* scale, int64_t groups, int dtype);
+void zlo_dequant_sum_quant_g32(const uint16_t* my, const int8_t* q_others, const uint16_t* scale_others, int8_t* out_q,
+                               uint16_t* out_scale, int64_t groups, int world, int dtype);
+void zlo_dequant_group_32(const int8_t* q, const uint16_t* scale, uint16_t* out, int64_t groups, int dtype);
+
 #ifdef __cplusplus
 }
 #endif

@@ -530,3 +530,47 @@ def quant_scale_back_f32(c, sx, sy):
     out = np.empty((m, n), np.uint16)
     lib().zlo_quant_scale_back_f32(_p(c), _p(sx), _p(sy), _p(out), _i(m), _i(n))
     return out
+
+
+# ---- INT8-compressed tensor-parallel reduce (model_context.cpp:244-326, quant_reduce_kernel.cu)
+def quant_group_32(x, dtype=0):
+    x = _c(x, np.uint16)
+    groups = x.size // 32
+    q, s = np.empty(x.shape, np.int8), np.empty(groups, np.uint16)
+    lib().zlo_quant_group_32(_p(x), _p(q), _p(s), _i(groups), C.c_int(dtype))
+    return q, s
+
+
+def dequant_sum_quant_g32(my, q_others, scale_others, dtype=0):
+    """my (M, 32) T bits; q_others (WS - 1, M, 32) int8; scale_others (WS - 1, M) T bits -> (q_sum (M, 32), scale_sum (M))"""
+    my, q_others, scale_others = _c(my, np.uint16), _c(q_others, np.int8), _c(scale_others, np.uint16)
+    groups, world = my.size // 32, q_others.shape[0] + 1
+    q, s = np.empty(my.shape, np.int8), np.empty(groups, np.uint16)
+    lib().zlo_dequant_sum_quant_g32(_p(my), _p(q_others), _p(scale_others), _p(q), _p(s), _i(groups), C.c_int(world), C.c_int(dtype))
+    return q, s
+
+
+def dequant_group_32(q, scale, dtype=0):
+    q, scale = _c(q, np.int8), _c(scale, np.uint16)
+    out = np.empty(q.shape, np.uint16)
+    lib().zlo_dequant_group_32(_p(q), _p(scale), _p(out), _i(q.size // 32), C.c_int(dtype))
+    return out
+
+
+def reduce_tp_int8(parts, dtype=0):
+    """ModelContext::reduce_tp_int8 over `parts` (one (n,) T-bit array per rank, n % (32 * WS) == 0): what EVERY rank ends
+    with -- slice r of the result is rank r's own (unquantised) slice plus its peers' group-32 codes, re-quantised, then
+    dequantised; the peers enter the sum in the order of increasing rank distance (rank + 1, rank + 2, ... mod WS)."""
+    ws = len(parts)
+    n = parts[0].size
+    m = n // ws // 32
+    qs = [quant_group_32(p, dtype) for p in parts]
+    out = np.empty(n, np.uint16)
+    for r in range(ws):
+        lo, hi = r * m * 32, (r + 1) * m * 32
+        order = [(r + i + 1) % ws for i in range(ws - 1)]
+        qo = np.stack([qs[p][0].reshape(-1)[lo:hi].reshape(m, 32) for p in order])
+        so = np.stack([qs[p][1][r * m:(r + 1) * m] for p in order])
+        q_sum, s_sum = dequant_sum_quant_g32(np.ascontiguousarray(parts[r].reshape(-1)[lo:hi]).reshape(m, 32), qo, so, dtype)
+        out[lo:hi] = dequant_group_32(q_sum, s_sum, dtype).reshape(-1)
+    return out

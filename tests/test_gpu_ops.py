@@ -669,3 +669,84 @@ def test_caller_supplied_outputs_are_checked(dev):
         ops.gemm_nt_small_m(x, dw, out=torch.empty(2, 256, dtype=torch.float16, device=dev))
     ok = torch.empty(3, 256, dtype=torch.float16, device=dev)
     assert ops.w4a16_gemm_mfma(x, w, out=ok) is ok and ops.gemm_nt(x, dw, out=ok) is ok
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_int8_compressed_reduce_kernels_bit_exact(oracle, dev, world, dtype):
+    """int8_op::quant_group_32 / dequant_sum_quant_g32 / dequant_group_32 (quant_reduce_kernel.cu:13-105, 270-330, 107-150): codes
+    and T scales bit for bit against the oracle's restatement, incl. a group of zeros and magnitudes that round up in T."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(90 + world + dtype)
+    groups = 8 * world * 5 + 3
+    x = (rng.standard_normal((groups, 32)) * rng.uniform(0.01, 30.0, (groups, 1))).astype(np.float32)
+    x[1] = 0.0
+    xb = _to_bits(x, dtype, oracle)
+    q_ref, s_ref = oracle.quant_group_32(xb, dtype)
+    q, s = ops.quant_group_32(_tt(xb, dev, dtype))
+    assert np.array_equal(_np(q), q_ref) and np.array_equal(_bits(s), s_ref)
+    qo = rng.integers(-127, 128, (world - 1, groups, 32), dtype=np.int8)
+    so = _to_bits(rng.uniform(1e-3, 0.3, (world - 1, groups)), dtype, oracle)
+    qs_ref, ss_ref = oracle.dequant_sum_quant_g32(xb, qo, so, dtype)
+    qs, ss = ops.dequant_sum_quant_g32(_tt(xb, dev, dtype), _t(qo, dev), _tt(so, dev, dtype))
+    assert np.array_equal(_np(qs), qs_ref) and np.array_equal(_bits(ss), ss_ref)
+    out = ops.dequant_group_32(qs, ss)
+    assert np.array_equal(_bits(out), oracle.dequant_group_32(qs_ref, ss_ref, dtype))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_reduce_tp_int8_composition(oracle, dev, world):
+    """DirectTPGroup.reduce_tp_int8 (ModelContext::reduce_tp_int8, model_context.cpp:244-326) with the RCCL send / recv rounds
+    replaced by an in-process mailbox (all ranks on this one GPU, run in lock step): every rank ends with the oracle's
+    composition of the reference's steps, bit for bit, and within int8 noise of the exact sum."""
+    import threading
+    from zhilight_amd.parallel import DirectTPGroup
+    rng = np.random.default_rng(5 + world)
+    rows, n = 4, 32 * world * 6
+    parts = [_to_bits(rng.standard_normal((rows, n)), 0, oracle) for _ in range(world)]
+    want = oracle.reduce_tp_int8([p.reshape(-1) for p in parts], 0).reshape(rows, n)
+    box, lock, bar = {}, threading.Lock(), threading.Barrier(world)
+
+    class MailComm:
+        def __init__(self, rank):
+            self.rank, self.pending = rank, []
+
+        def send(self, t, peer):
+            with lock:
+                box.setdefault((self.rank, peer), []).append(t.clone())
+
+        def recv(self, t, peer):
+            self.pending.append((t, peer))
+
+        def group_start(self):
+            self.pending = []
+
+        def group_end(self):
+            torch.cuda.synchronize()
+            bar.wait()                                   # every send of this round is posted
+            for t, peer in self.pending:
+                with lock:
+                    t.copy_(box[(peer, self.rank)].pop(0))
+            torch.cuda.synchronize()
+            bar.wait()
+
+    outs, errs = [None] * world, []
+
+    def run(r):
+        try:
+            g = DirectTPGroup.__new__(DirectTPGroup)
+            g.rank, g.size, g.comm = r, world, MailComm(r)
+            outs[r] = _bits(g.reduce_tp_int8(_tt(parts[r], dev, 0)))
+        except Exception as e:       # pragma: no cover
+            errs.append(e)
+            bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    for r in range(world):
+        assert np.array_equal(outs[r], want), r
+    exact = sum(oracle.u2h(p).astype(np.float64) for p in parts)
+    assert np.abs(oracle.u2h(want).astype(np.float64) - exact).max() <= 0.02 * np.abs(exact).max()

@@ -167,3 +167,22 @@ def test_moe_oracle_against_the_definition(oracle):
             want_dn += w * oracle.gptq_gemm_k_major_exact(oracle.h2u(a[mm, t:t + 1]), *dl[ex])[0]
         assert np.abs(dn[mm] - want_dn).max() <= 3e-3 * max(1.0, np.abs(want_dn).max())
         assert np.abs(dn_add[mm] - (want_dn + base[mm].astype(np.float64))).max() <= 4e-3 * max(1.0, np.abs(want_dn).max())
+
+
+def test_reduce_tp_int8_oracle_properties(oracle):
+    """The restated INT8-compressed reduce (model_context.cpp:244-326): within int8 noise of the exact sum, every group's codes
+    reach +-127, a zero group stays zero, and the result does not depend on which rank evaluates it (the oracle composes the
+    owner's view of every slice)."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    for ws in (2, 4, 8):
+        n = 32 * ws * 5
+        parts = [oracle.h2u(rng.standard_normal(n).astype(np.float16)) for _ in range(ws)]
+        for p in parts:
+            p[:32] = 0
+        out = oracle.u2h(oracle.reduce_tp_int8(parts)).astype(np.float64)
+        exact = sum(oracle.u2h(p).astype(np.float64) for p in parts)
+        assert np.all(out[:32] == 0)
+        assert np.abs(out - exact).max() <= (ws + 1) / 127.0 * np.abs(exact).max()
+        q, s = oracle.quant_group_32(parts[0])
+        assert np.abs(q.reshape(-1, 32)[1:]).max(axis=1).min() == 127

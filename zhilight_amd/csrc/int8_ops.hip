@@ -565,3 +565,94 @@ int zl_quant_back_copy_to_buffer(const int32_t* src, const float* scale_x, const
 }
 
 }  // extern "C"
+
+// ---- INT8-compressed tensor-parallel reduce: the kernels of ModelContext::reduce_tp_int8 (src/model/model_context.cpp:244-326;
+//      src/nn/quant/int8/quant_reduce_kernel.cu:13-105 quant_group_32, :107-150 dequant_group_32, :270-330
+//      dequant_sum_quant_g32).  One group of 32 values per half wavefront (the reference: one warp per group), 8 groups per
+//      workgroup; bit-exact against the oracle's restatement (tests/test_gpu_ops.py).  A group of zeros: codes 0, scale 0 (the
+//      reference divides by zero).
+namespace {
+
+__device__ __forceinline__ float half_wave_max(float v) {   // all-reduce over the 32 lanes of a group
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 32));
+    return v;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_quant_group_32(const uint16_t* __restrict__ x, int8_t* __restrict__ q,
+                                                        uint16_t* __restrict__ scale, int64_t groups) {
+    const int64_t g = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (g >= groups) return;
+    const int i = threadIdx.x & 31;
+    const float v = ZT<DT>::to_f32(x[g * 32 + i]);
+    const float amax = half_wave_max(fabsf(v));
+    float t = v * 127.0f;
+    asm volatile("" : "+v"(t));                                  // the product is rounded to fp32 before the division
+    q[g * 32 + i] = amax > 0.f ? (int8_t)nearbyintf(t / amax) : (int8_t)0;
+    if (i == 0) scale[g] = ZT<DT>::from_f32(amax / 127.0f);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_dequant_sum_quant_g32(const uint16_t* __restrict__ my, const int8_t* __restrict__ q_others,
+                                                               const uint16_t* __restrict__ scale_others, int8_t* __restrict__ out_q,
+                                                               uint16_t* __restrict__ out_scale, int64_t groups, int world) {
+    const int64_t g = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (g >= groups) return;
+    const int i = threadIdx.x & 31;
+    float sum = ZT<DT>::to_f32(my[g * 32 + i]);
+    for (int r = 0; r < world - 1; ++r)
+        sum = __builtin_fmaf((float)q_others[((int64_t)r * groups + g) * 32 + i], ZT<DT>::to_f32(scale_others[(int64_t)r * groups + g]), sum);
+    // warpReduceMaxB<T>(fabsf(sum)): the fp32 magnitude is rounded to T by the template argument before the maximum
+    const float amax = half_wave_max(ZT<DT>::to_f32(ZT<DT>::from_f32(fabsf(sum))));
+    float t = sum * 127.0f;
+    asm volatile("" : "+v"(t));
+    out_q[g * 32 + i] = amax > 0.f ? (int8_t)nearbyintf(t / amax) : (int8_t)0;
+    if (i == 0) out_scale[g] = ZT<DT>::from_f32(amax / 127.0f);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_dequant_group_32(const int8_t* __restrict__ q, const uint16_t* __restrict__ scale,
+                                                          uint16_t* __restrict__ out, int64_t groups) {
+    const int64_t g = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (g >= groups) return;
+    const int i = threadIdx.x & 31;
+    out[g * 32 + i] = ZT<DT>::from_f32((float)q[g * 32 + i] * ZT<DT>::to_f32(scale[g]));
+}
+
+}  // namespace
+
+extern "C" {
+
+int zl_quant_group_32(const uint16_t* x, int8_t* q, uint16_t* scale, int64_t groups, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(x && q && scale && groups > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    const dim3 grid((unsigned)((groups + 7) / 8));
+    if (dtype == ZL_F16) hipLaunchKernelGGL(k_quant_group_32<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, x, q, scale, groups);
+    else hipLaunchKernelGGL(k_quant_group_32<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, x, q, scale, groups);
+    return zl_launch_status();
+}
+
+int zl_dequant_sum_quant_g32(const uint16_t* my, const int8_t* q_others, const uint16_t* scale_others, int8_t* q_sum,
+                             uint16_t* scale_sum, int64_t groups, int world_size, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(my && q_others && scale_others && q_sum && scale_sum && groups > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(world_size == 2 || world_size == 4 || world_size == 8, ZL_ESHAPE);     // the reference's instantiations
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    const dim3 grid((unsigned)((groups + 7) / 8));
+    if (dtype == ZL_F16)
+        hipLaunchKernelGGL(k_dequant_sum_quant_g32<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, my, q_others, scale_others, q_sum, scale_sum, groups, world_size);
+    else
+        hipLaunchKernelGGL(k_dequant_sum_quant_g32<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, my, q_others, scale_others, q_sum, scale_sum, groups, world_size);
+    return zl_launch_status();
+}
+
+int zl_dequant_group_32(const int8_t* q, const uint16_t* scale, uint16_t* out, int64_t groups, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(q && scale && out && groups > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    const dim3 grid((unsigned)((groups + 7) / 8));
+    if (dtype == ZL_F16) hipLaunchKernelGGL(k_dequant_group_32<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, q, scale, out, groups);
+    else hipLaunchKernelGGL(k_dequant_group_32<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, q, scale, out, groups);
+    return zl_launch_status();
+}
+
+}  // extern "C"

@@ -699,6 +699,14 @@ class EncoderLayer:
         """hidden += sum over TP ranks of lin(x): ModelContext::reduce_sum on the fp16 partial outputs, then the
         residual add in T arithmetic (src/nn/block/block.cpp:123-140, src/model/model_context.cpp:203-242)"""
         part = self.row_partial(lin, x)
+        # REDUCE_TP_INT8_THRES (the reference's switch, model_context.cpp:221-227): above that many rows the partial sums travel
+        # as group-32 int8 codes (ModelContext::reduce_tp_int8)
+        thres = int(os.environ.get("REDUCE_TP_INT8_THRES", "0") or 0)
+        compressed = getattr(self.tp, "reduce_tp_int8", None)
+        if thres > 0 and compressed is not None and part.shape[0] > thres and part.numel() % (32 * self.tp.size) == 0 \
+                and getattr(self.tp, "comm", None) is not None:
+            ops.element_add_scale(hidden, compressed(part), 1.0, True, out=hidden)
+            return
         fused = getattr(self.tp, "all_reduce_add", None)
         if fused is not None and fused(part, hidden) is not None:      # one-shot all-reduce with the residual add in its launch
             return

@@ -1128,3 +1128,35 @@ def w4a8_linear(x, w8, w_scale, out=None):
     on the matrix cores, scale back with the fp32 weight scale."""
     xq, sx = quant_calc_scale(x)
     return quant_scale_back_f32(int8_gemm_nt(xq, w8), sx, w_scale, out=out)
+
+
+# ---- INT8-compressed tensor-parallel reduce (ModelContext::reduce_tp_int8, src/model/model_context.cpp:244-326)
+def quant_group_32(x):
+    """int8_op::quant_group_32: x (..., 32 * g) T -> (codes int8 same shape, scales T (groups,))"""
+    _chk_cuda(x)
+    if x.numel() % 32:
+        raise ZLError("[quant_group_32]")
+    groups = x.numel() // 32
+    q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    s = torch.empty(groups, dtype=x.dtype, device=x.device)
+    check(lib().zl_quant_group_32(_p(x), _p(q), _p(s), _i(groups), C.c_int(_dt(x)), _stream()), "quant_group_32")
+    return q, s
+
+
+def dequant_sum_quant_g32(my, q_others, scale_others):
+    """int8_op::dequant_sum_quant_g32: my (M, 32) T, q_others (WS - 1, M, 32) int8, scale_others (WS - 1, M) T"""
+    _chk_cuda(my, q_others, scale_others)
+    groups, world = my.numel() // 32, q_others.shape[0] + 1
+    q = torch.empty(my.shape, dtype=torch.int8, device=my.device)
+    s = torch.empty(groups, dtype=my.dtype, device=my.device)
+    check(lib().zl_dequant_sum_quant_g32(_p(my), _p(q_others), _p(scale_others), _p(q), _p(s), _i(groups), C.c_int(world),
+                                         C.c_int(_dt(my)), _stream()), "dequant_sum_quant_g32")
+    return q, s
+
+
+def dequant_group_32(q, scale, out=None):
+    _chk_cuda(q, scale)
+    if out is None:
+        out = torch.empty(q.shape, dtype=scale.dtype, device=q.device)
+    check(lib().zl_dequant_group_32(_p(q), _p(scale), _p(out), _i(q.numel() // 32), C.c_int(_dt(scale)), _stream()), "dequant_group_32")
+    return out
