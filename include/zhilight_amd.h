@@ -240,6 +240,20 @@ int zl_greedy_advance(const void* argmax_ws, int64_t m, int64_t n, int32_t* toke
 
 
 /* ------------------------------------------------------------------------------------------------
+ * a2 (W4A8, FP8 activations)  gptq_gemm_k_major's W4_FP8_ALGO branch (src/nn/quant/gptq/q_gemm_k_major.cu:1003-1035) for
+ * M > W4_A8_M_THRES rows: nn::fp8::calc_scale (one fp32 scale per tensor = max|x| / MAX, src/nn/quant/fp8/fp8_util.cu:100-195),
+ * nn::fp8::dynamic_scaled_quant's cast (OCP E4M3FN codes of T(x) * T(1 / scale), round to nearest even, saturating at 448;
+ * :56-78, 197-229) -- the same two calls on the dequantised weight matrix give Int4GPTQ::calc_w4a8_scale + KERNEL_dequant<half, 2>
+ * (linear.cpp:1124-1129, q_gemm_k_major.cu:843-906; MAX_WEIGHT_E4M3 = 256, MAX_ACT_E4M3 = 448) -- and the fp8 x fp8 GEMM with
+ * fp32 accumulation scaled by scale_a * scale_b (functions::Gemm kFP8_E4M3, cuBLASLt there; v_mfma_f32_16x16x32_fp8_fp8 here).
+ * K % 64 == 0.  `scale` is a DEVICE pointer throughout (no synchronisation).
+ * ---------------------------------------------------------------------------------------------- */
+int zl_fp8_calc_scale(const uint16_t* x, int64_t numel, float max_e4m3, float* scale, int dtype, zl_stream_t s);
+int zl_fp8_cvt_half(const uint16_t* x, const float* scale, uint8_t* out, int64_t numel, int dtype, zl_stream_t s);
+int zl_fp8_gemm_nt(const uint8_t* a /* (M, K) */, const uint8_t* b /* (N, K) */, const float* scale_a, const float* scale_b,
+                   uint16_t* out /* (M, N) fp16 */, int64_t m, int64_t n, int64_t k, zl_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * a20 (second half)  INT8-compressed tensor-parallel reduce: the three kernels ModelContext::reduce_tp_int8
  * (src/model/model_context.cpp:244-326, REDUCE_TP_INT8_THRES) runs around its send / recv rounds --
  * int8_op::quant_group_32, dequant_sum_quant_g32, dequant_group_32 (src/nn/quant/int8/quant_kernel.h:95-128,

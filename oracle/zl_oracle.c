@@ -1311,3 +1311,70 @@ void zlo_dequant_group_32(const int8_t* q, const uint16_t* scale, uint16_t* out,
     for (int64_t g = 0; g < groups; ++g)
         for (int i = 0; i < 32; ++i) out[g * 32 + i] = f2T((float)q[g * 32 + i] * T2f(scale[g], dtype), dtype);
 }
+
+/* ---- W4A8 with FP8 activations: gptq_gemm_k_major's W4_FP8_ALGO branch (src/nn/quant/gptq/q_gemm_k_major.cu:1003-1035) and
+ * nn::fp8::calc_scale / dynamic_scaled_quant (src/nn/quant/fp8/fp8_util.cu:20-29, 56-78, 100-229); weights through
+ * KERNEL_dequant<half, 2> (q_gemm_k_major.cu:843-906) with Int4GPTQ::calc_w4a8_scale's per-tensor scale
+ * (src/nn/linear/linear.cpp:1124-1129).  TEST INFRASTRUCTURE.
+ *   e4m3 = OCP E4M3FN (bias 7, 3 mantissa bits, no infinities, 0x7f = NaN, largest finite 448 = 0x7e); the reference converts
+ *   with cvt.rn.satfinite.e4m3x2.f16x2: round to nearest even on the e4m3 grid, magnitudes beyond 448 saturate to 448.
+ *   scale = max|x| / MAX (one fp32 per tensor); code = e4m3(T(x) * T(1 / scale)) -- the product is an fp16 hmul2 for fp16
+ *   inputs (one rounding to fp16 before the conversion) and an fp32 product rounded to fp16 for bf16 inputs.
+ *   GEMM: fp32 accumulation of exact fp8 x fp8 products (cuBLASLt), times scale_a * scale_b, one rounding to fp16; the
+ *   accumulation ORDER is the library's -- the oracle sums in fp64 and the parity bar is the fp16 output rounding. */
+uint8_t zlo_f32_to_e4m3(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    const uint32_t au = u & 0x7fffffffu;
+    if (au > 0x7f800000u) return (uint8_t)(sign | 0x7fu);              /* NaN */
+    float a;
+    memcpy(&a, &au, 4);
+    if (a >= 464.0f) return (uint8_t)(sign | 0x7eu);                   /* beyond the midpoint of 448 and the next grid point: satfinite */
+    if (a < 0.015625f) {                                               /* below 2^-6: subnormal grid of 2^-9 */
+        return (uint8_t)(sign | (uint8_t)nearbyintf(a * 512.0f));      /* 8 = the smallest normal: same code */
+    }
+    uint32_t r = au + 0x7ffffu + ((au >> 20) & 1u);                    /* RNE at bit 20 (3 mantissa bits kept) */
+    const int e = (int)(r >> 23) - 127 + 7;
+    uint32_t code = ((uint32_t)e << 3) | ((r >> 20) & 7u);
+    if (code > 0x7eu) code = 0x7eu;
+    return (uint8_t)(sign | code);
+}
+
+float zlo_e4m3_to_f32(uint8_t c) {
+    const int e = (c >> 3) & 15, m = c & 7;
+    float v;
+    if ((c & 0x7f) == 0x7f) v = NAN;
+    else if (e == 0) v = ldexpf((float)m, -9);
+    else v = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+    return (c & 0x80) ? -v : v;
+}
+
+void zlo_fp8_calc_scale(const uint16_t* x, int64_t numel, float max_e4m3, float* scale, int dtype) {
+    float amax = 0.f;
+    for (int64_t i = 0; i < numel; ++i) {
+        float v = fabsf(T2f(x[i], dtype));
+        amax = v > amax ? v : amax;
+    }
+    *scale = amax / max_e4m3;
+}
+
+void zlo_fp8_cvt_half(const uint16_t* x, int64_t numel, float scale, uint8_t* out, int dtype) {
+    const float inv = 1.f / scale;
+    for (int64_t i = 0; i < numel; ++i) {
+        uint16_t h;
+        if (dtype) h = zlo_f32_to_f16(inv * zlo_bf16_to_f32(x[i]));                     /* __floats2half2_rn(scale * float(bf16)) */
+        else h = zlo_f32_to_f16(zlo_f16_to_f32(x[i]) * zlo_f16_to_f32(zlo_f32_to_f16(inv)));   /* __hmul2(h2, half2(scale)): exact product, one rounding */
+        out[i] = zlo_f32_to_e4m3(zlo_f16_to_f32(h));
+    }
+}
+
+void zlo_fp8_gemm_nt(const uint8_t* a, const uint8_t* b, float scale_a, float scale_b, uint16_t* out, int64_t m, int64_t n, int64_t k) {
+    #pragma omp parallel for
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < n; ++j) {
+            double acc = 0.0;
+            for (int64_t t = 0; t < k; ++t) acc += (double)zlo_e4m3_to_f32(a[i * k + t]) * (double)zlo_e4m3_to_f32(b[j * k + t]);
+            out[i * n + j] = zlo_f32_to_f16((float)(acc * ((double)scale_a * (double)scale_b)));
+        }
+}

@@ -181,6 +181,13 @@ void zlo_awq_gemm_exact(const uint16_t* x, const uint16_t* w16, double* y, int64
 void zlo_w4a8_weight_to_int8(const uint16_t* w16, int8_t* w8, float* scale, int64_t n, int64_t k);
 void zlo_quant_scale_back_f32(const int32_t* c, const float* sx, const float* sy, uint16_t* out, int64_t m, int64_t n);
 
+/* W4A8 with FP8 activations (q_gemm_k_major.cu:1003-1035, fp8_util.cu) */
+uint8_t zlo_f32_to_e4m3(float f);
+float zlo_e4m3_to_f32(uint8_t c);
+void zlo_fp8_calc_scale(const uint16_t* x, int64_t numel, float max_e4m3, float* scale, int dtype);
+void zlo_fp8_cvt_half(const uint16_t* x, int64_t numel, float scale, uint8_t* out, int dtype);
+void zlo_fp8_gemm_nt(const uint8_t* a, const uint8_t* b, float scale_a, float scale_b, uint16_t* out, int64_t m, int64_t n, int64_t k);
+
 /* INT8-compressed tensor-parallel reduce (quant_reduce_kernel.cu) */
 void zlo_quant_group_32(const uint16_t* x, int8_t* q, uint16_t* scale, int64_t groups, int dtype);
 void zlo_dequant_sum_quant_g32(const uint16_t* my, const int8_t* q_others, const uint16_t* scale_others, int8_t* out_q,

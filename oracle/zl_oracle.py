@@ -574,3 +574,40 @@ def reduce_tp_int8(parts, dtype=0):
         q_sum, s_sum = dequant_sum_quant_g32(np.ascontiguousarray(parts[r].reshape(-1)[lo:hi]).reshape(m, 32), qo, so, dtype)
         out[lo:hi] = dequant_group_32(q_sum, s_sum, dtype).reshape(-1)
     return out
+
+
+# ---- W4A8 with FP8 activations (q_gemm_k_major.cu:1003-1035; fp8_util.cu)
+def f32_to_e4m3(x):
+    x = np.ascontiguousarray(x, np.float32)
+    lib().zlo_f32_to_e4m3.restype = C.c_uint8
+    lib().zlo_f32_to_e4m3.argtypes = [C.c_float]
+    return np.array([lib().zlo_f32_to_e4m3(float(v)) for v in x.reshape(-1)], np.uint8).reshape(x.shape)
+
+
+def e4m3_to_f32(c):
+    c = np.ascontiguousarray(c, np.uint8)
+    e, m = ((c >> 3) & 15).astype(np.int32), (c & 7).astype(np.float64)
+    v = np.where(e == 0, m * 2.0 ** -9, (1.0 + m / 8.0) * 2.0 ** (e - 7.0))
+    v = np.where((c & 0x7f) == 0x7f, np.nan, v)
+    return np.where(c & 0x80, -v, v)
+
+
+def fp8_calc_scale(x, max_e4m3=448.0, dtype=0):
+    x = _c(x, np.uint16)
+    s = C.c_float()
+    lib().zlo_fp8_calc_scale(_p(x), _i(x.size), _f(max_e4m3), C.byref(s), C.c_int(dtype))
+    return s.value
+
+
+def fp8_cvt_half(x, scale, dtype=0):
+    x = _c(x, np.uint16)
+    out = np.empty(x.shape, np.uint8)
+    lib().zlo_fp8_cvt_half(_p(x), _i(x.size), _f(scale), _p(out), C.c_int(dtype))
+    return out
+
+
+def fp8_gemm_nt(a, b, scale_a, scale_b):
+    a, b = _c(a, np.uint8), _c(b, np.uint8)
+    out = np.empty((a.shape[0], b.shape[0]), np.uint16)
+    lib().zlo_fp8_gemm_nt(_p(a), _p(b), _f(scale_a), _f(scale_b), _p(out), _i(a.shape[0]), _i(b.shape[0]), _i(a.shape[1]))
+    return out

@@ -151,3 +151,52 @@ def test_awq_checkpoint_model_native_and_rerouted_routes(oracle, dev, monkeypatc
         # native route: W16 carries one more fp16 rounding (rn16(d s)) and the split partials another
         assert np.abs(outs[route] - ref).max() <= (1e-3 if route == "1" else 3e-3) * scale, (route, np.abs(outs[route] - ref).max() / scale)
     assert np.abs(outs["0"] - outs["1"]).max() <= 3e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_fp8_casts_bit_exact(oracle, dev, dtype):
+    """nn::fp8::calc_scale + T_KERNEL_cvt_half_fp8 (fp8_util.cu:56-78, 100-195): the per-tensor scale and every E4M3FN code equal
+    the oracle's (whose cast is pinned by an exhaustive nearest-even search over all fp16 values, tests/test_oracle_selfcheck.py);
+    subnormal codes, saturation at 448 and both activation types."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(17 + dtype)
+    x = (rng.standard_normal((67, 512)) * np.exp(rng.uniform(-9, 3, (67, 512)))).astype(np.float32)
+    x[0, :8] = [0.0, -0.0, 1e-4, -2e-3, 448.0, -470.0, 3e4, 0.0175]
+    bits = oracle.f32_to_bf16(x) if dtype else oracle.h2u(x.astype(np.float16))
+    tx = torch.from_numpy(bits.view(np.int16)).to(dev).view(torch.bfloat16 if dtype else torch.float16)
+    for mx in (448.0, 256.0):
+        s_ref = oracle.fp8_calc_scale(bits, mx, dtype)
+        codes, s = ops.fp8_dynamic_scaled_quant(tx, mx)
+        assert s.item() == s_ref
+        assert np.array_equal(codes.cpu().numpy(), oracle.fp8_cvt_half(bits, s_ref, dtype))
+    # a fixed scale of 1 exercises the saturation and the subnormal grid directly
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    assert np.array_equal(ops.fp8_cvt_half(tx, one).cpu().numpy(), oracle.fp8_cvt_half(bits, 1.0, dtype))
+
+
+@pytest.mark.parametrize("m,k,n", [(41, 1024, 1280), (64, 4096, 2048), (300, 2048, 1536)])
+def test_w4a8_fp8_branch(oracle, dev, m, k, n):
+    """gptq_gemm_k_major's W4_FP8 branch (M > W4_A8_M_THRES = 40, N > 1024; q_gemm_k_major.cu:1003-1035): weight codes and scale
+    (MAX_WEIGHT_E4M3 = 256) and activation codes and scale (MAX_ACT_E4M3 = 448) bit-identical to the oracle; the fp8 x fp8 product
+    with fp32 accumulation within fp16 output rounding of the fp64 sum of the same codes (the reference's accumulation order is
+    cuBLASLt's)."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(m + n + 1)
+    qw, qz, sc = synth.gptq_hf(rng, k, n, 128)
+    km = oracle.gptq_prepare_k_major(qw, qz, sc, 128)
+    w16 = oracle.gptq_dequant_k_major(*km)                                     # (N, K) fp16 bits
+    ws_ref = oracle.fp8_calc_scale(w16, 256.0)
+    w8_ref = oracle.fp8_cvt_half(w16, ws_ref)
+    w = ops.W4Weight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), 128)
+    w8, ws = ops.w4a8_weight_to_fp8(w.dequant())
+    assert ws.item() == ws_ref and np.array_equal(w8.cpu().numpy(), w8_ref)
+    x = synth.act(rng, m, k, 2.0)
+    xs_ref = oracle.fp8_calc_scale(oracle.h2u(x), 448.0)
+    a8_ref = oracle.fp8_cvt_half(oracle.h2u(x), xs_ref)
+    a8, sa = ops.fp8_dynamic_scaled_quant(_t(x, dev), 448.0)
+    assert sa.item() == xs_ref and np.array_equal(a8.cpu().numpy(), a8_ref)
+    y = ops.w4a8_fp8_linear(_t(x, dev), w8, ws).float().cpu().numpy().astype(np.float64)
+    ref = oracle.u2h(oracle.fp8_gemm_nt(a8_ref, w8_ref, xs_ref, ws_ref)).astype(np.float64)
+    assert (np.abs(y - ref) <= 2.0 ** -10 * np.abs(ref) + 1e-5 * np.abs(ref).max()).all()
+    exact = oracle.gemm_nt(oracle.h2u(x), w16, exact=True)
+    assert np.sqrt(((y - exact) ** 2).mean()) <= 0.08 * np.sqrt((exact ** 2).mean())   # what the mode trades: ~5 % rms (3-bit mantissas on both sides)

@@ -186,3 +186,26 @@ def test_reduce_tp_int8_oracle_properties(oracle):
         assert np.abs(out - exact).max() <= (ws + 1) / 127.0 * np.abs(exact).max()
         q, s = oracle.quant_group_32(parts[0])
         assert np.abs(q.reshape(-1, 32)[1:]).max(axis=1).min() == 127
+
+
+def test_e4m3_cast_against_the_format_definition(oracle):
+    """zlo_f32_to_e4m3 (cvt.rn.satfinite.e4m3x2.f16x2 restated) pinned by the OCP E4M3FN definition: for a dense sample of all
+    non-negative finite fp16 values the code is the nearest representable value (ties to the even code), saturating at 448; the
+    decode table is monotone and holds the format's landmarks."""
+    import numpy as np
+    codes = np.arange(0, 0x7f, dtype=np.uint8)
+    grid = oracle.e4m3_to_f32(codes)
+    assert grid[0] == 0 and grid[1] == 2.0 ** -9 and grid[8] == 2.0 ** -6 and grid[0x7e] == 448.0 and np.all(np.diff(grid) > 0)
+    assert np.isnan(oracle.e4m3_to_f32(np.array([0x7f], np.uint8))[0])
+    h = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16).astype(np.float64)[::11]
+    got = oracle.f32_to_e4m3(h.astype(np.float32))
+    for v, c in zip(h, got):
+        if v >= 464:
+            best = 0x7e
+        else:
+            d = np.abs(grid - v)
+            j = np.flatnonzero(d == d.min())
+            best = j[0] if len(j) == 1 else (j[0] if codes[j[0]] % 2 == 0 else j[1])
+        assert best == c, (v, c, best)
+    neg = oracle.f32_to_e4m3(np.array([-1.0, -500.0, -0.0], np.float32))
+    assert list(neg) == [0x80 | 0x38, 0x80 | 0x7e, 0x80]

@@ -1160,3 +1160,48 @@ def dequant_group_32(q, scale, out=None):
         out = torch.empty(q.shape, dtype=scale.dtype, device=q.device)
     check(lib().zl_dequant_group_32(_p(q), _p(scale), _p(out), _i(q.numel() // 32), C.c_int(_dt(scale)), _stream()), "dequant_group_32")
     return out
+
+
+# ---- W4A8 with FP8 activations (gptq_gemm_k_major, W4_FP8_ALGO: q_gemm_k_major.cu:1003-1035; fp8_util.cu)
+def fp8_calc_scale(x, max_e4m3=448.0):
+    """nn::fp8::calc_scale: a (1,) fp32 DEVICE tensor max|x| / max_e4m3"""
+    _chk_cuda(x)
+    s = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(lib().zl_fp8_calc_scale(_p(x), _i(x.numel()), _f(max_e4m3), _p(s), C.c_int(_dt(x)), _stream()), "fp8_calc_scale")
+    return s
+
+
+def fp8_cvt_half(x, scale):
+    """E4M3FN codes (uint8) of T(x) * T(1 / scale), round to nearest even, saturating (T_KERNEL_cvt_half_fp8)"""
+    _chk_cuda(x, scale)
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib().zl_fp8_cvt_half(_p(x), _p(scale), _p(out), _i(x.numel()), C.c_int(_dt(x)), _stream()), "fp8_cvt_half")
+    return out
+
+
+def fp8_dynamic_scaled_quant(x, max_e4m3=448.0):
+    """nn::fp8::dynamic_scaled_quant: (codes, scale)"""
+    s = fp8_calc_scale(x, max_e4m3)
+    return fp8_cvt_half(x, s), s
+
+
+def w4a8_weight_to_fp8(w16, max_weight_e4m3=256.0):
+    """Int4GPTQ::calc_w4a8_scale (W4_FP8_ALGO) + dequant_k_major(out_type 2): W16 (N, K) fp16 -> (w8 E4M3 codes, scale (1,) fp32)"""
+    return fp8_dynamic_scaled_quant(w16, max_weight_e4m3)
+
+
+def fp8_gemm_nt(a8, b8, scale_a, scale_b, out=None):
+    _chk_cuda(a8, b8, scale_a, scale_b)
+    m, k = a8.shape
+    n = b8.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float16, device=a8.device)
+    check(lib().zl_fp8_gemm_nt(_p(a8), _p(b8), _p(scale_a), _p(scale_b), _p(out), _i(m), _i(n), _i(k), _stream()), "fp8_gemm_nt")
+    return out
+
+
+def w4a8_fp8_linear(x, w8, w_scale, max_act_e4m3=448.0, out=None):
+    """gptq_gemm_k_major's W4_FP8 branch: per-tensor dynamic E4M3 quantisation of the activations, fp8 x fp8 GEMM, scales folded
+    into the fp32 accumulators, one rounding to fp16"""
+    a8, sa = fp8_dynamic_scaled_quant(x, max_act_e4m3)
+    return fp8_gemm_nt(a8, w8, sa, w_scale, out=out)
