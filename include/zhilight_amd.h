@@ -585,6 +585,42 @@ int zl_quant_back_copy_to_buffer(const int32_t* src, const float* scale_x, const
                                  int64_t dim_head, int64_t len_buf, int64_t src_stride, int64_t dst_stride,
                                  int64_t place_stride, int dtype, zl_stream_t s);
 
+/* ------------------------------------------------------------------------------------------------
+ * Load-time / glue tensor operations behind the bmengine::functions names the reference's layer code calls around its
+ * GEMMs (the headers under 3rd/bmengine/bmengine/include/bmengine/functions; hostcpp/bm_functions.h binds them).  Off the decode step's
+ * critical path.  Element type codes `zl_elem_t` are bmengine's DataType enumerators (core/dtype.h:12-22).
+ *   zl_cast               functions::typecast (typecast.h:7): out[i] = OutT(in[i]) (through fp32; fp32 -> half/bf16 RNE)
+ *   zl_copy_2d            rows of width_bytes between pitched buffers: functions::concat_tensor / slice_last_dim /
+ *                         copy_last_dim (tensor_ops.h:8-12, index_select.h:33-47)
+ *   zl_index_select       functions::index_select (index_select.h:8-14): out[o, j, :] = in[o, index[j], :]
+ *   zl_reduce_abs_max     functions::reduce_abs_max (arthmetic.cu:14-45): per row max |x| (fp32 compare, start -1e4)
+ *   zl_binary_op          functions::BinaryElementwiseOp (element.cu:44-150): op 0 add 1 sub 2 mul 3 div 4 max;
+ *                         bmode 0 same shape, 1 b has one value per row (broadcast over the last dim), 2 b is one row
+ *   zl_scale              nn::multiply (src/nn/functions/element.cu:11-31): c = a * T(b)
+ *   zl_act_inplace        nn::silu_inplace / gelu_inplace (src/nn/linear/activation_kernel.cu:14-57): act 0 silu, 1 gelu(tanh)
+ *   zl_count_nonfinite    functions::check_numeric: adds the number of NaN / Inf elements to *counter (device int32)
+ *   zl_perm_narrow_u16    nn::gptq::int32_to_int16 (src/nn/quant/gptq/utils.cu:253-283)
+ *   zl_perm_reverse_u16   nn::gptq::reverse_perm (utils.cu:287-319): out[perm[i]] = i
+ *   zl_gptq_permute_rows  the make_sequential half of nn::gptq::gptq_shuffle with a q_perm (src/nn/quant/gptq/q_gemm.cu: the rows
+ *                         of the (K/8, N) nibble matrix regrouped so that row i is the checkpoint's row perm[i]; perm =
+ *                         argsort(g_idx), every value in [0, K))
+ *   zl_permute_input_u16  nn::gptq::permute_input (utils.cu:323-395) with the 16-bit permutation the reference keeps
+ * ---------------------------------------------------------------------------------------------- */
+enum zl_elem_t { ZL_T_F64 = 0, ZL_T_F32 = 1, ZL_T_F16 = 2, ZL_T_I8 = 3, ZL_T_I16 = 4, ZL_T_I32 = 5, ZL_T_BF16 = 6 };
+int zl_cast(const void* in, int in_type, void* out, int out_type, int64_t n, zl_stream_t s);
+int zl_copy_2d(const void* src, int64_t src_pitch, void* dst, int64_t dst_pitch, int64_t width_bytes, int64_t rows, zl_stream_t s);
+int zl_index_select(const void* in, void* out, const int32_t* index, int64_t outer, int64_t dim_in, int64_t n_index,
+                    int64_t inner_bytes, zl_stream_t s);
+int zl_reduce_abs_max(const void* x, void* out, int64_t rows, int64_t cols, int type, zl_stream_t s);
+int zl_binary_op(const void* a, const void* b, void* c, int64_t rows, int64_t cols, int op, int bmode, int type, zl_stream_t s);
+int zl_scale(const void* in, void* out, int64_t n, float factor, int type, zl_stream_t s);
+int zl_act_inplace(void* x, int64_t n, int act, int type, zl_stream_t s);
+int zl_count_nonfinite(const void* x, int64_t n, int type, int32_t* counter, zl_stream_t s);
+int zl_perm_narrow_u16(const int32_t* perm, uint16_t* out, int64_t k, zl_stream_t s);
+int zl_perm_reverse_u16(const int32_t* perm, uint16_t* out, int64_t k, zl_stream_t s);
+int zl_gptq_permute_rows(const uint32_t* qweight, uint32_t* out, const int32_t* perm, int64_t k8, int64_t n, zl_stream_t s);
+int zl_permute_input_u16(const uint16_t* x, int64_t ldx, const uint16_t* perm, uint16_t* out, int64_t rows, int64_t k, zl_stream_t s);
+
 
 #ifdef __cplusplus
 }

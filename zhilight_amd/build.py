@@ -53,6 +53,7 @@ def build(force=False, verbose=False):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
     build_hostcpp(force, verbose)
     build_comm(force, verbose)
+    build_refcompile(force, verbose)
     return OUT
 
 
@@ -78,6 +79,10 @@ def build_comm(force=False, verbose=False):
 HOSTCPP = os.path.join(HERE, "hostcpp")
 
 
+HOSTCPP_SOURCES = ("bm_hip.cpp", "bm_layer.cpp", "bm_functions.cpp", "nn_amd.cpp")
+HOSTCPP_HEADERS = ("bm_hip.h", "bm_layer.h", "bm_functions.h", "nn_amd.h")
+
+
 def hostcpp_target():
     import sysconfig
     return os.path.join(HERE, "zl_internals" + sysconfig.get_config_var("EXT_SUFFIX"))
@@ -88,19 +93,93 @@ def build_hostcpp(force=False, verbose=False):
     pybind11 test module zhilight_amd/zl_internals*.so.  Host code only: g++ against the HIP runtime headers."""
     import pybind11
     import sysconfig
-    srcs = [os.path.join(HOSTCPP, f) for f in ("bm_hip.cpp", "nn_amd.cpp", "py_internals.cpp")]
-    deps = srcs + [os.path.join(HOSTCPP, f) for f in ("bm_hip.h", "nn_amd.h")] + [os.path.join(HERE, "..", "include", "zhilight_amd.h")]
+    srcs = [os.path.join(HOSTCPP, f) for f in HOSTCPP_SOURCES + ("py_internals.cpp",)]
+    deps = srcs + [os.path.join(HOSTCPP, f) for f in HOSTCPP_HEADERS] + [os.path.join(HERE, "..", "include", "zhilight_amd.h")]
     target = hostcpp_target()
     if not (force or _stale(target, deps)):
         return target
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
-           "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]] + srcs + [
+           "-I" + os.path.join(HERE, "..", "include"), "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]] + srcs + [
            "-o", target, "-L" + HERE, "-lzhilight_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    return target
+
+
+REFERENCE = os.environ.get("ZL_REFERENCE_ROOT", "/root/reference")
+REFDIR = os.path.join(HERE, "_ref")
+# reference host translation units compiled UNMODIFIED, from where they lie, against hostcpp/refshim + the bmengine-on-HIP
+# headers (VERDICT r02 item 6: "prove the boundary compiles the reference")
+REF_TUS = ("src/nn/linear/linear.cpp",)
+
+
+def refcompile_target():
+    import sysconfig
+    return os.path.join(REFDIR, "zl_reflinear" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_refcompile(force=False, verbose=False):
+    """zhilight_amd/_ref/zl_reflinear*.so = the reference's own src/nn/linear/linear.cpp (read in place from
+    /root/reference, never copied) + hostcpp/refshim/ref_glue.cpp + the hostcpp layer, linked against libzhilight_amd.so.
+    Only where the reference tree exists (this container); the GPU box uses the prebuilt file.  _ref/ is git-ignored (it
+    holds compiled reference code) but travels with gpurun snapshots.  Returns the path, or None without a reference."""
+    import pybind11
+    import sysconfig
+    target = refcompile_target()
+    tus = [os.path.join(REFERENCE, t) for t in REF_TUS]
+    if not all(os.path.exists(t) for t in tus):
+        return target if os.path.exists(target) else None
+    shim = os.path.join(HOSTCPP, "refshim")
+    own = [os.path.join(HOSTCPP, f) for f in HOSTCPP_SOURCES] + [os.path.join(shim, "ref_glue.cpp")]
+    deps = tus + own + [os.path.join(HOSTCPP, f) for f in HOSTCPP_HEADERS] + [os.path.join(HERE, "..", "include", "zhilight_amd.h")]
+    for root, _, files in os.walk(shim):
+        deps += [os.path.join(root, f) for f in files]
+    if not (force or _stale(target, deps)):
+        return target
+    os.makedirs(REFDIR, exist_ok=True)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cxx = os.environ.get("CXX", "g++")
+    inc = ["-I" + shim, "-I" + HOSTCPP, "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(HERE, "..", "include"),
+           "-I" + os.path.join(REFERENCE, "src"), "-I" + REFERENCE, "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
+    common = [cxx, "-O1", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-w"] + inc
+    objs = []
+    jobs = []
+    for src in tus + own:
+        o = os.path.join(REFDIR, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        jobs.append(common + ["-c", src, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        list(ex.map(run, jobs))
+    run([cxx, "-shared", "-o", target] + objs + ["-L" + HERE, "-lzhilight_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+                                                   "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    for o in objs:
+        os.remove(o)
+    # every name the reference's translation unit needs must be DEFINED by the boundary (the CPython API aside, which the
+    # interpreter provides): a leftover undefined symbol would only surface as an ImportError on the GPU box
+    libs = [OUT, os.path.join(rocm, "lib", "libamdhip64.so")]
+    have = set()
+    for lib in libs:
+        for line in subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True).splitlines():
+            have.add(line.split()[-1])
+    missing = []
+    for line in subprocess.check_output(["nm", "-D", "-u", target], text=True).splitlines():
+        kind, sym = line.split()[-2:]
+        if kind in "wv" or "@" in sym or sym.startswith(("Py", "_Py", "__")) or sym in have:
+            continue
+        missing.append(sym)
+    if missing:
+        os.remove(target)
+        demangled = subprocess.run(["c++filt"], input="\n".join(missing), text=True, capture_output=True).stdout
+        raise RuntimeError("the reference translation unit needs names the boundary does not define:\n" + demangled)
     return target
 
 

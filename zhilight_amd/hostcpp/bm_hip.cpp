@@ -124,13 +124,14 @@ void Tensor::set_shape(const std::vector<size_t>& s) {
     strides_.assign(s.size(), 1);
     for (int i = (int)s.size() - 2; i >= 0; --i) strides_[i] = strides_[i + 1] * s[i + 1];
 }
-size_t Tensor::numel() const { return mem_ ? get_numel(shape_) : 0; }
+size_t Tensor::numel() const { return (mem_ || param_) ? get_numel(shape_) : 0; }
 int Tensor::normalize_dim(int dim) const {
     const int n = ndim();
     BM_ASSERT(dim >= -n && dim < n, "dim out of range");
     return dim < 0 ? dim + n : dim;
 }
 void* Tensor::data() const {
+    if (param_ && !mem_) return nullptr;             // Context::parameter(): declared, not loaded yet
     BM_ASSERT(mem_ && mem_->ptr, "Tensor is empty");
     return (char*)mem_->ptr + offset_;
 }
@@ -178,6 +179,56 @@ Tensor Tensor::virtual_slice(size_t from, size_t len, int dim) const {
     Tensor t(*this);
     t.offset_ = offset_ + from * strides_[d] * get_elem_size(dtype_);
     t.shape_[d] = len;
+    return t;
+}
+Tensor Tensor::virtual_transpose(int dim0, int dim1) const {
+    const int a = normalize_dim(dim0), b = normalize_dim(dim1);
+    Tensor t(*this);
+    std::swap(t.shape_[a], t.shape_[b]);
+    std::swap(t.strides_[a], t.strides_[b]);
+    return t;
+}
+// Re-shape a strided tensor without moving data: every new dimension must either split one old dimension or merge old
+// dimensions that are contiguous with respect to each other (stride[i] == stride[i+1] * shape[i+1]).
+Tensor Tensor::view_uncontinuous(const std::vector<size_t>& size) const {
+    BM_ASSERT_EQ(get_numel(size), get_numel(shape_), "view_uncontinuous: size mismatch");
+    // merge the old dimensions into maximal contiguous chunks (extent, stride of the innermost element)
+    std::vector<std::pair<size_t, size_t>> chunks;
+    for (int i = 0; i < ndim(); ++i) {
+        if (shape_[i] == 1) continue;
+        if (!chunks.empty() && chunks.back().second == strides_[i] * shape_[i]) {
+            chunks.back().first *= shape_[i];
+            chunks.back().second = strides_[i];
+        } else {
+            chunks.emplace_back(shape_[i], strides_[i]);
+        }
+    }
+    Tensor t(*this);
+    t.shape_ = size;
+    t.strides_.assign(size.size(), 1);
+    size_t c = 0, left = chunks.empty() ? 1 : chunks[0].first;   // elements of chunk c not yet covered by new dimensions
+    for (size_t i = 0; i < size.size(); ++i) {
+        if (size[i] == 1) {
+            t.strides_[i] = 1;
+            continue;
+        }
+        BM_ASSERT(c < chunks.size() && left % size[i] == 0, "view_uncontinuous: the new shape crosses a stride boundary");
+        left /= size[i];
+        t.strides_[i] = chunks[c].second * left;
+        if (left == 1 && ++c < chunks.size()) left = chunks[c].first;
+    }
+    return t;
+}
+Tensor Tensor::to_device(int dev_id) const {
+    BM_ASSERT(dev_id < 0 || device_ < 0 || dev_id == device_, "to_device: one process drives one device");
+    if (device_ >= 0 || !mem_) return *this;
+    int dev = dev_id;
+    if (dev < 0) BM_HIPRT_ASSERT(hipGetDevice(&dev));
+    void* p = nullptr;
+    BM_HIPRT_ASSERT(hipMalloc(&p, nbytes()));
+    BM_HIPRT_ASSERT(hipMemcpy(p, data(), nbytes(), hipMemcpyHostToDevice));
+    Tensor t = from_external(shape_, dtype_, p, nbytes(), dev, true);
+    t.name_ = name_;
     return t;
 }
 std::vector<Tensor> Tensor::chunk() const {
@@ -231,6 +282,55 @@ std::string Tensor::info(int) const {
     return os.str();
 }
 
+static float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) {
+            u = sign;
+        } else {   // subnormal: m * 2^-24
+            float f = (float)m * 5.9604644775390625e-8f;
+            std::memcpy(&u, &f, 4);
+            u |= sign;
+        }
+    } else if (e == 31) {
+        u = sign | 0x7f800000u | (m << 13);
+    } else {
+        u = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+std::ostream& operator<<(std::ostream& os, const Tensor& t) {
+    os << t.info();
+    if (t.numel() == 0 || !t.mem_ || !t.is_continuous()) return os;
+    // the first elements, read back synchronously (a debugging aid, as in the reference)
+    const size_t n = std::min<size_t>(t.numel(), 16), es = get_elem_size(t.dtype_);
+    std::vector<char> host(n * es);
+    if (t.device_ >= 0) {
+        if (hipMemcpy(host.data(), t.data(), n * es, hipMemcpyDeviceToHost) != hipSuccess) return os;
+    } else {
+        std::memcpy(host.data(), t.data(), n * es);
+    }
+    os << " [";
+    for (size_t i = 0; i < n; ++i) {
+        const char* p = host.data() + i * es;
+        os << (i ? ", " : "");
+        switch (t.dtype_) {
+        case DataType::kDouble: os << *(const double*)p; break;
+        case DataType::kFloat: os << *(const float*)p; break;
+        case DataType::kHalf: os << half_bits_to_float(*(const uint16_t*)p); break;
+        case DataType::kBFloat16: { uint32_t u = (uint32_t)*(const uint16_t*)p << 16; float f; std::memcpy(&f, &u, 4); os << f; } break;
+        case DataType::kInt8: os << (int)*(const int8_t*)p; break;
+        case DataType::kInt16: os << *(const int16_t*)p; break;
+        case DataType::kInt32: os << *(const int32_t*)p; break;
+        default: os << (unsigned)*(const uint8_t*)p; break;
+        }
+    }
+    return os << (n < t.numel() ? ", ...]" : "]");
+}
+
 // ---- Context -------------------------------------------------------------------------------------------------------
 class ContextImpl {
 public:
@@ -260,6 +360,23 @@ Context::Context(int device, int rank, int world_size) : pimpl(new ContextImpl) 
     pimpl->stream = get_stream();
 }
 Context::~Context() = default;
+Context::Context(Context&&) noexcept = default;
+Tensor Context::parameter(const std::vector<size_t>& size, DataType dtype) const {
+    for (size_t v : size) BM_ASSERT(v > 0, "parameter: zero-sized dimension");
+    Tensor t;
+    t.dtype_ = dtype;
+    t.device_ = pimpl->device;
+    t.param_ = true;
+    t.set_shape(size);
+    return t;
+}
+Tensor Context::tensor_s(const std::vector<long>& size, DataType dtype) const {
+    return tensor(std::vector<size_t>(size.begin(), size.end()), dtype);
+}
+void Context::print_memory_summary() const {
+    std::cerr << "device " << pimpl->device << ": used " << (pimpl->pool->used() >> 20) << " MB, peak " << (pimpl->pool->peak() >> 20)
+              << " MB" << std::endl;
+}
 int Context::active_device() const { return pimpl->device; }
 int Context::rank() const { return pimpl->rank; }
 int Context::world_size() const { return pimpl->world; }

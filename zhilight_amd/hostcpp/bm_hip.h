@@ -35,24 +35,20 @@ private:
     std::string text_;
 };
 
-#define BM_EXCEPTION(msg) throw BMEngineException(msg, __FILE__, __LINE__, __PRETTY_FUNCTION__)
+#define BM_EXCEPTION(msg) throw BMEngineException("Exception:\n", __FILE__, __LINE__, __PRETTY_FUNCTION__, msg)
+// statement macros of the `if (...) { throw }` form: the reference's callers also write them without a trailing semicolon
 #define BM_ASSERT(cond, msg)                                                                            \
-    do {                                                                                                \
-        if (__builtin_expect(!(cond), 0))                                                               \
-            throw BMEngineException("Assertion failed: " #cond, __FILE__, __LINE__, __PRETTY_FUNCTION__, msg); \
-    } while (0)
-#define BM_ASSERT_EQ(x, y, msg)                                                                         \
-    do {                                                                                                \
-        if (__builtin_expect((x) != (y), 0))                                                            \
-            throw BMEngineException(std::string("Assertion failed: " #x " != " #y " i.e. ") + std::to_string(x) + " != " + \
-                                        std::to_string(y), __FILE__, __LINE__, __PRETTY_FUNCTION__, msg); \
-    } while (0)
-#define BM_ASSERT_LE(x, y, msg)                                                                         \
-    do {                                                                                                \
-        if (__builtin_expect((x) > (y), 0))                                                             \
-            throw BMEngineException(std::string("Assertion failed: " #x " <= " #y " i.e. ") + std::to_string(x) + " <= " + \
-                                        std::to_string(y), __FILE__, __LINE__, __PRETTY_FUNCTION__, msg); \
-    } while (0)
+    if (__builtin_expect(!(cond), 0)) {                                                                 \
+        throw BMEngineException("Assertion failed: " #cond, __FILE__, __LINE__, __PRETTY_FUNCTION__, msg); \
+    }
+#define BM_ASSERT_CMP_(x, y, op, opname, msg)                                                           \
+    if (__builtin_expect(!((x)op(y)), 0)) {                                                             \
+        throw BMEngineException(std::string("Assertion failed: " #x " " opname " " #y " i.e. ") + std::to_string(x) + \
+                                    " " opname " " + std::to_string(y), __FILE__, __LINE__, __PRETTY_FUNCTION__, msg); \
+    }
+#define BM_ASSERT_EQ(x, y, msg) BM_ASSERT_CMP_(x, y, ==, "!=", msg)
+#define BM_ASSERT_LT(x, y, msg) BM_ASSERT_CMP_(x, y, <, "<", msg)
+#define BM_ASSERT_LE(x, y, msg) BM_ASSERT_CMP_(x, y, <=, "<=", msg)
 // the reference spells the runtime check BM_CUDART_ASSERT; both names are accepted
 #define BM_HIPRT_ASSERT(expr)                                                                           \
     do {                                                                                                \
@@ -71,6 +67,21 @@ const char* get_data_type_name(DataType dtype);
 DataType name_to_data_type(const std::string& name);
 size_t get_elem_size(DataType dtype);
 size_t get_numel(const std::vector<size_t>& size);
+
+// element type of a host vector handed to Context::tensor_of (dtype.h:27-49)
+template <typename T> struct DTypeDeducer {
+    static DataType data_type() { throw std::runtime_error("data_type must be overwrite"); }
+};
+template <> struct DTypeDeducer<int> { static DataType data_type() { return DataType::kInt32; } };
+template <> struct DTypeDeducer<int8_t> { static DataType data_type() { return DataType::kInt8; } };
+template <> struct DTypeDeducer<float> { static DataType data_type() { return DataType::kFloat; } };
+template <> struct DTypeDeducer<void*> { static DataType data_type() { return DataType::kDouble; } };   // 8-byte addresses
+
+// how a Linear weight (dim_out, dim_in) is split over the tensor-parallel ranks (tensor.h:18-21): COLUMNAR = the last
+// dimension, ROW = the one before it
+enum class DistLayout { COLUMNAR, ROW, REPLICATED };
+DistLayout transpose_layout(DistLayout dist_layout);
+const char* get_dist_layout_name(DistLayout dist_layout);
 
 struct Stream_ {
     hipStream_t ptr;
@@ -118,6 +129,7 @@ public:
     void* nullable_data() const;                     // nullptr for an empty tensor
     void* mutable_data() { return data(); }
     template <typename T> T* data() const { return reinterpret_cast<T*>(data()); }
+    template <typename T> void* nullable_data() const { return nullable_data(); }
     template <typename T> T* mutable_data() { return reinterpret_cast<T*>(data()); }
     size_t mem_bytes() const;
     int device() const { return device_; }           // -1: host
@@ -129,12 +141,15 @@ public:
     Tensor slice_dim0(size_t from, size_t to) const;
     Tensor slice_dim0_len(size_t from, size_t len) const { return slice_dim0(from, from + len); }
     Tensor virtual_slice(size_t from, size_t len, int dim = -1) const;   // strided: no longer continuous
+    Tensor virtual_transpose(int dim0, int dim1) const;                  // swaps two strides: no longer continuous
+    Tensor view_uncontinuous(const std::vector<size_t>& size) const;     // split / merge dimensions of a strided tensor
     bool is_continuous() const;
     std::vector<Tensor> chunk() const;
     Tensor squeeze() const;
 
     void from_buffer(const void* host, bool async = false, hipStream_t stream = nullptr);
     void to_buffer(void* host, hipStream_t stream = nullptr) const;
+    Tensor to_device(int dev_id = -1) const;         // one device per process: the tensor itself (or a copy of a host tensor)
     template <typename T> std::vector<T> to_vector(hipStream_t stream = nullptr) const {
         std::vector<T> v(nbytes() / sizeof(T));
         to_buffer(v.data(), stream);
@@ -144,6 +159,7 @@ public:
     static Tensor from_external(const std::vector<size_t>& shape, DataType dtype, void* ptr, size_t nbytes, int device = -1,
                                 bool own_ptr = false);
     std::string info(int level = 0) const;
+    friend std::ostream& operator<<(std::ostream& os, const Tensor& tensor);
 
 private:
     friend class Context;
@@ -152,21 +168,29 @@ private:
     std::vector<size_t> shape_, strides_;            // strides in elements
     DataType dtype_ = DataType::kHalf;
     int device_ = -1;
+    bool param_ = false;                             // Context::parameter(): shape and dtype, no memory yet
     mutable long id_ = -1;
     mutable std::string name_;
     void set_shape(const std::vector<size_t>& s);
 };
 
 class ContextImpl;
+class WithDevice;
+class ScopeDevice;
+class WithDebug;
 // One Context per device per thread (context.cpp:275-280).  All launches of the nn:: wrappers go to current_stream().
 class Context {
 public:
     static const std::string EMPTY_STR;
     explicit Context(int device, int rank = 0, int world_size = 1);
-    ~Context();
+    virtual ~Context();                              // model::ModelContext derives from it (src/model/model_context.h:77)
     Context(const Context&) = delete;
+    Context(Context&&) noexcept;
 
     int active_device() const;
+    int active_device_idx() const { return 0; }      // index in this context's device list: always the one device
+    const std::vector<int> devices() const { return {active_device()}; }
+    virtual bool switch_to_device(int idx) const;    // true when idx is the context's device; anything else throws
     int rank() const;
     int world_size() const;
     int get_compute_capability() const;              // 90: the reference gates dual-stream / wmma paths on > 80
@@ -178,10 +202,14 @@ public:
     void set_current_stream(Stream s);
     hipStream_t current_cuda_stream() const;         // (name kept from the reference)
     Stream get_stream() const;                       // a fresh non-blocking stream
+    // Int8Linear (linear.cpp:600-616) hands this to cublasLtMatmul; here the product is int8_op::int8_gemm_nt and the
+    // handle is only a token passed through (the refshim's cublasLtMatmul ignores it)
+    void* current_cublas_handle() const { return nullptr; }
 
     Tensor null_tensor() const { return Tensor(); }
     Tensor tensor(const std::vector<size_t>& size, DataType dtype, const std::string& name = EMPTY_STR,
                   size_t round_up_bytes = 1024) const;
+    Tensor tensor_s(const std::vector<long>& size, DataType dtype) const;
     Tensor cuda(const Tensor& cpu_tensor) const;     // host -> device copy on the current stream (synchronous)
     template <typename T> Tensor tensor_of(const std::vector<T>& data, const std::vector<size_t>& shape, DataType dt) const {
         Tensor t = tensor(shape, dt);
@@ -189,7 +217,35 @@ public:
         t.from_buffer(data.data());
         return t;
     }
+    template <typename T, typename DTD = DTypeDeducer<T>>
+    Tensor tensor_of(const std::vector<T>& data, const std::vector<size_t>& shape) const {
+        if (data.empty()) return Tensor();
+        Tensor t = tensor(shape, DTD::data_type());
+        if (data.size() != t.numel()) throw std::runtime_error("data not fit for tensor");
+        t.from_buffer(data.data());
+        return t;
+    }
+    template <typename T> Tensor tensor_of(const std::vector<T>& data) const { return tensor_of(data, {data.size()}); }
     const Tensor copy(const Tensor& t) const;
+
+    // ---- parameters (context.cpp:640-789) ---------------------------------------------------------------------------
+    // parameter(): shape and dtype without memory; load_parameter(): fill it from state_dict[name] (host or device
+    // tensors) -- whole when !parallel / world_size 1 / REPLICATED, else this rank's shard along the layout's dimension
+    // (ROW: dim -2, contiguous rows; COLUMNAR: dim -1, gathered row by row on the host).  int16 sources are bf16 bits.
+    Tensor parameter(const std::vector<size_t>& size, DataType dtype) const;
+    Tensor distribute_parameter(const Tensor& param, DistLayout layout) const;
+    void load_parameter(Tensor* weight, const std::string& name, const std::map<std::string, const Tensor>& state_dict,
+                        bool parallel, DistLayout layout) const;
+    void load_parameter_part(Tensor* weight, const std::string& name, const std::map<std::string, const Tensor>& state_dict,
+                             DistLayout layout, size_t part, size_t total) const;
+    void assign_or_copy(Tensor* dst, const Tensor* src) const;     // host source: upload into dst (allocating it); device: alias
+    const Tensor* identity(const Tensor* tensor, const std::string& name) const { (void)name; return tensor; }   // one device
+    void clear_identity_cache() {}
+    void init_parameter(const std::string& name, Tensor* tensor) const;   // allocate + zero
+
+    WithDevice with_device(int dev_id) const;
+    ScopeDevice scope_device(int dev_id) const;
+    WithDebug with_debug(int debug_level) const;
 
     // a persistent zero-initialised device buffer of at least `bytes` (the caller-provided scratch of the C ABI's K-split
     // launchers, zl_w4_opts_t::scratch): grown on demand, never while a stream capture is open
@@ -202,18 +258,25 @@ public:
 
     void recordEvent(const std::string& name, int ev_level = 2, float flops = 0) const;
     int debug() const { return 0; }
+    void enable_debug(int) const {}
+    bool checking_numerics() const { return false; }
+    int event_level() const { return -1; }
+    void set_event_level(int) const {}
+    void print_events() {}
+    void print_memory_summary() const;
     int current_layer() const { return cur_layer_; }
-    void set_current_layer(int i) { cur_layer_ = i; }
+    virtual void set_current_layer(int i) { cur_layer_ = i; }
+    bool is_layer(int layer, int rank = 0) const { return cur_layer_ == layer && this->rank() == rank; }
     int high_precision() const { return high_precision_; }
     void set_high_precision(int level) { high_precision_ = level; }
-    bool is_BSHD() const { return bshd_; }
+    virtual bool is_BSHD() const { return bshd_; }
     void set_BSHD(bool b) { bshd_ = b; }
 
     // tensor parallelism: sum over the ranks of the node (ModelContext::reduce_sum, model_context.cpp:203-242).  The hook
     // is installed by the communicator owner (RCCL / the one-shot xGMI all-reduce); with world_size 1 it is the identity.
     typedef std::function<void(Tensor& data, hipStream_t stream)> ReduceHook;
     void set_reduce_hook(ReduceHook h);
-    Tensor reduce_sum(Tensor& data, DataType out_type) const;
+    virtual Tensor reduce_sum(Tensor& data, DataType out_type) const;
 
 private:
     std::unique_ptr<ContextImpl> pimpl;
@@ -223,3 +286,8 @@ private:
 
 }  // namespace core
 }  // namespace bmengine
+
+namespace std {
+// BM_ASSERT_EQ prints both sides with std::to_string; the reference extends it to dtypes (dtype.h:125-129)
+static inline std::string to_string(bmengine::core::DataType dt) { return bmengine::core::get_data_type_name(dt); }
+}  // namespace std

@@ -3,6 +3,9 @@
 // context's current stream, status -> BMEngineException.  No kernel code here and no torch.
 #include "nn_amd.h"
 
+#include <cstring>
+#include <mutex>
+
 #include "../../include/zhilight_amd.h"
 
 using bmengine::core::Context;
@@ -40,7 +43,15 @@ namespace gptq {
 
 void gptq_shuffle(const Context& ctx, Tensor& q_weight, Tensor q_perm) {
     BM_ASSERT_EQ(q_weight.ndim(), 2, "q_weight is not 2d");
-    BM_ASSERT(q_perm.numel() == 0, "act-order checkpoints: regroup the rows at load (see INTEGRATION.md)");
+    if (q_perm.numel()) {     // act-order: row i of the regrouped matrix is the checkpoint's row q_perm[i] (make_sequential)
+        BM_ASSERT_EQ(q_perm.dtype(), DataType::kInt32, "q_perm must be int32");
+        BM_ASSERT_EQ(q_perm.numel(), q_weight.size(0) * 8, "q_perm length");
+        Tensor regrouped = ctx.tensor(q_weight.shape(), q_weight.dtype(), q_weight.name());
+        zl_check(zl_gptq_permute_rows(q_weight.data<uint32_t>(), regrouped.data<uint32_t>(), q_perm.data<int32_t>(), q_weight.size(0),
+                                      q_weight.size(1), st_of(ctx)), "gptq_shuffle (act-order)");
+        regrouped.quant_scale = q_weight.quant_scale;
+        q_weight = regrouped;
+    }
     zl_check(zl_gptq_shuffle(q_weight.data<uint32_t>(), q_weight.size(0), q_weight.size(1), st_of(ctx)), "gptq_shuffle");
 }
 void un_shuffle(const Context& ctx, Tensor& input) {
@@ -66,6 +77,41 @@ Tensor q4_to_q8(const Context& ctx, const Tensor& input) {
 }
 
 static bool is_packed(const Tensor& scales) { return scales.dtype() == DataType::kInt32; }
+
+// ---- weight-identity cache (nn_amd.h) ------------------------------------------------------------------------------
+namespace {
+struct WeightKey {
+    const void* p[6];
+    size_t n, k;
+    int flavour;       // 0: one k-major weight, 1: [gate; up] row-interleaved pair, 2: MoE stack, 3: MoE [gate; up] stack
+    bool operator<(const WeightKey& o) const { return std::memcmp(this, &o, sizeof(WeightKey)) < 0; }
+};
+struct WeightEntry {
+    std::vector<Tensor> raw;      // keeps the operands' storage (hence their addresses) alive
+    PackedW4 w4;
+    PackedMoE moe;
+};
+std::mutex g_cache_mu;
+std::map<WeightKey, WeightEntry> g_cache;
+WeightKey make_key(int flavour, size_t n, size_t k, std::initializer_list<const Tensor*> ts) {
+    WeightKey key;
+    std::memset(&key, 0, sizeof(key));
+    int i = 0;
+    for (const Tensor* t : ts) key.p[i++] = t->nullable_data();
+    key.n = n;
+    key.k = k;
+    key.flavour = flavour;
+    return key;
+}
+}  // namespace
+void amd_weight_cache_clear() {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache.clear();
+}
+size_t amd_weight_cache_size() {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    return g_cache.size();
+}
 
 PackedW4 amd_pack_k_major(const Context& ctx, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales,
                           bool row_interleave) {
@@ -113,7 +159,12 @@ Tensor dequant_k_major(const Context& ctx, const Tensor& q_weight, const Tensor&
         w8.set_quant_scale(*q_weight.quant_scale);
         return w8;
     }
-    BM_ASSERT_EQ(out_type, 0, "dequant_k_major: out_type 0 (half) or 1 (int8)");
+    if (out_type == 2) {     // W4_FP8_ALGO: E4M3 codes under the per-tensor scale on q_weight.quant_scale
+        BM_ASSERT(q_weight.quant_scale, "dequant_k_major(out_type 2) needs q_weight.quant_scale (fp8::calc_scale of the weight)");
+        Tensor w16 = dequant_k_major(ctx, q_weight, qzeros, scales, 0);
+        return fp8::cvt_half_to_fp8(ctx, w16, *q_weight.quant_scale);
+    }
+    BM_ASSERT_EQ(out_type, 0, "dequant_k_major: out_type 0 (half), 1 (int8) or 2 (fp8 e4m3)");
     if (is_packed(scales)) {
         auto raw = unpack(ctx, q_weight, scales);
         return dequant_k_major(ctx, std::get<0>(raw), std::get<1>(raw), std::get<2>(raw), 0);
@@ -131,24 +182,64 @@ Tensor dequant_k_major(const Context& ctx, const Tensor& q_weight, const Tensor&
     return out;
 }
 
-Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales,
+// the packed form of a raw k-major weight, re-tiled on first sight (see nn_amd.h); sym: every zero point is 8
+// (q_gemm_k_major.cu:148-150)
+static PackedW4 cached_pack(const Context& ctx, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales, bool sym) {
+    const WeightKey key = make_key(sym ? 4 : 0, q_weight.size(0), q_weight.size(1) * 8, {&q_weight, &qzeros, &scales});
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) return it->second.w4;
+    }
+    Tensor zeros = qzeros;
+    if (sym) {
+        zeros = ctx.tensor(scales.shape(), DataType::kInt8);
+        BM_HIPRT_ASSERT(hipMemsetAsync(zeros.data(), 8, zeros.nbytes(), ctx.current_cuda_stream()));
+    }
+    WeightEntry e;
+    e.raw = {q_weight, qzeros, scales};
+    e.w4 = amd_pack_k_major(ctx, q_weight, zeros, scales);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    return g_cache.emplace(key, std::move(e)).first->second.w4;
+}
+
+Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a0, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales,
                          const Tensor& q_perm, const Tensor& rev_perm, const Tensor* bias, bool sym, bool cache_only,
                          Tensor* output, const Tensor* precomputed_w8) {
-    BM_ASSERT(a.dtype() == DataType::kHalf, "A must be half");                       // q_gemm_k_major.cu:989
-    BM_ASSERT(q_perm.numel() == 0 && rev_perm.numel() == 0, "act-order: permute the input first (permute_input) and pass empty perms");
-    BM_ASSERT(!cache_only, "cache_only (layer_cache warm-up) has no meaning here: pass precomputed_w8");
     BM_ASSERT_EQ(q_weight.ndim(), 2, "q_weight is not 2d");
     const int64_t n = q_weight.size(0), k = q_weight.size(1) * 8;
-    BM_ASSERT_EQ((int64_t)a.size(-1), k, "size K mismatch");
+    zl_w4_layout_t L;
+    const bool raw = !is_packed(scales);
+    const int64_t g = raw ? k / (int64_t)scales.size(1) : 128;
+    const bool mfma_ok = !raw || (zl_w4m_layout(n, k, g, &L) == ZL_OK && L.np == n);
+    if (cache_only) {     // the reference warms ModelContext::layer_cache with the dequantised weight; here: the packed form
+        if (raw && mfma_ok) (void)cached_pack(ctx, q_weight, qzeros, scales, sym);
+        return Tensor();
+    }
+    BM_ASSERT(a0.dtype() == DataType::kHalf, "A must be half");                       // q_gemm_k_major.cu:989
+    BM_ASSERT_EQ((int64_t)a0.size(-1), k, "size K mismatch");
+    if (q_perm.numel()) {
+        BM_ASSERT_EQ((size_t)k, q_perm.size(0) * 2, "q_perm is not int16");
+        BM_ASSERT_EQ((size_t)k, rev_perm.size(0) * 2, "q_perm is not int16");
+    }
+    // act-order: the weight rows were regrouped at load, the activations follow (q_gemm_k_major.cu:1094,1104-1106)
+    const Tensor a = q_perm.numel() ? permute_input(ctx, a0, q_perm) : a0;
     const int64_t m = rows_of(a);
     if (precomputed_w8 && precomputed_w8->numel() && m > 40 && !bias && n > 1024) {
-        // W4A8 INT8 branch (q_gemm_k_major.cu:1036-1073): int8 rows x int8 codes -> int32, scaled back with the fp32 row scale
-        BM_ASSERT(precomputed_w8->quant_scale, "precomputed_w8 carries no scale");
-        Tensor aq = int8_op::quant_calc_scale(ctx, a);
-        Tensor acc = int8_op::int8_gemm_nt(ctx, aq, *precomputed_w8);
         std::vector<size_t> osh = a.shape();
         osh.back() = n;
         Tensor o = output ? *output : ctx.tensor(osh, DataType::kHalf);
+        BM_ASSERT(precomputed_w8->quant_scale, "precomputed_w8 carries no scale");
+        if (precomputed_w8->dtype() == DataType::kFP8_E4M3) {
+            // W4A8 FP8 branch (q_gemm_k_major.cu:1003-1035): per-tensor dynamic E4M3 activations x E4M3 codes, fp32 accumulate
+            Tensor aq = a.quant_scale ? *a.quant_scale : fp8::dynamic_scaled_quant(ctx, a, 448);
+            zl_check(zl_fp8_gemm_nt(aq.data<uint8_t>(), precomputed_w8->data<uint8_t>(), aq.quant_scale->data<float>(),
+                                    precomputed_w8->quant_scale->data<float>(), u16m(o), m, n, k, st_of(ctx)), "gptq_gemm_k_major (W4 FP8)");
+            return o;
+        }
+        // W4A8 INT8 branch (q_gemm_k_major.cu:1036-1073): int8 rows x int8 codes -> int32, scaled back with the fp32 row scale
+        Tensor aq = int8_op::quant_calc_scale(ctx, a);
+        Tensor acc = int8_op::int8_gemm_nt(ctx, aq, *precomputed_w8);
         zl_check(zl_quant_scale_back_f32(acc.data<int32_t>(), aq.quant_scale->data<float>(), precomputed_w8->quant_scale->data<float>(),
                                          u16m(o), m, n, st_of(ctx)), "gptq_gemm_k_major (W4A8)");
         return o;
@@ -161,29 +252,21 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a, const Tensor& q_we
     const uint16_t* bptr = bias && bias->numel() ? u16(*bias) : nullptr;
     const int epi = bptr ? ZL_EPI_BIAS : 0;
     const zl_w4_opts_t opts = w4_opts(ctx, m, n);
-    if (is_packed(scales)) {
-        zl_check(zl_w4a16_gemm_mfma_ex(u16(a), ldx, q_weight.data<uint32_t>(), scales.data<uint32_t>(), bptr, nullptr, u16m(out), m, n,
-                                       k, 128, nullptr, 0.f, epi, &opts, st_of(ctx)), "gptq_gemm_k_major");
+    if (mfma_ok) {
+        BM_ASSERT(!raw || scales.dtype() == DataType::kHalf, "scales must be half");
+        const PackedW4 p = raw ? cached_pack(ctx, q_weight, qzeros, scales, sym) : PackedW4{q_weight, Tensor(), scales};
+        zl_check(zl_w4a16_gemm_mfma_ex(u16(a), ldx, p.q_weight.data<uint32_t>(), p.scales.data<uint32_t>(), bptr, nullptr, u16m(out), m, n,
+                                       k, g, nullptr, 0.f, epi, &opts, st_of(ctx)), "gptq_gemm_k_major");
         return out;
     }
-    // raw k-major operands: re-tile into temporaries, then the same launch.  sym: every zero point is 8
-    // (q_gemm_k_major.cu:148-150)
+    // group sizes / row counts the matrix-core tiles do not take: the warp-reduce arithmetic kernel (bit-identical to
+    // KERNEL_gemm_warp_reduce, q_gemm_k_major.cu:127-237) on its own layout, re-tiled per call
     BM_ASSERT(scales.dtype() == DataType::kHalf, "scales must be half");
-    const int64_t g = k / scales.size(1);
     Tensor zeros = qzeros;
     if (sym) {
         zeros = ctx.tensor(scales.shape(), DataType::kInt8);
         BM_HIPRT_ASSERT(hipMemsetAsync(zeros.data(), 8, zeros.nbytes(), ctx.current_cuda_stream()));
     }
-    zl_w4_layout_t L;
-    if (zl_w4m_layout(n, k, g, &L) == ZL_OK && L.np == n) {
-        PackedW4 p = amd_pack_k_major(ctx, q_weight, zeros, scales);
-        zl_check(zl_w4a16_gemm_mfma_ex(u16(a), ldx, p.q_weight.data<uint32_t>(), p.scales.data<uint32_t>(), bptr, nullptr, u16m(out), m,
-                                       n, k, g, nullptr, 0.f, epi, &opts, st_of(ctx)), "gptq_gemm_k_major");
-        return out;
-    }
-    // group sizes / row counts the matrix-core tiles do not take: the warp-reduce arithmetic kernel (bit-identical to
-    // KERNEL_gemm_warp_reduce, q_gemm_k_major.cu:127-237) on its own layout
     zl_check(zl_w4_layout(n, k, g, &L), "gptq_gemm_k_major");
     Tensor qw = ctx.tensor({(size_t)L.qw_bytes / 4}, DataType::kInt32), sc = ctx.tensor({(size_t)L.scales_bytes / 2}, DataType::kHalf),
            zr = ctx.tensor({(size_t)L.zeros_bytes / 2}, DataType::kInt16);
@@ -197,13 +280,62 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a, const Tensor& q_we
 Tensor gemm_fuse_gate_in(const Context& ctx, const Tensor& a, const Tensor& q_weight1, const Tensor& qzeros1, const Tensor& scales1,
                          const Tensor& rev_perm1, const Tensor& q_weight2, const Tensor& qzeros2, const Tensor& scales2,
                          const Tensor& rev_perm2, bool sym) {
-    // silu(a W1^T) * (a W2^T).  Operands handed over separately: two GEMVs + the gated activation (the fused single
-    // launch needs the two matrices interleaved row by row -- amd_pack_k_major(row_interleave) on [W1; W2] at load and
-    // zl_w4a16_gemm_mfma(ZL_EPI_SILU_MUL), which is what the decode step of this repository runs)
-    Tensor g = gptq_gemm_k_major(ctx, a, q_weight1, qzeros1, scales1, Tensor(), rev_perm1, nullptr, sym);
-    Tensor u = gptq_gemm_k_major(ctx, a, q_weight2, qzeros2, scales2, Tensor(), rev_perm2, nullptr, sym);
-    gate_mul_inplace(ctx, g, u, "silu");
-    return g;
+    // silu(a W1^T) * (a W2^T) in ONE launch (q_gemm_k_major.cu:765-841 runs the two GEMVs in one kernel as well): the pair is
+    // re-tiled once as a row-interleaved [W1; W2] (amd_pack_k_major(row_interleave) -- the layout the decode step of this
+    // repository loads directly) and cached by operand identity; the launch is zl_w4a16_gemm_mfma_ex(ZL_EPI_SILU_MUL).
+    BM_ASSERT(a.dtype() == DataType::kHalf, "A must be half");
+    BM_ASSERT(rev_perm1.numel() == 0 && rev_perm2.numel() == 0, "gemm_fuse_gate_in: act-order weights take the two-GEMV path of the caller");
+    BM_ASSERT(q_weight1.shape() == q_weight2.shape() && scales1.shape() == scales2.shape(), "in and gate should have same shape.");
+    const int64_t n1 = q_weight1.size(0), k = q_weight1.size(1) * 8, g = k / (int64_t)scales1.size(1), m = rows_of(a);
+    BM_ASSERT_EQ((int64_t)a.size(-1), k, "size K mismatch");
+    zl_w4_layout_t L;
+    if (!(zl_w4m_layout(2 * n1, k, g, &L) == ZL_OK && L.np == 2 * n1)) {     // shapes the tiles do not take: two GEMVs + the gate
+        Tensor gt = gptq_gemm_k_major(ctx, a, q_weight1, qzeros1, scales1, Tensor(), Tensor(), nullptr, sym);
+        Tensor up = gptq_gemm_k_major(ctx, a, q_weight2, qzeros2, scales2, Tensor(), Tensor(), nullptr, sym);
+        gate_mul_inplace(ctx, gt, up, "silu");
+        return gt;
+    }
+    const WeightKey key = make_key(sym ? 5 : 1, n1, k, {&q_weight1, &qzeros1, &scales1, &q_weight2, &qzeros2, &scales2});
+    PackedW4 p;
+    bool hit = false;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) {
+            p = it->second.w4;
+            hit = true;
+        }
+    }
+    if (!hit) {
+        const size_t ng = (size_t)(k / g), qb = q_weight1.nbytes(), zb = (size_t)n1 * ng, sb = zb * 2;
+        Tensor cq = ctx.tensor({(size_t)(2 * n1), (size_t)k / 8}, DataType::kInt32), cz = ctx.tensor({(size_t)(2 * n1), ng}, DataType::kInt8),
+               cs = ctx.tensor({(size_t)(2 * n1), ng}, DataType::kHalf);
+        hipStream_t hs = ctx.current_cuda_stream();
+        BM_HIPRT_ASSERT(hipMemcpyAsync(cq.data(), q_weight1.data(), qb, hipMemcpyDeviceToDevice, hs));
+        BM_HIPRT_ASSERT(hipMemcpyAsync(cq.data<char>() + qb, q_weight2.data(), qb, hipMemcpyDeviceToDevice, hs));
+        if (sym) {
+            BM_HIPRT_ASSERT(hipMemsetAsync(cz.data(), 8, 2 * zb, hs));
+        } else {
+            BM_ASSERT(qzeros1.dtype() == DataType::kInt8 && qzeros2.dtype() == DataType::kInt8, "qzeros must be int8");
+            BM_HIPRT_ASSERT(hipMemcpyAsync(cz.data(), qzeros1.data(), zb, hipMemcpyDeviceToDevice, hs));
+            BM_HIPRT_ASSERT(hipMemcpyAsync(cz.data<char>() + zb, qzeros2.data(), zb, hipMemcpyDeviceToDevice, hs));
+        }
+        BM_HIPRT_ASSERT(hipMemcpyAsync(cs.data(), scales1.data(), sb, hipMemcpyDeviceToDevice, hs));
+        BM_HIPRT_ASSERT(hipMemcpyAsync(cs.data<char>() + sb, scales2.data(), sb, hipMemcpyDeviceToDevice, hs));
+        WeightEntry e;
+        e.raw = {q_weight1, qzeros1, scales1, q_weight2, qzeros2, scales2};
+        e.w4 = amd_pack_k_major(ctx, cq, cz, cs, true);
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        p = g_cache.emplace(key, std::move(e)).first->second.w4;
+    }
+    std::vector<size_t> oshape = a.shape();
+    oshape.back() = n1;
+    Tensor out = ctx.tensor(oshape, DataType::kHalf);
+    const int64_t ldx = a.ndim() >= 2 ? a.stride(-2) : k;
+    const zl_w4_opts_t opts = w4_opts(ctx, m, 2 * n1);
+    zl_check(zl_w4a16_gemm_mfma_ex(u16(a), ldx, p.q_weight.data<uint32_t>(), p.scales.data<uint32_t>(), nullptr, nullptr, u16m(out), m,
+                                   2 * n1, k, g, nullptr, 0.f, ZL_EPI_SILU_MUL, &opts, st_of(ctx)), "gemm_fuse_gate_in");
+    return out;
 }
 
 // ---- fused MoE GEMVs
@@ -304,7 +436,24 @@ Tensor gemm_moe_up(const Context& ctx, const Tensor& a, const Tensor& q_weight1,
     BM_ASSERT(qzeros1.dtype() == DataType::kInt8, "qzeros must be int8");
     BM_ASSERT(qzeros2.dtype() == DataType::kInt8, "qzeros must be int8");
     (void)sym;     // sym checkpoints carry zero points of 8: the packed zeros hold them
-    PackedMoE w = amd_pack_moe(ctx, q_weight1, qzeros1, scales1, &q_weight2, &qzeros2, &scales2);
+    const WeightKey key = make_key(3, q_weight1.size(1), q_weight1.size(2) * 8, {&q_weight1, &qzeros1, &scales1, &q_weight2, &qzeros2, &scales2});
+    PackedMoE w;
+    bool hit = false;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) {
+            w = it->second.moe;
+            hit = true;
+        }
+    }
+    if (!hit) {
+        WeightEntry e;
+        e.raw = {q_weight1, qzeros1, scales1, q_weight2, qzeros2, scales2};
+        e.moe = amd_pack_moe(ctx, q_weight1, qzeros1, scales1, &q_weight2, &qzeros2, &scales2);
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        w = g_cache.emplace(key, std::move(e)).first->second.moe;
+    }
     return gemm_moe_up_packed(ctx, a, w, expert_ids, n_shared_expert, exp_parallel);
 }
 
@@ -313,11 +462,91 @@ Tensor gemm_moe_down(const Context& ctx, const Tensor& a, const Tensor& q_weight
                      Tensor* output) {
     BM_ASSERT(qzeros.dtype() == DataType::kInt8, "qzeros must be int8");
     (void)sym;
-    PackedMoE w = amd_pack_moe(ctx, q_weight, qzeros, scales);
+    const WeightKey key = make_key(2, q_weight.size(1), q_weight.size(2) * 8, {&q_weight, &qzeros, &scales});
+    PackedMoE w;
+    bool hit = false;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) {
+            w = it->second.moe;
+            hit = true;
+        }
+    }
+    if (!hit) {
+        WeightEntry e;
+        e.raw = {q_weight, qzeros, scales};
+        e.moe = amd_pack_moe(ctx, q_weight, qzeros, scales);
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        w = g_cache.emplace(key, std::move(e)).first->second.moe;
+    }
     return gemm_moe_down_packed(ctx, a, w, expert_ids, expert_weights, n_shared_expert, exp_parallel, output);
 }
 
+// ---- act-order helpers (utils.cu:253-395) --------------------------------------------------------------------------
+Tensor int32_to_int16(const Context& ctx, const Tensor& input) {
+    BM_ASSERT_EQ(input.dtype(), DataType::kInt32, "");
+    std::vector<size_t> shape = input.shape();
+    BM_ASSERT(shape.back() % 2 == 0, "int32_to_int16: even length");
+    shape.back() /= 2;
+    Tensor out = ctx.tensor(shape, DataType::kInt32);
+    zl_check(zl_perm_narrow_u16(input.data<int32_t>(), out.data<uint16_t>(), input.numel(), st_of(ctx)), "int32_to_int16");
+    return out;
+}
+Tensor reverse_perm(const Context& ctx, const Tensor& input) {
+    BM_ASSERT(input.numel(), "g_perm is empty");
+    BM_ASSERT_EQ(input.dtype(), DataType::kInt32, "");
+    std::vector<size_t> shape = input.shape();
+    BM_ASSERT(shape.back() % 2 == 0, "reverse_perm: even length");
+    shape.back() /= 2;
+    Tensor out = ctx.tensor(shape, DataType::kInt32);
+    zl_check(zl_perm_reverse_u16(input.data<int32_t>(), out.data<uint16_t>(), input.numel(), st_of(ctx)), "reverse_perm");
+    return out;
+}
+Tensor permute_input(const Context& ctx, const Tensor& input, const Tensor& q_perm) {
+    const size_t k = input.size(-1), m = input.numel() / k;
+    BM_ASSERT(input.dtype() == DataType::kHalf, "A must be half");
+    BM_ASSERT_EQ(k, q_perm.numel() * 2, "q_perm is not int16");
+    Tensor out = ctx.tensor(input.shape(), input.dtype());
+    const int64_t ldx = input.ndim() >= 2 ? (int64_t)input.stride(-2) : (int64_t)k;
+    zl_check(zl_permute_input_u16(u16(input), ldx, q_perm.data<uint16_t>(), u16m(out), m, k, st_of(ctx)), "permute_input");
+    return out;
+}
+
 }  // namespace gptq
+
+namespace fp8 {
+Tensor calc_scale(const Context& ctx, const Tensor& input, float MAX_E4M3) {
+    Tensor scale = ctx.tensor({1}, DataType::kFloat);
+    zl_check(zl_fp8_calc_scale(u16(input), input.numel(), MAX_E4M3, scale.data<float>(), zdt(input.dtype()), st_of(ctx)), "fp8::calc_scale");
+    return scale;
+}
+Tensor cvt_half_to_fp8(const Context& ctx, const Tensor& input, const Tensor& scale) {
+    BM_ASSERT(scale.dtype() == DataType::kFloat && scale.numel() == 1, "fp8: a (1,) float scale");
+    Tensor out = ctx.tensor(input.shape(), DataType::kFP8_E4M3);
+    zl_check(zl_fp8_cvt_half(u16(input), scale.data<float>(), out.data<uint8_t>(), input.numel(), zdt(input.dtype()), st_of(ctx)),
+             "fp8::cvt_half_to_fp8");
+    out.set_quant_scale(scale);
+    return out;
+}
+Tensor dynamic_scaled_quant(const Context& ctx, const Tensor& input, float MAX_E4M3) {
+    return cvt_half_to_fp8(ctx, input, calc_scale(ctx, input, MAX_E4M3));
+}
+}  // namespace fp8
+
+static int elem_code(DataType t) {
+    BM_ASSERT(t == DataType::kHalf || t == DataType::kBFloat16 || t == DataType::kFloat, "half / bfloat16 / float expected");
+    return (int)t;
+}
+void gelu_inplace(const Tensor& inp, hipStream_t stream) {
+    zl_check(zl_act_inplace(inp.data(), inp.numel(), 1, elem_code(inp.dtype()), (zl_stream_t)stream), "gelu_inplace");
+}
+void silu_inplace(const Tensor& inp, hipStream_t stream) {
+    zl_check(zl_act_inplace(inp.data(), inp.numel(), 0, elem_code(inp.dtype()), (zl_stream_t)stream), "silu_inplace");
+}
+void multiply(const Context& ctx, const Tensor& a, float b, Tensor* c) {
+    zl_check(zl_scale(a.data(), c->data(), a.numel(), b, elem_code(a.dtype()), st_of(ctx)), "multiply");
+}
 
 namespace awq {
 Tensor awq_dequantize(const Context& ctx, Tensor _kernel, Tensor _scaling_factors, Tensor _zeros, int, int, int) {
@@ -461,6 +690,11 @@ static std::vector<size_t> scale_shape(const Tensor& x) { return std::vector<siz
 void quant_calc_scale(const Context& ctx, const Tensor& input, Tensor* output, Tensor* output_scale, int q_max, int q_zero) {
     BM_ASSERT_EQ(q_max, 127, "q_max");
     const int64_t k = input.size(-1), m = input.numel() / k;
+    // outputs are allocated here unless the caller passed matching ones (quant_kernel.cu:63-69); the codes in multiples of
+    // 32 rows: Int8Linear runs its IMMA product on M rounded up to GEMM_INT8_ALIGN_M = 32 (linear.cpp:590-593)
+    if (output->shape() != input.shape())
+        *output = ctx.tensor(input.shape(), DataType::kInt8, "", (size_t)(32 * k + 1023) / 1024 * 1024);
+    if (output_scale->shape() != scale_shape(input)) *output_scale = ctx.tensor(scale_shape(input), DataType::kFloat);
     if (q_zero == 0)
         zl_check(zl_quant_calc_scale(input.data<uint16_t>(), output->data<int8_t>(), output_scale->data<float>(), m, k, zdt(input.dtype()),
                                      st_of(ctx)), "quant_calc_scale");
@@ -469,8 +703,7 @@ void quant_calc_scale(const Context& ctx, const Tensor& input, Tensor* output, T
                                         zdt(input.dtype()), st_of(ctx)), "quant_calc_scale");
 }
 Tensor quant_calc_scale(const Context& ctx, const Tensor& input, int q_max, int q_zero) {
-    Tensor out = ctx.tensor(input.shape(), DataType::kInt8);
-    Tensor sc = ctx.tensor(scale_shape(input), DataType::kFloat);
+    Tensor out, sc;
     quant_calc_scale(ctx, input, &out, &sc, q_max, q_zero);
     out.set_quant_scale(sc);
     return out;

@@ -17,6 +17,9 @@
 //   src/nn/block/block_kernel.h                      | nn::{element_add_scale, element_add_scale_out}
 //   src/nn/linear/activation_kernel.h:8-16           | nn::gate_mul_inplace
 //   src/nn/layernorm/layernorm.h:7-37                | nn::LayerNorm {forward, fuse_add, inplace}
+//   src/nn/quant/gptq/gptq.h:150-160                  | nn::gptq::{int32_to_int16, reverse_perm, permute_input}
+//   src/nn/quant/fp8/fp8.h:7-19                       | nn::fp8::{cvt_half_to_fp8, calc_scale, dynamic_scaled_quant}
+//   src/nn/linear/activation_kernel.h:8-10, nn/functions/functions.h:60 | nn::{gelu_inplace, silu_inplace, multiply}
 #pragma once
 #include <map>
 #include <string>
@@ -31,11 +34,16 @@ using namespace bmengine;
 namespace gptq {
 
 // ---- load-time transforms (Int4GPTQ::load_state_dict, linear.cpp:1162-1244) -----------------------------------------
-void gptq_shuffle(const core::Context& ctx, core::Tensor& q_weight, core::Tensor q_perm);   // (K/8, N) int32 in place; q_perm must be empty
+void gptq_shuffle(const core::Context& ctx, core::Tensor& q_weight, core::Tensor q_perm);   // (K/8, N) int32; q_perm (K) int32 = argsort(g_idx) or empty
 void un_shuffle(const core::Context& ctx, core::Tensor& input);                             // AWQ nibble order -> natural, in place
 void increase_zero(const core::Context& ctx, core::Tensor& input);                          // every nibble + 1 (15 wraps to 0), in place
 core::Tensor shuffle_awq(const core::Context& ctx, core::Tensor& input, bool use_exllama);  // (K, N/8) -> (K/8, N)
 core::Tensor q4_to_q8(const core::Context& ctx, const core::Tensor& input);                 // int32 words -> one byte per nibble
+// act-order (desc_act): g_idx -> argsort on the host (Int4GPTQ::argsort_cpu) -> the 16-bit permutation and its inverse,
+// both returned as kInt32 tensors with the last dimension halved (two uint16 per word), as the reference stores them
+core::Tensor int32_to_int16(const core::Context& ctx, const core::Tensor& input);
+core::Tensor reverse_perm(const core::Context& ctx, const core::Tensor& input);             // out[input[i]] = i
+core::Tensor permute_input(const core::Context& ctx, const core::Tensor& input, const core::Tensor& q_perm);   // out[m, k] = in[m, q_perm[k]]
 
 // ---- the k-major GEMM family ---------------------------------------------------------------------------------------
 // q_weight (N, K/8) int32 exllama-shuffled words, qzeros (N, K/G) int8 (already +1), scales (N, K/G) half: the operands
@@ -43,15 +51,28 @@ core::Tensor q4_to_q8(const core::Context& ctx, const core::Tensor& input);     
 // built by amd_pack_k_major ONCE per weight (the one line a maintainer adds at the end of Int4GPTQ::load_state_dict),
 // which returns the packed tensors behind the same three names: q_weight' (N, K/8) int32 = ZLW4M nibble tiles, qzeros'
 // EMPTY, scales' (N, K/128) int32 = ZLW4M meta words.  gptq_gemm_k_major recognises the packed form by scales.dtype() ==
-// kInt32; handed the raw k-major operands it packs them into temporaries on every call (correct, slow: the path a
-// completely unmodified caller takes).  q_perm / rev_perm (act-order) must be empty here: see nn_amd.cpp.
+// kInt32; handed the raw k-major operands (the path a completely unmodified caller takes -- the reference's own
+// linear.cpp, compiled as it is, runs this way: hostcpp/refshim, tests/test_gpu_refcompile.py) it re-tiles them on first
+// sight into the weight-identity cache below.  q_perm / rev_perm (act-order): the 16-bit permutations Int4GPTQ keeps
+// (int32_to_int16 / reverse_perm of argsort(g_idx)); the activations are gathered through q_perm in front of the GEMM
+// (q_gemm_k_major.cu:1094,1104-1106), the rows were regrouped by gptq_shuffle at load.
 struct PackedW4 {
     core::Tensor q_weight, qzeros, scales;
 };
 PackedW4 amd_pack_k_major(const core::Context& ctx, const core::Tensor& q_weight, const core::Tensor& qzeros,
                           const core::Tensor& scales, bool row_interleave = false);
 
-// out_type 0: W16 (N, K) half.  out_type 1 (W4A8, q_gemm_k_major.cu:907-952 with KERNEL_dequant<int8_t,1>): int8 codes
+// A raw k-major weight handed to gptq_gemm_k_major / gemm_fuse_gate_in / gemm_moe_* (the path a completely unmodified
+// caller takes) is re-tiled ONCE: the packed form is kept in a process-wide cache keyed by the identity of the operand
+// tensors (data pointers + shape); the entry holds a reference to the raw tensors, so an address cannot be recycled
+// while its entry lives.  Cost: the raw copy stays resident next to the packed one -- callers that can spare one line
+// call amd_pack_k_major at load and drop the raw operands instead.  amd_weight_cache_clear() drops every entry (call it
+// when a model is unloaded); amd_weight_cache_size() counts them.
+void amd_weight_cache_clear();
+size_t amd_weight_cache_size();
+
+// out_type 0: W16 (N, K) half.  out_type 2 (W4_FP8_ALGO): E4M3 codes of W16 with the (1,) scale calc_w4a8_scale / the caller
+// left on q_weight.quant_scale.  out_type 1 (W4A8, q_gemm_k_major.cu:907-952 with KERNEL_dequant<int8_t,1>): int8 codes
 // (N, K) = nearbyintf(W16 / scale[n]); like the reference it needs q_weight.quant_scale, set by calc_w4a8_scale below
 // (Int4GPTQ::calc_w4a8_scale, linear.cpp:1101-1112: scale[n] = max_k |W16[n,k]| / 127, float).
 core::Tensor dequant_k_major(const core::Context& ctx, const core::Tensor& q_weight, const core::Tensor& qzeros,
@@ -108,6 +129,19 @@ core::Tensor awq_dequantize(const core::Context& ctx, core::Tensor _kernel, core
 core::Tensor awq_gemm(const core::Context& ctx, core::Tensor _in_feats, core::Tensor _kernel, core::Tensor _scaling_factors,
                       core::Tensor _zeros, size_t split_k_iters);
 }  // namespace awq
+
+namespace fp8 {
+// W4A8 with FP8 activations (W4_FP8_ALGO=1: gptq_gemm_k_major's first branch, q_gemm_k_major.cu:1003-1035).  Scales are (1,)
+// fp32 DEVICE tensors = amax / MAX_E4M3; codes are OCP E4M3FN bytes of T(x) * T(1 / scale), round-to-nearest-even, saturating
+// (fp8_util.cu).  dynamic_scaled_quant returns the codes with the scale attached as quant_scale.
+core::Tensor calc_scale(const core::Context& ctx, const core::Tensor& input, float MAX_E4M3 = 448);
+core::Tensor dynamic_scaled_quant(const core::Context& ctx, const core::Tensor& input, float MAX_E4M3 = 448);
+core::Tensor cvt_half_to_fp8(const core::Context& ctx, const core::Tensor& input, const core::Tensor& scale);
+}  // namespace fp8
+
+void gelu_inplace(const core::Tensor& inp, hipStream_t stream);
+void silu_inplace(const core::Tensor& inp, hipStream_t stream);
+void multiply(const core::Context& ctx, const core::Tensor& a, float b, core::Tensor* c);   // c = a * T(b)
 
 // ---- attention -----------------------------------------------------------------------------------------------------
 struct AttentionWorkspace {

@@ -1,0 +1,3 @@
+#pragma once
+#include "cublas_v2.h"
+#include "bm_hip.h"

@@ -1,0 +1,4 @@
+#pragma once
+#include "cublas_v2.h"
+#include "bm_hip.h"
+#include "bm_layer.h"

@@ -1,0 +1,2 @@
+#pragma once
+#include "bm_functions.h"

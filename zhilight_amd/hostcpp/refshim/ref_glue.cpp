@@ -1,0 +1,147 @@
+// ref_glue.cpp -- what is linked next to the REFERENCE's own src/nn/linear/linear.cpp (compiled unmodified from
+// /root/reference against hostcpp/refshim + bm_hip.h / bm_layer.h / bm_functions.h, see zhilight_amd/build.py:
+// build_refcompile) to turn it into a loadable test module:
+//   1. the names that translation unit references but that are OFF this boundary (Marlin, FP8 block / DeepGEMM, the
+//      GPTQ_KERNEL_ALGO=0 kernels): definitions that throw, so the object links and a call says what is missing;
+//   2. the out-of-line virtuals of model::ModelContext (src/model/model_context.h:77-215) -- linear.cpp only
+//      dynamic_casts to it, which needs its typeinfo; no ModelContext is ever constructed here;
+//   3. a pybind11 module driving nn::Linear (the reference's class, the reference's code) on host numpy arrays:
+//      construct -> load_state_dict -> forward, for the GPTQ (Int4GPTQ), INT8 (Int8Linear) and unquantised (NormalLinear)
+//      flavours.  tests/test_gpu_refcompile.py compares the results with the oracle.
+// Test infrastructure: nothing in the product links this file.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "model/model_context.h"
+#include "nn/linear/linear.h"
+#include "nn/quant/fp8/fp8.h"
+#include "nn/quant/gptq/gptq.h"
+#include "nn/quant/marlin/marlin.h"
+#include "3rd/deep_gemm/deep_gemm_api.h"
+
+namespace nn {
+namespace gptq {   // from hostcpp/nn_amd.h (not included: it re-declares the reference's gptq.h with its default arguments)
+void amd_weight_cache_clear();
+size_t amd_weight_cache_size();
+}  // namespace gptq
+}  // namespace nn
+
+#define ZL_OFF_BOUNDARY(what) \
+    throw BMEngineException(std::string(what) + " is not on the MI355X hot-path boundary (SURVEY.md section 8: out of scope)", __FILE__, __LINE__, __func__)
+
+// ---- 1. off-boundary names -------------------------------------------------------------------------------------------
+core::Tensor gptq_marlin_repack(const core::Context&, core::Tensor&, core::Tensor&, size_t, size_t, int64_t) { ZL_OFF_BOUNDARY("gptq_marlin_repack"); }
+core::Tensor gptq_marlin_gemm(const core::Context&, const core::Tensor&, core::Tensor&, core::Tensor&, core::Tensor&, core::Tensor&,
+                              core::Tensor&, core::Tensor&, size_t, size_t, size_t, bool, bool, bool) {
+    ZL_OFF_BOUNDARY("gptq_marlin_gemm");
+}
+namespace nn {
+namespace gptq {
+core::Tensor gptq_gemm(const core::Context&, core::Tensor, core::Tensor, core::Tensor, core::Tensor, core::Tensor, bool, int, int, int) {
+    ZL_OFF_BOUNDARY("nn::gptq::gptq_gemm (GPTQ_KERNEL_ALGO=0; the k-major kernels are the default)");
+}
+void reconstruct_exllama(const uint32_t*, const uint32_t*, const half*, const int*, half*, int, int, int, const cudaStream_t, int, int) {
+    ZL_OFF_BOUNDARY("nn::gptq::reconstruct_exllama (use dequant_k_major)");
+}
+void reconstruct_gptq(const uint32_t*, const uint32_t*, const half*, const int*, half*, int, int, int, const cudaStream_t) {
+    ZL_OFF_BOUNDARY("nn::gptq::reconstruct_gptq (use dequant_k_major)");
+}
+}  // namespace gptq
+}  // namespace nn
+namespace nn::fp8 {
+core::Tensor per_token_cast_to_fp8(const core::Context&, const core::Tensor&, bool, float) { ZL_OFF_BOUNDARY("nn::fp8::per_token_cast_to_fp8 (FP8 block linear, row f4)"); }
+core::Tensor dequant_fp8_block_weight(const core::Context&, const core::Tensor&, const core::Tensor&, core::DataType) {
+    ZL_OFF_BOUNDARY("nn::fp8::dequant_fp8_block_weight (FP8 block linear, row f4)");
+}
+}  // namespace nn::fp8
+
+// ---- 2. model::ModelContext's key functions ------------------------------------------------------------------------------
+namespace model {
+ModelContext::~ModelContext() = default;
+Tensor ModelContext::reduce_sum(Tensor& data, DataType out_type) const { return core::Context::reduce_sum(data, out_type); }
+}  // namespace model
+
+// ---- 3. the test module ----------------------------------------------------------------------------------------------
+namespace py = pybind11;
+using bmengine::core::Context;
+using bmengine::core::DataType;
+using bmengine::core::Tensor;
+
+namespace {
+
+DataType np_dtype(const py::array& a) {
+    const char k = a.dtype().kind();
+    const size_t sz = (size_t)a.dtype().itemsize();
+    if (k == 'f' && sz == 2) return DataType::kHalf;
+    if (k == 'f' && sz == 4) return DataType::kFloat;
+    if (k == 'i' && sz == 4) return DataType::kInt32;
+    if (k == 'i' && sz == 1) return DataType::kInt8;
+    if (k == 'i' && sz == 2) return DataType::kInt16;
+    throw std::runtime_error("unsupported numpy dtype");
+}
+// a HOST tensor aliasing a C-contiguous numpy array (what the reference's python binding hands load_state_dict)
+Tensor host_tensor(const py::array& a, const std::string& name) {
+    if (!(a.flags() & py::array::c_style)) throw std::runtime_error(name + ": C-contiguous array expected");
+    std::vector<size_t> shape(a.shape(), a.shape() + a.ndim());
+    Tensor t = Tensor::from_external(shape, np_dtype(a), const_cast<void*>(a.data()), (size_t)a.nbytes(), -1, false);
+    t.set_name(name);
+    return t;
+}
+py::array to_numpy(const Context& ctx, const Tensor& t) {
+    std::vector<py::ssize_t> shape(t.shape().begin(), t.shape().end());
+    py::dtype dt = t.dtype() == DataType::kHalf ? py::dtype("float16") : t.dtype() == DataType::kFloat ? py::dtype("float32")
+                 : t.dtype() == DataType::kInt32 ? py::dtype("int32") : py::dtype("int8");
+    py::array out(dt, shape);
+    t.to_buffer(out.mutable_data(), ctx.current_cuda_stream());
+    return out;
+}
+
+// One reference nn::Linear, loaded from numpy arrays, run on numpy activations
+class RefLinear {
+public:
+    RefLinear(int dim_in, int dim_out, int quant_type, int group_size, bool sym, bool act_order, const std::string& act_fn, int device,
+              bool weight_transposed)
+        : ctx_(device) {
+        model::QuantConfig qc(quant_type);
+        qc.group_size = group_size;
+        qc.sym = sym;
+        qc.act_order = act_order;
+        linear_.reset(new nn::Linear(ctx_, dim_in, dim_out, act_fn, qc, false, weight_transposed, false, bmengine::core::DistLayout::COLUMNAR, DataType::kHalf));
+    }
+    void load(const std::map<std::string, py::array>& arrays, const std::string& prefix) {
+        std::map<std::string, const Tensor> sd;
+        for (auto& kv : arrays) sd.emplace(kv.first, host_tensor(kv.second, kv.first));
+        linear_->load_state_dict(ctx_, sd, prefix, false);
+    }
+    py::array forward(const py::array& x) {
+        Tensor hx = host_tensor(x, "x");
+        Tensor dx = ctx_.tensor(hx.shape(), hx.dtype());
+        dx.from_buffer(hx.data(), false, ctx_.current_cuda_stream());
+        Tensor y = linear_->forward(ctx_, dx);
+        return to_numpy(ctx_, y);
+    }
+    py::array dequant_weight() { return to_numpy(ctx_, linear_->get_dequant_weight(ctx_)); }
+    std::string layer_type() const { return linear_->layer_type(); }
+
+private:
+    Context ctx_;
+    std::unique_ptr<nn::Linear> linear_;
+};
+
+}  // namespace
+
+PYBIND11_MODULE(zl_reflinear, m) {
+    m.doc() = "the reference's nn::Linear (src/nn/linear/linear.cpp, compiled unmodified) on the MI355X boundary";
+    py::class_<RefLinear>(m, "RefLinear")
+        .def(py::init<int, int, int, int, bool, bool, const std::string&, int, bool>(), py::arg("dim_in"), py::arg("dim_out"), py::arg("quant_type"),
+             py::arg("group_size") = 128, py::arg("sym") = false, py::arg("act_order") = false, py::arg("act_fn") = "", py::arg("device") = 0,
+             py::arg("weight_transposed") = false)
+        .def("load", &RefLinear::load)
+        .def("forward", &RefLinear::forward)
+        .def("dequant_weight", &RefLinear::dequant_weight)
+        .def("layer_type", &RefLinear::layer_type);
+    m.def("weight_cache_size", &nn::gptq::amd_weight_cache_size);
+    m.def("weight_cache_clear", &nn::gptq::amd_weight_cache_clear);
+    py::register_exception<BMEngineException>(m, "BMEngineException");
+}
