@@ -278,8 +278,14 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the activations have landed BEFORE the first weight is requested:
-    __builtin_amdgcn_sched_barrier(0);                 // issued behind the ring they come back 2 us later (bcast_probe.hip)
+    // the activations have landed BEFORE the first weight is requested: issued behind the ring they come back 2 us later
+    // (bcast_probe.hip).  The wait is the BUILTIN, not inline asm: the compiler's waitcnt pass models an S_WAITCNT it can see
+    // and stops treating the registers above as pending.  With an opaque asm it kept them pending, lost the count of later
+    // loads at the predicated ring issues and put its own `s_waitcnt vmcnt(0)` in front of every conversion slot -- AFTER
+    // ring items had been requested, so slot s waited for the weights issued during slot s - 1 (a first-byte latency per
+    // slot: the long-K kernel finished staging at 4.2 us)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), expcnt / lgkmcnt untouched
+    __builtin_amdgcn_sched_barrier(0);
     ZL_IPROBE(1);
 
     // ---- weight ring: wave w streams the items (tile0 + r, g = w + 8 gi), gi-major.  The D prologue items are issued
