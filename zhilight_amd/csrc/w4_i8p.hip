@@ -177,16 +177,22 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
             if (row < M) {
                 constexpr int kS = 16;
                 const int head = g < groups ? g : 0;
-                const size_t rec0 = ((size_t)row * groups + head) * p.mg_max_splits;
+                // records of (row, head) are consecutive: one descriptor per array, the record index in the scalar
+                // offset's place and u in the immediate -- no 64-bit address arithmetic per load, and a record past the
+                // end of the arrays (u >= max_splits on the last head) reads as zero instead of faulting
+                const uint32_t n_rec = (uint32_t)M * (uint32_t)groups * (uint32_t)p.mg_max_splits;
+                const __amdgpu_buffer_rsrc_t rpart = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.mg_part), 0, n_rec * 256u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rstat = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mg_stat), 0, n_rec * 8u, 0x00020000);
+                const uint32_t rec0 = ((uint32_t)row * (uint32_t)groups + (uint32_t)head) * (uint32_t)p.mg_max_splits;
+                const uint32_t po = rec0 * 256u + (uint32_t)uo * 16u, so = rec0 * 8u;
                 uint4 pv[kS];
                 float2 st[kS];
 #pragma unroll
                 for (int u = 0; u < kS; ++u) {           // every record the launch geometry allows; dead ones are masked below
-                    // (unconditional loads of a clamped record: behind a uniform branch each load is waited for at the
-                    //  join -- 16 dependent round trips, 8.0 instead of 6.7 us in the step)
-                    const size_t rec = rec0 + (u < p.mg_max_splits ? u : 0);
-                    pv[u] = *reinterpret_cast<const uint4*>(p.mg_part + rec * 128 + uo * 8);
-                    st[u] = *reinterpret_cast<const float2*>(p.mg_stat + rec * 2);
+                    // (unconditional loads: behind a uniform branch each load is waited for at the join -- 16 dependent
+                    //  round trips, 8.0 instead of 6.7 us in the step)
+                    pv[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rpart, po + (uint32_t)u * 256u, 0, 0));
+                    st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rstat, so + (uint32_t)u * 8u, 0, 0));
                 }
                 const int elen = min(p.buf_lens[row], p.mg_valid_lens[row]);
                 const int ns = min((elen + p.mg_split_len - 1) / p.mg_split_len, kS);
@@ -208,13 +214,15 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
                         z += f;
                     }
                 }
-                const float zi = z + 1e-20f;
+                // (one reciprocal instead of eight divisions: ~70 VALU of a front end every workgroup repeats; the product
+                //  differs from the quotient by at most an fp32 ulp before the rounding to fp16)
+                const float zi = 1.0f / (z + 1e-20f);
                 uint32_t o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     h16x2 hh;
-                    hh.x = zl_f32_to_f16(a[2 * e] / zi);
-                    hh.y = zl_f32_to_f16(a[2 * e + 1] / zi);
+                    hh.x = zl_f32_to_f16(a[2 * e] * zi);
+                    hh.y = zl_f32_to_f16(a[2 * e + 1] * zi);
                     o[e] = __builtin_bit_cast(uint32_t, hh);
                 }
                 if (g < groups) xr[s] = make_uint4(o[0], o[1], o[2], o[3]);
