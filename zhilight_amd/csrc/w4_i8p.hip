@@ -191,8 +191,11 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
                 for (int u = 0; u < kS; ++u) {           // every record the launch geometry allows; dead ones are masked below
                     // (unconditional loads: behind a uniform branch each load is waited for at the join -- 16 dependent
                     //  round trips, 8.0 instead of 6.7 us in the step)
-                    pv[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rpart, po + (uint32_t)u * 256u, 0, 0));
-                    st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rstat, so + (uint32_t)u * 8u, 0, 0));
+                    //  a record index past the launch's split count re-reads record 0 -- a line the wave already has -- rather
+                    //  than the next head's; scalar select, scalar offset operand)
+                    const uint32_t uc = u < p.mg_max_splits ? (uint32_t)u : 0u;
+                    pv[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rpart, po, uc * 256u, 0));
+                    st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rstat, so, uc * 8u, 0));
                 }
                 const int elen = min(p.buf_lens[row], p.mg_valid_lens[row]);
                 const int ns = min((elen + p.mg_split_len - 1) / p.mg_split_len, kS);
