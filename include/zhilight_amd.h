@@ -622,6 +622,39 @@ int zl_gptq_permute_rows(const uint32_t* qweight, uint32_t* out, const int32_t* 
 int zl_permute_input_u16(const uint16_t* x, int64_t ldx, const uint16_t* perm, uint16_t* out, int64_t rows, int64_t k, zl_stream_t s);
 
 
+/* ------------------------------------------------------------------------------------------------
+ * f4, first part: the FP8 128x128-block linear and the MoE router.
+ *   zl_fp8_per_token_cast   nn::fp8::per_token_cast_to_fp8 (src/nn/quant/fp8/fp8_util.cu:229-323): per (row, 128-column block)
+ *                           amax = max|x| clamped at 1e-4, codes = e4m3(float(x) * (MAX / amax)) (fp32, RNE, saturating), scale =
+ *                           amax / MAX at [block * aligned_m + row] (scale_col_major, what the GEMM reads) or [row * (n/128) + block].
+ *                           Codes and scales bit-exact against the oracle.
+ *   zl_fp8_block_dequant    nn::fp8::dequant_fp8_block_weight (:325-385): out = T(float(code) * scale[row/128][col/128]); bit-exact.
+ *   zl_fp8_block_gemm_group deep_gemm_fp8_block_h20_group (3rd/deep_gemm/deep_gemm_api.h, the call of Fp8Block::forward /
+ *                           grouped_gemm, src/nn/linear/linear.cpp:1863-1945): out[m, n] = T(sum_kb lhs_scales[kb, m] *
+ *                           rhs_scales[g][n/128][kb] * sum_{k in kb} lhs[m, k] rhs[g][n, k]), g = m_indices[m] (NULL: one
+ *                           matrix; negative: row skipped; groups contiguous and aligned to 16 rows).  fp32 accumulation per
+ *                           block on v_mfma_f32_16x16x32_fp8_fp8.  K % 128 == 0.  The reference's kernel is a closed binary:
+ *                           parity is against the format's definition in fp64 (oracle/zl_oracle.c: zlo_fp8_block_gemm).
+ *   zl_moe_top_k_softmax    nn::top_k_softmax (src/nn/feedforward/ff_kernel.cu:174-268); scoring 1 softmax, 2 sigmoid (as written
+ *                           there: 1 / (1 + expf(+x))), 3 linear; out_v / out_idx (tokens, top_k_ext), slots >= top_k get weight 1;
+ *                           worker_load[id % num_worker] / expert_load[id] are incremented when given.
+ *   zl_moe_group_topk       nn::group_topk_softmax (ff_kernel.cu:296-515): DeepSeek-V3's group-limited routing (best groups by
+ *                           their best biased score, weights = un-biased scores, renormalised, x weight_scale).
+ * ---------------------------------------------------------------------------------------------- */
+int zl_fp8_per_token_cast(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ld_out, float* scale, int64_t aligned_m, int64_t m, int64_t n,
+                          int scale_col_major, float max_e4m3, int dtype, zl_stream_t s);
+int zl_fp8_block_dequant(const uint8_t* w, const float* scale, uint16_t* out, int64_t rows, int64_t cols, int64_t stride_scale, int dtype,
+                         zl_stream_t s);
+int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t aligned_m, const uint8_t* rhs, const float* rhs_scales,
+                            const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype, zl_stream_t s);
+int zl_moe_top_k_softmax(const uint16_t* logits, int64_t tokens, int num_exp, int top_k, int top_k_ext, int renormalize, float weight_scale,
+                         int scoring, int dtype, float* out_v, int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker,
+                         zl_stream_t s);
+int zl_moe_group_topk(const uint16_t* logits, const float* correction_bias, int64_t tokens, int num_exp, int top_k, int top_k_ext,
+                      int renormalize, float weight_scale, int scoring, int num_group, int topk_group, int dtype, float* out_v,
+                      int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker, zl_stream_t s);
+
+
 #ifdef __cplusplus
 }
 #endif

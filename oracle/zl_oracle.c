@@ -1378,3 +1378,214 @@ void zlo_fp8_gemm_nt(const uint8_t* a, const uint8_t* b, float scale_a, float sc
             out[i * n + j] = zlo_f32_to_f16((float)(acc * ((double)scale_a * (double)scale_b)));
         }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* f4 (config 5, first part): FP8 128x128-block linear and the MoE router                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* KERNEL_per_token_cast_to_fp8 (src/nn/quant/fp8/fp8_util.cu:229-275): one scale per (row, 128-column block):
+ * amax = max |float(x)| clamped at 1e-4 (max_e4m3 = 448 in the reference), codes = e4m3(float(x) * (448 / amax)) with both
+ * operations in fp32, scale = amax / 448 stored at [block * aligned_m + row] (scale_col_major) or [row * nblocks + block]. */
+void zlo_fp8_per_token_cast(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ld_out, float* scale, int64_t aligned_m,
+                            int64_t m, int64_t n, int col_major, float max_e4m3, int dtype) {
+    const int64_t nb = n / 128;
+    for (int64_t r = 0; r < m; ++r)
+        for (int64_t b = 0; b < nb; ++b) {
+            float amax = 0.f;
+            for (int j = 0; j < 128; ++j) amax = fmaxf(amax, fabsf(T2f(x[r * ldx + b * 128 + j], dtype)));
+            if (amax < 1e-4f) amax = 1e-4f;
+            const float mul = max_e4m3 / amax;
+            for (int j = 0; j < 128; ++j) out[r * ld_out + b * 128 + j] = zlo_f32_to_e4m3(T2f(x[r * ldx + b * 128 + j], dtype) * mul);
+            scale[col_major ? b * aligned_m + r : r * nb + b] = amax / max_e4m3;
+        }
+}
+
+/* KERNEL_dequant_fp8_block (fp8_util.cu:325-357): out = T(float(code) * scale[row / 128][col / 128]) */
+void zlo_fp8_block_dequant(const uint8_t* w, const float* scale, uint16_t* out, int64_t rows, int64_t cols, int64_t stride_scale, int dtype) {
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c)
+            out[r * cols + c] = f2T(zlo_e4m3_to_f32(w[r * cols + c]) * scale[(r / 128) * stride_scale + c / 128], dtype);
+}
+
+/* The block-scaled product deep_gemm_fp8_block_h20_group computes (3rd/deep_gemm/deep_gemm_api.h; the kernel itself is a
+ * closed binary, so this is the format's definition in fp64, not a restatement of its rounding points):
+ * out[m, n] = T( sum_kb sa[kb, m] * sw[g(m)][n / 128][kb] * sum_{k in block kb} a[m, k] * w[g(m)][n, k] ),
+ * g(m) = m_indices[m] (rows with a negative index are left untouched), lhs scales column-major with leading dimension aligned_m. */
+void zlo_fp8_block_gemm(const uint8_t* a, const float* sa, int64_t aligned_m, const uint8_t* w, const float* sw, const int32_t* m_indices,
+                        uint16_t* out, int64_t m, int64_t n, int64_t k, int dtype) {
+    const int64_t kb = k / 128, nbw = (n + 127) / 128;
+    #pragma omp parallel for
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t g = m_indices ? m_indices[i] : 0;
+        if (g < 0) continue;
+        const uint8_t* wg = w + g * n * k;
+        const float* swg = sw + g * nbw * kb;
+        for (int64_t j = 0; j < n; ++j) {
+            double acc = 0.0;
+            for (int64_t b = 0; b < kb; ++b) {
+                double blk = 0.0;
+                for (int t = 0; t < 128; ++t) blk += (double)zlo_e4m3_to_f32(a[i * k + b * 128 + t]) * (double)zlo_e4m3_to_f32(wg[j * k + b * 128 + t]);
+                acc += blk * ((double)sa[b * aligned_m + i] * (double)swg[(j / 128) * kb + b]);
+            }
+            out[i * n + j] = dtype ? zlo_f32_to_bf16((float)acc) : zlo_f64_to_f16(acc);
+        }
+    }
+}
+
+/* ---- MoE router (src/nn/feedforward/ff_kernel.cu:92-470) ---- */
+static inline float warp32_tree_max(float* x) {      /* warpReduceMaxB: shuffle-down tree, lane 0 broadcast */
+    for (int off = 16; off > 0; off >>= 1)
+        for (int l = 0; l < off; ++l) x[l] = x[l] > x[l + off] ? x[l] : x[l + off];
+    return x[0];
+}
+/* DEV_softmax_inplace with `threads` threads (32: warp trees; more: block trees), data in place */
+static void route_softmax(float* data, int n, int threads) {
+    float part[1024];
+    for (int t = 0; t < threads; ++t) {
+        float mx = -1e20f;
+        for (int i = t; i < n; i += threads) mx = fmaxf(mx, data[i]);
+        part[t] = mx;
+    }
+    float gmax;
+    if (threads > 32) {      /* blockReduceMax: per-warp tree, then warp 0 over the per-warp results padded with -inf */
+        float wr[32];
+        for (int w = 0; w < 32; ++w) wr[w] = -INFINITY;
+        for (int w = 0; w < threads / 32; ++w) wr[w] = warp32_tree_max(part + 32 * w);
+        gmax = warp32_tree_max(wr);
+    } else gmax = warp32_tree_max(part);
+    for (int t = 0; t < threads; ++t) {
+        float sm = 1e-20f;
+        for (int i = t; i < n; i += threads) {
+            data[i] = expf(data[i] - gmax);
+            sm += data[i];
+        }
+        part[t] = sm;
+    }
+    const float gsum = threads > 32 ? block_tree_sum(part, threads) : warp32_tree_sum(part);
+    for (int i = 0; i < n; ++i) data[i] /= gsum;
+}
+
+/* KERNEL_top_k_softmax (ff_kernel.cu:174-236), 32 threads per token.  scoring: 1 softmax, 2 "sigmoid" -- the kernel computes
+ * 1 / (1 + expf(+x)) (DEV_route_score :158-160, no minus sign: restated as written), 3 linear.  Insertion sort, a later equal
+ * value does not displace an earlier one.  Slots k .. top_k_ext - 1: weight 1 (indices untouched).  load counters optional. */
+void zlo_moe_top_k_softmax(const uint16_t* logits, int64_t tokens, int num_exp, int k, int top_k_ext, int renormalize, float weight_scale,
+                           int scoring, int dtype, float* out_v, int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker) {
+    for (int64_t q = 0; q < tokens; ++q) {
+        float data[256];
+        for (int i = 0; i < num_exp; ++i) data[i] = T2f(logits[q * num_exp + i], dtype);
+        if (scoring == 1) route_softmax(data, num_exp, 32);
+        else if (scoring == 2) for (int i = 0; i < num_exp; ++i) data[i] = 1.f / (1.f + expf(data[i]));
+        float value[17];
+        int idx[17];
+        for (int i = 0; i < k; ++i) { value[i] = -1e20f; idx[i] = 0; }
+        for (int j = 0; j < num_exp; ++j) {
+            const float v = data[j];
+            int i;
+            for (i = k - 1; i >= 0; --i) {
+                if (v > value[i]) { value[i + 1] = value[i]; idx[i + 1] = idx[i]; }
+                else { value[i + 1] = v; idx[i + 1] = j; break; }
+            }
+            if (i < 0) { value[0] = v; idx[0] = j; }
+        }
+        float sum_e = 1.f;
+        if (renormalize) {
+            sum_e = 1.e-20f;
+            for (int i = 0; i < k; ++i) sum_e += value[i];
+        }
+        for (int i = 0; i < k; ++i) {
+            out_v[q * top_k_ext + i] = value[i] / sum_e * weight_scale;
+            out_idx[q * top_k_ext + i] = idx[i];
+            if (worker_load) worker_load[idx[i] % num_worker] += 1;
+            if (expert_load) expert_load[idx[i]] += 1;
+        }
+        for (int i = k; i < top_k_ext; ++i) out_v[q * top_k_ext + i] = 1.f;
+    }
+}
+
+/* warpBitonicSort<T, N> (ff_kernel.cu:273-291): descending, equal values ordered by smaller position first */
+static void bitonic_desc(float* v, int* pos, int n_lanes, int width) {
+    for (int base = 0; base < n_lanes; base += width)
+        for (int kk = 2; kk <= width; kk *= 2)
+            for (int j = kk / 2; j > 0; j /= 2) {
+                float nv[32];
+                int np[32];
+                for (int l = 0; l < width; ++l) {
+                    const int lane = l, other = l ^ j;
+                    const float v1 = v[base + lane], v2 = v[base + other];
+                    const int p1 = pos[base + lane], p2 = pos[base + other];
+                    const int desc = ((lane & kk) == 0) ^ 0, upper = (lane & j) != 0;
+                    const int take = desc ^ (v1 > v2 || (v1 == v2 && p1 < p2)) ^ upper;
+                    nv[l] = take ? v2 : v1;
+                    np[l] = take ? p2 : p1;
+                }
+                for (int l = 0; l < width; ++l) { v[base + l] = nv[l]; pos[base + l] = np[l]; }
+            }
+}
+
+/* KERNEL_group_topk (ff_kernel.cu:296-456), num_group warps per token: sigmoid 1 / (1 + expf(-x)) or block softmax; per group
+ * a 32-lane sort of (score + correction_bias); group score = its best entry; the topk_group best groups (8-lane sort) keep
+ * their k best entries; a final 32-lane sort picks k; the OUTPUT weight is the un-biased score when a bias is given.
+ * sum over the k weights + 1e-20 when renormalising (shuffle-down tree over 32 lanes, zeros beyond k). */
+void zlo_moe_group_topk(const uint16_t* logits, const float* correction_bias, int64_t tokens, int num_exp, int k, int top_k_ext,
+                        int renormalize, float weight_scale, int scoring, int num_group, int topk_group, int dtype, float* out_v,
+                        int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker) {
+    const int nig = num_exp / num_group;
+    for (int64_t q = 0; q < tokens; ++q) {
+        float data[512];
+        for (int i = 0; i < num_exp; ++i) data[i] = T2f(logits[q * num_exp + i], dtype);
+        if (scoring == 2) for (int i = 0; i < num_exp; ++i) data[i] = 1.f / (1.f + expf(-data[i]));
+        else route_softmax(data, num_exp, num_group * 32);
+        float gs[32][32];
+        int gp[32][32];
+        float shared_val[32], group_score[32];
+        int shared_pos[32], group_id[32], group_rank[32];
+        for (int g = 0; g < num_group; ++g) {
+            for (int l = 0; l < 32; ++l) {
+                gs[g][l] = -1e20f;
+                gp[g][l] = -1;
+                if (l < nig) {
+                    gp[g][l] = g * nig + l;
+                    gs[g][l] = data[gp[g][l]] + (correction_bias ? correction_bias[gp[g][l]] : 0.f);
+                }
+            }
+            bitonic_desc(gs[g], gp[g], 32, 32);
+            group_rank[g] = -1;
+        }
+        for (int l = 0; l < 32; ++l) {
+            group_score[l] = l < num_group ? gs[l][0] : -1e20f;
+            group_id[l] = l < num_group ? l : 0;      /* shared_gid beyond num_group is uninitialised in the kernel; never selected */
+        }
+        bitonic_desc(group_score, group_id, 8, 8);     /* only the first 8 lanes matter (num_group <= 8 asserted) */
+        for (int t = 0; t < topk_group; ++t) group_rank[group_id[t]] = t;
+        for (int l = 0; l < 32; ++l) { shared_val[l] = 0.f; shared_pos[l] = 0; }
+        for (int g = 0; g < num_group; ++g)
+            if (group_rank[g] >= 0)
+                for (int l = 0; l < k; ++l) {
+                    shared_val[group_rank[g] * k + l] = gs[g][l];
+                    shared_pos[group_rank[g] * k + l] = gp[g][l];
+                }
+        float fv[32];
+        int fp[32];
+        for (int l = 0; l < 32; ++l) {
+            fv[l] = l < topk_group * k ? shared_val[l] : -1e20f;
+            fp[l] = shared_pos[l];
+        }
+        bitonic_desc(fv, fp, 32, 32);
+        float w[32];
+        for (int l = 0; l < 32; ++l) w[l] = 0.f;
+        for (int l = 0; l < k; ++l) w[l] = correction_bias ? data[fp[l]] : fv[l];
+        float sum_e = 1.f;
+        if (renormalize) {
+            float tree[32];
+            for (int l = 0; l < 32; ++l) tree[l] = w[l];
+            sum_e = warp32_tree_sum(tree) + 1e-20f;
+        }
+        for (int l = 0; l < k; ++l) {
+            out_v[q * top_k_ext + l] = w[l] / sum_e * weight_scale;
+            out_idx[q * top_k_ext + l] = fp[l];
+            if (worker_load) worker_load[fp[l] % num_worker] += 1;
+            if (expert_load) expert_load[fp[l]] += 1;
+        }
+        for (int l = k; l < top_k_ext; ++l) { out_v[q * top_k_ext + l] = 1.f; out_idx[q * top_k_ext + l] = 0; }
+    }
+}

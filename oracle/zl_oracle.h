@@ -194,6 +194,19 @@ void zlo_dequant_sum_quant_g32(const uint16_t* my, const int8_t* q_others, const
                                uint16_t* out_scale, int64_t groups, int world, int dtype);
 void zlo_dequant_group_32(const int8_t* q, const uint16_t* scale, uint16_t* out, int64_t groups, int dtype);
 
+
+/* f4 (config 5, first part): FP8 128x128-block linear (fp8_util.cu:229-385, deep_gemm_api.h) and the MoE router (ff_kernel.cu:92-470) */
+void zlo_fp8_per_token_cast(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ld_out, float* scale, int64_t aligned_m,
+                            int64_t m, int64_t n, int col_major, float max_e4m3, int dtype);
+void zlo_fp8_block_dequant(const uint8_t* w, const float* scale, uint16_t* out, int64_t rows, int64_t cols, int64_t stride_scale, int dtype);
+void zlo_fp8_block_gemm(const uint8_t* a, const float* sa, int64_t aligned_m, const uint8_t* w, const float* sw, const int32_t* m_indices,
+                        uint16_t* out, int64_t m, int64_t n, int64_t k, int dtype);
+void zlo_moe_top_k_softmax(const uint16_t* logits, int64_t tokens, int num_exp, int k, int top_k_ext, int renormalize, float weight_scale,
+                           int scoring, int dtype, float* out_v, int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker);
+void zlo_moe_group_topk(const uint16_t* logits, const float* correction_bias, int64_t tokens, int num_exp, int k, int top_k_ext,
+                        int renormalize, float weight_scale, int scoring, int num_group, int topk_group, int dtype, float* out_v,
+                        int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker);
+
 #ifdef __cplusplus
 }
 #endif

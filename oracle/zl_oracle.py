@@ -611,3 +611,64 @@ def fp8_gemm_nt(a, b, scale_a, scale_b):
     out = np.empty((a.shape[0], b.shape[0]), np.uint16)
     lib().zlo_fp8_gemm_nt(_p(a), _p(b), _f(scale_a), _f(scale_b), _p(out), _i(a.shape[0]), _i(b.shape[0]), _i(a.shape[1]))
     return out
+
+
+# ---- f4 (config 5, first part): FP8 block linear + MoE router
+def fp8_per_token_cast(x, col_major=True, max_e4m3=448.0, dtype=0):
+    """(codes (m, n) uint8, scales fp32: (n/128, aligned_m) column-major or (m, n/128)); aligned_m = round_up(m, 4)"""
+    x = _c(x, np.uint16)
+    m, n = x.shape
+    am = (m + 3) // 4 * 4
+    out = np.empty((m, n), np.uint8)
+    sc = np.zeros((n // 128, am) if col_major else (am, n // 128), np.float32)
+    lib().zlo_fp8_per_token_cast(_p(x), _i(n), _p(out), _i(n), _p(sc), _i(am), _i(m), _i(n), C.c_int(int(col_major)), _f(max_e4m3), C.c_int(dtype))
+    return out, sc
+
+
+def fp8_block_dequant(w, scale, dtype=0):
+    w, scale = _c(w, np.uint8), _c(scale, np.float32)
+    out = np.empty(w.shape, np.uint16)
+    lib().zlo_fp8_block_dequant(_p(w), _p(scale), _p(out), _i(w.shape[0]), _i(w.shape[1]), _i(scale.shape[1]), C.c_int(dtype))
+    return out
+
+
+def fp8_block_gemm(a, sa, w, sw, m_indices=None, dtype=1):
+    """a (m, k) codes, sa (k/128, aligned_m) fp32, w (G, n, k) or (n, k) codes, sw (G, ceil(n/128), k/128); out (m, n) T bits"""
+    a, sa, w, sw = _c(a, np.uint8), _c(sa, np.float32), _c(w, np.uint8), _c(sw, np.float32)
+    m, k = a.shape
+    n = w.shape[-2]
+    out = np.zeros((m, n), np.uint16)
+    mi = None if m_indices is None else _c(m_indices, np.int32)
+    lib().zlo_fp8_block_gemm(_p(a), _p(sa), _i(sa.shape[1]), _p(w), _p(sw), _p(mi), _p(out), _i(m), _i(n), _i(k), C.c_int(dtype))
+    return out
+
+
+_SCORING = {"": 1, "softmax": 1, "sigmoid": 2, "linear": 3}
+
+
+def moe_top_k_softmax(logits, k, top_k_ext=None, renormalize=False, weight_scale=1.0, scoring="softmax", dtype=0, num_worker=0):
+    logits = _c(logits, np.uint16)
+    t, e = logits.shape
+    ext = top_k_ext or k
+    v, idx = np.zeros((t, ext), np.float32), np.zeros((t, ext), np.int32)
+    wl = np.zeros(max(num_worker, 1), np.int32)
+    el = np.zeros(e, np.int32)
+    lib().zlo_moe_top_k_softmax(_p(logits), _i(t), C.c_int(e), C.c_int(k), C.c_int(ext), C.c_int(int(renormalize)), _f(weight_scale),
+                                C.c_int(_SCORING[scoring]), C.c_int(dtype), _p(v), _p(idx), _p(wl) if num_worker else None, _p(el),
+                                C.c_int(num_worker))
+    return v, idx, wl, el
+
+
+def moe_group_topk(logits, bias, k, num_group, topk_group, top_k_ext=None, renormalize=True, weight_scale=1.0, scoring="sigmoid", dtype=0,
+                   num_worker=0):
+    logits = _c(logits, np.uint16)
+    t, e = logits.shape
+    ext = top_k_ext or k
+    b = None if bias is None else _c(bias, np.float32)
+    v, idx = np.zeros((t, ext), np.float32), np.zeros((t, ext), np.int32)
+    wl = np.zeros(max(num_worker, 1), np.int32)
+    el = np.zeros(e, np.int32)
+    lib().zlo_moe_group_topk(_p(logits), _p(b), _i(t), C.c_int(e), C.c_int(k), C.c_int(ext), C.c_int(int(renormalize)), _f(weight_scale),
+                             C.c_int(_SCORING[scoring]), C.c_int(num_group), C.c_int(topk_group), C.c_int(dtype), _p(v), _p(idx),
+                             _p(wl) if num_worker else None, _p(el), C.c_int(num_worker))
+    return v, idx, wl, el

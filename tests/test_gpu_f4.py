@@ -1,0 +1,197 @@
+"""f4, first part -- GPU parity through the C ABI:
+  * per-token 1x128 FP8 activation quantisation (fp8_util.cu:229-323): codes and scales BIT-EXACT against the oracle
+  * 128x128-block weight dequantisation (:325-385): bit-exact
+  * the block-scaled FP8 GEMM deep_gemm_fp8_block_h20_group stands for (closed binary in the reference): against the format's
+    definition in fp64, output rounding of T + fp32 accumulation noise; plain and grouped (m_indices) forms
+  * the MoE router: top_k_softmax and the group-limited top-k of DeepSeek-V3 -- expert ids EXACT, weights within a few fp32 ulp
+    (device expf vs glibc), load counters exact
+  * the reference's own Fp8Block layer (linear.cpp compiled unmodified, -DENABLE_DS_DEEP_GEMM) on top of them."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.view(dtype) if dtype is not None else t
+
+
+def _bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def _acts(rng, m, n, dtype):
+    x = (rng.standard_normal((m, n)) * np.exp(rng.standard_normal((m, 1)) * 2.0)).astype(np.float32)
+    x[:, :128] *= 1e-6                                   # a block below the 1e-4 clamp
+    t = torch.from_numpy(x).to(dtype)
+    return t
+
+
+@pytest.mark.parametrize("dtype,code", [(torch.float16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("col_major", [True, False])
+def test_per_token_cast_bit_exact(oracle, dev, dtype, code, col_major):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(3 + code)
+    for m, n in ((1, 7168), (5, 2048), (70, 512)):
+        x = _acts(rng, m, n, dtype)
+        pad = torch.zeros((m, n + 64), dtype=dtype)
+        pad[:, :n] = x                                    # strided rows
+        codes, scales = ops.fp8_per_token_cast(pad.to(dev)[:, :n], scale_col_major=col_major)
+        want_c, want_s = oracle.fp8_per_token_cast(_bits(x), col_major=col_major, dtype=code)
+        assert np.array_equal(codes.cpu().numpy(), want_c)
+        got_s = scales.cpu().numpy()
+        if col_major:
+            assert np.array_equal(got_s[:, :m].view(np.uint32), want_s[:, :m].view(np.uint32))
+        else:
+            assert np.array_equal(got_s[:m].view(np.uint32), want_s[:m].view(np.uint32))
+        # the format's promise: dequantised codes within half an E4M3 step (2^-4 relative) of x, the block maximum exact
+        deq = oracle.e4m3_to_f32(want_c).reshape(m, n // 128, 128) * (want_s[:, :m].T if col_major else want_s[:m])[:, :, None]
+        xf = x.float().numpy().reshape(m, n // 128, 128)
+        amax = np.maximum(np.abs(xf).max(axis=2, keepdims=True), 1e-4)
+        assert (np.abs(deq - xf) <= amax * 2.0 ** -4 * 1.001).all()
+
+
+@pytest.mark.parametrize("dtype,code", [(torch.float16, 0), (torch.bfloat16, 1)])
+def test_block_dequant_bit_exact(oracle, dev, dtype, code):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(9)
+    rows, cols = 300, 640                                 # ragged last row block
+    w8 = rng.integers(0, 256, size=(rows, cols), dtype=np.uint8)
+    w8[(w8 & 0x7f) == 0x7f] = 0x7e                        # no NaN codes in a checkpoint
+    sc = (np.abs(rng.standard_normal((3, 5))) * 0.01 + 1e-3).astype(np.float32)
+    got = ops.fp8_block_dequant(_t(w8, dev), _t(sc, dev), dtype)
+    assert np.array_equal(_bits(got), oracle.fp8_block_dequant(w8, sc, dtype=code))
+
+
+def _block_weight(rng, n, k, groups=None):
+    shape = (n, k) if groups is None else (groups, n, k)
+    w8 = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    w8[(w8 & 0x7f) == 0x7f] = 0x7e
+    w8[(w8 & 0x7f) > 0x70] -= 0x20                        # keep |w| moderate: the products stay far from fp16 overflow
+    sshape = ((n + 127) // 128, k // 128) if groups is None else (groups, (n + 127) // 128, k // 128)
+    sw = (np.abs(rng.standard_normal(sshape)) * 2e-3 + 1e-3).astype(np.float32)
+    return w8, sw
+
+
+def _gemm_bar(got_bits, want_bits, oracle, code):
+    f = (lambda b: oracle.u2h(b).astype(np.float64)) if code == 0 else (lambda b: (b.astype(np.uint32) << 16).view(np.float32).astype(np.float64))
+    got, want = f(got_bits), f(want_bits)
+    rms = np.sqrt((want ** 2).mean())
+    ulp = 2.0 ** (-10 if code == 0 else -7)               # one output rounding of T on either side + fp32 accumulation
+    assert (np.abs(got - want) <= ulp * np.abs(want) + 2e-5 * rms).all(), float((np.abs(got - want) / rms).max())
+
+
+@pytest.mark.parametrize("dtype,code", [(torch.bfloat16, 1), (torch.float16, 0)])
+@pytest.mark.parametrize("m,n,k", [(1, 512, 1024), (5, 200, 512), (70, 384, 640)])
+def test_block_gemm_against_the_format_definition(oracle, dev, dtype, code, m, n, k):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(m + n)
+    x = _acts(rng, m, k, dtype)
+    a8, sa = oracle.fp8_per_token_cast(_bits(x), dtype=code)
+    w8, sw = _block_weight(rng, n, k)
+    got = ops.fp8_block_gemm(_t(a8, dev), _t(sa, dev), _t(w8, dev), _t(sw, dev), dtype=dtype)
+    _gemm_bar(_bits(got), oracle.fp8_block_gemm(a8, sa, w8, sw, dtype=code), oracle, code)
+    # the composed linear (Fp8Block::forward) = the same launch behind the device-side cast
+    got2 = ops.fp8_block_linear(x.to(dev), _t(w8, dev), _t(sw, dev))
+    assert torch.equal(got2, got)
+    # and it is a sane quantisation of x . W^T: rms error of a few percent of the exact product of the dequantised operands
+    wd = oracle.e4m3_to_f32(w8) * np.repeat(np.repeat(sw, 128, axis=0)[:n], 128, axis=1)
+    ref = x.float().numpy().astype(np.float64) @ wd.T
+    g = got.float().cpu().numpy().astype(np.float64)
+    assert np.sqrt(((g - ref) ** 2).mean()) <= 0.05 * np.sqrt((ref ** 2).mean())
+
+
+def test_grouped_block_gemm(oracle, dev):
+    """the m-grouped contiguous layout of FP8Block::grouped_gemm: rows sorted by expert, 64-row aligned, -1 = padding row"""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(77)
+    groups, n, k = 3, 256, 512
+    m_idx = np.concatenate([np.full(64, 2), np.full(40, 0), np.full(24, -1), np.full(64, 1), np.full(10, 0), np.full(54, -1)]).astype(np.int32)
+    m = m_idx.size
+    x = _acts(rng, m, k, torch.bfloat16)
+    a8, sa = oracle.fp8_per_token_cast(_bits(x), dtype=1)
+    w8, sw = _block_weight(rng, n, k, groups)
+    sentinel = torch.full((m, n), 7.0, dtype=torch.bfloat16, device=dev)
+    got = ops.fp8_block_gemm(_t(a8, dev), _t(sa, dev), _t(w8, dev), _t(sw, dev), m_indices=_t(m_idx, dev), out=sentinel.clone())
+    want = oracle.fp8_block_gemm(a8, sa, w8, sw, m_indices=m_idx, dtype=1)
+    live = m_idx >= 0
+    _gemm_bar(_bits(got)[live], want[live], oracle, 1)
+    assert torch.equal(got[~torch.from_numpy(live).to(dev)], sentinel[~torch.from_numpy(live).to(dev)])     # padding rows untouched
+
+
+def _ulps(a, b):
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+@pytest.mark.parametrize("dtype,code", [(torch.float16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("scoring,renorm,ext", [("softmax", True, 8), ("softmax", False, 10), ("sigmoid", True, 8), ("linear", False, 8)])
+def test_top_k_softmax_router(oracle, dev, dtype, code, scoring, renorm, ext):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(11)
+    tokens, experts, k, world = 37, 128, 8, 4            # Qwen3-MoE: 128 experts, top 8
+    logits = torch.from_numpy(rng.standard_normal((tokens, experts)).astype(np.float32) * 1.5).to(dtype)
+    wl = torch.zeros(world, dtype=torch.int32, device=dev)
+    el = torch.zeros(experts, dtype=torch.int32, device=dev)
+    v, idx = ops.moe_top_k_softmax(logits.to(dev), k, ext, renorm, 1.25, scoring, wl, el, world)
+    wv, widx, wwl, wel = oracle.moe_top_k_softmax(_bits(logits), k, ext, renorm, 1.25, scoring, code, world)
+    assert np.array_equal(idx.cpu().numpy()[:, :k], widx[:, :k])
+    assert _ulps(v.cpu().numpy(), wv).max() <= 8
+    assert np.array_equal(wl.cpu().numpy(), wwl) and np.array_equal(el.cpu().numpy(), wel)
+    assert (v.cpu().numpy()[:, k:] == 1.0).all()
+
+
+@pytest.mark.parametrize("dtype,code", [(torch.float16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("experts,groups,topk_group,k,scoring,bias", [(256, 8, 4, 8, "sigmoid", True), (160, 8, 3, 6, "softmax", False),
+                                                                      (64, 4, 2, 4, "sigmoid", False)])
+def test_group_limited_router(oracle, dev, dtype, code, experts, groups, topk_group, k, scoring, bias):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(experts + k)
+    tokens, world, ext = 29, 8, k + 1                     # + one shared-expert slot (top_k_may_share)
+    logits = torch.from_numpy(rng.standard_normal((tokens, experts)).astype(np.float32) * 1.2).to(dtype)
+    b = (rng.standard_normal(experts) * 0.1).astype(np.float32) if bias else None
+    wl = torch.zeros(world, dtype=torch.int32, device=dev)
+    el = torch.zeros(experts, dtype=torch.int32, device=dev)
+    v, idx = ops.moe_group_topk(logits.to(dev), None if b is None else _t(b, dev), groups, topk_group, k, ext, True, 2.5, scoring, wl, el, world)
+    wv, widx, wwl, wel = oracle.moe_group_topk(_bits(logits), b, k, groups, topk_group, ext, True, 2.5, scoring, code, world)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    assert _ulps(v.cpu().numpy(), wv).max() <= 8
+    assert np.array_equal(wl.cpu().numpy(), wwl) and np.array_equal(el.cpu().numpy(), wel)
+    # the routing contract itself: ids inside the selected groups only, weights sum to the scaling factor
+    gi = idx.cpu().numpy()[:, :k] // (experts // groups)
+    assert all(len(set(r)) <= topk_group for r in gi)
+    assert np.allclose(v.cpu().numpy()[:, :k].sum(axis=1), 2.5, rtol=1e-5)
+
+
+def test_reference_fp8block_layer(oracle, dev):
+    """the reference's Fp8Block (src/nn/linear/linear.cpp:1697-1950, compiled unmodified with ENABLE_DS_DEEP_GEMM): load_parameter of
+    the fp8 weight + weight_scale_inv, quant_input -> per_token_cast_to_fp8, deep_gemm_fp8_block_h20_group = this boundary's GEMM"""
+    from zhilight_amd import _lib, build, ops
+    _lib.lib()
+    path = build.refcompile_target()
+    if not os.path.exists(path):
+        pytest.skip("zl_reflinear was not built (no reference tree at build time)")
+    sys.path.insert(0, os.path.dirname(path))
+    try:
+        import zl_reflinear
+    finally:
+        sys.path.pop(0)
+    rng = np.random.default_rng(5)
+    k, n, m = 1024, 384, 6
+    w8, sw = _block_weight(rng, n, k)
+    lin = zl_reflinear.RefLinear(k, n, 10, bf16=True)      # QuantType::FP8_Block
+    lin.load({"l.weight": w8.view(np.int8), "l.weight_scale_inv": sw}, "l")
+    x = _acts(rng, m, k, torch.bfloat16)
+    got = lin.forward(_bits(x))                           # uint16 = bf16 bits
+    want = ops.fp8_block_linear(x.to(dev), _t(w8, dev), _t(sw, dev))
+    assert np.array_equal(got, _bits(want))
+    a8, sa = oracle.fp8_per_token_cast(_bits(x), dtype=1)
+    _gemm_bar(got, oracle.fp8_block_gemm(a8, sa, w8, sw, dtype=1), oracle, 1)
+    # get_dequant_weight -> dequant_fp8_block_weight
+    assert np.array_equal(lin.dequant_weight(), oracle.fp8_block_dequant(w8, sw, dtype=1))

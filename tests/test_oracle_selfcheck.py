@@ -209,3 +209,63 @@ def test_e4m3_cast_against_the_format_definition(oracle):
         assert best == c, (v, c, best)
     neg = oracle.f32_to_e4m3(np.array([-1.0, -500.0, -0.0], np.float32))
     assert list(neg) == [0x80 | 0x38, 0x80 | 0x7e, 0x80]
+
+
+# ---- f4, first part: the FP8 block format and the router restatements against independent numpy statements -----------------
+def test_fp8_block_format_against_its_definition(oracle):
+    rng = np.random.default_rng(2)
+    m, k, n = 5, 512, 256
+    x = (rng.standard_normal((m, k)) * 3).astype(np.float16)
+    codes, sc = oracle.fp8_per_token_cast(x.view(np.uint16), dtype=0)
+    xb = x.astype(np.float32).reshape(m, k // 128, 128)
+    amax = np.maximum(np.abs(xb).max(axis=2), 1e-4).astype(np.float32)
+    assert np.array_equal(sc[:, :m].T, amax / np.float32(448.0))                       # scale = amax / 448 in fp32
+    deq = oracle.e4m3_to_f32(codes).reshape(m, k // 128, 128)
+    assert np.abs(deq).max() <= 448 and (np.abs(deq).max(axis=2) == 448).all()        # the block maximum lands on the largest code
+    assert (np.abs(deq * (amax / 448)[:, :, None] - xb) <= amax[:, :, None] * 2.0 ** -4 * 1.001).all()
+    # block GEMM == fp64 evaluation of the definition with numpy
+    w8 = rng.integers(0, 0x78, size=(n, k), dtype=np.uint8)
+    sw = (np.abs(rng.standard_normal((n // 128, k // 128))) * 0.01 + 1e-3).astype(np.float32)
+    out = oracle.fp8_block_gemm(codes, sc, w8, sw, dtype=0).view(np.float16).astype(np.float64)
+    a = oracle.e4m3_to_f32(codes).reshape(m, k // 128, 128)
+    w = oracle.e4m3_to_f32(w8).reshape(n, k // 128, 128)
+    blk = np.einsum("mbk,nbk->mnb", a, w)
+    ref = (blk * sc[:, :m].T.astype(np.float64)[:, None, :] * np.repeat(sw, 128, axis=0).astype(np.float64)[None, :, :]).sum(axis=2)
+    assert np.array_equal(out, ref.astype(np.float16).astype(np.float64))
+    # dequant: float(code) * scale rounded once
+    d = oracle.fp8_block_dequant(w8, sw, dtype=0).view(np.float16)
+    assert np.array_equal(d, (oracle.e4m3_to_f32(w8).astype(np.float32) * np.repeat(np.repeat(sw, 128, axis=0), 128, axis=1)).astype(np.float16))
+
+
+def test_router_restatements_against_numpy(oracle):
+    rng = np.random.default_rng(4)
+    tokens, e, k = 23, 128, 8
+    logits = (rng.standard_normal((tokens, e)) * 1.5).astype(np.float16)
+    v, idx, wl, el = oracle.moe_top_k_softmax(logits.view(np.uint16), k, k, True, 1.0, "softmax", 0, 4)
+    p = np.exp(logits.astype(np.float64) - logits.astype(np.float64).max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    want = np.argsort(-p, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(idx, want)
+    pw = np.take_along_axis(p, want, axis=1)
+    assert np.allclose(v, pw / pw.sum(axis=1, keepdims=True), rtol=2e-6)
+    assert el.sum() == tokens * k and np.array_equal(np.bincount(want.ravel() % 4, minlength=4), wl)
+    # the "sigmoid" of top_k_softmax is 1 / (1 + exp(+x)) in the reference (ff_kernel.cu:158-160): the SMALLEST logits win
+    v2, idx2, _, _ = oracle.moe_top_k_softmax(logits.view(np.uint16), k, k, False, 1.0, "sigmoid", 0, 0)
+    assert np.array_equal(idx2, np.argsort(logits.astype(np.float64), axis=1, kind="stable")[:, :k])
+    # group-limited routing (DeepSeek-V3 shape): groups by their best biased score, weights un-biased and renormalised
+    e, g, tg, k = 256, 8, 4, 8
+    logits = (rng.standard_normal((tokens, e)) * 1.2).astype(np.float16)
+    bias = (rng.standard_normal(e) * 0.1).astype(np.float32)
+    v, idx, _, el = oracle.moe_group_topk(logits.view(np.uint16), bias, k, g, tg, k, True, 2.5, "sigmoid", 0, 0)
+    s = 1.0 / (1.0 + np.exp(-logits.astype(np.float64)))
+    sb = s + bias
+    for t in range(tokens):
+        gs = sb[t].reshape(g, e // g).max(axis=1)
+        keep = np.argsort(-gs, kind="stable")[:tg]
+        masked = np.full(e, -np.inf)
+        for gg in keep:
+            masked[gg * (e // g):(gg + 1) * (e // g)] = sb[t, gg * (e // g):(gg + 1) * (e // g)]
+        want = np.argsort(-masked, kind="stable")[:k]
+        assert np.array_equal(idx[t], want), t
+        w = s[t, want]
+        assert np.allclose(v[t], w / w.sum() * 2.5, rtol=2e-6)

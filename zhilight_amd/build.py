@@ -144,7 +144,7 @@ def build_refcompile(force=False, verbose=False):
     cxx = os.environ.get("CXX", "g++")
     inc = ["-I" + shim, "-I" + HOSTCPP, "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(HERE, "..", "include"),
            "-I" + os.path.join(REFERENCE, "src"), "-I" + REFERENCE, "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
-    common = [cxx, "-O1", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-w"] + inc
+    common = [cxx, "-O1", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DENABLE_DS_DEEP_GEMM", "-w"] + inc
     objs = []
     jobs = []
     for src in tus + own:

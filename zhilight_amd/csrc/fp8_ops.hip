@@ -96,7 +96,105 @@ __global__ __launch_bounds__(256) void k_fp8_gemm_nt(const uint8_t* __restrict__
         }
 }
 
+// ---- f4, first part: the FP8 128x128-block linear of config 5 (src/nn/linear/linear.cpp:1697-1950) ------------------------------
+__device__ __forceinline__ float e4m3_to_f32(uint32_t c) {
+    const uint32_t e = (c >> 3) & 15u, m = c & 7u;
+    // normal: (1 + m/8) 2^(e-7) = bits ((e + 120) << 23) | (m << 20); subnormal: m 2^-9
+    const float v = e ? __builtin_bit_cast(float, ((e + 120u) << 23) | (m << 20)) : (float)m * 0.001953125f;
+    return (c & 0x80u) ? -v : v;
+}
+
+// KERNEL_per_token_cast_to_fp8 (fp8_util.cu:229-275): one wave per (row, 128-column block), two elements per lane
+template <int DT>
+__global__ __launch_bounds__(64) void k_fp8_per_token_cast(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out, int64_t ld_out,
+                                                           float* __restrict__ scale, int64_t aligned_m, int nblocks, int col_major, float max_e4m3) {
+    const int64_t row = blockIdx.y;
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    const uint32_t two = *reinterpret_cast<const uint32_t*>(x + row * ldx + blk * 128 + lane * 2);
+    const float f0 = ZT<DT>::to_f32((uint16_t)(two & 0xffffu)), f1 = ZT<DT>::to_f32((uint16_t)(two >> 16));
+    float amax = zl_wave_max(fmaxf(fabsf(f0), fabsf(f1)));
+    if (amax < 1e-4f) amax = 1e-4f;
+    const float mul = max_e4m3 / amax;
+    float p0 = f0 * mul, p1 = f1 * mul;
+    asm volatile("" : "+v"(p0), "+v"(p1));           // the fp32 products are materialised (no contraction into the cast)
+    const uint16_t codes = (uint16_t)f32_to_e4m3(p0) | (uint16_t)((uint16_t)f32_to_e4m3(p1) << 8);
+    *reinterpret_cast<uint16_t*>(out + row * ld_out + blk * 128 + lane * 2) = codes;
+    if (lane == 0) scale[col_major ? (int64_t)blk * aligned_m + row : row * nblocks + blk] = amax / max_e4m3;
+}
+
+// KERNEL_dequant_fp8_block (fp8_util.cu:325-357)
+template <int DT>
+__global__ __launch_bounds__(256) void k_fp8_block_dequant(const uint8_t* __restrict__ w, const float* __restrict__ scale,
+                                                            uint16_t* __restrict__ out, int64_t rows, int64_t cols, int64_t stride_scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols, c = i - r * cols;
+        float v = e4m3_to_f32(w[i]) * scale[(r / 128) * stride_scale + c / 128];
+        asm volatile("" : "+v"(v));
+        out[i] = ZT<DT>::from_f32(v);
+    }
+}
+
+// The block-scaled product of deep_gemm_fp8_block_h20_group (3rd/deep_gemm/deep_gemm_api.h): per 128-k block the fp8 x fp8
+// partial product is accumulated in fp32 on the matrix cores (4 x v_mfma_f32_16x16x32_fp8_fp8 from zero), then added to the
+// running sum scaled by sa[kb, m] * sw[n / 128, kb].  Same tile as k_fp8_gemm_nt (one wave = 16 weight rows x MT * 16
+// activation rows, fragments straight from global memory): correctness first, no LDS staging yet.  A 16-row tile takes the
+// expert (weight matrix) of its first row; rows of the tile carrying another index are not written (contiguous grouped
+// layout, groups aligned to 16 rows; DeepGEMM's own contract is alignment to its block_m = 64).
+template <int MT, int DT>
+__global__ __launch_bounds__(256) void k_fp8_block_gemm(const uint8_t* __restrict__ a, const float* __restrict__ sa, int64_t aligned_m,
+                                                        const uint8_t* __restrict__ w, const float* __restrict__ sw,
+                                                        const int32_t* __restrict__ m_indices, uint16_t* __restrict__ c, int m, int n, int k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * 16;
+    if (n0 >= n) return;
+    const int m0 = blockIdx.y * (MT * 16);
+    const int col = lane & 15, kq = lane >> 4;
+    const int kb_n = k / 128, nbw = (n + 127) / 128;
+    const bool ncol_ok = (n0 + col) < n;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int r0 = m0 + t * 16;
+        if (r0 >= m) break;
+        const int g = m_indices ? m_indices[r0] : 0;          // wave-uniform
+        if (g < 0) continue;
+        const uint8_t* brow = w + ((size_t)g * n + (n0 + col)) * k;
+        const float* swg = sw + ((size_t)g * nbw + n0 / 128) * kb_n;
+        const int arow = r0 + col;
+        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < kb_n; ++kb) {
+            f4 blk = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kk = kb * 128 + h * 64 + 16 * kq;
+                uint4 bf = make_uint4(0, 0, 0, 0), af = make_uint4(0, 0, 0, 0);
+                if (ncol_ok) bf = zl_load_nt(reinterpret_cast<const uint4*>(brow + kk));
+                if (arow < m) af = *reinterpret_cast<const uint4*>(a + (size_t)arow * k + kk);
+                const long b_lo = (long)(((unsigned long long)bf.y << 32) | bf.x), b_hi = (long)(((unsigned long long)bf.w << 32) | bf.z);
+                const long a_lo = (long)(((unsigned long long)af.y << 32) | af.x), a_hi = (long)(((unsigned long long)af.w << 32) | af.z);
+                blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_lo, b_lo, blk, 0, 0, 0);
+                blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_hi, b_hi, blk, 0, 0, 0);
+            }
+            const float ws = swg[kb];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = r0 + 4 * kq + i;
+                const float s = (row < m ? sa[(size_t)kb * aligned_m + row] : 0.f) * ws;
+                acc[i] = __builtin_fmaf(blk[i], s, acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 4 * kq + i;
+            if (row < m && ncol_ok && (!m_indices || m_indices[row] == g)) c[(size_t)row * n + n0 + col] = ZT<DT>::from_f32(acc[i]);
+        }
+    }
+}
+
 }  // namespace
+
+#define ZL_DT_SWITCH(dtype, EXPR_F16, EXPR_BF16) \
+    if ((dtype) == ZL_F16) { EXPR_F16; } else if ((dtype) == ZL_BF16) { EXPR_BF16; } else return ZL_EDTYPE;
 
 extern "C" {
 
@@ -127,6 +225,40 @@ int zl_fp8_gemm_nt(const uint8_t* a, const uint8_t* b, const float* scale_a, con
     ZL_CHECK_ARG(k % 64 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0, ZL_ESHAPE);
     const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((m + 63) / 64));
     hipLaunchKernelGGL(k_fp8_gemm_nt<4>, grid, dim3(256), 0, (hipStream_t)s, a, b, scale_a, scale_b, out, (int)m, (int)n, (int)k);
+    return zl_launch_status();
+}
+
+int zl_fp8_per_token_cast(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ld_out, float* scale, int64_t aligned_m, int64_t m, int64_t n,
+                          int scale_col_major, float max_e4m3, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(x && out && scale && m > 0 && n > 0 && max_e4m3 > 0.f, ZL_EINVAL);
+    ZL_CHECK_ARG(n % 128 == 0 && ldx >= n && ld_out >= n && ldx % 2 == 0 && ld_out % 2 == 0 && aligned_m >= m && m <= 65535, ZL_ESHAPE);
+    const dim3 grid((unsigned)(n / 128), (unsigned)m);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_fp8_per_token_cast<ZL_F16>, grid, dim3(64), 0, (hipStream_t)s, x, ldx, out, ld_out, scale, aligned_m, (int)(n / 128), scale_col_major, max_e4m3),
+        hipLaunchKernelGGL(k_fp8_per_token_cast<ZL_BF16>, grid, dim3(64), 0, (hipStream_t)s, x, ldx, out, ld_out, scale, aligned_m, (int)(n / 128), scale_col_major, max_e4m3))
+    return zl_launch_status();
+}
+
+int zl_fp8_block_dequant(const uint8_t* w, const float* scale, uint16_t* out, int64_t rows, int64_t cols, int64_t stride_scale, int dtype,
+                         zl_stream_t s) {
+    ZL_CHECK_ARG(w && scale && out && rows > 0 && cols > 0 && stride_scale * 128 >= cols, ZL_EINVAL);
+    int64_t g = (rows * cols + 255) / 256;
+    if (g > 65535 * 16) g = 65535 * 16;
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_fp8_block_dequant<ZL_F16>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)s, w, scale, out, rows, cols, stride_scale),
+        hipLaunchKernelGGL(k_fp8_block_dequant<ZL_BF16>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)s, w, scale, out, rows, cols, stride_scale))
+    return zl_launch_status();
+}
+
+int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t aligned_m, const uint8_t* rhs, const float* rhs_scales,
+                            const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(lhs && lhs_scales && rhs && rhs_scales && out && m > 0 && n > 0 && k > 0 && num_groups >= 1, ZL_EINVAL);
+    ZL_CHECK_ARG(k % 128 == 0 && aligned_m >= m && (num_groups == 1 || m_indices), ZL_ESHAPE);
+    ZL_CHECK_ARG(m < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) && (m + 63) / 64 <= 65535, ZL_ELIMIT);
+    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((m + 63) / 64));
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL((k_fp8_block_gemm<4, ZL_F16>), grid, dim3(256), 0, (hipStream_t)s, lhs, lhs_scales, aligned_m, rhs, rhs_scales, m_indices, out, (int)m, (int)n, (int)k),
+        hipLaunchKernelGGL((k_fp8_block_gemm<4, ZL_BF16>), grid, dim3(256), 0, (hipStream_t)s, lhs, lhs_scales, aligned_m, rhs, rhs_scales, m_indices, out, (int)m, (int)n, (int)k))
     return zl_launch_status();
 }
 

@@ -532,7 +532,80 @@ Tensor cvt_half_to_fp8(const Context& ctx, const Tensor& input, const Tensor& sc
 Tensor dynamic_scaled_quant(const Context& ctx, const Tensor& input, float MAX_E4M3) {
     return cvt_half_to_fp8(ctx, input, calc_scale(ctx, input, MAX_E4M3));
 }
+Tensor per_token_cast_to_fp8(const Context& ctx, const Tensor& input, bool scale_col_major, float MAX_E4M3) {
+    BM_ASSERT_EQ(input.ndim(), 2, "FP8 block_scale: input is not 2D");
+    BM_ASSERT_EQ(input.size(1) % 128, (size_t)0, "FP8 block_scale: input.size(1) can't divide 128");
+    const size_t m = input.size(0), n = input.size(1), aligned_m = (m + 3) / 4 * 4;
+    Tensor out = ctx.tensor(input.shape(), DataType::kFP8_E4M3, "", std::max<size_t>(32 * n, 1024));
+    Tensor scale = scale_col_major ? ctx.tensor({n / 128, aligned_m}, DataType::kFloat) : ctx.tensor({aligned_m, n / 128}, DataType::kFloat);
+    zl_check(zl_fp8_per_token_cast(u16(input), input.stride(0), out.data<uint8_t>(), n, scale.data<float>(), aligned_m, m, n, scale_col_major,
+                                   MAX_E4M3, zdt(input.dtype()), st_of(ctx)), "per_token_cast_to_fp8");
+    out.set_quant_scale(scale);
+    return out;
+}
+Tensor dequant_fp8_block_weight(const Context& ctx, const Tensor& weight, const Tensor& scale, DataType out_type) {
+    BM_ASSERT_EQ(scale.dtype(), DataType::kFloat, "");
+    BM_ASSERT_EQ(weight.ndim(), 2, "weight is not 2d");
+    BM_ASSERT_EQ(scale.ndim(), 2, "weight is not 2d");
+    BM_ASSERT_LE(weight.size(0), scale.size(0) * 128, "weight and scale dim0 mismatch");
+    BM_ASSERT_LE(weight.size(1), scale.size(1) * 128, "weight and scale dim0 mismatch");
+    Tensor out = ctx.tensor(weight.shape(), out_type);
+    zl_check(zl_fp8_block_dequant(weight.data<uint8_t>(), scale.data<float>(), out.data<uint16_t>(), weight.size(0), weight.size(1), scale.size(1),
+                                  zdt(out_type), st_of(ctx)), "dequant_fp8_block_weight");
+    return out;
+}
+Tensor fp8_block_gemm(const Context& ctx, const Tensor& a_quant, const Tensor& weight, const Tensor& weight_scale, DataType out_type,
+                      const Tensor* m_indices, Tensor* output) {
+    BM_ASSERT(a_quant.quant_scale && a_quant.quant_scale->dtype() == DataType::kFloat, "No quant_scale");
+    BM_ASSERT_EQ(a_quant.ndim(), 2, "input is not 2d");
+    const size_t m = a_quant.size(0), k = a_quant.size(1), n = weight.size(-2);
+    const int groups = weight.ndim() == 3 ? (int)weight.size(0) : 1;
+    BM_ASSERT_EQ(weight.size(-1), k, "size K mismatch");
+    BM_ASSERT(groups == 1 || (m_indices && m_indices->numel() == m), "grouped gemm needs m_indices (M)");
+    Tensor out = output ? *output : ctx.tensor({m, n}, out_type, "", 8 * n);
+    zl_check(zl_fp8_block_gemm_group(a_quant.data<uint8_t>(), a_quant.quant_scale->data<float>(), a_quant.quant_scale->size(1), weight.data<uint8_t>(),
+                                     weight_scale.data<float>(), m_indices ? m_indices->data<int32_t>() : nullptr, out.data<uint16_t>(), m, n, k,
+                                     groups, zdt(out.dtype()), st_of(ctx)), "fp8_block_gemm");
+    return out;
+}
 }  // namespace fp8
+
+static int scoring_code(const std::string& f) {
+    if (f.empty() || f == "softmax") return 1;
+    if (f == "sigmoid") return 2;
+    if (f == "linear") return 3;
+    BM_EXCEPTION("unknown scoring_func " + f);
+}
+std::tuple<Tensor, Tensor> top_k_softmax(const Context& ctx, const Tensor& input, const Tensor& worker_load, const Tensor& expert_load, int k,
+                                         int k_ext, bool norm_topk_prob, float weight_scale, const std::string& scoring_func) {
+    BM_ASSERT_EQ(input.ndim(), 2, "Wrong input dim");
+    BM_ASSERT_LE(k, 16, "k too big");
+    Tensor out = ctx.tensor({input.size(0), (size_t)k_ext}, DataType::kFloat), out_idx = ctx.tensor({input.size(0), (size_t)k_ext}, DataType::kInt32);
+    BM_HIPRT_ASSERT(hipMemsetAsync(out_idx.data(), 0, out_idx.nbytes(), ctx.current_cuda_stream()));
+    zl_check(zl_moe_top_k_softmax(u16(input), input.size(0), (int)input.size(1), k, k_ext, norm_topk_prob, weight_scale, scoring_code(scoring_func),
+                                  zdt(input.dtype()), out.data<float>(), out_idx.data<int32_t>(),
+                                  worker_load.numel() ? worker_load.data<int32_t>() : nullptr,
+                                  expert_load.numel() ? expert_load.data<int32_t>() : nullptr, ctx.world_size(), st_of(ctx)), "top_k_softmax");
+    return std::make_tuple(out, out_idx);
+}
+std::tuple<Tensor, Tensor> group_topk_softmax(const Context& ctx, const Tensor& input, const Tensor& score_correction_bias, const Tensor& worker_load,
+                                              const Tensor& expert_load, int num_group, int topk_group, int top_k, int top_k_ext,
+                                              bool norm_topk_prob, float weight_scale, const std::string& scoring_func) {
+    BM_ASSERT_EQ(input.ndim(), 2, "Wrong input dim");
+    BM_ASSERT_LE(num_group, 32, "num_group is too big");
+    BM_ASSERT_LE(top_k, 16, "k too big");
+    if (score_correction_bias.numel()) {
+        BM_ASSERT_EQ(score_correction_bias.numel(), input.size(1), "wrong correction_bias numel");
+        BM_ASSERT_EQ(score_correction_bias.dtype(), DataType::kFloat, "wrong correction_bias dtype");
+    }
+    Tensor out = ctx.tensor({input.size(0), (size_t)top_k_ext}, DataType::kFloat), out_idx = ctx.tensor({input.size(0), (size_t)top_k_ext}, DataType::kInt32);
+    zl_check(zl_moe_group_topk(u16(input), score_correction_bias.numel() ? score_correction_bias.data<float>() : nullptr, input.size(0),
+                               (int)input.size(1), top_k, top_k_ext, norm_topk_prob, weight_scale, scoring_code(scoring_func), num_group, topk_group,
+                               zdt(input.dtype()), out.data<float>(), out_idx.data<int32_t>(),
+                               worker_load.numel() ? worker_load.data<int32_t>() : nullptr,
+                               expert_load.numel() ? expert_load.data<int32_t>() : nullptr, ctx.world_size(), st_of(ctx)), "group_topk_softmax");
+    return std::make_tuple(out, out_idx);
+}
 
 static int elem_code(DataType t) {
     BM_ASSERT(t == DataType::kHalf || t == DataType::kBFloat16 || t == DataType::kFloat, "half / bfloat16 / float expected");

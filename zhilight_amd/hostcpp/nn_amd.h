@@ -18,7 +18,9 @@
 //   src/nn/linear/activation_kernel.h:8-16           | nn::gate_mul_inplace
 //   src/nn/layernorm/layernorm.h:7-37                | nn::LayerNorm {forward, fuse_add, inplace}
 //   src/nn/quant/gptq/gptq.h:150-160                  | nn::gptq::{int32_to_int16, reverse_perm, permute_input}
-//   src/nn/quant/fp8/fp8.h:7-19                       | nn::fp8::{cvt_half_to_fp8, calc_scale, dynamic_scaled_quant}
+//   src/nn/quant/fp8/fp8.h:7-33                       | nn::fp8::{cvt_half_to_fp8, calc_scale, dynamic_scaled_quant, per_token_cast_to_fp8,
+//                                                    |           dequant_fp8_block_weight} + fp8_block_gemm (deep_gemm_fp8_block_h20_group)
+//   src/nn/feedforward/ff_kernel.h:16-40              | nn::{top_k_softmax, group_topk_softmax}
 //   src/nn/linear/activation_kernel.h:8-10, nn/functions/functions.h:60 | nn::{gelu_inplace, silu_inplace, multiply}
 #pragma once
 #include <map>
@@ -137,7 +139,24 @@ namespace fp8 {
 core::Tensor calc_scale(const core::Context& ctx, const core::Tensor& input, float MAX_E4M3 = 448);
 core::Tensor dynamic_scaled_quant(const core::Context& ctx, const core::Tensor& input, float MAX_E4M3 = 448);
 core::Tensor cvt_half_to_fp8(const core::Context& ctx, const core::Tensor& input, const core::Tensor& scale);
+// FP8 128x128-block linear of config 5 (fp8.h:21-33, fp8_util.cu:229-385): per-token 1x128 activation scales (the codes carry
+// them as quant_scale: (n/128, aligned_m) column-major or (aligned_m, n/128)), block dequantisation of a weight
+core::Tensor per_token_cast_to_fp8(const core::Context& ctx, const core::Tensor& input, bool scale_col_major = true, float MAX_E4M3 = 448);
+core::Tensor dequant_fp8_block_weight(const core::Context& ctx, const core::Tensor& input, const core::Tensor& scale, core::DataType out_type);
+// the product Fp8Block::forward / grouped_gemm hand to deep_gemm_fp8_block_h20_group (linear.cpp:1863-1945); weight (N, K) or
+// (G, N, K) codes (kInt8 / kFP8_E4M3 storage), weight_scale (ceil(N/128), K/128) fp32 [x G], m_indices (M) int32 for G > 1
+core::Tensor fp8_block_gemm(const core::Context& ctx, const core::Tensor& a_quant, const core::Tensor& weight, const core::Tensor& weight_scale,
+                            core::DataType out_type, const core::Tensor* m_indices = nullptr, core::Tensor* output = nullptr);
 }  // namespace fp8
+
+// ---- MoE router (src/nn/feedforward/ff_kernel.h:16-40) -------------------------------------------------------------------
+std::tuple<core::Tensor, core::Tensor> top_k_softmax(const core::Context& ctx, const core::Tensor& input, const core::Tensor& worker_load,
+                                                     const core::Tensor& expert_load, int k, int k_ext, bool norm_topk_prob, float weight_scale,
+                                                     const std::string& scoring_func);
+std::tuple<core::Tensor, core::Tensor> group_topk_softmax(const core::Context& ctx, const core::Tensor& input,
+                                                          const core::Tensor& score_correction_bias, const core::Tensor& worker_load,
+                                                          const core::Tensor& expert_load, int num_group, int topk_group, int top_k, int top_k_ext,
+                                                          bool norm_topk_prob, float weight_scale, const std::string& scoring_func);
 
 void gelu_inplace(const core::Tensor& inp, hipStream_t stream);
 void silu_inplace(const core::Tensor& inp, hipStream_t stream);

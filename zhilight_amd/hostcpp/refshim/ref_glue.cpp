@@ -19,6 +19,7 @@
 #include "nn/quant/gptq/gptq.h"
 #include "nn/quant/marlin/marlin.h"
 #include "3rd/deep_gemm/deep_gemm_api.h"
+#include "zhilight_amd.h"
 
 namespace nn {
 namespace gptq {   // from hostcpp/nn_amd.h (not included: it re-declares the reference's gptq.h with its default arguments)
@@ -49,12 +50,16 @@ void reconstruct_gptq(const uint32_t*, const uint32_t*, const half*, const int*,
 }
 }  // namespace gptq
 }  // namespace nn
-namespace nn::fp8 {
-core::Tensor per_token_cast_to_fp8(const core::Context&, const core::Tensor&, bool, float) { ZL_OFF_BOUNDARY("nn::fp8::per_token_cast_to_fp8 (FP8 block linear, row f4)"); }
-core::Tensor dequant_fp8_block_weight(const core::Context&, const core::Tensor&, const core::Tensor&, core::DataType) {
-    ZL_OFF_BOUNDARY("nn::fp8::dequant_fp8_block_weight (FP8 block linear, row f4)");
+// deep_gemm_fp8_block_h20_group (3rd/deep_gemm/deep_gemm_api.h): the closed DeepGEMM entry point Fp8Block::forward / grouped_gemm call
+// (the reference TU is compiled with -DENABLE_DS_DEEP_GEMM here) = this boundary's block-scaled FP8 GEMM.  The C signature carries
+// neither aligned_m nor the output type: aligned_m = round_up(m, 4) (per_token_cast_to_fp8), output bf16 (DeepGEMM's only one).
+extern "C" int deep_gemm_fp8_block_h20_group(void* lhs, void* lhs_scales, void* rhs, void* rhs_scales, void* out, void* grouped_layout,
+                                             void* stream, int m, int n, int k, int /*block_m*/, int num_groups) {
+    const int st = zl_fp8_block_gemm_group((const uint8_t*)lhs, (const float*)lhs_scales, (m + 3) / 4 * 4, (const uint8_t*)rhs,
+                                           (const float*)rhs_scales, (const int32_t*)grouped_layout, (uint16_t*)out, m, n, k, num_groups,
+                                           ZL_BF16, (zl_stream_t)stream);
+    return st == 0 ? 0 : -1;
 }
-}  // namespace nn::fp8
 
 // ---- 2. model::ModelContext's key functions ------------------------------------------------------------------------------
 namespace model {
@@ -77,7 +82,8 @@ DataType np_dtype(const py::array& a) {
     if (k == 'f' && sz == 4) return DataType::kFloat;
     if (k == 'i' && sz == 4) return DataType::kInt32;
     if (k == 'i' && sz == 1) return DataType::kInt8;
-    if (k == 'i' && sz == 2) return DataType::kInt16;
+    if ((k == 'i' || k == 'u') && sz == 2) return DataType::kInt16;
+    if (k == 'u' && sz == 1) return DataType::kInt8;
     throw std::runtime_error("unsupported numpy dtype");
 }
 // a HOST tensor aliasing a C-contiguous numpy array (what the reference's python binding hands load_state_dict)
@@ -91,7 +97,8 @@ Tensor host_tensor(const py::array& a, const std::string& name) {
 py::array to_numpy(const Context& ctx, const Tensor& t) {
     std::vector<py::ssize_t> shape(t.shape().begin(), t.shape().end());
     py::dtype dt = t.dtype() == DataType::kHalf ? py::dtype("float16") : t.dtype() == DataType::kFloat ? py::dtype("float32")
-                 : t.dtype() == DataType::kInt32 ? py::dtype("int32") : py::dtype("int8");
+                 : t.dtype() == DataType::kInt32 ? py::dtype("int32") : t.dtype() == DataType::kBFloat16 ? py::dtype("uint16") /* raw bits */
+                 : py::dtype("int8");
     py::array out(dt, shape);
     t.to_buffer(out.mutable_data(), ctx.current_cuda_stream());
     return out;
@@ -101,13 +108,13 @@ py::array to_numpy(const Context& ctx, const Tensor& t) {
 class RefLinear {
 public:
     RefLinear(int dim_in, int dim_out, int quant_type, int group_size, bool sym, bool act_order, const std::string& act_fn, int device,
-              bool weight_transposed)
-        : ctx_(device) {
+              bool weight_transposed, bool bf16)
+        : ctx_(device), bf16_(bf16) {
         model::QuantConfig qc(quant_type);
         qc.group_size = group_size;
         qc.sym = sym;
         qc.act_order = act_order;
-        linear_.reset(new nn::Linear(ctx_, dim_in, dim_out, act_fn, qc, false, weight_transposed, false, bmengine::core::DistLayout::COLUMNAR, DataType::kHalf));
+        linear_.reset(new nn::Linear(ctx_, dim_in, dim_out, act_fn, qc, false, weight_transposed, false, bmengine::core::DistLayout::COLUMNAR, bf16 ? DataType::kBFloat16 : DataType::kHalf));
     }
     void load(const std::map<std::string, py::array>& arrays, const std::string& prefix) {
         std::map<std::string, const Tensor> sd;
@@ -118,6 +125,7 @@ public:
         Tensor hx = host_tensor(x, "x");
         Tensor dx = ctx_.tensor(hx.shape(), hx.dtype());
         dx.from_buffer(hx.data(), false, ctx_.current_cuda_stream());
+        if (bf16_ && dx.dtype() == DataType::kInt16) dx = dx.view_type(dx.shape(), DataType::kBFloat16);   // numpy has no bfloat16: int16 bits
         Tensor y = linear_->forward(ctx_, dx);
         return to_numpy(ctx_, y);
     }
@@ -126,6 +134,7 @@ public:
 
 private:
     Context ctx_;
+    bool bf16_;
     std::unique_ptr<nn::Linear> linear_;
 };
 
@@ -134,9 +143,9 @@ private:
 PYBIND11_MODULE(zl_reflinear, m) {
     m.doc() = "the reference's nn::Linear (src/nn/linear/linear.cpp, compiled unmodified) on the MI355X boundary";
     py::class_<RefLinear>(m, "RefLinear")
-        .def(py::init<int, int, int, int, bool, bool, const std::string&, int, bool>(), py::arg("dim_in"), py::arg("dim_out"), py::arg("quant_type"),
+        .def(py::init<int, int, int, int, bool, bool, const std::string&, int, bool, bool>(), py::arg("dim_in"), py::arg("dim_out"), py::arg("quant_type"),
              py::arg("group_size") = 128, py::arg("sym") = false, py::arg("act_order") = false, py::arg("act_fn") = "", py::arg("device") = 0,
-             py::arg("weight_transposed") = false)
+             py::arg("weight_transposed") = false, py::arg("bf16") = false)
         .def("load", &RefLinear::load)
         .def("forward", &RefLinear::forward)
         .def("dequant_weight", &RefLinear::dequant_weight)

@@ -1205,3 +1205,79 @@ def w4a8_fp8_linear(x, w8, w_scale, max_act_e4m3=448.0, out=None):
     into the fp32 accumulators, one rounding to fp16"""
     a8, sa = fp8_dynamic_scaled_quant(x, max_act_e4m3)
     return fp8_gemm_nt(a8, w8, sa, w_scale, out=out)
+
+
+# ---- f4, first part: FP8 128x128-block linear (config 5) and the MoE router ----------------------------------------------
+def fp8_per_token_cast(x, scale_col_major=True, max_e4m3=448.0):
+    """nn::fp8::per_token_cast_to_fp8: (codes (m, n) uint8, scales fp32 (n/128, aligned_m) column-major -- what fp8_block_gemm
+    reads -- or (aligned_m, n/128)); aligned_m = round_up(m, 4) like the reference's TMA alignment"""
+    _chk_cuda(x)
+    if x.dim() != 2 or x.shape[1] % 128:
+        raise ZLError("FP8 block_scale: input is not 2D / input.size(1) can't divide 128")
+    m, n = x.shape
+    am = (m + 3) // 4 * 4
+    out = torch.empty((m, n), dtype=torch.uint8, device=x.device)
+    sc = torch.zeros((n // 128, am) if scale_col_major else (am, n // 128), dtype=torch.float32, device=x.device)
+    check(lib().zl_fp8_per_token_cast(_p(x), _i(x.stride(0)), _p(out), _i(n), _p(sc), _i(am), _i(m), _i(n), C.c_int(int(scale_col_major)),
+                                      _f(max_e4m3), C.c_int(_dt(x)), _stream()), "fp8_per_token_cast")
+    return out, sc
+
+
+def fp8_block_dequant(w8, scale, dtype=torch.bfloat16):
+    """nn::fp8::dequant_fp8_block_weight: (N, K) codes x (ceil(N/128), ceil(K/128)) fp32 -> (N, K) T"""
+    _chk_cuda(w8, scale)
+    out = torch.empty(w8.shape, dtype=dtype, device=w8.device)
+    check(lib().zl_fp8_block_dequant(_p(w8), _p(scale), _p(out), _i(w8.shape[0]), _i(w8.shape[1]), _i(scale.shape[1]),
+                                     C.c_int(0 if dtype == torch.float16 else 1), _stream()), "fp8_block_dequant")
+    return out
+
+
+def fp8_block_gemm(a8, a_scale, w8, w_scale, m_indices=None, dtype=torch.bfloat16, out=None):
+    """deep_gemm_fp8_block_h20_group: a8 (m, k) codes with column-major scales (k/128, aligned_m); w8 (n, k) or (G, n, k) codes
+    with scales (ceil(n/128), k/128) or (G, ...); m_indices (m,) int32 = the expert of every row (grouped form)"""
+    _chk_cuda(a8, a_scale, w8, w_scale, m_indices)
+    m, k = a8.shape
+    n = w8.shape[-2]
+    groups = w8.shape[0] if w8.dim() == 3 else 1
+    if out is None:
+        out = torch.zeros((m, n), dtype=dtype, device=a8.device)
+    check(lib().zl_fp8_block_gemm_group(_p(a8), _p(a_scale), _i(a_scale.shape[1]), _p(w8), _p(w_scale), _p(m_indices), _p(out), _i(m), _i(n),
+                                        _i(k), C.c_int(groups), C.c_int(0 if out.dtype == torch.float16 else 1), _stream()), "fp8_block_gemm")
+    return out
+
+
+def fp8_block_linear(x, w8, w_scale, out=None):
+    """Fp8Block::forward (linear.cpp:1863-1905): per-token 1x128 activation quantisation + the block-scaled GEMM"""
+    a8, sa = fp8_per_token_cast(x)
+    return fp8_block_gemm(a8, sa, w8, w_scale, dtype=x.dtype, out=out)
+
+
+_SCORING = {"": 1, "softmax": 1, "sigmoid": 2, "linear": 3}
+
+
+def moe_top_k_softmax(logits, top_k, top_k_ext=None, norm_topk_prob=False, weight_scale=1.0, scoring_func="softmax", worker_load=None,
+                      expert_load=None, num_worker=1):
+    """nn::top_k_softmax: (weights fp32 (tokens, top_k_ext), expert ids int32 (tokens, top_k_ext))"""
+    _chk_cuda(logits, worker_load, expert_load)
+    t, e = logits.shape
+    ext = top_k_ext or top_k
+    v = torch.empty((t, ext), dtype=torch.float32, device=logits.device)
+    idx = torch.zeros((t, ext), dtype=torch.int32, device=logits.device)
+    check(lib().zl_moe_top_k_softmax(_p(logits), _i(t), C.c_int(e), C.c_int(top_k), C.c_int(ext), C.c_int(int(norm_topk_prob)), _f(weight_scale),
+                                     C.c_int(_SCORING[scoring_func]), C.c_int(_dt(logits)), _p(v), _p(idx), _p(worker_load), _p(expert_load),
+                                     C.c_int(num_worker), _stream()), "moe_top_k_softmax")
+    return v, idx
+
+
+def moe_group_topk(logits, score_correction_bias, num_group, topk_group, top_k, top_k_ext=None, norm_topk_prob=True, weight_scale=1.0,
+                   scoring_func="sigmoid", worker_load=None, expert_load=None, num_worker=1):
+    """nn::group_topk_softmax (DeepSeek-V3 group-limited routing)"""
+    _chk_cuda(logits, score_correction_bias, worker_load, expert_load)
+    t, e = logits.shape
+    ext = top_k_ext or top_k
+    v = torch.empty((t, ext), dtype=torch.float32, device=logits.device)
+    idx = torch.zeros((t, ext), dtype=torch.int32, device=logits.device)
+    check(lib().zl_moe_group_topk(_p(logits), _p(score_correction_bias), _i(t), C.c_int(e), C.c_int(top_k), C.c_int(ext), C.c_int(int(norm_topk_prob)),
+                                  _f(weight_scale), C.c_int(_SCORING[scoring_func]), C.c_int(num_group), C.c_int(topk_group), C.c_int(_dt(logits)),
+                                  _p(v), _p(idx), _p(worker_load), _p(expert_load), C.c_int(num_worker), _stream()), "moe_group_topk")
+    return v, idx
