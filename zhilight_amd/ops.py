@@ -1211,9 +1211,10 @@ def w4a8_fp8_linear(x, w8, w_scale, max_act_e4m3=448.0, out=None):
 def fp8_per_token_cast(x, scale_col_major=True, max_e4m3=448.0):
     """nn::fp8::per_token_cast_to_fp8: (codes (m, n) uint8, scales fp32 (n/128, aligned_m) column-major -- what fp8_block_gemm
     reads -- or (aligned_m, n/128)); aligned_m = round_up(m, 4) like the reference's TMA alignment"""
-    _chk_cuda(x)
-    if x.dim() != 2 or x.shape[1] % 128:
-        raise ZLError("FP8 block_scale: input is not 2D / input.size(1) can't divide 128")
+    if not (x.is_cuda and x.dim() == 2 and x.stride(1) == 1):        # rows may be strided (Fp8Block::support_uncontinuous_input)
+        raise ZLError("FP8 block_scale: input is not a 2D CUDA tensor with dense rows")
+    if x.shape[1] % 128:
+        raise ZLError("FP8 block_scale: input.size(1) can't divide 128")
     m, n = x.shape
     am = (m + 3) // 4 * 4
     out = torch.empty((m, n), dtype=torch.uint8, device=x.device)
