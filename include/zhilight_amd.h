@@ -190,11 +190,9 @@ typedef struct {
     int phase_rounds, phase_ksplit, phase_ksplit_min_m, phase_min_m, phase_max_m, phase_small_off;
     int tiled_min_m, tiled_bm, tiled_splitk;
     int mfma_ks, mfma_rounds;
-    int small_algo;   /* 1..8 rows (K <= 4096; 1..2 rows up to K = 16384): 0 = the integer-plane kernel (w4_i8p.hip: nibbles expanded to
-                         int8, activations as three byte planes of a per-group block-floating integer, v_mfma_i32_16x16x64_i8; the
-                         default for 1..4 rows, and for 5..8 rows of plain launches without a fused norm), 1 = the fp16-dequant kernels of
-                         rounds 1-2 (k_w4a16_phase / k_w4a16_mfma), 2 = integer planes up to 4 rows only, 3 = integer planes for every
-                         launch they cover (5..8 rows with fused norm / rotary / silu included: slower, kept for coverage) */
+    int small_algo;   /* 1..4 rows: 0 = the integer-plane kernel (w4_i8p.hip: nibbles expanded to int8, activations as three byte planes of a
+                         per-group block-floating integer, v_mfma_i32_16x16x64_i8; the default), 1 = the fp16-dequant kernels of
+                         rounds 1-2 (k_w4a16_phase / k_w4a16_mfma) */
     int tiled_wide;   /* prompt-chunk tiles (128 / 256 x 256 outputs per workgroup, M >= 128): 0 default (on, height by cost model), -1 off,
                          1 also for 32 < M < 128, 2 128-row tiles only, 3 256-row tiles whenever M > 128, 4 192-column tiles */
 } zl_w4_opts_t;

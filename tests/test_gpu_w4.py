@@ -640,18 +640,3 @@ def test_i8p_rows_repeated_against_fp16_kernels(dev, n, k, m):
         got = ops.w4a16_gemm_mfma(x, w)
         tol = 2.0 ** -10 * want.float().abs().max().item()      # both within fp16 output rounding of the exact product
         assert (got.float() - want.float()).abs().max().item() <= tol, it
-
-
-@pytest.mark.parametrize("m", [5, 6, 8])
-def test_i8p_second_row_block_all_fused_forms(oracle, dev, m, monkeypatch):
-    """5..8 rows on the integer planes (two MFMA row blocks, reduction buffer over the digit planes): by default only plain
-    launches without a fused norm take this path (it is slower otherwise); small_algo 3 forces it everywhere so
-    that the fused norm / residual / bias / silu / rotary forms of the second row block stay covered."""
-    monkeypatch.setenv("ZL_W4_SMALL_ALGO", "3")
-    _check_mfma(oracle, dev, 4096, 6144, m, 400 + m)
-    _check_mfma(oracle, dev, 4096, 4096, m, 410 + m, bias=True, residual=True)
-    _check_mfma(oracle, dev, 2048, 272, m, 420 + m, norm=True)
-    _check_mfma(oracle, dev, 1024, 48, m, 430 + m, bias=True, norm=True)
-    test_phase_gemm_silu_mul(oracle, dev, m)
-    test_fused_qkv_rotary_scatter_equals_two_call_sequence(oracle, dev, m, True, True)
-    test_fused_qkv_rotary_scatter_equals_two_call_sequence(oracle, dev, m, False, False)

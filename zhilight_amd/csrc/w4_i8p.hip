@@ -131,20 +131,14 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)
 // merged from the attention's split partials (k_decode_attn_combine's weights; the partials are normalised fp16 rows, so
 // out = sum_s l_s e^(m_s - m) O_s / sum_s l_s e^(m_s - m)): a wave reads only the heads of ITS groups, the workgroup as a whole
 // every partial once.
-// MB: blocks of four batch rows (MB = 2: 5..8 rows, K <= 4096).  A block is one MFMA pair per item -- the second block reuses
-// the expanded weight bytes -- with its own A fragments, constants and accumulators; the LDS image (K x 4 M bytes: 128 KiB
-// at 8 rows and K = 4096) then leaves room for one workgroup per CU, which is what the grids of the decode projections
-// give anyway (<= 256 workgroups), and the cross-wave reduction buffer aliases the digit planes.
-template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE = false, int MB = 1>
-__global__ __launch_bounds__(kT, MB == 2 ? 1 : 2) void k_w4a16_i8p(const I8Params p) {
+template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE = false>
+__global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
     static_assert(!MERGE || (!LONGK && !ROPE && !NORM), "split merge: one column block, plain prologue");
-    static_assert(MB == 1 || (MB == 2 && !LONGK && !MERGE), "second row block: short K, no merge front end");
     constexpr int XD = R >= 8 ? 1 : (8 / R > 0 ? 8 / R : 1);   // groups the ring runs ahead (8 KiB per wave in flight: with 16
     constexpr int D = R * XD;                                  // the issue itself stalls for microseconds)
-    constexpr int NS = LONGK ? 8 : 4 * MB;                     // activation octet slots per thread
-    constexpr int NR = LONGK ? 2 : 4 * MB;                     // rows
-    constexpr int NRC = 4 * MB;                                // constant records per group
+    constexpr int NS = LONGK ? 8 : 4;                          // activation octet slots per thread
+    constexpr int NR = LONGK ? 2 : 4;                          // rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ZL_IPROBE_INIT();
     ZL_IPROBE(0);
@@ -156,10 +150,9 @@ __global__ __launch_bounds__(kT, MB == 2 ? 1 : 2) void k_w4a16_i8p(const I8Param
     // LDS: wave-private regions -- nothing below needs a workgroup barrier before the final reduction (a wave's DS
     // instructions execute in order), except the eight partial sums of the fused RMSNorm
     unsigned char* planes = smem + (size_t)wave * Gw * 8 * rec;                       // [gi][mfma][kq][4 M slots][16]
-    float* cbase = reinterpret_cast<float*>(smem + (size_t)kW * Gw * 8 * rec);
-    float* consts = cbase + (size_t)wave * Gw * 4 * NRC;                               // [gi][row][4]
-    float* red = MB == 2 ? reinterpret_cast<float*>(smem) : cbase + (size_t)kW * Gw * 4 * NRC;   // [MB][R][8 waves][64]; MB = 2: over the
-    float* scratch = cbase + (size_t)kW * Gw * 4 * NRC + (MB == 2 ? 0 : R * kW * 64);            // planes, behind a barrier.  [rows][8 waves]
+    float* consts = reinterpret_cast<float*>(smem + (size_t)kW * Gw * 8 * rec) + (size_t)wave * Gw * 16;   // [gi][row 0..3][4]
+    float* red = reinterpret_cast<float*>(smem + (size_t)kW * Gw * 8 * rec) + (size_t)kW * Gw * 16;        // [R][8 waves][64]
+    float* scratch = red + R * kW * 64;                                               // [4 rows][8 waves]
 
     const int tile0 = ROPE ? (blockIdx.x / p.pair_stride) * 2 * p.pair_stride + blockIdx.x % p.pair_stride : blockIdx.x * R;
     const int tile_stride = ROPE ? p.pair_stride : 1;
@@ -444,7 +437,7 @@ __global__ __launch_bounds__(kT, MB == 2 ? 1 : 2) void k_w4a16_i8p(const I8Param
                 if (row == 0) *reinterpret_cast<uint2*>(dst + 48) = make_uint2(0, 0);          // the zero slot idle lanes read
                 if (uo == 0) {
                     const float bx = xscale * (float)sx;
-                    *reinterpret_cast<float4*>(consts + ((size_t)gi * NRC + row) * 4) = make_float4(xscale, 65536.f * xscale, bx, 1024.f * bx);
+                    *reinterpret_cast<float4*>(consts + ((size_t)gi * 4 + row) * 4) = make_float4(xscale, 65536.f * xscale, bx, 1024.f * bx);
                 }
             }
             if (row == 0 && c < NP / 4) ZL_ISSUE_RANGE(ZL_QLO(4 * c + 3), ZL_QLO(4 * c + 4))
@@ -458,22 +451,12 @@ __global__ __launch_bounds__(kT, MB == 2 ? 1 : 2) void k_w4a16_i8p(const I8Param
 
     // ---- main loop
     const int kq = lane >> 4, row16 = lane & 15;
-    // A rows: batch row r = rows 4 r .. 4 r + 2 (digits b2 b1 b0) of block r / 4; row 3 of a quadruple, and rows of batch rows
-    // that do not exist, read the zero slot
-    const unsigned char* a_base[MB];
-    int crow[MB];
+    const int aslot = (row16 < 4 * M && (row16 & 3) != 3) ? row16 : 3;   // A rows: batch row r = rows 4 r .. 4 r + 2 (digits b2 b1 b0)
+    const unsigned char* a_base = planes + (size_t)kq * rec + aslot * 16;
+    const int crow = min(kq, M - 1);                                     // C: lane = (batch row lane >> 4, column lane & 15)
+    float acc[R];
 #pragma unroll
-    for (int b = 0; b < MB; ++b) {
-        const int s16 = 16 * b + row16;
-        const int aslot = (s16 < 4 * M && (row16 & 3) != 3) ? s16 : 3;
-        a_base[b] = planes + (size_t)kq * rec + aslot * 16;
-        crow[b] = min(4 * b + kq, M - 1);                                // C: lane = (batch row 4 b + (lane >> 4), column lane & 15)
-    }
-    float acc[MB][R];
-#pragma unroll
-    for (int b = 0; b < MB; ++b)
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[b][r] = 0.f;
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
     const uint32_t m4 = __builtin_amdgcn_readfirstlane(0x0f0f0f0fu);
     const v4i zero4 = (v4i){0, 0, 0, 0};
 
@@ -482,14 +465,9 @@ __global__ __launch_bounds__(kT, MB == 2 ? 1 : 2) void k_w4a16_i8p(const I8Param
         for (int j = 0; j < XD; ++j) {
             const int gi = gi0 + j;
             if (j > 0 && gi >= my_groups) break;
-            v4i a0[MB], a1[MB];
-            float4 cst[MB];
-#pragma unroll
-            for (int b = 0; b < MB; ++b) {
-                a0[b] = *reinterpret_cast<const v4i*>(a_base[b] + (size_t)(gi * 2 + 0) * 4 * rec);
-                a1[b] = *reinterpret_cast<const v4i*>(a_base[b] + (size_t)(gi * 2 + 1) * 4 * rec);
-                cst[b] = *reinterpret_cast<const float4*>(consts + ((size_t)gi * NRC + crow[b]) * 4);
-            }
+            const v4i a0 = *reinterpret_cast<const v4i*>(a_base + (size_t)(gi * 2 + 0) * 4 * rec);
+            const v4i a1 = *reinterpret_cast<const v4i*>(a_base + (size_t)(gi * 2 + 1) * 4 * rec);
+            const float4 cst = *reinterpret_cast<const float4*>(consts + ((size_t)gi * 4 + crow) * 4);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int slot = j * R + r;
@@ -498,29 +476,22 @@ __global__ __launch_bounds__(kT, MB == 2 ? 1 : 2) void k_w4a16_i8p(const I8Param
                 v4i b0, b1;
                 b0[0] = (int)(w.x & m4); b0[1] = (int)((w.x >> 4) & m4); b0[2] = (int)(w.y & m4); b0[3] = (int)((w.y >> 4) & m4);
                 b1[0] = (int)(w.z & m4); b1[1] = (int)((w.z >> 4) & m4); b1[2] = (int)(w.w & m4); b1[3] = (int)((w.w >> 4) & m4);
-                v4i d[MB];
-#pragma unroll
-                for (int b = 0; b < MB; ++b) {
-                    d[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[b], b0, zero4, 0, 0, 0);
-                    d[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[b], b1, d[b], 0, 0, 0);
-                }
+                v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, zero4, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, d, 0, 0, 0);
                 issue(slot, gi + XD, r);
                 const h16x2 sm = __builtin_bit_cast(h16x2, mw);          // .x = scale, .y = -(1024 + zero)
-#pragma unroll
-                for (int b = 0; b < MB; ++b) {
-                    const float f12 = (float)((d[b][1] << 8) + d[b][2]), f0 = (float)d[b][0];
-                    float t = __builtin_fmaf((float)sm.y, cst[b].z, cst[b].w);      // -(1024 + z) B + 1024 B = -z B
-                    t = __builtin_fmaf(f12, cst[b].x, t);
-                    t = __builtin_fmaf(f0, cst[b].y, t);
-                    // The MFMA's A / B registers stay allocated until here.  hipcc (ROCm 7.2) lets a VALU instruction overwrite a
-                    // source of v_mfma_i32_16x16x64_i8 one issue slot after the MFMA (seen: v_cvt_f32_f16_sdwa into a dword of SrcA
-                    // right behind the group's last MFMA); the matrix pipe reads its 128-bit operands over several passes, and
-                    // the rows of the LAST pass (12..15 = batch row 3) then see the new value -- sporadically wrong outputs for
-                    // the fourth batch row only (tools/ubench/_dbg_m4.py).  `t` depends on the MFMA's result, so this point is
-                    // >= 30 cycles behind it.
-                    asm volatile("" : "+v"(t) : "v"(b0), "v"(b1), "v"(a0[b]), "v"(a1[b]));
-                    acc[b][r] = __builtin_fmaf((float)sm.x, t, acc[b][r]);
-                }
+                const float f12 = (float)((d[1] << 8) + d[2]), f0 = (float)d[0];
+                float t = __builtin_fmaf((float)sm.y, cst.z, cst.w);      // -(1024 + z) B + 1024 B = -z B
+                t = __builtin_fmaf(f12, cst.x, t);
+                t = __builtin_fmaf(f0, cst.y, t);
+                // The MFMA's A / B registers stay allocated until here.  hipcc (ROCm 7.2) lets a VALU instruction overwrite a
+                // source of v_mfma_i32_16x16x64_i8 one issue slot after the MFMA (seen: v_cvt_f32_f16_sdwa into a dword of SrcA
+                // right behind the group's last MFMA); the matrix pipe reads its 128-bit operands over several passes, and
+                // the rows of the LAST pass (12..15 = batch row 3) then see the new value -- sporadically wrong outputs for
+                // the fourth batch row only (tools/ubench/_dbg_m4.py).  `t` depends on the MFMA's result, so this point is
+                // >= 30 cycles behind it.
+                asm volatile("" : "+v"(t) : "v"(b0), "v"(b1), "v"(a0), "v"(a1));
+                acc[r] = __builtin_fmaf((float)sm.x, t, acc[r]);
 #ifdef ZL_I8P_PROBE
                 if (gi == 0 && r == 0) ZL_IPROBE(4);
 #endif
@@ -530,18 +501,14 @@ __global__ __launch_bounds__(kT, MB == 2 ? 1 : 2) void k_w4a16_i8p(const I8Param
 
     // ---- reduce over the 8 waves in fixed order, epilogue
     ZL_IPROBE(5);
-    if constexpr (MB == 2) __syncthreads();              // the reduction buffer lies over the digit planes other waves still read
 #pragma unroll
-    for (int b = 0; b < MB; ++b)
-#pragma unroll
-        for (int r = 0; r < R; ++r) red[((b * R + r) * kW + wave) * 64 + lane] = acc[b][r];
+    for (int r = 0; r < R; ++r) red[(r * kW + wave) * 64 + lane] = acc[r];
     __syncthreads();
     ZL_IPROBE(6);
     auto total_of = [&](int r, int n_local, int m) {
         float v = 0.f;
-        const int b = m >> 2;
 #pragma unroll
-        for (int w = 0; w < kW; ++w) v += red[((b * R + r) * kW + w) * 64 + (m & 3) * 16 + n_local];
+        for (int w = 0; w < kW; ++w) v += red[(r * kW + w) * 64 + m * 16 + n_local];
         return v;
     };
     if constexpr (ROPE) {
@@ -606,33 +573,26 @@ __global__ __launch_bounds__(kT, MB == 2 ? 1 : 2) void k_w4a16_i8p(const I8Param
     ZL_IPROBE(7);
 }
 
-// digit planes + constants + (up to 4 rows: the reduction buffer; above, it aliases the planes) + the norm's partial sums
 static size_t i8p_lds_bytes(int groups, int m, int r) {
-    const size_t gw = (groups + kW - 1) / kW, mb = m > 4 ? 2 : 1;
-    const size_t planes = kW * gw * 8 * 64 * (size_t)m, red = (size_t)mb * r * kW * 64 * 4;
-    const size_t tail = kW * gw * 16 * mb * 4 + (mb == 2 ? 0 : red) + 8 * kW * 4;
-    return (mb == 2 && red > planes ? red : planes) + tail;
+    const size_t gw = (groups + kW - 1) / kW;
+    return kW * gw * 8 * 64 * (size_t)m + kW * gw * 64 + (size_t)r * kW * 64 * 4 + 4 * kW * 4;
 }
 
-template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE = false, int MB = 1>
+template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE = false>
 int launch_i8p_n(const I8Params& p, int grid, hipStream_t hs) {
     const size_t lds = i8p_lds_bytes(p.groups, p.m, R);
     if (lds > 160 * 1024) return ZL_ELIMIT;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_i8p<R, LONGK, ROPE, NORM, MERGE, MB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_i8p<R, LONGK, ROPE, NORM, MERGE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return ZL_ELIMIT;
     }
-    hipLaunchKernelGGL((k_w4a16_i8p<R, LONGK, ROPE, NORM, MERGE, MB>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w4a16_i8p<R, LONGK, ROPE, NORM, MERGE>), dim3(grid), dim3(kT), lds, hs, p);
     return zl_launch_status();
 }
 template <int R, bool ROPE>
 int launch_i8p(const I8Params& p, int grid, hipStream_t hs) {
     const bool lk = p.groups > 4 * kW;
-    if (p.m > 4) {        // second row block: K <= 4096 only (zl_w4a16_i8p_covers)
-        if (lk) return ZL_ESHAPE;
-        return p.norm_w ? launch_i8p_n<R, false, ROPE, true, false, 2>(p, grid, hs) : launch_i8p_n<R, false, ROPE, false, false, 2>(p, grid, hs);
-    }
     if (p.norm_w) return lk ? launch_i8p_n<R, true, ROPE, true>(p, grid, hs) : launch_i8p_n<R, false, ROPE, true>(p, grid, hs);
     return lk ? launch_i8p_n<R, true, ROPE, false>(p, grid, hs) : launch_i8p_n<R, false, ROPE, false>(p, grid, hs);
 }
@@ -643,9 +603,9 @@ int launch_i8p(const I8Params& p, int grid, hipStream_t hs) {
 extern "C" int zl_debug_set_probe_i8p(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(zl_probe_i8), &p, sizeof(p)); }
 #endif
 
-// what the kernel covers: 1..8 rows with K <= 4096, 1..2 rows with K <= 16384, K a multiple of 128 (ZLW4M tiles), LDS
+// what the kernel covers: 1..4 rows with K <= 4096, 1..2 rows with K <= 16384, K a multiple of 128 (ZLW4M tiles), LDS
 bool zl_w4a16_i8p_covers(int64_t m, int64_t k) {
-    if (m < 1 || m > 8 || k < 128 || k % 128 != 0 || k > 16384 || (k > 4096 && m > 2)) return false;
+    if (m < 1 || m > 4 || k < 128 || k % 128 != 0 || k > 16384 || (k > 4096 && m > 2)) return false;
     return i8p_lds_bytes((int)(k / 128), (int)m, 8) <= 160 * 1024;
 }
 
@@ -667,9 +627,6 @@ int zl_w4a16_gemm_i8p(const uint16_t* x, int64_t ldx, const uint32_t* qw, const 
     int r = (tiles + cus - 1) / cus;
     if (r > 8) r = 8;
     if (rounds_override > 0 && rounds_override <= 8) r = rounds_override;
-    // every thread owns at most one output: R tiles x (16, or 8 gate / up pairs) columns x M rows <= 512
-    const int per_tile = ((epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) ? 8 : 16) * m;
-    while (r > 1 && r * per_tile > kT) --r;
     const int grid = (tiles + r - 1) / r;
 #define ZL_I8(RR) case RR: return launch_i8p<RR, false>(p, grid, hs);
     switch (r) { ZL_I8(1) ZL_I8(2) ZL_I8(3) ZL_I8(4) ZL_I8(5) ZL_I8(6) ZL_I8(7) ZL_I8(8) }

@@ -707,14 +707,8 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
     // 5..32 rows without a fused norm: the phase-pipelined streaming kernel (w4_phase.hip).  With more than 16
     // rows every workgroup pulls M x K activations through L2, so a long K (the down projection) stays on
     // the M-tiled kernel, whose 128-column workgroups share them.
-    // 1..4 rows (1..2 with a long K): the integer-plane kernel (w4_i8p.hip), the batch-1 decode default.  5..8 rows: only
-    // without a fused norm and with a plain epilogue -- converting 8 rows of activations per workgroup costs 3.8 us (plus
-    // 2.5 us of norm) before the first item, which the cheaper items win back on the short attn_out projection only
-    // (8.4 vs 9.5 us; qkv + norm 11.5 vs 9.5, gate|up + norm 18.0 vs 16.9: profiles/r03_i8p_timeline_m8.txt).
-    // small_algo 3 forces the integer planes for all 5..8-row launches (the test suite does, to cover the second row block)
-    const bool i8_rows = m <= 4 || o.small_algo == 3 || (o.small_algo == 0 && !norm_weight && !silu);
-    if ((o.small_algo == 0 || o.small_algo == 3 || (o.small_algo == 2 && m <= 4)) && i8_rows && zl_w4a16_i8p_covers(m, k) &&
-        L.qw_bytes < ((int64_t)1 << 32))
+    // 1..4 rows (1..2 with a long K): the integer-plane kernel (w4_i8p.hip), the batch-1 decode default
+    if (!o.small_algo && zl_w4a16_i8p_covers(m, k) && L.qw_bytes < ((int64_t)1 << 32))
         return zl_w4a16_gemm_i8p(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
                                  (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), norm_weight, norm_eps,
                                  o.phase_rounds, hs);
@@ -845,8 +839,7 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
     ZL_CHECK_ARG(!norm_weight || (m <= 8 && k <= 4096), ZL_ESHAPE);
     ZL_CHECK_ARG(m <= 16 || k <= 8192, ZL_ESHAPE);
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
-    const int sa = opts ? opts->small_algo : 0;
-    if (((sa == 0 || sa == 2) && m <= 4 || sa == 3) && zl_w4a16_i8p_covers(m, k))      // 5..8 rows: see zl_w4a16_gemm_mfma_ex
+    if (!(opts && opts->small_algo) && zl_w4a16_i8p_covers(m, k))
         return zl_w4a16_gemm_i8p_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n,
                                       (int)k, (int)L.q, (int)(L.np / 16), norm_weight, norm_eps, cosv, sinv, placement,
                                       buf_lens, k_bufs, v_bufs, q_out, (int)h, (int)hkv, (int)d, bshd, (hipStream_t)s);
