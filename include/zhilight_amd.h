@@ -490,6 +490,11 @@ int zl_permute_input(const uint16_t* x, int64_t ldx, const int32_t* perm, uint16
  * ---------------------------------------------------------------------------------------------- */
 int zl_embedding(const int32_t* ids, const uint16_t* weight, uint16_t* out, int64_t s_len, int64_t dim,
                  int32_t begin, int32_t end, float scale, int dtype, zl_stream_t s);
+/* zl_embedding + zl_rope_cos_sin (llama3 = 0) / zl_rope_cos_sin_llama3 (llama3 = 1) in one launch: the two independent kernels a
+ * decode step starts with (bit-identical outputs; d <= 256). */
+int zl_embedding_rope(const int32_t* ids, const uint16_t* weight, uint16_t* out, int64_t s_len, int64_t dim, int32_t begin, int32_t end,
+                      float scale, int dtype, const int32_t* pos, float* cosv, float* sinv, int64_t d, float base, int neox, int llama3,
+                      float factor, float low_freq_factor, float high_freq_factor, float old_context_len, zl_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * a8..a11  INT8 (W8A8, dynamic per-token).  Replaces int8_op::quant_calc_scale, layernorm_quant,

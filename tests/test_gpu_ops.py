@@ -750,3 +750,24 @@ def test_reduce_tp_int8_composition(oracle, dev, world):
         assert np.array_equal(outs[r], want), r
     exact = sum(oracle.u2h(p).astype(np.float64) for p in parts)
     assert np.abs(oracle.u2h(want).astype(np.float64) - exact).max() <= 0.02 * np.abs(exact).max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("llama3", [None, (8.0, 1.0, 4.0, 8192)])
+def test_embedding_rope_one_launch_equals_the_two_calls(dev, dtype, llama3):
+    """zl_embedding_rope = zl_embedding + zl_rope_cos_sin(_llama3), the first two launches of a decode step, bit for bit"""
+    from zhilight_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    vocab, dim, d = 1000, 4096, 128
+    w = (torch.randn(vocab, dim, generator=g) * 0.5).to(dtype).to(dev)
+    for b in (1, 7, 32):
+        ids = torch.randint(0, vocab, (b,), generator=g, dtype=torch.int32).to(dev)
+        pos = torch.randint(0, 9000, (b,), generator=g, dtype=torch.int32).to(dev)
+        h, cs, sn = ops.embedding_rope(ids, w, 12.0, pos, d, 5e5, True, llama3)
+        assert torch.equal(h, ops.embedding(ids, w, 12.0))
+        cs2, sn2 = ops.rope_cos_sin(pos, d, 5e5, True, llama3)
+        assert torch.equal(cs, cs2) and torch.equal(sn, sn2)
+    # odd widths keep the element-wise path of the gather
+    w2 = (torch.randn(50, 100, generator=g)).to(dtype).to(dev)
+    ids = torch.tensor([3, 49, 0], dtype=torch.int32, device=dev)
+    assert torch.equal(ops.embedding(ids, w2, 1.0), w2[ids.long()])

@@ -63,9 +63,9 @@ __device__ __forceinline__ int half_dim_index(int col, int half_dim, int neox) {
     return neox ? (col < half_dim ? col : col - half_dim) : col / 2;
 }
 
-__global__ void k_rope_cos_sin(const int32_t* __restrict__ pos, float* __restrict__ cosv, float* __restrict__ sinv,
-                               int d, float base, int neox, int llama3, float factor, float low_ff, float high_ff,
-                               float old_ctx) {
+__device__ __forceinline__ void rope_cos_sin_row(int row, const int32_t* __restrict__ pos, float* __restrict__ cosv, float* __restrict__ sinv,
+                                                 int d, float base, int neox, int llama3, float factor, float low_ff, float high_ff,
+                                                 float old_ctx) {
     const int col = threadIdx.x;
     if (col >= d) return;
     const int i = half_dim_index(col, d / 2, neox);
@@ -85,9 +85,14 @@ __global__ void k_rope_cos_sin(const int32_t* __restrict__ pos, float* __restric
             inv_freq = __builtin_fmaf(smooth, inv_freq, (1.f - smooth) * inv_freq / factor);
         }
     }
-    const float freq = (float)pos[blockIdx.x] * inv_freq;
-    cosv[(size_t)blockIdx.x * d + col] = cosf(freq);
-    sinv[(size_t)blockIdx.x * d + col] = sinf(freq);
+    const float freq = (float)pos[row] * inv_freq;
+    cosv[(size_t)row * d + col] = cosf(freq);
+    sinv[(size_t)row * d + col] = sinf(freq);
+}
+__global__ void k_rope_cos_sin(const int32_t* __restrict__ pos, float* __restrict__ cosv, float* __restrict__ sinv,
+                               int d, float base, int neox, int llama3, float factor, float low_ff, float high_ff,
+                               float old_ctx) {
+    rope_cos_sin_row(blockIdx.x, pos, cosv, sinv, d, base, neox, llama3, factor, low_ff, high_ff, old_ctx);
 }
 
 // dynamic-NTK and YaRN angle tables (RotaryEmbedding::impl "dynamic" / YarnImpl, src/nn/position/rotary_embedding.cu:19-61,
@@ -330,15 +335,49 @@ __global__ void k_gate_mul(const uint16_t* __restrict__ g, const uint16_t* __res
 }
 
 // embedding: grid (S), block 256, 16-byte lanes.  src/nn/embedding/embedding.cu:23-44
+// (16-byte lanes for real: with one 2-byte element per thread and iteration the 16 iterations of a 4096-wide row were 16
+//  dependent round trips, 8.7 us for one token inside the decode step)
+template <int DT>
+__device__ __forceinline__ void embedding_row(int row, const int32_t* __restrict__ ids, const uint16_t* __restrict__ w,
+                                              uint16_t* __restrict__ out, int dim, int begin, int end, float scale) {
+    int id = ids[row];
+    const bool in_range = id >= begin && id < end;
+    id -= begin;
+    const uint16_t* src = w + (size_t)(in_range ? id : 0) * dim;
+    uint16_t* dst = out + (size_t)row * dim;
+    if ((dim & 7) == 0 && ((((uintptr_t)w) | ((uintptr_t)out)) & 15) == 0) {
+        const int chunks = dim >> 3;
+        for (int c0 = threadIdx.x; c0 < chunks; c0 += 2 * blockDim.x) {
+            const int c1 = c0 + blockDim.x;
+            uint4 v0 = *reinterpret_cast<const uint4*>(src + (size_t)c0 * 8), v1 = make_uint4(0, 0, 0, 0);
+            if (c1 < chunks) v1 = *reinterpret_cast<const uint4*>(src + (size_t)c1 * 8);
+            auto conv = [&](uint32_t u) {
+                const uint16_t lo = in_range ? ZT<DT>::from_f32(ZT<DT>::to_f32((uint16_t)(u & 0xffffu)) * scale) : ZT<DT>::from_f32(0.f);
+                const uint16_t hi = in_range ? ZT<DT>::from_f32(ZT<DT>::to_f32((uint16_t)(u >> 16)) * scale) : ZT<DT>::from_f32(0.f);
+                return (uint32_t)lo | ((uint32_t)hi << 16);
+            };
+            *reinterpret_cast<uint4*>(dst + (size_t)c0 * 8) = make_uint4(conv(v0.x), conv(v0.y), conv(v0.z), conv(v0.w));
+            if (c1 < chunks) *reinterpret_cast<uint4*>(dst + (size_t)c1 * 8) = make_uint4(conv(v1.x), conv(v1.y), conv(v1.z), conv(v1.w));
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < dim; i += blockDim.x)
+        dst[i] = in_range ? ZT<DT>::from_f32(ZT<DT>::to_f32(src[i]) * scale) : ZT<DT>::from_f32(0.f);
+}
 template <int DT>
 __global__ void k_embedding(const int32_t* __restrict__ ids, const uint16_t* __restrict__ w, uint16_t* __restrict__ out,
                             int dim, int begin, int end, float scale) {
-    int id = ids[blockIdx.x];
-    const bool in_range = id >= begin && id < end;
-    id -= begin;
-    for (int i = threadIdx.x; i < dim; i += blockDim.x)
-        out[(size_t)blockIdx.x * dim + i] =
-            in_range ? ZT<DT>::from_f32(ZT<DT>::to_f32(w[(size_t)id * dim + i]) * scale) : ZT<DT>::from_f32(0.f);
+    embedding_row<DT>(blockIdx.x, ids, w, out, dim, begin, end, scale);
+}
+// the two independent launches a decode step starts with, as one: workgroups [0, S) gather the embedding rows, [S, 2 S) fill the
+// rotary tables (2 of the ~4 us each costs are the kernel boundary)
+template <int DT>
+__global__ __launch_bounds__(256) void k_embedding_rope(const int32_t* __restrict__ ids, const uint16_t* __restrict__ w, uint16_t* __restrict__ out,
+                                                        int dim, int begin, int end, float scale, int s_len, const int32_t* __restrict__ pos,
+                                                        float* __restrict__ cosv, float* __restrict__ sinv, int d, float base, int neox,
+                                                        int llama3, float factor, float low_ff, float high_ff, float old_ctx) {
+    if ((int)blockIdx.x < s_len) embedding_row<DT>(blockIdx.x, ids, w, out, dim, begin, end, scale);
+    else rope_cos_sin_row(blockIdx.x - s_len, pos, cosv, sinv, d, base, neox, llama3, factor, low_ff, high_ff, old_ctx);
 }
 
 inline int grid_1d(int64_t n, int threads) {
@@ -528,6 +567,20 @@ int zl_gate_mul(const uint16_t* gate, const uint16_t* up, uint16_t* out, int64_t
     ZL_DT_SWITCH(dtype,
         hipLaunchKernelGGL(k_gate_mul<ZL_F16>, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)s, gate, up, out, n, act),
         hipLaunchKernelGGL(k_gate_mul<ZL_BF16>, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)s, gate, up, out, n, act))
+    return zl_launch_status();
+}
+
+int zl_embedding_rope(const int32_t* ids, const uint16_t* weight, uint16_t* out, int64_t s_len, int64_t dim, int32_t begin, int32_t end,
+                      float scale, int dtype, const int32_t* pos, float* cosv, float* sinv, int64_t d, float base, int neox, int llama3,
+                      float factor, float low_freq_factor, float high_freq_factor, float old_context_len, zl_stream_t s) {
+    ZL_CHECK_ARG(ids && weight && out && pos && cosv && sinv && s_len > 0 && dim > 0 && d > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 256 && d % 2 == 0 && 2 * s_len < ((int64_t)1 << 31), ZL_ESHAPE);
+    const dim3 grid((unsigned)(2 * s_len)), block(256);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_embedding_rope<ZL_F16>, grid, block, 0, (hipStream_t)s, ids, weight, out, (int)dim, begin, end, scale, (int)s_len, pos,
+                           cosv, sinv, (int)d, base, neox, llama3, factor, low_freq_factor, high_freq_factor, old_context_len),
+        hipLaunchKernelGGL(k_embedding_rope<ZL_BF16>, grid, block, 0, (hipStream_t)s, ids, weight, out, (int)dim, begin, end, scale, (int)s_len, pos,
+                           cosv, sinv, (int)d, base, neox, llama3, factor, low_freq_factor, high_freq_factor, old_context_len))
     return zl_launch_status();
 }
 

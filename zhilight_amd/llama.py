@@ -940,11 +940,18 @@ class LLaMA:
         if workspace is None:
             workspace = self._bufs.setdefault(("ws", b, ctx.max_len_buf),
                                               ops.decode_attn_workspace(b, 1, c.num_heads, c.dim_head, ctx.max_len_buf, self.device))
+        rs = c.rope_scaling
+        kind = rs.get("rope_type", rs.get("type")) if rs else None
         if gemv_only:
             hidden = bufs["hidden"]
+            cos, sin = self._rope_tables(ctx.positions)
+        elif kind in (None, "default", "llama3") and c.dim_head <= 256 and self.token_embedding.shape[0] == c.vocab_size:
+            # token_embedding + RopePreparer in one launch (two independent ~4 us kernels, half of each a kernel boundary)
+            l3 = None if kind != "llama3" else (rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"])
+            hidden, cos, sin = ops.embedding_rope(ctx.tokens, self.token_embedding, c.scale_emb, ctx.positions, c.dim_head, c.rope_theta, True, l3)
         else:
             hidden = ops.embedding(ctx.tokens, self.token_embedding, c.scale_emb)  # token_embedding
-        cos, sin = self._rope_tables(ctx.positions)                                # RopePreparer
+            cos, sin = self._rope_tables(ctx.positions)                            # RopePreparer
         scale = 1.0 / math.sqrt(c.dim_head)
         mfma_attn = (c.dim_head == 128 and c.num_heads // c.num_kv_heads <= 16
                      and os.environ.get("ZL_ATTN_MFMA", "1") != "0")

@@ -892,6 +892,23 @@ def embedding(ids, weight, scale=1.0, begin=0, end=None):
     return out
 
 
+def embedding_rope(ids, weight, scale, pos, dim_head, base, neox=True, llama3=None):
+    """embedding + rope_cos_sin in one launch (the first two kernels of a decode step): (hidden, cos, sin), bit-identical to the
+    two calls"""
+    _chk_cuda(ids, weight, pos)
+    if ids.dtype != torch.int32 or pos.numel() != ids.numel():
+        raise ZLError("ids dtype mismatch / one position per token")
+    s = ids.numel()
+    out = torch.empty(tuple(ids.shape) + (weight.shape[1],), dtype=weight.dtype, device=weight.device)
+    cs = torch.empty((s, dim_head), dtype=torch.float32, device=pos.device)
+    sn = torch.empty_like(cs)
+    fac, low, high, old = llama3 if llama3 is not None else (1.0, 1.0, 1.0, 1.0)
+    check(lib().zl_embedding_rope(_p(ids), _p(weight), _p(out), _i(s), _i(weight.shape[1]), C.c_int32(0), C.c_int32(weight.shape[0]), _f(scale),
+                                  C.c_int(_dt(weight)), _p(pos), _p(cs), _p(sn), _i(dim_head), _f(base), C.c_int(int(neox)),
+                                  C.c_int(int(llama3 is not None)), _f(fac), _f(low), _f(high), _f(old), _stream()), "embedding_rope")
+    return out, cs, sn
+
+
 # --------------------------------------------------------------------------------------------------
 # a8..a11: INT8
 # --------------------------------------------------------------------------------------------------
