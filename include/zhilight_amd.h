@@ -660,6 +660,33 @@ int zl_moe_group_topk(const uint16_t* logits, const float* correction_bias, int6
                       int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker, zl_stream_t s);
 
 
+/* f4: the prompt-side MoE dispatch / combine around the grouped GEMMs (src/nn/feedforward/ff_kernel.h:42-96, ff_kernel.cu:518-1082).
+ * Integer outputs exact; the weighted sums accumulate in fp32 in slot order, one fma per term, one rounding to T.
+ *   zl_moe_sum_experts       nn::sum_experts (one concatenated input): out[q] = sum_i input[index[q K + i]] * weight[q K + i]
+ *   zl_moe_sum_experts_arr   nn::sum_experts (one input per expert; DEVICE array of row pointers): a single token reads row 0 of each
+ *                            expert and weight[k]; exp_parallel keeps the experts with (id & (world_size - 1)) == local_rank
+ *   zl_moe_route_shared_lb   nn::route_shared_lb: shared-expert slot s of token q -> the first rank with spare capacity
+ *                            (max_load - worker_load_base[r]), pseudo expert id (num_local_experts + s) * world_size + rank
+ *   zl_moe_plus_for_sort     nn::plus_for_sort: id + (id % world_size) * multiple (sort key that groups experts by rank)
+ *   zl_moe_calc_reverse_idx  nn::calc_reverse_idx's kernel: rev[indices[i]] = i - expert_offsets[exp_ids[indices[i]]]
+ *   zl_moe_fill_m_indices    nn::fill_m_indices_padded_indices' kernel: per local expert e with num_tokens[e] rows at offsets[e]:
+ *                            padded_indices[offsets[e] + s] = aligned_offsets[e] + s; m_indices[aligned_offsets[e] ..
+ *                            aligned_offsets[e + 1]) = e (every run padded to block_m rows: the layout zl_fp8_block_gemm_group reads)
+ * The prefix sums those last two take are the host loops of the reference (ops.py / nn_amd.cpp restate them). */
+int zl_moe_sum_experts(const uint16_t* input, const int32_t* index, const float* weight, uint16_t* out, int64_t seq_len, int top_k,
+                       int64_t dim_model, int dtype, zl_stream_t s);
+int zl_moe_sum_experts_arr(const uint16_t* const* input_arr, const int32_t* experts, const int32_t* index, const float* weight, uint16_t* out,
+                           int64_t seq_len, int top_k, int64_t dim_model, int exp_parallel, int world_size, int local_rank, int dtype,
+                           zl_stream_t s);
+int zl_moe_route_shared_lb(int32_t* exp_ids, const int32_t* worker_load_base, int32_t* worker_load, int32_t* expert_load, int max_load,
+                           int world_size, int64_t seq_len, int top_k, int top_k_ext, int num_local_experts, zl_stream_t s);
+int zl_moe_plus_for_sort(const int32_t* exp_ids, int32_t* out, int multiple, int world_size, int64_t numel, zl_stream_t s);
+int zl_moe_calc_reverse_idx(const int32_t* exp_ids, const int32_t* indices, const int32_t* expert_offsets, int32_t* rev_indices, int64_t numel,
+                            zl_stream_t s);
+int zl_moe_fill_m_indices(const int32_t* num_tokens, const int32_t* offsets, const int32_t* aligned_offsets, int32_t* padded_indices,
+                          int32_t* m_indices, int local_experts, int max_num_token, int block_m, zl_stream_t s);
+
+
 #ifdef __cplusplus
 }
 #endif

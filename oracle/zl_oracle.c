@@ -1589,3 +1589,91 @@ void zlo_moe_group_topk(const uint16_t* logits, const float* correction_bias, in
         for (int l = k; l < top_k_ext; ++l) { out_v[q * top_k_ext + l] = 1.f; out_idx[q * top_k_ext + l] = 0; }
     }
 }
+
+/* ---- MoE dispatch / combine (src/nn/feedforward/ff_kernel.cu:518-1082) ---- */
+/* KERNEL_sum_experts (:520-538); nvcc contracts `acc += float(x) * w` into one fused multiply-add */
+void zlo_moe_sum_experts(const uint16_t* input, const int32_t* index, const float* weight, uint16_t* out, int64_t seq_len, int k,
+                         int64_t dim_model, int dtype) {
+    for (int64_t q = 0; q < seq_len; ++q)
+        for (int64_t d = 0; d < dim_model; ++d) {
+            float acc = 0.f;
+            for (int i = 0; i < k; ++i) acc = fmaf(T2f(input[(int64_t)index[q * k + i] * dim_model + d], dtype), weight[q * k + i], acc);
+            out[q * dim_model + d] = f2T(acc, dtype);
+        }
+}
+/* KERNEL_sum_experts_arr (:541-600): inputs[e] = expert e's output rows (NULL allowed when never referenced) */
+void zlo_moe_sum_experts_arr(const uint16_t* const* inputs, const int32_t* experts, const int32_t* index, const float* weight, uint16_t* out,
+                             int64_t seq_len, int k, int64_t dim_model, int exp_parallel, int world_size, int local_rank, int dtype) {
+    for (int64_t q = 0; q < seq_len; ++q)
+        for (int64_t d = 0; d < dim_model; ++d) {
+            float acc = 0.f;
+            for (int j = 0; j < k; ++j) {
+                const int64_t i = q * k + j;
+                const int e = experts[i];
+                if (exp_parallel && ((e & (world_size - 1)) != local_rank)) continue;
+                if (seq_len == 1) acc = fmaf(T2f(inputs[e][d], dtype), weight[j], acc);
+                else acc = fmaf(T2f(inputs[e][(int64_t)index[i] * dim_model + d], dtype), weight[i], acc);
+            }
+            out[q * dim_model + d] = f2T(acc, dtype);
+        }
+}
+/* KERNEL_route_shared_lb (:797-832) */
+void zlo_moe_route_shared_lb(int32_t* exp_ids, const int32_t* worker_load_base, int32_t* worker_load, int32_t* expert_load, int max_load,
+                             int world_size, int64_t seq_len, int top_k, int top_k_ext, int num_local_experts) {
+    for (int s = 0; s < top_k_ext - top_k; ++s)
+        for (int64_t q = 0; q < seq_len; ++q) {
+            int r = 0;
+            int64_t skip = seq_len * s + q;
+            for (;;) {
+                const int cap = worker_load_base[r] >= max_load ? 0 : max_load - worker_load_base[r];
+                if (skip < cap || r == world_size - 1) break;
+                skip -= cap;
+                ++r;
+            }
+            const int e = (num_local_experts + s) * world_size + r;
+            exp_ids[q * top_k_ext + top_k + s] = e;
+            worker_load[r] += 1;
+            expert_load[e] += 1;
+        }
+}
+void zlo_moe_plus_for_sort(const int32_t* exp_ids, int32_t* out, int multiple, int world_size, int64_t numel) {
+    for (int64_t i = 0; i < numel; ++i) out[i] = exp_ids[i] + (exp_ids[i] % world_size) * multiple;
+}
+/* calc_reverse_idx (:886-942): the expert offsets of the host loop + the kernel */
+void zlo_moe_calc_reverse_idx(const int32_t* exp_ids, const int32_t* indices, const int32_t* all_loads, int num_experts, int world_size,
+                              int sorted_by_rank, int32_t* expert_offset, int32_t* rev_indices, int64_t numel) {
+    if (sorted_by_rank) {
+        const int32_t* rank_loads = all_loads + num_experts;
+        int rank_offset = 0;
+        for (int rank = 0; rank < world_size; ++rank) {
+            int offset = 0;
+            for (int i = rank; i < num_experts; i += world_size) {
+                expert_offset[i] = rank_offset + offset;
+                offset += all_loads[i];
+            }
+            rank_offset += rank_loads[rank];
+        }
+    } else {
+        int offset = 0;
+        for (int i = 0; i < num_experts; ++i) {
+            expert_offset[i] = offset;
+            offset += all_loads[i];
+        }
+    }
+    for (int64_t i = 0; i < numel; ++i) {
+        const int idx = indices[i];
+        rev_indices[idx] = (int32_t)i - expert_offset[exp_ids[idx]];
+    }
+}
+/* fill_m_indices_padded_indices (:964-1057): returns the aligned total; padded_indices (sum of the local loads), m_indices (aligned total) */
+int zlo_moe_fill_m_indices(const int32_t* all_loads, int block_m, int num_experts, int rank, int ws, int32_t* padded_indices, int32_t* m_indices) {
+    int offset = 0, a_offset = 0;
+    for (int i = 0, j = rank; j < num_experts; ++i, j += ws) {
+        const int nt = all_loads[j], an = (nt + block_m - 1) / block_m * block_m;
+        for (int s = 0; s < nt; ++s) padded_indices[offset + s] = a_offset + s;
+        for (int s = 0; s < an; ++s) m_indices[a_offset + s] = i;
+        offset += nt;
+        a_offset += an;
+    }
+    return a_offset;
+}

@@ -207,6 +207,19 @@ void zlo_moe_group_topk(const uint16_t* logits, const float* correction_bias, in
                         int renormalize, float weight_scale, int scoring, int num_group, int topk_group, int dtype, float* out_v,
                         int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker);
 
+
+/* MoE dispatch / combine (ff_kernel.cu:518-1082) */
+void zlo_moe_sum_experts(const uint16_t* input, const int32_t* index, const float* weight, uint16_t* out, int64_t seq_len, int k,
+                         int64_t dim_model, int dtype);
+void zlo_moe_sum_experts_arr(const uint16_t* const* inputs, const int32_t* experts, const int32_t* index, const float* weight, uint16_t* out,
+                             int64_t seq_len, int k, int64_t dim_model, int exp_parallel, int world_size, int local_rank, int dtype);
+void zlo_moe_route_shared_lb(int32_t* exp_ids, const int32_t* worker_load_base, int32_t* worker_load, int32_t* expert_load, int max_load,
+                             int world_size, int64_t seq_len, int top_k, int top_k_ext, int num_local_experts);
+void zlo_moe_plus_for_sort(const int32_t* exp_ids, int32_t* out, int multiple, int world_size, int64_t numel);
+void zlo_moe_calc_reverse_idx(const int32_t* exp_ids, const int32_t* indices, const int32_t* all_loads, int num_experts, int world_size,
+                              int sorted_by_rank, int32_t* expert_offset, int32_t* rev_indices, int64_t numel);
+int zlo_moe_fill_m_indices(const int32_t* all_loads, int block_m, int num_experts, int rank, int ws, int32_t* padded_indices, int32_t* m_indices);
+
 #ifdef __cplusplus
 }
 #endif

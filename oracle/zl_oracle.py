@@ -672,3 +672,62 @@ def moe_group_topk(logits, bias, k, num_group, topk_group, top_k_ext=None, renor
                              C.c_int(_SCORING[scoring]), C.c_int(num_group), C.c_int(topk_group), C.c_int(dtype), _p(v), _p(idx),
                              _p(wl) if num_worker else None, _p(el), C.c_int(num_worker))
     return v, idx, wl, el
+
+
+# ---- MoE dispatch / combine
+def moe_sum_experts(inp, index, weight, dtype=0):
+    inp, index, weight = _c(inp, np.uint16), _c(index, np.int32), _c(weight, np.float32)
+    seq, k = weight.shape
+    out = np.empty((seq, inp.shape[1]), np.uint16)
+    lib().zlo_moe_sum_experts(_p(inp), _p(index), _p(weight), _p(out), _i(seq), C.c_int(k), _i(inp.shape[1]), C.c_int(dtype))
+    return out
+
+
+def moe_sum_experts_arr(inputs, experts, index, weight, dim_model, exp_parallel=False, world_size=1, local_rank=0, dtype=0):
+    inputs = [None if a is None else _c(a, np.uint16) for a in inputs]
+    arr = (C.c_void_p * len(inputs))(*[None if a is None else a.ctypes.data for a in inputs])
+    experts, weight = _c(experts, np.int32), _c(weight, np.float32)
+    idx = None if index is None else _c(index, np.int32)
+    seq, k = weight.shape
+    out = np.empty((seq, dim_model), np.uint16)
+    lib().zlo_moe_sum_experts_arr(arr, _p(experts), _p(idx), _p(weight), _p(out), _i(seq), C.c_int(k), _i(dim_model), C.c_int(int(exp_parallel)),
+                                  C.c_int(world_size), C.c_int(local_rank), C.c_int(dtype))
+    return out
+
+
+def moe_route_shared_lb(exp_ids, worker_load, expert_load, top_k, num_local_experts):
+    """in place on copies; returns (exp_ids, worker_load, expert_load)"""
+    exp_ids, wl, el = _c(exp_ids, np.int32).copy(), _c(worker_load, np.int32).copy(), _c(expert_load, np.int32).copy()
+    base = wl.copy()
+    seq, ext = exp_ids.shape
+    ws = wl.size
+    max_load = (exp_ids.size + ws - 1) // ws
+    lib().zlo_moe_route_shared_lb(_p(exp_ids), _p(base), _p(wl), _p(el), C.c_int(max_load), C.c_int(ws), _i(seq), C.c_int(top_k), C.c_int(ext),
+                                  C.c_int(num_local_experts))
+    return exp_ids, wl, el
+
+
+def moe_plus_for_sort(exp_ids, num_experts, world_size):
+    exp_ids = _c(exp_ids, np.int32)
+    out = np.empty_like(exp_ids)
+    lib().zlo_moe_plus_for_sort(_p(exp_ids), _p(out), C.c_int(num_experts), C.c_int(world_size), _i(exp_ids.size))
+    return out
+
+
+def moe_calc_reverse_idx(exp_ids, indices, all_loads, num_experts, world_size=1, sorted_by_rank=False):
+    exp_ids, indices, all_loads = _c(exp_ids, np.int32), _c(indices, np.int32), _c(all_loads, np.int32)
+    off = np.zeros(num_experts, np.int32)
+    rev = np.zeros(indices.size, np.int32)
+    lib().zlo_moe_calc_reverse_idx(_p(exp_ids), _p(indices), _p(all_loads), C.c_int(num_experts), C.c_int(world_size), C.c_int(int(sorted_by_rank)),
+                                   _p(off), _p(rev), _i(indices.size))
+    return rev, off
+
+
+def moe_fill_m_indices(all_loads, block_m, num_experts, rank=0, ws=1):
+    all_loads = _c(all_loads, np.int32)
+    local = all_loads[rank:num_experts:ws]
+    pad = np.zeros(int(local.sum()), np.int32)
+    mi = np.zeros(int(((local + block_m - 1) // block_m * block_m).sum()), np.int32)
+    lib().zlo_moe_fill_m_indices.restype = C.c_int
+    total = lib().zlo_moe_fill_m_indices(_p(all_loads), C.c_int(block_m), C.c_int(num_experts), C.c_int(rank), C.c_int(ws), _p(pad), _p(mi))
+    return mi, pad, total

@@ -198,3 +198,74 @@ def test_reference_fp8block_layer(oracle, dev):
     _gemm_bar(got, oracle.fp8_block_gemm(a8, sa, w8, sw, dtype=1), oracle, 1)
     # get_dequant_weight -> dequant_fp8_block_weight
     assert np.array_equal(lin.dequant_weight(), oracle.fp8_block_dequant(w8, sw, dtype=1))
+
+
+@pytest.mark.parametrize("dtype,code", [(torch.float16, 0), (torch.bfloat16, 1)])
+def test_moe_dispatch_and_combine_bit_exact(oracle, dev, dtype, code):
+    """the index bookkeeping between router and grouped GEMMs and the weighted combine (ff_kernel.cu:518-1082), each against its
+    restatement, plus the property that ties them together: gathering by the computed positions and combining per expert
+    equals combining the concatenated layout"""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(21)
+    tokens, experts, k, world, dim = 45, 16, 4, 4, 384
+    ids = np.stack([rng.choice(experts, size=k, replace=False) for _ in range(tokens)]).astype(np.int32)
+    w = rng.random((tokens, k)).astype(np.float32)
+    loads = np.bincount(ids.ravel(), minlength=experts).astype(np.int32)
+    rank_loads = np.array([loads[r::world].sum() for r in range(world)], np.int32)
+    all_loads = np.concatenate([loads, rank_loads])
+    # plus_for_sort + the sort the reference runs on it (functions::sort: here a stable argsort of the same keys)
+    keys = ops.moe_plus_for_sort(_t(ids, dev), experts, world)
+    assert np.array_equal(keys.cpu().numpy(), oracle.moe_plus_for_sort(ids, experts, world))
+    for by_rank in (False, True):
+        order = np.argsort((keys.cpu().numpy() if by_rank else ids).ravel(), kind="stable").astype(np.int32)
+        rev = ops.moe_calc_reverse_idx(_t(ids, dev), _t(order, dev), all_loads, experts, world, by_rank)
+        want, _ = oracle.moe_calc_reverse_idx(ids, order, all_loads, experts, world, by_rank)
+        assert np.array_equal(rev.cpu().numpy(), want)
+        # a position inside an expert's run: 0 .. load - 1, every value once per expert
+        r = rev.cpu().numpy().reshape(tokens, k)
+        for e in range(experts):
+            assert sorted(r[ids == e].tolist()) == list(range(loads[e]))
+    # m-grouped layout of the local experts (all of them, and rank 1's under expert parallelism)
+    for ep, rk in ((False, 0), (True, 1)):
+        mi, pad, total = ops.moe_fill_m_indices_padded_indices(all_loads, 64, experts, dev, ep, rk, world)
+        wmi, wpad, wtotal = oracle.moe_fill_m_indices(all_loads, 64, experts, rk if ep else 0, world if ep else 1)
+        assert total == wtotal and np.array_equal(mi.cpu().numpy(), wmi) and np.array_equal(pad.cpu().numpy(), wpad)
+    # combine: concatenated form
+    order = np.argsort(ids.ravel(), kind="stable").astype(np.int32)
+    rev, off = oracle.moe_calc_reverse_idx(ids, order, all_loads, experts)
+    y = torch.from_numpy(rng.standard_normal((tokens * k, dim)).astype(np.float32)).to(dtype)     # expert outputs, sorted-by-expert rows
+    pos = (off[ids.ravel()] + rev).astype(np.int32)                                              # row of (token, slot) in y
+    got = ops.moe_sum_experts(y.to(dev), _t(pos, dev), _t(w, dev))
+    assert np.array_equal(_bits(got), oracle.moe_sum_experts(_bits(y), pos, w, dtype=code))
+    # per-expert form: the same rows split by expert, positions = rev; experts without tokens pass None
+    parts = [y[off[e]:off[e] + loads[e]].contiguous() if loads[e] else None for e in range(experts)]
+    got2 = ops.moe_sum_experts_arr([None if p is None else p.to(dev) for p in parts], _t(ids.ravel(), dev), _t(rev, dev), _t(w, dev))
+    assert torch.equal(got2, got)
+    want2 = oracle.moe_sum_experts_arr([None if p is None else _bits(p) for p in parts], ids.ravel(), rev, w, dim, dtype=code)
+    assert np.array_equal(_bits(got2), want2)
+    # expert parallelism: the ranks' partial sums of one token cover every expert exactly once
+    one = ids[:1]
+    rows = [torch.from_numpy(rng.standard_normal((1, dim)).astype(np.float32)).to(dtype) for _ in range(experts)]
+    full = oracle.moe_sum_experts_arr([_bits(r) for r in rows], one.ravel(), None, w[:1], dim, dtype=code)
+    acc = np.zeros((1, dim), np.float64)
+    for rk in range(world):
+        part = ops.moe_sum_experts_arr([r.to(dev) for r in rows], _t(one.ravel(), dev), None, _t(w[:1], dev), True, world, rk)
+        assert np.array_equal(_bits(part), oracle.moe_sum_experts_arr([_bits(r) for r in rows], one.ravel(), None, w[:1], dim, True, world, rk, code))
+        acc += part.float().cpu().numpy()
+    f = oracle.u2h(full).astype(np.float64) if code == 0 else (full.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    assert np.abs(acc - f).max() <= 2.0 ** (-6 if code else -9) * max(1.0, np.abs(f).max())
+
+
+def test_moe_shared_expert_load_balancing(oracle, dev):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(8)
+    tokens, k, ext, world, local = 23, 6, 8, 4, 16
+    ids = np.zeros((tokens, ext), np.int32)
+    ids[:, :k] = rng.integers(0, local * world, size=(tokens, k))
+    wl = np.bincount(ids[:, :k].ravel() % world, minlength=world).astype(np.int32)
+    el = np.zeros((local + ext - k) * world, np.int32)
+    t_ids, t_wl, t_el = _t(ids, dev), _t(wl, dev), _t(el, dev)
+    ops.moe_route_shared_lb(t_ids, torch.ones((tokens, ext), dtype=torch.float32, device=dev), t_wl, t_el, k, local)
+    w_ids, w_wl, w_el = oracle.moe_route_shared_lb(ids, wl, el, k, local)
+    assert np.array_equal(t_ids.cpu().numpy(), w_ids) and np.array_equal(t_wl.cpu().numpy(), w_wl) and np.array_equal(t_el.cpu().numpy(), w_el)
+    assert t_wl.cpu().numpy().max() <= (tokens * ext + world - 1) // world + 0      # nobody above the even share

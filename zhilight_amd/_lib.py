@@ -18,6 +18,8 @@ SO_PATH = os.environ.get("ZHILIGHT_AMD_SO") or os.path.join(_HERE, "libzhilight_
 
 # every entry point declared in include/zhilight_amd.h (kept in sync by tests/test_abi.py)
 SYMBOLS = [
+    "zl_moe_sum_experts", "zl_moe_sum_experts_arr", "zl_moe_route_shared_lb", "zl_moe_plus_for_sort", "zl_moe_calc_reverse_idx",
+    "zl_moe_fill_m_indices",
     "zl_embedding_rope",
     "zl_fp8_per_token_cast", "zl_fp8_block_dequant", "zl_fp8_block_gemm_group", "zl_moe_top_k_softmax", "zl_moe_group_topk",
     "zl_cast", "zl_copy_2d", "zl_index_select", "zl_reduce_abs_max", "zl_binary_op", "zl_scale", "zl_act_inplace",

@@ -255,3 +255,151 @@ int zl_moe_group_topk(const uint16_t* logits, const float* correction_bias, int6
 }
 
 }  // extern "C"
+
+// ---- dispatch / combine of the prompt-side MoE path (src/nn/feedforward/ff_kernel.cu:518-1082) -----------------------------------
+// Index bookkeeping between the router and the grouped GEMMs, and the weighted sum of the expert outputs.  Integer outputs
+// are exact; the sums accumulate in fp32 in slot order with one fused multiply-add per term (what nvcc makes of
+// `acc += float(x) * w`) and round once to T: bit-identical to the oracle.
+namespace {
+
+// KERNEL_sum_experts (:520-538): out[q, d] = T(sum_i float(input[index[q K + i], d]) * weight[q K + i])
+template <int DT>
+__global__ __launch_bounds__(256) void k_moe_sum_experts(int dim_model, int K, const uint16_t* __restrict__ input, const int32_t* __restrict__ index,
+                                                         const float* __restrict__ weight, uint16_t* __restrict__ out) {
+    const int q = blockIdx.x, d = blockIdx.y * blockDim.x + threadIdx.x;
+    if (d >= dim_model) return;
+    float acc = 0.f;
+    for (int i = 0; i < K; ++i)
+        acc = __builtin_fmaf(ZT<DT>::to_f32(input[(size_t)index[q * K + i] * dim_model + d]), weight[q * K + i], acc);
+    out[(size_t)q * dim_model + d] = ZT<DT>::from_f32(acc);
+}
+
+// KERNEL_sum_experts_arr / _inline_arr (:541-626): one input matrix per expert; a single token (grid.x == 1) reads row 0 of each
+// and weight[k]; with expert parallelism only the experts of this rank (exp & (world - 1)) == rank contribute
+template <int DT>
+__global__ __launch_bounds__(256) void k_moe_sum_experts_arr(int dim_model, int K, const uint16_t* const* __restrict__ input_arr,
+                                                             const int32_t* __restrict__ experts, const int32_t* __restrict__ index,
+                                                             const float* __restrict__ weight, uint16_t* __restrict__ out, int exp_parallel,
+                                                             int world_size_mask, int local_rank) {
+    const int q = blockIdx.x, d = blockIdx.y * blockDim.x + threadIdx.x;
+    if (d >= dim_model) return;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int i = q * K + k, e = experts[i];
+        if (exp_parallel && ((e & world_size_mask) != local_rank)) continue;
+        const uint16_t* input = input_arr[e];
+        if (gridDim.x == 1) acc = __builtin_fmaf(ZT<DT>::to_f32(input[d]), weight[k], acc);
+        else acc = __builtin_fmaf(ZT<DT>::to_f32(input[(size_t)index[i] * dim_model + d]), weight[i], acc);
+    }
+    out[(size_t)q * dim_model + d] = ZT<DT>::from_f32(acc);
+}
+
+// KERNEL_route_shared_lb (:797-832): shared-expert slot s of token q goes to the first rank with spare capacity, ranks filled in order
+__global__ void k_moe_route_shared_lb(int32_t* exp_ids, const int32_t* worker_load_base, int32_t* worker_load, int32_t* expert_load, int max_load,
+                                      int world_size, int seq_len, int top_k, int top_k_ext, int num_local_experts) {
+    const int q = blockIdx.x, s = blockIdx.y;
+    int r = 0, skip_len = seq_len * s + q;
+    for (;;) {
+        const int base = worker_load_base[r];
+        const int cap = base >= max_load ? 0 : max_load - base;
+        if (skip_len < cap || r == world_size - 1) break;      // (the reference asserts r < world_size)
+        skip_len -= cap;
+        ++r;
+    }
+    const int exp_id = (num_local_experts + s) * world_size + r;   // a pseudo expert id of rank r
+    exp_ids[q * top_k_ext + top_k + s] = exp_id;
+    atomicAdd(&worker_load[r], 1);
+    atomicAdd(&expert_load[exp_id], 1);
+}
+
+__global__ void k_moe_plus_for_sort(const int32_t* exp_ids, int32_t* out, int multiple, int world_size, int numel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < numel) out[i] = exp_ids[i] + (exp_ids[i] % world_size) * multiple;
+}
+
+// KERNEL_calc_reverse_idx (:886-898): position of every (token, slot) inside its expert's run of the sorted order
+__global__ void k_moe_calc_reverse_idx(const int32_t* exp_ids, const int32_t* indices, const int32_t* expert_offsets, int32_t* rev_indices,
+                                       int numel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numel) return;
+    const int idx = indices[i];
+    rev_indices[idx] = i - expert_offsets[exp_ids[idx]];
+}
+
+// KERNEL_fill_m_indices_padded_indices_temp (:946-962): rows of the m-grouped contiguous layout (every expert's run padded to block_m)
+__global__ void k_moe_fill_m_indices(const int32_t* num_tokens, const int32_t* offsets, const int32_t* aligned_offsets, int32_t* padded_indices,
+                                     int32_t* m_indices) {
+    const int e = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < num_tokens[e]) padded_indices[offsets[e] + s] = aligned_offsets[e] + s;
+    const int s2 = aligned_offsets[e] + s;
+    if (s2 < aligned_offsets[e + 1]) m_indices[s2] = e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zl_moe_sum_experts(const uint16_t* input, const int32_t* index, const float* weight, uint16_t* out, int64_t seq_len, int top_k,
+                       int64_t dim_model, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(input && index && weight && out && seq_len > 0 && top_k > 0 && dim_model > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(top_k <= kMaxTopK && seq_len < ((int64_t)1 << 31) && (dim_model + 255) / 256 <= 65535, ZL_ELIMIT);
+    const dim3 grid((unsigned)seq_len, (unsigned)((dim_model + 255) / 256));
+    if (dtype == ZL_F16) hipLaunchKernelGGL(k_moe_sum_experts<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, (int)dim_model, top_k, input, index, weight, out);
+    else if (dtype == ZL_BF16) hipLaunchKernelGGL(k_moe_sum_experts<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, (int)dim_model, top_k, input, index, weight, out);
+    else return ZL_EDTYPE;
+    return zl_launch_status();
+}
+
+int zl_moe_sum_experts_arr(const uint16_t* const* input_arr, const int32_t* experts, const int32_t* index, const float* weight, uint16_t* out,
+                           int64_t seq_len, int top_k, int64_t dim_model, int exp_parallel, int world_size, int local_rank, int dtype,
+                           zl_stream_t s) {
+    ZL_CHECK_ARG(input_arr && experts && weight && out && seq_len > 0 && top_k > 0 && dim_model > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(seq_len == 1 || index, ZL_EINVAL);
+    ZL_CHECK_ARG(!exp_parallel || (world_size > 0 && (world_size & (world_size - 1)) == 0), ZL_ESHAPE);     // the reference masks with world_size - 1
+    ZL_CHECK_ARG(top_k <= kMaxTopK && seq_len < ((int64_t)1 << 31) && (dim_model + 255) / 256 <= 65535, ZL_ELIMIT);
+    const dim3 grid((unsigned)seq_len, (unsigned)((dim_model + 255) / 256));
+    if (dtype == ZL_F16)
+        hipLaunchKernelGGL(k_moe_sum_experts_arr<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, (int)dim_model, top_k, input_arr, experts, index, weight,
+                           out, exp_parallel, world_size - 1, local_rank);
+    else if (dtype == ZL_BF16)
+        hipLaunchKernelGGL(k_moe_sum_experts_arr<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, (int)dim_model, top_k, input_arr, experts, index, weight,
+                           out, exp_parallel, world_size - 1, local_rank);
+    else return ZL_EDTYPE;
+    return zl_launch_status();
+}
+
+int zl_moe_route_shared_lb(int32_t* exp_ids, const int32_t* worker_load_base, int32_t* worker_load, int32_t* expert_load, int max_load,
+                           int world_size, int64_t seq_len, int top_k, int top_k_ext, int num_local_experts, zl_stream_t s) {
+    ZL_CHECK_ARG(exp_ids && worker_load_base && worker_load && expert_load && seq_len > 0 && world_size > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(top_k_ext > top_k && top_k >= 0 && top_k_ext - top_k <= 65535 && seq_len < ((int64_t)1 << 31), ZL_ESHAPE);
+    hipLaunchKernelGGL(k_moe_route_shared_lb, dim3((unsigned)seq_len, (unsigned)(top_k_ext - top_k)), dim3(1), 0, (hipStream_t)s, exp_ids,
+                       worker_load_base, worker_load, expert_load, max_load, world_size, (int)seq_len, top_k, top_k_ext, num_local_experts);
+    return zl_launch_status();
+}
+
+int zl_moe_plus_for_sort(const int32_t* exp_ids, int32_t* out, int multiple, int world_size, int64_t numel, zl_stream_t s) {
+    ZL_CHECK_ARG(exp_ids && out && numel > 0 && world_size > 0 && numel < ((int64_t)1 << 31), ZL_EINVAL);
+    hipLaunchKernelGGL(k_moe_plus_for_sort, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, (hipStream_t)s, exp_ids, out, multiple, world_size,
+                       (int)numel);
+    return zl_launch_status();
+}
+
+int zl_moe_calc_reverse_idx(const int32_t* exp_ids, const int32_t* indices, const int32_t* expert_offsets, int32_t* rev_indices, int64_t numel,
+                            zl_stream_t s) {
+    ZL_CHECK_ARG(exp_ids && indices && expert_offsets && rev_indices && numel > 0 && numel < ((int64_t)1 << 31), ZL_EINVAL);
+    hipLaunchKernelGGL(k_moe_calc_reverse_idx, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, (hipStream_t)s, exp_ids, indices, expert_offsets,
+                       rev_indices, (int)numel);
+    return zl_launch_status();
+}
+
+int zl_moe_fill_m_indices(const int32_t* num_tokens, const int32_t* offsets, const int32_t* aligned_offsets, int32_t* padded_indices,
+                          int32_t* m_indices, int local_experts, int max_num_token, int block_m, zl_stream_t s) {
+    ZL_CHECK_ARG(num_tokens && offsets && aligned_offsets && padded_indices && m_indices && local_experts > 0 && block_m > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(local_experts <= 65535 && block_m <= 1024, ZL_ELIMIT);
+    if (max_num_token <= 0) return ZL_OK;
+    hipLaunchKernelGGL(k_moe_fill_m_indices, dim3((unsigned)((max_num_token + block_m - 1) / block_m), (unsigned)local_experts), dim3((unsigned)block_m),
+                       0, (hipStream_t)s, num_tokens, offsets, aligned_offsets, padded_indices, m_indices);
+    return zl_launch_status();
+}
+
+}  // extern "C"

@@ -1299,3 +1299,98 @@ def moe_group_topk(logits, score_correction_bias, num_group, topk_group, top_k, 
                                   _f(weight_scale), C.c_int(_SCORING[scoring_func]), C.c_int(num_group), C.c_int(topk_group), C.c_int(_dt(logits)),
                                   _p(v), _p(idx), _p(worker_load), _p(expert_load), C.c_int(num_worker), _stream()), "moe_group_topk")
     return v, idx
+
+
+# ---- f4: MoE dispatch / combine of the prompt path (ff_kernel.h:42-96) ----------------------------------------------------------
+def moe_sum_experts(inp, index, weights):
+    """nn::sum_experts, one concatenated input (seq_len * K, dim_model)"""
+    _chk_cuda(inp, index, weights)
+    seq, k = weights.shape
+    out = torch.empty((seq, inp.shape[1]), dtype=inp.dtype, device=inp.device)
+    check(lib().zl_moe_sum_experts(_p(inp), _p(index), _p(weights), _p(out), _i(seq), C.c_int(k), _i(inp.shape[1]), C.c_int(_dt(inp)), _stream()),
+          "sum_experts")
+    return out
+
+
+def moe_sum_experts_arr(inputs, experts, index, weights, exp_parallel=False, world_size=1, local_rank=0):
+    """nn::sum_experts, one (rows, dim_model) input per expert (None / empty where an expert got no token)"""
+    live = [t for t in inputs if t is not None and t.numel()]
+    if not live:
+        raise ZLError("all inputs is empty")
+    _chk_cuda(experts, index, weights, *live)
+    dev, dim = live[0].device, live[0].shape[-1]
+    ptrs = torch.tensor([0 if (t is None or not t.numel()) else t.data_ptr() for t in inputs], dtype=torch.int64).to(dev)
+    seq, k = weights.shape
+    out = torch.empty((seq, dim), dtype=live[0].dtype, device=dev)
+    check(lib().zl_moe_sum_experts_arr(_p(ptrs), _p(experts), _p(index), _p(weights), _p(out), _i(seq), C.c_int(k), _i(dim), C.c_int(int(exp_parallel)),
+                                       C.c_int(world_size), C.c_int(local_rank), C.c_int(_dt(live[0])), _stream()), "sum_experts")
+    return out
+
+
+def moe_route_shared_lb(exp_ids, exp_weights, worker_load, expert_load, top_k, num_local_experts):
+    """nn::route_shared_lb: fills exp_ids[:, top_k:] in place, bumps the two load counters"""
+    _chk_cuda(exp_ids, exp_weights, worker_load, expert_load)
+    if exp_ids.shape != exp_weights.shape or exp_ids.dtype != torch.int32:
+        raise ZLError("shape mismatch")
+    seq, ext = exp_ids.shape
+    ws = worker_load.numel()
+    max_load = (exp_ids.numel() + ws - 1) // ws
+    base = worker_load.clone()
+    check(lib().zl_moe_route_shared_lb(_p(exp_ids), _p(base), _p(worker_load), _p(expert_load), C.c_int(max_load), C.c_int(ws), _i(seq), C.c_int(top_k),
+                                       C.c_int(ext), C.c_int(num_local_experts), _stream()), "route_shared_lb")
+
+
+def moe_plus_for_sort(exp_ids, num_experts, world_size):
+    _chk_cuda(exp_ids)
+    if num_experts % world_size:
+        raise ZLError("num_experts can't divide world_size")
+    out = torch.empty_like(exp_ids)
+    check(lib().zl_moe_plus_for_sort(_p(exp_ids), _p(out), C.c_int(num_experts), C.c_int(world_size), _i(exp_ids.numel()), _stream()), "plus_for_sort")
+    return out
+
+
+def moe_calc_reverse_idx(exp_ids, indices, all_loads, num_experts, world_size=1, sorted_by_rank=False):
+    """nn::calc_reverse_idx: all_loads = the host copy of [expert loads (num_experts) | rank loads (world_size)]"""
+    _chk_cuda(exp_ids, indices)
+    off = [0] * num_experts
+    if sorted_by_rank:
+        rank_offset = 0
+        for rank in range(world_size):
+            o = 0
+            for i in range(rank, num_experts, world_size):
+                off[i] = rank_offset + o
+                o += int(all_loads[i])
+            rank_offset += int(all_loads[num_experts + rank])
+    else:
+        o = 0
+        for i in range(num_experts):
+            off[i] = o
+            o += int(all_loads[i])
+    off_t = torch.tensor(off, dtype=torch.int32).to(exp_ids.device)
+    rev = torch.empty_like(indices)
+    check(lib().zl_moe_calc_reverse_idx(_p(exp_ids), _p(indices), _p(off_t), _p(rev), _i(indices.numel()), _stream()), "calc_reverse_idx")
+    return rev
+
+
+def moe_fill_m_indices_padded_indices(all_loads, block_m, num_experts, device, exp_parallel=False, rank=0, world_size=1):
+    """nn::fill_m_indices_padded_indices: (m_indices, padded_indices, total_tokens_aligned)"""
+    r, ws = (rank, world_size) if exp_parallel else (0, 1)
+    nt = [int(all_loads[j]) for j in range(r, num_experts, ws)]
+    offs, aoffs, o, a = [], [], 0, 0
+    for n in nt:
+        offs.append(o)
+        aoffs.append(a)
+        o += n
+        a += (n + block_m - 1) // block_m * block_m
+    aoffs.append(a)
+    if a == 0:
+        return None, None, 0
+    # one device tensor for the three small tables (kept alive in a local: temporaries would be freed -- and their block handed to
+    # the next one -- before the launch is even issued)
+    tab = torch.tensor(nt + offs + aoffs, dtype=torch.int32).to(device)
+    n = len(nt)
+    pad = torch.empty(max(o, 1), dtype=torch.int32, device=device)[:o]
+    mi = torch.empty(a, dtype=torch.int32, device=device)
+    check(lib().zl_moe_fill_m_indices(_p(tab[:n]), _p(tab[n:2 * n]), _p(tab[2 * n:]), _p(pad) if o else _p(mi), _p(mi), C.c_int(n), C.c_int(max(nt)),
+                                      C.c_int(block_m), _stream()), "fill_m_indices_padded_indices")
+    return mi, pad, a
