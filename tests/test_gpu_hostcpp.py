@@ -213,3 +213,33 @@ def test_moe_feed_forward_through_cpp_is_bit_exact(cx, oracle, prepack):
                                        a_in, ds[0].view(np.int32), ds[1], oracle.u2h(ds[2]), ids, wts, 0, prepack)
     assert np.array_equal(got_up.view(np.uint16), ref_up)
     assert np.array_equal(got_dn.view(np.uint16), ref_dn)
+
+
+def test_moe_router_dispatch_combine_through_cpp(cx, oracle):
+    """nn::top_k_softmax / group_topk_softmax / plus_for_sort / calc_reverse_idx / fill_m_indices_padded_indices / sum_experts
+    (src/nn/feedforward/ff_kernel.h:16-96) with the reference's signatures, against the oracle"""
+    rng = np.random.default_rng(12)
+    tokens, experts, k = 19, 64, 4
+    logits = (rng.standard_normal((tokens, experts)) * 1.3).astype(np.float16)
+    v, idx = cx.moe_route(logits, None, 1, 1, k, k, True, 1.0, "softmax")
+    wv, widx, _, _ = oracle.moe_top_k_softmax(logits.view(np.uint16), k, k, True, 1.0, "softmax", 0, 0)
+    assert np.array_equal(idx, widx) and np.abs(v.view(np.int32).astype(np.int64) - wv.view(np.int32)).max() <= 8
+    bias = (rng.standard_normal(experts) * 0.1).astype(np.float32)
+    v2, idx2 = cx.moe_route(logits, bias, 4, 2, k, k + 1, True, 2.5, "sigmoid")
+    wv2, widx2, _, _ = oracle.moe_group_topk(logits.view(np.uint16), bias, k, 4, 2, k + 1, True, 2.5, "sigmoid", 0, 0)
+    assert np.array_equal(idx2, widx2) and np.abs(v2.view(np.int32).astype(np.int64) - wv2.view(np.int32)).max() <= 8
+    # dispatch of the first routing result
+    loads = np.bincount(idx.ravel(), minlength=experts).astype(np.int32)
+    order = np.argsort(idx.ravel(), kind="stable").astype(np.int32)
+    keys, rev, mi, pad, total = cx.moe_dispatch(idx, order, loads.tolist(), experts, 64)
+    assert np.array_equal(keys, oracle.moe_plus_for_sort(idx, experts, 1))
+    wrev, off = oracle.moe_calc_reverse_idx(idx, order, loads, experts)
+    wmi, wpad, wtotal = oracle.moe_fill_m_indices(loads, 64, experts)
+    assert np.array_equal(rev, wrev) and np.array_equal(mi, wmi) and np.array_equal(pad, wpad) and total == wtotal
+    # combine per-expert outputs
+    dim = 256
+    y = rng.standard_normal((tokens * k, dim)).astype(np.float16)
+    parts = [y[off[e]:off[e] + loads[e]] if loads[e] else None for e in range(experts)]
+    got = cx.moe_combine(parts, idx.ravel(), rev, v)
+    want = oracle.moe_sum_experts_arr([None if p is None else p.view(np.uint16) for p in parts], idx.ravel(), rev, v, dim)
+    assert np.array_equal(got.view(np.uint16), want)

@@ -3,6 +3,7 @@
 // context's current stream, status -> BMEngineException.  No kernel code here and no torch.
 #include "nn_amd.h"
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -619,6 +620,127 @@ void silu_inplace(const Tensor& inp, hipStream_t stream) {
 }
 void multiply(const Context& ctx, const Tensor& a, float b, Tensor* c) {
     zl_check(zl_scale(a.data(), c->data(), a.numel(), b, elem_code(a.dtype()), st_of(ctx)), "multiply");
+}
+
+// ---- MoE dispatch / combine (ff_kernel.cu:518-1082): the host loops are the reference's, the kernels zl_moe_* ----------------
+Tensor sum_experts(const Context& ctx, const Tensor& input, const Tensor& index, const Tensor& weights) {
+    BM_ASSERT_EQ(input.ndim(), 2, "Wrong input dim");
+    BM_ASSERT_EQ(weights.ndim(), 2, "Wrong weights dim");
+    BM_ASSERT_EQ(weights.numel(), input.size(0), "Wrong weights size");
+    BM_ASSERT_EQ(weights.numel(), index.numel(), "Wrong reverse_idx size");
+    const size_t dim_model = input.size(-1), k = weights.size(1), seq_len = input.size(0) / k;
+    BM_ASSERT_LE(k, (size_t)16, "top k too big");
+    Tensor out = ctx.tensor({seq_len, dim_model}, input.dtype());
+    zl_check(zl_moe_sum_experts(u16(input), index.data<int32_t>(), weights.data<float>(), u16m(out), seq_len, (int)k, dim_model, zdt(input.dtype()),
+                                st_of(ctx)), "sum_experts");
+    return out;
+}
+Tensor sum_experts(const Context& ctx, std::vector<Tensor> inputs, const Tensor&, const Tensor& experts, const Tensor& index, const Tensor& weights,
+                   bool exp_parallel, int world_size, int local_rank) {
+    size_t dim_model = 0;
+    DataType dtype = DataType::kHalf;
+    std::vector<void*> ptrs;
+    for (auto& t : inputs) {
+        BM_ASSERT(t.ndim() == 2 || t.numel() == 0, "Wrong input dim");
+        ptrs.push_back(t.numel() ? t.data() : nullptr);
+        if (t.numel()) {
+            BM_ASSERT(dim_model == t.size(-1) || dim_model == 0, "dim_model mismatch");
+            dim_model = t.size(-1);
+            dtype = t.dtype();
+        }
+    }
+    BM_ASSERT(dim_model > 0, "all inputs is empty");
+    BM_ASSERT_EQ(weights.ndim(), 2, "Wrong weights dim");
+    BM_ASSERT_EQ(weights.numel(), experts.numel(), "Wrong weights size");
+    const size_t seq_len = weights.size(0), k = weights.size(1);
+    if (seq_len > 1) BM_ASSERT_EQ(weights.numel(), index.numel(), "Wrong reverse_idx size");
+    Tensor table = ctx.tensor({ptrs.size()}, DataType::kDouble);
+    table.from_buffer(ptrs.data(), false, ctx.current_cuda_stream());
+    Tensor out = ctx.tensor({seq_len, dim_model}, dtype, "", dim_model * 16);
+    zl_check(zl_moe_sum_experts_arr(table.data<const uint16_t*>(), experts.data<int32_t>(), index.numel() ? index.data<int32_t>() : nullptr,
+                                    weights.data<float>(), u16m(out), seq_len, (int)k, dim_model, exp_parallel, world_size > 0 ? world_size : 1,
+                                    local_rank, zdt(dtype), st_of(ctx)), "sum_experts");
+    return out;
+}
+void route_shared_lb(const Context& ctx, Tensor& exp_ids, Tensor& exp_weights, Tensor& worker_load, Tensor& expert_load, int top_k,
+                     int num_local_experts) {
+    BM_ASSERT_EQ(exp_ids.ndim(), 2, "Wrong exp_ids dim");
+    BM_ASSERT(exp_ids.shape() == exp_weights.shape(), "shape mismatch");
+    BM_ASSERT_EQ(exp_ids.dtype(), DataType::kInt32, "");
+    BM_ASSERT_EQ(exp_weights.dtype(), DataType::kFloat, "");
+    BM_ASSERT_EQ((int)worker_load.numel(), ctx.world_size(), "");
+    const int seq_len = (int)exp_ids.size(0), top_k_ext = (int)exp_ids.size(1), ws = (int)worker_load.numel();
+    const int max_load = ((int)exp_ids.numel() + ws - 1) / ws;
+    BM_ASSERT_LT(top_k, top_k_ext, "top k too big");
+    const Tensor base = ctx.copy(worker_load);
+    zl_check(zl_moe_route_shared_lb(exp_ids.data<int32_t>(), base.data<int32_t>(), worker_load.data<int32_t>(), expert_load.data<int32_t>(), max_load,
+                                    ws, seq_len, top_k, top_k_ext, num_local_experts, st_of(ctx)), "route_shared_lb");
+}
+Tensor plus_for_sort(const Context& ctx, Tensor& exp_ids, int num_experts) {
+    BM_ASSERT_EQ(num_experts % ctx.world_size(), 0, "num_experts can't divide world_size");
+    Tensor out = ctx.tensor(exp_ids.shape(), exp_ids.dtype());
+    zl_check(zl_moe_plus_for_sort(exp_ids.data<int32_t>(), out.data<int32_t>(), num_experts, ctx.world_size(), exp_ids.numel(), st_of(ctx)),
+             "plus_for_sort");
+    return out;
+}
+Tensor calc_reverse_idx(const Context& ctx, Tensor& exp_ids, Tensor& indices, const std::vector<int>& all_loads, int num_experts, bool sorted_by_rank) {
+    BM_ASSERT_EQ(exp_ids.ndim(), 2, "exp_ids is not 2D");
+    BM_ASSERT_EQ(indices.ndim(), 1, "idx is not 1D");
+    BM_ASSERT_EQ(indices.numel(), exp_ids.numel(), "idx and exp_ids numel mismatch");
+    const int world_size = ctx.world_size();
+    BM_ASSERT((int)all_loads.size() >= num_experts + (sorted_by_rank ? world_size : 0), "all_loads too short");
+    std::vector<int> expert_offset(num_experts);
+    if (sorted_by_rank) {
+        int rank_offset = 0;
+        for (int rank = 0; rank < world_size; ++rank) {
+            int offset = 0;
+            for (int i = rank; i < num_experts; i += world_size) {
+                expert_offset[i] = rank_offset + offset;
+                offset += all_loads[i];
+            }
+            rank_offset += all_loads[num_experts + rank];
+        }
+    } else {
+        int offset = 0;
+        for (int i = 0; i < num_experts; ++i) {
+            expert_offset[i] = offset;
+            offset += all_loads[i];
+        }
+    }
+    Tensor offs = ctx.tensor_of(expert_offset);
+    Tensor rev = ctx.tensor(indices.shape(), indices.dtype());
+    zl_check(zl_moe_calc_reverse_idx(exp_ids.data<int32_t>(), indices.data<int32_t>(), offs.data<int32_t>(), rev.data<int32_t>(), indices.numel(),
+                                     st_of(ctx)), "calc_reverse_idx");
+    return rev;
+}
+std::tuple<Tensor, Tensor, int> fill_m_indices_padded_indices(const Context& ctx, const std::vector<int>& all_loads, int block_m, int num_experts,
+                                                              bool exp_parallel) {
+    const int rank = exp_parallel ? ctx.rank() : 0, ws = exp_parallel ? ctx.world_size() : 1;
+    std::vector<int> table;      // [num_tokens | offsets | aligned_offsets (+1)]
+    std::vector<int> nt, offs, aoffs;
+    int offset = 0, a_offset = 0, max_nt = 0;
+    for (int j = rank; j < num_experts; j += ws) {
+        const int n = all_loads[j];
+        max_nt = std::max(max_nt, n);
+        nt.push_back(n);
+        offs.push_back(offset);
+        aoffs.push_back(a_offset);
+        offset += n;
+        a_offset += (n + block_m - 1) / block_m * block_m;
+    }
+    aoffs.push_back(a_offset);
+    if (a_offset == 0) return {Tensor(), Tensor(), 0};
+    table.insert(table.end(), nt.begin(), nt.end());
+    table.insert(table.end(), offs.begin(), offs.end());
+    table.insert(table.end(), aoffs.begin(), aoffs.end());
+    Tensor tab = ctx.tensor_of(table);
+    const size_t n = nt.size();
+    Tensor padded = ctx.tensor({(size_t)std::max(offset, 1)}, DataType::kInt32).slice_dim0(0, offset);
+    Tensor m_indices = ctx.tensor({(size_t)a_offset}, DataType::kInt32);
+    zl_check(zl_moe_fill_m_indices(tab.data<int32_t>(), tab.data<int32_t>() + n, tab.data<int32_t>() + 2 * n,
+                                   offset ? padded.data<int32_t>() : m_indices.data<int32_t>(), m_indices.data<int32_t>(), (int)n, max_nt, block_m,
+                                   st_of(ctx)), "fill_m_indices_padded_indices");
+    return {m_indices, padded, a_offset};
 }
 
 namespace awq {

@@ -157,6 +157,17 @@ std::tuple<core::Tensor, core::Tensor> group_topk_softmax(const core::Context& c
                                                           const core::Tensor& score_correction_bias, const core::Tensor& worker_load,
                                                           const core::Tensor& expert_load, int num_group, int topk_group, int top_k, int top_k_ext,
                                                           bool norm_topk_prob, float weight_scale, const std::string& scoring_func);
+// dispatch / combine of the prompt-side MoE path (ff_kernel.h:42-96); all_loads = HOST copy of [expert loads | rank loads]
+core::Tensor sum_experts(const core::Context& ctx, const core::Tensor& input, const core::Tensor& index, const core::Tensor& weights);
+core::Tensor sum_experts(const core::Context& ctx, std::vector<core::Tensor> inputs, const core::Tensor& concat_inputs, const core::Tensor& experts,
+                         const core::Tensor& index, const core::Tensor& weights, bool exp_parallel, int world_size = 0, int local_rank = 0);
+void route_shared_lb(const core::Context& ctx, core::Tensor& exp_ids, core::Tensor& exp_weights, core::Tensor& worker_load,
+                     core::Tensor& expert_load, int top_k, int num_local_experts);
+core::Tensor plus_for_sort(const core::Context& ctx, core::Tensor& exp_ids, int num_experts);
+core::Tensor calc_reverse_idx(const core::Context& ctx, core::Tensor& exp_ids, core::Tensor& idx, const std::vector<int>& all_loads, int num_experts,
+                              bool sorted_by_rank);
+std::tuple<core::Tensor, core::Tensor, int> fill_m_indices_padded_indices(const core::Context& ctx, const std::vector<int>& all_loads, int block_m,
+                                                                          int num_experts, bool exp_parallel);
 
 void gelu_inplace(const core::Tensor& inp, hipStream_t stream);
 void silu_inplace(const core::Tensor& inp, hipStream_t stream);

@@ -76,6 +76,29 @@ PYBIND11_MODULE(zl_internals, m) {
         .def("used_memory", [](PyCtx& c) { return c.ctx->used_memory(); })
         .def("peak_memory", [](PyCtx& c) { return c.ctx->peak_memory(); })
         .def("set_bshd", [](PyCtx& c, bool b) { c.ctx->set_BSHD(b); })
+        // ---- MoE router + dispatch / combine through the C++ names (ff_kernel.h)
+        .def("moe_route", [](PyCtx& c, py::array logits, py::object bias, int num_group, int topk_group, int k, int k_ext, bool renorm, float scale,
+                             std::string scoring, bool bf16) {
+            Tensor lg = c.up(logits, bf16 ? kBF : -1), none;
+            auto r = topk_group > 1 ? nn::group_topk_softmax(*c.ctx, lg, c.up_opt(bias), none, none, num_group, topk_group, k, k_ext, renorm, scale, scoring)
+                                    : nn::top_k_softmax(*c.ctx, lg, none, none, k, k_ext, renorm, scale, scoring);
+            return py::make_tuple(c.down(std::get<0>(r), "float32"), c.down(std::get<1>(r), "int32"));
+        }, py::arg("logits"), py::arg("bias"), py::arg("num_group"), py::arg("topk_group"), py::arg("k"), py::arg("k_ext"), py::arg("renorm"),
+           py::arg("scale"), py::arg("scoring"), py::arg("bf16") = false)
+        .def("moe_dispatch", [](PyCtx& c, py::array exp_ids, py::array order, std::vector<int> all_loads, int num_experts, int block_m) {
+            Tensor ids = c.up(exp_ids), ord = c.up(order);
+            Tensor keys = nn::plus_for_sort(*c.ctx, ids, num_experts);
+            Tensor rev = nn::calc_reverse_idx(*c.ctx, ids, ord, all_loads, num_experts, false);
+            auto f = nn::fill_m_indices_padded_indices(*c.ctx, all_loads, block_m, num_experts, false);
+            return py::make_tuple(c.down(keys, "int32"), c.down(rev, "int32"), c.down(std::get<0>(f), "int32"), c.down(std::get<1>(f), "int32"),
+                                  std::get<2>(f));
+        })
+        .def("moe_combine", [](PyCtx& c, py::list parts, py::array experts, py::array index, py::array weights) {
+            std::vector<Tensor> inputs;
+            for (auto h : parts) inputs.push_back(h.is_none() ? Tensor() : c.up(py::cast<py::array>(h)));
+            Tensor out = nn::sum_experts(*c.ctx, inputs, Tensor(), c.up(experts), c.up(index), c.up(weights), false);
+            return c.down(out, "float16");
+        })
         // ---- tensor surface (views, slices) exercised directly
         .def("tensor_roundtrip", [](PyCtx& c, py::array a, size_t from, size_t to) {
             Tensor t = c.up(a);
