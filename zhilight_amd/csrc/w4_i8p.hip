@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
                 // source of v_mfma_i32_16x16x64_i8 one issue slot after the MFMA (seen: v_cvt_f32_f16_sdwa into a dword of SrcA
                 // right behind the group's last MFMA); the matrix pipe reads its 128-bit operands over several passes, and
                 // the rows of the LAST pass (12..15 = batch row 3) then see the new value -- sporadically wrong outputs for
-                // the fourth batch row only (tools/ubench/_dbg_m4.py).  `t` depends on the MFMA's result, so this point is
+                // the fourth batch row only (tests/test_gpu_w4.py::test_i8p_rows_repeated_against_fp16_kernels).  `t` depends on the MFMA's result, so this point is
                 // >= 30 cycles behind it.
                 asm volatile("" : "+v"(t) : "v"(b0), "v"(b1), "v"(a0), "v"(a1));
                 acc[r] = __builtin_fmaf((float)sm.x, t, acc[r]);
