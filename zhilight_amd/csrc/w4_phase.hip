@@ -219,6 +219,27 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
 #pragma unroll
         for (int q = 0; q < XP; ++q) load_x(q, q);
     }
+    // ROPE: what this thread's epilogue needs from memory (rotation table entries, the task's slot, buffer length and buffer
+    // pointer; 16 m <= 512 outputs, one per thread) is requested here, next to the activations and ahead of the weight ring:
+    // in the epilogue they were two dependent round trips at the very end of the launch (w4_i8p.hip does the same)
+    float rp_c0 = 0.f, rp_s0 = 0.f, rp_c1 = 0.f, rp_s1 = 0.f;
+    int rp_place = -1, rp_blen = 0;
+    uint16_t* rp_kv = nullptr;
+    if constexpr (ROPE) {
+        if ((int)threadIdx.x < 16 * p.m) {
+            const int m = threadIdx.x >> 4, n0 = tile0 * 16 + (threadIdx.x & 15);
+            const int head = n0 / p.d, dcol = n0 % p.d, half = p.d / 2;
+            if (head < p.h + p.hkv) {
+                rp_c0 = p.cosv[(size_t)m * p.d + dcol]; rp_s0 = p.sinv[(size_t)m * p.d + dcol];
+                rp_c1 = p.cosv[(size_t)m * p.d + dcol + half]; rp_s1 = p.sinv[(size_t)m * p.d + dcol + half];
+            }
+            if (head >= p.h) {
+                rp_place = p.placement[m];
+                rp_blen = p.buf_lens[m];
+                rp_kv = head < p.h + p.hkv ? p.k_bufs[m] : p.v_bufs[m];
+            }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- weight ring.  Item sequence of wave w: for phase: for r < R: (tile0 + r, 8 phase + w); the byte
@@ -607,33 +628,25 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
             const float a = (float)zl_f32_to_f16(v0), bb = (float)zl_f32_to_f16(v1);   // the projection's fp16 outputs
             const int head = n0 / p.d, dcol = n0 % p.d;                 // dcol < half
             if (head < p.h + p.hkv) {
-                const float c0 = p.cosv[(size_t)m * p.d + dcol], s0 = p.sinv[(size_t)m * p.d + dcol];
-                const float c1 = p.cosv[(size_t)m * p.d + dcol + half], s1 = p.sinv[(size_t)m * p.d + dcol + half];
-                const uint16_t r0 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(-bb, s0, a * c0)));
-                const uint16_t r1 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(a, s1, bb * c1)));
+                const uint16_t r0 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(-bb, rp_s0, a * rp_c0)));
+                const uint16_t r1 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(a, rp_s1, bb * rp_c1)));
                 if (head < p.h) {
                     uint16_t* dst = p.q_out + ((size_t)m * p.h + head) * p.d + dcol;
                     dst[0] = r0;
                     dst[half] = r1;
-                } else {
-                    const int place = p.placement[m];
-                    if (place >= 0 && place < p.buf_lens[m]) {
-                        const int hk = head - p.h;
-                        const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
-                        uint16_t* dst = p.k_bufs[m] + row * p.d + dcol;
-                        dst[0] = r0;
-                        dst[half] = r1;
-                    }
+                } else if (rp_place >= 0 && rp_place < rp_blen) {
+                    const int hk = head - p.h;
+                    const size_t row = p.bshd ? (size_t)rp_place * p.hkv + hk : (size_t)hk * rp_blen + rp_place;
+                    uint16_t* dst = rp_kv + row * p.d + dcol;
+                    dst[0] = r0;
+                    dst[half] = r1;
                 }
-            } else {
-                const int place = p.placement[m];
-                if (place >= 0 && place < p.buf_lens[m]) {
-                    const int hk = head - p.h - p.hkv;
-                    const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
-                    uint16_t* dst = p.v_bufs[m] + row * p.d + dcol;
-                    dst[0] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v0));
-                    dst[half] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v1));
-                }
+            } else if (rp_place >= 0 && rp_place < rp_blen) {
+                const int hk = head - p.h - p.hkv;
+                const size_t row = p.bshd ? (size_t)rp_place * p.hkv + hk : (size_t)hk * rp_blen + rp_place;
+                uint16_t* dst = rp_kv + row * p.d + dcol;
+                dst[0] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v0));
+                dst[half] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v1));
             }
         }
         ZL_PPROBE(6);
