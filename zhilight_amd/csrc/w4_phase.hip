@@ -240,6 +240,24 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
             }
         }
     }
+    // the plain / bias / residual epilogues: the operands of this thread's FIRST output (its only one up to 512 outputs per
+    // workgroup) are requested here as well -- one more round trip at the very end of the launch otherwise
+    float ep_res0 = 0.f, ep_bias0 = 0.f;
+    bool ep_pref = false;
+    if constexpr (!ROPE && KS == 1) {
+        if (!(p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32))) {
+            const int per_tile_ = 16 * p.m, o_ = threadIdx.x;
+            if (o_ < R * per_tile_) {
+                const int r_ = o_ / per_tile_, rem_ = o_ % per_tile_, tile_ = tile0 + r_;
+                const int row_ = tile_ * 16 + (rem_ & 15);
+                if (tile_ < p.tiles && row_ < p.n) {
+                    if (p.epi & ZL_EPI_RESIDUAL) ep_res0 = (float)__builtin_bit_cast(_Float16, p.residual[(size_t)(rem_ >> 4) * p.ld_out + row_]);
+                    if ((p.epi & ZL_EPI_BIAS) && p.bias) ep_bias0 = (float)__builtin_bit_cast(_Float16, p.bias[row_]);
+                    ep_pref = true;
+                }
+            }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- weight ring.  Item sequence of wave w: for phase: for r < R: (tile0 + r, 8 phase + w); the byte
@@ -672,13 +690,14 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
             if (row < p.n) {
                 const float v = total_of(n_local, m);
                 const size_t orow = (size_t)m * p.ld_out;
-                const float bb = ((p.epi & ZL_EPI_BIAS) && p.bias) ? (float)__builtin_bit_cast(_Float16, p.bias[row]) : 0.f;
+                const bool pre = ep_pref && o == (int)threadIdx.x;     // operands that came with the prologue
+                const float bb = pre ? ep_bias0 : ((p.epi & ZL_EPI_BIAS) && p.bias) ? (float)__builtin_bit_cast(_Float16, p.bias[row]) : 0.f;
                 float ov;
                 if (p.epi & ZL_EPI_ADD_C) ov = ((float)__builtin_bit_cast(_Float16, p.y[orow + row]) + v) + bb;
                 else ov = v + bb;
                 _Float16 y16 = zl_f32_to_f16(ov);
                 if (p.epi & ZL_EPI_RESIDUAL)
-                    y16 = zl_f32_to_f16((float)__builtin_bit_cast(_Float16, p.residual[orow + row]) + (float)y16);
+                    y16 = zl_f32_to_f16((pre ? ep_res0 : (float)__builtin_bit_cast(_Float16, p.residual[orow + row])) + (float)y16);
                 p.y[orow + row] = __builtin_bit_cast(uint16_t, y16);
             }
         } else {
