@@ -101,6 +101,31 @@ __global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
     };
 #pragma unroll
     for (int q = 0; q < XP; ++q) load_x(q, q);
+    // ROPE: the operands of this thread's epilogue output (16 m <= 512, one per thread: both scales, the rotation table entries,
+    // the task's slot / buffer length / buffer pointer) are requested with the activations, ahead of the weight ring -- at the
+    // end of the launch they were two dependent round trips (w4_phase.hip, w4_i8p.hip do the same)
+    float rp_sx = 0.f, rp_c0 = 0.f, rp_s0 = 0.f, rp_c1 = 0.f, rp_s1 = 0.f;
+    uint16_t rp_sy0 = 0, rp_sy1 = 0;
+    int rp_place = -1, rp_blen = 0;
+    uint16_t* rp_kv = nullptr;
+    if constexpr (ROPE) {
+        if ((int)threadIdx.x < 16 * p.m) {
+            const int m = threadIdx.x >> 4, n0 = tile0 * 16 + (threadIdx.x & 15), half = p.d / 2;
+            const int head = n0 / p.d, dcol = n0 % p.d;
+            rp_sx = p.sx[m];
+            rp_sy0 = p.sy[n0];
+            rp_sy1 = p.sy[n0 + half];
+            if (head < p.h + p.hkv) {
+                rp_c0 = p.cosv[(size_t)m * p.d + dcol]; rp_s0 = p.sinv[(size_t)m * p.d + dcol];
+                rp_c1 = p.cosv[(size_t)m * p.d + dcol + half]; rp_s1 = p.sinv[(size_t)m * p.d + dcol + half];
+            }
+            if (head >= p.h) {
+                rp_place = p.placement[m];
+                rp_blen = p.buf_lens[m];
+                rp_kv = (head >= p.h + p.hkv ? p.v_bufs : p.k_bufs)[m];
+            }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- weight ring: item (tile, g) = 2 KiB at ((tile * groups + g) * 2048); wave w: for phase: for r: (tile0 + r, 8 ph + w)
@@ -203,16 +228,16 @@ __global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
                 c0 += redi[(((size_t)(0 * MB + b) * kW + w) * 64 + ln) * 4 + i];
                 c1 += redi[(((size_t)(1 * MB + b) * kW + w) * 64 + ln) * 4 + i];
             }
-            const int n0 = tile0 * 16 + n_local, n1 = n0 + half;
-            const float sx = p.sx[m];
+            const int n0 = tile0 * 16 + n_local;
+            const float sx = rp_sx;
             // the projection's T outputs (quant_scale_back), then the rotation in fp32 with one rounding to T
             uint16_t a16, b16;
             if (p.dtype == ZL_F16) {
-                a16 = ZT<ZL_F16>::from_f32(back<ZL_F16>(c0, sx, p.sy[n0]));
-                b16 = ZT<ZL_F16>::from_f32(back<ZL_F16>(c1, sx, p.sy[n1]));
+                a16 = ZT<ZL_F16>::from_f32(back<ZL_F16>(c0, sx, rp_sy0));
+                b16 = ZT<ZL_F16>::from_f32(back<ZL_F16>(c1, sx, rp_sy1));
             } else {
-                a16 = ZT<ZL_BF16>::from_f32(back<ZL_BF16>(c0, sx, p.sy[n0]));
-                b16 = ZT<ZL_BF16>::from_f32(back<ZL_BF16>(c1, sx, p.sy[n1]));
+                a16 = ZT<ZL_BF16>::from_f32(back<ZL_BF16>(c0, sx, rp_sy0));
+                b16 = ZT<ZL_BF16>::from_f32(back<ZL_BF16>(c1, sx, rp_sy1));
             }
             const int head = n0 / p.d, dcol = n0 % p.d;
             uint16_t* dst = nullptr;
@@ -220,22 +245,17 @@ __global__ __launch_bounds__(kT, 2) void k_w8a8_phase(const W8Params p) {
             if (head < p.h + p.hkv) {
                 const float a = p.dtype == ZL_F16 ? ZT<ZL_F16>::to_f32(a16) : ZT<ZL_BF16>::to_f32(a16);
                 const float bb = p.dtype == ZL_F16 ? ZT<ZL_F16>::to_f32(b16) : ZT<ZL_BF16>::to_f32(b16);
-                const float cs0 = p.cosv[(size_t)m * p.d + dcol], s0 = p.sinv[(size_t)m * p.d + dcol];
-                const float cs1 = p.cosv[(size_t)m * p.d + dcol + half], s1 = p.sinv[(size_t)m * p.d + dcol + half];
-                const float v0 = __builtin_fmaf(-bb, s0, a * cs0), v1 = __builtin_fmaf(a, s1, bb * cs1);
+                const float v0 = __builtin_fmaf(-bb, rp_s0, a * rp_c0), v1 = __builtin_fmaf(a, rp_s1, bb * rp_c1);
                 r0 = p.dtype == ZL_F16 ? ZT<ZL_F16>::from_f32(v0) : ZT<ZL_BF16>::from_f32(v0);
                 r1 = p.dtype == ZL_F16 ? ZT<ZL_F16>::from_f32(v1) : ZT<ZL_BF16>::from_f32(v1);
             }
             if (head < p.h) {
                 dst = p.q_out + ((size_t)m * p.h + head) * p.d + dcol;
-            } else {
-                const int place = p.placement[m];
-                if (place >= 0 && place < p.buf_lens[m]) {
-                    const bool is_v = head >= p.h + p.hkv;
-                    const int hk = head - p.h - (is_v ? p.hkv : 0);
-                    const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * p.buf_lens[m] + place;
-                    dst = (is_v ? p.v_bufs : p.k_bufs)[m] + row * p.d + dcol;
-                }
+            } else if (rp_place >= 0 && rp_place < rp_blen) {
+                const bool is_v = head >= p.h + p.hkv;
+                const int hk = head - p.h - (is_v ? p.hkv : 0);
+                const size_t row = p.bshd ? (size_t)rp_place * p.hkv + hk : (size_t)hk * rp_blen + rp_place;
+                dst = rp_kv + row * p.d + dcol;
             }
             if (dst) {
                 dst[0] = r0;
