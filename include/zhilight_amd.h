@@ -687,6 +687,19 @@ int zl_moe_fill_m_indices(const int32_t* num_tokens, const int32_t* offsets, con
                           int32_t* m_indices, int local_experts, int max_num_token, int block_m, zl_stream_t s);
 
 
+/* f4: multi-head latent attention (DeepSeek MLA) for decode rows over the compressed cache.  Replaces MLAImpl's attention over the latent
+ * cache (src/nn/attention/multi_head_latent_attention.cpp:836-872 gemm + attn_softmax + gemm; :877-1004 FlashMLA, closed): every head of
+ * task b attends to the same rows kv_bufs[b] (len_buf, kv_lora_rank + rope_dim): key = the whole row, value = its first kv_lora_rank values;
+ * q_adj (B, H, kv_lora_rank + rope_dim) is the absorbed query (q_nope . W_UK | q_rope); out (B, H, kv_lora_rank); keys 0 ..
+ * min(buf_lens[b], valid_lens[b]) - 1 are visible (valid_lens nullable).  fp32 scores / probabilities / accumulation, one rounding to T.
+ * kv_lora_rank = 512, rope_dim = 64, H % 4 == 0.  workspace: zl_mla_decode_workspace_bytes(b, h, max_len_buf) bytes.  VALU kernel,
+ * correctness first (csrc/mla_attn.hip). */
+int64_t zl_mla_decode_workspace_bytes(int64_t b, int64_t h, int64_t max_len_buf);
+int zl_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int32_t* valid_lens, const uint16_t* const* kv_bufs, uint16_t* out,
+                       void* workspace, int64_t b, int64_t h, int64_t kv_lora_rank, int64_t rope_dim, float scale, int64_t max_len_buf, int dtype,
+                       zl_stream_t s);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -1677,3 +1677,60 @@ int zlo_moe_fill_m_indices(const int32_t* all_loads, int block_m, int num_expert
     }
     return a_offset;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* f4: multi-head latent attention (DeepSeek MLA) over the latent cache, decode rows            */
+/* ------------------------------------------------------------------------------------------ */
+/* Attention::impl::MLAImpl over the compressed cache (src/nn/attention/multi_head_latent_attention.cpp:836-872, the open
+ * "gemm + attn_softmax + gemm" route; the FlashMLA route :877-1004 is a closed binary): one latent row of kv_rank + rope_dim
+ * values per key serves every head as key (all cache_dim values) and as value (its first kv_rank values):
+ *   out[b, h, :kv_rank] = softmax_j( scale * q_adj[b, h, :] . kv_b[j, :] ) . kv_b[j, :kv_rank],   j < min(buf_len, valid_len)
+ * flavour 0 = E (fp64).  flavour 1 = R, the rounding points of the open route: scores rounded to T (functions::Gemm output),
+ * multiplied by T(scale) in T (fused_scale_mask_softmax, attention_softmax_kernel.cu:104-160), softmax in fp32, probabilities
+ * rounded to T, second product accumulated in fp32, one rounding to T.  (The 1024-thread reduction trees of the softmax are not
+ * restated: sequential fp32 sums; the difference is below the T rounding of the probabilities.) */
+void zlo_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int32_t* valid_lens, const uint16_t* const* kv_bufs,
+                         uint16_t* out, int64_t b, int64_t h, int kv_rank, int rope_dim, float scale, int dtype, int flavour) {
+    const int cd = kv_rank + rope_dim;
+    for (int64_t t = 0; t < b; ++t) {
+        const int len = valid_lens && valid_lens[t] < buf_lens[t] ? valid_lens[t] : buf_lens[t];
+        const uint16_t* kv = kv_bufs[t];
+        #pragma omp parallel for
+        for (int64_t hh = 0; hh < h; ++hh) {
+            const uint16_t* q = q_adj + (t * h + hh) * cd;
+            uint16_t* o = out + (t * h + hh) * kv_rank;
+            if (len <= 0) { for (int d = 0; d < kv_rank; ++d) o[d] = f2T(0.f, dtype); continue; }
+            double* p = (double*)malloc(sizeof(double) * (size_t)len);
+            double mx = -1e300;
+            for (int j = 0; j < len; ++j) {
+                double s = 0.0;
+                for (int d = 0; d < cd; ++d) s += (double)T2f(q[d], dtype) * (double)T2f(kv[(int64_t)j * cd + d], dtype);
+                if (flavour) {
+                    const float sT = T2f(f2T((float)s, dtype), dtype);                       /* Gemm output in T */
+                    s = (double)T2f(f2T(sT * T2f(f2T(scale, dtype), dtype), dtype), dtype);   /* x * T(scale) in T */
+                } else s *= (double)scale;
+                p[j] = s;
+                if (s > mx) mx = s;
+            }
+            if (flavour) {
+                float sum = 1e-20f;
+                for (int j = 0; j < len; ++j) { const float e = expf((float)p[j] - (float)mx); p[j] = e; sum += e; }
+                for (int j = 0; j < len; ++j) p[j] = (double)T2f(f2T((float)p[j] / sum, dtype), dtype);
+                for (int d = 0; d < kv_rank; ++d) {
+                    float acc = 0.f;
+                    for (int j = 0; j < len; ++j) acc = fmaf((float)p[j], T2f(kv[(int64_t)j * cd + d], dtype), acc);
+                    o[d] = f2T(acc, dtype);
+                }
+            } else {
+                double sum = 0.0;
+                for (int j = 0; j < len; ++j) { p[j] = exp(p[j] - mx); sum += p[j]; }
+                for (int d = 0; d < kv_rank; ++d) {
+                    double acc = 0.0;
+                    for (int j = 0; j < len; ++j) acc += p[j] * (double)T2f(kv[(int64_t)j * cd + d], dtype);
+                    o[d] = dtype ? zlo_f32_to_bf16((float)(acc / sum)) : zlo_f64_to_f16(acc / sum);
+                }
+            }
+            free(p);
+        }
+    }
+}

@@ -220,6 +220,11 @@ void zlo_moe_calc_reverse_idx(const int32_t* exp_ids, const int32_t* indices, co
                               int sorted_by_rank, int32_t* expert_offset, int32_t* rev_indices, int64_t numel);
 int zlo_moe_fill_m_indices(const int32_t* all_loads, int block_m, int num_experts, int rank, int ws, int32_t* padded_indices, int32_t* m_indices);
 
+
+/* f4: MLA decode attention over the latent cache (multi_head_latent_attention.cpp:836-872); flavour 0 = E (fp64), 1 = R (open route) */
+void zlo_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int32_t* valid_lens, const uint16_t* const* kv_bufs,
+                         uint16_t* out, int64_t b, int64_t h, int kv_rank, int rope_dim, float scale, int dtype, int flavour);
+
 #ifdef __cplusplus
 }
 #endif

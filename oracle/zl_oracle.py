@@ -731,3 +731,18 @@ def moe_fill_m_indices(all_loads, block_m, num_experts, rank=0, ws=1):
     lib().zlo_moe_fill_m_indices.restype = C.c_int
     total = lib().zlo_moe_fill_m_indices(_p(all_loads), C.c_int(block_m), C.c_int(num_experts), C.c_int(rank), C.c_int(ws), _p(pad), _p(mi))
     return mi, pad, total
+
+
+# ---- f4: MLA decode attention over the latent cache
+def mla_decode_attn(q_adj, buf_lens, valid_lens, kv_bufs, kv_rank=512, rope_dim=64, scale=1.0, dtype=0, flavour="E"):
+    """q_adj (b, h, kv_rank + rope_dim) T bits; kv_bufs: list of (len_buf, kv_rank + rope_dim) T-bit arrays; out (b, h, kv_rank)"""
+    q_adj = _c(q_adj, np.uint16)
+    b, h, _ = q_adj.shape
+    bufs = [_c(a, np.uint16) for a in kv_bufs]
+    arr = _ptr_array(bufs)
+    bl = _c(buf_lens, np.int32)
+    vl = None if valid_lens is None else _c(valid_lens, np.int32)
+    out = np.zeros((b, h, kv_rank), np.uint16)
+    lib().zlo_mla_decode_attn(_p(q_adj), _p(bl), _p(vl), arr, _p(out), _i(b), _i(h), C.c_int(kv_rank), C.c_int(rope_dim), _f(scale),
+                              C.c_int(dtype), C.c_int(0 if flavour == "E" else 1))
+    return out

@@ -269,3 +269,34 @@ def test_moe_shared_expert_load_balancing(oracle, dev):
     w_ids, w_wl, w_el = oracle.moe_route_shared_lb(ids, wl, el, k, local)
     assert np.array_equal(t_ids.cpu().numpy(), w_ids) and np.array_equal(t_wl.cpu().numpy(), w_wl) and np.array_equal(t_el.cpu().numpy(), w_el)
     assert t_wl.cpu().numpy().max() <= (tokens * ext + world - 1) // world + 0      # nobody above the even share
+
+
+@pytest.mark.parametrize("dtype,code", [(torch.float16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("h", [16, 128])
+def test_mla_decode_attention_over_the_latent_cache(oracle, dev, dtype, code, h):
+    """DeepSeek MLA, decode rows: every head reads the same 576-value latent rows (key = all of it, value = the first 512).  Against
+    the fp64 statement (E) at T's output rounding, and against the reference's open route (R: scores and probabilities rounded to
+    T) within that route's own noise."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(h)
+    lens = [1, 64, 65, 700] if h == 16 else [130, 1]
+    b, max_len = len(lens), 768
+    q = torch.from_numpy((rng.standard_normal((b, h, 576)) * 0.4).astype(np.float32)).to(dtype)
+    bufs = [torch.from_numpy((rng.standard_normal((max_len, 576)) * 0.6).astype(np.float32)).to(dtype) for _ in range(b)]
+    for t in bufs:
+        t[-1] = float("nan")                                            # never visible: must not leak
+    dbufs = [t.to(dev) for t in bufs]
+    addrs = torch.tensor([t.data_ptr() for t in dbufs], dtype=torch.int64, device=dev)
+    buf_lens = torch.tensor([max_len - 1] * b, dtype=torch.int32, device=dev)
+    valid = torch.tensor(lens, dtype=torch.int32, device=dev)
+    scale = 0.1147
+    got = ops.mla_decode_attention(q.to(dev), buf_lens, addrs, scale, max_len, valid)
+    args = (_bits(q), [max_len - 1] * b, lens, [_bits(t) for t in bufs])
+    f = (lambda u: oracle.u2h(u).astype(np.float64)) if code == 0 else (lambda u: (u.astype(np.uint32) << 16).view(np.float32).astype(np.float64))
+    E = f(oracle.mla_decode_attn(*args, scale=scale, dtype=code, flavour="E"))
+    R = f(oracle.mla_decode_attn(*args, scale=scale, dtype=code, flavour="R"))
+    g = f(_bits(got))
+    assert np.isfinite(g).all()
+    ulp = 2.0 ** (-10 if code == 0 else -7)
+    assert (np.abs(g - E) <= ulp * np.abs(E) + 2e-5 * np.abs(E).max()).all(), float(np.abs(g - E).max() / np.abs(E).max())
+    assert np.abs(g - R).max() <= max(np.abs(R - E).max() * 1.5, 2 * ulp * np.abs(E).max())
