@@ -699,6 +699,16 @@ int zl_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int
                        void* workspace, int64_t b, int64_t h, int64_t kv_lora_rank, int64_t rope_dim, float scale, int64_t max_len_buf, int dtype,
                        zl_stream_t s);
 
+/* The same attention over a PAGED latent cache: what ds::mha_fwd_kvcache_mla (src/nn/attention/ds_flash_mla_api.h:16-30, .cpp:67-197: the
+ * binding of the closed FlashMLA library) computes for its non-causal calls (multi_head_latent_attention.cpp:913, :993 pass is_causal =
+ * false).  kcache (num_blocks, page_block_size, 1, kv_lora_rank + rope_dim); page i of task b is block_table[b * max_blocks_per_seq + i];
+ * keys 0 .. seqlens_k[b] - 1 are visible.  q_adj (B, H, 576) where H = len_q * num_heads (the reference folds the query rows into the head
+ * axis the same way, .cpp:121-126); out (B, H, 512); softmax_lse (B, H) fp32 = log sum exp(scale * score), nullable.  page_block_size a
+ * multiple of 64 (FlashMLA fixes 64).  workspace: zl_mla_decode_workspace_bytes(b, h, page_block_size * max_blocks_per_seq). */
+int zl_mla_decode_attn_paged(const uint16_t* q_adj, const uint16_t* kcache, const int32_t* block_table, const int32_t* seqlens_k, uint16_t* out,
+                             float* softmax_lse, void* workspace, int64_t b, int64_t h, int64_t kv_lora_rank, int64_t rope_dim,
+                             int64_t page_block_size, int64_t max_blocks_per_seq, float scale, int dtype, zl_stream_t s);
+
 
 #ifdef __cplusplus
 }

@@ -300,3 +300,54 @@ def test_mla_decode_attention_over_the_latent_cache(oracle, dev, dtype, code, h)
     ulp = 2.0 ** (-10 if code == 0 else -7)
     assert (np.abs(g - E) <= ulp * np.abs(E) + 2e-5 * np.abs(E).max()).all(), float(np.abs(g - E).max() / np.abs(E).max())
     assert np.abs(g - R).max() <= max(np.abs(R - E).max() * 1.5, 2 * ulp * np.abs(E).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_flash_mla_binding_over_a_paged_cache(dev, dtype):
+    """ds::mha_fwd_kvcache_mla (ds_flash_mla_api.h:16-30), the reference's FlashMLA FFI: the paged call returns the bits of the
+    contiguous-buffer call on the same rows (the same split plan, the same arithmetic), two query rows fold into the head axis
+    (ds_flash_mla_api.cpp:121-126), and softmax_lse is log sum exp of the scaled scores."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(11)
+    lens, len_q, h, page = [1, 64, 65, 300], 2, 16, 64
+    b, max_blocks = len(lens), 6
+    max_len = page * max_blocks
+    q = torch.from_numpy((rng.standard_normal((b, len_q, h, 576)) * 0.4).astype(np.float32)).to(dtype).to(dev)
+    bufs = [torch.from_numpy((rng.standard_normal((max_len, 576)) * 0.6).astype(np.float32)).to(dtype).to(dev) for _ in range(b)]
+    num_blocks = b * max_blocks + 3
+    order = rng.permutation(num_blocks)[: b * max_blocks].astype(np.int32).reshape(b, max_blocks)
+    kcache = torch.full((num_blocks, page, 1, 576), float("nan"), dtype=dtype, device=dev)
+    for i in range(b):
+        for j in range(max_blocks):
+            kcache[int(order[i, j]), :, 0, :] = bufs[i][j * page:(j + 1) * page]
+    table = torch.from_numpy(order).to(dev)
+    seqlens = torch.tensor(lens, dtype=torch.int32, device=dev)
+    scale = 0.1147
+    out, lse = ops.mha_fwd_kvcache_mla(q, kcache, 512, seqlens, table, scale)
+    assert out.shape == (b, len_q, h, 512) and lse.shape == (b, 1, len_q * h)
+    addrs = torch.tensor([t.data_ptr() for t in bufs], dtype=torch.int64, device=dev)
+    want = ops.mla_decode_attention(q.view(b, len_q * h, 576), seqlens, addrs, scale, max_len)
+    assert torch.equal(out.view(b, len_q * h, 512).view(torch.int16), want.view(torch.int16))
+    for i, n in enumerate(lens):
+        s = (q[i].view(len_q * h, 576).double() @ bufs[i][:n].double().T) * scale
+        assert torch.allclose(lse[i, 0].double(), torch.logsumexp(s, dim=-1), rtol=0, atol=2e-5)
+    with pytest.raises(ops.ZLError):
+        ops.mha_fwd_kvcache_mla(q, kcache, 512, seqlens, table, scale, is_causal=True)       # causal multi-row queries: not on this path
+
+
+def test_flash_mla_binding_through_the_cpp_names(dev):
+    """The same two functions under the reference's C++ names (hostcpp/nn_amd.h ds::get_mla_metadata / ds::mha_fwd_kvcache_mla)."""
+    from zhilight_amd import ops, zl_internals
+    rng = np.random.default_rng(12)
+    lens, h, page, max_blocks = [70, 129], 16, 64, 3
+    b = len(lens)
+    q = (rng.standard_normal((b, 1, h, 576)) * 0.4).astype(np.float16)
+    kcache = (rng.standard_normal((b * max_blocks, page, 1, 576)) * 0.6).astype(np.float16)
+    table = rng.permutation(b * max_blocks).astype(np.int32).reshape(b, max_blocks)
+    seqlens = np.asarray(lens, np.int32)
+    ctx = zl_internals.Context(0)
+    got, lse = ctx.mha_fwd_kvcache_mla(q, kcache, seqlens, table, 0.1147)
+    want, wlse = ops.mha_fwd_kvcache_mla(torch.from_numpy(q).to(dev), torch.from_numpy(kcache).to(dev), 512, torch.from_numpy(seqlens).to(dev),
+                                         torch.from_numpy(table).to(dev), 0.1147)
+    assert np.array_equal(got.view(np.uint16), want.cpu().numpy().view(np.uint16))
+    assert np.array_equal(lse, wlse.cpu().numpy())

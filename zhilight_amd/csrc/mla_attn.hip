@@ -29,6 +29,12 @@ struct MlaParams {
     float* ws;                         // (B, H, max_splits, kRec)
     int b, h, split_len, max_splits;
     float scale;
+    // paged form (FlashMLA's cache): rows of task b live in pages of `page` keys (a multiple of 64) of kcache, page i of the task =
+    // block_table[b * max_blocks + i]; kv_bufs is unused then
+    const uint16_t* kcache;
+    const int32_t* block_table;
+    int page, max_blocks;
+    float* lse;                        // optional (B, H): log-sum-exp of the scaled scores
 };
 
 template <int DT>
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(256) void k_mla_decode_partial(const MlaParams p) {
     const int len = p.valid_lens ? min(p.buf_lens[b], p.valid_lens[b]) : p.buf_lens[b];
     const int t0 = split * p.split_len, t1 = min(len, t0 + p.split_len);
     if (t0 >= len) return;                                                // (workgroup-uniform) the combine skips unwritten splits
-    const uint16_t* kv = p.kv_bufs[b];
+    const uint16_t* kv = p.block_table ? nullptr : p.kv_bufs[b];
     for (int i = threadIdx.x; i < kHG * kCD / 8; i += 256) {
         const int hl = i / (kCD / 8), c = i % (kCD / 8), head = hg * kHG + hl;
         float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -70,9 +76,12 @@ __global__ __launch_bounds__(256) void k_mla_decode_partial(const MlaParams p) {
     const float* q0 = qs + (wave * 4) * kCD;
     for (int key0 = t0; key0 < t1; key0 += 64) {
         // ---- scores: lane = key key0 + lane; its row against the four q rows
+        // a chunk of 64 keys never straddles a page (split_len and page are multiples of 64): one table lookup per chunk
+        const uint16_t* chunk = p.block_table ? p.kcache + ((size_t)p.block_table[(size_t)b * p.max_blocks + key0 / p.page] * p.page + key0 % p.page) * kCD
+                                              : kv + (size_t)key0 * kCD;
         const int key = key0 + lane;
         const bool live = key < t1;
-        const uint4* kp = reinterpret_cast<const uint4*>(kv + (size_t)(live ? key : t1 - 1) * kCD);
+        const uint4* kp = reinterpret_cast<const uint4*>(chunk + (size_t)(live ? lane : t1 - 1 - key0) * kCD);
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < kCD / 8; ++c) {
             float kf[8];
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(256) void k_mla_decode_partial(const MlaParams p) {
         }
         // ---- O += P . V: lane = output columns 8 lane .. 8 lane + 7; key j's probability comes from lane j
         const int nk = min(64, t1 - key0);
-        const uint16_t* vbase = kv + (size_t)key0 * kCD + lane * 8;
+        const uint16_t* vbase = chunk + lane * 8;
 #pragma unroll 4
         for (int j = 0; j < nk; ++j) {
             float vf[8];
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(64) void k_mla_combine(const MlaParams p) {
         z = __builtin_fmaf(rec[kRank + 1], f, z);
     }
     const float inv = ns > 0 ? 1.0f / (z + 1e-20f) : 0.f;
+    if (p.lse && lane == 0) p.lse[(size_t)b * p.h + head] = ns > 0 ? mx + logf(z) : -INFINITY;
     uint32_t w[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = (uint32_t)ZT<DT>::from_f32(o[2 * e] * inv) | ((uint32_t)ZT<DT>::from_f32(o[2 * e + 1] * inv) << 16);
@@ -165,6 +175,8 @@ inline int mla_split_len(int64_t b, int64_t h, int64_t max_len) {
     if (ls < 64) ls = 64;
     return (int)ls;
 }
+
+int mla_launch(const MlaParams& p, int dtype, hipStream_t hs);
 
 }  // namespace
 
@@ -189,7 +201,32 @@ int zl_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int
     p.b = (int)b; p.h = (int)h; p.split_len = mla_split_len(b, h, max_len_buf);
     p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
     p.scale = scale;
-    hipStream_t hs = (hipStream_t)s;
+    p.kcache = nullptr; p.block_table = nullptr; p.page = p.max_blocks = 0; p.lse = nullptr;
+    return mla_launch(p, dtype, (hipStream_t)s);
+}
+
+int zl_mla_decode_attn_paged(const uint16_t* q_adj, const uint16_t* kcache, const int32_t* block_table, const int32_t* seqlens_k, uint16_t* out,
+                             float* softmax_lse, void* workspace, int64_t b, int64_t h, int64_t kv_lora_rank, int64_t rope_dim,
+                             int64_t page_block_size, int64_t max_blocks_per_seq, float scale, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(q_adj && kcache && block_table && seqlens_k && out && workspace && b > 0 && h > 0 && max_blocks_per_seq > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(kv_lora_rank == kRank && rope_dim == kRope && h % 4 == 0 && page_block_size > 0 && page_block_size % 64 == 0, ZL_ESHAPE);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    ZL_CHECK_ARG(b <= 65535 && (h + kHG - 1) / kHG <= 65535 && page_block_size * max_blocks_per_seq < ((int64_t)1 << 31), ZL_ELIMIT);
+    const int64_t max_len = page_block_size * max_blocks_per_seq;
+    MlaParams p;
+    p.q = q_adj; p.buf_lens = seqlens_k; p.valid_lens = nullptr; p.kv_bufs = nullptr; p.out = out; p.ws = (float*)workspace;
+    p.b = (int)b; p.h = (int)h; p.split_len = mla_split_len(b, h, max_len);
+    p.max_splits = (int)((max_len + p.split_len - 1) / p.split_len);
+    p.scale = scale;
+    p.kcache = kcache; p.block_table = block_table; p.page = (int)page_block_size; p.max_blocks = (int)max_blocks_per_seq; p.lse = softmax_lse;
+    return mla_launch(p, dtype, (hipStream_t)s);
+}
+
+}  // extern "C"
+
+namespace {
+int mla_launch(const MlaParams& p, int dtype, hipStream_t hs) {
+    const int64_t h = p.h, b = p.b;
     const dim3 grid((unsigned)p.max_splits, (unsigned)((h + kHG - 1) / kHG), (unsigned)b);
     if (dtype == ZL_F16) hipLaunchKernelGGL(k_mla_decode_partial<ZL_F16>, grid, dim3(256), 0, hs, p);
     else hipLaunchKernelGGL(k_mla_decode_partial<ZL_BF16>, grid, dim3(256), 0, hs, p);
@@ -199,5 +236,4 @@ int zl_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int
     else hipLaunchKernelGGL(k_mla_combine<ZL_BF16>, dim3((unsigned)h, (unsigned)b), dim3(64), 0, hs, p);
     return zl_launch_status();
 }
-
-}  // extern "C"
+}  // namespace

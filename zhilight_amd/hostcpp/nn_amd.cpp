@@ -878,6 +878,48 @@ void LayerNorm::inplace(const Context& ctx, Tensor& x) {
 }  // namespace nn
 
 // ---- int8 ----------------------------------------------------------------------------------------------------------
+namespace ds {
+using bmengine::core::Context; using bmengine::core::Tensor; using bmengine::core::DataType;
+std::tuple<Tensor, Tensor> get_mla_metadata(const Context& ctx, const Tensor& seqlens_k, const size_t num_heads_per_head_k, const size_t num_heads_k) {
+    BM_ASSERT_EQ(seqlens_k.dtype(), DataType::kInt32, "seqlens_k must have dtype int32");
+    BM_ASSERT(num_heads_k == 1 && num_heads_per_head_k > 0, "MLA has one latent head");
+    Tensor meta = ctx.tensor({1, 8}, DataType::kInt32), splits = ctx.tensor({seqlens_k.numel() + 1}, DataType::kInt32);
+    BM_HIPRT_ASSERT(hipMemsetAsync(meta.data(), 0, meta.nbytes(), ctx.current_cuda_stream()));
+    BM_HIPRT_ASSERT(hipMemsetAsync(splits.data(), 0, splits.nbytes(), ctx.current_cuda_stream()));
+    return std::make_tuple(meta, splits);
+}
+std::tuple<Tensor, Tensor> mha_fwd_kvcache_mla(const Context& ctx, Tensor& q, const Tensor& kcache, const size_t head_size_v, const Tensor& seqlens_k,
+                                               const Tensor& block_table, const float softmax_scale, bool is_causal, const Tensor&, const Tensor&,
+                                               Tensor out_org) {
+    BM_ASSERT_EQ(kcache.dtype(), q.dtype(), "query and key must have the same dtype");
+    BM_ASSERT(q.dtype() == DataType::kHalf || q.dtype() == DataType::kBFloat16, "Unsupported tensor dtype for query");
+    BM_ASSERT_EQ(q.ndim(), 4, "q is not 4D");
+    BM_ASSERT_EQ(block_table.ndim(), 2, "block_table must be 2D");
+    BM_ASSERT_EQ(block_table.dtype(), DataType::kInt32, "block_table must have dtype torch.int32");
+    BM_ASSERT_EQ(kcache.ndim(), 4, "kcache is not 4D");
+    BM_ASSERT_EQ(kcache.size(1) % 64, 0, "block_size must be a multiple of 64");
+    BM_ASSERT_EQ(kcache.size(2), 1, "num_heads_k must be 1");
+    BM_ASSERT_EQ(kcache.size(3), 576, "head_size must be 576");
+    const size_t batch = q.size(0), len_q = q.size(1), heads = q.size(2), head_size = q.size(3);
+    BM_ASSERT(batch > 0, "batch size must be positive");
+    BM_ASSERT_EQ(head_size, 576, "head_size must be 576");
+    BM_ASSERT_EQ(head_size_v, 512, "head_size_v must be 512");
+    BM_ASSERT_EQ(block_table.size(0), batch, "block_table batch");
+    BM_ASSERT(seqlens_k.dtype() == DataType::kInt32 && seqlens_k.numel() == batch, "seqlens_k must be (batch) int32");
+    if (len_q == 1) is_causal = false;
+    BM_ASSERT(!is_causal, "causal multi-row queries are not on this path");
+    const size_t hh = len_q * heads, page = kcache.size(1), max_blocks = block_table.size(1);
+    q = q.view({batch, hh, 1, head_size});                                  // the reference swaps the two axes the same way (.cpp:121-126)
+    Tensor out = out_org.view({batch, hh, 1, head_size_v});
+    Tensor lse = ctx.tensor({batch, 1, hh}, DataType::kFloat);
+    Tensor ws = ctx.tensor({(size_t)zl_mla_decode_workspace_bytes(batch, hh, page * max_blocks)}, DataType::kInt8);
+    zl_check(zl_mla_decode_attn_paged(u16(q), u16(kcache), block_table.data<int32_t>(), seqlens_k.data<int32_t>(), out.data<uint16_t>(),
+                                      lse.data<float>(), ws.data(), batch, hh, head_size_v, head_size - head_size_v, page, max_blocks,
+                                      softmax_scale, zdt(q.dtype()), st_of(ctx)), "mha_fwd_kvcache_mla");
+    return std::make_tuple(out, lse);
+}
+}  // namespace ds
+
 namespace int8_op {
 
 static std::vector<size_t> scale_shape(const Tensor& x) { return std::vector<size_t>(x.shape().begin(), x.shape().end() - 1); }

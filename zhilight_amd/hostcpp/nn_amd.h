@@ -230,6 +230,21 @@ private:
 };
 }  // namespace nn
 
+// ---- FlashMLA binding (src/nn/attention/ds_flash_mla_api.h:6-32): the same two functions, same arguments, over zl_mla_decode_attn_paged.
+// The two tensors get_mla_metadata returns are opaque to the caller (multi_head_latent_attention.cpp:902-915 only hands them back);
+// here the split plan is a host-side function of (B, H, max_len), so they carry nothing the kernel reads.
+namespace ds {
+using namespace bmengine;
+std::tuple<core::Tensor, core::Tensor> get_mla_metadata(const core::Context& ctx, const core::Tensor& seqlens_k, const size_t num_heads_per_head_k,
+                                                        const size_t num_heads_k = 1);
+// q (B, len_q, H, 576); kcache (num_blocks, 64, 1, 576); seqlens_k (B) int32; block_table (B, max_blocks) int32; out (B, len_q, H, 512).
+// Returns (out viewed (B, len_q * H, 1, 512), softmax_lse (B, 1, len_q * H)) like the reference's folded views (.cpp:121-136).
+std::tuple<core::Tensor, core::Tensor> mha_fwd_kvcache_mla(const core::Context& ctx, core::Tensor& q, const core::Tensor& kcache,
+                                                           const size_t head_size_v, const core::Tensor& seqlens_k, const core::Tensor& block_table,
+                                                           const float softmax_scale, bool is_causal, const core::Tensor& tile_scheduler_metadata,
+                                                           const core::Tensor& num_splits, core::Tensor out);
+}  // namespace ds
+
 namespace int8_op {
 using namespace bmengine;
 

@@ -99,6 +99,13 @@ PYBIND11_MODULE(zl_internals, m) {
             Tensor out = nn::sum_experts(*c.ctx, inputs, Tensor(), c.up(experts), c.up(index), c.up(weights), false);
             return c.down(out, "float16");
         })
+        .def("mha_fwd_kvcache_mla", [](PyCtx& c, py::array q, py::array kcache, py::array seqlens_k, py::array block_table, float scale, bool bf16) {
+            Tensor tq = c.up(q, bf16 ? kBF : -1), tk = c.up(kcache, bf16 ? kBF : -1), ts = c.up(seqlens_k), tb = c.up(block_table);
+            auto meta = ds::get_mla_metadata(*c.ctx, ts, tq.size(1) * tq.size(2));
+            Tensor out = c.ctx->tensor({tq.size(0), tq.size(1), tq.size(2), 512}, tq.dtype());
+            auto r = ds::mha_fwd_kvcache_mla(*c.ctx, tq, tk, 512, ts, tb, scale, false, std::get<0>(meta), std::get<1>(meta), out);
+            return py::make_tuple(c.down(out, bf16 ? "int16" : "float16"), c.down(std::get<1>(r), "float32"));
+        }, py::arg("q"), py::arg("kcache"), py::arg("seqlens_k"), py::arg("block_table"), py::arg("scale"), py::arg("bf16") = false)
         // ---- tensor surface (views, slices) exercised directly
         .def("tensor_roundtrip", [](PyCtx& c, py::array a, size_t from, size_t to) {
             Tensor t = c.up(a);

@@ -1410,3 +1410,27 @@ def mla_decode_attention(q_adj, buf_lens, kv_buf_addrs, scale, max_len_buf, vali
     check(lib().zl_mla_decode_attn(_p(q_adj), _p(buf_lens), _p(valid_lens), _p(kv_buf_addrs), _p(out), _p(workspace), _i(b), _i(h), _i(kv_lora_rank),
                                    _i(rope_dim), _f(scale), _i(max_len_buf), C.c_int(_dt(q_adj)), _stream()), "mla_decode_attention")
     return out
+
+
+def mha_fwd_kvcache_mla(q, kcache, head_size_v, seqlens_k, block_table, softmax_scale, is_causal=False, out=None):
+    """ds::mha_fwd_kvcache_mla (ds_flash_mla_api.h:16-30): q (B, len_q, H, 576), kcache (num_blocks, page, 1, 576), seqlens_k (B,) int32,
+    block_table (B, max_blocks) int32 -> (out (B, len_q, H, 512), softmax_lse (B, 1, len_q * H) fp32).  Non-causal only (len_q == 1 or
+    is_causal False), as every reference call site is."""
+    _chk_cuda(q, kcache, seqlens_k, block_table)
+    b, len_q, h, cd = q.shape
+    if len_q > 1 and is_causal:
+        raise ZLError("mha_fwd_kvcache_mla: causal multi-row queries are not on this path")
+    if kcache.dim() != 4 or kcache.shape[2] != 1 or kcache.shape[3] != cd or not kcache.is_contiguous() or not q.is_contiguous():
+        raise ZLError("mha_fwd_kvcache_mla: kcache is (num_blocks, page_block_size, 1, head_size), contiguous like q")
+    if block_table.dim() != 2 or block_table.shape[0] != b or block_table.dtype != torch.int32 or seqlens_k.dtype != torch.int32:
+        raise ZLError("mha_fwd_kvcache_mla: block_table (B, max_blocks) int32, seqlens_k (B,) int32")
+    page, mb, hh = kcache.shape[1], block_table.shape[1], len_q * h
+    workspace = torch.empty(int(lib().zl_mla_decode_workspace_bytes(_i(b), _i(hh), _i(page * mb))), dtype=torch.uint8, device=q.device)
+    if out is None:
+        out = torch.empty((b, len_q, h, head_size_v), dtype=q.dtype, device=q.device)
+    lse = torch.empty((b, 1, hh), dtype=torch.float32, device=q.device)
+    block_table = block_table.contiguous()
+    check(lib().zl_mla_decode_attn_paged(_p(q), _p(kcache), _p(block_table), _p(seqlens_k), _p(out), _p(lse), _p(workspace), _i(b), _i(hh),
+                                         _i(head_size_v), _i(cd - head_size_v), _i(page), _i(mb), _f(softmax_scale), C.c_int(_dt(q)), _stream()),
+          "mha_fwd_kvcache_mla")
+    return out, lse
