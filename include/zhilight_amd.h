@@ -692,12 +692,19 @@ int zl_moe_fill_m_indices(const int32_t* num_tokens, const int32_t* offsets, con
  * task b attends to the same rows kv_bufs[b] (len_buf, kv_lora_rank + rope_dim): key = the whole row, value = its first kv_lora_rank values;
  * q_adj (B, H, kv_lora_rank + rope_dim) is the absorbed query (q_nope . W_UK | q_rope); out (B, H, kv_lora_rank); keys 0 ..
  * min(buf_lens[b], valid_lens[b]) - 1 are visible (valid_lens nullable).  fp32 scores / probabilities / accumulation, one rounding to T.
- * kv_lora_rank = 512, rope_dim = 64, H % 4 == 0.  workspace: zl_mla_decode_workspace_bytes(b, h, max_len_buf) bytes.  VALU kernel,
- * correctness first (csrc/mla_attn.hip). */
+ * kv_lora_rank = 512, rope_dim = 64, H % 4 == 0.  workspace: zl_mla_decode_workspace_bytes(b, h, max_len_buf) bytes
+ * (csrc/mla_attn.hip). */
 int64_t zl_mla_decode_workspace_bytes(int64_t b, int64_t h, int64_t max_len_buf);
 int zl_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int32_t* valid_lens, const uint16_t* const* kv_bufs, uint16_t* out,
                        void* workspace, int64_t b, int64_t h, int64_t kv_lora_rank, int64_t rope_dim, float scale, int64_t max_len_buf, int dtype,
                        zl_stream_t s);
+
+/* the same with the kernel choice spelled out: algo 0 = the matrix-core kernel (k_mla_decode_mfma: S^T = KV . Q^T on v_mfma_f32_16x16x32,
+ * O^T += V^T . P^T on v_mfma_f32_16x16x16 with hi + lo probability halves; what zl_mla_decode_attn runs), 1 = the VALU kernel of the
+ * first version (kept for the tests that compare the two). */
+int zl_mla_decode_attn_ex(const uint16_t* q_adj, const int32_t* buf_lens, const int32_t* valid_lens, const uint16_t* const* kv_bufs, uint16_t* out,
+                          void* workspace, int64_t b, int64_t h, int64_t kv_lora_rank, int64_t rope_dim, float scale, int64_t max_len_buf, int dtype,
+                          int algo, zl_stream_t s);
 
 /* The same attention over a PAGED latent cache: what ds::mha_fwd_kvcache_mla (src/nn/attention/ds_flash_mla_api.h:16-30, .cpp:67-197: the
  * binding of the closed FlashMLA library) computes for its non-causal calls (multi_head_latent_attention.cpp:913, :993 pass is_causal =

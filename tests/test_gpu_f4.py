@@ -271,15 +271,16 @@ def test_moe_shared_expert_load_balancing(oracle, dev):
     assert t_wl.cpu().numpy().max() <= (tokens * ext + world - 1) // world + 0      # nobody above the even share
 
 
+@pytest.mark.parametrize("algo", [0, 1])
 @pytest.mark.parametrize("dtype,code", [(torch.float16, 0), (torch.bfloat16, 1)])
-@pytest.mark.parametrize("h", [16, 128])
-def test_mla_decode_attention_over_the_latent_cache(oracle, dev, dtype, code, h):
+@pytest.mark.parametrize("h", [16, 128, 20])
+def test_mla_decode_attention_over_the_latent_cache(oracle, dev, dtype, code, h, algo):
     """DeepSeek MLA, decode rows: every head reads the same 576-value latent rows (key = all of it, value = the first 512).  Against
     the fp64 statement (E) at T's output rounding, and against the reference's open route (R: scores and probabilities rounded to
     T) within that route's own noise."""
     from zhilight_amd import ops
     rng = np.random.default_rng(h)
-    lens = [1, 64, 65, 700] if h == 16 else [130, 1]
+    lens = [1, 64, 65, 700] if h == 16 else ([130, 1] if h == 128 else [17, 767])      # (h = 20: a ragged last group of heads)
     b, max_len = len(lens), 768
     q = torch.from_numpy((rng.standard_normal((b, h, 576)) * 0.4).astype(np.float32)).to(dtype)
     bufs = [torch.from_numpy((rng.standard_normal((max_len, 576)) * 0.6).astype(np.float32)).to(dtype) for _ in range(b)]
@@ -290,7 +291,7 @@ def test_mla_decode_attention_over_the_latent_cache(oracle, dev, dtype, code, h)
     buf_lens = torch.tensor([max_len - 1] * b, dtype=torch.int32, device=dev)
     valid = torch.tensor(lens, dtype=torch.int32, device=dev)
     scale = 0.1147
-    got = ops.mla_decode_attention(q.to(dev), buf_lens, addrs, scale, max_len, valid)
+    got = ops.mla_decode_attention(q.to(dev), buf_lens, addrs, scale, max_len, valid, algo=algo)   # 0: matrix cores, 1: the VALU kernel
     args = (_bits(q), [max_len - 1] * b, lens, [_bits(t) for t in bufs])
     f = (lambda u: oracle.u2h(u).astype(np.float64)) if code == 0 else (lambda u: (u.astype(np.uint32) << 16).view(np.float32).astype(np.float64))
     E = f(oracle.mla_decode_attn(*args, scale=scale, dtype=code, flavour="E"))

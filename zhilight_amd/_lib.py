@@ -18,7 +18,7 @@ SO_PATH = os.environ.get("ZHILIGHT_AMD_SO") or os.path.join(_HERE, "libzhilight_
 
 # every entry point declared in include/zhilight_amd.h (kept in sync by tests/test_abi.py)
 SYMBOLS = [
-    "zl_mla_decode_workspace_bytes", "zl_mla_decode_attn", "zl_mla_decode_attn_paged",
+    "zl_mla_decode_workspace_bytes", "zl_mla_decode_attn", "zl_mla_decode_attn_ex", "zl_mla_decode_attn_paged",
     "zl_moe_sum_experts", "zl_moe_sum_experts_arr", "zl_moe_route_shared_lb", "zl_moe_plus_for_sort", "zl_moe_calc_reverse_idx",
     "zl_moe_fill_m_indices",
     "zl_embedding_rope",

@@ -10,8 +10,15 @@
 // keys, wave = 4 heads: a lane is a KEY for the scores (its 576-value row against the heads' q rows broadcast from LDS) and an
 // octet of the 512 output columns for the P.V product (probabilities cross over by lane shuffles); partial (max, sum, O) per
 // (task, head, split) go through the workspace, k_mla_combine merges them.  128 heads share every cache row, so the bytes are
-// small (1.2 MB for 1024 keys) and the kernel is arithmetic- and latency-bound: the matrix-core version (S^T = KV . Q^T with
-// 18 k-steps, O^T in 32 accumulator tiles per wave) is the next step, not this file.
+// small (1.2 MB for 1024 keys) and the kernel is arithmetic- and latency-bound.
+//
+// k_mla_decode_mfma (the default) is the same split on the matrix cores, built like k_decode_attn_mfma (attention.hip): a wave
+// owns 16 keys of a 64-key chunk, S^T = KV . Q^T in 18 k-steps of v_mfma_f32_16x16x32 (the latent rows are the A operand straight
+// from global memory, the 16 heads' q rows the B operand, resident in registers), the C layout of S^T is the B layout of P^T, the
+// value part of the SAME row fragments goes row-major into wave-private LDS and comes back transposed (ds_read_tr16_b64) as the A
+// operand of O^T += V^T . P^T (32 accumulator tiles of 16 output columns, v_mfma_f32_16x16x16); probabilities as hi + lo halves
+// (two MFMAs per tile) so that the product sees them to ~2^-22; the four waves merge through LDS.  zl_mla_decode_attn_ex(algo = 1)
+// keeps the VALU kernel reachable (tests compare the two).
 #include "zl_common.h"
 
 namespace {
@@ -140,6 +147,202 @@ __global__ __launch_bounds__(256) void k_mla_decode_partial(const MlaParams p) {
     }
 }
 
+// ---- the matrix-core kernel ------------------------------------------------------------------------------------------------------
+typedef float mf4 __attribute__((ext_vector_type(4)));
+typedef short ms4 __attribute__((ext_vector_type(4)));
+constexpr int kVS = kRank + 16;                                // LDS row stride of the staged value rows (halfs): 1056 B = 8 banks mod 64
+constexpr int kMlaStage = 4 * 16 * kVS * 2;                    // bytes of the four waves' staged value rows
+constexpr int kMS = kRank + 4;                                 // row stride of the wave merge (floats): 16-byte rows
+constexpr int kMlaLds = 4 * 16 * kMS * 4;                      // the wave merge (fp32 [4][16][516]) is the larger use (staging + q: 86 016 B)
+static_assert(kMlaStage + 18 * 64 * 16 <= kMlaLds, "the merge buffer covers the loop's LDS");
+
+template <int DT>
+__device__ __forceinline__ mf4 mla_mfma32(uint4 a, uint4 b, mf4 c) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    if constexpr (DT == ZL_F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+}
+template <int DT>
+__device__ __forceinline__ mf4 mla_mfma16(ms4 a, uint2 b, mf4 c) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    if constexpr (DT == ZL_F16) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, a), __builtin_bit_cast(h4, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(ms4, b), c, 0, 0, 0);
+}
+
+// grid (splits, ceil(H / 16), B), 256 threads; dynamic LDS kMlaLds
+template <int DT>
+__global__ __launch_bounds__(256) void k_mla_decode_mfma(const MlaParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mla_smem[];
+    const int split = blockIdx.x, hg = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    const int len = p.valid_lens ? min(p.buf_lens[b], p.valid_lens[b]) : p.buf_lens[b];
+    const int t0 = split * p.split_len, t1 = min(len, t0 + p.split_len);
+    if (t0 >= len) return;                                                // (workgroup-uniform) the combine skips unwritten splits
+    const int last_key = t1 - 1;
+    const uint16_t* kv = p.block_table ? nullptr : p.kv_bufs[b];
+
+    // Q^T fragments (B operand): lane = (head 16 hg + r, dims 32 t + 8 kq .. + 7); heads past H are zero rows.  They are the same for
+    // the four waves and for every piece: fragment t sits in LDS as 64 consecutive 16-byte lane slots (18 KB behind the staging; 72
+    // registers otherwise, next to 72 of row fragments and 128 accumulators)
+    uint4* qs = reinterpret_cast<uint4*>(mla_smem + kMlaStage);
+    {
+        const int head = hg * kHG + r;
+        const bool live = head < p.h;
+        const uint16_t* qp = p.q + ((size_t)b * p.h + (live ? head : 0)) * kCD + 8 * kq;
+        uint4 v[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] = *reinterpret_cast<const uint4*>(qp + 32 * min(wave + 4 * i, 17));     // (one round trip, not five)
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (wave + 4 * i < 18) qs[(wave + 4 * i) * 64 + lane] = live ? v[i] : make_uint4(0, 0, 0, 0);
+    }
+    // latent-row fragments (A operand): lane = (key c0 + r, dims 32 t + 8 kq .. + 7).  The 16 keys of a wave's piece lie in one
+    // 64-key block, hence in one page; a key past the split re-reads its last row (the clamp never leaves the piece)
+    uint4 kk[18];
+    int c0 = t0 + 16 * wave;
+    auto load_rows = [&](int base) {                                      // base: wave-uniform, < t1
+        const uint16_t* piece;
+        if (p.block_table) {
+            const int pg = __builtin_amdgcn_readfirstlane(base / p.page);                  // (scalar: one s_load per piece)
+            piece = p.kcache + ((size_t)p.block_table[(size_t)b * p.max_blocks + pg] * p.page + (base - pg * p.page)) * kCD;
+        } else {
+            piece = kv + (size_t)base * kCD;
+        }
+        const uint16_t* src = piece + (size_t)(min(base + r, last_key) - base) * kCD + 8 * kq;
+        // (the buffer pointer comes out of a table in memory: say that it is global memory, or every load is a flat_load)
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        typedef const u4v __attribute__((address_space(1)))* gptr4;
+        gptr4 g = (gptr4)reinterpret_cast<const u4v*>(src);
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+            const u4v v = g[4 * t];
+            kk[t] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    if (c0 < t1) load_rows(c0);
+    else c0 = -1;                                                          // a wave without keys: skip the loop, keep the merge
+    __syncthreads();                                                       // the q fragments are in place
+
+    mf4 o[32];
+#pragma unroll
+    for (int db = 0; db < 32; ++db) o[db] = (mf4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e20f, l_run = 0.f;
+    uint16_t* vsw = reinterpret_cast<uint16_t*>(mla_smem) + (size_t)wave * 16 * kVS;       // this wave's 16 staged value rows
+    const uint16_t* vtr = vsw + (4 * kq + (r >> 2)) * kVS + 4 * (r & 3);                    // transpose-read address of this lane
+
+    while (c0 >= 0) {
+        // ---- S^T = KV . Q^T: rows = keys, columns = heads
+        mf4 st = (mf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 18; ++t) st = mla_mfma32<DT>(kk[t], qs[t * 64 + lane], st);
+        // ---- the value part of the same rows to LDS (row-major), then the NEXT piece's loads: they fly during softmax and P.V
+        {
+            uint16_t* vdst = vsw + r * kVS + 8 * kq;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) *reinterpret_cast<uint4*>(vdst + 32 * t) = kk[t];
+        }
+        const int cur = c0;
+        c0 += 64;
+        if (c0 < t1) load_rows(c0);
+        // ---- online softmax of head r over this lane's 4 keys (+ the 3 other lanes of the head)
+        float sv[4], mloc = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sv[i] = cur + 4 * kq + i < t1 ? st[i] * p.scale : -INFINITY;
+            mloc = fmaxf(mloc, sv[i]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float pr[4], lsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pr[i] = __expf(sv[i] - m_new);
+            lsum += pr[i];
+        }
+        auto cvt = [](float x) -> uint16_t { return ZT<DT>::from_f32(x); };
+        auto hi_lo = [&](float a, float b2, uint32_t& hw, uint32_t& lw) {   // two probabilities -> packed hi word, lo word
+            const uint16_t ah = cvt(a), bh = cvt(b2);
+            hw = (uint32_t)ah | ((uint32_t)bh << 16);
+            lw = (uint32_t)cvt(a - ZT<DT>::to_f32(ah)) | ((uint32_t)cvt(b2 - ZT<DT>::to_f32(bh)) << 16);
+        };
+        uint2 pf, pl;
+        hi_lo(pr[0], pr[1], pf.x, pl.x);
+        hi_lo(pr[2], pr[3], pf.y, pl.y);
+        // the 128 accumulators live in AGPRs (the VALU cannot touch them without a round trip): rescale only when some head's
+        // maximum moved while it had anything accumulated -- otherwise every lane's alpha is exactly 1 (or its column is all zero)
+        const bool moved = alpha != 1.0f && l_run > 0.f;
+        l_run = l_run * alpha + lsum;
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+            for (int db = 0; db < 32; ++db) {
+                o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+            }
+        }
+        // ---- O^T += V^T . P^T: rows = output columns 16 db .. + 15, columns = heads, k = the piece's 16 keys
+#pragma unroll
+        for (int db = 0; db < 32; ++db) {
+            const ms4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ms4*)(vtr + 16 * db));
+            o[db] = mla_mfma16<DT>(a, pf, o[db]);
+            o[db] = mla_mfma16<DT>(a, pl, o[db]);
+        }
+        if (c0 >= t1) break;
+    }
+
+    // ---- merge: the head's normaliser lives in 4 lanes; then the 4 waves through LDS (aliases the staging)
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();
+    float* xw = reinterpret_cast<float*>(mla_smem);                       // [wave][16 heads][kMS]
+    {
+        float* dst = xw + ((size_t)wave * 16 + r) * kMS;
+#pragma unroll
+        for (int db = 0; db < 32; ++db) *reinterpret_cast<mf4*>(dst + 16 * db + 4 * kq) = o[db];
+        if (kq == 0) {
+            dst[kRank] = m_run;
+            dst[kRank + 1] = l_run;
+        }
+    }
+    __syncthreads();
+    // wave w writes the records of heads 4 w .. 4 w + 3: lane = 8 output columns, the four waves' rows merged in wave order
+    constexpr int WS = 16 * kMS;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const int i = wave * 4 + j, head = hg * kHG + i;
+        if (head >= p.h) break;                                           // (wave-uniform)
+        const float* src = xw + (size_t)i * kMS;
+        float f[4], mn = src[kRank], lt = 0.f;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, src[w * WS + kRank]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            f[w] = __expf(src[w * WS + kRank] - mn);
+            lt = __builtin_fmaf(src[w * WS + kRank + 1], f[w], lt);
+        }
+        mf4 a0 = (mf4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const mf4 x0 = *reinterpret_cast<const mf4*>(src + w * WS + lane * 8), x1 = *reinterpret_cast<const mf4*>(src + w * WS + lane * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[e] = __builtin_fmaf(x0[e], f[w], a0[e]);
+                a1[e] = __builtin_fmaf(x1[e], f[w], a1[e]);
+            }
+        }
+        float* rec = p.ws + (((size_t)b * p.h + head) * p.max_splits + split) * kRec;
+        *reinterpret_cast<float4*>(rec + lane * 8) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+        *reinterpret_cast<float4*>(rec + lane * 8 + 4) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        if (lane == 0) {
+            rec[kRank] = mn;
+            rec[kRank + 1] = lt;
+        }
+    }
+}
+
 // grid (H, B), 64 lanes: lane = 8 output columns; the splits that exist are the first ceil(len / split_len)
 template <int DT>
 __global__ __launch_bounds__(64) void k_mla_combine(const MlaParams p) {
@@ -147,16 +350,24 @@ __global__ __launch_bounds__(64) void k_mla_combine(const MlaParams p) {
     const int len = p.valid_lens ? min(p.buf_lens[b], p.valid_lens[b]) : p.buf_lens[b];
     const int ns = len > 0 ? min((len + p.split_len - 1) / p.split_len, p.max_splits) : 0;
     const float* rec0 = p.ws + ((size_t)b * p.h + head) * p.max_splits * kRec;
+    // the records' (max, sum) pairs: lane s of a block of 64 records loads its own -- one round trip per block instead of one per record
     float mx = -1e20f;
-    for (int s = 0; s < ns; ++s) mx = fmaxf(mx, rec0[(size_t)s * kRec + kRank]);
+    for (int s0 = 0; s0 < ns; s0 += 64) mx = fmaxf(mx, zl_wave_max(s0 + lane < ns ? rec0[(size_t)(s0 + lane) * kRec + kRank] : -1e20f));
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, z = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        const float* rec = rec0 + (size_t)s * kRec;
-        const float f = __expf(rec[kRank] - mx);
-        const float4 a = *reinterpret_cast<const float4*>(rec + lane * 8), c = *reinterpret_cast<const float4*>(rec + lane * 8 + 4);
-        o[0] = __builtin_fmaf(a.x, f, o[0]); o[1] = __builtin_fmaf(a.y, f, o[1]); o[2] = __builtin_fmaf(a.z, f, o[2]); o[3] = __builtin_fmaf(a.w, f, o[3]);
-        o[4] = __builtin_fmaf(c.x, f, o[4]); o[5] = __builtin_fmaf(c.y, f, o[5]); o[6] = __builtin_fmaf(c.z, f, o[6]); o[7] = __builtin_fmaf(c.w, f, o[7]);
-        z = __builtin_fmaf(rec[kRank + 1], f, z);
+    for (int s0 = 0; s0 < ns; s0 += 64) {
+        const bool mine = s0 + lane < ns;
+        const float fl = mine ? __expf(rec0[(size_t)(s0 + lane) * kRec + kRank] - mx) : 0.f;
+        const float zl = mine ? rec0[(size_t)(s0 + lane) * kRec + kRank + 1] : 0.f;
+        const int cnt = min(64, ns - s0);
+#pragma unroll 4
+        for (int j = 0; j < cnt; ++j) {                                  // record order: the sums are order-dependent
+            const float* rec = rec0 + (size_t)(s0 + j) * kRec;
+            const float f = __shfl(fl, j, 64);
+            const float4 a = *reinterpret_cast<const float4*>(rec + lane * 8), c = *reinterpret_cast<const float4*>(rec + lane * 8 + 4);
+            o[0] = __builtin_fmaf(a.x, f, o[0]); o[1] = __builtin_fmaf(a.y, f, o[1]); o[2] = __builtin_fmaf(a.z, f, o[2]); o[3] = __builtin_fmaf(a.w, f, o[3]);
+            o[4] = __builtin_fmaf(c.x, f, o[4]); o[5] = __builtin_fmaf(c.y, f, o[5]); o[6] = __builtin_fmaf(c.z, f, o[6]); o[7] = __builtin_fmaf(c.w, f, o[7]);
+            z = __builtin_fmaf(__shfl(zl, j, 64), f, z);
+        }
     }
     const float inv = ns > 0 ? 1.0f / (z + 1e-20f) : 0.f;
     if (p.lse && lane == 0) p.lse[(size_t)b * p.h + head] = ns > 0 ? mx + logf(z) : -INFINITY;
@@ -176,7 +387,7 @@ inline int mla_split_len(int64_t b, int64_t h, int64_t max_len) {
     return (int)ls;
 }
 
-int mla_launch(const MlaParams& p, int dtype, hipStream_t hs);
+int mla_launch(const MlaParams& p, int dtype, int algo, hipStream_t hs);
 
 }  // namespace
 
@@ -192,6 +403,13 @@ int64_t zl_mla_decode_workspace_bytes(int64_t b, int64_t h, int64_t max_len_buf)
 int zl_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int32_t* valid_lens, const uint16_t* const* kv_bufs, uint16_t* out,
                        void* workspace, int64_t b, int64_t h, int64_t kv_lora_rank, int64_t rope_dim, float scale, int64_t max_len_buf, int dtype,
                        zl_stream_t s) {
+    return zl_mla_decode_attn_ex(q_adj, buf_lens, valid_lens, kv_bufs, out, workspace, b, h, kv_lora_rank, rope_dim, scale, max_len_buf, dtype, 0, s);
+}
+
+int zl_mla_decode_attn_ex(const uint16_t* q_adj, const int32_t* buf_lens, const int32_t* valid_lens, const uint16_t* const* kv_bufs, uint16_t* out,
+                          void* workspace, int64_t b, int64_t h, int64_t kv_lora_rank, int64_t rope_dim, float scale, int64_t max_len_buf, int dtype,
+                          int algo, zl_stream_t s) {
+    ZL_CHECK_ARG(algo == 0 || algo == 1, ZL_EINVAL);
     ZL_CHECK_ARG(q_adj && buf_lens && kv_bufs && out && workspace && b > 0 && h > 0 && max_len_buf > 0, ZL_EINVAL);
     ZL_CHECK_ARG(kv_lora_rank == kRank && rope_dim == kRope && h % 4 == 0, ZL_ESHAPE);
     ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
@@ -202,7 +420,7 @@ int zl_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int
     p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
     p.scale = scale;
     p.kcache = nullptr; p.block_table = nullptr; p.page = p.max_blocks = 0; p.lse = nullptr;
-    return mla_launch(p, dtype, (hipStream_t)s);
+    return mla_launch(p, dtype, algo, (hipStream_t)s);
 }
 
 int zl_mla_decode_attn_paged(const uint16_t* q_adj, const uint16_t* kcache, const int32_t* block_table, const int32_t* seqlens_k, uint16_t* out,
@@ -219,17 +437,24 @@ int zl_mla_decode_attn_paged(const uint16_t* q_adj, const uint16_t* kcache, cons
     p.max_splits = (int)((max_len + p.split_len - 1) / p.split_len);
     p.scale = scale;
     p.kcache = kcache; p.block_table = block_table; p.page = (int)page_block_size; p.max_blocks = (int)max_blocks_per_seq; p.lse = softmax_lse;
-    return mla_launch(p, dtype, (hipStream_t)s);
+    return mla_launch(p, dtype, 0, (hipStream_t)s);
 }
 
 }  // extern "C"
 
 namespace {
-int mla_launch(const MlaParams& p, int dtype, hipStream_t hs) {
+int mla_launch(const MlaParams& p, int dtype, int algo, hipStream_t hs) {
     const int64_t h = p.h, b = p.b;
     const dim3 grid((unsigned)p.max_splits, (unsigned)((h + kHG - 1) / kHG), (unsigned)b);
-    if (dtype == ZL_F16) hipLaunchKernelGGL(k_mla_decode_partial<ZL_F16>, grid, dim3(256), 0, hs, p);
-    else hipLaunchKernelGGL(k_mla_decode_partial<ZL_BF16>, grid, dim3(256), 0, hs, p);
+    if (algo == 1) {
+        if (dtype == ZL_F16) hipLaunchKernelGGL(k_mla_decode_partial<ZL_F16>, grid, dim3(256), 0, hs, p);
+        else hipLaunchKernelGGL(k_mla_decode_partial<ZL_BF16>, grid, dim3(256), 0, hs, p);
+    } else {
+        const void* fn = dtype == ZL_F16 ? reinterpret_cast<const void*>(&k_mla_decode_mfma<ZL_F16>) : reinterpret_cast<const void*>(&k_mla_decode_mfma<ZL_BF16>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMlaLds) != hipSuccess) return ZL_ELIMIT;
+        if (dtype == ZL_F16) hipLaunchKernelGGL(k_mla_decode_mfma<ZL_F16>, grid, dim3(256), kMlaLds, hs, p);
+        else hipLaunchKernelGGL(k_mla_decode_mfma<ZL_BF16>, grid, dim3(256), kMlaLds, hs, p);
+    }
     int e = zl_launch_status();
     if (e) return e;
     if (dtype == ZL_F16) hipLaunchKernelGGL(k_mla_combine<ZL_F16>, dim3((unsigned)h, (unsigned)b), dim3(64), 0, hs, p);

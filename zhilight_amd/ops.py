@@ -1397,9 +1397,10 @@ def moe_fill_m_indices_padded_indices(all_loads, block_m, num_experts, device, e
 
 
 # ---- f4: MLA decode attention over the latent cache ------------------------------------------------------------------------------
-def mla_decode_attention(q_adj, buf_lens, kv_buf_addrs, scale, max_len_buf, valid_lens=None, kv_lora_rank=512, rope_dim=64, workspace=None):
+def mla_decode_attention(q_adj, buf_lens, kv_buf_addrs, scale, max_len_buf, valid_lens=None, kv_lora_rank=512, rope_dim=64, workspace=None,
+                         algo=0):
     """MLAImpl over the compressed cache for decode rows: q_adj (B, H, 576), kv_buf_addrs (B,) int64 device table of (len_buf, 576)
-    buffers -> (B, H, 512)"""
+    buffers -> (B, H, 512).  algo 0: the matrix-core kernel, 1: the VALU kernel (zl_mla_decode_attn_ex)."""
     _chk_cuda(q_adj, buf_lens, kv_buf_addrs, valid_lens)
     b, h, cd = q_adj.shape
     if cd != kv_lora_rank + rope_dim:
@@ -1407,8 +1408,9 @@ def mla_decode_attention(q_adj, buf_lens, kv_buf_addrs, scale, max_len_buf, vali
     if workspace is None:
         workspace = torch.empty(int(lib().zl_mla_decode_workspace_bytes(_i(b), _i(h), _i(max_len_buf))), dtype=torch.uint8, device=q_adj.device)
     out = torch.empty((b, h, kv_lora_rank), dtype=q_adj.dtype, device=q_adj.device)
-    check(lib().zl_mla_decode_attn(_p(q_adj), _p(buf_lens), _p(valid_lens), _p(kv_buf_addrs), _p(out), _p(workspace), _i(b), _i(h), _i(kv_lora_rank),
-                                   _i(rope_dim), _f(scale), _i(max_len_buf), C.c_int(_dt(q_adj)), _stream()), "mla_decode_attention")
+    check(lib().zl_mla_decode_attn_ex(_p(q_adj), _p(buf_lens), _p(valid_lens), _p(kv_buf_addrs), _p(out), _p(workspace), _i(b), _i(h),
+                                      _i(kv_lora_rank), _i(rope_dim), _f(scale), _i(max_len_buf), C.c_int(_dt(q_adj)), C.c_int(algo), _stream()),
+          "mla_decode_attention")
     return out
 
 
