@@ -137,57 +137,91 @@ __global__ __launch_bounds__(256) void k_fp8_block_dequant(const uint8_t* __rest
 
 // The block-scaled product of deep_gemm_fp8_block_h20_group (3rd/deep_gemm/deep_gemm_api.h): per 128-k block the fp8 x fp8
 // partial product is accumulated in fp32 on the matrix cores (4 x v_mfma_f32_16x16x32_fp8_fp8 from zero), then added to the
-// running sum scaled by sa[kb, m] * sw[n / 128, kb].  Same tile as k_fp8_gemm_nt (one wave = 16 weight rows x MT * 16
-// activation rows, fragments straight from global memory): correctness first, no LDS staging yet.  A 16-row tile takes the
-// expert (weight matrix) of its first row; rows of the tile carrying another index are not written (contiguous grouped
-// layout, groups aligned to 16 rows; DeepGEMM's own contract is alignment to its block_m = 64).
-template <int MT, int DT>
-__global__ __launch_bounds__(256) void k_fp8_block_gemm(const uint8_t* __restrict__ a, const float* __restrict__ sa, int64_t aligned_m,
+// running sum scaled by sa[kb, m] * sw[n / 128, kb].
+//
+// Shape of the kernel (decode row counts: the weights are the bytes).  A workgroup = 8 waves = 16 weight rows x the whole K: wave w
+// takes the 128-k blocks w, w + 8, ... (N / 16 workgroups x 8 waves of independent streams -- the first version's one wave per
+// 16 rows walked K with 2 KiB in flight: 0.1-0.2 TB/s), U blocks at a time with every load of the U blocks issued before the
+// first MFMA (weight fragments straight from global memory, non-temporal; a row's 128 bytes of a block are two 16-byte lane loads),
+// MT tiles of 16 activation rows share each weight fragment; the eight partial tiles meet in LDS and are summed in wave order
+// (deterministic).  A tile of 16 rows takes the expert (weight matrix) of its first row; rows of the tile carrying another index
+// are not written (contiguous grouped layout, groups aligned to 16 rows; DeepGEMM's own contract is alignment to its block_m =
+// 64); the grouped form runs with MT = 1 (neighbouring tiles may belong to different experts).
+template <int MT, int U, int DT>
+__global__ __launch_bounds__(512) void k_fp8_block_gemm(const uint8_t* __restrict__ a, const float* __restrict__ sa, int64_t aligned_m,
                                                         const uint8_t* __restrict__ w, const float* __restrict__ sw,
                                                         const int32_t* __restrict__ m_indices, uint16_t* __restrict__ c, int m, int n, int k) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = (blockIdx.x * 4 + wave) * 16;
-    if (n0 >= n) return;
-    const int m0 = blockIdx.y * (MT * 16);
+    __shared__ __attribute__((aligned(16))) float red[8][MT][256];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (MT * 16);
     const int col = lane & 15, kq = lane >> 4;
     const int kb_n = k / 128, nbw = (n + 127) / 128;
-    const bool ncol_ok = (n0 + col) < n;
+    const int g = m_indices ? m_indices[m0] : 0;              // workgroup-uniform (m0 < m by the grid)
+    if (g < 0) return;                                        // a padding tile of the grouped layout: nothing to write
+    // (clamped addresses: a column / row past the end re-reads the last one and is never stored)
+    const uint8_t* brow = w + ((size_t)g * n + min(n0 + col, n - 1)) * k + 16 * kq;
+    const float* swg = sw + ((size_t)g * nbw + n0 / 128) * kb_n;
+    const uint8_t* arow[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int r0 = m0 + t * 16;
-        if (r0 >= m) break;
-        const int g = m_indices ? m_indices[r0] : 0;          // wave-uniform
-        if (g < 0) continue;
-        const uint8_t* brow = w + ((size_t)g * n + (n0 + col)) * k;
-        const float* swg = sw + ((size_t)g * nbw + n0 / 128) * kb_n;
-        const int arow = r0 + col;
-        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
-        for (int kb = 0; kb < kb_n; ++kb) {
-            f4 blk = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t) arow[t] = a + (size_t)min(m0 + 16 * t + col, m - 1) * k + 16 * kq;
+    f4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kb0 = wave; kb0 < kb_n; kb0 += 8 * U) {
+        uint4 bf[U][2], af[U][MT][2];
+        float sc[U][MT][4], wsc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kb = kb0 + 8 * u;
+            const bool ok = kb < kb_n;                        // wave-uniform; a block past the end re-reads block kb0 with a zero scale
+            const int kbc = ok ? kb : kb0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int kk = kb * 128 + h * 64 + 16 * kq;
-                uint4 bf = make_uint4(0, 0, 0, 0), af = make_uint4(0, 0, 0, 0);
-                if (ncol_ok) bf = zl_load_nt(reinterpret_cast<const uint4*>(brow + kk));
-                if (arow < m) af = *reinterpret_cast<const uint4*>(a + (size_t)arow * k + kk);
-                const long b_lo = (long)(((unsigned long long)bf.y << 32) | bf.x), b_hi = (long)(((unsigned long long)bf.w << 32) | bf.z);
-                const long a_lo = (long)(((unsigned long long)af.y << 32) | af.x), a_hi = (long)(((unsigned long long)af.w << 32) | af.z);
-                blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_lo, b_lo, blk, 0, 0, 0);
-                blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_hi, b_hi, blk, 0, 0, 0);
-            }
-            const float ws = swg[kb];
+                bf[u][h] = zl_load_nt(reinterpret_cast<const uint4*>(brow + kbc * 128 + h * 64));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = r0 + 4 * kq + i;
-                const float s = (row < m ? sa[(size_t)kb * aligned_m + row] : 0.f) * ws;
-                acc[i] = __builtin_fmaf(blk[i], s, acc[i]);
+                for (int t = 0; t < MT; ++t) af[u][t][h] = *reinterpret_cast<const uint4*>(arow[t] + kbc * 128 + h * 64);
+            }
+            wsc[u] = ok ? swg[kbc] : 0.f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + 16 * t + 4 * kq + i;
+                    sc[u][t][i] = row < m ? sa[(size_t)kbc * aligned_m + row] : 0.f;
+                }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = r0 + 4 * kq + i;
-            if (row < m && ncol_ok && (!m_indices || m_indices[row] == g)) c[(size_t)row * n + n0 + col] = ZT<DT>::from_f32(acc[i]);
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                f4 blk = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint4 b4 = bf[u][h], a4 = af[u][t][h];
+                    const long b_lo = (long)(((unsigned long long)b4.y << 32) | b4.x), b_hi = (long)(((unsigned long long)b4.w << 32) | b4.z);
+                    const long a_lo = (long)(((unsigned long long)a4.y << 32) | a4.x), a_hi = (long)(((unsigned long long)a4.w << 32) | a4.z);
+                    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_lo, b_lo, blk, 0, 0, 0);
+                    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_hi, b_hi, blk, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_fmaf(blk[i], sc[u][t][i] * wsc[u], acc[t][i]);
+            }
         }
+    }
+    // ---- the eight k-slices meet in LDS: [wave][tile][C row 4 kq + i][column]
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][t][(4 * kq + i) * 16 + col] = acc[t][i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MT * 256; idx += 512) {
+        const int t = idx >> 8, e = idx & 255, row = m0 + 16 * t + (e >> 4), cc = n0 + (e & 15);
+        float v = red[0][t][e];
+#pragma unroll
+        for (int ws = 1; ws < 8; ++ws) v += red[ws][t][e];
+        if (row < m && cc < n && (!m_indices || m_indices[row] == g)) c[(size_t)row * n + cc] = ZT<DT>::from_f32(v);
     }
 }
 
@@ -254,11 +288,23 @@ int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t
                             const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype, zl_stream_t s) {
     ZL_CHECK_ARG(lhs && lhs_scales && rhs && rhs_scales && out && m > 0 && n > 0 && k > 0 && num_groups >= 1, ZL_EINVAL);
     ZL_CHECK_ARG(k % 128 == 0 && aligned_m >= m && (num_groups == 1 || m_indices), ZL_ESHAPE);
-    ZL_CHECK_ARG(m < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) && (m + 63) / 64 <= 65535, ZL_ELIMIT);
-    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((m + 63) / 64));
-    ZL_DT_SWITCH(dtype,
-        hipLaunchKernelGGL((k_fp8_block_gemm<4, ZL_F16>), grid, dim3(256), 0, (hipStream_t)s, lhs, lhs_scales, aligned_m, rhs, rhs_scales, m_indices, out, (int)m, (int)n, (int)k),
-        hipLaunchKernelGGL((k_fp8_block_gemm<4, ZL_BF16>), grid, dim3(256), 0, (hipStream_t)s, lhs, lhs_scales, aligned_m, rhs, rhs_scales, m_indices, out, (int)m, (int)n, (int)k))
+    ZL_CHECK_ARG(m < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) && (m + 15) / 16 <= 65535, ZL_ELIMIT);
+    hipStream_t hs = (hipStream_t)s;
+    const unsigned gx = (unsigned)((n + 15) / 16);
+#define ZL_FP8B(MT_, U_)                                                                                                                   \
+    {                                                                                                                                      \
+        const dim3 grid(gx, (unsigned)((m + 16 * MT_ - 1) / (16 * MT_)));                                                                  \
+        ZL_DT_SWITCH(dtype,                                                                                                                \
+            hipLaunchKernelGGL((k_fp8_block_gemm<MT_, U_, ZL_F16>), grid, dim3(512), 0, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales,    \
+                               m_indices, out, (int)m, (int)n, (int)k),                                                                    \
+            hipLaunchKernelGGL((k_fp8_block_gemm<MT_, U_, ZL_BF16>), grid, dim3(512), 0, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales,   \
+                               m_indices, out, (int)m, (int)n, (int)k))                                                                    \
+    }
+    // the grouped form: one 16-row tile per workgroup (neighbouring tiles may belong to different experts)
+    if (m_indices || m <= 16) ZL_FP8B(1, 4)
+    else if (m <= 32) ZL_FP8B(2, 2)
+    else ZL_FP8B(4, 1)
+#undef ZL_FP8B
     return zl_launch_status();
 }
 
