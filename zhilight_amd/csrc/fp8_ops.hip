@@ -288,6 +288,7 @@ int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t
                             const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype, zl_stream_t s) {
     ZL_CHECK_ARG(lhs && lhs_scales && rhs && rhs_scales && out && m > 0 && n > 0 && k > 0 && num_groups >= 1, ZL_EINVAL);
     ZL_CHECK_ARG(k % 128 == 0 && aligned_m >= m && (num_groups == 1 || m_indices), ZL_ESHAPE);
+    ZL_CHECK_ARG((((uintptr_t)lhs | (uintptr_t)rhs) & 15) == 0, ZL_ESHAPE);      // 16-byte fragment loads
     ZL_CHECK_ARG(m < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) && (m + 15) / 16 <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
     const unsigned gx = (unsigned)((n + 15) / 16);
