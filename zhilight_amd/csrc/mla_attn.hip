@@ -377,10 +377,11 @@ __global__ __launch_bounds__(64) void k_mla_combine(const MlaParams p) {
     *reinterpret_cast<uint4*>(p.out + ((size_t)b * p.h + head) * kRank + lane * 8) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-inline int mla_split_len(int64_t b, int64_t h, int64_t max_len) {
-    // about 512 workgroups of (16 heads, split): splits of 64 keys (one chunk) upward
-    const int64_t groups = b * ((h + kHG - 1) / kHG);
-    int64_t want_splits = (512 + groups - 1) / groups;
+inline int mla_split_len(int64_t b, int64_t h, int64_t max_len, int algo) {
+    // about one workgroup of (16 heads, split) per CU for the matrix-core kernel (its 129 KB of LDS leave one workgroup per CU; every
+    // further split is another record per head for the combine), about 512 for the VALU kernel; splits of 64 keys (one chunk) upward
+    const int64_t groups = b * ((h + kHG - 1) / kHG), target = algo == 1 ? 512 : 256;
+    int64_t want_splits = (target + groups - 1) / groups;
     if (want_splits < 1) want_splits = 1;
     int64_t ls = ((max_len + want_splits - 1) / want_splits + 63) / 64 * 64;
     if (ls < 64) ls = 64;
@@ -395,7 +396,7 @@ extern "C" {
 
 int64_t zl_mla_decode_workspace_bytes(int64_t b, int64_t h, int64_t max_len_buf) {
     if (b <= 0 || h <= 0 || max_len_buf <= 0) return ZL_EINVAL;
-    const int ls = mla_split_len(b, h, max_len_buf);
+    const int ls = mla_split_len(b, h, max_len_buf, 1);                   // (the finer of the two plans: enough for either kernel)
     const int64_t ms = (max_len_buf + ls - 1) / ls;
     return b * h * ms * kRec * 4;
 }
@@ -416,7 +417,7 @@ int zl_mla_decode_attn_ex(const uint16_t* q_adj, const int32_t* buf_lens, const 
     ZL_CHECK_ARG(b <= 65535 && (h + kHG - 1) / kHG <= 65535, ZL_ELIMIT);
     MlaParams p;
     p.q = q_adj; p.buf_lens = buf_lens; p.valid_lens = valid_lens; p.kv_bufs = kv_bufs; p.out = out; p.ws = (float*)workspace;
-    p.b = (int)b; p.h = (int)h; p.split_len = mla_split_len(b, h, max_len_buf);
+    p.b = (int)b; p.h = (int)h; p.split_len = mla_split_len(b, h, max_len_buf, algo);
     p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
     p.scale = scale;
     p.kcache = nullptr; p.block_table = nullptr; p.page = p.max_blocks = 0; p.lse = nullptr;
@@ -433,7 +434,7 @@ int zl_mla_decode_attn_paged(const uint16_t* q_adj, const uint16_t* kcache, cons
     const int64_t max_len = page_block_size * max_blocks_per_seq;
     MlaParams p;
     p.q = q_adj; p.buf_lens = seqlens_k; p.valid_lens = nullptr; p.kv_bufs = nullptr; p.out = out; p.ws = (float*)workspace;
-    p.b = (int)b; p.h = (int)h; p.split_len = mla_split_len(b, h, max_len);
+    p.b = (int)b; p.h = (int)h; p.split_len = mla_split_len(b, h, max_len, 0);
     p.max_splits = (int)((max_len + p.split_len - 1) / p.split_len);
     p.scale = scale;
     p.kcache = kcache; p.block_table = block_table; p.page = (int)page_block_size; p.max_blocks = (int)max_blocks_per_seq; p.lse = softmax_lse;
