@@ -352,3 +352,35 @@ def test_flash_mla_binding_through_the_cpp_names(dev):
                                          torch.from_numpy(table).to(dev), 0.1147)
     assert np.array_equal(got.view(np.uint16), want.cpu().numpy().view(np.uint16))
     assert np.array_equal(lse, wlse.cpu().numpy())
+
+
+@pytest.mark.parametrize("tokens", [3, 37])
+@pytest.mark.parametrize("router,dtype", [("top_k", torch.bfloat16), ("group", torch.bfloat16), ("top_k", torch.float16)])
+def test_moe_feed_forward_flow_equals_the_per_token_sum(dev, tokens, router, dtype):
+    """FeedForward::forward_gpu_dispatch (feedforward.cpp:1075-1150) strung together from the launchers (zhilight_amd/moe.py): route ->
+    m-grouped 64-aligned layout -> grouped FP8 block GEMMs -> act(in) * gated -> grouped GEMM -> weighted combine.  Every row of the
+    grouped GEMMs is computed from its own fragments, so the flow must return the BITS of the same sum written token by token and
+    slot by slot with Fp8Block::forward on single rows (3 tokens: most experts get nothing; 37: ragged runs, padding rows)."""
+    from zhilight_amd.moe import Fp8BlockMoE
+    g = torch.Generator(device="cpu").manual_seed(100 + tokens)
+    e, k, dim, ff = 64, 4, 256, 384
+
+    def codes(*shape):                                                        # finite e4m3 codes of either sign (0x7f / 0xff are NaN)
+        return (torch.randint(0, 0x78, shape, generator=g, dtype=torch.int32) | (torch.randint(0, 2, shape, generator=g, dtype=torch.int32) << 7)) \
+            .to(torch.uint8).to(dev)
+
+    def scales(*shape):
+        return (torch.rand(shape, generator=g) * 0.008 + 0.002).to(dev)
+
+    moe = Fp8BlockMoE((torch.randn(e, dim, generator=g) * 0.5).to(dtype).to(dev), codes(e, ff, dim), scales(e, ff // 128, dim // 128),
+                      codes(e, ff, dim), scales(e, ff // 128, dim // 128), codes(e, dim, ff), scales(e, dim // 128, ff // 128), top_k=k,
+                      scoring_func="sigmoid" if router == "group" else "softmax", n_group=4 if router == "group" else 1,
+                      topk_group=2 if router == "group" else 1, routed_scaling_factor=2.5 if router == "group" else 1.0,
+                      e_score_correction_bias=(torch.randn(e, generator=g) * 0.1).to(dev) if router == "group" else None)
+    x = torch.randn(tokens, dim, generator=g).to(dtype).to(dev)
+    ids, w, loads = moe.route(x)
+    assert int(loads[:e].sum()) == tokens * k and bool((ids >= 0).all()) and bool((ids < e).all())
+    got = moe.forward(x)
+    want = moe.forward_per_token(x)
+    assert got.shape == (tokens, dim) and torch.isfinite(got.float()).all() and float(got.float().abs().max()) > 0
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))

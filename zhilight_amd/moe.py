@@ -1,0 +1,105 @@
+"""Config 5's MoE feed-forward over FP8 128x128-block experts: the host flow of FeedForward's dispatch route
+(reference src/nn/feedforward/feedforward.cpp:417-482 route, :599-629 sort_token, :1045-1072 get_grouped_input_gpu, :1075-1150
+forward_gpu_dispatch), strung together from the C-ABI launchers of zhilight_amd/ops.py:
+
+    logits = router(x)                                   functions::Gemm                       -> zl_gemm_nt
+    ids, weights, loads = top-k / group-limited top-k    top_k_softmax / group_topk_softmax    -> zl_moe_top_k_softmax / zl_moe_group_topk
+    m_indices, padded positions, total                   fill_m_indices_padded_indices         -> zl_moe_fill_m_indices
+    order = sort of the (token, slot) pairs by expert    functions::sort_pair_1d (CUB)         -> the framework's stable device sort
+    rev = position of a pair inside its expert's run     calc_reverse_idx                      -> zl_moe_calc_reverse_idx
+    grouped input: per-token 1x128 cast, rows and scales scattered to the 64-aligned runs     -> zl_fp8_per_token_cast + row moves
+    w0, w1 = grouped GEMMs (in, gated); w0 = act(w0) * w1; w2 = grouped GEMM (out)            -> zl_fp8_block_gemm_group, zl_gate_mul
+    y[token] = sum_slot weight * w2[run(expert) + rev]   sum_experts (per-expert inputs)       -> zl_moe_sum_experts_arr
+
+One rank, no shared experts (expert / data parallel modes and route_shared_lb are wired in ops but not in this flow yet).  Row moves
+(gather of the sorted tokens, scatter into the padded layout, the scale transpose) and the sort are device-memory plumbing done with
+torch indexing, like the reference's functions::scatter_update_dim0 / Transpose / sort_pair_1d; every arithmetic step is a launcher
+of the C ABI -- there is no CPU or torch fallback for those."""
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class Fp8BlockMoE:
+    """experts: stacked FP8 block weights -- w_in / w_gated (E, dim_ff, dim_model) uint8 with scales (E, ceil(dim_ff / 128), dim_model / 128)
+    fp32, w_out (E, dim_model, dim_ff) with scales (E, ceil(dim_model / 128), dim_ff / 128); router (E, dim_model) in the activation dtype."""
+
+    def __init__(self, router, w_in, s_in, w_gated, s_gated, w_out, s_out, top_k, norm_topk_prob=True, routed_scaling_factor=1.0,
+                 scoring_func="softmax", n_group=1, topk_group=1, e_score_correction_bias: Optional[torch.Tensor] = None, act="silu",
+                 block_m=64):
+        self.router, self.top_k = router, top_k
+        self.w_in, self.s_in, self.w_gated, self.s_gated, self.w_out, self.s_out = w_in, s_in, w_gated, s_gated, w_out, s_out
+        self.num_experts = w_in.shape[0]
+        self.norm_topk_prob, self.routed_scaling_factor, self.scoring_func = norm_topk_prob, routed_scaling_factor, scoring_func
+        self.n_group, self.topk_group, self.bias, self.act, self.block_m = n_group, topk_group, e_score_correction_bias, act, block_m
+        if w_in.shape != w_gated.shape or w_out.shape[1] != w_in.shape[2] or w_out.shape[2] != w_in.shape[1]:
+            raise ops.ZLError("Fp8BlockMoE: expert weight shapes do not form in / gated / out projections")
+
+    def route(self, x):
+        """(ids (T, k) int32, weights (T, k) fp32, all_loads (E + 1,) int32: tokens per expert | per rank) -- FeedForward::route"""
+        logits = ops.gemm_nt(x, self.router)
+        all_loads = torch.zeros(self.num_experts + 1, dtype=torch.int32, device=x.device)
+        expert_load, worker_load = all_loads[:self.num_experts], all_loads[self.num_experts:]
+        if self.topk_group > 1:
+            w, ids = ops.moe_group_topk(logits, self.bias, self.n_group, self.topk_group, self.top_k, norm_topk_prob=self.norm_topk_prob,
+                                        weight_scale=self.routed_scaling_factor, scoring_func=self.scoring_func, worker_load=worker_load,
+                                        expert_load=expert_load, num_worker=1)
+        else:
+            w, ids = ops.moe_top_k_softmax(logits, self.top_k, norm_topk_prob=self.norm_topk_prob, weight_scale=self.routed_scaling_factor,
+                                           scoring_func=self.scoring_func, worker_load=worker_load, expert_load=expert_load, num_worker=1)
+        return ids, w, all_loads
+
+    def forward(self, x):
+        """x (T, dim_model) fp16 / bf16 -> (T, dim_model): FeedForward::forward_gpu_dispatch"""
+        if x.dim() != 2 or x.dtype not in (torch.float16, torch.bfloat16):
+            raise ops.ZLError("Fp8BlockMoE: (tokens, dim_model) half or bfloat16 rows")
+        tokens, dim = x.shape
+        e, k = self.num_experts, self.top_k
+        ids, weights, all_loads_t = self.route(x)
+        all_loads = all_loads_t.cpu().tolist()                               # (the reference's to_vector: the one host sync of the flow)
+        m_indices, padded_idx, total = ops.moe_fill_m_indices_padded_indices(all_loads, self.block_m, e, x.device)
+        if total == 0:
+            return torch.zeros_like(x)
+        # (token, slot) pairs sorted by expert, stable: sorted position j holds pair order[j]; its token is order[j] // k
+        order = torch.sort(ids.reshape(-1), stable=True).indices.to(torch.int32)
+        rev = ops.moe_calc_reverse_idx(ids, order, all_loads, e)
+        sorted_tokens = torch.div(order, k, rounding_mode="floor").long()
+        # grouped input: codes and 1x128 scales of the sorted tokens at the 64-aligned positions, padding rows zero
+        a8, sa = ops.fp8_per_token_cast(x, scale_col_major=False)
+        pos = padded_idx.long()
+        g8 = torch.zeros((total, dim), dtype=torch.uint8, device=x.device)
+        g8[pos] = a8[sorted_tokens]
+        gs = torch.zeros((total, dim // 128), dtype=torch.float32, device=x.device)
+        gs[pos] = sa[:tokens][sorted_tokens]
+        gs_t = gs.t().contiguous()                                            # (dim / 128, total): column-major scales, aligned_m = total
+        w0 = ops.fp8_block_gemm(g8, gs_t, self.w_in, self.s_in, m_indices=m_indices, dtype=x.dtype)
+        w1 = ops.fp8_block_gemm(g8, gs_t, self.w_gated, self.s_gated, m_indices=m_indices, dtype=x.dtype)
+        ops.gate_mul(w0, w1, self.act)
+        b8, sb = ops.fp8_per_token_cast(w0)                                   # Fp8Block::quant_input of the grouped rows (total % 4 == 0)
+        w2 = ops.fp8_block_gemm(b8, sb, self.w_out, self.s_out, m_indices=m_indices, dtype=x.dtype)
+        # each expert's run of w2 (global expert order, 64-aligned starts), then the weighted combine
+        parts, off = [], 0
+        for exp in range(e):
+            n = all_loads[exp]
+            parts.append(w2[off:off + n] if n > 0 else None)
+            off += (n + self.block_m - 1) // self.block_m * self.block_m
+        return ops.moe_sum_experts_arr(parts, ids.reshape(-1), rev, weights)
+
+    def forward_per_token(self, x):
+        """the same sum written token by token and slot by slot (Fp8Block::forward per expert on one row) -- what the grouped flow
+        must reproduce bit for bit; used by the tests"""
+        tokens, dim = x.shape
+        ids, weights, _ = self.route(x)
+        rows = []
+        for t, row_ids in enumerate(ids.cpu().tolist()):
+            xt = x[t:t + 1]
+            for exp in row_ids:
+                h0 = ops.fp8_block_linear(xt, self.w_in[exp], self.s_in[exp])
+                h1 = ops.fp8_block_linear(xt, self.w_gated[exp], self.s_gated[exp])
+                ops.gate_mul(h0, h1, self.act)
+                rows.append(ops.fp8_block_linear(h0, self.w_out[exp], self.s_out[exp]))
+        y = torch.cat(rows, dim=0)
+        pos = torch.arange(tokens * self.top_k, dtype=torch.int32, device=x.device)
+        return ops.moe_sum_experts(y, pos, weights)
