@@ -376,7 +376,9 @@ def test_moe_feed_forward_flow_equals_the_per_token_sum(dev, tokens, router, dty
                       codes(e, ff, dim), scales(e, ff // 128, dim // 128), codes(e, dim, ff), scales(e, dim // 128, ff // 128), top_k=k,
                       scoring_func="sigmoid" if router == "group" else "softmax", n_group=4 if router == "group" else 1,
                       topk_group=2 if router == "group" else 1, routed_scaling_factor=2.5 if router == "group" else 1.0,
-                      e_score_correction_bias=(torch.randn(e, generator=g) * 0.1).to(dev) if router == "group" else None)
+                      e_score_correction_bias=(torch.randn(e, generator=g) * 0.1).to(dev) if router == "group" else None,
+                      shared=(codes(2 * ff, dim), scales(2 * ff // 128, dim // 128), codes(2 * ff, dim), scales(2 * ff // 128, dim // 128),
+                              codes(dim, 2 * ff), scales(dim // 128, 2 * ff // 128)) if router == "group" else None)   # DeepSeek: + a shared expert
     x = torch.randn(tokens, dim, generator=g).to(dtype).to(dev)
     ids, w, loads = moe.route(x)
     assert int(loads[:e].sum()) == tokens * k and bool((ids >= 0).all()) and bool((ids < e).all())
@@ -384,3 +386,7 @@ def test_moe_feed_forward_flow_equals_the_per_token_sum(dev, tokens, router, dty
     want = moe.forward_per_token(x)
     assert got.shape == (tokens, dim) and torch.isfinite(got.float()).all() and float(got.float().abs().max()) > 0
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    if router == "group":                                                      # the shared expert is really in the sum
+        routed, moe.shared = moe.shared, None
+        assert not torch.equal(moe.forward(x), got)
+        moe.shared = routed

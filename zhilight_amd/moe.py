@@ -10,11 +10,12 @@ forward_gpu_dispatch), strung together from the C-ABI launchers of zhilight_amd/
     grouped input: per-token 1x128 cast, rows and scales scattered to the 64-aligned runs     -> zl_fp8_per_token_cast + row moves
     w0, w1 = grouped GEMMs (in, gated); w0 = act(w0) * w1; w2 = grouped GEMM (out)            -> zl_fp8_block_gemm_group, zl_gate_mul
     y[token] = sum_slot weight * w2[run(expert) + rev]   sum_experts (per-expert inputs)       -> zl_moe_sum_experts_arr
+    y += shared_expert(x)                                with_share (:483-492)                 -> zl_fp8_block_gemm_group x3, zl_element_add_scale
 
-One rank, no shared experts (expert / data parallel modes and route_shared_lb are wired in ops but not in this flow yet).  Row moves
-(gather of the sorted tokens, scatter into the padded layout, the scale transpose) and the sort are device-memory plumbing done with
-torch indexing, like the reference's functions::scatter_update_dim0 / Transpose / sort_pair_1d; every arithmetic step is a launcher
-of the C ABI -- there is no CPU or torch fallback for those."""
+One rank; the shared expert is the static one (expert / data parallel modes and the load-balanced shared experts of route_shared_lb
+are wired in ops but not in this flow yet).  Row moves (gather of the sorted tokens, scatter into the padded layout, the scale
+transpose) and the sort are device-memory plumbing done with torch indexing, like the reference's functions::scatter_update_dim0 /
+Transpose / sort_pair_1d; every arithmetic step is a launcher of the C ABI -- there is no CPU or torch fallback for those."""
 from typing import Optional
 
 import torch
@@ -28,12 +29,14 @@ class Fp8BlockMoE:
 
     def __init__(self, router, w_in, s_in, w_gated, s_gated, w_out, s_out, top_k, norm_topk_prob=True, routed_scaling_factor=1.0,
                  scoring_func="softmax", n_group=1, topk_group=1, e_score_correction_bias: Optional[torch.Tensor] = None, act="silu",
-                 block_m=64):
+                 block_m=64, shared=None):
+        """shared: None or (w_in (ff_s, dim), s_in, w_gated, s_gated, w_out (dim, ff_s), s_out) of the always-on shared expert"""
         self.router, self.top_k = router, top_k
         self.w_in, self.s_in, self.w_gated, self.s_gated, self.w_out, self.s_out = w_in, s_in, w_gated, s_gated, w_out, s_out
         self.num_experts = w_in.shape[0]
         self.norm_topk_prob, self.routed_scaling_factor, self.scoring_func = norm_topk_prob, routed_scaling_factor, scoring_func
         self.n_group, self.topk_group, self.bias, self.act, self.block_m = n_group, topk_group, e_score_correction_bias, act, block_m
+        self.shared = shared
         if w_in.shape != w_gated.shape or w_out.shape[1] != w_in.shape[2] or w_out.shape[2] != w_in.shape[1]:
             raise ops.ZLError("Fp8BlockMoE: expert weight shapes do not form in / gated / out projections")
 
@@ -51,6 +54,16 @@ class Fp8BlockMoE:
                                            scoring_func=self.scoring_func, worker_load=worker_load, expert_load=expert_load, num_worker=1)
         return ids, w, all_loads
 
+    def with_share(self, x, ret):
+        """FeedForward::with_share (feedforward.cpp:483-492): ret + shared_expert(x) when there is a static shared expert"""
+        if self.shared is None:
+            return ret
+        w_in, s_in, w_gated, s_gated, w_out, s_out = self.shared
+        h0 = ops.fp8_block_linear(x, w_in, s_in)
+        h1 = ops.fp8_block_linear(x, w_gated, s_gated)
+        ops.gate_mul(h0, h1, self.act)
+        return ops.element_add_scale(ret, ops.fp8_block_linear(h0, w_out, s_out), 1.0)
+
     def forward(self, x):
         """x (T, dim_model) fp16 / bf16 -> (T, dim_model): FeedForward::forward_gpu_dispatch"""
         if x.dim() != 2 or x.dtype not in (torch.float16, torch.bfloat16):
@@ -61,7 +74,7 @@ class Fp8BlockMoE:
         all_loads = all_loads_t.cpu().tolist()                               # (the reference's to_vector: the one host sync of the flow)
         m_indices, padded_idx, total = ops.moe_fill_m_indices_padded_indices(all_loads, self.block_m, e, x.device)
         if total == 0:
-            return torch.zeros_like(x)
+            return self.with_share(x, torch.zeros_like(x))
         # (token, slot) pairs sorted by expert, stable: sorted position j holds pair order[j]; its token is order[j] // k
         order = torch.sort(ids.reshape(-1), stable=True).indices.to(torch.int32)
         rev = ops.moe_calc_reverse_idx(ids, order, all_loads, e)
@@ -85,7 +98,7 @@ class Fp8BlockMoE:
             n = all_loads[exp]
             parts.append(w2[off:off + n] if n > 0 else None)
             off += (n + self.block_m - 1) // self.block_m * self.block_m
-        return ops.moe_sum_experts_arr(parts, ids.reshape(-1), rev, weights)
+        return self.with_share(x, ops.moe_sum_experts_arr(parts, ids.reshape(-1), rev, weights))
 
     def forward_per_token(self, x):
         """the same sum written token by token and slot by slot (Fp8Block::forward per expert on one row) -- what the grouped flow
@@ -102,4 +115,4 @@ class Fp8BlockMoE:
                 rows.append(ops.fp8_block_linear(h0, self.w_out[exp], self.s_out[exp]))
         y = torch.cat(rows, dim=0)
         pos = torch.arange(tokens * self.top_k, dtype=torch.int32, device=x.device)
-        return ops.moe_sum_experts(y, pos, weights)
+        return self.with_share(x, ops.moe_sum_experts(y, pos, weights))
