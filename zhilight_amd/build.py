@@ -54,6 +54,7 @@ def build(force=False, verbose=False):
     build_hostcpp(force, verbose)
     build_comm(force, verbose)
     build_refcompile(force, verbose)
+    build_refcheck(force, verbose)
     return OUT
 
 
@@ -114,6 +115,11 @@ REFDIR = os.path.join(HERE, "_ref")
 # reference host translation units compiled UNMODIFIED, from where they lie, against hostcpp/refshim + the bmengine-on-HIP
 # headers ("prove the boundary compiles the reference")
 REF_TUS = ("src/nn/linear/linear.cpp",)
+# reference translation units that are compiled unmodified and LINK-CHECKED only (build_refcheck): every name they reference in the
+# namespaces the boundary stands in for must be defined by the boundary under the same mangled name -- i.e. with the reference's
+# exact signature; names of layers that are not on the path (their device code lives in the reference's .cu files) are listed
+REF_CHECK_TUS = ("src/nn/attention/multi_head_latent_attention.cpp",)
+REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_op::")
 
 
 def refcompile_target():
@@ -181,6 +187,63 @@ def build_refcompile(force=False, verbose=False):
         demangled = subprocess.run(["c++filt"], input="\n".join(missing), text=True, capture_output=True).stdout
         raise RuntimeError("the reference translation unit needs names the boundary does not define:\n" + demangled)
     return target
+
+
+def refcheck_report():
+    return os.path.join(REFDIR, "linkcheck.json")
+
+
+def build_refcheck(force=False, verbose=False):
+    """Compile REF_CHECK_TUS in place against hostcpp/refshim and compare what they reference with what the boundary defines
+    (libzhilight_amd.so + the hostcpp layer inside the zl_reflinear module).  Writes zhilight_amd/_ref/linkcheck.json:
+    {tu: {"resolved": [...], "outside": [...]}} (demangled); raises when a name in REF_CHECK_NAMESPACES is not defined -- a
+    signature that drifted from the reference's.  Only where the reference tree exists; returns the report path or None."""
+    import json
+    import pybind11
+    import sysconfig
+    report = refcheck_report()
+    tus = [os.path.join(REFERENCE, t) for t in REF_CHECK_TUS]
+    module = build_refcompile(verbose=verbose)
+    if module is None or not all(os.path.exists(t) for t in tus):
+        return report if os.path.exists(report) else None
+    shim = os.path.join(HOSTCPP, "refshim")
+    deps = tus + [module, os.path.abspath(__file__)]
+    for root, _, files in os.walk(shim):
+        deps += [os.path.join(root, f) for f in files]
+    if not (force or _stale(report, deps)):
+        return report
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    inc = ["-I" + shim, "-I" + HOSTCPP, "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(HERE, "..", "include"),
+           "-I" + os.path.join(REFERENCE, "src"), "-I" + REFERENCE, "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
+    common = [os.environ.get("CXX", "g++"), "-O1", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DENABLE_DS_DEEP_GEMM", "-w"] + inc
+    have = set()
+    for lib in (OUT, module, os.path.join(rocm, "lib", "libamdhip64.so")):
+        for line in subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True).splitlines():
+            have.add(line.split()[-1])
+    out, drifted = {}, []
+    for rel, src in zip(REF_CHECK_TUS, tus):
+        obj = os.path.join(REFDIR, os.path.basename(src).rsplit(".", 1)[0] + ".check.o")
+        cmd = common + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        syms = [line.split()[-1] for line in subprocess.check_output(["nm", "-u", obj], text=True).splitlines()]
+        os.remove(obj)
+        names = subprocess.run(["c++filt"], input="\n".join(syms), text=True, capture_output=True).stdout.splitlines()
+        resolved, outside = [], []
+        for sym, name in zip(syms, names):
+            if sym == name:                                       # C symbols: libc / libm / the HIP runtime (versioned there)
+                continue
+            if name.startswith(("std::", "operator ", "vtable for", "typeinfo for", "VTT for", "__")):
+                continue
+            (resolved if sym in have else outside).append(name)
+        drifted += [n for n in outside if n.startswith(REF_CHECK_NAMESPACES)]
+        out[rel] = {"resolved": sorted(resolved), "outside": sorted(outside)}
+    if drifted:
+        raise RuntimeError("reference call sites name boundary functions the boundary does not define with that signature:\n" + "\n".join(drifted))
+    with open(report, "w") as f:
+        json.dump(out, f, indent=1)
+    return report
 
 
 if __name__ == "__main__":

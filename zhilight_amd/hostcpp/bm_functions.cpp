@@ -265,6 +265,34 @@ Tensor slice_last_dim(const Context& ctx, const Tensor& tensor, int from, int le
                         st_of(ctx)), "slice_last_dim");
     return out;
 }
+void copy_last_dim(hipStream_t stream, const Tensor& input, Tensor& output, int from, int to, bool padding_zero) {
+    BM_ASSERT_EQ(input.dtype(), output.dtype(), "type mismatch");
+    BM_ASSERT_EQ(input.ndim(), output.ndim(), "rank mismatch");
+    BM_ASSERT(input.is_continuous() && output.is_continuous() && from >= 0, "copy_last_dim: dense tensors");
+    const size_t width = output.size(-1), in_w = input.size(-1), rows = output.numel() / width;
+    BM_ASSERT_EQ(rows, input.numel() / in_w, "copy_last_dim: row count mismatch");
+    if (to == -1) to = from + (int)width;
+    if (!padding_zero) BM_ASSERT_LE((size_t)to, in_w, "to out of range");
+    const size_t es = core::get_elem_size(input.dtype());
+    const size_t take = (size_t)from >= in_w ? 0 : std::min(width, in_w - from);      // columns that exist in the input
+    if (take < width) BM_HIPRT_ASSERT(hipMemsetAsync(output.data(), 0, output.nbytes(), stream));
+    if (take) zl_check(zl_copy_2d((const char*)input.data() + from * es, in_w * es, output.data(), width * es, take * es, rows, (zl_stream_t)stream),
+                       "copy_last_dim");
+}
+Tensor concat_broadcast_b(const Context& ctx, const Tensor& A, const Tensor& B) {
+    BM_ASSERT_EQ(A.ndim(), 3, "");
+    BM_ASSERT_EQ(B.ndim(), 2, "");
+    BM_ASSERT_EQ(A.size(0), B.size(0), "");
+    BM_ASSERT_EQ(A.dtype(), B.dtype(), "type mismatch");
+    BM_ASSERT(A.is_continuous() && B.is_continuous(), "concat_broadcast_b: dense tensors");
+    const size_t L = A.size(0), M = A.size(1), pa = A.size(2), pb = B.size(1), pc = pa + pb, es = core::get_elem_size(A.dtype());
+    Tensor out = ctx.tensor({L, M, pc}, A.dtype());
+    zl_check(zl_copy_2d(A.data(), pa * es, out.data(), pc * es, pa * es, L * M, st_of(ctx)), "concat_broadcast_b");
+    // B's row l under every m: out viewed as (L, M * pc), the row's pb columns at offset m * pc + pa -- one strided copy per m
+    for (size_t m = 0; m < M; ++m)
+        zl_check(zl_copy_2d(B.data(), pb * es, (char*)out.data() + (m * pc + pa) * es, M * pc * es, pb * es, L, st_of(ctx)), "concat_broadcast_b");
+    return out;
+}
 Tensor index_select(const Context& ctx, const Tensor& input, int dim, const Tensor& index, Tensor* out) {
     BM_ASSERT_EQ(index.dtype(), DataType::kInt32, "index_select: int32 index");
     BM_ASSERT_EQ(index.ndim(), 1, "index_select: 1-d index");

@@ -62,6 +62,11 @@ core::Tensor stack_tensor(const core::Context& ctx, const std::vector<core::Tens
 core::Tensor index_select(const core::Context& ctx, const core::Tensor& input, int dim, const core::Tensor& index,
                           core::Tensor* out = nullptr);
 core::Tensor slice_last_dim(const core::Context& ctx, const core::Tensor& tensor, int from, int len, core::Tensor* out_ptr = nullptr);
+// index_select.h:32-39: output[..., i] = input[..., from + i] for i < output.size(-1); columns past the input's width are zero
+// when padding_zero (otherwise `to` = from + output.size(-1) must lie inside the input)
+void copy_last_dim(hipStream_t stream, const core::Tensor& input, core::Tensor& output, int from, int to = -1, bool padding_zero = false);
+// tensor_ops.h:13-14: C[l, m, :] = [A[l, m, :] | B[l, :]] for A (L, M, a), B (L, b)
+core::Tensor concat_broadcast_b(const core::Context& ctx, const core::Tensor& A, const core::Tensor& B);
 core::Tensor reduce_abs_max(const core::Context& ctx, const core::Tensor& a, int dim = 0);
 void zeros_(const core::Context& ctx, const core::Tensor& x);
 void ones_(const core::Context& ctx, const core::Tensor& x);

@@ -339,6 +339,7 @@ public:
     std::shared_ptr<Pool> pool;                      // shared with the tensors it handed out
     Stream stream;
     Context::ReduceHook reduce;
+    MemoryAllocator cache_arena;
     long next_id = 0;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -455,6 +456,17 @@ Tensor Context::reduce_sum(Tensor& data, DataType out_type) const {
     }
     return data;
 }
+
+Tensor Context::reduce_scatter(const Tensor& data) const {
+    BM_ASSERT(pimpl->world == 1, "reduce_scatter: this context owns no communicator for it (the decode path reduces with reduce_sum)");
+    return data;
+}
+Tensor Context::all_gather(const Tensor& data) const {
+    BM_ASSERT(pimpl->world == 1, "all_gather: this context owns no communicator for it (the decode path reduces with reduce_sum)");
+    return data;
+}
+MemoryAllocator* Context::get_cache_allocator() const { return &pimpl->cache_arena; }
+void Context::set_cache_arena(void* base) { pimpl->cache_arena.set_base_ptr(base); }
 
 }  // namespace core
 }  // namespace bmengine

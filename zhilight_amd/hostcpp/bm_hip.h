@@ -95,6 +95,15 @@ typedef std::shared_ptr<Stream_> Stream;
 
 class Context;
 struct Storage;   // ref-counted device (or host) block
+// private/allocator.h:13-66 as far as layer code sees it: the base address of the KV-cache arena
+class MemoryAllocator {
+    void* base_ptr_ = nullptr;
+
+public:
+    explicit MemoryAllocator(void* base = nullptr) : base_ptr_(base) {}
+    char* get_base_ptr() { return (char*)base_ptr_; }
+    void set_base_ptr(void* base) { base_ptr_ = base; }
+};
 
 class Tensor {
 public:
@@ -277,6 +286,13 @@ public:
     typedef std::function<void(Tensor& data, hipStream_t stream)> ReduceHook;
     void set_reduce_hook(ReduceHook h);
     virtual Tensor reduce_sum(Tensor& data, DataType out_type) const;
+    // the other two collectives of context.h:157-159: with one rank the identity; with more they need a communicator this
+    // context does not own (the all-reduce hook above is the only exchange the decode path has) and say so
+    virtual Tensor reduce_scatter(const Tensor& data) const;
+    virtual Tensor all_gather(const Tensor& data) const;
+    // the KV-cache arena's allocator (context.h:121; layer code asks it for the arena's base address only)
+    MemoryAllocator* get_cache_allocator() const;
+    void set_cache_arena(void* base);
 
 private:
     std::unique_ptr<ContextImpl> pimpl;

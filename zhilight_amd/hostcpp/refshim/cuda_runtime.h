@@ -6,6 +6,7 @@
 typedef hipStream_t cudaStream_t;
 typedef hipEvent_t cudaEvent_t;
 typedef hipError_t cudaError_t;
+typedef hipDeviceProp_t cudaDeviceProp;
 typedef __half half;
 #define cudaSuccess hipSuccess
 #define cudaGetErrorString hipGetErrorString
@@ -20,4 +21,6 @@ typedef __half half;
 #define cudaEventCreate hipEventCreate
 #define cudaEventRecord hipEventRecord
 #define cudaEventDestroy hipEventDestroy
+#define cudaEventSynchronize hipEventSynchronize
+#define cudaEventElapsedTime hipEventElapsedTime
 #define cudaStreamWaitEvent hipStreamWaitEvent
