@@ -80,8 +80,8 @@ def build_comm(force=False, verbose=False):
 HOSTCPP = os.path.join(HERE, "hostcpp")
 
 
-HOSTCPP_SOURCES = ("bm_hip.cpp", "bm_layer.cpp", "bm_functions.cpp", "nn_amd.cpp")
-HOSTCPP_HEADERS = ("bm_hip.h", "bm_layer.h", "bm_functions.h", "nn_amd.h")
+HOSTCPP_SOURCES = ("bm_hip.cpp", "bm_layer.cpp", "bm_functions.cpp", "bm_c10d.cpp", "nn_amd.cpp")
+HOSTCPP_HEADERS = ("bm_hip.h", "bm_layer.h", "bm_functions.h", "bm_c10d.h", "nn_amd.h")
 
 
 def hostcpp_target():
@@ -118,8 +118,14 @@ REF_TUS = ("src/nn/linear/linear.cpp",)
 # reference translation units that are compiled unmodified and LINK-CHECKED only (build_refcheck): every name they reference in the
 # namespaces the boundary stands in for must be defined by the boundary under the same mangled name -- i.e. with the reference's
 # exact signature; names of layers that are not on the path (their device code lives in the reference's .cu files) are listed
-REF_CHECK_TUS = ("src/nn/attention/multi_head_latent_attention.cpp",)
-REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_op::")
+REF_CHECK_TUS = ("src/nn/attention/multi_head_latent_attention.cpp", "src/nn/feedforward/feedforward.cpp")
+REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_op::", "nn::top_k_softmax(", "nn::group_topk_softmax(",
+                        "nn::sum_experts(", "nn::route_shared_lb(", "nn::plus_for_sort(", "nn::calc_reverse_idx(",
+                        "nn::fill_m_indices_padded_indices(", "nn::gate_mul_inplace(", "nn::gelu_inplace(", "nn::silu_inplace(")
+# declared by the shim so that the units compile, NOT provided by the boundary yet (bmengine's functions library: device helpers
+# that only the MoE dispatch route uses; zhilight_amd/moe.py does those steps with the framework's indexing): reported as "pending"
+REF_CHECK_PENDING = ("bmengine::functions::arange(", "bmengine::functions::sort_pair_1d(", "bmengine::functions::divide(",
+                     "bmengine::functions::scatter_update_dim0(")
 
 
 def refcompile_target():
@@ -196,8 +202,8 @@ def refcheck_report():
 def build_refcheck(force=False, verbose=False):
     """Compile REF_CHECK_TUS in place against hostcpp/refshim and compare what they reference with what the boundary defines
     (libzhilight_amd.so + the hostcpp layer inside the zl_reflinear module).  Writes zhilight_amd/_ref/linkcheck.json:
-    {tu: {"resolved": [...], "outside": [...]}} (demangled); raises when a name in REF_CHECK_NAMESPACES is not defined -- a
-    signature that drifted from the reference's.  Only where the reference tree exists; returns the report path or None."""
+    {tu: {"resolved": [...], "outside": [...], "pending": [...]}} (demangled); raises when a name in REF_CHECK_NAMESPACES is not
+    defined -- a signature that drifted from the reference's -- unless it is one of REF_CHECK_PENDING.  Only where the reference tree exists; returns the report path or None."""
     import json
     import pybind11
     import sysconfig
@@ -230,15 +236,18 @@ def build_refcheck(force=False, verbose=False):
         syms = [line.split()[-1] for line in subprocess.check_output(["nm", "-u", obj], text=True).splitlines()]
         os.remove(obj)
         names = subprocess.run(["c++filt"], input="\n".join(syms), text=True, capture_output=True).stdout.splitlines()
-        resolved, outside = [], []
+        resolved, outside, pending = [], [], []
         for sym, name in zip(syms, names):
             if sym == name:                                       # C symbols: libc / libm / the HIP runtime (versioned there)
                 continue
             if name.startswith(("std::", "operator ", "vtable for", "typeinfo for", "VTT for", "__")):
                 continue
+            if sym not in have and name.startswith(REF_CHECK_PENDING):
+                pending.append(name)
+                continue
             (resolved if sym in have else outside).append(name)
         drifted += [n for n in outside if n.startswith(REF_CHECK_NAMESPACES)]
-        out[rel] = {"resolved": sorted(resolved), "outside": sorted(outside)}
+        out[rel] = {"resolved": sorted(resolved), "outside": sorted(outside), "pending": sorted(pending)}
     if drifted:
         raise RuntimeError("reference call sites name boundary functions the boundary does not define with that signature:\n" + "\n".join(drifted))
     with open(report, "w") as f:

@@ -2,3 +2,4 @@
 #include "cublas_v2.h"
 #include "bm_hip.h"
 #include "bm_layer.h"
+#include "bmengine/core/exception.h"

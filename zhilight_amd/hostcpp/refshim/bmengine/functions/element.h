@@ -1,2 +1,9 @@
+// refshim: bmengine/functions/element.h.  divide (integer tensor by a float divisor) is DECLARED here so that FeedForward's dispatch
+// route compiles; the boundary does not define it yet (build_refcheck lists it as pending).
 #pragma once
 #include "bm_functions.h"
+namespace bmengine {
+namespace functions {
+core::Tensor divide(const core::Context& ctx, const core::Tensor& a, float divisor);
+}  // namespace functions
+}  // namespace bmengine

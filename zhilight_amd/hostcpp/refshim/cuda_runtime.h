@@ -24,3 +24,7 @@ typedef __half half;
 #define cudaEventSynchronize hipEventSynchronize
 #define cudaEventElapsedTime hipEventElapsedTime
 #define cudaStreamWaitEvent hipStreamWaitEvent
+#define cudaHostAlloc hipHostAlloc
+#define cudaFreeHost hipFreeHost
+#define cudaHostAllocDefault hipHostMallocDefault
+#define cudaHostAllocPortable hipHostMallocPortable
