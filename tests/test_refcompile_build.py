@@ -49,6 +49,29 @@ def test_reference_mla_tu_compiles_and_calls_the_boundary_by_its_own_signatures(
                       "kvcache::copy_to_buffer", "nn::attn_softmax", "nn::attention_qkv_rag_buffer", "nn::copy_to_rag_buffer"}, owners
 
 
+def test_reference_attention_tu_binds_the_decode_hot_path_names():
+    """src/nn/attention/attention.cpp -- NormalImpl::dynamic_batch_forward, the decode hot path itself (SURVEY 8b) -- compiled
+    unmodified: the operators the boundary stands in for (fused-attention kernel, its workspace, rotary variants, KV scatter, the
+    INT8-KV quantiser, Linear, LayerNorm, the bmengine functions it uses) are defined under the reference's signatures; outside stay
+    the classes whose device code is the reference's own (.cu / borrowed libraries)."""
+    import json
+    from zhilight_amd import build
+    build.build()
+    have_reference = all(os.path.exists(os.path.join(build.REFERENCE, t)) for t in build.REF_CHECK_TUS)
+    report = build.build_refcheck() if have_reference else build.refcheck_report()
+    if not (report and os.path.exists(report)):
+        pytest.skip("no reference tree and no prebuilt report")
+    v = json.load(open(report))["src/nn/attention/attention.cpp"]
+    for name in ("nn::multi_query_attention_rag_buffer(", "nn::get_mqa_workspace(", "nn::rope_qk_cache(", "nn::rotary_embedding_qk(",
+                 "nn::copy_to_rag_buffer2(", "int8_op::quant_calc_scale(", "nn::Linear::forward(", "nn::Linear::fuse(", "nn::LayerNorm::forward(",
+                 "bmengine::functions::Gemm::forward(", "bmengine::functions::transpose_2_1(", "bmengine::core::Context::get_allocator("):
+        assert any(n.startswith(name) for n in v["resolved"]), name
+    assert not v["pending"] and not [n for n in v["outside"] if n.startswith(build.REF_CHECK_NAMESPACES)]
+    owners = {n.split("(")[0].rsplit("::", 1)[0] if n.split("(")[0].count("::") > 1 else n.split("(")[0] for n in v["outside"]}
+    assert owners <= {"nn::FlashDecoding", "nn::RotaryEmbedding", "kvcache::TransformerBuffer", "kvcache::copy_to_buffer", "nn::attn_softmax",
+                      "nn::attention_qkv_rag_buffer", "nn::multi_query_self_attention", "nn::Attention::impl"}, owners
+
+
 def test_reference_feedforward_tu_binds_the_router_dispatch_and_fp8_names():
     """The same check on src/nn/feedforward/feedforward.cpp (1 290 lines: dense and MoE feed-forward incl. the dispatch route):
     the router, the dispatch / combine helpers of ff_kernel.h, nn::fp8::per_token_cast_to_fp8, the fused GPTQ MoE GEMVs, the grouped

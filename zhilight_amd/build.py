@@ -118,7 +118,7 @@ REF_TUS = ("src/nn/linear/linear.cpp",)
 # reference translation units that are compiled unmodified and LINK-CHECKED only (build_refcheck): every name they reference in the
 # namespaces the boundary stands in for must be defined by the boundary under the same mangled name -- i.e. with the reference's
 # exact signature; names of layers that are not on the path (their device code lives in the reference's .cu files) are listed
-REF_CHECK_TUS = ("src/nn/attention/multi_head_latent_attention.cpp", "src/nn/feedforward/feedforward.cpp")
+REF_CHECK_TUS = ("src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp", "src/nn/feedforward/feedforward.cpp")
 REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_op::", "nn::top_k_softmax(", "nn::group_topk_softmax(",
                         "nn::sum_experts(", "nn::route_shared_lb(", "nn::plus_for_sort(", "nn::calc_reverse_idx(",
                         "nn::fill_m_indices_padded_indices(", "nn::gate_mul_inplace(", "nn::gelu_inplace(", "nn::silu_inplace(")

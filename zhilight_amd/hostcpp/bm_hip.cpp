@@ -466,6 +466,17 @@ Tensor Context::all_gather(const Tensor& data) const {
     return data;
 }
 MemoryAllocator* Context::get_cache_allocator() const { return &pimpl->cache_arena; }
+MemoryAllocator* Context::get_allocator() const { return &pimpl->cache_arena; }
+size_t MemoryAllocator::get_memory_limit() const {
+    size_t free_b = 0, total_b = 0;
+    BM_HIPRT_ASSERT(hipMemGetInfo(&free_b, &total_b));
+    return total_b;
+}
+size_t MemoryAllocator::used_memory() const {
+    size_t free_b = 0, total_b = 0;
+    BM_HIPRT_ASSERT(hipMemGetInfo(&free_b, &total_b));
+    return total_b - free_b;
+}
 void Context::set_cache_arena(void* base) { pimpl->cache_arena.set_base_ptr(base); }
 
 }  // namespace core

@@ -95,7 +95,9 @@ typedef std::shared_ptr<Stream_> Stream;
 
 class Context;
 struct Storage;   // ref-counted device (or host) block
-// private/allocator.h:13-66 as far as layer code sees it: the base address of the KV-cache arena
+// private/allocator.h:13-66 as far as layer code sees it: the base address of the KV-cache arena (multi_head_latent_attention.cpp:
+// 924-925) and how much device memory is left (attention.cpp:159-170 sizes its KV-head splits of a long prompt by it).  Storage
+// here comes from a size-class pool over hipMalloc, so the numbers are the device's own (hipMemGetInfo).
 class MemoryAllocator {
     void* base_ptr_ = nullptr;
 
@@ -103,6 +105,9 @@ public:
     explicit MemoryAllocator(void* base = nullptr) : base_ptr_(base) {}
     char* get_base_ptr() { return (char*)base_ptr_; }
     void set_base_ptr(void* base) { base_ptr_ = base; }
+    size_t get_memory_limit() const;
+    size_t used_memory() const;
+    size_t get_free_memory() const { return get_memory_limit() - used_memory(); }
 };
 
 class Tensor {
@@ -292,12 +297,21 @@ public:
     virtual Tensor all_gather(const Tensor& data) const;
     // the KV-cache arena's allocator (context.h:121; layer code asks it for the arena's base address only)
     MemoryAllocator* get_cache_allocator() const;
+    MemoryAllocator* get_allocator() const;         // (context.h:120) the same object: one pool serves tensors and caches here
     void set_cache_arena(void* base);
 
 private:
     std::unique_ptr<ContextImpl> pimpl;
     int cur_layer_ = -1, high_precision_ = 0;
     bool bshd_ = true;                               // Python default flash_attention=True (zhilight/dynamic_batch.py:36)
+};
+
+// context.h:189-194: the reference pauses its compacting allocator while raw buffer addresses are in use; tensors here never
+// move (see the header comment), so holding one is free
+class GCStopper {
+public:
+    explicit GCStopper(const Context&) {}
+    ~GCStopper() {}
 };
 
 }  // namespace core
