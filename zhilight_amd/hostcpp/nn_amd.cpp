@@ -843,6 +843,19 @@ void gate_mul_inplace(const Context& ctx, Tensor& inp, const Tensor& in2, const 
     zl_check(zl_gate_mul(u16(inp), u16(in2), u16m(inp), inp.numel(), gate_type == "gelu", zdt(inp.dtype()), st_of(ctx)), "gate_mul");
 }
 
+Tensor gate_fuse(const Context& ctx, const Tensor& input, const std::string& act_fn_type) {
+    if (act_fn_type != "silu" && act_fn_type != "gelu") throw std::logic_error(act_fn_type + " activation is not supported");
+    BM_ASSERT(input.is_continuous() && input.size(-1) % 2 == 0, "gate_fuse: dense (..., 2 * dim_ff) input");
+    const size_t ff = input.size(-1) / 2, rows = input.numel() / input.size(-1), es = core::get_elem_size(input.dtype());
+    std::vector<size_t> shape = input.shape();
+    shape.back() = ff;
+    Tensor x = ctx.tensor(shape, input.dtype()), y = ctx.tensor(shape, input.dtype());
+    zl_check(zl_copy_2d(input.data(), 2 * ff * es, x.data(), ff * es, ff * es, rows, st_of(ctx)), "gate_fuse");
+    zl_check(zl_copy_2d((const char*)input.data() + ff * es, 2 * ff * es, y.data(), ff * es, ff * es, rows, st_of(ctx)), "gate_fuse");
+    zl_check(zl_gate_mul(u16(x), u16(y), u16m(x), x.numel(), act_fn_type == "gelu", zdt(x.dtype()), st_of(ctx)), "gate_fuse");
+    return x;
+}
+
 // ---- RMSNorm -------------------------------------------------------------------------------------------------------
 LayerNorm::LayerNorm(const Context&, int dim_model, bool, float eps, float scale, DataType dtype, int)
     : dim_model_(dim_model), eps_(eps), scale_(scale), dtype_(dtype) {}

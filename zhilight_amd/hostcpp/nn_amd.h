@@ -209,6 +209,9 @@ core::Tensor element_add_scale(const core::Context& ctx, const core::Tensor& a, 
 void element_add_scale_out(const core::Context& ctx, const core::Tensor& a, const core::Tensor& b, core::Tensor& c, float scale,
                            bool scale_residual = true);
 void gate_mul_inplace(const core::Context& ctx, core::Tensor& inp, const core::Tensor& in2, const std::string& gate_type);
+// ff_kernel.h:10-14 (ff_kernel.cu:33-78): input (..., 2 * dim_ff) = [in | gated] of a fused projection -> act(in) * gated, the arithmetic
+// of gate_mul_inplace (act in fp32, one rounding to T).  Two strided copies split the halves, then the same launch.
+core::Tensor gate_fuse(const core::Context& ctx, const core::Tensor& input, const std::string& act_fn_type);
 
 // ---- RMSNorm layer -------------------------------------------------------------------------------------------------
 class LayerNorm {

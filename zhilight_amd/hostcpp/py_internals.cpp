@@ -236,6 +236,7 @@ PYBIND11_MODULE(zl_internals, m) {
             nn::gate_mul_inplace(*c.ctx, ta, c.up(b), act);
             return c.down(ta, "float16");
         })
+        .def("gate_fuse", [](PyCtx& c, py::array a, std::string act) { return c.down(nn::gate_fuse(*c.ctx, c.up(a), act), "float16"); })
         // ---- int8
         .def("quant_calc_scale", [](PyCtx& c, py::array x) {
             Tensor q = int8_op::quant_calc_scale(*c.ctx, c.up(x));
