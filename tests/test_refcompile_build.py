@@ -46,7 +46,7 @@ def test_reference_mla_tu_compiles_and_calls_the_boundary_by_its_own_signatures(
     assert not [n for n in outside if n.startswith(build.REF_CHECK_NAMESPACES)]
     owners = {n.split("(")[0].rsplit("::", 1)[0] if n.split("(")[0].count("::") > 1 else n.split("(")[0] for n in outside}
     assert owners <= {"nn::FlashDecoding", "nn::RotaryEmbedding", "nn::LayerNorm", "model::ModelContext", "kvcache::TransformerBuffer",
-                      "kvcache::copy_to_buffer", "nn::attn_softmax", "nn::attention_qkv_rag_buffer", "nn::copy_to_rag_buffer"}, owners
+                      "kvcache::copy_to_buffer", "nn::attn_softmax", "nn::copy_to_rag_buffer"}, owners
 
 
 def test_reference_attention_tu_binds_the_decode_hot_path_names():
@@ -62,14 +62,14 @@ def test_reference_attention_tu_binds_the_decode_hot_path_names():
     if not (report and os.path.exists(report)):
         pytest.skip("no reference tree and no prebuilt report")
     v = json.load(open(report))["src/nn/attention/attention.cpp"]
-    for name in ("nn::multi_query_attention_rag_buffer(", "nn::get_mqa_workspace(", "nn::rope_qk_cache(", "nn::rotary_embedding_qk(",
+    for name in ("nn::multi_query_attention_rag_buffer(", "nn::attention_qkv_rag_buffer(", "nn::get_mqa_workspace(", "nn::rope_qk_cache(", "nn::rotary_embedding_qk(",
                  "nn::copy_to_rag_buffer2(", "int8_op::quant_calc_scale(", "nn::Linear::forward(", "nn::Linear::fuse(", "nn::LayerNorm::forward(",
                  "bmengine::functions::Gemm::forward(", "bmengine::functions::transpose_2_1(", "bmengine::core::Context::get_allocator("):
         assert any(n.startswith(name) for n in v["resolved"]), name
     assert not v["pending"] and not [n for n in v["outside"] if n.startswith(build.REF_CHECK_NAMESPACES)]
     owners = {n.split("(")[0].rsplit("::", 1)[0] if n.split("(")[0].count("::") > 1 else n.split("(")[0] for n in v["outside"]}
     assert owners <= {"nn::FlashDecoding", "nn::RotaryEmbedding", "kvcache::TransformerBuffer", "kvcache::copy_to_buffer", "nn::attn_softmax",
-                      "nn::attention_qkv_rag_buffer", "nn::multi_query_self_attention", "nn::Attention::impl"}, owners
+                      "nn::multi_query_self_attention", "nn::Attention::impl"}, owners
 
 
 def test_reference_feedforward_tu_binds_the_router_dispatch_and_fp8_names():

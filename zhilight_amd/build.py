@@ -121,7 +121,9 @@ REF_TUS = ("src/nn/linear/linear.cpp",)
 REF_CHECK_TUS = ("src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp", "src/nn/feedforward/feedforward.cpp")
 REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_op::", "nn::top_k_softmax(", "nn::group_topk_softmax(",
                         "nn::sum_experts(", "nn::route_shared_lb(", "nn::plus_for_sort(", "nn::calc_reverse_idx(",
-                        "nn::fill_m_indices_padded_indices(", "nn::gate_mul_inplace(", "nn::gate_fuse(", "nn::gelu_inplace(", "nn::silu_inplace(")
+                        "nn::fill_m_indices_padded_indices(", "nn::gate_mul_inplace(", "nn::gate_fuse(", "nn::gelu_inplace(", "nn::silu_inplace(",
+                        "nn::attention_qkv_rag_buffer(", "nn::multi_query_attention_rag_buffer(", "nn::get_mqa_workspace(", "nn::rope_qk_cache(",
+                        "nn::rotary_embedding_qk(", "nn::copy_to_rag_buffer2(")
 # declared by the shim so that the units compile, NOT provided by the boundary yet (bmengine's functions library: device helpers
 # that only the MoE dispatch route uses; zhilight_amd/moe.py does those steps with the framework's indexing): reported as "pending"
 REF_CHECK_PENDING = ("bmengine::functions::arange(", "bmengine::functions::sort_pair_1d(", "bmengine::functions::divide(",

@@ -803,6 +803,16 @@ void multi_query_attention_rag_buffer(const Context& ctx, const Tensor& batch_q,
              "multi_query_attention_rag_buffer");
 }
 
+void attention_qkv_rag_buffer(const Context& ctx, const Tensor& batch_q, const Tensor& buf_lens, const Tensor& key_buf_addrs,
+                              const Tensor& val_buf_addrs, const Tensor& mask, const Tensor& position_bias, float scale, int max_len_buf,
+                              Tensor& output) {
+    BM_ASSERT_EQ(batch_q.ndim(), 4, "batch_q is not 4d");
+    BM_ASSERT(position_bias.numel() == 0, "attention_qkv_rag_buffer: position_bias is not on this path");
+    BM_ASSERT(batch_q.size(-1) == 128 || batch_q.size(-1) == 64, "dim_head mismatch");
+    BM_ASSERT(batch_q.shape() == output.shape(), "shape mismatch");
+    multi_query_attention_rag_buffer(ctx, batch_q, buf_lens, key_buf_addrs, val_buf_addrs, mask, scale, max_len_buf, output, /*m_query=*/1);
+}
+
 // ---- rotary / scatter / element-wise -------------------------------------------------------------------------------
 void rotary_embedding_qk(const Context& ctx, const Tensor& pos, const Tensor& in, Tensor& out_q, Tensor& out_k, Tensor& out_v,
                          size_t num_heads, size_t num_kv_heads, size_t dim_head, float rope_theta, DataType dtype) {

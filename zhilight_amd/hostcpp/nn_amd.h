@@ -181,6 +181,11 @@ struct AttentionWorkspace {
 };
 AttentionWorkspace get_mqa_workspace(const core::Context& ctx, const core::Tensor& batch_q, int max_len_buf, bool is_quantized);
 
+// attention_kernel.h:39-50 (attention_kernel.cu:1150-1213): every query head has its own kv head -- the same launcher with one
+// query head per kv head.  position_bias (ALiBi-style models) and the 192 / 128 MLA head shape are not on this path: refused.
+void attention_qkv_rag_buffer(const core::Context& ctx, const core::Tensor& batch_q, const core::Tensor& buf_lens,
+                              const core::Tensor& key_buf_addrs, const core::Tensor& val_buf_addrs, const core::Tensor& mask,
+                              const core::Tensor& position_bias, float scale, int max_len_buf, core::Tensor& output);
 void multi_query_attention_rag_buffer(const core::Context& ctx,
                                       const core::Tensor& batch_q,        // (batch, len_q, num_kv_heads * m_query, dim_head)
                                       const core::Tensor& buf_lens,       // (batch)
