@@ -4,7 +4,6 @@ with the first setting's (settings that only move bytes earlier must not change 
 usage: python tools/ubench/step_variants.py "ZL_W4_L2_HINT=0" "ZL_W4_L2_HINT=1" "ZL_W4_L2_HINT=3" ..."""
 import os
 import sys
-import time
 
 import torch
 
