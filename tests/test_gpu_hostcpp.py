@@ -157,9 +157,16 @@ def test_rope_scatter_norm_elementwise_through_cpp(cx, oracle):
     assert np.array_equal(ssum.view(np.uint16), rsum)
     assert np.array_equal(cx.element_add_scale(xx, yy, 0.5, True).view(np.uint16), oracle.element_add_scale(oracle.h2u(xx), oracle.h2u(yy), 0.5, True))
     assert synth.ulp_diff_f16(cx.gate_mul(xx, yy, "silu").view(np.uint16), oracle.silu_mul(oracle.h2u(xx), oracle.h2u(yy))).max() <= 1
-    # gate_fuse (ff_kernel.h:10): the same arithmetic on the two halves of a fused (rows, 2 * dim_ff) projection
-    fused = np.ascontiguousarray(np.concatenate([xx, yy], axis=1))
-    assert np.array_equal(cx.gate_fuse(fused, "silu").view(np.uint16), cx.gate_mul(xx, yy, "silu").view(np.uint16))
+
+
+def test_gate_fuse_is_gate_mul_on_the_two_halves(cx):
+    """nn::gate_fuse (ff_kernel.h:10, ff_kernel.cu:33-78): act(in) * gated on the halves of a fused (rows, 2 * dim_ff) projection --
+    the bits of gate_mul_inplace on the separate halves, for both activations and a ragged row count"""
+    rng = np.random.default_rng(5)
+    for rows, ff, act in ((4, 4096, "silu"), (3, 1536, "gelu"), (1, 14336, "silu")):
+        xx, yy = synth.act(rng, rows, ff, 2.0), synth.act(rng, rows, ff)
+        fused = np.ascontiguousarray(np.concatenate([xx, yy], axis=1))
+        assert np.array_equal(cx.gate_fuse(fused, act).view(np.uint16), cx.gate_mul(xx, yy, act).view(np.uint16))
 
 
 def test_int8_route_through_cpp_is_bit_exact(cx, oracle):
