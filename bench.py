@@ -245,6 +245,21 @@ def extra_decode_run(model, cfg, batch, seq, steps, warmup, dev, int8):
             "roofline": roof}
 
 
+def config5_leg(timeout_s=180):
+    """row f4 numbers (MLA decode attention, FP8 block GEMM) from tools/bench_config5.py in a CHILD process: whatever happens there
+    -- an exception, a fault, a hang -- costs this field only, never the headline line"""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_config5.py")
+    try:
+        r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout).strip().splitlines()[-1][:200] if (r.stderr or r.stdout).strip() else "")}
+        return json.loads(lines[-1])
+    except Exception as e:                                  # noqa: BLE001 (timeouts, a missing interpreter, bad JSON: report, do not raise)
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def check_against_oracle(model, batch, dev):
     """Before anything is timed: the weights bench.py generates (directly in the packed ZLW4M layout, never seen by a
     test) are unpacked again (zl_w4m_unpack) and the four W4A16 linears of layer 0 and of the last layer, run through the
@@ -475,6 +490,7 @@ def main():
             "step_hbm_roofline_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
             "other_batches": extras,
+            "config5": config5_leg() if (world == 1 and not args.no_extras and not int8 and tp is None and batch == 1 and not args.layers) else None,
             "oracle_check": None if oracle_check is None else {
                 "what": "layer 0 and last layer, four W4A16 linears each, HIP output vs the CPU oracle's exact product of the "
                         "unpacked (zl_w4m_unpack) bench weights, before the timed region", "max_err_over_max_ref": round(oracle_check, 6)},
