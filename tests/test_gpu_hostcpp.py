@@ -169,6 +169,23 @@ def test_gate_fuse_is_gate_mul_on_the_two_halves(cx):
         assert np.array_equal(cx.gate_fuse(fused, act).view(np.uint16), cx.gate_mul(xx, yy, act).view(np.uint16))
 
 
+def test_functions_copy_last_dim_and_concat_broadcast(cx):
+    """bmengine::functions::copy_last_dim (index_select.h:32-39) and concat_broadcast_b (tensor_ops.h:13-14), the two helpers the
+    reference's MLA layer needs beyond the linear layers' set: pure data movement, compared with numpy bit for bit"""
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((3, 5, 192)).astype(np.float16)
+    for width, start, pad in ((64, 0, False), (64, 128, False), (128, 64, False), (96, 160, True), (64, 192, True)):
+        want = np.zeros((3, 5, width), np.float16)
+        take = max(0, min(width, 192 - start))
+        want[..., :take] = a[..., start:start + take]
+        assert np.array_equal(cx.copy_last_dim(a, width, start, pad).view(np.uint16), want.view(np.uint16)), (width, start, pad)
+    with pytest.raises(Exception):
+        cx.copy_last_dim(a, 96, 160, False)                                  # past the input's width without padding_zero
+    b = rng.standard_normal((3, 64)).astype(np.float16)
+    want = np.concatenate([a, np.broadcast_to(b[:, None, :], (3, 5, 64))], axis=-1)
+    assert np.array_equal(cx.concat_broadcast_b(a, b).view(np.uint16), want.view(np.uint16))
+
+
 def test_int8_route_through_cpp_is_bit_exact(cx, oracle):
     """Int8Linear::forward composed from the int8_op:: wrappers: quantised rows, int32 product and the scaled-back
     outputs are bit-identical to the oracle (north_star: bit-exact for INT8 GEMM)."""

@@ -6,6 +6,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include "bm_functions.h"
 #include "nn_amd.h"
 
 namespace py = pybind11;
@@ -237,6 +238,18 @@ PYBIND11_MODULE(zl_internals, m) {
             return c.down(ta, "float16");
         })
         .def("gate_fuse", [](PyCtx& c, py::array a, std::string act) { return c.down(nn::gate_fuse(*c.ctx, c.up(a), act), "float16"); })
+        // ---- bmengine::functions glue the attention layers call (index_select.h:32, tensor_ops.h:13)
+        .def("copy_last_dim", [](PyCtx& c, py::array a, size_t width, int from, bool padding_zero) {
+            Tensor in = c.up(a);
+            std::vector<size_t> shape = in.shape();
+            shape.back() = width;
+            Tensor out = c.ctx->tensor(shape, in.dtype());
+            bmengine::functions::copy_last_dim(c.ctx->current_cuda_stream(), in, out, from, -1, padding_zero);
+            return c.down(out, "float16");
+        })
+        .def("concat_broadcast_b", [](PyCtx& c, py::array a, py::array b) {
+            return c.down(bmengine::functions::concat_broadcast_b(*c.ctx, c.up(a), c.up(b)), "float16");
+        })
         // ---- int8
         .def("quant_calc_scale", [](PyCtx& c, py::array x) {
             Tensor q = int8_op::quant_calc_scale(*c.ctx, c.up(x));
