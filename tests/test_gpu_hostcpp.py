@@ -127,6 +127,24 @@ def test_multi_query_attention_rag_buffer_through_cpp(cx, oracle, b, len_q, lens
     assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
 
 
+def test_attention_qkv_rag_buffer_is_the_one_head_per_kv_head_form(cx, oracle):
+    """nn::attention_qkv_rag_buffer (attention_kernel.h:39-50): every query head owns its kv head -- the same launcher with m_query = 1,
+    checked against the oracle and, bit for bit, against that call"""
+    rng = np.random.default_rng(31)
+    b, len_q, h, d, lens = 2, 2, 16, 128, [96, 70]
+    q = synth.act(rng, b * len_q * h, d).reshape(b, len_q, h, d)
+    kb = [synth.act(rng, L * h, d).reshape(L, h, d) for L in lens]
+    vb = [synth.act(rng, L * h, d).reshape(L, h, d) for L in lens]
+    mask = np.concatenate([(rng.random((len_q, L)) < 0.8).astype(np.int8).reshape(-1) for L in lens])
+    scale = 1.0 / np.sqrt(d)
+    got = cx.attention_qkv_rag_buffer(q, np.asarray(lens, np.int32), kb, vb, mask, scale, max(lens))
+    same = cx.multi_query_attention_rag_buffer(q, np.asarray(lens, np.int32), kb, vb, mask, scale, max(lens), 1)
+    assert np.array_equal(got.view(np.uint16), same.view(np.uint16))
+    ref = oracle.mqa_rag_buffer(oracle.h2u(q), np.asarray(lens, np.int32), [oracle.h2u(a) for a in kb], [oracle.h2u(a) for a in vb], mask,
+                                h, scale, True, exact=True)
+    assert np.abs(got.astype(np.float64) - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
 def test_rope_scatter_norm_elementwise_through_cpp(cx, oracle):
     rng = np.random.default_rng(11)
     h, hkv, d, s = 8, 2, 128, 5

@@ -194,6 +194,15 @@ PYBIND11_MODULE(zl_internals, m) {
             return c.down(out, fdt(bf16));
         }, py::arg("q"), py::arg("buf_lens"), py::arg("k_bufs"), py::arg("v_bufs"), py::arg("mask"), py::arg("scale"), py::arg("max_len_buf"),
            py::arg("m_query"), py::arg("bf16") = false)
+        .def("attention_qkv_rag_buffer", [](PyCtx& c, py::array q, py::array buf_lens, py::list kbufs, py::list vbufs, py::array mask, float scale,
+                                             int max_len_buf) {
+            Tensor tq = c.up(q), tl = c.up(buf_lens), tm = c.up(mask);
+            auto ks = c.up_list(kbufs), vs = c.up_list(vbufs);
+            Tensor ka = c.addr_table(ks), va = c.addr_table(vs);
+            Tensor out = c.ctx->tensor(tq.shape(), tq.dtype());
+            nn::attention_qkv_rag_buffer(*c.ctx, tq, tl, ka, va, tm, Tensor(), scale, max_len_buf, out);
+            return c.down(out, "float16");
+        })
         .def("rope_qk_cache", [](PyCtx& c, py::array cosv, py::array sinv, py::array in, size_t h, size_t hkv, size_t d, bool neox) {
             Tensor ti = c.up(in);
             const size_t s = ti.size(0);
