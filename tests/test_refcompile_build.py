@@ -69,7 +69,31 @@ def test_reference_attention_tu_binds_the_decode_hot_path_names():
     assert not v["pending"] and not [n for n in v["outside"] if n.startswith(build.REF_CHECK_NAMESPACES)]
     owners = {n.split("(")[0].rsplit("::", 1)[0] if n.split("(")[0].count("::") > 1 else n.split("(")[0] for n in v["outside"]}
     assert owners <= {"nn::FlashDecoding", "nn::RotaryEmbedding", "kvcache::TransformerBuffer", "kvcache::copy_to_buffer", "nn::attn_softmax",
-                      "nn::multi_query_self_attention", "nn::Attention::impl"}, owners
+                      "nn::multi_query_self_attention"}, owners
+    assert any(n.startswith("nn::Attention::impl::create_mla_impl(") for n in v["reference"])     # defined by the MLA unit, also checked
+
+
+def test_reference_block_tu_binds_the_layer_orchestration_names():
+    """src/nn/block/block.cpp (EncoderLayer::forward, single_stream_encode, dual_stream_encode: SURVEY 8a row a19): the residual adds,
+    the fused add + norm, the stream / allocator switching of the dual-stream prompt path and bmengine's elementwise glue bind to the
+    boundary; Attention and FeedForward are the reference's own classes from the units checked above; the tensor-parallel reduces go
+    through ModelContext (the reference's model_context.cpp, outside this check)."""
+    import json
+    from zhilight_amd import build
+    build.build()
+    have_reference = all(os.path.exists(os.path.join(build.REFERENCE, t)) for t in build.REF_CHECK_TUS)
+    report = build.build_refcheck() if have_reference else build.refcheck_report()
+    if not (report and os.path.exists(report)):
+        pytest.skip("no reference tree and no prebuilt report")
+    v = json.load(open(report))["src/nn/block/block.cpp"]
+    for name in ("nn::element_add_scale_out(", "nn::LayerNorm::fuse_add(", "nn::LayerNorm::forward(", "bmengine::core::Context::use_cache_alloc(",
+                 "bmengine::core::Context::reserve_cache_alloc(", "bmengine::core::Context::set_current_stream(",
+                 "bmengine::functions::BinaryElementwiseOp::forward(", "bmengine::functions::reduce_abs_max("):
+        assert any(n.startswith(name) for n in v["resolved"]), name
+    for name in ("nn::Attention::forward(", "nn::FeedForward::forward("):
+        assert any(n.startswith(name) for n in v["reference"]), name
+    assert {n.split("(")[0] for n in v["pending"]} <= {"bmengine::functions::pow", "bmengine::functions::clamp"}
+    assert {n.split("(")[0].rsplit("::", 1)[0] for n in v["outside"]} <= {"model::ModelContext", "nn::LayerNorm"}
 
 
 def test_reference_feedforward_tu_binds_the_router_dispatch_and_fp8_names():

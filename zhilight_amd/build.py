@@ -118,7 +118,8 @@ REF_TUS = ("src/nn/linear/linear.cpp",)
 # reference translation units that are compiled unmodified and LINK-CHECKED only (build_refcheck): every name they reference in the
 # namespaces the boundary stands in for must be defined by the boundary under the same mangled name -- i.e. with the reference's
 # exact signature; names of layers that are not on the path (their device code lives in the reference's .cu files) are listed
-REF_CHECK_TUS = ("src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp", "src/nn/feedforward/feedforward.cpp")
+REF_CHECK_TUS = ("src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp", "src/nn/feedforward/feedforward.cpp",
+                 "src/nn/block/block.cpp")
 REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_op::", "nn::top_k_softmax(", "nn::group_topk_softmax(",
                         "nn::sum_experts(", "nn::route_shared_lb(", "nn::plus_for_sort(", "nn::calc_reverse_idx(",
                         "nn::fill_m_indices_padded_indices(", "nn::gate_mul_inplace(", "nn::gate_fuse(", "nn::gelu_inplace(", "nn::silu_inplace(",
@@ -127,7 +128,7 @@ REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_o
 # declared by the shim so that the units compile, NOT provided by the boundary yet (bmengine's functions library: device helpers
 # that only the MoE dispatch route uses; zhilight_amd/moe.py does those steps with the framework's indexing): reported as "pending"
 REF_CHECK_PENDING = ("bmengine::functions::arange(", "bmengine::functions::sort_pair_1d(", "bmengine::functions::divide(",
-                     "bmengine::functions::scatter_update_dim0(")
+                     "bmengine::functions::scatter_update_dim0(", "bmengine::functions::pow(", "bmengine::functions::clamp(")
 
 
 def refcompile_target():
@@ -204,7 +205,7 @@ def refcheck_report():
 def build_refcheck(force=False, verbose=False):
     """Compile REF_CHECK_TUS in place against hostcpp/refshim and compare what they reference with what the boundary defines
     (libzhilight_amd.so + the hostcpp layer inside the zl_reflinear module).  Writes zhilight_amd/_ref/linkcheck.json:
-    {tu: {"resolved": [...], "outside": [...], "pending": [...]}} (demangled); raises when a name in REF_CHECK_NAMESPACES is not
+    {tu: {"resolved": [...], "outside": [...], "pending": [...], "reference": [... defined by another checked unit]}} (demangled); raises when a name in REF_CHECK_NAMESPACES is not
     defined -- a signature that drifted from the reference's -- unless it is one of REF_CHECK_PENDING.  Only where the reference tree exists; returns the report path or None."""
     import json
     import pybind11
@@ -229,16 +230,27 @@ def build_refcheck(force=False, verbose=False):
         for line in subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True).splitlines():
             have.add(line.split()[-1])
     out, drifted = {}, []
-    for rel, src in zip(REF_CHECK_TUS, tus):
-        obj = os.path.join(REFDIR, os.path.basename(src).rsplit(".", 1)[0] + ".check.o")
+    objs = [os.path.join(REFDIR, os.path.basename(src).rsplit(".", 1)[0] + ".check.o") for src in tus]
+
+    def compile_one(job):
+        src, obj = job
         cmd = common + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        syms = [line.split()[-1] for line in subprocess.check_output(["nm", "-u", obj], text=True).splitlines()]
+
+    with ThreadPoolExecutor(max_workers=len(tus)) as ex:
+        list(ex.map(compile_one, zip(tus, objs)))
+    undefined, other_units = {}, set()               # names one checked unit needs and another one defines are the reference's own
+    for obj in objs:
+        undefined[obj] = [line.split()[-1] for line in subprocess.check_output(["nm", "-u", obj], text=True).splitlines()]
+        for line in subprocess.check_output(["nm", "--defined-only", obj], text=True).splitlines():
+            other_units.add(line.split()[-1])
         os.remove(obj)
+    for rel, obj in zip(REF_CHECK_TUS, objs):
+        syms = undefined[obj]
         names = subprocess.run(["c++filt"], input="\n".join(syms), text=True, capture_output=True).stdout.splitlines()
-        resolved, outside, pending = [], [], []
+        resolved, outside, pending, reference = [], [], [], []
         for sym, name in zip(syms, names):
             if sym == name:                                       # C symbols: libc / libm / the HIP runtime (versioned there)
                 continue
@@ -247,9 +259,12 @@ def build_refcheck(force=False, verbose=False):
             if sym not in have and name.startswith(REF_CHECK_PENDING):
                 pending.append(name)
                 continue
+            if sym not in have and sym in other_units:
+                reference.append(name)
+                continue
             (resolved if sym in have else outside).append(name)
         drifted += [n for n in outside if n.startswith(REF_CHECK_NAMESPACES)]
-        out[rel] = {"resolved": sorted(resolved), "outside": sorted(outside), "pending": sorted(pending)}
+        out[rel] = {"resolved": sorted(resolved), "outside": sorted(outside), "pending": sorted(pending), "reference": sorted(reference)}
     if drifted:
         raise RuntimeError("reference call sites name boundary functions the boundary does not define with that signature:\n" + "\n".join(drifted))
     with open(report, "w") as f:

@@ -340,6 +340,8 @@ public:
     Stream stream;
     Context::ReduceHook reduce;
     MemoryAllocator cache_arena;
+    std::shared_ptr<Pool> side_pool;                 // see Context::use_cache_alloc
+    bool use_side_pool = false;
     long next_id = 0;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -398,7 +400,9 @@ Tensor Context::tensor(const std::vector<size_t>& size, DataType dtype, const st
     if (nbytes == 0) return Tensor();
     const size_t want = (nbytes + round_up_bytes - 1) / round_up_bytes * round_up_bytes;
     const size_t cls = Pool::round(want);
-    std::shared_ptr<Pool> pool = pimpl->pool;
+    // (while use_cache_alloc(true) is in force -- the reduce-stream phases of dual_stream_encode -- blocks come from, and go back to,
+    //  a second pool: nothing freed under one stream is recycled under the other)
+    std::shared_ptr<Pool> pool = pimpl->use_side_pool ? pimpl->side_pool : pimpl->pool;
     Tensor t;
     t.mem_ = std::make_shared<Storage>();
     t.mem_->ptr = pool->get(cls);
@@ -464,6 +468,17 @@ Tensor Context::reduce_scatter(const Tensor& data) const {
 Tensor Context::all_gather(const Tensor& data) const {
     BM_ASSERT(pimpl->world == 1, "all_gather: this context owns no communicator for it (the decode path reduces with reduce_sum)");
     return data;
+}
+void Context::reserve_cache_alloc(size_t) {
+    if (!pimpl->side_pool) pimpl->side_pool = std::make_shared<Pool>(pimpl->device);     // grows on demand: nothing to reserve
+}
+void Context::use_cache_alloc(bool b) {
+    if (b && !pimpl->side_pool) pimpl->side_pool = std::make_shared<Pool>(pimpl->device);
+    pimpl->use_side_pool = b;
+}
+void Context::free_cache_alloc() {
+    pimpl->use_side_pool = false;
+    if (pimpl->side_pool) pimpl->side_pool->trim();                                      // blocks still held by tensors return later
 }
 MemoryAllocator* Context::get_cache_allocator() const { return &pimpl->cache_arena; }
 MemoryAllocator* Context::get_allocator() const { return &pimpl->cache_arena; }

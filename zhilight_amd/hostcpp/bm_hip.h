@@ -108,6 +108,7 @@ public:
     size_t get_memory_limit() const;
     size_t used_memory() const;
     size_t get_free_memory() const { return get_memory_limit() - used_memory(); }
+    void freeze_model_memory() {}                   // (allocator.h: the reference pins what was allocated so far; nothing moves here)
 };
 
 class Tensor {
@@ -299,6 +300,12 @@ public:
     MemoryAllocator* get_cache_allocator() const;
     MemoryAllocator* get_allocator() const;         // (context.h:120) the same object: one pool serves tensors and caches here
     void set_cache_arena(void* base);
+    // context.h:169-171: the reference carves a second arena for the reduce stream of dual_stream_encode (block.cpp:252-290, 429) so
+    // that nothing freed under one stream is recycled under the other; here: a second size-class pool, selected while
+    // use_cache_alloc(true) is in force (tensors return to the pool they came from)
+    void reserve_cache_alloc(size_t bytes);
+    void free_cache_alloc();
+    void use_cache_alloc(bool b);
 
 private:
     std::unique_ptr<ContextImpl> pimpl;

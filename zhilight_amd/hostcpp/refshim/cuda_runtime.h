@@ -28,3 +28,10 @@ typedef __half half;
 #define cudaFreeHost hipFreeHost
 #define cudaHostAllocDefault hipHostMallocDefault
 #define cudaHostAllocPortable hipHostMallocPortable
+#define cudaStreamCreateWithPriority hipStreamCreateWithPriority
+#define cudaStreamNonBlocking hipStreamNonBlocking
+#define cudaStreamDestroy hipStreamDestroy
+#define cudaEventCreateWithFlags hipEventCreateWithFlags
+#define cudaEventDefault hipEventDefault
+#define cudaEventQuery hipEventQuery
+#define cudaErrorNotReady hipErrorNotReady
