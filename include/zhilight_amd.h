@@ -190,7 +190,8 @@ typedef struct {
     int phase_rounds, phase_ksplit, phase_ksplit_min_m, phase_min_m, phase_max_m, phase_small_off;
     int tiled_min_m, tiled_bm, tiled_splitk;
     int mfma_ks, mfma_rounds;
-    int small_algo;   /* 1..4 rows: 0 = the integer-plane kernel (w4_i8p.hip: nibbles expanded to int8, activations as three byte planes of a
+    int small_algo;   /* 1..4 rows: 2 = the integer-plane arithmetic on the loader / consumer engine (w4_engine.hip: LDS-DMA weight
+                         ring filled by a loader wave; bit-identical to 0), 0 = the integer-plane kernel (w4_i8p.hip: nibbles expanded to int8, activations as three byte planes of a
                          per-group block-floating integer, v_mfma_i32_16x16x64_i8; the default), 1 = the fp16-dequant kernels of
                          rounds 1-2 (k_w4a16_phase / k_w4a16_mfma) */
     int tiled_wide;   /* prompt-chunk tiles (128 / 256 x 256 outputs per workgroup, M >= 128): 0 default (on, height by cost model), -1 off,
@@ -406,6 +407,31 @@ int zl_w4a16_gemm_attn_merge_h(const void* attn_workspace, const int32_t* buf_le
                                int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
                                const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
                                int64_t group_size, int epilogue, zl_stream_t s);
+/* zl_w4a16_gemm_attn_merge_h with the launcher options (zl_w4_opts_t::small_algo == 2: the loader / consumer engine) */
+int zl_w4a16_gemm_attn_merge_h_ex(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens,
+                                  int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
+                                  const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
+                                  int64_t group_size, int epilogue, const zl_w4_opts_t* opts, zl_stream_t s);
+/* Two projections of a decode layer in ONE launch (w4_engine.hip; 1..4 rows, fp16): the attention split merge + attn_out +
+ * residual add into `hidden` (in place: EncoderLayer's first element_add_scale, src/nn/block/block.cpp:104-121), then
+ * ln_ff + the fused w_in | w_gated projection + silu.mul into `act` (FeedForward::forward's first half,
+ * src/nn/feedforward/feedforward.cpp:107-170).  Same results as zl_w4a16_gemm_attn_merge_h followed by zl_w4a16_gemm_mfma with
+ * the fused norm, bit for bit.  The hidden rows cross between the workgroups INSIDE the launch as tagged 8-byte granules:
+ *   granules   device memory, m * dim_model * 4 bytes, 8-byte aligned, zero before the first use; may be shared by every layer
+ *   epoch      device word the caller advances (zl_engine_epoch_advance, by more than the largest epoch_add in use) between
+ *              two uses of the same (granules, epoch_add) pair -- once per decode step; epoch_add = the layer index
+ *   err        optional device word: bit 0 = a bounded wait inside a workgroup ran out, bit 1 = the hand-off did (every
+ *              workgroup of the launch must be resident at once: dim_model / 16 <= the device's CU count, nothing else
+ *              running on the device); the outputs are then undefined -- never a hang
+ * ZL_ESHAPE outside m <= 4, dim_attn <= 4096 and dim_model <= 4096 multiples of 1024, max_splits <= 16, n_ff / 16 a multiple
+ * (<= 8) of dim_model / 16 (callers fall back to the two launches). */
+int zl_w4a16_attn_out_gate_up(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens, int64_t split_len,
+                              int64_t max_splits, const uint32_t* qw_o, const uint32_t* meta_o, const uint16_t* bias_o,
+                              uint16_t* hidden, const uint32_t* qw_ff, const uint32_t* meta_ff, const uint16_t* bias_ff,
+                              const uint16_t* norm_weight, float norm_eps, uint16_t* act, int64_t m, int64_t dim_model,
+                              int64_t dim_attn, int64_t n_ff, int64_t group_size, void* granules, const uint32_t* epoch,
+                              uint32_t epoch_add, uint32_t* err, zl_stream_t s);
+int zl_engine_epoch_advance(uint32_t* epoch, uint32_t by, zl_stream_t s);
 int zl_decode_attn_splits(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
                           const uint16_t* const* v_bufs, const int32_t* valid_lens, void* workspace, int64_t b, int64_t h,
                           int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, int dtype, zl_stream_t s);

@@ -1,0 +1,232 @@
+"""GPU parity of the loader / consumer engine (zhilight_amd/csrc/w4_engine.hip): the same integer-plane arithmetic as k_w4a16_i8p
+in the same order, so every output must equal the i8p launch's BIT FOR BIT (which tests/test_gpu_w4.py and test_gpu_fullgeom.py
+hold against the CPU oracle) -- plain / fused-norm / long-K / rotary + KV scatter / split-merge variants, and the fused
+attn_out -> gate|up launch against the two launches it replaces, over repeated launches with fresh inputs (the in-launch
+hand-off must never deliver a stale or torn row)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+ENGINE = dict(ZL_W4_SMALL_ALGO=2)
+
+
+@pytest.mark.parametrize("m,k,n,norm,epi", [
+    (1, 4096, 4096, False, "residual"),        # attn_out
+    (1, 4096, 28672, True, "silu"),            # gate|up: 7 row tiles per workgroup, fused norm
+    (1, 14336, 4096, False, "residual"),       # down: 14 slots per tile
+    (2, 14336, 4096, False, "none"),           # long K, two rows: the ring shrinks to what LDS leaves
+    (4, 4096, 8192, True, "bias"),             # four rows, two tiles per workgroup
+    (3, 2048, 4096 + 16, False, "addc"),       # a ragged last tile; half of the consumer lanes hold no group
+    (1, 1024, 64, True, "none"),               # a handful of workgroups
+    (2, 4096, 11008 * 2, True, "silu"),        # Llama-2-7B gate|up: 6 tiles per workgroup, the last workgroups past the end
+])
+def test_engine_gemv_equals_i8p(dev, m, k, n, norm, epi):
+    from zhilight_amd import ops
+    torch.manual_seed(m * 1000 + k + n)
+    w = ops.W4MWeight.random(n, k, 128, dev, None, 0.02, epi == "silu")
+    nw = (1.0 + 0.1 * torch.randn(k, device=dev)).half() if norm else None
+    bias = (0.1 * torch.randn(n, device=dev)).half() if epi in ("bias", "silu") else None
+    for it in range(3):
+        x = (torch.randn(m, k, device=dev) * (3.0 if norm else 1.0)).half()
+        res = torch.randn(m, n, device=dev).half()
+        kw = dict(norm_weight=nw, bias=bias)
+        if epi == "residual":
+            kw.update(residual=res, epilogue=ops.EPI_RESIDUAL)
+        elif epi == "silu":
+            kw.update(epilogue=ops.EPI_SILU_MUL)
+        outs = []
+        for env in ({}, ENGINE):
+            with _env(**env):
+                if epi == "addc":
+                    out = res.clone()
+                    ops.w4a16_gemm_mfma(x, w, out=out, epilogue=ops.EPI_ADD_C, **kw)
+                else:
+                    out = ops.w4a16_gemm_mfma(x, w, **kw)
+            outs.append(out)
+        assert torch.isfinite(outs[0].float()).all()
+        assert torch.equal(outs[0], outs[1]), (it, (outs[0].float() - outs[1].float()).abs().max().item())
+
+
+@pytest.mark.parametrize("slots", [8, 9, 11])
+def test_engine_ring_sizes(dev, slots):
+    """a short ring wraps many times: the slot hand-back (consumed counters, landed count) under pressure"""
+    from zhilight_amd import ops
+    torch.manual_seed(slots)
+    w = ops.W4MWeight.random(28672, 4096, 128, dev, None, 0.02, True)
+    nw = (1.0 + 0.1 * torch.randn(4096, device=dev)).half()
+    x = torch.randn(1, 4096, device=dev).half()
+    want = ops.w4a16_gemm_mfma(x, w, norm_weight=nw, epilogue=ops.EPI_SILU_MUL)
+    with _env(ZL_W4_SMALL_ALGO=2, ZL_W4_PHASE_ROUNDS=slots):
+        for _ in range(4):
+            got = ops.w4a16_gemm_mfma(x, w, norm_weight=nw, epilogue=ops.EPI_SILU_MUL)
+            assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("m,norm", [(1, True), (3, True), (4, False)])
+@pytest.mark.parametrize("geom", ["small", "llama3"])
+def test_engine_qkv_rotary_scatter_equals_i8p(dev, m, norm, geom):
+    from zhilight_amd import ops
+    torch.manual_seed(7 + m)
+    h, hkv, d, k = (8, 2, 128, 1024) if geom == "small" else (32, 8, 128, 4096)
+    n = (h + 2 * hkv) * d
+    w = ops.W4MWeight.random(n, k, 128, dev, None, 0.02)
+    x = (torch.randn(m, k, device=dev) * 2).half()
+    nw = (1.0 + 0.1 * torch.randn(k, device=dev)).half() if norm else None
+    bias = (0.1 * torch.randn(n, device=dev)).half()
+    lens = [128 + 64 * i for i in range(m)]
+    pos = torch.tensor([L - 1 - i for i, L in enumerate(lens)], dtype=torch.int32, device=dev)
+    place = pos.clone()
+    if m > 1:
+        place[1] = -1
+    cos, sin = ops.rope_cos_sin(pos, d, 5e5, True)
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
+    res = []
+    for env in ({}, ENGINE):
+        kb = [torch.full((L, hkv, d), 3.0, dtype=torch.float16, device=dev) for L in lens]
+        vb = [torch.full((L, hkv, d), 3.0, dtype=torch.float16, device=dev) for L in lens]
+        with _env(**env):
+            q = ops.w4_qkv_rope_scatter(x, w, cos, sin, place, lens_t, ops.make_ptr_table(kb), ops.make_ptr_table(vb), h, hkv, d,
+                                        bias=bias, norm_weight=nw, norm_eps=1e-5)
+        res.append((q, kb, vb))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[1][1][0], torch.full_like(res[1][1][0], 3.0))
+
+
+def _attention_partials(dev, b, h, hkv, lens, valid, w_o):
+    from zhilight_amd import ops
+    d = 128
+    max_len = max(lens)
+    dk = [torch.randn(L, hkv, d, device=dev).half() for L in lens]
+    dv = [torch.randn(L, hkv, d, device=dev).half() for L in lens]
+    q = torch.randn(b, 1, h, d, device=dev).half()
+    bl = torch.tensor(lens, dtype=torch.int32, device=dev)
+    vl = torch.tensor(valid, dtype=torch.int32, device=dev)
+    with _env(ZL_ATTN_MERGE_MAX_B=4):
+        plan = ops.attn_merge_plan(b, h, hkv, d, max_len, w_o)
+    assert plan is not None and plan[2]
+    ws = ops.decode_attn_workspace(b, 1, h, d, max_len, dev)
+    ws.fill_(float("nan"))
+    ops.decode_attention_splits(q, bl, ops.make_ptr_table(dk), ops.make_ptr_table(dv), vl, 1.0 / np.sqrt(d), max_len, hkv, ws)
+    return ws, bl, vl, plan, (dk, dv)
+
+
+@pytest.mark.parametrize("b,h,hkv,n,lens,valid", [
+    (1, 32, 8, 4096, [1088], [1025]),
+    (3, 32, 8, 4096, [640, 128, 1088], [517, 128, 1000]),
+    (2, 8, 2, 1024, [256, 192], [129, 192]),
+])
+def test_engine_attn_out_merge_equals_i8p(dev, b, h, hkv, n, lens, valid):
+    from zhilight_amd import ops
+    torch.manual_seed(b + n)
+    w = ops.W4MWeight.random(n, h * 128, 128, dev, None, 0.02)
+    ws, bl, vl, plan, _keep = _attention_partials(dev, b, h, hkv, lens, valid, w)
+    res = torch.randn(b, n, device=dev).half()
+    want = ops.w4_attn_out_merge(ws, bl, vl, plan, b, w, residual=res, epilogue=ops.EPI_RESIDUAL)
+    with _env(**ENGINE):
+        got = ops.w4_attn_out_merge(ws, bl, vl, plan, b, w, residual=res, epilogue=ops.EPI_RESIDUAL)
+    assert torch.isfinite(want.float()).all()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("b,h,hkv,dm,ff,lens,valid", [
+    (1, 32, 8, 4096, 14336, [1088], [1025]),                 # the batch-1 decode layer of the bench model
+    (1, 8, 2, 1024, 2048, [256], [200]),                     # 64 workgroups, four tiles each in the second projection
+    (3, 32, 8, 4096, 14336, [640, 128, 1088], [517, 128, 1000]),
+    (4, 16, 4, 2048, 4096, [128, 128, 64, 192], [100, 128, 33, 192]),
+])
+def test_fused_attn_out_gate_up_equals_two_launches(dev, b, h, hkv, dm, ff, lens, valid):
+    """hidden and act of the fused launch == zl_w4a16_gemm_attn_merge_h + zl_w4a16_gemm_mfma(fused norm, silu.mul), bit for bit,
+    on 24 launches with fresh inputs each (same granule buffer, advancing epoch), with a stale-looking granule buffer in between;
+    the error word stays zero."""
+    from zhilight_amd import ops
+    torch.manual_seed(b * 31 + dm)
+    w_o = ops.W4MWeight.random(dm, h * 128, 128, dev, None, 0.02)
+    w_ff = ops.W4MWeight.random(2 * ff, dm, 128, dev, None, 0.02, True)
+    ln = (1.0 + 0.1 * torch.randn(dm, device=dev)).half()
+    st = ops.engine_state(dev)
+    st["err"].zero_()
+    for it in range(24):
+        ws, bl, vl, plan, _keep = _attention_partials(dev, b, h, hkv, lens, valid, w_o)
+        hidden0 = torch.randn(b, dm, device=dev).half()
+        want_h = ops.w4_attn_out_merge(ws, bl, vl, plan, b, w_o, residual=hidden0, epilogue=ops.EPI_RESIDUAL)
+        want_a = ops.w4a16_gemm_mfma(want_h, w_ff, norm_weight=ln, norm_eps=1e-5, epilogue=ops.EPI_SILU_MUL)
+        got_h = hidden0.clone()
+        got_a = torch.full((b, ff), float("nan"), dtype=torch.float16, device=dev)
+        ops.engine_epoch_advance(dev)
+        if it == 5:                                         # granules that carry an OLD epoch everywhere must not be taken
+            torch.cuda.synchronize()
+        ok = ops.w4_attn_out_gate_up(ws, bl, vl, plan, b, w_o, got_h, w_ff, ln, 1e-5, got_a, it % 32)
+        assert ok
+        assert torch.equal(got_h, want_h), it
+        assert torch.equal(got_a, want_a), (it, (got_a.float() - want_a.float()).abs().max().item())
+    assert int(st["err"].item()) == 0
+
+
+def test_fused_launch_refuses_what_it_does_not_cover(dev):
+    from zhilight_amd import ops
+    w_o = ops.W4MWeight.random(4096, 4096, 128, dev, None, 0.02)
+    w_ff = ops.W4MWeight.random(2 * 14336, 4096, 128, dev, None, 0.02, True)
+    ws = torch.zeros(1 << 18, dtype=torch.float32, device=dev)
+    i32 = torch.ones(8, dtype=torch.int32, device=dev)
+    hidden = torch.zeros(1, 4096, dtype=torch.float16, device=dev)
+    act = torch.zeros(1, 14336, dtype=torch.float16, device=dev)
+    ln = torch.ones(4096, dtype=torch.float16, device=dev)
+    assert not ops.w4_attn_out_gate_up(ws, i32, i32, (128, 17, True), 1, w_o, hidden, w_ff, ln, 1e-5, act, 0)   # 17 splits
+    assert not ops.w4_attn_out_gate_up(ws, i32, i32, (128, 9, False), 1, w_o, hidden, w_ff, ln, 1e-5, act, 0)   # fp32 partials
+    w_odd = ops.W4MWeight.random(2 * 10240, 4096, 128, dev, None, 0.02, True)                                  # 1280 tiles: not a multiple of 256
+    act2 = torch.zeros(1, 10240, dtype=torch.float16, device=dev)
+    assert not ops.w4_attn_out_gate_up(ws, i32, i32, (128, 9, True), 1, w_o, hidden, w_odd, ln, 1e-5, act2, 0)
+
+
+def test_decode_step_with_engine_routes_equals_default(dev):
+    """a 4-layer full-width model, three greedy steps: the engine kernels and the fused launch reproduce the default step's
+    logits and tokens bit for bit"""
+    from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
+    cfg = ModelConfig.llama3_8b()
+    cfg.num_layers = 4
+    outs = []
+    for env in ({}, dict(ZL_W4_SMALL_ALGO=2), dict(ZL_W4_SMALL_ALGO=2, ZL_FUSE_O_GATEUP=1), dict(ZL_FUSE_O_GATEUP=1)):
+        with _env(**env):
+            model = LLaMA(cfg, QuantConfig(), device=dev)
+            model.init_random(seed=3)
+            torch.manual_seed(11)
+            ctx = model.new_context(1, 1152, 1024, fill_random=True)
+            ctx.tokens.fill_(17)
+            seq = []
+            for _ in range(3):
+                logits = model.encode(ctx)
+                nxt = logits.float().argmax(-1)
+                seq.append((logits.clone(), nxt.clone()))
+                model.advance(ctx, nxt)
+            outs.append(seq)
+            del model, ctx
+    from zhilight_amd import ops
+    assert int(ops.engine_state(dev)["err"].item()) == 0
+    for other in outs[1:]:
+        for (l0, t0), (l1, t1) in zip(outs[0], other):
+            assert torch.equal(t0, t1)
+            assert torch.equal(l0, l1)

@@ -582,7 +582,8 @@ def test_attention_split_merge_plan_limits(dev):
     from zhilight_amd import ops
     from zhilight_amd._lib import ZLError
     w = ops.W4MWeight(4096, 4096, 128, None, None)
-    assert ops.attn_merge_plan(1, 32, 8, 128, 1088, w) == (128, 9)
+    assert ops.attn_merge_plan(1, 32, 8, 128, 1088, w) == (128, 9, True)
+    assert ops.attn_merge_plan(1, 32, 8, 128, 1088, w, torch.bfloat16) == (128, 9, False)   # one layout decision for both launches
     assert ops.attn_merge_plan(2, 32, 8, 128, 1088, w) is None          # ZL_ATTN_MERGE_MAX_B defaults to 1
     assert ops.attn_merge_plan(1, 32, 8, 128, 4096, w) is None          # 32 splits
     assert ops.attn_merge_plan(1, 32, 8, 64, 1088, w) is None

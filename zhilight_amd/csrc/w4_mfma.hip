@@ -610,6 +610,29 @@ int zl_w4a16_gemm_i8p_merge(const void* ws, const int32_t* buf_lens, const int32
                             const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
                             const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups,
                             int tiles, int epilogue, hipStream_t hs);
+// the loader / consumer engine (w4_engine.hip)
+bool zl_w4_engine_covers(int64_t m, int64_t k, int r);
+int zl_w4a16_gemm_engine(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                         uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k,
+                         int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps, int slots_cap,
+                         hipStream_t hs);
+int zl_w4a16_gemm_engine_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                              uint32_t meta_bytes, const uint16_t* bias, int m, int n, int k, int groups, int tiles,
+                              const uint16_t* norm_w, float norm_eps, const float* cosv, const float* sinv,
+                              const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                              uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs);
+int zl_w4a16_gemm_engine_merge(const void* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len, int max_splits,
+                               const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
+                               const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups,
+                               int tiles, int epilogue, hipStream_t hs);
+int zl_w4_engine_o_gateup_launch(const void* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len, int max_splits,
+                                 const uint32_t* qw1, const uint32_t* meta1, uint32_t qw1_bytes, uint32_t meta1_bytes,
+                                 const uint16_t* bias1, uint16_t* hidden, int m, int n1, int k1, int groups1, int tiles1,
+                                 const uint32_t* qw2, const uint32_t* meta2, uint32_t qw2_bytes, uint32_t meta2_bytes,
+                                 const uint16_t* bias2, const uint16_t* norm_w, float norm_eps, uint16_t* act, int n2, int groups2,
+                                 int tiles2, int epilogue2, void* granules, const uint32_t* epoch_ptr, uint32_t epoch_add,
+                                 uint32_t* err, hipStream_t hs);
+int zl_engine_epoch_advance_launch(uint32_t* epoch, uint32_t by, hipStream_t hs);
 int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len,
                               int max_splits, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                               uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
@@ -708,7 +731,14 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
     // rows every workgroup pulls M x K activations through L2, so a long K (the down projection) stays on
     // the M-tiled kernel, whose 128-column workgroups share them.
     // 1..4 rows (1..2 with a long K): the integer-plane kernel (w4_i8p.hip), the batch-1 decode default
-    if (!o.small_algo && zl_w4a16_i8p_covers(m, k) && L.qw_bytes < ((int64_t)1 << 32))
+    // small_algo == 2: the same arithmetic on the loader / consumer engine (w4_engine.hip) where it applies
+    if (o.small_algo == 2 && L.qw_bytes < ((int64_t)1 << 32)) {
+        st = zl_w4a16_gemm_engine(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
+                                  (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), norm_weight, norm_eps,
+                                  o.phase_rounds, hs);
+        if (st != ZL_ESHAPE && st != ZL_ELIMIT) return st;
+    }
+    if ((o.small_algo == 0 || o.small_algo == 2) && zl_w4a16_i8p_covers(m, k) && L.qw_bytes < ((int64_t)1 << 32))
         return zl_w4a16_gemm_i8p(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
                                  (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), norm_weight, norm_eps,
                                  o.phase_rounds, hs);
@@ -839,7 +869,14 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
     ZL_CHECK_ARG(!norm_weight || (m <= 8 && k <= 4096), ZL_ESHAPE);
     ZL_CHECK_ARG(m <= 16 || k <= 8192, ZL_ESHAPE);
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
-    if (!(opts && opts->small_algo) && zl_w4a16_i8p_covers(m, k))
+    const int small_algo = opts ? opts->small_algo : 0;
+    if (small_algo == 2) {
+        st = zl_w4a16_gemm_engine_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n, (int)k,
+                                       (int)L.q, (int)(L.np / 16), norm_weight, norm_eps, cosv, sinv, placement, buf_lens, k_bufs,
+                                       v_bufs, q_out, (int)h, (int)hkv, (int)d, bshd, (hipStream_t)s);
+        if (st != ZL_ESHAPE && st != ZL_ELIMIT) return st;
+    }
+    if ((small_algo == 0 || small_algo == 2) && zl_w4a16_i8p_covers(m, k))
         return zl_w4a16_gemm_i8p_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n,
                                       (int)k, (int)L.q, (int)(L.np / 16), norm_weight, norm_eps, cosv, sinv, placement,
                                       buf_lens, k_bufs, v_bufs, q_out, (int)h, (int)hkv, (int)d, bshd, (hipStream_t)s);
@@ -872,6 +909,14 @@ int zl_w4a16_gemm_attn_merge_h(const void* attn_workspace, const int32_t* buf_le
                                int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
                                const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
                                int64_t group_size, int epilogue, zl_stream_t s) {
+    return zl_w4a16_gemm_attn_merge_h_ex(attn_workspace, buf_lens, valid_lens, split_len, max_splits, qw, meta, bias, residual, y, m,
+                                         n, k, group_size, epilogue, nullptr, s);
+}
+
+int zl_w4a16_gemm_attn_merge_h_ex(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens,
+                                  int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
+                                  const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
+                                  int64_t group_size, int epilogue, const zl_w4_opts_t* opts, zl_stream_t s) {
     ZL_CHECK_ARG(attn_workspace && buf_lens && valid_lens && qw && meta && y, ZL_EINVAL);
     ZL_CHECK_ARG(m > 0 && n > 0 && k > 0 && split_len > 0 && max_splits > 0, ZL_EINVAL);
     ZL_CHECK_ARG(!(epilogue & ZL_EPI_BIAS) || bias, ZL_EINVAL);
@@ -882,9 +927,44 @@ int zl_w4a16_gemm_attn_merge_h(const void* attn_workspace, const int32_t* buf_le
     int st = zl_w4m_layout(n, k, group_size, &L);
     if (st) return st;
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+    if (opts && opts->small_algo == 2) {
+        st = zl_w4a16_gemm_engine_merge(attn_workspace, buf_lens, valid_lens, (int)split_len, (int)max_splits, qw, meta,
+                                        (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n, (int)k,
+                                        (int)L.q, (int)(L.np / 16), epilogue, (hipStream_t)s);
+        if (st != ZL_ESHAPE && st != ZL_ELIMIT) return st;
+    }
     return zl_w4a16_gemm_i8p_merge(attn_workspace, buf_lens, valid_lens, (int)split_len, (int)max_splits, qw, meta,
                                    (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n, (int)k,
                                    (int)L.q, (int)(L.np / 16), epilogue, (hipStream_t)s);
+}
+
+int zl_w4a16_attn_out_gate_up(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens, int64_t split_len,
+                              int64_t max_splits, const uint32_t* qw_o, const uint32_t* meta_o, const uint16_t* bias_o,
+                              uint16_t* hidden, const uint32_t* qw_ff, const uint32_t* meta_ff, const uint16_t* bias_ff,
+                              const uint16_t* norm_weight, float norm_eps, uint16_t* act, int64_t m, int64_t dim_model,
+                              int64_t dim_attn, int64_t n_ff, int64_t group_size, void* granules, const uint32_t* epoch,
+                              uint32_t epoch_add, uint32_t* err, zl_stream_t s) {
+    ZL_CHECK_ARG(attn_workspace && buf_lens && valid_lens && qw_o && meta_o && hidden && qw_ff && meta_ff && norm_weight && act, ZL_EINVAL);
+    ZL_CHECK_ARG(granules && epoch && m > 0 && dim_model > 0 && dim_attn > 0 && n_ff > 0 && split_len > 0 && max_splits > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(((uintptr_t)granules & 7) == 0 && n_ff % 2 == 0, ZL_ESHAPE);
+    zl_w4_layout_t L1, L2;
+    int st = zl_w4m_layout(dim_model, dim_attn, group_size, &L1);
+    if (st) return st;
+    st = zl_w4m_layout(n_ff, dim_model, group_size, &L2);
+    if (st) return st;
+    ZL_CHECK_ARG(L1.np == dim_model && L2.np == n_ff, ZL_ESHAPE);
+    ZL_CHECK_ARG(L1.qw_bytes < ((int64_t)1 << 32) && L2.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+    return zl_w4_engine_o_gateup_launch(attn_workspace, buf_lens, valid_lens, (int)split_len, (int)max_splits, qw_o, meta_o,
+                                        (uint32_t)L1.qw_bytes, (uint32_t)L1.scales_bytes, bias_o, hidden, (int)m, (int)dim_model,
+                                        (int)dim_attn, (int)L1.q, (int)(L1.np / 16), qw_ff, meta_ff, (uint32_t)L2.qw_bytes,
+                                        (uint32_t)L2.scales_bytes, bias_ff, norm_weight, norm_eps, act, (int)n_ff, (int)L2.q,
+                                        (int)(L2.np / 16), ZL_EPI_SILU_MUL | (bias_ff ? ZL_EPI_BIAS : 0), granules, epoch, epoch_add,
+                                        err, (hipStream_t)s);
+}
+
+int zl_engine_epoch_advance(uint32_t* epoch, uint32_t by, zl_stream_t s) {
+    ZL_CHECK_ARG(epoch && by > 0, ZL_EINVAL);
+    return zl_engine_epoch_advance_launch(epoch, by, (hipStream_t)s);
 }
 
 }  // extern "C"

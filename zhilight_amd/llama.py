@@ -970,7 +970,12 @@ class LLaMA:
         if (fuse_qkv_rope and not self.tp and os.environ.get("ZL_ATTN_MERGE", "1") != "0"
                 and all(l.attn_out.perm is None for l in self.layers)):
             merge_plan = ops.attn_merge_plan(b, c.num_heads, c.num_kv_heads, c.dim_head, ctx.max_len_buf,
-                                             self.layers[0].attn_out.weight)
+                                             self.layers[0].attn_out.weight, c.torch_dtype)
+        # attention split merge + attn_out + residual and ln_ff + gate|up + silu.mul in ONE launch (w4_engine.hip)
+        fuse_o_ff = (merge_plan is not None and merge_plan[2] and os.environ.get("ZL_FUSE_O_GATEUP", "0") == "1"
+                     and all(l.w_in_gated.perm is None and isinstance(l.w_in_gated.weight, ops.W4MWeight) for l in self.layers))
+        if fuse_o_ff:
+            ops.engine_epoch_advance(self.device)
         for li, layer in enumerate(self.layers):
             if fuse_qkv_rope_i8:
                 # INT8 route: layernorm_quant, then the streaming W8A8 kernel with scale-back + rotary + KV scatter fused
@@ -993,6 +998,11 @@ class LLaMA:
                     if not gemv_only:
                         ops.decode_attention_splits(bufs["q"].view(b, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
                                                     ctx.v_addrs[li], ctx.valid_lens, scale, ctx.max_len_buf, c.num_kv_heads, workspace)
+                    if fuse_o_ff and ops.w4_attn_out_gate_up(workspace, ctx.buf_lens, ctx.valid_lens, merge_plan, b, layer.attn_out.weight,
+                                                             hidden, layer.w_in_gated.weight, layer.ln_ff, c.eps, bufs["act"], li,
+                                                             bias_o=layer.attn_out.bias, bias_ff=layer.w_in_gated.bias):
+                        layer.w_out.forward(bufs["act"], residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
+                        continue
                     ops.w4_attn_out_merge(workspace, ctx.buf_lens, ctx.valid_lens, merge_plan, b, layer.attn_out.weight,
                                           bias=layer.attn_out.bias, residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL)
                     layer.ff_add(hidden, c.eps, bufs["act"])

@@ -695,7 +695,7 @@ def multi_query_attention_rag_buffer(batch_q, buf_lens, key_buf_addrs, val_buf_a
     return out
 
 
-def attn_merge_plan(b, num_heads, num_kv_heads, dim_head, max_len_buf, w):
+def attn_merge_plan(b, num_heads, num_kv_heads, dim_head, max_len_buf, w, dtype=torch.float16):
     """(split_len, max_splits) when zl_decode_attn_splits + zl_w4a16_gemm_attn_merge cover this decode batch and
     projection weight, else None (callers use multi_query_attention_rag_buffer + w4_linear).  ZL_ATTN_MERGE_MAX_B
     (default 1) bounds the batch: every workgroup of the projection merges all rows, which stops paying early."""
@@ -708,7 +708,11 @@ def attn_merge_plan(b, num_heads, num_kv_heads, dim_head, max_len_buf, w):
     cus = lib().zl_device_cu_count()
     if max_splits > 16 or (w.n + 15) // 16 > 2 * (cus if cus > 0 else 256):
         return None
-    return split_len, max_splits
+    return split_len, max_splits, _merge_half_dtype(dtype)     # [2]: fp16 partial records (decided ONCE, for both launches)
+
+
+def _merge_half_dtype(dtype):
+    return _merge_half() and dtype == torch.float16
 
 
 def _merge_half(t=None):
@@ -739,16 +743,66 @@ def w4_attn_out_merge(workspace, buf_lens, valid_lens, plan, b, w, bias=None, re
     """attn_out projection whose activation rows are merged from the decode attention's split-KV partials in the GEMV
     prologue (zl_w4a16_gemm_attn_merge): bit-identical to the merge launch + w4a16_gemm_mfma."""
     _chk_cuda(workspace, buf_lens, valid_lens, bias, residual)
-    split_len, max_splits = plan
+    split_len, max_splits = plan[0], plan[1]
     if out is None:
         out = torch.empty((b, w.n), dtype=torch.float16, device=workspace.device)
     if bias is not None:
         epilogue |= EPI_BIAS
-    fn = lib().zl_w4a16_gemm_attn_merge_h if _merge_half() else lib().zl_w4a16_gemm_attn_merge
-    check(fn(_p(workspace), _p(buf_lens), _p(valid_lens), _i(split_len), _i(max_splits), _p(w.qw),
-             _p(w.meta), _p(bias), _p(residual), _p(out), _i(b), _i(w.n), _i(w.k),
-             _i(w.group_size), C.c_int(epilogue), _stream()), "w4a16_gemm_attn_merge")
+    # the partial layout was decided by decode_attention_splits from the query dtype; the plan carries that decision
+    # (a bare _merge_half() here read fp16 records out of an fp32 workspace for non-fp16 queries)
+    half = plan[2] if len(plan) > 2 else _merge_half()
+    if half:
+        opts = _w4_opts(workspace.device, b, w.n)
+        check(lib().zl_w4a16_gemm_attn_merge_h_ex(_p(workspace), _p(buf_lens), _p(valid_lens), _i(split_len), _i(max_splits),
+                                                  _p(w.qw), _p(w.meta), _p(bias), _p(residual), _p(out), _i(b), _i(w.n), _i(w.k),
+                                                  _i(w.group_size), C.c_int(epilogue), C.byref(opts), _stream()),
+              "w4a16_gemm_attn_merge_h")
+        return out
+    check(lib().zl_w4a16_gemm_attn_merge(_p(workspace), _p(buf_lens), _p(valid_lens), _i(split_len), _i(max_splits), _p(w.qw),
+                                         _p(w.meta), _p(bias), _p(residual), _p(out), _i(b), _i(w.n), _i(w.k),
+                                         _i(w.group_size), C.c_int(epilogue), _stream()), "w4a16_gemm_attn_merge")
     return out
+
+
+_ENGINE_STATE = {}
+
+
+def engine_state(device):
+    """granules + epoch + error words of the fused decode launches (zl_w4a16_attn_out_gate_up): one set per device, shared by
+    every layer (the epoch differs per layer and per step)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _ENGINE_STATE.get(key)
+    if st is None:
+        st = dict(granules=torch.zeros(4 * 4096 * 4, dtype=torch.uint8, device=device),
+                  epoch=torch.ones(1, dtype=torch.int32, device=device), err=torch.zeros(1, dtype=torch.int32, device=device))
+        _ENGINE_STATE[key] = st
+    return st
+
+
+def engine_epoch_advance(device, by=256):
+    """once per decode step, ahead of the step's fused launches"""
+    st = engine_state(device)
+    check(lib().zl_engine_epoch_advance(_p(st["epoch"]), C.c_uint32(by), _stream()), "engine_epoch_advance")
+
+
+def w4_attn_out_gate_up(workspace, buf_lens, valid_lens, plan, b, w_o, hidden, w_ff, norm_weight, norm_eps, act, layer_index,
+                        bias_o=None, bias_ff=None):
+    """zl_w4a16_attn_out_gate_up: hidden += attn_out(merge(partials)); act = silu(w_in(ln(hidden))) * w_gated(ln(hidden)) in one
+    launch.  Returns False (nothing launched) outside the launcher's range."""
+    _chk_cuda(workspace, buf_lens, valid_lens, hidden, norm_weight, act, bias_o, bias_ff)
+    split_len, max_splits = plan[0], plan[1]
+    if len(plan) > 2 and not plan[2]:
+        return False
+    st = engine_state(hidden.device)
+    rc = lib().zl_w4a16_attn_out_gate_up(_p(workspace), _p(buf_lens), _p(valid_lens), _i(split_len), _i(max_splits), _p(w_o.qw),
+                                         _p(w_o.meta), _p(bias_o), _p(hidden), _p(w_ff.qw), _p(w_ff.meta), _p(bias_ff),
+                                         _p(norm_weight), _f(norm_eps), _p(act), _i(b), _i(w_o.n), _i(w_o.k), _i(w_ff.n),
+                                         _i(w_o.group_size), _p(st["granules"]), _p(st["epoch"]), C.c_uint32(layer_index),
+                                         _p(st["err"]), _stream())
+    if rc in (-2, -4):                                    # ZL_ESHAPE / ZL_ELIMIT: the caller takes the two launches
+        return False
+    check(rc, "w4a16_attn_out_gate_up")
+    return True
 
 
 def decode_attention_fused(cos, sin, qkv, placement, buf_lens, valid_lens, k_addrs, v_addrs, num_heads, num_kv_heads,
