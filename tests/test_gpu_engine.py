@@ -69,19 +69,22 @@ def test_engine_gemv_equals_i8p(dev, m, k, n, norm, epi):
         assert torch.equal(outs[0], outs[1]), (it, (outs[0].float() - outs[1].float()).abs().max().item())
 
 
-@pytest.mark.parametrize("slots", [8, 9, 11])
+@pytest.mark.parametrize("slots", [2, 3])
 def test_engine_ring_sizes(dev, slots):
-    """a short ring wraps many times: the slot hand-back (consumed counters, landed count) under pressure"""
+    """a ring of two rounds (and the qkv shape's three): the round hand-back (consumed counters, landed count) under pressure"""
     from zhilight_amd import ops
     torch.manual_seed(slots)
     w = ops.W4MWeight.random(28672, 4096, 128, dev, None, 0.02, True)
     nw = (1.0 + 0.1 * torch.randn(4096, device=dev)).half()
     x = torch.randn(1, 4096, device=dev).half()
     want = ops.w4a16_gemm_mfma(x, w, norm_weight=nw, epilogue=ops.EPI_SILU_MUL)
+    w2 = ops.W4MWeight.random(6144, 4096, 128, dev, None, 0.02)
+    want2 = ops.w4a16_gemm_mfma(x, w2, norm_weight=nw)
     with _env(ZL_W4_SMALL_ALGO=2, ZL_W4_PHASE_ROUNDS=slots):
         for _ in range(4):
             got = ops.w4a16_gemm_mfma(x, w, norm_weight=nw, epilogue=ops.EPI_SILU_MUL)
             assert torch.equal(got, want)
+            assert torch.equal(ops.w4a16_gemm_mfma(x, w2, norm_weight=nw), want2)
 
 
 @pytest.mark.parametrize("m,norm", [(1, True), (3, True), (4, False)])
@@ -180,7 +183,9 @@ def test_fused_attn_out_gate_up_equals_two_launches(dev, b, h, hkv, dm, ff, lens
         if it == 5:                                         # granules that carry an OLD epoch everywhere must not be taken
             torch.cuda.synchronize()
         ok = ops.w4_attn_out_gate_up(ws, bl, vl, plan, b, w_o, got_h, w_ff, ln, 1e-5, got_a, it % 32)
-        assert ok
+        if not ok:                                          # several rows at the full geometry: the planes leave the ring less than two
+            assert b > 1                                    # rounds and the launcher refuses (callers take the two launches); one row must fit
+            return
         assert torch.equal(got_h, want_h), it
         assert torch.equal(got_a, want_a), (it, (got_a.float() - want_a.float()).abs().max().item())
     assert int(st["err"].item()) == 0
@@ -197,8 +202,8 @@ def test_fused_launch_refuses_what_it_does_not_cover(dev):
     ln = torch.ones(4096, dtype=torch.float16, device=dev)
     assert not ops.w4_attn_out_gate_up(ws, i32, i32, (128, 17, True), 1, w_o, hidden, w_ff, ln, 1e-5, act, 0)   # 17 splits
     assert not ops.w4_attn_out_gate_up(ws, i32, i32, (128, 9, False), 1, w_o, hidden, w_ff, ln, 1e-5, act, 0)   # fp32 partials
-    w_odd = ops.W4MWeight.random(2 * 10240, 4096, 128, dev, None, 0.02, True)                                  # 1280 tiles: not a multiple of 256
-    act2 = torch.zeros(1, 10240, dtype=torch.float16, device=dev)
+    w_odd = ops.W4MWeight.random(2 * 10000, 4096, 128, dev, None, 0.02, True)                                  # 1250 tiles: not a multiple of 256
+    act2 = torch.zeros(1, 10000, dtype=torch.float16, device=dev)
     assert not ops.w4_attn_out_gate_up(ws, i32, i32, (128, 9, True), 1, w_o, hidden, w_odd, ln, 1e-5, act2, 0)
 
 

@@ -51,12 +51,15 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--variants", default="i8p,engine,i8p+fused,engine+fused")
-    ap.add_argument("--ring", type=int, default=0, help="cap the engine's ring at this many slots (plain launches only)")
+    ap.add_argument("--ring", type=int, default=0, help="cap the engine's ring at this many rounds")
     ap.add_argument("--no-ops", action="store_true")
+    ap.add_argument("--no-step", action="store_true", help="skip the whole-step and gemv-only graphs (per-projection numbers only)")
     a = ap.parse_args()
     from zhilight_amd import ops
     from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
     dev = torch.device("cuda:0")
+    from zhilight_amd._lib import lib
+    lib().zl_debug_engine_knobs(a.ring)
     cfg = ModelConfig.llama3_8b()
     cfg.num_layers = a.layers
     model = LLaMA(cfg, QuantConfig(), device=dev)
@@ -68,8 +71,6 @@ def main():
         for k in KEYS:
             os.environ.pop(k, None)
         os.environ.update(VARIANTS[name])
-        if a.ring and "engine" in name:
-            os.environ["ZL_W4_PHASE_ROUNDS"] = str(a.ring)
         torch.manual_seed(5)
         ctx = model.new_context(1, len_buf, a.seq, fill_random=True)
         ctx.tokens.fill_(11)
@@ -79,13 +80,17 @@ def main():
         if ref_hidden is None:
             ref_hidden = h
         same = bool(torch.equal(h, ref_hidden))
-        g_step = capture(lambda: model.step_greedy(ctx))
-        t_step = timed(g_step, a.reps)
-        bufs = model._buffers(1)
-        bufs["hidden"].normal_()
-        g_gemv = capture(lambda: model.encode(ctx, gemv_only=True))
-        t_gemv = timed(g_gemv, a.reps)
-        row = {"variant": name, "ms_per_step": round(t_step * 1e3, 4), "tokens_per_s": round(1.0 / t_step, 1),
+        if a.no_step:
+            g_step = g_gemv = None
+            t_step = t_gemv = float("nan")
+        else:
+            g_step = capture(lambda: model.step_greedy(ctx))
+            t_step = timed(g_step, a.reps)
+            bufs = model._buffers(1)
+            bufs["hidden"].normal_()
+            g_gemv = capture(lambda: model.encode(ctx, gemv_only=True))
+            t_gemv = timed(g_gemv, a.reps)
+        row = {"variant": name, "ring_cap": a.ring, "ms_per_step": round(t_step * 1e3, 4), "tokens_per_s": round(1.0 / t_step, 1),
                "us_per_layer_step": round((t_step * 1e6 - 166.0) / a.layers, 2),
                "gemv_only_us_per_layer": round(t_gemv * 1e6 / a.layers, 2), "hidden_equals_i8p": same,
                "engine_err": int(ops.engine_state(dev)["err"].item())}

@@ -14,12 +14,16 @@
 // slot, and its issue stalls cost nobody anything.  The eight CONSUMER waves are k_w4a16_i8p's: same activation staging
 // (block-floating digit planes, wave-private), same per-item arithmetic, same accumulation and reduction order -- the outputs
 // are bit-identical to k_w4a16_i8p's (tests/test_gpu_engine.py) -- but they read their 1 KiB items with ds_read_b128.
-//   ring      S slots x (8 items + their 8 x 16 meta words) = 8704 B; slot = one row tile x eight consecutive 128-k groups,
-//             consumer wave w takes item w.  S = whatever LDS is left (13-14 slots for K = 4096 at one row).
-//   landed    one LDS word, the number of slots whose data is in LDS: the loader keeps kInFlight slots between "issued" and
-//             "counted as landed" (s_waitcnt vmcnt(9 kInFlight), nine DMA instructions per slot) and publishes the rest.
-//   consumed  one LDS counter per ring slot, +1 per consumer wave and use, added BEHIND the wave's ds_reads of the slot (a
-//             wave's LDS operations execute in order); the loader refills a slot when it has seen 8 x (round) of them.
+//   ring      slots of 9 KiB (8 items + their 8 x 16 meta words + padding: every DMA destination 1 KiB aligned); slot = one row
+//             tile x eight consecutive 128-k groups, consumer wave w takes item w.  The ring is cut into NB ROUNDS of D slots
+//             (D = the register ring of a consumer wave = R tiles x XD groups, NB >= 2: 14 slots = 2 x 7 for gate|up at one row).
+//   landed    one LDS word, the number of slots whose data is in LDS: at most 7 slots sit between "issued" and "counted as
+//             landed" (nine DMA instructions per slot, vmcnt counts to 63); whenever the loader cannot issue (seven in flight, or
+//             the next round of the ring not handed back) it waits for the OLDEST slot with a counted s_waitcnt vmcnt and publishes it.
+//   rounds    a consumer wave looks at `landed` once per round, copies its D items from STATIC ring addresses into registers,
+//             hands the round back with one LDS add (8 adds = free) and then folds the D items with no bookkeeping in between:
+//             the per-item chain (nibble expansion, two dependent MFMAs, five fp32 ops) leaves no room -- with a poll, an
+//             address computation and a release PER ITEM the consumers alone needed 10.5 us for gate|up's 28 slots (r22).
 //   consumers never meet the loader at an s_barrier after the first one: their own two rendezvous (RMSNorm partial sums,
 //             the cross-wave reduction) are LDS counters.
 // The order at the head of a launch is the one the timeline probes of round 3 asked for: the consumers request their
@@ -41,18 +45,34 @@ namespace {
 
 constexpr int kCW = 8;                     // consumer waves
 constexpr int kET = (kCW + 1) * 64;        // threads: consumers + the loader wave
-constexpr int kSlot = 8 * 1024 + 8 * 64;   // bytes per ring slot
-constexpr int kInFlight = 6;               // slots between issued and known-landed (9 DMAs each; vmcnt counts to 63)
+constexpr int kSlot = 8 * 1024 + 1024;     // bytes per ring slot: 8 items + their 8 x 16 meta words (512 B) + 512 B of padding -- every DMA destination stays 1 KiB aligned
+constexpr int kInFlight = 7;               // slots between issued and known-landed (9 DMAs each; vmcnt counts to 63)
 constexpr int kFlagBytes = 256;
 constexpr uint32_t kSpinLimit = 1u << 21;  // bounded polls (~0.1 s): a lost hand-off ends in wrong numbers + an error word, never a hang
+
+// ---- optional timeline probe (build with -DZL_ENG_PROBE; tools/ubench/probe_engine.py): wall-clock stamps (100 MHz),
+//      [workgroup][wave < 10][2][68]: row 0 = {entry, past the barrier, activations landed, staged, slot stamps A...},
+//      row 1 = slot stamps B.  Loader: A[s] = slot s issued, B[j] = its j-th slot published; consumer: A[s] = slot s fetched,
+//      B[s] = slot s folded in.
+#ifdef ZL_ENG_PROBE
+__device__ unsigned long long* zl_probe_eng = nullptr;
+// (the pointer is read ONCE per wave, in eng_lds: a load per stamp costs ~0.8 us under a saturated memory pipe)
+#define ZL_EPROBE(wave, lane, row, idx)                                                                          \
+    do {                                                                                                         \
+        if (L.probe && (lane) == 0 && (idx) < 68)                                                                \
+            L.probe[(((size_t)blockIdx.x * 10 + (wave)) * 2 + (row)) * 68 + (idx)] = wall_clock64();             \
+    } while (0)
+#else
+#define ZL_EPROBE(wave, lane, row, idx) do {} while (0)
+#endif
 
 // LDS flag block (behind the ring)
 struct EngFlags {
     uint32_t landed;        // slots landed
+    uint32_t pad0;
     uint32_t bar;           // consumer rendezvous counter
     uint32_t abort_;        // some poll ran out
-    uint32_t pad;
-    uint32_t consumed[32];  // per ring slot
+    uint32_t consumed[32];  // per ring ROUND: +1 per consumer wave and use
 };
 
 // Every LDS access below goes through an explicit address_space(3) pointer built from a 32-bit LDS byte address: passed
@@ -64,28 +84,57 @@ struct EngLds {
     uint32_t consts;   // [8 waves][Gw][4 rows][4] floats
     uint32_t red;      // [Rmax][8 waves][64] floats
     uint32_t scratch;  // [4 rows][8 waves] floats
-    int S;
+    int S;             // ring slots = NB * D
+    int D, NB;         // slots per round, rounds in the ring
+    unsigned long long* probe;   // timeline stamps (ZL_ENG_PROBE builds), else null
 };
 #define ZL_LDS(T) __attribute__((address_space(3))) T
 template <typename T> __device__ __forceinline__ T lds_ld(uint32_t a) { return *(const ZL_LDS(T)*)(uintptr_t)a; }
 template <typename T> __device__ __forceinline__ void lds_st(uint32_t a, T v) { *(ZL_LDS(T)*)(uintptr_t)a = v; }
-__device__ __forceinline__ uint32_t lds_poll(uint32_t a) { return *(const volatile ZL_LDS(uint32_t)*)(uintptr_t)a; }
+// a look at a flag word: every lane reads the same word, and the value is handed back as a SCALAR -- a branch on the raw
+// VGPR is a divergent branch to the compiler, which then keeps the loader's / consumer's whole state machine (slot counters,
+// the vmcnt switch) in VGPRs under exec masks: ~100 extra instructions per slot on the one wave that bounds the stream
+__device__ __forceinline__ uint32_t lds_poll(uint32_t a) {
+    return __builtin_amdgcn_readfirstlane(*(const volatile ZL_LDS(uint32_t)*)(uintptr_t)a);
+}
 __device__ __forceinline__ void lds_st_v(uint32_t a, uint32_t v) { *(volatile ZL_LDS(uint32_t)*)(uintptr_t)a = v; }
 __device__ __forceinline__ void lds_inc(uint32_t a) {
     __hip_atomic_fetch_add((ZL_LDS(uint32_t)*)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-constexpr uint32_t kFlLanded = 0, kFlBar = 4, kFlAbort = 8, kFlConsumed = 16;   // offsets inside EngFlags
+constexpr uint32_t kFlLanded = 0, kFlBar = 8, kFlAbort = 12, kFlConsumed = 16;   // offsets inside EngFlags
+// (fused launches; rings have at most 8 rounds, the upper counters are free) consumer waves that have their first phase's inputs in
+// registers / that have started / finished gathering a hand-off
+constexpr uint32_t kFlStaged = kFlConsumed + 4 * 29, kFlGatherIn = kFlConsumed + 4 * 30, kFlGatherOut = kFlConsumed + 4 * 31;
 
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-// one 1 KiB LDS-DMA (64 lanes x 16 B, lane-linear destination), non-temporal; M0 is compiler-reserved: saved and restored inside
-// the statement that uses it.  Invisible to hipcc's s_waitcnt bookkeeping: the loader counts its own vmcnt.
-__device__ __forceinline__ void dma16_nt(const void* gsrc, uint32_t lds_dst) {
+// LDS-DMA, non-temporal: one instruction moves 1 KiB (64 lanes x 16 B, lane-linear destination = M0 + instruction offset + 16 lane).
+// The instruction offset moves the global source AND the LDS destination (tools/ubench/ldsdma_probe.hip), so FOUR consecutive
+// KiB go out behind one M0 write: scalar base, one 32-bit lane offset, offsets 0 / 1 / 2 / 3 KiB -- a third of the issue slots of
+// four (M0 save, M0 write, 64-bit address add, DMA, M0 restore) statements, and the loader's issue rate is what bounds the
+// stream (r04 timeline: 0.4 us per 8.5 KiB slot with single-DMA statements).  M0 is compiler-reserved: saved and restored
+// inside the statement.  Invisible to hipcc's s_waitcnt bookkeeping: the loader counts its own vmcnt.
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {      // in SGPRs whatever the compiler could prove
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (const void*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void dma4k_nt(const void* sbase, uint32_t voff, uint32_t lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma1k_nt(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
@@ -95,28 +144,53 @@ struct LoadPhase {
     const unsigned char* qw;
     const unsigned char* meta;
     int tile0, tile_stride, R, Gw, groups, tiles;
+    int thin;            // this phase's stream runs beside a hand-off sweep of the consumers
 };
 struct LoaderState {
     uint32_t s;         // slots issued so far (all phases)
-    int ridx;           // s mod S
-    uint32_t round;     // s div S
+    uint32_t round_no;  // round being filled (all phases; a phase starts on a round boundary)
+    int sir;            // slot inside the round
     int pending;        // issued, not yet counted as landed
 };
 
+// count the OLDEST slot in flight as landed: nine DMAs per slot, vmcnt retires in order
+__device__ __forceinline__ void publish_oldest(LoaderState& st, const EngLds& L, int lane) {
+    switch (st.pending) {
+        case 7: wait_vmcnt<54>(); break;
+        case 6: wait_vmcnt<45>(); break;
+        case 5: wait_vmcnt<36>(); break;
+        case 4: wait_vmcnt<27>(); break;
+        case 3: wait_vmcnt<18>(); break;
+        case 2: wait_vmcnt<9>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+    --st.pending;
+    if (lane == 0) lds_st_v(L.fl + kFlLanded, st.s - (uint32_t)st.pending);
+    ZL_EPROBE(kCW, lane, 1, 4 + (int)(st.s - (uint32_t)st.pending) - 1);
+}
+
 __device__ __forceinline__ void loader_phase(const LoadPhase& f, LoaderState& st, const EngLds& L, int lane) {
     const uint32_t ring0 = L.ring;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    if (st.sir != 0) { st.sir = 0; ++st.round_no; }                    // a phase starts on a round boundary (consumers agree)
     for (int gi = 0; gi < f.Gw; ++gi) {
         for (int r = 0; r < f.R; ++r) {
-            if (st.round > 0) {
-                const uint32_t need = (uint32_t)kCW * st.round;
-                if (lds_poll(L.fl + kFlConsumed + 4u * (uint32_t)st.ridx) < need) {
-                    // the ring is full: everything issued is wanted anyway -- count it all as landed first (the consumers
-                    // cannot free a slot they have not been told about), then wait for the oldest slot
-                    wait_vmcnt<0>();
-                    if (lane == 0) lds_st_v(L.fl + kFlLanded, st.s);
-                    st.pending = 0;
-                    uint32_t spins = 0;
-                    while (lds_poll(L.fl + kFlConsumed + 4u * (uint32_t)st.ridx) < need) {
+            // at most kInFlight slots between issued and counted (63 DMAs: the width of vmcnt); whenever the loader cannot
+            // issue it counts: a slot is published as soon as it has landed, never later than the next issue
+            while (st.pending >= kInFlight) publish_oldest(st, L, lane);
+            if (f.thin) {
+                // a consumer wave of this CU is sweeping a hand-off: its sc1 loads queue behind whatever the loader has in the
+                // CU's memory pipe (a sweep took 2-3 us behind seven slots, r29) -- one slot in flight until the sweep is over
+                while (st.pending >= 1 && lds_poll(L.fl + kFlGatherIn) != lds_poll(L.fl + kFlGatherOut)) publish_oldest(st, L, lane);
+            }
+            const uint32_t half = st.round_no % (uint32_t)L.NB;
+            if (st.sir == 0 && st.round_no >= (uint32_t)L.NB) {
+                // a new round of the ring: handed back when all eight consumer waves have copied its previous content
+                const uint32_t need = (uint32_t)kCW * (st.round_no / (uint32_t)L.NB);
+                uint32_t spins = 0;
+                while (lds_poll(L.fl + kFlConsumed + 4u * half) < need) {
+                    if (st.pending > 0) publish_oldest(st, L, lane);          // (the consumers cannot free what they were not told about)
+                    else {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > kSpinLimit || ((spins & 255u) == 0u && lds_poll(L.fl + kFlAbort))) { if (lane == 0) lds_st_v(L.fl + kFlAbort, 1u); break; }
                     }
@@ -125,31 +199,29 @@ __device__ __forceinline__ void loader_phase(const LoadPhase& f, LoaderState& st
             int tile = f.tile0 + r * f.tile_stride;
             if (tile >= f.tiles) tile = f.tiles - 1;          // a tile past the end: the slot is still counted, its content unused
             const size_t item0 = (size_t)tile * (size_t)f.groups + (size_t)gi * 8;
-            const unsigned char* src = f.qw + item0 * 1024 + (size_t)lane * 16;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)st.ridx * (uint32_t)kSlot);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dma16_nt(src + (size_t)i * 1024, dst + (uint32_t)i * 1024u);
-            // the eight items' meta words: 512 contiguous bytes = half a DMA (lanes 32..63 re-read the first half into the pad)
-            dma16_nt(f.meta + item0 * 64 + (size_t)(lane & 31) * 16, dst + 8192u);
+            const unsigned char* src = (const unsigned char*)uniform_ptr(f.qw + item0 * 1024);   // scalar base of the DMAs
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(ring0 + (half * (uint32_t)L.D + (uint32_t)st.sir) * (uint32_t)kSlot);
+            dma4k_nt(src, voff, dst);
+            dma4k_nt(src + 4096, voff, dst + 4096u);
+            // the eight items' meta words: 512 contiguous bytes = half a DMA (lanes 0..31; an inactive lane moves nothing)
+            const void* msrc = uniform_ptr(f.meta + item0 * 64);
+            if (lane < 32) dma1k_nt(msrc, voff, dst + 8192u);
+            ZL_EPROBE(kCW, lane, 0, 4 + (int)st.s);
             ++st.s;
-            if (++st.ridx == L.S) { st.ridx = 0; ++st.round; }
-            if (++st.pending > kInFlight) {
-                wait_vmcnt<9 * kInFlight>();
-                if (lane == 0) lds_st_v(L.fl + kFlLanded, st.s - (uint32_t)kInFlight);
-                st.pending = kInFlight;
-            }
+            ++st.pending;
+            if (++st.sir == L.D) { st.sir = 0; ++st.round_no; }
         }
     }
 }
 __device__ __forceinline__ void loader_finish(LoaderState& st, const EngLds& L, int lane) {
-    wait_vmcnt<0>();
-    if (lane == 0) lds_st_v(L.fl + kFlLanded, st.s);
+    while (st.pending > 0) publish_oldest(st, L, lane);
 }
 
 // ---- consumers ------------------------------------------------------------------------------------------------------------
 struct ConsState {
-    uint32_t s;          // next slot to consume (all phases)
-    int ridx;
+    uint32_t taken;      // slots taken so far (all phases) -- the loader's `landed` counts the same slots
+    uint32_t seen;       // landed count last read: the flag is looked at again only when a round runs past it
+    uint32_t round_no;   // round being read (all phases)
     uint32_t bar_target; // rendezvous count reached after the next consumer barrier
 };
 
@@ -166,22 +238,18 @@ __device__ __forceinline__ void consumer_barrier(ConsState& cs, const EngLds& L,
     asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ void fetch_item(ConsState& cs, const EngLds& L, int wave, int lane, uint4& w, uint32_t& mw) {
-    uint32_t spins = 0;
-    while (lds_poll(L.fl + kFlLanded) <= cs.s) {
+// wait until `upto` slots of the launch have landed
+__device__ __forceinline__ void wait_landed(ConsState& cs, const EngLds& L, uint32_t upto, int lane) {
+    if (cs.seen >= upto) return;
+    uint32_t spins = 0, v;
+    while ((v = lds_poll(L.fl + kFlLanded)) < upto) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kSpinLimit || ((spins & 255u) == 0u && lds_poll(L.fl + kFlAbort))) { if (lane == 0) lds_st_v(L.fl + kFlAbort, 1u); break; }
     }
+    cs.seen = v;
     asm volatile("" ::: "memory");
-    const uint32_t sl = L.ring + (uint32_t)cs.ridx * (uint32_t)kSlot;
-    const u32x4 wv = lds_ld<u32x4>(sl + (uint32_t)(wave * 1024 + lane * 16));
-    w = make_uint4(wv.x, wv.y, wv.z, wv.w);
-    mw = lds_ld<uint32_t>(sl + 8192u + (uint32_t)(wave * 64 + (lane & 15) * 4));
-    asm volatile("" ::: "memory");   // the release stays behind the two reads; the LDS executes a wave's operations in order
-    if (lane == 0) lds_inc(L.fl + kFlConsumed + 4u * (uint32_t)cs.ridx);
-    ++cs.s;
-    if (++cs.ridx == L.S) cs.ridx = 0;
 }
+
 
 // where a phase's activation rows come from / where its outputs go besides p.y
 enum { XS_GLOBAL = 0, XS_GRANULES = 1 };
@@ -196,7 +264,7 @@ typedef unsigned long long __attribute__((address_space(1))) gu64;
 // One projection on the consumer waves.  Template parameters as k_w4a16_i8p's; XS = where the activation rows come from,
 // PUB = publish the outputs as granules for a later phase of the SAME launch (besides the plain store to p.y).
 // FIRST: this phase runs at the head of the launch (its requests go out before the launch's one s_barrier).
-template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE, int XS, bool PUB, bool FIRST>
+template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE, int XS, bool PUB, bool FIRST, int D>
 __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange& ex, const EngLds& L, ConsState& cs,
                                               const int wave, const int lane) {
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
@@ -213,6 +281,14 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
 
     const int tile0 = ROPE ? (blockIdx.x / p.pair_stride) * 2 * p.pair_stride + blockIdx.x % p.pair_stride : blockIdx.x * R;
 
+    // MERGE: the launch's s_barrier comes FIRST -- the 32 record loads per lane of the split merge keep the CU's address unit busy
+    // for ~2 us (135 KB per workgroup), and a loader held back behind them starts the ring at 2.5 us (r27 timeline); the records'
+    // first touch is latency the ring can use
+    if constexpr (FIRST && MERGE) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- activations (k_w4a16_i8p's staging: a wave loads exactly the k ranges of ITS groups)
     uint4 xr[NS], nw[LONGK ? 4 : 1];
     const int lgi = lane >> 4, uo = lane & 15;
@@ -246,13 +322,6 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
                         st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rstat, so, uc * 8u, 0));
                     }
                     const int elen = min(p.buf_lens[row], p.mg_valid_lens[row]);
-                    if constexpr (FIRST) {
-                        if (s == 0) {                                 // the loader starts the ring behind these requests
-                            __builtin_amdgcn_sched_barrier(0);        // (pinned: the scheduler moved the merge arithmetic and its
-                            __builtin_amdgcn_s_barrier();             //  vmcnt waits in front of the barrier otherwise)
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
                     const int ns = min((elen + p.mg_split_len - 1) / p.mg_split_len, kS);
                     float mn = -1e20f;
 #pragma unroll
@@ -289,30 +358,51 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
             }
         }
     }
-    // epilogue operands, requested next to the activations (k_w4a16_i8p)
-    float rp_c0 = 0.f, rp_s0 = 0.f, rp_c1 = 0.f, rp_s1 = 0.f;
-    int rp_place = -1, rp_blen = 0;
-    uint16_t* rp_kv = nullptr;
+    // ---- the launch's one s_barrier: the activation requests are in the CU's memory queue, the loader may start the ring
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FIRST) ZL_EPROBE(wave, lane, 0, 0);
+    if constexpr (FIRST && !MERGE) __builtin_amdgcn_s_barrier();
+    if constexpr (FIRST) ZL_EPROBE(wave, lane, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue operands, requested now (behind the first ring slots: they are needed at the very end).  Branch-free and a
+    //      FIXED number of loads (kEpiLoads): the wait for the activations below is a counted vmcnt that leaves exactly these
+    //      in flight.  Operands that do not apply read through an empty descriptor / past its end and come back as zero.
+    const uint32_t kOob = 0x7ffffff0u;
+    constexpr int kEpiLoads = ROPE ? 10 : 4;
+    uint32_t rp_c0r = 0, rp_s0r = 0, rp_c1r = 0, rp_s1r = 0, rp_placer = 0, rp_blenr = 0, rp_b0r = 0, rp_b1r = 0;
+    unsigned long long rp_kptr = 0, rp_vptr = 0;
+    bool rp_kv_row = false;
     if constexpr (ROPE) {
-        if (tid < 16 * M) {
-            const int m = tid >> 4, n0 = tile0 * 16 + (tid & 15);
-            const int head = n0 / p.d, dcol = n0 % p.d, half = p.d / 2;
-            if (head < p.h + p.hkv) {
-                rp_c0 = p.cosv[(size_t)m * p.d + dcol]; rp_s0 = p.sinv[(size_t)m * p.d + dcol];
-                rp_c1 = p.cosv[(size_t)m * p.d + dcol + half]; rp_s1 = p.sinv[(size_t)m * p.d + dcol + half];
-            }
-            if (head >= p.h) {
-                rp_place = p.placement[m];
-                rp_blen = p.buf_lens[m];
-                rp_kv = head < p.h + p.hkv ? p.k_bufs[m] : p.v_bufs[m];
-            }
-        }
+        const int m = tid >> 4, n0 = tile0 * 16 + (tid & 15);
+        const int head = n0 / p.d, dcol = n0 % p.d, half = p.d / 2;
+        const bool mine = tid < 16 * M;
+        const bool rot = mine && head < p.h + p.hkv;
+        rp_kv_row = mine && head >= p.h;
+        const uint32_t tab_bytes = (uint32_t)M * (uint32_t)p.d * 4u;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.cosv), 0, tab_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.sinv), 0, tab_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.placement), 0, (uint32_t)M * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.buf_lens), 0, (uint32_t)M * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rkb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t**>(p.k_bufs), 0, (uint32_t)M * 8u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rvb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t**>(p.v_bufs), 0, (uint32_t)M * 8u, 0x00020000);
+        const bool has_bias = (p.epi & ZL_EPI_BIAS) && p.bias;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bias), 0, has_bias ? (uint32_t)p.n * 2u : 0u, 0x00020000);
+        const uint32_t toff = rot ? ((uint32_t)m * (uint32_t)p.d + (uint32_t)dcol) * 4u : kOob;
+        rp_c0r = __builtin_amdgcn_raw_buffer_load_b32(rc, toff, 0, 0);
+        rp_s0r = __builtin_amdgcn_raw_buffer_load_b32(rsn, toff, 0, 0);
+        rp_c1r = __builtin_amdgcn_raw_buffer_load_b32(rc, toff + (uint32_t)half * 4u, 0, 0);
+        rp_s1r = __builtin_amdgcn_raw_buffer_load_b32(rsn, toff + (uint32_t)half * 4u, 0, 0);
+        rp_placer = __builtin_amdgcn_raw_buffer_load_b32(rpl, rp_kv_row ? (uint32_t)m * 4u : kOob, 0, 0);
+        rp_blenr = __builtin_amdgcn_raw_buffer_load_b32(rbl, rp_kv_row ? (uint32_t)m * 4u : kOob, 0, 0);
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+        const u2 kp = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(rkb, rp_kv_row && head < p.h + p.hkv ? (uint32_t)m * 8u : kOob, 0, 0));
+        const u2 vp = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(rvb, rp_kv_row && head >= p.h + p.hkv ? (uint32_t)m * 8u : kOob, 0, 0));
+        rp_kptr = __builtin_bit_cast(unsigned long long, kp);
+        rp_vptr = __builtin_bit_cast(unsigned long long, vp);
+        rp_b0r = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rb, mine ? (uint32_t)n0 * 2u : kOob, 0, 0);
+        rp_b1r = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rb, mine ? (uint32_t)(n0 + half) * 2u : kOob, 0, 0);
     }
     const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
-    // (raw 16-bit patterns: a conversion here would make the compiler wait for the load -- and with it for every older request
-    //  of the wave -- in front of the launch's s_barrier, i.e. hold the loader back until the activations have landed)
-    // Branch-free: a load inside control flow costs a conservative vmcnt(0) at the join -- in front of the barrier.  Operands that
-    // do not apply read through an empty descriptor / past its end and come back as zero.
     uint32_t ep_b0r = 0, ep_b1r = 0, ep_resr = 0, ep_prevr = 0;
     int ep_r = 0, ep_m = 0, ep_nl = 0, ep_col = -1;
     if constexpr (!ROPE) {
@@ -325,7 +415,6 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
         const int col = silu ? tile * 8 + ep_nl : tile * 16 + ep_nl;           // output column (silu: the pair's index)
         const bool ok = mine && (silu ? 2 * col + 1 < p.n : col < p.n);
         ep_col = ok ? col : -1;
-        const uint32_t kOob = 0x7ffffff0u;
         const bool has_bias = (p.epi & ZL_EPI_BIAS) && p.bias;
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bias), 0, has_bias ? (uint32_t)p.n * 2u : 0u, 0x00020000);
         const uint32_t out_bytes = (uint32_t)M * (uint32_t)p.ld_out * 2u;
@@ -338,8 +427,8 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
         ep_prevr = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(ry, ooff, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (FIRST && !MERGE) __builtin_amdgcn_s_barrier();   // requests are in the CU's queue: the loader may start
     if constexpr (XS == XS_GRANULES) {
+        if (lane == 0) lds_inc(L.fl + kFlGatherIn);
         // the rows arrive from the previous phase of THIS launch: 8 halves per lane and slot = 4 granules, swept until every
         // tag carries the epoch (sc1 loads: another CU's write-through store is seen at the next sweep)
 #pragma unroll
@@ -349,15 +438,22 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
             xr[s] = make_uint4(0, 0, 0, 0);
             if (row < M && 4 * c < Gw) {
                 const gu64* src = (const gu64*)(ex.gran + ((size_t)row * K + (size_t)(g < groups ? g : 0) * 128 + uo * 8) / 2);
-                uint32_t v[4];
+                uint32_t v[4] = {0u, 0u, 0u, 0u};
+                bool have[4] = {false, false, false, false};
                 uint32_t spins = 0;
                 for (;;) {
+                    // only the granules still missing are read again, and the sweeps are ~0.2 us apart: eight waves sweeping
+                    // without a pause next to the loader stretched its slots from 3 to 4.6 us (r28 timeline; the guide's
+                    // polling-cost row)
                     bool ok = true;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const unsigned long long t = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v[e] = (uint32_t)t;
-                        ok &= (uint32_t)(t >> 32) == ex.epoch;
+                        if (!have[e]) {
+                            const unsigned long long t = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            have[e] = (uint32_t)(t >> 32) == ex.epoch;
+                            if (have[e]) v[e] = (uint32_t)t;
+                        }
+                        ok &= have[e];
                     }
                     if (__all(ok)) break;
                     __builtin_amdgcn_s_sleep(2);
@@ -369,12 +465,18 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
                 if (g < groups) xr[s] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
+        if (lane == 0) lds_inc(L.fl + kFlGatherOut);
     } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the activations have landed (builtin: see w4_i8p.hip)
+        // the activations (and norm weights) have landed; the kEpiLoads younger requests stay in flight (a builtin wait: hipcc
+        // models it, see w4_i8p.hip).  MERGE: the merge arithmetic above already consumed its records
+        if constexpr (!MERGE) __builtin_amdgcn_s_waitcnt(0x0F70 | kEpiLoads);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // (the patterns become visible to the compiler only here: it hoisted their conversions -- and a vmcnt(0) -- above the barrier)
-    asm volatile("" : "+v"(ep_b0r), "+v"(ep_b1r), "+v"(ep_resr), "+v"(ep_prevr));
+    if constexpr (FIRST && MERGE && PUB) {                     // fused launch: the loader may go on to the next projection's weights
+        asm volatile("" :: "v"(xr[0].x), "v"(xr[0].y), "v"(xr[0].z), "v"(xr[0].w));     // (after the merged row exists)
+        if (lane == 0) lds_inc(L.fl + kFlStaged);
+    }
+    ZL_EPROBE(wave, lane, FIRST ? 0 : 1, 2);
 
     // ---- fused RMSNorm: eight partial sums through LDS, consumer rendezvous
     float rs[NR];
@@ -482,6 +584,7 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    ZL_EPROBE(wave, lane, FIRST ? 0 : 1, 3);
 
     // ---- main loop: items come out of the LDS ring, one fetch ahead of the arithmetic
     const int kq = lane >> 4, row16 = lane & 15;
@@ -493,18 +596,44 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
     const uint32_t m4 = __builtin_amdgcn_readfirstlane(0x0f0f0f0fu);
     const v4i zero4 = (v4i){0, 0, 0, 0};
-    uint4 wn;
-    uint32_t mn_;
-    fetch_item(cs, L, wave, lane, wn, mn_);
-    for (int gi = 0; gi < Gw; ++gi) {
-        const v4i a0 = lds_ld<v4i>(a_base + (uint32_t)((gi * 2 + 0) * 4 * rec));
-        const v4i a1 = lds_ld<v4i>(a_base + (uint32_t)((gi * 2 + 1) * 4 * rec));
-        const f32x4 cst = lds_ld<f32x4>(consts + (uint32_t)((gi * 4 + crow) * 16));
+    // rounds of D = R x XD slots: one look at the landed count, D item reads from static ring addresses, one release, then
+    // D folds with nothing in between (see the header)
+    constexpr int XD = D / R;
+    static_assert(D % R == 0 && XD >= 1, "a round holds whole groups of R tiles");
+    for (int gi0 = 0; gi0 < Gw; gi0 += XD) {
+        const int n = min(XD, Gw - gi0) * R;                           // slots of this round
+        const uint32_t base = cs.taken;
+        const uint32_t roff = (cs.round_no % (uint32_t)L.NB) * (uint32_t)(D * kSlot);
+        const uint32_t rbase = L.ring + roff + (uint32_t)(wave * 1024 + lane * 16);
+        const uint32_t mbase = L.ring + roff + 8192u + (uint32_t)(wave * 64 + (lane & 15) * 4);
+        uint4 wq[D];
+        uint32_t mt[D];
+        auto read_item = [&](int q) {                                  // q static
+            wait_landed(cs, L, base + (uint32_t)q + 1u, lane);         // a scalar compare unless the consumers have caught up
+            const u32x4 wv = lds_ld<u32x4>(rbase + (uint32_t)(q * kSlot));
+            wq[q] = make_uint4(wv.x, wv.y, wv.z, wv.w);
+            mt[q] = lds_ld<uint32_t>(mbase + (uint32_t)(q * kSlot));
+        };
+        read_item(0);
+        v4i a0 = zero4, a1 = zero4;
+        f32x4 cst = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint4 w = wn;
-            const uint32_t mw = mn_;
-            if (!(gi == Gw - 1 && r == R - 1)) fetch_item(cs, L, wave, lane, wn, mn_);
+        for (int q = 0; q < D; ++q) {
+            if (q >= n) break;
+            constexpr int dummy = 0; (void)dummy;
+            const int j = q / R, r = q % R, gi = gi0 + j;
+            if (q + 1 < D && q + 1 < n) read_item(q + 1);              // one item ahead of the arithmetic
+            if (q + 1 == n) {                                          // every item of the round is on its way to registers: hand the round back
+                asm volatile("" ::: "memory");                         // (the release stays behind the reads; the LDS executes a wave's operations in order)
+                if (lane == 0) lds_inc(L.fl + kFlConsumed + 4u * (cs.round_no % (uint32_t)L.NB));
+            }
+            if (r == 0) {
+                a0 = lds_ld<v4i>(a_base + (uint32_t)((gi * 2 + 0) * 4 * rec));
+                a1 = lds_ld<v4i>(a_base + (uint32_t)((gi * 2 + 1) * 4 * rec));
+                cst = lds_ld<f32x4>(consts + (uint32_t)((gi * 4 + crow) * 16));
+            }
+            const uint4 w = wq[q];
+            const uint32_t mw = mt[q];
             v4i b0, b1;
             b0[0] = (int)(w.x & m4); b0[1] = (int)((w.x >> 4) & m4); b0[2] = (int)(w.y & m4); b0[3] = (int)((w.y >> 4) & m4);
             b1[0] = (int)(w.z & m4); b1[1] = (int)((w.z >> 4) & m4); b1[2] = (int)(w.w & m4); b1[3] = (int)((w.w >> 4) & m4);
@@ -517,13 +646,21 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
             t = __builtin_fmaf(f0, cst.y, t);
             asm volatile("" : "+v"(t) : "v"(b0), "v"(b1), "v"(a0), "v"(a1));   // MFMA source-operand hazard: w4_i8p.hip
             acc[r] = __builtin_fmaf((float)sm.x, t, acc[r]);
+            ZL_EPROBE(wave, lane, 1, 4 + (int)base + q);
         }
+        cs.taken = base + (uint32_t)n;
+        ++cs.round_no;
     }
 
     // ---- reduce over the 8 waves in fixed order, epilogue
 #pragma unroll
     for (int r = 0; r < R; ++r) lds_st<float>(red + 4u * (uint32_t)((r * kCW + wave) * 64 + lane), acc[r]);
     consumer_barrier(cs, L, lane);
+    // the epilogue operands become visible to the compiler only HERE (volatile statements keep their place): their first use --
+    // and with it the wait for the loads, which sit behind the first ring slots in the CU's queue -- cannot be scheduled earlier
+    asm volatile("" : "+v"(ep_b0r), "+v"(ep_b1r), "+v"(ep_resr), "+v"(ep_prevr));
+    asm volatile("" : "+v"(rp_c0r), "+v"(rp_s0r), "+v"(rp_c1r), "+v"(rp_s1r), "+v"(rp_placer), "+v"(rp_blenr), "+v"(rp_b0r), "+v"(rp_b1r));
+    asm volatile("" : "+v"(rp_kptr), "+v"(rp_vptr));
     auto total_of = [&](int r, int n_local, int m) {
         float v = 0.f;
 #pragma unroll
@@ -535,11 +672,15 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
         if (tid < 16 * M) {
             const int m = tid >> 4, n_local = tid & 15;
             float v0 = total_of(0, n_local, m), v1 = total_of(1, n_local, m);
-            const int n0 = tile0 * 16 + n_local, n1 = n0 + half;
+            const int n0 = tile0 * 16 + n_local;                       // columns n0 and n0 + half of the fused qkv row
             if ((p.epi & ZL_EPI_BIAS) && p.bias) {
-                v0 += (float)__builtin_bit_cast(_Float16, p.bias[n0]);
-                v1 += (float)__builtin_bit_cast(_Float16, p.bias[n1]);
+                v0 += (float)__builtin_bit_cast(_Float16, (uint16_t)rp_b0r);
+                v1 += (float)__builtin_bit_cast(_Float16, (uint16_t)rp_b1r);
             }
+            const float rp_c0 = __builtin_bit_cast(float, rp_c0r), rp_s0 = __builtin_bit_cast(float, rp_s0r);
+            const float rp_c1 = __builtin_bit_cast(float, rp_c1r), rp_s1 = __builtin_bit_cast(float, rp_s1r);
+            const int rp_place = rp_kv_row ? (int)rp_placer : -1, rp_blen = (int)rp_blenr;
+            uint16_t* rp_kv = reinterpret_cast<uint16_t*>(rp_kptr | rp_vptr);
             const float a = (float)zl_f32_to_f16(v0), bb = (float)zl_f32_to_f16(v1);
             const int head = n0 / p.d, dcol = n0 % p.d;
             if (head < p.h + p.hkv) {
@@ -594,6 +735,7 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
         p.y[(size_t)ep_m * p.ld_out + ep_col] = y16bits;
     }
     if constexpr (PUB) {
+        ZL_EPROBE(wave, lane, 1, 0);
         // hand the outputs to the next phase of this launch: neighbouring columns share a granule (even column = low half).
         // Only full tiles are published (n % 16 == 0 is a condition of the fused launcher).
         const uint32_t other = (uint32_t)__shfl_xor((int)y16bits, 1, 64);
@@ -606,22 +748,28 @@ __device__ __forceinline__ void consume_phase(const I8Params& p, const Exchange&
 
 // ---- LDS carve --------------------------------------------------------------------------------------------------------------
 struct EngGeom {
-    int S;              // ring slots
+    int S;              // ring slots = NB * D
+    int D, NB;          // slots per round, rounds in the ring
     int planes_off, consts_off, red_off, scratch_off, flags_off;
     int total;
 };
-static inline EngGeom eng_geom(int gw_max, int m, int r_max, int slots_cap) {
+// slots per round of a projection with R row tiles per workgroup: the consumer's register ring (R tiles x XD groups)
+constexpr int eng_round(int r) { return r >= 3 ? r : 4; }
+
+static inline EngGeom eng_geom(int gw_max, int m, int r_max, int d, int rounds_cap) {
     EngGeom g;
     const int planes = kCW * gw_max * 8 * 64 * m;
     const int consts = kCW * gw_max * 64;
     const int red = r_max * kCW * 64 * 4;
     const int scratch = 4 * kCW * 4;
     const int fixed = planes + consts + red + scratch + kFlagBytes;
-    int S = (160 * 1024 - fixed) / kSlot;
-    if (S > 32) S = 32;
-    if (slots_cap > 0 && S > slots_cap) S = slots_cap;
-    g.S = S;
-    g.flags_off = S * kSlot;
+    int nb = (160 * 1024 - fixed) / (kSlot * d);
+    if (nb > 8) nb = 8;
+    if (rounds_cap > 0 && nb > rounds_cap) nb = rounds_cap;
+    g.D = d;
+    g.NB = nb;
+    g.S = nb * d;
+    g.flags_off = g.S * kSlot;
     g.planes_off = g.flags_off + kFlagBytes;
     g.consts_off = g.planes_off + planes;
     g.red_off = g.consts_off + consts;
@@ -639,14 +787,22 @@ __device__ __forceinline__ EngLds eng_lds(unsigned char* smem, const EngGeom& g)
     L.red = base + (uint32_t)g.red_off;
     L.scratch = base + (uint32_t)g.scratch_off;
     L.S = g.S;
+    L.D = g.D;
+    L.NB = g.NB;
+    L.probe = nullptr;
+#ifdef ZL_ENG_PROBE
+    L.probe = blockIdx.x < 256 ? zl_probe_eng : nullptr;
+#endif
     return L;
 }
 
-__device__ __forceinline__ void loader_prologue(const EngLds& L, int lane) {
-    // the flag block is zeroed by the loader before the launch's one s_barrier; nobody reads it earlier
-    if (lane < (int)(sizeof(EngFlags) / 4)) lds_st_v(L.fl + 4u * (uint32_t)lane, 0u);
+__device__ __forceinline__ void loader_prologue(const EngLds& L, int lane, bool first) {
+    // the flag block is zeroed by the (first) loader before the launch's one s_barrier; nobody reads it earlier
+    if (first && lane < (int)(sizeof(EngFlags) / 4)) lds_st_v(L.fl + 4u * (uint32_t)lane, 0u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ZL_EPROBE(first ? kCW : kCW + 1, lane, 0, 0);
     __builtin_amdgcn_s_barrier();
+    ZL_EPROBE(first ? kCW : kCW + 1, lane, 0, 1);
 }
 __device__ __forceinline__ LoadPhase load_phase_of(const I8Params& p, int R, bool rope) {
     LoadPhase f;
@@ -658,6 +814,7 @@ __device__ __forceinline__ LoadPhase load_phase_of(const I8Params& p, int R, boo
     f.Gw = p.groups / kCW;
     f.groups = p.groups;
     f.tiles = p.tiles;
+    f.thin = 0;
     return f;
 }
 
@@ -668,17 +825,17 @@ __global__ __launch_bounds__(kET, 1) void k_w4_engine(const I8Params p, const En
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const EngLds L = eng_lds(smem, g);
-    if (wave == kCW) {
-        loader_prologue(L, lane);
-        LoaderState st = {0u, 0, 0u, 0};
+    if (wave >= kCW) {
+        loader_prologue(L, lane, true);
+        LoaderState st = {0u, 0u, 0, 0};
         const LoadPhase f = load_phase_of(p, R, ROPE);
         loader_phase(f, st, L, lane);
         loader_finish(st, L, lane);
         return;
     }
-    ConsState cs = {0u, 0, 0u};
+    ConsState cs = {0u, 0u, 0u, 0u};
     const Exchange ex = {nullptr, 0u, nullptr};
-    consume_phase<R, LONGK, ROPE, NORM, MERGE, XS_GLOBAL, false, true>(p, ex, L, cs, wave, lane);
+    consume_phase<R, LONGK, ROPE, NORM, MERGE, XS_GLOBAL, false, true, eng_round(R)>(p, ex, L, cs, wave, lane);
 }
 
 // attention split merge + attn_out + residual  ->  RMSNorm + gate|up + silu.mul, one launch (see the header)
@@ -690,23 +847,36 @@ __global__ __launch_bounds__(kET, 1) void k_w4_engine_o_gateup(const I8Params p1
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const EngLds L = eng_lds(smem, g);
-    if (wave == kCW) {
-        loader_prologue(L, lane);
-        LoaderState st = {0u, 0, 0u, 0};
+    if (wave >= kCW) {
+        loader_prologue(L, lane, true);
+        LoaderState st = {0u, 0u, 0, 0};
         const LoadPhase f1 = load_phase_of(p1, 1, false);
         loader_phase(f1, st, L, lane);
-        const LoadPhase f2 = load_phase_of(p2, R2, false);
+        // the second projection's stream starts when the first one's inputs are in registers: before that its requests would
+        // only slow the split merge's 32 record loads per lane down (and be slowed by them)
+        {
+            uint32_t spins = 0;
+            while (lds_poll(L.fl + kFlStaged) < (uint32_t)kCW) {
+                if (st.pending > 0) publish_oldest(st, L, lane);
+                else {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kSpinLimit) break;
+                }
+            }
+        }
+        LoadPhase f2 = load_phase_of(p2, R2, false);
+        f2.thin = 1;
         loader_phase(f2, st, L, lane);
         loader_finish(st, L, lane);
         return;
     }
-    ConsState cs = {0u, 0, 0u};
+    ConsState cs = {0u, 0u, 0u, 0u};
     Exchange ex;
     ex.gran = gran;
     ex.epoch = *epoch_ptr + epoch_add;
     ex.err = err;
-    consume_phase<1, false, false, false, true, XS_GLOBAL, true, true>(p1, ex, L, cs, wave, lane);
-    consume_phase<R2, false, false, true, false, XS_GRANULES, false, false>(p2, ex, L, cs, wave, lane);
+    consume_phase<1, false, false, false, true, XS_GLOBAL, true, true, eng_round(R2)>(p1, ex, L, cs, wave, lane);
+    consume_phase<R2, false, false, true, false, XS_GRANULES, false, false, eng_round(R2)>(p2, ex, L, cs, wave, lane);
     if (lane == 0 && wave == 0 && err && lds_poll(L.fl + kFlAbort)) atomicOr(err, 1u);
 }
 
@@ -724,10 +894,13 @@ static int eng_set_lds(KT kern, int bytes) {
     return ZL_OK;
 }
 
+// experiment knob (tools/bench_engine.py; not part of the ABI): cap on the rounds of the ring
+static int g_dbg_rounds_cap = 0;
+
 template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE>
-int launch_engine(const I8Params& p, int grid, int slots_cap, hipStream_t hs) {
-    const EngGeom g = eng_geom(p.groups / kCW, p.m, R, slots_cap);
-    if (g.S < kInFlight + 2) return ZL_ELIMIT;
+int launch_engine(const I8Params& p, int grid, int rounds_cap, hipStream_t hs) {
+    const EngGeom g = eng_geom(p.groups / kCW, p.m, R, eng_round(R), rounds_cap > 0 ? rounds_cap : g_dbg_rounds_cap);
+    if (g.NB < 2) return ZL_ELIMIT;
     int st = eng_set_lds(&k_w4_engine<R, LONGK, ROPE, NORM, MERGE>, g.total);
     if (st) return st;
     hipLaunchKernelGGL((k_w4_engine<R, LONGK, ROPE, NORM, MERGE>), dim3(grid), dim3(kET), g.total, hs, p, g);
@@ -753,7 +926,7 @@ I8Params eng_params(const uint16_t* x, int64_t ldx, const uint32_t* qw, const ui
 // leaves the loader a ring worth having
 bool zl_w4_engine_covers(int64_t m, int64_t k, int r) {
     if (m < 1 || m > 4 || k < 1024 || k % 1024 != 0 || k > 16384 || (k > 4096 && m > 2)) return false;
-    return eng_geom((int)(k / 1024), (int)m, r, 0).S >= kInFlight + 2;
+    return eng_geom((int)(k / 1024), (int)m, r, eng_round(r), 0).NB >= 2;
 }
 
 // internal (called by zl_w4a16_gemm_mfma_ex under zl_w4_opts_t::small_algo == 2)
@@ -841,8 +1014,8 @@ int zl_w4_engine_o_gateup_launch(const void* ws, const int32_t* buf_lens, const 
     I8Params p2 = eng_params(nullptr, 0, qw2, meta2, qw2_bytes, meta2_bytes, bias2, nullptr, act, m, n2, n1, groups2, tiles2,
                              epilogue2, n2 / 2, norm_w, norm_eps);
     const int gw = (groups1 > groups2 ? groups1 : groups2) / kCW;
-    const EngGeom g = eng_geom(gw, m, r2, 0);
-    if (g.S < kInFlight + 2) return ZL_ELIMIT;
+    const EngGeom g = eng_geom(gw, m, r2, eng_round(r2), g_dbg_rounds_cap);
+    if (g.NB < 2) return ZL_ELIMIT;
     unsigned long long* gran = reinterpret_cast<unsigned long long*>(granules);
 #define ZL_FUSE(RR)                                                                                                  \
     case RR: {                                                                                                       \
@@ -856,6 +1029,12 @@ int zl_w4_engine_o_gateup_launch(const void* ws, const int32_t* buf_lens, const 
 #undef ZL_FUSE
     return ZL_EINVAL;
 }
+
+#ifdef ZL_ENG_PROBE
+extern "C" int zl_debug_set_probe_engine(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(zl_probe_eng), &p, sizeof(p)); }
+#endif
+
+extern "C" void zl_debug_engine_knobs(int rounds_cap) { g_dbg_rounds_cap = rounds_cap; }
 
 int zl_engine_epoch_advance_launch(uint32_t* epoch, uint32_t by, hipStream_t hs) {
     hipLaunchKernelGGL(k_engine_epoch_advance, dim3(1), dim3(64), 0, hs, epoch, by);
