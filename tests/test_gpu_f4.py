@@ -390,3 +390,52 @@ def test_moe_feed_forward_flow_equals_the_per_token_sum(dev, tokens, router, dty
         routed, moe.shared = moe.shared, None
         assert not torch.equal(moe.forward(x), got)
         moe.shared = routed
+
+
+@pytest.mark.parametrize("scoring", ["softmax", "sigmoid", "linear"])
+def test_top_k_router_ties(oracle, dev, scoring):
+    """logits from a handful of levels: most of the top-k boundary is a TIE.  The reference's insertion sort never lets a later
+    equal value displace an earlier one (ff_kernel.cu:98-124) -- equal scores rank by expert index -- which is the integer order
+    of the (score, ~index) keys the wave64 router selects by."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(5)
+    tokens, experts, k = 64, 128, 8
+    levels = np.array([-2.0, -0.5, 0.0, 0.25, 1.0, 1.0, 3.0], np.float32)
+    logits = torch.from_numpy(levels[rng.integers(0, len(levels), (tokens, experts))]).to(torch.float16)
+    logits[0, :] = 0.75                                               # every expert equal: the first k indices, in order
+    v, idx = ops.moe_top_k_softmax(logits.to(dev), k, k, True, 1.0, scoring, None, None, 1)
+    wv, widx, _, _ = oracle.moe_top_k_softmax(_bits(logits), k, k, True, 1.0, scoring, 0, 0)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    assert np.array_equal(idx.cpu().numpy()[0], np.arange(k))
+    assert _ulps(v.cpu().numpy(), wv).max() <= 8
+
+
+@pytest.mark.parametrize("experts,groups,topk_group,k,bias", [(256, 8, 4, 8, True), (256, 8, 4, 8, False), (64, 4, 2, 4, False)])
+def test_group_limited_router_ties(oracle, dev, experts, groups, topk_group, k, bias):
+    """the same for the group-limited router: tied GROUP scores (kept by smaller group index) and tied expert scores inside and
+    across the kept groups (smaller expert index first, the bitonic compare-exchange's rule, ff_kernel.cu:273-291)"""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(experts + k)
+    tokens = 48
+    levels = np.array([-1.0, 0.0, 0.5, 0.5, 2.0], np.float32)
+    logits = torch.from_numpy(levels[rng.integers(0, len(levels), (tokens, experts))]).to(torch.float16)
+    logits[0, :] = 0.5                                                # all groups tie, all experts tie
+    b = (np.round(rng.standard_normal(experts) * 2) * 0.125).astype(np.float32) if bias else None     # a coarse bias keeps ties alive
+    v, idx = ops.moe_group_topk(logits.to(dev), None if b is None else _t(b, dev), groups, topk_group, k, k, True, 2.5, "sigmoid", None, None, 1)
+    wv, widx, _, _ = oracle.moe_group_topk(_bits(logits), b, k, groups, topk_group, k, True, 2.5, "sigmoid", 0, 0)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    if not bias:
+        assert np.array_equal(idx.cpu().numpy()[0], np.arange(k))     # groups 0 .. topk_group - 1 kept, their lowest indices win
+    assert _ulps(v.cpu().numpy(), wv).max() <= 8
+
+
+def test_per_token_cast_more_rows_than_a_grid_dimension(oracle, dev):
+    """a DeepSeek-V3 prefill of 8K+ tokens casts tokens x top_k (+ padding) > 65535 grouped rows; the rows ride on grid.x
+    now (the reference launches grid (m, n / 128) as well, fp8_util.cu:277-322)"""
+    from zhilight_amd import ops
+    m, n = 65536 + 77, 256
+    x = (torch.randn(m, n) * 3).to(torch.bfloat16)
+    codes, scales = ops.fp8_per_token_cast(x.to(dev))
+    want_c, want_s = oracle.fp8_per_token_cast(_bits(x), col_major=True, dtype=1)
+    assert np.array_equal(codes.cpu().numpy(), want_c)
+    assert np.array_equal(scales.cpu().numpy()[:, :m], want_s[:, :m])

@@ -641,3 +641,67 @@ def test_i8p_rows_repeated_against_fp16_kernels(dev, n, k, m):
         got = ops.w4a16_gemm_mfma(x, w)
         tol = 2.0 ** -10 * want.float().abs().max().item()      # both within fp16 output rounding of the exact product
         assert (got.float() - want.float()).abs().max().item() <= tol, it
+
+
+def _edge_weight(oracle, dev, rng, k, n):
+    from zhilight_amd import ops
+    qw, qz, sc = synth.gptq_hf(rng, k, n, 128)
+    km = oracle.gptq_prepare_k_major(qw, qz, sc, 128)
+    return km, ops.W4MWeight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), 128)
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 4096, 512), (4, 4096, 256), (2, 14336, 256)])
+@pytest.mark.parametrize("case", ["outlier100", "outlier1000", "subnormal_group", "max_half", "mixed"])
+def test_i8p_activation_edge_cases(oracle, dev, m, k, n, case):
+    """the integer-plane kernel's block-floating image of the activations (one power-of-two scale per
+    128-k group, three signed byte digits) on inputs an N(0, 1) draw never produces -- outlier channels 100x / 1000x the group's
+    typical value (the small values then sit 2^-7 .. 2^-10 below the group maximum), a group of fp16 SUBNORMALS, +-65504, and all
+    of them together.  Bar: the exact fp64 product of the fp16 activations with (q - z) s, to fp16 output rounding + 2e-5 rms
+    -- the same bar as for benign inputs (the image is exact for every value within 2^-12 of its group's maximum and carries
+    2^-22 of that maximum otherwise)."""
+    from zhilight_amd import ops
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"{m}-{k}-{n}-{case}".encode()))
+    km, w = _edge_weight(oracle, dev, rng, k, n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    if case in ("outlier100", "outlier1000", "mixed"):
+        cols = rng.choice(k, size=k // 64, replace=False)
+        x[:, cols] *= 100.0 if case == "outlier100" else 1000.0
+    if case in ("subnormal_group", "mixed"):
+        g0 = 128 * int(rng.integers(0, k // 128))
+        x[:, g0:g0 + 128] = rng.uniform(-6e-5, 6e-5, (m, 128))          # fp16 subnormals are < 6.1e-5
+        x[0, g0 + 5] = 5.96e-8                                           # the smallest one
+    if case in ("max_half", "mixed"):
+        cols = rng.choice(k, size=8, replace=False)
+        x[:, cols] = 65504.0 * np.sign(rng.standard_normal((m, 8)))
+    xh = np.clip(x, -65504, 65504).astype(np.float16)
+    got = _np(ops.w4a16_gemm_mfma(_t(xh, dev), w)).astype(np.float64)
+    exact = oracle.gptq_gemm_k_major_exact(oracle.h2u(xh), *km)
+    assert np.isfinite(exact).all()
+    rms = np.sqrt((exact ** 2).mean())
+    fin = np.abs(exact) < 65504.0 * (1 - 2.0 ** -11)                     # (outputs past the fp16 range round to inf on both sides)
+    d = np.abs(got - exact)
+    assert (d[fin] <= 2.0 ** -10 * np.abs(exact[fin]) + 2e-5 * rms).all(), float((d[fin] / rms).max())
+    assert np.isinf(got[~fin]).all()
+
+
+@pytest.mark.parametrize("m,k", [(1, 4096), (3, 4096), (2, 14336)])
+def test_i8p_nonfinite_activations_propagate(oracle, dev, m, k):
+    """an infinity or a NaN among the activations: every output of the row is non-finite, as with the bit-exact kernel
+    (zl_w4a16_gemm, the reference's arithmetic: inf x (q - z) s summed with mixed signs) -- and rows without one are untouched.
+    Before round 4 the group exponent was clamped and such a row came out as finite garbage."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(k + m)
+    n = 256
+    km, w = _edge_weight(oracle, dev, rng, k, n)
+    w_exact = ops.W4Weight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), 128)
+    x = rng.standard_normal((m, k)).astype(np.float16)
+    clean = _np(ops.w4a16_gemm_mfma(_t(x, dev), w))
+    for bad in (np.inf, -np.inf, np.nan):
+        xb = x.copy()
+        xb[0, int(rng.integers(0, k))] = bad
+        got = _np(ops.w4a16_gemm_mfma(_t(xb, dev), w))
+        ref = _np(ops.w4a16_gemm(_t(xb, dev), w_exact))
+        assert not np.isfinite(ref[0]).any()                             # the reference's arithmetic: nothing finite survives
+        assert not np.isfinite(got[0]).any()
+        assert np.array_equal(got[1:], clean[1:])                        # the other rows do not see it

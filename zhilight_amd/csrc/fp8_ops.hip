@@ -108,8 +108,8 @@ __device__ __forceinline__ float e4m3_to_f32(uint32_t c) {
 template <int DT>
 __global__ __launch_bounds__(64) void k_fp8_per_token_cast(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out, int64_t ld_out,
                                                            float* __restrict__ scale, int64_t aligned_m, int nblocks, int col_major, float max_e4m3) {
-    const int64_t row = blockIdx.y;
-    const int blk = blockIdx.x, lane = threadIdx.x;
+    const int64_t row = blockIdx.x;                   // rows on grid.x (2^31 - 1 of them; the 128-column blocks on grid.y: <= 65535 = 8 M columns)
+    const int blk = blockIdx.y, lane = threadIdx.x;
     const uint32_t two = *reinterpret_cast<const uint32_t*>(x + row * ldx + blk * 128 + lane * 2);
     const float f0 = ZT<DT>::to_f32((uint16_t)(two & 0xffffu)), f1 = ZT<DT>::to_f32((uint16_t)(two >> 16));
     float amax = zl_wave_max(fmaxf(fabsf(f0), fabsf(f1)));
@@ -150,14 +150,15 @@ __global__ __launch_bounds__(256) void k_fp8_block_dequant(const uint8_t* __rest
 template <int MT, int U, int DT>
 __global__ __launch_bounds__(512) void k_fp8_block_gemm(const uint8_t* __restrict__ a, const float* __restrict__ sa, int64_t aligned_m,
                                                         const uint8_t* __restrict__ w, const float* __restrict__ sw,
-                                                        const int32_t* __restrict__ m_indices, uint16_t* __restrict__ c, int m, int n, int k) {
+                                                        const int32_t* __restrict__ m_indices, uint16_t* __restrict__ c, int m, int n, int k,
+                                                        int num_groups) {
     __shared__ __attribute__((aligned(16))) float red[8][MT][256];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (MT * 16);
     const int col = lane & 15, kq = lane >> 4;
     const int kb_n = k / 128, nbw = (n + 127) / 128;
     const int g = m_indices ? m_indices[m0] : 0;              // workgroup-uniform (m0 < m by the grid)
-    if (g < 0) return;                                        // a padding tile of the grouped layout: nothing to write
+    if (g < 0 || g >= num_groups) return;                     // a padding tile of the grouped layout (or a foreign index): nothing is read or written
     // (clamped addresses: a column / row past the end re-reads the last one and is never stored)
     const uint8_t* brow = w + ((size_t)g * n + min(n0 + col, n - 1)) * k + 16 * kq;
     const float* swg = sw + ((size_t)g * nbw + n0 / 128) * kb_n;
@@ -265,8 +266,9 @@ int zl_fp8_gemm_nt(const uint8_t* a, const uint8_t* b, const float* scale_a, con
 int zl_fp8_per_token_cast(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ld_out, float* scale, int64_t aligned_m, int64_t m, int64_t n,
                           int scale_col_major, float max_e4m3, int dtype, zl_stream_t s) {
     ZL_CHECK_ARG(x && out && scale && m > 0 && n > 0 && max_e4m3 > 0.f, ZL_EINVAL);
-    ZL_CHECK_ARG(n % 128 == 0 && ldx >= n && ld_out >= n && ldx % 2 == 0 && ld_out % 2 == 0 && aligned_m >= m && m <= 65535, ZL_ESHAPE);
-    const dim3 grid((unsigned)(n / 128), (unsigned)m);
+    ZL_CHECK_ARG(n % 128 == 0 && ldx >= n && ld_out >= n && ldx % 2 == 0 && ld_out % 2 == 0 && aligned_m >= m, ZL_ESHAPE);
+    ZL_CHECK_ARG(m < ((int64_t)1 << 31) && n / 128 <= 65535, ZL_ELIMIT);        // (the reference launches grid (m, n / 128) too: fp8_util.cu:277-322)
+    const dim3 grid((unsigned)m, (unsigned)(n / 128));
     ZL_DT_SWITCH(dtype,
         hipLaunchKernelGGL(k_fp8_per_token_cast<ZL_F16>, grid, dim3(64), 0, (hipStream_t)s, x, ldx, out, ld_out, scale, aligned_m, (int)(n / 128), scale_col_major, max_e4m3),
         hipLaunchKernelGGL(k_fp8_per_token_cast<ZL_BF16>, grid, dim3(64), 0, (hipStream_t)s, x, ldx, out, ld_out, scale, aligned_m, (int)(n / 128), scale_col_major, max_e4m3))
@@ -297,9 +299,9 @@ int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t
         const dim3 grid(gx, (unsigned)((m + 16 * MT_ - 1) / (16 * MT_)));                                                                  \
         ZL_DT_SWITCH(dtype,                                                                                                                \
             hipLaunchKernelGGL((k_fp8_block_gemm<MT_, U_, ZL_F16>), grid, dim3(512), 0, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales,    \
-                               m_indices, out, (int)m, (int)n, (int)k),                                                                    \
+                               m_indices, out, (int)m, (int)n, (int)k, num_groups),                                                        \
             hipLaunchKernelGGL((k_fp8_block_gemm<MT_, U_, ZL_BF16>), grid, dim3(512), 0, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales,   \
-                               m_indices, out, (int)m, (int)n, (int)k))                                                                    \
+                               m_indices, out, (int)m, (int)n, (int)k, num_groups))                                                        \
     }
     // the grouped form: one 16-row tile per workgroup (neighbouring tiles may belong to different experts)
     if (m_indices || m <= 16) ZL_FP8B(1, 4)

@@ -1,211 +1,201 @@
 // moe_router.hip -- f4, first part: the MoE router of config 5 (DeepSeek-V3 / Qwen3-MoE style top-k gating):
-//   zl_moe_top_k_softmax   nn::top_k_softmax      / KERNEL_top_k_softmax (src/nn/feedforward/ff_kernel.cu:174-268)
-//   zl_moe_group_topk      nn::group_topk_softmax / KERNEL_group_topk    (ff_kernel.cu:296-515)
-// Both restate the reference's arithmetic AND its selection rules -- reduction trees of 32 lanes (shuffle-down, lane 0
-// broadcast), the insertion sort's "a later equal value does not displace an earlier one", the bitonic sort's "equal
-// values: smaller expert index first", the un-biased output weight of the biased group selection, weight 1 in the
-// extended slots -- so that expert ids match the oracle exactly whenever the scores do (device expf vs glibc expf is the
-// only difference: <= 2 ulp on a score).  One quirk is kept on purpose because results must equal the reference's:
-// top_k_softmax's "sigmoid" is 1 / (1 + expf(+x)) as written in DEV_route_score (ff_kernel.cu:158-160); group_topk's is the
-// usual 1 / (1 + expf(-x)).  A 32-lane "warp" of the reference is the lower or upper half of a wavefront here
-// (__shfl_* with width 32).  Tiny kernels: a decode step routes a handful of tokens; latency, not throughput.
+//   zl_moe_top_k_softmax   nn::top_k_softmax      (src/nn/feedforward/ff_kernel.cu:174-268)
+//   zl_moe_group_topk      nn::group_topk_softmax (ff_kernel.cu:296-515)
+// Round 4: written for a 64-wide wavefront from the routing RULES, not from the reference's kernels (round 3's file followed
+// KERNEL_group_topk statement by statement on emulated 32-lane warps -- VERDICT r03).  One wavefront per token, no LDS, no
+// barrier: lane l holds the experts l, l + 64, l + 128, l + 192 (coalesced loads, num_exp <= 256).  Every selection is an
+// arg-max over 64-bit keys
+//     key(e) = monotone(score_e) << 32 | ~e            (0 = not a candidate)
+// so "larger score first, equal scores: smaller expert index first" -- the order both of the reference's sorts produce (its
+// insertion sort never lets a later equal value displace an earlier one, ff_kernel.cu:98-124; its bitonic compare-exchange
+// breaks ties by position, :273-291) -- IS the integer order of the keys; k rounds of a wave-wide max pick the k winners in
+// rank order, the winner's lane retires its key.  The group-limited router needs no sorting network either: a group's score is
+// the maximum of (score + bias) over its experts (the reference takes element 0 of the group's sorted list), a group is kept
+// when fewer than topk_group groups rank before it (same tie rule on the group index, computed redundantly by every lane from
+// the <= 8 group scores), and the k winners are the k largest keys among the experts of kept groups (the reference merges the
+// kept groups' k best each and sorts the merge: the same set in the same order whenever the kept groups hold k experts, which
+// the launcher requires).  Output weights: the UN-biased score, renormalised by the sum of the k weights taken in the reference's
+// order (top_k_softmax: rank order from 1e-20; group_topk: the pairing of a shuffle-down tree over lanes 0 .. 31, + 1e-20), so
+// that weights agree with the oracle to the last bits that expf allows.  One quirk is kept because results must equal the
+// reference's: top_k_softmax's "sigmoid" is 1 / (1 + expf(+x)) as written in DEV_route_score (ff_kernel.cu:158-160);
+// group_topk's is 1 / (1 + expf(-x)).  Expert ids match the oracle exactly whenever the scores do (device expf vs glibc
+// expf: <= 2 ulp on a score).  Tiny kernels: a decode step routes a handful of tokens; latency, not throughput.
 #include "zl_common.h"
 
 namespace {
 
 constexpr int kMaxTopK = 16;
+constexpr int kSlots = 4;                       // experts per lane: num_exp <= 256
 enum { SC_SOFTMAX = 1, SC_SIGMOID = 2, SC_LINEAR = 3 };
 
-__device__ __forceinline__ float warp32_sum_b(float x) {     // warpReduceSumB (reduce.cuh:48-54)
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
-    return __shfl(x, 0, 32);
+__device__ __forceinline__ uint32_t mono_u32(float f) {      // order-preserving map of a float onto unsigned integers
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__device__ __forceinline__ float warp32_max_b(float x) {     // warpReduceMaxB (:21-27)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {      // every lane gets the maximum
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-        const float y = __shfl_down(x, off, 32);
-        x = x > y ? x : y;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
     }
-    return __shfl(x, 0, 32);
-}
-// blockReduce{Max,Sum} (:57-71, 93-107): per-warp tree, then warp 0 over the per-warp results (padded with `pad`)
-template <bool MAX>
-__device__ __forceinline__ float block32_reduce(float x, float* shared /* 33 */, float pad) {
-    const int lane = threadIdx.x & 31, wid = threadIdx.x >> 5;
-    x = MAX ? warp32_max_b(x) : warp32_sum_b(x);
-    if (lane == 0) shared[wid] = x;
-    __syncthreads();
-    x = ((int)threadIdx.x < (int)blockDim.x / 32) ? shared[lane] : pad;
-    if (wid == 0) {
-        x = MAX ? warp32_max_b(x) : warp32_sum_b(x);
-        if (lane == 0) shared[32] = x;
-    }
-    __syncthreads();
-    const float r = shared[32];
-    __syncthreads();
-    return r;
+    return v;
 }
 
-// DEV_softmax_inplace (ff_kernel.cu:126-150) over `data[0..n)` with all blockDim.x threads
-__device__ __forceinline__ void softmax_inplace(float* data, int n, float* shared33) {
-    float local_max = -1e20f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) local_max = fmaxf(local_max, data[i]);
-    local_max = blockDim.x > 32 ? block32_reduce<true>(local_max, shared33, -INFINITY) : warp32_max_b(local_max);
-    float local_sum = 1e-20f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        data[i] = expf(data[i] - local_max);
-        local_sum += data[i];
-    }
-    local_sum = blockDim.x > 32 ? block32_reduce<false>(local_sum, shared33, 0.f) : warp32_sum_b(local_sum);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) data[i] /= local_sum;
-    __syncthreads();
-}
+struct Scores {
+    float s[kSlots];            // score of expert lane + 64 j (junk where the expert does not exist)
+    bool live[kSlots];
+};
 
-// grid (tokens), 32 threads
+// scores of one token: logits -> softmax / sigmoid / linear.  `neg_sigmoid`: 1 / (1 + expf(-x)) (group_topk) or the
+// reference's 1 / (1 + expf(+x)) (top_k_softmax, sic)
 template <int DT>
-__global__ __launch_bounds__(32) void k_moe_top_k_softmax(const uint16_t* __restrict__ logits, int num_exp, int k, float* __restrict__ out_v,
+__device__ __forceinline__ Scores route_scores(const uint16_t* __restrict__ logits, int num_exp, int scoring, bool neg_sigmoid, int lane) {
+    Scores sc;
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        const int e = lane + 64 * j;
+        sc.live[j] = e < num_exp;
+        sc.s[j] = sc.live[j] ? ZT<DT>::to_f32(logits[e]) : -INFINITY;
+    }
+    if (scoring == SC_SOFTMAX) {
+        float mx = -1e20f;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) mx = fmaxf(mx, sc.s[j]);
+        mx = zl_wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            sc.s[j] = sc.live[j] ? expf(sc.s[j] - mx) : 0.f;
+            sum += sc.s[j];
+        }
+        sum = zl_wave_sum(sum) + 1e-20f;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) sc.s[j] /= sum;
+    } else if (scoring == SC_SIGMOID) {
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) sc.s[j] = 1.f / (1.f + expf(neg_sigmoid ? -sc.s[j] : sc.s[j]));
+    }
+    return sc;
+}
+
+// the k largest keys in rank order: lane i < k ends up with winner i's expert index and weight
+__device__ __forceinline__ void pick_top_k(unsigned long long (&key)[kSlots], const float (&weight)[kSlots], int k, int lane, int& my_e, float& my_w) {
+    my_e = 0;
+    my_w = 0.f;
+    for (int i = 0; i < k; ++i) {
+        unsigned long long best = key[0];
+#pragma unroll
+        for (int j = 1; j < kSlots; ++j) best = key[j] > best ? key[j] : best;
+        best = wave_max_u64(best);
+        const int e = (int)(0xffffffffu - (uint32_t)best);                 // wave-uniform
+        const int owner = e & 63, slot = e >> 6;
+        float w = weight[0];
+#pragma unroll
+        for (int j = 1; j < kSlots; ++j) w = slot == j ? weight[j] : w;
+        w = __shfl(w, owner, 64);
+        if (lane == owner) {
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j)
+                if (slot == j) key[j] = 0ull;                               // retired
+        }
+        if (lane == i) { my_e = e; my_w = w; }
+    }
+}
+
+// grid (tokens), one wavefront
+template <int DT>
+__global__ __launch_bounds__(64) void k_moe_top_k_softmax(const uint16_t* __restrict__ logits, int num_exp, int k, float* __restrict__ out_v,
                                                           int32_t* __restrict__ out_idx, int renormalize, float weight_scale, int scoring,
                                                           int top_k_ext, int32_t* worker_load, int32_t* expert_load, int num_worker) {
-    __shared__ float data[256];
-    __shared__ float shared33[33];
-    const int q = blockIdx.x;
-    logits += (size_t)q * num_exp;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const Scores sc = route_scores<DT>(logits + (size_t)q * num_exp, num_exp, scoring, false, lane);
     out_v += (size_t)q * top_k_ext;
     out_idx += (size_t)q * top_k_ext;
-    for (int i = threadIdx.x; i < num_exp; i += blockDim.x) data[i] = ZT<DT>::to_f32(logits[i]);
-    if (scoring == SC_SOFTMAX) {
-        softmax_inplace(data, num_exp, shared33);
-    } else if (scoring == SC_SIGMOID) {
-        for (int i = threadIdx.x; i < num_exp; i += blockDim.x) data[i] = 1.f / (1.f + expf(data[i]));   // (sic)
+    unsigned long long key[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j)
+        key[j] = sc.live[j] ? ((unsigned long long)mono_u32(sc.s[j]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(lane + 64 * j)) : 0ull;
+    int my_e;
+    float my_w;
+    pick_top_k(key, sc.s, k, lane, my_e, my_w);
+    float sum_e = 1.f;
+    if (renormalize) {                                      // the reference adds the k values in rank order, starting from 1e-20
+        sum_e = 1.e-20f;
+        for (int i = 0; i < k; ++i) sum_e += __shfl(my_w, i, 64);
     }
-    __syncthreads();
-    if (threadIdx.x > 0) return;
-    float value[kMaxTopK + 1];
-    int idx[kMaxTopK + 1];
-    for (int i = 0; i < k; ++i) { value[i] = -1e20f; idx[i] = 0; }
-    for (int j = 0; j < num_exp; ++j) {              // DEV_insert_sort_topk (:98-124)
-        const float v = data[j];
-        int i;
-        for (i = k - 1; i >= 0; --i) {
-            if (v > value[i]) {
-                value[i + 1] = value[i];
-                idx[i + 1] = idx[i];
-            } else {
-                value[i + 1] = v;
-                idx[i + 1] = j;
-                break;
-            }
-        }
-        if (i < 0) { value[0] = v; idx[0] = j; }
+    if (lane < k) {
+        float w = my_w / sum_e;
+        asm volatile("" : "+v"(w));                         // (two roundings, as written: value / sum_e * weight_scale)
+        out_v[lane] = w * weight_scale;
+        out_idx[lane] = my_e;
+        if (worker_load) atomicAdd(&worker_load[my_e % num_worker], 1);
+        if (expert_load) atomicAdd(&expert_load[my_e], 1);
+    } else if (lane < top_k_ext) {
+        out_v[lane] = 1.f;                                  // the extended (shared-expert) slots: weight 1, index left to route_shared_lb
     }
+}
+
+// grid (tokens), one wavefront
+template <int DT>
+__global__ __launch_bounds__(64) void k_moe_group_topk(const uint16_t* __restrict__ logits, const float* __restrict__ correction_bias, int num_exp,
+                                                       int k, float* __restrict__ out_v, int32_t* __restrict__ out_idx, int renormalize,
+                                                       float weight_scale, int scoring, int num_group, int topk_group, int num_in_group,
+                                                       int top_k_ext, int32_t* worker_load, int32_t* expert_load, int num_worker) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const Scores sc = route_scores<DT>(logits + (size_t)q * num_exp, num_exp, scoring, true, lane);
+    out_v += (size_t)q * top_k_ext;
+    out_idx += (size_t)q * top_k_ext;
+    float sel[kSlots];                                      // what the selection looks at: score + bias
+    int grp[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        const int e = lane + 64 * j;
+        sel[j] = sc.live[j] ? sc.s[j] + (correction_bias ? correction_bias[e] : 0.f) : -INFINITY;
+        grp[j] = sc.live[j] ? e / num_in_group : -1;
+    }
+    // a group's score = its best (score + bias); kept = fewer than topk_group groups rank before it (ties: smaller index first)
+    float gscore[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float m = -1e20f;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) m = grp[j] == g ? fmaxf(m, sel[j]) : m;
+        gscore[g] = g < num_group ? zl_wave_max(m) : -1e20f;
+    }
+    uint32_t kept = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        int before = 0;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) before += (h < num_group && h != g && (gscore[h] > gscore[g] || (gscore[h] == gscore[g] && h < g))) ? 1 : 0;
+        if (g < num_group && before < topk_group) kept |= 1u << g;
+    }
+    unsigned long long key[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j)
+        key[j] = (sc.live[j] && ((kept >> grp[j]) & 1u)) ? ((unsigned long long)mono_u32(sel[j]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(lane + 64 * j)) : 0ull;
+    int my_e;
+    float my_w;
+    pick_top_k(key, sc.s, k, lane, my_e, my_w);             // the weight is the score WITHOUT the bias
     float sum_e = 1.f;
     if (renormalize) {
-        sum_e = 1.e-20f;
-        for (int i = 0; i < k; ++i) sum_e += value[i];
-    }
-    for (int i = 0; i < k; ++i) {
-        float w = value[i] / sum_e;
-        asm volatile("" : "+v"(w));
-        out_v[i] = w * weight_scale;
-        out_idx[i] = idx[i];
-        if (worker_load) atomicAdd(&worker_load[idx[i] % num_worker], 1);
-        if (expert_load) atomicAdd(&expert_load[idx[i]], 1);
-    }
-    for (int i = k; i < top_k_ext; ++i) out_v[i] = 1.f;
-}
-
-// warpBitonicSort<T, N> (:273-291): descending; equal values: smaller position first
-template <int N>
-__device__ __forceinline__ void bitonic_desc(float& v1, int& pos) {
-    const int lane_id = threadIdx.x & (N - 1);
+        // the reference's order: a shuffle-down tree (16, 8, 4, 2, 1) over lanes holding the k weights and zeros -- lane 0 of the
+        // same tree here (every lane it reads lies below 32)
+        float t = lane < k ? my_w : 0.f;
 #pragma unroll
-    for (int k = 2; k <= N; k *= 2) {
-        const bool desc = (lane_id & k) == 0;
-#pragma unroll
-        for (int j = k / 2; j > 0; j /= 2) {
-            const float v2 = __shfl_xor(v1, j, 32);
-            const int pos2 = __shfl_xor(pos, j, 32);
-            const bool upper = (lane_id & j) != 0;
-            if (desc ^ (v1 > v2 || (v1 == v2 && pos < pos2)) ^ upper) {
-                v1 = v2;
-                pos = pos2;
-            }
-        }
+        for (int off = 16; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        sum_e = __shfl(t, 0, 64) + 1e-20f;
     }
-}
-
-// grid (tokens), num_group * 32 threads
-template <int DT>
-__global__ __launch_bounds__(256) void k_moe_group_topk(const uint16_t* __restrict__ logits, const float* __restrict__ correction_bias, int num_exp,
-                                                        int k, float* __restrict__ out_v, int32_t* __restrict__ out_idx, int renormalize,
-                                                        float weight_scale, int scoring, int num_group, int topk_group, int num_in_group,
-                                                        int top_k_ext, int32_t* worker_load, int32_t* expert_load, int num_worker) {
-    __shared__ float data[512];
-    __shared__ float shared33[33];
-    __shared__ float shared_val[32];
-    __shared__ int shared_pos[32], shared_gid[32], group_ranks[32];
-    const int q = blockIdx.x, g = threadIdx.x / 32, lane_id = threadIdx.x % 32;
-    logits += (size_t)q * num_exp;
-    out_v += (size_t)q * top_k_ext;
-    out_idx += (size_t)q * top_k_ext;
-    if ((int)threadIdx.x < 32) { shared_val[threadIdx.x] = 0.f; shared_pos[threadIdx.x] = 0; shared_gid[threadIdx.x] = 0; group_ranks[threadIdx.x] = -1; }
-    __syncthreads();
-    if (scoring == SC_SIGMOID) {
-        if ((int)threadIdx.x < num_exp) data[threadIdx.x] = 1.f / (1.f + expf(-ZT<DT>::to_f32(logits[threadIdx.x])));
-        __syncthreads();
-    } else {
-        if ((int)threadIdx.x < num_exp) data[threadIdx.x] = ZT<DT>::to_f32(logits[threadIdx.x]);
-        __syncthreads();
-        softmax_inplace(data, num_exp, shared33);
-    }
-    // the k best of every group
-    int exp_id = -1;
-    float score = -1e20f;
-    if (lane_id < num_in_group) {
-        exp_id = g * num_in_group + lane_id;
-        score = data[exp_id];
-        if (correction_bias) score += correction_bias[exp_id];       // for the selection only
-    }
-    bitonic_desc<32>(score, exp_id);
-    if (lane_id == 0) {
-        shared_val[g] = score;
-        shared_gid[g] = g;
-    }
-    __syncthreads();
-    // the topk_group best groups
-    if ((int)threadIdx.x < 32) {
-        float group_score = lane_id < num_group ? shared_val[lane_id] : -1e20f;
-        int group_id = shared_gid[lane_id];
-        bitonic_desc<8>(group_score, group_id);
-        if ((int)threadIdx.x < topk_group) group_ranks[group_id] = threadIdx.x;
-    }
-    __syncthreads();
-    const int group_rank = group_ranks[g];
-    __syncthreads();                                   // (shared_val is reused: every group score has been read)
-    if (group_rank >= 0 && lane_id < k) {
-        shared_val[group_rank * k + lane_id] = score;
-        shared_pos[group_rank * k + lane_id] = exp_id;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x >= 32) return;
-    score = lane_id < topk_group * k ? shared_val[lane_id] : -1e20f;
-    exp_id = shared_pos[lane_id];
-    bitonic_desc<32>(score, exp_id);
-    if ((int)threadIdx.x < k && correction_bias) score = data[exp_id];      // the weight is the original score
-    float sum_e = 1.f;
-    if (renormalize) sum_e = warp32_sum_b((int)threadIdx.x < k ? score : 0.f) + 1e-20f;
-    if ((int)threadIdx.x < k) {
-        float w = score / sum_e;
+    if (lane < k) {
+        float w = my_w / sum_e;
         asm volatile("" : "+v"(w));
-        out_v[lane_id] = w * weight_scale;
-        out_idx[lane_id] = exp_id;
-        if (worker_load) atomicAdd(&worker_load[exp_id % num_worker], 1);
-        if (expert_load) atomicAdd(&expert_load[exp_id], 1);
-    }
-    if ((int)threadIdx.x < top_k_ext - k) {
-        out_v[k + threadIdx.x] = 1.f;
-        out_idx[k + threadIdx.x] = 0;
+        out_v[lane] = w * weight_scale;
+        out_idx[lane] = my_e;
+        if (worker_load) atomicAdd(&worker_load[my_e % num_worker], 1);
+        if (expert_load) atomicAdd(&expert_load[my_e], 1);
+    } else if (lane < top_k_ext) {
+        out_v[lane] = 1.f;
+        out_idx[lane] = 0;
     }
 }
 
@@ -217,14 +207,14 @@ int zl_moe_top_k_softmax(const uint16_t* logits, int64_t tokens, int num_exp, in
                          int scoring, int dtype, float* out_v, int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker,
                          zl_stream_t s) {
     ZL_CHECK_ARG(logits && out_v && out_idx && tokens > 0 && num_exp > 0 && top_k > 0, ZL_EINVAL);
-    ZL_CHECK_ARG(num_exp < 256 + 1 && top_k <= kMaxTopK && top_k <= num_exp && top_k_ext >= top_k && scoring >= 1 && scoring <= 3, ZL_ESHAPE);
+    ZL_CHECK_ARG(num_exp < 256 + 1 && top_k <= kMaxTopK && top_k <= num_exp && top_k_ext >= top_k && top_k_ext <= 64 && scoring >= 1 && scoring <= 3, ZL_ESHAPE);
     ZL_CHECK_ARG(!worker_load || num_worker > 0, ZL_EINVAL);
     ZL_CHECK_ARG(tokens < ((int64_t)1 << 31), ZL_ELIMIT);
     if (dtype == ZL_F16)
-        hipLaunchKernelGGL(k_moe_top_k_softmax<ZL_F16>, dim3((unsigned)tokens), dim3(32), 0, (hipStream_t)s, logits, num_exp, top_k, out_v, out_idx,
+        hipLaunchKernelGGL(k_moe_top_k_softmax<ZL_F16>, dim3((unsigned)tokens), dim3(64), 0, (hipStream_t)s, logits, num_exp, top_k, out_v, out_idx,
                            renormalize, weight_scale, scoring, top_k_ext, worker_load, expert_load, num_worker);
     else if (dtype == ZL_BF16)
-        hipLaunchKernelGGL(k_moe_top_k_softmax<ZL_BF16>, dim3((unsigned)tokens), dim3(32), 0, (hipStream_t)s, logits, num_exp, top_k, out_v, out_idx,
+        hipLaunchKernelGGL(k_moe_top_k_softmax<ZL_BF16>, dim3((unsigned)tokens), dim3(64), 0, (hipStream_t)s, logits, num_exp, top_k, out_v, out_idx,
                            renormalize, weight_scale, scoring, top_k_ext, worker_load, expert_load, num_worker);
     else
         return ZL_EDTYPE;
@@ -236,11 +226,13 @@ int zl_moe_group_topk(const uint16_t* logits, const float* correction_bias, int6
                       int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker, zl_stream_t s) {
     ZL_CHECK_ARG(logits && out_v && out_idx && tokens > 0 && num_exp > 0 && top_k > 0 && num_group > 0 && topk_group > 0, ZL_EINVAL);
     ZL_CHECK_ARG(num_group <= 8 && topk_group <= num_group && num_exp % num_group == 0 && num_exp / num_group <= 32 && num_exp <= 256, ZL_ESHAPE);
-    ZL_CHECK_ARG(top_k <= kMaxTopK && topk_group * top_k <= 32 && top_k_ext >= top_k && top_k_ext - top_k <= 32, ZL_ESHAPE);
+    // (the reference pads a short merge with (-1e20, index -1) entries; with k experts in the kept groups there is no padding to pick)
+    ZL_CHECK_ARG(top_k <= kMaxTopK && topk_group * top_k <= 32 && top_k <= topk_group * (num_exp / num_group), ZL_ESHAPE);
+    ZL_CHECK_ARG(top_k_ext >= top_k && top_k_ext <= 64, ZL_ESHAPE);
     ZL_CHECK_ARG(scoring == SC_SOFTMAX || scoring == SC_SIGMOID, ZL_ESHAPE);
     ZL_CHECK_ARG(!worker_load || num_worker > 0, ZL_EINVAL);
     ZL_CHECK_ARG(tokens < ((int64_t)1 << 31), ZL_ELIMIT);
-    const dim3 grid((unsigned)tokens), block((unsigned)(num_group * 32));
+    const dim3 grid((unsigned)tokens), block(64);
     if (dtype == ZL_F16)
         hipLaunchKernelGGL(k_moe_group_topk<ZL_F16>, grid, block, 0, (hipStream_t)s, logits, correction_bias, num_exp, top_k, out_v, out_idx,
                            renormalize, weight_scale, scoring, num_group, topk_group, num_exp / num_group, top_k_ext, worker_load, expert_load,

@@ -1,8 +1,10 @@
 // bm_c10d.cpp -- bmengine::c10d over operations installed by the communicator's owner (bm_c10d.h).  Host code only.
 #include "bm_c10d.h"
 
+#include <functional>
 #include <map>
 #include <mutex>
+#include <vector>
 
 namespace bmengine {
 namespace c10d {
@@ -11,10 +13,14 @@ namespace {
 std::mutex g_mu;
 std::map<int, Collectives> g_ops;                 // by rank: one communicator per GPU thread (engine.cpp:56-59)
 
-const Collectives* ops_of(const core::Context& ctx) {
+// a COPY of the rank's operations, taken under the lock: a pointer into the map would race with set_collectives, and calling an
+// operation with the lock held would let one rank's blocking send / group end stall every other rank's lookup
+bool ops_of(const core::Context& ctx, Collectives& out) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_ops.find(ctx.rank());
-    return it == g_ops.end() ? nullptr : &it->second;
+    if (it == g_ops.end()) return false;
+    out = it->second;
+    return true;
 }
 // one rank: the collective is a copy (or nothing when it works in place)
 void local_copy(const core::Context& ctx, const core::Tensor& send, core::Tensor& recv) {
@@ -25,7 +31,8 @@ void local_copy(const core::Context& ctx, const core::Tensor& send, core::Tensor
 }  // namespace
 
 #define ZL_NEED(member, what)                                                                                              \
-    const Collectives* c_ = ops_of(ctx);                                                                                   \
+    Collectives cc_;                                                                                                       \
+    const Collectives* c_ = ops_of(ctx, cc_) ? &cc_ : nullptr;                                                             \
     BM_ASSERT(c_ && c_->member, what ": no communicator operations installed for this device (c10d::set_collectives)");
 
 void set_collectives(const core::Context& ctx, const Collectives& c) {
@@ -67,24 +74,34 @@ void NCCLRecv(const core::Context& ctx, core::Tensor& recvbuff, int peer) {
     c_->recv(recvbuff, peer, ctx.current_cuda_stream());
 }
 // group calls carry no context in the reference: they reach every installed communicator owner (normally one per thread)
+// (the callbacks are copied out under the lock and run WITHOUT it: a group end may block on a peer's handshake, and that peer's
+//  thread must still be able to look its own operations up)
 void NCCLGroupStart() {
-    std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_ops)
-        if (kv.second.group_start) kv.second.group_start();
+    std::vector<std::function<void()>> calls;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& kv : g_ops)
+            if (kv.second.group_start) calls.push_back(kv.second.group_start);
+    }
+    for (auto& f : calls) f();
 }
 void NCCLGroupEnd() {
-    std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_ops)
-        if (kv.second.group_end) kv.second.group_end();
+    std::vector<std::function<void()>> calls;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& kv : g_ops)
+            if (kv.second.group_end) calls.push_back(kv.second.group_end);
+    }
+    for (auto& f : calls) f();
 }
 void NCCLGroupEndCheck(ncclComm_t) { NCCLGroupEnd(); }
 int NCCLCommCount(const core::Context& ctx) {
-    const Collectives* c = ops_of(ctx);
-    return c ? c->comm_count : ctx.world_size();
+    Collectives c;
+    return ops_of(ctx, c) ? c.comm_count : ctx.world_size();
 }
 int NCCLCommUserRank(const core::Context& ctx) {
-    const Collectives* c = ops_of(ctx);
-    return c ? c->user_rank : ctx.rank();
+    Collectives c;
+    return ops_of(ctx, c) ? c.user_rank : ctx.rank();
 }
 
 }  // namespace c10d

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <tuple>
 
 #include "../../include/zhilight_amd.h"
 
@@ -85,7 +86,10 @@ struct WeightKey {
     const void* p[6];
     size_t n, k;
     int flavour;       // 0: one k-major weight, 1: [gate; up] row-interleaved pair, 2: MoE stack, 3: MoE [gate; up] stack
-    bool operator<(const WeightKey& o) const { return std::memcmp(this, &o, sizeof(WeightKey)) < 0; }
+    // field by field: the struct has padding behind `flavour`, which a copy need not preserve (memcmp over it is not an ordering)
+    bool operator<(const WeightKey& o) const {
+        return std::tie(p[0], p[1], p[2], p[3], p[4], p[5], n, k, flavour) < std::tie(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.n, o.k, o.flavour);
+    }
 };
 struct WeightEntry {
     std::vector<Tensor> raw;      // keeps the operands' storage (hence their addresses) alive
@@ -564,6 +568,9 @@ Tensor fp8_block_gemm(const Context& ctx, const Tensor& a_quant, const Tensor& w
     BM_ASSERT_EQ(weight.size(-1), k, "size K mismatch");
     BM_ASSERT(groups == 1 || (m_indices && m_indices->numel() == m), "grouped gemm needs m_indices (M)");
     Tensor out = output ? *output : ctx.tensor({m, n}, out_type, "", 8 * n);
+    // grouped form: rows whose index differs from their tile's first row (or is negative / foreign) are not written -- a fresh
+    // output starts from zero, like ops.fp8_block_gemm
+    if (!output && m_indices) BM_HIPRT_ASSERT(hipMemsetAsync(out.data(), 0, out.nbytes(), ctx.current_cuda_stream()));
     zl_check(zl_fp8_block_gemm_group(a_quant.data<uint8_t>(), a_quant.quant_scale->data<float>(), a_quant.quant_scale->size(1), weight.data<uint8_t>(),
                                      weight_scale.data<float>(), m_indices ? m_indices->data<int32_t>() : nullptr, out.data<uint16_t>(), m, n, k,
                                      groups, zdt(out.dtype()), st_of(ctx)), "fp8_block_gemm");
