@@ -976,7 +976,10 @@ class LLaMA:
                      and all(l.w_in_gated.perm is None and isinstance(l.w_in_gated.weight, ops.W4MWeight) for l in self.layers))
         if fuse_o_ff:
             ops.engine_epoch_advance(self.device)
+        trace = getattr(self, "trace_hidden", None)          # parity tests: the hidden rows entering every layer (eager runs only)
         for li, layer in enumerate(self.layers):
+            if trace is not None and not torch.cuda.is_current_stream_capturing():
+                trace.append(hidden.clone())
             if fuse_qkv_rope_i8:
                 # INT8 route: layernorm_quant, then the streaming W8A8 kernel with scale-back + rotary + KV scatter fused
                 _, xq, sx = ops.layernorm_quant(hidden, layer.ln_attn, c.eps)
