@@ -72,6 +72,7 @@ def cpu_baseline(cfg, batch, seq):
     t_step = cfg.num_layers * (t_lin + t_attn) + t_head
     return {
         "value": batch / t_step, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+        "extrapolated": "one of %d layers + 1/16 of the lm_head rows timed, scaled to a full step" % cfg.num_layers,
         "sample": (f"oracle/ R-flavour CPU port (the reference has no CPU path): 1 of {cfg.num_layers} layers' W4A16 linears "
                    f"({t_lin:.2f} s) + decode attention ({t_attn:.2f} s) + 1/16 of lm_head rows, extrapolated to a full step"),
     }
@@ -176,7 +177,42 @@ def roofline_w4(model, cfg, batch, dev, ctx, layers_override=False):
     e1.record()
     torch.cuda.synchronize()
     nl = len(lins) + (len(model.layers) if in_step and batch > 8 else 0)   # beyond 8 rows the qkv norm is its own (counted) launch
-    t_launch = e0.elapsed_time(e1) * 1e-3 / (reps * len(lins))
+    t_gemv_only = e0.elapsed_time(e1) * 1e-3 / (reps * len(lins))
+    # IN-STEP time of the same launches (what the 0.70 target is about): the whole greedy step minus the step with exactly
+    # these launches left out (LLaMA.encode(skip_gemv=True): embedding, rope table, attention, lm_head, greedy bookkeeping), both
+    # as hipGraph replays on a fresh context, HIP events.  Falls back to the GEMV-only graph where that mode does not apply.
+    t_launch, how = t_gemv_only, "gemv-only graph"
+    if in_step and batch <= 4 and not model.tp:
+        try:
+            len_buf = int(ctx.max_len_buf)
+            pos0 = int(ctx.positions[0].item()) if ctx.positions.numel() else 0
+            pos0 = min(pos0, len_buf - 40)
+
+            def graph_of(skip):
+                c2 = model.new_context(batch, len_buf, pos0, fill_random=True)
+                c2.tokens.copy_(ctx.tokens)
+                model.step_greedy(c2, skip_gemv=skip)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    model.step_greedy(c2, skip_gemv=skip)
+                g.replay()
+                torch.cuda.synchronize()
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    g.replay()
+                b_.record()
+                torch.cuda.synchronize()
+                t = a.elapsed_time(b_) * 1e-3 / reps
+                del g, c2
+                return t
+            t_full, t_rest = graph_of(False), graph_of(True)
+            if t_full > t_rest > 0:
+                t_launch, how = (t_full - t_rest) / len(lins), "step graph minus the step without these launches"
+            torch.cuda.empty_cache()
+        except Exception as e:                                  # noqa: BLE001 (the roofline leg must never cost the headline)
+            sys.stderr.write("bench: in-step GEMV timing unavailable (%s)\n" % str(e).splitlines()[0])
     tot_bytes = sum(alg_bytes_w4(lin.weight.n, lin.weight.k, lin.weight.group_size, batch) for lin in lins)
     per_launch = tot_bytes / len(lins)
     achieved = per_launch / t_launch / 1e9
@@ -200,8 +236,10 @@ def roofline_w4(model, cfg, batch, dev, ctx, layers_override=False):
             else kname + " (W4A16 GEMV, 4 launches/layer, plain variants)", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_launch": int(per_launch), "us_per_launch": round(t_launch * 1e6, 3), "launches_timed": nl,
+            "timing": how, "us_per_launch_gemv_only_graph": round(t_gemv_only * 1e6, 3),
+            "traffic_source": "offline rocprofv3 --pmc pass (profiles/r*_gemv_traffic.json), not measured in this run" if traffic is not None else None,
             "note": "avg over the %d GEMV launches of one step incl. the kernel boundaries between them (graph replay, HIP events); "
-                    "in-step rocprofv3 averages of the same kernels: profiles/r03_decode_kernel_stats.csv" % len(lins)}
+                    "in-step rocprofv3 averages of the same kernels: profiles/r04_decode_kernel_stats.csv" % len(lins)}
     return roof
 
 

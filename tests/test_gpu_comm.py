@@ -228,13 +228,14 @@ def _run_tp_workers(world, devices, rccl):
         outs = []
         for p in procs:
             try:
-                o, _ = p.communicate(timeout=300)
+                o, _ = p.communicate(timeout=600)
             except subprocess.TimeoutExpired:     # pragma: no cover
                 p.kill()
                 o, _ = p.communicate()
             outs.append(o)
         for r, o in enumerate(outs):
-            assert f"RESULT {r} ok" in o and "captured=True" in o, o[-3000:]
+            assert f"RESULT {r} ok" in o and "captured=True" in o and "dual_stream_runs=1" in o, o[-3000:]
+        print("\n".join(o.strip().splitlines()[-1] for o in outs))
         return outs
 
 

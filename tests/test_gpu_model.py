@@ -103,6 +103,20 @@ class OracleModel:
         o = self.o
         if flavour == "R":
             return o.gptq_gemm_k_major(x, *self.km[name])
+        tpw = getattr(self, "tp_world", 1)
+        if tpw > 1 and (name.endswith("o_proj") or name.endswith("down_proj")):
+            # tensor parallelism (the reference's and ours): a row-parallel linear is `tpw` partial products over contiguous K
+            # shards, each ROUNDED TO T by its rank, summed by the all-reduce (fp32, rank order) and rounded once more
+            qw, qz, sc = self.km[name]
+            k = x.shape[1]
+            ks = k // tpw
+            g = self.g
+            tot = np.zeros((x.shape[0], qw.shape[0]), np.float64)
+            for r in range(tpw):
+                part = o.gptq_gemm_k_major_exact(np.ascontiguousarray(x[:, r * ks:(r + 1) * ks]), np.ascontiguousarray(qw[:, r * ks // 8:(r + 1) * ks // 8]),
+                                                 np.ascontiguousarray(qz[:, r * ks // g:(r + 1) * ks // g]), np.ascontiguousarray(sc[:, r * ks // g:(r + 1) * ks // g]))
+                tot = (tot.astype(np.float32) + part.astype(np.float16).astype(np.float32)).astype(np.float64)
+            return o.h2u(tot.astype(np.float16))
         y = o.h2u(o.gptq_gemm_k_major_exact(x, *self.km[name]).astype(np.float16))
         if flavour == "T" and name.endswith("layers.0.self_attn.q_proj"):
             rng = np.random.default_rng(12345)
@@ -680,6 +694,7 @@ def test_tensor_parallel_decode_matches_single_gpu(oracle, dev):
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     om = OracleModel(oracle, cfg, sd_np, 128, 2, 64)
     om.rope_kind = "plain"
+    om.tp_world = 2          # the oracle of the TENSOR-PARALLEL network: row-parallel partial outputs are rounded to T per rank
     ref_model = LLaMA(cfg, QuantConfig(5, 128), dev).load_state_dict(sd)
     fake = _ThreadTP(2)
     models = [LLaMA(cfg, QuantConfig(5, 128), dev, tp=fake.view(r)).load_state_dict(sd) for r in range(2)]

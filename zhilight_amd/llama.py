@@ -926,11 +926,13 @@ class LLaMA:
         return self._bufs[b]
 
     # ---- one decode step -----------------------------------------------------------------------
-    def encode(self, ctx: DynBatchContext, workspace=None, argmax_ws=None, gemv_only=False):
+    def encode(self, ctx: DynBatchContext, workspace=None, argmax_ws=None, gemv_only=False, skip_gemv=False):
         """LLaMA::encode for a pure decode ("search") batch: returns logits (B, vocab) fp16.
         gemv_only (bench.py's roofline leg): issue ONLY the four quantised projections of every layer, exactly as the step
         launches them (fused norm / rotary + scatter / split merge / gated activation / residual), on whatever the buffers
-        hold -- no embedding, attention or lm_head; returns None."""
+        hold -- no embedding, attention or lm_head; returns None.
+        skip_gemv (bench.py again): the complement -- everything BUT those projections (embedding, rope table, attention, lm_head,
+        greedy bookkeeping), so that step time - this = the projections' time inside the step."""
         c = self.cfg
         b = ctx.tokens.numel()
         if ctx.steps_left <= 0 and not torch.cuda.is_current_stream_capturing():
@@ -991,6 +993,12 @@ class LLaMA:
                                                      workspace=workspace)
                 layer.attn_out_add(bufs["attn"], hidden)
                 layer.ff_add(hidden, c.eps, bufs["act"])
+                continue
+            if fuse_qkv_rope and skip_gemv:
+                if not merge_plan:
+                    raise ops.ZLError("skip_gemv: the fused W4 decode route with the merging attn_out projection only")
+                ops.decode_attention_splits(bufs["q"].view(b, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
+                                            ctx.v_addrs[li], ctx.valid_lens, scale, ctx.max_len_buf, c.num_kv_heads, workspace)
                 continue
             if fuse_qkv_rope:
                 xin = hidden if b <= 8 else ops.rmsnorm(hidden, layer.ln_attn, c.eps)
@@ -1300,7 +1308,7 @@ class LLaMA:
         ctx.steps_left = min(ctx.steps_left, ctx.max_len_buf - (pos0 + s))
         return logits
 
-    def step_greedy(self, ctx: DynBatchContext):
+    def step_greedy(self, ctx: DynBatchContext, skip_gemv=False):
         """One greedy decode step entirely on the device (graph-capturable): encode, pick the arg-max token
         inside the lm_head launch + one small reduction, and advance the batch state.  Returns
         (logits, next_tokens int64)."""
@@ -1315,7 +1323,7 @@ class LLaMA:
             self._bufs[key] = (ops.argmax_workspace(b, self.cfg.vocab_size, self.device),
                                torch.empty(b, dtype=torch.int64, device=self.device))
         ws, nxt = self._bufs[key]
-        logits = self.encode(ctx, argmax_ws=ws)
+        logits = self.encode(ctx, argmax_ws=ws, skip_gemv=skip_gemv)
         ops.greedy_advance(ws, b, self.cfg.vocab_size, ctx.tokens, ctx.positions, ctx.placement, ctx.valid_lens, nxt)
         ctx.steps_left -= 1
         return logits, nxt
