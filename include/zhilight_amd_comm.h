@@ -76,6 +76,14 @@ int zl_ar_init(void* state, int world_size, int rank, void* const* buffers /* ho
                int64_t max_message_bytes, zl_comm_stream_t s);
 int zl_ar_all_reduce(void* state, const uint16_t* x, const uint16_t* residual, uint16_t* out, int64_t n, int dtype,
                      zl_comm_stream_t s);
+/* The same message with the rows travelling as group-32 int8 codes + T scales -- ModelContext::reduce_tp_int8
+ * (src/model/model_context.cpp:244-326; the reference switches to it above REDUCE_TP_INT8_THRES rows) in ONE launch: quantise,
+ * peers read the codes of their own slice, sum with the unquantised own slice, re-quantise, everyone reads the re-quantised slices:
+ * 2 x 1.06 (W - 1) / W bytes per value over the links instead of 2 (W - 1).  Bit for bit the reference's five-step composition
+ * (quant_group_32 / dequant_sum_quant_g32 / dequant_group_32, quant_reduce_kernel.cu:13-330), then the residual add of
+ * zl_ar_all_reduce.  n % (64 world_size) == 0; n * 2 bytes <= max_message_bytes; world_size = the state's. */
+int zl_ar_all_reduce_int8(void* state, const uint16_t* x, const uint16_t* residual, uint16_t* out, int64_t n, int world_size, int dtype,
+                          zl_comm_stream_t s);
 /* error word of the state: 0 ok, else the number of bounded waits that expired (synchronises the stream it reads on) */
 int zl_ar_status(void* state, zl_comm_stream_t s);
 

@@ -92,10 +92,16 @@ if ok:
     tp.check()
     scale = ref_logits.abs().max().item()
     err_ref = (got - ref_logits).abs().max().item() / scale
-    import zl_oracle
-    om = OracleModel(zl_oracle, cfg, sd_np, 128, 1, len_buf2)
-    om.rope_kind = "plain"
-    ora = om.prefill(0, prompt.numpy())
+    # the CPU oracle's prompt encode: rank 0 computes it (all host cores), the others receive it
+    box = [None]
+    if rank == 0:
+        torch.set_num_threads(os.cpu_count() or 1)
+        import zl_oracle
+        om = OracleModel(zl_oracle, cfg, sd_np, 128, 1, len_buf2)
+        om.rope_kind = "plain"
+        box[0] = om.prefill(0, prompt.numpy())
+    dist.broadcast_object_list(box, src=0)
+    ora = box[0]
     err_ora = float(np.abs(got.cpu().numpy().astype(np.float64) - ora).max() / np.abs(ora).max())
     err_ref_ora = float(np.abs(ref_logits.cpu().numpy().astype(np.float64) - ora).max() / np.abs(ora).max())
     # this rank's KV heads against the unsharded model's (rank r holds kv heads [r * hkv_local, (r + 1) * hkv_local))

@@ -253,3 +253,105 @@ def test_model_on_the_direct_transport_two_gpus(dev):   # pragma: no cover  (1-G
     """the same with one process per GPU and the RCCL communicator created next to the one-shot exchange (xGMI peer reads)"""
     outs = _run_tp_workers(2, [0, 1], rccl=True)
     assert all("rccl_ranks=2" in o for o in outs)
+
+
+def _expected_int8(xs, res, dtype):
+    """ModelContext::reduce_tp_int8 step by step with the three kernels the oracle pins bit for bit (tests/test_gpu_ops.py):
+    quantise every slice, rank r sums its own unquantised slice with the peers' codes in rank-distance order and re-quantises,
+    the re-quantised slices are dequantised"""
+    from zhilight_amd import ops
+    ws, n = len(xs), xs[0].numel()
+    m = n // ws // 32
+    flats = [x.view(ws, m, 32) for x in xs]
+    qs = [ops.quant_group_32(f) for f in flats]
+    q_sum, s_sum = [], []
+    for r in range(ws):
+        src = [(r + i + 1) % ws for i in range(ws - 1)]
+        q_recv = torch.stack([qs[p][0][r] for p in src])
+        s_recv = torch.stack([qs[p][1].view(ws, m)[r] for p in src])
+        q, s = ops.dequant_sum_quant_g32(flats[r][r], q_recv, s_recv)
+        q_sum.append(q)
+        s_sum.append(s)
+    want = ops.dequant_group_32(torch.stack(q_sum), torch.stack(s_sum).view(-1)).view(-1)
+    if res is not None:
+        want = (res.float() + want.float()).to(dtype)
+    return want
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_shot_int8_all_reduce_equals_the_five_step_composition(dev, world):
+    """the INT8 codes INSIDE the one-shot exchange (zl_ar_all_reduce_int8: one launch, three flag phases)
+    against reduce_tp_int8's five steps composed from the kernels the oracle pins -- bit for bit, fp16 and bf16, with and without
+    the residual add, interleaved with ordinary fp16 messages (both kinds share the message numbers and the two slots), eager and
+    under hipGraph replay."""
+    from zhilight_amd.parallel import OneShotAllReduce
+    maxb = 1 << 21
+    addrs = [OneShotAllReduce.alloc(maxb)[0] for _ in range(world)]
+    ars = [OneShotAllReduce(r, world, addrs, maxb, dev) for r in range(world)]
+    streams = _concurrent_streams(world, dev)
+    torch.cuda.synchronize()
+    # (n, dtype, residual, int8)
+    msgs = [(64 * world, torch.float16, False, True), (4096, torch.float16, True, False), (32 * 4096, torch.float16, True, True),
+            (64 * 4096, torch.bfloat16, False, True), (8 * 4096, torch.float16, False, True), (4096, torch.float16, False, False),
+            (256 * 4096, torch.float16, True, True), (64 * world * 3, torch.bfloat16, True, True)]
+    ins = [[(torch.randn(n, device=dev) * (1 + r)).to(dt) for r in range(world)] for (n, dt, _, _) in msgs]
+    ins[4][0][:64] = 0                                           # a group of zeros: codes 0, scale 0
+    ress = [torch.randn(n, device=dev).to(dt) for (n, dt, _, _) in msgs]
+    results, errs = [[None] * len(msgs) for _ in range(world)], []
+    torch.cuda.synchronize()
+
+    def run(r):
+        try:
+            with torch.cuda.stream(streams[r]):
+                for i, (n, dt, wr, q8) in enumerate(msgs):
+                    out = torch.empty_like(ins[i][r])
+                    fn = ars[r].all_reduce_int8 if q8 else ars[r].all_reduce
+                    fn(ins[i][r], residual=ress[i] if wr else None, out=out)
+                    results[r][i] = out
+                streams[r].synchronize()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert all(a.status() == 0 for a in ars)
+    for i, (n, dt, wr, q8) in enumerate(msgs):
+        want = _expected_int8(ins[i], ress[i] if wr else None, dt) if q8 else _expected(ins[i], ress[i] if wr else None, dt)
+        for r in range(world):
+            assert torch.equal(results[r][i], want), (i, r, n, dt, q8)
+    # and close to the exact sum: two int8 roundings of group-32 blocks (the reference's own accuracy for this route)
+    exact = sum(x.float() for x in ins[2]) + ress[2].float()
+    assert (results[0][2].float() - exact).abs().max().item() <= 0.03 * exact.abs().max().item()
+    # hipGraph replay: two int8 messages captured per rank, replayed three times (device-side message numbers)
+    n, dt = 16 * 4096, torch.float16
+    gx = [torch.randn(n, device=dev).to(dt) for _ in range(world)]
+    outs = [torch.zeros(n, device=dev, dtype=dt) for _ in range(world)]
+    graphs = []
+    for r in range(world):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=streams[r]):
+            ars[r].all_reduce_int8(gx[r], out=outs[r])
+            ars[r].all_reduce_int8(gx[r], out=outs[r])
+        graphs.append(g)
+
+    def replay(r):
+        try:
+            with torch.cuda.stream(streams[r]):
+                for _ in range(3):
+                    graphs[r].replay()
+                streams[r].synchronize()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=replay, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    want = _expected_int8(gx, None, dt)
+    for r in range(world):
+        assert torch.equal(outs[r], want)
+    assert all(a.status() == 0 for a in ars)

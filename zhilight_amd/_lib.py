@@ -94,7 +94,7 @@ COMM_SYMBOLS = [
     "zl_comm_all_gather", "zl_comm_reduce_scatter_sum", "zl_comm_broadcast", "zl_comm_send", "zl_comm_recv",
     "zl_comm_group_start", "zl_comm_group_end",
     "zl_ar_buffer_bytes", "zl_ar_state_bytes", "zl_ar_alloc", "zl_ar_free", "zl_ar_export", "zl_ar_open", "zl_ar_close",
-    "zl_ar_init", "zl_ar_all_reduce", "zl_ar_status",
+    "zl_ar_init", "zl_ar_all_reduce", "zl_ar_all_reduce_int8", "zl_ar_status",
 ]
 _comm = None
 

@@ -168,6 +168,148 @@ __global__ __launch_bounds__(256) void k_ar(ArState* st, const uint16_t* __restr
     if (c == 0 && (int)threadIdx.x >= (int)gridDim.x && threadIdx.x < kMaxChunks) st->epoch[threadIdx.x] = e;
 }
 
+// ---- the same exchange with the rows travelling as group-32 INT8 codes + T scales: ModelContext::reduce_tp_int8
+// (src/model/model_context.cpp:244-326, src/nn/quant/int8/quant_reduce_kernel.cu:13-330) as ONE launch.  The reference moves
+// 1.06 bytes per value and hop instead of 2 in five steps (quantise all slices; all-to-all of the codes; dequantise + sum +
+// re-quantise the rank's own slice; all-gather of the re-quantised slices; dequantise); round 3 composed those from three
+// kernels and two RCCL send / recv rounds.  Here the steps are phases of k_ar's flag protocol:
+//   phase 1  every rank quantises its whole vector (quant_group_32: amax of the 32 T values, codes rint(x 127 / amax), scale
+//            T(amax / 127)) into ITS slot of the message's first parity, flags e1;
+//   phase 2  rank r reads the peers' codes + scales of SLICE r (n / W values: 1.06 (W - 1) n / W bytes over the links), adds its
+//            own UNQUANTISED slice -- fp32 fma chain in rank-distance order, dequant_sum_quant_g32 -- re-quantises (amax of the
+//            sums rounded to T) into its slot of the other parity, flags e2;
+//   phase 3  every rank reads the W re-quantised slices (another 1.06 (W - 1) n / W bytes) and dequantises: T(q scale), then the
+//            layer's residual add in T arithmetic (element_add_scale) if asked.
+// Bit for bit the values of the five-step composition (tests/test_gpu_comm.py).  A message = two message numbers (e1, e1 + 1):
+// the slot-parity argument of k_ar holds for both halves (a rank enters phase 1 of the next message only after every peer's e2
+// flag, i.e. after every peer has finished reading its phase-1 rows).  Lane = 4 consecutive values (one dword of codes), 8 lanes
+// = one group; workgroup c = the c-th block of groups of EVERY slice.
+__device__ __forceinline__ float group8_max(float v) {          // all-reduce over the 8 lanes of a group
+    v = fmaxf(v, __shfl_xor(v, 1, 8));
+    v = fmaxf(v, __shfl_xor(v, 2, 8));
+    v = fmaxf(v, __shfl_xor(v, 4, 8));
+    return v;
+}
+__device__ __forceinline__ uint32_t pack_codes(const float (&v)[4], float amax) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float t = v[j] * 127.0f;
+        asm volatile("" : "+v"(t));                               // the product is rounded to fp32 before the division
+        const int q = amax > 0.f ? (int)nearbyintf(t / amax) : 0;
+        w |= ((uint32_t)q & 0xffu) << (8 * j);
+    }
+    return w;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_ar_q8(ArState* st, const uint16_t* __restrict__ x, const uint16_t* __restrict__ residual,
+                                               uint16_t* __restrict__ out, int64_t n, int64_t gper) {
+    __shared__ unsigned s_epoch, s_timeout;
+    const int c = blockIdx.x, world = st->world, rank = st->rank;
+    if (threadIdx.x == 0) s_timeout = 0;
+    if (n * 2 > st->max_bytes) {
+        if (threadIdx.x == 0) atomicAdd(&st->err, 1u);
+        return;
+    }
+    if (threadIdx.x == 0) s_epoch = st->epoch[c] + 1u;
+    __syncthreads();
+    const unsigned e1 = s_epoch, e2 = e1 + 1u, pa = e1 & 1u, pb = e2 & 1u;
+    const int64_t m = n / world / 32;                              // groups per slice
+    const int64_t g0 = (int64_t)c * gper, g1 = g0 + gper < m ? g0 + gper : m;
+    const int l8 = threadIdx.x & 7;
+    const int64_t slice_codes = m * 32;                            // bytes of codes per slice
+    auto wait_peers = [&](unsigned e) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
+            __hip_atomic_store(flags_of(st, (int)threadIdx.x) + rank * kMaxChunks + c, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned* f = flags_of(st, rank) + (int)threadIdx.x * kMaxChunks + c;
+            unsigned polls = 0;
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > kMaxPolls) {
+                    atomicAdd(&st->err, 1u);
+                    s_timeout = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    };
+    // ---- phase 1: quantise block c of every slice into my slot of parity pa: [codes n bytes][scales n / 32 halfs]
+    {
+        uint8_t* area = reinterpret_cast<uint8_t*>(slot_of(st, rank, pa));
+        for (int s = 0; s < world; ++s) {
+            for (int64_t g = g0 + (threadIdx.x >> 3); g < g1; g += 32) {
+                const int64_t gi = (int64_t)s * m + g;
+                const uint2 raw = *reinterpret_cast<const uint2*>(x + gi * 32 + l8 * 4);
+                float v[4] = {to_f32<DT>((uint16_t)raw.x), to_f32<DT>((uint16_t)(raw.x >> 16)), to_f32<DT>((uint16_t)raw.y), to_f32<DT>((uint16_t)(raw.y >> 16))};
+                const float amax = group8_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                *reinterpret_cast<uint32_t*>(area + gi * 32 + l8 * 4) = pack_codes(v, amax);
+                if (l8 == 0) reinterpret_cast<uint16_t*>(area + n)[gi] = from_f32<DT>(amax / 127.0f);
+            }
+        }
+    }
+    wait_peers(e1);
+    // ---- phase 2: my slice: own unquantised rows + the peers' codes (rank-distance order), re-quantised into parity pb:
+    //      [codes n / W bytes][scales n / 32 / W halfs]
+    {
+        uint8_t* area = reinterpret_cast<uint8_t*>(slot_of(st, rank, pb));
+        for (int64_t g = g0 + (threadIdx.x >> 3); g < g1; g += 32) {
+            const int64_t gi = (int64_t)rank * m + g;
+            const uint2 raw = *reinterpret_cast<const uint2*>(x + gi * 32 + l8 * 4);
+            float sum[4] = {to_f32<DT>((uint16_t)raw.x), to_f32<DT>((uint16_t)(raw.x >> 16)), to_f32<DT>((uint16_t)raw.y), to_f32<DT>((uint16_t)(raw.y >> 16))};
+            for (int i = 0; i < world - 1; ++i) {
+                const int src = (rank + i + 1) % world;
+                const uint8_t* peer = reinterpret_cast<const uint8_t*>(slot_of(st, src, pa));
+                const uint32_t codes = __hip_atomic_load(reinterpret_cast<const uint32_t*>(peer + gi * 32 + l8 * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // (a 16-bit scale: read the aligned dword that holds it)
+                const uint32_t sw = __hip_atomic_load(reinterpret_cast<const uint32_t*>(peer + n) + (gi >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const float sc = to_f32<DT>((uint16_t)(sw >> (16 * (int)(gi & 1))));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[j] = __builtin_fmaf((float)(int8_t)(codes >> (8 * j)), sc, sum[j]);
+            }
+            // warpReduceMaxB<T>(fabsf(sum)): the magnitude is rounded to T before the maximum
+            float mag = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mag = fmaxf(mag, to_f32<DT>(from_f32<DT>(fabsf(sum[j]))));
+            const float amax = group8_max(mag);
+            *reinterpret_cast<uint32_t*>(area + g * 32 + l8 * 4) = pack_codes(sum, amax);
+            if (l8 == 0) reinterpret_cast<uint16_t*>(area + slice_codes)[g] = from_f32<DT>(amax / 127.0f);
+        }
+    }
+    wait_peers(e2);
+    // ---- phase 3: dequantise block c of every slice (+ residual)
+    for (int s = 0; s < world; ++s) {
+        const uint8_t* area = reinterpret_cast<const uint8_t*>(slot_of(st, s, pb));
+        for (int64_t g = g0 + (threadIdx.x >> 3); g < g1; g += 32) {
+            const uint32_t codes = __hip_atomic_load(reinterpret_cast<const uint32_t*>(area + g * 32 + l8 * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t sw = __hip_atomic_load(reinterpret_cast<const uint32_t*>(area + slice_codes) + (g >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const float sc = to_f32<DT>((uint16_t)(sw >> (16 * (int)(g & 1))));
+            uint16_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pr = (float)(int8_t)(codes >> (8 * j)) * sc;
+                o[j] = from_f32<DT>(pr);
+                if (s_timeout) o[j] = DT == ZL_F16 ? (uint16_t)0x7e00 : (uint16_t)0x7fc0;       // an expired wait: poison, never a silent wrong sum
+            }
+            const int64_t at = ((int64_t)s * m + g) * 32 + l8 * 4;
+            if (residual) {
+                const uint2 rv = *reinterpret_cast<const uint2*>(residual + at);
+                const uint16_t ru[4] = {(uint16_t)rv.x, (uint16_t)(rv.x >> 16), (uint16_t)rv.y, (uint16_t)(rv.y >> 16)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = from_f32<DT>(to_f32<DT>(ru[j]) + to_f32<DT>(o[j]));
+            }
+            *reinterpret_cast<uint2*>(out + at) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
+        }
+    }
+    if (threadIdx.x == 0) st->epoch[c] = e2;
+    if (c == 0 && (int)threadIdx.x >= (int)gridDim.x && threadIdx.x < kMaxChunks) st->epoch[threadIdx.x] = e2;
+}
+
 }  // namespace
 
 extern "C" {
@@ -330,6 +472,26 @@ int zl_ar_all_reduce(void* state, const uint16_t* x, const uint16_t* residual, u
     ArState* st = reinterpret_cast<ArState*>(state);
     if (dtype == ZL_F16) hipLaunchKernelGGL(k_ar<0>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)s, st, x, residual, out, n, per);
     else hipLaunchKernelGGL(k_ar<1>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)s, st, x, residual, out, n, per);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ZL_OK : (int)e;
+}
+int zl_ar_all_reduce_int8(void* state, const uint16_t* x, const uint16_t* residual, uint16_t* out, int64_t n, int world_size, int dtype,
+                          zl_comm_stream_t s) {
+    ZL_CHECK_ARG(state && x && out && n > 0 && world_size >= 2 && world_size <= ZL_AR_MAX_RANKS, ZL_EINVAL);
+    ZL_CHECK_ARG(n % (32 * (int64_t)world_size) == 0 && n % 64 == 0, ZL_ESHAPE);           // whole groups per slice; aligned scale rows
+    ZL_CHECK_ARG((n / world_size / 32) % 2 == 0, ZL_ESHAPE);                                 // (scales are read as aligned dwords)
+    ZL_CHECK_ARG(((uintptr_t)x & 7) == 0 && ((uintptr_t)out & 7) == 0 && (!residual || ((uintptr_t)residual & 7) == 0), ZL_ESHAPE);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    // chunking is a function of (n, world) only: >= 32 groups of every slice per workgroup, at most kMaxChunks
+    const int64_t m = n / world_size / 32;
+    int64_t chunks = (m + 31) / 32;
+    if (chunks > kMaxChunks) chunks = kMaxChunks;
+    int64_t gper = (m + chunks - 1) / chunks;
+    gper = (gper + 1) / 2 * 2;
+    chunks = (m + gper - 1) / gper;
+    ArState* st = reinterpret_cast<ArState*>(state);
+    if (dtype == ZL_F16) hipLaunchKernelGGL(k_ar_q8<0>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)s, st, x, residual, out, n, gper);
+    else hipLaunchKernelGGL(k_ar_q8<1>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)s, st, x, residual, out, n, gper);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ZL_OK : (int)e;
 }

@@ -8,6 +8,8 @@ input columns, group boundaries must divide: src/nn/linear/linear.cpp:1212-1234)
 all-reduce SUM of the (M, dim_model) fp16 partial outputs (src/model/model_context.cpp:203-242).
 Independent requests additionally shard as replicas (no collective), which is what bench.py runs.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -205,6 +207,18 @@ class OneShotAllReduce:
                                         _C.c_int64(x.numel()), _DT[x.dtype], _stream()), "zl_ar_all_reduce")
         return out
 
+    def all_reduce_int8(self, x, residual=None, out=None):
+        """the same sum with the rows travelling as group-32 int8 codes (ModelContext::reduce_tp_int8 as one launch):
+        out = T(dequantised reduce) (+ residual in T arithmetic); numel % (64 * world) == 0"""
+        if x.numel() * 2 > self.max_bytes:
+            from ._lib import ZLError
+            raise ZLError("one-shot all-reduce: message larger than the exchange buffers")
+        out = torch.empty_like(x) if out is None else out
+        _check(_comm().zl_ar_all_reduce_int8(_C.c_void_p(self.state.data_ptr()), _C.c_void_p(x.data_ptr()),
+                                             _C.c_void_p(residual.data_ptr()) if residual is not None else None, _C.c_void_p(out.data_ptr()),
+                                             _C.c_int64(x.numel()), _C.c_int(self.size), _DT[x.dtype], _stream()), "zl_ar_all_reduce_int8")
+        return out
+
     def status(self):
         return int(_comm().zl_ar_status(_C.c_void_p(self.state.data_ptr()), _stream()))
 
@@ -266,6 +280,9 @@ class DirectTPGroup(TPGroup):
         receive the WS - 1 peers' codes of MY slice (rank distance order); add my own unquantised slice, re-quantise; all-gather
         the re-quantised slices; dequantise.  data (rows, n) T with rows * n % (32 * WS) == 0; returns a new tensor."""
         from . import ops
+        if (data.numel() * 2 <= self.oneshot_bytes and data.numel() % (64 * self.size) == 0 and data.is_contiguous()
+                and data.dtype in (torch.float16, torch.bfloat16) and os.environ.get("ZL_REDUCE_INT8_ONESHOT", "1") != "0"):
+            return self.oneshot.all_reduce_int8(data)           # the five steps as one launch, same bits (csrc_comm/comm.hip: k_ar_q8)
         comm = self._need_rccl("reduce_tp_int8")
         ws, rank = self.size, self.rank
         n = data.numel()
