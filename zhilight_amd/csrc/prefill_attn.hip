@@ -122,22 +122,37 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) 
                 st[kb] = pf_mfma<DT>(a, qf[t], st[kb]);
             }
         }
-        // ---- scale, causal mask, online softmax for query nq (its 64 scores live in 4 lanes x 16 registers)
+        // ---- scale, causal mask, online softmax for query nq (its 64 scores live in 4 lanes x 16 registers).  Scores are kept in
+        //      the log2 domain (scale * log2 e folded into one multiply, v_exp_f32 is exp2); the causal select runs only on tiles
+        //      that reach this wave's diagonal (wave-uniform: every other tile is fully visible)
+        const float sl2 = p.scale * 1.44269504088896340736f;
+        const bool diag = key0 + kBK - 1 > p.pos0 + q0 + wave * 16;      // some key of the tile lies beyond the wave's first query
         float mloc = -INFINITY;
+        if (diag) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
+            for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int key = key0 + kb * 16 + 4 * kq + i;
-                const float sv = key <= qpos ? st[kb][i] * p.scale : -INFINITY;
-                st[kb][i] = sv;
-                mloc = fmaxf(mloc, sv);
+                for (int i = 0; i < 4; ++i) {
+                    const int key = key0 + kb * 16 + 4 * kq + i;
+                    const float sv = key <= qpos ? st[kb][i] * sl2 : -INFINITY;
+                    st[kb][i] = sv;
+                    mloc = fmaxf(mloc, sv);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    st[kb][i] *= sl2;
+                    mloc = fmaxf(mloc, st[kb][i]);
+                }
             }
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float lsum = 0.f;
         uint4 pf[2];                                      // P as the A operand of P.V: k-chunk kq of key group j
@@ -155,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) 
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
                 for (int i2 = 0; i2 < 2; ++i2) {
-                    const uint16_t p0 = cvt(__expf(st[2 * j + half][2 * i2] - m_new));
-                    const uint16_t p1 = cvt(__expf(st[2 * j + half][2 * i2 + 1] - m_new));
+                    const uint16_t p0 = cvt(__builtin_amdgcn_exp2f(st[2 * j + half][2 * i2] - m_new));
+                    const uint16_t p1 = cvt(__builtin_amdgcn_exp2f(st[2 * j + half][2 * i2 + 1] - m_new));
                     lsum += ZT<DT>::to_f32(p0) + ZT<DT>::to_f32(p1);   // the normaliser sums what the product uses
                     w[half * 2 + i2] = (uint32_t)p0 | ((uint32_t)p1 << 16);
                 }
@@ -164,13 +179,16 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) 
             pf[j] = make_uint4(w[0], w[1], w[2], w[3]);
         }
         l_run = l_run * alpha + lsum;                     // per-lane partial; lanes of a query are merged at the end
-        // ---- rescale O: the factor of row q = 4 kq + i comes from the lane whose nq is that row
-        if (kq == 0) strip[wave][nq] = alpha;
-        __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the strip write has landed (wave-private)
-        const f4 al = *reinterpret_cast<const f4*>(&strip[wave][4 * kq]);
+        // ---- rescale O: the factor of row q = 4 kq + i comes from the lane whose nq is that row -- only when some row's maximum
+        //      moved (wave-uniform; after the first tiles it rarely does: 32 multiplies and an LDS round trip per tile otherwise)
+        if (!__all(alpha == 1.0f)) {
+            if (kq == 0) strip[wave][nq] = alpha;
+            __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the strip write has landed (wave-private)
+            const f4 al = *reinterpret_cast<const f4*>(&strip[wave][4 * kq]);
 #pragma unroll
-        for (int db = 0; db < 8; ++db) {
-            o[db][0] *= al[0]; o[db][1] *= al[1]; o[db][2] *= al[2]; o[db][3] *= al[3];
+            for (int db = 0; db < 8; ++db) {
+                o[db][0] *= al[0]; o[db][1] *= al[1]; o[db][2] *= al[2]; o[db][3] *= al[3];
+            }
         }
         // ---- O += P . V : 2 key groups x 8 d blocks; B fragment (column d = 16 db + nq, keys 32 j + {4 kq + i, 16 + 4 kq + i})
         //      = two transposed 8-byte reads of the row-major V tile

@@ -704,7 +704,7 @@ class EncoderLayer:
         thres = int(os.environ.get("REDUCE_TP_INT8_THRES", "0") or 0)
         compressed = getattr(self.tp, "reduce_tp_int8", None)
         if thres > 0 and compressed is not None and part.shape[0] > thres and part.numel() % (32 * self.tp.size) == 0 \
-                and getattr(self.tp, "comm", None) is not None:
+                and (getattr(self.tp, "comm", None) is not None or getattr(self.tp, "oneshot", None) is not None):
             ops.element_add_scale(hidden, compressed(part), 1.0, True, out=hidden)
             return
         fused = getattr(self.tp, "all_reduce_add", None)
@@ -1221,8 +1221,7 @@ class LLaMA:
         for k in range(len(bounds)):
             hidden[k] = ops.element_add_scale(hidden[k], reduced(k), 1.0, True)
         self.dual_stream_runs = getattr(self, "dual_stream_runs", 0) + 1
-        logits = self._logits(hidden[-1][-1:])
-        ctx.tokens[task] = torch.argmax(logits[0].float()).to(torch.int32)
+        logits = self._prompt_logits_and_pick(ctx, task, hidden[-1][-1:])
         ctx.positions[task] = pos0 + s
         ctx.placement[task] = pos0 + s
         ctx.valid_lens[task] = pos0 + s + 1
@@ -1300,12 +1299,28 @@ class LLaMA:
                                                            scale, ctx.max_len_buf, c.num_kv_heads, workspace=ws)
             layer.attn_out_add(att.view(s, -1), hidden)
             layer.ff_add(hidden, c.eps)
-        logits = self._logits(hidden[s - 1:s])
-        ctx.tokens[task] = torch.argmax(logits[0].float()).to(torch.int32)
+        logits = self._prompt_logits_and_pick(ctx, task, hidden[s - 1:s])
         ctx.positions[task] = pos0 + s
         ctx.placement[task] = pos0 + s
         ctx.valid_lens[task] = pos0 + s + 1
         ctx.steps_left = min(ctx.steps_left, ctx.max_len_buf - (pos0 + s))
+        return logits
+
+    def _prompt_logits_and_pick(self, ctx, task, last_hidden):
+        """logits of a prompt's last row and the first generated token into ctx.tokens[task]: the pick rides the lm_head launch
+        (zl_gemm_nt_small_m_argmax leaves one candidate per wavefront, zl_greedy_advance reduces them -- first index on ties,
+        as torch.argmax) instead of three torch launches over the 128 k logits; TP keeps the plain arg-max on the gathered row"""
+        if self.tp:
+            logits = self._logits(last_hidden)
+            ctx.tokens[task] = torch.argmax(logits[0].float()).to(torch.int32)
+            return logits
+        key = ("argmax", 1)
+        if key not in self._bufs:
+            self._bufs[key] = (ops.argmax_workspace(1, self.cfg.vocab_size, self.device),
+                               torch.empty(1, dtype=torch.int64, device=self.device))
+        ws = self._bufs[key][0]
+        logits = self._logits(last_hidden, argmax_ws=ws)
+        ops.greedy_advance(ws, 1, self.cfg.vocab_size, tokens=ctx.tokens[task:task + 1])
         return logits
 
     def step_greedy(self, ctx: DynBatchContext, skip_gemv=False):
