@@ -385,6 +385,27 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
                                  int64_t hkv, int64_t d, int64_t k, int64_t group_size, int bshd, const zl_w4_opts_t* opts,
                                  zl_stream_t s);
 
+/* Decode batches of 5..32 rows on the integer matrix cores (round 4).  The activation matrix becomes digit planes ONCE --
+ * zl_w4a16_planes: per row and 128-k group X = rint(x * 2^(36 - Ef)) (Ef: exponent field of the group's largest fp16 magnitude,
+ * |X| < 2^22: exact for every value within 2^-12 of the group maximum), three balanced byte digits in the register layout of
+ * v_mfma_i32_16x16x64_i8's A operand, plus (2^(Ef - 36), that times sum X) per row and group; with norm_weight the RMSNorm of the
+ * row (LayerNorm::forward, src/nn/layernorm/layernorm.cu:10-42) runs first, so the normalised row is never written.  `planes`:
+ * zl_w4a16_planes_bytes(m, k) bytes, 16-byte aligned; 1 <= m <= 32, k % 128 == 0, k <= 16384 (ZL_ESHAPE otherwise).
+ * zl_w4a16_gemm_planes is zl_w4a16_gemm_mfma_ex on such planes (no norm_weight: it went into the planes): the same ZLW4M
+ * operands and epilogues, every 1 KiB weight item expanded to bytes once for all rows, the group sums exact integers -- the
+ * branch of gptq_gemm_k_major for 5 <= M <= 40 (src/nn/quant/gptq/q_gemm_k_major.cu:580-686, which streams the weights once per
+ * 16 rows) with one pass over the weights for up to 32 rows.  zl_w4a16_qkv_rope_scatter_planes: zl_w4a16_qkv_rope_scatter likewise. */
+int64_t zl_w4a16_planes_bytes(int64_t m, int64_t k);
+int zl_w4a16_planes(const uint16_t* x, int64_t ldx, int64_t m, int64_t k, const uint16_t* norm_weight, float norm_eps, void* planes,
+                    zl_stream_t s);
+int zl_w4a16_gemm_planes(const void* planes, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias, const uint16_t* residual,
+                         uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t group_size, int epilogue, const zl_w4_opts_t* opts,
+                         zl_stream_t s);
+int zl_w4a16_qkv_rope_scatter_planes(const void* planes, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias, const float* cosv,
+                                     const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                                     uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h, int64_t hkv, int64_t d, int64_t k,
+                                     int64_t group_size, int bshd, zl_stream_t s);
+
 /* Decode attention with the split merge folded into the attention output projection (len_q == 1 per task, prefix
  * visibility, D == 128, H / Hkv <= 16: the matrix-core kernel).  zl_decode_attn_splits is zl_decode_attn without its
  * merge launch: it leaves the split-KV partials in `workspace`; zl_w4a16_gemm_attn_merge is zl_w4a16_gemm_mfma of the

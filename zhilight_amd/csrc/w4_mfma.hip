@@ -644,6 +644,16 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
                              const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
                              uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs);
 
+int64_t zl_w4_planes_bytes_(int64_t m, int64_t k);
+int zl_w4_planes_launch(const uint16_t* x, int64_t ldx, int m, int k, const uint16_t* norm_w, float norm_eps, void* planes, hipStream_t hs);
+int zl_w4a16_gemm_phase_planes(const void* planes, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
+                               const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups, int tiles,
+                               int epilogue, int ld_out, const zl_w4_opts_t* opts, hipStream_t hs);
+int zl_w4a16_gemm_phase_planes_rope(const void* planes, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
+                                    const uint16_t* bias, int m, int n, int k, int groups, int tiles, const float* cosv, const float* sinv,
+                                    const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs, uint16_t* const* v_bufs,
+                                    uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs);
+
 extern "C" {
 
 #ifdef ZL_W4M_PROBE
@@ -883,6 +893,50 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
     return zl_w4a16_gemm_phase_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n,
                                     (int)k, (int)L.q, (int)(L.np / 16), norm_weight, norm_eps, cosv, sinv, placement,
                                     buf_lens, k_bufs, v_bufs, q_out, (int)h, (int)hkv, (int)d, bshd, (hipStream_t)s);
+}
+
+int64_t zl_w4a16_planes_bytes(int64_t m, int64_t k) { return zl_w4_planes_bytes_(m, k); }
+
+int zl_w4a16_planes(const uint16_t* x, int64_t ldx, int64_t m, int64_t k, const uint16_t* norm_weight, float norm_eps, void* planes,
+                    zl_stream_t s) {
+    ZL_CHECK_ARG(x && planes && m > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(ldx >= k && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 15) == 0, ZL_ESHAPE);
+    ZL_CHECK_ARG(zl_w4_planes_bytes_(m, k) > 0, ZL_ESHAPE);
+    return zl_w4_planes_launch(x, ldx, (int)m, (int)k, norm_weight, norm_eps, planes, (hipStream_t)s);
+}
+
+int zl_w4a16_gemm_planes(const void* planes, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias, const uint16_t* residual,
+                         uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t group_size, int epilogue, const zl_w4_opts_t* opts,
+                         zl_stream_t s) {
+    ZL_CHECK_ARG(planes && qw && meta && y && m > 0 && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(!(epilogue & ZL_EPI_RESIDUAL) || residual, ZL_EINVAL);
+    ZL_CHECK_ARG(zl_w4_planes_bytes_(m, k) > 0 && ((uintptr_t)planes & 15) == 0, ZL_ESHAPE);
+    zl_w4_layout_t L;
+    int st = zl_w4m_layout(n, k, group_size, &L);
+    if (st) return st;
+    const bool silu = epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32);
+    ZL_CHECK_ARG(!silu || n % 2 == 0, ZL_ESHAPE);
+    ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+    return zl_w4a16_gemm_phase_planes(planes, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
+                                      (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), opts, (hipStream_t)s);
+}
+
+int zl_w4a16_qkv_rope_scatter_planes(const void* planes, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias, const float* cosv,
+                                     const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                                     uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h, int64_t hkv, int64_t d, int64_t k,
+                                     int64_t group_size, int bshd, zl_stream_t s) {
+    ZL_CHECK_ARG(planes && qw && meta && cosv && sinv && placement && buf_lens && k_bufs && v_bufs && q_out, ZL_EINVAL);
+    ZL_CHECK_ARG(m > 0 && h > 0 && hkv > 0 && d > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(zl_w4_planes_bytes_(m, k) > 0 && ((uintptr_t)planes & 15) == 0, ZL_ESHAPE);
+    const int64_t n = (h + 2 * hkv) * d;
+    zl_w4_layout_t L;
+    int st = zl_w4m_layout(n, k, group_size, &L);
+    if (st) return st;
+    ZL_CHECK_ARG(d % 32 == 0 && L.np == n, ZL_ESHAPE);
+    ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+    return zl_w4a16_gemm_phase_planes_rope(planes, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n, (int)k,
+                                           (int)L.q, (int)(L.np / 16), cosv, sinv, placement, buf_lens, k_bufs, v_bufs, q_out, (int)h,
+                                           (int)hkv, (int)d, bshd, (hipStream_t)s);
 }
 
 int zl_w4a16_gemm_attn_merge(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens,

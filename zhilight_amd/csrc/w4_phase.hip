@@ -19,6 +19,7 @@
 // MB = 1: M <= 16, MB = 2: M <= 32 (two accumulator sets share every dequantised weight fragment).
 #include <type_traits>
 #include "zl_common.h"
+#include "w4_i8p_common.h"
 
 #ifdef ZL_PHASE_PROBE
 static int zl_probe_seq = 0;
@@ -95,6 +96,11 @@ struct PhaseParams {
     const float* mg_ws;
     const int32_t* mg_valid_lens;
     int mg_split_len, mg_max_splits;
+    // I8 instantiations (5..32 rows on the integer matrix cores): the activations arrive as digit planes made ONCE per
+    // activation matrix by k_w4_planes (below) instead of fp16 rows staged and dequantised against by every workgroup
+    const unsigned char* planes;   // [group][row block][digit 2 1 0][mfma 0 1][64 lanes][16 bytes]: A operands as they sit in registers
+    const float* pconsts;          // [group][row block][16 rows][xscale, xscale * sum X]
+    uint32_t planes_bytes, pconsts_bytes;
 #ifdef ZL_PHASE_PROBE
     int probe_id;
 #endif
@@ -141,8 +147,6 @@ __device__ __forceinline__ h8 dequant_word(uint32_t w, hv2 z1, hv2 z16, uint32_t
 struct Guard { static constexpr bool value = true; };
 struct NoGuard { static constexpr bool value = false; };
 
-__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
-
 // NORM (MB = 1, M <= 4, K <= 4096): the whole activation block is register-resident from the start (thread t holds
 // halfs 8 t .. 8 t + 7 of every row, the stand-alone RMSNorm kernel's assignment and summation order, so the
 // normalised values are bit-identical to a separate zl_rmsnorm launch); the thread quarter that holds phase p's
@@ -154,17 +158,26 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)
 // task m, computed per thread for its own 8 halfs with k_decode_attn_combine's arithmetic and order (bit-identical).
 // One workgroup per CU (the grid has at most one generation), so the prologue may hold 16 splits x 8 floats in VGPRs
 // and have every load of a row in flight at once.
-template <int R, int MB, bool NORM, bool ROPE, int KS = 1, bool MERGE = false>
-__global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhaseParams p) {
+// I8 (rows 5..32, no NORM / MERGE): integer digit planes from memory (PhaseParams::planes) instead of fp16 rows through LDS.
+// A wave's A operands of a phase -- its own group, all row blocks, three digits, two MFMAs: 6 MB KiB -- are loaded straight into
+// registers in MFMA layout one phase ahead (two sets), so there is NO activation staging, NO LDS traffic in the stream and NO
+// phase barrier: the eight waves only meet at the final reduction.  Per item: 8 VALU expand the nibbles to bytes (shared by all
+// rows), 6 MB v_mfma_i32_16x16x64_i8, and per row of the lane 6 VALU turn the three exact digit sums into the fp32 group value
+//     xscale * (65536 D2 + 256 D1 + D0) - z * xscale * sum X          (w4_i8p.hip's arithmetic; the group constants per row
+// come from the planes' side table, parked in LDS per wave at kernel entry), scale-accumulated one step later like the fp16 path.
+template <int R, int MB, bool NORM, bool ROPE, int KS = 1, bool MERGE = false, bool I8 = false>
+__global__ __launch_bounds__(kT, (MERGE || I8) ? 1 : 2) void k_w4a16_phase(const PhaseParams p) {
     static_assert(!MERGE || (NORM && !ROPE && KS == 1), "split merge: register-resident staging");
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
     static_assert(KS == 1 || (!ROPE && !NORM), "K split: plain / bias / residual epilogues only");
-    constexpr int D = ring_depth(R, NORM), XP = NORM ? 1 : x_ahead(R), BODY = lcm_(D, R * XP);
+    static_assert(!I8 || (!NORM && !MERGE), "digit planes: the norm / merge happened where the planes were made");
+    constexpr int D = I8 ? (R <= 2 ? R + 2 : R == 3 ? 4 : R) : ring_depth(R, NORM);
+    constexpr int XP = I8 ? 2 : NORM ? 1 : x_ahead(R), BODY = lcm_(D, R * XP);
     static_assert(!NORM || MB == 1, "fused norm: one row block");
     constexpr int XC = 4 * MB;                       // 16-byte x chunks per thread per phase (16 MB rows x 128 chunks)
     constexpr int kBuf = MB * 16 * kXS;              // halfs per LDS phase buffer
     static_assert(BODY % R == 0 && (BODY / R) % XP == 0 && BODY % D == 0, "static ring / accumulator / x-set indices");
-    static_assert(NORM || XP * R >= D - 2, "x loads must be older than the weights in flight when they are consumed");
+    static_assert(NORM || I8 || XP * R >= D - 2, "x loads must be older than the weights in flight when they are consumed");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* xs = reinterpret_cast<uint16_t*>(smem);
     ZL_PPROBE_INIT();
@@ -215,9 +228,34 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
             }
         }
         if (p.norm_w) nw4 = *reinterpret_cast<const uint4*>(p.norm_w + (idx < p.k ? idx : 0));
-    } else {
+    } else if constexpr (!I8) {
 #pragma unroll
         for (int q = 0; q < XP; ++q) load_x(q, q);
+    }
+    // I8: the A operands of phase 0 and this wave's group constants of every phase, ahead of the weight ring
+    v4i A[I8 ? 2 : 1][MB][3][2];
+    uint4 craw[2 * MB];
+    const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.planes), 0, I8 ? p.planes_bytes : 0, 0x00020000);
+    const uint32_t kOob = 0x80000000u;               // a lane offset no descriptor covers: the load returns zero and moves nothing
+    auto load_A = [&](int set, int ph) {             // set: static
+        const uint32_t g = (uint32_t)((ph0 + ph) * kW + wave);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            const uint32_t vo = (b * 16 + nrow < p.m && ph < P) ? (uint32_t)lane * 16u : kOob;
+#pragma unroll
+            for (int jm = 0; jm < 6; ++jm)
+                A[set][b][jm >> 1][jm & 1] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rpl, vo, ((g * MB + b) * 6u + jm) * 1024u, 0));
+        }
+    };
+    if constexpr (I8) {
+        load_A(0, 0);
+        const __amdgpu_buffer_rsrc_t rpc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pconsts), 0, p.pconsts_bytes, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < 2 * MB; ++c) {           // 16 phases x MB blocks x 8 pieces of 16 bytes = 128 MB pieces per wave
+            const int idx = c * 64 + lane, ph = idx / (8 * MB), within = idx % (8 * MB);
+            const uint32_t g = (uint32_t)((ph0 + ph) * kW + wave);
+            craw[c] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rpc, ph < P ? g * (uint32_t)(MB * 128) + within * 16u : kOob, 0, 0));
+        }
     }
     // ROPE: what this thread's epilogue needs from memory (rotation table entries, the task's slot, buffer length and buffer
     // pointer; 16 m <= 512 outputs, one per thread) is requested here, next to the activations and ahead of the weight ring:
@@ -307,6 +345,11 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
             }
         }
     };
+    unsigned char* cw = smem + (size_t)wave * (16 * MB * 128);   // I8: this wave's group constants, [phase][block][16 rows][2]
+    if constexpr (I8) {
+#pragma unroll
+        for (int c = 0; c < 2 * MB; ++c) *reinterpret_cast<uint4*>(cw + (size_t)(c * 64 + lane) * 16) = craw[c];
+    } else
     if constexpr (NORM) {
       // (norm_w == null: the register-resident staging alone -- up to 4 rows it beats the per-phase loads: 4.9 vs 5.1 us
       //  on the o projection at one row)
@@ -428,7 +471,7 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
     } else {
         store_x(0, 0);
     }
-    __syncthreads();
+    if constexpr (!I8) __syncthreads();
     ZL_PPROBE(2);
 
     const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
@@ -525,6 +568,44 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
         for (int b = 0; b < MB; ++b) accg_prev[b] = accg[b];
         issue(pslot, r_issue);
     };
+    // the integer step: same ring / accumulator discipline, the group value formed from exact digit sums
+    float cst[MB][8];
+    const uint32_t m4 = __builtin_amdgcn_readfirstlane(0x0f0f0f0fu);
+    auto step_i8 = [&](int slot, int pslot, int rp, int r_issue, int set) {
+        const uint4 w = wq[slot];
+        const uint32_t mw = mt[slot];
+        v4i b0, b1;
+        b0[0] = (int)(w.x & m4); b0[1] = (int)((w.x >> 4) & m4); b0[2] = (int)(w.y & m4); b0[3] = (int)((w.y >> 4) & m4);
+        b1[0] = (int)(w.z & m4); b1[1] = (int)((w.z >> 4) & m4); b1[2] = (int)(w.w & m4); b1[3] = (int)((w.w >> 4) & m4);
+        finish_prev(rp, pslot);
+        __builtin_amdgcn_sched_barrier(0);
+        const v4i zero4 = (v4i){0, 0, 0, 0};
+        v4i d[MB][3];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                d[b][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[set][b][j][0], b0, zero4, 0, 0, 0);
+                d[b][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[set][b][j][1], b1, d[b][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const hv2 sm = __builtin_bit_cast(hv2, mw);              // .x = scale, .y = -(1024 + zero)
+        const float zf = (float)sm.y + 1024.f;                    // -zero, exact
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float f12 = (float)((d[b][1][i] << 8) + d[b][2][i]);
+                const float u = __builtin_fmaf((float)d[b][0][i], 65536.f, f12);
+                accg_prev[b][i] = __builtin_fmaf(zf, cst[b][2 * i + 1], u * cst[b][2 * i]);
+            }
+        }
+        // the B registers stay allocated until the results have been read (w4_i8p.hip: a VALU write one slot behind the MFMA
+        // reached the rows of its last pass)
+        asm volatile("" : "+v"(accg_prev[0][0]) : "v"(b0), "v"(b1));
+        issue(pslot, r_issue);
+    };
     // BODY steps starting at a phase boundary (k, ph); GUARD: the stream may end inside (wave-uniform tests)
     auto body = [&](int k, int ph, auto guard_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;
@@ -533,6 +614,20 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
             if (GUARD && k + s >= total) break;
             const int r = s % R, j = s / R;          // static
             const int php = ph + j;
+            if constexpr (I8) {
+                if (r == 0) {
+                    load_A((j + 1) & 1, php + 1);    // the other set: last read by phase php - 1
+#pragma unroll
+                    for (int b = 0; b < MB; ++b) {
+                        const float4 c0 = *reinterpret_cast<const float4*>(cw + (size_t)(php * MB + b) * 128 + kq * 32);
+                        const float4 c1 = *reinterpret_cast<const float4*>(cw + (size_t)(php * MB + b) * 128 + kq * 32 + 16);
+                        cst[b][0] = c0.x; cst[b][1] = c0.y; cst[b][2] = c0.z; cst[b][3] = c0.w;
+                        cst[b][4] = c1.x; cst[b][5] = c1.y; cst[b][6] = c1.z; cst[b][7] = c1.w;
+                    }
+                }
+                step_i8(s % D, (s + D - 1) % D, (s + R - 1) % R, (s + D - 1) % R, j & 1);
+                continue;
+            }
             if (!NORM && r == 0) load_x(j % XP, php + XP);   // set (phase % XP): free since the end of phase php - 1
             step(s % D, (s + D - 1) % D, (s + R - 1) % R, (s + D - 1) % R, php);
 #ifdef ZL_PHASE_PROBE
@@ -724,26 +819,129 @@ __global__ __launch_bounds__(kT, MERGE ? 1 : 2) void k_w4a16_phase(const PhasePa
     ZL_PPROBE(6);
 }
 
-template <int R, int MB, bool NORM, bool ROPE = false, int KS = 1, bool MERGE = false>
+template <int R, int MB, bool NORM, bool ROPE = false, int KS = 1, bool MERGE = false, bool I8 = false>
 int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
-    constexpr size_t x_bytes = 2 * (size_t)MB * 16 * kXS * 2 + (NORM ? 8 * kW * 4 : 0);
+    constexpr size_t x_bytes = I8 ? (size_t)kW * 16 * MB * 128 : 2 * (size_t)MB * 16 * kXS * 2 + (NORM ? 8 * kW * 4 : 0);
     constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
     constexpr size_t lds = x_bytes > red_bytes ? x_bytes : red_bytes;
     static_assert(lds <= 160 * 1024, "LDS");
     if (lds > 64 * 1024) {
         // every launch: the attribute is per device, and one process may drive several
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE, I8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return ZL_ELIMIT;
     }
 #ifdef ZL_PHASE_PROBE
     PhaseParams pp = p;
     pp.probe_id = zl_probe_seq++;     // host-side launch number (all instantiations share it)
-    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE>), dim3(grid), dim3(kT), lds, hs, pp);
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE, I8>), dim3(grid), dim3(kT), lds, hs, pp);
 #else
-    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE, I8>), dim3(grid), dim3(kT), lds, hs, p);
 #endif
     return zl_launch_status();
+}
+
+// ---- digit planes of an activation matrix (the producer side of the I8 instantiations) ------------------------------------
+// One workgroup per row.  Octet o of the row (8 consecutive k) belongs to group o / 16; a DPP row of 16 lanes holds one group,
+// so the group's largest magnitude and its sum of integers are row rotations.  Arithmetic = w4_i8p.hip's conversion slot:
+// X = rint(x * 2^(36 - Ef)) (Ef = exponent field of the group's largest fp16 magnitude, |X| < 2^22), balanced byte digits
+// X = 65536 b2 + 256 b1 + b0 read off Y = X + 0x808080; xscale = 2^(Ef - 36), NaN for a group that holds an inf / NaN.
+// NORM: RMSNorm of the row first (LayerNorm::forward, src/nn/layernorm/layernorm.cu:10-42; T(x * rs * w) like the fused
+// prologues), so the normalised row is never written anywhere.  NO = octets per thread (K <= 4096 NO).
+template <int NO>
+__global__ __launch_bounds__(512) void k_w4_planes(const uint16_t* __restrict__ x, int64_t ldx, int m, int k,
+                                                   const uint16_t* __restrict__ norm_w, float norm_eps,
+                                                   unsigned char* __restrict__ planes, float* __restrict__ pconsts, int mb) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, b = row >> 4, rib = row & 15, groups = k >> 7;
+    if (row >= m) {                                   // a row block's unused rows: neutral constants (their planes are never read)
+        for (int g = threadIdx.x; g < groups; g += 512)
+            *reinterpret_cast<float2*>(pconsts + (((size_t)g * mb + b) * 16 + rib) * 2) = make_float2(0.f, 0.f);
+        return;
+    }
+    uint4 xr[NO], nw[NO];
+    float part = 0.f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        const int oct = threadIdx.x + 512 * o;
+        const bool live = oct * 8 < k;
+        xr[o] = *reinterpret_cast<const uint4*>(x + (live ? (size_t)row * ldx + oct * 8 : 0));
+        if (!live) xr[o] = make_uint4(0, 0, 0, 0);
+        nw[o] = norm_w ? *reinterpret_cast<const uint4*>(norm_w + (live ? oct * 8 : 0)) : make_uint4(0, 0, 0, 0);
+    }
+    if (norm_w) {                                     // kernel-uniform
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const uint32_t u[4] = {xr[o].x, xr[o].y, xr[o].z, xr[o].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const hv2 hh = __builtin_bit_cast(hv2, u[e]);
+                part = __builtin_fmaf((float)hh.x, (float)hh.x, part);
+                part = __builtin_fmaf((float)hh.y, (float)hh.y, part);
+            }
+        }
+        const float rs = zl_rsqrt_rn(zl_block_sum(part, red) / (float)k + norm_eps);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            uint32_t u[4] = {xr[o].x, xr[o].y, xr[o].z, xr[o].w};
+            const uint32_t wu[4] = {nw[o].x, nw[o].y, nw[o].z, nw[o].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const hv2 hh = __builtin_bit_cast(hv2, u[e]), ww = __builtin_bit_cast(hv2, wu[e]);
+                hv2 q;
+                q.x = zl_f32_to_f16((float)hh.x * rs * (float)ww.x);
+                q.y = zl_f32_to_f16((float)hh.y * rs * (float)ww.y);
+                u[e] = __builtin_bit_cast(uint32_t, q);
+            }
+            xr[o] = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        const int oct = threadIdx.x + 512 * o, g = oct >> 4, uo = oct & 15;
+        const bool live = oct * 8 < k;                // whole DPP rows are live or not (k % 128 == 0)
+        const uint32_t u[4] = {xr[o].x, xr[o].y, xr[o].z, xr[o].w};
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const us2 m01 = __builtin_elementwise_max(__builtin_bit_cast(us2, u[0] & 0x7fff7fffu), __builtin_bit_cast(us2, u[1] & 0x7fff7fffu));
+        const us2 m23 = __builtin_elementwise_max(__builtin_bit_cast(us2, u[2] & 0x7fff7fffu), __builtin_bit_cast(us2, u[3] & 0x7fff7fffu));
+        const us2 mm = __builtin_elementwise_max(m01, m23);
+        int am = max((int)mm.x, (int)mm.y);
+        am = row16_max(am);
+        const int ef = min(am >> 10, 30);
+        const float up = __builtin_bit_cast(float, (uint32_t)(163 - ef) << 23);          // 2^(36 - Ef)
+        const float xscale = am >= 0x7c00 ? __builtin_bit_cast(float, 0x7fc00000u) : __builtin_bit_cast(float, (uint32_t)(91 + ef) << 23);
+        uint32_t Y[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const hv2 hh = __builtin_bit_cast(hv2, u[e]);
+            Y[2 * e] = (uint32_t)__builtin_fmaf((float)hh.x, up, 8421504.f);
+            Y[2 * e + 1] = (uint32_t)__builtin_fmaf((float)hh.y, up, 8421504.f);
+        }
+        int sx = (int)(((Y[0] + Y[1]) + (Y[2] + Y[3])) + ((Y[4] + Y[5]) + (Y[6] + Y[7]))) - 8 * 0x808080;
+        sx = row16_sum(sx);
+        // byte gather: k offsets [0 4 1 5 | 2 6 3 7] of the octet, the order (w & 0x0f0f0f0f | (w >> 4) & 0x0f0f0f0f) leaves the nibbles in
+        auto planes_of = [&](int i0, int i1, int i2, int i3, uint32_t& d2, uint32_t& d1, uint32_t& d0) {
+            const uint32_t P = __builtin_amdgcn_perm(Y[i1], Y[i0], 0x05010400u);
+            const uint32_t Q = __builtin_amdgcn_perm(Y[i3], Y[i2], 0x05010400u);
+            const uint32_t P2 = __builtin_amdgcn_perm(Y[i1], Y[i0], 0x0c0c0602u);
+            const uint32_t Q2 = __builtin_amdgcn_perm(Y[i3], Y[i2], 0x0c0c0602u);
+            d0 = __builtin_amdgcn_perm(Q, P, 0x05040100u) ^ 0x80808080u;
+            d1 = __builtin_amdgcn_perm(Q, P, 0x07060302u) ^ 0x80808080u;
+            d2 = __builtin_amdgcn_perm(Q2, P2, 0x05040100u) ^ 0x80808080u;
+        };
+        uint32_t a2, a1, a0, b2, b1, b0;
+        planes_of(0, 4, 1, 5, a2, a1, a0);
+        planes_of(2, 6, 3, 7, b2, b1, b0);
+        if (live) {
+            // octet uo: MFMA uo / 8, lane quarter kq = uo % 4, half (uo / 4) % 2 of the lane's 16 bytes
+            unsigned char* dst = planes + ((((size_t)g * mb + b) * 6 + (uo >> 3)) * 64 + (uo & 3) * 16 + rib) * 16 + ((uo >> 2) & 1) * 8;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(a2, b2);                  // digit 2: tile pair 0
+            *reinterpret_cast<uint2*>(dst + 2 * 1024) = make_uint2(a1, b1);       // digit 1
+            *reinterpret_cast<uint2*>(dst + 4 * 1024) = make_uint2(a0, b0);       // digit 0
+            if (uo == 0)
+                *reinterpret_cast<float2*>(pconsts + (((size_t)g * mb + b) * 16 + rib) * 2) = make_float2(xscale, xscale * (float)sx);
+        }
+    }
 }
 
 }  // namespace
@@ -767,7 +965,7 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
     const int rounds_override = o.phase_rounds;
     if (norm_w && (m > 8 || k > 4096)) return ZL_ESHAPE;
-    PhaseParams p;
+    PhaseParams p = {};
     p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
     p.meta_bytes = meta_bytes; p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k;
     p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = epilogue; p.ld_out = ld_out; p.norm_w = norm_w; p.norm_eps = norm_eps;
@@ -819,7 +1017,7 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
                              uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs) {
     if (m < 1 || m > 32 || d % 32 != 0 || n != (h + 2 * hkv) * d || tiles * 16 != n) return ZL_ESHAPE;
     if (norm_w && (m > 8 || k > 4096)) return ZL_ESHAPE;
-    PhaseParams p;
+    PhaseParams p = {};
     p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
     p.meta_bytes = meta_bytes; p.bias = bias; p.residual = nullptr; p.y = nullptr; p.m = m; p.n = n; p.k = k;
     p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = bias ? ZL_EPI_BIAS : 0; p.ld_out = n;
@@ -846,7 +1044,7 @@ int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const in
     if (cus <= 0) cus = 256;
     const int r = (tiles + cus - 1) / cus;
     if (r > 2) return ZL_ESHAPE;
-    PhaseParams p;
+    PhaseParams p = {};
     p.x = nullptr; p.ldx = 0; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
     p.meta_bytes = meta_bytes; p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k;
     p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = epilogue; p.ld_out = n;
@@ -857,4 +1055,101 @@ int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const in
     p.mg_ws = ws; p.mg_valid_lens = valid_lens; p.mg_split_len = split_len; p.mg_max_splits = max_splits;
     const int grid = (tiles + r - 1) / r;
     return r == 1 ? launch_phase<1, 1, true, false, 1, true>(p, grid, hs) : launch_phase<2, 1, true, false, 1, true>(p, grid, hs);
+}
+
+// ---- digit planes: producer launch and the I8 instantiations ----------------------------------------------------------------
+// planes buffer of an (m, k) activation matrix: [k / 128 groups][mb row blocks][6 KiB of A operands], then the constants
+// [groups][mb][16 rows][2 floats]; mb = 1 up to 16 rows, 2 up to 32
+int64_t zl_w4_planes_bytes_(int64_t m, int64_t k) {
+    if (m < 1 || m > 32 || k < 128 || k % 128 != 0 || k > 16384) return ZL_ESHAPE;
+    const int64_t mb = m <= 16 ? 1 : 2;
+    return (k / 128) * mb * (6 * 1024 + 128);
+}
+
+int zl_w4_planes_launch(const uint16_t* x, int64_t ldx, int m, int k, const uint16_t* norm_w, float norm_eps, void* planes, hipStream_t hs) {
+    if (zl_w4_planes_bytes_(m, k) < 0) return ZL_ESHAPE;
+    const int mb = m <= 16 ? 1 : 2, groups = k / 128;
+    unsigned char* pl = static_cast<unsigned char*>(planes);
+    float* pc = reinterpret_cast<float*>(pl + (size_t)groups * mb * 6 * 1024);
+    const int no = (k / 8 + 511) / 512;
+    const dim3 grid(mb * 16), block(512);
+    if (no <= 1) hipLaunchKernelGGL(k_w4_planes<1>, grid, block, 0, hs, x, ldx, m, k, norm_w, norm_eps, pl, pc, mb);
+    else if (no <= 2) hipLaunchKernelGGL(k_w4_planes<2>, grid, block, 0, hs, x, ldx, m, k, norm_w, norm_eps, pl, pc, mb);
+    else hipLaunchKernelGGL(k_w4_planes<4>, grid, block, 0, hs, x, ldx, m, k, norm_w, norm_eps, pl, pc, mb);
+    return zl_launch_status();
+}
+
+static void planes_params(PhaseParams& p, const void* planes, int m, int k) {
+    const int mb = m <= 16 ? 1 : 2, groups = k / 128;
+    p.x = nullptr; p.ldx = 0;
+    p.planes = static_cast<const unsigned char*>(planes);
+    p.planes_bytes = (uint32_t)((size_t)groups * mb * 6 * 1024);
+    p.pconsts = reinterpret_cast<const float*>(p.planes + p.planes_bytes);
+    p.pconsts_bytes = (uint32_t)((size_t)groups * mb * 128);
+}
+
+// internal (called by zl_w4a16_gemm_planes): 5 <= m <= 32 rows as digit planes (zl_w4_planes_launch), k % 128 == 0, k <= 16384
+int zl_w4a16_gemm_phase_planes(const void* planes, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
+                               const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups, int tiles,
+                               int epilogue, int ld_out, const zl_w4_opts_t* opts, hipStream_t hs) {
+    static const zl_w4_opts_t kNoOpts = {};
+    const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
+    if (zl_w4_planes_bytes_(m, k) < 0 || groups * 128 != k) return ZL_ESHAPE;
+    PhaseParams p = {};
+    planes_params(p, planes, m, k);
+    p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
+    p.meta_bytes = meta_bytes; p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k;
+    p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = epilogue; p.ld_out = ld_out; p.norm_w = nullptr; p.norm_eps = 0.f;
+    p.cosv = p.sinv = nullptr; p.placement = p.buf_lens = nullptr; p.k_bufs = p.v_bufs = nullptr; p.q_out = nullptr;
+    p.h = p.hkv = p.d = p.bshd = 0; p.pair_stride = 1;
+    p.ks_ws = nullptr; p.ks_counter = nullptr;
+    p.mg_ws = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    const int mb = m <= 16 ? 1 : 2;
+    {   // few tiles and a long K (the down projection): K split over 2 / 4 workgroups of 2 / 4 tiles -- a workgroup pulls
+        // 1 / KS of the planes through L2 and the grid keeps its size; partials and counters in the caller's scratch
+        const int ksplit = o.phase_ksplit ? o.phase_ksplit : 4;
+        const bool plain = !(epilogue & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32));
+        const int64_t need = ZL_SCRATCH_HEADER + (int64_t)ksplit * m * n * (int64_t)sizeof(float);
+        if ((ksplit == 2 || ksplit == 4) && k > 8192 && tiles <= 2 * cus && plain && o.scratch && o.scratch_bytes >= need) {
+            p.ks_counter = reinterpret_cast<int*>(o.scratch);
+            p.ks_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(o.scratch) + ZL_SCRATCH_HEADER);
+            const int grid = (tiles + ksplit - 1) / ksplit * ksplit;
+            if (mb == 1) return ksplit == 2 ? launch_phase<2, 1, false, false, 2, false, true>(p, grid, hs) : launch_phase<4, 1, false, false, 4, false, true>(p, grid, hs);
+            return ksplit == 2 ? launch_phase<2, 2, false, false, 2, false, true>(p, grid, hs) : launch_phase<4, 2, false, false, 4, false, true>(p, grid, hs);
+        }
+    }
+    int r = (tiles + cus - 1) / cus;
+    if (r > 8) r = 8;
+    if (o.phase_rounds > 0 && o.phase_rounds <= 8) r = o.phase_rounds;
+    const int grid = (tiles + r - 1) / r;
+#define ZL_PH8(RR)                                                                                             \
+    case RR:                                                                                                   \
+        return mb == 1 ? launch_phase<RR, 1, false, false, 1, false, true>(p, grid, hs) : launch_phase<RR, 2, false, false, 1, false, true>(p, grid, hs);
+    switch (r) {
+        ZL_PH8(1) ZL_PH8(2) ZL_PH8(3) ZL_PH8(4) ZL_PH8(5) ZL_PH8(6) ZL_PH8(7) ZL_PH8(8)
+    }
+#undef ZL_PH8
+    return ZL_EINVAL;
+}
+
+// internal (called by zl_w4a16_qkv_rope_scatter_planes)
+int zl_w4a16_gemm_phase_planes_rope(const void* planes, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
+                                    const uint16_t* bias, int m, int n, int k, int groups, int tiles, const float* cosv, const float* sinv,
+                                    const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs, uint16_t* const* v_bufs,
+                                    uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs) {
+    if (zl_w4_planes_bytes_(m, k) < 0 || groups * 128 != k || d % 32 != 0 || n != (h + 2 * hkv) * d || tiles * 16 != n) return ZL_ESHAPE;
+    PhaseParams p = {};
+    planes_params(p, planes, m, k);
+    p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
+    p.meta_bytes = meta_bytes; p.bias = bias; p.residual = nullptr; p.y = nullptr; p.m = m; p.n = n; p.k = k;
+    p.groups = groups; p.tiles = tiles; p.phases = (groups + kW - 1) / kW; p.epi = bias ? ZL_EPI_BIAS : 0; p.ld_out = n;
+    p.norm_w = nullptr; p.norm_eps = 0.f;
+    p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs;
+    p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd; p.pair_stride = d / 32;
+    p.ks_ws = nullptr; p.ks_counter = nullptr;
+    p.mg_ws = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
+    const int grid = tiles / 2;
+    return m <= 16 ? launch_phase<2, 1, false, true, 1, false, true>(p, grid, hs) : launch_phase<2, 2, false, true, 1, false, true>(p, grid, hs);
 }

@@ -427,6 +427,66 @@ def w4a16_gemm_tiled(x, w, bias=None, residual=None, out=None, epilogue=0):
     return out
 
 
+def w4_planes_ok(m, k):
+    """what the digit-plane route of the W4A16 linears covers: decode batches of 5..32 rows (1..4 rows: the integer-plane GEMV
+    converts inside its own prologue), K a multiple of 128 up to 16384"""
+    return 5 <= m <= 32 and k % 128 == 0 and k <= 16384
+
+
+def w4_planes(x, norm_weight=None, norm_eps=1e-5, out=None):
+    """digit planes of an activation matrix (zl_w4a16_planes): x (M <= 32, K) fp16 -> an opaque uint8 buffer for
+    w4_linear_planes / w4_qkv_rope_scatter_planes; with norm_weight the RMSNorm of every row is applied first."""
+    if x.dtype != torch.float16:
+        raise ZLError("A must be half")
+    _chk_cuda(x, norm_weight, out)
+    x2 = x.reshape(-1, x.shape[-1])
+    m, k = x2.shape
+    nbytes = int(lib().zl_w4a16_planes_bytes(_i(m), _i(k)))
+    if nbytes < 0:
+        check(nbytes, "w4a16_planes_bytes")
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    elif out.numel() < nbytes or out.dtype != torch.uint8:
+        raise ZLError("w4_planes: out too small")
+    check(lib().zl_w4a16_planes(_p(x2), _i(x2.stride(0)), _i(m), _i(k), _p(norm_weight), _f(norm_eps), _p(out), _stream()),
+          "w4a16_planes")
+    return out
+
+
+def w4_linear_planes(planes, m, w, bias=None, residual=None, out=None, epilogue=0):
+    """w4a16_gemm_mfma on digit planes (zl_w4a16_gemm_planes): planes = w4_planes(x) of an (m, w.k) matrix."""
+    _chk_cuda(planes, bias, residual)
+    if not isinstance(w, W4MWeight):
+        raise ZLError("w4_linear_planes: a ZLW4M weight")
+    silu = epilogue & (EPI_SILU_MUL | EPI_SILU_MUL_F32)
+    n_out = w.n // 2 if silu else w.n
+    if out is None:
+        out = torch.empty((m, n_out), dtype=torch.float16, device=planes.device)
+    else:
+        _chk_out(out, m, n_out, torch.float16, planes.device, "w4_linear_planes")
+    if bias is not None:
+        epilogue |= EPI_BIAS
+    opts = _w4_opts(planes.device, m, w.n)
+    check(lib().zl_w4a16_gemm_planes(_p(planes), _p(w.qw), _p(w.meta), _p(bias), _p(residual), _p(out), _i(m), _i(w.n), _i(w.k),
+                                     _i(w.group_size), C.c_int(epilogue), C.byref(opts), _stream()), "w4a16_gemm_planes")
+    return out
+
+
+def w4_qkv_rope_scatter_planes(planes, m, w, cos, sin, placement, buf_lens, k_addrs, v_addrs, num_heads, num_kv_heads, dim_head,
+                               bias=None, bshd=True, q_out=None):
+    """w4_qkv_rope_scatter on digit planes (the norm went into w4_planes)"""
+    _chk_cuda(planes, cos, sin, placement, buf_lens, k_addrs, v_addrs, bias)
+    if not isinstance(w, W4MWeight):
+        raise ZLError("w4_qkv_rope_scatter_planes: a ZLW4M weight")
+    if q_out is None:
+        q_out = torch.empty((m, num_heads * dim_head), dtype=torch.float16, device=planes.device)
+    check(lib().zl_w4a16_qkv_rope_scatter_planes(_p(planes), _p(w.qw), _p(w.meta), _p(bias), _p(cos), _p(sin), _p(placement),
+                                                 _p(buf_lens), _p(k_addrs), _p(v_addrs), _p(q_out), _i(m), _i(num_heads),
+                                                 _i(num_kv_heads), _i(dim_head), _i(w.k), _i(w.group_size), C.c_int(int(bshd)),
+                                                 _stream()), "w4a16_qkv_rope_scatter_planes")
+    return q_out
+
+
 def w4_linear(x, w, **kw):
     """W4A16 linear on whichever packed layout the weight holds (W4Weight: bit-exact warp-reduce
     arithmetic; W4MWeight: fp32-accumulating MFMA arithmetic)."""
