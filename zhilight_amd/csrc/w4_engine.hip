@@ -38,6 +38,19 @@
 // the caller advances once per step; MI355X guide, "Inter-workgroup communication", recipe R2).  While the consumers finish
 // the first projection and wait for the hand-off, the loader is already 10 slots (85 KiB per CU) into gate|up's weights --
 // the part of the stream that a kernel boundary would have left idle.
+//
+// Measured (round 4, profiles/r04_engine_ab.txt, r04_engine_timeline.txt, r04_ldsdma_stream.txt): bit-identical to k_w4a16_i8p
+// and NOT faster -- which is why it is an opt-in route (zl_w4_opts_t::small_algo = 2; LLaMA: ZL_W4_SMALL_ALGO=2,
+// ZL_FUSE_O_GATEUP=1) and k_w4a16_i8p stays the default.  Stand-alone launches: 43.1 us per layer in the step against 39.2-39.8;
+// with the fused launch on k_w4a16_i8p's other three launches: 39.8-39.9 (a tie).  Why the guide's engine row does not
+// transfer to this layer: (1) an LDS-DMA costs the loader wave ~85 cycles of issue per KiB (the texture-address path, not
+// HBM): a bare loader stream reaches 6.0 TB/s on 224 KiB per workgroup (register ring: 5.4-5.5), but every poll, counted wait
+// and round hand-back the loader does between DMAs comes straight out of that -- inside the engine a slot takes 0.45 us
+// instead of 0.30; (2) the consumers' per-item chain (expand, two dependent MFMAs, five fp32 ops: 0.25-0.3 us per slot and
+// wave) has no slack to hide ring bookkeeping, so the ring is consumed in rounds and a round's tail waits for its slowest
+// wave; (3) the fused hand-off costs what the boundary it removes costs: granule publish -> all 256 workgroups have swept
+// them = 2.0-2.5 us, plus 1.6 us of RMSNorm + plane conversion that cannot start earlier, while the 14-slot ring (126 of
+// 160 KiB of LDS) is full after 9.5 us and the loader idles until the first round is handed back.
 #include "zl_common.h"
 #include "w4_i8p_common.h"
 
@@ -852,9 +865,12 @@ __global__ __launch_bounds__(kET, 1) void k_w4_engine_o_gateup(const I8Params p1
         LoaderState st = {0u, 0u, 0, 0};
         const LoadPhase f1 = load_phase_of(p1, 1, false);
         loader_phase(f1, st, L, lane);
-        // the second projection's stream starts when the first one's inputs are in registers: before that its requests would
-        // only slow the split merge's 32 record loads per lane down (and be slowed by them)
-        {
+        // Two schedules of the second projection's stream were measured (profiles/r04_engine_ab.txt): started at once and running
+        // at full depth beside the hand-off sweep (kFusedHoldBack = false: 39.8 us per layer in the step, run r28), or held back
+        // until the first projection's inputs are in registers and thinned to one slot in flight while a consumer wave sweeps
+        // the granules (true: 43.4-43.5, runs r29 / r30 -- the loader's own polls cost more than the sweep gains).
+        constexpr bool kFusedHoldBack = false;
+        if (kFusedHoldBack) {
             uint32_t spins = 0;
             while (lds_poll(L.fl + kFlStaged) < (uint32_t)kCW) {
                 if (st.pending > 0) publish_oldest(st, L, lane);
@@ -865,7 +881,7 @@ __global__ __launch_bounds__(kET, 1) void k_w4_engine_o_gateup(const I8Params p1
             }
         }
         LoadPhase f2 = load_phase_of(p2, R2, false);
-        f2.thin = 1;
+        f2.thin = kFusedHoldBack ? 1 : 0;
         loader_phase(f2, st, L, lane);
         loader_finish(st, L, lane);
         return;
