@@ -15,6 +15,18 @@
  * binding.  Each declaration cites the reference interface it replaces (paths relative to the
  * ZhiLight tree).
  *
+ * Entry points that come in pairs (round 3 VERDICT item 9):
+ *   NAME / NAME_ex   -- NAME_ex is the implementation and takes the launcher options (zl_w4_opts_t, or a tuning struct of its
+ *       own) as one more argument; NAME is `return NAME_ex(..., NULL, s)`: the launcher's own choices, no scratch (K-split routes
+ *       off).  Both stay: NAME is what a binding written against the reference's operator signature calls
+ *       (zl_w4a16_gemm_mfma, zl_w4a16_gemm_tiled, zl_w4a16_qkv_rope_scatter, zl_decode_attn, zl_decode_attn_quant,
+ *       zl_w8a8_gemm_phase, zl_mla_decode_attn), NAME_ex what a host that owns scratch memory and knobs calls (ops.py does).
+ *   NAME / NAME_h    -- two FORMATS of the same hand-over, not two versions: zl_decode_attn_splits leaves fp32 split partials
+ *       (130 floats per record; consumed by zl_w4a16_gemm_attn_merge, the fp16-dequant route, and by zl_decode_attn's own merge),
+ *       zl_decode_attn_splits_h half-precision ones (256 B + an 8-byte (max, sum) pair; consumed by
+ *       zl_w4a16_gemm_attn_merge_h[_ex] on the integer-plane kernel).  A caller picks the pair that matches its projection
+ *       route (ops.attn_merge_plan returns which); mixing them is ZL_ESHAPE / garbage, hence distinct names.
+ *
  * dtype codes: ZL_F16 = 0 (IEEE half), ZL_BF16 = 1.  All tensors are dense row-major unless a
  * stride is passed.  "T" below means the activation dtype.
  */
