@@ -147,6 +147,81 @@ __global__ __launch_bounds__(512, 1) void k_reg(const unsigned char* buf, int ki
     if (sink && acc == 0x12345678u) sink[lane] = acc;
 }
 
+// wave-private DMA rings: no loader wave, no cross-wave bookkeeping -- each of the 8 waves moves ITS items (item i of the workgroup
+// belongs to wave i % 8) through its own ring of D x 1 KiB LDS slots with one global_load_lds_dwordx4 per item, waits with a counted
+// vmcnt, reads the item back with ds_read_b128 and refills the slot.  WORK = 1: two i8 MFMAs + a few VALU per item (the integer-plane
+// kernel's per-item load), 0: an xor.
+template <int D, int WORK>
+__global__ __launch_bounds__(512, 1) void k_wave_dma(const unsigned char* buf, int kib_per_wg, uint32_t* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int items = kib_per_wg, n = (items - wave + 7) / 8;
+    const unsigned char* base = buf + (size_t)blockIdx.x * kib_per_wg * 1024;
+    const uint32_t ring0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + (uint32_t)wave * D * 1024u;
+    const uint32_t voff = lane * 16u;
+    auto dma1k = [&](int item, int slot) {
+        const unsigned char* src = uptr(base + (size_t)(wave + 8 * item) * 1024);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)slot * 1024u);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) if (j < n) dma1k(j, j);
+    v4i acc = {0, 0, 0, 0};
+    uint32_t x = 0;
+    float f = 0.f;
+    typedef __attribute__((address_space(3))) const v4i* lds_v4i;
+    for (int j = 0; j < n; ++j) {
+        if (j + D <= n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D - 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const v4i w = *reinterpret_cast<lds_v4i>((uintptr_t)(ring0 + (uint32_t)(j % D) * 1024u + voff));
+        if (WORK) {
+            v4i b0, b1;
+            b0[0] = w[0] & 0x0f0f0f0f; b0[1] = (w[0] >> 4) & 0x0f0f0f0f; b0[2] = w[1] & 0x0f0f0f0f; b0[3] = (w[1] >> 4) & 0x0f0f0f0f;
+            b1[0] = w[2] & 0x0f0f0f0f; b1[1] = (w[2] >> 4) & 0x0f0f0f0f; b1[2] = w[3] & 0x0f0f0f0f; b1[3] = (w[3] >> 4) & 0x0f0f0f0f;
+            v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(b0, b1, (v4i){0, 0, 0, 0}, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, b0, d, 0, 0, 0);
+            f = __builtin_fmaf((float)((d[1] << 8) + d[2]), 1.5f, __builtin_fmaf((float)d[0], 0.25f, f));
+            acc[0] ^= d[3];
+        } else {
+            x ^= (uint32_t)(w[0] ^ w[1] ^ w[2] ^ w[3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read before it is refilled
+        if (j + D < n) dma1k(j + D, j % D);
+    }
+    if (sink && (acc[0] + (int)x + (int)f) == 0x12345678) sink[lane] = 1;
+}
+
+// the register ring with the same per-item work (WORK = 1 above), RD items per wave in flight
+template <int RD>
+__global__ __launch_bounds__(512, 1) void k_reg_work(const unsigned char* buf, int kib_per_wg, uint32_t* sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int items = kib_per_wg;
+    const v4i* base = reinterpret_cast<const v4i*>(buf + (size_t)blockIdx.x * kib_per_wg * 1024) + lane;
+    v4i r[RD], acc = {0, 0, 0, 0};
+    float f = 0.f;
+    int it = wave;
+#pragma unroll
+    for (int j = 0; j < RD; ++j) { r[j] = __builtin_nontemporal_load(base + (size_t)(it < items ? it : wave) * 64); it += 8; }
+    for (int c = wave; c < items; c += 8 * RD) {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) {
+            const v4i w = r[j];
+            v4i b0, b1;
+            b0[0] = w[0] & 0x0f0f0f0f; b0[1] = (w[0] >> 4) & 0x0f0f0f0f; b0[2] = w[1] & 0x0f0f0f0f; b0[3] = (w[1] >> 4) & 0x0f0f0f0f;
+            b1[0] = w[2] & 0x0f0f0f0f; b1[1] = (w[2] >> 4) & 0x0f0f0f0f; b1[2] = w[3] & 0x0f0f0f0f; b1[3] = (w[3] >> 4) & 0x0f0f0f0f;
+            v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(b0, b1, (v4i){0, 0, 0, 0}, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, b0, d, 0, 0, 0);
+            f = __builtin_fmaf((float)((d[1] << 8) + d[2]), 1.5f, __builtin_fmaf((float)d[0], 0.25f, f));
+            acc[0] ^= d[3];
+            r[j] = __builtin_nontemporal_load(base + (size_t)(it < items ? it : wave) * 64);
+            it += 8;
+        }
+    }
+    if (sink && (acc[0] + (int)f) == 0x12345678) sink[lane] = 1;
+}
+
 int main() {
     const int nbuf = 6, kibs[] = {32, 224};
     const size_t bytes = 256u * 224u * 1024u;
@@ -204,6 +279,21 @@ int main() {
         }
         BUSY(6, 0, "asleep") BUSY(6, 1, "asleep, 160 KiB LDS") BUSY(1, 0, "polling an LDS word") BUSY(2, 0, "reading the ring (ds_read_b128)")
         BUSY(3, 0, "on the i8 matrix cores") BUSY(4, 0, "in a VALU loop") BUSY(5, 0, "poll + read + MFMA") BUSY(5, 1, "poll + read + MFMA, 160 KiB LDS")
+        {
+#define RREG(RD)                                                                                                            \
+            {                                                                                                               \
+                const float usw = time_chain([&](unsigned char* b) { hipLaunchKernelGGL(k_reg_work<RD>, dim3(256), dim3(512), 0, st, b, kib, sink); }); \
+                printf("  register ring, 8 waves x %d KiB, nt, 2 MFMA + 5 VALU per item         : %6.2f us  %5.2f TB/s\n", RD, usw, 256.0 * kib * 1024 / usw / 1e6); \
+            }
+            RREG(2) RREG(3) RREG(4) RREG(6) RREG(8)
+        }
+#define WDMA(DD, WORK, LABEL)                                                                                              \
+        {                                                                                                                  \
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_dma<DD, WORK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            const float us4 = time_chain([&](unsigned char* b) { hipLaunchKernelGGL((k_wave_dma<DD, WORK>), dim3(256), dim3(512), 8 * DD * 1024, st, b, kib, sink); }); \
+            printf("  wave-private DMA rings, 8 waves x %2d KiB, nt, %-28s: %6.2f us  %5.2f TB/s\n", DD, LABEL, us4, 256.0 * kib * 1024 / us4 / 1e6); \
+        }
+        WDMA(2, 1, "2 MFMA + 5 VALU per item") WDMA(3, 1, "2 MFMA + 5 VALU per item") WDMA(4, 0, "xor") WDMA(8, 0, "xor") WDMA(16, 0, "xor") WDMA(4, 1, "2 MFMA + 5 VALU per item") WDMA(8, 1, "2 MFMA + 5 VALU per item") WDMA(16, 1, "2 MFMA + 5 VALU per item")
     }
     return 0;
 }

@@ -33,6 +33,9 @@
 namespace {
 
 constexpr int kT = 512, kW = 8;
+#ifndef ZL_I8P_RING
+#define ZL_I8P_RING 8            // 1 KiB items a wave keeps in flight (rounded down to whole groups of R tiles)
+#endif
 
 // ---- optional timeline probe (build with -DZL_I8P_PROBE; tools/ubench/probe_i8p.py): wall-clock stamps (100 MHz) per wave,
 //      [workgroup][wave][8]; every launch overwrites them, so after a replayed chain they describe its last launch
@@ -61,7 +64,7 @@ template <int R, bool LONGK, bool ROPE, bool NORM, bool MERGE = false>
 __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
     static_assert(!MERGE || (!LONGK && !ROPE && !NORM), "split merge: one column block, plain prologue");
-    constexpr int XD = R >= 8 ? 1 : (8 / R > 0 ? 8 / R : 1);   // groups the ring runs ahead (8 KiB per wave in flight: with 16
+    constexpr int XD = R >= ZL_I8P_RING ? 1 : (ZL_I8P_RING / R > 0 ? ZL_I8P_RING / R : 1);   // groups the ring runs ahead (8 KiB per wave in flight: with 16
     constexpr int D = R * XD;                                  // the issue itself stalls for microseconds)
     constexpr int NS = LONGK ? 8 : 4;                          // activation octet slots per thread
     constexpr int NR = LONGK ? 2 : 4;                          // rows
