@@ -303,6 +303,47 @@ def test_mla_decode_attention_over_the_latent_cache(oracle, dev, dtype, code, h,
     assert np.abs(g - R).max() <= max(np.abs(R - E).max() * 1.5, 2 * ulp * np.abs(E).max())
 
 
+@pytest.mark.parametrize("dtype,code", [(torch.float16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("b,max_len", [(3, 768), (9, 320), (32, 1088), (16, 2112)])
+def test_mla_decode_wide_kernel(oracle, dev, dtype, code, b, max_len):
+    """k_mla_decode_wide (all 128 heads of a task in one workgroup, latent rows through LDS by LDS-DMA; zl_mla_decode_attn_ex algo 2,
+    and what algo 0 picks from 16 tasks with 2048-key buffers on): against the fp64 statement at T's output rounding, against the 16-heads-per-workgroup
+    kernel within two output roundings (different split plans), ragged lengths incl. 1 key, a split boundary, 16 k + 1 keys, the
+    whole buffer, and an empty task."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(1000 * b + code)
+    h = 128
+    pool = [1, 16, 17, 63, 64, 65, 129, max_len // 2 + 1, max_len - 1, max_len - 2, 0]
+    lens = [pool[i % len(pool)] if i < len(pool) else int(rng.integers(1, max_len)) for i in range(b)]
+    q = torch.from_numpy((rng.standard_normal((b, h, 576)) * 0.4).astype(np.float32)).to(dtype)
+    bufs = [torch.from_numpy((rng.standard_normal((max_len, 576)) * 0.6).astype(np.float32)).to(dtype) for _ in range(b)]
+    for t in bufs:
+        t[-1] = float("nan")                                            # never visible: must not leak
+    dbufs = [t.to(dev) for t in bufs]
+    addrs = torch.tensor([t.data_ptr() for t in dbufs], dtype=torch.int64, device=dev)
+    buf_lens = torch.tensor([max_len - 1] * b, dtype=torch.int32, device=dev)
+    valid = torch.tensor(lens, dtype=torch.int32, device=dev)
+    scale = 0.1147
+    wide = ops.mla_decode_attention(q.to(dev), buf_lens, addrs, scale, max_len, valid, algo=2)
+    auto = ops.mla_decode_attention(q.to(dev), buf_lens, addrs, scale, max_len, valid, algo=0)
+    picks_wide = b >= 16 and max_len >= 2048
+    if picks_wide:
+        assert torch.equal(wide.view(torch.int16), auto.view(torch.int16))           # algo 0 IS the wide kernel there
+    live = [i for i, n in enumerate(lens) if n > 0]
+    args = (_bits(q[live]), [max_len - 1] * len(live), [lens[i] for i in live], [_bits(bufs[i]) for i in live])
+    f = (lambda u: oracle.u2h(u).astype(np.float64)) if code == 0 else (lambda u: (u.astype(np.uint32) << 16).view(np.float32).astype(np.float64))
+    E = f(oracle.mla_decode_attn(*args, scale=scale, dtype=code, flavour="E"))
+    g = f(_bits(wide))[live]
+    assert np.isfinite(g).all()
+    ulp = 2.0 ** (-10 if code == 0 else -7)
+    assert (np.abs(g - E) <= ulp * np.abs(E) + 2e-5 * np.abs(E).max()).all(), float(np.abs(g - E).max() / np.abs(E).max())
+    if not picks_wide:
+        a = f(_bits(auto))[live]
+        assert np.abs(g - a).max() <= 2 * ulp * np.abs(E).max()
+    dead = [i for i, n in enumerate(lens) if n == 0]
+    assert all(float(wide[i].float().abs().max()) == 0.0 for i in dead)               # an empty task: zeros, as the other kernels
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_flash_mla_binding_over_a_paged_cache(dev, dtype):
     """ds::mha_fwd_kvcache_mla (ds_flash_mla_api.h:16-30), the reference's FlashMLA FFI: the paged call returns the bits of the

@@ -42,6 +42,7 @@ struct MlaParams {
     const int32_t* block_table;
     int page, max_blocks;
     float* lse;                        // optional (B, H): log-sum-exp of the scaled scores
+    int dbg;                           // ablation bits of the wide kernel (zl_debug_mla): 1 no P.V, 2 no scores, 4 no staging waits, 8 no records
 };
 
 template <int DT>
@@ -343,6 +344,165 @@ __global__ __launch_bounds__(256) void k_mla_decode_mfma(const MlaParams p) {
     }
 }
 
+
+// ---- the wide kernel: ALL 128 heads of a task in one workgroup (round 4) ------------------------------------------------------------
+// k_mla_decode_mfma gives a workgroup 16 heads, so eight workgroups pull every latent row of a task through their CU's memory path:
+// at batch 32 each CU moves 1.18 MB for 59 us (20 GB/s, the per-CU rate of any streaming kernel here) -- 8 x the cache bytes.
+// Here the WAVES split the heads (wave w = heads 16 w .. 16 w + 15, 8 waves) and share the rows through LDS, so a row enters the CU
+// once: a 16-key piece (16 x 1152 B) is moved global -> LDS by LDS-DMA (18 global_load_lds_dwordx4 spread over the eight waves, three
+// pieces ahead of the one being consumed, non-temporal: nobody else reads these rows), every wave reads it as the A operand of
+// S^T = KV . Q^T (18 ds_read_b128; its own heads' q fragments live in registers) and, transposed (ds_read_tr16_b64), as the A
+// operand of O^T += V^T . P^T -- the arithmetic, the hi + lo probability split and the record format are k_mla_decode_mfma's, and
+// a wave owns its heads for ALL keys of the split, so there is no wave merge at the end.  One barrier per piece.
+// LDS image of a piece = FRAGMENT-major: 16-byte unit (column unit cu = 0..71, row rho = 0..15) sits at unit index 16 cu + rho, so
+// the A fragment of k-step t is 1 KiB of consecutive units in lane order (lane = 16 kq + r reads unit 16 (4 t + kq) + r:
+// conflict-free by construction) and DMA d of a piece (64 consecutive units) gathers column units 4 d .. 4 d + 3 of the 16 rows
+// (64 contiguous bytes per row).  A transposed read of (row rho, columns c .. c + 3) finds them inside unit 16 (c / 8) + rho.
+// grid (splits, B), 512 threads, H == 128.
+constexpr int kWPiece = 16 * kCD * 2;                          // bytes per staged 16-key piece (18 432), no padding
+constexpr int kWAhead = 7, kWRing = kWAhead + 1;               // pieces requested ahead of the one consumed (126 KB per CU in flight: with 3 a piece
+constexpr int kWLds = kWRing * kWPiece;                        // waited 1.0 us for its rows, tools/ubench/mla_ablate.py); ring slots; 147 456 B
+constexpr int kWideMinBatch = 16, kWideMinLen = 2048;          // zl_mla_decode_attn takes the wide kernel from this many tasks / keys on (H == 128)
+
+__device__ __forceinline__ void mla_dma16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int DT>
+__global__ __launch_bounds__(512, 1) void k_mla_decode_wide(const MlaParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mla_smem[];
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    const int len = p.valid_lens ? min(p.buf_lens[b], p.valid_lens[b]) : p.buf_lens[b];
+    const int t0 = split * p.split_len, t1 = min(len, t0 + p.split_len);
+    if (t0 >= len) return;                                                // (workgroup-uniform) the combine skips unwritten splits
+    const int last_key = t1 - 1, pieces = (t1 - t0 + 15) >> 4;
+    const uint16_t* kv = p.block_table ? nullptr : p.kv_bufs[b];
+
+    // this wave's Q^T fragments (B operand): lane = (head 16 wave + r, dims 32 t + 8 kq .. + 7)
+    uint4 qf[18];
+    {
+        const uint16_t* qp = p.q + ((size_t)b * p.h + wave * 16 + r) * kCD + 8 * kq;
+#pragma unroll
+        for (int t = 0; t < 18; ++t) qf[t] = *reinterpret_cast<const uint4*>(qp + 32 * t);
+    }
+    // DMA plan: wave w issues DMAs d = w, w + 8, w + 16 (< 18) of a piece; lane = (column unit 4 d + kq, row r)
+    const int nd = wave < 2 ? 3 : 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)mla_smem;
+    auto issue_piece = [&](int i) {                                       // i: wave-uniform, < pieces
+        const int base = t0 + 16 * i;
+        const uint16_t* piece;
+        if (p.block_table) {
+            const int pg = __builtin_amdgcn_readfirstlane(base / p.page);
+            piece = p.kcache + ((size_t)p.block_table[(size_t)b * p.max_blocks + pg] * p.page + (base - pg * p.page)) * kCD;
+        } else {
+            piece = kv + (size_t)base * kCD;
+        }
+        const uint64_t pa = (uint64_t)piece;
+        const uint32_t pa_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa), pa_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
+        const void* sb = (const void*)(((uint64_t)pa_hi << 32) | (uint64_t)pa_lo);       // (readfirstlane returns int: no sign extension)
+        const uint32_t slot = lds0 + (uint32_t)(i % kWRing) * kWPiece;
+        const uint32_t rowoff = (uint32_t)min(r, last_key - base) * (uint32_t)(kCD * 2) + (uint32_t)kq * 16u;   // (a key past the split re-reads the split's last row)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int d = wave + 8 * j;
+            if (d < 18) mla_dma16(sb, rowoff + (uint32_t)d * 64u, __builtin_amdgcn_readfirstlane(slot + (uint32_t)d * 1024u));
+        }
+    };
+    for (int i = 0; i < kWAhead && i < pieces; ++i) issue_piece(i);
+
+    mf4 o[32];
+#pragma unroll
+    for (int db = 0; db < 32; ++db) o[db] = (mf4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e20f, l_run = 0.f;
+
+    for (int i = 0; i < pieces; ++i) {
+        // this wave's DMAs of piece i have landed (pieces i + 1 .. i + kWAhead - 1 may still fly: nd DMAs each, at most 18) ...
+        const int after = min(kWAhead - 1, pieces - 1 - i);
+        if (!(p.dbg & 4)) {
+            switch (after * nd) {                                          // (wave-uniform; s_waitcnt takes an immediate)
+#define ZL_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+                ZL_W(0) ZL_W(2) ZL_W(3) ZL_W(4) ZL_W(6) ZL_W(8) ZL_W(9) ZL_W(10) ZL_W(12) ZL_W(15) ZL_W(18)
+#undef ZL_W
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        }
+        if (!(p.dbg & 4)) __syncthreads();                                 // ... and everybody's; piece i - 1 has been consumed by all waves
+        if (i + kWAhead < pieces && !(p.dbg & 4)) issue_piece(i + kWAhead);   // into the slot piece i - 1 sat in
+        const unsigned char* stage = mla_smem + (size_t)(i % kWRing) * kWPiece;
+        const int cur = t0 + 16 * i;
+        // ---- S^T = KV . Q^T: rows = the piece's 16 keys, columns = this wave's 16 heads
+        mf4 st = (mf4){0.f, 0.f, 0.f, 0.f};
+        const unsigned char* arow = stage + lane * 16;
+        if (!(p.dbg & 2)) {
+#pragma unroll
+        for (int t = 0; t < 18; ++t) st = mla_mfma32<DT>(*reinterpret_cast<const uint4*>(arow + 1024 * t), qf[t], st);
+        }
+        // ---- online softmax of head r over this lane's 4 keys (+ the 3 other lanes of the head)
+        float sv[4], mloc = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sv[e] = cur + 4 * kq + e < t1 ? st[e] * p.scale : -INFINITY;
+            mloc = fmaxf(mloc, sv[e]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float pr[4], lsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pr[e] = __expf(sv[e] - m_new);
+            lsum += pr[e];
+        }
+        auto cvt = [](float x) -> uint16_t { return ZT<DT>::from_f32(x); };
+        auto hi_lo = [&](float a, float b2, uint32_t& hw, uint32_t& lw) {
+            const uint16_t ah = cvt(a), bh = cvt(b2);
+            hw = (uint32_t)ah | ((uint32_t)bh << 16);
+            lw = (uint32_t)cvt(a - ZT<DT>::to_f32(ah)) | ((uint32_t)cvt(b2 - ZT<DT>::to_f32(bh)) << 16);
+        };
+        uint2 pf, pl;
+        hi_lo(pr[0], pr[1], pf.x, pl.x);
+        hi_lo(pr[2], pr[3], pf.y, pl.y);
+        const bool moved = alpha != 1.0f && l_run > 0.f;
+        l_run = l_run * alpha + lsum;
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+            for (int db = 0; db < 32; ++db) {
+                o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+            }
+        }
+        // ---- O^T += V^T . P^T: rows = output columns 16 db .. + 15, columns = heads, k = the piece's 16 keys.  This lane's four
+        //      values: row rho = 4 kq + (r >> 2), columns 16 db + 4 (r & 3) .. + 3 = half (r & 1) of unit 16 (2 db + ((r & 3) >> 1)) + rho
+        const unsigned char* vtr = stage + (size_t)((((r & 3) >> 1) * 16 + 4 * kq + (r >> 2)) * 16 + (r & 1) * 8);
+        if (!(p.dbg & 1))
+#pragma unroll
+        for (int db = 0; db < 32; ++db) {
+            const ms4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ms4*)(vtr + 512 * db));
+            o[db] = mla_mfma16<DT>(a, pf, o[db]);
+            o[db] = mla_mfma16<DT>(a, pl, o[db]);
+        }
+    }
+    // ---- the records of this wave's 16 heads: lane = (head r, output columns 16 db + 4 kq .. + 3)
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    float* rec = p.ws + (((size_t)b * p.h + wave * 16 + r) * p.max_splits + split) * kRec;
+    if (p.dbg & 8) {
+        if (kq == 0) rec[0] = o[0][0] + o[31][3];
+        return;
+    }
+#pragma unroll
+    for (int db = 0; db < 32; ++db) *reinterpret_cast<mf4*>(rec + 16 * db + 4 * kq) = o[db];
+    if (kq == 0) {
+        rec[kRank] = m_run;
+        rec[kRank + 1] = l_run;
+    }
+}
+
 // grid (H, B), 64 lanes: lane = 8 output columns; the splits that exist are the first ceil(len / split_len)
 template <int DT>
 __global__ __launch_bounds__(64) void k_mla_combine(const MlaParams p) {
@@ -380,6 +540,15 @@ __global__ __launch_bounds__(64) void k_mla_combine(const MlaParams p) {
 inline int mla_split_len(int64_t b, int64_t h, int64_t max_len, int algo) {
     // about one workgroup of (16 heads, split) per CU for the matrix-core kernel (its 129 KB of LDS leave one workgroup per CU; every
     // further split is another record per head for the combine), about 512 for the VALU kernel; splits of 64 keys (one chunk) upward
+    if (algo == 2) {
+        // the wide kernel: one workgroup per (task, split); a split costs a record per head (2 KB), so at most 8 of them -- 256
+        // workgroups from batch 32 on, fewer below (batch 8: 64 workgroups of 128 keys pull 147 KB each)
+        int64_t want = (256 + b - 1) / b;
+        if (want > 8) want = 8;
+        if (want < 1) want = 1;
+        int64_t ls = ((max_len + want - 1) / want + 63) / 64 * 64;
+        return (int)(ls < 64 ? 64 : ls);
+    }
     const int64_t groups = b * ((h + kHG - 1) / kHG), target = algo == 1 ? 512 : 256;
     int64_t want_splits = (target + groups - 1) / groups;
     if (want_splits < 1) want_splits = 1;
@@ -392,12 +561,19 @@ int mla_launch(const MlaParams& p, int dtype, int algo, hipStream_t hs);
 
 }  // namespace
 
+static int zl_mla_dbg = 0;
+extern "C" void zl_debug_mla(int bits) { zl_mla_dbg = bits; }
+
 extern "C" {
 
 int64_t zl_mla_decode_workspace_bytes(int64_t b, int64_t h, int64_t max_len_buf) {
     if (b <= 0 || h <= 0 || max_len_buf <= 0) return ZL_EINVAL;
-    const int ls = mla_split_len(b, h, max_len_buf, 1);                   // (the finer of the two plans: enough for either kernel)
-    const int64_t ms = (max_len_buf + ls - 1) / ls;
+    int64_t ms = 1;                                                       // the finest of the three plans: enough for any kernel
+    for (int algo = 0; algo < 3; ++algo) {
+        const int ls = mla_split_len(b, h, max_len_buf, algo);
+        const int64_t m = (max_len_buf + ls - 1) / ls;
+        if (m > ms) ms = m;
+    }
     return b * h * ms * kRec * 4;
 }
 
@@ -410,7 +586,10 @@ int zl_mla_decode_attn(const uint16_t* q_adj, const int32_t* buf_lens, const int
 int zl_mla_decode_attn_ex(const uint16_t* q_adj, const int32_t* buf_lens, const int32_t* valid_lens, const uint16_t* const* kv_bufs, uint16_t* out,
                           void* workspace, int64_t b, int64_t h, int64_t kv_lora_rank, int64_t rope_dim, float scale, int64_t max_len_buf, int dtype,
                           int algo, zl_stream_t s) {
-    ZL_CHECK_ARG(algo == 0 || algo == 1, ZL_EINVAL);
+    ZL_CHECK_ARG(algo >= 0 && algo <= 3, ZL_EINVAL);                      // 0 pick, 1 VALU, 2 wide, 3 the 16-heads-per-workgroup matrix-core kernel
+    ZL_CHECK_ARG(algo != 2 || h == 128, ZL_ESHAPE);
+    if (algo == 0 && h == 128 && b >= kWideMinBatch && max_len_buf >= kWideMinLen) algo = 2;            // every latent row enters a CU once instead of eight times
+    if (algo == 3) algo = 0;
     ZL_CHECK_ARG(q_adj && buf_lens && kv_bufs && out && workspace && b > 0 && h > 0 && max_len_buf > 0, ZL_EINVAL);
     ZL_CHECK_ARG(kv_lora_rank == kRank && rope_dim == kRope && h % 4 == 0, ZL_ESHAPE);
     ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
@@ -420,7 +599,7 @@ int zl_mla_decode_attn_ex(const uint16_t* q_adj, const int32_t* buf_lens, const 
     p.b = (int)b; p.h = (int)h; p.split_len = mla_split_len(b, h, max_len_buf, algo);
     p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
     p.scale = scale;
-    p.kcache = nullptr; p.block_table = nullptr; p.page = p.max_blocks = 0; p.lse = nullptr;
+    p.kcache = nullptr; p.block_table = nullptr; p.page = p.max_blocks = 0; p.lse = nullptr; p.dbg = zl_mla_dbg;
     return mla_launch(p, dtype, algo, (hipStream_t)s);
 }
 
@@ -434,11 +613,12 @@ int zl_mla_decode_attn_paged(const uint16_t* q_adj, const uint16_t* kcache, cons
     const int64_t max_len = page_block_size * max_blocks_per_seq;
     MlaParams p;
     p.q = q_adj; p.buf_lens = seqlens_k; p.valid_lens = nullptr; p.kv_bufs = nullptr; p.out = out; p.ws = (float*)workspace;
-    p.b = (int)b; p.h = (int)h; p.split_len = mla_split_len(b, h, max_len, 0);
+    const int algo = h == 128 && b >= kWideMinBatch && max_len >= kWideMinLen ? 2 : 0;
+    p.b = (int)b; p.h = (int)h; p.split_len = mla_split_len(b, h, max_len, algo);
     p.max_splits = (int)((max_len + p.split_len - 1) / p.split_len);
     p.scale = scale;
-    p.kcache = kcache; p.block_table = block_table; p.page = (int)page_block_size; p.max_blocks = (int)max_blocks_per_seq; p.lse = softmax_lse;
-    return mla_launch(p, dtype, 0, (hipStream_t)s);
+    p.kcache = kcache; p.block_table = block_table; p.page = (int)page_block_size; p.max_blocks = (int)max_blocks_per_seq; p.lse = softmax_lse; p.dbg = 0;
+    return mla_launch(p, dtype, algo, (hipStream_t)s);
 }
 
 }  // extern "C"
@@ -447,7 +627,13 @@ namespace {
 int mla_launch(const MlaParams& p, int dtype, int algo, hipStream_t hs) {
     const int64_t h = p.h, b = p.b;
     const dim3 grid((unsigned)p.max_splits, (unsigned)((h + kHG - 1) / kHG), (unsigned)b);
-    if (algo == 1) {
+    if (algo == 2) {
+        const void* fn = dtype == ZL_F16 ? reinterpret_cast<const void*>(&k_mla_decode_wide<ZL_F16>) : reinterpret_cast<const void*>(&k_mla_decode_wide<ZL_BF16>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kWLds) != hipSuccess) return ZL_ELIMIT;
+        const dim3 wgrid((unsigned)p.max_splits, (unsigned)b);
+        if (dtype == ZL_F16) hipLaunchKernelGGL(k_mla_decode_wide<ZL_F16>, wgrid, dim3(512), kWLds, hs, p);
+        else hipLaunchKernelGGL(k_mla_decode_wide<ZL_BF16>, wgrid, dim3(512), kWLds, hs, p);
+    } else if (algo == 1) {
         if (dtype == ZL_F16) hipLaunchKernelGGL(k_mla_decode_partial<ZL_F16>, grid, dim3(256), 0, hs, p);
         else hipLaunchKernelGGL(k_mla_decode_partial<ZL_BF16>, grid, dim3(256), 0, hs, p);
     } else {
