@@ -125,3 +125,172 @@ def test_reference_code_reports_what_is_off_the_boundary(ref):
     lin = ref.RefLinear(1024, 256, 8)                     # QuantType::GPTQ_Marlin
     with pytest.raises(Exception):
         lin.forward(np.zeros((1, 1024), np.float16))
+
+
+# ---- the reference's nn::Attention decode path (src/nn/attention/attention.cpp, compiled unmodified) -------------------------------
+def _attn_case(oracle, rng, dm, h, hkv, d, g=128):
+    """weights of one attention layer under the reference's parameter names + their k-major oracle forms"""
+    sd, km = {}, {}
+    for name, (k, n) in {"project_q": (dm, h * d), "project_k": (dm, hkv * d), "project_v": (dm, hkv * d), "attn_out": (h * d, dm)}.items():
+        qw, qz, sc = synth.gptq_hf(rng, k, n, g)
+        km[name] = oracle.gptq_prepare_k_major(qw, qz, sc, g)
+        sd[f"a.{name}.qweight"] = np.ascontiguousarray(qw.view(np.int32))
+        sd[f"a.{name}.qzeros"] = np.ascontiguousarray(qz.view(np.int32))
+        sd[f"a.{name}.scales"] = np.ascontiguousarray(sc.view(np.float16))
+    return sd, km
+
+
+def _rope_neox(oracle, x, pos, d, theta):
+    """rows (n, heads * d) fp16 rotated at positions pos: fp64 arithmetic on the oracle's fp32 tables, one rounding to fp16"""
+    cs, sn = oracle.rope_cos_sin(pos.astype(np.int32), d, theta, True, None)
+    n = x.shape[0]
+    xr = x.astype(np.float64).reshape(n, -1, d)
+    c, s = cs.astype(np.float64)[:, None, :], sn.astype(np.float64)[:, None, :]
+    half = d // 2
+    rot = np.concatenate([-xr[..., half:], xr[..., :half]], axis=-1)
+    return (xr * c + rot * s).astype(np.float16).reshape(n, -1)
+
+
+def _attention_reference(oracle, km, x, pos, hist_k, hist_v, h, hkv, d, theta):
+    """what the layer computes, in fp64 with the layer's roundings to fp16 between the operators; returns (out, new k rows, new v rows)"""
+    f = lambda a: a.astype(np.float64)
+    lin = lambda name, a: oracle.gptq_gemm_k_major_exact(oracle.h2u(a), *km[name]).astype(np.float16)
+    q, k, v = lin("project_q", x), lin("project_k", x), lin("project_v", x)
+    q, k = _rope_neox(oracle, q, pos, d, theta), _rope_neox(oracle, k, pos, d, theta)
+    outs = []
+    for b in range(x.shape[0]):
+        keys = np.concatenate([f(hist_k[b]), f(k[b]).reshape(1, hkv, d)], axis=0)       # (n + 1, hkv, d)
+        vals = np.concatenate([f(hist_v[b]), f(v[b]).reshape(1, hkv, d)], axis=0)
+        qb = f(q[b]).reshape(h, d)
+        o = np.zeros((h, d))
+        for hh in range(h):
+            kv = hh // (h // hkv)
+            sc = keys[:, kv, :] @ qb[hh] / np.sqrt(d)
+            p = np.exp(sc - sc.max())
+            o[hh] = (p / p.sum()) @ vals[:, kv, :]
+        outs.append(o.reshape(-1))
+    att = np.stack(outs).astype(np.float16)
+    return oracle.gptq_gemm_k_major_exact(oracle.h2u(att), *km["attn_out"]), k.reshape(-1, hkv, d), v.reshape(-1, hkv, d)
+
+
+@pytest.mark.parametrize("h,hkv", [(8, 2), (4, 4)])
+def test_reference_attention_decode_step(ref, oracle, h, hkv):
+    """VERDICT r03 item 7: the reference's own NormalImpl::dynamic_batch_forward (attention.cpp:846-964) -> attn_search_rag (:636-741)
+    runs decode steps on the GPU -- the reference's ModelContext / DynBatchContext / RagBufferContext objects, its nn::Linear
+    layers, its control flow; under it the boundary's operators (gptq_gemm_k_major, rotary, copy_to_rag_buffer2,
+    multi_query_attention_rag_buffer / attention_qkv_rag_buffer) and this repository's TransformerBuffer / RotaryEmbedding.  Three
+    tasks with ragged histories and buffer lengths, two steps (the second attends to the row the first one wrote), against an
+    fp64 restatement with the layer's fp16 roundings."""
+    rng = np.random.default_rng(31 + h)
+    dm, d, theta = 1024, 128, 5e5
+    sd, km = _attn_case(oracle, rng, dm, h, hkv, d)
+    ref.weight_cache_clear()
+    layer = ref.RefAttention(dm, h, hkv, d, rope_theta=theta, num_layers=2)
+    layer.load(sd, "a")
+    lens, bufs = [5, 40, 17], [64, 96, 64]
+    hist_k = [(rng.standard_normal((n, hkv, d)) * 0.5).astype(np.float16) for n in lens]
+    hist_v = [(rng.standard_normal((n, hkv, d)) * 0.5).astype(np.float16) for n in lens]
+    for b in range(3):
+        layer.set_history(b, 1, bufs[b], hist_k[b], hist_v[b])
+    pos = np.array(lens, np.int32)
+    for step in range(2):
+        x = synth.act(rng, 3, dm)
+        mask = np.concatenate([(np.arange(bufs[b]) <= pos[b]).astype(np.int8) for b in range(3)])
+        got = layer.decode_step(1, x, pos, pos.copy(), mask).astype(np.float64)
+        want, new_k, new_v = _attention_reference(oracle, km, x, pos, hist_k, hist_v, h, hkv, d, theta)
+        assert got.shape == (3, dm) and np.isfinite(got).all()
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err <= 2e-3, (step, err)
+        for b in range(3):      # the new key / value rows sit at their placement in the reference's buffers, everything else untouched
+            kb, vb = layer.get_k(b, 1), layer.get_v(b, 1)
+            assert kb.shape == (bufs[b], hkv, d)
+            assert np.abs(kb[pos[b]].astype(np.float64) - new_k[b].astype(np.float64)).max() <= 2.0 ** -9 * np.abs(new_k[b].astype(np.float64)).max()
+            assert np.abs(vb[pos[b]].astype(np.float64) - new_v[b].astype(np.float64)).max() <= 2.0 ** -9 * np.abs(new_v[b].astype(np.float64)).max()
+            assert np.array_equal(kb[:lens[b]], hist_k[b][:lens[b]]) and not kb[pos[b] + 1:].any()
+            hist_k[b] = np.concatenate([hist_k[b], kb[pos[b]][None]], axis=0)           # the next step sees what the layer stored
+            hist_v[b] = np.concatenate([hist_v[b], vb[pos[b]][None]], axis=0)
+        pos = pos + 1
+    ref.weight_cache_clear()
+
+
+def test_reference_attention_decode_step_fused_qkv(dev):
+    """The same layer under CPM_FUSE_QKV=1 (the reference reads the switch once per process, hence a child process): Linear::fuse
+    at load, ONE projection, then rope_qk_cache on DynBatchContext::rope_cache (RopePreparer's tables) in the first step and
+    rotary_embedding_qk without them in the second."""
+    import subprocess
+    env = dict(os.environ, CPM_FUSE_QKV="1", ZL_REFATTN_CHILD="1")
+    code = ("import sys, os; sys.path.insert(0, os.path.join(%r, 'tests')); import pytest; "
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', os.path.join(%r, 'tests', 'test_gpu_refcompile.py'), '-k', 'fused_child']))") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(os.environ.get("ZL_REFATTN_CHILD") != "1", reason="runs inside test_reference_attention_decode_step_fused_qkv's child process")
+def test_reference_attention_fused_child(ref, oracle):
+    rng = np.random.default_rng(77)
+    dm, h, hkv, d, theta = 1024, 8, 2, 128, 5e5
+    sd, km = _attn_case(oracle, rng, dm, h, hkv, d)
+    layer = ref.RefAttention(dm, h, hkv, d, rope_theta=theta, num_layers=1)
+    layer.load(sd, "a")
+    lens, bufs = [9, 33], [64, 64]
+    hist_k = [(rng.standard_normal((n, hkv, d)) * 0.5).astype(np.float16) for n in lens]
+    hist_v = [(rng.standard_normal((n, hkv, d)) * 0.5).astype(np.float16) for n in lens]
+    for b in range(2):
+        layer.set_history(b, 0, bufs[b], hist_k[b], hist_v[b])
+    pos = np.array(lens, np.int32)
+    for step in range(2):
+        x = synth.act(rng, 2, dm)
+        mask = np.concatenate([(np.arange(bufs[b]) <= pos[b]).astype(np.int8) for b in range(2)])
+        got = layer.decode_step(0, x, pos, pos.copy(), mask, with_rope_cache=(step == 0)).astype(np.float64)
+        want, _, _ = _attention_reference(oracle, km, x, pos, hist_k, hist_v, h, hkv, d, theta)
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err <= 2e-3, (step, err)
+        for b in range(2):
+            hist_k[b] = np.concatenate([hist_k[b], layer.get_k(b, 0)[pos[b]][None]], axis=0)
+            hist_v[b] = np.concatenate([hist_v[b], layer.get_v(b, 0)[pos[b]][None]], axis=0)
+        pos = pos + 1
+
+
+def test_reference_attention_prompt_chunks_then_decode(ref, oracle):
+    """The ENCODE part of the same function (attn_encode_group, attention.cpp:442-622, flash branch): two prompt chunks of one task
+    -- TransformerBuffer::copy puts the chunk's keys / values into the task's buffer, FlashDecoding::mha_fwd attends causally over
+    everything stored so far -- then a decode step on top of that cache, all through the reference's control flow."""
+    rng = np.random.default_rng(91)
+    dm, h, hkv, d, theta, len_buf = 1024, 8, 2, 128, 5e5, 320
+    sd, km = _attn_case(oracle, rng, dm, h, hkv, d)
+    layer = ref.RefAttention(dm, h, hkv, d, rope_theta=theta, num_layers=1)
+    layer.load(sd, "a")
+    f = lambda a: a.astype(np.float64)
+    lin = lambda name, a: oracle.gptq_gemm_k_major_exact(oracle.h2u(a), *km[name]).astype(np.float16)
+    keys, vals, pos0 = np.zeros((0, hkv, d), np.float16), np.zeros((0, hkv, d), np.float16), 0
+    for n in (200, 56):
+        x = synth.act(rng, n, dm)
+        got = layer.encode(0, 0, len_buf, x, pos0).astype(np.float64)
+        pos = np.arange(pos0, pos0 + n)
+        q = _rope_neox(oracle, lin("project_q", x), pos, d, theta)
+        k = _rope_neox(oracle, lin("project_k", x), pos, d, theta).reshape(n, hkv, d)
+        v = lin("project_v", x).reshape(n, hkv, d)
+        keys, vals = np.concatenate([keys, k]), np.concatenate([vals, v])
+        att = np.zeros((n, h, d))
+        for hh in range(h):
+            kv = hh // (h // hkv)
+            sc = f(q).reshape(n, h, d)[:, hh, :] @ f(keys[:, kv, :]).T / np.sqrt(d)          # (n, pos0 + n)
+            sc = np.where(np.arange(pos0 + n)[None, :] <= pos[:, None], sc, -np.inf)
+            p = np.exp(sc - sc.max(axis=1, keepdims=True))
+            att[:, hh, :] = (p / p.sum(axis=1, keepdims=True)) @ f(vals[:, kv, :])
+        want = oracle.gptq_gemm_k_major_exact(oracle.h2u(att.reshape(n, -1).astype(np.float16)), *km["attn_out"])
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err <= 3e-3, (n, err)
+        stored = layer.get_k(0, 0)
+        assert np.abs(f(stored[pos0:pos0 + n]) - f(k)).max() <= 2.0 ** -9 * np.abs(f(k)).max() and not stored[pos0 + n:].any()
+        pos0 += n
+    # a decode step on top of the 256 stored rows
+    x = synth.act(rng, 1, dm)
+    p1 = np.array([pos0], np.int32)
+    mask = (np.arange(len_buf) <= pos0).astype(np.int8)
+    got = layer.decode_step(0, x, p1, p1.copy(), mask).astype(np.float64)
+    want, _, _ = _attention_reference(oracle, km, x, p1, [layer.get_k(0, 0)[:pos0]], [layer.get_v(0, 0)[:pos0]], h, hkv, d, theta)
+    assert np.abs(got - want).max() / np.abs(want).max() <= 2e-3
+    ref.weight_cache_clear()

@@ -67,10 +67,12 @@ def test_reference_attention_tu_binds_the_decode_hot_path_names():
                  "bmengine::functions::Gemm::forward(", "bmengine::functions::transpose_2_1(", "bmengine::core::Context::get_allocator("):
         assert any(n.startswith(name) for n in v["resolved"]), name
     assert not v["pending"] and not [n for n in v["outside"] if n.startswith(build.REF_CHECK_NAMESPACES)]
-    owners = {n.split("(")[0].rsplit("::", 1)[0] if n.split("(")[0].count("::") > 1 else n.split("(")[0] for n in v["outside"]}
-    assert owners <= {"nn::FlashDecoding", "nn::RotaryEmbedding", "kvcache::TransformerBuffer", "kvcache::copy_to_buffer", "nn::attn_softmax",
-                      "nn::multi_query_self_attention"}, owners
-    assert any(n.startswith("nn::Attention::impl::create_mla_impl(") for n in v["reference"])     # defined by the MLA unit, also checked
+    # round 4: the unit is linked into the executed test module (zl_reflinear: hostcpp/ref_attention_glue.cpp provides the KV buffer
+    # class, RotaryEmbedding, FlashDecoding::mha_fwd over zl_prefill_attn, ModelContext's constructor) -- nothing is left outside,
+    # and tests/test_gpu_refcompile.py RUNS its decode and encode paths
+    assert not v["outside"], v["outside"]
+    for name in ("kvcache::TransformerBuffer::copy(", "nn::RotaryEmbedding::forward(", "nn::FlashDecoding::mha_fwd(", "nn::Attention::impl::create_mla_impl("):
+        assert any(n.startswith(name) for n in v["resolved"]), name
 
 
 def test_reference_block_tu_binds_the_layer_orchestration_names():
@@ -90,8 +92,8 @@ def test_reference_block_tu_binds_the_layer_orchestration_names():
                  "bmengine::core::Context::reserve_cache_alloc(", "bmengine::core::Context::set_current_stream(",
                  "bmengine::functions::BinaryElementwiseOp::forward(", "bmengine::functions::reduce_abs_max("):
         assert any(n.startswith(name) for n in v["resolved"]), name
-    for name in ("nn::Attention::forward(", "nn::FeedForward::forward("):
-        assert any(n.startswith(name) for n in v["reference"]), name
+    assert any(n.startswith("nn::FeedForward::forward(") for n in v["reference"])
+    assert any(n.startswith("nn::Attention::forward(") for n in v["resolved"] + v["reference"])      # (round 4: attention.cpp is in the executed module)
     assert {n.split("(")[0] for n in v["pending"]} <= {"bmengine::functions::pow", "bmengine::functions::clamp"}
     assert {n.split("(")[0].rsplit("::", 1)[0] for n in v["outside"]} <= {"model::ModelContext", "nn::LayerNorm"}
 

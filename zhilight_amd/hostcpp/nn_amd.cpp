@@ -821,10 +821,19 @@ void attention_qkv_rag_buffer(const Context& ctx, const Tensor& batch_q, const T
 }
 
 // ---- rotary / scatter / element-wise -------------------------------------------------------------------------------
+// the reference's call sites (attention.cpp:872-888) hand EMPTY q / k / v tensors to the fused rotary kernels and read them back
+// filled: the callee allocates what it is not given (found by running the reference's dynamic_batch_forward, round 4)
+static void alloc_qkv_outputs(const Context& ctx, size_t s, size_t num_heads, size_t num_kv_heads, size_t dim_head, DataType dtype, Tensor& out_q,
+                              Tensor& out_k, Tensor& out_v) {
+    if (out_q.numel() == 0) out_q = ctx.tensor({s, num_heads * dim_head}, dtype);
+    if (out_k.numel() == 0) out_k = ctx.tensor({s, num_kv_heads * dim_head}, dtype);
+    if (out_v.numel() == 0) out_v = ctx.tensor({s, num_kv_heads * dim_head}, dtype);
+}
 void rotary_embedding_qk(const Context& ctx, const Tensor& pos, const Tensor& in, Tensor& out_q, Tensor& out_k, Tensor& out_v,
                          size_t num_heads, size_t num_kv_heads, size_t dim_head, float rope_theta, DataType dtype) {
     const size_t s = pos.numel();
     BM_ASSERT_EQ(in.numel(), s * (num_heads + 2 * num_kv_heads) * dim_head, "in shape mismatch");
+    alloc_qkv_outputs(ctx, s, num_heads, num_kv_heads, dim_head, dtype, out_q, out_k, out_v);
     zl_check(zl_rotary_embedding_qk(pos.data<int32_t>(), u16(in), u16m(out_q), u16m(out_k), u16m(out_v), s, num_heads, num_kv_heads,
                                     dim_head, rope_theta, zdt(dtype), st_of(ctx)), "rotary_embedding_qk");
 }
@@ -833,6 +842,7 @@ void rope_qk_cache(const Context& ctx, const Tensor& cos, const Tensor& sin, con
     BM_ASSERT(cos.dtype() == DataType::kFloat && sin.dtype() == DataType::kFloat, "cos / sin must be float");
     const size_t s = cos.numel() / dim_head;
     BM_ASSERT_EQ(in.numel(), s * (num_heads + 2 * num_kv_heads) * dim_head, "in shape mismatch");
+    alloc_qkv_outputs(ctx, s, num_heads, num_kv_heads, dim_head, dtype, out_q, out_k, out_v);
     zl_check(zl_rope_qk_cache(cos.data<float>(), sin.data<float>(), u16(in), u16m(out_q), u16m(out_k), u16m(out_v), s, num_heads,
                               num_kv_heads, dim_head, neox_style, zdt(dtype), st_of(ctx)), "rope_qk_cache");
 }

@@ -140,6 +140,8 @@ private:
 
 }  // namespace
 
+void bind_ref_attention(py::module_& m);      // ref_attention_glue.cpp: the reference's nn::Attention decode path
+
 PYBIND11_MODULE(zl_reflinear, m) {
     m.doc() = "the reference's nn::Linear (src/nn/linear/linear.cpp, compiled unmodified) on the MI355X boundary";
     py::class_<RefLinear>(m, "RefLinear")
@@ -150,6 +152,7 @@ PYBIND11_MODULE(zl_reflinear, m) {
         .def("forward", &RefLinear::forward)
         .def("dequant_weight", &RefLinear::dequant_weight)
         .def("layer_type", &RefLinear::layer_type);
+    bind_ref_attention(m);
     m.def("weight_cache_size", &nn::gptq::amd_weight_cache_size);
     m.def("weight_cache_clear", &nn::gptq::amd_weight_cache_clear);
     py::register_exception<BMEngineException>(m, "BMEngineException");
