@@ -294,3 +294,52 @@ def test_reference_attention_prompt_chunks_then_decode(ref, oracle):
     want, _, _ = _attention_reference(oracle, km, x, p1, [layer.get_k(0, 0)[:pos0]], [layer.get_v(0, 0)[:pos0]], h, hkv, d, theta)
     assert np.abs(got - want).max() / np.abs(want).max() <= 2e-3
     ref.weight_cache_clear()
+
+
+def test_reference_encoder_layer_decode_step(ref, oracle):
+    """A whole transformer layer of the reference -- nn::EncoderLayer::forward (src/nn/block/block.cpp:86-143) over its own
+    LayerNorm calls, nn::Attention (attention.cpp), the residual adds and nn::FeedForward (feedforward.cpp), all four units compiled
+    unmodified -- runs decode steps on the GPU for two tasks with ragged caches; against an fp64 restatement with the layer's fp16
+    roundings (norm outputs, projections, attention output, residual sums, gate product)."""
+    rng = np.random.default_rng(123)
+    dm, h, hkv, d, dff, theta, eps = 1024, 8, 2, 128, 2048, 5e5, 1e-5
+    sd_a, km = _attn_case(oracle, rng, dm, h, hkv, d)
+    sd = {k.replace("a.", "l.attn.", 1): v for k, v in sd_a.items()}
+    for name, (k, n) in {"w_in": (dm, dff), "w_gated": (dm, dff), "w_out": (dff, dm)}.items():
+        qw, qz, sc = synth.gptq_hf(rng, k, n, 128)
+        km[name] = oracle.gptq_prepare_k_major(qw, qz, sc, 128)
+        sd[f"l.ff.{name}.qweight"] = np.ascontiguousarray(qw.view(np.int32))
+        sd[f"l.ff.{name}.qzeros"] = np.ascontiguousarray(qz.view(np.int32))
+        sd[f"l.ff.{name}.scales"] = np.ascontiguousarray(sc.view(np.float16))
+    ln_attn = (1.0 + 0.1 * rng.standard_normal(dm)).astype(np.float16)
+    ln_ff = (1.0 + 0.1 * rng.standard_normal(dm)).astype(np.float16)
+    sd["l.ln_attn.weight"], sd["l.ln_ff.weight"] = ln_attn, ln_ff
+    ref.weight_cache_clear()
+    layer = ref.RefEncoderLayer(dm, h, hkv, d, dff, rope_theta=theta, eps=eps)
+    layer.load(sd, "l")
+    lens, bufs = [21, 70], [64, 128]
+    hist_k = [(rng.standard_normal((n, hkv, d)) * 0.5).astype(np.float16) for n in lens]
+    hist_v = [(rng.standard_normal((n, hkv, d)) * 0.5).astype(np.float16) for n in lens]
+    for b in range(2):
+        layer.set_history(b, bufs[b], hist_k[b], hist_v[b])
+    pos = np.array(lens, np.int32)
+    f = lambda a: a.astype(np.float64)
+    lin = lambda name, a: oracle.gptq_gemm_k_major_exact(oracle.h2u(a), *km[name]).astype(np.float16)
+    norm = lambda a, w: oracle.u2h(oracle.rmsnorm(oracle.h2u(a), oracle.h2u(w), eps))
+    for step in range(2):
+        x = synth.act(rng, 2, dm, 2.0)
+        mask = np.concatenate([(np.arange(bufs[b]) <= pos[b]).astype(np.int8) for b in range(2)])
+        got = layer.decode_step(x, pos, pos.copy(), mask).astype(np.float64)
+        att, _, _ = _attention_reference(oracle, km, norm(x, ln_attn), pos, hist_k, hist_v, h, hkv, d, theta)
+        h1 = (f(x) + f(att.astype(np.float16))).astype(np.float16)
+        xn = norm(h1, ln_ff)
+        g, u = f(lin("w_in", xn)), f(lin("w_gated", xn))
+        act = ((g / (1.0 + np.exp(-g))).astype(np.float16).astype(np.float64) * u).astype(np.float16) if False else (g / (1.0 + np.exp(-g)) * u).astype(np.float16)
+        want = f(h1) + f(lin("w_out", act))
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert got.shape == (2, dm) and np.isfinite(got).all() and err <= 3e-3, (step, err)
+        for b in range(2):
+            hist_k[b] = np.concatenate([hist_k[b], layer.get_k(b)[pos[b]][None]], axis=0)
+            hist_v[b] = np.concatenate([hist_v[b], layer.get_v(b)[pos[b]][None]], axis=0)
+        pos = pos + 1
+    ref.weight_cache_clear()

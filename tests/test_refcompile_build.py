@@ -92,10 +92,12 @@ def test_reference_block_tu_binds_the_layer_orchestration_names():
                  "bmengine::core::Context::reserve_cache_alloc(", "bmengine::core::Context::set_current_stream(",
                  "bmengine::functions::BinaryElementwiseOp::forward(", "bmengine::functions::reduce_abs_max("):
         assert any(n.startswith(name) for n in v["resolved"]), name
-    assert any(n.startswith("nn::FeedForward::forward(") for n in v["reference"])
-    assert any(n.startswith("nn::Attention::forward(") for n in v["resolved"] + v["reference"])      # (round 4: attention.cpp is in the executed module)
+    # round 4: block.cpp, feedforward.cpp and attention.cpp are all in the executed module (tests/test_gpu_refcompile.py runs
+    # EncoderLayer::forward): the reference's own classes resolve against each other's units
+    for name in ("nn::FeedForward::forward(", "nn::Attention::forward("):
+        assert any(n.startswith(name) for n in v["resolved"] + v["reference"]), name
     assert {n.split("(")[0] for n in v["pending"]} <= {"bmengine::functions::pow", "bmengine::functions::clamp"}
-    assert {n.split("(")[0].rsplit("::", 1)[0] for n in v["outside"]} <= {"model::ModelContext", "nn::LayerNorm"}
+    assert not v["outside"], v["outside"]     # (round 3: four ModelContext members and two of LayerNorm; hostcpp/ref_block_glue.cpp provides them)
 
 
 def test_reference_feedforward_tu_binds_the_router_dispatch_and_fp8_names():

@@ -884,6 +884,10 @@ Tensor gate_fuse(const Context& ctx, const Tensor& input, const std::string& act
 }
 
 // ---- RMSNorm -------------------------------------------------------------------------------------------------------
+// (a module that links the REFERENCE's units which hold nn::LayerNorm members by value -- block.cpp, attention.cpp -- must see the
+//  reference's class layout (a core::Layer with a pimpl), not this one: it provides its own definitions and compiles this file
+//  with -DZL_REF_LAYERNORM_EXTERNAL, hostcpp/ref_block_glue.cpp)
+#ifndef ZL_REF_LAYERNORM_EXTERNAL
 LayerNorm::LayerNorm(const Context&, int dim_model, bool, float eps, float scale, DataType dtype, int)
     : dim_model_(dim_model), eps_(eps), scale_(scale), dtype_(dtype) {}
 void LayerNorm::load_state_dict(const Context& ctx, const std::map<std::string, const Tensor>& state_dict, const std::string& prefix,
@@ -914,6 +918,7 @@ void LayerNorm::inplace(const Context& ctx, Tensor& x) {
     zl_check(zl_rmsnorm(u16(x), u16(weight_), u16m(x), rows_of(x), dim_model_, eps_, scale_, nullptr, nullptr, zdt(x.dtype()),
                         st_of(ctx)), "LayerNorm::inplace");
 }
+#endif  // ZL_REF_LAYERNORM_EXTERNAL
 
 }  // namespace nn
 

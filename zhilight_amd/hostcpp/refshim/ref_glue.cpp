@@ -140,7 +140,8 @@ private:
 
 }  // namespace
 
-void bind_ref_attention(py::module_& m);      // ref_attention_glue.cpp: the reference's nn::Attention decode path
+void bind_ref_attention(py::module_& m);      // hostcpp/ref_attention_glue.cpp: the reference's nn::Attention decode / encode paths
+void bind_ref_block(py::module_& m);          // hostcpp/ref_block_glue.cpp: the reference's nn::EncoderLayer
 
 PYBIND11_MODULE(zl_reflinear, m) {
     m.doc() = "the reference's nn::Linear (src/nn/linear/linear.cpp, compiled unmodified) on the MI355X boundary";
@@ -153,6 +154,7 @@ PYBIND11_MODULE(zl_reflinear, m) {
         .def("dequant_weight", &RefLinear::dequant_weight)
         .def("layer_type", &RefLinear::layer_type);
     bind_ref_attention(m);
+    bind_ref_block(m);
     m.def("weight_cache_size", &nn::gptq::amd_weight_cache_size);
     m.def("weight_cache_clear", &nn::gptq::amd_weight_cache_clear);
     py::register_exception<BMEngineException>(m, "BMEngineException");
