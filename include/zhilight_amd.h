@@ -322,6 +322,17 @@ int zl_rotary_embedding_qk(const int32_t* pos, const uint16_t* in, uint16_t* q, 
 int zl_rope_qk_cache(const float* cosv, const float* sinv, const uint16_t* in, uint16_t* q, uint16_t* k,
                      uint16_t* v, int64_t s_len, int64_t h, int64_t hkv, int64_t d, int neox, int dtype,
                      zl_stream_t s);
+/* RotaryEmbedding::rotate / rotate_inplace (src/nn/position/rotary_embedding.h:20-31) on a STRIDED operand: x viewed as
+ * (n, heads, d) with element strides (x_stride_n, x_stride_h, 1), rotated by the rows' cached cos / sin (n, d) into out
+ * (out_stride_n, out_stride_h, 1); out == x allowed.  MLAImpl rotates the 64 rope dimensions inside q's 192-wide heads and
+ * inside the fused qkv_a projection this way (multi_head_latent_attention.cpp:527, 540-541, 586-600).  Same fp32 expression and
+ * single rounding as zl_rope_qk_cache. */
+int zl_rope_rotate(const float* cosv, const float* sinv, const uint16_t* x, uint16_t* out, int64_t n, int64_t heads, int64_t d,
+                   int64_t x_stride_n, int64_t x_stride_h, int64_t out_stride_n, int64_t out_stride_h, int neox, int dtype, zl_stream_t s);
+/* valid_lens[b] = 1 + the last visible key of task b's last query row in the concatenated int8 visibility mask the reference hands
+ * its search kernels (DynBatchContext::s_mask: task b = len_q rows of buf_lens[b] entries): the bridge from that mask to the
+ * prefix-visibility kernels (zl_mla_decode_attn, zl_decode_attn's valid_lens). */
+int zl_mask_valid_lens(const int8_t* mask, const int32_t* buf_lens, int32_t* valid_lens, int64_t b, int64_t len_q, zl_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * a14  Scatter new K/V rows into the per-task ragged buffers.

@@ -343,3 +343,76 @@ def test_reference_encoder_layer_decode_step(ref, oracle):
             hist_v[b] = np.concatenate([hist_v[b], layer.get_v(b)[pos[b]][None]], axis=0)
         pos = pos + 1
     ref.weight_cache_clear()
+
+
+def test_reference_mla_layer_latent_cache_decode(dev):
+    """The reference's MLA attention layer (MLAImpl, src/nn/attention/multi_head_latent_attention.cpp, compiled unmodified) with the
+    compressed cache: LATENT_CACHE=1 FUSE_ATTN_SEARCH=1, both read once per process, hence a child process."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LATENT_CACHE="1", FUSE_ATTN_SEARCH="1", ZL_REFMLA_CHILD="1")
+    code = ("import sys, os; sys.path.insert(0, os.path.join(%r, 'tests')); import pytest; "
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', os.path.join(%r, 'tests', 'test_gpu_refcompile.py'), '-k', 'mla_child']))") % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(os.environ.get("ZL_REFMLA_CHILD") != "1", reason="runs inside test_reference_mla_layer_latent_cache_decode's child process")
+def test_reference_mla_child(ref, oracle):
+    """MLAImpl::forward_compressed_cache (:603-655) -> search_compressed_cache (:1006-1094) for two decode tasks: the fused q_a | kv_a |
+    k_pe projection (Linear::fuse at load), the two RMSNorms, rope on the 64 rope dimensions (strided slices), the latent row
+    written into the task's compressed cache (copy_to_rag_buffer, one 576-wide "head"), q up-projection, the ABSORBED key projection
+    (batched Gemm with W_UK split from kv_b_proj at load), multi_query_attention_rag_buffer over the latent cache (= zl_mla_decode_attn
+    behind the reference's call), the absorbed value projection and o_proj -- all in the reference's control flow; against an fp64
+    restatement with the flow's fp16 roundings."""
+    rng = np.random.default_rng(2024)
+    dm, H, ql, kvl, nope, rp, vd, theta, eps = 1024, 16, 384, 512, 128, 64, 128, 1e4, 1e-5
+    w = lambda n, k, s=1.0: (rng.standard_normal((n, k)) * s / np.sqrt(k)).astype(np.float16)
+    W = {"q_a_proj": w(ql, dm), "q_b_proj": w(H * (nope + rp), ql), "kv_a_proj_with_mqa": w(kvl + rp, dm), "kv_b_proj": w(H * (nope + vd), kvl),
+         "attn_out": w(dm, H * vd)}
+    ln_q = (1.0 + 0.1 * rng.standard_normal(ql)).astype(np.float16)
+    ln_kv = (1.0 + 0.1 * rng.standard_normal(kvl)).astype(np.float16)
+    sd = {f"a.{k}.weight": v for k, v in W.items()}
+    sd["a.q_a_layernorm.weight"], sd["a.kv_a_layernorm.weight"] = ln_q, ln_kv
+    layer = ref.RefAttention(dm, H, H, nope + rp, rope_theta=theta, model_type="deepseek_v2", quant_type=0, num_layers=1, mla=[ql, kvl, nope, rp, vd])
+    assert layer.latent_cache()
+    layer.load(sd, "a")
+    lens, bufs = [37, 150], [64, 192]
+    hist = [(rng.standard_normal((n, 1, kvl + rp)) * 0.5).astype(np.float16) for n in lens]
+    for b in range(2):
+        layer.set_history(b, 0, bufs[b], hist[b], hist[b])
+    f = lambda a: a.astype(np.float64)
+    h16 = lambda a: a.astype(np.float16)
+    lin = lambda a, name: h16(f(a) @ f(W[name]).T)
+    norm = lambda a, g: oracle.u2h(oracle.rmsnorm(oracle.h2u(np.ascontiguousarray(a)), oracle.h2u(g), eps))
+    wkv = f(W["kv_b_proj"]).reshape(H, nope + vd, kvl)
+    w_uk, w_uv = wkv[:, :nope, :], wkv[:, nope:, :]
+    pos = np.array(lens, np.int32)
+    for step in range(2):
+        x = synth.act(rng, 2, dm)
+        mask = np.concatenate([(np.arange(bufs[b]) <= pos[b]).astype(np.int8) for b in range(2)])
+        got = layer.decode_step(0, x, pos, pos.copy(), mask).astype(np.float64)
+        qa, kva = lin(x, "q_a_proj"), lin(x, "kv_a_proj_with_mqa")
+        qa_n, kv_n = norm(qa, ln_q), norm(kva[:, :kvl], ln_kv)
+        k_pe = _rope_neox(oracle, np.ascontiguousarray(kva[:, kvl:]), pos, rp, theta)
+        row = np.concatenate([kv_n, k_pe], axis=1)                                       # the latent rows (2, 576)
+        q = lin(qa_n, "q_b_proj").reshape(2, H, nope + rp)
+        q_pe = _rope_neox(oracle, np.ascontiguousarray(q[:, :, nope:]).reshape(2, H * rp), pos, rp, theta).reshape(2, H, rp)
+        q_adj_nope = h16(np.einsum("bhn,hnk->bhk", f(q[:, :, :nope]), w_uk))
+        q_adj = np.concatenate([q_adj_nope, q_pe], axis=2)                               # (2, H, 576)
+        outs = []
+        for b in range(2):
+            rows = np.concatenate([f(hist[b][:, 0, :]), f(row[b])[None]], axis=0)       # (n + 1, 576)
+            sc = f(q_adj[b]) @ rows.T / np.sqrt(nope + rp)
+            p = np.exp(sc - sc.max(axis=1, keepdims=True))
+            v_attn = h16((p / p.sum(axis=1, keepdims=True)) @ rows[:, :kvl])            # (H, 512)
+            outs.append(h16(np.einsum("hk,hvk->hv", f(v_attn), w_uv)).reshape(-1))
+            stored = layer.get_k(b, 0)
+            assert stored.shape == (bufs[b], 1, kvl + rp)
+            assert np.abs(f(stored[pos[b], 0]) - f(row[b])).max() <= 2.0 ** -8 * np.abs(f(row[b])).max()      # the latent row reached the cache
+            hist[b] = np.concatenate([hist[b], stored[pos[b]][None]], axis=0)
+        want = f(lin(np.stack(outs), "attn_out"))
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert got.shape == (2, dm) and np.isfinite(got).all() and err <= 4e-3, (step, err)
+        pos = pos + 1

@@ -114,7 +114,8 @@ REFERENCE = os.environ.get("ZL_REFERENCE_ROOT", "/root/reference")
 REFDIR = os.path.join(HERE, "_ref")
 # reference host translation units compiled UNMODIFIED, from where they lie, against hostcpp/refshim + the bmengine-on-HIP
 # headers ("prove the boundary compiles the reference")
-REF_TUS = ("src/nn/linear/linear.cpp", "src/nn/attention/attention.cpp", "src/nn/feedforward/feedforward.cpp", "src/nn/block/block.cpp")
+REF_TUS = ("src/nn/linear/linear.cpp", "src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp",
+           "src/nn/feedforward/feedforward.cpp", "src/nn/block/block.cpp")
 # reference translation units that are compiled unmodified and LINK-CHECKED only (build_refcheck): every name they reference in the
 # namespaces the boundary stands in for must be defined by the boundary under the same mangled name -- i.e. with the reference's
 # exact signature; names of layers that are not on the path (their device code lives in the reference's .cu files) are listed

@@ -191,6 +191,50 @@ __global__ void k_rope_qk(const int32_t* __restrict__ pos, const float* __restri
     dst[col] = ZT<DT>::from_f32(r);
 }
 
+// Rotation of the heads of a STRIDED tensor: x viewed as (n, heads, d) with element strides (x_sn, x_sh, 1) -> out (o_sn, o_sh, 1),
+// cached cos / sin of the rows (n, d); in place allowed (every thread reads its pair before anyone writes).  grid (n, heads), block d.
+// RotaryEmbedding::rotate / rotate_inplace on last-dimension slices (MLAImpl: the 64 rope dimensions inside q's 192 and inside the
+// fused qkv_a output, multi_head_latent_attention.cpp:527, 540-541, 586-600); same fp32 expression per element as the fused kernels.
+template <int DT>
+__global__ void k_rope_heads(const float* __restrict__ cosv, const float* __restrict__ sinv, const uint16_t* x, uint16_t* out, int d,
+                             int64_t x_sn, int64_t x_sh, int64_t o_sn, int64_t o_sh, int neox) {
+    const int t = blockIdx.x, head = blockIdx.y, col = threadIdx.x, half = d / 2;
+    const uint16_t* src = x + (int64_t)t * x_sn + (int64_t)head * x_sh;
+    float r = 0.f;
+    if (col < d) {
+        const float c = cosv[(size_t)t * d + col], s = sinv[(size_t)t * d + col];
+        const float a = ZT<DT>::to_f32(src[col]);
+        if (neox)
+            r = col < half ? rope_val(a, ZT<DT>::to_f32(src[col + half]), c, s, true) : rope_val(a, ZT<DT>::to_f32(src[col - half]), c, s, false);
+        else
+            r = (col & 1) == 0 ? rope_val(a, ZT<DT>::to_f32(src[col + 1]), c, s, true) : rope_val(a, ZT<DT>::to_f32(src[col - 1]), c, s, false);
+    }
+    __syncthreads();
+    if (col < d) out[(int64_t)t * o_sn + (int64_t)head * o_sh + col] = ZT<DT>::from_f32(r);
+}
+
+// valid_lens[b] = 1 + the last visible key of task b's LAST query row in a concatenated int8 visibility mask (task b: len_q rows of
+// buf_lens[b] entries): what a prefix-visibility kernel needs where the caller only has the mask (the MLA search over the latent
+// cache is handed DynBatchContext::s_mask, multi_head_latent_attention.cpp:1053-1069).  grid B, block 256.
+__global__ __launch_bounds__(256) void k_mask_valid_lens(const int8_t* __restrict__ mask, const int32_t* __restrict__ buf_lens, int32_t* __restrict__ out,
+                                                         int len_q) {
+    __shared__ int red[256];
+    const int b = blockIdx.x;
+    int64_t off = 0;
+    for (int i = 0; i < b; ++i) off += (int64_t)len_q * buf_lens[i];
+    const int len_buf = buf_lens[b];
+    const int8_t* row = mask + off + (int64_t)(len_q - 1) * len_buf;
+    int last = 0;
+    for (int j = threadIdx.x; j < len_buf; j += 256) if (row[j]) last = j + 1;
+    red[threadIdx.x] = last;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[b] = red[0];
+}
+
 // Prompt-sized rope_qk_cache: grid S, block 256; a thread rotates 8 consecutive head-dim elements per trip (16-byte
 // accesses; the element-per-thread kernel above spent 15.8 us on a 1024-token chunk, 2-byte accesses).  Same fp32
 // expression per element (rope_val), so the outputs are bit-identical.
@@ -504,6 +548,23 @@ int zl_rope_qk_cache(const float* cosv, const float* sinv, const uint16_t* in, u
     ZL_DT_SWITCH(dtype,
         hipLaunchKernelGGL((k_rope_qk<ZL_F16, 1>), grid, dim3((unsigned)d), 0, (hipStream_t)s, nullptr, cosv, sinv, in, q, k, v, (int)h, (int)hkv, (int)d, 0.f, neox),
         hipLaunchKernelGGL((k_rope_qk<ZL_BF16, 1>), grid, dim3((unsigned)d), 0, (hipStream_t)s, nullptr, cosv, sinv, in, q, k, v, (int)h, (int)hkv, (int)d, 0.f, neox))
+    return zl_launch_status();
+}
+
+int zl_rope_rotate(const float* cosv, const float* sinv, const uint16_t* x, uint16_t* out, int64_t n, int64_t heads, int64_t d, int64_t x_stride_n,
+                   int64_t x_stride_h, int64_t out_stride_n, int64_t out_stride_h, int neox, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(cosv && sinv && x && out && n > 0 && heads > 0 && d > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(d <= 1024 && d % 2 == 0 && heads <= 65535 && x_stride_h >= d && out_stride_h >= d, ZL_ESHAPE);
+    dim3 grid((unsigned)n, (unsigned)heads);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_rope_heads<ZL_F16>, grid, dim3((unsigned)d), 0, (hipStream_t)s, cosv, sinv, x, out, (int)d, x_stride_n, x_stride_h, out_stride_n, out_stride_h, neox),
+        hipLaunchKernelGGL(k_rope_heads<ZL_BF16>, grid, dim3((unsigned)d), 0, (hipStream_t)s, cosv, sinv, x, out, (int)d, x_stride_n, x_stride_h, out_stride_n, out_stride_h, neox))
+    return zl_launch_status();
+}
+
+int zl_mask_valid_lens(const int8_t* mask, const int32_t* buf_lens, int32_t* valid_lens, int64_t b, int64_t len_q, zl_stream_t s) {
+    ZL_CHECK_ARG(mask && buf_lens && valid_lens && b > 0 && len_q > 0, ZL_EINVAL);
+    hipLaunchKernelGGL(k_mask_valid_lens, dim3((unsigned)b), dim3(256), 0, (hipStream_t)s, mask, buf_lens, valid_lens, (int)len_q);
     return zl_launch_status();
 }
 

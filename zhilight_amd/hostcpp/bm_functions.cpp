@@ -65,7 +65,11 @@ void Gemm::set_A_scale(const Tensor& s) { pimpl->a_scale = s.data(); }
 void Gemm::set_B_scale(const Tensor& s) { pimpl->b_scale = s.data(); }
 
 Tensor Gemm::forward(const Context& ctx, const Tensor& A0, const Tensor& B0, Tensor* output, const Tensor* bias) {
-    BM_ASSERT(A0.ndim() >= 2 && B0.ndim() == 2, "Gemm: A (..., M, K) x B 2-d (a batched B goes through batch_3d)");
+    // (batch, M, K) x (batch, ., .): the reference's forward is cublasGemmStridedBatched for these (gemm.cpp:505-542; MLAImpl's absorbed
+    // projections call it that way, multi_head_latent_attention.cpp:1033, 1087-1091) -- one product per batch entry here
+    if (A0.ndim() == 3 && B0.ndim() == 3 && !bias && A0.size(0) == B0.size(0) && A0.is_continuous() && B0.is_continuous())
+        return batch_3d(ctx, A0, B0, output);
+    BM_ASSERT(A0.ndim() >= 2 && B0.ndim() == 2, "Gemm: A (..., M, K) x B 2-d, or two dense 3-d operands with equal batch");
     BM_ASSERT_EQ(A0.dtype(), pimpl->dtype, "Gemm: A dtype");
     BM_ASSERT_EQ(B0.dtype(), pimpl->dtype, "Gemm: B dtype");
     Transpose tr(ctx);
@@ -109,12 +113,12 @@ Tensor Gemm::forward(const Context& ctx, const Tensor& A0, const Tensor& B0, Ten
 Tensor Gemm::batch_3d(const Context& ctx, const Tensor& A, const Tensor& B, Tensor* output) {
     BM_ASSERT(A.ndim() == 3 && B.ndim() == 3 && A.size(0) == B.size(0), "batch_3d: (B, M, K) x (B, N, K) or (B, K, N)");
     const size_t m = pimpl->transA ? A.size(2) : A.size(1), n = pimpl->transB ? B.size(1) : B.size(2);
-    Tensor out = output ? *output : ctx.tensor({A.size(0), m, n}, pimpl->out_type);
+    Tensor out = output ? output->view({A.size(0), m, n}) : ctx.tensor({A.size(0), m, n}, pimpl->out_type);
     for (size_t b = 0; b < A.size(0); ++b) {
         Tensor o = out.index_dim0(b);
         forward(ctx, A.index_dim0(b), B.index_dim0(b), &o, nullptr);
     }
-    return out;
+    return output ? *output : out;
 }
 
 // ---- Transpose ---------------------------------------------------------------------------------------------------------

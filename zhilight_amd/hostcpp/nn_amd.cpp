@@ -791,6 +791,23 @@ void multi_query_attention_rag_buffer(const Context& ctx, const Tensor& batch_q,
     BM_ASSERT(m_query > 0 && h % m_query == 0, "num_heads must be a multiple of m_query");
     BM_ASSERT_EQ((int64_t)buf_lens.numel(), b, "buf_lens size mismatch");
     BM_ASSERT_EQ((int64_t)key_buf_addrs.numel(), b, "key_buf_addrs size mismatch");
+    // MLA over the latent cache (MLAImpl::search_compressed_cache under FUSE_ATTN_SEARCH, multi_head_latent_attention.cpp:1053-1069):
+    // every head attends to the same 576-value rows -- as keys whole, as values their first 512 -- with the absorbed query; the key and
+    // value tables are the SAME table and the output is 512 wide.  That is zl_mla_decode_attn; the visibility mask of a decode row is
+    // a prefix, which zl_mask_valid_lens turns into the lengths that kernel takes.
+    if (d == 576 && output.size(-1) == 512 && m_query == h && key_buf_addrs.data() == val_buf_addrs.data() && !scale_key_addrs.numel()) {
+        BM_ASSERT(len_q == 1, "MLA search over the latent cache: one query row per task");
+        BM_ASSERT(mask.numel(), "mask is required (int8, concatenated per task)");
+        Tensor valid = ctx.tensor({(size_t)b}, DataType::kInt32);
+        zl_check(zl_mask_valid_lens(mask.data<const int8_t>(), buf_lens.data<int32_t>(), valid.data<int32_t>(), b, len_q, st_of(ctx)), "mask_valid_lens");
+        const int64_t wbytes = zl_mla_decode_workspace_bytes(b, h, max_len_buf);
+        BM_ASSERT(wbytes > 0, "mla workspace");
+        Tensor wsp = ctx.tensor({(size_t)wbytes}, DataType::kInt8);
+        zl_check(zl_mla_decode_attn(u16(batch_q), buf_lens.data<int32_t>(), valid.data<int32_t>(), key_buf_addrs.data<const uint16_t* const>(), u16m(output),
+                                    wsp.data(), b, h, 512, 64, scale, max_len_buf, zdt(batch_q.dtype()), st_of(ctx)),
+                 "multi_query_attention_rag_buffer (MLA latent cache)");
+        return;
+    }
     BM_ASSERT_EQ(output.numel(), batch_q.numel(), "output shape mismatch");
     AttentionWorkspace local = ws.cache.numel() ? ws : get_mqa_workspace(ctx, batch_q, max_len_buf, scale_key_addrs.numel() > 0);
     const int8_t* mptr = mask.numel() ? mask.data<const int8_t>() : nullptr;
@@ -853,6 +870,14 @@ void copy_to_rag_buffer2(const Context& ctx, const Tensor& placement, const Tens
     zl_check(zl_copy_to_rag_buffer2(placement.data<int32_t>(), buf_lens.data<int32_t>(), u16(k_src), u16(v_src),
                                     buf_k_addr->data<uint16_t* const>(), buf_v_addr->data<uint16_t* const>(), k_src.size(0), k_src.size(1),
                                     k_src.size(2), k_src.size(3), ctx.is_BSHD(), st_of(ctx)), "copy_to_rag_buffer2");
+}
+// the one-tensor form (ragged_buffer_kernel.h:20-26): MLAImpl writes the 576-wide latent rows of its compressed cache with it, as a
+// fake single head (multi_head_latent_attention.cpp:812-831) -- the two-tensor kernel with the same source and table twice
+void copy_to_rag_buffer(const Context& ctx, const Tensor& src, const Tensor& placement, const Tensor& buf_lens, const Tensor& buf_addr) {
+    BM_ASSERT_EQ(src.ndim(), 4, "src is not (batch, len_q, num_kv_heads, dim_head)");
+    zl_check(zl_copy_to_rag_buffer2(placement.data<int32_t>(), buf_lens.data<int32_t>(), u16(src), u16(src), buf_addr.data<uint16_t* const>(),
+                                    buf_addr.data<uint16_t* const>(), src.size(0), src.size(1), src.size(2), src.size(3), ctx.is_BSHD(), st_of(ctx)),
+             "copy_to_rag_buffer");
 }
 void element_add_scale_out(const Context& ctx, const Tensor& a, const Tensor& b, Tensor& c, float scale, bool scale_residual) {
     BM_ASSERT_EQ(a.numel(), b.numel(), "shape mismatch");

@@ -152,8 +152,8 @@ public:
     bool llama3() const { return cfg.rope_cfg.type == "llama3"; }
     bool plain() const { return cfg.rope_cfg.type.empty() || cfg.rope_cfg.type == "default" || cfg.rope_cfg.type == "rope"; }
     // cos / sin (n, dim_head) fp32 of the rows' positions
-    void tables(const core::Context& ctx, const core::Tensor& pos, core::Tensor* cs, core::Tensor* sn) const {
-        const size_t n = pos.numel(), d = cfg.dim_head;
+    void tables(const core::Context& ctx, const core::Tensor& pos, size_t d, core::Tensor* cs, core::Tensor* sn) const {
+        const size_t n = pos.numel();
         BM_ASSERT(pos.dtype() == DataType::kInt32, "positions are int32");
         *cs = ctx.tensor({n, d}, DataType::kFloat);
         *sn = ctx.tensor({n, d}, DataType::kFloat);
@@ -168,22 +168,32 @@ public:
         else
             ZL_OFF_PATH("RotaryEmbedding with rope type '" + cfg.rope_cfg.type + "'");
     }
-    // rotate the heads of x (n, heads * dim_head): rope_qk_cache with x standing in for q and a one-head zero block for k / v
+    // rotate the heads of x at the rows' positions.  x: (n, heads * d) or (n, heads, d), possibly a last-dimension SLICE of a wider
+    // tensor (MLAImpl rotates the 64 rope dimensions inside 192-wide heads, and a 64-wide slice of the fused qkv_a output): the
+    // rotation width d is the operand's own head width there (qk_rope_head_dim), strides come from the tensor
     core::Tensor rotate(const core::Context& ctx, const core::Tensor& pos, const core::Tensor& x, core::Tensor* output) const {
-        const size_t n = x.numel() / x.size(-1), w = x.size(-1), d = cfg.dim_head;
-        BM_ASSERT(w % d == 0 && pos.numel() == n, "RotaryEmbedding: shape mismatch");
-        const size_t heads = w / d, esz = core::get_elem_size(x.dtype());
+        const size_t n = pos.numel();
+        BM_ASSERT(x.ndim() == 2 || x.ndim() == 3, "RotaryEmbedding: (n, heads * d) or (n, heads, d)");
+        BM_ASSERT_EQ(x.size(0), n, "RotaryEmbedding: rows != positions");
+        const size_t d = cfg.qk_rope_head_dim > 0 ? (size_t)cfg.qk_rope_head_dim : (size_t)cfg.dim_head;
+        size_t heads, x_sh;
+        if (x.ndim() == 3) {
+            BM_ASSERT(x.size(2) == d && x.stride(2) == 1, "RotaryEmbedding: head width");
+            heads = x.size(1);
+            x_sh = x.stride(1);
+        } else {
+            BM_ASSERT(x.size(1) % d == 0 && x.stride(1) == 1, "RotaryEmbedding: row width");
+            heads = x.size(1) / d;
+            x_sh = d;
+        }
         core::Tensor cs, sn;
-        tables(ctx, pos, &cs, &sn);
-        hipStream_t st = ctx.current_cuda_stream();
-        core::Tensor in = ctx.tensor({n, (heads + 2) * d}, x.dtype());
-        BM_CUDART_ASSERT(hipMemsetAsync(in.data(), 0, in.nbytes(), st));
-        BM_CUDART_ASSERT(hipMemcpy2DAsync(in.data(), (heads + 2) * d * esz, x.data(), w * esz, w * esz, n, hipMemcpyDeviceToDevice, st));
+        tables(ctx, pos, d, &cs, &sn);
         core::Tensor out = output ? *output : ctx.tensor(x.shape(), x.dtype());
-        core::Tensor k = ctx.tensor({n, d}, x.dtype()), v = ctx.tensor({n, d}, x.dtype());
-        ZL_CK(zl_rope_qk_cache(cs.data<float>(), sn.data<float>(), in.data<uint16_t>(), out.data<uint16_t>(), k.data<uint16_t>(), v.data<uint16_t>(),
-                               n, heads, 1, d, cfg.rope_cfg.neox_style ? 1 : 0, x.dtype() == DataType::kHalf ? ZL_F16 : ZL_BF16, (zl_stream_t)st),
-              "rope_qk_cache");
+        BM_ASSERT(out.numel() == x.numel() && out.stride(-1) == 1, "RotaryEmbedding: output shape");
+        const size_t o_sh = out.ndim() == 3 ? out.stride(1) : d;
+        ZL_CK(zl_rope_rotate(cs.data<float>(), sn.data<float>(), x.data<uint16_t>(), out.data<uint16_t>(), n, heads, d, x.stride(0), x_sh, out.stride(0), o_sh,
+                             cfg.rope_cfg.neox_style ? 1 : 0, x.dtype() == DataType::kHalf ? ZL_F16 : ZL_BF16, (zl_stream_t)ctx.current_cuda_stream()),
+              "rope_rotate");
         return out;
     }
 };
@@ -199,6 +209,7 @@ std::tuple<core::Tensor, core::Tensor> RotaryEmbedding::forward(const core::Cont
 core::Tensor RotaryEmbedding::rotate(const core::Context& ctx, const core::Tensor& pos, const core::Tensor& q, core::Tensor* output) {
     return pimpl->rotate(ctx, pos, q, output);
 }
+void RotaryEmbedding::rotate_inplace(const core::Context& ctx, const core::Tensor& pos, core::Tensor& q) { pimpl->rotate(ctx, pos, q, &q); }
 
 // ---- 4. off-path names ------------------------------------------------------------------------------------------------------
 FlashDecoding::FlashDecoding(const Context&) {}
@@ -234,9 +245,6 @@ void attn_softmax(const core::Context&, float, const core::Tensor&, const core::
 void multi_query_self_attention(const core::Context&, const core::Tensor&, const core::Tensor&, const core::Tensor&, const core::Tensor&, float, core::Tensor&, int) {
     ZL_OFF_PATH("nn::multi_query_self_attention (prompt encode without flash attention)");
 }
-Attention::impl* Attention::impl::create_mla_impl(const core::Context&, const model::ModelConfig&, model::QuantConfig) {
-    ZL_OFF_PATH("nn::Attention::impl::create_mla_impl (multi_head_latent_attention.cpp is link-checked only)");
-}
 
 }  // namespace nn
 
@@ -246,6 +254,7 @@ ModelContext::ModelContext(bmengine::core::Context&& ctx, const ModelBase& md, i
     : bmengine::core::Context(std::move(ctx)), cfg(md.cfg), model_(md), parallel_(parallel) {
     layer_devices.assign(md.num_layers, active_device());
     set_BSHD(BSHD);
+    latent_cache_ = cfg.kv_lora_rank > 0 && std::getenv("LATENT_CACHE") && std::atoi(std::getenv("LATENT_CACHE")) == 1;   // (model_context.cpp: the same switch)
 }
 }  // namespace model
 
@@ -293,18 +302,33 @@ public:
 // One reference nn::Attention layer inside a reference ModelContext with reference DynBatchContext / RagBufferContext objects
 class RefAttention {
 public:
+    // mla = (q_lora_rank, kv_lora_rank, qk_nope_head_dim, qk_rope_head_dim, v_head_dim), all zero for ordinary attention.  With
+    // kv_lora_rank > 0 the reference builds its MLAImpl (multi_head_latent_attention.cpp) and -- under LATENT_CACHE=1 -- the task
+    // buffers hold ONE 576-wide latent row per key and no value buffer (RagBufferContext::has_v, rag_buffer_context.h:88-90)
     RefAttention(int dim_model, int num_heads, int num_kv_heads, int dim_head, float rope_theta, const std::string& model_type, int quant_type,
-                 int group_size, int num_layers, bool bshd, int device)
-        : cfg_(model_type, num_layers, dim_model, num_heads, dim_head, 4 * dim_model, 1024, 1e-5f, num_kv_heads, DataType::kHalf),
-          md_((cfg_.rope_theta = rope_theta, cfg_)),
+                 int group_size, int num_layers, bool bshd, int device, const std::vector<int>& mla)
+        : cfg_(with_mla(model::ModelConfig(model_type, num_layers, dim_model, num_heads, dim_head, 4 * dim_model, 1024, 1e-5f, num_kv_heads, DataType::kHalf),
+                        rope_theta, mla)),
+          md_(cfg_),
           ctx_(Context(device), md_, 1, false, bshd),
           num_layers_(num_layers) {
         model::QuantConfig qc(quant_type);
         qc.group_size = group_size;
         attn_.reset(new nn::Attention(ctx_, cfg_, qc, false));
-        kvcache::KVCacheConfig kc{num_layers, num_kv_heads, dim_head, DataType::kHalf, bshd, nullptr, std::vector<int>(num_layers, device)};
-        rag_ = std::make_shared<model::RagBufferContext>(kc, kc);
+        const bool latent = cfg_.kv_lora_rank > 0 && ctx_.latent_cache();
+        kvcache::KVCacheConfig kc{num_layers, latent ? 1 : num_kv_heads, latent ? cfg_.kv_lora_rank + cfg_.qk_rope_head_dim : dim_head, DataType::kHalf, bshd,
+                                  nullptr, std::vector<int>(num_layers, device)};
+        kvcache::KVCacheConfig vc = kc;
+        if (latent) vc.dim_head = 0;
+        rag_ = std::make_shared<model::RagBufferContext>(kc, vc);
         ctx_.set_rag_buffer(rag_);
+    }
+    static model::ModelConfig with_mla(model::ModelConfig c, float rope_theta, const std::vector<int>& mla) {
+        c.rope_theta = rope_theta;
+        if (mla.size() == 5 && mla[1] > 0) {
+            c.q_lora_rank = mla[0]; c.kv_lora_rank = mla[1]; c.qk_nope_head_dim = mla[2]; c.qk_rope_head_dim = mla[3]; c.v_head_dim = mla[4];
+        }
+        return c;
     }
     void load(const std::map<std::string, py::array>& arrays, const std::string& prefix) {
         std::map<std::string, const Tensor> sd;
@@ -315,10 +339,11 @@ public:
     void set_history(int b, int layer, int len_buf, const py::array& k, const py::array& v) {
         rag_->resize_task_buf(ctx_, b, (size_t)len_buf);
         fill(rag_->buf_k(b)[layer], k);
-        fill(rag_->buf_v(b)[layer], v);
+        if (rag_->config_v_.dim_head > 0) fill(rag_->buf_v(b)[layer], v);
     }
     py::array get_k(int b, int layer) { return to_numpy(ctx_, rag_->buf_k(b, layer)); }
     py::array get_v(int b, int layer) { return to_numpy(ctx_, rag_->buf_v(b, layer)); }
+    bool latent_cache() { return ctx_.latent_cache(); }
     // one decode step of `layer` for the tasks 0 .. B - 1: hidden (B, dim_model) fp16, positions (B) int32, placement (B) int32 = the
     // buffer row the new key goes to, mask (sum over tasks of len_buf) int8.  with_rope_cache: DynBatchContext::rope_cache filled
     // (RopePreparer's tables), the reference then takes rope_qk_cache instead of rotary_embedding_qk.
@@ -333,7 +358,6 @@ public:
         for (size_t b = 0; b < B; ++b) dyn->sv_len_buf.push_back((int)rag_->get_buf_len(b));
         dyn->s_len_buf = ctx_.tensor_of(dyn->sv_len_buf);
         if (with_rope_cache) {
-            nn::RotaryEmbedding rope(ctx_, cfg_);
             // (the tables RopePreparer leaves in the context: cos / sin of every row's position)
             Tensor cs = ctx_.tensor({B, (size_t)cfg_.dim_head}, DataType::kFloat), sn = ctx_.tensor({B, (size_t)cfg_.dim_head}, DataType::kFloat);
             ZL_CK(zl_rope_cos_sin(dyn->s_position.data<int32_t>(), cs.data<float>(), sn.data<float>(), B, cfg_.dim_head, cfg_.rope_theta, 1,
@@ -397,9 +421,10 @@ private:
 
 void bind_ref_attention(py::module_& m) {
     py::class_<RefAttention>(m, "RefAttention")
-        .def(py::init<int, int, int, int, float, const std::string&, int, int, int, bool, int>(), py::arg("dim_model"), py::arg("num_heads"),
+        .def(py::init<int, int, int, int, float, const std::string&, int, int, int, bool, int, const std::vector<int>&>(), py::arg("dim_model"), py::arg("num_heads"),
              py::arg("num_kv_heads"), py::arg("dim_head"), py::arg("rope_theta") = 10000.0f, py::arg("model_type") = "llama", py::arg("quant_type") = 5,
-             py::arg("group_size") = 128, py::arg("num_layers") = 1, py::arg("bshd") = true, py::arg("device") = 0)
+             py::arg("group_size") = 128, py::arg("num_layers") = 1, py::arg("bshd") = true, py::arg("device") = 0, py::arg("mla") = std::vector<int>())
+        .def("latent_cache", &RefAttention::latent_cache)
         .def("load", &RefAttention::load)
         .def("set_history", &RefAttention::set_history)
         .def("get_k", &RefAttention::get_k)

@@ -57,6 +57,15 @@ public:
         BM_ASSERT_EQ((int)x.size(-1), dim_model, "LayerNorm: dim mismatch");
         BM_ASSERT(weight.numel() == (size_t)dim_model, "LayerNorm: weight not loaded");
     }
+    // rows of a possibly STRIDED (rows, dim) operand into a possibly strided output: zl_head_norm with one "head" per row
+    void rows_into(const core::Context& ctx, const core::Tensor& x, core::Tensor& out) const {
+        check(x);
+        BM_ASSERT(x.ndim() == 2 && out.ndim() == 2 && x.stride(1) == 1 && out.stride(1) == 1 && out.size(0) == x.size(0) && out.size(1) == x.size(1),
+                  "LayerNorm::forward_2: (rows, dim) operands, dense last dimension");
+        BM_ASSERT(scale == 1.0f && dim_model <= 1024, "LayerNorm::forward_2: scale 1, dim <= 1024");
+        ZL_CK(zl_head_norm(x.data<uint16_t>(), weight.data<uint16_t>(), out.data<uint16_t>(), x.size(0), 1, dim_model, x.stride(0), out.stride(0), eps, 0, zdt(x),
+                           (zl_stream_t)ctx.current_cuda_stream()), "head_norm(rows)");
+    }
 };
 
 LayerNorm::LayerNorm(const core::Context&, int dim_model, bool quant, float eps, float scale, core::DataType dtype, int num_head)
@@ -97,9 +106,14 @@ void LayerNorm::inplace(const core::Context& ctx, core::Tensor& x) {
     ZL_CK(zl_rmsnorm(x.data<uint16_t>(), pimpl->weight.data<uint16_t>(), x.data<uint16_t>(), x.numel() / x.size(-1), pimpl->dim_model, pimpl->eps,
                      pimpl->scale, nullptr, nullptr, pimpl->zdt(x), (zl_stream_t)ctx.current_cuda_stream()), "rmsnorm(inplace)");
 }
+// two norms in one call (MLAImpl's q_a / kv_a norms, multi_head_latent_attention.cpp:526): inputs AND outputs may be last-dimension
+// slices of wider tensors (the fused qkv_a projection; the compressed_kv row under construction) and the outputs are written in
+// place when the caller hands them allocated -- rows through zl_head_norm (one "head" per row, explicit row strides)
 void LayerNorm::forward_2(const core::Context& ctx, core::Tensor& x, core::Tensor& y, core::Tensor& x_out, core::Tensor& y_out, LayerNorm* la, LayerNorm* lb) {
-    x_out = la->forward(ctx, x);       // (the reference fuses the two launches; MLA's q_a / kv_a norms)
-    y_out = lb->forward(ctx, y);
+    if (x_out.numel() == 0) x_out = ctx.tensor(x.shape(), x.dtype());
+    if (y_out.numel() == 0) y_out = ctx.tensor(y.shape(), y.dtype());
+    la->pimpl->rows_into(ctx, x, x_out);
+    lb->pimpl->rows_into(ctx, y, y_out);
 }
 
 }  // namespace nn
