@@ -686,6 +686,16 @@ int zl_cast(const void* in, int in_type, void* out, int out_type, int64_t n, zl_
 int zl_copy_2d(const void* src, int64_t src_pitch, void* dst, int64_t dst_pitch, int64_t width_bytes, int64_t rows, zl_stream_t s);
 int zl_index_select(const void* in, void* out, const int32_t* index, int64_t outer, int64_t dim_in, int64_t n_index,
                     int64_t inner_bytes, zl_stream_t s);
+/* the index plumbing of the MoE dispatch route (FeedForward::forward_gpu_dispatch, src/nn/feedforward/feedforward.cpp:599-629,
+ * 1040-1075), bmengine's functions::arange (init.h:10), divide on int32 (element.h:25: truncating integer quotient), scatter_update_dim0
+ * (scatter.h:7-13: dst[dst_index[i], :] = src[src_index ? src_index[i] : i, :]) and sort_pair_1d (sort.h:8-12; cub's stable radix sort
+ * there): a STABLE sort of (int32 key >= 0, int32 value) pairs, one workgroup, n <= 2^20, `workspace` 8 n bytes. */
+int zl_arange_i32(int32_t* out, int32_t start, int32_t step, int64_t n, zl_stream_t s);
+int zl_divide_i32(const int32_t* a, int32_t* out, int32_t divisor, int64_t n, zl_stream_t s);
+int zl_scatter_update_dim0(void* dst, const int32_t* dst_index, const void* src, const int32_t* src_index, int64_t n_index, int64_t row_bytes,
+                           int64_t dst_rows, int64_t src_rows, zl_stream_t s);
+int zl_sort_pairs_i32(const int32_t* keys, const int32_t* values, int32_t* keys_out, int32_t* values_out, void* workspace, int64_t n,
+                      int32_t max_key, zl_stream_t s);
 int zl_reduce_abs_max(const void* x, void* out, int64_t rows, int64_t cols, int type, zl_stream_t s);
 int zl_binary_op(const void* a, const void* b, void* c, int64_t rows, int64_t cols, int op, int bmode, int type, zl_stream_t s);
 int zl_scale(const void* in, void* out, int64_t n, float factor, int type, zl_stream_t s);

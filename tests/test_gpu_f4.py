@@ -480,3 +480,39 @@ def test_per_token_cast_more_rows_than_a_grid_dimension(oracle, dev):
     want_c, want_s = oracle.fp8_per_token_cast(_bits(x), col_major=True, dtype=1)
     assert np.array_equal(codes.cpu().numpy(), want_c)
     assert np.array_equal(scales.cpu().numpy()[:, :m], want_s[:, :m])
+
+
+@pytest.mark.parametrize("n,max_key", [(1, 7), (255, 16), (256, 512), (4097, 300), (32768, 2304), (100000, 0)])
+def test_dispatch_index_helpers(dev, n, max_key):
+    """functions::arange / sort_pair_1d / divide / scatter_update_dim0 of the MoE dispatch route (feedforward.cpp:599-629, 1040-1075) as
+    kernels: the sort is STABLE (equal keys keep their input order -- the dispatch relies on it), against numpy's stable argsort."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(n)
+    hi = max_key if max_key else 2 ** 31 - 1
+    keys = rng.integers(0, hi + 1 if max_key else hi, n).astype(np.int32)
+    if n > 10:
+        keys[:5] = hi if max_key else hi - 1                                     # the largest key, and ties at the front
+    vals = ops.arange_i32(n, dev)
+    assert np.array_equal(vals.cpu().numpy(), np.arange(n, dtype=np.int32))
+    ko, vo = ops.sort_pairs_i32(_t(keys, dev), vals, max_key=max_key)
+    order = np.argsort(keys, kind="stable").astype(np.int32)
+    assert np.array_equal(ko.cpu().numpy(), keys[order]) and np.array_equal(vo.cpu().numpy(), order)
+    assert np.array_equal(ops.divide_i32(vo, 6).cpu().numpy(), order // 6)
+    assert np.array_equal(ops.arange_i32(5, dev, start=3, step=4).cpu().numpy(), np.array([3, 7, 11, 15, 19], np.int32))
+    # scatter: dst rows named by dst_index <- src rows named by src_index (repeats allowed on the source side)
+    m = min(n, 300)
+    for dtype, width in ((torch.uint8, 512), (torch.float32, 7 * 2), (torch.float16, 129)):
+        src = torch.from_numpy(rng.integers(0, 250, (97, width)).astype(np.float32)).to(dtype).to(dev)
+        dst = torch.zeros((m + 11, width), dtype=dtype, device=dev)
+        di = rng.permutation(m + 11)[:m].astype(np.int32)
+        si = rng.integers(0, 97, m).astype(np.int32)
+        ops.scatter_update_dim0(dst, _t(di, dev), src, _t(si, dev))
+        want = np.zeros((m + 11, width), np.float32)
+        want[di] = src.float().cpu().numpy()[si]
+        assert np.array_equal(dst.float().cpu().numpy(), want)
+        dst2 = torch.zeros((m + 11, width), dtype=dtype, device=dev)
+        mm = min(m, 50)
+        ops.scatter_update_dim0(dst2, _t(di[:mm], dev), src[:mm].contiguous())           # no source index: row i
+        want2 = np.zeros((m + 11, width), np.float32)
+        want2[di[:mm]] = src.float().cpu().numpy()[:mm]
+        assert np.array_equal(dst2.float().cpu().numpy(), want2)

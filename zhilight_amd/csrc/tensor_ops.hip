@@ -176,6 +176,105 @@ __global__ void k_permute_input_u16(const uint16_t* __restrict__ x, int64_t ldx,
     default: return ZL_EDTYPE;                 \
     }
 
+// ---- the MoE dispatch route's index plumbing (functions::arange / sort_pair_1d / divide / scatter_update_dim0) ------------------------
+__global__ void k_arange_i32(int32_t* __restrict__ out, int start, int step, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = start + (int)i * step;
+}
+__global__ void k_divide_i32(const int32_t* __restrict__ a, int32_t* __restrict__ out, int divisor, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] / divisor;
+}
+// dst[dst_index[i], :] = src[src_index ? src_index[i] : i, :]; rows of row_bytes (a multiple of 2); grid n_index
+__global__ __launch_bounds__(256) void k_scatter_rows(unsigned char* __restrict__ dst, const int32_t* __restrict__ dst_index,
+                                                       const unsigned char* __restrict__ src, const int32_t* __restrict__ src_index, int64_t row_bytes,
+                                                       int64_t dst_rows, int64_t src_rows) {
+    const int64_t i = blockIdx.x;
+    const int64_t x = dst_index[i], y = src_index ? src_index[i] : i;
+    if (x < 0 || x >= dst_rows || y < 0 || y >= src_rows) return;            // (the reference asserts; here an index outside is dropped)
+    const unsigned char* sp = src + y * row_bytes;
+    unsigned char* dp = dst + x * row_bytes;
+    if (row_bytes % 16 == 0 && (((uintptr_t)sp | (uintptr_t)dp) & 15) == 0) {
+        for (int64_t o = threadIdx.x * 16; o < row_bytes; o += 256 * 16) *reinterpret_cast<uint4*>(dp + o) = *reinterpret_cast<const uint4*>(sp + o);
+    } else {
+        for (int64_t o = threadIdx.x * 2; o < row_bytes; o += 256 * 2) *reinterpret_cast<uint16_t*>(dp + o) = *reinterpret_cast<const uint16_t*>(sp + o);
+    }
+}
+// Stable least-significant-digit radix sort of (int32 key >= 0, int32 value) pairs in ONE workgroup of 512 threads, 4 bits per pass:
+// thread t owns the contiguous chunk [t c, (t + 1) c) of the current order, counts its 16 digit values, an exclusive scan over
+// (digit, thread) in LDS gives every thread the output position of its first element per digit, and the chunk is written in order --
+// stable by construction (cub::DeviceRadixSort::SortPairs, which functions::sort_pair_1d wraps, is stable too: the MoE dispatch
+// relies on tokens staying in order inside an expert's run, feedforward.cpp:599-629).  bits = ceil(log2(max_key + 1)), 32 when
+// max_key == 0.  n <= 2^20: a decode / prompt-chunk routing table (tokens x top_k), not a general-purpose sort.
+__global__ __launch_bounds__(512) void k_sort_pairs_i32(const int32_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in, int32_t* keys_a,
+                                                          int32_t* vals_a, int32_t* keys_b, int32_t* vals_b, int n, int bits) {
+    __shared__ int cnt[16 * 512];                    // [digit][thread]
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, c = (n + 511) / 512, lo = min(n, t * c), hi = min(n, lo + c);
+    const int passes = (bits + 3) / 4;
+    // the result must land in (keys_a, vals_a): with an odd number of passes the first pass writes a, else b
+    const int32_t* ksrc = keys_in;
+    const int32_t* vsrc = vals_in;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_a = ((passes - 1 - p) & 1) == 0;
+        int32_t* kdst = to_a ? keys_a : keys_b;
+        int32_t* vdst = to_a ? vals_a : vals_b;
+        const int shift = 4 * p;
+        int local[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) local[d] = 0;
+        for (int i = lo; i < hi; ++i) {
+            const int d = (ksrc[i] >> shift) & 15;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) local[e] += (e == d);
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[d * 512 + t] = local[d];
+        __syncthreads();
+        // exclusive scan over the flattened (digit, thread) order: 16 x 512 entries, 16 per thread
+        int run = 0, mine[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            mine[j] = cnt[t * 16 + j];
+            run += mine[j];
+        }
+        // block-wide exclusive scan of `run`
+        __shared__ int part[512];
+        part[t] = run;
+        __syncthreads();
+        for (int off = 1; off < 512; off <<= 1) {
+            const int v = t >= off ? part[t - off] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        int base = part[t] - run;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            cnt[t * 16 + j] = base;
+            base += mine[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 16; ++d) local[d] = cnt[d * 512 + t];
+        for (int i = lo; i < hi; ++i) {
+            const int k = ksrc[i], d = (k >> shift) & 15;
+            int pos = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (e == d) { pos = local[e]; local[e] += 1; }
+            }
+            kdst[pos] = k;
+            vdst[pos] = vsrc[i];
+        }
+        __threadfence_block();
+        __syncthreads();
+        ksrc = kdst;
+        vsrc = vdst;
+        (void)wsum;
+    }
+}
+
 extern "C" {
 
 int zl_cast(const void* in, int in_type, void* out, int out_type, int64_t n, zl_stream_t s) {
@@ -227,6 +326,38 @@ int zl_index_select(const void* in, void* out, const int32_t* index, int64_t out
     else
         hipLaunchKernelGGL(k_index_select<uint8_t>, dim3(grid_for(rows * inner_bytes, 256)), dim3(256), 0, hs, (const uint8_t*)in,
                            (uint8_t*)out, index, outer, dim_in, n_index, inner_bytes);
+    return zl_launch_status();
+}
+
+int zl_arange_i32(int32_t* out, int32_t start, int32_t step, int64_t n, zl_stream_t s) {
+    ZL_CHECK_ARG(out && n > 0 && step != 0, ZL_EINVAL);
+    hipLaunchKernelGGL(k_arange_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, out, start, step, n);
+    return zl_launch_status();
+}
+int zl_divide_i32(const int32_t* a, int32_t* out, int32_t divisor, int64_t n, zl_stream_t s) {
+    ZL_CHECK_ARG(a && out && n > 0 && divisor != 0, ZL_EINVAL);
+    hipLaunchKernelGGL(k_divide_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, a, out, divisor, n);
+    return zl_launch_status();
+}
+int zl_scatter_update_dim0(void* dst, const int32_t* dst_index, const void* src, const int32_t* src_index, int64_t n_index, int64_t row_bytes,
+                           int64_t dst_rows, int64_t src_rows, zl_stream_t s) {
+    ZL_CHECK_ARG(dst && dst_index && src && n_index > 0 && row_bytes > 0 && dst_rows > 0 && src_rows > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(row_bytes % 2 == 0 && n_index < ((int64_t)1 << 31), ZL_ESHAPE);
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)n_index), dim3(256), 0, (hipStream_t)s, (unsigned char*)dst, dst_index, (const unsigned char*)src, src_index,
+                       row_bytes, dst_rows, src_rows);
+    return zl_launch_status();
+}
+int zl_sort_pairs_i32(const int32_t* keys, const int32_t* values, int32_t* keys_out, int32_t* values_out, void* workspace, int64_t n, int32_t max_key,
+                      zl_stream_t s) {
+    ZL_CHECK_ARG(keys && values && keys_out && values_out && workspace && n > 0 && max_key >= 0, ZL_EINVAL);
+    ZL_CHECK_ARG(n <= ((int64_t)1 << 20), ZL_ELIMIT);
+    int bits = 31;                                   // non-negative keys
+    if (max_key > 0) {
+        bits = 1;
+        while ((max_key >> bits) != 0) ++bits;
+    }
+    int32_t* kb = static_cast<int32_t*>(workspace);
+    hipLaunchKernelGGL(k_sort_pairs_i32, dim3(1), dim3(512), 0, (hipStream_t)s, keys, values, keys_out, values_out, kb, kb + n, (int)n, bits);
     return zl_launch_status();
 }
 

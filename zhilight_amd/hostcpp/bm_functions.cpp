@@ -121,6 +121,49 @@ Tensor Gemm::batch_3d(const Context& ctx, const Tensor& A, const Tensor& B, Tens
     return output ? *output : out;
 }
 
+// ---- the MoE dispatch route's index plumbing (init.h:10, element.h:25, scatter.h:7-13, sort.h:8-17) ----------------------------------
+Tensor arange(const Context& ctx, int start, int end, int step) {
+    BM_ASSERT(step != 0 && (end - start) / step >= 0, "arange: empty or reversed range");
+    const size_t num = size_t(end - start) / step;
+    Tensor out = ctx.tensor({num}, DataType::kInt32);
+    if (num) zl_check(zl_arange_i32(out.data<int32_t>(), start, step, num, st_of(ctx)), "arange");
+    return out;
+}
+Tensor divide(const Context& ctx, const Tensor& a, float divisor) {
+    // the reference divides in the element type (UnaryOpDivide<T>: T(divisor)); the dispatch route calls it on int32 token indices
+    BM_ASSERT(a.dtype() == DataType::kInt32 && a.is_continuous(), "divide: int32 (the index form) is what this boundary provides");
+    BM_ASSERT((float)(int)divisor == divisor && (int)divisor != 0, "divide: integral divisor");
+    Tensor out = ctx.tensor(a.shape(), a.dtype());
+    if (a.numel()) zl_check(zl_divide_i32(a.data<int32_t>(), out.data<int32_t>(), (int)divisor, a.numel(), st_of(ctx)), "divide");
+    return out;
+}
+void scatter_update_dim0(const Context& ctx, Tensor& dst, const Tensor& dst_index, const Tensor& src, const Tensor& src_index) {
+    BM_ASSERT_EQ(dst.dtype(), src.dtype(), "src dst dtype mismatch");
+    BM_ASSERT(dst.ndim() == 2 && src.ndim() == 2 && dst.size(-1) == src.size(-1), "scatter_update_dim0: (X, D) <- (Y, D)");
+    BM_ASSERT(dst.is_continuous() && src.is_continuous(), "scatter_update_dim0: dense operands");
+    BM_ASSERT(dst_index.dtype() == DataType::kInt32 && dst_index.ndim() == 1, "dst_index is not 1-d int");
+    const bool has_src = src_index.numel() > 0;
+    if (has_src) BM_ASSERT(src_index.dtype() == DataType::kInt32 && src_index.numel() == dst_index.numel(), "src_index / dst_index mismatch");
+    if (!dst_index.numel()) return;
+    const size_t row_bytes = src.size(-1) * core::get_elem_size(src.dtype());
+    BM_ASSERT(row_bytes % 2 == 0, "scatter_update_dim0: rows of an even number of bytes");
+    zl_check(zl_scatter_update_dim0(dst.data(), dst_index.data<int32_t>(), src.data(), has_src ? src_index.data<int32_t>() : nullptr, dst_index.numel(),
+                                    row_bytes, dst.size(0), src.size(0), st_of(ctx)), "scatter_update_dim0");
+}
+std::pair<Tensor, Tensor> sort_pair_1d(const Context& ctx, const Tensor& keys, const Tensor& values, int max_key) {
+    BM_ASSERT(keys.ndim() == 1 && values.ndim() == 1 && keys.numel() == values.numel(), "sort_pair_1d: two 1-d tensors of one length");
+    BM_ASSERT(keys.dtype() == DataType::kInt32 && values.dtype() == DataType::kInt32, "sort_pair_1d: int32 keys (non-negative) and values");
+    Tensor ko = ctx.tensor(keys.shape(), keys.dtype()), vo = ctx.tensor(values.shape(), values.dtype());
+    if (!keys.numel()) return {ko, vo};
+    Tensor wsp = ctx.tensor({keys.numel() * 2}, DataType::kInt32);
+    zl_check(zl_sort_pairs_i32(keys.data<int32_t>(), values.data<int32_t>(), ko.data<int32_t>(), vo.data<int32_t>(), wsp.data(), keys.numel(), max_key,
+                               st_of(ctx)), "sort_pair_1d");
+    return {ko, vo};
+}
+std::pair<Tensor, Tensor> sort_with_indices_1d(const Context& ctx, const Tensor& keys, int max_key) {
+    return sort_pair_1d(ctx, keys, arange(ctx, 0, (int)keys.numel(), 1), max_key);
+}
+
 // ---- Transpose ---------------------------------------------------------------------------------------------------------
 class Transpose::impl {};
 Transpose::Transpose(const Context&) : pimpl(new impl) {}

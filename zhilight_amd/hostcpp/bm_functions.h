@@ -68,6 +68,12 @@ void copy_last_dim(hipStream_t stream, const core::Tensor& input, core::Tensor& 
 // tensor_ops.h:13-14: C[l, m, :] = [A[l, m, :] | B[l, :]] for A (L, M, a), B (L, b)
 core::Tensor concat_broadcast_b(const core::Context& ctx, const core::Tensor& A, const core::Tensor& B);
 core::Tensor reduce_abs_max(const core::Context& ctx, const core::Tensor& a, int dim = 0);
+// the MoE dispatch route's index plumbing (init.h:10, element.h:25, scatter.h:7-13, sort.h:8-17): int32 forms
+core::Tensor arange(const core::Context& ctx, int start, int end, int step);
+core::Tensor divide(const core::Context& ctx, const core::Tensor& a, float divisor);
+void scatter_update_dim0(const core::Context& ctx, core::Tensor& dst, const core::Tensor& dst_index, const core::Tensor& src, const core::Tensor& src_index);
+std::pair<core::Tensor, core::Tensor> sort_pair_1d(const core::Context& ctx, const core::Tensor& keys, const core::Tensor& values, int max_key);
+std::pair<core::Tensor, core::Tensor> sort_with_indices_1d(const core::Context& ctx, const core::Tensor& keys, int max_key);
 void zeros_(const core::Context& ctx, const core::Tensor& x);
 void ones_(const core::Context& ctx, const core::Tensor& x);
 void fill(const core::Context& ctx, const core::Tensor& x, float value);

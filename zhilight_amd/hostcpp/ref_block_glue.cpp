@@ -6,8 +6,9 @@
 //      boundary's own nn::LayerNorm in nn_amd.h is a different class under the same name, so nn_amd.cpp leaves its definitions out
 //      of this module: -DZL_REF_LAYERNORM_EXTERNAL) over zl_rmsnorm;
 //   2. the four ModelContext members block.cpp calls (model_context.cpp:133-136, 221-242, 328-341) for ONE rank;
-//   3. bmengine::functions helpers only the MoE dispatch route / smooth-quant calibration use (arange, sort_pair_1d, divide,
-//      scatter_update_dim0, pow, clamp): declared by the shim, not on this path -- definitions that throw;
+//   3. bmengine::functions helpers only the smooth-quant calibration uses (pow, clamp): declared by the shim, not on this path --
+//      definitions that throw (the MoE dispatch route's arange / sort_pair_1d / divide / scatter_update_dim0 are real since
+//      round 4: bm_functions.cpp over zl_arange_i32 / zl_sort_pairs_i32 / zl_divide_i32 / zl_scatter_update_dim0);
 //   4. the pybind11 class RefEncoderLayer: load a layer under the reference's parameter names, fill KV histories, run decode steps.
 // Test infrastructure: nothing in the product links this file.
 #include <pybind11/numpy.h>
@@ -137,14 +138,6 @@ void ModelContext::check_numeric(const core::Tensor& t) const {
 // ---- 3. functions helpers off this path ---------------------------------------------------------------------------------------
 namespace bmengine {
 namespace functions {
-core::Tensor arange(const core::Context&, int, int, int) { ZL_OFF_PATH("functions::arange (MoE dispatch route)"); }
-core::Tensor divide(const core::Context&, const core::Tensor&, float) { ZL_OFF_PATH("functions::divide (MoE dispatch route)"); }
-void scatter_update_dim0(const core::Context&, core::Tensor&, const core::Tensor&, const core::Tensor&, const core::Tensor&) {
-    ZL_OFF_PATH("functions::scatter_update_dim0 (MoE dispatch route)");
-}
-std::pair<core::Tensor, core::Tensor> sort_pair_1d(const core::Context&, const core::Tensor&, const core::Tensor&, int) {
-    ZL_OFF_PATH("functions::sort_pair_1d (MoE dispatch route)");
-}
 core::Tensor pow(const core::Context&, const core::Tensor&, float) { ZL_OFF_PATH("functions::pow (smooth-quant calibration)"); }
 core::Tensor clamp(const core::Context&, const core::Tensor&, float, float) { ZL_OFF_PATH("functions::clamp (smooth-quant calibration)"); }
 }  // namespace functions

@@ -5,17 +5,17 @@ forward_gpu_dispatch), strung together from the C-ABI launchers of zhilight_amd/
     logits = router(x)                                   functions::Gemm                       -> zl_gemm_nt
     ids, weights, loads = top-k / group-limited top-k    top_k_softmax / group_topk_softmax    -> zl_moe_top_k_softmax / zl_moe_group_topk
     m_indices, padded positions, total                   fill_m_indices_padded_indices         -> zl_moe_fill_m_indices
-    order = sort of the (token, slot) pairs by expert    functions::sort_pair_1d (CUB)         -> the framework's stable device sort
+    order = sort of the (token, slot) pairs by expert    functions::arange, sort_pair_1d (CUB) -> zl_arange_i32, zl_sort_pairs_i32 (stable), zl_divide_i32
     rev = position of a pair inside its expert's run     calc_reverse_idx                      -> zl_moe_calc_reverse_idx
-    grouped input: per-token 1x128 cast, rows and scales scattered to the 64-aligned runs     -> zl_fp8_per_token_cast + row moves
+    grouped input: per-token 1x128 cast, rows and scales scattered to the 64-aligned runs     -> zl_fp8_per_token_cast, zl_scatter_update_dim0
     w0, w1 = grouped GEMMs (in, gated); w0 = act(w0) * w1; w2 = grouped GEMM (out)            -> zl_fp8_block_gemm_group, zl_gate_mul
     y[token] = sum_slot weight * w2[run(expert) + rev]   sum_experts (per-expert inputs)       -> zl_moe_sum_experts_arr
     y += shared_expert(x)                                with_share (:483-492)                 -> zl_fp8_block_gemm_group x3, zl_element_add_scale
 
 One rank; the shared expert is the static one (expert / data parallel modes and the load-balanced shared experts of route_shared_lb
-are wired in ops but not in this flow yet).  Row moves (gather of the sorted tokens, scatter into the padded layout, the scale
-transpose) and the sort are device-memory plumbing done with torch indexing, like the reference's functions::scatter_update_dim0 /
-Transpose / sort_pair_1d; every arithmetic step is a launcher of the C ABI -- there is no CPU or torch fallback for those."""
+are wired in ops but not in this flow yet).  Since round 4 the sort and the row scatters are launchers of the C ABI as well
+(functions::arange / sort_pair_1d / divide / scatter_update_dim0); what is left to the framework is the scale transpose and
+slicing views -- there is no CPU or torch fallback for any arithmetic or index step."""
 from typing import Optional
 
 import torch
@@ -76,16 +76,18 @@ class Fp8BlockMoE:
         if total == 0:
             return self.with_share(x, torch.zeros_like(x))
         # (token, slot) pairs sorted by expert, stable: sorted position j holds pair order[j]; its token is order[j] // k
-        order = torch.sort(ids.reshape(-1), stable=True).indices.to(torch.int32)
+        # FeedForward::sort_token (feedforward.cpp:599-629): arange, stable sort_pair_1d by expert id, divide by top_k -- kernels since round 4
+        flat = ids.reshape(-1).contiguous()
+        _, order = ops.sort_pairs_i32(flat, ops.arange_i32(flat.numel(), x.device), max_key=2 * e)
         rev = ops.moe_calc_reverse_idx(ids, order, all_loads, e)
-        sorted_tokens = torch.div(order, k, rounding_mode="floor").long()
-        # grouped input: codes and 1x128 scales of the sorted tokens at the 64-aligned positions, padding rows zero
+        sorted_tokens = ops.divide_i32(order, k)
+        # grouped input (get_grouped_input_gpu, :1040-1075): codes and 1x128 scales of the sorted tokens scattered to the 64-aligned
+        # positions (scatter_update_dim0), padding rows zero
         a8, sa = ops.fp8_per_token_cast(x, scale_col_major=False)
-        pos = padded_idx.long()
         g8 = torch.zeros((total, dim), dtype=torch.uint8, device=x.device)
-        g8[pos] = a8[sorted_tokens]
+        ops.scatter_update_dim0(g8, padded_idx, a8, sorted_tokens)
         gs = torch.zeros((total, dim // 128), dtype=torch.float32, device=x.device)
-        gs[pos] = sa[:tokens][sorted_tokens]
+        ops.scatter_update_dim0(gs, padded_idx, sa[:tokens].contiguous(), sorted_tokens)
         gs_t = gs.t().contiguous()                                            # (dim / 128, total): column-major scales, aligned_m = total
         w0 = ops.fp8_block_gemm(g8, gs_t, self.w_in, self.s_in, m_indices=m_indices, dtype=x.dtype)
         w1 = ops.fp8_block_gemm(g8, gs_t, self.w_gated, self.s_gated, m_indices=m_indices, dtype=x.dtype)
@@ -114,5 +116,5 @@ class Fp8BlockMoE:
                 ops.gate_mul(h0, h1, self.act)
                 rows.append(ops.fp8_block_linear(h0, self.w_out[exp], self.s_out[exp]))
         y = torch.cat(rows, dim=0)
-        pos = torch.arange(tokens * self.top_k, dtype=torch.int32, device=x.device)
+        pos = ops.arange_i32(tokens * self.top_k, x.device)
         return self.with_share(x, ops.moe_sum_experts(y, pos, weights))

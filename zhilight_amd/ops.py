@@ -427,6 +427,47 @@ def w4a16_gemm_tiled(x, w, bias=None, residual=None, out=None, epilogue=0):
     return out
 
 
+def arange_i32(n, device, start=0, step=1):
+    """functions::arange (bmengine init.h:10) as a kernel: int32 start, start + step, ..."""
+    out = torch.empty(n, dtype=torch.int32, device=device)
+    if n:
+        check(lib().zl_arange_i32(_p(out), C.c_int32(start), C.c_int32(step), _i(n), _stream()), "arange_i32")
+    return out
+
+
+def divide_i32(a, divisor):
+    """functions::divide on int32 (element.h:25): truncating integer quotient"""
+    _chk_cuda(a)
+    out = torch.empty_like(a)
+    if a.numel():
+        check(lib().zl_divide_i32(_p(a), _p(out), C.c_int32(int(divisor)), _i(a.numel()), _stream()), "divide_i32")
+    return out
+
+
+def sort_pairs_i32(keys, values, max_key=0):
+    """functions::sort_pair_1d (sort.h:8-12): STABLE sort of (int32 key >= 0, int32 value) pairs by key -> (keys, values)"""
+    _chk_cuda(keys, values)
+    if keys.dtype != torch.int32 or values.dtype != torch.int32 or keys.numel() != values.numel():
+        raise ZLError("sort_pairs_i32: two int32 tensors of one length")
+    ko, vo = torch.empty_like(keys), torch.empty_like(values)
+    n = keys.numel()
+    if n:
+        ws = torch.empty(2 * n, dtype=torch.int32, device=keys.device)
+        check(lib().zl_sort_pairs_i32(_p(keys), _p(values), _p(ko), _p(vo), _p(ws), _i(n), C.c_int32(int(max_key)), _stream()), "sort_pairs_i32")
+    return ko, vo
+
+
+def scatter_update_dim0(dst, dst_index, src, src_index=None):
+    """functions::scatter_update_dim0 (scatter.h:7-13): dst[dst_index[i], :] = src[src_index[i] if given else i, :] in place"""
+    _chk_cuda(dst, dst_index, src, src_index)
+    if dst.dim() != 2 or src.dim() != 2 or dst.shape[1] != src.shape[1] or dst.dtype != src.dtype or not (dst.is_contiguous() and src.is_contiguous()):
+        raise ZLError("scatter_update_dim0: dense (X, D) <- (Y, D) of one dtype")
+    if dst_index.numel():
+        check(lib().zl_scatter_update_dim0(_p(dst), _p(dst_index), _p(src), _p(src_index), _i(dst_index.numel()), _i(src.shape[1] * src.element_size()),
+                                           _i(dst.shape[0]), _i(src.shape[0]), _stream()), "scatter_update_dim0")
+    return dst
+
+
 def w4_planes_ok(m, k):
     """what the digit-plane route of the W4A16 linears covers: decode batches of 5..32 rows (1..4 rows: the integer-plane GEMV
     converts inside its own prologue), K a multiple of 128 up to 16384"""
