@@ -42,7 +42,7 @@ extern "C" {
 
 #define ZL_VERSION 100 /* 0.1.0 */
 
-enum { ZL_F16 = 0, ZL_BF16 = 1 };
+enum { ZL_F16 = 0, ZL_BF16 = 1, ZL_F32 = 2 /* accepted where a function says so: the MoE routers' logits */ };
 
 enum {
     ZL_OK = 0,
@@ -237,6 +237,10 @@ int zl_gemm_nt_small_m(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K
  * prompt chunks) on the matrix cores: fp32-accumulating MFMA GEMM, one rounding to T; K % 128 == 0. */
 int zl_gemm_nt(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K) */, const uint16_t* bias, uint16_t* y,
                int64_t m, int64_t n, int64_t k, float alpha, int dtype, zl_stream_t s);
+/* The same product with fp32 OUTPUT and no rounding to T: functions::Gemm / nn::Linear after set_output_type(kFloat) -- the MoE
+ * router's logits (src/nn/feedforward/feedforward.cpp:285-286), whose top-k must see the fp32 sums.  K % 8 == 0; small N x M. */
+int zl_gemm_nt_f32(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K) */, float* y, int64_t m, int64_t n, int64_t k, float alpha,
+                   int dtype, zl_stream_t s);
 
 /* lm_head + greedy pick without a separate argmax pass over the logits: the GEMV leaves each wavefront's
  * best (rounded logit, row index) in argmax_ws (zl_argmax_workspace_bytes(m, n) bytes); zl_greedy_advance
@@ -720,6 +724,7 @@ int zl_permute_input_u16(const uint16_t* x, int64_t ldx, const uint16_t* perm, u
  *                           matrix; negative: row skipped; groups contiguous and aligned to 16 rows).  fp32 accumulation per
  *                           block on v_mfma_f32_16x16x32_fp8_fp8.  K % 128 == 0.  The reference's kernel is a closed binary:
  *                           parity is against the format's definition in fp64 (oracle/zl_oracle.c: zlo_fp8_block_gemm).
+ *   (both routers take logits of dtype ZL_F16 / ZL_BF16 / ZL_F32 -- the reference's router Linear writes fp32 logits, feedforward.cpp:285-286)
  *   zl_moe_top_k_softmax    nn::top_k_softmax (src/nn/feedforward/ff_kernel.cu:174-268); scoring 1 softmax, 2 sigmoid (as written
  *                           there: 1 / (1 + expf(+x))), 3 linear; out_v / out_idx (tokens, top_k_ext), slots >= top_k get weight 1;
  *                           worker_load[id % num_worker] / expert_load[id] are incremented when given.

@@ -416,3 +416,56 @@ def test_reference_mla_child(ref, oracle):
         err = np.abs(got - want).max() / np.abs(want).max()
         assert got.shape == (2, dm) and np.isfinite(got).all() and err <= 4e-3, (step, err)
         pos = pos + 1
+
+
+def _moe_case(rng, dm, e, inter, shared):
+    w = lambda n, k: (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float16)
+    sd = {"f.router.weight": w(e, dm)}
+    for i in range(e):
+        sd[f"f.experts.{i}.w_in.weight"], sd[f"f.experts.{i}.w_gated.weight"], sd[f"f.experts.{i}.w_out.weight"] = w(inter, dm), w(inter, dm), w(dm, inter)
+    if shared:
+        sd["f.shared_expert.w_in.weight"], sd["f.shared_expert.w_gated.weight"], sd["f.shared_expert.w_out.weight"] = w(shared, dm), w(shared, dm), w(dm, shared)
+    return sd
+
+
+def _moe_reference(sd, x, e, k, shared, norm_topk_prob=True):
+    f = lambda a: a.astype(np.float64)
+    h16 = lambda a: a.astype(np.float16)
+    def expert(prefix, xt):
+        g, u = f(h16(f(xt) @ f(sd[prefix + ".w_in.weight"]).T)), f(h16(f(xt) @ f(sd[prefix + ".w_gated.weight"]).T))
+        return f(h16(f(h16(g / (1.0 + np.exp(-g)) * u)) @ f(sd[prefix + ".w_out.weight"]).T))
+    logits = (f(x) @ f(sd["f.router.weight"]).T).astype(np.float32).astype(np.float64)
+    p = np.exp(logits - logits.max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    out = np.zeros((x.shape[0], x.shape[1]))
+    for t in range(x.shape[0]):
+        ids = np.argsort(-p[t], kind="stable")[:k]
+        wts = p[t][ids] / (p[t][ids].sum() if norm_topk_prob else 1.0)
+        for i, wt in zip(ids, wts):
+            out[t] += wt * expert(f"f.experts.{i}", x[t:t + 1])[0]
+        out[t] = f(h16(out[t]))
+        if shared:
+            out[t] = f(h16(out[t] + expert("f.shared_expert", x[t:t + 1])[0]))
+    return out
+
+
+@pytest.mark.parametrize("route", ["host", "device"])
+def test_reference_moe_feedforward(ref, monkeypatch, route):
+    """The reference's MoE feed-forward (MOEImpl, src/nn/feedforward/feedforward.cpp:190-792, compiled unmodified): router Linear ->
+    top_k_softmax -> its host-side token dispatch, or -- MOE_GPU_DISPATCH_THRES=0 -- forward_gpu_dispatch (:631-700: arange /
+    sort_pair_1d / divide as kernels, calc_reverse_idx, index_select) -> the experts' NormalImpl::forward -> sum_experts -> the shared
+    expert; 8 experts, top-2, unquantised; decode (1 row) and a 6-row batch, against an fp64 restatement."""
+    rng = np.random.default_rng(5)
+    dm, e, k, inter, shared = 512, 8, 2, 256, 384
+    if route == "device":
+        monkeypatch.setenv("MOE_GPU_DISPATCH_THRES", "0")
+        monkeypatch.setenv("MOE_EXP_PARALLEL", "1")      # (the device route gathers the tokens only in expert-parallel mode, :657-662; one rank here)
+    sd = _moe_case(rng, dm, e, inter, shared)
+    layer = ref.RefFeedForward(dm, 1024, moe=[e, k, inter, shared])
+    layer.load(sd, "f")
+    for n in (1, 6):
+        x = synth.act(rng, n, dm)
+        got = layer.forward(x).astype(np.float64)
+        want = _moe_reference(sd, x, e, k, shared)
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert got.shape == (n, dm) and np.isfinite(got).all() and err <= 4e-3, (route, n, err)

@@ -30,7 +30,7 @@ SYMBOLS = [
     "zl_awq_un_shuffle", "zl_awq_shuffle",
     "zl_w4_layout", "zl_w4_pack", "zl_w4_dequant", "zl_w4a16_gemm",
     "zl_w4m_layout", "zl_w4m_pack", "zl_w4m_unpack", "zl_w4a16_gemm_mfma", "zl_w4a16_gemm_tiled", "zl_w4a16_scratch_bytes", "zl_w4a16_gemm_mfma_ex", "zl_w4a16_gemm_tiled_ex",
-    "zl_gemm_nt_small_m", "zl_gemm_nt", "zl_argmax_workspace_bytes", "zl_gemm_nt_small_m_argmax", "zl_greedy_advance",
+    "zl_gemm_nt_small_m", "zl_gemm_nt", "zl_gemm_nt_f32", "zl_argmax_workspace_bytes", "zl_gemm_nt_small_m_argmax", "zl_greedy_advance",
     "zl_rmsnorm",
     "zl_w4a16_moe_up", "zl_w4a16_moe_down", "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rope_cos_sin_dynamic", "zl_rope_cos_sin_yarn", "zl_head_norm", "zl_rotary_embedding_qk", "zl_rope_qk_cache", "zl_rope_rotate", "zl_mask_valid_lens",
     "zl_copy_to_rag_buffer2", "zl_rope_scatter_decode", "zl_w4a16_qkv_rope_scatter", "zl_w4a16_qkv_rope_scatter_ex", "zl_decode_attn_splits_h", "zl_w4a16_gemm_attn_merge_h", "zl_w4a16_gemm_attn_merge_h_ex", "zl_w4a16_attn_out_gate_up", "zl_engine_epoch_advance",

@@ -206,6 +206,29 @@ int launch(const DenseParams& p, int gx, int gy, hipStream_t st) {
     return zl_launch_status();
 }
 
+// y (M, N) fp32 = alpha * x (M, K) . W (N, K)^T with NO rounding to T: the MoE router's logits (Linear::set_output_type(kFloat),
+// src/nn/feedforward/feedforward.cpp:285-286: the top-k must see what the fp32 accumulation produced).  One wavefront per output,
+// 16-byte loads, fp32 fma chain per lane + wave sum; N = experts (a few hundred) x M = tokens: small.
+template <int DT>
+__global__ __launch_bounds__(64) void k_gemm_nt_f32(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ w, float* __restrict__ y,
+                                                    int n, int k, float alpha) {
+    const int col = blockIdx.x, row = blockIdx.y, lane = threadIdx.x;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    const uint16_t* wr = w + (int64_t)col * k;
+    float acc = 0.f;
+    for (int i = lane * 8; i + 8 <= k; i += 64 * 8) {
+        const uint4 a = *reinterpret_cast<const uint4*>(xr + i), b = *reinterpret_cast<const uint4*>(wr + i);
+        const uint32_t au[4] = {a.x, a.y, a.z, a.w}, bu[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc = __builtin_fmaf(ZT<DT>::to_f32((uint16_t)(au[e] & 0xffffu)), ZT<DT>::to_f32((uint16_t)(bu[e] & 0xffffu)), acc);
+            acc = __builtin_fmaf(ZT<DT>::to_f32((uint16_t)(au[e] >> 16)), ZT<DT>::to_f32((uint16_t)(bu[e] >> 16)), acc);
+        }
+    }
+    acc = zl_wave_sum(acc);
+    if (lane == 0) y[(int64_t)row * n + col] = alpha * acc;
+}
+
 }  // namespace
 
 static int dense_waves(int64_t n, int* rows_per_wave, int* gx) {
@@ -265,6 +288,17 @@ extern "C" int zl_gemm_nt_small_m_argmax(const uint16_t* x, int64_t ldx, const u
                                          const uint16_t* norm_weight, float norm_eps, void* argmax_ws, zl_stream_t s) {
     ZL_CHECK_ARG(argmax_ws, ZL_EINVAL);
     return gemm_nt_small_m_impl(x, ldx, w, bias, y, m, n, k, alpha, dtype, norm_weight, norm_eps, argmax_ws, s);
+}
+
+extern "C" int zl_gemm_nt_f32(const uint16_t* x, int64_t ldx, const uint16_t* w, float* y, int64_t m, int64_t n, int64_t k, float alpha, int dtype,
+                              zl_stream_t s) {
+    ZL_CHECK_ARG(x && w && y && m > 0 && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(k % 8 == 0 && ldx >= k && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && m <= 65535 && n < ((int64_t)1 << 31), ZL_ESHAPE);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    const dim3 grid((unsigned)n, (unsigned)m);
+    if (dtype == ZL_F16) hipLaunchKernelGGL(k_gemm_nt_f32<ZL_F16>, grid, dim3(64), 0, (hipStream_t)s, x, ldx, w, y, (int)n, (int)k, alpha);
+    else hipLaunchKernelGGL(k_gemm_nt_f32<ZL_BF16>, grid, dim3(64), 0, (hipStream_t)s, x, ldx, w, y, (int)n, (int)k, alpha);
+    return zl_launch_status();
 }
 
 extern "C" int zl_greedy_advance(const void* argmax_ws, int64_t m, int64_t n, int32_t* tokens, int32_t* positions,

@@ -46,6 +46,12 @@ struct Scores {
     bool live[kSlots];
 };
 
+// a token's logit e: T bits, or fp32 (DT == ZL_F32: the router Linear of the reference writes fp32 logits, feedforward.cpp:285-286)
+template <int DT>
+__device__ __forceinline__ float load_logit(const uint16_t* __restrict__ logits, int e) {
+    if constexpr (DT == ZL_F32) return reinterpret_cast<const float*>(logits)[e];
+    else return ZT<DT>::to_f32(logits[e]);
+}
 // scores of one token: logits -> softmax / sigmoid / linear.  `neg_sigmoid`: 1 / (1 + expf(-x)) (group_topk) or the
 // reference's 1 / (1 + expf(+x)) (top_k_softmax, sic)
 template <int DT>
@@ -55,7 +61,7 @@ __device__ __forceinline__ Scores route_scores(const uint16_t* __restrict__ logi
     for (int j = 0; j < kSlots; ++j) {
         const int e = lane + 64 * j;
         sc.live[j] = e < num_exp;
-        sc.s[j] = sc.live[j] ? ZT<DT>::to_f32(logits[e]) : -INFINITY;
+        sc.s[j] = sc.live[j] ? load_logit<DT>(logits, e) : -INFINITY;
     }
     if (scoring == SC_SOFTMAX) {
         float mx = -1e20f;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(64) void k_moe_top_k_softmax(const uint16_t* __rest
                                                           int32_t* __restrict__ out_idx, int renormalize, float weight_scale, int scoring,
                                                           int top_k_ext, int32_t* worker_load, int32_t* expert_load, int num_worker) {
     const int q = blockIdx.x, lane = threadIdx.x;
-    const Scores sc = route_scores<DT>(logits + (size_t)q * num_exp, num_exp, scoring, false, lane);
+    const Scores sc = route_scores<DT>(logits + (size_t)q * num_exp * (DT == ZL_F32 ? 2 : 1), num_exp, scoring, false, lane);
     out_v += (size_t)q * top_k_ext;
     out_idx += (size_t)q * top_k_ext;
     unsigned long long key[kSlots];
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(64) void k_moe_group_topk(const uint16_t* __restric
                                                        float weight_scale, int scoring, int num_group, int topk_group, int num_in_group,
                                                        int top_k_ext, int32_t* worker_load, int32_t* expert_load, int num_worker) {
     const int q = blockIdx.x, lane = threadIdx.x;
-    const Scores sc = route_scores<DT>(logits + (size_t)q * num_exp, num_exp, scoring, true, lane);
+    const Scores sc = route_scores<DT>(logits + (size_t)q * num_exp * (DT == ZL_F32 ? 2 : 1), num_exp, scoring, true, lane);
     out_v += (size_t)q * top_k_ext;
     out_idx += (size_t)q * top_k_ext;
     float sel[kSlots];                                      // what the selection looks at: score + bias
@@ -216,6 +222,9 @@ int zl_moe_top_k_softmax(const uint16_t* logits, int64_t tokens, int num_exp, in
     else if (dtype == ZL_BF16)
         hipLaunchKernelGGL(k_moe_top_k_softmax<ZL_BF16>, dim3((unsigned)tokens), dim3(64), 0, (hipStream_t)s, logits, num_exp, top_k, out_v, out_idx,
                            renormalize, weight_scale, scoring, top_k_ext, worker_load, expert_load, num_worker);
+    else if (dtype == ZL_F32)
+        hipLaunchKernelGGL(k_moe_top_k_softmax<ZL_F32>, dim3((unsigned)tokens), dim3(64), 0, (hipStream_t)s, logits, num_exp, top_k, out_v, out_idx,
+                           renormalize, weight_scale, scoring, top_k_ext, worker_load, expert_load, num_worker);
     else
         return ZL_EDTYPE;
     return zl_launch_status();
@@ -239,6 +248,10 @@ int zl_moe_group_topk(const uint16_t* logits, const float* correction_bias, int6
                            num_worker);
     else if (dtype == ZL_BF16)
         hipLaunchKernelGGL(k_moe_group_topk<ZL_BF16>, grid, block, 0, (hipStream_t)s, logits, correction_bias, num_exp, top_k, out_v, out_idx,
+                           renormalize, weight_scale, scoring, num_group, topk_group, num_exp / num_group, top_k_ext, worker_load, expert_load,
+                           num_worker);
+    else if (dtype == ZL_F32)
+        hipLaunchKernelGGL(k_moe_group_topk<ZL_F32>, grid, block, 0, (hipStream_t)s, logits, correction_bias, num_exp, top_k, out_v, out_idx,
                            renormalize, weight_scale, scoring, num_group, topk_group, num_exp / num_group, top_k_ext, worker_load, expert_load,
                            num_worker);
     else

@@ -57,7 +57,12 @@ Gemm::Gemm(const Context&, DataType dtype, bool transA, bool transB, float alpha
 Gemm::~Gemm() = default;
 void Gemm::scale_output(float factor) { pimpl->alpha *= factor; }
 void Gemm::set_output_type(DataType dtype) {
-    BM_ASSERT(dtype == pimpl->out_type, "Gemm::set_output_type: this boundary produces the input type (int32 for int8, half for fp8)");
+    // fp32 output of a half / bf16 product (the MoE router's logits): zl_gemm_nt_f32, no rounding to T in between
+    if (dtype == DataType::kFloat && (pimpl->dtype == DataType::kHalf || pimpl->dtype == DataType::kBFloat16)) {
+        pimpl->out_type = DataType::kFloat;
+        return;
+    }
+    BM_ASSERT(dtype == pimpl->out_type, "Gemm::set_output_type: this boundary produces the input type (int32 for int8, half for fp8; fp32 on request for half / bf16)");
 }
 void Gemm::set_compute_type(cublasComputeType_t) {}    // always fp32 (int32) accumulation
 void Gemm::set_algo_id(int, int, bool) {}
@@ -101,6 +106,11 @@ Tensor Gemm::forward(const Context& ctx, const Tensor& A0, const Tensor& B0, Ten
         return out;
     }
     const int dt = zdt(pimpl->dtype);
+    if (pimpl->out_type == DataType::kFloat) {
+        BM_ASSERT(!bias || !bias->numel(), "Gemm(fp32 output): no bias");
+        zl_check(zl_gemm_nt_f32(A.data<uint16_t>(), lda, B.data<uint16_t>(), out.data<float>(), m, n, k, pimpl->alpha, dt, st_of(ctx)), "Gemm (fp32 output)");
+        return out;
+    }
     const uint16_t* bp = bias && bias->numel() ? bias->data<uint16_t>() : nullptr;
     if (m <= 4 || k % 128 != 0)
         zl_check(zl_gemm_nt_small_m(A.data<uint16_t>(), lda, B.data<uint16_t>(), bp, out.data<uint16_t>(), m, n, k, pimpl->alpha, dt, nullptr,

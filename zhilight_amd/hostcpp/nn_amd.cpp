@@ -584,14 +584,17 @@ static int scoring_code(const std::string& f) {
     if (f == "linear") return 3;
     BM_EXCEPTION("unknown scoring_func " + f);
 }
+static int logit_code(DataType t) {      // router logits: T, or fp32 (Linear::set_output_type(kFloat))
+    return t == DataType::kFloat ? ZL_F32 : zdt(t);
+}
 std::tuple<Tensor, Tensor> top_k_softmax(const Context& ctx, const Tensor& input, const Tensor& worker_load, const Tensor& expert_load, int k,
                                          int k_ext, bool norm_topk_prob, float weight_scale, const std::string& scoring_func) {
     BM_ASSERT_EQ(input.ndim(), 2, "Wrong input dim");
     BM_ASSERT_LE(k, 16, "k too big");
     Tensor out = ctx.tensor({input.size(0), (size_t)k_ext}, DataType::kFloat), out_idx = ctx.tensor({input.size(0), (size_t)k_ext}, DataType::kInt32);
     BM_HIPRT_ASSERT(hipMemsetAsync(out_idx.data(), 0, out_idx.nbytes(), ctx.current_cuda_stream()));
-    zl_check(zl_moe_top_k_softmax(u16(input), input.size(0), (int)input.size(1), k, k_ext, norm_topk_prob, weight_scale, scoring_code(scoring_func),
-                                  zdt(input.dtype()), out.data<float>(), out_idx.data<int32_t>(),
+    zl_check(zl_moe_top_k_softmax((const uint16_t*)input.data(), input.size(0), (int)input.size(1), k, k_ext, norm_topk_prob, weight_scale, scoring_code(scoring_func),
+                                  logit_code(input.dtype()), out.data<float>(), out_idx.data<int32_t>(),
                                   worker_load.numel() ? worker_load.data<int32_t>() : nullptr,
                                   expert_load.numel() ? expert_load.data<int32_t>() : nullptr, ctx.world_size(), st_of(ctx)), "top_k_softmax");
     return std::make_tuple(out, out_idx);
@@ -607,9 +610,9 @@ std::tuple<Tensor, Tensor> group_topk_softmax(const Context& ctx, const Tensor& 
         BM_ASSERT_EQ(score_correction_bias.dtype(), DataType::kFloat, "wrong correction_bias dtype");
     }
     Tensor out = ctx.tensor({input.size(0), (size_t)top_k_ext}, DataType::kFloat), out_idx = ctx.tensor({input.size(0), (size_t)top_k_ext}, DataType::kInt32);
-    zl_check(zl_moe_group_topk(u16(input), score_correction_bias.numel() ? score_correction_bias.data<float>() : nullptr, input.size(0),
+    zl_check(zl_moe_group_topk((const uint16_t*)input.data(), score_correction_bias.numel() ? score_correction_bias.data<float>() : nullptr, input.size(0),
                                (int)input.size(1), top_k, top_k_ext, norm_topk_prob, weight_scale, scoring_code(scoring_func), num_group, topk_group,
-                               zdt(input.dtype()), out.data<float>(), out_idx.data<int32_t>(),
+                               logit_code(input.dtype()), out.data<float>(), out_idx.data<int32_t>(),
                                worker_load.numel() ? worker_load.data<int32_t>() : nullptr,
                                expert_load.numel() ? expert_load.data<int32_t>() : nullptr, ctx.world_size(), st_of(ctx)), "group_topk_softmax");
     return std::make_tuple(out, out_idx);

@@ -23,6 +23,7 @@
 #include "model/model_context.h"
 #include "model/rag_buffer_context.h"
 #include "nn/block/block.h"
+#include "nn/feedforward/feedforward.h"
 #include "nn/layernorm/layernorm.h"
 #include "zhilight_amd.h"
 
@@ -245,9 +246,48 @@ private:
     std::shared_ptr<model::RagBufferContext> rag_;
 };
 
+// One reference nn::FeedForward (dense, or the MoE implementations feedforward.cpp picks from its switches at construction:
+// MOEImpl -- host routing, or its device dispatch route under MOE_GPU_DISPATCH_THRES -- and GPTQMOE under FUSE_GPTQ_MOE)
+class RefFeedForward {
+public:
+    // moe = (num_experts, top_k, moe_intermediate_size, shared_expert_intermediate_size), zeros for the dense layer
+    RefFeedForward(int dim_model, int dim_ff, const std::vector<int>& moe, bool norm_topk_prob, float routed_scaling_factor, int quant_type, int group_size,
+                   int device)
+        : cfg_("llama", 1, dim_model, 8, dim_model / 8, dim_ff, 1024, 1e-5f, 8, DataType::kHalf), ctx_(device) {
+        if (moe.size() == 4 && moe[0] > 0) {
+            cfg_.moe_num_experts = moe[0]; cfg_.moe_top_k = moe[1]; cfg_.moe_intermediate_size = moe[2]; cfg_.shared_expert_intermediate_size = moe[3];
+            cfg_.norm_topk_prob = norm_topk_prob; cfg_.routed_scaling_factor = routed_scaling_factor;
+        }
+        model::QuantConfig qc(quant_type);
+        qc.group_size = group_size;
+        ctx_.set_current_layer(0);
+        ff_.reset(new nn::FeedForward(ctx_, cfg_, qc, false));
+    }
+    void load(const std::map<std::string, py::array>& arrays, const std::string& prefix) {
+        std::map<std::string, const Tensor> sd;
+        for (auto& kv : arrays) sd.emplace(kv.first, host_tensor(kv.second, kv.first));
+        ff_->load_state_dict(ctx_, sd, prefix, false);
+    }
+    py::array forward(const py::array& x) {
+        Tensor dx = to_device(ctx_, x, "x");
+        return to_numpy(ctx_, ff_->forward(ctx_, dx));
+    }
+
+private:
+    model::ModelConfig cfg_;
+    Context ctx_;
+    std::unique_ptr<nn::FeedForward> ff_;
+};
+
 }  // namespace
 
 void bind_ref_block(py::module_& m) {
+    py::class_<RefFeedForward>(m, "RefFeedForward")
+        .def(py::init<int, int, const std::vector<int>&, bool, float, int, int, int>(), py::arg("dim_model"), py::arg("dim_ff"),
+             py::arg("moe") = std::vector<int>(), py::arg("norm_topk_prob") = true, py::arg("routed_scaling_factor") = 1.0f, py::arg("quant_type") = 0,
+             py::arg("group_size") = 128, py::arg("device") = 0)
+        .def("load", &RefFeedForward::load)
+        .def("forward", &RefFeedForward::forward);
     py::class_<RefEncoderLayer>(m, "RefEncoderLayer")
         .def(py::init<int, int, int, int, int, float, float, int, int, int>(), py::arg("dim_model"), py::arg("num_heads"), py::arg("num_kv_heads"),
              py::arg("dim_head"), py::arg("dim_ff"), py::arg("rope_theta") = 10000.0f, py::arg("eps") = 1e-5f, py::arg("quant_type") = 5,
