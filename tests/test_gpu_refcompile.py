@@ -469,3 +469,46 @@ def test_reference_moe_feedforward(ref, monkeypatch, route):
         want = _moe_reference(sd, x, e, k, shared)
         err = np.abs(got - want).max() / np.abs(want).max()
         assert got.shape == (n, dm) and np.isfinite(got).all() and err <= 4e-3, (route, n, err)
+
+
+@pytest.mark.parametrize("tokens", [5, 40])
+def test_reference_fp8_block_moe_equals_the_python_flow(ref, dev, monkeypatch, tokens):
+    """Config 5's feed-forward in the reference's own code: FP8BlockMOE (feedforward.cpp:922-1240, GROUPED_FP8_GEMM=1) -- experts'
+    Fp8Block linears fused at load (Linear::fuse), router -> top_k_softmax -> host dispatch -> 64-aligned grouped input (per-token
+    FP8 cast + scatter_update_dim0) -> three grouped FP8 block GEMMs (DeepGEMM's C entry point = zl_fp8_block_gemm_group) ->
+    sum_experts -> shared expert.  zhilight_amd/moe.py strings the same launchers together in Python: the two must return the SAME
+    BITS (same kernels, same order, same layouts), which pins the Python mirror to the reference's flow."""
+    import torch
+    from zhilight_amd.moe import Fp8BlockMoE
+    monkeypatch.setenv("GROUPED_FP8_GEMM", "1")
+    monkeypatch.setenv("MOE_EXP_PARALLEL", "1")       # (the grouped layout is built for expert parallelism only, feedforward.cpp:993-998; one rank here)
+    g = torch.Generator(device="cpu").manual_seed(7 + tokens)
+    e, k, dim, ff, ffs = 8, 2, 256, 384, 512
+
+    def codes(*shape):
+        return (torch.randint(0, 0x78, shape, generator=g, dtype=torch.int32) | (torch.randint(0, 2, shape, generator=g, dtype=torch.int32) << 7)).to(torch.uint8)
+
+    def scales(*shape):
+        return torch.rand(shape, generator=g) * 0.008 + 0.002
+
+    router = (torch.randn(e, dim, generator=g) * 0.5).to(torch.bfloat16)
+    W = {n: (codes(e, *shp), scales(e, shp[0] // 128, shp[1] // 128)) for n, shp in (("w_in", (ff, dim)), ("w_gated", (ff, dim)), ("w_out", (dim, ff)))}
+    S = {n: (codes(*shp), scales(shp[0] // 128, shp[1] // 128)) for n, shp in (("w_in", (ffs, dim)), ("w_gated", (ffs, dim)), ("w_out", (dim, ffs)))}
+    sd = {"f.router.weight": router.view(torch.int16).numpy()}
+    for n, (c, s) in W.items():
+        for i in range(e):
+            sd[f"f.experts.{i}.{n}.weight"] = np.ascontiguousarray(c[i].numpy().view(np.int8))
+            sd[f"f.experts.{i}.{n}.weight_scale_inv"] = np.ascontiguousarray(s[i].numpy())
+    for n, (c, s) in S.items():
+        sd[f"f.shared_expert.{n}.weight"] = np.ascontiguousarray(c.numpy().view(np.int8))
+        sd[f"f.shared_expert.{n}.weight_scale_inv"] = np.ascontiguousarray(s.numpy())
+    layer = ref.RefFeedForward(dim, 1024, moe=[e, k, ff, ffs], quant_type=10, bf16=True)       # QuantType::FP8_Block
+    layer.load(sd, "f")
+    d = lambda t: t.to(dev)
+    moe = Fp8BlockMoE(d(router), d(W["w_in"][0]), d(W["w_in"][1]), d(W["w_gated"][0]), d(W["w_gated"][1]), d(W["w_out"][0]), d(W["w_out"][1]), top_k=k,
+                      shared=tuple(d(t) for n in ("w_in", "w_gated", "w_out") for t in S[n]))
+    x = torch.randn(tokens, dim, generator=g).to(torch.bfloat16)
+    got = layer.forward(np.ascontiguousarray(x.view(torch.int16).numpy()))
+    want = moe.forward(d(x)).view(torch.int16).cpu().numpy().view(np.uint16)
+    assert got.shape == (tokens, dim) and got.dtype == np.uint16
+    assert np.array_equal(got, want), float((got != want).mean())

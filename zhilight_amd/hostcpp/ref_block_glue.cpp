@@ -252,8 +252,8 @@ class RefFeedForward {
 public:
     // moe = (num_experts, top_k, moe_intermediate_size, shared_expert_intermediate_size), zeros for the dense layer
     RefFeedForward(int dim_model, int dim_ff, const std::vector<int>& moe, bool norm_topk_prob, float routed_scaling_factor, int quant_type, int group_size,
-                   int device)
-        : cfg_("llama", 1, dim_model, 8, dim_model / 8, dim_ff, 1024, 1e-5f, 8, DataType::kHalf), ctx_(device) {
+                   int device, bool bf16)
+        : cfg_("llama", 1, dim_model, 8, dim_model / 8, dim_ff, 1024, 1e-5f, 8, bf16 ? DataType::kBFloat16 : DataType::kHalf), ctx_(device), bf16_(bf16) {
         if (moe.size() == 4 && moe[0] > 0) {
             cfg_.moe_num_experts = moe[0]; cfg_.moe_top_k = moe[1]; cfg_.moe_intermediate_size = moe[2]; cfg_.shared_expert_intermediate_size = moe[3];
             cfg_.norm_topk_prob = norm_topk_prob; cfg_.routed_scaling_factor = routed_scaling_factor;
@@ -268,14 +268,24 @@ public:
         for (auto& kv : arrays) sd.emplace(kv.first, host_tensor(kv.second, kv.first));
         ff_->load_state_dict(ctx_, sd, prefix, false);
     }
+    // x: float16, or -- bf16 layer -- the bf16 bits as int16 / uint16 (numpy has no bfloat16); the result likewise
     py::array forward(const py::array& x) {
         Tensor dx = to_device(ctx_, x, "x");
-        return to_numpy(ctx_, ff_->forward(ctx_, dx));
+        if (bf16_ && dx.dtype() == DataType::kInt16) dx = dx.view_type(dx.shape(), DataType::kBFloat16);
+        Tensor y = ff_->forward(ctx_, dx);
+        if (y.dtype() == DataType::kBFloat16) {
+            std::vector<py::ssize_t> shape(y.shape().begin(), y.shape().end());
+            py::array out(py::dtype("uint16"), shape);
+            y.to_buffer(out.mutable_data(), ctx_.current_cuda_stream());
+            return out;
+        }
+        return to_numpy(ctx_, y);
     }
 
 private:
     model::ModelConfig cfg_;
     Context ctx_;
+    bool bf16_;
     std::unique_ptr<nn::FeedForward> ff_;
 };
 
@@ -283,9 +293,9 @@ private:
 
 void bind_ref_block(py::module_& m) {
     py::class_<RefFeedForward>(m, "RefFeedForward")
-        .def(py::init<int, int, const std::vector<int>&, bool, float, int, int, int>(), py::arg("dim_model"), py::arg("dim_ff"),
+        .def(py::init<int, int, const std::vector<int>&, bool, float, int, int, int, bool>(), py::arg("dim_model"), py::arg("dim_ff"),
              py::arg("moe") = std::vector<int>(), py::arg("norm_topk_prob") = true, py::arg("routed_scaling_factor") = 1.0f, py::arg("quant_type") = 0,
-             py::arg("group_size") = 128, py::arg("device") = 0)
+             py::arg("group_size") = 128, py::arg("device") = 0, py::arg("bf16") = false)
         .def("load", &RefFeedForward::load)
         .def("forward", &RefFeedForward::forward);
     py::class_<RefEncoderLayer>(m, "RefEncoderLayer")

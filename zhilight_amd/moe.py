@@ -42,7 +42,7 @@ class Fp8BlockMoE:
 
     def route(self, x):
         """(ids (T, k) int32, weights (T, k) fp32, all_loads (E + 1,) int32: tokens per expert | per rank) -- FeedForward::route"""
-        logits = ops.gemm_nt(x, self.router)
+        logits = ops.gemm_nt_f32(x, self.router)                               # fp32 logits, as the reference's router Linear (set_output_type(kFloat))
         all_loads = torch.zeros(self.num_experts + 1, dtype=torch.int32, device=x.device)
         expert_load, worker_load = all_loads[:self.num_experts], all_loads[self.num_experts:]
         if self.topk_group > 1:

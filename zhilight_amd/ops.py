@@ -51,6 +51,11 @@ def _dt(t):
     raise ZLError(f"unsupported activation dtype {t.dtype}")
 
 
+def _dt_logits(t):
+    """router logits: T, or fp32 (ZL_F32 = 2) -- the reference's router Linear writes fp32 logits (feedforward.cpp:285-286)"""
+    return 2 if t.dtype == torch.float32 else _dt(t)
+
+
 def _chk_cuda(*ts):
     for t in ts:
         if t is not None and not (t.is_cuda and t.is_contiguous()):
@@ -573,6 +578,19 @@ def gemm_nt(x, weight, bias=None, alpha=1.0, out=None):
         _chk_out(out, m, n, x.dtype, x.device, "gemm_nt")
     check(lib().zl_gemm_nt(_p(x2), _i(x2.stride(0)), _p(weight), _p(bias), _p(out), _i(m), _i(n), _i(k), _f(alpha),
                            C.c_int(_dt(x)), _stream()), "gemm_nt")
+    return out
+
+
+def gemm_nt_f32(x, weight, alpha=1.0):
+    """functions::Gemm(trans_b=True) with set_output_type(kFloat): fp32 output, no rounding to T (the MoE router's logits)"""
+    _chk_cuda(x, weight)
+    x2 = x.reshape(-1, x.shape[-1])
+    m, k = x2.shape
+    n = weight.shape[0]
+    if weight.shape[1] != k or weight.dtype != x.dtype:
+        raise ZLError("size K / dtype mismatch")
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    check(lib().zl_gemm_nt_f32(_p(x2), _i(x2.stride(0)), _p(weight), _p(out), _i(m), _i(n), _i(k), _f(alpha), C.c_int(_dt(x)), _stream()), "gemm_nt_f32")
     return out
 
 
@@ -1437,7 +1455,7 @@ def moe_top_k_softmax(logits, top_k, top_k_ext=None, norm_topk_prob=False, weigh
     v = torch.empty((t, ext), dtype=torch.float32, device=logits.device)
     idx = torch.zeros((t, ext), dtype=torch.int32, device=logits.device)
     check(lib().zl_moe_top_k_softmax(_p(logits), _i(t), C.c_int(e), C.c_int(top_k), C.c_int(ext), C.c_int(int(norm_topk_prob)), _f(weight_scale),
-                                     C.c_int(_SCORING[scoring_func]), C.c_int(_dt(logits)), _p(v), _p(idx), _p(worker_load), _p(expert_load),
+                                     C.c_int(_SCORING[scoring_func]), C.c_int(_dt_logits(logits)), _p(v), _p(idx), _p(worker_load), _p(expert_load),
                                      C.c_int(num_worker), _stream()), "moe_top_k_softmax")
     return v, idx
 
@@ -1451,7 +1469,7 @@ def moe_group_topk(logits, score_correction_bias, num_group, topk_group, top_k, 
     v = torch.empty((t, ext), dtype=torch.float32, device=logits.device)
     idx = torch.zeros((t, ext), dtype=torch.int32, device=logits.device)
     check(lib().zl_moe_group_topk(_p(logits), _p(score_correction_bias), _i(t), C.c_int(e), C.c_int(top_k), C.c_int(ext), C.c_int(int(norm_topk_prob)),
-                                  _f(weight_scale), C.c_int(_SCORING[scoring_func]), C.c_int(num_group), C.c_int(topk_group), C.c_int(_dt(logits)),
+                                  _f(weight_scale), C.c_int(_SCORING[scoring_func]), C.c_int(num_group), C.c_int(topk_group), C.c_int(_dt_logits(logits)),
                                   _p(v), _p(idx), _p(worker_load), _p(expert_load), C.c_int(num_worker), _stream()), "moe_group_topk")
     return v, idx
 
