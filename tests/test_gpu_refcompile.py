@@ -512,3 +512,49 @@ def test_reference_fp8_block_moe_equals_the_python_flow(ref, dev, monkeypatch, t
     want = moe.forward(d(x)).view(torch.int16).cpu().numpy().view(np.uint16)
     assert got.shape == (tokens, dim) and got.dtype == np.uint16
     assert np.array_equal(got, want), float((got != want).mean())
+
+
+def test_reference_gptq_fused_moe_decode(ref, oracle, monkeypatch):
+    """FUSE_GPTQ_MOE=1: the reference's GPTQMOE (feedforward.cpp:871-918) for a decode row -- the experts' GPTQ linears fused at load
+    (Linear::fuse over Int4GPTQ), router -> top_k_softmax, then nn::gptq::gemm_moe_up / gemm_moe_down (the fused MoE GEMVs of
+    q_gemm_k_major.cu:243-520 = k_w4a16_moe behind the reference's call) and the shared expert; and the same layer on six rows, which
+    GPTQMOE hands to MOEImpl's per-expert route.  Against an fp64 restatement on the dequantised weights."""
+    rng = np.random.default_rng(11)
+    monkeypatch.setenv("FUSE_GPTQ_MOE", "1")
+    dm, e, k, inter, shared, g = 512, 8, 2, 256, 512, 128
+    sd, km = {"f.router.weight": (rng.standard_normal((e, dm)) / np.sqrt(dm)).astype(np.float16)}, {}
+    names = [f"experts.{i}.{n}" for i in range(e) for n in ("w_in", "w_gated", "w_out")] + [f"shared_expert.{n}" for n in ("w_in", "w_gated", "w_out")]
+    for name in names:
+        ff = shared if name.startswith("shared") else inter
+        kk, nn_ = (ff, dm) if name.endswith("w_out") else (dm, ff)
+        qw, qz, sc = synth.gptq_hf(rng, kk, nn_, g)
+        km[name] = oracle.gptq_prepare_k_major(qw, qz, sc, g)
+        sd[f"f.{name}.qweight"] = np.ascontiguousarray(qw.view(np.int32))
+        sd[f"f.{name}.qzeros"] = np.ascontiguousarray(qz.view(np.int32))
+        sd[f"f.{name}.scales"] = np.ascontiguousarray(sc.view(np.float16))
+    ref.weight_cache_clear()
+    layer = ref.RefFeedForward(dm, 1024, moe=[e, k, inter, shared], quant_type=5, group_size=g)
+    layer.load(sd, "f")
+    f = lambda a: a.astype(np.float64)
+    h16 = lambda a: a.astype(np.float16)
+    lin = lambda name, a: oracle.gptq_gemm_k_major_exact(oracle.h2u(a), *km[name])
+
+    def expert(prefix, xt):
+        gt, up = f(h16(lin(prefix + ".w_in", xt))), f(h16(lin(prefix + ".w_gated", xt)))
+        return lin(prefix + ".w_out", h16(gt / (1.0 + np.exp(-gt)) * up))
+    for n in (1, 6):
+        x = synth.act(rng, n, dm)
+        got = layer.forward(x).astype(np.float64)
+        logits = (f(x) @ f(sd["f.router.weight"]).T).astype(np.float32).astype(np.float64)
+        p = np.exp(logits - logits.max(axis=1, keepdims=True))
+        p /= p.sum(axis=1, keepdims=True)
+        want = np.zeros((n, dm))
+        for t in range(n):
+            ids = np.argsort(-p[t], kind="stable")[:k]
+            wts = p[t][ids] / p[t][ids].sum()
+            for i, wt in zip(ids, wts):
+                want[t] += wt * expert(f"experts.{i}", x[t:t + 1])[0]
+            want[t] += expert("shared_expert", x[t:t + 1])[0]
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert got.shape == (n, dm) and np.isfinite(got).all() and err <= 4e-3, (n, err)
+    ref.weight_cache_clear()
