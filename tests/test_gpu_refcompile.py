@@ -558,3 +558,47 @@ def test_reference_gptq_fused_moe_decode(ref, oracle, monkeypatch):
         err = np.abs(got - want).max() / np.abs(want).max()
         assert got.shape == (n, dm) and np.isfinite(got).all() and err <= 4e-3, (n, err)
     ref.weight_cache_clear()
+
+
+def test_reference_llama_model_decode_steps(ref, oracle):
+    """The north star's path from its TOP, in the reference's own code: model::LLaMA (src/model/llama.cpp, compiled unmodified) ->
+    LLaMA::encode (:75-151) -> EncoderLayer::forward x layers (block.cpp) -> Attention / FeedForward / Linear (attention.cpp,
+    feedforward.cpp, linear.cpp) -> get_logits (:159-165), inside the reference's ModelContext with its DynBatchContext /
+    RagBufferContext -- whole-model decode steps on the GPU, three tasks, against the SAME CPU oracle model and the same 1e-3 bar the
+    repository's own LLaMA is held to (tests/test_gpu_model.py::test_decode_steps_match_oracle)."""
+    from zhilight_amd.llama import ModelConfig
+    from test_gpu_model import OracleModel, _hf_state
+    rng = np.random.default_rng(0)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2, eps=1e-5, rope_theta=5e5)
+    g, batch, len_buf = 128, 3, 64
+    sd = _hf_state(rng, cfg, g)
+    names = {"self_attn.q_proj": "attn.project_q", "self_attn.k_proj": "attn.project_k", "self_attn.v_proj": "attn.project_v", "self_attn.o_proj": "attn.attn_out",
+             "mlp.gate_proj": "ff.w_in", "mlp.up_proj": "ff.w_gated", "mlp.down_proj": "ff.w_out", "input_layernorm": "ln_attn",
+             "post_attention_layernorm": "ln_ff"}
+    rsd = {"m.token_embedding.weight": sd["model.embed_tokens.weight"], "m.lm_head.weight": sd["lm_head.weight"], "m.output_layernorm.weight": sd["model.norm.weight"]}
+    for key, val in sd.items():                       # the reference's parameter names (what its own loader renames the HF names to)
+        if key.startswith("model.layers."):
+            _, _, i, rest = key.split(".", 3)
+            for hf, zl in names.items():
+                if rest.startswith(hf + "."):
+                    rsd[f"m.layers.{i}.{zl}.{rest[len(hf) + 1:]}"] = np.ascontiguousarray(val)
+    ref.weight_cache_clear()
+    model = ref.RefLLaMA(cfg.num_layers, cfg.dim_model, cfg.num_heads, cfg.num_kv_heads, cfg.dim_head, cfg.dim_ff, cfg.vocab_size, eps=cfg.eps,
+                         rope_theta=cfg.rope_theta, quant_type=5, group_size=g)
+    model.load(rsd, "m")
+    empty = np.zeros((cfg.num_layers, 0, cfg.num_kv_heads, cfg.dim_head), np.float16)
+    for b in range(batch):
+        model.set_history(b, len_buf, empty, empty)
+    om = OracleModel(oracle, cfg, sd, g, batch, len_buf)
+    om.rope_kind = "plain"
+    tokens = rng.integers(0, cfg.vocab_size, batch).astype(np.int32)
+    for step in range(3):
+        pos = np.full(batch, step, np.int32)
+        mask = np.concatenate([(np.arange(len_buf) <= step).astype(np.int8) for _ in range(batch)])
+        got = model.decode_step(tokens, pos, mask).astype(np.float64)
+        want, _ = om.step(tokens, [step] * batch)
+        scale = np.abs(want).max()
+        assert got.shape == (batch, cfg.vocab_size) and np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 1e-3 * scale + 2.0 ** -11 * scale, (step, np.abs(got - want).max() / scale)
+        tokens = want.argmax(axis=1).astype(np.int32)
+    ref.weight_cache_clear()

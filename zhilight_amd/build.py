@@ -115,12 +115,12 @@ REFDIR = os.path.join(HERE, "_ref")
 # reference host translation units compiled UNMODIFIED, from where they lie, against hostcpp/refshim + the bmengine-on-HIP
 # headers ("prove the boundary compiles the reference")
 REF_TUS = ("src/nn/linear/linear.cpp", "src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp",
-           "src/nn/feedforward/feedforward.cpp", "src/nn/block/block.cpp")
+           "src/nn/feedforward/feedforward.cpp", "src/nn/block/block.cpp", "src/model/llama.cpp")
 # reference translation units that are compiled unmodified and LINK-CHECKED only (build_refcheck): every name they reference in the
 # namespaces the boundary stands in for must be defined by the boundary under the same mangled name -- i.e. with the reference's
 # exact signature; names of layers that are not on the path (their device code lives in the reference's .cu files) are listed
 REF_CHECK_TUS = ("src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp", "src/nn/feedforward/feedforward.cpp",
-                 "src/nn/block/block.cpp")
+                 "src/nn/block/block.cpp", "src/model/llama.cpp")
 REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_op::", "nn::top_k_softmax(", "nn::group_topk_softmax(",
                         "nn::sum_experts(", "nn::route_shared_lb(", "nn::plus_for_sort(", "nn::calc_reverse_idx(",
                         "nn::fill_m_indices_padded_indices(", "nn::gate_mul_inplace(", "nn::gate_fuse(", "nn::gelu_inplace(", "nn::silu_inplace(",
@@ -148,7 +148,7 @@ def build_refcompile(force=False, verbose=False):
     if not all(os.path.exists(t) for t in tus):
         return target if os.path.exists(target) else None
     shim = os.path.join(HOSTCPP, "refshim")
-    own = [os.path.join(HOSTCPP, f) for f in HOSTCPP_SOURCES] + [os.path.join(shim, "ref_glue.cpp"), os.path.join(HOSTCPP, "ref_attention_glue.cpp"), os.path.join(HOSTCPP, "ref_block_glue.cpp")]
+    own = [os.path.join(HOSTCPP, f) for f in HOSTCPP_SOURCES] + [os.path.join(shim, "ref_glue.cpp"), os.path.join(HOSTCPP, "ref_attention_glue.cpp"), os.path.join(HOSTCPP, "ref_block_glue.cpp"), os.path.join(HOSTCPP, "ref_model_glue.cpp")]
     deps = tus + own + [os.path.join(HOSTCPP, f) for f in HOSTCPP_HEADERS] + [os.path.join(HERE, "..", "include", "zhilight_amd.h")]
     for root, _, files in os.walk(shim):
         deps += [os.path.join(root, f) for f in files]

@@ -141,7 +141,8 @@ private:
 }  // namespace
 
 void bind_ref_attention(py::module_& m);      // hostcpp/ref_attention_glue.cpp: the reference's nn::Attention decode / encode paths
-void bind_ref_block(py::module_& m);          // hostcpp/ref_block_glue.cpp: the reference's nn::EncoderLayer
+void bind_ref_block(py::module_& m);          // hostcpp/ref_block_glue.cpp: the reference's nn::EncoderLayer, nn::FeedForward
+void bind_ref_model(py::module_& m);          // hostcpp/ref_model_glue.cpp: the reference's model::LLaMA
 
 PYBIND11_MODULE(zl_reflinear, m) {
     m.doc() = "the reference's nn::Linear (src/nn/linear/linear.cpp, compiled unmodified) on the MI355X boundary";
@@ -155,6 +156,7 @@ PYBIND11_MODULE(zl_reflinear, m) {
         .def("layer_type", &RefLinear::layer_type);
     bind_ref_attention(m);
     bind_ref_block(m);
+    bind_ref_model(m);
     m.def("weight_cache_size", &nn::gptq::amd_weight_cache_size);
     m.def("weight_cache_clear", &nn::gptq::amd_weight_cache_clear);
     py::register_exception<BMEngineException>(m, "BMEngineException");
