@@ -560,6 +560,20 @@ def test_reference_gptq_fused_moe_decode(ref, oracle, monkeypatch):
     ref.weight_cache_clear()
 
 
+def test_reference_llama_model_production_switches(dev):
+    """The same whole-model run under the switches a deployment sets (read once per process by the reference, hence a child process):
+    CPM_FUSE_QKV=1 (one qkv projection per layer, Linear::fuse at load), ROPE_CACHE=1 (RopePreparer's tables in the context ->
+    rope_qk_cache), CPM_FUSE_FF_IN=1 (w_in | w_gated as one projection -> gate_fuse)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CPM_FUSE_QKV="1", ROPE_CACHE="1", CPM_FUSE_FF_IN="1", ZL_REFLLAMA_CHILD="1")
+    code = ("import sys, os; sys.path.insert(0, os.path.join(%r, 'tests')); import pytest; "
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', os.path.join(%r, 'tests', 'test_gpu_refcompile.py'), '-k', 'llama_model_decode_steps']))") % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout, r.stdout[-2000:]
+
+
 def test_reference_llama_model_decode_steps(ref, oracle):
     """The north star's path from its TOP, in the reference's own code: model::LLaMA (src/model/llama.cpp, compiled unmodified) ->
     LLaMA::encode (:75-151) -> EncoderLayer::forward x layers (block.cpp) -> Attention / FeedForward / Linear (attention.cpp,
