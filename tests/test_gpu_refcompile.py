@@ -616,3 +616,51 @@ def test_reference_llama_model_decode_steps(ref, oracle):
         assert np.abs(got - want).max() <= 1e-3 * scale + 2.0 ** -11 * scale, (step, np.abs(got - want).max() / scale)
         tokens = want.argmax(axis=1).astype(np.int32)
     ref.weight_cache_clear()
+
+
+def test_reference_llama_model_prompt_then_decode(ref, oracle):
+    """The reference's LLaMA::encode on a PROMPT (the encode part of a dynamic batch: attn_encode_group -> TransformerBuffer::copy +
+    FlashDecoding::mha_fwd per layer; the linears take their M > 40 branch) in two chunks, then decode steps on top of the cache it
+    left -- logits against the CPU oracle model's prefill / step at 1e-3, the prompt's K rows against the oracle's."""
+    from zhilight_amd.llama import ModelConfig
+    from test_gpu_model import OracleModel, _hf_state
+    rng = np.random.default_rng(3)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2, eps=1e-5, rope_theta=5e5)
+    g, s, len_buf = 128, 70, 128
+    sd = _hf_state(rng, cfg, g)
+    names = {"self_attn.q_proj": "attn.project_q", "self_attn.k_proj": "attn.project_k", "self_attn.v_proj": "attn.project_v", "self_attn.o_proj": "attn.attn_out",
+             "mlp.gate_proj": "ff.w_in", "mlp.up_proj": "ff.w_gated", "mlp.down_proj": "ff.w_out", "input_layernorm": "ln_attn",
+             "post_attention_layernorm": "ln_ff"}
+    rsd = {"m.token_embedding.weight": sd["model.embed_tokens.weight"], "m.lm_head.weight": sd["lm_head.weight"], "m.output_layernorm.weight": sd["model.norm.weight"]}
+    for key, val in sd.items():
+        if key.startswith("model.layers."):
+            _, _, i, rest = key.split(".", 3)
+            for hf, zl in names.items():
+                if rest.startswith(hf + "."):
+                    rsd[f"m.layers.{i}.{zl}.{rest[len(hf) + 1:]}"] = np.ascontiguousarray(val)
+    ref.weight_cache_clear()
+    model = ref.RefLLaMA(cfg.num_layers, cfg.dim_model, cfg.num_heads, cfg.num_kv_heads, cfg.dim_head, cfg.dim_ff, cfg.vocab_size, eps=cfg.eps,
+                         rope_theta=cfg.rope_theta, quant_type=5, group_size=g)
+    model.load(rsd, "m")
+    om = OracleModel(oracle, cfg, sd, g, 1, len_buf)
+    om.rope_kind = "plain"
+    prompt = rng.integers(0, cfg.vocab_size, s).astype(np.int32)
+    model.prefill(0, len_buf, np.ascontiguousarray(prompt[:43]), 0)                      # chunk 1 (its logits are not used)
+    got = model.prefill(0, len_buf, np.ascontiguousarray(prompt[43:]), 43).astype(np.float64)
+    want = om.prefill(0, prompt)
+    scale = np.abs(want).max()
+    assert got.shape == (1, cfg.vocab_size) and np.abs(got - want).max() <= 1e-3 * scale + 2.0 ** -11 * scale, np.abs(got - want).max() / scale
+    for li in range(cfg.num_layers):
+        gk = model.get_k(0, li)[:s].astype(np.float64)
+        rk = oracle.u2h(om.kb[li][0][:s]).astype(np.float64)
+        assert np.abs(gk - rk).max() <= 2.0 ** -8 * np.abs(rk).max()
+    tok = want.argmax(axis=1).astype(np.int32)
+    for step in range(2):
+        pos = np.array([s + step], np.int32)
+        mask = (np.arange(len_buf) <= s + step).astype(np.int8)
+        got = model.decode_step(tok, pos, mask).astype(np.float64)
+        want, _ = om.step(tok, [s + step])
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 1e-3 * scale + 2.0 ** -11 * scale, (step, np.abs(got - want).max() / scale)
+        tok = want.argmax(axis=1).astype(np.int32)
+    ref.weight_cache_clear()

@@ -222,6 +222,36 @@ public:
         return out;
     }
 
+    // the prompt of task b through the whole model (the encode part of a dynamic batch: DynBatchContext's e_* fields for one task at
+    // positions pos0 .. pos0 + n - 1) -> the logits of its last token (1, vocab)
+    py::array prefill(int b, int len_buf, const py::array& tokens, int pos0) {
+        const size_t n = (size_t)tokens.shape(0);
+        rag_->resize_task_buf(ctx_, b, (size_t)len_buf);
+        auto dyn = std::make_shared<model::DynBatchContext>();
+        std::vector<int> pos(n);
+        for (size_t i = 0; i < n; ++i) pos[i] = pos0 + (int)i;
+        dyn->e_token = to_device(ctx_, tokens, "e_token");
+        dyn->e_placement = ctx_.tensor_of(pos);
+        dyn->e_position = ctx_.tensor_of(pos);
+        std::vector<int8_t> mask(n * (size_t)len_buf);
+        for (size_t i = 0; i < n; ++i)
+            for (int j = 0; j < len_buf; ++j) mask[i * len_buf + j] = j <= pos0 + (int)i;
+        dyn->e_mask = ctx_.tensor_of(mask);
+        dyn->ev_batch = {b};
+        dyn->ev_input_len = {(int)n};
+        dyn->full_input_len = {pos0 + (int)n};
+        dyn->ev_len_buf = {len_buf};
+        ctx_.set_dyn_batch(dyn);
+        Tensor none;
+        Tensor hidden = model_->encode(ctx_, dyn->e_token, dyn->e_position, none, none, none, none, none, true);      // (n, dim_model), final norm applied
+        Tensor logits = model_->get_logits(ctx_, hidden.slice_dim0(n - 1, n), false);
+        py::array out = to_numpy(ctx_, logits);
+        ctx_.set_dyn_batch(nullptr);
+        return out;
+    }
+    py::array get_k(int b, int layer) { return to_numpy(ctx_, rag_->buf_k(b, layer)); }
+    py::array get_v(int b, int layer) { return to_numpy(ctx_, rag_->buf_v(b, layer)); }
+
 private:
     model::ModelConfig cfg_;
     DummyModel md_;
@@ -239,5 +269,8 @@ void bind_ref_model(py::module_& m) {
              py::arg("quant_type") = 5, py::arg("group_size") = 128, py::arg("device") = 0)
         .def("load", &RefLLaMA::load)
         .def("set_history", &RefLLaMA::set_history)
+        .def("prefill", &RefLLaMA::prefill, py::arg("b"), py::arg("len_buf"), py::arg("tokens"), py::arg("pos0") = 0)
+        .def("get_k", &RefLLaMA::get_k)
+        .def("get_v", &RefLLaMA::get_v)
         .def("decode_step", &RefLLaMA::decode_step);
 }
