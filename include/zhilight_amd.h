@@ -347,6 +347,11 @@ int zl_mask_valid_lens(const int8_t* mask, const int32_t* buf_lens, int32_t* val
 int zl_copy_to_rag_buffer2(const int32_t* placement, const int32_t* buf_lens, const uint16_t* k_src,
                            const uint16_t* v_src, uint16_t* const* k_bufs, uint16_t* const* v_bufs,
                            int64_t b, int64_t len_q, int64_t hkv, int64_t d, int bshd, zl_stream_t s);
+/* the same scatter with the row size in BYTES (row_bytes % 4 == 0) for sources that are not 16-bit: the INT8 KV cache's u8 code rows
+ * (dim_head bytes) and its fp32 scale "rows" (4 bytes; copy_to_rag_buffer2(..., is_scale = true), attention.cpp:663-669) as the
+ * reference issues them one after the other (zl_quant_copy_to_rag_buffer is the fused form). */
+int zl_copy_to_rag_buffer_bytes(const int32_t* placement, const int32_t* buf_lens, const void* k_src, const void* v_src, void* const* k_bufs,
+                                void* const* v_bufs, int64_t b, int64_t len_q, int64_t hkv, int64_t row_bytes, int bshd, zl_stream_t s);
 
 /* Fused decode-step front end: split fused qkv rows, rotate q and k with cached cos/sin, write q
  * and scatter k,v straight into the ragged buffers (rope_qk_cache + copy_to_rag_buffer2 in one
@@ -513,6 +518,10 @@ int zl_w4a16_gemm_attn_merge(const void* attn_workspace, const int32_t* buf_lens
  * ---------------------------------------------------------------------------------------------- */
 int zl_quant_calc_scale_zp(const uint16_t* x, uint8_t* q, float* scale, int64_t m, int64_t k, int q_zero, int dtype,
                            zl_stream_t s);
+/* rows of g codes back to T, out = rn_T((code - q_zero) * scale[row]); q_zero = 128: unsigned cache codes, 0: signed.  Replaces
+ * int8_op::dequant_group (src/nn/quant/int8/quant_reduce_kernel.cu:144-190), which TransformerBuffer::copy uses to hand a prompt
+ * chunk the already cached rows of a quantised buffer (src/kvcache/transformer_buffer.cu:135-151). */
+int zl_dequant_group(const void* q, const float* scale, uint16_t* out, int64_t m, int64_t g, int q_zero, int dtype, zl_stream_t s);
 int zl_quant_copy_to_rag_buffer(const int32_t* placement, const int32_t* buf_lens, const uint16_t* k_src,
                                 const uint16_t* v_src, uint8_t* const* k_bufs, uint8_t* const* v_bufs,
                                 float* const* k_scales, float* const* v_scales, int64_t b, int64_t len_q,

@@ -296,6 +296,103 @@ def test_reference_attention_prompt_chunks_then_decode(ref, oracle):
     ref.weight_cache_clear()
 
 
+def test_reference_attention_int8_kv_cache(dev):
+    """The reference's INT8 KV cache path (KV_CACHE_DTYPE=int8, read by ModelContext::get_kv_cache_config) through its own attention
+    code, in a child process like the other process-wide switches."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KV_CACHE_DTYPE="int8", ZL_REFKV8_CHILD="1")
+    code = ("import sys, os; sys.path.insert(0, os.path.join(%r, 'tests')); import pytest; "
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', os.path.join(%r, 'tests', 'test_gpu_refcompile.py'), '-k', 'kv8_child']))") % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout, r.stdout[-2000:]
+
+
+def _quant_rows_u8(x):
+    """int8_op::quant_calc_scale(x, 127, 128) of rows (..., d) fp16: u8 codes 128 + rint(x * 127 / amax), fp32 scale amax / 127"""
+    xf = x.astype(np.float32)
+    amax = np.abs(xf).max(axis=-1, keepdims=True)
+    bs = np.where(amax > 0, np.float32(127.0) / np.where(amax > 0, amax, 1), 0).astype(np.float32)
+    codes = (128.0 + np.rint(xf * bs)).astype(np.uint8)
+    return codes, (amax[..., 0] / np.float32(127.0)).astype(np.float32)
+
+
+@pytest.mark.skipif(os.environ.get("ZL_REFKV8_CHILD") != "1", reason="runs inside test_reference_attention_int8_kv_cache's child process")
+def test_reference_attention_kv8_child(ref, oracle):
+    """attn_encode_group's quantised branch (attention.cpp:494-514: TransformerBuffer::copy quantises the chunk into the task's u8
+    buffer + fp32 scales, a later chunk gets the cached rows back through dequant_group) and attn_search_rag's
+    (attention.cpp:656-676, :713-737: 2 x quant_calc_scale(127, 128), copy_to_rag_buffer2 for the codes and again, is_scale, for the
+    scales, multi_query_attention_rag_buffer with scale_k / scale_v) -- the reference's control flow over zl_quant_calc_scale_zp,
+    zl_dequant_group, zl_copy_to_rag_buffer_bytes and zl_decode_attn_quant."""
+    rng = np.random.default_rng(123)
+    dm, h, hkv, d, theta, len_buf = 1024, 8, 2, 128, 5e5, 192
+    sd, km = _attn_case(oracle, rng, dm, h, hkv, d)
+    layer = ref.RefAttention(dm, h, hkv, d, rope_theta=theta, num_layers=1)
+    assert layer.cache_quant()
+    layer.load(sd, "a")
+    f = lambda a: a.astype(np.float64)
+    lin = lambda name, a: oracle.gptq_gemm_k_major_exact(oracle.h2u(a), *km[name]).astype(np.float16)
+    deq = lambda c, sc: ((c.astype(np.float32) - 128.0) * sc[..., None]).astype(np.float16)      # dequant_group: one rounding to fp16
+    keys, vals, pos0 = np.zeros((0, hkv, d), np.float16), np.zeros((0, hkv, d), np.float16), 0
+    for n in (100, 28):
+        x = synth.act(rng, n, dm)
+        got = layer.encode(0, 0, len_buf, x, pos0).astype(np.float64)
+        pos = np.arange(pos0, pos0 + n)
+        q = _rope_neox(oracle, lin("project_q", x), pos, d, theta)
+        k = _rope_neox(oracle, lin("project_k", x), pos, d, theta).reshape(n, hkv, d)
+        v = lin("project_v", x).reshape(n, hkv, d)
+        # what the cache holds now, and what a later chunk sees of it
+        kc, ks, vc, vs = layer.get_k(0, 0).view(np.uint8), layer.get_k_scale(0, 0), layer.get_v(0, 0).view(np.uint8), layer.get_v_scale(0, 0)
+        assert kc.shape == (len_buf, hkv, d) and ks.shape == (len_buf, hkv) and ks.dtype == np.float32
+        for name, rows, codes, scales in (("k", k, kc, ks), ("v", v, vc, vs)):
+            wc, wsc = _quant_rows_u8(rows)
+            # (the device's own k / v rows differ from the fp64 restatement by an fp16 ulp here and there: codes within one step)
+            assert np.abs(codes[pos0:pos0 + n].astype(np.int32) - wc.astype(np.int32)).max() <= 1, name
+            assert (codes[pos0:pos0 + n] == wc).mean() >= 0.97, name
+            assert np.abs(scales[pos0:pos0 + n] - wsc).max() <= 2.0 ** -9 * wsc.max(), name
+            assert not codes[pos0 + n:].any() and not scales[pos0 + n:].any(), name
+        keys_seen = np.concatenate([keys, k])          # cached rows (dequantised on an earlier chunk) + this chunk's own rows
+        vals_seen = np.concatenate([vals, v])
+        att = np.zeros((n, h, d))
+        for hh in range(h):
+            kv = hh // (h // hkv)
+            sc = f(q).reshape(n, h, d)[:, hh, :] @ f(keys_seen[:, kv, :]).T / np.sqrt(d)
+            sc = np.where(np.arange(pos0 + n)[None, :] <= pos[:, None], sc, -np.inf)
+            p = np.exp(sc - sc.max(axis=1, keepdims=True))
+            att[:, hh, :] = (p / p.sum(axis=1, keepdims=True)) @ f(vals_seen[:, kv, :])
+        want = oracle.gptq_gemm_k_major_exact(oracle.h2u(att.reshape(n, -1).astype(np.float16)), *km["attn_out"])
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err <= 3e-3, (n, err)
+        pos0 += n
+        keys, vals = deq(kc[:pos0], ks[:pos0]), deq(vc[:pos0], vs[:pos0])
+    # two decode steps over the quantised rows: softmax(scale * sk_j * q.(K_j - 128)) . (sv_j * (V_j - 128)), the new row included
+    for step in range(2):
+        x = synth.act(rng, 1, dm)
+        p1 = np.array([pos0], np.int32)
+        mask = (np.arange(len_buf) <= pos0).astype(np.int8)
+        got = layer.decode_step(0, x, p1, p1.copy(), mask).astype(np.float64)
+        kc, ks, vc, vs = layer.get_k(0, 0).view(np.uint8), layer.get_k_scale(0, 0), layer.get_v(0, 0).view(np.uint8), layer.get_v_scale(0, 0)
+        q = _rope_neox(oracle, lin("project_q", x), p1, d, theta)
+        k1 = _rope_neox(oracle, lin("project_k", x), p1, d, theta).reshape(1, hkv, d)
+        wc, wsc = _quant_rows_u8(k1)
+        assert np.abs(kc[pos0].astype(np.int32) - wc[0].astype(np.int32)).max() <= 1 and np.abs(ks[pos0] - wsc[0]).max() <= 2.0 ** -9 * wsc.max()
+        assert not kc[pos0 + 1:].any() and not ks[pos0 + 1:].any()
+        kd = (f(kc[:pos0 + 1]) - 128.0) * f(ks[:pos0 + 1])[..., None]
+        vd = (f(vc[:pos0 + 1]) - 128.0) * f(vs[:pos0 + 1])[..., None]
+        o = np.zeros((h, d))
+        for hh in range(h):
+            kv = hh // (h // hkv)
+            sc = kd[:, kv, :] @ f(q).reshape(h, d)[hh] / np.sqrt(d)
+            p = np.exp(sc - sc.max())
+            o[hh] = (p / p.sum()) @ vd[:, kv, :]
+        want = oracle.gptq_gemm_k_major_exact(oracle.h2u(o.reshape(1, -1).astype(np.float16)), *km["attn_out"])
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err <= 3e-3, (step, err)
+        pos0 += 1
+    ref.weight_cache_clear()
+
+
 def test_reference_encoder_layer_decode_step(ref, oracle):
     """A whole transformer layer of the reference -- nn::EncoderLayer::forward (src/nn/block/block.cpp:86-143) over its own
     LayerNorm calls, nn::Attention (attention.cpp), the residual adds and nn::FeedForward (feedforward.cpp), all four units compiled

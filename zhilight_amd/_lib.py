@@ -33,13 +33,13 @@ SYMBOLS = [
     "zl_gemm_nt_small_m", "zl_gemm_nt", "zl_gemm_nt_f32", "zl_argmax_workspace_bytes", "zl_gemm_nt_small_m_argmax", "zl_greedy_advance",
     "zl_rmsnorm",
     "zl_w4a16_moe_up", "zl_w4a16_moe_down", "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rope_cos_sin_dynamic", "zl_rope_cos_sin_yarn", "zl_head_norm", "zl_rotary_embedding_qk", "zl_rope_qk_cache", "zl_rope_rotate", "zl_mask_valid_lens",
-    "zl_copy_to_rag_buffer2", "zl_rope_scatter_decode", "zl_w4a16_qkv_rope_scatter", "zl_w4a16_qkv_rope_scatter_ex", "zl_decode_attn_splits_h", "zl_w4a16_gemm_attn_merge_h", "zl_w4a16_gemm_attn_merge_h_ex", "zl_w4a16_attn_out_gate_up", "zl_engine_epoch_advance",
+    "zl_copy_to_rag_buffer2", "zl_copy_to_rag_buffer_bytes", "zl_rope_scatter_decode", "zl_w4a16_qkv_rope_scatter", "zl_w4a16_qkv_rope_scatter_ex", "zl_decode_attn_splits_h", "zl_w4a16_gemm_attn_merge_h", "zl_w4a16_gemm_attn_merge_h_ex", "zl_w4a16_attn_out_gate_up", "zl_engine_epoch_advance",
     "zl_w4a16_planes_bytes", "zl_w4a16_planes", "zl_w4a16_gemm_planes", "zl_w4a16_qkv_rope_scatter_planes",
     "zl_quant_group_32", "zl_dequant_sum_quant_g32", "zl_dequant_group_32",
     "zl_fp8_calc_scale", "zl_fp8_cvt_half", "zl_fp8_gemm_nt",
     "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_ex", "zl_decode_attn_fused",
     "zl_decode_attn_split_len", "zl_decode_attn_splits", "zl_w4a16_gemm_attn_merge",
-    "zl_quant_calc_scale_zp", "zl_quant_copy_to_rag_buffer", "zl_rope_quant_scatter_decode", "zl_decode_attn_quant", "zl_decode_attn_quant_ex",
+    "zl_quant_calc_scale_zp", "zl_dequant_group", "zl_quant_copy_to_rag_buffer", "zl_rope_quant_scatter_decode", "zl_decode_attn_quant", "zl_decode_attn_quant_ex",
     "zl_prefill_attn",
     "zl_element_add_scale", "zl_gate_mul", "zl_permute_input", "zl_embedding",
     "zl_w8m_bytes", "zl_w8m_pack", "zl_w8a8_gemm_phase", "zl_w8a8_gemm_phase_ex", "zl_w8a8_qkv_rope_scatter",

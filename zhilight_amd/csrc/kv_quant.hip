@@ -36,6 +36,19 @@ __global__ __launch_bounds__(256) void k_quant_rows_zp(const uint16_t* __restric
     if (threadIdx.x == 0) scale[blockIdx.x] = amax / 127.f;
 }
 
+// rows of g codes back to T: out = rn_T((code - q_zero) * scale[row]) -- int8_op::dequant_group (quant_reduce_kernel.cu:144-175), the
+// fp32 product rounded once.  q_zero != 0: the codes are unsigned (the INT8 KV cache, q_zero 128).  grid (m), block 256
+template <int DT>
+__global__ __launch_bounds__(256) void k_dequant_group(const uint8_t* __restrict__ q, const float* __restrict__ scale, uint16_t* __restrict__ out, int g,
+                                                       float q_zero) {
+    const size_t off = (size_t)blockIdx.x * g;
+    const float sc = scale[blockIdx.x];
+    for (int i = threadIdx.x; i < g; i += 256) {
+        const float v = q_zero != 0.f ? (float)q[off + i] : (float)(int8_t)q[off + i];
+        out[off + i] = ZT<DT>::from_f32((v - q_zero) * sc);
+    }
+}
+
 struct KvQuantParams {
     const float* cosv;          // (tokens, D) or null (no rotation: rows are final)
     const float* sinv;
@@ -114,6 +127,15 @@ int zl_quant_calc_scale_zp(const uint16_t* x, uint8_t* q, float* scale, int64_t 
     ZL_DT_SWITCH(dtype,
         hipLaunchKernelGGL(k_quant_rows_zp<ZL_F16>, dim3((unsigned)m), dim3(256), 0, (hipStream_t)s, x, q, scale, (int)k, (float)q_zero),
         hipLaunchKernelGGL(k_quant_rows_zp<ZL_BF16>, dim3((unsigned)m), dim3(256), 0, (hipStream_t)s, x, q, scale, (int)k, (float)q_zero))
+    return zl_launch_status();
+}
+
+int zl_dequant_group(const void* q, const float* scale, uint16_t* out, int64_t m, int64_t g, int q_zero, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(q && scale && out && m > 0 && g > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(q_zero >= 0 && q_zero <= 128 && m < ((int64_t)1 << 31), ZL_EINVAL);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_dequant_group<ZL_F16>, dim3((unsigned)m), dim3(256), 0, (hipStream_t)s, (const uint8_t*)q, scale, out, (int)g, (float)q_zero),
+        hipLaunchKernelGGL(k_dequant_group<ZL_BF16>, dim3((unsigned)m), dim3(256), 0, (hipStream_t)s, (const uint8_t*)q, scale, out, (int)g, (float)q_zero))
     return zl_launch_status();
 }
 

@@ -308,6 +308,25 @@ __global__ void k_copy_to_rag_buffer2(const int32_t* __restrict__ placement, con
     }
 }
 
+// the same scatter for rows of ANY element type, sizes in bytes (row_bytes % 4 == 0): the INT8 KV cache of the reference writes its
+// u8 codes (row = dim_head bytes) and its fp32 scales (row = 4 bytes, is_scale = true) through copy_to_rag_buffer2 as well
+// (attention.cpp:663-669, ragged_buffer_kernel.cu:254-300).  grid (B, len_q, Hkv), block 64
+__global__ void k_copy_to_rag_buffer_bytes(const int32_t* __restrict__ placement, const int32_t* __restrict__ buf_lens, const unsigned char* __restrict__ k_src,
+                                           const unsigned char* __restrict__ v_src, unsigned char* const* __restrict__ k_bufs,
+                                           unsigned char* const* __restrict__ v_bufs, int row_bytes, int bshd) {
+    const int b = blockIdx.x, len_q = gridDim.y, hkv = gridDim.z, head = blockIdx.z;
+    const int xi = b * len_q + blockIdx.y;
+    const int p = placement[xi];
+    const int64_t len_buf = buf_lens[b];
+    if (p < 0 || p >= len_buf) return;
+    const size_t so = ((size_t)xi * hkv + head) * row_bytes;
+    const size_t dof = (bshd ? ((size_t)p * hkv + head) : ((size_t)head * len_buf + p)) * row_bytes;
+    for (int i = threadIdx.x * 4; i < row_bytes; i += blockDim.x * 4) {
+        *reinterpret_cast<uint32_t*>(k_bufs[b] + dof + i) = *reinterpret_cast<const uint32_t*>(k_src + so + i);
+        *reinterpret_cast<uint32_t*>(v_bufs[b] + dof + i) = *reinterpret_cast<const uint32_t*>(v_src + so + i);
+    }
+}
+
 // fused decode front end: grid (B, H + 2Hkv), block D; q rotated -> q out, k rotated -> cache, v -> cache
 template <int DT>
 __global__ void k_rope_scatter_decode(const float* __restrict__ cosv, const float* __restrict__ sinv,
@@ -576,6 +595,16 @@ int zl_copy_to_rag_buffer2(const int32_t* placement, const int32_t* buf_lens, co
     dim3 grid((unsigned)b, (unsigned)len_q, (unsigned)hkv);
     hipLaunchKernelGGL(k_copy_to_rag_buffer2, grid, dim3(64), 0, (hipStream_t)s, placement, buf_lens, k_src, v_src,
                        k_bufs, v_bufs, (int)d, bshd);
+    return zl_launch_status();
+}
+
+int zl_copy_to_rag_buffer_bytes(const int32_t* placement, const int32_t* buf_lens, const void* k_src, const void* v_src, void* const* k_bufs,
+                                void* const* v_bufs, int64_t b, int64_t len_q, int64_t hkv, int64_t row_bytes, int bshd, zl_stream_t s) {
+    ZL_CHECK_ARG(placement && buf_lens && k_src && v_src && k_bufs && v_bufs && b > 0 && len_q > 0 && hkv > 0 && row_bytes > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(row_bytes % 4 == 0 && len_q <= 65535 && hkv <= 65535 && row_bytes < ((int64_t)1 << 30), ZL_ESHAPE);
+    dim3 grid((unsigned)b, (unsigned)len_q, (unsigned)hkv);
+    hipLaunchKernelGGL(k_copy_to_rag_buffer_bytes, grid, dim3(64), 0, (hipStream_t)s, placement, buf_lens, (const unsigned char*)k_src, (const unsigned char*)v_src,
+                       (unsigned char* const*)k_bufs, (unsigned char* const*)v_bufs, (int)row_bytes, bshd);
     return zl_launch_status();
 }
 

@@ -868,7 +868,16 @@ void rope_qk_cache(const Context& ctx, const Tensor& cos, const Tensor& sin, con
 }
 void copy_to_rag_buffer2(const Context& ctx, const Tensor& placement, const Tensor& buf_lens, const Tensor& k_src, const Tensor& v_src,
                          Tensor* buf_k_addr, Tensor* buf_v_addr, bool is_scale) {
-    BM_ASSERT(!is_scale, "scale rows travel with zl_quant_copy_to_rag_buffer on this path");
+    // the INT8 KV cache of the reference comes through here twice: the u8 codes (a 4-d int8 source) and, is_scale = true, the fp32
+    // scales (batch, len_q, num_kv_heads) -- rows by their size in bytes
+    if (is_scale || k_src.dtype() == DataType::kInt8) {
+        BM_ASSERT(is_scale ? (k_src.ndim() >= 3 && k_src.dtype() == DataType::kFloat) : k_src.ndim() == 4, "copy_to_rag_buffer2: code rows are 4-d int8, scale rows fp32");
+        const size_t b = k_src.size(0), len_q = k_src.size(1), hkv = k_src.size(2);
+        const size_t row_bytes = is_scale ? sizeof(float) : k_src.size(3);
+        zl_check(zl_copy_to_rag_buffer_bytes(placement.data<int32_t>(), buf_lens.data<int32_t>(), k_src.data(), v_src.data(), buf_k_addr->data<void* const>(),
+                                             buf_v_addr->data<void* const>(), b, len_q, hkv, row_bytes, ctx.is_BSHD(), st_of(ctx)), "copy_to_rag_buffer2 (bytes)");
+        return;
+    }
     BM_ASSERT_EQ(k_src.ndim(), 4, "k_src is not (batch, len_q, num_kv_heads, dim_head)");
     zl_check(zl_copy_to_rag_buffer2(placement.data<int32_t>(), buf_lens.data<int32_t>(), u16(k_src), u16(v_src),
                                     buf_k_addr->data<uint16_t* const>(), buf_v_addr->data<uint16_t* const>(), k_src.size(0), k_src.size(1),

@@ -119,11 +119,29 @@ void TransformerBuffer::resize(const core::Context& ctx, size_t new_length) {
 // scatter the rows of src (n, heads, dim) into layer `layer` at the buffer rows `placement` names and hand the layer's buffer back
 // (attn_encode_group, attention.cpp:513-514: the prompt's keys / values enter the task's buffer here): zl_copy_to_rag_buffer2 with
 // one task whose "value" operand is the same tensor
-core::Tensor TransformerBuffer::copy(const core::Context& ctx, int layer, const core::Tensor& src, const core::Tensor& placement, int /*start*/,
+core::Tensor TransformerBuffer::copy(const core::Context& ctx, int layer, const core::Tensor& src, const core::Tensor& placement, int start,
                                      bool need_dequant) {
     check_layer(layer);
-    if (need_dequant || scale_dtype_) ZL_OFF_PATH("kvcache::TransformerBuffer::copy on a quantised cache");
     core::Tensor& buf = buffer[layer];
+    if (scale_dtype_) {
+        // the INT8 cache (transformer_buffer.cu:128-152): the chunk's rows become u8 codes + one fp32 scale per (row, head) at rows
+        // start .. start + n - 1 (the reference ignores `placement` here as well); the caller attends over `src` itself, or -- a later
+        // chunk, need_dequant -- over the already cached rows brought back to T in front of it
+        BM_ASSERT(BSHD && src.ndim() == 3 && *scale_dtype_ == core::DataType::kFloat, "quantised buffers: (len, heads, dim) u8 codes with fp32 scales");
+        const int64_t n = (int64_t)src.size(0), len_buf = (int64_t)buf.size(0), row = (int64_t)num_heads * dim_head;
+        BM_ASSERT(start >= 0 && start + n <= len_buf, "TransformerBuffer::copy: rows past the buffer");
+        const int dt = src.dtype() == core::DataType::kHalf ? ZL_F16 : ZL_BF16;
+        zl_stream_t st = (zl_stream_t)ctx.current_cuda_stream();
+        core::Tensor& sc = scales_[layer];
+        ZL_CK(zl_quant_calc_scale_zp(src.data<uint16_t>(), buf.data<uint8_t>() + (size_t)start * row, sc.data<float>() + (size_t)start * num_heads,
+                                     n * (int64_t)num_heads, (int64_t)dim_head, 128, dt, st), "quant_calc_scale");
+        if (!(need_dequant && start > 0)) return src;
+        core::Tensor out = ctx.tensor({(size_t)len_buf, num_heads, dim_head}, src.dtype());
+        BM_CUDART_ASSERT(hipMemsetAsync(out.data(), 0, out.nbytes(), ctx.current_cuda_stream()));
+        ZL_CK(zl_dequant_group(buf.data(), sc.data<float>(), out.data<uint16_t>(), (int64_t)start * num_heads, (int64_t)dim_head, 128, dt, st), "dequant_group");
+        BM_CUDART_ASSERT(hipMemcpyAsync(out.data<char>() + (size_t)start * row * 2, src.data(), src.nbytes(), hipMemcpyDeviceToDevice, ctx.current_cuda_stream()));
+        return out;
+    }
     const int64_t n = (int64_t)placement.numel();
     BM_ASSERT(src.numel() == (size_t)n * num_heads * dim_head && placement.dtype() == core::DataType::kInt32, "TransformerBuffer::copy: shape mismatch");
     const int len_buf = (int)buf.size(BSHD ? 0 : 1);
@@ -316,8 +334,13 @@ public:
         qc.group_size = group_size;
         attn_.reset(new nn::Attention(ctx_, cfg_, qc, false));
         const bool latent = cfg_.kv_lora_rank > 0 && ctx_.latent_cache();
-        kvcache::KVCacheConfig kc{num_layers, latent ? 1 : num_kv_heads, latent ? cfg_.kv_lora_rank + cfg_.qk_rope_head_dim : dim_head, DataType::kHalf, bshd,
-                                  nullptr, std::vector<int>(num_layers, device)};
+        // KV_CACHE_DTYPE=int8: u8 codes + fp32 scales, the switch ModelContext::get_kv_cache_config reads (model_context.cpp:61-80)
+        const char* kvd = std::getenv("KV_CACHE_DTYPE");
+        const bool kv_int8 = kvd && std::string(kvd) == "int8";
+        BM_ASSERT(!(kv_int8 && latent), "the latent cache is not quantised");
+        kvcache::KVCacheConfig kc{num_layers, latent ? 1 : num_kv_heads, latent ? cfg_.kv_lora_rank + cfg_.qk_rope_head_dim : dim_head,
+                                  kv_int8 ? DataType::kInt8 : DataType::kHalf, bshd,
+                                  kv_int8 ? std::make_shared<DataType>(DataType::kFloat) : nullptr, std::vector<int>(num_layers, device)};
         kvcache::KVCacheConfig vc = kc;
         if (latent) vc.dim_head = 0;
         rag_ = std::make_shared<model::RagBufferContext>(kc, vc);
@@ -343,6 +366,18 @@ public:
     }
     py::array get_k(int b, int layer) { return to_numpy(ctx_, rag_->buf_k(b, layer)); }
     py::array get_v(int b, int layer) { return to_numpy(ctx_, rag_->buf_v(b, layer)); }
+    // a quantised cache: the fp32 scales next to the codes, and history given as codes + scales
+    py::array get_k_scale(int b, int layer) { return to_numpy(ctx_, rag_->buf_k(b).get_scale(layer)); }
+    py::array get_v_scale(int b, int layer) { return to_numpy(ctx_, rag_->buf_v(b).get_scale(layer)); }
+    void set_history_quant(int b, int layer, int len_buf, const py::array& k, const py::array& v, const py::array& ks, const py::array& vs) {
+        BM_ASSERT(rag_->is_cache_quant(), "set_history_quant: KV_CACHE_DTYPE=int8 only");
+        rag_->resize_task_buf(ctx_, b, (size_t)len_buf);
+        fill(rag_->buf_k(b)[layer], k);
+        fill(rag_->buf_v(b)[layer], v);
+        fill(const_cast<Tensor&>(rag_->buf_k(b).get_scale(layer)), ks);
+        fill(const_cast<Tensor&>(rag_->buf_v(b).get_scale(layer)), vs);
+    }
+    bool cache_quant() { return rag_->is_cache_quant(); }
     bool latent_cache() { return ctx_.latent_cache(); }
     // one decode step of `layer` for the tasks 0 .. B - 1: hidden (B, dim_model) fp16, positions (B) int32, placement (B) int32 = the
     // buffer row the new key goes to, mask (sum over tasks of len_buf) int8.  with_rope_cache: DynBatchContext::rope_cache filled
@@ -428,6 +463,10 @@ void bind_ref_attention(py::module_& m) {
         .def("load", &RefAttention::load)
         .def("set_history", &RefAttention::set_history)
         .def("get_k", &RefAttention::get_k)
+        .def("get_k_scale", &RefAttention::get_k_scale)
+        .def("get_v_scale", &RefAttention::get_v_scale)
+        .def("set_history_quant", &RefAttention::set_history_quant)
+        .def("cache_quant", &RefAttention::cache_quant)
         .def("get_v", &RefAttention::get_v)
         .def("encode", &RefAttention::encode, py::arg("layer"), py::arg("b"), py::arg("len_buf"), py::arg("hidden"), py::arg("pos0") = 0)
         .def("decode_step", &RefAttention::decode_step, py::arg("layer"), py::arg("hidden"), py::arg("positions"), py::arg("placement"), py::arg("mask"),
