@@ -709,6 +709,13 @@ int zl_scatter_update_dim0(void* dst, const int32_t* dst_index, const void* src,
                            int64_t dst_rows, int64_t src_rows, zl_stream_t s);
 int zl_sort_pairs_i32(const int32_t* keys, const int32_t* values, int32_t* keys_out, int32_t* values_out, void* workspace, int64_t n,
                       int32_t max_key, zl_stream_t s);
+/* greedy pick over whole logit rows (rows, n; row stride ld elements; type = ZL_T_F16 / ZL_T_BF16 / ZL_T_F32) + the between-steps
+ * bookkeeping in one launch: tokens[r] = next_tokens[r] = arg-max of row r (first index of the largest value, NaN largest -- torch.argmax),
+ * positions / placement / valid_lens += 1 (any of the five may be null, tokens or next_tokens must be given).  The host-side loop it
+ * stands for: fill_search_tokens, src/generator/batch_generator.cpp:1226-1335.  zl_gemm_nt_small_m_argmax + zl_greedy_advance are the
+ * form that never writes the pick's logits pass for <= 4 rows. */
+int zl_argmax_advance(const void* logits, int type, int64_t rows, int64_t n, int64_t ld, int32_t* tokens, int32_t* positions, int32_t* placement,
+                      int32_t* valid_lens, int64_t* next_tokens, zl_stream_t s);
 int zl_reduce_abs_max(const void* x, void* out, int64_t rows, int64_t cols, int type, zl_stream_t s);
 int zl_binary_op(const void* a, const void* b, void* c, int64_t rows, int64_t cols, int op, int bmode, int type, zl_stream_t s);
 int zl_scale(const void* in, void* out, int64_t n, float factor, int type, zl_stream_t s);

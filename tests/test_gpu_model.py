@@ -343,6 +343,43 @@ def test_step_greedy_matches_argmax_and_advances(dev):
         assert pos.tolist() == [4] * m and place.tolist() == [5] * m and valid.tolist() == [6] * m
 
 
+@pytest.mark.parametrize("dt", ["float16", "bfloat16", "float32"])
+def test_argmax_advance_over_logit_rows(dev, dt):
+    """zl_argmax_advance (decode batches past the small-M lm_head, TP's gathered rows): the first index of the largest value per row
+    -- ties, negative rows, a NaN (largest, as torch.argmax), -inf rows, strided rows -- and the batch counters advanced by one."""
+    from zhilight_amd import ops
+    tdt = getattr(torch, dt)
+    rng = np.random.default_rng(17)
+    for m, n in [(1, 5), (8, 128256), (32, 4099), (3, 1024)]:
+        base = torch.from_numpy(rng.standard_normal((m, n + 8)).astype(np.float32)).to(dev).to(tdt)
+        x = base[:, :n]                                  # row stride n + 8
+        if n > 100:
+            x[0, 70] = x[0].max()                        # a tie: index min(70, where the maximum sits) wins
+            x[0, 90] = x[0, 70]
+        if m > 1:
+            x[1] = -x[1].abs() - 1                       # an all-negative row
+        if m > 2:
+            x[2, n // 2] = float("nan")                  # NaN counts as the largest value
+            x[2, n - 1] = float("nan")
+        if m > 3:
+            x[3] = float("-inf")                         # nothing but -inf: index 0
+        i32 = dict(dtype=torch.int32, device=dev)
+        tokens, pos, place, valid = torch.zeros(m, **i32), torch.full((m,), 3, **i32), torch.full((m,), 4, **i32), torch.full((m,), 5, **i32)
+        nxt = torch.full((m,), -1, dtype=torch.int64, device=dev)
+        ops.argmax_advance(x, tokens, pos, place, valid, nxt)
+        xf = x.float()
+        for r in range(m):
+            row = xf[r]
+            nan = torch.isnan(row)
+            first = int(nan.nonzero()[0, 0]) if bool(nan.any()) else int((row == row.max()).nonzero()[0, 0])
+            assert int(nxt[r]) == first, (dt, m, n, r, int(nxt[r]), first)
+        assert torch.equal(tokens.long(), nxt)
+        assert pos.tolist() == [4] * m and place.tolist() == [5] * m and valid.tolist() == [6] * m
+    only = torch.zeros(2, dtype=torch.int32, device=dev)          # tokens alone (the prompt's first pick under TP)
+    ops.argmax_advance(torch.tensor([[1.0, 3.0, 3.0], [2.0, -1.0, 0.0]], device=dev, dtype=tdt), tokens=only)
+    assert only.tolist() == [1, 0]
+
+
 def test_prefill_then_decode_matches_oracle(oracle, dev):
     """Prompt encode (M-tiled W4A16 GEMM, causal attention through the mask form) + decode continuation
     against the oracle's restatement of the reference's two branches (M > 40: dequant + GEMM; decode: the

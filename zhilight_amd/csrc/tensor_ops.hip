@@ -176,6 +176,42 @@ __global__ void k_permute_input_u16(const uint16_t* __restrict__ x, int64_t ldx,
     default: return ZL_EDTYPE;                 \
     }
 
+// Greedy pick over whole logit rows + the between-steps bookkeeping in ONE launch (decode batches past the small-M lm_head, TP's gathered
+// rows): row r's arg-max -- the FIRST index of the largest value, a NaN counting as largest, as torch.argmax / the reference's host-side
+// pick over the logits (src/generator/batch_generator.cpp:1226-1335 fill_search_tokens) -- into tokens / next_tokens, the three
+// counters += 1.  One 64-bit key per element: (monotone(value) << 32) | ~index, so "larger value, then smaller index" is one unsigned max.
+template <int TI>
+__global__ __launch_bounds__(1024) void k_argmax_advance(const typename EL<TI>::type* __restrict__ x, int64_t ld, int n, int32_t* __restrict__ tokens,
+                                                         int32_t* __restrict__ positions, int32_t* __restrict__ placement, int32_t* __restrict__ valid_lens,
+                                                         int64_t* __restrict__ next_tokens) {
+    __shared__ unsigned long long red[16];
+    const typename EL<TI>::type* row = x + (size_t)blockIdx.x * ld;
+    unsigned long long best = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float v = EL<TI>::ld(row, i);
+        uint32_t u = __builtin_bit_cast(uint32_t, v);
+        u = (v != v) ? 0xffffffffu : (u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u));
+        const unsigned long long key = ((unsigned long long)u << 32) | (uint32_t)~(uint32_t)i;
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) best = red[w] > best ? red[w] : best;
+        const int32_t idx = (int32_t)~(uint32_t)(best & 0xffffffffull);
+        if (tokens) tokens[blockIdx.x] = idx;
+        if (next_tokens) next_tokens[blockIdx.x] = idx;
+        if (positions) positions[blockIdx.x] += 1;
+        if (placement) placement[blockIdx.x] += 1;
+        if (valid_lens) valid_lens[blockIdx.x] += 1;
+    }
+}
+
 // ---- the MoE dispatch route's index plumbing (functions::arange / sort_pair_1d / divide / scatter_update_dim0) ------------------------
 __global__ void k_arange_i32(int32_t* __restrict__ out, int start, int step, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -326,6 +362,21 @@ int zl_index_select(const void* in, void* out, const int32_t* index, int64_t out
     else
         hipLaunchKernelGGL(k_index_select<uint8_t>, dim3(grid_for(rows * inner_bytes, 256)), dim3(256), 0, hs, (const uint8_t*)in,
                            (uint8_t*)out, index, outer, dim_in, n_index, inner_bytes);
+    return zl_launch_status();
+}
+
+int zl_argmax_advance(const void* logits, int type, int64_t rows, int64_t n, int64_t ld, int32_t* tokens, int32_t* positions, int32_t* placement,
+                      int32_t* valid_lens, int64_t* next_tokens, zl_stream_t s) {
+    ZL_CHECK_ARG(logits && rows > 0 && n > 0 && ld >= n && (tokens || next_tokens), ZL_EINVAL);
+    ZL_CHECK_ARG(n < ((int64_t)1 << 31) && rows < ((int64_t)1 << 31), ZL_ESHAPE);
+    hipStream_t hs = (hipStream_t)s;
+    const dim3 g((unsigned)rows), b(1024);
+    switch (type) {
+    case T_F16: hipLaunchKernelGGL(k_argmax_advance<T_F16>, g, b, 0, hs, (const uint16_t*)logits, ld, (int)n, tokens, positions, placement, valid_lens, next_tokens); break;
+    case T_BF16: hipLaunchKernelGGL(k_argmax_advance<T_BF16>, g, b, 0, hs, (const uint16_t*)logits, ld, (int)n, tokens, positions, placement, valid_lens, next_tokens); break;
+    case T_F32: hipLaunchKernelGGL(k_argmax_advance<T_F32>, g, b, 0, hs, (const float*)logits, ld, (int)n, tokens, positions, placement, valid_lens, next_tokens); break;
+    default: return ZL_EDTYPE;
+    }
     return zl_launch_status();
 }
 

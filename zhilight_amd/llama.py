@@ -1309,10 +1309,10 @@ class LLaMA:
     def _prompt_logits_and_pick(self, ctx, task, last_hidden):
         """logits of a prompt's last row and the first generated token into ctx.tokens[task]: the pick rides the lm_head launch
         (zl_gemm_nt_small_m_argmax leaves one candidate per wavefront, zl_greedy_advance reduces them -- first index on ties,
-        as torch.argmax) instead of three torch launches over the 128 k logits; TP keeps the plain arg-max on the gathered row"""
+        as torch.argmax) instead of three torch launches over the 128 k logits; TP picks on the gathered row (zl_argmax_advance)"""
         if self.tp:
             logits = self._logits(last_hidden)
-            ctx.tokens[task] = torch.argmax(logits[0].float()).to(torch.int32)
+            ops.argmax_advance(logits[:1], tokens=ctx.tokens[task:task + 1])
             return logits
         key = ("argmax", 1)
         if key not in self._bufs:
@@ -1328,10 +1328,15 @@ class LLaMA:
         inside the lm_head launch + one small reduction, and advance the batch state.  Returns
         (logits, next_tokens int64)."""
         b = ctx.tokens.numel()
-        if b > 4 or self.tp:   # the in-launch pick rides the small-M GEMV; bigger batches / TP: plain argmax on the logits
+        if b > 4 or self.tp:   # the in-launch pick rides the small-M GEMV; bigger batches / TP: one pick + advance launch over the logits
             logits = self.encode(ctx)
-            nxt = torch.argmax(logits, dim=-1)
-            self.advance(ctx, nxt)
+            key = ("next", b)
+            if key not in self._bufs:
+                self._bufs[key] = torch.empty(b, dtype=torch.int64, device=self.device)
+            nxt = self._bufs[key]
+            ops.argmax_advance(logits, tokens=ctx.tokens, positions=ctx.positions, placement=ctx.placement, valid_lens=ctx.valid_lens,
+                               next_tokens=nxt)
+            ctx.steps_left -= 1
             return logits, nxt
         key = ("argmax", b)
         if key not in self._bufs:

@@ -610,6 +610,19 @@ def greedy_advance(argmax_ws, m, n, tokens=None, positions=None, placement=None,
     return next_tokens
 
 
+def argmax_advance(logits, tokens=None, positions=None, placement=None, valid_lens=None, next_tokens=None):
+    """Greedy pick over whole logit rows (first index of the largest value, as torch.argmax) and the batch state's advance in one
+    launch: tokens <- pick (int32), next_tokens <- pick (int64), the three counters += 1."""
+    _chk_cuda(tokens, positions, placement, valid_lens, next_tokens)
+    if not (logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1 and logits.stride(0) >= logits.shape[1]):
+        raise ZLError("argmax_advance: (rows, n) CUDA logits with unit column stride")
+    rows, n = logits.shape
+    code = {torch.float16: 2, torch.bfloat16: 6, torch.float32: 1}[logits.dtype]
+    check(lib().zl_argmax_advance(_p(logits), C.c_int(code), _i(rows), _i(n), _i(logits.stride(0)), _p(tokens), _p(positions), _p(placement),
+                                  _p(valid_lens), _p(next_tokens), _stream()), "argmax_advance")
+    return next_tokens if next_tokens is not None else tokens
+
+
 # --------------------------------------------------------------------------------------------------
 # a17 / a13 / a14 / a18 / a22
 # --------------------------------------------------------------------------------------------------
