@@ -39,14 +39,14 @@ def main():
         lens = torch.full((b,), 1024, dtype=torch.int32, device=dev)
         out["mla_decode_us"]["batch_%d" % b] = round(timed(lambda i=0: ops.mla_decode_attention(q, lens, addrs, 0.1, 1024), 20), 2)
     for name, n, k in (("experts_gate_up_4096x7168", 4096, 7168), ("experts_down_7168x2048", 7168, 2048)):
-        nb = 8
+        nb = max(8, -(-640_000_000 // (n * k)))      # rotating weights: > 2 x the 256 MiB Infinity Cache, so every launch streams from HBM
         ws = [torch.randint(0, 120, (n, k), dtype=torch.uint8, device=dev) for _ in range(nb)]
         sw = torch.rand((n + 127) // 128, k // 128, dtype=torch.float32, device=dev) * 0.01 + 0.001
         for m in (1, 32):
             x = torch.randn(m, k, device=dev).to(torch.bfloat16)
             a8, sa = ops.fp8_per_token_cast(x)
             y = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
-            us = timed(lambda i=0: ops.fp8_block_gemm(a8, sa, ws[i % nb], sw, out=y), 16)
+            us = timed(lambda i=0: ops.fp8_block_gemm(a8, sa, ws[i % nb], sw, out=y), nb)
             out["fp8_block_gemm_us"]["%s_m%d" % (name, m)] = {"us": round(us, 2), "tb_per_s": round(n * k / us / 1e6, 2)}
         del ws
     print(json.dumps(out), flush=True)

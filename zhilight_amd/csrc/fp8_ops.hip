@@ -304,9 +304,16 @@ int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t
                                m_indices, out, (int)m, (int)n, (int)k, num_groups))                                                        \
     }
     // the grouped form: one 16-row tile per workgroup (neighbouring tiles may belong to different experts)
-    if (m_indices || m <= 16) ZL_FP8B(1, 4)
-    else if (m <= 32) ZL_FP8B(2, 2)
-    else ZL_FP8B(4, 1)
+    // U = blocks a wave has in flight per round: a wave owns ceil(K / 1024) blocks, and every round pays a full memory latency, so the
+    // decode shapes take them all at once when the registers allow (K = 7168: 7 blocks per wave, one round instead of two / four)
+    const int64_t bpw = (k / 128 + 7) / 8;
+    if (m_indices || m <= 16) {
+        if (bpw > 4) ZL_FP8B(1, 8)
+        else ZL_FP8B(1, 4)
+    } else if (m <= 32) {
+        if (bpw > 2) ZL_FP8B(2, 4)
+        else ZL_FP8B(2, 2)
+    } else ZL_FP8B(4, 1)
 #undef ZL_FP8B
     return zl_launch_status();
 }
