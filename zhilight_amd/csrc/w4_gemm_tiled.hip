@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
                 load_x1(blk >> 1, g + 2);
             }
 #endif
-            ZL_WIDE_MFMA(2)
+            if constexpr (NT > 2) ZL_WIDE_MFMA(2)
             ZL_WIDE_DEQ(3)
             if constexpr (NT > 3) ZL_WIDE_MFMA(3)
 #undef ZL_WIDE_DEQ
@@ -759,13 +759,15 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
         // (dequant and the rest of the VALU) + the per-chunk remainder (measured: 3 850 for 128 x 256, ~7 000 for 256 x 256);
         // a launch takes ceil(tiles x splits / CUs) rounds of chunks / splits chunks; fewer tiles than CUs split K just far
         // enough to give every CU one workgroup -- fp32 partials through the caller's scratch, summed in split order.
-        // 192-column tiles exist for N that 256 leaves short of the chip: N = 6144 (qkv) = 24 x 256 = 32 x 192.
+        // 192-column tiles exist for N that 256 leaves short of the chip: N = 6144 (qkv) = 24 x 256 = 32 x 192; 128-column tiles for
+        // N = 4096 with a short K (attn_out: 32 x 8 = 256 workgroups without splitting K).
         int best_rb = 8, best_nt = 4, best_splits = 1;
         double best_cost = -1;
-        for (int nt = 4; nt >= 3; --nt)
+        for (int nt = 4; nt >= 2; --nt)
             for (int rb = 8; rb <= 16; rb += 8) {
                 if (rb == 16 && (m <= 128 || o.tiled_wide == 2)) continue;    // (tiled_wide == 2: 128-row tiles only)
                 if (nt == 4 && L.np < 256) continue;
+                if (nt == 2 && rb == 16) continue;                            // (128-column tiles: 128 rows only)
                 const int64_t tiles = ((L.np + 64 * nt - 1) / (64 * nt)) * ((m + 16 * rb - 1) / (16 * rb));
                 int sp = 1;
                 if (tiles * 4 <= (int64_t)cus * 3) {
@@ -778,7 +780,10 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
                 const int64_t need = ZL_SCRATCH_HEADER + (int64_t)sp * m * L.np * (int64_t)sizeof(float);
                 if (sp > 1 && !(o.scratch && o.scratch_bytes >= need)) sp = 1;
                 const int64_t rounds = (tiles * sp + cus - 1) / cus;
-                const double chunk = 64.0 * rb * nt + 281.0 * nt + (rb == 16 ? 1780.0 : 700.0);
+                // 128-column tiles (nt = 2) feed two MFMAs per activation fragment instead of four: 2 870 cycles per chunk measured
+                // (attn_out at 1 024 rows: 45.9 us unsplit against 52.1 us for 256-column tiles with two K splits + their epilogue;
+                // every other Llama shape keeps the wider tile)
+                const double chunk = 64.0 * rb * nt + 281.0 * nt + (nt == 2 ? 1290.0 : (rb == 16 ? 1780.0 : 700.0));
                 const double cost = (double)rounds * (double)((p.groups + sp - 1) / sp) * chunk +
                                     (sp > 1 ? 0.004 * (double)sp * (double)m * (double)L.np : 0.0);
                 if (best_cost < 0 || cost < best_cost * 0.97) {             // (3 %: prefer the earlier, wider candidate on a tie)
@@ -790,6 +795,7 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
             }
         if (o.tiled_wide == 3 && m > 128) best_rb = 16;                    // (experiments: force the 256-row tile)
         if (o.tiled_wide == 4) best_nt = 3;                                 // (experiments: force 192-column tiles)
+        if (o.tiled_wide == 5) { best_nt = 2; best_rb = 8; best_splits = 1; }  // (experiments: 128 x 128 tiles, no K split)
         const int rbw = best_rb, ntw = best_nt;
         const int gxw = (int)((L.np + 64 * ntw - 1) / (64 * ntw)), gyw = (int)((m + 16 * rbw - 1) / (16 * rbw));
         int splits = best_splits;
@@ -820,9 +826,11 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
         hipLaunchKernelGGL((k_w4a16_gemm_wide<RBV, NTV>), gridw, dim3(256), ldsw, hs, p, gxw, gyw);                          \
     }
         if (rbw == 16 && ntw == 4) ZL_WIDE_LAUNCH(16, 4)
-        else if (rbw == 16) ZL_WIDE_LAUNCH(16, 3)
+        else if (rbw == 16 && ntw == 3) ZL_WIDE_LAUNCH(16, 3)
+        else if (rbw == 16) ZL_WIDE_LAUNCH(16, 2)
         else if (ntw == 4) ZL_WIDE_LAUNCH(8, 4)
-        else ZL_WIDE_LAUNCH(8, 3)
+        else if (ntw == 3) ZL_WIDE_LAUNCH(8, 3)
+        else ZL_WIDE_LAUNCH(8, 2)
 #undef ZL_WIDE_LAUNCH
         st = zl_launch_status();
         if (st || splits <= 1) return st;
