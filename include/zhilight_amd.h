@@ -208,7 +208,8 @@ typedef struct {
                          rounds 1-2 (k_w4a16_phase / k_w4a16_mfma) */
     int tiled_wide;   /* prompt-chunk tiles (128 / 256 x 256 outputs per workgroup, M >= 128): 0 default (on, height by cost model), -1 off,
                          1 also for 32 < M < 128, 2 128-row tiles only, 3 256-row tiles whenever M > 128, 4 192-column tiles, 5 128 x 128 tiles without
-                         a K split (the cost model picks those itself for N = 4096, K = 4096: attn_out of a prompt chunk) */
+                         a K split (the cost model picks those itself for N = 4096, K = 4096: attn_out of a prompt chunk), 6 no two-height plan (256-row
+                         tiles + 192-row tiles in two launches when one height leaves the last round of workgroups partly empty) */
 } zl_w4_opts_t;
 int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n);
 int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias,

@@ -289,6 +289,40 @@ def test_wide_gemm_shapes(oracle, dev, m, k, n, splitk, force, monkeypatch):
     _check_mfma(oracle, dev, k, n, m, seed=72 + m, residual=True, force_tiled=True)
 
 
+@pytest.mark.parametrize("m,n,k", [(1024, 28672, 256), (768, 28672, 128), (2048, 14336, 128)])
+def test_wide_gemm_two_tile_heights(oracle, dev, m, n, k, monkeypatch):
+    """The two-height plan of k_w4a16_gemm_wide (256-row tiles over all column strips + 192-row tiles over the rows the tall ones
+    leave on some strips, two launches that each fill the chip once -- gate|up of a 1 024-token prompt chunk): every output is
+    still one workgroup's sum over K in chunk order, so the result equals the one-height tiling (ZL_W4_TILED_WIDE=6) BIT FOR BIT,
+    plain / bias / residual / silu.mul epilogues; and rows on both sides of every tile seam against the oracle's product."""
+    from zhilight_amd import ops
+    _u16 = lambda t: _np(t).view(np.uint16)
+    rng = np.random.default_rng(900 + m + k)
+    g = 128
+    qw, qz, sc = synth.gptq_hf(rng, k, n, g)
+    km = oracle.gptq_prepare_k_major(qw, qz, sc, g)
+    w = ops.W4MWeight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), g)
+    x = synth.act(rng, m, k)
+    b = (rng.standard_normal(n) * 0.1).astype(np.float16)
+    res = synth.act(rng, m, n)
+    outs = {}
+    for mode in ("0", "6"):
+        monkeypatch.setenv("ZL_W4_TILED_WIDE", mode)
+        outs[mode] = [_u16(ops.w4a16_gemm_tiled(_t(x, dev), w)),
+                      _u16(ops.w4a16_gemm_tiled(_t(x, dev), w, bias=_t(b, dev))),
+                      _u16(ops.w4a16_gemm_tiled(_t(x, dev), w, residual=_t(res, dev), epilogue=ops.EPI_RESIDUAL)),
+                      _u16(ops.w4a16_gemm_tiled(_t(x, dev), w, epilogue=ops.EPI_SILU_MUL))]
+    for a, c in zip(outs["0"], outs["6"]):
+        assert np.array_equal(a, c)
+    # seams: 256-row tiles start at 0, 256, ...; the 192-row tiles at 256 kbig + 192 i
+    rows = sorted({r for s0 in range(0, m, 64) for r in (s0, s0 + 63)} | {m - 1})
+    w16 = oracle.gptq_dequant_k_major(*km)
+    ref = oracle.gemm_nt(oracle.h2u(x[rows]), w16, None, exact=True)
+    got = outs["0"][0].view(np.float16)[rows].astype(np.float64)
+    rms = np.sqrt((ref ** 2).mean())
+    assert (np.abs(got - ref) <= 2.0 ** -10 * np.abs(ref) + 2e-5 * rms).all()
+
+
 @pytest.mark.parametrize("rounds", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("m", [5, 16, 17, 32])
 def test_phase_gemm_rounds(oracle, dev, m, rounds, monkeypatch):

@@ -322,8 +322,16 @@ __device__ __forceinline__ uint32_t wv_pk_mul(uint32_t a, uint32_t b) {
 #endif
 // NT = 16-column weight tiles per wave (4: 256 columns per workgroup; 3: 192 -- N = 6144 = 32 x 192 gives the qkv projection
 // of a 1024-token chunk 256 workgroups instead of 192)
+// workgroup -> tile map of one launch: column strips cx_base .. cx_base + gx - 1; the first s0 of them carry gy row tiles each, the
+// others gy2 (0: none); row tile ry starts at row_base + ry x (16 RB).  The plain launch is {gx, gy, gx, 0, 0, 0}; the two-height
+// plan of a prompt GEMM whose tile count is not a multiple of the CU count runs TWO launches (256-row tiles, then 192-row tiles over
+// the rows the first one left) that each fill the chip exactly once -- see the launcher.
+struct WideMap {
+    int gx, gy, s0, gy2, cx_base, row_base;
+};
+
 template <int RB, int NT>
-__global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const TiledParams p, const int gx, const int gy) {
+__global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const TiledParams p, const WideMap mp) {
     constexpr int kWideBM = 16 * RB;
     constexpr int kWideChunkBytes = kWideBM * 128 * 2;         // one 128-k activation chunk in LDS
     constexpr int NBLK = 4 * RB;                               // blocks of 4 MFMAs per chunk
@@ -332,9 +340,22 @@ __global__ __launch_bounds__(256, ZL_WIDE_OCC) void k_w4a16_gemm_wide(const Tile
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nrow = lane & 15, kq = lane >> 4;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int ry = local % gy, cx = (local / gy) * 8 + xcd;
-    if (cx >= gx) return;
-    const int m0 = ry * kWideBM;
+    // strips xcd, xcd + 8, ... of the launch belong to this XCD: first those below s0 (gy row tiles each), then the rest (gy2 each)
+    const int nx = mp.s0 > xcd ? (mp.s0 - xcd + 7) >> 3 : 0;
+    int rel, ry;
+    if (local < nx * mp.gy) {
+        rel = (local / mp.gy) * 8 + xcd;
+        ry = local % mp.gy;
+    } else {
+        if (mp.gy2 <= 0) return;
+        const int l2 = local - nx * mp.gy;
+        rel = (nx + l2 / mp.gy2) * 8 + xcd;
+        ry = l2 % mp.gy2;
+    }
+    if (rel >= mp.gx) return;
+    const int cx = mp.cx_base + rel;
+    const int m0 = mp.row_base + ry * kWideBM;
+    if (m0 >= p.m) return;
     const int tile0 = cx * (4 * NT) + wave * NT;               // this wave's NT 16-column weight tiles
     const int g_begin = p.ws ? blockIdx.y * p.split_chunks : 0;
     const int G = p.ws ? min(p.groups, g_begin + p.split_chunks) : p.groups;
@@ -813,18 +834,51 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
         }
         const int64_t wgs = (int64_t)((gxw + 7) / 8) * 8 * gyw;
         ZL_CHECK_ARG(wgs <= 0x7fffffff, ZL_ELIMIT);
-        const size_t ldsw = (size_t)2 * 16 * rbw * 256;
-        const dim3 gridw((unsigned)wgs, (unsigned)splits);
-#define ZL_WIDE_LAUNCH(RBV, NTV)                                                                                             \
+#define ZL_WIDE_LAUNCH_MAP(RBV, NTV, MAP, WGS, SPLITS)                                                                       \
     {                                                                                                                        \
-        if (ldsw > 64 * 1024) {                                                                                              \
+        const size_t lds_ = (size_t)2 * 16 * RBV * 256;                                                                      \
+        if (lds_ > 64 * 1024) {                                                                                              \
             /* every launch: the attribute is per device, and one process may drive several (the reference's engine) */      \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_gemm_wide<RBV, NTV>),                             \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw) != hipSuccess)                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess)                    \
                 return ZL_ELIMIT;                                                                                            \
         }                                                                                                                    \
-        hipLaunchKernelGGL((k_w4a16_gemm_wide<RBV, NTV>), gridw, dim3(256), ldsw, hs, p, gxw, gyw);                          \
+        hipLaunchKernelGGL((k_w4a16_gemm_wide<RBV, NTV>), dim3((unsigned)(WGS), (unsigned)(SPLITS)), dim3(256), lds_, hs, p, MAP); \
     }
+        // Two tile heights when the 256-row tiling leaves the last round of workgroups partly empty (gate|up of a 1 024-token chunk:
+        // 112 strips x 4 = 448 tiles on 256 CUs = two rounds for 1.75 rounds of work): `ystrips` of the column strips carry kbig
+        // 256-row tiles and jsmall 192-row tiles (256 kbig + 192 jsmall = M) instead of M / 256 tall ones, chosen so that the tall
+        // tiles of ALL strips and the 192-row tiles each come to whole rounds; two launches, one height each.  Every output is
+        // still one workgroup's sum over K in chunk order: bit-identical to the plain tiling.
+        if (splits == 1 && rbw == 16 && ntw == 4 && m % 256 == 0 && o.tiled_wide != 3 && o.tiled_wide != 6) {
+            const int64_t c16 = 64 * 16 * 4 + 281 * 4 + 1780, c12 = 64 * 12 * 4 + 281 * 4 + 1240;
+            const int64_t plain = ((int64_t)gxw * gyw + cus - 1) / cus * c16;
+            int64_t best = plain;
+            int by = 0, bk = 0, bj = 0;
+            for (int kbig = gyw - 1; kbig >= 0; --kbig) {
+                const int64_t rem = m - 256 * (int64_t)kbig;
+                if (rem % 192) continue;
+                const int js = (int)(rem / 192);
+                for (int ys = 8; ys <= gxw; ys += 8) {
+                    const int64_t big = (int64_t)gyw * (gxw - ys) + (int64_t)kbig * ys, small = (int64_t)js * ys;
+                    const int64_t cost = (big + cus - 1) / cus * c16 + (small + cus - 1) / cus * c12;
+                    if (cost < best) { best = cost; by = ys; bk = kbig; bj = js; }
+                }
+            }
+            if (by > 0 && best * 100 <= plain * 95) {
+                const int s0 = gxw - by;
+                const int64_t per_xcd_a = (int64_t)((s0 + 7) / 8) * gyw + (int64_t)((by + 7) / 8) * bk;
+                const WideMap ma = {gxw, gyw, s0, bk, 0, 0};
+                const WideMap mb = {by, bj, by, 0, s0, 256 * bk};
+                ZL_WIDE_LAUNCH_MAP(16, 4, ma, per_xcd_a * 8, 1)
+                st = zl_launch_status();
+                if (st) return st;
+                ZL_WIDE_LAUNCH_MAP(12, 4, mb, (int64_t)((by + 7) / 8) * 8 * bj, 1)
+                return zl_launch_status();
+            }
+        }
+        const WideMap mw = {gxw, gyw, gxw, 0, 0, 0};
+#define ZL_WIDE_LAUNCH(RBV, NTV) ZL_WIDE_LAUNCH_MAP(RBV, NTV, mw, wgs, splits)
         if (rbw == 16 && ntw == 4) ZL_WIDE_LAUNCH(16, 4)
         else if (rbw == 16 && ntw == 3) ZL_WIDE_LAUNCH(16, 3)
         else if (rbw == 16) ZL_WIDE_LAUNCH(16, 2)
@@ -832,6 +886,7 @@ extern "C" int zl_w4a16_gemm_tiled_ex(const uint16_t* x, int64_t ldx, const uint
         else if (ntw == 3) ZL_WIDE_LAUNCH(8, 3)
         else ZL_WIDE_LAUNCH(8, 2)
 #undef ZL_WIDE_LAUNCH
+#undef ZL_WIDE_LAUNCH_MAP
         st = zl_launch_status();
         if (st || splits <= 1) return st;
         return launch_splitk_epilogue(p.ws, splits, m, n, p.ld_ws, bias, residual, y, epilogue, p.ld_out, hs);
