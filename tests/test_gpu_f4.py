@@ -433,6 +433,73 @@ def test_moe_feed_forward_flow_equals_the_per_token_sum(dev, tokens, router, dty
         moe.shared = routed
 
 
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("tokens", [5, 41])
+def test_moe_feed_forward_expert_parallel(dev, tokens, world):
+    """MOE_EXP_PARALLEL of the reference (feedforward.cpp:251-305, :599-629, :1079-1150) in zhilight_amd/moe.py: rank r holds the experts
+    e % world == r, routes every token, sorts the (token, slot) pairs by (rank, expert), takes its slice, and returns the PARTIAL sum of
+    its experts (+ its shard of the tensor-parallel shared expert) that the layer's all-reduce completes.  All ranks run here one after
+    the other on one device: a token whose experts all live on one rank comes out of that rank with the BITS of the one-rank flow minus
+    the shared part and as exact zeros from the others; every row's rank partials add up to the one-rank result within the roundings
+    of the partials."""
+    from zhilight_amd.moe import Fp8BlockMoE
+    g = torch.Generator(device="cpu").manual_seed(300 + tokens + world)
+    e, k, dim, ff, dtype = 32, 2, 256, 256, torch.bfloat16
+
+    def codes(*shape):
+        return (torch.randint(0, 0x78, shape, generator=g, dtype=torch.int32) | (torch.randint(0, 2, shape, generator=g, dtype=torch.int32) << 7)) \
+            .to(torch.uint8).to(dev)
+
+    def scales(*shape):
+        return (torch.rand(shape, generator=g) * 0.008 + 0.002).to(dev)
+
+    router = (torch.randn(e, dim, generator=g) * 0.5).to(dtype).to(dev)
+    w_in, s_in, w_g, s_g = codes(e, ff, dim), scales(e, ff // 128, dim // 128), codes(e, ff, dim), scales(e, ff // 128, dim // 128)
+    w_out, s_out = codes(e, dim, ff), scales(e, dim // 128, ff // 128)
+    ffs = 128 * world                                                          # the shared expert: one 128-row block of dim_ff per rank
+    sh = (codes(ffs, dim), scales(ffs // 128, dim // 128), codes(ffs, dim), scales(ffs // 128, dim // 128), codes(dim, ffs), scales(dim // 128, ffs // 128))
+    x = torch.randn(tokens, dim, generator=g).to(dtype).to(dev)
+    one = Fp8BlockMoE(router, w_in, s_in, w_g, s_g, w_out, s_out, top_k=k)
+    want_routed = one.forward(x).float()
+    one.shared = sh
+    want = one.forward(x).float()
+    ids = one.route(x)[0].cpu().numpy()
+    parts_routed, parts = [], []
+    for r in range(world):
+        sl = slice(r, None, world)
+        moe = Fp8BlockMoE(router, w_in[sl].contiguous(), s_in[sl].contiguous(), w_g[sl].contiguous(), s_g[sl].contiguous(), w_out[sl].contiguous(),
+                          s_out[sl].contiguous(), top_k=k, world_size=world, rank=r)
+        parts_routed.append(moe.forward(x))
+        blk = slice(128 * r, 128 * (r + 1))
+        moe.shared = (sh[0][blk].contiguous(), sh[1][r:r + 1].contiguous(), sh[2][blk].contiguous(), sh[3][r:r + 1].contiguous(),
+                      sh[4][:, blk].contiguous(), sh[5][:, r:r + 1].contiguous())
+        parts.append(moe.forward(x))
+    one.shared = None
+    bits_one = one.forward(x).view(torch.int16)
+    seen_single = 0
+    for t in range(tokens):
+        owners = {int(i) % world for i in ids[t]}
+        if len(owners) == 1:                                                   # all of the token's experts on one rank
+            seen_single += 1
+            own = owners.pop()
+            for r in range(world):
+                row = parts_routed[r][t]
+                if r == own:
+                    assert torch.equal(row.view(torch.int16), bits_one[t]), (t, r)
+                else:
+                    assert not row.float().abs().any(), (t, r)
+    assert seen_single > 0 or tokens < 8
+    # bf16 roundings (half an ulp = 2^-8 relative at worst): per rank the routed partial, the shared partial and their sum; on the
+    # one-rank side the routed sum, the shared output and the total.  (A wrong expert, weight or row would be off by O(1) relative.)
+    mag = sum(pr_.float().abs() + (p_.float() - pr_.float()).abs() for pr_, p_ in zip(parts_routed, parts))
+    for pr, w_, m_ in ((parts_routed, want_routed, sum(p_.float().abs() for p_ in parts_routed)), (parts, want, mag)):
+        total = sum(p_.float() for p_ in pr)
+        bar = 2.0 ** -6 * m_ + 2.0 ** -7 * (want_routed.abs() + (want - want_routed).abs()) + 1e-6
+        bad = (total - w_).abs() > bar
+        assert not bool(bad.any()), (int(bad.sum()), float(((total - w_).abs() / (m_ + 1e-9)).max()))
+        assert float(w_.abs().max()) > 0
+
+
 @pytest.mark.parametrize("scoring", ["softmax", "sigmoid", "linear"])
 def test_top_k_router_ties(oracle, dev, scoring):
     """logits from a handful of levels: most of the top-k boundary is a TIE.  The reference's insertion sort never lets a later

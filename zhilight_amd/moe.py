@@ -12,8 +12,12 @@ forward_gpu_dispatch), strung together from the C-ABI launchers of zhilight_amd/
     y[token] = sum_slot weight * w2[run(expert) + rev]   sum_experts (per-expert inputs)       -> zl_moe_sum_experts_arr
     y += shared_expert(x)                                with_share (:483-492)                 -> zl_fp8_block_gemm_group x3, zl_element_add_scale
 
-One rank; the shared expert is the static one (expert / data parallel modes and the load-balanced shared experts of route_shared_lb
-are wired in ops but not in this flow yet).  Since round 4 the sort and the row scatters are launchers of the C ABI as well
+Expert parallel (MOE_EXP_PARALLEL=1 in the reference, feedforward.cpp:251-305): rank r of `world_size` holds the experts e with
+e % world_size == r (local index e // world_size); every rank routes ALL tokens (the hidden rows are replicated), sorts the (token, slot)
+pairs by (rank, expert) -- plus_for_sort -- takes ITS slice of the order, runs its grouped GEMMs and combines only its experts' rows;
+forward() then returns this rank's PARTIAL sum, which the layer's ordinary all-reduce (ModelContext::reduce_sum, block.cpp:123-140)
+completes.  A static shared expert is tensor-parallel in that mode (its dim_ff sharded: the caller passes the rank's shard), so its partial
+rides the same all-reduce.  The load-balanced shared experts of route_shared_lb (MOE_DYN_SHARED) are wired in ops but not in this flow.  Since round 4 the sort and the row scatters are launchers of the C ABI as well
 (functions::arange / sort_pair_1d / divide / scatter_update_dim0); what is left to the framework is the scale transpose and
 slicing views -- there is no CPU or torch fallback for any arithmetic or index step."""
 from typing import Optional
@@ -29,11 +33,18 @@ class Fp8BlockMoE:
 
     def __init__(self, router, w_in, s_in, w_gated, s_gated, w_out, s_out, top_k, norm_topk_prob=True, routed_scaling_factor=1.0,
                  scoring_func="softmax", n_group=1, topk_group=1, e_score_correction_bias: Optional[torch.Tensor] = None, act="silu",
-                 block_m=64, shared=None):
-        """shared: None or (w_in (ff_s, dim), s_in, w_gated, s_gated, w_out (dim, ff_s), s_out) of the always-on shared expert"""
+                 block_m=64, shared=None, world_size=1, rank=0):
+        """shared: None or (w_in (ff_s, dim), s_in, w_gated, s_gated, w_out (dim, ff_s), s_out) of the always-on shared expert.
+        world_size > 1: expert parallel -- the stacked weights hold THIS rank's experts (global e = local * world_size + rank), the router
+        stays global (E = experts_local * world_size rows)"""
+        self.world_size, self.rank = int(world_size), int(rank)
+        if self.world_size < 1 or not 0 <= self.rank < self.world_size:
+            raise ops.ZLError("Fp8BlockMoE: rank outside the world")
         self.router, self.top_k = router, top_k
         self.w_in, self.s_in, self.w_gated, self.s_gated, self.w_out, self.s_out = w_in, s_in, w_gated, s_gated, w_out, s_out
-        self.num_experts = w_in.shape[0]
+        self.num_experts = w_in.shape[0] * self.world_size                  # global
+        if router.shape[0] != self.num_experts:
+            raise ops.ZLError("Fp8BlockMoE: the router has one row per GLOBAL expert")
         self.norm_topk_prob, self.routed_scaling_factor, self.scoring_func = norm_topk_prob, routed_scaling_factor, scoring_func
         self.n_group, self.topk_group, self.bias, self.act, self.block_m = n_group, topk_group, e_score_correction_bias, act, block_m
         self.shared = shared
@@ -43,15 +54,15 @@ class Fp8BlockMoE:
     def route(self, x):
         """(ids (T, k) int32, weights (T, k) fp32, all_loads (E + 1,) int32: tokens per expert | per rank) -- FeedForward::route"""
         logits = ops.gemm_nt_f32(x, self.router)                               # fp32 logits, as the reference's router Linear (set_output_type(kFloat))
-        all_loads = torch.zeros(self.num_experts + 1, dtype=torch.int32, device=x.device)
+        all_loads = torch.zeros(self.num_experts + self.world_size, dtype=torch.int32, device=x.device)
         expert_load, worker_load = all_loads[:self.num_experts], all_loads[self.num_experts:]
         if self.topk_group > 1:
             w, ids = ops.moe_group_topk(logits, self.bias, self.n_group, self.topk_group, self.top_k, norm_topk_prob=self.norm_topk_prob,
                                         weight_scale=self.routed_scaling_factor, scoring_func=self.scoring_func, worker_load=worker_load,
-                                        expert_load=expert_load, num_worker=1)
+                                        expert_load=expert_load, num_worker=self.world_size)
         else:
             w, ids = ops.moe_top_k_softmax(logits, self.top_k, norm_topk_prob=self.norm_topk_prob, weight_scale=self.routed_scaling_factor,
-                                           scoring_func=self.scoring_func, worker_load=worker_load, expert_load=expert_load, num_worker=1)
+                                           scoring_func=self.scoring_func, worker_load=worker_load, expert_load=expert_load, num_worker=self.world_size)
         return ids, w, all_loads
 
     def with_share(self, x, ret):
@@ -72,14 +83,22 @@ class Fp8BlockMoE:
         e, k = self.num_experts, self.top_k
         ids, weights, all_loads_t = self.route(x)
         all_loads = all_loads_t.cpu().tolist()                               # (the reference's to_vector: the one host sync of the flow)
-        m_indices, padded_idx, total = ops.moe_fill_m_indices_padded_indices(all_loads, self.block_m, e, x.device)
-        if total == 0:
+        ws, rk = self.world_size, self.rank
+        ep = ws > 1
+        m_indices, padded_idx, total = ops.moe_fill_m_indices_padded_indices(all_loads, self.block_m, e, x.device, exp_parallel=ep, rank=rk,
+                                                                            world_size=ws)
+        if total == 0:                                                        # (EP: none of this rank's experts was picked)
             return self.with_share(x, torch.zeros_like(x))
         # (token, slot) pairs sorted by expert, stable: sorted position j holds pair order[j]; its token is order[j] // k
-        # FeedForward::sort_token (feedforward.cpp:599-629): arange, stable sort_pair_1d by expert id, divide by top_k -- kernels since round 4
+        # FeedForward::sort_token (feedforward.cpp:599-629): arange, stable sort_pair_1d by expert id -- by (rank, expert id) under EP:
+        # plus_for_sort -- then THIS rank's slice of the order, divided by top_k; kernels since round 4
         flat = ids.reshape(-1).contiguous()
-        _, order = ops.sort_pairs_i32(flat, ops.arange_i32(flat.numel(), x.device), max_key=2 * e)
-        rev = ops.moe_calc_reverse_idx(ids, order, all_loads, e)
+        keys = ops.moe_plus_for_sort(flat, e, ws) if ep else flat
+        _, order = ops.sort_pairs_i32(keys, ops.arange_i32(flat.numel(), x.device), max_key=e * (1 + ws))
+        rev = ops.moe_calc_reverse_idx(ids, order, all_loads, e, world_size=ws, sorted_by_rank=ep)
+        if ep:
+            local_start, rank_load = sum(all_loads[e:e + rk]), all_loads[e + rk]
+            order = order[local_start:local_start + rank_load].contiguous()
         sorted_tokens = ops.divide_i32(order, k)
         # grouped input (get_grouped_input_gpu, :1040-1075): codes and 1x128 scales of the sorted tokens scattered to the 64-aligned
         # positions (scatter_update_dim0), padding rows zero
@@ -95,12 +114,16 @@ class Fp8BlockMoE:
         b8, sb = ops.fp8_per_token_cast(w0)                                   # Fp8Block::quant_input of the grouped rows (total % 4 == 0)
         w2 = ops.fp8_block_gemm(b8, sb, self.w_out, self.s_out, m_indices=m_indices, dtype=x.dtype)
         # each expert's run of w2 (global expert order, 64-aligned starts), then the weighted combine
+        # (EP: only this rank's experts have rows; sum_experts skips the others, so the result is the rank's partial)
         parts, off = [], 0
         for exp in range(e):
             n = all_loads[exp]
-            parts.append(w2[off:off + n] if n > 0 else None)
-            off += (n + self.block_m - 1) // self.block_m * self.block_m
-        return self.with_share(x, ops.moe_sum_experts_arr(parts, ids.reshape(-1), rev, weights))
+            if n > 0 and exp % ws == rk:
+                parts.append(w2[off:off + n])
+                off += (n + self.block_m - 1) // self.block_m * self.block_m
+            else:
+                parts.append(None)
+        return self.with_share(x, ops.moe_sum_experts_arr(parts, ids.reshape(-1), rev, weights, exp_parallel=ep, world_size=ws, local_rank=rk))
 
     def forward_per_token(self, x):
         """the same sum written token by token and slot by slot (Fp8Block::forward per expert on one row) -- what the grouped flow
