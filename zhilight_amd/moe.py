@@ -38,8 +38,9 @@ class Fp8BlockMoE:
         world_size > 1: expert parallel -- the stacked weights hold THIS rank's experts (global e = local * world_size + rank), the router
         stays global (E = experts_local * world_size rows)"""
         self.world_size, self.rank = int(world_size), int(rank)
-        if self.world_size < 1 or not 0 <= self.rank < self.world_size:
-            raise ops.ZLError("Fp8BlockMoE: rank outside the world")
+        if self.world_size < 1 or not 0 <= self.rank < self.world_size or self.world_size & (self.world_size - 1):
+            raise ops.ZLError("Fp8BlockMoE: world_size is a power of two (the combine masks expert ids with world_size - 1, as the "
+                              "reference does) and 0 <= rank < world_size")
         self.router, self.top_k = router, top_k
         self.w_in, self.s_in, self.w_gated, self.s_gated, self.w_out, self.s_out = w_in, s_in, w_gated, s_gated, w_out, s_out
         self.num_experts = w_in.shape[0] * self.world_size                  # global
