@@ -500,6 +500,56 @@ def test_moe_feed_forward_expert_parallel(dev, tokens, world):
         assert float(w_.abs().max()) > 0
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_moe_feed_forward_load_balanced_shared_expert(dev, world):
+    """MOE_DYN_SHARED of the reference (feedforward.cpp:268-276 pseudo expert ids, :459-462 route_shared_lb): every rank keeps a copy of the
+    shared expert behind its routed ones, the router writes top_k + 1 slots (the extra one with weight 1) and route_shared_lb gives each
+    token's shared slot to the first rank with spare capacity.  The rank partials must add up to the one-rank flow with the STATIC shared
+    expert, every token's shared slot must name a pseudo expert, and the ranks' loads must be level (the point of the exercise)."""
+    from zhilight_amd.moe import Fp8BlockMoE
+    g = torch.Generator(device="cpu").manual_seed(500 + world)
+    e, k, dim, ff, tokens, dtype = 16, 2, 256, 256, 45, torch.bfloat16
+
+    def codes(*shape):
+        return (torch.randint(0, 0x78, shape, generator=g, dtype=torch.int32) | (torch.randint(0, 2, shape, generator=g, dtype=torch.int32) << 7)) \
+            .to(torch.uint8).to(dev)
+
+    def scales(*shape):
+        return (torch.rand(shape, generator=g) * 0.008 + 0.002).to(dev)
+
+    router = (torch.randn(e, dim, generator=g) * 0.5).to(dtype).to(dev)
+    w_in, s_in, w_g, s_g = codes(e, ff, dim), scales(e, ff // 128, dim // 128), codes(e, ff, dim), scales(e, ff // 128, dim // 128)
+    w_out, s_out = codes(e, dim, ff), scales(e, dim // 128, ff // 128)
+    sh = (codes(ff, dim), scales(ff // 128, dim // 128), codes(ff, dim), scales(ff // 128, dim // 128), codes(dim, ff), scales(dim // 128, ff // 128))
+    x = torch.randn(tokens, dim, generator=g).to(dtype).to(dev)
+    one = Fp8BlockMoE(router, w_in, s_in, w_g, s_g, w_out, s_out, top_k=k, shared=sh)
+    want = one.forward(x).float()
+    one.shared = None
+    want_routed = one.forward(x).float()
+    parts = []
+    for r in range(world):
+        sl = slice(r, None, world)
+        stack = lambda routed, extra: torch.cat([routed[sl], extra[None]], dim=0).contiguous()
+        moe = Fp8BlockMoE(router, stack(w_in, sh[0]), stack(s_in, sh[1]), stack(w_g, sh[2]), stack(s_g, sh[3]), stack(w_out, sh[4]), stack(s_out, sh[5]),
+                          top_k=k, world_size=world, rank=r, dyn_shared=1)
+        if r == 0:
+            ids, w, loads = moe.route(x)
+            ids, w, loads = ids.cpu().numpy(), w.cpu().numpy(), loads.cpu().numpy()
+            assert ids.shape == (tokens, k + 1) and (w[:, k] == 1.0).all()
+            assert (ids[:, :k] < e).all() and (ids[:, k] >= e).all() and (ids[:, k] < e + world).all()
+            rank_loads = loads[e + world:]
+            assert rank_loads.sum() == tokens * (k + 1) and loads[:e + world].sum() == tokens * (k + 1)
+            routed_only = np.array([(ids[:, :k] % world == rr).sum() for rr in range(world)])
+            assert (rank_loads >= routed_only).all()
+            assert rank_loads.max() - rank_loads.min() <= max(1, routed_only.max() - routed_only.min())      # the shared slots level the ranks
+        parts.append(moe.forward(x))
+    total = sum(p_.float() for p_ in parts)
+    mag = sum(p_.float().abs() for p_ in parts) + want_routed.abs() + (want - want_routed).abs()
+    bad = (total - want).abs() > 2.0 ** -6 * mag + 1e-6
+    assert not bool(bad.any()), (int(bad.sum()), float(((total - want).abs() / (mag + 1e-9)).max()))
+    assert float((want - want_routed).abs().max()) > 0
+
+
 @pytest.mark.parametrize("scoring", ["softmax", "sigmoid", "linear"])
 def test_top_k_router_ties(oracle, dev, scoring):
     """logits from a handful of levels: most of the top-k boundary is a TIE.  The reference's insertion sort never lets a later

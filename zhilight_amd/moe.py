@@ -17,7 +17,10 @@ e % world_size == r (local index e // world_size); every rank routes ALL tokens 
 pairs by (rank, expert) -- plus_for_sort -- takes ITS slice of the order, runs its grouped GEMMs and combines only its experts' rows;
 forward() then returns this rank's PARTIAL sum, which the layer's ordinary all-reduce (ModelContext::reduce_sum, block.cpp:123-140)
 completes.  A static shared expert is tensor-parallel in that mode (its dim_ff sharded: the caller passes the rank's shard), so its partial
-rides the same all-reduce.  The load-balanced shared experts of route_shared_lb (MOE_DYN_SHARED) are wired in ops but not in this flow.  Since round 4 the sort and the row scatters are launchers of the C ABI as well
+rides the same all-reduce.  Load-balanced shared experts (MOE_DYN_SHARED=1, feedforward.cpp:268-276, :459-462): every rank keeps a full
+copy of the n shared experts BEHIND its routed ones (pseudo expert ids (experts_local + s) * world_size + rank); the router writes
+top_k + n slots per token, the extra ones with weight 1, and route_shared_lb hands each of them to the first rank that still has spare
+capacity -- from there on they are ordinary experts of the grouped flow.  Since round 4 the sort and the row scatters are launchers of the C ABI as well
 (functions::arange / sort_pair_1d / divide / scatter_update_dim0); what is left to the framework is the scale transpose and
 slicing views -- there is no CPU or torch fallback for any arithmetic or index step."""
 from typing import Optional
@@ -33,19 +36,25 @@ class Fp8BlockMoE:
 
     def __init__(self, router, w_in, s_in, w_gated, s_gated, w_out, s_out, top_k, norm_topk_prob=True, routed_scaling_factor=1.0,
                  scoring_func="softmax", n_group=1, topk_group=1, e_score_correction_bias: Optional[torch.Tensor] = None, act="silu",
-                 block_m=64, shared=None, world_size=1, rank=0):
+                 block_m=64, shared=None, world_size=1, rank=0, dyn_shared=0):
         """shared: None or (w_in (ff_s, dim), s_in, w_gated, s_gated, w_out (dim, ff_s), s_out) of the always-on shared expert.
         world_size > 1: expert parallel -- the stacked weights hold THIS rank's experts (global e = local * world_size + rank), the router
-        stays global (E = experts_local * world_size rows)"""
+        stays global (E = experts_local * world_size rows).
+        dyn_shared = n > 0: the LAST n experts of the stack are this rank's copies of the n load-balanced shared experts (the router then has
+        (experts_local - n) * world_size rows); excludes a static `shared`"""
         self.world_size, self.rank = int(world_size), int(rank)
         if self.world_size < 1 or not 0 <= self.rank < self.world_size or self.world_size & (self.world_size - 1):
             raise ops.ZLError("Fp8BlockMoE: world_size is a power of two (the combine masks expert ids with world_size - 1, as the "
                               "reference does) and 0 <= rank < world_size")
         self.router, self.top_k = router, top_k
         self.w_in, self.s_in, self.w_gated, self.s_gated, self.w_out, self.s_out = w_in, s_in, w_gated, s_gated, w_out, s_out
-        self.num_experts = w_in.shape[0] * self.world_size                  # global
-        if router.shape[0] != self.num_experts:
-            raise ops.ZLError("Fp8BlockMoE: the router has one row per GLOBAL expert")
+        self.dyn_shared = int(dyn_shared)
+        self.num_experts = w_in.shape[0] * self.world_size                  # global, pseudo ids of the balanced shared experts included
+        self.num_routed = self.num_experts - self.dyn_shared * self.world_size
+        if self.dyn_shared < 0 or self.num_routed <= 0 or (self.dyn_shared and shared is not None):
+            raise ops.ZLError("Fp8BlockMoE: dyn_shared experts sit behind at least one routed expert and exclude a static shared expert")
+        if router.shape[0] != self.num_routed:
+            raise ops.ZLError("Fp8BlockMoE: the router has one row per GLOBAL routed expert")
         self.norm_topk_prob, self.routed_scaling_factor, self.scoring_func = norm_topk_prob, routed_scaling_factor, scoring_func
         self.n_group, self.topk_group, self.bias, self.act, self.block_m = n_group, topk_group, e_score_correction_bias, act, block_m
         self.shared = shared
@@ -57,13 +66,16 @@ class Fp8BlockMoE:
         logits = ops.gemm_nt_f32(x, self.router)                               # fp32 logits, as the reference's router Linear (set_output_type(kFloat))
         all_loads = torch.zeros(self.num_experts + self.world_size, dtype=torch.int32, device=x.device)
         expert_load, worker_load = all_loads[:self.num_experts], all_loads[self.num_experts:]
+        ext = self.top_k + self.dyn_shared
         if self.topk_group > 1:
-            w, ids = ops.moe_group_topk(logits, self.bias, self.n_group, self.topk_group, self.top_k, norm_topk_prob=self.norm_topk_prob,
+            w, ids = ops.moe_group_topk(logits, self.bias, self.n_group, self.topk_group, self.top_k, top_k_ext=ext, norm_topk_prob=self.norm_topk_prob,
                                         weight_scale=self.routed_scaling_factor, scoring_func=self.scoring_func, worker_load=worker_load,
                                         expert_load=expert_load, num_worker=self.world_size)
         else:
-            w, ids = ops.moe_top_k_softmax(logits, self.top_k, norm_topk_prob=self.norm_topk_prob, weight_scale=self.routed_scaling_factor,
+            w, ids = ops.moe_top_k_softmax(logits, self.top_k, top_k_ext=ext, norm_topk_prob=self.norm_topk_prob, weight_scale=self.routed_scaling_factor,
                                            scoring_func=self.scoring_func, worker_load=worker_load, expert_load=expert_load, num_worker=self.world_size)
+        if self.dyn_shared:                                                    # the extra slots: the first rank with spare capacity (route_shared_lb)
+            ops.moe_route_shared_lb(ids, w, worker_load, expert_load, self.top_k, self.num_routed // self.world_size)
         return ids, w, all_loads
 
     def with_share(self, x, ret):
@@ -81,7 +93,7 @@ class Fp8BlockMoE:
         if x.dim() != 2 or x.dtype not in (torch.float16, torch.bfloat16):
             raise ops.ZLError("Fp8BlockMoE: (tokens, dim_model) half or bfloat16 rows")
         tokens, dim = x.shape
-        e, k = self.num_experts, self.top_k
+        e, k = self.num_experts, self.top_k + self.dyn_shared              # (num_experts_may_share, top_k_may_share)
         ids, weights, all_loads_t = self.route(x)
         all_loads = all_loads_t.cpu().tolist()                               # (the reference's to_vector: the one host sync of the flow)
         ws, rk = self.world_size, self.rank
