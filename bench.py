@@ -327,6 +327,88 @@ def check_against_oracle(model, batch, dev):
     return worst
 
 
+def check_logits_against_oracle(model, ctx, dev):
+    """a LOGIT of the timed model, not isolated linears.  Before anything is timed the step bench.py is about to
+    time -- all 32 layers, the synthetic 1 024-key history, the full lm_head -- runs once eagerly, and the CPU oracle evaluates the
+    SAME network: every packed weight unpacked again (zl_w4m_unpack: fused q|k|v rows split, gate / up de-interleaved), the KV
+    buffers and norm weights copied from the device, exact (fp64) linears rounded once to fp16 ("E", the flavour the 1e-3 bar of
+    tests/test_gpu_fullgeom.py is held against).  Reports max|logit - ref| / max|ref|; never raises (a failure here must not cost
+    the bench line: it is reported as {"error": ...})."""
+    import time
+    import numpy as np
+    try:
+        t0 = time.time()
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import zl_oracle as zo
+        from test_gpu_model import OracleModel
+        from zhilight_amd import ops
+        cfg = model.cfg
+        b = ctx.tokens.numel()
+        hd, kvd = cfg.num_heads * cfg.dim_head, cfg.num_kv_heads * cfg.dim_head
+        u16 = lambda t: t.detach().to(torch.float16).cpu().numpy().view(np.uint16)
+        om = OracleModel.__new__(OracleModel)
+        om.o, om.cfg, om.g, om.kv_quant, om.exact_attention = zo, cfg, 128, False, False
+        rs = cfg.rope_scaling
+        om.rope_kind = (rs.get("rope_type", rs.get("type")) or "plain") if rs else "plain"
+        if om.rope_kind == "default":
+            om.rope_kind = "plain"
+        tokens = ctx.tokens.cpu().numpy().astype(np.int32)
+        pos = [int(p) for p in ctx.positions.cpu().numpy()]
+        # the embedding rows of the step's tokens as a table of their own (token i -> row i), norms and lm_head as they are
+        om.sd = {"model.embed_tokens.weight": u16(model.token_embedding[torch.from_numpy(tokens).long().to(dev)]).view(np.float16),
+                 "model.norm.weight": u16(model.output_layernorm).view(np.float16), "lm_head.weight": u16(model.lm_head).view(np.float16)}
+        om.km = {}
+
+        def unpack(w):
+            qw, qz, sc = (t.cpu().numpy() for t in w.to_k_major())          # checkpoint row order (a row-interleaved weight is undone)
+            return qw.view(np.uint32), qz, sc.view(np.uint16)
+
+        def rows(km, sl):
+            return tuple(np.ascontiguousarray(a[sl]) for a in km)
+        ff = cfg.dim_ff
+        for i, layer in enumerate(model.layers):
+            for lin in (layer.qkv, layer.attn_out, layer.w_in_gated, layer.w_out):
+                if not isinstance(lin.weight, ops.W4MWeight) or lin.perm is not None or lin.bias is not None:
+                    return None
+            pfx = "model.layers.%d." % i
+            om.sd[pfx + "input_layernorm.weight"] = u16(layer.ln_attn).view(np.float16)
+            om.sd[pfx + "post_attention_layernorm.weight"] = u16(layer.ln_ff).view(np.float16)
+            qkv, gu = unpack(layer.qkv.weight), unpack(layer.w_in_gated.weight)
+            om.km[pfx + "self_attn.q_proj"] = rows(qkv, slice(0, hd))
+            om.km[pfx + "self_attn.k_proj"] = rows(qkv, slice(hd, hd + kvd))
+            om.km[pfx + "self_attn.v_proj"] = rows(qkv, slice(hd + kvd, hd + 2 * kvd))
+            om.km[pfx + "self_attn.o_proj"] = unpack(layer.attn_out.weight)
+            om.km[pfx + "mlp.gate_proj"] = rows(gu, slice(0, ff))            # w_in (the activated half), then w_gated
+            om.km[pfx + "mlp.up_proj"] = rows(gu, slice(ff, 2 * ff))
+            om.km[pfx + "mlp.down_proj"] = unpack(layer.w_out.weight)
+        om.len_buf = int(ctx.kv[0].shape[2])
+        om.kb = [[u16(ctx.kv[t][i, 0]).copy() for t in range(b)] for i in range(cfg.num_layers)]
+        om.vb = [[u16(ctx.kv[t][i, 1]).copy() for t in range(b)] for i in range(cfg.num_layers)]
+        got = model.encode(ctx).float().cpu().numpy().astype(np.float64)
+        ids = np.arange(b, dtype=np.int32)
+        ref, _ = om.step(ids, pos, flavour="E", commit=False)
+        # the network's own conditioning: E with ONE fp16 rounding in 2 000 of layer 0's q projection moved by an ulp ("T": what any
+        # other equally exact kernel does), and the reference's arithmetic ("R": fp16 partial sums of its warp-reduce kernel)
+        ref_t, _ = om.step(ids, pos, flavour="T", commit=False)
+        ref_r, _ = om.step(ids, pos, flavour="R", commit=False)
+        scale = np.abs(ref).max()
+        dist = lambda a, c: float(np.abs(a - c).max() / scale)
+        err, t_e, r_e, err_r = dist(got, ref), dist(ref_t, ref), dist(ref_r, ref), dist(got, ref_r)
+        best = ref.argmax(axis=1)
+        same = bool(all(ref[r, best[r]] - ref[r, int(got[r].argmax())] <= 2e-3 * scale for r in range(b)))
+        return {"what": "logits of the step that is timed (32 layers, %d keys of history, %d-row lm_head) vs the CPU oracle's evaluation of the "
+                        "same network from the unpacked bench weights.  E: exact linears rounded once to fp16; T: E with one rounding in 2000 "
+                        "of layer 0's q projection moved by an ulp (the network's conditioning); R: the reference's fp16 partial sums.  "
+                        "Distances are max|a - b| / max|E|" % (pos[0], ref.shape[1]),
+                "vs_E": round(err, 6), "T_vs_E": round(t_e, 6), "R_vs_E": round(r_e, 6), "vs_R": round(err_r, 6),
+                # the two bars of tests/test_gpu_fullgeom.py: the conditioned one against E, north_star's against the reference path
+                "within_conditioned_bar_vs_E": bool(err <= max(1e-3, 1.25 * t_e)), "within_bar_vs_R": bool(err_r <= 1e-3 + r_e),
+                "greedy_token_agrees": same, "seconds": round(time.time() - t0, 1)}
+    except Exception as e:      # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -384,6 +466,10 @@ def main():
     ctx = model.new_context(batch, len_buf, seq, fill_random=True, kv_cache_dtype=None if args.kv_cache_dtype == "fp16" else "int8")
     ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
     oracle_check = check_against_oracle(model, batch, dev) if (rank == 0 and not int8 and tp is None) else None
+    logit_check = None
+    if (rank == 0 and world == 1 and not int8 and tp is None and batch == 1 and not args.no_cpu_baseline and not args.layers
+            and args.kv_cache_dtype == "fp16" and os.environ.get("ZL_BENCH_LOGIT_CHECK", "1") != "0"):
+        logit_check = check_logits_against_oracle(model, ctx, dev)
 
     # ---- TTFT leg (rank 0, reported next to the decode metric): encode a `seq`-token prompt of one task
     # (M-tiled W4A16 GEMMs, causal attention) and pick the first token.  HIP events around eager launches.
@@ -532,6 +618,7 @@ def main():
             "oracle_check": None if oracle_check is None else {
                 "what": "layer 0 and last layer, four W4A16 linears each, HIP output vs the CPU oracle's exact product of the "
                         "unpacked (zl_w4m_unpack) bench weights, before the timed region", "max_err_over_max_ref": round(oracle_check, 6)},
+            "logit_check": logit_check,
         }
         if world == 1 and not args.no_cpu_baseline and not int8:
             out["cpu_baseline"] = cpu_baseline(cfg, batch, seq)
