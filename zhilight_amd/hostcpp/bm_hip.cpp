@@ -248,8 +248,12 @@ void Tensor::from_buffer(const void* host, bool async, hipStream_t stream) {
         std::memcpy(data(), host, nbytes());
         return;
     }
+    // No stream given: the copy would ride the null stream, which does NOT order against the context's non-blocking stream -- and the
+    // pool hands out blocks whose last kernel may still be queued there (a copy racing that kernel is a corrupted tensor, timing
+    // dependent).  Wait for the device first; callers that know their stream pass it (Context::tensor_of does).
+    if (!stream) BM_HIPRT_ASSERT(hipDeviceSynchronize());
     BM_HIPRT_ASSERT(hipMemcpyAsync(data(), host, nbytes(), hipMemcpyHostToDevice, stream));
-    if (!async) BM_HIPRT_ASSERT(hipStreamSynchronize(stream));
+    if (!async || !stream) BM_HIPRT_ASSERT(hipStreamSynchronize(stream));
 }
 void Tensor::to_buffer(void* host, hipStream_t stream) const {
     BM_ASSERT(is_continuous(), "to_buffer needs a continuous tensor");
@@ -257,6 +261,7 @@ void Tensor::to_buffer(void* host, hipStream_t stream) const {
         std::memcpy(host, data(), nbytes());
         return;
     }
+    if (!stream) BM_HIPRT_ASSERT(hipDeviceSynchronize());      // (as above: the producer may still be queued on the context's stream)
     BM_HIPRT_ASSERT(hipMemcpyAsync(host, data(), nbytes(), hipMemcpyDeviceToHost, stream));
     BM_HIPRT_ASSERT(hipStreamSynchronize(stream));
 }

@@ -229,7 +229,7 @@ public:
     template <typename T> Tensor tensor_of(const std::vector<T>& data, const std::vector<size_t>& shape, DataType dt) const {
         Tensor t = tensor(shape, dt);
         BM_ASSERT_EQ(data.size() * sizeof(T), t.nbytes(), "data not fit for tensor");
-        t.from_buffer(data.data());
+        t.from_buffer(data.data(), false, current_cuda_stream());     // ordered behind the block's previous user on this stream
         return t;
     }
     template <typename T, typename DTD = DTypeDeducer<T>>
@@ -237,7 +237,7 @@ public:
         if (data.empty()) return Tensor();
         Tensor t = tensor(shape, DTD::data_type());
         if (data.size() != t.numel()) throw std::runtime_error("data not fit for tensor");
-        t.from_buffer(data.data());
+        t.from_buffer(data.data(), false, current_cuda_stream());
         return t;
     }
     template <typename T> Tensor tensor_of(const std::vector<T>& data) const { return tensor_of(data, {data.size()}); }
