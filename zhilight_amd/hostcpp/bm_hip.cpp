@@ -314,6 +314,7 @@ std::ostream& operator<<(std::ostream& os, const Tensor& t) {
     const size_t n = std::min<size_t>(t.numel(), 16), es = get_elem_size(t.dtype_);
     std::vector<char> host(n * es);
     if (t.device_ >= 0) {
+        if (hipDeviceSynchronize() != hipSuccess) return os;      // (the producer may still be queued on a non-blocking stream)
         if (hipMemcpy(host.data(), t.data(), n * es, hipMemcpyDeviceToHost) != hipSuccess) return os;
     } else {
         std::memcpy(host.data(), t.data(), n * es);
