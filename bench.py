@@ -402,6 +402,9 @@ def check_logits_against_oracle(model, ctx, dev):
                         "of layer 0's q projection moved by an ulp (the network's conditioning); R: the reference's fp16 partial sums.  "
                         "Distances are max|a - b| / max|E|" % (pos[0], ref.shape[1]),
                 "vs_E": round(err, 6), "T_vs_E": round(t_e, 6), "R_vs_E": round(r_e, 6), "vs_R": round(err_r, 6),
+                # north_star's bar, unconditioned: within 1e-3 of the exact-linear network AND no further from the reference's arithmetic
+                # than its own fp16 noise + 1e-3 (bench.py exits non-zero when this is false on the 8(d) weights)
+                "within_north_star_bar": bool(err <= 1e-3 and err_r <= 1e-3 + r_e),
                 # the two bars of tests/test_gpu_fullgeom.py: the conditioned one against E, north_star's against the reference path
                 "within_conditioned_bar_vs_E": bool(err <= max(1e-3, 1.25 * t_e)), "within_bar_vs_R": bool(err_r <= 1e-3 + r_e),
                 "greedy_token_agrees": same, "seconds": round(time.time() - t0, 1)}
@@ -461,7 +464,15 @@ def main():
             sys.stderr.write("bench: direct TP transports unavailable (%s); using torch.distributed collectives\n" % str(e).splitlines()[0])
             tp = TPGroup()
         torch.manual_seed(1234)            # every rank must draw the same tokens / KV contents
-    model = LLaMA(cfg, QuantConfig(2, 0) if int8 else QuantConfig(5, 128), dev, tp=tp).init_random(seed=1234 + rank)
+    model = LLaMA(cfg, QuantConfig(2, 0) if int8 else QuantConfig(5, 128), dev, tp=tp)
+    # weights: SURVEY 8(d)'s synthetic GPTQ checkpoint (the recipe of tests/synth.py / tests/test_gpu_fullgeom.py, drawn on the device
+    # and taken through the real load path) -- the draw the hard 1e-3 logit bar is held on.  The INT8 route and the TP leg keep
+    # the direct packed draw (init_random); ZL_BENCH_WEIGHTS=random forces it for an A/B.
+    synth_weights = not int8 and tp is None and os.environ.get("ZL_BENCH_WEIGHTS", "synthetic") != "random"
+    if synth_weights:
+        model.init_synthetic(seed=1234 + rank)
+    else:
+        model.init_random(seed=1234 + rank)
     len_buf = (seq + args.warmup + args.steps + 4 + 63) // 64 * 64
     ctx = model.new_context(batch, len_buf, seq, fill_random=True, kv_cache_dtype=None if args.kv_cache_dtype == "fp16" else "int8")
     ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
@@ -602,7 +613,9 @@ def main():
                        "parallelism": ("tp%d (one model over %d GPUs, RCCL all-reduce)" % (world, world)) if tp else "dp%d (independent TP=1 replicas)" % world,
                        "global_batch": (1 if tp else world) * batch, "seq_len": seq, "valid": not args.layers,
                        "kv_cache_dtype": args.kv_cache_dtype,
-                       "w4_algo": None if int8 else ("mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "exact")},
+                       "w4_algo": None if int8 else ("mfma" if isinstance(model.layers[0].qkv.weight, ops.W4MWeight) else "exact"),
+                       "weights": "SURVEY 8(d) synthetic GPTQ checkpoint (uniform nibbles, zeros 1..15, half-normal scales), device-drawn, "
+                                  "loaded through the checkpoint path" if synth_weights else "packed-layout random draw (init_random)"},
             "per_gpu_tokens_per_s": round(value / world, 2),
             "note_tp": ("TP transports: %s, RCCL communicator over %d ranks (0 = none), one-shot exchange expired waits: %s, step %s; the "
                         "builder's boxes have one GPU: the exchange step is covered there by a two-process model test on one device "
@@ -625,6 +638,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+        if (synth_weights and isinstance(logit_check, dict) and logit_check.get("within_north_star_bar") is False
+                and os.environ.get("ZL_BENCH_PARITY_SOFT", "0") != "1"):
+            sys.stderr.write("bench: the timed model's logits miss north_star's 1e-3 bar on the SURVEY 8(d) weights: %s\n" % json.dumps(logit_check))
+            sys.exit(3)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

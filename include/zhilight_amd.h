@@ -495,6 +495,24 @@ int zl_w4a16_gemm_attn_merge(const void* attn_workspace, const int32_t* buf_lens
                              const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
                              int64_t group_size, int epilogue, zl_stream_t s);
 
+/* Decode attention with the split merge INSIDE the launch (round 5; len_q == 1, prefix visibility, D == 128, H / Hkv <= 16).
+ * Replaces the same reference pair as zl_decode_attn -- KERNEL_mqa_rag_buffer_split_kv + KERNEL_mqa_combine
+ * (src/nn/attention/attention_kernel.cu:729-923, launched :1384-1457) -- with ONE launch and no merging prologue downstream:
+ * every (task, kv head, split) workgroup publishes its (acc[128], max, sum) record write-through, counts its arrival on the
+ * pair's word, and the pair's LAST arriver merges the records (KERNEL_mqa_combine's formula, k_decode_attn_combine's order:
+ * bit-identical to zl_decode_attn for the same split length up to 16 splits) and writes out (B, H, 128) T.  Splits are multiples
+ * of 32 keys (one matrix-core chunk per wave; 1 / 2 / 4 waves per workgroup), so a batch-1 step can spread a 1 024-key
+ * history over every CU: split_len = 0 lets the launcher choose (zl_decode_attn_la_split_len), at most 64 splits per task.
+ * half_partials != 0: records as fp16 normalised rows + fp32 (max, sum) (zl_decode_attn_splits_h's format and
+ * zl_w4a16_gemm_attn_merge_h's arithmetic; fp16 only).
+ * workspace: zl_decode_attn_la_workspace_bytes(b, h, hkv, max_len_buf, split_len) bytes, ZERO-INITIALISED ONCE by the caller
+ * (the arrival words at its head; every launch leaves them zero), not shared by two launches that may overlap in time. */
+int64_t zl_decode_attn_la_split_len(int64_t b, int64_t hkv, int64_t max_len_buf);
+int64_t zl_decode_attn_la_workspace_bytes(int64_t b, int64_t h, int64_t hkv, int64_t max_len_buf, int64_t split_len);
+int zl_decode_attn_la(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs, const uint16_t* const* v_bufs,
+                      const int32_t* valid_lens, uint16_t* out, void* workspace, int64_t b, int64_t h, int64_t hkv, int64_t d,
+                      float scale, int64_t max_len_buf, int bshd, int dtype, int64_t split_len, int half_partials, zl_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * a15q  INT8 KV cache (RagBufferContext::is_cache_quant, src/model/rag_buffer_context.h:96).
  * A cached K/V row of one kv head is D unsigned codes + one fp32 scale:

@@ -739,3 +739,107 @@ def test_i8p_nonfinite_activations_propagate(oracle, dev, m, k):
         assert not np.isfinite(ref[0]).any()                             # the reference's arithmetic: nothing finite survives
         assert not np.isfinite(got[0]).any()
         assert np.array_equal(got[1:], clean[1:])                        # the other rows do not see it
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: the RMSNorm of 9..32 decode rows DEFERRED into the phase kernel (w4_phase.hip DN) -- no stand-alone norm launch
+# ---------------------------------------------------------------------------------------------------------------------
+def _dn_bound(exact, lin=0.0):
+    """What separates the deferred norm from norm-then-GEMM is WHERE the activation is rounded to fp16: T(x w) rs against
+    T(x rs w), 2^-12 rms relative noise per activation either way, independent between the two -> ~2e-4 rms(y) per output
+    between them (random signs over K), 4.5 sigma over a few 1e5 outputs; plus the fp16 rounding of the output itself."""
+    rms = np.sqrt((exact ** 2).mean())
+    return 2.0 ** -10 * (np.abs(exact) + lin) + 1.5e-3 * rms
+
+
+@pytest.mark.parametrize("m", [9, 16, 17, 32])
+@pytest.mark.parametrize("k,n,epi", [(4096, 6144, "plain"), (4096, 2 * 1024, "silu"), (1024 + 256, 264, "bias"), (4096, 28672, "silu"),
+                                     (2048, 4096, "residual")])
+def test_deferred_norm_rows_9_32(oracle, dev, m, k, n, epi):
+    """zl_w4a16_gemm_mfma with a norm weight and 9..32 rows (every tile count per workgroup the Llama shapes produce, one and two
+    row blocks, the gated / bias / residual epilogues) against the exact product of the oracle's normalised rows."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(900 + m + n % 97)
+    g = 128
+    silu = epi == "silu"
+    kms = []
+    for _ in range(2 if silu else 1):
+        qw, qz, sc = synth.gptq_hf(rng, k, n // 2 if silu else n, g)
+        kms.append(oracle.gptq_prepare_k_major(qw, qz, sc, g))
+    km = tuple(np.concatenate([kk[i] for kk in kms], axis=0) for i in range(3))
+    w = ops.W4MWeight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), g, row_interleave=silu)
+    x = synth.act(rng, m, k, 3.0)
+    x[m // 2] *= np.float16(0.05)                           # rows of very different norms: rs is per row
+    nw = (1.0 + 0.2 * rng.standard_normal(k)).astype(np.float16)
+    b = (rng.standard_normal(n) * 0.1).astype(np.float16) if epi == "bias" else None
+    res = synth.act(rng, m, n) if epi == "residual" else None
+    xin = oracle.rmsnorm(oracle.h2u(x), oracle.h2u(nw), 1e-5)
+    y = ops.w4a16_gemm_mfma(_t(x, dev), w, bias=None if b is None else _t(b, dev), residual=None if res is None else _t(res, dev),
+                            norm_weight=_t(nw, dev), norm_eps=1e-5,
+                            epilogue=ops.EPI_SILU_MUL if silu else ops.EPI_RESIDUAL if res is not None else 0)
+    got = _np(y).astype(np.float64)
+    if silu:
+        gate = oracle.gptq_gemm_k_major_exact(xin, *kms[0]).astype(np.float16)
+        up = oracle.gptq_gemm_k_major_exact(xin, *kms[1]).astype(np.float16)
+        ref = oracle.u2h(oracle.silu_mul(oracle.h2u(gate), oracle.h2u(up))).astype(np.float64)
+        gu = np.abs(gate.astype(np.float64)) * np.abs(up.astype(np.float64))
+        rms = np.sqrt((ref ** 2).mean())
+        # gate and up each carry the activation-rounding noise (1.5e-3 of THEIR rms); silu' <= 1.1
+        rg, ru = np.sqrt((gate.astype(np.float64) ** 2).mean()), np.sqrt((up.astype(np.float64) ** 2).mean())
+        tol = 2.0 ** -9 * np.abs(ref) + 2.0 ** -10 * gu + 1.5e-3 * (1.1 * rg * np.abs(up.astype(np.float64)) + ru * np.abs(gate.astype(np.float64))) + 3e-4 * rms
+        bad = np.abs(got - ref) > tol
+        assert not bad.any(), (int(bad.sum()), float((np.abs(got - ref) / rms).max()))
+        return
+    exact = oracle.gptq_gemm_k_major_exact(xin, *km, bias=None if b is None else oracle.h2u(b))
+    lin = 0.0
+    if res is not None:
+        lin = np.abs(exact)
+        exact = res.astype(np.float64) + exact.astype(np.float16).astype(np.float64)
+    d = np.abs(got - exact)
+    assert (d <= _dn_bound(exact, lin)).all(), float((d / np.sqrt((exact ** 2).mean())).max())
+    # and no further from the unfused sequence (stand-alone norm launch, then the same kernel) than that
+    y2 = ops.w4a16_gemm_mfma(ops.rmsnorm(_t(x, dev), _t(nw, dev), 1e-5), w, bias=None if b is None else _t(b, dev),
+                             residual=None if res is None else _t(res, dev), epilogue=ops.EPI_RESIDUAL if res is not None else 0)
+    d2 = np.abs(got - _np(y2).astype(np.float64))
+    assert (d2 <= _dn_bound(exact, lin)).all()
+
+
+@pytest.mark.parametrize("m", [9, 16, 17, 32])
+@pytest.mark.parametrize("bshd", [True, False])
+def test_deferred_norm_fused_qkv_rotary_scatter(oracle, dev, m, bshd):
+    """zl_w4a16_qkv_rope_scatter with a norm weight and 9..32 rows against the unfused sequence (norm launch, projection,
+    rope + scatter launch): q and the new K / V rows within the activation-rounding bound, slots and untouched rows identical."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(180 + m)
+    h, hkv, d, k, g = 8, 2, 128, 4096, 128
+    n = (h + 2 * hkv) * d
+    qw, qz, sc = synth.gptq_hf(rng, k, n, g)
+    km = oracle.gptq_prepare_k_major(qw, qz, sc, g)
+    w = ops.W4MWeight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), g)
+    x = _t(synth.act(rng, m, k, 2.0), dev)
+    bias = _t((rng.standard_normal(n) * 0.1).astype(np.float16), dev)
+    nw = _t((1.0 + 0.1 * rng.standard_normal(k)).astype(np.float16), dev)
+    lens = [int(v) for v in rng.integers(2, 6, m) * 32]
+    pos = np.array([int(rng.integers(0, L)) for L in lens], np.int32)
+    pos[0] = lens[0] - 1
+    placement = pos.copy()
+    placement[1] = -1
+    cs, sn = oracle.rope_cos_sin(pos, d, 5e5, True, (8.0, 1.0, 4.0, 8192.0))
+    shape = (lambda L: (L, hkv, d)) if bshd else (lambda L: (hkv, L, d))
+    mk = lambda: [torch.full(shape(L), 3.0, dtype=torch.float16, device=dev) for L in lens]
+    k1, v1, k2, v2 = mk(), mk(), mk(), mk()
+    lens_t, place_t = _t(np.array(lens, np.int32), dev), _t(placement, dev)
+    qkv = ops.w4a16_gemm_mfma(ops.rmsnorm(x, nw, 1e-5), w, bias=bias)
+    q_ref = ops.rope_scatter_decode(_t(cs, dev), _t(sn, dev), qkv, place_t, lens_t, ops.make_ptr_table(k1), ops.make_ptr_table(v1),
+                                    h, hkv, d, True, bshd)
+    assert ops.w4_qkv_rope_scatter_ok(m, k, d, True)
+    q_got = ops.w4_qkv_rope_scatter(x, w, _t(cs, dev), _t(sn, dev), place_t, lens_t, ops.make_ptr_table(k2), ops.make_ptr_table(v2),
+                                    h, hkv, d, bias=bias, norm_weight=nw, norm_eps=1e-5, bshd=bshd)
+    ref = q_ref.float().cpu().numpy().astype(np.float64)
+    rms = np.sqrt((ref ** 2).mean())
+    assert (np.abs(q_got.float().cpu().numpy() - ref) <= 2.0 ** -9 * np.abs(ref) + 2e-3 * rms).all()
+    for a, b_ in zip(k1 + v1, k2 + v2):
+        a64, b64 = a.float().cpu().numpy().astype(np.float64), b_.float().cpu().numpy().astype(np.float64)
+        assert (np.abs(a64 - b64) <= 2.0 ** -9 * np.abs(a64) + 2e-3 * rms).all()
+        assert np.array_equal(a64 == 3.0, b64 == 3.0) or np.abs(a64 - b64).max() <= 2e-3 * rms     # untouched slots stay untouched
+    assert not torch.equal(k2[0], torch.full_like(k2[0], 3.0))

@@ -39,6 +39,7 @@ SYMBOLS = [
     "zl_fp8_calc_scale", "zl_fp8_cvt_half", "zl_fp8_gemm_nt",
     "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_ex", "zl_decode_attn_fused",
     "zl_decode_attn_split_len", "zl_decode_attn_splits", "zl_w4a16_gemm_attn_merge",
+    "zl_decode_attn_la_split_len", "zl_decode_attn_la_workspace_bytes", "zl_decode_attn_la",
     "zl_quant_calc_scale_zp", "zl_dequant_group", "zl_quant_copy_to_rag_buffer", "zl_rope_quant_scatter_decode", "zl_decode_attn_quant", "zl_decode_attn_quant_ex",
     "zl_prefill_attn",
     "zl_element_add_scale", "zl_gate_mul", "zl_permute_input", "zl_embedding",
@@ -80,6 +81,8 @@ def lib():
         l.zl_status_string.restype = C.c_char_p
         l.zl_decode_attn_workspace_bytes.restype = C.c_int64
         l.zl_decode_attn_split_len.restype = C.c_int64
+        l.zl_decode_attn_la_split_len.restype = C.c_int64
+        l.zl_decode_attn_la_workspace_bytes.restype = C.c_int64
         l.zl_argmax_workspace_bytes.restype = C.c_int64
         l.zl_w8m_bytes.restype = C.c_int64
         l.zl_mla_decode_workspace_bytes.restype = C.c_int64

@@ -53,6 +53,11 @@ struct AttnParams {
     // k_decode_attn_mfma: 1 = partials leave as NORMALISED fp16 rows [vh][split][128] + fp32 (max, sum) pairs behind them
     // (zl_decode_attn_splits_h: 264 instead of 520 bytes per (head, split) for the merging projection to re-read)
     int half_partials;
+    // k_decode_attn_mfma, last-arriver merge (zl_decode_attn_la): la = 1 -> every workgroup publishes its split record write-through,
+    // counts its arrival on la_cnt[task * hkv + kv head] and the LAST one of the pair merges the pair's records into `out`
+    // (no merge launch, no merging prologue); la_cnt is all zero between launches (the last arriver resets its word)
+    int la;
+    int* la_cnt;
 };
 
 typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
@@ -650,6 +655,148 @@ __device__ __forceinline__ f4v mfma_t(uint4 a, uint4 b, f4v c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8v, a), __builtin_bit_cast(b8v, b), c, 0, 0, 0);
 }
 
+// ---- last-arriver merge (zl_decode_attn_la) ------------------------------------------------------------------------------
+// The tail of k_decode_attn_mfma when the split merge happens INSIDE the launch.  xw holds the nw waves' (O[128], m, l) of the
+// workgroup's <= 16 query rows.  The workgroup folds them into the split's record, publishes the record with write-through
+// (sc1) 8-byte stores, waits for the stores (vmcnt(0)) and counts its arrival on the (task, kv head) pair's word with one
+// agent-scope atomic; the workgroup that draws the last ticket re-reads the pair's records with sc1 loads (another CU's
+// write-through store is in memory by the time its ticket is; nothing here is cached in this CU's L1) and writes the merged
+// attention rows -- k_decode_attn_combine's arithmetic in its order (fp32 records: bit-identical to zl_decode_attn up to 16
+// splits), or the merging projection's (half records: w4_i8p.hip MERGE).  The last arriver puts the word back to zero: the
+// counters need zeroing once, when the workspace is made.  A pair with a single live split skips all of it and writes its rows.
+// Records: fp32 [vh][split][128 acc | max | sum], or (half) fp16 [vh][split][128] normalised rows + fp32 (max, sum) pairs behind them.
+constexpr int kLaMaxSplits = 64;      // statistics of a pair in LDS: 16 rows x 64 splits x (max, sum)
+
+template <int DT>
+__device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int b, int hk, int split, int nw, int ns) {
+    constexpr int WS = 16 * (kMD + 2);
+    const int nthr = nw * 64;
+    const bool direct = ns == 1;
+    const size_t stat0 = (size_t)p.b * p.len_q * p.h * p.max_splits * (kMD / 2);      // half records: floats in front of the pairs
+    // ---- this split's record: thread -> (row i, 4 consecutive d)
+    for (int it = threadIdx.x; it < p.rows * (kMD / 4); it += nthr) {
+        const int i = it / (kMD / 4), d0 = (it % (kMD / 4)) * 4;
+        const float* src = xw + (size_t)i * (kMD + 2);
+        float mn = src[kMD];
+        for (int w = 1; w < nw; ++w) mn = fmaxf(mn, src[w * WS + kMD]);
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, lt = 0.f;
+        for (int w = 0; w < nw; ++w) {
+            const float f = __expf(src[w * WS + kMD] - mn);
+            const f4v v = *reinterpret_cast<const f4v*>(src + w * WS + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(v[e], f, a[e]);
+            lt = __builtin_fmaf(src[w * WS + kMD + 1], f, lt);
+        }
+        const int qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
+        const size_t vh = ((size_t)b * p.len_q + qi) * p.h + head;
+        const size_t rec = vh * p.max_splits + split;
+        if (direct) {                                   // what the merge makes of a single record
+            uint16_t o4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float ov;
+                if (p.half_partials) ov = ((float)(_Float16)(a[e] / lt) * lt) * (1.0f / (lt + 1e-20f));
+                else ov = a[e] / (lt + 1e-20f);
+                o4[e] = ZT<DT>::from_f32(ov);
+            }
+            *reinterpret_cast<uint2*>(p.out + vh * kMD + d0) = make_uint2((uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16));
+            continue;
+        }
+        auto st8 = [](void* dst, uint32_t lo, uint32_t hi) {     // one write-through 8-byte store (global_store_dwordx2 sc1)
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(dst), (uint64_t)lo | ((uint64_t)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (p.half_partials) {
+            uint32_t w2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                w2[e] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)(a[2 * e] / lt)) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)(a[2 * e + 1] / lt)) << 16);
+            st8(reinterpret_cast<uint16_t*>(p.ws) + rec * kMD + d0, w2[0], w2[1]);
+            if (d0 == 0) st8(p.ws + stat0 + rec * 2, __builtin_bit_cast(uint32_t, mn), __builtin_bit_cast(uint32_t, lt));
+        } else {
+            float* dst = p.ws + rec * (kMD + 2) + d0;   // 130 floats per record: 8-byte aligned
+            st8(dst, __builtin_bit_cast(uint32_t, a[0]), __builtin_bit_cast(uint32_t, a[1]));
+            st8(dst + 2, __builtin_bit_cast(uint32_t, a[2]), __builtin_bit_cast(uint32_t, a[3]));
+            if (d0 == 0) st8(dst + kMD, __builtin_bit_cast(uint32_t, mn), __builtin_bit_cast(uint32_t, lt));
+        }
+    }
+    if (direct) return;
+    // ---- arrival.  The stores above are write-through; once vmcnt is zero they are where an sc1 load of any CU finds them.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // ... for every wave of the workgroup; xw is free from here on
+    int* flag = reinterpret_cast<int*>(xw);
+    if (threadIdx.x == 0) {
+        int* cnt = p.la_cnt + (size_t)b * p.hkv + hk;
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == ns - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = old == ns - 1;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    __syncthreads();                                    // the flag has been read by everyone before LDS is reused
+    // ---- the pair's last arriver: statistics of all (row, split) to LDS, then thread -> (row i, 4 consecutive d)
+    float* sm = xw;                                     // [16 rows][kLaMaxSplits][max, sum]
+    for (int t = threadIdx.x; t < p.rows * ns; t += nthr) {
+        const int i = t / ns, u = t % ns;
+        const int qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
+        const size_t rec = (((size_t)b * p.len_q + qi) * p.h + head) * p.max_splits + u;
+        const float* st = p.half_partials ? p.ws + stat0 + rec * 2 : p.ws + rec * (kMD + 2) + kMD;
+        const uint64_t ml = __hip_atomic_load(reinterpret_cast<const uint64_t*>(st), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm[(i * kLaMaxSplits + u) * 2] = __builtin_bit_cast(float, (uint32_t)ml);
+        sm[(i * kLaMaxSplits + u) * 2 + 1] = __builtin_bit_cast(float, (uint32_t)(ml >> 32));
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < p.rows * (kMD / 4); it += nthr) {
+        const int i = it / (kMD / 4), d0 = (it % (kMD / 4)) * 4;
+        const int qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
+        const size_t vh = ((size_t)b * p.len_q + qi) * p.h + head;
+        const float* st = sm + (size_t)i * kLaMaxSplits * 2;
+        float mn = -1e20f;
+        for (int u = 0; u < ns; ++u) mn = fmaxf(mn, st[2 * u]);
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, z = 0.f;
+        for (int u0 = 0; u0 < ns; u0 += 16) {           // 16 records in flight at a time
+            uint64_t lo[16], hi[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int u = min(u0 + j, ns - 1);
+                if (p.half_partials) {
+                    lo[j] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint16_t*>(p.ws) + ((vh * p.max_splits + u) * kMD + d0)),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi[j] = 0;
+                } else {
+                    const uint64_t* src = reinterpret_cast<const uint64_t*>(p.ws + (vh * p.max_splits + u) * (kMD + 2) + d0);
+                    lo[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi[j] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int u = u0 + j;
+                if (u < ns) {
+                    if (p.half_partials) {              // w4_i8p.hip MERGE: weight l e^(m - M) on the normalised row
+                        const float f = st[2 * u + 1] * __expf(st[2 * u] - mn);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            a[e] = __builtin_fmaf((float)__builtin_bit_cast(_Float16, (uint16_t)(lo[j] >> (16 * e))), f, a[e]);
+                        z += f;
+                    } else {                            // k_decode_attn_combine
+                        const float f = __expf(st[2 * u] - mn);
+                        a[0] = __builtin_fmaf(__builtin_bit_cast(float, (uint32_t)lo[j]), f, a[0]);
+                        a[1] = __builtin_fmaf(__builtin_bit_cast(float, (uint32_t)(lo[j] >> 32)), f, a[1]);
+                        a[2] = __builtin_fmaf(__builtin_bit_cast(float, (uint32_t)hi[j]), f, a[2]);
+                        a[3] = __builtin_fmaf(__builtin_bit_cast(float, (uint32_t)(hi[j] >> 32)), f, a[3]);
+                        z = __builtin_fmaf(st[2 * u + 1], f, z);
+                    }
+                }
+            }
+        }
+        uint16_t o4[4];
+        const float zi = 1.0f / (z + 1e-20f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = ZT<DT>::from_f32(p.half_partials ? a[e] * zi : a[e] / (z + 1e-20f));
+        *reinterpret_cast<uint2*>(p.out + vh * kMD + d0) = make_uint2((uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16));
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t vs[4][32 * kMVS];      // 36 KB; reused for the wave merge
@@ -660,7 +807,16 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
     const uint16_t* vbase = p.v_bufs[b];
     const int elen = min(len, vlen_in);
     const int t0 = split * p.split_len;
-    if (t0 >= elen || len <= 0) return;
+    const int nw = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));   // 4 waves; 1 / 2 / 4 under the last-arriver launcher
+    if (t0 >= elen || len <= 0) {
+        // LA: a task without a visible key has no arriver at all -- split 0 leaves the rows the merge launch would (zeros)
+        if (p.la && split == 0)
+            for (int idx = threadIdx.x; idx < p.rows * kMD; idx += nw * 64) {
+                const int i = idx / kMD, qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
+                p.out[(((size_t)b * p.len_q + qi) * p.h + head) * kMD + idx % kMD] = 0;
+            }
+        return;
+    }
     const int t1 = min(elen, t0 + p.split_len);
     const int last_key = t1 - 1;
 
@@ -731,7 +887,7 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
 #undef ZL_MFMA_VST
         }
         const int cur = c0;
-        c0 += 4 * 32;
+        c0 += nw * 32;
         ZL_MFMA_LOAD_K(c0)
         ZL_MFMA_LOAD_V(c0)
         // ---- online softmax of query row r over this lane's 8 keys (+ the 3 other lanes of the row)
@@ -801,7 +957,7 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
 #undef ZL_MFMA_LOAD_V
 #undef ZL_MFMA_V1
 
-    // ---- merge: the row's normaliser lives in 4 lanes; then the 4 waves through LDS (aliases the V staging)
+    // ---- merge: the row's normaliser lives in 4 lanes; then the waves through LDS (aliases the V staging)
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     __syncthreads();
@@ -816,16 +972,18 @@ __global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p)
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < p.rows * kMD; idx += 256) {
+    if (p.la) {
+        attn_tail_la<DT>(p, xw, b, hk, split, nw, (elen + p.split_len - 1) / p.split_len);
+        return;
+    }
+    for (int idx = threadIdx.x; idx < p.rows * kMD; idx += nw * 64) {
         const int i = idx / kMD, d = idx % kMD;
         const float* src = xw + (size_t)i * (kMD + 2);
         constexpr int WS = 16 * (kMD + 2);
         float mn = src[kMD];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, src[w * WS + kMD]);
+        for (int w = 1; w < nw; ++w) mn = fmaxf(mn, src[w * WS + kMD]);
         float a = 0.f, lt = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < nw; ++w) {
             const float f = __expf(src[w * WS + kMD] - mn);
             a = __builtin_fmaf(src[w * WS + d], f, a);
             lt = __builtin_fmaf(src[w * WS + kMD + 1], f, lt);
@@ -1209,7 +1367,7 @@ int zl_decode_attn_ex(const uint16_t* q, const int32_t* buf_lens, const uint16_t
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
-    p.k_scales = p.v_scales = nullptr; p.half_partials = 0;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 0; p.la = 0; p.la_cnt = nullptr;
     {   // decode fast path on the matrix cores: all query rows of a kv head in one 16-row MFMA block
         if (algo != 1 && !mask && d == kMD && p.rows <= 16) {
             p.passes = 1;
@@ -1256,7 +1414,7 @@ int zl_decode_attn_splits(const uint16_t* q, const int32_t* buf_lens, const uint
     ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
-    p.k_scales = p.v_scales = nullptr; p.half_partials = 0;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 0; p.la = 0; p.la_cnt = nullptr;
     const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
     if (dtype == ZL_F16) hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, p);
     else hipLaunchKernelGGL(k_decode_attn_mfma<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, p);
@@ -1279,9 +1437,65 @@ int zl_decode_attn_splits_h(const uint16_t* q, const int32_t* buf_lens, const ui
     ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
-    p.k_scales = p.v_scales = nullptr; p.half_partials = 1;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 1; p.la = 0; p.la_cnt = nullptr;
     const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
     hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, p);
+    return zl_launch_status();
+}
+
+// ---- decode attention with the split merge inside the launch (last-arriver; k_decode_attn_mfma + attn_tail_la) -------------
+static inline int la_split_len(int64_t b, int64_t hkv, int64_t max_len) {
+    // about 1024 workgroups of >= 32 keys (one 32-key chunk per wave, 1 / 2 / 4 waves per workgroup): batch 1 x 8 kv heads x 1088
+    // slots -> 34 single-wave workgroups per kv head (16 KB of K / V each, spread over every CU instead of 72 of them)
+    int64_t ls = (max_len * b * hkv / 1024) / 32 * 32;
+    if (ls < 32) ls = 32;
+    if (ls > 128) ls = ls / 128 * 128;
+    if (ls > 2048) ls = 2048;
+    while ((max_len + ls - 1) / ls > kLaMaxSplits) ls += ls >= 128 ? 128 : 32;
+    return (int)ls;
+}
+
+int64_t zl_decode_attn_la_split_len(int64_t b, int64_t hkv, int64_t max_len_buf) {
+    if (b <= 0 || hkv <= 0 || max_len_buf <= 0) return ZL_EINVAL;
+    return la_split_len(b, hkv, max_len_buf);
+}
+
+static inline int64_t la_counter_bytes(int64_t b, int64_t hkv) { return (b * hkv * 4 + 255) / 256 * 256; }
+
+int64_t zl_decode_attn_la_workspace_bytes(int64_t b, int64_t h, int64_t hkv, int64_t max_len_buf, int64_t split_len) {
+    if (b <= 0 || h <= 0 || hkv <= 0 || max_len_buf <= 0 || split_len < 0 || split_len % 32 != 0) return ZL_EINVAL;
+    if (split_len == 0) split_len = 32;                // any split length the launcher may pick
+    const int64_t splits = (max_len_buf + split_len - 1) / split_len;
+    return la_counter_bytes(b, hkv) + b * h * splits * (kMD + 2) * 4;
+}
+
+int zl_decode_attn_la(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs, const uint16_t* const* v_bufs,
+                      const int32_t* valid_lens, uint16_t* out, void* workspace, int64_t b, int64_t h, int64_t hkv, int64_t d,
+                      float scale, int64_t max_len_buf, int bshd, int dtype, int64_t split_len, int half_partials, zl_stream_t s) {
+    ZL_CHECK_ARG(q && buf_lens && k_bufs && v_bufs && valid_lens && out && workspace, ZL_EINVAL);
+    ZL_CHECK_ARG(b > 0 && h > 0 && hkv > 0 && d > 0 && max_len_buf > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(h % hkv == 0 && d == kMD && h / hkv <= 16 && b <= 65535 && hkv <= 65535, ZL_ESHAPE);   // the matrix-core kernel
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    ZL_CHECK_ARG(!half_partials || dtype == ZL_F16, ZL_EDTYPE);
+    ZL_CHECK_ARG(split_len >= 0 && split_len % 32 == 0, ZL_EINVAL);
+    AttnParams p;
+    p.q = q; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs; p.mask = nullptr; p.valid_lens = valid_lens;
+    p.out = out;
+    p.la = 1; p.la_cnt = reinterpret_cast<int*>(workspace);
+    p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + la_counter_bytes(b, hkv));
+    p.b = (int)b; p.len_q = 1; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
+    p.rows = p.n_rep; p.passes = 1;
+    p.split_len = split_len ? (int)split_len : la_split_len(b, hkv, max_len_buf);
+    p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    ZL_CHECK_ARG(p.max_splits <= kLaMaxSplits, ZL_ELIMIT);
+    ZL_CHECK_ARG((int64_t)b * h * p.max_splits * (kMD + 2) * 4 < ((int64_t)1 << 31), ZL_ELIMIT);
+    p.scale = scale; p.bshd = bshd;
+    p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = half_partials ? 1 : 0;
+    const int nw = p.split_len >= 128 ? 4 : p.split_len / 32;
+    const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
+    if (dtype == ZL_F16) hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(64 * nw), 0, (hipStream_t)s, p);
+    else hipLaunchKernelGGL(k_decode_attn_mfma<ZL_BF16>, grid, dim3(64 * nw), 0, (hipStream_t)s, p);
     return zl_launch_status();
 }
 
@@ -1307,7 +1521,7 @@ int zl_decode_attn_fused(const float* cosv, const float* sinv, const uint16_t* q
     ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     p.qkv = qkv; p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.k_bufs_w = k_bufs; p.v_bufs_w = v_bufs; p.neox = neox;
-    p.k_scales = p.v_scales = nullptr; p.half_partials = 0;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 0; p.la = 0; p.la_cnt = nullptr;
     ZL_CHECK_ARG((int64_t)p.b * p.passes <= 65535 && hkv <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
     if (dtype == ZL_F16) { ZL_ATTN_D(ZL_F16, true) }
@@ -1338,7 +1552,7 @@ int zl_decode_attn_quant_ex(const uint16_t* q, const int32_t* buf_lens, const ui
     p.q = q; p.buf_lens = buf_lens;
     p.k_bufs = reinterpret_cast<const uint16_t* const*>(k_bufs);
     p.v_bufs = reinterpret_cast<const uint16_t* const*>(v_bufs);
-    p.k_scales = k_scales; p.v_scales = v_scales; p.half_partials = 0;
+    p.k_scales = k_scales; p.v_scales = v_scales; p.half_partials = 0; p.la = 0; p.la_cnt = nullptr;
     p.mask = mask; p.valid_lens = valid_lens; p.out = out; p.ws = (float*)workspace;
     p.b = (int)b; p.len_q = (int)len_q; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
     p.rows = p.len_q * p.n_rep;

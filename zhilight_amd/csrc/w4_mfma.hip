@@ -760,7 +760,9 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
         const int ph_maxk_32 = can_split ? (1 << 30) : 8192;
         const bool rows_5_32 = !norm_weight && m >= ph_min_m && m <= ph_max_m && m <= 32 && k <= (m <= 16 ? (1 << 30) : ph_maxk_32);
         const bool rows_1_4 = !o.phase_small_off && k <= 4096 && (norm_weight ? m <= 8 : (m <= 4 && m < ph_min_m));   // fused norm: <= 8 rows
-        if ((rows_5_32 || rows_1_4) && L.qw_bytes < ((int64_t)1 << 32))
+        // fused norm with 9..32 rows: the phase kernel's DEFERRED norm (w4_phase.hip DN: T(x w) staged, rs applied to the fp32 totals)
+        const bool rows_9_32_dn = norm_weight && m >= 9 && m <= 32 && k % 128 == 0 && k <= (m <= 16 ? (1 << 30) : 8192);
+        if ((rows_5_32 || rows_1_4 || rows_9_32_dn) && L.qw_bytes < ((int64_t)1 << 32))
             return zl_w4a16_gemm_phase(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y,
                                        (int)m, (int)n, (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n),
                                        norm_weight, norm_eps, &o, hs);
@@ -876,7 +878,7 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
     // what the phase-pipelined kernel covers (zl_w4a16_gemm_mfma's own dispatch rules); callers fall back to
     // zl_w4a16_gemm_mfma + zl_rope_scatter_decode outside of it
     ZL_CHECK_ARG(m <= 32 && d % 32 == 0 && h % 1 == 0 && L.np == n, ZL_ESHAPE);
-    ZL_CHECK_ARG(!norm_weight || (m <= 8 && k <= 4096), ZL_ESHAPE);
+    ZL_CHECK_ARG(!norm_weight || k <= 4096 || m > 8, ZL_ESHAPE);     // <= 8 rows: register-resident staging; 9..32: deferred norm
     ZL_CHECK_ARG(m <= 16 || k <= 8192, ZL_ESHAPE);
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
     const int small_algo = opts ? opts->small_algo : 0;

@@ -165,8 +165,18 @@ struct NoGuard { static constexpr bool value = false; };
 // rows), 6 MB v_mfma_i32_16x16x64_i8, and per row of the lane 6 VALU turn the three exact digit sums into the fp32 group value
 //     xscale * (65536 D2 + 256 D1 + D0) - z * xscale * sum X          (w4_i8p.hip's arithmetic; the group constants per row
 // come from the planes' side table, parked in LDS per wave at kernel entry), scale-accumulated one step later like the fp16 path.
-template <int R, int MB, bool NORM, bool ROPE, int KS = 1, bool MERGE = false, bool I8 = false>
+// DN (rows 9..32 with a fused RMSNorm, no NORM / MERGE / I8 / K split): the norm DEFERRED.  x reaches a workgroup one K phase at a
+// time, so the row's sum of squares is not known when a phase is staged; but y = W (x . w rs) = rs (W (x . w)) -- rs is one scalar
+// per row.  Staging multiplies the phase's slice by the norm weight (one packed fp16 multiply: T(x w), a single rounding, where
+// the stand-alone kernel rounds T(x rs w) once) and adds the slice's squares to the thread's row sums (v_dot2_f32_f16); after the
+// last phase the 128 threads that staged a row meet in LDS, and the epilogue scales the fp32 totals by rs[row] before bias /
+// rotation / activation.  Two stand-alone k_rmsnorm launches per layer at batch 32 (9 % of the step) go away;
+// the result differs from norm-then-GEMM by the rounding of T(x w) against T(x rs w) -- the same 2^-11 relative noise per
+// activation, at a different place -- not bit-identical, tests/test_gpu_w4.py::test_deferred_norm_rows_9_32 holds it to the
+// output rounding.
+template <int R, int MB, bool NORM, bool ROPE, int KS = 1, bool MERGE = false, bool I8 = false, bool DN = false>
 __global__ __launch_bounds__(kT, (MERGE || I8) ? 1 : 2) void k_w4a16_phase(const PhaseParams p) {
+    static_assert(!DN || (!NORM && !MERGE && !I8 && KS == 1), "deferred norm: the plain staged-activation instantiations");
     static_assert(!MERGE || (NORM && !ROPE && KS == 1), "split merge: register-resident staging");
     static_assert(!ROPE || R == 2, "fused rotary: a tile and its partner tile");
     static_assert(KS == 1 || (!ROPE && !NORM), "K split: plain / bias / residual epilogues only");
@@ -196,7 +206,10 @@ __global__ __launch_bounds__(kT, (MERGE || I8) ? 1 : 2) void k_w4a16_phase(const
 
     // ---- activations: chunk c of a thread = row (tid >> 7) + 4 c, halfs 8 (tid & 127) .. +7 of the phase
     const int xrow0 = threadIdx.x >> 7, xcc = (threadIdx.x & 127) * 8;
-    uint4 xr[XP][XC];
+    uint4 xr[XP][XC], nwr[DN ? XP : 1];
+    float ss[DN ? XC : 1];                           // DN: sum of squares of the slices this thread staged, per row xrow0 + 4 c
+#pragma unroll
+    for (int c = 0; c < (DN ? XC : 1); ++c) ss[c] = 0.f;
     auto load_x = [&](int set, int ph) {             // set: static
 #pragma unroll
         for (int c = 0; c < XC; ++c) {
@@ -206,9 +219,28 @@ __global__ __launch_bounds__(kT, (MERGE || I8) ? 1 : 2) void k_w4a16_phase(const
             xr[set][c] = *reinterpret_cast<const uint4*>(src);
             if (!live) xr[set][c] = make_uint4(0, 0, 0, 0);
         }
+        if constexpr (DN) {
+            const int kk = (ph0 + ph) * kPK + xcc;
+            nwr[set] = *reinterpret_cast<const uint4*>(p.norm_w + ((kk < p.k && ph < P) ? kk : 0));
+        }
     };
     auto store_x = [&](int set, int ph) {            // into buffer ph & 1
         uint16_t* dst = xs + (ph & 1) * kBuf + xcc;
+        if constexpr (DN) {
+            const uint32_t wu[4] = {nwr[set].x, nwr[set].y, nwr[set].z, nwr[set].w};
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
+                uint32_t u[4] = {xr[set][c].x, xr[set][c].y, xr[set][c].z, xr[set][c].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const hv2 hh = __builtin_bit_cast(hv2, u[e]);
+                    ss[c] = __builtin_amdgcn_fdot2(hh, hh, ss[c], false);
+                    u[e] = __builtin_bit_cast(uint32_t, hh * __builtin_bit_cast(hv2, wu[e]));   // v_pk_mul_f16: T(x w), one rounding
+                }
+                *reinterpret_cast<uint4*>(dst + (xrow0 + 4 * c) * kXS) = make_uint4(u[0], u[1], u[2], u[3]);
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < XC; ++c) *reinterpret_cast<uint4*>(dst + (xrow0 + 4 * c) * kXS) = xr[set][c];
     };
@@ -664,6 +696,24 @@ __global__ __launch_bounds__(kT, (MERGE || I8) ? 1 : 2) void k_w4a16_phase(const
         }
     }
     ZL_PPROBE(4);
+    // DN: the row sums meet here -- 64-lane butterfly, then the two waves of a row quarter side by side in LDS (behind the
+    // x / reduction area); the barriers below order them before the epilogue reads
+    constexpr size_t kMainLds = (2 * (size_t)MB * 16 * kXS * 2 > (size_t)R * MB * kW * 64 * 16) ? 2 * (size_t)MB * 16 * kXS * 2 : (size_t)R * MB * kW * 64 * 16;
+    float* dn_scr = reinterpret_cast<float*>(smem + kMainLds);       // [16 MB rows][2 waves]
+    if constexpr (DN) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int c = 0; c < XC; ++c) ss[c] += __shfl_xor(ss[c], off, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < XC; ++c) dn_scr[(xrow0 + 4 * c) * 2 + (wave & 1)] = ss[c];
+        }
+    }
+    auto dn_rs = [&](int m) -> float {               // rs of row m (DN only)
+        return zl_rsqrt_rn((dn_scr[2 * m] + dn_scr[2 * m + 1]) / (float)p.k + p.norm_eps);
+    };
     __syncthreads();                                  // every wave is done with the x buffers: reuse them
 
     // ---- park the partial C fragments, reduce over the 8 waves in fixed order, epilogue
@@ -734,12 +784,18 @@ __global__ __launch_bounds__(kT, (MERGE || I8) ? 1 : 2) void k_w4a16_phase(const
                 v1 += redf[(((size_t)(1 * MB + b) * kW + w) * 64 + ln) * 4 + i];
             }
             const int n0 = tile0 * 16 + n_local, n1 = n0 + half;       // columns of the fused qkv row
+            if constexpr (DN) {
+                const float rs = dn_rs(m);
+                v0 *= rs;
+                v1 *= rs;
+            }
             if ((p.epi & ZL_EPI_BIAS) && p.bias) {
                 v0 += (float)__builtin_bit_cast(_Float16, p.bias[n0]);
                 v1 += (float)__builtin_bit_cast(_Float16, p.bias[n1]);
             }
             const float a = (float)zl_f32_to_f16(v0), bb = (float)zl_f32_to_f16(v1);   // the projection's fp16 outputs
             const int head = n0 / p.d, dcol = n0 % p.d;                 // dcol < half
+            // (more than 32 outputs per thread never happens: 16 m <= 512; the prologue's table entries belong to o = threadIdx.x)
             if (head < p.h + p.hkv) {
                 const uint16_t r0 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(-bb, rp_s0, a * rp_c0)));
                 const uint16_t r1 = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(a, rp_s1, bb * rp_c1)));
@@ -783,7 +839,8 @@ __global__ __launch_bounds__(kT, (MERGE || I8) ? 1 : 2) void k_w4a16_phase(const
             const int m = rem >> 4, n_local = rem & 15;
             const int row = tile * 16 + n_local;
             if (row < p.n) {
-                const float v = total_of(n_local, m);
+                float v = total_of(n_local, m);
+                if constexpr (DN) v *= dn_rs(m);
                 const size_t orow = (size_t)m * p.ld_out;
                 const bool pre = ep_pref && o == (int)threadIdx.x;     // operands that came with the prologue
                 const float bb = pre ? ep_bias0 : ((p.epi & ZL_EPI_BIAS) && p.bias) ? (float)__builtin_bit_cast(_Float16, p.bias[row]) : 0.f;
@@ -800,6 +857,11 @@ __global__ __launch_bounds__(kT, (MERGE || I8) ? 1 : 2) void k_w4a16_phase(const
             const int pr = tile * 8 + j;
             if (2 * pr + 1 < p.n) {
                 float g = total_of(2 * j, m), u = total_of(2 * j + 1, m);
+                if constexpr (DN) {
+                    const float rs = dn_rs(m);
+                    g *= rs;
+                    u *= rs;
+                }
                 if ((p.epi & ZL_EPI_BIAS) && p.bias) {
                     g += (float)__builtin_bit_cast(_Float16, p.bias[2 * pr]);
                     u += (float)__builtin_bit_cast(_Float16, p.bias[2 * pr + 1]);
@@ -819,24 +881,24 @@ __global__ __launch_bounds__(kT, (MERGE || I8) ? 1 : 2) void k_w4a16_phase(const
     ZL_PPROBE(6);
 }
 
-template <int R, int MB, bool NORM, bool ROPE = false, int KS = 1, bool MERGE = false, bool I8 = false>
+template <int R, int MB, bool NORM, bool ROPE = false, int KS = 1, bool MERGE = false, bool I8 = false, bool DN = false>
 int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
     constexpr size_t x_bytes = I8 ? (size_t)kW * 16 * MB * 128 : 2 * (size_t)MB * 16 * kXS * 2 + (NORM ? 8 * kW * 4 : 0);
     constexpr size_t red_bytes = (size_t)R * MB * kW * 64 * 16;
-    constexpr size_t lds = x_bytes > red_bytes ? x_bytes : red_bytes;
+    constexpr size_t lds = (x_bytes > red_bytes ? x_bytes : red_bytes) + (DN ? 16 * MB * 2 * 4 : 0);   // DN: the row sums behind both
     static_assert(lds <= 160 * 1024, "LDS");
     if (lds > 64 * 1024) {
         // every launch: the attribute is per device, and one process may drive several
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE, I8>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE, I8, DN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return ZL_ELIMIT;
     }
 #ifdef ZL_PHASE_PROBE
     PhaseParams pp = p;
     pp.probe_id = zl_probe_seq++;     // host-side launch number (all instantiations share it)
-    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE, I8>), dim3(grid), dim3(kT), lds, hs, pp);
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE, I8, DN>), dim3(grid), dim3(kT), lds, hs, pp);
 #else
-    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE, I8>), dim3(grid), dim3(kT), lds, hs, p);
+    hipLaunchKernelGGL((k_w4a16_phase<R, MB, NORM, ROPE, KS, MERGE, I8, DN>), dim3(grid), dim3(kT), lds, hs, p);
 #endif
     return zl_launch_status();
 }
@@ -964,7 +1026,8 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     static const zl_w4_opts_t kNoOpts = {};
     const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
     const int rounds_override = o.phase_rounds;
-    if (norm_w && (m > 8 || k > 4096)) return ZL_ESHAPE;
+    if (norm_w && m <= 8 && k > 4096) return ZL_ESHAPE;        // register-resident staging; 9..32 rows: the deferred norm (DN), any K
+    if (norm_w && m > 32) return ZL_ESHAPE;
     PhaseParams p = {};
     p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
     p.meta_bytes = meta_bytes; p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k;
@@ -999,6 +1062,9 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
     const int mb = m <= 16 ? 1 : 2;
 #define ZL_PH(RR)                                                                                              \
     case RR:                                                                                                   \
+        if (norm_w && m > 8)                                                                                   \
+            return mb == 1 ? launch_phase<RR, 1, false, false, 1, false, false, true>(p, grid, hs)             \
+                           : launch_phase<RR, 2, false, false, 1, false, false, true>(p, grid, hs);            \
         if (norm_w || (m <= 4 && k <= 4096)) return launch_phase<RR, 1, true>(p, grid, hs);                    \
         return mb == 1 ? launch_phase<RR, 1, false>(p, grid, hs) : launch_phase<RR, 2, false>(p, grid, hs);
     switch (r) {
@@ -1016,7 +1082,7 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
                              const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
                              uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs) {
     if (m < 1 || m > 32 || d % 32 != 0 || n != (h + 2 * hkv) * d || tiles * 16 != n) return ZL_ESHAPE;
-    if (norm_w && (m > 8 || k > 4096)) return ZL_ESHAPE;
+    if (norm_w && m <= 8 && k > 4096) return ZL_ESHAPE;
     PhaseParams p = {};
     p.x = x; p.ldx = ldx; p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes;
     p.meta_bytes = meta_bytes; p.bias = bias; p.residual = nullptr; p.y = nullptr; p.m = m; p.n = n; p.k = k;
@@ -1027,6 +1093,9 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
     p.ks_ws = nullptr; p.ks_counter = nullptr;
     p.mg_ws = nullptr; p.mg_valid_lens = nullptr; p.mg_split_len = p.mg_max_splits = 0;
     const int grid = tiles / 2;
+    if (norm_w && m > 8)                               // 9..32 rows: the deferred norm
+        return m <= 16 ? launch_phase<2, 1, false, true, 1, false, false, true>(p, grid, hs)
+                       : launch_phase<2, 2, false, true, 1, false, false, true>(p, grid, hs);
     if (norm_w || (m <= 4 && k <= 4096)) return launch_phase<2, 1, true, true>(p, grid, hs);
     return m <= 16 ? launch_phase<2, 1, false, true>(p, grid, hs) : launch_phase<2, 2, false, true>(p, grid, hs);
 }

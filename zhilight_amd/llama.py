@@ -557,10 +557,21 @@ class Int8EncoderLayer:
         ops.quant_back_element_add_scale(self.w_out.gemm(aq), sa, self.w_out.scale, hidden, 1.0, out=hidden)
 
 
+# decode attention with the split merge inside its launch (zl_decode_attn_la): default of the ZL_ATTN_LA switch
+_ATTN_LA_DEFAULT = "0"
+
+
+# 9..32 decode rows: RMSNorm deferred into the phase kernel (w4_phase.hip DN) instead of a stand-alone launch: the ZL_DEFER_NORM switch
+_DEFER_NORM_DEFAULT = "0"
+
+
 def _fused_norm_rows(weight):
-    """rows up to which the W4A16 kernel of this weight fuses the RMSNorm prologue: 8 for the phase-pipelined MFMA kernel
-    (register-resident activations, K <= 4096), 4 otherwise"""
-    return 8 if isinstance(weight, ops.W4MWeight) and weight.k <= 4096 and weight.group_size % 128 == 0 else 4
+    """rows up to which the W4A16 kernel of this weight fuses the RMSNorm: 8 for the phase-pipelined MFMA kernel
+    (register-resident activations, K <= 4096; bit-identical to the stand-alone launch), 32 with the deferred norm on
+    (ZL_DEFER_NORM=1: rs applied to the fp32 totals, not bit-identical), 4 otherwise"""
+    if not (isinstance(weight, ops.W4MWeight) and weight.k <= 4096 and weight.group_size % 128 == 0):
+        return 4
+    return 32 if os.environ.get("ZL_DEFER_NORM", _DEFER_NORM_DEFAULT) != "0" else 8
 
 
 class EncoderLayer:
@@ -875,6 +886,54 @@ class LLaMA:
                 layer.k_norm = (1.0 + 0.1 * torch.randn(nk, device=dev, generator=gen)).to(dt)
         return self
 
+    def init_synthetic(self, seed=0):
+        """Synthetic GPTQ checkpoint of this geometry with SURVEY 8(d)'s recipe -- the one tests/synth.py::gptq_hf and
+        tests/test_gpu_model.py::_hf_state draw on the host -- generated on the device and taken through the REAL load path
+        (EncoderLayer.load_state_dict: shuffle, zero + 1, transposes, fusion, ZLW4M packing), one layer at a time:
+          qweight (K/8, N) int32 from uniform nibbles 0..15; qzeros (K/G, N/8) int32 from nibbles 0..14 stored as zero - 1;
+          scales (K/G, N) fp16 = |N(0,1)| * (0.5 / sqrt(K)) / 4 + 1e-4 (activations stay O(1): _hf_state's magnitude, = 8(d)'s
+          0.02 / 8 at K = 4096 within 25 %); norm weights 1 + 0.1 N(0,1); embedding uniform integers / 128, lm_head uniform
+          integers * 0.05 / 64 (tests/test_gpu_fullgeom.py::_state).
+        W4 route, no tensor parallelism (bench.py's TP leg keeps init_random: every rank would have to draw the full matrices)."""
+        c, dev, q = self.cfg, self.device, self.quant
+        if self.tp or not all(isinstance(l, EncoderLayer) for l in self.layers) or q.act_order or q.awq:
+            raise ops.ZLError("init_synthetic: the plain GPTQ layer stack")
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        g = q.group_size
+        i64 = dict(dtype=torch.int64, device=dev, generator=gen)
+
+        def pack8(nib, dim):                            # 8 nibbles along `dim` (stride 8) -> one int32 word, nibble j at bits 4 j
+            word = torch.zeros_like(nib.select(dim, 0).unsqueeze(dim).expand(*[s // 8 if i == dim else s for i, s in enumerate(nib.shape)])).contiguous()
+            for j in range(8):
+                word |= (nib[j::8] if dim == 0 else nib[:, j::8]) << (4 * j)
+            return torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(torch.int32)
+
+        def lin(sd, name, din, dout):
+            sd[name + ".qweight"] = pack8(torch.randint(0, 16, (din, dout), **i64), 0)
+            sd[name + ".qzeros"] = pack8(torch.randint(0, 15, (din // g, dout), **i64), 1)
+            sd[name + ".scales"] = (torch.randn(din // g, dout, device=dev, generator=gen).abs() * ((0.5 / math.sqrt(din)) / 4) + 1e-4).to(torch.float16)
+        hd, kvd = c.num_heads * c.dim_head, c.num_kv_heads * c.dim_head
+        dt = c.torch_dtype
+        for i, layer in enumerate(self.layers):
+            pfx = f"llama.layers.{i}"
+            sd = {pfx + ".ln_attn.weight": (1 + 0.1 * torch.randn(c.dim_model, device=dev, generator=gen)).to(torch.float16),
+                  pfx + ".ln_ff.weight": (1 + 0.1 * torch.randn(c.dim_model, device=dev, generator=gen)).to(torch.float16)}
+            lin(sd, pfx + ".attn.project_q", c.dim_model, hd)
+            lin(sd, pfx + ".attn.project_k", c.dim_model, kvd)
+            lin(sd, pfx + ".attn.project_v", c.dim_model, kvd)
+            lin(sd, pfx + ".attn.attn_out", hd, c.dim_model)
+            lin(sd, pfx + ".ff.w_in", c.dim_model, c.dim_ff)
+            lin(sd, pfx + ".ff.w_gated", c.dim_model, c.dim_ff)
+            lin(sd, pfx + ".ff.w_out", c.dim_ff, c.dim_model)
+            layer.load_state_dict(sd, pfx, dev)
+            layer.q_norm = layer.k_norm = None
+            del sd
+        u8 = lambda: torch.randint(-127, 128, (c.vocab_size, c.dim_model), dtype=torch.int8, device=dev, generator=gen)
+        self.token_embedding = (u8().to(dt) * (1.0 / 128)).contiguous()
+        self.output_layernorm = (1 + 0.1 * torch.randn(c.dim_model, device=dev, generator=gen)).to(dt)
+        self.lm_head = self.token_embedding if c.tie_lm_head else (u8().to(dt) * (0.05 / 64)).contiguous()
+        return self
+
     # ---- KV state ------------------------------------------------------------------------------
     def new_context(self, batch: int, len_buf: int, start_pos: int, fill_random=False, kv_cache_dtype=None) -> DynBatchContext:
         """`batch` tasks whose first `start_pos` tokens are already in the KV buffers (zero- or
@@ -963,7 +1022,7 @@ class LLaMA:
                          and all(isinstance(l, EncoderLayer) and l.unfused is None and l.qkv.perm is None
                                  and isinstance(l.qkv.weight, ops.W4MWeight)
                                  for l in self.layers)
-                         and ops.w4_qkv_rope_scatter_ok(b, c.dim_model, c.dim_head, norm=b <= 8))
+                         and ops.w4_qkv_rope_scatter_ok(b, c.dim_model, c.dim_head, norm=b <= max(8, _fused_norm_rows(self.layers[0].qkv.weight))))
         fuse_qkv_rope_i8 = (mfma_attn and not ctx.kv_quant and b <= 32 and c.dim_head % 32 == 0 and not c.qk_norm
                             and os.environ.get("ZL_FUSE_QKV_ROPE", "1") != "0"
                             and all(isinstance(l, Int8EncoderLayer) and l._stream(b) for l in self.layers))
@@ -973,6 +1032,30 @@ class LLaMA:
                 and all(l.attn_out.perm is None for l in self.layers)):
             merge_plan = ops.attn_merge_plan(b, c.num_heads, c.num_kv_heads, c.dim_head, ctx.max_len_buf,
                                              self.layers[0].attn_out.weight, c.torch_dtype)
+        # round 5: the split merge INSIDE the attention launch (last-arriving workgroup of a (task, kv head) pair, zl_decode_attn_la):
+        # no merge launch at any batch size, no merging prologue in attn_out.  ZL_ATTN_LA: 0 off, 1 on (the launcher's split length),
+        # ZL_ATTN_LA_SPLIT = keys per split (multiple of 32), ZL_ATTN_LA_HALF = 1 half-precision split records
+        la = None
+        if (mfma_attn and not ctx.kv_quant and c.dim_head == 128 and os.environ.get("ZL_ATTN_LA", _ATTN_LA_DEFAULT) != "0"):
+            la_split = int(os.environ.get("ZL_ATTN_LA_SPLIT", "0") or 0)
+            la_half = os.environ.get("ZL_ATTN_LA_HALF", "0") == "1" and c.torch_dtype == torch.float16
+            eff = la_split or ops.decode_attn_la_split_len(b, c.num_kv_heads, ctx.max_len_buf)
+            if (ctx.max_len_buf + eff - 1) // eff <= 64:
+                key = ("la_ws", b, ctx.max_len_buf)
+                if key not in self._bufs:
+                    self._bufs[key] = ops.decode_attn_la_workspace(b, c.num_heads, c.num_kv_heads, ctx.max_len_buf, self.device)
+                la = (self._bufs[key], la_split, la_half)
+                merge_plan = None
+
+        def attend(li, out):
+            """decode attention of layer li over the tasks' buffers: bufs["q"] -> out (B, H * D)"""
+            q4 = bufs["q"].view(b, 1, c.num_heads, c.dim_head)
+            if la is not None:
+                return ops.decode_attention_la(q4, ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li], ctx.valid_lens, scale, ctx.max_len_buf,
+                                               c.num_kv_heads, la[0], out=out.view(b, 1, c.num_heads, c.dim_head), split_len=la[1], half=la[2])
+            return ops.multi_query_attention_rag_buffer(q4, ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li], None, scale, ctx.max_len_buf,
+                                                        c.num_kv_heads, valid_lens=ctx.valid_lens, out=out.view(b, 1, c.num_heads, c.dim_head),
+                                                        workspace=workspace)
         # attention split merge + attn_out + residual and ln_ff + gate|up + silu.mul in ONE launch (w4_engine.hip)
         fuse_o_ff = (merge_plan is not None and merge_plan[2] and os.environ.get("ZL_FUSE_O_GATEUP", "0") == "1"
                      and all(l.w_in_gated.perm is None and isinstance(l.w_in_gated.weight, ops.W4MWeight) for l in self.layers))
@@ -987,12 +1070,12 @@ class LLaMA:
                 _, xq, sx = ops.layernorm_quant(hidden, layer.ln_attn, c.eps)
                 ops.w8a8_qkv_rope_scatter(xq, sx, layer.qkv.stream_weight(), cos, sin, ctx.placement, ctx.buf_lens, ctx.k_addrs[li],
                                           ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, q_out=bufs["q"])
-                ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
-                                                     ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
-                                                     valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
-                                                     workspace=workspace)
+                attend(li, bufs["attn"])
                 layer.attn_out_add(bufs["attn"], hidden)
                 layer.ff_add(hidden, c.eps, bufs["act"])
+                continue
+            if fuse_qkv_rope and skip_gemv and la is not None:
+                attend(li, bufs["attn"])
                 continue
             if fuse_qkv_rope and skip_gemv:
                 if not merge_plan:
@@ -1001,10 +1084,11 @@ class LLaMA:
                                             ctx.v_addrs[li], ctx.valid_lens, scale, ctx.max_len_buf, c.num_kv_heads, workspace)
                 continue
             if fuse_qkv_rope:
-                xin = hidden if b <= 8 else ops.rmsnorm(hidden, layer.ln_attn, c.eps)
+                fused_norm = b <= max(8, _fused_norm_rows(layer.qkv.weight))    # 9..32 rows: the deferred norm (ZL_DEFER_NORM)
+                xin = hidden if fused_norm else ops.rmsnorm(hidden, layer.ln_attn, c.eps)
                 ops.w4_qkv_rope_scatter(xin, layer.qkv.weight, cos, sin, ctx.placement, ctx.buf_lens, ctx.k_addrs[li],
                                         ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, bias=layer.qkv.bias,
-                                        norm_weight=layer.ln_attn if b <= 8 else None, norm_eps=c.eps, q_out=bufs["q"])
+                                        norm_weight=layer.ln_attn if fused_norm else None, norm_eps=c.eps, q_out=bufs["q"])
                 if merge_plan:
                     if not gemv_only:
                         ops.decode_attention_splits(bufs["q"].view(b, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
@@ -1019,10 +1103,7 @@ class LLaMA:
                     layer.ff_add(hidden, c.eps, bufs["act"])
                     continue
                 if not gemv_only:
-                    ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
-                                                         ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
-                                                         valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
-                                                         workspace=workspace)
+                    attend(li, bufs["attn"])
                 layer.attn_out_add(bufs["attn"], hidden)
                 layer.ff_add(hidden, c.eps, bufs["act"])
                 continue
@@ -1044,10 +1125,7 @@ class LLaMA:
                 # k_decode_attn_mfma; 11.0 / 18.7 / 39.8 us vs 11.9 / 24.0 / 49.7 us for the fused VALU kernel at batch 1 / 8 / 32)
                 ops.rope_scatter_decode(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.k_addrs[li], ctx.v_addrs[li],
                                         c.num_heads, c.num_kv_heads, c.dim_head, q_out=bufs["q"])
-                ops.multi_query_attention_rag_buffer(bufs["q"].view(b, 1, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
-                                                     ctx.v_addrs[li], None, scale, ctx.max_len_buf, c.num_kv_heads,
-                                                     valid_lens=ctx.valid_lens, out=bufs["attn"].view(b, 1, c.num_heads, c.dim_head),
-                                                     workspace=workspace)
+                attend(li, bufs["attn"])
             else:
                 ops.decode_attention_fused(cos, sin, bufs["qkv"], ctx.placement, ctx.buf_lens, ctx.valid_lens, ctx.k_addrs[li],
                                            ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, scale, ctx.max_len_buf,

@@ -781,7 +781,7 @@ def rope_scatter_decode(cos, sin, qkv, placement, buf_lens, k_addrs, v_addrs, nu
 
 def w4_qkv_rope_scatter_ok(m, k, dim_head, norm):
     """what zl_w4a16_qkv_rope_scatter covers (otherwise: w4_linear + rope_scatter_decode)"""
-    return m <= 32 and dim_head % 32 == 0 and (not norm or (m <= 8 and k <= 4096)) and (m <= 16 or k <= 8192)
+    return m <= 32 and dim_head % 32 == 0 and (not norm or k <= 4096 or m > 8) and (m <= 16 or k <= 8192)
 
 
 def w4_qkv_rope_scatter(x, w, cos, sin, placement, buf_lens, k_addrs, v_addrs, num_heads, num_kv_heads, dim_head, bias=None,
@@ -824,6 +824,38 @@ def multi_query_attention_rag_buffer(batch_q, buf_lens, key_buf_addrs, val_buf_a
                                _p(valid_lens), _p(out), _p(workspace), _i(b), _i(len_q), _i(h), _i(num_kv_heads),
                                _i(d), _f(scale), _i(max_len_buf), C.c_int(int(bshd)), C.c_int(_dt(batch_q)),
                                C.c_int(_attn_algo()), _stream()), "decode_attn")
+    return out
+
+
+def decode_attn_la_split_len(b, num_kv_heads, max_len_buf):
+    """keys per split zl_decode_attn_la picks for this batch geometry (a multiple of 32)"""
+    return int(lib().zl_decode_attn_la_split_len(_i(b), _i(num_kv_heads), _i(max_len_buf)))
+
+
+def decode_attn_la_workspace(b, h, num_kv_heads, max_len_buf, device, split_len=0):
+    """zero-initialised workspace of decode_attention_la (arrival words + split records); split_len = 0: large enough for any
+    split length.  One per stream of launches that may overlap."""
+    nbytes = lib().zl_decode_attn_la_workspace_bytes(_i(b), _i(h), _i(num_kv_heads), _i(max_len_buf), _i(split_len))
+    if nbytes < 0:
+        check(int(nbytes), "decode_attn_la_workspace_bytes")
+    return torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+def decode_attention_la(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, valid_lens, scale, max_len_buf, num_kv_heads, workspace,
+                        out=None, bshd=True, split_len=0, half=False):
+    """multi_query_attention_rag_buffer for decode rows (len_q = 1, prefix visibility) as ONE launch: the split merge is done by
+    the last-arriving workgroup of every (task, kv head) pair (zl_decode_attn_la).  batch_q (B, 1, H, 128) or (B, H, 128);
+    workspace from decode_attn_la_workspace (zeroed once).  Returns out, shaped like batch_q."""
+    _chk_cuda(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, valid_lens, workspace)
+    b, h, d = batch_q.shape[0], batch_q.shape[-2], batch_q.shape[-1]
+    if batch_q.dim() == 4 and batch_q.shape[1] != 1:
+        raise ZLError("decode_attention_la: one query row per task")
+    if out is None:
+        out = torch.empty_like(batch_q)
+    check(lib().zl_decode_attn_la(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(valid_lens), _p(out),
+                                  _p(workspace), _i(b), _i(h), _i(num_kv_heads), _i(d), _f(scale), _i(max_len_buf),
+                                  C.c_int(int(bshd)), C.c_int(_dt(batch_q)), _i(split_len), C.c_int(int(bool(half))), _stream()),
+          "decode_attn_la")
     return out
 
 
