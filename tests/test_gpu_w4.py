@@ -746,10 +746,12 @@ def test_i8p_nonfinite_activations_propagate(oracle, dev, m, k):
 # ---------------------------------------------------------------------------------------------------------------------
 def _dn_bound(exact, lin=0.0):
     """What separates the deferred norm from norm-then-GEMM is WHERE the activation is rounded to fp16: T(x w) rs against
-    T(x rs w), 2^-12 rms relative noise per activation either way, independent between the two -> ~2e-4 rms(y) per output
-    between them (random signs over K), 4.5 sigma over a few 1e5 outputs; plus the fp16 rounding of the output itself."""
+    T(x rs w) -- a relative rounding error of rms ~0.6 x 2^-11 per activation either way, independent between the two -> ~4-5e-4
+    rms(y) per output between them (random signs over K; measured 4.9e-4 on the 6144 x 4096 matrix), 4.5 sigma over 2e5 outputs
+    = 2.2e-3 measured; the bound leaves 1.6 x that.  Plus the fp16 rounding of the output itself.  For scale: E's own distance to
+    the unrounded-activation product is the same 3-4e-4 rms, the reference's fp16 partial sums (R) sit 1e-2 rms from E."""
     rms = np.sqrt((exact ** 2).mean())
-    return 2.0 ** -10 * (np.abs(exact) + lin) + 1.5e-3 * rms
+    return 2.0 ** -10 * (np.abs(exact) + lin) + 3.5e-3 * rms
 
 
 @pytest.mark.parametrize("m", [9, 16, 17, 32])
@@ -786,7 +788,7 @@ def test_deferred_norm_rows_9_32(oracle, dev, m, k, n, epi):
         rms = np.sqrt((ref ** 2).mean())
         # gate and up each carry the activation-rounding noise (1.5e-3 of THEIR rms); silu' <= 1.1
         rg, ru = np.sqrt((gate.astype(np.float64) ** 2).mean()), np.sqrt((up.astype(np.float64) ** 2).mean())
-        tol = 2.0 ** -9 * np.abs(ref) + 2.0 ** -10 * gu + 1.5e-3 * (1.1 * rg * np.abs(up.astype(np.float64)) + ru * np.abs(gate.astype(np.float64))) + 3e-4 * rms
+        tol = 2.0 ** -9 * np.abs(ref) + 2.0 ** -10 * gu + 3.5e-3 * (1.1 * rg * np.abs(up.astype(np.float64)) + ru * np.abs(gate.astype(np.float64))) + 3e-4 * rms
         bad = np.abs(got - ref) > tol
         assert not bad.any(), (int(bad.sum()), float((np.abs(got - ref) / rms).max()))
         return
@@ -837,9 +839,9 @@ def test_deferred_norm_fused_qkv_rotary_scatter(oracle, dev, m, bshd):
                                     h, hkv, d, bias=bias, norm_weight=nw, norm_eps=1e-5, bshd=bshd)
     ref = q_ref.float().cpu().numpy().astype(np.float64)
     rms = np.sqrt((ref ** 2).mean())
-    assert (np.abs(q_got.float().cpu().numpy() - ref) <= 2.0 ** -9 * np.abs(ref) + 2e-3 * rms).all()
+    assert (np.abs(q_got.float().cpu().numpy() - ref) <= 2.0 ** -9 * np.abs(ref) + 4e-3 * rms).all()
     for a, b_ in zip(k1 + v1, k2 + v2):
         a64, b64 = a.float().cpu().numpy().astype(np.float64), b_.float().cpu().numpy().astype(np.float64)
-        assert (np.abs(a64 - b64) <= 2.0 ** -9 * np.abs(a64) + 2e-3 * rms).all()
-        assert np.array_equal(a64 == 3.0, b64 == 3.0) or np.abs(a64 - b64).max() <= 2e-3 * rms     # untouched slots stay untouched
+        assert (np.abs(a64 - b64) <= 2.0 ** -9 * np.abs(a64) + 4e-3 * rms).all()
+        assert np.array_equal(a64 == 3.0, b64 == 3.0) or np.abs(a64 - b64).max() <= 4e-3 * rms     # untouched slots stay untouched
     assert not torch.equal(k2[0], torch.full_like(k2[0], 3.0))

@@ -665,7 +665,7 @@ __device__ __forceinline__ f4v mfma_t(uint4 a, uint4 b, f4v c) {
 // splits), or the merging projection's (half records: w4_i8p.hip MERGE).  The last arriver puts the word back to zero: the
 // counters need zeroing once, when the workspace is made.  A pair with a single live split skips all of it and writes its rows.
 // Records: fp32 [vh][split][128 acc | max | sum], or (half) fp16 [vh][split][128] normalised rows + fp32 (max, sum) pairs behind them.
-constexpr int kLaMaxSplits = 64;      // statistics of a pair in LDS: 16 rows x 64 splits x (max, sum)
+constexpr int kLaMaxSplits = 64;      // splits per task the launcher allows (the last arriver walks them 16 at a time)
 
 template <int DT>
 __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int b, int hk, int split, int nw, int ns) {
@@ -732,59 +732,59 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
     }
     __syncthreads();
     if (!*flag) return;
-    __syncthreads();                                    // the flag has been read by everyone before LDS is reused
-    // ---- the pair's last arriver: statistics of all (row, split) to LDS, then thread -> (row i, 4 consecutive d)
-    float* sm = xw;                                     // [16 rows][kLaMaxSplits][max, sum]
-    for (int t = threadIdx.x; t < p.rows * ns; t += nthr) {
-        const int i = t / ns, u = t % ns;
-        const int qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
-        const size_t rec = (((size_t)b * p.len_q + qi) * p.h + head) * p.max_splits + u;
-        const float* st = p.half_partials ? p.ws + stat0 + rec * 2 : p.ws + rec * (kMD + 2) + kMD;
-        const uint64_t ml = __hip_atomic_load(reinterpret_cast<const uint64_t*>(st), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sm[(i * kLaMaxSplits + u) * 2] = __builtin_bit_cast(float, (uint32_t)ml);
-        sm[(i * kLaMaxSplits + u) * 2 + 1] = __builtin_bit_cast(float, (uint32_t)(ml >> 32));
-    }
-    __syncthreads();
+    // ---- the pair's last arriver: thread -> (row i, 4 consecutive d).  Statistics AND record slices of up to 16 splits are
+    //      requested together (one memory round trip; the statistics are the same 8 bytes for the 32 threads of a row); more
+    //      than 16 splits continue in further batches with the running maximum carried along (flash-decoding's rescale)
     for (int it = threadIdx.x; it < p.rows * (kMD / 4); it += nthr) {
         const int i = it / (kMD / 4), d0 = (it % (kMD / 4)) * 4;
         const int qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
         const size_t vh = ((size_t)b * p.len_q + qi) * p.h + head;
-        const float* st = sm + (size_t)i * kLaMaxSplits * 2;
-        float mn = -1e20f;
-        for (int u = 0; u < ns; ++u) mn = fmaxf(mn, st[2 * u]);
-        float a[4] = {0.f, 0.f, 0.f, 0.f}, z = 0.f;
-        for (int u0 = 0; u0 < ns; u0 += 16) {           // 16 records in flight at a time
-            uint64_t lo[16], hi[16];
+        float mn = -1e20f, a[4] = {0.f, 0.f, 0.f, 0.f}, z = 0.f;
+        for (int u0 = 0; u0 < ns; u0 += 16) {
+            uint64_t lo[16], hi[16], ml[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int u = min(u0 + j, ns - 1);
+                const size_t rec = vh * p.max_splits + min(u0 + j, ns - 1);
                 if (p.half_partials) {
-                    lo[j] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint16_t*>(p.ws) + ((vh * p.max_splits + u) * kMD + d0)),
+                    lo[j] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint16_t*>(p.ws) + (rec * kMD + d0)),
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hi[j] = 0;
+                    ml[j] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p.ws + stat0 + rec * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
-                    const uint64_t* src = reinterpret_cast<const uint64_t*>(p.ws + (vh * p.max_splits + u) * (kMD + 2) + d0);
+                    const uint64_t* src = reinterpret_cast<const uint64_t*>(p.ws + rec * (kMD + 2) + d0);
                     lo[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hi[j] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ml[j] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p.ws + rec * (kMD + 2) + kMD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            float mb = mn;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (u0 + j < ns) mb = fmaxf(mb, __builtin_bit_cast(float, (uint32_t)ml[j]));
+            if (u0 > 0) {                               // (never taken up to 16 splits: the arithmetic there is the merge kernel's)
+                const float r = __expf(mn - mb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] *= r;
+                z *= r;
+            }
+            mn = mb;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int u = u0 + j;
-                if (u < ns) {
+                if (u0 + j < ns) {
+                    const float ms = __builtin_bit_cast(float, (uint32_t)ml[j]), ls = __builtin_bit_cast(float, (uint32_t)(ml[j] >> 32));
                     if (p.half_partials) {              // w4_i8p.hip MERGE: weight l e^(m - M) on the normalised row
-                        const float f = st[2 * u + 1] * __expf(st[2 * u] - mn);
+                        const float f = ls * __expf(ms - mn);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             a[e] = __builtin_fmaf((float)__builtin_bit_cast(_Float16, (uint16_t)(lo[j] >> (16 * e))), f, a[e]);
                         z += f;
                     } else {                            // k_decode_attn_combine
-                        const float f = __expf(st[2 * u] - mn);
+                        const float f = __expf(ms - mn);
                         a[0] = __builtin_fmaf(__builtin_bit_cast(float, (uint32_t)lo[j]), f, a[0]);
                         a[1] = __builtin_fmaf(__builtin_bit_cast(float, (uint32_t)(lo[j] >> 32)), f, a[1]);
                         a[2] = __builtin_fmaf(__builtin_bit_cast(float, (uint32_t)hi[j]), f, a[2]);
                         a[3] = __builtin_fmaf(__builtin_bit_cast(float, (uint32_t)(hi[j] >> 32)), f, a[3]);
-                        z = __builtin_fmaf(st[2 * u + 1], f, z);
+                        z = __builtin_fmaf(ls, f, z);
                     }
                 }
             }
@@ -1445,13 +1445,12 @@ int zl_decode_attn_splits_h(const uint16_t* q, const int32_t* buf_lens, const ui
 
 // ---- decode attention with the split merge inside the launch (last-arriver; k_decode_attn_mfma + attn_tail_la) -------------
 static inline int la_split_len(int64_t b, int64_t hkv, int64_t max_len) {
-    // about 1024 workgroups of >= 32 keys (one 32-key chunk per wave, 1 / 2 / 4 waves per workgroup): batch 1 x 8 kv heads x 1088
-    // slots -> 34 single-wave workgroups per kv head (16 KB of K / V each, spread over every CU instead of 72 of them)
-    int64_t ls = (max_len * b * hkv / 1024) / 32 * 32;
-    if (ls < 32) ls = 32;
-    if (ls > 128) ls = ls / 128 * 128;
-    if (ls > 2048) ls = 2048;
-    while ((max_len + ls - 1) / ls > kLaMaxSplits) ls += ls >= 128 ? 128 : 32;
+    // the two-launch path's split length (attn_split_len: multiples of 128 keys, 4 waves per workgroup) -- with it the records and
+    // the merge are the ones of zl_decode_attn, bit for bit.  Finer splits (32 / 64 keys: every CU pulls a share of a batch-1
+    // history) were measured and LOSE: the last arriver's serial chain (write-through drain, ticket, re-read) grows with the
+    // record count faster than the per-CU pull shrinks (profiles/r05_attn_la_ab.txt)
+    int64_t ls = attn_split_len(b, hkv, max_len);
+    while ((max_len + ls - 1) / ls > kLaMaxSplits) ls += 128;
     return (int)ls;
 }
 

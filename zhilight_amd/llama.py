@@ -558,11 +558,11 @@ class Int8EncoderLayer:
 
 
 # decode attention with the split merge inside its launch (zl_decode_attn_la): default of the ZL_ATTN_LA switch
-_ATTN_LA_DEFAULT = "0"
+_ATTN_LA_DEFAULT = "auto"
 
 
 # 9..32 decode rows: RMSNorm deferred into the phase kernel (w4_phase.hip DN) instead of a stand-alone launch: the ZL_DEFER_NORM switch
-_DEFER_NORM_DEFAULT = "0"
+_DEFER_NORM_DEFAULT = "1"
 
 
 def _fused_norm_rows(weight):
@@ -1032,11 +1032,15 @@ class LLaMA:
                 and all(l.attn_out.perm is None for l in self.layers)):
             merge_plan = ops.attn_merge_plan(b, c.num_heads, c.num_kv_heads, c.dim_head, ctx.max_len_buf,
                                              self.layers[0].attn_out.weight, c.torch_dtype)
-        # round 5: the split merge INSIDE the attention launch (last-arriving workgroup of a (task, kv head) pair, zl_decode_attn_la):
-        # no merge launch at any batch size, no merging prologue in attn_out.  ZL_ATTN_LA: 0 off, 1 on (the launcher's split length),
-        # ZL_ATTN_LA_SPLIT = keys per split (multiple of 32), ZL_ATTN_LA_HALF = 1 half-precision split records
+        # round 5: the split merge INSIDE the attention launch (last-arriving workgroup of a (task, kv head) pair, zl_decode_attn_la)
+        # wherever the step would otherwise run the two-launch path (split kernel + merge kernel): same records, same merge
+        # arithmetic, one launch less per layer.  Batch 1 keeps the merge in attn_out's prologue: there the in-launch merge was
+        # measured 1.4 us per layer SLOWER at the same split length and worse with finer splits (profiles/r05_attn_la_ab.txt).
+        # ZL_ATTN_LA: auto (default) / 0 off / 1 everywhere; ZL_ATTN_LA_SPLIT = keys per split (multiple of 32, 0 = the two-launch
+        # path's), ZL_ATTN_LA_HALF = 1 half-precision split records
         la = None
-        if (mfma_attn and not ctx.kv_quant and c.dim_head == 128 and os.environ.get("ZL_ATTN_LA", _ATTN_LA_DEFAULT) != "0"):
+        la_mode = os.environ.get("ZL_ATTN_LA", _ATTN_LA_DEFAULT)
+        if (mfma_attn and not ctx.kv_quant and c.dim_head == 128 and (la_mode == "1" or (la_mode == "auto" and merge_plan is None))):
             la_split = int(os.environ.get("ZL_ATTN_LA_SPLIT", "0") or 0)
             la_half = os.environ.get("ZL_ATTN_LA_HALF", "0") == "1" and c.torch_dtype == torch.float16
             eff = la_split or ops.decode_attn_la_split_len(b, c.num_kv_heads, ctx.max_len_buf)
