@@ -521,6 +521,8 @@ class OracleInt8Model:
         mask = np.concatenate([(np.arange(self.len_buf) <= p).astype(np.int8) for p in pos])
         for i in range(c.num_layers):
             p = f"model.layers.{i}."
+            if getattr(self, "trace_hidden", None) is not None:
+                self.trace_hidden.append(h.copy())          # the hidden rows entering layer i (parity-at-depth records)
             _, xq, sx = o.rmsnorm_quant(h, o.h2u(self.sd[p + "input_layernorm.weight"]), c.eps)
             qkv = np.concatenate([o.quant_scale_back(o.int8_gemm_nt(xq, self.w[p + "self_attn." + n + "_proj"][0]), sx,
                                                      self.w[p + "self_attn." + n + "_proj"][1]) for n in "qkv"], axis=1)
@@ -574,6 +576,46 @@ def test_int8_model_decode_matches_oracle(oracle, dev, batch):
         assert np.abs(got - ref).max() <= 2e-3 * scale, (step, np.abs(got - ref).max() / scale)
         tokens = ref.argmax(axis=1).astype(np.int32)
         model.advance(ctx, torch.from_numpy(tokens).to(dev))
+
+
+def int8_layer_ops_oracle(om, i, h, pos, attn_exact=False):
+    """One layer of OracleInt8Model op by op from the hidden rows `h` (fp16 bits): the outputs of every op in order, as a dict
+    name -> array -- what tests/test_gpu_fullgeom.py compares with the HIP ops run on the same input to name the FIRST op whose
+    output differs.  Writes the layer's new K / V rows into om.kb / om.vb (as step does)."""
+    o, c = om.o, om.cfg
+    b = h.shape[0]
+    p = f"model.layers.{i}."
+    cs, sn = o.rope_cos_sin(np.asarray(pos, np.int32), c.dim_head, c.rope_theta, True, (8.0, 1.0, 4.0, 8192.0))
+    lens = np.full(b, om.len_buf, np.int32)
+    mask = np.concatenate([(np.arange(om.len_buf) <= q).astype(np.int8) for q in pos])
+    out = {}
+    _, xq, sx = o.rmsnorm_quant(h, o.h2u(om.sd[p + "input_layernorm.weight"]), c.eps)
+    out["ln_attn+quant codes"], out["ln_attn+quant scales"] = xq, sx
+    qkv = np.concatenate([o.quant_scale_back(o.int8_gemm_nt(xq, om.w[p + "self_attn." + n + "_proj"][0]), sx,
+                                             om.w[p + "self_attn." + n + "_proj"][1]) for n in "qkv"], axis=1)
+    q, k, v = o.rope_qk_cache(cs, sn, qkv, c.num_heads, c.num_kv_heads, c.dim_head, True)
+    out["qkv projection + rotary: q"] = q
+    out["qkv projection + rotary: new k"], out["qkv projection: new v"] = k, v
+    o.copy_to_rag_buffer2(np.asarray(pos, np.int32).reshape(b, 1), lens, k.reshape(b, 1, c.num_kv_heads, c.dim_head),
+                          v.reshape(b, 1, c.num_kv_heads, c.dim_head), om.kb[i], om.vb[i], True)
+    if attn_exact:
+        att = o.h2u(o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, om.kb[i], om.vb[i], mask,
+                                     c.num_kv_heads, 1.0 / np.sqrt(c.dim_head), True, exact=True).astype(np.float16)).reshape(b, -1)
+    else:
+        att = o.mqa_rag_buffer(q.reshape(b, 1, c.num_heads, c.dim_head), lens, om.kb[i], om.vb[i], mask, c.num_kv_heads,
+                               1.0 / np.sqrt(c.dim_head), True).reshape(b, -1)
+    out["decode attention"] = att
+    aq, sa = o.quant_calc_scale(att)
+    wo = om.w[p + "self_attn.o_proj"]
+    h1 = o.quant_back_element_add_scale(o.int8_gemm_nt(aq, wo[0]), sa, wo[1], h, 1.0)
+    out["attn_out + residual"] = h1
+    _, xq, sx = o.rmsnorm_quant(h1, o.h2u(om.sd[p + "post_attention_layernorm.weight"]), c.eps)
+    wg, wu, wd = om.w[p + "mlp.gate_proj"], om.w[p + "mlp.up_proj"], om.w[p + "mlp.down_proj"]
+    act = o.quant_back_act_mul(o.int8_gemm_nt(xq, wg[0]), sx, wg[1], o.int8_gemm_nt(xq, wu[0]), sx, wu[1], "silu")
+    out["ln_ff + gate|up + silu.mul"] = act
+    aq, sa = o.quant_calc_scale(act)
+    out["w_out + residual"] = o.quant_back_element_add_scale(o.int8_gemm_nt(aq, wd[0]), sa, wd[1], h1, 1.0)
+    return out
 
 
 class OracleDenseModel:

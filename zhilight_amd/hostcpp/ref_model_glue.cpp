@@ -222,6 +222,78 @@ public:
         return out;
     }
 
+    // Timing of the path a maintainer binding the boundary gets: `iters` back-to-back decode steps of the
+    // reference's LLaMA::encode + get_logits (same tokens / positions: every step rewrites the same KV slot), HIP events on the
+    // context's stream; eager (one C-ABI launch + one pooled ctx.tensor per reference op), and -- graph = true -- ONE step
+    // captured into a hipGraph and replayed (possible because the pool makes ctx.tensor allocation-free in steady state and the
+    // wrappers launch on the context's stream only).  Returns {"eager_ms", "graph_ms" or "graph_error"}.
+    py::dict time_decode_steps(const py::array& tokens, const py::array& positions, const py::array& mask, int warmup, int iters, bool graph) {
+        const size_t B = (size_t)tokens.shape(0);
+        auto dyn = std::make_shared<model::DynBatchContext>();
+        dyn->s_token = to_device(ctx_, tokens, "s_token");
+        dyn->s_position = to_device(ctx_, positions, "s_position");
+        dyn->s_placement = to_device(ctx_, positions, "s_placement").view({B, 1});
+        dyn->s_mask = to_device(ctx_, mask, "s_mask");
+        for (size_t b = 0; b < B; ++b) dyn->sv_len_buf.push_back((int)rag_->get_buf_len(b));
+        dyn->s_len_buf = ctx_.tensor_of(dyn->sv_len_buf);
+        ctx_.set_dyn_batch(dyn);
+        rag_->set_buffer_addr(ctx_);
+        hipStream_t st = ctx_.current_cuda_stream();
+        auto one = [&]() {
+            Tensor none;
+            Tensor hidden = model_->encode(ctx_, dyn->s_token, dyn->s_position, none, none, none, none, none, true);
+            Tensor logits = model_->get_logits(ctx_, hidden, false);
+        };
+        py::dict out;
+        hipEvent_t e0, e1;
+        BM_CUDART_ASSERT(hipEventCreate(&e0));
+        BM_CUDART_ASSERT(hipEventCreate(&e1));
+        for (int i = 0; i < warmup; ++i) one();
+        BM_CUDART_ASSERT(hipStreamSynchronize(st));
+        BM_CUDART_ASSERT(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) one();
+        BM_CUDART_ASSERT(hipEventRecord(e1, st));
+        BM_CUDART_ASSERT(hipEventSynchronize(e1));
+        float ms = 0.f;
+        BM_CUDART_ASSERT(hipEventElapsedTime(&ms, e0, e1));
+        out["eager_ms"] = ms / iters;
+        if (graph) {
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            std::string err;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) err = "hipStreamBeginCapture failed";
+            else {
+                try {
+                    one();
+                } catch (const std::exception& e) {
+                    err = std::string("encode under capture: ") + e.what();
+                }
+                const hipError_t ec = hipStreamEndCapture(st, &g);
+                if (err.empty() && ec != hipSuccess) err = std::string("hipStreamEndCapture: ") + hipGetErrorString(ec);
+            }
+            if (err.empty() && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) err = "hipGraphInstantiate failed";
+            if (err.empty()) {
+                for (int i = 0; i < warmup; ++i) (void)hipGraphLaunch(ge, st);
+                BM_CUDART_ASSERT(hipStreamSynchronize(st));
+                BM_CUDART_ASSERT(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; ++i) (void)hipGraphLaunch(ge, st);
+                BM_CUDART_ASSERT(hipEventRecord(e1, st));
+                BM_CUDART_ASSERT(hipEventSynchronize(e1));
+                BM_CUDART_ASSERT(hipEventElapsedTime(&ms, e0, e1));
+                out["graph_ms"] = ms / iters;
+            } else {
+                (void)hipGetLastError();
+                out["graph_error"] = err;
+            }
+            if (ge) (void)hipGraphExecDestroy(ge);
+            if (g) (void)hipGraphDestroy(g);
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        ctx_.set_dyn_batch(nullptr);
+        return out;
+    }
+
     // the prompt of task b through the whole model (the encode part of a dynamic batch: DynBatchContext's e_* fields for one task at
     // positions pos0 .. pos0 + n - 1) -> the logits of its last token (1, vocab)
     py::array prefill(int b, int len_buf, const py::array& tokens, int pos0) {
@@ -272,5 +344,7 @@ void bind_ref_model(py::module_& m) {
         .def("prefill", &RefLLaMA::prefill, py::arg("b"), py::arg("len_buf"), py::arg("tokens"), py::arg("pos0") = 0)
         .def("get_k", &RefLLaMA::get_k)
         .def("get_v", &RefLLaMA::get_v)
-        .def("decode_step", &RefLLaMA::decode_step);
+        .def("decode_step", &RefLLaMA::decode_step)
+        .def("time_decode_steps", &RefLLaMA::time_decode_steps, py::arg("tokens"), py::arg("positions"), py::arg("mask"), py::arg("warmup") = 3,
+             py::arg("iters") = 20, py::arg("graph") = true);
 }

@@ -886,7 +886,7 @@ class LLaMA:
                 layer.k_norm = (1.0 + 0.1 * torch.randn(nk, device=dev, generator=gen)).to(dt)
         return self
 
-    def init_synthetic(self, seed=0):
+    def init_synthetic(self, seed=0, sink=None):
         """Synthetic GPTQ checkpoint of this geometry with SURVEY 8(d)'s recipe -- the one tests/synth.py::gptq_hf and
         tests/test_gpu_model.py::_hf_state draw on the host -- generated on the device and taken through the REAL load path
         (EncoderLayer.load_state_dict: shuffle, zero + 1, transposes, fusion, ZLW4M packing), one layer at a time:
@@ -894,7 +894,10 @@ class LLaMA:
           scales (K/G, N) fp16 = |N(0,1)| * (0.5 / sqrt(K)) / 4 + 1e-4 (activations stay O(1): _hf_state's magnitude, = 8(d)'s
           0.02 / 8 at K = 4096 within 25 %); norm weights 1 + 0.1 N(0,1); embedding uniform integers / 128, lm_head uniform
           integers * 0.05 / 64 (tests/test_gpu_fullgeom.py::_state).
-        W4 route, no tensor parallelism (bench.py's TP leg keeps init_random: every rank would have to draw the full matrices)."""
+        W4 route, no tensor parallelism (bench.py's TP leg keeps init_random: every rank would have to draw the full matrices).
+        sink(name -> device tensor): called with every checkpoint tensor under the reference's parameter names ("llama.layers.3.attn.
+        project_q.qweight", "llama.token_embedding.weight", ...) before it is consumed -- tools/bench_boundary.py hands the same
+        checkpoint to the reference's own model::LLaMA."""
         c, dev, q = self.cfg, self.device, self.quant
         if self.tp or not all(isinstance(l, EncoderLayer) for l in self.layers) or q.act_order or q.awq:
             raise ops.ZLError("init_synthetic: the plain GPTQ layer stack")
@@ -925,6 +928,8 @@ class LLaMA:
             lin(sd, pfx + ".ff.w_in", c.dim_model, c.dim_ff)
             lin(sd, pfx + ".ff.w_gated", c.dim_model, c.dim_ff)
             lin(sd, pfx + ".ff.w_out", c.dim_ff, c.dim_model)
+            if sink is not None:
+                sink(sd)
             layer.load_state_dict(sd, pfx, dev)
             layer.q_norm = layer.k_norm = None
             del sd
@@ -932,6 +937,9 @@ class LLaMA:
         self.token_embedding = (u8().to(dt) * (1.0 / 128)).contiguous()
         self.output_layernorm = (1 + 0.1 * torch.randn(c.dim_model, device=dev, generator=gen)).to(dt)
         self.lm_head = self.token_embedding if c.tie_lm_head else (u8().to(dt) * (0.05 / 64)).contiguous()
+        if sink is not None:
+            sink({"llama.token_embedding.weight": self.token_embedding, "llama.output_layernorm.weight": self.output_layernorm,
+                  "llama.lm_head.weight": self.lm_head})
         return self
 
     # ---- KV state ------------------------------------------------------------------------------
