@@ -53,9 +53,8 @@ __global__ __launch_bounds__(256) void k_quant_rows(const uint16_t* __restrict__
     if (threadIdx.x == 0) scale[blockIdx.x] = amax / 127.f;
 }
 
-// VEC (dim % 8 == 0): 16-byte loads into two LDS rows (v and v*w), then the per-thread strided sum of squares runs
-// over the LDS copy in the ORIGINAL order (thread t: elements t, t + 256, ...), so the result is bit-identical to
-// the scalar form while the row is fetched in one round trip.
+// VEC (dim % 8 == 0): 16-byte loads into two LDS rows (v and v*w); the sum of squares then runs over the LDS copy in the
+// reference's own thread / tree order (below), while the row is fetched in one round trip.
 template <int DT, bool VEC>
 __global__ __launch_bounds__(256) void k_rmsnorm_quant(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                        uint16_t* __restrict__ out, int8_t* __restrict__ q,
@@ -82,20 +81,51 @@ __global__ __launch_bounds__(256) void k_rmsnorm_quant(const uint16_t* __restric
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < dim; i += 256) {
-            const float v = vv[i];
-            ss = __builtin_fmaf(v, v, ss);
-        }
     } else {
         for (int i = threadIdx.x; i < dim; i += 256) {
             const float v = ZT<DT>::to_f32(x[off + i]);
-            ss = __builtin_fmaf(v, v, ss);
             const float pw = v * ZT<DT>::to_f32(w[i]);
             vw[i] = pw;
             amax = fmaxf(amax, fabsf(pw));
         }
     }
-    ss = zl_block_sum(ss, red);
+    // Sum of squares in the REFERENCE's order (round 5; quant_kernel.cu:120-133 + reduce.cuh:92-107): its block has
+    // T = min(round_up(dim, 32), 1024) threads, thread t chains fma over the elements t, t + T, ..., a 32-lane shuffle-down tree per
+    // warp, then warp 0 trees the per-warp results.  The rows' rs -- and with it the fp32 activation scale amax * rs / 127 every
+    // scale-back multiplies by -- then carry the reference's bits: with the 256-thread order used before, one row in four came out
+    // one fp32 ulp away, which is where the INT8 route's first differing bit entered (tests/test_gpu_fullgeom.py::
+    // test_int8_depth_record_and_first_differing_op).  Thread p plays the reference's threads p, p + 256, ...: the 32 lanes of a
+    // reference warp are one half of a wavefront, the xor butterfly leaves lane 0 of each half with the shuffle-down tree's value.
+    {
+        const int vt = min((dim + 31) / 32 * 32, 1024);
+        __shared__ float wres[32], tot;
+        if (threadIdx.x < 32) wres[threadIdx.x] = 0.f;
+        __syncthreads();
+        for (int t0 = 0; t0 < vt; t0 += 256) {
+            const int t = t0 + (int)threadIdx.x;
+            float part = 0.f;
+            if (t < vt) {
+                for (int i = t; i < dim; i += vt) {
+                    float v;
+                    if constexpr (VEC) v = vv[i];
+                    else v = ZT<DT>::to_f32(x[off + i]);
+                    part = __builtin_fmaf(v, v, part);
+                }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            if ((threadIdx.x & 31) == 0 && t < vt) wres[t >> 5] = part;
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float v = wres[threadIdx.x];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (threadIdx.x == 0) tot = v;
+        }
+        __syncthreads();
+        ss = tot;
+    }
     const float rs = zl_rsqrt_rn(ss / (float)dim + eps);
     amax = zl_block_max(amax, red);
     amax = ZT<DT>::to_f32(ZT<DT>::from_f32(amax));             // the reference reduces the max in T

@@ -36,6 +36,13 @@ constexpr int kT = 512, kW = 8;
 #ifndef ZL_I8P_RING
 #define ZL_I8P_RING 8            // 1 KiB items a wave keeps in flight (rounded down to whole groups of R tiles)
 #endif
+// ZL_I8P_EARLY: ring items a wave requests BEHIND its activation loads but BEFORE waiting for them (round 5 experiment).  The
+// activations are older, so `s_waitcnt vmcnt(2 E)` still hands them over first; the question is whether E KiB per wave of weights
+// (8 E KiB per CU instead of the 64 KiB of a full ring, which delayed every workgroup's activations by ~2 us) buys back part of the
+// first-byte latency the x-first order spends: profiles/r05_i8p_early.txt.
+#ifndef ZL_I8P_EARLY
+#define ZL_I8P_EARLY 0
+#endif
 
 // ---- optional timeline probe (build with -DZL_I8P_PROBE; tools/ubench/probe_i8p.py): wall-clock stamps (100 MHz) per wave,
 //      [workgroup][wave][8]; every launch overwrites them, so after a replayed chain they describe its last launch
@@ -87,6 +94,31 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
     const int tile_stride = ROPE ? p.pair_stride : 1;
     const int my_groups = wave < groups ? (groups - wave + kW - 1) / kW : 0;          // groups this wave owns
 
+    // ---- weight ring state (declared here: ZL_I8P_EARLY items go out between the activation loads and their wait).
+    //      Wave w streams the items (tile0 + r, g = w + 8 gi), gi-major.
+    constexpr int E = ZL_I8P_EARLY < D ? ZL_I8P_EARLY : D;
+    uint4 wq[D];
+    uint32_t mt[D];
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, 0, 0x00020000);
+    const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)(lane & 15) * 4u;
+    auto issue = [&](int slot, int gi, int r) {        // slot, r: static
+        const int g = wave + kW * gi;
+        const bool ok = g < groups;                    // wave-uniform; tiles past the end fall outside the descriptor
+        const uint32_t it = (uint32_t)(tile0 + r * tile_stride) * (uint32_t)groups + (uint32_t)g;
+        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rq : rnull, q_off, it * 1024u, 2 /* nt */));
+        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(ok ? rm : rnull, m_off, it * 64u, 2);
+    };
+    auto issue_early = [&]() {
+        if constexpr (E > 0) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < E; ++q) issue(q, q / R, q % R);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // ---- activations first.  A wave loads exactly the k ranges of ITS groups: slot s = (row, column block c), lane l holds
     //      octet l & 15 of group g = w + 8 (4 c + (l >> 4)) -- one 16-byte load per lane covers four groups of a row
     uint4 xr[NS], nw[LONGK ? 4 : 1];
@@ -126,6 +158,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
                     pv[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rpart, po, uc * 256u, 0));
                     st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rstat, so, uc * 8u, 0));
                 }
+                if (s == 0) issue_early();               // behind row 0's records (older: they are handed over first)
                 const int elen = min(p.buf_lens[row], p.mg_valid_lens[row]);
                 const int ns = min((elen + p.mg_split_len - 1) / p.mg_split_len, kS);
                 float mn = -1e20f;
@@ -217,6 +250,7 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
             }
         }
     }
+    if constexpr (!MERGE) issue_early();
     __builtin_amdgcn_sched_barrier(0);
     // the activations have landed BEFORE the first weight is requested: issued behind the ring they come back 2 us later
     // (bcast_probe.hip).  The wait is the BUILTIN, not inline asm: the compiler's waitcnt pass models an S_WAITCNT it can see
@@ -224,30 +258,18 @@ __global__ __launch_bounds__(kT, 2) void k_w4a16_i8p(const I8Params p) {
     // loads at the predicated ring issues and put its own `s_waitcnt vmcnt(0)` in front of every conversion slot -- AFTER
     // ring items had been requested, so slot s waited for the weights issued during slot s - 1 (a first-byte latency per
     // slot: the long-K kernel finished staging at 4.2 us)
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), expcnt / lgkmcnt untouched
+    static_assert(2 * E < 16, "vmcnt immediate");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * E));      // vmcnt(2 E): everything but the E early items (two loads each), expcnt / lgkmcnt untouched
     __builtin_amdgcn_sched_barrier(0);
     ZL_IPROBE(1);
 
     // ---- weight ring: wave w streams the items (tile0 + r, g = w + 8 gi), gi-major.  The D prologue items are issued
     //      IN BETWEEN the stages of the activation conversion below: a wave that issues them back to back sits in VMEM issue
     //      for 0.6-1.5 us (a CU takes ~10 B/clk of misses whatever is queued) with its VALU work stuck behind
-    uint4 wq[D];
-    uint32_t mt[D];
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, 0, 0x00020000);
-    const uint32_t q_off = (uint32_t)lane * 16u, m_off = (uint32_t)(lane & 15) * 4u;
-    auto issue = [&](int slot, int gi, int r) {        // slot, r: static
-        const int g = wave + kW * gi;
-        const bool ok = g < groups;                    // wave-uniform; tiles past the end fall outside the descriptor
-        const uint32_t it = (uint32_t)(tile0 + r * tile_stride) * (uint32_t)groups + (uint32_t)g;
-        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rq : rnull, q_off, it * 1024u, 2 /* nt */));
-        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(ok ? rm : rnull, m_off, it * 64u, 2);
-    };
 #define ZL_ISSUE_RANGE(LO, HI)                                     \
     {                                                              \
         __builtin_amdgcn_sched_barrier(0);                         \
-        _Pragma("unroll") for (int q = (LO); q < (HI); ++q) issue(q, q / R, q % R); \
+        _Pragma("unroll") for (int q = ((LO) > E ? (LO) : E); q < (HI); ++q) issue(q, q / R, q % R); \
         __builtin_amdgcn_sched_barrier(0);                         \
     }
     // prologue items [0, Q0) go ahead of the norm's barrier, the rest between the four stages of the first slot's conversion
