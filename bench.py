@@ -298,6 +298,25 @@ def config5_leg(timeout_s=180):
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
+def boundary_leg(timeout_s=240):
+    """VERDICT r04 item 5: the decode step as the drop-in BOUNDARY offers it -- the reference's own model::LLaMA (compiled unmodified,
+    zhilight_amd/_ref) running LLaMA::encode + get_logits on hostcpp/nn_amd.cpp over the C ABI, one launch per reference op, same
+    synthetic checkpoint, 32 layers, batch 1 -- timed by tools/bench_boundary.py in a CHILD process under the switches a deployment
+    sets (CPM_FUSE_QKV=1, CPM_FUSE_FF_IN=1, ROPE_CACHE=1: the reference reads them itself), eager and under hipGraph replay, next to
+    the Python driver's fused step on the same weights in the same process.  Whatever happens there costs this field only."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "bench_boundary.py")
+    env = dict(os.environ, CPM_FUSE_QKV="1", CPM_FUSE_FF_IN="1", ROPE_CACHE="1")
+    try:
+        r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=timeout_s, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout).strip().splitlines()[-1][:200] if (r.stderr or r.stdout).strip() else "")}
+        return json.loads(lines[-1])
+    except Exception as e:                                  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def check_against_oracle(model, batch, dev):
     """Before anything is timed: the weights bench.py generates (directly in the packed ZLW4M layout, never seen by a
     test) are unpacked again (zl_w4m_unpack) and the four W4A16 linears of layer 0 and of the last layer, run through the
@@ -628,6 +647,7 @@ def main():
             "roofline": roof,
             "other_batches": extras,
             "config5": config5_leg() if (world == 1 and not args.no_extras and not int8 and tp is None and batch == 1 and not args.layers) else None,
+            "boundary_path": boundary_leg() if (world == 1 and not args.no_extras and not int8 and tp is None and batch == 1 and not args.layers) else None,
             "oracle_check": None if oracle_check is None else {
                 "what": "layer 0 and last layer, four W4A16 linears each, HIP output vs the CPU oracle's exact product of the "
                         "unpacked (zl_w4m_unpack) bench weights, before the timed region", "max_err_over_max_ref": round(oracle_check, 6)},

@@ -574,6 +574,14 @@ int zl_decode_attn_quant_ex(const uint16_t* q, const int32_t* buf_lens, const ui
 int zl_prefill_attn(const uint16_t* q, const uint16_t* k_buf, const uint16_t* v_buf, uint16_t* out, int64_t s_q,
                     int64_t pos0, int64_t h, int64_t hkv, int64_t d, float scale, int64_t len_buf, int bshd,
                     int dtype, zl_stream_t s);
+/* groups: wave groups per workgroup, 1 / 2 / 4 (round 5): the key tiles of a 64-query tile are dealt round-robin to `groups` sets
+ * of four waves with their own K / V staging and their own (O, max, sum), folded together once at the end -- every workgroup of a
+ * prompt is resident at once, so the launch lasts as long as the query tile with the most key tiles, and this cuts that chain
+ * `groups`-fold.  0 = the launcher's choice (zl_prefill_attn's): 4 from 8 key tiles on, 2 from 3.  Same arithmetic per tile; the
+ * order in which tiles enter a row's running maximum / sum changes with `groups` (within the op's 1e-3 test bar). */
+int zl_prefill_attn_ex(const uint16_t* q, const uint16_t* k_buf, const uint16_t* v_buf, uint16_t* out, int64_t s_q,
+                       int64_t pos0, int64_t h, int64_t hkv, int64_t d, float scale, int64_t len_buf, int bshd,
+                       int dtype, int groups, zl_stream_t s);
 
 
 /* ------------------------------------------------------------------------------------------------

@@ -16,6 +16,12 @@
 // query (lane & 15) -- row maxima need two cross-lane steps -- and, rounded to fp16, ARE the A operand
 // of the P.V product (k index = key) with no transposition.  O accumulates in the C layout (rows 4 kq + i),
 // its per-row rescale factors cross over through a 64-byte LDS strip per wave.
+//
+// Round 5: G wave GROUPS per workgroup (G x 4 waves).  All 512 workgroups of a 1 024-token prompt are resident at once, so the
+// launch lasted as long as its longest workgroup: 16 key tiles in a row at ~2.7 us each (41 us, 0.08 of the MFMA peak) while the
+// CUs holding the short ones idled.  Group g of a workgroup now walks the key tiles g, g + G, ... of the SAME 64 queries with its
+// own K / V staging buffers and its own (O, m, l); the groups meet once at the end (LDS, flash-decoding's rescale).  The chain is
+// cut G-fold; heavy query tiles are dispatched first.
 #include <stdlib.h>
 #include "zl_common.h"
 
@@ -48,16 +54,20 @@ __device__ __forceinline__ f4 pf_mfma(uint4 a, uint4 b, f4 c) {
 }
 
 // DT = ZL_F16 / ZL_BF16: probabilities are rounded to T for the P.V product (flash-attention arithmetic)
-template <int DT>
-__global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) {
-    __shared__ __attribute__((aligned(16))) uint16_t ks[kBK * kKRow];
-    __shared__ __attribute__((aligned(16))) uint16_t vt[kBK * kVRow];
-    __shared__ __attribute__((aligned(16))) float strip[4][16];
+constexpr int kGroupLds = (kBK * kKRow + kBK * kVRow) * 2;     // one group's K + V tile: 35 840 bytes (>= its 32.5 KB merge record)
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <int DT, int G>
+__global__ __launch_bounds__(256 * G, G == 1 ? 2 : 4) void k_prefill_attn(const PrefillParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pf[];
+    const int group = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));     // 4 waves each
+    uint16_t* ks = reinterpret_cast<uint16_t*>(smem_pf + (size_t)group * kGroupLds);
+    uint16_t* vt = ks + kBK * kKRow;
+    float (*strip)[16] = reinterpret_cast<float (*)[16]>(smem_pf + (size_t)G * kGroupLds);     // [4 G waves][16]
+
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, wave_all = threadIdx.x >> 6;
     const int nq = lane & 15, kq = lane >> 4;
     const int head = blockIdx.y, hk = head / p.n_rep;
-    const int q0 = blockIdx.x * kBQ;
+    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * kBQ;      // the query tiles with the most keys first
     const int qrow = q0 + wave * 16 + nq;                 // the query this lane's scores belong to
     const int qpos = p.pos0 + qrow;                       // its position: keys 0 .. qpos are visible
     const size_t kv_stride = p.bshd ? (size_t)p.hkv * kD : (size_t)kD;
@@ -84,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) 
     // K / V tile loads ride in registers one tile ahead (thread -> key = tid % 64, d chunks tid / 64 + 4 c): a workgroup
     // is one latency chain per tile otherwise (3 us per 64-key tile, ~2 of them waiting for the loads)
     uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;         // (named: as arrays filled from two places they end up on the stack)
-    const int skey = threadIdx.x & 63, sdch = threadIdx.x >> 6;
+    const int skey = threadIdx.x & 63, sdch = (threadIdx.x >> 6) & 3;
 #define ZL_PF_LOAD1(c_, kp_, vp_, dead_)                                                                   \
     kr##c_ = *reinterpret_cast<const uint4*>((kp_) + (sdch + 4 * c_) * 8);                               \
     vr##c_ = *reinterpret_cast<const uint4*>((vp_) + (sdch + 4 * c_) * 8);                               \
@@ -98,18 +108,22 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) 
         const bool dead_ = kg_ >= n_keys;                                                                  \
         ZL_PF_LOAD1(0, kp_, vp_, dead_) ZL_PF_LOAD1(1, kp_, vp_, dead_) ZL_PF_LOAD1(2, kp_, vp_, dead_) ZL_PF_LOAD1(3, kp_, vp_, dead_) \
     }
-    ZL_PF_LOAD(0)
+    ZL_PF_LOAD(group)
 
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    // group g walks the tiles g, g + G, ...; the barriers are the workgroup's, so every group runs the same number of rounds
+    // (a group past its last tile only keeps the barriers company)
+    for (int tile = group; tile - group < n_tiles; tile += G) {
         const int key0 = tile * kBK;
+        const bool live = tile < n_tiles;                 // group-uniform
         __syncthreads();                                  // previous tile fully consumed
 #define ZL_PF_ST(c_)                                                                                       \
         *reinterpret_cast<uint4*>(&ks[skey * kKRow + (sdch + 4 * c_) * 8]) = kr##c_;                       \
         *reinterpret_cast<uint4*>(&vt[skey * kVRow + (sdch + 4 * c_) * 8]) = vr##c_;
-        ZL_PF_ST(0) ZL_PF_ST(1) ZL_PF_ST(2) ZL_PF_ST(3)
+        if (live) { ZL_PF_ST(0) ZL_PF_ST(1) ZL_PF_ST(2) ZL_PF_ST(3) }
 #undef ZL_PF_ST
         __syncthreads();
-        ZL_PF_LOAD(tile + 1)                              // clamped past the end; in flight during this tile's MFMAs
+        if (!live) continue;
+        ZL_PF_LOAD(tile + G)                              // clamped past the end; in flight during this tile's MFMAs
 
         // ---- S^T = K . Q^T : 4 key blocks x 4 d steps; lane: query nq, keys key0 + 16 kb + 4 kq + i
         f4 st[4];
@@ -182,9 +196,9 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) 
         // ---- rescale O: the factor of row q = 4 kq + i comes from the lane whose nq is that row -- only when some row's maximum
         //      moved (wave-uniform; after the first tiles it rarely does: 32 multiplies and an LDS round trip per tile otherwise)
         if (!__all(alpha == 1.0f)) {
-            if (kq == 0) strip[wave][nq] = alpha;
+            if (kq == 0) strip[wave_all][nq] = alpha;
             __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the strip write has landed (wave-private)
-            const f4 al = *reinterpret_cast<const f4*>(&strip[wave][4 * kq]);
+            const f4 al = *reinterpret_cast<const f4*>(&strip[wave_all][4 * kq]);
 #pragma unroll
             for (int db = 0; db < 8; ++db) {
                 o[db][0] *= al[0]; o[db][1] *= al[1]; o[db][2] *= al[2]; o[db][3] *= al[3];
@@ -209,12 +223,50 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) 
 
 #undef ZL_PF_LOAD
 #undef ZL_PF_LOAD1
+    // ---- the groups meet: groups 1 .. G - 1 park (O, m, l) in their own tile area, group 0 folds them in with the usual
+    //      rescale (scores live in the log2 domain: exp2).  l is still the lane's partial sum; the lanes of a query share m.
+    if constexpr (G > 1) {
+        __syncthreads();                                  // every group is done with its tiles
+        float* rec = reinterpret_cast<float*>(smem_pf + (size_t)group * kGroupLds);     // [wave][16 rows][128] O, then [wave][64 lanes] m, l
+        if (group > 0) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rec[(wave * 16 + 4 * kq + i) * kD + 16 * db + nq] = o[db][i];
+            rec[4 * 16 * kD + wave * 64 + lane] = m_run;
+            rec[4 * 16 * kD + 4 * 64 + wave * 64 + lane] = l_run;
+        }
+        __syncthreads();
+        if (group > 0) return;
+#pragma unroll 1
+        for (int g = 1; g < G; ++g) {
+            const float* rg = reinterpret_cast<const float*>(smem_pf + (size_t)g * kGroupLds);
+            const float mg = rg[4 * 16 * kD + wave * 64 + lane], lg = rg[4 * 16 * kD + 4 * 64 + wave * 64 + lane];
+            const float m_new = fmaxf(m_run, mg);
+            const float a0 = __builtin_amdgcn_exp2f(m_run - m_new), ag = __builtin_amdgcn_exp2f(mg - m_new);
+            m_run = m_new;
+            l_run = l_run * a0 + lg * ag;
+            if (kq == 0) {
+                strip[wave_all][nq] = a0;
+                strip[4 + wave_all][nq] = ag;            // group 0's waves are 0 .. 3: the strips of waves 4 .. 7 are free now
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const f4 f0 = *reinterpret_cast<const f4*>(&strip[wave_all][4 * kq]);
+            const f4 fg = *reinterpret_cast<const f4*>(&strip[4 + wave_all][4 * kq]);
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    o[db][i] = o[db][i] * f0[i] + rg[(wave * 16 + 4 * kq + i) * kD + 16 * db + nq] * fg[i];
+            __builtin_amdgcn_s_waitcnt(0xc07f);           // the strip is read before the next round overwrites it (wave-private)
+        }
+    }
     // ---- normalise: l of query nq = sum over its 4 lanes; bring 1/l to the C layout through the strip
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
-    if (kq == 0) strip[wave][nq] = 1.0f / (l_run + 1e-20f);
+    if (kq == 0) strip[wave_all][nq] = 1.0f / (l_run + 1e-20f);
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    const f4 inv = *reinterpret_cast<const f4*>(&strip[wave][4 * kq]);
+    const f4 inv = *reinterpret_cast<const f4*>(&strip[wave_all][4 * kq]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = q0 + wave * 16 + 4 * kq + i;
@@ -227,20 +279,53 @@ __global__ __launch_bounds__(256, 2) void k_prefill_attn(const PrefillParams p) 
 
 }  // namespace
 
+extern "C" int zl_prefill_attn_ex(const uint16_t* q, const uint16_t* k_buf, const uint16_t* v_buf, uint16_t* out, int64_t s_q,
+                                  int64_t pos0, int64_t h, int64_t hkv, int64_t d, float scale, int64_t len_buf, int bshd,
+                                  int dtype, int groups, zl_stream_t s);
+
 extern "C" int zl_prefill_attn(const uint16_t* q, const uint16_t* k_buf, const uint16_t* v_buf, uint16_t* out, int64_t s_q,
                                int64_t pos0, int64_t h, int64_t hkv, int64_t d, float scale, int64_t len_buf, int bshd,
                                int dtype, zl_stream_t s) {
+    return zl_prefill_attn_ex(q, k_buf, v_buf, out, s_q, pos0, h, hkv, d, scale, len_buf, bshd, dtype, 0, s);
+}
+
+template <int DT, int G>
+static int launch_prefill(const PrefillParams& p, dim3 grid, hipStream_t hs) {
+    const size_t lds = (size_t)G * kGroupLds + (size_t)4 * G * 16 * sizeof(float);       // tiles + one 64-byte strip per wave
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prefill_attn<DT, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ZL_ELIMIT;
+    }
+    hipLaunchKernelGGL((k_prefill_attn<DT, G>), grid, dim3(256 * G), lds, hs, p);
+    return zl_launch_status();
+}
+
+// groups: wave groups per workgroup (1 / 2 / 4: the key tiles of a query tile are dealt to them round-robin); 0 = the launcher's
+// choice: as many as the longest query tile has key tiles to hand out, up to 4
+extern "C" int zl_prefill_attn_ex(const uint16_t* q, const uint16_t* k_buf, const uint16_t* v_buf, uint16_t* out, int64_t s_q,
+                                  int64_t pos0, int64_t h, int64_t hkv, int64_t d, float scale, int64_t len_buf, int bshd,
+                                  int dtype, int groups, zl_stream_t s) {
     ZL_CHECK_ARG(q && k_buf && v_buf && out && s_q > 0 && pos0 >= 0 && h > 0 && hkv > 0 && len_buf > 0, ZL_EINVAL);
     ZL_CHECK_ARG(h % hkv == 0 && pos0 + s_q <= len_buf, ZL_ESHAPE);
     ZL_CHECK_ARG(d == kD, ZL_ESHAPE);          // other head sizes: the mask form of zl_decode_attn
     ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
     ZL_CHECK_ARG(h <= 65535, ZL_ELIMIT);
+    ZL_CHECK_ARG(groups == 0 || groups == 1 || groups == 2 || groups == 4, ZL_EINVAL);
     PrefillParams p;
     p.q = q; p.k = k_buf; p.v = v_buf; p.out = out;
     p.s_q = (int)s_q; p.pos0 = (int)pos0; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
     p.len_buf = (int)len_buf; p.bshd = bshd; p.scale = scale;
     const dim3 grid((unsigned)((s_q + kBQ - 1) / kBQ), (unsigned)h);
-    if (dtype == ZL_F16) hipLaunchKernelGGL(k_prefill_attn<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, p);
-    else hipLaunchKernelGGL(k_prefill_attn<ZL_BF16>, grid, dim3(256), 0, (hipStream_t)s, p);
-    return zl_launch_status();
+    if (groups == 0) {
+        const int64_t max_tiles = (pos0 + s_q + kBK - 1) / kBK;
+        groups = max_tiles >= 8 ? 4 : (max_tiles >= 3 ? 2 : 1);
+    }
+    hipStream_t hs = (hipStream_t)s;
+#define ZL_PF_G(GG) return dtype == ZL_F16 ? launch_prefill<ZL_F16, GG>(p, grid, hs) : launch_prefill<ZL_BF16, GG>(p, grid, hs);
+    switch (groups) {
+        case 1: ZL_PF_G(1)
+        case 2: ZL_PF_G(2)
+        default: ZL_PF_G(4)
+    }
+#undef ZL_PF_G
 }

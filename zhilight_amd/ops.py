@@ -1044,7 +1044,7 @@ def multi_query_attention_rag_buffer_quant(batch_q, buf_lens, key_buf_addrs, val
     return out
 
 
-def prefill_attention(q, k_buf, v_buf, pos0, num_kv_heads, scale, bshd=True, out=None):
+def prefill_attention(q, k_buf, v_buf, pos0, num_kv_heads, scale, bshd=True, out=None, groups=None):
     """Causal attention of one task's prompt chunk (attn_encode_group -> flash attention in the reference,
     src/nn/attention/attention.cpp:442-622).  q (s_q, H, D); k_buf / v_buf the task's buffers (len_buf, Hkv, D)
     [bshd] or (Hkv, len_buf, D), already holding the chunk's rows at pos0 .. pos0 + s_q - 1."""
@@ -1055,8 +1055,9 @@ def prefill_attention(q, k_buf, v_buf, pos0, num_kv_heads, scale, bshd=True, out
     len_buf = k_buf.shape[0] if bshd else k_buf.shape[1]
     if out is None:
         out = torch.empty_like(q)
-    check(lib().zl_prefill_attn(_p(q), _p(k_buf), _p(v_buf), _p(out), _i(s_q), _i(pos0), _i(h), _i(num_kv_heads), _i(d),
-                                _f(scale), _i(len_buf), C.c_int(int(bshd)), C.c_int(_dt(q)), _stream()), "prefill_attn")
+    groups = int(os.environ.get("ZL_PREFILL_GROUPS", "0") or 0) if groups is None else groups     # 0: the launcher's choice
+    check(lib().zl_prefill_attn_ex(_p(q), _p(k_buf), _p(v_buf), _p(out), _i(s_q), _i(pos0), _i(h), _i(num_kv_heads), _i(d),
+                                   _f(scale), _i(len_buf), C.c_int(int(bshd)), C.c_int(_dt(q)), C.c_int(groups), _stream()), "prefill_attn")
     return out
 
 
