@@ -436,7 +436,11 @@ def test_int8_depth_record_and_first_differing_op(oracle, dev):
         li = first[name] - 1
         h_in = h_impl[li]
         assert np.array_equal(h_in, hs[name][li])
-        want = int8_layer_ops_oracle(om, li, h_in.copy(), pos, attn_exact=exact)
+        host_cs, host_sn = oracle.rope_cos_sin(np.asarray(pos, np.int32), c.dim_head, c.rope_theta, True, l3)
+        dev_cs, dev_sn = cos.cpu().numpy(), sin.cpu().numpy()
+        table_ulps = int(max(np.abs(dev_cs.view(np.int32).astype(np.int64) - host_cs.view(np.int32)).max(),
+                             np.abs(dev_sn.view(np.int32).astype(np.int64) - host_sn.view(np.int32)).max()))
+        want = int8_layer_ops_oracle(om, li, h_in.copy(), pos, attn_exact=exact, tables=(dev_cs, dev_sn))
         layer = model.layers[li]
         hid = torch.from_numpy(h_in.view(np.float16).copy()).to(dev)
         got = {}
@@ -478,7 +482,8 @@ def test_int8_depth_record_and_first_differing_op(oracle, dev):
                 dist = float(np.abs(g.astype(np.float64) - w.astype(np.float64)).max())
             report.append(dict(op=op, differing=ndiff, of=int(w.size), max_ulps_or_abs=dist))
         first_op = next((r for r in report if r["differing"]), None)
-        _record(case="int8 first differing op", against=name, depth=first[name], layer=li, first_op=first_op, ops=report)
+        _record(case="int8 first differing op", against=name, depth=first[name], layer=li, first_op=first_op, ops=report,
+                rope_table_device_vs_libm_max_fp32_ulps=table_ulps)
         print("int8 first differing bit vs", name, ": depth", first[name], "layer", li, "first op:", first_op)
         assert first_op is not None
         # the integer GEMMs, the scale-backs, the rotary and the quantisers reproduce the oracle's bits; what differs first is

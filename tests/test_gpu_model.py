@@ -578,14 +578,16 @@ def test_int8_model_decode_matches_oracle(oracle, dev, batch):
         model.advance(ctx, torch.from_numpy(tokens).to(dev))
 
 
-def int8_layer_ops_oracle(om, i, h, pos, attn_exact=False):
+def int8_layer_ops_oracle(om, i, h, pos, attn_exact=False, tables=None):
     """One layer of OracleInt8Model op by op from the hidden rows `h` (fp16 bits): the outputs of every op in order, as a dict
     name -> array -- what tests/test_gpu_fullgeom.py compares with the HIP ops run on the same input to name the FIRST op whose
     output differs.  Writes the layer's new K / V rows into om.kb / om.vb (as step does)."""
     o, c = om.o, om.cfg
     b = h.shape[0]
     p = f"model.layers.{i}."
-    cs, sn = o.rope_cos_sin(np.asarray(pos, np.int32), c.dim_head, c.rope_theta, True, (8.0, 1.0, 4.0, 8192.0))
+    # tables: the cos / sin rows to rotate with (the device's own, when the caller compares op by op: the device's cosf / sinf and
+    # libm's differ in the last bit of a few entries, which is a property of the table, not of the rotation kernel)
+    cs, sn = tables if tables is not None else o.rope_cos_sin(np.asarray(pos, np.int32), c.dim_head, c.rope_theta, True, (8.0, 1.0, 4.0, 8192.0))
     lens = np.full(b, om.len_buf, np.int32)
     mask = np.concatenate([(np.arange(om.len_buf) <= q).astype(np.int8) for q in pos])
     out = {}

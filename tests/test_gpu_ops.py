@@ -443,6 +443,31 @@ def test_prefill_attention(oracle, dev, s_q, pos0, h, hkv, bshd):
     assert np.abs(gb - refb).max() <= 1.5e-2 * np.abs(refb).max(), np.abs(gb - refb).max() / np.abs(refb).max()
 
 
+@pytest.mark.parametrize("groups", [1, 2, 4])
+@pytest.mark.parametrize("s_q,pos0,h,hkv", [(1024, 0, 8, 2), (300, 517, 4, 4), (65, 0, 4, 1), (130, 64, 8, 8), (1024, 0, 32, 8)])
+def test_prefill_attention_wave_groups(oracle, dev, s_q, pos0, h, hkv, groups):
+    """zl_prefill_attn_ex: the key tiles of a query tile dealt to 1 / 2 / 4 wave groups, and the workgroup -> work item maps of the
+    launcher (longest first; long / short pairs when the whole launch is resident: the 32-head 1 024-token case) -- every form
+    against the oracle's exact causal attention (same bar as before), incl. query tiles with fewer key tiles than groups, a ragged
+    last query tile, a chunk that starts inside the buffer, NaN behind the visible keys; and the launcher's own choice (groups = 0)."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(7 * s_q + pos0 + groups)
+    d = 128
+    len_buf = (pos0 + s_q + 63) // 64 * 64 + 64
+    q = (rng.standard_normal((s_q, h, d)) * 1.5).astype(np.float16)
+    kb = rng.standard_normal((len_buf, hkv, d)).astype(np.float16)
+    vb = rng.standard_normal((len_buf, hkv, d)).astype(np.float16)
+    vb_ref = vb.copy()
+    vb[pos0 + s_q:] = np.float16(np.nan)                    # never visible: must not leak
+    mask = (np.arange(len_buf)[None, :] <= (pos0 + np.arange(s_q))[:, None]).astype(np.int8)
+    ref = oracle.mqa_rag_buffer(oracle.h2u(q)[None], np.array([len_buf], np.int32), [oracle.h2u(kb)], [oracle.h2u(vb_ref)], mask, hkv,
+                                1.0 / np.sqrt(d), True, exact=True)[0]
+    for g in ((groups, 0) if groups == 4 else (groups,)):
+        got = _np(ops.prefill_attention(_t(q, dev), _t(kb, dev), _t(vb, dev), pos0, hkv, 1.0 / np.sqrt(d), True, groups=g)).astype(np.float64)
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), (g, np.abs(got - ref).max() / np.abs(ref).max())
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("m,n,k", [(5, 1000, 256), (16, 128, 128), (33, 4100, 512), (100, 300, 1024), (8, 128256, 128)])
 def test_dense_gemm_nt_mfma(oracle, dev, dtype, m, n, k):

@@ -42,6 +42,7 @@ struct PrefillParams {
     uint16_t* out;          // (s_q, h, D)
     int s_q, pos0, h, hkv, n_rep, len_buf, bshd;
     float scale;
+    int nx, pair;           // query tiles; workgroup -> work item map (see the kernel)
 };
 
 template <int DT>
@@ -66,8 +67,16 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : 4) void k_prefill_attn(const 
 
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, wave_all = threadIdx.x >> 6;
     const int nq = lane & 15, kq = lane >> 4;
-    const int head = blockIdx.y, hk = head / p.n_rep;
-    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * kBQ;      // the query tiles with the most keys first
+    // work item k of the launch, longest first: query tile nx - 1 - k / h of head k % h.  Workgroup i takes item i (LPT order:
+    // later workgroups fill the slots the short ones free) -- or, when every workgroup is resident at once (pair != 0: at most two
+    // per CU), the first half takes the long items in order and the second half the short ones in REVERSE, so that the two
+    // workgroups a CU receives (i and i + half in dispatch order) add up to the same number of key tiles: a 1 024-token prompt
+    // gave CU c the query tile c % 16 twice -- 2 to 32 key tiles per CU, 43 us for the unlucky ones, 23 us of work on average
+    const int total = p.nx * p.h;
+    int item = (int)blockIdx.x;
+    if (p.pair && item >= total / 2) item = total - 1 - (item - total / 2);
+    const int head = item % p.h, hk = head / p.n_rep;
+    const int q0 = (p.nx - 1 - item / p.h) * kBQ;
     const int qrow = q0 + wave * 16 + nq;                 // the query this lane's scores belong to
     const int qpos = p.pos0 + qrow;                       // its position: keys 0 .. qpos are visible
     const size_t kv_stride = p.bshd ? (size_t)p.hkv * kD : (size_t)kD;
@@ -315,11 +324,16 @@ extern "C" int zl_prefill_attn_ex(const uint16_t* q, const uint16_t* k_buf, cons
     p.q = q; p.k = k_buf; p.v = v_buf; p.out = out;
     p.s_q = (int)s_q; p.pos0 = (int)pos0; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
     p.len_buf = (int)len_buf; p.bshd = bshd; p.scale = scale;
-    const dim3 grid((unsigned)((s_q + kBQ - 1) / kBQ), (unsigned)h);
-    if (groups == 0) {
-        const int64_t max_tiles = (pos0 + s_q + kBK - 1) / kBK;
-        groups = max_tiles >= 8 ? 4 : (max_tiles >= 3 ? 2 : 1);
-    }
+    p.nx = (int)((s_q + kBQ - 1) / kBQ);
+    ZL_CHECK_ARG((int64_t)p.nx * h < ((int64_t)1 << 31), ZL_ELIMIT);
+    const dim3 grid((unsigned)(p.nx * (int)h));
+    // measured (profiles/r05_prefill_attn.txt): more wave groups make the launch SLOWER (43 -> 72 us per layer at 1 024 tokens with
+    // four): a CU is throughput-bound from two 4-wave workgroups on, what a long query tile lacked was a short neighbour, not waves
+    if (groups == 0) groups = 1;
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    const int total = p.nx * (int)h;
+    p.pair = (groups == 1 && total % 2 == 0 && total <= 2 * cus) ? 1 : 0;
     hipStream_t hs = (hipStream_t)s;
 #define ZL_PF_G(GG) return dtype == ZL_F16 ? launch_prefill<ZL_F16, GG>(p, grid, hs) : launch_prefill<ZL_BF16, GG>(p, grid, hs);
     switch (groups) {
