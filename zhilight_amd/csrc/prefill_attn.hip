@@ -74,9 +74,14 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : 4) void k_prefill_attn(const 
     // gave CU c the query tile c % 16 twice -- 2 to 32 key tiles per CU, 43 us for the unlucky ones, 23 us of work on average
     const int total = p.nx * p.h;
     int item = (int)blockIdx.x;
-    if (p.pair && item >= total / 2) item = total - 1 - (item - total / 2);
-    const int head = item % p.h, hk = head / p.n_rep;
-    const int q0 = (p.nx - 1 - item / p.h) * kBQ;
+    if (p.pair == 1 && item >= total / 2) item = total - 1 - (item - total / 2);
+    int head = item % p.h, qt = p.nx - 1 - item / p.h;
+    if (p.pair == 2) {                                    // the round-4 map (A/B): query tile fastest, in ascending order
+        head = item / p.nx;
+        qt = item % p.nx;
+    }
+    const int hk = head / p.n_rep;
+    const int q0 = qt * kBQ;
     const int qrow = q0 + wave * 16 + nq;                 // the query this lane's scores belong to
     const int qpos = p.pos0 + qrow;                       // its position: keys 0 .. qpos are visible
     const size_t kv_stride = p.bshd ? (size_t)p.hkv * kD : (size_t)kD;
@@ -319,6 +324,8 @@ extern "C" int zl_prefill_attn_ex(const uint16_t* q, const uint16_t* k_buf, cons
     ZL_CHECK_ARG(d == kD, ZL_ESHAPE);          // other head sizes: the mask form of zl_decode_attn
     ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
     ZL_CHECK_ARG(h <= 65535, ZL_ELIMIT);
+    const bool plain_map = groups == -1;               // A/B switch: one group, work items in plain dispatch order (the round-4 launch)
+    if (plain_map) groups = 1;
     ZL_CHECK_ARG(groups == 0 || groups == 1 || groups == 2 || groups == 4, ZL_EINVAL);
     PrefillParams p;
     p.q = q; p.k = k_buf; p.v = v_buf; p.out = out;
@@ -334,6 +341,7 @@ extern "C" int zl_prefill_attn_ex(const uint16_t* q, const uint16_t* k_buf, cons
     if (cus <= 0) cus = 256;
     const int total = p.nx * (int)h;
     p.pair = (groups == 1 && total % 2 == 0 && total <= 2 * cus) ? 1 : 0;
+    if (plain_map) p.pair = 2;
     hipStream_t hs = (hipStream_t)s;
 #define ZL_PF_G(GG) return dtype == ZL_F16 ? launch_prefill<ZL_F16, GG>(p, grid, hs) : launch_prefill<ZL_BF16, GG>(p, grid, hs);
     switch (groups) {
