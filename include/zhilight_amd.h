@@ -212,6 +212,24 @@ typedef struct {
                          tiles + 192-row tiles in two launches when one height leaves the last round of workgroups partly empty) */
 } zl_w4_opts_t;
 int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n);
+/* WHICH KERNEL A SHAPE TAKES (defaults; group size a multiple of 128 = the ZLW4M operands of this entry point; M = rows of x):
+ *   M = 1..4, K <= 4096 (1..2 rows up to K = 16384)   k_w4a16_i8p   (w4_i8p.hip: integer planes, v_mfma_i32_16x16x64_i8; fused RMSNorm
+ *                                                     prologue with norm_weight; the batch-1 decode step's four projections)
+ *   M = 5..32 (17..32: K <= 8192, or any K with        k_w4a16_phase (w4_phase.hip: fp16 dequant, activations through LDS in 1024-k
+ *     scratch for the K split)                         phases; one row block to 16 rows, two to 32; norm_weight: register-resident
+ *                                                     fused RMSNorm up to 8 rows, the DEFERRED norm for 9..32 -- see below)
+ *   M = 1..8 with norm_weight and K <= 4096            k_w4a16_phase<NORM> (bit-identical to zl_rmsnorm + this call)
+ *   M >= 17 otherwise, M > 32 always                   k_w4a16_gemm_tiled / k_w4a16_gemm_wide (w4_gemm_tiled.hip: the reference's
+ *                                                     M > 40 arithmetic W16 = rn16(rn16(q - z) s); 128 / 256-row tiles from M = 128,
+ *                                                     split K for short grids)
+ *   anything else (odd K tails, huge K)                k_w4a16_mfma (w4_mfma.hip: whole activation block staged in LDS, 16 rows per pass)
+ *   group size not a multiple of 128                   not this entry point: zl_w4a16_gemm (w4_gemv.hip, the warp-reduce arithmetic)
+ * norm_weight with 9..32 rows (round 5) runs the phase kernel's DEFERRED norm: the staged activation is T(x w) and the row's
+ * rsqrt(mean x^2 + eps) multiplies the fp32 totals in the epilogue -- one launch less, but NOT the roundings of zl_rmsnorm + GEMM
+ * (T(x w) rs against T(x rs w): ~5e-4 rms of an output, 1e-2 of the largest logit after a few layers of the synthetic network),
+ * so the decode step does not use it by default (ZL_DEFER_NORM=1 in zhilight_amd/llama.py).
+ * Opt-in routes that were measured and do not pay (zl_w4_opts_t::small_algo = 2, the *_planes entry points, the fused
+ * attn_out + gate|up launch) exist only in a ZL_BUILD_EXPERIMENTAL=1 build: see the #ifdef ZL_EXPERIMENTAL blocks below. */
 int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, const uint16_t* bias,
                           const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k, int64_t group_size,
                           const uint16_t* norm_weight, float norm_eps, int epilogue, const zl_w4_opts_t* opts, zl_stream_t s);
@@ -419,6 +437,7 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
                                  int64_t hkv, int64_t d, int64_t k, int64_t group_size, int bshd, const zl_w4_opts_t* opts,
                                  zl_stream_t s);
 
+#ifdef ZL_EXPERIMENTAL   /* digit-plane route for 5..32 rows: built, exact, not faster -- only in a ZL_BUILD_EXPERIMENTAL=1 build */
 /* Decode batches of 5..32 rows on the integer matrix cores (round 4).  The activation matrix becomes digit planes ONCE --
  * zl_w4a16_planes: per row and 128-k group X = rint(x * 2^(36 - Ef)) (Ef: exponent field of the group's largest fp16 magnitude,
  * |X| < 2^22: exact for every value within 2^-12 of the group maximum), three balanced byte digits in the register layout of
@@ -439,6 +458,7 @@ int zl_w4a16_qkv_rope_scatter_planes(const void* planes, const uint32_t* qw, con
                                      const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
                                      uint16_t* const* v_bufs, uint16_t* q_out, int64_t m, int64_t h, int64_t hkv, int64_t d, int64_t k,
                                      int64_t group_size, int bshd, zl_stream_t s);
+#endif  /* ZL_EXPERIMENTAL */
 
 /* Decode attention with the split merge folded into the attention output projection (len_q == 1 per task, prefix
  * visibility, D == 128, H / Hkv <= 16: the matrix-core kernel).  zl_decode_attn_splits is zl_decode_attn without its
@@ -467,6 +487,7 @@ int zl_w4a16_gemm_attn_merge_h_ex(const void* attn_workspace, const int32_t* buf
                                   int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
                                   const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
                                   int64_t group_size, int epilogue, const zl_w4_opts_t* opts, zl_stream_t s);
+#ifdef ZL_EXPERIMENTAL   /* the loader / consumer engine's fused launch (w4_engine.hip): ties the two launches it replaces */
 /* Two projections of a decode layer in ONE launch (w4_engine.hip; 1..4 rows, fp16): the attention split merge + attn_out +
  * residual add into `hidden` (in place: EncoderLayer's first element_add_scale, src/nn/block/block.cpp:104-121), then
  * ln_ff + the fused w_in | w_gated projection + silu.mul into `act` (FeedForward::forward's first half,
@@ -487,6 +508,7 @@ int zl_w4a16_attn_out_gate_up(const void* attn_workspace, const int32_t* buf_len
                               int64_t dim_attn, int64_t n_ff, int64_t group_size, void* granules, const uint32_t* epoch,
                               uint32_t epoch_add, uint32_t* err, zl_stream_t s);
 int zl_engine_epoch_advance(uint32_t* epoch, uint32_t by, zl_stream_t s);
+#endif  /* ZL_EXPERIMENTAL */
 int zl_decode_attn_splits(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
                           const uint16_t* const* v_bufs, const int32_t* valid_lens, void* workspace, int64_t b, int64_t h,
                           int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, int dtype, zl_stream_t s);

@@ -7,21 +7,26 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(experimental=False):
     src = open(os.path.join(ROOT, "include", "zhilight_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    if not experimental:                                    # entry points of a ZL_BUILD_EXPERIMENTAL=1 build only
+        src = re.sub(r"#ifdef ZL_EXPERIMENTAL.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(zl_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_symbols_exported():
     from zhilight_amd import _lib, build
     build.build()
-    names = _declared()
+    _lib.lib()
+    names = _declared(_lib.experimental)
     assert len(names) >= 30
     lib = ctypes.CDLL(_lib.SO_PATH)
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert sorted(_lib.SYMBOLS) == names
+    assert sorted(_lib.SYMBOLS + (_lib.EXPERIMENTAL_SYMBOLS if _lib.experimental else [])) == names
+    # the default library carries neither the engine nor the digit-plane entry points
+    assert sorted(set(_declared(True)) - set(_declared(False))) == sorted(_lib.EXPERIMENTAL_SYMBOLS)
 
 
 def test_version_and_status_strings_without_gpu():

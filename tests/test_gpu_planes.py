@@ -13,6 +13,14 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
+# off the product path since round 5 (include/zhilight_amd.h, #ifdef ZL_EXPERIMENTAL): built only by ZL_BUILD_EXPERIMENTAL=1 python -m zhilight_amd.build
+@pytest.fixture(autouse=True)
+def _experimental_build_only():
+    from zhilight_amd import ops
+    if not ops.experimental_build():
+        pytest.skip("not a ZL_BUILD_EXPERIMENTAL=1 build of libzhilight_amd.so")
+
+
 def _t(a, dev, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     if dtype is not None:

@@ -33,8 +33,7 @@ SYMBOLS = [
     "zl_gemm_nt_small_m", "zl_gemm_nt", "zl_gemm_nt_f32", "zl_argmax_workspace_bytes", "zl_gemm_nt_small_m_argmax", "zl_greedy_advance",
     "zl_rmsnorm",
     "zl_w4a16_moe_up", "zl_w4a16_moe_down", "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rope_cos_sin_dynamic", "zl_rope_cos_sin_yarn", "zl_head_norm", "zl_rotary_embedding_qk", "zl_rope_qk_cache", "zl_rope_rotate", "zl_mask_valid_lens",
-    "zl_copy_to_rag_buffer2", "zl_copy_to_rag_buffer_bytes", "zl_rope_scatter_decode", "zl_w4a16_qkv_rope_scatter", "zl_w4a16_qkv_rope_scatter_ex", "zl_decode_attn_splits_h", "zl_w4a16_gemm_attn_merge_h", "zl_w4a16_gemm_attn_merge_h_ex", "zl_w4a16_attn_out_gate_up", "zl_engine_epoch_advance",
-    "zl_w4a16_planes_bytes", "zl_w4a16_planes", "zl_w4a16_gemm_planes", "zl_w4a16_qkv_rope_scatter_planes",
+    "zl_copy_to_rag_buffer2", "zl_copy_to_rag_buffer_bytes", "zl_rope_scatter_decode", "zl_w4a16_qkv_rope_scatter", "zl_w4a16_qkv_rope_scatter_ex", "zl_decode_attn_splits_h", "zl_w4a16_gemm_attn_merge_h", "zl_w4a16_gemm_attn_merge_h_ex",
     "zl_quant_group_32", "zl_dequant_sum_quant_g32", "zl_dequant_group_32",
     "zl_fp8_calc_scale", "zl_fp8_cvt_half", "zl_fp8_gemm_nt",
     "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_ex", "zl_decode_attn_fused",
@@ -50,6 +49,13 @@ SYMBOLS = [
     "zl_w4a8_weight_to_int8", "zl_quant_scale_back_f32",
     "zl_awq_dequantize", "zl_awq_gemm_workspace_bytes", "zl_awq_gemm",
 ]
+
+
+# entry points of a ZL_BUILD_EXPERIMENTAL=1 build only (include/zhilight_amd.h, #ifdef ZL_EXPERIMENTAL): the digit-plane route for
+# 5..32 rows and the loader / consumer engine's fused launch -- built, exact, measured not faster, off the product path
+EXPERIMENTAL_SYMBOLS = ["zl_w4a16_attn_out_gate_up", "zl_engine_epoch_advance",
+                        "zl_w4a16_planes_bytes", "zl_w4a16_planes", "zl_w4a16_gemm_planes", "zl_w4a16_qkv_rope_scatter_planes"]
+experimental = False      # set by lib(): the loaded library exports all of them
 
 
 class W4Opts(C.Structure):
@@ -87,7 +93,10 @@ def lib():
         l.zl_w8m_bytes.restype = C.c_int64
         l.zl_mla_decode_workspace_bytes.restype = C.c_int64
         l.zl_w4a16_scratch_bytes.restype = C.c_int64
-        l.zl_w4a16_planes_bytes.restype = C.c_int64
+        global experimental
+        experimental = all(hasattr(l, name) for name in EXPERIMENTAL_SYMBOLS)
+        if experimental:
+            l.zl_w4a16_planes_bytes.restype = C.c_int64
         l.zl_awq_gemm_workspace_bytes.restype = C.c_int64
         _lib = l
     return _lib

@@ -17,8 +17,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-fno-fast-math", "-ffp-contract=off"]
 
 
+# ZL_BUILD_EXPERIMENTAL=1: also build what was measured and left off the product path: the loader / consumer
+# engine (w4_engine.hip) and the digit-plane entry points for 5..32 rows -- the header declares them under #ifdef ZL_EXPERIMENTAL,
+# tests/test_gpu_engine.py and tests/test_gpu_planes.py skip without them.  The default library carries neither.
+EXPERIMENTAL = os.environ.get("ZL_BUILD_EXPERIMENTAL", "0") == "1"
+EXPERIMENTAL_ONLY = ("w4_engine.hip",)
+
+
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and (EXPERIMENTAL or f not in EXPERIMENTAL_ONLY))
 
 
 def _stale(target, deps):
@@ -34,13 +41,17 @@ def build(force=False, verbose=False):
     hdrs.append(os.path.join(HERE, "..", "include", "zhilight_amd.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    flags = FLAGS + (["-DZL_EXPERIMENTAL"] if EXPERIMENTAL else [])
+    stamp = os.path.join(objdir, ".flags")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True                                   # another flavour's objects: rebuild all of them
     objs = []
     jobs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -51,6 +62,8 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if jobs or force or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    with open(stamp, "w") as fh:
+        fh.write(" ".join(flags))
     build_hostcpp(force, verbose)
     build_comm(force, verbose)
     build_refcompile(force, verbose)
@@ -126,6 +139,8 @@ REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_o
                         "nn::fill_m_indices_padded_indices(", "nn::gate_mul_inplace(", "nn::gate_fuse(", "nn::gelu_inplace(", "nn::silu_inplace(",
                         "nn::attention_qkv_rag_buffer(", "nn::multi_query_attention_rag_buffer(", "nn::get_mqa_workspace(", "nn::rope_qk_cache(",
                         "nn::rotary_embedding_qk(", "nn::copy_to_rag_buffer2(")
+# attempted and REPORTED only (never fail the build): what a full drop-in of zhilight.C would still need
+REF_REPORT_TUS = ("src/py_export/bind.cpp", "src/generator/batch_generator.cpp", "src/model/model_context.cpp")
 # declared by the shim so that the units compile, NOT provided by the boundary (smooth-quant calibration helpers): reported as "pending"
 # (round 4: the MoE dispatch route's arange / sort_pair_1d / divide / scatter_update_dim0 left this list -- bm_functions.cpp)
 REF_CHECK_PENDING = ("bmengine::functions::pow(", "bmengine::functions::clamp(")
@@ -267,6 +282,25 @@ def build_refcheck(force=False, verbose=False):
         out[rel] = {"resolved": sorted(resolved), "outside": sorted(outside), "pending": sorted(pending), "reference": sorted(reference)}
     if drifted:
         raise RuntimeError("reference call sites name boundary functions the boundary does not define with that signature:\n" + "\n".join(drifted))
+    # REPORT ONLY (VERDICT r04 missing 5 / item 9): the units above the model -- the Python binding, the batch generator, the model
+    # context with its engine -- attempted against the same shim.  Nothing here fails the build: the report says how far each gets.
+    for rel in REF_REPORT_TUS:
+        src = os.path.join(REFERENCE, rel)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(REFDIR, os.path.basename(src).rsplit(".", 1)[0] + ".report.o")
+        r = subprocess.run(common + ["-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            errs = [ln for ln in r.stderr.splitlines() if " error" in ln or "fatal" in ln]
+            out[rel] = {"report_only": True, "compiles": False, "errors": len(errs),
+                        "first_errors": [e.replace(REFERENCE + "/", "").replace(HERE + "/", "") for e in errs[:6]]}
+            continue
+        syms = [line.split()[-1] for line in subprocess.check_output(["nm", "-u", obj], text=True).splitlines()]
+        os.remove(obj)
+        names = subprocess.run(["c++filt"], input="\n".join(syms), text=True, capture_output=True).stdout.splitlines()
+        res = [n for sy, n in zip(syms, names) if sy != n and sy in have]
+        outside = [n for sy, n in zip(syms, names) if sy != n and sy not in have and not n.startswith(("std::", "operator ", "vtable for", "typeinfo for", "VTT for", "__"))]
+        out[rel] = {"report_only": True, "compiles": True, "resolved": sorted(res), "outside": sorted(outside)}
     with open(report, "w") as f:
         json.dump(out, f, indent=1)
     return report

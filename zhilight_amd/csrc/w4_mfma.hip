@@ -610,7 +610,8 @@ int zl_w4a16_gemm_i8p_merge(const void* ws, const int32_t* buf_lens, const int32
                             const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
                             const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups,
                             int tiles, int epilogue, hipStream_t hs);
-// the loader / consumer engine (w4_engine.hip)
+#ifdef ZL_EXPERIMENTAL
+// the loader / consumer engine (w4_engine.hip; experimental build only)
 bool zl_w4_engine_covers(int64_t m, int64_t k, int r);
 int zl_w4a16_gemm_engine(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                          uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k,
@@ -633,6 +634,7 @@ int zl_w4_engine_o_gateup_launch(const void* ws, const int32_t* buf_lens, const 
                                  int tiles2, int epilogue2, void* granules, const uint32_t* epoch_ptr, uint32_t epoch_add,
                                  uint32_t* err, hipStream_t hs);
 int zl_engine_epoch_advance_launch(uint32_t* epoch, uint32_t by, hipStream_t hs);
+#endif
 int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const int32_t* valid_lens, int split_len,
                               int max_splits, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                               uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n,
@@ -644,6 +646,7 @@ int zl_w4a16_gemm_phase_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw,
                              const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
                              uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs);
 
+#ifdef ZL_EXPERIMENTAL
 int64_t zl_w4_planes_bytes_(int64_t m, int64_t k);
 int zl_w4_planes_launch(const uint16_t* x, int64_t ldx, int m, int k, const uint16_t* norm_w, float norm_eps, void* planes, hipStream_t hs);
 int zl_w4a16_gemm_phase_planes(const void* planes, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
@@ -653,6 +656,7 @@ int zl_w4a16_gemm_phase_planes_rope(const void* planes, const uint32_t* qw, cons
                                     const uint16_t* bias, int m, int n, int k, int groups, int tiles, const float* cosv, const float* sinv,
                                     const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs, uint16_t* const* v_bufs,
                                     uint16_t* q_out, int h, int hkv, int d, int bshd, hipStream_t hs);
+#endif
 
 extern "C" {
 
@@ -742,12 +746,14 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
     // the M-tiled kernel, whose 128-column workgroups share them.
     // 1..4 rows (1..2 with a long K): the integer-plane kernel (w4_i8p.hip), the batch-1 decode default
     // small_algo == 2: the same arithmetic on the loader / consumer engine (w4_engine.hip) where it applies
+#ifdef ZL_EXPERIMENTAL
     if (o.small_algo == 2 && L.qw_bytes < ((int64_t)1 << 32)) {
         st = zl_w4a16_gemm_engine(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
                                   (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), norm_weight, norm_eps,
                                   o.phase_rounds, hs);
         if (st != ZL_ESHAPE && st != ZL_ELIMIT) return st;
     }
+#endif
     if ((o.small_algo == 0 || o.small_algo == 2) && zl_w4a16_i8p_covers(m, k) && L.qw_bytes < ((int64_t)1 << 32))
         return zl_w4a16_gemm_i8p(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
                                  (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), norm_weight, norm_eps,
@@ -882,12 +888,14 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
     ZL_CHECK_ARG(m <= 16 || k <= 8192, ZL_ESHAPE);
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
     const int small_algo = opts ? opts->small_algo : 0;
+#ifdef ZL_EXPERIMENTAL
     if (small_algo == 2) {
         st = zl_w4a16_gemm_engine_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n, (int)k,
                                        (int)L.q, (int)(L.np / 16), norm_weight, norm_eps, cosv, sinv, placement, buf_lens, k_bufs,
                                        v_bufs, q_out, (int)h, (int)hkv, (int)d, bshd, (hipStream_t)s);
         if (st != ZL_ESHAPE && st != ZL_ELIMIT) return st;
     }
+#endif
     if ((small_algo == 0 || small_algo == 2) && zl_w4a16_i8p_covers(m, k))
         return zl_w4a16_gemm_i8p_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n,
                                       (int)k, (int)L.q, (int)(L.np / 16), norm_weight, norm_eps, cosv, sinv, placement,
@@ -897,6 +905,7 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
                                     buf_lens, k_bufs, v_bufs, q_out, (int)h, (int)hkv, (int)d, bshd, (hipStream_t)s);
 }
 
+#ifdef ZL_EXPERIMENTAL
 int64_t zl_w4a16_planes_bytes(int64_t m, int64_t k) { return zl_w4_planes_bytes_(m, k); }
 
 int zl_w4a16_planes(const uint16_t* x, int64_t ldx, int64_t m, int64_t k, const uint16_t* norm_weight, float norm_eps, void* planes,
@@ -941,6 +950,8 @@ int zl_w4a16_qkv_rope_scatter_planes(const void* planes, const uint32_t* qw, con
                                            (int)hkv, (int)d, bshd, (hipStream_t)s);
 }
 
+#endif  // ZL_EXPERIMENTAL (digit-plane entry points)
+
 int zl_w4a16_gemm_attn_merge(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens,
                              int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
                              const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,
@@ -983,17 +994,20 @@ int zl_w4a16_gemm_attn_merge_h_ex(const void* attn_workspace, const int32_t* buf
     int st = zl_w4m_layout(n, k, group_size, &L);
     if (st) return st;
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
+#ifdef ZL_EXPERIMENTAL
     if (opts && opts->small_algo == 2) {
         st = zl_w4a16_gemm_engine_merge(attn_workspace, buf_lens, valid_lens, (int)split_len, (int)max_splits, qw, meta,
                                         (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n, (int)k,
                                         (int)L.q, (int)(L.np / 16), epilogue, (hipStream_t)s);
         if (st != ZL_ESHAPE && st != ZL_ELIMIT) return st;
     }
+#endif
     return zl_w4a16_gemm_i8p_merge(attn_workspace, buf_lens, valid_lens, (int)split_len, (int)max_splits, qw, meta,
                                    (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n, (int)k,
                                    (int)L.q, (int)(L.np / 16), epilogue, (hipStream_t)s);
 }
 
+#ifdef ZL_EXPERIMENTAL
 int zl_w4a16_attn_out_gate_up(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens, int64_t split_len,
                               int64_t max_splits, const uint32_t* qw_o, const uint32_t* meta_o, const uint16_t* bias_o,
                               uint16_t* hidden, const uint32_t* qw_ff, const uint32_t* meta_ff, const uint16_t* bias_ff,
@@ -1022,5 +1036,6 @@ int zl_engine_epoch_advance(uint32_t* epoch, uint32_t by, zl_stream_t s) {
     ZL_CHECK_ARG(epoch && by > 0, ZL_EINVAL);
     return zl_engine_epoch_advance_launch(epoch, by, (hipStream_t)s);
 }
+#endif  // ZL_EXPERIMENTAL (fused engine launch)
 
 }  // extern "C"

@@ -903,7 +903,8 @@ int launch_phase(const PhaseParams& p, int grid, hipStream_t hs) {
     return zl_launch_status();
 }
 
-// ---- digit planes of an activation matrix (the producer side of the I8 instantiations) ------------------------------------
+#ifdef ZL_EXPERIMENTAL
+// ---- digit planes of an activation matrix (the producer side of the I8 instantiations; experimental build only) -------------
 // One workgroup per row.  Octet o of the row (8 consecutive k) belongs to group o / 16; a DPP row of 16 lanes holds one group,
 // so the group's largest magnitude and its sum of integers are row rotations.  Arithmetic = w4_i8p.hip's conversion slot:
 // X = rint(x * 2^(36 - Ef)) (Ef = exponent field of the group's largest fp16 magnitude, |X| < 2^22), balanced byte digits
@@ -1005,6 +1006,8 @@ __global__ __launch_bounds__(512) void k_w4_planes(const uint16_t* __restrict__ 
         }
     }
 }
+
+#endif  // ZL_EXPERIMENTAL
 
 }  // namespace
 
@@ -1126,6 +1129,7 @@ int zl_w4a16_gemm_phase_merge(const float* ws, const int32_t* buf_lens, const in
     return r == 1 ? launch_phase<1, 1, true, false, 1, true>(p, grid, hs) : launch_phase<2, 1, true, false, 1, true>(p, grid, hs);
 }
 
+#ifdef ZL_EXPERIMENTAL
 // ---- digit planes: producer launch and the I8 instantiations ----------------------------------------------------------------
 // planes buffer of an (m, k) activation matrix: [k / 128 groups][mb row blocks][6 KiB of A operands], then the constants
 // [groups][mb][16 rows][2 floats]; mb = 1 up to 16 rows, 2 up to 32
@@ -1222,3 +1226,4 @@ int zl_w4a16_gemm_phase_planes_rope(const void* planes, const uint32_t* qw, cons
     const int grid = tiles / 2;
     return m <= 16 ? launch_phase<2, 1, false, true, 1, false, true>(p, grid, hs) : launch_phase<2, 2, false, true, 1, false, true>(p, grid, hs);
 }
+#endif  // ZL_EXPERIMENTAL

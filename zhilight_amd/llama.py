@@ -1073,7 +1073,7 @@ class LLaMA:
                                                         c.num_kv_heads, valid_lens=ctx.valid_lens, out=out.view(b, 1, c.num_heads, c.dim_head),
                                                         workspace=workspace)
         # attention split merge + attn_out + residual and ln_ff + gate|up + silu.mul in ONE launch (w4_engine.hip)
-        fuse_o_ff = (merge_plan is not None and merge_plan[2] and os.environ.get("ZL_FUSE_O_GATEUP", "0") == "1"
+        fuse_o_ff = (merge_plan is not None and merge_plan[2] and os.environ.get("ZL_FUSE_O_GATEUP", "0") == "1" and ops.experimental_build()
                      and all(l.w_in_gated.perm is None and isinstance(l.w_in_gated.weight, ops.W4MWeight) for l in self.layers))
         if fuse_o_ff:
             ops.engine_epoch_advance(self.device)

@@ -14,6 +14,7 @@ import math
 
 import torch
 
+from . import _lib
 from ._lib import W4Layout, W4Opts, ZLError, check, lib
 
 F16, BF16 = 0, 1
@@ -473,15 +474,27 @@ def scatter_update_dim0(dst, dst_index, src, src_index=None):
     return dst
 
 
+def experimental_build():
+    """True when the loaded library is a ZL_BUILD_EXPERIMENTAL=1 build (digit-plane route, engine's fused launch)"""
+    lib()
+    return _lib.experimental
+
+
+def _need_experimental(what):
+    if not experimental_build():
+        raise ZLError(what + ": only in a ZL_BUILD_EXPERIMENTAL=1 build of libzhilight_amd.so (measured, not faster: DESIGN 5.R4)")
+
+
 def w4_planes_ok(m, k):
     """what the digit-plane route of the W4A16 linears covers: decode batches of 5..32 rows (1..4 rows: the integer-plane GEMV
     converts inside its own prologue), K a multiple of 128 up to 16384"""
-    return 5 <= m <= 32 and k % 128 == 0 and k <= 16384
+    return experimental_build() and 5 <= m <= 32 and k % 128 == 0 and k <= 16384
 
 
 def w4_planes(x, norm_weight=None, norm_eps=1e-5, out=None):
     """digit planes of an activation matrix (zl_w4a16_planes): x (M <= 32, K) fp16 -> an opaque uint8 buffer for
     w4_linear_planes / w4_qkv_rope_scatter_planes; with norm_weight the RMSNorm of every row is applied first."""
+    _need_experimental("w4_planes")
     if x.dtype != torch.float16:
         raise ZLError("A must be half")
     _chk_cuda(x, norm_weight, out)
@@ -945,6 +958,7 @@ def engine_state(device):
 
 def engine_epoch_advance(device, by=256):
     """once per decode step, ahead of the step's fused launches"""
+    _need_experimental("engine_epoch_advance")
     st = engine_state(device)
     check(lib().zl_engine_epoch_advance(_p(st["epoch"]), C.c_uint32(by), _stream()), "engine_epoch_advance")
 
@@ -955,7 +969,7 @@ def w4_attn_out_gate_up(workspace, buf_lens, valid_lens, plan, b, w_o, hidden, w
     launch.  Returns False (nothing launched) outside the launcher's range."""
     _chk_cuda(workspace, buf_lens, valid_lens, hidden, norm_weight, act, bias_o, bias_ff)
     split_len, max_splits = plan[0], plan[1]
-    if len(plan) > 2 and not plan[2]:
+    if (len(plan) > 2 and not plan[2]) or not experimental_build():
         return False
     st = engine_state(hidden.device)
     rc = lib().zl_w4a16_attn_out_gate_up(_p(workspace), _p(buf_lens), _p(valid_lens), _i(split_len), _i(max_splits), _p(w_o.qw),
