@@ -33,7 +33,7 @@ def _la(ops, q, lens, valid, dk, dv, scale, hkv, dev, dtype, bshd=True, split_le
 @pytest.mark.parametrize("h,hkv", [(32, 8), (32, 32), (16, 1), (28, 4)])
 @pytest.mark.parametrize("bshd", [True, False])
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("split_len", [0, 32, 64, 96, 128, 256])
+@pytest.mark.parametrize("split_len", [0, 32, 64, 96, 128, 256, 288, 544, 1088])     # >= 256: the 8-wave instantiation; 1088: no split at all
 def test_last_arriver_attention_against_the_oracle(oracle, dev, h, hkv, bshd, dtype, split_len):
     from zhilight_amd import ops
     rng = np.random.default_rng(330 + split_len)
@@ -82,7 +82,7 @@ def test_last_arriver_equals_the_two_launch_path_bitwise(oracle, dev, b):
     assert np.array_equal(_bits(got), _bits(two))
 
 
-@pytest.mark.parametrize("b,split_len", [(1, 32), (8, 64), (32, 128)])
+@pytest.mark.parametrize("b,split_len", [(1, 32), (8, 64), (32, 128), (16, 0), (32, 0)])     # 0: the launcher's choice (8-wave workgroups, 2 / 1 splits)
 def test_last_arriver_hand_off_under_load(oracle, dev, b, split_len):
     """300 launches back to back on one workspace, eager and replayed from a graph, with a copy stream hammering HBM next to
     them: every launch's output equals the first one's word for word, and the arrival words end at zero."""

@@ -797,9 +797,11 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
     }
 }
 
-template <int DT>
-__global__ __launch_bounds__(256, 4) void k_decode_attn_mfma(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) uint16_t vs[4][32 * kMVS];      // 36 KB; reused for the wave merge
+// NW: waves per workgroup the instantiation is built for (4: every launcher; 8: zl_decode_attn_la's long splits -- a whole 1 088-slot
+// buffer per workgroup at batch 32, where one workgroup per (task, kv head) fills the chip and needs no split, no record, no merge)
+template <int DT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_decode_attn_mfma(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t vs[NW][32 * kMVS];     // 9 KB per wave (36 / 72 KB); reused for the wave merge
     const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
     const int len = p.buf_lens[b];
     const int vlen_in = p.valid_lens[b];
@@ -1450,6 +1452,17 @@ static inline int la_split_len(int64_t b, int64_t hkv, int64_t max_len) {
     // history) were measured and LOSE: the last arriver's serial chain (write-through drain, ticket, re-read) grows with the
     // record count faster than the per-CU pull shrinks (profiles/r05_attn_la_ab.txt)
     int64_t ls = attn_split_len(b, hkv, max_len);
+    // Many (task, kv head) pairs -- at least half as many as CUs (batch 16 / 32 with 8 kv heads): as few splits as give every CU
+    // one 8-wave workgroup, i.e. NONE at batch 32: the workgroup walks its whole buffer, writes the attention rows itself and there is
+    // no record, no arrival, no re-read.  The per-CU pull is the same 525 KB either way; what goes is the ~4 us tail.
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    const int64_t pairs = b * hkv;
+    if (pairs * 2 >= cus && max_len <= 16384) {
+        const int64_t splits = pairs >= cus ? 1 : (cus + pairs - 1) / pairs;
+        ls = ((max_len + splits - 1) / splits + 31) / 32 * 32;
+        if (ls < 256) ls = 256;
+    }
     while ((max_len + ls - 1) / ls > kLaMaxSplits) ls += 128;
     return (int)ls;
 }
@@ -1491,10 +1504,15 @@ int zl_decode_attn_la(const uint16_t* q, const int32_t* buf_lens, const uint16_t
     p.scale = scale; p.bshd = bshd;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
     p.k_scales = p.v_scales = nullptr; p.half_partials = half_partials ? 1 : 0;
-    const int nw = p.split_len >= 128 ? 4 : p.split_len / 32;
+    const int nw = p.split_len >= 256 ? 8 : (p.split_len >= 128 ? 4 : p.split_len / 32);
     const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
-    if (dtype == ZL_F16) hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(64 * nw), 0, (hipStream_t)s, p);
-    else hipLaunchKernelGGL(k_decode_attn_mfma<ZL_BF16>, grid, dim3(64 * nw), 0, (hipStream_t)s, p);
+    if (nw == 8) {
+        if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 8>), grid, dim3(512), 0, (hipStream_t)s, p);
+        else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 8>), grid, dim3(512), 0, (hipStream_t)s, p);
+    } else {
+        if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 4>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
+        else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 4>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
+    }
     return zl_launch_status();
 }
 
