@@ -797,10 +797,14 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
     }
 }
 
+#ifndef ZL_ATTN8_WAVES_PER_SIMD
+#define ZL_ATTN8_WAVES_PER_SIMD 2      // 8-wave instantiation: 2 = one workgroup per CU (135 VGPRs), 4 = two (128 VGPRs, a few spilled)
+#endif
+#define ZL_ATTN8_OCC(NW_) ((NW_) == 4 ? 4 : ZL_ATTN8_WAVES_PER_SIMD)
 // NW: waves per workgroup the instantiation is built for (4: every launcher; 8: zl_decode_attn_la's long splits -- a whole 1 088-slot
 // buffer per workgroup at batch 32, where one workgroup per (task, kv head) fills the chip and needs no split, no record, no merge)
 template <int DT, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_decode_attn_mfma(const AttnParams p) {
+__global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t vs[NW][32 * kMVS];     // 9 KB per wave (36 / 72 KB); reused for the wave merge
     const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
     const int len = p.buf_lens[b];
@@ -1488,7 +1492,7 @@ int zl_decode_attn_la(const uint16_t* q, const int32_t* buf_lens, const uint16_t
     ZL_CHECK_ARG(b > 0 && h > 0 && hkv > 0 && d > 0 && max_len_buf > 0, ZL_EINVAL);
     ZL_CHECK_ARG(h % hkv == 0 && d == kMD && h / hkv <= 16 && b <= 65535 && hkv <= 65535, ZL_ESHAPE);   // the matrix-core kernel
     ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
-    ZL_CHECK_ARG(!half_partials || dtype == ZL_F16, ZL_EDTYPE);
+    ZL_CHECK_ARG(!(half_partials & 1) || dtype == ZL_F16, ZL_EDTYPE);
     ZL_CHECK_ARG(split_len >= 0 && split_len % 32 == 0, ZL_EINVAL);
     AttnParams p;
     p.q = q; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs; p.mask = nullptr; p.valid_lens = valid_lens;
@@ -1503,8 +1507,11 @@ int zl_decode_attn_la(const uint16_t* q, const int32_t* buf_lens, const uint16_t
     ZL_CHECK_ARG((int64_t)b * h * p.max_splits * (kMD + 2) * 4 < ((int64_t)1 << 31), ZL_ELIMIT);
     p.scale = scale; p.bshd = bshd;
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
-    p.k_scales = p.v_scales = nullptr; p.half_partials = half_partials ? 1 : 0;
-    const int nw = p.split_len >= 256 ? 8 : (p.split_len >= 128 ? 4 : p.split_len / 32);
+    p.k_scales = p.v_scales = nullptr; p.half_partials = (half_partials & 1) ? 1 : 0;
+    // bits 8.. of the flags word: waves per workgroup (0 = 8 from 256-key splits on, 4 from 128, else one per 32 keys) -- A/B only
+    int nw = p.split_len >= 256 ? 8 : (p.split_len >= 128 ? 4 : p.split_len / 32);
+    const int nw_req = (half_partials >> 8) & 0xff;
+    if (nw_req == 1 || nw_req == 2 || nw_req == 4 || nw_req == 8) nw = nw_req * 32 <= p.split_len ? nw_req : nw;
     const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
     if (nw == 8) {
         if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 8>), grid, dim3(512), 0, (hipStream_t)s, p);

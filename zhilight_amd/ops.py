@@ -867,7 +867,8 @@ def decode_attention_la(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, valid_l
         out = torch.empty_like(batch_q)
     check(lib().zl_decode_attn_la(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(valid_lens), _p(out),
                                   _p(workspace), _i(b), _i(h), _i(num_kv_heads), _i(d), _f(scale), _i(max_len_buf),
-                                  C.c_int(int(bshd)), C.c_int(_dt(batch_q)), _i(split_len), C.c_int(int(bool(half))), _stream()),
+                                  C.c_int(int(bshd)), C.c_int(_dt(batch_q)), _i(split_len),
+                                  C.c_int(int(bool(half)) | (int(os.environ.get("ZL_ATTN_LA_WAVES", "0") or 0) << 8)), _stream()),
           "decode_attn_la")
     return out
 
