@@ -523,13 +523,14 @@ int zl_w4a16_gemm_attn_merge(const void* attn_workspace, const int32_t* buf_lens
  * every (task, kv head, split) workgroup publishes its (acc[128], max, sum) record write-through, counts its arrival on the
  * pair's word, and the pair's LAST arriver merges the records (KERNEL_mqa_combine's formula, k_decode_attn_combine's order:
  * bit-identical to zl_decode_attn for the same split length up to 16 splits) and writes out (B, H, 128) T.  Splits are multiples
- * of 32 keys (one matrix-core chunk per wave; 1 / 2 / 4 waves per workgroup); split_len = 0 takes zl_decode_attn's own split
- * length (zl_decode_attn_la_split_len: then the result IS zl_decode_attn's), at most 64 splits per task.  Measured (round 5,
+ * of 32 keys (one matrix-core chunk per wave; 1 / 2 / 4 waves per workgroup); split_len = 0: zl_decode_attn_la_split_len -- zl_decode_attn's
+ * own split length for a few tasks (then the result IS zl_decode_attn's), and as few splits as give every CU one workgroup once
+ * tasks x kv heads reach a quarter of the CU count (none at batch 32 x 8 kv heads: no record, no merge at all); at most 64 splits per task.  Measured (round 5,
  * profiles/r05_attn_la_ab.txt): pays from 2 rows up (the merge launch it removes costs 5 us per layer, its own tail 3.6-4);
  * at one row the merging projection (zl_w4a16_gemm_attn_merge_h) stays 1.4 us per layer ahead, and 32- / 64-key splits lose.
  * half_partials bit 0: records as fp16 normalised rows + fp32 (max, sum) (zl_decode_attn_splits_h's format and
  * zl_w4a16_gemm_attn_merge_h's arithmetic; fp16 only); bits 8..15: waves per workgroup for A/B runs (1 / 2 / 4 / 8; 0 = the launcher's:
- * 8 from 256-key splits on, 4 from 128 keys, one per 32 keys below).
+ * 4 from 128-key splits on, one per 32 keys below; 8 was measured behind 4).
  * workspace: zl_decode_attn_la_workspace_bytes(b, h, hkv, max_len_buf, split_len) bytes, ZERO-INITIALISED ONCE by the caller
  * (the arrival words at its head; every launch leaves them zero), not shared by two launches that may overlap in time. */
 int64_t zl_decode_attn_la_split_len(int64_t b, int64_t hkv, int64_t max_len_buf);

@@ -33,7 +33,7 @@ def _la(ops, q, lens, valid, dk, dv, scale, hkv, dev, dtype, bshd=True, split_le
 @pytest.mark.parametrize("h,hkv", [(32, 8), (32, 32), (16, 1), (28, 4)])
 @pytest.mark.parametrize("bshd", [True, False])
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("split_len", [0, 32, 64, 96, 128, 256, 288, 544, 1088])     # >= 256: the 8-wave instantiation; 1088: no split at all
+@pytest.mark.parametrize("split_len", [0, 32, 64, 96, 128, 256, 288, 544, 1088])     # 1088: no split at all (the workgroup writes the rows itself)
 def test_last_arriver_attention_against_the_oracle(oracle, dev, h, hkv, bshd, dtype, split_len):
     from zhilight_amd import ops
     rng = np.random.default_rng(330 + split_len)

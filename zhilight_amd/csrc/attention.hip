@@ -1456,16 +1456,19 @@ static inline int la_split_len(int64_t b, int64_t hkv, int64_t max_len) {
     // history) were measured and LOSE: the last arriver's serial chain (write-through drain, ticket, re-read) grows with the
     // record count faster than the per-CU pull shrinks (profiles/r05_attn_la_ab.txt)
     int64_t ls = attn_split_len(b, hkv, max_len);
-    // Many (task, kv head) pairs -- at least half as many as CUs (batch 16 / 32 with 8 kv heads): as few splits as give every CU
-    // one 8-wave workgroup, i.e. NONE at batch 32: the workgroup walks its whole buffer, writes the attention rows itself and there is
-    // no record, no arrival, no re-read.  The per-CU pull is the same 525 KB either way; what goes is the ~4 us tail.
+    // Many (task, kv head) pairs -- a quarter of the CU count or more (batch 8 / 16 / 32 with 8 kv heads): as few splits as give every
+    // CU one workgroup -- 4, 2, and NONE at batch 32, where the workgroup walks its whole buffer, writes the attention rows itself
+    // and there is no record, no arrival, no re-read.  The per-CU pull is the same either way; what shrinks is the ~4 us tail (fewer
+    // records) and the fixed cost per workgroup.  Measured on one box (profiles/r05_attn_la_ab.txt, call 10), tokens/s of the step:
+    // batch 32: 8 698 (three 384-key splits) -> 8 966 unsplit with 4 waves (8 833 with 8 waves per workgroup); batch 16: 5 720 -> 5 858
+    // (two 576-key splits); batch 8: 3 480 -> 3 501 .. 3 535 (288- / 384-key splits).
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
     const int64_t pairs = b * hkv;
-    if (pairs * 2 >= cus && max_len <= 16384) {
+    if (pairs * 4 >= cus && max_len <= 16384) {
         const int64_t splits = pairs >= cus ? 1 : (cus + pairs - 1) / pairs;
         ls = ((max_len + splits - 1) / splits + 31) / 32 * 32;
-        if (ls < 256) ls = 256;
+        if (ls < 128) ls = 128;
     }
     while ((max_len + ls - 1) / ls > kLaMaxSplits) ls += 128;
     return (int)ls;
@@ -1509,7 +1512,7 @@ int zl_decode_attn_la(const uint16_t* q, const int32_t* buf_lens, const uint16_t
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
     p.k_scales = p.v_scales = nullptr; p.half_partials = (half_partials & 1) ? 1 : 0;
     // bits 8.. of the flags word: waves per workgroup (0 = 8 from 256-key splits on, 4 from 128, else one per 32 keys) -- A/B only
-    int nw = p.split_len >= 256 ? 8 : (p.split_len >= 128 ? 4 : p.split_len / 32);
+    int nw = p.split_len >= 128 ? 4 : p.split_len / 32;      // (8 waves per workgroup: measured behind 4 at every batch, on request only)
     const int nw_req = (half_partials >> 8) & 0xff;
     if (nw_req == 1 || nw_req == 2 || nw_req == 4 || nw_req == 8) nw = nw_req * 32 <= p.split_len ? nw_req : nw;
     const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
