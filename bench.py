@@ -239,7 +239,7 @@ def roofline_w4(model, cfg, batch, dev, ctx, layers_override=False):
             "timing": how, "us_per_launch_gemv_only_graph": round(t_gemv_only * 1e6, 3),
             "traffic_source": "offline rocprofv3 --pmc pass (profiles/r*_gemv_traffic.json), not measured in this run" if traffic is not None else None,
             "note": "avg over the %d GEMV launches of one step incl. the kernel boundaries between them (graph replay, HIP events); "
-                    "in-step rocprofv3 averages of the same kernels: profiles/r04_decode_kernel_stats.csv" % len(lins)}
+                    "in-step rocprofv3 averages of the same kernels: profiles/r05_decode_kernel_stats.csv" % len(lins)}
     return roof
 
 
