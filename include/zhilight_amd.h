@@ -756,7 +756,9 @@ int zl_index_select(const void* in, void* out, const int32_t* index, int64_t out
 /* the index plumbing of the MoE dispatch route (FeedForward::forward_gpu_dispatch, src/nn/feedforward/feedforward.cpp:599-629,
  * 1040-1075), bmengine's functions::arange (init.h:10), divide on int32 (element.h:25: truncating integer quotient), scatter_update_dim0
  * (scatter.h:7-13: dst[dst_index[i], :] = src[src_index ? src_index[i] : i, :]) and sort_pair_1d (sort.h:8-12; cub's stable radix sort
- * there): a STABLE sort of (int32 key >= 0, int32 value) pairs, one workgroup, n <= 2^20, `workspace` 8 n bytes. */
+ * there): a STABLE sort of (int32 key, int32 value) pairs, one workgroup, n <= 2^20, `workspace` 8 n bytes.  max_key > 0: keys lie in
+ * [0, max_key] and only the bits that can differ are sorted on; max_key <= 0: the full signed 32-bit order (negative keys first), as
+ * cub sorts int32 -- an unfilled -1 expert id lands where the reference puts it. */
 int zl_arange_i32(int32_t* out, int32_t start, int32_t step, int64_t n, zl_stream_t s);
 int zl_divide_i32(const int32_t* a, int32_t* out, int32_t divisor, int64_t n, zl_stream_t s);
 int zl_scatter_update_dim0(void* dst, const int32_t* dst_index, const void* src, const int32_t* src_index, int64_t n_index, int64_t row_bytes,

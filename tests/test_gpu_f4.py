@@ -615,6 +615,16 @@ def test_dispatch_index_helpers(dev, n, max_key):
     order = np.argsort(keys, kind="stable").astype(np.int32)
     assert np.array_equal(ko.cpu().numpy(), keys[order]) and np.array_equal(vo.cpu().numpy(), order)
     assert np.array_equal(ops.divide_i32(vo, 6).cpu().numpy(), order // 6)
+    if max_key == 0 and n > 10:
+        # no key bound: the full signed order of cub's int32 radix sort -- negative keys (an unfilled -1 expert id) first, stable
+        sk = keys.copy()
+        sk[::7] = -1
+        sk[3] = -(2 ** 31)
+        ko2, vo2 = ops.sort_pairs_i32(_t(sk, dev), vals, max_key=0)
+        order2 = np.argsort(sk, kind="stable").astype(np.int32)
+        assert np.array_equal(ko2.cpu().numpy(), sk[order2]) and np.array_equal(vo2.cpu().numpy(), order2)
+        ko3, vo3 = ops.sort_pairs_i32(_t(sk, dev), vals, max_key=-1)              # a negative bound means the same
+        assert torch.equal(ko3, ko2) and torch.equal(vo3, vo2)
     assert np.array_equal(ops.arange_i32(5, dev, start=3, step=4).cpu().numpy(), np.array([3, 7, 11, 15, 19], np.int32))
     # scatter: dst rows named by dst_index <- src rows named by src_index (repeats allowed on the source side)
     m = min(n, 300)

@@ -665,6 +665,10 @@ __device__ __forceinline__ f4v mfma_t(uint4 a, uint4 b, f4v c) {
 // splits), or the merging projection's (half records: w4_i8p.hip MERGE).  The last arriver puts the word back to zero: the
 // counters need zeroing once, when the workspace is made.  A pair with a single live split skips all of it and writes its rows.
 // Records: fp32 [vh][split][128 acc | max | sum], or (half) fp16 [vh][split][128] normalised rows + fp32 (max, sum) pairs behind them.
+#ifndef ZL_LA_BATCH
+#define ZL_LA_BATCH 16
+#endif
+constexpr int kLaBatch = ZL_LA_BATCH;   // split records a last arriver holds in registers at once
 constexpr int kLaMaxSplits = 64;      // splits per task the launcher allows (the last arriver walks them 16 at a time)
 
 template <int DT>
@@ -734,16 +738,16 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
     if (!*flag) return;
     // ---- the pair's last arriver: thread -> (row i, 4 consecutive d).  Statistics AND record slices of up to 16 splits are
     //      requested together (one memory round trip; the statistics are the same 8 bytes for the 32 threads of a row); more
-    //      than 16 splits continue in further batches with the running maximum carried along (flash-decoding's rescale)
+    //      than kLaBatch splits continue in further batches with the running maximum carried along (flash-decoding's rescale)
     for (int it = threadIdx.x; it < p.rows * (kMD / 4); it += nthr) {
         const int i = it / (kMD / 4), d0 = (it % (kMD / 4)) * 4;
         const int qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
         const size_t vh = ((size_t)b * p.len_q + qi) * p.h + head;
         float mn = -1e20f, a[4] = {0.f, 0.f, 0.f, 0.f}, z = 0.f;
-        for (int u0 = 0; u0 < ns; u0 += 16) {
-            uint64_t lo[16], hi[16], ml[16];
+        for (int u0 = 0; u0 < ns; u0 += kLaBatch) {
+            uint64_t lo[kLaBatch], hi[kLaBatch], ml[kLaBatch];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < kLaBatch; ++j) {
                 const size_t rec = vh * p.max_splits + min(u0 + j, ns - 1);
                 if (p.half_partials) {
                     lo[j] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint16_t*>(p.ws) + (rec * kMD + d0)),
@@ -759,7 +763,7 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
             }
             float mb = mn;
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
+            for (int j = 0; j < kLaBatch; ++j)
                 if (u0 + j < ns) mb = fmaxf(mb, __builtin_bit_cast(float, (uint32_t)ml[j]));
             if (u0 > 0) {                               // (never taken up to 16 splits: the arithmetic there is the merge kernel's)
                 const float r = __expf(mn - mb);
@@ -769,7 +773,7 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
             }
             mn = mb;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < kLaBatch; ++j) {
                 if (u0 + j < ns) {
                     const float ms = __builtin_bit_cast(float, (uint32_t)ml[j]), ls = __builtin_bit_cast(float, (uint32_t)(ml[j] >> 32));
                     if (p.half_partials) {              // w4_i8p.hip MERGE: weight l e^(m - M) on the normalised row
@@ -803,7 +807,10 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
 #define ZL_ATTN8_OCC(NW_) ((NW_) == 4 ? 4 : ZL_ATTN8_WAVES_PER_SIMD)
 // NW: waves per workgroup the instantiation is built for (4: every launcher; 8: zl_decode_attn_la's long splits -- a whole 1 088-slot
 // buffer per workgroup at batch 32, where one workgroup per (task, kv head) fills the chip and needs no split, no record, no merge)
-template <int DT, int NW = 4>
+// LA: the in-launch merge (zl_decode_attn_la) is compiled in and the wave count comes from the launch; without it the kernel is the
+// round-4 one -- four waves as a compile-time constant, no tail code (the batch-1 step's launch: with the runtime wave count and the
+// tail behind a branch it measured 6.95 us against 5.90, profiles/r05_decode_kernel_stats.csv history in DESIGN 5.R5)
+template <int DT, int NW = 4, bool LA = false>
 __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t vs[NW][32 * kMVS];     // 9 KB per wave (36 / 72 KB); reused for the wave merge
     const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
@@ -813,14 +820,16 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
     const uint16_t* vbase = p.v_bufs[b];
     const int elen = min(len, vlen_in);
     const int t0 = split * p.split_len;
-    const int nw = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));   // 4 waves; 1 / 2 / 4 under the last-arriver launcher
+    const int nw = LA ? __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6)) : NW;   // LA: 1 / 2 / 4 (8) waves, as launched
     if (t0 >= elen || len <= 0) {
         // LA: a task without a visible key has no arriver at all -- split 0 leaves the rows the merge launch would (zeros)
-        if (p.la && split == 0)
-            for (int idx = threadIdx.x; idx < p.rows * kMD; idx += nw * 64) {
-                const int i = idx / kMD, qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
-                p.out[(((size_t)b * p.len_q + qi) * p.h + head) * kMD + idx % kMD] = 0;
-            }
+        if constexpr (LA) {
+            if (split == 0)
+                for (int idx = threadIdx.x; idx < p.rows * kMD; idx += nw * 64) {
+                    const int i = idx / kMD, qi = i / p.n_rep, head = hk * p.n_rep + i % p.n_rep;
+                    p.out[(((size_t)b * p.len_q + qi) * p.h + head) * kMD + idx % kMD] = 0;
+                }
+        }
         return;
     }
     const int t1 = min(elen, t0 + p.split_len);
@@ -978,18 +987,20 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
         }
     }
     __syncthreads();
-    if (p.la) {
+    if constexpr (LA) {
         attn_tail_la<DT>(p, xw, b, hk, split, nw, (elen + p.split_len - 1) / p.split_len);
         return;
     }
-    for (int idx = threadIdx.x; idx < p.rows * kMD; idx += nw * 64) {
+    for (int idx = threadIdx.x; idx < p.rows * kMD; idx += NW * 64) {
         const int i = idx / kMD, d = idx % kMD;
         const float* src = xw + (size_t)i * (kMD + 2);
         constexpr int WS = 16 * (kMD + 2);
         float mn = src[kMD];
-        for (int w = 1; w < nw; ++w) mn = fmaxf(mn, src[w * WS + kMD]);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mn = fmaxf(mn, src[w * WS + kMD]);
         float a = 0.f, lt = 0.f;
-        for (int w = 0; w < nw; ++w) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
             const float f = __expf(src[w * WS + kMD] - mn);
             a = __builtin_fmaf(src[w * WS + d], f, a);
             lt = __builtin_fmaf(src[w * WS + kMD + 1], f, lt);
@@ -1517,11 +1528,11 @@ int zl_decode_attn_la(const uint16_t* q, const int32_t* buf_lens, const uint16_t
     if (nw_req == 1 || nw_req == 2 || nw_req == 4 || nw_req == 8) nw = nw_req * 32 <= p.split_len ? nw_req : nw;
     const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
     if (nw == 8) {
-        if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 8>), grid, dim3(512), 0, (hipStream_t)s, p);
-        else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 8>), grid, dim3(512), 0, (hipStream_t)s, p);
+        if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 8, true>), grid, dim3(512), 0, (hipStream_t)s, p);
+        else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 8, true>), grid, dim3(512), 0, (hipStream_t)s, p);
     } else {
-        if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 4>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
-        else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 4>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
+        if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 4, true>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
+        else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 4, true>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
     }
     return zl_launch_status();
 }

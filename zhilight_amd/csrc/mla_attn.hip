@@ -561,8 +561,14 @@ int mla_launch(const MlaParams& p, int dtype, int algo, hipStream_t hs);
 
 }  // namespace
 
+// ablation bits of the wide kernel: only a -DZL_MLA_DEBUG build can set them (a process-global switch that skips waits
+// and barriers must not be reachable from a production library; without the macro the public entry points always pass 0)
+#ifdef ZL_MLA_DEBUG
 static int zl_mla_dbg = 0;
 extern "C" void zl_debug_mla(int bits) { zl_mla_dbg = bits; }
+#else
+static constexpr int zl_mla_dbg = 0;
+#endif
 
 extern "C" {
 

@@ -240,10 +240,9 @@ __global__ __launch_bounds__(256) void k_scatter_rows(unsigned char* __restrict_
 // thread t owns the contiguous chunk [t c, (t + 1) c) of the current order, counts its 16 digit values, an exclusive scan over
 // (digit, thread) in LDS gives every thread the output position of its first element per digit, and the chunk is written in order --
 // stable by construction (cub::DeviceRadixSort::SortPairs, which functions::sort_pair_1d wraps, is stable too: the MoE dispatch
-// relies on tokens staying in order inside an expert's run, feedforward.cpp:599-629).  bits = ceil(log2(max_key + 1)), 32 when
-// max_key == 0.  n <= 2^20: a decode / prompt-chunk routing table (tokens x top_k), not a general-purpose sort.
+// relies on tokens staying in order inside an expert's run, feedforward.cpp:599-629).  bits = ceil(log2(max_key + 1)); max_key <= 0: all 32 bits in signed order (sign bit flipped).  n <= 2^20: a decode / prompt-chunk routing table (tokens x top_k), not a general-purpose sort.
 __global__ __launch_bounds__(512) void k_sort_pairs_i32(const int32_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in, int32_t* keys_a,
-                                                          int32_t* vals_a, int32_t* keys_b, int32_t* vals_b, int n, int bits) {
+                                                          int32_t* vals_a, int32_t* keys_b, int32_t* vals_b, int n, int bits, uint32_t flip) {
     __shared__ int cnt[16 * 512];                    // [digit][thread]
     __shared__ int wsum[16];
     const int t = threadIdx.x, c = (n + 511) / 512, lo = min(n, t * c), hi = min(n, lo + c);
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(512) void k_sort_pairs_i32(const int32_t* __restric
 #pragma unroll
         for (int d = 0; d < 16; ++d) local[d] = 0;
         for (int i = lo; i < hi; ++i) {
-            const int d = (ksrc[i] >> shift) & 15;
+            const int d = (int)((((uint32_t)ksrc[i]) ^ flip) >> shift) & 15;
 #pragma unroll
             for (int e = 0; e < 16; ++e) local[e] += (e == d);
         }
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(512) void k_sort_pairs_i32(const int32_t* __restric
 #pragma unroll
         for (int d = 0; d < 16; ++d) local[d] = cnt[d * 512 + t];
         for (int i = lo; i < hi; ++i) {
-            const int k = ksrc[i], d = (k >> shift) & 15;
+            const int k = ksrc[i], d = (int)((((uint32_t)k) ^ flip) >> shift) & 15;
             int pos = 0;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -400,15 +399,20 @@ int zl_scatter_update_dim0(void* dst, const int32_t* dst_index, const void* src,
 }
 int zl_sort_pairs_i32(const int32_t* keys, const int32_t* values, int32_t* keys_out, int32_t* values_out, void* workspace, int64_t n, int32_t max_key,
                       zl_stream_t s) {
-    ZL_CHECK_ARG(keys && values && keys_out && values_out && workspace && n > 0 && max_key >= 0, ZL_EINVAL);
+    ZL_CHECK_ARG(keys && values && keys_out && values_out && workspace && n > 0, ZL_EINVAL);
     ZL_CHECK_ARG(n <= ((int64_t)1 << 20), ZL_ELIMIT);
-    int bits = 31;                                   // non-negative keys
+    // max_key > 0: keys in [0, max_key], only the bits that can differ.  max_key <= 0: the FULL 32-bit SIGNED order of
+    // cub::DeviceRadixSort on int32 (what functions::sort_pair_1d does without a key bound): eight passes with the sign bit
+    // flipped, so that a negative key -- an unfilled -1 expert id -- sorts in front, as in the reference
+    int bits = 32;
+    uint32_t flip = 0x80000000u;
     if (max_key > 0) {
         bits = 1;
-        while ((max_key >> bits) != 0) ++bits;
+        flip = 0;
+        while (bits < 31 && (max_key >> bits) != 0) ++bits;
     }
     int32_t* kb = static_cast<int32_t*>(workspace);
-    hipLaunchKernelGGL(k_sort_pairs_i32, dim3(1), dim3(512), 0, (hipStream_t)s, keys, values, keys_out, values_out, kb, kb + n, (int)n, bits);
+    hipLaunchKernelGGL(k_sort_pairs_i32, dim3(1), dim3(512), 0, (hipStream_t)s, keys, values, keys_out, values_out, kb, kb + n, (int)n, bits, flip);
     return zl_launch_status();
 }
 

@@ -204,11 +204,13 @@ __device__ __forceinline__ uint32_t pack_codes(const float (&v)[4], float amax) 
 
 template <int DT>
 __global__ __launch_bounds__(256) void k_ar_q8(ArState* st, const uint16_t* __restrict__ x, const uint16_t* __restrict__ residual,
-                                               uint16_t* __restrict__ out, int64_t n, int64_t gper) {
+                                               uint16_t* __restrict__ out, int64_t n, int64_t gper, int world_arg) {
     __shared__ unsigned s_epoch, s_timeout;
     const int c = blockIdx.x, world = st->world, rank = st->rank;
     if (threadIdx.x == 0) s_timeout = 0;
-    if (n * 2 > st->max_bytes) {
+    // the host cut the grid for world_arg ranks (the caller's argument); the exchange geometry is the state's: a mismatch would pass
+    // every host check and exchange the wrong regions silently -- it is an error like an oversized message
+    if (n * 2 > st->max_bytes || world_arg != world) {
         if (threadIdx.x == 0) atomicAdd(&st->err, 1u);
         return;
     }
@@ -490,8 +492,8 @@ int zl_ar_all_reduce_int8(void* state, const uint16_t* x, const uint16_t* residu
     gper = (gper + 1) / 2 * 2;
     chunks = (m + gper - 1) / gper;
     ArState* st = reinterpret_cast<ArState*>(state);
-    if (dtype == ZL_F16) hipLaunchKernelGGL(k_ar_q8<0>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)s, st, x, residual, out, n, gper);
-    else hipLaunchKernelGGL(k_ar_q8<1>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)s, st, x, residual, out, n, gper);
+    if (dtype == ZL_F16) hipLaunchKernelGGL(k_ar_q8<0>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)s, st, x, residual, out, n, gper, world_size);
+    else hipLaunchKernelGGL(k_ar_q8<1>, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)s, st, x, residual, out, n, gper, world_size);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ZL_OK : (int)e;
 }

@@ -718,10 +718,16 @@ class EncoderLayer:
         # as group-32 int8 codes (ModelContext::reduce_tp_int8)
         thres = int(os.environ.get("REDUCE_TP_INT8_THRES", "0") or 0)
         compressed = getattr(self.tp, "reduce_tp_int8", None)
-        if thres > 0 and compressed is not None and part.shape[0] > thres and part.numel() % (32 * self.tp.size) == 0 \
-                and (getattr(self.tp, "comm", None) is not None or getattr(self.tp, "oneshot", None) is not None):
-            ops.element_add_scale(hidden, compressed(part), 1.0, True, out=hidden)
-            return
+        if thres > 0 and compressed is not None and part.shape[0] > thres and part.numel() % (32 * self.tp.size) == 0:
+            # the one-shot INT8 exchange takes whole 64-element groups per rank, a contiguous 8-byte-aligned message that fits its
+            # buffer; everything else needs the RCCL composition -- and without either transport the fp16 all-reduce below runs
+            # (the branch used to be entered with only `oneshot` present and then raised for shapes it does not take)
+            one = getattr(self.tp, "oneshot", None)
+            fits = (one is not None and part.is_contiguous() and part.data_ptr() % 8 == 0 and part.numel() % (64 * self.tp.size) == 0
+                    and part.numel() * 2 <= getattr(self.tp, "oneshot_bytes", 0))
+            if fits or getattr(self.tp, "comm", None) is not None:
+                ops.element_add_scale(hidden, compressed(part), 1.0, True, out=hidden)
+                return
         fused = getattr(self.tp, "all_reduce_add", None)
         if fused is not None and fused(part, hidden) is not None:      # one-shot all-reduce with the residual add in its launch
             return

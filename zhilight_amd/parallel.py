@@ -280,7 +280,7 @@ class DirectTPGroup(TPGroup):
         receive the WS - 1 peers' codes of MY slice (rank distance order); add my own unquantised slice, re-quantise; all-gather
         the re-quantised slices; dequantise.  data (rows, n) T with rows * n % (32 * WS) == 0; returns a new tensor."""
         from . import ops
-        if (getattr(self, "oneshot", None) is not None and data.numel() * 2 <= self.oneshot_bytes and data.numel() % (64 * self.size) == 0 and data.is_contiguous()
+        if (getattr(self, "oneshot", None) is not None and data.numel() * 2 <= self.oneshot_bytes and data.numel() % (64 * self.size) == 0 and data.is_contiguous() and data.data_ptr() % 8 == 0
                 and data.dtype in (torch.float16, torch.bfloat16) and os.environ.get("ZL_REDUCE_INT8_ONESHOT", "1") != "0"):
             return self.oneshot.all_reduce_int8(data)           # the five steps as one launch, same bits (csrc_comm/comm.hip: k_ar_q8)
         comm = self._need_rccl("reduce_tp_int8")
