@@ -187,13 +187,42 @@ __global__ __launch_bounds__(1024) void k_argmax_advance(const typename EL<TI>::
     __shared__ unsigned long long red[16];
     const typename EL<TI>::type* row = x + (size_t)blockIdx.x * ld;
     unsigned long long best = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const float v = EL<TI>::ld(row, i);
+    auto take = [&](float v, int i) {
         uint32_t u = __builtin_bit_cast(uint32_t, v);
         u = (v != v) ? 0xffffffffu : (u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u));
         const unsigned long long key = ((unsigned long long)u << 32) | (uint32_t)~(uint32_t)i;
         best = key > best ? key : best;
+    };
+    int i0 = 0;
+    if constexpr (sizeof(typename EL<TI>::type) == 2) {
+        // 16-byte lanes, four loads in flight per thread: one element per thread and trip was a chain of ~125 dependent 2-byte
+        // round trips -- 46 us per step at 8 and at 32 rows (profiles/r05_bench_b8_kernel_stats.csv), 2 % of the batch-8 step
+        if ((((uintptr_t)row) & 15) == 0) {
+            const int nv = n / 8;
+            for (int c0 = threadIdx.x; c0 < nv; c0 += 4 * 1024) {
+                uint4 v4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + u * 1024;
+                    v4[u] = *reinterpret_cast<const uint4*>(row + (size_t)(c < nv ? c : c0) * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + u * 1024;
+                    if (c < nv) {
+                        const uint32_t w[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const uint16_t h = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+                            take(EL<TI>::ld(&h, 0), c * 8 + e);
+                        }
+                    }
+                }
+            }
+            i0 = nv * 8;
+        }
     }
+    for (int i = i0 + threadIdx.x; i < n; i += 1024) take(EL<TI>::ld(row, i), i);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(best, o, 64);
