@@ -255,6 +255,36 @@ def test_model_on_the_direct_transport_two_gpus(dev):   # pragma: no cover  (1-G
     assert all("rccl_ranks=2" in o for o in outs)
 
 
+@pytest.mark.skipif(bool(os.environ.get("ZL_SKIP_QWEN_TP4")), reason="ZL_SKIP_QWEN_TP4 set (builder's quick runs)")
+def test_qwen2_72b_shaped_model_tp4_four_processes_one_gpu(dev):
+    """BASELINE configs[3] as a MODEL (VERDICT r04 missing 4): Qwen2-72B geometry (dim 8192, 64 / 8 heads, dim_ff 29696, qkv bias,
+    GPTQ-Int4) cut to 2 layers, TP = 4 as FOUR processes on device 0 over DirectTPGroup: a 4096-token prompt in two chunks under
+    DUAL_STREAM=1, then decode steps under hipGraph replay, against the TP-aware CPU oracle at 1e-3; the per-rank record line goes to
+    gpurun_out/qwen_tp4.txt (profiles/r05_qwen2_72b_tp4_model.txt)."""
+    layers, s_prompt, world = int(os.environ.get("ZL_QWEN_TP4_LAYERS", "2")), int(os.environ.get("ZL_QWEN_TP4_PROMPT", "4096")), 4
+    with tempfile.TemporaryDirectory() as d:
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_tp_qwen_worker.py"), str(r), str(world), d, "0", str(layers), str(s_prompt)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        outs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=1500)
+            except subprocess.TimeoutExpired:     # pragma: no cover
+                p.kill()
+                o, _ = p.communicate()
+            outs.append(o)
+    lines = [o.strip().splitlines()[-1] if o.strip() else "" for o in outs]
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "qwen_tp4.txt"), "a") as fh:
+            fh.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    print("\n".join(lines))
+    for r, o in enumerate(outs):
+        assert f"RESULT {r} ok" in o and "captured=True" in o and "dual_stream_runs=2" in o, o[-3000:]
+
+
 def _expected_int8(xs, res, dtype):
     """ModelContext::reduce_tp_int8 step by step with the three kernels the oracle pins bit for bit (tests/test_gpu_ops.py):
     quantise every slice, rank r sums its own unquantised slice with the peers' codes in rank-distance order and re-quantises,

@@ -101,8 +101,10 @@ class OracleModel:
         ~1e-5 relative, which flips ~3 % of ITS roundings, and three projections later every element carries an
         independent fp16 rounding's worth of difference."""
         o = self.o
+        bias = self.sd.get(name + ".bias")                   # Qwen2: q / k / v projections carry one (attention.cpp:105-109)
+        bias = None if bias is None else o.h2u(np.asarray(bias, np.float16))
         if flavour == "R":
-            return o.gptq_gemm_k_major(x, *self.km[name])
+            return o.gptq_gemm_k_major(x, *self.km[name], bias=bias) if bias is not None else o.gptq_gemm_k_major(x, *self.km[name])
         tpw = getattr(self, "tp_world", 1)
         if tpw > 1 and (name.endswith("o_proj") or name.endswith("down_proj")):
             # tensor parallelism (the reference's and ours): a row-parallel linear is `tpw` partial products over contiguous K
@@ -117,7 +119,7 @@ class OracleModel:
                                                  np.ascontiguousarray(qz[:, r * ks // g:(r + 1) * ks // g]), np.ascontiguousarray(sc[:, r * ks // g:(r + 1) * ks // g]))
                 tot = (tot.astype(np.float32) + part.astype(np.float16).astype(np.float32)).astype(np.float64)
             return o.h2u(tot.astype(np.float16))
-        y = o.h2u(o.gptq_gemm_k_major_exact(x, *self.km[name]).astype(np.float16))
+        y = o.h2u((o.gptq_gemm_k_major_exact(x, *self.km[name], bias=bias) if bias is not None else o.gptq_gemm_k_major_exact(x, *self.km[name])).astype(np.float16))
         if flavour == "T" and name.endswith("layers.0.self_attn.q_proj"):
             rng = np.random.default_rng(12345)
             y = y.copy()
@@ -195,7 +197,20 @@ class OracleModel:
         o = self.o
         if name not in self.w16:
             self.w16[name] = o.gptq_dequant_k_major(*self.km[name])
-        return o.h2u(o.gemm_nt(x, self.w16[name], exact=True).astype(np.float16))
+        bias = self.sd.get(name + ".bias")
+        bias = None if bias is None else o.h2u(np.asarray(bias, np.float16))
+        tpw = getattr(self, "tp_world", 1)
+        if tpw > 1 and (name.endswith("o_proj") or name.endswith("down_proj")):
+            # a row-parallel linear of a tensor-parallel prompt: per-rank partial products over contiguous K shards, each rounded to
+            # T by its rank, summed by the all-reduce in fp32 in rank order (as _gemv does for decode rows)
+            k = x.shape[1]
+            ks = k // tpw
+            tot = np.zeros((x.shape[0], self.w16[name].shape[0]), np.float32)
+            for r in range(tpw):
+                part = o.gemm_nt(np.ascontiguousarray(x[:, r * ks:(r + 1) * ks]), np.ascontiguousarray(self.w16[name][:, r * ks:(r + 1) * ks]), exact=True)
+                tot = tot + part.astype(np.float16).astype(np.float32)
+            return o.h2u(tot.astype(np.float16))
+        return o.h2u(o.gemm_nt(x, self.w16[name], bias, exact=True).astype(np.float16))
 
     def prefill(self, task, tokens):
         """One task's prompt (encode part): causal attention over the prompt, KV written at slots 0..S-1."""
