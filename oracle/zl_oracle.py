@@ -372,6 +372,18 @@ def embedding(ids, weight, scale=1.0, begin=0, end=None, dtype=0):
     return out
 
 
+def gemm_nt_exact_blas(x, w, bias=None, dtype=0):
+    """zlo_gemm_nt_exact's value -- x (M, K) . w (N, K)^T + bias in fp64, every product of two T values exact -- through numpy's fp64
+    matmul instead of the C triple loop (0.3 GFLOP/s per core: a 2048-token prompt through one Qwen2-72B-shaped layer took 12 minutes).
+    BLAS sums in another order than the loop; in fp64 that moves the 16th digit of a sum that is rounded to T right after."""
+    xf = to_f32(_c(x, np.uint16), dtype).astype(np.float64)
+    wf = to_f32(_c(w, np.uint16), dtype).astype(np.float64)
+    y = xf @ wf.T
+    if bias is not None:
+        y = y + to_f32(_c(bias, np.uint16), dtype).astype(np.float64)[None, :]
+    return y
+
+
 def gemm_nt(x, w, bias=None, alpha=1.0, dtype=0, exact=False):
     x, w = _c(x, np.uint16), _c(w, np.uint16)
     m, k = x.shape

@@ -200,6 +200,8 @@ class OracleModel:
         bias = self.sd.get(name + ".bias")
         bias = None if bias is None else o.h2u(np.asarray(bias, np.float16))
         tpw = getattr(self, "tp_world", 1)
+        big = x.shape[0] * self.w16[name].shape[0] * x.shape[1] > (1 << 33)      # prompt-sized products: the oracle's BLAS form of the exact GEMM
+        exact_nt = (lambda a, w, b: o.gemm_nt_exact_blas(a, w, b)) if big else (lambda a, w, b: o.gemm_nt(a, w, b, exact=True))
         if tpw > 1 and (name.endswith("o_proj") or name.endswith("down_proj")):
             # a row-parallel linear of a tensor-parallel prompt: per-rank partial products over contiguous K shards, each rounded to
             # T by its rank, summed by the all-reduce in fp32 in rank order (as _gemv does for decode rows)
@@ -207,10 +209,10 @@ class OracleModel:
             ks = k // tpw
             tot = np.zeros((x.shape[0], self.w16[name].shape[0]), np.float32)
             for r in range(tpw):
-                part = o.gemm_nt(np.ascontiguousarray(x[:, r * ks:(r + 1) * ks]), np.ascontiguousarray(self.w16[name][:, r * ks:(r + 1) * ks]), exact=True)
+                part = exact_nt(np.ascontiguousarray(x[:, r * ks:(r + 1) * ks]), np.ascontiguousarray(self.w16[name][:, r * ks:(r + 1) * ks]), None)
                 tot = tot + part.astype(np.float16).astype(np.float32)
             return o.h2u(tot.astype(np.float16))
-        return o.h2u(o.gemm_nt(x, self.w16[name], bias, exact=True).astype(np.float16))
+        return o.h2u(exact_nt(x, self.w16[name], bias).astype(np.float16))
 
     def prefill(self, task, tokens):
         """One task's prompt (encode part): causal attention over the prompt, KV written at slots 0..S-1."""
