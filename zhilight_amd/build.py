@@ -128,22 +128,35 @@ REFDIR = os.path.join(HERE, "_ref")
 # reference host translation units compiled UNMODIFIED, from where they lie, against hostcpp/refshim + the bmengine-on-HIP
 # headers ("prove the boundary compiles the reference")
 REF_TUS = ("src/nn/linear/linear.cpp", "src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp",
-           "src/nn/feedforward/feedforward.cpp", "src/nn/block/block.cpp", "src/model/llama.cpp")
+           "src/nn/feedforward/feedforward.cpp", "src/nn/block/block.cpp", "src/model/llama.cpp", "src/model/model_context.cpp",
+           "src/model/buffer_context.cpp", "src/kvcache/block_allocator.cpp")
 # reference translation units that are compiled unmodified and LINK-CHECKED only (build_refcheck): every name they reference in the
 # namespaces the boundary stands in for must be defined by the boundary under the same mangled name -- i.e. with the reference's
 # exact signature; names of layers that are not on the path (their device code lives in the reference's .cu files) are listed
 REF_CHECK_TUS = ("src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp", "src/nn/feedforward/feedforward.cpp",
-                 "src/nn/block/block.cpp", "src/model/llama.cpp")
+                 "src/nn/block/block.cpp", "src/model/llama.cpp", "src/model/model_context.cpp", "src/model/buffer_context.cpp")
 REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_op::", "nn::top_k_softmax(", "nn::group_topk_softmax(",
                         "nn::sum_experts(", "nn::route_shared_lb(", "nn::plus_for_sort(", "nn::calc_reverse_idx(",
                         "nn::fill_m_indices_padded_indices(", "nn::gate_mul_inplace(", "nn::gate_fuse(", "nn::gelu_inplace(", "nn::silu_inplace(",
                         "nn::attention_qkv_rag_buffer(", "nn::multi_query_attention_rag_buffer(", "nn::get_mqa_workspace(", "nn::rope_qk_cache(",
                         "nn::rotary_embedding_qk(", "nn::copy_to_rag_buffer2(")
 # attempted and REPORTED only (never fail the build): what a full drop-in of zhilight.C would still need
-REF_REPORT_TUS = ("src/py_export/bind.cpp", "src/generator/batch_generator.cpp", "src/model/model_context.cpp")
+REF_REPORT_TUS = ("src/py_export/bind.cpp", "src/generator/batch_generator.cpp", "src/model/host_all_reducer.cpp")
 # declared by the shim so that the units compile, NOT provided by the boundary (smooth-quant calibration helpers): reported as "pending"
 # (round 4: the MoE dispatch route's arange / sort_pair_1d / divide / scatter_update_dim0 left this list -- bm_functions.cpp)
 REF_CHECK_PENDING = ("bmengine::functions::pow(", "bmengine::functions::clamp(")
+
+
+# the host library: the bmengine-on-HIP layer, the engine, the classes around the operators (host_*.cpp) and the reference's units
+HOST_SOURCES = HOSTCPP_SOURCES + ("bm_engine.cpp", "host_kvcache.cpp", "host_position.cpp", "host_embedding.cpp", "host_layernorm.cpp",
+                                  "host_attention_ext.cpp", "host_offpath.cpp")
+HOST_HEADERS = HOSTCPP_HEADERS + ("bm_engine.h", "host_common.h")
+# the pybind11 harness around it (test infrastructure)
+HARNESS_SOURCES = (os.path.join("refshim", "ref_glue.cpp"), "ref_attention_glue.cpp", "ref_block_glue.cpp", "ref_model_glue.cpp")
+
+
+def host_target():
+    return os.path.join(REFDIR, "libzhilight_amd_host.so")
 
 
 def refcompile_target():
@@ -151,30 +164,55 @@ def refcompile_target():
     return os.path.join(REFDIR, "zl_reflinear" + sysconfig.get_config_var("EXT_SUFFIX"))
 
 
-def build_refcompile(force=False, verbose=False):
-    """zhilight_amd/_ref/zl_reflinear*.so = the reference's own src/nn/linear/linear.cpp (read in place from
-    /root/reference, never copied) + hostcpp/refshim/ref_glue.cpp + the hostcpp layer, linked against libzhilight_amd.so.
-    Only where the reference tree exists (this container); the GPU box uses the prebuilt file.  _ref/ is git-ignored (it
-    holds compiled reference code) but travels with gpurun snapshots.  Returns the path, or None without a reference."""
+def _ref_compile_env():
     import pybind11
     import sysconfig
-    target = refcompile_target()
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    shim = os.path.join(HOSTCPP, "refshim")
+    inc = ["-I" + shim, "-I" + HOSTCPP, "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(HERE, "..", "include"),
+           "-I" + os.path.join(REFERENCE, "src"), "-I" + REFERENCE, "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
+    cxx = os.environ.get("CXX", "g++")
+    return rocm, shim, cxx, [cxx, "-O1", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DENABLE_DS_DEEP_GEMM", "-DZL_REF_LAYERNORM_EXTERNAL", "-w"] + inc
+
+
+def _undefined_outside(target, libs):
+    """names `target` needs that none of `libs` defines (the CPython API and the C / C++ runtime aside)"""
+    have = set()
+    for lib in libs:
+        for line in subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True).splitlines():
+            have.add(line.split()[-1])
+    missing = []
+    for line in subprocess.check_output(["nm", "-D", "-u", target], text=True).splitlines():
+        kind, sym = line.split()[-2:]
+        if kind in "wv" or "@" in sym or sym.startswith(("Py", "_Py", "__")) or sym in have:
+            continue
+        missing.append(sym)
+    return missing
+
+
+def build_host(force=False, verbose=False):
+    """zhilight_amd/_ref/libzhilight_amd_host.so = the host library a drop-in of the reference links instead of its .cu files and
+    bmengine: the bmengine-on-HIP layer (Context / Tensor / Layer / functions / c10d), core::Engine (one thread + one exchange state +
+    one RCCL communicator per tensor-parallel rank, bm_engine.cpp), the operator wrappers under the reference's names (nn_amd.cpp), the
+    classes around them (host_*.cpp: TransformerBuffer, RotaryEmbedding, RopePreparer, RawEmbedding incl. its vocab-parallel form,
+    the reference-layout LayerNorm, FlashDecoding::mha_fwd) -- and, compiled UNMODIFIED from where they lie in /root/reference,
+    the reference's own host translation units REF_TUS (linear, attention, MLA, feed-forward, block, llama, model_context,
+    buffer_context).  Links libzhilight_amd.so and libzhilight_amd_comm.so.  Only where the reference tree exists (this
+    container); the GPU box uses the prebuilt file.  _ref/ is git-ignored (it holds compiled reference code) but travels with
+    gpurun snapshots.  Returns the path, or None without a reference."""
+    target = host_target()
     tus = [os.path.join(REFERENCE, t) for t in REF_TUS]
     if not all(os.path.exists(t) for t in tus):
         return target if os.path.exists(target) else None
-    shim = os.path.join(HOSTCPP, "refshim")
-    own = [os.path.join(HOSTCPP, f) for f in HOSTCPP_SOURCES] + [os.path.join(shim, "ref_glue.cpp"), os.path.join(HOSTCPP, "ref_attention_glue.cpp"), os.path.join(HOSTCPP, "ref_block_glue.cpp"), os.path.join(HOSTCPP, "ref_model_glue.cpp")]
-    deps = tus + own + [os.path.join(HOSTCPP, f) for f in HOSTCPP_HEADERS] + [os.path.join(HERE, "..", "include", "zhilight_amd.h")]
+    rocm, shim, cxx, common = _ref_compile_env()
+    own = [os.path.join(HOSTCPP, f) for f in HOST_SOURCES]
+    deps = tus + own + [os.path.join(HOSTCPP, f) for f in HOST_HEADERS] + [os.path.join(HERE, "..", "include", "zhilight_amd.h"),
+                                                                            os.path.join(HERE, "..", "include", "zhilight_amd_comm.h"), OUT, COMM_OUT]
     for root, _, files in os.walk(shim):
-        deps += [os.path.join(root, f) for f in files]
+        deps += [os.path.join(root, f) for f in files if f != "ref_glue.cpp"]
     if not (force or _stale(target, deps)):
         return target
     os.makedirs(REFDIR, exist_ok=True)
-    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-    cxx = os.environ.get("CXX", "g++")
-    inc = ["-I" + shim, "-I" + HOSTCPP, "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(HERE, "..", "include"),
-           "-I" + os.path.join(REFERENCE, "src"), "-I" + REFERENCE, "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
-    common = [cxx, "-O1", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DENABLE_DS_DEEP_GEMM", "-DZL_REF_LAYERNORM_EXTERNAL", "-w"] + inc
     objs = []
     jobs = []
     for src in tus + own:
@@ -187,29 +225,56 @@ def build_refcompile(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
-    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+    with ThreadPoolExecutor(max_workers=min(16, len(jobs))) as ex:
         list(ex.map(run, jobs))
-    run([cxx, "-shared", "-o", target] + objs + ["-L" + HERE, "-lzhilight_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+    run([cxx, "-shared", "-o", target] + objs + ["-L" + HERE, "-lzhilight_amd", "-lzhilight_amd_comm", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lpthread",
                                                    "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(rocm, "lib")])
     for o in objs:
         os.remove(o)
-    # every name the reference's translation unit needs must be DEFINED by the boundary (the CPython API aside, which the
-    # interpreter provides): a leftover undefined symbol would only surface as an ImportError on the GPU box
-    libs = [OUT, os.path.join(rocm, "lib", "libamdhip64.so")]
-    have = set()
-    for lib in libs:
-        for line in subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True).splitlines():
-            have.add(line.split()[-1])
-    missing = []
-    for line in subprocess.check_output(["nm", "-D", "-u", target], text=True).splitlines():
-        kind, sym = line.split()[-2:]
-        if kind in "wv" or "@" in sym or sym.startswith(("Py", "_Py", "__")) or sym in have:
-            continue
-        missing.append(sym)
+    # every name the reference's translation units need must be DEFINED by the boundary: a leftover undefined symbol would only
+    # surface as an ImportError on the GPU box
+    missing = _undefined_outside(target, [OUT, COMM_OUT, os.path.join(rocm, "lib", "libamdhip64.so")])
     if missing:
         os.remove(target)
         demangled = subprocess.run(["c++filt"], input="\n".join(missing), text=True, capture_output=True).stdout
-        raise RuntimeError("the reference translation unit needs names the boundary does not define:\n" + demangled)
+        raise RuntimeError("the reference translation units need names the boundary does not define:\n" + demangled)
+    return target
+
+
+def build_refcompile(force=False, verbose=False):
+    """zhilight_amd/_ref/zl_reflinear*.so = the pybind11 TEST module around libzhilight_amd_host.so (HARNESS_SOURCES: RefLinear,
+    RefAttention, RefEncoderLayer, RefFeedForward, RefLLaMA, RefEngineLLaMA).  Returns the path, or None without a reference."""
+    target = refcompile_target()
+    host = build_host(force, verbose)
+    if host is None or not os.path.exists(REFERENCE):
+        return target if os.path.exists(target) and host is not None else None
+    rocm, shim, cxx, common = _ref_compile_env()
+    srcs = [os.path.join(HOSTCPP, f) for f in HARNESS_SOURCES]
+    if not (force or _stale(target, srcs + [host])):
+        return target
+    objs = []
+    jobs = []
+    for src in srcs:
+        o = os.path.join(REFDIR, "harness_" + os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        jobs.append(common + ["-c", src, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        list(ex.map(run, jobs))
+    run([cxx, "-shared", "-o", target] + objs + ["-L" + REFDIR, "-lzhilight_amd_host", "-L" + HERE, "-lzhilight_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+                                                   "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    for o in objs:
+        os.remove(o)
+    missing = _undefined_outside(target, [host, OUT, os.path.join(rocm, "lib", "libamdhip64.so")])
+    if missing:
+        os.remove(target)
+        demangled = subprocess.run(["c++filt"], input="\n".join(missing), text=True, capture_output=True).stdout
+        raise RuntimeError("the test module needs names the host library does not define:\n" + demangled)
     return target
 
 
@@ -219,7 +284,7 @@ def refcheck_report():
 
 def build_refcheck(force=False, verbose=False):
     """Compile REF_CHECK_TUS in place against hostcpp/refshim and compare what they reference with what the boundary defines
-    (libzhilight_amd.so + the hostcpp layer inside the zl_reflinear module).  Writes zhilight_amd/_ref/linkcheck.json:
+    (libzhilight_amd.so + libzhilight_amd_host.so).  Writes zhilight_amd/_ref/linkcheck.json:
     {tu: {"resolved": [...], "outside": [...], "pending": [...], "reference": [... defined by another checked unit]}} (demangled); raises when a name in REF_CHECK_NAMESPACES is not
     defined -- a signature that drifted from the reference's -- unless it is one of REF_CHECK_PENDING.  Only where the reference tree exists; returns the report path or None."""
     import json
@@ -241,7 +306,7 @@ def build_refcheck(force=False, verbose=False):
            "-I" + os.path.join(REFERENCE, "src"), "-I" + REFERENCE, "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
     common = [os.environ.get("CXX", "g++"), "-O1", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DENABLE_DS_DEEP_GEMM", "-w"] + inc
     have = set()
-    for lib in (OUT, module, os.path.join(rocm, "lib", "libamdhip64.so")):
+    for lib in (OUT, host_target(), os.path.join(rocm, "lib", "libamdhip64.so")):
         for line in subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True).splitlines():
             have.add(line.split()[-1])
     out, drifted = {}, []

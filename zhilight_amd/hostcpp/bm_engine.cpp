@@ -1,0 +1,306 @@
+// bm_engine.cpp -- bmengine::core::Engine on MI355X (bm_engine.h): one thread, one exchange buffer, one one-shot all-reduce
+// state and -- between distinct devices -- one RCCL communicator per tensor-parallel rank, all inside one process
+// (3rd/bmengine/bmengine/core/engine.cpp:56-59, 140-157, 307-340 is what it stands in for).  Host code only; the transports
+// are libzhilight_amd_comm.so's (include/zhilight_amd_comm.h).
+#include "bm_engine.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+#include <set>
+
+#include "bm_c10d.h"
+#include "zhilight_amd.h"
+#include "zhilight_amd_comm.h"
+
+namespace bmengine {
+namespace core {
+
+namespace {
+
+std::string comm_status(int st) {
+    if (st >= 1000) return "ncclResult_t " + std::to_string(st - 1000);
+    return zl_status_string(st);
+}
+#define EN_CK(call, what)                                                                                              \
+    do {                                                                                                               \
+        const int st_ = (call);                                                                                        \
+        if (st_ != 0) throw BMEngineException(std::string(what) + ": " + comm_status(st_), __FILE__, __LINE__, __func__); \
+    } while (0)
+
+// dtype codes of zhilight_amd_comm.h
+int comm_dtype(DataType dt) {
+    switch (dt) {
+    case DataType::kHalf: return 0;
+    case DataType::kBFloat16: return 1;
+    case DataType::kFloat: return 2;
+    case DataType::kInt32: return 3;
+    case DataType::kInt8: return 4;
+    default: return -1;
+    }
+}
+bool is_16bit_float(DataType dt) { return dt == DataType::kHalf || dt == DataType::kBFloat16; }
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+int64_t env_i64(const char* name, int64_t dflt) {
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoll(v) : dflt;
+}
+
+}  // namespace
+
+class EngineImpl {
+public:
+    struct Rank {
+        int device = 0;
+        zl_comm_t* comm = nullptr;
+        void* ar_buffer = nullptr;
+        void* ar_state = nullptr;
+        hipStream_t setup_stream = nullptr;
+        MemoryAllocator allocator;
+        std::unique_ptr<TaskThreadPool> thread;
+    };
+    std::vector<Rank> ranks;
+    bool rccl = false;
+    int64_t oneshot_bytes = 8 << 20;
+    int world() const { return (int)ranks.size(); }
+
+    // every rank's thread runs fn(rank) at the same time (the communicator handshake needs them concurrent); the first failure
+    // is rethrown after all of them finished
+    void foreach_rank(const std::function<void(int)>& fn) {
+        for (int r = 0; r < world(); ++r) {
+            const int dev = ranks[r].device;
+            ranks[r].thread->run([fn, r, dev] {
+                BM_HIPRT_ASSERT(hipSetDevice(dev));
+                fn(r);
+            });
+        }
+        std::exception_ptr first;
+        for (int r = 0; r < world(); ++r) {
+            try {
+                ranks[r].thread->wait();
+            } catch (...) {
+                if (!first) first = std::current_exception();
+            }
+        }
+        if (first) std::rethrow_exception(first);
+    }
+
+    // ---- the collectives of one rank (stream-ordered, no host synchronisation) ------------------------------------------------
+    // fp16 / bf16 sums: the one-shot exchange (in pieces when the message outgrows the exchange buffers and there is no RCCL)
+    bool oneshot_fits(const void* send, const void* recv, size_t count, DataType dt) const {
+        if (!is_16bit_float(dt) || count % 8 || !aligned16(send) || !aligned16(recv)) return false;
+        return !rccl || (int64_t)(count * 2) <= oneshot_bytes;
+    }
+    void all_reduce_sum(int r, const void* send, void* recv, size_t count, DataType dt, hipStream_t st) const {
+        const Rank& R = ranks[r];
+        if (oneshot_fits(send, recv, count, dt)) {
+            const size_t per = (size_t)oneshot_bytes / 2;
+            for (size_t off = 0; off < count; off += per) {
+                const size_t n = std::min(per, count - off);
+                EN_CK(zl_ar_all_reduce(R.ar_state, (const uint16_t*)send + off, nullptr, (uint16_t*)recv + off, (int64_t)n, comm_dtype(dt), st),
+                      "one-shot all-reduce");
+            }
+            return;
+        }
+        BM_ASSERT(rccl, "all-reduce of this dtype / shape / alignment needs the RCCL communicator, and the ranks of this engine share a device "
+                        "(fp16 / bf16 messages of a multiple of 8 elements at 16-byte aligned addresses run on the one-shot exchange)");
+        BM_ASSERT(comm_dtype(dt) >= 0, "all-reduce: dtype without an RCCL type");
+        EN_CK(zl_comm_all_reduce_sum(R.comm, send, recv, (int64_t)count, comm_dtype(dt), st), "ncclAllReduce");
+    }
+    // a gather as the sum of the ranks' zero-padded slices (ranks sharing a device: no RCCL): adding zeros is exact (a -0.0 comes
+    // back as +0.0)
+    void gather_by_sum(int r, const void* send, void* recv, size_t count, DataType dt, hipStream_t st) const {
+        const size_t esz = get_elem_size(dt);
+        BM_ASSERT(is_16bit_float(dt), "all-gather between ranks that share a device: fp16 / bf16 only (the sum of zero-padded slices)");
+        BM_HIPRT_ASSERT(hipMemsetAsync(recv, 0, count * esz * world(), st));
+        BM_HIPRT_ASSERT(hipMemcpyAsync((char*)recv + (size_t)r * count * esz, send, count * esz, hipMemcpyDeviceToDevice, st));
+        all_reduce_sum(r, recv, recv, count * world(), dt, st);
+    }
+};
+
+Engine::Engine(const std::vector<DeviceConfiguration>& dev_cfg, const DistConfiguration& dist_cfg) : pimpl(new EngineImpl) {
+    const int world = (int)dev_cfg.size();
+    BM_ASSERT(world >= 1 && world <= ZL_AR_MAX_RANKS, "Engine: 1 .. 8 ranks on one node");
+    BM_ASSERT(dist_cfg.tp <= 0 || dist_cfg.tp == world, "Engine: tp must equal the number of devices (no pipeline parallelism on this path)");
+    BM_ASSERT(dist_cfg.nnodes == 1, "Engine: one node");
+    std::set<int> distinct;
+    pimpl->ranks.resize(world);
+    for (int r = 0; r < world; ++r) {
+        pimpl->ranks[r].device = dev_cfg[r].device_id;
+        pimpl->ranks[r].thread.reset(new TaskThreadPool(1, r));
+        distinct.insert(dev_cfg[r].device_id);
+    }
+    const bool all_distinct = (int)distinct.size() == world;
+    pimpl->rccl = world > 1 && all_distinct && env_i64("ZL_ENGINE_RCCL", 1) != 0;
+    pimpl->oneshot_bytes = std::max<int64_t>(4096, env_i64("ZL_ENGINE_ONESHOT_BYTES", 8 << 20)) / 16 * 16;
+    EngineImpl* impl = pimpl.get();
+    // phase 1: streams, exchange buffers, peer access
+    impl->foreach_rank([impl, world, all_distinct](int r) {
+        EngineImpl::Rank& R = impl->ranks[r];
+        BM_HIPRT_ASSERT(hipStreamCreateWithFlags(&R.setup_stream, hipStreamNonBlocking));
+        if (world == 1) return;
+        EN_CK(zl_ar_alloc(zl_ar_buffer_bytes(impl->oneshot_bytes), &R.ar_buffer), "exchange buffer");
+        BM_HIPRT_ASSERT(hipMalloc(&R.ar_state, (size_t)zl_ar_state_bytes()));
+        BM_HIPRT_ASSERT(hipMemset(R.ar_state, 0, (size_t)zl_ar_state_bytes()));
+        if (all_distinct)
+            for (int p = 0; p < world; ++p) {
+                if (p == r) continue;
+                const hipError_t e = hipDeviceEnablePeerAccess(impl->ranks[p].device, 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                else BM_HIPRT_ASSERT(e);
+            }
+    });
+    if (world == 1) return;
+    // phase 2: the communicator handshake (every rank at once) and the address tables of the one-shot exchange
+    char uid[ZL_COMM_UNIQUE_ID_BYTES];
+    std::memset(uid, 0, sizeof(uid));
+    if (impl->rccl) EN_CK(zl_comm_unique_id(uid), "ncclGetUniqueId");
+    std::vector<void*> buffers(world);
+    for (int r = 0; r < world; ++r) buffers[r] = impl->ranks[r].ar_buffer;
+    impl->foreach_rank([impl, world, &uid, &buffers](int r) {
+        EngineImpl::Rank& R = impl->ranks[r];
+        if (impl->rccl) EN_CK(zl_comm_create(&R.comm, world, r, uid), "ncclCommInitRank");
+        EN_CK(zl_ar_init(R.ar_state, world, r, buffers.data(), impl->oneshot_bytes, R.setup_stream), "one-shot exchange setup");
+    });
+}
+
+Engine::~Engine() {
+    EngineImpl* impl = pimpl.get();
+    try {
+        impl->foreach_rank([impl](int r) {
+            EngineImpl::Rank& R = impl->ranks[r];
+            (void)hipDeviceSynchronize();
+            if (R.comm) (void)zl_comm_destroy(R.comm);
+            if (R.ar_buffer) (void)zl_ar_free(R.ar_buffer);
+            if (R.ar_state) (void)hipFree(R.ar_state);
+            if (R.setup_stream) (void)hipStreamDestroy(R.setup_stream);
+        });
+    } catch (...) {
+    }
+}
+
+int Engine::num_gpus() const { return pimpl->world(); }
+int Engine::world_size() const { return pimpl->world(); }
+int Engine::local_ranks() const { return pimpl->world(); }
+bool Engine::has_rccl() const { return pimpl->rccl; }
+MemoryAllocator* Engine::get_allocator(int dev_id) {
+    BM_ASSERT(dev_id >= 0 && dev_id < pimpl->world(), "Engine::get_allocator: rank out of range");
+    return &pimpl->ranks[dev_id].allocator;
+}
+GPUInfo Engine::get_gpu_info(int device_idx) const {
+    BM_ASSERT(device_idx >= 0 && device_idx < pimpl->world(), "Engine::get_gpu_info: rank out of range");
+    GPUInfo info{};
+    info.real_device_idx = pimpl->ranks[device_idx].device;
+    info.compute_capability = 90;      // (Context::get_compute_capability: what the reference's > 80 gates see)
+    int prev = 0;
+    BM_HIPRT_ASSERT(hipGetDevice(&prev));
+    BM_HIPRT_ASSERT(hipSetDevice(info.real_device_idx));
+    size_t free_b = 0, total_b = 0;
+    BM_HIPRT_ASSERT(hipMemGetInfo(&free_b, &total_b));
+    BM_HIPRT_ASSERT(hipSetDevice(prev));
+    info.total_memory = total_b;
+    info.free_memory = free_b;
+    info.alloc_memory = total_b - free_b;
+    return info;
+}
+void Engine::print_memory_summary() {
+    for (int r = 0; r < pimpl->world(); ++r) {
+        const GPUInfo g = get_gpu_info(r);
+        std::cerr << "rank " << r << " device " << g.real_device_idx << ": " << (g.alloc_memory >> 20) << " MB in use of " << (g.total_memory >> 20) << " MB\n";
+    }
+}
+void Engine::device_foreach(std::function<void(int)> fn) { pimpl->foreach_rank(fn); }
+void Engine::run(int rank, std::function<void()> fn) {
+    BM_ASSERT(rank >= 0 && rank < pimpl->world(), "Engine::run: rank out of range");
+    const int dev = pimpl->ranks[rank].device;
+    pimpl->ranks[rank].thread->runSync([fn, dev] {
+        BM_HIPRT_ASSERT(hipSetDevice(dev));
+        fn();
+    });
+}
+int Engine::exchange_errors(int rank) const {
+    BM_ASSERT(rank >= 0 && rank < pimpl->world(), "Engine::exchange_errors: rank out of range");
+    const EngineImpl::Rank& R = pimpl->ranks[rank];
+    return R.ar_state ? zl_ar_status(R.ar_state, R.setup_stream) : 0;
+}
+
+Context Engine::create_context() const { return create_context_rank(0); }
+Context Engine::create_context(const std::vector<int>& devices) const {
+    BM_ASSERT(devices.size() == 1, "Engine::create_context: one device per context (tensor parallelism = one context per rank)");
+    return create_context_rank(devices[0]);
+}
+
+Context Engine::create_context_rank(int rank) const {
+    EngineImpl* impl = pimpl.get();
+    const int world = impl->world();
+    BM_ASSERT(rank >= 0 && rank < world, "Engine::create_context_rank: rank out of range");
+    Context ctx(impl->ranks[rank].device, rank, world);
+    if (world == 1) return ctx;
+    const int r = rank;
+    c10d::Collectives c;
+    c.comm_count = world;
+    c.user_rank = rank;
+    c.all_reduce = [impl, r](const Tensor& send, Tensor& recv, ncclRedOp_t op, hipStream_t st) {
+        BM_ASSERT(op == ncclSum, "NCCLAllReduce: the path sums (ModelContext::reduce_sum2, model_context.cpp:236)");
+        BM_ASSERT_EQ(send.nbytes(), recv.nbytes(), "NCCLAllReduce: send / recv sizes differ");
+        impl->all_reduce_sum(r, send.data(), recv.data(), send.numel(), send.dtype(), st);
+    };
+    c.all_gather = [impl, r, world](const Tensor& send, Tensor& recv, hipStream_t st) {
+        BM_ASSERT_EQ(send.nbytes() * (size_t)world, recv.nbytes(), "NCCLAllGather: recv is world x send");
+        if (impl->rccl) {
+            BM_ASSERT(comm_dtype(send.dtype()) >= 0, "NCCLAllGather: dtype without an RCCL type");
+            EN_CK(zl_comm_all_gather(impl->ranks[r].comm, send.data(), recv.data(), (int64_t)send.numel(), comm_dtype(send.dtype()), st), "ncclAllGather");
+        } else {
+            impl->gather_by_sum(r, send.data(), recv.data(), send.numel(), send.dtype(), st);
+        }
+    };
+    c.broadcast = [impl, r](const Tensor& send, Tensor& recv, int root, hipStream_t st) {
+        BM_ASSERT(root >= 0 && root < impl->world(), "NCCLBroadcast: root out of range");
+        if (r == root) {
+            BM_ASSERT_EQ(send.nbytes(), recv.nbytes(), "NCCLBroadcast: send / recv sizes differ");
+            if (send.data() != recv.data()) BM_HIPRT_ASSERT(hipMemcpyAsync(recv.data(), send.data(), send.nbytes(), hipMemcpyDeviceToDevice, st));
+        }
+        if (impl->rccl) {
+            BM_ASSERT(comm_dtype(recv.dtype()) >= 0, "NCCLBroadcast: dtype without an RCCL type");
+            EN_CK(zl_comm_broadcast(impl->ranks[r].comm, recv.data(), (int64_t)recv.numel(), comm_dtype(recv.dtype()), root, st), "ncclBroadcast");
+        } else {
+            BM_ASSERT(is_16bit_float(recv.dtype()), "broadcast between ranks that share a device: fp16 / bf16 only (the sum with zeros)");
+            if (r != root) BM_HIPRT_ASSERT(hipMemsetAsync(recv.data(), 0, recv.nbytes(), st));
+            impl->all_reduce_sum(r, recv.data(), recv.data(), recv.numel(), recv.dtype(), st);
+        }
+    };
+    c.reduce_scatter = [impl, r, world](const Tensor& send, Tensor& recv, ncclRedOp_t op, hipStream_t st) {
+        BM_ASSERT(op == ncclSum, "NCCLReduceScatter: sum only");
+        BM_ASSERT_EQ(recv.nbytes() * (size_t)world, send.nbytes(), "NCCLReduceScatter: send is world x recv");
+        if (impl->rccl) {
+            BM_ASSERT(comm_dtype(send.dtype()) >= 0, "NCCLReduceScatter: dtype without an RCCL type");
+            EN_CK(zl_comm_reduce_scatter_sum(impl->ranks[r].comm, send.data(), recv.data(), (int64_t)recv.numel(), comm_dtype(send.dtype()), st),
+                  "ncclReduceScatter");
+        } else {
+            void* tmp = nullptr;                                   // (ranks sharing a device: the whole sum, then this rank's slice)
+            BM_HIPRT_ASSERT(hipMallocAsync(&tmp, send.nbytes(), st));
+            impl->all_reduce_sum(r, send.data(), tmp, send.numel(), send.dtype(), st);
+            BM_HIPRT_ASSERT(hipMemcpyAsync(recv.data(), (char*)tmp + (size_t)r * recv.nbytes(), recv.nbytes(), hipMemcpyDeviceToDevice, st));
+            BM_HIPRT_ASSERT(hipFreeAsync(tmp, st));
+        }
+    };
+    if (impl->rccl) {
+        c.send = [impl, r](const Tensor& buf, int peer, hipStream_t st) {
+            EN_CK(zl_comm_send(impl->ranks[r].comm, buf.data(), (int64_t)buf.numel(), comm_dtype(buf.dtype()), peer, st), "ncclSend");
+        };
+        c.recv = [impl, r](Tensor& buf, int peer, hipStream_t st) {
+            EN_CK(zl_comm_recv(impl->ranks[r].comm, buf.data(), (int64_t)buf.numel(), comm_dtype(buf.dtype()), peer, st), "ncclRecv");
+        };
+        // (group calls carry no context and reach every rank's entry, bm_c10d.cpp: ncclGroupStart / End are per calling thread)
+        c.group_start = [] { EN_CK(zl_comm_group_start(), "ncclGroupStart"); };
+        c.group_end = [] { EN_CK(zl_comm_group_end(), "ncclGroupEnd"); };
+    }
+    c10d::set_collectives(ctx, c);
+    // Context::reduce_sum of a plain (non-model) context: in place
+    ctx.set_reduce_hook([impl, r](Tensor& data, hipStream_t st) { impl->all_reduce_sum(r, data.data(), data.data(), data.numel(), data.dtype(), st); });
+    return ctx;
+}
+
+}  // namespace core
+}  // namespace bmengine

@@ -1,6 +1,7 @@
 #include <vector>
 // bm_hip.cpp -- storage, tensors and the per-device context behind bm_hip.h (HIP runtime only; no torch, no BLAS).
 #include "bm_hip.h"
+#include "bm_c10d.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -461,19 +462,31 @@ void Context::set_reduce_hook(ReduceHook h) { pimpl->reduce = std::move(h); }
 Tensor Context::reduce_sum(Tensor& data, DataType out_type) const {
     BM_ASSERT(out_type == data.dtype(), "reduce_sum: the output type is the input type on this path");
     if (pimpl->world > 1) {
-        BM_ASSERT(pimpl->reduce, "reduce_sum: no communicator installed (Context::set_reduce_hook)");
-        pimpl->reduce(data, current_cuda_stream());
+        // the communicator owner's hook (in place), else the rank's c10d operations (bm_engine.cpp installs both)
+        if (pimpl->reduce) pimpl->reduce(data, current_cuda_stream());
+        else c10d::NCCLAllReduce(*this, data, data, ncclSum);
     }
     return data;
 }
 
+// context.cpp:862-876: a new tensor with dimension 0 divided / multiplied by the world size, filled by the rank's collectives
 Tensor Context::reduce_scatter(const Tensor& data) const {
-    BM_ASSERT(pimpl->world == 1, "reduce_scatter: this context owns no communicator for it (the decode path reduces with reduce_sum)");
-    return data;
+    if (pimpl->world == 1) return data;
+    std::vector<size_t> shape = data.shape();
+    BM_ASSERT(!shape.empty() && shape[0] % (size_t)pimpl->world == 0, "reduce_scatter: dimension 0 must divide by the world size");
+    shape[0] /= (size_t)pimpl->world;
+    Tensor out = tensor(shape, data.dtype());
+    c10d::NCCLReduceScatter(*this, data, out, ncclSum);
+    return out;
 }
 Tensor Context::all_gather(const Tensor& data) const {
-    BM_ASSERT(pimpl->world == 1, "all_gather: this context owns no communicator for it (the decode path reduces with reduce_sum)");
-    return data;
+    if (pimpl->world == 1) return data;
+    std::vector<size_t> shape = data.shape();
+    BM_ASSERT(!shape.empty(), "all_gather: a tensor with at least one dimension");
+    shape[0] *= (size_t)pimpl->world;
+    Tensor out = tensor(shape, data.dtype());
+    c10d::NCCLAllGather(*this, data, out);
+    return out;
 }
 void Context::reserve_cache_alloc(size_t) {
     if (!pimpl->side_pool) pimpl->side_pool = std::make_shared<Pool>(pimpl->device);     // grows on demand: nothing to reserve

@@ -150,7 +150,7 @@ protected:
     void execution_loop();
 };
 
-class Engine;            // the reference's multi-device owner: opaque, never constructed (one process per GPU)
+class Engine;            // the multi-rank owner of one node: bm_engine.h
 class MemoryAllocator;
 
 // Create and record an event pair around a scope (context.h:176-187); recordEvent is a no-op unless tracing is on

@@ -1029,6 +1029,42 @@ Tensor quant_calc_scale(const Context& ctx, const Tensor& input, int q_max, int 
 }
 void set_quant_scale(Tensor& tensor, const Tensor& scale) { tensor.set_quant_scale(scale); }
 
+// ---- the group-32 codes of the INT8-compressed reduce (quant_reduce_kernel.cu:13-330; ModelContext::reduce_tp_int8 composes them
+// with send / recv rounds, model_context.cpp:244-326) --------------------------------------------------------------------------
+std::tuple<Tensor, Tensor> quant_group_32(const Context& ctx, const Tensor& input) {
+    const size_t k = input.size(-1), m = input.numel() / k;
+    BM_ASSERT_EQ(k, (size_t)32, "[quant_group_32]");
+    Tensor q = ctx.tensor(input.shape(), DataType::kInt8, "", 32 * k);
+    std::vector<size_t> sshape(input.shape().begin(), input.shape().end() - 1);
+    Tensor sc = ctx.tensor(sshape, input.dtype());
+    zl_check(zl_quant_group_32(input.data<uint16_t>(), q.data<int8_t>(), sc.data<uint16_t>(), (int64_t)m, zdt(input.dtype()), st_of(ctx)), "quant_group_32");
+    return std::make_tuple(q, sc);
+}
+void dequant_group_32(const Context& ctx, const Tensor& q, const Tensor& scale, Tensor* output) {
+    const size_t m = q.numel() / q.size(-1);
+    BM_ASSERT_EQ(q.size(-1), (size_t)32, "dequant_group_32");
+    BM_ASSERT(output, "dequant_group_32: output");
+    BM_ASSERT(scale.dtype() == DataType::kHalf || scale.dtype() == DataType::kBFloat16, "dequant_group_32: the scales carry the output type (fp16 / bf16)");
+    if (output->numel() == 0) *output = ctx.tensor(q.shape(), scale.dtype());
+    zl_check(zl_dequant_group_32(q.data<int8_t>(), scale.data<uint16_t>(), output->data<uint16_t>(), (int64_t)m, zdt(scale.dtype()), st_of(ctx)), "dequant_group_32");
+}
+void dequant_sum_quant_g32(const Context& ctx, const Tensor& my, const Tensor& q_others, const Tensor& scale_others, Tensor* q_sum, Tensor* scale_sum) {
+    BM_ASSERT(q_sum && scale_sum, "dequant_sum_quant_g32: outputs");
+    BM_ASSERT_EQ(q_others.ndim(), 3, "");
+    const size_t ws = q_others.size(0) + 1, m = q_others.size(1), g = q_others.size(2);
+    BM_ASSERT(ws == 2 || ws == 4 || ws == 8, "");
+    BM_ASSERT_EQ(g, (size_t)32, "");
+    BM_ASSERT_EQ(ws - 1, scale_others.size(0), "");
+    BM_ASSERT_EQ(m, scale_others.size(1), "");
+    BM_ASSERT_EQ(m, my.size(0), "");
+    BM_ASSERT_EQ(g, my.size(1), "");
+    BM_ASSERT_EQ(m, q_sum->size(0), "");
+    BM_ASSERT_EQ(g, q_sum->size(1), "");
+    BM_ASSERT_EQ(m, scale_sum->size(0), "");
+    zl_check(zl_dequant_sum_quant_g32(my.data<uint16_t>(), q_others.data<int8_t>(), scale_others.data<uint16_t>(), q_sum->data<int8_t>(), scale_sum->data<uint16_t>(),
+                                      (int64_t)m, (int)ws, zdt(my.dtype()), st_of(ctx)), "dequant_sum_quant_g32");
+}
+
 Tensor quant_scale_back(const Context& ctx, const Tensor& input, const Tensor* scale_x, const Tensor* scale_y, DataType out_type,
                         Tensor* output) {
     BM_ASSERT(input.dtype() == DataType::kInt32, "input must be int32");

@@ -260,6 +260,10 @@ void quant_calc_scale(const core::Context& ctx, const core::Tensor& input, core:
                       int q_max = 127, int q_zero = 0);
 core::Tensor quant_calc_scale(const core::Context& ctx, const core::Tensor& input, int q_max = 127, int q_zero = 0);
 void set_quant_scale(core::Tensor& tensor, const core::Tensor& scale);
+std::tuple<core::Tensor, core::Tensor> quant_group_32(const core::Context& ctx, const core::Tensor& input);
+void dequant_group_32(const core::Context& ctx, const core::Tensor& q, const core::Tensor& scale, core::Tensor* out);
+void dequant_sum_quant_g32(const core::Context& ctx, const core::Tensor& my, const core::Tensor& q_others, const core::Tensor& scale_others,
+                           core::Tensor* q_sum, core::Tensor* scale_sum);
 core::Tensor quant_scale_back(const core::Context& ctx, const core::Tensor& input, const core::Tensor* scale_x,
                               const core::Tensor* scale_y, core::DataType out_type = core::DataType::kDouble,
                               core::Tensor* output = nullptr);

@@ -1,13 +1,12 @@
-// ref_model_glue.cpp -- what is linked next to the REFERENCE's own src/model/llama.cpp (compiled unmodified, zhilight_amd/build.py:
-// build_refcompile) so that the path BASELINE.json's north star names from its TOP -- LLaMA::encode (src/model/llama.cpp:75-151)
-// -> EncoderLayer::forward (block.cpp) -> Attention (attention.cpp) / FeedForward (feedforward.cpp) -> Linear (linear.cpp), then
-// get_logits (llama.cpp:159-165) -- EXECUTES decode steps on the MI355X boundary, five reference units deep.
-//   1. nn::RawEmbedding (src/nn/embedding/embedding.h:24-47; embedding.cu:260-289): token lookup = zl_embedding, projection = the
-//      lm_head product (zl_gemm_nt_small_m / zl_gemm_nt);
-//   2. nn::RopePreparer (src/nn/position/rope_preparer.h): the cos / sin tables of ROPE_CACHE=1 = zl_rope_cos_sin*;
-//   3. names of llama.cpp's loss / scoring helpers that are not on the decode path: definitions that throw;
-//   4. the pybind11 class RefLLaMA: load a whole model under the reference's parameter names, fill KV histories, run decode steps
-//      and read the logits.  tests/test_gpu_refcompile.py compares with the SAME CPU oracle the repository's own LLaMA is held to.
+// ref_model_glue.cpp -- the pybind11 harness classes around the REFERENCE's model::LLaMA (src/model/llama.cpp, compiled unmodified
+// into libzhilight_amd_host.so): the path BASELINE.json's north star names from its TOP -- LLaMA::encode (llama.cpp:75-151) ->
+// EncoderLayer::forward (block.cpp) -> Attention (attention.cpp) / FeedForward (feedforward.cpp) -> Linear (linear.cpp), then
+// get_logits (llama.cpp:159-165) -- inside the reference's own ModelContext (model_context.cpp, compiled unmodified):
+//   RefLLaMA        one rank: load a whole model under the reference's parameter names, fill KV histories, run decode steps, time them;
+//   RefEngineLLaMA  tensor-parallel: a core::Engine (hostcpp/bm_engine.cpp) with one thread per rank, ModelContext::create on every
+//                   rank's thread, LLaMA(parallel = true) sharding its weights by ctx.rank(), decode steps with every reduce going
+//                   ModelContext::reduce_sum -> c10d::NCCLAllReduce -> the engine's transports.
+// tests/test_gpu_refcompile.py compares with the SAME CPU oracle the repository's own LLaMA is held to.
 // Test infrastructure: nothing in the product links this file.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
@@ -15,6 +14,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
+#include "bm_engine.h"
 #include "model/dyn_batch_context.h"
 #include "model/llama.h"
 #include "model/model_context.h"
@@ -37,96 +39,7 @@ using bmengine::core::Tensor;
         if (st_ != 0) throw BMEngineException(std::string(what) + ": " + zl_status_string(st_), __FILE__, __LINE__, __func__); \
     } while (0)
 
-namespace nn {
-
-// ---- 1. RawEmbedding ----------------------------------------------------------------------------------------------------------
-class RawEmbedding::impl {
-public:
-    int dim_model, vocab_size;
-    core::DataType dtype;
-    float scale = 1.0f, logit_scale = 1.0f;
-    core::Tensor weight;
-    int zdt() const { return dtype == DataType::kHalf ? ZL_F16 : ZL_BF16; }
-};
-RawEmbedding::RawEmbedding(const core::Context& ctx, int dim_model, int vocab_size, bool scale_weights, core::DataType dtype, bool parallel)
-    : pimpl(new impl) {
-    BM_ASSERT(!parallel || ctx.world_size() == 1, "RawEmbedding: one rank here");
-    pimpl->dim_model = dim_model;
-    pimpl->vocab_size = vocab_size;
-    pimpl->dtype = dtype;
-    if (scale_weights) pimpl->scale = 1.0f / sqrtf((float)dim_model);
-    pimpl->weight = ctx.parameter({(size_t)vocab_size, (size_t)dim_model}, dtype);
-    add_parameter("weight", pimpl->weight);
-}
-RawEmbedding::~RawEmbedding() = default;
-void RawEmbedding::set_scale_weights(bool b) { pimpl->scale = b ? 1.0f / sqrtf((float)pimpl->dim_model) : 1.0f; }
-void RawEmbedding::set_scale_factor(float b) { pimpl->scale = b; }
-void RawEmbedding::set_logit_scale(float b) { pimpl->logit_scale = b; }
-void RawEmbedding::load_state_dict(const core::Context& ctx, const std::map<std::string, const core::Tensor>& state_dict, const std::string& prefix,
-                                   bool allow_missing) {
-    core::Layer::load_state_dict(ctx, state_dict, prefix, allow_missing);
-}
-core::Tensor RawEmbedding::forward(const core::Context& ctx, const core::Tensor& ids) {
-    BM_ASSERT(ids.dtype() == DataType::kInt32, "token ids are int32");
-    const size_t n = ids.numel();
-    std::vector<size_t> shape = ids.shape();
-    shape.push_back((size_t)pimpl->dim_model);
-    core::Tensor out = ctx.tensor(shape, pimpl->dtype);
-    ZL_CK(zl_embedding(ids.data<int32_t>(), pimpl->weight.data<uint16_t>(), out.data<uint16_t>(), n, pimpl->dim_model, 0, pimpl->vocab_size, pimpl->scale,
-                       pimpl->zdt(), (zl_stream_t)ctx.current_cuda_stream()), "embedding");
-    return out;
-}
-core::Tensor RawEmbedding::projection(const core::Context& ctx, const core::Tensor& input) {
-    const int64_t m = input.numel() / input.size(-1), k = input.size(-1), n = pimpl->vocab_size;
-    BM_ASSERT_EQ(k, (int64_t)pimpl->dim_model, "RawEmbedding::projection: dim mismatch");
-    std::vector<size_t> shape = input.shape();
-    shape.back() = (size_t)n;
-    core::Tensor out = ctx.tensor(shape, pimpl->dtype);
-    const float alpha = pimpl->logit_scale;
-    if (m <= 4)
-        ZL_CK(zl_gemm_nt_small_m(input.data<uint16_t>(), k, pimpl->weight.data<uint16_t>(), nullptr, out.data<uint16_t>(), m, n, k, alpha, pimpl->zdt(), nullptr, 0.f,
-                                 (zl_stream_t)ctx.current_cuda_stream()), "lm_head (row-streaming)");
-    else
-        ZL_CK(zl_gemm_nt(input.data<uint16_t>(), k, pimpl->weight.data<uint16_t>(), nullptr, out.data<uint16_t>(), m, n, k, alpha, pimpl->zdt(),
-                         (zl_stream_t)ctx.current_cuda_stream()), "lm_head");
-    return out;
-}
-
-// ---- 2. RopePreparer ----------------------------------------------------------------------------------------------------------
-class RopePreparer::impl {
-public:
-    model::ModelConfig cfg;
-    explicit impl(const model::ModelConfig& c) : cfg(c) {}
-};
-RopePreparer::RopePreparer(const core::Context&, model::ModelConfig cfg) : pimpl(new impl(cfg)) {}
-RopePreparer::~RopePreparer() = default;
-std::tuple<core::Tensor, core::Tensor> RopePreparer::forward(const core::Context& ctx, const core::Tensor&, const core::Tensor& pos) {
-    const model::ModelConfig& c = pimpl->cfg;
-    const size_t n = pos.numel(), d = c.dim_head;
-    core::Tensor cs = ctx.tensor({n, d}, DataType::kFloat), sn = ctx.tensor({n, d}, DataType::kFloat);
-    zl_stream_t st = (zl_stream_t)ctx.current_cuda_stream();
-    if (c.rope_cfg.type == "llama3")
-        ZL_CK(zl_rope_cos_sin_llama3(pos.data<int32_t>(), cs.data<float>(), sn.data<float>(), n, d, c.rope_theta, c.rope_cfg.factor, c.rope_cfg.low_freq_factor,
-                                     c.rope_cfg.high_freq_factor, (float)c.rope_cfg.original_max_position, c.rope_cfg.neox_style ? 1 : 0, st), "rope_cos_sin_llama3");
-    else
-        ZL_CK(zl_rope_cos_sin(pos.data<int32_t>(), cs.data<float>(), sn.data<float>(), n, d, c.rope_theta, c.rope_cfg.neox_style ? 1 : 0, st), "rope_cos_sin");
-    return std::make_tuple(cs, sn);
-}
-
-// ---- 3. off-path names ----------------------------------------------------------------------------------------------------------
-std::tuple<float, core::Tensor> log_prob_raw(const core::Context&, const core::Tensor&, const core::Tensor&, int32_t) { ZL_OFF_PATH("nn::log_prob_raw (scoring)"); }
-int greedy_match_raw(const core::Context&, const core::Tensor&, const core::Tensor&, int32_t) { ZL_OFF_PATH("nn::greedy_match_raw (scoring)"); }
-std::tuple<float, core::Tensor> cross_entropy_raw(const core::Context&, const core::Tensor&, const core::Tensor&, int32_t, float) {
-    ZL_OFF_PATH("nn::cross_entropy_raw (loss)");
-}
-
-}  // namespace nn
-
-namespace model {
-core::Tensor convert_fp32(const core::Context& ctx, const core::Tensor& logits) { return bmengine::functions::typecast(ctx, logits, DataType::kFloat); }
-}  // namespace model
-
-// ---- 4. the test class ----------------------------------------------------------------------------------------------------------
+// ---- the test classes ----------------------------------------------------------------------------------------------------------
 namespace {
 
 DataType np_dtype(const py::array& a) {
@@ -332,6 +245,170 @@ private:
     std::shared_ptr<model::RagBufferContext> rag_;
 };
 
+
+// The reference's model::LLaMA, tensor-parallel: a core::Engine with one thread per rank (hostcpp/bm_engine.cpp), the reference's
+// ModelContext::create (model_context.cpp:89-122) on every rank's thread, LLaMA(parallel = true) -- column / row sharded linears,
+// KV heads dealt to the ranks, vocab-parallel embedding and lm_head -- and every reduce through ModelContext::reduce_sum ->
+// reduce_sum2 -> c10d::NCCLAllReduce -> the engine's transports.  `devices` may name one device several times
+// (the one-GPU test box: the ranks then exchange over the one-shot transport only).  Python objects are touched on the calling
+// thread only: the rank threads see host tensors aliasing the numpy arrays and plain vectors.
+class RefEngineLLaMA {
+public:
+    RefEngineLLaMA(int num_layers, int dim_model, int num_heads, int num_kv_heads, int dim_head, int dim_ff, int vocab_size, float eps, float rope_theta,
+                   int quant_type, int group_size, const std::vector<int>& devices)
+        : cfg_(RefLLaMA::make_cfg(num_layers, dim_model, num_heads, num_kv_heads, dim_head, dim_ff, vocab_size, eps, rope_theta)), md_(cfg_) {
+        std::vector<bmengine::core::DeviceConfiguration> dc;
+        for (int d : devices) dc.emplace_back(d, (size_t)0);
+        engine_.reset(new bmengine::core::Engine(dc));
+        ranks_.resize(devices.size());
+        model::QuantConfig qc(quant_type);
+        qc.group_size = group_size;
+        model::DynBatchConfig bc;
+        bc.rag_buffer = true;
+        bc.flash_attention = true;
+        engine_->device_foreach([&](int r) {
+            Rank& R = ranks_[r];
+            R.ctx.reset(new model::ModelContext(model::ModelContext::create(*engine_, md_, bc, r, true)));
+            R.model.reset(new model::LLaMA(*R.ctx, cfg_, qc, true));
+        });
+    }
+    ~RefEngineLLaMA() {
+        try {
+            engine_->device_foreach([&](int r) {           // models and contexts die on the threads that made them, before the engine
+                (void)hipDeviceSynchronize();
+                ranks_[r].model.reset();
+                ranks_[r].ctx.reset();
+            });
+        } catch (...) {
+        }
+    }
+    int world_size() const { return engine_->world_size(); }
+    bool has_rccl() const { return engine_->has_rccl(); }
+    std::vector<int> exchange_errors() {
+        std::vector<int> e(ranks_.size());
+        engine_->device_foreach([&](int r) { e[r] = engine_->exchange_errors(r); });
+        return e;
+    }
+    void load(const std::map<std::string, py::array>& arrays, const std::string& prefix) {
+        std::map<std::string, const Tensor> sd;
+        for (auto& kv : arrays) sd.emplace(kv.first, host_tensor(kv.second, kv.first));
+        engine_->device_foreach([&](int r) { ranks_[r].model->load_state_dict(*ranks_[r].ctx, sd, prefix, false); });
+    }
+    // task b, every layer: k / v (num_layers, n, hkv, d) -- ALL kv heads; every rank keeps its hkv / world heads in rows 0 .. n - 1
+    void set_history(int b, int len_buf, const py::array& k, const py::array& v) {
+        Tensor hk = host_tensor(k, "k"), hv = host_tensor(v, "v");
+        BM_ASSERT(hk.ndim() == 4 && hk.shape() == hv.shape() && hk.dtype() == DataType::kHalf, "history: (layers, n, hkv, d) fp16");
+        const size_t layers = hk.size(0), n = hk.size(1), hkv = hk.size(2), d = hk.size(3), world = ranks_.size();
+        BM_ASSERT(hkv % world == 0, "kv heads must divide by the world size");
+        const size_t local = hkv / world;
+        engine_->device_foreach([&](int r) {
+            Rank& R = ranks_[r];
+            auto rag = R.ctx->rag_buffer();
+            rag->resize_task_buf(*R.ctx, b, (size_t)len_buf);
+            for (size_t l = 0; l < layers && n > 0; ++l) {
+                const char* sk = hk.data<char>() + ((l * n * hkv) + (size_t)r * local) * d * 2;
+                const char* sv = hv.data<char>() + ((l * n * hkv) + (size_t)r * local) * d * 2;
+                BM_CUDART_ASSERT(hipMemcpy2D(rag->buf_k(b)[(int)l].data(), local * d * 2, sk, hkv * d * 2, local * d * 2, n, hipMemcpyHostToDevice));
+                BM_CUDART_ASSERT(hipMemcpy2D(rag->buf_v(b)[(int)l].data(), local * d * 2, sv, hkv * d * 2, local * d * 2, n, hipMemcpyHostToDevice));
+            }
+        });
+    }
+    // one decode step of the whole model on every rank: tokens (B) int32 at positions (B) -> the ranks' logits (world, B, vocab)
+    py::array decode_step(const py::array& tokens, const py::array& positions, const py::array& mask) {
+        const size_t B = (size_t)tokens.shape(0), world = ranks_.size(), vocab = (size_t)cfg_.vocab_size;
+        Tensor ht = host_tensor(tokens, "s_token"), hp = host_tensor(positions, "s_position"), hm = host_tensor(mask, "s_mask");
+        std::vector<std::vector<uint16_t>> out(world, std::vector<uint16_t>(B * vocab));
+        engine_->device_foreach([&](int r) {
+            Rank& R = ranks_[r];
+            model::ModelContext& ctx = *R.ctx;
+            auto rag = ctx.rag_buffer();
+            auto dyn = std::make_shared<model::DynBatchContext>();
+            dyn->s_token = upload(ctx, ht);
+            dyn->s_position = upload(ctx, hp);
+            dyn->s_placement = upload(ctx, hp).view({B, 1});
+            dyn->s_mask = upload(ctx, hm);
+            for (size_t b = 0; b < B; ++b) dyn->sv_len_buf.push_back((int)rag->get_buf_len(b));
+            dyn->s_len_buf = ctx.tensor_of(dyn->sv_len_buf);
+            ctx.set_dyn_batch(dyn);
+            rag->set_buffer_addr(ctx);
+            Tensor none;
+            Tensor hidden = R.model->encode(ctx, dyn->s_token, dyn->s_position, none, none, none, none, none, true);
+            Tensor logits = R.model->get_logits(ctx, hidden, false);
+            BM_ASSERT_EQ(logits.numel(), B * vocab, "logits (B, vocab)");
+            logits.to_buffer(out[r].data(), ctx.current_cuda_stream());
+            ctx.set_dyn_batch(nullptr);
+        });
+        return stack(out, B, vocab);
+    }
+    // the prompt of task b through the whole model on every rank -> the ranks' logits of its last token (world, 1, vocab)
+    py::array prefill(int b, int len_buf, const py::array& tokens, int pos0) {
+        const size_t n = (size_t)tokens.shape(0), world = ranks_.size(), vocab = (size_t)cfg_.vocab_size;
+        Tensor ht = host_tensor(tokens, "e_token");
+        std::vector<int> pos(n);
+        for (size_t i = 0; i < n; ++i) pos[i] = pos0 + (int)i;
+        std::vector<int8_t> mask(n * (size_t)len_buf);
+        for (size_t i = 0; i < n; ++i)
+            for (int j = 0; j < len_buf; ++j) mask[i * len_buf + j] = j <= pos0 + (int)i;
+        std::vector<std::vector<uint16_t>> out(world, std::vector<uint16_t>(vocab));
+        engine_->device_foreach([&](int r) {
+            Rank& R = ranks_[r];
+            model::ModelContext& ctx = *R.ctx;
+            ctx.rag_buffer()->resize_task_buf(ctx, b, (size_t)len_buf);
+            auto dyn = std::make_shared<model::DynBatchContext>();
+            dyn->e_token = upload(ctx, ht);
+            dyn->e_placement = ctx.tensor_of(pos);
+            dyn->e_position = ctx.tensor_of(pos);
+            dyn->e_mask = ctx.tensor_of(mask);
+            dyn->ev_batch = {b};
+            dyn->ev_input_len = {(int)n};
+            dyn->full_input_len = {pos0 + (int)n};
+            dyn->ev_len_buf = {len_buf};
+            ctx.set_dyn_batch(dyn);
+            Tensor none;
+            Tensor hidden = R.model->encode(ctx, dyn->e_token, dyn->e_position, none, none, none, none, none, true);
+            Tensor logits = R.model->get_logits(ctx, hidden.slice_dim0(n - 1, n), false);
+            BM_ASSERT_EQ(logits.numel(), vocab, "logits (1, vocab)");
+            logits.to_buffer(out[r].data(), ctx.current_cuda_stream());
+            ctx.set_dyn_batch(nullptr);
+        });
+        return stack(out, 1, vocab);
+    }
+    // rank r's K rows of task b in `layer`: (len_buf, hkv / world, d)
+    py::array get_k(int r, int b, int layer) {
+        std::vector<uint16_t> host;
+        std::vector<size_t> shape;
+        engine_->run(r, [&] {
+            const Tensor& t = ranks_[r].ctx->rag_buffer()->buf_k(b, layer);
+            shape = t.shape();
+            host.resize(t.numel());
+            t.to_buffer(host.data(), ranks_[r].ctx->current_cuda_stream());
+        });
+        py::array out(py::dtype("float16"), std::vector<py::ssize_t>(shape.begin(), shape.end()));
+        std::memcpy(out.mutable_data(), host.data(), host.size() * 2);
+        return out;
+    }
+
+private:
+    struct Rank {
+        std::unique_ptr<model::ModelContext> ctx;
+        std::unique_ptr<model::LLaMA> model;
+    };
+    static Tensor upload(const Context& ctx, const Tensor& host) {
+        Tensor d = ctx.tensor(host.shape(), host.dtype());
+        d.from_buffer(host.data(), false, ctx.current_cuda_stream());
+        return d;
+    }
+    static py::array stack(const std::vector<std::vector<uint16_t>>& out, size_t rows, size_t vocab) {
+        py::array res(py::dtype("float16"), std::vector<py::ssize_t>{(py::ssize_t)out.size(), (py::ssize_t)rows, (py::ssize_t)vocab});
+        for (size_t r = 0; r < out.size(); ++r) std::memcpy((char*)res.mutable_data() + r * rows * vocab * 2, out[r].data(), rows * vocab * 2);
+        return res;
+    }
+    model::ModelConfig cfg_;
+    DummyModel md_;
+    std::unique_ptr<bmengine::core::Engine> engine_;
+    std::vector<Rank> ranks_;
+};
+
 }  // namespace
 
 void bind_ref_model(py::module_& m) {
@@ -347,4 +424,16 @@ void bind_ref_model(py::module_& m) {
         .def("decode_step", &RefLLaMA::decode_step)
         .def("time_decode_steps", &RefLLaMA::time_decode_steps, py::arg("tokens"), py::arg("positions"), py::arg("mask"), py::arg("warmup") = 3,
              py::arg("iters") = 20, py::arg("graph") = true);
+    py::class_<RefEngineLLaMA>(m, "RefEngineLLaMA")
+        .def(py::init<int, int, int, int, int, int, int, float, float, int, int, const std::vector<int>&>(), py::arg("num_layers"), py::arg("dim_model"),
+             py::arg("num_heads"), py::arg("num_kv_heads"), py::arg("dim_head"), py::arg("dim_ff"), py::arg("vocab_size"), py::arg("eps") = 1e-5f,
+             py::arg("rope_theta") = 10000.0f, py::arg("quant_type") = 5, py::arg("group_size") = 128, py::arg("devices") = std::vector<int>{0, 0})
+        .def("world_size", &RefEngineLLaMA::world_size)
+        .def("has_rccl", &RefEngineLLaMA::has_rccl)
+        .def("exchange_errors", &RefEngineLLaMA::exchange_errors)
+        .def("load", &RefEngineLLaMA::load)
+        .def("set_history", &RefEngineLLaMA::set_history)
+        .def("prefill", &RefEngineLLaMA::prefill, py::arg("b"), py::arg("len_buf"), py::arg("tokens"), py::arg("pos0") = 0)
+        .def("get_k", &RefEngineLLaMA::get_k)
+        .def("decode_step", &RefEngineLLaMA::decode_step);
 }

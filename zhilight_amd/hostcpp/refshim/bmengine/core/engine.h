@@ -1,2 +1,3 @@
 #pragma once
 #include "bm_layer.h"
+#include "bm_engine.h"

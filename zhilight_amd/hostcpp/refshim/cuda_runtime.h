@@ -35,3 +35,6 @@ typedef __half half;
 #define cudaEventDefault hipEventDefault
 #define cudaEventQuery hipEventQuery
 #define cudaErrorNotReady hipErrorNotReady
+#define cudaMemcpyPeer hipMemcpyPeer
+#define cudaGetDevice hipGetDevice
+#define cudaSetDevice hipSetDevice

@@ -1,14 +1,8 @@
-// ref_glue.cpp -- what is linked next to the REFERENCE's own src/nn/linear/linear.cpp (compiled unmodified from
-// /root/reference against hostcpp/refshim + bm_hip.h / bm_layer.h / bm_functions.h, see zhilight_amd/build.py:
-// build_refcompile) to turn it into a loadable test module:
-//   1. the names that translation unit references but that are OFF this boundary (Marlin, FP8 block / DeepGEMM, the
-//      GPTQ_KERNEL_ALGO=0 kernels): definitions that throw, so the object links and a call says what is missing;
-//   2. the out-of-line virtuals of model::ModelContext (src/model/model_context.h:77-215) -- linear.cpp only
-//      dynamic_casts to it, which needs its typeinfo; no ModelContext is ever constructed here;
-//   3. a pybind11 module driving nn::Linear (the reference's class, the reference's code) on host numpy arrays:
-//      construct -> load_state_dict -> forward, for the GPTQ (Int4GPTQ), INT8 (Int8Linear) and unquantised (NormalLinear)
-//      flavours.  tests/test_gpu_refcompile.py compares the results with the oracle.
-// Test infrastructure: nothing in the product links this file.
+// ref_glue.cpp -- the pybind11 TEST module zl_reflinear: the reference's own host translation units (compiled unmodified from
+// /root/reference into libzhilight_amd_host.so, zhilight_amd/build.py: build_host) driven from numpy.  This file: nn::Linear (the
+// reference's class, the reference's code: construct -> load_state_dict -> forward) for the GPTQ (Int4GPTQ), INT8 (Int8Linear),
+// FP8-block and unquantised flavours; ref_attention_glue.cpp / ref_block_glue.cpp / ref_model_glue.cpp add the layers above it.
+// tests/test_gpu_refcompile.py compares the results with the oracle.  Test infrastructure: nothing in the product links this file.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -28,46 +22,7 @@ size_t amd_weight_cache_size();
 }  // namespace gptq
 }  // namespace nn
 
-#define ZL_OFF_BOUNDARY(what) \
-    throw BMEngineException(std::string(what) + " is not on the MI355X hot-path boundary (SURVEY.md section 8: out of scope)", __FILE__, __LINE__, __func__)
-
-// ---- 1. off-boundary names -------------------------------------------------------------------------------------------
-core::Tensor gptq_marlin_repack(const core::Context&, core::Tensor&, core::Tensor&, size_t, size_t, int64_t) { ZL_OFF_BOUNDARY("gptq_marlin_repack"); }
-core::Tensor gptq_marlin_gemm(const core::Context&, const core::Tensor&, core::Tensor&, core::Tensor&, core::Tensor&, core::Tensor&,
-                              core::Tensor&, core::Tensor&, size_t, size_t, size_t, bool, bool, bool) {
-    ZL_OFF_BOUNDARY("gptq_marlin_gemm");
-}
-namespace nn {
-namespace gptq {
-core::Tensor gptq_gemm(const core::Context&, core::Tensor, core::Tensor, core::Tensor, core::Tensor, core::Tensor, bool, int, int, int) {
-    ZL_OFF_BOUNDARY("nn::gptq::gptq_gemm (GPTQ_KERNEL_ALGO=0; the k-major kernels are the default)");
-}
-void reconstruct_exllama(const uint32_t*, const uint32_t*, const half*, const int*, half*, int, int, int, const cudaStream_t, int, int) {
-    ZL_OFF_BOUNDARY("nn::gptq::reconstruct_exllama (use dequant_k_major)");
-}
-void reconstruct_gptq(const uint32_t*, const uint32_t*, const half*, const int*, half*, int, int, int, const cudaStream_t) {
-    ZL_OFF_BOUNDARY("nn::gptq::reconstruct_gptq (use dequant_k_major)");
-}
-}  // namespace gptq
-}  // namespace nn
-// deep_gemm_fp8_block_h20_group (3rd/deep_gemm/deep_gemm_api.h): the closed DeepGEMM entry point Fp8Block::forward / grouped_gemm call
-// (the reference TU is compiled with -DENABLE_DS_DEEP_GEMM here) = this boundary's block-scaled FP8 GEMM.  The C signature carries
-// neither aligned_m nor the output type: aligned_m = round_up(m, 4) (per_token_cast_to_fp8), output bf16 (DeepGEMM's only one).
-extern "C" int deep_gemm_fp8_block_h20_group(void* lhs, void* lhs_scales, void* rhs, void* rhs_scales, void* out, void* grouped_layout,
-                                             void* stream, int m, int n, int k, int /*block_m*/, int num_groups) {
-    const int st = zl_fp8_block_gemm_group((const uint8_t*)lhs, (const float*)lhs_scales, (m + 3) / 4 * 4, (const uint8_t*)rhs,
-                                           (const float*)rhs_scales, (const int32_t*)grouped_layout, (uint16_t*)out, m, n, k, num_groups,
-                                           ZL_BF16, (zl_stream_t)stream);
-    return st == 0 ? 0 : -1;
-}
-
-// ---- 2. model::ModelContext's key functions ------------------------------------------------------------------------------
-namespace model {
-ModelContext::~ModelContext() = default;
-Tensor ModelContext::reduce_sum(Tensor& data, DataType out_type) const { return core::Context::reduce_sum(data, out_type); }
-}  // namespace model
-
-// ---- 3. the test module ----------------------------------------------------------------------------------------------
+// ---- the test module ----------------------------------------------------------------------------------------------
 namespace py = pybind11;
 using bmengine::core::Context;
 using bmengine::core::DataType;
