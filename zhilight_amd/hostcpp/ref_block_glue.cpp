@@ -72,21 +72,47 @@ public:
     const char* layer_type() const override { return "DummyModel"; }
 };
 
-// One reference nn::EncoderLayer inside a reference ModelContext
+// One reference nn::EncoderLayer inside a reference ModelContext.
+// mla = (q_lora_rank, kv_lora_rank, qk_nope_head_dim, qk_rope_head_dim, v_head_dim): the reference builds its MLAImpl and -- under
+// LATENT_CACHE=1 -- the task buffers hold ONE (kv_lora_rank + qk_rope_head_dim)-wide latent row per key and no value buffer;
+// moe = (num_experts, top_k, moe_intermediate_size, shared_expert_intermediate_size): FeedForward picks MOEImpl / GPTQMOE / FP8BlockMOE
+// from its switches; bf16: the layer's dtype (hidden rows then travel as bf16 bits in int16 / uint16 arrays).  With all three and
+// quant_type = FP8_Block this is a DeepSeek-V3-SHAPED layer: MLAImpl over Fp8Block linears followed by FP8BlockMOE.
 class RefEncoderLayer {
 public:
     RefEncoderLayer(int dim_model, int num_heads, int num_kv_heads, int dim_head, int dim_ff, float rope_theta, float eps, int quant_type, int group_size,
-                    int device)
-        : cfg_("llama", 1, dim_model, num_heads, dim_head, dim_ff, 1024, eps, num_kv_heads, DataType::kHalf),
-          md_((cfg_.rope_theta = rope_theta, cfg_)),
-          ctx_(Context(device), md_, 1, false, true) {
+                    int device, const std::string& model_type, const std::vector<int>& mla, const std::vector<int>& moe, bool norm_topk_prob,
+                    float routed_scaling_factor, bool bf16)
+        : cfg_(make_cfg(model_type, dim_model, num_heads, num_kv_heads, dim_head, dim_ff, rope_theta, eps, mla, moe, norm_topk_prob, routed_scaling_factor, bf16)),
+          md_(cfg_),
+          ctx_(Context(device), md_, 1, false, true),
+          bf16_(bf16) {
         model::QuantConfig qc(quant_type);
         qc.group_size = group_size;
         ctx_.set_current_layer(0);
         layer_.reset(new nn::EncoderLayer(ctx_, cfg_, qc, false));
-        kvcache::KVCacheConfig kc{1, num_kv_heads, dim_head, DataType::kHalf, true, nullptr, std::vector<int>(1, device)};
-        rag_ = std::make_shared<model::RagBufferContext>(kc, kc);
+        const bool latent = cfg_.kv_lora_rank > 0 && ctx_.latent_cache();
+        BM_ASSERT(cfg_.kv_lora_rank == 0 || latent, "RefEncoderLayer: the MLA layer runs over the compressed cache here (LATENT_CACHE=1)");
+        kvcache::KVCacheConfig kc{1, latent ? 1 : num_kv_heads, latent ? cfg_.kv_lora_rank + cfg_.qk_rope_head_dim : dim_head, cfg_.dtype, true, nullptr,
+                                  std::vector<int>(1, device)};
+        kvcache::KVCacheConfig vc = kc;
+        if (latent) vc.dim_head = 0;
+        rag_ = std::make_shared<model::RagBufferContext>(kc, vc);
         ctx_.set_rag_buffer(rag_);
+    }
+    static model::ModelConfig make_cfg(const std::string& model_type, int dim_model, int num_heads, int num_kv_heads, int dim_head, int dim_ff, float rope_theta,
+                                       float eps, const std::vector<int>& mla, const std::vector<int>& moe, bool norm_topk_prob, float routed_scaling_factor,
+                                       bool bf16) {
+        model::ModelConfig c(model_type, 1, dim_model, num_heads, dim_head, dim_ff, 1024, eps, num_kv_heads, bf16 ? DataType::kBFloat16 : DataType::kHalf);
+        c.rope_theta = rope_theta;
+        if (mla.size() == 5 && mla[1] > 0) {
+            c.q_lora_rank = mla[0]; c.kv_lora_rank = mla[1]; c.qk_nope_head_dim = mla[2]; c.qk_rope_head_dim = mla[3]; c.v_head_dim = mla[4];
+        }
+        if (moe.size() == 4 && moe[0] > 0) {
+            c.moe_num_experts = moe[0]; c.moe_top_k = moe[1]; c.moe_intermediate_size = moe[2]; c.shared_expert_intermediate_size = moe[3];
+            c.norm_topk_prob = norm_topk_prob; c.routed_scaling_factor = routed_scaling_factor;
+        }
+        return c;
     }
     void load(const std::map<std::string, py::array>& arrays, const std::string& prefix) {
         std::map<std::string, const Tensor> sd;
@@ -96,11 +122,12 @@ public:
     void set_history(int b, int len_buf, const py::array& k, const py::array& v) {
         rag_->resize_task_buf(ctx_, b, (size_t)len_buf);
         fill(rag_->buf_k(b)[0], k);
-        fill(rag_->buf_v(b)[0], v);
+        if (rag_->config_v_.dim_head > 0) fill(rag_->buf_v(b)[0], v);
     }
-    py::array get_k(int b) { return to_numpy(ctx_, rag_->buf_k(b, 0)); }
-    py::array get_v(int b) { return to_numpy(ctx_, rag_->buf_v(b, 0)); }
-    // one decode step: hidden (B, dim_model) fp16 -> the layer's output (B, dim_model)
+    py::array get_k(int b) { return out_array(rag_->buf_k(b, 0)); }
+    py::array get_v(int b) { return out_array(rag_->buf_v(b, 0)); }
+    bool latent_cache() { return ctx_.latent_cache(); }
+    // one decode step: hidden (B, dim_model) fp16 (bf16 layer: the bits as int16 / uint16) -> the layer's output (B, dim_model), likewise
     py::array decode_step(const py::array& hidden, const py::array& positions, const py::array& placement, const py::array& mask) {
         const size_t B = (size_t)hidden.shape(0);
         auto dyn = std::make_shared<model::DynBatchContext>();
@@ -113,15 +140,29 @@ public:
         ctx_.set_current_layer(0);
         rag_->set_buffer_addr(ctx_);
         Tensor x = to_device(ctx_, hidden, "hidden");
+        if (bf16_) {
+            BM_ASSERT(x.dtype() == DataType::kInt16, "bf16 layer: hidden rows as int16 / uint16 bits");
+            x = x.view_type(x.shape(), DataType::kBFloat16);
+        }
         Tensor none;
         Tensor y = layer_->forward(ctx_, x, none, dyn->s_position, none, none, nullptr, nullptr, nullptr, nullptr);
-        py::array out = to_numpy(ctx_, y);
+        py::array out = out_array(y);
         ctx_.set_dyn_batch(nullptr);
         return out;
     }
 
 private:
+    py::array out_array(const Tensor& t) {
+        if (t.dtype() == DataType::kBFloat16) {
+            std::vector<py::ssize_t> shape(t.shape().begin(), t.shape().end());
+            py::array out(py::dtype("uint16"), shape);
+            t.to_buffer(out.mutable_data(), ctx_.current_cuda_stream());
+            return out;
+        }
+        return to_numpy(ctx_, t);
+    }
     void fill(Tensor& dst, const py::array& src) {
+        if (src.nbytes() == 0) return;
         Tensor h = host_tensor(src, "history");
         BM_ASSERT(h.nbytes() <= dst.nbytes(), "history rows: (n, hkv, d) into a BSHD buffer");
         BM_CUDART_ASSERT(hipMemcpy(dst.data(), h.data(), h.nbytes(), hipMemcpyHostToDevice));
@@ -129,6 +170,7 @@ private:
     model::ModelConfig cfg_;
     DummyModel md_;
     model::ModelContext ctx_;
+    bool bf16_;
     std::unique_ptr<nn::EncoderLayer> layer_;
     std::shared_ptr<model::RagBufferContext> rag_;
 };
@@ -186,9 +228,12 @@ void bind_ref_block(py::module_& m) {
         .def("load", &RefFeedForward::load)
         .def("forward", &RefFeedForward::forward);
     py::class_<RefEncoderLayer>(m, "RefEncoderLayer")
-        .def(py::init<int, int, int, int, int, float, float, int, int, int>(), py::arg("dim_model"), py::arg("num_heads"), py::arg("num_kv_heads"),
+        .def(py::init<int, int, int, int, int, float, float, int, int, int, const std::string&, const std::vector<int>&, const std::vector<int>&, bool, float, bool>(),
+             py::arg("dim_model"), py::arg("num_heads"), py::arg("num_kv_heads"),
              py::arg("dim_head"), py::arg("dim_ff"), py::arg("rope_theta") = 10000.0f, py::arg("eps") = 1e-5f, py::arg("quant_type") = 5,
-             py::arg("group_size") = 128, py::arg("device") = 0)
+             py::arg("group_size") = 128, py::arg("device") = 0, py::arg("model_type") = "llama", py::arg("mla") = std::vector<int>(),
+             py::arg("moe") = std::vector<int>(), py::arg("norm_topk_prob") = true, py::arg("routed_scaling_factor") = 1.0f, py::arg("bf16") = false)
+        .def("latent_cache", &RefEncoderLayer::latent_cache)
         .def("load", &RefEncoderLayer::load)
         .def("set_history", &RefEncoderLayer::set_history)
         .def("get_k", &RefEncoderLayer::get_k)
