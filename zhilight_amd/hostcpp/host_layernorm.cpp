@@ -27,7 +27,21 @@ public:
         check(x);
         BM_ASSERT(x.ndim() == 2 && out.ndim() == 2 && x.stride(1) == 1 && out.stride(1) == 1 && out.size(0) == x.size(0) && out.size(1) == x.size(1),
                   "LayerNorm::forward_2: (rows, dim) operands, dense last dimension");
-        BM_ASSERT(scale == 1.0f && dim_model <= 1024, "LayerNorm::forward_2: scale 1, dim <= 1024");
+        BM_ASSERT(scale == 1.0f, "LayerNorm::forward_2: scale 1");
+        if (dim_model > 1024) {
+            // wider than the per-head kernel serves (DeepSeek-V3's q_lora_rank = 1536): the rows are gathered dense, normed by the row
+            // kernel and -- a strided output -- scattered back
+            const size_t rows = x.size(0), wb = (size_t)dim_model * 2;
+            zl_stream_t st = (zl_stream_t)ctx.current_cuda_stream();
+            core::Tensor dense = ctx.tensor({rows, (size_t)dim_model}, x.dtype());
+            ZL_CK(zl_copy_2d(x.data(), x.stride(0) * 2, dense.data(), wb, wb, rows, st), "copy_2d(gather rows)");
+            const bool direct = out.stride(0) == (size_t)dim_model;
+            core::Tensor normed = direct ? out : ctx.tensor({rows, (size_t)dim_model}, x.dtype());
+            ZL_CK(zl_rmsnorm(dense.data<uint16_t>(), weight.data<uint16_t>(), normed.data<uint16_t>(), rows, dim_model, eps, 1.0f, nullptr, nullptr, zdt(x), st),
+                  "rmsnorm(rows)");
+            if (!direct) ZL_CK(zl_copy_2d(normed.data(), wb, out.data(), out.stride(0) * 2, wb, rows, st), "copy_2d(scatter rows)");
+            return;
+        }
         ZL_CK(zl_head_norm(x.data<uint16_t>(), weight.data<uint16_t>(), out.data<uint16_t>(), x.size(0), 1, dim_model, x.stride(0), out.stride(0), eps, 0, zdt(x),
                            (zl_stream_t)ctx.current_cuda_stream()), "head_norm(rows)");
     }
