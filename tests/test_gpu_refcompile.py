@@ -1017,12 +1017,14 @@ def test_reference_deepseek_v3_shaped_layer(dev):
 @pytest.mark.skipif(os.environ.get("ZL_REFDS_CHILD") != "1", reason="runs inside test_reference_deepseek_v3_shaped_layer's child process")
 def test_reference_deepseek_child(ref, oracle):
     """Three decode tasks with ragged compressed caches, two steps, against _DeepSeekLayerOracle.  The bar: an FP8 pipeline amplifies
-    one-ulp differences of a bf16 intermediate (the fp8 MFMA's accumulation floor moves ~7 % of a GEMM's outputs by one bf16 ulp
-    against the exact sum, tests/test_gpu_f4.py::_gemm_bar) into e4m3 code flips of the next per-token cast (6-12 % of THAT element),
-    ~0.6 % rms per Fp8Block stage by that arithmetic; seven stages deep the branch outputs may differ by a few percent rms while a
-    wrong flow differs by O(1).  Asserted: rms error <= 3e-2 of the rms of what the layer ADDS to its input, max error <= 8e-2 of its
-    max, routing margins far above the logit noise, the latent rows within one bf16 rounding; the measured errors are written to
-    gpurun_out/ for DESIGN.md."""
+    one-ulp differences of a bf16 intermediate (the fp8 MFMA's accumulation floor moves a few percent of a GEMM's outputs by one bf16
+    ulp against the exact sum, tests/test_gpu_f4.py::_gemm_bar) into e4m3 code flips of the next per-token cast -- the block's
+    amax moves, 6-12 % steps of single elements -- so that seven Fp8Block stages deep the branch outputs differ by a few percent rms
+    while a wrong flow differs by O(1).  That floor is MEASURED on the oracle itself: moving 3 % / 7 % / 15 % of every Fp8Block
+    output by one bf16 ulp changes what the layer adds to its input by 2.9e-2 / 3.2e-2 / 3.5e-2 rms
+    (tests/test_oracle_deepseek_layer.py); the GPU sits at 2.8e-2 rms / 4.0e-2 max (profiles/r05_deepseek_layer_parity.json).
+    Asserted: rms error <= 5e-2 of the rms of what the layer ADDS to its input, max error <= 1e-1 of its max, routing margins far
+    above the logit noise, the latent rows within one bf16 rounding plus the same floor; the measured errors go to gpurun_out/."""
     import json
     rng = np.random.default_rng(4)              # (a draw whose routing margins -- 0.94 and 3.3 logit units -- sit far above the logit noise)
     dm, H, ql, kvl, nope, rp, vd, e, k, shared, inter = _DS_DIMS
@@ -1060,7 +1062,7 @@ def test_reference_deepseek_child(ref, oracle):
             got_row, want_row = om.f(stored[pos[b], 0]), om.f(row[b])
             assert np.abs(got_row - want_row).max() <= 2.0 ** -7 * np.abs(want_row).max() + 2e-2 * np.sqrt((want_row ** 2).mean()), (step, b)
             hist[b] = np.concatenate([hist[b], stored[pos[b]].reshape(1, -1).view(np.uint16)], axis=0)      # the next step attends over the layer's own rows
-        assert rms_rel <= 3e-2 and max_rel <= 8e-2, record
+        assert rms_rel <= 5e-2 and max_rel <= 1e-1, record
         pos = pos + 1
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)

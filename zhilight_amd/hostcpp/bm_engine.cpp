@@ -59,6 +59,7 @@ public:
         hipStream_t setup_stream = nullptr;
         MemoryAllocator allocator;
         std::unique_ptr<TaskThreadPool> thread;
+        int share_index = 0;          // how many lower ranks sit on the same device
     };
     std::vector<Rank> ranks;
     bool rccl = false;
@@ -132,6 +133,8 @@ Engine::Engine(const std::vector<DeviceConfiguration>& dev_cfg, const DistConfig
         distinct.insert(dev_cfg[r].device_id);
     }
     const bool all_distinct = (int)distinct.size() == world;
+    for (int r = 0; r < world; ++r)
+        for (int p = 0; p < r; ++p) pimpl->ranks[r].share_index += pimpl->ranks[p].device == pimpl->ranks[r].device;
     pimpl->rccl = world > 1 && all_distinct && env_i64("ZL_ENGINE_RCCL", 1) != 0;
     pimpl->oneshot_bytes = std::max<int64_t>(4096, env_i64("ZL_ENGINE_ONESHOT_BYTES", 8 << 20)) / 16 * 16;
     EngineImpl* impl = pimpl.get();
@@ -142,7 +145,9 @@ Engine::Engine(const std::vector<DeviceConfiguration>& dev_cfg, const DistConfig
         if (world == 1) return;
         EN_CK(zl_ar_alloc(zl_ar_buffer_bytes(impl->oneshot_bytes), &R.ar_buffer), "exchange buffer");
         BM_HIPRT_ASSERT(hipMalloc(&R.ar_state, (size_t)zl_ar_state_bytes()));
-        BM_HIPRT_ASSERT(hipMemset(R.ar_state, 0, (size_t)zl_ar_state_bytes()));
+        // zeroed on the stream zl_ar_init writes the state on (a null-stream memset would be unordered against that non-blocking stream)
+        BM_HIPRT_ASSERT(hipMemsetAsync(R.ar_state, 0, (size_t)zl_ar_state_bytes(), R.setup_stream));
+        BM_HIPRT_ASSERT(hipStreamSynchronize(R.setup_stream));
         if (all_distinct)
             for (int p = 0; p < world; ++p) {
                 if (p == r) continue;
@@ -237,6 +242,23 @@ Context Engine::create_context_rank(int rank) const {
     BM_ASSERT(rank >= 0 && rank < world, "Engine::create_context_rank: rank out of range");
     Context ctx(impl->ranks[rank].device, rank, world);
     if (world == 1) return ctx;
+    bool shared_device = false;
+    for (int p = 0; p < world; ++p) shared_device |= p != rank && impl->ranks[p].device == impl->ranks[rank].device;
+    if (shared_device) {
+        // Ranks that share a device exchange through kernels that WAIT for each other inside a launch: their streams must sit on
+        // different hardware queues, or one rank's waiting kernel blocks the peer's kernel queued behind it until the bounded wait
+        // expires (measured: whole steps timing out alternately on either rank whenever the runtime's round-robin put both streams on
+        // one of its 4 queues, gpurun_out/r16_diag_tp.log).  The runtime keeps one queue pool per stream PRIORITY, so ranks of one
+        // device get streams of different priorities -- as many ranks per device as there are priority levels.
+        int least = 0, greatest = 0;
+        BM_HIPRT_ASSERT(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int levels = least - greatest + 1;
+        BM_ASSERT(impl->ranks[rank].share_index < levels,
+                  "Engine: more ranks share one device than the runtime has stream priority levels (use one process per rank there)");
+        hipStream_t s = nullptr;
+        BM_HIPRT_ASSERT(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest + impl->ranks[rank].share_index));
+        ctx.set_current_stream(std::make_shared<Stream_>(s, [](hipStream_t p) { (void)hipStreamDestroy(p); }));
+    }
     const int r = rank;
     c10d::Collectives c;
     c.comm_count = world;
