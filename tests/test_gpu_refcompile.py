@@ -933,8 +933,24 @@ class _DeepSeekLayerOracle:
         g, u = self.lin(x_bits, prefix + ".w_in"), self.lin(x_bits, prefix + ".w_gated")
         return self.lin(self.o.silu_mul(g, u, dtype=1), prefix + ".w_out")
 
-    def step(self, x_bits, pos, hist):
-        """x_bits (B, dm) bf16 bits, pos (B,), hist: per task (n, kvl + rp) bits -> (out bits (B, dm), latent rows (B, kvl + rp), router margin)"""
+    def shared_partial(self, x_bits, r, world):
+        """rank r's partial of the tensor-parallel shared expert: its dim_ff / world rows of w_in | w_gated, the matching columns of w_out"""
+        sp = self.shared // world
+        def rows(name):
+            c, sw = self.W[name]
+            return c[r * sp:(r + 1) * sp], sw[r * sp // 128:(r + 1) * sp // 128]
+        def cast_gemm(a_bits, c, sw):
+            a8, sa = self.o.fp8_per_token_cast(a_bits, dtype=1)
+            return self.o.fp8_block_gemm(a8, sa, np.ascontiguousarray(c), np.ascontiguousarray(sw), dtype=1)
+        g, u = cast_gemm(x_bits, *rows("ff.shared_expert.w_in")), cast_gemm(x_bits, *rows("ff.shared_expert.w_gated"))
+        c, sw = self.W["ff.shared_expert.w_out"]
+        return cast_gemm(self.o.silu_mul(g, u, dtype=1), c[:, r * sp:(r + 1) * sp], sw[:, r * sp // 128:(r + 1) * sp // 128])
+
+    def step(self, x_bits, pos, hist, world=1):
+        """x_bits (B, dm) bf16 bits, pos (B,), hist: per task (n, kvl + rp) bits -> (out bits (B, dm), latent rows (B, kvl + rp), router margin).
+        world > 1: the sharding of ATTN_DATA_PARALLEL=1 + MOE_EXP_PARALLEL=1 -- attention per task on one rank at full width (the
+        layer's reduce adds zeros: the world-1 values), experts e % world == rank summed per rank into a bf16 partial, the shared expert
+        tensor-parallel (dim_ff split) added to the rank's partial, the partials summed in fp32 in rank order and rounded once."""
         o, B, H = self.o, x_bits.shape[0], self.H
         h = o.rmsnorm(x_bits, self.W["ln_attn"], self.eps, dtype=1)
         qa, kva = self.lin(h, "attn.q_a_proj"), self.lin(h, "attn.kv_a_proj_with_mqa")
@@ -962,15 +978,26 @@ class _DeepSeekLayerOracle:
         wts = (wts / wts.sum(axis=1, keepdims=True)).astype(np.float32)
         srt = np.sort(logits.astype(np.float64), axis=1)
         margin = float((srt[:, -self.k] - srt[:, -self.k - 1]).min())              # gap between the last chosen and the first rejected expert
-        y = np.zeros((B, self.dm), np.uint16)
-        for t in range(B):
-            acc = np.zeros(self.dm, np.float32)
-            for s in range(self.k):
-                d = self.ffn(xn[t:t + 1], f"ff.experts.{int(ids[t, s])}")
-                acc = (acc.astype(np.float64) + self.f(d)[0] * np.float64(wts[t, s])).astype(np.float32)   # one fma per term, fp32 accumulator
-            y[t] = self.bf(acc)
-        if self.shared:
-            y = o.element_add_scale(y, self.ffn(xn, "ff.shared_expert"), 1.0, True, dtype=1)
+        parts = []
+        for r in range(world):
+            y = np.zeros((B, self.dm), np.uint16)
+            for t in range(B):
+                acc = np.zeros(self.dm, np.float32)
+                for s in range(self.k):
+                    if int(ids[t, s]) % world != r:
+                        continue
+                    d = self.ffn(xn[t:t + 1], f"ff.experts.{int(ids[t, s])}")
+                    acc = (acc.astype(np.float64) + self.f(d)[0] * np.float64(wts[t, s])).astype(np.float32)   # one fma per term, fp32 accumulator
+                y[t] = self.bf(acc)
+            if self.shared:
+                y = o.element_add_scale(y, self.ffn(xn, "ff.shared_expert") if world == 1 else self.shared_partial(xn, r, world), 1.0, True, dtype=1)
+            parts.append(y)
+        y = parts[0]
+        if world > 1:
+            acc = np.zeros((B, self.dm), np.float32)
+            for part in parts:
+                acc = (acc + o.bf16_to_f32(part)).astype(np.float32)                 # the exchange: fp32 sum in rank order, one rounding
+            y = self.bf(acc)
         return o.element_add_scale(h1, y, 1.0, True, dtype=1), row, margin
 
 
@@ -1068,4 +1095,79 @@ def test_reference_deepseek_child(ref, oracle):
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "deepseek_layer_parity.json"), "w") as fh:
         json.dump(record, fh, indent=1)
+    ref.weight_cache_clear()
+
+
+def test_reference_deepseek_v3_shaped_layer_sharded_two_ranks(dev):
+    """Config 5's SHARDING on one device (VERDICT r04 missing 1a / 1c): the same DeepSeek-V3-shaped layer at world size 2 on the
+    engine -- ATTN_DATA_PARALLEL=1: MLAImpl::forward_compressed_dp_v1 (multi_head_latent_attention.cpp:1097-1232: replicated
+    compressed cache, decode tasks dealt to the ranks, full-width projections split / kept by on_load's split_out / split_in, FlashMLA
+    binding per task) and MOE_EXP_PARALLEL=1: experts e % 2 == rank, tensor-parallel shared expert, route's broadcasts -- every
+    exchange on the engine's one-shot transport.  The switches are read once per process: a child process."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LATENT_CACHE="1", FUSE_ATTN_SEARCH="1", GROUPED_FP8_GEMM="1", MOE_EXP_PARALLEL="1", ATTN_DATA_PARALLEL="1", USE_FLASH_MLA="1",
+               ZL_REFDS2_CHILD="1")
+    code = ("import sys, os; sys.path.insert(0, os.path.join(%r, 'tests')); import pytest; "
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', os.path.join(%r, 'tests', 'test_gpu_refcompile.py'), '-k', 'deepseek_sharded_child']))") % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(os.environ.get("ZL_REFDS2_CHILD") != "1", reason="runs inside test_reference_deepseek_v3_shaped_layer_sharded_two_ranks' child process")
+def test_reference_deepseek_sharded_child(ref, oracle):
+    """Three decode tasks (rank 0 attends for tasks 0 and 1, rank 1 for task 2), two steps: both ranks must hold bit-identical layer
+    outputs and identical latent rows, no exchange may time out, and the output sits at the FP8 pipeline's floor from
+    _DeepSeekLayerOracle's world-2 composition (bars and their derivation: test_reference_deepseek_child)."""
+    import json
+    if not hasattr(ref, "RefEngineEncoderLayer"):
+        pytest.skip("prebuilt test module without the engine harness")
+    rng = np.random.default_rng(4)
+    dm, H, ql, kvl, nope, rp, vd, e, k, shared, inter = _DS_DIMS
+    theta, eps = 1e4, 1e-6
+    W, sd = _deepseek_case(oracle, rng, _DS_DIMS)
+    layer = ref.RefEngineEncoderLayer(dm, H, H, nope + rp, 1024, rope_theta=theta, eps=eps, quant_type=10, model_type="deepseek_v2", mla=[ql, kvl, nope, rp, vd],
+                                      moe=[e, k, inter, shared], norm_topk_prob=True, routed_scaling_factor=1.0, bf16=True, devices=[0, 0])
+    assert layer.world_size() == 2
+    layer.load(sd, "l")
+    om = _DeepSeekLayerOracle(oracle, W, (dm, H, ql, kvl, nope, rp, vd, e, k, shared), theta, eps)
+    lens, bufs = [37, 150, 5], [64, 192, 64]
+    B = len(lens)
+    hist = [oracle.f32_to_bf16((rng.standard_normal((n, kvl + rp)) * 0.5).astype(np.float32)) for n in lens]
+    for b in range(B):
+        layer.set_history(b, bufs[b], np.ascontiguousarray(hist[b].reshape(lens[b], 1, kvl + rp).view(np.int16)))
+    pos = np.array(lens, np.int32)
+    record = []
+    errs0 = None
+    for step in range(2):
+        x = oracle.f32_to_bf16(synth.act(rng, B, dm).astype(np.float32))
+        mask = np.concatenate([(np.arange(bufs[b]) <= pos[b]).astype(np.int8) for b in range(B)])
+        args = (np.ascontiguousarray(x.view(np.int16)), pos, pos.copy(), mask)
+        if step == 0:
+            layer.decode_step(*args)                                  # warm-up of both rank threads (the step rewrites the same cache rows)
+            errs0 = layer.exchange_errors()
+        both = layer.decode_step(*args)
+        assert both.shape == (2, B, dm) and np.array_equal(both[0], both[1]), "the ranks' outputs differ"
+        want_bits, row, margin = om.step(x, pos, hist, world=2)
+        got, want, xin = om.f(both[0]), om.f(want_bits), om.f(x)
+        assert np.isfinite(got).all() and margin > 0.5
+        added, err = want - xin, got - want
+        rms_rel = float(np.sqrt((err ** 2).mean()) / np.sqrt((added ** 2).mean()))
+        max_rel = float(np.abs(err).max() / np.abs(added).max())
+        record.append({"step": step, "world": 2, "rms_err_over_rms_added": rms_rel, "max_err_over_max_added": max_rel, "router_margin": margin})
+        for b in range(B):
+            k0, k1 = layer.get_k(0, b), layer.get_k(1, b)
+            assert k0.shape == (bufs[b], 1, kvl + rp) and np.array_equal(k0, k1), "the replicated caches differ"
+            got_row, want_row = om.f(k0[pos[b], 0]), om.f(row[b])
+            assert np.abs(got_row - want_row).max() <= 2.0 ** -7 * np.abs(want_row).max() + 2e-2 * np.sqrt((want_row ** 2).mean()), (step, b)
+            hist[b] = np.concatenate([hist[b], k0[pos[b]].reshape(1, -1)], axis=0)
+        assert rms_rel <= 5e-2 and max_rel <= 1e-1, record
+        pos = pos + 1
+    assert layer.exchange_errors() == errs0, (errs0, layer.exchange_errors())
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "deepseek_layer_parity_world2.json"), "w") as fh:
+        json.dump(record, fh, indent=1)
+    del layer
     ref.weight_cache_clear()

@@ -109,14 +109,30 @@ public:
         BM_ASSERT(comm_dtype(dt) >= 0, "all-reduce: dtype without an RCCL type");
         EN_CK(zl_comm_all_reduce_sum(R.comm, send, recv, (int64_t)count, comm_dtype(dt), st), "ncclAllReduce");
     }
-    // a gather as the sum of the ranks' zero-padded slices (ranks sharing a device: no RCCL): adding zeros is exact (a -0.0 comes
-    // back as +0.0)
+    // Ranks that share a device have no RCCL: gathers and broadcasts are sums of zero-padded slices on the one-shot exchange (adding
+    // zeros is exact; a -0.0 comes back as +0.0).  fp16 / bf16 payloads travel as they are; ANY other payload travels byte by byte as
+    // the fp16 value of each byte's int8 reading (-128 .. 127 are exact in fp16, x + 0 is exact, the way back is exact): bit-exact
+    // for int32 routing tables and fp32 routing weights (FeedForward::route broadcasts them, feedforward.cpp:472-478).
+    void sum_bytes(int r, void* buf, size_t nbytes, hipStream_t st) const {
+        const size_t padded = (nbytes + 7) / 8 * 8;
+        void* tmp = nullptr;
+        BM_HIPRT_ASSERT(hipMallocAsync(&tmp, padded * 2, st));
+        if (padded != nbytes) BM_HIPRT_ASSERT(hipMemsetAsync(tmp, 0, padded * 2, st));
+        EN_CK(zl_cast(buf, ZL_T_I8, tmp, ZL_T_F16, (int64_t)nbytes, st), "bytes -> fp16");
+        all_reduce_sum(r, tmp, tmp, padded, DataType::kHalf, st);
+        EN_CK(zl_cast(tmp, ZL_T_F16, buf, ZL_T_I8, (int64_t)nbytes, st), "fp16 -> bytes");
+        BM_HIPRT_ASSERT(hipFreeAsync(tmp, st));
+    }
+    // recv holds this rank's contribution and zeros elsewhere -> the sum over the ranks, in place
+    void sum_padded(int r, void* recv, size_t count, DataType dt, hipStream_t st) const {
+        if (is_16bit_float(dt) && count % 8 == 0 && aligned16(recv)) all_reduce_sum(r, recv, recv, count, dt, st);
+        else sum_bytes(r, recv, count * get_elem_size(dt), st);
+    }
     void gather_by_sum(int r, const void* send, void* recv, size_t count, DataType dt, hipStream_t st) const {
         const size_t esz = get_elem_size(dt);
-        BM_ASSERT(is_16bit_float(dt), "all-gather between ranks that share a device: fp16 / bf16 only (the sum of zero-padded slices)");
         BM_HIPRT_ASSERT(hipMemsetAsync(recv, 0, count * esz * world(), st));
         BM_HIPRT_ASSERT(hipMemcpyAsync((char*)recv + (size_t)r * count * esz, send, count * esz, hipMemcpyDeviceToDevice, st));
-        all_reduce_sum(r, recv, recv, count * world(), dt, st);
+        sum_padded(r, recv, count * world(), dt, st);
     }
 };
 
@@ -287,9 +303,8 @@ Context Engine::create_context_rank(int rank) const {
             BM_ASSERT(comm_dtype(recv.dtype()) >= 0, "NCCLBroadcast: dtype without an RCCL type");
             EN_CK(zl_comm_broadcast(impl->ranks[r].comm, recv.data(), (int64_t)recv.numel(), comm_dtype(recv.dtype()), root, st), "ncclBroadcast");
         } else {
-            BM_ASSERT(is_16bit_float(recv.dtype()), "broadcast between ranks that share a device: fp16 / bf16 only (the sum with zeros)");
             if (r != root) BM_HIPRT_ASSERT(hipMemsetAsync(recv.data(), 0, recv.nbytes(), st));
-            impl->all_reduce_sum(r, recv.data(), recv.data(), recv.numel(), recv.dtype(), st);
+            impl->sum_padded(r, recv.data(), recv.numel(), recv.dtype(), st);
         }
     };
     c.reduce_scatter = [impl, r, world](const Tensor& send, Tensor& recv, ncclRedOp_t op, hipStream_t st) {

@@ -14,7 +14,9 @@
 //   * an RCCL communicator per rank (zl_comm_*: ncclCommInitRank on the rank's thread) for everything else -- created only when
 //     the ranks sit on DISTINCT devices, RCCL refuses duplicates.  Ranks that share a device (the one-GPU test box) run every
 //     collective on the one-shot transport: larger sums in pieces, gathers / broadcasts / reduce-scatters as sums of zero-padded
-//     slices (adding zeros is exact), send / recv not at all.
+//     slices (adding zeros is exact; payloads other than fp16 / bf16 travel byte by byte as exact fp16 integers), send / recv not
+//     at all.  Their contexts get streams of DIFFERENT PRIORITIES: the exchange kernels wait for each other inside a launch, and two
+//     streams of one priority may share a hardware queue, where the waiting kernel would block its peer's (bm_engine.cpp).
 // A Context stays bound to the thread that created it (bm_hip.h); create the rank's Context ON the rank's thread
 // (device_foreach, or Engine::run).
 #pragma once

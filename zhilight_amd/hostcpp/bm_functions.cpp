@@ -88,6 +88,19 @@ Tensor Gemm::forward(const Context& ctx, const Tensor& A0, const Tensor& B0, Ten
     BM_ASSERT_EQ(A.stride(-1), (size_t)1, "Gemm: the last dimension of A must be dense");
     std::vector<size_t> oshape = A.shape();
     oshape.back() = n;
+    if (output && !output->is_continuous()) {
+        // a strided (rows, n) output -- MLAImpl's data-parallel decode writes the absorbed value projection of each head straight into
+        // a (rows, heads, v_head_dim) tensor viewed head-major (multi_head_latent_attention.cpp:1203-1212): the product into a dense
+        // block, then a pitched copy of its rows
+        BM_ASSERT(output->ndim() == 2 && output->stride(1) == 1 && (int64_t)output->size(0) == m && (int64_t)output->size(1) == n,
+                  "Gemm: a strided output is (rows, n) with a dense last dimension");
+        BM_ASSERT_EQ(output->dtype(), pimpl->out_type, "Gemm: output dtype");
+        Tensor dense = ctx.tensor({(size_t)m, (size_t)n}, pimpl->out_type);
+        forward(ctx, A0, B0, &dense, bias);
+        const size_t row_bytes = (size_t)n * core::get_elem_size(pimpl->out_type);
+        zl_check(zl_copy_2d(dense.data(), row_bytes, output->data(), output->stride_bytes(0), row_bytes, m, st_of(ctx)), "Gemm (strided output rows)");
+        return *output;
+    }
     Tensor out = output ? *output : ctx.tensor(oshape, pimpl->out_type);
     BM_ASSERT_EQ(out.numel(), (size_t)(m * n), "Gemm: output shape mismatch");
     BM_ASSERT_EQ(out.dtype(), pimpl->out_type, "Gemm: output dtype");
@@ -123,6 +136,14 @@ Tensor Gemm::forward(const Context& ctx, const Tensor& A0, const Tensor& B0, Ten
 Tensor Gemm::batch_3d(const Context& ctx, const Tensor& A, const Tensor& B, Tensor* output) {
     BM_ASSERT(A.ndim() == 3 && B.ndim() == 3 && A.size(0) == B.size(0), "batch_3d: (B, M, K) x (B, N, K) or (B, K, N)");
     const size_t m = pimpl->transA ? A.size(2) : A.size(1), n = pimpl->transB ? B.size(1) : B.size(2);
+    if (output && !output->is_continuous()) {                  // (batch, m, n) with arbitrary batch / row strides: entry by entry
+        BM_ASSERT(output->ndim() == 3 && output->size(0) == A.size(0) && output->size(1) == m && output->size(2) == n, "batch_3d: output shape");
+        for (size_t b = 0; b < A.size(0); ++b) {
+            Tensor o = output->index_dim0(b);
+            forward(ctx, A.index_dim0(b), B.index_dim0(b), &o, nullptr);
+        }
+        return *output;
+    }
     Tensor out = output ? output->view({A.size(0), m, n}) : ctx.tensor({A.size(0), m, n}, pimpl->out_type);
     for (size_t b = 0; b < A.size(0); ++b) {
         Tensor o = out.index_dim0(b);

@@ -8,6 +8,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
+#include "bm_engine.h"
 #include "bmengine/functions/all.h"
 #include "model/dyn_batch_context.h"
 #include "model/model.h"
@@ -175,6 +178,137 @@ private:
     std::shared_ptr<model::RagBufferContext> rag_;
 };
 
+// The same layer TENSOR-PARALLEL on a core::Engine (one thread per rank; `devices` may repeat one device): the reference's
+// ModelContext::create on every rank's thread, EncoderLayer(parallel = true).  With the DeepSeek configuration this is config 5's
+// sharding on one box: ATTN_DATA_PARALLEL=1 -- MLAImpl::forward_compressed_dp_v1 (multi_head_latent_attention.cpp:1097-1232): the
+// compressed cache replicated, the decode tasks dealt to the ranks, full-width q_b / absorbed k / v / o projections on the rank's
+// tasks, the layer's reduce_sum assembling the rows -- or head-parallel MLA; MOE_EXP_PARALLEL=1 -- experts e % world == rank, the
+// shared expert tensor-parallel, FeedForward::route's broadcasts -- with every exchange on the engine's transports.
+class RefEngineEncoderLayer {
+public:
+    RefEngineEncoderLayer(int dim_model, int num_heads, int num_kv_heads, int dim_head, int dim_ff, float rope_theta, float eps, int quant_type, int group_size,
+                          const std::string& model_type, const std::vector<int>& mla, const std::vector<int>& moe, bool norm_topk_prob,
+                          float routed_scaling_factor, bool bf16, const std::vector<int>& devices)
+        : cfg_(RefEncoderLayer::make_cfg(model_type, dim_model, num_heads, num_kv_heads, dim_head, dim_ff, rope_theta, eps, mla, moe, norm_topk_prob,
+                                         routed_scaling_factor, bf16)),
+          md_(cfg_),
+          bf16_(bf16) {
+        std::vector<bmengine::core::DeviceConfiguration> dc;
+        for (int d : devices) dc.emplace_back(d, (size_t)0);
+        engine_.reset(new bmengine::core::Engine(dc));
+        ranks_.resize(devices.size());
+        model::QuantConfig qc(quant_type);
+        qc.group_size = group_size;
+        model::DynBatchConfig bc;
+        bc.rag_buffer = true;
+        bc.flash_attention = true;
+        engine_->device_foreach([&](int r) {
+            Rank& R = ranks_[r];
+            R.ctx.reset(new model::ModelContext(model::ModelContext::create(*engine_, md_, bc, r, true)));
+            R.ctx->set_current_layer(0);
+            R.layer.reset(new nn::EncoderLayer(*R.ctx, cfg_, qc, true));
+        });
+    }
+    ~RefEngineEncoderLayer() {
+        try {
+            engine_->device_foreach([&](int r) {
+                (void)hipDeviceSynchronize();
+                ranks_[r].layer.reset();
+                ranks_[r].ctx.reset();
+            });
+        } catch (...) {
+        }
+    }
+    int world_size() const { return engine_->world_size(); }
+    std::vector<int> exchange_errors() {
+        std::vector<int> e(ranks_.size());
+        engine_->device_foreach([&](int r) { e[r] = engine_->exchange_errors(r); });
+        return e;
+    }
+    void load(const std::map<std::string, py::array>& arrays, const std::string& prefix) {
+        std::map<std::string, const Tensor> sd;
+        for (auto& kv : arrays) sd.emplace(kv.first, host_tensor(kv.second, kv.first));
+        engine_->device_foreach([&](int r) { ranks_[r].layer->load_state_dict(*ranks_[r].ctx, sd, prefix, false); });
+    }
+    // the compressed cache is REPLICATED: every rank gets task b's rows k (n, 1, kv_lora_rank + rope) in a buffer of len_buf rows
+    void set_history(int b, int len_buf, const py::array& k) {
+        Tensor hk = host_tensor(k, "k");
+        engine_->device_foreach([&](int r) {
+            Rank& R = ranks_[r];
+            auto rag = R.ctx->rag_buffer();
+            BM_ASSERT(rag->config_v_.dim_head == 0, "RefEngineEncoderLayer: the compressed (latent) cache only (LATENT_CACHE=1)");
+            rag->resize_task_buf(*R.ctx, b, (size_t)len_buf);
+            Tensor& dst = rag->buf_k(b)[0];
+            BM_ASSERT(hk.nbytes() <= dst.nbytes(), "history rows into the task buffer");
+            if (hk.nbytes()) BM_CUDART_ASSERT(hipMemcpy(dst.data(), hk.data(), hk.nbytes(), hipMemcpyHostToDevice));
+        });
+    }
+    // one decode step on every rank: hidden (B, dim_model) 16-bit rows -> the ranks' outputs (world, B, dim_model) as uint16 bits
+    py::array decode_step(const py::array& hidden, const py::array& positions, const py::array& placement, const py::array& mask) {
+        const size_t B = (size_t)hidden.shape(0), world = ranks_.size(), dm = (size_t)cfg_.dim_model;
+        Tensor hx = host_tensor(hidden, "hidden"), hp = host_tensor(positions, "s_position"), hpl = host_tensor(placement, "s_placement"),
+               hm = host_tensor(mask, "s_mask");
+        BM_ASSERT(hx.numel() == B * dm && bmengine::core::get_elem_size(hx.dtype()) == 2 && hp.dtype() == DataType::kInt32, "hidden (B, dim_model) 16-bit, int32 positions");
+        std::vector<int> pos_host((const int*)hp.data(), (const int*)hp.data() + B);
+        std::vector<std::vector<uint16_t>> out(world, std::vector<uint16_t>(B * dm));
+        engine_->device_foreach([&](int r) {
+            Rank& R = ranks_[r];
+            model::ModelContext& ctx = *R.ctx;
+            auto rag = ctx.rag_buffer();
+            auto dyn = std::make_shared<model::DynBatchContext>();
+            dyn->s_placement = upload(ctx, hpl).view({B, 1});
+            dyn->s_position = upload(ctx, hp);
+            dyn->sv_position = pos_host;                                  // (MLAImpl::attn_by_flash_mla reads the host copy)
+            dyn->s_mask = upload(ctx, hm);
+            for (size_t b = 0; b < B; ++b) dyn->sv_len_buf.push_back((int)rag->get_buf_len(b));
+            dyn->s_len_buf = ctx.tensor_of(dyn->sv_len_buf);
+            ctx.set_dyn_batch(dyn);
+            ctx.set_current_layer(0);
+            rag->set_buffer_addr(ctx);
+            Tensor x = upload(ctx, hx);
+            x = x.view_type({B, dm}, bf16_ ? DataType::kBFloat16 : DataType::kHalf);
+            Tensor none;
+            Tensor y = R.layer->forward(ctx, x, none, dyn->s_position, none, none, nullptr, nullptr, nullptr, nullptr);
+            BM_ASSERT_EQ(y.numel(), B * dm, "layer output (B, dim_model)");
+            y.to_buffer(out[r].data(), ctx.current_cuda_stream());
+            ctx.set_dyn_batch(nullptr);
+        });
+        py::array res(py::dtype("uint16"), std::vector<py::ssize_t>{(py::ssize_t)world, (py::ssize_t)B, (py::ssize_t)dm});
+        for (size_t r = 0; r < world; ++r) std::memcpy((char*)res.mutable_data() + r * B * dm * 2, out[r].data(), B * dm * 2);
+        return res;
+    }
+    // rank r's compressed-cache rows of task b: (len_buf, 1, kv_lora_rank + rope) as uint16 bits
+    py::array get_k(int r, int b) {
+        std::vector<uint16_t> host;
+        std::vector<size_t> shape;
+        engine_->run(r, [&] {
+            const Tensor& t = ranks_[r].ctx->rag_buffer()->buf_k(b, 0);
+            shape = t.shape();
+            host.resize(t.numel());
+            t.to_buffer(host.data(), ranks_[r].ctx->current_cuda_stream());
+        });
+        py::array out(py::dtype("uint16"), std::vector<py::ssize_t>(shape.begin(), shape.end()));
+        std::memcpy(out.mutable_data(), host.data(), host.size() * 2);
+        return out;
+    }
+
+private:
+    struct Rank {
+        std::unique_ptr<model::ModelContext> ctx;
+        std::unique_ptr<nn::EncoderLayer> layer;
+    };
+    static Tensor upload(const Context& ctx, const Tensor& host) {
+        Tensor d = ctx.tensor(host.shape(), host.dtype());
+        d.from_buffer(host.data(), false, ctx.current_cuda_stream());
+        return d;
+    }
+    model::ModelConfig cfg_;
+    DummyModel md_;
+    bool bf16_;
+    std::unique_ptr<bmengine::core::Engine> engine_;
+    std::vector<Rank> ranks_;
+};
+
 // One reference nn::FeedForward (dense, or the MoE implementations feedforward.cpp picks from its switches at construction:
 // MOEImpl -- host routing, or its device dispatch route under MOE_GPU_DISPATCH_THRES -- and GPTQMOE under FUSE_GPTQ_MOE)
 class RefFeedForward {
@@ -221,6 +355,19 @@ private:
 }  // namespace
 
 void bind_ref_block(py::module_& m) {
+    py::class_<RefEngineEncoderLayer>(m, "RefEngineEncoderLayer")
+        .def(py::init<int, int, int, int, int, float, float, int, int, const std::string&, const std::vector<int>&, const std::vector<int>&, bool, float, bool,
+                      const std::vector<int>&>(),
+             py::arg("dim_model"), py::arg("num_heads"), py::arg("num_kv_heads"), py::arg("dim_head"), py::arg("dim_ff"), py::arg("rope_theta") = 10000.0f,
+             py::arg("eps") = 1e-5f, py::arg("quant_type") = 5, py::arg("group_size") = 128, py::arg("model_type") = "llama",
+             py::arg("mla") = std::vector<int>(), py::arg("moe") = std::vector<int>(), py::arg("norm_topk_prob") = true,
+             py::arg("routed_scaling_factor") = 1.0f, py::arg("bf16") = false, py::arg("devices") = std::vector<int>{0, 0})
+        .def("world_size", &RefEngineEncoderLayer::world_size)
+        .def("exchange_errors", &RefEngineEncoderLayer::exchange_errors)
+        .def("load", &RefEngineEncoderLayer::load)
+        .def("set_history", &RefEngineEncoderLayer::set_history)
+        .def("get_k", &RefEngineEncoderLayer::get_k)
+        .def("decode_step", &RefEngineEncoderLayer::decode_step);
     py::class_<RefFeedForward>(m, "RefFeedForward")
         .def(py::init<int, int, const std::vector<int>&, bool, float, int, int, int, bool>(), py::arg("dim_model"), py::arg("dim_ff"),
              py::arg("moe") = std::vector<int>(), py::arg("norm_topk_prob") = true, py::arg("routed_scaling_factor") = 1.0f, py::arg("quant_type") = 0,
