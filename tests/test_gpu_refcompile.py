@@ -1148,6 +1148,10 @@ def test_reference_deepseek_sharded_child(ref, oracle):
             layer.decode_step(*args)                                  # warm-up of both rank threads (the step rewrites the same cache rows)
             errs0 = layer.exchange_errors()
         both = layer.decode_step(*args)
+        if os.environ.get("ZL_DUMP_DS2"):                                 # (offline analysis of a failing run: the raw outputs next to the inputs)
+            dump = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+            os.makedirs(dump, exist_ok=True)
+            np.savez(os.path.join(dump, f"deepseek_world2_step{step}.npz"), both=both, x=x, pos=pos, **{f"hist{b}": hist[b] for b in range(B)})
         assert both.shape == (2, B, dm) and np.array_equal(both[0], both[1]), "the ranks' outputs differ"
         want_bits, row, margin = om.step(x, pos, hist, world=2)
         got, want, xin = om.f(both[0]), om.f(want_bits), om.f(x)
@@ -1171,3 +1175,38 @@ def test_reference_deepseek_sharded_child(ref, oracle):
         json.dump(record, fh, indent=1)
     del layer
     ref.weight_cache_clear()
+
+
+def test_engine_collectives_two_ranks_one_device(ref):
+    """core::Engine's collectives (hostcpp/bm_engine.cpp) through the c10d names the reference's layer code calls, two rank threads on
+    one device (no RCCL: everything on the one-shot exchange): broadcasts and gathers of payloads that are NOT 16-bit floats travel
+    byte by byte as exact fp16 integers and must come back bit for bit (FeedForward::route broadcasts int32 expert ids and fp32
+    weights, feedforward.cpp:472-478); fp16 sums in rank order; a reduce-scatter as the sum's slice."""
+    if not hasattr(ref, "RefEngine"):
+        pytest.skip("prebuilt test module without the engine harness")
+    rng = np.random.default_rng(77)
+    eng = ref.RefEngine([0, 0])
+    def bits(a):
+        return np.ascontiguousarray(a).view(np.uint8)
+    for dtype, n in ((np.int32, 6), (np.float32, 6), (np.int8, 7), (np.int32, 1000), (np.float16, 16)):
+        for root in (0, 1):
+            xs = [(rng.standard_normal(n) * 1000).astype(dtype) for _ in range(2)]
+            got = eng.run("broadcast", xs, root)
+            for r in range(2):
+                assert np.array_equal(bits(got[r]), bits(xs[root])), (dtype, n, root, r)
+    for dtype, n in ((np.float16, 24), (np.int32, 5), (np.float32, 129)):
+        xs = [(rng.standard_normal(n) * 100).astype(dtype) for _ in range(2)]
+        got = eng.run("all_gather", xs)
+        want = np.concatenate(xs)
+        for r in range(2):
+            assert np.array_equal(bits(got[r]), bits(want)), (dtype, n, r)
+    xs = [rng.standard_normal(3072).astype(np.float16) for _ in range(2)]
+    got = eng.run("all_reduce", xs)
+    want = (xs[0].astype(np.float32) + xs[1].astype(np.float32)).astype(np.float16)
+    assert np.array_equal(got[0].view(np.uint16), want.view(np.uint16)) and np.array_equal(got[1].view(np.uint16), want.view(np.uint16))
+    xs = [rng.standard_normal(32).astype(np.float16) for _ in range(2)]
+    got = eng.run("reduce_scatter", xs)
+    want = (xs[0].astype(np.float32) + xs[1].astype(np.float32)).astype(np.float16)
+    assert np.array_equal(got[0].view(np.uint16), want[:16].view(np.uint16)) and np.array_equal(got[1].view(np.uint16), want[16:].view(np.uint16))
+    assert eng.exchange_errors() == [0, 0]
+    del eng

@@ -56,6 +56,7 @@ public:
         zl_comm_t* comm = nullptr;
         void* ar_buffer = nullptr;
         void* ar_state = nullptr;
+        void* staging = nullptr;      // ranks that share a device: scratch of the byte-wise collectives (oneshot_bytes; no allocation per call)
         hipStream_t setup_stream = nullptr;
         MemoryAllocator allocator;
         std::unique_ptr<TaskThreadPool> thread;
@@ -114,14 +115,19 @@ public:
     // the fp16 value of each byte's int8 reading (-128 .. 127 are exact in fp16, x + 0 is exact, the way back is exact): bit-exact
     // for int32 routing tables and fp32 routing weights (FeedForward::route broadcasts them, feedforward.cpp:472-478).
     void sum_bytes(int r, void* buf, size_t nbytes, hipStream_t st) const {
-        const size_t padded = (nbytes + 7) / 8 * 8;
-        void* tmp = nullptr;
-        BM_HIPRT_ASSERT(hipMallocAsync(&tmp, padded * 2, st));
-        if (padded != nbytes) BM_HIPRT_ASSERT(hipMemsetAsync(tmp, 0, padded * 2, st));
-        EN_CK(zl_cast(buf, ZL_T_I8, tmp, ZL_T_F16, (int64_t)nbytes, st), "bytes -> fp16");
-        all_reduce_sum(r, tmp, tmp, padded, DataType::kHalf, st);
-        EN_CK(zl_cast(tmp, ZL_T_F16, buf, ZL_T_I8, (int64_t)nbytes, st), "fp16 -> bytes");
-        BM_HIPRT_ASSERT(hipFreeAsync(tmp, st));
+        // through the rank's persistent staging block, in pieces of oneshot_bytes / 2 payload bytes (one fp16 per byte).  (A
+        // stream-ordered allocation per call handed blocks back and forth between the two ranks' streams through the device's
+        // shared pool; the second broadcast of a step then came back as zeros on one rank -- gpurun_out/r21_ds.log.)
+        const Rank& R = ranks[r];
+        BM_ASSERT(R.staging, "byte-wise collective without a staging block");
+        const size_t piece = (size_t)oneshot_bytes / 2;
+        for (size_t off = 0; off < nbytes; off += piece) {
+            const size_t n = std::min(piece, nbytes - off), padded = (n + 7) / 8 * 8;
+            if (padded != n) BM_HIPRT_ASSERT(hipMemsetAsync(R.staging, 0, padded * 2, st));
+            EN_CK(zl_cast((const char*)buf + off, ZL_T_I8, R.staging, ZL_T_F16, (int64_t)n, st), "bytes -> fp16");
+            all_reduce_sum(r, R.staging, R.staging, padded, DataType::kHalf, st);
+            EN_CK(zl_cast(R.staging, ZL_T_F16, (char*)buf + off, ZL_T_I8, (int64_t)n, st), "fp16 -> bytes");
+        }
     }
     // recv holds this rank's contribution and zeros elsewhere -> the sum over the ranks, in place
     void sum_padded(int r, void* recv, size_t count, DataType dt, hipStream_t st) const {
@@ -163,6 +169,7 @@ Engine::Engine(const std::vector<DeviceConfiguration>& dev_cfg, const DistConfig
         BM_HIPRT_ASSERT(hipMalloc(&R.ar_state, (size_t)zl_ar_state_bytes()));
         // zeroed on the stream zl_ar_init writes the state on (a null-stream memset would be unordered against that non-blocking stream)
         BM_HIPRT_ASSERT(hipMemsetAsync(R.ar_state, 0, (size_t)zl_ar_state_bytes(), R.setup_stream));
+        if (!all_distinct) BM_HIPRT_ASSERT(hipMalloc(&R.staging, (size_t)impl->oneshot_bytes));
         BM_HIPRT_ASSERT(hipStreamSynchronize(R.setup_stream));
         if (all_distinct)
             for (int p = 0; p < world; ++p) {
@@ -195,6 +202,7 @@ Engine::~Engine() {
             if (R.comm) (void)zl_comm_destroy(R.comm);
             if (R.ar_buffer) (void)zl_ar_free(R.ar_buffer);
             if (R.ar_state) (void)hipFree(R.ar_state);
+            if (R.staging) (void)hipFree(R.staging);
             if (R.setup_stream) (void)hipStreamDestroy(R.setup_stream);
         });
     } catch (...) {
@@ -315,11 +323,11 @@ Context Engine::create_context_rank(int rank) const {
             EN_CK(zl_comm_reduce_scatter_sum(impl->ranks[r].comm, send.data(), recv.data(), (int64_t)recv.numel(), comm_dtype(send.dtype()), st),
                   "ncclReduceScatter");
         } else {
-            void* tmp = nullptr;                                   // (ranks sharing a device: the whole sum, then this rank's slice)
-            BM_HIPRT_ASSERT(hipMallocAsync(&tmp, send.nbytes(), st));
+            // ranks sharing a device: the whole sum in the staging block, then this rank's slice
+            BM_ASSERT((int64_t)send.nbytes() <= impl->oneshot_bytes && impl->ranks[r].staging, "reduce-scatter between ranks that share a device: within the staging block");
+            void* tmp = impl->ranks[r].staging;
             impl->all_reduce_sum(r, send.data(), tmp, send.numel(), send.dtype(), st);
             BM_HIPRT_ASSERT(hipMemcpyAsync(recv.data(), (char*)tmp + (size_t)r * recv.nbytes(), recv.nbytes(), hipMemcpyDeviceToDevice, st));
-            BM_HIPRT_ASSERT(hipFreeAsync(tmp, st));
         }
     };
     if (impl->rccl) {

@@ -84,7 +84,7 @@ Tensor Gemm::forward(const Context& ctx, const Tensor& A0, const Tensor& B0, Ten
     const int64_t k = A.size(-1), n = B.size(0), m = rows_of(A);
     BM_ASSERT_EQ((int64_t)B.size(1), k, "Matrix dimensions mismatch");
     if (A.ndim() > 2) BM_ASSERT(A.is_continuous(), "Gemm: a batched A must be dense");
-    const int64_t lda = A.ndim() == 2 ? (int64_t)A.stride(0) : k;
+    const int64_t lda = A.ndim() == 2 && m > 1 ? (int64_t)A.stride(0) : k;      // (the stride of a single row is meaningless: views leave 1 there)
     BM_ASSERT_EQ(A.stride(-1), (size_t)1, "Gemm: the last dimension of A must be dense");
     std::vector<size_t> oshape = A.shape();
     oshape.back() = n;
@@ -98,7 +98,8 @@ Tensor Gemm::forward(const Context& ctx, const Tensor& A0, const Tensor& B0, Ten
         Tensor dense = ctx.tensor({(size_t)m, (size_t)n}, pimpl->out_type);
         forward(ctx, A0, B0, &dense, bias);
         const size_t row_bytes = (size_t)n * core::get_elem_size(pimpl->out_type);
-        zl_check(zl_copy_2d(dense.data(), row_bytes, output->data(), output->stride_bytes(0), row_bytes, m, st_of(ctx)), "Gemm (strided output rows)");
+        zl_check(zl_copy_2d(dense.data(), row_bytes, output->data(), m > 1 ? output->stride_bytes(0) : row_bytes, row_bytes, m, st_of(ctx)),
+                 "Gemm (strided output rows)");
         return *output;
     }
     Tensor out = output ? *output : ctx.tensor(oshape, pimpl->out_type);

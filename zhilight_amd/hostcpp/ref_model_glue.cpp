@@ -16,6 +16,7 @@
 
 #include <cstring>
 
+#include "bm_c10d.h"
 #include "bm_engine.h"
 #include "model/dyn_batch_context.h"
 #include "model/llama.h"
@@ -409,6 +410,77 @@ private:
     std::vector<Rank> ranks_;
 };
 
+
+// The engine's collectives on their own: one Context per rank thread, every rank calling the c10d entry point the reference's layer
+// code calls (bm_c10d.h) on ITS array; returns what every rank holds afterwards.  Arrays of any element size: ranks that share a
+// device move non-16-bit-float payloads byte by byte (bm_engine.cpp), which must be bit-exact.
+class RefEngine {
+public:
+    explicit RefEngine(const std::vector<int>& devices) {
+        std::vector<bmengine::core::DeviceConfiguration> dc;
+        for (int d : devices) dc.emplace_back(d, (size_t)0);
+        engine_.reset(new bmengine::core::Engine(dc));
+        ctx_.resize(devices.size());
+        engine_->device_foreach([&](int r) { ctx_[r].reset(new Context(engine_->create_context_rank(r))); });
+    }
+    ~RefEngine() {
+        try {
+            engine_->device_foreach([&](int r) {
+                (void)hipDeviceSynchronize();
+                ctx_[r].reset();
+            });
+        } catch (...) {
+        }
+    }
+    std::vector<int> exchange_errors() {
+        std::vector<int> e(ctx_.size());
+        engine_->device_foreach([&](int r) { e[r] = engine_->exchange_errors(r); });
+        return e;
+    }
+    // op: "broadcast" (root), "all_gather", "all_reduce" (fp16 sums), "reduce_scatter"; per_rank: one array per rank, equal shapes
+    std::vector<py::array> run(const std::string& op, const std::vector<py::array>& per_rank, int root) {
+        const size_t world = ctx_.size();
+        BM_ASSERT(per_rank.size() == world, "one array per rank");
+        std::vector<Tensor> host;
+        for (auto& a : per_rank) host.push_back(host_tensor(a, "x"));
+        const size_t nbytes = host[0].nbytes();
+        const size_t out_bytes = op == "all_gather" ? nbytes * world : op == "reduce_scatter" ? nbytes / world : nbytes;
+        std::vector<std::vector<char>> out(world, std::vector<char>(out_bytes));
+        engine_->device_foreach([&](int r) {
+            const Context& ctx = *ctx_[r];
+            Tensor x = ctx.tensor(host[r].shape(), host[r].dtype());
+            x.from_buffer(host[r].data(), false, ctx.current_cuda_stream());
+            Tensor y;
+            if (op == "broadcast") {
+                bmengine::c10d::NCCLBroadcast(ctx, x, x, root);
+                y = x;
+            } else if (op == "all_gather") {
+                y = ctx.all_gather(x);
+            } else if (op == "reduce_scatter") {
+                y = ctx.reduce_scatter(x);
+            } else if (op == "all_reduce") {
+                y = ctx.tensor(x.shape(), x.dtype());
+                bmengine::c10d::NCCLAllReduce(ctx, x, y, ncclSum);
+            } else {
+                BM_EXCEPTION("unknown op " + op);
+            }
+            BM_ASSERT_EQ(y.nbytes(), out_bytes, "result size");
+            y.to_buffer(out[r].data(), ctx.current_cuda_stream());
+        });
+        std::vector<py::array> res;
+        for (size_t r = 0; r < world; ++r) {
+            py::array a(per_rank[0].dtype(), std::vector<py::ssize_t>{(py::ssize_t)(out_bytes / per_rank[0].dtype().itemsize())});
+            std::memcpy(a.mutable_data(), out[r].data(), out_bytes);
+            res.push_back(a);
+        }
+        return res;
+    }
+
+private:
+    std::unique_ptr<bmengine::core::Engine> engine_;
+    std::vector<std::unique_ptr<Context>> ctx_;
+};
+
 }  // namespace
 
 void bind_ref_model(py::module_& m) {
@@ -424,6 +496,10 @@ void bind_ref_model(py::module_& m) {
         .def("decode_step", &RefLLaMA::decode_step)
         .def("time_decode_steps", &RefLLaMA::time_decode_steps, py::arg("tokens"), py::arg("positions"), py::arg("mask"), py::arg("warmup") = 3,
              py::arg("iters") = 20, py::arg("graph") = true);
+    py::class_<RefEngine>(m, "RefEngine")
+        .def(py::init<const std::vector<int>&>(), py::arg("devices") = std::vector<int>{0, 0})
+        .def("exchange_errors", &RefEngine::exchange_errors)
+        .def("run", &RefEngine::run, py::arg("op"), py::arg("per_rank"), py::arg("root") = 0);
     py::class_<RefEngineLLaMA>(m, "RefEngineLLaMA")
         .def(py::init<int, int, int, int, int, int, int, float, float, int, int, const std::vector<int>&>(), py::arg("num_layers"), py::arg("dim_model"),
              py::arg("num_heads"), py::arg("num_kv_heads"), py::arg("dim_head"), py::arg("dim_ff"), py::arg("vocab_size"), py::arg("eps") = 1e-5f,
