@@ -44,6 +44,7 @@ struct Storage {
     void* ptr = nullptr;
     size_t bytes = 0;
     int device = -1;
+    hipStream_t home = nullptr;                      // the owning context's stream when the block was handed out (Context::tensor)
     std::function<void(void*, size_t)> release;      // back to the pool / hipFree / free / nothing (borrowed)
     ~Storage() {
         if (release) release(ptr, bytes);
@@ -251,10 +252,21 @@ void Tensor::from_buffer(const void* host, bool async, hipStream_t stream) {
     }
     // No stream given: the copy would ride the null stream, which does NOT order against the context's non-blocking stream -- and the
     // pool hands out blocks whose last kernel may still be queued there (a copy racing that kernel is a corrupted tensor, timing
-    // dependent).  Wait for the device first; callers that know their stream pass it (Context::tensor_of does).
+    // dependent).  The copy therefore rides the stream of the context that handed the block out; a tensor without one (external
+    // memory) waits for the device first.  (Not a device-wide wait where it can be avoided: with several rank threads on one device
+    // it would wait for a peer's exchange kernel that is itself waiting for THIS rank -- bm_engine.cpp.)
+    const bool defaulted = !stream;
+    if (defaulted) stream = mem_ ? mem_->home : nullptr;
     if (!stream) BM_HIPRT_ASSERT(hipDeviceSynchronize());
-    BM_HIPRT_ASSERT(hipMemcpyAsync(data(), host, nbytes(), hipMemcpyHostToDevice, stream));
-    if (!async || !stream) BM_HIPRT_ASSERT(hipStreamSynchronize(stream));
+    hipError_t e = hipMemcpyAsync(data(), host, nbytes(), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess && defaulted && stream) {          // (the owning context's stream is gone: the old, device-wide route)
+        (void)hipGetLastError();
+        stream = nullptr;
+        BM_HIPRT_ASSERT(hipDeviceSynchronize());
+        e = hipMemcpyAsync(data(), host, nbytes(), hipMemcpyHostToDevice, stream);
+    }
+    BM_HIPRT_ASSERT(e);
+    if (!async || defaulted) BM_HIPRT_ASSERT(hipStreamSynchronize(stream));
 }
 void Tensor::to_buffer(void* host, hipStream_t stream) const {
     BM_ASSERT(is_continuous(), "to_buffer needs a continuous tensor");
@@ -262,8 +274,17 @@ void Tensor::to_buffer(void* host, hipStream_t stream) const {
         std::memcpy(host, data(), nbytes());
         return;
     }
-    if (!stream) BM_HIPRT_ASSERT(hipDeviceSynchronize());      // (as above: the producer may still be queued on the context's stream)
-    BM_HIPRT_ASSERT(hipMemcpyAsync(host, data(), nbytes(), hipMemcpyDeviceToHost, stream));
+    const bool defaulted = !stream;
+    if (defaulted) stream = mem_ ? mem_->home : nullptr;     // (as above: the producer is queued on the owning context's stream)
+    if (!stream) BM_HIPRT_ASSERT(hipDeviceSynchronize());
+    hipError_t e = hipMemcpyAsync(host, data(), nbytes(), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess && defaulted && stream) {
+        (void)hipGetLastError();
+        stream = nullptr;
+        BM_HIPRT_ASSERT(hipDeviceSynchronize());
+        e = hipMemcpyAsync(host, data(), nbytes(), hipMemcpyDeviceToHost, stream);
+    }
+    BM_HIPRT_ASSERT(e);
     BM_HIPRT_ASSERT(hipStreamSynchronize(stream));
 }
 Tensor Tensor::from_external(const std::vector<size_t>& shape, DataType dtype, void* ptr, size_t nbytes, int device, bool own_ptr) {
@@ -415,6 +436,7 @@ Tensor Context::tensor(const std::vector<size_t>& size, DataType dtype, const st
     t.mem_->ptr = pool->get(cls);
     t.mem_->bytes = cls;
     t.mem_->device = pimpl->device;
+    t.mem_->home = pimpl->stream ? pimpl->stream->ptr : nullptr;
     t.mem_->release = [pool, cls](void* p, size_t) { pool->put(p, cls); };
     t.dtype_ = dtype;
     t.device_ = pimpl->device;

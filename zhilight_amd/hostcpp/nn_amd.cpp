@@ -668,21 +668,6 @@ Tensor sum_experts(const Context& ctx, std::vector<Tensor> inputs, const Tensor&
     if (seq_len > 1) BM_ASSERT_EQ(weights.numel(), index.numel(), "Wrong reverse_idx size");
     Tensor table = ctx.tensor({ptrs.size()}, DataType::kDouble);
     table.from_buffer(ptrs.data(), false, ctx.current_cuda_stream());
-    if (std::getenv("ZL_DEBUG_MOE")) {
-        std::vector<int> ids = experts.to_vector<int>(ctx.current_cuda_stream());
-        std::vector<float> w = weights.to_vector<float>(ctx.current_cuda_stream());
-        std::vector<int> idx = index.numel() ? index.to_vector<int>(ctx.current_cuda_stream()) : std::vector<int>();
-        std::string line = "[sum_experts rank " + std::to_string(ctx.rank()) + " ep " + std::to_string(exp_parallel) + " ws " + std::to_string(world_size) + " lr " +
-                           std::to_string(local_rank) + "] ids";
-        for (int v : ids) line += " " + std::to_string(v);
-        line += " | w";
-        for (float v : w) line += " " + std::to_string(v);
-        line += " | idx";
-        for (int v : idx) line += " " + std::to_string(v);
-        line += " | rows";
-        for (auto& t : inputs) line += " " + (t.numel() ? std::to_string(t.size(0)) : std::string("-"));
-        fprintf(stderr, "%s\n", line.c_str());
-    }
     Tensor out = ctx.tensor({seq_len, dim_model}, dtype, "", dim_model * 16);
     zl_check(zl_moe_sum_experts_arr(table.data<const uint16_t*>(), experts.data<int32_t>(), index.numel() ? index.data<int32_t>() : nullptr,
                                     weights.data<float>(), u16m(out), seq_len, (int)k, dim_model, exp_parallel, world_size > 0 ? world_size : 1,
