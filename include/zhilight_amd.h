@@ -772,6 +772,24 @@ int zl_sort_pairs_i32(const int32_t* keys, const int32_t* values, int32_t* keys_
  * form that never writes the pick's logits pass for <= 4 rows. */
 int zl_argmax_advance(const void* logits, int type, int64_t rows, int64_t n, int64_t ld, int32_t* tokens, int32_t* positions, int32_t* placement,
                       int32_t* valid_lens, int64_t* next_tokens, zl_stream_t s);
+/* The logit post-processing of the reference's batch generator (src/generator/beam_util.cu, 3rd/bmengine/bmengine/functions/{softmax,topk}.cu):
+ * what src/generator/batch_generator.cpp calls between a decode step and its host-side search, so that the py_export surface (zhilight.C)
+ * links against this boundary.  Rows of n logits of type ZL_T_F16 / ZL_T_BF16 / ZL_T_F32; fp32 arithmetic, one rounding to T.
+ *   zl_log_softmax_bias    beam_utility::log_softmax_bias (beam_util.cu:19-128): out = T((x - max) / temperature - log(sum) + bias[row]); temperature 0:
+ *                          the form without the division (:44-66); bias may be NULL (zeros)
+ *   zl_softmax_rows        functions::softmax (softmax.cu:8-30): out = T(exp(x / t - max / t) / sum)
+ *   zl_topk_rows           functions::TopK::forward (topk.cu:280-293): the `top` largest of every row, descending, with int32 positions; ties -> lower index
+ *   zl_gather_logits       beam_utility::gather_logits (:130-157): out[i] = float(logits[index[i]]) over the flattened logits
+ *   zl_scatter_logits      beam_utility::scatter_update (:224-241): logits[batch_ids[i] * stride + token_ids[i]] = T(values[i]) (add: += in T)
+ *   zl_repetition_penalty  beam_utility::beam_repetition_penalty (:199-222): l = presence != 0 ? l - T(presence) : (l < 0 ? l * T(factor) : l / T(factor)) */
+int zl_log_softmax_bias(const void* logits, const float* bias, void* out, int64_t rows, int64_t n, float temperature, int type, zl_stream_t s);
+int zl_softmax_rows(const void* logits, void* out, int64_t rows, int64_t n, float temperature, int type, zl_stream_t s);
+int zl_topk_rows(const void* x, void* out_v, int32_t* out_i, int64_t rows, int64_t n, int top, int type, zl_stream_t s);
+int zl_gather_logits(const int32_t* index, const void* logits, float* out, int64_t n, int type, zl_stream_t s);
+int zl_scatter_logits(const float* values, const int32_t* token_ids, const int32_t* batch_ids, void* logits, int64_t n, int64_t stride, int add, int type,
+                      zl_stream_t s);
+int zl_repetition_penalty(const float* factor, const float* presence, const int32_t* tokens, const int32_t* batch_ids, void* logits, int64_t n, int64_t vocab,
+                          int type, zl_stream_t s);
 int zl_reduce_abs_max(const void* x, void* out, int64_t rows, int64_t cols, int type, zl_stream_t s);
 int zl_binary_op(const void* a, const void* b, void* c, int64_t rows, int64_t cols, int op, int bmode, int type, zl_stream_t s);
 int zl_scale(const void* in, void* out, int64_t n, float factor, int type, zl_stream_t s);

@@ -67,6 +67,7 @@ def build(force=False, verbose=False):
     build_hostcpp(force, verbose)
     build_comm(force, verbose)
     build_refcompile(force, verbose)
+    build_binding(force, verbose)
     build_refcheck(force, verbose)
     return OUT
 
@@ -129,7 +130,7 @@ REFDIR = os.path.join(HERE, "_ref")
 # headers ("prove the boundary compiles the reference")
 REF_TUS = ("src/nn/linear/linear.cpp", "src/nn/attention/attention.cpp", "src/nn/attention/multi_head_latent_attention.cpp",
            "src/nn/feedforward/feedforward.cpp", "src/nn/block/block.cpp", "src/model/llama.cpp", "src/model/model_context.cpp",
-           "src/model/buffer_context.cpp", "src/kvcache/block_allocator.cpp")
+           "src/model/buffer_context.cpp", "src/kvcache/block_allocator.cpp", "src/model/host_all_reducer.cpp")
 # reference translation units that are compiled unmodified and LINK-CHECKED only (build_refcheck): every name they reference in the
 # namespaces the boundary stands in for must be defined by the boundary under the same mangled name -- i.e. with the reference's
 # exact signature; names of layers that are not on the path (their device code lives in the reference's .cu files) are listed
@@ -141,7 +142,8 @@ REF_CHECK_NAMESPACES = ("ds::", "bmengine::", "nn::fp8::", "nn::gptq::", "int8_o
                         "nn::attention_qkv_rag_buffer(", "nn::multi_query_attention_rag_buffer(", "nn::get_mqa_workspace(", "nn::rope_qk_cache(",
                         "nn::rotary_embedding_qk(", "nn::copy_to_rag_buffer2(")
 # attempted and REPORTED only (never fail the build): what a full drop-in of zhilight.C would still need
-REF_REPORT_TUS = ("src/py_export/bind.cpp", "src/generator/batch_generator.cpp", "src/model/host_all_reducer.cpp")
+REF_REPORT_TUS = ("src/py_export/bind.cpp", "src/py_export/py_batch_generator.cpp", "src/py_export/py_llama.cpp", "src/py_export/py_model_base.cpp",
+                  "src/py_export/py_model_config.cpp", "src/py_export/py_utils.cpp", "src/generator/batch_generator.cpp")
 # declared by the shim so that the units compile, NOT provided by the boundary (smooth-quant calibration helpers): reported as "pending"
 # (round 4: the MoE dispatch route's arange / sort_pair_1d / divide / scatter_update_dim0 left this list -- bm_functions.cpp)
 REF_CHECK_PENDING = ("bmengine::functions::pow(", "bmengine::functions::clamp(")
@@ -149,7 +151,7 @@ REF_CHECK_PENDING = ("bmengine::functions::pow(", "bmengine::functions::clamp(")
 
 # the host library: the bmengine-on-HIP layer, the engine, the classes around the operators (host_*.cpp) and the reference's units
 HOST_SOURCES = HOSTCPP_SOURCES + ("bm_engine.cpp", "host_kvcache.cpp", "host_position.cpp", "host_embedding.cpp", "host_layernorm.cpp",
-                                  "host_attention_ext.cpp", "host_offpath.cpp")
+                                  "host_attention_ext.cpp", "host_offpath.cpp", "host_generator_ext.cpp")
 HOST_HEADERS = HOSTCPP_HEADERS + ("bm_engine.h", "host_common.h")
 # the pybind11 harness around it (test infrastructure)
 HARNESS_SOURCES = (os.path.join("refshim", "ref_glue.cpp"), "ref_attention_glue.cpp", "ref_block_glue.cpp", "ref_model_glue.cpp")
@@ -278,6 +280,57 @@ def build_refcompile(force=False, verbose=False):
     return target
 
 
+# the reference's Python binding and dynamic-batch scheduler, compiled UNMODIFIED: together with libzhilight_amd_host.so they ARE zhilight.C
+REF_BINDING_TUS = ("src/py_export/bind.cpp", "src/py_export/py_batch_generator.cpp", "src/py_export/py_llama.cpp", "src/py_export/py_model_base.cpp",
+                   "src/py_export/py_model_config.cpp", "src/py_export/py_utils.cpp", "src/generator/batch_generator.cpp")
+
+
+def binding_target():
+    import sysconfig
+    return os.path.join(REFDIR, "C" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_binding(force=False, verbose=False):
+    """zhilight_amd/_ref/C*.so = the reference's own `zhilight.C` extension module: src/py_export/*.cpp (the pybind11 surface zhilight.llama /
+    zhilight.dynamic_batch import) and src/generator/batch_generator.cpp (the dynamic-batch scheduler: task queue, chunked prefill, beam /
+    greedy / random search), every unit compiled unmodified from where it lies, linked against libzhilight_amd_host.so -- no unit of this
+    repository is compiled into it.  Fails on a leftover undefined symbol.  Returns the path, or None without a reference."""
+    target = binding_target()
+    host = build_host(force, verbose)
+    tus = [os.path.join(REFERENCE, t) for t in REF_BINDING_TUS]
+    if host is None or not all(os.path.exists(t) for t in tus):
+        return target if os.path.exists(target) and host is not None else None
+    rocm, shim, cxx, common = _ref_compile_env()
+    deps = tus + [host]
+    for root, _, files in os.walk(shim):
+        deps += [os.path.join(root, f) for f in files if f != "ref_glue.cpp"]
+    if not (force or _stale(target, deps)):
+        return target
+    objs, jobs = [], []
+    for src in tus:
+        o = os.path.join(REFDIR, "binding_" + os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        jobs.append(common + ["-c", src, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        list(ex.map(run, jobs))
+    run([cxx, "-shared", "-o", target] + objs + ["-L" + REFDIR, "-lzhilight_amd_host", "-L" + HERE, "-lzhilight_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+                                                   "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    for o in objs:
+        os.remove(o)
+    missing = _undefined_outside(target, [host, OUT, os.path.join(rocm, "lib", "libamdhip64.so")])
+    if missing:
+        os.remove(target)
+        demangled = subprocess.run(["c++filt"], input="\n".join(missing), text=True, capture_output=True).stdout
+        raise RuntimeError("zhilight.C needs names the host library does not define:\n" + demangled)
+    return target
+
+
 def refcheck_report():
     return os.path.join(REFDIR, "linkcheck.json")
 
@@ -349,6 +402,7 @@ def build_refcheck(force=False, verbose=False):
         raise RuntimeError("reference call sites name boundary functions the boundary does not define with that signature:\n" + "\n".join(drifted))
     # REPORT ONLY (VERDICT r04 missing 5 / item 9): the units above the model -- the Python binding, the batch generator, the model
     # context with its engine -- attempted against the same shim.  Nothing here fails the build: the report says how far each gets.
+    report_objs, report_defined = {}, set()
     for rel in REF_REPORT_TUS:
         src = os.path.join(REFERENCE, rel)
         if not os.path.exists(src):
@@ -360,12 +414,18 @@ def build_refcheck(force=False, verbose=False):
             out[rel] = {"report_only": True, "compiles": False, "errors": len(errs),
                         "first_errors": [e.replace(REFERENCE + "/", "").replace(HERE + "/", "") for e in errs[:6]]}
             continue
+        report_objs[rel] = obj
+        for line in subprocess.check_output(["nm", "--defined-only", obj], text=True).splitlines():
+            report_defined.add(line.split()[-1])
+    for rel, obj in report_objs.items():
         syms = [line.split()[-1] for line in subprocess.check_output(["nm", "-u", obj], text=True).splitlines()]
         os.remove(obj)
         names = subprocess.run(["c++filt"], input="\n".join(syms), text=True, capture_output=True).stdout.splitlines()
         res = [n for sy, n in zip(syms, names) if sy != n and sy in have]
-        outside = [n for sy, n in zip(syms, names) if sy != n and sy not in have and not n.startswith(("std::", "operator ", "vtable for", "typeinfo for", "VTT for", "__"))]
-        out[rel] = {"report_only": True, "compiles": True, "resolved": sorted(res), "outside": sorted(outside)}
+        own = [n for sy, n in zip(syms, names) if sy != n and sy not in have and sy in report_defined]     # defined by another unit of the binding
+        outside = [n for sy, n in zip(syms, names) if sy != n and sy not in have and sy not in report_defined
+                   and not n.startswith(("std::", "operator ", "vtable for", "typeinfo for", "VTT for", "__", "pybind11::", "Py"))]
+        out[rel] = {"report_only": True, "compiles": True, "resolved": sorted(res), "reference": sorted(own), "outside": sorted(outside)}
     with open(report, "w") as f:
         json.dump(out, f, indent=1)
     return report

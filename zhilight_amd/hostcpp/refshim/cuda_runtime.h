@@ -38,3 +38,7 @@ typedef __half half;
 #define cudaMemcpyPeer hipMemcpyPeer
 #define cudaGetDevice hipGetDevice
 #define cudaSetDevice hipSetDevice
+#define cudaEventDisableTiming hipEventDisableTiming
+#define cudaMallocHost hipHostMalloc
+#define cudaGetDeviceCount hipGetDeviceCount
+#define cudaMemGetInfo hipMemGetInfo
