@@ -23,7 +23,7 @@ SYMBOLS = [
     "zl_moe_fill_m_indices",
     "zl_embedding_rope",
     "zl_fp8_per_token_cast", "zl_fp8_block_dequant", "zl_fp8_block_gemm_group", "zl_moe_top_k_softmax", "zl_moe_group_topk",
-    "zl_cast", "zl_copy_2d", "zl_index_select", "zl_argmax_advance", "zl_arange_i32", "zl_divide_i32", "zl_scatter_update_dim0", "zl_sort_pairs_i32", "zl_reduce_abs_max", "zl_binary_op", "zl_scale", "zl_act_inplace",
+    "zl_cast", "zl_copy_2d", "zl_index_select", "zl_argmax_advance", "zl_arange_i32", "zl_divide_i32", "zl_scatter_update_dim0", "zl_sort_pairs_i32", "zl_log_softmax_bias", "zl_softmax_rows", "zl_topk_rows", "zl_gather_logits", "zl_scatter_logits", "zl_repetition_penalty", "zl_reduce_abs_max", "zl_binary_op", "zl_scale", "zl_act_inplace",
     "zl_count_nonfinite", "zl_perm_narrow_u16", "zl_perm_reverse_u16", "zl_permute_input_u16", "zl_gptq_permute_rows",
     "zl_version", "zl_status_string", "zl_device_cu_count",
     "zl_gptq_shuffle", "zl_gptq_increase_zero", "zl_gptq_q4_to_q8", "zl_transpose_2d",
