@@ -44,7 +44,8 @@ struct Storage {
     void* ptr = nullptr;
     size_t bytes = 0;
     int device = -1;
-    hipStream_t home = nullptr;                      // the owning context's stream when the block was handed out (Context::tensor)
+    Stream home_keep;                                // the owning context's stream when the block was handed out (Context::tensor), kept
+    hipStream_t home = nullptr;                      // alive with the block: the binding creates a context per call and drops it
     std::function<void(void*, size_t)> release;      // back to the pool / hipFree / free / nothing (borrowed)
     ~Storage() {
         if (release) release(ptr, bytes);
@@ -436,6 +437,7 @@ Tensor Context::tensor(const std::vector<size_t>& size, DataType dtype, const st
     t.mem_->ptr = pool->get(cls);
     t.mem_->bytes = cls;
     t.mem_->device = pimpl->device;
+    t.mem_->home_keep = pimpl->stream;
     t.mem_->home = pimpl->stream ? pimpl->stream->ptr : nullptr;
     t.mem_->release = [pool, cls](void* p, size_t) { pool->put(p, cls); };
     t.dtype_ = dtype;
