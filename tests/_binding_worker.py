@@ -1,0 +1,132 @@
+"""Child process of tests/test_gpu_binding.py: the reference's own `zhilight.C` extension module (zhilight_amd/_ref/C*.so = src/py_export/*.cpp +
+src/generator/batch_generator.cpp compiled unmodified, linked on libzhilight_amd_host.so) driven the way zhilight/dynamic_batch.py drives it:
+Engine -> LLaMA -> load_state_dict -> BatchGenerator on its own thread -> SearchTask submit / batch_search.  Prints ONE JSON line.
+(The module travels prebuilt; nothing here reads /root/reference.)"""
+import faulthandler
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+faulthandler.enable()
+faulthandler.dump_traceback_later(240, exit=True)            # a scheduler thread that never answers must not hang the box
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, "tests"))
+from zhilight_amd import _lib, build          # noqa: E402
+
+_lib.lib()
+sys.path.insert(0, os.path.dirname(build.binding_target()))
+import C                                    # noqa: E402
+import oracle.zl_oracle as oracle           # noqa: E402
+from test_gpu_model import OracleModel, _hf_state          # noqa: E402
+from test_gpu_refcompile import _reference_names_state    # noqa: E402
+from zhilight_amd.llama import ModelConfig  # noqa: E402
+
+oracle.lib()
+BOS, EOS = 2, 1
+
+
+def greedy_oracle(cfg, sd, g, prompt, n_new):
+    """the CPU oracle's greedy continuation; bos / eos are pushed to -50000 at the first step, as SearcherImplV1::apply_repetition_penalty does
+    (src/generator/batch_generator.cpp:1639-1660)"""
+    om = OracleModel(oracle, cfg, sd, g, 1, 128)
+    om.rope_kind = "plain"
+    logits = om.prefill(0, np.array(prompt, np.int32))
+    out, margins = [], []
+    for step in range(n_new):
+        row = logits[0].astype(np.float64).copy()
+        if step == 0:
+            row[BOS] = row[EOS] = -50000
+        order = np.argsort(-row, kind="stable")
+        out.append(int(order[0]))
+        margins.append(float(row[order[0]] - row[order[1]]) / float(np.abs(row).max()))
+        if step + 1 < n_new:
+            logits, _ = om.step(np.array([out[-1]], np.int32), [len(prompt) + step])
+    return out, min(margins)
+
+
+def main():
+    rng = np.random.default_rng(21)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2, eps=1e-5, rope_theta=5e5)
+    g = 128
+    sd = _hf_state(rng, cfg, g)
+    state = {k.replace("m.", "llama.", 1): v for k, v in _reference_names_state(sd).items()}
+    mc = C.ModelConfig({"model_type": "llama", "num_layers": cfg.num_layers, "dim_model": cfg.dim_model, "num_heads": cfg.num_heads, "dim_head": cfg.dim_head,
+                        "dim_ff": cfg.dim_ff, "vocab_size": cfg.vocab_size, "eps": cfg.eps, "num_kv_heads": cfg.num_kv_heads, "dtype": "half",
+                        "rope_theta": cfg.rope_theta})
+    dist = C.DistConfig(1, "", 1, 0)
+    engine = C.Engine(0, 8 << 30, dist)
+    model = C.LLaMA(engine, mc, C.QuantConfig(5, True, False, g, False), dist)
+    model.load_state_dict(state)
+    dc = C.DynBatchConfig()
+    dc.max_batch, dc.max_beam_size, dc.task_queue_size, dc.max_total_token = 4, 2, 8, 1024
+    dc.eos_id, dc.bos_id, dc.unk_id = EOS, BOS, 0
+    dc.rag_buffer, dc.flash_attention, dc.ignore_eos = True, True, True
+    gen = C.BatchGenerator(dc, model)
+    errors = []
+
+    def run():
+        try:
+            gen.run()
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(repr(e)[:2000])
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+
+    def task(prompt, n_new, beam=1, top_p=1.0, top_k=0, seed=0, temperature=1.0):
+        # (tokens, beam_size, max_length, presence_penalty, repetition_penalty, ngram_penalty, diverse, seed, temperature, num_results, top_p, top_k,
+        #  bee_answer_multi_span, top_logprobs, stream, output_hidden_states): src/py_export/py_batch_generator.cpp:38-56
+        return C.SearchTask([int(t) for t in prompt], beam, n_new, 0.0, 1.0, 1.0, False, seed, temperature, 1, top_p, top_k, False, 0, 0, 0)
+
+    def wait(t, seconds=60):
+        t0 = time.time()
+        while time.time() - t0 < seconds and not errors:
+            if t.has_result():
+                return t.get_result(1.0)
+            time.sleep(0.02)
+        return None
+
+    out = {"errors": errors}
+    # 1. one greedy task through submit / get_result
+    p1 = rng.integers(3, cfg.vocab_size, 17)
+    t1 = task(p1, 6)
+    assert gen.submit(t1, True)
+    r1 = wait(t1)
+    want1, m1 = greedy_oracle(cfg, sd, g, p1, 6)
+    out["greedy"] = {"got": list(r1[3][0][0]) if r1 and r1[3] else None, "oracle": want1, "margin": m1, "first_token_delay_ms": r1[3][0][3] if r1 and r1[3] else None}
+    # 2. three tasks of different lengths at once: dynamic batching (one joins while the others decode), batch_search
+    prompts = [rng.integers(3, cfg.vocab_size, n) for n in (5, 40, 23)]
+    res = gen.batch_search([task(p, 5) for p in prompts]) if not errors else []
+    out["batch"] = []
+    for p, r in zip(prompts, res):
+        want, m = greedy_oracle(cfg, sd, g, p, 5)
+        out["batch"].append({"got": list(r[0][0]), "oracle": want, "margin": m})
+    # 3. sampling (top_p < 1): the host-side sampler behind random_sampler_gpu with the counter-based generator -- the same seed draws the same tokens
+    if not errors:
+        draws = []
+        for _ in range(2):
+            ts = task(p1, 6, top_p=0.9, seed=1234, temperature=0.8)
+            assert gen.submit(ts, True)
+            rs = wait(ts)
+            draws.append(list(rs[3][0][0]) if rs and rs[3] else None)
+        out["sampling"] = {"draws": draws, "vocab": cfg.vocab_size}
+    # 4. beam search with two beams: the best hypothesis scores at least the greedy one
+    if not errors:
+        tb = task(p1, 6, beam=2)
+        assert gen.submit(tb, True)
+        rb = wait(tb)
+        out["beam2"] = {"got": list(rb[3][0][0]) if rb and rb[3] else None, "score": rb[3][0][1] if rb and rb[3] else None,
+                        "greedy_score": r1[3][0][1] if r1 and r1[3] else None}
+    gen.stop()
+    th.join(timeout=10)
+    print("BINDING_RESULT " + json.dumps(out), flush=True)
+    os._exit(0)
+
+
+if __name__ == "__main__":
+    main()
