@@ -758,3 +758,41 @@ def mla_decode_attn(q_adj, buf_lens, valid_lens, kv_bufs, kv_rank=512, rope_dim=
     lib().zlo_mla_decode_attn(_p(q_adj), _p(bl), _p(vl), arr, _p(out), _i(b), _i(h), C.c_int(kv_rank), C.c_int(rope_dim), _f(scale),
                               C.c_int(dtype), C.c_int(0 if flavour == "E" else 1))
     return out
+
+
+# ---- the batch generator's logit post-processing (numpy restatements; test infrastructure like everything in oracle/) -------------------------------
+# src/generator/beam_util.cu:19-128, 130-157, 199-241; 3rd/bmengine/bmengine/functions/softmax.cu:8-30, topk.cu:280-293.  The reference reduces in
+# fp32 over 1024 threads; these sum in fp64 -- the tests allow one rounding of T plus the fp32 reduction noise.  x: (rows, n) float64 VALUES of the T logits.
+def log_softmax_bias_ref(x, bias, temperature=0.0):
+    x = np.asarray(x, np.float64)
+    m = np.maximum(x.max(axis=1, keepdims=True), -1e20)
+    d = (x - m) / temperature if temperature != 0.0 else (x - m)
+    s = np.exp(d).sum(axis=1, keepdims=True) + 1e-20
+    return d - np.log(s) + np.asarray(bias, np.float64).reshape(-1, 1)
+
+
+def softmax_rows_ref(x, temperature=1.0):
+    x = np.asarray(x, np.float64)
+    m = np.maximum(x.max(axis=1, keepdims=True), -1e20) / temperature
+    e = np.exp(x / temperature - m)
+    return e / (e.sum(axis=1, keepdims=True) + 1e-20)
+
+
+def topk_rows_ref(x, top):
+    """values (descending) and int32 positions; ties go to the lower index (stable sort of the negated values)"""
+    x = np.asarray(x)
+    idx = np.argsort(-x.astype(np.float64), axis=1, kind="stable")[:, :top].astype(np.int32)
+    return np.take_along_axis(x, idx, axis=1), idx
+
+
+def repetition_penalty_ref(logits_T, factor_T, presence_T, tokens, batch_ids, rnd):
+    """logits_T (rows, vocab) float64 values of T; factor_T / presence_T: the penalties ALREADY rounded to T (the kernel casts them first); rnd rounds a
+    float64 array to T.  Sequential like the kernel for distinct (row, token) pairs."""
+    out = np.array(logits_T, np.float64)
+    for i, (t, b) in enumerate(zip(tokens, batch_ids)):
+        l = out[b, t]
+        if presence_T is not None and presence_T[i] != 0.0:
+            out[b, t] = rnd(np.array([l - presence_T[i]]))[0]
+        else:
+            out[b, t] = rnd(np.array([l * factor_T[i] if l < 0 else l / factor_T[i]]))[0]
+    return out

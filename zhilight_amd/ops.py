@@ -637,6 +637,69 @@ def argmax_advance(logits, tokens=None, positions=None, placement=None, valid_le
 
 
 # --------------------------------------------------------------------------------------------------
+# the batch generator's logit post-processing (src/generator/beam_util.cu, bmengine functions/{softmax,topk}.cu): csrc/sampling_ops.hip
+# --------------------------------------------------------------------------------------------------
+_ELEM = {torch.float16: 2, torch.bfloat16: 6, torch.float32: 1}
+
+
+def _rows2d(logits, what):
+    if not (logits.is_cuda and logits.dim() == 2 and logits.is_contiguous() and logits.dtype in _ELEM):
+        raise ZLError(what + ": contiguous (rows, n) CUDA logits of fp16 / bf16 / fp32")
+    return logits.shape
+
+
+def log_softmax_bias(logits, bias=None, temperature=0.0, out=None):
+    """beam_utility::log_softmax_bias: T((x - max) / temperature - log(sum) + bias[row]); temperature 0 = the form without the division"""
+    rows, n = _rows2d(logits, "log_softmax_bias")
+    out = torch.empty_like(logits) if out is None else out
+    check(lib().zl_log_softmax_bias(_p(logits), _p(bias), _p(out), _i(rows), _i(n), _f(temperature), C.c_int(_ELEM[logits.dtype]), _stream()), "log_softmax_bias")
+    return out
+
+
+def softmax_rows(logits, temperature=1.0, out=None):
+    """functions::softmax: T(exp(x / t - max / t) / sum)"""
+    rows, n = _rows2d(logits, "softmax_rows")
+    out = torch.empty_like(logits) if out is None else out
+    check(lib().zl_softmax_rows(_p(logits), _p(out), _i(rows), _i(n), _f(temperature), C.c_int(_ELEM[logits.dtype]), _stream()), "softmax_rows")
+    return out
+
+
+def topk_rows(x, top):
+    """functions::TopK::forward: (values (rows, top) descending in x's dtype, positions int32); ties go to the lower index"""
+    rows, n = _rows2d(x, "topk_rows")
+    v = torch.empty((rows, top), dtype=x.dtype, device=x.device)
+    i = torch.empty((rows, top), dtype=torch.int32, device=x.device)
+    check(lib().zl_topk_rows(_p(x), _p(v), _p(i), _i(rows), _i(n), C.c_int(top), C.c_int(_ELEM[x.dtype]), _stream()), "topk_rows")
+    return v, i
+
+
+def gather_logits(index, logits):
+    """beam_utility::gather_logits: float32 values of the flattened logits at int32 positions"""
+    _chk_cuda(index, logits)
+    out = torch.empty(index.shape, dtype=torch.float32, device=logits.device)
+    check(lib().zl_gather_logits(_p(index), _p(logits), _p(out), _i(index.numel()), C.c_int(_ELEM[logits.dtype]), _stream()), "gather_logits")
+    return out
+
+
+def scatter_logits(values, token_ids, batch_ids, logits, add=False):
+    """beam_utility::scatter_update, in place: logits[batch_ids[i], token_ids[i]] = T(values[i]) (add: += in T)"""
+    rows, n = _rows2d(logits, "scatter_logits")
+    _chk_cuda(values, token_ids, batch_ids)
+    check(lib().zl_scatter_logits(_p(values), _p(token_ids), _p(batch_ids), _p(logits), _i(token_ids.numel()), _i(n), C.c_int(int(add)),
+                                  C.c_int(_ELEM[logits.dtype]), _stream()), "scatter_logits")
+    return logits
+
+
+def repetition_penalty(factor, tokens, batch_ids, logits, presence=None):
+    """beam_utility::beam_repetition_penalty, in place: l = presence != 0 ? l - T(presence) : (l < 0 ? l * T(factor) : l / T(factor))"""
+    rows, n = _rows2d(logits, "repetition_penalty")
+    _chk_cuda(factor, tokens, batch_ids, presence)
+    check(lib().zl_repetition_penalty(_p(factor), _p(presence), _p(tokens), _p(batch_ids), _p(logits), _i(tokens.numel()), _i(n),
+                                      C.c_int(_ELEM[logits.dtype]), _stream()), "repetition_penalty")
+    return logits
+
+
+# --------------------------------------------------------------------------------------------------
 # a17 / a13 / a14 / a18 / a22
 # --------------------------------------------------------------------------------------------------
 def rmsnorm(x, weight, eps, scale=1.0, x2=None, out=None, out_sum=None):
