@@ -4,7 +4,8 @@
 // (src/kvcache/transformer_buffer.cu:420-540) and the handful of cuRAND entry points its samplers are written against.
 //   on the device (sampling_ops.hip over the C ABI): log_softmax_bias, softmax, TopK, gather_logits, scatter_update, the repetition /
 //       presence penalties;
-//   on the host, restated from the behaviour: calc_repetition_ngram (longest repeated n-gram ending at every position -> penalty ^ (n + 1)),
+//   on the host, restated from the behaviour: calc_repetition_ngram (the token that followed an earlier occurrence of the current n-token suffix
+//       is penalised by penalty ^ (n + 1)),
 //       the per-hypothesis loops around the penalty kernel, random_sampler_gpu (sort descending, inclusive sum, u ~ U(0, top_p'),
 //       first index whose cumulative mass reaches u -- sampling is off the hot path and runs on the host here);
 //   curand*: a counter-based generator (seed, offset) -> uniforms in (0, 1]: the samplers need A reproducible stream, not cuRAND's.
@@ -172,9 +173,10 @@ void scatter_update(const core::Context& ctx, const std::vector<float>& values, 
                             tcode(logits.dtype()), st_of(ctx)), "scatter_update");
     BM_CUDART_ASSERT(hipStreamSynchronize(ctx.current_cuda_stream()));
 }
-// For every position the longest earlier-starting repeat that ENDS there (prefix-function style, on the sequence as given -- the
-// callers hand it newest token first); the token that STARTS such a repeat of length n is penalised by ngram_penalty ^ (n + 1), and a
-// token keeps its largest penalty.
+// The callers hand the hypothesis NEWEST TOKEN FIRST.  border[i] (prefix function) = the longest run of most-recent tokens that re-occurs
+// ending at position i; the element just in front of that re-occurrence (index i - len) is the token that FOLLOWED the earlier occurrence of
+// the current len-token suffix -- generating it again would extend the repeat to len + 1 tokens, so it is penalised by
+// ngram_penalty ^ (len + 1) (every token at least by ngram_penalty ^ 1), and a token keeps its largest penalty.
 std::unordered_map<int, float> calc_repetition_ngram(const std::vector<int>& token_ids, float ngram_penalty) {
     std::unordered_map<int, float> ret;
     const int n = (int)token_ids.size();
