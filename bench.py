@@ -75,6 +75,8 @@ def cpu_baseline(cfg, batch, seq):
         "extrapolated": "one of %d layers + 1/16 of the lm_head rows timed, scaled to a full step" % cfg.num_layers,
         "sample": (f"oracle/ R-flavour CPU port (the reference has no CPU path): 1 of {cfg.num_layers} layers' W4A16 linears "
                    f"({t_lin:.2f} s) + decode attention ({t_attn:.2f} s) + 1/16 of lm_head rows, extrapolated to a full step"),
+        "note": "a bit-faithful EMULATION of the reference kernels' fp16 arithmetic (soft-float rounding points, their reduction order), "
+                "not an optimised CPU GEMV: a reported baseline, never a ratio to quote",
     }
 
 
