@@ -78,5 +78,15 @@ void zeros_(const core::Context& ctx, const core::Tensor& x);
 void ones_(const core::Context& ctx, const core::Tensor& x);
 void fill(const core::Context& ctx, const core::Tensor& x, float value);
 
+// What the batch generator runs on logits between decode steps (softmax.h:8-12, topk.h:9-23); defined in host_generator_ext.cpp (part of the
+// host library, not of zl_internals) over zl_softmax_rows / zl_topk_rows
+void softmax(const core::Context& ctx, const core::Tensor& logits, const core::Tensor& output, float temperature = 1.0f);   // rows of the last dimension
+void bitonic_topk(const core::Context& ctx, const core::Tensor& x, const core::Tensor& out, const core::Tensor& pos);
+class TopK : public core::Layer {      // forward: (values (batch, top) descending, int32 positions (batch, top)) of a (batch, n) input
+    BM_LAYER_DEF(TopK)
+    explicit TopK(const core::Context& ctx);
+    std::pair<core::Tensor, core::Tensor> forward(const core::Context& ctx, const core::Tensor& inp, int top);
+};
+
 }  // namespace functions
 }  // namespace bmengine
