@@ -467,8 +467,9 @@ def test_reference_mla_child(ref, oracle):
     k_pe projection (Linear::fuse at load), the two RMSNorms, rope on the 64 rope dimensions (strided slices), the latent row
     written into the task's compressed cache (copy_to_rag_buffer, one 576-wide "head"), q up-projection, the ABSORBED key projection
     (batched Gemm with W_UK split from kv_b_proj at load), multi_query_attention_rag_buffer over the latent cache (= zl_mla_decode_attn
-    behind the reference's call), the absorbed value projection and o_proj -- all in the reference's control flow; against an fp64
-    restatement with the flow's fp16 roundings."""
+    behind the reference's call), the absorbed value projection and o_proj -- all in the reference's control flow; against a chain of
+    oracle/ functions (gemm_nt exact, rmsnorm, rope_qk_cache, mla_decode_attn) with the flow's fp16 roundings -- on the CPU it reproduces
+    the fp64 numpy restatement this test used before bit for bit."""
     rng = np.random.default_rng(2024)
     dm, H, ql, kvl, nope, rp, vd, theta, eps = 1024, 16, 384, 512, 128, 64, 128, 1e4, 1e-5
     w = lambda n, k, s=1.0: (rng.standard_normal((n, k)) * s / np.sqrt(k)).astype(np.float16)
@@ -487,10 +488,11 @@ def test_reference_mla_child(ref, oracle):
         layer.set_history(b, 0, bufs[b], hist[b], hist[b])
     f = lambda a: a.astype(np.float64)
     h16 = lambda a: a.astype(np.float16)
-    lin = lambda a, name: h16(f(a) @ f(W[name]).T)
+    gemm = lambda a, w_: oracle.gemm_nt(oracle.h2u(np.ascontiguousarray(a)), oracle.h2u(np.ascontiguousarray(w_)), dtype=0, exact=True).astype(np.float16)
+    lin = lambda a, name: gemm(a, W[name])
     norm = lambda a, g: oracle.u2h(oracle.rmsnorm(oracle.h2u(np.ascontiguousarray(a)), oracle.h2u(g), eps))
-    wkv = f(W["kv_b_proj"]).reshape(H, nope + vd, kvl)
-    w_uk, w_uv = wkv[:, :nope, :], wkv[:, nope:, :]
+    wkv = W["kv_b_proj"].reshape(H, nope + vd, kvl)
+    w_uk, w_uv = wkv[:, :nope, :], wkv[:, nope:, :]                      # (H, nope, kvl), (H, vd, kvl): what on_load splits from kv_b_proj
     pos = np.array(lens, np.int32)
     for step in range(2):
         x = synth.act(rng, 2, dm)
@@ -502,15 +504,16 @@ def test_reference_mla_child(ref, oracle):
         row = np.concatenate([kv_n, k_pe], axis=1)                                       # the latent rows (2, 576)
         q = lin(qa_n, "q_b_proj").reshape(2, H, nope + rp)
         q_pe = _rope_neox(oracle, np.ascontiguousarray(q[:, :, nope:]).reshape(2, H * rp), pos, rp, theta).reshape(2, H, rp)
-        q_adj_nope = h16(np.einsum("bhn,hnk->bhk", f(q[:, :, :nope]), w_uk))
+        # absorbed key projection per head: q_nope (2, nope) x W_UK[h] (nope, kvl) -> (2, kvl); gemm_nt takes the weight as (n, k) rows
+        q_adj_nope = np.stack([gemm(q[:, hh, :nope], np.ascontiguousarray(w_uk[hh].T)) for hh in range(H)], axis=1)
         q_adj = np.concatenate([q_adj_nope, q_pe], axis=2)                               # (2, H, 576)
+        rows_b = [np.concatenate([hist[b][:, 0, :], row[b][None]], axis=0) for b in range(2)]       # (n + 1, 576) per task
+        lens_b = np.array([r.shape[0] for r in rows_b], np.int32)
+        v_attn_all = oracle.u2h(oracle.mla_decode_attn(oracle.h2u(q_adj), lens_b, lens_b, [oracle.h2u(r) for r in rows_b], kv_rank=kvl, rope_dim=rp,
+                                                       scale=1.0 / np.sqrt(nope + rp), dtype=0))          # (2, H, 512)
         outs = []
         for b in range(2):
-            rows = np.concatenate([f(hist[b][:, 0, :]), f(row[b])[None]], axis=0)       # (n + 1, 576)
-            sc = f(q_adj[b]) @ rows.T / np.sqrt(nope + rp)
-            p = np.exp(sc - sc.max(axis=1, keepdims=True))
-            v_attn = h16((p / p.sum(axis=1, keepdims=True)) @ rows[:, :kvl])            # (H, 512)
-            outs.append(h16(np.einsum("hk,hvk->hv", f(v_attn), w_uv)).reshape(-1))
+            outs.append(np.stack([gemm(v_attn_all[b, hh][None], w_uv[hh])[0] for hh in range(H)], axis=0).reshape(-1))
             stored = layer.get_k(b, 0)
             assert stored.shape == (bufs[b], 1, kvl + rp)
             assert np.abs(f(stored[pos[b], 0]) - f(row[b])).max() <= 2.0 ** -8 * np.abs(f(row[b])).max()      # the latent row reached the cache
