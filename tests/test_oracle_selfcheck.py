@@ -269,3 +269,31 @@ def test_router_restatements_against_numpy(oracle):
         assert np.array_equal(idx[t], want), t
         w = s[t, want]
         assert np.allclose(v[t], w / w.sum() * 2.5, rtol=2e-6)
+
+
+def test_sampling_restatements_self_consistent(oracle):
+    """the numpy restatements of the batch generator's logit post-processing (oracle/zl_oracle.py: what tests/test_gpu_zz_sampling.py holds
+    csrc/sampling_ops.hip to): probabilities sum to one, the bias is additive, temperature 0 is the plain form, top-k is descending with ties
+    to the lower index, the penalties follow beam_util.cu:199-222"""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((3, 200)) * 3.0
+    bias = np.array([0.0, 1.5, -2.0])
+    a = oracle.log_softmax_bias_ref(x, bias, 0.7)
+    assert np.allclose(np.exp(a - bias[:, None]).sum(axis=1), 1.0, rtol=1e-12)
+    assert np.allclose(oracle.log_softmax_bias_ref(x, bias, 0.0), oracle.log_softmax_bias_ref(x, bias, 1.0), rtol=0, atol=1e-12)
+    assert np.allclose(oracle.softmax_rows_ref(x, 0.7), np.exp(oracle.log_softmax_bias_ref(x, np.zeros(3), 0.7)), rtol=1e-12)
+    y = x.copy()
+    y[:, 50] = y[:, 120]                                     # a tie: the lower index first
+    v, i = oracle.topk_rows_ref(y, 200)
+    assert (np.diff(v, axis=1) <= 0).all() and i.dtype == np.int32
+    for r in range(3):
+        pos = list(i[r])
+        assert pos.index(50) + 1 == pos.index(120) and sorted(pos) == list(range(200))
+    rnd = lambda t: np.asarray(t, np.float64).astype(np.float16).astype(np.float64)
+    lg = rnd(rng.standard_normal((2, 16)))
+    lg[0, 3], lg[1, 5], lg[1, 7] = 2.0, -2.0, 1.0
+    out = oracle.repetition_penalty_ref(lg, rnd([1.25, 1.25, 1.25]), rnd([0.0, 0.0, 0.5]), [3, 5, 7], [0, 1, 1], rnd)
+    assert out[0, 3] == rnd(2.0 / 1.25) and out[1, 5] == rnd(-2.0 * 1.25) and out[1, 7] == 0.5       # divide positives, multiply negatives, presence subtracts
+    untouched = np.ones_like(lg, bool)
+    untouched[0, 3] = untouched[1, 5] = untouched[1, 7] = False
+    assert np.array_equal(out[untouched], lg[untouched])
