@@ -174,3 +174,28 @@ def test_reference_binding_links_and_imports():
         for rel in build.REF_REPORT_TUS:
             if rel in r:
                 assert r[rel]["compiles"] and not r[rel]["outside"], (rel, r[rel].get("outside"), r[rel].get("first_errors"))
+
+
+def test_host_library_carries_the_engine_the_host_classes_and_the_reference_units():
+    """libzhilight_amd_host.so (round 5): one library with core::Engine, the classes the reference keeps in .cu files, and the reference's own
+    host units -- among them model_context.cpp, so ModelContext::create / reduce_sum / reduce_sum2 are the reference's code -- every name resolved
+    against libzhilight_amd.so / libzhilight_amd_comm.so (build_host raises otherwise)."""
+    import subprocess
+    from zhilight_amd import build
+    build.build()
+    have_reference = all(os.path.exists(os.path.join(build.REFERENCE, t)) for t in build.REF_TUS)
+    path = build.build_host() if have_reference else build.host_target()
+    if not (path and os.path.exists(path)):
+        pytest.skip("no reference tree and no prebuilt library")
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", "-C", path], text=True)
+    for name in ("bmengine::core::Engine::create_context_rank(int) const", "bmengine::core::Engine::device_foreach(",
+                 "model::ModelContext::create(", "model::ModelContext::reduce_sum(", "model::ModelContext::reduce_sum2(", "model::ModelContext::reduce_tp_int8(",
+                 "model::LLaMA::encode(", "nn::EncoderLayer::forward(", "nn::Attention::dyn_rag_forward(", "nn::FeedForward::forward(", "nn::Linear::forward(",
+                 "kvcache::TransformerBuffer::resize(", "kvcache::TransformerBuffer::dump_slice(", "nn::RotaryEmbedding::rotate(", "nn::RopePreparer::forward(",
+                 "nn::RawEmbedding::projection(", "nn::LayerNorm::forward_2(", "nn::FlashDecoding::mha_fwd(", "bmengine::functions::TopK::forward(",
+                 "beam_utility::log_softmax_bias(", "beam_utility::random_sampler_gpu(", "bmengine::c10d::NCCLAllReduce(", "int8_op::quant_group_32(",
+                 "deep_gemm_fp8_block_h20_group", "curandGenerateUniform"):
+        assert name in syms, name
+    needed = subprocess.check_output(["readelf", "-d", path], text=True)
+    assert "libzhilight_amd.so" in needed and "libzhilight_amd_comm.so" in needed
+    assert "libcudart" not in needed and "libnccl" not in needed and "libcublas" not in needed
