@@ -1,14 +1,18 @@
-"""The reference's OWN host code on the MI355X boundary: zhilight_amd/_ref/zl_reflinear*.so is the reference's
-src/nn/linear/linear.cpp compiled UNMODIFIED (read in place from /root/reference by zhilight_amd.build.build_refcompile,
-never copied) against hostcpp/refshim + bm_hip.h / bm_layer.h / bm_functions.h / nn_amd.cpp, linked with
-libzhilight_amd.so.  Here nn::Linear -- the reference's class, constructor dispatch, load_state_dict and forward -- runs
-on the GPU for the three flavours on the hot path and is checked against the oracle:
-  GPTQ      Int4GPTQ: load_parameter -> gptq_shuffle / increase_zero / q4_to_q8 / 3x Transpose -> gptq_gemm_k_major with the
-            raw k-major operands (re-tiled once through the weight-identity cache), plus the act-order variant
-  AutoInt8  Int8Linear: quant_calc_scale at load and per call, the cublasLt IMMA call (refshim -> zl_int8_gemm_nt),
-            quant_scale_back -- integer product exact, so the result is bit-identical to the oracle chain
-  NoQuant   NormalLinear: functions::Gemm
-The prebuilt module travels to the GPU box with the snapshot; nothing here reads /root/reference at run time."""
+"""The reference's OWN host code on the MI355X boundary.  zhilight_amd/_ref/libzhilight_amd_host.so holds this repository's host layer
+(hostcpp/: bmengine on HIP, core::Engine, the operator wrappers, the classes around them) TOGETHER WITH the reference's host translation
+units compiled UNMODIFIED, read in place from /root/reference by zhilight_amd.build.build_host and never copied: src/nn/linear/linear.cpp,
+attention/attention.cpp, attention/multi_head_latent_attention.cpp, feedforward/feedforward.cpp, block/block.cpp, src/model/llama.cpp,
+model_context.cpp, buffer_context.cpp, host_all_reducer.cpp.  zl_reflinear*.so is the pybind11 harness around it (hostcpp/ref_*_glue.cpp).
+What runs here, each against the oracle:
+  nn::Linear        Int4GPTQ (+ act-order), Int8Linear (bit-exact), NormalLinear, Fp8Block
+  nn::Attention     decode steps, fused qkv, prompt chunks, INT8 KV cache; MLAImpl over its compressed cache
+  nn::FeedForward   dense, MOEImpl (host and device dispatch), GPTQMOE, FP8BlockMOE
+  nn::EncoderLayer  a Llama layer; a DeepSeek-V3-SHAPED layer (MLA over Fp8Block + FP8BlockMOE), alone and sharded over two ranks
+                    (ATTN_DATA_PARALLEL + MOE_EXP_PARALLEL) on core::Engine
+  model::LLaMA      whole-model decode and prompt + decode; the same at WORLD SIZE 2 (two rank threads on one device: the reference's
+                    ModelContext::create / reduce_sum over the engine's transports)
+  core::Engine      its collectives on their own, bit-exact for payloads of any type
+The prebuilt modules travel to the GPU box with the snapshot; nothing here reads /root/reference at run time."""
 import os
 import sys
 
