@@ -330,17 +330,19 @@ def test_phase_gemm_rounds(oracle, dev, m, rounds, monkeypatch):
     counts: ragged N (tile overrun of the last workgroup), K with a partial last phase, K shorter than one ring,
     bias / residual epilogues."""
     monkeypatch.setenv("ZL_W4_PHASE_ROUNDS", str(rounds))
+    monkeypatch.setenv("ZL_W4_SLAB", "-1")                # 9..32 rows default to w4_slab.hip since round 6: this test is the phase kernel's
     _check_mfma(oracle, dev, 1152, 16 * (3 * rounds - 1) + 8, m, seed=70 + m + rounds)                 # 2 phases, partial
     _check_mfma(oracle, dev, 4096, 16 * 2 * rounds, m, seed=71 + m + rounds, bias=True)                # 4 phases
     _check_mfma(oracle, dev, 9 * 1024 + 256, 16 * rounds + 16, m, seed=72 + m + rounds, residual=True)  # 10 phases, beyond any BODY
 
 
 @pytest.mark.parametrize("m", [13, 16, 17, 25, 32])
-def test_phase_gemm_k_split(oracle, dev, m):
+def test_phase_gemm_k_split(oracle, dev, m, monkeypatch):
     """17..32 rows with K > 8192: K split over adjacent workgroups, partials merged by the last arriver in split order
     (deterministic); ragged N, K with a partial last phase and an odd phase count, bias / residual; repeated launches
     leave the arrival counters clean"""
     from zhilight_amd import ops
+    monkeypatch.setenv("ZL_W4_SLAB", "-1")                # the phase kernel's own K split (w4_slab.hip is the default since round 6)
     _check_mfma(oracle, dev, 9 * 1024 + 256, 16 * 9 + 8, m, seed=110 + m)
     _check_mfma(oracle, dev, 14336, 256, m, seed=111 + m, bias=True)
     _check_mfma(oracle, dev, 14336, 512, m, seed=112 + m, residual=True)
@@ -390,7 +392,56 @@ def test_streaming_gemm_random_shapes(oracle, dev, monkeypatch):
         _check_mfma(oracle, dev, k, n, m, seed=1000 + case, bias=kind == 1, residual=kind == 2 and not norm, norm=norm)
 
 
-@pytest.mark.parametrize("m", [8, 24])
+@pytest.mark.parametrize("geom", [None, (4, 1), (8, 2), (4, 4)])
+@pytest.mark.parametrize("m", [9, 16, 17, 32])
+def test_slab_gemm_geometries(oracle, dev, m, geom, monkeypatch):
+    """w4_slab.hip (9..32 rows, round 6): the planner's own geometry and forced (waves per workgroup, groups per wave) pairs, one
+    and two row blocks -- ragged N (a partial last tile group and a partial tile), K with a partial last split and K shorter than
+    one workgroup's slice, bias / residual epilogues, every K-split count from 1 to 18; same bars as the phase kernel."""
+    if geom is not None:
+        monkeypatch.setenv("ZL_W4_SLAB_NW", str(geom[0]))
+        monkeypatch.setenv("ZL_W4_SLAB_GPW", str(geom[1]))
+    _check_mfma(oracle, dev, 1152, 16 * 11 + 8, m, seed=500 + m)
+    _check_mfma(oracle, dev, 4096, 512, m, seed=501 + m, bias=True)
+    _check_mfma(oracle, dev, 9 * 1024 + 256, 144, m, seed=502 + m, residual=True)
+    _check_mfma(oracle, dev, 128, 40, m, seed=503 + m)
+    _check_mfma(oracle, dev, 14336, 256, m, seed=504 + m, residual=True, bias=True)
+
+
+def test_slab_gemm_llama_shapes_repeatable(oracle, dev):
+    """the four projections of a Llama-3-8B layer at 32 rows through the slab kernel: two runs return the same bits (every sum
+    has a fixed order), interleaved launches of different shapes share the scratch, the arrival counters end at zero."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(77)
+    ws = {(n, k): ops.W4MWeight.random(n, k, 128, dev) for n, k in [(6144, 4096), (4096, 4096), (4096, 14336)]}
+    xs = {k: _t(synth.act(rng, 32, k), dev) for k in (4096, 14336)}
+    first = {key: ops.w4a16_gemm_mfma(xs[key[1]], w) for key, w in ws.items()}
+    for _ in range(4):
+        for key, w in ws.items():
+            assert torch.equal(ops.w4a16_gemm_mfma(xs[key[1]], w), first[key])
+    scratch = ops.w4_scratch(dev, 32, 6144)
+    torch.cuda.synchronize()
+    assert int(scratch[:65536].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("m", [9, 20, 32])
+def test_slab_against_phase_kernel(dev, m, monkeypatch):
+    """same operands through w4_slab.hip and through w4_phase.hip: the per-(column, group) arithmetic is identical, only the
+    order of the fp32 additions over the K / 128 groups differs -- outputs agree to a few fp32 roundings of the sum, i.e. the
+    fp16 results differ on rounding ties only (<= 1 ulp, rarely)."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(78 + m)
+    w = ops.W4MWeight.random(1024, 4096, 128, dev)
+    x = _t(synth.act(rng, m, 4096), dev)
+    a = ops.w4a16_gemm_mfma(x, w).float()
+    monkeypatch.setenv("ZL_W4_SLAB", "-1")
+    b = ops.w4a16_gemm_mfma(x, w).float()
+    diff = (a - b).abs()
+    assert float((diff > 0).float().mean()) < 0.02
+    assert bool((diff <= 2.0 ** -10 * b.abs() + 1e-6).all())
+
+
+@pytest.mark.parametrize("m", [8, 9, 24, 32])
 def test_phase_gemm_silu_mul(oracle, dev, m):
     from zhilight_amd import ops
     rng = np.random.default_rng(62)
@@ -513,14 +564,27 @@ def test_act_order_linear(oracle, dev, algo, monkeypatch):
              "l.scales": torch.from_numpy(sc.view(np.float16)), "l.g_idx": torch.from_numpy(bad)}, "l", dev)
 
 
-@pytest.mark.parametrize("m,norm", [(1, True), (3, True), (4, False), (6, True), (8, True), (8, False), (16, False), (17, False), (32, False)])
+@pytest.mark.parametrize("m,norm", [(1, True), (3, True), (4, False), (6, True), (8, True), (8, False), (9, False), (16, False), (17, False), (32, False)])
 @pytest.mark.parametrize("bshd", [True, False])
 def test_fused_qkv_rotary_scatter_equals_two_call_sequence(oracle, dev, m, norm, bshd):
     """zl_w4a16_qkv_rope_scatter == zl_w4a16_gemm_mfma + zl_rope_scatter_decode, bit for bit: rotated q, and the K / V
     buffers (incl. a task whose placement is -1 and the last slot of a buffer); bias on."""
     from zhilight_amd import ops
+    _fused_qkv_rope_case(oracle, dev, m, norm, bshd, 8, 2, 128, 1024 + 256)
+
+
+@pytest.mark.parametrize("m", [12, 32])
+@pytest.mark.parametrize("h,hkv,d,k", [(6, 3, 64, 4096), (5, 1, 32, 1152), (4, 4, 128, 8192)])
+def test_fused_qkv_rotary_scatter_slab_head_sizes(oracle, dev, m, h, hkv, d, k):
+    """the slab kernel's rotation epilogue (9..32 rows): head sizes 32 / 64 / 128 (a workgroup's eight tiles hold 4 / 2 / 1 heads),
+    a head count that leaves the last tile group partial, K = 8192 (K split 4)"""
+    _fused_qkv_rope_case(oracle, dev, m, False, True, h, hkv, d, k)
+
+
+def _fused_qkv_rope_case(oracle, dev, m, norm, bshd, h, hkv, d, k):
+    from zhilight_amd import ops
     rng = np.random.default_rng(80 + m)
-    h, hkv, d, k, g = 8, 2, 128, 1024 + 256, 128
+    g = 128
     n = (h + 2 * hkv) * d
     qw, qz, sc = synth.gptq_hf(rng, k, n, g)
     km = oracle.gptq_prepare_k_major(qw, qz, sc, g)
@@ -757,10 +821,15 @@ def _dn_bound(exact, lin=0.0):
 @pytest.mark.parametrize("m", [9, 16, 17, 32])
 @pytest.mark.parametrize("k,n,epi", [(4096, 6144, "plain"), (4096, 2 * 1024, "silu"), (1024 + 256, 264, "bias"), (4096, 28672, "silu"),
                                      (2048, 4096, "residual")])
-def test_deferred_norm_rows_9_32(oracle, dev, m, k, n, epi):
+def test_deferred_norm_rows_9_32(oracle, dev, m, k, n, epi, monkeypatch):
     """zl_w4a16_gemm_mfma with a norm weight and 9..32 rows (every tile count per workgroup the Llama shapes produce, one and two
-    row blocks, the gated / bias / residual epilogues) against the exact product of the oracle's normalised rows."""
+    row blocks, the gated / bias / residual epilogues) against the exact product of the oracle's normalised rows.  On request only
+    (zl_w4_opts_t::defer_norm, ADVICE r05): without it the boundary refuses the shape."""
     from zhilight_amd import ops
+    xr, wr = torch.zeros((m, 1024), dtype=torch.float16, device=dev), ops.W4MWeight.random(64, 1024, 128, dev)
+    with pytest.raises(ops.ZLError):
+        ops.w4a16_gemm_mfma(xr, wr, norm_weight=torch.ones(1024, dtype=torch.float16, device=dev))
+    monkeypatch.setenv("ZL_DEFER_NORM", "1")
     rng = np.random.default_rng(900 + m + n % 97)
     g = 128
     silu = epi == "silu"
@@ -808,10 +877,11 @@ def test_deferred_norm_rows_9_32(oracle, dev, m, k, n, epi):
 
 @pytest.mark.parametrize("m", [9, 16, 17, 32])
 @pytest.mark.parametrize("bshd", [True, False])
-def test_deferred_norm_fused_qkv_rotary_scatter(oracle, dev, m, bshd):
+def test_deferred_norm_fused_qkv_rotary_scatter(oracle, dev, m, bshd, monkeypatch):
     """zl_w4a16_qkv_rope_scatter with a norm weight and 9..32 rows against the unfused sequence (norm launch, projection,
     rope + scatter launch): q and the new K / V rows within the activation-rounding bound, slots and untouched rows identical."""
     from zhilight_amd import ops
+    monkeypatch.setenv("ZL_DEFER_NORM", "1")
     rng = np.random.default_rng(180 + m)
     h, hkv, d, k, g = 8, 2, 128, 4096, 128
     n = (h + 2 * hkv) * d

@@ -62,7 +62,8 @@ class W4Opts(C.Structure):
     """zl_w4_opts_t: caller-provided scratch + explicit tuning overrides of the W4A16 matrix-core launchers"""
     _fields_ = [("scratch", C.c_void_p), ("scratch_bytes", C.c_int64)] + [(n, C.c_int) for n in (
         "phase_rounds", "phase_ksplit", "phase_ksplit_min_m", "phase_min_m", "phase_max_m", "phase_small_off",
-        "tiled_min_m", "tiled_bm", "tiled_splitk", "mfma_ks", "mfma_rounds", "small_algo", "tiled_wide")]
+        "tiled_min_m", "tiled_bm", "tiled_splitk", "mfma_ks", "mfma_rounds", "small_algo", "tiled_wide",
+        "slab", "slab_min_m", "slab_nw", "slab_gpw", "slab_r", "defer_norm")]
 
 
 class W4Layout(C.Structure):

@@ -19,6 +19,7 @@
 //    fp32 registers per lane-group and is merged group->wave->workgroup at the end.
 //  * partial (acc[D], m, l) per split goes to a small fp32 workspace; a second tiny kernel merges
 //    the splits:  out = sum_s acc_s e^{m_s-M} / (sum_s l_s e^{m_s-M} + 1e-20).
+#include <algorithm>
 #include "zl_common.h"
 
 namespace {
@@ -1494,8 +1495,11 @@ static inline int64_t la_counter_bytes(int64_t b, int64_t hkv) { return (b * hkv
 
 int64_t zl_decode_attn_la_workspace_bytes(int64_t b, int64_t h, int64_t hkv, int64_t max_len_buf, int64_t split_len) {
     if (b <= 0 || h <= 0 || hkv <= 0 || max_len_buf <= 0 || split_len < 0 || split_len % 32 != 0) return ZL_EINVAL;
-    if (split_len == 0) split_len = 32;                // any split length the launcher may pick
-    const int64_t splits = (max_len_buf + split_len - 1) / split_len;
+    // split_len == 0: any split length the launcher may pick.  It never runs more than kLaMaxSplits splits (la_split_len grows the
+    // length until they fit), so that is the record count to provide for -- not max_len_buf / 32 (545 MB at 32 tasks
+    // x 32K keys where 35 MB are used)
+    int64_t splits = split_len ? (max_len_buf + split_len - 1) / split_len : std::min<int64_t>(kLaMaxSplits, (max_len_buf + 31) / 32);
+    if (splits > kLaMaxSplits) return ZL_ELIMIT;      // an explicit split length the launcher would refuse
     return la_counter_bytes(b, hkv) + b * h * splits * (kMD + 2) * 4;
 }
 

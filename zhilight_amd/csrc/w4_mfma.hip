@@ -596,6 +596,16 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
                         int k, int groups, int tiles, int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps,
                         const zl_w4_opts_t* opts, hipStream_t hs);
 
+// w4_slab.hip: 9..32 rows on 128-column x K-slice tiles (round 6); ZL_ESHAPE = not this shape / no scratch for the K split
+int zl_w4a16_gemm_slab(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
+                       const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups, int tiles,
+                       int epilogue, int ld_out, const zl_w4_opts_t* opts, hipStream_t hs);
+int zl_w4a16_gemm_slab_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                            uint32_t meta_bytes, const uint16_t* bias, int m, int n, int k, int groups, int tiles, const float* cosv,
+                            const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                            uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, const zl_w4_opts_t* opts,
+                            hipStream_t hs);
+
 bool zl_w4a16_i8p_covers(int64_t m, int64_t k);
 int zl_w4a16_gemm_i8p(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                       uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k,
@@ -758,6 +768,14 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
         return zl_w4a16_gemm_i8p(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
                                  (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), norm_weight, norm_eps,
                                  o.phase_rounds, hs);
+    // 9..32 rows without a fused norm (round 6): 128-column x K-slice tiles, activation fragments straight from global memory
+    // (w4_slab.hip) -- a workgroup's activation bytes ~ its weight bytes instead of M x K per 16 R columns
+    if (o.slab >= 0 && !norm_weight && m >= (o.slab_min_m > 0 ? o.slab_min_m : 9) && m <= 32 && k % 128 == 0 &&
+        L.qw_bytes < ((int64_t)1 << 32)) {
+        st = zl_w4a16_gemm_slab(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
+                                (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), &o, hs);
+        if (st != ZL_ESHAPE) return st;
+    }
     {
         const int ph_min_m = o.phase_min_m > 0 ? o.phase_min_m : 5, ph_max_m = o.phase_max_m > 0 ? o.phase_max_m : 32;
         const int ph_ksplit = o.phase_ksplit ? o.phase_ksplit : 2;   // long K, 13..32 rows: K split inside the phase kernel
@@ -767,6 +785,8 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
         const bool rows_5_32 = !norm_weight && m >= ph_min_m && m <= ph_max_m && m <= 32 && k <= (m <= 16 ? (1 << 30) : ph_maxk_32);
         const bool rows_1_4 = !o.phase_small_off && k <= 4096 && (norm_weight ? m <= 8 : (m <= 4 && m < ph_min_m));   // fused norm: <= 8 rows
         // fused norm with 9..32 rows: the phase kernel's DEFERRED norm (w4_phase.hip DN: T(x w) staged, rs applied to the fp32 totals)
+        //   -- only on request (zl_w4_opts_t::defer_norm): it is NOT zl_rmsnorm + GEMM bit for bit, and parity is the first gate
+        ZL_CHECK_ARG(!(norm_weight && m >= 9 && m <= 32) || o.defer_norm == 1, ZL_ESHAPE);
         const bool rows_9_32_dn = norm_weight && m >= 9 && m <= 32 && k % 128 == 0 && k <= (m <= 16 ? (1 << 30) : 8192);
         if ((rows_5_32 || rows_1_4 || rows_9_32_dn) && L.qw_bytes < ((int64_t)1 << 32))
             return zl_w4a16_gemm_phase(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y,
@@ -888,6 +908,13 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
     ZL_CHECK_ARG(m <= 16 || k <= 8192, ZL_ESHAPE);
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
     const int small_algo = opts ? opts->small_algo : 0;
+    ZL_CHECK_ARG(!(norm_weight && m >= 9) || (opts && opts->defer_norm == 1), ZL_ESHAPE);   // the deferred norm: on request only
+    if (opts && opts->slab >= 0 && !norm_weight && m >= (opts->slab_min_m > 0 ? opts->slab_min_m : 9) && k % 128 == 0) {
+        st = zl_w4a16_gemm_slab_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n, (int)k,
+                                     (int)L.q, (int)(L.np / 16), cosv, sinv, placement, buf_lens, k_bufs, v_bufs, q_out, (int)h,
+                                     (int)hkv, (int)d, bshd, opts, (hipStream_t)s);
+        if (st != ZL_ESHAPE) return st;
+    }
 #ifdef ZL_EXPERIMENTAL
     if (small_algo == 2) {
         st = zl_w4a16_gemm_engine_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n, (int)k,

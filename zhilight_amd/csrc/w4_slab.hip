@@ -1,0 +1,599 @@
+// w4_slab.hip -- W4A16 GEMM for decode batches of 9..32 rows (round 6): 2-D tiles with an optional K split, activations by
+// LDS-DMA into wave-private fragment stores.
+//
+// Why (profiles/r06_rows_ablation.txt, profiles/r06_phase_timeline_rows.txt): the phase kernel (w4_phase.hip) gives a workgroup
+// 16 R output columns and the WHOLE K and feeds the activations through ONE LDS phase buffer behind a workgroup barrier per
+// 1024 k.  With few tiles per workgroup (attn_out, down: R = 1) a phase is ONE weight item per wave, so the launch is a chain
+// of barrier + stage + barrier round trips: ~1 us per phase (attn_out at 32 rows: 4 phases in 4.3 us, 10.3 us per launch for
+// 8.7 MB; down: 20 us for 30.5 MB).  With the staging and the barriers ablated the four projections of a Llama-3-8B layer take
+// 44.9 us instead of 61.3 at 32 rows; with the arithmetic ablated instead, still 49.1: the batch pays per ROW for how the
+// activations reach the matrix cores, not for FLOPs and not for weight bytes.
+//
+// Here no two waves share an activation fragment, so nothing needs a workgroup barrier until the partial tiles meet:
+//   * a workgroup owns R row tiles (16 R output columns; R = 1 / 2 / 4 / 8) x one K slice of NW x GPW 128-k groups (KS slices
+//     cover K); wave w owns GPW consecutive groups for ALL R tiles;
+//   * the activations of a group (16 MB rows x 256 B) go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no registers,
+//     no ds_write, asynchronous), row-contiguous and therefore coalesced (a first cut loaded the MFMA fragments straight from
+//     global memory: 16 bytes out of 16 different cache lines per 16 lanes -- 64 L1 tag look-ups per instruction, and every
+//     launch 5..8 us SLOWER than the phase kernel, profiles/r06_slab_v1_sweep.txt).  The 16-byte pieces of a row are stored
+//     XOR-swizzled by the row (piece q of row r at position q ^ (r & 15): the lane picks the global piece that belongs at ITS
+//     LDS position), so the fragment reads (ds_read_b128, lane = (row, k quarter)) touch every bank exactly once;
+//   * a wave reads a group's fragments ONCE into registers (16 MB VGPRs) and keeps them for the group's R weight items -- an
+//     R-th of the phase kernel's LDS reads; the region is wave-private (no barrier), two groups deep (the DMA of group j + 2 is
+//     issued when group j has been read), and waited for with counted vmcnt: the DMAs are older than every weight load that
+//     may still be in flight when they are needed;
+//   * the weight stream is w4_phase.hip's: 1 KiB ZLW4M items + one meta word through a ring of up to 8 non-temporal buffer
+//     loads, exact (q - z) on the VALU (0x6400 trick), fp32 group sums on the matrix cores, one v_fma_mix_f32 with the group's
+//     scale per C register -- bit for bit the per-(column, group) arithmetic of k_w4a16_phase / k_w4a16_mfma;
+//   * the NW waves' partial tiles meet in LDS in wave order; with a K split (long K: the down projection) the workgroup then
+//     writes its fp32 slab write-through (16-byte sc1 stores, drained with vmcnt(0)), draws a ticket on its tile group's counter,
+//     and the LAST arriver adds the KS slabs in split order (sc1 loads) and runs the epilogue -- the guide's publish-large /
+//     splitk-seam form.  Everything is summed in a fixed order: two runs return the same bits.
+// The accumulation ORDER over the K / 128 groups differs from the phase kernel's (wave-major instead of phase-major), so the
+// two kernels agree to fp32 rounding of the sums, not bit for bit; both are held to the same bars against the oracle
+// (tests/test_gpu_w4.py, test_gpu_fullgeom.py).
+// Reference: gptq_gemm_k_major's M <= 40 route, src/nn/quant/gptq/q_gemm_k_major.cu:580-686 (streams the weights once per 16
+// rows: twice at M = 32).
+#include <type_traits>
+#include "zl_common.h"
+#include "w4_i8p_common.h"
+
+namespace {
+
+constexpr int kMaxKS = 32;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
+
+struct SlabParams {
+    const uint16_t* x;
+    int64_t ldx;
+    uint32_t x_bytes;
+    const uint4* qw;
+    const uint32_t* meta;
+    uint32_t qw_bytes, meta_bytes;
+    const uint16_t* bias;
+    const uint16_t* residual;
+    uint16_t* y;
+    int m, n, k;
+    int groups;        // 128-k items per row tile
+    int tiles;         // 16-row tiles
+    int epi, ld_out;
+    int ks;            // K splits (workgroups per tile group)
+    f4* ws;            // [grid][R MB 64] fp32 slabs (ks > 1)
+    int* counters;     // one per tile group, zero between launches
+    // ROPE instantiation (the fused qkv projection of a decode step)
+    const float* cosv;
+    const float* sinv;
+    const int32_t* placement;
+    const int32_t* buf_lens;
+    uint16_t* const* k_bufs;
+    uint16_t* const* v_bufs;
+    uint16_t* q_out;
+    int h, hkv, d, bshd;
+};
+
+__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_s, uint32_t magic_v) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mask_s), "v"(magic_v));
+    return r;
+}
+
+// eight nibbles of a ZLW4M word -> eight halves (q - z), exact (w4_phase.hip dequant_word)
+__device__ __forceinline__ h8 dequant_word(uint32_t w, hv2 z1, hv2 z16, uint32_t mask_lo, uint32_t mask_hi, uint32_t magic) {
+    const hv2 one16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+    const hv2 d0 = __builtin_bit_cast(hv2, and_or(w, mask_lo, magic)) + z1;
+    const hv2 d1 = __builtin_elementwise_fma(__builtin_bit_cast(hv2, and_or(w, mask_hi, magic)), one16, z16);
+    const uint32_t wb = w >> 8;
+    const hv2 d2 = __builtin_bit_cast(hv2, and_or(wb, mask_lo, magic)) + z1;
+    const hv2 d3 = __builtin_elementwise_fma(__builtin_bit_cast(hv2, and_or(wb, mask_hi, magic)), one16, z16);
+    h8 a;
+    a[0] = d0.x; a[1] = d0.y; a[2] = d1.x; a[3] = d1.y; a[4] = d2.x; a[5] = d2.y; a[6] = d3.x; a[7] = d3.y;
+    return a;
+}
+
+__device__ __forceinline__ void store_sc1(f4* dst, f4 v) {      // write-through 16-byte store
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ f4 load_sc1(const f4* src) {          // L1-bypassing read of a slab entry: two 8-byte sc1 loads the compiler can see
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(src);
+    const uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f4 v;
+    v[0] = __builtin_bit_cast(float, (uint32_t)lo); v[1] = __builtin_bit_cast(float, (uint32_t)(lo >> 32));
+    v[2] = __builtin_bit_cast(float, (uint32_t)hi); v[3] = __builtin_bit_cast(float, (uint32_t)(hi >> 32));
+    return v;
+}
+
+// vmcnt field of s_waitcnt on gfx9 (6 bits: [3:0] and [15:14]); expcnt / lgkmcnt left at "no wait"
+constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
+
+template <int R, int GPW, int MB, bool ROPE>
+__global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
+    constexpr int TOTAL = R * GPW, D = TOTAL < 8 ? TOTAL : 8;
+    constexpr int XS = GPW < 2 ? GPW : 2;             // activation groups resident in the wave's LDS region
+    constexpr int DM = 4 * MB;                        // DMA instructions per group: 4 rows x 256 B each
+    constexpr int kSet = MB * 16 * 256;               // bytes per group image
+    constexpr int SLOTS = R * MB * 64;                // float4 per workgroup tile: slot = (r MB + b) 64 + lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    const int nrow = lane & 15, kq = lane >> 4;
+    const int ksi = (int)(blockIdx.x % (unsigned)p.ks), tg = (int)(blockIdx.x / (unsigned)p.ks);
+    const int tile0 = tg * R;
+    const int g0 = (ksi * nw + wave) * GPW;           // this wave's first 128-k group
+
+    // ---- activations: group image [16 MB rows][16 pieces of 16 B], piece q of row r at position q ^ (r & 15)
+    const uint32_t kOob = 0x80000000u;                // a lane offset no descriptor covers: returns zero, moves nothing
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    unsigned char* xw = smem + (size_t)wave * (XS * kSet);
+    // DMA lane -> (row 4 i + (lane >> 4), position lane & 15): rows past M re-read the last row (their outputs are never
+    // stored, and a row of C depends on its own row of x only)
+    uint32_t x_off[DM];
+#pragma unroll
+    for (int i = 0; i < DM; ++i) {
+        const int row = min(4 * i + (lane >> 4), p.m - 1);
+        x_off[i] = (uint32_t)((row * (int)p.ldx) * 2 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16));
+    }
+    // No control flow around the DMAs: behind a branch the compiler's waitcnt pass merges the two paths' pending counts and
+    // then waits for the weight items as if no DMA were in flight, i.e. for the DMAs too.  A group past K (a partial last split)
+    // reads through an out-of-range lane offset instead -- zeros; and since it also meets zero WEIGHTS, whose 0 x inf would be
+    // NaN, the wave's region is cleared once up front in case such a load leaves LDS alone.
+    if (g0 + GPW > p.groups) {                        // wave-uniform, rare: this wave's slice reaches past K
+#pragma unroll
+        for (int i = 0; i < XS * DM; ++i) *reinterpret_cast<uint4*>(xw + i * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    auto dma_x = [&](int set, int j) {                // both static; group g0 + j into region `set`
+        const bool live = g0 + j < p.groups;
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(xw + set * kSet + i * 1024), 16, live ? x_off[i] : kOob, (g0 + j) * 256, 0, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < XS; ++j) dma_x(j, j);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- weight ring: item i = (group j = i / R, tile r = i % R)
+    uint4 wq[D];
+    uint32_t mt[D];
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.qw), 0, p.qw_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, p.meta_bytes, 0x00020000);
+    // groups past K: the lane offset goes out of range (zeros, nothing moved); tiles past N (a ragged last tile group): the
+    // item of the LAST tile instead -- real memory, and the epilogue never writes a tile >= tiles
+    uint32_t q_off[GPW], m_off[GPW];
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) {
+        q_off[j] = g0 + j < p.groups ? (uint32_t)lane * 16u : kOob;
+        m_off[j] = g0 + j < p.groups ? (uint32_t)nrow * 4u : kOob;
+    }
+    auto issue = [&](int slot, int i) {               // both static
+        const int j = i / R, r = i % R;
+        const uint32_t it = (uint32_t)min(tile0 + r, p.tiles - 1) * (uint32_t)p.groups + (uint32_t)(g0 + j);
+        wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off[j], it * 1024u, 2 /* nt */));
+        mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(rm, m_off[j], it * 64u, 2);
+    };
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) {
+        issue(s, s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mt[D - 1] = 0;                                    // the neutral "previous item" of the first step
+    wq[D - 1] = make_uint4(0, 0, 0, 0);
+
+    const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
+    const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(0x00f000f0u);
+    uint32_t magic = 0x64006400u;
+    asm volatile("" : "+v"(magic));
+
+    f4 acc[R][MB], accg_prev[MB];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[r][b] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b) accg_prev[b] = (f4){0.f, 0.f, 0.f, 0.f};
+    auto finish_prev = [&](int rp, int pslot) {       // acc[rp] += scale * group sums of the previous item
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            asm("v_fma_mix_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n\t"
+                "v_fma_mix_f32 %1, %5, %8, %1 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n\t"
+                "v_fma_mix_f32 %2, %6, %8, %2 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n\t"
+                "v_fma_mix_f32 %3, %7, %8, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]"
+                : "+v"(acc[rp][b][0]), "+v"(acc[rp][b][1]), "+v"(acc[rp][b][2]), "+v"(acc[rp][b][3])
+                : "v"(accg_prev[b][0]), "v"(accg_prev[b][1]), "v"(accg_prev[b][2]), "v"(accg_prev[b][3]), "v"(mt[pslot]));
+        }
+    };
+
+    // fragment reads: the asm keeps the compiler from putting its own (conservative: vmcnt(0)) wait between an LDS-DMA and a
+    // read of LDS -- the wait in front of the reads is the counted one below
+    const uint32_t xr_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)xw + (uint32_t)nrow * 256u;
+    uint4 xa[MB][4];
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i) {
+        const int slot = i % D, pslot = (i + D - 1) % D, r = i % R, j = i / R, set = j % XS;
+        if (r == 0) {
+            // Group j's image has landed once at most the loads issued AFTER its DMAs are outstanding (in-order return): the DMAs
+            // of group j + 1 (requested in the prologue for j = 0, at the start of group j - 1 otherwise) and the ring items in
+            // flight.  That is laxer than what item i itself needs, so the wait costs nothing on top.
+            const int younger_groups = (j == 0) ? (XS - 1 < GPW - 1 ? XS - 1 : GPW - 1) : ((j + 1 < GPW) ? 1 : 0);
+            const int ring_fly = (TOTAL - i) < (D - 1) ? (TOTAL - i) : (D - 1);
+            switch (younger_groups * DM + 2 * ring_fly) {     // (the builtin wants an immediate: static after unrolling)
+#define ZL_W(n) case n: __builtin_amdgcn_s_waitcnt(vmcnt_imm(n)); break;
+                ZL_W(0) ZL_W(2) ZL_W(4) ZL_W(6) ZL_W(8) ZL_W(10) ZL_W(12) ZL_W(14) ZL_W(16) ZL_W(18) ZL_W(20) ZL_W(22)
+#undef ZL_W
+                default: __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); break;
+            }
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t addr = xr_base + (uint32_t)(set * kSet + b * 4096) + (uint32_t)(((4 * t + kq) ^ nrow) * 16);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(xa[b][t]) : "v"(addr) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (j + XS < GPW) dma_x(set, j + XS);     // the region is free again: two groups ahead
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const hv2 z1 = __builtin_bit_cast(hv2, __builtin_amdgcn_perm(mt[slot], mt[slot], 0x03020302u));
+        const hv2 c960 = {(_Float16)960.f, (_Float16)960.f};
+        const hv2 z16 = z1 + c960;
+        const uint32_t wds[4] = {wq[slot].x, wq[slot].y, wq[slot].z, wq[slot].w};
+        h8 a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = dequant_word(wds[t], z1, z16, mask_lo, mask_hi, magic);
+        finish_prev((i + R - 1) % R, pslot);
+        __builtin_amdgcn_sched_barrier(0);
+        f4 accg[MB];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) accg[b] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+                accg[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, xa[b][t]), a[t], accg[b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) accg_prev[b] = accg[b];
+        if (i + D - 1 < TOTAL) issue(pslot, i + D - 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    finish_prev((TOTAL - 1) % R, (TOTAL - 1) % D);
+    __syncthreads();                                   // every wave is done with its activation region: LDS is reused below
+
+    // ---- the NW partial tiles meet in LDS, summed in wave order
+    f4* red = reinterpret_cast<f4*>(smem);             // [nw][R MB][64]
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) red[((size_t)(wave * R + r) * MB + b) * 64 + lane] = acc[r][b];
+    }
+    __syncthreads();
+    constexpr int kMaxIt = SLOTS < 256 ? 1 : SLOTS / 256;   // slots per thread at the smallest workgroup (4 waves)
+    f4 val[kMaxIt];
+    const int bd = (int)blockDim.x;
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) {
+        const int s = (int)threadIdx.x + it * bd;
+        f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+        if (s < SLOTS) {
+            for (int w = 0; w < nw; ++w) v += red[(size_t)w * SLOTS + s];
+        }
+        val[it] = v;
+    }
+
+    if (p.ks > 1) {
+        // ---- K split: slab out (write-through), ticket, the last arriver of the tile group folds the KS slabs in split order
+        f4* slab = p.ws + (size_t)blockIdx.x * SLOTS;
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int s = (int)threadIdx.x + it * bd;
+            if (s < SLOTS) store_sc1(slab + s, val[it]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // every wave's stores are out; red is free
+        int* flag = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(p.counters + tg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == p.ks - 1) __hip_atomic_store(p.counters + tg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = old == p.ks - 1;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        const f4* first = p.ws + (size_t)tg * p.ks * SLOTS;
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int s = (int)threadIdx.x + it * bd;
+            f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+            if (s < SLOTS) {
+                for (int sp0 = 0; sp0 < p.ks; sp0 += 8) {
+                    f4 part[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) part[u] = load_sc1(first + (size_t)min(sp0 + u, p.ks - 1) * SLOTS + s);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (sp0 + u < p.ks) v += part[u];
+                    }
+                }
+            }
+            val[it] = v;
+        }
+    }
+
+    if constexpr (ROPE) {
+        // ---- rotate q and k (neox) on the fp16-rounded projection outputs, scatter k / v into the ragged buffers
+        //      (rope_qk_cache + copy_to_rag_buffer2, src/nn/position/rotary_embedding_fuse_cache.cu:65-125,
+        //      src/kvcache/ragged_buffer_kernel.cu:194-222; roundings of the separate kernels: rope_common.cuh:14-34)
+        f4* fin = reinterpret_cast<f4*>(smem);         // [SLOTS]
+        __syncthreads();                               // every thread is done with red / the flag: smem is reused
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int s = (int)threadIdx.x + it * bd;
+            if (s < SLOTS) fin[s] = val[it];
+        }
+        __syncthreads();
+        const float* finf = reinterpret_cast<const float*>(fin);
+        const int tph = p.d >> 4, half_t = tph >> 1, half = p.d >> 1;      // tiles per head; R % tph == 0
+        const int nout = (R / 2) * 16 * p.m;
+        for (int o = (int)threadIdx.x; o < nout; o += bd) {
+            const int n_local = o & 15, m = (o >> 4) % p.m, pr = (o >> 4) / p.m;     // pr: first-half tile of a head, 0 .. R/2 - 1
+            const int r0 = (pr / half_t) * tph + pr % half_t, r1 = r0 + half_t;
+            const int tile = tile0 + r0;
+            if (tile >= p.tiles) continue;
+            const int b = m >> 4, ln = ((m & 15) >> 2) * 16 + n_local, i = m & 3;
+            float v0 = finf[((size_t)(r0 * MB + b) * 64 + ln) * 4 + i], v1 = finf[((size_t)(r1 * MB + b) * 64 + ln) * 4 + i];
+            const int n0 = tile * 16 + n_local, n1 = n0 + half;
+            if ((p.epi & ZL_EPI_BIAS) && p.bias) {
+                v0 += (float)__builtin_bit_cast(_Float16, p.bias[n0]);
+                v1 += (float)__builtin_bit_cast(_Float16, p.bias[n1]);
+            }
+            const float a = (float)zl_f32_to_f16(v0), bb = (float)zl_f32_to_f16(v1);
+            const int head = n0 / p.d, dcol = n0 % p.d;
+            if (head < p.h + p.hkv) {
+                const float c0 = p.cosv[(size_t)m * p.d + dcol], s0 = p.sinv[(size_t)m * p.d + dcol];
+                const float c1 = p.cosv[(size_t)m * p.d + dcol + half], s1 = p.sinv[(size_t)m * p.d + dcol + half];
+                const uint16_t r0v = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(-bb, s0, a * c0)));
+                const uint16_t r1v = __builtin_bit_cast(uint16_t, zl_f32_to_f16(__builtin_fmaf(a, s1, bb * c1)));
+                if (head < p.h) {
+                    uint16_t* dst = p.q_out + ((size_t)m * p.h + head) * p.d + dcol;
+                    dst[0] = r0v;
+                    dst[half] = r1v;
+                } else {
+                    const int place = p.placement[m], blen = p.buf_lens[m];
+                    if (place >= 0 && place < blen) {
+                        const int hk = head - p.h;
+                        const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * blen + place;
+                        uint16_t* dst = p.k_bufs[m] + row * p.d + dcol;
+                        dst[0] = r0v;
+                        dst[half] = r1v;
+                    }
+                }
+            } else {
+                const int place = p.placement[m], blen = p.buf_lens[m];
+                if (place >= 0 && place < blen) {
+                    const int hk = head - p.h - p.hkv;
+                    const size_t row = p.bshd ? (size_t)place * p.hkv + hk : (size_t)hk * blen + place;
+                    uint16_t* dst = p.v_bufs[m] + row * p.d + dcol;
+                    dst[0] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v0));
+                    dst[half] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(v1));
+                }
+            }
+        }
+        return;
+    } else {
+        // ---- epilogue from the C fragment: a thread holds rows 16 b + 4 (lane >> 4) + i, i < 4, of ONE output column
+        const bool silu = (p.epi & (ZL_EPI_SILU_MUL | ZL_EPI_SILU_MUL_F32)) != 0;
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int s = (int)threadIdx.x + it * bd;
+            if (s >= SLOTS) continue;                 // wave-uniform (bd and SLOTS are multiples of 64)
+            const int rb = s >> 6, ln = s & 63, r = rb / MB, b = rb % MB;
+            const int tile = tile0 + r, n_local = ln & 15, mrow0 = b * 16 + (ln >> 4) * 4;
+            f4 v = val[it];
+            if (silu) {
+                // gate at even, up at odd columns of the interleaved weight: the neighbour lane holds the other one
+                f4 u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = __shfl_xor(v[i], 1, 64);
+                const int prc = tile * 8 + (n_local >> 1);
+                if ((n_local & 1) || tile >= p.tiles || 2 * prc + 1 >= p.n) continue;
+                const bool has_bias = (p.epi & ZL_EPI_BIAS) && p.bias;
+                const float bg = has_bias ? (float)__builtin_bit_cast(_Float16, p.bias[2 * prc]) : 0.f;
+                const float bu = has_bias ? (float)__builtin_bit_cast(_Float16, p.bias[2 * prc + 1]) : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = mrow0 + i;
+                    if (m >= p.m) continue;
+                    float g = has_bias ? v[i] + bg : v[i], uu = has_bias ? u[i] + bu : u[i];
+                    float ov;
+                    if (p.epi & ZL_EPI_SILU_MUL) {
+                        g = (float)zl_f32_to_f16(g);
+                        uu = (float)zl_f32_to_f16(uu);
+                        ov = silu_f32(g) * uu;
+                    } else {
+                        ov = (float)((double)g / (1.0 + (double)expf(-g))) * uu;
+                    }
+                    p.y[(size_t)m * p.ld_out + prc] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(ov));
+                }
+                continue;
+            }
+            const int col = tile * 16 + n_local;
+            if (tile >= p.tiles || col >= p.n) continue;
+            const float bb = ((p.epi & ZL_EPI_BIAS) && p.bias) ? (float)__builtin_bit_cast(_Float16, p.bias[col]) : 0.f;
+            float res[4] = {0.f, 0.f, 0.f, 0.f}, cin[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {             // operands first, arithmetic after: one round trip for the four rows
+                const int m = mrow0 + i;
+                if (m < p.m) {
+                    if (p.epi & ZL_EPI_RESIDUAL) res[i] = (float)__builtin_bit_cast(_Float16, p.residual[(size_t)m * p.ld_out + col]);
+                    if (p.epi & ZL_EPI_ADD_C) cin[i] = (float)__builtin_bit_cast(_Float16, p.y[(size_t)m * p.ld_out + col]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mrow0 + i;
+                if (m >= p.m) continue;
+                float ov;
+                if (p.epi & ZL_EPI_ADD_C) ov = (cin[i] + v[i]) + bb;
+                else ov = v[i] + bb;
+                _Float16 y16 = zl_f32_to_f16(ov);
+                if (p.epi & ZL_EPI_RESIDUAL) y16 = zl_f32_to_f16(res[i] + (float)y16);
+                p.y[(size_t)m * p.ld_out + col] = __builtin_bit_cast(uint16_t, y16);
+            }
+        }
+    }
+}
+
+template <int R, int GPW, int MB, bool ROPE>
+int launch_slab(const SlabParams& p, int grid, int nw, hipStream_t hs) {
+    const size_t red_bytes = (size_t)nw * R * MB * 64 * 16, x_bytes = (size_t)nw * (GPW < 2 ? GPW : 2) * MB * 16 * 256;
+    const size_t lds = red_bytes > x_bytes ? red_bytes : x_bytes;
+    if (lds > 64 * 1024) {
+        // every launch: the attribute is per device, and one process may drive several
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_w4a16_slab<R, GPW, MB, ROPE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ZL_ELIMIT;
+    }
+    hipLaunchKernelGGL((k_w4a16_slab<R, GPW, MB, ROPE>), dim3(grid), dim3(64 * nw), lds, hs, p);
+    return zl_launch_status();
+}
+
+template <int R, bool ROPE>
+int launch_slab_r(const SlabParams& p, int gpw, int mb, int grid, int nw, hipStream_t hs) {
+    if (mb == 1) {
+        if (gpw == 1) return launch_slab<R, 1, 1, ROPE>(p, grid, nw, hs);
+        if (gpw == 2) return launch_slab<R, 2, 1, ROPE>(p, grid, nw, hs);
+        return launch_slab<R, 4, 1, ROPE>(p, grid, nw, hs);
+    }
+    if (gpw == 1) return launch_slab<R, 1, 2, ROPE>(p, grid, nw, hs);
+    if (gpw == 2) return launch_slab<R, 2, 2, ROPE>(p, grid, nw, hs);
+    return launch_slab<R, 4, 2, ROPE>(p, grid, nw, hs);
+}
+
+struct SlabPlan {
+    int r, nw, gpw, ks, grid;
+};
+
+// Tiles per workgroup (1 / 2 / 4 / 8), waves per workgroup (4 / 8), groups per wave (1 / 2 / 4) and the K split that follows.
+// Every candidate that runs as ONE generation of workgroups (8-wave workgroups: one per CU; 4-wave ones: two) is priced by a
+// three-term model fitted to profiles/r06_slab_sweep.txt -- bytes through the busiest CU (weights + activations, the activations
+// at a discount: they come from L2), a fixed cost per launch, and the K-split tail (slab out, ticket, fold of KS slabs) -- and the
+// cheapest wins.  rope: eight tiles per workgroup (whole heads).
+bool plan_slab(int m, int tiles, int groups, bool have_scratch, bool rope, const zl_w4_opts_t& o, SlabPlan* out) {
+    int cus = zl_device_cu_count();
+    if (cus <= 0) cus = 256;
+    const int mb = m <= 16 ? 1 : 2;
+    double best = 1e30;
+    for (int r = rope ? 8 : 1; r <= 8; r *= 2) {
+        if (o.slab_r && r != o.slab_r) continue;
+        const int ntg = (tiles + r - 1) / r;
+        for (int nw = 4; nw <= 8; nw += 4) {
+            if (o.slab_nw && nw != o.slab_nw) continue;
+            for (int gpw = 1; gpw <= 4; gpw *= 2) {
+                if (o.slab_gpw && gpw != o.slab_gpw) continue;
+                const int gw = nw * gpw, ks = (groups + gw - 1) / gw;
+                if (ks > kMaxKS || (ks > 1 && !have_scratch)) continue;
+                if (gw - groups >= gpw * 2 && ks == 1) continue;             // more than a wave or two with nothing to do
+                const long grid = (long)ntg * ks, cap = (long)cus * (nw == 4 ? 2 : 1);
+                const bool forced = o.slab_r && o.slab_nw && o.slab_gpw;
+                if (grid > cap && !forced) continue;                        // a second generation: the phase kernel does better
+                const double wgs_per_cu = (double)((grid + cus - 1) / cus);
+                const double w_kb = (double)r * gw * 1.0625, x_kb = (double)(16 * mb) * gw * 0.25;
+                const double stream = wgs_per_cu * (w_kb + 0.5 * x_kb) / 26.0;                  // us at ~26 KB/us per CU
+                const double idle = grid < cus ? 1.0 + 0.5 * (double)(cus - grid) / cus : 1.0;   // a partly empty chip streams slower per byte
+                const double tail = ks > 1 ? 3.5 + 0.2 * ks : 0.0;
+                const double cost = 3.0 + stream * idle + tail;
+                if (cost < best) {
+                    best = cost;
+                    out->r = r; out->nw = nw; out->gpw = gpw; out->ks = ks; out->grid = (int)grid;
+                }
+            }
+        }
+    }
+    return best < 1e30;
+}
+
+template <bool ROPE>
+int launch_slab_any(const SlabParams& p, const SlabPlan& pl, int mb, hipStream_t hs) {
+    if constexpr (ROPE) return launch_slab_r<8, true>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
+    else switch (pl.r) {
+        case 1: return launch_slab_r<1, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
+        case 2: return launch_slab_r<2, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
+        case 4: return launch_slab_r<4, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
+        default: return launch_slab_r<8, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
+    }
+}
+
+void fill_common(SlabParams& p, const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                 uint32_t meta_bytes, const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups,
+                 int tiles, int epilogue, int ld_out) {
+    p.x = x; p.ldx = ldx; p.x_bytes = (uint32_t)((((int64_t)m - 1) * ldx + k) * 2);
+    p.qw = reinterpret_cast<const uint4*>(qw); p.meta = meta; p.qw_bytes = qw_bytes; p.meta_bytes = meta_bytes;
+    p.bias = bias; p.residual = residual; p.y = y; p.m = m; p.n = n; p.k = k; p.groups = groups; p.tiles = tiles;
+    p.epi = epilogue; p.ld_out = ld_out;
+}
+
+bool slab_shape_ok(int m, int k, int groups, int tiles, int64_t ldx, uint32_t qw_bytes) {
+    if (m < 1 || m > 32 || k % 128 != 0 || groups * 128 != k) return false;
+    if ((((int64_t)m - 1) * ldx + k) * 2 >= ((int64_t)1 << 31)) return false;                     // 32-bit lane offsets into x
+    if (((int64_t)tiles + 8) * groups * 1024 >= ((int64_t)1 << 32) || qw_bytes == 0) return false;    // 32-bit item offsets
+    return true;
+}
+
+bool take_scratch(const zl_w4_opts_t& o, const SlabPlan& pl, int mb, int tiles, SlabParams& p) {
+    const int64_t need = ZL_SCRATCH_HEADER + (int64_t)pl.grid * pl.r * mb * 64 * 16;
+    if (!o.scratch || o.scratch_bytes < need || (tiles + pl.r - 1) / pl.r > ZL_SCRATCH_HEADER / 4) return false;
+    p.counters = reinterpret_cast<int*>(o.scratch);
+    p.ws = reinterpret_cast<f4*>(reinterpret_cast<char*>(o.scratch) + ZL_SCRATCH_HEADER);
+    return true;
+}
+
+}  // namespace
+
+// internal (zl_w4a16_gemm_mfma_ex): rows 1..32 without a fused norm, K a multiple of 128.  Returns ZL_ESHAPE when the shape (or
+// the caller's scratch) does not fit -- the caller then takes the phase kernel.
+int zl_w4a16_gemm_slab(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
+                       const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups, int tiles,
+                       int epilogue, int ld_out, const zl_w4_opts_t* opts, hipStream_t hs) {
+    static const zl_w4_opts_t kNoOpts = {};
+    const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
+    if (!slab_shape_ok(m, k, groups, tiles, ldx, qw_bytes)) return ZL_ESHAPE;
+    SlabPlan pl;
+    if (!plan_slab(m, tiles, groups, o.scratch != nullptr, false, o, &pl)) return ZL_ESHAPE;
+    SlabParams p = {};
+    fill_common(p, x, ldx, qw, meta, qw_bytes, meta_bytes, bias, residual, y, m, n, k, groups, tiles, epilogue, ld_out);
+    const int mb = m <= 16 ? 1 : 2;
+    p.ks = pl.ks;
+    if (pl.ks > 1 && !take_scratch(o, pl, mb, tiles, p)) return ZL_ESHAPE;
+    return launch_slab_any<false>(p, pl, mb, hs);
+}
+
+// internal (zl_w4a16_qkv_rope_scatter): the fused qkv projection of a decode step with the neox rotation and the KV scatter in
+// the epilogue; d in {32, 64, 128} (a workgroup's eight tiles hold whole heads, so a column and its rotation partner meet)
+int zl_w4a16_gemm_slab_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
+                            uint32_t meta_bytes, const uint16_t* bias, int m, int n, int k, int groups, int tiles, const float* cosv,
+                            const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                            uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, const zl_w4_opts_t* opts,
+                            hipStream_t hs) {
+    static const zl_w4_opts_t kNoOpts = {};
+    const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
+    if (!slab_shape_ok(m, k, groups, tiles, ldx, qw_bytes)) return ZL_ESHAPE;
+    if ((d != 32 && d != 64 && d != 128) || n != (h + 2 * hkv) * d || tiles * 16 != n) return ZL_ESHAPE;
+    SlabPlan pl;
+    if (!plan_slab(m, tiles, groups, o.scratch != nullptr, true, o, &pl)) return ZL_ESHAPE;
+    SlabParams p = {};
+    fill_common(p, x, ldx, qw, meta, qw_bytes, meta_bytes, bias, nullptr, nullptr, m, n, k, groups, tiles, bias ? ZL_EPI_BIAS : 0, n);
+    p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs;
+    p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd;
+    const int mb = m <= 16 ? 1 : 2;
+    p.ks = pl.ks;
+    if (pl.ks > 1 && !take_scratch(o, pl, mb, tiles, p)) return ZL_ESHAPE;
+    return launch_slab_any<true>(p, pl, mb, hs);
+}

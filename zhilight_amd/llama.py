@@ -1063,9 +1063,13 @@ class LLaMA:
             la_half = os.environ.get("ZL_ATTN_LA_HALF", "0") == "1" and c.torch_dtype == torch.float16
             eff = la_split or ops.decode_attn_la_split_len(b, c.num_kv_heads, ctx.max_len_buf)
             if (ctx.max_len_buf + eff - 1) // eff <= 64:
-                key = ("la_ws", b, ctx.max_len_buf)
+                # one block per (batch, power-of-two bucket of the buffer length): records are addressed by the launch's own split
+                # count, so a block sized for a longer buffer serves every shorter one; a captured graph keeps its block's address,
+                # hence buckets instead of regrowing in place -- at most log2 blocks per batch, < 2 x the largest
+                bucket = 1 << max(10, (ctx.max_len_buf - 1).bit_length())
+                key = ("la_ws", b, bucket)
                 if key not in self._bufs:
-                    self._bufs[key] = ops.decode_attn_la_workspace(b, c.num_heads, c.num_kv_heads, ctx.max_len_buf, self.device)
+                    self._bufs[key] = ops.decode_attn_la_workspace(b, c.num_heads, c.num_kv_heads, bucket, self.device)
                 la = (self._bufs[key], la_split, la_half)
                 merge_plan = None
 

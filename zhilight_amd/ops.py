@@ -340,7 +340,9 @@ _SCRATCH_RETIRED = []   # outgrown scratch buffers, kept alive for the graphs th
 # tests and micro-benchmarks sweep them
 _W4_ENV = (("phase_rounds", "ZL_W4_PHASE_ROUNDS"), ("phase_ksplit", "ZL_W4_PHASE_KSPLIT"), ("phase_ksplit_min_m", "ZL_W4_PHASE_KSPLIT_MINM"),
            ("phase_min_m", "ZL_W4_PHASE_MIN_M"), ("phase_max_m", "ZL_W4_PHASE_MAX_M"), ("tiled_min_m", "ZL_W4_TILED_MIN_M"),
-           ("tiled_bm", "ZL_W4_TILED_BM"), ("tiled_splitk", "ZL_W4_TILED_SPLITK"), ("mfma_ks", "ZL_MFMA_KS"), ("mfma_rounds", "ZL_MFMA_ROUNDS"), ("tiled_wide", "ZL_W4_TILED_WIDE"))
+           ("tiled_bm", "ZL_W4_TILED_BM"), ("tiled_splitk", "ZL_W4_TILED_SPLITK"), ("mfma_ks", "ZL_MFMA_KS"), ("mfma_rounds", "ZL_MFMA_ROUNDS"), ("tiled_wide", "ZL_W4_TILED_WIDE"),
+           ("slab", "ZL_W4_SLAB"), ("slab_min_m", "ZL_W4_SLAB_MIN_M"), ("slab_nw", "ZL_W4_SLAB_NW"), ("slab_gpw", "ZL_W4_SLAB_GPW"), ("slab_r", "ZL_W4_SLAB_R"),
+           ("defer_norm", "ZL_DEFER_NORM"))
 
 
 def w4_scratch(device, m, n):
