@@ -70,6 +70,11 @@ int zl_gptq_shuffle(uint32_t* qweight /* (K/8,N) in place */, int64_t k8, int64_
 int zl_gptq_increase_zero(uint32_t* qzeros /* in place */, int64_t nwords, zl_stream_t s);
 int zl_gptq_q4_to_q8(const uint32_t* in, uint8_t* out /* 8*nwords bytes */, int64_t nwords, zl_stream_t s);
 int zl_transpose_2d(const void* in, void* out, int64_t rows, int64_t cols, int elem_size /*1,2,4*/, zl_stream_t s);
+/* nn::gptq::reconstruct_gptq (src/nn/quant/gptq/q_gemm.cu:641-700): the checkpoint-order (K/8, N) weight of the legacy route
+ * (GPTQ_KERNEL_ALGO=0 without exllama) dequantised to a dense fp16 (K, N) matrix, out[k][n] = hmul(half(q - zero[g][n]), scale[g][n])
+ * with g = g_idx[k] (NULL: k / (K / groups)); qzeros (groups, N/8) nibbles as they sit on the device (after increase_zero). */
+int zl_gptq_reconstruct(const uint32_t* qweight, const uint32_t* qzeros, const uint16_t* scales, const int32_t* g_idx, uint16_t* out,
+                        int64_t k, int64_t n, int64_t groups, zl_stream_t s);
 int zl_awq_un_shuffle(uint32_t* q /* (dim0,n) in place */, int64_t dim0, int64_t n, zl_stream_t s);
 int zl_awq_shuffle(const uint32_t* in /* (K,N/8) */, uint32_t* out /* (K/8,N) */, int64_t k, int64_t n,
                    int use_exllama, zl_stream_t s);

@@ -133,6 +133,42 @@ def gptq_dequant_hf_naive(qweight_hf, qzeros_hf, scales_hf, group_size, g_idx=No
     return out
 
 
+def gptq_reconstruct(qweight, qzeros_plus1, scales, g_idx=None):
+    """nn::gptq::reconstruct_gptq (src/nn/quant/gptq/q_gemm.cu:641-676): the legacy (K/8, N) weight -- checkpoint word order,
+    qzeros (K/G, N/8) as they sit on the device AFTER increase_zero (utils.cu:61-88) -- as fp16 bits (K, N):
+        out[k][n] = hmul(int2half(q[k][n] - zero[g][n]), scale[g][n]),   g = g_idx[k] (None: k // group_size).
+    q - zero is an integer of magnitude <= 15 (exact in fp16); __hmul is one fp16 rounding of the exact product."""
+    qw, qz, sc = _c(qweight, np.uint32), _c(qzeros_plus1, np.uint32), _c(scales, np.uint16).view(np.float16)
+    k, n, groups = qw.shape[0] * 8, qw.shape[1], qz.shape[0]
+    q = np.zeros((k, n), np.int32)
+    for j in range(8):
+        q[j::8] = (qw >> np.uint32(4 * j)) & 0xF
+    z = np.zeros((groups, n), np.int32)
+    for j in range(8):
+        z[:, j::8] = (qz >> np.uint32(4 * j)) & 0xF
+    g = (np.arange(k) // (k // groups)) if g_idx is None else np.asarray(g_idx, np.int64)
+    d = (q - z[g]).astype(np.float32)
+    return (d * sc[g].astype(np.float32)).astype(np.float16).view(np.uint16)       # fp32 product of two halves is exact
+
+
+def gptq_gemm_legacy_exact(x, qweight, qzeros_plus1, scales, g_idx=None):
+    """the product nn::gptq::gptq_gemm stands for (q_gemm.cu:874-918, kernels :104-251 / :481-590) in fp64:
+    y[m][n] = sum_k x[m][k] (q[k][n] - zero[g(k)][n]) scale[g(k)][n].  The reference's kernels add fp16 partials per 128-k
+    block with atomicAdd in retirement order (non-deterministic), so there is no single R value to restate: implementations are
+    held to the exact sum."""
+    qw, qz, sc = _c(qweight, np.uint32), _c(qzeros_plus1, np.uint32), _c(scales, np.uint16).view(np.float16)
+    k, n, groups = qw.shape[0] * 8, qw.shape[1], qz.shape[0]
+    q = np.zeros((k, n), np.int32)
+    for j in range(8):
+        q[j::8] = (qw >> np.uint32(4 * j)) & 0xF
+    z = np.zeros((groups, n), np.int32)
+    for j in range(8):
+        z[:, j::8] = (qz >> np.uint32(4 * j)) & 0xF
+    g = (np.arange(k) // (k // groups)) if g_idx is None else np.asarray(g_idx, np.int64)
+    w = (q - z[g]).astype(np.float64) * sc[g].astype(np.float64)
+    return u2h(x).astype(np.float64) @ w
+
+
 # ----------------------------------------------------------------------------- a2/a3/a5 GEMM
 def gptq_gemm_k_major(x, qw, qz, sc, bias=None, sym=False, add_c=None):
     x, qw, qz, sc = _c(x, np.uint16), _c(qw, np.uint32), _c(qz, np.uint8), _c(sc, np.uint16)

@@ -49,7 +49,97 @@ def greedy_oracle(cfg, sd, g, prompt, n_new):
     return out, margins
 
 
+def fixture_main(case):
+    """ZL_BINDING_FIXTURE=<case>: drive `C` with EXACTLY what the reference's Python layer produced for a synthetic HF checkpoint --
+    tests/golden/python_layer_<case>.{json,npz}, written by tools/gen_python_layer_fixture.py where /root/reference exists: the dict
+    zhilight/llama.py hands to C.ModelConfig, quant_config_to_c's arguments, the environment switches zhilight/quant.py / llama.py set
+    (desc_act: GPTQ_KERNEL_ALGO=0 -> nn::gptq::gptq_gemm, SURVEY 8a row a6), the renamed / re-viewed state dict of
+    LLaMALoader + load_state_dict_pt, DynamicBatchConfig.c_config()'s fields, to_c_task's SearchTask arguments, and the engine /
+    dist arguments LLaMA.__init__ uses by default (device -1, memory limit 0, DistConfig())."""
+    from tools.gen_python_layer_fixture import hf_tensors, paths
+    jp, npz = paths(case)
+    meta = json.load(open(jp))
+    out = {"errors": [], "case": case}
+    for k, v in meta["env"].items():
+        os.environ[k] = v
+    config = dict(meta["config"])
+    if meta.get("quantization_config"):
+        config["quantization_config"] = meta["quantization_config"]
+    with np.load(npz) as z:
+        state = {k: z[k] for k in z.files}
+    cfg, sd, _ = hf_tensors(case)
+    g = 128
+    # the fixture IS the synthetic checkpoint under the reference's names: tie it to the tensors the oracle model is built from
+    mine = {k.replace("m.", "llama.", 1): v for k, v in _reference_names_state(sd).items()}
+    out["names_match"] = sorted(mine) == sorted(state)
+    out["tensors_match"] = out["names_match"] and all(np.array_equal(np.asarray(mine[k]).view(np.uint8), state[k].view(np.uint8)) for k in mine)
+    mc = C.ModelConfig(config)
+    dist = C.DistConfig(-1, "", 1, 0)                    # DistConfig().to_c_config() (zhilight/config/dist_config.py)
+    engine = C.Engine(-1, int(os.environ.get("ZL_BINDING_MEM", "0")), dist)   # LLaMA.__init__ defaults (zhilight/llama.py:121-141)
+    qa = meta["quant_config_to_c"]
+    model = C.LLaMA(engine, mc, C.QuantConfig(int(qa[0]), qa[1], bool(qa[2]), int(qa[3]), bool(qa[4])), dist)
+    model.load_state_dict(state)
+    dc = C.DynBatchConfig()
+    for f, v in meta["dyn_batch_config"].items():
+        setattr(dc, f, v)
+    gen = C.BatchGenerator(dc, model)
+    errors = out["errors"]
+
+    def run():
+        try:
+            gen.run()
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(repr(e)[:2000])
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    prompt = meta["prompt"]
+    t1 = C.SearchTask(prompt, *meta["search_task_args"])
+    assert gen.submit(t1, True)
+    t0, r1 = time.time(), None
+    while time.time() - t0 < 60 and not errors:
+        if t1.has_result():
+            r1 = t1.get_result(1.0)
+            break
+        time.sleep(0.02)
+    # the oracle: the CPU model over the same checkpoint; a desc_act checkpoint through its dense W16 matrices (reconstruct_gptq's)
+    om_sd = dict(sd)
+    w16 = None
+    if any(k.endswith(".g_idx") for k in sd):
+        w16 = {}
+        for key in [k for k in sd if k.endswith(".qweight")]:
+            base = key[:-8]
+            zp1 = oracle.gptq_increase_zero(sd[base + ".qzeros"].view(np.uint32))
+            w_kn = oracle.gptq_reconstruct(sd[key].view(np.uint32), zp1, sd[base + ".scales"].view(np.uint16), sd[base + ".g_idx"])
+            w16[base] = np.ascontiguousarray(w_kn.T)
+    n_new = meta["search_task_args"][1]
+    om = OracleModel(oracle, cfg, om_sd, g, 1, 128)
+    om.rope_kind = "plain"
+    if w16 is not None:
+        om.w16 = w16
+    logits = om.prefill(0, np.array(prompt, np.int32))
+    want, margins = [], []
+    for step in range(n_new):
+        row = logits[0].astype(np.float64).copy()
+        if step == 0:
+            row[meta["dyn_batch_config"]["bos_id"]] = row[meta["dyn_batch_config"]["eos_id"]] = -50000
+        order = np.argsort(-row, kind="stable")
+        want.append(int(order[0]))
+        margins.append(float(row[order[0]] - row[order[1]]) / float(np.abs(row).max()))
+        if step + 1 < n_new:
+            logits, _ = om.step(np.array([want[-1]], np.int32), [len(prompt) + step])
+    out["greedy"] = {"got": list(r1[3][0][0]) if r1 and r1[3] else None, "oracle": want, "margins": margins,
+                     "first_token_delay_ms": r1[3][0][3] if r1 and r1[3] else None}
+    out["env"] = meta["env"]
+    print("BINDING_RESULT " + json.dumps(out), flush=True)
+    gen.stop()
+    th.join(timeout=10)
+    os._exit(0)
+
+
 def main():
+    if os.environ.get("ZL_BINDING_FIXTURE"):
+        return fixture_main(os.environ["ZL_BINDING_FIXTURE"])
     rng = np.random.default_rng(21)
     cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2, eps=1e-5, rope_theta=5e5)
     g = 128

@@ -104,6 +104,30 @@ def test_awq_and_w4a8_through_cpp(cx, oracle):
     assert np.array_equal(y.view(np.uint16), oracle.quant_scale_back_f32(oracle.int8_gemm_nt(rq, rw8), rsx, rs))
 
 
+@pytest.mark.parametrize("act_order", [False, True])
+def test_gptq_legacy_route_reconstruct_and_alt_gemm(cx, oracle, act_order):
+    """SURVEY 8a row a6, the part without exllama (a row-parallel act-order shard under GPTQ_KERNEL_ALGO=0): nn::gptq::reconstruct_gptq
+    bit-exact against its restatement (q_gemm.cu:641-676), and nn::gptq::gptq_gemm(use_exllama = false) -- checkpoint-order words,
+    raw g_idx -- against the exact product (the reference's alt kernel adds fp16 partials atomically: no bit pattern to match)."""
+    rng = np.random.default_rng(61 + act_order)
+    k, n, g = 1024, 264, 128
+    qw, qz, sc, g_idx, w16 = synth.gptq_act_order_hf(rng, k, n, g)
+    if not act_order:
+        g_idx = (np.arange(k) // g).astype(np.int32)
+    zp1 = oracle.gptq_increase_zero(qz)
+    got = cx.gptq_reconstruct(qw.view(np.int32), zp1.view(np.int32), sc.view(np.float16), g_idx)
+    assert np.array_equal(got.view(np.uint16), oracle.gptq_reconstruct(qw, zp1, sc, g_idx))
+    if act_order:                                        # ... which is the matrix the k-major dequantiser produces for the same checkpoint
+        assert np.array_equal(got.view(np.uint16), np.ascontiguousarray(w16.T).view(np.uint16))
+    for m in (1, 6, 40):
+        x = synth.act(rng, m, k)
+        y = cx.gptq_gemm_legacy(x, qw.view(np.int32), zp1.view(np.int32), sc.view(np.float16), g_idx, False, g).astype(np.float64)
+        want = oracle.gptq_gemm_legacy_exact(oracle.h2u(x), qw, zp1, sc, g_idx)
+        rms = np.sqrt((want ** 2).mean())
+        # the dense GEMM multiplies with the fp16-rounded weights (reconstruct_gptq + cuBLAS in the reference above 8 rows)
+        assert np.abs(y - want).max() <= 2.0 ** -10 * np.abs(want).max() + 2e-3 * rms, (m, np.abs(y - want).max() / rms)
+
+
 def test_gptq_load_transforms_bit_exact(cx, oracle):
     rng = np.random.default_rng(7)
     qw, qz, sc = synth.gptq_hf(rng, 1024, 256, 128)

@@ -92,6 +92,39 @@ def test_reference_int4gptq_layer_act_order(ref, oracle):
     ref.weight_cache_clear()
 
 
+@pytest.mark.parametrize("act_order", [True, False])
+def test_reference_int4gptq_layer_legacy_kernel_algo(ref, oracle, act_order, monkeypatch):
+    """GPTQ_KERNEL_ALGO=0 -- what zhilight/quant.py:73-76 sets for every desc_act checkpoint -- takes
+    Int4GPTQ::forward to nn::gptq::gptq_gemm (linear.cpp:1000) with the (K/8, N) operands preprocess_weight leaves without
+    transpose_weight.  The boundary computes it on the k-major kernels (hostcpp/nn_amd.cpp): the reference's own layer, loaded by
+    its own load_state_dict, against the dense product of the checkpoint's dequantised matrix -- rows 1 / 5 (its fp16-atomics GEMV
+    range), 60 (its reconstruct + cuBLAS range); the re-layout happens once (cached by operand identity)."""
+    monkeypatch.setenv("GPTQ_KERNEL_ALGO", "0")
+    rng = np.random.default_rng(23 + act_order)
+    k, n, g = 1024, 256, 128
+    if act_order:
+        qw, qz, sc, g_idx, w16 = synth.gptq_act_order_hf(rng, k, n, g)
+    else:
+        qw, qz, sc = synth.gptq_hf(rng, k, n, g)
+        g_idx = None
+        w16 = oracle.u2h(oracle.gptq_dequant_k_major(*oracle.gptq_prepare_k_major(qw, qz, sc, g)))
+    ref.weight_cache_clear()
+    lin = ref.RefLinear(k, n, 5, group_size=g, act_order=act_order)
+    lin.load(_gptq_state(qw, qz, sc, g_idx), "l")
+    for m in (1, 5, 60):
+        x = synth.act(rng, m, k)
+        got = lin.forward(x).astype(np.float64)
+        want = x.astype(np.float64) @ w16.astype(np.float64).T
+        rms = np.sqrt((want ** 2).mean())
+        assert got.shape == (m, n)
+        assert np.abs(got - want).max() <= 2.0 ** -10 * np.abs(want).max() + 6e-3 * rms, (m, np.abs(got - want).max() / rms)
+    assert ref.weight_cache_size() >= 1                   # the legacy operands' k-major form + its packed tiles, made once
+    size = ref.weight_cache_size()
+    lin.forward(synth.act(rng, 3, k))
+    assert ref.weight_cache_size() == size
+    ref.weight_cache_clear()
+
+
 @pytest.mark.parametrize("m", [1, 7, 32, 45])
 def test_reference_int8linear_layer_bit_exact(ref, oracle, m):
     """AutoInt8: the weight is quantised per row at load (quant_calc_scale), the activations per token per call; the

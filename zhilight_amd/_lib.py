@@ -26,7 +26,7 @@ SYMBOLS = [
     "zl_cast", "zl_copy_2d", "zl_index_select", "zl_argmax_advance", "zl_arange_i32", "zl_divide_i32", "zl_scatter_update_dim0", "zl_sort_pairs_i32", "zl_log_softmax_bias", "zl_softmax_rows", "zl_topk_rows", "zl_gather_logits", "zl_scatter_logits", "zl_repetition_penalty", "zl_reduce_abs_max", "zl_binary_op", "zl_scale", "zl_act_inplace",
     "zl_count_nonfinite", "zl_perm_narrow_u16", "zl_perm_reverse_u16", "zl_permute_input_u16", "zl_gptq_permute_rows",
     "zl_version", "zl_status_string", "zl_device_cu_count",
-    "zl_gptq_shuffle", "zl_gptq_increase_zero", "zl_gptq_q4_to_q8", "zl_transpose_2d",
+    "zl_gptq_shuffle", "zl_gptq_increase_zero", "zl_gptq_q4_to_q8", "zl_transpose_2d", "zl_gptq_reconstruct",
     "zl_awq_un_shuffle", "zl_awq_shuffle",
     "zl_w4_layout", "zl_w4_pack", "zl_w4_dequant", "zl_w4a16_gemm",
     "zl_w4m_layout", "zl_w4m_pack", "zl_w4m_unpack", "zl_w4a16_gemm_mfma", "zl_w4a16_gemm_tiled", "zl_w4a16_scratch_bytes", "zl_w4a16_gemm_mfma_ex", "zl_w4a16_gemm_tiled_ex",

@@ -192,6 +192,39 @@ int zl_gptq_q4_to_q8(const uint32_t* in, uint8_t* out, int64_t nwords, zl_stream
     return zl_launch_status();
 }
 
+// nn::gptq::reconstruct_gptq (src/nn/quant/gptq/q_gemm.cu:641-676): the (K/8, N) checkpoint-order weight of the legacy route
+// (GPTQ_KERNEL_ALGO=0 without exllama: a row-parallel act-order shard) as a dense fp16 (K, N) matrix,
+//     out[k][n] = hmul(int2half(q[k][n] - zero[g][n]), scale[g][n]),  g = g_idx[k] (or k / group_size),
+// zero = the stored nibble (increase_zero already ran at load).  One thread per (word row, column): eight k of one column.
+namespace {
+__global__ __launch_bounds__(256) void k_gptq_reconstruct(const uint32_t* __restrict__ qw, const uint32_t* __restrict__ qz,
+                                                          const uint16_t* __restrict__ sc, const int32_t* __restrict__ g_idx,
+                                                          uint16_t* __restrict__ out, int64_t k, int64_t n, int64_t groups) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, row8 = blockIdx.y;
+    if (col >= n) return;
+    const uint32_t w = qw[row8 * n + col];
+    const int64_t gsz = k / groups;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t kk = row8 * 8 + e;
+        const int64_t g = g_idx ? (int64_t)g_idx[kk] : kk / gsz;
+        const int z = (int)((qz[g * (n / 8) + col / 8] >> ((col & 7) * 4)) & 0xf);
+        const _Float16 d = (_Float16)((int)((w >> (4 * e)) & 0xf) - z);                  // |value| <= 15: exact
+        const _Float16 v = d * __builtin_bit_cast(_Float16, sc[g * n + col]);            // __hmul: one fp16 rounding
+        out[kk * n + col] = __builtin_bit_cast(uint16_t, v);
+    }
+}
+}  // namespace
+
+int zl_gptq_reconstruct(const uint32_t* qweight, const uint32_t* qzeros, const uint16_t* scales, const int32_t* g_idx, uint16_t* out,
+                        int64_t k, int64_t n, int64_t groups, zl_stream_t s) {
+    ZL_CHECK_ARG(qweight && qzeros && scales && out && k > 0 && n > 0 && groups > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(k % 8 == 0 && n % 8 == 0 && k % groups == 0 && k / 8 <= 65535, ZL_ESHAPE);
+    hipLaunchKernelGGL(k_gptq_reconstruct, dim3((unsigned)((n + 255) / 256), (unsigned)(k / 8)), dim3(256), 0, (hipStream_t)s, qweight,
+                       qzeros, scales, g_idx, out, k, n, groups);
+    return zl_launch_status();
+}
+
 int zl_transpose_2d(const void* in, void* out, int64_t rows, int64_t cols, int elem_size, zl_stream_t s) {
     ZL_CHECK_ARG(in && out && rows > 0 && cols > 0, ZL_EINVAL);
     dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));

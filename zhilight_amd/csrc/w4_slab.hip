@@ -73,6 +73,7 @@ struct SlabParams {
     uint16_t* const* v_bufs;
     uint16_t* q_out;
     int h, hkv, d, bshd;
+    int tstride;       // tiles between a workgroup's consecutive tiles: 1; ROPE: d / 32 (a column block and its rotation partners)
 };
 
 __device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_s, uint32_t magic_v) {
@@ -112,7 +113,7 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) |
 
 template <int R, int GPW, int MB, bool ROPE>
 __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
-    constexpr int TOTAL = R * GPW, D = TOTAL < 8 ? TOTAL : 8;
+    constexpr int TOTAL = R * GPW, D = TOTAL < 8 ? TOTAL + 1 : 8;   // ring slots: D - 1 items in flight + the one being finished
     constexpr int XS = GPW < 2 ? GPW : 2;             // activation groups resident in the wave's LDS region
     constexpr int DM = 4 * MB;                        // DMA instructions per group: 4 rows x 256 B each
     constexpr int kSet = MB * 16 * 256;               // bytes per group image
@@ -124,7 +125,10 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
     const int nw = (int)(blockDim.x >> 6);
     const int nrow = lane & 15, kq = lane >> 4;
     const int ksi = (int)(blockIdx.x % (unsigned)p.ks), tg = (int)(blockIdx.x / (unsigned)p.ks);
-    const int tile0 = tg * R;
+    // ROPE (R = 2): workgroup tg owns tiles {base, base + s}, base = (tg / s) * 2 s + tg % s, s = d / 32 -- a column block and the
+    // block D / 2 columns further, its partners in the neox rotation (w4_phase.hip's pairing)
+    const int tile0 = ROPE ? (tg / p.tstride) * 2 * p.tstride + tg % p.tstride : tg * R;
+    const int tstride = ROPE ? p.tstride : 1;
     const int g0 = (ksi * nw + wave) * GPW;           // this wave's first 128-k group
 
     // ---- activations: group image [16 MB rows][16 pieces of 16 B], piece q of row r at position q ^ (r & 15)
@@ -151,8 +155,13 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
     auto dma_x = [&](int set, int j) {                // both static; group g0 + j into region `set`
         const bool live = g0 + j < p.groups;
 #pragma unroll
-        for (int i = 0; i < DM; ++i)
+        for (int i = 0; i < DM; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass silently drops a kernel stub whose body names this builtin: ROCm 7.2)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(xw + set * kSet + i * 1024), 16, live ? x_off[i] : kOob, (g0 + j) * 256, 0, 0);
+#else
+            (void)live;
+#endif
+        }
     };
 #pragma unroll
     for (int j = 0; j < XS; ++j) dma_x(j, j);
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
     }
     auto issue = [&](int slot, int i) {               // both static
         const int j = i / R, r = i % R;
-        const uint32_t it = (uint32_t)min(tile0 + r, p.tiles - 1) * (uint32_t)p.groups + (uint32_t)(g0 + j);
+        const uint32_t it = (uint32_t)min(tile0 + r * tstride, p.tiles - 1) * (uint32_t)p.groups + (uint32_t)(g0 + j);
         wq[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off[j], it * 1024u, 2 /* nt */));
         mt[slot] = __builtin_amdgcn_raw_buffer_load_b32(rm, m_off[j], it * 64u, 2);
     };
@@ -218,11 +227,17 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
     for (int i = 0; i < TOTAL; ++i) {
         const int slot = i % D, pslot = (i + D - 1) % D, r = i % R, j = i / R, set = j % XS;
         if (r == 0) {
-            // Group j's image has landed once at most the loads issued AFTER its DMAs are outstanding (in-order return): the DMAs
-            // of group j + 1 (requested in the prologue for j = 0, at the start of group j - 1 otherwise) and the ring items in
-            // flight.  That is laxer than what item i itself needs, so the wait costs nothing on top.
+            // Group j's image has landed once at most the loads issued AFTER its DMAs are outstanding (in-order return):
+            //   * the DMAs of group j + 1 (requested in the prologue for j = 0, at the start of group j - 1 otherwise);
+            //   * the ring items in flight that were requested after them.  The DMAs of a group j >= XS go out at the start of group
+            //     j - XS, behind that step's fragment reads and ahead of its refill, so only items from (j - XS) R + D - 1 on are
+            //     younger; with few tiles per workgroup (R = 1, 2) the items in flight are mostly OLDER -- counting them all let the
+            //     fragment reads run ahead of the DMA (the first cut of this kernel: wrong rows for R <= 2 with four groups per wave).
+            // The count never exceeds what item i itself has to wait for, so the wait costs nothing on top.
             const int younger_groups = (j == 0) ? (XS - 1 < GPW - 1 ? XS - 1 : GPW - 1) : ((j + 1 < GPW) ? 1 : 0);
-            const int ring_fly = (TOTAL - i) < (D - 1) ? (TOTAL - i) : (D - 1);
+            const int fly_hi = (i + D - 2) < (TOTAL - 1) ? (i + D - 2) : (TOTAL - 1);
+            const int first_younger = j < XS ? i : ((j - XS) * R + D - 1 > i ? (j - XS) * R + D - 1 : i);
+            const int ring_fly = fly_hi - first_younger + 1 > 0 ? fly_hi - first_younger + 1 : 0;
             switch (younger_groups * DM + 2 * ring_fly) {     // (the builtin wants an immediate: static after unrolling)
 #define ZL_W(n) case n: __builtin_amdgcn_s_waitcnt(vmcnt_imm(n)); break;
                 ZL_W(0) ZL_W(2) ZL_W(4) ZL_W(6) ZL_W(8) ZL_W(10) ZL_W(12) ZL_W(14) ZL_W(16) ZL_W(18) ZL_W(20) ZL_W(22)
@@ -265,7 +280,19 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
         if (i + D - 1 < TOTAL) issue(pslot, i + D - 1);
         __builtin_amdgcn_sched_barrier(0);
     }
-    finish_prev((TOTAL - 1) % R, (TOTAL - 1) % D);
+    {
+        // The last item's scale-accumulate, in plain C++: inside the loop a dequantisation block (>= 36 VALU) sits between an
+        // item's MFMAs and the asm that reads their results; here nothing does, and the hazard recognizer does not look into
+        // inline asm -- the v_fma_mix read the accumulators before the matrix pipe had written them (the first cuts: the LAST
+        // tile of every workgroup wrong in rows 4 q + {0, 1, 2}).  fma(group sum, float(scale), acc) is what v_fma_mix_f32 computes.
+        constexpr int rl = (TOTAL - 1) % R, sl = (TOTAL - 1) % D;
+        const float sc_last = (float)__builtin_bit_cast(hv2, mt[sl]).x;
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[rl][b][e] = __builtin_fmaf(accg_prev[b][e], sc_last, acc[rl][b][e]);
+        }
+    }
     __syncthreads();                                   // every wave is done with its activation region: LDS is reused below
 
     // ---- the NW partial tiles meet in LDS, summed in wave order
@@ -340,15 +367,14 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
         }
         __syncthreads();
         const float* finf = reinterpret_cast<const float*>(fin);
-        const int tph = p.d >> 4, half_t = tph >> 1, half = p.d >> 1;      // tiles per head; R % tph == 0
-        const int nout = (R / 2) * 16 * p.m;
+        const int half = p.d >> 1;
+        const int nout = 16 * p.m;
         for (int o = (int)threadIdx.x; o < nout; o += bd) {
-            const int n_local = o & 15, m = (o >> 4) % p.m, pr = (o >> 4) / p.m;     // pr: first-half tile of a head, 0 .. R/2 - 1
-            const int r0 = (pr / half_t) * tph + pr % half_t, r1 = r0 + half_t;
-            const int tile = tile0 + r0;
+            const int n_local = o & 15, m = o >> 4;
+            const int tile = tile0;
             if (tile >= p.tiles) continue;
             const int b = m >> 4, ln = ((m & 15) >> 2) * 16 + n_local, i = m & 3;
-            float v0 = finf[((size_t)(r0 * MB + b) * 64 + ln) * 4 + i], v1 = finf[((size_t)(r1 * MB + b) * 64 + ln) * 4 + i];
+            float v0 = finf[((size_t)(0 * MB + b) * 64 + ln) * 4 + i], v1 = finf[((size_t)(1 * MB + b) * 64 + ln) * 4 + i];
             const int n0 = tile * 16 + n_local, n1 = n0 + half;
             if ((p.epi & ZL_EPI_BIAS) && p.bias) {
                 v0 += (float)__builtin_bit_cast(_Float16, p.bias[n0]);
@@ -395,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
             const int s = (int)threadIdx.x + it * bd;
             if (s >= SLOTS) continue;                 // wave-uniform (bd and SLOTS are multiples of 64)
             const int rb = s >> 6, ln = s & 63, r = rb / MB, b = rb % MB;
-            const int tile = tile0 + r, n_local = ln & 15, mrow0 = b * 16 + (ln >> 4) * 4;
+            const int tile = tile0 + r * tstride, n_local = ln & 15, mrow0 = b * 16 + (ln >> 4) * 4;
             f4 v = val[it];
             if (silu) {
                 // gate at even, up at odd columns of the interleaved weight: the neighbour lane holds the other one
@@ -481,48 +507,39 @@ struct SlabPlan {
     int r, nw, gpw, ks, grid;
 };
 
-// Tiles per workgroup (1 / 2 / 4 / 8), waves per workgroup (4 / 8), groups per wave (1 / 2 / 4) and the K split that follows.
-// Every candidate that runs as ONE generation of workgroups (8-wave workgroups: one per CU; 4-wave ones: two) is priced by a
-// three-term model fitted to profiles/r06_slab_sweep.txt -- bytes through the busiest CU (weights + activations, the activations
-// at a discount: they come from L2), a fixed cost per launch, and the K-split tail (slab out, ticket, fold of KS slabs) -- and the
-// cheapest wins.  rope: eight tiles per workgroup (whole heads).
+// Geometry, from the sweep in profiles/r06_slab_sweep.txt (Llama-3-8B shapes, 9 / 16 / 32 rows; every (R, NW, GPW) that fits):
+//   * eight waves x four groups per wave win wherever K allows (32 groups = 4096 k per workgroup: the most weight items per wave,
+//     and no K split up to K = 4096 -- a split costs its tail, 3..5 us: slab out, ticket, fold); shorter K: fewer groups per wave;
+//   * longer K splits: KS = ceil(groups / 32) (down: 4);
+//   * R = the fewest tiles per workgroup that still give ONE generation of workgroups (attn_out 1, qkv 2, down 4): more tiles per
+//     workgroup would cut activation traffic further but leave CUs without a workgroup, which costs more;
+//   * many tiles per CU (gate|up: 7) -- the phase kernel already amortises its staging there and ties or wins: not taken.
 bool plan_slab(int m, int tiles, int groups, bool have_scratch, bool rope, const zl_w4_opts_t& o, SlabPlan* out) {
+    (void)m;
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
-    const int mb = m <= 16 ? 1 : 2;
-    double best = 1e30;
-    for (int r = rope ? 8 : 1; r <= 8; r *= 2) {
-        if (o.slab_r && r != o.slab_r) continue;
-        const int ntg = (tiles + r - 1) / r;
-        for (int nw = 4; nw <= 8; nw += 4) {
-            if (o.slab_nw && nw != o.slab_nw) continue;
-            for (int gpw = 1; gpw <= 4; gpw *= 2) {
-                if (o.slab_gpw && gpw != o.slab_gpw) continue;
-                const int gw = nw * gpw, ks = (groups + gw - 1) / gw;
-                if (ks > kMaxKS || (ks > 1 && !have_scratch)) continue;
-                if (gw - groups >= gpw * 2 && ks == 1) continue;             // more than a wave or two with nothing to do
-                const long grid = (long)ntg * ks, cap = (long)cus * (nw == 4 ? 2 : 1);
-                const bool forced = o.slab_r && o.slab_nw && o.slab_gpw;
-                if (grid > cap && !forced) continue;                        // a second generation: the phase kernel does better
-                const double wgs_per_cu = (double)((grid + cus - 1) / cus);
-                const double w_kb = (double)r * gw * 1.0625, x_kb = (double)(16 * mb) * gw * 0.25;
-                const double stream = wgs_per_cu * (w_kb + 0.5 * x_kb) / 26.0;                  // us at ~26 KB/us per CU
-                const double idle = grid < cus ? 1.0 + 0.5 * (double)(cus - grid) / cus : 1.0;   // a partly empty chip streams slower per byte
-                const double tail = ks > 1 ? 3.5 + 0.2 * ks : 0.0;
-                const double cost = 3.0 + stream * idle + tail;
-                if (cost < best) {
-                    best = cost;
-                    out->r = r; out->nw = nw; out->gpw = gpw; out->ks = ks; out->grid = (int)grid;
-                }
-            }
-        }
+    int nw = groups >= 8 ? 8 : 4, gpw = groups > 16 ? 4 : groups > 8 ? 2 : 1;
+    if (o.slab_nw) nw = o.slab_nw;
+    if (o.slab_gpw) gpw = o.slab_gpw;
+    const int gw = nw * gpw, ks = (groups + gw - 1) / gw;
+    if (ks > kMaxKS || (ks > 1 && !have_scratch)) return false;
+    const bool forced = o.slab_r != 0;
+    int r = rope ? 2 : 1;
+    if (forced) r = o.slab_r;
+    else if (!rope) {
+        if (tiles > 3 * cus) return false;
+        while (r < 8 && (long)((tiles + r - 1) / r) * ks > cus) r *= 2;
     }
-    return best < 1e30;
+    if (rope && r != 2) return false;
+    const long grid = (long)((tiles + r - 1) / r) * ks;
+    if (grid > 2L * cus && !forced) return false;
+    out->r = r; out->nw = nw; out->gpw = gpw; out->ks = ks; out->grid = (int)grid;
+    return true;
 }
 
 template <bool ROPE>
 int launch_slab_any(const SlabParams& p, const SlabPlan& pl, int mb, hipStream_t hs) {
-    if constexpr (ROPE) return launch_slab_r<8, true>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
+    if constexpr (ROPE) return launch_slab_r<2, true>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
     else switch (pl.r) {
         case 1: return launch_slab_r<1, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
         case 2: return launch_slab_r<2, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
@@ -576,7 +593,7 @@ int zl_w4a16_gemm_slab(const uint16_t* x, int64_t ldx, const uint32_t* qw, const
 }
 
 // internal (zl_w4a16_qkv_rope_scatter): the fused qkv projection of a decode step with the neox rotation and the KV scatter in
-// the epilogue; d in {32, 64, 128} (a workgroup's eight tiles hold whole heads, so a column and its rotation partner meet)
+// the epilogue; d % 32 == 0 (a workgroup's two tiles are a column block and its rotation partners)
 int zl_w4a16_gemm_slab_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                             uint32_t meta_bytes, const uint16_t* bias, int m, int n, int k, int groups, int tiles, const float* cosv,
                             const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
@@ -585,13 +602,13 @@ int zl_w4a16_gemm_slab_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, 
     static const zl_w4_opts_t kNoOpts = {};
     const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
     if (!slab_shape_ok(m, k, groups, tiles, ldx, qw_bytes)) return ZL_ESHAPE;
-    if ((d != 32 && d != 64 && d != 128) || n != (h + 2 * hkv) * d || tiles * 16 != n) return ZL_ESHAPE;
+    if (d % 32 != 0 || n != (h + 2 * hkv) * d || tiles * 16 != n) return ZL_ESHAPE;
     SlabPlan pl;
     if (!plan_slab(m, tiles, groups, o.scratch != nullptr, true, o, &pl)) return ZL_ESHAPE;
     SlabParams p = {};
     fill_common(p, x, ldx, qw, meta, qw_bytes, meta_bytes, bias, nullptr, nullptr, m, n, k, groups, tiles, bias ? ZL_EPI_BIAS : 0, n);
     p.cosv = cosv; p.sinv = sinv; p.placement = placement; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs;
-    p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd;
+    p.q_out = q_out; p.h = h; p.hkv = hkv; p.d = d; p.bshd = bshd; p.tstride = d / 32;
     const int mb = m <= 16 ? 1 : 2;
     p.ks = pl.ks;
     if (pl.ks > 1 && !take_scratch(o, pl, mb, tiles, p)) return ZL_ESHAPE;

@@ -1,5 +1,5 @@
-// host_offpath.cpp -- names the reference's host translation units reference that are OFF the MI355X hot-path boundary (Marlin, the
-// GPTQ_KERNEL_ALGO=0 kernels, smooth-quant calibration helpers, the loss / scoring helpers of llama.cpp): definitions that throw,
+// host_offpath.cpp -- names the reference's host translation units reference that are OFF the MI355X hot-path boundary (Marlin,
+// reconstruct_exllama, smooth-quant calibration helpers, the loss / scoring helpers of llama.cpp): definitions that throw,
 // so that the library links and a call says what is missing -- plus the two that are ON it under another party's name:
 //   deep_gemm_fp8_block_h20_group (3rd/deep_gemm/deep_gemm_api.h): the closed DeepGEMM entry point Fp8Block::forward / grouped_gemm
 //       call (linear.cpp:1697-1950; the reference unit is compiled with -DENABLE_DS_DEEP_GEMM) = this boundary's block-scaled FP8 GEMM;
@@ -24,14 +24,10 @@ core::Tensor gptq_marlin_gemm(const core::Context&, const core::Tensor&, core::T
 }
 namespace nn {
 namespace gptq {
-core::Tensor gptq_gemm(const core::Context&, core::Tensor, core::Tensor, core::Tensor, core::Tensor, core::Tensor, bool, int, int, int) {
-    ZL_OFF_BOUNDARY("nn::gptq::gptq_gemm (GPTQ_KERNEL_ALGO=0; the k-major kernels are the default)");
-}
+// (nn::gptq::gptq_gemm and reconstruct_gptq -- the GPTQ_KERNEL_ALGO=0 route zhilight/quant.py:73-76 selects for desc_act
+//  checkpoints -- are ON the path: nn_amd.cpp)
 void reconstruct_exllama(const uint32_t*, const uint32_t*, const half*, const int*, half*, int, int, int, const cudaStream_t, int, int) {
-    ZL_OFF_BOUNDARY("nn::gptq::reconstruct_exllama (use dequant_k_major)");
-}
-void reconstruct_gptq(const uint32_t*, const uint32_t*, const half*, const int*, half*, int, int, int, const cudaStream_t) {
-    ZL_OFF_BOUNDARY("nn::gptq::reconstruct_gptq (use dequant_k_major)");
+    ZL_OFF_BOUNDARY("nn::gptq::reconstruct_exllama (Int4GPTQ::get_dequant_weight without the k-major layout; use dequant_k_major)");
 }
 }  // namespace gptq
 

@@ -11,6 +11,7 @@
 #include <tuple>
 
 #include "../../include/zhilight_amd.h"
+#include "bm_functions.h"
 
 using bmengine::core::Context;
 using bmengine::core::DataType;
@@ -100,6 +101,10 @@ struct WeightEntry {
 };
 std::mutex g_cache_mu;
 std::map<WeightKey, WeightEntry> g_cache;
+struct LegacyKMajor {      // gptq_gemm (GPTQ_KERNEL_ALGO=0): the k-major form of the legacy operands, see below
+    Tensor qweight, qzeros, scales, q_perm_i16, rev_perm;
+};
+std::map<WeightKey, LegacyKMajor> g_legacy;     // guarded by g_cache_mu; cleared with the weight cache
 WeightKey make_key(int flavour, size_t n, size_t k, std::initializer_list<const Tensor*> ts) {
     WeightKey key;
     std::memset(&key, 0, sizeof(key));
@@ -114,6 +119,7 @@ WeightKey make_key(int flavour, size_t n, size_t k, std::initializer_list<const 
 void amd_weight_cache_clear() {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     g_cache.clear();
+    g_legacy.clear();
 }
 size_t amd_weight_cache_size() {
     std::lock_guard<std::mutex> lk(g_cache_mu);
@@ -282,6 +288,75 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a0, const Tensor& q_w
     zl_check(zl_w4a16_gemm(u16(a), ldx, qw.data<uint32_t>(), sc.data<uint16_t>(), zr.data<uint16_t>(), bptr, nullptr, u16m(out), m, n, k,
                            g, 0, nullptr, 0.f, epi, st_of(ctx)), "gptq_gemm_k_major");
     return out;
+}
+
+// ---- the legacy route: GPTQ_KERNEL_ALGO=0 (src/nn/quant/gptq/q_gemm.cu:874-918) ------------------------------------------------
+// Int4GPTQ::forward calls this when new_kernel is off (linear.cpp:1000) -- which zhilight/quant.py:73-76 forces for every desc_act
+// checkpoint.  The operands are what Int4GPTQ::preprocess_weight leaves WITHOUT transpose_weight:
+//   use_exllama: b_q_weight (K/8, N) rows regrouped by q_perm = argsort(g_idx) and nibble-shuffled (gptq_shuffle), qzeros
+//                (K/G, N/8) + 1, scales (K/G, N), b_g_idx = q_perm (K) int32 or empty.  The reference multiplies with
+//                gemm_half_q_half_gptq_kernel (q_gemm.cu:104-251: a[perm[k]] gathered per 128-k block, fp16 hfma2 dots, fp32 per
+//                32 k, fp16 atomicAdd of the per-block partials -- in whatever order the blocks retire) or, above 50 rows,
+//                reconstruct_exllama + cuBLAS.  Here: the SAME product on the k-major kernels -- the operands take
+//                transpose_weight's steps once (q4_to_q8, three transposes, int32_to_int16 / reverse_perm; cached by operand
+//                identity like every other re-layout of this file), then gptq_gemm_k_major: permute_input + the streaming GEMV /
+//                GEMM with fp32 accumulation, deterministic.  Same (q - z) s x[perm] terms, fewer roundings than the atomics.
+//   otherwise    (a row-parallel act-order shard: the rows of a K slice reference groups freely, so they cannot be regrouped):
+//                checkpoint-order weight + raw g_idx.  The reference runs gemm_half_q_half_alt_kernel up to 8 rows and
+//                reconstruct_gptq + cuBLAS above; here reconstruct_gptq's matrix (bit-exact, zl_gptq_reconstruct) + the dense
+//                GEMM for every row count.
+// size_n1 / size_n2 (fused q|k|v with one permutation each) cannot occur: Int4GPTQ::fuse2 / fuse3 refuse act-order operands
+// (linear.cpp:800, 836), and without act-order there is no permutation at all.
+void reconstruct_gptq(const uint32_t* b_q_weight, const uint32_t* b_gptq_qzeros, const __half* b_gptq_scales, const int* b_g_idx,
+                      __half* out, int height, int width, int num_group, const hipStream_t stream) {
+    zl_check(zl_gptq_reconstruct(b_q_weight, b_gptq_qzeros, reinterpret_cast<const uint16_t*>(b_gptq_scales), b_g_idx,
+                                 reinterpret_cast<uint16_t*>(out), height, width, num_group, (zl_stream_t)stream), "reconstruct_gptq");
+}
+
+Tensor gptq_gemm(const Context& ctx, Tensor a, Tensor b_q_weight, Tensor b_gptq_qzeros, Tensor b_gptq_scales, Tensor b_g_idx,
+                 bool use_exllama, int group_size, int size_n1, int size_n2) {
+    BM_ASSERT_EQ(b_q_weight.ndim(), 2, "gptq_gemm: b_q_weight (K/8, N)");
+    const size_t K = b_q_weight.size(0) * 8, N = b_q_weight.size(1);
+    BM_ASSERT_EQ(a.size(-1), K, "");
+    BM_ASSERT(a.dtype() == DataType::kHalf, "A must be half");
+    BM_ASSERT(group_size > 0 && K % (size_t)group_size == 0, "gptq_gemm: group_size");
+    (void)size_n1; (void)size_n2;
+    if (!use_exllama) {
+        BM_ASSERT(b_g_idx.numel() == K, "gptq_gemm (alt route): g_idx (K)");
+        Tensor w = ctx.tensor({K, N}, DataType::kHalf, "gptq_gemm.temp_dq");
+        reconstruct_gptq(b_q_weight.data<uint32_t>(), b_gptq_qzeros.data<uint32_t>(), reinterpret_cast<const __half*>(b_gptq_scales.data()),
+                         b_g_idx.data<int>(), reinterpret_cast<__half*>(w.mutable_data()), (int)K, (int)N, (int)(K / group_size),
+                         ctx.current_cuda_stream());
+        bmengine::functions::Gemm gemm(ctx, DataType::kHalf, false, false);
+        return gemm.forward(ctx, a, w);
+    }
+    BM_ASSERT(b_g_idx.numel() == 0 || b_g_idx.numel() == K, "gptq_gemm: one permutation (q_perm of K entries) or none");
+    const WeightKey key = make_key(5, N, K, {&b_q_weight, &b_gptq_qzeros, &b_gptq_scales, &b_g_idx});
+    LegacyKMajor km;
+    bool hit = false;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_legacy.find(key);
+        if (it != g_legacy.end()) { km = it->second; hit = true; }
+    }
+    if (!hit) {
+        // Int4GPTQ::transpose_weight (linear.cpp:1085-1099), on copies: the layer keeps its own tensors
+        bmengine::functions::Transpose transpose(ctx);
+        Tensor z8 = q4_to_q8(ctx, b_gptq_qzeros);
+        km.qweight = transpose.forward(ctx, b_q_weight);
+        km.qzeros = transpose.forward(ctx, z8);
+        km.scales = transpose.forward(ctx, b_gptq_scales);
+        if (b_g_idx.numel()) {
+            km.q_perm_i16 = int32_to_int16(ctx, b_g_idx);
+            km.rev_perm = reverse_perm(ctx, b_g_idx);
+        }
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_legacy.emplace(key, km);
+        WeightEntry e;                                  // the operands' storage (hence their addresses) stays alive with the entry
+        e.raw = {b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx};
+        g_cache.emplace(key, std::move(e));
+    }
+    return gptq_gemm_k_major(ctx, a, km.qweight, km.qzeros, km.scales, km.q_perm_i16, km.rev_perm, nullptr, false);
 }
 
 Tensor gemm_fuse_gate_in(const Context& ctx, const Tensor& a, const Tensor& q_weight1, const Tensor& qzeros1, const Tensor& scales1,

@@ -28,6 +28,8 @@
 #include <tuple>
 #include <vector>
 
+#include <hip/hip_fp16.h>   // __half: the reference spells reconstruct_gptq's operands `half`
+
 #include "bm_hip.h"
 
 namespace nn {
@@ -46,6 +48,16 @@ core::Tensor q4_to_q8(const core::Context& ctx, const core::Tensor& input);     
 core::Tensor int32_to_int16(const core::Context& ctx, const core::Tensor& input);
 core::Tensor reverse_perm(const core::Context& ctx, const core::Tensor& input);             // out[input[i]] = i
 core::Tensor permute_input(const core::Context& ctx, const core::Tensor& input, const core::Tensor& q_perm);   // out[m, k] = in[m, q_perm[k]]
+
+// ---- the legacy route, GPTQ_KERNEL_ALGO=0 (src/nn/quant/gptq/gptq.h:10-22, 62-72; q_gemm.cu:874-918, 641-700) ------------------
+// what Int4GPTQ::forward calls without the k-major layout (linear.cpp:1000) -- zhilight/quant.py:73-76 selects it for every
+// desc_act checkpoint.  b_q_weight (K/8, N) as gptq_shuffle left it (use_exllama) or in checkpoint order (otherwise), qzeros
+// (K/G, N/8) + 1, scales (K/G, N), b_g_idx = argsort(g_idx) (use_exllama, or empty) / the raw g_idx.  Computed on the k-major
+// kernels (see nn_amd.cpp); reconstruct_gptq is bit-exact.
+core::Tensor gptq_gemm(const core::Context& ctx, core::Tensor a, core::Tensor b_q_weight, core::Tensor b_gptq_qzeros,
+                       core::Tensor b_gptq_scales, core::Tensor b_g_idx, bool use_exllama, int group_size, int size_n1, int size_n2);
+void reconstruct_gptq(const uint32_t* b_q_weight, const uint32_t* b_gptq_qzeros, const __half* b_gptq_scales, const int* b_g_idx,
+                      __half* out, int height, int width, int num_group, const hipStream_t stream);
 
 // ---- the k-major GEMM family ---------------------------------------------------------------------------------------
 // q_weight (N, K/8) int32 exllama-shuffled words, qzeros (N, K/G) int8 (already +1), scales (N, K/G) half: the operands

@@ -127,6 +127,21 @@ PYBIND11_MODULE(zl_internals, m) {
             return c.down(y, "float16");
         }, py::arg("x"), py::arg("qweight"), py::arg("qzeros"), py::arg("scales"), py::arg("bias") = py::none(), py::arg("sym") = false,
            py::arg("prepack") = true)
+        .def("gptq_gemm_legacy", [](PyCtx& c, py::array x, py::array qweight, py::array qzeros, py::array scales, py::object g_idx,
+                                    bool use_exllama, int group_size) {
+            // nn::gptq::gptq_gemm (GPTQ_KERNEL_ALGO=0, q_gemm.cu:874-918): operands as Int4GPTQ::preprocess_weight(trans = false) leaves them
+            Tensor gi = c.up_opt(g_idx);
+            return c.down(nn::gptq::gptq_gemm(*c.ctx, c.up(x), c.up(qweight), c.up(qzeros), c.up(scales), gi, use_exllama, group_size,
+                                              (int)qweight.shape(1), (int)qweight.shape(1)), "float16");
+        })
+        .def("gptq_reconstruct", [](PyCtx& c, py::array qweight, py::array qzeros, py::array scales, py::object g_idx) {
+            Tensor qw = c.up(qweight), qz = c.up(qzeros), sc = c.up(scales), gi = c.up_opt(g_idx);
+            Tensor out = c.ctx->tensor({qw.size(0) * 8, qw.size(1)}, DataType::kHalf);
+            nn::gptq::reconstruct_gptq(qw.data<uint32_t>(), qz.data<uint32_t>(), reinterpret_cast<const __half*>(sc.data()),
+                                       gi.numel() ? gi.data<int>() : nullptr, reinterpret_cast<__half*>(out.mutable_data()), (int)qw.size(0) * 8,
+                                       (int)qw.size(1), (int)qz.size(0), c.ctx->current_cuda_stream());
+            return c.down(out, "float16");
+        })
         .def("gptq_dequant_k_major", [](PyCtx& c, py::array qw, py::array qz, py::array sc, bool prepack) {
             Tensor tq = c.up(qw), tz = c.up(qz), ts = c.up(sc);
             if (prepack) {
