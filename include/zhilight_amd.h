@@ -216,8 +216,8 @@ typedef struct {
                          a K split (the cost model picks those itself for N = 4096, K = 4096: attn_out of a prompt chunk), 6 no two-height plan (256-row
                          tiles + 192-row tiles in two launches when one height leaves the last round of workgroups partly empty) */
     /* round 6 (appended: zero-initialised structs of older callers keep their meaning) */
-    int slab;         /* 9..32 rows without a fused norm on the 2-D K-split tiles of w4_slab.hip: 0 default (on), -1 off */
-    int slab_min_m;   /* rows from which the slab kernel takes over (default 9) */
+    int slab;         /* 5..32 rows without a fused norm on the 2-D K-split tiles of w4_slab.hip: 0 default (on), -1 off */
+    int slab_min_m;   /* rows from which the slab kernel takes over (default 5) */
     int slab_nw, slab_gpw;   /* its geometry, for sweeps: waves per workgroup (4 / 8) and 128-k groups per wave (1 / 2 / 4); 0 = planned */
     int slab_r;       /* ... and 16-column tiles per workgroup (1 / 2 / 4 / 8); 0 = planned */
     int defer_norm;   /* 1: norm_weight with 9..32 rows may take the phase kernel's DEFERRED norm (not zl_rmsnorm's roundings, see
@@ -236,7 +236,7 @@ int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n);
  *                                                     split K for short grids)
  *   anything else (odd K tails, huge K)                k_w4a16_mfma (w4_mfma.hip: whole activation block staged in LDS, 16 rows per pass)
  *   group size not a multiple of 128                   not this entry point: zl_w4a16_gemm (w4_gemv.hip, the warp-reduce arithmetic)
- *   M = 9..32 without norm_weight, K % 128 == 0        k_w4a16_slab  (w4_slab.hip, round 6: 128-column x K-slice tiles, activation
+ *   M = 5..32 without norm_weight, K % 128 == 0        k_w4a16_slab  (w4_slab.hip, round 6: 128-column x K-slice tiles, activation
  *     (scratch for the K split; else the phase kernel)  fragments straight from global memory, split-K slabs folded by the last arriver)
  * norm_weight with 9..32 rows and zl_w4_opts_t::defer_norm = 1 runs the phase kernel's DEFERRED norm: the staged activation is T(x w) and the row's
  * rsqrt(mean x^2 + eps) multiplies the fp32 totals in the epilogue -- one launch less, but NOT the roundings of zl_rmsnorm + GEMM

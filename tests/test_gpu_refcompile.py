@@ -922,6 +922,55 @@ def test_reference_llama_tensor_parallel_engine_prompt_then_decode(ref, oracle):
     ref.weight_cache_clear()
 
 
+def test_reference_dual_stream_encode_on_the_engine_world2(ref, oracle, monkeypatch, capfd):
+    """the reference's OWN dual_stream_encode (src/nn/block/block.cpp:205-441, compiled
+    unmodified) on the engine at world size 2 -- DUAL_STREAM=1, a prompt chunk of 100 tokens > 2 x DUAL_STREAM_THRESHOLD (32): the chunk
+    is split in two parts (split_encode / split_tensor, buffer_context.cpp), each part's attention and feed-forward partial sums go
+    to the REDUCE stream the function creates (cudaStreamCreateWithPriority -> this shim), events order the two streams
+    (cudaEventRecord / cudaStreamWaitEvent / cudaEventSynchronize on bm_hip's streams), the reduced halves come back through
+    add_fuse_ln (LayerNorm::fuse_add) while the main stream computes the other half.  Logits against the tensor-parallel oracle's
+    prefill at 1e-3, both ranks bit-identical, FIVE runs, no exchange wait expired; the function's own start-up line on stdout shows
+    that it was the dual-stream path that ran."""
+    from zhilight_amd.llama import ModelConfig
+    from test_gpu_model import OracleModel, _hf_state
+    if not hasattr(ref, "RefEngineLLaMA"):
+        pytest.skip("prebuilt test module without the engine harness")
+    monkeypatch.setenv("DUAL_STREAM", "1")
+    monkeypatch.setenv("DUAL_STREAM_THRESHOLD", "32")
+    rng = np.random.default_rng(14)
+    cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2, eps=1e-5, rope_theta=5e5)
+    g, s, len_buf = 128, 100, 128
+    sd = _hf_state(rng, cfg, g)
+    ref.weight_cache_clear()
+    model = ref.RefEngineLLaMA(cfg.num_layers, cfg.dim_model, cfg.num_heads, cfg.num_kv_heads, cfg.dim_head, cfg.dim_ff, cfg.vocab_size, eps=cfg.eps,
+                               rope_theta=cfg.rope_theta, quant_type=5, group_size=g, devices=[0, 0])
+    model.load(_reference_names_state(sd), "m")
+    om = OracleModel(oracle, cfg, sd, g, 1, len_buf)
+    om.rope_kind = "plain"
+    om.tp_world = 2
+    prompt = rng.integers(0, cfg.vocab_size, s).astype(np.int32)
+    want = om.prefill(0, prompt)
+    scale = np.abs(want).max()
+    model.prefill(0, len_buf, np.ascontiguousarray(prompt), 0)                           # warm-up of both threads
+    errs0 = model.exchange_errors()
+    for run in range(5):
+        both = model.prefill(0, len_buf, np.ascontiguousarray(prompt), 0)
+        assert model.exchange_errors() == errs0, (run, errs0, model.exchange_errors())        # an expired exchange wait first: it explains garbage
+        assert both.shape == (2, 1, cfg.vocab_size) and np.array_equal(both[0].view(np.uint16), both[1].view(np.uint16)), run
+        got = both[0].astype(np.float64)
+        assert np.abs(got - want).max() <= 1e-3 * scale + 2.0 ** -11 * scale, (run, np.abs(got - want).max() / scale)
+    assert model.exchange_errors() == errs0, (errs0, model.exchange_errors())
+    # a decode step on the cache the dual-stream pass left (single-stream: one row is below the threshold)
+    tok = want.argmax(axis=1).astype(np.int32)
+    both = model.decode_step(tok, np.array([s], np.int32), (np.arange(len_buf) <= s).astype(np.int8))
+    wstep, _ = om.step(tok, [s])
+    assert np.abs(both[0].astype(np.float64) - wstep).max() <= 1e-3 * np.abs(wstep).max() + 2.0 ** -11 * np.abs(wstep).max()
+    out = capfd.readouterr().out
+    assert ">>> HOST_REDUCE:" in out, "dual_stream_encode did not run (block.cpp:215 prints this line on its first call)"
+    del model
+    ref.weight_cache_clear()
+
+
 # ---- config 5 as a LAYER: MLAImpl over Fp8Block linears + FP8BlockMOE through the reference's EncoderLayer ------------------------
 def _fp8_block_quant(oracle, w):
     """a (n, k) float weight as a DeepSeek-V3 checkpoint stores it: e4m3 codes + one fp32 scale (amax / 448) per 128 x 128 block"""

@@ -392,15 +392,19 @@ def test_streaming_gemm_random_shapes(oracle, dev, monkeypatch):
         _check_mfma(oracle, dev, k, n, m, seed=1000 + case, bias=kind == 1, residual=kind == 2 and not norm, norm=norm)
 
 
-@pytest.mark.parametrize("geom", [None, (4, 1), (8, 2), (4, 4)])
-@pytest.mark.parametrize("m", [9, 16, 17, 32])
+@pytest.mark.parametrize("geom", [None, (4, 1), (8, 2), (4, 4), (1, 8, 4), (2, 8, 4), (7, 8, 4), (8, 8, 4)])
+@pytest.mark.parametrize("m", [5, 8, 9, 16, 17, 32])
 def test_slab_gemm_geometries(oracle, dev, m, geom, monkeypatch):
-    """w4_slab.hip (9..32 rows, round 6): the planner's own geometry and forced (waves per workgroup, groups per wave) pairs, one
+    """w4_slab.hip (5..32 rows, round 6): the planner's own geometry and forced (waves per workgroup, groups per wave) pairs -- with the
+    tiles per workgroup forced as well in the 3-tuples: the two-groups-resident / DMA-two-groups-ahead schedule with 1, 2, 7, 8 weight
+    items per group --, one
     and two row blocks -- ragged N (a partial last tile group and a partial tile), K with a partial last split and K shorter than
     one workgroup's slice, bias / residual epilogues, every K-split count from 1 to 18; same bars as the phase kernel."""
     if geom is not None:
-        monkeypatch.setenv("ZL_W4_SLAB_NW", str(geom[0]))
-        monkeypatch.setenv("ZL_W4_SLAB_GPW", str(geom[1]))
+        if len(geom) == 3:
+            monkeypatch.setenv("ZL_W4_SLAB_R", str(geom[0]))
+        monkeypatch.setenv("ZL_W4_SLAB_NW", str(geom[-2]))
+        monkeypatch.setenv("ZL_W4_SLAB_GPW", str(geom[-1]))
     _check_mfma(oracle, dev, 1152, 16 * 11 + 8, m, seed=500 + m)
     _check_mfma(oracle, dev, 4096, 512, m, seed=501 + m, bias=True)
     _check_mfma(oracle, dev, 9 * 1024 + 256, 144, m, seed=502 + m, residual=True)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--shapes", nargs="+", default=["qkv", "o", "gate_up", "down"])
+    ap.add_argument("--full", action="store_true", help="every forced geometry as well")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     shapes = {"qkv": (6144, 4096, 0), "o": (4096, 4096, 0), "gate_up": (28672, 4096, ops.EPI_SILU_MUL), "down": (4096, 14336, 0)}
@@ -48,8 +49,8 @@ def main():
             out = torch.empty(m, n // 2 if epi else n, dtype=torch.float16, device=dev)
             ops.w4_scratch_reserve(dev, 32, 28672)
             rows = []
-            cfgs = [("phase", {"ZL_W4_SLAB": "-1"}), ("planned", {})]
-            for r in (1, 2, 4, 8):
+            cfgs = [("phase", {"ZL_W4_SLAB": "-1"}), ("planned", {}), ("planned, many tiles too (slab = 2)", {"ZL_W4_SLAB": "2"})]
+            for r in ((1, 2, 4, 7, 8) if a.full else ()):
                 for nw in (4, 8):
                     for gpw in (1, 2, 4):
                         cfgs.append((f"r{r} nw{nw} gpw{gpw}", {"ZL_W4_SLAB_R": str(r), "ZL_W4_SLAB_NW": str(nw), "ZL_W4_SLAB_GPW": str(gpw)}))

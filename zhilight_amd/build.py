@@ -17,15 +17,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-fno-fast-math", "-ffp-contract=off"]
 
 
-# ZL_BUILD_EXPERIMENTAL=1: also build what was measured and left off the product path: the loader / consumer
-# engine (w4_engine.hip) and the digit-plane entry points for 5..32 rows -- the header declares them under #ifdef ZL_EXPERIMENTAL,
-# tests/test_gpu_engine.py and tests/test_gpu_planes.py skip without them.  The default library carries neither.
+# ZL_BUILD_EXPERIMENTAL=1: also build what was measured and left off the product path: the loader /
+# consumer engine (tools/experimental/w4_engine.hip -- it is not in csrc/) and the digit-plane entry points for 5..32 rows (the
+# #ifdef ZL_EXPERIMENTAL blocks of w4_phase.hip / w4_mfma.hip); their tests live next to the engine, tools/experimental/test_gpu_*.py
+# (python -m pytest tools/experimental -m gpu, after such a build).  The default library and the default test run carry neither.
 EXPERIMENTAL = os.environ.get("ZL_BUILD_EXPERIMENTAL", "0") == "1"
-EXPERIMENTAL_ONLY = ("w4_engine.hip",)
+EXPERIMENTAL_DIR = os.path.join(HERE, "..", "tools", "experimental")
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and (EXPERIMENTAL or f not in EXPERIMENTAL_ONLY))
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    if EXPERIMENTAL:
+        srcs.append(os.path.join(EXPERIMENTAL_DIR, "w4_engine.hip"))
+    return srcs
 
 
 def _stale(target, deps):
@@ -41,7 +45,7 @@ def build(force=False, verbose=False):
     hdrs.append(os.path.join(HERE, "..", "include", "zhilight_amd.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = FLAGS + (["-DZL_EXPERIMENTAL"] if EXPERIMENTAL else [])
+    flags = FLAGS + (["-DZL_EXPERIMENTAL", "-I" + CSRC] if EXPERIMENTAL else [])
     stamp = os.path.join(objdir, ".flags")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
         force = True                                   # another flavour's objects: rebuild all of them

@@ -770,7 +770,7 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
                                  o.phase_rounds, hs);
     // 9..32 rows without a fused norm (round 6): 128-column x K-slice tiles, activation fragments straight from global memory
     // (w4_slab.hip) -- a workgroup's activation bytes ~ its weight bytes instead of M x K per 16 R columns
-    if (o.slab >= 0 && !norm_weight && m >= (o.slab_min_m > 0 ? o.slab_min_m : 9) && m <= 32 && k % 128 == 0 &&
+    if (o.slab >= 0 && !norm_weight && m >= (o.slab_min_m > 0 ? o.slab_min_m : 5) && m <= 32 && k % 128 == 0 &&
         L.qw_bytes < ((int64_t)1 << 32)) {
         st = zl_w4a16_gemm_slab(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
                                 (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), &o, hs);
@@ -909,7 +909,7 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
     const int small_algo = opts ? opts->small_algo : 0;
     ZL_CHECK_ARG(!(norm_weight && m >= 9) || (opts && opts->defer_norm == 1), ZL_ESHAPE);   // the deferred norm: on request only
-    if (opts && opts->slab >= 0 && !norm_weight && m >= (opts->slab_min_m > 0 ? opts->slab_min_m : 9) && k % 128 == 0) {
+    if (opts && opts->slab >= 0 && !norm_weight && m >= (opts->slab_min_m > 0 ? opts->slab_min_m : 5) && k % 128 == 0) {
         st = zl_w4a16_gemm_slab_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n, (int)k,
                                      (int)L.q, (int)(L.np / 16), cosv, sinv, placement, buf_lens, k_bufs, v_bufs, q_out, (int)h,
                                      (int)hkv, (int)d, bshd, opts, (hipStream_t)s);

@@ -41,6 +41,9 @@
 namespace {
 
 constexpr int kMaxKS = 32;
+#ifndef ZL_SLAB_DMAX
+#define ZL_SLAB_DMAX 8
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -113,7 +116,9 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) |
 
 template <int R, int GPW, int MB, bool ROPE>
 __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
-    constexpr int TOTAL = R * GPW, D = TOTAL < 8 ? TOTAL + 1 : 8;   // ring slots: D - 1 items in flight + the one being finished
+    // ring slots: D - 1 weight items (1 KiB + a meta word each) in flight per wave + the one being finished.  An 8-wave workgroup per CU
+    // is all the registers allow at two row blocks, so the bytes in flight per CU are 8 (D - 1) KiB: profiles/r06_slab_ring_depth.txt
+    constexpr int TOTAL = R * GPW, D = TOTAL < ZL_SLAB_DMAX ? TOTAL + 1 : ZL_SLAB_DMAX;
     constexpr int XS = GPW < 2 ? GPW : 2;             // activation groups resident in the wave's LDS region
     constexpr int DM = 4 * MB;                        // DMA instructions per group: 4 rows x 256 B each
     constexpr int kSet = MB * 16 * 256;               // bytes per group image
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
             const int ring_fly = fly_hi - first_younger + 1 > 0 ? fly_hi - first_younger + 1 : 0;
             switch (younger_groups * DM + 2 * ring_fly) {     // (the builtin wants an immediate: static after unrolling)
 #define ZL_W(n) case n: __builtin_amdgcn_s_waitcnt(vmcnt_imm(n)); break;
-                ZL_W(0) ZL_W(2) ZL_W(4) ZL_W(6) ZL_W(8) ZL_W(10) ZL_W(12) ZL_W(14) ZL_W(16) ZL_W(18) ZL_W(20) ZL_W(22)
+                ZL_W(0) ZL_W(2) ZL_W(4) ZL_W(6) ZL_W(8) ZL_W(10) ZL_W(12) ZL_W(14) ZL_W(16) ZL_W(18) ZL_W(20) ZL_W(22) ZL_W(24) ZL_W(26)
+                ZL_W(28) ZL_W(30) ZL_W(32) ZL_W(34) ZL_W(36) ZL_W(38) ZL_W(40) ZL_W(42) ZL_W(44) ZL_W(46) ZL_W(48) ZL_W(50) ZL_W(52) ZL_W(54)
 #undef ZL_W
                 default: __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); break;
             }
@@ -513,9 +519,10 @@ struct SlabPlan {
 //   * longer K splits: KS = ceil(groups / 32) (down: 4);
 //   * R = the fewest tiles per workgroup that still give ONE generation of workgroups (attn_out 1, qkv 2, down 4): more tiles per
 //     workgroup would cut activation traffic further but leave CUs without a workgroup, which costs more;
-//   * many tiles per CU (gate|up: 7) -- the phase kernel already amortises its staging there and ties or wins: not taken.
+//   * many tiles per CU (gate|up: 7 x 256) -- the phase kernel already amortises its staging there: a tie up to 16 rows (not taken),
+//     20.9 against 22..23 us with 17..32 rows (taken, R = 7);
+//   * the ring depth (8 / 12 / 16 slots) changes nothing (profiles/r06_slab_ring_depth.txt): 8.
 bool plan_slab(int m, int tiles, int groups, bool have_scratch, bool rope, const zl_w4_opts_t& o, SlabPlan* out) {
-    (void)m;
     int cus = zl_device_cu_count();
     if (cus <= 0) cus = 256;
     int nw = groups >= 8 ? 8 : 4, gpw = groups > 16 ? 4 : groups > 8 ? 2 : 1;
@@ -527,8 +534,9 @@ bool plan_slab(int m, int tiles, int groups, bool have_scratch, bool rope, const
     int r = rope ? 2 : 1;
     if (forced) r = o.slab_r;
     else if (!rope) {
-        if (tiles > 3 * cus) return false;
+        if (tiles > 3 * cus && o.slab != 2 && m <= 16) return false;   // (two row blocks: 20.9 vs 22..23 us on gate|up, taken; one: a tie)
         while (r < 8 && (long)((tiles + r - 1) / r) * ks > cus) r *= 2;
+        if (r == 8 && (long)((tiles + 6) / 7) * ks <= cus) r = 7;      // gate|up: 1792 tiles = 256 x 7
     }
     if (rope && r != 2) return false;
     const long grid = (long)((tiles + r - 1) / r) * ks;
@@ -544,6 +552,7 @@ int launch_slab_any(const SlabParams& p, const SlabPlan& pl, int mb, hipStream_t
         case 1: return launch_slab_r<1, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
         case 2: return launch_slab_r<2, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
         case 4: return launch_slab_r<4, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
+        case 7: return launch_slab_r<7, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
         default: return launch_slab_r<8, false>(p, pl.gpw, mb, pl.grid, pl.nw, hs);
     }
 }

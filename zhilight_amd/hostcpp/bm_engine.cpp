@@ -58,6 +58,7 @@ public:
         void* ar_state = nullptr;
         void* staging = nullptr;      // ranks that share a device: scratch of the byte-wise collectives (oneshot_bytes; no allocation per call)
         hipStream_t setup_stream = nullptr;
+        hipStream_t secondary_stream = nullptr;   // ranks that share a device: the rank's second stream (bm_hip.h set_shared_device_rank)
         MemoryAllocator allocator;
         std::unique_ptr<TaskThreadPool> thread;
         int share_index = 0;          // how many lower ranks sit on the same device
@@ -157,6 +158,19 @@ Engine::Engine(const std::vector<DeviceConfiguration>& dev_cfg, const DistConfig
     const bool all_distinct = (int)distinct.size() == world;
     for (int r = 0; r < world; ++r)
         for (int p = 0; p < r; ++p) pimpl->ranks[r].share_index += pimpl->ranks[p].device == pimpl->ranks[r].device;
+    if (world > 1 && !all_distinct) {
+        // The ranks' SECONDARY streams (what dual_stream_encode asks cudaStreamCreateWithPriority for, block.cpp:221-224): created
+        // here, one after the other and before anything else touches the runtime's lowest-priority queue pool -- the runtime deals
+        // a pool's hardware queues in creation order, so no two of them share a queue, and none shares one with a rank's main stream
+        // (those sit in the higher-priority pools, create_context_rank).  They live as long as the engine; a rank thread's request
+        // hands its own out, and "destroying" one is a no-op (zl_shim_stream_destroy).
+        int least = 0, greatest = 0;
+        BM_HIPRT_ASSERT(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        for (int r = 0; r < world; ++r) {
+            BM_HIPRT_ASSERT(hipSetDevice(pimpl->ranks[r].device));
+            BM_HIPRT_ASSERT(hipStreamCreateWithPriority(&pimpl->ranks[r].secondary_stream, hipStreamNonBlocking, least));
+        }
+    }
     pimpl->rccl = world > 1 && all_distinct && env_i64("ZL_ENGINE_RCCL", 1) != 0;
     pimpl->oneshot_bytes = std::max<int64_t>(4096, env_i64("ZL_ENGINE_ONESHOT_BYTES", 8 << 20)) / 16 * 16;
     EngineImpl* impl = pimpl.get();
@@ -204,6 +218,10 @@ Engine::~Engine() {
             if (R.ar_state) (void)hipFree(R.ar_state);
             if (R.staging) (void)hipFree(R.staging);
             if (R.setup_stream) (void)hipStreamDestroy(R.setup_stream);
+            if (R.secondary_stream) {
+                forget_secondary_stream(R.secondary_stream);
+                (void)hipStreamDestroy(R.secondary_stream);
+            }
         });
     } catch (...) {
     }
@@ -276,7 +294,9 @@ Context Engine::create_context_rank(int rank) const {
         // device get streams of different priorities -- as many ranks per device as there are priority levels.
         int least = 0, greatest = 0;
         BM_HIPRT_ASSERT(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const int levels = least - greatest + 1;
+        // (the lowest level is kept for the ranks' SECONDARY streams: dual_stream_encode's reduce stream, bm_hip.h set_shared_device_rank)
+        const int levels = least - greatest;
+        set_shared_device_rank(impl->ranks[rank].share_index, impl->ranks[rank].secondary_stream);
         BM_ASSERT(impl->ranks[rank].share_index < levels,
                   "Engine: more ranks share one device than the runtime has stream priority levels (use one process per rank there)");
         hipStream_t s = nullptr;

@@ -1,6 +1,9 @@
 #include <vector>
 // bm_hip.cpp -- storage, tensors and the per-device context behind bm_hip.h (HIP runtime only; no torch, no BLAS).
 #include "bm_hip.h"
+
+#include <mutex>
+#include <set>
 #include "bm_c10d.h"
 
 #include <algorithm>
@@ -19,6 +22,31 @@ BMEngineException::BMEngineException(const std::string& msg, const char* file, i
 
 namespace bmengine {
 namespace core {
+
+namespace {
+thread_local int tl_shared_device_rank = -1;
+thread_local hipStream_t tl_secondary_stream = nullptr;
+std::mutex g_secondary_mu;
+std::set<hipStream_t> g_secondary_streams;       // engine-owned: never destroyed through the shim
+}
+void set_shared_device_rank(int share_index, hipStream_t secondary) {
+    tl_shared_device_rank = share_index;
+    tl_secondary_stream = secondary;
+    if (secondary) {
+        std::lock_guard<std::mutex> lk(g_secondary_mu);
+        g_secondary_streams.insert(secondary);
+    }
+}
+void forget_secondary_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_secondary_mu);
+    g_secondary_streams.erase(s);
+}
+hipStream_t shim_secondary_stream() { return tl_shared_device_rank >= 0 ? tl_secondary_stream : nullptr; }
+bool shim_is_secondary_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_secondary_mu);
+    return g_secondary_streams.count(s) != 0;
+}
+int shared_device_rank() { return tl_shared_device_rank; }
 
 static const char* kTypeNames[] = {"double", "float", "half", "int8", "int16", "int32", "bfloat", "fp8_e4m3", "fp8_e5m2"};
 static const size_t kTypeSizes[] = {8, 4, 2, 1, 2, 4, 2, 1, 1};
@@ -539,3 +567,17 @@ void Context::set_cache_arena(void* base) { pimpl->cache_arena.set_base_ptr(base
 
 }  // namespace core
 }  // namespace bmengine
+
+
+// the reference's cudaStreamCreateWithPriority / cudaStreamDestroy (refshim/cuda_runtime.h): see bm_hip.h set_shared_device_rank
+extern "C" hipError_t zl_shim_stream_create_with_priority(hipStream_t* stream, unsigned int flags, int priority) {
+    if (hipStream_t s = bmengine::core::shim_secondary_stream()) {
+        *stream = s;
+        return hipSuccess;
+    }
+    return hipStreamCreateWithPriority(stream, flags, priority);
+}
+extern "C" hipError_t zl_shim_stream_destroy(hipStream_t stream) {
+    if (bmengine::core::shim_is_secondary_stream(stream)) return hipStreamSynchronize(stream);
+    return hipStreamDestroy(stream);
+}

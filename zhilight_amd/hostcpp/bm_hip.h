@@ -83,6 +83,16 @@ enum class DistLayout { COLUMNAR, ROW, REPLICATED };
 DistLayout transpose_layout(DistLayout dist_layout);
 const char* get_dist_layout_name(DistLayout dist_layout);
 
+// Engine ranks that share ONE device (the one-GPU test mode of hostcpp/bm_engine.cpp) exchange through kernels that wait for
+// each other inside a launch, so no two of their streams may sit on one hardware queue.  The engine creates every rank's
+// SECONDARY stream up front (consecutively, in the runtime's lowest-priority queue pool, which nothing else uses) and marks its
+// rank threads with it; zl_shim_stream_create_with_priority / zl_shim_stream_destroy -- what the reference's
+// cudaStreamCreateWithPriority / cudaStreamDestroy become (refshim/cuda_runtime.h) -- then hand that stream out and leave it
+// alive.  Threads that are not so marked (every rank of a distinct-device engine, every other caller) get the plain HIP calls.
+void set_shared_device_rank(int share_index, hipStream_t secondary = nullptr);     // -1: not a shared-device rank thread (the default)
+int shared_device_rank();
+void forget_secondary_stream(hipStream_t s);     // the engine is about to destroy it
+
 struct Stream_ {
     hipStream_t ptr;
     std::function<void(hipStream_t)> deleter;

@@ -1,5 +1,6 @@
-// refshim: the CUDA toolkit names the reference's HOST translation units spell, as aliases of the HIP runtime's.  Used only
-// by the compile-the-reference check (hostcpp/refcompile.py); nothing in the product includes this directory.
+// refshim: the CUDA toolkit names the reference's HOST translation units spell, as aliases of the HIP runtime's.  This directory is
+// on the include path ONLY when a unit of /root/reference is compiled (zhilight_amd/build.py: the host library's reference units,
+// the zhilight.C binding, the link check); no source file of this repository includes it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -28,9 +29,14 @@ typedef __half half;
 #define cudaFreeHost hipFreeHost
 #define cudaHostAllocDefault hipHostMallocDefault
 #define cudaHostAllocPortable hipHostMallocPortable
-#define cudaStreamCreateWithPriority hipStreamCreateWithPriority
+// block.cpp's dual_stream_encode creates its reduce stream with this call (block.cpp:221-224).  A passthrough to the HIP runtime --
+// except on a rank thread of an Engine whose ranks SHARE a device (the one-GPU test mode, hostcpp/bm_engine.cpp), where the stream
+// must not share a hardware queue with any other rank's stream: see zl_shim_stream_create_with_priority in hostcpp/bm_hip.cpp.
+extern "C" hipError_t zl_shim_stream_create_with_priority(hipStream_t* stream, unsigned int flags, int priority);
+extern "C" hipError_t zl_shim_stream_destroy(hipStream_t stream);
+#define cudaStreamCreateWithPriority zl_shim_stream_create_with_priority
 #define cudaStreamNonBlocking hipStreamNonBlocking
-#define cudaStreamDestroy hipStreamDestroy
+#define cudaStreamDestroy zl_shim_stream_destroy
 #define cudaEventCreateWithFlags hipEventCreateWithFlags
 #define cudaEventDefault hipEventDefault
 #define cudaEventQuery hipEventQuery
