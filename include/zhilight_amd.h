@@ -630,6 +630,9 @@ int zl_element_add_scale(const uint16_t* a, const uint16_t* b, uint16_t* c, int6
                          int scale_residual, int dtype, zl_stream_t s);
 int zl_gate_mul(const uint16_t* gate, const uint16_t* up, uint16_t* out, int64_t n, int act, int dtype,
                 zl_stream_t s);
+/* nn::gate_fuse (src/nn/linear/ff_kernel.cu:33-90): out (rows, ff) = act(in[:, :ff]) * in[:, ff:] over the (rows, 2 ff) output of the
+ * fused w_in | w_gated linear -- one launch, the arithmetic of zl_gate_mul on the two halves of every row. */
+int zl_gate_fuse(const uint16_t* in, uint16_t* out, int64_t rows, int64_t ff, int act, int dtype, zl_stream_t s);
 /* a6  act-order (desc_act) checkpoints: out[r, i] = x[r, perm[i]] over 16-bit elements, x rows ldx apart.  Replaces
  * nn::gptq::permute_input (src/nn/quant/gptq/gptq.h:155-159), which gptq_gemm_k_major runs in front of its kernels when
  * q_perm is given (q_gemm_k_major.cu:1095,1105); perm = argsort(g_idx), the order the weight rows were regrouped in. */

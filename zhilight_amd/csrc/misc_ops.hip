@@ -397,6 +397,21 @@ __global__ void k_gate_mul(const uint16_t* __restrict__ g, const uint16_t* __res
     }
 }
 
+// nn::gate_fuse (src/nn/linear/ff_kernel.cu:33-90): out[r, j] = act(in[r, j]) * in[r, ff + j] over a (rows, 2 ff) product of the fused
+// w_in | w_gated linear (CPM_FUSE_FF_IN=1) -- k_gate_mul's arithmetic on the two halves of a row, without copying them out first
+template <int DT>
+__global__ void k_gate_fuse(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int64_t ff, int act) {
+    const int64_t n = rows * ff;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ff, j = i - r * ff;
+        const float x = ZT<DT>::to_f32(in[r * 2 * ff + j]);
+        float a;
+        if (act == 0) a = x / (1.0f + expf(-x));
+        else a = 0.5f * x * (1.0f + tanhf(0.7978845608028654f * x * (1.0f + 0.044715f * x * x)));
+        out[i] = ZT<DT>::from_f32(a * ZT<DT>::to_f32(in[r * 2 * ff + ff + j]));
+    }
+}
+
 // embedding: grid (S), block 256, 16-byte lanes.  src/nn/embedding/embedding.cu:23-44
 // (16-byte lanes for real: with one 2-byte element per thread and iteration the 16 iterations of a 4096-wide row were 16
 //  dependent round trips, 8.7 us for one token inside the decode step)
@@ -649,6 +664,14 @@ int zl_element_add_scale(const uint16_t* a, const uint16_t* b, uint16_t* c, int6
         hipLaunchKernelGGL(k_add_scale<ZL_BF16>, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)s, a, b, c, n, (uint16_t)(u >> 16), scale_residual);
     } else
         return ZL_EDTYPE;
+    return zl_launch_status();
+}
+
+int zl_gate_fuse(const uint16_t* in, uint16_t* out, int64_t rows, int64_t ff, int act, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(in && out && rows > 0 && ff > 0 && (act == 0 || act == 1), ZL_EINVAL);
+    ZL_DT_SWITCH(dtype,
+        hipLaunchKernelGGL(k_gate_fuse<ZL_F16>, dim3(grid_1d(rows * ff, 256)), dim3(256), 0, (hipStream_t)s, in, out, rows, ff, act),
+        hipLaunchKernelGGL(k_gate_fuse<ZL_BF16>, dim3(grid_1d(rows * ff, 256)), dim3(256), 0, (hipStream_t)s, in, out, rows, ff, act))
     return zl_launch_status();
 }
 

@@ -161,11 +161,139 @@ int Tensor::normalize_dim(int dim) const {
     BM_ASSERT(dim >= -n && dim < n, "dim out of range");
     return dim < 0 ? dim + n : dim;
 }
+// ---- deferred launches (bm_hip.h) ------------------------------------------------------------------------------------------------
+namespace {
+thread_local std::vector<DeferredOp> tl_deferred;
+thread_local bool tl_flushing = false;
+struct Poisoned {
+    const void* y;
+    size_t bytes;
+    std::weak_ptr<void> alive;
+};
+thread_local std::vector<Poisoned> tl_poisoned;
+bool overlaps(const void* a, size_t an, const void* b, size_t bn) {
+    return (const char*)a < (const char*)b + bn && (const char*)b < (const char*)a + an;
+}
+void prune_dead() {
+    for (size_t i = 0; i < tl_deferred.size();)
+        if (tl_deferred[i].y_alive.expired()) tl_deferred.erase(tl_deferred.begin() + (long)i);
+        else ++i;
+}
+}  // namespace
+bool boundary_fusion_enabled() {
+    static const bool on = [] { const char* e = getenv("ZL_BOUNDARY_FUSE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+void defer_op(DeferredOp&& op) {
+    prune_dead();
+    while (tl_deferred.size() >= 4) {                 // a handful at most: the oldest goes out as an ordinary launch
+        DeferredOp d = std::move(tl_deferred.front());
+        tl_deferred.erase(tl_deferred.begin());
+        tl_flushing = true;
+        d.launch();
+        tl_flushing = false;
+    }
+    tl_deferred.push_back(std::move(op));
+}
+DeferredOp* find_deferred(const void* y, int kind) {
+    if (tl_deferred.empty() || !y) return nullptr;
+    prune_dead();
+    for (auto& d : tl_deferred)
+        if (d.y == y && d.kind == kind) return &d;
+    return nullptr;
+}
+void drop_deferred(const void* y) {
+    for (size_t i = 0; i < tl_deferred.size(); ++i)
+        if (tl_deferred[i].y == y) {
+            tl_deferred.erase(tl_deferred.begin() + (long)i);
+            return;
+        }
+}
+void flush_deferred_touching(const void* p, size_t bytes) {
+    if (tl_flushing) return;                          // the launch closure itself reads its operands
+    prune_dead();
+    for (size_t i = 0; i < tl_deferred.size();) {
+        DeferredOp& d = tl_deferred[i];
+        if (overlaps(p, bytes, d.y, d.y_bytes) || overlaps(p, bytes, d.x, d.x_bytes)) {
+            DeferredOp run = std::move(d);
+            tl_deferred.erase(tl_deferred.begin() + (long)i);
+            tl_flushing = true;
+            run.launch();
+            tl_flushing = false;
+            i = 0;                                    // the launch may have touched the list
+        } else {
+            ++i;
+        }
+    }
+}
+void flush_deferred_producing(const void* p, size_t bytes) {
+    if (tl_flushing || tl_deferred.empty() || !p) return;
+    prune_dead();
+    for (size_t i = 0; i < tl_deferred.size();) {
+        if (overlaps(p, bytes, tl_deferred[i].y, tl_deferred[i].y_bytes)) {
+            DeferredOp run = std::move(tl_deferred[i]);
+            tl_deferred.erase(tl_deferred.begin() + (long)i);
+            tl_flushing = true;
+            run.launch();
+            tl_flushing = false;
+            i = 0;
+        } else {
+            ++i;
+        }
+    }
+}
+void retire_deferred_inputs(const void* p, size_t bytes) {
+    if (tl_flushing) return;
+    prune_dead();
+    for (size_t i = 0; i < tl_deferred.size();) {
+        DeferredOp& d = tl_deferred[i];
+        if (!overlaps(p, bytes, d.x, d.x_bytes) && !overlaps(p, bytes, d.y, d.y_bytes)) {
+            ++i;
+            continue;
+        }
+        DeferredOp run = std::move(d);
+        tl_deferred.erase(tl_deferred.begin() + (long)i);
+        if (run.consumed && !overlaps(p, bytes, run.y, run.y_bytes)) {
+            tl_poisoned.push_back({run.y, run.y_bytes, run.y_alive});
+        } else {
+            tl_flushing = true;
+            run.launch();
+            tl_flushing = false;
+        }
+        i = 0;
+    }
+}
+void flush_all_deferred() {
+    if (tl_flushing) return;
+    prune_dead();
+    while (!tl_deferred.empty()) {
+        DeferredOp run = std::move(tl_deferred.front());
+        tl_deferred.erase(tl_deferred.begin());
+        tl_flushing = true;
+        run.launch();
+        tl_flushing = false;
+    }
+}
+
 void* Tensor::data() const {
     if (param_ && !mem_) return nullptr;             // Context::parameter(): declared, not loaded yet
     BM_ASSERT(mem_ && mem_->ptr, "Tensor is empty");
+    if (!tl_deferred.empty()) flush_deferred_touching((char*)mem_->ptr + offset_, mem_->bytes - offset_);
+    if (!tl_poisoned.empty()) {
+        for (size_t i = 0; i < tl_poisoned.size();) {
+            if (tl_poisoned[i].alive.expired()) {
+                tl_poisoned.erase(tl_poisoned.begin() + (long)i);
+                continue;
+            }
+            BM_ASSERT(!overlaps((char*)mem_->ptr + offset_, mem_->bytes - offset_, tl_poisoned[i].y, tl_poisoned[i].bytes),
+                      "boundary fusion: a normalised tensor is read after its fused consumer ran AND its input was overwritten in place -- "
+                      "set ZL_BOUNDARY_FUSE=0 for this call sequence");
+            ++i;
+        }
+    }
     return (char*)mem_->ptr + offset_;
 }
+std::weak_ptr<void> Tensor::storage_token() const { return std::weak_ptr<void>(std::static_pointer_cast<void>(mem_)); }
 void* Tensor::nullable_data() const { return mem_ && mem_->ptr ? (char*)mem_->ptr + offset_ : nullptr; }
 size_t Tensor::mem_bytes() const { return mem_ ? mem_->bytes - offset_ : 0; }
 bool Tensor::is_continuous() const {

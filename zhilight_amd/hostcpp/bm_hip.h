@@ -103,6 +103,51 @@ struct Stream_ {
 };
 typedef std::shared_ptr<Stream_> Stream;
 
+// ---- deferred launches: what lets the boundary fuse ACROSS two calls of the reference's unchanged call sequence (round 6) ----------
+// The reference's layer code calls LayerNorm::forward and hands the result to Linear::forward, calls Linear::forward and hands the
+// result to element_add_scale_out (block.cpp:86-143): two launches each where the kernels of this repository fuse the norm into the
+// GEMV's prologue and the residual add into its epilogue.  So a producer may hand back its result tensor WITHOUT launching and leave a
+// DeferredOp behind; a consumer that recognises the address (find_deferred, before it touches any operand) launches the fused form.
+// Everything else stays exactly as it was:
+//   * Tensor::data() on memory that overlaps a deferred op's result OR its input launches the op first, on its stream -- whoever reads
+//     the result finds it, whoever is about to overwrite the input finds the op already queued in front of him (stream order);
+//   * a result nobody ever reads dies with its tensor: the op holds only a weak token of the result's block and is dropped, unlaunched,
+//     once that expires (checked whenever the list is consulted);
+//   * per thread (a Context is bound to its thread), a handful of entries; ZL_BOUNDARY_FUSE=0 turns deferral off.
+struct DeferredOp {
+    int kind = 0;                                     // 1: RMSNorm rows -> y      2: W4A16 linear -> y
+    const void* y = nullptr;                          // where the result belongs
+    size_t y_bytes = 0;
+    const void* x = nullptr;                          // the input a late launch reads
+    size_t x_bytes = 0;
+    std::weak_ptr<void> y_alive;
+    hipStream_t stream = nullptr;
+    std::function<void()> launch;                     // the unfused launch (keeps the input tensors alive, NOT the result)
+    bool consumed = false;                            // a fused consumer already used it (the result was never materialised)
+    // kind 1: what a GEMV with a fused norm prologue needs
+    const uint16_t* norm_w = nullptr;
+    float eps = 0.f;
+    int64_t rows = 0, dim = 0;
+    // kind 2: the same linear with a residual operand / another output (residual may be null)
+    std::function<void(const uint16_t* residual, uint16_t* out)> launch_into;
+    // ... or as the fused qkv projection + neox rotation, q / k / v rows scattered through per-task tables (zl_w4a16_qkv_rope_scatter_ex);
+    // returns false when the kernels do not cover the shape
+    std::function<bool(const float* cosv, const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                       uint16_t* const* v_bufs, uint16_t* q_out, int64_t h, int64_t hkv, int64_t d)> launch_rope;
+    int64_t m = 0, n = 0;
+};
+bool boundary_fusion_enabled();
+void defer_op(DeferredOp&& op);
+DeferredOp* find_deferred(const void* y, int kind);  // by result address; never launches
+void drop_deferred(const void* y);                    // a consumer launched the fused form: the plain one is not needed
+void flush_deferred_touching(const void* p, size_t bytes);
+void flush_deferred_producing(const void* p, size_t bytes);   // only ops whose RESULT overlaps: for a wrapper's read-only operands
+// [p, p + bytes) is about to be OVERWRITTEN by a fused consumer (which does not go through Tensor::data()): ops that read it as their
+// input are launched first -- except ops a fused consumer has already used: their result is not materialised (that would be the
+// launch the fusion saves) but POISONED -- a later Tensor::data() on it throws instead of returning stale rows.
+void retire_deferred_inputs(const void* p, size_t bytes);
+void flush_all_deferred();
+
 class Context;
 struct Storage;   // ref-counted device (or host) block
 // private/allocator.h:13-66 as far as layer code sees it: the base address of the KV-cache arena (multi_head_latent_attention.cpp:
@@ -150,8 +195,9 @@ public:
     size_t stride(int dim) const { return strides_[normalize_dim(dim)]; }
     size_t stride_bytes(int dim) const { return stride(dim) * get_elem_size(dtype_); }
 
-    void* data() const;                              // throws on an empty tensor
-    void* nullable_data() const;                     // nullptr for an empty tensor
+    void* data() const;                              // throws on an empty tensor; launches a deferred op whose operands it touches (below)
+    void* nullable_data() const;                     // nullptr for an empty tensor; never launches anything
+    std::weak_ptr<void> storage_token() const;       // expires when the last tensor over this block dies (deferred ops watch their result's)
     void* mutable_data() { return data(); }
     template <typename T> T* data() const { return reinterpret_cast<T*>(data()); }
     template <typename T> void* nullable_data() const { return nullable_data(); }

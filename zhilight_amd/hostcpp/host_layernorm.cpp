@@ -67,6 +67,31 @@ void LayerNorm::load_state_dict(const core::Context& ctx, const std::map<std::st
 core::Tensor LayerNorm::forward(const core::Context& ctx, const core::Tensor& x) {
     pimpl->check(x);
     core::Tensor out = ctx.tensor(x.shape(), x.dtype());
+    const int64_t rows = (int64_t)(x.numel() / x.size(-1));
+    if (core::boundary_fusion_enabled() && x.dtype() == DataType::kHalf && pimpl->scale == 1.0f && rows <= 8 && pimpl->dim_model <= 4096 &&
+        pimpl->dim_model % 128 == 0 && x.is_continuous()) {
+        // a few decode rows: the W4 GEMVs carry this norm in their prologue (bit-identical to this launch + the GEMV, include/
+        // zhilight_amd.h "M = 1..8 with norm_weight").  Hand the result tensor back unlaunched; nn::gptq::gptq_gemm_k_major /
+        // gemm_fuse_gate_in recognise it, anybody else who touches it (or the input) gets the ordinary launch first (bm_hip.h DeferredOp).
+        core::DeferredOp d;
+        d.kind = 1;
+        d.y = out.nullable_data(); d.y_bytes = out.nbytes();
+        d.x = x.nullable_data(); d.x_bytes = x.nbytes();
+        d.y_alive = out.storage_token();
+        d.stream = ctx.current_cuda_stream();
+        d.norm_w = pimpl->weight.data<uint16_t>(); d.eps = pimpl->eps; d.rows = rows; d.dim = pimpl->dim_model;
+        const core::Tensor xin = x, w = pimpl->weight;
+        void* yp = out.nullable_data();
+        const float eps = pimpl->eps;
+        const int dim = pimpl->dim_model, dt = pimpl->zdt(x);
+        const hipStream_t st = d.stream;
+        d.launch = [xin, w, yp, rows, dim, eps, dt, st]() {
+            ZL_CK(zl_rmsnorm((const uint16_t*)xin.nullable_data(), (const uint16_t*)w.nullable_data(), (uint16_t*)yp, rows, dim, eps, 1.0f, nullptr, nullptr, dt,
+                             (zl_stream_t)st), "rmsnorm (deferred)");
+        };
+        core::defer_op(std::move(d));
+        return out;
+    }
     ZL_CK(zl_rmsnorm(x.data<uint16_t>(), pimpl->weight.data<uint16_t>(), out.data<uint16_t>(), x.numel() / x.size(-1), pimpl->dim_model, pimpl->eps,
                      pimpl->scale, nullptr, nullptr, pimpl->zdt(x), (zl_stream_t)ctx.current_cuda_stream()), "rmsnorm");
     return out;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <tuple>
 
@@ -235,6 +236,62 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a0, const Tensor& q_w
         BM_ASSERT_EQ((size_t)k, q_perm.size(0) * 2, "q_perm is not int16");
         BM_ASSERT_EQ((size_t)k, rev_perm.size(0) * 2, "q_perm is not int16");
     }
+    // ---- boundary fusion (bm_hip.h DeferredOp): the activations are an RMSNorm the caller's LayerNorm::forward has not launched
+    //      yet -> the GEMV's norm prologue; and this linear's own launch is held back in case element_add_scale_out consumes it
+    //      (residual epilogue).  Only the plain decode shape of the path: packed / packable operands, no act-order, no W4A8, <= 8 rows.
+    if (bmengine::core::boundary_fusion_enabled() && mfma_ok && !q_perm.numel() && !(precomputed_w8 && precomputed_w8->numel()) &&
+        rows_of(a0) <= 8 && a0.is_continuous() && (!output || output->is_continuous())) {
+        const int64_t m = rows_of(a0);
+        bmengine::core::DeferredOp* nd = bmengine::core::find_deferred(a0.nullable_data(), 1);
+        const bool norm_ok = nd && nd->rows == m && nd->dim == k && k <= 4096 && nd->stream == ctx.current_cuda_stream();
+        if (nd && !norm_ok) nd = nullptr;              // (touching a0 below launches it the ordinary way)
+        if (nd) nd->consumed = true;
+        BM_ASSERT(!raw || scales.dtype() == DataType::kHalf, "scales must be half");
+        const PackedW4 p = raw ? cached_pack(ctx, q_weight, qzeros, scales, sym) : PackedW4{q_weight, Tensor(), scales};
+        std::vector<size_t> oshape = a0.shape();
+        oshape.back() = n;
+        Tensor out = output ? *output : ctx.tensor(oshape, DataType::kHalf);
+        BM_ASSERT_EQ(out.numel(), (size_t)(m * n), "output shape mismatch");
+        const uint16_t* bptr = bias && bias->numel() ? u16(*bias) : nullptr;
+        const zl_w4_opts_t opts = w4_opts(ctx, m, n);
+        const uint16_t* xin = (const uint16_t*)(nd ? nd->x : a0.data());
+        const uint16_t* nw = nd ? nd->norm_w : nullptr;
+        const float eps = nd ? nd->eps : 0.f;
+        const Tensor keep_q = p.q_weight, keep_s = p.scales, keep_a = a0, keep_b = bias ? *bias : Tensor();
+        const hipStream_t st = ctx.current_cuda_stream();
+        auto launch_into = [=](const uint16_t* residual, uint16_t* dst) {
+            zl_check(zl_w4a16_gemm_mfma_ex(xin, k, (const uint32_t*)keep_q.nullable_data(), (const uint32_t*)keep_s.nullable_data(), bptr, residual, dst, m,
+                                           n, k, g, nw, eps, (bptr ? ZL_EPI_BIAS : 0) | (residual ? ZL_EPI_RESIDUAL : 0), &opts, (zl_stream_t)st),
+                     "gptq_gemm_k_major (boundary fusion)");
+            (void)keep_a; (void)keep_b;
+        };
+        // (a caller-provided output is deferred like an allocated one: Int4GPTQ::forward always hands one in, linear.cpp:985-988,
+        //  and passes it up unread to the layer's residual add)
+        bmengine::core::retire_deferred_inputs(out.nullable_data(), out.nbytes());      // `out` will be overwritten, now or later
+        bmengine::core::DeferredOp d;
+        d.kind = 2;
+        d.y = out.nullable_data(); d.y_bytes = out.nbytes();
+        d.x = nd ? nd->x : a0.nullable_data(); d.x_bytes = a0.nbytes();
+        d.y_alive = out.storage_token();
+        d.stream = st;
+        d.m = m; d.n = n;
+        uint16_t* yp = (uint16_t*)out.nullable_data();
+        d.launch_into = launch_into;
+        d.launch = [launch_into, yp]() { launch_into(nullptr, yp); };
+        d.launch_rope = [=](const float* cosv, const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
+                            uint16_t* const* v_bufs, uint16_t* q_out, int64_t h, int64_t hkv, int64_t dh) -> bool {
+            if ((h + 2 * hkv) * dh != n) return false;
+            const int st_ = zl_w4a16_qkv_rope_scatter_ex(xin, k, (const uint32_t*)keep_q.nullable_data(), (const uint32_t*)keep_s.nullable_data(), bptr, nw,
+                                                         eps, cosv, sinv, placement, buf_lens, k_bufs, v_bufs, q_out, m, h, hkv, dh, k, g, 1, &opts,
+                                                         (zl_stream_t)st);
+            if (st_ == ZL_ESHAPE) return false;
+            zl_check(st_, "gptq_gemm_k_major + rope_qk_cache (boundary fusion)");
+            (void)keep_a; (void)keep_b;
+            return true;
+        };
+        bmengine::core::defer_op(std::move(d));
+        return out;
+    }
     // act-order: the weight rows were regrouped at load, the activations follow (q_gemm_k_major.cu:1094,1104-1106)
     const Tensor a = q_perm.numel() ? permute_input(ctx, a0, q_perm) : a0;
     const int64_t m = rows_of(a);
@@ -413,8 +470,17 @@ Tensor gemm_fuse_gate_in(const Context& ctx, const Tensor& a, const Tensor& q_we
     std::vector<size_t> oshape = a.shape();
     oshape.back() = n1;
     Tensor out = ctx.tensor(oshape, DataType::kHalf);
-    const int64_t ldx = a.ndim() >= 2 ? a.stride(-2) : k;
     const zl_w4_opts_t opts = w4_opts(ctx, m, 2 * n1);
+    // boundary fusion (bm_hip.h DeferredOp): `a` is an RMSNorm that LayerNorm::forward has not launched -> this launch's norm prologue
+    if (bmengine::core::DeferredOp* nd = bmengine::core::boundary_fusion_enabled() ? bmengine::core::find_deferred(a.nullable_data(), 1) : nullptr) {
+        if (nd->rows == m && nd->dim == k && k <= 4096 && m <= 8 && nd->stream == ctx.current_cuda_stream()) {
+            nd->consumed = true;
+            zl_check(zl_w4a16_gemm_mfma_ex((const uint16_t*)nd->x, k, p.q_weight.data<uint32_t>(), p.scales.data<uint32_t>(), nullptr, nullptr, u16m(out),
+                                           m, 2 * n1, k, g, nd->norm_w, nd->eps, ZL_EPI_SILU_MUL, &opts, st_of(ctx)), "gemm_fuse_gate_in (fused norm)");
+            return out;
+        }
+    }
+    const int64_t ldx = a.ndim() >= 2 ? a.stride(-2) : k;
     zl_check(zl_w4a16_gemm_mfma_ex(u16(a), ldx, p.q_weight.data<uint32_t>(), p.scales.data<uint32_t>(), nullptr, nullptr, u16m(out), m,
                                    2 * n1, k, g, nullptr, 0.f, ZL_EPI_SILU_MUL, &opts, st_of(ctx)), "gemm_fuse_gate_in");
     return out;
@@ -920,6 +986,47 @@ void attention_qkv_rag_buffer(const Context& ctx, const Tensor& batch_q, const T
 // ---- rotary / scatter / element-wise -------------------------------------------------------------------------------
 // the reference's call sites (attention.cpp:872-888) hand EMPTY q / k / v tensors to the fused rotary kernels and read them back
 // filled: the callee allocates what it is not given (found by running the reference's dynamic_batch_forward, round 4)
+// per-row "ragged buffer" tables that make the fused qkv + rotary + scatter kernel write DENSE (rows, Hkv D) k / v tensors: task m's
+// buffer is one slot long and starts at row m of the output (see rope_qk_cache).  Device arrays, built once per (k, v, rows) and kept.
+namespace {
+struct RopeTables {
+    int32_t* placement;
+    int32_t* buf_lens;
+    uint16_t** k_bufs;
+    uint16_t** v_bufs;
+};
+const RopeTables* rope_tables(const Context& ctx, uint16_t* k, uint16_t* v, size_t rows, size_t row_elems) {
+    static thread_local std::map<std::tuple<void*, void*, size_t>, RopeTables> cache;
+    const auto key = std::make_tuple((void*)k, (void*)v, rows);
+    auto it = cache.find(key);
+    if (it != cache.end()) return &it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx.current_cuda_stream(), &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // build outside capture only
+    if (cache.size() > 256) return nullptr;
+    char* block = nullptr;
+    if (hipMalloc(&block, rows * 24) != hipSuccess) return nullptr;
+    std::vector<int32_t> i32(2 * rows);
+    std::vector<uint16_t*> ptrs(2 * rows);
+    for (size_t m = 0; m < rows; ++m) {
+        i32[m] = 0;                 // placement: slot 0
+        i32[rows + m] = 1;          // buffer length: one slot
+        ptrs[m] = k + m * row_elems;
+        ptrs[rows + m] = v + m * row_elems;
+    }
+    RopeTables t;
+    t.k_bufs = reinterpret_cast<uint16_t**>(block);
+    t.v_bufs = t.k_bufs + rows;
+    t.placement = reinterpret_cast<int32_t*>(block + rows * 16);
+    t.buf_lens = t.placement + rows;
+    if (hipMemcpy(block, ptrs.data(), rows * 16, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(block + rows * 16, i32.data(), rows * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(block);
+        return nullptr;
+    }
+    return &cache.emplace(key, t).first->second;
+}
+}  // namespace
+
 static void alloc_qkv_outputs(const Context& ctx, size_t s, size_t num_heads, size_t num_kv_heads, size_t dim_head, DataType dtype, Tensor& out_q,
                               Tensor& out_k, Tensor& out_v) {
     if (out_q.numel() == 0) out_q = ctx.tensor({s, num_heads * dim_head}, dtype);
@@ -940,6 +1047,29 @@ void rope_qk_cache(const Context& ctx, const Tensor& cos, const Tensor& sin, con
     const size_t s = cos.numel() / dim_head;
     BM_ASSERT_EQ(in.numel(), s * (num_heads + 2 * num_kv_heads) * dim_head, "in shape mismatch");
     alloc_qkv_outputs(ctx, s, num_heads, num_kv_heads, dim_head, dtype, out_q, out_k, out_v);
+    // boundary fusion (bm_hip.h DeferredOp): `in` is the fused qkv projection, not launched yet -> ONE launch computes it, rotates q
+    // and k and writes the three outputs (the decode step's fused kernel, zl_w4a16_qkv_rope_scatter: "scattering" through per-row
+    // tables that point at out_k / out_v themselves -- row m of a one-slot BSHD buffer at out_k + m Hkv D).  The tables are built once
+    // per (out_k, out_v, rows) -- the pool hands the same blocks out every step -- outside stream capture.
+    if (neox_style && dtype == DataType::kHalf && s <= 8 && dim_head % 32 == 0 && out_k.is_continuous() && out_v.is_continuous() && out_q.is_continuous()) {
+        if (bmengine::core::DeferredOp* d = bmengine::core::find_deferred(in.nullable_data(), 2)) {
+            if (d->launch_rope && (size_t)d->m == s && d->stream == ctx.current_cuda_stream()) {
+                if (const RopeTables* t = rope_tables(ctx, (uint16_t*)out_k.nullable_data(), (uint16_t*)out_v.nullable_data(), s, num_kv_heads * dim_head)) {
+                    auto launch_rope = d->launch_rope;
+                    const void* yb = d->y;
+                    const float* cp = cos.data<float>();
+                    const float* sp = sin.data<float>();
+                    (void)out_q.data(); (void)out_k.data(); (void)out_v.data();          // written: whatever is pending on them goes first
+                    if (bmengine::core::find_deferred(yb, 2) &&
+                        launch_rope(cp, sp, t->placement, t->buf_lens, t->k_bufs, t->v_bufs, (uint16_t*)out_q.nullable_data(), (int64_t)num_heads,
+                                    (int64_t)num_kv_heads, (int64_t)dim_head)) {
+                        bmengine::core::drop_deferred(yb);
+                        return;
+                    }
+                }
+            }
+        }
+    }
     zl_check(zl_rope_qk_cache(cos.data<float>(), sin.data<float>(), u16(in), u16m(out_q), u16m(out_k), u16m(out_v), s, num_heads,
                               num_kv_heads, dim_head, neox_style, zdt(dtype), st_of(ctx)), "rope_qk_cache");
 }
@@ -970,8 +1100,30 @@ void copy_to_rag_buffer(const Context& ctx, const Tensor& src, const Tensor& pla
 }
 void element_add_scale_out(const Context& ctx, const Tensor& a, const Tensor& b, Tensor& c, float scale, bool scale_residual) {
     BM_ASSERT_EQ(a.numel(), b.numel(), "shape mismatch");
-    zl_check(zl_element_add_scale(u16(a), u16(b), u16m(c), a.numel(), scale, scale_residual, zdt(a.dtype()), st_of(ctx)),
-             "element_add_scale");
+    // boundary fusion (bm_hip.h DeferredOp): b is a W4 linear that has not been launched -> its residual epilogue writes c = a + b
+    // (scale 1: half(float(a) + float(half(acc + bias))), the roundings of the GEMV launch followed by this add)
+    if (scale == 1.0f && a.dtype() == DataType::kHalf && c.numel() == a.numel() && a.is_continuous() && c.is_continuous()) {
+        if (bmengine::core::DeferredOp* d = bmengine::core::find_deferred(b.nullable_data(), 2)) {
+            if ((size_t)(d->m * d->n) == a.numel() && d->stream == ctx.current_cuda_stream() && a.nullable_data() != b.nullable_data()) {
+                auto launch_into = d->launch_into;
+                const void* yb = d->y;
+                bmengine::core::drop_deferred(yb);
+                bmengine::core::retire_deferred_inputs(c.nullable_data(), c.nbytes());   // c is about to be overwritten
+                // (a may be the deferred norm's input or c itself: read without launching anything; an in-place c == a is
+                //  element-wise safe -- a thread reads its residual element before it writes that element)
+                launch_into((const uint16_t*)a.nullable_data(), (uint16_t*)c.nullable_data());
+                return;
+            }
+        }
+    }
+    // a and b are only READ: launch what PRODUCES them if it is still pending, but not a pending op that merely reads them too
+    // (Tensor::data() cannot tell a reader from a writer and launches both kinds); c goes through data(): it is written
+    bmengine::core::flush_deferred_producing(a.nullable_data(), a.nbytes());
+    bmengine::core::flush_deferred_producing(b.nullable_data(), b.nbytes());
+    if (c.nullable_data() != a.nullable_data() && c.nullable_data() != b.nullable_data()) (void)c.data();
+    else bmengine::core::retire_deferred_inputs(c.nullable_data(), c.nbytes());
+    zl_check(zl_element_add_scale((const uint16_t*)a.nullable_data(), (const uint16_t*)b.nullable_data(), (uint16_t*)c.nullable_data(), a.numel(), scale,
+                                  scale_residual, zdt(a.dtype()), st_of(ctx)), "element_add_scale");
 }
 Tensor element_add_scale(const Context& ctx, const Tensor& a, const Tensor& b, float scale, bool scale_residual) {
     Tensor c = ctx.tensor(a.shape(), a.dtype());
@@ -990,10 +1142,9 @@ Tensor gate_fuse(const Context& ctx, const Tensor& input, const std::string& act
     const size_t ff = input.size(-1) / 2, rows = input.numel() / input.size(-1), es = core::get_elem_size(input.dtype());
     std::vector<size_t> shape = input.shape();
     shape.back() = ff;
-    Tensor x = ctx.tensor(shape, input.dtype()), y = ctx.tensor(shape, input.dtype());
-    zl_check(zl_copy_2d(input.data(), 2 * ff * es, x.data(), ff * es, ff * es, rows, st_of(ctx)), "gate_fuse");
-    zl_check(zl_copy_2d((const char*)input.data() + ff * es, 2 * ff * es, y.data(), ff * es, ff * es, rows, st_of(ctx)), "gate_fuse");
-    zl_check(zl_gate_mul(u16(x), u16(y), u16m(x), x.numel(), act_fn_type == "gelu", zdt(x.dtype()), st_of(ctx)), "gate_fuse");
+    (void)es;
+    Tensor x = ctx.tensor(shape, input.dtype());
+    zl_check(zl_gate_fuse(u16(input), u16m(x), rows, ff, act_fn_type == "gelu", zdt(x.dtype()), st_of(ctx)), "gate_fuse");
     return x;
 }
 
