@@ -222,8 +222,23 @@ typedef struct {
     int slab_r;       /* ... and 16-column tiles per workgroup (1 / 2 / 4 / 8); 0 = planned */
     int defer_norm;   /* 1: norm_weight with 9..32 rows may take the phase kernel's DEFERRED norm (not zl_rmsnorm's roundings, see
                          below); 0: such calls return ZL_ESHAPE and the caller runs zl_rmsnorm first */
+    /* ROW STATISTICS HAND-OFF (5..32 rows): the launch that PRODUCES the residual stream leaves, per row and 16-column tile, the
+       sum of squares of the fp16 values it stored; the launch that NORMALISES that stream (norm_weight) reads them instead of
+       walking the rows again.  Same rounding points as zl_rmsnorm + GEMM -- T(x rs w) per element, rs = rsqrt_rn(sum / K + eps) --
+       with the row's sum taken in the statistics' order (tile sums by a 16-lane butterfly, tiles by lane then a 64-lane
+       butterfly) instead of zl_rmsnorm's: rs agrees to an fp32 rounding. */
+    const float* row_ss;   /* in:  [m][k / 16] tile sums of x (zl_row_ss, or the producing launch's row_ss_out); with norm_weight */
+    float* row_ss_out;     /* out: [m][n / 16] tile sums of the rows this launch stores (plain / bias / ADD_C / residual epilogues of
+                                   the slab kernel; other routes ignore it: check zl_w4a16_emits_row_ss) */
 } zl_w4_opts_t;
 int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n);
+/* tile sums of squares of m rows of k fp16 values, out[row][k / 16] (k % 16 == 0): the stand-alone producer of zl_w4_opts_t::row_ss
+ * (the first layer's input; tests) -- bit for bit what a producing GEMM launch leaves in row_ss_out for the same stored rows */
+int zl_row_ss(const uint16_t* x, int64_t ldx, int64_t m, int64_t k, float* out, zl_stream_t s);
+/* 1 when zl_w4a16_gemm_mfma_ex(m rows, n, k, this epilogue, these options) would fill row_ss_out, 0 when its route ignores it */
+int zl_w4a16_emits_row_ss(int64_t m, int64_t n, int64_t k, int64_t group_size, int epilogue, const zl_w4_opts_t* opts);
+/* ... and 1 when the same call with norm_weight (or zl_w4a16_qkv_rope_scatter_ex when rope != 0) would consume row_ss */
+int zl_w4a16_takes_row_ss(int64_t m, int64_t n, int64_t k, int64_t group_size, int rope, const zl_w4_opts_t* opts);
 /* WHICH KERNEL A SHAPE TAKES (defaults; group size a multiple of 128 = the ZLW4M operands of this entry point; M = rows of x):
  *   M = 1..4, K <= 4096 (1..2 rows up to K = 16384)   k_w4a16_i8p   (w4_i8p.hip: integer planes, v_mfma_i32_16x16x64_i8; fused RMSNorm
  *                                                     prologue with norm_weight; the batch-1 decode step's four projections)
@@ -236,8 +251,10 @@ int64_t zl_w4a16_scratch_bytes(int64_t m, int64_t n);
  *                                                     split K for short grids)
  *   anything else (odd K tails, huge K)                k_w4a16_mfma (w4_mfma.hip: whole activation block staged in LDS, 16 rows per pass)
  *   group size not a multiple of 128                   not this entry point: zl_w4a16_gemm (w4_gemv.hip, the warp-reduce arithmetic)
- *   M = 5..32 without norm_weight, K % 128 == 0        k_w4a16_slab  (w4_slab.hip, round 6: 128-column x K-slice tiles, activation
- *     (scratch for the K split; else the phase kernel)  fragments straight from global memory, split-K slabs folded by the last arriver)
+ *   M = 5..32 without norm_weight, K % 128 == 0        k_w4a16_slab  (w4_slab.hip, round 6: 16 R-column x K-slice tiles, activations by
+ *     (scratch for the K split; else the phase kernel)  LDS-DMA into wave-private fragment stores, split-K slabs folded by the last arriver)
+ *   M = 5..32 with norm_weight AND zl_w4_opts_t::row_ss, k_w4a16_slab<NORM>: rs from the rows' tile sums, T(x rs w) on the fragments (see
+ *     K % 1024 == 0, 2048 < K <= 8192                   zl_w4_opts_t::row_ss; zl_w4a16_takes_row_ss answers without launching)
  * norm_weight with 9..32 rows and zl_w4_opts_t::defer_norm = 1 runs the phase kernel's DEFERRED norm: the staged activation is T(x w) and the row's
  * rsqrt(mean x^2 + eps) multiplies the fp32 totals in the epilogue -- one launch less, but NOT the roundings of zl_rmsnorm + GEMM
  * (T(x w) rs against T(x rs w): ~5e-4 rms of an output, 1e-2 of the largest logit after a few layers of the synthetic network),

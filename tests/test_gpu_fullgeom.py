@@ -200,10 +200,20 @@ def test_stack_of_eight_full_layers(oracle, dev, batch, layers):
     # Round 6: T perturbs ONE projection of ONE layer, an implementation every projection of every layer -- at the SAME rate: both
     # W4 streaming kernels return something other than the correctly rounded exact sum for 0.05 .. 0.1 % of their outputs
     # (tools/ubench/tie_rate.py, profiles/r06_tie_rate.txt: w4_slab.hip 0.046 .. 0.098 %, w4_phase.hip 0.067 .. 0.085 %), and which
-    # outputs depends on the order of the fp32 additions.  With w4_slab.hip in place of w4_phase.hip the same 4-layer stack landed
-    # at 2.3e-3 (rms 6.8e-4) -- a different draw of the same noise, not a less exact kernel.  T2 is the faithful model: E with one
-    # output in 2000 of EVERY projection moved by one ulp; the implementation is held to 1.25 x the larger of the two draws.
+    # outputs depends on the order of the fp32 additions.  T2 is that model: E with one output in 2000 of EVERY projection moved by
+    # one ulp.  And ONE draw of it says little about the largest of 131 072 logits: eight draws of T2 on this very case (another
+    # seed each; tools/ubench/t2_draws.py, CPU only, tests/golden/t2_draws_stack4_b32.json, profiles/r06_t2_draws.txt) land between
+    # 0.78e-3 and 2.37e-3 of the largest logit (rms 4.7e-4 .. 7.2e-4).  The round-5 kernels drew 1.29e-3, w4_slab.hip 2.30e-3 and
+    # 2.33e-3 (rms 6.8e-4) -- inside the spread of equally exact implementations, so the implementation is held to 1.25 x the
+    # largest draw on record; the T and T2 draws computed HERE must reproduce the record's (it is this case and no other).
     cond_max, cond_rms = max(rec["T_vs_E_max"], rec["T2_vs_E_max"]), max(rec["T_vs_E_rms"], rec["T2_vs_E_rms"])
+    if batch == 32 and layers == 4:
+        with open(os.path.join(ROOT, "tests", "golden", "t2_draws_stack4_b32.json")) as fh:
+            spread = json.load(fh)
+        for fl, key in (("T", "T_vs_E"), ("T2", "T2_vs_E")):
+            assert abs(spread["draws"][fl]["max"] - rec[key + "_max"]) <= 1e-3 * rec[key + "_max"], (fl, spread["draws"][fl], rec)
+            assert abs(spread["draws"][fl]["rms"] - rec[key + "_rms"]) <= 1e-3 * rec[key + "_rms"], (fl, spread["draws"][fl], rec)
+        cond_max, cond_rms = max(cond_max, spread["max_over_draws"]), max(cond_rms, spread["rms_over_draws"])
     assert rec["logits_vs_E_max"] <= max(1e-3, 1.25 * cond_max), rec
     assert rec["logits_vs_E_rms"] <= max(5e-4, 1.25 * cond_rms), rec
 

@@ -919,3 +919,128 @@ def test_deferred_norm_fused_qkv_rotary_scatter(oracle, dev, m, bshd, monkeypatc
         assert (np.abs(a64 - b64) <= 2.0 ** -9 * np.abs(a64) + 4e-3 * rms).all()
         assert np.array_equal(a64 == 3.0, b64 == 3.0) or np.abs(a64 - b64).max() <= 4e-3 * rms     # untouched slots stay untouched
     assert not torch.equal(k2[0], torch.full_like(k2[0], 3.0))
+
+
+# ---- round 6: the rows' statistics travel with the residual stream (zl_w4_opts_t::row_ss / row_ss_out) -----------------------------
+def _tile_ss(x16):
+    """numpy statement of a tile's sum of squares (zl_sum16): pairwise tree over the tile's 16 columns, fp32"""
+    v = x16.astype(np.float32).reshape(x16.shape[0], -1, 16)
+    v = v * v                                          # exact: 11-bit significands
+    while v.shape[-1] > 1:
+        v = v[..., 0::2] + v[..., 1::2]
+    return v[..., 0]
+
+
+def _rs_from_ss(ss, k, eps):
+    """... and of the normalising launch's rs: lane q sums the tile sums 4 q .. 4 q + 3 (+ 64 u, u ascending) as (p0 + p1) + (p2 + p3),
+    then the same 16-lane tree; rs = 1 / sqrt(sum / K + eps) in fp32"""
+    m, parts = ss.shape
+    p = ss.reshape(m, parts // 64, 16, 4)
+    t = np.zeros((m, 16), np.float32)
+    for u in range(parts // 64):
+        t = t + ((p[:, u, :, 0] + p[:, u, :, 1]) + (p[:, u, :, 2] + p[:, u, :, 3]))
+    while t.shape[-1] > 1:
+        t = t[..., 0::2] + t[..., 1::2]
+    val = t[:, 0] / np.float32(k) + np.float32(eps)
+    return (np.float32(1.0) / np.sqrt(val, dtype=np.float32)).astype(np.float32)
+
+
+@pytest.mark.parametrize("m,k", [(1, 16), (7, 4096), (32, 8192), (5, 1040)])
+def test_row_ss_bit_exact(dev, m, k):
+    from zhilight_amd import ops
+    rng = np.random.default_rng(900 + m)
+    x = synth.act(rng, m, k, 3.0)
+    got = _np(ops.row_ss(_t(x, dev)))
+    assert np.array_equal(got, _tile_ss(x))
+
+
+@pytest.mark.parametrize("m", [5, 8, 9, 16, 17, 32])
+@pytest.mark.parametrize("n,k,epi", [(4096, 4096, "residual"), (4096, 14336, "residual"), (1024 + 16, 4096, "bias"), (512, 2048, "addc")])
+def test_slab_leaves_row_statistics(dev, m, n, k, epi):
+    """a producing launch's row_ss_out == zl_row_ss of the rows it stored, bit for bit (one K slice, K split 4 folded by the last
+    arriver, a ragged tile count, ADD_C), and the route question agrees with what the launch did"""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(910 + m)
+    w = ops.W4MWeight.random(n, k, 128, dev)
+    x = _t(synth.act(rng, m, k), dev)
+    res = _t(synth.act(rng, m, n, 2.0), dev)
+    ss = torch.full((m, n // 16), -1.0, dtype=torch.float32, device=dev)
+    kw = {}
+    if epi == "residual":
+        kw = dict(residual=res, epilogue=ops.EPI_RESIDUAL)
+    elif epi == "bias":
+        kw = dict(bias=_t((rng.standard_normal(n) * 0.1).astype(np.float16), dev))
+    out = res.clone() if epi == "addc" else None
+    if epi == "addc":
+        kw = dict(epilogue=ops.EPI_ADD_C)
+    assert ops.w4_row_ss_routes(m, [w], [], dev)
+    y = ops.w4a16_gemm_mfma(x, w, out=out, row_ss_out=ss, **kw)
+    assert torch.equal(ss, ops.row_ss(y))
+    plain = ops.w4a16_gemm_mfma(x, w, out=res.clone() if epi == "addc" else None, **kw)
+    assert torch.equal(plain, y)                       # and the rows themselves are what the launch stores without it
+
+
+@pytest.mark.parametrize("m", [5, 8, 9, 16, 17, 32])
+@pytest.mark.parametrize("n,k,epi", [(6144, 4096, 0), (2048, 4096, "silu"), (512 + 16, 8192, "bias"), (4096, 3072, "residual"),
+                                     (28672, 4096, "silu"), (16 * 8 * 256, 4096, 0)])       # 7 and 8 tiles per workgroup
+def test_slab_norm_from_row_statistics(oracle, dev, m, n, k, epi, monkeypatch):
+    """norm_weight + row_ss on the slab kernel's NORM instantiations: the launch returns the BITS of the same kernel fed with
+    T(x rs w) formed on the host from the statistics' definition (rs in the statistics' summation order, zl_rmsnorm's two products and one
+    rounding per element), and sits inside the fused-norm bar of the exact product"""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(920 + m)
+    inter = epi == "silu"
+    w = ops.W4MWeight.random(n, k, 128, dev, row_interleave=inter)
+    x = synth.act(rng, m, k, 2.0)
+    nw = (1.0 + 0.1 * rng.standard_normal(k)).astype(np.float16)
+    ss = ops.row_ss(_t(x, dev))
+    rs = _rs_from_ss(_np(ss), k, 1e-5)
+    xn = ((x.astype(np.float32) * rs[:, None]) * nw.astype(np.float32)[None, :]).astype(np.float16)
+    # the stand-alone norm agrees with that to a rounding of rs: a few elements of a row by one ulp
+    xn_ref = oracle.u2h(oracle.rmsnorm(oracle.h2u(x), oracle.h2u(nw), 1e-5))
+    d = np.abs(xn.astype(np.float64) - xn_ref.astype(np.float64))
+    assert (d <= np.abs(xn_ref.astype(np.float64)) * 2.0 ** -10).all() and (d > 0).mean() < 0.02
+    kw = {}
+    if epi == "silu":
+        kw = dict(epilogue=ops.EPI_SILU_MUL)
+    elif epi == "bias":
+        kw = dict(bias=_t((rng.standard_normal(n) * 0.1).astype(np.float16), dev))
+    elif epi == "residual":
+        kw = dict(residual=_t(synth.act(rng, m, n), dev), epilogue=ops.EPI_RESIDUAL)
+    assert ops.w4_row_ss_routes(m, [], [(w, False)], dev)
+    got = ops.w4a16_gemm_mfma(_t(x, dev), w, norm_weight=_t(nw, dev), norm_eps=1e-5, row_ss=ss, **kw)
+    monkeypatch.setenv("ZL_W4_SLAB", "2")              # the same geometry for the plain launch (gate|up-sized grids at <= 16 rows)
+    want = ops.w4a16_gemm_mfma(_t(xn, dev), w, **kw)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("m", [5, 8, 12, 32])
+@pytest.mark.parametrize("h,hkv,d,k", [(32, 8, 128, 4096), (6, 3, 64, 4096), (4, 4, 128, 8192)])
+def test_slab_norm_fused_qkv_rotary_scatter_from_row_statistics(oracle, dev, m, h, hkv, d, k):
+    """the decode step's first launch in that mode: norm (from the statistics) + qkv + rotation + KV scatter == the plain fused launch on
+    the host-normalised rows, bit for bit (q, K and V buffers)"""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(930 + m)
+    n = (h + 2 * hkv) * d
+    w = ops.W4MWeight.random(n, k, 128, dev)
+    x = synth.act(rng, m, k, 2.0)
+    nw = (1.0 + 0.1 * rng.standard_normal(k)).astype(np.float16)
+    ss = ops.row_ss(_t(x, dev))
+    rs = _rs_from_ss(_np(ss), k, 1e-5)
+    xn = ((x.astype(np.float32) * rs[:, None]) * nw.astype(np.float32)[None, :]).astype(np.float16)
+    lens = [int(v) for v in rng.integers(2, 6, m) * 32]
+    pos = np.array([int(rng.integers(0, L)) for L in lens], np.int32)
+    placement = pos.copy()
+    placement[1] = -1
+    cs, sn = oracle.rope_cos_sin(pos, d, 5e5, True, None)
+    mk = lambda: [torch.full((L, hkv, d), 3.0, dtype=torch.float16, device=dev) for L in lens]
+    k1, v1, k2, v2 = mk(), mk(), mk(), mk()
+    lens_t, place_t = _t(np.array(lens, np.int32), dev), _t(placement, dev)
+    assert ops.w4_row_ss_routes(m, [], [(w, True)], dev)
+    q_got = ops.w4_qkv_rope_scatter(_t(x, dev), w, _t(cs, dev), _t(sn, dev), place_t, lens_t, ops.make_ptr_table(k1), ops.make_ptr_table(v1),
+                                    h, hkv, d, norm_weight=_t(nw, dev), norm_eps=1e-5, row_ss=ss)
+    q_ref = ops.w4_qkv_rope_scatter(_t(xn, dev), w, _t(cs, dev), _t(sn, dev), place_t, lens_t, ops.make_ptr_table(k2), ops.make_ptr_table(v2),
+                                    h, hkv, d)
+    assert torch.equal(q_got, q_ref)
+    for a, b_ in zip(k1 + v1, k2 + v2):
+        assert torch.equal(a, b_)

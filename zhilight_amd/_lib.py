@@ -41,7 +41,7 @@ SYMBOLS = [
     "zl_decode_attn_la_split_len", "zl_decode_attn_la_workspace_bytes", "zl_decode_attn_la",
     "zl_quant_calc_scale_zp", "zl_dequant_group", "zl_quant_copy_to_rag_buffer", "zl_rope_quant_scatter_decode", "zl_decode_attn_quant", "zl_decode_attn_quant_ex",
     "zl_prefill_attn", "zl_prefill_attn_ex",
-    "zl_element_add_scale", "zl_gate_mul", "zl_gate_fuse", "zl_permute_input", "zl_embedding",
+    "zl_element_add_scale", "zl_gate_mul", "zl_gate_fuse", "zl_row_ss", "zl_w4a16_emits_row_ss", "zl_w4a16_takes_row_ss", "zl_permute_input", "zl_embedding",
     "zl_w8m_bytes", "zl_w8m_pack", "zl_w8a8_gemm_phase", "zl_w8a8_gemm_phase_ex", "zl_w8a8_qkv_rope_scatter",
     "zl_quant_calc_scale", "zl_rmsnorm_quant", "zl_int8_gemm_nt", "zl_quant_scale_back",
     "zl_quant_back_act_mul", "zl_quant_scale_back3", "zl_quant_back_element_add_scale", "zl_quant_back_transpose",
@@ -63,7 +63,7 @@ class W4Opts(C.Structure):
     _fields_ = [("scratch", C.c_void_p), ("scratch_bytes", C.c_int64)] + [(n, C.c_int) for n in (
         "phase_rounds", "phase_ksplit", "phase_ksplit_min_m", "phase_min_m", "phase_max_m", "phase_small_off",
         "tiled_min_m", "tiled_bm", "tiled_splitk", "mfma_ks", "mfma_rounds", "small_algo", "tiled_wide",
-        "slab", "slab_min_m", "slab_nw", "slab_gpw", "slab_r", "defer_norm")]
+        "slab", "slab_min_m", "slab_nw", "slab_gpw", "slab_r", "defer_norm")] + [("row_ss", C.c_void_p), ("row_ss_out", C.c_void_p)]
 
 
 class W4Layout(C.Structure):

@@ -15,6 +15,10 @@ OUT = os.path.join(HERE, "libzhilight_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-fast-math", "-ffp-contract=off"]
+# per-source extras.  w4_slab.hip: its item loops (up to 4 groups x 8 tiles, the next group's normalisation in slices between the
+# items) must unroll completely -- ring slots, accumulators and wait counts are static only then -- and the NORM instantiations
+# exceed the unroller's default budget for `#pragma unroll` (16 K): the ring went to scratch behind dynamic indices
+EXTRA_FLAGS = {"w4_slab.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 
 
 # ZL_BUILD_EXPERIMENTAL=1: also build what was measured and left off the product path: the loader /
@@ -55,7 +59,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + flags + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + flags + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -670,10 +670,25 @@ __device__ __forceinline__ f4v mfma_t(uint4 a, uint4 b, f4v c) {
 #define ZL_LA_BATCH 16
 #endif
 constexpr int kLaBatch = ZL_LA_BATCH;   // split records a last arriver holds in registers at once
+// ---- optional timeline probe of the in-launch-merge kernel (build a variant with -DZL_ATTN_PROBE; tools/ubench/probe_attn_la.py)
+#ifdef ZL_ATTN_PROBE
+__device__ unsigned long long* zl_aprobe_p = nullptr;   // [workgroups * 8 waves][8] wall-clock ticks (100 MHz)
+#define ZL_APROBE_INIT()                                                                                           \
+    unsigned long long* ap_ = nullptr;                                                                             \
+    {                                                                                                              \
+        const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                        \
+        if (zl_aprobe_p && (threadIdx.x & 63) == 0 && wg_ < 8192) ap_ = zl_aprobe_p + ((size_t)wg_ * 8 + (threadIdx.x >> 6)) * 8; \
+    }
+#define ZL_APROBE(slot) do { if (ap_) ap_[slot] = wall_clock64(); } while (0)
+#else
+#define ZL_APROBE_INIT() do {} while (0)
+#define ZL_APROBE(slot) do {} while (0)
+#endif
 constexpr int kLaMaxSplits = 64;      // splits per task the launcher allows (the last arriver walks them 16 at a time)
 
 template <int DT>
-__device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int b, int hk, int split, int nw, int ns) {
+__device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int b, int hk, int split, int nw, int ns, unsigned long long* ap_) {
+    (void)ap_;
     constexpr int WS = 16 * (kMD + 2);
     const int nthr = nw * 64;
     const bool direct = ns == 1;
@@ -728,6 +743,7 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
     // ---- arrival.  The stores above are write-through; once vmcnt is zero they are where an sc1 load of any CU finds them.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // ... for every wave of the workgroup; xw is free from here on
+    ZL_APROBE(5);
     int* flag = reinterpret_cast<int*>(xw);
     if (threadIdx.x == 0) {
         int* cnt = p.la_cnt + (size_t)b * p.hkv + hk;
@@ -736,6 +752,7 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
         *flag = old == ns - 1;
     }
     __syncthreads();
+    ZL_APROBE(6);
     if (!*flag) return;
     // ---- the pair's last arriver: thread -> (row i, 4 consecutive d).  Statistics AND record slices of up to 16 splits are
     //      requested together (one memory round trip; the statistics are the same 8 bytes for the 32 threads of a row); more
@@ -800,6 +817,7 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
         for (int e = 0; e < 4; ++e) o4[e] = ZT<DT>::from_f32(p.half_partials ? a[e] * zi : a[e] / (z + 1e-20f));
         *reinterpret_cast<uint2*>(p.out + vh * kMD + d0) = make_uint2((uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16));
     }
+    ZL_APROBE(7);
 }
 
 #ifndef ZL_ATTN8_WAVES_PER_SIMD
@@ -822,6 +840,8 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
     const int elen = min(len, vlen_in);
     const int t0 = split * p.split_len;
     const int nw = LA ? __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6)) : NW;   // LA: 1 / 2 / 4 (8) waves, as launched
+    ZL_APROBE_INIT();
+    ZL_APROBE(0);
     if (t0 >= elen || len <= 0) {
         // LA: a task without a visible key has no arriver at all -- split 0 leaves the rows the merge launch would (zeros)
         if constexpr (LA) {
@@ -861,6 +881,7 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
     ZL_MFMA_V1(5, base) ZL_MFMA_V1(6, base) ZL_MFMA_V1(7, base)
     ZL_MFMA_LOAD_K(c0)
     ZL_MFMA_LOAD_V(c0)
+    ZL_APROBE(1);
 
     // Q^T fragments: query row m = r -> (qi, head)
     uint4 qf[4];
@@ -922,6 +943,9 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __expf(m_run - m_new);
+#ifdef ZL_ATTN_PROBE
+        if (m_run == -1e20f && m_new > -1e19f) ZL_APROBE(2);     // the wave's first scores are in hand
+#endif
         m_run = m_new;
         // probabilities as hi + lo fp16 parts (two MFMAs per V fragment): the product sees p to ~2^-22, i.e. the fp32
         // probabilities of the reference's decode kernel, not flash-attention's fp16 ones
@@ -974,6 +998,7 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
 #undef ZL_MFMA_V1
 
     // ---- merge: the row's normaliser lives in 4 lanes; then the waves through LDS (aliases the V staging)
+    ZL_APROBE(3);
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     __syncthreads();
@@ -989,7 +1014,12 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
     }
     __syncthreads();
     if constexpr (LA) {
-        attn_tail_la<DT>(p, xw, b, hk, split, nw, (elen + p.split_len - 1) / p.split_len);
+        ZL_APROBE(4);
+#ifdef ZL_ATTN_PROBE
+        attn_tail_la<DT>(p, xw, b, hk, split, nw, (elen + p.split_len - 1) / p.split_len, ap_);
+#else
+        attn_tail_la<DT>(p, xw, b, hk, split, nw, (elen + p.split_len - 1) / p.split_len, nullptr);
+#endif
         return;
     }
     for (int idx = threadIdx.x; idx < p.rows * kMD; idx += NW * 64) {
@@ -1626,3 +1656,7 @@ int zl_decode_attn_quant_ex(const uint16_t* q, const int32_t* buf_lens, const ui
 }
 
 }  // extern "C"
+
+#ifdef ZL_ATTN_PROBE
+extern "C" int zl_debug_set_attn_probe(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(zl_aprobe_p), &p, sizeof(p)); }
+#endif

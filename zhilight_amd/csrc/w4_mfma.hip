@@ -599,12 +599,12 @@ int zl_w4a16_gemm_phase(const uint16_t* x, int64_t ldx, const uint32_t* qw, cons
 // w4_slab.hip: 9..32 rows on 128-column x K-slice tiles (round 6); ZL_ESHAPE = not this shape / no scratch for the K split
 int zl_w4a16_gemm_slab(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes, uint32_t meta_bytes,
                        const uint16_t* bias, const uint16_t* residual, uint16_t* y, int m, int n, int k, int groups, int tiles,
-                       int epilogue, int ld_out, const zl_w4_opts_t* opts, hipStream_t hs);
+                       int epilogue, int ld_out, const uint16_t* norm_w, float norm_eps, const zl_w4_opts_t* opts, hipStream_t hs);
 int zl_w4a16_gemm_slab_rope(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
                             uint32_t meta_bytes, const uint16_t* bias, int m, int n, int k, int groups, int tiles, const float* cosv,
                             const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
-                            uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, const zl_w4_opts_t* opts,
-                            hipStream_t hs);
+                            uint16_t* const* v_bufs, uint16_t* q_out, int h, int hkv, int d, int bshd, const uint16_t* norm_w,
+                            float norm_eps, const zl_w4_opts_t* opts, hipStream_t hs);
 
 bool zl_w4a16_i8p_covers(int64_t m, int64_t k);
 int zl_w4a16_gemm_i8p(const uint16_t* x, int64_t ldx, const uint32_t* qw, const uint32_t* meta, uint32_t qw_bytes,
@@ -770,10 +770,11 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
                                  o.phase_rounds, hs);
     // 9..32 rows without a fused norm (round 6): 128-column x K-slice tiles, activation fragments straight from global memory
     // (w4_slab.hip) -- a workgroup's activation bytes ~ its weight bytes instead of M x K per 16 R columns
-    if (o.slab >= 0 && !norm_weight && m >= (o.slab_min_m > 0 ? o.slab_min_m : 5) && m <= 32 && k % 128 == 0 &&
+    // ... and WITH a norm when the caller hands over the rows' statistics (zl_w4_opts_t::row_ss): the slab kernel's NORM instantiations
+    if (o.slab >= 0 && (!norm_weight || o.row_ss) && m >= (o.slab_min_m > 0 ? o.slab_min_m : 5) && m <= 32 && k % 128 == 0 &&
         L.qw_bytes < ((int64_t)1 << 32)) {
         st = zl_w4a16_gemm_slab(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
-                                (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), &o, hs);
+                                (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), norm_weight, norm_eps, &o, hs);
         if (st != ZL_ESHAPE) return st;
     }
     {
@@ -904,17 +905,17 @@ int zl_w4a16_qkv_rope_scatter_ex(const uint16_t* x, int64_t ldx, const uint32_t*
     // what the phase-pipelined kernel covers (zl_w4a16_gemm_mfma's own dispatch rules); callers fall back to
     // zl_w4a16_gemm_mfma + zl_rope_scatter_decode outside of it
     ZL_CHECK_ARG(m <= 32 && d % 32 == 0 && h % 1 == 0 && L.np == n, ZL_ESHAPE);
-    ZL_CHECK_ARG(!norm_weight || k <= 4096 || m > 8, ZL_ESHAPE);     // <= 8 rows: register-resident staging; 9..32: deferred norm
     ZL_CHECK_ARG(m <= 16 || k <= 8192, ZL_ESHAPE);
     ZL_CHECK_ARG(L.qw_bytes < ((int64_t)1 << 32), ZL_ELIMIT);
     const int small_algo = opts ? opts->small_algo : 0;
-    ZL_CHECK_ARG(!(norm_weight && m >= 9) || (opts && opts->defer_norm == 1), ZL_ESHAPE);   // the deferred norm: on request only
-    if (opts && opts->slab >= 0 && !norm_weight && m >= (opts->slab_min_m > 0 ? opts->slab_min_m : 5) && k % 128 == 0) {
+    if (opts && opts->slab >= 0 && (!norm_weight || opts->row_ss) && m >= (opts->slab_min_m > 0 ? opts->slab_min_m : 5) && k % 128 == 0) {
         st = zl_w4a16_gemm_slab_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n, (int)k,
                                      (int)L.q, (int)(L.np / 16), cosv, sinv, placement, buf_lens, k_bufs, v_bufs, q_out, (int)h,
-                                     (int)hkv, (int)d, bshd, opts, (hipStream_t)s);
+                                     (int)hkv, (int)d, bshd, norm_weight, norm_eps, opts, (hipStream_t)s);
         if (st != ZL_ESHAPE) return st;
     }
+    ZL_CHECK_ARG(!norm_weight || k <= 4096 || m > 8, ZL_ESHAPE);     // <= 8 rows: register-resident staging; 9..32: deferred norm
+    ZL_CHECK_ARG(!(norm_weight && m >= 9) || (opts && opts->defer_norm == 1), ZL_ESHAPE);   // the deferred norm: on request only
 #ifdef ZL_EXPERIMENTAL
     if (small_algo == 2) {
         st = zl_w4a16_gemm_engine_rope(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, (int)m, (int)n, (int)k,

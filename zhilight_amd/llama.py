@@ -1073,6 +1073,21 @@ class LLaMA:
                 la = (self._bufs[key], la_split, la_half)
                 merge_plan = None
 
+        # round 6: the rows' statistics travel with the residual stream (zl_w4_opts_t::row_ss / row_ss_out): attn_out and w_out leave
+        # per row and 16-column tile the sum of squares of what they store, the normalising projections (qkv, gate|up) read those
+        # 256 numbers per row instead of running -- or waiting for -- an RMSNorm pass over the rows: no stand-alone norm launch from
+        # 9 rows on, no register-resident norm prologue below.  ZL_ROW_SS=0 off; ZL_ROW_SS_MIN_M: rows it starts at
+        stats = None
+        if (fuse_qkv_rope and la is not None and not self.tp and os.environ.get("ZL_ROW_SS", "1") != "0"
+                and int(os.environ.get("ZL_ROW_SS_MIN_M", "8")) <= b <= 32 and c.dim_model % 1024 == 0
+                and all(l.attn_out.perm is None and l.w_out.perm is None and l.w_in_gated.perm is None for l in self.layers)
+                and ops.w4_row_ss_routes(b, [self.layers[0].attn_out.weight, self.layers[0].w_out.weight],
+                                         [(self.layers[0].qkv.weight, True), (self.layers[0].w_in_gated.weight, False)], self.device)):
+            key = ("row_ss", b)
+            if key not in self._bufs:
+                self._bufs[key] = torch.empty((2, b, c.dim_model // 16), dtype=torch.float32, device=self.device)
+            stats = self._bufs[key]
+
         def attend(li, out):
             """decode attention of layer li over the tasks' buffers: bufs["q"] -> out (B, H * D)"""
             q4 = bufs["q"].view(b, 1, c.num_heads, c.dim_head)
@@ -1108,6 +1123,19 @@ class LLaMA:
                     raise ops.ZLError("skip_gemv: the fused W4 decode route with the merging attn_out projection only")
                 ops.decode_attention_splits(bufs["q"].view(b, c.num_heads, c.dim_head), ctx.buf_lens, ctx.k_addrs[li],
                                             ctx.v_addrs[li], ctx.valid_lens, scale, ctx.max_len_buf, c.num_kv_heads, workspace)
+                continue
+            if fuse_qkv_rope and stats is not None:
+                if li == 0:
+                    ops.row_ss(hidden, out=stats[0])          # (the embedding's rows: the only statistics no projection produced)
+                ops.w4_qkv_rope_scatter(hidden, layer.qkv.weight, cos, sin, ctx.placement, ctx.buf_lens, ctx.k_addrs[li],
+                                        ctx.v_addrs[li], c.num_heads, c.num_kv_heads, c.dim_head, bias=layer.qkv.bias,
+                                        norm_weight=layer.ln_attn, norm_eps=c.eps, q_out=bufs["q"], row_ss=stats[0])
+                if not gemv_only:
+                    attend(li, bufs["attn"])
+                layer.attn_out.forward(bufs["attn"], residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL, row_ss_out=stats[1])
+                ops.w4_linear(hidden, layer.w_in_gated.weight, bias=layer.w_in_gated.bias, out=bufs["act"], norm_weight=layer.ln_ff,
+                              norm_eps=c.eps, epilogue=ops.EPI_SILU_MUL, row_ss=stats[1])
+                layer.w_out.forward(bufs["act"], residual=hidden, out=hidden, epilogue=ops.EPI_RESIDUAL, row_ss_out=stats[0])
                 continue
             if fuse_qkv_rope:
                 fused_norm = b <= max(8, _fused_norm_rows(layer.qkv.weight))    # 9..32 rows: the deferred norm (ZL_DEFER_NORM)

@@ -388,8 +388,40 @@ def _w4_opts(device, m, n):
     return o
 
 
-def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, norm_eps=1e-5, epilogue=0):
-    """MFMA flavour of w4a16_gemm (fp32 accumulation = the numerics of the reference's M > 40 branch)."""
+def row_ss(x, out=None):
+    """zl_row_ss: per row and 16-column tile the sum of squares of x (M, K) -> fp32 (M, K / 16): the statistics a normalising
+    W4 launch takes through row_ss= instead of walking the rows again (zl_w4_opts_t::row_ss)"""
+    _chk_cuda(x, out)
+    if x.dtype != torch.float16 or x.dim() != 2 or x.shape[1] % 16:
+        raise ZLError("row_ss: fp16 (M, K), K a multiple of 16")
+    m, k = x.shape
+    if out is None:
+        out = torch.empty((m, k // 16), dtype=torch.float32, device=x.device)
+    check(lib().zl_row_ss(_p(x), _i(x.stride(0)), _i(m), _i(k), _p(out), _stream()), "row_ss")
+    return out
+
+
+def w4_row_ss_routes(m, w_producers, w_consumers, device):
+    """does every producing projection (plain / residual epilogue) leave the rows' statistics and every normalising one take them?
+    (the route questions of zl_w4a16_gemm_mfma_ex, asked without launching; consumers: (weight, rope) pairs)"""
+    dummy = C.c_void_p(16)
+    for w in w_producers:
+        o = _w4_opts(device, m, w.n)
+        o.row_ss_out = dummy
+        if not isinstance(w, W4MWeight) or not lib().zl_w4a16_emits_row_ss(_i(m), _i(w.n), _i(w.k), _i(w.group_size), C.c_int(EPI_RESIDUAL), C.byref(o)):
+            return False
+    for w, rope in w_consumers:
+        o = _w4_opts(device, m, w.n)
+        o.row_ss = dummy
+        if not isinstance(w, W4MWeight) or not lib().zl_w4a16_takes_row_ss(_i(m), _i(w.n), _i(w.k), _i(w.group_size), C.c_int(int(rope)), C.byref(o)):
+            return False
+    return True
+
+
+def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, norm_eps=1e-5, epilogue=0, row_ss=None, row_ss_out=None):
+    """MFMA flavour of w4a16_gemm (fp32 accumulation = the numerics of the reference's M > 40 branch).
+    row_ss (M, K / 16) fp32 with norm_weight: the rows' statistics (ops.row_ss or a producing launch's row_ss_out);
+    row_ss_out (M, N / 16): filled with the statistics of the rows this launch stores where its route does that (w4_row_ss_routes)."""
     if x.dtype != torch.float16:
         raise ZLError("A must be half")
     _chk_cuda(x, bias, residual, norm_weight)
@@ -406,6 +438,11 @@ def w4a16_gemm_mfma(x, w, bias=None, residual=None, out=None, norm_weight=None, 
     if bias is not None:
         epilogue |= EPI_BIAS
     opts = _w4_opts(x.device, m, w.n)
+    _chk_cuda(row_ss, row_ss_out)
+    if row_ss is not None:
+        opts.row_ss = row_ss.data_ptr()
+    if row_ss_out is not None:
+        opts.row_ss_out = row_ss_out.data_ptr()
     check(lib().zl_w4a16_gemm_mfma_ex(_p(x2), _i(x2.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(residual),
                                       _p(out), _i(m), _i(w.n), _i(k), _i(w.group_size), _p(norm_weight), _f(norm_eps),
                                       C.c_int(epilogue), C.byref(opts), _stream()), "w4a16_gemm_mfma")
@@ -863,7 +900,7 @@ def w4_qkv_rope_scatter_ok(m, k, dim_head, norm):
 
 
 def w4_qkv_rope_scatter(x, w, cos, sin, placement, buf_lens, k_addrs, v_addrs, num_heads, num_kv_heads, dim_head, bias=None,
-                        norm_weight=None, norm_eps=1e-5, bshd=True, q_out=None):
+                        norm_weight=None, norm_eps=1e-5, bshd=True, q_out=None, row_ss=None):
     """fused qkv projection (W4MWeight w, (H + 2 Hkv) D rows) + neox rotary + KV scatter for decode rows; returns the
     rotated q (M, H*D).  Bit-identical to w4_linear(..) followed by rope_scatter_decode(..)."""
     _chk_cuda(x, cos, sin, placement, buf_lens, k_addrs, v_addrs, bias, norm_weight)
@@ -873,6 +910,9 @@ def w4_qkv_rope_scatter(x, w, cos, sin, placement, buf_lens, k_addrs, v_addrs, n
     if q_out is None:
         q_out = torch.empty((m, num_heads * dim_head), dtype=x.dtype, device=x.device)
     opts = _w4_opts(x.device, m, w.n)
+    if row_ss is not None:
+        _chk_cuda(row_ss)
+        opts.row_ss = row_ss.data_ptr()
     check(lib().zl_w4a16_qkv_rope_scatter_ex(_p(x), _i(x.stride(0)), _p(w.qw), _p(w.meta), _p(bias), _p(norm_weight),
                                              _f(norm_eps), _p(cos), _p(sin), _p(placement), _p(buf_lens), _p(k_addrs),
                                              _p(v_addrs), _p(q_out), _i(m), _i(num_heads), _i(num_kv_heads), _i(dim_head),
