@@ -39,7 +39,12 @@ __device__ __forceinline__ f4 mfma16(uint4 a, uint4 b, f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
 }
 
-template <int DT, int BM>
+// NS: weight ring slots = chunks in flight per wave (2 KiB each).  Round 6 measured 4 instead of 2 on the decode batches' lm_head
+// (1.05 GB, a pure weight stream at 5.0 TB/s: 208 / 227 us at 8 / 32 rows against 158 for the one-row GEMV): SLOWER, 228 / 250 us
+// (tools/ubench/bench_lm_head.py, profiles/r06_lm_head_ring_depth.txt) -- bytes in flight are not what holds it back; a lane's
+// 16-byte load is a quarter of a 64-byte run per row (16 rows per instruction, every 128-byte line touched by two instructions),
+// which is what the MFMA B layout asks for and what a row-contiguous loader (LDS-DMA, the slab kernel's x path) would not do.  2.
+template <int DT, int BM, int NS = 2>
 __global__ __launch_bounds__(kDT, 2) void k_dense_gemm(const DenseGemmParams p) {
     constexpr int RB = BM / 16, XR = BM / 16;
     __shared__ __attribute__((aligned(16))) uint16_t xs[2][BM * kDRow];
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(kDT, 2) void k_dense_gemm(const DenseGemmParams p) 
         const int n = n_base + 16 * j + nrow;
         nr[j] = n < p.n ? n : p.n - 1;
     }
-    uint4 wf[2][2][4];                       // [ring slot][tile][t]
+    uint4 wf[NS][2][4];                      // [ring slot][tile][t]
     auto load_w = [&](int slot, int g) {
         const int gc = g < G ? g : G - 1;
 #pragma unroll
@@ -86,8 +91,8 @@ __global__ __launch_bounds__(kDT, 2) void k_dense_gemm(const DenseGemmParams p) 
     };
 
     load_x(0);
-    load_w(0, 0);
-    load_w(1, 1);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) load_w(u, u);
     store_x(0);
     load_x(1);
     __syncthreads();
@@ -101,11 +106,11 @@ __global__ __launch_bounds__(kDT, 2) void k_dense_gemm(const DenseGemmParams p) 
 
     int g = 0;
 #pragma unroll 1
-    for (; g < G; g += 2) {
+    for (; g < G; g += NS) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (g + u < G) {                 // workgroup-uniform; g even: chunk parity = u
-                const uint16_t* xb = &xs[u][nrow * kDRow + kq * 8];
+        for (int u = 0; u < NS; ++u) {
+            if (g + u < G) {                 // workgroup-uniform; g a multiple of NS (even): chunk parity = u & 1
+                const uint16_t* xb = &xs[u & 1][nrow * kDRow + kq * 8];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -115,8 +120,8 @@ __global__ __launch_bounds__(kDT, 2) void k_dense_gemm(const DenseGemmParams p) 
                         acc[rb][1] = mfma16<DT>(a, wf[u][1][t], acc[rb][1]);
                     }
                 }
-                load_w(u, g + u + 2);        // the slot just consumed <- two chunks ahead
-                store_x(u ^ 1);
+                load_w(u, g + u + NS);       // the slot just consumed <- NS chunks ahead
+                store_x((u & 1) ^ 1);
                 load_x(g + u + 2);
                 __syncthreads();
             }
@@ -153,9 +158,12 @@ extern "C" int zl_gemm_nt(const uint16_t* x, int64_t ldx, const uint16_t* w, con
     const int bm = m <= 16 ? 16 : (m <= 32 ? 32 : 64);
     ZL_CHECK_ARG((m + bm - 1) / bm <= 65535, ZL_ELIMIT);
     const dim3 grid(gx, (unsigned)((m + bm - 1) / bm));
+#ifndef ZL_DENSE_NS
+#define ZL_DENSE_NS 2        // (tools/ubench/variant.sh ... -DZL_DENSE_NS=4 rebuilds the deeper ring for A/B runs)
+#endif
 #define ZL_DG(DT)                                                                              \
-    if (bm == 16) hipLaunchKernelGGL((k_dense_gemm<DT, 16>), grid, dim3(kDT), 0, hs, p);       \
-    else if (bm == 32) hipLaunchKernelGGL((k_dense_gemm<DT, 32>), grid, dim3(kDT), 0, hs, p);  \
+    if (bm == 16) hipLaunchKernelGGL((k_dense_gemm<DT, 16, ZL_DENSE_NS>), grid, dim3(kDT), 0, hs, p);       \
+    else if (bm == 32) hipLaunchKernelGGL((k_dense_gemm<DT, 32, ZL_DENSE_NS>), grid, dim3(kDT), 0, hs, p);  \
     else hipLaunchKernelGGL((k_dense_gemm<DT, 64>), grid, dim3(kDT), 0, hs, p);
     if (dtype == ZL_F16) { ZL_DG(ZL_F16) } else { ZL_DG(ZL_BF16) }
 #undef ZL_DG

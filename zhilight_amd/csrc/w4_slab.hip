@@ -204,6 +204,28 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
             }
         }
     }
+    // ---- NORM: rs = rsqrt_rn(sum x^2 / K + eps) per row, through LDS to the lanes that hold the row's fragments
+    float rs[MB];
+    auto compute_rs = [&]() {
+      if constexpr (NORM) {
+        float* rsl = reinterpret_cast<float*>(smem + (size_t)nw * (XS * kSet) + (size_t)nw * 1024);
+#pragma unroll
+        for (int ps = 0; ps < kSP; ++ps) {
+            float t = 0.f;
+#pragma unroll
+            for (int u = 0; u < kSU; ++u) t += (sst[ps][u][0] + sst[ps][u][1]) + (sst[ps][u][2] + sst[ps][u][3]);
+            t = zl_sum16(t);
+            const int row = (ps * nw + wave) * 4 + (lane >> 4);
+            if ((lane & 15) == 0 && row < 16 * MB) rsl[row] = zl_rsqrt_rn(t / (float)p.k + p.eps);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (not __syncthreads: its fence would drain the weight ring)
+#pragma unroll
+        for (int b = 0; b < MB; ++b) rs[b] = rsl[16 * b + nrow];
+    }
+    };
+#ifdef ZL_SLAB_STATS_FIRST
+    compute_rs();                                     // (A/B: the barrier at entry, before anything else is requested)
+#endif
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, p.x_bytes, 0x00020000);
     unsigned char* xw = smem + (size_t)wave * (XS * kSet);
     // DMA lane -> (row 4 i + (lane >> 4), position lane & 15): rows past M re-read the last row (their outputs are never
@@ -275,23 +297,9 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
     wq[D - 1] = make_uint4(0, 0, 0, 0);
     ZL_SPROBE(1);                                     // prologue requested
 
-    // ---- NORM: rs = rsqrt_rn(sum x^2 / K + eps) per row, through LDS to the lanes that hold the row's fragments
-    float rs[MB];
-    if constexpr (NORM) {
-        float* rsl = reinterpret_cast<float*>(smem + (size_t)nw * (XS * kSet) + (size_t)nw * 1024);
-#pragma unroll
-        for (int ps = 0; ps < kSP; ++ps) {
-            float t = 0.f;
-#pragma unroll
-            for (int u = 0; u < kSU; ++u) t += (sst[ps][u][0] + sst[ps][u][1]) + (sst[ps][u][2] + sst[ps][u][3]);
-            t = zl_sum16(t);
-            const int row = (ps * nw + wave) * 4 + (lane >> 4);
-            if ((lane & 15) == 0 && row < 16 * MB) rsl[row] = zl_rsqrt_rn(t / (float)p.k + p.eps);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (not __syncthreads: its fence would drain the weight ring)
-#pragma unroll
-        for (int b = 0; b < MB; ++b) rs[b] = rsl[16 * b + nrow];
-    }
+#ifndef ZL_SLAB_STATS_FIRST
+    compute_rs();
+#endif
 
     const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(0x000f000fu);
     const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(0x00f000f0u);
