@@ -69,8 +69,12 @@ def fixture_main(case):
         state = {k: z[k] for k in z.files}
     cfg, sd, _ = hf_tensors(case)
     g = 128
+    dense = cfg.dtype == "bfloat16"                     # the MiniCPM case: unquantised bf16, tied lm_head
     # the fixture IS the synthetic checkpoint under the reference's names: tie it to the tensors the oracle model is built from
-    mine = {k.replace("m.", "llama.", 1): v for k, v in _reference_names_state(sd).items()}
+    named = dict(sd, **{"lm_head.weight": sd["model.embed_tokens.weight"]}) if dense else sd
+    mine = {k.replace("m.", "llama.", 1): v for k, v in _reference_names_state(named).items()}
+    if dense:
+        del mine["llama.lm_head.weight"]
     out["names_match"] = sorted(mine) == sorted(state)
     out["tensors_match"] = out["names_match"] and all(np.array_equal(np.asarray(mine[k]).view(np.uint8), state[k].view(np.uint8)) for k in mine)
     mc = C.ModelConfig(config)
@@ -113,6 +117,30 @@ def fixture_main(case):
             w_kn = oracle.gptq_reconstruct(sd[key].view(np.uint32), zp1, sd[base + ".scales"].view(np.uint16), sd[base + ".g_idx"])
             w16[base] = np.ascontiguousarray(w_kn.T)
     n_new = meta["search_task_args"][1]
+    if dense:
+        # the oracle: the CPU dense model (bf16 rounding points, MiniCPM scalings) fed the prompt token by token, then its own picks
+        from test_gpu_model import OracleDenseModel
+        om = OracleDenseModel(oracle, cfg, sd, 1, 128, 1)
+        logits = None
+        for i, tok in enumerate(prompt):
+            logits = om.step(np.array([tok], np.int32), [i])
+        want, margins = [], []
+        for step in range(n_new):
+            row = np.asarray(logits[0], np.float64).copy()
+            if step == 0:
+                row[meta["dyn_batch_config"]["bos_id"]] = row[meta["dyn_batch_config"]["eos_id"]] = -50000
+            order = np.argsort(-row, kind="stable")
+            want.append(int(order[0]))
+            margins.append(float(row[order[0]] - row[order[1]]) / float(np.abs(row).max()))
+            if step + 1 < n_new:
+                logits = om.step(np.array([want[-1]], np.int32), [len(prompt) + step])
+        out["greedy"] = {"got": list(r1[3][0][0]) if r1 and r1[3] else None, "oracle": want, "margins": margins,
+                         "first_token_delay_ms": r1[3][0][3] if r1 and r1[3] else None}
+        out["env"] = meta["env"]
+        print("BINDING_RESULT " + json.dumps(out), flush=True)
+        gen.stop()
+        th.join(timeout=10)
+        os._exit(0)
     om = OracleModel(oracle, cfg, om_sd, g, 1, 128)
     om.rope_kind = "plain"
     if w16 is not None:

@@ -47,7 +47,7 @@ def test_reference_binding_generates_the_oracles_greedy_tokens(binding):
     assert g["first_token_delay_ms"] is not None and g["first_token_delay_ms"] > 0
 
 
-@pytest.mark.parametrize("case", ["llama_gptq", "llama_gptq_desc_act"])
+@pytest.mark.parametrize("case", ["llama_gptq", "llama_gptq_desc_act", "minicpm_bf16"])
 def test_binding_fed_by_the_reference_python_layer(dev, case):
     """VERDICT r05 item 3, the GPU half (the CPU half: tests/test_host_logic.py::test_python_layer_fixture_*): `zhilight.C` driven
     with exactly what the reference's OWN Python layer -- zhilight/llama.py, loader.py, quant.py, dynamic_batch.py, imported against
@@ -74,7 +74,7 @@ def test_binding_fed_by_the_reference_python_layer(dev, case):
     got = g["got"][-len(g["oracle"]):]
     decided = 0
     for m in g["margins"]:
-        if m <= 2e-3:
+        if m <= (4e-2 if case == "minicpm_bf16" else 2e-3):      # bf16 carries 8 mantissa bits through every rounding point: 2e-2 logit bar
             break
         decided += 1
     assert got[:decided] == g["oracle"][:decided], g

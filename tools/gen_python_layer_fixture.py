@@ -37,6 +37,9 @@ CASES = {
     "llama_gptq": dict(seed=5, layers=2, dim=256, heads=2, kv_heads=1, dim_head=128, ff=512, vocab=256, desc_act=False),
     # the same checkpoint format with desc_act: zhilight/quant.py:73-76 switches the GPTQ_KERNEL_ALGO=0 route on
     "llama_gptq_desc_act": dict(seed=6, layers=2, dim=256, heads=2, kv_heads=1, dim_head=128, ff=512, vocab=256, desc_act=True),
+    # BASELINE configs[0] in miniature: MiniCPM ("cpm_dragonfly": scale_emb, scale_depth residuals, dim_model_base logit scaling, tied
+    # lm_head, 64-wide heads), unquantised bf16 -- the checkpoint in the model family's own config keys, bf16 tensors in the safetensors
+    "minicpm_bf16": dict(seed=7, layers=2, dim=256, heads=4, kv_heads=4, dim_head=64, ff=512, vocab=256, desc_act=False, minicpm=True),
 }
 
 
@@ -60,6 +63,22 @@ def hf_tensors(case):
     from test_gpu_model import _hf_state
     from zhilight_amd.llama import ModelConfig
     c = CASES[case]
+    if c.get("minicpm"):
+        from test_gpu_model import _dense_state
+        cfg = ModelConfig(num_layers=c["layers"], dim_model=c["dim"], num_heads=c["heads"], dim_head=c["dim_head"], dim_ff=c["ff"],
+                          vocab_size=c["vocab"], num_kv_heads=c["kv_heads"], eps=1e-5, rope_theta=1e4, dtype="bfloat16", scale_emb=12.0,
+                          scale_depth=1.4, dim_model_base=256, tie_lm_head=True)
+        rng = np.random.default_rng(c["seed"])
+        sd32 = _dense_state(rng, cfg)
+        sd32["model.embed_tokens.weight"] = (sd32["model.embed_tokens.weight"].astype(np.float32) * 0.08).astype(np.float16)
+        del sd32["lm_head.weight"]                      # tied: the checkpoint has none
+        import oracle.zl_oracle as zo
+        sd = {k: zo.f32_to_bf16(v.astype(np.float32)) for k, v in sd32.items()}          # bf16 bit patterns (uint16)
+        native = {"model_type": "cpm_dragonfly", "num_layers": c["layers"], "dim_model": c["dim"], "num_heads": c["heads"],
+                  "num_kv_heads": c["kv_heads"], "dim_head": c["dim_head"], "dim_ff": c["ff"], "vocab_size": c["vocab"], "eps": 1e-5,
+                  "rope_theta": 1e4, "scale_emb": 12.0, "scale_depth": 1.4, "dim_model_base": 256, "_dtype": "bf16",
+                  "activate_fn": "silu", "max_token": 2048, "bos_token_id": 2, "eos_token_id": 1}
+        return cfg, sd, native
     cfg = ModelConfig(num_layers=c["layers"], dim_model=c["dim"], num_heads=c["heads"], dim_head=c["dim_head"], dim_ff=c["ff"],
                       vocab_size=c["vocab"], num_kv_heads=c["kv_heads"], eps=1e-5, rope_theta=5e5)
     rng = np.random.default_rng(c["seed"])
@@ -86,6 +105,12 @@ def hf_checkpoint(case, directory):
     _, sd, hf_cfg = hf_tensors(case)
     with open(os.path.join(directory, "config.json"), "w") as fh:
         json.dump(hf_cfg, fh)
+    if CASES[case].get("minicpm"):                     # bf16 tensors: numpy has no such dtype, the torch writer does
+        import torch
+        from safetensors.torch import save_file as save_torch
+        save_torch({k: torch.from_numpy(np.ascontiguousarray(v).view(np.int16)).view(torch.bfloat16) for k, v in sd.items()},
+                   os.path.join(directory, "model.safetensors"))
+        return hf_cfg, sd
     save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, os.path.join(directory, "model.safetensors"))
     return hf_cfg, sd
 
