@@ -47,6 +47,18 @@ def test_reference_binding_generates_the_oracles_greedy_tokens(binding):
     assert g["first_token_delay_ms"] is not None and g["first_token_delay_ms"] > 0
 
 
+def test_reference_binding_sampling_is_seeded(binding):
+    """top_p / temperature sampling through the reference's scheduler (one task at a time: beyond that the reference's own assertion at
+    batch_generator.cpp:751 ends the scheduler thread, see tests/_binding_worker.py): the same seed draws the same continuation, every
+    token is a vocabulary index, and the task completes with the requested length."""
+    sm = binding.get("sampling")
+    assert sm and all(d is not None for d in sm["draws"]), binding
+    a, b, c = sm["draws"]
+    assert a[-6:] == b[-6:], sm
+    assert all(0 <= t < sm["vocab"] for d in (a, b, c) for t in d), sm
+    assert len(a) >= 6 and len(c) >= 6
+
+
 @pytest.mark.parametrize("case", ["llama_gptq", "llama_gptq_desc_act", "minicpm_bf16"])
 def test_binding_fed_by_the_reference_python_layer(dev, case):
     """VERDICT r05 item 3, the GPU half (the CPU half: tests/test_host_logic.py::test_python_layer_fixture_*): `zhilight.C` driven
