@@ -1187,6 +1187,101 @@ def test_reference_deepseek_child(ref, oracle):
     ref.weight_cache_clear()
 
 
+def test_reference_deepseek_v3_shaped_logits_four_layers(dev):
+    """one DeepSeek-shaped LOGIT record -- four distinct config-5 layers of the reference's own code (MLA over
+    Fp8Block linears + FP8BlockMOE) chained, final RMSNorm, bf16 lm_head -- so that north_star's metric is on file for this
+    configuration too (profiles/r06_deepseek_logits.json).  Child process for the same reason as the layer test."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LATENT_CACHE="1", FUSE_ATTN_SEARCH="1", GROUPED_FP8_GEMM="1", MOE_EXP_PARALLEL="1", ZL_REFDSL_CHILD="1")
+    code = ("import sys, os; sys.path.insert(0, os.path.join(%r, 'tests')); import pytest; "
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', os.path.join(%r, 'tests', 'test_gpu_refcompile.py'), '-k', 'deepseek_logits_child']))") % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(os.environ.get("ZL_REFDSL_CHILD") != "1", reason="runs inside test_reference_deepseek_v3_shaped_logits_four_layers' child process")
+def test_reference_deepseek_logits_child(ref, oracle, dev):
+    """Three decode tasks (ragged compressed caches per layer), one step through four layers + norm + a 2048-row lm_head, against
+    the chained _DeepSeekLayerOracle.  north_star's 1e-3 logit bar is a statement about fp16 / int4 arithmetic; a pipeline that
+    re-quantises every activation to e4m3 with a per-128 amax cannot hold it against ITSELF: moving 3 % / 15 % of every Fp8Block
+    output of the ORACLE by one bf16 ulp (what any correct fp8 GEMM does against the exact sum) moves the final hidden state by
+    6.8e-2 of its rms after four layers (measured below, on the same draw, and recorded).  Asserted: the implementation's logits no
+    further from the oracle's than 1.5 x that floor (rms) and every routing decision far from a tie; the numbers go to
+    gpurun_out/deepseek_logits.json."""
+    import json
+    import torch
+    from test_oracle_deepseek_layer import _OneUlpNoise
+    from zhilight_amd import ops
+    rng = np.random.default_rng(43)             # (a draw whose 4 x 3 routing margins all exceed 0.4 logit units)
+    dm, H, ql, kvl, nope, rp, vd, e, k, shared, inter = _DS_DIMS
+    dims = (dm, H, ql, kvl, nope, rp, vd, e, k, shared)
+    theta, eps, L, vocab = 1e4, 1e-6, 4, 2048
+    cases = [_deepseek_case(oracle, rng, _DS_DIMS) for _ in range(L)]
+    lens, bufs = [37, 150, 5], [64, 192, 64]
+    B = len(lens)
+    hists = [[oracle.f32_to_bf16((rng.standard_normal((n, kvl + rp)) * 0.5).astype(np.float32)) for n in lens] for _ in range(L)]
+    x = oracle.f32_to_bf16(synth.act(rng, B, dm).astype(np.float32))
+    ln_out = oracle.f32_to_bf16((1.0 + 0.1 * rng.standard_normal(dm)).astype(np.float32))
+    head = oracle.f32_to_bf16((rng.standard_normal((vocab, dm)) * 0.05).astype(np.float32))
+    pos = np.array(lens, np.int32)
+    f = lambda bits: oracle.bf16_to_f32(bits).astype(np.float64)
+
+    def oracle_logits(cls, frac=0.0):
+        h, margins = x, []
+        for li in range(L):
+            om = cls(oracle, cases[li][0], dims, theta, eps)
+            if frac:
+                om.frac, om.prng = frac, np.random.default_rng(99 + li)
+            h, _, m = om.step(h, pos, hists[li])
+            margins.append(m)
+        xn = oracle.rmsnorm(h, ln_out, eps, dtype=1)
+        return f(h), oracle.gemm_nt(xn, head, None, 1.0, 1, exact=True).astype(np.float64), margins
+
+    hid_ref, logit_ref, margins = oracle_logits(_DeepSeekLayerOracle)
+    assert min(margins) > 0.3, margins
+    floors = {}
+    for frac in (0.03, 0.15):
+        hid_n, logit_n, m_n = oracle_logits(_OneUlpNoise, frac)
+        floors[frac] = {"hidden_rms": float(np.sqrt(((hid_n - hid_ref) ** 2).mean()) / np.sqrt((hid_ref ** 2).mean())),
+                        "logits_rms": float(np.sqrt(((logit_n - logit_ref) ** 2).mean()) / np.sqrt((logit_ref ** 2).mean())),
+                        "logits_max_over_max": float(np.abs(logit_n - logit_ref).max() / np.abs(logit_ref).max()), "min_margin": float(min(m_n))}
+    # the implementation: the reference's EncoderLayer x 4 on the boundary, then the boundary's own norm + dense GEMM
+    mask = np.concatenate([(np.arange(bufs[b]) <= pos[b]).astype(np.int8) for b in range(B)])
+    h = x
+    for li in range(L):
+        layer = ref.RefEncoderLayer(dm, H, H, nope + rp, 1024, rope_theta=theta, eps=eps, quant_type=10, model_type="deepseek_v2", mla=[ql, kvl, nope, rp, vd],
+                                    moe=[e, k, inter, shared], norm_topk_prob=True, routed_scaling_factor=1.0, bf16=True)
+        layer.load(cases[li][1], "l")
+        for b in range(B):
+            layer.set_history(b, bufs[b], np.ascontiguousarray(hists[li][b].reshape(lens[b], 1, kvl + rp).view(np.int16)), np.zeros((0,), np.int16))
+        h = layer.decode_step(np.ascontiguousarray(h.view(np.int16)), pos, pos.copy(), mask).view(np.uint16)
+        del layer
+        ref.weight_cache_clear()
+    ht = torch.from_numpy(np.ascontiguousarray(h).view(np.int16)).to(dev).view(torch.bfloat16)
+    xn = ops.rmsnorm(ht, torch.from_numpy(ln_out.view(np.int16)).to(dev).view(torch.bfloat16), eps)
+    logits = ops.gemm_nt(xn, torch.from_numpy(head.view(np.int16)).to(dev).view(torch.bfloat16)).float().cpu().numpy().astype(np.float64)
+    hid = f(h)
+    rec = {"what": "DeepSeek-V3-shaped stack: 4 layers (MLA over Fp8Block linears + FP8 MoE, 8 experts top 2 + shared) + RMSNorm + 2048 x 1024 bf16 lm_head, "
+                   "3 decode tasks with 37 / 150 / 5 cached latent rows per layer; implementation = the reference's EncoderLayer on the boundary",
+           "logits_rms_err_over_rms": float(np.sqrt(((logits - logit_ref) ** 2).mean()) / np.sqrt((logit_ref ** 2).mean())),
+           "logits_max_err_over_max": float(np.abs(logits - logit_ref).max() / np.abs(logit_ref).max()),
+           "hidden_rms_err_over_rms": float(np.sqrt(((hid - hid_ref) ** 2).mean()) / np.sqrt((hid_ref ** 2).mean())),
+           "greedy_token_agrees": [bool(a == b) for a, b in zip(logits.argmax(axis=1), logit_ref.argmax(axis=1))],
+           "oracle_top1_top2_margin_over_max": [float((np.sort(r)[-1] - np.sort(r)[-2]) / np.abs(logit_ref).max()) for r in logit_ref],
+           "router_margins": margins, "oracle_one_ulp_floor": {str(k_): v for k_, v in floors.items()},
+           "north_star_bar": "1e-3 of the largest logit: not attainable by ANY implementation of this fp8 pipeline against another (floor above)"}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "deepseek_logits.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    floor = max(v["logits_rms"] for v in floors.values())
+    assert np.isfinite(logits).all()
+    assert rec["logits_rms_err_over_rms"] <= 1.5 * floor, rec
+    assert rec["hidden_rms_err_over_rms"] <= 1.5 * max(v["hidden_rms"] for v in floors.values()), rec
+
+
 def test_reference_deepseek_v3_shaped_layer_sharded_two_ranks(dev):
     """Config 5's SHARDING on one device (VERDICT r04 missing 1a / 1c): the same DeepSeek-V3-shaped layer at world size 2 on the
     engine -- ATTN_DATA_PARALLEL=1: MLAImpl::forward_compressed_dp_v1 (multi_head_latent_attention.cpp:1097-1232: replicated
