@@ -180,7 +180,17 @@ __global__ __launch_bounds__(256) void k_mla_decode_mfma(const MlaParams p) {
     const int r = lane & 15, kq = lane >> 4;
     const int len = p.valid_lens ? min(p.buf_lens[b], p.valid_lens[b]) : p.buf_lens[b];
     const int t0 = split * p.split_len, t1 = min(len, t0 + p.split_len);
-    if (t0 >= len) return;                                                // (workgroup-uniform) the combine skips unwritten splits
+    if (t0 >= len) {                                                      // (workgroup-uniform) the combine skips unwritten splits
+        if (p.max_splits == 1) {                                          // ... and without a combine launch a task without keys gets its
+            for (int j = 0; j < 4; ++j) {                                 // zero rows (and lse = -inf) here, as k_mla_combine leaves them
+                const int head = hg * kHG + wave * 4 + j;
+                if (head >= p.h) break;
+                *reinterpret_cast<uint4*>(p.out + ((size_t)b * p.h + head) * kRank + lane * 8) = make_uint4(0, 0, 0, 0);
+                if (p.lse && lane == 0) p.lse[(size_t)b * p.h + head] = -INFINITY;
+            }
+        }
+        return;
+    }
     const int last_key = t1 - 1;
     const uint16_t* kv = p.block_table ? nullptr : p.kv_bufs[b];
 
@@ -333,6 +343,21 @@ __global__ __launch_bounds__(256) void k_mla_decode_mfma(const MlaParams p) {
                 a0[e] = __builtin_fmaf(x0[e], f[w], a0[e]);
                 a1[e] = __builtin_fmaf(x1[e], f[w], a1[e]);
             }
+        }
+        if (p.max_splits == 1) {
+            // ONE split per (task, head) -- batch 32 x 1024 keys: 256 workgroups without any -- needs no record and no combine launch:
+            // what k_mla_combine makes of a single record (weight e^0 = 1: the sums are the record's own), written here.  Round 6:
+            // 8.4 MB of records out and in again + 4 096 64-lane workgroups for nothing
+            const float inv = 1.0f / (lt + 1e-20f);
+            if (p.lse && lane == 0) p.lse[(size_t)b * p.h + head] = mn + logf(lt);
+            uint32_t w4[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                w4[e] = (uint32_t)ZT<DT>::from_f32(a0[2 * e] * inv) | ((uint32_t)ZT<DT>::from_f32(a0[2 * e + 1] * inv) << 16);
+                w4[2 + e] = (uint32_t)ZT<DT>::from_f32(a1[2 * e] * inv) | ((uint32_t)ZT<DT>::from_f32(a1[2 * e + 1] * inv) << 16);
+            }
+            *reinterpret_cast<uint4*>(p.out + ((size_t)b * p.h + head) * kRank + lane * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            continue;
         }
         float* rec = p.ws + (((size_t)b * p.h + head) * p.max_splits + split) * kRec;
         *reinterpret_cast<float4*>(rec + lane * 8) = make_float4(a0[0], a0[1], a0[2], a0[3]);
@@ -650,6 +675,7 @@ int mla_launch(const MlaParams& p, int dtype, int algo, hipStream_t hs) {
     }
     int e = zl_launch_status();
     if (e) return e;
+    if (algo == 0 && p.max_splits == 1) return 0;      // the matrix-core kernel wrote the rows itself (tasks without a visible key: below)
     if (dtype == ZL_F16) hipLaunchKernelGGL(k_mla_combine<ZL_F16>, dim3((unsigned)h, (unsigned)b), dim3(64), 0, hs, p);
     else hipLaunchKernelGGL(k_mla_combine<ZL_BF16>, dim3((unsigned)h, (unsigned)b), dim3(64), 0, hs, p);
     return zl_launch_status();
