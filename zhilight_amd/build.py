@@ -211,6 +211,17 @@ def build_host(force=False, verbose=False):
     container); the GPU box uses the prebuilt file.  _ref/ is git-ignored (it holds compiled reference code) but travels with
     gpurun snapshots.  Returns the path, or None without a reference."""
     target = host_target()
+    if target in _HOST_BUILT:                           # once per process: build_refcompile and build_binding both ask (ADVICE r05: a
+        return _HOST_BUILT[target]                      # forced build compiled every reference unit twice)
+    _HOST_BUILT[target] = _build_host(force, verbose)
+    return _HOST_BUILT[target]
+
+
+_HOST_BUILT = {}
+
+
+def _build_host(force, verbose):
+    target = host_target()
     tus = [os.path.join(REFERENCE, t) for t in REF_TUS]
     if not all(os.path.exists(t) for t in tus):
         return target if os.path.exists(target) else None

@@ -702,7 +702,10 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
         float a[4] = {0.f, 0.f, 0.f, 0.f}, lt = 0.f;
         for (int w = 0; w < nw; ++w) {
             const float f = __expf(src[w * WS + kMD] - mn);
-            const f4v v = *reinterpret_cast<const f4v*>(src + w * WS + d0);
+            // (two 8-byte reads: a row is kMD + 2 = 130 floats, so odd rows start 8 bytes off a 16-byte boundary -- ADVICE r05)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            const f2v v01 = *reinterpret_cast<const f2v*>(src + w * WS + d0), v23 = *reinterpret_cast<const f2v*>(src + w * WS + d0 + 2);
+            const f4v v = (f4v){v01[0], v01[1], v23[0], v23[1]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(v[e], f, a[e]);
             lt = __builtin_fmaf(src[w * WS + kMD + 1], f, lt);
@@ -741,6 +744,11 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
     }
     if (direct) return;
     // ---- arrival.  The stores above are write-through; once vmcnt is zero they are where an sc1 load of any CU finds them.
+    //      (gfx9-family reasoning -- stores counted by vmcnt, sc1 = write-through to the level every CU reads with sc1 -- not the
+    //      HIP memory model's: relaxed agent-scope atomics carry the data, the drain orders it.  Pinned to the target below.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "attn_tail_la's hand-off is written for gfx950 (vmcnt-tracked write-through stores); revisit it for any other target"
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // ... for every wave of the workgroup; xw is free from here on
     ZL_APROBE(5);

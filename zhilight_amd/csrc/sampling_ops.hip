@@ -110,15 +110,34 @@ __global__ __launch_bounds__(kThreads) void k_topk_rows(const typename ET<TY>::t
     for (int t = 0; t < top; ++t) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-        for (int64_t i = threadIdx.x; i < n; i += kThreads) {
-            const float v = ET<TY>::ld(x, off + i);
-            if (!(v == v)) continue;                                     // NaN never wins
-            const bool after_prev = prev_i < 0 || v < prev_v || (v == prev_v && (int)i > prev_i);
-            if (after_prev && (v > bv || (v == bv && (int)i < bi))) {
+        auto consider = [&](float v, int i) {
+            if (!(v == v)) return;                                       // NaN never wins
+            const bool after_prev = prev_i < 0 || v < prev_v || (v == prev_v && i > prev_i);
+            if (after_prev && (v > bv || (v == bv && i < bi))) {
                 bv = v;
-                bi = (int)i;
+                bi = i;
+            }
+        };
+        int64_t i0 = 0;
+        if constexpr (sizeof(typename ET<TY>::type) == 2) {
+            // 16-byte loads where the row allows it (the pick is a maximum under a total order: any visiting order gives the same
+            // element); ADVICE r05: 2-byte loads made a 128 K-entry row ~500 dependent loads per thread and pass
+            if ((reinterpret_cast<uintptr_t>(x + off) & 15) == 0) {
+                const uint4* row = reinterpret_cast<const uint4*>(x + off);
+                const int64_t nv = n / 8;
+                for (int64_t j = threadIdx.x; j < nv; j += kThreads) {
+                    const uint4 u = row[j];
+                    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint16_t h = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+                        consider(ET<TY>::ld(&h, 0), (int)(j * 8 + e));
+                    }
+                }
+                i0 = nv * 8;
             }
         }
+        for (int64_t i = i0 + threadIdx.x; i < n; i += kThreads) consider(ET<TY>::ld(x, off + i), (int)i);
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o, 64);
             const int oi = __shfl_xor(bi, o, 64);

@@ -8,6 +8,7 @@
 #include <cmath>
 
 #include "bm_c10d.h"
+#include "bm_functions.h"
 #include "host_common.h"
 #include "nn/embedding/embedding.h"
 
@@ -56,15 +57,26 @@ void RawEmbedding::load_state_dict(const core::Context& ctx, const std::map<std:
     auto it = state_dict.find(prefix + ".weight");
     BM_ASSERT(it != state_dict.end(), "Weight not found: " + prefix + ".weight");
     const core::Tensor& src = it->second;
-    BM_ASSERT(src.ndim() == 2 && src.size(0) == vocab && src.size(1) == dim && core::get_elem_size(src.dtype()) == 2,
-              "RawEmbedding: (vocab, dim_model) weight of 16-bit elements");
+    BM_ASSERT(src.ndim() == 2 && src.size(0) == vocab && src.size(1) == dim, "RawEmbedding: (vocab, dim_model) weight");
+    BM_ASSERT(src.dtype() == DataType::kHalf || src.dtype() == DataType::kBFloat16 || src.dtype() == DataType::kFloat,
+              "RawEmbedding: half, bfloat16 or float weight");
     pimpl->weight = ctx.tensor({part, dim}, pimpl->dtype);
     hipStream_t st = ctx.current_cuda_stream();
     BM_CUDART_ASSERT(hipMemsetAsync(pimpl->weight.data(), 0, pimpl->weight.nbytes(), st));
     const size_t first = (size_t)pimpl->begin, last = std::min((size_t)pimpl->end, vocab);
     if (first < last) {
         const core::Tensor rows = src.slice_dim0(first, last);
-        BM_CUDART_ASSERT(hipMemcpyAsync(pimpl->weight.data(), rows.data(), rows.nbytes(), src.device() >= 0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        const hipMemcpyKind kind = src.device() >= 0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        if (src.dtype() == pimpl->dtype) {
+            BM_CUDART_ASSERT(hipMemcpyAsync(pimpl->weight.data(), rows.data(), rows.nbytes(), kind, st));
+        } else {
+            // another element type than the model's (a bf16 checkpoint into an fp16 model, fp32 sources: the reference's assign_or_copy +
+            // typecast, embedding.cu load_state_dict / EMBEDDING_AUTO_CAST): stage the rank's rows and convert, never reinterpret
+            core::Tensor staged = ctx.tensor({last - first, dim}, src.dtype());
+            BM_CUDART_ASSERT(hipMemcpyAsync(staged.data(), rows.data(), rows.nbytes(), kind, st));
+            core::Tensor conv = bmengine::functions::typecast(ctx, staged, pimpl->dtype);
+            BM_CUDART_ASSERT(hipMemcpyAsync(pimpl->weight.data(), conv.data(), conv.nbytes(), hipMemcpyDeviceToDevice, st));
+        }
     }
     BM_CUDART_ASSERT(hipStreamSynchronize(st));          // (the source may be a host array the caller frees)
 }
