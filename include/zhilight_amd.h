@@ -288,6 +288,14 @@ int zl_gemm_nt_small_m(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K
  * prompt chunks) on the matrix cores: fp32-accumulating MFMA GEMM, one rounding to T; K % 128 == 0. */
 int zl_gemm_nt(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K) */, const uint16_t* bias, uint16_t* y,
                int64_t m, int64_t n, int64_t k, float alpha, int dtype, zl_stream_t s);
+/* ZLD16M: a dense (N, K) fp16 / bf16 matrix re-tiled for streaming with a few rows -- [N / 16][K / 128][4][64 lanes][8 values], so that a
+ * wavefront's load of one MFMA B-fragment step is 1 KiB contiguous (what ZLW4M is for int4 weights).  zl_dense_m_bytes: size of the
+ * packed copy (rows padded to 16 with zeros); zl_dense_pack_m: once at load; zl_gemm_nt_packed: zl_gemm_nt's results bit for bit for
+ * m <= 32 (the lm_head of a decode batch above the 4 rows the wave-per-row GEMV takes, RawEmbedding::projection, embedding.cu:274-289). */
+int64_t zl_dense_m_bytes(int64_t n, int64_t k);
+int zl_dense_pack_m(const uint16_t* w, uint16_t* out, int64_t n, int64_t k, zl_stream_t s);
+int zl_gemm_nt_packed(const uint16_t* x, int64_t ldx, const uint16_t* wp, const uint16_t* bias, uint16_t* y, int64_t m,
+                      int64_t n, int64_t k, float alpha, int dtype, zl_stream_t s);
 /* The same product with fp32 OUTPUT and no rounding to T: functions::Gemm / nn::Linear after set_output_type(kFloat) -- the MoE
  * router's logits (src/nn/feedforward/feedforward.cpp:285-286), whose top-k must see the fp32 sums.  K % 8 == 0; small N x M. */
 int zl_gemm_nt_f32(const uint16_t* x, int64_t ldx, const uint16_t* w /* (N,K) */, float* y, int64_t m, int64_t n, int64_t k, float alpha,

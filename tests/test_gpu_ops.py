@@ -796,3 +796,19 @@ def test_embedding_rope_one_launch_equals_the_two_calls(dev, dtype, llama3):
     w2 = (torch.randn(50, 100, generator=g)).to(dtype).to(dev)
     ids = torch.tensor([3, 49, 0], dtype=torch.int32, device=dev)
     assert torch.equal(ops.embedding(ids, w2, 1.0), w2[ids.long()])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,n,k", [(5, 1000, 1024), (8, 128256 // 8, 4096), (16, 272, 128), (17, 2048 + 16, 2048), (32, 4096, 4096)])
+def test_gemm_nt_on_the_packed_dense_layout(dev, dtype, m, n, k):
+    """ZLD16M (zl_dense_pack_m + zl_gemm_nt_packed): the lm_head of a 5..32-row decode batch read in 1 KiB contiguous fragment loads --
+    the same arithmetic in the same order as zl_gemm_nt on the row-major matrix, so the same bits; ragged N (a partial last tile, a
+    partial last workgroup), bias, one and two row blocks"""
+    from zhilight_amd import ops
+    g = torch.Generator(device=dev).manual_seed(m * 7 + n)
+    w = (torch.randn(n, k, generator=g, device=dev) * 0.05).to(dtype)
+    x = torch.randn(m, k, generator=g, device=dev).to(dtype)
+    bias = (torch.randn(n, generator=g, device=dev) * 0.1).to(dtype)
+    wp = ops.DenseMWeight(w)
+    assert torch.equal(ops.gemm_nt_packed(x, wp), ops.gemm_nt(x, w))
+    assert torch.equal(ops.gemm_nt_packed(x, wp, bias=bias, alpha=0.5), ops.gemm_nt(x, w, bias=bias, alpha=0.5))

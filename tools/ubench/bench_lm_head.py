@@ -22,3 +22,18 @@ for m in (5, 8, 16, 32):
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / 30
     print(f"rows {m:2d}: {us:7.1f} us per launch  {n * k * 2 / us / 1e6:5.2f} TB/s")
+wps = [ops.DenseMWeight(w) for w in ws]
+for m in (5, 8, 16, 32):
+    x = torch.randn(m, k, dtype=torch.float16, device=dev)
+    out = torch.empty(m, n, dtype=torch.float16, device=dev)
+    for w in wps:
+        ops.gemm_nt_packed(x, w, out=out)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(30):
+        ops.gemm_nt_packed(x, wps[i % 3], out=out)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1e3 / 30
+    print(f"rows {m:2d} (ZLD16M): {us:7.1f} us per launch  {n * k * 2 / us / 1e6:5.2f} TB/s")

@@ -41,7 +41,7 @@ SYMBOLS = [
     "zl_decode_attn_la_split_len", "zl_decode_attn_la_workspace_bytes", "zl_decode_attn_la",
     "zl_quant_calc_scale_zp", "zl_dequant_group", "zl_quant_copy_to_rag_buffer", "zl_rope_quant_scatter_decode", "zl_decode_attn_quant", "zl_decode_attn_quant_ex",
     "zl_prefill_attn", "zl_prefill_attn_ex",
-    "zl_element_add_scale", "zl_gate_mul", "zl_gate_fuse", "zl_row_ss", "zl_w4a16_emits_row_ss", "zl_w4a16_takes_row_ss", "zl_permute_input", "zl_embedding",
+    "zl_element_add_scale", "zl_gate_mul", "zl_gate_fuse", "zl_dense_m_bytes", "zl_dense_pack_m", "zl_gemm_nt_packed", "zl_row_ss", "zl_w4a16_emits_row_ss", "zl_w4a16_takes_row_ss", "zl_permute_input", "zl_embedding",
     "zl_w8m_bytes", "zl_w8m_pack", "zl_w8a8_gemm_phase", "zl_w8a8_gemm_phase_ex", "zl_w8a8_qkv_rope_scatter",
     "zl_quant_calc_scale", "zl_rmsnorm_quant", "zl_int8_gemm_nt", "zl_quant_scale_back",
     "zl_quant_back_act_mul", "zl_quant_scale_back3", "zl_quant_back_element_add_scale", "zl_quant_back_transpose",
@@ -92,6 +92,7 @@ def lib():
         l.zl_decode_attn_la_workspace_bytes.restype = C.c_int64
         l.zl_argmax_workspace_bytes.restype = C.c_int64
         l.zl_w8m_bytes.restype = C.c_int64
+        l.zl_dense_m_bytes.restype = C.c_int64
         l.zl_mla_decode_workspace_bytes.restype = C.c_int64
         l.zl_w4a16_scratch_bytes.restype = C.c_int64
         global experimental

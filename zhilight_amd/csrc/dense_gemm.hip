@@ -41,10 +41,13 @@ __device__ __forceinline__ f4 mfma16(uint4 a, uint4 b, f4 c) {
 
 // NS: weight ring slots = chunks in flight per wave (2 KiB each).  Round 6 measured 4 instead of 2 on the decode batches' lm_head
 // (1.05 GB, a pure weight stream at 5.0 TB/s: 208 / 227 us at 8 / 32 rows against 158 for the one-row GEMV): SLOWER, 228 / 250 us
-// (tools/ubench/bench_lm_head.py, profiles/r06_lm_head_ring_depth.txt) -- bytes in flight are not what holds it back; a lane's
+// (tools/ubench/bench_lm_head.py, profiles/r06_lm_head.txt) -- bytes in flight are not what holds it back; a lane's
 // 16-byte load is a quarter of a 64-byte run per row (16 rows per instruction, every 128-byte line touched by two instructions),
 // which is what the MFMA B layout asks for and what a row-contiguous loader (LDS-DMA, the slab kernel's x path) would not do.  2.
-template <int DT, int BM, int NS = 2>
+// PACKED: the weights in the ZLD16M layout (zl_dense_pack_m): [N / 16][K / 128][t = 4][lane = 64][8 values] -- a wave's load of one
+// (tile, chunk, t) is 1 KiB CONTIGUOUS instead of sixteen 64-byte runs in sixteen rows; what the W4 kernels' ZLW4M layout does for
+// int4 weights, for a dense matrix that is streamed with a few rows (the lm_head of a decode batch)
+template <int DT, int BM, int NS = 2, bool PACKED = false>
 __global__ __launch_bounds__(kDT, 2) void k_dense_gemm(const DenseGemmParams p) {
     constexpr int RB = BM / 16, XR = BM / 16;
     __shared__ __attribute__((aligned(16))) uint16_t xs[2][BM * kDRow];
@@ -68,9 +71,16 @@ __global__ __launch_bounds__(kDT, 2) void k_dense_gemm(const DenseGemmParams p) 
         const int gc = g < G ? g : G - 1;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const uint16_t* src = p.w + (size_t)nr[j] * p.k + (size_t)gc * 128 + 8 * kq;
+            if constexpr (PACKED) {
+                const int tile = min((n_base >> 4) + j, (p.n + 15) / 16 - 1);       // (a tile past N: the last one; its columns are never stored)
+                const uint4* src = reinterpret_cast<const uint4*>(p.w) + ((size_t)tile * G + gc) * 256 + lane;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) wf[slot][j][t] = zl_load_nt(reinterpret_cast<const uint4*>(src + 32 * t));
+                for (int t = 0; t < 4; ++t) wf[slot][j][t] = zl_load_nt(src + 64 * t);
+            } else {
+                const uint16_t* src = p.w + (size_t)nr[j] * p.k + (size_t)gc * 128 + 8 * kq;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wf[slot][j][t] = zl_load_nt(reinterpret_cast<const uint4*>(src + 32 * t));
+            }
         }
     };
     const int xrow = threadIdx.x >> 4, xcol = (threadIdx.x & 15) * 8;
@@ -143,7 +153,57 @@ __global__ __launch_bounds__(kDT, 2) void k_dense_gemm(const DenseGemmParams p) 
     }
 }
 
+// ZLD16M pack: one thread per 16-byte unit of the output
+__global__ __launch_bounds__(256) void k_dense_pack_m(const uint16_t* __restrict__ w, uint4* __restrict__ out, int n, int k, int64_t units) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    const int G = k / 128;
+    const int lane = (int)(u & 63), t = (int)((u >> 6) & 3);
+    const int64_t tg = u >> 8;
+    const int g = (int)(tg % G);
+    const int64_t tile = tg / G;
+    const int64_t row = tile * 16 + (lane & 15);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n) v = *reinterpret_cast<const uint4*>(w + row * k + (size_t)g * 128 + 32 * t + 8 * (lane >> 4));
+    out[u] = v;
+}
+
 }  // namespace
+
+extern "C" int64_t zl_dense_m_bytes(int64_t n, int64_t k) {
+    if (n <= 0 || k <= 0 || k % 128 != 0) return ZL_ESHAPE;
+    return (n + 15) / 16 * 16 * k * 2;
+}
+
+extern "C" int zl_dense_pack_m(const uint16_t* w, uint16_t* out, int64_t n, int64_t k, zl_stream_t s) {
+    ZL_CHECK_ARG(w && out && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(k % 128 == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0 && n < ((int64_t)1 << 31) && k < ((int64_t)1 << 31), ZL_ESHAPE);
+    const int64_t units = (n + 15) / 16 * (k / 128) * 256;
+    hipLaunchKernelGGL(k_dense_pack_m, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)s, w, reinterpret_cast<uint4*>(out), (int)n, (int)k, units);
+    return zl_launch_status();
+}
+
+// zl_gemm_nt on a ZLD16M-packed weight (m <= 32: the decode batches' lm_head; the arithmetic and the order of the sums are
+// zl_gemm_nt's, the results bit for bit)
+extern "C" int zl_gemm_nt_packed(const uint16_t* x, int64_t ldx, const uint16_t* wp, const uint16_t* bias, uint16_t* y, int64_t m,
+                                 int64_t n, int64_t k, float alpha, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(x && wp && y && m > 0 && n > 0 && k > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(k % 128 == 0 && ldx % 8 == 0 && ldx >= k && ((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0 && m <= 32, ZL_ESHAPE);
+    ZL_CHECK_ARG(dtype == ZL_F16 || dtype == ZL_BF16, ZL_EDTYPE);
+    DenseGemmParams p;
+    p.x = x; p.ldx = ldx; p.w = wp; p.bias = bias; p.y = y; p.alpha = alpha;
+    p.m = (int)m; p.n = (int)n; p.k = (int)k; p.groups = (int)(k / 128);
+    const dim3 grid((unsigned)((n + kDBN - 1) / kDBN), 1);
+    hipStream_t hs = (hipStream_t)s;
+    if (dtype == ZL_F16) {
+        if (m <= 16) hipLaunchKernelGGL((k_dense_gemm<ZL_F16, 16, 2, true>), grid, dim3(kDT), 0, hs, p);
+        else hipLaunchKernelGGL((k_dense_gemm<ZL_F16, 32, 2, true>), grid, dim3(kDT), 0, hs, p);
+    } else {
+        if (m <= 16) hipLaunchKernelGGL((k_dense_gemm<ZL_BF16, 16, 2, true>), grid, dim3(kDT), 0, hs, p);
+        else hipLaunchKernelGGL((k_dense_gemm<ZL_BF16, 32, 2, true>), grid, dim3(kDT), 0, hs, p);
+    }
+    return zl_launch_status();
+}
 
 extern "C" int zl_gemm_nt(const uint16_t* x, int64_t ldx, const uint16_t* w, const uint16_t* bias, uint16_t* y, int64_t m,
                           int64_t n, int64_t k, float alpha, int dtype, zl_stream_t s) {

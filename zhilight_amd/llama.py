@@ -1208,7 +1208,14 @@ class LLaMA:
         if (rows > 4 and argmax_ws is None and c.dim_model % 128 == 0) or ln_scale != 1.0:
             xn = ops.rmsnorm(hidden, self.output_layernorm, c.eps, ln_scale)
             if rows > 4 and argmax_ws is None and c.dim_model % 128 == 0:
-                return ops.gemm_nt(xn, self.lm_head, out=out)      # more rows than the streaming GEMV takes per pass
+                # more rows than the streaming GEMV takes per pass: the MFMA GEMM; up to 32 rows (decode batches) on the ZLD16M copy of
+                # the matrix -- packed on first use, OUTSIDE stream capture (run a step eagerly before capturing it, as bench.py does)
+                if rows <= 32 and os.environ.get("ZL_LM_HEAD_PACKED", "1") != "0":
+                    if getattr(self, "_lm_head_m", None) is None and not torch.cuda.is_current_stream_capturing():
+                        self._lm_head_m = ops.DenseMWeight(self.lm_head)
+                    if getattr(self, "_lm_head_m", None) is not None:
+                        return ops.gemm_nt_packed(xn, self._lm_head_m, out=out)
+                return ops.gemm_nt(xn, self.lm_head, out=out)
             return ops.gemm_nt_small_m(xn, self.lm_head, out=out, argmax_ws=argmax_ws)
         return ops.gemm_nt_small_m(hidden, self.lm_head, out=out, norm_weight=self.output_layernorm, norm_eps=c.eps,
                                    argmax_ws=argmax_ws)

@@ -633,6 +633,39 @@ def gemm_nt(x, weight, bias=None, alpha=1.0, out=None):
     return out
 
 
+class DenseMWeight:
+    """A dense (N, K) fp16 / bf16 matrix in the ZLD16M layout (zl_dense_pack_m): 16-row x 128-k tiles whose MFMA fragments are 1 KiB
+    contiguous -- for matrices streamed with 5..32 rows (the lm_head of a decode batch).  A second copy of the matrix: the row-major one
+    stays what the embedding, the 1..4-row GEMV and the prompt GEMM read."""
+
+    def __init__(self, weight):
+        _chk_cuda(weight)
+        n, k = weight.shape
+        nbytes = int(lib().zl_dense_m_bytes(_i(n), _i(k)))
+        if nbytes < 0:
+            check(nbytes, "dense_m_bytes")
+        self.n, self.k, self.dtype = n, k, weight.dtype
+        self.data = torch.empty(nbytes // 2, dtype=weight.dtype, device=weight.device)
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        check(lib().zl_dense_pack_m(_p(w), _p(self.data), _i(n), _i(k), _stream()), "dense_pack_m")
+
+
+def gemm_nt_packed(x, w, bias=None, alpha=1.0, out=None):
+    """gemm_nt on a DenseMWeight for up to 32 rows: the same bits, the weights streamed in 1 KiB contiguous fragment loads"""
+    _chk_cuda(x, bias)
+    x2 = x.reshape(-1, x.shape[-1])
+    m, k = x2.shape
+    if k != w.k or x.dtype != w.dtype:
+        raise ZLError("gemm_nt_packed: size K / dtype mismatch")
+    if out is None:
+        out = torch.empty((m, w.n), dtype=x.dtype, device=x.device)
+    else:
+        _chk_out(out, m, w.n, x.dtype, x.device, "gemm_nt_packed")
+    check(lib().zl_gemm_nt_packed(_p(x2), _i(x2.stride(0)), _p(w.data), _p(bias), _p(out), _i(m), _i(w.n), _i(k), _f(alpha),
+                                  C.c_int(_dt(x)), _stream()), "gemm_nt_packed")
+    return out
+
+
 def gemm_nt_f32(x, weight, alpha=1.0):
     """functions::Gemm(trans_b=True) with set_output_type(kFloat): fp32 output, no rounding to T (the MoE router's logits)"""
     _chk_cuda(x, weight)
