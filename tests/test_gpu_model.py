@@ -690,10 +690,12 @@ class OracleDenseModel:
         return o.gemm_nt(xn, self._w(head), None, 1.0, dt, exact=True)
 
 
+@pytest.mark.parametrize("batch", [2, 6])
 @pytest.mark.parametrize("dtype,minicpm", [(0, False), (1, True)])
-def test_dense_model_decode_matches_oracle(oracle, dev, dtype, minicpm):
+def test_dense_model_decode_matches_oracle(oracle, dev, dtype, minicpm, batch):
     """Unquantised models (BASELINE configs[0] in miniature when minicpm: bf16, scale_emb, scale_depth residuals,
-    dim_model_base logit scaling, tied lm_head) through the dense GEMV / MFMA GEMM kernels."""
+    dim_model_base logit scaling, tied lm_head) through the dense GEMV (batch 2) / the MFMA GEMM on the ZLD16M-packed
+    copies of the matrices (batch 6: more rows than the GEMV takes per pass)."""
     from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
     rng = np.random.default_rng(31 + dtype)
     cfg = ModelConfig(num_layers=2, dim_model=512, num_heads=4, dim_head=128, dim_ff=1024, vocab_size=384, num_kv_heads=4,
@@ -706,7 +708,7 @@ def test_dense_model_decode_matches_oracle(oracle, dev, dtype, minicpm):
     bits = {k: _to_T_bits(oracle, v, dtype) for k, v in sd32.items()}
     tdt = torch.bfloat16 if dtype else torch.float16
     sd_t = {k: torch.from_numpy(v.view(np.int16)).view(tdt) for k, v in bits.items()}
-    batch, len_buf = 2, 64
+    len_buf = 64
     model = LLaMA(cfg, QuantConfig(0, 0), dev).load_state_dict(sd_t)
     ctx = model.new_context(batch, len_buf, 0)
     om = OracleDenseModel(oracle, cfg, bits, batch, len_buf, dtype)

@@ -369,6 +369,14 @@ class NormalLinear:
             return ops.gemm_nt_small_m(x2, self.weight, bias=self.bias, out=out, norm_weight=norm_weight, norm_eps=norm_eps)
         if norm_weight is not None:
             x2 = ops.rmsnorm(x2, norm_weight, norm_eps)
+        # 5..32 rows (decode batches of the unquantised models, BASELINE configs[0]): the ZLD16M copy of the matrix -- 1 KiB contiguous
+        # fragment loads, 5.95 instead of 5.0 TB/s on the Llama-3 lm_head, the same bits; packed on first use outside stream capture.
+        # A second copy of the weights: ZL_DENSE_PACKED=0 keeps only the row-major one
+        if x2.shape[0] <= 32 and os.environ.get("ZL_DENSE_PACKED", "1") != "0":
+            if getattr(self, "weight_m", None) is None and not torch.cuda.is_current_stream_capturing():
+                self.weight_m = ops.DenseMWeight(self.weight)
+            if getattr(self, "weight_m", None) is not None:
+                return ops.gemm_nt_packed(x2, self.weight_m, bias=self.bias, out=out)
         return ops.gemm_nt(x2, self.weight, bias=self.bias, out=out)
 
 
