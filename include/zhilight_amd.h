@@ -217,7 +217,8 @@ typedef struct {
                          tiles + 192-row tiles in two launches when one height leaves the last round of workgroups partly empty) */
     /* round 6 (appended: zero-initialised structs of older callers keep their meaning) */
     int slab;         /* 5..32 rows without a fused norm on the 2-D K-split tiles of w4_slab.hip: 0 default (on), -1 off */
-    int slab_min_m;   /* rows from which the slab kernel takes over (default 5) */
+    int slab_min_m;   /* rows from which the slab kernel takes over (default 3; 1..4 rows with K <= 4096 -- 1..2 up to 16384 -- stay on
+                         k_w4a16_i8p, which is asked first; the fused qkv + rotary entry point: 5) */
     int slab_nw, slab_gpw;   /* its geometry, for sweeps: waves per workgroup (4 / 8) and 128-k groups per wave (1 / 2 / 4); 0 = planned */
     int slab_r;       /* ... and 16-column tiles per workgroup (1 / 2 / 4 / 8); 0 = planned */
     int defer_norm;   /* 1: norm_weight with 9..32 rows may take the phase kernel's DEFERRED norm (not zl_rmsnorm's roundings, see
@@ -251,7 +252,8 @@ int zl_w4a16_takes_row_ss(int64_t m, int64_t n, int64_t k, int64_t group_size, i
  *                                                     split K for short grids)
  *   anything else (odd K tails, huge K)                k_w4a16_mfma (w4_mfma.hip: whole activation block staged in LDS, 16 rows per pass)
  *   group size not a multiple of 128                   not this entry point: zl_w4a16_gemm (w4_gemv.hip, the warp-reduce arithmetic)
- *   M = 5..32 without norm_weight, K % 128 == 0        k_w4a16_slab  (w4_slab.hip, round 6: 16 R-column x K-slice tiles, activations by
+ *   M = 5..32 (3..4 where k_w4a16_i8p does not      k_w4a16_slab 
+ *     reach: K > 4096) without norm_weight, K % 128 == 0  (w4_slab.hip, round 6: 16 R-column x K-slice tiles, activations by
  *     (scratch for the K split; else the phase kernel)  LDS-DMA into wave-private fragment stores, split-K slabs folded by the last arriver)
  *   M = 5..32 with norm_weight AND zl_w4_opts_t::row_ss, k_w4a16_slab<NORM>: rs from the rows' tile sums, T(x rs w) on the fragments (see
  *     K % 1024 == 0, 2048 < K <= 8192                   zl_w4_opts_t::row_ss; zl_w4a16_takes_row_ss answers without launching)

@@ -393,7 +393,7 @@ def test_streaming_gemm_random_shapes(oracle, dev, monkeypatch):
 
 
 @pytest.mark.parametrize("geom", [None, (4, 1), (8, 2), (4, 4), (1, 8, 4), (2, 8, 4), (7, 8, 4), (8, 8, 4)])
-@pytest.mark.parametrize("m", [5, 8, 9, 16, 17, 32])
+@pytest.mark.parametrize("m", [3, 5, 8, 9, 16, 17, 32])
 def test_slab_gemm_geometries(oracle, dev, m, geom, monkeypatch):
     """w4_slab.hip (5..32 rows, round 6): the planner's own geometry and forced (waves per workgroup, groups per wave) pairs -- with the
     tiles per workgroup forced as well in the 3-tuples: the two-groups-resident / DMA-two-groups-ahead schedule with 1, 2, 7, 8 weight

@@ -1,0 +1,6 @@
+export TMPDIR=/tmp
+bench() { timeout 600 python bench.py --batch $1 --steps 30 --warmup 5 --no-ttft --no-cpu-baseline --no-extras 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$2 batch', $1, d['value'], d['ms_per_step'])"; }
+for b in 3 4; do
+  bench $b "default          "
+  ZL_W4_SLAB_MIN_M=3 bench $b "slab from 3 rows "
+done

@@ -771,7 +771,7 @@ int zl_w4a16_gemm_mfma_ex(const uint16_t* x, int64_t ldx, const uint32_t* qw, co
     // 9..32 rows without a fused norm (round 6): 128-column x K-slice tiles, activation fragments straight from global memory
     // (w4_slab.hip) -- a workgroup's activation bytes ~ its weight bytes instead of M x K per 16 R columns
     // ... and WITH a norm when the caller hands over the rows' statistics (zl_w4_opts_t::row_ss): the slab kernel's NORM instantiations
-    if (o.slab >= 0 && (!norm_weight || o.row_ss) && m >= (o.slab_min_m > 0 ? o.slab_min_m : 5) && m <= 32 && k % 128 == 0 &&
+    if (o.slab >= 0 && (!norm_weight || o.row_ss) && m >= (o.slab_min_m > 0 ? o.slab_min_m : (o.small_algo == 1 ? 5 : 3)) && m <= 32 && k % 128 == 0 &&
         L.qw_bytes < ((int64_t)1 << 32)) {
         st = zl_w4a16_gemm_slab(x, ldx, qw, meta, (uint32_t)L.qw_bytes, (uint32_t)L.scales_bytes, bias, residual, y, (int)m, (int)n,
                                 (int)k, (int)L.q, (int)(L.np / 16), epilogue, (int)(silu ? n / 2 : n), norm_weight, norm_eps, &o, hs);

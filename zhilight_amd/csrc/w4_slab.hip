@@ -889,7 +889,7 @@ bool zl_slab_route(int64_t m, int64_t n, int64_t k, int64_t group_size, bool rop
     static const zl_w4_opts_t kNoOpts = {};
     const zl_w4_opts_t& o = opts ? *opts : kNoOpts;
     if (o.slab < 0 || group_size <= 0 || group_size % 128 != 0 || k % 128 != 0 || n % 16 != 0) return false;
-    if (m < (o.slab_min_m > 0 ? o.slab_min_m : 5) || m > 32) return false;
+    if (m < (o.slab_min_m > 0 ? o.slab_min_m : (rope || o.small_algo == 1 ? 5 : 3)) || m > 32) return false;
     if (norm && !(o.row_ss != nullptr && k % 1024 == 0 && k <= 8192 && k > 2048)) return false;
     if (rope && !opts) return false;
     (void)silu;

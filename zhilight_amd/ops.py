@@ -374,7 +374,7 @@ def w4_scratch_reserve(device, m_max, n_max):
 
 def _w4_opts(device, m, n):
     o = W4Opts()
-    buf = w4_scratch(device, m, n) if m > 4 else None   # up to 4 rows no launcher splits over workgroups
+    buf = w4_scratch(device, m, n) if m > 2 else None   # up to 2 rows no launcher splits over workgroups (3..4: the long-K slab route)
     if buf is not None:
         o.scratch, o.scratch_bytes = buf.data_ptr(), buf.numel()
     for field, env in _W4_ENV:
