@@ -259,15 +259,25 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
     };
     // NORM: the norm weights of the wave's GPW groups (GPW x 256 B, consecutive) behind the x regions, one DMA
     unsigned char* nww = smem + (size_t)nw * (XS * kSet) + (size_t)wave * 1024;
-    if constexpr (NORM) {
+    auto dma_prologue = [&]() {
+        if constexpr (NORM) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.norm_w), 0, (uint32_t)p.k * 2u, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rn, (lds_ptr)nww, 16, (uint32_t)lane * 16u, g0 * 256, 0, 0);
+            const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.norm_w), 0, (uint32_t)p.k * 2u, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rn, (lds_ptr)nww, 16, (uint32_t)lane * 16u, g0 * 256, 0, 0);
 #endif
-    }
+        }
 #pragma unroll
-    for (int j = 0; j < XS; ++j) dma_x(j, j);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < XS; ++j) dma_x(j, j);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ZL_SLAB_RING_FIRST (A/B): the weight ring's prologue is requested BEFORE the activation DMAs -- HBM requests leave 1..3 us
+    // earlier, the images (L2) land behind them; the prologue items are then OLDER than DMA(0) / DMA(1) in the wait counts below
+#ifdef ZL_SLAB_RING_FIRST
+    constexpr bool kRingFirst = true;
+#else
+    constexpr bool kRingFirst = false;
+    dma_prologue();
+#endif
 
     // ---- weight ring: item i = (group j = i / R, tile r = i % R)
     uint4 wq[D];
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
     }
     mt[D - 1] = 0;                                    // the neutral "previous item" of the first step
     wq[D - 1] = make_uint4(0, 0, 0, 0);
+    if constexpr (kRingFirst) dma_prologue();
     ZL_SPROBE(1);                                     // prologue requested
 
 #ifndef ZL_SLAB_STATS_FIRST
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
         // group j + 1 is read at the START of group j and normalised in R slices in front of group j's items' MFMAs -- a burst of ~200
         // VALU per group in front of its first item keeps the wave from refilling its ring for that long.
         // DMA order: groups 0, 1 in the prologue, 2 here, g + 2 when group g has been read.
-        wait_vm((GPW > 1 ? DM : 0) + 2 * (D - 1));
+        wait_vm((GPW > 1 ? DM : 0) + (kRingFirst ? 0 : 2 * (D - 1)));
         read_group(0, 0);
         ZL_SPROBE(2);
         if (XS < GPW) dma_x(0, XS);
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
                 // younger than DMA(g): DMA(g + 1) (requested when group g - 1 was read), and the ring items requested after DMA(g) went
                 // out -- in the prologue for g < XS (all D - 1 prologue items follow it), else when group g - XS was read, i.e. ahead of
                 // the refill that follows item max(0, g - XS - 1) R
-                const int fy = g < XS ? 0 : ((g - XS - 1 > 0 ? g - XS - 1 : 0) * R + D - 1);
+                const int fy = g < XS ? (kRingFirst ? D - 1 : 0) : ((g - XS - 1 > 0 ? g - XS - 1 : 0) * R + D - 1);
                 const int lo = i > fy ? i : fy, hi = (i + D - 2) < (TOTAL - 1) ? (i + D - 2) : (TOTAL - 1);
                 wait_vm((g + 1 < GPW ? DM : 0) + 2 * (hi - lo + 1 > 0 ? hi - lo + 1 : 0));
                 read_group(cur ^ 1, g);
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void k_w4a16_slab(const SlabParams p) {
             // of its refill: only items from (j - XS) R + D - 1 on are younger
             const int younger_groups = (j == 0) ? (XS - 1 < GPW - 1 ? XS - 1 : GPW - 1) : ((j + 1 < GPW) ? 1 : 0);
             const int fly_hi = (i + D - 2) < (TOTAL - 1) ? (i + D - 2) : (TOTAL - 1);
-            const int first_younger = j < XS ? i : ((j - XS) * R + D - 1 > i ? (j - XS) * R + D - 1 : i);
+            const int first_younger = j < XS ? (kRingFirst && D - 1 > i ? D - 1 : i) : ((j - XS) * R + D - 1 > i ? (j - XS) * R + D - 1 : i);
             const int ring_fly = fly_hi - first_younger + 1 > 0 ? fly_hi - first_younger + 1 : 0;
             wait_vm(younger_groups * DM + 2 * ring_fly);
             read_group(0, j);
