@@ -643,3 +643,26 @@ def test_dispatch_index_helpers(dev, n, max_key):
         want2 = np.zeros((m + 11, width), np.float32)
         want2[di[:mm]] = src.float().cpu().numpy()[:mm]
         assert np.array_equal(dst2.float().cpu().numpy(), want2)
+
+
+@pytest.mark.parametrize("dtype,code", [(torch.bfloat16, 1), (torch.float16, 0)])
+@pytest.mark.parametrize("m,n,k", [(17, 256, 1024), (32, 4096, 7168), (25, 200, 2048), (32, 512, 4096), (20, 144, 8192), (32, 128, 1536 + 512)])
+def test_block_gemm_17_32_rows_with_lds_dma_activations(oracle, dev, dtype, code, m, n, k):
+    """k_fp8_block_gemm_dma (round 6: 17..32 rows, the wave's activation blocks moved global -> LDS by LDS-DMA, XOR-swizzled): a row of
+    the product depends on its own row of the activations only and a wave walks its blocks in the same order, so the launch returns the
+    BITS of the 16-row launches (k_fp8_block_gemm<1, ..>) on the two halves of the rows -- 1, 2, 4, 7, 8 blocks per wave, a ragged K
+    (the last round of blocks partly past the end), ragged N and M; and it sits inside the format's bar."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(m * 31 + n)
+    x = _acts(rng, m, k, dtype)
+    a8, sa = oracle.fp8_per_token_cast(_bits(x), dtype=code)
+    w8, sw = _block_weight(rng, n, k)
+    a8_t, w8_t, sw_t = _t(a8, dev), _t(w8, dev), _t(sw, dev)
+    got = ops.fp8_block_gemm(a8_t, _t(sa, dev), w8_t, sw_t, dtype=dtype)
+    for lo, hi in ((0, 16), (16, m)):
+        a8h, sah = oracle.fp8_per_token_cast(_bits(x[lo:hi]), dtype=code)
+        assert np.array_equal(a8h, a8[lo:hi])
+        part = ops.fp8_block_gemm(_t(a8h, dev), _t(sah, dev), w8_t, sw_t, dtype=dtype)
+        assert torch.equal(got[lo:hi], part), (lo, hi)
+    if n * k <= 512 * 4096:
+        _gemm_bar(_bits(got), oracle.fp8_block_gemm(a8, sa, w8, sw, dtype=code), oracle, code)

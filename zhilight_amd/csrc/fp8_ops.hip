@@ -226,6 +226,124 @@ __global__ __launch_bounds__(512) void k_fp8_block_gemm(const uint8_t* __restric
     }
 }
 
+// 17..32 rows (round 6): k_fp8_block_gemm<2, ..> loads its activation fragments straight from global memory -- 16 bytes out of 16
+// different rows per 16 lanes, the access pattern that cost the first cut of w4_slab.hip 5..8 us per launch -- and every workgroup
+// pulls ALL of the activations (32 x K bytes: twice its weight bytes).  Here a wave moves the 32 rows x 128 bytes of ITS next block
+// global -> LDS by LDS-DMA (row-contiguous; 16-byte pieces XOR-swizzled by the row so the ds_read_b128 fragment reads are
+// conflict-free), one block ahead, next to the weight fragments and the per-token scales of that block; the arithmetic, the order
+// of a wave's blocks and the cross-wave sum are k_fp8_block_gemm's: the same bits.
+typedef __attribute__((address_space(3))) void* fp8_lds_ptr;
+constexpr int fp8_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
+// NB = blocks per wave = ceil(K / 1024) (compile-time: the block loop is unrolled, LDS sets and registers statically indexed).
+// Issue order: the weight fragments and scales of ALL the wave's blocks first (the HBM stream: 2 KB per block and wave in flight,
+// as in k_fp8_block_gemm<.., U = NB>), then the activation images of the first three blocks (L2); image i + 3 is requested when
+// block i has been used.  In-order return makes "image i has landed" = "at most the two younger images outstanding".
+template <int DT, int NB>
+__global__ __launch_bounds__(512, 1) void k_fp8_block_gemm_dma(const uint8_t* __restrict__ a, const float* __restrict__ sa, int64_t aligned_m,
+                                                               const uint8_t* __restrict__ w, const float* __restrict__ sw,
+                                                               uint16_t* __restrict__ c, int m, int n, int k) {
+    constexpr int MT = 2, SETS = NB < 3 ? NB : 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];       // [8 waves][SETS][32 rows][128 B], then red[8][MT][256]
+    float* red = reinterpret_cast<float*>(fsm + 8 * SETS * 4096);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 32;
+    const int col = lane & 15, kq = lane >> 4;
+    const int kb_n = k / 128;
+    const uint8_t* brow = w + (size_t)min(n0 + col, n - 1) * k + 16 * kq;
+    const float* swg = sw + (size_t)(n0 / 128) * kb_n;
+    unsigned char* region = fsm + wave * (SETS * 4096);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a), 0, (uint32_t)((size_t)m * k), 0x00020000);
+    // DMA d of a block: lane -> (row 8 d + (lane >> 3), LDS piece lane & 7), which holds the row's piece (lane & 7) ^ (row & 7)
+    uint32_t x_off[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int row = 8 * d + (lane >> 3);
+        x_off[d] = (uint32_t)min(m0 + row, m - 1) * (uint32_t)k + (uint32_t)(((lane & 7) ^ (row & 7)) * 16);
+    }
+    // block i of this wave = k-block wave + 8 i; past the end of K (the last round of a ragged K): block `wave` again with a zero
+    // scale (real bytes: an e4m3 NaN pattern out of stale LDS would survive the zero)
+    uint4 bf[NB][2];
+    float sc[NB][MT][4], wsc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const bool ok = wave + 8 * i < kb_n;
+        const int kb = ok ? wave + 8 * i : min(wave, kb_n - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) bf[i][h] = zl_load_nt(reinterpret_cast<const uint4*>(brow + (size_t)kb * 128 + h * 64));
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sc[i][t][q] = sa[(size_t)kb * aligned_m + min(m0 + 16 * t + 4 * kq + q, m - 1)];
+        wsc[i] = ok ? swg[kb] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto dma = [&](int i) {                                                    // static i
+        const int kb = wave + 8 * i < kb_n ? wave + 8 * i : min(wave, kb_n - 1);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (fp8_lds_ptr)(region + (i % SETS) * 4096 + d * 1024), 16, x_off[d], kb * 128, 0, 0);
+#endif
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < SETS; ++i) dma(i);
+    __builtin_amdgcn_sched_barrier(0);
+    f4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t rbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)region;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        // images younger than image i that may still be outstanding: i + 1 .. min(i + SETS - 1, NB - 1) (image i + SETS goes out below)
+        const int younger = (i + SETS - 1 < NB - 1 ? i + SETS - 1 : NB - 1) - i;
+        if (younger >= 2) __builtin_amdgcn_s_waitcnt(fp8_vmcnt(8));
+        else if (younger == 1) __builtin_amdgcn_s_waitcnt(fp8_vmcnt(4));
+        else __builtin_amdgcn_s_waitcnt(fp8_vmcnt(0));
+        uint4 af[MT][2];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t addr = rbase + (uint32_t)((i % SETS) * 4096 + (16 * t + col) * 128 + (((kq + 4 * h) ^ (col & 7)) * 16));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(af[t][h]) : "v"(addr) : "memory");
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (i + SETS < NB) dma(i + SETS);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            f4 blk = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint4 b4 = bf[i][h], a4 = af[t][h];
+                const long b_lo = (long)(((unsigned long long)b4.y << 32) | b4.x), b_hi = (long)(((unsigned long long)b4.w << 32) | b4.z);
+                const long a_lo = (long)(((unsigned long long)a4.y << 32) | a4.x), a_hi = (long)(((unsigned long long)a4.w << 32) | a4.z);
+                blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_lo, b_lo, blk, 0, 0, 0);
+                blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a_hi, b_hi, blk, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float s_row = (m0 + 16 * t + 4 * kq + q) < m ? sc[i][t][q] : 0.f;
+                acc[t][q] = __builtin_fmaf(blk[q], s_row * wsc[i], acc[t][q]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[(wave * MT + t) * 256 + (4 * kq + q) * 16 + col] = acc[t][q];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MT * 256; idx += 512) {
+        const int t = idx >> 8, e = idx & 255, row = m0 + 16 * t + (e >> 4), cc = n0 + (e & 15);
+        float v = red[t * 256 + e];
+#pragma unroll
+        for (int ws = 1; ws < 8; ++ws) v += red[(ws * MT + t) * 256 + e];
+        if (row < m && cc < n) c[(size_t)row * n + cc] = ZT<DT>::from_f32(v);
+    }
+}
+
 }  // namespace
 
 #define ZL_DT_SWITCH(dtype, EXPR_F16, EXPR_BF16) \
@@ -311,6 +429,31 @@ int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t
         if (bpw > 4) ZL_FP8B(1, 8)
         else ZL_FP8B(1, 4)
     } else if (m <= 32) {
+#ifndef ZL_FP8_NO_DMA
+        // 17..32 rows: activations by LDS-DMA (k_fp8_block_gemm_dma; same bits) for the block counts per wave it is built for
+        if ((int64_t)m * k < ((int64_t)1 << 31) && (bpw == 1 || bpw == 2 || bpw == 4 || bpw == 7 || bpw == 8)) {
+            const dim3 grid(gx, (unsigned)((m + 31) / 32));
+#define ZL_FP8D(NB_)                                                                                                                        \
+            {                                                                                                                                \
+                const int lds = 8 * (NB_ < 3 ? NB_ : 3) * 4096 + 8 * 2 * 256 * 4;                                                           \
+                const void* fn = dtype == ZL_F16 ? reinterpret_cast<const void*>(&k_fp8_block_gemm_dma<ZL_F16, NB_>)                        \
+                                                 : reinterpret_cast<const void*>(&k_fp8_block_gemm_dma<ZL_BF16, NB_>);                      \
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return ZL_ELIMIT;               \
+                ZL_DT_SWITCH(dtype,                                                                                                          \
+                    hipLaunchKernelGGL((k_fp8_block_gemm_dma<ZL_F16, NB_>), grid, dim3(512), lds, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales, out, (int)m, (int)n, (int)k), \
+                    hipLaunchKernelGGL((k_fp8_block_gemm_dma<ZL_BF16, NB_>), grid, dim3(512), lds, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales, out, (int)m, (int)n, (int)k)) \
+            }
+            switch ((int)bpw) {
+                case 1: ZL_FP8D(1) break;
+                case 2: ZL_FP8D(2) break;
+                case 4: ZL_FP8D(4) break;
+                case 7: ZL_FP8D(7) break;
+                default: ZL_FP8D(8) break;
+            }
+#undef ZL_FP8D
+            return zl_launch_status();
+        }
+#endif
         if (bpw > 2) ZL_FP8B(2, 4)
         else ZL_FP8B(2, 2)
     } else ZL_FP8B(4, 1)
