@@ -871,6 +871,16 @@ int zl_fp8_block_dequant(const uint8_t* w, const float* scale, uint16_t* out, in
                          zl_stream_t s);
 int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t aligned_m, const uint8_t* rhs, const float* rhs_scales,
                             const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype, zl_stream_t s);
+/* ZLF8M: the (groups, N, K) e4m3 codes of a block-scaled weight re-tiled for streaming -- [group][N / 16][K / 128][2][64 lanes][16 codes],
+ * a wavefront's fragment load of one (16-row tile, 128-k block, half) 1 KiB contiguous (what ZLW4M / ZLD16M are for int4 / 16-bit
+ * weights); the scales keep their layout.  zl_fp8_block_pack once at load (zl_fp8_block_packed_bytes: size, rows padded to 16 with
+ * zero codes); zl_fp8_block_gemm_group_packed: zl_fp8_block_gemm_group's results bit for bit, for the decode shapes (m <= 32 per launch,
+ * or the grouped form). */
+int64_t zl_fp8_block_packed_bytes(int64_t n, int64_t k, int64_t num_groups);
+int zl_fp8_block_pack(const uint8_t* w, uint8_t* out, int64_t n, int64_t k, int64_t num_groups, zl_stream_t s);
+int zl_fp8_block_gemm_group_packed(const uint8_t* lhs, const float* lhs_scales, int64_t aligned_m, const uint8_t* rhs_packed, const float* rhs_scales,
+                                   const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype,
+                                   zl_stream_t s);
 int zl_moe_top_k_softmax(const uint16_t* logits, int64_t tokens, int num_exp, int top_k, int top_k_ext, int renormalize, float weight_scale,
                          int scoring, int dtype, float* out_v, int32_t* out_idx, int32_t* worker_load, int32_t* expert_load, int num_worker,
                          zl_stream_t s);

@@ -666,3 +666,37 @@ def test_block_gemm_17_32_rows_with_lds_dma_activations(oracle, dev, dtype, code
         assert torch.equal(got[lo:hi], part), (lo, hi)
     if n * k <= 512 * 4096:
         _gemm_bar(_bits(got), oracle.fp8_block_gemm(a8, sa, w8, sw, dtype=code), oracle, code)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k", [(1, 512, 1024), (5, 200, 512), (16, 4096, 7168), (17, 256, 1024), (32, 2048, 7168), (25, 200, 2048), (32, 144, 1536)])
+def test_block_gemm_on_the_packed_weight_layout(oracle, dev, dtype, m, n, k):
+    """ZLF8M (zl_fp8_block_pack + zl_fp8_block_gemm_group_packed): the same kernels reading the weight codes in 1 KiB contiguous
+    fragment loads -- the bits of the launch on the row-major codes; 1..16 rows, 17..32 rows (LDS-DMA activations, and the block
+    counts per wave that kernel is not built for), ragged N."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(m * 13 + n)
+    code = 1 if dtype == torch.bfloat16 else 0
+    x = _acts(rng, m, k, dtype)
+    a8, sa = oracle.fp8_per_token_cast(_bits(x), dtype=code)
+    w8, sw = _block_weight(rng, n, k)
+    w8_t, sw_t = _t(w8, dev), _t(sw, dev)
+    wp = ops.Fp8BlockMWeight(w8_t)
+    want = ops.fp8_block_gemm(_t(a8, dev), _t(sa, dev), w8_t, sw_t, dtype=dtype)
+    assert torch.equal(ops.fp8_block_gemm(_t(a8, dev), _t(sa, dev), wp, sw_t, dtype=dtype), want)
+
+
+def test_grouped_block_gemm_on_the_packed_weight_layout(oracle, dev):
+    """the m-grouped form (an expert per 64-row run, padding rows untouched) on packed (G, N, K) codes: the bits of the row-major launch"""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(77)
+    G, n, k, m = 4, 256, 1024, 256
+    x = _acts(rng, m, k, torch.bfloat16)
+    a8, sa = oracle.fp8_per_token_cast(_bits(x), dtype=1)
+    ws = [_block_weight(rng, n, k) for _ in range(G)]
+    w8 = _t(np.stack([w[0] for w in ws]), dev)
+    sw = _t(np.stack([w[1] for w in ws]), dev)
+    idx = np.repeat(np.array([2, -1, 0, 3], np.int32), 64)
+    want = ops.fp8_block_gemm(_t(a8, dev), _t(sa, dev), w8, sw, m_indices=_t(idx, dev))
+    got = ops.fp8_block_gemm(_t(a8, dev), _t(sa, dev), ops.Fp8BlockMWeight(w8), sw, m_indices=_t(idx, dev))
+    assert torch.equal(got, want)

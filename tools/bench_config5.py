@@ -48,7 +48,15 @@ def main():
             y = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
             us = timed(lambda i=0: ops.fp8_block_gemm(a8, sa, ws[i % nb], sw, out=y), nb)
             out["fp8_block_gemm_us"]["%s_m%d" % (name, m)] = {"us": round(us, 2), "tb_per_s": round(n * k / us / 1e6, 2)}
+        wps = [ops.Fp8BlockMWeight(w) for w in ws]      # the same codes in the ZLF8M layout (1 KiB contiguous fragment loads)
         del ws
+        for m in (1, 32):
+            x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+            a8, sa = ops.fp8_per_token_cast(x)
+            y = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+            us = timed(lambda i=0: ops.fp8_block_gemm(a8, sa, wps[i % nb], sw, out=y), nb)
+            out["fp8_block_gemm_us"]["%s_m%d_packed" % (name, m)] = {"us": round(us, 2), "tb_per_s": round(n * k / us / 1e6, 2)}
+        del wps
     print(json.dumps(out), flush=True)
 
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "zl_moe_sum_experts", "zl_moe_sum_experts_arr", "zl_moe_route_shared_lb", "zl_moe_plus_for_sort", "zl_moe_calc_reverse_idx",
     "zl_moe_fill_m_indices",
     "zl_embedding_rope",
-    "zl_fp8_per_token_cast", "zl_fp8_block_dequant", "zl_fp8_block_gemm_group", "zl_moe_top_k_softmax", "zl_moe_group_topk",
+    "zl_fp8_per_token_cast", "zl_fp8_block_dequant", "zl_fp8_block_gemm_group", "zl_fp8_block_packed_bytes", "zl_fp8_block_pack", "zl_fp8_block_gemm_group_packed", "zl_moe_top_k_softmax", "zl_moe_group_topk",
     "zl_cast", "zl_copy_2d", "zl_index_select", "zl_argmax_advance", "zl_arange_i32", "zl_divide_i32", "zl_scatter_update_dim0", "zl_sort_pairs_i32", "zl_log_softmax_bias", "zl_softmax_rows", "zl_topk_rows", "zl_gather_logits", "zl_scatter_logits", "zl_repetition_penalty", "zl_reduce_abs_max", "zl_binary_op", "zl_scale", "zl_act_inplace",
     "zl_count_nonfinite", "zl_perm_narrow_u16", "zl_perm_reverse_u16", "zl_permute_input_u16", "zl_gptq_permute_rows",
     "zl_version", "zl_status_string", "zl_device_cu_count",
@@ -93,6 +93,7 @@ def lib():
         l.zl_argmax_workspace_bytes.restype = C.c_int64
         l.zl_w8m_bytes.restype = C.c_int64
         l.zl_dense_m_bytes.restype = C.c_int64
+        l.zl_fp8_block_packed_bytes.restype = C.c_int64
         l.zl_mla_decode_workspace_bytes.restype = C.c_int64
         l.zl_w4a16_scratch_bytes.restype = C.c_int64
         global experimental

@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void k_fp8_block_dequant(const uint8_t* __rest
 // (deterministic).  A tile of 16 rows takes the expert (weight matrix) of its first row; rows of the tile carrying another index
 // are not written (contiguous grouped layout, groups aligned to 16 rows; DeepGEMM's own contract is alignment to its block_m =
 // 64); the grouped form runs with MT = 1 (neighbouring tiles may belong to different experts).
-template <int MT, int U, int DT>
+// PACKED (round 6): the weights in the ZLF8M layout (zl_fp8_block_pack): [group][N / 16][K / 128][2][64 lanes][16 codes] -- a wave's
+// fragment load of one (tile, block, half) is 1 KiB contiguous instead of sixteen 64-byte runs in sixteen rows
+template <int MT, int U, int DT, bool PACKED = false>
 __global__ __launch_bounds__(512) void k_fp8_block_gemm(const uint8_t* __restrict__ a, const float* __restrict__ sa, int64_t aligned_m,
                                                         const uint8_t* __restrict__ w, const float* __restrict__ sw,
                                                         const int32_t* __restrict__ m_indices, uint16_t* __restrict__ c, int m, int n, int k,
@@ -160,7 +162,9 @@ __global__ __launch_bounds__(512) void k_fp8_block_gemm(const uint8_t* __restric
     const int g = m_indices ? m_indices[m0] : 0;              // workgroup-uniform (m0 < m by the grid)
     if (g < 0 || g >= num_groups) return;                     // a padding tile of the grouped layout (or a foreign index): nothing is read or written
     // (clamped addresses: a column / row past the end re-reads the last one and is never stored)
-    const uint8_t* brow = w + ((size_t)g * n + min(n0 + col, n - 1)) * k + 16 * kq;
+    const uint8_t* brow = PACKED ? w + (((size_t)g * ((n + 15) / 16) + blockIdx.x) * kb_n) * 2048 + lane * 16
+                                 : w + ((size_t)g * n + min(n0 + col, n - 1)) * k + 16 * kq;
+    constexpr int kBlk = PACKED ? 2048 : 128, kHalf = PACKED ? 1024 : 64;       // byte strides of a k-block / of its second half
     const float* swg = sw + ((size_t)g * nbw + n0 / 128) * kb_n;
     const uint8_t* arow[MT];
 #pragma unroll
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(512) void k_fp8_block_gemm(const uint8_t* __restric
             const int kbc = ok ? kb : kb0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                bf[u][h] = zl_load_nt(reinterpret_cast<const uint4*>(brow + kbc * 128 + h * 64));
+                bf[u][h] = zl_load_nt(reinterpret_cast<const uint4*>(brow + (size_t)kbc * kBlk + h * kHalf));
 #pragma unroll
                 for (int t = 0; t < MT; ++t) af[u][t][h] = *reinterpret_cast<const uint4*>(arow[t] + kbc * 128 + h * 64);
             }
@@ -238,7 +242,7 @@ constexpr int fp8_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) |
 // Issue order: the weight fragments and scales of ALL the wave's blocks first (the HBM stream: 2 KB per block and wave in flight,
 // as in k_fp8_block_gemm<.., U = NB>), then the activation images of the first three blocks (L2); image i + 3 is requested when
 // block i has been used.  In-order return makes "image i has landed" = "at most the two younger images outstanding".
-template <int DT, int NB>
+template <int DT, int NB, bool PACKED = false>
 __global__ __launch_bounds__(512, 1) void k_fp8_block_gemm_dma(const uint8_t* __restrict__ a, const float* __restrict__ sa, int64_t aligned_m,
                                                                const uint8_t* __restrict__ w, const float* __restrict__ sw,
                                                                uint16_t* __restrict__ c, int m, int n, int k) {
@@ -249,7 +253,8 @@ __global__ __launch_bounds__(512, 1) void k_fp8_block_gemm_dma(const uint8_t* __
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 32;
     const int col = lane & 15, kq = lane >> 4;
     const int kb_n = k / 128;
-    const uint8_t* brow = w + (size_t)min(n0 + col, n - 1) * k + 16 * kq;
+    const uint8_t* brow = PACKED ? w + ((size_t)blockIdx.x * kb_n) * 2048 + lane * 16 : w + (size_t)min(n0 + col, n - 1) * k + 16 * kq;
+    constexpr int kBlk = PACKED ? 2048 : 128, kHalf = PACKED ? 1024 : 64;
     const float* swg = sw + (size_t)(n0 / 128) * kb_n;
     unsigned char* region = fsm + wave * (SETS * 4096);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a), 0, (uint32_t)((size_t)m * k), 0x00020000);
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void k_fp8_block_gemm_dma(const uint8_t* __
         const bool ok = wave + 8 * i < kb_n;
         const int kb = ok ? wave + 8 * i : min(wave, kb_n - 1);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) bf[i][h] = zl_load_nt(reinterpret_cast<const uint4*>(brow + (size_t)kb * 128 + h * 64));
+        for (int h = 0; h < 2; ++h) bf[i][h] = zl_load_nt(reinterpret_cast<const uint4*>(brow + (size_t)kb * kBlk + h * kHalf));
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -344,6 +349,23 @@ __global__ __launch_bounds__(512, 1) void k_fp8_block_gemm_dma(const uint8_t* __
     }
 }
 
+// ZLF8M pack: one thread per 16-byte unit of the output
+__global__ __launch_bounds__(256) void k_fp8_block_pack(const uint8_t* __restrict__ w, uint4* __restrict__ out, int n, int k, int64_t units) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    const int kb_n = k / 128, tiles = (n + 15) / 16;
+    const int lane = (int)(u & 63), h = (int)((u >> 6) & 1);
+    const int64_t tk = u >> 7;
+    const int kb = (int)(tk % kb_n);
+    const int64_t gt = tk / kb_n;
+    const int tile = (int)(gt % tiles);
+    const int64_t g = gt / tiles;
+    const int row = tile * 16 + (lane & 15);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n) v = *reinterpret_cast<const uint4*>(w + ((size_t)g * n + row) * k + (size_t)kb * 128 + 64 * h + 16 * (lane >> 4));
+    out[u] = v;
+}
+
 }  // namespace
 
 #define ZL_DT_SWITCH(dtype, EXPR_F16, EXPR_BF16) \
@@ -404,23 +426,55 @@ int zl_fp8_block_dequant(const uint8_t* w, const float* scale, uint16_t* out, in
     return zl_launch_status();
 }
 
+int64_t zl_fp8_block_packed_bytes(int64_t n, int64_t k, int64_t num_groups) {
+    if (n <= 0 || k <= 0 || k % 128 != 0 || num_groups < 1) return ZL_ESHAPE;
+    return num_groups * ((n + 15) / 16 * 16) * k;
+}
+
+int zl_fp8_block_pack(const uint8_t* w, uint8_t* out, int64_t n, int64_t k, int64_t num_groups, zl_stream_t s) {
+    ZL_CHECK_ARG(w && out && n > 0 && k > 0 && num_groups >= 1, ZL_EINVAL);
+    ZL_CHECK_ARG(k % 128 == 0 && (((uintptr_t)w | (uintptr_t)out) & 15) == 0 && n < ((int64_t)1 << 31) && k < ((int64_t)1 << 31), ZL_ESHAPE);
+    const int64_t units = num_groups * ((n + 15) / 16) * (k / 128) * 128;
+    ZL_CHECK_ARG((units + 255) / 256 < ((int64_t)1 << 31), ZL_ELIMIT);
+    hipLaunchKernelGGL(k_fp8_block_pack, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)s, w, reinterpret_cast<uint4*>(out), (int)n, (int)k, units);
+    return zl_launch_status();
+}
+
+static int fp8_block_gemm_impl(const uint8_t* lhs, const float* lhs_scales, int64_t aligned_m, const uint8_t* rhs, const float* rhs_scales,
+                               const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype, bool packed,
+                               zl_stream_t s);
+
 int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t aligned_m, const uint8_t* rhs, const float* rhs_scales,
                             const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype, zl_stream_t s) {
+    return fp8_block_gemm_impl(lhs, lhs_scales, aligned_m, rhs, rhs_scales, m_indices, out, m, n, k, num_groups, dtype, false, s);
+}
+
+// ... on a ZLF8M-packed weight (zl_fp8_block_pack; up to 32 rows per launch or the grouped form: the decode shapes): the same bits
+int zl_fp8_block_gemm_group_packed(const uint8_t* lhs, const float* lhs_scales, int64_t aligned_m, const uint8_t* rhs_packed, const float* rhs_scales,
+                                   const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype, zl_stream_t s) {
+    ZL_CHECK_ARG(m_indices || m <= 32, ZL_ESHAPE);
+    return fp8_block_gemm_impl(lhs, lhs_scales, aligned_m, rhs_packed, rhs_scales, m_indices, out, m, n, k, num_groups, dtype, true, s);
+}
+
+static int fp8_block_gemm_impl(const uint8_t* lhs, const float* lhs_scales, int64_t aligned_m, const uint8_t* rhs, const float* rhs_scales,
+                               const int32_t* m_indices, uint16_t* out, int64_t m, int64_t n, int64_t k, int num_groups, int dtype, bool packed,
+                               zl_stream_t s) {
     ZL_CHECK_ARG(lhs && lhs_scales && rhs && rhs_scales && out && m > 0 && n > 0 && k > 0 && num_groups >= 1, ZL_EINVAL);
     ZL_CHECK_ARG(k % 128 == 0 && aligned_m >= m && (num_groups == 1 || m_indices), ZL_ESHAPE);
     ZL_CHECK_ARG((((uintptr_t)lhs | (uintptr_t)rhs) & 15) == 0, ZL_ESHAPE);      // 16-byte fragment loads
     ZL_CHECK_ARG(m < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) && (m + 15) / 16 <= 65535, ZL_ELIMIT);
     hipStream_t hs = (hipStream_t)s;
     const unsigned gx = (unsigned)((n + 15) / 16);
-#define ZL_FP8B(MT_, U_)                                                                                                                   \
+#define ZL_FP8B_(MT_, U_, P_)                                                                                                              \
     {                                                                                                                                      \
         const dim3 grid(gx, (unsigned)((m + 16 * MT_ - 1) / (16 * MT_)));                                                                  \
         ZL_DT_SWITCH(dtype,                                                                                                                \
-            hipLaunchKernelGGL((k_fp8_block_gemm<MT_, U_, ZL_F16>), grid, dim3(512), 0, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales,    \
+            hipLaunchKernelGGL((k_fp8_block_gemm<MT_, U_, ZL_F16, P_>), grid, dim3(512), 0, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales, \
                                m_indices, out, (int)m, (int)n, (int)k, num_groups),                                                        \
-            hipLaunchKernelGGL((k_fp8_block_gemm<MT_, U_, ZL_BF16>), grid, dim3(512), 0, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales,   \
+            hipLaunchKernelGGL((k_fp8_block_gemm<MT_, U_, ZL_BF16, P_>), grid, dim3(512), 0, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales, \
                                m_indices, out, (int)m, (int)n, (int)k, num_groups))                                                        \
     }
+#define ZL_FP8B(MT_, U_) { if (packed) ZL_FP8B_(MT_, U_, true) else ZL_FP8B_(MT_, U_, false) }
     // the grouped form: one 16-row tile per workgroup (neighbouring tiles may belong to different experts)
     // U = blocks a wave has in flight per round: a wave owns ceil(K / 1024) blocks, and every round pays a full memory latency, so the
     // decode shapes take them all at once when the registers allow (K = 7168: 7 blocks per wave, one round instead of two / four)
@@ -433,16 +487,17 @@ int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t
         // 17..32 rows: activations by LDS-DMA (k_fp8_block_gemm_dma; same bits) for the block counts per wave it is built for
         if ((int64_t)m * k < ((int64_t)1 << 31) && (bpw == 1 || bpw == 2 || bpw == 4 || bpw == 7 || bpw == 8)) {
             const dim3 grid(gx, (unsigned)((m + 31) / 32));
-#define ZL_FP8D(NB_)                                                                                                                        \
+#define ZL_FP8D_(NB_, P_)                                                                                                                   \
             {                                                                                                                                \
                 const int lds = 8 * (NB_ < 3 ? NB_ : 3) * 4096 + 8 * 2 * 256 * 4;                                                           \
-                const void* fn = dtype == ZL_F16 ? reinterpret_cast<const void*>(&k_fp8_block_gemm_dma<ZL_F16, NB_>)                        \
-                                                 : reinterpret_cast<const void*>(&k_fp8_block_gemm_dma<ZL_BF16, NB_>);                      \
+                const void* fn = dtype == ZL_F16 ? reinterpret_cast<const void*>(&k_fp8_block_gemm_dma<ZL_F16, NB_, P_>)                    \
+                                                 : reinterpret_cast<const void*>(&k_fp8_block_gemm_dma<ZL_BF16, NB_, P_>);                  \
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return ZL_ELIMIT;               \
                 ZL_DT_SWITCH(dtype,                                                                                                          \
-                    hipLaunchKernelGGL((k_fp8_block_gemm_dma<ZL_F16, NB_>), grid, dim3(512), lds, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales, out, (int)m, (int)n, (int)k), \
-                    hipLaunchKernelGGL((k_fp8_block_gemm_dma<ZL_BF16, NB_>), grid, dim3(512), lds, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales, out, (int)m, (int)n, (int)k)) \
+                    hipLaunchKernelGGL((k_fp8_block_gemm_dma<ZL_F16, NB_, P_>), grid, dim3(512), lds, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales, out, (int)m, (int)n, (int)k), \
+                    hipLaunchKernelGGL((k_fp8_block_gemm_dma<ZL_BF16, NB_, P_>), grid, dim3(512), lds, hs, lhs, lhs_scales, aligned_m, rhs, rhs_scales, out, (int)m, (int)n, (int)k)) \
             }
+#define ZL_FP8D(NB_) { if (packed) ZL_FP8D_(NB_, true) else ZL_FP8D_(NB_, false) }
             switch ((int)bpw) {
                 case 1: ZL_FP8D(1) break;
                 case 2: ZL_FP8D(2) break;
@@ -451,6 +506,7 @@ int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t
                 default: ZL_FP8D(8) break;
             }
 #undef ZL_FP8D
+#undef ZL_FP8D_
             return zl_launch_status();
         }
 #endif
@@ -458,6 +514,7 @@ int zl_fp8_block_gemm_group(const uint8_t* lhs, const float* lhs_scales, int64_t
         else ZL_FP8B(2, 2)
     } else ZL_FP8B(4, 1)
 #undef ZL_FP8B
+#undef ZL_FP8B_
     return zl_launch_status();
 }
 

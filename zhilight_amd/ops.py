@@ -1622,9 +1622,36 @@ def fp8_block_dequant(w8, scale, dtype=torch.bfloat16):
     return out
 
 
+class Fp8BlockMWeight:
+    """The e4m3 codes of a block-scaled weight -- (N, K) or (G, N, K) -- in the ZLF8M layout (zl_fp8_block_pack): fragment loads of
+    1 KiB contiguous.  Pass it as `w8` to fp8_block_gemm / fp8_block_linear (up to 32 rows per launch, or the grouped form)."""
+
+    def __init__(self, w8):
+        _chk_cuda(w8)
+        if w8.dtype != torch.uint8 or w8.dim() not in (2, 3):
+            raise ZLError("Fp8BlockMWeight: (N, K) or (G, N, K) uint8 codes")
+        self.groups = w8.shape[0] if w8.dim() == 3 else 1
+        self.n, self.k = w8.shape[-2], w8.shape[-1]
+        nbytes = int(lib().zl_fp8_block_packed_bytes(_i(self.n), _i(self.k), _i(self.groups)))
+        if nbytes < 0:
+            check(nbytes, "fp8_block_packed_bytes")
+        self.data = torch.empty(nbytes, dtype=torch.uint8, device=w8.device)
+        w = w8 if w8.is_contiguous() else w8.contiguous()
+        check(lib().zl_fp8_block_pack(_p(w), _p(self.data), _i(self.n), _i(self.k), _i(self.groups), _stream()), "fp8_block_pack")
+
+
 def fp8_block_gemm(a8, a_scale, w8, w_scale, m_indices=None, dtype=torch.bfloat16, out=None):
     """deep_gemm_fp8_block_h20_group: a8 (m, k) codes with column-major scales (k/128, aligned_m); w8 (n, k) or (G, n, k) codes
     with scales (ceil(n/128), k/128) or (G, ...); m_indices (m,) int32 = the expert of every row (grouped form)"""
+    if isinstance(w8, Fp8BlockMWeight):
+        _chk_cuda(a8, a_scale, w_scale, m_indices)
+        m, k = a8.shape
+        if out is None:
+            out = torch.zeros((m, w8.n), dtype=dtype, device=a8.device)
+        check(lib().zl_fp8_block_gemm_group_packed(_p(a8), _p(a_scale), _i(a_scale.shape[1]), _p(w8.data), _p(w_scale), _p(m_indices), _p(out), _i(m),
+                                                   _i(w8.n), _i(k), C.c_int(w8.groups), C.c_int(0 if out.dtype == torch.float16 else 1), _stream()),
+              "fp8_block_gemm_packed")
+        return out
     _chk_cuda(a8, a_scale, w8, w_scale, m_indices)
     m, k = a8.shape
     n = w8.shape[-2]
