@@ -837,8 +837,12 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
 // LA: the in-launch merge (zl_decode_attn_la) is compiled in and the wave count comes from the launch; without it the kernel is the
 // round-4 one -- four waves as a compile-time constant, no tail code (the batch-1 step's launch: with the runtime wave count and the
 // tail behind a branch it measured 6.95 us against 5.90, profiles/r05_decode_kernel_stats.csv history in DESIGN 5.R5)
-template <int DT, int NW = 4, bool LA = false>
-__global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(const AttnParams p) {
+// PF: chunks requested ahead of the one in use.  1 = rounds 4-5 (the next chunk's loads go out when this chunk's V rows are in LDS).
+// 2 (round 6, the in-launch-merge launches of decode batches): a second K / V register set, the chunk after next in flight as well --
+// at batch >= 8 a workgroup has its CU to itself (256 workgroups of 4 waves: one wave per SIMD), so the 64 extra VGPRs cost no
+// occupancy, and what bounded the launch was the one-chunk-ahead dependency chain, not the bytes
+template <int DT, int NW = 4, bool LA = false, int PF = 1>
+__global__ __launch_bounds__(64 * NW, PF >= 3 ? 1 : PF == 2 ? 2 : ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t vs[NW][32 * kMVS];     // 9 KB per wave (36 / 72 KB); reused for the wave merge
     const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
     const int len = p.buf_lens[b];
@@ -869,26 +873,36 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
     const size_t kv_stride = p.bshd ? (size_t)p.hkv * kMD : (size_t)kMD;
     const size_t kv_off = p.bshd ? (size_t)hk * kMD : (size_t)hk * len * kMD;
 
-    uint4 kk[2][4], vv0, vv1, vv2, vv3, vv4, vv5, vv6, vv7;
+    uint4 kkA[2][4], kkB[PF >= 2 ? 2 : 1][4], kkC[PF >= 3 ? 2 : 1][4];
+    uint4 vA0, vA1, vA2, vA3, vA4, vA5, vA6, vA7, vB0, vB1, vB2, vB3, vB4, vB5, vB6, vB7, vC0, vC1, vC2, vC3, vC4, vC5, vC6, vC7;
     int c0 = t0 + wave * 32;
+    const int cstep = nw * 32;
     // clamped, branch-free: past the end of the split the loads re-read its last row (cache hits)
-#define ZL_MFMA_LOAD_K(base)                                                                                   \
+#define ZL_MFMA_LOAD_K(KK, base)                                                                                  \
     _Pragma("unroll") for (int blk_ = 0; blk_ < 2; ++blk_) {                                                   \
         const int key_ = (base) + 16 * blk_ + r;                                                               \
         const uint16_t* src_ = kbase + kv_off + (size_t)(key_ < last_key ? key_ : last_key) * kv_stride + 8 * kq; \
-        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) kk[blk_][t_] = *reinterpret_cast<const uint4*>(src_ + 32 * t_); \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) KK[blk_][t_] = *reinterpret_cast<const uint4*>(src_ + 32 * t_); \
     }
-    // (vv as eight named registers: as an indexed array the compiler left it on the stack)
-#define ZL_MFMA_V1(j_, base)                                                                                   \
+    // (the V rows as eight NAMED registers per set -- prefix VS: as an indexed array, or as a struct, the compiler left them on the stack)
+#define ZL_MFMA_V1(VS, j_, base)                                                                                 \
     {                                                                                                          \
         const int key_ = (base) + 4 * j_ + (lane >> 4);                                                        \
-        vv##j_ = *reinterpret_cast<const uint4*>(vbase + kv_off + (size_t)(key_ < last_key ? key_ : last_key) * kv_stride + (lane & 15) * 8); \
+        VS##j_ = *reinterpret_cast<const uint4*>(vbase + kv_off + (size_t)(key_ < last_key ? key_ : last_key) * kv_stride + (lane & 15) * 8); \
     }
-#define ZL_MFMA_LOAD_V(base)                                                                                   \
-    ZL_MFMA_V1(0, base) ZL_MFMA_V1(1, base) ZL_MFMA_V1(2, base) ZL_MFMA_V1(3, base) ZL_MFMA_V1(4, base)        \
-    ZL_MFMA_V1(5, base) ZL_MFMA_V1(6, base) ZL_MFMA_V1(7, base)
-    ZL_MFMA_LOAD_K(c0)
-    ZL_MFMA_LOAD_V(c0)
+#define ZL_MFMA_LOAD_V(VS, base)                                                                               \
+    ZL_MFMA_V1(VS, 0, base) ZL_MFMA_V1(VS, 1, base) ZL_MFMA_V1(VS, 2, base) ZL_MFMA_V1(VS, 3, base) ZL_MFMA_V1(VS, 4, base) \
+    ZL_MFMA_V1(VS, 5, base) ZL_MFMA_V1(VS, 6, base) ZL_MFMA_V1(VS, 7, base)
+    ZL_MFMA_LOAD_K(kkA, c0)
+    ZL_MFMA_LOAD_V(vA, c0)
+    if constexpr (PF >= 2) {
+        ZL_MFMA_LOAD_K(kkB, c0 + cstep)
+        ZL_MFMA_LOAD_V(vB, c0 + cstep)
+    }
+    if constexpr (PF >= 3) {
+        ZL_MFMA_LOAD_K(kkC, c0 + 2 * cstep)
+        ZL_MFMA_LOAD_V(vC, c0 + 2 * cstep)
+    }
     ZL_APROBE(1);
 
     // Q^T fragments: query row m = r -> (qi, head)
@@ -914,7 +928,8 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
     const uint16_t* vtr = vsw + (4 * kq + (r >> 2)) * kMVS + 4 * (r & 3);   // transpose-read address of this lane
 
     if (c0 >= t1) c0 = -1;                             // a wave without keys: skip the loop, keep the merge
-    while (c0 >= 0) {
+    auto chunk = [&](uint4 (&KK)[2][4], uint4& v0, uint4& v1, uint4& v2, uint4& v3, uint4& v4, uint4& v5, uint4& v6, uint4& v7,
+                     const int cur) __attribute__((always_inline)) {
         // ---- S^T = K . Q^T
         f4v st[2];
 #pragma unroll
@@ -922,19 +937,17 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
             st[blk] = (f4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                st[blk] = mfma_t<DT>(kk[blk][t], qf[t], st[blk]);
+                st[blk] = mfma_t<DT>(KK[blk][t], qf[t], st[blk]);
         }
         // ---- the V chunk to LDS (row-major), then the NEXT chunk's loads: they fly during softmax and P.V
         {
             uint16_t* vdst = vsw + (lane >> 4) * kMVS + (lane & 15) * 8;
-#define ZL_MFMA_VST(j_) *reinterpret_cast<uint4*>(vdst + 4 * j_ * kMVS) = vv##j_;
+#define ZL_MFMA_VST(j_) *reinterpret_cast<uint4*>(vdst + 4 * j_ * kMVS) = v##j_;
             ZL_MFMA_VST(0) ZL_MFMA_VST(1) ZL_MFMA_VST(2) ZL_MFMA_VST(3) ZL_MFMA_VST(4) ZL_MFMA_VST(5) ZL_MFMA_VST(6) ZL_MFMA_VST(7)
 #undef ZL_MFMA_VST
         }
-        const int cur = c0;
-        c0 += nw * 32;
-        ZL_MFMA_LOAD_K(c0)
-        ZL_MFMA_LOAD_V(c0)
+        ZL_MFMA_LOAD_K(KK, cur + PF * cstep)          // this set's next chunk: PF chunks on
+        ZL_MFMA_LOAD_V(v, cur + PF * cstep)
         // ---- online softmax of query row r over this lane's 8 keys (+ the 3 other lanes of the row)
         float sv[2][4];
         float mloc = -INFINITY;
@@ -999,7 +1012,21 @@ __global__ __launch_bounds__(64 * NW, ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(
             o[db] = mfma_t<DT>(__builtin_bit_cast(uint4, a), pf, o[db]);
             o[db] = mfma_t<DT>(__builtin_bit_cast(uint4, a), pl, o[db]);
         }
+    };
+    while (c0 >= 0) {
+        chunk(kkA, vA0, vA1, vA2, vA3, vA4, vA5, vA6, vA7, c0);
+        c0 += cstep;
         if (c0 >= t1) break;
+        if constexpr (PF >= 2) {
+            chunk(kkB, vB0, vB1, vB2, vB3, vB4, vB5, vB6, vB7, c0);
+            c0 += cstep;
+            if (c0 >= t1) break;
+        }
+        if constexpr (PF >= 3) {
+            chunk(kkC, vC0, vC1, vC2, vC3, vC4, vC5, vC6, vC7, c0);
+            c0 += cstep;
+            if (c0 >= t1) break;
+        }
     }
 #undef ZL_MFMA_LOAD_K
 #undef ZL_MFMA_LOAD_V
@@ -1573,8 +1600,11 @@ int zl_decode_attn_la(const uint16_t* q, const int32_t* buf_lens, const uint16_t
         if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 8, true>), grid, dim3(512), 0, (hipStream_t)s, p);
         else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 8, true>), grid, dim3(512), 0, (hipStream_t)s, p);
     } else {
-        if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 4, true>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
-        else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 4, true>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
+#ifndef ZL_ATTN_LA_PF
+#define ZL_ATTN_LA_PF 2        // (tools/ubench/variant.sh ... -DZL_ATTN_LA_PF=1 rebuilds the one-chunk-ahead launch for A/B runs)
+#endif
+        if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 4, true, ZL_ATTN_LA_PF>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
+        else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 4, true, ZL_ATTN_LA_PF>), grid, dim3(64 * nw), 0, (hipStream_t)s, p);
     }
     return zl_launch_status();
 }
