@@ -519,6 +519,18 @@ int64_t zl_decode_attn_split_len(int64_t b, int64_t hkv, int64_t max_len_buf);
 int zl_decode_attn_splits_h(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
                             const uint16_t* const* v_bufs, const int32_t* valid_lens, void* workspace, int64_t b, int64_t h,
                             int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, zl_stream_t s);
+/* zl_decode_attn_splits_h with the reference's int8 visibility mask (one row of buf_lens[b] entries per task, concatenated: what
+ * nn::multi_query_attention_rag_buffer is handed, attention_kernel.cu:1252-1457) instead of prefix lengths: every split of the
+ * BUFFER leaves a record (a split without a visible key: a zero row, (max, sum) = (-1e20, 0)); an invisible key's K / V are never
+ * multiplied in.  The merging projection takes these records with valid_lens = buf_lens. */
+int zl_decode_attn_splits_h_mask(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
+                                 const uint16_t* const* v_bufs, const int8_t* mask, void* workspace, int64_t b, int64_t h,
+                                 int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, zl_stream_t s);
+/* The merge of the half-precision records as a launch of its own -- zl_w4a16_gemm_attn_merge_h's prologue arithmetic and order, so
+ * out (B, H, 128) fp16 holds bit for bit the rows that projection would have multiplied: for a caller whose next call turned out
+ * not to be the projection (the host library's deferred merge, hostcpp/nn_amd.cpp).  valid_lens may be NULL (mask form). */
+int zl_decode_attn_combine_h(const void* workspace, const int32_t* buf_lens, const int32_t* valid_lens, uint16_t* out, int64_t b,
+                             int64_t h, int64_t hkv, int64_t max_len_buf, zl_stream_t s);
 int zl_w4a16_gemm_attn_merge_h(const void* attn_workspace, const int32_t* buf_lens, const int32_t* valid_lens,
                                int64_t split_len, int64_t max_splits, const uint32_t* qw, const uint32_t* meta,
                                const uint16_t* bias, const uint16_t* residual, uint16_t* y, int64_t m, int64_t n, int64_t k,

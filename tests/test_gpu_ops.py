@@ -215,6 +215,57 @@ def test_decode_attention_matrix_core_path(oracle, dev, h, hkv, len_q, bshd, dty
     assert np.abs(g - exact).max() < rel * max(1.0, np.abs(exact).max()), np.abs(g - exact).max()
 
 
+@pytest.mark.parametrize("h,hkv", [(32, 8), (32, 32), (16, 1), (28, 4)])
+@pytest.mark.parametrize("bshd", [True, False])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_decode_attention_matrix_core_mask_form(oracle, dev, h, hkv, bshd, dtype):
+    """the reference's int8 visibility mask (what multi_query_attention_rag_buffer is handed, attention_kernel.cu:1252-1457), one
+    query row per task, D = 128: k_decode_attn_mfma's mask form vs the fp64 oracle -- masks with holes (beam hypotheses), prefixes,
+    a split without a visible key, a task without one; NaN in K and V of every invisible key must not leak."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(34)
+    d = 128
+    lens = [64, 33, 160, 1088, 1088, 640, 300, 1]
+    b = len(lens)
+    kb, vb, dk, dv = _make_kv(rng, lens, hkv, d, bshd, dev, dtype, oracle)
+    tdt = torch.bfloat16 if dtype else torch.float16
+    masks = []
+    for bi, L in enumerate(lens):
+        if bi == 3:
+            m = (np.arange(L) < 1025).astype(np.int8)            # a decode row's prefix
+        elif bi == 4:
+            m = (rng.random(L) < 0.5).astype(np.int8)
+            m[:300] = 0                                          # the first splits see nothing
+            m[700] = 1
+        elif bi == 6:
+            m = np.zeros(L, np.int8)                             # nothing visible: zeros (Z = 1e-20)
+        else:
+            m = (rng.random(L) < 0.7).astype(np.int8)
+            m[0] = 1
+        masks.append(m)
+        nan = np.uint16(0x7fc0 if dtype else 0x7e00)
+        pk, pv = kb[bi].copy(), vb[bi].copy()
+        if bshd:
+            pk[m == 0] = nan
+            pv[m == 0] = nan
+        else:
+            pk[:, m == 0] = nan
+            pv[:, m == 0] = nan
+        dk[bi].copy_(_t(pk.view(np.int16), dev, tdt))
+        dv[bi].copy_(_t(pv.view(np.int16), dev, tdt))
+    mask = np.concatenate(masks)
+    q = _to_bits(rng.standard_normal((b, 1, h, d)), dtype, oracle)
+    scale = 1.0 / np.sqrt(d)
+    exact = oracle.mqa_rag_buffer(q, np.array(lens, np.int32), kb, vb, mask, hkv, scale, bshd, dtype=dtype, exact=True)
+    got = ops.multi_query_attention_rag_buffer(_tt(q, dev, dtype), _t(np.array(lens, np.int32), dev), ops.make_ptr_table(dk),
+                                               ops.make_ptr_table(dv), _t(mask, dev), scale, max(lens), hkv, bshd=bshd)
+    g = oracle.to_f32(_bits(got), dtype).astype(np.float64)
+    assert np.isfinite(g).all()
+    assert not g[6].any()
+    rel = 5e-3 if dtype else 1e-3                        # bf16 output rounding is 2^-9 relative
+    assert np.abs(g - exact).max() < rel * max(1.0, np.abs(exact).max()), np.abs(g - exact).max()
+
+
 def test_decode_attention_long_split(oracle, dev):
     """L = 32768 exercises many splits + combine; checked against the fp64 oracle and against the
     reference's split-KV + combine restatement."""

@@ -214,36 +214,39 @@ def _attention_reference(oracle, km, x, pos, hist_k, hist_v, h, hkv, d, theta):
     return oracle.gptq_gemm_k_major_exact(oracle.h2u(att), *km["attn_out"]), k.reshape(-1, hkv, d), v.reshape(-1, hkv, d)
 
 
+@pytest.mark.parametrize("ntask", [3, 1])
 @pytest.mark.parametrize("h,hkv", [(8, 2), (4, 4)])
-def test_reference_attention_decode_step(ref, oracle, h, hkv):
+def test_reference_attention_decode_step(ref, oracle, h, hkv, ntask):
     """VERDICT r03 item 7: the reference's own NormalImpl::dynamic_batch_forward (attention.cpp:846-964) -> attn_search_rag (:636-741)
     runs decode steps on the GPU -- the reference's ModelContext / DynBatchContext / RagBufferContext objects, its nn::Linear
     layers, its control flow; under it the boundary's operators (gptq_gemm_k_major, rotary, copy_to_rag_buffer2,
     multi_query_attention_rag_buffer / attention_qkv_rag_buffer) and this repository's TransformerBuffer / RotaryEmbedding.  Three
     tasks with ragged histories and buffer lengths, two steps (the second attends to the row the first one wrote), against an
-    fp64 restatement with the layer's fp16 roundings."""
+    fp64 restatement with the layer's fp16 roundings.  Three tasks: the matrix-core kernel's mask form + the merge launch; ONE task:
+    the attention launch leaves half-precision split records and the reference's attn_out.forward merges them in its GEMV's prologue
+    (bm_hip.h DeferredOp kind 3)."""
     rng = np.random.default_rng(31 + h)
     dm, d, theta = 1024, 128, 5e5
     sd, km = _attn_case(oracle, rng, dm, h, hkv, d)
     ref.weight_cache_clear()
     layer = ref.RefAttention(dm, h, hkv, d, rope_theta=theta, num_layers=2)
     layer.load(sd, "a")
-    lens, bufs = [5, 40, 17], [64, 96, 64]
+    lens, bufs = ([5, 40, 17], [64, 96, 64]) if ntask == 3 else ([150], [320])
     hist_k = [(rng.standard_normal((n, hkv, d)) * 0.5).astype(np.float16) for n in lens]
     hist_v = [(rng.standard_normal((n, hkv, d)) * 0.5).astype(np.float16) for n in lens]
-    for b in range(3):
+    for b in range(ntask):
         layer.set_history(b, 1, bufs[b], hist_k[b], hist_v[b])
     pos = np.array(lens, np.int32)
     for step in range(2):
-        x = synth.act(rng, 3, dm)
-        mask = np.concatenate([(np.arange(bufs[b]) <= pos[b]).astype(np.int8) for b in range(3)])
+        x = synth.act(rng, ntask, dm)
+        mask = np.concatenate([(np.arange(bufs[b]) <= pos[b]).astype(np.int8) for b in range(ntask)])
         got = layer.decode_step(1, x, pos, pos.copy(), mask).astype(np.float64)
         want, new_k, new_v = _attention_reference(oracle, km, x, pos, hist_k, hist_v, h, hkv, d, theta)
-        assert got.shape == (3, dm) and np.isfinite(got).all()
+        assert got.shape == (ntask, dm) and np.isfinite(got).all()
         err = np.abs(got - want).max() / np.abs(want).max()
-        print("reference attention decode step", h, hkv, step, "err", err)
+        print("reference attention decode step", h, hkv, ntask, step, "err", err)
         assert err <= UNIT_BAR, (step, err)
-        for b in range(3):      # the new key / value rows sit at their placement in the reference's buffers, everything else untouched
+        for b in range(ntask):  # the new key / value rows sit at their placement in the reference's buffers, everything else untouched
             kb, vb = layer.get_k(b, 1), layer.get_v(b, 1)
             assert kb.shape == (bufs[b], hkv, d)
             assert np.abs(kb[pos[b]].astype(np.float64) - new_k[b].astype(np.float64)).max() <= 2.0 ** -9 * np.abs(new_k[b].astype(np.float64)).max()

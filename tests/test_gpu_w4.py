@@ -680,6 +680,76 @@ def test_attention_split_merge_in_attn_out_projection(oracle, dev, b, h, hkv, n,
         assert abs(diff.mean().item()) <= 0.05 * tol
 
 
+@pytest.mark.parametrize("b,h,hkv,n,lens", [
+    (1, 32, 8, 4096, [1088]),
+    (1, 16, 4, 2048 + 16, [2048]),
+    (3, 32, 8, 4096, [640, 128, 1088]),
+    (4, 32, 4, 8192, [256, 192, 33, 256]),
+])
+@pytest.mark.parametrize("mode", ["holes", "prefix"])
+def test_attention_mask_form_split_records_merge(oracle, dev, b, h, hkv, n, lens, mode):
+    """The reference's int8 visibility mask on the split-record route the host library defers (hostcpp/nn_amd.cpp, DeferredOp kind 3):
+    zl_decode_attn_splits_h_mask leaves half records of every split of the buffer; their stand-alone merge (zl_decode_attn_combine_h)
+    against the fp64 oracle (the records pass through fp16 once: 2^-10 of the largest row on top of the 1e-3 bar), and the merging
+    projection (zl_w4a16_gemm_attn_merge_h with valid_lens = buf_lens) bit for bit against the plain projection of those merged rows --
+    whichever the next call turns out to be, the layer sees the same bits.  NaN in K / V of every invisible key must not leak."""
+    from zhilight_amd import ops
+    rng = np.random.default_rng(700 + b + n)
+    d, g, k = 128, 128, h * 128
+    n8 = (n + 7) // 8 * 8
+    qw, qz, sc = synth.gptq_hf(rng, k, n8, g)
+    km = tuple(np.ascontiguousarray(a[:n]) for a in oracle.gptq_prepare_k_major(qw, qz, sc, g))
+    w = ops.W4MWeight.from_k_major(_t(km[0].view(np.int32), dev), _t(km[1], dev), _t(km[2], dev, torch.float16), g)
+    max_len = max(lens)
+    kh = [rng.standard_normal((L, hkv, d)).astype(np.float16) for L in lens]
+    vh = [rng.standard_normal((L, hkv, d)).astype(np.float16) for L in lens]
+    masks = []
+    for i, L in enumerate(lens):
+        if mode == "prefix":
+            m = (np.arange(L) < max(1, L - 63)).astype(np.int8)
+        else:
+            m = (rng.random(L) < 0.6).astype(np.int8)
+            m[: min(L // 2, 300)] = 0                          # whole splits without a visible key
+            m[L - 1] = 1
+        masks.append(m)
+    mask = np.concatenate(masks)
+    dk, dv = [], []
+    for i, L in enumerate(lens):                               # the device copies carry NaN where nothing may be read
+        pk, pv = kh[i].copy(), vh[i].copy()
+        pk[masks[i] == 0] = np.nan
+        pv[masks[i] == 0] = np.nan
+        dk.append(_t(pk, dev))
+        dv.append(_t(pv, dev))
+    qh = rng.standard_normal((b, 1, h, d)).astype(np.float16)
+    q = _t(qh, dev)
+    bl = _t(np.array(lens, np.int32), dev)
+    ka, va = ops.make_ptr_table(dk), ops.make_ptr_table(dv)
+    scale = 1.0 / np.sqrt(d)
+    exact = oracle.mqa_rag_buffer(qh.view(np.uint16), np.array(lens, np.int32), [a.view(np.uint16) for a in kh], [a.view(np.uint16) for a in vh],
+                                  mask, hkv, scale, True, exact=True)
+    import os
+    os.environ["ZL_ATTN_MERGE_MAX_B"] = "4"
+    try:
+        plan = ops.attn_merge_plan(b, h, hkv, d, max_len, w)
+    finally:
+        del os.environ["ZL_ATTN_MERGE_MAX_B"]
+    assert plan is not None and plan[2]
+    ws = ops.decode_attn_workspace(b, 1, h, d, max_len, dev)
+    ws.fill_(float("nan"))
+    ops.decode_attention_splits_mask(q, bl, ka, va, _t(mask, dev), scale, max_len, hkv, ws)
+    att = ops.decode_attention_combine_h(ws, bl, None, b, h, hkv, max_len)
+    ga = att.float().cpu().numpy().astype(np.float64)
+    assert np.isfinite(ga).all()
+    top = max(1.0, np.abs(exact).max())
+    assert np.abs(ga - exact.reshape(ga.shape)).max() < (1e-3 + 2.0 ** -10) * top, np.abs(ga - exact.reshape(ga.shape)).max()
+    res = torch.randn(b, n, device=dev).half()
+    want = ops.w4a16_gemm_mfma(att.view(b, k), w)
+    want_res = ops.w4a16_gemm_mfma(att.view(b, k), w, residual=res, epilogue=ops.EPI_RESIDUAL)
+    got = ops.w4_attn_out_merge(ws, bl, bl, plan, b, w)
+    got_res = ops.w4_attn_out_merge(ws, bl, bl, plan, b, w, residual=res, epilogue=ops.EPI_RESIDUAL)
+    assert torch.equal(got, want) and torch.equal(got_res, want_res)
+
+
 def test_attention_split_merge_plan_limits(dev):
     from zhilight_amd import ops
     from zhilight_amd._lib import ZLError

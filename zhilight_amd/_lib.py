@@ -33,7 +33,7 @@ SYMBOLS = [
     "zl_gemm_nt_small_m", "zl_gemm_nt", "zl_gemm_nt_f32", "zl_argmax_workspace_bytes", "zl_gemm_nt_small_m_argmax", "zl_greedy_advance",
     "zl_rmsnorm",
     "zl_w4a16_moe_up", "zl_w4a16_moe_down", "zl_rope_cos_sin", "zl_rope_cos_sin_llama3", "zl_rope_cos_sin_dynamic", "zl_rope_cos_sin_yarn", "zl_head_norm", "zl_rotary_embedding_qk", "zl_rope_qk_cache", "zl_rope_rotate", "zl_mask_valid_lens",
-    "zl_copy_to_rag_buffer2", "zl_copy_to_rag_buffer_bytes", "zl_rope_scatter_decode", "zl_w4a16_qkv_rope_scatter", "zl_w4a16_qkv_rope_scatter_ex", "zl_decode_attn_splits_h", "zl_w4a16_gemm_attn_merge_h", "zl_w4a16_gemm_attn_merge_h_ex",
+    "zl_copy_to_rag_buffer2", "zl_copy_to_rag_buffer_bytes", "zl_rope_scatter_decode", "zl_w4a16_qkv_rope_scatter", "zl_w4a16_qkv_rope_scatter_ex", "zl_decode_attn_splits_h", "zl_decode_attn_splits_h_mask", "zl_decode_attn_combine_h", "zl_w4a16_gemm_attn_merge_h", "zl_w4a16_gemm_attn_merge_h_ex",
     "zl_quant_group_32", "zl_dequant_sum_quant_g32", "zl_dequant_group_32",
     "zl_fp8_calc_scale", "zl_fp8_cvt_half", "zl_fp8_gemm_nt",
     "zl_decode_attn_workspace_bytes", "zl_decode_attn", "zl_decode_attn_ex", "zl_decode_attn_fused",

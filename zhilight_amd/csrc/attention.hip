@@ -841,12 +841,24 @@ __device__ __forceinline__ void attn_tail_la(const AttnParams& p, float* xw, int
 // 2 (round 6, the in-launch-merge launches of decode batches): a second K / V register set, the chunk after next in flight as well --
 // at batch >= 8 a workgroup has its CU to itself (256 workgroups of 4 waves: one wave per SIMD), so the 64 extra VGPRs cost no
 // occupancy, and what bounded the launch was the one-chunk-ahead dependency chain, not the bytes
-template <int DT, int NW = 4, bool LA = false, int PF = 1>
-__global__ __launch_bounds__(64 * NW, PF >= 3 ? 1 : PF == 2 ? 2 : ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(const AttnParams p) {
+// MASKED (one query row per task, the reference's int8 visibility row instead of a prefix length -- what
+// multi_query_attention_rag_buffer is handed, attention_kernel.cu:1252-1457): every key of the buffer is walked, a chunk's 32
+// visibility bytes travel with its K / V loads (one byte per lane) and become a wave-uniform 32-bit word by ballot; an invisible
+// key scores -inf AND its V row is zeroed before the product (a buffer's tail is not initialised: 0 x NaN must not reach the MFMA).
+template <int DT, int NW = 4, bool LA = false, int PF = 1, bool MASKED = false>
+__global__ __launch_bounds__(64 * NW, PF >= 3 ? 1 : (PF == 2 || MASKED) ? 2 : ZL_ATTN8_OCC(NW)) void k_decode_attn_mfma(const AttnParams p) {
+    // (MASKED: two workgroups per SIMD set -- under the prefix form's 128-register budget the visibility word sent the V set to scratch)
+    static_assert(!MASKED || (!LA && PF == 1), "the mask form exists for the two-launch route only");
     __shared__ __attribute__((aligned(16))) uint16_t vs[NW][32 * kMVS];     // 9 KB per wave (36 / 72 KB); reused for the wave merge
     const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
     const int len = p.buf_lens[b];
-    const int vlen_in = p.valid_lens[b];
+    const int vlen_in = MASKED ? 0x7fffffff : p.valid_lens[b];
+    const int8_t* mrow = nullptr;
+    if constexpr (MASKED) {
+        size_t mask_off = 0;
+        for (int i = 0; i < b; ++i) mask_off += (size_t)p.buf_lens[i];
+        mrow = p.mask + mask_off;                        // len_q == 1: one row of len entries per task
+    }
     const uint16_t* kbase = p.k_bufs[b];
     const uint16_t* vbase = p.v_bufs[b];
     const int elen = min(len, vlen_in);
@@ -893,6 +905,13 @@ __global__ __launch_bounds__(64 * NW, PF >= 3 ? 1 : PF == 2 ? 2 : ZL_ATTN8_OCC(N
 #define ZL_MFMA_LOAD_V(VS, base)                                                                               \
     ZL_MFMA_V1(VS, 0, base) ZL_MFMA_V1(VS, 1, base) ZL_MFMA_V1(VS, 2, base) ZL_MFMA_V1(VS, 3, base) ZL_MFMA_V1(VS, 4, base) \
     ZL_MFMA_V1(VS, 5, base) ZL_MFMA_V1(VS, 6, base) ZL_MFMA_V1(VS, 7, base)
+    int mbA = 1, mbX = 1;                                 // MASKED: this lane's visibility byte of the set's chunk (lanes 0..31)
+#define ZL_MFMA_LOAD_M(MB, base)                                                                               \
+    if constexpr (MASKED) {                                                                                    \
+        const int key_ = (base) + (lane & 31);                                                                 \
+        MB = mrow[key_ < last_key ? key_ : last_key];                                                          \
+    }
+    ZL_MFMA_LOAD_M(mbA, c0)                               // first: loads return in order, the ballot must not wait for K and V
     ZL_MFMA_LOAD_K(kkA, c0)
     ZL_MFMA_LOAD_V(vA, c0)
     if constexpr (PF >= 2) {
@@ -929,7 +948,15 @@ __global__ __launch_bounds__(64 * NW, PF >= 3 ? 1 : PF == 2 ? 2 : ZL_ATTN8_OCC(N
 
     if (c0 >= t1) c0 = -1;                             // a wave without keys: skip the loop, keep the merge
     auto chunk = [&](uint4 (&KK)[2][4], uint4& v0, uint4& v1, uint4& v2, uint4& v3, uint4& v4, uint4& v5, uint4& v6, uint4& v7,
-                     const int cur) __attribute__((always_inline)) {
+                     int& MB, const int cur) __attribute__((always_inline)) {
+        uint32_t vbits = 0xffffffffu;                  // bit j: key cur + j is visible
+        if constexpr (MASKED) {
+            vbits = (uint32_t)__ballot(lane < 32 && MB != 0 && cur + lane < t1);
+            const int vsh = lane >> 4;
+#define ZL_MFMA_VZ(j_) if (!((vbits >> (4 * j_ + vsh)) & 1u)) v##j_ = make_uint4(0, 0, 0, 0);
+            ZL_MFMA_VZ(0) ZL_MFMA_VZ(1) ZL_MFMA_VZ(2) ZL_MFMA_VZ(3) ZL_MFMA_VZ(4) ZL_MFMA_VZ(5) ZL_MFMA_VZ(6) ZL_MFMA_VZ(7)
+#undef ZL_MFMA_VZ
+        }
         // ---- S^T = K . Q^T
         f4v st[2];
 #pragma unroll
@@ -946,6 +973,7 @@ __global__ __launch_bounds__(64 * NW, PF >= 3 ? 1 : PF == 2 ? 2 : ZL_ATTN8_OCC(N
             ZL_MFMA_VST(0) ZL_MFMA_VST(1) ZL_MFMA_VST(2) ZL_MFMA_VST(3) ZL_MFMA_VST(4) ZL_MFMA_VST(5) ZL_MFMA_VST(6) ZL_MFMA_VST(7)
 #undef ZL_MFMA_VST
         }
+        ZL_MFMA_LOAD_M(MB, cur + PF * cstep)
         ZL_MFMA_LOAD_K(KK, cur + PF * cstep)          // this set's next chunk: PF chunks on
         ZL_MFMA_LOAD_V(v, cur + PF * cstep)
         // ---- online softmax of query row r over this lane's 8 keys (+ the 3 other lanes of the row)
@@ -956,7 +984,9 @@ __global__ __launch_bounds__(64 * NW, PF >= 3 ? 1 : PF == 2 ? 2 : ZL_ATTN8_OCC(N
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int key = cur + 16 * blk + 4 * kq + i;
-                sv[blk][i] = key < t1 ? st[blk][i] * p.scale : -INFINITY;
+                bool vis = key < t1;
+                if constexpr (MASKED) vis = (vbits >> (16 * blk + 4 * kq + i)) & 1u;      // the ballot already holds key < t1
+                sv[blk][i] = vis ? st[blk][i] * p.scale : -INFINITY;
                 mloc = fmaxf(mloc, sv[blk][i]);
             }
         }
@@ -1014,22 +1044,23 @@ __global__ __launch_bounds__(64 * NW, PF >= 3 ? 1 : PF == 2 ? 2 : ZL_ATTN8_OCC(N
         }
     };
     while (c0 >= 0) {
-        chunk(kkA, vA0, vA1, vA2, vA3, vA4, vA5, vA6, vA7, c0);
+        chunk(kkA, vA0, vA1, vA2, vA3, vA4, vA5, vA6, vA7, mbA, c0);
         c0 += cstep;
         if (c0 >= t1) break;
         if constexpr (PF >= 2) {
-            chunk(kkB, vB0, vB1, vB2, vB3, vB4, vB5, vB6, vB7, c0);
+            chunk(kkB, vB0, vB1, vB2, vB3, vB4, vB5, vB6, vB7, mbX, c0);
             c0 += cstep;
             if (c0 >= t1) break;
         }
         if constexpr (PF >= 3) {
-            chunk(kkC, vC0, vC1, vC2, vC3, vC4, vC5, vC6, vC7, c0);
+            chunk(kkC, vC0, vC1, vC2, vC3, vC4, vC5, vC6, vC7, mbX, c0);
             c0 += cstep;
             if (c0 >= t1) break;
         }
     }
 #undef ZL_MFMA_LOAD_K
 #undef ZL_MFMA_LOAD_V
+#undef ZL_MFMA_LOAD_M
 #undef ZL_MFMA_V1
 
     // ---- merge: the row's normaliser lives in 4 lanes; then the waves through LDS (aliases the V staging)
@@ -1075,7 +1106,8 @@ __global__ __launch_bounds__(64 * NW, PF >= 3 ? 1 : PF == 2 ? 2 : ZL_ATTN8_OCC(N
         const size_t rec = (((size_t)b * p.len_q + qi) * p.h + head) * p.max_splits + split;
         if (p.half_partials) {
             uint16_t* hp = reinterpret_cast<uint16_t*>(p.ws);
-            hp[rec * kMD + d] = __builtin_bit_cast(uint16_t, (_Float16)(a / lt));      // lt >= 1: the split's largest score gives exp(0)
+            // lt >= 1: the split's largest score gives exp(0) -- except, in the mask form, a split without a visible key (lt = 0)
+            hp[rec * kMD + d] = __builtin_bit_cast(uint16_t, (_Float16)((MASKED && lt == 0.f) ? 0.f : a / lt));
             if (d == 0) {
                 float* st = p.ws + (size_t)p.b * p.len_q * p.h * p.max_splits * (kMD / 2) + rec * 2;
                 st[0] = mn;
@@ -1369,6 +1401,29 @@ __global__ void k_decode_attn_combine(const AttnParams p) {
     p.out[(size_t)vh * D + d] = ZT<DT>::from_f32(a / (z + 1e-20f));
 }
 
+// The merge of HALF-PRECISION split records (zl_decode_attn_splits_h[_mask]'s format) as a launch of its own: the arithmetic and the
+// order of the merging projection's prologue (w4_i8p.hip MERGE), so a caller whose projection did not take the records over gets the
+// rows that projection would have read.  grid (B * H), block 128; p.valid_lens may be null (mask form: every split of the buffer).
+__global__ __launch_bounds__(kMD) void k_decode_attn_combine_h(const AttnParams p) {
+    const int vh = blockIdx.x, b = vh / p.h, d = threadIdx.x;
+    const int len = p.buf_lens[b];
+    const int elen = p.valid_lens ? min(len, p.valid_lens[b]) : len;
+    const int ns = min((elen + p.split_len - 1) / p.split_len, p.max_splits);
+    const uint16_t* part = reinterpret_cast<const uint16_t*>(p.ws) + (size_t)vh * p.max_splits * kMD;
+    const float2* stat = reinterpret_cast<const float2*>(p.ws + (size_t)p.b * p.h * p.max_splits * (kMD / 2)) + (size_t)vh * p.max_splits;
+    float mn = -1e20f;
+    for (int u = 0; u < ns; ++u) mn = fmaxf(mn, stat[u].x);
+    float a = 0.f, z = 0.f;
+    for (int u = 0; u < ns; ++u) {
+        const float2 st = stat[u];
+        const float f = st.y * __expf(st.x - mn);
+        a = __builtin_fmaf((float)__builtin_bit_cast(_Float16, part[(size_t)u * kMD + d]), f, a);
+        z += f;
+    }
+    const float zi = 1.0f / (z + 1e-20f);
+    p.out[(size_t)vh * kMD + d] = __builtin_bit_cast(uint16_t, zl_f32_to_f16(a * zi));
+}
+
 template <int DT, int D, bool FUSE>
 int launch_d(const AttnParams& p, hipStream_t st) {
     dim3 grid((unsigned)p.max_splits, (unsigned)p.hkv, (unsigned)(p.b * p.passes));
@@ -1452,10 +1507,14 @@ int zl_decode_attn_ex(const uint16_t* q, const int32_t* buf_lens, const uint16_t
     p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
     p.k_scales = p.v_scales = nullptr; p.half_partials = 0; p.la = 0; p.la_cnt = nullptr;
     {   // decode fast path on the matrix cores: all query rows of a kv head in one 16-row MFMA block
-        if (algo != 1 && !mask && d == kMD && p.rows <= 16) {
+        // with the reference's visibility mask instead of prefix lengths: the same kernel's mask form, for one query row per task
+        if (algo != 1 && (!mask || (len_q == 1 && !valid_lens)) && d == kMD && p.rows <= 16) {
             p.passes = 1;
             const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
-            if (dtype == ZL_F16) hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, hs, p);
+            if (mask) {
+                if (dtype == ZL_F16) hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 4, false, 1, true>), grid, dim3(256), 0, hs, p);
+                else hipLaunchKernelGGL((k_decode_attn_mfma<ZL_BF16, 4, false, 1, true>), grid, dim3(256), 0, hs, p);
+            } else if (dtype == ZL_F16) hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, hs, p);
             else hipLaunchKernelGGL(k_decode_attn_mfma<ZL_BF16>, grid, dim3(256), 0, hs, p);
             int e = zl_launch_status();
             if (e) return e;
@@ -1523,6 +1582,46 @@ int zl_decode_attn_splits_h(const uint16_t* q, const int32_t* buf_lens, const ui
     p.k_scales = p.v_scales = nullptr; p.half_partials = 1; p.la = 0; p.la_cnt = nullptr;
     const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
     hipLaunchKernelGGL(k_decode_attn_mfma<ZL_F16>, grid, dim3(256), 0, (hipStream_t)s, p);
+    return zl_launch_status();
+}
+
+int zl_decode_attn_splits_h_mask(const uint16_t* q, const int32_t* buf_lens, const uint16_t* const* k_bufs,
+                                 const uint16_t* const* v_bufs, const int8_t* mask, void* workspace, int64_t b, int64_t h,
+                                 int64_t hkv, int64_t d, float scale, int64_t max_len_buf, int bshd, zl_stream_t s) {
+    ZL_CHECK_ARG(q && buf_lens && k_bufs && v_bufs && mask && workspace, ZL_EINVAL);
+    ZL_CHECK_ARG(b > 0 && h > 0 && hkv > 0 && d > 0 && max_len_buf > 0, ZL_EINVAL);
+    ZL_CHECK_ARG(h % hkv == 0 && d == kMD && h / hkv <= 16 && b <= 65535 && hkv <= 65535, ZL_ESHAPE);   // the matrix-core kernel
+    AttnParams p;
+    p.q = q; p.buf_lens = buf_lens; p.k_bufs = k_bufs; p.v_bufs = v_bufs; p.mask = mask; p.valid_lens = nullptr;
+    p.out = nullptr; p.ws = (float*)workspace;
+    p.b = (int)b; p.len_q = 1; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv);
+    p.rows = p.n_rep; p.passes = 1;
+    p.split_len = attn_split_len(b, hkv, max_len_buf);
+    p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
+    p.scale = scale; p.bshd = bshd;
+    p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 1; p.la = 0; p.la_cnt = nullptr;
+    const dim3 grid((unsigned)p.max_splits, (unsigned)hkv, (unsigned)b);
+    hipLaunchKernelGGL((k_decode_attn_mfma<ZL_F16, 4, false, 1, true>), grid, dim3(256), 0, (hipStream_t)s, p);
+    return zl_launch_status();
+}
+
+int zl_decode_attn_combine_h(const void* workspace, const int32_t* buf_lens, const int32_t* valid_lens, uint16_t* out, int64_t b,
+                             int64_t h, int64_t hkv, int64_t max_len_buf, zl_stream_t s) {
+    ZL_CHECK_ARG(workspace && buf_lens && out, ZL_EINVAL);
+    ZL_CHECK_ARG(b > 0 && h > 0 && hkv > 0 && max_len_buf > 0, ZL_EINVAL);
+    AttnParams p;
+    p.q = nullptr; p.buf_lens = buf_lens; p.k_bufs = p.v_bufs = nullptr; p.mask = nullptr; p.valid_lens = valid_lens;
+    p.out = out; p.ws = (float*)const_cast<void*>(workspace);
+    p.b = (int)b; p.len_q = 1; p.h = (int)h; p.hkv = (int)hkv; p.n_rep = (int)(h / hkv); p.rows = p.n_rep; p.passes = 1;
+    p.split_len = attn_split_len(b, hkv, max_len_buf);
+    p.max_splits = (int)((max_len_buf + p.split_len - 1) / p.split_len);
+    ZL_CHECK_ARG(p.max_splits <= kMaxSplits, ZL_ELIMIT);
+    p.scale = 0.f; p.bshd = 1;
+    p.qkv = nullptr; p.cosv = p.sinv = nullptr; p.placement = nullptr; p.k_bufs_w = p.v_bufs_w = nullptr; p.neox = 1;
+    p.k_scales = p.v_scales = nullptr; p.half_partials = 1; p.la = 0; p.la_cnt = nullptr;
+    hipLaunchKernelGGL(k_decode_attn_combine_h, dim3((unsigned)(b * h)), dim3(kMD), 0, (hipStream_t)s, p);
     return zl_launch_status();
 }
 

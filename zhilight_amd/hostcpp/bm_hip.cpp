@@ -186,7 +186,7 @@ bool boundary_fusion_enabled() {
 }
 void defer_op(DeferredOp&& op) {
     prune_dead();
-    while (tl_deferred.size() >= 4) {                 // a handful at most: the oldest goes out as an ordinary launch
+    while (tl_deferred.size() >= 6) {                 // a handful at most: the oldest goes out as an ordinary launch
         DeferredOp d = std::move(tl_deferred.front());
         tl_deferred.erase(tl_deferred.begin());
         tl_flushing = true;

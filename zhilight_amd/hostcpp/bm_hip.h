@@ -114,8 +114,9 @@ typedef std::shared_ptr<Stream_> Stream;
 //   * a result nobody ever reads dies with its tensor: the op holds only a weak token of the result's block and is dropped, unlaunched,
 //     once that expires (checked whenever the list is consulted);
 //   * per thread (a Context is bound to its thread), a handful of entries; ZL_BOUNDARY_FUSE=0 turns deferral off.
+class Context;
 struct DeferredOp {
-    int kind = 0;                                     // 1: RMSNorm rows -> y      2: W4A16 linear -> y
+    int kind = 0;                                     // 1: RMSNorm rows -> y      2: W4A16 linear -> y      3: decode attention split merge -> y
     const void* y = nullptr;                          // where the result belongs
     size_t y_bytes = 0;
     const void* x = nullptr;                          // the input a late launch reads
@@ -135,6 +136,16 @@ struct DeferredOp {
     std::function<bool(const float* cosv, const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
                        uint16_t* const* v_bufs, uint16_t* q_out, int64_t h, int64_t hkv, int64_t d)> launch_rope;
     int64_t m = 0, n = 0;
+    // ... or as the fused gate|up projection with the activation in its epilogue: out (m, n / 2) = silu(y[:, :n/2]) * y[:, n/2:] from a
+    // row-interleaved packing of the same weight (made once, cached by the weight's identity) -- what functions::gate_fuse computes
+    // from y, bit for bit (feedforward.cpp:107-170 under CPM_FUSE_FF_IN); returns false when the kernels do not cover the case
+    std::function<bool(const Context& ctx, uint16_t* out)> launch_gated;
+    // kind 3: the half-precision split records of a decode attention launch that has ALREADY run (zl_decode_attn_splits_h_mask); what is
+    // held back is only their merge -- the attention output projection takes the records over in its prologue (zl_w4a16_gemm_attn_merge_h),
+    // `launch` is the stand-alone merge (zl_decode_attn_combine_h, the same arithmetic).  rows = tasks, dim = heads x 128; x = the records.
+    const int32_t* attn_buf_lens = nullptr;
+    int64_t split_len = 0, max_splits = 0;
+    std::shared_ptr<void> keep;                       // the records' and the lengths' blocks, for whoever takes the op over
 };
 bool boundary_fusion_enabled();
 void defer_op(DeferredOp&& op);

@@ -198,8 +198,10 @@ Tensor dequant_k_major(const Context& ctx, const Tensor& q_weight, const Tensor&
 
 // the packed form of a raw k-major weight, re-tiled on first sight (see nn_amd.h); sym: every zero point is 8
 // (q_gemm_k_major.cu:148-150)
-static PackedW4 cached_pack(const Context& ctx, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales, bool sym) {
-    const WeightKey key = make_key(sym ? 4 : 0, q_weight.size(0), q_weight.size(1) * 8, {&q_weight, &qzeros, &scales});
+// gated: the row-interleaved packing (row 2 j = gate j, row 2 j + 1 = up j of a [gate; up] weight) the ZL_EPI_SILU_MUL epilogue reads --
+// a second packed copy next to the plain one, made when functions::gate_fuse first meets this weight's deferred launch
+static PackedW4 cached_pack(const Context& ctx, const Tensor& q_weight, const Tensor& qzeros, const Tensor& scales, bool sym, bool gated = false) {
+    const WeightKey key = make_key((sym ? 4 : 0) | (gated ? 8 : 0), q_weight.size(0), q_weight.size(1) * 8, {&q_weight, &qzeros, &scales});
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         auto it = g_cache.find(key);
@@ -212,7 +214,7 @@ static PackedW4 cached_pack(const Context& ctx, const Tensor& q_weight, const Te
     }
     WeightEntry e;
     e.raw = {q_weight, qzeros, scales};
-    e.w4 = amd_pack_k_major(ctx, q_weight, zeros, scales);
+    e.w4 = amd_pack_k_major(ctx, q_weight, zeros, scales, gated);
     std::lock_guard<std::mutex> lk(g_cache_mu);
     return g_cache.emplace(key, std::move(e)).first->second.w4;
 }
@@ -246,6 +248,16 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a0, const Tensor& q_w
         const bool norm_ok = nd && nd->rows == m && nd->dim == k && k <= 4096 && nd->stream == ctx.current_cuda_stream();
         if (nd && !norm_ok) nd = nullptr;              // (touching a0 below launches it the ordinary way)
         if (nd) nd->consumed = true;
+        // ... or the rows are a decode attention's split records whose merge has not been launched (kind 3): this GEMV's merge prologue
+        bmengine::core::DeferredOp* ad = nd ? nullptr : bmengine::core::find_deferred(a0.nullable_data(), 3);
+        if (ad) {                                      // what zl_w4a16_gemm_attn_merge_h covers (ops.attn_merge_plan's conditions)
+            int cus = zl_device_cu_count();
+            if (cus <= 0) cus = 256;
+            if (!(ad->rows == m && ad->dim == k && m <= 4 && k <= 4096 && g == 128 && ad->max_splits <= 16 && (n + 15) / 16 <= 2 * (int64_t)cus &&
+                  ad->stream == ctx.current_cuda_stream() && a0.dtype() == DataType::kHalf))
+                ad = nullptr;                          // (touching a0 below launches the stand-alone merge)
+        }
+        if (ad) ad->consumed = true;
         BM_ASSERT(!raw || scales.dtype() == DataType::kHalf, "scales must be half");
         const PackedW4 p = raw ? cached_pack(ctx, q_weight, qzeros, scales, sym) : PackedW4{q_weight, Tensor(), scales};
         std::vector<size_t> oshape = a0.shape();
@@ -254,12 +266,24 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a0, const Tensor& q_w
         BM_ASSERT_EQ(out.numel(), (size_t)(m * n), "output shape mismatch");
         const uint16_t* bptr = bias && bias->numel() ? u16(*bias) : nullptr;
         const zl_w4_opts_t opts = w4_opts(ctx, m, n);
-        const uint16_t* xin = (const uint16_t*)(nd ? nd->x : a0.data());
+        const uint16_t* xin = (const uint16_t*)(nd ? nd->x : ad ? nullptr : a0.data());
+        const void* mg_rec = ad ? ad->x : nullptr;
+        const int32_t* mg_lens = ad ? ad->attn_buf_lens : nullptr;
+        const int64_t mg_sl = ad ? ad->split_len : 0, mg_ms = ad ? ad->max_splits : 0;
+        const std::shared_ptr<void> mg_keep = ad ? ad->keep : nullptr;
         const uint16_t* nw = nd ? nd->norm_w : nullptr;
         const float eps = nd ? nd->eps : 0.f;
         const Tensor keep_q = p.q_weight, keep_s = p.scales, keep_a = a0, keep_b = bias ? *bias : Tensor();
         const hipStream_t st = ctx.current_cuda_stream();
         auto launch_into = [=](const uint16_t* residual, uint16_t* dst) {
+            if (mg_rec) {      // every split of the buffer left a record (mask form): valid_lens = buf_lens
+                zl_check(zl_w4a16_gemm_attn_merge_h_ex(mg_rec, mg_lens, mg_lens, mg_sl, mg_ms, (const uint32_t*)keep_q.nullable_data(),
+                                                       (const uint32_t*)keep_s.nullable_data(), bptr, residual, dst, m, n, k, g,
+                                                       (bptr ? ZL_EPI_BIAS : 0) | (residual ? ZL_EPI_RESIDUAL : 0), &opts, (zl_stream_t)st),
+                         "gptq_gemm_k_major (boundary fusion: attention merge prologue)");
+                (void)mg_keep; (void)keep_a; (void)keep_b;
+                return;
+            }
             zl_check(zl_w4a16_gemm_mfma_ex(xin, k, (const uint32_t*)keep_q.nullable_data(), (const uint32_t*)keep_s.nullable_data(), bptr, residual, dst, m,
                                            n, k, g, nw, eps, (bptr ? ZL_EPI_BIAS : 0) | (residual ? ZL_EPI_RESIDUAL : 0), &opts, (zl_stream_t)st),
                      "gptq_gemm_k_major (boundary fusion)");
@@ -271,7 +295,7 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a0, const Tensor& q_w
         bmengine::core::DeferredOp d;
         d.kind = 2;
         d.y = out.nullable_data(); d.y_bytes = out.nbytes();
-        d.x = nd ? nd->x : a0.nullable_data(); d.x_bytes = a0.nbytes();
+        d.x = nd ? nd->x : ad ? ad->x : a0.nullable_data(); d.x_bytes = ad ? ad->x_bytes : a0.nbytes();
         d.y_alive = out.storage_token();
         d.stream = st;
         d.m = m; d.n = n;
@@ -280,7 +304,7 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a0, const Tensor& q_w
         d.launch = [launch_into, yp]() { launch_into(nullptr, yp); };
         d.launch_rope = [=](const float* cosv, const float* sinv, const int32_t* placement, const int32_t* buf_lens, uint16_t* const* k_bufs,
                             uint16_t* const* v_bufs, uint16_t* q_out, int64_t h, int64_t hkv, int64_t dh) -> bool {
-            if ((h + 2 * hkv) * dh != n) return false;
+            if ((h + 2 * hkv) * dh != n || mg_rec) return false;
             const int st_ = zl_w4a16_qkv_rope_scatter_ex(xin, k, (const uint32_t*)keep_q.nullable_data(), (const uint32_t*)keep_s.nullable_data(), bptr, nw,
                                                          eps, cosv, sinv, placement, buf_lens, k_bufs, v_bufs, q_out, m, h, hkv, dh, k, g, 1, &opts,
                                                          (zl_stream_t)st);
@@ -289,6 +313,18 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a0, const Tensor& q_w
             (void)keep_a; (void)keep_b;
             return true;
         };
+        if (raw && !bptr && !mg_rec && n % 32 == 0) {
+            const Tensor kq = q_weight, kz = qzeros, ks = scales;
+            d.launch_gated = [=](const Context& c2, uint16_t* dst) -> bool {
+                const PackedW4 pg = cached_pack(c2, kq, kz, ks, sym, /*gated=*/true);
+                const int st_ = zl_w4a16_gemm_mfma_ex(xin, k, (const uint32_t*)pg.q_weight.nullable_data(), (const uint32_t*)pg.scales.nullable_data(), nullptr,
+                                                      nullptr, dst, m, n, k, g, nw, eps, ZL_EPI_SILU_MUL, &opts, (zl_stream_t)st);
+                if (st_ == ZL_ESHAPE) return false;
+                zl_check(st_, "gptq_gemm_k_major + gate_fuse (boundary fusion)");
+                (void)keep_a;
+                return true;
+            };
+        }
         bmengine::core::defer_op(std::move(d));
         return out;
     }
@@ -955,10 +991,50 @@ void multi_query_attention_rag_buffer(const Context& ctx, const Tensor& batch_q,
         return;
     }
     BM_ASSERT_EQ(output.numel(), batch_q.numel(), "output shape mismatch");
-    AttentionWorkspace local = ws.cache.numel() ? ws : get_mqa_workspace(ctx, batch_q, max_len_buf, scale_key_addrs.numel() > 0);
     const int8_t* mptr = mask.numel() ? mask.data<const int8_t>() : nullptr;
     BM_ASSERT(mptr, "mask is required (int8, concatenated per task)");
     const int hkv = (int)(h / m_query);
+    // ---- boundary fusion (bm_hip.h DeferredOp kind 3): a few decode rows -- the attention launch leaves half-precision split records
+    //      and NO merge launch; NormalImpl hands `output` (a view of attn_val_g) straight to attn_out.forward (attention.cpp:944-958), whose
+    //      GEMV merges the records in its prologue.  Anyone else who touches `output` first gets the stand-alone merge, the same bits.
+    // (one task by default, as the Python driver: every workgroup of the projection merges all rows, which stops paying early)
+    static const int64_t merge_max_b = [] { const char* e = getenv("ZL_BOUNDARY_MERGE_MAX_B"); return e && *e ? (int64_t)atoi(e) : (int64_t)1; }();
+    if (bmengine::core::boundary_fusion_enabled() && len_q == 1 && d == 128 && batch_q.dtype() == DataType::kHalf && b <= std::min<int64_t>(4, merge_max_b) && h * d <= 4096 &&
+        m_query <= 16 && !scale_key_addrs.numel() && batch_q.is_continuous() && output.is_continuous()) {
+        const int64_t sl = zl_decode_attn_split_len(b, hkv, max_len_buf);
+        const int64_t ms = sl > 0 ? (max_len_buf + sl - 1) / sl : 0;
+        if (ms >= 1 && ms <= 16) {
+            Tensor rec = ctx.tensor({(size_t)(b * h * ms * (256 + 8))}, DataType::kInt8, "mqa_split_records");
+            const hipStream_t st = ctx.current_cuda_stream();
+            zl_check(zl_decode_attn_splits_h_mask(u16(batch_q), buf_lens.data<int32_t>(), key_buf_addrs.data<const uint16_t* const>(),
+                                                  val_buf_addrs.data<const uint16_t* const>(), mptr, rec.data(), b, h, hkv, d, scale, max_len_buf,
+                                                  ctx.is_BSHD(), (zl_stream_t)st),
+                     "multi_query_attention_rag_buffer (split records)");
+            bmengine::core::retire_deferred_inputs(output.nullable_data(), output.nbytes());   // `output` will be overwritten, now or later
+            bmengine::core::DeferredOp dop;
+            dop.kind = 3;
+            dop.y = output.nullable_data(); dop.y_bytes = output.nbytes();
+            dop.x = rec.nullable_data(); dop.x_bytes = rec.nbytes();
+            dop.y_alive = output.storage_token();
+            dop.stream = st;
+            dop.rows = b; dop.dim = h * d;
+            dop.attn_buf_lens = buf_lens.data<int32_t>();
+            dop.split_len = sl; dop.max_splits = ms;
+            dop.keep = std::make_shared<std::pair<Tensor, Tensor>>(rec, buf_lens);
+            const void* recp = rec.nullable_data();
+            const int32_t* lens = dop.attn_buf_lens;
+            uint16_t* outp = (uint16_t*)output.nullable_data();
+            const std::shared_ptr<void> keep = dop.keep;
+            dop.launch = [=]() {
+                zl_check(zl_decode_attn_combine_h(recp, lens, nullptr, outp, b, h, hkv, max_len_buf, (zl_stream_t)st),
+                         "multi_query_attention_rag_buffer (merge of the split records)");
+                (void)keep;
+            };
+            bmengine::core::defer_op(std::move(dop));
+            return;
+        }
+    }
+    AttentionWorkspace local = ws.cache.numel() ? ws : get_mqa_workspace(ctx, batch_q, max_len_buf, scale_key_addrs.numel() > 0);
     if (scale_key_addrs.numel()) {
         zl_check(zl_decode_attn_quant(u16(batch_q), buf_lens.data<int32_t>(), key_buf_addrs.data<const uint8_t* const>(),
                                       val_buf_addrs.data<const uint8_t* const>(), scale_key_addrs.data<const float* const>(),
@@ -1144,6 +1220,20 @@ Tensor gate_fuse(const Context& ctx, const Tensor& input, const std::string& act
     shape.back() = ff;
     (void)es;
     Tensor x = ctx.tensor(shape, input.dtype());
+    // boundary fusion (bm_hip.h DeferredOp): `input` is the fused gate|up projection, not launched yet -> ONE launch with the activation
+    // in its epilogue.  The op stays listed as consumed: should anyone still read `input`, it is launched the plain way then.
+    if (act_fn_type == "silu" && input.dtype() == DataType::kHalf && bmengine::core::boundary_fusion_enabled()) {
+        if (bmengine::core::DeferredOp* d = bmengine::core::find_deferred(input.nullable_data(), 2)) {
+            if (d->launch_gated && !d->consumed && (size_t)d->n == 2 * ff && (size_t)d->m == rows && d->stream == ctx.current_cuda_stream()) {
+                auto launch_gated = d->launch_gated;
+                uint16_t* xp = u16m(x);              // (x.data() may touch the list: look the op up again)
+                if (launch_gated(ctx, xp)) {
+                    if (bmengine::core::DeferredOp* d2 = bmengine::core::find_deferred(input.nullable_data(), 2)) d2->consumed = true;
+                    return x;
+                }
+            }
+        }
+    }
     zl_check(zl_gate_fuse(u16(input), u16m(x), rows, ff, act_fn_type == "gelu", zdt(x.dtype()), st_of(ctx)), "gate_fuse");
     return x;
 }

@@ -1055,6 +1055,31 @@ def decode_attention_splits(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, val
     return workspace
 
 
+def decode_attention_splits_mask(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, mask, scale, max_len_buf, num_kv_heads, workspace,
+                                 bshd=True):
+    """decode_attention_splits with the reference's int8 visibility mask (one row of buf_lens[b] entries per task) instead of prefix
+    lengths (zl_decode_attn_splits_h_mask): half-precision records of EVERY split of the buffer; the merging projection
+    (w4_attn_out_merge) and decode_attention_combine_h take them with valid_lens = buf_lens.  fp16 only."""
+    _chk_cuda(batch_q, buf_lens, key_buf_addrs, val_buf_addrs, mask, workspace)
+    b, h, d = batch_q.shape[0], batch_q.shape[-2], batch_q.shape[-1]
+    if batch_q.dtype != torch.float16:
+        raise ZLError("decode_attention_splits_mask: fp16 rows")
+    check(lib().zl_decode_attn_splits_h_mask(_p(batch_q), _p(buf_lens), _p(key_buf_addrs), _p(val_buf_addrs), _p(mask), _p(workspace),
+                                             _i(b), _i(h), _i(num_kv_heads), _i(d), _f(scale), _i(max_len_buf), C.c_int(int(bshd)),
+                                             _stream()), "decode_attn_splits_h_mask")
+
+
+def decode_attention_combine_h(workspace, buf_lens, valid_lens, b, h, num_kv_heads, max_len_buf, out=None):
+    """the merge of half-precision split records as a launch of its own (zl_decode_attn_combine_h): bit for bit the rows
+    w4_attn_out_merge's prologue multiplies.  valid_lens None: every split of the buffer (the mask form's records)."""
+    _chk_cuda(workspace, buf_lens, valid_lens)
+    if out is None:
+        out = torch.empty((b, 1, h, 128), dtype=torch.float16, device=workspace.device)
+    check(lib().zl_decode_attn_combine_h(_p(workspace), _p(buf_lens), _p(valid_lens), _p(out), _i(b), _i(h), _i(num_kv_heads),
+                                         _i(max_len_buf), _stream()), "decode_attn_combine_h")
+    return out
+
+
 def w4_attn_out_merge(workspace, buf_lens, valid_lens, plan, b, w, bias=None, residual=None, out=None, epilogue=0):
     """attn_out projection whose activation rows are merged from the decode attention's split-KV partials in the GEMV
     prologue (zl_w4a16_gemm_attn_merge): bit-identical to the merge launch + w4a16_gemm_mfma."""
