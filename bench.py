@@ -220,8 +220,9 @@ def roofline_w4(model, cfg, batch, dev, ctx, layers_override=False):
     achieved = per_launch / t_launch / 1e9
     mfma = isinstance(model.layers[0].qkv.weight, ops.W4MWeight)
     small = os.environ.get("ZL_W4_SMALL_ALGO", "0") != "1"
-    # 1..4 rows: k_w4a16_i8p (integer planes) for all four; 5..32: k_w4a16_phase (+ k_w4a16_mfma / k_w4a16_gemm_tiled on the long K)
-    kname = ("k_w4a16_i8p" if batch <= 4 and small else "k_w4a16_phase+k_w4a16_mfma") if mfma else "k_w4a16_gemm"
+    # 1..2 rows: k_w4a16_i8p (integer planes) for all four; 3..4: the same except the long-K down projection (k_w4a16_slab);
+    # 5..32: k_w4a16_slab (2-D K-split tiles, round 6) for all four
+    kname = ("k_w4a16_i8p" if batch <= 2 and small else "k_w4a16_i8p+k_w4a16_slab" if batch <= 4 and small else "k_w4a16_slab") if mfma else "k_w4a16_gemm"
     # HBM traffic per launch: measured off-line with rocprofv3 --pmc (a counter pass cannot run inside
     # this process); the committed summary is per kernel flavour and for these four shapes only
     traffic = None
@@ -241,7 +242,7 @@ def roofline_w4(model, cfg, batch, dev, ctx, layers_override=False):
             "timing": how, "us_per_launch_gemv_only_graph": round(t_gemv_only * 1e6, 3),
             "traffic_source": "offline rocprofv3 --pmc pass (profiles/r*_gemv_traffic.json), not measured in this run" if traffic is not None else None,
             "note": "avg over the %d GEMV launches of one step incl. the kernel boundaries between them (graph replay, HIP events); "
-                    "in-step rocprofv3 averages of the same kernels: profiles/r05_decode_kernel_stats.csv" % len(lins)}
+                    "in-step rocprofv3 averages of the same kernels: profiles/r06_bench_kernel_stats.csv (batch 8 / 32: r06_bench_b8 / b32_kernel_stats.csv)" % len(lins)}
     return roof
 
 
