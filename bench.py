@@ -451,6 +451,9 @@ def main():
     ap.add_argument("--kv-cache-dtype", choices=["fp16", "int8"], default="fp16",
                     help="int8: the reference's KV_CACHE_DTYPE=int8 cache (u8 codes + fp32 scales); not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234,
+                    help="seed of the synthetic KV history and step tokens (torch's default generator is seeded from the OS per process "
+                         "on this build: unseeded, every run timed -- and logit-checked -- another draw; profiles/r06_logit_check_draws.txt)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra legs of the default run (batch 8 / 32 of the headline model, INT8 route at batch 32)")
     args = ap.parse_args()
@@ -496,6 +499,7 @@ def main():
     else:
         model.init_random(seed=1234 + rank)
     len_buf = (seq + args.warmup + args.steps + 4 + 63) // 64 * 64
+    torch.manual_seed(args.seed)           # the history and the tokens: one reproducible draw (every rank the same one)
     ctx = model.new_context(batch, len_buf, seq, fill_random=True, kv_cache_dtype=None if args.kv_cache_dtype == "fp16" else "int8")
     ctx.tokens.copy_(torch.randint(0, cfg.vocab_size, (batch,), device=dev, dtype=torch.int32))
     oracle_check = check_against_oracle(model, batch, dev) if (rank == 0 and not int8 and tp is None) else None
@@ -628,7 +632,7 @@ def main():
             "metric": "decode tokens/s (Llama-3-8B %s, TP=1 per GPU, batch %d, seq %d)" % ("INT8" if int8 else "GPTQ-Int4", batch, seq),
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic", "seed": args.seed,
             "config": {"workload": ("Llama-3-8B INT8 (AutoInt8 linears) TP=1 batch=%d decode seq=%d (BASELINE configs[2])" if int8 else
                                     "Llama-3-8B GPTQ-Int4 g128 TP=1 batch=%d decode seq=%d (BASELINE configs[1])") % (batch, seq),
                        "layers": cfg.num_layers,

@@ -5,7 +5,7 @@ and the C ABI: one launch and one pooled ctx.tensor per reference op, no fused f
 1024 keys of history, the SAME synthetic GPTQ checkpoint bench.py times (LLaMA.init_synthetic, seed 1234).  Prints ONE JSON line:
 tokens/s eager and under hipGraph replay, next to the Python driver's (zhilight_amd/llama.py: fused launches under hipGraph) on
 the same weights in the same process, and the distance between the two paths' logits.
-usage: python tools/bench_boundary.py [--layers L] [--iters N]      (env CPM_FUSE_QKV / CPM_FUSE_FF_IN / ROPE_CACHE: the reference's
+usage: python tools/bench_boundary.py [--layers L] [--iters N] [--batch B]      (env CPM_FUSE_QKV / CPM_FUSE_FF_IN / ROPE_CACHE: the reference's
 own switches, read by its code)"""
 import argparse
 import json
@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--seq", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=1, help="decode tasks in the step (every task: --seq keys of history)")
     args = ap.parse_args()
     from zhilight_amd import _lib, build
     from zhilight_amd.llama import LLaMA, ModelConfig, QuantConfig
@@ -55,14 +56,16 @@ def main():
     rm.load(rsd, "m")
     del rsd
     torch.manual_seed(7)
-    ctx = model.new_context(1, len_buf, seq, fill_random=True)
-    k = torch.stack([ctx.kv[0][l, 0, :seq] for l in range(cfg.num_layers)]).cpu().numpy()
-    v = torch.stack([ctx.kv[0][l, 1, :seq] for l in range(cfg.num_layers)]).cpu().numpy()
-    rm.set_history(0, len_buf, np.ascontiguousarray(k), np.ascontiguousarray(v))
-    tokens = np.array([17], np.int32)
+    nb = args.batch
+    ctx = model.new_context(nb, len_buf, seq, fill_random=True)
+    for b in range(nb):
+        k = torch.stack([ctx.kv[b][l, 0, :seq] for l in range(cfg.num_layers)]).cpu().numpy()
+        v = torch.stack([ctx.kv[b][l, 1, :seq] for l in range(cfg.num_layers)]).cpu().numpy()
+        rm.set_history(b, len_buf, np.ascontiguousarray(k), np.ascontiguousarray(v))
+    tokens = (17 + 3 * np.arange(nb)).astype(np.int32)
     ctx.tokens.copy_(torch.from_numpy(tokens))
-    pos = np.array([seq], np.int32)
-    mask = (np.arange(len_buf) <= seq).astype(np.int8)
+    pos = np.full(nb, seq, np.int32)
+    mask = np.tile((np.arange(len_buf) <= seq).astype(np.int8), nb)
     # parity of the two paths on the same weights and history (before anything is timed)
     got_ref = rm.decode_step(tokens, pos, mask).astype(np.float64)
     got_py = model.encode(ctx).float().cpu().numpy().astype(np.float64)
@@ -84,14 +87,14 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     py_ms = e0.elapsed_time(e1) / args.iters
-    out = {"what": "reference model::LLaMA::encode + get_logits on the boundary (hostcpp/nn_amd.cpp over the C ABI), %d layers, batch 1, %d keys; "
-                   "one launch + one pooled ctx.tensor per reference op" % (cfg.num_layers, seq),
+    out = {"what": "reference model::LLaMA::encode + get_logits on the boundary (hostcpp/nn_amd.cpp over the C ABI), %d layers, batch %d, %d keys; "
+                   "one launch + one pooled ctx.tensor per reference op" % (cfg.num_layers, nb, seq),
            "switches": {k: os.environ.get(k) for k in ("CPM_FUSE_QKV", "CPM_FUSE_FF_IN", "ROPE_CACHE")},
-           "boundary_path_tokens_per_s": round(1e3 / t["eager_ms"], 1), "boundary_path_ms_per_step": round(t["eager_ms"], 4),
-           "boundary_path_graph_tokens_per_s": round(1e3 / t["graph_ms"], 1) if "graph_ms" in t else None,
+           "boundary_path_tokens_per_s": round(nb * 1e3 / t["eager_ms"], 1), "boundary_path_ms_per_step": round(t["eager_ms"], 4),
+           "boundary_path_graph_tokens_per_s": round(nb * 1e3 / t["graph_ms"], 1) if "graph_ms" in t else None,
            "boundary_path_graph_ms_per_step": round(t["graph_ms"], 4) if "graph_ms" in t else None,
            "graph_error": t.get("graph_error"),
-           "python_driver_tokens_per_s": round(1e3 / py_ms, 1), "python_driver_ms_per_step": round(py_ms, 4),
+           "python_driver_tokens_per_s": round(nb * 1e3 / py_ms, 1), "python_driver_ms_per_step": round(py_ms, 4),
            "ratio_boundary_over_driver": round(py_ms / (t.get("graph_ms") or t["eager_ms"]), 3),
            "logits_boundary_vs_driver_max_over_max": round(dist, 6)}
     print(json.dumps(out), flush=True)

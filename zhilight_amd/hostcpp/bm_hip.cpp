@@ -709,3 +709,8 @@ extern "C" hipError_t zl_shim_stream_destroy(hipStream_t stream) {
     if (bmengine::core::shim_is_secondary_stream(stream)) return hipStreamSynchronize(stream);
     return hipStreamDestroy(stream);
 }
+// the reference's cudaEventRecord (refshim/cuda_runtime.h): what this thread still holds back goes out first
+extern "C" hipError_t zl_shim_event_record(hipEvent_t event, hipStream_t stream) {
+    bmengine::core::flush_all_deferred();
+    return hipEventRecord(event, stream);
+}

@@ -20,7 +20,10 @@ typedef __half half;
 #define cudaStreamSynchronize hipStreamSynchronize
 #define cudaDeviceSynchronize hipDeviceSynchronize
 #define cudaEventCreate hipEventCreate
-#define cudaEventRecord hipEventRecord
+// an event another stream will wait on must see everything the host library is still holding back on this thread (bm_hip.h DeferredOp:
+// results handed back unlaunched): the deferred launches go out, on their streams, before the event is recorded
+extern "C" hipError_t zl_shim_event_record(hipEvent_t event, hipStream_t stream);
+#define cudaEventRecord zl_shim_event_record
 #define cudaEventDestroy hipEventDestroy
 #define cudaEventSynchronize hipEventSynchronize
 #define cudaEventElapsedTime hipEventElapsedTime
