@@ -720,17 +720,19 @@ def test_reference_llama_model_production_switches(dev):
     assert "1 passed" in r.stdout, r.stdout[-2000:]
 
 
-def test_reference_llama_model_decode_steps(ref, oracle):
+@pytest.mark.parametrize("batch", [3, 6, 12])
+def test_reference_llama_model_decode_steps(ref, oracle, batch):
     """The north star's path from its TOP, in the reference's own code: model::LLaMA (src/model/llama.cpp, compiled unmodified) ->
     LLaMA::encode (:75-151) -> EncoderLayer::forward x layers (block.cpp) -> Attention / FeedForward / Linear (attention.cpp,
     feedforward.cpp, linear.cpp) -> get_logits (:159-165), inside the reference's ModelContext with its DynBatchContext /
     RagBufferContext -- whole-model decode steps on the GPU, three tasks, against the SAME CPU oracle model and the same 1e-3 bar the
-    repository's own LLaMA is held to (tests/test_gpu_model.py::test_decode_steps_match_oracle)."""
+    repository's own LLaMA is held to (tests/test_gpu_model.py::test_decode_steps_match_oracle).  Six tasks: the lm_head
+    (RawEmbedding::projection) from its ZLD16M-packed copy, the linears up to 8 rows still deferred; twelve: nothing deferred."""
     from zhilight_amd.llama import ModelConfig
     from test_gpu_model import OracleModel, _hf_state
     rng = np.random.default_rng(0)
     cfg = ModelConfig(num_layers=2, dim_model=1024, num_heads=8, dim_head=128, dim_ff=2048, vocab_size=512, num_kv_heads=2, eps=1e-5, rope_theta=5e5)
-    g, batch, len_buf = 128, 3, 64
+    g, len_buf = 128, 64
     sd = _hf_state(rng, cfg, g)
     names = {"self_attn.q_proj": "attn.project_q", "self_attn.k_proj": "attn.project_k", "self_attn.v_proj": "attn.project_v", "self_attn.o_proj": "attn.attn_out",
              "mlp.gate_proj": "ff.w_in", "mlp.up_proj": "ff.w_gated", "mlp.down_proj": "ff.w_out", "input_layernorm": "ln_attn",

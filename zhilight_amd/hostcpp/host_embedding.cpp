@@ -20,6 +20,10 @@ public:
     core::DataType dtype;
     float scale = 1.0f, logit_scale = 1.0f;
     core::Tensor weight;
+    // ZLD16M copy of `weight` (zl_dense_pack_m: a wavefront's MFMA fragment load is 1 KiB contiguous), made when a projection of 5..32 rows
+    // first needs it -- what the Python driver keeps for the lm_head of a decode batch (176-186 us against 210-680 us row-major)
+    core::Tensor packed;
+    const void* packed_of = nullptr;
     bool parallel = false;
     int begin = 0, end = 0;               // the vocabulary rows this rank holds
     int zdt() const { return dtype == DataType::kHalf ? ZL_F16 : ZL_BF16; }
@@ -45,6 +49,8 @@ void RawEmbedding::set_scale_factor(float b) { pimpl->scale = b; }
 void RawEmbedding::set_logit_scale(float b) { pimpl->logit_scale = b; }
 void RawEmbedding::load_state_dict(const core::Context& ctx, const std::map<std::string, const core::Tensor>& state_dict, const std::string& prefix,
                                    bool allow_missing) {
+    pimpl->packed_of = nullptr;           // a packed copy of the previous contents is stale
+    pimpl->packed = core::Tensor();
     if (!pimpl->parallel) {
         core::Layer::load_state_dict(ctx, state_dict, prefix, allow_missing);
         return;
@@ -104,7 +110,16 @@ core::Tensor RawEmbedding::projection(const core::Context& ctx, const core::Tens
     if (m <= 4)
         ZL_CK(zl_gemm_nt_small_m(input.data<uint16_t>(), k, pimpl->weight.data<uint16_t>(), nullptr, local.data<uint16_t>(), m, n, k, alpha, pimpl->zdt(), nullptr, 0.f, st),
               "lm_head (row-streaming)");
-    else
+    else if (m <= 32 && k % 128 == 0 && zl_dense_m_bytes(n, k) > 0) {
+        // a decode batch: the same product (zl_gemm_nt's bits) from the packed copy
+        if (pimpl->packed_of != pimpl->weight.data()) {
+            pimpl->packed = ctx.tensor({(size_t)zl_dense_m_bytes(n, k)}, DataType::kInt8, "lm_head_zld16m");
+            ZL_CK(zl_dense_pack_m(pimpl->weight.data<uint16_t>(), (uint16_t*)pimpl->packed.data(), n, k, st), "lm_head (ZLD16M pack)");
+            pimpl->packed_of = pimpl->weight.data();
+        }
+        ZL_CK(zl_gemm_nt_packed(input.data<uint16_t>(), k, (const uint16_t*)pimpl->packed.data(), nullptr, local.data<uint16_t>(), m, n, k, alpha, pimpl->zdt(), st),
+              "lm_head (packed)");
+    } else
         ZL_CK(zl_gemm_nt(input.data<uint16_t>(), k, pimpl->weight.data<uint16_t>(), nullptr, local.data<uint16_t>(), m, n, k, alpha, pimpl->zdt(), st), "lm_head");
     if (!pimpl->parallel) return local;
     // (world, m, part) -> (m, vocab): rank r's part becomes columns r * part .. of every row (the padding past the vocabulary is dropped)
