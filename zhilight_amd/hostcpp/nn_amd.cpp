@@ -241,8 +241,12 @@ Tensor gptq_gemm_k_major(const Context& ctx, const Tensor& a0, const Tensor& q_w
     // ---- boundary fusion (bm_hip.h DeferredOp): the activations are an RMSNorm the caller's LayerNorm::forward has not launched
     //      yet -> the GEMV's norm prologue; and this linear's own launch is held back in case element_add_scale_out consumes it
     //      (residual epilogue).  Only the plain decode shape of the path: packed / packable operands, no act-order, no W4A8, <= 8 rows.
+    //      (kMaxDeferRows = 32 was measured at the end of round 6 -- the residual and gate_fuse epilogues for every decode batch: the
+    //      boundary's batch-32 step 8 036 -> 8 440 tokens/s, every test of tests/test_gpu_refcompile.py green -- and not kept: the GPU
+    //      budget ended before the rest of the suite had run on it.  docs/lab/r06.md section 13.)
+    constexpr int64_t kMaxDeferRows = 8;
     if (bmengine::core::boundary_fusion_enabled() && mfma_ok && !q_perm.numel() && !(precomputed_w8 && precomputed_w8->numel()) &&
-        rows_of(a0) <= 8 && a0.is_continuous() && (!output || output->is_continuous())) {
+        (int64_t)rows_of(a0) <= kMaxDeferRows && a0.is_continuous() && (!output || output->is_continuous())) {
         const int64_t m = rows_of(a0);
         bmengine::core::DeferredOp* nd = bmengine::core::find_deferred(a0.nullable_data(), 1);
         const bool norm_ok = nd && nd->rows == m && nd->dim == k && k <= 4096 && nd->stream == ctx.current_cuda_stream();
