@@ -100,6 +100,34 @@ def test_attention_oracle_flavours_agree(oracle):
     assert np.abs(a - e).max() < 2e-3 and np.abs(b - e).max() < 2e-3
 
 
+def test_attention_oracle_splits_and_tasks_without_a_visible_key(oracle):
+    """What the mask form of the matrix-core decode kernel is checked against (tests/test_gpu_ops.py::
+    test_decode_attention_matrix_core_mask_form, test_gpu_w4.py::test_attention_mask_form_split_records_merge): the restatement of the
+    reference's split-KV kernel + KERNEL_mqa_combine (attention_kernel.cu:673-923: running max from -1e20, Z from 1e-20) on masks with
+    holes -- a split without any visible key contributes nothing, a task without one yields zeros -- agrees with the unsplit and the
+    fp64 flavours."""
+    rng = np.random.default_rng(6)
+    h, hkv, d = 8, 2, 128
+    lens = [700, 300, 64]
+    kb = [oracle.h2u(rng.standard_normal((L, hkv, d)).astype(np.float16)) for L in lens]
+    vb = [oracle.h2u(rng.standard_normal((L, hkv, d)).astype(np.float16)) for L in lens]
+    q = oracle.h2u(rng.standard_normal((3, 1, h, d)).astype(np.float16))
+    m0 = (rng.random(700) < 0.5).astype(np.int8)
+    m0[:350] = 0                                   # with four splits of 175 keys: the first two see nothing
+    m0[699] = 1
+    m1 = np.zeros(300, np.int8)                    # a task without a visible key
+    m2 = (rng.random(64) < 0.7).astype(np.int8)
+    m2[0] = 1
+    mask = np.concatenate([m0, m1, m2])
+    la = np.array(lens, np.int32)
+    a = oracle.u2h(oracle.mqa_rag_buffer(q, la, kb, vb, mask, hkv, 0.088)).astype(np.float64)
+    b = oracle.u2h(oracle.mqa_rag_buffer(q, la, kb, vb, mask, hkv, 0.088, num_split=4)).astype(np.float64)
+    e = oracle.mqa_rag_buffer(q, la, kb, vb, mask, hkv, 0.088, exact=True)
+    assert np.isfinite(a).all() and np.isfinite(b).all() and np.isfinite(e).all()
+    assert not a[1].any() and not b[1].any() and not e[1].any()
+    assert np.abs(a - e).max() < 2e-3 and np.abs(b - e).max() < 2e-3
+
+
 def test_awq_oracle_matches_the_format_definition_and_its_own_exact_product():
     """native AWQ restatement: dequantize == (q - z) * s from the integers the AutoAWQ tensors were packed from
     (one fp16 rounding), == the dense matrix the AWQ-as-exllama re-route dequantises (transposed); the split-K result with
